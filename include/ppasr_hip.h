@@ -1,0 +1,116 @@
+/*
+ * ppasr_hip.h -- C-ABI of libppasr_hip.so, the MI355X (gfx950) implementation of
+ * PPASR's encoder-forward + CTC-decode hot path.
+ *
+ * PPASR has no FFI of its own (it is pure Python on PaddlePaddle); the boundary a
+ * maintainer would bind is the set of Python call sites listed per entry point
+ * below (paths relative to the reference checkout, `ppasr/...`).  INTEGRATION.md
+ * shows the ctypes stub for each.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *   - all work is enqueued on the caller's HIP stream (`stream`, a hipStream_t
+ *     passed as void*); nothing synchronises, nothing allocates after create();
+ *   - the caller owns every buffer including the scratch workspace
+ *     (size from ppasr_workspace_bytes); the handle owns only packed weights;
+ *   - a handle is not re-entrant; distinct handles are independent;
+ *   - no exceptions cross the ABI: int status + ppasr_last_error() (thread-local).
+ */
+#ifndef PPASR_HIP_H
+#define PPASR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ppasr_model_s* ppasr_handle;
+typedef struct ppasr_stream_s* ppasr_stream;
+
+typedef enum {
+  PPASR_OK = 0,
+  PPASR_EINVAL = 1,       /* bad argument / shape */
+  PPASR_EHIP = 2,         /* a HIP runtime call failed */
+  PPASR_EUNSUPPORTED = 3, /* configuration outside what the kernels are built for */
+  PPASR_EMISSING = 4,     /* a required weight blob is absent */
+  PPASR_ENOSPACE = 5      /* workspace too small */
+} ppasr_status;
+
+enum { PPASR_MODEL_CONFORMER = 0, PPASR_MODEL_EFFICIENT_CONFORMER = 1,
+       PPASR_MODEL_SQUEEZEFORMER = 2, PPASR_MODEL_DEEPSPEECH2 = 3 };
+
+/* One named parameter of a Paddle state dict (`model.pdparams`, trainer.py:302-328):
+ * float32, C-contiguous, HOST memory, Paddle layout (Linear.weight is [in,out]). */
+typedef struct {
+  const char* name;
+  const float* data_host;
+  int ndim;
+  int64_t shape[4];
+} ppasr_weight_blob;
+
+/* Mirrors `encoder_conf` of configs/conformer.yml:2-16 plus the constructor
+ * arguments of ConformerModel (model_utils/conformer/model.py:17-29). */
+typedef struct {
+  int model_type;        /* PPASR_MODEL_* */
+  int input_dim;         /* fbank bins F (80) */
+  int vocab_size;        /* V */
+  int output_size;       /* d (256) */
+  int attention_heads;   /* h (4) */
+  int linear_units;      /* FFN hidden (2048) */
+  int num_blocks;        /* L (12) */
+  int cnn_module_kernel; /* 15 */
+  int causal;            /* streaming model => causal depthwise conv (model.py:35-39) */
+  int max_len;           /* positional table length (embedding.py:30), 5000 */
+} ppasr_model_desc;
+
+const char* ppasr_last_error(void);
+const char* ppasr_version(void);
+
+/* Replaces: model construction + paddle.inference.create_predictor
+ * (infer_utils/inference_predictor.py:41-77) / PPASRTrainer.__setup_model
+ * (trainer.py:172-210).  Uploads and re-packs the weights into MFMA fragment order. */
+ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob* weights_host, int n_weights,
+                          ppasr_handle* out);
+ppasr_status ppasr_destroy(ppasr_handle h);
+
+/* frames after the conv front-end: ((T-1)/2-1)/2  (conformer/subsampling.py:84-94,115) */
+int ppasr_out_frames(ppasr_handle h, int T);
+size_t ppasr_workspace_bytes(ppasr_handle h, int B, int T);
+
+/* Replaces ConformerModel.get_encoder_out (model_utils/conformer/model.py:148-162), as called by
+ * PPASRTrainer.evaluate (trainer.py:626) and InferencePredictor.predict (inference_predictor.py:103-145).
+ *   feats [B,T,F] f32 zero-padded, lens [B] i64  ->  any of
+ *   probs  [B,T',V] f32  softmax(ctc_lo(enc))       (what the reference returns)
+ *   logits [B,T',V] f32  pre-softmax                (parity tap)
+ *   frame_argmax [B,T'] i32, frame_maxprob [B,T'] f32: per-frame argmax / probability at the
+ *     argmax, produced inside the CTC-head kernel (fused ctc_greedy first stage,
+ *     decoders/ctc_greedy_decoder.py:21-22); pass NULL for outputs not wanted. */
+ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* lens, int B, int T,
+                          float* probs, float* logits, int32_t* frame_argmax, float* frame_maxprob,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* Debug taps: when set (host call, before ppasr_encode), intermediate activations are copied
+ * to `taps` in the order documented in DESIGN.md; pass NULL to clear. */
+ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats);
+
+/* Replaces greedy_decoder / greedy_decoder_batch (decoders/ctc_greedy_decoder.py:6-49), as called
+ * from PPASRPredictor.decode (predict.py:128) and PPASRTrainer.__decoder_result (trainer.py:351).
+ *   probs [B,Tp,V] f32 (any row-normalised or not: argmax + value at argmax)
+ *   frame_lens [B] i32 or NULL (NULL = decode all Tp rows, the reference's batch behaviour)
+ *   tokens [B,Tp] i32 (-1 padded), n_tokens [B] i32, score [B] f64 (mean non-blank max prob * 100) */
+ppasr_status ppasr_ctc_greedy(const float* probs, const int32_t* frame_lens, int B, int Tp, int V, int blank,
+                              int32_t* tokens, int32_t* n_tokens, double* score,
+                              void* workspace /* >= 8*B*Tp bytes */, size_t workspace_bytes, void* stream);
+
+/* Second stage only: collapse repeats / drop blank / score, from per-frame argmax+maxprob
+ * (the outputs of ppasr_encode).  Same outputs as ppasr_ctc_greedy. */
+ppasr_status ppasr_ctc_collapse(const int32_t* frame_argmax, const float* frame_maxprob, const int32_t* frame_lens,
+                                int B, int Tp, int blank, int32_t* tokens, int32_t* n_tokens, double* score,
+                                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPASR_HIP_H */

@@ -1,0 +1,83 @@
+"""ctypes binding of libppasr_hip.so (C-ABI in include/ppasr_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, this
+module raises.  The product path never routes through ``oracle/`` or any CPU
+implementation.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libppasr_hip.so")
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+
+PPASR_MODEL_CONFORMER = 0
+PPASR_MODEL_EFFICIENT_CONFORMER = 1
+PPASR_MODEL_SQUEEZEFORMER = 2
+PPASR_MODEL_DEEPSPEECH2 = 3
+
+
+class WeightBlob(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("data_host", ctypes.c_void_p), ("ndim", ctypes.c_int),
+                ("shape", ctypes.c_int64 * 4)]
+
+
+class ModelDesc(ctypes.Structure):
+    _fields_ = [("model_type", ctypes.c_int), ("input_dim", ctypes.c_int), ("vocab_size", ctypes.c_int),
+                ("output_size", ctypes.c_int), ("attention_heads", ctypes.c_int), ("linear_units", ctypes.c_int),
+                ("num_blocks", ctypes.c_int), ("cnn_module_kernel", ctypes.c_int), ("causal", ctypes.c_int),
+                ("max_len", ctypes.c_int)]
+
+
+# every symbol include/ppasr_hip.h declares: (name, restype, argtypes)
+_vp = ctypes.c_void_p
+SYMBOLS = [
+    ("ppasr_last_error", ctypes.c_char_p, []),
+    ("ppasr_version", ctypes.c_char_p, []),
+    ("ppasr_create", ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.POINTER(WeightBlob), ctypes.c_int,
+                                    ctypes.POINTER(_vp)]),
+    ("ppasr_destroy", ctypes.c_int, [_vp]),
+    ("ppasr_out_frames", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("ppasr_workspace_bytes", ctypes.c_size_t, [_vp, ctypes.c_int, ctypes.c_int]),
+    ("ppasr_encode", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp,
+                                    ctypes.c_size_t, _vp]),
+    ("ppasr_set_debug_taps", ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    ("ppasr_ctc_greedy", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp,
+                                        _vp, _vp, ctypes.c_size_t, _vp]),
+    ("ppasr_ctc_collapse", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
+                                          _vp]),
+]
+
+_lib = None
+
+
+class PPASRHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PPASRHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        msg = load().ppasr_last_error()
+        raise PPASRHipError(f"libppasr_hip status {status}: {msg.decode() if msg else ''}")

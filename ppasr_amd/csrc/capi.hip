@@ -1,0 +1,425 @@
+// capi.hip -- the C-ABI of libppasr_hip.so (declared in include/ppasr_hip.h).
+// Host side: weight re-packing into MFMA fragment order, workspace carving, launch sequence.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ppasr_hip.h"
+#include "conformer_kernels.h"
+
+using namespace ppasr;
+
+namespace {
+
+thread_local std::string g_err;
+ppasr_status fail(ppasr_status s, const std::string& msg) {
+  g_err = msg;
+  return s;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return fail(PPASR_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+struct Blob {
+  const float* p;
+  int ndim;
+  int64_t shape[4];
+  size_t numel() const {
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    return n;
+  }
+};
+
+// Fragment-order packing of a [K][N] weight (y = x W): for 32-column tile nt, 8-wide k-group g,
+// lane l: 4 consecutive floats = W[8g + 4(l>>5) + 0..3][32 nt + (l&31)].  One wave-level
+// global_load_dwordx4 then yields the B operands of 4 successive v_mfma_f32_32x32x2_f32.
+template <typename Acc>
+std::vector<float> pack_b(int K, int N, Acc w) {
+  const int n_tiles = (N + 31) / 32, G = K / 8;
+  std::vector<float> out((size_t)n_tiles * G * 256, 0.f);
+  for (int nt = 0; nt < n_tiles; ++nt)
+    for (int g = 0; g < G; ++g)
+      for (int l = 0; l < 64; ++l) {
+        int n = nt * 32 + (l & 31);
+        if (n >= N) continue;
+        float* dst = &out[(((size_t)nt * G + g) * 64 + l) * 4];
+        for (int j = 0; j < 4; ++j) dst[j] = w(8 * g + 4 * (l >> 5) + j, n);
+      }
+  return out;
+}
+
+}  // namespace
+
+struct ppasr_model_s {
+  ppasr_model_desc desc;
+  int F1, F2;
+  std::vector<void*> allocs;
+  FrontW front;
+  std::vector<LayerW> layers;
+  HeadW head;
+  float* taps = nullptr;
+  size_t taps_floats = 0;
+
+  ppasr_status upload(const std::vector<float>& v, const float** out) {
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, v.size() * sizeof(float)));
+    allocs.push_back(d);
+    HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = static_cast<const float*>(d);
+    return PPASR_OK;
+  }
+  ppasr_status upload4(const std::vector<float>& v, const f32x4** out) {
+    const float* p = nullptr;
+    ppasr_status s = upload(v, &p);
+    *out = reinterpret_cast<const f32x4*>(p);
+    return s;
+  }
+  ~ppasr_model_s() {
+    for (void* p : allocs) (void)hipFree(p);
+  }
+};
+
+extern "C" {
+
+const char* ppasr_last_error(void) { return g_err.c_str(); }
+const char* ppasr_version(void) { return "ppasr_hip 0.1 (gfx950, fp32 MFMA)"; }
+
+ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob* blobs, int n_blobs, ppasr_handle* out) {
+  if (!desc || !blobs || !out) return fail(PPASR_EINVAL, "null argument");
+  if (desc->model_type != PPASR_MODEL_CONFORMER) return fail(PPASR_EUNSUPPORTED, "only model_type=conformer is built");
+  if (desc->output_size != kD) return fail(PPASR_EUNSUPPORTED, "kernels are specialised for output_size=256");
+  if (desc->attention_heads * 64 != kD) return fail(PPASR_EUNSUPPORTED, "kernels are specialised for d_k=64");
+  if (desc->linear_units % 256 != 0 || desc->linear_units <= 0) return fail(PPASR_EUNSUPPORTED, "linear_units % 256 != 0");
+  if (desc->cnn_module_kernel != 15 && desc->cnn_module_kernel != 31 && desc->cnn_module_kernel != 7)
+    return fail(PPASR_EUNSUPPORTED, "cnn_module_kernel must be 7, 15 or 31");
+  if (!desc->causal) return fail(PPASR_EUNSUPPORTED, "only the causal (streaming-trained) conv module is built");
+  if (desc->input_dim > 128 || desc->input_dim < 7) return fail(PPASR_EUNSUPPORTED, "input_dim out of range");
+  HIP_TRY(configure_kernels());
+
+  std::unordered_map<std::string, Blob> sd;
+  for (int i = 0; i < n_blobs; ++i) {
+    Blob b{blobs[i].data_host, blobs[i].ndim, {0, 0, 0, 0}};
+    for (int j = 0; j < blobs[i].ndim && j < 4; ++j) b.shape[j] = blobs[i].shape[j];
+    sd[blobs[i].name] = b;
+  }
+  std::string missing;
+  auto get = [&](const std::string& name, size_t numel) -> const float* {
+    auto it = sd.find(name);
+    if (it == sd.end() || it->second.numel() != numel) {
+      missing = name;
+      return nullptr;
+    }
+    return it->second.p;
+  };
+#define GET(var, name, numel)                         \
+  const float* var = get(name, (size_t)(numel));      \
+  if (!var) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + missing)
+
+  auto* m = new ppasr_model_s();
+  std::unique_ptr<ppasr_model_s> guard(m);
+  m->desc = *desc;
+  const int F = desc->input_dim, d = kD, H = desc->linear_units, V = desc->vocab_size, KS = desc->cnn_module_kernel;
+  m->F1 = (F - 1) / 2;
+  m->F2 = (m->F1 - 1) / 2;
+  const int F2 = m->F2;
+  ppasr_status st;
+#define UP(vec, dst) \
+  if ((st = m->upload(vec, &(dst))) != PPASR_OK) return st
+#define UP4(vec, dst) \
+  if ((st = m->upload4(vec, &(dst))) != PPASR_OK) return st
+  auto vec_of = [](const float* p, size_t n) { return std::vector<float>(p, p + n); };
+
+  {  // ---- front end ----
+    GET(mean, "encoder.global_cmvn.mean", F);
+    GET(istd, "encoder.global_cmvn.istd", F);
+    GET(c1w, "encoder.embed.conv.0.weight", d * 9);
+    GET(c1b, "encoder.embed.conv.0.bias", d);
+    GET(c2w, "encoder.embed.conv.2.weight", (size_t)d * d * 9);
+    GET(c2b, "encoder.embed.conv.2.bias", d);
+    GET(ew, "encoder.embed.out.0.weight", (size_t)d * F2 * d);
+    GET(eb, "encoder.embed.out.0.bias", d);
+    UP(vec_of(mean, F), m->front.cmvn_mean);
+    UP(vec_of(istd, F), m->front.cmvn_istd);
+    std::vector<float> c1(9 * d);
+    for (int c = 0; c < d; ++c)
+      for (int j = 0; j < 9; ++j) c1[j * d + c] = c1w[c * 9 + j];
+    UP(c1, m->front.conv1_w);
+    UP(vec_of(c1b, d), m->front.conv1_b);
+    // conv2: K index = (kh*3+kw)*256 + cin ; weight layout [cout][cin][kh][kw]
+    UP4(pack_b(9 * d, d, [&](int k, int n) { return c2w[((size_t)n * d + (k % d)) * 9 + (k / d)]; }), m->front.conv2_w);
+    UP(vec_of(c2b, d), m->front.conv2_b);
+    // embed: our K index = f*256 + c ; Paddle's = c*F2 + f (subsampling.py:113 transpose+reshape)
+    UP4(pack_b(F2 * d, d, [&](int k, int n) { return ew[((size_t)(k % d) * F2 + (k / d)) * d + n]; }), m->front.embed_w);
+    UP(vec_of(eb, d), m->front.embed_b);
+  }
+
+  // ---- positional table (embedding.py:38-53) ----
+  const int max_len = desc->max_len > 0 ? desc->max_len : 5000;
+  m->desc.max_len = max_len;
+  const float* pe_dev = nullptr;
+  {
+    std::vector<float> pe((size_t)max_len * d);
+    auto it = sd.find("__pe_table__");
+    if (it != sd.end() && it->second.numel() == pe.size()) {
+      std::memcpy(pe.data(), it->second.p, pe.size() * sizeof(float));
+    } else {
+      for (int i = 0; i < d / 2; ++i) {
+        float div = expf((float)(2 * i) * (float)(-(std::log(10000.0) / d)));
+        for (int pos = 0; pos < max_len; ++pos) {
+          float a = (float)pos * div;
+          pe[(size_t)pos * d + 2 * i] = sinf(a);
+          pe[(size_t)pos * d + 2 * i + 1] = cosf(a);
+        }
+      }
+    }
+    UP(pe, pe_dev);
+  }
+
+  m->layers.resize(desc->num_blocks);
+  for (int i = 0; i < desc->num_blocks; ++i) {
+    LayerW& L = m->layers[i];
+    const std::string p = "encoder.encoders." + std::to_string(i) + ".";
+    auto ln = [&](const std::string& n, const float** g, const float** b) -> ppasr_status {
+      const float* gw = get(p + n + ".weight", d);
+      const float* gb = get(p + n + ".bias", d);
+      if (!gw || !gb) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + missing);
+      ppasr_status s1 = m->upload(vec_of(gw, d), g);
+      if (s1 != PPASR_OK) return s1;
+      return m->upload(vec_of(gb, d), b);
+    };
+    if ((st = ln("norm_ff_macaron", &L.ln_mac_g, &L.ln_mac_b)) != PPASR_OK) return st;
+    if ((st = ln("norm_mha", &L.ln_mha_g, &L.ln_mha_b)) != PPASR_OK) return st;
+    if ((st = ln("norm_conv", &L.ln_conv_g, &L.ln_conv_b)) != PPASR_OK) return st;
+    if ((st = ln("norm_ff", &L.ln_ff_g, &L.ln_ff_b)) != PPASR_OK) return st;
+    if ((st = ln("norm_final", &L.ln_fin_g, &L.ln_fin_b)) != PPASR_OK) return st;
+    if ((st = ln("conv_module.norm", &L.ln_cm_g, &L.ln_cm_b)) != PPASR_OK) return st;
+    auto ffn = [&](const std::string& n, const f32x4** w1, const float** b1, const f32x4** w2,
+                   const float** b2) -> ppasr_status {
+      const float* a1 = get(p + n + ".w_1.weight", (size_t)d * H);
+      const float* c1 = get(p + n + ".w_1.bias", H);
+      const float* a2 = get(p + n + ".w_2.weight", (size_t)H * d);
+      const float* c2 = get(p + n + ".w_2.bias", d);
+      if (!a1 || !c1 || !a2 || !c2) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + missing);
+      ppasr_status s;
+      if ((s = m->upload4(pack_b(d, H, [&](int k, int nn) { return a1[(size_t)k * H + nn]; }), w1)) != PPASR_OK) return s;
+      if ((s = m->upload(vec_of(c1, H), b1)) != PPASR_OK) return s;
+      if ((s = m->upload4(pack_b(H, d, [&](int k, int nn) { return a2[(size_t)k * d + nn]; }), w2)) != PPASR_OK) return s;
+      return m->upload(vec_of(c2, d), b2);
+    };
+    if ((st = ffn("feed_forward_macaron", &L.ffm_w1, &L.ffm_b1, &L.ffm_w2, &L.ffm_b2)) != PPASR_OK) return st;
+    if ((st = ffn("feed_forward", &L.ff_w1, &L.ff_b1, &L.ff_w2, &L.ff_b2)) != PPASR_OK) return st;
+    {
+      GET(wq, p + "self_attn.linear_q.weight", d * d);
+      GET(wk, p + "self_attn.linear_k.weight", d * d);
+      GET(wv, p + "self_attn.linear_v.weight", d * d);
+      GET(bq, p + "self_attn.linear_q.bias", d);
+      GET(bk, p + "self_attn.linear_k.bias", d);
+      GET(bv, p + "self_attn.linear_v.bias", d);
+      GET(wo, p + "self_attn.linear_out.weight", d * d);
+      GET(bo, p + "self_attn.linear_out.bias", d);
+      GET(wp, p + "self_attn.linear_pos.weight", d * d);
+      GET(pu, p + "self_attn.pos_bias_u", d);
+      GET(pv, p + "self_attn.pos_bias_v", d);
+      const float* ws[3] = {wq, wk, wv};
+      UP4(pack_b(d, 3 * d, [&](int k, int n) { return ws[n / d][(size_t)k * d + (n % d)]; }), L.wqkv);
+      std::vector<float> bqkv(3 * d);
+      std::memcpy(&bqkv[0], bq, d * sizeof(float));
+      std::memcpy(&bqkv[d], bk, d * sizeof(float));
+      std::memcpy(&bqkv[2 * d], bv, d * sizeof(float));
+      UP(bqkv, L.bqkv);
+      UP4(pack_b(d, d, [&](int k, int n) { return wo[(size_t)k * d + n]; }), L.wo);
+      UP(vec_of(bo, d), L.bo);
+      UP(vec_of(pu, d), L.pos_u);
+      UP(vec_of(pv, d), L.pos_v);
+      const float* wpos_dev = nullptr;
+      UP(vec_of(wp, (size_t)d * d), wpos_dev);
+      void* pt = nullptr;
+      HIP_TRY(hipMalloc(&pt, (size_t)max_len * d * sizeof(float)));
+      m->allocs.push_back(pt);
+      launch_posproj(pe_dev, wpos_dev, static_cast<float*>(pt), max_len, nullptr);
+      HIP_TRY(hipGetLastError());
+      L.ptab = static_cast<const float*>(pt);
+    }
+    {
+      GET(p1w, p + "conv_module.pointwise_conv1.weight", 2 * d * d);
+      GET(p1b, p + "conv_module.pointwise_conv1.bias", 2 * d);
+      GET(dww, p + "conv_module.depthwise_conv.weight", d * KS);
+      GET(dwb, p + "conv_module.depthwise_conv.bias", d);
+      GET(p2w, p + "conv_module.pointwise_conv2.weight", d * d);
+      GET(p2b, p + "conv_module.pointwise_conv2.bias", d);
+      // column permutation: packed col n' = w*128 + half*64 + j  <-  Conv1D out channel half*256 + w*64 + j
+      auto orig = [&](int np) { return ((np >> 6) & 1) * d + (np >> 7) * 64 + (np & 63); };
+      UP4(pack_b(d, 2 * d, [&](int k, int np) { return p1w[(size_t)orig(np) * d + k]; }), L.pw1);
+      std::vector<float> b1p(2 * d), gp(d);
+      for (int np = 0; np < 2 * d; ++np) b1p[np] = p1b[orig(np)];
+      for (int c = 0; c < d; ++c) gp[c] = p1b[c] * (1.0f / (1.0f + expf(-p1b[c + d])));
+      UP(b1p, L.pw1_b);
+      UP(gp, L.glu_pad);
+      std::vector<float> dwt((size_t)KS * d);
+      for (int c = 0; c < d; ++c)
+        for (int j = 0; j < KS; ++j) dwt[(size_t)j * d + c] = dww[(size_t)c * KS + j];
+      UP(dwt, L.dw_w);
+      UP(vec_of(dwb, d), L.dw_b);
+      UP4(pack_b(d, d, [&](int k, int n) { return p2w[(size_t)n * d + k]; }), L.pw2);
+      UP(vec_of(p2b, d), L.pw2_b);
+    }
+  }
+  {
+    GET(ag, "encoder.after_norm.weight", d);
+    GET(ab, "encoder.after_norm.bias", d);
+    GET(cw, "ctc.ctc_lo.weight", (size_t)d * V);
+    GET(cb, "ctc.ctc_lo.bias", V);
+    UP(vec_of(ag, d), m->head.ln_g);
+    UP(vec_of(ab, d), m->head.ln_b);
+    m->head.V = V;
+    m->head.n_tiles = (V + 31) / 32;
+    UP4(pack_b(d, V, [&](int k, int n) { return cw[(size_t)k * V + n]; }), m->head.w);
+    std::vector<float> cbp((size_t)m->head.n_tiles * 32, 0.f);
+    std::memcpy(cbp.data(), cb, V * sizeof(float));
+    UP(cbp, m->head.b);
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  *out = guard.release();
+  return PPASR_OK;
+#undef GET
+#undef UP
+#undef UP4
+}
+
+ppasr_status ppasr_destroy(ppasr_handle h) {
+  delete h;
+  return PPASR_OK;
+}
+
+int ppasr_out_frames(ppasr_handle h, int T) {
+  (void)h;
+  if (T < 7) return 0;
+  return ((T - 1) / 2 - 1) / 2;
+}
+
+namespace {
+struct WsLayout {
+  size_t y1, y2, xa, xb, xc, qkv, ctx, g, rmax, rsum, fa, fp, total;  // offsets in floats
+};
+WsLayout ws_layout(const ppasr_model_s* m, int B, int T) {
+  const size_t T1 = (T - 1) / 2, Tp = (T1 - 1) / 2;
+  const size_t M = (size_t)B * Tp;
+  auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };
+  WsLayout w;
+  size_t o = 0;
+  w.y1 = o; o += al((size_t)B * T1 * m->F1 * kD);
+  w.y2 = o; o += al(M * m->F2 * kD);
+  w.xa = o; o += al(M * kD);
+  w.xb = o; o += al(M * kD);
+  w.xc = o; o += al(M * kD);
+  w.qkv = o; o += al(M * 3 * kD);
+  w.ctx = o; o += al(M * kD);
+  w.g = o; o += al(M * kD);
+  w.rmax = o; o += al(M);
+  w.rsum = o; o += al(M);
+  w.fa = o; o += al(M);
+  w.fp = o; o += al(M);
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+size_t ppasr_workspace_bytes(ppasr_handle h, int B, int T) {
+  if (!h || B <= 0 || T < 7) return 0;
+  return ws_layout(h, B, T).total * sizeof(float);
+}
+
+ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats) {
+  if (!h) return fail(PPASR_EINVAL, "null handle");
+  h->taps = taps;
+  h->taps_floats = taps ? n_floats : 0;
+  return PPASR_OK;
+}
+
+ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* lens, int B, int T, float* probs,
+                          float* logits, int32_t* frame_argmax, float* frame_maxprob, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  if (!h || !feats || !workspace) return fail(PPASR_EINVAL, "null argument");
+  if (B <= 0 || T < 7) return fail(PPASR_EINVAL, "need B > 0 and T >= 7 frames");
+  const int F = h->desc.input_dim, T1 = (T - 1) / 2, F1 = h->F1, Tp = (T1 - 1) / 2, F2 = h->F2;
+  if (Tp >= h->desc.max_len) return fail(PPASR_EINVAL, "utterance longer than the positional table (embedding.py:64-66)");
+  const int M = B * Tp;
+  const WsLayout wl = ws_layout(h, B, T);
+  if (workspace_bytes < wl.total * sizeof(float)) return fail(PPASR_ENOSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* ws = static_cast<float*>(workspace);
+  float *y1 = ws + wl.y1, *y2 = ws + wl.y2, *xa = ws + wl.xa, *xb = ws + wl.xb, *xc = ws + wl.xc;
+  float *qkv = ws + wl.qkv, *ctx = ws + wl.ctx, *g = ws + wl.g;
+  size_t tap_off = 0;
+  auto tap = [&](const float* src, size_t n) {
+    if (h->taps && tap_off + n <= h->taps_floats)
+      (void)hipMemcpyAsync(h->taps + tap_off, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    tap_off += n;
+  };
+  launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st);
+  launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st);
+  launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), st);
+  tap(xa, (size_t)M * kD);
+  const int n_chunks = h->desc.linear_units / 256;
+  for (int i = 0; i < h->desc.num_blocks; ++i) {
+    const LayerW& L = h->layers[i];
+    launch_ffn_qkv(xa, xb, qkv, L, M, n_chunks, st);
+    tap(xb, (size_t)M * kD);
+    tap(qkv, (size_t)M * 3 * kD);
+    launch_attention(qkv, L, lens, ctx, B, Tp, h->desc.attention_heads, st);
+    tap(ctx, (size_t)M * kD);
+    launch_out_glu(ctx, xb, xc, g, L, lens, M, Tp, st);
+    tap(xc, (size_t)M * kD);
+    tap(g, (size_t)M * kD);
+    launch_conv_ffn(g, xc, xa, L, lens, M, Tp, n_chunks, h->desc.cnn_module_kernel, st);
+    tap(xa, (size_t)M * kD);
+  }
+  float* lg = logits ? logits : probs;  // probs are produced in place from the logits tap
+  int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
+  float* fp = frame_maxprob ? frame_maxprob : ws + wl.fp;
+  launch_ctc_head(xa, h->head, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, M, st);
+  if (probs) {
+    if (logits)
+      HIP_TRY(hipMemcpyAsync(probs, logits, (size_t)M * h->head.V * sizeof(float), hipMemcpyDeviceToDevice, st));
+    launch_softmax_from_stats(probs, ws + wl.rmax, ws + wl.rsum, M, h->head.V, st);
+  }
+  HIP_TRY(hipGetLastError());
+  return PPASR_OK;
+}
+
+ppasr_status ppasr_ctc_collapse(const int32_t* frame_argmax, const float* frame_maxprob, const int32_t* frame_lens, int B,
+                                int Tp, int blank, int32_t* tokens, int32_t* n_tokens, double* score, void* stream) {
+  if (!frame_argmax || !frame_maxprob || !tokens || !n_tokens || !score) return fail(PPASR_EINVAL, "null argument");
+  if (B <= 0 || Tp <= 0) return fail(PPASR_EINVAL, "empty batch");
+  launch_ctc_collapse(frame_argmax, frame_maxprob, frame_lens, B, Tp, blank, tokens, n_tokens, score,
+                      static_cast<hipStream_t>(stream));
+  HIP_TRY(hipGetLastError());
+  return PPASR_OK;
+}
+
+ppasr_status ppasr_ctc_greedy(const float* probs, const int32_t* frame_lens, int B, int Tp, int V, int blank,
+                              int32_t* tokens, int32_t* n_tokens, double* score, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  if (!probs || !tokens || !n_tokens || !score || !workspace) return fail(PPASR_EINVAL, "null argument");
+  if (B <= 0 || Tp <= 0 || V <= 0) return fail(PPASR_EINVAL, "empty batch");
+  const size_t n = (size_t)B * Tp;
+  if (workspace_bytes < n * (sizeof(int32_t) + sizeof(float))) return fail(PPASR_ENOSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int32_t* fa = static_cast<int32_t*>(workspace);
+  float* fp = reinterpret_cast<float*>(fa + n);
+  launch_frame_argmax(probs, fa, fp, B * Tp, V, st);
+  launch_ctc_collapse(fa, fp, frame_lens, B, Tp, blank, tokens, n_tokens, score, st);
+  HIP_TRY(hipGetLastError());
+  return PPASR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// conformer_kernels.h -- launch interface between the C-ABI (capi.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rowblock.h"
+
+namespace ppasr {
+
+// Device pointers of one ConformerEncoderLayer (conformer/encoder.py:286-344), re-packed:
+// dense weights in MFMA fragment order (see pack_b in capi.hip), vectors as plain float arrays.
+struct LayerW {
+  const float *ln_mac_g, *ln_mac_b, *ln_mha_g, *ln_mha_b, *ln_conv_g, *ln_conv_b;
+  const float *ln_ff_g, *ln_ff_b, *ln_fin_g, *ln_fin_b, *ln_cm_g, *ln_cm_b;
+  const f32x4 *ffm_w1, *ffm_w2, *ff_w1, *ff_w2, *wqkv, *wo, *pw1, *pw2;
+  const float *ffm_b1, *ffm_b2, *ff_b1, *ff_b2, *bqkv, *bo, *pw1_b, *pw2_b;
+  const float *dw_w;     // [k][256] tap-major depthwise weights
+  const float *dw_b;     // [256]
+  const float *glu_pad;  // [256] GLU(pointwise_conv1(0)) = value of a zero-padded frame after GLU
+  const float *pos_u, *pos_v;  // [256] = [h][dk]
+  const float *ptab;     // [max_len][256] linear_pos(pe)  (weight-only, folded at create time)
+};
+
+struct FrontW {
+  const float *cmvn_mean, *cmvn_istd;  // [F]
+  const float *conv1_w, *conv1_b;      // [9][256] tap-major, [256]
+  const f32x4 *conv2_w;                // packed, K = 9*256 ordered (kh,kw,cin)
+  const float *conv2_b;
+  const f32x4 *embed_w;                // packed, K = f2*256 ordered (f', c)
+  const float *embed_b;
+};
+
+struct HeadW {
+  const float *ln_g, *ln_b;  // encoder.after_norm
+  const f32x4 *w;            // packed [256][Vpad]
+  const float *b;            // [Vpad]
+  int V, n_tiles;
+};
+
+// ---- launchers (all asynchronous on `st`) ----
+void launch_posproj(const float* pe, const float* wpos /*[256][256] in,out*/, float* ptab, int max_len, hipStream_t st);
+void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T, int F, int T1, int F1, hipStream_t st);
+void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st);
+void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, hipStream_t st);
+void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st);
+void launch_attention(const float* qkv, const LayerW& w, const int64_t* lens, float* ctx, int B, int Tp, int H,
+                      hipStream_t st);
+void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, const LayerW& w, const int64_t* lens,
+                    int M, int Tp, hipStream_t st);
+void launch_conv_ffn(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int M, int Tp,
+                     int n_chunks, int ksize, hipStream_t st);
+void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr_argmax, float* fr_maxprob,
+                     float* row_max, float* row_sum, int M, hipStream_t st);
+void launch_softmax_from_stats(float* probs_inout, const float* row_max, const float* row_sum, int M, int V,
+                               hipStream_t st);
+void launch_frame_argmax(const float* probs, int32_t* fr_argmax, float* fr_maxprob, int M, int V, hipStream_t st);
+void launch_ctc_collapse(const int32_t* fr_argmax, const float* fr_maxprob, const int32_t* frame_lens, int B, int Tp,
+                         int blank, int32_t* tokens, int32_t* n_tokens, double* score, hipStream_t st);
+hipError_t configure_kernels();  // opt in to >64 KiB dynamic LDS
+
+}  // namespace ppasr

@@ -1,0 +1,872 @@
+// conformer_kernels.hip -- gfx950 kernels of the Conformer encoder + CTC head hot path.
+// Reference semantics: ppasr/model_utils/conformer/{encoder,attention,convolution,positionwise,
+// subsampling,embedding}.py, model_utils/loss/ctc.py, decoders/ctc_greedy_decoder.py
+// (file:line cited per kernel).  All arithmetic is fp32 (the reference's inference dtype).
+#include "conformer_kernels.h"
+
+#include <math.h>
+
+namespace ppasr {
+
+// =====================================================================================
+// create-time: ptab[pos][n] = sum_k pe[pos][k] * Wpos[k][n]   (attention.py:234, bias-free)
+// weight-only constant folding; not on the timed path, so a plain fmaf kernel.
+// =====================================================================================
+__global__ void k_posproj(const float* __restrict__ pe, const float* __restrict__ wpos, float* __restrict__ ptab,
+                          int max_len) {
+  int pos = blockIdx.x;
+  int n = threadIdx.x;
+  __shared__ float row[kD];
+  row[n] = pe[(size_t)pos * kD + n];
+  __syncthreads();
+  float acc = 0.f;
+  for (int k = 0; k < kD; ++k) acc = fmaf(row[k], wpos[k * kD + n], acc);
+  ptab[(size_t)pos * kD + n] = acc;
+}
+void launch_posproj(const float* pe, const float* wpos, float* ptab, int max_len, hipStream_t st) {
+  hipLaunchKernelGGL(k_posproj, dim3(max_len), dim3(kD), 0, st, pe, wpos, ptab, max_len);
+}
+
+// =====================================================================================
+// conv1: GlobalCMVN (utils/cmvn.py:29-31) + Conv2D(1->256, 3x3, s2) + ReLU
+// (conformer/subsampling.py:84-86).  Output NHWC [B][T1][F1][256] so that the implicit-GEMM
+// A rows of conv2 are contiguous 1 KiB runs.  One block per (t1, b); thread = channel.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ feats, FrontW fw, float* __restrict__ y1,
+                                               int T, int F, int T1, int F1) {
+  __shared__ float xs[3][128];
+  const int b = blockIdx.y, t1 = blockIdx.x, tid = threadIdx.x;
+  for (int idx = tid; idx < 3 * F; idx += 256) {
+    int i = idx / F, f = idx - i * F;
+    float v = feats[((size_t)b * T + 2 * t1 + i) * F + f];
+    xs[i][f] = (v - fw.cmvn_mean[f]) * fw.cmvn_istd[f];
+  }
+  __syncthreads();
+  float w[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) w[j] = fw.conv1_w[j * 256 + tid];
+  const float bias = fw.conv1_b[tid];
+  float* out = y1 + ((size_t)(b * T1 + t1) * F1) * 256 + tid;
+  for (int f1 = 0; f1 < F1; ++f1) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc = fmaf(w[i * 3 + j], xs[i][2 * f1 + j], acc);
+    acc += bias;
+    out[(size_t)f1 * 256] = fmaxf(acc, 0.f);
+  }
+}
+void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T, int F, int T1, int F1, hipStream_t st) {
+  hipLaunchKernelGGL(k_conv1, dim3(T1, B), dim3(256), 0, st, feats, fw, y1, T, F, T1, F1);
+}
+
+// =====================================================================================
+// Streamed-A GEMM: out[M][256] = act(A[M][K] * W + b) * scale, A rows gathered from global
+// in KC-wide chunks through a double-buffered LDS tile, W streamed in fragment order.
+//   conv2  (subsampling.py:87-88): implicit GEMM, K = (kh,kw,cin) = 2304, ReLU, MT=4 (128 rows)
+//   embed  (subsampling.py:89,113 + embedding.py:112): K = f2*256, *sqrt(d), MT=1
+// =====================================================================================
+struct Conv2Src {
+  const float* y1;
+  int T1, F1, Tp, F2;
+  __device__ __forceinline__ const float* base(int m) const {
+    int f2 = m % F2;
+    int bt = m / F2;
+    int tp = bt % Tp;
+    int b = bt / Tp;
+    return y1 + ((size_t)((b * T1 + 2 * tp) * F1 + 2 * f2)) * 256;
+  }
+  // KC = 64: chunk kc -> tap kc>>2 (kh,kw), channel quarter kc&3
+  __device__ __forceinline__ size_t chunk_off(int kc) const {
+    int tap = kc >> 2;
+    int kh = tap / 3, kw = tap - 3 * kh;
+    return ((size_t)(kh * F1 + kw)) * 256 + (kc & 3) * 64;
+  }
+};
+struct DenseSrc {
+  const float* a;
+  int K, KC;
+  __device__ __forceinline__ const float* base(int m) const { return a + (size_t)m * K; }
+  __device__ __forceinline__ size_t chunk_off(int kc) const { return (size_t)kc * KC; }
+};
+
+template <int MT, int KC, bool RELU, typename Src>
+__global__ __launch_bounds__(256) void k_gemm_stream(Src src, const f32x4* __restrict__ wp, const float* __restrict__ bias,
+                                                     float* __restrict__ out, int M, int n_chunks, float scale) {
+  constexpr int BM = 32 * MT;
+  constexpr int LD = KC + 4;
+  constexpr int F4_PER_ROW = KC / 4;
+  constexpr int NL = BM * F4_PER_ROW / 256;  // float4 loads per thread per chunk
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  const int r0 = blockIdx.x * BM;
+  const float* rowp[NL];
+  int lds_off[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    int idx = tid + 256 * i;
+    int row = idx / F4_PER_ROW, c4 = idx - row * F4_PER_ROW;
+    int m = r0 + row;
+    rowp[i] = (m < M) ? src.base(m) + 4 * c4 : nullptr;
+    lds_off[i] = row * LD + 4 * c4;
+  }
+  f32x4 stg[NL];
+  auto load_chunk = [&](int kc) {
+    size_t off = src.chunk_off(kc);
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      stg[i] = rowp[i] ? *reinterpret_cast<const f32x4*>(rowp[i] + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto write_chunk = [&](float* buf) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4*>(buf + lds_off[i]) = stg[i];
+  };
+  f32x16 acc[MT][2];
+  acc_zero(acc);
+  const int tile_stride = n_chunks * (KC / 8) * 64;
+  const f32x4* wbase = wp + (size_t)(wave * 2) * tile_stride;
+  load_chunk(0);
+  write_chunk(smem);
+  __syncthreads();
+  for (int kc = 0; kc < n_chunks; ++kc) {
+    float* cur = smem + (kc & 1) * BM * LD;
+    float* nxt = smem + ((kc + 1) & 1) * BM * LD;
+    if (kc + 1 < n_chunks) load_chunk(kc + 1);
+    rb_gemm<MT, 2>(cur, LD, wbase + (size_t)kc * (KC / 8) * 64, tile_stride, KC / 8, acc);
+    if (kc + 1 < n_chunks) write_chunk(nxt);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = wave * 64 + nt * 32 + (lane & 31);
+      const float bv = bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = r0 + mt * 32 + acc_row(r, lane);
+        float v = acc[mt][nt][r] + bv;
+        if (RELU) v = fmaxf(v, 0.f);
+        v *= scale;
+        if (m < M) out[(size_t)m * kD + col] = v;
+      }
+    }
+}
+
+void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st) {
+  Conv2Src src{y1, T1, F1, Tp, F2};
+  int M = B * Tp * F2;
+  constexpr int MT = 4, KC = 64;
+  size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
+  hipLaunchKernelGGL((k_gemm_stream<MT, KC, true, Conv2Src>), dim3((M + 32 * MT - 1) / (32 * MT)), dim3(256), lds, st, src,
+                     fw.conv2_w, fw.conv2_b, y2, M, 36, 1.0f);
+}
+void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, hipStream_t st) {
+  constexpr int MT = 1, KC = 256;
+  DenseSrc src{y2, K, KC};
+  size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
+  hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, DenseSrc>), dim3((M + 31) / 32), dim3(256), lds, st, src, fw.embed_w,
+                     fw.embed_b, x0, M, K / KC, xscale);
+}
+
+// =====================================================================================
+// Row-block phases shared by the per-layer kernels
+// =====================================================================================
+
+// PositionwiseFeedForward (positionwise.py:32-39): acc2 += swish(A*W1 + b1) * W2, hidden
+// dimension processed in 256-wide chunks that never leave LDS (double-buffered bufH).
+__device__ __forceinline__ void ffn_phase(const float* bufA, float* bufH, const f32x4* __restrict__ w1,
+                                          const float* __restrict__ b1, const f32x4* __restrict__ w2, int n_chunks,
+                                          f32x16 (&acc2)[1][2]) {
+  const int lane = lane_id(), wave = wave_id();
+  const int ts1 = (kD / 8) * 64;            // W1: K = 256
+  const int ts2 = (n_chunks * 256 / 8) * 64;  // W2: K = hidden
+  for (int c = 0; c < n_chunks; ++c) {
+    f32x16 acc1[1][2];
+    acc_zero(acc1);
+    rb_gemm<1, 2>(bufA, kLda, w1 + (size_t)(c * 8 + wave * 2) * ts1, ts1, kD / 8, acc1);
+    float* hb = bufH + (c & 1) * kRows * kLda;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int colh = wave * 64 + nt * 32 + (lane & 31);
+      const float bv = b1[c * 256 + colh];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hb[acc_row(r, lane) * kLda + colh] = swishf(acc1[0][nt][r] + bv);
+    }
+    __syncthreads();
+    rb_gemm<1, 2>(hb, kLda, w2 + (size_t)(wave * 2) * ts2 + (size_t)c * 32 * 64, ts2, kD / 8, acc2);
+  }
+}
+
+// bufX[row][col] += scale * (acc + bias[col])    (residual update, each element owned by one lane)
+__device__ __forceinline__ void residual_epilogue(float* bufX, const f32x16 (&acc)[1][2], const float* __restrict__ bias,
+                                                  float scale) {
+  const int lane = lane_id(), wave = wave_id();
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int col = wave * 64 + nt * 32 + (lane & 31);
+    const float bv = bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float* p = bufX + acc_row(r, lane) * kLda + col;
+      *p = *p + scale * (acc[0][nt][r] + bv);
+    }
+  }
+}
+
+struct PadRows {  // conv-module pad masking (convolution.py:104-106,138-140): frame t of utterance b is PAD iff 4t >= len[b]
+  const int64_t* lens;
+  int r0, Tp, M;
+  __device__ __forceinline__ bool operator()(int row) const {
+    if (!lens) return false;
+    int m = r0 + row;
+    if (m >= M) return false;
+    int b = m / Tp, t = m - b * Tp;
+    return 4 * (int64_t)t >= lens[b];
+  }
+};
+
+// -------------------------------------------------------------------------------------
+// S1: x1 = x + 0.5*FFN_macaron(LN(x)) ; qkv = LN_mha(x1) * [Wq|Wk|Wv] + b
+// (encoder.py:380-391, attention.py:75-77)
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ffn_qkv(const float* __restrict__ x_in, float* __restrict__ x1,
+                                                 float* __restrict__ qkv, LayerW w, int M, int n_chunks) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufX = smem;
+  float* bufA = bufX + kRows * kLda;
+  float* bufH = bufA + kRows * kLda;
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, M - r0);
+  rb_load_rows(bufX, kLda, x_in + (size_t)r0 * kD, kRows, valid);
+  rb_layernorm(bufX, bufA, kLda, kRows, w.ln_mac_g, w.ln_mac_b, 1e-5f, NoZero());
+  __syncthreads();
+  f32x16 acc2[1][2];
+  acc_zero(acc2);
+  ffn_phase(bufA, bufH, w.ffm_w1, w.ffm_b1, w.ffm_w2, n_chunks, acc2);
+  residual_epilogue(bufX, acc2, w.ffm_b2, 0.5f);
+  __syncthreads();
+  rb_store_rows(x1 + (size_t)r0 * kD, bufX, kLda, kRows, valid);
+  rb_layernorm(bufX, bufA, kLda, kRows, w.ln_mha_g, w.ln_mha_b, 1e-5f, NoZero());
+  __syncthreads();
+  const int ts = (kD / 8) * 64;
+  for (int c = 0; c < 3; ++c) {
+    f32x16 acc[1][2];
+    acc_zero(acc);
+    rb_gemm<1, 2>(bufA, kLda, w.wqkv + (size_t)(c * 8 + wave * 2) * ts, ts, kD / 8, acc);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = c * 256 + wave * 64 + nt * 32 + (lane & 31);
+      const float bv = w.bqkv[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = acc_row(r, lane);
+        if (row < valid) qkv[(size_t)(r0 + row) * 768 + col] = acc[0][nt][r] + bv;
+      }
+    }
+  }
+}
+constexpr size_t kLdsFfnQkv = 4 * kRows * kLda * sizeof(float);
+void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st) {
+  hipLaunchKernelGGL(k_ffn_qkv, dim3((M + kRows - 1) / kRows), dim3(256), kLdsFfnQkv, st, x_in, x1, qkv, w, M, n_chunks);
+}
+
+// -------------------------------------------------------------------------------------
+// Attention: RelPositionMultiHeadedAttention.forward + forward_attention
+// (attention.py:198-262, 86-126).  scores = ((q+u) k^T + (q+v) p^T) / sqrt(dk) (rel_shift is
+// disabled in the reference, :256-258) == one contraction over the concatenated 128-wide
+// operands Q' = [q+u | q+v], K' = [k | p].  Key-padding mask from lengths (key j masked iff
+// 4j >= len[b], subsampling.py:115), softmax, masked probs -> 0, times V.  Flash-style over
+// 128-key blocks with running (max, sum) so any key count fits the same LDS footprint.
+// Block = (32-query tile, head, utterance); waves split keys for QK^T and (column tile,
+// key half) for PV.
+// -------------------------------------------------------------------------------------
+constexpr int kQld = 132, kSld = 129, kKld = 36, kVld = 68;
+constexpr int kAttnLdsFloats = 32 * kQld + 32 * kSld + 128 * kVld + 96;
+constexpr size_t kLdsAttn = kAttnLdsFloats * sizeof(float);
+
+__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, LayerW w, const int64_t* __restrict__ lens,
+                                                   float* __restrict__ ctx, int Tp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;               // [32][132]  Q' = [q+u | q+v]
+  float* Ss = Qs + 32 * kQld;     // [32][129]  scores / probabilities of the current key block
+  float* KV = Ss + 32 * kSld;     // union: K' chunk [128][36]  |  V block [128][68]
+  float* stM = KV + 128 * kVld;   // running max   [32]
+  float* stL = stM + 32;          // running sum   [32]
+  float* stA = stL + 32;          // rescale alpha [32]
+  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  const int T1 = Tp, T2 = Tp;
+  const size_t row0 = (size_t)b * Tp;
+  const int64_t len_b = lens ? lens[b] : (int64_t)4 * T2;
+
+  // ---- Q' ----
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int idx = tid + 256 * i;
+    int row = idx >> 4, f4 = idx & 15;
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    if (q0 + row < T1) q = *reinterpret_cast<const f32x4*>(qkv + (row0 + q0 + row) * 768 + h * 64 + f4 * 4);
+    f32x4 u = *reinterpret_cast<const f32x4*>(w.pos_u + h * 64 + f4 * 4);
+    f32x4 v = *reinterpret_cast<const f32x4*>(w.pos_v + h * 64 + f4 * 4);
+    *reinterpret_cast<f32x4*>(Qs + row * kQld + f4 * 4) = q + u;
+    *reinterpret_cast<f32x4*>(Qs + row * kQld + 64 + f4 * 4) = q + v;
+  }
+  if (tid < 32) {
+    stM[tid] = -INFINITY;
+    stL[tid] = 0.f;
+  }
+  f32x16 acc_o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_o[r] = 0.f;
+  const int ct = wave & 1, kh = wave >> 1;
+
+  const int nkb = (T2 + 127) / 128;
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int key0 = kb * 128;
+    // ---- S = Q' K'^T over four 32-feature chunks (k: chunks 0,1 ; p: chunks 2,3) ----
+    f32x16 acc_s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_s[r] = 0.f;
+    f32x4 stg[4];
+    auto load_kchunk = [&](int fc) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int idx = tid + 256 * i;
+        int key = idx >> 3, f4 = idx & 7;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (key0 + key < T2) {
+          const float* p = (fc < 2) ? qkv + (row0 + key0 + key) * 768 + 256 + h * 64 + fc * 32 + f4 * 4
+                                    : w.ptab + (size_t)(key0 + key) * kD + h * 64 + (fc - 2) * 32 + f4 * 4;
+          v = *reinterpret_cast<const f32x4*>(p);
+        }
+        stg[i] = v;
+      }
+    };
+    auto write_kchunk = [&]() {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int idx = tid + 256 * i;
+        int key = idx >> 3, f4 = idx & 7;
+        *reinterpret_cast<f32x4*>(KV + key * kKld + f4 * 4) = stg[i];
+      }
+    };
+    load_kchunk(0);
+    for (int fc = 0; fc < 4; ++fc) {
+      __syncthreads();  // previous readers of KV (PV of last block / MFMAs of last chunk) are done
+      write_kchunk();
+      __syncthreads();
+      if (fc + 1 < 4) load_kchunk(fc + 1);
+      const float* a_ptr = Qs + (lane & 31) * kQld + fc * 32 + 4 * (lane >> 5);
+      const float* b_ptr = KV + (wave * 32 + (lane & 31)) * kKld + 4 * (lane >> 5);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(a_ptr + 8 * g);
+        f32x4 bb = *reinterpret_cast<const f32x4*>(b_ptr + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc_s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bb[j], acc_s, 0, 0, 0);
+      }
+    }
+    // issue the V block loads early; they land in registers while the softmax pass runs
+    f32x4 vst[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int idx = tid + 256 * i;
+      int key = idx >> 4, f4 = idx & 15;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (key0 + key < T2) v = *reinterpret_cast<const f32x4*>(qkv + (row0 + key0 + key) * 768 + 512 + h * 64 + f4 * 4);
+      vst[i] = v;
+    }
+    {
+      const int kl = wave * 32 + (lane & 31);
+      const int key = key0 + kl;
+      const bool masked = (key >= T2) || (4 * (int64_t)key >= len_b);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ss[acc_row(r, lane) * kSld + kl] = masked ? -INFINITY : acc_s[r] * 0.125f;
+    }
+    __syncthreads();  // S complete; all K' reads done -> KV may be overwritten with V
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int idx = tid + 256 * i;
+      int key = idx >> 4, f4 = idx & 15;
+      *reinterpret_cast<f32x4*>(KV + key * kVld + f4 * 4) = vst[i];
+    }
+    // ---- online softmax over this block's 128 keys; wave handles rows 8w..8w+7 ----
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = wave * 8 + rr;
+      float v0 = Ss[row * kSld + lane], v1 = Ss[row * kSld + lane + 64];
+      float bm = wave_max(fmaxf(v0, v1));
+      float m_old = stM[row];
+      float m_new = fmaxf(m_old, bm);
+      float alpha, p0, p1;
+      if (m_new == -INFINITY) {  // nothing unmasked so far
+        alpha = 1.f;
+        p0 = 0.f;
+        p1 = 0.f;
+      } else {
+        alpha = expf(m_old - m_new);
+        p0 = expf(v0 - m_new);
+        p1 = expf(v1 - m_new);
+      }
+      float ps = wave_sum(p0 + p1);
+      Ss[row * kSld + lane] = p0;
+      Ss[row * kSld + lane + 64] = p1;
+      if (lane == 0) {
+        stM[row] = m_new;
+        stL[row] = stL[row] * alpha + ps;
+        stA[row] = alpha;
+      }
+    }
+    __syncthreads();
+    // ---- O = O*alpha + P V : wave -> (32-column tile ct, 64-key half kh) ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[r] *= stA[acc_row(r, lane)];
+    {
+      const float* a_ptr = Ss + (lane & 31) * kSld + kh * 64 + (lane >> 5);
+      const float* b_ptr = KV + (kh * 64 + (lane >> 5)) * kVld + ct * 32 + (lane & 31);
+#pragma unroll 8
+      for (int s = 0; s < 32; ++s)
+        acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[2 * s], b_ptr[2 * s * kVld], acc_o, 0, 0, 0);
+    }
+    // next iteration's first __syncthreads() protects KV / Ss
+  }
+  __syncthreads();
+  // combine the two key halves, normalise, store
+  float* Osum = Ss;  // [2][32][33]
+  if (kh == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Osum[(ct * 32 + acc_row(r, lane)) * 33 + (lane & 31)] = acc_o[r];
+  }
+  __syncthreads();
+  if (kh == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = acc_row(r, lane);
+      float l = stL[row];
+      float o = acc_o[r] + Osum[(ct * 32 + row) * 33 + (lane & 31)];
+      o = (l > 0.f) ? o / l : 0.f;  // fully masked row -> 0 (attention.py:118)
+      if (q0 + row < T1) ctx[(row0 + q0 + row) * kD + h * 64 + ct * 32 + (lane & 31)] = o;
+    }
+  }
+}
+void launch_attention(const float* qkv, const LayerW& w, const int64_t* lens, float* ctx, int B, int Tp, int H,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(k_attention, dim3((Tp + 31) / 32, H, B), dim3(256), kLdsAttn, st, qkv, w, lens, ctx, Tp);
+}
+
+// -------------------------------------------------------------------------------------
+// S3: x2 = x1 + ctx*Wo + bo ; g = GLU(pointwise_conv1(mask(LN_conv(x2))))
+// (attention.py:126, encoder.py:399-409, convolution.py:104-106,125-126)
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_out_glu(const float* __restrict__ ctx, const float* __restrict__ x1,
+                                                 float* __restrict__ x2, float* __restrict__ g, LayerW w,
+                                                 const int64_t* __restrict__ lens, int M, int Tp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufX = smem;
+  float* bufA = bufX + kRows * kLda;
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, M - r0);
+  rb_load_rows(bufA, kLda, ctx + (size_t)r0 * kD, kRows, valid);
+  __syncthreads();
+  const int ts = (kD / 8) * 64;
+  {
+    f32x16 acc[1][2];
+    acc_zero(acc);
+    rb_gemm<1, 2>(bufA, kLda, w.wo + (size_t)(wave * 2) * ts, ts, kD / 8, acc);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = wave * 64 + nt * 32 + (lane & 31);
+      const float bv = w.bo[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = acc_row(r, lane);
+        float v = 0.f;
+        if (row < valid) {
+          v = x1[(size_t)(r0 + row) * kD + col] + (acc[0][nt][r] + bv);
+          x2[(size_t)(r0 + row) * kD + col] = v;
+        }
+        bufX[row * kLda + col] = v;
+      }
+    }
+  }
+  __syncthreads();
+  rb_layernorm(bufX, bufA, kLda, kRows, w.ln_conv_g, w.ln_conv_b, 1e-5f, PadRows{lens, r0, Tp, M});
+  __syncthreads();
+  {
+    // pointwise_conv1 columns are host-permuted so wave w owns value cols [64w,64w+64) (tiles 4w, 4w+1)
+    // and the matching gate cols 256+[64w,64w+64) (tiles 4w+2, 4w+3)
+    f32x16 acc[1][4];
+    acc_zero(acc);
+    rb_gemm<1, 4>(bufA, kLda, w.pw1 + (size_t)(wave * 4) * ts, ts, kD / 8, acc);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int cl = nt * 32 + (lane & 31);
+      const float bval = w.pw1_b[wave * 128 + cl];
+      const float bgate = w.pw1_b[wave * 128 + 64 + cl];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = acc_row(r, lane);
+        float val = acc[0][nt][r] + bval;
+        float gate = acc[0][nt + 2][r] + bgate;
+        if (row < valid) g[(size_t)(r0 + row) * kD + wave * 64 + cl] = val * sigmoidf(gate);
+      }
+    }
+  }
+}
+constexpr size_t kLdsOutGlu = 2 * kRows * kLda * sizeof(float);
+void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, const LayerW& w, const int64_t* lens, int M,
+                    int Tp, hipStream_t st) {
+  hipLaunchKernelGGL(k_out_glu, dim3((M + kRows - 1) / kRows), dim3(256), kLdsOutGlu, st, ctx, x1, x2, g, w, lens, M, Tp);
+}
+
+// -------------------------------------------------------------------------------------
+// S4: causal depthwise conv (k taps, left context k-1; frames before the utterance start
+// read GLU(pointwise_conv1(0)) because the reference zero-pads BEFORE pointwise_conv1,
+// convolution.py:108-126) -> LayerNorm -> swish -> pointwise_conv2 -> pad mask -> +residual
+// -> LN_ff -> FFN -> +0.5 residual -> LN_final     (convolution.py:129-140, encoder.py:416-429)
+// -------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void k_conv_ffn(const float* __restrict__ g, const float* __restrict__ x2,
+                                                  float* __restrict__ x_out, LayerW w, const int64_t* __restrict__ lens,
+                                                  int M, int Tp, int n_chunks) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufX = smem;
+  float* bufA = bufX + kRows * kLda;
+  float* bufH = bufA + kRows * kLda;
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, M - r0);
+  constexpr int LO = KS - 1;
+  {
+    // wave handles block rows 8w..8w+7; lane handles channels 4*lane..4*lane+3
+    const int m0 = r0 + wave * 8;
+    f32x4 win[LO + 8];
+#pragma unroll
+    for (int q = 0; q < LO + 8; ++q) {
+      int mq = m0 - LO + q;
+      win[q] = (mq >= 0 && mq < M) ? *reinterpret_cast<const f32x4*>(g + (size_t)mq * kD + 4 * lane)
+                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const f32x4 gp = *reinterpret_cast<const f32x4*>(w.glu_pad + 4 * lane);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(w.dw_b + 4 * lane);
+    f32x4 out[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int t_of[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t_of[i] = (m0 + i) % Tp;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const f32x4 wj = *reinterpret_cast<const f32x4*>(w.dw_w + j * kD + 4 * lane);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        f32x4 v = (t_of[i] - LO + j >= 0) ? win[i + j] : gp;
+        out[i] += wj * v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(bufA + (wave * 8 + i) * kLda + 4 * lane) = out[i] + bias;
+  }
+  __syncthreads();
+  {  // conv-module LayerNorm (nn.LayerNorm(channels), eps 1e-5) + swish, in place
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(w.ln_cm_g + 4 * lane);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(w.ln_cm_b + 4 * lane);
+    for (int row = wave; row < kRows; row += 4) {
+      f32x4 x = *reinterpret_cast<const f32x4*>(bufA + row * kLda + 4 * lane);
+      float mean = wave_sum(x[0] + x[1] + x[2] + x[3]) * (1.0f / kD);
+      f32x4 c = x - mean;
+      float var = wave_sum(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3]) * (1.0f / kD);
+      float rstd = 1.0f / sqrtf(var + 1e-5f);
+      f32x4 y = c * rstd * gg + bb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = swishf(y[e]);
+      *reinterpret_cast<f32x4*>(bufA + row * kLda + 4 * lane) = y;
+    }
+  }
+  __syncthreads();
+  const int ts = (kD / 8) * 64;
+  PadRows is_pad{lens, r0, Tp, M};
+  {
+    f32x16 acc[1][2];
+    acc_zero(acc);
+    rb_gemm<1, 2>(bufA, kLda, w.pw2 + (size_t)(wave * 2) * ts, ts, kD / 8, acc);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = wave * 64 + nt * 32 + (lane & 31);
+      const float bv = w.pw2_b[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = acc_row(r, lane);
+        float v = 0.f;
+        if (row < valid) {
+          float c = is_pad(row) ? 0.f : acc[0][nt][r] + bv;
+          v = x2[(size_t)(r0 + row) * kD + col] + c;
+        }
+        bufX[row * kLda + col] = v;
+      }
+    }
+  }
+  __syncthreads();
+  rb_layernorm(bufX, bufA, kLda, kRows, w.ln_ff_g, w.ln_ff_b, 1e-5f, NoZero());
+  __syncthreads();
+  f32x16 acc2[1][2];
+  acc_zero(acc2);
+  ffn_phase(bufA, bufH, w.ff_w1, w.ff_b1, w.ff_w2, n_chunks, acc2);
+  residual_epilogue(bufX, acc2, w.ff_b2, 0.5f);
+  __syncthreads();
+  rb_layernorm(bufX, bufX, kLda, kRows, w.ln_fin_g, w.ln_fin_b, 1e-5f, NoZero());
+  // rb_layernorm and rb_store_rows use the same wave->row mapping: no barrier needed
+  rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);
+}
+constexpr size_t kLdsConvFfn = 4 * kRows * kLda * sizeof(float);
+void launch_conv_ffn(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int M, int Tp,
+                     int n_chunks, int ksize, hipStream_t st) {
+  dim3 grid((M + kRows - 1) / kRows);
+  if (ksize == 15)
+    hipLaunchKernelGGL(k_conv_ffn<15>, grid, dim3(256), kLdsConvFfn, st, g, x2, x_out, w, lens, M, Tp, n_chunks);
+  else if (ksize == 31)
+    hipLaunchKernelGGL(k_conv_ffn<31>, grid, dim3(256), kLdsConvFfn, st, g, x2, x_out, w, lens, M, Tp, n_chunks);
+  else if (ksize == 7)
+    hipLaunchKernelGGL(k_conv_ffn<7>, grid, dim3(256), kLdsConvFfn, st, g, x2, x_out, w, lens, M, Tp, n_chunks);
+}
+
+// -------------------------------------------------------------------------------------
+// CTC head: after_norm (encoder.py:201-202) -> ctc_lo (loss/ctc.py:27) -> per-frame softmax
+// statistics + argmax (loss/ctc.py:62-70, ctc_greedy_decoder.py:21-22) without materialising
+// the [B,T',V] probability tensor.  Optional logits tap.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ctc_head(const float* __restrict__ x, HeadW hw, float* __restrict__ logits,
+                                                  int32_t* __restrict__ fr_argmax, float* __restrict__ fr_maxprob,
+                                                  float* __restrict__ row_max, float* __restrict__ row_sum, int M) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufA = smem;                         // [32][260]
+  float* redM = bufA + kRows * kLda;          // [4][32]
+  float* redS = redM + 128;                   // [4][32]
+  int* redI = reinterpret_cast<int*>(redS + 128);  // [4][32]
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, M - r0);
+  const int V = hw.V;
+  rb_load_rows(bufA, kLda, x + (size_t)r0 * kD, kRows, valid);
+  rb_layernorm(bufA, bufA, kLda, kRows, hw.ln_g, hw.ln_b, 1e-5f, NoZero());
+  __syncthreads();
+  float mx[16], sm[16];
+  int ix[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    mx[r] = -INFINITY;
+    sm[r] = 0.f;
+    ix[r] = 0x7fffffff;
+  }
+  const int ts = (kD / 8) * 64;
+  for (int tile = wave; tile < hw.n_tiles; tile += 4) {
+    f32x16 acc[1][1];
+    acc_zero(acc);
+    rb_gemm<1, 1>(bufA, kLda, hw.w + (size_t)tile * ts, ts, kD / 8, acc);
+    const int col = tile * 32 + (lane & 31);
+    const bool cv = col < V;
+    const float bv = hw.b[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[0][0][r] + bv;
+      int row = acc_row(r, lane);
+      if (cv) {
+        if (logits && row < valid) logits[(size_t)(r0 + row) * V + col] = v;
+        if (v > mx[r]) {
+          sm[r] = sm[r] * __expf(mx[r] - v) + 1.0f;
+          mx[r] = v;
+          ix[r] = col;
+        } else {
+          sm[r] += __expf(v - mx[r]);
+        }
+      }
+    }
+  }
+  // reduce over the 32 lanes (columns) of each half-wave; ties -> lowest column (numpy argmax)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float m = mx[r], s = sm[r];
+    int i = ix[r];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      float m2 = __shfl_xor(m, o), s2 = __shfl_xor(s, o);
+      int i2 = __shfl_xor(i, o);
+      float mn = fmaxf(m, m2);
+      float sa = (m == -INFINITY) ? 0.f : s * __expf(m - mn);
+      float sb = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mn);
+      bool take2 = (m2 > m) || (m2 == m && i2 < i);
+      i = take2 ? i2 : i;
+      m = mn;
+      s = sa + sb;
+    }
+    if ((lane & 31) == 0) {
+      int row = acc_row(r, lane);
+      redM[wave * 32 + row] = m;
+      redS[wave * 32 + row] = s;
+      redI[wave * 32 + row] = i;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int row = threadIdx.x;
+    float m = redM[row], s = redS[row];
+    int i = redI[row];
+    for (int wv = 1; wv < 4; ++wv) {
+      float m2 = redM[wv * 32 + row], s2 = redS[wv * 32 + row];
+      int i2 = redI[wv * 32 + row];
+      float mn = fmaxf(m, m2);
+      float sa = (m == -INFINITY) ? 0.f : s * __expf(m - mn);
+      float sb = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mn);
+      bool take2 = (m2 > m) || (m2 == m && i2 < i);
+      i = take2 ? i2 : i;
+      m = mn;
+      s = sa + sb;
+    }
+    if (row < valid) {
+      if (fr_argmax) fr_argmax[r0 + row] = i;
+      if (fr_maxprob) fr_maxprob[r0 + row] = 1.0f / s;
+      if (row_max) row_max[r0 + row] = m;
+      if (row_sum) row_sum[r0 + row] = s;
+    }
+  }
+}
+constexpr size_t kLdsCtc = (kRows * kLda + 3 * 128) * sizeof(float);
+void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr_argmax, float* fr_maxprob, float* row_max,
+                     float* row_sum, int M, hipStream_t st) {
+  hipLaunchKernelGGL(k_ctc_head, dim3((M + kRows - 1) / kRows), dim3(256), kLdsCtc, st, x, hw, logits, fr_argmax,
+                     fr_maxprob, row_max, row_sum, M);
+}
+
+// probs = softmax(logits) recomputed exactly (max, then exp(x-max)/sum) in place; one wave per row.
+__global__ __launch_bounds__(256) void k_softmax_rows(float* __restrict__ p, int M, int V) {
+  const int row = blockIdx.x * 4 + wave_id();
+  if (row >= M) return;
+  const int lane = lane_id();
+  float* x = p + (size_t)row * V;
+  float m = -INFINITY;
+  for (int c = lane; c < V; c += 64) m = fmaxf(m, x[c]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < V; c += 64) {
+    float e = expf(x[c] - m);
+    x[c] = e;
+    s += e;
+  }
+  s = wave_sum(s);
+  for (int c = lane; c < V; c += 64) x[c] = x[c] / s;
+}
+void launch_softmax_from_stats(float* probs_inout, const float*, const float*, int M, int V, hipStream_t st) {
+  hipLaunchKernelGGL(k_softmax_rows, dim3((M + 3) / 4), dim3(256), 0, st, probs_inout, M, V);
+}
+
+// =====================================================================================
+// CTC greedy decode (decoders/ctc_greedy_decoder.py:6-31)
+// =====================================================================================
+// stage 1 from materialised probabilities: np.argmax(axis=1) (first max wins) + prob at argmax
+__global__ __launch_bounds__(256) void k_frame_argmax(const float* __restrict__ probs, int32_t* __restrict__ fr_argmax,
+                                                      float* __restrict__ fr_maxprob, int M, int V) {
+  const int row = blockIdx.x * 4 + wave_id();
+  if (row >= M) return;
+  const int lane = lane_id();
+  const float* x = probs + (size_t)row * V;
+  float m = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int c = lane; c < V; c += 64) {
+    float v = x[c];
+    if (v > m || idx == 0x7fffffff) {  // first element always taken (handles -inf / NaN-free inputs)
+      m = v;
+      idx = c;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float m2 = __shfl_xor(m, o);
+    int i2 = __shfl_xor(idx, o);
+    bool take2 = (i2 != 0x7fffffff) && (idx == 0x7fffffff || m2 > m || (m2 == m && i2 < idx));
+    if (take2) {
+      m = m2;
+      idx = i2;
+    }
+  }
+  if (lane == 0) {
+    fr_argmax[row] = idx;
+    fr_maxprob[row] = m;
+  }
+}
+void launch_frame_argmax(const float* probs, int32_t* fr_argmax, float* fr_maxprob, int M, int V, hipStream_t st) {
+  hipLaunchKernelGGL(k_frame_argmax, dim3((M + 3) / 4), dim3(256), 0, st, probs, fr_argmax, fr_maxprob, M, V);
+}
+
+// stage 2: groupby-collapse, drop blank, score = mean(non-blank max probs)*100; one wave per utterance
+__global__ __launch_bounds__(64) void k_ctc_collapse(const int32_t* __restrict__ fr_argmax, const float* __restrict__ fr_maxprob,
+                                                     const int32_t* __restrict__ frame_lens, int Tp, int blank,
+                                                     int32_t* __restrict__ tokens, int32_t* __restrict__ n_tokens,
+                                                     double* __restrict__ score) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int n = frame_lens ? frame_lens[b] : Tp;
+  n = max(0, min(n, Tp));
+  const int32_t* ids = fr_argmax + (size_t)b * Tp;
+  const float* pr = fr_maxprob + (size_t)b * Tp;
+  int32_t* out = tokens + (size_t)b * Tp;
+  int count = 0;
+  int prev_last = -2;
+  double dsum = 0.0;
+  int nnb = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const bool in = i < n;
+    const int id = in ? ids[i] : -3;
+    int prev = __shfl_up(id, 1);
+    if (lane == 0) prev = prev_last;
+    const bool nonblank = in && id != blank;
+    const bool keep = nonblank && id != prev;
+    if (nonblank) {
+      dsum += (double)pr[i];
+      nnb += 1;
+    }
+    unsigned long long mask = __ballot(keep);
+    int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+    if (keep) out[pos] = id;
+    count += __popcll(mask);
+    prev_last = __shfl(id, 63);
+  }
+  // deterministic tree reduction of the fp64 partial sums
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    dsum += __shfl_xor(dsum, o);
+    nnb += __shfl_xor(nnb, o);
+  }
+  for (int i = count + lane; i < Tp; i += 64) out[i] = -1;
+  if (lane == 0) {
+    n_tokens[b] = count;
+    score[b] = nnb > 0 ? (dsum / (double)nnb) * 100.0 : 0.0;
+  }
+}
+void launch_ctc_collapse(const int32_t* fr_argmax, const float* fr_maxprob, const int32_t* frame_lens, int B, int Tp,
+                         int blank, int32_t* tokens, int32_t* n_tokens, double* score, hipStream_t st) {
+  hipLaunchKernelGGL(k_ctc_collapse, dim3(B), dim3(64), 0, st, fr_argmax, fr_maxprob, frame_lens, Tp, blank, tokens,
+                     n_tokens, score);
+}
+
+hipError_t configure_kernels() {
+  hipError_t e;
+#define SET_LDS(fn, bytes)                                                                                     \
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+  if (e != hipSuccess) return e;
+  SET_LDS(k_ffn_qkv, kLdsFfnQkv);
+  SET_LDS(k_attention, kLdsAttn);
+  SET_LDS(k_out_glu, kLdsOutGlu);
+  SET_LDS(k_conv_ffn<15>, kLdsConvFfn);
+  SET_LDS(k_conv_ffn<31>, kLdsConvFfn);
+  SET_LDS(k_conv_ffn<7>, kLdsConvFfn);
+  SET_LDS(k_ctc_head, kLdsCtc);
+  SET_LDS((k_gemm_stream<4, 64, true, Conv2Src>), 2 * 128 * 68 * sizeof(float));
+  SET_LDS((k_gemm_stream<1, 256, false, DenseSrc>), 2 * 32 * 260 * sizeof(float));
+#undef SET_LDS
+  return hipSuccess;
+}
+
+}  // namespace ppasr

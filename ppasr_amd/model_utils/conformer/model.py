@@ -1,0 +1,161 @@
+"""Host-side mirror of ``ppasr/model_utils/conformer/model.py`` (``ConformerModel``),
+inference surface only: ``get_encoder_out`` (:148-162) and ``get_encoder_out_chunk``
+(:164-184), backed by the HIP kernels through the C-ABI (``include/ppasr_hip.h``).
+
+torch is used for device memory and streams only; all compute is in libppasr_hip.so.
+"""
+import ctypes
+import json
+import math
+
+import numpy as np
+import torch
+
+from ppasr_amd import _lib
+
+__all__ = ["ConformerModel"]
+
+
+def _pe_table(d_model, max_len):
+    # PositionalEncoding.__init__  (conformer/embedding.py:38-53), fp32 like the reference
+    pe = torch.zeros(max_len, d_model, dtype=torch.float32)
+    position = torch.arange(0, max_len, dtype=torch.float32).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * -(math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe.numpy()
+
+
+class ConformerModel:
+    """Drop-in for the inference half of the reference ``ConformerModel``.
+
+    Args mirror ``conformer/model.py:17-29``; the training-only arguments
+    (decoder_conf, ctc_weight, ...) are accepted and ignored.  ``state_dict`` is a
+    Paddle-layout ``{name: np.ndarray}`` (what ``paddle.load('model.pdparams')`` holds).
+    """
+
+    def __init__(self, input_dim, vocab_size, mean_istd_path=None, streaming=True, encoder_conf=None,
+                 decoder_conf=None, ctc_weight=0.5, state_dict=None, device="cuda:0", **_ignored):
+        if state_dict is None:
+            raise ValueError("state_dict (Paddle-layout parameter dict) is required")
+        if not torch.cuda.is_available():
+            raise _lib.PPASRHipError("no HIP device visible: ppasr_amd has no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.input_dim = input_dim
+        self.vocab_size = vocab_size
+        self.streaming = streaming
+        conf = dict(encoder_conf or {})
+        self.output_size = int(conf.get("output_size", 256))
+        self.attention_heads = int(conf.get("attention_heads", 4))
+        self.linear_units = int(conf.get("linear_units", 2048))
+        self.num_blocks = int(conf.get("num_blocks", 6))
+        self.cnn_module_kernel = int(conf.get("cnn_module_kernel", 15))
+        self.max_len = int(conf.get("max_len", 5000))
+        for key, want in (("input_layer", "conv2d"), ("pos_enc_layer_type", "rel_pos"), ("activation_type", "swish"),
+                          ("normalize_before", True), ("use_cnn_module", True), ("cnn_module_norm", "layer_norm"),
+                          ("macaron_style", True)):
+            if key in conf and conf[key] != want:
+                raise NotImplementedError(f"encoder_conf.{key}={conf[key]!r}: only {want!r} is built")
+        sd = dict(state_dict)
+        if mean_istd_path is not None:
+            # FeatureNormalizer JSON {"mean": [...], "istd": [...]}  (data_utils/normalizer.py:35-41)
+            with open(mean_istd_path, "r", encoding="utf-8") as f:
+                js = json.load(f)
+            sd["encoder.global_cmvn.mean"] = np.asarray(js["mean"], np.float32)
+            sd["encoder.global_cmvn.istd"] = np.asarray(js["istd"], np.float32)
+        sd["__pe_table__"] = _pe_table(self.output_size, self.max_len)
+        keep = []  # keep the numpy buffers alive during ppasr_create
+        blobs = (_lib.WeightBlob * len(sd))()
+        for i, (name, arr) in enumerate(sd.items()):
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            if a.ndim > 4:
+                raise ValueError(f"{name}: ndim > 4")
+            keep.append(a)
+            blobs[i].name = name.encode()
+            blobs[i].data_host = a.ctypes.data
+            blobs[i].ndim = a.ndim
+            for j in range(a.ndim):
+                blobs[i].shape[j] = a.shape[j]
+        desc = _lib.ModelDesc(_lib.PPASR_MODEL_CONFORMER, input_dim, vocab_size, self.output_size,
+                              self.attention_heads, self.linear_units, self.num_blocks, self.cnn_module_kernel,
+                              1 if streaming else 0, self.max_len)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ppasr_create(ctypes.byref(desc), blobs, len(sd), ctypes.byref(handle)))
+        self._h = handle
+        self._ws = None
+        self._taps = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self.lib.ppasr_destroy(h)
+            self._h = None
+
+    # ------------------------------------------------------------------
+    def out_frames(self, T):
+        return int(self.lib.ppasr_out_frames(self._h, int(T)))
+
+    def _workspace(self, B, T):
+        need = int(self.lib.ppasr_workspace_bytes(self._h, B, T))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _prep(self, speech, speech_lengths):
+        speech = torch.as_tensor(speech, dtype=torch.float32).to(self.device).contiguous()
+        lens = torch.as_tensor(speech_lengths, dtype=torch.int64).to(self.device).contiguous()
+        assert speech.dim() == 3 and speech.shape[2] == self.input_dim and lens.shape[0] == speech.shape[0]
+        return speech, lens
+
+    def _encode(self, speech, lens, probs=None, logits=None, fa=None, fp=None):
+        B, T, _ = speech.shape
+        ws = self._workspace(B, T)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib.ppasr_encode(self._h, speech.data_ptr(), lens.data_ptr(), B, T, ptr(probs), ptr(logits),
+                                         ptr(fa), ptr(fp), ws.data_ptr(), ws.numel(), stream))
+
+    def get_encoder_out(self, speech, speech_lengths, return_logits=False):
+        """-> ctc_probs [B, T', V] (device tensor).  conformer/model.py:148-162"""
+        speech, lens = self._prep(speech, speech_lengths)
+        B, T, _ = speech.shape
+        Tp = self.out_frames(T)
+        probs = torch.empty(B, Tp, self.vocab_size, dtype=torch.float32, device=self.device)
+        logits = torch.empty_like(probs) if return_logits else None
+        with torch.cuda.device(self.device):
+            self._encode(speech, lens, probs=probs, logits=logits)
+        return (probs, logits) if return_logits else probs
+
+    def encode_greedy(self, speech, speech_lengths, trim_to_length=False, blank=0):
+        """Fused path: features -> (tokens [B,T'] i32 (-1 padded), n_tokens [B] i32, score [B] f64), all on
+        device; the [B,T',V] probability tensor is never materialised.  Equivalent to
+        ``greedy_decoder_batch(get_encoder_out(...))`` (trainer.py:626,351); ``trim_to_length=False``
+        reproduces the reference, which decodes all T' rows including PAD frames."""
+        speech, lens = self._prep(speech, speech_lengths)
+        B, T, _ = speech.shape
+        Tp = self.out_frames(T)
+        fa = torch.empty(B, Tp, dtype=torch.int32, device=self.device)
+        fp = torch.empty(B, Tp, dtype=torch.float32, device=self.device)
+        tokens = torch.empty(B, Tp, dtype=torch.int32, device=self.device)
+        n_tokens = torch.empty(B, dtype=torch.int32, device=self.device)
+        score = torch.empty(B, dtype=torch.float64, device=self.device)
+        frame_lens = None
+        if trim_to_length:
+            frame_lens = torch.clamp((lens + 3) // 4, max=Tp).to(torch.int32)  # frame t valid iff 4t < len
+        with torch.cuda.device(self.device):
+            self._encode(speech, lens, fa=fa, fp=fp)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self.lib.ppasr_ctc_collapse(fa.data_ptr(), fp.data_ptr(),
+                                                   None if frame_lens is None else frame_lens.data_ptr(), B, Tp,
+                                                   blank, tokens.data_ptr(), n_tokens.data_ptr(), score.data_ptr(),
+                                                   stream))
+        return tokens, n_tokens, score
+
+    def set_debug_taps(self, n_floats):
+        """Allocate a tap buffer; layout in DESIGN.md (x0, then per layer x1,qkv,ctx,x2,g,x_out)."""
+        self._taps = torch.zeros(n_floats, dtype=torch.float32, device=self.device) if n_floats else None
+        _lib.check(self.lib.ppasr_set_debug_taps(self._h, None if self._taps is None else self._taps.data_ptr(),
+                                                 n_floats))
+        return self._taps

@@ -1,0 +1,127 @@
+"""Seeded synthetic checkpoints / features / vocabularies for the hot path.
+
+No PPASR checkpoint is reachable offline, so tests and bench.py
+run random-init weights drawn with the reference's own initialisers:
+
+* ``ppasr/model_utils/utils/base.py:58-78`` (``Linear``/``Conv1D``/``Conv2D``:
+  KaimingUniform(negative_slope=sqrt(5)) -> U(+-1/sqrt(fan_in)))
+* plain ``nn.Linear`` for ``embed.out`` (``conformer/subsampling.py:87``) and
+  ``ctc_lo`` (``loss/ctc.py:27``): Xavier-uniform weight, zero bias
+* ``pos_bias_u/v``: Xavier-uniform (``conformer/attention.py:193-196``)
+* LayerNorm gamma=1, beta=0 (``base.py:7-21``)
+
+Parameter names and layouts are the Paddle ones (``Linear.weight`` is
+``[in, out]``), i.e. exactly what a ``model.pdparams`` state dict holds, so a
+real checkpoint can be dropped in later.  Everything is numpy float32.
+"""
+import math
+
+import numpy as np
+
+__all__ = ["conformer_state_dict", "synth_features", "synth_vocabulary", "DEFAULT_VOCAB_SIZE"]
+
+DEFAULT_VOCAB_SIZE = 4233  # <blank>, <unk>, 4230 CJK chars, <eos>  
+
+
+def _uniform(rng, shape, bound):
+    return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+
+
+def _kaiming(rng, shape, fan_in):
+    return _uniform(rng, shape, 1.0 / math.sqrt(fan_in))
+
+
+def _xavier(rng, shape, fan_in, fan_out):
+    return _uniform(rng, shape, math.sqrt(6.0 / (fan_in + fan_out)))
+
+
+def _layernorm(sd, prefix, size, rng, perturb):
+    if perturb:
+        sd[prefix + ".weight"] = (1.0 + 0.1 * rng.standard_normal(size)).astype(np.float32)
+        sd[prefix + ".bias"] = (0.1 * rng.standard_normal(size)).astype(np.float32)
+    else:
+        sd[prefix + ".weight"] = np.ones(size, np.float32)
+        sd[prefix + ".bias"] = np.zeros(size, np.float32)
+
+
+def _linear(sd, prefix, fin, fout, rng, bias=True):
+    # base.Linear: Paddle layout [in, out]; fan_in = shape[0]
+    sd[prefix + ".weight"] = _kaiming(rng, (fin, fout), fin)
+    if bias:
+        # KaimingUniform on a 1-D tensor: fan_in = shape[0]
+        sd[prefix + ".bias"] = _kaiming(rng, (fout,), fout)
+
+
+def conformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, output_size=256, attention_heads=4,
+                         linear_units=2048, num_blocks=12, cnn_module_kernel=15, seed=1234,
+                         ctc_sharpen=8.0, perturb_norm=False, cmvn_mean=10.0, cmvn_istd=1.0 / 3.3):
+    """Random-init ``ConformerModel`` inference parameters (encoder + CTC head).
+
+    ``ctc_sharpen`` multiplies ``ctc.ctc_lo.weight`` so that greedy top-1 margins
+    are realistic for un-trained weights (documented deviation).
+    ``perturb_norm`` draws LayerNorm gamma/beta away from (1, 0) so tests notice
+    a dropped affine term.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    d, h = output_size, attention_heads
+    dk = d // h
+    f2 = ((input_dim - 1) // 2 - 1) // 2
+    sd = {}
+    sd["encoder.global_cmvn.mean"] = np.full(input_dim, cmvn_mean, np.float32)
+    sd["encoder.global_cmvn.istd"] = np.full(input_dim, cmvn_istd, np.float32)
+    if perturb_norm:
+        sd["encoder.global_cmvn.mean"] += (0.5 * rng.standard_normal(input_dim)).astype(np.float32)
+        sd["encoder.global_cmvn.istd"] *= (1.0 + 0.1 * rng.uniform(-1, 1, input_dim)).astype(np.float32)
+    # Conv2dSubsampling4: base.Conv2D (Kaiming, fan_in = Cin*kh*kw)
+    sd["encoder.embed.conv.0.weight"] = _kaiming(rng, (d, 1, 3, 3), 9)
+    sd["encoder.embed.conv.0.bias"] = _kaiming(rng, (d,), d)
+    sd["encoder.embed.conv.2.weight"] = _kaiming(rng, (d, d, 3, 3), d * 9)
+    sd["encoder.embed.conv.2.bias"] = _kaiming(rng, (d,), d)
+    sd["encoder.embed.out.0.weight"] = _xavier(rng, (d * f2, d), d * f2, d)
+    sd["encoder.embed.out.0.bias"] = np.zeros(d, np.float32)
+    for i in range(num_blocks):
+        p = f"encoder.encoders.{i}."
+        for name in ("linear_q", "linear_k", "linear_v", "linear_out"):
+            _linear(sd, p + "self_attn." + name, d, d, rng)
+        _linear(sd, p + "self_attn.linear_pos", d, d, rng, bias=False)
+        sd[p + "self_attn.pos_bias_u"] = _xavier(rng, (h, dk), h, dk)
+        sd[p + "self_attn.pos_bias_v"] = _xavier(rng, (h, dk), h, dk)
+        for ff in ("feed_forward", "feed_forward_macaron"):
+            _linear(sd, p + ff + ".w_1", d, linear_units, rng)
+            _linear(sd, p + ff + ".w_2", linear_units, d, rng)
+        # ConvolutionModule: base.Conv1D, weight [out, in/groups, k]
+        sd[p + "conv_module.pointwise_conv1.weight"] = _kaiming(rng, (2 * d, d, 1), d)
+        sd[p + "conv_module.pointwise_conv1.bias"] = _kaiming(rng, (2 * d,), 2 * d)
+        sd[p + "conv_module.depthwise_conv.weight"] = _kaiming(rng, (d, 1, cnn_module_kernel), cnn_module_kernel)
+        sd[p + "conv_module.depthwise_conv.bias"] = _kaiming(rng, (d,), d)
+        _layernorm(sd, p + "conv_module.norm", d, rng, perturb_norm)
+        sd[p + "conv_module.pointwise_conv2.weight"] = _kaiming(rng, (d, d, 1), d)
+        sd[p + "conv_module.pointwise_conv2.bias"] = _kaiming(rng, (d,), d)
+        for n in ("norm_ff", "norm_mha", "norm_ff_macaron", "norm_conv", "norm_final"):
+            _layernorm(sd, p + n, d, rng, perturb_norm)
+    _layernorm(sd, "encoder.after_norm", d, rng, perturb_norm)
+    sd["ctc.ctc_lo.weight"] = _xavier(rng, (d, vocab_size), d, vocab_size) * np.float32(ctc_sharpen)
+    sd["ctc.ctc_lo.bias"] = np.zeros(vocab_size, np.float32)
+    if perturb_norm:
+        sd["ctc.ctc_lo.bias"] = (0.1 * rng.standard_normal(vocab_size)).astype(np.float32)
+    return sd
+
+
+def synth_features(batch, frames, n_mels=80, lens=None, seed=20240, mean=10.0, std=3.3):
+    """``feats = mean + std*N(0,1)`` float32 ``[B, T, F]``; rows >= len are zero
+    (the reference's collate_fn zero-pads, ``data_utils/collate_fn.py:17``)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = (mean + std * rng.standard_normal((batch, frames, n_mels))).astype(np.float32)
+    if lens is None:
+        lens = np.full(batch, frames, np.int64)
+    lens = np.asarray(lens, np.int64)
+    for b in range(batch):
+        x[b, int(lens[b]):] = 0.0
+    return x, lens
+
+
+def synth_vocabulary(vocab_size=DEFAULT_VOCAB_SIZE):
+    """``<blank>`` (id 0), ``<unk>``, CJK characters, ``<eos>`` last
+    (vocabulary layout of ``ppasr/trainer.py:480-487``)."""
+    chars = [chr(0x4E00 + i) for i in range(vocab_size - 3)]
+    return ["<blank>", "<unk>"] + chars + ["<eos>"]
