@@ -95,6 +95,15 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
  * to `taps` in the order documented in DESIGN.md; pass NULL to clear. */
 ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats);
 
+/* Measurement hook (bench.py roofline leg; no reference counterpart): when enabled, every kernel launch
+ * of the next ppasr_encode is bracketed by a HIP event pair on the caller's stream; ppasr_profile_read
+ * synchronises those events and returns, per kernel class, the summed duration (ms) and launch count
+ * into HOST arrays of PPASR_N_KERNEL_CLASSES entries. */
+#define PPASR_N_KERNEL_CLASSES 8
+ppasr_status ppasr_profile_enable(ppasr_handle h, int enable);
+ppasr_status ppasr_profile_read(ppasr_handle h, float* total_ms_host, int* launches_host);
+const char* ppasr_kernel_class_name(int cls);
+
 /* Replaces greedy_decoder / greedy_decoder_batch (decoders/ctc_greedy_decoder.py:6-49), as called
  * from PPASRPredictor.decode (predict.py:128) and PPASRTrainer.__decoder_result (trainer.py:351).
  *   probs [B,Tp,V] f32 (any row-normalised or not: argmax + value at argmax)

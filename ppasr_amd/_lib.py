@@ -19,6 +19,7 @@ PPASR_MODEL_CONFORMER = 0
 PPASR_MODEL_EFFICIENT_CONFORMER = 1
 PPASR_MODEL_SQUEEZEFORMER = 2
 PPASR_MODEL_DEEPSPEECH2 = 3
+N_KERNEL_CLASSES = 8
 
 
 class WeightBlob(ctypes.Structure):
@@ -46,6 +47,9 @@ SYMBOLS = [
     ("ppasr_encode", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp,
                                     ctypes.c_size_t, _vp]),
     ("ppasr_set_debug_taps", ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    ("ppasr_profile_enable", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("ppasr_profile_read", ctypes.c_int, [_vp, c_f32p, c_i32p]),
+    ("ppasr_kernel_class_name", ctypes.c_char_p, [ctypes.c_int]),
     ("ppasr_ctc_greedy", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp,
                                         _vp, _vp, ctypes.c_size_t, _vp]),
     ("ppasr_ctc_collapse", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,

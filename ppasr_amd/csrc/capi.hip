@@ -68,6 +68,12 @@ struct ppasr_model_s {
   HeadW head;
   float* taps = nullptr;
   size_t taps_floats = 0;
+  // optional per-kernel timing (bench.py roofline leg): one event pair per launch on the caller's stream
+  bool prof = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  struct Span { int cls; hipEvent_t a, b; };
+  std::vector<Span> spans;
 
   ppasr_status upload(const std::vector<float>& v, const float** out) {
     void* d = nullptr;
@@ -83,8 +89,17 @@ struct ppasr_model_s {
     *out = reinterpret_cast<const f32x4*>(p);
     return s;
   }
+  hipEvent_t next_event() {
+    if (ev_used == ev_pool.size()) {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      ev_pool.push_back(e);
+    }
+    return ev_pool[ev_used++];
+  }
   ~ppasr_model_s() {
     for (void* p : allocs) (void)hipFree(p);
+    for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
   }
 };
 
@@ -365,28 +380,43 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       (void)hipMemcpyAsync(h->taps + tap_off, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
     tap_off += n;
   };
-  launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st);
-  launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st);
-  launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), st);
+  if (h->prof) {
+    h->ev_used = 0;
+    h->spans.clear();
+  }
+  auto timed = [&](int cls, auto&& fn) {
+    if (!h->prof) {
+      fn();
+      return;
+    }
+    hipEvent_t a = h->next_event(), b = h->next_event();
+    (void)hipEventRecord(a, st);
+    fn();
+    (void)hipEventRecord(b, st);
+    h->spans.push_back({cls, a, b});
+  };
+  timed(0, [&] { launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st); });
+  timed(1, [&] { launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st); });
+  timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), st); });
   tap(xa, (size_t)M * kD);
   const int n_chunks = h->desc.linear_units / 256;
   for (int i = 0; i < h->desc.num_blocks; ++i) {
     const LayerW& L = h->layers[i];
-    launch_ffn_qkv(xa, xb, qkv, L, M, n_chunks, st);
+    timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, M, n_chunks, st); });
     tap(xb, (size_t)M * kD);
     tap(qkv, (size_t)M * 3 * kD);
-    launch_attention(qkv, L, lens, ctx, B, Tp, h->desc.attention_heads, st);
+    timed(4, [&] { launch_attention(qkv, L, lens, ctx, B, Tp, h->desc.attention_heads, st); });
     tap(ctx, (size_t)M * kD);
-    launch_out_glu(ctx, xb, xc, g, L, lens, M, Tp, st);
+    timed(5, [&] { launch_out_glu(ctx, xb, xc, g, L, lens, M, Tp, st); });
     tap(xc, (size_t)M * kD);
     tap(g, (size_t)M * kD);
-    launch_conv_ffn(g, xc, xa, L, lens, M, Tp, n_chunks, h->desc.cnn_module_kernel, st);
+    timed(6, [&] { launch_conv_ffn(g, xc, xa, L, lens, M, Tp, n_chunks, h->desc.cnn_module_kernel, st); });
     tap(xa, (size_t)M * kD);
   }
   float* lg = logits ? logits : probs;  // probs are produced in place from the logits tap
   int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
   float* fp = frame_maxprob ? frame_maxprob : ws + wl.fp;
-  launch_ctc_head(xa, h->head, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, M, st);
+  timed(7, [&] { launch_ctc_head(xa, h->head, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, M, st); });
   if (probs) {
     if (logits)
       HIP_TRY(hipMemcpyAsync(probs, logits, (size_t)M * h->head.V * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -394,6 +424,38 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   }
   HIP_TRY(hipGetLastError());
   return PPASR_OK;
+}
+
+static const char* kKernelClassNames[PPASR_N_KERNEL_CLASSES] = {
+    "k_conv1", "k_gemm_stream<conv2>", "k_gemm_stream<embed>", "k_ffn_qkv", "k_attention", "k_out_glu", "k_conv_ffn",
+    "k_ctc_head"};
+
+ppasr_status ppasr_profile_enable(ppasr_handle h, int enable) {
+  if (!h) return fail(PPASR_EINVAL, "null handle");
+  h->prof = enable != 0;
+  h->spans.clear();
+  h->ev_used = 0;
+  return PPASR_OK;
+}
+
+ppasr_status ppasr_profile_read(ppasr_handle h, float* total_ms_host, int* launches_host) {
+  if (!h || !total_ms_host || !launches_host) return fail(PPASR_EINVAL, "null argument");
+  for (int i = 0; i < PPASR_N_KERNEL_CLASSES; ++i) {
+    total_ms_host[i] = 0.f;
+    launches_host[i] = 0;
+  }
+  for (auto& sp : h->spans) {
+    HIP_TRY(hipEventSynchronize(sp.b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, sp.a, sp.b));
+    total_ms_host[sp.cls] += ms;
+    launches_host[sp.cls] += 1;
+  }
+  return PPASR_OK;
+}
+
+const char* ppasr_kernel_class_name(int cls) {
+  return (cls >= 0 && cls < PPASR_N_KERNEL_CLASSES) ? kKernelClassNames[cls] : "";
 }
 
 ppasr_status ppasr_ctc_collapse(const int32_t* frame_argmax, const float* frame_maxprob, const int32_t* frame_lens, int B,

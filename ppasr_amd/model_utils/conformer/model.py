@@ -159,3 +159,14 @@ class ConformerModel:
         _lib.check(self.lib.ppasr_set_debug_taps(self._h, None if self._taps is None else self._taps.data_ptr(),
                                                  n_floats))
         return self._taps
+
+    def profile_kernels(self, enable=True):
+        _lib.check(self.lib.ppasr_profile_enable(self._h, 1 if enable else 0))
+
+    def read_kernel_profile(self):
+        """-> {kernel class name: (total_ms, launches)} for the last profiled encode (synchronises)."""
+        ms = (ctypes.c_float * _lib.N_KERNEL_CLASSES)()
+        n = (ctypes.c_int32 * _lib.N_KERNEL_CLASSES)()
+        _lib.check(self.lib.ppasr_profile_read(self._h, ms, n))
+        return {self.lib.ppasr_kernel_class_name(i).decode(): (float(ms[i]), int(n[i]))
+                for i in range(_lib.N_KERNEL_CLASSES)}
