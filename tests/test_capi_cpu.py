@@ -1,0 +1,58 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads (no GPU needed) and exports every
+symbol include/ppasr_hip.h declares; argument validation fails loudly; no compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from ppasr_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "ppasr_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ppasr_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ppasr_hip.h but not exported"
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert set(names) == bound, (set(names) ^ bound)
+
+
+def test_version_and_error_strings():
+    lib = _lib.load()
+    assert b"gfx950" in lib.ppasr_version()
+    # NULL arguments are rejected before any HIP call
+    rc = lib.ppasr_create(None, None, 0, None)
+    assert rc == 1 and b"null" in lib.ppasr_last_error()
+    assert lib.ppasr_workspace_bytes(None, 1, 100) == 0
+    with pytest.raises(_lib.PPASRHipError):
+        _lib.check(lib.ppasr_set_debug_taps(None, None, 0))
+
+
+def test_unsupported_configs_are_refused_not_emulated():
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    blob = (_lib.WeightBlob * 1)()
+    for desc in (_lib.ModelDesc(3, 80, 100, 256, 4, 2048, 2, 15, 1, 5000),   # deepspeech2 not via this entry
+                 _lib.ModelDesc(0, 80, 100, 512, 8, 2048, 2, 15, 1, 5000),   # d != 256
+                 _lib.ModelDesc(0, 80, 100, 256, 4, 2000, 2, 15, 1, 5000)):  # ffn % 256
+        rc = lib.ppasr_create(ctypes.byref(desc), blob, 1, ctypes.byref(h))
+        assert rc == 3, lib.ppasr_last_error()
+
+
+def test_model_wrapper_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    with pytest.raises(_lib.PPASRHipError):
+        ConformerModel(80, 10, state_dict={"x": [0.0]})
