@@ -271,11 +271,9 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
       GET(dwb, p + "conv_module.depthwise_conv.bias", d);
       GET(p2w, p + "conv_module.pointwise_conv2.weight", d * d);
       GET(p2b, p + "conv_module.pointwise_conv2.bias", d);
-      // column permutation: packed col n' = w*128 + half*64 + j  <-  Conv1D out channel half*256 + w*64 + j
-      auto orig = [&](int np) { return ((np >> 6) & 1) * d + (np >> 7) * 64 + (np & 63); };
-      UP4(pack_b(d, 2 * d, [&](int k, int np) { return p1w[(size_t)orig(np) * d + k]; }), L.pw1);
-      std::vector<float> b1p(2 * d), gp(d);
-      for (int np = 0; np < 2 * d; ++np) b1p[np] = p1b[orig(np)];
+      // Conv1D weight [out][in][1]: W[k][n] = w[n][k]; GLU value = channels [0,256), gate = [256,512)
+      UP4(pack_b(d, 2 * d, [&](int k, int n) { return p1w[(size_t)n * d + k]; }), L.pw1);
+      std::vector<float> b1p(p1b, p1b + 2 * d), gp(d);
       for (int c = 0; c < d; ++c) gp[c] = p1b[c] * (1.0f / (1.0f + expf(-p1b[c + d])));
       UP(b1p, L.pw1_b);
       UP(gp, L.glu_pad);

@@ -92,20 +92,26 @@ struct DenseSrc {
 };
 
 template <int MT, int KC, bool RELU, typename Src>
-__global__ __launch_bounds__(256) void k_gemm_stream(Src src, const f32x4* __restrict__ wp, const float* __restrict__ bias,
-                                                     float* __restrict__ out, int M, int n_chunks, float scale) {
+__global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* __restrict__ wp,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int M,
+                                                          int n_chunks, float scale) {
   constexpr int BM = 32 * MT;
   constexpr int LD = KC + 4;
   constexpr int F4_PER_ROW = KC / 4;
-  constexpr int NL = BM * F4_PER_ROW / 256;  // float4 loads per thread per chunk
+  constexpr int NL = BM * F4_PER_ROW / kThreads;  // float4 loads per thread per chunk
+  constexpr int G = KC / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const int r0 = blockIdx.x * BM;
+  const int tile_stride = n_chunks * G * 64;
+  const f32x4* wbase = wp + (size_t)wave * tile_stride;
+  BRing<1> ring;
+  ring_prime(ring, wbase, 0);
   const float* rowp[NL];
   int lds_off[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
-    int idx = tid + 256 * i;
+    int idx = tid + kThreads * i;
     int row = idx / F4_PER_ROW, c4 = idx - row * F4_PER_ROW;
     int m = r0 + row;
     rowp[i] = (m < M) ? src.base(m) + 4 * c4 : nullptr;
@@ -122,35 +128,32 @@ __global__ __launch_bounds__(256) void k_gemm_stream(Src src, const f32x4* __res
 #pragma unroll
     for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4*>(buf + lds_off[i]) = stg[i];
   };
-  f32x16 acc[MT][2];
+  f32x16 acc[MT][1];
   acc_zero(acc);
-  const int tile_stride = n_chunks * (KC / 8) * 64;
-  const f32x4* wbase = wp + (size_t)(wave * 2) * tile_stride;
   load_chunk(0);
   write_chunk(smem);
   __syncthreads();
   for (int kc = 0; kc < n_chunks; ++kc) {
     float* cur = smem + (kc & 1) * BM * LD;
     float* nxt = smem + ((kc + 1) & 1) * BM * LD;
-    if (kc + 1 < n_chunks) load_chunk(kc + 1);
-    rb_gemm<MT, 2>(cur, LD, wbase + (size_t)kc * (KC / 8) * 64, tile_stride, KC / 8, acc);
-    if (kc + 1 < n_chunks) write_chunk(nxt);
+    const bool more = kc + 1 < n_chunks;
+    if (more) load_chunk(kc + 1);
+    const f32x4* seg = wbase + (size_t)kc * G * 64;
+    rb_gemm<MT, 1, G>(cur, LD, seg, 0, more ? seg + G * 64 : nullptr, 0, ring, acc);
+    if (more) write_chunk(nxt);
     __syncthreads();
   }
+  const int col = wave * 32 + (lane & 31);
+  const float bv = bias[col];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int col = wave * 64 + nt * 32 + (lane & 31);
-      const float bv = bias[col];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int m = r0 + mt * 32 + acc_row(r, lane);
-        float v = acc[mt][nt][r] + bv;
-        if (RELU) v = fmaxf(v, 0.f);
-        v *= scale;
-        if (m < M) out[(size_t)m * kD + col] = v;
-      }
+    for (int r = 0; r < 16; ++r) {
+      int m = r0 + mt * 32 + acc_row(r, lane);
+      float v = acc[mt][0][r] + bv;
+      if (RELU) v = fmaxf(v, 0.f);
+      v *= scale;
+      if (m < M) out[(size_t)m * kD + col] = v;
     }
 }
 
@@ -159,14 +162,14 @@ void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, i
   int M = B * Tp * F2;
   constexpr int MT = 4, KC = 64;
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
-  hipLaunchKernelGGL((k_gemm_stream<MT, KC, true, Conv2Src>), dim3((M + 32 * MT - 1) / (32 * MT)), dim3(256), lds, st, src,
+  hipLaunchKernelGGL((k_gemm_stream<MT, KC, true, Conv2Src>), dim3((M + 32 * MT - 1) / (32 * MT)), dim3(kThreads), lds, st, src,
                      fw.conv2_w, fw.conv2_b, y2, M, 36, 1.0f);
 }
 void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, hipStream_t st) {
   constexpr int MT = 1, KC = 256;
   DenseSrc src{y2, K, KC};
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
-  hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, DenseSrc>), dim3((M + 31) / 32), dim3(256), lds, st, src, fw.embed_w,
+  hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src, fw.embed_w,
                      fw.embed_b, x0, M, K / KC, xscale);
 }
 
@@ -174,44 +177,64 @@ void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, fl
 // Row-block phases shared by the per-layer kernels
 // =====================================================================================
 
-// PositionwiseFeedForward (positionwise.py:32-39): acc2 += swish(A*W1 + b1) * W2, hidden
-// dimension processed in 256-wide chunks that never leave LDS (double-buffered bufH).
+// Epilogue slice of the previous W1 tile, interleaved with the MFMAs of the next one:
+// H[row][col] = swish(acc + b1)   (two accumulator registers per k-group pair)
+struct SwishSide {
+  const f32x16& acc;
+  float* hb;
+  float bias;
+  int lane, col;
+  __device__ __forceinline__ void operator()(int g) const {
+    if ((g & 1) == 0) {
+      const int r = g >> 1;
+      hb[acc_row(r, lane) * kLda + col] = swishf(acc[r] + bias);
+    }
+  }
+};
+
+// PositionwiseFeedForward (positionwise.py:32-39): acc2 += swish(A*W1 + b1) * W2.  The hidden
+// dimension is processed in 256-wide chunks that never leave LDS (double-buffered bufH); wave w
+// owns hidden columns [32w,32w+32) of each chunk and output columns [32w,32w+32).
+// Weight stream order: W1(0), W1(1), W2(0), W1(2), W2(1), ..., W2(n-1), then `after`.
+// The swish epilogue of chunk c runs inside the W1(c+1) MFMA stream.
 __device__ __forceinline__ void ffn_phase(const float* bufA, float* bufH, const f32x4* __restrict__ w1,
                                           const float* __restrict__ b1, const f32x4* __restrict__ w2, int n_chunks,
-                                          f32x16 (&acc2)[1][2]) {
+                                          const f32x4* __restrict__ after, BRing<1>& ring, f32x16 (&acc2)[1][1]) {
   const int lane = lane_id(), wave = wave_id();
-  const int ts1 = (kD / 8) * 64;            // W1: K = 256
-  const int ts2 = (n_chunks * 256 / 8) * 64;  // W2: K = hidden
+  const int ts2 = n_chunks * 32 * 64;  // W2: K = hidden
+  const int col = wave * 32 + (lane & 31);
+  auto w1seg = [&](int c) { return w1 + (size_t)(c * 8 + wave) * kTs256; };
+  auto w2seg = [&](int c) { return w2 + (size_t)wave * ts2 + (size_t)c * 32 * 64; };
+  f32x16 cur[1][1], nx[1][1];
+  acc_zero(cur);
+  rb_gemm<1, 1, kG256>(bufA, kLda, w1seg(0), 0, n_chunks > 1 ? w1seg(1) : w2seg(0), 0, ring, cur);
   for (int c = 0; c < n_chunks; ++c) {
-    f32x16 acc1[1][2];
-    acc_zero(acc1);
-    rb_gemm<1, 2>(bufA, kLda, w1 + (size_t)(c * 8 + wave * 2) * ts1, ts1, kD / 8, acc1);
     float* hb = bufH + (c & 1) * kRows * kLda;
+    const float bias = b1[c * 256 + col];
+    if (c + 1 < n_chunks) {
+      acc_zero(nx);
+      rb_gemm<1, 1, kG256>(bufA, kLda, w1seg(c + 1), 0, w2seg(c), 0, ring, nx, SwishSide{cur[0][0], hb, bias, lane, col});
+    } else {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int colh = wave * 64 + nt * 32 + (lane & 31);
-      const float bv = b1[c * 256 + colh];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hb[acc_row(r, lane) * kLda + colh] = swishf(acc1[0][nt][r] + bv);
+      for (int r = 0; r < 16; ++r) hb[acc_row(r, lane) * kLda + col] = swishf(cur[0][0][r] + bias);
     }
     __syncthreads();
-    rb_gemm<1, 2>(hb, kLda, w2 + (size_t)(wave * 2) * ts2 + (size_t)c * 32 * 64, ts2, kD / 8, acc2);
+    const f32x4* nseg = (c + 2 < n_chunks) ? w1seg(c + 2) : (c + 1 < n_chunks ? w2seg(c + 1) : after);
+    rb_gemm<1, 1, kG256>(hb, kLda, w2seg(c), 0, nseg, 0, ring, acc2);
+    cur[0][0] = nx[0][0];
   }
 }
 
 // bufX[row][col] += scale * (acc + bias[col])    (residual update, each element owned by one lane)
-__device__ __forceinline__ void residual_epilogue(float* bufX, const f32x16 (&acc)[1][2], const float* __restrict__ bias,
+__device__ __forceinline__ void residual_epilogue(float* bufX, const f32x16 (&acc)[1][1], const float* __restrict__ bias,
                                                   float scale) {
   const int lane = lane_id(), wave = wave_id();
+  const int col = wave * 32 + (lane & 31);
+  const float bv = bias[col];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int col = wave * 64 + nt * 32 + (lane & 31);
-    const float bv = bias[col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float* p = bufX + acc_row(r, lane) * kLda + col;
-      *p = *p + scale * (acc[0][nt][r] + bv);
-    }
+  for (int r = 0; r < 16; ++r) {
+    float* p = bufX + acc_row(r, lane) * kLda + col;
+    *p = *p + scale * (acc[0][0][r] + bv);
   }
 }
 
@@ -231,8 +254,8 @@ struct PadRows {  // conv-module pad masking (convolution.py:104-106,138-140): f
 // S1: x1 = x + 0.5*FFN_macaron(LN(x)) ; qkv = LN_mha(x1) * [Wq|Wk|Wv] + b
 // (encoder.py:380-391, attention.py:75-77)
 // -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ffn_qkv(const float* __restrict__ x_in, float* __restrict__ x1,
-                                                 float* __restrict__ qkv, LayerW w, int M, int n_chunks) {
+__global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ x_in, float* __restrict__ x1,
+                                                      float* __restrict__ qkv, LayerW w, int M, int n_chunks) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
@@ -240,37 +263,39 @@ __global__ __launch_bounds__(256) void k_ffn_qkv(const float* __restrict__ x_in,
   const int lane = lane_id(), wave = wave_id();
   const int r0 = blockIdx.x * kRows;
   const int valid = min(kRows, M - r0);
+  BRing<1> ring;
+  ring_prime(ring, w.ffm_w1 + (size_t)wave * kTs256, 0);
   rb_load_rows(bufX, kLda, x_in + (size_t)r0 * kD, kRows, valid);
-  rb_layernorm(bufX, bufA, kLda, kRows, w.ln_mac_g, w.ln_mac_b, 1e-5f, NoZero());
+  rb_layernorm(bufX, bufA, kLda, kRows, w.ln_mac_g, w.ln_mac_b, 1e-5f);
   __syncthreads();
-  f32x16 acc2[1][2];
+  f32x16 acc2[1][1];
   acc_zero(acc2);
-  ffn_phase(bufA, bufH, w.ffm_w1, w.ffm_b1, w.ffm_w2, n_chunks, acc2);
+  const f32x4* wq = w.wqkv + (size_t)wave * kTs256;
+  ffn_phase(bufA, bufH, w.ffm_w1, w.ffm_b1, w.ffm_w2, n_chunks, wq, ring, acc2);
   residual_epilogue(bufX, acc2, w.ffm_b2, 0.5f);
   __syncthreads();
   rb_store_rows(x1 + (size_t)r0 * kD, bufX, kLda, kRows, valid);
-  rb_layernorm(bufX, bufA, kLda, kRows, w.ln_mha_g, w.ln_mha_b, 1e-5f, NoZero());
+  rb_layernorm(bufX, bufA, kLda, kRows, w.ln_mha_g, w.ln_mha_b, 1e-5f);
   __syncthreads();
-  const int ts = (kD / 8) * 64;
+#pragma unroll
   for (int c = 0; c < 3; ++c) {
-    f32x16 acc[1][2];
+    f32x16 acc[1][1];
     acc_zero(acc);
-    rb_gemm<1, 2>(bufA, kLda, w.wqkv + (size_t)(c * 8 + wave * 2) * ts, ts, kD / 8, acc);
+    const f32x4* seg = w.wqkv + (size_t)(c * 8 + wave) * kTs256;
+    rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, c < 2 ? seg + 8 * kTs256 : nullptr, 0, ring, acc);
+    const int col = c * 256 + wave * 32 + (lane & 31);
+    const float bv = w.bqkv[col];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int col = c * 256 + wave * 64 + nt * 32 + (lane & 31);
-      const float bv = w.bqkv[col];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int row = acc_row(r, lane);
-        if (row < valid) qkv[(size_t)(r0 + row) * 768 + col] = acc[0][nt][r] + bv;
-      }
+    for (int r = 0; r < 16; ++r) {
+      int row = acc_row(r, lane);
+      if (row < valid) qkv[(size_t)(r0 + row) * 768 + col] = acc[0][0][r] + bv;
     }
   }
 }
 constexpr size_t kLdsFfnQkv = 4 * kRows * kLda * sizeof(float);
 void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st) {
-  hipLaunchKernelGGL(k_ffn_qkv, dim3((M + kRows - 1) / kRows), dim3(256), kLdsFfnQkv, st, x_in, x1, qkv, w, M, n_chunks);
+  hipLaunchKernelGGL(k_ffn_qkv, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsFfnQkv, st, x_in, x1, qkv, w, M,
+                     n_chunks);
 }
 
 // -------------------------------------------------------------------------------------
@@ -460,66 +485,64 @@ void launch_attention(const float* qkv, const LayerW& w, const int64_t* lens, fl
 // S3: x2 = x1 + ctx*Wo + bo ; g = GLU(pointwise_conv1(mask(LN_conv(x2))))
 // (attention.py:126, encoder.py:399-409, convolution.py:104-106,125-126)
 // -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_out_glu(const float* __restrict__ ctx, const float* __restrict__ x1,
-                                                 float* __restrict__ x2, float* __restrict__ g, LayerW w,
-                                                 const int64_t* __restrict__ lens, int M, int Tp) {
+__global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ ctx, const float* __restrict__ x1,
+                                                      float* __restrict__ x2, float* __restrict__ g, LayerW w,
+                                                      const int64_t* __restrict__ lens, int M, int Tp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
   const int lane = lane_id(), wave = wave_id();
   const int r0 = blockIdx.x * kRows;
   const int valid = min(kRows, M - r0);
+  const int col = wave * 32 + (lane & 31);
+  BRing<1> ring;
+  const f32x4* seg_o = w.wo + (size_t)wave * kTs256;
+  const f32x4* seg_val = w.pw1 + (size_t)wave * kTs256;         // GLU value columns [32w, 32w+32)
+  const f32x4* seg_gate = w.pw1 + (size_t)(8 + wave) * kTs256;  // GLU gate columns 256 + [32w, 32w+32)
+  ring_prime(ring, seg_o, 0);
   rb_load_rows(bufA, kLda, ctx + (size_t)r0 * kD, kRows, valid);
   __syncthreads();
-  const int ts = (kD / 8) * 64;
   {
-    f32x16 acc[1][2];
+    f32x16 acc[1][1];
     acc_zero(acc);
-    rb_gemm<1, 2>(bufA, kLda, w.wo + (size_t)(wave * 2) * ts, ts, kD / 8, acc);
+    rb_gemm<1, 1, kG256>(bufA, kLda, seg_o, 0, seg_val, 0, ring, acc);
+    const float bv = w.bo[col];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int col = wave * 64 + nt * 32 + (lane & 31);
-      const float bv = w.bo[col];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int row = acc_row(r, lane);
-        float v = 0.f;
-        if (row < valid) {
-          v = x1[(size_t)(r0 + row) * kD + col] + (acc[0][nt][r] + bv);
-          x2[(size_t)(r0 + row) * kD + col] = v;
-        }
-        bufX[row * kLda + col] = v;
+    for (int r = 0; r < 16; ++r) {
+      int row = acc_row(r, lane);
+      float v = 0.f;
+      if (row < valid) {
+        v = x1[(size_t)(r0 + row) * kD + col] + (acc[0][0][r] + bv);
+        x2[(size_t)(r0 + row) * kD + col] = v;
       }
+      bufX[row * kLda + col] = v;
     }
   }
   __syncthreads();
-  rb_layernorm(bufX, bufA, kLda, kRows, w.ln_conv_g, w.ln_conv_b, 1e-5f, PadRows{lens, r0, Tp, M});
+  rb_layernorm<false>(bufX, bufA, kLda, kRows, w.ln_conv_g, w.ln_conv_b, 1e-5f, PadRows{lens, r0, Tp, M});
   __syncthreads();
   {
-    // pointwise_conv1 columns are host-permuted so wave w owns value cols [64w,64w+64) (tiles 4w, 4w+1)
-    // and the matching gate cols 256+[64w,64w+64) (tiles 4w+2, 4w+3)
-    f32x16 acc[1][4];
-    acc_zero(acc);
-    rb_gemm<1, 4>(bufA, kLda, w.pw1 + (size_t)(wave * 4) * ts, ts, kD / 8, acc);
+    f32x16 av[1][1], ag[1][1];
+    acc_zero(av);
+    acc_zero(ag);
+    rb_gemm<1, 1, kG256>(bufA, kLda, seg_val, 0, seg_gate, 0, ring, av);
+    rb_gemm<1, 1, kG256>(bufA, kLda, seg_gate, 0, nullptr, 0, ring, ag);
+    const float bval = w.pw1_b[col];
+    const float bgate = w.pw1_b[kD + col];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int cl = nt * 32 + (lane & 31);
-      const float bval = w.pw1_b[wave * 128 + cl];
-      const float bgate = w.pw1_b[wave * 128 + 64 + cl];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int row = acc_row(r, lane);
-        float val = acc[0][nt][r] + bval;
-        float gate = acc[0][nt + 2][r] + bgate;
-        if (row < valid) g[(size_t)(r0 + row) * kD + wave * 64 + cl] = val * sigmoidf(gate);
-      }
+    for (int r = 0; r < 16; ++r) {
+      int row = acc_row(r, lane);
+      float val = av[0][0][r] + bval;
+      float gate = ag[0][0][r] + bgate;
+      if (row < valid) g[(size_t)(r0 + row) * kD + col] = val * sigmoidf(gate);
     }
   }
 }
 constexpr size_t kLdsOutGlu = 2 * kRows * kLda * sizeof(float);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, const LayerW& w, const int64_t* lens, int M,
                     int Tp, hipStream_t st) {
-  hipLaunchKernelGGL(k_out_glu, dim3((M + kRows - 1) / kRows), dim3(256), kLdsOutGlu, st, ctx, x1, x2, g, w, lens, M, Tp);
+  hipLaunchKernelGGL(k_out_glu, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsOutGlu, st, ctx, x1, x2, g, w, lens, M,
+                     Tp);
 }
 
 // -------------------------------------------------------------------------------------
@@ -529,9 +552,9 @@ void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, cons
 // -> LN_ff -> FFN -> +0.5 residual -> LN_final     (convolution.py:129-140, encoder.py:416-429)
 // -------------------------------------------------------------------------------------
 template <int KS>
-__global__ __launch_bounds__(256) void k_conv_ffn(const float* __restrict__ g, const float* __restrict__ x2,
-                                                  float* __restrict__ x_out, LayerW w, const int64_t* __restrict__ lens,
-                                                  int M, int Tp, int n_chunks) {
+__global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__ g, const float* __restrict__ x2,
+                                                       float* __restrict__ x_out, LayerW w,
+                                                       const int64_t* __restrict__ lens, int M, int Tp, int n_chunks) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
@@ -539,85 +562,73 @@ __global__ __launch_bounds__(256) void k_conv_ffn(const float* __restrict__ g, c
   const int lane = lane_id(), wave = wave_id();
   const int r0 = blockIdx.x * kRows;
   const int valid = min(kRows, M - r0);
+  const int col = wave * 32 + (lane & 31);
   constexpr int LO = KS - 1;
+  constexpr int RW = kRows / kWaves;  // rows per wave in the depthwise stage
+  BRing<1> ring;
+  const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
+  ring_prime(ring, seg_pw2, 0);
   {
-    // wave handles block rows 8w..8w+7; lane handles channels 4*lane..4*lane+3
-    const int m0 = r0 + wave * 8;
-    f32x4 win[LO + 8];
+    // wave handles block rows RW*w .. RW*w+RW-1; lane handles channels 4*lane..4*lane+3
+    const int m0 = r0 + wave * RW;
+    f32x4 win[LO + RW];
 #pragma unroll
-    for (int q = 0; q < LO + 8; ++q) {
+    for (int q = 0; q < LO + RW; ++q) {
       int mq = m0 - LO + q;
       win[q] = (mq >= 0 && mq < M) ? *reinterpret_cast<const f32x4*>(g + (size_t)mq * kD + 4 * lane)
                                    : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const f32x4 gp = *reinterpret_cast<const f32x4*>(w.glu_pad + 4 * lane);
     const f32x4 bias = *reinterpret_cast<const f32x4*>(w.dw_b + 4 * lane);
-    f32x4 out[8];
+    f32x4 out[RW];
+    int t_of[RW];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int t_of[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t_of[i] = (m0 + i) % Tp;
+    for (int i = 0; i < RW; ++i) {
+      out[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      t_of[i] = (m0 + i) % Tp;
+    }
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
       const f32x4 wj = *reinterpret_cast<const f32x4*>(w.dw_w + j * kD + 4 * lane);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < RW; ++i) {
         f32x4 v = (t_of[i] - LO + j >= 0) ? win[i + j] : gp;
         out[i] += wj * v;
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(bufA + (wave * 8 + i) * kLda + 4 * lane) = out[i] + bias;
+    for (int i = 0; i < RW; ++i) *reinterpret_cast<f32x4*>(bufA + (wave * RW + i) * kLda + 4 * lane) = out[i] + bias;
   }
   __syncthreads();
-  {  // conv-module LayerNorm (nn.LayerNorm(channels), eps 1e-5) + swish, in place
-    const f32x4 gg = *reinterpret_cast<const f32x4*>(w.ln_cm_g + 4 * lane);
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(w.ln_cm_b + 4 * lane);
-    for (int row = wave; row < kRows; row += 4) {
-      f32x4 x = *reinterpret_cast<const f32x4*>(bufA + row * kLda + 4 * lane);
-      float mean = wave_sum(x[0] + x[1] + x[2] + x[3]) * (1.0f / kD);
-      f32x4 c = x - mean;
-      float var = wave_sum(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3]) * (1.0f / kD);
-      float rstd = 1.0f / sqrtf(var + 1e-5f);
-      f32x4 y = c * rstd * gg + bb;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) y[e] = swishf(y[e]);
-      *reinterpret_cast<f32x4*>(bufA + row * kLda + 4 * lane) = y;
-    }
-  }
+  // conv-module LayerNorm (nn.LayerNorm(channels), eps 1e-5, convolution.py:71) + swish, in place
+  rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
   __syncthreads();
-  const int ts = (kD / 8) * 64;
   PadRows is_pad{lens, r0, Tp, M};
   {
-    f32x16 acc[1][2];
+    f32x16 acc[1][1];
     acc_zero(acc);
-    rb_gemm<1, 2>(bufA, kLda, w.pw2 + (size_t)(wave * 2) * ts, ts, kD / 8, acc);
+    rb_gemm<1, 1, kG256>(bufA, kLda, seg_pw2, 0, w.ff_w1 + (size_t)wave * kTs256, 0, ring, acc);
+    const float bv = w.pw2_b[col];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int col = wave * 64 + nt * 32 + (lane & 31);
-      const float bv = w.pw2_b[col];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int row = acc_row(r, lane);
-        float v = 0.f;
-        if (row < valid) {
-          float c = is_pad(row) ? 0.f : acc[0][nt][r] + bv;
-          v = x2[(size_t)(r0 + row) * kD + col] + c;
-        }
-        bufX[row * kLda + col] = v;
+    for (int r = 0; r < 16; ++r) {
+      int row = acc_row(r, lane);
+      float v = 0.f;
+      if (row < valid) {
+        float c = is_pad(row) ? 0.f : acc[0][0][r] + bv;
+        v = x2[(size_t)(r0 + row) * kD + col] + c;
       }
+      bufX[row * kLda + col] = v;
     }
   }
   __syncthreads();
-  rb_layernorm(bufX, bufA, kLda, kRows, w.ln_ff_g, w.ln_ff_b, 1e-5f, NoZero());
+  rb_layernorm(bufX, bufA, kLda, kRows, w.ln_ff_g, w.ln_ff_b, 1e-5f);
   __syncthreads();
-  f32x16 acc2[1][2];
+  f32x16 acc2[1][1];
   acc_zero(acc2);
-  ffn_phase(bufA, bufH, w.ff_w1, w.ff_b1, w.ff_w2, n_chunks, acc2);
+  ffn_phase(bufA, bufH, w.ff_w1, w.ff_b1, w.ff_w2, n_chunks, nullptr, ring, acc2);
   residual_epilogue(bufX, acc2, w.ff_b2, 0.5f);
   __syncthreads();
-  rb_layernorm(bufX, bufX, kLda, kRows, w.ln_fin_g, w.ln_fin_b, 1e-5f, NoZero());
+  rb_layernorm(bufX, bufX, kLda, kRows, w.ln_fin_g, w.ln_fin_b, 1e-5f);
   // rb_layernorm and rb_store_rows use the same wave->row mapping: no barrier needed
   rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);
 }
@@ -626,32 +637,37 @@ void launch_conv_ffn(const float* g, const float* x2, float* x_out, const LayerW
                      int n_chunks, int ksize, hipStream_t st) {
   dim3 grid((M + kRows - 1) / kRows);
   if (ksize == 15)
-    hipLaunchKernelGGL(k_conv_ffn<15>, grid, dim3(256), kLdsConvFfn, st, g, x2, x_out, w, lens, M, Tp, n_chunks);
+    hipLaunchKernelGGL(k_conv_ffn<15>, grid, dim3(kThreads), kLdsConvFfn, st, g, x2, x_out, w, lens, M, Tp, n_chunks);
   else if (ksize == 31)
-    hipLaunchKernelGGL(k_conv_ffn<31>, grid, dim3(256), kLdsConvFfn, st, g, x2, x_out, w, lens, M, Tp, n_chunks);
+    hipLaunchKernelGGL(k_conv_ffn<31>, grid, dim3(kThreads), kLdsConvFfn, st, g, x2, x_out, w, lens, M, Tp, n_chunks);
   else if (ksize == 7)
-    hipLaunchKernelGGL(k_conv_ffn<7>, grid, dim3(256), kLdsConvFfn, st, g, x2, x_out, w, lens, M, Tp, n_chunks);
+    hipLaunchKernelGGL(k_conv_ffn<7>, grid, dim3(kThreads), kLdsConvFfn, st, g, x2, x_out, w, lens, M, Tp, n_chunks);
 }
 
 // -------------------------------------------------------------------------------------
 // CTC head: after_norm (encoder.py:201-202) -> ctc_lo (loss/ctc.py:27) -> per-frame softmax
 // statistics + argmax (loss/ctc.py:62-70, ctc_greedy_decoder.py:21-22) without materialising
-// the [B,T',V] probability tensor.  Optional logits tap.
+// the [B,T',V] probability tensor.  Optional logits tap (LOGITS).
+// Wave w walks vocabulary tiles w, w+8, ...; each lane keeps a running (max, sum-exp, argmax)
+// for its 16 rows, merged across lanes / waves at the end (ties -> lowest index = numpy argmax).
 // -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ctc_head(const float* __restrict__ x, HeadW hw, float* __restrict__ logits,
-                                                  int32_t* __restrict__ fr_argmax, float* __restrict__ fr_maxprob,
-                                                  float* __restrict__ row_max, float* __restrict__ row_sum, int M) {
+template <bool LOGITS>
+__global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__ x, HeadW hw, float* __restrict__ logits,
+                                                       int32_t* __restrict__ fr_argmax, float* __restrict__ fr_maxprob,
+                                                       float* __restrict__ row_max, float* __restrict__ row_sum, int M) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* bufA = smem;                         // [32][260]
-  float* redM = bufA + kRows * kLda;          // [4][32]
-  float* redS = redM + 128;                   // [4][32]
-  int* redI = reinterpret_cast<int*>(redS + 128);  // [4][32]
+  float* bufA = smem;                                          // [32][260]
+  float* redM = bufA + kRows * kLda;                           // [8][32]
+  float* redS = redM + kWaves * 32;                            // [8][32]
+  int* redI = reinterpret_cast<int*>(redS + kWaves * 32);      // [8][32]
   const int lane = lane_id(), wave = wave_id();
   const int r0 = blockIdx.x * kRows;
   const int valid = min(kRows, M - r0);
   const int V = hw.V;
+  BRing<1> ring;
+  if (wave < hw.n_tiles) ring_prime(ring, hw.w + (size_t)wave * kTs256, 0);
   rb_load_rows(bufA, kLda, x + (size_t)r0 * kD, kRows, valid);
-  rb_layernorm(bufA, bufA, kLda, kRows, hw.ln_g, hw.ln_b, 1e-5f, NoZero());
+  rb_layernorm(bufA, bufA, kLda, kRows, hw.ln_g, hw.ln_b, 1e-5f);
   __syncthreads();
   float mx[16], sm[16];
   int ix[16];
@@ -661,31 +677,31 @@ __global__ __launch_bounds__(256) void k_ctc_head(const float* __restrict__ x, H
     sm[r] = 0.f;
     ix[r] = 0x7fffffff;
   }
-  const int ts = (kD / 8) * 64;
-  for (int tile = wave; tile < hw.n_tiles; tile += 4) {
+  for (int tile = wave; tile < hw.n_tiles; tile += kWaves) {
     f32x16 acc[1][1];
     acc_zero(acc);
-    rb_gemm<1, 1>(bufA, kLda, hw.w + (size_t)tile * ts, ts, kD / 8, acc);
+    const f32x4* seg = hw.w + (size_t)tile * kTs256;
+    rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, tile + kWaves < hw.n_tiles ? seg + (size_t)kWaves * kTs256 : nullptr, 0, ring,
+                         acc);
     const int col = tile * 32 + (lane & 31);
-    const bool cv = col < V;
-    const float bv = hw.b[col];
+    const float bv = (col < V) ? hw.b[col] : -INFINITY;  // padded columns never win and add exp(-inf)=0
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float v = acc[0][0][r] + bv;
-      int row = acc_row(r, lane);
-      if (cv) {
-        if (logits && row < valid) logits[(size_t)(r0 + row) * V + col] = v;
-        if (v > mx[r]) {
-          sm[r] = sm[r] * __expf(mx[r] - v) + 1.0f;
-          mx[r] = v;
-          ix[r] = col;
-        } else {
-          sm[r] += __expf(v - mx[r]);
-        }
+      const float v = acc[0][0][r] + bv;
+      if (LOGITS) {
+        const int row = acc_row(r, lane);
+        if (col < V && row < valid) logits[(size_t)(r0 + row) * V + col] = v;
       }
+      const float mn = fmaxf(mx[r], v);
+      // first valid column: mx = -inf -> exp(-inf) = 0; padded column with mx finite: exp(-inf) = 0
+      const float e_old = (mx[r] == mn) ? 1.0f : __expf(mx[r] - mn);
+      const float e_new = (v == -INFINITY) ? 0.f : __expf(v - mn);
+      sm[r] = sm[r] * e_old + e_new;
+      ix[r] = (v > mx[r]) ? col : ix[r];
+      mx[r] = mn;
     }
   }
-  // reduce over the 32 lanes (columns) of each half-wave; ties -> lowest column (numpy argmax)
+  // reduce over the 32 lanes (columns) of each half-wave
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     float m = mx[r], s = sm[r];
@@ -714,7 +730,7 @@ __global__ __launch_bounds__(256) void k_ctc_head(const float* __restrict__ x, H
     const int row = threadIdx.x;
     float m = redM[row], s = redS[row];
     int i = redI[row];
-    for (int wv = 1; wv < 4; ++wv) {
+    for (int wv = 1; wv < kWaves; ++wv) {
       float m2 = redM[wv * 32 + row], s2 = redS[wv * 32 + row];
       int i2 = redI[wv * 32 + row];
       float mn = fmaxf(m, m2);
@@ -733,11 +749,16 @@ __global__ __launch_bounds__(256) void k_ctc_head(const float* __restrict__ x, H
     }
   }
 }
-constexpr size_t kLdsCtc = (kRows * kLda + 3 * 128) * sizeof(float);
+constexpr size_t kLdsCtc = (kRows * kLda + 3 * kWaves * 32) * sizeof(float);
 void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr_argmax, float* fr_maxprob, float* row_max,
                      float* row_sum, int M, hipStream_t st) {
-  hipLaunchKernelGGL(k_ctc_head, dim3((M + kRows - 1) / kRows), dim3(256), kLdsCtc, st, x, hw, logits, fr_argmax,
-                     fr_maxprob, row_max, row_sum, M);
+  dim3 grid((M + kRows - 1) / kRows);
+  if (logits)
+    hipLaunchKernelGGL(k_ctc_head<true>, grid, dim3(kThreads), kLdsCtc, st, x, hw, logits, fr_argmax, fr_maxprob, row_max,
+                       row_sum, M);
+  else
+    hipLaunchKernelGGL(k_ctc_head<false>, grid, dim3(kThreads), kLdsCtc, st, x, hw, logits, fr_argmax, fr_maxprob, row_max,
+                       row_sum, M);
 }
 
 // probs = softmax(logits) recomputed exactly (max, then exp(x-max)/sum) in place; one wave per row.
@@ -862,7 +883,8 @@ hipError_t configure_kernels() {
   SET_LDS(k_conv_ffn<15>, kLdsConvFfn);
   SET_LDS(k_conv_ffn<31>, kLdsConvFfn);
   SET_LDS(k_conv_ffn<7>, kLdsConvFfn);
-  SET_LDS(k_ctc_head, kLdsCtc);
+  SET_LDS(k_ctc_head<true>, kLdsCtc);
+  SET_LDS(k_ctc_head<false>, kLdsCtc);
   SET_LDS((k_gemm_stream<4, 64, true, Conv2Src>), 2 * 128 * 68 * sizeof(float));
   SET_LDS((k_gemm_stream<1, 256, false, DenseSrc>), 2 * 32 * 260 * sizeof(float));
 #undef SET_LDS

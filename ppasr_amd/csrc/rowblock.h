@@ -1,6 +1,6 @@
 // rowblock.h -- device-side toolkit shared by the gfx950 kernels.
 //
-// Execution model ("row-block"): a 256-thread workgroup (4 wave64, one per SIMD) owns
+// Execution model ("row-block"): a 512-thread workgroup (8 wave64, two per SIMD) owns
 // 32*MT consecutive rows of the flattened [B*T', d] activation matrix and keeps them in
 // LDS across a whole chain of dense layers.  Dense contractions run on the exact-fp32
 // matrix core (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain):
@@ -9,8 +9,12 @@
 //   * the B operand (weights) is streamed from global/L2 straight into VGPRs in a layout
 //     pre-packed on the host in MFMA fragment order, so every load is a fully coalesced
 //     1 KiB global_load_dwordx4 per wave and needs no LDS staging (each wave owns its own
-//     64 output columns, so B is not shared between waves);
-//   * a 4-deep register ring prefetches B four k-groups (2048 MFMA cycles) ahead.
+//     32 output columns, so B is not shared between waves);
+//   * a PF-deep register ring prefetches B PF k-groups ahead and is carried ACROSS calls
+//     (each call names the segment the stream continues with), so the weight stream never
+//     drains at GEMM / phase boundaries or barriers;
+//   * a "side" functor is invoked once per k-group so VALU epilogue work of the previous
+//     tile can be interleaved with the MFMAs of the current one (separate pipes).
 //
 // Fragment maps (MI355X guide §3): A lane l holds A[i=l&31][k=l>>5]; B lane l holds
 // B[k=l>>5][j=l&31]; C/D lane l, reg r holds D[(r&3)+8*(r>>2)+4*(l>>5)][l&31].
@@ -26,7 +30,10 @@ namespace ppasr {
 constexpr int kD = 256;        // model width the kernels are specialised for
 constexpr int kLda = kD + 4;   // LDS row stride (floats) of a [rows][256] activation buffer
 constexpr int kRows = 32;      // rows per MFMA row tile
-constexpr int kThreads = 256;  // 4 wave64
+constexpr int kWaves = 8;      // waves per row-block workgroup
+constexpr int kThreads = 64 * kWaves;
+constexpr int kG256 = kD / 8;  // k-groups of a K=256 contraction
+constexpr int kTs256 = kG256 * 64;  // packed tile stride (f32x4 units) of a K=256 weight
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
@@ -45,7 +52,8 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid / swish on the hardware exp + rcp (about 1 ulp each; well inside the 1e-3 logit budget)
+__device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float swishf(float x) { return x * sigmoidf(x); }
 
 template <int MT, int NT>
@@ -58,78 +66,114 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[MT][NT]) {
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 }
 
-// acc[mt][nt] += A[32*MT x 8*g_count] * Bpacked.
-//   a_lds : LDS, row 0 / k 0 of the A block, row stride lda floats (lda % 64 == 4)
-//   bp    : packed weights, positioned at (this wave's first n-tile, first k-group);
-//           n-tile nt of this call lives at bp + nt*tile_stride (units: f32x4)
-//   g_count: number of 8-wide k-groups; must be a multiple of PF
-template <int MT, int NT, int PF = 4>
-__device__ __forceinline__ void rb_gemm(const float* a_lds, int lda, const f32x4* __restrict__ bp,
-                                        int tile_stride, int g_count, f32x16 (&acc)[MT][NT]) {
-  const int lane = lane_id();
-  const float* a_ptr = a_lds + (lane & 31) * lda + 4 * (lane >> 5);
-  const f32x4* b_ptr = bp + lane;
-  f32x4 bq[PF][NT];
+// ---- weight stream ring -----------------------------------------------------------------
+template <int NT, int PF = 4>
+struct BRing {
+  f32x4 q[PF][NT];
+};
+
+// fill the ring with k-groups 0..PF-1 of the segment starting at bp (n-tile nt at bp + nt*tile_stride)
+template <int NT, int PF>
+__device__ __forceinline__ void ring_prime(BRing<NT, PF>& ring, const f32x4* __restrict__ bp, int tile_stride) {
+  const f32x4* p = bp + lane_id();
 #pragma unroll
   for (int s = 0; s < PF; ++s)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bq[s][nt] = b_ptr[(size_t)nt * tile_stride + s * 64];
-  for (int g0 = 0; g0 < g_count; g0 += PF) {
+    for (int nt = 0; nt < NT; ++nt) ring.q[s][nt] = p[(size_t)nt * tile_stride + s * 64];
+}
+
+struct NoSide {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+// acc[mt][nt] += A[32*MT x 8*G] * Bpacked, G k-groups (compile-time, multiple of PF).
+//   a_lds : LDS, row 0 / k 0 of the A block, row stride lda floats (lda % 64 == 4)
+//   bp    : packed weights of THIS call, positioned at (first n-tile, first k-group); the
+//           ring must already hold its first PF k-groups (ring_prime or a previous call's nxt)
+//   nxt   : segment the stream continues with after this call (nullptr: stream ends); must
+//           have the same NT; its n-tile stride is nxt_stride
+//   side(g): called once per k-group, after that group's MFMAs were issued
+template <int MT, int NT, int G, int PF = 4, typename Side = NoSide>
+__device__ __forceinline__ void rb_gemm(const float* a_lds, int lda, const f32x4* __restrict__ bp, int tile_stride,
+                                        const f32x4* __restrict__ nxt, int nxt_stride, BRing<NT, PF>& ring,
+                                        f32x16 (&acc)[MT][NT], Side side = Side()) {
+  static_assert(G % PF == 0, "k-groups must be a multiple of the ring depth");
+  const int lane = lane_id();
+  const float* a_ptr = a_lds + (lane & 31) * lda + 4 * (lane >> 5);
+  const f32x4* b_ptr = bp + lane;
+  const f32x4* n_ptr = nxt + lane;
+  f32x4 a_cur[MT], a_nxt[MT];
 #pragma unroll
-    for (int s = 0; s < PF; ++s) {
-      const int g = g0 + s;
-      f32x4 a[MT];
+  for (int mt = 0; mt < MT; ++mt) a_cur[mt] = *reinterpret_cast<const f32x4*>(a_ptr + mt * 32 * lda);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(a_ptr + mt * 32 * lda + 8 * g);
-      f32x4 b[NT];
+  for (int g = 0; g < G; ++g) {
+    const int s = g % PF;
+    // software pipeline: LDS read of the next k-group is issued before this group's MFMAs
+    if (g + 1 < G) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt] = bq[s][nt];
-      if (g + PF < g_count) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bq[s][nt] = b_ptr[(size_t)nt * tile_stride + (size_t)(g + PF) * 64];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+      for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = *reinterpret_cast<const f32x4*>(a_ptr + mt * 32 * lda + 8 * (g + 1));
     }
+    f32x4 b[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = ring.q[s][nt];
+    if (g + PF < G) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) ring.q[s][nt] = b_ptr[(size_t)nt * tile_stride + (size_t)(g + PF) * 64];
+    } else if (nxt) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) ring.q[s][nt] = n_ptr[(size_t)nt * nxt_stride + (size_t)(g + PF - G) * 64];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+    side(g);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+    // keep the unrolled k-groups in program order: bounds live ranges (the scheduler would otherwise
+    // hoist every LDS read / weight load of the whole tile to the top and spill)
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 // LayerNorm over the 256 columns of LDS rows (biased variance, eps inside the sqrt),
-// nn.LayerNorm semantics (utils/base.py:7-21).  Each wave normalises rows w, w+4, ...;
+// nn.LayerNorm semantics (utils/base.py:7-21).  Each wave normalises rows w, w+8, ...;
 // one ds_read_b128 per lane covers a whole row.  src == dst is allowed.
-// If zero_row(row) is true the output row is forced to 0 (conv-module pad masking).
-template <typename ZeroRow>
+// If zero_row(row) is true the output row is forced to 0 (conv-module pad masking);
+// POST is applied elementwise after the affine (identity or swish).
+struct NoZero {
+  __device__ __forceinline__ bool operator()(int) const { return false; }
+};
+template <bool SWISH = false, typename ZeroRow = NoZero>
 __device__ __forceinline__ void rb_layernorm(const float* src, float* dst, int lda, int nrows,
                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                             float eps, ZeroRow zero_row) {
+                                             float eps, ZeroRow zero_row = ZeroRow()) {
   const int lane = lane_id();
   const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * lane);
   const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * lane);
-  for (int row = wave_id(); row < nrows; row += 4) {
+  for (int row = wave_id(); row < nrows; row += kWaves) {
     f32x4 x = *reinterpret_cast<const f32x4*>(src + row * lda + 4 * lane);
     float mean = wave_sum(x[0] + x[1] + x[2] + x[3]) * (1.0f / kD);
     f32x4 c = x - mean;
     float var = wave_sum(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3]) * (1.0f / kD);
     float rstd = 1.0f / sqrtf(var + eps);
     f32x4 y = c * rstd * g + b;
+    if (SWISH) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = swishf(y[e]);
+    }
     if (zero_row(row)) y = f32x4{0.f, 0.f, 0.f, 0.f};
     *reinterpret_cast<f32x4*>(dst + row * lda + 4 * lane) = y;
   }
 }
 
-struct NoZero {
-  __device__ __forceinline__ bool operator()(int) const { return false; }
-};
-
 // copy nrows x 256 floats global(row stride 256) -> LDS(row stride lda); rows >= valid are zeroed
 __device__ __forceinline__ void rb_load_rows(float* dst, int lda, const float* __restrict__ src, int nrows, int valid) {
   const int lane = lane_id();
-  for (int row = wave_id(); row < nrows; row += 4) {
+  for (int row = wave_id(); row < nrows; row += kWaves) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (row < valid) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * kD + 4 * lane);
     *reinterpret_cast<f32x4*>(dst + row * lda + 4 * lane) = v;
@@ -139,7 +183,7 @@ __device__ __forceinline__ void rb_load_rows(float* dst, int lda, const float* _
 // LDS(row stride lda) -> global(row stride 256) for rows < valid
 __device__ __forceinline__ void rb_store_rows(float* __restrict__ dst, const float* src, int lda, int nrows, int valid) {
   const int lane = lane_id();
-  for (int row = wave_id(); row < nrows && row < valid; row += 4)
+  for (int row = wave_id(); row < nrows && row < valid; row += kWaves)
     *reinterpret_cast<f32x4*>(dst + (size_t)row * kD + 4 * lane) =
         *reinterpret_cast<const f32x4*>(src + row * lda + 4 * lane);
 }
