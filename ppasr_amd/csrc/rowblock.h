@@ -67,7 +67,8 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[MT][NT]) {
 }
 
 // ---- weight stream ring -----------------------------------------------------------------
-template <int NT, int PF = 4>
+constexpr int kPF = 4;  // weight-stream prefetch depth (k-groups = 1 KiB loads in flight per wave)
+template <int NT, int PF = kPF>
 struct BRing {
   f32x4 q[PF][NT];
 };
@@ -93,7 +94,7 @@ struct NoSide {
 //   nxt   : segment the stream continues with after this call (nullptr: stream ends); must
 //           have the same NT; its n-tile stride is nxt_stride
 //   side(g): called once per k-group, after that group's MFMAs were issued
-template <int MT, int NT, int G, int PF = 4, typename Side = NoSide>
+template <int MT, int NT, int G, int PF = kPF, typename Side = NoSide>
 __device__ __forceinline__ void rb_gemm(const float* a_lds, int lda, const f32x4* __restrict__ bp, int tile_stride,
                                         const f32x4* __restrict__ nxt, int nxt_stride, BRing<NT, PF>& ring,
                                         f32x16 (&acc)[MT][NT], Side side = Side()) {
@@ -156,9 +157,15 @@ __device__ __forceinline__ void rb_layernorm(const float* src, float* dst, int l
   const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * lane);
   for (int row = wave_id(); row < nrows; row += kWaves) {
     f32x4 x = *reinterpret_cast<const f32x4*>(src + row * lda + 4 * lane);
+#ifdef PPASR_ABLATE_LN
+    float mean = 0.f;
+    f32x4 c = x - mean;
+    float var = 1.f;
+#else
     float mean = wave_sum(x[0] + x[1] + x[2] + x[3]) * (1.0f / kD);
     f32x4 c = x - mean;
     float var = wave_sum(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3]) * (1.0f / kD);
+#endif
     float rstd = 1.0f / sqrtf(var + eps);
     f32x4 y = c * rstd * g + b;
     if (SWISH) {

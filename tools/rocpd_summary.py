@@ -11,11 +11,11 @@ for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_d
     print(f"{name} | {calls} | {total:.1f} | {avg:.2f} | {pct:.2f}")
 try:
     rows = list(cur.execute(
-        "select k.name, p.counter_name, count(*), sum(p.value), avg(p.value) from pmc_events p "
-        "join kernels k on p.dispatch_id = k.dispatch_id group by k.name, p.counter_name"))
+        "select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
+        "group by kernel_name, counter_name order by kernel_name, counter_name"))
     if rows:
-        print("\n# PMC: kernel | counter | dispatches | sum | avg per dispatch")
+        print("\n# PMC (rocprofv3 --pmc, summed over XCDs/SEs): kernel | counter | dispatches | avg value per dispatch | avg ns")
         for r in rows:
-            print(" | ".join(str(x) for x in r))
+            print(f"{r[0][:60]} | {r[1]} | {r[2]} | {r[3]:.0f} | {r[4]:.0f}")
 except sqlite3.Error as e:
     print("# (no pmc table:", e, ")")
