@@ -95,6 +95,29 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
  * to `taps` in the order documented in DESIGN.md; pass NULL to clear. */
 ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats);
 
+/* ---- streaming: ConformerModel.get_encoder_out_chunk (model_utils/conformer/model.py:164-184) =
+ * ConformerEncoder.forward_chunk (conformer/encoder.py:208-283) + ctc softmax, as driven by
+ * InferencePredictor.predict_chunk_conformer / reset_stream (inference_predictor.py:184-220) and
+ * PPASRPredictor.predict_stream (predict.py:232-337).  The attention key/value cache and the conv-module
+ * cache stay resident on the device inside the stream object; `offset` (inference_predictor.py:39,211)
+ * is tracked by the object.  B = 1 per stream (encoder.py:238); run several streams for several sessions. */
+ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out);
+ppasr_status ppasr_stream_destroy(ppasr_stream s);
+ppasr_status ppasr_stream_reset(ppasr_stream s, void* stream);
+int ppasr_stream_offset(ppasr_stream s);        /* encoder frames emitted so far */
+int ppasr_stream_cache_frames(ppasr_stream s);  /* cache_t1: key/value frames currently cached */
+size_t ppasr_chunk_workspace_bytes(ppasr_handle h, int T);
+/*   feats [1,T,F] f32; required_cache_size as in encoder.py:255-260 (<0 keep everything, the value
+ *   predict_stream uses; 0 none; >0 last n frames); probs [1,c,V] or NULL; c = ((T-1)/2-1)/2 is also
+ *   written to *c_out_host (host int, may be NULL). */
+ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int required_cache_size, float* probs,
+                                int32_t* frame_argmax, float* frame_maxprob, int* c_out_host, void* workspace,
+                                size_t workspace_bytes, void* stream);
+/* Reference tensor layouts of the caches: att_cache [L][h][t][2*dk], cnn_cache [L][1][d][k-1]. */
+ppasr_status ppasr_stream_export_cache(ppasr_stream s, float* att_cache, float* cnn_cache, void* stream);
+ppasr_status ppasr_stream_import_cache(ppasr_stream s, const float* att_cache, int cache_t, const float* cnn_cache,
+                                       int offset, void* stream);
+
 /* Measurement hook (bench.py roofline leg; no reference counterpart): when enabled, every kernel launch
  * of the next ppasr_encode is bracketed by a HIP event pair on the caller's stream; ppasr_profile_read
  * synchronises those events and returns, per kernel class, the summed duration (ms) and launch count

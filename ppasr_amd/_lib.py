@@ -47,6 +47,16 @@ SYMBOLS = [
     ("ppasr_encode", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp,
                                     ctypes.c_size_t, _vp]),
     ("ppasr_set_debug_taps", ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    ("ppasr_stream_create", ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    ("ppasr_stream_destroy", ctypes.c_int, [_vp]),
+    ("ppasr_stream_reset", ctypes.c_int, [_vp, _vp]),
+    ("ppasr_stream_offset", ctypes.c_int, [_vp]),
+    ("ppasr_stream_cache_frames", ctypes.c_int, [_vp]),
+    ("ppasr_chunk_workspace_bytes", ctypes.c_size_t, [_vp, ctypes.c_int]),
+    ("ppasr_encode_chunk", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
+                                          ctypes.POINTER(ctypes.c_int), _vp, ctypes.c_size_t, _vp]),
+    ("ppasr_stream_export_cache", ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    ("ppasr_stream_import_cache", ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, ctypes.c_int, _vp]),
     ("ppasr_profile_enable", ctypes.c_int, [_vp, ctypes.c_int]),
     ("ppasr_profile_read", ctypes.c_int, [_vp, c_f32p, c_i32p]),
     ("ppasr_kernel_class_name", ctypes.c_char_p, [ctypes.c_int]),

@@ -37,18 +37,40 @@ struct HeadW {
   int V, n_tiles;
 };
 
+// Attention operands: queries / keys / values may live in different buffers (streaming reads K/V from
+// the per-layer device caches).  Row strides in floats; utterance b starts at row b*T1 (q, ctx) / b*T2 (k, v).
+struct AttnArgs {
+  const float* q;
+  int q_stride;
+  const float* k;
+  int k_stride;
+  const float* v;
+  int v_stride;
+  int T1, T2;           // queries / keys per utterance
+  int pos0;             // position of key 0 in the positional table (encoder.py:253: offset - cache_t1)
+  const int64_t* lens;  // feature lengths for the key-padding mask, or nullptr (streaming: no mask)
+  float* ctx;           // [B*T1][256]
+};
+
 // ---- launchers (all asynchronous on `st`) ----
 void launch_posproj(const float* pe, const float* wpos /*[256][256] in,out*/, float* ptab, int max_len, hipStream_t st);
 void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T, int F, int T1, int F1, hipStream_t st);
 void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st);
 void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, hipStream_t st);
 void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st);
-void launch_attention(const float* qkv, const LayerW& w, const int64_t* lens, float* ctx, int B, int Tp, int H,
-                      hipStream_t st);
-void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, const LayerW& w, const int64_t* lens,
-                    int M, int Tp, hipStream_t st);
-void launch_conv_ffn(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int M, int Tp,
-                     int n_chunks, int ksize, hipStream_t st);
+void launch_attention(const AttnArgs& a, const LayerW& w, int B, int H, hipStream_t st);
+void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
+                    const int64_t* lens, int M, int Tp, hipStream_t st);
+void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
+                     const int64_t* lens, int M, int Tp, int n_chunks, int ksize, hipStream_t st);
+// streaming helpers
+void launch_pw1_glu(const float* xhat, float* g, const LayerW& w, int M, hipStream_t st);
+void launch_kv_append(const float* qkv, float* kc, float* vc, int n_rows, hipStream_t st);
+void launch_hist_update(float* hist, const float* fresh, int n, int lo, hipStream_t st);
+void launch_cache_export(const float* kc, const float* vc, float* att, int T, hipStream_t st);
+void launch_cache_import(const float* att, float* kc, float* vc, int T, hipStream_t st);
+void launch_cnn_transpose(const float* src, float* dst, int lo, int to_ref, hipStream_t st);
+void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStream_t st);
 void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr_argmax, float* fr_maxprob,
                      float* row_max, float* row_sum, int M, hipStream_t st);
 void launch_softmax_from_stats(float* probs_inout, const float* row_max, const float* row_sum, int M, int V,

@@ -312,8 +312,7 @@ constexpr int kQld = 132, kSld = 129, kKld = 36, kVld = 68;
 constexpr int kAttnLdsFloats = 32 * kQld + 32 * kSld + 128 * kVld + 96;
 constexpr size_t kLdsAttn = kAttnLdsFloats * sizeof(float);
 
-__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, LayerW w, const int64_t* __restrict__ lens,
-                                                   float* __restrict__ ctx, int Tp) {
+__global__ __launch_bounds__(256) void k_attention(AttnArgs a, LayerW w) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;               // [32][132]  Q' = [q+u | q+v]
   float* Ss = Qs + 32 * kQld;     // [32][129]  scores / probabilities of the current key block
@@ -323,9 +322,13 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   float* stA = stL + 32;          // rescale alpha [32]
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
-  const int T1 = Tp, T2 = Tp;
-  const size_t row0 = (size_t)b * Tp;
-  const int64_t len_b = lens ? lens[b] : (int64_t)4 * T2;
+  const int T1 = a.T1, T2 = a.T2;
+  const float* __restrict__ qb = a.q + (size_t)b * T1 * a.q_stride;
+  const float* __restrict__ kbp = a.k + (size_t)b * T2 * a.k_stride;
+  const float* __restrict__ vbp = a.v + (size_t)b * T2 * a.v_stride;
+  const float* __restrict__ ptab = w.ptab + (size_t)a.pos0 * kD;
+  float* __restrict__ ctx = a.ctx + (size_t)b * T1 * kD;
+  const int64_t len_b = a.lens ? a.lens[b] : (int64_t)4 * T2;
 
   // ---- Q' ----
 #pragma unroll
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     int idx = tid + 256 * i;
     int row = idx >> 4, f4 = idx & 15;
     f32x4 q = {0.f, 0.f, 0.f, 0.f};
-    if (q0 + row < T1) q = *reinterpret_cast<const f32x4*>(qkv + (row0 + q0 + row) * 768 + h * 64 + f4 * 4);
+    if (q0 + row < T1) q = *reinterpret_cast<const f32x4*>(qb + (size_t)(q0 + row) * a.q_stride + h * 64 + f4 * 4);
     f32x4 u = *reinterpret_cast<const f32x4*>(w.pos_u + h * 64 + f4 * 4);
     f32x4 v = *reinterpret_cast<const f32x4*>(w.pos_v + h * 64 + f4 * 4);
     *reinterpret_cast<f32x4*>(Qs + row * kQld + f4 * 4) = q + u;
@@ -363,8 +366,8 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
         int key = idx >> 3, f4 = idx & 7;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (key0 + key < T2) {
-          const float* p = (fc < 2) ? qkv + (row0 + key0 + key) * 768 + 256 + h * 64 + fc * 32 + f4 * 4
-                                    : w.ptab + (size_t)(key0 + key) * kD + h * 64 + (fc - 2) * 32 + f4 * 4;
+          const float* p = (fc < 2) ? kbp + (size_t)(key0 + key) * a.k_stride + h * 64 + fc * 32 + f4 * 4
+                                    : ptab + (size_t)(key0 + key) * kD + h * 64 + (fc - 2) * 32 + f4 * 4;
           v = *reinterpret_cast<const f32x4*>(p);
         }
         stg[i] = v;
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
       int idx = tid + 256 * i;
       int key = idx >> 4, f4 = idx & 15;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (key0 + key < T2) v = *reinterpret_cast<const f32x4*>(qkv + (row0 + key0 + key) * 768 + 512 + h * 64 + f4 * 4);
+      if (key0 + key < T2) v = *reinterpret_cast<const f32x4*>(vbp + (size_t)(key0 + key) * a.v_stride + h * 64 + f4 * 4);
       vst[i] = v;
     }
     {
@@ -472,13 +475,12 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
       float l = stL[row];
       float o = acc_o[r] + Osum[(ct * 32 + row) * 33 + (lane & 31)];
       o = (l > 0.f) ? o / l : 0.f;  // fully masked row -> 0 (attention.py:118)
-      if (q0 + row < T1) ctx[(row0 + q0 + row) * kD + h * 64 + ct * 32 + (lane & 31)] = o;
+      if (q0 + row < T1) ctx[(size_t)(q0 + row) * kD + h * 64 + ct * 32 + (lane & 31)] = o;
     }
   }
 }
-void launch_attention(const float* qkv, const LayerW& w, const int64_t* lens, float* ctx, int B, int Tp, int H,
-                      hipStream_t st) {
-  hipLaunchKernelGGL(k_attention, dim3((Tp + 31) / 32, H, B), dim3(256), kLdsAttn, st, qkv, w, lens, ctx, Tp);
+void launch_attention(const AttnArgs& a, const LayerW& w, int B, int H, hipStream_t st) {
+  hipLaunchKernelGGL(k_attention, dim3((a.T1 + 31) / 32, H, B), dim3(256), kLdsAttn, st, a, w);
 }
 
 // -------------------------------------------------------------------------------------
@@ -486,7 +488,8 @@ void launch_attention(const float* qkv, const LayerW& w, const int64_t* lens, fl
 // (attention.py:126, encoder.py:399-409, convolution.py:104-106,125-126)
 // -------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ ctx, const float* __restrict__ x1,
-                                                      float* __restrict__ x2, float* __restrict__ g, LayerW w,
+                                                      float* __restrict__ x2, float* __restrict__ g,
+                                                      float* __restrict__ xhat_out, LayerW w,
                                                       const int64_t* __restrict__ lens, int M, int Tp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bufX = smem;
@@ -520,6 +523,8 @@ __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ 
   }
   __syncthreads();
   rb_layernorm<false>(bufX, bufA, kLda, kRows, w.ln_conv_g, w.ln_conv_b, 1e-5f, PadRows{lens, r0, Tp, M});
+  // streaming: the conv-module input (what the reference keeps as cnn_cache, convolution.py:117)
+  if (xhat_out) rb_store_rows(xhat_out + (size_t)r0 * kD, bufA, kLda, kRows, valid);
   __syncthreads();
   {
     f32x16 av[1][1], ag[1][1];
@@ -539,10 +544,120 @@ __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ 
   }
 }
 constexpr size_t kLdsOutGlu = 2 * kRows * kLda * sizeof(float);
-void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, const LayerW& w, const int64_t* lens, int M,
-                    int Tp, hipStream_t st) {
-  hipLaunchKernelGGL(k_out_glu, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsOutGlu, st, ctx, x1, x2, g, w, lens, M,
-                     Tp);
+void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
+                    const int64_t* lens, int M, int Tp, hipStream_t st) {
+  hipLaunchKernelGGL(k_out_glu, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsOutGlu, st, ctx, x1, x2, g, xhat_out, w,
+                     lens, M, Tp);
+}
+
+// streaming: g_hist = GLU(pointwise_conv1(cnn_cache rows))  -- the reference re-applies pointwise_conv1+GLU
+// to the cached frames on every chunk (convolution.py:113,125-126); here once per chunk on <= 32 rows.
+__global__ __launch_bounds__(kThreads) void k_pw1_glu(const float* __restrict__ xhat, float* __restrict__ g, LayerW w, int M) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufA = smem;
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, M - r0);
+  const int col = wave * 32 + (lane & 31);
+  BRing<1> ring;
+  const f32x4* seg_val = w.pw1 + (size_t)wave * kTs256;
+  const f32x4* seg_gate = w.pw1 + (size_t)(8 + wave) * kTs256;
+  ring_prime(ring, seg_val, 0);
+  rb_load_rows(bufA, kLda, xhat + (size_t)r0 * kD, kRows, valid);
+  __syncthreads();
+  f32x16 av[1][1], ag[1][1];
+  acc_zero(av);
+  acc_zero(ag);
+  rb_gemm<1, 1, kG256>(bufA, kLda, seg_val, 0, seg_gate, 0, ring, av);
+  rb_gemm<1, 1, kG256>(bufA, kLda, seg_gate, 0, nullptr, 0, ring, ag);
+  const float bval = w.pw1_b[col];
+  const float bgate = w.pw1_b[kD + col];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int row = acc_row(r, lane);
+    if (row < valid) g[(size_t)(r0 + row) * kD + col] = (av[0][0][r] + bval) * sigmoidf(ag[0][0][r] + bgate);
+  }
+}
+constexpr size_t kLdsPw1Glu = kRows * kLda * sizeof(float);
+void launch_pw1_glu(const float* xhat, float* g, const LayerW& w, int M, hipStream_t st) {
+  hipLaunchKernelGGL(k_pw1_glu, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsPw1Glu, st, xhat, g, w, M);
+}
+
+// streaming: append this chunk's keys / values (columns 256.. / 512.. of qkv) to the per-layer caches
+__global__ void k_kv_append(const float* __restrict__ qkv, float* __restrict__ kc, float* __restrict__ vc, int n_rows) {
+  const int row = blockIdx.x, t = threadIdx.x;  // 128 threads x float4 = 512 floats (k | v)
+  const f32x4 v = *reinterpret_cast<const f32x4*>(qkv + (size_t)row * 768 + 256 + 4 * t);
+  float* dst = (t < 64) ? kc + (size_t)row * kD + 4 * t : vc + (size_t)row * kD + 4 * (t - 64);
+  *reinterpret_cast<f32x4*>(dst) = v;
+}
+void launch_kv_append(const float* qkv, float* kc, float* vc, int n_rows, hipStream_t st) {
+  hipLaunchKernelGGL(k_kv_append, dim3(n_rows), dim3(128), 0, st, qkv, kc, vc, n_rows);
+}
+
+// streaming: hist <- last `lo` rows of concat(hist[lo], fresh[n]); single block, read-all-then-write
+__global__ __launch_bounds__(256) void k_hist_update(float* __restrict__ hist, const float* __restrict__ fresh, int n, int lo) {
+  const int tid = threadIdx.x;
+  constexpr int kMaxPer = 32;  // lo <= 30 rows of 64 float4 = 1920 float4 / 256 threads
+  f32x4 tmp[kMaxPer / 4];
+  const int total = lo * 64;
+#pragma unroll
+  for (int i = 0; i < kMaxPer / 4; ++i) {
+    int idx = tid + 256 * i;
+    if (idx < total) {
+      int row = idx >> 6, c4 = idx & 63;
+      int j = n + row;  // row index inside concat(hist, fresh)
+      tmp[i] = (j < lo) ? *reinterpret_cast<const f32x4*>(hist + (size_t)j * kD + 4 * c4)
+                        : *reinterpret_cast<const f32x4*>(fresh + (size_t)(j - lo) * kD + 4 * c4);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kMaxPer / 4; ++i) {
+    int idx = tid + 256 * i;
+    if (idx < total) *reinterpret_cast<f32x4*>(hist + (size_t)(idx >> 6) * kD + 4 * (idx & 63)) = tmp[i];
+  }
+}
+void launch_hist_update(float* hist, const float* fresh, int n, int lo, hipStream_t st) {
+  hipLaunchKernelGGL(k_hist_update, dim3(1), dim3(256), 0, st, hist, fresh, n, lo);
+}
+
+// [T][256] (col = h*64+f) k/v caches  <->  reference att_cache layout [h][T][2*dk]  (attention.py:232)
+__global__ void k_cache_export(const float* __restrict__ kc, const float* __restrict__ vc, float* __restrict__ att, int T) {
+  const int t = blockIdx.x, tid = threadIdx.x;  // 256 threads: (h, f)
+  const int h = tid >> 6, f = tid & 63;
+  att[((size_t)h * T + t) * 128 + f] = kc[(size_t)t * kD + tid];
+  att[((size_t)h * T + t) * 128 + 64 + f] = vc[(size_t)t * kD + tid];
+}
+__global__ void k_cache_import(const float* __restrict__ att, float* __restrict__ kc, float* __restrict__ vc, int T) {
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int h = tid >> 6, f = tid & 63;
+  kc[(size_t)t * kD + tid] = att[((size_t)h * T + t) * 128 + f];
+  vc[(size_t)t * kD + tid] = att[((size_t)h * T + t) * 128 + 64 + f];
+}
+// cnn cache: ours [lo][256] (row = frame)  <->  reference [256][lo]
+__global__ void k_cnn_transpose(const float* __restrict__ src, float* __restrict__ dst, int lo, int to_ref) {
+  const int c = threadIdx.x;
+  for (int j = 0; j < lo; ++j) {
+    if (to_ref) dst[(size_t)c * lo + j] = src[(size_t)j * kD + c];
+    else dst[(size_t)j * kD + c] = src[(size_t)c * lo + j];
+  }
+}
+void launch_cache_export(const float* kc, const float* vc, float* att, int T, hipStream_t st) {
+  if (T > 0) hipLaunchKernelGGL(k_cache_export, dim3(T), dim3(256), 0, st, kc, vc, att, T);
+}
+void launch_cache_import(const float* att, float* kc, float* vc, int T, hipStream_t st) {
+  if (T > 0) hipLaunchKernelGGL(k_cache_import, dim3(T), dim3(256), 0, st, att, kc, vc, T);
+}
+void launch_cnn_transpose(const float* src, float* dst, int lo, int to_ref, hipStream_t st) {
+  hipLaunchKernelGGL(k_cnn_transpose, dim3(1), dim3(256), 0, st, src, dst, lo, to_ref);
+}
+void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStream_t st);
+__global__ void k_fill_rows(float* __restrict__ dst, const float* __restrict__ row, int n_rows) {
+  const int r = blockIdx.x, c = threadIdx.x;
+  dst[(size_t)r * kD + c] = row ? row[c] : 0.f;
+}
+void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStream_t st) {
+  hipLaunchKernelGGL(k_fill_rows, dim3(n_rows), dim3(256), 0, st, dst, row_or_null, n_rows);
 }
 
 // -------------------------------------------------------------------------------------
@@ -551,9 +666,9 @@ void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, cons
 // convolution.py:108-126) -> LayerNorm -> swish -> pointwise_conv2 -> pad mask -> +residual
 // -> LN_ff -> FFN -> +0.5 residual -> LN_final     (convolution.py:129-140, encoder.py:416-429)
 // -------------------------------------------------------------------------------------
-template <int KS>
-__global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__ g, const float* __restrict__ x2,
-                                                       float* __restrict__ x_out, LayerW w,
+template <int KS, bool STREAM>
+__global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__ g, const float* __restrict__ g_hist,
+                                                       const float* __restrict__ x2, float* __restrict__ x_out, LayerW w,
                                                        const int64_t* __restrict__ lens, int M, int Tp, int n_chunks) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bufX = smem;
@@ -575,8 +690,11 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
 #pragma unroll
     for (int q = 0; q < LO + RW; ++q) {
       int mq = m0 - LO + q;
-      win[q] = (mq >= 0 && mq < M) ? *reinterpret_cast<const f32x4*>(g + (size_t)mq * kD + 4 * lane)
-                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (STREAM && mq < 0)  // single stream: rows are frames; frames before the chunk come from the cache
+        win[q] = *reinterpret_cast<const f32x4*>(g_hist + (size_t)(LO + mq) * kD + 4 * lane);
+      else
+        win[q] = (mq >= 0 && mq < M) ? *reinterpret_cast<const f32x4*>(g + (size_t)mq * kD + 4 * lane)
+                                     : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const f32x4 gp = *reinterpret_cast<const f32x4*>(w.glu_pad + 4 * lane);
     const f32x4 bias = *reinterpret_cast<const f32x4*>(w.dw_b + 4 * lane);
@@ -592,7 +710,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
       const f32x4 wj = *reinterpret_cast<const f32x4*>(w.dw_w + j * kD + 4 * lane);
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
-        f32x4 v = (t_of[i] - LO + j >= 0) ? win[i + j] : gp;
+        f32x4 v = (STREAM || t_of[i] - LO + j >= 0) ? win[i + j] : gp;
         out[i] += wj * v;
       }
     }
@@ -633,15 +751,24 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);
 }
 constexpr size_t kLdsConvFfn = 4 * kRows * kLda * sizeof(float);
-void launch_conv_ffn(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int M, int Tp,
-                     int n_chunks, int ksize, hipStream_t st) {
+void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
+                     const int64_t* lens, int M, int Tp, int n_chunks, int ksize, hipStream_t st) {
   dim3 grid((M + kRows - 1) / kRows);
-  if (ksize == 15)
-    hipLaunchKernelGGL(k_conv_ffn<15>, grid, dim3(kThreads), kLdsConvFfn, st, g, x2, x_out, w, lens, M, Tp, n_chunks);
-  else if (ksize == 31)
-    hipLaunchKernelGGL(k_conv_ffn<31>, grid, dim3(kThreads), kLdsConvFfn, st, g, x2, x_out, w, lens, M, Tp, n_chunks);
-  else if (ksize == 7)
-    hipLaunchKernelGGL(k_conv_ffn<7>, grid, dim3(kThreads), kLdsConvFfn, st, g, x2, x_out, w, lens, M, Tp, n_chunks);
+#define LAUNCH_CF(KS)                                                                                               \
+  if (g_hist)                                                                                                       \
+    hipLaunchKernelGGL((k_conv_ffn<KS, true>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, M, \
+                       Tp, n_chunks);                                                                               \
+  else                                                                                                              \
+    hipLaunchKernelGGL((k_conv_ffn<KS, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, M, \
+                       Tp, n_chunks);
+  if (ksize == 15) {
+    LAUNCH_CF(15)
+  } else if (ksize == 31) {
+    LAUNCH_CF(31)
+  } else if (ksize == 7) {
+    LAUNCH_CF(7)
+  }
+#undef LAUNCH_CF
 }
 
 // -------------------------------------------------------------------------------------
@@ -880,9 +1007,13 @@ hipError_t configure_kernels() {
   SET_LDS(k_ffn_qkv, kLdsFfnQkv);
   SET_LDS(k_attention, kLdsAttn);
   SET_LDS(k_out_glu, kLdsOutGlu);
-  SET_LDS(k_conv_ffn<15>, kLdsConvFfn);
-  SET_LDS(k_conv_ffn<31>, kLdsConvFfn);
-  SET_LDS(k_conv_ffn<7>, kLdsConvFfn);
+  SET_LDS((k_conv_ffn<15, false>), kLdsConvFfn);
+  SET_LDS((k_conv_ffn<31, false>), kLdsConvFfn);
+  SET_LDS((k_conv_ffn<7, false>), kLdsConvFfn);
+  SET_LDS((k_conv_ffn<15, true>), kLdsConvFfn);
+  SET_LDS((k_conv_ffn<31, true>), kLdsConvFfn);
+  SET_LDS((k_conv_ffn<7, true>), kLdsConvFfn);
+  SET_LDS(k_pw1_glu, kLdsPw1Glu);
   SET_LDS(k_ctc_head<true>, kLdsCtc);
   SET_LDS(k_ctc_head<false>, kLdsCtc);
   SET_LDS((k_gemm_stream<4, 64, true, Conv2Src>), 2 * 128 * 68 * sizeof(float));

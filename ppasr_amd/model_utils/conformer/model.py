@@ -170,3 +170,105 @@ class ConformerModel:
         _lib.check(self.lib.ppasr_profile_read(self._h, ms, n))
         return {self.lib.ppasr_kernel_class_name(i).decode(): (float(ms[i]), int(n[i]))
                 for i in range(_lib.N_KERNEL_CLASSES)}
+
+    # ---- streaming -----------------------------------------------------------------
+    def new_stream(self):
+        """Device-resident streaming state (attention K/V cache, conv cache, offset) for one session."""
+        return ConformerStream(self)
+
+    def get_encoder_out_chunk(self, speech, offset, required_cache_size, att_cache=None, cnn_cache=None):
+        """Stateless signature of the reference (conformer/model.py:164-184):
+        (speech [1,t,F], offset, required_cache_size, att_cache [L,h,t1,2dk], cnn_cache [L,1,d,k-1])
+        -> (ctc_probs [1,c,V], new att_cache, new cnn_cache), device tensors in the reference layouts.
+        The caches are imported into / exported from a scratch stream object; sessions that keep the
+        state on the device should use ``new_stream()`` (what InferencePredictor does)."""
+        if getattr(self, "_scratch_stream", None) is None:
+            self._scratch_stream = self.new_stream()
+        s = self._scratch_stream
+        s.load_caches(att_cache, cnn_cache, int(offset))
+        probs = s.encode_chunk(speech, int(required_cache_size))
+        att, cnn = s.export_caches()
+        return probs, att, cnn
+
+
+class ConformerStream:
+    def __init__(self, model):
+        self.model = model
+        self.lib = model.lib
+        self._s = ctypes.c_void_p()
+        with torch.cuda.device(model.device):
+            _lib.check(self.lib.ppasr_stream_create(model._h, ctypes.byref(self._s)))
+        self._ws = None
+
+    def __del__(self):
+        s = getattr(self, "_s", None)
+        if s is not None and s.value:
+            self.lib.ppasr_stream_destroy(s)
+            self._s = None
+
+    @property
+    def offset(self):
+        return int(self.lib.ppasr_stream_offset(self._s))
+
+    @property
+    def cache_frames(self):
+        return int(self.lib.ppasr_stream_cache_frames(self._s))
+
+    def reset(self):
+        m = self.model
+        with torch.cuda.device(m.device):
+            _lib.check(self.lib.ppasr_stream_reset(self._s, torch.cuda.current_stream(m.device).cuda_stream))
+
+    def encode_chunk(self, speech, required_cache_size=-1, want_probs=True, want_frames=False):
+        """speech [1,t,F] -> ctc_probs [1,c,V] (device tensor); caches / offset advance on the device."""
+        m = self.model
+        x = torch.as_tensor(speech, dtype=torch.float32).to(m.device).contiguous()
+        assert x.dim() == 3 and x.shape[0] == 1 and x.shape[2] == m.input_dim  # encoder.py:238
+        T = int(x.shape[1])
+        c = m.out_frames(T)
+        need = int(self.lib.ppasr_chunk_workspace_bytes(m._h, T))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=m.device)
+        probs = torch.empty(1, max(c, 0), m.vocab_size, dtype=torch.float32, device=m.device) if want_probs else None
+        fa = torch.empty(1, max(c, 0), dtype=torch.int32, device=m.device) if want_frames else None
+        fp = torch.empty(1, max(c, 0), dtype=torch.float32, device=m.device) if want_frames else None
+        c_out = ctypes.c_int(0)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(m.device):
+            stream = torch.cuda.current_stream(m.device).cuda_stream
+            _lib.check(self.lib.ppasr_encode_chunk(self._s, x.data_ptr(), T, int(required_cache_size), ptr(probs),
+                                                   ptr(fa), ptr(fp), ctypes.byref(c_out), self._ws.data_ptr(),
+                                                   self._ws.numel(), stream))
+        if want_frames:
+            return probs, fa, fp
+        return probs
+
+    def export_caches(self):
+        """-> (att_cache [L,h,t,2dk], cnn_cache [L,1,d,k-1]) device tensors, reference layouts."""
+        m = self.model
+        t = self.cache_frames
+        att = torch.empty(m.num_blocks, m.attention_heads, t, 2 * (m.output_size // m.attention_heads),
+                          dtype=torch.float32, device=m.device)
+        cnn = torch.empty(m.num_blocks, 1, m.output_size, m.cnn_module_kernel - 1, dtype=torch.float32,
+                          device=m.device)
+        with torch.cuda.device(m.device):
+            stream = torch.cuda.current_stream(m.device).cuda_stream
+            _lib.check(self.lib.ppasr_stream_export_cache(self._s, att.data_ptr() if t > 0 else None, cnn.data_ptr(),
+                                                          stream))
+        return att, cnn
+
+    def load_caches(self, att_cache, cnn_cache, offset):
+        m = self.model
+        att = cnn = None
+        t = 0
+        if att_cache is not None and att_cache.numel() > 0:
+            att = torch.as_tensor(att_cache, dtype=torch.float32).to(m.device).contiguous()
+            t = int(att.shape[2])
+        if cnn_cache is not None and cnn_cache.numel() > 0:
+            cnn = torch.as_tensor(cnn_cache, dtype=torch.float32).to(m.device).contiguous()
+        with torch.cuda.device(m.device):
+            stream = torch.cuda.current_stream(m.device).cuda_stream
+            _lib.check(self.lib.ppasr_stream_import_cache(self._s, None if att is None else att.data_ptr(), t,
+                                                          None if cnn is None else cnn.data_ptr(), int(offset),
+                                                          stream))
+            torch.cuda.current_stream(m.device).synchronize()  # att / cnn temporaries must outlive the copy
