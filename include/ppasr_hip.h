@@ -95,6 +95,24 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
  * to `taps` in the order documented in DESIGN.md; pass NULL to clear. */
 ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats);
 
+/* Replaces the third-party `paddlespeech_ctcdecoders` entry points PPASR calls:
+ *   ctc_beam_search_decoding / ctc_beam_search_decoding_batch  (decoders/swig_wrapper.py:61-62,98-100,
+ *     from BeamSearchDecoder.decode_beam_search_offline / decode_batch_beam_search_offline,
+ *     decoders/beam_search_decoder.py:45-73), with init_state = 1;
+ *   CtcBeamSearchDecoderBatch.next() + decode() (swig_wrapper.py:106-121, beam_search_decoder.py:75-96):
+ *     call again with init_state = 0 and the SAME state buffer for every further chunk.
+ * CTC prefix beam search WITHOUT an external scorer (no KenLM file offline).
+ *   probs [B,T,V] f32, frame_lens [B] i32 or NULL; per utterance the `nbest` best prefixes:
+ *   tokens [B,nbest,max_tokens] i32 (-1 padded), lens [B,nbest] (-1 = no such hypothesis),
+ *   scores [B,nbest] f64 = -log P(prefix) (the upstream return convention).
+ *   state: device scratch of ppasr_ctc_beam_state_bytes(B, max total frames, beam_size) bytes that
+ *   holds the beam and the prefix arena (kept between chunk calls). */
+size_t ppasr_ctc_beam_state_bytes(int B, int max_frames, int beam_size);
+ppasr_status ppasr_ctc_beam_search(const float* probs, const int32_t* frame_lens, int B, int T, int V, int beam_size,
+                                   double cutoff_prob, int cutoff_top_n, int blank, int nbest, int max_tokens,
+                                   int32_t* tokens, int32_t* lens, double* scores, void* state, size_t state_bytes,
+                                   int init_state, void* stream);
+
 /* ---- streaming: ConformerModel.get_encoder_out_chunk (model_utils/conformer/model.py:164-184) =
  * ConformerEncoder.forward_chunk (conformer/encoder.py:208-283) + ctc softmax, as driven by
  * InferencePredictor.predict_chunk_conformer / reset_stream (inference_predictor.py:184-220) and

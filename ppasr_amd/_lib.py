@@ -47,6 +47,10 @@ SYMBOLS = [
     ("ppasr_encode", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp,
                                     ctypes.c_size_t, _vp]),
     ("ppasr_set_debug_taps", ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    ("ppasr_ctc_beam_state_bytes", ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    ("ppasr_ctc_beam_search", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             _vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_int, _vp]),
     ("ppasr_stream_create", ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     ("ppasr_stream_destroy", ctypes.c_int, [_vp]),
     ("ppasr_stream_reset", ctypes.c_int, [_vp, _vp]),

@@ -12,6 +12,7 @@
 
 #include "../../include/ppasr_hip.h"
 #include "conformer_kernels.h"
+#include "ctc_beam.h"
 
 using namespace ppasr;
 
@@ -595,6 +596,59 @@ ppasr_status ppasr_stream_import_cache(ppasr_stream s, const float* att_cache, i
   s->cache_t = cache_t;
   s->offset = offset;
   HIP_TRY(hipGetLastError());
+  return PPASR_OK;
+}
+
+
+// =====================================================================================
+// CTC prefix beam search (see ctc_beam.hip)
+// =====================================================================================
+static ppasr_status beam_config(int V, int beam_size, double cutoff_prob, int cutoff_top_n, int blank, int nbest,
+                                int max_tokens, BeamConfig* c) {
+  if (V <= 1 || V >= 16384) return fail(PPASR_EUNSUPPORTED, "beam search: vocabulary must be in (1, 16384)");
+  if (beam_size < 1 || beam_size > kMaxBeam) return fail(PPASR_EUNSUPPORTED, "beam search: beam_size must be in [1, 512]");
+  if (blank < 0 || blank >= V) return fail(PPASR_EINVAL, "beam search: blank id out of range");
+  if (nbest < 1 || nbest > beam_size || max_tokens < 1) return fail(PPASR_EINVAL, "beam search: bad nbest / max_tokens");
+  if (cutoff_top_n < 1) return fail(PPASR_EINVAL, "beam search: cutoff_top_n < 1");
+  // candidates per frame: pruned to cutoff_top_n only when cutoff_prob < 1 (upstream get_pruned_log_probs)
+  const int n_cand = (cutoff_prob < 1.0) ? (cutoff_top_n < V ? cutoff_top_n : V) : V;
+  if (n_cand > kMaxBeamCand)
+    return fail(PPASR_EUNSUPPORTED, "beam search: more than 128 characters per frame survive pruning "
+                                    "(cutoff_prob >= 1 disables cutoff_top_n upstream); lower cutoff_prob / cutoff_top_n");
+  c->V = V; c->beam = beam_size; c->blank = blank; c->cutoff_top_n = cutoff_top_n; c->cutoff_prob = cutoff_prob;
+  c->n_cand_max = n_cand; c->nbest = nbest; c->max_tokens = max_tokens; c->max_nodes = 0;
+  if (beam_lds_bytes(*c) > 160 * 1024) return fail(PPASR_EUNSUPPORTED, "beam search: beam x candidates does not fit LDS");
+  return PPASR_OK;
+}
+
+size_t ppasr_ctc_beam_state_bytes(int B, int max_frames, int beam_size) {
+  if (B <= 0 || max_frames < 0 || beam_size < 1) return 0;
+  BeamConfig c{};
+  c.beam = beam_size;
+  c.max_nodes = 1 + (max_frames + 1) * beam_size;
+  return (size_t)B * beam_state_bytes(c) + (size_t)B * sizeof(int32_t);
+}
+
+ppasr_status ppasr_ctc_beam_search(const float* probs, const int32_t* frame_lens, int B, int T, int V, int beam_size,
+                                   double cutoff_prob, int cutoff_top_n, int blank, int nbest, int max_tokens,
+                                   int32_t* tokens, int32_t* lens, double* scores, void* state, size_t state_bytes,
+                                   int init_state, void* stream) {
+  if (!tokens || !lens || !scores || !state || (!probs && T > 0)) return fail(PPASR_EINVAL, "null argument");
+  if (B <= 0 || T < 0) return fail(PPASR_EINVAL, "empty batch");
+  BeamConfig c{};
+  ppasr_status s = beam_config(V, beam_size, cutoff_prob, cutoff_top_n, blank, nbest, max_tokens, &c);
+  if (s != PPASR_OK) return s;
+  // state = B x [header | beam arrays | arena] + B status words; arena capacity from the buffer size
+  const size_t per_utt = (state_bytes - (size_t)B * 4) / (size_t)B / 4;  // words
+  const size_t fixed = 2 + (size_t)6 * beam_size;
+  if (state_bytes < (size_t)B * 4 || per_utt < fixed + 2 * (size_t)(1 + 2 * beam_size))
+    return fail(PPASR_ENOSPACE, "beam search: state buffer too small");
+  c.max_nodes = (int)((per_utt - fixed) / 2);
+  int32_t* st_words = static_cast<int32_t*>(state);
+  int32_t* status = st_words + (size_t)B * (fixed + 2 * (size_t)c.max_nodes);
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  if (init_state) HIP_TRY(hipMemsetAsync(status, 0, (size_t)B * 4, hs));
+  HIP_TRY(launch_ctc_beam(probs, frame_lens, B, T, c, st_words, init_state, 1, tokens, lens, scores, status, hs));
   return PPASR_OK;
 }
 

@@ -1,0 +1,26 @@
+// ctc_beam.h -- launch interface of the CTC prefix beam search kernel (ctc_beam.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ppasr {
+
+constexpr int kMaxBeamCand = 128;  // pruned characters per frame the kernel can hold
+constexpr int kMaxBeam = 512;
+
+struct BeamConfig {
+  int V, beam, blank;
+  int cutoff_top_n;
+  double cutoff_prob;
+  int n_cand_max;  // min(kMaxBeamCand, what the pruning rule can produce)
+  int max_nodes;   // arena capacity per utterance
+  int nbest, max_tokens;
+};
+
+size_t beam_lds_bytes(const BeamConfig& c);
+size_t beam_state_bytes(const BeamConfig& c);  // per utterance
+hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B, int T, const BeamConfig& cfg,
+                           int32_t* state, int init_state, int finalize, int32_t* out_tokens, int32_t* out_lens,
+                           double* out_scores, int32_t* status, hipStream_t st);
+
+}  // namespace ppasr

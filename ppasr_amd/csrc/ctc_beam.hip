@@ -1,0 +1,395 @@
+// ctc_beam.hip -- CTC prefix beam search on the GPU: one workgroup per utterance, beam hypotheses,
+// the pruned character list and the frame's log-probabilities resident in LDS.
+//
+// Replaces the third-party C++/SWIG module `paddlespeech_ctcdecoders` that PPASR calls from
+// ppasr/decoders/swig_wrapper.py:61-62 (ctc_beam_search_decoding), :98-100 (..._batch) and
+// :119-121 (CtcBeamSearchDecoderBatch, streaming), via decoders/beam_search_decoder.py:45-96.
+// Algorithm = PaddleSpeech third_party/ctc_decoders (prefix trie, float log-probs, per-frame
+// vocabulary pruning by cutoff_prob / cutoff_top_n, top-beam_size selection with prefix_compare:
+// score desc, then last character asc), restated on flat arrays:
+//   * a hypothesis = (node id, last char, parent node id, log P_blank, log P_nonblank, score); the
+//     prefix strings live in a parent-pointer arena in HBM and are only walked at the end;
+//   * "does child (prefix, c) already exist in the beam" (the trie lookup) = a flag table built from
+//     each hypothesis' parent slot; every hypothesis receives at most two non-blank contributions
+//     (its own repeated character, the extension from its parent), so no floating-point atomics
+//     and the same log_sum_exp values as the serial trie walk;
+//   * top-k = exact MSD radix select on unique 64-bit keys (score | char | element id) recomputed on
+//     the fly, then an ordered compaction -- nothing of size beam x candidates is ever stored.
+// No external scorer (KenLM): the LM branch of the reference needs a 2.8 GB model file that is
+// unreachable offline.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "ctc_beam.h"
+
+namespace ppasr {
+
+namespace {
+
+constexpr int kBT = 256;  // threads per utterance
+constexpr float kNegInf = -FLT_MAX;  // NUM_FLT_INF of decoder_utils.h
+constexpr float kNotCand = FLT_MAX;  // marker in lp[]: character not in the pruned list
+
+__device__ __forceinline__ float lse(float x, float y) {  // log_sum_exp (decoder_utils.h)
+  if (x <= kNegInf) return y;
+  if (y <= kNegInf) return x;
+  float m = fmaxf(x, y);
+  return logf(expf(x - m) + expf(y - m)) + m;
+}
+
+// ascending-sortable image of a float, inverted so that LARGER scores sort FIRST
+__device__ __forceinline__ uint32_t desc_key(float s) {
+  uint32_t u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ~u;
+}
+// unique total-order key: score desc | (char+1) asc | element id asc
+__device__ __forceinline__ uint64_t make_key(float score, int ch, int id) {
+  return ((uint64_t)desc_key(score) << 32) | ((uint64_t)(uint32_t)(ch + 1) << 18) | (uint64_t)(uint32_t)id;
+}
+
+struct Beam {  // one double-buffer half, all in LDS
+  int* node;
+  int* chr;
+  int* par;
+  float* b;
+  float* nb;
+  float* score;
+};
+
+__device__ __forceinline__ Beam carve_beam(char*& p, int cap) {
+  Beam b;
+  b.node = reinterpret_cast<int*>(p); p += cap * 4;
+  b.chr = reinterpret_cast<int*>(p); p += cap * 4;
+  b.par = reinterpret_cast<int*>(p); p += cap * 4;
+  b.b = reinterpret_cast<float*>(p); p += cap * 4;
+  b.nb = reinterpret_cast<float*>(p); p += cap * 4;
+  b.score = reinterpret_cast<float*>(p); p += cap * 4;
+  return b;
+}
+
+// block-wide exclusive scan of one int per thread (256 threads = 4 waves); returns (exclusive, total)
+__device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /*[4] LDS*/, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    int t = wave_tot[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  total = tot;
+  return base + incl - v;
+}
+
+}  // namespace
+
+size_t beam_lds_bytes(const BeamConfig& c) {
+  const int Vp = (c.V + 3) & ~3;
+  size_t n = 16 + 256 * 4 + 16 + 16 + 16 + 32;  // scalars, histogram, reduction scratch
+  n += (size_t)Vp * 4;                             // lp
+  n += (size_t)kMaxBeamCand * 8;                   // cand_c, cand_lp
+  n += (size_t)2 * c.beam * 24;                    // two beam halves
+  n += (size_t)c.beam * 12;                        // new_b, new_nb, new_score
+  n += (size_t)Vp * 2;                             // kidx (int16)
+  n += (size_t)c.beam * c.n_cand_max;              // exists flags
+  return (n + 15) & ~(size_t)15;
+}
+
+// state layout per utterance in HBM (int32 words):
+//   [0] n_beam  [1] n_nodes  then 6 arrays of `beam` words (node, chr, par, b, nb, score), then the arena
+//   (2 words per node: parent, char).
+__host__ __device__ inline size_t beam_state_words(int beam, int max_nodes) { return 2 + (size_t)6 * beam + (size_t)2 * max_nodes; }
+size_t beam_state_bytes(const BeamConfig& c) { return beam_state_words(c.beam, c.max_nodes) * 4; }
+
+__global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ probs, const int32_t* __restrict__ frame_lens,
+                                                  int T, BeamConfig cfg, int32_t* __restrict__ state, int init_state,
+                                                  int finalize, int32_t* __restrict__ out_tokens,
+                                                  int32_t* __restrict__ out_lens, double* __restrict__ out_scores,
+                                                  int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u = blockIdx.x;
+  const int V = cfg.V, beam = cfg.beam, blank = cfg.blank, CM = cfg.n_cand_max;
+  const int Vp = (V + 3) & ~3;
+  char* p = smem;
+  double* sh_d = reinterpret_cast<double*>(p); p += 16;      // cumulative probability
+  int* hist = reinterpret_cast<int*>(p); p += 256 * 4;
+  int* wave_tot = reinterpret_cast<int*>(p); p += 16;
+  float* red_p = reinterpret_cast<float*>(p); p += 16;
+  int* red_i = reinterpret_cast<int*>(p); p += 16;
+  int* sh_i = reinterpret_cast<int*>(p); p += 32;            // misc shared ints
+  float* lp = reinterpret_cast<float*>(p); p += (size_t)Vp * 4;
+  int* cand_c = reinterpret_cast<int*>(p); p += kMaxBeamCand * 4;
+  float* cand_lp = reinterpret_cast<float*>(p); p += kMaxBeamCand * 4;
+  Beam cur = carve_beam(p, beam);
+  Beam nxt = carve_beam(p, beam);
+  float* new_b = reinterpret_cast<float*>(p); p += beam * 4;
+  float* new_nb = reinterpret_cast<float*>(p); p += beam * 4;
+  float* new_score = reinterpret_cast<float*>(p); p += beam * 4;
+  int16_t* kidx = reinterpret_cast<int16_t*>(p); p += (size_t)Vp * 2;
+  uint8_t* exists = reinterpret_cast<uint8_t*>(p);
+
+  int32_t* st = state + (size_t)u * beam_state_words(beam, cfg.max_nodes);
+  int32_t* g_arr = st + 2;
+  int32_t* arena = st + 2 + (size_t)6 * beam;
+  int nb, n_nodes;
+  if (init_state) {
+    nb = 1;
+    n_nodes = 1;
+    if (tid == 0) {
+      cur.node[0] = 0; cur.chr[0] = -1; cur.par[0] = -1;
+      cur.b[0] = 0.f; cur.nb[0] = kNegInf; cur.score[0] = 0.f;  // root.score = root.log_prob_b_prev = 0
+      arena[0] = -1; arena[1] = -1;
+    }
+  } else {
+    nb = st[0];
+    n_nodes = st[1];
+    for (int i = tid; i < nb; i += kBT) {
+      cur.node[i] = g_arr[i]; cur.chr[i] = g_arr[beam + i]; cur.par[i] = g_arr[2 * beam + i];
+      cur.b[i] = __int_as_float(g_arr[3 * beam + i]); cur.nb[i] = __int_as_float(g_arr[4 * beam + i]);
+      cur.score[i] = __int_as_float(g_arr[5 * beam + i]);
+    }
+  }
+  __syncthreads();
+
+  const int n_frames = frame_lens ? min(max(frame_lens[u], 0), T) : T;
+  const bool prune = (cfg.cutoff_prob < 1.0) || (cfg.cutoff_top_n < V);
+  for (int t = 0; t < n_frames; ++t) {
+    const float* row = probs + ((size_t)u * T + t) * V;
+    for (int v = tid; v < V; v += kBT) lp[v] = row[v];
+    __syncthreads();
+    // ---- (b) get_pruned_log_probs: successive maxima in (prob desc, index asc) order ----
+    int C = 0;
+    if (prune) {
+      float last_p = INFINITY;
+      int last_i = -1;
+      if (tid == 0) sh_d[0] = 0.0;
+      for (;;) {
+        float bp = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int v = tid; v < V; v += kBT) {
+          float pv = lp[v];
+          bool after = (pv < last_p) || (pv == last_p && v > last_i);
+          if (after && (pv > bp || (pv == bp && v < bi))) { bp = pv; bi = v; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          float p2 = __shfl_xor(bp, o);
+          int i2 = __shfl_xor(bi, o);
+          if (p2 > bp || (p2 == bp && i2 < bi)) { bp = p2; bi = i2; }
+        }
+        if (lane == 0) { red_p[wave] = bp; red_i[wave] = bi; }
+        __syncthreads();
+        bp = red_p[0]; bi = red_i[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+          float p2 = red_p[w]; int i2 = red_i[w];
+          if (p2 > bp || (p2 == bp && i2 < bi)) { bp = p2; bi = i2; }
+        }
+        bool stop;
+        if (bi == 0x7fffffff) {
+          stop = true;  // vocabulary exhausted
+        } else {
+          if (tid == 0) {
+            cand_c[C] = bi;
+            cand_lp[C] = (float)log((double)bp + (double)FLT_MIN);
+            sh_d[0] += (double)bp;
+          }
+          C += 1;
+          last_p = bp; last_i = bi;
+          __syncthreads();
+          if (cfg.cutoff_prob < 1.0) stop = (sh_d[0] >= cfg.cutoff_prob) || (C >= cfg.cutoff_top_n);
+          else stop = (C >= V);  // upstream sorts but does not truncate when cutoff_prob >= 1
+        }
+        __syncthreads();
+        if (stop || C >= CM) break;
+      }
+    } else {
+      C = V;  // no pruning: vocabulary order (host guarantees V <= n_cand_max)
+      for (int v = tid; v < V; v += kBT) { cand_c[v] = v; cand_lp[v] = (float)log((double)lp[v] + (double)FLT_MIN); }
+      __syncthreads();
+    }
+    // ---- (c) lp[] <- log-prob of candidates / marker; kidx[] <- candidate index ----
+    for (int v = tid; v < V; v += kBT) { lp[v] = kNotCand; kidx[v] = -1; }
+    for (int e = tid; e < nb * C; e += kBT) exists[e] = 0;
+    __syncthreads();
+    for (int k = tid; k < C; k += kBT) { lp[cand_c[k]] = cand_lp[k]; kidx[cand_c[k]] = (int16_t)k; }
+    __syncthreads();
+    // ---- (d) contributions received by the hypotheses already in the beam ----
+    const float lpb = lp[blank];
+    for (int q = tid; q < nb; q += kBT) {
+      const int cq = cur.chr[q];
+      float bc = (lpb != kNotCand) ? lpb + cur.score[q] : kNegInf;
+      float nbc = kNegInf;
+      const float lq = (cq >= 0) ? lp[cq] : kNotCand;
+      if (lq != kNotCand && cq != blank) {
+        nbc = lq + cur.nb[q];  // repeated character
+        const int pn = cur.par[q];
+        int pi = -1;
+        for (int i = 0; i < nb; ++i)
+          if (cur.node[i] == pn) pi = i;
+        if (pi >= 0) {  // extension of the parent hypothesis by cq lands on this existing prefix
+          float log_p = kNegInf;
+          if (cq == cur.chr[pi]) { if (cur.b[pi] > kNegInf) log_p = lq + cur.b[pi]; }
+          else log_p = lq + cur.score[pi];
+          nbc = lse(nbc, log_p);
+          exists[pi * C + kidx[cq]] = 1;
+        }
+      }
+      new_b[q] = bc;
+      new_nb[q] = nbc;
+      new_score[q] = lse(bc, nbc);
+    }
+    __syncthreads();
+    // ---- (e) element space: [0,nb) existing hypotheses, nb + i*C + k = child (i, cand k) ----
+    const int N = nb + nb * C;
+    auto elem_key = [&](int e, uint64_t& key) -> bool {
+      if (e < nb) { key = make_key(new_score[e], cur.chr[e], e); return true; }
+      const int r = e - nb, i = r / C, k = r - i * C;
+      const int c = cand_c[k];
+      if (c == blank || exists[r]) return false;
+      float log_p = kNegInf;
+      if (c == cur.chr[i]) { if (cur.b[i] > kNegInf) log_p = cand_lp[k] + cur.b[i]; }
+      else log_p = cand_lp[k] + cur.score[i];
+      key = make_key(log_p, c, e);
+      return true;
+    };
+    int my_valid = 0;
+    for (int e = tid; e < N; e += kBT) { uint64_t k; my_valid += elem_key(e, k) ? 1 : 0; }
+    int n_valid;
+    (void)block_excl_scan(my_valid, wave_tot, n_valid);
+    const int k_sel = n_valid >= beam ? beam : n_valid;
+    // ---- (f) exact k_sel-th smallest key by MSD radix select (keys are unique) ----
+    uint64_t thr = ~0ull;
+    if (k_sel < n_valid) {
+      uint64_t prefix = 0;
+      int k_rem = k_sel;  // 1-based rank searched inside the current prefix class
+      for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        const uint64_t hi_mask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+        hist[tid] = 0;
+        __syncthreads();
+        for (int e = tid; e < N; e += kBT) {
+          uint64_t k;
+          if (elem_key(e, k) && (k & hi_mask) == prefix) atomicAdd(&hist[(int)((k >> shift) & 0xff)], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          int acc = 0, bsel = 255;
+          for (int bkt = 0; bkt < 256; ++bkt) {
+            if (acc + hist[bkt] >= k_rem) { bsel = bkt; break; }
+            acc += hist[bkt];
+          }
+          sh_i[0] = bsel;
+          sh_i[1] = k_rem - acc;
+        }
+        __syncthreads();
+        prefix |= (uint64_t)sh_i[0] << shift;
+        k_rem = sh_i[1];
+        __syncthreads();
+      }
+      thr = prefix;
+    }
+    // ---- (g) ordered compaction of the survivors into the next beam ----
+    int filled = 0;
+    for (int base = 0; base < N; base += kBT) {
+      const int e = base + tid;
+      uint64_t k = 0;
+      const bool keep = (e < N) && elem_key(e, k) && k <= thr;
+      int tot;
+      const int pos = filled + block_excl_scan(keep ? 1 : 0, wave_tot, tot);
+      if (keep && pos < beam) {
+        if (e < nb) {
+          nxt.node[pos] = cur.node[e]; nxt.chr[pos] = cur.chr[e]; nxt.par[pos] = cur.par[e];
+          nxt.b[pos] = new_b[e]; nxt.nb[pos] = new_nb[e]; nxt.score[pos] = new_score[e];
+        } else {
+          const int r = e - nb, i = r / C, kk = r - i * C;
+          const int c = cand_c[kk];
+          float log_p = kNegInf;
+          if (c == cur.chr[i]) { if (cur.b[i] > kNegInf) log_p = cand_lp[kk] + cur.b[i]; }
+          else log_p = cand_lp[kk] + cur.score[i];
+          const int id = n_nodes + pos;
+          if (id < cfg.max_nodes) { arena[2 * (size_t)id] = cur.node[i]; arena[2 * (size_t)id + 1] = c; }
+          nxt.node[pos] = id; nxt.chr[pos] = c; nxt.par[pos] = cur.node[i];
+          nxt.b[pos] = kNegInf; nxt.nb[pos] = log_p; nxt.score[pos] = log_p;
+        }
+      }
+      filled += tot;
+    }
+    __syncthreads();
+    n_nodes += k_sel;
+    nb = k_sel;
+    if (n_nodes + beam > cfg.max_nodes) {  // arena exhausted: report, stop consuming frames
+      if (tid == 0 && status) status[u] = 1;
+      Beam tmp = cur; cur = nxt; nxt = tmp;
+      break;
+    }
+    Beam tmp = cur; cur = nxt; nxt = tmp;
+  }
+  __syncthreads();
+  // ---- persist the state (streaming: CtcBeamSearchDecoderBatch keeps its trie between next() calls) ----
+  if (tid == 0) { st[0] = nb; st[1] = n_nodes; }
+  for (int i = tid; i < nb; i += kBT) {
+    g_arr[i] = cur.node[i]; g_arr[beam + i] = cur.chr[i]; g_arr[2 * beam + i] = cur.par[i];
+    g_arr[3 * beam + i] = __float_as_int(cur.b[i]); g_arr[4 * beam + i] = __float_as_int(cur.nb[i]);
+    g_arr[5 * beam + i] = __float_as_int(cur.score[i]);
+  }
+  if (!finalize) return;
+  __threadfence_block();
+  __syncthreads();
+  // ---- get_beam_search_result: rank the beam by prefix_compare, emit the n-best paths ----
+  // rank of slot q = number of slots that sort before it (beam <= a few hundred: O(beam^2 / 256))
+  for (int q = tid; q < nb; q += kBT) {
+    const uint64_t kq = make_key(cur.score[q], cur.chr[q], q);
+    int rank = 0;
+    for (int i = 0; i < nb; ++i) rank += (make_key(cur.score[i], cur.chr[i], i) < kq) ? 1 : 0;
+    if (rank < cfg.nbest) {
+      int len = 0;
+      for (int n = cur.node[q]; n > 0; n = arena[2 * (size_t)n]) ++len;
+      int32_t* dst = out_tokens + ((size_t)u * cfg.nbest + rank) * cfg.max_tokens;
+      for (int j = 0; j < cfg.max_tokens; ++j) dst[j] = -1;
+      int j = len;
+      for (int n = cur.node[q]; n > 0; n = arena[2 * (size_t)n]) {
+        --j;
+        if (j < cfg.max_tokens) dst[j] = arena[2 * (size_t)n + 1];
+      }
+      out_lens[(size_t)u * cfg.nbest + rank] = len;
+      out_scores[(size_t)u * cfg.nbest + rank] = -(double)cur.score[q];
+    }
+  }
+  // ranks >= nb (beam smaller than nbest): mark empty
+  for (int r = nb + tid; r < cfg.nbest; r += kBT) {
+    out_lens[(size_t)u * cfg.nbest + r] = -1;
+    out_scores[(size_t)u * cfg.nbest + r] = 0.0;
+  }
+}
+
+hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B, int T, const BeamConfig& cfg,
+                           int32_t* state, int init_state, int finalize, int32_t* out_tokens, int32_t* out_lens,
+                           double* out_scores, int32_t* status, hipStream_t st) {
+  const size_t lds = beam_lds_bytes(cfg);
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_beam),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    configured = lds;
+  }
+  hipLaunchKernelGGL(k_ctc_beam, dim3(B), dim3(kBT), lds, st, probs, frame_lens, T, cfg, state, init_state, finalize,
+                     out_tokens, out_lens, out_scores, status);
+  return hipGetLastError();
+}
+
+}  // namespace ppasr

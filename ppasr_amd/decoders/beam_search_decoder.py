@@ -1,0 +1,154 @@
+"""Drop-in for ``ppasr/decoders/beam_search_decoder.py`` (``BeamSearchDecoder``) and the
+``paddlespeech_ctcdecoders`` wrappers of ``ppasr/decoders/swig_wrapper.py``, backed by the HIP prefix
+beam search (``ppasr_ctc_beam_search`` in include/ppasr_hip.h).
+
+Deviation (documented in DESIGN.md): no external scorer.  The reference always builds a KenLM
+``Scorer`` (beam_search_decoder.py:28-29) from a 2.8 GB model that is unreachable offline; here
+``alpha`` / ``beta`` / ``language_model_path`` are accepted and ignored (a warning is printed once when a
+language model path is given).  Returned scores follow the upstream convention: -log P(prefix).
+"""
+import warnings
+
+import numpy as np
+import torch
+
+from ppasr_amd import _lib
+
+__all__ = ["BeamSearchDecoder", "ctc_beam_search_decoding", "ctc_beam_search_decoding_batch", "beam_search_ids"]
+
+
+def _text(ids, vocabulary):
+    return "".join(vocabulary[i] for i in ids)
+
+
+class _BeamState:
+    """Device buffer holding the beam + prefix arena of a batch of utterances (kept across chunks)."""
+
+    def __init__(self, B, max_frames, beam_size, device):
+        lib = _lib.load()
+        self.bytes = int(lib.ppasr_ctc_beam_state_bytes(B, max_frames, beam_size))
+        self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device)
+        self.B, self.max_frames, self.beam_size = B, max_frames, beam_size
+        self.frames = 0
+        self.fresh = True
+
+
+def beam_search_ids(probs, beam_size, cutoff_prob=1.0, cutoff_top_n=40, blank_id=0, frame_lens=None, nbest=1,
+                    state=None, max_frames=None):
+    """probs [B,T,V] (numpy or device tensor) -> (tokens [B,nbest,L] i32, lens [B,nbest] i32, scores [B,nbest] f64)
+    device tensors.  ``state`` (a _BeamState) continues a previous call (streaming)."""
+    lib = _lib.load()
+    if not torch.cuda.is_available():
+        raise _lib.PPASRHipError("no HIP device visible: ppasr_amd has no CPU fallback")
+    dev = probs.device if isinstance(probs, torch.Tensor) and probs.is_cuda else torch.device(
+        "cuda", torch.cuda.current_device())
+    p = torch.as_tensor(probs, dtype=torch.float32).to(dev).contiguous()
+    B, T, V = p.shape
+    if state is None:
+        state = _BeamState(B, max_frames if max_frames is not None else T, beam_size, dev)
+    if state.frames + T > state.max_frames:
+        raise _lib.PPASRHipError("beam-search state buffer exhausted: create the decoder with a larger max_frames")
+    L = max(state.frames + T, 1)
+    tokens = torch.empty(B, nbest, L, dtype=torch.int32, device=dev)
+    lens = torch.empty(B, nbest, dtype=torch.int32, device=dev)
+    scores = torch.empty(B, nbest, dtype=torch.float64, device=dev)
+    fl = None if frame_lens is None else torch.as_tensor(frame_lens, dtype=torch.int32).to(dev).contiguous()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.ppasr_ctc_beam_search(p.data_ptr() if T > 0 else None, None if fl is None else fl.data_ptr(), B,
+                                             T, V, int(beam_size), float(cutoff_prob), int(cutoff_top_n),
+                                             int(blank_id), int(nbest), L, tokens.data_ptr(), lens.data_ptr(),
+                                             scores.data_ptr(), state.buf.data_ptr(), state.bytes,
+                                             1 if state.fresh else 0, stream))
+    state.fresh = False
+    state.frames += T
+    return tokens, lens, scores, state
+
+
+def _results(tokens, lens, scores, vocabulary, b):
+    tk, ln, sc = tokens[b].cpu().numpy(), lens[b].cpu().numpy(), scores[b].cpu().numpy()
+    out = []
+    for r in range(tk.shape[0]):
+        if ln[r] < 0:
+            continue
+        out.append((float(sc[r]), _text(tk[r, :ln[r]].tolist(), vocabulary)))
+    return out
+
+
+def ctc_beam_search_decoding(probs_seq, vocabulary, beam_size, cutoff_prob=1.0, cutoff_top_n=40, blank_id=0,
+                             ext_scoring_func=None):
+    """swig_wrapper.py:35-64 -> list of (score, text), best first (all ``beam_size`` hypotheses)."""
+    p = probs_seq if isinstance(probs_seq, torch.Tensor) else np.asarray(probs_seq, np.float32)
+    tokens, lens, scores, _ = beam_search_ids(torch.as_tensor(p)[None], beam_size, cutoff_prob, cutoff_top_n, blank_id,
+                                              nbest=beam_size)
+    return _results(tokens, lens, scores, vocabulary, 0)
+
+
+def ctc_beam_search_decoding_batch(probs_split, vocabulary, beam_size, num_processes=1, cutoff_prob=1.0,
+                                   cutoff_top_n=40, blank_id=0, ext_scoring_func=None):
+    """swig_wrapper.py:67-103 -> per utterance a list of (score, text).  ``num_processes`` (CPU threads in
+    the reference) is meaningless here: one workgroup per utterance."""
+    if isinstance(probs_split, torch.Tensor) and probs_split.dim() == 3:
+        tokens, lens, scores, _ = beam_search_ids(probs_split, beam_size, cutoff_prob, cutoff_top_n, blank_id,
+                                                  nbest=beam_size)
+        return [_results(tokens, lens, scores, vocabulary, b) for b in range(probs_split.shape[0])]
+    shapes = {tuple(np.shape(p)) for p in probs_split}
+    if len(shapes) == 1:  # equal lengths: one launch
+        batch = torch.stack([torch.as_tensor(p, dtype=torch.float32) for p in probs_split])
+        return ctc_beam_search_decoding_batch(batch.cuda(), vocabulary, beam_size, num_processes, cutoff_prob,
+                                              cutoff_top_n, blank_id)
+    return [ctc_beam_search_decoding(p, vocabulary, beam_size, cutoff_prob, cutoff_top_n, blank_id)
+            for p in probs_split]
+
+
+class BeamSearchDecoder:
+    """beam_search_decoder.py:8-96 (same constructor arguments / methods)."""
+
+    _warned = False
+
+    def __init__(self, alpha, beta, beam_size, cutoff_prob, cutoff_top_n, vocab_list, num_processes=10, blank_id=0,
+                 language_model_path=None, max_stream_frames=5000):
+        self.alpha, self.beta = alpha, beta
+        self.beam_size = int(beam_size)
+        self.cutoff_prob, self.cutoff_top_n = cutoff_prob, cutoff_top_n
+        self.vocab_list = vocab_list
+        self.num_processes = num_processes
+        self.blank_id = blank_id
+        self._ext_scorer = None
+        if language_model_path and not BeamSearchDecoder._warned:
+            warnings.warn("ppasr_amd BeamSearchDecoder runs WITHOUT the KenLM scorer (alpha/beta ignored): "
+                          "the language-model branch is not built (DESIGN.md §7)")
+            BeamSearchDecoder._warned = True
+        self._max_stream_frames = int(max_stream_frames)
+        self._state = None
+
+    def decode_beam_search_offline(self, probs_split):
+        """-> (score, text) of the best hypothesis.  beam_search_decoder.py:45-56"""
+        p = probs_split if isinstance(probs_split, torch.Tensor) else np.asarray(probs_split, np.float32)
+        tokens, lens, scores, _ = beam_search_ids(torch.as_tensor(p)[None], self.beam_size, self.cutoff_prob,
+                                                  self.cutoff_top_n, self.blank_id, nbest=1)
+        return _results(tokens, lens, scores, self.vocab_list, 0)[0]
+
+    def decode_batch_beam_search_offline(self, probs_split):
+        """-> list[str].  beam_search_decoder.py:59-73 (every row of every table is decoded)."""
+        res = ctc_beam_search_decoding_batch(probs_split, self.vocab_list, self.beam_size, self.num_processes,
+                                             self.cutoff_prob, self.cutoff_top_n, self.blank_id)
+        return [r[0][1] for r in res]
+
+    def decode_chunk(self, probs, logits_lens):
+        """Streaming: feed one chunk [B=1,c,V], return the current best (score, text).
+        beam_search_decoder.py:75-91"""
+        p = torch.as_tensor(probs, dtype=torch.float32)
+        if p.dim() == 2:
+            p = p[None]
+        if self._state is None:
+            dev = p.device if p.is_cuda else torch.device("cuda", torch.cuda.current_device())
+            self._state = _BeamState(p.shape[0], self._max_stream_frames, self.beam_size, dev)
+        lens = np.asarray(logits_lens).astype(np.int32)
+        tokens, ln, scores, _ = beam_search_ids(p, self.beam_size, self.cutoff_prob, self.cutoff_top_n, self.blank_id,
+                                                frame_lens=lens, nbest=1, state=self._state)
+        return _results(tokens, ln, scores, self.vocab_list, 0)[0]
+
+    def reset_decoder(self):
+        """beam_search_decoder.py:93-96"""
+        self._state = None

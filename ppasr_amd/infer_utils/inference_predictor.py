@@ -1,0 +1,103 @@
+"""Drop-in for ``ppasr/infer_utils/inference_predictor.py`` (``InferencePredictor``): same constructor
+arguments, methods and attributes; the paddle.inference handles (named inputs ``speech``,
+``speech_lengths``, ``offset``, ``required_cache_size``, ``att_cache``, ``cnn_cache``, :80-97) are
+replaced by the HIP library, and the streaming caches stay on the device (``att_cache`` / ``cnn_cache``
+/ ``offset`` are materialised in the reference layouts only when read).
+
+numpy in, numpy out, like the reference (:103-145, :184-212).  ``predict_device`` /
+``predict_greedy`` are the zero-copy entry points.
+"""
+import os
+
+import numpy as np
+import torch
+
+from ppasr_amd.model_utils.conformer.model import ConformerModel
+from ppasr_amd.utils.checkpoint import find_state_dict, load_state_dict
+
+__all__ = ["InferencePredictor"]
+
+
+def _get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+class InferencePredictor:
+    def __init__(self, configs, use_model, streaming=True, model_dir="models/conformer_streaming_fbank/infer/",
+                 use_gpu=True, use_tensorrt=False, gpu_mem=1000, num_threads=10, state_dict=None, vocab_size=None,
+                 device="cuda:0"):
+        if not use_gpu:
+            raise Exception("ppasr_amd has no CPU path (use_gpu=False is not supported)")
+        self.configs = configs
+        self.use_model = use_model
+        self.streaming = streaming
+        if use_model != "conformer":
+            raise NotImplementedError(f"use_model={use_model!r}: built in this round: 'conformer' (see DESIGN.md §7)")
+        if state_dict is None:
+            if not os.path.exists(model_dir):
+                raise Exception("模型文件不存在，请检查%s是否存在！" % model_dir)
+            state_dict = load_state_dict(find_state_dict(model_dir))
+        enc = _get(configs, "encoder_conf", {})
+        enc = dict(enc) if isinstance(enc, dict) else dict(vars(enc))
+        pre = _get(configs, "preprocess_conf", {})
+        input_dim = int(_get(pre, "n_mels", 80))
+        if vocab_size is None:
+            vocab_size = int(state_dict["ctc.ctc_lo.bias"].shape[0])
+        self.model = ConformerModel(input_dim, vocab_size, streaming=streaming, encoder_conf=enc,
+                                    state_dict=state_dict, device=device)
+        self._stream = self.model.new_stream() if streaming else None
+        self.output_state_h = None
+        self.output_state_c = None
+
+    # ---- reference attributes, materialised lazily from the device state ----
+    @property
+    def offset(self):
+        return np.array([self._stream.offset if self._stream else 0], dtype=np.int32)
+
+    @property
+    def att_cache(self):
+        if self._stream is None or self._stream.cache_frames == 0:
+            return np.zeros([0, 0, 0, 0], dtype=np.float32)
+        return self._stream.export_caches()[0].cpu().numpy()
+
+    @property
+    def cnn_cache(self):
+        if self._stream is None or self._stream.offset == 0:
+            return np.zeros([0, 0, 0, 0], dtype=np.float32)
+        return self._stream.export_caches()[1].cpu().numpy()
+
+    # ---- full utterance ----
+    def predict_device(self, speech, speech_lengths):
+        """-> probs [B,T',V] device tensor (no host round trip)."""
+        return self.model.get_encoder_out(speech, speech_lengths)
+
+    def predict_greedy(self, speech, speech_lengths, trim_to_length=False):
+        """Fused encoder + greedy decode: -> (tokens, n_tokens, score) device tensors."""
+        return self.model.encode_greedy(speech, speech_lengths, trim_to_length=trim_to_length)
+
+    def predict(self, speech, speech_lengths):
+        """inference_predictor.py:103-145: probs [B,T',V] numpy.  (The reference's exported streaming
+        graph runs the utterance as one chunk with empty caches and no mask, :127-137 — identical to
+        get_encoder_out for un-padded input; padded batches use the masked batch path here.)"""
+        if self.streaming:
+            self.reset_stream()
+        return self.predict_device(speech, speech_lengths).cpu().numpy()
+
+    # ---- streaming ----
+    def predict_chunk_conformer(self, x_chunk, required_cache_size):
+        """inference_predictor.py:184-212 -> probs [1,c,V] numpy; caches/offset advance on the device."""
+        if not ("former" in self.use_model and self.streaming):
+            raise Exception(f"当前模型不支持该方法，当前模型为：{self.use_model}")
+        return self._stream.encode_chunk(np.asarray(x_chunk, np.float32), int(required_cache_size)).cpu().numpy()
+
+    def predict_chunk_deepspeech(self, x_chunk):
+        raise Exception(f"当前模型不支持该方法，当前模型为：{self.use_model}")
+
+    def reset_stream(self):
+        """inference_predictor.py:215-220"""
+        self.output_state_h = None
+        self.output_state_c = None
+        if self._stream is not None:
+            self._stream.reset()

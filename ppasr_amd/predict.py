@@ -1,0 +1,142 @@
+"""Drop-in for ``ppasr/predict.py`` (``PPASRPredictor``): ``predict`` (:163-187), ``predict_stream``
+(:232-337), ``reset_stream`` (:340-347), ``decode`` (:114-140) with the same arguments and return
+dicts.  Audio -> fbank is host-side glue (``data_utils/featurizer.py``); encoder + CTC decode run in
+the HIP library.  VAD (`predict_long`), punctuation and ITN are separate models outside the hot
+path and are not provided (``use_pun=True`` / ``is_itn=True`` raise).
+"""
+import numpy as np
+import yaml
+
+from ppasr_amd.data_utils.featurizer import AudioFeaturizer, TextFeaturizer, load_audio, pcm_bytes_to_float
+from ppasr_amd.decoders.ctc_greedy_decoder import greedy_decoder, greedy_decoder_chunk
+from ppasr_amd.infer_utils.inference_predictor import InferencePredictor
+
+__all__ = ["PPASRPredictor"]
+
+
+class _Cfg(dict):
+    """dict_to_object (utils/utils.py:45-56): nested attribute access."""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+        return _Cfg(v) if isinstance(v, dict) else v
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+class PPASRPredictor:
+    def __init__(self, configs=None, model_tag=None, model_path="models/conformer_streaming_fbank/infer/",
+                 use_pun=False, pun_model_dir="models/pun_models/", use_gpu=True, state_dict=None, vocab_list=None,
+                 warmup=True):
+        if configs is None:
+            raise Exception("configs (yaml path or dict) is required: model download is unavailable offline")
+        if isinstance(configs, str):
+            with open(configs, "r", encoding="utf-8") as f:
+                configs = yaml.load(f.read(), Loader=yaml.FullLoader)
+        if use_pun:
+            raise NotImplementedError("punctuation model is outside the hot path (SURVEY.md §2 row 19)")
+        self.configs = _Cfg(configs)
+        self.running = False
+        if vocab_list is not None:
+            self._text_featurizer = TextFeaturizer(vocab_list=vocab_list)
+        else:
+            self._text_featurizer = TextFeaturizer(vocab_filepath=self.configs.dataset_conf.dataset_vocab)
+        self._audio_featurizer = AudioFeaturizer(**self.configs.preprocess_conf)
+        self.remained_wav = None
+        self.cached_feat = None
+        self.greedy_last_max_prob_list = None
+        self.greedy_last_max_index_list = None
+        self.beam_search_decoder = None
+        if self.configs.decoder == "ctc_beam_search":
+            from ppasr_amd.decoders.beam_search_decoder import BeamSearchDecoder
+            self.beam_search_decoder = BeamSearchDecoder(vocab_list=self._text_featurizer.vocab_list,
+                                                         **self.configs.ctc_beam_search_decoder_conf)
+        self.predictor = InferencePredictor(configs=self.configs, use_model=self.configs.use_model,
+                                            streaming=self.configs.streaming, model_dir=model_path, use_gpu=use_gpu,
+                                            state_dict=state_dict, vocab_size=self._text_featurizer.vocab_size)
+        if warmup:  # predict.py:88-89
+            self.predict(audio_data=np.random.uniform(low=-2.0, high=2.0, size=(134240,)).astype(np.float32))
+
+    def decode(self, output_data, use_pun=False, is_itn=False):
+        """predict.py:114-140"""
+        if use_pun or is_itn:
+            raise NotImplementedError("punctuation / ITN are outside the hot path")
+        if self.configs.decoder == "ctc_beam_search":
+            result = self.beam_search_decoder.decode_beam_search_offline(probs_split=output_data)
+        else:
+            result = greedy_decoder(probs_seq=output_data, vocabulary=self._text_featurizer.vocab_list)
+        return result[0], result[1]
+
+    def predict(self, audio_data, use_pun=False, is_itn=False, sample_rate=16000):
+        """-> {'text': str, 'score': float}.  predict.py:163-187"""
+        samples, sr = load_audio(audio_data, sample_rate)
+        feat = self._audio_featurizer.featurize(samples, sr)
+        input_data = np.asarray(feat, np.float32)[np.newaxis, :]
+        audio_len = np.array([input_data.shape[1]]).astype(np.int64)
+        probs = self.predictor.predict_device(input_data, audio_len)[0]  # stays on the device
+        score, text = self.decode(output_data=probs, use_pun=use_pun, is_itn=is_itn)
+        return {"text": text, "score": score}
+
+    def predict_long(self, *a, **k):
+        raise NotImplementedError("predict_long needs the Silero VAD model (SURVEY.md §2 row 18), out of scope")
+
+    def predict_stream(self, audio_data, is_end=False, use_pun=False, is_itn=False, channels=1, samp_width=2,
+                       sample_rate=16000):
+        """predict.py:232-337 (same windowing constants: 16 output frames per 67-frame window, stride 64,
+        3 cached feature frames, required_cache_size = -16)."""
+        if not self.configs.streaming:
+            raise Exception(f"不支持改该模型流式识别，当前模型：{self.configs.use_model}")
+        if isinstance(audio_data, np.ndarray):
+            samples, _ = load_audio(audio_data, sample_rate)
+        elif isinstance(audio_data, bytes):
+            samples = pcm_bytes_to_float(audio_data, channels, samp_width)
+        else:
+            raise Exception(f"不支持该数据类型，当前数据类型为：{type(audio_data)}")
+        self.remained_wav = samples if self.remained_wav is None else np.concatenate([self.remained_wav, samples])
+        x_chunk = self._audio_featurizer.featurize(self.remained_wav, sample_rate)
+        x_chunk = np.asarray(x_chunk, np.float32)[np.newaxis, :]
+        self.cached_feat = x_chunk if self.cached_feat is None else np.concatenate([self.cached_feat, x_chunk], axis=1)
+        self.remained_wav = self.remained_wav[160 * x_chunk.shape[1]:]
+
+        decoding_chunk_size, context, subsampling = 16, 7, 4
+        cached_feature_num = context - subsampling
+        decoding_window = (decoding_chunk_size - 1) * subsampling + context
+        stride = subsampling * decoding_chunk_size
+        num_frames = self.cached_feat.shape[1]
+        if num_frames < decoding_window and not is_end:
+            return None
+        if num_frames < context:
+            return None
+        left_frames = context if is_end else decoding_window
+        score, text, end = None, None, None
+        for cur in range(0, num_frames - left_frames + 1, stride):
+            end = min(cur + decoding_window, num_frames)
+            x = self.cached_feat[:, cur:end, :]
+            required_cache_size = decoding_chunk_size * -1
+            probs = self.predictor._stream.encode_chunk(x, required_cache_size)  # device tensor [1,c,V]
+            if self.configs.decoder == "ctc_beam_search":
+                lens = np.array([probs.shape[1]])
+                score, text = self.beam_search_decoder.decode_chunk(probs=probs, logits_lens=lens)
+            else:
+                score, text, self.greedy_last_max_prob_list, self.greedy_last_max_index_list = greedy_decoder_chunk(
+                    probs_seq=probs[0], vocabulary=self._text_featurizer.vocab_list,
+                    last_max_index_list=self.greedy_last_max_index_list,
+                    last_max_prob_list=self.greedy_last_max_prob_list)
+        self.cached_feat = self.cached_feat[:, end - cached_feature_num:, :]
+        if use_pun or is_itn:
+            raise NotImplementedError("punctuation / ITN are outside the hot path")
+        return {"text": text, "score": score}
+
+    def reset_stream(self):
+        """predict.py:340-347"""
+        self.predictor.reset_stream()
+        self.remained_wav = None
+        self.cached_feat = None
+        self.greedy_last_max_prob_list = None
+        self.greedy_last_max_index_list = None
+        if self.configs.decoder == "ctc_beam_search" and self.beam_search_decoder is not None:
+            self.beam_search_decoder.reset_decoder()

@@ -1,0 +1,123 @@
+"""GPU parity of the HIP prefix beam search against the C oracle (oracle/ctc_beam_search_oracle.c,
+a restatement of the upstream paddlespeech_ctcdecoders algorithm -- parity UNPINNED by the
+reference, see the oracle header).  Token sequences must match exactly; scores to float round-off
+(logf/expf differ by <= 1 ulp between glibc and the GPU math library)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle():
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libctc_beam_oracle.so"))
+    lib.ctc_beam_oracle_decode.restype = ctypes.c_int
+    lib.ctc_beam_oracle_create.restype = ctypes.c_void_p
+    lib.ctc_beam_oracle_next.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    lib.ctc_beam_oracle_result.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p]
+    lib.ctc_beam_oracle_free.argtypes = [ctypes.c_void_p]
+    return lib
+
+
+def _oracle_decode(lib, p, beam, cutoff_prob, top_n, blank, nbest):
+    T, V = p.shape
+    L = max(T, 1)
+    tokens = np.empty((nbest, L), np.int32)
+    lens = np.empty(nbest, np.int32)
+    scores = np.empty(nbest, np.float64)
+    p = np.ascontiguousarray(p, np.float32)
+    n = lib.ctc_beam_oracle_decode(p.ctypes.data_as(ctypes.c_void_p), T, V, beam, ctypes.c_double(cutoff_prob), top_n,
+                                   blank, nbest, L, tokens.ctypes.data_as(ctypes.c_void_p),
+                                   lens.ctypes.data_as(ctypes.c_void_p), scores.ctypes.data_as(ctypes.c_void_p))
+    return [(tokens[i, :lens[i]].tolist(), scores[i]) for i in range(n)]
+
+
+def _probs(rng, T, V, kind):
+    logits = rng.standard_normal((T, V)).astype(np.float32)
+    if kind == "peaky":
+        idx = np.repeat(rng.integers(0, V, size=(T + 2) // 3), 3)[:T]
+        logits[np.arange(T), idx] += 6.0
+        logits[:, 0] += np.where(rng.random(T) < 0.4, 7.0, 0.0).astype(np.float32)
+    elif kind == "flat":
+        logits *= 0.3
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    return (e / e.sum(1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.parametrize("T,V,beam,cutoff_prob,top_n", [
+    (50, 30, 8, 1.0, 40),        # english-style config: no pruning (cutoff_prob 1.0, V < top_n)
+    (120, 500, 10, 0.99, 40),    # configs[3]-style: beam 10
+    (249, 4233, 10, 0.99, 40),
+    (60, 4233, 64, 0.99, 40),
+    (40, 200, 300, 0.99, 40),    # the reference's default beam_size (conformer.yml:82)
+    (1, 100, 5, 0.99, 40),
+])
+@pytest.mark.parametrize("kind", ["peaky", "flat"])
+def test_beam_search_matches_c_oracle(T, V, beam, cutoff_prob, top_n, kind):
+    from ppasr_amd.decoders.beam_search_decoder import beam_search_ids
+    lib = _oracle()
+    rng = np.random.Generator(np.random.PCG64(T * 7 + V + beam))
+    B = 3
+    batch = np.stack([_probs(rng, T, V, kind) for _ in range(B)])
+    nbest = min(beam, 5)
+    tokens, lens, scores, _ = beam_search_ids(torch.from_numpy(batch).cuda(), beam, cutoff_prob, top_n, 0, nbest=nbest)
+    torch.cuda.synchronize()
+    tokens, lens, scores = tokens.cpu().numpy(), lens.cpu().numpy(), scores.cpu().numpy()
+    for b in range(B):
+        ref = _oracle_decode(lib, batch[b], beam, cutoff_prob, top_n, 0, nbest)
+        assert tokens[b, 0, :lens[b, 0]].tolist() == ref[0][0], (b, ref[0])
+        assert abs(scores[b, 0] - ref[0][1]) <= 1e-4 * max(1.0, abs(ref[0][1]))
+        # the rest of the n-best list: same hypotheses unless two scores are within float noise
+        for r in range(1, len(ref)):
+            if abs(ref[r][1] - ref[r - 1][1]) > 1e-4 and (r + 1 >= len(ref) or abs(ref[r + 1][1] - ref[r][1]) > 1e-4):
+                assert tokens[b, r, :lens[b, r]].tolist() == ref[r][0], (b, r)
+
+
+def test_streaming_chunks_equal_offline_and_oracle_object():
+    """CtcBeamSearchDecoderBatch semantics: next(chunk) ... decode() == one-shot decode of the whole table."""
+    from ppasr_amd.decoders.beam_search_decoder import BeamSearchDecoder
+    lib = _oracle()
+    rng = np.random.Generator(np.random.PCG64(5))
+    V, beam = 300, 10
+    vocab = ["<blank>"] + [chr(0x4E00 + i) for i in range(V - 1)]
+    p = _probs(rng, 100, V, "peaky")
+    dec = BeamSearchDecoder(2.2, 4.3, beam, 0.99, 40, vocab)
+    off_score, off_text = dec.decode_beam_search_offline(p)
+    h = lib.ctc_beam_oracle_create(V, beam, ctypes.c_double(0.99), 40, 0)
+    text = None
+    for s in range(0, 100, 16):
+        chunk = np.ascontiguousarray(p[s:s + 16])
+        score, text = dec.decode_chunk(chunk[None], np.array([chunk.shape[0]]))
+        lib.ctc_beam_oracle_next(h, chunk.ctypes.data_as(ctypes.c_void_p), chunk.shape[0])
+        tk = np.empty((1, 200), np.int32); ln = np.empty(1, np.int32); sc = np.empty(1, np.float64)
+        lib.ctc_beam_oracle_result(h, 1, 200, tk.ctypes.data_as(ctypes.c_void_p), ln.ctypes.data_as(ctypes.c_void_p),
+                                   sc.ctypes.data_as(ctypes.c_void_p))
+        assert text == "".join(vocab[i] for i in tk[0, :ln[0]])
+    lib.ctc_beam_oracle_free(h)
+    assert text == off_text and abs(score - off_score) < 1e-4 * max(1.0, abs(off_score))
+    dec.reset_decoder()
+    assert dec.decode_chunk(p[None, :16], np.array([16]))[1] != ""  # fresh state after reset
+
+
+def test_frame_lens_and_batch_api():
+    from ppasr_amd.decoders.beam_search_decoder import BeamSearchDecoder, beam_search_ids
+    lib = _oracle()
+    rng = np.random.Generator(np.random.PCG64(9))
+    V, beam, T = 120, 6, 40
+    vocab = ["<blank>"] + [chr(0x4E00 + i) for i in range(V - 1)]
+    batch = np.stack([_probs(rng, T, V, "peaky") for _ in range(4)])
+    lens = np.array([40, 17, 0, 5], np.int32)
+    tokens, ln, sc, _ = beam_search_ids(torch.from_numpy(batch).cuda(), beam, 0.99, 40, 0, frame_lens=lens)
+    for b in range(4):
+        ref = _oracle_decode(lib, batch[b, :lens[b]], beam, 0.99, 40, 0, 1)
+        assert tokens[b, 0, :int(ln[b, 0])].tolist() == ref[0][0]
+    dec = BeamSearchDecoder(2.2, 4.3, beam, 0.99, 40, vocab)
+    texts = dec.decode_batch_beam_search_offline(list(batch))
+    for b in range(4):
+        ref = _oracle_decode(lib, batch[b], beam, 0.99, 40, 0, 1)
+        assert texts[b] == "".join(vocab[i] for i in ref[0][0])
