@@ -63,6 +63,14 @@ typedef struct {
   int cnn_module_kernel; /* 15 */
   int causal;            /* streaming model => causal depthwise conv (model.py:35-39) */
   int max_len;           /* positional table length (embedding.py:30), 5000 */
+  /* Squeezeformer (configs/squeezeformer.yml:7-8, squeezeformer/encoder.py:30-31); -1 = none */
+  int reduce_idx;
+  int recover_idx;
+  /* Efficient-Conformer (configs/efficient_conformer.yml:16-21) */
+  int stride_layer_idx;   /* layer with the stride-2 depthwise conv, -1 = none */
+  int group_layer_mask;   /* bit i set: layer i uses grouped attention */
+  int group_size;
+  int reserved[3];
 } ppasr_model_desc;
 
 const char* ppasr_last_error(void);

@@ -31,7 +31,9 @@ class ModelDesc(ctypes.Structure):
     _fields_ = [("model_type", ctypes.c_int), ("input_dim", ctypes.c_int), ("vocab_size", ctypes.c_int),
                 ("output_size", ctypes.c_int), ("attention_heads", ctypes.c_int), ("linear_units", ctypes.c_int),
                 ("num_blocks", ctypes.c_int), ("cnn_module_kernel", ctypes.c_int), ("causal", ctypes.c_int),
-                ("max_len", ctypes.c_int)]
+                ("max_len", ctypes.c_int), ("reduce_idx", ctypes.c_int), ("recover_idx", ctypes.c_int),
+                ("stride_layer_idx", ctypes.c_int), ("group_layer_mask", ctypes.c_int), ("group_size", ctypes.c_int),
+                ("reserved", ctypes.c_int * 3)]
 
 
 # every symbol include/ppasr_hip.h declares: (name, restype, argtypes)

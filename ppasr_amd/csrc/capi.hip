@@ -1,108 +1,31 @@
 // capi.hip -- the C-ABI of libppasr_hip.so (declared in include/ppasr_hip.h).
 // Host side: weight re-packing into MFMA fragment order, workspace carving, launch sequence.
-#include <hip/hip_runtime.h>
+#include "capi_internal.h"
 
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <memory>
-#include <string>
-#include <unordered_map>
-#include <vector>
+static thread_local std::string g_err;
+std::string& ppasr_err_slot() { return g_err; }
 
-#include "../../include/ppasr_hip.h"
-#include "conformer_kernels.h"
-#include "ctc_beam.h"
 
-using namespace ppasr;
-
-namespace {
-
-thread_local std::string g_err;
-ppasr_status fail(ppasr_status s, const std::string& msg) {
-  g_err = msg;
-  return s;
-}
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t _e = (expr);                                                                        \
-    if (_e != hipSuccess) return fail(PPASR_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-  } while (0)
-
-struct Blob {
-  const float* p;
-  int ndim;
-  int64_t shape[4];
-  size_t numel() const {
-    size_t n = 1;
-    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
-    return n;
-  }
-};
-
-// Fragment-order packing of a [K][N] weight (y = x W): for 32-column tile nt, 8-wide k-group g,
-// lane l: 4 consecutive floats = W[8g + 4(l>>5) + 0..3][32 nt + (l&31)].  One wave-level
-// global_load_dwordx4 then yields the B operands of 4 successive v_mfma_f32_32x32x2_f32.
-template <typename Acc>
-std::vector<float> pack_b(int K, int N, Acc w) {
-  const int n_tiles = (N + 31) / 32, G = K / 8;
-  std::vector<float> out((size_t)n_tiles * G * 256, 0.f);
-  for (int nt = 0; nt < n_tiles; ++nt)
-    for (int g = 0; g < G; ++g)
-      for (int l = 0; l < 64; ++l) {
-        int n = nt * 32 + (l & 31);
-        if (n >= N) continue;
-        float* dst = &out[(((size_t)nt * G + g) * 64 + l) * 4];
-        for (int j = 0; j < 4; ++j) dst[j] = w(8 * g + 4 * (l >> 5) + j, n);
+ppasr_status upload_pe_table(ppasr_model_s* m, BlobMap& sd, const float** pe_dev) {
+  const int d = kD;
+  const int max_len = m->desc.max_len > 0 ? m->desc.max_len : 5000;
+  m->desc.max_len = max_len;
+  std::vector<float> pe((size_t)max_len * d);
+  auto it = sd.find("__pe_table__");
+  if (it != sd.end() && it->second.numel() == pe.size()) {
+    std::memcpy(pe.data(), it->second.p, pe.size() * sizeof(float));
+  } else {  // PositionalEncoding.__init__ (embedding.py:38-53)
+    for (int i = 0; i < d / 2; ++i) {
+      float div = expf((float)(2 * i) * (float)(-(std::log(10000.0) / d)));
+      for (int pos = 0; pos < max_len; ++pos) {
+        float a = (float)pos * div;
+        pe[(size_t)pos * d + 2 * i] = sinf(a);
+        pe[(size_t)pos * d + 2 * i + 1] = cosf(a);
       }
-  return out;
-}
-
-}  // namespace
-
-struct ppasr_model_s {
-  ppasr_model_desc desc;
-  int F1, F2;
-  std::vector<void*> allocs;
-  FrontW front;
-  std::vector<LayerW> layers;
-  HeadW head;
-  float* taps = nullptr;
-  size_t taps_floats = 0;
-  // optional per-kernel timing (bench.py roofline leg): one event pair per launch on the caller's stream
-  bool prof = false;
-  std::vector<hipEvent_t> ev_pool;
-  size_t ev_used = 0;
-  struct Span { int cls; hipEvent_t a, b; };
-  std::vector<Span> spans;
-
-  ppasr_status upload(const std::vector<float>& v, const float** out) {
-    void* d = nullptr;
-    HIP_TRY(hipMalloc(&d, v.size() * sizeof(float)));
-    allocs.push_back(d);
-    HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
-    *out = static_cast<const float*>(d);
-    return PPASR_OK;
-  }
-  ppasr_status upload4(const std::vector<float>& v, const f32x4** out) {
-    const float* p = nullptr;
-    ppasr_status s = upload(v, &p);
-    *out = reinterpret_cast<const f32x4*>(p);
-    return s;
-  }
-  hipEvent_t next_event() {
-    if (ev_used == ev_pool.size()) {
-      hipEvent_t e;
-      (void)hipEventCreate(&e);
-      ev_pool.push_back(e);
     }
-    return ev_pool[ev_used++];
   }
-  ~ppasr_model_s() {
-    for (void* p : allocs) (void)hipFree(p);
-    for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
-  }
-};
+  return m->upload(pe, pe_dev);
+}
 
 extern "C" {
 
@@ -111,17 +34,21 @@ const char* ppasr_version(void) { return "ppasr_hip 0.1 (gfx950, fp32 MFMA)"; }
 
 ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob* blobs, int n_blobs, ppasr_handle* out) {
   if (!desc || !blobs || !out) return fail(PPASR_EINVAL, "null argument");
-  if (desc->model_type != PPASR_MODEL_CONFORMER) return fail(PPASR_EUNSUPPORTED, "only model_type=conformer is built");
+  if (desc->model_type != PPASR_MODEL_CONFORMER && desc->model_type != PPASR_MODEL_SQUEEZEFORMER)
+    return fail(PPASR_EUNSUPPORTED, "model_type not built (conformer, squeezeformer are)");
   if (desc->output_size != kD) return fail(PPASR_EUNSUPPORTED, "kernels are specialised for output_size=256");
   if (desc->attention_heads * 64 != kD) return fail(PPASR_EUNSUPPORTED, "kernels are specialised for d_k=64");
   if (desc->linear_units % 256 != 0 || desc->linear_units <= 0) return fail(PPASR_EUNSUPPORTED, "linear_units % 256 != 0");
   if (desc->cnn_module_kernel != 15 && desc->cnn_module_kernel != 31 && desc->cnn_module_kernel != 7)
     return fail(PPASR_EUNSUPPORTED, "cnn_module_kernel must be 7, 15 or 31");
+  if (desc->model_type == PPASR_MODEL_SQUEEZEFORMER && desc->cnn_module_kernel == 7)
+    return fail(PPASR_EUNSUPPORTED, "squeezeformer: cnn_module_kernel must be 15 or 31");
   if (!desc->causal) return fail(PPASR_EUNSUPPORTED, "only the causal (streaming-trained) conv module is built");
   if (desc->input_dim > 128 || desc->input_dim < 7) return fail(PPASR_EUNSUPPORTED, "input_dim out of range");
   HIP_TRY(configure_kernels());
+  HIP_TRY(configure_squeezeformer_kernels());
 
-  std::unordered_map<std::string, Blob> sd;
+  BlobMap sd;
   for (int i = 0; i < n_blobs; ++i) {
     Blob b{blobs[i].data_host, blobs[i].ndim, {0, 0, 0, 0}};
     for (int j = 0; j < blobs[i].ndim && j < 4; ++j) b.shape[j] = blobs[i].shape[j];
@@ -154,6 +81,14 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
   if ((st = m->upload4(vec, &(dst))) != PPASR_OK) return st
   auto vec_of = [](const float* p, size_t n) { return std::vector<float>(p, p + n); };
 
+  if (desc->model_type == PPASR_MODEL_SQUEEZEFORMER) {
+    const float* pe_sq = nullptr;
+    if ((st = upload_pe_table(m, sd, &pe_sq)) != PPASR_OK) return st;
+    if ((st = squeezeformer_create(m, sd, pe_sq)) != PPASR_OK) return st;
+    HIP_TRY(hipDeviceSynchronize());
+    *out = guard.release();
+    return PPASR_OK;
+  }
   {  // ---- front end ----
     GET(mean, "encoder.global_cmvn.mean", F);
     GET(istd, "encoder.global_cmvn.istd", F);
@@ -178,28 +113,9 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
     UP(vec_of(eb, d), m->front.embed_b);
   }
 
-  // ---- positional table (embedding.py:38-53) ----
-  const int max_len = desc->max_len > 0 ? desc->max_len : 5000;
-  m->desc.max_len = max_len;
   const float* pe_dev = nullptr;
-  {
-    std::vector<float> pe((size_t)max_len * d);
-    auto it = sd.find("__pe_table__");
-    if (it != sd.end() && it->second.numel() == pe.size()) {
-      std::memcpy(pe.data(), it->second.p, pe.size() * sizeof(float));
-    } else {
-      for (int i = 0; i < d / 2; ++i) {
-        float div = expf((float)(2 * i) * (float)(-(std::log(10000.0) / d)));
-        for (int pos = 0; pos < max_len; ++pos) {
-          float a = (float)pos * div;
-          pe[(size_t)pos * d + 2 * i] = sinf(a);
-          pe[(size_t)pos * d + 2 * i + 1] = cosf(a);
-        }
-      }
-    }
-    UP(pe, pe_dev);
-  }
-
+  if ((st = upload_pe_table(m, sd, &pe_dev)) != PPASR_OK) return st;
+  const int max_len = m->desc.max_len;
   m->layers.resize(desc->num_blocks);
   for (int i = 0; i < desc->num_blocks; ++i) {
     LayerW& L = m->layers[i];
@@ -261,7 +177,7 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
       void* pt = nullptr;
       HIP_TRY(hipMalloc(&pt, (size_t)max_len * d * sizeof(float)));
       m->allocs.push_back(pt);
-      launch_posproj(pe_dev, wpos_dev, static_cast<float*>(pt), max_len, nullptr);
+      launch_posproj(pe_dev, wpos_dev, nullptr, static_cast<float*>(pt), max_len, nullptr);
       HIP_TRY(hipGetLastError());
       L.ptab = static_cast<const float*>(pt);
     }
@@ -320,10 +236,7 @@ int ppasr_out_frames(ppasr_handle h, int T) {
   return ((T - 1) / 2 - 1) / 2;
 }
 
-namespace {
-struct WsLayout {
-  size_t y1, y2, xa, xb, xc, qkv, ctx, g, rmax, rsum, fa, fp, total;  // offsets in floats
-};
+}  // extern "C"
 WsLayout ws_layout(const ppasr_model_s* m, int B, int T) {
   const size_t T1 = (T - 1) / 2, Tp = (T1 - 1) / 2;
   const size_t M = (size_t)B * Tp;
@@ -342,10 +255,11 @@ WsLayout ws_layout(const ppasr_model_s* m, int B, int T) {
   w.rsum = o; o += al(M);
   w.fa = o; o += al(M);
   w.fp = o; o += al(M);
+  w.xs = o; o += al(M * kD);  // saved full-resolution activations (Squeezeformer time reduction)
   w.total = o;
   return w;
 }
-}  // namespace
+extern "C" {
 
 size_t ppasr_workspace_bytes(ppasr_handle h, int B, int T) {
   if (!h || B <= 0 || T < 7) return 0;
@@ -371,6 +285,8 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   if (workspace_bytes < wl.total * sizeof(float)) return fail(PPASR_ENOSPACE, "workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(workspace);
+  if (h->desc.model_type == PPASR_MODEL_SQUEEZEFORMER)
+    return squeezeformer_encode(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, ws, wl, st);
   float *y1 = ws + wl.y1, *y2 = ws + wl.y2, *xa = ws + wl.xa, *xb = ws + wl.xb, *xc = ws + wl.xc;
   float *qkv = ws + wl.qkv, *ctx = ws + wl.ctx, *g = ws + wl.g;
   size_t tap_off = 0;
@@ -396,7 +312,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   };
   timed(0, [&] { launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st); });
   timed(1, [&] { launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st); });
-  timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), st); });
+  timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st); });
   tap(xa, (size_t)M * kD);
   const int n_chunks = h->desc.linear_units / 256;
   for (int i = 0; i < h->desc.num_blocks; ++i) {
@@ -405,8 +321,8 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     tap(xb, (size_t)M * kD);
     tap(qkv, (size_t)M * 3 * kD);
     timed(4, [&] {
-      AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Tp, Tp, 0, lens, ctx};
-      launch_attention(a, L, B, h->desc.attention_heads, st);
+      AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Tp, Tp, 0, lens, ctx, L.pos_u, L.pos_v, L.ptab, 1, 4};
+      launch_attention(a, B, h->desc.attention_heads, st);
     });
     tap(ctx, (size_t)M * kD);
     timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, L, lens, M, Tp, st); });
@@ -518,7 +434,7 @@ ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int r
   const int M = c;
   launch_conv1(feats, h->front, y1, 1, T, F, T1, F1, st);
   launch_conv2(y1, h->front, y2, 1, T1, F1, c, F2, st);
-  launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), st);
+  launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st);
   const int n_chunks = h->desc.linear_units / 256;
   const int lo = s->lo;
   for (int i = 0; i < h->desc.num_blocks; ++i) {
@@ -528,8 +444,8 @@ ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int r
     float* xh = s->xh_hist + (size_t)i * lo * kD;
     launch_ffn_qkv(xa, xb, qkv, L, M, n_chunks, st);
     launch_kv_append(qkv, kc + (size_t)s->cache_t * kD, vc + (size_t)s->cache_t * kD, c, st);
-    AttnArgs a{qkv, 768, kc, kD, vc, kD, c, T2, s->offset - s->cache_t, nullptr, ctx};
-    launch_attention(a, L, 1, h->desc.attention_heads, st);
+    AttnArgs a{qkv, 768, kc, kD, vc, kD, c, T2, s->offset - s->cache_t, nullptr, ctx, L.pos_u, L.pos_v, L.ptab, 1, 4};
+    launch_attention(a, 1, h->desc.attention_heads, st);
     launch_pw1_glu(xh, s->g_hist, L, lo, st);
     launch_out_glu(ctx, xb, xc, g, xhat, L, nullptr, M, c, st);
     launch_conv_ffn(g, s->g_hist, xc, xa, L, nullptr, M, c, n_chunks, h->desc.cnn_module_kernel, st);

@@ -1,0 +1,125 @@
+// capi_internal.h -- definitions shared by the C-ABI translation units (capi*.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ppasr_hip.h"
+#include "conformer_kernels.h"
+#include "ctc_beam.h"
+
+using namespace ppasr;
+
+#include "squeezeformer_kernels.h"
+
+std::string& ppasr_err_slot();  // thread-local error string (defined in capi.hip)
+inline ppasr_status fail(ppasr_status s, const std::string& msg) {
+  ppasr_err_slot() = msg;
+  return s;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return fail(PPASR_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+struct Blob {
+  const float* p;
+  int ndim;
+  int64_t shape[4];
+  size_t numel() const {
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    return n;
+  }
+};
+
+// Fragment-order packing of a [K][N] weight (y = x W): for 32-column tile nt, 8-wide k-group g,
+// lane l: 4 consecutive floats = W[8g + 4(l>>5) + 0..3][32 nt + (l&31)].  One wave-level
+// global_load_dwordx4 then yields the B operands of 4 successive v_mfma_f32_32x32x2_f32.
+template <typename Acc>
+inline std::vector<float> pack_b(int K, int N, Acc w) {
+  const int n_tiles = (N + 31) / 32, G = K / 8;
+  std::vector<float> out((size_t)n_tiles * G * 256, 0.f);
+  for (int nt = 0; nt < n_tiles; ++nt)
+    for (int g = 0; g < G; ++g)
+      for (int l = 0; l < 64; ++l) {
+        int n = nt * 32 + (l & 31);
+        if (n >= N) continue;
+        float* dst = &out[(((size_t)nt * G + g) * 64 + l) * 4];
+        for (int j = 0; j < 4; ++j) dst[j] = w(8 * g + 4 * (l >> 5) + j, n);
+      }
+  return out;
+}
+
+typedef std::unordered_map<std::string, Blob> BlobMap;
+
+struct ppasr_model_s {
+  ppasr_model_desc desc;
+  int F1, F2;
+  std::vector<void*> allocs;
+  FrontW front;
+  std::vector<LayerW> layers;
+  HeadW head;
+  // Squeezeformer (model_type == PPASR_MODEL_SQUEEZEFORMER)
+  std::vector<SqLayerW> sq_layers;
+  SqReduceW sq_reduce{};
+  const f32x4* sq_wrec = nullptr;
+  const float* sq_brec = nullptr;
+  const float *preln_g = nullptr, *preln_b = nullptr;
+  float* taps = nullptr;
+  size_t taps_floats = 0;
+  // optional per-kernel timing (bench.py roofline leg): one event pair per launch on the caller's stream
+  bool prof = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  struct Span { int cls; hipEvent_t a, b; };
+  std::vector<Span> spans;
+
+  ppasr_status upload(const std::vector<float>& v, const float** out) {
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, v.size() * sizeof(float)));
+    allocs.push_back(d);
+    HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = static_cast<const float*>(d);
+    return PPASR_OK;
+  }
+  ppasr_status upload4(const std::vector<float>& v, const f32x4** out) {
+    const float* p = nullptr;
+    ppasr_status s = upload(v, &p);
+    *out = reinterpret_cast<const f32x4*>(p);
+    return s;
+  }
+  hipEvent_t next_event() {
+    if (ev_used == ev_pool.size()) {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      ev_pool.push_back(e);
+    }
+    return ev_pool[ev_used++];
+  }
+  ~ppasr_model_s() {
+    for (void* p : allocs) (void)hipFree(p);
+    for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+  }
+};
+
+
+struct WsLayout {
+  size_t y1, y2, xa, xb, xc, qkv, ctx, g, rmax, rsum, fa, fp, xs, total;  // offsets in floats
+};
+WsLayout ws_layout(const ppasr_model_s* m, int B, int T);
+
+ppasr_status upload_pe_table(ppasr_model_s* m, BlobMap& sd, const float** pe_dev);
+
+// model-family back ends
+ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe_dev);
+ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const int64_t* lens, int B, int T, float* probs,
+                                  float* logits, int32_t* frame_argmax, float* frame_maxprob, float* ws,
+                                  const WsLayout& wl, hipStream_t st);

@@ -1,0 +1,275 @@
+// capi_squeezeformer.hip -- weight packing and launch sequence of the Squeezeformer encoder
+// (ppasr/model_utils/squeezeformer/{encoder,attention,convolution,positionwise,subsampling,
+// time_reduction}.py) behind ppasr_create / ppasr_encode.
+#include "capi_internal.h"
+
+namespace {
+
+struct Getter {
+  BlobMap& sd;
+  std::string missing;
+  const float* operator()(const std::string& name, size_t numel) {
+    auto it = sd.find(name);
+    if (it == sd.end() || it->second.numel() != numel) {
+      if (missing.empty()) missing = name;
+      return nullptr;
+    }
+    return it->second.p;
+  }
+};
+
+std::vector<float> vec_of(const float* p, size_t n) { return std::vector<float>(p, p + n); }
+
+}  // namespace
+
+#define GETW(var, name, numel)                 \
+  const float* var = get(name, (size_t)(numel)); \
+  if (!var) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + get.missing)
+#define UP(vec, dst) \
+  if ((st = m->upload(vec, &(dst))) != PPASR_OK) return st
+#define UP4(vec, dst) \
+  if ((st = m->upload4(vec, &(dst))) != PPASR_OK) return st
+
+ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe_dev) {
+  const ppasr_model_desc& dsc = m->desc;
+  const int F = dsc.input_dim, d = kD, H = dsc.linear_units, V = dsc.vocab_size, KS = dsc.cnn_module_kernel;
+  const int F2 = m->F2, L = dsc.num_blocks, max_len = dsc.max_len;
+  if (dsc.reduce_idx >= 0 && (dsc.recover_idx <= dsc.reduce_idx || dsc.recover_idx >= L || dsc.reduce_idx == 0))
+    return fail(PPASR_EUNSUPPORTED, "squeezeformer: need 0 < reduce_idx < recover_idx < num_blocks (or reduce_idx = -1)");
+  Getter get{sd, ""};
+  ppasr_status st;
+  {  // DepthwiseConv2DSubsampling4 with dw_stride=False (subsampling.py:36-47): two ordinary 3x3/s2 convs
+    GETW(mean, "encoder.global_cmvn.mean", F);
+    GETW(istd, "encoder.global_cmvn.istd", F);
+    GETW(c1w, "encoder.embed.pw_conv.weight", d * 9);
+    GETW(c1b, "encoder.embed.pw_conv.bias", d);
+    GETW(c2w, "encoder.embed.dw_conv.weight", (size_t)d * d * 9);
+    GETW(c2b, "encoder.embed.dw_conv.bias", d);
+    GETW(ew, "encoder.embed.input_proj.0.weight", (size_t)d * F2 * d);
+    GETW(eb, "encoder.embed.input_proj.0.bias", d);
+    GETW(pg, "encoder.preln.weight", d);
+    GETW(pb, "encoder.preln.bias", d);
+    UP(vec_of(mean, F), m->front.cmvn_mean);
+    UP(vec_of(istd, F), m->front.cmvn_istd);
+    std::vector<float> c1(9 * d);
+    for (int c = 0; c < d; ++c)
+      for (int j = 0; j < 9; ++j) c1[j * d + c] = c1w[c * 9 + j];
+    UP(c1, m->front.conv1_w);
+    UP(vec_of(c1b, d), m->front.conv1_b);
+    UP4(pack_b(9 * d, d, [&](int k, int n) { return c2w[((size_t)n * d + (k % d)) * 9 + (k / d)]; }), m->front.conv2_w);
+    UP(vec_of(c2b, d), m->front.conv2_b);
+    UP4(pack_b(F2 * d, d, [&](int k, int n) { return ew[((size_t)(k % d) * F2 + (k / d)) * d + n]; }), m->front.embed_w);
+    UP(vec_of(eb, d), m->front.embed_b);
+    UP(vec_of(pg, d), m->preln_g);
+    UP(vec_of(pb, d), m->preln_b);
+  }
+  m->sq_layers.resize(L);
+  for (int i = 0; i < L; ++i) {
+    SqLayerW& W = m->sq_layers[i];
+    const std::string p = "encoder.encoders." + std::to_string(i) + ".";
+    auto ln = [&](const std::string& n, const float** g, const float** b) -> ppasr_status {
+      const float* gw = get(p + n + ".weight", d);
+      const float* gb = get(p + n + ".bias", d);
+      if (!gw || !gb) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + get.missing);
+      ppasr_status s1 = m->upload(vec_of(gw, d), g);
+      return s1 != PPASR_OK ? s1 : m->upload(vec_of(gb, d), b);
+    };
+    if ((st = ln("layer_norm1", &W.ln1_g, &W.ln1_b)) != PPASR_OK) return st;
+    if ((st = ln("layer_norm2", &W.ln2_g, &W.ln2_b)) != PPASR_OK) return st;
+    if ((st = ln("layer_norm3", &W.ln3_g, &W.ln3_b)) != PPASR_OK) return st;
+    if ((st = ln("layer_norm4", &W.ln4_g, &W.ln4_b)) != PPASR_OK) return st;
+    if ((st = ln("conv_module.norm", &W.ln_cm_g, &W.ln_cm_b)) != PPASR_OK) return st;
+    // FFN with the adaptive scale folded into w_1:  (s.x + a) W1 + b1 = x (diag(s) W1) + (a W1 + b1)
+    auto ffn = [&](const std::string& n, const f32x4** w1, const float** b1, const f32x4** w2,
+                   const float** b2) -> ppasr_status {
+      const float* a1 = get(p + n + ".w_1.weight", (size_t)d * H);
+      const float* c1 = get(p + n + ".w_1.bias", H);
+      const float* a2 = get(p + n + ".w_2.weight", (size_t)H * d);
+      const float* c2 = get(p + n + ".w_2.bias", d);
+      const float* as = get(p + n + ".ada_scale", d);
+      const float* ab = get(p + n + ".ada_bias", d);
+      if (!a1 || !c1 || !a2 || !c2 || !as || !ab) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + get.missing);
+      std::vector<float> b1f(c1, c1 + H);
+      for (int nn = 0; nn < H; ++nn) {
+        double acc = 0.0;
+        for (int k = 0; k < d; ++k) acc += (double)ab[k] * (double)a1[(size_t)k * H + nn];
+        b1f[nn] = (float)((double)c1[nn] + acc);
+      }
+      ppasr_status s;
+      if ((s = m->upload4(pack_b(d, H, [&](int k, int nn) { return as[k] * a1[(size_t)k * H + nn]; }), w1)) != PPASR_OK) return s;
+      if ((s = m->upload(b1f, b1)) != PPASR_OK) return s;
+      if ((s = m->upload4(pack_b(H, d, [&](int k, int nn) { return a2[(size_t)k * d + nn]; }), w2)) != PPASR_OK) return s;
+      return m->upload(vec_of(c2, d), b2);
+    };
+    if ((st = ffn("ffn1", &W.ff1_w1, &W.ff1_b1, &W.ff1_w2, &W.ff1_b2)) != PPASR_OK) return st;
+    if ((st = ffn("ffn2", &W.ff2_w1, &W.ff2_b1, &W.ff2_w2, &W.ff2_b2)) != PPASR_OK) return st;
+    {
+      GETW(wq, p + "self_attn.linear_q.weight", d * d);
+      GETW(wk, p + "self_attn.linear_k.weight", d * d);
+      GETW(wv, p + "self_attn.linear_v.weight", d * d);
+      GETW(bq, p + "self_attn.linear_q.bias", d);
+      GETW(bk, p + "self_attn.linear_k.bias", d);
+      GETW(bv, p + "self_attn.linear_v.bias", d);
+      GETW(wo, p + "self_attn.linear_out.weight", d * d);
+      GETW(bo, p + "self_attn.linear_out.bias", d);
+      GETW(wp, p + "self_attn.linear_pos.weight", d * d);
+      GETW(bp, p + "self_attn.linear_pos.bias", d);  // linear_pos HAS a bias here (squeezeformer/attention.py:28)
+      GETW(pu, p + "self_attn.pos_bias_u", d);
+      GETW(pv, p + "self_attn.pos_bias_v", d);
+      GETW(as, p + "self_attn.ada_scale", d);
+      GETW(ab, p + "self_attn.ada_bias", d);
+      const float* ws[3] = {wq, wk, wv};
+      const float* bs[3] = {bq, bk, bv};
+      UP4(pack_b(d, 3 * d, [&](int k, int n) { return as[k] * ws[n / d][(size_t)k * d + (n % d)]; }), W.wqkv);
+      std::vector<float> bqkv(3 * d);
+      for (int n = 0; n < 3 * d; ++n) {
+        double acc = 0.0;
+        for (int k = 0; k < d; ++k) acc += (double)ab[k] * (double)ws[n / d][(size_t)k * d + (n % d)];
+        bqkv[n] = (float)((double)bs[n / d][n % d] + acc);
+      }
+      UP(bqkv, W.bqkv);
+      UP4(pack_b(d, d, [&](int k, int n) { return wo[(size_t)k * d + n]; }), W.wo);
+      UP(vec_of(bo, d), W.bo);
+      UP(vec_of(pu, d), W.pos_u);
+      UP(vec_of(pv, d), W.pos_v);
+      const float* wpos_dev = nullptr;
+      UP(vec_of(wp, (size_t)d * d), wpos_dev);
+      const float* bpos_dev = nullptr;
+      UP(vec_of(bp, d), bpos_dev);
+      void* pt = nullptr;
+      HIP_TRY(hipMalloc(&pt, (size_t)max_len * d * sizeof(float)));
+      m->allocs.push_back(pt);
+      launch_posproj(pe_dev, wpos_dev, bpos_dev, static_cast<float*>(pt), max_len, nullptr);
+      HIP_TRY(hipGetLastError());
+      W.ptab = static_cast<const float*>(pt);
+    }
+    {
+      GETW(p1w, p + "conv_module.pointwise_conv1.weight", 2 * d * d);
+      GETW(p1b, p + "conv_module.pointwise_conv1.bias", 2 * d);
+      GETW(dww, p + "conv_module.depthwise_conv.weight", d * KS);
+      GETW(dwb, p + "conv_module.depthwise_conv.bias", d);
+      GETW(p2w, p + "conv_module.pointwise_conv2.weight", d * d);
+      GETW(p2b, p + "conv_module.pointwise_conv2.bias", d);
+      GETW(as, p + "conv_module.ada_scale", d);
+      GETW(ab, p + "conv_module.ada_bias", d);
+      UP4(pack_b(d, 2 * d, [&](int k, int n) { return as[k] * p1w[(size_t)n * d + k]; }), W.pw1);
+      std::vector<float> b1f(2 * d), gp(d);
+      for (int n = 0; n < 2 * d; ++n) {
+        double acc = 0.0;
+        for (int k = 0; k < d; ++k) acc += (double)ab[k] * (double)p1w[(size_t)n * d + k];
+        b1f[n] = (float)((double)p1b[n] + acc);
+      }
+      // zero-padded / PAD frames see pointwise_conv1(0) = the ORIGINAL bias (mask is applied after the scale)
+      for (int c = 0; c < d; ++c) gp[c] = p1b[c] * (1.0f / (1.0f + expf(-p1b[c + d])));
+      UP(b1f, W.pw1_b);
+      UP(gp, W.glu_pad);
+      std::vector<float> dwt((size_t)KS * d);
+      for (int c = 0; c < d; ++c)
+        for (int j = 0; j < KS; ++j) dwt[(size_t)j * d + c] = dww[(size_t)c * KS + j];
+      UP(dwt, W.dw_w);
+      UP(vec_of(dwb, d), W.dw_b);
+      UP4(pack_b(d, d, [&](int k, int n) { return p2w[(size_t)n * d + k]; }), W.pw2);
+      UP(vec_of(p2b, d), W.pw2_b);
+    }
+  }
+  if (dsc.reduce_idx >= 0) {
+    GETW(rdw, "encoder.time_reduction_layer.dw_conv.weight", d);
+    GETW(rdb, "encoder.time_reduction_layer.dw_conv.bias", d);
+    GETW(rpw, "encoder.time_reduction_layer.pw_conv.weight", d * d);
+    GETW(rpb, "encoder.time_reduction_layer.pw_conv.bias", d);
+    GETW(rw, "encoder.time_recover_layer.weight", d * d);
+    GETW(rb, "encoder.time_recover_layer.bias", d);
+    UP(vec_of(rdw, d), m->sq_reduce.dw_w);
+    UP(vec_of(rdb, d), m->sq_reduce.dw_b);
+    UP4(pack_b(d, d, [&](int k, int n) { return rpw[(size_t)n * d + k]; }), m->sq_reduce.pw);
+    UP(vec_of(rpb, d), m->sq_reduce.pw_b);
+    UP4(pack_b(d, d, [&](int k, int n) { return rw[(size_t)k * d + n]; }), m->sq_wrec);
+    UP(vec_of(rb, d), m->sq_brec);
+  }
+  {
+    GETW(cw, "ctc.ctc_lo.weight", (size_t)d * V);
+    GETW(cb, "ctc.ctc_lo.bias", V);
+    m->head.ln_g = nullptr;  // no after_norm in Squeezeformer
+    m->head.ln_b = nullptr;
+    m->head.V = V;
+    m->head.n_tiles = (V + 31) / 32;
+    UP4(pack_b(d, V, [&](int k, int n) { return cw[(size_t)k * V + n]; }), m->head.w);
+    std::vector<float> cbp((size_t)m->head.n_tiles * 32, 0.f);
+    std::memcpy(cbp.data(), cb, V * sizeof(float));
+    UP(cbp, m->head.b);
+  }
+  return PPASR_OK;
+}
+
+// SqueezeformerEncoder.forward (squeezeformer/encoder.py:172-236) + ctc softmax
+ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const int64_t* lens, int B, int T, float* probs,
+                                  float* logits, int32_t* frame_argmax, float* frame_maxprob, float* ws,
+                                  const WsLayout& wl, hipStream_t st) {
+  const int F = h->desc.input_dim, T1 = (T - 1) / 2, F1 = h->F1, Tp = (T1 - 1) / 2, F2 = h->F2;
+  const int Tr = (Tp + 1) / 2;  // Conv1D(k=1, stride 2): ceil(T'/2) frames (time_reduction.py:186,196-199)
+  const int M = B * Tp, L = h->desc.num_blocks, H = h->desc.attention_heads;
+  const int n_chunks = h->desc.linear_units / 256, KS = h->desc.cnn_module_kernel;
+  float *y1 = ws + wl.y1, *y2 = ws + wl.y2, *xa = ws + wl.xa, *xb = ws + wl.xb, *xc = ws + wl.xc;
+  float *qkv = ws + wl.qkv, *ctx = ws + wl.ctx, *g = ws + wl.g, *xs = ws + wl.xs;
+  size_t tap_off = 0;
+  auto tap = [&](const float* src, size_t n) {
+    if (h->taps && tap_off + n <= h->taps_floats)
+      (void)hipMemcpyAsync(h->taps + tap_off, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    tap_off += n;
+  };
+  launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st);
+  launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st);
+  launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/true, st);
+  launch_ln_rows(xa, h->preln_g, h->preln_b, M, st);
+  tap(xa, (size_t)M * kD);
+  float* x = xa;      // current layer input / residual
+  float* other = xb;  // ping-pong partner
+  bool reduced = false;
+  bool have_qkv = false;
+  for (int i = 0; i < L; ++i) {
+    const SqLayerW& W = h->sq_layers[i];
+    if (i == h->desc.reduce_idx) {
+      // recover_activations.append(xs) ; time_reduction_layer ; pos_emb[:, ::2]  (encoder.py:210-216)
+      HIP_TRY(hipMemcpyAsync(xs, x, (size_t)M * kD * sizeof(float), hipMemcpyDeviceToDevice, st));
+      launch_sq_reduce(x, other, qkv, h->sq_reduce, W.wqkv, W.bqkv, lens, B, Tp, Tr, st);
+      std::swap(x, other);
+      reduced = true;
+      have_qkv = true;
+    }
+    if (i == h->desc.recover_idx && reduced) {
+      launch_sq_recover(x, xs, other, qkv, h->sq_wrec, h->sq_brec, W.wqkv, W.bqkv, B, Tp, Tr, st);
+      std::swap(x, other);
+      reduced = false;
+      have_qkv = true;
+    }
+    const int Ti = reduced ? Tr : Tp;
+    const int Mi = B * Ti;
+    const int mul = reduced ? 8 : 4;
+    if (!have_qkv) launch_sq_qkv(x, qkv, W.wqkv, W.bqkv, Mi, st);
+    tap(qkv, (size_t)Mi * 3 * kD);
+    AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Ti, Ti, 0, lens, ctx, W.pos_u, W.pos_v, W.ptab, reduced ? 2 : 1, mul};
+    launch_attention(a, B, H, st);
+    tap(ctx, (size_t)Mi * kD);
+    launch_sq_mid(ctx, x, xc, g, W, lens, Mi, Ti, mul, n_chunks, st);
+    tap(xc, (size_t)Mi * kD);
+    tap(g, (size_t)Mi * kD);
+    const bool fuse_next = (i + 1 < L) && (i + 1 != h->desc.reduce_idx) && !(i + 1 == h->desc.recover_idx && reduced);
+    const SqLayerW* Wn = fuse_next ? &h->sq_layers[i + 1] : nullptr;
+    launch_sq_tail(g, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, lens, Mi, Ti, mul, n_chunks, KS,
+                   st);
+    std::swap(x, other);
+    have_qkv = fuse_next;
+    tap(x, (size_t)Mi * kD);
+  }
+  float* lg = logits ? logits : probs;
+  int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
+  float* fp = frame_maxprob ? frame_maxprob : ws + wl.fp;
+  launch_ctc_head(x, h->head, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, M, st);
+  if (probs) {
+    if (logits)
+      HIP_TRY(hipMemcpyAsync(probs, logits, (size_t)M * h->head.V * sizeof(float), hipMemcpyDeviceToDevice, st));
+    launch_softmax_from_stats(probs, ws + wl.rmax, ws + wl.rsum, M, h->head.V, st);
+  }
+  HIP_TRY(hipGetLastError());
+  return PPASR_OK;
+}

@@ -50,15 +50,23 @@ struct AttnArgs {
   int pos0;             // position of key 0 in the positional table (encoder.py:253: offset - cache_t1)
   const int64_t* lens;  // feature lengths for the key-padding mask, or nullptr (streaming: no mask)
   float* ctx;           // [B*T1][256]
+  const float *pos_u, *pos_v;  // [256] = [h][dk]
+  const float* ptab;           // [max_len][256] projected positional table of this layer
+  int pos_stride;       // key j uses table row pos0 + j*pos_stride (2 on Squeezeformer's time-reduced layers)
+  int mask_mul;         // key j is PAD iff mask_mul*j >= len (4; 8 on time-reduced layers)
 };
 
 // ---- launchers (all asynchronous on `st`) ----
-void launch_posproj(const float* pe, const float* wpos /*[256][256] in,out*/, float* ptab, int max_len, hipStream_t st);
+void launch_posproj(const float* pe, const float* wpos /*[256][256] in,out*/, const float* bpos_or_null, float* ptab,
+                    int max_len, hipStream_t st);
 void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T, int F, int T1, int F1, hipStream_t st);
 void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st);
-void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, hipStream_t st);
+// scale_before_bias: Squeezeformer scales the 4864-wide conv output by sqrt(d) BEFORE input_proj
+// (squeezeformer/subsampling.py:66-67) -> acc*scale + b ; Conformer: (acc + b)*scale (embedding.py:112)
+void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, bool scale_before_bias,
+                  hipStream_t st);
 void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st);
-void launch_attention(const AttnArgs& a, const LayerW& w, int B, int H, hipStream_t st);
+void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
                     const int64_t* lens, int M, int Tp, hipStream_t st);
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
@@ -71,6 +79,7 @@ void launch_cache_export(const float* kc, const float* vc, float* att, int T, hi
 void launch_cache_import(const float* att, float* kc, float* vc, int T, hipStream_t st);
 void launch_cnn_transpose(const float* src, float* dst, int lo, int to_ref, hipStream_t st);
 void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStream_t st);
+// hw.ln_g == nullptr: no final LayerNorm (Squeezeformer has no after_norm, squeezeformer/encoder.py:232-235)
 void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr_argmax, float* fr_maxprob,
                      float* row_max, float* row_sum, int M, hipStream_t st);
 void launch_softmax_from_stats(float* probs_inout, const float* row_max, const float* row_sum, int M, int V,

@@ -3,6 +3,7 @@
 // subsampling,embedding}.py, model_utils/loss/ctc.py, decoders/ctc_greedy_decoder.py
 // (file:line cited per kernel).  All arithmetic is fp32 (the reference's inference dtype).
 #include "conformer_kernels.h"
+#include "phases.h"
 
 #include <math.h>
 
@@ -12,8 +13,8 @@ namespace ppasr {
 // create-time: ptab[pos][n] = sum_k pe[pos][k] * Wpos[k][n]   (attention.py:234, bias-free)
 // weight-only constant folding; not on the timed path, so a plain fmaf kernel.
 // =====================================================================================
-__global__ void k_posproj(const float* __restrict__ pe, const float* __restrict__ wpos, float* __restrict__ ptab,
-                          int max_len) {
+__global__ void k_posproj(const float* __restrict__ pe, const float* __restrict__ wpos,
+                          const float* __restrict__ bpos, float* __restrict__ ptab, int max_len) {
   int pos = blockIdx.x;
   int n = threadIdx.x;
   __shared__ float row[kD];
@@ -21,10 +22,11 @@ __global__ void k_posproj(const float* __restrict__ pe, const float* __restrict_
   __syncthreads();
   float acc = 0.f;
   for (int k = 0; k < kD; ++k) acc = fmaf(row[k], wpos[k * kD + n], acc);
+  if (bpos) acc += bpos[n];  // Squeezeformer / Efficient-Conformer linear_pos has a bias
   ptab[(size_t)pos * kD + n] = acc;
 }
-void launch_posproj(const float* pe, const float* wpos, float* ptab, int max_len, hipStream_t st) {
-  hipLaunchKernelGGL(k_posproj, dim3(max_len), dim3(kD), 0, st, pe, wpos, ptab, max_len);
+void launch_posproj(const float* pe, const float* wpos, const float* bpos, float* ptab, int max_len, hipStream_t st) {
+  hipLaunchKernelGGL(k_posproj, dim3(max_len), dim3(kD), 0, st, pe, wpos, bpos, ptab, max_len);
 }
 
 // =====================================================================================
@@ -91,7 +93,7 @@ struct DenseSrc {
   __device__ __forceinline__ size_t chunk_off(int kc) const { return (size_t)kc * KC; }
 };
 
-template <int MT, int KC, bool RELU, typename Src>
+template <int MT, int KC, bool RELU, bool SB, typename Src>
 __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ out, int M,
                                                           int n_chunks, float scale) {
@@ -150,9 +152,8 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int m = r0 + mt * 32 + acc_row(r, lane);
-      float v = acc[mt][0][r] + bv;
+      float v = SB ? acc[mt][0][r] * scale + bv : (acc[mt][0][r] + bv) * scale;
       if (RELU) v = fmaxf(v, 0.f);
-      v *= scale;
       if (m < M) out[(size_t)m * kD + col] = v;
     }
 }
@@ -162,93 +163,25 @@ void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, i
   int M = B * Tp * F2;
   constexpr int MT = 4, KC = 64;
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
-  hipLaunchKernelGGL((k_gemm_stream<MT, KC, true, Conv2Src>), dim3((M + 32 * MT - 1) / (32 * MT)), dim3(kThreads), lds, st, src,
+  hipLaunchKernelGGL((k_gemm_stream<MT, KC, true, false, Conv2Src>), dim3((M + 32 * MT - 1) / (32 * MT)), dim3(kThreads), lds, st, src,
                      fw.conv2_w, fw.conv2_b, y2, M, 36, 1.0f);
 }
-void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, hipStream_t st) {
+void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, bool scale_before_bias,
+                  hipStream_t st) {
   constexpr int MT = 1, KC = 256;
   DenseSrc src{y2, K, KC};
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
-  hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src, fw.embed_w,
-                     fw.embed_b, x0, M, K / KC, xscale);
+  if (scale_before_bias)
+    hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, true, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src,
+                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale);
+  else
+    hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src,
+                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale);
 }
 
 // =====================================================================================
 // Row-block phases shared by the per-layer kernels
 // =====================================================================================
-
-// Epilogue slice of the previous W1 tile, interleaved with the MFMAs of the next one:
-// H[row][col] = swish(acc + b1)   (two accumulator registers per k-group pair)
-struct SwishSide {
-  const f32x16& acc;
-  float* hb;
-  float bias;
-  int lane, col;
-  __device__ __forceinline__ void operator()(int g) const {
-    if ((g & 1) == 0) {
-      const int r = g >> 1;
-      hb[acc_row(r, lane) * kLda + col] = swishf(acc[r] + bias);
-    }
-  }
-};
-
-// PositionwiseFeedForward (positionwise.py:32-39): acc2 += swish(A*W1 + b1) * W2.  The hidden
-// dimension is processed in 256-wide chunks that never leave LDS (double-buffered bufH); wave w
-// owns hidden columns [32w,32w+32) of each chunk and output columns [32w,32w+32).
-// Weight stream order: W1(0), W1(1), W2(0), W1(2), W2(1), ..., W2(n-1), then `after`.
-// The swish epilogue of chunk c runs inside the W1(c+1) MFMA stream.
-__device__ __forceinline__ void ffn_phase(const float* bufA, float* bufH, const f32x4* __restrict__ w1,
-                                          const float* __restrict__ b1, const f32x4* __restrict__ w2, int n_chunks,
-                                          const f32x4* __restrict__ after, BRing<1>& ring, f32x16 (&acc2)[1][1]) {
-  const int lane = lane_id(), wave = wave_id();
-  const int ts2 = n_chunks * 32 * 64;  // W2: K = hidden
-  const int col = wave * 32 + (lane & 31);
-  auto w1seg = [&](int c) { return w1 + (size_t)(c * 8 + wave) * kTs256; };
-  auto w2seg = [&](int c) { return w2 + (size_t)wave * ts2 + (size_t)c * 32 * 64; };
-  f32x16 cur[1][1], nx[1][1];
-  acc_zero(cur);
-  rb_gemm<1, 1, kG256>(bufA, kLda, w1seg(0), 0, n_chunks > 1 ? w1seg(1) : w2seg(0), 0, ring, cur);
-  for (int c = 0; c < n_chunks; ++c) {
-    float* hb = bufH + (c & 1) * kRows * kLda;
-    const float bias = b1[c * 256 + col];
-    if (c + 1 < n_chunks) {
-      acc_zero(nx);
-      rb_gemm<1, 1, kG256>(bufA, kLda, w1seg(c + 1), 0, w2seg(c), 0, ring, nx, SwishSide{cur[0][0], hb, bias, lane, col});
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hb[acc_row(r, lane) * kLda + col] = swishf(cur[0][0][r] + bias);
-    }
-    __syncthreads();
-    const f32x4* nseg = (c + 2 < n_chunks) ? w1seg(c + 2) : (c + 1 < n_chunks ? w2seg(c + 1) : after);
-    rb_gemm<1, 1, kG256>(hb, kLda, w2seg(c), 0, nseg, 0, ring, acc2);
-    cur[0][0] = nx[0][0];
-  }
-}
-
-// bufX[row][col] += scale * (acc + bias[col])    (residual update, each element owned by one lane)
-__device__ __forceinline__ void residual_epilogue(float* bufX, const f32x16 (&acc)[1][1], const float* __restrict__ bias,
-                                                  float scale) {
-  const int lane = lane_id(), wave = wave_id();
-  const int col = wave * 32 + (lane & 31);
-  const float bv = bias[col];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float* p = bufX + acc_row(r, lane) * kLda + col;
-    *p = *p + scale * (acc[0][0][r] + bv);
-  }
-}
-
-struct PadRows {  // conv-module pad masking (convolution.py:104-106,138-140): frame t of utterance b is PAD iff 4t >= len[b]
-  const int64_t* lens;
-  int r0, Tp, M;
-  __device__ __forceinline__ bool operator()(int row) const {
-    if (!lens) return false;
-    int m = r0 + row;
-    if (m >= M) return false;
-    int b = m / Tp, t = m - b * Tp;
-    return 4 * (int64_t)t >= lens[b];
-  }
-};
 
 // -------------------------------------------------------------------------------------
 // S1: x1 = x + 0.5*FFN_macaron(LN(x)) ; qkv = LN_mha(x1) * [Wq|Wk|Wv] + b
@@ -312,7 +245,7 @@ constexpr int kQld = 132, kSld = 129, kKld = 36, kVld = 68;
 constexpr int kAttnLdsFloats = 32 * kQld + 32 * kSld + 128 * kVld + 96;
 constexpr size_t kLdsAttn = kAttnLdsFloats * sizeof(float);
 
-__global__ __launch_bounds__(256) void k_attention(AttnArgs a, LayerW w) {
+__global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;               // [32][132]  Q' = [q+u | q+v]
   float* Ss = Qs + 32 * kQld;     // [32][129]  scores / probabilities of the current key block
@@ -326,9 +259,10 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a, LayerW w) {
   const float* __restrict__ qb = a.q + (size_t)b * T1 * a.q_stride;
   const float* __restrict__ kbp = a.k + (size_t)b * T2 * a.k_stride;
   const float* __restrict__ vbp = a.v + (size_t)b * T2 * a.v_stride;
-  const float* __restrict__ ptab = w.ptab + (size_t)a.pos0 * kD;
+  const float* __restrict__ ptab = a.ptab + (size_t)a.pos0 * kD;
+  const int pstride = a.pos_stride;
   float* __restrict__ ctx = a.ctx + (size_t)b * T1 * kD;
-  const int64_t len_b = a.lens ? a.lens[b] : (int64_t)4 * T2;
+  const int64_t len_b = a.lens ? a.lens[b] : (int64_t)a.mask_mul * T2;
 
   // ---- Q' ----
 #pragma unroll
@@ -337,8 +271,8 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a, LayerW w) {
     int row = idx >> 4, f4 = idx & 15;
     f32x4 q = {0.f, 0.f, 0.f, 0.f};
     if (q0 + row < T1) q = *reinterpret_cast<const f32x4*>(qb + (size_t)(q0 + row) * a.q_stride + h * 64 + f4 * 4);
-    f32x4 u = *reinterpret_cast<const f32x4*>(w.pos_u + h * 64 + f4 * 4);
-    f32x4 v = *reinterpret_cast<const f32x4*>(w.pos_v + h * 64 + f4 * 4);
+    f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + h * 64 + f4 * 4);
+    f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + h * 64 + f4 * 4);
     *reinterpret_cast<f32x4*>(Qs + row * kQld + f4 * 4) = q + u;
     *reinterpret_cast<f32x4*>(Qs + row * kQld + 64 + f4 * 4) = q + v;
   }
@@ -367,7 +301,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a, LayerW w) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (key0 + key < T2) {
           const float* p = (fc < 2) ? kbp + (size_t)(key0 + key) * a.k_stride + h * 64 + fc * 32 + f4 * 4
-                                    : ptab + (size_t)(key0 + key) * kD + h * 64 + (fc - 2) * 32 + f4 * 4;
+                                    : ptab + (size_t)(key0 + key) * pstride * kD + h * 64 + (fc - 2) * 32 + f4 * 4;
           v = *reinterpret_cast<const f32x4*>(p);
         }
         stg[i] = v;
@@ -410,7 +344,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a, LayerW w) {
     {
       const int kl = wave * 32 + (lane & 31);
       const int key = key0 + kl;
-      const bool masked = (key >= T2) || (4 * (int64_t)key >= len_b);
+      const bool masked = (key >= T2) || (a.mask_mul * (int64_t)key >= len_b);
 #pragma unroll
       for (int r = 0; r < 16; ++r) Ss[acc_row(r, lane) * kSld + kl] = masked ? -INFINITY : acc_s[r] * 0.125f;
     }
@@ -479,8 +413,8 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a, LayerW w) {
     }
   }
 }
-void launch_attention(const AttnArgs& a, const LayerW& w, int B, int H, hipStream_t st) {
-  hipLaunchKernelGGL(k_attention, dim3((a.T1 + 31) / 32, H, B), dim3(256), kLdsAttn, st, a, w);
+void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st) {
+  hipLaunchKernelGGL(k_attention, dim3((a.T1 + 31) / 32, H, B), dim3(256), kLdsAttn, st, a);
 }
 
 // -------------------------------------------------------------------------------------
@@ -678,45 +612,10 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   const int r0 = blockIdx.x * kRows;
   const int valid = min(kRows, M - r0);
   const int col = wave * 32 + (lane & 31);
-  constexpr int LO = KS - 1;
-  constexpr int RW = kRows / kWaves;  // rows per wave in the depthwise stage
   BRing<1> ring;
   const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
   ring_prime(ring, seg_pw2, 0);
-  {
-    // wave handles block rows RW*w .. RW*w+RW-1; lane handles channels 4*lane..4*lane+3
-    const int m0 = r0 + wave * RW;
-    f32x4 win[LO + RW];
-#pragma unroll
-    for (int q = 0; q < LO + RW; ++q) {
-      int mq = m0 - LO + q;
-      if (STREAM && mq < 0)  // single stream: rows are frames; frames before the chunk come from the cache
-        win[q] = *reinterpret_cast<const f32x4*>(g_hist + (size_t)(LO + mq) * kD + 4 * lane);
-      else
-        win[q] = (mq >= 0 && mq < M) ? *reinterpret_cast<const f32x4*>(g + (size_t)mq * kD + 4 * lane)
-                                     : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const f32x4 gp = *reinterpret_cast<const f32x4*>(w.glu_pad + 4 * lane);
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(w.dw_b + 4 * lane);
-    f32x4 out[RW];
-    int t_of[RW];
-#pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      out[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      t_of[i] = (m0 + i) % Tp;
-    }
-#pragma unroll
-    for (int j = 0; j < KS; ++j) {
-      const f32x4 wj = *reinterpret_cast<const f32x4*>(w.dw_w + j * kD + 4 * lane);
-#pragma unroll
-      for (int i = 0; i < RW; ++i) {
-        f32x4 v = (STREAM || t_of[i] - LO + j >= 0) ? win[i + j] : gp;
-        out[i] += wj * v;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < RW; ++i) *reinterpret_cast<f32x4*>(bufA + (wave * RW + i) * kLda + 4 * lane) = out[i] + bias;
-  }
+  dwconv_phase<KS, STREAM>(g, g_hist, bufA, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp);
   __syncthreads();
   // conv-module LayerNorm (nn.LayerNorm(channels), eps 1e-5, convolution.py:71) + swish, in place
   rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
@@ -794,7 +693,7 @@ __global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__
   BRing<1> ring;
   if (wave < hw.n_tiles) ring_prime(ring, hw.w + (size_t)wave * kTs256, 0);
   rb_load_rows(bufA, kLda, x + (size_t)r0 * kD, kRows, valid);
-  rb_layernorm(bufA, bufA, kLda, kRows, hw.ln_g, hw.ln_b, 1e-5f);
+  if (hw.ln_g) rb_layernorm(bufA, bufA, kLda, kRows, hw.ln_g, hw.ln_b, 1e-5f);
   __syncthreads();
   float mx[16], sm[16];
   int ix[16];
@@ -1016,8 +915,9 @@ hipError_t configure_kernels() {
   SET_LDS(k_pw1_glu, kLdsPw1Glu);
   SET_LDS(k_ctc_head<true>, kLdsCtc);
   SET_LDS(k_ctc_head<false>, kLdsCtc);
-  SET_LDS((k_gemm_stream<4, 64, true, Conv2Src>), 2 * 128 * 68 * sizeof(float));
-  SET_LDS((k_gemm_stream<1, 256, false, DenseSrc>), 2 * 32 * 260 * sizeof(float));
+  SET_LDS((k_gemm_stream<4, 64, true, false, Conv2Src>), 2 * 128 * 68 * sizeof(float));
+  SET_LDS((k_gemm_stream<1, 256, false, false, DenseSrc>), 2 * 32 * 260 * sizeof(float));
+  SET_LDS((k_gemm_stream<1, 256, false, true, DenseSrc>), 2 * 32 * 260 * sizeof(float));
 #undef SET_LDS
   return hipSuccess;
 }

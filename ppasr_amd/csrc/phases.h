@@ -1,0 +1,130 @@
+// phases.h -- row-block phase functions shared by the encoder kernels (Conformer, Squeezeformer,
+// Efficient-Conformer): FFN with LDS-resident hidden chunks, residual epilogue, causal depthwise
+// conv, pad-row predicate.  See rowblock.h for the execution model.
+#pragma once
+#include "rowblock.h"
+
+namespace ppasr {
+
+// Epilogue slice of the previous W1 tile, interleaved with the MFMAs of the next one:
+// H[row][col] = swish(acc + b1)   (two accumulator registers per k-group pair)
+struct SwishSide {
+  const f32x16& acc;
+  float* hb;
+  float bias;
+  int lane, col;
+  __device__ __forceinline__ void operator()(int g) const {
+    if ((g & 1) == 0) {
+      const int r = g >> 1;
+      hb[acc_row(r, lane) * kLda + col] = swishf(acc[r] + bias);
+    }
+  }
+};
+
+// PositionwiseFeedForward (positionwise.py:32-39): acc2 += swish(A*W1 + b1) * W2.  The hidden
+// dimension is processed in 256-wide chunks that never leave LDS (double-buffered bufH); wave w
+// owns hidden columns [32w,32w+32) of each chunk and output columns [32w,32w+32).
+// Weight stream order: W1(0), W1(1), W2(0), W1(2), W2(1), ..., W2(n-1), then `after`.
+// The swish epilogue of chunk c runs inside the W1(c+1) MFMA stream.
+__device__ __forceinline__ void ffn_phase(const float* bufA, float* bufH, const f32x4* __restrict__ w1,
+                                          const float* __restrict__ b1, const f32x4* __restrict__ w2, int n_chunks,
+                                          const f32x4* __restrict__ after, BRing<1>& ring, f32x16 (&acc2)[1][1]) {
+  const int lane = lane_id(), wave = wave_id();
+  const int ts2 = n_chunks * 32 * 64;  // W2: K = hidden
+  const int col = wave * 32 + (lane & 31);
+  auto w1seg = [&](int c) { return w1 + (size_t)(c * 8 + wave) * kTs256; };
+  auto w2seg = [&](int c) { return w2 + (size_t)wave * ts2 + (size_t)c * 32 * 64; };
+  f32x16 cur[1][1], nx[1][1];
+  acc_zero(cur);
+  rb_gemm<1, 1, kG256>(bufA, kLda, w1seg(0), 0, n_chunks > 1 ? w1seg(1) : w2seg(0), 0, ring, cur);
+  for (int c = 0; c < n_chunks; ++c) {
+    float* hb = bufH + (c & 1) * kRows * kLda;
+    const float bias = b1[c * 256 + col];
+    if (c + 1 < n_chunks) {
+      acc_zero(nx);
+      rb_gemm<1, 1, kG256>(bufA, kLda, w1seg(c + 1), 0, w2seg(c), 0, ring, nx, SwishSide{cur[0][0], hb, bias, lane, col});
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hb[acc_row(r, lane) * kLda + col] = swishf(cur[0][0][r] + bias);
+    }
+    __syncthreads();
+    const f32x4* nseg = (c + 2 < n_chunks) ? w1seg(c + 2) : (c + 1 < n_chunks ? w2seg(c + 1) : after);
+    rb_gemm<1, 1, kG256>(hb, kLda, w2seg(c), 0, nseg, 0, ring, acc2);
+    cur[0][0] = nx[0][0];
+  }
+}
+
+// bufX[row][col] += scale * (acc + bias[col])    (residual update, each element owned by one lane)
+__device__ __forceinline__ void residual_epilogue(float* bufX, const f32x16 (&acc)[1][1], const float* __restrict__ bias,
+                                                  float scale) {
+  const int lane = lane_id(), wave = wave_id();
+  const int col = wave * 32 + (lane & 31);
+  const float bv = bias[col];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float* p = bufX + acc_row(r, lane) * kLda + col;
+    *p = *p + scale * (acc[0][0][r] + bv);
+  }
+}
+
+struct PadRows {  // conv-module pad masking (convolution.py:104-106,138-140): frame t of utterance b is PAD iff
+                  // mul*t >= len[b]  (mul = 4 after the conv front-end, 8 on time-reduced rows)
+  const int64_t* lens;
+  int r0, Tp, M;
+  int mul = 4;
+  __device__ __forceinline__ bool operator()(int row) const {
+    if (!lens) return false;
+    int m = r0 + row;
+    if (m >= M) return false;
+    int b = m / Tp, t = m - b * Tp;
+    return mul * (int64_t)t >= lens[b];
+  }
+};
+
+
+// Causal depthwise conv over the GLU output g [M][256] (row = frame): KS taps, left context KS-1.
+// Frames before the utterance start read `gp` = GLU(pointwise_conv1(0)) because the reference
+// zero-pads BEFORE pointwise_conv1 (convolution.py:108-126); with STREAM (single stream, rows are
+// frames of one chunk) they come from the cache rows g_hist [KS-1][256] instead.
+// Output (conv + bias) -> bufA rows.  wave handles rows RW*w..; lane handles 4 channels.
+template <int KS, bool STREAM>
+__device__ __forceinline__ void dwconv_phase(const float* __restrict__ g, const float* __restrict__ g_hist, float* bufA,
+                                             const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+                                             const float* __restrict__ glu_pad, int r0, int M, int Tp) {
+  const int lane = lane_id(), wave = wave_id();
+  constexpr int LO = KS - 1;
+  constexpr int RW = kRows / kWaves;
+  const int m0 = r0 + wave * RW;
+  f32x4 win[LO + RW];
+#pragma unroll
+  for (int q = 0; q < LO + RW; ++q) {
+    int mq = m0 - LO + q;
+    if (STREAM && mq < 0)
+      win[q] = *reinterpret_cast<const f32x4*>(g_hist + (size_t)(LO + mq) * kD + 4 * lane);
+    else
+      win[q] = (mq >= 0 && mq < M) ? *reinterpret_cast<const f32x4*>(g + (size_t)mq * kD + 4 * lane)
+                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const f32x4 gp = *reinterpret_cast<const f32x4*>(glu_pad + 4 * lane);
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(dw_b + 4 * lane);
+  f32x4 out[RW];
+  int t_of[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    out[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    t_of[i] = (m0 + i) % Tp;
+  }
+#pragma unroll
+  for (int j = 0; j < KS; ++j) {
+    const f32x4 wj = *reinterpret_cast<const f32x4*>(dw_w + j * kD + 4 * lane);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      f32x4 v = (STREAM || t_of[i] - LO + j >= 0) ? win[i + j] : gp;
+      out[i] += wj * v;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RW; ++i) *reinterpret_cast<f32x4*>(bufA + (wave * RW + i) * kLda + 4 * lane) = out[i] + bias;
+}
+
+}  // namespace ppasr

@@ -1,0 +1,38 @@
+// squeezeformer_kernels.h -- launch interface of the Squeezeformer row-block kernels
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rowblock.h"
+
+namespace ppasr {
+
+// One SqueezeformerEncoderLayer (squeezeformer/encoder.py:386-433); adaptive scale folded into
+// wqkv / ff*_w1 / pw1 (+ their biases) at pack time.
+struct SqLayerW {
+  const f32x4 *wqkv, *wo, *ff1_w1, *ff1_w2, *pw1, *pw2, *ff2_w1, *ff2_w2;
+  const float *bqkv, *bo, *ff1_b1, *ff1_b2, *pw1_b, *pw2_b, *ff2_b1, *ff2_b2;
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b, *ln4_g, *ln4_b, *ln_cm_g, *ln_cm_b;
+  const float *dw_w, *dw_b, *glu_pad;
+  const float *pos_u, *pos_v, *ptab;
+};
+struct SqReduceW {
+  const float *dw_w, *dw_b;  // [256] depthwise k=1 stride-2 conv
+  const f32x4* pw;           // packed 256x256
+  const float* pw_b;
+};
+
+void launch_sq_qkv(const float* x, float* qkv, const f32x4* wqkv, const float* bqkv, int M, hipStream_t st);
+void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, const SqLayerW& w, const int64_t* lens, int M,
+                   int Tp, int mask_mul, int n_chunks, hipStream_t st);
+void launch_sq_tail(const float* g, const float* x2, float* x_out, float* qkv_next, const SqLayerW& w,
+                    const f32x4* wqkv_next, const float* bqkv_next, const int64_t* lens, int M, int Tp, int mask_mul,
+                    int n_chunks, int ksize, hipStream_t st);
+void launch_sq_reduce(const float* x, float* xr, float* qkv, const SqReduceW& rw, const f32x4* wqkv, const float* bqkv,
+                      const int64_t* lens, int B, int Tp, int Tr, hipStream_t st);
+void launch_sq_recover(const float* xr, const float* saved, float* x, float* qkv, const f32x4* wrec, const float* brec,
+                       const f32x4* wqkv, const float* bqkv, int B, int Tp, int Tr, hipStream_t st);
+void launch_ln_rows(float* x, const float* g, const float* b, int M, hipStream_t st);
+hipError_t configure_squeezeformer_kernels();
+
+}  // namespace ppasr

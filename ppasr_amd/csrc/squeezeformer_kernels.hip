@@ -1,0 +1,343 @@
+// squeezeformer_kernels.hip -- row-block kernels of the Squeezeformer encoder layer
+// (ppasr/model_utils/squeezeformer/encoder.py:386-506: post-LN, order MHA -> FFN -> Conv -> FFN),
+// time reduction / recovery (encoder.py:210-230, time_reduction.py:183-206) built from phases.h.
+//
+// Adaptive scale (x <- ada_scale*x + ada_bias in front of MHA / FFN / conv module,
+// attention.py:120-123, positionwise.py:63-64, convolution.py:119-120) is folded into the following
+// dense layer on the host:  (s.x + a) W + c = x (diag(s) W) + (a W + c).  The conv module zeroes PAD
+// frames AFTER the scale (convolution.py:121-127), so PAD rows bypass the folded GEMM and take
+// GLU(bias) = `glu_pad` directly.
+#include "squeezeformer_kernels.h"
+
+#include "phases.h"
+
+namespace ppasr {
+
+// qkv = x * Wqkv' + b'  (first layer, after preln)
+__global__ __launch_bounds__(kThreads) void k_sq_qkv(const float* __restrict__ x, float* __restrict__ qkv,
+                                                     const f32x4* __restrict__ wqkv, const float* __restrict__ bqkv, int M) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufA = smem;
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, M - r0);
+  BRing<1> ring;
+  ring_prime(ring, wqkv + (size_t)wave * kTs256, 0);
+  rb_load_rows(bufA, kLda, x + (size_t)r0 * kD, kRows, valid);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    f32x16 acc[1][1];
+    acc_zero(acc);
+    const f32x4* seg = wqkv + (size_t)(c * 8 + wave) * kTs256;
+    rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, c < 2 ? seg + 8 * kTs256 : nullptr, 0, ring, acc);
+    const int col = c * 256 + wave * 32 + (lane & 31);
+    const float bv = bqkv[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = acc_row(r, lane);
+      if (row < valid) qkv[(size_t)(r0 + row) * 768 + col] = acc[0][0][r] + bv;
+    }
+  }
+}
+
+// shared tail: qkv = bufX * Wqkv + b  (ring already continues into wqkv tile `wave`)
+__device__ __forceinline__ void qkv_from_lds(const float* bufX, float* __restrict__ qkv, const f32x4* __restrict__ wqkv,
+                                             const float* __restrict__ bqkv, int r0, int valid, BRing<1>& ring) {
+  const int lane = lane_id(), wave = wave_id();
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    f32x16 acc[1][1];
+    acc_zero(acc);
+    const f32x4* seg = wqkv + (size_t)(c * 8 + wave) * kTs256;
+    rb_gemm<1, 1, kG256>(bufX, kLda, seg, 0, c < 2 ? seg + 8 * kTs256 : nullptr, 0, ring, acc);
+    const int col = c * 256 + wave * 32 + (lane & 31);
+    const float bv = bqkv[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = acc_row(r, lane);
+      if (row < valid) qkv[(size_t)(r0 + row) * 768 + col] = acc[0][0][r] + bv;
+    }
+  }
+}
+
+// K_B: x1 = LN1(x + ctx Wo + bo) ; x2 = LN2(x1 + FFN1(x1)) ; g = GLU(pw1(x2))   (encoder.py:469-497)
+__global__ __launch_bounds__(kThreads) void k_sq_mid(const float* __restrict__ ctx, const float* __restrict__ x,
+                                                     float* __restrict__ x2, float* __restrict__ g, SqLayerW w,
+                                                     const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
+                                                     int n_chunks) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufX = smem;
+  float* bufH = bufX + kRows * kLda;  // 2 buffers; bufH[0] doubles as the ctx staging tile
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, M - r0);
+  const int col = wave * 32 + (lane & 31);
+  BRing<1> ring;
+  const f32x4* seg_o = w.wo + (size_t)wave * kTs256;
+  const f32x4* seg_val = w.pw1 + (size_t)wave * kTs256;
+  const f32x4* seg_gate = w.pw1 + (size_t)(8 + wave) * kTs256;
+  ring_prime(ring, seg_o, 0);
+  rb_load_rows(bufH, kLda, ctx + (size_t)r0 * kD, kRows, valid);
+  __syncthreads();
+  {
+    f32x16 acc[1][1];
+    acc_zero(acc);
+    rb_gemm<1, 1, kG256>(bufH, kLda, seg_o, 0, w.ff1_w1 + (size_t)wave * kTs256, 0, ring, acc);
+    const float bv = w.bo[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = acc_row(r, lane);
+      float v = 0.f;
+      if (row < valid) v = x[(size_t)(r0 + row) * kD + col] + (acc[0][0][r] + bv);
+      bufX[row * kLda + col] = v;
+    }
+  }
+  __syncthreads();
+  rb_layernorm(bufX, bufX, kLda, kRows, w.ln1_g, w.ln1_b, 1e-5f);
+  __syncthreads();
+  f32x16 acc2[1][1];
+  acc_zero(acc2);
+  ffn_phase(bufX, bufH, w.ff1_w1, w.ff1_b1, w.ff1_w2, n_chunks, seg_val, ring, acc2);
+  residual_epilogue(bufX, acc2, w.ff1_b2, 1.0f);
+  __syncthreads();
+  rb_layernorm(bufX, bufX, kLda, kRows, w.ln2_g, w.ln2_b, 1e-5f);
+  rb_store_rows(x2 + (size_t)r0 * kD, bufX, kLda, kRows, valid);
+  __syncthreads();
+  {
+    f32x16 av[1][1], ag[1][1];
+    acc_zero(av);
+    acc_zero(ag);
+    rb_gemm<1, 1, kG256>(bufX, kLda, seg_val, 0, seg_gate, 0, ring, av);
+    rb_gemm<1, 1, kG256>(bufX, kLda, seg_gate, 0, nullptr, 0, ring, ag);
+    const float bval = w.pw1_b[col], bgate = w.pw1_b[kD + col];
+    const float gpad = w.glu_pad[col];
+    PadRows is_pad{lens, r0, Tp, M, mask_mul};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = acc_row(r, lane);
+      float v = (av[0][0][r] + bval) * sigmoidf(ag[0][0][r] + bgate);
+      if (is_pad(row)) v = gpad;
+      if (row < valid) g[(size_t)(r0 + row) * kD + col] = v;
+    }
+  }
+}
+constexpr size_t kLdsSqMid = 3 * kRows * kLda * sizeof(float);
+
+// K_C: x3 = LN3(x2 + mask(pw2(swish(LN(dwconv(g)))))) ; x4 = LN4(x3 + FFN2(x3)) ; [qkv of the next layer]
+template <int KS>
+__global__ __launch_bounds__(kThreads) void k_sq_tail(const float* __restrict__ g, const float* __restrict__ x2,
+                                                      float* __restrict__ x_out, float* __restrict__ qkv_next,
+                                                      SqLayerW w, const f32x4* __restrict__ wqkv_next,
+                                                      const float* __restrict__ bqkv_next,
+                                                      const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
+                                                      int n_chunks) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufX = smem;
+  float* bufA = bufX + kRows * kLda;
+  float* bufH = bufA + kRows * kLda;
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, M - r0);
+  const int col = wave * 32 + (lane & 31);
+  BRing<1> ring;
+  const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
+  ring_prime(ring, seg_pw2, 0);
+  dwconv_phase<KS, false>(g, nullptr, bufA, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp);
+  __syncthreads();
+  rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
+  __syncthreads();
+  PadRows is_pad{lens, r0, Tp, M, mask_mul};
+  {
+    f32x16 acc[1][1];
+    acc_zero(acc);
+    rb_gemm<1, 1, kG256>(bufA, kLda, seg_pw2, 0, w.ff2_w1 + (size_t)wave * kTs256, 0, ring, acc);
+    const float bv = w.pw2_b[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = acc_row(r, lane);
+      float v = 0.f;
+      if (row < valid) {
+        float c = is_pad(row) ? 0.f : acc[0][0][r] + bv;
+        v = x2[(size_t)(r0 + row) * kD + col] + c;
+      }
+      bufX[row * kLda + col] = v;
+    }
+  }
+  __syncthreads();
+  rb_layernorm(bufX, bufX, kLda, kRows, w.ln3_g, w.ln3_b, 1e-5f);
+  __syncthreads();
+  f32x16 acc2[1][1];
+  acc_zero(acc2);
+  ffn_phase(bufX, bufH, w.ff2_w1, w.ff2_b1, w.ff2_w2, n_chunks,
+            wqkv_next ? wqkv_next + (size_t)wave * kTs256 : nullptr, ring, acc2);
+  residual_epilogue(bufX, acc2, w.ff2_b2, 1.0f);
+  __syncthreads();
+  rb_layernorm(bufX, bufX, kLda, kRows, w.ln4_g, w.ln4_b, 1e-5f);
+  rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);
+  if (wqkv_next) {
+    __syncthreads();
+    qkv_from_lds(bufX, qkv_next, wqkv_next, bqkv_next, r0, valid, ring);
+  }
+}
+constexpr size_t kLdsSqTail = 4 * kRows * kLda * sizeof(float);
+
+// Time reduction (TimeReductionLayerStream, time_reduction.py:183-206): zero PAD frames, depthwise
+// Conv1D(k=1, stride 2) = per-channel scale+bias of every second frame, pointwise Conv1D 256->256;
+// then the QKV projection of the first reduced layer.  Rows here are REDUCED rows (b, j) <- frame 2j.
+__global__ __launch_bounds__(kThreads) void k_sq_reduce(const float* __restrict__ x, float* __restrict__ xr,
+                                                        float* __restrict__ qkv, SqReduceW rw,
+                                                        const f32x4* __restrict__ wqkv, const float* __restrict__ bqkv,
+                                                        const int64_t* __restrict__ lens, int B, int Tp, int Tr) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufA = smem;
+  float* bufX = bufA + kRows * kLda;
+  const int lane = lane_id(), wave = wave_id();
+  const int Mr = B * Tr;
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, Mr - r0);
+  const int col = wave * 32 + (lane & 31);
+  BRing<1> ring;
+  const f32x4* seg_pw = rw.pw + (size_t)wave * kTs256;
+  ring_prime(ring, seg_pw, 0);
+  {
+    const f32x4 dw = *reinterpret_cast<const f32x4*>(rw.dw_w + 4 * lane);
+    const f32x4 db = *reinterpret_cast<const f32x4*>(rw.dw_b + 4 * lane);
+    for (int row = wave; row < kRows; row += kWaves) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < valid) {
+        const int mr = r0 + row, b = mr / Tr, j = mr - b * Tr;
+        const int t = 2 * j;
+        f32x4 xv = *reinterpret_cast<const f32x4*>(x + ((size_t)b * Tp + t) * kD + 4 * lane);
+        if (lens && 4 * (int64_t)t >= lens[b]) xv = f32x4{0.f, 0.f, 0.f, 0.f};  // masked_fill(xs, mask_pad==0, 0)
+        v = xv * dw + db;
+      }
+      *reinterpret_cast<f32x4*>(bufA + row * kLda + 4 * lane) = v;
+    }
+  }
+  __syncthreads();
+  {
+    f32x16 acc[1][1];
+    acc_zero(acc);
+    rb_gemm<1, 1, kG256>(bufA, kLda, seg_pw, 0, wqkv + (size_t)wave * kTs256, 0, ring, acc);
+    const float bv = rw.pw_b[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = acc_row(r, lane);
+      float v = acc[0][0][r] + bv;
+      bufX[row * kLda + col] = row < valid ? v : 0.f;
+      if (row < valid) xr[(size_t)(r0 + row) * kD + col] = v;
+    }
+  }
+  __syncthreads();
+  qkv_from_lds(bufX, qkv, wqkv, bqkv, r0, valid, ring);
+}
+
+// Time recovery (encoder.py:219-230): repeat_interleave(x, 2) -> Linear -> + saved ; then QKV.
+// Rows are full-resolution rows (b, t) <- reduced row (b, t >> 1).
+__global__ __launch_bounds__(kThreads) void k_sq_recover(const float* __restrict__ xr, const float* __restrict__ saved,
+                                                         float* __restrict__ x, float* __restrict__ qkv,
+                                                         const f32x4* __restrict__ wrec, const float* __restrict__ brec,
+                                                         const f32x4* __restrict__ wqkv, const float* __restrict__ bqkv,
+                                                         int B, int Tp, int Tr) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufA = smem;
+  float* bufX = bufA + kRows * kLda;
+  const int lane = lane_id(), wave = wave_id();
+  const int M = B * Tp;
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, M - r0);
+  const int col = wave * 32 + (lane & 31);
+  BRing<1> ring;
+  const f32x4* seg = wrec + (size_t)wave * kTs256;
+  ring_prime(ring, seg, 0);
+  for (int row = wave; row < kRows; row += kWaves) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < valid) {
+      const int m = r0 + row, b = m / Tp, t = m - b * Tp;
+      v = *reinterpret_cast<const f32x4*>(xr + ((size_t)b * Tr + (t >> 1)) * kD + 4 * lane);
+    }
+    *reinterpret_cast<f32x4*>(bufA + row * kLda + 4 * lane) = v;
+  }
+  __syncthreads();
+  {
+    f32x16 acc[1][1];
+    acc_zero(acc);
+    rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, wqkv + (size_t)wave * kTs256, 0, ring, acc);
+    const float bv = brec[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = acc_row(r, lane);
+      float v = 0.f;
+      if (row < valid) {
+        v = saved[(size_t)(r0 + row) * kD + col] + (acc[0][0][r] + bv);
+        x[(size_t)(r0 + row) * kD + col] = v;
+      }
+      bufX[row * kLda + col] = v;
+    }
+  }
+  __syncthreads();
+  qkv_from_lds(bufX, qkv, wqkv, bqkv, r0, valid, ring);
+}
+
+// in-place LayerNorm of [M][256] rows (preln, encoder.py:207)
+__global__ __launch_bounds__(kThreads) void k_ln_rows(float* __restrict__ x, const float* __restrict__ g,
+                                                      const float* __restrict__ b, int M) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, M - r0);
+  rb_load_rows(smem, kLda, x + (size_t)r0 * kD, kRows, valid);
+  rb_layernorm(smem, smem, kLda, kRows, g, b, 1e-5f);
+  rb_store_rows(x + (size_t)r0 * kD, smem, kLda, kRows, valid);
+}
+
+// ---- launchers ----
+static inline dim3 rb_grid(int M) { return dim3((M + kRows - 1) / kRows); }
+constexpr size_t kLds1 = kRows * kLda * sizeof(float);
+constexpr size_t kLds2 = 2 * kRows * kLda * sizeof(float);
+
+void launch_sq_qkv(const float* x, float* qkv, const f32x4* wqkv, const float* bqkv, int M, hipStream_t st) {
+  hipLaunchKernelGGL(k_sq_qkv, rb_grid(M), dim3(kThreads), kLds1, st, x, qkv, wqkv, bqkv, M);
+}
+void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, const SqLayerW& w, const int64_t* lens, int M,
+                   int Tp, int mask_mul, int n_chunks, hipStream_t st) {
+  hipLaunchKernelGGL(k_sq_mid, rb_grid(M), dim3(kThreads), kLdsSqMid, st, ctx, x, x2, g, w, lens, M, Tp, mask_mul, n_chunks);
+}
+void launch_sq_tail(const float* g, const float* x2, float* x_out, float* qkv_next, const SqLayerW& w,
+                    const f32x4* wqkv_next, const float* bqkv_next, const int64_t* lens, int M, int Tp, int mask_mul,
+                    int n_chunks, int ksize, hipStream_t st) {
+  if (ksize == 31)
+    hipLaunchKernelGGL(k_sq_tail<31>, rb_grid(M), dim3(kThreads), kLdsSqTail, st, g, x2, x_out, qkv_next, w, wqkv_next,
+                       bqkv_next, lens, M, Tp, mask_mul, n_chunks);
+  else if (ksize == 15)
+    hipLaunchKernelGGL(k_sq_tail<15>, rb_grid(M), dim3(kThreads), kLdsSqTail, st, g, x2, x_out, qkv_next, w, wqkv_next,
+                       bqkv_next, lens, M, Tp, mask_mul, n_chunks);
+}
+void launch_sq_reduce(const float* x, float* xr, float* qkv, const SqReduceW& rw, const f32x4* wqkv, const float* bqkv,
+                      const int64_t* lens, int B, int Tp, int Tr, hipStream_t st) {
+  hipLaunchKernelGGL(k_sq_reduce, rb_grid(B * Tr), dim3(kThreads), kLds2, st, x, xr, qkv, rw, wqkv, bqkv, lens, B, Tp, Tr);
+}
+void launch_sq_recover(const float* xr, const float* saved, float* x, float* qkv, const f32x4* wrec, const float* brec,
+                       const f32x4* wqkv, const float* bqkv, int B, int Tp, int Tr, hipStream_t st) {
+  hipLaunchKernelGGL(k_sq_recover, rb_grid(B * Tp), dim3(kThreads), kLds2, st, xr, saved, x, qkv, wrec, brec, wqkv, bqkv, B,
+                     Tp, Tr);
+}
+void launch_ln_rows(float* x, const float* g, const float* b, int M, hipStream_t st) {
+  hipLaunchKernelGGL(k_ln_rows, rb_grid(M), dim3(kThreads), kLds1, st, x, g, b, M);
+}
+
+hipError_t configure_squeezeformer_kernels() {
+  hipError_t e;
+#define SET_LDS(fn, bytes)                                                                                     \
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+  if (e != hipSuccess) return e;
+  SET_LDS(k_sq_mid, kLdsSqMid);
+  SET_LDS(k_sq_tail<31>, kLdsSqTail);
+  SET_LDS(k_sq_tail<15>, kLdsSqTail);
+  SET_LDS(k_sq_reduce, kLds2);
+  SET_LDS(k_sq_recover, kLds2);
+#undef SET_LDS
+  return hipSuccess;
+}
+
+}  // namespace ppasr

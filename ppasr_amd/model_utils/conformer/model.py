@@ -79,7 +79,7 @@ class ConformerModel:
                 blobs[i].shape[j] = a.shape[j]
         desc = _lib.ModelDesc(_lib.PPASR_MODEL_CONFORMER, input_dim, vocab_size, self.output_size,
                               self.attention_heads, self.linear_units, self.num_blocks, self.cnn_module_kernel,
-                              1 if streaming else 0, self.max_len)
+                              1 if streaming else 0, self.max_len, -1, -1, -1, 0, 0)
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ppasr_create(ctypes.byref(desc), blobs, len(sd), ctypes.byref(handle)))

@@ -1,0 +1,69 @@
+"""Host-side mirror of ``ppasr/model_utils/squeezeformer/model.py`` (``SqueezeformerModel``), inference
+surface: ``get_encoder_out`` (full utterance, batched).  Shares the C-ABI plumbing with the Conformer
+wrapper; only the model descriptor and parameter names differ."""
+import ctypes
+
+import numpy as np
+import torch
+
+from ppasr_amd import _lib
+from ppasr_amd.model_utils.conformer.model import ConformerModel, _pe_table
+
+__all__ = ["SqueezeformerModel"]
+
+
+class SqueezeformerModel(ConformerModel):
+    def __init__(self, input_dim, vocab_size, mean_istd_path=None, streaming=True, encoder_conf=None,
+                 decoder_conf=None, ctc_weight=0.5, state_dict=None, device="cuda:0", **_ignored):
+        if state_dict is None:
+            raise ValueError("state_dict (Paddle-layout parameter dict) is required")
+        if not torch.cuda.is_available():
+            raise _lib.PPASRHipError("no HIP device visible: ppasr_amd has no CPU fallback")
+        if not streaming:
+            raise NotImplementedError("only the streaming configuration (causal conv, stream time-reduction) is built")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.input_dim, self.vocab_size, self.streaming = input_dim, vocab_size, streaming
+        conf = dict(encoder_conf or {})
+        self.output_size = int(conf.get("encoder_dim", 256))
+        if int(conf.get("output_size", self.output_size)) != self.output_size:
+            raise NotImplementedError("final_proj (output_size != encoder_dim) is not built")
+        self.attention_heads = int(conf.get("attention_heads", 4))
+        self.linear_units = self.output_size * int(conf.get("feed_forward_expansion_factor", 8))
+        self.num_blocks = int(conf.get("num_blocks", 12))
+        self.cnn_module_kernel = int(conf.get("cnn_module_kernel", 31))
+        self.max_len = int(conf.get("max_len", 5000))
+        self.reduce_idx = conf.get("reduce_idx", 5)
+        self.recover_idx = conf.get("recover_idx", 11)
+        for key, want in (("pos_enc_layer_type", "rel_pos"), ("activation_type", "swish"), ("normalize_before", False),
+                          ("adaptive_scale", True), ("dw_stride", False), ("cnn_norm_type", "layer_norm")):
+            if key in conf and conf[key] != want:
+                raise NotImplementedError(f"encoder_conf.{key}={conf[key]!r}: only {want!r} is built")
+        sd = dict(state_dict)
+        sd["__pe_table__"] = _pe_table(self.output_size, self.max_len)
+        keep = []
+        blobs = (_lib.WeightBlob * len(sd))()
+        for i, (name, arr) in enumerate(sd.items()):
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            keep.append(a)
+            blobs[i].name = name.encode()
+            blobs[i].data_host = a.ctypes.data
+            blobs[i].ndim = min(a.ndim, 4)
+            for j in range(min(a.ndim, 4)):
+                blobs[i].shape[j] = a.shape[j]
+        desc = _lib.ModelDesc(_lib.PPASR_MODEL_SQUEEZEFORMER, input_dim, vocab_size, self.output_size,
+                              self.attention_heads, self.linear_units, self.num_blocks, self.cnn_module_kernel, 1,
+                              self.max_len, -1 if self.reduce_idx is None else int(self.reduce_idx),
+                              -1 if self.recover_idx is None else int(self.recover_idx), -1, 0, 0)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ppasr_create(ctypes.byref(desc), blobs, len(sd), ctypes.byref(handle)))
+        self._h = handle
+        self._ws = None
+        self._taps = None
+
+    def new_stream(self):
+        raise NotImplementedError("Squeezeformer forward_chunk is not built yet (DESIGN.md §7)")
+
+    def get_encoder_out_chunk(self, *a, **k):
+        raise NotImplementedError("Squeezeformer forward_chunk is not built yet (DESIGN.md §7)")

@@ -18,7 +18,7 @@ import math
 
 import numpy as np
 
-__all__ = ["conformer_state_dict", "synth_features", "synth_vocabulary", "DEFAULT_VOCAB_SIZE"]
+__all__ = ["conformer_state_dict", "squeezeformer_state_dict", "synth_features", "synth_vocabulary", "DEFAULT_VOCAB_SIZE"]
 
 DEFAULT_VOCAB_SIZE = 4233  # <blank>, <unk>, 4230 CJK chars, <eos>  
 
@@ -125,3 +125,68 @@ def synth_vocabulary(vocab_size=DEFAULT_VOCAB_SIZE):
     (vocabulary layout of ``ppasr/trainer.py:480-487``)."""
     chars = [chr(0x4E00 + i) for i in range(vocab_size - 3)]
     return ["<blank>", "<unk>"] + chars + ["<eos>"]
+
+
+def squeezeformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, encoder_dim=256, attention_heads=4,
+                             feed_forward_expansion_factor=8, num_blocks=12, cnn_module_kernel=31, seed=1234,
+                             ctc_sharpen=8.0, perturb_norm=False, cmvn_mean=10.0, cmvn_istd=1.0 / 3.3):
+    """Random-init ``SqueezeformerModel`` inference parameters.  The reference's ``init_weights()`` calls have
+    no effect on the values (SURVEY Appendix B.14): every layer keeps the ``utils/base.py`` Kaiming-uniform init;
+    attention / conv ``ada_scale``/``ada_bias`` are 1/0, the FFN ones are Xavier-uniform
+    (squeezeformer/positionwise.py:39-42).  ``perturb_norm`` randomises every norm / adaptive-scale vector."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    d, h = encoder_dim, attention_heads
+    dk = d // h
+    ff = d * feed_forward_expansion_factor
+    f2 = ((input_dim - 1) // 2 - 1) // 2
+    sd = {}
+    sd["encoder.global_cmvn.mean"] = np.full(input_dim, cmvn_mean, np.float32)
+    sd["encoder.global_cmvn.istd"] = np.full(input_dim, cmvn_istd, np.float32)
+    sd["encoder.embed.pw_conv.weight"] = _kaiming(rng, (d, 1, 3, 3), 9)
+    sd["encoder.embed.pw_conv.bias"] = _kaiming(rng, (d,), d)
+    sd["encoder.embed.dw_conv.weight"] = _kaiming(rng, (d, d, 3, 3), d * 9)
+    sd["encoder.embed.dw_conv.bias"] = _kaiming(rng, (d,), d)
+    _linear(sd, "encoder.embed.input_proj.0", d * f2, d, rng)
+    _layernorm(sd, "encoder.preln", d, rng, perturb_norm)
+
+    def ada(prefix, xavier):
+        if xavier:
+            b = math.sqrt(6.0 / (2 * d))
+            sd[prefix + ".ada_scale"] = _uniform(rng, (1, 1, d), b)
+            sd[prefix + ".ada_bias"] = _uniform(rng, (1, 1, d), b)
+        elif perturb_norm:
+            sd[prefix + ".ada_scale"] = (1.0 + 0.1 * rng.standard_normal((1, 1, d))).astype(np.float32)
+            sd[prefix + ".ada_bias"] = (0.1 * rng.standard_normal((1, 1, d))).astype(np.float32)
+        else:
+            sd[prefix + ".ada_scale"] = np.ones((1, 1, d), np.float32)
+            sd[prefix + ".ada_bias"] = np.zeros((1, 1, d), np.float32)
+
+    for i in range(num_blocks):
+        p = f"encoder.encoders.{i}."
+        for name in ("linear_q", "linear_k", "linear_v", "linear_out", "linear_pos"):
+            _linear(sd, p + "self_attn." + name, d, d, rng)
+        sd[p + "self_attn.pos_bias_u"] = _xavier(rng, (h, dk), h, dk)
+        sd[p + "self_attn.pos_bias_v"] = _xavier(rng, (h, dk), h, dk)
+        ada(p + "self_attn", False)
+        for ffn in ("ffn1", "ffn2"):
+            _linear(sd, p + ffn + ".w_1", d, ff, rng)
+            _linear(sd, p + ffn + ".w_2", ff, d, rng)
+            ada(p + ffn, True)
+        ada(p + "conv_module", False)
+        sd[p + "conv_module.pointwise_conv1.weight"] = _kaiming(rng, (2 * d, d, 1), d)
+        sd[p + "conv_module.pointwise_conv1.bias"] = _kaiming(rng, (2 * d,), 2 * d)
+        sd[p + "conv_module.depthwise_conv.weight"] = _kaiming(rng, (d, 1, cnn_module_kernel), cnn_module_kernel)
+        sd[p + "conv_module.depthwise_conv.bias"] = _kaiming(rng, (d,), d)
+        _layernorm(sd, p + "conv_module.norm", d, rng, perturb_norm)
+        sd[p + "conv_module.pointwise_conv2.weight"] = _kaiming(rng, (d, d, 1), d)
+        sd[p + "conv_module.pointwise_conv2.bias"] = _kaiming(rng, (d,), d)
+        for n in ("layer_norm1", "layer_norm2", "layer_norm3", "layer_norm4"):
+            _layernorm(sd, p + n, d, rng, perturb_norm)
+    sd["encoder.time_reduction_layer.dw_conv.weight"] = _kaiming(rng, (d, 1, 1), 1)
+    sd["encoder.time_reduction_layer.dw_conv.bias"] = _kaiming(rng, (d,), d)
+    sd["encoder.time_reduction_layer.pw_conv.weight"] = _kaiming(rng, (d, d, 1), d)
+    sd["encoder.time_reduction_layer.pw_conv.bias"] = _kaiming(rng, (d,), d)
+    _linear(sd, "encoder.time_recover_layer", d, d, rng)
+    sd["ctc.ctc_lo.weight"] = _xavier(rng, (d, vocab_size), d, vocab_size) * np.float32(ctc_sharpen)
+    sd["ctc.ctc_lo.bias"] = np.zeros(vocab_size, np.float32)
+    return sd
