@@ -34,8 +34,17 @@ const char* ppasr_version(void) { return "ppasr_hip 0.1 (gfx950, fp32 MFMA)"; }
 
 ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob* blobs, int n_blobs, ppasr_handle* out) {
   if (!desc || !blobs || !out) return fail(PPASR_EINVAL, "null argument");
-  if (desc->model_type != PPASR_MODEL_CONFORMER && desc->model_type != PPASR_MODEL_SQUEEZEFORMER)
-    return fail(PPASR_EUNSUPPORTED, "model_type not built (conformer, squeezeformer are)");
+  if (desc->model_type != PPASR_MODEL_CONFORMER && desc->model_type != PPASR_MODEL_SQUEEZEFORMER &&
+      desc->model_type != PPASR_MODEL_EFFICIENT_CONFORMER)
+    return fail(PPASR_EUNSUPPORTED, "model_type not built (conformer, efficient_conformer, squeezeformer are)");
+  const bool eff = desc->model_type == PPASR_MODEL_EFFICIENT_CONFORMER;
+  if (eff) {
+    if (desc->group_layer_mask != 0 && desc->group_size != 3)
+      return fail(PPASR_EUNSUPPORTED, "efficient_conformer: grouped attention is built for group_size=3");
+    if (desc->stride_layer_idx >= desc->num_blocks) return fail(PPASR_EINVAL, "stride_layer_idx out of range");
+    if (desc->stride_layer_idx >= 0 && desc->cnn_module_kernel != 15)
+      return fail(PPASR_EUNSUPPORTED, "efficient_conformer: cnn_module_kernel must be 15 (7 after the stride layer)");
+  }
   if (desc->output_size != kD) return fail(PPASR_EUNSUPPORTED, "kernels are specialised for output_size=256");
   if (desc->attention_heads * 64 != kD) return fail(PPASR_EUNSUPPORTED, "kernels are specialised for d_k=64");
   if (desc->linear_units % 256 != 0 || desc->linear_units <= 0) return fail(PPASR_EUNSUPPORTED, "linear_units % 256 != 0");
@@ -117,8 +126,16 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
   if ((st = upload_pe_table(m, sd, &pe_dev)) != PPASR_OK) return st;
   const int max_len = m->desc.max_len;
   m->layers.resize(desc->num_blocks);
+  m->layer_ks.assign(desc->num_blocks, KS);
+  m->layer_group.assign(desc->num_blocks, 1);
   for (int i = 0; i < desc->num_blocks; ++i) {
     LayerW& L = m->layers[i];
+    // Efficient-Conformer: kernel halves after the stride layer (encoder.py:123-128), grouped attention layers
+    const int KSi = (eff && desc->stride_layer_idx >= 0 && i > desc->stride_layer_idx) ? KS / 2 : KS;
+    const bool grouped = eff && ((desc->group_layer_mask >> i) & 1);
+    m->layer_ks[i] = KSi;
+    m->layer_group[i] = grouped ? 3 : 1;
+    const int pbn = grouped ? 3 * d : d;  // pos_bias_u/v are [h][dk*group_size] on grouped layers
     const std::string p = "encoder.encoders." + std::to_string(i) + ".";
     auto ln = [&](const std::string& n, const float** g, const float** b) -> ppasr_status {
       const float* gw = get(p + n + ".weight", d);
@@ -159,8 +176,13 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
       GET(wo, p + "self_attn.linear_out.weight", d * d);
       GET(bo, p + "self_attn.linear_out.bias", d);
       GET(wp, p + "self_attn.linear_pos.weight", d * d);
-      GET(pu, p + "self_attn.pos_bias_u", d);
-      GET(pv, p + "self_attn.pos_bias_v", d);
+      GET(pu, p + "self_attn.pos_bias_u", pbn);
+      GET(pv, p + "self_attn.pos_bias_v", pbn);
+      const float* bp = nullptr;  // linear_pos has a bias only in GroupedRelPositionMultiHeadedAttention
+      if (grouped) {
+        bp = get(p + "self_attn.linear_pos.bias", d);
+        if (!bp) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + missing);
+      }
       const float* ws[3] = {wq, wk, wv};
       UP4(pack_b(d, 3 * d, [&](int k, int n) { return ws[n / d][(size_t)k * d + (n % d)]; }), L.wqkv);
       std::vector<float> bqkv(3 * d);
@@ -170,21 +192,23 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
       UP(bqkv, L.bqkv);
       UP4(pack_b(d, d, [&](int k, int n) { return wo[(size_t)k * d + n]; }), L.wo);
       UP(vec_of(bo, d), L.bo);
-      UP(vec_of(pu, d), L.pos_u);
-      UP(vec_of(pv, d), L.pos_v);
+      UP(vec_of(pu, pbn), L.pos_u);
+      UP(vec_of(pv, pbn), L.pos_v);
+      const float* bpos_dev = nullptr;
+      if (bp) UP(vec_of(bp, d), bpos_dev);
       const float* wpos_dev = nullptr;
       UP(vec_of(wp, (size_t)d * d), wpos_dev);
       void* pt = nullptr;
       HIP_TRY(hipMalloc(&pt, (size_t)max_len * d * sizeof(float)));
       m->allocs.push_back(pt);
-      launch_posproj(pe_dev, wpos_dev, nullptr, static_cast<float*>(pt), max_len, nullptr);
+      launch_posproj(pe_dev, wpos_dev, bpos_dev, static_cast<float*>(pt), max_len, nullptr);
       HIP_TRY(hipGetLastError());
       L.ptab = static_cast<const float*>(pt);
     }
     {
       GET(p1w, p + "conv_module.pointwise_conv1.weight", 2 * d * d);
       GET(p1b, p + "conv_module.pointwise_conv1.bias", 2 * d);
-      GET(dww, p + "conv_module.depthwise_conv.weight", d * KS);
+      GET(dww, p + "conv_module.depthwise_conv.weight", d * KSi);
       GET(dwb, p + "conv_module.depthwise_conv.bias", d);
       GET(p2w, p + "conv_module.pointwise_conv2.weight", d * d);
       GET(p2b, p + "conv_module.pointwise_conv2.bias", d);
@@ -194,9 +218,9 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
       for (int c = 0; c < d; ++c) gp[c] = p1b[c] * (1.0f / (1.0f + expf(-p1b[c + d])));
       UP(b1p, L.pw1_b);
       UP(gp, L.glu_pad);
-      std::vector<float> dwt((size_t)KS * d);
+      std::vector<float> dwt((size_t)KSi * d);
       for (int c = 0; c < d; ++c)
-        for (int j = 0; j < KS; ++j) dwt[(size_t)j * d + c] = dww[(size_t)c * KS + j];
+        for (int j = 0; j < KSi; ++j) dwt[(size_t)j * d + c] = dww[(size_t)c * KSi + j];
       UP(dwt, L.dw_w);
       UP(vec_of(dwb, d), L.dw_b);
       UP4(pack_b(d, d, [&](int k, int n) { return p2w[(size_t)n * d + k]; }), L.pw2);
@@ -231,9 +255,11 @@ ppasr_status ppasr_destroy(ppasr_handle h) {
 }
 
 int ppasr_out_frames(ppasr_handle h, int T) {
-  (void)h;
   if (T < 7) return 0;
-  return ((T - 1) / 2 - 1) / 2;
+  int tp = ((T - 1) / 2 - 1) / 2;
+  // Efficient-Conformer: the stride-2 conv layer halves the frame rate (ceil), efficient_conformer/encoder.py:252-257
+  if (h && h->desc.model_type == PPASR_MODEL_EFFICIENT_CONFORMER && h->desc.stride_layer_idx >= 0) tp = (tp + 1) / 2;
+  return tp;
 }
 
 }  // extern "C"
@@ -315,30 +341,45 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st); });
   tap(xa, (size_t)M * kD);
   const int n_chunks = h->desc.linear_units / 256;
+  const bool eff = h->desc.model_type == PPASR_MODEL_EFFICIENT_CONFORMER;
+  int Ti = Tp, mul = 4, pstride = 1;  // frames per utterance / pad-mask multiplier / positional stride of the current layer
   for (int i = 0; i < h->desc.num_blocks; ++i) {
     const LayerW& L = h->layers[i];
-    timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, M, n_chunks, st); });
-    tap(xb, (size_t)M * kD);
-    tap(qkv, (size_t)M * 3 * kD);
+    const int Mi = B * Ti;
+    const int grp = h->layer_group[i];
+    timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st); });
+    tap(xb, (size_t)Mi * kD);
+    tap(qkv, (size_t)Mi * 3 * kD);
     timed(4, [&] {
-      AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Tp, Tp, 0, lens, ctx, L.pos_u, L.pos_v, L.ptab, 1, 4};
+      const int Tt = (Ti + grp - 1) / grp;  // tokens: frames, or zero-padded groups of 3 (pad4group)
+      AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Tt, Tt, 0, lens, ctx, L.pos_u, L.pos_v, L.ptab, pstride,
+                 mul * grp, Ti, Ti, grp};
       launch_attention(a, B, h->desc.attention_heads, st);
     });
-    tap(ctx, (size_t)M * kD);
-    timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, L, lens, M, Tp, st); });
-    tap(xc, (size_t)M * kD);
-    tap(g, (size_t)M * kD);
-    timed(6, [&] { launch_conv_ffn(g, nullptr, xc, xa, L, lens, M, Tp, n_chunks, h->desc.cnn_module_kernel, st); });
-    tap(xa, (size_t)M * kD);
+    tap(ctx, (size_t)Mi * kD);
+    timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, L, lens, Mi, Ti, mul, st); });
+    tap(xc, (size_t)Mi * kD);
+    tap(g, (size_t)Mi * kD);
+    if (eff && i == h->desc.stride_layer_idx) {
+      const int Ts = (Ti + 1) / 2;
+      timed(6, [&] { launch_conv_ffn_stride(g, xc, xa, L, lens, B, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st); });
+      Ti = Ts;  // masks[:, :, ::2], pos_emb[:, ::2]  (efficient_conformer/encoder.py:252-257)
+      mul *= 2;
+      pstride *= 2;
+    } else {
+      timed(6, [&] { launch_conv_ffn(g, nullptr, xc, xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul, st); });
+    }
+    tap(xa, (size_t)B * Ti * kD);
   }
+  const int Mo = B * Ti;
   float* lg = logits ? logits : probs;  // probs are produced in place from the logits tap
   int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
   float* fp = frame_maxprob ? frame_maxprob : ws + wl.fp;
-  timed(7, [&] { launch_ctc_head(xa, h->head, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, M, st); });
+  timed(7, [&] { launch_ctc_head(xa, h->head, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, Mo, st); });
   if (probs) {
     if (logits)
-      HIP_TRY(hipMemcpyAsync(probs, logits, (size_t)M * h->head.V * sizeof(float), hipMemcpyDeviceToDevice, st));
-    launch_softmax_from_stats(probs, ws + wl.rmax, ws + wl.rsum, M, h->head.V, st);
+      HIP_TRY(hipMemcpyAsync(probs, logits, (size_t)Mo * h->head.V * sizeof(float), hipMemcpyDeviceToDevice, st));
+    launch_softmax_from_stats(probs, ws + wl.rmax, ws + wl.rsum, Mo, h->head.V, st);
   }
   HIP_TRY(hipGetLastError());
   return PPASR_OK;
@@ -363,6 +404,8 @@ struct ppasr_stream_s {
 
 ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out) {
   if (!h || !out) return fail(PPASR_EINVAL, "null argument");
+  if (h->desc.model_type != PPASR_MODEL_CONFORMER)
+    return fail(PPASR_EUNSUPPORTED, "forward_chunk streaming is built for model_type=conformer only");
   auto* s = new ppasr_stream_s();
   s->m = h;
   s->cap = h->desc.max_len;
@@ -444,11 +487,11 @@ ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int r
     float* xh = s->xh_hist + (size_t)i * lo * kD;
     launch_ffn_qkv(xa, xb, qkv, L, M, n_chunks, st);
     launch_kv_append(qkv, kc + (size_t)s->cache_t * kD, vc + (size_t)s->cache_t * kD, c, st);
-    AttnArgs a{qkv, 768, kc, kD, vc, kD, c, T2, s->offset - s->cache_t, nullptr, ctx, L.pos_u, L.pos_v, L.ptab, 1, 4};
+    AttnArgs a{qkv, 768, kc, kD, vc, kD, c, T2, s->offset - s->cache_t, nullptr, ctx, L.pos_u, L.pos_v, L.ptab, 1, 4, c, T2, 1};
     launch_attention(a, 1, h->desc.attention_heads, st);
     launch_pw1_glu(xh, s->g_hist, L, lo, st);
-    launch_out_glu(ctx, xb, xc, g, xhat, L, nullptr, M, c, st);
-    launch_conv_ffn(g, s->g_hist, xc, xa, L, nullptr, M, c, n_chunks, h->desc.cnn_module_kernel, st);
+    launch_out_glu(ctx, xb, xc, g, xhat, L, nullptr, M, c, 4, st);
+    launch_conv_ffn(g, s->g_hist, xc, xa, L, nullptr, M, c, n_chunks, h->desc.cnn_module_kernel, 4, st);
     launch_hist_update(xh, xhat, c, lo, st);
   }
   int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);

@@ -66,6 +66,8 @@ struct ppasr_model_s {
   std::vector<void*> allocs;
   FrontW front;
   std::vector<LayerW> layers;
+  std::vector<int> layer_ks;     // depthwise kernel size per layer (Efficient-Conformer halves it after the stride layer)
+  std::vector<int> layer_group;  // 1, or 3 on grouped-attention layers
   HeadW head;
   // Squeezeformer (model_type == PPASR_MODEL_SQUEEZEFORMER)
   std::vector<SqLayerW> sq_layers;

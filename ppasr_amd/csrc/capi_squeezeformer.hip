@@ -247,7 +247,7 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
     const int mul = reduced ? 8 : 4;
     if (!have_qkv) launch_sq_qkv(x, qkv, W.wqkv, W.bqkv, Mi, st);
     tap(qkv, (size_t)Mi * 3 * kD);
-    AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Ti, Ti, 0, lens, ctx, W.pos_u, W.pos_v, W.ptab, reduced ? 2 : 1, mul};
+    AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Ti, Ti, 0, lens, ctx, W.pos_u, W.pos_v, W.ptab, reduced ? 2 : 1, mul, Ti, Ti, 1};
     launch_attention(a, B, H, st);
     tap(ctx, (size_t)Mi * kD);
     launch_sq_mid(ctx, x, xc, g, W, lens, Mi, Ti, mul, n_chunks, st);

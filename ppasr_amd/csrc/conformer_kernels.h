@@ -46,14 +46,16 @@ struct AttnArgs {
   int k_stride;
   const float* v;
   int v_stride;
-  int T1, T2;           // queries / keys per utterance
+  int T1, T2;           // query / key TOKENS per utterance (= frames, or ceil(frames/3) with grouped attention)
   int pos0;             // position of key 0 in the positional table (encoder.py:253: offset - cache_t1)
   const int64_t* lens;  // feature lengths for the key-padding mask, or nullptr (streaming: no mask)
   float* ctx;           // [B*T1][256]
   const float *pos_u, *pos_v;  // [256] = [h][dk]
   const float* ptab;           // [max_len][256] projected positional table of this layer
   int pos_stride;       // key j uses table row pos0 + j*pos_stride (2 on Squeezeformer's time-reduced layers)
-  int mask_mul;         // key j is PAD iff mask_mul*j >= len (4; 8 on time-reduced layers)
+  int mask_mul;         // key j is PAD iff mask_mul*j >= len (4; 8 on time-reduced layers; x3 when grouped)
+  int q_frames, kv_frames;  // valid frames behind the query / key tokens (== T1 / T2 unless grouped)
+  int group;            // 1, or 3 = GroupedRelPositionMultiHeadedAttention (pos_u / pos_v are then [h][192])
 };
 
 // ---- launchers (all asynchronous on `st`) ----
@@ -68,9 +70,11 @@ void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, fl
 void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st);
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
-                    const int64_t* lens, int M, int Tp, hipStream_t st);
+                    const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st);
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
-                     const int64_t* lens, int M, int Tp, int n_chunks, int ksize, hipStream_t st);
+                     const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, hipStream_t st);
+void launch_conv_ffn_stride(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int B,
+                            int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out, hipStream_t st);
 // streaming helpers
 void launch_pw1_glu(const float* xhat, float* g, const LayerW& w, int M, hipStream_t st);
 void launch_kv_append(const float* qkv, float* kc, float* vc, int n_rows, hipStream_t st);

@@ -234,61 +234,95 @@ void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, i
 // -------------------------------------------------------------------------------------
 // Attention: RelPositionMultiHeadedAttention.forward + forward_attention
 // (attention.py:198-262, 86-126).  scores = ((q+u) k^T + (q+v) p^T) / sqrt(dk) (rel_shift is
-// disabled in the reference, :256-258) == one contraction over the concatenated 128-wide
-// operands Q' = [q+u | q+v], K' = [k | p].  Key-padding mask from lengths (key j masked iff
-// 4j >= len[b], subsampling.py:115), softmax, masked probs -> 0, times V.  Flash-style over
+// disabled in the reference, :256-258) == one contraction over the concatenated operands
+// Q' = [q+u | q+v], K' = [k | p].  Key-padding mask from lengths (token j masked iff
+// mask_mul*j >= len[b], subsampling.py:115), softmax, masked probs -> 0, times V.  Flash-style over
 // 128-key blocks with running (max, sum) so any key count fits the same LDS footprint.
-// Block = (32-query tile, head, utterance); waves split keys for QK^T and (column tile,
-// key half) for PV.
+// Block = (32-query tile, head, utterance); waves split keys for QK^T and (column tiles, key half) for PV.
+//
+// DK = 64: plain heads.  DK = 192: GroupedRelPositionMultiHeadedAttention of the Efficient-Conformer
+// (efficient_conformer/attention.py:40-79,128-193, group_size 3): the time axis is zero-padded to a
+// multiple of 3 and every 3 consecutive frames (3 x 256 contiguous floats) are re-cut into 4 "heads"
+// of 192, i.e. token j / head h / feature f lives at flat offset j*768 + h*192 + f of the utterance's
+// [T'][256] activations -- the same formula as DK = 64 with a token stride of 256.
 // -------------------------------------------------------------------------------------
-constexpr int kQld = 132, kSld = 129, kKld = 36, kVld = 68;
-constexpr int kAttnLdsFloats = 32 * kQld + 32 * kSld + 128 * kVld + 96;
-constexpr size_t kLdsAttn = kAttnLdsFloats * sizeof(float);
+constexpr int kSld = 129, kKld = 36;
+template <int DK>
+struct AttnCfg {
+  static constexpr int G = DK / 64;             // frames per token
+  static constexpr int NFC = 2 * DK / 32;       // 32-feature chunks of K' = [k | p]
+  static constexpr int QLD = 2 * DK + 4;
+  static constexpr int NCT = DK / 32;           // 32-column tiles of the context
+  static constexpr int VLD = DK + 4;
+  static constexpr int VKEYS = DK == 64 ? 128 : 64;  // keys per V stage
+  static constexpr int KVF = (128 * kKld > VKEYS * VLD) ? 128 * kKld : VKEYS * VLD;
+  static constexpr int LDS_FLOATS = 32 * QLD + 32 * kSld + KVF + 96;
+};
 
+template <int DK>
 __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
+  using C = AttnCfg<DK>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Qs = smem;               // [32][132]  Q' = [q+u | q+v]
-  float* Ss = Qs + 32 * kQld;     // [32][129]  scores / probabilities of the current key block
-  float* KV = Ss + 32 * kSld;     // union: K' chunk [128][36]  |  V block [128][68]
-  float* stM = KV + 128 * kVld;   // running max   [32]
-  float* stL = stM + 32;          // running sum   [32]
-  float* stA = stL + 32;          // rescale alpha [32]
+  float* Qs = smem;                 // [32][QLD]  Q' = [q+u | q+v]
+  float* Ss = Qs + 32 * C::QLD;     // [32][129]  scores / probabilities of the current key block
+  float* KV = Ss + 32 * kSld;       // union: K' chunk [128][36]  |  V stage [VKEYS][VLD]  |  final O scratch
+  float* stM = KV + C::KVF;         // running max   [32]
+  float* stL = stM + 32;            // running sum   [32]
+  float* stA = stL + 32;            // rescale alpha [32]
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
-  const int T1 = a.T1, T2 = a.T2;
-  const float* __restrict__ qb = a.q + (size_t)b * T1 * a.q_stride;
-  const float* __restrict__ kbp = a.k + (size_t)b * T2 * a.k_stride;
-  const float* __restrict__ vbp = a.v + (size_t)b * T2 * a.v_stride;
+  const int T1 = a.T1, T2 = a.T2;   // tokens
+  const int F1 = a.q_frames, F2 = a.kv_frames;  // valid frames behind the tokens (== tokens when G == 1)
+  const float* __restrict__ qb = a.q + (size_t)b * F1 * a.q_stride;
+  const float* __restrict__ kbp = a.k + (size_t)b * F2 * a.k_stride;
+  const float* __restrict__ vbp = a.v + (size_t)b * F2 * a.v_stride;
   const float* __restrict__ ptab = a.ptab + (size_t)a.pos0 * kD;
   const int pstride = a.pos_stride;
-  float* __restrict__ ctx = a.ctx + (size_t)b * T1 * kD;
+  float* __restrict__ ctx = a.ctx + (size_t)b * F1 * kD;
   const int64_t len_b = a.lens ? a.lens[b] : (int64_t)a.mask_mul * T2;
+  // element (token j, head h, feature f) of a [frames][stride] buffer, zero beyond the valid frames
+  auto tok = [&](const float* base, int stride, int nframes, int j, int f) -> f32x4 {
+    const int flat = j * (C::G * kD) + h * DK + f;
+    const int frame = flat >> 8, feat = flat & 255;
+    if (frame >= nframes) return f32x4{0.f, 0.f, 0.f, 0.f};
+    return *reinterpret_cast<const f32x4*>(base + (size_t)frame * stride + feat);
+  };
+  auto tok_pos = [&](int j, int f) -> f32x4 {
+    const int flat = j * (C::G * kD) + h * DK + f;
+    const int frame = flat >> 8, feat = flat & 255;
+    if (frame >= F2) return f32x4{0.f, 0.f, 0.f, 0.f};
+    return *reinterpret_cast<const f32x4*>(ptab + (size_t)frame * pstride * kD + feat);
+  };
 
   // ---- Q' ----
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 32 * DK / 4 / 256; ++i) {
     int idx = tid + 256 * i;
-    int row = idx >> 4, f4 = idx & 15;
+    int row = idx / (DK / 4), f4 = idx - row * (DK / 4);
     f32x4 q = {0.f, 0.f, 0.f, 0.f};
-    if (q0 + row < T1) q = *reinterpret_cast<const f32x4*>(qb + (size_t)(q0 + row) * a.q_stride + h * 64 + f4 * 4);
-    f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + h * 64 + f4 * 4);
-    f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + h * 64 + f4 * 4);
-    *reinterpret_cast<f32x4*>(Qs + row * kQld + f4 * 4) = q + u;
-    *reinterpret_cast<f32x4*>(Qs + row * kQld + 64 + f4 * 4) = q + v;
+    if (q0 + row < T1) q = tok(qb, a.q_stride, F1, q0 + row, f4 * 4);
+    f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + h * DK + f4 * 4);
+    f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + h * DK + f4 * 4);
+    *reinterpret_cast<f32x4*>(Qs + row * C::QLD + f4 * 4) = q + u;
+    *reinterpret_cast<f32x4*>(Qs + row * C::QLD + DK + f4 * 4) = q + v;
   }
   if (tid < 32) {
     stM[tid] = -INFINITY;
     stL[tid] = 0.f;
   }
-  f32x16 acc_o;
+  constexpr int NO = C::NCT / 2;  // context column tiles per wave
+  f32x16 acc_o[NO];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc_o[r] = 0.f;
-  const int ct = wave & 1, kh = wave >> 1;
+  for (int t = 0; t < NO; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[t][r] = 0.f;
+  const int ctg = wave & 1, kh = wave >> 1;
+  const float score_div = DK == 64 ? 8.0f : 13.856406460551018f;  // sqrt(d_k [* group_size])
 
   const int nkb = (T2 + 127) / 128;
   for (int kb = 0; kb < nkb; ++kb) {
     const int key0 = kb * 128;
-    // ---- S = Q' K'^T over four 32-feature chunks (k: chunks 0,1 ; p: chunks 2,3) ----
+    // ---- S = Q' K'^T over 32-feature chunks (first half of the chunks: k, second half: p) ----
     f32x16 acc_s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_s[r] = 0.f;
@@ -300,9 +334,8 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
         int key = idx >> 3, f4 = idx & 7;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (key0 + key < T2) {
-          const float* p = (fc < 2) ? kbp + (size_t)(key0 + key) * a.k_stride + h * 64 + fc * 32 + f4 * 4
-                                    : ptab + (size_t)(key0 + key) * pstride * kD + h * 64 + (fc - 2) * 32 + f4 * 4;
-          v = *reinterpret_cast<const f32x4*>(p);
+          v = (fc < C::NFC / 2) ? tok(kbp, a.k_stride, F2, key0 + key, fc * 32 + f4 * 4)
+                                : tok_pos(key0 + key, (fc - C::NFC / 2) * 32 + f4 * 4);
         }
         stg[i] = v;
       }
@@ -316,45 +349,31 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
       }
     };
     load_kchunk(0);
-    for (int fc = 0; fc < 4; ++fc) {
+    for (int fc = 0; fc < C::NFC; ++fc) {
       __syncthreads();  // previous readers of KV (PV of last block / MFMAs of last chunk) are done
       write_kchunk();
       __syncthreads();
-      if (fc + 1 < 4) load_kchunk(fc + 1);
-      const float* a_ptr = Qs + (lane & 31) * kQld + fc * 32 + 4 * (lane >> 5);
+      if (fc + 1 < C::NFC) load_kchunk(fc + 1);
+      // Q' columns: chunk fc of k pairs with (q+u) columns, chunk of p with (q+v) columns
+      const int qcol = (fc < C::NFC / 2) ? fc * 32 : DK + (fc - C::NFC / 2) * 32;
+      const float* a_ptr = Qs + (lane & 31) * C::QLD + qcol + 4 * (lane >> 5);
       const float* b_ptr = KV + (wave * 32 + (lane & 31)) * kKld + 4 * (lane >> 5);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        f32x4 a = *reinterpret_cast<const f32x4*>(a_ptr + 8 * g);
+        f32x4 av = *reinterpret_cast<const f32x4*>(a_ptr + 8 * g);
         f32x4 bb = *reinterpret_cast<const f32x4*>(b_ptr + 8 * g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc_s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bb[j], acc_s, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc_s = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bb[j], acc_s, 0, 0, 0);
       }
-    }
-    // issue the V block loads early; they land in registers while the softmax pass runs
-    f32x4 vst[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int idx = tid + 256 * i;
-      int key = idx >> 4, f4 = idx & 15;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (key0 + key < T2) v = *reinterpret_cast<const f32x4*>(vbp + (size_t)(key0 + key) * a.v_stride + h * 64 + f4 * 4);
-      vst[i] = v;
     }
     {
       const int kl = wave * 32 + (lane & 31);
       const int key = key0 + kl;
       const bool masked = (key >= T2) || (a.mask_mul * (int64_t)key >= len_b);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Ss[acc_row(r, lane) * kSld + kl] = masked ? -INFINITY : acc_s[r] * 0.125f;
+      for (int r = 0; r < 16; ++r) Ss[acc_row(r, lane) * kSld + kl] = masked ? -INFINITY : acc_s[r] / score_div;
     }
     __syncthreads();  // S complete; all K' reads done -> KV may be overwritten with V
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int idx = tid + 256 * i;
-      int key = idx >> 4, f4 = idx & 15;
-      *reinterpret_cast<f32x4*>(KV + key * kVld + f4 * 4) = vst[i];
-    }
     // ---- online softmax over this block's 128 keys; wave handles rows 8w..8w+7 ----
     for (int rr = 0; rr < 8; ++rr) {
       const int row = wave * 8 + rr;
@@ -382,39 +401,71 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
       }
     }
     __syncthreads();
-    // ---- O = O*alpha + P V : wave -> (32-column tile ct, 64-key half kh) ----
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc_o[r] *= stA[acc_row(r, lane)];
-    {
-      const float* a_ptr = Ss + (lane & 31) * kSld + kh * 64 + (lane >> 5);
-      const float* b_ptr = KV + (kh * 64 + (lane >> 5)) * kVld + ct * 32 + (lane & 31);
-#pragma unroll 8
-      for (int s = 0; s < 32; ++s)
-        acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[2 * s], b_ptr[2 * s * kVld], acc_o, 0, 0, 0);
+    for (int t = 0; t < NO; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_o[t][r] *= stA[acc_row(r, lane)];
+    // ---- O += P V, V staged VKEYS keys at a time; wave -> (column-tile group ctg, key half kh) ----
+    for (int vs = 0; vs < 128 / C::VKEYS; ++vs) {
+      if (vs > 0) __syncthreads();  // previous stage fully consumed
+      constexpr int NV = C::VKEYS * DK / 4 / 256;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        int idx = tid + 256 * i;
+        int key = idx / (DK / 4), f4 = idx - key * (DK / 4);
+        const int kg = key0 + vs * C::VKEYS + key;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (kg < T2) v = tok(vbp, a.v_stride, F2, kg, f4 * 4);
+        *reinterpret_cast<f32x4*>(KV + key * C::VLD + f4 * 4) = v;
+      }
+      __syncthreads();
+      constexpr int KW = C::VKEYS / 2;  // keys per wave in this stage
+      const float* a_ptr = Ss + (lane & 31) * kSld + vs * C::VKEYS + kh * KW + (lane >> 5);
+      const float* b_ptr = KV + (kh * KW + (lane >> 5)) * C::VLD + ctg * NO * 32 + (lane & 31);
+#pragma unroll 4
+      for (int s = 0; s < KW / 2; ++s) {
+        const float av = a_ptr[2 * s];
+#pragma unroll
+        for (int t = 0; t < NO; ++t)
+          acc_o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_ptr[2 * s * C::VLD + t * 32], acc_o[t], 0, 0, 0);
+      }
     }
     // next iteration's first __syncthreads() protects KV / Ss
   }
   __syncthreads();
   // combine the two key halves, normalise, store
-  float* Osum = Ss;  // [2][32][33]
+  float* Osum = KV;  // [NCT][32][33]
   if (kh == 1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Osum[(ct * 32 + acc_row(r, lane)) * 33 + (lane & 31)] = acc_o[r];
+    for (int t = 0; t < NO; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Osum[((ctg * NO + t) * 32 + acc_row(r, lane)) * 33 + (lane & 31)] = acc_o[t][r];
   }
   __syncthreads();
   if (kh == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int row = acc_row(r, lane);
-      float l = stL[row];
-      float o = acc_o[r] + Osum[(ct * 32 + row) * 33 + (lane & 31)];
-      o = (l > 0.f) ? o / l : 0.f;  // fully masked row -> 0 (attention.py:118)
-      if (q0 + row < T1) ctx[(size_t)(q0 + row) * kD + h * 64 + ct * 32 + (lane & 31)] = o;
-    }
+    for (int t = 0; t < NO; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = acc_row(r, lane);
+        float l = stL[row];
+        float o = acc_o[t][r] + Osum[((ctg * NO + t) * 32 + row) * 33 + (lane & 31)];
+        o = (l > 0.f) ? o / l : 0.f;  // fully masked row -> 0 (attention.py:118)
+        if (q0 + row < T1) {
+          const int flat = (q0 + row) * (C::G * kD) + h * DK + (ctg * NO + t) * 32 + (lane & 31);
+          const int frame = flat >> 8, feat = flat & 255;
+          if (frame < F1) ctx[(size_t)frame * kD + feat] = o;  // x[:, :T - padding_q]  (efficient attention.py:124-125)
+        }
+      }
   }
 }
+constexpr size_t kLdsAttn = AttnCfg<64>::LDS_FLOATS * sizeof(float);
+constexpr size_t kLdsAttnG = AttnCfg<192>::LDS_FLOATS * sizeof(float);
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st) {
-  hipLaunchKernelGGL(k_attention, dim3((a.T1 + 31) / 32, H, B), dim3(256), kLdsAttn, st, a);
+  if (a.group == 3)
+    hipLaunchKernelGGL(k_attention<192>, dim3((a.T1 + 31) / 32, H, B), dim3(256), kLdsAttnG, st, a);
+  else
+    hipLaunchKernelGGL(k_attention<64>, dim3((a.T1 + 31) / 32, H, B), dim3(256), kLdsAttn, st, a);
 }
 
 // -------------------------------------------------------------------------------------
@@ -424,7 +475,7 @@ void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st) {
 __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ ctx, const float* __restrict__ x1,
                                                       float* __restrict__ x2, float* __restrict__ g,
                                                       float* __restrict__ xhat_out, LayerW w,
-                                                      const int64_t* __restrict__ lens, int M, int Tp) {
+                                                      const int64_t* __restrict__ lens, int M, int Tp, int mask_mul) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
@@ -456,7 +507,7 @@ __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ 
     }
   }
   __syncthreads();
-  rb_layernorm<false>(bufX, bufA, kLda, kRows, w.ln_conv_g, w.ln_conv_b, 1e-5f, PadRows{lens, r0, Tp, M});
+  rb_layernorm<false>(bufX, bufA, kLda, kRows, w.ln_conv_g, w.ln_conv_b, 1e-5f, PadRows{lens, r0, Tp, M, mask_mul});
   // streaming: the conv-module input (what the reference keeps as cnn_cache, convolution.py:117)
   if (xhat_out) rb_store_rows(xhat_out + (size_t)r0 * kD, bufA, kLda, kRows, valid);
   __syncthreads();
@@ -479,9 +530,9 @@ __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ 
 }
 constexpr size_t kLdsOutGlu = 2 * kRows * kLda * sizeof(float);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
-                    const int64_t* lens, int M, int Tp, hipStream_t st) {
+                    const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st) {
   hipLaunchKernelGGL(k_out_glu, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsOutGlu, st, ctx, x1, x2, g, xhat_out, w,
-                     lens, M, Tp);
+                     lens, M, Tp, mask_mul);
 }
 
 // streaming: g_hist = GLU(pointwise_conv1(cnn_cache rows))  -- the reference re-applies pointwise_conv1+GLU
@@ -603,7 +654,8 @@ void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStrea
 template <int KS, bool STREAM>
 __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__ g, const float* __restrict__ g_hist,
                                                        const float* __restrict__ x2, float* __restrict__ x_out, LayerW w,
-                                                       const int64_t* __restrict__ lens, int M, int Tp, int n_chunks) {
+                                                       const int64_t* __restrict__ lens, int M, int Tp, int n_chunks,
+                                                       int mask_mul) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
@@ -620,7 +672,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   // conv-module LayerNorm (nn.LayerNorm(channels), eps 1e-5, convolution.py:71) + swish, in place
   rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
   __syncthreads();
-  PadRows is_pad{lens, r0, Tp, M};
+  PadRows is_pad{lens, r0, Tp, M, mask_mul};
   {
     f32x16 acc[1][1];
     acc_zero(acc);
@@ -651,15 +703,15 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
 }
 constexpr size_t kLdsConvFfn = 4 * kRows * kLda * sizeof(float);
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
-                     const int64_t* lens, int M, int Tp, int n_chunks, int ksize, hipStream_t st) {
+                     const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, hipStream_t st) {
   dim3 grid((M + kRows - 1) / kRows);
 #define LAUNCH_CF(KS)                                                                                               \
   if (g_hist)                                                                                                       \
     hipLaunchKernelGGL((k_conv_ffn<KS, true>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, M, \
-                       Tp, n_chunks);                                                                               \
+                       Tp, n_chunks, mask_mul);                                                                     \
   else                                                                                                              \
     hipLaunchKernelGGL((k_conv_ffn<KS, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, M, \
-                       Tp, n_chunks);
+                       Tp, n_chunks, mask_mul);
   if (ksize == 15) {
     LAUNCH_CF(15)
   } else if (ksize == 31) {
@@ -668,6 +720,96 @@ void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float
     LAUNCH_CF(7)
   }
 #undef LAUNCH_CF
+}
+
+// -------------------------------------------------------------------------------------
+// Efficient-Conformer stride layer (StrideConformerEncoderLayer, efficient_conformer/encoder.py:455-548;
+// strided ConvolutionModule, efficient_conformer/convolution.py:80-138): the causal depthwise conv has
+// stride 2 (output frame j reads g frames 2j-(K-1)..2j), the residual goes through
+// AvgPool1D(2, 2, ceil_mode, exclusive) (encoder.py:171-172,521-531), the pad mask is mask_pad[:, :, ::2].
+// Rows of this kernel are OUTPUT rows (b, j), j < Ts = ceil(Tp/2); g and x2 are full-resolution.
+// -------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __restrict__ g, const float* __restrict__ x2,
+                                                              float* __restrict__ x_out, LayerW w,
+                                                              const int64_t* __restrict__ lens, int B, int Tp, int Ts,
+                                                              int n_chunks, int mask_mul_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufX = smem;
+  float* bufA = bufX + kRows * kLda;
+  float* bufH = bufA + kRows * kLda;
+  const int lane = lane_id(), wave = wave_id();
+  const int Mo = B * Ts;
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, Mo - r0);
+  const int col = wave * 32 + (lane & 31);
+  constexpr int LO = KS - 1;
+  BRing<1> ring;
+  const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
+  ring_prime(ring, seg_pw2, 0);
+  {
+    const f32x4 gp = *reinterpret_cast<const f32x4*>(w.glu_pad + 4 * lane);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(w.dw_b + 4 * lane);
+    for (int row = wave; row < kRows; row += kWaves) {
+      f32x4 out = bias;
+      if (row < valid) {
+        const int mo = r0 + row, b = mo / Ts, j = mo - b * Ts;
+        const float* gb = g + (size_t)b * Tp * kD + 4 * lane;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+          const int f = 2 * j - LO + t;
+          const f32x4 wj = *reinterpret_cast<const f32x4*>(w.dw_w + t * kD + 4 * lane);
+          const f32x4 v = (f >= 0) ? *reinterpret_cast<const f32x4*>(gb + (size_t)f * kD) : gp;
+          out += wj * v;
+        }
+      }
+      *reinterpret_cast<f32x4*>(bufA + row * kLda + 4 * lane) = out;
+    }
+  }
+  __syncthreads();
+  rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
+  __syncthreads();
+  PadRows is_pad{lens, r0, Ts, Mo, mask_mul_out};
+  {
+    f32x16 acc[1][1];
+    acc_zero(acc);
+    rb_gemm<1, 1, kG256>(bufA, kLda, seg_pw2, 0, w.ff_w1 + (size_t)wave * kTs256, 0, ring, acc);
+    const float bv = w.pw2_b[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = acc_row(r, lane);
+      float v = 0.f;
+      if (row < valid) {
+        const int mo = r0 + row, b = mo / Ts, j = mo - b * Ts;
+        const float* xb = x2 + ((size_t)b * Tp + 2 * j) * kD + col;
+        float res = xb[0];
+        if (2 * j + 1 < Tp) res = (res + xb[kD]) * 0.5f;  // exclusive average of the (possibly partial) window
+        float c = is_pad(row) ? 0.f : acc[0][0][r] + bv;
+        v = res + c;
+      }
+      bufX[row * kLda + col] = v;
+    }
+  }
+  __syncthreads();
+  rb_layernorm(bufX, bufA, kLda, kRows, w.ln_ff_g, w.ln_ff_b, 1e-5f);
+  __syncthreads();
+  f32x16 acc2[1][1];
+  acc_zero(acc2);
+  ffn_phase(bufA, bufH, w.ff_w1, w.ff_b1, w.ff_w2, n_chunks, nullptr, ring, acc2);
+  residual_epilogue(bufX, acc2, w.ff_b2, 0.5f);
+  __syncthreads();
+  rb_layernorm(bufX, bufX, kLda, kRows, w.ln_fin_g, w.ln_fin_b, 1e-5f);
+  rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);
+}
+void launch_conv_ffn_stride(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int B,
+                            int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out, hipStream_t st) {
+  dim3 grid((B * Ts + kRows - 1) / kRows);
+  if (ksize == 15)
+    hipLaunchKernelGGL(k_conv_ffn_stride<15>, grid, dim3(kThreads), kLdsConvFfn, st, g, x2, x_out, w, lens, B, Tp, Ts,
+                       n_chunks, mask_mul_out);
+  else if (ksize == 7)
+    hipLaunchKernelGGL(k_conv_ffn_stride<7>, grid, dim3(kThreads), kLdsConvFfn, st, g, x2, x_out, w, lens, B, Tp, Ts,
+                       n_chunks, mask_mul_out);
 }
 
 // -------------------------------------------------------------------------------------
@@ -904,7 +1046,8 @@ hipError_t configure_kernels() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
   if (e != hipSuccess) return e;
   SET_LDS(k_ffn_qkv, kLdsFfnQkv);
-  SET_LDS(k_attention, kLdsAttn);
+  SET_LDS(k_attention<64>, kLdsAttn);
+  SET_LDS(k_attention<192>, kLdsAttnG);
   SET_LDS(k_out_glu, kLdsOutGlu);
   SET_LDS((k_conv_ffn<15, false>), kLdsConvFfn);
   SET_LDS((k_conv_ffn<31, false>), kLdsConvFfn);
@@ -913,6 +1056,8 @@ hipError_t configure_kernels() {
   SET_LDS((k_conv_ffn<31, true>), kLdsConvFfn);
   SET_LDS((k_conv_ffn<7, true>), kLdsConvFfn);
   SET_LDS(k_pw1_glu, kLdsPw1Glu);
+  SET_LDS(k_conv_ffn_stride<15>, kLdsConvFfn);
+  SET_LDS(k_conv_ffn_stride<7>, kLdsConvFfn);
   SET_LDS(k_ctc_head<true>, kLdsCtc);
   SET_LDS(k_ctc_head<false>, kLdsCtc);
   SET_LDS((k_gemm_stream<4, 64, true, false, Conv2Src>), 2 * 128 * 68 * sizeof(float));

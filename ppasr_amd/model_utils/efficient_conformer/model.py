@@ -1,0 +1,90 @@
+"""Host-side mirror of ``ppasr/model_utils/efficient_conformer/model.py`` (``EfficientConformerModel``),
+inference surface ``get_encoder_out`` (full utterance, batched): grouped attention on
+``group_layer_idx`` layers, a stride-2 conv layer at ``stride_layer_idx`` (output frame rate 80 ms)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from ppasr_amd import _lib
+from ppasr_amd.model_utils.conformer.model import ConformerModel, _pe_table
+
+__all__ = ["EfficientConformerModel"]
+
+
+class EfficientConformerModel(ConformerModel):
+    def __init__(self, input_dim, vocab_size, mean_istd_path=None, streaming=True, encoder_conf=None,
+                 decoder_conf=None, ctc_weight=0.5, state_dict=None, device="cuda:0", **_ignored):
+        if state_dict is None:
+            raise ValueError("state_dict (Paddle-layout parameter dict) is required")
+        if not torch.cuda.is_available():
+            raise _lib.PPASRHipError("no HIP device visible: ppasr_amd has no CPU fallback")
+        if not streaming:
+            raise NotImplementedError("only the streaming configuration (causal conv) is built")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.input_dim, self.vocab_size, self.streaming = input_dim, vocab_size, streaming
+        conf = dict(encoder_conf or {})
+        eff = dict(conf.get("efficient_conf") or {})
+        self.output_size = int(conf.get("output_size", 256))
+        self.attention_heads = int(conf.get("attention_heads", 4))
+        self.linear_units = int(conf.get("linear_units", 2048))
+        self.num_blocks = int(conf.get("num_blocks", 6))
+        self.cnn_module_kernel = int(conf.get("cnn_module_kernel", 15))
+        self.max_len = int(conf.get("max_len", 5000))
+
+        def one(v, default):
+            v = conf.get(v, eff.get(v, default))
+            return v
+
+        stride_idx = one("stride_layer_idx", 3)
+        if isinstance(stride_idx, (list, tuple)):
+            if len(stride_idx) > 1:
+                raise NotImplementedError("one stride layer is built")
+            stride_idx = stride_idx[0] if stride_idx else None
+        stride = one("stride", 2)
+        stride = stride[0] if isinstance(stride, (list, tuple)) and stride else stride
+        if stride_idx is not None and stride != 2:
+            raise NotImplementedError("stride 2 is built")
+        groups = one("group_layer_idx", (0, 1, 2, 3))
+        groups = [groups] if isinstance(groups, int) else list(groups or [])
+        self.stride_layer_idx = stride_idx
+        self.group_layer_idx = groups
+        self.group_size = int(one("group_size", 3))
+        if not one("stride_kernel", True):
+            raise NotImplementedError("stride_kernel=False is not built")
+        for key, want in (("input_layer", "conv2d"), ("pos_enc_layer_type", "rel_pos"), ("activation_type", "swish"),
+                          ("normalize_before", True), ("use_cnn_module", True), ("cnn_module_norm", "layer_norm")):
+            if key in conf and conf[key] != want:
+                raise NotImplementedError(f"encoder_conf.{key}={conf[key]!r}: only {want!r} is built")
+        sd = dict(state_dict)
+        sd["__pe_table__"] = _pe_table(self.output_size, self.max_len)
+        keep = []
+        blobs = (_lib.WeightBlob * len(sd))()
+        for i, (name, arr) in enumerate(sd.items()):
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            keep.append(a)
+            blobs[i].name = name.encode()
+            blobs[i].data_host = a.ctypes.data
+            blobs[i].ndim = min(a.ndim, 4)
+            for j in range(min(a.ndim, 4)):
+                blobs[i].shape[j] = a.shape[j]
+        mask = 0
+        for g in groups:
+            mask |= 1 << int(g)
+        desc = _lib.ModelDesc(_lib.PPASR_MODEL_EFFICIENT_CONFORMER, input_dim, vocab_size, self.output_size,
+                              self.attention_heads, self.linear_units, self.num_blocks, self.cnn_module_kernel, 1,
+                              self.max_len, -1, -1, -1 if stride_idx is None else int(stride_idx), mask,
+                              self.group_size)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ppasr_create(ctypes.byref(desc), blobs, len(sd), ctypes.byref(handle)))
+        self._h = handle
+        self._ws = None
+        self._taps = None
+
+    def new_stream(self):
+        raise NotImplementedError("Efficient-Conformer forward_chunk is not built yet (DESIGN.md §7)")
+
+    def get_encoder_out_chunk(self, *a, **k):
+        raise NotImplementedError("Efficient-Conformer forward_chunk is not built yet (DESIGN.md §7)")

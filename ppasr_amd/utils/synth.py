@@ -18,7 +18,7 @@ import math
 
 import numpy as np
 
-__all__ = ["conformer_state_dict", "squeezeformer_state_dict", "synth_features", "synth_vocabulary", "DEFAULT_VOCAB_SIZE"]
+__all__ = ["conformer_state_dict", "squeezeformer_state_dict", "efficient_conformer_state_dict", "synth_features", "synth_vocabulary", "DEFAULT_VOCAB_SIZE"]
 
 DEFAULT_VOCAB_SIZE = 4233  # <blank>, <unk>, 4230 CJK chars, <eos>  
 
@@ -189,4 +189,27 @@ def squeezeformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, encode
     _linear(sd, "encoder.time_recover_layer", d, d, rng)
     sd["ctc.ctc_lo.weight"] = _xavier(rng, (d, vocab_size), d, vocab_size) * np.float32(ctc_sharpen)
     sd["ctc.ctc_lo.bias"] = np.zeros(vocab_size, np.float32)
+    return sd
+
+
+def efficient_conformer_state_dict(stride_layer_idx=3, group_layer_idx=(0, 1, 2, 3), group_size=3, cnn_module_kernel=15,
+                                   attention_heads=4, output_size=256, num_blocks=12, seed=1234, **kw):
+    """Random-init ``EfficientConformerModel`` inference parameters: the Conformer dict with
+    (a) ``pos_bias_u/v`` of shape [h, d_k*group_size] and a ``linear_pos.bias`` on grouped-attention layers
+    (efficient_conformer/attention.py:31-37), (b) depthwise kernels of size k//2 after the stride layer
+    (efficient_conformer/encoder.py:123-128)."""
+    sd = conformer_state_dict(cnn_module_kernel=cnn_module_kernel, attention_heads=attention_heads,
+                              output_size=output_size, num_blocks=num_blocks, seed=seed, **kw)
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    d, h = output_size, attention_heads
+    dk = d // h
+    for i in range(num_blocks):
+        p = f"encoder.encoders.{i}."
+        if i in tuple(group_layer_idx or ()):
+            sd[p + "self_attn.pos_bias_u"] = _xavier(rng, (h, dk * group_size), h, dk * group_size)
+            sd[p + "self_attn.pos_bias_v"] = _xavier(rng, (h, dk * group_size), h, dk * group_size)
+            sd[p + "self_attn.linear_pos.bias"] = _kaiming(rng, (d,), d)
+        if stride_layer_idx is not None and i > stride_layer_idx:
+            k2 = cnn_module_kernel // 2
+            sd[p + "conv_module.depthwise_conv.weight"] = _kaiming(rng, (d, 1, k2), k2)
     return sd
