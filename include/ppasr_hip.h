@@ -144,6 +144,18 @@ ppasr_status ppasr_stream_export_cache(ppasr_stream s, float* att_cache, float* 
 ppasr_status ppasr_stream_import_cache(ppasr_stream s, const float* att_cache, int cache_t, const float* cnn_cache,
                                        int offset, void* stream);
 
+/* ---- DeepSpeech2: DeepSpeech2Model.get_encoder_out / get_encoder_out_chunk (model_utils/deepspeech2/model.py:62-72),
+ * as called by trainer.py:626 and InferencePredictor.predict / predict_chunk_deepspeech
+ * (inference_predictor.py:103-145,147-182).  Create the handle with model_type = PPASR_MODEL_DEEPSPEECH2,
+ * output_size = rnn_size, num_blocks = num_rnn_layers, causal = 1 for the streaming ('forward') model and 0 for
+ * the bidirectional one (deepspeech2/model.py:40).
+ *   feats [B,T,F], lens [B] i64 -> probs [B,T',V] f32, out_lens [B] i64 (= ((len-1)/2-1)/2, may be NULL);
+ *   init_h / init_c / final_h / final_c: [num_rnn_layers*dirs, B, rnn_size] state boxes (NULL = zeros / not wanted). */
+size_t ppasr_ds2_workspace_bytes(ppasr_handle h, int B, int T);
+ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, const int64_t* lens, int B, int T, const float* init_h,
+                              const float* init_c, float* probs, int64_t* out_lens, float* final_h, float* final_c,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* Measurement hook (bench.py roofline leg; no reference counterpart): when enabled, every kernel launch
  * of the next ppasr_encode is bracketed by a HIP event pair on the caller's stream; ppasr_profile_read
  * synchronises those events and returns, per kernel class, the summed duration (ms) and launch count

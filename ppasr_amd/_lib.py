@@ -63,6 +63,9 @@ SYMBOLS = [
                                           ctypes.POINTER(ctypes.c_int), _vp, ctypes.c_size_t, _vp]),
     ("ppasr_stream_export_cache", ctypes.c_int, [_vp, _vp, _vp, _vp]),
     ("ppasr_stream_import_cache", ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, ctypes.c_int, _vp]),
+    ("ppasr_ds2_workspace_bytes", ctypes.c_size_t, [_vp, ctypes.c_int, ctypes.c_int]),
+    ("ppasr_ds2_encode", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        ctypes.c_size_t, _vp]),
     ("ppasr_profile_enable", ctypes.c_int, [_vp, ctypes.c_int]),
     ("ppasr_profile_read", ctypes.c_int, [_vp, c_f32p, c_i32p]),
     ("ppasr_kernel_class_name", ctypes.c_char_p, [ctypes.c_int]),

@@ -34,6 +34,26 @@ const char* ppasr_version(void) { return "ppasr_hip 0.1 (gfx950, fp32 MFMA)"; }
 
 ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob* blobs, int n_blobs, ppasr_handle* out) {
   if (!desc || !blobs || !out) return fail(PPASR_EINVAL, "null argument");
+  if (desc->model_type == PPASR_MODEL_DEEPSPEECH2) {
+    if (desc->input_dim > 128 || desc->input_dim < 7) return fail(PPASR_EUNSUPPORTED, "input_dim out of range");
+    HIP_TRY(configure_kernels());
+    BlobMap sd2;
+    for (int i = 0; i < n_blobs; ++i) {
+      Blob b{blobs[i].data_host, blobs[i].ndim, {0, 0, 0, 0}};
+      for (int j = 0; j < blobs[i].ndim && j < 4; ++j) b.shape[j] = blobs[i].shape[j];
+      sd2[blobs[i].name] = b;
+    }
+    std::unique_ptr<ppasr_model_s> g2(new ppasr_model_s());
+    g2->desc = *desc;
+    g2->F1 = (desc->input_dim - 1) / 2;
+    g2->F2 = (g2->F1 - 1) / 2;
+    if (g2->F1 > 40) return fail(PPASR_EUNSUPPORTED, "deepspeech2: input_dim <= 81");
+    ppasr_status s2 = ds2_create(g2.get(), sd2);
+    if (s2 != PPASR_OK) return s2;
+    HIP_TRY(hipDeviceSynchronize());
+    *out = g2.release();
+    return PPASR_OK;
+  }
   if (desc->model_type != PPASR_MODEL_CONFORMER && desc->model_type != PPASR_MODEL_SQUEEZEFORMER &&
       desc->model_type != PPASR_MODEL_EFFICIENT_CONFORMER)
     return fail(PPASR_EUNSUPPORTED, "model_type not built (conformer, efficient_conformer, squeezeformer are)");
@@ -304,6 +324,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
                           size_t workspace_bytes, void* stream) {
   if (!h || !feats || !workspace) return fail(PPASR_EINVAL, "null argument");
   if (B <= 0 || T < 7) return fail(PPASR_EINVAL, "need B > 0 and T >= 7 frames");
+  if (h->desc.model_type == PPASR_MODEL_DEEPSPEECH2) return fail(PPASR_EINVAL, "deepspeech2 handles use ppasr_ds2_encode");
   const int F = h->desc.input_dim, T1 = (T - 1) / 2, F1 = h->F1, Tp = (T1 - 1) / 2, F2 = h->F2;
   if (Tp >= h->desc.max_len) return fail(PPASR_EINVAL, "utterance longer than the positional table (embedding.py:64-66)");
   const int M = B * Tp;

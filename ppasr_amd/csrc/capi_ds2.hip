@@ -1,0 +1,196 @@
+// capi_ds2.hip -- DeepSpeech2Model.get_encoder_out / get_encoder_out_chunk (ppasr/model_utils/deepspeech2/
+// model.py:62-72) behind the C-ABI: weight packing and launch sequence of CRNNEncoder.forward
+// (deepspeech2/encoder.py:61-104) + ctc softmax.
+#include "capi_internal.h"
+
+namespace {
+struct Getter {
+  BlobMap& sd;
+  std::string missing;
+  const float* operator()(const std::string& name, size_t numel) {
+    auto it = sd.find(name);
+    if (it == sd.end() || it->second.numel() != numel) {
+      if (missing.empty()) missing = name;
+      return nullptr;
+    }
+    return it->second.p;
+  }
+};
+std::vector<float> vec_of(const float* p, size_t n) { return std::vector<float>(p, p + n); }
+size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
+}  // namespace
+
+#define GETW(var, name, numel)                   \
+  const float* var = get(name, (size_t)(numel)); \
+  if (!var) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + get.missing)
+#define UP(vec, dst) \
+  if ((st = m->upload(vec, &(dst))) != PPASR_OK) return st
+#define UP4(vec, dst) \
+  if ((st = m->upload4(vec, &(dst))) != PPASR_OK) return st
+
+// desc fields for DeepSpeech2: output_size = rnn_size, num_blocks = num_rnn_layers, causal = streaming
+// (rnn_direction 'forward', deepspeech2/model.py:40) else 'bidirect'.
+ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd) {
+  const ppasr_model_desc& dsc = m->desc;
+  const int F = dsc.input_dim, H = dsc.output_size, L = dsc.num_blocks, V = dsc.vocab_size;
+  const int dirs = dsc.causal ? 1 : 2;
+  if (H % 1024 != 0 || H > 2048) return fail(PPASR_EUNSUPPORTED, "deepspeech2: rnn_size must be 1024 or 2048");
+  if (L < 1 || L > 16) return fail(PPASR_EUNSUPPORTED, "deepspeech2: bad num_rnn_layers");
+  const int F2 = m->F2, C = 32;
+  Getter get{sd, ""};
+  ppasr_status st;
+  Ds2W& W = m->ds2;
+  W.H = H; W.dirs = dirs; W.n_layers = L; W.V = V;
+  W.Vpad = (V + 255) / 256 * 256;
+  W.ldx = (C * F2 + 255) / 256 * 256;  // conv feature width padded to the GEMM's K granularity
+  {
+    GETW(mean, "encoder.global_cmvn.mean", F);
+    GETW(istd, "encoder.global_cmvn.istd", F);
+    GETW(c1w, "encoder.conv.conv.0.weight", C * 9);
+    GETW(c1b, "encoder.conv.conv.0.bias", C);
+    GETW(c2w, "encoder.conv.conv.2.weight", C * C * 9);
+    GETW(c2b, "encoder.conv.conv.2.bias", C);
+    UP(vec_of(mean, F), W.cmvn_mean);
+    UP(vec_of(istd, F), W.cmvn_istd);
+    std::vector<float> w1(9 * C), w2((size_t)9 * C * C);
+    for (int c = 0; c < C; ++c)
+      for (int j = 0; j < 9; ++j) w1[j * C + c] = c1w[c * 9 + j];
+    for (int co = 0; co < C; ++co)
+      for (int ci = 0; ci < C; ++ci)
+        for (int j = 0; j < 9; ++j) w2[((size_t)j * C + ci) * C + co] = c2w[((size_t)co * C + ci) * 9 + j];
+    UP(w1, W.c1_w);
+    UP(vec_of(c1b, C), W.c1_b);
+    UP(w2, W.c2_w);
+    UP(vec_of(c2b, C), W.c2_b);
+  }
+  m->ds2_layers.resize(L);
+  for (int l = 0; l < L; ++l) {
+    Ds2LayerW& Lw = m->ds2_layers[l];
+    const int in_dim = l == 0 ? C * F2 : dirs * H;
+    const int in_pad = l == 0 ? W.ldx : dirs * H;
+    Lw.in_dim_padded = in_pad;
+    const std::string p = "encoder.rnn." + std::to_string(l) + ".";
+    const float* wih[2] = {nullptr, nullptr};
+    const float* whh[2] = {nullptr, nullptr};
+    const float* bih[2] = {nullptr, nullptr};
+    const float* bhh[2] = {nullptr, nullptr};
+    for (int d = 0; d < dirs; ++d) {
+      const std::string sfx = d == 0 ? "_l0" : "_l0_reverse";
+      wih[d] = get(p + "weight_ih" + sfx, (size_t)4 * H * in_dim);
+      whh[d] = get(p + "weight_hh" + sfx, (size_t)4 * H * H);
+      bih[d] = get(p + "bias_ih" + sfx, 4 * H);
+      bhh[d] = get(p + "bias_hh" + sfx, 4 * H);
+      if (!wih[d] || !whh[d] || !bih[d] || !bhh[d]) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + get.missing);
+    }
+    // one GEMM per layer: columns [d*4H, (d+1)*4H) = direction d's gate pre-activations; W[k][n] = weight_ih[n][k]
+    const int N = dirs * 4 * H;
+    UP4(pack_b(in_pad, N, [&](int k, int n) {
+          if (k >= in_dim) return 0.f;
+          const int d = n / (4 * H), r = n % (4 * H);
+          return wih[d][(size_t)r * in_dim + k];
+        }), Lw.w_ih);
+    std::vector<float> bsum(N), hh((size_t)dirs * 4 * H * H);
+    for (int d = 0; d < dirs; ++d) {
+      for (int r = 0; r < 4 * H; ++r) bsum[d * 4 * H + r] = bih[d][r] + bhh[d][r];
+      std::memcpy(&hh[(size_t)d * 4 * H * H], whh[d], (size_t)4 * H * H * sizeof(float));
+    }
+    UP(bsum, Lw.b_sum);
+    UP(hh, Lw.w_hh);
+    GETW(lg, "encoder.layernorm_list." + std::to_string(l) + ".weight", dirs * H);
+    GETW(lb, "encoder.layernorm_list." + std::to_string(l) + ".bias", dirs * H);
+    UP(vec_of(lg, dirs * H), Lw.ln_g);
+    UP(vec_of(lb, dirs * H), Lw.ln_b);
+  }
+  {
+    GETW(cw, "decoder.ctc_lo.weight", (size_t)dirs * H * V);
+    GETW(cb, "decoder.ctc_lo.bias", V);
+    UP4(pack_b(dirs * H, W.Vpad, [&](int k, int n) { return n < V ? cw[(size_t)k * V + n] : 0.f; }), W.ctc_w);
+    std::vector<float> cbp(W.Vpad, 0.f);
+    std::memcpy(cbp.data(), cb, V * sizeof(float));
+    UP(cbp, W.ctc_b);
+  }
+  return PPASR_OK;
+}
+
+struct Ds2Ws {
+  size_t y1, x, gx, ya, yb, h0, h1, c, lens32, total;  // float offsets
+};
+static Ds2Ws ds2_ws(const ppasr_model_s* m, int B, int T) {
+  const Ds2W& W = m->ds2;
+  const size_t T1 = (T - 1) / 2, Tp = (T1 - 1) / 2, M = (size_t)B * Tp;
+  Ds2Ws w;
+  size_t o = 0;
+  w.y1 = o; o += al64((size_t)B * T1 * m->F1 * 32);
+  w.x = o; o += al64(M * W.ldx);
+  w.gx = o; o += al64(M * W.dirs * 4 * W.H);
+  w.ya = o; o += al64(M * W.dirs * W.H);
+  w.yb = o; o += al64(M * W.dirs * W.H);
+  w.h0 = o; o += al64((size_t)W.dirs * B * W.H);
+  w.h1 = o; o += al64((size_t)W.dirs * B * W.H);
+  w.c = o; o += al64((size_t)W.dirs * B * W.H);
+  w.lens32 = o; o += al64(B);
+  w.total = o;
+  return w;
+}
+
+extern "C" size_t ppasr_ds2_workspace_bytes(ppasr_handle h, int B, int T) {
+  if (!h || h->desc.model_type != PPASR_MODEL_DEEPSPEECH2 || B <= 0 || T < 7) return 0;
+  return ds2_ws(h, B, T).total * sizeof(float);
+}
+
+// states: [L*dirs][B][H] in the reference's box layout (layer-major, then direction), or NULL for zeros.
+extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, const int64_t* lens, int B, int T,
+                                         const float* init_h, const float* init_c, float* probs, int64_t* out_lens,
+                                         float* final_h, float* final_c, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  if (!h || !feats || !lens || !probs || !workspace) return fail(PPASR_EINVAL, "null argument");
+  if (h->desc.model_type != PPASR_MODEL_DEEPSPEECH2) return fail(PPASR_EINVAL, "handle is not a deepspeech2 model");
+  if (B <= 0 || T < 7) return fail(PPASR_EINVAL, "need B > 0 and T >= 7 frames");
+  const Ds2W& W = h->ds2;
+  const Ds2Ws wl = ds2_ws(h, B, T);
+  if (workspace_bytes < wl.total * sizeof(float)) return fail(PPASR_ENOSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* ws = static_cast<float*>(workspace);
+  const int F = h->desc.input_dim, T1 = (T - 1) / 2, F1 = h->F1, Tp = (T1 - 1) / 2, F2 = h->F2;
+  const int M = B * Tp, H = W.H, dirs = W.dirs;
+  float *y1 = ws + wl.y1, *x = ws + wl.x, *gx = ws + wl.gx, *ya = ws + wl.ya, *yb = ws + wl.yb;
+  float *h0 = ws + wl.h0, *h1 = ws + wl.h1, *c = ws + wl.c;
+  int32_t* lens32 = reinterpret_cast<int32_t*>(ws + wl.lens32);
+  launch_ds2_conv1(feats, W.cmvn_mean, W.cmvn_istd, W.c1_w, W.c1_b, y1, B, T, F, T1, F1, st);
+  launch_ds2_conv2(y1, W.c2_w, W.c2_b, x, B, T1, F1, Tp, F2, W.ldx, st);
+  launch_ds2_lens(lens, lens32, out_lens, B, Tp, st);
+  const float* in = x;
+  int in_ld = W.ldx;
+  float* out = ya;
+  const size_t sbytes = (size_t)dirs * B * H * sizeof(float);
+  for (int l = 0; l < W.n_layers; ++l) {
+    const Ds2LayerW& Lw = h->ds2_layers[l];
+    // gate pre-activations of all frames and both directions: [M][dirs*4H]; the step kernel wants [dirs][M][4H]
+    // -> run one GEMM per direction into its own slab
+    for (int d = 0; d < dirs; ++d)
+      launch_dense(in, in_ld, Lw.w_ih + (size_t)d * (4 * H / 32) * (Lw.in_dim_padded / 8) * 64, Lw.b_sum + d * 4 * H,
+                   gx + (size_t)d * M * 4 * H, M, Lw.in_dim_padded, 4 * H, 4 * H, 4 * H, st);
+    // initial states
+    if (init_h) HIP_TRY(hipMemcpyAsync(h0, init_h + (size_t)l * dirs * B * H, sbytes, hipMemcpyDeviceToDevice, st));
+    else HIP_TRY(hipMemsetAsync(h0, 0, sbytes, st));
+    if (init_c) HIP_TRY(hipMemcpyAsync(c, init_c + (size_t)l * dirs * B * H, sbytes, hipMemcpyDeviceToDevice, st));
+    else HIP_TRY(hipMemsetAsync(c, 0, sbytes, st));
+    HIP_TRY(hipMemsetAsync(out, 0, (size_t)M * dirs * H * sizeof(float), st));
+    float* hp = h0;
+    float* hn = h1;
+    for (int s = 0; s < Tp; ++s) {
+      launch_lstm_step(gx, Lw.w_hh, hp, hn, c, out, lens32, B, Tp, H, dirs, s, st);
+      std::swap(hp, hn);
+    }
+    if (final_h) HIP_TRY(hipMemcpyAsync(final_h + (size_t)l * dirs * B * H, hp, sbytes, hipMemcpyDeviceToDevice, st));
+    if (final_c) HIP_TRY(hipMemcpyAsync(final_c + (size_t)l * dirs * B * H, c, sbytes, hipMemcpyDeviceToDevice, st));
+    launch_ln_wide(out, Lw.ln_g, Lw.ln_b, M, dirs * H, st);
+    in = out;
+    in_ld = dirs * H;
+    out = (out == ya) ? yb : ya;
+  }
+  launch_dense(in, in_ld, W.ctc_w, W.ctc_b, probs, M, dirs * H, W.Vpad, W.V, W.V, st);
+  launch_softmax_from_stats(probs, nullptr, nullptr, M, W.V, st);
+  HIP_TRY(hipGetLastError());
+  return PPASR_OK;
+}

@@ -17,6 +17,7 @@
 using namespace ppasr;
 
 #include "squeezeformer_kernels.h"
+#include "ds2_kernels.h"
 
 std::string& ppasr_err_slot();  // thread-local error string (defined in capi.hip)
 inline ppasr_status fail(ppasr_status s, const std::string& msg) {
@@ -75,6 +76,9 @@ struct ppasr_model_s {
   const f32x4* sq_wrec = nullptr;
   const float* sq_brec = nullptr;
   const float *preln_g = nullptr, *preln_b = nullptr;
+  // DeepSpeech2 (model_type == PPASR_MODEL_DEEPSPEECH2)
+  Ds2W ds2{};
+  std::vector<Ds2LayerW> ds2_layers;
   float* taps = nullptr;
   size_t taps_floats = 0;
   // optional per-kernel timing (bench.py roofline leg): one event pair per launch on the caller's stream
@@ -121,6 +125,7 @@ WsLayout ws_layout(const ppasr_model_s* m, int B, int T);
 ppasr_status upload_pe_table(ppasr_model_s* m, BlobMap& sd, const float** pe_dev);
 
 // model-family back ends
+ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd);
 ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe_dev);
 ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const int64_t* lens, int B, int T, float* probs,
                                   float* logits, int32_t* frame_argmax, float* frame_maxprob, float* ws,

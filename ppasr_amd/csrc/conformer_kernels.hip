@@ -96,7 +96,7 @@ struct DenseSrc {
 template <int MT, int KC, bool RELU, bool SB, typename Src>
 __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ out, int M,
-                                                          int n_chunks, float scale) {
+                                                          int n_chunks, float scale, int ldc, int n_valid) {
   constexpr int BM = 32 * MT;
   constexpr int LD = KC + 4;
   constexpr int F4_PER_ROW = KC / 4;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const int r0 = blockIdx.x * BM;
   const int tile_stride = n_chunks * G * 64;
-  const f32x4* wbase = wp + (size_t)wave * tile_stride;
+  const f32x4* wbase = wp + (size_t)(blockIdx.y * kWaves + wave) * tile_stride;  // blockIdx.y = 256-column block
   BRing<1> ring;
   ring_prime(ring, wbase, 0);
   const float* rowp[NL];
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
     if (more) write_chunk(nxt);
     __syncthreads();
   }
-  const int col = wave * 32 + (lane & 31);
+  const int col = blockIdx.y * 256 + wave * 32 + (lane & 31);
   const float bv = bias[col];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
       int m = r0 + mt * 32 + acc_row(r, lane);
       float v = SB ? acc[mt][0][r] * scale + bv : (acc[mt][0][r] + bv) * scale;
       if (RELU) v = fmaxf(v, 0.f);
-      if (m < M) out[(size_t)m * kD + col] = v;
+      if (m < M && col < n_valid) out[(size_t)m * ldc + col] = v;
     }
 }
 
@@ -164,7 +164,7 @@ void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, i
   constexpr int MT = 4, KC = 64;
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
   hipLaunchKernelGGL((k_gemm_stream<MT, KC, true, false, Conv2Src>), dim3((M + 32 * MT - 1) / (32 * MT)), dim3(kThreads), lds, st, src,
-                     fw.conv2_w, fw.conv2_b, y2, M, 36, 1.0f);
+                     fw.conv2_w, fw.conv2_b, y2, M, 36, 1.0f, kD, kD);
 }
 void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, bool scale_before_bias,
                   hipStream_t st) {
@@ -173,10 +173,21 @@ void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, fl
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
   if (scale_before_bias)
     hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, true, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src,
-                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale);
+                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD);
   else
     hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src,
-                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale);
+                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD);
+}
+
+// out[M][ldc] (columns < n_valid) = A[M][K] * Wpacked + bias ; K % 256 == 0 ; weights / bias padded to a multiple of
+// 256 columns.  Used by the DeepSpeech2 path (LSTM input projections, CTC head).
+void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, float* out, int M, int K, int n_cols_padded,
+                  int ldc, int n_valid, hipStream_t st) {
+  constexpr int MT = 1, KC = 256;
+  DenseSrc src{a, lda, KC};
+  size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
+  hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, n_cols_padded / 256),
+                     dim3(kThreads), lds, st, src, w, bias, out, M, K / KC, 1.0f, ldc, n_valid);
 }
 
 // =====================================================================================

@@ -1,0 +1,191 @@
+// ds2_kernels.hip -- DeepSpeech2 conv + LSTM stack (ppasr/model_utils/deepspeech2/{encoder,conv}.py).
+//   conv front-end  : Conv2dSubsampling4Pure (conv.py:5-21): Conv2D(1->32,3,s2)+ReLU, Conv2D(32->32,3,s2)+ReLU,
+//                     [B,T',32*19] with feature index c*19+f, x_len = ((len-1)//2-1)//2
+//   LSTM layer      : input projection for all frames at once on the MFMA GEMM (launch_dense), then the
+//                     recurrence as one small kernel per time step: the 4H x H recurrent matrix is sharded
+//                     over 256 workgroups (4 hidden units x 4 gates = 16 rows = 64 KiB each, served from the
+//                     XCD's own L2 slice after the first step because block->XCD placement is stable);
+//                     sequence_length semantics of paddle.nn.LSTM (encoder.py:89-91): steps >= len leave the
+//                     state untouched and the output zero; the reverse direction walks t = len-1-s.
+//   LayerNorm       : nn.LayerNorm over 1024 / 2048 features (encoder.py:54,93)
+// The recurrence is latency-bound (one dependent step = h_{t-1} broadcast + 16 dot products per
+// workgroup), not MFMA- or HBM-bound.
+#include "ds2_kernels.h"
+
+#include <math.h>
+
+namespace ppasr {
+
+// CMVN + conv1 (1->32) + ReLU -> y1 [B][T1][F1][32]
+__global__ __launch_bounds__(256) void k_ds2_conv1(const float* __restrict__ feats, const float* __restrict__ mean,
+                                                   const float* __restrict__ istd, const float* __restrict__ w /*[9][32]*/,
+                                                   const float* __restrict__ bias, float* __restrict__ y1, int T, int F,
+                                                   int T1, int F1) {
+  __shared__ float xs[3][128];
+  const int b = blockIdx.y, t1 = blockIdx.x, tid = threadIdx.x;
+  for (int idx = tid; idx < 3 * F; idx += 256) {
+    int i = idx / F, f = idx - i * F;
+    xs[i][f] = (feats[((size_t)b * T + 2 * t1 + i) * F + f] - mean[f]) * istd[f];
+  }
+  __syncthreads();
+  const int c = tid & 31;
+  float wr[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) wr[j] = w[j * 32 + c];
+  const float bv = bias[c];
+  for (int f1 = tid >> 5; f1 < F1; f1 += 8) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc = fmaf(wr[i * 3 + j], xs[i][2 * f1 + j], acc);
+    y1[(((size_t)b * T1 + t1) * F1 + f1) * 32 + c] = fmaxf(acc + bv, 0.f);
+  }
+}
+
+// conv2 (32->32, 3x3, s2) + ReLU -> x [B*Tp][ldx] with feature index c*F2 + f (conv.py:19 transpose+reshape);
+// columns [32*F2, ldx) are zero (K padding of the following GEMM).
+__global__ __launch_bounds__(256) void k_ds2_conv2(const float* __restrict__ y1, const float* __restrict__ w /*[9][32 ci][32 co]*/,
+                                                   const float* __restrict__ bias, float* __restrict__ x, int T1, int F1,
+                                                   int Tp, int F2, int ldx) {
+  __shared__ float tile[3][40][32];  // 3 rows x F1 (<=40) x 32 channels
+  const int b = blockIdx.y, tp = blockIdx.x, tid = threadIdx.x;
+  for (int idx = tid; idx < 3 * F1 * 32; idx += 256) {
+    int i = idx / (F1 * 32), r = idx - i * F1 * 32;
+    tile[i][r >> 5][r & 31] = y1[(((size_t)b * T1 + 2 * tp + i) * F1) * 32 + r];
+  }
+  __syncthreads();
+  const int co = tid & 31;
+  float* row = x + ((size_t)b * Tp + tp) * ldx;
+  for (int f2 = tid >> 5; f2 < F2; f2 += 8) {
+    float acc = 0.f;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        const float* wp = w + ((i * 3 + j) * 32) * 32 + co;
+        const float* tp_ = &tile[i][2 * f2 + j][0];
+#pragma unroll 8
+        for (int ci = 0; ci < 32; ++ci) acc = fmaf(wp[ci * 32], tp_[ci], acc);
+      }
+    row[co * F2 + f2] = fmaxf(acc + bias[co], 0.f);
+  }
+  for (int c = 32 * F2 + tid; c < ldx; c += 256) row[c] = 0.f;
+}
+
+__global__ void k_ds2_lens(const int64_t* __restrict__ lens, int32_t* __restrict__ out32, int64_t* __restrict__ out64, int B,
+                           int Tp) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int64_t l = ((lens[b] - 1) / 2 - 1) / 2;  // conv.py:20
+  l = l < 0 ? 0 : (l > Tp ? Tp : l);
+  out32[b] = (int32_t)l;
+  if (out64) out64[b] = l;
+}
+
+// One LSTM time step for all utterances, both directions (blockIdx.y).  Gate order i, f, g, o (paddle.nn.LSTM).
+//   gx    [dirs][B*T][4H]  input projections + b_ih + b_hh
+//   whh   [dirs][4H][H]
+//   hprev / hnext [dirs][B][H] (ping-pong), c [dirs][B][H] (in place: a block owns its 4 units)
+//   y     [B*T][dirs*H], pre-zeroed (frames >= len stay zero)
+__global__ __launch_bounds__(256) void k_lstm_step(const float* __restrict__ gx, const float* __restrict__ whh,
+                                                   const float* __restrict__ hprev, float* __restrict__ hnext,
+                                                   float* __restrict__ c, float* __restrict__ y,
+                                                   const int32_t* __restrict__ lens, int B, int T, int H, int dirs,
+                                                   int step) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* hs = smem;          // [H]
+  float* gates = smem + H;   // [16]
+  const int dir = blockIdx.y, j0 = blockIdx.x * 4, tid = threadIdx.x;
+  const int r = tid >> 4, part = tid & 15;  // r = gate*4 + unit ; 16 threads per row
+  const int gate = r >> 2, unit = r & 3;
+  const int per = H / 16;                  // elements per thread (64 for H = 1024)
+  const float* wrow = whh + ((size_t)dir * 4 * H + (size_t)gate * H + j0 + unit) * H + part * per;
+  const float* hp = hprev + (size_t)dir * B * H;
+  float* hn = hnext + (size_t)dir * B * H;
+  float* cc = c + (size_t)dir * B * H;
+  const float* gxd = gx + (size_t)dir * B * T * 4 * H;
+  for (int b = 0; b < B; ++b) {
+    const int len = lens[b];
+    if (step >= len) {  // finished utterance: carry the state (final state = last valid step)
+      if (tid < 4) hn[(size_t)b * H + j0 + tid] = hp[(size_t)b * H + j0 + tid];
+      continue;
+    }
+    const int t = dir == 0 ? step : len - 1 - step;
+    for (int k = tid * 4; k < H; k += 1024) *reinterpret_cast<f32x4*>(hs + k) = *reinterpret_cast<const f32x4*>(hp + (size_t)b * H + k);
+    __syncthreads();
+    float acc = 0.f;
+    for (int k = 0; k < per; k += 4) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + k);
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(hs + part * per + k);
+      acc = fmaf(wv[0], hv[0], acc);
+      acc = fmaf(wv[1], hv[1], acc);
+      acc = fmaf(wv[2], hv[2], acc);
+      acc = fmaf(wv[3], hv[3], acc);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (part == 0) gates[r] = acc + gxd[((size_t)b * T + t) * 4 * H + (size_t)gate * H + j0 + unit];
+    __syncthreads();
+    if (tid < 4) {
+      const float gi = 1.0f / (1.0f + expf(-gates[0 + tid]));
+      const float gf = 1.0f / (1.0f + expf(-gates[4 + tid]));
+      const float gg = tanhf(gates[8 + tid]);
+      const float go = 1.0f / (1.0f + expf(-gates[12 + tid]));
+      const size_t si = (size_t)b * H + j0 + tid;
+      const float cn = gf * cc[si] + gi * gg;
+      const float hv = go * tanhf(cn);
+      cc[si] = cn;
+      hn[si] = hv;
+      y[((size_t)b * T + t) * (size_t)(dirs * H) + (size_t)dir * H + j0 + tid] = hv;
+    }
+    __syncthreads();
+  }
+}
+
+// LayerNorm over N features (N % 256 == 0, N <= 4096), in place; one wave per row
+__global__ __launch_bounds__(256) void k_ln_wide(float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                 int M, int N) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float* p = x + (size_t)row * N;
+  const int n4 = N / 256;  // float4 per lane
+  f32x4 v[16];
+  float s = 0.f;
+  for (int i = 0; i < n4; ++i) {
+    v[i] = *reinterpret_cast<const f32x4*>(p + (i * 64 + lane) * 4);
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  const float mean = wave_sum(s) / (float)N;
+  float q = 0.f;
+  for (int i = 0; i < n4; ++i) {
+    v[i] = v[i] - mean;
+    q += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)N + 1e-5f);
+  for (int i = 0; i < n4; ++i) {
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + (i * 64 + lane) * 4);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(b + (i * 64 + lane) * 4);
+    *reinterpret_cast<f32x4*>(p + (i * 64 + lane) * 4) = v[i] * rstd * gv + bv;
+  }
+}
+
+void launch_ds2_conv1(const float* feats, const float* mean, const float* istd, const float* w, const float* bias, float* y1,
+                      int B, int T, int F, int T1, int F1, hipStream_t st) {
+  hipLaunchKernelGGL(k_ds2_conv1, dim3(T1, B), dim3(256), 0, st, feats, mean, istd, w, bias, y1, T, F, T1, F1);
+}
+void launch_ds2_conv2(const float* y1, const float* w, const float* bias, float* x, int B, int T1, int F1, int Tp, int F2,
+                      int ldx, hipStream_t st) {
+  hipLaunchKernelGGL(k_ds2_conv2, dim3(Tp, B), dim3(256), 0, st, y1, w, bias, x, T1, F1, Tp, F2, ldx);
+}
+void launch_ds2_lens(const int64_t* lens, int32_t* out32, int64_t* out64, int B, int Tp, hipStream_t st) {
+  hipLaunchKernelGGL(k_ds2_lens, dim3((B + 63) / 64), dim3(64), 0, st, lens, out32, out64, B, Tp);
+}
+void launch_lstm_step(const float* gx, const float* whh, const float* hprev, float* hnext, float* c, float* y,
+                      const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st) {
+  hipLaunchKernelGGL(k_lstm_step, dim3(H / 4, dirs), dim3(256), (H + 16) * sizeof(float), st, gx, whh, hprev, hnext, c, y,
+                     lens, B, T, H, dirs, step);
+}
+void launch_ln_wide(float* x, const float* g, const float* b, int M, int N, hipStream_t st) {
+  hipLaunchKernelGGL(k_ln_wide, dim3((M + 3) / 4), dim3(256), 0, st, x, g, b, M, N);
+}
+
+}  // namespace ppasr

@@ -18,7 +18,7 @@ import math
 
 import numpy as np
 
-__all__ = ["conformer_state_dict", "squeezeformer_state_dict", "efficient_conformer_state_dict", "synth_features", "synth_vocabulary", "DEFAULT_VOCAB_SIZE"]
+__all__ = ["conformer_state_dict", "squeezeformer_state_dict", "efficient_conformer_state_dict", "deepspeech2_state_dict", "synth_features", "synth_vocabulary", "DEFAULT_VOCAB_SIZE"]
 
 DEFAULT_VOCAB_SIZE = 4233  # <blank>, <unk>, 4230 CJK chars, <eos>  
 
@@ -212,4 +212,33 @@ def efficient_conformer_state_dict(stride_layer_idx=3, group_layer_idx=(0, 1, 2,
         if stride_layer_idx is not None and i > stride_layer_idx:
             k2 = cnn_module_kernel // 2
             sd[p + "conv_module.depthwise_conv.weight"] = _kaiming(rng, (d, 1, k2), k2)
+    return sd
+
+
+def deepspeech2_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, num_rnn_layers=5, rnn_size=1024, streaming=True,
+                           seed=1234, ctc_sharpen=4.0, perturb_norm=False, cmvn_mean=10.0, cmvn_istd=1.0 / 3.3):
+    """Random-init ``DeepSpeech2Model`` inference parameters (deepspeech2/encoder.py:8-55): plain ``nn.Conv2D``
+    (fan-in uniform), ``nn.LSTM`` (U(+-1/sqrt(H)), Paddle default), ``nn.LayerNorm``, CTC ``nn.Linear``."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    H, D = rnn_size, (1 if streaming else 2)
+    f2 = ((input_dim - 1) // 2 - 1) // 2
+    sd = {}
+    sd["encoder.global_cmvn.mean"] = np.full(input_dim, cmvn_mean, np.float32)
+    sd["encoder.global_cmvn.istd"] = np.full(input_dim, cmvn_istd, np.float32)
+    sd["encoder.conv.conv.0.weight"] = _kaiming(rng, (32, 1, 3, 3), 9)
+    sd["encoder.conv.conv.0.bias"] = _kaiming(rng, (32,), 9)
+    sd["encoder.conv.conv.2.weight"] = _kaiming(rng, (32, 32, 3, 3), 32 * 9)
+    sd["encoder.conv.conv.2.bias"] = _kaiming(rng, (32,), 32 * 9)
+    for l in range(num_rnn_layers):
+        in_dim = 32 * f2 if l == 0 else D * H
+        for d in range(D):
+            sfx = "_l0" if d == 0 else "_l0_reverse"
+            p = f"encoder.rnn.{l}."
+            sd[p + "weight_ih" + sfx] = _kaiming(rng, (4 * H, in_dim), H)
+            sd[p + "weight_hh" + sfx] = _kaiming(rng, (4 * H, H), H)
+            sd[p + "bias_ih" + sfx] = _kaiming(rng, (4 * H,), H)
+            sd[p + "bias_hh" + sfx] = _kaiming(rng, (4 * H,), H)
+        _layernorm(sd, f"encoder.layernorm_list.{l}", D * H, rng, perturb_norm)
+    sd["decoder.ctc_lo.weight"] = _xavier(rng, (D * H, vocab_size), D * H, vocab_size) * np.float32(ctc_sharpen)
+    sd["decoder.ctc_lo.bias"] = np.zeros(vocab_size, np.float32)
     return sd

@@ -1,0 +1,71 @@
+"""GPU parity: HIP DeepSpeech2 path (conv + LSTM stack + LayerNorm + CTC) vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.deepspeech2_oracle import DeepSpeech2Oracle
+from ppasr_amd.utils.synth import deepspeech2_state_dict, synth_features
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _model(sd, V, L, streaming):
+    from ppasr_amd.model_utils.deepspeech2.model import DeepSpeech2Model
+    return DeepSpeech2Model(80, V, streaming=streaming, encoder_conf=dict(num_rnn_layers=L, rnn_size=1024),
+                            state_dict=sd, device="cuda:0")
+
+
+@pytest.mark.parametrize("streaming", [True, False])
+def test_deepspeech2_matches_oracle(streaming):
+    V, L = 200, 2
+    sd = deepspeech2_state_dict(vocab_size=V, num_rnn_layers=L, streaming=streaming, seed=91, perturb_norm=True)
+    x, lens = synth_features(3, 131, lens=[131, 90, 40], seed=92)
+    model = _model(sd, V, L, streaming)
+    probs, out_lens, fh, fc = model.get_encoder_out_chunk(x, lens)
+    torch.cuda.synchronize()
+    rp, rl, rh, rc = DeepSpeech2Oracle(sd, L, 1024, streaming).forward(x, lens)
+    assert out_lens.cpu().tolist() == rl.tolist()
+    assert _rel(probs.cpu().numpy(), rp.numpy()) < TOL
+    assert _rel(fh.cpu().numpy(), rh.numpy()) < TOL and _rel(fc.cpu().numpy(), rc.numpy()) < TOL
+
+
+def test_deepspeech2_streaming_state_carry():
+    """predict_chunk_deepspeech semantics (inference_predictor.py:147-182): feeding the final states of one
+    call as the initial states of the next matches the oracle doing the same."""
+    V, L = 120, 2
+    sd = deepspeech2_state_dict(vocab_size=V, num_rnn_layers=L, streaming=True, seed=93)
+    x, _ = synth_features(1, 67 * 2, seed=94)
+    model = _model(sd, V, L, True)
+    oracle = DeepSpeech2Oracle(sd, L, 1024, True)
+    h = c = rh = rc = None
+    for s in (0, 67):
+        chunk = x[:, s:s + 67]
+        lens = np.array([67])
+        probs, _, h, c = model.get_encoder_out_chunk(chunk, lens, h, c)
+        rp, _, rh, rc = oracle.forward(chunk, lens, rh, rc)
+        assert _rel(probs.cpu().numpy(), rp.numpy()) < TOL
+
+
+def test_deepspeech2_config1_shape():
+    """BASELINE configs[0]: DeepSpeech2 non-streaming (bidirectional), 5 layers x 1024, B=1, 5 s utterance, greedy."""
+    from ppasr_amd.decoders.ctc_greedy_decoder import greedy_decode_ids
+    V, L = 4233, 5
+    sd = deepspeech2_state_dict(vocab_size=V, num_rnn_layers=L, streaming=False, seed=95)
+    x, lens = synth_features(1, 498, seed=96)
+    model = _model(sd, V, L, False)
+    probs = model.get_encoder_out(x, lens)
+    assert tuple(probs.shape) == (1, 123, V)
+    rp, _, _, _ = DeepSpeech2Oracle(sd, L, 1024, False).forward(x, lens)
+    assert _rel(probs.cpu().numpy(), rp.numpy()) < TOL
+    tokens, n, score, _, _ = greedy_decode_ids(probs)
+    ref = rp[0].numpy().argmax(1)
+    keep = np.r_[True, ref[1:] != ref[:-1]]
+    ids = ref[keep]
+    assert np.array_equal(tokens[0, :int(n[0])].cpu().numpy(), ids[ids != 0])
