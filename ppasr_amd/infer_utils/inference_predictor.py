@@ -33,8 +33,8 @@ class InferencePredictor:
         self.configs = configs
         self.use_model = use_model
         self.streaming = streaming
-        if use_model != "conformer":
-            raise NotImplementedError(f"use_model={use_model!r}: built in this round: 'conformer' (see DESIGN.md §7)")
+        if use_model not in ("conformer", "efficient_conformer", "squeezeformer", "deepspeech2"):
+            raise Exception(f"没有该模型：{use_model}")  # SUPPORT_MODEL, ppasr/__init__.py:3
         if state_dict is None:
             if not os.path.exists(model_dir):
                 raise Exception("模型文件不存在，请检查%s是否存在！" % model_dir)
@@ -44,10 +44,20 @@ class InferencePredictor:
         pre = _get(configs, "preprocess_conf", {})
         input_dim = int(_get(pre, "n_mels", 80))
         if vocab_size is None:
-            vocab_size = int(state_dict["ctc.ctc_lo.bias"].shape[0])
-        self.model = ConformerModel(input_dim, vocab_size, streaming=streaming, encoder_conf=enc,
-                                    state_dict=state_dict, device=device)
-        self._stream = self.model.new_stream() if streaming else None
+            key = "decoder.ctc_lo.bias" if use_model == "deepspeech2" else "ctc.ctc_lo.bias"
+            vocab_size = int(state_dict[key].shape[0])
+        # model factory (trainer.py:172-210)
+        if use_model == "conformer":
+            cls = ConformerModel
+        elif use_model == "efficient_conformer":
+            from ppasr_amd.model_utils.efficient_conformer.model import EfficientConformerModel as cls
+        elif use_model == "squeezeformer":
+            from ppasr_amd.model_utils.squeezeformer.model import SqueezeformerModel as cls
+        else:
+            from ppasr_amd.model_utils.deepspeech2.model import DeepSpeech2Model as cls
+        self.model = cls(input_dim, vocab_size, streaming=streaming, encoder_conf=enc, state_dict=state_dict,
+                         device=device)
+        self._stream = self.model.new_stream() if (streaming and use_model == "conformer") else None
         self.output_state_h = None
         self.output_state_c = None
 
@@ -75,13 +85,18 @@ class InferencePredictor:
 
     def predict_greedy(self, speech, speech_lengths, trim_to_length=False):
         """Fused encoder + greedy decode: -> (tokens, n_tokens, score) device tensors."""
+        if self.use_model == "deepspeech2":
+            from ppasr_amd.decoders.ctc_greedy_decoder import greedy_decode_ids
+            probs, out_lens, _, _ = self.model._run(speech, speech_lengths)
+            t, n, s, _, _ = greedy_decode_ids(probs, out_lens.to(torch.int32) if trim_to_length else None)
+            return t, n, s
         return self.model.encode_greedy(speech, speech_lengths, trim_to_length=trim_to_length)
 
     def predict(self, speech, speech_lengths):
         """inference_predictor.py:103-145: probs [B,T',V] numpy.  (The reference's exported streaming
         graph runs the utterance as one chunk with empty caches and no mask, :127-137 — identical to
         get_encoder_out for un-padded input; padded batches use the masked batch path here.)"""
-        if self.streaming:
+        if self.streaming and self._stream is not None:
             self.reset_stream()
         return self.predict_device(speech, speech_lengths).cpu().numpy()
 
@@ -90,10 +105,20 @@ class InferencePredictor:
         """inference_predictor.py:184-212 -> probs [1,c,V] numpy; caches/offset advance on the device."""
         if not ("former" in self.use_model and self.streaming):
             raise Exception(f"当前模型不支持该方法，当前模型为：{self.use_model}")
+        if self._stream is None:
+            raise NotImplementedError(f"forward_chunk of {self.use_model} is not built yet (DESIGN.md §7)")
         return self._stream.encode_chunk(np.asarray(x_chunk, np.float32), int(required_cache_size)).cpu().numpy()
 
     def predict_chunk_deepspeech(self, x_chunk):
-        raise Exception(f"当前模型不支持该方法，当前模型为：{self.use_model}")
+        """inference_predictor.py:147-182 -> (probs [B,c,V], lens [B]) numpy; the LSTM states
+        (output_state_h / output_state_c, [layers,B,rnn_size]) stay on the device between calls."""
+        if not (self.use_model == "deepspeech2" and self.streaming):
+            raise Exception(f"当前模型不支持该方法，当前模型为：{self.use_model}")
+        x = np.asarray(x_chunk, np.float32)
+        lens = np.full(x.shape[0], x.shape[1], np.int64)
+        probs, out_lens, self.output_state_h, self.output_state_c = self.model.get_encoder_out_chunk(
+            x, lens, self.output_state_h, self.output_state_c)
+        return probs.cpu().numpy(), out_lens.cpu().numpy()
 
     def reset_stream(self):
         """inference_predictor.py:215-220"""

@@ -5,6 +5,7 @@ the HIP library.  VAD (`predict_long`), punctuation and ITN are separate models 
 path and are not provided (``use_pun=True`` / ``is_itn=True`` raise).
 """
 import numpy as np
+import torch
 import yaml
 
 from ppasr_amd.data_utils.featurizer import AudioFeaturizer, TextFeaturizer, load_audio, pcm_bytes_to_float
@@ -116,10 +117,16 @@ class PPASRPredictor:
         for cur in range(0, num_frames - left_frames + 1, stride):
             end = min(cur + decoding_window, num_frames)
             x = self.cached_feat[:, cur:end, :]
-            required_cache_size = decoding_chunk_size * -1
-            probs = self.predictor._stream.encode_chunk(x, required_cache_size)  # device tensor [1,c,V]
-            if self.configs.decoder == "ctc_beam_search":
+            if self.configs.use_model == "deepspeech2":
+                probs_np, lens = self.predictor.predict_chunk_deepspeech(x_chunk=x)
+                probs = torch.from_numpy(probs_np)
+            else:
+                required_cache_size = decoding_chunk_size * -1
+                if self.predictor._stream is None:
+                    raise NotImplementedError(f"streaming of {self.configs.use_model} is not built yet")
+                probs = self.predictor._stream.encode_chunk(x, required_cache_size)  # device tensor [1,c,V]
                 lens = np.array([probs.shape[1]])
+            if self.configs.decoder == "ctc_beam_search":
                 score, text = self.beam_search_decoder.decode_chunk(probs=probs, logits_lens=lens)
             else:
                 score, text, self.greedy_last_max_prob_list, self.greedy_last_max_index_list = greedy_decoder_chunk(

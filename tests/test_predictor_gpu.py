@@ -1,0 +1,88 @@
+"""GPU tests of the drop-in surface B1/B2: PPASRPredictor.predict / predict_stream / reset_stream and
+InferencePredictor (ppasr/predict.py, ppasr/infer_utils/inference_predictor.py) on synthetic audio."""
+import numpy as np
+import pytest
+import torch
+
+from ppasr_amd.utils.synth import conformer_state_dict, deepspeech2_state_dict, synth_vocabulary
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(use_model="conformer", decoder="ctc_greedy", L=2):
+    enc = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
+    if use_model == "deepspeech2":
+        enc = dict(num_rnn_layers=L, rnn_size=1024, use_gru=False)
+    return dict(encoder_conf=enc, preprocess_conf=dict(feature_method="fbank", n_mels=80, sample_rate=16000,
+                                                        use_dB_normalization=True, target_dB=-20),
+                ctc_beam_search_decoder_conf=dict(alpha=2.2, beta=4.3, beam_size=10, num_processes=10, cutoff_prob=0.99,
+                                                  cutoff_top_n=40, language_model_path=None),
+                use_model=use_model, streaming=True, decoder=decoder, metrics_type="cer")
+
+
+def _audio(seconds, seed=0):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    t = np.arange(int(16000 * seconds)) / 16000.0
+    x = 0.1 * np.sin(2 * np.pi * 220 * t) * (1 + 0.5 * np.sin(2 * np.pi * 3 * t)) + 0.02 * rng.standard_normal(t.shape)
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize("decoder", ["ctc_greedy", "ctc_beam_search"])
+def test_predict_and_predict_stream_conformer(decoder):
+    from ppasr_amd.predict import PPASRPredictor
+    V = 300
+    vocab = synth_vocabulary(V)
+    sd = conformer_state_dict(vocab_size=V, num_blocks=2, seed=3)
+    p = PPASRPredictor(configs=_cfg(decoder=decoder), state_dict=sd, vocab_list=vocab, warmup=True)
+    wav = _audio(3.0)
+    res = p.predict(audio_data=wav)
+    assert set(res) == {"text", "score"} and isinstance(res["text"], str)
+    # streaming: 0.5 s PCM16 chunks (infer_path.py:49-65 drives predict_stream this way)
+    pcm = (np.clip(wav, -1, 1) * 32767).astype(np.int16).tobytes()
+    step = 16000 * 2 // 2
+    out = None
+    n_none = 0
+    for i in range(0, len(pcm), step):
+        r = p.predict_stream(audio_data=pcm[i:i + step], is_end=(i + step >= len(pcm)))
+        if r is None:
+            n_none += 1
+        else:
+            out = r
+    assert out is not None and isinstance(out["text"], str)
+    assert n_none >= 1  # nothing is returned until 67 feature frames are buffered (predict.py:287)
+    assert p.predictor.offset[0] > 0 and p.predictor.att_cache.shape[2] == p.predictor.offset[0]
+    p.reset_stream()
+    assert p.predictor.offset[0] == 0 and p.predictor.att_cache.shape == (0, 0, 0, 0)
+
+
+def test_inference_predictor_matches_model_and_numpy_io():
+    from ppasr_amd.infer_utils.inference_predictor import InferencePredictor
+    V = 200
+    sd = conformer_state_dict(vocab_size=V, num_blocks=2, seed=5)
+    ip = InferencePredictor(_cfg(), "conformer", streaming=True, state_dict=sd)
+    x = np.random.default_rng(0).standard_normal((1, 131, 80)).astype(np.float32) * 3 + 10
+    probs = ip.predict(x, np.array([131], np.int64))
+    assert isinstance(probs, np.ndarray) and probs.shape == (1, 32, V)
+    c1 = ip.predict_chunk_conformer(x[:, :67], -16)
+    c2 = ip.predict_chunk_conformer(x[:, 64:131], -16)
+    assert c1.shape == (1, 16, V) and c2.shape == (1, 16, V) and int(ip.offset[0]) == 32
+    assert ip.cnn_cache.shape == (2, 1, 256, 14) and ip.att_cache.shape == (2, 4, 32, 128)
+    with pytest.raises(Exception):
+        ip.predict_chunk_deepspeech(x)
+
+
+def test_deepspeech2_predictor_streaming():
+    from ppasr_amd.predict import PPASRPredictor
+    V = 120
+    sd = deepspeech2_state_dict(vocab_size=V, num_rnn_layers=2, streaming=True, seed=7)
+    p = PPASRPredictor(configs=_cfg("deepspeech2"), state_dict=sd, vocab_list=synth_vocabulary(V), warmup=False)
+    wav = _audio(2.0, 1)
+    assert isinstance(p.predict(audio_data=wav)["text"], str)
+    pcm = (np.clip(wav, -1, 1) * 32767).astype(np.int16).tobytes()
+    r = None
+    for i in range(0, len(pcm), 32000):
+        r = p.predict_stream(audio_data=pcm[i:i + 32000], is_end=(i + 32000 >= len(pcm))) or r
+    assert r is not None
+    assert p.predictor.output_state_h.shape == (2, 1, 1024)
+    p.reset_stream()
+    assert p.predictor.output_state_h is None
