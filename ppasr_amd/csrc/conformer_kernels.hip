@@ -257,33 +257,39 @@ void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, i
 // of 192, i.e. token j / head h / feature f lives at flat offset j*768 + h*192 + f of the utterance's
 // [T'][256] activations -- the same formula as DK = 64 with a token stride of 256.
 // -------------------------------------------------------------------------------------
-constexpr int kSld = 129, kKld = 36;
+constexpr int kSld = 129;
 template <int DK>
 struct AttnCfg {
-  static constexpr int G = DK / 64;             // frames per token
-  static constexpr int NFC = 2 * DK / 32;       // 32-feature chunks of K' = [k | p]
+  static constexpr int G = DK / 64;        // frames per token
+  static constexpr int NG = 2 * DK / 8;    // 8-wide k-groups of the score contraction over K' = [k | p]
   static constexpr int QLD = 2 * DK + 4;
-  static constexpr int NCT = DK / 32;           // 32-column tiles of the context
-  static constexpr int VLD = DK + 4;
-  static constexpr int VKEYS = DK == 64 ? 128 : 64;  // keys per V stage
-  static constexpr int KVF = (128 * kKld > VKEYS * VLD) ? 128 * kKld : VKEYS * VLD;
-  static constexpr int LDS_FLOATS = 32 * QLD + 32 * kSld + KVF + 96;
+  static constexpr int NCT = DK / 32;      // 32-column tiles of the context
+  static constexpr int NO = NCT / 2;       // context column tiles per wave
+  static constexpr int QT = 64;            // queries per workgroup (two MFMA row tiles)
+  static constexpr int LDS_FLOATS = QT * QLD + QT * kSld + 3 * QT;
 };
 
+// Block = (64-query tile, head, utterance), 4 waves.  Per 128-key block:
+//   S phase : wave w owns keys [32w, 32w+32); the B operand (K' rows) is read straight from global / L2 into
+//             registers (lane = key, 4 consecutive features per load, the row-block GEMM's fragment trick) with a
+//             4-deep prefetch ring -- no LDS staging, no barriers; A = Q' from LDS; two row tiles share each B load.
+//   softmax : online (running max / sum per query row), 16-lane groups handle one row each (4 rows per wave-op).
+//   PV      : wave = (column-tile group, key half); B = V rows from global (one dword per lane per MFMA, two
+//             coalesced 128-B segments per wave-load), A = P from LDS.
+// Three barriers per key block; LDS holds only Q' and the score block, so several workgroups share a CU.
 template <int DK>
 __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   using C = AttnCfg<DK>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Qs = smem;                 // [32][QLD]  Q' = [q+u | q+v]
-  float* Ss = Qs + 32 * C::QLD;     // [32][129]  scores / probabilities of the current key block
-  float* KV = Ss + 32 * kSld;       // union: K' chunk [128][36]  |  V stage [VKEYS][VLD]  |  final O scratch
-  float* stM = KV + C::KVF;         // running max   [32]
-  float* stL = stM + 32;            // running sum   [32]
-  float* stA = stL + 32;            // rescale alpha [32]
+  float* Qs = smem;                      // [64][QLD]  Q' = [q+u | q+v]
+  float* Ss = Qs + C::QT * C::QLD;       // [64][129]  scores / probabilities of the current key block; final O scratch
+  float* stM = Ss + C::QT * kSld;        // running max   [64]
+  float* stL = stM + C::QT;              // running sum   [64]
+  float* stA = stL + C::QT;              // rescale alpha [64]
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-  const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
-  const int T1 = a.T1, T2 = a.T2;   // tokens
-  const int F1 = a.q_frames, F2 = a.kv_frames;  // valid frames behind the tokens (== tokens when G == 1)
+  const int q0 = blockIdx.x * C::QT, h = blockIdx.y, b = blockIdx.z;
+  const int T1 = a.T1, T2 = a.T2;                // tokens
+  const int F1 = a.q_frames, F2 = a.kv_frames;   // valid frames behind the tokens (== tokens when G == 1)
   const float* __restrict__ qb = a.q + (size_t)b * F1 * a.q_stride;
   const float* __restrict__ kbp = a.k + (size_t)b * F2 * a.k_stride;
   const float* __restrict__ vbp = a.v + (size_t)b * F2 * a.v_stride;
@@ -291,192 +297,222 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   const int pstride = a.pos_stride;
   float* __restrict__ ctx = a.ctx + (size_t)b * F1 * kD;
   const int64_t len_b = a.lens ? a.lens[b] : (int64_t)a.mask_mul * T2;
-  // element (token j, head h, feature f) of a [frames][stride] buffer, zero beyond the valid frames
-  auto tok = [&](const float* base, int stride, int nframes, int j, int f) -> f32x4 {
+  // element (token j, head h, feature f) lives at flat offset j*G*256 + h*DK + f of the utterance's [frames][256]
+  // activations (G = 1: plain heads; G = 3: pad4group's re-cut of 3 frames into 4 heads of 192); zero beyond the
+  // valid frames (the zero-padded tail group).
+  auto tok4 = [&](const float* base, int stride, int nframes, int j, int f) -> f32x4 {
     const int flat = j * (C::G * kD) + h * DK + f;
     const int frame = flat >> 8, feat = flat & 255;
     if (frame >= nframes) return f32x4{0.f, 0.f, 0.f, 0.f};
     return *reinterpret_cast<const f32x4*>(base + (size_t)frame * stride + feat);
   };
-  auto tok_pos = [&](int j, int f) -> f32x4 {
+  // K' fragment of k-group g for key j: features 8g+4*(lane>>5).. ; first DK/8 groups from k, the rest from p
+  auto kfrag = [&](int j, int g) -> f32x4 {
+    if (j >= T2) return f32x4{0.f, 0.f, 0.f, 0.f};
+    const int f = 8 * (g < DK / 8 ? g : g - DK / 8) + 4 * (lane >> 5);
+    if (g < DK / 8) return tok4(kbp, a.k_stride, F2, j, f);
     const int flat = j * (C::G * kD) + h * DK + f;
     const int frame = flat >> 8, feat = flat & 255;
     if (frame >= F2) return f32x4{0.f, 0.f, 0.f, 0.f};
     return *reinterpret_cast<const f32x4*>(ptab + (size_t)frame * pstride * kD + feat);
   };
+  auto vval = [&](int j, int col) -> float {
+    if (j >= T2) return 0.f;
+    const int flat = j * (C::G * kD) + h * DK + col;
+    const int frame = flat >> 8, feat = flat & 255;
+    return frame < F2 ? vbp[(size_t)frame * a.v_stride + feat] : 0.f;
+  };
 
   // ---- Q' ----
 #pragma unroll
-  for (int i = 0; i < 32 * DK / 4 / 256; ++i) {
+  for (int i = 0; i < C::QT * DK / 4 / 256; ++i) {
     int idx = tid + 256 * i;
     int row = idx / (DK / 4), f4 = idx - row * (DK / 4);
     f32x4 q = {0.f, 0.f, 0.f, 0.f};
-    if (q0 + row < T1) q = tok(qb, a.q_stride, F1, q0 + row, f4 * 4);
+    if (q0 + row < T1) q = tok4(qb, a.q_stride, F1, q0 + row, f4 * 4);
     f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + h * DK + f4 * 4);
     f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + h * DK + f4 * 4);
     *reinterpret_cast<f32x4*>(Qs + row * C::QLD + f4 * 4) = q + u;
     *reinterpret_cast<f32x4*>(Qs + row * C::QLD + DK + f4 * 4) = q + v;
   }
-  if (tid < 32) {
+  if (tid < C::QT) {
     stM[tid] = -INFINITY;
     stL[tid] = 0.f;
   }
-  constexpr int NO = C::NCT / 2;  // context column tiles per wave
-  f32x16 acc_o[NO];
+  f32x16 acc_o[2][C::NO];
 #pragma unroll
-  for (int t = 0; t < NO; ++t)
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc_o[t][r] = 0.f;
+    for (int t = 0; t < C::NO; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_o[mt][t][r] = 0.f;
   const int ctg = wave & 1, kh = wave >> 1;
   const float score_div = DK == 64 ? 8.0f : 13.856406460551018f;  // sqrt(d_k [* group_size])
+  __syncthreads();
 
   const int nkb = (T2 + 127) / 128;
   for (int kb = 0; kb < nkb; ++kb) {
     const int key0 = kb * 128;
-    // ---- S = Q' K'^T over 32-feature chunks (first half of the chunks: k, second half: p) ----
-    f32x16 acc_s;
+    // ---- S = Q' K'^T : keys of this wave = key0 + 32*wave + (lane & 31) ----
+    f32x16 acc_s[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc_s[r] = 0.f;
-    f32x4 stg[4];
-    auto load_kchunk = [&](int fc) {
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int idx = tid + 256 * i;
-        int key = idx >> 3, f4 = idx & 7;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (key0 + key < T2) {
-          v = (fc < C::NFC / 2) ? tok(kbp, a.k_stride, F2, key0 + key, fc * 32 + f4 * 4)
-                                : tok_pos(key0 + key, (fc - C::NFC / 2) * 32 + f4 * 4);
+      for (int r = 0; r < 16; ++r) acc_s[mt][r] = 0.f;
+    {
+      const int jkey = key0 + wave * 32 + (lane & 31);
+      constexpr int PF = 4;
+      f32x4 ring[PF];
+#pragma unroll
+      for (int s = 0; s < PF; ++s) ring[s] = kfrag(jkey, s);
+      const float* a_ptr = Qs + (lane & 31) * C::QLD + 4 * (lane >> 5);
+#pragma unroll
+      for (int g = 0; g < C::NG; ++g) {
+        const f32x4 bb = ring[g % PF];
+        if (g + PF < C::NG) ring[g % PF] = kfrag(jkey, g + PF);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(a_ptr + 8 * g);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(a_ptr + 32 * C::QLD + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc_s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb[j], acc_s[0], 0, 0, 0);
+          acc_s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bb[j], acc_s[1], 0, 0, 0);
         }
-        stg[i] = v;
-      }
-    };
-    auto write_kchunk = [&]() {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int idx = tid + 256 * i;
-        int key = idx >> 3, f4 = idx & 7;
-        *reinterpret_cast<f32x4*>(KV + key * kKld + f4 * 4) = stg[i];
-      }
-    };
-    load_kchunk(0);
-    for (int fc = 0; fc < C::NFC; ++fc) {
-      __syncthreads();  // previous readers of KV (PV of last block / MFMAs of last chunk) are done
-      write_kchunk();
-      __syncthreads();
-      if (fc + 1 < C::NFC) load_kchunk(fc + 1);
-      // Q' columns: chunk fc of k pairs with (q+u) columns, chunk of p with (q+v) columns
-      const int qcol = (fc < C::NFC / 2) ? fc * 32 : DK + (fc - C::NFC / 2) * 32;
-      const float* a_ptr = Qs + (lane & 31) * C::QLD + qcol + 4 * (lane >> 5);
-      const float* b_ptr = KV + (wave * 32 + (lane & 31)) * kKld + 4 * (lane >> 5);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 av = *reinterpret_cast<const f32x4*>(a_ptr + 8 * g);
-        f32x4 bb = *reinterpret_cast<const f32x4*>(b_ptr + 8 * g);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc_s = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bb[j], acc_s, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (kb > 0) __syncthreads();  // every wave finished the previous block's PV reads of Ss
     {
       const int kl = wave * 32 + (lane & 31);
       const int key = key0 + kl;
       const bool masked = (key >= T2) || (a.mask_mul * (int64_t)key >= len_b);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Ss[acc_row(r, lane) * kSld + kl] = masked ? -INFINITY : acc_s[r] / score_div;
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Ss[(mt * 32 + acc_row(r, lane)) * kSld + kl] = masked ? -INFINITY : acc_s[mt][r] / score_div;
     }
-    __syncthreads();  // S complete; all K' reads done -> KV may be overwritten with V
-    // ---- online softmax over this block's 128 keys; wave handles rows 8w..8w+7 ----
-    for (int rr = 0; rr < 8; ++rr) {
-      const int row = wave * 8 + rr;
-      float v0 = Ss[row * kSld + lane], v1 = Ss[row * kSld + lane + 64];
-      float bm = wave_max(fmaxf(v0, v1));
-      float m_old = stM[row];
-      float m_new = fmaxf(m_old, bm);
-      float alpha, p0, p1;
-      if (m_new == -INFINITY) {  // nothing unmasked so far
-        alpha = 1.f;
-        p0 = 0.f;
-        p1 = 0.f;
-      } else {
-        alpha = expf(m_old - m_new);
-        p0 = expf(v0 - m_new);
-        p1 = expf(v1 - m_new);
-      }
-      float ps = wave_sum(p0 + p1);
-      Ss[row * kSld + lane] = p0;
-      Ss[row * kSld + lane + 64] = p1;
-      if (lane == 0) {
-        stM[row] = m_new;
-        stL[row] = stL[row] * alpha + ps;
-        stA[row] = alpha;
+    __syncthreads();
+    // ---- online softmax: a 16-lane group owns one row (8 keys per lane); 4 rows per wave-op, 16 rows per wave ----
+    {
+      const int grp = lane >> 4, gl = lane & 15;
+#pragma unroll 1
+      for (int it = 0; it < 4; ++it) {
+        const int row = wave * 16 + it * 4 + grp;
+        float* srow = Ss + row * kSld + gl;
+        float v[8];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = srow[16 * e];
+          bm = fmaxf(bm, v[e]);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o));
+        const float m_old = stM[row];
+        const float m_new = fmaxf(m_old, bm);
+        float alpha = 1.f, ps = 0.f;
+        if (m_new != -INFINITY) {
+          alpha = expf(m_old - m_new);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] = expf(v[e] - m_new);
+            ps += v[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ps += __shfl_xor(ps, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) srow[16 * e] = v[e];
+        if (gl == 0) {
+          stM[row] = m_new;
+          stL[row] = stL[row] * alpha + ps;
+          stA[row] = alpha;
+        }
       }
     }
     __syncthreads();
+    // ---- O = O*alpha + P V : wave -> (column-tile group ctg, 64-key half kh) ----
 #pragma unroll
-    for (int t = 0; t < NO; ++t)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc_o[t][r] *= stA[acc_row(r, lane)];
-    // ---- O += P V, V staged VKEYS keys at a time; wave -> (column-tile group ctg, key half kh) ----
-    for (int vs = 0; vs < 128 / C::VKEYS; ++vs) {
-      if (vs > 0) __syncthreads();  // previous stage fully consumed
-      constexpr int NV = C::VKEYS * DK / 4 / 256;
+      for (int t = 0; t < C::NO; ++t)
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        int idx = tid + 256 * i;
-        int key = idx / (DK / 4), f4 = idx - key * (DK / 4);
-        const int kg = key0 + vs * C::VKEYS + key;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (kg < T2) v = tok(vbp, a.v_stride, F2, kg, f4 * 4);
-        *reinterpret_cast<f32x4*>(KV + key * C::VLD + f4 * 4) = v;
-      }
-      __syncthreads();
-      constexpr int KW = C::VKEYS / 2;  // keys per wave in this stage
-      const float* a_ptr = Ss + (lane & 31) * kSld + vs * C::VKEYS + kh * KW + (lane >> 5);
-      const float* b_ptr = KV + (kh * KW + (lane >> 5)) * C::VLD + ctg * NO * 32 + (lane & 31);
-#pragma unroll 4
-      for (int s = 0; s < KW / 2; ++s) {
-        const float av = a_ptr[2 * s];
+        for (int r = 0; r < 16; ++r) acc_o[mt][t][r] *= stA[mt * 32 + acc_row(r, lane)];
+    {
+      const int kbase = key0 + kh * 64 + (lane >> 5);
+      const int cbase = ctg * C::NO * 32 + (lane & 31);
+      const float* a_ptr = Ss + (lane & 31) * kSld + kh * 64 + (lane >> 5);
+      constexpr int PFV = 8;
+      float ringv[PFV][C::NO];
 #pragma unroll
-        for (int t = 0; t < NO; ++t)
-          acc_o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_ptr[2 * s * C::VLD + t * 32], acc_o[t], 0, 0, 0);
+      for (int s = 0; s < PFV; ++s)
+#pragma unroll
+        for (int t = 0; t < C::NO; ++t) ringv[s][t] = vval(kbase + 2 * s, cbase + t * 32);
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        float bv[C::NO];
+#pragma unroll
+        for (int t = 0; t < C::NO; ++t) bv[t] = ringv[s % PFV][t];
+        if (s + PFV < 32) {
+#pragma unroll
+          for (int t = 0; t < C::NO; ++t) ringv[s % PFV][t] = vval(kbase + 2 * (s + PFV), cbase + t * 32);
+        }
+        const float a0 = a_ptr[2 * s];
+        const float a1 = a_ptr[32 * kSld + 2 * s];
+#pragma unroll
+        for (int t = 0; t < C::NO; ++t) {
+          acc_o[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[t], acc_o[0][t], 0, 0, 0);
+          acc_o[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[t], acc_o[1][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // next iteration's first __syncthreads() protects KV / Ss
   }
   __syncthreads();
   // combine the two key halves, normalise, store
-  float* Osum = KV;  // [NCT][32][33]
+  float* Osum = Ss;  // [NCT][64][33]  (NCT*64*33 <= 64*129 for NCT <= 3 ... checked below)
+  static_assert(C::NO * 2 * 64 * 33 <= 2 * 64 * kSld || DK == 192, "scratch");
+  // DK = 192 needs 6*64*33 floats = 12672 > 64*129: the Q' region (64*388 floats) is free by now
+  float* scratch = (DK == 192) ? Qs : Osum;
   if (kh == 1) {
 #pragma unroll
-    for (int t = 0; t < NO; ++t)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Osum[((ctg * NO + t) * 32 + acc_row(r, lane)) * 33 + (lane & 31)] = acc_o[t][r];
+      for (int t = 0; t < C::NO; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          scratch[((ctg * C::NO + t) * 64 + mt * 32 + acc_row(r, lane)) * 33 + (lane & 31)] = acc_o[mt][t][r];
   }
   __syncthreads();
   if (kh == 0) {
 #pragma unroll
-    for (int t = 0; t < NO; ++t)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int row = acc_row(r, lane);
-        float l = stL[row];
-        float o = acc_o[t][r] + Osum[((ctg * NO + t) * 32 + row) * 33 + (lane & 31)];
-        o = (l > 0.f) ? o / l : 0.f;  // fully masked row -> 0 (attention.py:118)
-        if (q0 + row < T1) {
-          const int flat = (q0 + row) * (C::G * kD) + h * DK + (ctg * NO + t) * 32 + (lane & 31);
-          const int frame = flat >> 8, feat = flat & 255;
-          if (frame < F1) ctx[(size_t)frame * kD + feat] = o;  // x[:, :T - padding_q]  (efficient attention.py:124-125)
+      for (int t = 0; t < C::NO; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mt * 32 + acc_row(r, lane);
+          const float l = stL[row];
+          float o = acc_o[mt][t][r] + scratch[((ctg * C::NO + t) * 64 + row) * 33 + (lane & 31)];
+          o = (l > 0.f) ? o / l : 0.f;  // fully masked row -> 0 (attention.py:118)
+          if (q0 + row < T1) {
+            const int flat = (q0 + row) * (C::G * kD) + h * DK + (ctg * C::NO + t) * 32 + (lane & 31);
+            const int frame = flat >> 8, feat = flat & 255;
+            if (frame < F1) ctx[(size_t)frame * kD + feat] = o;  // x[:, :T - padding_q] (efficient attention.py:124-125)
+          }
         }
-      }
   }
 }
 constexpr size_t kLdsAttn = AttnCfg<64>::LDS_FLOATS * sizeof(float);
 constexpr size_t kLdsAttnG = AttnCfg<192>::LDS_FLOATS * sizeof(float);
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st) {
   if (a.group == 3)
-    hipLaunchKernelGGL(k_attention<192>, dim3((a.T1 + 31) / 32, H, B), dim3(256), kLdsAttnG, st, a);
+    hipLaunchKernelGGL(k_attention<192>, dim3((a.T1 + 63) / 64, H, B), dim3(256), kLdsAttnG, st, a);
   else
-    hipLaunchKernelGGL(k_attention<64>, dim3((a.T1 + 31) / 32, H, B), dim3(256), kLdsAttn, st, a);
+    hipLaunchKernelGGL(k_attention<64>, dim3((a.T1 + 63) / 64, H, B), dim3(256), kLdsAttn, st, a);
 }
 
 // -------------------------------------------------------------------------------------
@@ -678,7 +714,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   BRing<1> ring;
   const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
   ring_prime(ring, seg_pw2, 0);
-  dwconv_phase<KS, STREAM>(g, g_hist, bufA, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp);
+  dwconv_phase<KS, STREAM>(g, g_hist, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp);
   __syncthreads();
   // conv-module LayerNorm (nn.LayerNorm(channels), eps 1e-5, convolution.py:71) + swish, in place
   rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);

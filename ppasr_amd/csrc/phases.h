@@ -86,45 +86,42 @@ struct PadRows {  // conv-module pad masking (convolution.py:104-106,138-140): f
 // Frames before the utterance start read `gp` = GLU(pointwise_conv1(0)) because the reference
 // zero-pads BEFORE pointwise_conv1 (convolution.py:108-126); with STREAM (single stream, rows are
 // frames of one chunk) they come from the cache rows g_hist [KS-1][256] instead.
-// Output (conv + bias) -> bufA rows.  wave handles rows RW*w..; lane handles 4 channels.
+// The block's input window (KS-1 halo rows + 32 rows) and the tap weights are staged in LDS
+// (win_lds: (KS-1+32) x kLda floats, w_lds: KS x kLda floats -- both buffers are free at this point of
+// the kernels), so the phase needs few registers whatever KS is.  Output (conv + bias) -> bufA rows.
 template <int KS, bool STREAM>
 __device__ __forceinline__ void dwconv_phase(const float* __restrict__ g, const float* __restrict__ g_hist, float* bufA,
-                                             const float* __restrict__ dw_w, const float* __restrict__ dw_b,
-                                             const float* __restrict__ glu_pad, int r0, int M, int Tp) {
+                                             float* win_lds, float* w_lds, const float* __restrict__ dw_w,
+                                             const float* __restrict__ dw_b, const float* __restrict__ glu_pad, int r0,
+                                             int M, int Tp) {
   const int lane = lane_id(), wave = wave_id();
   constexpr int LO = KS - 1;
   constexpr int RW = kRows / kWaves;
-  const int m0 = r0 + wave * RW;
-  f32x4 win[LO + RW];
-#pragma unroll
-  for (int q = 0; q < LO + RW; ++q) {
-    int mq = m0 - LO + q;
-    if (STREAM && mq < 0)
-      win[q] = *reinterpret_cast<const f32x4*>(g_hist + (size_t)(LO + mq) * kD + 4 * lane);
-    else
-      win[q] = (mq >= 0 && mq < M) ? *reinterpret_cast<const f32x4*>(g + (size_t)mq * kD + 4 * lane)
-                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int q = wave; q < LO + kRows; q += kWaves) {
+    const int mq = r0 - LO + q;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (STREAM && mq < 0) v = *reinterpret_cast<const f32x4*>(g_hist + (size_t)(LO + mq) * kD + 4 * lane);
+    else if (mq >= 0 && mq < M) v = *reinterpret_cast<const f32x4*>(g + (size_t)mq * kD + 4 * lane);
+    *reinterpret_cast<f32x4*>(win_lds + q * kLda + 4 * lane) = v;
   }
+  for (int j = wave; j < KS; j += kWaves)
+    *reinterpret_cast<f32x4*>(w_lds + j * kLda + 4 * lane) = *reinterpret_cast<const f32x4*>(dw_w + j * kD + 4 * lane);
   const f32x4 gp = *reinterpret_cast<const f32x4*>(glu_pad + 4 * lane);
   const f32x4 bias = *reinterpret_cast<const f32x4*>(dw_b + 4 * lane);
-  f32x4 out[RW];
-  int t_of[RW];
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < RW; ++i) {
-    out[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    t_of[i] = (m0 + i) % Tp;
-  }
+    const int row = wave * RW + i;
+    const int t = (r0 + row) % Tp;
+    f32x4 acc = bias;
 #pragma unroll
-  for (int j = 0; j < KS; ++j) {
-    const f32x4 wj = *reinterpret_cast<const f32x4*>(dw_w + j * kD + 4 * lane);
-#pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      f32x4 v = (STREAM || t_of[i] - LO + j >= 0) ? win[i + j] : gp;
-      out[i] += wj * v;
+    for (int j = 0; j < KS; ++j) {
+      const f32x4 wj = *reinterpret_cast<const f32x4*>(w_lds + j * kLda + 4 * lane);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(win_lds + (row + j) * kLda + 4 * lane);
+      acc += wj * ((STREAM || t - LO + j >= 0) ? xv : gp);
     }
+    *reinterpret_cast<f32x4*>(bufA + row * kLda + 4 * lane) = acc;
   }
-#pragma unroll
-  for (int i = 0; i < RW; ++i) *reinterpret_cast<f32x4*>(bufA + (wave * RW + i) * kLda + 4 * lane) = out[i] + bias;
 }
 
 }  // namespace ppasr

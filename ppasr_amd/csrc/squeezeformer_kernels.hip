@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kThreads) void k_sq_tail(const float* __restrict__ 
   BRing<1> ring;
   const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
   ring_prime(ring, seg_pw2, 0);
-  dwconv_phase<KS, false>(g, nullptr, bufA, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp);
+  dwconv_phase<KS, false>(g, nullptr, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp);
   __syncthreads();
   rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
   __syncthreads();
