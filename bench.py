@@ -34,14 +34,17 @@ def conformer_flops_per_utt(T, F=80, d=256, ff=2048, L=12, k=15, V=4233):
     linear_pos(pos_emb) is weight-only and folded at create time -> not counted."""
     t1, f1 = (T - 1) // 2, (F - 1) // 2
     tp, f2 = (t1 - 1) // 2, (f1 - 1) // 2
-    per = {
+    s1 = (4 * d * ff + 6 * d * d) * tp            # one k_ffn_qkv launch (FFN_macaron + QKV)
+    s4 = (2 * k * d + 2 * d * d + 4 * d * ff) * tp  # one k_conv_ffn launch (dwconv + pw2 + FFN)
+    per = {  # FLOPs per utterance of ONE launch of each kernel class
         "k_conv1": 2 * 9 * d * t1 * f1,
         "k_gemm_stream<conv2>": 2 * 9 * d * d * tp * f2,
         "k_gemm_stream<embed>": 2 * (d * f2) * d * tp,
-        "k_ffn_qkv": L * (4 * d * ff + 6 * d * d) * tp,
-        "k_attention": L * 6 * tp * tp * d,
-        "k_out_glu": L * (2 * d * d + 4 * d * d) * tp,
-        "k_conv_ffn": L * (2 * k * d + 2 * d * d + 4 * d * ff) * tp,
+        "k_ffn_qkv": s1,
+        "k_attention": 6 * tp * tp * d,
+        "k_out_glu": (2 * d * d + 4 * d * d) * tp,
+        "k_conv_ffn": s4,
+        "k_conv_ffn+ffn_qkv": s4 + s1,  # layer i's tail fused with layer i+1's head
         "k_ctc_head": 2 * d * V * tp,
     }
     return per, tp
@@ -127,8 +130,9 @@ def main():
                 a[1] += n
         model.profile_kernels(False)
         total_ms = sum(a[0] for a in acc.values()) / reps
+        acc = {k: v for k, v in acc.items() if v[1] > 0}
         for name, (ms, n) in acc.items():
-            flops_launch = per_utt[name] * B / (n / reps)
+            flops_launch = per_utt[name] * B
             avg_ms = ms / n
             kernels[name] = {"launches_per_step": n // reps, "avg_ms": round(avg_ms, 4),
                              "tflops": round(flops_launch / (avg_ms * 1e-3) / 1e12, 2),
@@ -138,7 +142,8 @@ def main():
         roofline = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "avg_launch_ms": kernels[dom]["avg_ms"],
-                    "whole_path_tflops_per_gpu": round(sum(per_utt.values()) * B / (ms_per_step * 1e-3) / 1e12, 2),
+                    "whole_path_tflops_per_gpu": round(sum(per_utt[k] * acc[k][1] / reps for k in acc) * B
+                                                       / (ms_per_step * 1e-3) / 1e12, 2),
                     "kernels": kernels}
 
     # ---- CPU baseline leg (rank 0, N=1 only): the oracle on this host's cores ----

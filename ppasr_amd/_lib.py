@@ -19,7 +19,7 @@ PPASR_MODEL_CONFORMER = 0
 PPASR_MODEL_EFFICIENT_CONFORMER = 1
 PPASR_MODEL_SQUEEZEFORMER = 2
 PPASR_MODEL_DEEPSPEECH2 = 3
-N_KERNEL_CLASSES = 8
+N_KERNEL_CLASSES = 9
 
 
 class WeightBlob(ctypes.Structure):

@@ -364,11 +364,13 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   const int n_chunks = h->desc.linear_units / 256;
   const bool eff = h->desc.model_type == PPASR_MODEL_EFFICIENT_CONFORMER;
   int Ti = Tp, mul = 4, pstride = 1;  // frames per utterance / pad-mask multiplier / positional stride of the current layer
+  bool s1_done = false;               // this layer's S1 already ran inside the previous layer's last launch
   for (int i = 0; i < h->desc.num_blocks; ++i) {
     const LayerW& L = h->layers[i];
     const int Mi = B * Ti;
     const int grp = h->layer_group[i];
-    timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st); });
+    if (!s1_done) timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st); });
+    s1_done = false;
     tap(xb, (size_t)Mi * kD);
     tap(qkv, (size_t)Mi * 3 * kD);
     timed(4, [&] {
@@ -388,7 +390,12 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       mul *= 2;
       pstride *= 2;
     } else {
-      timed(6, [&] { launch_conv_ffn(g, nullptr, xc, xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul, st); });
+      // fuse the next layer's S1 into this launch (it writes xb / qkv, which this layer no longer reads)
+      const LayerW* next = (i + 1 < h->desc.num_blocks) ? &h->layers[i + 1] : nullptr;
+      timed(next ? 8 : 6, [&] {
+        launch_conv_ffn(g, nullptr, xc, xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul, next, xb, qkv, st);
+      });
+      s1_done = next != nullptr;
     }
     tap(xa, (size_t)B * Ti * kD);
   }
@@ -512,7 +519,7 @@ ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int r
     launch_attention(a, 1, h->desc.attention_heads, st);
     launch_pw1_glu(xh, s->g_hist, L, lo, st);
     launch_out_glu(ctx, xb, xc, g, xhat, L, nullptr, M, c, 4, st);
-    launch_conv_ffn(g, s->g_hist, xc, xa, L, nullptr, M, c, n_chunks, h->desc.cnn_module_kernel, 4, st);
+    launch_conv_ffn(g, s->g_hist, xc, xa, L, nullptr, M, c, n_chunks, h->desc.cnn_module_kernel, 4, nullptr, nullptr, nullptr, st);
     launch_hist_update(xh, xhat, c, lo, st);
   }
   int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
@@ -634,7 +641,7 @@ ppasr_status ppasr_ctc_beam_search(const float* probs, const int32_t* frame_lens
 
 static const char* kKernelClassNames[PPASR_N_KERNEL_CLASSES] = {
     "k_conv1", "k_gemm_stream<conv2>", "k_gemm_stream<embed>", "k_ffn_qkv", "k_attention", "k_out_glu", "k_conv_ffn",
-    "k_ctc_head"};
+    "k_ctc_head", "k_conv_ffn+ffn_qkv"};
 
 ppasr_status ppasr_profile_enable(ppasr_handle h, int enable) {
   if (!h) return fail(PPASR_EINVAL, "null handle");

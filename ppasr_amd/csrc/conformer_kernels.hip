@@ -79,11 +79,11 @@ struct Conv2Src {
     int b = bt / Tp;
     return y1 + ((size_t)((b * T1 + 2 * tp) * F1 + 2 * f2)) * 256;
   }
-  // KC = 64: chunk kc -> tap kc>>2 (kh,kw), channel quarter kc&3
+  // KC = 128: chunk kc -> tap kc>>1 (kh,kw), channel half kc&1
   __device__ __forceinline__ size_t chunk_off(int kc) const {
-    int tap = kc >> 2;
+    int tap = kc >> 1;
     int kh = tap / 3, kw = tap - 3 * kh;
-    return ((size_t)(kh * F1 + kw)) * 256 + (kc & 3) * 64;
+    return ((size_t)(kh * F1 + kw)) * 256 + (kc & 1) * 128;
   }
 };
 struct DenseSrc {
@@ -161,10 +161,10 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
 void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st) {
   Conv2Src src{y1, T1, F1, Tp, F2};
   int M = B * Tp * F2;
-  constexpr int MT = 4, KC = 64;
+  constexpr int MT = 4, KC = 128;
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
   hipLaunchKernelGGL((k_gemm_stream<MT, KC, true, false, Conv2Src>), dim3((M + 32 * MT - 1) / (32 * MT)), dim3(kThreads), lds, st, src,
-                     fw.conv2_w, fw.conv2_b, y2, M, 36, 1.0f, kD, kD);
+                     fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD);
 }
 void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, bool scale_before_bias,
                   hipStream_t st) {
@@ -198,18 +198,12 @@ void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, fl
 // S1: x1 = x + 0.5*FFN_macaron(LN(x)) ; qkv = LN_mha(x1) * [Wq|Wk|Wv] + b
 // (encoder.py:380-391, attention.py:75-77)
 // -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ x_in, float* __restrict__ x1,
-                                                      float* __restrict__ qkv, LayerW w, int M, int n_chunks) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* bufX = smem;
-  float* bufA = bufX + kRows * kLda;
-  float* bufH = bufA + kRows * kLda;
+// Body of S1 on LDS-resident rows (bufX = layer input): FFN_macaron, residual, LN_mha, QKV.
+// `ring` must already stream w.ffm_w1 (tile `wave`).
+__device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bufH, float* __restrict__ x1,
+                                             float* __restrict__ qkv, const LayerW& w, int r0, int valid, int n_chunks,
+                                             BRing<1>& ring) {
   const int lane = lane_id(), wave = wave_id();
-  const int r0 = blockIdx.x * kRows;
-  const int valid = min(kRows, M - r0);
-  BRing<1> ring;
-  ring_prime(ring, w.ffm_w1 + (size_t)wave * kTs256, 0);
-  rb_load_rows(bufX, kLda, x_in + (size_t)r0 * kD, kRows, valid);
   rb_layernorm(bufX, bufA, kLda, kRows, w.ln_mac_g, w.ln_mac_b, 1e-5f);
   __syncthreads();
   f32x16 acc2[1][1];
@@ -235,6 +229,21 @@ __global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ 
       if (row < valid) qkv[(size_t)(r0 + row) * 768 + col] = acc[0][0][r] + bv;
     }
   }
+}
+
+__global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ x_in, float* __restrict__ x1,
+                                                      float* __restrict__ qkv, LayerW w, int M, int n_chunks) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufX = smem;
+  float* bufA = bufX + kRows * kLda;
+  float* bufH = bufA + kRows * kLda;
+  const int wave = wave_id();
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, M - r0);
+  BRing<1> ring;
+  ring_prime(ring, w.ffm_w1 + (size_t)wave * kTs256, 0);
+  rb_load_rows(bufX, kLda, x_in + (size_t)r0 * kD, kRows, valid);
+  ffn_qkv_body(bufX, bufA, bufH, x1, qkv, w, r0, valid, n_chunks, ring);
 }
 constexpr size_t kLdsFfnQkv = 4 * kRows * kLda * sizeof(float);
 void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st) {
@@ -308,6 +317,13 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   };
   // K' fragment of k-group g for key j: features 8g+4*(lane>>5).. ; first DK/8 groups from k, the rest from p
   auto kfrag = [&](int j, int g) -> f32x4 {
+    if (C::G == 1) {
+      // keys >= T2 are masked to -inf afterwards, so any in-bounds row will do: clamp instead of branching
+      const int jc = min(j, T2 - 1);
+      const float* base = (g < DK / 8) ? kbp + (size_t)jc * a.k_stride + h * DK + 8 * g + 4 * (lane >> 5)
+                                       : ptab + (size_t)jc * pstride * kD + h * DK + 8 * (g - DK / 8) + 4 * (lane >> 5);
+      return *reinterpret_cast<const f32x4*>(base);
+    }
     if (j >= T2) return f32x4{0.f, 0.f, 0.f, 0.f};
     const int f = 8 * (g < DK / 8 ? g : g - DK / 8) + 4 * (lane >> 5);
     if (g < DK / 8) return tok4(kbp, a.k_stride, F2, j, f);
@@ -317,6 +333,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
     return *reinterpret_cast<const f32x4*>(ptab + (size_t)frame * pstride * kD + feat);
   };
   auto vval = [&](int j, int col) -> float {
+    if (C::G == 1) return vbp[(size_t)min(j, T2 - 1) * a.v_stride + h * DK + col];  // P is 0 for keys >= T2
     if (j >= T2) return 0.f;
     const int flat = j * (C::G * kD) + h * DK + col;
     const int frame = flat >> 8, feat = flat & 255;
@@ -347,7 +364,12 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc_o[mt][t][r] = 0.f;
   const int ctg = wave & 1, kh = wave >> 1;
-  const float score_div = DK == 64 ? 8.0f : 13.856406460551018f;  // sqrt(d_k [* group_size])
+  const float score_mul = DK == 64 ? 0.125f : 0.07216878364870322f;  // 1 / sqrt(d_k [* group_size])
+  constexpr int PF = 4, PFV = 8;
+  f32x4 ring[PF];           // K' fragments, primed one key block ahead (loads stay in flight across softmax / PV)
+  float ringv[PFV][C::NO];  // V values, primed before the softmax pass
+#pragma unroll
+  for (int s = 0; s < PF; ++s) ring[s] = kfrag(wave * 32 + (lane & 31), s);
   __syncthreads();
 
   const int nkb = (T2 + 127) / 128;
@@ -361,15 +383,12 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
       for (int r = 0; r < 16; ++r) acc_s[mt][r] = 0.f;
     {
       const int jkey = key0 + wave * 32 + (lane & 31);
-      constexpr int PF = 4;
-      f32x4 ring[PF];
-#pragma unroll
-      for (int s = 0; s < PF; ++s) ring[s] = kfrag(jkey, s);
       const float* a_ptr = Qs + (lane & 31) * C::QLD + 4 * (lane >> 5);
 #pragma unroll
       for (int g = 0; g < C::NG; ++g) {
         const f32x4 bb = ring[g % PF];
         if (g + PF < C::NG) ring[g % PF] = kfrag(jkey, g + PF);
+        else if (kb + 1 < nkb) ring[g % PF] = kfrag(jkey + 128, g + PF - C::NG);  // next key block's first groups
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(a_ptr + 8 * g);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(a_ptr + 32 * C::QLD + 8 * g);
 #pragma unroll
@@ -389,9 +408,15 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          Ss[(mt * 32 + acc_row(r, lane)) * kSld + kl] = masked ? -INFINITY : acc_s[mt][r] / score_div;
+          Ss[(mt * 32 + acc_row(r, lane)) * kSld + kl] = masked ? -INFINITY : acc_s[mt][r] * score_mul;
     }
     __syncthreads();
+    const int kbase = key0 + kh * 64 + (lane >> 5);
+    const int cbase = ctg * C::NO * 32 + (lane & 31);
+#pragma unroll
+    for (int s = 0; s < PFV; ++s)
+#pragma unroll
+      for (int t = 0; t < C::NO; ++t) ringv[s][t] = vval(kbase + 2 * s, cbase + t * 32);
     // ---- online softmax: a 16-lane group owns one row (8 keys per lane); 4 rows per wave-op, 16 rows per wave ----
     {
       const int grp = lane >> 4, gl = lane & 15;
@@ -412,10 +437,10 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
         const float m_new = fmaxf(m_old, bm);
         float alpha = 1.f, ps = 0.f;
         if (m_new != -INFINITY) {
-          alpha = expf(m_old - m_new);
+          alpha = __expf(m_old - m_new);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            v[e] = expf(v[e] - m_new);
+            v[e] = __expf(v[e] - m_new);
             ps += v[e];
           }
         } else {
@@ -442,15 +467,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[mt][t][r] *= stA[mt * 32 + acc_row(r, lane)];
     {
-      const int kbase = key0 + kh * 64 + (lane >> 5);
-      const int cbase = ctg * C::NO * 32 + (lane & 31);
       const float* a_ptr = Ss + (lane & 31) * kSld + kh * 64 + (lane >> 5);
-      constexpr int PFV = 8;
-      float ringv[PFV][C::NO];
-#pragma unroll
-      for (int s = 0; s < PFV; ++s)
-#pragma unroll
-        for (int t = 0; t < C::NO; ++t) ringv[s][t] = vval(kbase + 2 * s, cbase + t * 32);
 #pragma unroll
       for (int s = 0; s < 32; ++s) {
         float bv[C::NO];
@@ -698,11 +715,14 @@ void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStrea
 // convolution.py:108-126) -> LayerNorm -> swish -> pointwise_conv2 -> pad mask -> +residual
 // -> LN_ff -> FFN -> +0.5 residual -> LN_final     (convolution.py:129-140, encoder.py:416-429)
 // -------------------------------------------------------------------------------------
-template <int KS, bool STREAM>
+// NEXT: the following layer's S1 (FFN_macaron + QKV, encoder.py:380-391) runs in the same launch on the rows that
+// are already LDS-resident (one launch, one store/load of the residual stream and one pipeline fill saved per layer).
+template <int KS, bool STREAM, bool NEXT>
 __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__ g, const float* __restrict__ g_hist,
                                                        const float* __restrict__ x2, float* __restrict__ x_out, LayerW w,
                                                        const int64_t* __restrict__ lens, int M, int Tp, int n_chunks,
-                                                       int mask_mul) {
+                                                       int mask_mul, LayerW wn, float* __restrict__ x1_next,
+                                                       float* __restrict__ qkv_next) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
@@ -741,24 +761,31 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   __syncthreads();
   f32x16 acc2[1][1];
   acc_zero(acc2);
-  ffn_phase(bufA, bufH, w.ff_w1, w.ff_b1, w.ff_w2, n_chunks, nullptr, ring, acc2);
+  ffn_phase(bufA, bufH, w.ff_w1, w.ff_b1, w.ff_w2, n_chunks, NEXT ? wn.ffm_w1 + (size_t)wave * kTs256 : nullptr, ring,
+            acc2);
   residual_epilogue(bufX, acc2, w.ff_b2, 0.5f);
   __syncthreads();
   rb_layernorm(bufX, bufX, kLda, kRows, w.ln_fin_g, w.ln_fin_b, 1e-5f);
   // rb_layernorm and rb_store_rows use the same wave->row mapping: no barrier needed
   rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);
+  if (NEXT) ffn_qkv_body(bufX, bufA, bufH, x1_next, qkv_next, wn, r0, valid, n_chunks, ring);
 }
 constexpr size_t kLdsConvFfn = 4 * kRows * kLda * sizeof(float);
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
-                     const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, hipStream_t st) {
+                     const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,
+                     float* x1_next, float* qkv_next, hipStream_t st) {
   dim3 grid((M + kRows - 1) / kRows);
-#define LAUNCH_CF(KS)                                                                                               \
-  if (g_hist)                                                                                                       \
-    hipLaunchKernelGGL((k_conv_ffn<KS, true>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, M, \
-                       Tp, n_chunks, mask_mul);                                                                     \
-  else                                                                                                              \
-    hipLaunchKernelGGL((k_conv_ffn<KS, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, M, \
-                       Tp, n_chunks, mask_mul);
+  const LayerW& wn = next ? *next : w;
+#define LAUNCH_CF(KS)                                                                                                  \
+  if (g_hist)                                                                                                          \
+    hipLaunchKernelGGL((k_conv_ffn<KS, true, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next);                                        \
+  else if (next)                                                                                                       \
+    hipLaunchKernelGGL((k_conv_ffn<KS, false, true>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next);                                        \
+  else                                                                                                                 \
+    hipLaunchKernelGGL((k_conv_ffn<KS, false, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, \
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next);
   if (ksize == 15) {
     LAUNCH_CF(15)
   } else if (ksize == 31) {
@@ -1096,18 +1123,21 @@ hipError_t configure_kernels() {
   SET_LDS(k_attention<64>, kLdsAttn);
   SET_LDS(k_attention<192>, kLdsAttnG);
   SET_LDS(k_out_glu, kLdsOutGlu);
-  SET_LDS((k_conv_ffn<15, false>), kLdsConvFfn);
-  SET_LDS((k_conv_ffn<31, false>), kLdsConvFfn);
-  SET_LDS((k_conv_ffn<7, false>), kLdsConvFfn);
-  SET_LDS((k_conv_ffn<15, true>), kLdsConvFfn);
-  SET_LDS((k_conv_ffn<31, true>), kLdsConvFfn);
-  SET_LDS((k_conv_ffn<7, true>), kLdsConvFfn);
+  SET_LDS((k_conv_ffn<15, false, false>), kLdsConvFfn);
+  SET_LDS((k_conv_ffn<31, false, false>), kLdsConvFfn);
+  SET_LDS((k_conv_ffn<7, false, false>), kLdsConvFfn);
+  SET_LDS((k_conv_ffn<15, false, true>), kLdsConvFfn);
+  SET_LDS((k_conv_ffn<31, false, true>), kLdsConvFfn);
+  SET_LDS((k_conv_ffn<7, false, true>), kLdsConvFfn);
+  SET_LDS((k_conv_ffn<15, true, false>), kLdsConvFfn);
+  SET_LDS((k_conv_ffn<31, true, false>), kLdsConvFfn);
+  SET_LDS((k_conv_ffn<7, true, false>), kLdsConvFfn);
   SET_LDS(k_pw1_glu, kLdsPw1Glu);
   SET_LDS(k_conv_ffn_stride<15>, kLdsConvFfn);
   SET_LDS(k_conv_ffn_stride<7>, kLdsConvFfn);
   SET_LDS(k_ctc_head<true>, kLdsCtc);
   SET_LDS(k_ctc_head<false>, kLdsCtc);
-  SET_LDS((k_gemm_stream<4, 64, true, false, Conv2Src>), 2 * 128 * 68 * sizeof(float));
+  SET_LDS((k_gemm_stream<4, 128, true, false, Conv2Src>), 2 * 128 * 132 * sizeof(float));
   SET_LDS((k_gemm_stream<1, 256, false, false, DenseSrc>), 2 * 32 * 260 * sizeof(float));
   SET_LDS((k_gemm_stream<1, 256, false, true, DenseSrc>), 2 * 32 * 260 * sizeof(float));
 #undef SET_LDS

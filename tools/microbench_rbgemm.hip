@@ -37,9 +37,10 @@ __global__ __launch_bounds__(kThreads) void k_mb(const f32x4* __restrict__ w, fl
   }
 }
 
+static size_t g_lds_override = 0;
 template <int MT, int MODE>
 void run(const f32x4* w, float* out, int blocks, int iters, int n_seg, const char* name) {
-  size_t lds = 32 * MT * kLda * sizeof(float);
+  size_t lds = g_lds_override ? g_lds_override : 32 * MT * kLda * sizeof(float);
   hipFuncSetAttribute(reinterpret_cast<const void*>(k_mb<MT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   static long long* clk = nullptr;
   if (!clk) hipMalloc(&clk, 16);
@@ -82,5 +83,14 @@ int main() {
   run<1, 0>(w, out, 128, iters, n_seg, "MT=1 stream 128 blocks");
   run<1, 0>(w, out, 64, iters, n_seg, "MT=1 stream 64 blocks");
   run<1, 0>(w, out, 8, iters, n_seg, "MT=1 stream 8 blocks");
+  // fixed cost of a row-block kernel: time vs number of 128-MFMA GEMM calls, small and large LDS footprints
+  for (size_t lds : {(size_t)33280, (size_t)133120}) {
+    g_lds_override = lds;
+    for (int it : {0, 1, 2, 4, 8, 16}) {
+      char name[64];
+      snprintf(name, sizeof name, "lds=%zuK iters=%d", lds / 1024, it);
+      run<1, 0>(w, out, 249, it, n_seg, name);
+    }
+  }
   return 0;
 }

@@ -15,10 +15,12 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--frames", type=int, default=1000)
 ap.add_argument("--blocks", type=int, default=12)
+ap.add_argument("--ffn", type=int, default=2048)
+ap.add_argument("--profile", action="store_true")
 args = ap.parse_args()
 V, L = DEFAULT_VOCAB_SIZE, args.blocks
-conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
-sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=1234)
+conf = dict(output_size=256, attention_heads=4, linear_units=args.ffn, num_blocks=L, cnn_module_kernel=15)
+sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=1234, linear_units=args.ffn)
 model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
 x, lens = synth_features(args.batch, args.frames, seed=20440)
 x = torch.from_numpy(x).cuda()
@@ -26,4 +28,9 @@ lens = torch.from_numpy(lens).cuda()
 for _ in range(args.steps):
     model.encode_greedy(x, lens)
 torch.cuda.synchronize()
+if args.profile:
+    model.profile_kernels(True)
+    model.encode_greedy(x, lens)
+    for k, (ms, n) in model.read_kernel_profile().items():
+        print(f"{k:24s} n={n:3d} avg_us={1e3 * ms / max(n, 1):8.1f}")
 print("done")
