@@ -93,11 +93,45 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /*[4] LDS*/,
   return base + incl - v;
 }
 
+// Executed by wave 0 only: find the histogram bin holding the k_rem-th element (1-based) when bins are walked in
+// ascending (desc == false) or descending (desc == true) order; writes {bin, rank inside the bin, bin count} to out[0..2].
+__device__ __forceinline__ void select_bin(const int* hist, int k_rem, bool desc, int* out) {
+  const int lane = threadIdx.x & 63;
+  int c[4], sum = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int pos = 4 * lane + j;  // position in walk order
+    c[j] = hist[desc ? 255 - pos : pos];
+    sum += c[j];
+  }
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  int before = incl - sum;
+  const bool mine = (before < k_rem) && (incl >= k_rem);
+  if (mine) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (before + c[j] >= k_rem) {
+        const int pos = 4 * lane + j;
+        out[0] = desc ? 255 - pos : pos;
+        out[1] = k_rem - before;
+        out[2] = c[j];
+        break;
+      }
+      before += c[j];
+    }
+  }
+}
+
 }  // namespace
 
 size_t beam_lds_bytes(const BeamConfig& c) {
   const int Vp = (c.V + 3) & ~3;
-  size_t n = 16 + 256 * 4 + 16 + 16 + 16 + 32;  // scalars, histogram, reduction scratch
+  size_t n = 16 + 256 * 4 + 16 + 16 + 16 + 32 + kMaxBeamCand * 8;  // scalars, histogram, reduction scratch, gather buffers
   n += (size_t)Vp * 4;                             // lp
   n += (size_t)kMaxBeamCand * 8;                   // cand_c, cand_lp
   n += (size_t)2 * c.beam * 24;                    // two beam halves
@@ -130,6 +164,8 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
   float* red_p = reinterpret_cast<float*>(p); p += 16;
   int* red_i = reinterpret_cast<int*>(p); p += 16;
   int* sh_i = reinterpret_cast<int*>(p); p += 32;            // misc shared ints
+  int* tmp_c = reinterpret_cast<int*>(p); p += kMaxBeamCand * 4;     // unsorted pruned characters
+  float* tmp_p = reinterpret_cast<float*>(p); p += kMaxBeamCand * 4;
   float* lp = reinterpret_cast<float*>(p); p += (size_t)Vp * 4;
   int* cand_c = reinterpret_cast<int*>(p); p += kMaxBeamCand * 4;
   float* cand_lp = reinterpret_cast<float*>(p); p += kMaxBeamCand * 4;
@@ -170,9 +206,81 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
     const float* row = probs + ((size_t)u * T + t) * V;
     for (int v = tid; v < V; v += kBT) lp[v] = row[v];
     __syncthreads();
-    // ---- (b) get_pruned_log_probs: successive maxima in (prob desc, index asc) order ----
+    // ---- (b) get_pruned_log_probs (decoder_utils.cpp): the n_sel largest probabilities in (prob desc, index asc)
+    // order, cut where the cumulative probability reaches cutoff_prob.  Fast path: exact 4-pass radix select of the
+    // n_sel-th largest value, unordered gather, rank sort of the <= 128 survivors.  Excess ties at the threshold
+    // (more equal values than slots) fall back to the successive-maxima loop below.
     int C = 0;
-    if (prune) {
+    bool slow_path = false;
+    const int n_sel = (cfg.cutoff_prob < 1.0) ? min(cfg.cutoff_top_n, V) : V;
+    if (prune && n_sel <= CM) {
+      uint32_t thr_u = 0;
+      if (n_sel < V) {
+        uint32_t prefix = 0;
+        int k_rem = n_sel;
+        for (int pass = 0; pass < 4; ++pass) {
+          const int shift = 24 - 8 * pass;
+          const uint32_t hi_mask = pass == 0 ? 0u : (~0u << (shift + 8));
+          hist[tid] = 0;
+          __syncthreads();
+          for (int v = tid; v < V; v += kBT) {
+            const uint32_t u = __float_as_uint(lp[v]);
+            if ((u & hi_mask) == prefix) atomicAdd(&hist[(u >> shift) & 0xff], 1);
+          }
+          __syncthreads();
+          if (wave == 0) select_bin(hist, k_rem, true, sh_i);
+          __syncthreads();
+          prefix |= (uint32_t)sh_i[0] << shift;
+          k_rem = sh_i[1];
+          if (pass == 3 && sh_i[2] > k_rem) slow_path = true;  // more values equal to the threshold than slots left
+          __syncthreads();
+        }
+        thr_u = prefix;
+      }
+      if (!slow_path) {
+        if (tid == 0) sh_i[4] = 0;
+        __syncthreads();
+        for (int v = tid; v < V; v += kBT) {
+          const float pv = lp[v];
+          if (__float_as_uint(pv) >= thr_u) {
+            const int pos = atomicAdd(&sh_i[4], 1);
+            if (pos < kMaxBeamCand) { tmp_c[pos] = v; tmp_p[pos] = pv; }
+          }
+        }
+        __syncthreads();
+        const int n_got = min(sh_i[4], kMaxBeamCand);
+        if (tid < n_got) {  // rank sort: (prob desc, index asc)
+          const float pv = tmp_p[tid];
+          const int iv = tmp_c[tid];
+          int rank = 0;
+          for (int s2 = 0; s2 < n_got; ++s2) rank += (tmp_p[s2] > pv || (tmp_p[s2] == pv && tmp_c[s2] < iv)) ? 1 : 0;
+          cand_c[rank] = iv;
+          cand_lp[rank] = pv;  // probability for now
+        }
+        __syncthreads();
+        if (tid == 0) {
+          int len = n_got;
+          if (cfg.cutoff_prob < 1.0) {
+            double cum = 0.0;
+            len = 0;
+            for (int i = 0; i < n_got; ++i) {
+              cum += (double)cand_lp[i];
+              len += 1;
+              if (cum >= cfg.cutoff_prob || len >= cfg.cutoff_top_n) break;
+            }
+          }
+          sh_i[5] = len;
+        }
+        __syncthreads();
+        C = sh_i[5];
+        if (tid < C) cand_lp[tid] = (float)log((double)cand_lp[tid] + (double)FLT_MIN);
+        __syncthreads();
+      }
+    } else if (prune) {
+      slow_path = true;
+    }
+    if (slow_path) {
+      C = 0;
       float last_p = INFINITY;
       int last_i = -1;
       if (tid == 0) sh_d[0] = 0.0;
@@ -216,7 +324,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
         __syncthreads();
         if (stop || C >= CM) break;
       }
-    } else {
+    } else if (!prune) {
       C = V;  // no pruning: vocabulary order (host guarantees V <= n_cand_max)
       for (int v = tid; v < V; v += kBT) { cand_c[v] = v; cand_lp[v] = (float)log((double)lp[v] + (double)FLT_MIN); }
       __syncthreads();
@@ -286,19 +394,16 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
           if (elem_key(e, k) && (k & hi_mask) == prefix) atomicAdd(&hist[(int)((k >> shift) & 0xff)], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-          int acc = 0, bsel = 255;
-          for (int bkt = 0; bkt < 256; ++bkt) {
-            if (acc + hist[bkt] >= k_rem) { bsel = bkt; break; }
-            acc += hist[bkt];
-          }
-          sh_i[0] = bsel;
-          sh_i[1] = k_rem - acc;
-        }
+        if (wave == 0) select_bin(hist, k_rem, false, sh_i);
         __syncthreads();
         prefix |= (uint64_t)sh_i[0] << shift;
         k_rem = sh_i[1];
+        const bool whole_class = (sh_i[2] == k_rem);  // the searched key is the last of its class: take the class
         __syncthreads();
+        if (whole_class) {
+          prefix |= (shift == 0) ? 0ull : ((1ull << shift) - 1ull);
+          break;
+        }
       }
       thr = prefix;
     }

@@ -1,0 +1,91 @@
+"""GPU edge cases of the Conformer path: minimum / ragged / long inputs, empty utterances, determinism and
+size-independent properties at the BASELINE shape (B=32, T=1000, V=4233)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.conformer_oracle import ConformerOracle
+from oracle.ctc_decoders_oracle import greedy_tokens
+from ppasr_amd.utils.synth import conformer_state_dict, synth_features
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _model(sd, V, L):
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
+    return ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+
+
+@pytest.mark.parametrize("B,T,lens", [
+    (1, 7, [7]),                 # one output frame (the conv front-end's receptive field)
+    (2, 11, [11, 7]),            # two frames
+    (3, 131, [131, 1, 0]),       # lengths 1 and 0: every key masked -> fully masked attention rows -> zeros
+    (1, 3000, [3000]),           # 30 s: T' = 749 (6 key blocks)
+    (5, 67, [67, 66, 65, 64, 63]),
+])
+def test_ragged_and_extreme_lengths_match_oracle(B, T, lens):
+    L, V = 2, 97
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=101, perturb_norm=True)
+    x, lens = synth_features(B, T, lens=lens, seed=102)
+    model = _model(sd, V, L)
+    probs, logits = model.get_encoder_out(x, lens, return_logits=True)
+    torch.cuda.synchronize()
+    ref_probs, ref_logits = ConformerOracle(sd, num_blocks=L).get_encoder_out(x, lens, return_logits=True)
+    assert tuple(probs.shape) == tuple(ref_probs.shape)
+    assert torch.isfinite(probs).all()
+    assert _rel(logits.cpu().numpy(), ref_logits.numpy()) < TOL
+
+
+def test_too_short_input_is_refused():
+    from ppasr_amd import _lib
+    sd = conformer_state_dict(vocab_size=50, num_blocks=1, seed=1)
+    model = _model(sd, 50, 1)
+    with pytest.raises(_lib.PPASRHipError):
+        model.get_encoder_out(np.zeros((1, 6, 80), np.float32), [6])
+
+
+def test_baseline_shape_properties():
+    """B=32 x 1000 frames, V=4233, 12 blocks (the bench workload): (i) bit-identical across runs, (ii) utterance
+    independence: every utterance decoded alone gives the same tokens as inside the batch (no cross-utterance
+    state: LayerNorm / global CMVN only), (iii) the first utterances match the CPU oracle token for token."""
+    L, V, B, T = 12, 4233, 32, 1000
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=1234)
+    x, lens = synth_features(B, T, seed=20440)
+    model = _model(sd, V, L)
+    t1, n1, s1 = model.encode_greedy(x, lens)
+    t2, n2, s2 = model.encode_greedy(x, lens)
+    torch.cuda.synchronize()
+    assert torch.equal(t1, t2) and torch.equal(n1, n2) and torch.equal(s1, s2)
+    for b in (0, 7, 31):
+        tb, nb, sb = model.encode_greedy(x[b:b + 1], lens[b:b + 1])
+        assert torch.equal(tb[0, :int(nb[0])], t1[b, :int(n1[b])])
+        assert abs(float(sb[0]) - float(s1[b])) < 1e-9
+    ref = ConformerOracle(sd, num_blocks=L).get_encoder_out(x[:2], lens[:2])
+    for b in range(2):
+        ids, _, max_prob = greedy_tokens(ref[b].numpy())
+        assert np.array_equal(ids, t1[b, :int(n1[b])].cpu().numpy())
+        assert abs(float(s1[b]) - float(np.mean(max_prob.astype(np.float64))) * 100) < 1e-3
+
+
+def test_padding_invariance_of_valid_frames():
+    """Garbage in feature rows that only feed masked frames leaves the valid frames bit-identical
+    (same property as tests/test_oracle.py::test_masked_frames_do_not_influence_valid_frames)."""
+    L, V = 2, 64
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=77, perturb_norm=True)
+    x, lens = synth_features(2, 99, lens=[99, 61], seed=78)
+    model = _model(sd, V, L)
+    n_valid = (61 + 3) // 4
+    base = model.get_encoder_out(x, lens)[1].cpu().numpy()
+    x2 = x.copy()
+    x2[1, 4 * (n_valid - 1) + 7:] = 123.0
+    pert = model.get_encoder_out(x2, lens)[1].cpu().numpy()
+    assert np.array_equal(base[:n_valid], pert[:n_valid])
+    assert not np.array_equal(base[n_valid:], pert[n_valid:])
