@@ -385,7 +385,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     tap(g, (size_t)Mi * kD);
     if (eff && i == h->desc.stride_layer_idx) {
       const int Ts = (Ti + 1) / 2;
-      timed(6, [&] { launch_conv_ffn_stride(g, xc, xa, L, lens, B, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st); });
+      timed(6, [&] { launch_conv_ffn_stride(g, nullptr, xc, xa, L, lens, B, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st); });
       Ti = Ts;  // masks[:, :, ::2], pos_emb[:, ::2]  (efficient_conformer/encoder.py:252-257)
       mul *= 2;
       pstride *= 2;
@@ -409,179 +409,6 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       HIP_TRY(hipMemcpyAsync(probs, logits, (size_t)Mo * h->head.V * sizeof(float), hipMemcpyDeviceToDevice, st));
     launch_softmax_from_stats(probs, ws + wl.rmax, ws + wl.rsum, Mo, h->head.V, st);
   }
-  HIP_TRY(hipGetLastError());
-  return PPASR_OK;
-}
-
-
-// =====================================================================================
-// Streaming: ConformerEncoder.forward_chunk (conformer/encoder.py:208-283) with the attention
-// K/V cache and the conv-module cache resident on the device inside a stream-state object
-// (the reference round-trips both through the host on every chunk, inference_predictor.py:196-210).
-// =====================================================================================
-struct ppasr_stream_s {
-  ppasr_model_s* m;
-  int cap;      // key capacity per layer (frames)
-  int cache_t;  // cached key/value frames (cache_t1 in the reference)
-  int offset;   // encoder-output frames emitted so far
-  int lo;       // conv left context = kernel - 1
-  float *kc, *vc;   // [L][cap][256]
-  float* xh_hist;   // [L][lo][256]  conv-module input history (the reference's cnn_cache, frame-major)
-  float* g_hist;    // [lo][256] scratch: GLU(pointwise_conv1(history)) of the layer being processed
-};
-
-ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out) {
-  if (!h || !out) return fail(PPASR_EINVAL, "null argument");
-  if (h->desc.model_type != PPASR_MODEL_CONFORMER)
-    return fail(PPASR_EUNSUPPORTED, "forward_chunk streaming is built for model_type=conformer only");
-  auto* s = new ppasr_stream_s();
-  s->m = h;
-  s->cap = h->desc.max_len;
-  s->lo = h->desc.cnn_module_kernel - 1;
-  const size_t L = h->desc.num_blocks;
-  hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&s->kc), L * s->cap * kD * sizeof(float));
-  hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&s->vc), L * s->cap * kD * sizeof(float));
-  hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&s->xh_hist), L * s->lo * kD * sizeof(float));
-  hipError_t e4 = hipMalloc(reinterpret_cast<void**>(&s->g_hist), (size_t)s->lo * kD * sizeof(float));
-  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
-    (void)hipFree(s->kc); (void)hipFree(s->vc); (void)hipFree(s->xh_hist); (void)hipFree(s->g_hist);
-    delete s;
-    return fail(PPASR_EHIP, "hipMalloc failed for the stream caches");
-  }
-  s->cache_t = 0;
-  s->offset = 0;
-  hipError_t e5 = hipMemset(s->xh_hist, 0, L * s->lo * kD * sizeof(float));
-  if (e5 != hipSuccess) return fail(PPASR_EHIP, "hipMemset failed");
-  *out = s;
-  return PPASR_OK;
-}
-
-ppasr_status ppasr_stream_destroy(ppasr_stream s) {
-  if (!s) return PPASR_OK;
-  (void)hipFree(s->kc); (void)hipFree(s->vc); (void)hipFree(s->xh_hist); (void)hipFree(s->g_hist);
-  delete s;
-  return PPASR_OK;
-}
-
-// InferencePredictor.reset_stream (inference_predictor.py:215-220): empty caches, offset 0
-ppasr_status ppasr_stream_reset(ppasr_stream s, void* stream) {
-  if (!s) return fail(PPASR_EINVAL, "null stream");
-  s->cache_t = 0;
-  s->offset = 0;
-  HIP_TRY(hipMemsetAsync(s->xh_hist, 0, (size_t)s->m->desc.num_blocks * s->lo * kD * sizeof(float),
-                         static_cast<hipStream_t>(stream)));
-  return PPASR_OK;
-}
-
-int ppasr_stream_offset(ppasr_stream s) { return s ? s->offset : -1; }
-int ppasr_stream_cache_frames(ppasr_stream s) { return s ? s->cache_t : -1; }
-
-size_t ppasr_chunk_workspace_bytes(ppasr_handle h, int T) {
-  if (!h || T < 7) return 0;
-  const size_t Tp = ((T - 1) / 2 - 1) / 2;
-  // the full-utterance layout for B=1, plus the conv-module input rows and a cache-shift scratch
-  return (ws_layout(h, 1, T).total + Tp * kD + 64 + (size_t)h->desc.max_len * kD) * sizeof(float);
-}
-
-ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int required_cache_size, float* probs,
-                                int32_t* frame_argmax, float* frame_maxprob, int* c_out_host, void* workspace,
-                                size_t workspace_bytes, void* stream) {
-  if (!s || !feats || !workspace) return fail(PPASR_EINVAL, "null argument");
-  ppasr_model_s* h = s->m;
-  if (T < 7) return fail(PPASR_EINVAL, "chunk shorter than the conv front-end's receptive field (7 frames)");
-  const int F = h->desc.input_dim, T1 = (T - 1) / 2, F1 = h->F1, c = (T1 - 1) / 2, F2 = h->F2;
-  const int T2 = s->cache_t + c;
-  if (T2 > s->cap) return fail(PPASR_EINVAL, "attention cache capacity exceeded");
-  // embedding.py:64-66,84: offset + size < max_len
-  if (s->offset + c >= h->desc.max_len) return fail(PPASR_EINVAL, "offset + chunk exceeds the positional table (max_len)");
-  if (workspace_bytes < ppasr_chunk_workspace_bytes(h, T)) return fail(PPASR_ENOSPACE, "workspace too small");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const WsLayout wl = ws_layout(h, 1, T);
-  float* ws = static_cast<float*>(workspace);
-  float *y1 = ws + wl.y1, *y2 = ws + wl.y2, *xa = ws + wl.xa, *xb = ws + wl.xb, *xc = ws + wl.xc;
-  float *qkv = ws + wl.qkv, *ctx = ws + wl.ctx, *g = ws + wl.g;
-  float* xhat = ws + wl.total;
-  float* shift_tmp = xhat + (((size_t)c * kD + 63) & ~(size_t)63);
-  const int M = c;
-  launch_conv1(feats, h->front, y1, 1, T, F, T1, F1, st);
-  launch_conv2(y1, h->front, y2, 1, T1, F1, c, F2, st);
-  launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st);
-  const int n_chunks = h->desc.linear_units / 256;
-  const int lo = s->lo;
-  for (int i = 0; i < h->desc.num_blocks; ++i) {
-    const LayerW& L = h->layers[i];
-    float* kc = s->kc + (size_t)i * s->cap * kD;
-    float* vc = s->vc + (size_t)i * s->cap * kD;
-    float* xh = s->xh_hist + (size_t)i * lo * kD;
-    launch_ffn_qkv(xa, xb, qkv, L, M, n_chunks, st);
-    launch_kv_append(qkv, kc + (size_t)s->cache_t * kD, vc + (size_t)s->cache_t * kD, c, st);
-    AttnArgs a{qkv, 768, kc, kD, vc, kD, c, T2, s->offset - s->cache_t, nullptr, ctx, L.pos_u, L.pos_v, L.ptab, 1, 4, c, T2, 1};
-    launch_attention(a, 1, h->desc.attention_heads, st);
-    launch_pw1_glu(xh, s->g_hist, L, lo, st);
-    launch_out_glu(ctx, xb, xc, g, xhat, L, nullptr, M, c, 4, st);
-    launch_conv_ffn(g, s->g_hist, xc, xa, L, nullptr, M, c, n_chunks, h->desc.cnn_module_kernel, 4, nullptr, nullptr, nullptr, st);
-    launch_hist_update(xh, xhat, c, lo, st);
-  }
-  int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
-  float* fp = frame_maxprob ? frame_maxprob : ws + wl.fp;
-  launch_ctc_head(xa, h->head, probs, fa, fp, ws + wl.rmax, ws + wl.rsum, M, st);
-  if (probs) launch_softmax_from_stats(probs, ws + wl.rmax, ws + wl.rsum, M, h->head.V, st);
-  // next_cache_start (encoder.py:255-260)
-  int keep;
-  if (required_cache_size < 0) keep = T2;
-  else if (required_cache_size == 0) keep = 0;
-  else keep = required_cache_size < T2 ? required_cache_size : T2;
-  if (keep > 0 && keep < T2) {
-    const size_t bytes = (size_t)keep * kD * sizeof(float);
-    for (int i = 0; i < h->desc.num_blocks; ++i) {
-      float* bufs[2] = {s->kc + (size_t)i * s->cap * kD, s->vc + (size_t)i * s->cap * kD};
-      for (float* b : bufs) {
-        HIP_TRY(hipMemcpyAsync(shift_tmp, b + (size_t)(T2 - keep) * kD, bytes, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(b, shift_tmp, bytes, hipMemcpyDeviceToDevice, st));
-      }
-    }
-  }
-  s->cache_t = keep;
-  s->offset += c;
-  if (c_out_host) *c_out_host = c;
-  HIP_TRY(hipGetLastError());
-  return PPASR_OK;
-}
-
-// Reference-layout views of the caches (what get_encoder_out_chunk returns, conformer/model.py:164-184):
-// att_cache [L][h][t][2*dk] (t = ppasr_stream_cache_frames), cnn_cache [L][1][256][lo].
-ppasr_status ppasr_stream_export_cache(ppasr_stream s, float* att_cache, float* cnn_cache, void* stream) {
-  if (!s) return fail(PPASR_EINVAL, "null stream");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int L = s->m->desc.num_blocks, t = s->cache_t;
-  for (int i = 0; i < L; ++i) {
-    if (att_cache && t > 0)
-      launch_cache_export(s->kc + (size_t)i * s->cap * kD, s->vc + (size_t)i * s->cap * kD,
-                          att_cache + (size_t)i * 4 * t * 128, t, st);
-    if (cnn_cache) launch_cnn_transpose(s->xh_hist + (size_t)i * s->lo * kD, cnn_cache + (size_t)i * kD * s->lo, s->lo, 1, st);
-  }
-  HIP_TRY(hipGetLastError());
-  return PPASR_OK;
-}
-
-ppasr_status ppasr_stream_import_cache(ppasr_stream s, const float* att_cache, int cache_t, const float* cnn_cache,
-                                       int offset, void* stream) {
-  if (!s) return fail(PPASR_EINVAL, "null stream");
-  if (cache_t < 0 || cache_t > s->cap || offset < 0) return fail(PPASR_EINVAL, "bad cache_t / offset");
-  if (cache_t > 0 && !att_cache) return fail(PPASR_EINVAL, "att_cache missing");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int L = s->m->desc.num_blocks;
-  for (int i = 0; i < L; ++i) {
-    if (cache_t > 0)
-      launch_cache_import(att_cache + (size_t)i * 4 * cache_t * 128, s->kc + (size_t)i * s->cap * kD,
-                          s->vc + (size_t)i * s->cap * kD, cache_t, st);
-    if (cnn_cache)
-      launch_cnn_transpose(cnn_cache + (size_t)i * kD * s->lo, s->xh_hist + (size_t)i * s->lo * kD, s->lo, 0, st);
-  }
-  if (!cnn_cache)
-    HIP_TRY(hipMemsetAsync(s->xh_hist, 0, (size_t)L * s->lo * kD * sizeof(float), st));
-  s->cache_t = cache_t;
-  s->offset = offset;
   HIP_TRY(hipGetLastError());
   return PPASR_OK;
 }

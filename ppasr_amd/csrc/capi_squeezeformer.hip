@@ -163,6 +163,10 @@ ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe
       for (int c = 0; c < d; ++c) gp[c] = p1b[c] * (1.0f / (1.0f + expf(-p1b[c + d])));
       UP(b1f, W.pw1_b);
       UP(gp, W.glu_pad);
+      UP(vec_of(as, d), W.cm_scale);
+      UP(vec_of(ab, d), W.cm_bias);
+      UP4(pack_b(d, 2 * d, [&](int k, int n) { return p1w[(size_t)n * d + k]; }), W.pw1_raw);
+      UP(vec_of(p1b, 2 * d), W.pw1_b_raw);
       std::vector<float> dwt((size_t)KS * d);
       for (int c = 0; c < d; ++c)
         for (int j = 0; j < KS; ++j) dwt[(size_t)j * d + c] = dww[(size_t)c * KS + j];
@@ -250,12 +254,12 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
     AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Ti, Ti, 0, lens, ctx, W.pos_u, W.pos_v, W.ptab, reduced ? 2 : 1, mul, Ti, Ti, 1};
     launch_attention(a, B, H, st);
     tap(ctx, (size_t)Mi * kD);
-    launch_sq_mid(ctx, x, xc, g, W, lens, Mi, Ti, mul, n_chunks, st);
+    launch_sq_mid(ctx, x, xc, g, nullptr, W, lens, Mi, Ti, mul, n_chunks, st);
     tap(xc, (size_t)Mi * kD);
     tap(g, (size_t)Mi * kD);
     const bool fuse_next = (i + 1 < L) && (i + 1 != h->desc.reduce_idx) && !(i + 1 == h->desc.recover_idx && reduced);
     const SqLayerW* Wn = fuse_next ? &h->sq_layers[i + 1] : nullptr;
-    launch_sq_tail(g, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, lens, Mi, Ti, mul, n_chunks, KS,
+    launch_sq_tail(g, nullptr, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, lens, Mi, Ti, mul, n_chunks, KS,
                    st);
     std::swap(x, other);
     have_qkv = fuse_next;

@@ -1,0 +1,366 @@
+// capi_stream.hip -- streaming entry points: <Family>Encoder.forward_chunk with the attention K/V cache and the
+// conv-module cache resident on the device inside a stream-state object (the reference round-trips both through the
+// host on every chunk, infer_utils/inference_predictor.py:196-210).
+//   Conformer            conformer/encoder.py:208-283
+//   Squeezeformer        squeezeformer/encoder.py:260-381   (time-reduced layers 5..10, recover at 11)
+//   Efficient-Conformer  efficient_conformer/encoder.py:266-393 (grouped attention 0..3, stride layer 3, 7-tap convs after)
+//
+// Cache bookkeeping.  Every layer owns K and V caches [cap][256] (row = frame) and a conv-module input history
+// [lo_max][256] (the reference's cnn_cache, frame-major; its first lo_i rows are used, lo_i = kernel_i - 1).
+// Layers that run at half rate (after a time reduction / the stride layer) hold each cached frame ONCE; the reference
+// stores those caches repeat_interleave'd to the full rate and reads them back with [::2], which is the identity on
+// the values.  The frame COUNTS follow the reference's slicing exactly (including Squeezeformer's trim of the reduced
+// cache to len(pos_emb) - len(xs) and of the exported cache to the first layer's length); a combination for which the
+// reference itself fails with a shape error (odd cache lengths) is refused with PPASR_EINVAL.
+#include <algorithm>
+
+#include "capi_internal.h"
+
+struct ppasr_stream_s {
+  ppasr_model_s* m;
+  int cap;      // key capacity per layer (frames)
+  int cache_t;  // cached key/value frames of the full-rate layers (cache_t1 in the reference)
+  int cache_r;  // frames held by the half-rate layers
+  int offset;   // encoder-output frames emitted so far (the reference's `offset` argument)
+  int lo;       // longest conv left context = cnn_module_kernel - 1
+  float *kc, *vc;   // [L][cap][256]
+  float* xh_hist;   // [L][lo][256]  conv-module input history
+  float* g_hist;    // [lo][256] scratch: GLU(pointwise_conv1(history)) of the layer being processed
+};
+
+namespace {
+
+inline bool is_sq(const ppasr_model_s* h) { return h->desc.model_type == PPASR_MODEL_SQUEEZEFORMER; }
+inline bool is_eff(const ppasr_model_s* h) { return h->desc.model_type == PPASR_MODEL_EFFICIENT_CONFORMER; }
+
+// calculate_downsampling_factor (squeezeformer/encoder.py:246-258, efficient_conformer/encoder.py:205-210)
+inline int layer_factor(const ppasr_model_s* h, int i) {
+  if (is_sq(h)) return (h->desc.reduce_idx >= 0 && i >= h->desc.reduce_idx && !(h->desc.recover_idx >= 0 && i >= h->desc.recover_idx)) ? 2 : 1;
+  if (is_eff(h)) return (h->desc.stride_layer_idx >= 0 && i > h->desc.stride_layer_idx) ? 2 : 1;
+  return 1;
+}
+inline int layer_lo(const ppasr_model_s* h, int i) {
+  return (is_sq(h) ? h->desc.cnn_module_kernel : h->layer_ks[i]) - 1;
+}
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// keep rows [from, from+keep) of a [cap][256] cache at its start
+ppasr_status shift_cache(float* buf, int from, int keep, float* tmp, hipStream_t st) {
+  if (keep <= 0 || from <= 0) return PPASR_OK;
+  const size_t bytes = (size_t)keep * kD * sizeof(float);
+  HIP_TRY(hipMemcpyAsync(tmp, buf + (size_t)from * kD, bytes, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(buf, tmp, bytes, hipMemcpyDeviceToDevice, st));
+  return PPASR_OK;
+}
+
+// pointwise_conv1 + GLU of the cached conv inputs of layer i -> s->g_hist (lo_i rows)
+void history_glu(ppasr_stream_s* s, int i, hipStream_t st) {
+  ppasr_model_s* h = s->m;
+  const int lo_i = layer_lo(h, i);
+  const float* xh = s->xh_hist + (size_t)i * s->lo * kD;
+  if (is_sq(h)) {
+    LayerW t{};
+    t.pw1 = h->sq_layers[i].pw1_raw;
+    t.pw1_b = h->sq_layers[i].pw1_b_raw;
+    launch_pw1_glu(xh, s->g_hist, t, lo_i, st);
+  } else {
+    launch_pw1_glu(xh, s->g_hist, h->layers[i], lo_i, st);
+  }
+}
+
+struct ChunkPlan {
+  int c;        // full-rate frames of this chunk
+  int c_r;      // half-rate frames
+  int used_r;   // half-rate cache frames that take part
+  int T2, T2_r; // keys of the full-rate / half-rate layers
+  int ncs;      // next_cache_start
+  int pos0;     // position of key 0
+};
+
+// the reference's shape arithmetic for one chunk
+ppasr_status plan_chunk(const ppasr_stream_s* s, int c, int required_cache_size, ChunkPlan* p) {
+  const ppasr_model_s* h = s->m;
+  p->c = c;
+  p->c_r = ceil_div(c, 2);  // Conv1D(k=1, s=2) / stride-2 depthwise conv + ceil-mode AvgPool
+  p->T2 = s->cache_t + c;
+  const int pos_len_r = ceil_div(s->cache_t + c, 2);  // pos_emb[:, ::2]
+  if (is_sq(h)) {
+    // att_cache[i][:, :, ::2][:, :, :pos_len - xs_len] of a cache exported as repeat_interleave(...)[:max_att_len]
+    const int avail = ceil_div(std::min(2 * s->cache_r, s->cache_t), 2);
+    p->used_r = std::min(avail, pos_len_r - p->c_r);
+  } else {
+    p->used_r = s->cache_r;  // att_cache[i][:, :, ::2], no trim
+  }
+  p->T2_r = p->used_r + p->c_r;
+  const bool has_half = is_sq(h) ? h->desc.reduce_idx >= 0 : (is_eff(h) && h->desc.stride_layer_idx >= 0);
+  if (has_half && p->T2_r != pos_len_r)
+    return fail(PPASR_EINVAL, "half-rate attention cache does not line up with the strided positional table "
+                              "(the reference fails on matrix_ac + matrix_bd here): keep cache lengths even");
+  if (required_cache_size < 0) p->ncs = 0;
+  else if (required_cache_size == 0) p->ncs = p->T2;
+  else p->ncs = std::max(p->T2 - required_cache_size, 0);
+  // efficient_conformer/encoder.py:305: offset *= calculate_downsampling_factor(num_blocks + 1)
+  const int off = is_eff(h) && h->desc.stride_layer_idx >= 0 ? 2 * s->offset : s->offset;
+  p->pos0 = off - s->cache_t;
+  if (p->pos0 < 0) return fail(PPASR_EINVAL, "offset smaller than the attention cache length");
+  if (p->pos0 + p->T2 >= h->desc.max_len) return fail(PPASR_EINVAL, "offset + chunk exceeds the positional table (max_len)");
+  if (p->T2 > s->cap) return fail(PPASR_EINVAL, "attention cache capacity exceeded");
+  return PPASR_OK;
+}
+
+ppasr_status finish_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* shift_tmp, hipStream_t st) {
+  ppasr_model_s* h = s->m;
+  const int keep = p.T2 - p.ncs;
+  const int from_r = p.ncs / 2;
+  const int keep_r = std::max(p.T2_r - from_r, 0);
+  for (int i = 0; i < h->desc.num_blocks; ++i) {
+    float* bufs[2] = {s->kc + (size_t)i * s->cap * kD, s->vc + (size_t)i * s->cap * kD};
+    const bool half = layer_factor(h, i) == 2;
+    for (float* b : bufs) {
+      ppasr_status r = half ? shift_cache(b, from_r, keep_r, shift_tmp, st) : shift_cache(b, p.ncs, keep, shift_tmp, st);
+      if (r != PPASR_OK) return r;
+    }
+  }
+  s->cache_t = keep;
+  s->cache_r = keep_r;
+  return PPASR_OK;
+}
+
+// ---- Conformer / Efficient-Conformer ----
+ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, float* xb, float* xc, float* qkv, float* ctx,
+                             float* g, float* xhat, int* frames_out, hipStream_t st) {
+  ppasr_model_s* h = s->m;
+  const int n_chunks = h->desc.linear_units / 256;
+  const int H = h->desc.attention_heads;
+  int Ti = p.c, mul = 4, pstride = 1;
+  bool half = false;
+  for (int i = 0; i < h->desc.num_blocks; ++i) {
+    const LayerW& L = h->layers[i];
+    const int grp = h->layer_group[i];
+    const int n_cache = half ? p.used_r : s->cache_t;
+    const int T2f = n_cache + Ti;
+    float* kc = s->kc + (size_t)i * s->cap * kD;
+    float* vc = s->vc + (size_t)i * s->cap * kD;
+    float* xh = s->xh_hist + (size_t)i * s->lo * kD;
+    const int lo_i = layer_lo(h, i);
+    launch_ffn_qkv(xa, xb, qkv, L, Ti, n_chunks, st);
+    launch_kv_append(qkv, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD, Ti, st);
+    // grouped attention re-cuts cache + chunk frames into groups of 3 from the START of the cache (pad4group on the
+    // concatenated keys, efficient_conformer/attention.py:160-175), zero-padded tail group
+    AttnArgs a{qkv, 768, kc, kD, vc, kD, ceil_div(Ti, grp), ceil_div(T2f, grp), p.pos0, nullptr, ctx, L.pos_u, L.pos_v,
+               L.ptab, pstride, mul * grp, Ti, T2f, grp};
+    launch_attention(a, 1, H, st);
+    history_glu(s, i, st);
+    launch_out_glu(ctx, xb, xc, g, xhat, L, nullptr, Ti, Ti, mul, st);
+    if (is_eff(h) && i == h->desc.stride_layer_idx) {
+      const int Ts = ceil_div(Ti, 2);
+      launch_conv_ffn_stride(g, s->g_hist, xc, xa, L, nullptr, 1, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st);
+      launch_hist_update(xh, xhat, Ti, lo_i, st);
+      Ti = Ts;
+      mul *= 2;
+      pstride *= 2;
+      half = true;
+    } else {
+      launch_conv_ffn(g, s->g_hist, xc, xa, L, nullptr, Ti, Ti, n_chunks, h->layer_ks[i], mul, nullptr, nullptr, nullptr, st);
+      launch_hist_update(xh, xhat, Ti, lo_i, st);
+    }
+  }
+  *frames_out = Ti;
+  return PPASR_OK;
+}
+
+// ---- Squeezeformer ----
+ppasr_status squeezeformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, float* xb, float* xc, float* qkv,
+                                 float* ctx, float* g, float* xs, float* xhat, float** x_final, hipStream_t st) {
+  ppasr_model_s* h = s->m;
+  const int L = h->desc.num_blocks, H = h->desc.attention_heads;
+  const int n_chunks = h->desc.linear_units / 256, KS = h->desc.cnn_module_kernel;
+  launch_ln_rows(xa, h->preln_g, h->preln_b, p.c, st);
+  float* x = xa;
+  float* other = xb;
+  bool reduced = false, have_qkv = false;
+  for (int i = 0; i < L; ++i) {
+    const SqLayerW& W = h->sq_layers[i];
+    if (i == h->desc.reduce_idx) {
+      HIP_TRY(hipMemcpyAsync(xs, x, (size_t)p.c * kD * sizeof(float), hipMemcpyDeviceToDevice, st));
+      launch_sq_reduce(x, other, qkv, h->sq_reduce, W.wqkv, W.bqkv, nullptr, 1, p.c, p.c_r, st);
+      std::swap(x, other);
+      reduced = true;
+      have_qkv = true;
+    }
+    if (i == h->desc.recover_idx && reduced) {
+      launch_sq_recover(x, xs, other, qkv, h->sq_wrec, h->sq_brec, W.wqkv, W.bqkv, 1, p.c, p.c_r, st);
+      std::swap(x, other);
+      reduced = false;
+      have_qkv = true;
+    }
+    const int Ti = reduced ? p.c_r : p.c;
+    const int mul = reduced ? 8 : 4;
+    const int n_cache = reduced ? p.used_r : s->cache_t;
+    float* kc = s->kc + (size_t)i * s->cap * kD;
+    float* vc = s->vc + (size_t)i * s->cap * kD;
+    float* xh = s->xh_hist + (size_t)i * s->lo * kD;
+    if (!have_qkv) launch_sq_qkv(x, qkv, W.wqkv, W.bqkv, Ti, st);
+    launch_kv_append(qkv, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD, Ti, st);
+    AttnArgs a{qkv, 768, kc, kD, vc, kD, Ti, n_cache + Ti, p.pos0, nullptr, ctx, W.pos_u, W.pos_v, W.ptab, reduced ? 2 : 1,
+               mul, Ti, n_cache + Ti, 1};
+    launch_attention(a, 1, H, st);
+    history_glu(s, i, st);
+    launch_sq_mid(ctx, x, xc, g, xhat, W, nullptr, Ti, Ti, mul, n_chunks, st);
+    const bool fuse_next = (i + 1 < L) && (i + 1 != h->desc.reduce_idx) && !(i + 1 == h->desc.recover_idx && reduced);
+    const SqLayerW* Wn = fuse_next ? &h->sq_layers[i + 1] : nullptr;
+    launch_sq_tail(g, s->g_hist, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, nullptr, Ti, Ti, mul,
+                   n_chunks, KS, st);
+    launch_hist_update(xh, xhat, Ti, KS - 1, st);
+    std::swap(x, other);
+    have_qkv = fuse_next;
+  }
+  *x_final = x;
+  return PPASR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out) {
+  if (!h || !out) return fail(PPASR_EINVAL, "null argument");
+  if (h->desc.model_type == PPASR_MODEL_DEEPSPEECH2)
+    return fail(PPASR_EUNSUPPORTED, "deepspeech2 streams carry their state in the h/c boxes of ppasr_ds2_encode");
+  auto* s = new ppasr_stream_s();
+  s->m = h;
+  s->cap = h->desc.max_len;
+  s->lo = h->desc.cnn_module_kernel - 1;
+  const size_t L = h->desc.num_blocks;
+  hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&s->kc), L * s->cap * kD * sizeof(float));
+  hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&s->vc), L * s->cap * kD * sizeof(float));
+  hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&s->xh_hist), L * s->lo * kD * sizeof(float));
+  hipError_t e4 = hipMalloc(reinterpret_cast<void**>(&s->g_hist), (size_t)s->lo * kD * sizeof(float));
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+    (void)hipFree(s->kc); (void)hipFree(s->vc); (void)hipFree(s->xh_hist); (void)hipFree(s->g_hist);
+    delete s;
+    return fail(PPASR_EHIP, "hipMalloc failed for the stream caches");
+  }
+  s->cache_t = 0;
+  s->cache_r = 0;
+  s->offset = 0;
+  hipError_t e5 = hipMemset(s->xh_hist, 0, L * s->lo * kD * sizeof(float));
+  if (e5 != hipSuccess) return fail(PPASR_EHIP, "hipMemset failed");
+  *out = s;
+  return PPASR_OK;
+}
+
+ppasr_status ppasr_stream_destroy(ppasr_stream s) {
+  if (!s) return PPASR_OK;
+  (void)hipFree(s->kc); (void)hipFree(s->vc); (void)hipFree(s->xh_hist); (void)hipFree(s->g_hist);
+  delete s;
+  return PPASR_OK;
+}
+
+// InferencePredictor.reset_stream (inference_predictor.py:215-220): empty caches, offset 0
+ppasr_status ppasr_stream_reset(ppasr_stream s, void* stream) {
+  if (!s) return fail(PPASR_EINVAL, "null stream");
+  s->cache_t = 0;
+  s->cache_r = 0;
+  s->offset = 0;
+  HIP_TRY(hipMemsetAsync(s->xh_hist, 0, (size_t)s->m->desc.num_blocks * s->lo * kD * sizeof(float),
+                         static_cast<hipStream_t>(stream)));
+  return PPASR_OK;
+}
+
+int ppasr_stream_offset(ppasr_stream s) { return s ? s->offset : -1; }
+int ppasr_stream_cache_frames(ppasr_stream s) { return s ? s->cache_t : -1; }
+
+size_t ppasr_chunk_workspace_bytes(ppasr_handle h, int T) {
+  if (!h || T < 7) return 0;
+  const size_t Tp = ((T - 1) / 2 - 1) / 2;
+  // the full-utterance layout for B=1, plus the conv-module input rows and a cache-shift scratch
+  return (ws_layout(h, 1, T).total + Tp * kD + 64 + (size_t)h->desc.max_len * kD) * sizeof(float);
+}
+
+ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int required_cache_size, float* probs,
+                                int32_t* frame_argmax, float* frame_maxprob, int* c_out_host, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  if (!s || !feats || !workspace) return fail(PPASR_EINVAL, "null argument");
+  ppasr_model_s* h = s->m;
+  if (T < 7) return fail(PPASR_EINVAL, "chunk shorter than the conv front-end's receptive field (7 frames)");
+  const int F = h->desc.input_dim, T1 = (T - 1) / 2, F1 = h->F1, c = (T1 - 1) / 2, F2 = h->F2;
+  if (workspace_bytes < ppasr_chunk_workspace_bytes(h, T)) return fail(PPASR_ENOSPACE, "workspace too small");
+  ChunkPlan p{};
+  ppasr_status r = plan_chunk(s, c, required_cache_size, &p);
+  if (r != PPASR_OK) return r;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const WsLayout wl = ws_layout(h, 1, T);
+  float* ws = static_cast<float*>(workspace);
+  float *y1 = ws + wl.y1, *y2 = ws + wl.y2, *xa = ws + wl.xa, *xb = ws + wl.xb, *xc = ws + wl.xc;
+  float *qkv = ws + wl.qkv, *ctx = ws + wl.ctx, *g = ws + wl.g;
+  float* xhat = ws + wl.total;
+  float* shift_tmp = xhat + (((size_t)c * kD + 63) & ~(size_t)63);
+  launch_conv1(feats, h->front, y1, 1, T, F, T1, F1, st);
+  launch_conv2(y1, h->front, y2, 1, T1, F1, c, F2, st);
+  launch_embed(y2, h->front, xa, c, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/is_sq(h), st);
+  float* x_final = xa;
+  int frames = c;
+  if (is_sq(h)) r = squeezeformer_chunk(s, p, xa, xb, xc, qkv, ctx, g, ws + wl.xs, xhat, &x_final, st);
+  else r = conformer_chunk(s, p, xa, xb, xc, qkv, ctx, g, xhat, &frames, st);
+  if (r != PPASR_OK) return r;
+  int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
+  float* fp = frame_maxprob ? frame_maxprob : ws + wl.fp;
+  launch_ctc_head(x_final, h->head, probs, fa, fp, ws + wl.rmax, ws + wl.rsum, frames, st);
+  if (probs) launch_softmax_from_stats(probs, ws + wl.rmax, ws + wl.rsum, frames, h->head.V, st);
+  r = finish_chunk(s, p, shift_tmp, st);
+  if (r != PPASR_OK) return r;
+  s->offset += frames;
+  if (c_out_host) *c_out_host = frames;
+  HIP_TRY(hipGetLastError());
+  return PPASR_OK;
+}
+
+// Reference-layout views of the caches (what get_encoder_out_chunk returns, conformer/model.py:164-184):
+// att_cache [L][h][t][2*dk] (t = ppasr_stream_cache_frames), cnn_cache [L][1][256][lo].
+ppasr_status ppasr_stream_export_cache(ppasr_stream s, float* att_cache, float* cnn_cache, void* stream) {
+  if (!s) return fail(PPASR_EINVAL, "null stream");
+  ppasr_model_s* h = s->m;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int L = h->desc.num_blocks, t = s->cache_t;
+  for (int i = 0; i < L; ++i) {
+    const int div = layer_factor(h, i);
+    if (att_cache && t > 0) {
+      // repeat_interleave(cache, 2)[:max_att_len] must cover t frames, or the reference's concat over layers fails
+      if (div == 2 && (2 * s->cache_r < t || (is_eff(h) && 2 * s->cache_r != t)))
+        return fail(PPASR_EINVAL, "half-rate cache does not match the first layer's cache length (odd cache length)");
+      launch_cache_export(s->kc + (size_t)i * s->cap * kD, s->vc + (size_t)i * s->cap * kD,
+                          att_cache + (size_t)i * 4 * t * 128, t, div, st);
+    }
+    if (cnn_cache)
+      launch_cnn_transpose(s->xh_hist + (size_t)i * s->lo * kD, cnn_cache + (size_t)i * kD * s->lo, layer_lo(h, i), s->lo, 1, st);
+  }
+  HIP_TRY(hipGetLastError());
+  return PPASR_OK;
+}
+
+ppasr_status ppasr_stream_import_cache(ppasr_stream s, const float* att_cache, int cache_t, const float* cnn_cache,
+                                       int offset, void* stream) {
+  if (!s) return fail(PPASR_EINVAL, "null stream");
+  if (cache_t < 0 || cache_t > s->cap || offset < 0) return fail(PPASR_EINVAL, "bad cache_t / offset");
+  if (cache_t > 0 && !att_cache) return fail(PPASR_EINVAL, "att_cache missing");
+  ppasr_model_s* h = s->m;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int L = h->desc.num_blocks;
+  for (int i = 0; i < L; ++i) {
+    if (cache_t > 0)
+      launch_cache_import(att_cache + (size_t)i * 4 * cache_t * 128, s->kc + (size_t)i * s->cap * kD,
+                          s->vc + (size_t)i * s->cap * kD, cache_t, layer_factor(h, i), st);
+    if (cnn_cache)
+      launch_cnn_transpose(cnn_cache + (size_t)i * kD * s->lo, s->xh_hist + (size_t)i * s->lo * kD, layer_lo(h, i), s->lo, 0, st);
+  }
+  if (!cnn_cache)
+    HIP_TRY(hipMemsetAsync(s->xh_hist, 0, (size_t)L * s->lo * kD * sizeof(float), st));
+  s->cache_t = cache_t;
+  s->cache_r = ceil_div(cache_t, 2);  // att_cache[i][:, :, ::2]
+  s->offset = offset;
+  HIP_TRY(hipGetLastError());
+  return PPASR_OK;
+}
+
+}  // extern "C"

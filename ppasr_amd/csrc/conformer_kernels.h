@@ -77,15 +77,15 @@ void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, floa
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                      const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,
                      float* x1_next, float* qkv_next, hipStream_t st);
-void launch_conv_ffn_stride(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int B,
+void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int B,
                             int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out, hipStream_t st);
 // streaming helpers
 void launch_pw1_glu(const float* xhat, float* g, const LayerW& w, int M, hipStream_t st);
 void launch_kv_append(const float* qkv, float* kc, float* vc, int n_rows, hipStream_t st);
 void launch_hist_update(float* hist, const float* fresh, int n, int lo, hipStream_t st);
-void launch_cache_export(const float* kc, const float* vc, float* att, int T, hipStream_t st);
-void launch_cache_import(const float* att, float* kc, float* vc, int T, hipStream_t st);
-void launch_cnn_transpose(const float* src, float* dst, int lo, int to_ref, hipStream_t st);
+void launch_cache_export(const float* kc, const float* vc, float* att, int T, int div, hipStream_t st);
+void launch_cache_import(const float* att, float* kc, float* vc, int T, int div, hipStream_t st);
+void launch_cnn_transpose(const float* src, float* dst, int lo, int lo_ref, int to_ref, hipStream_t st);
 void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStream_t st);
 // hw.ln_g == nullptr: no final LayerNorm (Squeezeformer has no after_norm, squeezeformer/encoder.py:232-235)
 void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr_argmax, float* fr_maxprob,

@@ -671,34 +671,42 @@ void launch_hist_update(float* hist, const float* fresh, int n, int lo, hipStrea
 }
 
 // [T][256] (col = h*64+f) k/v caches  <->  reference att_cache layout [h][T][2*dk]  (attention.py:232)
-__global__ void k_cache_export(const float* __restrict__ kc, const float* __restrict__ vc, float* __restrict__ att, int T) {
+// `div` = 2 on time-reduced layers: the reference stores their cache repeat_interleave'd to the full rate and reads it
+// back with [::2] (squeezeformer/encoder.py:355,367-369; efficient_conformer/encoder.py:349,368); ours holds each frame once.
+__global__ void k_cache_export(const float* __restrict__ kc, const float* __restrict__ vc, float* __restrict__ att, int T,
+                               int div) {
   const int t = blockIdx.x, tid = threadIdx.x;  // 256 threads: (h, f)
   const int h = tid >> 6, f = tid & 63;
-  att[((size_t)h * T + t) * 128 + f] = kc[(size_t)t * kD + tid];
-  att[((size_t)h * T + t) * 128 + 64 + f] = vc[(size_t)t * kD + tid];
+  att[((size_t)h * T + t) * 128 + f] = kc[(size_t)(t / div) * kD + tid];
+  att[((size_t)h * T + t) * 128 + 64 + f] = vc[(size_t)(t / div) * kD + tid];
 }
-__global__ void k_cache_import(const float* __restrict__ att, float* __restrict__ kc, float* __restrict__ vc, int T) {
-  const int t = blockIdx.x, tid = threadIdx.x;
+__global__ void k_cache_import(const float* __restrict__ att, float* __restrict__ kc, float* __restrict__ vc, int T, int div) {
+  const int j = blockIdx.x, tid = threadIdx.x;  // j = stored frame <- exported frame j * div
   const int h = tid >> 6, f = tid & 63;
-  kc[(size_t)t * kD + tid] = att[((size_t)h * T + t) * 128 + f];
-  vc[(size_t)t * kD + tid] = att[((size_t)h * T + t) * 128 + 64 + f];
+  kc[(size_t)j * kD + tid] = att[((size_t)h * T + (size_t)j * div) * 128 + f];
+  vc[(size_t)j * kD + tid] = att[((size_t)h * T + (size_t)j * div) * 128 + 64 + f];
 }
 // cnn cache: ours [lo][256] (row = frame)  <->  reference [256][lo]
-__global__ void k_cnn_transpose(const float* __restrict__ src, float* __restrict__ dst, int lo, int to_ref) {
+// `lo_ref` >= lo: width of the reference tensor; ours maps to its LAST lo columns, the rest is zero on export
+// (F.pad to cnn_module_kernel-1, efficient_conformer/encoder.py:371-374; convolution.py:106 reads cache[:, :, -lorder:]).
+__global__ void k_cnn_transpose(const float* __restrict__ src, float* __restrict__ dst, int lo, int lo_ref, int to_ref) {
   const int c = threadIdx.x;
+  const int skip = lo_ref - lo;
+  if (to_ref)
+    for (int j = 0; j < skip; ++j) dst[(size_t)c * lo_ref + j] = 0.f;
   for (int j = 0; j < lo; ++j) {
-    if (to_ref) dst[(size_t)c * lo + j] = src[(size_t)j * kD + c];
-    else dst[(size_t)j * kD + c] = src[(size_t)c * lo + j];
+    if (to_ref) dst[(size_t)c * lo_ref + skip + j] = src[(size_t)j * kD + c];
+    else dst[(size_t)j * kD + c] = src[(size_t)c * lo_ref + skip + j];
   }
 }
-void launch_cache_export(const float* kc, const float* vc, float* att, int T, hipStream_t st) {
-  if (T > 0) hipLaunchKernelGGL(k_cache_export, dim3(T), dim3(256), 0, st, kc, vc, att, T);
+void launch_cache_export(const float* kc, const float* vc, float* att, int T, int div, hipStream_t st) {
+  if (T > 0) hipLaunchKernelGGL(k_cache_export, dim3(T), dim3(256), 0, st, kc, vc, att, T, div);
 }
-void launch_cache_import(const float* att, float* kc, float* vc, int T, hipStream_t st) {
-  if (T > 0) hipLaunchKernelGGL(k_cache_import, dim3(T), dim3(256), 0, st, att, kc, vc, T);
+void launch_cache_import(const float* att, float* kc, float* vc, int T, int div, hipStream_t st) {
+  if (T > 0) hipLaunchKernelGGL(k_cache_import, dim3((T + div - 1) / div), dim3(256), 0, st, att, kc, vc, T, div);
 }
-void launch_cnn_transpose(const float* src, float* dst, int lo, int to_ref, hipStream_t st) {
-  hipLaunchKernelGGL(k_cnn_transpose, dim3(1), dim3(256), 0, st, src, dst, lo, to_ref);
+void launch_cnn_transpose(const float* src, float* dst, int lo, int lo_ref, int to_ref, hipStream_t st) {
+  hipLaunchKernelGGL(k_cnn_transpose, dim3(1), dim3(256), 0, st, src, dst, lo, lo_ref, to_ref);
 }
 void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStream_t st);
 __global__ void k_fill_rows(float* __restrict__ dst, const float* __restrict__ row, int n_rows) {
@@ -804,8 +812,9 @@ void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float
 // Rows of this kernel are OUTPUT rows (b, j), j < Ts = ceil(Tp/2); g and x2 are full-resolution.
 // -------------------------------------------------------------------------------------
 template <int KS>
-__global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __restrict__ g, const float* __restrict__ x2,
-                                                              float* __restrict__ x_out, LayerW w,
+__global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __restrict__ g, const float* __restrict__ g_hist,
+                                                              const float* __restrict__ x2, float* __restrict__ x_out,
+                                                              LayerW w,
                                                               const int64_t* __restrict__ lens, int B, int Tp, int Ts,
                                                               int n_chunks, int mask_mul_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -833,7 +842,9 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __res
         for (int t = 0; t < KS; ++t) {
           const int f = 2 * j - LO + t;
           const f32x4 wj = *reinterpret_cast<const f32x4*>(w.dw_w + t * kD + 4 * lane);
-          const f32x4 v = (f >= 0) ? *reinterpret_cast<const f32x4*>(gb + (size_t)f * kD) : gp;
+          f32x4 v = gp;
+          if (f >= 0) v = *reinterpret_cast<const f32x4*>(gb + (size_t)f * kD);
+          else if (g_hist) v = *reinterpret_cast<const f32x4*>(g_hist + (size_t)(LO + f) * kD + 4 * lane);  // streaming, B = 1
           out += wj * v;
         }
       }
@@ -875,14 +886,15 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __res
   rb_layernorm(bufX, bufX, kLda, kRows, w.ln_fin_g, w.ln_fin_b, 1e-5f);
   rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);
 }
-void launch_conv_ffn_stride(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int B,
-                            int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out, hipStream_t st) {
+void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
+                            const int64_t* lens, int B, int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out,
+                            hipStream_t st) {
   dim3 grid((B * Ts + kRows - 1) / kRows);
   if (ksize == 15)
-    hipLaunchKernelGGL(k_conv_ffn_stride<15>, grid, dim3(kThreads), kLdsConvFfn, st, g, x2, x_out, w, lens, B, Tp, Ts,
+    hipLaunchKernelGGL(k_conv_ffn_stride<15>, grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, B, Tp, Ts,
                        n_chunks, mask_mul_out);
   else if (ksize == 7)
-    hipLaunchKernelGGL(k_conv_ffn_stride<7>, grid, dim3(kThreads), kLdsConvFfn, st, g, x2, x_out, w, lens, B, Tp, Ts,
+    hipLaunchKernelGGL(k_conv_ffn_stride<7>, grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, B, Tp, Ts,
                        n_chunks, mask_mul_out);
 }
 

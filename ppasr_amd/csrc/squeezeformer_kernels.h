@@ -15,6 +15,11 @@ struct SqLayerW {
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b, *ln4_g, *ln4_b, *ln_cm_g, *ln_cm_b;
   const float *dw_w, *dw_b, *glu_pad;
   const float *pos_u, *pos_v, *ptab;
+  // streaming (forward_chunk): the conv-module cache holds SCALED inputs ada_scale*x + ada_bias
+  // (convolution.py:119-137), re-projected every chunk with the UNFOLDED pointwise_conv1
+  const float *cm_scale, *cm_bias;
+  const f32x4* pw1_raw;
+  const float* pw1_b_raw;
 };
 struct SqReduceW {
   const float *dw_w, *dw_b;  // [256] depthwise k=1 stride-2 conv
@@ -23,9 +28,10 @@ struct SqReduceW {
 };
 
 void launch_sq_qkv(const float* x, float* qkv, const f32x4* wqkv, const float* bqkv, int M, hipStream_t st);
-void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, const SqLayerW& w, const int64_t* lens, int M,
-                   int Tp, int mask_mul, int n_chunks, hipStream_t st);
-void launch_sq_tail(const float* g, const float* x2, float* x_out, float* qkv_next, const SqLayerW& w,
+void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, float* xhat_out, const SqLayerW& w,
+                   const int64_t* lens, int M, int Tp, int mask_mul, int n_chunks, hipStream_t st);
+// g_hist != nullptr: streaming (single stream, rows = frames of one chunk; left context from g_hist [ksize-1][256])
+void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float* x_out, float* qkv_next, const SqLayerW& w,
                     const f32x4* wqkv_next, const float* bqkv_next, const int64_t* lens, int M, int Tp, int mask_mul,
                     int n_chunks, int ksize, hipStream_t st);
 void launch_sq_reduce(const float* x, float* xr, float* qkv, const SqReduceW& rw, const f32x4* wqkv, const float* bqkv,

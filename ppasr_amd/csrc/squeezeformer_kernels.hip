@@ -63,7 +63,8 @@ __device__ __forceinline__ void qkv_from_lds(const float* bufX, float* __restric
 
 // K_B: x1 = LN1(x + ctx Wo + bo) ; x2 = LN2(x1 + FFN1(x1)) ; g = GLU(pw1(x2))   (encoder.py:469-497)
 __global__ __launch_bounds__(kThreads) void k_sq_mid(const float* __restrict__ ctx, const float* __restrict__ x,
-                                                     float* __restrict__ x2, float* __restrict__ g, SqLayerW w,
+                                                     float* __restrict__ x2, float* __restrict__ g,
+                                                     float* __restrict__ xhat_out, SqLayerW w,
                                                      const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
                                                      int n_chunks) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -103,6 +104,13 @@ __global__ __launch_bounds__(kThreads) void k_sq_mid(const float* __restrict__ c
   __syncthreads();
   rb_layernorm(bufX, bufX, kLda, kRows, w.ln2_g, w.ln2_b, 1e-5f);
   rb_store_rows(x2 + (size_t)r0 * kD, bufX, kLda, kRows, valid);
+  if (xhat_out) {  // streaming: what the reference keeps as cnn_cache = the scaled conv-module input
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(w.cm_scale + 4 * lane);
+    const f32x4 sb = *reinterpret_cast<const f32x4*>(w.cm_bias + 4 * lane);
+    for (int row = wave; row < valid; row += kWaves)
+      *reinterpret_cast<f32x4*>(xhat_out + (size_t)(r0 + row) * kD + 4 * lane) =
+          sc * *reinterpret_cast<const f32x4*>(bufX + row * kLda + 4 * lane) + sb;
+  }
   __syncthreads();
   {
     f32x16 av[1][1], ag[1][1];
@@ -125,8 +133,9 @@ __global__ __launch_bounds__(kThreads) void k_sq_mid(const float* __restrict__ c
 constexpr size_t kLdsSqMid = 3 * kRows * kLda * sizeof(float);
 
 // K_C: x3 = LN3(x2 + mask(pw2(swish(LN(dwconv(g)))))) ; x4 = LN4(x3 + FFN2(x3)) ; [qkv of the next layer]
-template <int KS>
-__global__ __launch_bounds__(kThreads) void k_sq_tail(const float* __restrict__ g, const float* __restrict__ x2,
+template <int KS, bool STREAM>
+__global__ __launch_bounds__(kThreads) void k_sq_tail(const float* __restrict__ g, const float* __restrict__ g_hist,
+                                                      const float* __restrict__ x2,
                                                       float* __restrict__ x_out, float* __restrict__ qkv_next,
                                                       SqLayerW w, const f32x4* __restrict__ wqkv_next,
                                                       const float* __restrict__ bqkv_next,
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void k_sq_tail(const float* __restrict__ 
   BRing<1> ring;
   const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
   ring_prime(ring, seg_pw2, 0);
-  dwconv_phase<KS, false>(g, nullptr, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp);
+  dwconv_phase<KS, STREAM>(g, g_hist, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp);
   __syncthreads();
   rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
   __syncthreads();
@@ -299,19 +308,23 @@ constexpr size_t kLds2 = 2 * kRows * kLda * sizeof(float);
 void launch_sq_qkv(const float* x, float* qkv, const f32x4* wqkv, const float* bqkv, int M, hipStream_t st) {
   hipLaunchKernelGGL(k_sq_qkv, rb_grid(M), dim3(kThreads), kLds1, st, x, qkv, wqkv, bqkv, M);
 }
-void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, const SqLayerW& w, const int64_t* lens, int M,
-                   int Tp, int mask_mul, int n_chunks, hipStream_t st) {
-  hipLaunchKernelGGL(k_sq_mid, rb_grid(M), dim3(kThreads), kLdsSqMid, st, ctx, x, x2, g, w, lens, M, Tp, mask_mul, n_chunks);
+void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, float* xhat_out, const SqLayerW& w,
+                   const int64_t* lens, int M, int Tp, int mask_mul, int n_chunks, hipStream_t st) {
+  hipLaunchKernelGGL(k_sq_mid, rb_grid(M), dim3(kThreads), kLdsSqMid, st, ctx, x, x2, g, xhat_out, w, lens, M, Tp, mask_mul,
+                     n_chunks);
 }
-void launch_sq_tail(const float* g, const float* x2, float* x_out, float* qkv_next, const SqLayerW& w,
+void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float* x_out, float* qkv_next, const SqLayerW& w,
                     const f32x4* wqkv_next, const float* bqkv_next, const int64_t* lens, int M, int Tp, int mask_mul,
                     int n_chunks, int ksize, hipStream_t st) {
-  if (ksize == 31)
-    hipLaunchKernelGGL(k_sq_tail<31>, rb_grid(M), dim3(kThreads), kLdsSqTail, st, g, x2, x_out, qkv_next, w, wqkv_next,
-                       bqkv_next, lens, M, Tp, mask_mul, n_chunks);
-  else if (ksize == 15)
-    hipLaunchKernelGGL(k_sq_tail<15>, rb_grid(M), dim3(kThreads), kLdsSqTail, st, g, x2, x_out, qkv_next, w, wqkv_next,
-                       bqkv_next, lens, M, Tp, mask_mul, n_chunks);
+#define SQ_TAIL(KS, STREAM)                                                                                          \
+  hipLaunchKernelGGL((k_sq_tail<KS, STREAM>), rb_grid(M), dim3(kThreads), kLdsSqTail, st, g, g_hist, x2, x_out, qkv_next, w, \
+                     wqkv_next, bqkv_next, lens, M, Tp, mask_mul, n_chunks)
+  if (ksize == 31) {
+    if (g_hist) SQ_TAIL(31, true); else SQ_TAIL(31, false);
+  } else if (ksize == 15) {
+    if (g_hist) SQ_TAIL(15, true); else SQ_TAIL(15, false);
+  }
+#undef SQ_TAIL
 }
 void launch_sq_reduce(const float* x, float* xr, float* qkv, const SqReduceW& rw, const f32x4* wqkv, const float* bqkv,
                       const int64_t* lens, int B, int Tp, int Tr, hipStream_t st) {
@@ -332,8 +345,10 @@ hipError_t configure_squeezeformer_kernels() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
   if (e != hipSuccess) return e;
   SET_LDS(k_sq_mid, kLdsSqMid);
-  SET_LDS(k_sq_tail<31>, kLdsSqTail);
-  SET_LDS(k_sq_tail<15>, kLdsSqTail);
+  SET_LDS((k_sq_tail<31, false>), kLdsSqTail);
+  SET_LDS((k_sq_tail<15, false>), kLdsSqTail);
+  SET_LDS((k_sq_tail<31, true>), kLdsSqTail);
+  SET_LDS((k_sq_tail<15, true>), kLdsSqTail);
   SET_LDS(k_sq_reduce, kLds2);
   SET_LDS(k_sq_recover, kLds2);
 #undef SET_LDS

@@ -57,7 +57,7 @@ class InferencePredictor:
             from ppasr_amd.model_utils.deepspeech2.model import DeepSpeech2Model as cls
         self.model = cls(input_dim, vocab_size, streaming=streaming, encoder_conf=enc, state_dict=state_dict,
                          device=device)
-        self._stream = self.model.new_stream() if (streaming and use_model == "conformer") else None
+        self._stream = self.model.new_stream() if (streaming and "former" in use_model) else None
         self.output_state_h = None
         self.output_state_c = None
 

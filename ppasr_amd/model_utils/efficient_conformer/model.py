@@ -82,9 +82,3 @@ class EfficientConformerModel(ConformerModel):
         self._h = handle
         self._ws = None
         self._taps = None
-
-    def new_stream(self):
-        raise NotImplementedError("Efficient-Conformer forward_chunk is not built yet (DESIGN.md §7)")
-
-    def get_encoder_out_chunk(self, *a, **k):
-        raise NotImplementedError("Efficient-Conformer forward_chunk is not built yet (DESIGN.md §7)")

@@ -1,5 +1,6 @@
 """Host-side mirror of ``ppasr/model_utils/squeezeformer/model.py`` (``SqueezeformerModel``), inference
-surface: ``get_encoder_out`` (full utterance, batched).  Shares the C-ABI plumbing with the Conformer
+surface: ``get_encoder_out`` (full utterance, batched) and ``get_encoder_out_chunk`` / ``new_stream`` (forward_chunk,
+inherited from the Conformer wrapper: the C-ABI stream object handles the family's cache layout).  Shares the C-ABI plumbing with the Conformer
 wrapper; only the model descriptor and parameter names differ."""
 import ctypes
 
@@ -61,9 +62,3 @@ class SqueezeformerModel(ConformerModel):
         self._h = handle
         self._ws = None
         self._taps = None
-
-    def new_stream(self):
-        raise NotImplementedError("Squeezeformer forward_chunk is not built yet (DESIGN.md §7)")
-
-    def get_encoder_out_chunk(self, *a, **k):
-        raise NotImplementedError("Squeezeformer forward_chunk is not built yet (DESIGN.md §7)")

@@ -86,3 +86,37 @@ def test_deepspeech2_predictor_streaming():
     assert p.predictor.output_state_h.shape == (2, 1, 1024)
     p.reset_stream()
     assert p.predictor.output_state_h is None
+
+
+@pytest.mark.parametrize("use_model", ["squeezeformer", "efficient_conformer"])
+def test_predict_stream_other_conformer_families(use_model):
+    """predict_stream drives forward_chunk of every *former family (predict.py:300-309 -> predict_chunk_conformer)."""
+    from ppasr_amd.predict import PPASRPredictor
+    from ppasr_amd.utils.synth import efficient_conformer_state_dict, squeezeformer_state_dict
+    V = 300
+    vocab = synth_vocabulary(V)
+    cfg = _cfg(use_model=use_model, L=4)
+    if use_model == "squeezeformer":
+        cfg["encoder_conf"] = dict(encoder_dim=256, output_size=256, attention_heads=4, num_blocks=4, reduce_idx=1,
+                                   recover_idx=3, feed_forward_expansion_factor=8, cnn_module_kernel=31)
+        sd = squeezeformer_state_dict(vocab_size=V, num_blocks=4, seed=5)
+    else:
+        cfg["encoder_conf"] = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=4, cnn_module_kernel=15,
+                                   cnn_module_norm="layer_norm",
+                                   efficient_conf=dict(stride_layer_idx=[1], stride=[2], group_layer_idx=[0, 1], group_size=3,
+                                                       stride_kernel=True))
+        sd = efficient_conformer_state_dict(vocab_size=V, num_blocks=4, seed=5, stride_layer_idx=1, group_layer_idx=(0, 1))
+    p = PPASRPredictor(configs=cfg, state_dict=sd, vocab_list=vocab, warmup=False)
+    wav = _audio(2.6)
+    pcm = (np.clip(wav, -1, 1) * 32767).astype(np.int16).tobytes()
+    step = 16000 * 2 // 2
+    out = None
+    for i in range(0, len(pcm), step):
+        r = p.predict_stream(audio_data=pcm[i:i + step], is_end=False)
+        out = r or out
+    assert out is not None and isinstance(out["text"], str)
+    per_chunk = 8 if use_model == "efficient_conformer" else 16
+    assert p.predictor.offset[0] > 0 and p.predictor.offset[0] % per_chunk == 0
+    assert p.predictor.att_cache.shape[2] == p.predictor.offset[0] * (16 // per_chunk)
+    p.reset_stream()
+    assert p.predictor.offset[0] == 0
