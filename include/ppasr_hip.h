@@ -180,6 +180,20 @@ ppasr_status ppasr_ctc_collapse(const int32_t* frame_argmax, const float* frame_
                                 int B, int Tp, int blank, int32_t* tokens, int32_t* n_tokens, double* score,
                                 void* stream);
 
+/* ---- Kaldi-compatible fbank front-end --------------------------------------------
+ * Replaces AudioFeaturizer.featurize (ppasr/data_utils/featurizer/audio_featurizer.py:37-67,120-138):
+ * AudioSegment.normalize(target_dB) (data_utils/audio.py:287-304) -> .to('int16') (audio.py:244) ->
+ * paddleaudio.compliance.kaldi.fbank(n_mels, frame_length=25, frame_shift=10, dither=0, sr) (third-party,
+ * paddleaudio>=1.0.1).  samples: device f32 mono in [-1,1]; feats: device f32 [frames][n_mels]. */
+typedef struct ppasr_fbank_s* ppasr_fbank_handle;
+ppasr_status ppasr_fbank_create(int sample_rate, int n_mels, float frame_length_ms, float frame_shift_ms,
+                                ppasr_fbank_handle* out);
+ppasr_status ppasr_fbank_destroy(ppasr_fbank_handle f);
+int          ppasr_fbank_frames(ppasr_fbank_handle f, int n_samples);          /* snip_edges frame count */
+size_t       ppasr_fbank_workspace_bytes(ppasr_fbank_handle f, int n_samples);
+ppasr_status ppasr_fbank_compute(ppasr_fbank_handle f, const float* samples, int n_samples, int use_db_norm,
+                                 float target_db, float* feats, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

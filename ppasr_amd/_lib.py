@@ -73,6 +73,13 @@ SYMBOLS = [
                                         _vp, _vp, ctypes.c_size_t, _vp]),
     ("ppasr_ctc_collapse", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
                                           _vp]),
+    ("ppasr_fbank_create", ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                          ctypes.POINTER(_vp)]),
+    ("ppasr_fbank_destroy", ctypes.c_int, [_vp]),
+    ("ppasr_fbank_frames", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("ppasr_fbank_workspace_bytes", ctypes.c_size_t, [_vp, ctypes.c_int]),
+    ("ppasr_fbank_compute", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp, _vp,
+                                           ctypes.c_size_t, _vp]),
 ]
 
 _lib = None

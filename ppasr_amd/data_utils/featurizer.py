@@ -1,15 +1,14 @@
-"""Host-side feature front-end that feeds the hot path (NOT part of the hand-written-kernel scope:
-SURVEY.md §8f ranks a HIP fbank as the next row).  Mirrors the inference behaviour of
-``ppasr/data_utils/featurizer/audio_featurizer.py`` (dB normalisation -> int16 scale -> Kaldi fbank,
-dither 0 at inference, :37-67,120-138) and ``text_featurizer.py`` (vocabulary file loader).
+"""Feature front-end that feeds the hot path: the host-side mirror of
+``ppasr/data_utils/featurizer/audio_featurizer.py`` (dB normalisation -> int16 scale -> Kaldi fbank, dither 0 at
+inference, :37-67,120-138) and ``text_featurizer.py`` (vocabulary file loader).
 
-The fbank follows Kaldi's published algorithm with the defaults of
-``paddleaudio.compliance.kaldi.fbank`` (snip_edges, remove DC, pre-emphasis 0.97, povey window,
-512-point FFT, power spectrum, 80 mel bins from 20 Hz to Nyquist, log with float eps floor).
-paddleaudio is not installable offline, so this front-end is "parity unpinned".
+The arithmetic runs in ``csrc/fbank.hip`` behind ``ppasr_fbank_*`` (one workgroup per frame, frame resident in LDS
+from the raw samples to the 80 log-mel values); this module only loads audio and moves buffers.  There is no CPU
+path: without a HIP device ``featurize`` raises.  paddleaudio is not installable offline, so the front-end is
+"parity unpinned" (checked against ``oracle/fbank_oracle.py``, a float64 restatement of Kaldi's algorithm).
 """
+import ctypes
 import io
-import math
 import wave
 
 import numpy as np
@@ -17,7 +16,6 @@ import torch
 
 __all__ = ["AudioFeaturizer", "TextFeaturizer", "load_audio"]
 
-_EPS = float(np.finfo(np.float32).eps)
 
 
 def load_audio(audio_data, sample_rate=16000):
@@ -47,24 +45,6 @@ def pcm_bytes_to_float(data, channels=1, samp_width=2):
     return x
 
 
-def _mel(f):
-    return 1127.0 * np.log(1.0 + f / 700.0)
-
-
-def _mel_banks(n_mels, n_fft, sr, low=20.0, high=0.0):
-    nyq = 0.5 * sr
-    high = high + nyq if high <= 0 else high
-    fft_bin_width = sr / n_fft
-    mel_lo, mel_hi = _mel(low), _mel(high)
-    delta = (mel_hi - mel_lo) / (n_mels + 1)
-    b = np.arange(n_mels)[:, None]
-    left, center, right = mel_lo + b * delta, mel_lo + (b + 1) * delta, mel_lo + (b + 2) * delta
-    mel = _mel(fft_bin_width * np.arange(n_fft // 2))[None, :]
-    up = (mel - left) / (center - left)
-    down = (right - mel) / (right - center)
-    return np.maximum(0.0, np.minimum(up, down)).astype(np.float32)  # [n_mels, n_fft/2]
-
-
 class AudioFeaturizer:
     def __init__(self, feature_method="fbank", n_mels=80, n_mfcc=40, sample_rate=16000, use_dB_normalization=True,
                  target_dB=-20, train=False, device=None, **_ignored):
@@ -74,43 +54,58 @@ class AudioFeaturizer:
         self._sr = sample_rate
         self._use_db = use_dB_normalization
         self._target_db = target_dB
-        self._device = device
-        self._win = int(sample_rate * 0.025)
-        self._shift = int(sample_rate * 0.010)
-        self._nfft = 1 << (self._win - 1).bit_length()
-        self._banks = None
+        self._device = torch.device(device or "cuda:0")
+        self._h = None
+        self._ws = None
+
+    def _handle(self):
+        if self._h is None:
+            from ppasr_amd import _lib
+            if not torch.cuda.is_available():
+                raise _lib.PPASRHipError("no HIP device visible: the fbank front-end has no CPU fallback")
+            self._lib = _lib.load()
+            h = ctypes.c_void_p()
+            with torch.cuda.device(self._device):
+                _lib.check(self._lib.ppasr_fbank_create(self._sr, self._n_mels, 25.0, 10.0, ctypes.byref(h)))
+            self._h = h
+        return self._h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._lib.ppasr_fbank_destroy(h)
+            self._h = None
 
     @property
     def feature_dim(self):
         return self._n_mels
 
-    def featurize(self, samples, sample_rate=None):
-        """float32 mono samples -> fbank [T, n_mels] float32 (numpy)."""
-        x = np.asarray(samples, np.float32).copy()
+    def featurize_device(self, samples, sample_rate=None):
+        """float32 mono samples in [-1, 1] (numpy or tensor) -> fbank [T, n_mels] float32 DEVICE tensor."""
+        from ppasr_amd import _lib
         sr = sample_rate or self._sr
         if sr != self._sr:
             raise NotImplementedError("resampling is outside the hot path; feed audio at the model's sample rate")
-        if self._use_db:  # AudioSegment.normalize (audio.py:287-304)
-            ms = float(np.mean(x ** 2)) if x.size else 0.0
-            rms_db = 10 * math.log10(ms if ms != 0 else 1)
-            x *= 10.0 ** ((self._target_db - rms_db) / 20.0)
-        x = np.clip(x * 32768.0, -32768, 32767).astype(np.int16).astype(np.float32)  # .to('int16') (audio.py:244)
-        if len(x) < self._win:
-            return np.zeros((0, self._n_mels), np.float32)
-        dev = self._device or ("cuda" if torch.cuda.is_available() else "cpu")
-        w = torch.from_numpy(x).to(dev)
-        n = 1 + (len(x) - self._win) // self._shift  # snip_edges
-        frames = w.unfold(0, self._win, self._shift)[:n]
-        frames = frames - frames.mean(dim=1, keepdim=True)  # remove_dc_offset
-        prev = torch.cat([frames[:, :1], frames[:, :-1]], dim=1)
-        frames = frames - 0.97 * prev  # pre-emphasis
-        win = torch.hann_window(self._win, periodic=False, dtype=torch.float32, device=dev).pow(0.85)  # povey
-        frames = frames * win
-        spec = torch.fft.rfft(frames, n=self._nfft).abs().pow(2.0)  # power spectrum [n, nfft/2+1]
-        if self._banks is None or self._banks.device != spec.device:
-            self._banks = torch.from_numpy(_mel_banks(self._n_mels, self._nfft, self._sr)).to(spec.device)
-        mel = spec[:, : self._nfft // 2] @ self._banks.T
-        return torch.log(torch.clamp(mel, min=_EPS)).cpu().numpy().astype(np.float32)
+        h = self._handle()
+        x = torch.as_tensor(samples, dtype=torch.float32).reshape(-1).to(self._device).contiguous()
+        n = int(x.numel())
+        frames = int(self._lib.ppasr_fbank_frames(h, n))
+        feats = torch.empty(frames, self._n_mels, dtype=torch.float32, device=self._device)
+        if frames == 0:
+            return feats
+        need = int(self._lib.ppasr_fbank_workspace_bytes(h, n))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self._device)
+        with torch.cuda.device(self._device):
+            stream = torch.cuda.current_stream(self._device).cuda_stream
+            _lib.check(self._lib.ppasr_fbank_compute(h, x.data_ptr(), n, int(bool(self._use_db)), float(self._target_db),
+                                                     feats.data_ptr(), self._ws.data_ptr(), self._ws.numel(), stream))
+            torch.cuda.current_stream(self._device).synchronize()  # `x` must outlive the kernel
+        return feats
+
+    def featurize(self, samples, sample_rate=None):
+        """float32 mono samples -> fbank [T, n_mels] float32 (numpy), the reference's return type."""
+        return self.featurize_device(samples, sample_rate).cpu().numpy()
 
 
 class TextFeaturizer:
