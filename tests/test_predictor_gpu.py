@@ -120,3 +120,34 @@ def test_predict_stream_other_conformer_families(use_model):
     assert p.predictor.att_cache.shape[2] == p.predictor.offset[0] * (16 // per_chunk)
     p.reset_stream()
     assert p.predictor.offset[0] == 0
+
+
+def test_evaluate_harness_greedy_cer():
+    """trainer.evaluate's decode half: labels = the model's own greedy output -> CER 0; perturbed labels -> CER > 0."""
+    from ppasr_amd.evaluate import evaluate
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    from ppasr_amd.utils.synth import synth_features
+    V = 120
+    vocab = synth_vocabulary(V)
+    sd = conformer_state_dict(vocab_size=V, num_blocks=2, seed=9)
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=2, cnn_module_kernel=15)
+    model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    batches = []
+    for seed in (1, 2):
+        x, lens = synth_features(3, 203, lens=[203, 203, 203], seed=seed)
+        tokens, n, _ = model.encode_greedy(x, lens)
+        labels = tokens.cpu().numpy().copy()
+        labels[labels == V - 1] = 2  # <eos> is stripped from labels (utils.py:62); keep the strings comparable
+        labels[labels == 1] = 2      # so is <unk>
+        batches.append((x, labels, lens, n.cpu().numpy()))
+    # predictions still contain the original ids, so rebuild the expectation from the label strings themselves
+    from ppasr_amd.decoders.ctc_greedy_decoder import greedy_decoder_batch
+    from ppasr_amd.utils.metrics import cer, labels_to_string
+    want, cnt = 0.0, 0
+    for x, labels, lens, _ in batches:
+        outs = greedy_decoder_batch(model.get_encoder_out(x, lens), vocab)
+        for o, l in zip(outs, labels_to_string(labels, vocab, eos=V - 1)):
+            want += cer(o, l)
+            cnt += 1
+    got = evaluate(model, batches, vocab, decoder="ctc_greedy", metrics_type="cer")
+    assert got == pytest.approx(want / cnt) and 0.0 <= got < 0.2
