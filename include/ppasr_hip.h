@@ -109,7 +109,7 @@ ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats);
  *     decoders/beam_search_decoder.py:45-73), with init_state = 1;
  *   CtcBeamSearchDecoderBatch.next() + decode() (swig_wrapper.py:106-121, beam_search_decoder.py:75-96):
  *     call again with init_state = 0 and the SAME state buffer for every further chunk.
- * CTC prefix beam search WITHOUT an external scorer (no KenLM file offline).
+ * CTC prefix beam search; the external scorer variant is ppasr_ctc_beam_search_lm below.
  *   probs [B,T,V] f32, frame_lens [B] i32 or NULL; per utterance the `nbest` best prefixes:
  *   tokens [B,nbest,max_tokens] i32 (-1 padded), lens [B,nbest] (-1 = no such hypothesis),
  *   scores [B,nbest] f64 = -log P(prefix) (the upstream return convention).
@@ -120,6 +120,25 @@ ppasr_status ppasr_ctc_beam_search(const float* probs, const int32_t* frame_lens
                                    double cutoff_prob, int cutoff_top_n, int blank, int nbest, int max_tokens,
                                    int32_t* tokens, int32_t* lens, double* scores, void* state, size_t state_bytes,
                                    int init_state, void* stream);
+
+/* External scorer = `Scorer(alpha, beta, model_path, vocabulary)` of paddlespeech_ctcdecoders (decoders/swig_wrapper.py:18-33,
+ * built by BeamSearchDecoder.__init__, decoders/beam_search_decoder.py:19-29): back-off n-gram model, CHARACTER-based
+ * (every LM word is one UTF-8 character, as PPASR's Mandarin models are); read from the ARPA text format (KenLM .klm
+ * binaries are refused with PPASR_EUNSUPPORTED, as are word-based models, which need the OpenFST dictionary).
+ * vocab_utf8[V]: the acoustic vocabulary (token id -> string), used to map token ids to LM words (unknown -> OOV). */
+typedef struct ppasr_lm_s* ppasr_lm_handle;
+ppasr_status ppasr_lm_create_arpa(const char* arpa_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
+ppasr_status ppasr_lm_destroy(ppasr_lm_handle lm);
+int          ppasr_lm_order(ppasr_lm_handle lm);
+int          ppasr_lm_is_character_based(ppasr_lm_handle lm);
+long long    ppasr_lm_ngram_count(ppasr_lm_handle lm);
+/* ppasr_ctc_beam_search with the scorer: alpha * ln P_lm(c | prefix) + beta on every extension, the min_cutoff pruning
+ * of ctc_beam_search_decoder.cpp, and result scores = -(score - len*beta - alpha*ln P_lm(sentence)) ("approx_ctc").
+ * lm == NULL: identical to ppasr_ctc_beam_search. */
+ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_lens, int B, int T, int V, int beam_size,
+                                      double cutoff_prob, int cutoff_top_n, int blank, int nbest, int max_tokens,
+                                      int32_t* tokens, int32_t* lens, double* scores, void* state, size_t state_bytes,
+                                      int init_state, ppasr_lm_handle lm, double alpha, double beta, void* stream);
 
 /* ---- streaming: ConformerModel.get_encoder_out_chunk (model_utils/conformer/model.py:164-184) =
  * ConformerEncoder.forward_chunk (conformer/encoder.py:208-283) + ctc softmax, as driven by

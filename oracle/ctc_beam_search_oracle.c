@@ -10,8 +10,9 @@
  * (ctc_beam_search_decoder.cpp / path_trie.cpp / decoder_utils.cpp, itself DeepSpeech's decoder):
  * float-valued log probabilities on a prefix trie, per-frame vocabulary pruning
  * (cutoff_prob / cutoff_top_n), top-`beam_size` selection with prefix_compare (score desc, then
- * last character asc), result score = -log P(prefix).  No external scorer (no KenLM file is
- * reachable offline): PPASR's `ext_scoring_func` branch is not restated.
+ * last character asc), result score = -log P(prefix).  The `ext_scorer` branch (scorer.cpp, character-based
+ * back-off n-gram model: min_cutoff pruning, alpha * ln P_lm + beta per extension, approx_ctc result score) is restated
+ * over n-gram arrays handed in by the tests (which parse the ARPA file themselves); KenLM itself is not available.
  *
  * Build: make -C oracle   ->  oracle/_build/libctc_beam_oracle.so   (loaded with ctypes by tests/)
  */
@@ -172,6 +173,63 @@ static int pruned_log_probs(const float* prob, int V, double cutoff_prob, int cu
   return cutoff_len;
 }
 
+/* ---- external scorer (scorer.cpp), character-based ---- */
+#define LM_MAX_ORDER 6
+#define OOV_SCORE (-1000.0)
+static const float NUM_FLT_LOGE = 0.4342944819f;
+typedef struct {
+  int n;                 /* order of this n-gram */
+  int w[LM_MAX_ORDER];   /* LM word ids */
+  float prob, backoff;   /* log10 */
+} NGram;
+static int cmp_ngram(const void* a, const void* b) {
+  const NGram* x = (const NGram*)a;
+  const NGram* y = (const NGram*)b;
+  if (x->n != y->n) return x->n - y->n;
+  for (int i = 0; i < x->n; ++i)
+    if (x->w[i] != y->w[i]) return x->w[i] < y->w[i] ? -1 : 1;
+  return 0;
+}
+typedef struct {
+  int order, n_grams, bos, eos;
+  NGram* grams; /* sorted by (n, words) */
+  int* tok2lm;  /* [V], 0 = OOV */
+  double alpha, beta;
+} Lm;
+static const NGram* lm_find(const Lm* lm, const int* w, int n) {
+  NGram key;
+  key.n = n;
+  for (int i = 0; i < n; ++i) key.w[i] = w[i];
+  return (const NGram*)bsearch(&key, lm->grams, lm->n_grams, sizeof(NGram), cmp_ngram);
+}
+/* Scorer::get_log_cond_prob: ln P(last word | the others), OOV_SCORE if any word of the window is unknown;
+ * ARPA back-off recursion, float accumulation like KenLM, / log10(e) in double */
+static double lm_log_cond_prob(const Lm* lm, const int* win) {
+  for (int i = 0; i < lm->order; ++i)
+    if (win[i] == 0) return OOV_SCORE;
+  float acc = 0.f;
+  for (int n = lm->order; n >= 1; --n) {
+    const NGram* g = lm_find(lm, win + lm->order - n, n);
+    if (g) return (double)(acc + g->prob) / (double)NUM_FLT_LOGE;
+    if (n > 1) {
+      const NGram* c = lm_find(lm, win + lm->order - n, n - 1);
+      if (c) acc += c->backoff;
+    }
+  }
+  return OOV_SCORE;
+}
+/* Scorer::make_ngram for a character-based model: the last `order` characters of the prefix, <s>-padded */
+static void make_ngram(const Lm* lm, const PathTrie* node, int* win) {
+  for (int j = lm->order - 1; j >= 0; --j) {
+    if (node && node->parent) {
+      win[j] = lm->tok2lm[node->character];
+      node = node->parent;
+    } else {
+      win[j] = lm->bos;
+    }
+  }
+}
+
 typedef struct {
   PathTrie* root;
   Vec prefixes;
@@ -180,6 +238,7 @@ typedef struct {
   int* idx;
   float* logp;
   ProbIdx* tmp;
+  Lm* lm;
 } Decoder;
 
 void* ctc_beam_oracle_create(int V, int beam_size, double cutoff_prob, int cutoff_top_n, int blank_id) {
@@ -198,8 +257,37 @@ void* ctc_beam_oracle_create(int V, int beam_size, double cutoff_prob, int cutof
   return d;
 }
 
+/* attach a character-based n-gram model: gram_n[i] words of gram_w[i*6 ..], log10 prob / backoff */
+void ctc_beam_oracle_set_lm(void* h, int order, int n_grams, const int* gram_n, const int* gram_w, const float* prob,
+                            const float* backoff, const int* tok2lm, int bos, int eos, double alpha, double beta) {
+  Decoder* d = (Decoder*)h;
+  Lm* lm = (Lm*)calloc(1, sizeof(Lm));
+  lm->order = order;
+  lm->n_grams = n_grams;
+  lm->bos = bos;
+  lm->eos = eos;
+  lm->alpha = alpha;
+  lm->beta = beta;
+  lm->grams = (NGram*)calloc(n_grams, sizeof(NGram));
+  for (int i = 0; i < n_grams; ++i) {
+    lm->grams[i].n = gram_n[i];
+    for (int j = 0; j < gram_n[i]; ++j) lm->grams[i].w[j] = gram_w[(size_t)i * LM_MAX_ORDER + j];
+    lm->grams[i].prob = prob[i];
+    lm->grams[i].backoff = backoff[i];
+  }
+  qsort(lm->grams, n_grams, sizeof(NGram), cmp_ngram);
+  lm->tok2lm = (int*)malloc(sizeof(int) * d->V);
+  memcpy(lm->tok2lm, tok2lm, sizeof(int) * d->V);
+  d->lm = lm;
+}
+
 void ctc_beam_oracle_free(void* h) {
   Decoder* d = (Decoder*)h;
+  if (d->lm) {
+    free(d->lm->grams);
+    free(d->lm->tok2lm);
+    free(d->lm);
+  }
   trie_free(d->root);
   free(d->prefixes.v);
   free(d->idx);
@@ -213,12 +301,22 @@ void ctc_beam_oracle_next(void* h, const float* probs, int T) {
   Decoder* d = (Decoder*)h;
   for (int t = 0; t < T; ++t) {
     const float* prob = probs + (size_t)t * d->V;
+    float min_cutoff = -NUM_FLT_INF;
+    int full_beam = 0;
+    if (d->lm) {
+      int num_prefixes = d->prefixes.n < d->beam_size ? d->prefixes.n : d->beam_size;
+      qsort(d->prefixes.v, num_prefixes, sizeof(PathTrie*), cmp_prefix);
+      min_cutoff = (float)((double)d->prefixes.v[num_prefixes - 1]->score + log((double)prob[d->blank_id]) -
+                           (d->lm->beta > 0.0 ? d->lm->beta : 0.0));
+      full_beam = (num_prefixes == d->beam_size);
+    }
     int n = pruned_log_probs(prob, d->V, d->cutoff_prob, d->cutoff_top_n, d->idx, d->logp, d->tmp);
     for (int k = 0; k < n; ++k) {
       int c = d->idx[k];
       float log_prob_c = d->logp[k];
       for (int i = 0; i < d->prefixes.n && i < d->beam_size; ++i) {
         PathTrie* prefix = d->prefixes.v[i];
+        if (full_beam && log_prob_c + prefix->score < min_cutoff) break;
         if (c == d->blank_id) {
           prefix->log_prob_b_cur = log_sum_exp(prefix->log_prob_b_cur, log_prob_c + prefix->score);
           continue;
@@ -231,6 +329,13 @@ void ctc_beam_oracle_next(void* h, const float* probs, int T) {
           log_p = log_prob_c + prefix->log_prob_b_prev;
         else if (c != prefix->character)
           log_p = log_prob_c + prefix->score;
+        if (d->lm) { /* character-based scorer: every extension is scored on the NEW prefix */
+          int win[LM_MAX_ORDER];
+          make_ngram(d->lm, pn, win);
+          float score = (float)(lm_log_cond_prob(d->lm, win) * d->lm->alpha);
+          log_p += score;
+          log_p = (float)((double)log_p + d->lm->beta);
+        }
         pn->log_prob_nb_cur = log_sum_exp(pn->log_prob_nb_cur, log_p);
       }
     }
@@ -265,7 +370,28 @@ int ctc_beam_oracle_result(void* h, int nbest, int max_len, int* tokens, int* le
       --j;
       if (j < max_len) row[j] = p->character;
     }
-    scores[i] = -(double)s[i]->score;
+    double approx_ctc = (double)s[i]->score;
+    if (d->lm) {
+      /* approx_ctc -= prefix_length * beta + alpha * get_sent_log_prob(words); sentence = <s>^(order-1) words </s>,
+       * one window per position (scorer.cpp get_sent_log_prob / get_log_prob) */
+      const Lm* lm = d->lm;
+      int total = lm->order - 1 + len + 1;
+      if (len == 0) total = lm->order + 1;
+      int* sent = (int*)malloc(sizeof(int) * total);
+      int pos = 0;
+      for (int q = 0; q < (len == 0 ? lm->order : lm->order - 1); ++q) sent[pos++] = lm->bos;
+      {
+        int jj = pos + len;
+        for (PathTrie* p = s[i]; p->parent; p = p->parent) sent[--jj] = lm->tok2lm[p->character];
+        pos += len;
+      }
+      sent[pos++] = lm->eos;
+      double lp = 0.0;
+      for (int q = 0; q + lm->order <= total; ++q) lp += lm_log_cond_prob(lm, sent + q);
+      free(sent);
+      approx_ctc = approx_ctc - (double)len * lm->beta - lp * lm->alpha;
+    }
+    scores[i] = -approx_ctc;
   }
   free(s);
   return out;

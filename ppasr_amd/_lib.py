@@ -73,6 +73,16 @@ SYMBOLS = [
                                         _vp, _vp, ctypes.c_size_t, _vp]),
     ("ppasr_ctc_collapse", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
                                           _vp]),
+    ("ppasr_lm_create_arpa", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int,
+                                            ctypes.POINTER(_vp)]),
+    ("ppasr_lm_destroy", ctypes.c_int, [_vp]),
+    ("ppasr_lm_order", ctypes.c_int, [_vp]),
+    ("ppasr_lm_is_character_based", ctypes.c_int, [_vp]),
+    ("ppasr_lm_ngram_count", ctypes.c_longlong, [_vp]),
+    ("ppasr_ctc_beam_search_lm", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                _vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_int, _vp, ctypes.c_double,
+                                                ctypes.c_double, _vp]),
     ("ppasr_fbank_create", ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                           ctypes.POINTER(_vp)]),
     ("ppasr_fbank_destroy", ctypes.c_int, [_vp]),

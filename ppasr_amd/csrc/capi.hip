@@ -443,18 +443,33 @@ size_t ppasr_ctc_beam_state_bytes(int B, int max_frames, int beam_size) {
   return (size_t)B * beam_state_bytes(c) + (size_t)B * sizeof(int32_t);
 }
 
+const ppasr::LmDev* ppasr_lm_device_view(ppasr_lm_handle lm);  // lm.hip
+
 ppasr_status ppasr_ctc_beam_search(const float* probs, const int32_t* frame_lens, int B, int T, int V, int beam_size,
                                    double cutoff_prob, int cutoff_top_n, int blank, int nbest, int max_tokens,
                                    int32_t* tokens, int32_t* lens, double* scores, void* state, size_t state_bytes,
                                    int init_state, void* stream) {
+  return ppasr_ctc_beam_search_lm(probs, frame_lens, B, T, V, beam_size, cutoff_prob, cutoff_top_n, blank, nbest, max_tokens,
+                                  tokens, lens, scores, state, state_bytes, init_state, nullptr, 0.0, 0.0, stream);
+}
+
+ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_lens, int B, int T, int V, int beam_size,
+                                      double cutoff_prob, int cutoff_top_n, int blank, int nbest, int max_tokens,
+                                      int32_t* tokens, int32_t* lens, double* scores, void* state, size_t state_bytes,
+                                      int init_state, ppasr_lm_handle lm, double alpha, double beta, void* stream) {
   if (!tokens || !lens || !scores || !state || (!probs && T > 0)) return fail(PPASR_EINVAL, "null argument");
   if (B <= 0 || T < 0) return fail(PPASR_EINVAL, "empty batch");
   BeamConfig c{};
+  if (lm) {  // before beam_config: the LDS budget depends on it
+    c.lm = *ppasr_lm_device_view(lm);
+    c.alpha = alpha;
+    c.beta = beta;
+  }
   ppasr_status s = beam_config(V, beam_size, cutoff_prob, cutoff_top_n, blank, nbest, max_tokens, &c);
   if (s != PPASR_OK) return s;
   // state = B x [header | beam arrays | arena] + B status words; arena capacity from the buffer size
   const size_t per_utt = (state_bytes - (size_t)B * 4) / (size_t)B / 4;  // words
-  const size_t fixed = 2 + (size_t)6 * beam_size;
+  const size_t fixed = 2 + (size_t)kBeamStateArrays * beam_size;
   if (state_bytes < (size_t)B * 4 || per_utt < fixed + 2 * (size_t)(1 + 2 * beam_size))
     return fail(PPASR_ENOSPACE, "beam search: state buffer too small");
   c.max_nodes = (int)((per_utt - fixed) / 2);

@@ -3,10 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lm.h"
+
 namespace ppasr {
 
 constexpr int kMaxBeamCand = 128;  // pruned characters per frame the kernel can hold
 constexpr int kMaxBeam = 512;
+constexpr int kLmCtx = kLmMaxOrder - 1;       // LM context words carried per hypothesis
+constexpr int kBeamStateArrays = 6 + kLmCtx;  // per-hypothesis words persisted between streaming calls
 
 struct BeamConfig {
   int V, beam, blank;
@@ -15,6 +19,9 @@ struct BeamConfig {
   int n_cand_max;  // min(kMaxBeamCand, what the pruning rule can produce)
   int max_nodes;   // arena capacity per utterance
   int nbest, max_tokens;
+  // external scorer (ctc_beam_search_decoder.cpp `ext_scorer`): lm.order == 0 -> none
+  LmDev lm;
+  double alpha, beta;
 };
 
 size_t beam_lds_bytes(const BeamConfig& c);

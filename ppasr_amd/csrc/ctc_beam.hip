@@ -15,8 +15,10 @@
 //     and the same log_sum_exp values as the serial trie walk;
 //   * top-k = exact MSD radix select on unique 64-bit keys (score | char | element id) recomputed on
 //     the fly, then an ordered compaction -- nothing of size beam x candidates is ever stored.
-// No external scorer (KenLM): the LM branch of the reference needs a 2.8 GB model file that is
-// unreachable offline.
+// External scorer (`ext_scorer`, character-based n-gram LM, lm.h): the min_cutoff pruning of (character, prefix) pairs,
+// alpha * log P_lm + beta on every extension, and the approximate-CTC result score with the LM weight removed.  The LM
+// term of every (hypothesis, candidate) pair is computed once per frame into LDS; each hypothesis carries its last
+// order-1 LM word ids, shifted on extension.
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <math.h>
@@ -57,6 +59,7 @@ struct Beam {  // one double-buffer half, all in LDS
   float* b;
   float* nb;
   float* score;
+  int* ctx;  // [cap][kLmCtx] last LM word ids, most recent last, <s>-padded
 };
 
 __device__ __forceinline__ Beam carve_beam(char*& p, int cap) {
@@ -67,6 +70,7 @@ __device__ __forceinline__ Beam carve_beam(char*& p, int cap) {
   b.b = reinterpret_cast<float*>(p); p += cap * 4;
   b.nb = reinterpret_cast<float*>(p); p += cap * 4;
   b.score = reinterpret_cast<float*>(p); p += cap * 4;
+  b.ctx = reinterpret_cast<int*>(p); p += cap * 4 * kLmCtx;
   return b;
 }
 
@@ -134,17 +138,20 @@ size_t beam_lds_bytes(const BeamConfig& c) {
   size_t n = 16 + 256 * 4 + 16 + 16 + 16 + 32 + kMaxBeamCand * 8;  // scalars, histogram, reduction scratch, gather buffers
   n += (size_t)Vp * 4;                             // lp
   n += (size_t)kMaxBeamCand * 8;                   // cand_c, cand_lp
-  n += (size_t)2 * c.beam * 24;                    // two beam halves
+  n += (size_t)2 * c.beam * (24 + 4 * kLmCtx);     // two beam halves
   n += (size_t)c.beam * 12;                        // new_b, new_nb, new_score
   n += (size_t)Vp * 2;                             // kidx (int16)
+  if (c.lm.order > 0) n += (size_t)c.beam * c.n_cand_max * 4;  // LM term of every (hypothesis, candidate) pair
   n += (size_t)c.beam * c.n_cand_max;              // exists flags
   return (n + 15) & ~(size_t)15;
 }
 
 // state layout per utterance in HBM (int32 words):
-//   [0] n_beam  [1] n_nodes  then 6 arrays of `beam` words (node, chr, par, b, nb, score), then the arena
-//   (2 words per node: parent, char).
-__host__ __device__ inline size_t beam_state_words(int beam, int max_nodes) { return 2 + (size_t)6 * beam + (size_t)2 * max_nodes; }
+//   [0] n_beam  [1] n_nodes  then kBeamStateArrays arrays of `beam` words (node, chr, par, b, nb, score, ctx[5]), then the
+//   arena (2 words per node: parent, char).
+__host__ __device__ inline size_t beam_state_words(int beam, int max_nodes) {
+  return 2 + (size_t)kBeamStateArrays * beam + (size_t)2 * max_nodes;
+}
 size_t beam_state_bytes(const BeamConfig& c) { return beam_state_words(c.beam, c.max_nodes) * 4; }
 
 __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ probs, const int32_t* __restrict__ frame_lens,
@@ -175,11 +182,14 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
   float* new_nb = reinterpret_cast<float*>(p); p += beam * 4;
   float* new_score = reinterpret_cast<float*>(p); p += beam * 4;
   int16_t* kidx = reinterpret_cast<int16_t*>(p); p += (size_t)Vp * 2;
+  const bool has_lm = cfg.lm.order > 0;
+  float* lm_sc = reinterpret_cast<float*>(p);  // [nb][C] alpha * log P_lm of child (hypothesis, candidate)
+  if (has_lm) p += (size_t)beam * CM * 4;
   uint8_t* exists = reinterpret_cast<uint8_t*>(p);
 
   int32_t* st = state + (size_t)u * beam_state_words(beam, cfg.max_nodes);
   int32_t* g_arr = st + 2;
-  int32_t* arena = st + 2 + (size_t)6 * beam;
+  int32_t* arena = st + 2 + (size_t)kBeamStateArrays * beam;
   int nb, n_nodes;
   if (init_state) {
     nb = 1;
@@ -187,6 +197,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
     if (tid == 0) {
       cur.node[0] = 0; cur.chr[0] = -1; cur.par[0] = -1;
       cur.b[0] = 0.f; cur.nb[0] = kNegInf; cur.score[0] = 0.f;  // root.score = root.log_prob_b_prev = 0
+      for (int j = 0; j < kLmCtx; ++j) cur.ctx[j] = cfg.lm.bos;  // Scorer::make_ngram pads with START_TOKEN
       arena[0] = -1; arena[1] = -1;
     }
   } else {
@@ -196,6 +207,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       cur.node[i] = g_arr[i]; cur.chr[i] = g_arr[beam + i]; cur.par[i] = g_arr[2 * beam + i];
       cur.b[i] = __int_as_float(g_arr[3 * beam + i]); cur.nb[i] = __int_as_float(g_arr[4 * beam + i]);
       cur.score[i] = __int_as_float(g_arr[5 * beam + i]);
+      for (int j = 0; j < kLmCtx; ++j) cur.ctx[i * kLmCtx + j] = g_arr[(6 + j) * beam + i];
     }
   }
   __syncthreads();
@@ -335,24 +347,65 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
     __syncthreads();
     for (int k = tid; k < C; k += kBT) { lp[cand_c[k]] = cand_lp[k]; kidx[cand_c[k]] = (int16_t)k; }
     __syncthreads();
+    // ---- external scorer: pruning threshold of this frame and the LM term of every possible extension ----
+    // (ctc_beam_search_decoder.cpp: prefixes sorted, min_cutoff = worst score + log(p_blank) - max(0, beta), and the
+    //  `break` on log_prob_c + prefix->score < min_cutoff once the beam is full: it skips the blank, repeat and
+    //  extension updates of that (character, prefix) pair; sorted order makes `break` == "skip every failing pair")
+    float min_cutoff = kNegInf;
+    bool full_beam = false;
+    if (has_lm) {
+      float m = FLT_MAX;
+      for (int q = tid; q < nb; q += kBT) m = fminf(m, cur.score[q]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+      if (lane == 0) red_p[wave] = m;
+      __syncthreads();
+      m = fminf(fminf(red_p[0], red_p[1]), fminf(red_p[2], red_p[3]));
+      min_cutoff = (float)((double)m + log((double)row[blank]) - fmax(0.0, cfg.beta));
+      full_beam = (nb == beam);
+      for (int r = tid; r < nb * C; r += kBT) {
+        const int i = r / C, k = r - i * C;
+        const int c = cand_c[k];
+        float sc = 0.f;
+        if (c != blank) {
+          int32_t win[kLmMaxOrder];
+          const int order = cfg.lm.order;
+          for (int j = 0; j < order - 1; ++j) win[j] = cur.ctx[i * kLmCtx + (kLmCtx - (order - 1)) + j];
+          win[order - 1] = cfg.lm.tok2lm[c];
+          sc = (float)(lm_log_cond_prob(cfg.lm, win) * cfg.alpha);
+        }
+        lm_sc[r] = sc;
+      }
+      __syncthreads();
+    }
+    auto pruned = [&](float lp_c, int q) -> bool { return full_beam && (lp_c + cur.score[q] < min_cutoff); };
+    // log-probability carried by the extension of hypothesis i with candidate k (its LM term included)
+    auto ext_logp = [&](int i, int k) -> float {
+      const int c = cand_c[k];
+      float log_p = kNegInf;
+      if (c == cur.chr[i]) { if (cur.b[i] > kNegInf) log_p = cand_lp[k] + cur.b[i]; }
+      else log_p = cand_lp[k] + cur.score[i];
+      if (has_lm) {
+        log_p += lm_sc[i * C + k];
+        log_p = (float)((double)log_p + cfg.beta);
+      }
+      return log_p;
+    };
     // ---- (d) contributions received by the hypotheses already in the beam ----
     const float lpb = lp[blank];
     for (int q = tid; q < nb; q += kBT) {
       const int cq = cur.chr[q];
-      float bc = (lpb != kNotCand) ? lpb + cur.score[q] : kNegInf;
+      float bc = (lpb != kNotCand && !pruned(lpb, q)) ? lpb + cur.score[q] : kNegInf;
       float nbc = kNegInf;
       const float lq = (cq >= 0) ? lp[cq] : kNotCand;
       if (lq != kNotCand && cq != blank) {
-        nbc = lq + cur.nb[q];  // repeated character
+        if (!pruned(lq, q)) nbc = lq + cur.nb[q];  // repeated character
         const int pn = cur.par[q];
         int pi = -1;
         for (int i = 0; i < nb; ++i)
           if (cur.node[i] == pn) pi = i;
         if (pi >= 0) {  // extension of the parent hypothesis by cq lands on this existing prefix
-          float log_p = kNegInf;
-          if (cq == cur.chr[pi]) { if (cur.b[pi] > kNegInf) log_p = lq + cur.b[pi]; }
-          else log_p = lq + cur.score[pi];
-          nbc = lse(nbc, log_p);
+          if (!pruned(lq, pi)) nbc = lse(nbc, ext_logp(pi, kidx[cq]));
           exists[pi * C + kidx[cq]] = 1;
         }
       }
@@ -367,11 +420,8 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       if (e < nb) { key = make_key(new_score[e], cur.chr[e], e); return true; }
       const int r = e - nb, i = r / C, k = r - i * C;
       const int c = cand_c[k];
-      if (c == blank || exists[r]) return false;
-      float log_p = kNegInf;
-      if (c == cur.chr[i]) { if (cur.b[i] > kNegInf) log_p = cand_lp[k] + cur.b[i]; }
-      else log_p = cand_lp[k] + cur.score[i];
-      key = make_key(log_p, c, e);
+      if (c == blank || exists[r] || pruned(cand_lp[k], i)) return false;
+      key = make_key(ext_logp(i, k), c, e);
       return true;
     };
     int my_valid = 0;
@@ -419,12 +469,13 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
         if (e < nb) {
           nxt.node[pos] = cur.node[e]; nxt.chr[pos] = cur.chr[e]; nxt.par[pos] = cur.par[e];
           nxt.b[pos] = new_b[e]; nxt.nb[pos] = new_nb[e]; nxt.score[pos] = new_score[e];
+          for (int j = 0; j < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[e * kLmCtx + j];
         } else {
           const int r = e - nb, i = r / C, kk = r - i * C;
           const int c = cand_c[kk];
-          float log_p = kNegInf;
-          if (c == cur.chr[i]) { if (cur.b[i] > kNegInf) log_p = cand_lp[kk] + cur.b[i]; }
-          else log_p = cand_lp[kk] + cur.score[i];
+          const float log_p = ext_logp(i, kk);
+          for (int j = 0; j + 1 < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[i * kLmCtx + j + 1];
+          nxt.ctx[pos * kLmCtx + kLmCtx - 1] = has_lm ? cfg.lm.tok2lm[c] : 0;
           const int id = n_nodes + pos;
           if (id < cfg.max_nodes) { arena[2 * (size_t)id] = cur.node[i]; arena[2 * (size_t)id + 1] = c; }
           nxt.node[pos] = id; nxt.chr[pos] = c; nxt.par[pos] = cur.node[i];
@@ -450,6 +501,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
     g_arr[i] = cur.node[i]; g_arr[beam + i] = cur.chr[i]; g_arr[2 * beam + i] = cur.par[i];
     g_arr[3 * beam + i] = __float_as_int(cur.b[i]); g_arr[4 * beam + i] = __float_as_int(cur.nb[i]);
     g_arr[5 * beam + i] = __float_as_int(cur.score[i]);
+    for (int j = 0; j < kLmCtx; ++j) g_arr[(6 + j) * beam + i] = cur.ctx[i * kLmCtx + j];
   }
   if (!finalize) return;
   __threadfence_block();
@@ -471,7 +523,34 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
         if (j < cfg.max_tokens) dst[j] = arena[2 * (size_t)n + 1];
       }
       out_lens[(size_t)u * cfg.nbest + rank] = len;
-      out_scores[(size_t)u * cfg.nbest + rank] = -(double)cur.score[q];
+      double approx_ctc = (double)cur.score[q];
+      if (has_lm) {
+        // approx_ctc = score - prefix_length * beta - alpha * Scorer::get_sent_log_prob(words): the sentence is
+        // <s> x (order-1) + words + </s>, scored window by window (scorer.cpp get_log_prob)
+        const int order = cfg.lm.order;
+        double sent = 0.0;
+        int32_t win[kLmMaxOrder];
+        auto window_of = [&](int node, int last_word) {  // words before `node` (exclusive of last_word's own slot)
+          win[order - 1] = last_word;
+          int n = node;
+          for (int j = order - 2; j >= 0; --j) {
+            if (n > 0) { win[j] = cfg.lm.tok2lm[arena[2 * (size_t)n + 1]]; n = arena[2 * (size_t)n]; }
+            else win[j] = cfg.lm.bos;
+          }
+        };
+        if (len == 0) {
+          for (int j = 0; j < order; ++j) win[j] = cfg.lm.bos;
+          sent += lm_log_cond_prob(cfg.lm, win);
+        }
+        window_of(cur.node[q], cfg.lm.eos);
+        sent += lm_log_cond_prob(cfg.lm, win);
+        for (int n = cur.node[q]; n > 0; n = arena[2 * (size_t)n]) {
+          window_of(arena[2 * (size_t)n], cfg.lm.tok2lm[arena[2 * (size_t)n + 1]]);
+          sent += lm_log_cond_prob(cfg.lm, win);
+        }
+        approx_ctc = approx_ctc - (double)len * cfg.beta - sent * cfg.alpha;
+      }
+      out_scores[(size_t)u * cfg.nbest + rank] = -approx_ctc;
     }
   }
   // ranks >= nb (beam smaller than nbest): mark empty

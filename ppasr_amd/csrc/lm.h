@@ -1,0 +1,75 @@
+// lm.h -- back-off n-gram language model on the device, for the external scorer of the CTC prefix beam search
+// (PaddleSpeech third_party/ctc_decoders scorer.cpp: `Scorer::get_log_cond_prob` walks KenLM's `BaseScore` over the
+// n-gram window; PPASR builds it in decoders/beam_search_decoder.py:28-29 via decoders/swig_wrapper.py:18-33).
+//
+// All n-grams of all orders live in ONE open-addressing hash table keyed by a 64-bit hash of (order, word ids) --
+// the layout KenLM's "probing" model uses, flattened: slot = (key, log10 prob, log10 back-off).  A conditional
+// probability costs at most 2*order - 1 probes; the table is read-only and L2-resident.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ppasr {
+
+constexpr int kLmMaxOrder = 6;
+constexpr double kLmOovScore = -1000.0;              // OOV_SCORE (scorer.h)
+constexpr float kLmLog10E = 0.4342944819f;           // NUM_FLT_LOGE (decoder_utils.h)
+
+struct LmDev {
+  int order;                 // 0 = no language model
+  int bos, eos;              // word index of <s>, </s>
+  uint32_t mask;             // table size - 1 (power of two)
+  const uint64_t* keys;      // 0 = empty slot
+  const float* prob;         // log10 P
+  const float* backoff;      // log10 back-off weight (0 when absent)
+  const int32_t* tok2lm;     // [V] acoustic-vocabulary id -> LM word index, 0 = OOV (<unk>)
+};
+
+__host__ __device__ inline uint64_t lm_mix(uint64_t h, uint64_t v) {
+  h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+  h *= 0xff51afd7ed558ccdull;
+  h ^= h >> 33;
+  return h;
+}
+// hash of the n-gram w[0..n-1] (never 0)
+__host__ __device__ inline uint64_t lm_key(const int32_t* w, int n) {
+  uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)n;
+  for (int i = 0; i < n; ++i) h = lm_mix(h, (uint64_t)(uint32_t)w[i]);
+  return h | 1ull;
+}
+
+__device__ inline bool lm_find(const LmDev& lm, const int32_t* w, int n, float& prob, float& backoff) {
+  const uint64_t key = lm_key(w, n);
+  uint32_t slot = (uint32_t)(key >> 17) & lm.mask;
+  for (;;) {
+    const uint64_t k = lm.keys[slot];
+    if (k == key) {
+      prob = lm.prob[slot];
+      backoff = lm.backoff[slot];
+      return true;
+    }
+    if (k == 0) return false;
+    slot = (slot + 1) & lm.mask;
+  }
+}
+
+// Scorer::get_log_cond_prob(ngram) for an n-gram window of `order` words (oldest first, <s>-padded): natural-log
+// probability of the LAST word given the others, or OOV_SCORE when ANY word of the window is out of vocabulary
+// (scorer.cpp returns OOV_SCORE from inside the loop over the window).  Back-off recursion of ARPA models:
+//   p(w | ctx) = p(ctx w)                      if the n-gram exists
+//              = bo(ctx) * p(w | ctx[1:])      otherwise (bo = 1 when the context is not in the model)
+// KenLM accumulates prob + back-offs in float; the division by log10(e) is done in double (scorer.cpp).
+__device__ inline double lm_log_cond_prob(const LmDev& lm, const int32_t* win /*[order]*/) {
+  const int order = lm.order;
+  for (int i = 0; i < order; ++i)
+    if (win[i] == 0) return kLmOovScore;
+  float acc = 0.f;
+  for (int n = order; n >= 1; --n) {
+    float p, b;
+    if (lm_find(lm, win + order - n, n, p, b)) return (double)(acc + p) / (double)kLmLog10E;
+    if (n > 1 && lm_find(lm, win + order - n, n - 1, p, b)) acc += b;
+  }
+  return kLmOovScore;  // the unigram of an in-vocabulary word always exists; defensive
+}
+
+}  // namespace ppasr

@@ -2,19 +2,60 @@
 ``paddlespeech_ctcdecoders`` wrappers of ``ppasr/decoders/swig_wrapper.py``, backed by the HIP prefix
 beam search (``ppasr_ctc_beam_search`` in include/ppasr_hip.h).
 
-Deviation (documented in DESIGN.md): no external scorer.  The reference always builds a KenLM
-``Scorer`` (beam_search_decoder.py:28-29) from a 2.8 GB model that is unreachable offline; here
-``alpha`` / ``beta`` / ``language_model_path`` are accepted and ignored (a warning is printed once when a
-language model path is given).  Returned scores follow the upstream convention: -log P(prefix).
+External scorer: the reference always builds a KenLM ``Scorer`` (beam_search_decoder.py:28-29).  Here
+``language_model_path`` may point to an ARPA text model of a CHARACTER-based n-gram LM (``Scorer`` below, backed by
+``ppasr_lm_*`` / ``ppasr_ctc_beam_search_lm``); KenLM binaries (.klm) and word-based models raise.  Without a model
+path the search runs without a scorer (alpha / beta unused).  Returned scores follow the upstream convention:
+-log P(prefix), with the LM weight removed when a scorer is used ("approx_ctc").
 """
-import warnings
+import ctypes
+import os
 
 import numpy as np
 import torch
 
 from ppasr_amd import _lib
 
-__all__ = ["BeamSearchDecoder", "ctc_beam_search_decoding", "ctc_beam_search_decoding_batch", "beam_search_ids"]
+__all__ = ["BeamSearchDecoder", "Scorer", "ctc_beam_search_decoding", "ctc_beam_search_decoding_batch",
+           "beam_search_ids"]
+
+
+class Scorer:
+    """swig_wrapper.py:18-33 ``Scorer(alpha, beta, model_path, vocabulary)``: external scorer for the beam search.
+    The n-gram table lives on the device (hash table, csrc/lm.h); ``alpha`` / ``beta`` may be changed afterwards
+    (``reset_params``) like upstream."""
+
+    def __init__(self, alpha, beta, model_path, vocabulary, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.PPASRHipError("no HIP device visible: ppasr_amd has no CPU fallback")
+        if not os.path.exists(model_path):
+            raise Exception(f"language model not found: {model_path}")
+        self.alpha, self.beta = float(alpha), float(beta)
+        self._lib = _lib.load()
+        self._device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        words = (ctypes.c_char_p * len(vocabulary))(*[str(w).encode("utf-8") for w in vocabulary])
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self._device):
+            _lib.check(self._lib.ppasr_lm_create_arpa(str(model_path).encode(), words, len(vocabulary), ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._lib.ppasr_lm_destroy(h)
+            self._h = None
+
+    def reset_params(self, alpha, beta):
+        self.alpha, self.beta = float(alpha), float(beta)
+
+    def get_max_order(self):
+        return int(self._lib.ppasr_lm_order(self._h))
+
+    def is_character_based(self):
+        return bool(self._lib.ppasr_lm_is_character_based(self._h))
+
+    def ngram_count(self):
+        return int(self._lib.ppasr_lm_ngram_count(self._h))
 
 
 def _text(ids, vocabulary):
@@ -34,9 +75,9 @@ class _BeamState:
 
 
 def beam_search_ids(probs, beam_size, cutoff_prob=1.0, cutoff_top_n=40, blank_id=0, frame_lens=None, nbest=1,
-                    state=None, max_frames=None):
+                    state=None, max_frames=None, ext_scorer=None):
     """probs [B,T,V] (numpy or device tensor) -> (tokens [B,nbest,L] i32, lens [B,nbest] i32, scores [B,nbest] f64)
-    device tensors.  ``state`` (a _BeamState) continues a previous call (streaming)."""
+    device tensors.  ``state`` (a _BeamState) continues a previous call (streaming); ``ext_scorer`` is a ``Scorer``."""
     lib = _lib.load()
     if not torch.cuda.is_available():
         raise _lib.PPASRHipError("no HIP device visible: ppasr_amd has no CPU fallback")
@@ -55,11 +96,13 @@ def beam_search_ids(probs, beam_size, cutoff_prob=1.0, cutoff_top_n=40, blank_id
     fl = None if frame_lens is None else torch.as_tensor(frame_lens, dtype=torch.int32).to(dev).contiguous()
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(lib.ppasr_ctc_beam_search(p.data_ptr() if T > 0 else None, None if fl is None else fl.data_ptr(), B,
-                                             T, V, int(beam_size), float(cutoff_prob), int(cutoff_top_n),
-                                             int(blank_id), int(nbest), L, tokens.data_ptr(), lens.data_ptr(),
-                                             scores.data_ptr(), state.buf.data_ptr(), state.bytes,
-                                             1 if state.fresh else 0, stream))
+        _lib.check(lib.ppasr_ctc_beam_search_lm(p.data_ptr() if T > 0 else None, None if fl is None else fl.data_ptr(),
+                                                B, T, V, int(beam_size), float(cutoff_prob), int(cutoff_top_n),
+                                                int(blank_id), int(nbest), L, tokens.data_ptr(), lens.data_ptr(),
+                                                scores.data_ptr(), state.buf.data_ptr(), state.bytes,
+                                                1 if state.fresh else 0, None if ext_scorer is None else ext_scorer._h,
+                                                0.0 if ext_scorer is None else ext_scorer.alpha,
+                                                0.0 if ext_scorer is None else ext_scorer.beta, stream))
     state.fresh = False
     state.frames += T
     return tokens, lens, scores, state
@@ -80,7 +123,7 @@ def ctc_beam_search_decoding(probs_seq, vocabulary, beam_size, cutoff_prob=1.0, 
     """swig_wrapper.py:35-64 -> list of (score, text), best first (all ``beam_size`` hypotheses)."""
     p = probs_seq if isinstance(probs_seq, torch.Tensor) else np.asarray(probs_seq, np.float32)
     tokens, lens, scores, _ = beam_search_ids(torch.as_tensor(p)[None], beam_size, cutoff_prob, cutoff_top_n, blank_id,
-                                              nbest=beam_size)
+                                              nbest=beam_size, ext_scorer=ext_scoring_func)
     return _results(tokens, lens, scores, vocabulary, 0)
 
 
@@ -90,21 +133,19 @@ def ctc_beam_search_decoding_batch(probs_split, vocabulary, beam_size, num_proce
     the reference) is meaningless here: one workgroup per utterance."""
     if isinstance(probs_split, torch.Tensor) and probs_split.dim() == 3:
         tokens, lens, scores, _ = beam_search_ids(probs_split, beam_size, cutoff_prob, cutoff_top_n, blank_id,
-                                                  nbest=beam_size)
+                                                  nbest=beam_size, ext_scorer=ext_scoring_func)
         return [_results(tokens, lens, scores, vocabulary, b) for b in range(probs_split.shape[0])]
     shapes = {tuple(np.shape(p)) for p in probs_split}
     if len(shapes) == 1:  # equal lengths: one launch
         batch = torch.stack([torch.as_tensor(p, dtype=torch.float32) for p in probs_split])
         return ctc_beam_search_decoding_batch(batch.cuda(), vocabulary, beam_size, num_processes, cutoff_prob,
-                                              cutoff_top_n, blank_id)
-    return [ctc_beam_search_decoding(p, vocabulary, beam_size, cutoff_prob, cutoff_top_n, blank_id)
+                                              cutoff_top_n, blank_id, ext_scoring_func)
+    return [ctc_beam_search_decoding(p, vocabulary, beam_size, cutoff_prob, cutoff_top_n, blank_id, ext_scoring_func)
             for p in probs_split]
 
 
 class BeamSearchDecoder:
     """beam_search_decoder.py:8-96 (same constructor arguments / methods)."""
-
-    _warned = False
 
     def __init__(self, alpha, beta, beam_size, cutoff_prob, cutoff_top_n, vocab_list, num_processes=10, blank_id=0,
                  language_model_path=None, max_stream_frames=5000):
@@ -114,11 +155,8 @@ class BeamSearchDecoder:
         self.vocab_list = vocab_list
         self.num_processes = num_processes
         self.blank_id = blank_id
-        self._ext_scorer = None
-        if language_model_path and not BeamSearchDecoder._warned:
-            warnings.warn("ppasr_amd BeamSearchDecoder runs WITHOUT the KenLM scorer (alpha/beta ignored): "
-                          "the language-model branch is not built (DESIGN.md §7)")
-            BeamSearchDecoder._warned = True
+        # beam_search_decoder.py:19-29 downloads a default model when the path does not exist; offline that is an error
+        self._ext_scorer = Scorer(alpha, beta, language_model_path, vocab_list) if language_model_path else None
         self._max_stream_frames = int(max_stream_frames)
         self._state = None
 
@@ -126,13 +164,13 @@ class BeamSearchDecoder:
         """-> (score, text) of the best hypothesis.  beam_search_decoder.py:45-56"""
         p = probs_split if isinstance(probs_split, torch.Tensor) else np.asarray(probs_split, np.float32)
         tokens, lens, scores, _ = beam_search_ids(torch.as_tensor(p)[None], self.beam_size, self.cutoff_prob,
-                                                  self.cutoff_top_n, self.blank_id, nbest=1)
+                                                  self.cutoff_top_n, self.blank_id, nbest=1, ext_scorer=self._ext_scorer)
         return _results(tokens, lens, scores, self.vocab_list, 0)[0]
 
     def decode_batch_beam_search_offline(self, probs_split):
         """-> list[str].  beam_search_decoder.py:59-73 (every row of every table is decoded)."""
         res = ctc_beam_search_decoding_batch(probs_split, self.vocab_list, self.beam_size, self.num_processes,
-                                             self.cutoff_prob, self.cutoff_top_n, self.blank_id)
+                                             self.cutoff_prob, self.cutoff_top_n, self.blank_id, self._ext_scorer)
         return [r[0][1] for r in res]
 
     def decode_chunk(self, probs, logits_lens):
@@ -146,7 +184,7 @@ class BeamSearchDecoder:
             self._state = _BeamState(p.shape[0], self._max_stream_frames, self.beam_size, dev)
         lens = np.asarray(logits_lens).astype(np.int32)
         tokens, ln, scores, _ = beam_search_ids(p, self.beam_size, self.cutoff_prob, self.cutoff_top_n, self.blank_id,
-                                                frame_lens=lens, nbest=1, state=self._state)
+                                                frame_lens=lens, nbest=1, state=self._state, ext_scorer=self._ext_scorer)
         return _results(tokens, ln, scores, self.vocab_list, 0)[0]
 
     def reset_decoder(self):
