@@ -98,10 +98,17 @@ class ConformerModel:
         return int(self.lib.ppasr_out_frames(self._h, int(T)))
 
     def _workspace(self, B, T):
+        """One workspace per HIP stream: encodes issued on different streams (length buckets that do not fill the
+        chip on their own) may overlap; the handle itself is read-only during an encode."""
         need = int(self.lib.ppasr_workspace_bytes(self._h, B, T))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        if not isinstance(self._ws, dict):
+            self._ws = {}
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
 
     def _prep(self, speech, speech_lengths):
         speech = torch.as_tensor(speech, dtype=torch.float32).to(self.device).contiguous()
