@@ -43,6 +43,7 @@ def conformer_flops_per_utt(T, F=80, d=256, ff=2048, L=12, k=15, V=4233):
         "k_ffn_qkv": s1,
         "k_attention": 6 * tp * tp * d,
         "k_out_glu": (2 * d * d + 4 * d * d) * tp,
+        "k_attn_out_glu": 6 * tp * tp * d + (2 * d * d + 4 * d * d) * tp,  # attention + out-projection/GLU in one launch
         "k_conv_ffn": s4,
         "k_conv_ffn+ffn_qkv": s4 + s1,  # layer i's tail fused with layer i+1's head
         "k_ctc_head": 2 * d * V * tp,

@@ -179,7 +179,7 @@ ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, const int64_t*
  * of the next ppasr_encode is bracketed by a HIP event pair on the caller's stream; ppasr_profile_read
  * synchronises those events and returns, per kernel class, the summed duration (ms) and launch count
  * into HOST arrays of PPASR_N_KERNEL_CLASSES entries. */
-#define PPASR_N_KERNEL_CLASSES 9
+#define PPASR_N_KERNEL_CLASSES 10
 ppasr_status ppasr_profile_enable(ppasr_handle h, int enable);
 ppasr_status ppasr_profile_read(ppasr_handle h, float* total_ms_host, int* launches_host);
 const char* ppasr_kernel_class_name(int cls);

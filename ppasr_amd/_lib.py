@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libppasr_hip.so")
+LIB_PATH = os.environ.get("PPASR_HIP_LIB") or os.path.join(_HERE, "libppasr_hip.so")  # override: kernel experiments
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
@@ -19,7 +19,7 @@ PPASR_MODEL_CONFORMER = 0
 PPASR_MODEL_EFFICIENT_CONFORMER = 1
 PPASR_MODEL_SQUEEZEFORMER = 2
 PPASR_MODEL_DEEPSPEECH2 = 3
-N_KERNEL_CLASSES = 9
+N_KERNEL_CLASSES = 10
 
 
 class WeightBlob(ctypes.Structure):

@@ -373,14 +373,19 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     s1_done = false;
     tap(xb, (size_t)Mi * kD);
     tap(qkv, (size_t)Mi * 3 * kD);
-    timed(4, [&] {
-      const int Tt = (Ti + grp - 1) / grp;  // tokens: frames, or zero-padded groups of 3 (pad4group)
-      AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Tt, Tt, 0, lens, ctx, L.pos_u, L.pos_v, L.ptab, pstride,
-                 mul * grp, Ti, Ti, grp};
-      launch_attention(a, B, h->desc.attention_heads, st);
-    });
-    tap(ctx, (size_t)Mi * kD);
-    timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, L, lens, Mi, Ti, mul, st); });
+    const int Tt = (Ti + grp - 1) / grp;  // tokens: frames, or zero-padded groups of 3 (pad4group)
+    AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Tt, Tt, 0, lens, ctx, L.pos_u, L.pos_v, L.ptab, pstride,
+               mul * grp, Ti, Ti, grp};
+    // plain 4 x 64 heads: attention and the out-projection / GLU stage run as one launch (context rows stay in LDS);
+    // the debug taps need the context tensor, so they take the two-kernel route
+    const bool fuse_attn = (grp == 1) && (h->desc.attention_heads == 4) && !h->taps;
+    if (fuse_attn) {
+      timed(9, [&] { launch_attn_out_glu(a, B, xb, xc, g, L, st); });
+    } else {
+      timed(4, [&] { launch_attention(a, B, h->desc.attention_heads, st); });
+      tap(ctx, (size_t)Mi * kD);
+      timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, L, lens, Mi, Ti, mul, st); });
+    }
     tap(xc, (size_t)Mi * kD);
     tap(g, (size_t)Mi * kD);
     if (eff && i == h->desc.stride_layer_idx) {
@@ -483,7 +488,7 @@ ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_l
 
 static const char* kKernelClassNames[PPASR_N_KERNEL_CLASSES] = {
     "k_conv1", "k_gemm_stream<conv2>", "k_gemm_stream<embed>", "k_ffn_qkv", "k_attention", "k_out_glu", "k_conv_ffn",
-    "k_ctc_head", "k_conv_ffn+ffn_qkv"};
+    "k_ctc_head", "k_conv_ffn+ffn_qkv", "k_attn_out_glu"};
 
 ppasr_status ppasr_profile_enable(ppasr_handle h, int enable) {
   if (!h) return fail(PPASR_EINVAL, "null handle");

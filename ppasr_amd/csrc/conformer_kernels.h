@@ -80,6 +80,8 @@ void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float
 void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int B,
                             int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out, hipStream_t st);
 // streaming helpers
+// fused S2+S3 for the batched plain-head path (4 heads x 64): attention + out-projection + LN_conv + pw1 + GLU
+void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, float* g, const LayerW& w, hipStream_t st);
 void launch_pw1_glu(const float* xhat, float* g, const LayerW& w, int M, hipStream_t st);
 void launch_kv_append(const float* qkv, float* kc, float* vc, int n_rows, hipStream_t st);
 void launch_hist_update(float* hist, const float* fresh, int n, int lo, hipStream_t st);

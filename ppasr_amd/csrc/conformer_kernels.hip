@@ -599,6 +599,303 @@ void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, floa
                      lens, M, Tp, mask_mul);
 }
 
+// -------------------------------------------------------------------------------------
+// S2 + S3 in one launch (batched path, plain 64-wide heads): relative-position attention of a 32-query block for
+// ALL heads with the context rows kept in LDS, then k_out_glu's tail (out-projection -> +residual -> LN_conv -> mask
+// -> pointwise_conv1 -> GLU) on them.  Saves the context round trip through HBM, one launch and one pipeline
+// fill per layer, and gives every CU one workgroup (B x ceil(T'/32) = 256 for 32 x 249 frames).
+// Block = (query block, utterance), 8 waves = 2 head groups x 4 waves; two rounds cover the 4 heads.  A head group
+// walks the phases  S = Q'K'^T (wave w: keys [32w,32w+32) and +128 of a 256-key block, K' fragments straight from
+// L2)  ->  online softmax (16-lane groups own a row)  ->  PV (wave = (column tile, 128-key half))  per key block.
+// The two groups run the SAME phase sequence skewed by one phase: every SIMD hosts one wave of each group, so the
+// MFMA phases of one group overlap the softmax (VALU / LDS) and the operand latencies of the other.  One workgroup
+// barrier separates consecutive steps.
+// -------------------------------------------------------------------------------------
+constexpr int kFQld = 132;   // Q' row stride: [q+u | q+v] (128) + 4
+constexpr int kFSld = 257;   // score row stride (256-key block + 1)
+constexpr int kFScr = 2 * 32 * 33;  // key-half combine scratch per head group
+constexpr int kFusedAttnFloats = 2 * 32 * kFQld + 2 * 32 * kFSld + 2 * kFScr + 2 * 2 * 32 * 3 + kRows * kLda;
+static_assert(2 * kRows * kLda <= 2 * 32 * kFQld + 2 * 32 * kFSld, "bufX/bufA alias the attention scratch");
+static_assert(kFusedAttnFloats * 4 <= 160 * 1024, "LDS budget");
+#ifndef PPASR_ABL
+#define PPASR_ABL 0
+#endif
+__global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const float* __restrict__ x1, float* __restrict__ x2,
+                                                           float* __restrict__ g, LayerW w) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;                         // [2 groups][32][132]
+  float* Ss = Qs + 2 * 32 * kFQld;          // [2 groups][32][257]
+  float* Scr = Ss + 2 * 32 * kFSld;         // [2 groups][2 column tiles][32][33]
+  float* St = Scr + 2 * kFScr;              // [2 rounds][2 groups][3][32]: running max, running sum, rescale factor
+  float* bufC = St + 2 * 2 * 32 * 3;        // [32][260] context rows, all heads
+  float* bufX = smem;                       // out phase (aliases Qs / Ss)
+  float* bufA = bufX + kRows * kLda;
+  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  const int hg = wave >> 2, w4 = wave & 3, gt = tid & 255;  // head group, wave / thread inside the group
+  const int q0 = blockIdx.x * 32, b = blockIdx.y;
+  const int T = a.T1, T2 = a.T2;
+  const int valid = min(32, T - q0);
+  const float* __restrict__ qb = a.q + (size_t)b * T * a.q_stride;
+  const float* __restrict__ kbp = a.k + (size_t)b * T2 * a.k_stride;
+  const float* __restrict__ vbp = a.v + (size_t)b * T2 * a.v_stride;
+  const float* __restrict__ ptab = a.ptab + (size_t)a.pos0 * kD;
+  const int pstride = a.pos_stride;
+  const int64_t len_b = a.lens ? a.lens[b] : (int64_t)a.mask_mul * T2;
+  float* Qh = Qs + hg * 32 * kFQld;
+  float* Sh = Ss + hg * 32 * kFSld;
+  float* scratch = Scr + hg * kFScr;
+  BRing<1> ring;
+  const f32x4* seg_o = w.wo + (size_t)wave * kTs256;
+  const f32x4* seg_val = w.pw1 + (size_t)wave * kTs256;
+  const f32x4* seg_gate = w.pw1 + (size_t)(8 + wave) * kTs256;
+  const int nkb = (T2 + 255) / 256;
+  constexpr int NG = 16, PF = 4, PFV = 16;
+  const int ctg = w4 & 1, kh = w4 >> 1;
+  f32x16 acc_o;
+
+  auto load_q = [&](int rd) {  // Q' = [q+u | q+v] of head 2*rd + hg: 32 rows x 16 float4 over the group's 256 threads
+    const int head = 2 * rd + hg;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = gt + 256 * i;
+      const int row = idx >> 4, f4 = idx & 15;
+      f32x4 q = {0.f, 0.f, 0.f, 0.f};
+      if (row < valid) q = *reinterpret_cast<const f32x4*>(qb + (size_t)(q0 + row) * a.q_stride + head * 64 + f4 * 4);
+      const f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + head * 64 + f4 * 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + head * 64 + f4 * 4);
+      *reinterpret_cast<f32x4*>(Qh + row * kFQld + f4 * 4) = q + u;
+      *reinterpret_cast<f32x4*>(Qh + row * kFQld + 64 + f4 * 4) = q + v;
+    }
+  };
+  auto stat = [&](int rd, int which) -> float* { return St + ((rd * 2 + hg) * 3 + which) * 32; };
+
+  auto phase_s = [&](int rd, int kb) {
+    const int h = 2 * rd + hg;
+    const int key0 = kb * 256;
+    auto kfrag = [&](int j, int gk) -> f32x4 {
+      const int jc = min(j, T2 - 1);  // keys >= T2 are masked afterwards
+      const float* base = (gk < 8) ? kbp + (size_t)jc * a.k_stride + h * 64 + 8 * gk + 4 * (lane >> 5)
+                                   : ptab + (size_t)jc * pstride * kD + h * 64 + 8 * (gk - 8) + 4 * (lane >> 5);
+      return *reinterpret_cast<const f32x4*>(base);
+    };
+    const int jk0 = key0 + w4 * 32 + (lane & 31), jk1 = jk0 + 128;
+    f32x4 ringk[PF][2];
+#pragma unroll
+    for (int sx = 0; sx < PF; ++sx) {
+      ringk[sx][0] = kfrag(jk0, sx);
+      ringk[sx][1] = kfrag(jk1, sx);
+    }
+    f32x16 acc_s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_s[t][r] = 0.f;
+    const float* a_ptr = Qh + (lane & 31) * kFQld + 4 * (lane >> 5);
+#pragma unroll
+    for (int gk = 0; gk < NG; ++gk) {
+      const f32x4 b0 = ringk[gk % PF][0], b1 = ringk[gk % PF][1];
+      if (gk + PF < NG) {
+        ringk[gk % PF][0] = kfrag(jk0, gk + PF);
+        ringk[gk % PF][1] = kfrag(jk1, gk + PF);
+      }
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(a_ptr + 8 * gk);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc_s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc_s[0], 0, 0, 0);
+        acc_s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc_s[1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int kl = t * 128 + w4 * 32 + (lane & 31);
+      const int key = key0 + kl;
+      const bool masked = (key >= T2) || (a.mask_mul * (int64_t)key >= len_b);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Sh[acc_row(r, lane) * kFSld + kl] = masked ? -INFINITY : acc_s[t][r] * 0.125f;
+    }
+  };
+
+  auto phase_softmax = [&](int rd) {  // 16-lane group = one row (16 keys per lane); 8 rows per wave
+    const int grp = lane >> 4, gl = lane & 15;
+    float* stM = stat(rd, 0);
+    float* stL = stat(rd, 1);
+    float* stA = stat(rd, 2);
+#pragma unroll 1
+    for (int it = 0; it < 2; ++it) {
+      const int row = w4 * 8 + it * 4 + grp;
+      float* srow = Sh + row * kFSld + gl;
+      float v[16];
+      float bm = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        v[e] = srow[16 * e];
+        bm = fmaxf(bm, v[e]);
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o));
+      const float m_old = stM[row];
+      const float m_new = fmaxf(m_old, bm);
+      float alpha = 1.f, ps = 0.f;
+      if (m_new != -INFINITY) {
+        alpha = __expf(m_old - m_new);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          v[e] = __expf(v[e] - m_new);
+          ps += v[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = 0.f;
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) ps += __shfl_xor(ps, o);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) srow[16 * e] = v[e];
+      if (gl == 0) {
+        stM[row] = m_new;
+        stL[row] = stL[row] * alpha + ps;
+        stA[row] = alpha;
+      }
+    }
+  };
+
+  auto phase_pv = [&](int rd, int kb) {  // O = O*alpha + P V : wave -> (column tile ctg, 128-key half kh)
+    const int h = 2 * rd + hg;
+    const int kbase = kb * 256 + kh * 128 + (lane >> 5);
+    const float* vcol = vbp + h * 64 + ctg * 32 + (lane & 31);
+    auto vval = [&](int j) -> float { return vcol[(size_t)min(j, T2 - 1) * a.v_stride]; };  // P is 0 for keys >= T2
+    float ringv[PFV];
+#pragma unroll
+    for (int sx = 0; sx < PFV; ++sx) ringv[sx] = vval(kbase + 2 * sx);
+    const float* stA = stat(rd, 2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[r] *= stA[acc_row(r, lane)];
+    const float* a_ptr = Sh + (lane & 31) * kFSld + kh * 128 + (lane >> 5);
+#pragma unroll
+    for (int sx = 0; sx < 64; ++sx) {
+      const float bv = ringv[sx % PFV];
+      if (sx + PFV < 64) ringv[sx % PFV] = vval(kbase + 2 * (sx + PFV));
+      acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[2 * sx], bv, acc_o, 0, 0, 0);
+      if ((sx & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  auto combine_write = [&]() {
+    if (kh == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scratch[(ctg * 32 + acc_row(r, lane)) * 33 + (lane & 31)] = acc_o[r];
+    }
+  };
+  auto combine_read = [&](int rd) {  // sum the key halves, normalise, context -> bufC[row][h*64 + ...]
+    if (kh == 0) {
+      const int h = 2 * rd + hg;
+      const float* stL = stat(rd, 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lane);
+        const float l = stL[row];
+        float o = acc_o[r] + scratch[(ctg * 32 + row) * 33 + (lane & 31)];
+        o = (l > 0.f) ? o / l : 0.f;  // fully masked row -> 0 (attention.py:118)
+        bufC[row * kLda + h * 64 + ctg * 32 + (lane & 31)] = (row < valid) ? o : 0.f;
+      }
+    }
+  };
+
+  // ---- skewed phase schedule ----
+  if (tid < 128) {  // [rd][hg] x 32 rows: max = -inf, sum = 0
+    const int blk = tid >> 5, row = tid & 31;
+    St[(blk * 3 + 0) * 32 + row] = -INFINITY;
+    St[(blk * 3 + 1) * 32 + row] = 0.f;
+  }
+  load_q(0);
+  __syncthreads();
+  const int per_round = 3 * nkb;
+  const int P = 2 * per_round + 1;  // phases of one group: (S, softmax, PV) x key blocks x 2 rounds, final combine
+#if PPASR_ABL == 6
+  for (int s = P + 1; s < P + 1; ++s) {
+#else
+  for (int s = 0; s < P + 1; ++s) {
+#endif
+    const int p = s - hg;
+    if (p >= 0 && p < P) {
+      if (p == P - 1) {
+        combine_read(1);
+      } else {
+        const int rd = p / per_round, q = p - rd * per_round;
+        const int kb = q / 3, ph = q - 3 * kb;
+        if (ph == 0) {
+          if (kb == 0) {
+            if (rd == 1) combine_read(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[r] = 0.f;
+          }
+          phase_s(rd, kb);
+        } else if (ph == 1) {
+          phase_softmax(rd);
+          if (rd == 0 && kb == nkb - 1) load_q(1);  // this round's last S is done: Q' of the next head may land
+        } else {
+          phase_pv(rd, kb);
+          if (kb == nkb - 1) combine_write();
+        }
+      }
+    }
+    if (s == P - 1) ring_prime(ring, seg_o, 0);  // out-projection weights in flight during the last step
+    __syncthreads();
+  }
+#if PPASR_ABL == 6
+  ring_prime(ring, seg_o, 0);
+#endif
+  // ---- k_out_glu tail on the LDS-resident context ----
+  const int r0 = b * T + q0;
+  const int M = gridDim.y * T;
+  const int col = wave * 32 + (lane & 31);
+  {
+    float res[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, lane);
+      res[r] = (row < valid) ? x1[(size_t)(r0 + row) * kD + col] : 0.f;
+    }
+    f32x16 acc[1][1];
+    acc_zero(acc);
+    rb_gemm<1, 1, kG256>(bufC, kLda, seg_o, 0, seg_val, 0, ring, acc);
+    const float bv = w.bo[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, lane);
+      float v = 0.f;
+      if (row < valid) {
+        v = res[r] + (acc[0][0][r] + bv);
+        x2[(size_t)(r0 + row) * kD + col] = v;
+      }
+      bufX[row * kLda + col] = v;
+    }
+  }
+  __syncthreads();
+  rb_layernorm<false>(bufX, bufA, kLda, kRows, w.ln_conv_g, w.ln_conv_b, 1e-5f, PadRows{a.lens, r0, T, M, a.mask_mul});
+  __syncthreads();
+  {
+    f32x16 av[1][1], ag[1][1];
+    acc_zero(av);
+    acc_zero(ag);
+    rb_gemm<1, 1, kG256>(bufA, kLda, seg_val, 0, seg_gate, 0, ring, av);
+    rb_gemm<1, 1, kG256>(bufA, kLda, seg_gate, 0, nullptr, 0, ring, ag);
+    const float bval = w.pw1_b[col];
+    const float bgate = w.pw1_b[kD + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, lane);
+      if (row < valid) g[(size_t)(r0 + row) * kD + col] = (av[0][0][r] + bval) * sigmoidf(ag[0][0][r] + bgate);
+    }
+  }
+}
+constexpr size_t kLdsAttnOutGlu = (size_t)kFusedAttnFloats * sizeof(float);
+// a: plain-head batched attention arguments (group == 1, T1 == T2 frames, keys/values in the layer's own buffers)
+void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, float* g, const LayerW& w, hipStream_t st) {
+  hipLaunchKernelGGL(k_attn_out_glu, dim3((a.T1 + 31) / 32, B), dim3(kThreads), kLdsAttnOutGlu, st, a, x1, x2, g, w);
+}
+
 // streaming: g_hist = GLU(pointwise_conv1(cnn_cache rows))  -- the reference re-applies pointwise_conv1+GLU
 // to the cached frames on every chunk (convolution.py:113,125-126); here once per chunk on <= 32 rows.
 __global__ __launch_bounds__(kThreads) void k_pw1_glu(const float* __restrict__ xhat, float* __restrict__ g, LayerW w, int M) {
@@ -1145,6 +1442,7 @@ hipError_t configure_kernels() {
   SET_LDS((k_conv_ffn<31, true, false>), kLdsConvFfn);
   SET_LDS((k_conv_ffn<7, true, false>), kLdsConvFfn);
   SET_LDS(k_pw1_glu, kLdsPw1Glu);
+  SET_LDS(k_attn_out_glu, kLdsAttnOutGlu);
   SET_LDS(k_conv_ffn_stride<15>, kLdsConvFfn);
   SET_LDS(k_conv_ffn_stride<7>, kLdsConvFfn);
   SET_LDS(k_ctc_head<true>, kLdsCtc);

@@ -101,3 +101,29 @@ def test_fused_greedy_tokens_match_oracle(trim):
         assert (tokens[b, int(n_tokens[b]):] == -1).all()
         ref_score = float(np.mean(max_prob.astype(np.float64))) * 100.0 if len(max_prob) else 0.0
         assert abs(float(score[b]) - ref_score) <= 1e-3 * max(1.0, abs(ref_score)), (float(score[b]), ref_score)
+
+
+@pytest.mark.parametrize("B,T,lens", [(3, 331, [331, 250, 90]), (2, 1000, [1000, 640]), (1, 135, [135]),
+                                     (2, 2300, [2300, 1100])])  # T' = 574: three 256-key blocks, online softmax
+def test_fused_attention_route_equals_two_kernel_route(B, T, lens):
+    """Without debug taps the batched path runs attention + out-projection/GLU as ONE launch (k_attn_out_glu); with taps
+    set it runs k_attention + k_out_glu.  Both must give the same logits (same arithmetic, different blocking) and match
+    the oracle."""
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    from ppasr_amd.utils.synth import conformer_state_dict, synth_features
+    from oracle.conformer_oracle import ConformerOracle
+    L, V = 3, 260
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=77, perturb_norm=True)
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
+    x, lens = synth_features(B, T, lens=lens, seed=78)
+    m = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    _, fused = m.get_encoder_out(x, lens, return_logits=True)
+    m.set_debug_taps(1 << 16)  # any tap buffer switches to the two-kernel route
+    _, split = m.get_encoder_out(x, lens, return_logits=True)
+    m.set_debug_taps(0)
+    torch.cuda.synchronize()
+    ref = ConformerOracle(sd, num_blocks=L).get_encoder_out(x, lens, return_logits=True)[1].numpy()
+    f, s = fused.cpu().numpy(), split.cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(f - s).max() / scale < 1e-5
+    assert np.abs(f - ref).max() / scale < 1e-3
