@@ -202,7 +202,7 @@ void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, fl
 // `ring` must already stream w.ffm_w1 (tile `wave`).
 __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bufH, float* __restrict__ x1,
                                              float* __restrict__ qkv, const LayerW& w, int r0, int valid, int n_chunks,
-                                             BRing<1>& ring) {
+                                             BRing<1>& ring, const KPack& kp) {
   const int lane = lane_id(), wave = wave_id();
   rb_layernorm(bufX, bufA, kLda, kRows, w.ln_mac_g, w.ln_mac_b, 1e-5f);
   __syncthreads();
@@ -228,11 +228,24 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
       int row = acc_row(r, lane);
       if (row < valid) qkv[(size_t)(r0 + row) * 768 + col] = acc[0][0][r] + bv;
     }
+    if (c == 1 && kp.p) {  // keys once more, in fragment order (KPack)
+      const int f = wave * 32 + (lane & 31);  // key feature 0..255
+      const int h = f >> 6, fi = f & 63;
+      const int sub = ((fi >> 3) << 8) + (((fi >> 2) & 1) << 7) + (fi & 3);  // gk*256 + lane_half*32*4 + j
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lane);
+        if (row < valid) {
+          const int m = r0 + row, b = m / kp.T, t = m - b * kp.T;
+          kp.p[((((size_t)(b * 4 + h) * kp.nt + (t >> 5)) * 8) << 8) + sub + ((t & 31) << 2)] = acc[0][0][r] + bv;
+        }
+      }
+    }
   }
 }
 
 __global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ x_in, float* __restrict__ x1,
-                                                      float* __restrict__ qkv, LayerW w, int M, int n_chunks) {
+                                                      float* __restrict__ qkv, LayerW w, int M, int n_chunks, KPack kp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
@@ -243,12 +256,28 @@ __global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ 
   BRing<1> ring;
   ring_prime(ring, w.ffm_w1 + (size_t)wave * kTs256, 0);
   rb_load_rows(bufX, kLda, x_in + (size_t)r0 * kD, kRows, valid);
-  ffn_qkv_body(bufX, bufA, bufH, x1, qkv, w, r0, valid, n_chunks, ring);
+  ffn_qkv_body(bufX, bufA, bufH, x1, qkv, w, r0, valid, n_chunks, ring, kp);
 }
 constexpr size_t kLdsFfnQkv = 4 * kRows * kLda * sizeof(float);
-void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st) {
+void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
+                    KPack kp) {
   hipLaunchKernelGGL(k_ffn_qkv, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsFfnQkv, st, x_in, x1, qkv, w, M,
-                     n_chunks);
+                     n_chunks, kp);
+}
+
+// ptab [max_len][256] -> fragment order [h][position tile][gk][lane][4] (positions >= max_len read 0)
+__global__ void k_pack_ptab(const float* __restrict__ ptab, float* __restrict__ pp, int max_len, int npt) {
+  const int pt = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;  // 256 threads: (gk, lane half, j) x ... 
+  for (int e = tid; e < 8 * 256; e += 256) {
+    const int gk = e >> 8, lane = (e >> 2) & 63, j = e & 3;
+    const int pos = pt * 32 + (lane & 31);
+    const int feat = h * 64 + 8 * gk + 4 * (lane >> 5) + j;
+    pp[(((size_t)h * npt + pt) * 8 << 8) + e] = pos < max_len ? ptab[(size_t)pos * kD + feat] : 0.f;
+  }
+}
+void launch_pack_ptab(const float* ptab, float* ptab_pack, int max_len, hipStream_t st) {
+  const int npt = (max_len + 31) / 32;
+  hipLaunchKernelGGL(k_pack_ptab, dim3(npt, 4), dim3(256), 0, st, ptab, ptab_pack, max_len, npt);
 }
 
 // -------------------------------------------------------------------------------------
@@ -612,14 +641,14 @@ void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, floa
 // barrier separates consecutive steps.
 // -------------------------------------------------------------------------------------
 constexpr int kFQld = 132;   // Q' row stride: [q+u | q+v] (128) + 4
-constexpr int kFSld = 257;   // score row stride (256-key block + 1)
+constexpr int kFSld = 260;   // score row stride: 256-key block + 4 (float4-aligned, conflict-free for the PV operand reads)
 constexpr int kFScr = 2 * 32 * 33;  // key-half combine scratch per head group
 constexpr int kFusedAttnFloats = 2 * 32 * kFQld + 2 * 32 * kFSld + 2 * kFScr + 2 * 2 * 32 * 3 + kRows * kLda;
 static_assert(2 * kRows * kLda <= 2 * 32 * kFQld + 2 * 32 * kFSld, "bufX/bufA alias the attention scratch");
 static_assert(kFusedAttnFloats * 4 <= 160 * 1024, "LDS budget");
-#ifndef PPASR_ABL
-#define PPASR_ABL 0
-#endif
+// PACKED: keys and positional rows come from the fragment-ordered copies (KPack / ptab_pack): one fully coalesced 1 KiB
+// load per fragment instead of 64 lanes x 16 B out of 32 different cache lines.
+template <bool PACKED>
 __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const float* __restrict__ x1, float* __restrict__ x2,
                                                            float* __restrict__ g, LayerW w) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -649,7 +678,7 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
   const f32x4* seg_val = w.pw1 + (size_t)wave * kTs256;
   const f32x4* seg_gate = w.pw1 + (size_t)(8 + wave) * kTs256;
   const int nkb = (T2 + 255) / 256;
-  constexpr int NG = 16, PF = 4, PFV = 16;
+  constexpr int NG = 16, PF = 4;  // k-groups of the score contraction, K' fragment pairs in flight
   const int ctg = w4 & 1, kh = w4 >> 1;
   f32x16 acc_o;
 
@@ -669,41 +698,61 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
   };
   auto stat = [&](int rd, int which) -> float* { return St + ((rd * 2 + hg) * 3 + which) * 32; };
 
+  // K' fragment of k-group gk for key j of head h: features 8gk + 4*(lane>>5) .. +3; first 8 groups from k, the rest from p
+  auto kfrag = [&](int h, int j, int gk) -> f32x4 {
+    if (PACKED) {
+      const int kt = j >> 5;  // the wave's 32-key tile (uniform); tiles past the utterance are masked afterwards
+      const float* base = (gk < 8)
+          ? a.kpack + (((((size_t)(b * 4 + h) * a.nt + min(kt, a.nt - 1)) * 8 + gk) << 8) + 4 * lane)
+          : a.ptab_pack + (((((size_t)h * a.npt + min(kt, a.npt - 1)) * 8 + (gk - 8)) << 8) + 4 * lane);
+      return *reinterpret_cast<const f32x4*>(base);
+    }
+    const int jc = min(j, T2 - 1);  // keys >= T2 are masked afterwards
+    const float* base = (gk < 8) ? kbp + (size_t)jc * a.k_stride + h * 64 + 8 * gk + 4 * (lane >> 5)
+                                 : ptab + (size_t)jc * pstride * kD + h * 64 + 8 * (gk - 8) + 4 * (lane >> 5);
+    return *reinterpret_cast<const f32x4*>(base);
+  };
+  // the K' ring of the NEXT S phase is primed one phase early (at the end of the group's previous PV / before the
+  // first step), so that the first fragments are in registers when the phase starts
+  // A wave keeps TWO independent accumulator chains in every MFMA phase (a single dependent chain of
+  // v_mfma_f32_32x32x2_f32 issues only every ~100 cycles when no second wave of the SIMD has MFMAs to interleave,
+  // which is the normal case in the skewed schedule): the S phase alternates its two key tiles.
+  f32x4 ringk[PF][2];
+  auto prime_k = [&](int rd, int kb) {
+    const int h = 2 * rd + hg;
+    const int jk0 = kb * 256 + w4 * 32 + (lane & 31);
+#pragma unroll
+    for (int sx = 0; sx < PF; ++sx) {
+      ringk[sx][0] = kfrag(h, jk0, sx);
+      ringk[sx][1] = kfrag(h, jk0 + 128, sx);
+    }
+  };
+
   auto phase_s = [&](int rd, int kb) {
     const int h = 2 * rd + hg;
     const int key0 = kb * 256;
-    auto kfrag = [&](int j, int gk) -> f32x4 {
-      const int jc = min(j, T2 - 1);  // keys >= T2 are masked afterwards
-      const float* base = (gk < 8) ? kbp + (size_t)jc * a.k_stride + h * 64 + 8 * gk + 4 * (lane >> 5)
-                                   : ptab + (size_t)jc * pstride * kD + h * 64 + 8 * (gk - 8) + 4 * (lane >> 5);
-      return *reinterpret_cast<const f32x4*>(base);
-    };
     const int jk0 = key0 + w4 * 32 + (lane & 31), jk1 = jk0 + 128;
-    f32x4 ringk[PF][2];
-#pragma unroll
-    for (int sx = 0; sx < PF; ++sx) {
-      ringk[sx][0] = kfrag(jk0, sx);
-      ringk[sx][1] = kfrag(jk1, sx);
-    }
     f32x16 acc_s[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc_s[t][r] = 0.f;
     const float* a_ptr = Qh + (lane & 31) * kFQld + 4 * (lane >> 5);
+    f32x4 a_cur = *reinterpret_cast<const f32x4*>(a_ptr), a_nxt = a_cur;
 #pragma unroll
     for (int gk = 0; gk < NG; ++gk) {
+      if (gk + 1 < NG) a_nxt = *reinterpret_cast<const f32x4*>(a_ptr + 8 * (gk + 1));  // LDS read one k-group ahead
       const f32x4 b0 = ringk[gk % PF][0], b1 = ringk[gk % PF][1];
       if (gk + PF < NG) {
-        ringk[gk % PF][0] = kfrag(jk0, gk + PF);
-        ringk[gk % PF][1] = kfrag(jk1, gk + PF);
+        ringk[gk % PF][0] = kfrag(h, jk0, gk + PF);
+        ringk[gk % PF][1] = kfrag(h, jk1, gk + PF);
       }
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(a_ptr + 8 * gk);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc_s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc_s[0], 0, 0, 0);
-        acc_s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc_s[1], 0, 0, 0);
+        acc_s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], b0[j], acc_s[0], 0, 0, 0);
+        acc_s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], b1[j], acc_s[1], 0, 0, 0);
       }
+      a_cur = a_nxt;
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -760,25 +809,50 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
     }
   };
 
-  auto phase_pv = [&](int rd, int kb) {  // O = O*alpha + P V : wave -> (column tile ctg, 128-key half kh)
+  // O = O*alpha + P V : wave -> (column tile ctg, 128-key half kh).  Inside a group of 8 keys the MFMA k index is
+  // permuted (lane half hh, MFMA j) -> key 8*gq + 4*hh + j, so that the A operand (P) is one ds_read_b128 per 4 MFMAs
+  // (the row-block GEMM's fragment trick); the B operand (V) follows the same permutation.
+  auto phase_pv = [&](int rd, int kb) {
     const int h = 2 * rd + hg;
-    const int kbase = kb * 256 + kh * 128 + (lane >> 5);
+    const int kbase = kb * 256 + kh * 128 + 4 * (lane >> 5);
     const float* vcol = vbp + h * 64 + ctg * 32 + (lane & 31);
-    auto vval = [&](int j) -> float { return vcol[(size_t)min(j, T2 - 1) * a.v_stride]; };  // P is 0 for keys >= T2
-    float ringv[PFV];
+    auto vval = [&](int j) -> float {
+      return vcol[(size_t)min(j, T2 - 1) * a.v_stride];  // P is 0 for keys >= T2
+    };
+    constexpr int NQ = 16, PQ = 4;  // 8-key groups per half, groups of V values in flight
+    float ringv[PQ][4];
 #pragma unroll
-    for (int sx = 0; sx < PFV; ++sx) ringv[sx] = vval(kbase + 2 * sx);
+    for (int sx = 0; sx < PQ; ++sx)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ringv[sx][j] = vval(kbase + 8 * sx + j);
     const float* stA = stat(rd, 2);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_o[r] *= stA[acc_row(r, lane)];
-    const float* a_ptr = Sh + (lane & 31) * kFSld + kh * 128 + (lane >> 5);
+    const float* a_ptr = Sh + (lane & 31) * kFSld + kh * 128 + 4 * (lane >> 5);
+    auto a_load = [&](int gq) -> f32x4 { return *reinterpret_cast<const f32x4*>(a_ptr + 8 * gq); };
+    f32x4 a_cur = a_load(0), a_nxt = a_cur;
+    f32x16 acc_b;  // second chain (odd MFMAs), folded into acc_o at the end
 #pragma unroll
-    for (int sx = 0; sx < 64; ++sx) {
-      const float bv = ringv[sx % PFV];
-      if (sx + PFV < 64) ringv[sx % PFV] = vval(kbase + 2 * (sx + PFV));
-      acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[2 * sx], bv, acc_o, 0, 0, 0);
-      if ((sx & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    for (int r = 0; r < 16; ++r) acc_b[r] = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < NQ; ++gq) {
+      if (gq + 1 < NQ) a_nxt = a_load(gq + 1);
+      float bv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = ringv[gq % PQ][j];
+      if (gq + PQ < NQ) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ringv[gq % PQ][j] = vval(kbase + 8 * (gq + PQ) + j);
+      }
+      acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], bv[0], acc_o, 0, 0, 0);
+      acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], bv[1], acc_b, 0, 0, 0);
+      acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], bv[2], acc_o, 0, 0, 0);
+      acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], bv[3], acc_b, 0, 0, 0);
+      a_cur = a_nxt;
+      __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[r] += acc_b[r];
   };
 
   auto combine_write = [&]() {
@@ -809,14 +883,11 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
     St[(blk * 3 + 1) * 32 + row] = 0.f;
   }
   load_q(0);
+  prime_k(0, 0);
   __syncthreads();
   const int per_round = 3 * nkb;
   const int P = 2 * per_round + 1;  // phases of one group: (S, softmax, PV) x key blocks x 2 rounds, final combine
-#if PPASR_ABL == 6
-  for (int s = P + 1; s < P + 1; ++s) {
-#else
   for (int s = 0; s < P + 1; ++s) {
-#endif
     const int p = s - hg;
     if (p >= 0 && p < P) {
       if (p == P - 1) {
@@ -837,15 +908,15 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
         } else {
           phase_pv(rd, kb);
           if (kb == nkb - 1) combine_write();
+          // fragments of the group's next S phase (next key block, or the next round's first)
+          if (kb + 1 < nkb) prime_k(rd, kb + 1);
+          else if (rd == 0) prime_k(1, 0);
         }
       }
     }
     if (s == P - 1) ring_prime(ring, seg_o, 0);  // out-projection weights in flight during the last step
     __syncthreads();
   }
-#if PPASR_ABL == 6
-  ring_prime(ring, seg_o, 0);
-#endif
   // ---- k_out_glu tail on the LDS-resident context ----
   const int r0 = b * T + q0;
   const int M = gridDim.y * T;
@@ -893,7 +964,11 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
 constexpr size_t kLdsAttnOutGlu = (size_t)kFusedAttnFloats * sizeof(float);
 // a: plain-head batched attention arguments (group == 1, T1 == T2 frames, keys/values in the layer's own buffers)
 void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, float* g, const LayerW& w, hipStream_t st) {
-  hipLaunchKernelGGL(k_attn_out_glu, dim3((a.T1 + 31) / 32, B), dim3(kThreads), kLdsAttnOutGlu, st, a, x1, x2, g, w);
+  const dim3 grid((a.T1 + 31) / 32, B);
+  if (a.kpack && a.ptab_pack && a.pos0 == 0 && a.pos_stride == 1)
+    hipLaunchKernelGGL(k_attn_out_glu<true>, grid, dim3(kThreads), kLdsAttnOutGlu, st, a, x1, x2, g, w);
+  else
+    hipLaunchKernelGGL(k_attn_out_glu<false>, grid, dim3(kThreads), kLdsAttnOutGlu, st, a, x1, x2, g, w);
 }
 
 // streaming: g_hist = GLU(pointwise_conv1(cnn_cache rows))  -- the reference re-applies pointwise_conv1+GLU
@@ -1027,7 +1102,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
                                                        const float* __restrict__ x2, float* __restrict__ x_out, LayerW w,
                                                        const int64_t* __restrict__ lens, int M, int Tp, int n_chunks,
                                                        int mask_mul, LayerW wn, float* __restrict__ x1_next,
-                                                       float* __restrict__ qkv_next) {
+                                                       float* __restrict__ qkv_next, KPack kp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
@@ -1073,24 +1148,24 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   rb_layernorm(bufX, bufX, kLda, kRows, w.ln_fin_g, w.ln_fin_b, 1e-5f);
   // rb_layernorm and rb_store_rows use the same wave->row mapping: no barrier needed
   rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);
-  if (NEXT) ffn_qkv_body(bufX, bufA, bufH, x1_next, qkv_next, wn, r0, valid, n_chunks, ring);
+  if (NEXT) ffn_qkv_body(bufX, bufA, bufH, x1_next, qkv_next, wn, r0, valid, n_chunks, ring, kp);
 }
 constexpr size_t kLdsConvFfn = 4 * kRows * kLda * sizeof(float);
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                      const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,
-                     float* x1_next, float* qkv_next, hipStream_t st) {
+                     float* x1_next, float* qkv_next, hipStream_t st, KPack kp) {
   dim3 grid((M + kRows - 1) / kRows);
   const LayerW& wn = next ? *next : w;
 #define LAUNCH_CF(KS)                                                                                                  \
   if (g_hist)                                                                                                          \
     hipLaunchKernelGGL((k_conv_ffn<KS, true, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
-                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next);                                        \
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, kp);                                    \
   else if (next)                                                                                                       \
     hipLaunchKernelGGL((k_conv_ffn<KS, false, true>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
-                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next);                                        \
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, kp);                                    \
   else                                                                                                                 \
     hipLaunchKernelGGL((k_conv_ffn<KS, false, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, \
-                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next);
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, kp);
   if (ksize == 15) {
     LAUNCH_CF(15)
   } else if (ksize == 31) {
@@ -1442,7 +1517,8 @@ hipError_t configure_kernels() {
   SET_LDS((k_conv_ffn<31, true, false>), kLdsConvFfn);
   SET_LDS((k_conv_ffn<7, true, false>), kLdsConvFfn);
   SET_LDS(k_pw1_glu, kLdsPw1Glu);
-  SET_LDS(k_attn_out_glu, kLdsAttnOutGlu);
+  SET_LDS(k_attn_out_glu<true>, kLdsAttnOutGlu);
+  SET_LDS(k_attn_out_glu<false>, kLdsAttnOutGlu);
   SET_LDS(k_conv_ffn_stride<15>, kLdsConvFfn);
   SET_LDS(k_conv_ffn_stride<7>, kLdsConvFfn);
   SET_LDS(k_ctc_head<true>, kLdsCtc);
