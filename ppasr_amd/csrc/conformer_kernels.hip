@@ -96,7 +96,7 @@ struct DenseSrc {
 template <int MT, int KC, bool RELU, bool SB, typename Src>
 __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ out, int M,
-                                                          int n_chunks, float scale, int ldc, int n_valid) {
+                                                          int n_chunks, float scale, int ldc, int n_valid, int m0) {
   constexpr int BM = 32 * MT;
   constexpr int LD = KC + 4;
   constexpr int F4_PER_ROW = KC / 4;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
   constexpr int G = KC / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-  const int r0 = blockIdx.x * BM;
+  const int r0 = m0 + blockIdx.x * BM;  // m0: first row of this launch (row ranges split across launches)
   const int tile_stride = n_chunks * G * 64;
   const f32x4* wbase = wp + (size_t)(blockIdx.y * kWaves + wave) * tile_stride;  // blockIdx.y = 256-column block
   BRing<1> ring;
@@ -160,11 +160,31 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
 
 void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st) {
   Conv2Src src{y1, T1, F1, Tp, F2};
-  int M = B * Tp * F2;
-  constexpr int MT = 4, KC = 128;
-  size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
-  hipLaunchKernelGGL((k_gemm_stream<MT, KC, true, false, Conv2Src>), dim3((M + 32 * MT - 1) / (32 * MT)), dim3(kThreads), lds, st, src,
-                     fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD);
+  const int M = B * Tp * F2;
+  constexpr int KC = 128, kCUs = 256;
+  auto lds_of = [](int mt) { return (size_t)2 * (32 * mt) * (KC + 4) * sizeof(float); };
+  // Wave quantisation: 128-row tiles over 256 CUs (one workgroup per CU at this LDS footprint) would run
+  // ceil(tiles / 256) rounds, the last one mostly empty (1183 tiles = 4.62 rounds for 32 x 10 s).  The whole rounds
+  // run with 128-row tiles; the remainder is re-cut into <= 256 tiles of 32 / 64 / 96 rows (one shorter round).
+  const int tiles4 = (M + 127) / 128;
+  const int full = (tiles4 / kCUs) * kCUs;
+  const int rem_rows = M - full * 128;
+  int mt_rem = (rem_rows + 32 * kCUs - 1) / (32 * kCUs);  // rows per remainder tile / 32
+  if (full == 0 || rem_rows <= 0 || mt_rem >= 4) {
+    hipLaunchKernelGGL((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(tiles4), dim3(kThreads), lds_of(4), st, src,
+                       fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, 0);
+    return;
+  }
+  hipLaunchKernelGGL((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(full), dim3(kThreads), lds_of(4), st, src,
+                     fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, 0);
+  const int m0 = full * 128;
+#define CONV2_REM(MTR)                                                                                                    \
+  hipLaunchKernelGGL((k_gemm_stream<MTR, KC, true, false, Conv2Src>), dim3((rem_rows + 32 * MTR - 1) / (32 * MTR)),       \
+                     dim3(kThreads), lds_of(MTR), st, src, fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, m0)
+  if (mt_rem <= 1) CONV2_REM(1);
+  else if (mt_rem == 2) CONV2_REM(2);
+  else CONV2_REM(3);
+#undef CONV2_REM
 }
 void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, bool scale_before_bias,
                   hipStream_t st) {
@@ -173,10 +193,10 @@ void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, fl
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
   if (scale_before_bias)
     hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, true, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src,
-                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD);
+                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD, 0);
   else
     hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src,
-                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD);
+                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD, 0);
 }
 
 // out[M][ldc] (columns < n_valid) = A[M][K] * Wpacked + bias ; K % 256 == 0 ; weights / bias padded to a multiple of
@@ -187,7 +207,7 @@ void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, fl
   DenseSrc src{a, lda, KC};
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
   hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, n_cols_padded / 256),
-                     dim3(kThreads), lds, st, src, w, bias, out, M, K / KC, 1.0f, ldc, n_valid);
+                     dim3(kThreads), lds, st, src, w, bias, out, M, K / KC, 1.0f, ldc, n_valid, 0);
 }
 
 // =====================================================================================
@@ -1524,6 +1544,9 @@ hipError_t configure_kernels() {
   SET_LDS(k_ctc_head<true>, kLdsCtc);
   SET_LDS(k_ctc_head<false>, kLdsCtc);
   SET_LDS((k_gemm_stream<4, 128, true, false, Conv2Src>), 2 * 128 * 132 * sizeof(float));
+  SET_LDS((k_gemm_stream<3, 128, true, false, Conv2Src>), 2 * 96 * 132 * sizeof(float));
+  SET_LDS((k_gemm_stream<2, 128, true, false, Conv2Src>), 2 * 64 * 132 * sizeof(float));
+  SET_LDS((k_gemm_stream<1, 128, true, false, Conv2Src>), 2 * 32 * 132 * sizeof(float));
   SET_LDS((k_gemm_stream<1, 256, false, false, DenseSrc>), 2 * 32 * 260 * sizeof(float));
   SET_LDS((k_gemm_stream<1, 256, false, true, DenseSrc>), 2 * 32 * 260 * sizeof(float));
 #undef SET_LDS
