@@ -225,7 +225,7 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
       HIP_TRY(hipGetLastError());
       L.ptab = static_cast<const float*>(pt);
       L.ptab_pack = nullptr;
-      if (!grouped && H == 4) {  // fragment-ordered copy for the fused attention kernel's coalesced loads (KPack)
+      if (!grouped && desc->attention_heads == 4) {  // fragment-ordered copy for the fused attention kernel's coalesced loads (KPack)
         void* pp = nullptr;
         const size_t npt = (size_t)(max_len + 31) / 32;
         HIP_TRY(hipMalloc(&pp, 4 * npt * 8 * 256 * sizeof(float)));
