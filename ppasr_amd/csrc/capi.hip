@@ -224,16 +224,6 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
       launch_posproj(pe_dev, wpos_dev, bpos_dev, static_cast<float*>(pt), max_len, nullptr);
       HIP_TRY(hipGetLastError());
       L.ptab = static_cast<const float*>(pt);
-      L.ptab_pack = nullptr;
-      if (!grouped && desc->attention_heads == 4) {  // fragment-ordered copy for the fused attention kernel's coalesced loads (KPack)
-        void* pp = nullptr;
-        const size_t npt = (size_t)(max_len + 31) / 32;
-        HIP_TRY(hipMalloc(&pp, 4 * npt * 8 * 256 * sizeof(float)));
-        m->allocs.push_back(pp);
-        launch_pack_ptab(L.ptab, static_cast<float*>(pp), max_len, nullptr);
-        HIP_TRY(hipGetLastError());
-        L.ptab_pack = static_cast<const float*>(pp);
-      }
     }
     {
       GET(p1w, p + "conv_module.pointwise_conv1.weight", 2 * d * d);
@@ -312,7 +302,6 @@ WsLayout ws_layout(const ppasr_model_s* m, int B, int T) {
   w.fa = o; o += al(M);
   w.fp = o; o += al(M);
   w.xs = o; o += al(M * kD);  // saved full-resolution activations (Squeezeformer time reduction)
-  w.kp = o; o += al((size_t)B * 4 * ((Tp + 31) / 32) * 2048);  // fragment-ordered keys (KPack)
   w.total = o;
   return w;
 }
@@ -386,19 +375,13 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       return h->layer_group[layer] == 1 && h->desc.attention_heads == 4 && !h->taps;
     };
     const bool fuse_attn = fusable(i);
-    // the fused kernel streams the keys from a fragment-ordered copy written by the QKV epilogue
-    auto kpack_for = [&](int layer) {
-      const bool want = fusable(layer) && pstride == 1 && h->layers[layer].ptab_pack;
-      return KPack{want ? ws + wl.kp : nullptr, Ti, (Ti + 31) / 32};
-    };
-    const KPack kp_i = kpack_for(i);
-    if (!s1_done) timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st, kp_i); });
+    if (!s1_done) timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st); });
     s1_done = false;
     tap(xb, (size_t)Mi * kD);
     tap(qkv, (size_t)Mi * 3 * kD);
     const int Tt = (Ti + grp - 1) / grp;  // tokens: frames, or zero-padded groups of 3 (pad4group)
     AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Tt, Tt, 0, lens, ctx, L.pos_u, L.pos_v, L.ptab, pstride,
-               mul * grp, Ti, Ti, grp, kp_i.p, L.ptab_pack, kp_i.nt, (h->desc.max_len + 31) / 32};
+               mul * grp, Ti, Ti, grp};
     if (fuse_attn) {
       timed(9, [&] { launch_attn_out_glu(a, B, xb, xc, g, L, st); });
     } else {
@@ -418,8 +401,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       // fuse the next layer's S1 into this launch (it writes xb / qkv, which this layer no longer reads)
       const LayerW* next = (i + 1 < h->desc.num_blocks) ? &h->layers[i + 1] : nullptr;
       timed(next ? 8 : 6, [&] {
-        launch_conv_ffn(g, nullptr, xc, xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul, next, xb, qkv, st,
-                        next ? kpack_for(i + 1) : KPack{nullptr, 0, 0});
+        launch_conv_ffn(g, nullptr, xc, xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul, next, xb, qkv, st);
       });
       s1_done = next != nullptr;
     }

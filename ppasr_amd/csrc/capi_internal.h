@@ -118,7 +118,7 @@ struct ppasr_model_s {
 
 
 struct WsLayout {
-  size_t y1, y2, xa, xb, xc, qkv, ctx, g, rmax, rsum, fa, fp, xs, kp, total;  // offsets in floats
+  size_t y1, y2, xa, xb, xc, qkv, ctx, g, rmax, rsum, fa, fp, xs, total;  // offsets in floats
 };
 WsLayout ws_layout(const ppasr_model_s* m, int B, int T);
 

@@ -19,18 +19,6 @@ struct LayerW {
   const float *glu_pad;  // [256] GLU(pointwise_conv1(0)) = value of a zero-padded frame after GLU
   const float *pos_u, *pos_v;  // [256] = [h][dk]
   const float *ptab;     // [max_len][256] linear_pos(pe)  (weight-only, folded at create time)
-  const float *ptab_pack;  // same table in MFMA fragment order (see KPack), or nullptr
-};
-
-// Fragment-ordered copy of the attention keys: for utterance b, head h, 32-key tile kt and 8-feature group gk the 64
-// lanes x 4 floats an MFMA B-operand load wants ( lane l: key kt*32 + (l & 31), features 8gk + 4(l >> 5) .. +3 ) are
-// contiguous (1 KiB), exactly like the packed weights.  Written by the QKV epilogue next to the row-major qkv tensor;
-// the fused attention kernel streams it with fully coalesced loads (a row-major key tile costs 32 partially used cache
-// lines per load).  Address of (b, h, kt, gk) = p + ((((b*4 + h)*nt + kt)*8 + gk) << 8).
-struct KPack {
-  float* p;   // nullptr: not requested
-  int T;      // frames per utterance
-  int nt;     // key tiles per utterance = ceil(T / 32)
 };
 
 struct FrontW {
@@ -68,9 +56,6 @@ struct AttnArgs {
   int mask_mul;         // key j is PAD iff mask_mul*j >= len (4; 8 on time-reduced layers; x3 when grouped)
   int q_frames, kv_frames;  // valid frames behind the query / key tokens (== T1 / T2 unless grouped)
   int group;            // 1, or 3 = GroupedRelPositionMultiHeadedAttention (pos_u / pos_v are then [h][192])
-  const float* kpack;   // fragment-ordered keys (KPack) or nullptr; needs ptab_pack, pos0 == 0, pos_stride == 1
-  const float* ptab_pack;
-  int nt, npt;          // key tiles per utterance in kpack; position tiles per head in ptab_pack
 };
 
 // ---- launchers (all asynchronous on `st`) ----
@@ -84,17 +69,14 @@ void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, fl
                   hipStream_t st);
 void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, float* out, int M, int K, int n_cols_padded,
                   int ldc, int n_valid, hipStream_t st);
-void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
-                    KPack kp = KPack{nullptr, 0, 0});
-void launch_pack_ptab(const float* ptab, float* ptab_pack, int max_len, hipStream_t st);
+void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st);
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
                     const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st);
 // next != nullptr: also run the following layer's S1 (writes x1_next, qkv_next) in the same launch
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                      const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,
-                     float* x1_next, float* qkv_next, hipStream_t st,
-                     KPack kp = KPack{nullptr, 0, 0});
+                     float* x1_next, float* qkv_next, hipStream_t st);
 void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int B,
                             int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out, hipStream_t st);
 // streaming helpers

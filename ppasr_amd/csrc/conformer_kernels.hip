@@ -222,7 +222,7 @@ void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, fl
 // `ring` must already stream w.ffm_w1 (tile `wave`).
 __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bufH, float* __restrict__ x1,
                                              float* __restrict__ qkv, const LayerW& w, int r0, int valid, int n_chunks,
-                                             BRing<1>& ring, const KPack& kp) {
+                                             BRing<1>& ring) {
   const int lane = lane_id(), wave = wave_id();
   rb_layernorm(bufX, bufA, kLda, kRows, w.ln_mac_g, w.ln_mac_b, 1e-5f);
   __syncthreads();
@@ -248,24 +248,11 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
       int row = acc_row(r, lane);
       if (row < valid) qkv[(size_t)(r0 + row) * 768 + col] = acc[0][0][r] + bv;
     }
-    if (c == 1 && kp.p) {  // keys once more, in fragment order (KPack)
-      const int f = wave * 32 + (lane & 31);  // key feature 0..255
-      const int h = f >> 6, fi = f & 63;
-      const int sub = ((fi >> 3) << 8) + (((fi >> 2) & 1) << 7) + (fi & 3);  // gk*256 + lane_half*32*4 + j
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, lane);
-        if (row < valid) {
-          const int m = r0 + row, b = m / kp.T, t = m - b * kp.T;
-          kp.p[((((size_t)(b * 4 + h) * kp.nt + (t >> 5)) * 8) << 8) + sub + ((t & 31) << 2)] = acc[0][0][r] + bv;
-        }
-      }
-    }
   }
 }
 
 __global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ x_in, float* __restrict__ x1,
-                                                      float* __restrict__ qkv, LayerW w, int M, int n_chunks, KPack kp) {
+                                                      float* __restrict__ qkv, LayerW w, int M, int n_chunks) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
@@ -276,28 +263,12 @@ __global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ 
   BRing<1> ring;
   ring_prime(ring, w.ffm_w1 + (size_t)wave * kTs256, 0);
   rb_load_rows(bufX, kLda, x_in + (size_t)r0 * kD, kRows, valid);
-  ffn_qkv_body(bufX, bufA, bufH, x1, qkv, w, r0, valid, n_chunks, ring, kp);
+  ffn_qkv_body(bufX, bufA, bufH, x1, qkv, w, r0, valid, n_chunks, ring);
 }
 constexpr size_t kLdsFfnQkv = 4 * kRows * kLda * sizeof(float);
-void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
-                    KPack kp) {
+void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st) {
   hipLaunchKernelGGL(k_ffn_qkv, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsFfnQkv, st, x_in, x1, qkv, w, M,
-                     n_chunks, kp);
-}
-
-// ptab [max_len][256] -> fragment order [h][position tile][gk][lane][4] (positions >= max_len read 0)
-__global__ void k_pack_ptab(const float* __restrict__ ptab, float* __restrict__ pp, int max_len, int npt) {
-  const int pt = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;  // 256 threads: (gk, lane half, j) x ... 
-  for (int e = tid; e < 8 * 256; e += 256) {
-    const int gk = e >> 8, lane = (e >> 2) & 63, j = e & 3;
-    const int pos = pt * 32 + (lane & 31);
-    const int feat = h * 64 + 8 * gk + 4 * (lane >> 5) + j;
-    pp[(((size_t)h * npt + pt) * 8 << 8) + e] = pos < max_len ? ptab[(size_t)pos * kD + feat] : 0.f;
-  }
-}
-void launch_pack_ptab(const float* ptab, float* ptab_pack, int max_len, hipStream_t st) {
-  const int npt = (max_len + 31) / 32;
-  hipLaunchKernelGGL(k_pack_ptab, dim3(npt, 4), dim3(256), 0, st, ptab, ptab_pack, max_len, npt);
+                     n_chunks);
 }
 
 // -------------------------------------------------------------------------------------
@@ -666,9 +637,6 @@ constexpr int kFScr = 2 * 32 * 33;  // key-half combine scratch per head group
 constexpr int kFusedAttnFloats = 2 * 32 * kFQld + 2 * 32 * kFSld + 2 * kFScr + 2 * 2 * 32 * 3 + kRows * kLda;
 static_assert(2 * kRows * kLda <= 2 * 32 * kFQld + 2 * 32 * kFSld, "bufX/bufA alias the attention scratch");
 static_assert(kFusedAttnFloats * 4 <= 160 * 1024, "LDS budget");
-// PACKED: keys and positional rows come from the fragment-ordered copies (KPack / ptab_pack): one fully coalesced 1 KiB
-// load per fragment instead of 64 lanes x 16 B out of 32 different cache lines.
-template <bool PACKED>
 __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const float* __restrict__ x1, float* __restrict__ x2,
                                                            float* __restrict__ g, LayerW w) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -720,13 +688,6 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
 
   // K' fragment of k-group gk for key j of head h: features 8gk + 4*(lane>>5) .. +3; first 8 groups from k, the rest from p
   auto kfrag = [&](int h, int j, int gk) -> f32x4 {
-    if (PACKED) {
-      const int kt = j >> 5;  // the wave's 32-key tile (uniform); tiles past the utterance are masked afterwards
-      const float* base = (gk < 8)
-          ? a.kpack + (((((size_t)(b * 4 + h) * a.nt + min(kt, a.nt - 1)) * 8 + gk) << 8) + 4 * lane)
-          : a.ptab_pack + (((((size_t)h * a.npt + min(kt, a.npt - 1)) * 8 + (gk - 8)) << 8) + 4 * lane);
-      return *reinterpret_cast<const f32x4*>(base);
-    }
     const int jc = min(j, T2 - 1);  // keys >= T2 are masked afterwards
     const float* base = (gk < 8) ? kbp + (size_t)jc * a.k_stride + h * 64 + 8 * gk + 4 * (lane >> 5)
                                  : ptab + (size_t)jc * pstride * kD + h * 64 + 8 * (gk - 8) + 4 * (lane >> 5);
@@ -984,11 +945,7 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
 constexpr size_t kLdsAttnOutGlu = (size_t)kFusedAttnFloats * sizeof(float);
 // a: plain-head batched attention arguments (group == 1, T1 == T2 frames, keys/values in the layer's own buffers)
 void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, float* g, const LayerW& w, hipStream_t st) {
-  const dim3 grid((a.T1 + 31) / 32, B);
-  if (a.kpack && a.ptab_pack && a.pos0 == 0 && a.pos_stride == 1)
-    hipLaunchKernelGGL(k_attn_out_glu<true>, grid, dim3(kThreads), kLdsAttnOutGlu, st, a, x1, x2, g, w);
-  else
-    hipLaunchKernelGGL(k_attn_out_glu<false>, grid, dim3(kThreads), kLdsAttnOutGlu, st, a, x1, x2, g, w);
+  hipLaunchKernelGGL(k_attn_out_glu, dim3((a.T1 + 31) / 32, B), dim3(kThreads), kLdsAttnOutGlu, st, a, x1, x2, g, w);
 }
 
 // streaming: g_hist = GLU(pointwise_conv1(cnn_cache rows))  -- the reference re-applies pointwise_conv1+GLU
@@ -1122,7 +1079,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
                                                        const float* __restrict__ x2, float* __restrict__ x_out, LayerW w,
                                                        const int64_t* __restrict__ lens, int M, int Tp, int n_chunks,
                                                        int mask_mul, LayerW wn, float* __restrict__ x1_next,
-                                                       float* __restrict__ qkv_next, KPack kp) {
+                                                       float* __restrict__ qkv_next) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
@@ -1168,24 +1125,24 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   rb_layernorm(bufX, bufX, kLda, kRows, w.ln_fin_g, w.ln_fin_b, 1e-5f);
   // rb_layernorm and rb_store_rows use the same wave->row mapping: no barrier needed
   rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);
-  if (NEXT) ffn_qkv_body(bufX, bufA, bufH, x1_next, qkv_next, wn, r0, valid, n_chunks, ring, kp);
+  if (NEXT) ffn_qkv_body(bufX, bufA, bufH, x1_next, qkv_next, wn, r0, valid, n_chunks, ring);
 }
 constexpr size_t kLdsConvFfn = 4 * kRows * kLda * sizeof(float);
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                      const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,
-                     float* x1_next, float* qkv_next, hipStream_t st, KPack kp) {
+                     float* x1_next, float* qkv_next, hipStream_t st) {
   dim3 grid((M + kRows - 1) / kRows);
   const LayerW& wn = next ? *next : w;
 #define LAUNCH_CF(KS)                                                                                                  \
   if (g_hist)                                                                                                          \
     hipLaunchKernelGGL((k_conv_ffn<KS, true, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
-                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, kp);                                    \
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next);                                    \
   else if (next)                                                                                                       \
     hipLaunchKernelGGL((k_conv_ffn<KS, false, true>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
-                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, kp);                                    \
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next);                                    \
   else                                                                                                                 \
     hipLaunchKernelGGL((k_conv_ffn<KS, false, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, \
-                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, kp);
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next);
   if (ksize == 15) {
     LAUNCH_CF(15)
   } else if (ksize == 31) {
@@ -1537,8 +1494,7 @@ hipError_t configure_kernels() {
   SET_LDS((k_conv_ffn<31, true, false>), kLdsConvFfn);
   SET_LDS((k_conv_ffn<7, true, false>), kLdsConvFfn);
   SET_LDS(k_pw1_glu, kLdsPw1Glu);
-  SET_LDS(k_attn_out_glu<true>, kLdsAttnOutGlu);
-  SET_LDS(k_attn_out_glu<false>, kLdsAttnOutGlu);
+  SET_LDS(k_attn_out_glu, kLdsAttnOutGlu);
   SET_LDS(k_conv_ffn_stride<15>, kLdsConvFfn);
   SET_LDS(k_conv_ffn_stride<7>, kLdsConvFfn);
   SET_LDS(k_ctc_head<true>, kLdsCtc);
