@@ -72,7 +72,8 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
     return fail(PPASR_EUNSUPPORTED, "cnn_module_kernel must be 7, 15 or 31");
   if (desc->model_type == PPASR_MODEL_SQUEEZEFORMER && desc->cnn_module_kernel == 7)
     return fail(PPASR_EUNSUPPORTED, "squeezeformer: cnn_module_kernel must be 15 or 31");
-  if (!desc->causal) return fail(PPASR_EUNSUPPORTED, "only the causal (streaming-trained) conv module is built");
+  if (!desc->causal && desc->model_type != PPASR_MODEL_CONFORMER)
+    return fail(PPASR_EUNSUPPORTED, "the non-causal conv module (streaming=False) is built for model_type=conformer only");
   if (desc->input_dim > 128 || desc->input_dim < 7) return fail(PPASR_EUNSUPPORTED, "input_dim out of range");
   HIP_TRY(configure_kernels());
   HIP_TRY(configure_squeezeformer_kernels());
@@ -401,7 +402,8 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       // fuse the next layer's S1 into this launch (it writes xb / qkv, which this layer no longer reads)
       const LayerW* next = (i + 1 < h->desc.num_blocks) ? &h->layers[i + 1] : nullptr;
       timed(next ? 8 : 6, [&] {
-        launch_conv_ffn(g, nullptr, xc, xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul, next, xb, qkv, st);
+        launch_conv_ffn(g, nullptr, xc, xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul, next, xb, qkv, st,
+                        h->desc.causal != 0);
       });
       s1_done = next != nullptr;
     }

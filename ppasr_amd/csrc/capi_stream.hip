@@ -227,6 +227,8 @@ ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out) {
   if (!h || !out) return fail(PPASR_EINVAL, "null argument");
   if (h->desc.model_type == PPASR_MODEL_DEEPSPEECH2)
     return fail(PPASR_EUNSUPPORTED, "deepspeech2 streams carry their state in the h/c boxes of ppasr_ds2_encode");
+  if (!h->desc.causal)
+    return fail(PPASR_EUNSUPPORTED, "forward_chunk needs the causal conv module (a streaming=True model)");
   auto* s = new ppasr_stream_s();
   s->m = h;
   s->cap = h->desc.max_len;

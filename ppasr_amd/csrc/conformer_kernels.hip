@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
                                                        const float* __restrict__ x2, float* __restrict__ x_out, LayerW w,
                                                        const int64_t* __restrict__ lens, int M, int Tp, int n_chunks,
                                                        int mask_mul, LayerW wn, float* __restrict__ x1_next,
-                                                       float* __restrict__ qkv_next) {
+                                                       float* __restrict__ qkv_next, int left_ctx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   BRing<1> ring;
   const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
   ring_prime(ring, seg_pw2, 0);
-  dwconv_phase<KS, STREAM>(g, g_hist, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp);
+  dwconv_phase<KS, STREAM>(g, g_hist, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp, left_ctx);
   __syncthreads();
   // conv-module LayerNorm (nn.LayerNorm(channels), eps 1e-5, convolution.py:71) + swish, in place
   rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
@@ -1130,19 +1130,20 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
 constexpr size_t kLdsConvFfn = 4 * kRows * kLda * sizeof(float);
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                      const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,
-                     float* x1_next, float* qkv_next, hipStream_t st) {
+                     float* x1_next, float* qkv_next, hipStream_t st, bool causal) {
   dim3 grid((M + kRows - 1) / kRows);
+  const int left_ctx = causal ? ksize - 1 : (ksize - 1) / 2;
   const LayerW& wn = next ? *next : w;
 #define LAUNCH_CF(KS)                                                                                                  \
   if (g_hist)                                                                                                          \
     hipLaunchKernelGGL((k_conv_ffn<KS, true, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
-                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next);                                    \
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx);                                    \
   else if (next)                                                                                                       \
     hipLaunchKernelGGL((k_conv_ffn<KS, false, true>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
-                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next);                                    \
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx);                                    \
   else                                                                                                                 \
     hipLaunchKernelGGL((k_conv_ffn<KS, false, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, \
-                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next);
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx);
   if (ksize == 15) {
     LAUNCH_CF(15)
   } else if (ksize == 31) {

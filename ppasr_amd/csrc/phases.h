@@ -91,16 +91,20 @@ struct PadRows {  // conv-module pad masking (convolution.py:104-106,138-140): f
 // The block's input window (KS-1 halo rows + 32 rows) and the tap weights are staged in LDS
 // (win_lds: (KS-1+32) x kLda floats, w_lds: KS x kLda floats -- both buffers are free at this point of
 // the kernels), so the phase needs few registers whatever KS is.  Output (conv + bias) -> bufA rows.
+// `left` = frames of left context: KS-1 for the causal module (lorder, convolution.py:47-49), (KS-1)/2 for the
+// non-causal one (streaming=False models), whose depthwise conv zero-pads its INPUT symmetrically
+// (convolution.py:50-52: padding=(k-1)//2), so out-of-utterance taps read 0 instead of GLU(bias).
 template <int KS, bool STREAM>
 __device__ __forceinline__ void dwconv_phase(const float* __restrict__ g, const float* __restrict__ g_hist, float* bufA,
                                              float* win_lds, float* w_lds, const float* __restrict__ dw_w,
                                              const float* __restrict__ dw_b, const float* __restrict__ glu_pad, int r0,
-                                             int M, int Tp) {
+                                             int M, int Tp, int left = KS - 1) {
   const int lane = lane_id(), wave = wave_id();
   constexpr int LO = KS - 1;
   constexpr int RW = kRows / kWaves;
+  const bool causal = (left == LO);
   for (int q = wave; q < LO + kRows; q += kWaves) {
-    const int mq = r0 - LO + q;
+    const int mq = r0 - left + q;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (STREAM && mq < 0) v = *reinterpret_cast<const f32x4*>(g_hist + (size_t)(LO + mq) * kD + 4 * lane);
     else if (mq >= 0 && mq < M) v = *reinterpret_cast<const f32x4*>(g + (size_t)mq * kD + 4 * lane);
@@ -108,7 +112,8 @@ __device__ __forceinline__ void dwconv_phase(const float* __restrict__ g, const 
   }
   for (int j = wave; j < KS; j += kWaves)
     *reinterpret_cast<f32x4*>(w_lds + j * kLda + 4 * lane) = *reinterpret_cast<const f32x4*>(dw_w + j * kD + 4 * lane);
-  const f32x4 gp = *reinterpret_cast<const f32x4*>(glu_pad + 4 * lane);
+  f32x4 gp = *reinterpret_cast<const f32x4*>(glu_pad + 4 * lane);
+  if (!causal) gp = f32x4{0.f, 0.f, 0.f, 0.f};
   const f32x4 bias = *reinterpret_cast<const f32x4*>(dw_b + 4 * lane);
   __syncthreads();
 #pragma unroll
@@ -120,7 +125,8 @@ __device__ __forceinline__ void dwconv_phase(const float* __restrict__ g, const 
     for (int j = 0; j < KS; ++j) {
       const f32x4 wj = *reinterpret_cast<const f32x4*>(w_lds + j * kLda + 4 * lane);
       const f32x4 xv = *reinterpret_cast<const f32x4*>(win_lds + (row + j) * kLda + 4 * lane);
-      acc += wj * ((STREAM || t - LO + j >= 0) ? xv : gp);
+      const int tt = t - left + j;  // frame this tap reads inside the utterance
+      acc += wj * ((STREAM || (tt >= 0 && tt < Tp)) ? xv : gp);
     }
     *reinterpret_cast<f32x4*>(bufA + row * kLda + 4 * lane) = acc;
   }

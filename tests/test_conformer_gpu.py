@@ -127,3 +127,30 @@ def test_fused_attention_route_equals_two_kernel_route(B, T, lens):
     scale = np.abs(ref).max()
     assert np.abs(f - s).max() / scale < 1e-5
     assert np.abs(f - ref).max() / scale < 1e-3
+
+
+@pytest.mark.parametrize("B,T,lens,k", [(3, 331, [331, 250, 90], 15), (2, 523, [523, 300], 31), (1, 67, [67], 7)])
+def test_non_streaming_model_non_causal_conv(B, T, lens, k):
+    """streaming=False models use the non-causal conv module (symmetric zero padding of the depthwise conv input,
+    conformer/convolution.py:50-52) and full attention: logits / greedy ids vs the oracle built with causal=False."""
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    L, V = 2, 210
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=123, perturb_norm=True, cnn_module_kernel=k)
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=k)
+    x, lens = synth_features(B, T, lens=lens, seed=124)
+    m = ConformerModel(80, V, streaming=False, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    probs, logits = m.get_encoder_out(x, lens, return_logits=True)
+    torch.cuda.synchronize()
+    oracle = ConformerOracle(sd, num_blocks=L, cnn_module_kernel=k, causal=False)
+    ref_probs, ref_logits = oracle.get_encoder_out(x, lens, return_logits=True)
+    assert np.abs(logits.cpu().numpy() - ref_logits.numpy()).max() / np.abs(ref_logits.numpy()).max() < 1e-3
+    # and it differs from the causal module on the same weights (the test would be vacuous otherwise)
+    causal_logits = ConformerOracle(sd, num_blocks=L, cnn_module_kernel=k, causal=True).get_encoder_out(
+        x, lens, return_logits=True)[1]
+    assert np.abs(causal_logits.numpy() - ref_logits.numpy()).max() > 1e-2
+    tokens, n_tokens, _ = m.encode_greedy(x, lens)
+    for b in range(B):
+        ids, _, _ = greedy_tokens(ref_probs[b].numpy())
+        assert np.array_equal(ids, tokens[b, : int(n_tokens[b])].cpu().numpy())
+    with pytest.raises(Exception):
+        m.new_stream()  # forward_chunk needs the causal module
