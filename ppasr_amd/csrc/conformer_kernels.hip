@@ -649,7 +649,16 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
   float* bufA = bufX + kRows * kLda;
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const int hg = wave >> 2, w4 = wave & 3, gt = tid & 255;  // head group, wave / thread inside the group
-  const int q0 = blockIdx.x * 32, b = blockIdx.y;
+  // XCD-aware block -> (utterance, query block) map.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8),
+  // and every XCD has its own 4 MiB L2.  All query blocks of utterance b run on XCD b % 8, so an XCD's L2 holds the
+  // keys / values / positional rows of B/8 utterances (3.3 MB for 32 x 249 frames) instead of every XCD streaming
+  // all of them from HBM (the plain (qblk, b) grid put the 8 blocks of an utterance on 8 different XCDs).
+  const int nq = (a.T1 + 31) / 32;
+  const int slot = blockIdx.x >> 3;
+  const int b = (slot / nq) * 8 + (blockIdx.x & 7);
+  const int q0 = (slot % nq) * 32;
+  const int B = a.kv_frames;  // batch size (launch_attn_out_glu stores it here; plain heads need no frame count)
+  if (b >= B) return;  // batch not a multiple of 8: the padded slots are empty
   const int T = a.T1, T2 = a.T2;
   const int valid = min(32, T - q0);
   const float* __restrict__ qb = a.q + (size_t)b * T * a.q_stride;
@@ -900,7 +909,7 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
   }
   // ---- k_out_glu tail on the LDS-resident context ----
   const int r0 = b * T + q0;
-  const int M = gridDim.y * T;
+  const int M = B * T;
   const int col = wave * 32 + (lane & 31);
   {
     float res[16];
@@ -945,7 +954,11 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
 constexpr size_t kLdsAttnOutGlu = (size_t)kFusedAttnFloats * sizeof(float);
 // a: plain-head batched attention arguments (group == 1, T1 == T2 frames, keys/values in the layer's own buffers)
 void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, float* g, const LayerW& w, hipStream_t st) {
-  hipLaunchKernelGGL(k_attn_out_glu, dim3((a.T1 + 31) / 32, B), dim3(kThreads), kLdsAttnOutGlu, st, a, x1, x2, g, w);
+  // 1-D grid of nq * ceil(B/8) * 8 workgroups (see the XCD map in the kernel); B travels in a.q_frames' neighbour field
+  AttnArgs aa = a;
+  aa.kv_frames = B;  // unused by this kernel otherwise (plain heads: frames == tokens)
+  const int nq = (a.T1 + 31) / 32;
+  hipLaunchKernelGGL(k_attn_out_glu, dim3(nq * ((B + 7) / 8) * 8), dim3(kThreads), kLdsAttnOutGlu, st, aa, x1, x2, g, w);
 }
 
 // streaming: g_hist = GLU(pointwise_conv1(cnn_cache rows))  -- the reference re-applies pointwise_conv1+GLU
