@@ -1111,19 +1111,25 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   __syncthreads();
   PadRows is_pad{lens, r0, Tp, M, mask_mul};
   {
+    // residual rows and pad flags are fetched BEFORE the GEMM, branch-free (clamped row): inside the epilogue the 16
+    // conditional global loads per lane (x2, lens) were issued one dependent round trip after the other (9 us)
+    float res[16];
+    unsigned pad_bits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, lane);
+      res[r] = x2[(size_t)(r0 + min(row, valid - 1)) * kD + col];
+      pad_bits |= (is_pad(row) ? 1u : 0u) << r;
+    }
     f32x16 acc[1][1];
     acc_zero(acc);
     rb_gemm<1, 1, kG256>(bufA, kLda, seg_pw2, 0, w.ff_w1 + (size_t)wave * kTs256, 0, ring, acc);
     const float bv = w.pw2_b[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      int row = acc_row(r, lane);
-      float v = 0.f;
-      if (row < valid) {
-        float c = is_pad(row) ? 0.f : acc[0][0][r] + bv;
-        v = x2[(size_t)(r0 + row) * kD + col] + c;
-      }
-      bufX[row * kLda + col] = v;
+      const int row = acc_row(r, lane);
+      const float c = ((pad_bits >> r) & 1u) ? 0.f : acc[0][0][r] + bv;
+      bufX[row * kLda + col] = (row < valid) ? res[r] + c : 0.f;
     }
   }
   __syncthreads();
