@@ -1104,23 +1104,24 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   BRing<1> ring;
   const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
   ring_prime(ring, seg_pw2, 0);
+  // residual rows and pad flags of the pointwise_conv2 epilogue: requested first thing, branch-free (clamped row),
+  // so that their global round trips (~2.5 us each under load) overlap the depthwise-conv and LayerNorm phases.
+  // (Inside the epilogue the 16 conditional loads per lane ran as dependent round trips: 9 us.)
+  PadRows is_pad{lens, r0, Tp, M, mask_mul};
+  float res[16];
+  unsigned pad_bits = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, lane);
+    res[r] = x2[(size_t)(r0 + min(row, valid - 1)) * kD + col];
+    pad_bits |= (is_pad(row) ? 1u : 0u) << r;
+  }
   dwconv_phase<KS, STREAM>(g, g_hist, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp, left_ctx);
   __syncthreads();
   // conv-module LayerNorm (nn.LayerNorm(channels), eps 1e-5, convolution.py:71) + swish, in place
   rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
   __syncthreads();
-  PadRows is_pad{lens, r0, Tp, M, mask_mul};
   {
-    // residual rows and pad flags are fetched BEFORE the GEMM, branch-free (clamped row): inside the epilogue the 16
-    // conditional global loads per lane (x2, lens) were issued one dependent round trip after the other (9 us)
-    float res[16];
-    unsigned pad_bits = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = acc_row(r, lane);
-      res[r] = x2[(size_t)(r0 + min(row, valid - 1)) * kD + col];
-      pad_bits |= (is_pad(row) ? 1u : 0u) << r;
-    }
     f32x16 acc[1][1];
     acc_zero(acc);
     rb_gemm<1, 1, kG256>(bufA, kLda, seg_pw2, 0, w.ff_w1 + (size_t)wave * kTs256, 0, ring, acc);
