@@ -575,18 +575,18 @@ __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ 
   rb_load_rows(bufA, kLda, ctx + (size_t)r0 * kD, kRows, valid);
   __syncthreads();
   {
+    float res[16];  // residual rows requested before the GEMM, branch-free (clamped row; see k_conv_ffn)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[r] = x1[(size_t)(r0 + min(acc_row(r, lane), valid - 1)) * kD + col];
     f32x16 acc[1][1];
     acc_zero(acc);
     rb_gemm<1, 1, kG256>(bufA, kLda, seg_o, 0, seg_val, 0, ring, acc);
     const float bv = w.bo[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      int row = acc_row(r, lane);
-      float v = 0.f;
-      if (row < valid) {
-        v = x1[(size_t)(r0 + row) * kD + col] + (acc[0][0][r] + bv);
-        x2[(size_t)(r0 + row) * kD + col] = v;
-      }
+      const int row = acc_row(r, lane);
+      const float v = (row < valid) ? res[r] + (acc[0][0][r] + bv) : 0.f;
+      if (row < valid) x2[(size_t)(r0 + row) * kD + col] = v;
       bufX[row * kLda + col] = v;
     }
   }

@@ -82,16 +82,19 @@ __global__ __launch_bounds__(kThreads) void k_sq_mid(const float* __restrict__ c
   rb_load_rows(bufH, kLda, ctx + (size_t)r0 * kD, kRows, valid);
   __syncthreads();
   {
+    // residual rows requested before the GEMM, branch-free (clamped row): conditional loads inside the epilogue run as
+    // dependent round trips (see k_conv_ffn)
+    float res[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[r] = x[(size_t)(r0 + min(acc_row(r, lane), valid - 1)) * kD + col];
     f32x16 acc[1][1];
     acc_zero(acc);
     rb_gemm<1, 1, kG256>(bufH, kLda, seg_o, 0, w.ff1_w1 + (size_t)wave * kTs256, 0, ring, acc);
     const float bv = w.bo[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      int row = acc_row(r, lane);
-      float v = 0.f;
-      if (row < valid) v = x[(size_t)(r0 + row) * kD + col] + (acc[0][0][r] + bv);
-      bufX[row * kLda + col] = v;
+      const int row = acc_row(r, lane);
+      bufX[row * kLda + col] = (row < valid) ? res[r] + (acc[0][0][r] + bv) : 0.f;
     }
   }
   __syncthreads();
@@ -152,11 +155,20 @@ __global__ __launch_bounds__(kThreads) void k_sq_tail(const float* __restrict__ 
   BRing<1> ring;
   const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
   ring_prime(ring, seg_pw2, 0);
+  // residual rows / pad flags of the pointwise_conv2 epilogue, requested first thing and branch-free (see k_conv_ffn)
+  PadRows is_pad{lens, r0, Tp, M, mask_mul};
+  float res[16];
+  unsigned pad_bits = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, lane);
+    res[r] = x2[(size_t)(r0 + min(row, valid - 1)) * kD + col];
+    pad_bits |= (is_pad(row) ? 1u : 0u) << r;
+  }
   dwconv_phase<KS, STREAM>(g, g_hist, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp);
   __syncthreads();
   rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
   __syncthreads();
-  PadRows is_pad{lens, r0, Tp, M, mask_mul};
   {
     f32x16 acc[1][1];
     acc_zero(acc);
@@ -164,13 +176,9 @@ __global__ __launch_bounds__(kThreads) void k_sq_tail(const float* __restrict__ 
     const float bv = w.pw2_b[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      int row = acc_row(r, lane);
-      float v = 0.f;
-      if (row < valid) {
-        float c = is_pad(row) ? 0.f : acc[0][0][r] + bv;
-        v = x2[(size_t)(r0 + row) * kD + col] + c;
-      }
-      bufX[row * kLda + col] = v;
+      const int row = acc_row(r, lane);
+      const float c = ((pad_bits >> r) & 1u) ? 0.f : acc[0][0][r] + bv;
+      bufX[row * kLda + col] = (row < valid) ? res[r] + c : 0.f;
     }
   }
   __syncthreads();
