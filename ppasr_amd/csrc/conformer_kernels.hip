@@ -679,15 +679,27 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
   const int ctg = w4 & 1, kh = w4 >> 1;
   f32x16 acc_o;
 
-  auto load_q = [&](int rd) {  // Q' = [q+u | q+v] of head 2*rd + hg: 32 rows x 16 float4 over the group's 256 threads
+  // Q' = [q+u | q+v] of head 2*rd + hg: 32 rows x 16 float4 over the group's 256 threads.  Split into the global
+  // requests (branch-free: rows past the utterance are clamped and zeroed afterwards) and the LDS commit one phase
+  // later, so that the round trip (~2.5 us under load) is never waited for.
+  f32x4 qreg[2];
+  auto fetch_q = [&](int rd) {
     const int head = 2 * rd + hg;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = gt + 256 * i;
       const int row = idx >> 4, f4 = idx & 15;
-      f32x4 q = {0.f, 0.f, 0.f, 0.f};
-      if (row < valid) q = *reinterpret_cast<const f32x4*>(qb + (size_t)(q0 + row) * a.q_stride + head * 64 + f4 * 4);
-      const f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + head * 64 + f4 * 4);
+      qreg[i] = *reinterpret_cast<const f32x4*>(qb + (size_t)(q0 + min(row, valid - 1)) * a.q_stride + head * 64 + f4 * 4);
+    }
+  };
+  auto commit_q = [&](int rd) {
+    const int head = 2 * rd + hg;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = gt + 256 * i;
+      const int row = idx >> 4, f4 = idx & 15;
+      const f32x4 q = (row < valid) ? qreg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + head * 64 + f4 * 4);  // 2 KB, cache-resident
       const f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + head * 64 + f4 * 4);
       *reinterpret_cast<f32x4*>(Qh + row * kFQld + f4 * 4) = q + u;
       *reinterpret_cast<f32x4*>(Qh + row * kFQld + 64 + f4 * 4) = q + v;
@@ -704,9 +716,7 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
   };
   // the K' ring of the NEXT S phase is primed one phase early (at the end of the group's previous PV / before the
   // first step), so that the first fragments are in registers when the phase starts
-  // A wave keeps TWO independent accumulator chains in every MFMA phase (a single dependent chain of
-  // v_mfma_f32_32x32x2_f32 issues only every ~100 cycles when no second wave of the SIMD has MFMAs to interleave,
-  // which is the normal case in the skewed schedule): the S phase alternates its two key tiles.
+  // the S phase alternates its two key tiles (two independent accumulator chains)
   f32x4 ringk[PF][2];
   auto prime_k = [&](int rd, int kb) {
     const int h = 2 * rd + hg;
@@ -802,28 +812,27 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
   // O = O*alpha + P V : wave -> (column tile ctg, 128-key half kh).  Inside a group of 8 keys the MFMA k index is
   // permuted (lane half hh, MFMA j) -> key 8*gq + 4*hh + j, so that the A operand (P) is one ds_read_b128 per 4 MFMAs
   // (the row-block GEMM's fragment trick); the B operand (V) follows the same permutation.
-  auto phase_pv = [&](int rd, int kb) {
-    const int h = 2 * rd + hg;
+  constexpr int NQ = 16, PQ = 4;  // 8-key groups per key half, groups of V values in flight
+  float ringv[PQ][4];
+  auto vval = [&](int rd, int j) -> float {
+    return vbp[(size_t)min(j, T2 - 1) * a.v_stride + (2 * rd + hg) * 64 + ctg * 32 + (lane & 31)];  // P is 0 for keys >= T2
+  };
+  auto prime_v = [&](int rd, int kb) {
     const int kbase = kb * 256 + kh * 128 + 4 * (lane >> 5);
-    const float* vcol = vbp + h * 64 + ctg * 32 + (lane & 31);
-    auto vval = [&](int j) -> float {
-      return vcol[(size_t)min(j, T2 - 1) * a.v_stride];  // P is 0 for keys >= T2
-    };
-    constexpr int NQ = 16, PQ = 4;  // 8-key groups per half, groups of V values in flight
-    float ringv[PQ][4];
 #pragma unroll
     for (int sx = 0; sx < PQ; ++sx)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ringv[sx][j] = vval(kbase + 8 * sx + j);
+      for (int j = 0; j < 4; ++j) ringv[sx][j] = vval(rd, kbase + 8 * sx + j);
+  };
+  auto phase_pv = [&](int rd, int kb) {
+    const int kbase = kb * 256 + kh * 128 + 4 * (lane >> 5);
+    prime_v(rd, kb);
     const float* stA = stat(rd, 2);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_o[r] *= stA[acc_row(r, lane)];
     const float* a_ptr = Sh + (lane & 31) * kFSld + kh * 128 + 4 * (lane >> 5);
     auto a_load = [&](int gq) -> f32x4 { return *reinterpret_cast<const f32x4*>(a_ptr + 8 * gq); };
     f32x4 a_cur = a_load(0), a_nxt = a_cur;
-    f32x16 acc_b;  // second chain (odd MFMAs), folded into acc_o at the end
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc_b[r] = 0.f;
 #pragma unroll
     for (int gq = 0; gq < NQ; ++gq) {
       if (gq + 1 < NQ) a_nxt = a_load(gq + 1);
@@ -832,17 +841,13 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
       for (int j = 0; j < 4; ++j) bv[j] = ringv[gq % PQ][j];
       if (gq + PQ < NQ) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ringv[gq % PQ][j] = vval(kbase + 8 * (gq + PQ) + j);
+        for (int j = 0; j < 4; ++j) ringv[gq % PQ][j] = vval(rd, kbase + 8 * (gq + PQ) + j);
       }
-      acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], bv[0], acc_o, 0, 0, 0);
-      acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], bv[1], acc_b, 0, 0, 0);
-      acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], bv[2], acc_o, 0, 0, 0);
-      acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], bv[3], acc_b, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], bv[j], acc_o, 0, 0, 0);
       a_cur = a_nxt;
       __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc_o[r] += acc_b[r];
   };
 
   auto combine_write = [&]() {
@@ -872,8 +877,9 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
     St[(blk * 3 + 0) * 32 + row] = -INFINITY;
     St[(blk * 3 + 1) * 32 + row] = 0.f;
   }
-  load_q(0);
+  fetch_q(0);
   prime_k(0, 0);
+  commit_q(0);
   __syncthreads();
   const int per_round = 3 * nkb;
   const int P = 2 * per_round + 1;  // phases of one group: (S, softmax, PV) x key blocks x 2 rounds, final combine
@@ -891,10 +897,11 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc_o[r] = 0.f;
           }
+          if (rd == 0 && kb == nkb - 1) fetch_q(1);  // next head's queries: in flight during this S phase
           phase_s(rd, kb);
         } else if (ph == 1) {
           phase_softmax(rd);
-          if (rd == 0 && kb == nkb - 1) load_q(1);  // this round's last S is done: Q' of the next head may land
+          if (rd == 0 && kb == nkb - 1) commit_q(1);  // this round's last S is done: Q' of the next head may land
         } else {
           phase_pv(rd, kb);
           if (kb == nkb - 1) combine_write();
