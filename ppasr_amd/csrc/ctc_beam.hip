@@ -142,7 +142,8 @@ size_t beam_lds_bytes(const BeamConfig& c) {
   n += (size_t)c.beam * 12;                        // new_b, new_nb, new_score
   n += (size_t)Vp * 2;                             // kidx (int16)
   if (c.lm.order > 0) n += (size_t)c.beam * c.n_cand_max * 4;  // LM term of every (hypothesis, candidate) pair
-  n += (size_t)c.beam * c.n_cand_max;              // exists flags
+  n += (((size_t)c.beam * c.n_cand_max) + 3) & ~(size_t)3;  // exists flags
+  n += (size_t)c.beam * (1 + c.n_cand_max) * 4;    // score keys
   return (n + 15) & ~(size_t)15;
 }
 
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
   const bool has_lm = cfg.lm.order > 0;
   float* lm_sc = reinterpret_cast<float*>(p);  // [nb][C] alpha * log P_lm of child (hypothesis, candidate)
   if (has_lm) p += (size_t)beam * CM * 4;
-  uint8_t* exists = reinterpret_cast<uint8_t*>(p);
+  uint8_t* exists = reinterpret_cast<uint8_t*>(p); p += (((size_t)beam * CM) + 3) & ~(size_t)3;
+  uint32_t* skey = reinterpret_cast<uint32_t*>(p);  // [beam * (1 + CM)] score keys of the frame's elements
 
   int32_t* st = state + (size_t)u * beam_state_words(beam, cfg.max_nodes);
   int32_t* g_arr = st + 2;
@@ -414,75 +416,113 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       new_score[q] = lse(bc, nbc);
     }
     __syncthreads();
-    // ---- (e) element space: [0,nb) existing hypotheses, nb + i*C + k = child (i, cand k) ----
+    // ---- (e) element space: [0,nb) existing hypotheses, nb + i*C + k = child (i, cand k).  The 32-bit score key of
+    // every element is computed ONCE into LDS (0xFFFFFFFF = not a candidate); thread t owns the contiguous range
+    // [t*per, (t+1)*per) so that the compaction below keeps element order with a single block scan ----
     const int N = nb + nb * C;
-    auto elem_key = [&](int e, uint64_t& key) -> bool {
-      if (e < nb) { key = make_key(new_score[e], cur.chr[e], e); return true; }
-      const int r = e - nb, i = r / C, k = r - i * C;
-      const int c = cand_c[k];
-      if (c == blank || exists[r] || pruned(cand_lp[k], i)) return false;
-      key = make_key(ext_logp(i, k), c, e);
-      return true;
-    };
+    const int per = (N + kBT - 1) / kBT;
+    const int e_lo = min(tid * per, N), e_hi = min(e_lo + per, N);
+    auto elem_char = [&](int e) -> int { return e < nb ? cur.chr[e] : cand_c[(e - nb) % C]; };
     int my_valid = 0;
-    for (int e = tid; e < N; e += kBT) { uint64_t k; my_valid += elem_key(e, k) ? 1 : 0; }
+    {
+      int i = 0, k = 0;
+      if (e_lo >= nb) { i = (e_lo - nb) / C; k = (e_lo - nb) - i * C; }
+      for (int e = e_lo; e < e_hi; ++e) {
+        uint32_t key = 0xFFFFFFFFu;
+        if (e < nb) {
+          key = desc_key(new_score[e]);
+        } else {
+          const int c = cand_c[k];
+          if (c != blank && !exists[e - nb] && !pruned(cand_lp[k], i)) key = desc_key(ext_logp(i, k));
+          if (++k == C) { k = 0; ++i; }
+        }
+        skey[e] = key;
+        my_valid += key != 0xFFFFFFFFu ? 1 : 0;
+      }
+    }
     int n_valid;
-    (void)block_excl_scan(my_valid, wave_tot, n_valid);
+    (void)block_excl_scan(my_valid, wave_tot, n_valid);  // (barriers inside: skey[] is complete afterwards)
     const int k_sel = n_valid >= beam ? beam : n_valid;
-    // ---- (f) exact k_sel-th smallest key by MSD radix select (keys are unique) ----
-    uint64_t thr = ~0ull;
-    if (k_sel < n_valid) {
-      uint64_t prefix = 0;
-      int k_rem = k_sel;  // 1-based rank searched inside the current prefix class
-      for (int pass = 0; pass < 8; ++pass) {
-        const int shift = 56 - 8 * pass;
-        const uint64_t hi_mask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+    // ---- (f) exact top-k_sel in prefix_compare order = ascending (score key, char, element id): MSD radix select of
+    // the k_sel-th smallest 32-bit score key over the LDS array; if the threshold class has more members than slots
+    // left (ties), a second select over (char, id) inside that class ----
+    // 4-pass radix select of the k-th smallest value of f(e) over elements with pred(e); returns the value and how
+    // many members of its class are needed (k_need) / exist (k_have)
+    auto radix_select32 = [&](auto&& value_of, int k, uint32_t& out, int& k_need, int& k_have) {
+      uint32_t prefix = 0;
+      int k_rem = k;
+      k_have = 0;
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        const uint32_t hi_mask = pass == 0 ? 0u : (~0u << (shift + 8));
         hist[tid] = 0;
         __syncthreads();
         for (int e = tid; e < N; e += kBT) {
-          uint64_t k;
-          if (elem_key(e, k) && (k & hi_mask) == prefix) atomicAdd(&hist[(int)((k >> shift) & 0xff)], 1);
+          uint32_t v;
+          if (value_of(e, v) && (v & hi_mask) == prefix) atomicAdd(&hist[(int)((v >> shift) & 0xff)], 1);
         }
         __syncthreads();
         if (wave == 0) select_bin(hist, k_rem, false, sh_i);
         __syncthreads();
-        prefix |= (uint64_t)sh_i[0] << shift;
+        prefix |= (uint32_t)sh_i[0] << shift;
         k_rem = sh_i[1];
-        const bool whole_class = (sh_i[2] == k_rem);  // the searched key is the last of its class: take the class
+        k_have = sh_i[2];
         __syncthreads();
-        if (whole_class) {
-          prefix |= (shift == 0) ? 0ull : ((1ull << shift) - 1ull);
+        if (k_have == k_rem && shift > 0) {  // the searched value is the last of its class: take the whole class
+          prefix |= (1u << shift) - 1u;
           break;
         }
       }
-      thr = prefix;
-    }
-    // ---- (g) ordered compaction of the survivors into the next beam ----
-    int filled = 0;
-    for (int base = 0; base < N; base += kBT) {
-      const int e = base + tid;
-      uint64_t k = 0;
-      const bool keep = (e < N) && elem_key(e, k) && k <= thr;
-      int tot;
-      const int pos = filled + block_excl_scan(keep ? 1 : 0, wave_tot, tot);
-      if (keep && pos < beam) {
-        if (e < nb) {
-          nxt.node[pos] = cur.node[e]; nxt.chr[pos] = cur.chr[e]; nxt.par[pos] = cur.par[e];
-          nxt.b[pos] = new_b[e]; nxt.nb[pos] = new_nb[e]; nxt.score[pos] = new_score[e];
-          for (int j = 0; j < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[e * kLmCtx + j];
-        } else {
-          const int r = e - nb, i = r / C, kk = r - i * C;
-          const int c = cand_c[kk];
-          const float log_p = ext_logp(i, kk);
-          for (int j = 0; j + 1 < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[i * kLmCtx + j + 1];
-          nxt.ctx[pos * kLmCtx + kLmCtx - 1] = has_lm ? cfg.lm.tok2lm[c] : 0;
-          const int id = n_nodes + pos;
-          if (id < cfg.max_nodes) { arena[2 * (size_t)id] = cur.node[i]; arena[2 * (size_t)id + 1] = c; }
-          nxt.node[pos] = id; nxt.chr[pos] = c; nxt.par[pos] = cur.node[i];
-          nxt.b[pos] = kNegInf; nxt.nb[pos] = log_p; nxt.score[pos] = log_p;
-        }
+      out = prefix;
+      k_need = k_rem;
+    };
+    uint32_t thr1 = 0xFFFFFFFEu, thr2 = 0xFFFFFFFFu;  // keep: key < thr1, or key == thr1 and (char, id) <= thr2
+    bool exact_class = false;                        // thr1 names one exact key value whose class is only partly taken
+    if (k_sel < n_valid) {
+      int need, have;
+      radix_select32([&](int e, uint32_t& v) { v = skey[e]; return v != 0xFFFFFFFFu; }, k_sel, thr1, need, have);
+      // after an early exit thr1 is an upper bound of a wholly taken class; after 4 passes it is an exact key value
+      if (need < have) {
+        exact_class = true;
+        const uint32_t eq = thr1;
+        int n2, h2;
+        radix_select32([&](int e, uint32_t& v) {
+          if (skey[e] != eq) return false;
+          v = ((uint32_t)(elem_char(e) + 1) << 18) | (uint32_t)e;
+          return true;
+        }, need, thr2, n2, h2);
       }
-      filled += tot;
+    }
+    auto keeps = [&](int e) -> bool {
+      const uint32_t v = skey[e];
+      if (v == 0xFFFFFFFFu) return false;
+      if (!exact_class) return v <= thr1;
+      if (v != thr1) return v < thr1;
+      return (((uint32_t)(elem_char(e) + 1) << 18) | (uint32_t)e) <= thr2;
+    };
+    // ---- (g) ordered compaction of the survivors into the next beam: one block scan over per-thread counts ----
+    int my_keep = 0;
+    for (int e = e_lo; e < e_hi; ++e) my_keep += keeps(e) ? 1 : 0;
+    int tot_keep;
+    int pos = block_excl_scan(my_keep, wave_tot, tot_keep);
+    for (int e = e_lo; e < e_hi; ++e) {
+      if (!keeps(e) || pos >= beam) continue;
+      if (e < nb) {
+        nxt.node[pos] = cur.node[e]; nxt.chr[pos] = cur.chr[e]; nxt.par[pos] = cur.par[e];
+        nxt.b[pos] = new_b[e]; nxt.nb[pos] = new_nb[e]; nxt.score[pos] = new_score[e];
+        for (int j = 0; j < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[e * kLmCtx + j];
+      } else {
+        const int r = e - nb, i = r / C, kk = r - i * C;
+        const int c = cand_c[kk];
+        const float log_p = ext_logp(i, kk);
+        for (int j = 0; j + 1 < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[i * kLmCtx + j + 1];
+        nxt.ctx[pos * kLmCtx + kLmCtx - 1] = has_lm ? cfg.lm.tok2lm[c] : 0;
+        const int id = n_nodes + pos;
+        if (id < cfg.max_nodes) { arena[2 * (size_t)id] = cur.node[i]; arena[2 * (size_t)id + 1] = c; }
+        nxt.node[pos] = id; nxt.chr[pos] = c; nxt.par[pos] = cur.node[i];
+        nxt.b[pos] = kNegInf; nxt.nb[pos] = log_p; nxt.score[pos] = log_p;
+      }
+      ++pos;
     }
     __syncthreads();
     n_nodes += k_sel;
