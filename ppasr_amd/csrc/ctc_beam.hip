@@ -97,6 +97,26 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /*[4] LDS*/,
   return base + incl - v;
 }
 
+// Histogram increments with run-length pre-aggregation per thread: consecutive elements of a thread that fall into
+// the same bin cost one LDS atomic.  The leading bytes of scores / probabilities are concentrated in a handful of bins
+// (nearly every element of the first pass hits the same address, which LDS atomics serialise); with diverse bins this
+// degenerates to one atomic per element, as before.
+struct RunHist {
+  int* hist;
+  int bin, cnt;
+  __device__ __forceinline__ explicit RunHist(int* h) : hist(h), bin(-1), cnt(0) {}
+  __device__ __forceinline__ void add(int b) {
+    if (b == bin) { ++cnt; return; }
+    if (cnt) atomicAdd(&hist[bin], cnt);
+    bin = b;
+    cnt = 1;
+  }
+  __device__ __forceinline__ void flush() {
+    if (cnt) atomicAdd(&hist[bin], cnt);
+    cnt = 0;
+  }
+};
+
 // Executed by wave 0 only: find the histogram bin holding the k_rem-th element (1-based) when bins are walked in
 // ascending (desc == false) or descending (desc == true) order; writes {bin, rank inside the bin, bin count} to out[0..2].
 __device__ __forceinline__ void select_bin(const int* hist, int k_rem, bool desc, int* out) {
@@ -237,17 +257,23 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
           const uint32_t hi_mask = pass == 0 ? 0u : (~0u << (shift + 8));
           hist[tid] = 0;
           __syncthreads();
-          for (int v = tid; v < V; v += kBT) {
-            const uint32_t u = __float_as_uint(lp[v]);
-            if ((u & hi_mask) == prefix) atomicAdd(&hist[(u >> shift) & 0xff], 1);
+          {
+            RunHist rh(hist);
+            for (int v = tid; v < V; v += kBT) {
+              const uint32_t u = __float_as_uint(lp[v]);
+              if ((u & hi_mask) == prefix) rh.add((int)((u >> shift) & 0xff));
+            }
+            rh.flush();
           }
           __syncthreads();
           if (wave == 0) select_bin(hist, k_rem, true, sh_i);
           __syncthreads();
           prefix |= (uint32_t)sh_i[0] << shift;
           k_rem = sh_i[1];
-          if (pass == 3 && sh_i[2] > k_rem) slow_path = true;  // more values equal to the threshold than slots left
+          const int in_class = sh_i[2];
+          if (pass == 3 && in_class > k_rem) slow_path = true;  // more values equal to the threshold than slots left
           __syncthreads();
+          if (in_class == k_rem) break;  // the whole class is wanted: everything >= prefix (low bits 0) is selected
         }
         thr_u = prefix;
       }
@@ -425,19 +451,33 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
     auto elem_char = [&](int e) -> int { return e < nb ? cur.chr[e] : cand_c[(e - nb) % C]; };
     int my_valid = 0;
     {
-      int i = 0, k = 0;
-      if (e_lo >= nb) { i = (e_lo - nb) / C; k = (e_lo - nb) - i * C; }
-      for (int e = e_lo; e < e_hi; ++e) {
-        uint32_t key = 0xFFFFFFFFu;
-        if (e < nb) {
-          key = desc_key(new_score[e]);
-        } else {
+      int e = e_lo;
+      for (; e < e_hi && e < nb; ++e) {  // hypotheses already in the beam
+        skey[e] = desc_key(new_score[e]);
+        ++my_valid;
+      }
+      while (e < e_hi) {  // children: one hypothesis i at a time (its fields stay in registers), candidates k0..k1
+        const int r = e - nb, i = r / C, k0 = r - i * C;
+        const int k1 = min(C, k0 + (e_hi - e));
+        const int ci = cur.chr[i];
+        const float bi = cur.b[i], si = cur.score[i];
+        for (int k = k0; k < k1; ++k, ++e) {
           const int c = cand_c[k];
-          if (c != blank && !exists[e - nb] && !pruned(cand_lp[k], i)) key = desc_key(ext_logp(i, k));
-          if (++k == C) { k = 0; ++i; }
+          const float lpk = cand_lp[k];
+          uint32_t key = 0xFFFFFFFFu;
+          if (c != blank && !exists[e - nb] && !(full_beam && (lpk + si < min_cutoff))) {
+            float log_p = kNegInf;
+            if (c == ci) { if (bi > kNegInf) log_p = lpk + bi; }
+            else log_p = lpk + si;
+            if (has_lm) {
+              log_p += lm_sc[i * C + k];
+              log_p = (float)((double)log_p + cfg.beta);
+            }
+            key = desc_key(log_p);
+            ++my_valid;
+          }
+          skey[e] = key;
         }
-        skey[e] = key;
-        my_valid += key != 0xFFFFFFFFu ? 1 : 0;
       }
     }
     int n_valid;
@@ -457,9 +497,13 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
         const uint32_t hi_mask = pass == 0 ? 0u : (~0u << (shift + 8));
         hist[tid] = 0;
         __syncthreads();
-        for (int e = tid; e < N; e += kBT) {
-          uint32_t v;
-          if (value_of(e, v) && (v & hi_mask) == prefix) atomicAdd(&hist[(int)((v >> shift) & 0xff)], 1);
+        {
+          RunHist rh(hist);
+          for (int e = tid; e < N; e += kBT) {
+            uint32_t v;
+            if (value_of(e, v) && (v & hi_mask) == prefix) rh.add((int)((v >> shift) & 0xff));
+          }
+          rh.flush();
         }
         __syncthreads();
         if (wave == 0) select_bin(hist, k_rem, false, sh_i);
@@ -500,13 +544,20 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       if (v != thr1) return v < thr1;
       return (((uint32_t)(elem_char(e) + 1) << 18) | (uint32_t)e) <= thr2;
     };
-    // ---- (g) ordered compaction of the survivors into the next beam: one block scan over per-thread counts ----
+    // ---- (g) ordered compaction: survivors' element ids in element order (one block scan over per-thread counts), then
+    // slot p of the next beam is materialised by thread p (the survivors of one thread's range can be many) ----
     int my_keep = 0;
     for (int e = e_lo; e < e_hi; ++e) my_keep += keeps(e) ? 1 : 0;
     int tot_keep;
-    int pos = block_excl_scan(my_keep, wave_tot, tot_keep);
+    int wpos = block_excl_scan(my_keep, wave_tot, tot_keep);
+    int* surv = nxt.par;  // temporary list in the next beam's `par` column: slot p is read, then overwritten, by thread p
     for (int e = e_lo; e < e_hi; ++e) {
-      if (!keeps(e) || pos >= beam) continue;
+      if (!keeps(e) || wpos >= beam) continue;
+      surv[wpos++] = e;
+    }
+    __syncthreads();
+    for (int pos = tid; pos < k_sel; pos += kBT) {
+      const int e = surv[pos];
       if (e < nb) {
         nxt.node[pos] = cur.node[e]; nxt.chr[pos] = cur.chr[e]; nxt.par[pos] = cur.par[e];
         nxt.b[pos] = new_b[e]; nxt.nb[pos] = new_nb[e]; nxt.score[pos] = new_score[e];
@@ -522,7 +573,6 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
         nxt.node[pos] = id; nxt.chr[pos] = c; nxt.par[pos] = cur.node[i];
         nxt.b[pos] = kNegInf; nxt.nb[pos] = log_p; nxt.score[pos] = log_p;
       }
-      ++pos;
     }
     __syncthreads();
     n_nodes += k_sel;
