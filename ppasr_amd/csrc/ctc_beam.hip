@@ -30,7 +30,9 @@ namespace ppasr {
 
 namespace {
 
-constexpr int kBT = 256;  // threads per utterance
+constexpr int kBT = 1024;  // threads per utterance: 16 waves = 4 per SIMD (a batch of 32 utterances occupies 32 CUs with one
+                          // workgroup each, and every phase is a chain of dependent LDS reads: latency hidden by wave count)
+constexpr int kBW = kBT / 64;  // waves
 constexpr float kNegInf = -FLT_MAX;  // NUM_FLT_INF of decoder_utils.h
 constexpr float kNotCand = FLT_MAX;  // marker in lp[]: character not in the pruned list
 
@@ -75,7 +77,7 @@ __device__ __forceinline__ Beam carve_beam(char*& p, int cap) {
 }
 
 // block-wide exclusive scan of one int per thread (256 threads = 4 waves); returns (exclusive, total)
-__device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /*[4] LDS*/, int& total) {
+__device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /*[kBW] LDS*/, int& total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int incl = v;
 #pragma unroll
@@ -87,7 +89,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /*[4] LDS*/,
   __syncthreads();
   int base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < kBW; ++w) {
     int t = wave_tot[w];
     if (w < wave) base += t;
     tot += t;
@@ -155,7 +157,7 @@ __device__ __forceinline__ void select_bin(const int* hist, int k_rem, bool desc
 
 size_t beam_lds_bytes(const BeamConfig& c) {
   const int Vp = (c.V + 3) & ~3;
-  size_t n = 16 + 256 * 4 + 16 + 16 + 16 + 32 + kMaxBeamCand * 8;  // scalars, histogram, reduction scratch, gather buffers
+  size_t n = 16 + 256 * 4 + 3 * (kBT / 64) * 4 + 32 + kMaxBeamCand * 8;  // scalars, histogram, reduction scratch, gather buffers
   n += (size_t)Vp * 4;                             // lp
   n += (size_t)kMaxBeamCand * 8;                   // cand_c, cand_lp
   n += (size_t)2 * c.beam * (24 + 4 * kLmCtx);     // two beam halves
@@ -188,9 +190,9 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
   char* p = smem;
   double* sh_d = reinterpret_cast<double*>(p); p += 16;      // cumulative probability
   int* hist = reinterpret_cast<int*>(p); p += 256 * 4;
-  int* wave_tot = reinterpret_cast<int*>(p); p += 16;
-  float* red_p = reinterpret_cast<float*>(p); p += 16;
-  int* red_i = reinterpret_cast<int*>(p); p += 16;
+  int* wave_tot = reinterpret_cast<int*>(p); p += kBW * 4;
+  float* red_p = reinterpret_cast<float*>(p); p += kBW * 4;
+  int* red_i = reinterpret_cast<int*>(p); p += kBW * 4;
   int* sh_i = reinterpret_cast<int*>(p); p += 32;            // misc shared ints
   int* tmp_c = reinterpret_cast<int*>(p); p += kMaxBeamCand * 4;     // unsorted pruned characters
   float* tmp_p = reinterpret_cast<float*>(p); p += kMaxBeamCand * 4;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
         for (int pass = 0; pass < 4; ++pass) {
           const int shift = 24 - 8 * pass;
           const uint32_t hi_mask = pass == 0 ? 0u : (~0u << (shift + 8));
-          hist[tid] = 0;
+          if (tid < 256) hist[tid] = 0;
           __syncthreads();
           {
             RunHist rh(hist);
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
         __syncthreads();
         bp = red_p[0]; bi = red_i[0];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < kBW; ++w) {
           float p2 = red_p[w]; int i2 = red_i[w];
           if (p2 > bp || (p2 == bp && i2 < bi)) { bp = p2; bi = i2; }
         }
@@ -388,7 +390,8 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
       if (lane == 0) red_p[wave] = m;
       __syncthreads();
-      m = fminf(fminf(red_p[0], red_p[1]), fminf(red_p[2], red_p[3]));
+      m = red_p[0];
+      for (int w = 1; w < kBW; ++w) m = fminf(m, red_p[w]);
       min_cutoff = (float)((double)m + log((double)row[blank]) - fmax(0.0, cfg.beta));
       full_beam = (nb == beam);
       for (int r = tid; r < nb * C; r += kBT) {
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
         const uint32_t hi_mask = pass == 0 ? 0u : (~0u << (shift + 8));
-        hist[tid] = 0;
+        if (tid < 256) hist[tid] = 0;
         __syncthreads();
         {
           RunHist rh(hist);
