@@ -291,27 +291,39 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
         }
         __syncthreads();
         const int n_got = min(sh_i[4], kMaxBeamCand);
-        if (tid < n_got) {  // rank sort: (prob desc, index asc)
-          const float pv = tmp_p[tid];
-          const int iv = tmp_c[tid];
+        // rank sort (prob desc, index asc): 8 threads per element, each counting a slice of the list
+        if (tid < 8 * n_got) {
+          const int t = tid >> 3, part = tid & 7;
+          const float pv = tmp_p[t];
+          const int iv = tmp_c[t];
           int rank = 0;
-          for (int s2 = 0; s2 < n_got; ++s2) rank += (tmp_p[s2] > pv || (tmp_p[s2] == pv && tmp_c[s2] < iv)) ? 1 : 0;
-          cand_c[rank] = iv;
-          cand_lp[rank] = pv;  // probability for now
+          for (int s2 = part; s2 < n_got; s2 += 8) rank += (tmp_p[s2] > pv || (tmp_p[s2] == pv && tmp_c[s2] < iv)) ? 1 : 0;
+          rank += __shfl_xor(rank, 1);
+          rank += __shfl_xor(rank, 2);
+          rank += __shfl_xor(rank, 4);
+          if (part == 0) {
+            cand_c[rank] = iv;
+            cand_lp[rank] = pv;  // probability for now
+          }
         }
         __syncthreads();
-        if (tid == 0) {
+        if (wave == 0) {
+          // cumulative cut (sequential double additions in sorted order, like upstream); the sorted probabilities are
+          // held by the lanes of wave 0 and read with readlane instead of one LDS round trip per step
+          const float p0 = lane < n_got ? cand_lp[lane] : 0.f;
+          const float p1 = lane + 64 < n_got ? cand_lp[lane + 64] : 0.f;
           int len = n_got;
           if (cfg.cutoff_prob < 1.0) {
             double cum = 0.0;
             len = 0;
             for (int i = 0; i < n_got; ++i) {
-              cum += (double)cand_lp[i];
+              const float pi = i < 64 ? __shfl(p0, i) : __shfl(p1, i - 64);
+              cum += (double)pi;
               len += 1;
               if (cum >= cfg.cutoff_prob || len >= cfg.cutoff_top_n) break;
             }
           }
-          sh_i[5] = len;
+          if (lane == 0) sh_i[5] = len;
         }
         __syncthreads();
         C = sh_i[5];
