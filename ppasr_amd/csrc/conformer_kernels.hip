@@ -637,8 +637,8 @@ constexpr int kFScr = 2 * 32 * 33;  // key-half combine scratch per head group
 constexpr int kFusedAttnFloats = 2 * 32 * kFQld + 2 * 32 * kFSld + 2 * kFScr + 2 * 2 * 32 * 3 + kRows * kLda;
 static_assert(2 * kRows * kLda <= 2 * 32 * kFQld + 2 * 32 * kFSld, "bufX/bufA alias the attention scratch");
 static_assert(kFusedAttnFloats * 4 <= 160 * 1024, "LDS budget");
-__global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const float* __restrict__ x1, float* __restrict__ x2,
-                                                           float* __restrict__ g, LayerW w) {
+__global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, const float* __restrict__ x1,
+                                                           float* __restrict__ x2, float* __restrict__ g, LayerW w) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;                         // [2 groups][32][132]
   float* Ss = Qs + 2 * 32 * kFQld;          // [2 groups][32][257]
@@ -657,7 +657,6 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
   const int slot = blockIdx.x >> 3;
   const int b = (slot / nq) * 8 + (blockIdx.x & 7);
   const int q0 = (slot % nq) * 32;
-  const int B = a.kv_frames;  // batch size (launch_attn_out_glu stores it here; plain heads need no frame count)
   if (b >= B) return;  // batch not a multiple of 8: the padded slots are empty
   const int T = a.T1, T2 = a.T2;
   const int valid = min(32, T - q0);
@@ -961,11 +960,9 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, const flo
 constexpr size_t kLdsAttnOutGlu = (size_t)kFusedAttnFloats * sizeof(float);
 // a: plain-head batched attention arguments (group == 1, T1 == T2 frames, keys/values in the layer's own buffers)
 void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, float* g, const LayerW& w, hipStream_t st) {
-  // 1-D grid of nq * ceil(B/8) * 8 workgroups (see the XCD map in the kernel); B travels in a.q_frames' neighbour field
-  AttnArgs aa = a;
-  aa.kv_frames = B;  // unused by this kernel otherwise (plain heads: frames == tokens)
+  // 1-D grid of nq * ceil(B/8) * 8 workgroups (see the XCD map in the kernel)
   const int nq = (a.T1 + 31) / 32;
-  hipLaunchKernelGGL(k_attn_out_glu, dim3(nq * ((B + 7) / 8) * 8), dim3(kThreads), kLdsAttnOutGlu, st, aa, x1, x2, g, w);
+  hipLaunchKernelGGL(k_attn_out_glu, dim3(nq * ((B + 7) / 8) * 8), dim3(kThreads), kLdsAttnOutGlu, st, a, B, x1, x2, g, w);
 }
 
 // streaming: g_hist = GLU(pointwise_conv1(cnn_cache rows))  -- the reference re-applies pointwise_conv1+GLU
