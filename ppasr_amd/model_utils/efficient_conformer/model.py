@@ -1,6 +1,9 @@
-"""Host-side mirror of ``ppasr/model_utils/efficient_conformer/model.py`` (``EfficientConformerModel``),
-inference surface ``get_encoder_out`` (full utterance, batched): grouped attention on
-``group_layer_idx`` layers, a stride-2 conv layer at ``stride_layer_idx`` (output frame rate 80 ms)."""
+"""Host-side mirror of ``ppasr/model_utils/efficient_conformer/model.py`` (``EfficientConformerModel``, ctor :17-29,
+``get_encoder_out`` :147-161, ``get_encoder_out_chunk`` :163-183), inference surface: grouped attention on
+``group_layer_idx`` layers (efficient_conformer/attention.py:128-193), a stride-2 conv layer at ``stride_layer_idx``
+(efficient_conformer/encoder.py:455-548; output frame rate 80 ms), 7-tap conv modules after it (encoder.py:123-128).
+``get_encoder_out_chunk`` / ``new_stream`` (``EfficientConformerEncoder.forward_chunk``, encoder.py:266-393) are inherited
+from the Conformer wrapper: the C-ABI stream object handles this family's cache layout (csrc/capi_stream.hip)."""
 import ctypes
 
 import numpy as np

@@ -1,7 +1,10 @@
-"""Host-side mirror of ``ppasr/model_utils/squeezeformer/model.py`` (``SqueezeformerModel``), inference
-surface: ``get_encoder_out`` (full utterance, batched) and ``get_encoder_out_chunk`` / ``new_stream`` (forward_chunk,
-inherited from the Conformer wrapper: the C-ABI stream object handles the family's cache layout).  Shares the C-ABI plumbing with the Conformer
-wrapper; only the model descriptor and parameter names differ."""
+"""Host-side mirror of ``ppasr/model_utils/squeezeformer/model.py`` (``SqueezeformerModel``, ctor :17-29,
+``get_encoder_out`` :156-170, ``get_encoder_out_chunk`` :172-192), inference surface: post-LN blocks with adaptive scale
+(squeezeformer/encoder.py:435-506), time reduction / recovery around ``reduce_idx`` / ``recover_idx``
+(encoder.py:210-230, time_reduction.py:183-206), depthwise-conv subsampling (subsampling.py:53-68).
+``get_encoder_out_chunk`` / ``new_stream`` (``SqueezeformerEncoder.forward_chunk``, encoder.py:260-381) are inherited from
+the Conformer wrapper: the C-ABI stream object handles this family's cache layout (csrc/capi_stream.hip).  Shares the
+C-ABI plumbing with the Conformer wrapper; only the model descriptor and parameter names differ."""
 import ctypes
 
 import numpy as np
