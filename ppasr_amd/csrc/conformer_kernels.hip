@@ -624,31 +624,33 @@ void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, floa
 // ALL heads with the context rows kept in LDS, then k_out_glu's tail (out-projection -> +residual -> LN_conv -> mask
 // -> pointwise_conv1 -> GLU) on them.  Saves the context round trip through HBM, one launch and one pipeline
 // fill per layer, and gives every CU one workgroup (B x ceil(T'/32) = 256 for 32 x 249 frames).
-// Block = (query block, utterance), 8 waves = 2 head groups x 4 waves; two rounds cover the 4 heads.  A head group
-// walks the phases  S = Q'K'^T (wave w: keys [32w,32w+32) and +128 of a 256-key block, K' fragments straight from
-// L2)  ->  online softmax (16-lane groups own a row)  ->  PV (wave = (column tile, 128-key half))  per key block.
-// The two groups run the SAME phase sequence skewed by one phase: every SIMD hosts one wave of each group, so the
-// MFMA phases of one group overlap the softmax (VALU / LDS) and the operand latencies of the other.  One workgroup
-// barrier separates consecutive steps.
+//
+// Attention part: NO workgroup barriers.  Wave w = (head h = w >> 1, key half w & 1) is an independent flash-attention
+// worker: it owns the keys [128*half, 128*half + 128) of every 256-key block, keeps its Q' fragments (the MFMA A
+// operand) in 64 VGPRs, runs S = Q'K'^T for 64 keys at a time (K' fragments straight from L2), does the online softmax
+// on its private 32x64 score tile in LDS (each lane owns half a row), and accumulates O += P V into two accumulator
+// tiles.  Only the wave itself reads what it wrote, so `s_waitcnt` replaces every barrier; the two waves of a head sit
+// on the same SIMD and fill each other's latency gaps.  One barrier at the end merges the two key halves
+// (flash-decoding style: O = (O0 e^{m0-m} + O1 e^{m1-m}) / (l0 e^{m0-m} + l1 e^{m1-m})).
+// (The previous design -- waves of a head group sharing score tiles, three barriers per key block -- spent half of
+// its time at those barriers and in first-touch latencies that nothing overlapped.)
 // -------------------------------------------------------------------------------------
-constexpr int kFQld = 132;   // Q' row stride: [q+u | q+v] (128) + 4
-constexpr int kFSld = 260;   // score row stride: 256-key block + 4 (float4-aligned, conflict-free for the PV operand reads)
-constexpr int kFScr = 2 * 32 * 33;  // key-half combine scratch per head group
-constexpr int kFusedAttnFloats = 2 * 32 * kFQld + 2 * 32 * kFSld + 2 * kFScr + 2 * 2 * 32 * 3 + kRows * kLda;
-static_assert(2 * kRows * kLda <= 2 * 32 * kFQld + 2 * 32 * kFSld, "bufX/bufA alias the attention scratch");
+constexpr int kPLd = 68;                       // private score-tile row stride: 64 keys + 4
+constexpr int kPTile = 32 * kPLd;              // floats per wave
+constexpr int kFusedAttnFloats = kWaves * kPTile + kWaves * 64 + kRows * kLda;
+static_assert(2 * kRows * kLda <= kWaves * kPTile + kWaves * 64, "bufX/bufA alias the attention scratch");
+static_assert(32 * 65 <= kPTile, "merge scratch fits a wave's score tile");
 static_assert(kFusedAttnFloats * 4 <= 160 * 1024, "LDS budget");
 __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, const float* __restrict__ x1,
                                                            float* __restrict__ x2, float* __restrict__ g, LayerW w) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Qs = smem;                         // [2 groups][32][132]
-  float* Ss = Qs + 2 * 32 * kFQld;          // [2 groups][32][257]
-  float* Scr = Ss + 2 * 32 * kFSld;         // [2 groups][2 column tiles][32][33]
-  float* St = Scr + 2 * kFScr;              // [2 rounds][2 groups][3][32]: running max, running sum, rescale factor
-  float* bufC = St + 2 * 2 * 32 * 3;        // [32][260] context rows, all heads
-  float* bufX = smem;                       // out phase (aliases Qs / Ss)
+  float* Ps = smem;                          // [8 waves][32][68] private score / probability tiles
+  float* Stat = Ps + kWaves * kPTile;        // [8 waves][2][32]: running max, running sum of each wave's key half
+  float* bufC = Stat + kWaves * 64;          // [32][260] context rows, all heads
+  float* bufX = smem;                        // out phase (aliases the tiles)
   float* bufA = bufX + kRows * kLda;
-  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-  const int hg = wave >> 2, w4 = wave & 3, gt = tid & 255;  // head group, wave / thread inside the group
+  const int lane = lane_id(), wave = wave_id();
+  const int h = wave >> 1, khalf = wave & 1;
   // XCD-aware block -> (utterance, query block) map.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8),
   // and every XCD has its own 4 MiB L2.  All query blocks of utterance b run on XCD b % 8, so an XCD's L2 holds the
   // keys / values / positional rows of B/8 utterances (3.3 MB for 32 x 249 frames) instead of every XCD streaming
@@ -666,253 +668,196 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
   const float* __restrict__ ptab = a.ptab + (size_t)a.pos0 * kD;
   const int pstride = a.pos_stride;
   const int64_t len_b = a.lens ? a.lens[b] : (int64_t)a.mask_mul * T2;
-  float* Qh = Qs + hg * 32 * kFQld;
-  float* Sh = Ss + hg * 32 * kFSld;
-  float* scratch = Scr + hg * kFScr;
+  float* P = Ps + wave * kPTile;
   BRing<1> ring;
   const f32x4* seg_o = w.wo + (size_t)wave * kTs256;
   const f32x4* seg_val = w.pw1 + (size_t)wave * kTs256;
   const f32x4* seg_gate = w.pw1 + (size_t)(8 + wave) * kTs256;
-  const int nkb = (T2 + 255) / 256;
-  constexpr int NG = 16, PF = 4;  // k-groups of the score contraction, K' fragment pairs in flight
-  const int ctg = w4 & 1, kh = w4 >> 1;
-  f32x16 acc_o;
+  const int hh = lane >> 5, l31 = lane & 31;
+  constexpr int NG = 16, PF = 4;
 
-  // Q' = [q+u | q+v] of head 2*rd + hg: 32 rows x 16 float4 over the group's 256 threads.  Split into the global
-  // requests (branch-free: rows past the utterance are clamped and zeroed afterwards) and the LDS commit one phase
-  // later, so that the round trip (~2.5 us under load) is never waited for.
-  f32x4 qreg[2];
-  auto fetch_q = [&](int rd) {
-    const int head = 2 * rd + hg;
+  // ---- Q' fragments in registers: qa[gk][j] = Q'[row l31][8 gk + 4 hh + j], Q' = [q+u | q+v] ----
+  f32x4 qa[NG];
+  {
+    const float* qrow = qb + (size_t)(q0 + min(l31, valid - 1)) * a.q_stride + h * 64 + 4 * hh;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = gt + 256 * i;
-      const int row = idx >> 4, f4 = idx & 15;
-      qreg[i] = *reinterpret_cast<const f32x4*>(qb + (size_t)(q0 + min(row, valid - 1)) * a.q_stride + head * 64 + f4 * 4);
+    for (int gq = 0; gq < 8; ++gq) {
+      f32x4 q = *reinterpret_cast<const f32x4*>(qrow + 8 * gq);
+      if (l31 >= valid) q = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + h * 64 + 8 * gq + 4 * hh);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + h * 64 + 8 * gq + 4 * hh);
+      qa[gq] = q + u;
+      qa[gq + 8] = q + v;
     }
-  };
-  auto commit_q = [&](int rd) {
-    const int head = 2 * rd + hg;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = gt + 256 * i;
-      const int row = idx >> 4, f4 = idx & 15;
-      const f32x4 q = (row < valid) ? qreg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-      const f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + head * 64 + f4 * 4);  // 2 KB, cache-resident
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + head * 64 + f4 * 4);
-      *reinterpret_cast<f32x4*>(Qh + row * kFQld + f4 * 4) = q + u;
-      *reinterpret_cast<f32x4*>(Qh + row * kFQld + 64 + f4 * 4) = q + v;
-    }
-  };
-  auto stat = [&](int rd, int which) -> float* { return St + ((rd * 2 + hg) * 3 + which) * 32; };
-
-  // K' fragment of k-group gk for key j of head h: features 8gk + 4*(lane>>5) .. +3; first 8 groups from k, the rest from p
-  auto kfrag = [&](int h, int j, int gk) -> f32x4 {
+  }
+  // K' fragment of k-group gk for key j: features 8gk + 4hh .. +3; the first 8 groups from k, the rest from p
+  auto kfrag = [&](int j, int gk) -> f32x4 {
     const int jc = min(j, T2 - 1);  // keys >= T2 are masked afterwards
-    const float* base = (gk < 8) ? kbp + (size_t)jc * a.k_stride + h * 64 + 8 * gk + 4 * (lane >> 5)
-                                 : ptab + (size_t)jc * pstride * kD + h * 64 + 8 * (gk - 8) + 4 * (lane >> 5);
+    const float* base = (gk < 8) ? kbp + (size_t)jc * a.k_stride + h * 64 + 8 * gk + 4 * hh
+                                 : ptab + (size_t)jc * pstride * kD + h * 64 + 8 * (gk - 8) + 4 * hh;
     return *reinterpret_cast<const f32x4*>(base);
   };
-  // the K' ring of the NEXT S phase is primed one phase early (at the end of the group's previous PV / before the
-  // first step), so that the first fragments are in registers when the phase starts
-  // the S phase alternates its two key tiles (two independent accumulator chains)
-  f32x4 ringk[PF][2];
-  auto prime_k = [&](int rd, int kb) {
-    const int h = 2 * rd + hg;
-    const int jk0 = kb * 256 + w4 * 32 + (lane & 31);
+  f32x16 acc_o[2];
 #pragma unroll
-    for (int sx = 0; sx < PF; ++sx) {
-      ringk[sx][0] = kfrag(h, jk0, sx);
-      ringk[sx][1] = kfrag(h, jk0 + 128, sx);
-    }
-  };
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // of row l31 (both lane halves hold the same values)
 
-  auto phase_s = [&](int rd, int kb) {
-    const int h = 2 * rd + hg;
-    const int key0 = kb * 256;
-    const int jk0 = key0 + w4 * 32 + (lane & 31), jk1 = jk0 + 128;
-    f32x16 acc_s[2];
+  const int nkb = (T2 + 255) / 256;
+  for (int kb = 0; kb < nkb; ++kb) {
+    for (int sb = 0; sb < 2; ++sb) {
+      const int key0 = kb * 256 + khalf * 128 + sb * 64;
+      if (key0 >= T2) break;  // wave-uniform
+      // ---- S = Q' K'^T for 64 keys (two 32-key tiles, two independent accumulator chains) ----
+      f32x4 ringk[PF][2];
+      const int jk0 = key0 + l31, jk1 = jk0 + 32;
+#pragma unroll
+      for (int sx = 0; sx < PF; ++sx) {
+        ringk[sx][0] = kfrag(jk0, sx);
+        ringk[sx][1] = kfrag(jk1, sx);
+      }
+      f32x16 acc_s[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_s[t][r] = 0.f;
+#pragma unroll
+      for (int gk = 0; gk < NG; ++gk) {
+        const f32x4 b0 = ringk[gk % PF][0], b1 = ringk[gk % PF][1];
+        if (gk + PF < NG) {
+          ringk[gk % PF][0] = kfrag(jk0, gk + PF);
+          ringk[gk % PF][1] = kfrag(jk1, gk + PF);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc_s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[gk][j], b0[j], acc_s[0], 0, 0, 0);
+          acc_s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[gk][j], b1[j], acc_s[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // V operands of this sub-block's first groups: requested now, consumed after the softmax
+      const float* vcol = vbp + h * 64 + l31;
+      auto vval = [&](int key, int ct) -> float { return vcol[(size_t)min(key, T2 - 1) * a.v_stride + ct * 32]; };
+      constexpr int PQ = 2;
+      float ringv[PQ][4][2];
+#pragma unroll
+      for (int sx = 0; sx < PQ; ++sx)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) ringv[sx][j][ct] = vval(key0 + 8 * sx + 4 * hh + j, ct);
+      // ---- scores -> private LDS tile (masked, scaled) ----
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int key = key0 + t * 32 + l31;
+        const bool masked = (key >= T2) || (a.mask_mul * (int64_t)key >= len_b);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P[acc_row(r, lane) * kPLd + t * 32 + l31] = masked ? -INFINITY : acc_s[t][r] * 0.125f;
+      }
+      // ---- online softmax: lane (row l31, half hh) owns 32 scores of its row ----
+      float alpha;
+      {
+        float* prow = P + l31 * kPLd + hh * 32;
+        f32x4 sv[8];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          sv[i] = *reinterpret_cast<const f32x4*>(prow + 4 * i);
+          bm = fmaxf(bm, fmaxf(fmaxf(sv[i][0], sv[i][1]), fmaxf(sv[i][2], sv[i][3])));
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        const float m_new = fmaxf(m_run, bm);
+        float ps = 0.f;
+        alpha = 1.f;
+        if (m_new != -INFINITY) {
+          alpha = __expf(m_run - m_new);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              sv[i][e] = __expf(sv[i][e] - m_new);
+              ps += sv[i][e];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) sv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        ps += __shfl_xor(ps, 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(prow + 4 * i) = sv[i];
+        m_run = m_new;
+        l_run = l_run * alpha + ps;
+      }
+      // ---- O = O * alpha + P V (alpha of row r lives in lane r) ----
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float ar = __shfl(alpha, acc_row(r, lane));
+        acc_o[0][r] *= ar;
+        acc_o[1][r] *= ar;
+      }
+      {
+        const float* a_ptr = P + l31 * kPLd + 4 * hh;
+        f32x4 a_cur = *reinterpret_cast<const f32x4*>(a_ptr), a_nxt = a_cur;
+#pragma unroll
+        for (int gq = 0; gq < 8; ++gq) {
+          if (gq + 1 < 8) a_nxt = *reinterpret_cast<const f32x4*>(a_ptr + 8 * (gq + 1));
+          float bv[4][2];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) bv[j][ct] = ringv[gq % PQ][j][ct];
+          if (gq + PQ < 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int ct = 0; ct < 2; ++ct) ringv[gq % PQ][j][ct] = vval(key0 + 8 * (gq + PQ) + 4 * hh + j, ct);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc_o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], bv[j][0], acc_o[0], 0, 0, 0);
+            acc_o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], bv[j][1], acc_o[1], 0, 0, 0);
+          }
+          a_cur = a_nxt;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  // ---- merge the two key halves of every head, normalise -> bufC ----
+  if (hh == 0) {
+    Stat[wave * 64 + l31] = m_run;
+    Stat[wave * 64 + 32 + l31] = l_run;
+  }
+  if (khalf == 1) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc_s[t][r] = 0.f;
-    const float* a_ptr = Qh + (lane & 31) * kFQld + 4 * (lane >> 5);
-    f32x4 a_cur = *reinterpret_cast<const f32x4*>(a_ptr), a_nxt = a_cur;
-#pragma unroll
-    for (int gk = 0; gk < NG; ++gk) {
-      if (gk + 1 < NG) a_nxt = *reinterpret_cast<const f32x4*>(a_ptr + 8 * (gk + 1));  // LDS read one k-group ahead
-      const f32x4 b0 = ringk[gk % PF][0], b1 = ringk[gk % PF][1];
-      if (gk + PF < NG) {
-        ringk[gk % PF][0] = kfrag(h, jk0, gk + PF);
-        ringk[gk % PF][1] = kfrag(h, jk1, gk + PF);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc_s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], b0[j], acc_s[0], 0, 0, 0);
-        acc_s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], b1[j], acc_s[1], 0, 0, 0);
-      }
-      a_cur = a_nxt;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int kl = t * 128 + w4 * 32 + (lane & 31);
-      const int key = key0 + kl;
-      const bool masked = (key >= T2) || (a.mask_mul * (int64_t)key >= len_b);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Sh[acc_row(r, lane) * kFSld + kl] = masked ? -INFINITY : acc_s[t][r] * 0.125f;
-    }
-  };
-
-  auto phase_softmax = [&](int rd) {  // 16-lane group = one row (16 keys per lane); 8 rows per wave
-    const int grp = lane >> 4, gl = lane & 15;
-    float* stM = stat(rd, 0);
-    float* stL = stat(rd, 1);
-    float* stA = stat(rd, 2);
-#pragma unroll 1
-    for (int it = 0; it < 2; ++it) {
-      const int row = w4 * 8 + it * 4 + grp;
-      float* srow = Sh + row * kFSld + gl;
-      float v[16];
-      float bm = -INFINITY;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        v[e] = srow[16 * e];
-        bm = fmaxf(bm, v[e]);
-      }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o));
-      const float m_old = stM[row];
-      const float m_new = fmaxf(m_old, bm);
-      float alpha = 1.f, ps = 0.f;
-      if (m_new != -INFINITY) {
-        alpha = __expf(m_old - m_new);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          v[e] = __expf(v[e] - m_new);
-          ps += v[e];
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = 0.f;
-      }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) ps += __shfl_xor(ps, o);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) srow[16 * e] = v[e];
-      if (gl == 0) {
-        stM[row] = m_new;
-        stL[row] = stL[row] * alpha + ps;
-        stA[row] = alpha;
-      }
-    }
-  };
-
-  // O = O*alpha + P V : wave -> (column tile ctg, 128-key half kh).  Inside a group of 8 keys the MFMA k index is
-  // permuted (lane half hh, MFMA j) -> key 8*gq + 4*hh + j, so that the A operand (P) is one ds_read_b128 per 4 MFMAs
-  // (the row-block GEMM's fragment trick); the B operand (V) follows the same permutation.
-  constexpr int NQ = 16, PQ = 4;  // 8-key groups per key half, groups of V values in flight
-  float ringv[PQ][4];
-  auto vval = [&](int rd, int j) -> float {
-    return vbp[(size_t)min(j, T2 - 1) * a.v_stride + (2 * rd + hg) * 64 + ctg * 32 + (lane & 31)];  // P is 0 for keys >= T2
-  };
-  auto prime_v = [&](int rd, int kb) {
-    const int kbase = kb * 256 + kh * 128 + 4 * (lane >> 5);
-#pragma unroll
-    for (int sx = 0; sx < PQ; ++sx)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ringv[sx][j] = vval(rd, kbase + 8 * sx + j);
-  };
-  auto phase_pv = [&](int rd, int kb) {
-    const int kbase = kb * 256 + kh * 128 + 4 * (lane >> 5);
-    prime_v(rd, kb);
-    const float* stA = stat(rd, 2);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc_o[r] *= stA[acc_row(r, lane)];
-    const float* a_ptr = Sh + (lane & 31) * kFSld + kh * 128 + 4 * (lane >> 5);
-    auto a_load = [&](int gq) -> f32x4 { return *reinterpret_cast<const f32x4*>(a_ptr + 8 * gq); };
-    f32x4 a_cur = a_load(0), a_nxt = a_cur;
-#pragma unroll
-    for (int gq = 0; gq < NQ; ++gq) {
-      if (gq + 1 < NQ) a_nxt = a_load(gq + 1);
-      float bv[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bv[j] = ringv[gq % PQ][j];
-      if (gq + PQ < NQ) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ringv[gq % PQ][j] = vval(rd, kbase + 8 * (gq + PQ) + j);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], bv[j], acc_o, 0, 0, 0);
-      a_cur = a_nxt;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  auto combine_write = [&]() {
-    if (kh == 1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) scratch[(ctg * 32 + acc_row(r, lane)) * 33 + (lane & 31)] = acc_o[r];
-    }
-  };
-  auto combine_read = [&](int rd) {  // sum the key halves, normalise, context -> bufC[row][h*64 + ...]
-    if (kh == 0) {
-      const int h = 2 * rd + hg;
-      const float* stL = stat(rd, 1);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, lane);
-        const float l = stL[row];
-        float o = acc_o[r] + scratch[(ctg * 32 + row) * 33 + (lane & 31)];
-        o = (l > 0.f) ? o / l : 0.f;  // fully masked row -> 0 (attention.py:118)
-        bufC[row * kLda + h * 64 + ctg * 32 + (lane & 31)] = (row < valid) ? o : 0.f;
-      }
-    }
-  };
-
-  // ---- skewed phase schedule ----
-  if (tid < 128) {  // [rd][hg] x 32 rows: max = -inf, sum = 0
-    const int blk = tid >> 5, row = tid & 31;
-    St[(blk * 3 + 0) * 32 + row] = -INFINITY;
-    St[(blk * 3 + 1) * 32 + row] = 0.f;
+      for (int r = 0; r < 16; ++r) P[acc_row(r, lane) * 65 + t * 32 + l31] = acc_o[t][r];
   }
-  fetch_q(0);
-  prime_k(0, 0);
-  commit_q(0);
+  ring_prime(ring, seg_o, 0);  // out-projection weights in flight across the barrier
   __syncthreads();
-  const int per_round = 3 * nkb;
-  const int P = 2 * per_round + 1;  // phases of one group: (S, softmax, PV) x key blocks x 2 rounds, final combine
-  for (int s = 0; s < P + 1; ++s) {
-    const int p = s - hg;
-    if (p >= 0 && p < P) {
-      if (p == P - 1) {
-        combine_read(1);
-      } else {
-        const int rd = p / per_round, q = p - rd * per_round;
-        const int kb = q / 3, ph = q - 3 * kb;
-        if (ph == 0) {
-          if (kb == 0) {
-            if (rd == 1) combine_read(0);
+  if (khalf == 0) {
+    const float* P1 = Ps + (wave + 1) * kPTile;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[r] = 0.f;
-          }
-          if (rd == 0 && kb == nkb - 1) fetch_q(1);  // next head's queries: in flight during this S phase
-          phase_s(rd, kb);
-        } else if (ph == 1) {
-          phase_softmax(rd);
-          if (rd == 0 && kb == nkb - 1) commit_q(1);  // this round's last S is done: Q' of the next head may land
-        } else {
-          phase_pv(rd, kb);
-          if (kb == nkb - 1) combine_write();
-          // fragments of the group's next S phase (next key block, or the next round's first)
-          if (kb + 1 < nkb) prime_k(rd, kb + 1);
-          else if (rd == 0) prime_k(1, 0);
-        }
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, lane);
+      const float m0 = Stat[wave * 64 + row], l0 = Stat[wave * 64 + 32 + row];
+      const float m1 = Stat[(wave + 1) * 64 + row], l1 = Stat[(wave + 1) * 64 + 32 + row];
+      const float m = fmaxf(m0, m1);
+      const float e0 = (m0 == -INFINITY) ? 0.f : __expf(m0 - m);
+      const float e1 = (m1 == -INFINITY) ? 0.f : __expf(m1 - m);
+      const float l = l0 * e0 + l1 * e1;
+      const float inv = (l > 0.f) ? 1.0f / l : 0.f;  // fully masked row -> 0 (attention.py:118)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float o = (acc_o[t][r] * e0 + P1[row * 65 + t * 32 + l31] * e1) * inv;
+        bufC[row * kLda + h * 64 + t * 32 + l31] = (row < valid) ? o : 0.f;
       }
     }
-    if (s == P - 1) ring_prime(ring, seg_o, 0);  // out-projection weights in flight during the last step
-    __syncthreads();
   }
+  __syncthreads();
   // ---- k_out_glu tail on the LDS-resident context ----
   const int r0 = b * T + q0;
   const int M = B * T;
@@ -920,10 +865,7 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
   {
     float res[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = acc_row(r, lane);
-      res[r] = (row < valid) ? x1[(size_t)(r0 + row) * kD + col] : 0.f;
-    }
+    for (int r = 0; r < 16; ++r) res[r] = x1[(size_t)(r0 + min(acc_row(r, lane), valid - 1)) * kD + col];
     f32x16 acc[1][1];
     acc_zero(acc);
     rb_gemm<1, 1, kG256>(bufC, kLda, seg_o, 0, seg_val, 0, ring, acc);
