@@ -89,3 +89,25 @@ def test_padding_invariance_of_valid_frames():
     pert = model.get_encoder_out(x2, lens)[1].cpu().numpy()
     assert np.array_equal(base[:n_valid], pert[:n_valid])
     assert not np.array_equal(base[n_valid:], pert[n_valid:])
+
+
+def test_maximum_length_and_one_past_it():
+    """The positional table holds max_len = 5000 positions (embedding.py:27-53,64-66): T' = 4999 is the longest
+    utterance the reference accepts (200 s); one more output frame is refused."""
+    from ppasr_amd import _lib
+    L, V = 1, 61
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=131, perturb_norm=True)
+    model = _model(sd, V, L)
+    x, lens = synth_features(1, 19999, seed=132)
+    assert model.out_frames(19999) == 4999
+    probs, logits = model.get_encoder_out(x, lens, return_logits=True)
+    torch.cuda.synchronize()
+    ref_probs, ref_logits = ConformerOracle(sd, num_blocks=L).get_encoder_out(x, lens, return_logits=True)
+    assert _rel(logits.cpu().numpy(), ref_logits.numpy()) < TOL
+    tokens, n_tokens, _ = model.encode_greedy(x, lens)
+    ids, _, _ = greedy_tokens(ref_probs[0].numpy())
+    assert np.array_equal(ids, tokens[0, : int(n_tokens[0])].cpu().numpy())
+    x2, lens2 = synth_features(1, 20003, seed=133)
+    assert model.out_frames(20003) == 5000
+    with pytest.raises(_lib.PPASRHipError):
+        model.get_encoder_out(x2, lens2)
