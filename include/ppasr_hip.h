@@ -199,6 +199,23 @@ ppasr_status ppasr_ctc_collapse(const int32_t* frame_argmax, const float* frame_
                                 int B, int Tp, int blank, int32_t* tokens, int32_t* n_tokens, double* score,
                                 void* stream);
 
+/* ---- multi-session streaming (no reference counterpart: PPASR streams one session per call) -----------------------
+ * A group of Conformer sessions whose K/V and conv caches live in one allocation; ppasr_encode_chunk_group advances
+ * any subset of them by one chunk with ONE set of launches (rows of all listed sessions stacked).  Every session
+ * follows the single-session arithmetic of ppasr_encode_chunk with required_cache_size < 0 (full history, what
+ * PPASRPredictor.predict_stream passes, predict.py:306-307).  max_frames caps the per-session cache (<= max_len).
+ *   sessions_host [n] distinct slot indices; feats [n][T][F]; outputs by list position: probs [n][c][V] or NULL,
+ *   frame_argmax / frame_maxprob [n][c] or NULL. */
+typedef struct ppasr_stream_group_s* ppasr_stream_group;
+ppasr_status ppasr_stream_group_create(ppasr_handle h, int n_sessions, int max_frames, ppasr_stream_group* out);
+ppasr_status ppasr_stream_group_destroy(ppasr_stream_group g);
+ppasr_status ppasr_stream_group_reset(ppasr_stream_group g, int session /* < 0: all */, void* stream);
+int          ppasr_stream_group_offset(ppasr_stream_group g, int session);
+size_t       ppasr_group_chunk_workspace_bytes(ppasr_handle h, int n, int T);
+ppasr_status ppasr_encode_chunk_group(ppasr_stream_group g, const int* sessions_host, int n, const float* feats, int T,
+                                      float* probs, int32_t* frame_argmax, float* frame_maxprob, int* c_out_host,
+                                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- Kaldi-compatible fbank front-end --------------------------------------------
  * Replaces AudioFeaturizer.featurize (ppasr/data_utils/featurizer/audio_featurizer.py:37-67,120-138):
  * AudioSegment.normalize(target_dB) (data_utils/audio.py:287-304) -> .to('int16') (audio.py:244) ->

@@ -83,6 +83,13 @@ SYMBOLS = [
                                                 ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 _vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_int, _vp, ctypes.c_double,
                                                 ctypes.c_double, _vp]),
+    ("ppasr_stream_group_create", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
+    ("ppasr_stream_group_destroy", ctypes.c_int, [_vp]),
+    ("ppasr_stream_group_reset", ctypes.c_int, [_vp, ctypes.c_int, _vp]),
+    ("ppasr_stream_group_offset", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("ppasr_group_chunk_workspace_bytes", ctypes.c_size_t, [_vp, ctypes.c_int, ctypes.c_int]),
+    ("ppasr_encode_chunk_group", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.c_int, _vp, ctypes.c_int, _vp,
+                                                _vp, _vp, ctypes.POINTER(ctypes.c_int), _vp, ctypes.c_size_t, _vp]),
     ("ppasr_fbank_create", ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                           ctypes.POINTER(_vp)]),
     ("ppasr_fbank_destroy", ctypes.c_int, [_vp]),

@@ -365,4 +365,167 @@ ppasr_status ppasr_stream_import_cache(ppasr_stream s, const float* att_cache, i
   return PPASR_OK;
 }
 
+// =====================================================================================
+// Multi-session streaming: a group of Conformer sessions whose caches live in one allocation and advance with ONE set
+// of launches per chunk round (the rows of all active sessions are stacked: n x c frames -> ceil(n*c/32) row blocks
+// per kernel instead of one).  No reference counterpart: PPASR streams one session per call
+// (predict.py:232-337, forward_chunk asserts B = 1); each session here follows exactly the single-session arithmetic
+// (required_cache_size < 0: the full history is kept, what PPASRPredictor passes, predict.py:306-307).
+// =====================================================================================
+struct ppasr_stream_group_s {
+  ppasr_model_s* m;
+  int n_sessions, cap, lo;
+  float *kc, *vc;     // [n_sessions][L][cap][256]
+  float* xh_hist;     // [n_sessions][L][lo][256]
+  // per-call descriptors: a ring of pinned host staging buffers + device copies, each guarded by an event, so that a
+  // call never overwrites a buffer an earlier (still queued) call reads
+  static constexpr int kRing = 8;
+  SessDesc* desc_host;  // pinned [kRing][n_sessions]
+  SessDesc* desc_dev;   // device [kRing][n_sessions]
+  hipEvent_t ev[kRing];
+  int slot;
+  std::vector<int> cache_t, offset;
+};
+
+ppasr_status ppasr_stream_group_create(ppasr_handle h, int n_sessions, int max_frames, ppasr_stream_group* out) {
+  if (!h || !out || n_sessions < 1) return fail(PPASR_EINVAL, "bad argument");
+  if (h->desc.model_type != PPASR_MODEL_CONFORMER || !h->desc.causal)
+    return fail(PPASR_EUNSUPPORTED, "session groups are built for streaming (causal) model_type=conformer");
+  auto g = std::make_unique<ppasr_stream_group_s>();
+  g->m = h;
+  g->n_sessions = n_sessions;
+  g->cap = (max_frames > 0 && max_frames < h->desc.max_len) ? max_frames : h->desc.max_len;
+  g->lo = h->desc.cnn_module_kernel - 1;
+  const size_t L = h->desc.num_blocks;
+  const size_t kv = (size_t)n_sessions * L * g->cap * kD * sizeof(float);
+  const size_t hb = (size_t)n_sessions * L * g->lo * kD * sizeof(float);
+  g->kc = g->vc = g->xh_hist = nullptr;
+  g->desc_dev = g->desc_host = nullptr;
+  g->slot = 0;
+  const size_t db = (size_t)ppasr_stream_group_s::kRing * n_sessions * sizeof(SessDesc);
+  hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&g->kc), kv);
+  hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&g->vc), kv);
+  hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&g->xh_hist), hb);
+  hipError_t e4 = hipMalloc(reinterpret_cast<void**>(&g->desc_dev), db);
+  hipError_t e5 = hipHostMalloc(reinterpret_cast<void**>(&g->desc_host), db, hipHostMallocDefault);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
+    (void)hipFree(g->kc); (void)hipFree(g->vc); (void)hipFree(g->xh_hist); (void)hipFree(g->desc_dev);
+    (void)hipHostFree(g->desc_host);
+    return fail(PPASR_EHIP, "allocation failed for the session-group caches");
+  }
+  for (int i = 0; i < ppasr_stream_group_s::kRing; ++i) HIP_TRY(hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming));
+  HIP_TRY(hipMemset(g->xh_hist, 0, hb));
+  g->cache_t.assign(n_sessions, 0);
+  g->offset.assign(n_sessions, 0);
+  *out = g.release();
+  return PPASR_OK;
+}
+
+ppasr_status ppasr_stream_group_destroy(ppasr_stream_group g) {
+  if (!g) return PPASR_OK;
+  (void)hipFree(g->kc); (void)hipFree(g->vc); (void)hipFree(g->xh_hist); (void)hipFree(g->desc_dev);
+  (void)hipHostFree(g->desc_host);
+  for (int i = 0; i < ppasr_stream_group_s::kRing; ++i) (void)hipEventDestroy(g->ev[i]);
+  delete g;
+  return PPASR_OK;
+}
+
+// session < 0: every session
+ppasr_status ppasr_stream_group_reset(ppasr_stream_group g, int session, void* stream) {
+  if (!g || session >= g->n_sessions) return fail(PPASR_EINVAL, "bad session");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t per = (size_t)g->m->desc.num_blocks * g->lo * kD;
+  if (session < 0) {
+    HIP_TRY(hipMemsetAsync(g->xh_hist, 0, per * g->n_sessions * sizeof(float), st));
+    std::fill(g->cache_t.begin(), g->cache_t.end(), 0);
+    std::fill(g->offset.begin(), g->offset.end(), 0);
+  } else {
+    HIP_TRY(hipMemsetAsync(g->xh_hist + per * session, 0, per * sizeof(float), st));
+    g->cache_t[session] = 0;
+    g->offset[session] = 0;
+  }
+  return PPASR_OK;
+}
+
+int ppasr_stream_group_offset(ppasr_stream_group g, int session) {
+  return (g && session >= 0 && session < g->n_sessions) ? g->offset[session] : -1;
+}
+
+size_t ppasr_group_chunk_workspace_bytes(ppasr_handle h, int n, int T) {
+  if (!h || n < 1 || T < 7) return 0;
+  const size_t Tp = ((T - 1) / 2 - 1) / 2;
+  // the batched layout for B = n, plus the conv-module input rows and the GLU'd histories of the active sessions
+  return (ws_layout(h, n, T).total + (size_t)n * Tp * kD + 64 + (size_t)n * (h->desc.cnn_module_kernel - 1) * kD * 2 + 64) *
+         sizeof(float);
+}
+
+// One chunk [T frames] for each of the n DISTINCT sessions listed in sessions_host; feats [n][T][F] (device).
+// Outputs are indexed by position in the list: probs [n][c][V] (or NULL), frame_argmax / frame_maxprob [n][c].
+ppasr_status ppasr_encode_chunk_group(ppasr_stream_group g, const int* sessions_host, int n, const float* feats, int T,
+                                      float* probs, int32_t* frame_argmax, float* frame_maxprob, int* c_out_host,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || !sessions_host || !feats || !workspace || n < 1 || n > g->n_sessions) return fail(PPASR_EINVAL, "bad argument");
+  ppasr_model_s* h = g->m;
+  if (T < 7) return fail(PPASR_EINVAL, "chunk shorter than the conv front-end's receptive field (7 frames)");
+  if (workspace_bytes < ppasr_group_chunk_workspace_bytes(h, n, T)) return fail(PPASR_ENOSPACE, "workspace too small");
+  const int F = h->desc.input_dim, T1 = (T - 1) / 2, F1 = h->F1, c = (T1 - 1) / 2, F2 = h->F2;
+  const int slot = g->slot;
+  g->slot = (slot + 1) % ppasr_stream_group_s::kRing;
+  HIP_TRY(hipEventSynchronize(g->ev[slot]));  // the call that last used this slot has consumed it (no-op when unused)
+  SessDesc* desc = g->desc_host + (size_t)slot * g->n_sessions;
+  SessDesc* desc_dev = g->desc_dev + (size_t)slot * g->n_sessions;
+  std::vector<char> seen(g->n_sessions, 0);
+  for (int b = 0; b < n; ++b) {
+    const int sidx = sessions_host[b];
+    if (sidx < 0 || sidx >= g->n_sessions || seen[sidx]) return fail(PPASR_EINVAL, "session index out of range or repeated");
+    seen[sidx] = 1;
+    if (g->cache_t[sidx] + c > g->cap) return fail(PPASR_EINVAL, "attention cache capacity exceeded");
+    if (g->offset[sidx] + c >= h->desc.max_len) return fail(PPASR_EINVAL, "offset + chunk exceeds the positional table (max_len)");
+    desc[b] = SessDesc{sidx, g->cache_t[sidx], g->offset[sidx] - g->cache_t[sidx], 0};
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(desc_dev, desc, (size_t)n * sizeof(SessDesc), hipMemcpyHostToDevice, st));
+  const WsLayout wl = ws_layout(h, n, T);
+  float* ws = static_cast<float*>(workspace);
+  float *y1 = ws + wl.y1, *y2 = ws + wl.y2, *xa = ws + wl.xa, *xb = ws + wl.xb, *xc = ws + wl.xc;
+  float *qkv = ws + wl.qkv, *ctx = ws + wl.ctx, *gg = ws + wl.g;
+  float* xhat = ws + wl.total;
+  const int lo = g->lo;
+  float* xh_act = xhat + (((size_t)n * c * kD + 63) & ~(size_t)63);  // [n][lo][256] gathered histories
+  float* g_hist = xh_act + (size_t)n * lo * kD;                       // [n][lo][256] GLU(pointwise_conv1(history))
+  const int M = n * c, L = h->desc.num_blocks, H = h->desc.attention_heads;
+  const int n_chunks = h->desc.linear_units / 256;
+  const long long kv_sess = (long long)L * g->cap * kD, hist_sess = (long long)L * lo * kD;
+  launch_conv1(feats, h->front, y1, n, T, F, T1, F1, st);
+  launch_conv2(y1, h->front, y2, n, T1, F1, c, F2, st);
+  launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st);
+  for (int i = 0; i < L; ++i) {
+    const LayerW& W = h->layers[i];
+    float* kc = g->kc + (size_t)i * g->cap * kD;
+    float* vc = g->vc + (size_t)i * g->cap * kD;
+    float* xh = g->xh_hist + (size_t)i * lo * kD;
+    launch_ffn_qkv(xa, xb, qkv, W, M, n_chunks, st);
+    launch_kv_append_group(qkv, kc, vc, kv_sess, desc_dev, n, c, st);
+    AttnArgs a{qkv, 768, kc, kD, vc, kD, c, c, 0, nullptr, ctx, W.pos_u, W.pos_v, W.ptab, 1, 4, c, c, 1, desc_dev, kv_sess};
+    launch_attention(a, n, H, st);
+    launch_hist_gather(xh, hist_sess, desc_dev, xh_act, n, lo, st);
+    launch_pw1_glu(xh_act, g_hist, W, n * lo, st);
+    launch_out_glu(ctx, xb, xc, gg, xhat, W, nullptr, M, c, 4, st);
+    launch_conv_ffn(gg, g_hist, xc, xa, W, nullptr, M, c, n_chunks, h->desc.cnn_module_kernel, 4, nullptr, nullptr, nullptr, st);
+    launch_hist_update_group(xh, hist_sess, desc_dev, xhat, n, c, lo, st);
+  }
+  int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
+  float* fp = frame_maxprob ? frame_maxprob : ws + wl.fp;
+  launch_ctc_head(xa, h->head, probs, fa, fp, ws + wl.rmax, ws + wl.rsum, M, st);
+  if (probs) launch_softmax_from_stats(probs, ws + wl.rmax, ws + wl.rsum, M, h->head.V, st);
+  for (int b = 0; b < n; ++b) {
+    g->cache_t[sessions_host[b]] += c;
+    g->offset[sessions_host[b]] += c;
+  }
+  HIP_TRY(hipEventRecord(g->ev[slot], st));
+  if (c_out_host) *c_out_host = c;
+  HIP_TRY(hipGetLastError());
+  return PPASR_OK;
+}
+
 }  // extern "C"

@@ -37,6 +37,15 @@ struct HeadW {
   int V, n_tiles;
 };
 
+// One entry per active session of a multi-session streaming call (ppasr_encode_chunk_group): which cache slot it
+// uses, how many frames that cache holds and the positional-table row of its first key.
+struct SessDesc {
+  int sess;     // slot in the group's cache arrays
+  int cache_t;  // cached frames before this chunk
+  int pos0;     // offset - cache_t  (encoder.py:253)
+  int pad;
+};
+
 // Attention operands: queries / keys / values may live in different buffers (streaming reads K/V from
 // the per-layer device caches).  Row strides in floats; utterance b starts at row b*T1 (q, ctx) / b*T2 (k, v).
 struct AttnArgs {
@@ -56,6 +65,10 @@ struct AttnArgs {
   int mask_mul;         // key j is PAD iff mask_mul*j >= len (4; 8 on time-reduced layers; x3 when grouped)
   int q_frames, kv_frames;  // valid frames behind the query / key tokens (== T1 / T2 unless grouped)
   int group;            // 1, or 3 = GroupedRelPositionMultiHeadedAttention (pos_u / pos_v are then [h][192])
+  // multi-session streaming (plain heads only): utterance b = session sess[b]: keys / values at k + sess*sess_stride,
+  // T2 = cache_t + T1 keys, positional rows from pos0; nullptr otherwise
+  const SessDesc* sess;
+  long long sess_stride;
 };
 
 // ---- launchers (all asynchronous on `st`) ----
@@ -84,6 +97,13 @@ void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2
 void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, float* g, const LayerW& w, hipStream_t st);
 void launch_pw1_glu(const float* xhat, float* g, const LayerW& w, int M, hipStream_t st);
 void launch_kv_append(const float* qkv, float* kc, float* vc, int n_rows, hipStream_t st);
+// multi-session variants: row (b, t) of the chunk batch <-> session sess[b]
+void launch_kv_append_group(const float* qkv, float* kc, float* vc, long long sess_stride, const SessDesc* sess, int n, int c,
+                            hipStream_t st);
+void launch_hist_gather(const float* hist, long long sess_stride, const SessDesc* sess, float* dst, int n, int lo,
+                        hipStream_t st);
+void launch_hist_update_group(float* hist, long long sess_stride, const SessDesc* sess, const float* fresh, int n, int c,
+                              int lo, hipStream_t st);
 void launch_hist_update(float* hist, const float* fresh, int n, int lo, hipStream_t st);
 void launch_cache_export(const float* kc, const float* vc, float* att, int T, int div, hipStream_t st);
 void launch_cache_import(const float* att, float* kc, float* vc, int T, int div, hipStream_t st);

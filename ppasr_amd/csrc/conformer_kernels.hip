@@ -317,12 +317,20 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   float* stA = stL + C::QT;              // rescale alpha [64]
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const int q0 = blockIdx.x * C::QT, h = blockIdx.y, b = blockIdx.z;
-  const int T1 = a.T1, T2 = a.T2;                // tokens
-  const int F1 = a.q_frames, F2 = a.kv_frames;   // valid frames behind the tokens (== tokens when G == 1)
+  const int T1 = a.T1;                           // query tokens
+  int T2 = a.T2, F2 = a.kv_frames;               // key tokens / valid key frames (== tokens when G == 1)
+  const int F1 = a.q_frames;
   const float* __restrict__ qb = a.q + (size_t)b * F1 * a.q_stride;
   const float* __restrict__ kbp = a.k + (size_t)b * F2 * a.k_stride;
   const float* __restrict__ vbp = a.v + (size_t)b * F2 * a.v_stride;
   const float* __restrict__ ptab = a.ptab + (size_t)a.pos0 * kD;
+  if (a.sess) {  // multi-session streaming: per-session cache slot, length and position
+    const SessDesc d = a.sess[b];
+    T2 = F2 = d.cache_t + T1;
+    kbp = a.k + (size_t)d.sess * a.sess_stride;
+    vbp = a.v + (size_t)d.sess * a.sess_stride;
+    ptab = a.ptab + (size_t)d.pos0 * kD;
+  }
   const int pstride = a.pos_stride;
   float* __restrict__ ctx = a.ctx + (size_t)b * F1 * kD;
   const int64_t len_b = a.lens ? a.lens[b] : (int64_t)a.mask_mul * T2;
@@ -976,6 +984,65 @@ __global__ __launch_bounds__(256) void k_hist_update(float* __restrict__ hist, c
 }
 void launch_hist_update(float* hist, const float* fresh, int n, int lo, hipStream_t st) {
   hipLaunchKernelGGL(k_hist_update, dim3(1), dim3(256), 0, st, hist, fresh, n, lo);
+}
+
+// ---- multi-session streaming helpers (one launch for all active sessions) ----
+// keys / values of chunk row (b, t) -> cache row cache_t[b] + t of session sess[b]
+__global__ void k_kv_append_group(const float* __restrict__ qkv, float* __restrict__ kc, float* __restrict__ vc,
+                                  long long sess_stride, const SessDesc* __restrict__ sess, int c) {
+  const int row = blockIdx.x, t = threadIdx.x;  // 128 threads x float4 = 512 floats (k | v)
+  const int b = row / c, tt = row - b * c;
+  const SessDesc d = sess[b];
+  const size_t dst_row = (size_t)d.sess * sess_stride + (size_t)(d.cache_t + tt) * kD;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(qkv + (size_t)row * 768 + 256 + 4 * t);
+  float* dst = (t < 64) ? kc + dst_row + 4 * t : vc + dst_row + 4 * (t - 64);
+  *reinterpret_cast<f32x4*>(dst) = v;
+}
+void launch_kv_append_group(const float* qkv, float* kc, float* vc, long long sess_stride, const SessDesc* sess, int n, int c,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(k_kv_append_group, dim3(n * c), dim3(128), 0, st, qkv, kc, vc, sess_stride, sess, c);
+}
+// dst[b][lo][256] <- conv-module input history of session sess[b] (this layer)
+__global__ void k_hist_gather(const float* __restrict__ hist, long long sess_stride, const SessDesc* __restrict__ sess,
+                              float* __restrict__ dst, int lo) {
+  const int b = blockIdx.x / lo, j = blockIdx.x - b * lo, t = threadIdx.x;  // 64 threads x float4
+  *reinterpret_cast<f32x4*>(dst + ((size_t)b * lo + j) * kD + 4 * t) =
+      *reinterpret_cast<const f32x4*>(hist + (size_t)sess[b].sess * sess_stride + (size_t)j * kD + 4 * t);
+}
+void launch_hist_gather(const float* hist, long long sess_stride, const SessDesc* sess, float* dst, int n, int lo,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(k_hist_gather, dim3(n * lo), dim3(64), 0, st, hist, sess_stride, sess, dst, lo);
+}
+// hist[sess[b]] <- last `lo` rows of concat(hist[sess[b]], fresh[b][c]); one 256-thread block per session
+__global__ __launch_bounds__(256) void k_hist_update_group(float* __restrict__ hist, long long sess_stride,
+                                                           const SessDesc* __restrict__ sess,
+                                                           const float* __restrict__ fresh, int c, int lo) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float* h = hist + (size_t)sess[b].sess * sess_stride;
+  const float* f = fresh + (size_t)b * c * kD;
+  constexpr int kMaxPer = 32;
+  f32x4 tmp[kMaxPer / 4];
+  const int total = lo * 64;
+#pragma unroll
+  for (int i = 0; i < kMaxPer / 4; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < total) {
+      const int row = idx >> 6, c4 = idx & 63;
+      const int j = c + row;  // row index inside concat(hist, fresh)
+      tmp[i] = (j < lo) ? *reinterpret_cast<const f32x4*>(h + (size_t)j * kD + 4 * c4)
+                        : *reinterpret_cast<const f32x4*>(f + (size_t)(j - lo) * kD + 4 * c4);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kMaxPer / 4; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < total) *reinterpret_cast<f32x4*>(h + (size_t)(idx >> 6) * kD + 4 * (idx & 63)) = tmp[i];
+  }
+}
+void launch_hist_update_group(float* hist, long long sess_stride, const SessDesc* sess, const float* fresh, int n, int c,
+                              int lo, hipStream_t st) {
+  hipLaunchKernelGGL(k_hist_update_group, dim3(n), dim3(256), 0, st, hist, sess_stride, sess, fresh, c, lo);
 }
 
 // [T][256] (col = h*64+f) k/v caches  <->  reference att_cache layout [h][T][2*dk]  (attention.py:232)

@@ -86,8 +86,8 @@ struct PadRows {  // conv-module pad masking (convolution.py:104-106,138-140): f
 
 // Causal depthwise conv over the GLU output g [M][256] (row = frame): KS taps, left context KS-1.
 // Frames before the utterance start read `gp` = GLU(pointwise_conv1(0)) because the reference
-// zero-pads BEFORE pointwise_conv1 (convolution.py:108-126); with STREAM (single stream, rows are
-// frames of one chunk) they come from the cache rows g_hist [KS-1][256] instead.
+// zero-pads BEFORE pointwise_conv1 (convolution.py:108-126); with STREAM (rows = the frames of one chunk per
+// session, Tp frames each) they come from the session's cache rows g_hist [session][KS-1][256] instead.
 // The block's input window (KS-1 halo rows + 32 rows) and the tap weights are staged in LDS
 // (win_lds: (KS-1+32) x kLda floats, w_lds: KS x kLda floats -- both buffers are free at this point of
 // the kernels), so the phase needs few registers whatever KS is.  Output (conv + bias) -> bufA rows.
@@ -106,8 +106,7 @@ __device__ __forceinline__ void dwconv_phase(const float* __restrict__ g, const 
   for (int q = wave; q < LO + kRows; q += kWaves) {
     const int mq = r0 - left + q;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (STREAM && mq < 0) v = *reinterpret_cast<const f32x4*>(g_hist + (size_t)(LO + mq) * kD + 4 * lane);
-    else if (mq >= 0 && mq < M) v = *reinterpret_cast<const f32x4*>(g + (size_t)mq * kD + 4 * lane);
+    if (mq >= 0 && mq < M) v = *reinterpret_cast<const f32x4*>(g + (size_t)mq * kD + 4 * lane);
     *reinterpret_cast<f32x4*>(win_lds + q * kLda + 4 * lane) = v;
   }
   for (int j = wave; j < KS; j += kWaves)
@@ -119,14 +118,23 @@ __device__ __forceinline__ void dwconv_phase(const float* __restrict__ g, const 
 #pragma unroll
   for (int i = 0; i < RW; ++i) {
     const int row = wave * RW + i;
-    const int t = (r0 + row) % Tp;
+    const int m = r0 + row;
+    const int b = m / Tp, t = m - b * Tp;
+    // STREAM: left-context frames of this row's session (window rows left of the session start belong to another
+    // session's chunk, so they are replaced one by one)
+    const float* hist = STREAM ? g_hist + ((size_t)b * LO) * kD + 4 * lane : nullptr;
     f32x4 acc = bias;
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
       const f32x4 wj = *reinterpret_cast<const f32x4*>(w_lds + j * kLda + 4 * lane);
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(win_lds + (row + j) * kLda + 4 * lane);
-      const int tt = t - left + j;  // frame this tap reads inside the utterance
-      acc += wj * ((STREAM || (tt >= 0 && tt < Tp)) ? xv : gp);
+      f32x4 xv = *reinterpret_cast<const f32x4*>(win_lds + (row + j) * kLda + 4 * lane);
+      const int tt = t - left + j;  // frame this tap reads inside the utterance / chunk
+      if (STREAM) {
+        if (tt < 0 && m < M) xv = *reinterpret_cast<const f32x4*>(hist + (size_t)(LO + tt) * kD);
+      } else if (!(tt >= 0 && tt < Tp)) {
+        xv = gp;
+      }
+      acc += wj * xv;
     }
     *reinterpret_cast<f32x4*>(bufA + row * kLda + 4 * lane) = acc;
   }

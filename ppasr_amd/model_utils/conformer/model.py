@@ -279,3 +279,62 @@ class ConformerStream:
                                                           None if cnn is None else cnn.data_ptr(), int(offset),
                                                           stream))
             torch.cuda.current_stream(m.device).synchronize()  # att / cnn temporaries must outlive the copy
+
+
+class ConformerStreamGroup:
+    """Many streaming sessions advanced together (no reference counterpart: PPASR streams one session per call,
+    predict.py:232-337).  The sessions' K/V and conv caches live in one device allocation;
+    ``encode_chunks(sessions, feats)`` advances the listed sessions by one chunk each with ONE set of kernel launches
+    (their rows are stacked), so a server's throughput is no longer bound by per-chunk launch overhead.  Every session
+    follows ``ConformerStream.encode_chunk(chunk, required_cache_size=-16)`` exactly (full history)."""
+
+    def __init__(self, model, n_sessions, max_frames=0):
+        self.model = model
+        self.lib = model.lib
+        self.n_sessions = int(n_sessions)
+        self._g = ctypes.c_void_p()
+        with torch.cuda.device(model.device):
+            _lib.check(self.lib.ppasr_stream_group_create(model._h, self.n_sessions, int(max_frames),
+                                                          ctypes.byref(self._g)))
+        self._ws = {}
+
+    def __del__(self):
+        g = getattr(self, "_g", None)
+        if g is not None and g.value:
+            self.lib.ppasr_stream_group_destroy(g)
+            self._g = None
+
+    def offset(self, session):
+        return int(self.lib.ppasr_stream_group_offset(self._g, int(session)))
+
+    def reset(self, session=-1):
+        m = self.model
+        with torch.cuda.device(m.device):
+            _lib.check(self.lib.ppasr_stream_group_reset(self._g, int(session),
+                                                         torch.cuda.current_stream(m.device).cuda_stream))
+
+    def encode_chunks(self, sessions, speech, want_probs=False):
+        """sessions: list of distinct slot indices (len n); speech [n,t,F] -> (frame_argmax [n,c] i32, frame_maxprob [n,c])
+        device tensors, plus ctc_probs [n,c,V] when ``want_probs``."""
+        m = self.model
+        x = torch.as_tensor(speech, dtype=torch.float32).to(m.device).contiguous()
+        n, T = int(x.shape[0]), int(x.shape[1])
+        assert x.dim() == 3 and x.shape[2] == m.input_dim and n == len(sessions)
+        c = m.out_frames(T)
+        need = int(self.lib.ppasr_group_chunk_workspace_bytes(m._h, n, T))
+        key = torch.cuda.current_stream(m.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=m.device)
+            self._ws[key] = ws
+        probs = torch.empty(n, c, m.vocab_size, dtype=torch.float32, device=m.device) if want_probs else None
+        fa = torch.empty(n, c, dtype=torch.int32, device=m.device)
+        fp = torch.empty(n, c, dtype=torch.float32, device=m.device)
+        ids = (ctypes.c_int * n)(*[int(s) for s in sessions])
+        c_out = ctypes.c_int(0)
+        with torch.cuda.device(m.device):
+            _lib.check(self.lib.ppasr_encode_chunk_group(self._g, ids, n, x.data_ptr(), T,
+                                                         None if probs is None else probs.data_ptr(), fa.data_ptr(),
+                                                         fp.data_ptr(), ctypes.byref(c_out), ws.data_ptr(), ws.numel(),
+                                                         key))
+        return (fa, fp, probs) if want_probs else (fa, fp)

@@ -83,3 +83,42 @@ def test_stateless_chunk_signature_and_one_giant_chunk():
     torch.cuda.synchronize()
     assert _rel(got2.cpu().numpy(), ref2.numpy()) < TOL
     assert att2.shape[2] == r_att.shape[2] + 16
+
+
+def test_session_group_equals_independent_streams():
+    """ppasr_encode_chunk_group: sessions that start at different times (different offsets / cache lengths) advanced with
+    one set of launches give exactly what independent single-session streams give."""
+    from ppasr_amd.model_utils.conformer.model import ConformerStreamGroup
+    L, V = 2, 150
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=61, perturb_norm=True)
+    model = _model(sd, V, L)
+    n_sessions, n_rounds = 5, 6
+    feats = [synth_features(1, 64 * n_rounds + 3, seed=70 + s)[0] for s in range(n_sessions)]
+    group = ConformerStreamGroup(model, n_sessions, max_frames=256)
+    singles = [model.new_stream() for _ in range(n_sessions)]
+    start = [0, 0, 1, 2, 4]  # round in which each session joins
+    for r in range(n_rounds):
+        active = [s for s in range(n_sessions) if r >= start[s]]
+        if r == 3:
+            active.remove(1)  # a session may skip a round
+        chunks = np.concatenate([feats[s][:, 64 * (r - start[s]) - (64 if (s == 1 and r > 3) else 0):][:, :67]
+                                 for s in active], axis=0)
+        fa, fp, probs = group.encode_chunks(active, chunks, want_probs=True)
+        torch.cuda.synchronize()
+        for i, s in enumerate(active):
+            ref = singles[s].encode_chunk(chunks[i:i + 1], -16)
+            torch.cuda.synchronize()
+            assert group.offset(s) == singles[s].offset
+            err = _rel(probs[i].cpu().numpy(), ref[0].cpu().numpy())
+            assert err < 1e-5, (r, s, err)
+            assert np.array_equal(fa[i].cpu().numpy(), ref[0].argmax(dim=1).cpu().numpy())
+    # reset one session: it restarts from offset 0 while the others keep their state
+    group.reset(2)
+    singles[2].reset()
+    fa, fp, probs = group.encode_chunks([2, 0], np.concatenate([feats[2][:, :67], feats[0][:, 64 * n_rounds - 64:][:, :67]]),
+                                        want_probs=True)
+    ref2 = singles[2].encode_chunk(feats[2][:, :67], -16)
+    torch.cuda.synchronize()
+    assert group.offset(2) == 16 and _rel(probs[0].cpu().numpy(), ref2[0].cpu().numpy()) < 1e-5
+    with pytest.raises(Exception):
+        group.encode_chunks([1, 1], np.concatenate([feats[1][:, :67]] * 2))

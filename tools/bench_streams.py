@@ -31,3 +31,21 @@ for n_sessions in (1, 8, 32, 64):
     audio = n_sessions * n_chunks * 0.64
     print(json.dumps({"sessions": n_sessions, "ms_per_chunk_round": round(dt / n_chunks * 1e3, 2),
                       "audio_s_per_s": round(audio / dt, 1)}), flush=True)
+
+# ---- the same sessions advanced as ONE group call per chunk round ----
+from ppasr_amd.model_utils.conformer.model import ConformerStreamGroup
+for n_sessions in (8, 64, 256, 496):
+    group = ConformerStreamGroup(model, n_sessions, max_frames=16 * (n_chunks * 2 + 2))
+    batch = chunk.repeat(n_sessions, 1, 1).contiguous()
+    ids = list(range(n_sessions))
+    for rep in range(2):
+        group.reset()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n_chunks):
+            group.encode_chunks(ids, batch)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+    print(json.dumps({"group_sessions": n_sessions, "ms_per_chunk_round": round(dt / n_chunks * 1e3, 2),
+                      "audio_s_per_s": round(n_sessions * n_chunks * 0.64 / dt, 1)}), flush=True)
+    del group
