@@ -151,3 +151,39 @@ def test_evaluate_harness_greedy_cer():
             cnt += 1
     got = evaluate(model, batches, vocab, decoder="ctc_greedy", metrics_type="cer")
     assert got == pytest.approx(want / cnt) and 0.0 <= got < 0.2
+
+
+def test_stream_pool_equals_predict_stream_per_session():
+    """serving.StreamPool (session groups) reproduces PPASRPredictor.predict_stream for every session."""
+    from ppasr_amd.predict import PPASRPredictor
+    from ppasr_amd.serving import StreamPool
+    V = 300
+    vocab = synth_vocabulary(V)
+    sd = conformer_state_dict(vocab_size=V, num_blocks=2, seed=3)
+    cfg = _cfg(decoder="ctc_greedy")
+    wavs = [_audio(2.4, seed=s) for s in range(3)]
+    pcms = [(np.clip(w, -1, 1) * 32767).astype(np.int16).tobytes() for w in wavs]
+    step = 16000 * 2 // 2  # 0.5 s packets
+    want = []
+    p = PPASRPredictor(configs=cfg, state_dict=sd, vocab_list=vocab, warmup=False)
+    for pcm in pcms:
+        p.reset_stream()
+        out = None
+        for i in range(0, len(pcm), step):
+            out = p.predict_stream(audio_data=pcm[i:i + step], is_end=False) or out
+        want.append(out)
+    pool = StreamPool(p.predictor.model, vocab, n_sessions=3, preprocess_conf=cfg["preprocess_conf"])
+    got = [None] * 3
+    for i in range(0, max(len(x) for x in pcms), step):
+        for s, pcm in enumerate(pcms):
+            if i < len(pcm) and not (s == 2 and i == 0):  # session 2 joins one packet late...
+                pool.feed(s, pcm[i - step if s == 2 else i:][:step])
+        for s, r in pool.step().items():
+            got[s] = r
+    pool.feed(2, pcms[2][len(pcms[2]) - step:])  # ...and receives its last packet afterwards
+    for s, r in pool.step().items():
+        got[s] = r
+    for s in range(3):
+        assert got[s] is not None and want[s] is not None
+        assert got[s]["text"] == want[s]["text"], s
+        assert abs(got[s]["score"] - want[s]["score"]) < 1e-3
