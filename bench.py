@@ -149,7 +149,7 @@ def main():
         except OSError:
             pass
         roofline = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC)",
                     "avg_launch_ms": kernels[dom]["avg_ms"],
                     "whole_path_tflops_per_gpu": round(sum(per_utt[k] * acc[k][1] / reps for k in acc) * B
                                                        / (ms_per_step * 1e-3) / 1e12, 2),
