@@ -49,6 +49,10 @@ __device__ __forceinline__ uint32_t desc_key(float s) {
   u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
   return ~u;
 }
+__device__ __forceinline__ float score_of_key(uint32_t key) {  // inverse of desc_key
+  const uint32_t v = ~key;
+  return __uint_as_float((v & 0x80000000u) ? (v & 0x7fffffffu) : ~v);
+}
 // unique total-order key: score desc | (char+1) asc | element id asc
 __device__ __forceinline__ uint64_t make_key(float score, int ch, int id) {
   return ((uint64_t)desc_key(score) << 32) | ((uint64_t)(uint32_t)(ch + 1) << 18) | (uint64_t)(uint32_t)id;
@@ -163,7 +167,6 @@ size_t beam_lds_bytes(const BeamConfig& c) {
   n += (size_t)2 * c.beam * (24 + 4 * kLmCtx);     // two beam halves
   n += (size_t)c.beam * 12;                        // new_b, new_nb, new_score
   n += (size_t)Vp * 2;                             // kidx (int16)
-  if (c.lm.order > 0) n += (size_t)c.beam * c.n_cand_max * 4;  // LM term of every (hypothesis, candidate) pair
   n += (((size_t)c.beam * c.n_cand_max) + 3) & ~(size_t)3;  // exists flags
   n += (size_t)c.beam * (1 + c.n_cand_max) * 4;    // score keys
   return (n + 15) & ~(size_t)15;
@@ -206,8 +209,6 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
   float* new_score = reinterpret_cast<float*>(p); p += beam * 4;
   int16_t* kidx = reinterpret_cast<int16_t*>(p); p += (size_t)Vp * 2;
   const bool has_lm = cfg.lm.order > 0;
-  float* lm_sc = reinterpret_cast<float*>(p);  // [nb][C] alpha * log P_lm of child (hypothesis, candidate)
-  if (has_lm) p += (size_t)beam * CM * 4;
   uint8_t* exists = reinterpret_cast<uint8_t*>(p); p += (((size_t)beam * CM) + 3) & ~(size_t)3;
   uint32_t* skey = reinterpret_cast<uint32_t*>(p);  // [beam * (1 + CM)] score keys of the frame's elements
 
@@ -406,22 +407,16 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       for (int w = 1; w < kBW; ++w) m = fminf(m, red_p[w]);
       min_cutoff = (float)((double)m + log((double)row[blank]) - fmax(0.0, cfg.beta));
       full_beam = (nb == beam);
-      for (int r = tid; r < nb * C; r += kBT) {
-        const int i = r / C, k = r - i * C;
-        const int c = cand_c[k];
-        float sc = 0.f;
-        if (c != blank) {
-          int32_t win[kLmMaxOrder];
-          const int order = cfg.lm.order;
-          for (int j = 0; j < order - 1; ++j) win[j] = cur.ctx[i * kLmCtx + (kLmCtx - (order - 1)) + j];
-          win[order - 1] = cfg.lm.tok2lm[c];
-          sc = (float)(lm_log_cond_prob(cfg.lm, win) * cfg.alpha);
-        }
-        lm_sc[r] = sc;
-      }
-      __syncthreads();
     }
     auto pruned = [&](float lp_c, int q) -> bool { return full_beam && (lp_c + cur.score[q] < min_cutoff); };
+    // alpha * ln P_lm(c | last order-1 words of hypothesis i): the scorer term of the extension (i, c)
+    auto lm_term = [&](int i, int c) -> float {
+      int32_t win[kLmMaxOrder];
+      const int order = cfg.lm.order;
+      for (int j = 0; j < order - 1; ++j) win[j] = cur.ctx[i * kLmCtx + (kLmCtx - (order - 1)) + j];
+      win[order - 1] = cfg.lm.tok2lm[c];
+      return (float)(lm_log_cond_prob(cfg.lm, win) * cfg.alpha);
+    };
     // log-probability carried by the extension of hypothesis i with candidate k (its LM term included)
     auto ext_logp = [&](int i, int k) -> float {
       const int c = cand_c[k];
@@ -429,7 +424,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       if (c == cur.chr[i]) { if (cur.b[i] > kNegInf) log_p = cand_lp[k] + cur.b[i]; }
       else log_p = cand_lp[k] + cur.score[i];
       if (has_lm) {
-        log_p += lm_sc[i * C + k];
+        log_p += lm_term(i, c);
         log_p = (float)((double)log_p + cfg.beta);
       }
       return log_p;
@@ -485,7 +480,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
             if (c == ci) { if (bi > kNegInf) log_p = lpk + bi; }
             else log_p = lpk + si;
             if (has_lm) {
-              log_p += lm_sc[i * C + k];
+              log_p += lm_term(i, c);
               log_p = (float)((double)log_p + cfg.beta);
             }
             key = desc_key(log_p);
@@ -580,7 +575,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       } else {
         const int r = e - nb, i = r / C, kk = r - i * C;
         const int c = cand_c[kk];
-        const float log_p = ext_logp(i, kk);
+        const float log_p = score_of_key(skey[e]);  // the extension's log-probability, computed once in (e)
         for (int j = 0; j + 1 < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[i * kLmCtx + j + 1];
         nxt.ctx[pos * kLmCtx + kLmCtx - 1] = has_lm ? cfg.lm.tok2lm[c] : 0;
         const int id = n_nodes + pos;

@@ -51,6 +51,7 @@ def _oracle_lm_decode(lib, chunks, V, beam, cutoff_prob, top_n, lm, alpha, beta,
     (80, 300, 8, 5, 0.5, -1.5, "peaky"),     # negative beta: max(0, beta) in min_cutoff
     (50, 4233, 10, 4, 2.2, 4.3, "peaky"),
     (30, 120, 300, 3, 2.2, 4.3, "flat"),     # the reference's default beam_size
+    (20, 4233, 300, 3, 2.2, 4.3, "flat"),    # ... with the full vocabulary (LDS budget of beam x candidates)
     (1, 120, 5, 3, 2.2, 4.3, "flat"),
 ])
 def test_beam_search_with_scorer_matches_c_oracle(tmp_path, T, V, beam, order, alpha, beta, kind):
@@ -124,3 +125,32 @@ def test_scorer_rejects_unsupported_models(tmp_path):
         Scorer(1.0, 1.0, str(word), vocab)
     with pytest.raises(Exception, match="not found"):
         Scorer(1.0, 1.0, str(tmp_path / "missing.arpa"), vocab)
+
+
+def test_seeded_fuzz_against_oracle(tmp_path):
+    """Random (frames, vocabulary, beam, pruning, scorer on/off, weights) draws: best hypothesis and score equal the C oracle."""
+    from ppasr_amd.decoders.beam_search_decoder import Scorer, beam_search_ids
+    lib = _oracle()
+    for seed in range(24):
+        rng = np.random.Generator(np.random.PCG64(5000 + seed))
+        T = int(rng.integers(1, 100))
+        V = int(rng.choice([40, 97, 300, 1000, 4233]))
+        beam = int(rng.choice([1, 2, 5, 10, 33, 100, 300]))
+        order = int(rng.integers(2, 6))
+        use_lm = bool(rng.integers(0, 2))
+        kind = str(rng.choice(["peaky", "flat"]))
+        cp, tn = float(rng.choice([0.99, 0.9, 0.5])), int(rng.choice([40, 10, 3]))
+        alpha, beta = float(rng.uniform(0.2, 3)), float(rng.uniform(-2, 5))
+        vocab = _vocab(V)
+        lm = scorer = None
+        if use_lm:
+            known = [c for c in vocab[2:-1] if rng.random() < 0.8][:300]
+            arpa = write_synthetic_arpa(str(tmp_path / f"lm{seed}.arpa"), known, order=order, seed=seed)
+            lm = read_arpa(arpa, vocab)
+            scorer = Scorer(alpha, beta, arpa, vocab)
+        p = _probs(rng, T, V, kind)
+        tk, ln, sc, _ = beam_search_ids(torch.from_numpy(p)[None].cuda(), beam, cp, tn, 0, nbest=1, ext_scorer=scorer)
+        ref = _oracle_lm_decode(lib, [p], V, beam, cp, tn, lm, alpha, beta, 1)
+        got = tk[0, 0, :int(ln[0, 0])].cpu().numpy().tolist()
+        assert got == ref[0][0], (seed, T, V, beam, use_lm)
+        assert abs(float(sc[0, 0]) - ref[0][1]) <= 2e-4 * max(1.0, abs(ref[0][1])), (seed, float(sc[0, 0]), ref[0][1])
