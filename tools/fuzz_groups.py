@@ -1,0 +1,37 @@
+"""Ad-hoc fuzz of session groups: random subsets of sessions advance by random chunk lengths each round; every session must
+equal an independent single-session stream fed the same chunks."""
+import sys, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ppasr_amd.model_utils.conformer.model import ConformerModel, ConformerStreamGroup
+from ppasr_amd.utils.synth import conformer_state_dict, synth_features
+
+V, L = 120, 3
+sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=5, perturb_norm=True)
+conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
+model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd)
+bad = 0; n = 0
+for seed in range(6):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    S = int(rng.integers(2, 40))
+    group = ConformerStreamGroup(model, S, max_frames=1200)
+    singles = [model.new_stream() for _ in range(S)]
+    for rnd in range(8):
+        k = int(rng.integers(1, S + 1))
+        active = sorted(rng.choice(S, size=k, replace=False).tolist())
+        T = int(rng.choice([67, 67, 35, 99, 23, 8, 131]))
+        if rng.random() < 0.1:
+            s = int(rng.integers(0, S)); group.reset(s); singles[s].reset()
+        x = np.concatenate([synth_features(1, T, seed=seed * 1000 + rnd * 50 + s)[0] for s in active], axis=0)
+        fa, fp, probs = group.encode_chunks(active, x, want_probs=True)
+        torch.cuda.synchronize()
+        for i, s in enumerate(active):
+            ref = singles[s].encode_chunk(x[i:i + 1], -16)
+            torch.cuda.synchronize()
+            err = float((probs[i] - ref[0]).abs().max() / ref[0].abs().max())
+            n += 1
+            if err > 1e-5 or group.offset(s) != singles[s].offset:
+                bad += 1
+                print("MISMATCH", seed, rnd, s, T, err, group.offset(s), singles[s].offset)
+    del group
+print("fuzz_groups done:", n, "session-chunks,", bad, "problems")
