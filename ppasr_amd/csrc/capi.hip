@@ -445,12 +445,17 @@ static ppasr_status beam_config(int V, int beam_size, double cutoff_prob, int cu
   return PPASR_OK;
 }
 
+// state buffer = B x [header | beam arrays | arena of 1 + (F+1)*beam nodes] | B status words | scratch of the pruning
+// pre-pass (B x F frame records of the largest record size), F = max_frames.  The layout is recomputed from
+// (state_bytes, B, beam_size) on every call, so it is the same for every chunk of a streaming decode.
+static size_t beam_utt_fixed_bytes(int beam_size) {
+  return 4 + 4 * (2 + (size_t)kBeamStateArrays * beam_size) + 8 * (size_t)(1 + beam_size);
+}
+static size_t beam_frame_bytes(int beam_size) { return 8 * (size_t)beam_size + 4 * (size_t)prune_rec_words(kMaxBeamCand); }
+
 size_t ppasr_ctc_beam_state_bytes(int B, int max_frames, int beam_size) {
   if (B <= 0 || max_frames < 0 || beam_size < 1) return 0;
-  BeamConfig c{};
-  c.beam = beam_size;
-  c.max_nodes = 1 + (max_frames + 1) * beam_size;
-  return (size_t)B * beam_state_bytes(c) + (size_t)B * sizeof(int32_t);
+  return (size_t)B * (beam_utt_fixed_bytes(beam_size) + (size_t)max_frames * beam_frame_bytes(beam_size));
 }
 
 const ppasr::LmDev* ppasr_lm_device_view(ppasr_lm_handle lm);  // lm.hip
@@ -477,17 +482,19 @@ ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_l
   }
   ppasr_status s = beam_config(V, beam_size, cutoff_prob, cutoff_top_n, blank, nbest, max_tokens, &c);
   if (s != PPASR_OK) return s;
-  // state = B x [header | beam arrays | arena] + B status words; arena capacity from the buffer size
-  const size_t per_utt = (state_bytes - (size_t)B * 4) / (size_t)B / 4;  // words
-  const size_t fixed = 2 + (size_t)kBeamStateArrays * beam_size;
-  if (state_bytes < (size_t)B * 4 || per_utt < fixed + 2 * (size_t)(1 + 2 * beam_size))
+  const size_t per_utt_bytes = state_bytes / (size_t)B;
+  if (per_utt_bytes < beam_utt_fixed_bytes(beam_size) + beam_frame_bytes(beam_size))
     return fail(PPASR_ENOSPACE, "beam search: state buffer too small");
-  c.max_nodes = (int)((per_utt - fixed) / 2);
+  const size_t F = (per_utt_bytes - beam_utt_fixed_bytes(beam_size)) / beam_frame_bytes(beam_size);  // frame capacity
+  if ((size_t)T > F) return fail(PPASR_ENOSPACE, "beam search: more frames in one call than the state buffer was sized for");
+  const size_t fixed = 2 + (size_t)kBeamStateArrays * beam_size;
+  c.max_nodes = (int)(1 + (F + 1) * (size_t)beam_size);
   int32_t* st_words = static_cast<int32_t*>(state);
   int32_t* status = st_words + (size_t)B * (fixed + 2 * (size_t)c.max_nodes);
+  int32_t* prune_recs = status + B;
   hipStream_t hs = static_cast<hipStream_t>(stream);
   if (init_state) HIP_TRY(hipMemsetAsync(status, 0, (size_t)B * 4, hs));
-  HIP_TRY(launch_ctc_beam(probs, frame_lens, B, T, c, st_words, init_state, 1, tokens, lens, scores, status, hs));
+  HIP_TRY(launch_ctc_beam(probs, frame_lens, B, T, c, prune_recs, st_words, init_state, 1, tokens, lens, scores, status, hs));
   return PPASR_OK;
 }
 

@@ -24,10 +24,13 @@ struct BeamConfig {
   double alpha, beta;
 };
 
+// words of one frame record of the pruning pre-pass: C, p_blank, n_cand_max characters, n_cand_max log-probs
+__host__ __device__ inline int prune_rec_words(int n_cand_max) { return 2 + 2 * n_cand_max; }
 size_t beam_lds_bytes(const BeamConfig& c);
 size_t beam_state_bytes(const BeamConfig& c);  // per utterance
+// prune_recs: device scratch of B * T * prune_rec_words(cfg.n_cand_max) words
 hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B, int T, const BeamConfig& cfg,
-                           int32_t* state, int init_state, int finalize, int32_t* out_tokens, int32_t* out_lens,
+                           int32_t* prune_recs, int32_t* state, int init_state, int finalize, int32_t* out_tokens, int32_t* out_lens,
                            double* out_scores, int32_t* status, hipStream_t st);
 
 }  // namespace ppasr

@@ -161,7 +161,7 @@ __device__ __forceinline__ void select_bin(const int* hist, int k_rem, bool desc
 
 size_t beam_lds_bytes(const BeamConfig& c) {
   const int Vp = (c.V + 3) & ~3;
-  size_t n = 16 + 256 * 4 + 3 * (kBT / 64) * 4 + 32 + kMaxBeamCand * 8;  // scalars, histogram, reduction scratch, gather buffers
+  size_t n = 256 * 4 + 2 * (kBT / 64) * 4 + 32;    // histogram, reduction scratch, scalars
   n += (size_t)Vp * 4;                             // lp
   n += (size_t)kMaxBeamCand * 8;                   // cand_c, cand_lp
   n += (size_t)2 * c.beam * (24 + 4 * kLmCtx);     // two beam halves
@@ -180,68 +180,44 @@ __host__ __device__ inline size_t beam_state_words(int beam, int max_nodes) {
 }
 size_t beam_state_bytes(const BeamConfig& c) { return beam_state_words(c.beam, c.max_nodes) * 4; }
 
-__global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ probs, const int32_t* __restrict__ frame_lens,
-                                                  int T, BeamConfig cfg, int32_t* __restrict__ state, int init_state,
-                                                  int finalize, int32_t* __restrict__ out_tokens,
-                                                  int32_t* __restrict__ out_lens, double* __restrict__ out_scores,
-                                                  int32_t* __restrict__ status) {
+constexpr int kPruneThreads = 256;
+static size_t prune_lds_bytes(const BeamConfig& c) {
+  const int Vp = (c.V + 3) & ~3;
+  return (16 + 256 * 4 + 2 * (kPruneThreads / 64) * 4 + 32 + 4 * kMaxBeamCand * 4 + (size_t)Vp * 4 + 15) & ~(size_t)15;
+}
+
+
+// ---- frame-parallel pre-pass: get_pruned_log_probs of every frame ----
+// The pruned character list of a frame does not depend on the beam, so it is computed for all frames at once by a
+// chip-wide launch (one workgroup per frame) instead of inside the sequential per-utterance loop.  Record of frame
+// (u, t) in HBM (int32 words): [0] C  [1] p_blank (raw probability, float bits)  [2 .. 2+CM) characters in
+// (prob desc, index asc) order  [2+CM .. 2+2CM) their log(p + FLT_MIN).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_ctc_prune(const float* __restrict__ probs, const int32_t* __restrict__ frame_lens,
+                                                  int T, BeamConfig cfg, int32_t* __restrict__ recs) {
+  constexpr int NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int u = blockIdx.x;
-  const int V = cfg.V, beam = cfg.beam, blank = cfg.blank, CM = cfg.n_cand_max;
+  const int t = blockIdx.x, u = blockIdx.y;
+  const int n_frames = frame_lens ? min(max(frame_lens[u], 0), T) : T;
+  if (t >= n_frames) return;
+  const int V = cfg.V, CM = cfg.n_cand_max, blank = cfg.blank;
   const int Vp = (V + 3) & ~3;
   char* p = smem;
-  double* sh_d = reinterpret_cast<double*>(p); p += 16;      // cumulative probability
+  double* sh_d = reinterpret_cast<double*>(p); p += 16;
   int* hist = reinterpret_cast<int*>(p); p += 256 * 4;
-  int* wave_tot = reinterpret_cast<int*>(p); p += kBW * 4;
-  float* red_p = reinterpret_cast<float*>(p); p += kBW * 4;
-  int* red_i = reinterpret_cast<int*>(p); p += kBW * 4;
-  int* sh_i = reinterpret_cast<int*>(p); p += 32;            // misc shared ints
-  int* tmp_c = reinterpret_cast<int*>(p); p += kMaxBeamCand * 4;     // unsorted pruned characters
+  float* red_p = reinterpret_cast<float*>(p); p += NW * 4;
+  int* red_i = reinterpret_cast<int*>(p); p += NW * 4;
+  int* sh_i = reinterpret_cast<int*>(p); p += 32;
+  int* tmp_c = reinterpret_cast<int*>(p); p += kMaxBeamCand * 4;
   float* tmp_p = reinterpret_cast<float*>(p); p += kMaxBeamCand * 4;
-  float* lp = reinterpret_cast<float*>(p); p += (size_t)Vp * 4;
   int* cand_c = reinterpret_cast<int*>(p); p += kMaxBeamCand * 4;
   float* cand_lp = reinterpret_cast<float*>(p); p += kMaxBeamCand * 4;
-  Beam cur = carve_beam(p, beam);
-  Beam nxt = carve_beam(p, beam);
-  float* new_b = reinterpret_cast<float*>(p); p += beam * 4;
-  float* new_nb = reinterpret_cast<float*>(p); p += beam * 4;
-  float* new_score = reinterpret_cast<float*>(p); p += beam * 4;
-  int16_t* kidx = reinterpret_cast<int16_t*>(p); p += (size_t)Vp * 2;
-  const bool has_lm = cfg.lm.order > 0;
-  uint8_t* exists = reinterpret_cast<uint8_t*>(p); p += (((size_t)beam * CM) + 3) & ~(size_t)3;
-  uint32_t* skey = reinterpret_cast<uint32_t*>(p);  // [beam * (1 + CM)] score keys of the frame's elements
-
-  int32_t* st = state + (size_t)u * beam_state_words(beam, cfg.max_nodes);
-  int32_t* g_arr = st + 2;
-  int32_t* arena = st + 2 + (size_t)kBeamStateArrays * beam;
-  int nb, n_nodes;
-  if (init_state) {
-    nb = 1;
-    n_nodes = 1;
-    if (tid == 0) {
-      cur.node[0] = 0; cur.chr[0] = -1; cur.par[0] = -1;
-      cur.b[0] = 0.f; cur.nb[0] = kNegInf; cur.score[0] = 0.f;  // root.score = root.log_prob_b_prev = 0
-      for (int j = 0; j < kLmCtx; ++j) cur.ctx[j] = cfg.lm.bos;  // Scorer::make_ngram pads with START_TOKEN
-      arena[0] = -1; arena[1] = -1;
-    }
-  } else {
-    nb = st[0];
-    n_nodes = st[1];
-    for (int i = tid; i < nb; i += kBT) {
-      cur.node[i] = g_arr[i]; cur.chr[i] = g_arr[beam + i]; cur.par[i] = g_arr[2 * beam + i];
-      cur.b[i] = __int_as_float(g_arr[3 * beam + i]); cur.nb[i] = __int_as_float(g_arr[4 * beam + i]);
-      cur.score[i] = __int_as_float(g_arr[5 * beam + i]);
-      for (int j = 0; j < kLmCtx; ++j) cur.ctx[i * kLmCtx + j] = g_arr[(6 + j) * beam + i];
-    }
-  }
-  __syncthreads();
-
-  const int n_frames = frame_lens ? min(max(frame_lens[u], 0), T) : T;
+  float* lp = reinterpret_cast<float*>(p); p += (size_t)Vp * 4;
   const bool prune = (cfg.cutoff_prob < 1.0) || (cfg.cutoff_top_n < V);
-  for (int t = 0; t < n_frames; ++t) {
+  {
     const float* row = probs + ((size_t)u * T + t) * V;
-    for (int v = tid; v < V; v += kBT) lp[v] = row[v];
+    for (int v = tid; v < V; v += NT) lp[v] = row[v];
     __syncthreads();
     // ---- (b) get_pruned_log_probs (decoder_utils.cpp): the n_sel largest probabilities in (prob desc, index asc)
     // order, cut where the cumulative probability reaches cutoff_prob.  Fast path: exact 4-pass radix select of the
@@ -262,7 +238,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
           __syncthreads();
           {
             RunHist rh(hist);
-            for (int v = tid; v < V; v += kBT) {
+            for (int v = tid; v < V; v += NT) {
               const uint32_t u = __float_as_uint(lp[v]);
               if ((u & hi_mask) == prefix) rh.add((int)((u >> shift) & 0xff));
             }
@@ -283,7 +259,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       if (!slow_path) {
         if (tid == 0) sh_i[4] = 0;
         __syncthreads();
-        for (int v = tid; v < V; v += kBT) {
+        for (int v = tid; v < V; v += NT) {
           const float pv = lp[v];
           if (__float_as_uint(pv) >= thr_u) {
             const int pos = atomicAdd(&sh_i[4], 1);
@@ -293,8 +269,8 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
         __syncthreads();
         const int n_got = min(sh_i[4], kMaxBeamCand);
         // rank sort (prob desc, index asc): 8 threads per element, each counting a slice of the list
-        if (tid < 8 * n_got) {
-          const int t = tid >> 3, part = tid & 7;
+        for (int idx = tid; idx < 8 * n_got; idx += NT) {  // (NT is a multiple of 8: the 8 parts of an element share a wave)
+          const int t = idx >> 3, part = idx & 7;
           const float pv = tmp_p[t];
           const int iv = tmp_c[t];
           int rank = 0;
@@ -342,7 +318,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       for (;;) {
         float bp = -INFINITY;
         int bi = 0x7fffffff;
-        for (int v = tid; v < V; v += kBT) {
+        for (int v = tid; v < V; v += NT) {
           float pv = lp[v];
           bool after = (pv < last_p) || (pv == last_p && v > last_i);
           if (after && (pv > bp || (pv == bp && v < bi))) { bp = pv; bi = v; }
@@ -357,7 +333,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
         __syncthreads();
         bp = red_p[0]; bi = red_i[0];
 #pragma unroll
-        for (int w = 1; w < kBW; ++w) {
+        for (int w = 1; w < NW; ++w) {
           float p2 = red_p[w]; int i2 = red_i[w];
           if (p2 > bp || (p2 == bp && i2 < bi)) { bp = p2; bi = i2; }
         }
@@ -381,14 +357,98 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       }
     } else if (!prune) {
       C = V;  // no pruning: vocabulary order (host guarantees V <= n_cand_max)
-      for (int v = tid; v < V; v += kBT) { cand_c[v] = v; cand_lp[v] = (float)log((double)lp[v] + (double)FLT_MIN); }
+      for (int v = tid; v < V; v += NT) { cand_c[v] = v; cand_lp[v] = (float)log((double)lp[v] + (double)FLT_MIN); }
       __syncthreads();
     }
-    // ---- (c) lp[] <- log-prob of candidates / marker; kidx[] <- candidate index ----
-    for (int v = tid; v < V; v += kBT) { lp[v] = kNotCand; kidx[v] = -1; }
+    int32_t* rec = recs + ((size_t)u * T + t) * prune_rec_words(CM);
+    if (tid == 0) { rec[0] = C; rec[1] = __float_as_int(lp[blank]); }
+    for (int k = tid; k < C; k += NT) { rec[2 + k] = cand_c[k]; rec[2 + CM + k] = __float_as_int(cand_lp[k]); }
+  }
+}
+
+__global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ probs, const int32_t* __restrict__ frame_lens,
+                                                  int T, BeamConfig cfg, const int32_t* __restrict__ recs,
+                                                  int32_t* __restrict__ state, int init_state,
+                                                  int finalize, int32_t* __restrict__ out_tokens,
+                                                  int32_t* __restrict__ out_lens, double* __restrict__ out_scores,
+                                                  int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u = blockIdx.x;
+  const int V = cfg.V, beam = cfg.beam, blank = cfg.blank, CM = cfg.n_cand_max;
+  const int Vp = (V + 3) & ~3;
+  char* p = smem;
+  int* hist = reinterpret_cast<int*>(p); p += 256 * 4;
+  int* wave_tot = reinterpret_cast<int*>(p); p += kBW * 4;
+  float* red_p = reinterpret_cast<float*>(p); p += kBW * 4;
+  int* sh_i = reinterpret_cast<int*>(p); p += 32;            // misc shared ints
+  float* lp = reinterpret_cast<float*>(p); p += (size_t)Vp * 4;
+  int* cand_c = reinterpret_cast<int*>(p); p += kMaxBeamCand * 4;
+  float* cand_lp = reinterpret_cast<float*>(p); p += kMaxBeamCand * 4;
+  Beam cur = carve_beam(p, beam);
+  Beam nxt = carve_beam(p, beam);
+  float* new_b = reinterpret_cast<float*>(p); p += beam * 4;
+  float* new_nb = reinterpret_cast<float*>(p); p += beam * 4;
+  float* new_score = reinterpret_cast<float*>(p); p += beam * 4;
+  int16_t* kidx = reinterpret_cast<int16_t*>(p); p += (size_t)Vp * 2;
+  const bool has_lm = cfg.lm.order > 0;
+  uint8_t* exists = reinterpret_cast<uint8_t*>(p); p += (((size_t)beam * CM) + 3) & ~(size_t)3;
+  uint32_t* skey = reinterpret_cast<uint32_t*>(p);  // [beam * (1 + CM)] score keys of the frame's elements
+
+  int32_t* st = state + (size_t)u * beam_state_words(beam, cfg.max_nodes);
+  int32_t* g_arr = st + 2;
+  int32_t* arena = st + 2 + (size_t)kBeamStateArrays * beam;
+  int nb, n_nodes;
+  if (init_state) {
+    nb = 1;
+    n_nodes = 1;
+    if (tid == 0) {
+      cur.node[0] = 0; cur.chr[0] = -1; cur.par[0] = -1;
+      cur.b[0] = 0.f; cur.nb[0] = kNegInf; cur.score[0] = 0.f;  // root.score = root.log_prob_b_prev = 0
+      for (int j = 0; j < kLmCtx; ++j) cur.ctx[j] = cfg.lm.bos;  // Scorer::make_ngram pads with START_TOKEN
+      arena[0] = -1; arena[1] = -1;
+    }
+  } else {
+    nb = st[0];
+    n_nodes = st[1];
+    for (int i = tid; i < nb; i += kBT) {
+      cur.node[i] = g_arr[i]; cur.chr[i] = g_arr[beam + i]; cur.par[i] = g_arr[2 * beam + i];
+      cur.b[i] = __int_as_float(g_arr[3 * beam + i]); cur.nb[i] = __int_as_float(g_arr[4 * beam + i]);
+      cur.score[i] = __int_as_float(g_arr[5 * beam + i]);
+      for (int j = 0; j < kLmCtx; ++j) cur.ctx[i * kLmCtx + j] = g_arr[(6 + j) * beam + i];
+    }
+  }
+  __syncthreads();
+
+  const int n_frames = frame_lens ? min(max(frame_lens[u], 0), T) : T;
+  // lp[] = log-prob of the frame's candidates / marker, kidx[] = candidate index: cleared once, then only the entries of
+  // the previous frame's characters are reset
+  for (int v = tid; v < V; v += kBT) { lp[v] = kNotCand; kidx[v] = -1; }
+  // per-frame records of the pruning pre-pass (k_ctc_prune); the next frame's record is fetched into registers while
+  // the current frame is processed
+  const int RW = prune_rec_words(CM);
+  const int32_t* rec_u = recs + (size_t)u * T * RW;
+  int pre_C = 0, pre_pb = 0, pre_c = 0, pre_lp = 0;
+  auto fetch = [&](int t) {
+    const int32_t* r = rec_u + (size_t)t * RW;
+    pre_C = r[0];
+    pre_pb = r[1];
+    if (tid < CM) { pre_c = r[2 + tid]; pre_lp = r[2 + CM + tid]; }
+  };
+  if (n_frames > 0) fetch(0);
+  __syncthreads();
+  for (int t = 0; t < n_frames; ++t) {
+    // ---- (b, c) this frame's pruned characters (get_pruned_log_probs, done by the pre-pass) ----
+    const int C = pre_C;
+    const float p_blank = __int_as_float(pre_pb);
+    if (tid < C) {
+      cand_c[tid] = pre_c;
+      cand_lp[tid] = __int_as_float(pre_lp);
+      lp[pre_c] = __int_as_float(pre_lp);
+      kidx[pre_c] = (int16_t)tid;
+    }
+    if (t + 1 < n_frames) fetch(t + 1);
     for (int e = tid; e < nb * C; e += kBT) exists[e] = 0;
-    __syncthreads();
-    for (int k = tid; k < C; k += kBT) { lp[cand_c[k]] = cand_lp[k]; kidx[cand_c[k]] = (int16_t)k; }
     __syncthreads();
     // ---- external scorer: pruning threshold of this frame and the LM term of every possible extension ----
     // (ctc_beam_search_decoder.cpp: prefixes sorted, min_cutoff = worst score + log(p_blank) - max(0, beta), and the
@@ -405,7 +465,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       __syncthreads();
       m = red_p[0];
       for (int w = 1; w < kBW; ++w) m = fminf(m, red_p[w]);
-      min_cutoff = (float)((double)m + log((double)row[blank]) - fmax(0.0, cfg.beta));
+      min_cutoff = (float)((double)m + log((double)p_blank) - fmax(0.0, cfg.beta));
       full_beam = (nb == beam);
     }
     auto pruned = [&](float lp_c, int q) -> bool { return full_beam && (lp_c + cur.score[q] < min_cutoff); };
@@ -584,6 +644,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
         nxt.b[pos] = kNegInf; nxt.nb[pos] = log_p; nxt.score[pos] = log_p;
       }
     }
+    if (tid < C) { lp[cand_c[tid]] = kNotCand; kidx[cand_c[tid]] = -1; }  // reset for the next frame
     __syncthreads();
     n_nodes += k_sel;
     nb = k_sel;
@@ -661,18 +722,27 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
 }
 
 hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B, int T, const BeamConfig& cfg,
-                           int32_t* state, int init_state, int finalize, int32_t* out_tokens, int32_t* out_lens,
-                           double* out_scores, int32_t* status, hipStream_t st) {
-  const size_t lds = beam_lds_bytes(cfg);
-  static size_t configured = 0;
+                           int32_t* prune_recs, int32_t* state, int init_state, int finalize, int32_t* out_tokens,
+                           int32_t* out_lens, double* out_scores, int32_t* status, hipStream_t st) {
+  const size_t lds = beam_lds_bytes(cfg), plds = prune_lds_bytes(cfg);
+  static size_t configured = 0, pconfigured = 0;
   if (lds > configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_beam),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     configured = lds;
   }
-  hipLaunchKernelGGL(k_ctc_beam, dim3(B), dim3(kBT), lds, st, probs, frame_lens, T, cfg, state, init_state, finalize,
-                     out_tokens, out_lens, out_scores, status);
+  if (plds > pconfigured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_prune<kPruneThreads>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+    if (e != hipSuccess) return e;
+    pconfigured = plds;
+  }
+  if (T > 0)
+    hipLaunchKernelGGL(k_ctc_prune<kPruneThreads>, dim3(T, B), dim3(kPruneThreads), plds, st, probs, frame_lens, T, cfg,
+                       prune_recs);
+  hipLaunchKernelGGL(k_ctc_beam, dim3(B), dim3(kBT), lds, st, probs, frame_lens, T, cfg, prune_recs, state, init_state,
+                     finalize, out_tokens, out_lens, out_scores, status);
   return hipGetLastError();
 }
 
