@@ -114,7 +114,8 @@ ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats);
  *   tokens [B,nbest,max_tokens] i32 (-1 padded), lens [B,nbest] (-1 = no such hypothesis),
  *   scores [B,nbest] f64 = -log P(prefix) (the upstream return convention).
  *   state: device scratch of ppasr_ctc_beam_state_bytes(B, max total frames, beam_size) bytes that
- *   holds the beam and the prefix arena (kept between chunk calls). */
+ *   holds the beam, the prefix arena (both kept between chunk calls) and the per-frame records of the
+ *   pruning pre-pass (get_pruned_log_probs of every frame of the call: T <= max total frames). */
 size_t ppasr_ctc_beam_state_bytes(int B, int max_frames, int beam_size);
 ppasr_status ppasr_ctc_beam_search(const float* probs, const int32_t* frame_lens, int B, int T, int V, int beam_size,
                                    double cutoff_prob, int cutoff_top_n, int blank, int nbest, int max_tokens,

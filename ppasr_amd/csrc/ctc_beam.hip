@@ -23,6 +23,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ctc_beam.h"
 
@@ -80,26 +81,38 @@ __device__ __forceinline__ Beam carve_beam(char*& p, int cap) {
   return b;
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load / store
+// (vmcnt(0)), which would serialise the record prefetch of the next frame and the arena stores with each step.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / row broadcasts (a few cycles per step; the
+// __shfl_up formulation goes through ds_bpermute, i.e. one LDS round trip per step -- and these scans sit on the
+// critical path of every frame).
+__device__ __forceinline__ int wave_incl_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
 // block-wide exclusive scan of one int per thread (256 threads = 4 waves); returns (exclusive, total)
-__device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /*[kBW] LDS*/, int& total) {
+template <int BW>
+__device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /*[BW] LDS, private to the call site*/, int& total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int incl = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int t = __shfl_up(incl, o);
-    if (lane >= o) incl += t;
-  }
+  const int incl = wave_incl_scan(v);
   if (lane == 63) wave_tot[wave] = incl;
-  __syncthreads();
+  lds_barrier();
   int base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < kBW; ++w) {
+  for (int w = 0; w < BW; ++w) {
     int t = wave_tot[w];
     if (w < wave) base += t;
     tot += t;
   }
-  __syncthreads();
-  total = tot;
+  total = tot;  // no trailing barrier: every call site owns its wave_tot[] and is separated from its next use by others
   return base + incl - v;
 }
 
@@ -119,6 +132,21 @@ struct RunHist {
   }
   __device__ __forceinline__ void flush() {
     if (cnt) atomicAdd(&hist[bin], cnt);
+    cnt = 0;
+  }
+  // flush called by ALL lanes of the wave: the pending runs that share the first pending lane's bin (in the leading-byte
+  // passes: all of them) are summed across the wave and cost one atomic instead of one per lane on the same address
+  __device__ __forceinline__ void flush_wave() {
+    const unsigned long long pend = __ballot(cnt > 0);
+    if (pend) {
+      const int lane = threadIdx.x & 63;
+      const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)pend) - 1);
+      const int b0 = __builtin_amdgcn_readlane(bin, leader);
+      const bool same = cnt > 0 && bin == b0;
+      const int total = __builtin_amdgcn_readlane(wave_incl_scan(same ? cnt : 0), 63);
+      if (lane == leader) atomicAdd(&hist[b0], total);
+      if (cnt > 0 && !same) atomicAdd(&hist[bin], cnt);
+    }
     cnt = 0;
   }
 };
@@ -157,11 +185,45 @@ __device__ __forceinline__ void select_bin(const int* hist, int k_rem, bool desc
   }
 }
 
+// select_bin computed redundantly by EVERY wave from the same LDS histogram: results in registers of all lanes, no
+// broadcast through LDS and no barrier
+__device__ __forceinline__ void select_bin_reg(const int* hist, int k_rem, int& bin, int& rank, int& count) {
+  const int lane = threadIdx.x & 63;
+  int c[4], sum = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    c[j] = hist[4 * lane + j];
+    sum += c[j];
+  }
+  const int incl = wave_incl_scan(sum);
+  int before = incl - sum;
+  const bool mine = (before < k_rem) && (incl >= k_rem);
+  int b = 0, r = 0, n = 0;
+  if (mine) {
+    bool found = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!found && before + c[j] >= k_rem) {
+        b = 4 * lane + j;
+        r = k_rem - before;
+        n = c[j];
+        found = true;
+      }
+      before += c[j];
+    }
+  }
+  const unsigned long long m = __ballot(mine);
+  const int src = __builtin_amdgcn_readfirstlane(m ? (__ffsll((long long)m) - 1) : 0);
+  bin = __builtin_amdgcn_readlane(b, src);
+  rank = __builtin_amdgcn_readlane(r, src);
+  count = __builtin_amdgcn_readlane(n, src);
+}
+
 }  // namespace
 
 size_t beam_lds_bytes(const BeamConfig& c) {
   const int Vp = (c.V + 3) & ~3;
-  size_t n = 256 * 4 + 2 * (kBT / 64) * 4 + 32;    // histogram, reduction scratch, scalars
+  size_t n = 8 * 256 * 4 + 3 * (kBT / 64) * 4 + 32;  // per-pass histograms, scan / reduction scratch, scalars
   n += (size_t)Vp * 4;                             // lp
   n += (size_t)kMaxBeamCand * 8;                   // cand_c, cand_lp
   n += (size_t)2 * c.beam * (24 + 4 * kLmCtx);     // two beam halves
@@ -366,7 +428,8 @@ __global__ __launch_bounds__(NT) void k_ctc_prune(const float* __restrict__ prob
   }
 }
 
-__global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ probs, const int32_t* __restrict__ frame_lens,
+template <int BT>
+__global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs, const int32_t* __restrict__ frame_lens,
                                                   int T, BeamConfig cfg, const int32_t* __restrict__ recs,
                                                   int32_t* __restrict__ state, int init_state,
                                                   int finalize, int32_t* __restrict__ out_tokens,
@@ -378,9 +441,9 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
   const int V = cfg.V, beam = cfg.beam, blank = cfg.blank, CM = cfg.n_cand_max;
   const int Vp = (V + 3) & ~3;
   char* p = smem;
-  int* hist = reinterpret_cast<int*>(p); p += 256 * 4;
-  int* wave_tot = reinterpret_cast<int*>(p); p += kBW * 4;
-  float* red_p = reinterpret_cast<float*>(p); p += kBW * 4;
+  int* hist = reinterpret_cast<int*>(p); p += 8 * 256 * 4;
+  int* wave_tot = reinterpret_cast<int*>(p); p += 2 * (BT / 64) * 4;
+  float* red_p = reinterpret_cast<float*>(p); p += (BT / 64) * 4;
   int* sh_i = reinterpret_cast<int*>(p); p += 32;            // misc shared ints
   float* lp = reinterpret_cast<float*>(p); p += (size_t)Vp * 4;
   int* cand_c = reinterpret_cast<int*>(p); p += kMaxBeamCand * 4;
@@ -411,7 +474,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
   } else {
     nb = st[0];
     n_nodes = st[1];
-    for (int i = tid; i < nb; i += kBT) {
+    for (int i = tid; i < nb; i += BT) {
       cur.node[i] = g_arr[i]; cur.chr[i] = g_arr[beam + i]; cur.par[i] = g_arr[2 * beam + i];
       cur.b[i] = __int_as_float(g_arr[3 * beam + i]); cur.nb[i] = __int_as_float(g_arr[4 * beam + i]);
       cur.score[i] = __int_as_float(g_arr[5 * beam + i]);
@@ -423,33 +486,54 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
   const int n_frames = frame_lens ? min(max(frame_lens[u], 0), T) : T;
   // lp[] = log-prob of the frame's candidates / marker, kidx[] = candidate index: cleared once, then only the entries of
   // the previous frame's characters are reset
-  for (int v = tid; v < V; v += kBT) { lp[v] = kNotCand; kidx[v] = -1; }
+  for (int v = tid; v < V; v += BT) { lp[v] = kNotCand; kidx[v] = -1; }
   // per-frame records of the pruning pre-pass (k_ctc_prune); the next frame's record is fetched into registers while
   // the current frame is processed
   const int RW = prune_rec_words(CM);
   const int32_t* rec_u = recs + (size_t)u * T * RW;
-  int pre_C = 0, pre_pb = 0, pre_c = 0, pre_lp = 0;
+  constexpr int KPT = (kMaxBeamCand + BT - 1) / BT;  // candidates per thread
+  int pre_C = 0, pre_pb = 0, pre_c[KPT], pre_lp[KPT];
   auto fetch = [&](int t) {
     const int32_t* r = rec_u + (size_t)t * RW;
     pre_C = r[0];
     pre_pb = r[1];
-    if (tid < CM) { pre_c = r[2 + tid]; pre_lp = r[2 + CM + tid]; }
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int k = tid + j * BT;
+      pre_c[j] = 0;
+      pre_lp[j] = 0;
+      if (k < CM) { pre_c[j] = r[2 + k]; pre_lp[j] = r[2 + CM + k]; }
+    }
   };
   if (n_frames > 0) fetch(0);
   __syncthreads();
+#ifdef PPASR_BEAM_TS
+  long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ts_last = wall_clock64(), ts_n = 0, ts_c = 0, ts_nb = 0;
+#define TS(i) do { if (tid == 0 && u == 0) { long long now = wall_clock64(); ts_acc[i] += now - ts_last; ts_last = now; } } while (0)
+#define TSN() do { ts_n += N; ts_c += C; ts_nb += nb; } while (0)
+#else
+#define TS(i)
+#define TSN()
+#endif
   for (int t = 0; t < n_frames; ++t) {
     // ---- (b, c) this frame's pruned characters (get_pruned_log_probs, done by the pre-pass) ----
     const int C = pre_C;
     const float p_blank = __int_as_float(pre_pb);
-    if (tid < C) {
-      cand_c[tid] = pre_c;
-      cand_lp[tid] = __int_as_float(pre_lp);
-      lp[pre_c] = __int_as_float(pre_lp);
-      kidx[pre_c] = (int16_t)tid;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int k = tid + j * BT;
+      if (k < C) {
+        cand_c[k] = pre_c[j];
+        cand_lp[k] = __int_as_float(pre_lp[j]);
+        lp[pre_c[j]] = __int_as_float(pre_lp[j]);
+        kidx[pre_c[j]] = (int16_t)k;
+      }
     }
     if (t + 1 < n_frames) fetch(t + 1);
-    for (int e = tid; e < nb * C; e += kBT) exists[e] = 0;
-    __syncthreads();
+    for (int e = tid; e < nb * C; e += BT) exists[e] = 0;
+    for (int i = tid; i < 8 * 256; i += BT) hist[i] = 0;  // 4 + 4 per-pass histograms of the two selects below
+    lds_barrier();
+    TS(0);
     // ---- external scorer: pruning threshold of this frame and the LM term of every possible extension ----
     // (ctc_beam_search_decoder.cpp: prefixes sorted, min_cutoff = worst score + log(p_blank) - max(0, beta), and the
     //  `break` on log_prob_c + prefix->score < min_cutoff once the beam is full: it skips the blank, repeat and
@@ -458,13 +542,13 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
     bool full_beam = false;
     if (has_lm) {
       float m = FLT_MAX;
-      for (int q = tid; q < nb; q += kBT) m = fminf(m, cur.score[q]);
+      for (int q = tid; q < nb; q += BT) m = fminf(m, cur.score[q]);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
       if (lane == 0) red_p[wave] = m;
-      __syncthreads();
+      lds_barrier();
       m = red_p[0];
-      for (int w = 1; w < kBW; ++w) m = fminf(m, red_p[w]);
+      for (int w = 1; w < (BT / 64); ++w) m = fminf(m, red_p[w]);
       min_cutoff = (float)((double)m + log((double)p_blank) - fmax(0.0, cfg.beta));
       full_beam = (nb == beam);
     }
@@ -489,9 +573,10 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       }
       return log_p;
     };
+    TS(1);
     // ---- (d) contributions received by the hypotheses already in the beam ----
     const float lpb = lp[blank];
-    for (int q = tid; q < nb; q += kBT) {
+    for (int q = tid; q < nb; q += BT) {
       const int cq = cur.chr[q];
       float bc = (lpb != kNotCand && !pruned(lpb, q)) ? lpb + cur.score[q] : kNegInf;
       float nbc = kNegInf;
@@ -511,12 +596,13 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       new_nb[q] = nbc;
       new_score[q] = lse(bc, nbc);
     }
-    __syncthreads();
+    lds_barrier();
+    TS(2);
     // ---- (e) element space: [0,nb) existing hypotheses, nb + i*C + k = child (i, cand k).  The 32-bit score key of
     // every element is computed ONCE into LDS (0xFFFFFFFF = not a candidate); thread t owns the contiguous range
     // [t*per, (t+1)*per) so that the compaction below keeps element order with a single block scan ----
     const int N = nb + nb * C;
-    const int per = (N + kBT - 1) / kBT;
+    const int per = (N + BT - 1) / BT;
     const int e_lo = min(tid * per, N), e_hi = min(e_lo + per, N);
     auto elem_char = [&](int e) -> int { return e < nb ? cur.chr[e] : cand_c[(e - nb) % C]; };
     int my_valid = 0;
@@ -551,37 +637,34 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
       }
     }
     int n_valid;
-    (void)block_excl_scan(my_valid, wave_tot, n_valid);  // (barriers inside: skey[] is complete afterwards)
+    (void)block_excl_scan<BT / 64>(my_valid, wave_tot, n_valid);  // (barrier inside: skey[] is complete afterwards)
     const int k_sel = n_valid >= beam ? beam : n_valid;
+    TS(3); TSN();
     // ---- (f) exact top-k_sel in prefix_compare order = ascending (score key, char, element id): MSD radix select of
     // the k_sel-th smallest 32-bit score key over the LDS array; if the threshold class has more members than slots
     // left (ties), a second select over (char, id) inside that class ----
     // 4-pass radix select of the k-th smallest value of f(e) over elements with pred(e); returns the value and how
     // many members of its class are needed (k_need) / exist (k_have)
-    auto radix_select32 = [&](auto&& value_of, int k, uint32_t& out, int& k_need, int& k_have) {
+    auto radix_select32 = [&](auto&& value_of, int k, int* hists, uint32_t& out, int& k_need, int& k_have) {
       uint32_t prefix = 0;
       int k_rem = k;
       k_have = 0;
       for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
         const uint32_t hi_mask = pass == 0 ? 0u : (~0u << (shift + 8));
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
+        int* h = hists + pass * 256;  // zeroed at the start of the frame; one histogram per pass = one barrier per pass
         {
-          RunHist rh(hist);
-          for (int e = tid; e < N; e += kBT) {
+          RunHist rh(h);
+          for (int e = tid; e < N; e += BT) {
             uint32_t v;
             if (value_of(e, v) && (v & hi_mask) == prefix) rh.add((int)((v >> shift) & 0xff));
           }
-          rh.flush();
+          rh.flush_wave();
         }
-        __syncthreads();
-        if (wave == 0) select_bin(hist, k_rem, false, sh_i);
-        __syncthreads();
-        prefix |= (uint32_t)sh_i[0] << shift;
-        k_rem = sh_i[1];
-        k_have = sh_i[2];
-        __syncthreads();
+        lds_barrier();
+        int bin;
+        select_bin_reg(h, k_rem, bin, k_rem, k_have);
+        prefix |= (uint32_t)bin << shift;
         if (k_have == k_rem && shift > 0) {  // the searched value is the last of its class: take the whole class
           prefix |= (1u << shift) - 1u;
           break;
@@ -594,7 +677,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
     bool exact_class = false;                        // thr1 names one exact key value whose class is only partly taken
     if (k_sel < n_valid) {
       int need, have;
-      radix_select32([&](int e, uint32_t& v) { v = skey[e]; return v != 0xFFFFFFFFu; }, k_sel, thr1, need, have);
+      radix_select32([&](int e, uint32_t& v) { v = skey[e]; return v != 0xFFFFFFFFu; }, k_sel, hist, thr1, need, have);
       // after an early exit thr1 is an upper bound of a wholly taken class; after 4 passes it is an exact key value
       if (need < have) {
         exact_class = true;
@@ -604,9 +687,10 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
           if (skey[e] != eq) return false;
           v = ((uint32_t)(elem_char(e) + 1) << 18) | (uint32_t)e;
           return true;
-        }, need, thr2, n2, h2);
+        }, need, hist + 4 * 256, thr2, n2, h2);
       }
     }
+    TS(5);
     auto keeps = [&](int e) -> bool {
       const uint32_t v = skey[e];
       if (v == 0xFFFFFFFFu) return false;
@@ -619,14 +703,15 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
     int my_keep = 0;
     for (int e = e_lo; e < e_hi; ++e) my_keep += keeps(e) ? 1 : 0;
     int tot_keep;
-    int wpos = block_excl_scan(my_keep, wave_tot, tot_keep);
+    int wpos = block_excl_scan<BT / 64>(my_keep, wave_tot + BT / 64, tot_keep);
     int* surv = nxt.par;  // temporary list in the next beam's `par` column: slot p is read, then overwritten, by thread p
     for (int e = e_lo; e < e_hi; ++e) {
       if (!keeps(e) || wpos >= beam) continue;
       surv[wpos++] = e;
     }
-    __syncthreads();
-    for (int pos = tid; pos < k_sel; pos += kBT) {
+    lds_barrier();
+    TS(6);
+    for (int pos = tid; pos < k_sel; pos += BT) {
       const int e = surv[pos];
       if (e < nb) {
         nxt.node[pos] = cur.node[e]; nxt.chr[pos] = cur.chr[e]; nxt.par[pos] = cur.par[e];
@@ -644,8 +729,9 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
         nxt.b[pos] = kNegInf; nxt.nb[pos] = log_p; nxt.score[pos] = log_p;
       }
     }
-    if (tid < C) { lp[cand_c[tid]] = kNotCand; kidx[cand_c[tid]] = -1; }  // reset for the next frame
-    __syncthreads();
+    for (int k = tid; k < C; k += BT) { lp[cand_c[k]] = kNotCand; kidx[cand_c[k]] = -1; }  // reset for the next frame
+    lds_barrier();
+    TS(7);
     n_nodes += k_sel;
     nb = k_sel;
     if (n_nodes + beam > cfg.max_nodes) {  // arena exhausted: report, stop consuming frames
@@ -656,9 +742,15 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
     Beam tmp = cur; cur = nxt; nxt = tmp;
   }
   __syncthreads();
+#ifdef PPASR_BEAM_TS
+  if (tid == 0 && u == 0 && n_frames > 0)
+    printf("beam ts (x10ns/frame): inst %lld lm %lld contrib %lld keys %lld sel %lld keep %lld mat %lld | N %lld C %lld nb %lld frames %d\n",
+           ts_acc[0] / n_frames, ts_acc[1] / n_frames, ts_acc[2] / n_frames, ts_acc[3] / n_frames, ts_acc[5] / n_frames,
+           ts_acc[6] / n_frames, ts_acc[7] / n_frames, ts_n / n_frames, ts_c / n_frames, ts_nb / n_frames, n_frames);
+#endif
   // ---- persist the state (streaming: CtcBeamSearchDecoderBatch keeps its trie between next() calls) ----
   if (tid == 0) { st[0] = nb; st[1] = n_nodes; }
-  for (int i = tid; i < nb; i += kBT) {
+  for (int i = tid; i < nb; i += BT) {
     g_arr[i] = cur.node[i]; g_arr[beam + i] = cur.chr[i]; g_arr[2 * beam + i] = cur.par[i];
     g_arr[3 * beam + i] = __float_as_int(cur.b[i]); g_arr[4 * beam + i] = __float_as_int(cur.nb[i]);
     g_arr[5 * beam + i] = __float_as_int(cur.score[i]);
@@ -669,7 +761,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
   __syncthreads();
   // ---- get_beam_search_result: rank the beam by prefix_compare, emit the n-best paths ----
   // rank of slot q = number of slots that sort before it (beam <= a few hundred: O(beam^2 / 256))
-  for (int q = tid; q < nb; q += kBT) {
+  for (int q = tid; q < nb; q += BT) {
     const uint64_t kq = make_key(cur.score[q], cur.chr[q], q);
     int rank = 0;
     for (int i = 0; i < nb; ++i) rank += (make_key(cur.score[i], cur.chr[i], i) < kq) ? 1 : 0;
@@ -715,7 +807,7 @@ __global__ __launch_bounds__(kBT) void k_ctc_beam(const float* __restrict__ prob
     }
   }
   // ranks >= nb (beam smaller than nbest): mark empty
-  for (int r = nb + tid; r < cfg.nbest; r += kBT) {
+  for (int r = nb + tid; r < cfg.nbest; r += BT) {
     out_lens[(size_t)u * cfg.nbest + r] = -1;
     out_scores[(size_t)u * cfg.nbest + r] = 0.0;
   }
@@ -725,12 +817,25 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
                            int32_t* prune_recs, int32_t* state, int init_state, int finalize, int32_t* out_tokens,
                            int32_t* out_lens, double* out_scores, int32_t* status, hipStream_t st) {
   const size_t lds = beam_lds_bytes(cfg), plds = prune_lds_bytes(cfg);
-  static size_t configured = 0, pconfigured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_beam),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t configured[5] = {0, 0, 0, 0, 0}, pconfigured = 0;
+  // threads per utterance by the number of (hypothesis, candidate) elements of a frame: every phase is a chain of
+  // block-wide steps, and a barrier over few waves is cheaper than one over 16
+  const int n_elem = cfg.beam * (1 + cfg.n_cand_max);
+  static const int kSizes[5] = {64, 128, 256, 512, 1024};
+  int sel = n_elem <= 1024 ? 3 : 4;
+  if (const char* e = getenv("PPASR_BEAM_THREADS")) {
+    sel = 4;
+    for (int i = 4; i >= 0; --i)
+      if (atoi(e) <= kSizes[i]) sel = i;
+  }
+  const void* fns[5] = {reinterpret_cast<const void*>(k_ctc_beam<64>), reinterpret_cast<const void*>(k_ctc_beam<128>),
+                        reinterpret_cast<const void*>(k_ctc_beam<256>), reinterpret_cast<const void*>(k_ctc_beam<512>),
+                        reinterpret_cast<const void*>(k_ctc_beam<1024>)};
+  const void* fn = fns[sel];
+  if (lds > configured[sel]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    configured = lds;
+    configured[sel] = lds;
   }
   if (plds > pconfigured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_prune<kPruneThreads>),
@@ -741,8 +846,17 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
   if (T > 0)
     hipLaunchKernelGGL(k_ctc_prune<kPruneThreads>, dim3(T, B), dim3(kPruneThreads), plds, st, probs, frame_lens, T, cfg,
                        prune_recs);
-  hipLaunchKernelGGL(k_ctc_beam, dim3(B), dim3(kBT), lds, st, probs, frame_lens, T, cfg, prune_recs, state, init_state,
-                     finalize, out_tokens, out_lens, out_scores, status);
+#define PPASR_LAUNCH_BEAM(BT)                                                                                          \
+  hipLaunchKernelGGL(k_ctc_beam<BT>, dim3(B), dim3(BT), lds, st, probs, frame_lens, T, cfg, prune_recs, state, init_state, \
+                     finalize, out_tokens, out_lens, out_scores, status)
+  switch (sel) {
+    case 0: PPASR_LAUNCH_BEAM(64); break;
+    case 1: PPASR_LAUNCH_BEAM(128); break;
+    case 2: PPASR_LAUNCH_BEAM(256); break;
+    case 3: PPASR_LAUNCH_BEAM(512); break;
+    default: PPASR_LAUNCH_BEAM(1024); break;
+  }
+#undef PPASR_LAUNCH_BEAM
   return hipGetLastError();
 }
 
