@@ -41,10 +41,21 @@ __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 // row of accumulator register r inside a 32x32 tile for this lane
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// Sum over the 64 lanes, returned to every lane.  DPP row shifts / row broadcasts (VALU adds with a lane-permuting
+// operand, a few cycles each) instead of the __shfl_xor butterfly, which compiles to ds_bpermute = one LDS crossbar
+// round trip per step; the total lands in lane 63 and is read back as a wave-uniform value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or_zero(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_or_zero<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_or_zero<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_or_zero<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_or_zero<0x118, 0xf>(v);  // row_shr:8
+  v += dpp_or_zero<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
+  v += dpp_or_zero<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
