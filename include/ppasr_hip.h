@@ -103,6 +103,15 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
  * to `taps` in the order documented in DESIGN.md; pass NULL to clear. */
 ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats);
 
+/* Ragged batches.  The reference computes every padded row of a batch (its batched decoders even consume them,
+ * trainer.py:347).  With enable != 0, ppasr_encode computes, per utterance, only the rows its VALID output frames
+ * depend on (t < ceil(len/4), or ceil(len/8) after a rate change, plus a few rows of slack for the grouped-attention /
+ * stride / time-reduction reads): whole 32-row blocks behind them are skipped in every kernel and attention stops at
+ * the last valid key.  Valid rows are bit-identical to the default mode; rows of `probs` / `logits` behind an
+ * utterance's last valid frame are set to 0, `frame_argmax` to 0 (blank) and `frame_maxprob` to 0 -- pass frame_lens
+ * to the decoders.  Default: off (= the reference's outputs for every row). */
+ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable);
+
 /* Replaces the third-party `paddlespeech_ctcdecoders` entry points PPASR calls:
  *   ctc_beam_search_decoding / ctc_beam_search_decoding_batch  (decoders/swig_wrapper.py:61-62,98-100,
  *     from BeamSearchDecoder.decode_beam_search_offline / decode_batch_beam_search_offline,

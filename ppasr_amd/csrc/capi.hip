@@ -320,6 +320,12 @@ ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats) 
   return PPASR_OK;
 }
 
+ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable) {
+  if (!h) return fail(PPASR_EINVAL, "null handle");
+  h->skip_padding = enable != 0;
+  return PPASR_OK;
+}
+
 ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* lens, int B, int T, float* probs,
                           float* logits, int32_t* frame_argmax, float* frame_maxprob, void* workspace,
                           size_t workspace_bytes, void* stream) {
@@ -358,12 +364,28 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     (void)hipEventRecord(b, st);
     h->spans.push_back({cls, a, b});
   };
-  timed(0, [&] { launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st); });
-  timed(1, [&] { launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st); });
-  timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st); });
+  // ragged batches (ppasr_set_skip_padding): rows behind an utterance's valid frames + slack are skipped.  Slack =
+  // what valid outputs read from the rows behind them: the right context of the non-causal conv module, and with a
+  // rate change (Efficient-Conformer) the stride layer's 2j / 2j+1 rows and the 3-frame groups of grouped attention.
+  const bool eff = h->desc.model_type == PPASR_MODEL_EFFICIENT_CONFORMER;
+  const bool skip = h->skip_padding && lens && !h->taps;
+  const int rc = h->desc.causal ? 0 : (h->desc.cnn_module_kernel - 1) / 2;
+  const int slack_half = rc + 4, slack_full = eff ? 2 * slack_half + rc + 8 : rc + 4;
+  auto pskip = [&](int Tcur, int mul_cur) {
+    PadSkip ps;
+    if (skip) {
+      ps.lens = lens;
+      ps.Tp = Tcur;
+      ps.mul = mul_cur;
+      ps.slack = mul_cur == 4 ? slack_full : slack_half;
+    }
+    return ps;
+  };
+  timed(0, [&] { launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, pskip(Tp, 4)); });
+  timed(1, [&] { launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, pskip(Tp, 4)); });
+  timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st, pskip(Tp, 4)); });
   tap(xa, (size_t)M * kD);
   const int n_chunks = h->desc.linear_units / 256;
-  const bool eff = h->desc.model_type == PPASR_MODEL_EFFICIENT_CONFORMER;
   int Ti = Tp, mul = 4, pstride = 1;  // frames per utterance / pad-mask multiplier / positional stride of the current layer
   bool s1_done = false;               // this layer's S1 already ran inside the previous layer's last launch
   for (int i = 0; i < h->desc.num_blocks; ++i) {
@@ -376,25 +398,30 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       return h->layer_group[layer] == 1 && h->desc.attention_heads == 4 && !h->taps;
     };
     const bool fuse_attn = fusable(i);
-    if (!s1_done) timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st); });
+    const PadSkip ps = pskip(Ti, mul);
+    if (!s1_done) timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st, ps); });
     s1_done = false;
     tap(xb, (size_t)Mi * kD);
     tap(qkv, (size_t)Mi * 3 * kD);
     const int Tt = (Ti + grp - 1) / grp;  // tokens: frames, or zero-padded groups of 3 (pad4group)
     AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Tt, Tt, 0, lens, ctx, L.pos_u, L.pos_v, L.ptab, pstride,
                mul * grp, Ti, Ti, grp};
+    a.pad_skip = skip ? ps.slack + 1 : 0;
     if (fuse_attn) {
       timed(9, [&] { launch_attn_out_glu(a, B, xb, xc, g, L, st); });
     } else {
       timed(4, [&] { launch_attention(a, B, h->desc.attention_heads, st); });
       tap(ctx, (size_t)Mi * kD);
-      timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, L, lens, Mi, Ti, mul, st); });
+      timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, L, lens, Mi, Ti, mul, st, ps); });
     }
     tap(xc, (size_t)Mi * kD);
     tap(g, (size_t)Mi * kD);
     if (eff && i == h->desc.stride_layer_idx) {
       const int Ts = (Ti + 1) / 2;
-      timed(6, [&] { launch_conv_ffn_stride(g, nullptr, xc, xa, L, lens, B, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st); });
+      timed(6, [&] {
+        launch_conv_ffn_stride(g, nullptr, xc, xa, L, lens, B, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st,
+                               pskip(Ts, mul * 2));
+      });
       Ti = Ts;  // masks[:, :, ::2], pos_emb[:, ::2]  (efficient_conformer/encoder.py:252-257)
       mul *= 2;
       pstride *= 2;
@@ -403,7 +430,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       const LayerW* next = (i + 1 < h->desc.num_blocks) ? &h->layers[i + 1] : nullptr;
       timed(next ? 8 : 6, [&] {
         launch_conv_ffn(g, nullptr, xc, xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul, next, xb, qkv, st,
-                        h->desc.causal != 0);
+                        h->desc.causal != 0, ps);
       });
       s1_done = next != nullptr;
     }
@@ -413,12 +440,13 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   float* lg = logits ? logits : probs;  // probs are produced in place from the logits tap
   int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
   float* fp = frame_maxprob ? frame_maxprob : ws + wl.fp;
-  timed(7, [&] { launch_ctc_head(xa, h->head, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, Mo, st); });
+  timed(7, [&] { launch_ctc_head(xa, h->head, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, Mo, st, pskip(Ti, mul)); });
   if (probs) {
     if (logits)
       HIP_TRY(hipMemcpyAsync(probs, logits, (size_t)Mo * h->head.V * sizeof(float), hipMemcpyDeviceToDevice, st));
-    launch_softmax_from_stats(probs, ws + wl.rmax, ws + wl.rsum, Mo, h->head.V, st);
+    launch_softmax_from_stats(probs, ws + wl.rmax, ws + wl.rsum, Mo, h->head.V, st, pskip(Ti, mul));
   }
+  if (skip) launch_zero_pad_rows(probs, logits, fa, fp, lens, B, Ti, mul, h->head.V, st);
   HIP_TRY(hipGetLastError());
   return PPASR_OK;
 }

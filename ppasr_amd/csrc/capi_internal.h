@@ -83,6 +83,7 @@ struct ppasr_model_s {
   size_t taps_floats = 0;
   // optional per-kernel timing (bench.py roofline leg): one event pair per launch on the caller's stream
   bool prof = false;
+  bool skip_padding = false;  // ppasr_set_skip_padding: ragged batches compute only the rows valid outputs depend on
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   struct Span { int cls; hipEvent_t a, b; };

@@ -221,10 +221,24 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
       (void)hipMemcpyAsync(h->taps + tap_off, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
     tap_off += n;
   };
-  launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st);
-  launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st);
-  launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/true, st);
-  launch_ln_rows(xa, h->preln_g, h->preln_b, M, st);
+  // ragged batches (ppasr_set_skip_padding, see ppasr_encode): the conv module is causal here, so the slack only
+  // covers the time-reduction layer (reduced row j reads full-rate row 2j) and the recovery (row t reads reduced row t/2)
+  const bool skip = h->skip_padding && lens && !h->taps;
+  auto pskip = [&](int Tcur, int mul_cur) {
+    PadSkip ps;
+    if (skip) {
+      ps.lens = lens;
+      ps.Tp = Tcur;
+      ps.mul = mul_cur;
+      ps.slack = mul_cur == 4 ? 16 : 4;
+    }
+    return ps;
+  };
+  const PadSkip psF = pskip(Tp, 4), psH = pskip(Tr, 8);
+  launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, psF);
+  launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, psF);
+  launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/true, st, psF);
+  launch_ln_rows(xa, h->preln_g, h->preln_b, M, st, psF);
   tap(xa, (size_t)M * kD);
   float* x = xa;      // current layer input / residual
   float* other = xb;  // ping-pong partner
@@ -235,13 +249,13 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
     if (i == h->desc.reduce_idx) {
       // recover_activations.append(xs) ; time_reduction_layer ; pos_emb[:, ::2]  (encoder.py:210-216)
       HIP_TRY(hipMemcpyAsync(xs, x, (size_t)M * kD * sizeof(float), hipMemcpyDeviceToDevice, st));
-      launch_sq_reduce(x, other, qkv, h->sq_reduce, W.wqkv, W.bqkv, lens, B, Tp, Tr, st);
+      launch_sq_reduce(x, other, qkv, h->sq_reduce, W.wqkv, W.bqkv, lens, B, Tp, Tr, st, psH);
       std::swap(x, other);
       reduced = true;
       have_qkv = true;
     }
     if (i == h->desc.recover_idx && reduced) {
-      launch_sq_recover(x, xs, other, qkv, h->sq_wrec, h->sq_brec, W.wqkv, W.bqkv, B, Tp, Tr, st);
+      launch_sq_recover(x, xs, other, qkv, h->sq_wrec, h->sq_brec, W.wqkv, W.bqkv, B, Tp, Tr, st, psF);
       std::swap(x, other);
       reduced = false;
       have_qkv = true;
@@ -249,18 +263,20 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
     const int Ti = reduced ? Tr : Tp;
     const int Mi = B * Ti;
     const int mul = reduced ? 8 : 4;
-    if (!have_qkv) launch_sq_qkv(x, qkv, W.wqkv, W.bqkv, Mi, st);
+    const PadSkip& ps = reduced ? psH : psF;
+    if (!have_qkv) launch_sq_qkv(x, qkv, W.wqkv, W.bqkv, Mi, st, ps);
     tap(qkv, (size_t)Mi * 3 * kD);
     AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Ti, Ti, 0, lens, ctx, W.pos_u, W.pos_v, W.ptab, reduced ? 2 : 1, mul, Ti, Ti, 1};
+    a.pad_skip = skip ? ps.slack + 1 : 0;
     launch_attention(a, B, H, st);
     tap(ctx, (size_t)Mi * kD);
-    launch_sq_mid(ctx, x, xc, g, nullptr, W, lens, Mi, Ti, mul, n_chunks, st);
+    launch_sq_mid(ctx, x, xc, g, nullptr, W, lens, Mi, Ti, mul, n_chunks, st, ps);
     tap(xc, (size_t)Mi * kD);
     tap(g, (size_t)Mi * kD);
     const bool fuse_next = (i + 1 < L) && (i + 1 != h->desc.reduce_idx) && !(i + 1 == h->desc.recover_idx && reduced);
     const SqLayerW* Wn = fuse_next ? &h->sq_layers[i + 1] : nullptr;
     launch_sq_tail(g, nullptr, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, lens, Mi, Ti, mul, n_chunks, KS,
-                   st);
+                   st, ps);
     std::swap(x, other);
     have_qkv = fuse_next;
     tap(x, (size_t)Mi * kD);
@@ -268,12 +284,16 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
   float* lg = logits ? logits : probs;
   int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
   float* fp = frame_maxprob ? frame_maxprob : ws + wl.fp;
-  launch_ctc_head(x, h->head, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, M, st);
+  // (the encoder ends at the full rate after the recovery; without one it stays reduced and M rows = B * Tp is the
+  //  caller's contract either way)
+  const PadSkip psO = reduced ? PadSkip{} : psF;
+  launch_ctc_head(x, h->head, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, M, st, psO);
   if (probs) {
     if (logits)
       HIP_TRY(hipMemcpyAsync(probs, logits, (size_t)M * h->head.V * sizeof(float), hipMemcpyDeviceToDevice, st));
-    launch_softmax_from_stats(probs, ws + wl.rmax, ws + wl.rsum, M, h->head.V, st);
+    launch_softmax_from_stats(probs, ws + wl.rmax, ws + wl.rsum, M, h->head.V, st, psO);
   }
+  if (skip && !reduced) launch_zero_pad_rows(probs, logits, fa, fp, lens, B, Tp, 4, h->head.V, st);
   HIP_TRY(hipGetLastError());
   return PPASR_OK;
 }

@@ -69,29 +69,37 @@ struct AttnArgs {
   // T2 = cache_t + T1 keys, positional rows from pos0; nullptr otherwise
   const SessDesc* sess;
   long long sess_stride;
+  // ragged batches: 0 = every query row / key block is computed; n > 0 = query rows behind the valid frames + (n - 1)
+  // are skipped and the key loop stops after the last valid key (masked keys contribute exact zeros either way)
+  int pad_skip;
 };
 
 // ---- launchers (all asynchronous on `st`) ----
 void launch_posproj(const float* pe, const float* wpos /*[256][256] in,out*/, const float* bpos_or_null, float* ptab,
                     int max_len, hipStream_t st);
-void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T, int F, int T1, int F1, hipStream_t st);
-void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st);
+// every row-block launcher takes an optional PadSkip (rowblock.h): default = compute all rows
+void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T, int F, int T1, int F1, hipStream_t st,
+                  const PadSkip& ps = PadSkip{});
+void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st,
+                  const PadSkip& ps = PadSkip{});
 // scale_before_bias: Squeezeformer scales the 4864-wide conv output by sqrt(d) BEFORE input_proj
 // (squeezeformer/subsampling.py:66-67) -> acc*scale + b ; Conformer: (acc + b)*scale (embedding.py:112)
 void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, bool scale_before_bias,
-                  hipStream_t st);
+                  hipStream_t st, const PadSkip& ps = PadSkip{});
 void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, float* out, int M, int K, int n_cols_padded,
                   int ldc, int n_valid, hipStream_t st);
-void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st);
+void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
+                    const PadSkip& ps = PadSkip{});
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
-                    const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st);
+                    const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps = PadSkip{});
 // next != nullptr: also run the following layer's S1 (writes x1_next, qkv_next) in the same launch
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                      const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,
-                     float* x1_next, float* qkv_next, hipStream_t st, bool causal = true);
+                     float* x1_next, float* qkv_next, hipStream_t st, bool causal = true, const PadSkip& ps = PadSkip{});
 void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int B,
-                            int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out, hipStream_t st);
+                            int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out, hipStream_t st,
+                            const PadSkip& ps = PadSkip{});
 // streaming helpers
 // fused S2+S3 for the batched plain-head path (4 heads x 64): attention + out-projection + LN_conv + pw1 + GLU
 void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, float* g, const LayerW& w, hipStream_t st);
@@ -111,12 +119,15 @@ void launch_cnn_transpose(const float* src, float* dst, int lo, int lo_ref, int 
 void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStream_t st);
 // hw.ln_g == nullptr: no final LayerNorm (Squeezeformer has no after_norm, squeezeformer/encoder.py:232-235)
 void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr_argmax, float* fr_maxprob,
-                     float* row_max, float* row_sum, int M, hipStream_t st);
+                     float* row_max, float* row_sum, int M, hipStream_t st, const PadSkip& ps = PadSkip{});
 void launch_softmax_from_stats(float* probs_inout, const float* row_max, const float* row_sum, int M, int V,
-                               hipStream_t st);
+                               hipStream_t st, const PadSkip& ps = PadSkip{});
 void launch_frame_argmax(const float* probs, int32_t* fr_argmax, float* fr_maxprob, int M, int V, hipStream_t st);
 void launch_ctc_collapse(const int32_t* fr_argmax, const float* fr_maxprob, const int32_t* frame_lens, int B, int Tp,
                          int blank, int32_t* tokens, int32_t* n_tokens, double* score, hipStream_t st);
+// ragged batches (skip_padding): rows t with mul*t >= lens[b] of the outputs <- 0 (any pointer may be null)
+void launch_zero_pad_rows(float* probs, float* logits, int32_t* fr_argmax, float* fr_maxprob, const int64_t* lens, int B,
+                          int Tp, int mul, int V, hipStream_t st);
 hipError_t configure_kernels();  // opt in to >64 KiB dynamic LDS
 
 }  // namespace ppasr

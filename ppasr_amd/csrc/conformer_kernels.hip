@@ -35,9 +35,10 @@ void launch_posproj(const float* pe, const float* wpos, const float* bpos, float
 // A rows of conv2 are contiguous 1 KiB runs.  One block per (t1, b); thread = channel.
 // =====================================================================================
 __global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ feats, FrontW fw, float* __restrict__ y1,
-                                               int T, int F, int T1, int F1) {
+                                               int T, int F, int T1, int F1, PadSkip ps) {
   __shared__ float xs[3][128];
   const int b = blockIdx.y, t1 = blockIdx.x, tid = threadIdx.x;
+  if (ps.lens && t1 > 2 * pad_need_steps(ps, b)) return;  // conv2 output frame t' reads conv1 frames 2t' .. 2t'+2
   for (int idx = tid; idx < 3 * F; idx += 256) {
     int i = idx / F, f = idx - i * F;
     float v = feats[((size_t)b * T + 2 * t1 + i) * F + f];
@@ -59,8 +60,9 @@ __global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ feats, 
     out[(size_t)f1 * 256] = fmaxf(acc, 0.f);
   }
 }
-void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T, int F, int T1, int F1, hipStream_t st) {
-  hipLaunchKernelGGL(k_conv1, dim3(T1, B), dim3(256), 0, st, feats, fw, y1, T, F, T1, F1);
+void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T, int F, int T1, int F1, hipStream_t st,
+                  const PadSkip& ps) {
+  hipLaunchKernelGGL(k_conv1, dim3(T1, B), dim3(256), 0, st, feats, fw, y1, T, F, T1, F1, ps);
 }
 
 // =====================================================================================
@@ -96,8 +98,10 @@ struct DenseSrc {
 template <int MT, int KC, bool RELU, bool SB, typename Src>
 __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ out, int M,
-                                                          int n_chunks, float scale, int ldc, int n_valid, int m0) {
+                                                          int n_chunks, float scale, int ldc, int n_valid, int m0,
+                                                          PadSkip ps) {
   constexpr int BM = 32 * MT;
+  if (pad_block_skippable(ps, m0 + blockIdx.x * BM, BM, M)) return;
   constexpr int LD = KC + 4;
   constexpr int F4_PER_ROW = KC / 4;
   constexpr int NL = BM * F4_PER_ROW / kThreads;  // float4 loads per thread per chunk
@@ -158,8 +162,11 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
     }
 }
 
-void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st) {
+void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st,
+                  const PadSkip& ps_frames) {
   Conv2Src src{y1, T1, F1, Tp, F2};
+  PadSkip ps = ps_frames;
+  ps.unit = F2;  // rows are (frame, f2) pairs
   const int M = B * Tp * F2;
   constexpr int KC = 128, kCUs = 256;
   auto lds_of = [](int mt) { return (size_t)2 * (32 * mt) * (KC + 4) * sizeof(float); };
@@ -172,31 +179,31 @@ void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, i
   int mt_rem = (rem_rows + 32 * kCUs - 1) / (32 * kCUs);  // rows per remainder tile / 32
   if (full == 0 || rem_rows <= 0 || mt_rem >= 4) {
     hipLaunchKernelGGL((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(tiles4), dim3(kThreads), lds_of(4), st, src,
-                       fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, 0);
+                       fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, 0, ps);
     return;
   }
   hipLaunchKernelGGL((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(full), dim3(kThreads), lds_of(4), st, src,
-                     fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, 0);
+                     fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, 0, ps);
   const int m0 = full * 128;
 #define CONV2_REM(MTR)                                                                                                    \
   hipLaunchKernelGGL((k_gemm_stream<MTR, KC, true, false, Conv2Src>), dim3((rem_rows + 32 * MTR - 1) / (32 * MTR)),       \
-                     dim3(kThreads), lds_of(MTR), st, src, fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, m0)
+                     dim3(kThreads), lds_of(MTR), st, src, fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, m0, ps)
   if (mt_rem <= 1) CONV2_REM(1);
   else if (mt_rem == 2) CONV2_REM(2);
   else CONV2_REM(3);
 #undef CONV2_REM
 }
 void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, bool scale_before_bias,
-                  hipStream_t st) {
+                  hipStream_t st, const PadSkip& ps) {
   constexpr int MT = 1, KC = 256;
   DenseSrc src{y2, K, KC};
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
   if (scale_before_bias)
     hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, true, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src,
-                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD, 0);
+                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD, 0, ps);
   else
     hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src,
-                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD, 0);
+                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD, 0, ps);
 }
 
 // out[M][ldc] (columns < n_valid) = A[M][K] * Wpacked + bias ; K % 256 == 0 ; weights / bias padded to a multiple of
@@ -207,7 +214,7 @@ void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, fl
   DenseSrc src{a, lda, KC};
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
   hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, n_cols_padded / 256),
-                     dim3(kThreads), lds, st, src, w, bias, out, M, K / KC, 1.0f, ldc, n_valid, 0);
+                     dim3(kThreads), lds, st, src, w, bias, out, M, K / KC, 1.0f, ldc, n_valid, 0, PadSkip{});
 }
 
 // =====================================================================================
@@ -252,8 +259,9 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
 }
 
 __global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ x_in, float* __restrict__ x1,
-                                                      float* __restrict__ qkv, LayerW w, int M, int n_chunks) {
+                                                      float* __restrict__ qkv, LayerW w, int M, int n_chunks, PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
   float* bufH = bufA + kRows * kLda;
@@ -266,9 +274,10 @@ __global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ 
   ffn_qkv_body(bufX, bufA, bufH, x1, qkv, w, r0, valid, n_chunks, ring);
 }
 constexpr size_t kLdsFfnQkv = 4 * kRows * kLda * sizeof(float);
-void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st) {
+void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
+                    const PadSkip& ps) {
   hipLaunchKernelGGL(k_ffn_qkv, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsFfnQkv, st, x_in, x1, qkv, w, M,
-                     n_chunks);
+                     n_chunks, ps);
 }
 
 // -------------------------------------------------------------------------------------
@@ -334,6 +343,13 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   const int pstride = a.pos_stride;
   float* __restrict__ ctx = a.ctx + (size_t)b * F1 * kD;
   const int64_t len_b = a.lens ? a.lens[b] : (int64_t)a.mask_mul * T2;
+  if (a.pad_skip > 0 && a.lens) {  // ragged batch: query tokens behind the needed frames, key blocks behind the valid keys
+    const int64_t lb = len_b > 0 ? len_b : 0;
+    const int fmul = a.mask_mul / C::G;  // frame f is valid iff fmul * f < len
+    const int need_frames = (int)min((int64_t)F1, (lb + fmul - 1) / fmul + (a.pad_skip - 1));
+    if (q0 * C::G >= need_frames) return;  // (uniform: before any barrier)
+    T2 = (int)max((int64_t)1, min((int64_t)T2, (lb + a.mask_mul - 1) / a.mask_mul));
+  }
   // element (token j, head h, feature f) lives at flat offset j*G*256 + h*DK + f of the utterance's [frames][256]
   // activations (G = 1: plain heads; G = 3: pad4group's re-cut of 3 frames into 4 heads of 192); zero beyond the
   // valid frames (the zero-padded tail group).
@@ -567,8 +583,10 @@ void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st) {
 __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ ctx, const float* __restrict__ x1,
                                                       float* __restrict__ x2, float* __restrict__ g,
                                                       float* __restrict__ xhat_out, LayerW w,
-                                                      const int64_t* __restrict__ lens, int M, int Tp, int mask_mul) {
+                                                      const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
+                                                      PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
   const int lane = lane_id(), wave = wave_id();
@@ -622,9 +640,9 @@ __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ 
 }
 constexpr size_t kLdsOutGlu = 2 * kRows * kLda * sizeof(float);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
-                    const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st) {
+                    const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps) {
   hipLaunchKernelGGL(k_out_glu, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsOutGlu, st, ctx, x1, x2, g, xhat_out, w,
-                     lens, M, Tp, mask_mul);
+                     lens, M, Tp, mask_mul, ps);
 }
 
 // -------------------------------------------------------------------------------------
@@ -668,14 +686,21 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
   const int b = (slot / nq) * 8 + (blockIdx.x & 7);
   const int q0 = (slot % nq) * 32;
   if (b >= B) return;  // batch not a multiple of 8: the padded slots are empty
-  const int T = a.T1, T2 = a.T2;
+  const int T = a.T1;
   const int valid = min(32, T - q0);
   const float* __restrict__ qb = a.q + (size_t)b * T * a.q_stride;
-  const float* __restrict__ kbp = a.k + (size_t)b * T2 * a.k_stride;
-  const float* __restrict__ vbp = a.v + (size_t)b * T2 * a.v_stride;
+  const float* __restrict__ kbp = a.k + (size_t)b * a.T2 * a.k_stride;
+  const float* __restrict__ vbp = a.v + (size_t)b * a.T2 * a.v_stride;
   const float* __restrict__ ptab = a.ptab + (size_t)a.pos0 * kD;
   const int pstride = a.pos_stride;
-  const int64_t len_b = a.lens ? a.lens[b] : (int64_t)a.mask_mul * T2;
+  const int64_t len_b = a.lens ? a.lens[b] : (int64_t)a.mask_mul * a.T2;
+  int T2 = a.T2;  // keys walked: all of them, or (ragged batch) only up to the last valid one
+  if (a.pad_skip > 0 && a.lens) {
+    const int64_t lb = len_b > 0 ? len_b : 0;
+    const int64_t n_valid = (lb + a.mask_mul - 1) / a.mask_mul;
+    if (q0 >= min((int64_t)T, n_valid + (a.pad_skip - 1))) return;  // whole row block behind the needed frames
+    T2 = (int)max((int64_t)1, min((int64_t)T2, n_valid));
+  }
   float* P = Ps + wave * kPTile;
   BRing<1> ring;
   const f32x4* seg_o = w.wo + (size_t)wave * kTs256;
@@ -1105,8 +1130,9 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
                                                        const float* __restrict__ x2, float* __restrict__ x_out, LayerW w,
                                                        const int64_t* __restrict__ lens, int M, int Tp, int n_chunks,
                                                        int mask_mul, LayerW wn, float* __restrict__ x1_next,
-                                                       float* __restrict__ qkv_next, int left_ctx) {
+                                                       float* __restrict__ qkv_next, int left_ctx, PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
   float* bufH = bufA + kRows * kLda;
@@ -1163,20 +1189,20 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
 constexpr size_t kLdsConvFfn = 4 * kRows * kLda * sizeof(float);
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                      const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,
-                     float* x1_next, float* qkv_next, hipStream_t st, bool causal) {
+                     float* x1_next, float* qkv_next, hipStream_t st, bool causal, const PadSkip& ps) {
   dim3 grid((M + kRows - 1) / kRows);
   const int left_ctx = causal ? ksize - 1 : (ksize - 1) / 2;
   const LayerW& wn = next ? *next : w;
 #define LAUNCH_CF(KS)                                                                                                  \
   if (g_hist)                                                                                                          \
     hipLaunchKernelGGL((k_conv_ffn<KS, true, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
-                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx);                                    \
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps);                                    \
   else if (next)                                                                                                       \
     hipLaunchKernelGGL((k_conv_ffn<KS, false, true>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
-                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx);                                    \
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps);                                    \
   else                                                                                                                 \
     hipLaunchKernelGGL((k_conv_ffn<KS, false, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, \
-                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx);
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps);
   if (ksize == 15) {
     LAUNCH_CF(15)
   } else if (ksize == 31) {
@@ -1199,8 +1225,9 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __res
                                                               const float* __restrict__ x2, float* __restrict__ x_out,
                                                               LayerW w,
                                                               const int64_t* __restrict__ lens, int B, int Tp, int Ts,
-                                                              int n_chunks, int mask_mul_out) {
+                                                              int n_chunks, int mask_mul_out, PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, B * Ts)) return;  // (ps describes the OUTPUT rows)
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
   float* bufH = bufA + kRows * kLda;
@@ -1271,14 +1298,14 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __res
 }
 void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                             const int64_t* lens, int B, int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out,
-                            hipStream_t st) {
+                            hipStream_t st, const PadSkip& ps) {
   dim3 grid((B * Ts + kRows - 1) / kRows);
   if (ksize == 15)
     hipLaunchKernelGGL(k_conv_ffn_stride<15>, grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, B, Tp, Ts,
-                       n_chunks, mask_mul_out);
+                       n_chunks, mask_mul_out, ps);
   else if (ksize == 7)
     hipLaunchKernelGGL(k_conv_ffn_stride<7>, grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, B, Tp, Ts,
-                       n_chunks, mask_mul_out);
+                       n_chunks, mask_mul_out, ps);
 }
 
 // -------------------------------------------------------------------------------------
@@ -1291,8 +1318,10 @@ void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2
 template <bool LOGITS>
 __global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__ x, HeadW hw, float* __restrict__ logits,
                                                        int32_t* __restrict__ fr_argmax, float* __restrict__ fr_maxprob,
-                                                       float* __restrict__ row_max, float* __restrict__ row_sum, int M) {
+                                                       float* __restrict__ row_max, float* __restrict__ row_sum, int M,
+                                                       PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
   float* bufA = smem;                                          // [32][260]
   float* redM = bufA + kRows * kLda;                           // [8][32]
   float* redS = redM + kWaves * 32;                            // [8][32]
@@ -1388,20 +1417,22 @@ __global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__
 }
 constexpr size_t kLdsCtc = (kRows * kLda + 3 * kWaves * 32) * sizeof(float);
 void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr_argmax, float* fr_maxprob, float* row_max,
-                     float* row_sum, int M, hipStream_t st) {
+                     float* row_sum, int M, hipStream_t st, const PadSkip& ps) {
   dim3 grid((M + kRows - 1) / kRows);
   if (logits)
     hipLaunchKernelGGL(k_ctc_head<true>, grid, dim3(kThreads), kLdsCtc, st, x, hw, logits, fr_argmax, fr_maxprob, row_max,
-                       row_sum, M);
+                       row_sum, M, ps);
   else
     hipLaunchKernelGGL(k_ctc_head<false>, grid, dim3(kThreads), kLdsCtc, st, x, hw, logits, fr_argmax, fr_maxprob, row_max,
-                       row_sum, M);
+                       row_sum, M, ps);
 }
 
 // probs = softmax(logits) recomputed exactly (max, then exp(x-max)/sum) in place; one wave per row.
-__global__ __launch_bounds__(256) void k_softmax_rows(float* __restrict__ p, int M, int V) {
+__global__ __launch_bounds__(256) void k_softmax_rows(float* __restrict__ p, int M, int V, PadSkip ps) {
   const int row = blockIdx.x * 4 + wave_id();
   if (row >= M) return;
+  // ragged batch: the CTC head skipped whole 32-row blocks; the same blocks keep their cleared (all-zero) rows here
+  if (pad_block_skippable(ps, row & ~(kRows - 1), kRows, M)) return;
   const int lane = lane_id();
   float* x = p + (size_t)row * V;
   float m = -INFINITY;
@@ -1416,8 +1447,33 @@ __global__ __launch_bounds__(256) void k_softmax_rows(float* __restrict__ p, int
   s = wave_sum(s);
   for (int c = lane; c < V; c += 64) x[c] = x[c] / s;
 }
-void launch_softmax_from_stats(float* probs_inout, const float*, const float*, int M, int V, hipStream_t st) {
-  hipLaunchKernelGGL(k_softmax_rows, dim3((M + 3) / 4), dim3(256), 0, st, probs_inout, M, V);
+void launch_softmax_from_stats(float* probs_inout, const float*, const float*, int M, int V, hipStream_t st,
+                               const PadSkip& ps) {
+  hipLaunchKernelGGL(k_softmax_rows, dim3((M + 3) / 4), dim3(256), 0, st, probs_inout, M, V, ps);
+}
+
+__global__ __launch_bounds__(256) void k_zero_pad_rows(float* __restrict__ probs, float* __restrict__ logits,
+                                                       int32_t* __restrict__ fa, float* __restrict__ fp,
+                                                       const int64_t* __restrict__ lens, int M, int Tp, int mul, int V) {
+  const int row = blockIdx.x * 4 + wave_id();
+  if (row >= M) return;
+  const int b = row / Tp, t = row - b * Tp;
+  if ((int64_t)mul * t < lens[b]) return;
+  const int lane = lane_id();
+  if (probs)
+    for (int c = lane; c < V; c += 64) probs[(size_t)row * V + c] = 0.f;
+  if (logits)
+    for (int c = lane; c < V; c += 64) logits[(size_t)row * V + c] = 0.f;
+  if (lane == 0) {
+    if (fa) fa[row] = 0;
+    if (fp) fp[row] = 0.f;
+  }
+}
+void launch_zero_pad_rows(float* probs, float* logits, int32_t* fr_argmax, float* fr_maxprob, const int64_t* lens, int B,
+                          int Tp, int mul, int V, hipStream_t st) {
+  const int M = B * Tp;
+  hipLaunchKernelGGL(k_zero_pad_rows, dim3((M + 3) / 4), dim3(256), 0, st, probs, logits, fr_argmax, fr_maxprob, lens, M, Tp,
+                     mul, V);
 }
 
 // =====================================================================================

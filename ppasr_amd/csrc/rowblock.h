@@ -38,6 +38,34 @@ constexpr int kTs256 = kG256 * 64;  // packed tile stride (f32x4 units) of a K=2
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
+// Optional skipping of padding rows of a ragged batch (ppasr_set_skip_padding): utterance b occupies `Tp` time steps
+// of `unit` rows each, time step t is valid iff mul*t < lens[b], and only the first need(b) = min(Tp, valid + slack)
+// time steps are computed -- `slack` covers what valid outputs read from the rows behind them (right context of a
+// non-causal conv module, the stride / time-reduction layers, the 3-frame groups of grouped attention).  A workgroup
+// whose rows all lie behind need(b) returns at once; its outputs keep the zeros the workspace was cleared to.
+struct PadSkip {
+  const int64_t* lens = nullptr;  // nullptr: every row is computed (the reference's behaviour)
+  int Tp = 0, mul = 4, slack = 0, unit = 1;
+};
+__device__ __forceinline__ int pad_need_steps(const PadSkip& s, int b) {
+  const long long len = s.lens[b];
+  const long long v = (len > 0 ? (len + s.mul - 1) / s.mul : 0) + s.slack;
+  return (int)(v < (long long)s.Tp ? v : (long long)s.Tp);
+}
+// rows [m0, m0 + n_rows) of the flattened [B * Tp * unit] row space
+__device__ __forceinline__ bool pad_block_skippable(const PadSkip& s, int m0, int n_rows, int M) {
+  if (!s.lens) return false;
+  const int m1 = min(m0 + n_rows, M) - 1;
+  if (m1 < m0) return false;
+  const int stride = s.Tp * s.unit;
+  const int b1 = m1 / stride;
+  for (int b = m0 / stride; b <= b1; ++b) {
+    const int first = max(m0 - b * stride, 0);
+    if (first < pad_need_steps(s, b) * s.unit) return false;
+  }
+  return true;
+}
+
 // row of accumulator register r inside a 32x32 tile for this lane
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

@@ -27,18 +27,21 @@ struct SqReduceW {
   const float* pw_b;
 };
 
-void launch_sq_qkv(const float* x, float* qkv, const f32x4* wqkv, const float* bqkv, int M, hipStream_t st);
+void launch_sq_qkv(const float* x, float* qkv, const f32x4* wqkv, const float* bqkv, int M, hipStream_t st,
+                   const PadSkip& ps = PadSkip{});
 void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, float* xhat_out, const SqLayerW& w,
-                   const int64_t* lens, int M, int Tp, int mask_mul, int n_chunks, hipStream_t st);
+                   const int64_t* lens, int M, int Tp, int mask_mul, int n_chunks, hipStream_t st,
+                   const PadSkip& ps = PadSkip{});
 // g_hist != nullptr: streaming (single stream, rows = frames of one chunk; left context from g_hist [ksize-1][256])
 void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float* x_out, float* qkv_next, const SqLayerW& w,
                     const f32x4* wqkv_next, const float* bqkv_next, const int64_t* lens, int M, int Tp, int mask_mul,
-                    int n_chunks, int ksize, hipStream_t st);
+                    int n_chunks, int ksize, hipStream_t st, const PadSkip& ps = PadSkip{});
 void launch_sq_reduce(const float* x, float* xr, float* qkv, const SqReduceW& rw, const f32x4* wqkv, const float* bqkv,
-                      const int64_t* lens, int B, int Tp, int Tr, hipStream_t st);
+                      const int64_t* lens, int B, int Tp, int Tr, hipStream_t st, const PadSkip& ps = PadSkip{});
 void launch_sq_recover(const float* xr, const float* saved, float* x, float* qkv, const f32x4* wrec, const float* brec,
-                       const f32x4* wqkv, const float* bqkv, int B, int Tp, int Tr, hipStream_t st);
-void launch_ln_rows(float* x, const float* g, const float* b, int M, hipStream_t st);
+                       const f32x4* wqkv, const float* bqkv, int B, int Tp, int Tr, hipStream_t st,
+                       const PadSkip& ps = PadSkip{});
+void launch_ln_rows(float* x, const float* g, const float* b, int M, hipStream_t st, const PadSkip& ps = PadSkip{});
 hipError_t configure_squeezeformer_kernels();
 
 }  // namespace ppasr

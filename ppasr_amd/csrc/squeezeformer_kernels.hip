@@ -15,8 +15,10 @@ namespace ppasr {
 
 // qkv = x * Wqkv' + b'  (first layer, after preln)
 __global__ __launch_bounds__(kThreads) void k_sq_qkv(const float* __restrict__ x, float* __restrict__ qkv,
-                                                     const f32x4* __restrict__ wqkv, const float* __restrict__ bqkv, int M) {
+                                                     const f32x4* __restrict__ wqkv, const float* __restrict__ bqkv, int M,
+                                                     PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
   float* bufA = smem;
   const int lane = lane_id(), wave = wave_id();
   const int r0 = blockIdx.x * kRows;
@@ -66,8 +68,9 @@ __global__ __launch_bounds__(kThreads) void k_sq_mid(const float* __restrict__ c
                                                      float* __restrict__ x2, float* __restrict__ g,
                                                      float* __restrict__ xhat_out, SqLayerW w,
                                                      const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
-                                                     int n_chunks) {
+                                                     int n_chunks, PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
   float* bufX = smem;
   float* bufH = bufX + kRows * kLda;  // 2 buffers; bufH[0] doubles as the ctx staging tile
   const int lane = lane_id(), wave = wave_id();
@@ -143,8 +146,9 @@ __global__ __launch_bounds__(kThreads) void k_sq_tail(const float* __restrict__ 
                                                       SqLayerW w, const f32x4* __restrict__ wqkv_next,
                                                       const float* __restrict__ bqkv_next,
                                                       const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
-                                                      int n_chunks) {
+                                                      int n_chunks, PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
   float* bufH = bufA + kRows * kLda;
@@ -205,8 +209,10 @@ constexpr size_t kLdsSqTail = 4 * kRows * kLda * sizeof(float);
 __global__ __launch_bounds__(kThreads) void k_sq_reduce(const float* __restrict__ x, float* __restrict__ xr,
                                                         float* __restrict__ qkv, SqReduceW rw,
                                                         const f32x4* __restrict__ wqkv, const float* __restrict__ bqkv,
-                                                        const int64_t* __restrict__ lens, int B, int Tp, int Tr) {
+                                                        const int64_t* __restrict__ lens, int B, int Tp, int Tr,
+                                                        PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, B * Tr)) return;  // (ps: the reduced OUTPUT rows)
   float* bufA = smem;
   float* bufX = bufA + kRows * kLda;
   const int lane = lane_id(), wave = wave_id();
@@ -256,8 +262,9 @@ __global__ __launch_bounds__(kThreads) void k_sq_recover(const float* __restrict
                                                          float* __restrict__ x, float* __restrict__ qkv,
                                                          const f32x4* __restrict__ wrec, const float* __restrict__ brec,
                                                          const f32x4* __restrict__ wqkv, const float* __restrict__ bqkv,
-                                                         int B, int Tp, int Tr) {
+                                                         int B, int Tp, int Tr, PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, B * Tp)) return;
   float* bufA = smem;
   float* bufX = bufA + kRows * kLda;
   const int lane = lane_id(), wave = wave_id();
@@ -299,8 +306,9 @@ __global__ __launch_bounds__(kThreads) void k_sq_recover(const float* __restrict
 
 // in-place LayerNorm of [M][256] rows (preln, encoder.py:207)
 __global__ __launch_bounds__(kThreads) void k_ln_rows(float* __restrict__ x, const float* __restrict__ g,
-                                                      const float* __restrict__ b, int M) {
+                                                      const float* __restrict__ b, int M, PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
   const int r0 = blockIdx.x * kRows;
   const int valid = min(kRows, M - r0);
   rb_load_rows(smem, kLda, x + (size_t)r0 * kD, kRows, valid);
@@ -313,20 +321,21 @@ static inline dim3 rb_grid(int M) { return dim3((M + kRows - 1) / kRows); }
 constexpr size_t kLds1 = kRows * kLda * sizeof(float);
 constexpr size_t kLds2 = 2 * kRows * kLda * sizeof(float);
 
-void launch_sq_qkv(const float* x, float* qkv, const f32x4* wqkv, const float* bqkv, int M, hipStream_t st) {
-  hipLaunchKernelGGL(k_sq_qkv, rb_grid(M), dim3(kThreads), kLds1, st, x, qkv, wqkv, bqkv, M);
+void launch_sq_qkv(const float* x, float* qkv, const f32x4* wqkv, const float* bqkv, int M, hipStream_t st,
+                   const PadSkip& ps) {
+  hipLaunchKernelGGL(k_sq_qkv, rb_grid(M), dim3(kThreads), kLds1, st, x, qkv, wqkv, bqkv, M, ps);
 }
 void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, float* xhat_out, const SqLayerW& w,
-                   const int64_t* lens, int M, int Tp, int mask_mul, int n_chunks, hipStream_t st) {
+                   const int64_t* lens, int M, int Tp, int mask_mul, int n_chunks, hipStream_t st, const PadSkip& ps) {
   hipLaunchKernelGGL(k_sq_mid, rb_grid(M), dim3(kThreads), kLdsSqMid, st, ctx, x, x2, g, xhat_out, w, lens, M, Tp, mask_mul,
-                     n_chunks);
+                     n_chunks, ps);
 }
 void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float* x_out, float* qkv_next, const SqLayerW& w,
                     const f32x4* wqkv_next, const float* bqkv_next, const int64_t* lens, int M, int Tp, int mask_mul,
-                    int n_chunks, int ksize, hipStream_t st) {
+                    int n_chunks, int ksize, hipStream_t st, const PadSkip& ps) {
 #define SQ_TAIL(KS, STREAM)                                                                                          \
   hipLaunchKernelGGL((k_sq_tail<KS, STREAM>), rb_grid(M), dim3(kThreads), kLdsSqTail, st, g, g_hist, x2, x_out, qkv_next, w, \
-                     wqkv_next, bqkv_next, lens, M, Tp, mask_mul, n_chunks)
+                     wqkv_next, bqkv_next, lens, M, Tp, mask_mul, n_chunks, ps)
   if (ksize == 31) {
     if (g_hist) SQ_TAIL(31, true); else SQ_TAIL(31, false);
   } else if (ksize == 15) {
@@ -335,16 +344,17 @@ void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float*
 #undef SQ_TAIL
 }
 void launch_sq_reduce(const float* x, float* xr, float* qkv, const SqReduceW& rw, const f32x4* wqkv, const float* bqkv,
-                      const int64_t* lens, int B, int Tp, int Tr, hipStream_t st) {
-  hipLaunchKernelGGL(k_sq_reduce, rb_grid(B * Tr), dim3(kThreads), kLds2, st, x, xr, qkv, rw, wqkv, bqkv, lens, B, Tp, Tr);
+                      const int64_t* lens, int B, int Tp, int Tr, hipStream_t st, const PadSkip& ps) {
+  hipLaunchKernelGGL(k_sq_reduce, rb_grid(B * Tr), dim3(kThreads), kLds2, st, x, xr, qkv, rw, wqkv, bqkv, lens, B, Tp, Tr,
+                     ps);
 }
 void launch_sq_recover(const float* xr, const float* saved, float* x, float* qkv, const f32x4* wrec, const float* brec,
-                       const f32x4* wqkv, const float* bqkv, int B, int Tp, int Tr, hipStream_t st) {
+                       const f32x4* wqkv, const float* bqkv, int B, int Tp, int Tr, hipStream_t st, const PadSkip& ps) {
   hipLaunchKernelGGL(k_sq_recover, rb_grid(B * Tp), dim3(kThreads), kLds2, st, xr, saved, x, qkv, wrec, brec, wqkv, bqkv, B,
-                     Tp, Tr);
+                     Tp, Tr, ps);
 }
-void launch_ln_rows(float* x, const float* g, const float* b, int M, hipStream_t st) {
-  hipLaunchKernelGGL(k_ln_rows, rb_grid(M), dim3(kThreads), kLds1, st, x, g, b, M);
+void launch_ln_rows(float* x, const float* g, const float* b, int M, hipStream_t st, const PadSkip& ps) {
+  hipLaunchKernelGGL(k_ln_rows, rb_grid(M), dim3(kThreads), kLds1, st, x, g, b, M, ps);
 }
 
 hipError_t configure_squeezeformer_kernels() {

@@ -160,6 +160,15 @@ class ConformerModel:
                                                    stream))
         return tokens, n_tokens, score
 
+    def set_skip_padding(self, enable=True):
+        """Ragged batches: compute, per utterance, only the rows its valid output frames depend on
+        (``ppasr_set_skip_padding``).  Valid rows are bit-identical to the default mode; rows of the returned
+        probabilities behind an utterance's last valid frame (``4 t >= len``; ``8 t`` for the Efficient-Conformer)
+        are 0, so decode with ``frame_lens`` / ``trim_to_length=True``.  Off by default: the reference computes (and
+        its batched decoders consume, trainer.py:347) every padded row."""
+        self.skip_padding = bool(enable)
+        _lib.check(self.lib.ppasr_set_skip_padding(self._h, 1 if enable else 0))
+
     def set_debug_taps(self, n_floats):
         """Allocate a tap buffer; layout in DESIGN.md (x0, then per layer x1,qkv,ctx,x2,g,x_out)."""
         self._taps = torch.zeros(n_floats, dtype=torch.float32, device=self.device) if n_floats else None

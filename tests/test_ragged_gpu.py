@@ -1,0 +1,86 @@
+"""Ragged batches with ``set_skip_padding`` (ppasr_set_skip_padding): per utterance only the rows its valid output
+frames depend on are computed.  The valid rows must be BIT-identical to the default mode (which the other test files
+hold against the oracles), everything behind them zero / blank, and the greedy tokens with length trimming equal."""
+import numpy as np
+import pytest
+import torch
+
+from ppasr_amd.utils.synth import (conformer_state_dict, efficient_conformer_state_dict, squeezeformer_state_dict,
+                                   synth_features)
+
+pytestmark = pytest.mark.gpu
+
+
+def _conformer(V, streaming):
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    L = 3
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=5, perturb_norm=True)
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
+    return ConformerModel(80, V, streaming=streaming, encoder_conf=conf, state_dict=sd, device="cuda:0"), 4
+
+
+def _squeezeformer(V):
+    from ppasr_amd.model_utils.squeezeformer.model import SqueezeformerModel
+    L = 4
+    sd = squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=6, perturb_norm=True)
+    conf = dict(encoder_dim=256, output_size=256, attention_heads=4, num_blocks=L, reduce_idx=1, recover_idx=3,
+                feed_forward_expansion_factor=8, cnn_module_kernel=31)
+    return SqueezeformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0"), 4
+
+
+def _efficient(V):
+    from ppasr_amd.model_utils.efficient_conformer.model import EfficientConformerModel
+    L = 4
+    sd = efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=7, perturb_norm=True, stride_layer_idx=1,
+                                        group_layer_idx=(0, 1))
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15,
+                cnn_module_norm="layer_norm",
+                efficient_conf=dict(stride_layer_idx=[1], stride=[2], group_layer_idx=[0, 1], group_size=3,
+                                    stride_kernel=True))
+    return EfficientConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0"), 8
+
+
+FAMILIES = {
+    "conformer": lambda V: _conformer(V, True),
+    "conformer-noncausal": lambda V: _conformer(V, False),
+    "squeezeformer": _squeezeformer,
+    "efficient": _efficient,
+}
+
+
+@pytest.mark.parametrize("family", list(FAMILIES))
+@pytest.mark.parametrize("lens", [[900, 611, 420, 133, 36, 7], [1203, 1203, 300], [260, 258, 257, 131, 129, 128, 127, 1]])
+def test_skip_padding_equals_default_on_valid_rows(family, lens):
+    V = 211
+    model, mul = FAMILIES[family](V)
+    B, T = len(lens), max(lens)
+    x, lens_a = synth_features(B, T, lens=lens, seed=T + B)
+    p0, l0 = model.get_encoder_out(x, lens_a, return_logits=True)
+    t0, n0, s0 = model.encode_greedy(x, lens_a, trim_to_length=True) if mul == 4 else (None, None, None)
+    model.set_skip_padding(True)
+    try:
+        p1, l1 = model.get_encoder_out(x, lens_a, return_logits=True)
+        t1, n1, s1 = model.encode_greedy(x, lens_a, trim_to_length=True) if mul == 4 else (None, None, None)
+    finally:
+        model.set_skip_padding(False)
+    torch.cuda.synchronize()
+    Tp = p0.shape[1]
+    for b, ln in enumerate(lens):
+        nv = min(Tp, (ln + mul - 1) // mul)
+        assert torch.equal(p0[b, :nv], p1[b, :nv]), (family, b, ln)
+        assert torch.equal(l0[b, :nv], l1[b, :nv]), (family, b, ln)
+        assert not bool(p1[b, nv:].any()) and not bool(l1[b, nv:].any()), (family, b, ln)
+    assert bool(torch.isfinite(p1).all())
+    if mul == 4:
+        assert torch.equal(n0, n1) and torch.equal(t0, t1)
+        assert np.allclose(s0.cpu().numpy(), s1.cpu().numpy(), rtol=0, atol=0)
+
+
+def test_skip_padding_without_lengths_is_the_default_mode():
+    model, _ = _conformer(97, True)
+    x, lens = synth_features(2, 200, seed=3)
+    p0 = model.get_encoder_out(x, lens)
+    model.set_skip_padding(True)
+    p1 = model.get_encoder_out(x, lens)  # full-length utterances: nothing to skip
+    model.set_skip_padding(False)
+    assert torch.equal(p0, p1)

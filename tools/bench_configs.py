@@ -84,10 +84,30 @@ def cfg5():
         for st in streams:
             main.wait_stream(st)
     dt = timeit(step, 3, 1)
-    return {"config": "cfg5 Squeezeformer 16 var-len utterances (2-30 s) in 200-frame buckets, beam=10",
-            "buckets": len(batches), "ms": round(dt * 1e3, 2), "audio_s_per_s": round(float(lens.sum()) * 0.01 / dt, 1)}
+    out = [{"config": "cfg5 Squeezeformer 16 var-len utterances (2-30 s) in 200-frame buckets, beam=10",
+            "buckets": len(batches), "ms": round(dt * 1e3, 2), "audio_s_per_s": round(float(lens.sum()) * 0.01 / dt, 1)}]
+    # the same 16 utterances as ONE batch padded to the longest, without / with skip_padding (ragged-batch mode:
+    # rows behind each utterance's valid frames are not computed)
+    x, l = synth_features(16, int(lens[0]), lens=[int(v) for v in lens], seed=20740)
+    x, l = torch.from_numpy(x).cuda(), torch.from_numpy(l).cuda()
+    fl = torch.clamp((l + 3) // 4, max=m.out_frames(x.shape[1])).int()
+
+    def one():
+        probs = m.get_encoder_out(x, l)
+        beam_search_ids(probs, 10, 0.99, 40, 0, frame_lens=fl)
+    for skip in (False, True):
+        m.set_skip_padding(skip)
+        enc = timeit(lambda: m.get_encoder_out(x, l), 3, 1)
+        dt = timeit(one, 3, 1)
+        out.append({"config": "cfg5 as one padded batch of 16" + (", skip_padding" if skip else ""),
+                    "encoder_ms": round(enc * 1e3, 2), "ms": round(dt * 1e3, 2),
+                    "audio_s_per_s": round(float(lens.sum()) * 0.01 / dt, 1)})
+    m.set_skip_padding(False)
+    return out
 
 
 if __name__ == "__main__":
     for f in (cfg1, cfg4, cfg5):
-        print(json.dumps(f()), flush=True)
+        r = f()
+        for line in (r if isinstance(r, list) else [r]):
+            print(json.dumps(line), flush=True)
