@@ -6,24 +6,39 @@ With ``torch.distributed`` initialised, every rank evaluates the batches ``rank:
 rates are summed with one all-reduce (utterance data parallelism)."""
 import torch
 
-from ppasr_amd.decoders.ctc_greedy_decoder import greedy_decoder_batch
+from ppasr_amd.decoders.beam_search_decoder import beam_search_ids
+from ppasr_amd.decoders.ctc_greedy_decoder import greedy_decode_ids, greedy_decoder_batch
 from ppasr_amd.utils.metrics import cer, labels_to_string, wer
 
 __all__ = ["decoder_result", "evaluate"]
 
 
-def decoder_result(outs, vocabulary, decoder="ctc_greedy", beam_search_decoder=None):
-    """trainer.py:330-352: outs [B,T',V] (device tensor or numpy) -> list[str]; every one of the T' rows is decoded."""
+def decoder_result(outs, vocabulary, decoder="ctc_greedy", beam_search_decoder=None, frame_lens=None):
+    """trainer.py:330-352: outs [B,T',V] (device tensor or numpy) -> list[str]; every one of the T' rows is decoded
+    (the reference's behaviour) unless ``frame_lens`` [B] names the valid frames of every utterance."""
+    if frame_lens is None:
+        if decoder == "ctc_greedy" or beam_search_decoder is None:
+            return greedy_decoder_batch(outs, vocabulary)
+        return beam_search_decoder.decode_batch_beam_search_offline(probs_split=outs)
     if decoder == "ctc_greedy" or beam_search_decoder is None:
-        return greedy_decoder_batch(outs, vocabulary)
-    return beam_search_decoder.decode_batch_beam_search_offline(probs_split=outs)
+        tokens, n, _, _, _ = greedy_decode_ids(outs, frame_lens)
+    else:
+        d = beam_search_decoder
+        tokens, n, _, _ = beam_search_ids(outs, d.beam_size, d.cutoff_prob, d.cutoff_top_n, d.blank_id,
+                                          frame_lens=frame_lens, nbest=1, ext_scorer=d._ext_scorer)
+        tokens, n = tokens[:, 0], n[:, 0]
+    tk, nn = tokens.cpu(), n.cpu()
+    return ["".join(vocabulary[i] for i in tk[b, :max(int(nn[b]), 0)].tolist()).replace("<space>", " ")
+            for b in range(tk.shape[0])]
 
 
 def evaluate(model, batches, vocab_list, decoder="ctc_greedy", metrics_type="cer", beam_search_decoder=None,
-             display_result=False):
+             display_result=False, trim_padding=False):
     """model: any ppasr_amd model with ``get_encoder_out(inputs, input_lens)``;
     batches: iterable of (inputs [B,T,F], labels [B,U] (-1 padded), input_lens [B], label_lens [B]) like the reference's
-    test_loader.  -> mean error rate (float), -1 if there is nothing to score (trainer.py:643)."""
+    test_loader.  -> mean error rate (float), -1 if there is nothing to score (trainer.py:643).
+    ``trim_padding=True`` (not the reference's behaviour, which decodes the padded rows of every utterance too): the
+    encoder runs in its ragged-batch mode and the decoders stop at each utterance's last valid frame."""
     dist = torch.distributed.is_available() and torch.distributed.is_initialized()
     rank = torch.distributed.get_rank() if dist else 0
     world = torch.distributed.get_world_size() if dist else 1
@@ -32,8 +47,16 @@ def evaluate(model, batches, vocab_list, decoder="ctc_greedy", metrics_type="cer
     for batch_id, (inputs, labels, input_lens, _label_lens) in enumerate(batches):
         if batch_id % world != rank:
             continue
-        outs = model.get_encoder_out(inputs, input_lens)
-        out_strings = decoder_result(outs, vocab_list, decoder, beam_search_decoder)
+        frame_lens = None
+        if trim_padding:
+            model.set_skip_padding(True)
+            frame_lens = model.valid_out_frames(input_lens, inputs.shape[1])
+        try:
+            outs = model.get_encoder_out(inputs, input_lens)
+        finally:
+            if trim_padding:
+                model.set_skip_padding(False)
+        out_strings = decoder_result(outs, vocab_list, decoder, beam_search_decoder, frame_lens)
         labels_str = labels_to_string(labels, vocab_list, eos=eos)
         for out_string, label in zip(out_strings, labels_str):
             err = wer(out_string, label) if metrics_type == "wer" else cer(out_string, label)

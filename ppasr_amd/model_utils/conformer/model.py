@@ -160,6 +160,14 @@ class ConformerModel:
                                                    stream))
         return tokens, n_tokens, score
 
+    def valid_out_frames(self, speech_lengths, T):
+        """Output frames that are not padding, per utterance (int32 device tensor): frame t of the output is valid iff
+        ``mul * t < len`` with ``mul`` = the model's total time reduction (the reference's mask slicing,
+        subsampling.py:115; x2 behind the Efficient-Conformer's stride layer)."""
+        lens = torch.as_tensor(speech_lengths, dtype=torch.int64).to(self.device)
+        mul = 8 if getattr(self, "stride_layer_idx", None) is not None else 4
+        return torch.clamp((lens + mul - 1) // mul, min=0, max=self.out_frames(int(T))).to(torch.int32)
+
     def set_skip_padding(self, enable=True):
         """Ragged batches: compute, per utterance, only the rows its valid output frames depend on
         (``ppasr_set_skip_padding``).  Valid rows are bit-identical to the default mode; rows of the returned

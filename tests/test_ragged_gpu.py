@@ -84,3 +84,34 @@ def test_skip_padding_without_lengths_is_the_default_mode():
     p1 = model.get_encoder_out(x, lens)  # full-length utterances: nothing to skip
     model.set_skip_padding(False)
     assert torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize("decoder", ["ctc_greedy", "ctc_beam_search"])
+def test_evaluate_trim_padding(decoder):
+    """evaluate(trim_padding=True) on a ragged batch = decoding, per utterance, only the rows the reference's own
+    length mask calls valid (4t < len) of the default-mode probabilities; the reference's default additionally decodes
+    the padded rows of the shorter utterances."""
+    from ppasr_amd.decoders.beam_search_decoder import BeamSearchDecoder
+    from ppasr_amd.decoders.ctc_greedy_decoder import greedy_decoder_batch
+    from ppasr_amd.evaluate import evaluate
+    from ppasr_amd.utils.metrics import cer, labels_to_string
+    from ppasr_amd.utils.synth import synth_vocabulary
+    V = 150
+    vocab = synth_vocabulary(V)
+    model, _ = _conformer(V, True)
+    bsd = BeamSearchDecoder(0.0, 0.0, 8, 0.99, 40, vocab) if decoder == "ctc_beam_search" else None
+    lens = [403, 251, 120, 64]
+    x, la = synth_features(len(lens), max(lens), lens=lens, seed=11)
+    rng = np.random.Generator(np.random.PCG64(5))
+    labels = rng.integers(2, V - 1, size=(len(lens), 30)).astype(np.int64)
+    probs = model.get_encoder_out(x, la)
+    nv = model.valid_out_frames(la, x.shape[1]).cpu().tolist()
+    assert nv == [min(probs.shape[1], (ln + 3) // 4) for ln in lens]
+    want = 0.0
+    for b in range(len(lens)):
+        one = probs[b:b + 1, :nv[b]].contiguous()
+        text = bsd.decode_batch_beam_search_offline(one)[0] if bsd else greedy_decoder_batch(one, vocab)[0]
+        want += cer(text, labels_to_string(labels[b:b + 1], vocab, eos=V - 1)[0])
+    got = evaluate(model, [(x, labels, la, None)], vocab, decoder=decoder, beam_search_decoder=bsd, trim_padding=True)
+    assert got == pytest.approx(want / len(lens))
+    assert not model.__dict__.get("skip_padding", False)  # evaluate restores the default mode
