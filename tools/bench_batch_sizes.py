@@ -1,0 +1,49 @@
+"""Encoder + greedy throughput of the three *former families over batch sizes (32 x 10 s is the bench shape): shows the
+row-block quantisation -- a kernel with <= 256 row blocks takes one round whatever their number, so the half-rate layers
+of Squeezeformer / Efficient-Conformer only fill the chip from B = 64."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ppasr_amd.utils.synth import (conformer_state_dict, efficient_conformer_state_dict, squeezeformer_state_dict,
+                                   synth_features)
+
+V, L = 4233, 12
+
+
+def models():
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    from ppasr_amd.model_utils.efficient_conformer.model import EfficientConformerModel
+    from ppasr_amd.model_utils.squeezeformer.model import SqueezeformerModel
+    yield "conformer", ConformerModel(80, V, streaming=True, encoder_conf=dict(
+        output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15),
+        state_dict=conformer_state_dict(vocab_size=V, num_blocks=L, seed=1))
+    yield "squeezeformer", SqueezeformerModel(80, V, streaming=True, encoder_conf=dict(
+        encoder_dim=256, output_size=256, attention_heads=4, num_blocks=L, reduce_idx=5, recover_idx=11,
+        feed_forward_expansion_factor=8, cnn_module_kernel=31), state_dict=squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=1))
+    yield "efficient_conformer", EfficientConformerModel(80, V, streaming=True, encoder_conf=dict(
+        output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15,
+        efficient_conf=dict(stride_layer_idx=[3], stride=[2], group_layer_idx=[0, 1, 2, 3], group_size=3)),
+        state_dict=efficient_conformer_state_dict(vocab_size=V, seed=1))
+
+
+for name, m in models():
+    for B in (16, 32, 64, 128):
+        x, lens = synth_features(B, 1000, seed=B)
+        x, lens = torch.from_numpy(x).cuda(), torch.from_numpy(lens).cuda()
+        for _ in range(2):
+            m.encode_greedy(x, lens)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        n = 5
+        for _ in range(n):
+            m.encode_greedy(x, lens)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / n
+        print(json.dumps({"model": name, "B": B, "ms": round(dt * 1e3, 2), "audio_s_per_s": round(B * 10 / dt)}), flush=True)
+    del m
+    torch.cuda.empty_cache()
