@@ -1,5 +1,5 @@
-// ctc_beam.hip -- CTC prefix beam search on the GPU: one workgroup per utterance, beam hypotheses,
-// the pruned character list and the frame's log-probabilities resident in LDS.
+// ctc_beam.hip -- CTC prefix beam search on the GPU: a frame-parallel pruning pre-pass, then one workgroup per
+// utterance with the beam hypotheses and the frame's pruned character list resident in LDS.
 //
 // Replaces the third-party C++/SWIG module `paddlespeech_ctcdecoders` that PPASR calls from
 // ppasr/decoders/swig_wrapper.py:61-62 (ctc_beam_search_decoding), :98-100 (..._batch) and
@@ -17,8 +17,10 @@
 //     the fly, then an ordered compaction -- nothing of size beam x candidates is ever stored.
 // External scorer (`ext_scorer`, character-based n-gram LM, lm.h): the min_cutoff pruning of (character, prefix) pairs,
 // alpha * log P_lm + beta on every extension, and the approximate-CTC result score with the LM weight removed.  The LM
-// term of every (hypothesis, candidate) pair is computed once per frame into LDS; each hypothesis carries its last
-// order-1 LM word ids, shifted on extension.
+// term of a (hypothesis, candidate) pair is computed on the fly inside its score key (the key is inverted back to the
+// extension's log-probability when the pair survives); each hypothesis carries its last order-1 LM word ids, shifted on
+// extension.
+// The vocabulary pruning of ALL frames runs first, frame-parallel (k_ctc_prune); k_ctc_beam consumes its records.
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <math.h>
