@@ -730,6 +730,17 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
                                  : ptab + (size_t)jc * pstride * kD + h * 64 + 8 * (gk - 8) + 4 * hh;
     return *reinterpret_cast<const f32x4*>(base);
   };
+  // K' fragments of a sub-block's first PF k-groups: requested one sub-block ahead (right before the previous
+  // sub-block's PV phase, when the score accumulators are dead) so that their L2 round trip hides behind PV
+  f32x4 ringk[PF][2];
+  auto prime_k = [&](int k0) {
+#pragma unroll
+    for (int sx = 0; sx < PF; ++sx) {
+      ringk[sx][0] = kfrag(k0 + l31, sx);
+      ringk[sx][1] = kfrag(k0 + l31 + 32, sx);
+    }
+  };
+  if (khalf * 128 < T2) prime_k(khalf * 128);
   f32x16 acc_o[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -742,14 +753,11 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
     for (int sb = 0; sb < 2; ++sb) {
       const int key0 = kb * 256 + khalf * 128 + sb * 64;
       if (key0 >= T2) break;  // wave-uniform
+      // the sub-block this wave handles next (wave-uniform), or -1
+      int key_next = sb == 0 ? key0 + 64 : (kb + 1) * 256 + khalf * 128;
+      if (key_next >= T2) key_next = (sb == 0 && (kb + 1) * 256 + khalf * 128 < T2) ? (kb + 1) * 256 + khalf * 128 : -1;
       // ---- S = Q' K'^T for 64 keys (two 32-key tiles, two independent accumulator chains) ----
-      f32x4 ringk[PF][2];
       const int jk0 = key0 + l31, jk1 = jk0 + 32;
-#pragma unroll
-      for (int sx = 0; sx < PF; ++sx) {
-        ringk[sx][0] = kfrag(jk0, sx);
-        ringk[sx][1] = kfrag(jk1, sx);
-      }
       f32x16 acc_s[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -823,6 +831,7 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
         m_run = m_new;
         l_run = l_run * alpha + ps;
       }
+      if (key_next >= 0) prime_k(key_next);
       // ---- O = O * alpha + P V (alpha of row r lives in lane r) ----
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
