@@ -712,11 +712,18 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
   // ---- Q' fragments in registers: qa[gk][j] = Q'[row l31][8 gk + 4 hh + j], Q' = [q+u | q+v] ----
   f32x4 qa[NG];
   {
-    const float* qrow = qb + (size_t)(q0 + min(l31, valid - 1)) * a.q_stride + h * 64 + 4 * hh;
+    // the block's query rows go through LDS (bufC is free until the merge): whole 1 KiB rows per wave-load instead of
+    // 64 scattered 16-byte pieces per fragment load
+    for (int row = wave; row < kRows; row += kWaves) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < valid) v = *reinterpret_cast<const f32x4*>(qb + (size_t)(q0 + row) * a.q_stride + 4 * lane);
+      *reinterpret_cast<f32x4*>(bufC + row * kLda + 4 * lane) = v;
+    }
+    __syncthreads();
+    const float* qrow = bufC + l31 * kLda + h * 64 + 4 * hh;
 #pragma unroll
     for (int gq = 0; gq < 8; ++gq) {
-      f32x4 q = *reinterpret_cast<const f32x4*>(qrow + 8 * gq);
-      if (l31 >= valid) q = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 q = *reinterpret_cast<const f32x4*>(qrow + 8 * gq);
       const f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + h * 64 + 8 * gq + 4 * hh);
       const f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + h * 64 + 8 * gq + 4 * hh);
       qa[gq] = q + u;
