@@ -112,6 +112,14 @@ ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats);
  * to the decoders.  Default: off (= the reference's outputs for every row). */
 ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable);
 
+/* Under-filled launches.  A kernel with fewer 32-row blocks than the chip has CUs takes as long as a full one.  When a
+ * call has <= 128 row blocks (small batches, the half-rate layers of the Efficient-Conformer, a single streaming
+ * session) the Conformer-family layer tail is cut at its two feed-forward modules and each module's hidden dimension is
+ * split over 2 / 4 / 8 workgroups per row block (partial sums joined by the next launch).  Same arithmetic up to the
+ * order of the final sum over hidden chunks.  mode: -1 = decide by grid size (default), 0 = never (always the fused
+ * kernels), 2 / 4 / 8 = always that many slices. */
+ppasr_status ppasr_set_ffn_split(ppasr_handle h, int mode);
+
 /* Replaces the third-party `paddlespeech_ctcdecoders` entry points PPASR calls:
  *   ctc_beam_search_decoding / ctc_beam_search_decoding_batch  (decoders/swig_wrapper.py:61-62,98-100,
  *     from BeamSearchDecoder.decode_beam_search_offline / decode_batch_beam_search_offline,

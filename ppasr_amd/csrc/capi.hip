@@ -306,6 +306,17 @@ WsLayout ws_layout(const ppasr_model_s* m, int B, int T) {
   w.total = o;
   return w;
 }
+int ffn_split_for(const ppasr_model_s* m, int M) {
+  if (m->desc.model_type == PPASR_MODEL_SQUEEZEFORMER || m->desc.model_type == PPASR_MODEL_DEEPSPEECH2) return 1;
+  const int n_chunks = m->desc.linear_units / 256;
+  if (m->ffn_split >= 0) return m->ffn_split > 1 ? m->ffn_split : 1;
+  const int blocks = (M + kRows - 1) / kRows;
+  if (blocks > 128) return 1;
+  int S = 8;
+  while (S > 1 && (blocks * S > 256 || n_chunks % S != 0)) S >>= 1;
+  return S;
+}
+
 extern "C" {
 
 size_t ppasr_workspace_bytes(ppasr_handle h, int B, int T) {
@@ -317,6 +328,14 @@ ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats) 
   if (!h) return fail(PPASR_EINVAL, "null handle");
   h->taps = taps;
   h->taps_floats = taps ? n_floats : 0;
+  return PPASR_OK;
+}
+
+ppasr_status ppasr_set_ffn_split(ppasr_handle h, int mode) {
+  if (!h) return fail(PPASR_EINVAL, "null handle");
+  if (mode != -1 && mode != 0 && mode != 2 && mode != 4 && mode != 8) return fail(PPASR_EINVAL, "ffn split: -1, 0, 2, 4 or 8");
+  if (mode > 0 && (h->desc.linear_units / 256) % mode != 0) return fail(PPASR_EINVAL, "ffn split must divide linear_units / 256");
+  h->ffn_split = mode;
   return PPASR_OK;
 }
 
@@ -399,7 +418,21 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     };
     const bool fuse_attn = fusable(i);
     const PadSkip ps = pskip(Ti, mul);
-    if (!s1_done) timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st, ps); });
+    // under-filled grid: FFNs split over S workgroups per row block (partial sums in the conv1 buffer, free by now)
+    const int S = ffn_split_for(h, Mi);
+    float* partial = y1;
+    float* x3 = ctx;
+    if (!s1_done) {
+      if (S > 1) {
+        timed(3, [&] {
+          launch_ffn_split(xa, L.ln_mac_g, L.ln_mac_b, L.ffm_w1, L.ffm_b1, L.ffm_w2, L.ffm_b2, 0.5f, nullptr, nullptr, partial,
+                           xb, Mi, n_chunks, S, st, ps);
+          launch_ln_qkv(xb, qkv, L, Mi, st, ps);
+        });
+      } else {
+        timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st, ps); });
+      }
+    }
     s1_done = false;
     tap(xb, (size_t)Mi * kD);
     tap(qkv, (size_t)Mi * 3 * kD);
@@ -425,6 +458,12 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       Ti = Ts;  // masks[:, :, ::2], pos_emb[:, ::2]  (efficient_conformer/encoder.py:252-257)
       mul *= 2;
       pstride *= 2;
+    } else if (S > 1) {
+      timed(6, [&] {
+        launch_conv_pre(g, nullptr, xc, x3, L, lens, Mi, Ti, h->layer_ks[i], mul, st, h->desc.causal != 0, ps);
+        launch_ffn_split(x3, L.ln_ff_g, L.ln_ff_b, L.ff_w1, L.ff_b1, L.ff_w2, L.ff_b2, 0.5f, L.ln_fin_g, L.ln_fin_b, partial,
+                         xa, Mi, n_chunks, S, st, ps);
+      });
     } else {
       // fuse the next layer's S1 into this launch (it writes xb / qkv, which this layer no longer reads)
       const LayerW* next = (i + 1 < h->desc.num_blocks) ? &h->layers[i + 1] : nullptr;

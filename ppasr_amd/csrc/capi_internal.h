@@ -83,6 +83,7 @@ struct ppasr_model_s {
   size_t taps_floats = 0;
   // optional per-kernel timing (bench.py roofline leg): one event pair per launch on the caller's stream
   bool prof = false;
+  int ffn_split = -1;  // ppasr_set_ffn_split: -1 = by grid size, 0 = never, 2 / 4 / 8 = always that many slices
   bool skip_padding = false;  // ppasr_set_skip_padding: ragged batches compute only the rows valid outputs depend on
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -122,6 +123,8 @@ struct WsLayout {
   size_t y1, y2, xa, xb, xc, qkv, ctx, g, rmax, rsum, fa, fp, xs, total;  // offsets in floats
 };
 WsLayout ws_layout(const ppasr_model_s* m, int B, int T);
+// hidden-dimension slices per row block for M rows (1 = the fused kernels), see ppasr_set_ffn_split
+int ffn_split_for(const ppasr_model_s* m, int M);
 
 ppasr_status upload_pe_table(ppasr_model_s* m, BlobMap& sd, const float** pe_dev);
 

@@ -26,14 +26,18 @@ struct SwishSide {
 // owns hidden columns [32w,32w+32) of each chunk and output columns [32w,32w+32).
 // Weight stream order: W1(0), W1(1), W2(0), W1(2), W2(1), ..., W2(n-1), then `after`.
 // The swish epilogue of chunk c runs inside the W1(c+1) MFMA stream.
+// c0 / n_total: the call covers hidden chunks [c0, c0 + n_chunks) of a layer with n_total chunks (a slice of the hidden
+// dimension = a partial sum of the output, k_ffn_part); default = all of them.
 __device__ __forceinline__ void ffn_phase(const float* bufA, float* bufH, const f32x4* __restrict__ w1,
                                           const float* __restrict__ b1, const f32x4* __restrict__ w2, int n_chunks,
-                                          const f32x4* __restrict__ after, BRing<1>& ring, f32x16 (&acc2)[1][1]) {
+                                          const f32x4* __restrict__ after, BRing<1>& ring, f32x16 (&acc2)[1][1],
+                                          int c0 = 0, int n_total = -1) {
   const int lane = lane_id(), wave = wave_id();
-  const int ts2 = n_chunks * 32 * 64;  // W2: K = hidden
+  const int ts2 = (n_total > 0 ? n_total : n_chunks) * 32 * 64;  // W2: K = hidden
   const int col = wave * 32 + (lane & 31);
-  auto w1seg = [&](int c) { return w1 + (size_t)(c * 8 + wave) * kTs256; };
-  auto w2seg = [&](int c) { return w2 + (size_t)wave * ts2 + (size_t)c * 32 * 64; };
+  b1 += c0 * 256;
+  auto w1seg = [&](int c) { return w1 + (size_t)((c0 + c) * 8 + wave) * kTs256; };
+  auto w2seg = [&](int c) { return w2 + (size_t)wave * ts2 + (size_t)(c0 + c) * 32 * 64; };
   f32x16 cur[1][1], nx[1][1];
   acc_zero(cur);
   rb_gemm<1, 1, kG256>(bufA, kLda, w1seg(0), 0, n_chunks > 1 ? w1seg(1) : w2seg(0), 0, ring, cur);

@@ -177,6 +177,12 @@ class ConformerModel:
         self.skip_padding = bool(enable)
         _lib.check(self.lib.ppasr_set_skip_padding(self._h, 1 if enable else 0))
 
+    def set_ffn_split(self, mode=-1):
+        """Under-filled launches (``ppasr_set_ffn_split``): -1 = split the feed-forward modules' hidden dimension over
+        2 / 4 / 8 workgroups per row block when a call has <= 128 row blocks (default), 0 = always the fused kernels,
+        2 / 4 / 8 = always that many slices."""
+        _lib.check(self.lib.ppasr_set_ffn_split(self._h, int(mode)))
+
     def set_debug_taps(self, n_floats):
         """Allocate a tap buffer; layout in DESIGN.md (x0, then per layer x1,qkv,ctx,x2,g,x_out)."""
         self._taps = torch.zeros(n_floats, dtype=torch.float32, device=self.device) if n_floats else None

@@ -31,19 +31,30 @@ def models():
         state_dict=efficient_conformer_state_dict(vocab_size=V, seed=1))
 
 
+only = sys.argv[1:]  # optional: model names
 for name, m in models():
-    for B in (16, 32, 64, 128):
+    if only and name not in only:
+        continue
+    for B in (4, 8, 16, 32, 64, 128):
         x, lens = synth_features(B, 1000, seed=B)
         x, lens = torch.from_numpy(x).cuda(), torch.from_numpy(lens).cuda()
-        for _ in range(2):
-            m.encode_greedy(x, lens)
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        n = 5
-        for _ in range(n):
-            m.encode_greedy(x, lens)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t) / n
-        print(json.dumps({"model": name, "B": B, "ms": round(dt * 1e3, 2), "audio_s_per_s": round(B * 10 / dt)}), flush=True)
+        res = {"model": name, "B": B}
+        for label, mode in (("fused", 0), ("auto", -1)):  # always the fused kernels / split route for under-filled grids
+            if hasattr(m, "set_ffn_split") and name != "squeezeformer":
+                m.set_ffn_split(mode)
+            elif mode == -1:
+                continue
+            for _ in range(2):
+                m.encode_greedy(x, lens)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            n = 5
+            for _ in range(n):
+                m.encode_greedy(x, lens)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) / n
+            res[label + "_ms"] = round(dt * 1e3, 2)
+            res[label + "_audio_s_per_s"] = round(B * 10 / dt)
+        print(json.dumps(res), flush=True)
     del m
     torch.cuda.empty_cache()
