@@ -127,8 +127,10 @@ ppasr_status finish_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* shift_tm
 }
 
 // ---- Conformer / Efficient-Conformer ----
+// `partial`: scratch for the split route of under-filled launches (ppasr_set_ffn_split; a chunk is ONE row block, so by
+// default its feed-forward modules are split over 8 workgroups) -- the conv1 buffer, free after the front-end
 ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, float* xb, float* xc, float* qkv, float* ctx,
-                             float* g, float* xhat, int* frames_out, hipStream_t st) {
+                             float* g, float* xhat, float* partial, int* frames_out, hipStream_t st) {
   ppasr_model_s* h = s->m;
   const int n_chunks = h->desc.linear_units / 256;
   const int H = h->desc.attention_heads;
@@ -143,7 +145,14 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
     float* vc = s->vc + (size_t)i * s->cap * kD;
     float* xh = s->xh_hist + (size_t)i * s->lo * kD;
     const int lo_i = layer_lo(h, i);
-    launch_ffn_qkv(xa, xb, qkv, L, Ti, n_chunks, st);
+    const int S = ffn_split_for(h, Ti);
+    if (S > 1) {
+      launch_ffn_split(xa, L.ln_mac_g, L.ln_mac_b, L.ffm_w1, L.ffm_b1, L.ffm_w2, L.ffm_b2, 0.5f, nullptr, nullptr, partial, xb,
+                       Ti, n_chunks, S, st);
+      launch_ln_qkv(xb, qkv, L, Ti, st);
+    } else {
+      launch_ffn_qkv(xa, xb, qkv, L, Ti, n_chunks, st);
+    }
     launch_kv_append(qkv, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD, Ti, st);
     // grouped attention re-cuts cache + chunk frames into groups of 3 from the START of the cache (pad4group on the
     // concatenated keys, efficient_conformer/attention.py:160-175), zero-padded tail group
@@ -161,7 +170,13 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
       pstride *= 2;
       half = true;
     } else {
-      launch_conv_ffn(g, s->g_hist, xc, xa, L, nullptr, Ti, Ti, n_chunks, h->layer_ks[i], mul, nullptr, nullptr, nullptr, st);
+      if (S > 1) {
+        launch_conv_pre(g, s->g_hist, xc, ctx, L, nullptr, Ti, Ti, h->layer_ks[i], mul, st);
+        launch_ffn_split(ctx, L.ln_ff_g, L.ln_ff_b, L.ff_w1, L.ff_b1, L.ff_w2, L.ff_b2, 0.5f, L.ln_fin_g, L.ln_fin_b, partial,
+                         xa, Ti, n_chunks, S, st);
+      } else {
+        launch_conv_ffn(g, s->g_hist, xc, xa, L, nullptr, Ti, Ti, n_chunks, h->layer_ks[i], mul, nullptr, nullptr, nullptr, st);
+      }
       launch_hist_update(xh, xhat, Ti, lo_i, st);
     }
   }
@@ -304,7 +319,7 @@ ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int r
   float* x_final = xa;
   int frames = c;
   if (is_sq(h)) r = squeezeformer_chunk(s, p, xa, xb, xc, qkv, ctx, g, ws + wl.xs, xhat, &x_final, st);
-  else r = conformer_chunk(s, p, xa, xb, xc, qkv, ctx, g, xhat, &frames, st);
+  else r = conformer_chunk(s, p, xa, xb, xc, qkv, ctx, g, xhat, y1, &frames, st);
   if (r != PPASR_OK) return r;
   int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
   float* fp = frame_maxprob ? frame_maxprob : ws + wl.fp;
@@ -504,14 +519,27 @@ ppasr_status ppasr_encode_chunk_group(ppasr_stream_group g, const int* sessions_
     float* kc = g->kc + (size_t)i * g->cap * kD;
     float* vc = g->vc + (size_t)i * g->cap * kD;
     float* xh = g->xh_hist + (size_t)i * lo * kD;
-    launch_ffn_qkv(xa, xb, qkv, W, M, n_chunks, st);
+    const int S = ffn_split_for(h, M);  // few sessions = an under-filled grid: split route (partial sums in y1)
+    if (S > 1) {
+      launch_ffn_split(xa, W.ln_mac_g, W.ln_mac_b, W.ffm_w1, W.ffm_b1, W.ffm_w2, W.ffm_b2, 0.5f, nullptr, nullptr, y1, xb, M,
+                       n_chunks, S, st);
+      launch_ln_qkv(xb, qkv, W, M, st);
+    } else {
+      launch_ffn_qkv(xa, xb, qkv, W, M, n_chunks, st);
+    }
     launch_kv_append_group(qkv, kc, vc, kv_sess, desc_dev, n, c, st);
     AttnArgs a{qkv, 768, kc, kD, vc, kD, c, c, 0, nullptr, ctx, W.pos_u, W.pos_v, W.ptab, 1, 4, c, c, 1, desc_dev, kv_sess};
     launch_attention(a, n, H, st);
     launch_hist_gather(xh, hist_sess, desc_dev, xh_act, n, lo, st);
     launch_pw1_glu(xh_act, g_hist, W, n * lo, st);
     launch_out_glu(ctx, xb, xc, gg, xhat, W, nullptr, M, c, 4, st);
-    launch_conv_ffn(gg, g_hist, xc, xa, W, nullptr, M, c, n_chunks, h->desc.cnn_module_kernel, 4, nullptr, nullptr, nullptr, st);
+    if (S > 1) {
+      launch_conv_pre(gg, g_hist, xc, ctx, W, nullptr, M, c, h->desc.cnn_module_kernel, 4, st);
+      launch_ffn_split(ctx, W.ln_ff_g, W.ln_ff_b, W.ff_w1, W.ff_b1, W.ff_w2, W.ff_b2, 0.5f, W.ln_fin_g, W.ln_fin_b, y1, xa, M,
+                       n_chunks, S, st);
+    } else {
+      launch_conv_ffn(gg, g_hist, xc, xa, W, nullptr, M, c, n_chunks, h->desc.cnn_module_kernel, 4, nullptr, nullptr, nullptr, st);
+    }
     launch_hist_update_group(xh, hist_sess, desc_dev, xhat, n, c, lo, st);
   }
   int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
