@@ -307,7 +307,7 @@ WsLayout ws_layout(const ppasr_model_s* m, int B, int T) {
   return w;
 }
 int ffn_split_for(const ppasr_model_s* m, int M) {
-  if (m->desc.model_type == PPASR_MODEL_SQUEEZEFORMER || m->desc.model_type == PPASR_MODEL_DEEPSPEECH2) return 1;
+  if (m->desc.model_type == PPASR_MODEL_DEEPSPEECH2) return 1;
   const int n_chunks = m->desc.linear_units / 256;
   if (m->ffn_split >= 0) return m->ffn_split > 1 ? m->ffn_split : 1;
   const int blocks = (M + kRows - 1) / kRows;

@@ -125,6 +125,7 @@ struct WsLayout {
 WsLayout ws_layout(const ppasr_model_s* m, int B, int T);
 // hidden-dimension slices per row block for M rows (1 = the fused kernels), see ppasr_set_ffn_split
 int ffn_split_for(const ppasr_model_s* m, int M);
+ppasr::LayerW sq_conv_view(const ppasr::SqLayerW& W);  // capi_squeezeformer.hip
 
 ppasr_status upload_pe_table(ppasr_model_s* m, BlobMap& sd, const float** pe_dev);
 

@@ -205,6 +205,15 @@ ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe
   return PPASR_OK;
 }
 
+// the conv-module fields of a Squeezeformer layer as the LayerW view k_conv_pre reads
+LayerW sq_conv_view(const SqLayerW& W) {
+  LayerW v{};
+  v.dw_w = W.dw_w; v.dw_b = W.dw_b; v.glu_pad = W.glu_pad;
+  v.ln_cm_g = W.ln_cm_g; v.ln_cm_b = W.ln_cm_b;
+  v.pw2 = W.pw2; v.pw2_b = W.pw2_b;
+  return v;
+}
+
 // SqueezeformerEncoder.forward (squeezeformer/encoder.py:172-236) + ctc softmax
 ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const int64_t* lens, int B, int T, float* probs,
                                   float* logits, int32_t* frame_argmax, float* frame_maxprob, float* ws,
@@ -270,13 +279,28 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
     a.pad_skip = skip ? ps.slack + 1 : 0;
     launch_attention(a, B, H, st);
     tap(ctx, (size_t)Mi * kD);
-    launch_sq_mid(ctx, x, xc, g, nullptr, W, lens, Mi, Ti, mul, n_chunks, st, ps);
-    tap(xc, (size_t)Mi * kD);
-    tap(g, (size_t)Mi * kD);
+    // under-filled grid (ppasr_set_ffn_split): K_B / K_C cut at their feed-forward modules, partial sums in the conv1 buffer
+    const int S = ffn_split_for(h, Mi);
     const bool fuse_next = (i + 1 < L) && (i + 1 != h->desc.reduce_idx) && !(i + 1 == h->desc.recover_idx && reduced);
     const SqLayerW* Wn = fuse_next ? &h->sq_layers[i + 1] : nullptr;
-    launch_sq_tail(g, nullptr, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, lens, Mi, Ti, mul, n_chunks, KS,
-                   st, ps);
+    if (S > 1) {
+      launch_sq_oproj(ctx, x, other, W, Mi, st, ps);  // x1 = LN1(x + MHA) in `other` (free until this layer's output)
+      launch_ffn_split(other, nullptr, nullptr, W.ff1_w1, W.ff1_b1, W.ff1_w2, W.ff1_b2, 1.0f, W.ln2_g, W.ln2_b, y1, xc, Mi,
+                       n_chunks, S, st, ps);
+      launch_sq_pw1glu(xc, g, nullptr, W, lens, Mi, Ti, mul, st, ps);
+      tap(xc, (size_t)Mi * kD);
+      tap(g, (size_t)Mi * kD);
+      launch_conv_pre(g, nullptr, xc, ctx, sq_conv_view(W), lens, Mi, Ti, KS, mul, st, true, ps);
+      launch_ffn_split(ctx, W.ln3_g, W.ln3_b, W.ff2_w1, W.ff2_b1, W.ff2_w2, W.ff2_b2, 1.0f, W.ln4_g, W.ln4_b, y1, other, Mi,
+                       n_chunks, S, st, ps, /*residual_is_normed=*/true);
+      if (Wn) launch_sq_qkv(other, qkv, Wn->wqkv, Wn->bqkv, Mi, st, ps);
+    } else {
+      launch_sq_mid(ctx, x, xc, g, nullptr, W, lens, Mi, Ti, mul, n_chunks, st, ps);
+      tap(xc, (size_t)Mi * kD);
+      tap(g, (size_t)Mi * kD);
+      launch_sq_tail(g, nullptr, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, lens, Mi, Ti, mul,
+                     n_chunks, KS, st, ps);
+    }
     std::swap(x, other);
     have_qkv = fuse_next;
     tap(x, (size_t)Mi * kD);

@@ -186,7 +186,8 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
 
 // ---- Squeezeformer ----
 ppasr_status squeezeformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, float* xb, float* xc, float* qkv,
-                                 float* ctx, float* g, float* xs, float* xhat, float** x_final, hipStream_t st) {
+                                 float* ctx, float* g, float* xs, float* xhat, float* partial, float** x_final,
+                                 hipStream_t st) {
   ppasr_model_s* h = s->m;
   const int L = h->desc.num_blocks, H = h->desc.attention_heads;
   const int n_chunks = h->desc.linear_units / 256, KS = h->desc.cnn_module_kernel;
@@ -221,11 +222,23 @@ ppasr_status squeezeformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* x
                mul, Ti, n_cache + Ti, 1};
     launch_attention(a, 1, H, st);
     history_glu(s, i, st);
-    launch_sq_mid(ctx, x, xc, g, xhat, W, nullptr, Ti, Ti, mul, n_chunks, st);
     const bool fuse_next = (i + 1 < L) && (i + 1 != h->desc.reduce_idx) && !(i + 1 == h->desc.recover_idx && reduced);
     const SqLayerW* Wn = fuse_next ? &h->sq_layers[i + 1] : nullptr;
-    launch_sq_tail(g, s->g_hist, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, nullptr, Ti, Ti, mul,
-                   n_chunks, KS, st);
+    const int S = ffn_split_for(h, Ti);  // one row block: split route (see squeezeformer_encode)
+    if (S > 1) {
+      launch_sq_oproj(ctx, x, other, W, Ti, st);
+      launch_ffn_split(other, nullptr, nullptr, W.ff1_w1, W.ff1_b1, W.ff1_w2, W.ff1_b2, 1.0f, W.ln2_g, W.ln2_b, partial, xc,
+                       Ti, n_chunks, S, st);
+      launch_sq_pw1glu(xc, g, xhat, W, nullptr, Ti, Ti, mul, st);
+      launch_conv_pre(g, s->g_hist, xc, ctx, sq_conv_view(W), nullptr, Ti, Ti, KS, mul, st);
+      launch_ffn_split(ctx, W.ln3_g, W.ln3_b, W.ff2_w1, W.ff2_b1, W.ff2_w2, W.ff2_b2, 1.0f, W.ln4_g, W.ln4_b, partial, other,
+                       Ti, n_chunks, S, st, PadSkip{}, /*residual_is_normed=*/true);
+      if (Wn) launch_sq_qkv(other, qkv, Wn->wqkv, Wn->bqkv, Ti, st);
+    } else {
+      launch_sq_mid(ctx, x, xc, g, xhat, W, nullptr, Ti, Ti, mul, n_chunks, st);
+      launch_sq_tail(g, s->g_hist, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, nullptr, Ti, Ti, mul,
+                     n_chunks, KS, st);
+    }
     launch_hist_update(xh, xhat, Ti, KS - 1, st);
     std::swap(x, other);
     have_qkv = fuse_next;
@@ -318,7 +331,7 @@ ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int r
   launch_embed(y2, h->front, xa, c, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/is_sq(h), st);
   float* x_final = xa;
   int frames = c;
-  if (is_sq(h)) r = squeezeformer_chunk(s, p, xa, xb, xc, qkv, ctx, g, ws + wl.xs, xhat, &x_final, st);
+  if (is_sq(h)) r = squeezeformer_chunk(s, p, xa, xb, xc, qkv, ctx, g, ws + wl.xs, xhat, y1, &x_final, st);
   else r = conformer_chunk(s, p, xa, xb, xc, qkv, ctx, g, xhat, y1, &frames, st);
   if (r != PPASR_OK) return r;
   int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);

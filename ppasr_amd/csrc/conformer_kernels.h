@@ -102,10 +102,12 @@ void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float
 void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float* x3, const LayerW& w, const int64_t* lens,
                      int M, int Tp, int ksize, int mask_mul, hipStream_t st, bool causal = true,
                      const PadSkip& ps = PadSkip{});
-// out = LN_out?(x + scale * (FFN(LN(x)) )) ; partial: S * M * 256 floats of scratch
+// out = LN_out?(r + scale * FFN(LN?(x))) with r = x (pre-LN blocks) or r = LN(x) (residual_is_normed: post-LN blocks);
+// ln_g == nullptr: no LN in front of the FFN; partial: S * M * 256 floats of scratch
 void launch_ffn_split(const float* x, const float* ln_g, const float* ln_b, const f32x4* w1, const float* b1,
                       const f32x4* w2, const float* b2, float scale, const float* out_ln_g, const float* out_ln_b,
-                      float* partial, float* out, int M, int n_chunks, int S, hipStream_t st, const PadSkip& ps = PadSkip{});
+                      float* partial, float* out, int M, int n_chunks, int S, hipStream_t st, const PadSkip& ps = PadSkip{},
+                      bool residual_is_normed = false);
 void launch_ln_qkv(const float* x1, float* qkv, const LayerW& w, int M, hipStream_t st, const PadSkip& ps = PadSkip{});
 void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int B,
                             int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out, hipStream_t st,

@@ -1297,7 +1297,8 @@ __global__ __launch_bounds__(kThreads) void k_ffn_part(const float* __restrict__
   BRing<1> ring;
   ring_prime(ring, w1 + (size_t)(c0 * 8 + wave) * kTs256, 0);
   rb_load_rows(bufA, kLda, x + (size_t)r0 * kD, kRows, valid);
-  rb_layernorm(bufA, bufA, kLda, kRows, ln_g, ln_b, 1e-5f);  // (same wave -> row mapping as the load: no barrier between)
+  // (same wave -> row mapping as the load: no barrier between; ln_g == nullptr: the rows are used as they are)
+  if (ln_g) rb_layernorm(bufA, bufA, kLda, kRows, ln_g, ln_b, 1e-5f);
   __syncthreads();
   f32x16 acc2[1][1];
   acc_zero(acc2);
@@ -1311,11 +1312,19 @@ __global__ __launch_bounds__(kThreads) void k_ffn_part(const float* __restrict__
   }
 }
 
-// one wave per row: out = LN?(x + scale * (sum_s partial[s] + b2))
+__device__ __forceinline__ f32x4 ln_row(f32x4 y, const float* __restrict__ g, const float* __restrict__ b, int lane) {
+  const float mean = wave_sum(y[0] + y[1] + y[2] + y[3]) * (1.0f / kD);
+  const f32x4 c = y - mean;
+  const float var = wave_sum(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3]) * (1.0f / kD);
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  return c * rstd * *reinterpret_cast<const f32x4*>(g + 4 * lane) + *reinterpret_cast<const f32x4*>(b + 4 * lane);
+}
+// one wave per row: out = LN_out?(LN_pre?(x) + scale * (sum_s partial[s] + b2))
 __global__ __launch_bounds__(256) void k_ffn_join(const float* __restrict__ x, const float* __restrict__ partial, int S,
                                                   const float* __restrict__ b2, float scale, const float* __restrict__ ln_g,
                                                   const float* __restrict__ ln_b, float* __restrict__ out, int M,
-                                                  PadSkip ps) {
+                                                  PadSkip ps, const float* __restrict__ pre_g,
+                                                  const float* __restrict__ pre_b) {
   const int row = blockIdx.x * 4 + wave_id();
   if (row >= M) return;
   if (pad_block_skippable(ps, row & ~(kRows - 1), kRows, M)) return;
@@ -1324,15 +1333,10 @@ __global__ __launch_bounds__(256) void k_ffn_join(const float* __restrict__ x, c
   for (int s = 1; s < S; ++s) acc += *reinterpret_cast<const f32x4*>(partial + ((size_t)s * M + row) * kD + 4 * lane);
   const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + 4 * lane);
   f32x4 y = *reinterpret_cast<const f32x4*>(x + (size_t)row * kD + 4 * lane);
+  if (pre_g) y = ln_row(y, pre_g, pre_b, lane);
 #pragma unroll
   for (int e = 0; e < 4; ++e) y[e] = y[e] + scale * (acc[e] + bv[e]);
-  if (ln_g) {
-    const float mean = wave_sum(y[0] + y[1] + y[2] + y[3]) * (1.0f / kD);
-    const f32x4 c = y - mean;
-    const float var = wave_sum(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3]) * (1.0f / kD);
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    y = c * rstd * *reinterpret_cast<const f32x4*>(ln_g + 4 * lane) + *reinterpret_cast<const f32x4*>(ln_b + 4 * lane);
-  }
+  if (ln_g) y = ln_row(y, ln_g, ln_b, lane);
   *reinterpret_cast<f32x4*>(out + (size_t)row * kD + 4 * lane) = y;
 }
 
@@ -1388,11 +1392,12 @@ void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float
 }
 void launch_ffn_split(const float* x, const float* ln_g, const float* ln_b, const f32x4* w1, const float* b1,
                       const f32x4* w2, const float* b2, float scale, const float* out_ln_g, const float* out_ln_b,
-                      float* partial, float* out, int M, int n_chunks, int S, hipStream_t st, const PadSkip& ps) {
+                      float* partial, float* out, int M, int n_chunks, int S, hipStream_t st, const PadSkip& ps,
+                      bool residual_is_normed) {
   hipLaunchKernelGGL(k_ffn_part, dim3((M + kRows - 1) / kRows, S), dim3(kThreads), kLdsFfnPart, st, x, ln_g, ln_b, w1, b1,
                      w2, partial, M, n_chunks, ps);
   hipLaunchKernelGGL(k_ffn_join, dim3((M + 3) / 4), dim3(256), 0, st, x, partial, S, b2, scale, out_ln_g, out_ln_b, out, M,
-                     ps);
+                     ps, residual_is_normed ? ln_g : nullptr, residual_is_normed ? ln_b : nullptr);
 }
 void launch_ln_qkv(const float* x1, float* qkv, const LayerW& w, int M, hipStream_t st, const PadSkip& ps) {
   hipLaunchKernelGGL(k_ln_qkv, dim3((M + kRows - 1) / kRows, 3), dim3(kThreads), kLdsLnQkv, st, x1, qkv, w, M, ps);

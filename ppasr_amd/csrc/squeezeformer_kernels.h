@@ -36,6 +36,11 @@ void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, float*
 void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float* x_out, float* qkv_next, const SqLayerW& w,
                     const f32x4* wqkv_next, const float* bqkv_next, const int64_t* lens, int M, int Tp, int mask_mul,
                     int n_chunks, int ksize, hipStream_t st, const PadSkip& ps = PadSkip{});
+// split route for under-filled launches (ppasr_set_ffn_split): the pieces of K_B / K_C around their feed-forward modules
+void launch_sq_oproj(const float* ctx, const float* x, float* x1, const SqLayerW& w, int M, hipStream_t st,
+                     const PadSkip& ps = PadSkip{});
+void launch_sq_pw1glu(const float* x2, float* g, float* xhat_out, const SqLayerW& w, const int64_t* lens, int M, int Tp,
+                      int mask_mul, hipStream_t st, const PadSkip& ps = PadSkip{});
 void launch_sq_reduce(const float* x, float* xr, float* qkv, const SqReduceW& rw, const f32x4* wqkv, const float* bqkv,
                       const int64_t* lens, int B, int Tp, int Tr, hipStream_t st, const PadSkip& ps = PadSkip{});
 void launch_sq_recover(const float* xr, const float* saved, float* x, float* qkv, const f32x4* wrec, const float* brec,

@@ -138,6 +138,83 @@ __global__ __launch_bounds__(kThreads) void k_sq_mid(const float* __restrict__ c
 }
 constexpr size_t kLdsSqMid = 3 * kRows * kLda * sizeof(float);
 
+// ---- split route for under-filled launches (conformer_kernels.hip, k_conv_pre / k_ffn_part / k_ffn_join): K_B and K_C
+// cut at their feed-forward modules.  K_B = k_sq_oproj -> FFN1 split -> k_sq_pw1glu ; K_C = k_conv_pre -> FFN2 split
+// [-> k_sq_qkv of the next layer] ----
+// x1 = LN1(x + ctx Wo + bo)
+__global__ __launch_bounds__(kThreads) void k_sq_oproj(const float* __restrict__ ctx, const float* __restrict__ x,
+                                                       float* __restrict__ x1, SqLayerW w, int M, PadSkip ps) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
+  float* bufX = smem;
+  float* bufH = bufX + kRows * kLda;
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, M - r0);
+  const int col = wave * 32 + (lane & 31);
+  BRing<1> ring;
+  const f32x4* seg_o = w.wo + (size_t)wave * kTs256;
+  ring_prime(ring, seg_o, 0);
+  rb_load_rows(bufH, kLda, ctx + (size_t)r0 * kD, kRows, valid);
+  __syncthreads();
+  float res[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) res[r] = x[(size_t)(r0 + min(acc_row(r, lane), valid - 1)) * kD + col];
+  f32x16 acc[1][1];
+  acc_zero(acc);
+  rb_gemm<1, 1, kG256>(bufH, kLda, seg_o, 0, nullptr, 0, ring, acc);
+  const float bv = w.bo[col];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, lane);
+    bufX[row * kLda + col] = (row < valid) ? res[r] + (acc[0][0][r] + bv) : 0.f;
+  }
+  __syncthreads();
+  rb_layernorm(bufX, bufX, kLda, kRows, w.ln1_g, w.ln1_b, 1e-5f);
+  rb_store_rows(x1 + (size_t)r0 * kD, bufX, kLda, kRows, valid);
+}
+// g = GLU(pw1(x2)) with PAD frames = GLU(pw1(0)); xhat_out (streaming) = the scaled conv-module input
+__global__ __launch_bounds__(kThreads) void k_sq_pw1glu(const float* __restrict__ x2, float* __restrict__ g,
+                                                        float* __restrict__ xhat_out, SqLayerW w,
+                                                        const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
+                                                        PadSkip ps) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
+  float* bufX = smem;
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, M - r0);
+  const int col = wave * 32 + (lane & 31);
+  BRing<1> ring;
+  const f32x4* seg_val = w.pw1 + (size_t)wave * kTs256;
+  const f32x4* seg_gate = w.pw1 + (size_t)(8 + wave) * kTs256;
+  ring_prime(ring, seg_val, 0);
+  rb_load_rows(bufX, kLda, x2 + (size_t)r0 * kD, kRows, valid);
+  if (xhat_out) {  // (same wave -> row mapping as the load)
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(w.cm_scale + 4 * lane);
+    const f32x4 sb = *reinterpret_cast<const f32x4*>(w.cm_bias + 4 * lane);
+    for (int row = wave; row < valid; row += kWaves)
+      *reinterpret_cast<f32x4*>(xhat_out + (size_t)(r0 + row) * kD + 4 * lane) =
+          sc * *reinterpret_cast<const f32x4*>(bufX + row * kLda + 4 * lane) + sb;
+  }
+  __syncthreads();
+  f32x16 av[1][1], ag[1][1];
+  acc_zero(av);
+  acc_zero(ag);
+  rb_gemm<1, 1, kG256>(bufX, kLda, seg_val, 0, seg_gate, 0, ring, av);
+  rb_gemm<1, 1, kG256>(bufX, kLda, seg_gate, 0, nullptr, 0, ring, ag);
+  const float bval = w.pw1_b[col], bgate = w.pw1_b[kD + col];
+  const float gpad = w.glu_pad[col];
+  PadRows is_pad{lens, r0, Tp, M, mask_mul};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int row = acc_row(r, lane);
+    float v = (av[0][0][r] + bval) * sigmoidf(ag[0][0][r] + bgate);
+    if (is_pad(row)) v = gpad;
+    if (row < valid) g[(size_t)(r0 + row) * kD + col] = v;
+  }
+}
+
 // K_C: x3 = LN3(x2 + mask(pw2(swish(LN(dwconv(g)))))) ; x4 = LN4(x3 + FFN2(x3)) ; [qkv of the next layer]
 template <int KS, bool STREAM>
 __global__ __launch_bounds__(kThreads) void k_sq_tail(const float* __restrict__ g, const float* __restrict__ g_hist,
@@ -343,6 +420,13 @@ void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float*
   }
 #undef SQ_TAIL
 }
+void launch_sq_oproj(const float* ctx, const float* x, float* x1, const SqLayerW& w, int M, hipStream_t st, const PadSkip& ps) {
+  hipLaunchKernelGGL(k_sq_oproj, rb_grid(M), dim3(kThreads), kLds2, st, ctx, x, x1, w, M, ps);
+}
+void launch_sq_pw1glu(const float* x2, float* g, float* xhat_out, const SqLayerW& w, const int64_t* lens, int M, int Tp,
+                      int mask_mul, hipStream_t st, const PadSkip& ps) {
+  hipLaunchKernelGGL(k_sq_pw1glu, rb_grid(M), dim3(kThreads), kLds1, st, x2, g, xhat_out, w, lens, M, Tp, mask_mul, ps);
+}
 void launch_sq_reduce(const float* x, float* xr, float* qkv, const SqReduceW& rw, const f32x4* wqkv, const float* bqkv,
                       const int64_t* lens, int B, int Tp, int Tr, hipStream_t st, const PadSkip& ps) {
   hipLaunchKernelGGL(k_sq_reduce, rb_grid(B * Tr), dim3(kThreads), kLds2, st, x, xr, qkv, rw, wqkv, bqkv, lens, B, Tp, Tr,
@@ -368,6 +452,7 @@ hipError_t configure_squeezeformer_kernels() {
   SET_LDS((k_sq_tail<31, true>), kLdsSqTail);
   SET_LDS((k_sq_tail<15, true>), kLdsSqTail);
   SET_LDS(k_sq_reduce, kLds2);
+  SET_LDS(k_sq_oproj, kLds2);
   SET_LDS(k_sq_recover, kLds2);
 #undef SET_LDS
   return hipSuccess;

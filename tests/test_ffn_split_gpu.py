@@ -7,7 +7,8 @@ import pytest
 import torch
 
 from oracle.ctc_decoders_oracle import greedy_tokens
-from ppasr_amd.utils.synth import conformer_state_dict, efficient_conformer_state_dict, synth_features
+from ppasr_amd.utils.synth import (conformer_state_dict, efficient_conformer_state_dict, squeezeformer_state_dict,
+                                   synth_features)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -43,10 +44,21 @@ def _efficient():
             EfficientConformerOracle(sd, num_blocks=L, stride_layer_idx=1, group_layer_idx=(0, 1)))
 
 
-@pytest.mark.parametrize("family", ["conformer", "efficient"])
+def _squeezeformer():
+    from oracle.squeezeformer_oracle import SqueezeformerOracle
+    from ppasr_amd.model_utils.squeezeformer.model import SqueezeformerModel
+    V, L = 131, 4
+    sd = squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=23, perturb_norm=True)
+    conf = dict(encoder_dim=256, output_size=256, attention_heads=4, num_blocks=L, reduce_idx=1, recover_idx=3,
+                feed_forward_expansion_factor=8, cnn_module_kernel=31)
+    return (SqueezeformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0"),
+            SqueezeformerOracle(sd, num_blocks=L, reduce_idx=1, recover_idx=3))
+
+
+@pytest.mark.parametrize("family", ["conformer", "efficient", "squeezeformer"])
 @pytest.mark.parametrize("lens", [[333, 280, 120], [67]])
 def test_every_split_mode_matches_the_oracle(family, lens):
-    model, oracle = _conformer(True) if family == "conformer" else _efficient()
+    model, oracle = {"conformer": lambda: _conformer(True), "efficient": _efficient, "squeezeformer": _squeezeformer}[family]()
     x, la = synth_features(len(lens), max(lens), lens=lens, seed=sum(lens))
     ref_probs, ref_logits = oracle.get_encoder_out(x, la, return_logits=True)
     outs = {}

@@ -1,6 +1,7 @@
-"""Encoder + greedy throughput of the three *former families over batch sizes (32 x 10 s is the bench shape): shows the
-row-block quantisation -- a kernel with <= 256 row blocks takes one round whatever their number, so the half-rate layers
-of Squeezeformer / Efficient-Conformer only fill the chip from B = 64."""
+"""Encoder + greedy throughput of the three *former families over batch sizes (32 x 10 s is the bench shape), with the
+fused layer kernels only ("fused") and with the default route selection ("auto": launches with <= 128 row blocks take
+the split route, ppasr_set_ffn_split).  A kernel with <= 256 row blocks takes one round whatever their number, so
+small batches and the half-rate layers of Squeezeformer / Efficient-Conformer leave CUs idle on the fused route."""
 import json
 import os
 import sys
@@ -40,10 +41,7 @@ for name, m in models():
         x, lens = torch.from_numpy(x).cuda(), torch.from_numpy(lens).cuda()
         res = {"model": name, "B": B}
         for label, mode in (("fused", 0), ("auto", -1)):  # always the fused kernels / split route for under-filled grids
-            if hasattr(m, "set_ffn_split") and name != "squeezeformer":
-                m.set_ffn_split(mode)
-            elif mode == -1:
-                continue
+            m.set_ffn_split(mode)
             for _ in range(2):
                 m.encode_greedy(x, lens)
             torch.cuda.synchronize()
