@@ -65,7 +65,15 @@ def test_baseline_shape_properties():
     torch.cuda.synchronize()
     assert torch.equal(t1, t2) and torch.equal(n1, n2) and torch.equal(s1, s2)
     for b in (0, 7, 31):
+        # a single utterance is an under-filled launch and takes the split route by default (ppasr_set_ffn_split): same
+        # arithmetic up to the order of the sum over feed-forward hidden chunks -> same tokens, scores to round-off
         tb, nb, sb = model.encode_greedy(x[b:b + 1], lens[b:b + 1])
+        assert torch.equal(tb[0, :int(nb[0])], t1[b, :int(n1[b])])
+        assert abs(float(sb[0]) - float(s1[b])) < 1e-3
+        # on the same (fused) route the utterance is bit-identical alone and inside the batch
+        model.set_ffn_split(0)
+        tb, nb, sb = model.encode_greedy(x[b:b + 1], lens[b:b + 1])
+        model.set_ffn_split(-1)
         assert torch.equal(tb[0, :int(nb[0])], t1[b, :int(n1[b])])
         assert abs(float(sb[0]) - float(s1[b])) < 1e-9
     ref = ConformerOracle(sd, num_blocks=L).get_encoder_out(x[:2], lens[:2])
