@@ -479,7 +479,10 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   float* lg = logits ? logits : probs;  // probs are produced in place from the logits tap
   int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
   float* fp = frame_maxprob ? frame_maxprob : ws + wl.fp;
-  timed(7, [&] { launch_ctc_head(xa, h->head, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, Mo, st, pskip(Ti, mul)); });
+  // (under-filled launch: the vocabulary tiles are split over several workgroups per row block, scratch = conv1 buffer)
+  timed(7, [&] {
+    launch_ctc_head(xa, h->head, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, Mo, st, pskip(Ti, mul), ffn_split_for(h, Mo), y1);
+  });
   if (probs) {
     if (logits)
       HIP_TRY(hipMemcpyAsync(probs, logits, (size_t)Mo * h->head.V * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -336,7 +336,8 @@ ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int r
   if (r != PPASR_OK) return r;
   int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
   float* fp = frame_maxprob ? frame_maxprob : ws + wl.fp;
-  launch_ctc_head(x_final, h->head, probs, fa, fp, ws + wl.rmax, ws + wl.rsum, frames, st);
+  launch_ctc_head(x_final, h->head, probs, fa, fp, ws + wl.rmax, ws + wl.rsum, frames, st, PadSkip{}, ffn_split_for(h, frames),
+                  y1);
   if (probs) launch_softmax_from_stats(probs, ws + wl.rmax, ws + wl.rsum, frames, h->head.V, st);
   r = finish_chunk(s, p, shift_tmp, st);
   if (r != PPASR_OK) return r;
@@ -557,7 +558,7 @@ ppasr_status ppasr_encode_chunk_group(ppasr_stream_group g, const int* sessions_
   }
   int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
   float* fp = frame_maxprob ? frame_maxprob : ws + wl.fp;
-  launch_ctc_head(xa, h->head, probs, fa, fp, ws + wl.rmax, ws + wl.rsum, M, st);
+  launch_ctc_head(xa, h->head, probs, fa, fp, ws + wl.rmax, ws + wl.rsum, M, st, PadSkip{}, ffn_split_for(h, M), y1);
   if (probs) launch_softmax_from_stats(probs, ws + wl.rmax, ws + wl.rsum, M, h->head.V, st);
   for (int b = 0; b < n; ++b) {
     g->cache_t[sessions_host[b]] += c;

@@ -177,7 +177,20 @@ void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, i
   const int full = (tiles4 / kCUs) * kCUs;
   const int rem_rows = M - full * 128;
   int mt_rem = (rem_rows + 32 * kCUs - 1) / (32 * kCUs);  // rows per remainder tile / 32
-  if (full == 0 || rem_rows <= 0 || mt_rem >= 4) {
+  if (full == 0) {
+    // less than one round of 128-row tiles (a single utterance, a streaming chunk): smaller tiles fill more CUs
+    const int mt = (M + 32 * kCUs - 1) / (32 * kCUs);  // 1 .. 4
+#define CONV2_ALL(MTA)                                                                                                    \
+  hipLaunchKernelGGL((k_gemm_stream<MTA, KC, true, false, Conv2Src>), dim3((M + 32 * MTA - 1) / (32 * MTA)),              \
+                     dim3(kThreads), lds_of(MTA), st, src, fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, 0, ps)
+    if (mt <= 1) CONV2_ALL(1);
+    else if (mt == 2) CONV2_ALL(2);
+    else if (mt == 3) CONV2_ALL(3);
+    else CONV2_ALL(4);
+#undef CONV2_ALL
+    return;
+  }
+  if (rem_rows <= 0 || mt_rem >= 4) {
     hipLaunchKernelGGL((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(tiles4), dim3(kThreads), lds_of(4), st, src,
                        fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, 0, ps);
     return;
@@ -1509,9 +1522,12 @@ template <bool LOGITS>
 __global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__ x, HeadW hw, float* __restrict__ logits,
                                                        int32_t* __restrict__ fr_argmax, float* __restrict__ fr_maxprob,
                                                        float* __restrict__ row_max, float* __restrict__ row_sum, int M,
-                                                       PadSkip ps) {
+                                                       PadSkip ps, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
+  // gridDim.y > 1 (under-filled launches): workgroup y walks vocabulary tiles wave + 8 (y + gridDim.y k) and leaves its
+  // per-row (max, sum-exp, argmax) in part[3][gridDim.y][M]; k_ctc_merge combines the slices
+  const int ny = gridDim.y, y = blockIdx.y;
   float* bufA = smem;                                          // [32][260]
   float* redM = bufA + kRows * kLda;                           // [8][32]
   float* redS = redM + kWaves * 32;                            // [8][32]
@@ -1521,7 +1537,7 @@ __global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__
   const int valid = min(kRows, M - r0);
   const int V = hw.V;
   BRing<1> ring;
-  if (wave < hw.n_tiles) ring_prime(ring, hw.w + (size_t)wave * kTs256, 0);
+  if (wave + 8 * y < hw.n_tiles) ring_prime(ring, hw.w + (size_t)(wave + 8 * y) * kTs256, 0);
   rb_load_rows(bufA, kLda, x + (size_t)r0 * kD, kRows, valid);
   if (hw.ln_g) rb_layernorm(bufA, bufA, kLda, kRows, hw.ln_g, hw.ln_b, 1e-5f);
   __syncthreads();
@@ -1533,12 +1549,12 @@ __global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__
     sm[r] = 0.f;
     ix[r] = 0x7fffffff;
   }
-  for (int tile = wave; tile < hw.n_tiles; tile += kWaves) {
+  const int tstep = kWaves * ny;
+  for (int tile = wave + 8 * y; tile < hw.n_tiles; tile += tstep) {
     f32x16 acc[1][1];
     acc_zero(acc);
     const f32x4* seg = hw.w + (size_t)tile * kTs256;
-    rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, tile + kWaves < hw.n_tiles ? seg + (size_t)kWaves * kTs256 : nullptr, 0, ring,
-                         acc);
+    rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, tile + tstep < hw.n_tiles ? seg + (size_t)tstep * kTs256 : nullptr, 0, ring, acc);
     const int col = tile * 32 + (lane & 31);
     const float bv = (col < V) ? hw.b[col] : -INFINITY;  // padded columns never win and add exp(-inf)=0
 #pragma unroll
@@ -1598,23 +1614,57 @@ __global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__
       s = sa + sb;
     }
     if (row < valid) {
-      if (fr_argmax) fr_argmax[r0 + row] = i;
-      if (fr_maxprob) fr_maxprob[r0 + row] = 1.0f / s;
-      if (row_max) row_max[r0 + row] = m;
-      if (row_sum) row_sum[r0 + row] = s;
+      if (ny > 1) {
+        part[(size_t)y * M + r0 + row] = m;
+        part[((size_t)ny + y) * M + r0 + row] = s;
+        reinterpret_cast<int*>(part)[((size_t)2 * ny + y) * M + r0 + row] = i;
+      } else {
+        if (fr_argmax) fr_argmax[r0 + row] = i;
+        if (fr_maxprob) fr_maxprob[r0 + row] = 1.0f / s;
+        if (row_max) row_max[r0 + row] = m;
+        if (row_sum) row_sum[r0 + row] = s;
+      }
     }
   }
 }
+__global__ void k_ctc_merge(const float* __restrict__ part, int ny, int32_t* __restrict__ fr_argmax,
+                            float* __restrict__ fr_maxprob, float* __restrict__ row_max, float* __restrict__ row_sum, int M,
+                            PadSkip ps) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= M) return;
+  if (pad_block_skippable(ps, row & ~(kRows - 1), kRows, M)) return;
+  float m = part[row], s = part[(size_t)ny * M + row];
+  int i = reinterpret_cast<const int*>(part)[(size_t)2 * ny * M + row];
+  for (int y = 1; y < ny; ++y) {
+    const float m2 = part[(size_t)y * M + row], s2 = part[((size_t)ny + y) * M + row];
+    const int i2 = reinterpret_cast<const int*>(part)[((size_t)2 * ny + y) * M + row];
+    const float mn = fmaxf(m, m2);
+    const float sa = (m == -INFINITY) ? 0.f : s * __expf(m - mn);
+    const float sb = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mn);
+    const bool take2 = (m2 > m) || (m2 == m && i2 < i);
+    i = take2 ? i2 : i;
+    m = mn;
+    s = sa + sb;
+  }
+  if (fr_argmax) fr_argmax[row] = i;
+  if (fr_maxprob) fr_maxprob[row] = 1.0f / s;
+  if (row_max) row_max[row] = m;
+  if (row_sum) row_sum[row] = s;
+}
 constexpr size_t kLdsCtc = (kRows * kLda + 3 * kWaves * 32) * sizeof(float);
 void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr_argmax, float* fr_maxprob, float* row_max,
-                     float* row_sum, int M, hipStream_t st, const PadSkip& ps) {
-  dim3 grid((M + kRows - 1) / kRows);
+                     float* row_sum, int M, hipStream_t st, const PadSkip& ps, int n_slices, float* part) {
+  const int ny = (n_slices > 1 && part) ? n_slices : 1;
+  dim3 grid((M + kRows - 1) / kRows, ny);
   if (logits)
     hipLaunchKernelGGL(k_ctc_head<true>, grid, dim3(kThreads), kLdsCtc, st, x, hw, logits, fr_argmax, fr_maxprob, row_max,
-                       row_sum, M, ps);
+                       row_sum, M, ps, part);
   else
     hipLaunchKernelGGL(k_ctc_head<false>, grid, dim3(kThreads), kLdsCtc, st, x, hw, logits, fr_argmax, fr_maxprob, row_max,
-                       row_sum, M, ps);
+                       row_sum, M, ps, part);
+  if (ny > 1)
+    hipLaunchKernelGGL(k_ctc_merge, dim3((M + 255) / 256), dim3(256), 0, st, part, ny, fr_argmax, fr_maxprob, row_max, row_sum,
+                       M, ps);
 }
 
 // probs = softmax(logits) recomputed exactly (max, then exp(x-max)/sum) in place; one wave per row.
