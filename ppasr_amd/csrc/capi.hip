@@ -402,7 +402,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   };
   timed(0, [&] { launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, pskip(Tp, 4)); });
   timed(1, [&] { launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, pskip(Tp, 4)); });
-  timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st, pskip(Tp, 4)); });
+  timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st, pskip(Tp, 4), ffn_split_for(h, M), y1); });
   tap(xa, (size_t)M * kD);
   const int n_chunks = h->desc.linear_units / 256;
   int Ti = Tp, mul = 4, pstride = 1;  // frames per utterance / pad-mask multiplier / positional stride of the current layer

@@ -328,7 +328,8 @@ ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int r
   float* shift_tmp = xhat + (((size_t)c * kD + 63) & ~(size_t)63);
   launch_conv1(feats, h->front, y1, 1, T, F, T1, F1, st);
   launch_conv2(y1, h->front, y2, 1, T1, F1, c, F2, st);
-  launch_embed(y2, h->front, xa, c, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/is_sq(h), st);
+  launch_embed(y2, h->front, xa, c, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/is_sq(h), st, PadSkip{},
+               ffn_split_for(h, c), y1);
   float* x_final = xa;
   int frames = c;
   if (is_sq(h)) r = squeezeformer_chunk(s, p, xa, xb, xc, qkv, ctx, g, ws + wl.xs, xhat, y1, &x_final, st);
@@ -527,7 +528,7 @@ ppasr_status ppasr_encode_chunk_group(ppasr_stream_group g, const int* sessions_
   const long long kv_sess = (long long)L * g->cap * kD, hist_sess = (long long)L * lo * kD;
   launch_conv1(feats, h->front, y1, n, T, F, T1, F1, st);
   launch_conv2(y1, h->front, y2, n, T1, F1, c, F2, st);
-  launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st);
+  launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st, PadSkip{}, ffn_split_for(h, M), y1);
   for (int i = 0; i < L; ++i) {
     const LayerW& W = h->layers[i];
     float* kc = g->kc + (size_t)i * g->cap * kD;

@@ -84,8 +84,10 @@ void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, i
                   const PadSkip& ps = PadSkip{});
 // scale_before_bias: Squeezeformer scales the 4864-wide conv output by sqrt(d) BEFORE input_proj
 // (squeezeformer/subsampling.py:66-67) -> acc*scale + b ; Conformer: (acc + b)*scale (embedding.py:112)
+// k_slices > 1 (under-filled launches): the contraction is split over that many workgroups per row block, partial sums
+// in part (k_slices * M * 256 floats)
 void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, bool scale_before_bias,
-                  hipStream_t st, const PadSkip& ps = PadSkip{});
+                  hipStream_t st, const PadSkip& ps = PadSkip{}, int k_slices = 1, float* part = nullptr);
 void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, float* out, int M, int K, int n_cols_padded,
                   int ldc, int n_valid, hipStream_t st);
 void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,

@@ -110,9 +110,12 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const int r0 = m0 + blockIdx.x * BM;  // m0: first row of this launch (row ranges split across launches)
   const int tile_stride = n_chunks * G * 64;
+  // gridDim.z > 1 (under-filled launches): workgroup z contracts K chunks [kc0, kc1) only and stores its raw partial sums
+  // to out + z * M * ldc; k_gemm_join adds them up and applies bias / scale / activation
+  const int kc0 = (int)((long long)blockIdx.z * n_chunks / gridDim.z), kc1 = (int)((long long)(blockIdx.z + 1) * n_chunks / gridDim.z);
   const f32x4* wbase = wp + (size_t)(blockIdx.y * kWaves + wave) * tile_stride;  // blockIdx.y = 256-column block
   BRing<1> ring;
-  ring_prime(ring, wbase, 0);
+  ring_prime(ring, wbase + (size_t)kc0 * G * 64, 0);
   const float* rowp[NL];
   int lds_off[NL];
 #pragma unroll
@@ -136,13 +139,13 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
   };
   f32x16 acc[MT][1];
   acc_zero(acc);
-  load_chunk(0);
-  write_chunk(smem);
+  load_chunk(kc0);
+  write_chunk(smem + (kc0 & 1) * BM * LD);
   __syncthreads();
-  for (int kc = 0; kc < n_chunks; ++kc) {
+  for (int kc = kc0; kc < kc1; ++kc) {
     float* cur = smem + (kc & 1) * BM * LD;
     float* nxt = smem + ((kc + 1) & 1) * BM * LD;
-    const bool more = kc + 1 < n_chunks;
+    const bool more = kc + 1 < kc1;
     if (more) load_chunk(kc + 1);
     const f32x4* seg = wbase + (size_t)kc * G * 64;
     rb_gemm<MT, 1, G>(cur, LD, seg, 0, more ? seg + G * 64 : nullptr, 0, ring, acc);
@@ -150,6 +153,17 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
     __syncthreads();
   }
   const int col = blockIdx.y * 256 + wave * 32 + (lane & 31);
+  if (gridDim.z > 1) {
+    float* po = out + (size_t)blockIdx.z * M * ldc;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = r0 + mt * 32 + acc_row(r, lane);
+        if (m < M && col < n_valid) po[(size_t)m * ldc + col] = acc[mt][0][r];
+      }
+    return;
+  }
   const float bv = bias[col];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -160,6 +174,21 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
       if (RELU) v = fmaxf(v, 0.f);
       if (m < M && col < n_valid) out[(size_t)m * ldc + col] = v;
     }
+}
+// out[m][c] = (sum_z part[z][m][c] + bias[c]) * scale   or   sum * scale + bias (scale_before_bias); one float4 per thread
+__global__ __launch_bounds__(256) void k_gemm_join(const float* __restrict__ part, int nz, const float* __restrict__ bias,
+                                                   float scale, int scale_before_bias, float* __restrict__ out, int M,
+                                                   PadSkip ps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  if (pad_block_skippable(ps, row & ~(kRows - 1), kRows, M)) return;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(part + (size_t)row * kD + 4 * lane);
+  for (int z = 1; z < nz; ++z) acc += *reinterpret_cast<const f32x4*>(part + ((size_t)z * M + row) * kD + 4 * lane);
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * lane);
+  f32x4 y;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) y[e] = scale_before_bias ? acc[e] * scale + bv[e] : (acc[e] + bv[e]) * scale;
+  *reinterpret_cast<f32x4*>(out + (size_t)row * kD + 4 * lane) = y;
 }
 
 void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st,
@@ -207,10 +236,17 @@ void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, i
 #undef CONV2_REM
 }
 void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, bool scale_before_bias,
-                  hipStream_t st, const PadSkip& ps) {
+                  hipStream_t st, const PadSkip& ps, int k_slices, float* part) {
   constexpr int MT = 1, KC = 256;
   DenseSrc src{y2, K, KC};
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
+  if (k_slices > 1 && part) {  // under-filled launch: the K = 4864 contraction over k_slices workgroups per row block
+    hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, 1, k_slices), dim3(kThreads), lds,
+                       st, src, fw.embed_w, fw.embed_b, part, M, K / KC, xscale, kD, kD, 0, ps);
+    hipLaunchKernelGGL(k_gemm_join, dim3((M + 3) / 4), dim3(256), 0, st, part, k_slices, fw.embed_b, xscale,
+                       scale_before_bias ? 1 : 0, x0, M, ps);
+    return;
+  }
   if (scale_before_bias)
     hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, true, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src,
                        fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD, 0, ps);
