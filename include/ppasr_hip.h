@@ -120,6 +120,10 @@ ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable);
  * kernels), 2 / 4 / 8 = always that many slices. */
 ppasr_status ppasr_set_ffn_split(ppasr_handle h, int mode);
 
+/* Host helper (no device work): Levenshtein distance between two int32 sequences -- what ppasr/utils/metrics.py:4-29
+ * (cer / wer) gets from the `Levenshtein` C extension.  Returns -1 on a null argument with a positive length. */
+long long ppasr_edit_distance(const int32_t* a, int na, const int32_t* b, int nb);
+
 /* Replaces the third-party `paddlespeech_ctcdecoders` entry points PPASR calls:
  *   ctc_beam_search_decoding / ctc_beam_search_decoding_batch  (decoders/swig_wrapper.py:61-62,98-100,
  *     from BeamSearchDecoder.decode_beam_search_offline / decode_batch_beam_search_offline,

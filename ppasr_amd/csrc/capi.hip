@@ -331,6 +331,28 @@ ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats) 
   return PPASR_OK;
 }
 
+long long ppasr_edit_distance(const int32_t* a, int na, const int32_t* b, int nb) {
+  if (na < 0 || nb < 0 || (na > 0 && !a) || (nb > 0 && !b)) return -1;
+  if (na < nb) {
+    std::swap(a, b);
+    std::swap(na, nb);
+  }
+  if (nb == 0) return na;
+  std::vector<int> prev(nb + 1), cur(nb + 1);
+  for (int j = 0; j <= nb; ++j) prev[j] = j;
+  for (int i = 1; i <= na; ++i) {
+    cur[0] = i;
+    const int32_t ca = a[i - 1];
+    for (int j = 1; j <= nb; ++j) {
+      const int sub = prev[j - 1] + (ca != b[j - 1]);
+      const int del = prev[j] + 1, ins = cur[j - 1] + 1;
+      cur[j] = sub < del ? (sub < ins ? sub : ins) : (del < ins ? del : ins);
+    }
+    std::swap(prev, cur);
+  }
+  return prev[nb];
+}
+
 ppasr_status ppasr_set_ffn_split(ppasr_handle h, int mode) {
   if (!h) return fail(PPASR_EINVAL, "null handle");
   if (mode != -1 && mode != 0 && mode != 2 && mode != 4 && mode != 8) return fail(PPASR_EINVAL, "ffn split: -1, 0, 2, 4 or 8");

@@ -169,6 +169,13 @@ class BeamSearchDecoder:
 
     def decode_batch_beam_search_offline(self, probs_split):
         """-> list[str].  beam_search_decoder.py:59-73 (every row of every table is decoded)."""
+        if isinstance(probs_split, torch.Tensor) and probs_split.dim() == 3:
+            # only the best hypothesis is used (beam_search_decoder.py:72): ask the kernel for nbest = 1 instead of
+            # copying and stringifying all beam_size hypotheses of every utterance
+            tokens, lens, scores, _ = beam_search_ids(probs_split, self.beam_size, self.cutoff_prob, self.cutoff_top_n,
+                                                      self.blank_id, nbest=1, ext_scorer=self._ext_scorer)
+            tk, ln = tokens[:, 0].cpu(), lens[:, 0].cpu()
+            return [_text(tk[b, :max(int(ln[b]), 0)].tolist(), self.vocab_list) for b in range(tk.shape[0])]
         res = ctc_beam_search_decoding_batch(probs_split, self.vocab_list, self.beam_size, self.num_processes,
                                              self.cutoff_prob, self.cutoff_top_n, self.blank_id, self._ext_scorer)
         return [r[0][1] for r in res]

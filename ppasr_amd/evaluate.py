@@ -33,20 +33,23 @@ def decoder_result(outs, vocabulary, decoder="ctc_greedy", beam_search_decoder=N
 
 
 def evaluate(model, batches, vocab_list, decoder="ctc_greedy", metrics_type="cer", beam_search_decoder=None,
-             display_result=False, trim_padding=False):
+             display_result=False, trim_padding=False, overlap_decode=True):
     """model: any ppasr_amd model with ``get_encoder_out(inputs, input_lens)``;
     batches: iterable of (inputs [B,T,F], labels [B,U] (-1 padded), input_lens [B], label_lens [B]) like the reference's
     test_loader.  -> mean error rate (float), -1 if there is nothing to score (trainer.py:643).
     ``trim_padding=True`` (not the reference's behaviour, which decodes the padded rows of every utterance too): the
-    encoder runs in its ragged-batch mode and the decoders stop at each utterance's last valid frame."""
+    encoder runs in its ragged-batch mode and the decoders stop at each utterance's last valid frame.
+    ``overlap_decode``: encode batch i+1 on a second HIP stream while batch i is being decoded (same results)."""
     dist = torch.distributed.is_available() and torch.distributed.is_initialized()
     rank = torch.distributed.get_rank() if dist else 0
     world = torch.distributed.get_world_size() if dist else 1
     eos = len(vocab_list) - 1
     total, count = 0.0, 0
-    for batch_id, (inputs, labels, input_lens, _label_lens) in enumerate(batches):
-        if batch_id % world != rank:
-            continue
+    dev = getattr(model, "device", None)
+    pipelined = overlap_decode and dev is not None and torch.device(dev).type == "cuda"
+    enc_stream = torch.cuda.Stream(device=dev) if pipelined else None
+
+    def encode(inputs, input_lens):
         frame_lens = None
         if trim_padding:
             model.set_skip_padding(True)
@@ -56,6 +59,10 @@ def evaluate(model, batches, vocab_list, decoder="ctc_greedy", metrics_type="cer
         finally:
             if trim_padding:
                 model.set_skip_padding(False)
+        return outs, frame_lens
+
+    def score(outs, frame_lens, labels):
+        nonlocal total, count
         out_strings = decoder_result(outs, vocab_list, decoder, beam_search_decoder, frame_lens)
         labels_str = labels_to_string(labels, vocab_list, eos=eos)
         for out_string, label in zip(out_strings, labels_str):
@@ -64,6 +71,32 @@ def evaluate(model, batches, vocab_list, decoder="ctc_greedy", metrics_type="cer
             count += 1
             if display_result:
                 print(f"pred: {out_string}\nlabel: {label}\n{metrics_type}: {round(err, 6)}")
+
+    # Two-stage pipeline on two HIP streams: the encoder of batch i+1 is queued on its own stream before the host waits
+    # for the decode of batch i (beam search occupies one CU per utterance -- the rest of the chip encodes meanwhile).
+    pending = None  # (outs, frame_lens, labels, event) of the batch whose decode has not run yet
+    for batch_id, (inputs, labels, input_lens, _label_lens) in enumerate(batches):
+        if batch_id % world != rank:
+            continue
+        if not pipelined:
+            outs, frame_lens = encode(inputs, input_lens)
+            score(outs, frame_lens, labels)
+            continue
+        dec_stream = torch.cuda.current_stream(dev)
+        enc_stream.wait_stream(dec_stream)  # (inputs prepared on the caller's stream)
+        with torch.cuda.stream(enc_stream):
+            outs, frame_lens = encode(inputs, input_lens)
+            ev = torch.cuda.Event()
+            ev.record(enc_stream)
+        if pending is not None:
+            score(*pending[:3])
+        dec_stream.wait_event(ev)
+        outs.record_stream(dec_stream)
+        if frame_lens is not None:
+            frame_lens.record_stream(dec_stream)
+        pending = (outs, frame_lens, labels)
+    if pending is not None:
+        score(*pending[:3])
     if dist:
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.distributed.get_backend() == "nccl" else "cpu"
         t = torch.tensor([total, float(count)], dtype=torch.float64, device=dev)

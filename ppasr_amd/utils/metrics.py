@@ -1,24 +1,29 @@
 """Host-side mirror of ``ppasr/utils/metrics.py`` (``cer`` :4-13, ``wer`` :16-29) and of ``labels_to_string``
 (``ppasr/utils/utils.py:59-65``).  The reference calls the ``Levenshtein`` C extension (not installable offline);
 the edit distance here is the classic two-row dynamic programme (insert / delete / substitute, unit costs), which is
-what ``Levenshtein.distance`` computes."""
+what ``Levenshtein.distance`` computes -- as host code of the C library, like the reference's C extension."""
 
 __all__ = ["edit_distance", "cer", "wer", "labels_to_string"]
 
 
 def edit_distance(a, b):
-    """Levenshtein distance between two sequences (strings or lists)."""
-    if len(a) < len(b):
-        a, b = b, a
-    if len(b) == 0:
-        return len(a)
-    prev = list(range(len(b) + 1))
-    for i, ca in enumerate(a, 1):
-        cur = [i] + [0] * len(b)
-        for j, cb in enumerate(b, 1):
-            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb))
-        prev = cur
-    return prev[-1]
+    """Levenshtein distance between two sequences (strings or lists of hashable items): the two-row dynamic programme
+    in the C library (``ppasr_edit_distance``, host code)."""
+    import numpy as np
+
+    from ppasr_amd import _lib
+    if isinstance(a, str) and isinstance(b, str):
+        ia = np.frombuffer(a.encode("utf-32-le"), dtype=np.int32)
+        ib = np.frombuffer(b.encode("utf-32-le"), dtype=np.int32)
+    else:
+        ids = {}
+        ia = np.array([ids.setdefault(x, len(ids)) for x in a], dtype=np.int32)
+        ib = np.array([ids.setdefault(x, len(ids)) for x in b], dtype=np.int32)
+    d = _lib.load().ppasr_edit_distance(ia.ctypes.data if len(ia) else None, len(ia), ib.ctypes.data if len(ib) else None,
+                                        len(ib))
+    if d < 0:
+        raise ValueError("edit_distance: bad arguments")
+    return int(d)
 
 
 def cer(prediction, label):
