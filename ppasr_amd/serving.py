@@ -70,6 +70,22 @@ class StreamPool:
                 updated[i] = s.result
         return updated
 
+    def finish(self, session):
+        """End of a session's audio (``predict_stream(..., is_end=True)``, predict.py:291-298): run the buffered full
+        windows, then the last, shorter window if at least 7 frames (the conv front-end's context) are left.
+        -> the session's final result dict (None if it never produced output).  The session keeps its state until
+        ``reset``."""
+        self.step()
+        s = self.sessions[session]
+        if s.cached_feat is not None and s.cached_feat.shape[1] >= _CONTEXT:
+            fa, fp = self.group.encode_chunks([session], s.cached_feat)
+            fa, fp = fa.cpu().numpy(), fp.cpu().numpy()
+            s.frame_ids.extend(fa[0].tolist())
+            s.frame_probs.extend(fp[0][fa[0] != self.blank].tolist())
+            s.cached_feat = s.cached_feat[:, s.cached_feat.shape[1] - _KEEP:]
+            s.result = self._result(s)
+        return s.result
+
     def _result(self, s):
         hist = np.asarray(s.frame_ids, np.int64)
         keep = np.ones(len(hist), bool)

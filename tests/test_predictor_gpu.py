@@ -214,3 +214,34 @@ def test_evaluate_overlapped_decode_gives_the_same_result(decoder):
         a = evaluate(model, batches, vocab, decoder=decoder, beam_search_decoder=bsd, trim_padding=trim, overlap_decode=False)
         b = evaluate(model, batches, vocab, decoder=decoder, beam_search_decoder=bsd, trim_padding=trim, overlap_decode=True)
         assert a == b and a >= 0
+
+
+def test_stream_pool_finish_equals_predict_stream_is_end():
+    """StreamPool.finish flushes the last, shorter window like predict_stream(is_end=True) (predict.py:291-298)."""
+    from ppasr_amd.predict import PPASRPredictor
+    from ppasr_amd.serving import StreamPool
+    V = 300
+    vocab = synth_vocabulary(V)
+    sd = conformer_state_dict(vocab_size=V, num_blocks=2, seed=3)
+    cfg = _cfg(decoder="ctc_greedy")
+    wavs = [_audio(1.93, seed=11), _audio(2.71, seed=12)]
+    pcms = [(np.clip(w, -1, 1) * 32767).astype(np.int16).tobytes() for w in wavs]
+    step = 16000  # 0.5 s packets
+    p = PPASRPredictor(configs=cfg, state_dict=sd, vocab_list=vocab, warmup=False)
+    want = []
+    for pcm in pcms:
+        p.reset_stream()
+        out = None
+        for i in range(0, len(pcm), step):
+            out = p.predict_stream(audio_data=pcm[i:i + step], is_end=(i + step >= len(pcm))) or out
+        want.append(out)
+    pool = StreamPool(p.predictor.model, vocab, n_sessions=2, preprocess_conf=cfg["preprocess_conf"])
+    for i in range(0, max(len(x) for x in pcms), step):
+        for s, pcm in enumerate(pcms):
+            if i < len(pcm):
+                pool.feed(s, pcm[i:i + step])
+        pool.step()
+    for s in range(2):
+        got = pool.finish(s)
+        assert got is not None and got["text"] == want[s]["text"], s
+        assert abs(got["score"] - want[s]["score"]) < 1e-3
