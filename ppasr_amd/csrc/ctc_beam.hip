@@ -604,7 +604,9 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
     // every element is computed ONCE into LDS (0xFFFFFFFF = not a candidate); thread t owns the contiguous range
     // [t*per, (t+1)*per) so that the compaction below keeps element order with a single block scan ----
     const int N = nb + nb * C;
-    const int per = (N + BT - 1) / BT;
+    // (an ODD range length: thread t starts at word t*per of skey[], and an even stride would put the 64 lanes of a
+    //  wave on 16 or fewer of the 64 LDS banks)
+    const int per = ((N + BT - 1) / BT) | 1;
     const int e_lo = min(tid * per, N), e_hi = min(e_lo + per, N);
     auto elem_char = [&](int e) -> int { return e < nb ? cur.chr[e] : cand_c[(e - nb) % C]; };
     int my_valid = 0;
@@ -703,12 +705,18 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
     // ---- (g) ordered compaction: survivors' element ids in element order (one block scan over per-thread counts), then
     // slot p of the next beam is materialised by thread p (the survivors of one thread's range can be many) ----
     int my_keep = 0;
-    for (int e = e_lo; e < e_hi; ++e) my_keep += keeps(e) ? 1 : 0;
+    unsigned long long keep_bits = 0;  // verdicts of the first 64 elements of this thread's range, evaluated once
+    for (int e = e_lo; e < e_hi; ++e) {
+      const bool k = keeps(e);
+      my_keep += k ? 1 : 0;
+      if (e - e_lo < 64) keep_bits |= (unsigned long long)(k ? 1 : 0) << (e - e_lo);
+    }
     int tot_keep;
     int wpos = block_excl_scan<BT / 64>(my_keep, wave_tot + BT / 64, tot_keep);
     int* surv = nxt.par;  // temporary list in the next beam's `par` column: slot p is read, then overwritten, by thread p
     for (int e = e_lo; e < e_hi; ++e) {
-      if (!keeps(e) || wpos >= beam) continue;
+      const bool k = (e - e_lo < 64) ? (((keep_bits >> (e - e_lo)) & 1ull) != 0) : keeps(e);
+      if (!k || wpos >= beam) continue;
       surv[wpos++] = e;
     }
     lds_barrier();
