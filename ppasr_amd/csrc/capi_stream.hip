@@ -25,7 +25,8 @@ struct ppasr_stream_s {
   int lo;       // longest conv left context = cnn_module_kernel - 1
   float *kc, *vc;   // [L][cap][256]
   float* xh_hist;   // [L][lo][256]  conv-module input history
-  float* g_hist;    // [lo][256] scratch: GLU(pointwise_conv1(history)) of the layer being processed
+  float* g_hist;    // [L][lo][256] GLU(pointwise_conv1(history)) of every layer, recomputed at the start of each chunk
+  HistLayer* hist_tab;  // device [L]: per-layer pointwise_conv1 weights / history rows for that launch
 };
 
 namespace {
@@ -53,19 +54,10 @@ ppasr_status shift_cache(float* buf, int from, int keep, float* tmp, hipStream_t
   return PPASR_OK;
 }
 
-// pointwise_conv1 + GLU of the cached conv inputs of layer i -> s->g_hist (lo_i rows)
-void history_glu(ppasr_stream_s* s, int i, hipStream_t st) {
-  ppasr_model_s* h = s->m;
-  const int lo_i = layer_lo(h, i);
-  const float* xh = s->xh_hist + (size_t)i * s->lo * kD;
-  if (is_sq(h)) {
-    LayerW t{};
-    t.pw1 = h->sq_layers[i].pw1_raw;
-    t.pw1_b = h->sq_layers[i].pw1_b_raw;
-    launch_pw1_glu(xh, s->g_hist, t, lo_i, st);
-  } else {
-    launch_pw1_glu(xh, s->g_hist, h->layers[i], lo_i, st);
-  }
+// pointwise_conv1 + GLU of the cached conv inputs of EVERY layer -> s->g_hist[i] (lo_i rows each), one launch: the
+// histories are last chunk's state (hist_update of layer i runs after layer i has consumed g_hist[i])
+void history_glu_all(ppasr_stream_s* s, hipStream_t st) {
+  launch_pw1_glu_layers(s->xh_hist, s->g_hist, s->hist_tab, s->m->desc.num_blocks, s->lo, st);
 }
 
 struct ChunkPlan {
@@ -136,6 +128,7 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
   const int H = h->desc.attention_heads;
   int Ti = p.c, mul = 4, pstride = 1;
   bool half = false;
+  history_glu_all(s, st);
   for (int i = 0; i < h->desc.num_blocks; ++i) {
     const LayerW& L = h->layers[i];
     const int grp = h->layer_group[i];
@@ -159,11 +152,11 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
     AttnArgs a{qkv, 768, kc, kD, vc, kD, ceil_div(Ti, grp), ceil_div(T2f, grp), p.pos0, nullptr, ctx, L.pos_u, L.pos_v,
                L.ptab, pstride, mul * grp, Ti, T2f, grp};
     launch_attention(a, 1, H, st);
-    history_glu(s, i, st);
+    float* gh = s->g_hist + (size_t)i * s->lo * kD;
     launch_out_glu(ctx, xb, xc, g, xhat, L, nullptr, Ti, Ti, mul, st);
     if (is_eff(h) && i == h->desc.stride_layer_idx) {
       const int Ts = ceil_div(Ti, 2);
-      launch_conv_ffn_stride(g, s->g_hist, xc, xa, L, nullptr, 1, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st);
+      launch_conv_ffn_stride(g, gh, xc, xa, L, nullptr, 1, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st);
       launch_hist_update(xh, xhat, Ti, lo_i, st);
       Ti = Ts;
       mul *= 2;
@@ -171,11 +164,11 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
       half = true;
     } else {
       if (S > 1) {
-        launch_conv_pre(g, s->g_hist, xc, ctx, L, nullptr, Ti, Ti, h->layer_ks[i], mul, st);
+        launch_conv_pre(g, gh, xc, ctx, L, nullptr, Ti, Ti, h->layer_ks[i], mul, st);
         launch_ffn_split(ctx, L.ln_ff_g, L.ln_ff_b, L.ff_w1, L.ff_b1, L.ff_w2, L.ff_b2, 0.5f, L.ln_fin_g, L.ln_fin_b, partial,
                          xa, Ti, n_chunks, S, st);
       } else {
-        launch_conv_ffn(g, s->g_hist, xc, xa, L, nullptr, Ti, Ti, n_chunks, h->layer_ks[i], mul, nullptr, nullptr, nullptr, st);
+        launch_conv_ffn(g, gh, xc, xa, L, nullptr, Ti, Ti, n_chunks, h->layer_ks[i], mul, nullptr, nullptr, nullptr, st);
       }
       launch_hist_update(xh, xhat, Ti, lo_i, st);
     }
@@ -192,6 +185,7 @@ ppasr_status squeezeformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* x
   const int L = h->desc.num_blocks, H = h->desc.attention_heads;
   const int n_chunks = h->desc.linear_units / 256, KS = h->desc.cnn_module_kernel;
   launch_ln_rows(xa, h->preln_g, h->preln_b, p.c, st);
+  history_glu_all(s, st);
   float* x = xa;
   float* other = xb;
   bool reduced = false, have_qkv = false;
@@ -221,7 +215,7 @@ ppasr_status squeezeformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* x
     AttnArgs a{qkv, 768, kc, kD, vc, kD, Ti, n_cache + Ti, p.pos0, nullptr, ctx, W.pos_u, W.pos_v, W.ptab, reduced ? 2 : 1,
                mul, Ti, n_cache + Ti, 1};
     launch_attention(a, 1, H, st);
-    history_glu(s, i, st);
+    float* gh = s->g_hist + (size_t)i * s->lo * kD;
     const bool fuse_next = (i + 1 < L) && (i + 1 != h->desc.reduce_idx) && !(i + 1 == h->desc.recover_idx && reduced);
     const SqLayerW* Wn = fuse_next ? &h->sq_layers[i + 1] : nullptr;
     const int S = ffn_split_for(h, Ti);  // one row block: split route (see squeezeformer_encode)
@@ -230,13 +224,13 @@ ppasr_status squeezeformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* x
       launch_ffn_split(other, nullptr, nullptr, W.ff1_w1, W.ff1_b1, W.ff1_w2, W.ff1_b2, 1.0f, W.ln2_g, W.ln2_b, partial, xc,
                        Ti, n_chunks, S, st);
       launch_sq_pw1glu(xc, g, xhat, W, nullptr, Ti, Ti, mul, st);
-      launch_conv_pre(g, s->g_hist, xc, ctx, sq_conv_view(W), nullptr, Ti, Ti, KS, mul, st);
+      launch_conv_pre(g, gh, xc, ctx, sq_conv_view(W), nullptr, Ti, Ti, KS, mul, st);
       launch_ffn_split(ctx, W.ln3_g, W.ln3_b, W.ff2_w1, W.ff2_b1, W.ff2_w2, W.ff2_b2, 1.0f, W.ln4_g, W.ln4_b, partial, other,
                        Ti, n_chunks, S, st, PadSkip{}, /*residual_is_normed=*/true);
       if (Wn) launch_sq_qkv(other, qkv, Wn->wqkv, Wn->bqkv, Ti, st);
     } else {
       launch_sq_mid(ctx, x, xc, g, xhat, W, nullptr, Ti, Ti, mul, n_chunks, st);
-      launch_sq_tail(g, s->g_hist, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, nullptr, Ti, Ti, mul,
+      launch_sq_tail(g, gh, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, nullptr, Ti, Ti, mul,
                      n_chunks, KS, st);
     }
     launch_hist_update(xh, xhat, Ti, KS - 1, st);
@@ -265,9 +259,12 @@ ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out) {
   hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&s->kc), L * s->cap * kD * sizeof(float));
   hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&s->vc), L * s->cap * kD * sizeof(float));
   hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&s->xh_hist), L * s->lo * kD * sizeof(float));
-  hipError_t e4 = hipMalloc(reinterpret_cast<void**>(&s->g_hist), (size_t)s->lo * kD * sizeof(float));
+  hipError_t e4 = hipMalloc(reinterpret_cast<void**>(&s->g_hist), L * s->lo * kD * sizeof(float));
+  s->hist_tab = nullptr;
+  if (e4 == hipSuccess) e4 = hipMalloc(reinterpret_cast<void**>(&s->hist_tab), L * sizeof(HistLayer));
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
     (void)hipFree(s->kc); (void)hipFree(s->vc); (void)hipFree(s->xh_hist); (void)hipFree(s->g_hist);
+    (void)hipFree(s->hist_tab);
     delete s;
     return fail(PPASR_EHIP, "hipMalloc failed for the stream caches");
   }
@@ -275,7 +272,16 @@ ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out) {
   s->cache_r = 0;
   s->offset = 0;
   hipError_t e5 = hipMemset(s->xh_hist, 0, L * s->lo * kD * sizeof(float));
-  if (e5 != hipSuccess) return fail(PPASR_EHIP, "hipMemset failed");
+  std::vector<HistLayer> tab(L);
+  for (size_t i = 0; i < L; ++i) {
+    if (is_sq(h)) tab[i] = HistLayer{h->sq_layers[i].pw1_raw, h->sq_layers[i].pw1_b_raw, layer_lo(h, (int)i), 0};
+    else tab[i] = HistLayer{h->layers[i].pw1, h->layers[i].pw1_b, layer_lo(h, (int)i), 0};
+  }
+  if (e5 == hipSuccess) e5 = hipMemcpy(s->hist_tab, tab.data(), L * sizeof(HistLayer), hipMemcpyHostToDevice);
+  if (e5 != hipSuccess) {
+    (void)ppasr_stream_destroy(s);
+    return fail(PPASR_EHIP, "initialising the stream caches failed");
+  }
   *out = s;
   return PPASR_OK;
 }
@@ -283,6 +289,7 @@ ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out) {
 ppasr_status ppasr_stream_destroy(ppasr_stream s) {
   if (!s) return PPASR_OK;
   (void)hipFree(s->kc); (void)hipFree(s->vc); (void)hipFree(s->xh_hist); (void)hipFree(s->g_hist);
+  (void)hipFree(s->hist_tab);
   delete s;
   return PPASR_OK;
 }

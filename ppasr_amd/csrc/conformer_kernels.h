@@ -118,6 +118,15 @@ void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2
 // fused S2+S3 for the batched plain-head path (4 heads x 64): attention + out-projection + LN_conv + pw1 + GLU
 void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, float* g, const LayerW& w, hipStream_t st);
 void launch_pw1_glu(const float* xhat, float* g, const LayerW& w, int M, hipStream_t st);
+// all layers' conv histories in one launch: layer i reads xh_hist + i*lo_stride*256 (tab[i].rows <= 32 rows), writes
+// g_hist + i*lo_stride*256; tab is a DEVICE array
+struct HistLayer {
+  const f32x4* pw1;    // packed pointwise_conv1 [256][512]
+  const float* pw1_b;  // [512]
+  int rows, pad;
+};
+void launch_pw1_glu_layers(const float* xh_hist, float* g_hist, const HistLayer* tab, int n_layers, int lo_stride,
+                           hipStream_t st);
 void launch_kv_append(const float* qkv, float* kc, float* vc, int n_rows, hipStream_t st);
 // multi-session variants: row (b, t) of the chunk batch <-> session sess[b]
 void launch_kv_append_group(const float* qkv, float* kc, float* vc, long long sess_stride, const SessDesc* sess, int n, int c,

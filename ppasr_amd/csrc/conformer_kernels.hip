@@ -1033,7 +1033,42 @@ __global__ __launch_bounds__(kThreads) void k_pw1_glu(const float* __restrict__ 
     if (row < valid) g[(size_t)(r0 + row) * kD + col] = (av[0][0][r] + bval) * sigmoidf(ag[0][0][r] + bgate);
   }
 }
+// the same for every layer's history in ONE launch (single-session streaming: the histories only depend on the previous
+// chunk, so the twelve small launches need not sit between the layers): block i = layer i, tab[i] = its weights / rows
+__global__ __launch_bounds__(kThreads) void k_pw1_glu_layers(const float* __restrict__ xh_hist, float* __restrict__ g_hist,
+                                                             const HistLayer* __restrict__ tab, int lo_stride) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufA = smem;
+  const HistLayer t = tab[blockIdx.x];
+  const float* xhat = xh_hist + (size_t)blockIdx.x * lo_stride * kD;
+  float* g = g_hist + (size_t)blockIdx.x * lo_stride * kD;
+  const int lane = lane_id(), wave = wave_id();
+  const int valid = min(kRows, t.rows);
+  const int col = wave * 32 + (lane & 31);
+  BRing<1> ring;
+  const f32x4* seg_val = t.pw1 + (size_t)wave * kTs256;
+  const f32x4* seg_gate = t.pw1 + (size_t)(8 + wave) * kTs256;
+  ring_prime(ring, seg_val, 0);
+  rb_load_rows(bufA, kLda, xhat, kRows, valid);
+  __syncthreads();
+  f32x16 av[1][1], ag[1][1];
+  acc_zero(av);
+  acc_zero(ag);
+  rb_gemm<1, 1, kG256>(bufA, kLda, seg_val, 0, seg_gate, 0, ring, av);
+  rb_gemm<1, 1, kG256>(bufA, kLda, seg_gate, 0, nullptr, 0, ring, ag);
+  const float bval = t.pw1_b[col];
+  const float bgate = t.pw1_b[kD + col];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int row = acc_row(r, lane);
+    if (row < valid) g[(size_t)row * kD + col] = (av[0][0][r] + bval) * sigmoidf(ag[0][0][r] + bgate);
+  }
+}
 constexpr size_t kLdsPw1Glu = kRows * kLda * sizeof(float);
+void launch_pw1_glu_layers(const float* xh_hist, float* g_hist, const HistLayer* tab, int n_layers, int lo_stride,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(k_pw1_glu_layers, dim3(n_layers), dim3(kThreads), kLdsPw1Glu, st, xh_hist, g_hist, tab, lo_stride);
+}
 void launch_pw1_glu(const float* xhat, float* g, const LayerW& w, int M, hipStream_t st) {
   hipLaunchKernelGGL(k_pw1_glu, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsPw1Glu, st, xhat, g, w, M);
 }
