@@ -142,11 +142,11 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
     if (S > 1) {
       launch_ffn_split(xa, L.ln_mac_g, L.ln_mac_b, L.ffm_w1, L.ffm_b1, L.ffm_w2, L.ffm_b2, 0.5f, nullptr, nullptr, partial, xb,
                        Ti, n_chunks, S, st);
-      launch_ln_qkv(xb, qkv, L, Ti, st);
+      launch_ln_qkv(xb, qkv, L, Ti, st, PadSkip{}, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD);
     } else {
       launch_ffn_qkv(xa, xb, qkv, L, Ti, n_chunks, st);
+      launch_kv_append(qkv, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD, Ti, st);
     }
-    launch_kv_append(qkv, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD, Ti, st);
     // grouped attention re-cuts cache + chunk frames into groups of 3 from the START of the cache (pad4group on the
     // concatenated keys, efficient_conformer/attention.py:160-175), zero-padded tail group
     AttnArgs a{qkv, 768, kc, kD, vc, kD, ceil_div(Ti, grp), ceil_div(T2f, grp), p.pos0, nullptr, ctx, L.pos_u, L.pos_v,

@@ -110,7 +110,9 @@ void launch_ffn_split(const float* x, const float* ln_g, const float* ln_b, cons
                       const f32x4* w2, const float* b2, float scale, const float* out_ln_g, const float* out_ln_b,
                       float* partial, float* out, int M, int n_chunks, int S, hipStream_t st, const PadSkip& ps = PadSkip{},
                       bool residual_is_normed = false);
-void launch_ln_qkv(const float* x1, float* qkv, const LayerW& w, int M, hipStream_t st, const PadSkip& ps = PadSkip{});
+// kc / vc: write the K / V thirds to these cache rows instead of qkv (single-session streaming)
+void launch_ln_qkv(const float* x1, float* qkv, const LayerW& w, int M, hipStream_t st, const PadSkip& ps = PadSkip{},
+                   float* kc = nullptr, float* vc = nullptr);
 void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int B,
                             int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out, hipStream_t st,
                             const PadSkip& ps = PadSkip{});

@@ -1424,8 +1424,10 @@ __global__ __launch_bounds__(256) void k_ffn_join(const float* __restrict__ x, c
   *reinterpret_cast<f32x4*>(out + (size_t)row * kD + 4 * lane) = y;
 }
 
+// kc / vc != nullptr (single-session streaming): the K and V thirds go straight to the session's cache rows (row m of
+// the chunk -> kc + m*256) instead of qkv -- the separate append launch disappears
 __global__ __launch_bounds__(kThreads) void k_ln_qkv(const float* __restrict__ x1, float* __restrict__ qkv, LayerW w, int M,
-                                                     PadSkip ps) {
+                                                     PadSkip ps, float* __restrict__ kc, float* __restrict__ vc) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
   float* bufA = smem;
@@ -1444,10 +1446,13 @@ __global__ __launch_bounds__(kThreads) void k_ln_qkv(const float* __restrict__ x
   rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, nullptr, 0, ring, acc);
   const int col = c * 256 + wave * 32 + (lane & 31);
   const float bv = w.bqkv[col];
+  float* cache = (c == 1) ? kc : (c == 2 ? vc : nullptr);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = acc_row(r, lane);
-    if (row < valid) qkv[(size_t)(r0 + row) * 768 + col] = acc[0][0][r] + bv;
+    if (row >= valid) continue;
+    if (cache) cache[(size_t)(r0 + row) * kD + wave * 32 + (lane & 31)] = acc[0][0][r] + bv;
+    else qkv[(size_t)(r0 + row) * 768 + col] = acc[0][0][r] + bv;
   }
 }
 
@@ -1483,8 +1488,9 @@ void launch_ffn_split(const float* x, const float* ln_g, const float* ln_b, cons
   hipLaunchKernelGGL(k_ffn_join, dim3((M + 3) / 4), dim3(256), 0, st, x, partial, S, b2, scale, out_ln_g, out_ln_b, out, M,
                      ps, residual_is_normed ? ln_g : nullptr, residual_is_normed ? ln_b : nullptr);
 }
-void launch_ln_qkv(const float* x1, float* qkv, const LayerW& w, int M, hipStream_t st, const PadSkip& ps) {
-  hipLaunchKernelGGL(k_ln_qkv, dim3((M + kRows - 1) / kRows, 3), dim3(kThreads), kLdsLnQkv, st, x1, qkv, w, M, ps);
+void launch_ln_qkv(const float* x1, float* qkv, const LayerW& w, int M, hipStream_t st, const PadSkip& ps, float* kc,
+                   float* vc) {
+  hipLaunchKernelGGL(k_ln_qkv, dim3((M + kRows - 1) / kRows, 3), dim3(kThreads), kLdsLnQkv, st, x1, qkv, w, M, ps, kc, vc);
 }
 
 // -------------------------------------------------------------------------------------
