@@ -1,5 +1,7 @@
 // capi.hip -- the C-ABI of libppasr_hip.so (declared in include/ppasr_hip.h).
 // Host side: weight re-packing into MFMA fragment order, workspace carving, launch sequence.
+#include <cstdlib>
+
 #include "capi_internal.h"
 
 static thread_local std::string g_err;
@@ -435,8 +437,13 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     const int grp = h->layer_group[i];
     // plain 4 x 64 heads: attention and the out-projection / GLU stage run as one launch (context rows stay in LDS);
     // the debug taps need the context tensor, so they take the two-kernel route
+    // (an under-filled grid is latency-bound either way, and the two-kernel route then has 4x the workgroups in its
+    //  attention half, one per head: 2 - 6 % faster end to end up to 128 row blocks (tools/ab_attention_route.py), 10 %
+    //  slower at the bench shape; PPASR_ATTN_FUSE_MIN_BLOCKS overrides the threshold)
+    static const int fuse_min_blocks =
+        getenv("PPASR_ATTN_FUSE_MIN_BLOCKS") ? atoi(getenv("PPASR_ATTN_FUSE_MIN_BLOCKS")) : 128;
     auto fusable = [&](int layer) {
-      return h->layer_group[layer] == 1 && h->desc.attention_heads == 4 && !h->taps;
+      return h->layer_group[layer] == 1 && h->desc.attention_heads == 4 && !h->taps && (Mi + kRows - 1) / kRows > fuse_min_blocks;
     };
     const bool fuse_attn = fusable(i);
     const PadSkip ps = pskip(Ti, mul);
