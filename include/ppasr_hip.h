@@ -117,7 +117,7 @@ ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable);
  * session) the Conformer-family layer tail is cut at its two feed-forward modules and each module's hidden dimension is
  * split over 2 / 4 / 8 workgroups per row block (partial sums joined by the next launch).  Same arithmetic up to the
  * order of the final sum over hidden chunks.  mode: -1 = decide by grid size (default), 0 = never (always the fused
- * kernels), 2 / 4 / 8 = always that many slices. */
+ * kernels, the fused attention kernel included), 2 / 4 / 8 = always that many slices. */
 ppasr_status ppasr_set_ffn_split(ppasr_handle h, int mode);
 
 /* Host helper (no device work): Levenshtein distance between two int32 sequences -- what ppasr/utils/metrics.py:4-29

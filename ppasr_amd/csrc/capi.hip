@@ -443,7 +443,8 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     static const int fuse_min_blocks =
         getenv("PPASR_ATTN_FUSE_MIN_BLOCKS") ? atoi(getenv("PPASR_ATTN_FUSE_MIN_BLOCKS")) : 128;
     auto fusable = [&](int layer) {
-      return h->layer_group[layer] == 1 && h->desc.attention_heads == 4 && !h->taps && (Mi + kRows - 1) / kRows > fuse_min_blocks;
+      return h->layer_group[layer] == 1 && h->desc.attention_heads == 4 && !h->taps &&
+             (h->ffn_split == 0 || (Mi + kRows - 1) / kRows > fuse_min_blocks);  // (ppasr_set_ffn_split(0): always fused)
     };
     const bool fuse_attn = fusable(i);
     const PadSkip ps = pskip(Ti, mul);

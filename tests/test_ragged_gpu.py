@@ -50,9 +50,11 @@ FAMILIES = {
 
 @pytest.mark.parametrize("family", list(FAMILIES))
 @pytest.mark.parametrize("lens", [[900, 611, 420, 133, 36, 7], [1203, 1203, 300], [260, 258, 257, 131, 129, 128, 127, 1]])
-def test_skip_padding_equals_default_on_valid_rows(family, lens):
+@pytest.mark.parametrize("route", [-1, 0])  # default route selection / always the fused kernels (ppasr_set_ffn_split)
+def test_skip_padding_equals_default_on_valid_rows(family, lens, route):
     V = 211
     model, mul = FAMILIES[family](V)
+    model.set_ffn_split(route)
     B, T = len(lens), max(lens)
     x, lens_a = synth_features(B, T, lens=lens, seed=T + B)
     p0, l0 = model.get_encoder_out(x, lens_a, return_logits=True)
