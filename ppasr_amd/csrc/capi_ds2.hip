@@ -96,6 +96,21 @@ ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd) {
     }
     UP(bsum, Lw.b_sum);
     UP(hh, Lw.w_hh);
+    // fragment-ordered copy for the batched step kernel: per direction, packed column 32 t + 8 gate + u = row
+    // gate * H + 8 t + u of weight_hh (every gate of units 8t .. 8t+7 in one 32-column tile)
+    {
+      std::vector<float> pk;
+      pk.reserve((size_t)dirs * 4 * H * H);
+      for (int d = 0; d < dirs; ++d) {
+        const float* wd = whh[d];
+        std::vector<float> one = pack_b(H, 4 * H, [&](int k, int n) {
+          const int t = n / 32, r = n % 32, gate = r / 8, u = r % 8;
+          return wd[(size_t)(gate * H + 8 * t + u) * H + k];
+        });
+        pk.insert(pk.end(), one.begin(), one.end());
+      }
+      UP4(pk, Lw.w_hh_pk);
+    }
     GETW(lg, "encoder.layernorm_list." + std::to_string(l) + ".weight", dirs * H);
     GETW(lb, "encoder.layernorm_list." + std::to_string(l) + ".bias", dirs * H);
     UP(vec_of(lg, dirs * H), Lw.ln_g);
@@ -178,8 +193,11 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
     HIP_TRY(hipMemsetAsync(out, 0, (size_t)M * dirs * H * sizeof(float), st));
     float* hp = h0;
     float* hn = h1;
+    // the matrix-core step needs H % 64 == 0 (8 waves x whole 8-wide k-groups); the VALU kernel handles the rest
+    const bool mfma_step = (H % 64 == 0) && B >= 2;  // (one utterance: the VALU kernel's 5.8 us per step is the faster one)
     for (int s = 0; s < Tp; ++s) {
-      launch_lstm_step(gx, Lw.w_hh, hp, hn, c, out, lens32, B, Tp, H, dirs, s, st);
+      if (mfma_step) launch_lstm_step_mfma(gx, Lw.w_hh_pk, hp, hn, c, out, lens32, B, Tp, H, dirs, s, st);
+      else launch_lstm_step(gx, Lw.w_hh, hp, hn, c, out, lens32, B, Tp, H, dirs, s, st);
       std::swap(hp, hn);
     }
     if (final_h) HIP_TRY(hipMemcpyAsync(final_h + (size_t)l * dirs * B * H, hp, sbytes, hipMemcpyDeviceToDevice, st));

@@ -141,6 +141,98 @@ __global__ __launch_bounds__(256) void k_lstm_step(const float* __restrict__ gx,
   }
 }
 
+// The same step on the matrix cores, for batches: k_lstm_step walks the utterances one by one (B x the time); here a
+// workgroup owns 8 hidden units (their 4 gates = one 32-column MFMA tile, weights re-packed accordingly) for up to 32
+// utterances (the 32 rows of the tile), its 8 waves split the K = H contraction (a 32x32 tile with K = 1024 on one
+// wave would be a chain of 512 dependent MFMAs = 16 us; 64 per wave = 2 us) and the partial tiles are summed through
+// LDS.  H / 8 workgroups per direction = 256 for the bidirectional 1024-unit layer: one per CU.
+__global__ __launch_bounds__(kThreads) void k_lstm_step_mfma(const float* __restrict__ gx, const f32x4* __restrict__ whh_pk,
+                                                             const float* __restrict__ hprev, float* __restrict__ hnext,
+                                                             float* __restrict__ c, float* __restrict__ y,
+                                                             const int32_t* __restrict__ lens, int B, int T, int H, int dirs,
+                                                             int step) {
+  __shared__ float part[kWaves][32][33];
+  __shared__ float gates[32][33];
+  const int tile = blockIdx.x, dir = blockIdx.y, b0 = blockIdx.z * 32;
+  const int lane = lane_id(), wave = wave_id();
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int n_groups = H / 8;             // 8-wide k-groups of the contraction
+  const int gpw = n_groups / kWaves;      // k-groups per wave (16 for H = 1024)
+  const int g0 = wave * gpw;
+  const int b = b0 + l31;
+  const bool row_live = b < B && step < lens[min(b, B - 1)];
+  // A operand straight from global memory in fragment order (lane = utterance row, 4 consecutive k per load); staging
+  // the rows through LDS with whole-row loads was measured and is slower here (11.6 against 9.2 ms per 32 x 5 s batch)
+  const float* hrow = hprev + ((size_t)dir * B + min(b, B - 1)) * H + 4 * hh;
+  const f32x4* wp = whh_pk + ((size_t)dir * (H / 8) + tile) * n_groups * 64 + lane;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int PFD = 8;  // k-groups in flight
+  f32x4 ra[PFD], rb[PFD];
+#pragma unroll
+  for (int s = 0; s < PFD; ++s) {
+    ra[s] = row_live ? *reinterpret_cast<const f32x4*>(hrow + 8 * (g0 + s)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    rb[s] = wp[(size_t)(g0 + s) * 64];
+  }
+  for (int g = 0; g < gpw; g += PFD) {
+#pragma unroll
+    for (int s = 0; s < PFD; ++s) {
+      const f32x4 a = ra[s], bq = rb[s];
+      if (g + PFD + s < gpw) {
+        ra[s] = row_live ? *reinterpret_cast<const f32x4*>(hrow + 8 * (g0 + g + PFD + s)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        rb[s] = wp[(size_t)(g0 + g + PFD + s) * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bq[j], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[wave][acc_row(r, lane)][l31] = acc[r];
+  __syncthreads();
+  // sum of the 8 partial tiles + input projection: thread -> (row, col) = 2 of the 1024 tile elements
+  const float* gxd = gx + (size_t)dir * B * T * 4 * H;
+  for (int e = threadIdx.x; e < 32 * 32; e += kThreads) {
+    const int row = e >> 5, col = e & 31;
+    const int bb = b0 + row;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) v += part[w][row][col];
+    if (bb < B) {
+      const int len = lens[bb];
+      if (step < len) {
+        const int t = dir == 0 ? step : len - 1 - step;
+        const int gate = col >> 3, unit = tile * 8 + (col & 7);
+        v += gxd[((size_t)bb * T + t) * 4 * H + (size_t)gate * H + unit];
+      }
+    }
+    gates[row][col] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32 * 8) {
+    const int row = threadIdx.x >> 3, u = threadIdx.x & 7;
+    const int bb = b0 + row;
+    if (bb < B) {
+      const int len = lens[bb];
+      const size_t si = ((size_t)dir * B + bb) * H + tile * 8 + u;
+      if (step >= len) {
+        hnext[si] = hprev[si];  // finished utterance: carry the state (final state = last valid step)
+      } else {
+        const int t = dir == 0 ? step : len - 1 - step;
+        const float gi = 1.0f / (1.0f + expf(-gates[row][0 + u]));
+        const float gf = 1.0f / (1.0f + expf(-gates[row][8 + u]));
+        const float gg = tanhf(gates[row][16 + u]);
+        const float go = 1.0f / (1.0f + expf(-gates[row][24 + u]));
+        const float cn = gf * c[si] + gi * gg;
+        const float hv = go * tanhf(cn);
+        c[si] = cn;
+        hnext[si] = hv;
+        y[((size_t)bb * T + t) * (size_t)(dirs * H) + (size_t)dir * H + tile * 8 + u] = hv;
+      }
+    }
+  }
+}
+
 // LayerNorm over N features (N % 256 == 0, N <= 4096), in place; one wave per row
 __global__ __launch_bounds__(256) void k_ln_wide(float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
                                                  int M, int N) {
@@ -182,6 +274,11 @@ void launch_ds2_lens(const int64_t* lens, int32_t* out32, int64_t* out64, int B,
 void launch_lstm_step(const float* gx, const float* whh, const float* hprev, float* hnext, float* c, float* y,
                       const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st) {
   hipLaunchKernelGGL(k_lstm_step, dim3(H / 4, dirs), dim3(256), (H + 16) * sizeof(float), st, gx, whh, hprev, hnext, c, y,
+                     lens, B, T, H, dirs, step);
+}
+void launch_lstm_step_mfma(const float* gx, const f32x4* whh_pk, const float* hprev, float* hnext, float* c, float* y,
+                           const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st) {
+  hipLaunchKernelGGL(k_lstm_step_mfma, dim3(H / 8, dirs, (B + 31) / 32), dim3(kThreads), 0, st, gx, whh_pk, hprev, hnext, c, y,
                      lens, B, T, H, dirs, step);
 }
 void launch_ln_wide(float* x, const float* g, const float* b, int M, int N, hipStream_t st) {
