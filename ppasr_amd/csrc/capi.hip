@@ -475,7 +475,9 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     } else {
       timed(4, [&] { launch_attention(a, B, h->desc.attention_heads, st); });
       tap(ctx, (size_t)Mi * kD);
-      timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, L, lens, Mi, Ti, mul, st, ps); });
+      // (under-filled launch: pointwise_conv1 + GLU as its own two-column-half launch; the LayerNorm'd rows pass through
+      //  xa, which is free between this layer's S1 and its output)
+      timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, L, lens, Mi, Ti, mul, st, ps, S > 1 ? xa : nullptr); });
     }
     tap(xc, (size_t)Mi * kD);
     tap(g, (size_t)Mi * kD);

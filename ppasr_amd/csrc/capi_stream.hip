@@ -153,7 +153,7 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
                L.ptab, pstride, mul * grp, Ti, T2f, grp};
     launch_attention(a, 1, H, st);
     float* gh = s->g_hist + (size_t)i * s->lo * kD;
-    launch_out_glu(ctx, xb, xc, g, xhat, L, nullptr, Ti, Ti, mul, st);
+    launch_out_glu(ctx, xb, xc, g, xhat, L, nullptr, Ti, Ti, mul, st, PadSkip{}, S > 1 ? xhat : nullptr);
     if (is_eff(h) && i == h->desc.stride_layer_idx) {
       const int Ts = ceil_div(Ti, 2);
       launch_conv_ffn_stride(g, gh, xc, xa, L, nullptr, 1, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st);
@@ -554,7 +554,7 @@ ppasr_status ppasr_encode_chunk_group(ppasr_stream_group g, const int* sessions_
     launch_attention(a, n, H, st);
     launch_hist_gather(xh, hist_sess, desc_dev, xh_act, n, lo, st);
     launch_pw1_glu(xh_act, g_hist, W, n * lo, st);
-    launch_out_glu(ctx, xb, xc, gg, xhat, W, nullptr, M, c, 4, st);
+    launch_out_glu(ctx, xb, xc, gg, xhat, W, nullptr, M, c, 4, st, PadSkip{}, S > 1 ? xhat : nullptr);
     if (S > 1) {
       launch_conv_pre(gg, g_hist, xc, ctx, W, nullptr, M, c, h->desc.cnn_module_kernel, 4, st);
       launch_ffn_split(ctx, W.ln_ff_g, W.ln_ff_b, W.ff_w1, W.ff_b1, W.ff_w2, W.ff_b2, 0.5f, W.ln_fin_g, W.ln_fin_b, y1, xa, M,

@@ -94,7 +94,8 @@ void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, i
                     const PadSkip& ps = PadSkip{});
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
-                    const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps = PadSkip{});
+                    const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps = PadSkip{},
+                    float* split_xhat = nullptr);  // != nullptr: two launches (under-filled grids), M*256 floats of scratch
 // next != nullptr: also run the following layer's S1 (writes x1_next, qkv_next) in the same launch
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                      const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,

@@ -633,7 +633,7 @@ __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ 
                                                       float* __restrict__ x2, float* __restrict__ g,
                                                       float* __restrict__ xhat_out, LayerW w,
                                                       const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
-                                                      PadSkip ps) {
+                                                      PadSkip ps, int stop_after_ln) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
   float* bufX = smem;
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ 
     for (int r = 0; r < 16; ++r) res[r] = x1[(size_t)(r0 + min(acc_row(r, lane), valid - 1)) * kD + col];
     f32x16 acc[1][1];
     acc_zero(acc);
-    rb_gemm<1, 1, kG256>(bufA, kLda, seg_o, 0, seg_val, 0, ring, acc);
+    rb_gemm<1, 1, kG256>(bufA, kLda, seg_o, 0, stop_after_ln ? nullptr : seg_val, 0, ring, acc);
     const float bv = w.bo[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -669,6 +669,7 @@ __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ 
   rb_layernorm<false>(bufX, bufA, kLda, kRows, w.ln_conv_g, w.ln_conv_b, 1e-5f, PadRows{lens, r0, Tp, M, mask_mul});
   // streaming: the conv-module input (what the reference keeps as cnn_cache, convolution.py:117)
   if (xhat_out) rb_store_rows(xhat_out + (size_t)r0 * kD, bufA, kLda, kRows, valid);
+  if (stop_after_ln) return;  // under-filled launches: pointwise_conv1 + GLU run as k_pw1_glu_cols (two column halves)
   __syncthreads();
   {
     f32x16 av[1][1], ag[1][1];
@@ -687,11 +688,53 @@ __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ 
     }
   }
 }
+// pointwise_conv1 + GLU of LayerNorm'd (and pad-masked) rows, the 256 output columns over gridDim.y = 2 workgroups:
+// waves 0-3 compute the VALUE tiles of the workgroup's 128 columns, waves 4-7 the GATE tiles of the same columns (one
+// GEMM unit each instead of two in sequence); values cross to the gate waves through LDS.
+__global__ __launch_bounds__(kThreads) void k_pw1_glu_cols(const float* __restrict__ xhat, float* __restrict__ g, LayerW w,
+                                                           int M, PadSkip ps) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
+  float* bufA = smem;
+  float* vals = bufA + kRows * kLda;  // [32][132]
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blockIdx.x * kRows;
+  const int valid = min(kRows, M - r0);
+  const int is_gate = wave >> 2, t = wave & 3, y = blockIdx.y;
+  const int col = 128 * y + 32 * t + (lane & 31);              // output column
+  const f32x4* seg = w.pw1 + (size_t)((is_gate ? 8 : 0) + 4 * y + t) * kTs256;
+  BRing<1> ring;
+  ring_prime(ring, seg, 0);
+  rb_load_rows(bufA, kLda, xhat + (size_t)r0 * kD, kRows, valid);
+  __syncthreads();
+  f32x16 acc[1][1];
+  acc_zero(acc);
+  rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, nullptr, 0, ring, acc);
+  const float bv = w.pw1_b[(is_gate ? kD : 0) + col];
+  if (!is_gate) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vals[acc_row(r, lane) * 132 + 32 * t + (lane & 31)] = acc[0][0][r] + bv;
+  }
+  __syncthreads();
+  if (is_gate) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, lane);
+      if (row < valid) g[(size_t)(r0 + row) * kD + col] = vals[row * 132 + 32 * t + (lane & 31)] * sigmoidf(acc[0][0][r] + bv);
+    }
+  }
+}
 constexpr size_t kLdsOutGlu = 2 * kRows * kLda * sizeof(float);
+constexpr size_t kLdsPw1Cols = (kRows * kLda + kRows * 132) * sizeof(float);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
-                    const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps) {
-  hipLaunchKernelGGL(k_out_glu, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsOutGlu, st, ctx, x1, x2, g, xhat_out, w,
-                     lens, M, Tp, mask_mul, ps);
+                    const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps, float* split_xhat) {
+  // split_xhat != nullptr (under-filled launches): out-projection + LayerNorm in one launch (the LayerNorm'd rows go to
+  // split_xhat), pointwise_conv1 + GLU in a second one with the columns over two workgroups per row block
+  float* xh = xhat_out ? xhat_out : split_xhat;
+  hipLaunchKernelGGL(k_out_glu, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsOutGlu, st, ctx, x1, x2, g, xh, w, lens,
+                     M, Tp, mask_mul, ps, split_xhat ? 1 : 0);
+  if (split_xhat)
+    hipLaunchKernelGGL(k_pw1_glu_cols, dim3((M + kRows - 1) / kRows, 2), dim3(kThreads), kLdsPw1Cols, st, xh, g, w, M, ps);
 }
 
 // -------------------------------------------------------------------------------------
@@ -1891,6 +1934,7 @@ hipError_t configure_kernels() {
   SET_LDS(k_attention<64>, kLdsAttn);
   SET_LDS(k_attention<192>, kLdsAttnG);
   SET_LDS(k_out_glu, kLdsOutGlu);
+  SET_LDS(k_pw1_glu_cols, kLdsPw1Cols);
   SET_LDS((k_conv_ffn<15, false, false>), kLdsConvFfn);
   SET_LDS((k_conv_ffn<31, false, false>), kLdsConvFfn);
   SET_LDS((k_conv_ffn<7, false, false>), kLdsConvFfn);
