@@ -64,6 +64,8 @@ ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd) {
     UP(vec_of(c2b, C), W.c2_b);
   }
   m->ds2_layers.resize(L);
+  std::vector<Ds2WaveLayer> wave(L);           // unidirectional models: table of the wavefront path (k_lstm_wave)
+  std::vector<float> prev_g, prev_b;           // LayerNorm of the previous layer (folded into this layer's W_ih there)
   for (int l = 0; l < L; ++l) {
     Ds2LayerW& Lw = m->ds2_layers[l];
     const int in_dim = l == 0 ? C * F2 : dirs * H;
@@ -111,10 +113,43 @@ ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd) {
       }
       UP4(pk, Lw.w_hh_pk);
     }
+    if (dirs == 1) {
+      wave[l] = Ds2WaveLayer{Lw.w_hh_pk, nullptr, nullptr, nullptr};
+      if (l > 0) {
+        // W' = W_ih diag(gamma_{l-1}) in the gate-interleaved fragment order; s_n = its column sums;
+        // c_n = W_ih beta_{l-1} + b_ih + b_hh  (k_lstm_wave applies the LayerNorm through mean / rstd of the raw row)
+        const float* wd = wih[0];
+        auto rowof = [&](int n) { const int t = n / 32, r = n % 32; return (r / 8) * H + 8 * t + (r % 8); };
+        std::vector<float> sn(4 * H), cn(4 * H);
+        for (int n = 0; n < 4 * H; ++n) {
+          const float* wr = wd + (size_t)rowof(n) * H;
+          double a = 0.0, c0 = 0.0;
+          for (int k = 0; k < H; ++k) {
+            a += (double)prev_g[k] * (double)wr[k];
+            c0 += (double)prev_b[k] * (double)wr[k];
+          }
+          sn[n] = (float)a;
+          cn[n] = (float)(c0 + (double)bih[0][rowof(n)] + (double)bhh[0][rowof(n)]);
+        }
+        UP4(pack_b(H, 4 * H, [&](int k, int n) { return prev_g[k] * wd[(size_t)rowof(n) * H + k]; }), wave[l].wih_pk);
+        UP(sn, wave[l].s_n);
+        UP(cn, wave[l].c_n);
+      }
+    }
     GETW(lg, "encoder.layernorm_list." + std::to_string(l) + ".weight", dirs * H);
     GETW(lb, "encoder.layernorm_list." + std::to_string(l) + ".bias", dirs * H);
     UP(vec_of(lg, dirs * H), Lw.ln_g);
     UP(vec_of(lb, dirs * H), Lw.ln_b);
+    prev_g = vec_of(lg, dirs * H);
+    prev_b = vec_of(lb, dirs * H);
+  }
+  if (dirs == 1 && H % 64 == 0) {
+    void* d = nullptr;
+    if (hipMalloc(&d, L * sizeof(Ds2WaveLayer)) != hipSuccess) return fail(PPASR_EHIP, "hipMalloc failed");
+    m->allocs.push_back(d);
+    if (hipMemcpy(d, wave.data(), L * sizeof(Ds2WaveLayer), hipMemcpyHostToDevice) != hipSuccess)
+      return fail(PPASR_EHIP, "hipMemcpy failed");
+    W.wave_tab = static_cast<const Ds2WaveLayer*>(d);
   }
   {
     GETW(cw, "decoder.ctc_lo.weight", (size_t)dirs * H * V);
@@ -128,7 +163,7 @@ ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd) {
 }
 
 struct Ds2Ws {
-  size_t y1, x, gx, ya, yb, h0, h1, c, lens32, total;  // float offsets
+  size_t y1, x, gx, ya, yb, h0, h1, c, lens32, hbuf, cbuf, yring, total;  // float offsets
 };
 static Ds2Ws ds2_ws(const ppasr_model_s* m, int B, int T) {
   const Ds2W& W = m->ds2;
@@ -144,6 +179,10 @@ static Ds2Ws ds2_ws(const ppasr_model_s* m, int B, int T) {
   w.h1 = o; o += al64((size_t)W.dirs * B * W.H);
   w.c = o; o += al64((size_t)W.dirs * B * W.H);
   w.lens32 = o; o += al64(B);
+  // wavefront path (unidirectional models): per-layer state / output rings
+  w.hbuf = o; o += al64((size_t)W.n_layers * 2 * B * W.H);
+  w.cbuf = o; o += al64((size_t)W.n_layers * B * W.H);
+  w.yring = o; o += al64((size_t)W.n_layers * 2 * B * W.H);
   w.total = o;
   return w;
 }
@@ -178,6 +217,37 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
   int in_ld = W.ldx;
   float* out = ya;
   const size_t sbytes = (size_t)dirs * B * H * sizeof(float);
+  // (the matrix-core tiles have 32 rows whatever the batch: below 4 utterances the per-step kernels are the faster ones)
+  if (W.wave_tab && dirs == 1 && Tp > 0 && B >= 4) {
+    // ---- unidirectional stack: wavefront over (layer, time), Tp + L - 1 dependent launches (k_lstm_wave) ----
+    const int L = W.n_layers;
+    const Ds2LayerW& L0 = h->ds2_layers[0];
+    launch_dense(x, W.ldx, L0.w_ih, L0.b_sum, gx, M, L0.in_dim_padded, 4 * H, 4 * H, 4 * H, st);
+    float *hbuf = ws + wl.hbuf, *cbuf = ws + wl.cbuf, *yring = ws + wl.yring;
+    const size_t BH = (size_t)B * H;
+    for (int l = 0; l < L; ++l) {
+      float* h_l = hbuf + (size_t)l * 2 * BH;  // slot 0 = state before time 0
+      if (init_h) HIP_TRY(hipMemcpyAsync(h_l, init_h + (size_t)l * BH, BH * sizeof(float), hipMemcpyDeviceToDevice, st));
+      else HIP_TRY(hipMemsetAsync(h_l, 0, BH * sizeof(float), st));
+      if (init_c) HIP_TRY(hipMemcpyAsync(cbuf + (size_t)l * BH, init_c + (size_t)l * BH, BH * sizeof(float), hipMemcpyDeviceToDevice, st));
+      else HIP_TRY(hipMemsetAsync(cbuf + (size_t)l * BH, 0, BH * sizeof(float), st));
+    }
+    HIP_TRY(hipMemsetAsync(out, 0, (size_t)M * H * sizeof(float), st));
+    for (int s = 0; s < Tp + L - 1; ++s) {
+      const int l_lo = s - (Tp - 1) > 0 ? s - (Tp - 1) : 0, l_hi = s < L - 1 ? s : L - 1;
+      launch_lstm_wave(gx, W.wave_tab, hbuf, cbuf, yring, out, lens32, B, Tp, H, L, s, l_lo, l_hi - l_lo + 1, st);
+    }
+    for (int l = 0; l < L; ++l) {
+      if (final_h) HIP_TRY(hipMemcpyAsync(final_h + (size_t)l * BH, hbuf + ((size_t)l * 2 + (Tp & 1)) * BH, BH * sizeof(float), hipMemcpyDeviceToDevice, st));
+      if (final_c) HIP_TRY(hipMemcpyAsync(final_c + (size_t)l * BH, cbuf + (size_t)l * BH, BH * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    const Ds2LayerW& Ll = h->ds2_layers[L - 1];
+    launch_ln_wide(out, Ll.ln_g, Ll.ln_b, M, H, st);
+    launch_dense(out, H, W.ctc_w, W.ctc_b, probs, M, H, W.Vpad, W.V, W.V, st);
+    launch_softmax_from_stats(probs, nullptr, nullptr, M, W.V, st);
+    HIP_TRY(hipGetLastError());
+    return PPASR_OK;
+  }
   for (int l = 0; l < W.n_layers; ++l) {
     const Ds2LayerW& Lw = h->ds2_layers[l];
     // gate pre-activations of all frames and both directions: [M][dirs*4H]; the step kernel wants [dirs][M][4H]

@@ -17,11 +17,19 @@ struct Ds2LayerW {
   const float *ln_g, *ln_b;  // [dirs*H]
   int in_dim_padded;
 };
+// unidirectional stack as a wavefront over (layer, time) -- see k_lstm_wave: per-layer device pointers
+struct Ds2WaveLayer {
+  const f32x4* whh_pk;  // recurrent weights, fragment order, gate-interleaved tiles (as Ds2LayerW::w_hh_pk)
+  const f32x4* wih_pk;  // layers >= 1: input weights with the previous layer's LayerNorm gamma folded in, same order
+  const float* s_n;     // [4H] column sums of those folded weights (gate-interleaved order)
+  const float* c_n;     // [4H] b_ih + b_hh + W_ih * beta of the previous layer's LayerNorm
+};
 struct Ds2W {
   const float *cmvn_mean, *cmvn_istd, *c1_w, *c1_b, *c2_w, *c2_b;
   const f32x4* ctc_w;  // packed [dirs*H][Vpad]
   const float* ctc_b;  // [Vpad]
   int H, dirs, n_layers, V, Vpad, ldx;
+  const Ds2WaveLayer* wave_tab = nullptr;  // device [n_layers]; nullptr: no wavefront path (bidirectional models)
 };
 
 void launch_ds2_conv1(const float* feats, const float* mean, const float* istd, const float* w, const float* bias, float* y1,
@@ -35,6 +43,11 @@ void launch_lstm_step(const float* gx, const float* whh, const float* hprev, flo
 // gates = h_prev W_hh^T as a [32 x H] x [H x 32] MFMA tile per workgroup, the contraction split over its 8 waves.
 void launch_lstm_step_mfma(const float* gx, const f32x4* whh_pk, const float* hprev, float* hnext, float* c, float* y,
                            const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st);
+// One wavefront launch of the unidirectional stack: layers l_lo .. l_lo + n_l - 1, layer l at time s - l.
+//   gx0 [B*T][4H] layer-0 input projections; hbuf [L][2][B][H] (slot = time parity), cbuf [L][B][H],
+//   yring [L][2][B][H] raw outputs of the last two time steps, out [B*T][H] raw outputs of the last layer (pre-zeroed)
+void launch_lstm_wave(const float* gx0, const Ds2WaveLayer* tab, float* hbuf, float* cbuf, float* yring, float* out,
+                      const int32_t* lens, int B, int T, int H, int L, int s, int l_lo, int n_l, hipStream_t st);
 void launch_ln_wide(float* x, const float* g, const float* b, int M, int N, hipStream_t st);
 
 }  // namespace ppasr

@@ -233,6 +233,152 @@ __global__ __launch_bounds__(kThreads) void k_lstm_step_mfma(const float* __rest
   }
 }
 
+// Wavefront over (layer, time) for the UNIDIRECTIONAL stack (streaming models): layer l+1 at time t only needs layer l at
+// time t, so launch s runs every layer l with 0 <= s - l < T at time t = s - l: T + L - 1 dependent launches instead
+// of T * L.  For l >= 1 the input projection is folded into the step (there is no [B*T][4H] pre-pass to wait for):
+//   W_ih LN(y) + b = rstd * (W' y - mean * colsum(W')) + (W_ih beta + b),   W' = W_ih diag(gamma)
+// so the MFMA runs on the RAW previous-layer output y_{l-1}[t] (a second accumulator tile next to h_{t-1} W_hh^T) and
+// the LayerNorm of the row enters through its mean / rstd, which the waves accumulate from the very A fragments they
+// load (sum and sum of squares per row).  Same workgroup shape as k_lstm_step_mfma.
+__global__ __launch_bounds__(kThreads) void k_lstm_wave(const float* __restrict__ gx0, const Ds2WaveLayer* __restrict__ tab,
+                                                        float* __restrict__ hbuf, float* __restrict__ cbuf,
+                                                        float* __restrict__ yring, float* __restrict__ out,
+                                                        const int32_t* __restrict__ lens, int B, int T, int H, int L, int s,
+                                                        int l_lo) {
+  // every wave contracts its K slice of BOTH products (two accumulator tiles); splitting the waves by product instead
+  // (4 + 4, half the partial tiles) was measured and is slower: 7.9 against 6.8 ms per 32 x 5 s batch
+  __shared__ float part_h[kWaves][32][33];
+  __shared__ float part_i[kWaves][32][33];
+  __shared__ float stat_s[kWaves][32], stat_q[kWaves][32];
+  __shared__ float gates[32][33];
+  const int tile = blockIdx.x, l = l_lo + blockIdx.y, t = s - l, b0 = blockIdx.z * 32;
+  const Ds2WaveLayer lay = tab[l];
+  const int lane = lane_id(), wave = wave_id();
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int n_groups = H / 8, gpw = n_groups / kWaves, g0 = wave * gpw;
+  const int b = b0 + l31;
+  const bool row_live = b < B && t < lens[min(b, B - 1)];
+  const size_t BH = (size_t)B * H;
+  const float* hprev = hbuf + ((size_t)l * 2 + (t & 1)) * BH;
+  float* hnext = hbuf + ((size_t)l * 2 + ((t + 1) & 1)) * BH;
+  float* cc = cbuf + (size_t)l * BH;
+  const float* yprev = l > 0 ? yring + ((size_t)(l - 1) * 2 + (t & 1)) * BH : nullptr;
+  float* ycur = yring + ((size_t)l * 2 + (t & 1)) * BH;
+  const size_t rowoff = (size_t)min(b, B - 1) * H + 4 * hh;
+  const f32x4* wh = lay.whh_pk + (size_t)tile * n_groups * 64 + lane;
+  const f32x4* wi = lay.wih_pk + (size_t)tile * n_groups * 64 + lane;
+  f32x16 acc_h, acc_i;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_h[r] = acc_i[r] = 0.f;
+  constexpr int PFD = 8;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  {  // ---- h_{t-1} W_hh^T ----
+    f32x4 ra[PFD], rb[PFD];
+#pragma unroll
+    for (int q = 0; q < PFD; ++q) {
+      ra[q] = row_live ? *reinterpret_cast<const f32x4*>(hprev + rowoff + 8 * (g0 + q)) : zero4;
+      rb[q] = wh[(size_t)(g0 + q) * 64];
+    }
+    for (int g = 0; g < gpw; g += PFD) {
+#pragma unroll
+      for (int q = 0; q < PFD; ++q) {
+        const f32x4 a = ra[q], bq = rb[q];
+        if (g + PFD + q < gpw) {
+          ra[q] = row_live ? *reinterpret_cast<const f32x4*>(hprev + rowoff + 8 * (g0 + g + PFD + q)) : zero4;
+          rb[q] = wh[(size_t)(g0 + g + PFD + q) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc_h = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bq[j], acc_h, 0, 0, 0);
+      }
+    }
+  }
+  float sum = 0.f, sq = 0.f;
+  if (l > 0) {  // ---- y_{l-1}[t] W'_ih^T on the raw row, LayerNorm statistics on the side ----
+    f32x4 ra[PFD], rb[PFD];
+#pragma unroll
+    for (int q = 0; q < PFD; ++q) {
+      ra[q] = row_live ? *reinterpret_cast<const f32x4*>(yprev + rowoff + 8 * (g0 + q)) : zero4;
+      rb[q] = wi[(size_t)(g0 + q) * 64];
+    }
+    for (int g = 0; g < gpw; g += PFD) {
+#pragma unroll
+      for (int q = 0; q < PFD; ++q) {
+        const f32x4 a = ra[q], bq = rb[q];
+        if (g + PFD + q < gpw) {
+          ra[q] = row_live ? *reinterpret_cast<const f32x4*>(yprev + rowoff + 8 * (g0 + g + PFD + q)) : zero4;
+          rb[q] = wi[(size_t)(g0 + g + PFD + q) * 64];
+        }
+        sum += a[0] + a[1] + a[2] + a[3];
+        sq += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc_i = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bq[j], acc_i, 0, 0, 0);
+      }
+    }
+    sum += __shfl_xor(sum, 32);
+    sq += __shfl_xor(sq, 32);
+    if (hh == 0) {
+      stat_s[wave][l31] = sum;
+      stat_q[wave][l31] = sq;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    part_h[wave][acc_row(r, lane)][l31] = acc_h[r];
+    if (l > 0) part_i[wave][acc_row(r, lane)][l31] = acc_i[r];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * 32; e += kThreads) {
+    const int row = e >> 5, col = e & 31;
+    const int bb = b0 + row;
+    float vh = 0.f, vi = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) vh += part_h[w][row][col];
+    float v = vh;
+    if (bb < B && t < lens[bb]) {
+      const int n = tile * 32 + col;  // gate-interleaved column
+      if (l == 0) {
+        v += gx0[((size_t)bb * T + t) * 4 * H + (size_t)(col >> 3) * H + tile * 8 + (col & 7)];
+      } else {
+        float ss = 0.f, qq = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+          vi += part_i[w][row][col];
+          ss += stat_s[w][row];
+          qq += stat_q[w][row];
+        }
+        const float mean = ss / (float)H;
+        const float var = fmaxf(qq / (float)H - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        v += rstd * (vi - mean * lay.s_n[n]) + lay.c_n[n];
+      }
+    }
+    gates[row][col] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32 * 8) {
+    const int row = threadIdx.x >> 3, u = threadIdx.x & 7;
+    const int bb = b0 + row;
+    if (bb < B) {
+      const int len = lens[bb];
+      const size_t si = (size_t)bb * H + tile * 8 + u;
+      if (t >= len) {
+        hnext[si] = hprev[si];  // finished utterance: carry the state (final state = last valid step)
+      } else {
+        const float gi = 1.0f / (1.0f + expf(-gates[row][0 + u]));
+        const float gf = 1.0f / (1.0f + expf(-gates[row][8 + u]));
+        const float gg = tanhf(gates[row][16 + u]);
+        const float go = 1.0f / (1.0f + expf(-gates[row][24 + u]));
+        const float cn = gf * cc[si] + gi * gg;
+        const float hv = go * tanhf(cn);
+        cc[si] = cn;
+        hnext[si] = hv;
+        ycur[si] = hv;
+        if (l == L - 1) out[((size_t)bb * T + t) * (size_t)H + tile * 8 + u] = hv;
+      }
+    }
+  }
+}
+
 // LayerNorm over N features (N % 256 == 0, N <= 4096), in place; one wave per row
 __global__ __launch_bounds__(256) void k_ln_wide(float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
                                                  int M, int N) {
@@ -280,6 +426,11 @@ void launch_lstm_step_mfma(const float* gx, const f32x4* whh_pk, const float* hp
                            const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st) {
   hipLaunchKernelGGL(k_lstm_step_mfma, dim3(H / 8, dirs, (B + 31) / 32), dim3(kThreads), 0, st, gx, whh_pk, hprev, hnext, c, y,
                      lens, B, T, H, dirs, step);
+}
+void launch_lstm_wave(const float* gx0, const Ds2WaveLayer* tab, float* hbuf, float* cbuf, float* yring, float* out,
+                      const int32_t* lens, int B, int T, int H, int L, int s, int l_lo, int n_l, hipStream_t st) {
+  hipLaunchKernelGGL(k_lstm_wave, dim3(H / 8, n_l, (B + 31) / 32), dim3(kThreads), 0, st, gx0, tab, hbuf, cbuf, yring, out, lens,
+                     B, T, H, L, s, l_lo);
 }
 void launch_ln_wide(float* x, const float* g, const float* b, int M, int N, hipStream_t st) {
   hipLaunchKernelGGL(k_ln_wide, dim3((M + 3) / 4), dim3(256), 0, st, x, g, b, M, N);

@@ -69,3 +69,24 @@ def test_deepspeech2_config1_shape():
     keep = np.r_[True, ref[1:] != ref[:-1]]
     ids = ref[keep]
     assert np.array_equal(tokens[0, :int(n[0])].cpu().numpy(), ids[ids != 0])
+
+
+def test_deepspeech2_streaming_batch_wavefront_with_state_carry():
+    """B >= 4 unidirectional batches take the wavefront path (k_lstm_wave: T + L - 1 launches over (layer, time), the
+    LayerNorm + input projection of layers >= 1 folded into the step): ragged lengths, three layers, and the final
+    states of one call as the initial states of the next, against the oracle."""
+    V, L = 90, 3
+    sd = deepspeech2_state_dict(vocab_size=V, num_rnn_layers=L, streaming=True, seed=97, perturb_norm=True)
+    model = _model(sd, V, L, True)
+    oracle = DeepSpeech2Oracle(sd, L, 1024, True)
+    x, _ = synth_features(6, 150, seed=98)
+    h = c = rh = rc = None
+    for s0, lens in ((0, [75, 75, 60, 33, 9, 75]), (75, [75, 51, 75, 20, 75, 64])):
+        chunk = x[:, s0:s0 + 75]
+        la = np.array(lens)
+        probs, ol, h, c = model.get_encoder_out_chunk(chunk, la, h, c)
+        rp, rl, rh, rc = oracle.forward(chunk, la, rh, rc)
+        torch.cuda.synchronize()
+        assert ol.cpu().tolist() == rl.tolist()
+        assert _rel(probs.cpu().numpy(), rp.numpy()) < TOL
+        assert _rel(h.cpu().numpy(), rh.numpy()) < TOL and _rel(c.cpu().numpy(), rc.numpy()) < TOL
