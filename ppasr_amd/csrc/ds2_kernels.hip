@@ -246,9 +246,10 @@ __global__ __launch_bounds__(kThreads) void k_lstm_wave(const float* __restrict_
                                                         const int32_t* __restrict__ lens, int B, int T, int H, int L, int s,
                                                         int l_lo) {
   // every wave contracts its K slice of BOTH products (two accumulator tiles); splitting the waves by product instead
-  // (4 + 4, half the partial tiles) was measured and is slower: 7.9 against 6.8 ms per 32 x 5 s batch
-  __shared__ float part_h[kWaves][32][33];
-  __shared__ float part_i[kWaves][32][33];
+  // (4 + 4) was measured and is slower: 7.9 against 6.8 ms per 32 x 5 s batch
+  // (ONE partial-tile buffer used twice -- for h W_hh^T, then for y W'_ih^T -- keeps the workgroup at 40 KB of LDS: the up
+  //  to 5 x 128 workgroups of a launch then fit the chip in one round)
+  __shared__ float part[kWaves][32][33];
   __shared__ float stat_s[kWaves][32], stat_q[kWaves][32];
   __shared__ float gates[32][33];
   const int tile = blockIdx.x, l = l_lo + blockIdx.y, t = s - l, b0 = blockIdx.z * 32;
@@ -322,18 +323,30 @@ __global__ __launch_bounds__(kThreads) void k_lstm_wave(const float* __restrict_
     }
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    part_h[wave][acc_row(r, lane)][l31] = acc_h[r];
-    if (l > 0) part_i[wave][acc_row(r, lane)][l31] = acc_i[r];
-  }
+  for (int r = 0; r < 16; ++r) part[wave][acc_row(r, lane)][l31] = acc_h[r];
   __syncthreads();
-  for (int e = threadIdx.x; e < 32 * 32; e += kThreads) {
+  float vh2[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = threadIdx.x + q * kThreads, row = e >> 5, col = e & 31;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) v += part[w][row][col];
+    vh2[q] = v;
+  }
+  if (l > 0) {  // (block-uniform)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][acc_row(r, lane)][l31] = acc_i[r];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = threadIdx.x + q * kThreads;
     const int row = e >> 5, col = e & 31;
     const int bb = b0 + row;
-    float vh = 0.f, vi = 0.f;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) vh += part_h[w][row][col];
-    float v = vh;
+    float vi = 0.f;
+    float v = vh2[q];
     if (bb < B && t < lens[bb]) {
       const int n = tile * 32 + col;  // gate-interleaved column
       if (l == 0) {
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(kThreads) void k_lstm_wave(const float* __restrict_
         float ss = 0.f, qq = 0.f;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) {
-          vi += part_i[w][row][col];
+          vi += part[w][row][col];
           ss += stat_s[w][row];
           qq += stat_q[w][row];
         }
