@@ -82,8 +82,31 @@ class PPASRPredictor:
         score, text = self.decode(output_data=probs, use_pun=use_pun, is_itn=is_itn)
         return {"text": text, "score": score}
 
-    def predict_long(self, *a, **k):
-        raise NotImplementedError("predict_long needs the Silero VAD model (SURVEY.md §2 row 18), out of scope")
+    def predict_long(self, audio_data, use_pun=False, is_itn=False, sample_rate=16000, speech_timestamps=None,
+                     vad_predictor=None):
+        """predict.py:190-229: recognise the speech segments of a long recording one by one and join the texts with
+        '，'; score = mean of the segment scores (2 decimals).  The reference finds the segments with its Silero VAD
+        model (``init_vad``), which is a separate model outside this path: pass the segments as ``speech_timestamps``
+        (``[{'start': sample, 'end': sample}, ...]``, what ``get_speech_timestamps`` returns) or an object with that
+        method as ``vad_predictor``."""
+        if use_pun:
+            raise NotImplementedError("punctuation is a separate model outside the hot path")
+        samples, sr = load_audio(audio_data, sample_rate)
+        if speech_timestamps is None:
+            if vad_predictor is None:
+                raise NotImplementedError("predict_long needs speech_timestamps or a vad_predictor: the Silero VAD "
+                                          "model is not part of this library")
+            speech_timestamps = vad_predictor.get_speech_timestamps(samples, sr)
+        texts, scores = "", []
+        for t in speech_timestamps:
+            result = self.predict(audio_data=samples[t["start"]:t["end"]], use_pun=False, is_itn=is_itn, sample_rate=sr)
+            score, text = result["score"], result["text"]
+            if text != "":
+                texts = texts + "，" + text
+            scores.append(score)
+        if texts[:1] == "，":
+            texts = texts[1:]
+        return {"text": texts, "score": round(sum(scores) / len(scores), 2) if scores else 0}
 
     def predict_stream(self, audio_data, is_end=False, use_pun=False, is_itn=False, channels=1, samp_width=2,
                        sample_rate=16000):

@@ -245,3 +245,27 @@ def test_stream_pool_finish_equals_predict_stream_is_end():
         got = pool.finish(s)
         assert got is not None and got["text"] == want[s]["text"], s
         assert abs(got["score"] - want[s]["score"]) < 1e-3
+
+
+def test_predict_long_with_given_segments():
+    """predict.py:190-229 with the VAD result supplied by the caller: per-segment predict, texts joined with '，',
+    mean score."""
+    from ppasr_amd.predict import PPASRPredictor
+    V = 300
+    vocab = synth_vocabulary(V)
+    sd = conformer_state_dict(vocab_size=V, num_blocks=2, seed=3)
+    p = PPASRPredictor(configs=_cfg(decoder="ctc_greedy"), state_dict=sd, vocab_list=vocab, warmup=False)
+    wav = _audio(6.0, seed=4)
+    segs = [{"start": 1600, "end": 30000}, {"start": 40000, "end": 70000}, {"start": 72000, "end": 96000}]
+    parts = [p.predict(audio_data=wav[t["start"]:t["end"]]) for t in segs]
+    res = p.predict_long(audio_data=wav, speech_timestamps=segs)
+    assert res["text"] == "，".join(r["text"] for r in parts if r["text"] != "")
+    assert res["score"] == round(sum(r["score"] for r in parts) / len(parts), 2)
+
+    class _Vad:
+        def get_speech_timestamps(self, samples, sr):
+            assert sr == 16000 and len(samples) == len(wav)
+            return segs[:2]
+    assert p.predict_long(audio_data=wav, vad_predictor=_Vad())["text"] == "，".join(r["text"] for r in parts[:2] if r["text"])
+    with pytest.raises(NotImplementedError):
+        p.predict_long(audio_data=wav)
