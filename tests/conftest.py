@@ -8,3 +8,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    """The built artefacts are git-ignored: on a fresh checkout (no libppasr_hip.so / oracle library yet) build them once
+    -- hipcc cross-compiles gfx950 without a GPU -- so that the suite does not depend on who ran build() before."""
+    lib = os.path.join(ROOT, "ppasr_amd", "libppasr_hip.so")
+    orc = os.path.join(ROOT, "oracle", "_build", "libctc_beam_oracle.so")
+    if os.path.exists(lib) and os.path.exists(orc):
+        return
+    import importlib
+    entry = importlib.import_module("__graft_entry__")
+    entry.build()
