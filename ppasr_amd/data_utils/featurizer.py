@@ -36,6 +36,21 @@ def load_audio(audio_data, sample_rate=16000):
     raise Exception(f"unsupported audio_data type: {type(audio_data)}")
 
 
+def resample(samples, sample_rate, target_sample_rate):
+    """``AudioSegment.resample`` (data_utils/audio.py:306-317).  The reference calls ``resampy.resample(...,
+    filter='kaiser_best')``; resampy is not installable offline, so this is scipy's polyphase resampler with a Kaiser
+    window (``scipy.signal.resample_poly``): the same kind of band-limited interpolation, not bit-identical to resampy.
+    Host code on the audio I/O side of the path."""
+    if int(sample_rate) == int(target_sample_rate):
+        return np.asarray(samples, np.float32)
+    from math import gcd
+
+    from scipy.signal import resample_poly
+    g = gcd(int(sample_rate), int(target_sample_rate))
+    up, down = int(target_sample_rate) // g, int(sample_rate) // g
+    return resample_poly(np.asarray(samples, np.float64), up, down, window=("kaiser", 14.769656459379492)).astype(np.float32)
+
+
 def pcm_bytes_to_float(data, channels=1, samp_width=2):
     """AudioSegment.from_pcm_bytes (data_utils/audio.py:122-139)."""
     dt = {1: np.int8, 2: np.int16, 4: np.int32}[samp_width]
@@ -84,8 +99,8 @@ class AudioFeaturizer:
         """float32 mono samples in [-1, 1] (numpy or tensor) -> fbank [T, n_mels] float32 DEVICE tensor."""
         from ppasr_amd import _lib
         sr = sample_rate or self._sr
-        if sr != self._sr:
-            raise NotImplementedError("resampling is outside the hot path; feed audio at the model's sample rate")
+        if sr != self._sr:  # audio_featurizer.py:46-47: up / down-sample to the model's rate first (host side)
+            samples = resample(np.asarray(torch.as_tensor(samples).cpu(), np.float32).reshape(-1), sr, self._sr)
         h = self._handle()
         x = torch.as_tensor(samples, dtype=torch.float32).reshape(-1).to(self._device).contiguous()
         n = int(x.numel())

@@ -42,3 +42,19 @@ def test_labels_to_string():
     vocab = ["<blank>", "<unk>", "a", "b", "<space>", "<eos>"]
     labels = np.array([[2, 4, 3, 5, -1], [1, 2, 0, 3, -1]])
     assert labels_to_string(labels, vocab, eos=5) == ["a b", "ab"]
+
+
+def test_resample_keeps_a_tone_and_the_duration():
+    """Host-side resampler behind AudioFeaturizer (the reference resamples to the model's rate first,
+    audio_featurizer.py:46-47): 8 kHz -> 16 kHz and 44.1 kHz -> 16 kHz keep a 440 Hz tone's frequency and level."""
+    import numpy as np
+
+    from ppasr_amd.data_utils.featurizer import resample
+    for sr in (8000, 44100, 16000):
+        t = np.arange(sr) / sr
+        x = (0.5 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+        y = resample(x, sr, 16000)
+        assert y.dtype == np.float32 and abs(len(y) - 16000) <= 1
+        spec = np.abs(np.fft.rfft(y[2000:14000] * np.hanning(12000)))
+        assert abs(np.argmax(spec) * 16000 / 12000 - 440) < 2.0
+        assert abs(np.sqrt(np.mean(y[2000:14000] ** 2)) - 0.5 / np.sqrt(2)) < 5e-3
