@@ -65,3 +65,39 @@ def test_stream_chunk_and_group_stay_inside_their_workspaces():
         g.encode_chunks([0, 1, 2, 3, 4], chunks)
     torch.cuda.synchronize()
     assert _intact(ws, need)
+
+
+@pytest.mark.parametrize("streaming,B", [(True, 1), (True, 6), (False, 3)])
+def test_deepspeech2_stays_inside_its_workspace(streaming, B):
+    from ppasr_amd.model_utils.deepspeech2.model import DeepSpeech2Model
+    from ppasr_amd.utils.synth import deepspeech2_state_dict
+    V, L = 60, 3
+    sd = deepspeech2_state_dict(vocab_size=V, num_rnn_layers=L, streaming=streaming, seed=5)
+    m = DeepSpeech2Model(80, V, streaming=streaming, encoder_conf=dict(num_rnn_layers=L, rnn_size=1024), state_dict=sd,
+                         device="cuda:0")
+    x, la = synth_features(B, 131, lens=[131] + [int(v) for v in np.linspace(20, 120, B - 1)], seed=B)
+    need = int(m.lib.ppasr_ds2_workspace_bytes(m._h, B, 131))
+    ws = _guarded(need, m.device)
+    m._ws = ws[:need]
+    probs, _, h, c = m.get_encoder_out_chunk(x, la)
+    torch.cuda.synchronize()
+    assert _intact(ws, need) and bool(torch.isfinite(probs).all()) and bool(torch.isfinite(h).all())
+
+
+@pytest.mark.parametrize("beam,chunks", [(10, 1), (300, 1), (25, 3)])
+def test_beam_search_stays_inside_its_state_buffer(beam, chunks):
+    from ppasr_amd.decoders import beam_search_decoder as bsd
+    rng = np.random.Generator(np.random.PCG64(beam))
+    B, T, V = 3, 60, 500
+    p = rng.random((B, T * chunks, V)).astype(np.float32) ** 8
+    p /= p.sum(-1, keepdims=True)
+    dev = torch.device("cuda:0")
+    st = bsd._BeamState(B, T * chunks, beam, dev)
+    guard = _guarded(st.bytes, dev)
+    st.buf = guard[:st.bytes]
+    for k in range(chunks):
+        tokens, lens, scores, st = bsd.beam_search_ids(torch.from_numpy(p[:, k * T:(k + 1) * T]).cuda(), beam, 0.99, 40, 0,
+                                                       state=st)
+    torch.cuda.synchronize()
+    assert _intact(guard, st.bytes)
+    assert int(lens.min()) >= 0
