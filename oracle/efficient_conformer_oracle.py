@@ -13,8 +13,9 @@ class EfficientConformerOracle(ConformerOracle):
     """EfficientConformerModel.get_encoder_out for the streaming configuration (causal conv)."""
 
     def __init__(self, sd, attention_heads=4, num_blocks=12, cnn_module_kernel=15, stride_layer_idx=3,
-                 group_layer_idx=(0, 1, 2, 3), group_size=3, max_len=5000, dtype=torch.float32):
-        super().__init__(sd, attention_heads, num_blocks, cnn_module_kernel, True, max_len, dtype)
+                 group_layer_idx=(0, 1, 2, 3), group_size=3, max_len=5000, dtype=torch.float32, causal=True):
+        # causal conv <=> streaming model (efficient_conformer/model.py: causal = streaming)
+        super().__init__(sd, attention_heads, num_blocks, cnn_module_kernel, causal, max_len, dtype)
         self.stride_layer_idx = stride_layer_idx
         self.group_layer_idx = tuple(group_layer_idx or ())
         self.group_size = group_size
@@ -73,17 +74,21 @@ class EfficientConformerOracle(ConformerOracle):
 
     def _conv_eff(self, x, mask_pad, prefix, ksize, stride, cache=None):
         # efficient_conformer/convolution.py:80-138 ; mask_pad True = valid
-        lorder = ksize - 1
+        lorder = ksize - 1 if self.causal else 0  # convolution.py ctor: causal -> lorder = k - 1, padding 0;
+        padding = 0 if self.causal else (ksize - 1) // 2  # else lorder 0, depthwise padding (k - 1) // 2
         x = x.transpose(1, 2).masked_fill(~mask_pad, 0.0)
-        if cache is None or cache.shape[-1] == 0:
-            x = F.pad(x, (lorder, 0), "constant", 0.0)
+        if lorder > 0:
+            if cache is None or cache.shape[-1] == 0:
+                x = F.pad(x, (lorder, 0), "constant", 0.0)
+            else:
+                x = torch.cat((cache[:, :, -lorder:], x), dim=2)  # :105-109
+            new_cache = x[:, :, -lorder:]
         else:
-            x = torch.cat((cache[:, :, -lorder:], x), dim=2)  # :105-109
-        new_cache = x[:, :, -lorder:]
+            new_cache = x[:, :, :0]
         x = F.conv1d(x, self.p[prefix + ".pointwise_conv1.weight"], self.p[prefix + ".pointwise_conv1.bias"])
         x = F.glu(x, dim=1)
         x = F.conv1d(x, self.p[prefix + ".depthwise_conv.weight"], self.p[prefix + ".depthwise_conv.bias"],
-                     stride=stride, groups=x.shape[1])
+                     stride=stride, padding=padding, groups=x.shape[1])
         x = x.transpose(1, 2)
         x = self._swish(self._ln(x, prefix + ".norm"))
         x = x.transpose(1, 2)

@@ -74,8 +74,8 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
     return fail(PPASR_EUNSUPPORTED, "cnn_module_kernel must be 7, 15 or 31");
   if (desc->model_type == PPASR_MODEL_SQUEEZEFORMER && desc->cnn_module_kernel == 7)
     return fail(PPASR_EUNSUPPORTED, "squeezeformer: cnn_module_kernel must be 15 or 31");
-  if (!desc->causal && desc->model_type != PPASR_MODEL_CONFORMER)
-    return fail(PPASR_EUNSUPPORTED, "the non-causal conv module (streaming=False) is built for model_type=conformer only");
+  if (!desc->causal && desc->model_type == PPASR_MODEL_SQUEEZEFORMER)
+    return fail(PPASR_EUNSUPPORTED, "squeezeformer: the non-streaming variant (other time-reduction layer, non-causal conv) is not built");
   if (desc->input_dim > 128 || desc->input_dim < 7) return fail(PPASR_EUNSUPPORTED, "input_dim out of range");
   HIP_TRY(configure_kernels());
   HIP_TRY(configure_squeezeformer_kernels());
@@ -485,7 +485,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       const int Ts = (Ti + 1) / 2;
       timed(6, [&] {
         launch_conv_ffn_stride(g, nullptr, xc, xa, L, lens, B, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st,
-                               pskip(Ts, mul * 2));
+                               pskip(Ts, mul * 2), h->desc.causal != 0);
       });
       Ti = Ts;  // masks[:, :, ::2], pos_emb[:, ::2]  (efficient_conformer/encoder.py:252-257)
       mul *= 2;

@@ -1548,7 +1548,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __res
                                                               const float* __restrict__ x2, float* __restrict__ x_out,
                                                               LayerW w,
                                                               const int64_t* __restrict__ lens, int B, int Tp, int Ts,
-                                                              int n_chunks, int mask_mul_out, PadSkip ps) {
+                                                              int n_chunks, int mask_mul_out, PadSkip ps, int causal) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, B * Ts)) return;  // (ps describes the OUTPUT rows)
   float* bufX = smem;
@@ -1573,11 +1573,13 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __res
         const float* gb = g + (size_t)b * Tp * kD + 4 * lane;
 #pragma unroll
         for (int t = 0; t < KS; ++t) {
-          const int f = 2 * j - LO + t;
+          // causal: left context KS-1, frames before the start = GLU(pointwise_conv1(0)) (the reference pads before
+          // pointwise_conv1); non-causal: the depthwise conv itself zero-pads (KS-1)/2 frames on both sides
+          const int f = 2 * j - (causal ? LO : LO / 2) + t;
           const f32x4 wj = *reinterpret_cast<const f32x4*>(w.dw_w + t * kD + 4 * lane);
-          f32x4 v = gp;
-          if (f >= 0) v = *reinterpret_cast<const f32x4*>(gb + (size_t)f * kD);
-          else if (g_hist) v = *reinterpret_cast<const f32x4*>(g_hist + (size_t)(LO + f) * kD + 4 * lane);  // streaming, B = 1
+          f32x4 v = causal ? gp : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (f >= 0 && f < Tp) v = *reinterpret_cast<const f32x4*>(gb + (size_t)f * kD);
+          else if (f < 0 && g_hist) v = *reinterpret_cast<const f32x4*>(g_hist + (size_t)(LO + f) * kD + 4 * lane);  // streaming, B = 1
           out += wj * v;
         }
       }
@@ -1621,14 +1623,14 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __res
 }
 void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                             const int64_t* lens, int B, int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out,
-                            hipStream_t st, const PadSkip& ps) {
+                            hipStream_t st, const PadSkip& ps, bool causal) {
   dim3 grid((B * Ts + kRows - 1) / kRows);
   if (ksize == 15)
     hipLaunchKernelGGL(k_conv_ffn_stride<15>, grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, B, Tp, Ts,
-                       n_chunks, mask_mul_out, ps);
+                       n_chunks, mask_mul_out, ps, causal ? 1 : 0);
   else if (ksize == 7)
     hipLaunchKernelGGL(k_conv_ffn_stride<7>, grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, B, Tp, Ts,
-                       n_chunks, mask_mul_out, ps);
+                       n_chunks, mask_mul_out, ps, causal ? 1 : 0);
 }
 
 // -------------------------------------------------------------------------------------

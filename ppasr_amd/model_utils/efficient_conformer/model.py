@@ -22,8 +22,6 @@ class EfficientConformerModel(ConformerModel):
             raise ValueError("state_dict (Paddle-layout parameter dict) is required")
         if not torch.cuda.is_available():
             raise _lib.PPASRHipError("no HIP device visible: ppasr_amd has no CPU fallback")
-        if not streaming:
-            raise NotImplementedError("only the streaming configuration (causal conv) is built")
         self.lib = _lib.load()
         self.device = torch.device(device)
         self.input_dim, self.vocab_size, self.streaming = input_dim, vocab_size, streaming
@@ -76,7 +74,8 @@ class EfficientConformerModel(ConformerModel):
         for g in groups:
             mask |= 1 << int(g)
         desc = _lib.ModelDesc(_lib.PPASR_MODEL_EFFICIENT_CONFORMER, input_dim, vocab_size, self.output_size,
-                              self.attention_heads, self.linear_units, self.num_blocks, self.cnn_module_kernel, 1,
+                              self.attention_heads, self.linear_units, self.num_blocks, self.cnn_module_kernel,
+                              1 if streaming else 0,  # causal conv <=> streaming (efficient_conformer/model.py)
                               self.max_len, -1, -1, -1 if stride_idx is None else int(stride_idx), mask,
                               self.group_size)
         handle = ctypes.c_void_p()

@@ -66,3 +66,33 @@ def test_efficient_conformer_full_config_beam_search():
     assert _rel(logits.cpu().numpy(), ref_logits.numpy()) < TOL
     tokens, ln, sc, _ = beam_search_ids(probs, 10, 0.99, 40, 0)
     assert int(ln[0, 0]) > 0
+
+
+@pytest.mark.parametrize("B,T,lens", [(3, 203, [203, 150, 67]), (2, 411, [411, 300]), (1, 131, [131])])
+@pytest.mark.parametrize("route", [-1, 0])
+def test_efficient_conformer_non_streaming_matches_oracle(B, T, lens, route):
+    """streaming=False: non-causal conv modules (depthwise padding (k-1)//2 on both sides, the strided one included,
+    efficient_conformer/convolution.py ctor), full attention as before."""
+    from ppasr_amd.model_utils.efficient_conformer.model import EfficientConformerModel
+    V, L = 113, 4
+    sd = efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=B * 100 + T, perturb_norm=True, stride_layer_idx=1,
+                                        group_layer_idx=(0, 1))
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15,
+                cnn_module_norm="layer_norm",
+                efficient_conf=dict(stride_layer_idx=[1], stride=[2], group_layer_idx=[0, 1], group_size=3,
+                                    stride_kernel=True))
+    model = EfficientConformerModel(80, V, streaming=False, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    model.set_ffn_split(route)
+    oracle = EfficientConformerOracle(sd, num_blocks=L, stride_layer_idx=1, group_layer_idx=(0, 1), causal=False)
+    x, la = synth_features(B, T, lens=lens, seed=T)
+    probs, logits = model.get_encoder_out(x, la, return_logits=True)
+    ref_probs, ref_logits = oracle.get_encoder_out(x, la, return_logits=True)
+    torch.cuda.synchronize()
+    assert tuple(logits.shape) == tuple(ref_logits.shape)
+    assert _rel(logits.cpu().numpy(), ref_logits.numpy()) < TOL
+    # the non-causal modules must actually differ from the causal ones
+    causal = EfficientConformerOracle(sd, num_blocks=L, stride_layer_idx=1, group_layer_idx=(0, 1)).get_encoder_out(
+        x, la, return_logits=True)[1]
+    assert _rel(causal.numpy(), ref_logits.numpy()) > 1e-2
+    with pytest.raises(Exception):
+        model.new_stream()  # forward_chunk needs the causal module

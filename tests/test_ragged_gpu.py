@@ -40,11 +40,24 @@ def _efficient(V):
     return EfficientConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0"), 8
 
 
+def _efficient_noncausal(V):
+    from ppasr_amd.model_utils.efficient_conformer.model import EfficientConformerModel
+    L = 4
+    sd = efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=8, perturb_norm=True, stride_layer_idx=1,
+                                        group_layer_idx=(0, 1))
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15,
+                cnn_module_norm="layer_norm",
+                efficient_conf=dict(stride_layer_idx=[1], stride=[2], group_layer_idx=[0, 1], group_size=3,
+                                    stride_kernel=True))
+    return EfficientConformerModel(80, V, streaming=False, encoder_conf=conf, state_dict=sd, device="cuda:0"), 8
+
+
 FAMILIES = {
     "conformer": lambda V: _conformer(V, True),
     "conformer-noncausal": lambda V: _conformer(V, False),
     "squeezeformer": _squeezeformer,
     "efficient": _efficient,
+    "efficient-noncausal": _efficient_noncausal,
 }
 
 
