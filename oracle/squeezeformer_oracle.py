@@ -14,10 +14,11 @@ class SqueezeformerOracle(ConformerOracle):
     (causal conv module, TimeReductionLayerStream; squeezeformer/model.py:35-39)."""
 
     def __init__(self, sd, attention_heads=4, num_blocks=12, cnn_module_kernel=31, reduce_idx=5, recover_idx=11,
-                 max_len=5000, dtype=torch.float32):
+                 max_len=5000, dtype=torch.float32, causal=True):
+        # causal=False: the non-streaming model (non-causal conv modules, TimeReductionLayer1D; model.py:35-39)
         sd = dict(sd)
         sd.setdefault("encoder.after_norm.weight", sd["encoder.preln.weight"])  # only used for self.d
-        super().__init__(sd, attention_heads, num_blocks, cnn_module_kernel, True, max_len, dtype)
+        super().__init__(sd, attention_heads, num_blocks, cnn_module_kernel, causal, max_len, dtype)
         self.reduce_idx = reduce_idx
         self.recover_idx = recover_idx
 
@@ -69,17 +70,20 @@ class SqueezeformerOracle(ConformerOracle):
         x = self.p[prefix + ".ada_scale"].reshape(1, 1, -1) * x + self.p[prefix + ".ada_bias"].reshape(1, 1, -1)
         x = x.transpose(1, 2)
         x = x.masked_fill(~mask_pad, 0.0)
-        if cache is None or cache.shape[-1] == 0:
-            x = F.pad(x, (self.lorder, 0), "constant", 0.0)
+        if self.lorder > 0:
+            if cache is None or cache.shape[-1] == 0:
+                x = F.pad(x, (self.lorder, 0), "constant", 0.0)
+            else:
+                x = torch.cat((cache, x), dim=2)  # the cache holds SCALED inputs (convolution.py:119-137)
+            new_cache = x[:, :, -self.lorder:]
         else:
-            x = torch.cat((cache, x), dim=2)  # the cache holds SCALED inputs (convolution.py:119-137)
-        new_cache = x[:, :, -self.lorder:]
+            new_cache = x[:, :, :0]
         x = F.conv1d(x, self.p[prefix + ".pointwise_conv1.weight"], self.p[prefix + ".pointwise_conv1.bias"])
         x = F.glu(x, dim=1)
         if self.trace is not None:
             self.trace[prefix + ".glu"] = x.transpose(1, 2)
         x = F.conv1d(x, self.p[prefix + ".depthwise_conv.weight"], self.p[prefix + ".depthwise_conv.bias"],
-                     groups=x.shape[1])
+                     padding=0 if self.causal else (self.k - 1) // 2, groups=x.shape[1])
         x = x.transpose(1, 2)
         x = self._swish(self._ln(x, prefix + ".norm"))
         x = x.transpose(1, 2)
@@ -103,10 +107,12 @@ class SqueezeformerOracle(ConformerOracle):
         return x
 
     def _time_reduce(self, xs, mask_pad):
-        # TimeReductionLayerStream.forward  time_reduction.py:183-206
+        # TimeReductionLayerStream.forward  time_reduction.py:183-206 (kernel 1, no padding) or, for the non-streaming
+        # model, TimeReductionLayer1D.forward  :62-85 (kernel 5, padding = kernel - stride = 3 on both sides)
         y = xs.transpose(1, 2).masked_fill(mask_pad == 0, 0.0)
-        y = F.conv1d(y, self.p["encoder.time_reduction_layer.dw_conv.weight"],
-                     self.p["encoder.time_reduction_layer.dw_conv.bias"], stride=2, groups=y.shape[1])
+        w = self.p["encoder.time_reduction_layer.dw_conv.weight"]
+        y = F.conv1d(y, w, self.p["encoder.time_reduction_layer.dw_conv.bias"], stride=2,
+                     padding=max(0, w.shape[-1] - 2), groups=y.shape[1])
         y = F.conv1d(y, self.p["encoder.time_reduction_layer.pw_conv.weight"],
                      self.p["encoder.time_reduction_layer.pw_conv.bias"])
         xs = y.transpose(1, 2)

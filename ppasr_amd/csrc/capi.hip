@@ -74,8 +74,6 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
     return fail(PPASR_EUNSUPPORTED, "cnn_module_kernel must be 7, 15 or 31");
   if (desc->model_type == PPASR_MODEL_SQUEEZEFORMER && desc->cnn_module_kernel == 7)
     return fail(PPASR_EUNSUPPORTED, "squeezeformer: cnn_module_kernel must be 15 or 31");
-  if (!desc->causal && desc->model_type == PPASR_MODEL_SQUEEZEFORMER)
-    return fail(PPASR_EUNSUPPORTED, "squeezeformer: the non-streaming variant (other time-reduction layer, non-causal conv) is not built");
   if (desc->input_dim > 128 || desc->input_dim < 7) return fail(PPASR_EUNSUPPORTED, "input_dim out of range");
   HIP_TRY(configure_kernels());
   HIP_TRY(configure_squeezeformer_kernels());

@@ -177,13 +177,27 @@ ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe
     }
   }
   if (dsc.reduce_idx >= 0) {
-    GETW(rdw, "encoder.time_reduction_layer.dw_conv.weight", d);
+    // TimeReductionLayerStream: depthwise kernel 1; TimeReductionLayer1D (non-streaming model): kernel 5
+    int tr_k = 1;
+    const float* rdw = get("encoder.time_reduction_layer.dw_conv.weight", d);
+    if (!rdw) {
+      get.missing.clear();
+      rdw = get("encoder.time_reduction_layer.dw_conv.weight", (size_t)d * 5);
+      tr_k = 5;
+    }
+    if (!rdw) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + get.missing);
     GETW(rdb, "encoder.time_reduction_layer.dw_conv.bias", d);
     GETW(rpw, "encoder.time_reduction_layer.pw_conv.weight", d * d);
     GETW(rpb, "encoder.time_reduction_layer.pw_conv.bias", d);
     GETW(rw, "encoder.time_recover_layer.weight", d * d);
     GETW(rb, "encoder.time_recover_layer.bias", d);
-    UP(vec_of(rdw, d), m->sq_reduce.dw_w);
+    {
+      std::vector<float> taps((size_t)tr_k * d);  // [C][1][k] -> tap-major [k][C]
+      for (int c = 0; c < d; ++c)
+        for (int k = 0; k < tr_k; ++k) taps[(size_t)k * d + c] = rdw[(size_t)c * tr_k + k];
+      UP(taps, m->sq_reduce.dw_w);
+      m->sq_reduce.ks = tr_k;
+    }
     UP(vec_of(rdb, d), m->sq_reduce.dw_b);
     UP4(pack_b(d, d, [&](int k, int n) { return rpw[(size_t)n * d + k]; }), m->sq_reduce.pw);
     UP(vec_of(rpb, d), m->sq_reduce.pw_b);
@@ -230,16 +244,19 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
       (void)hipMemcpyAsync(h->taps + tap_off, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
     tap_off += n;
   };
-  // ragged batches (ppasr_set_skip_padding, see ppasr_encode): the conv module is causal here, so the slack only
-  // covers the time-reduction layer (reduced row j reads full-rate row 2j) and the recovery (row t reads reduced row t/2)
+  // ragged batches (ppasr_set_skip_padding, see ppasr_encode): the slack covers the time-reduction layer (reduced row
+  // j reads full-rate rows 2j - 3 .. 2j + 1 at most), the recovery (row t reads reduced row t/2) and, for the
+  // non-streaming model, the right context of the non-causal conv module
   const bool skip = h->skip_padding && lens && !h->taps;
+  const bool causal = h->desc.causal != 0;
+  const int rc = causal ? 0 : (KS - 1) / 2;
   auto pskip = [&](int Tcur, int mul_cur) {
     PadSkip ps;
     if (skip) {
       ps.lens = lens;
       ps.Tp = Tcur;
       ps.mul = mul_cur;
-      ps.slack = mul_cur == 4 ? 16 : 4;
+      ps.slack = mul_cur == 4 ? 2 * (rc + 4) + rc + 8 : rc + 4;
     }
     return ps;
   };
@@ -290,7 +307,7 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
       launch_sq_pw1glu(xc, g, nullptr, W, lens, Mi, Ti, mul, st, ps);
       tap(xc, (size_t)Mi * kD);
       tap(g, (size_t)Mi * kD);
-      launch_conv_pre(g, nullptr, xc, ctx, sq_conv_view(W), lens, Mi, Ti, KS, mul, st, true, ps);
+      launch_conv_pre(g, nullptr, xc, ctx, sq_conv_view(W), lens, Mi, Ti, KS, mul, st, causal, ps);
       launch_ffn_split(ctx, W.ln3_g, W.ln3_b, W.ff2_w1, W.ff2_b1, W.ff2_w2, W.ff2_b2, 1.0f, W.ln4_g, W.ln4_b, y1, other, Mi,
                        n_chunks, S, st, ps, /*residual_is_normed=*/true);
       if (Wn) launch_sq_qkv(other, qkv, Wn->wqkv, Wn->bqkv, Mi, st, ps);
@@ -299,7 +316,7 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
       tap(xc, (size_t)Mi * kD);
       tap(g, (size_t)Mi * kD);
       launch_sq_tail(g, nullptr, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, lens, Mi, Ti, mul,
-                     n_chunks, KS, st, ps);
+                     n_chunks, KS, st, ps, causal);
     }
     std::swap(x, other);
     have_qkv = fuse_next;

@@ -22,7 +22,8 @@ struct SqLayerW {
   const float* pw1_b_raw;
 };
 struct SqReduceW {
-  const float *dw_w, *dw_b;  // [256] depthwise k=1 stride-2 conv
+  const float *dw_w, *dw_b;  // [ks][256] tap-major depthwise stride-2 conv, [256]
+  int ks = 1;                // 1: TimeReductionLayerStream; 5: TimeReductionLayer1D (padding ks - 2 on both sides)
   const f32x4* pw;           // packed 256x256
   const float* pw_b;
 };
@@ -35,7 +36,7 @@ void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, float*
 // g_hist != nullptr: streaming (single stream, rows = frames of one chunk; left context from g_hist [ksize-1][256])
 void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float* x_out, float* qkv_next, const SqLayerW& w,
                     const f32x4* wqkv_next, const float* bqkv_next, const int64_t* lens, int M, int Tp, int mask_mul,
-                    int n_chunks, int ksize, hipStream_t st, const PadSkip& ps = PadSkip{});
+                    int n_chunks, int ksize, hipStream_t st, const PadSkip& ps = PadSkip{}, bool causal = true);
 // split route for under-filled launches (ppasr_set_ffn_split): the pieces of K_B / K_C around their feed-forward modules
 void launch_sq_oproj(const float* ctx, const float* x, float* x1, const SqLayerW& w, int M, hipStream_t st,
                      const PadSkip& ps = PadSkip{});

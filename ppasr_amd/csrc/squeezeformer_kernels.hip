@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kThreads) void k_sq_tail(const float* __restrict__ 
                                                       SqLayerW w, const f32x4* __restrict__ wqkv_next,
                                                       const float* __restrict__ bqkv_next,
                                                       const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
-                                                      int n_chunks, PadSkip ps) {
+                                                      int n_chunks, PadSkip ps, int left_ctx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
   float* bufX = smem;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kThreads) void k_sq_tail(const float* __restrict__ 
     res[r] = x2[(size_t)(r0 + min(row, valid - 1)) * kD + col];
     pad_bits |= (is_pad(row) ? 1u : 0u) << r;
   }
-  dwconv_phase<KS, STREAM>(g, g_hist, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp);
+  dwconv_phase<KS, STREAM>(g, g_hist, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp, left_ctx);
   __syncthreads();
   rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
   __syncthreads();
@@ -301,16 +301,20 @@ __global__ __launch_bounds__(kThreads) void k_sq_reduce(const float* __restrict_
   const f32x4* seg_pw = rw.pw + (size_t)wave * kTs256;
   ring_prime(ring, seg_pw, 0);
   {
-    const f32x4 dw = *reinterpret_cast<const f32x4*>(rw.dw_w + 4 * lane);
     const f32x4 db = *reinterpret_cast<const f32x4*>(rw.dw_b + 4 * lane);
+    const int pad = rw.ks > 2 ? rw.ks - 2 : 0;  // Conv1D(kernel ks, stride 2, padding max(0, ks - stride))
     for (int row = wave; row < kRows; row += kWaves) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row < valid) {
         const int mr = r0 + row, b = mr / Tr, j = mr - b * Tr;
-        const int t = 2 * j;
-        f32x4 xv = *reinterpret_cast<const f32x4*>(x + ((size_t)b * Tp + t) * kD + 4 * lane);
-        if (lens && 4 * (int64_t)t >= lens[b]) xv = f32x4{0.f, 0.f, 0.f, 0.f};  // masked_fill(xs, mask_pad==0, 0)
-        v = xv * dw + db;
+        v = db;
+        for (int k = 0; k < rw.ks; ++k) {
+          const int t = 2 * j - pad + k;
+          if (t < 0 || t >= Tp) continue;                       // the conv's own zero padding
+          if (lens && 4 * (int64_t)t >= lens[b]) continue;      // masked_fill(xs, mask_pad==0, 0)
+          v += *reinterpret_cast<const f32x4*>(x + ((size_t)b * Tp + t) * kD + 4 * lane) *
+               *reinterpret_cast<const f32x4*>(rw.dw_w + (size_t)k * kD + 4 * lane);
+        }
       }
       *reinterpret_cast<f32x4*>(bufA + row * kLda + 4 * lane) = v;
     }
@@ -409,10 +413,11 @@ void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, float*
 }
 void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float* x_out, float* qkv_next, const SqLayerW& w,
                     const f32x4* wqkv_next, const float* bqkv_next, const int64_t* lens, int M, int Tp, int mask_mul,
-                    int n_chunks, int ksize, hipStream_t st, const PadSkip& ps) {
+                    int n_chunks, int ksize, hipStream_t st, const PadSkip& ps, bool causal) {
+  const int left_ctx = causal ? ksize - 1 : (ksize - 1) / 2;
 #define SQ_TAIL(KS, STREAM)                                                                                          \
   hipLaunchKernelGGL((k_sq_tail<KS, STREAM>), rb_grid(M), dim3(kThreads), kLdsSqTail, st, g, g_hist, x2, x_out, qkv_next, w, \
-                     wqkv_next, bqkv_next, lens, M, Tp, mask_mul, n_chunks, ps)
+                     wqkv_next, bqkv_next, lens, M, Tp, mask_mul, n_chunks, ps, left_ctx)
   if (ksize == 31) {
     if (g_hist) SQ_TAIL(31, true); else SQ_TAIL(31, false);
   } else if (ksize == 15) {

@@ -23,8 +23,6 @@ class SqueezeformerModel(ConformerModel):
             raise ValueError("state_dict (Paddle-layout parameter dict) is required")
         if not torch.cuda.is_available():
             raise _lib.PPASRHipError("no HIP device visible: ppasr_amd has no CPU fallback")
-        if not streaming:
-            raise NotImplementedError("only the streaming configuration (causal conv, stream time-reduction) is built")
         self.lib = _lib.load()
         self.device = torch.device(device)
         self.input_dim, self.vocab_size, self.streaming = input_dim, vocab_size, streaming
@@ -56,7 +54,8 @@ class SqueezeformerModel(ConformerModel):
             for j in range(min(a.ndim, 4)):
                 blobs[i].shape[j] = a.shape[j]
         desc = _lib.ModelDesc(_lib.PPASR_MODEL_SQUEEZEFORMER, input_dim, vocab_size, self.output_size,
-                              self.attention_heads, self.linear_units, self.num_blocks, self.cnn_module_kernel, 1,
+                              self.attention_heads, self.linear_units, self.num_blocks, self.cnn_module_kernel,
+                              1 if streaming else 0,  # causal conv + stream time-reduction <=> streaming (model.py:35-39)
                               self.max_len, -1 if self.reduce_idx is None else int(self.reduce_idx),
                               -1 if self.recover_idx is None else int(self.recover_idx), -1, 0, 0)
         handle = ctypes.c_void_p()

@@ -129,8 +129,10 @@ def synth_vocabulary(vocab_size=DEFAULT_VOCAB_SIZE):
 
 def squeezeformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, encoder_dim=256, attention_heads=4,
                              feed_forward_expansion_factor=8, num_blocks=12, cnn_module_kernel=31, seed=1234,
-                             ctc_sharpen=8.0, perturb_norm=False, cmvn_mean=10.0, cmvn_istd=1.0 / 3.3):
-    """Random-init ``SqueezeformerModel`` inference parameters.  The reference's ``init_weights()`` calls have
+                             ctc_sharpen=8.0, perturb_norm=False, cmvn_mean=10.0, cmvn_istd=1.0 / 3.3, streaming=True):
+    """Random-init ``SqueezeformerModel`` inference parameters (``streaming=False``: the time-reduction layer is
+    ``TimeReductionLayer1D`` with a 5-tap depthwise conv instead of the 1-tap ``TimeReductionLayerStream``,
+    squeezeformer/model.py:35-39).  The reference's ``init_weights()`` calls have
     no effect on the values (SURVEY Appendix B.14): every layer keeps the ``utils/base.py`` Kaiming-uniform init;
     attention / conv ``ada_scale``/``ada_bias`` are 1/0, the FFN ones are Xavier-uniform
     (squeezeformer/positionwise.py:39-42).  ``perturb_norm`` randomises every norm / adaptive-scale vector."""
@@ -182,7 +184,8 @@ def squeezeformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, encode
         sd[p + "conv_module.pointwise_conv2.bias"] = _kaiming(rng, (d,), d)
         for n in ("layer_norm1", "layer_norm2", "layer_norm3", "layer_norm4"):
             _layernorm(sd, p + n, d, rng, perturb_norm)
-    sd["encoder.time_reduction_layer.dw_conv.weight"] = _kaiming(rng, (d, 1, 1), 1)
+    tr_k = 1 if streaming else 5
+    sd["encoder.time_reduction_layer.dw_conv.weight"] = _kaiming(rng, (d, 1, tr_k), tr_k)
     sd["encoder.time_reduction_layer.dw_conv.bias"] = _kaiming(rng, (d,), d)
     sd["encoder.time_reduction_layer.pw_conv.weight"] = _kaiming(rng, (d, d, 1), d)
     sd["encoder.time_reduction_layer.pw_conv.bias"] = _kaiming(rng, (d,), d)

@@ -52,12 +52,22 @@ def _efficient_noncausal(V):
     return EfficientConformerModel(80, V, streaming=False, encoder_conf=conf, state_dict=sd, device="cuda:0"), 8
 
 
+def _squeezeformer_noncausal(V):
+    from ppasr_amd.model_utils.squeezeformer.model import SqueezeformerModel
+    L = 4
+    sd = squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=9, perturb_norm=True, streaming=False)
+    conf = dict(encoder_dim=256, output_size=256, attention_heads=4, num_blocks=L, reduce_idx=1, recover_idx=3,
+                feed_forward_expansion_factor=8, cnn_module_kernel=31)
+    return SqueezeformerModel(80, V, streaming=False, encoder_conf=conf, state_dict=sd, device="cuda:0"), 4
+
+
 FAMILIES = {
     "conformer": lambda V: _conformer(V, True),
     "conformer-noncausal": lambda V: _conformer(V, False),
     "squeezeformer": _squeezeformer,
     "efficient": _efficient,
     "efficient-noncausal": _efficient_noncausal,
+    "squeezeformer-noncausal": _squeezeformer_noncausal,
 }
 
 

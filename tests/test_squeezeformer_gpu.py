@@ -60,3 +60,29 @@ def test_squeezeformer_full_config_runs():
     probs, logits = model.get_encoder_out(x, lens, return_logits=True)
     ref_probs, ref_logits = SqueezeformerOracle(sd, num_blocks=L).get_encoder_out(x, lens, return_logits=True)
     assert _rel(logits.cpu().numpy(), ref_logits.numpy()) < TOL
+
+
+@pytest.mark.parametrize("B,T,lens", [(3, 203, [203, 150, 67]), (2, 411, [411, 300]), (1, 131, [131])])
+@pytest.mark.parametrize("route", [-1, 0])
+def test_squeezeformer_non_streaming_matches_oracle(B, T, lens, route):
+    """streaming=False (squeezeformer/model.py:35-39): non-causal conv modules (depthwise padding 15 on both sides) and
+    TimeReductionLayer1D (5-tap depthwise conv, stride 2, padding 3) instead of the 1-tap stream layer."""
+    import numpy as np
+    from oracle.squeezeformer_oracle import SqueezeformerOracle
+    from ppasr_amd.model_utils.squeezeformer.model import SqueezeformerModel
+    from ppasr_amd.utils.synth import squeezeformer_state_dict, synth_features
+    V, L = 131, 4
+    sd = squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=B * 100 + T, perturb_norm=True, streaming=False)
+    conf = dict(encoder_dim=256, output_size=256, attention_heads=4, num_blocks=L, reduce_idx=1, recover_idx=3,
+                feed_forward_expansion_factor=8, cnn_module_kernel=31)
+    model = SqueezeformerModel(80, V, streaming=False, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    model.set_ffn_split(route)
+    oracle = SqueezeformerOracle(sd, num_blocks=L, reduce_idx=1, recover_idx=3, causal=False)
+    x, la = synth_features(B, T, lens=lens, seed=T)
+    _, logits = model.get_encoder_out(x, la, return_logits=True)
+    _, ref = oracle.get_encoder_out(x, la, return_logits=True)
+    torch.cuda.synchronize()
+    a, b = logits.cpu().numpy().astype(np.float64), ref.numpy().astype(np.float64)
+    assert a.shape == b.shape and np.abs(a - b).max() / np.abs(b).max() < 1e-3
+    with pytest.raises(Exception):
+        model.new_stream()  # forward_chunk needs the causal module
