@@ -15,8 +15,9 @@ def _t(sd, name, dtype):
 
 
 class DeepSpeech2Oracle:
-    def __init__(self, sd, num_rnn_layers=5, rnn_size=1024, streaming=True, dtype=torch.float32):
+    def __init__(self, sd, num_rnn_layers=5, rnn_size=1024, streaming=True, dtype=torch.float32, use_gru=False):
         self.p = {k: _t(sd, k, dtype) for k in sd}
+        self.use_gru = use_gru  # nn.GRU instead of nn.LSTM (deepspeech2/encoder.py:36-42)
         self.L, self.H = num_rnn_layers, rnn_size
         self.dirs = 1 if streaming else 2  # rnn_direction 'forward' / 'bidirect' (deepspeech2/model.py:40)
         self.dtype = dtype
@@ -33,6 +34,16 @@ class DeepSpeech2Oracle:
             h, c = h0[bi], c0[bi]
             order = range(n - 1, -1, -1) if reverse else range(n)
             for t in order:
+                if self.use_gru:
+                    # paddle GRUCell: r, z, c rows; c = tanh(x_c + r * (W_hc h + b_hc)); h = (h - c) * z + c
+                    xg = w_ih @ x[bi, t] + self.p[prefix + "bias_ih" + sfx]
+                    hg = w_hh @ h + self.p[prefix + "bias_hh" + sfx]
+                    r = torch.sigmoid(xg[:H] + hg[:H])
+                    z = torch.sigmoid(xg[H:2 * H] + hg[H:2 * H])
+                    cand = torch.tanh(xg[2 * H:] + r * hg[2 * H:])
+                    h = (h - cand) * z + cand
+                    out[bi, t] = h
+                    continue
                 g = w_ih @ x[bi, t] + w_hh @ h + b
                 i, f, gg, o = g[:H], g[H:2 * H], g[2 * H:3 * H], g[3 * H:]
                 c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
@@ -72,4 +83,6 @@ class DeepSpeech2Oracle:
                 x = F.layer_norm(x, (x.shape[-1],), self.p[f"encoder.layernorm_list.{l}.weight"],
                                  self.p[f"encoder.layernorm_list.{l}.bias"], 1e-5)
             logits = x @ self.p["decoder.ctc_lo.weight"] + self.p["decoder.ctc_lo.bias"]
-            return torch.softmax(logits, dim=2), x_lens, torch.stack(hs), torch.stack(cs)
+            # GRU: the c box is handed through unchanged (encoder.py:95-97)
+            c_box = torch.stack(cs) if not self.use_gru else (None if init_c is None else torch.as_tensor(init_c))
+            return torch.softmax(logits, dim=2), x_lens, torch.stack(hs), c_box

@@ -1,0 +1,2 @@
+"""ORACLE (test infrastructure) -- import-only stub of `resampy`: the reference imports it at module load
+(data_utils/audio.py, data_utils/utils.py); nothing on the encoder path calls it."""

@@ -219,11 +219,14 @@ def efficient_conformer_state_dict(stride_layer_idx=3, group_layer_idx=(0, 1, 2,
 
 
 def deepspeech2_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, num_rnn_layers=5, rnn_size=1024, streaming=True,
-                           seed=1234, ctc_sharpen=4.0, perturb_norm=False, cmvn_mean=10.0, cmvn_istd=1.0 / 3.3):
+                           seed=1234, ctc_sharpen=4.0, perturb_norm=False, cmvn_mean=10.0, cmvn_istd=1.0 / 3.3,
+                           use_gru=False):
     """Random-init ``DeepSpeech2Model`` inference parameters (deepspeech2/encoder.py:8-55): plain ``nn.Conv2D``
-    (fan-in uniform), ``nn.LSTM`` (U(+-1/sqrt(H)), Paddle default), ``nn.LayerNorm``, CTC ``nn.Linear``."""
+    (fan-in uniform), ``nn.LSTM`` / ``nn.GRU`` when ``use_gru`` (U(+-1/sqrt(H)), Paddle default; 4H / 3H gate rows),
+    ``nn.LayerNorm``, CTC ``nn.Linear``."""
     rng = np.random.Generator(np.random.PCG64(seed))
     H, D = rnn_size, (1 if streaming else 2)
+    G = 3 if use_gru else 4
     f2 = ((input_dim - 1) // 2 - 1) // 2
     sd = {}
     sd["encoder.global_cmvn.mean"] = np.full(input_dim, cmvn_mean, np.float32)
@@ -237,10 +240,10 @@ def deepspeech2_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, num_rnn_
         for d in range(D):
             sfx = "_l0" if d == 0 else "_l0_reverse"
             p = f"encoder.rnn.{l}."
-            sd[p + "weight_ih" + sfx] = _kaiming(rng, (4 * H, in_dim), H)
-            sd[p + "weight_hh" + sfx] = _kaiming(rng, (4 * H, H), H)
-            sd[p + "bias_ih" + sfx] = _kaiming(rng, (4 * H,), H)
-            sd[p + "bias_hh" + sfx] = _kaiming(rng, (4 * H,), H)
+            sd[p + "weight_ih" + sfx] = _kaiming(rng, (G * H, in_dim), H)
+            sd[p + "weight_hh" + sfx] = _kaiming(rng, (G * H, H), H)
+            sd[p + "bias_ih" + sfx] = _kaiming(rng, (G * H,), H)
+            sd[p + "bias_hh" + sfx] = _kaiming(rng, (G * H,), H)
         _layernorm(sd, f"encoder.layernorm_list.{l}", D * H, rng, perturb_norm)
     sd["decoder.ctc_lo.weight"] = _xavier(rng, (D * H, vocab_size), D * H, vocab_size) * np.float32(ctc_sharpen)
     sd["decoder.ctc_lo.bias"] = np.zeros(vocab_size, np.float32)

@@ -1,0 +1,144 @@
+"""Seeded cases shared by tests/golden/make_ref_goldens.py (which runs the REFERENCE's own model source on them through
+oracle/paddle_shim) and by the tests that compare the oracles (CPU) and the HIP path (GPU) with the stored outputs.
+
+Only outputs are stored in tests/golden/ref_*.npz; weights and features are regenerated from the seeds here."""
+import numpy as np
+
+from ppasr_amd.utils.synth import (conformer_state_dict, deepspeech2_state_dict, efficient_conformer_state_dict,
+                                   squeezeformer_state_dict, synth_features)
+
+WINDOW, STRIDE, CONTEXT = 67, 64, 7  # predict.py:277-283
+
+
+def windows(n_frames, window=WINDOW, stride=STRIDE):
+    """Chunk plan of PPASRPredictor.predict_stream with is_end=True (predict.py:291-298)."""
+    return [(cur, min(cur + window, n_frames)) for cur in range(0, n_frames - CONTEXT + 1, stride)]
+
+
+def _former(family, streaming, L, V, sd_seed, x_spec, chunk_frames=None, required=(), **kw):
+    return dict(family=family, streaming=streaming, L=L, V=V, sd_seed=sd_seed, x_spec=x_spec, chunk_frames=chunk_frames,
+                required=tuple(required), kw=kw)
+
+
+# ---- small cases: every family, both `streaming` variants, ragged batches, chunked streaming -------------------------
+SMALL = {
+    # Conformer (configs/conformer.yml shape, fewer blocks)
+    "conf_s": _former("conformer", True, 3, 61, 501, (3, 163, [163, 101, 37], 502), chunk_frames=64 * 4 + 30,
+                      required=(-16, 32, 0)),
+    "conf_n": _former("conformer", False, 2, 61, 503, (2, 131, [131, 77], 504)),
+    # Efficient-Conformer: grouped attention on layers 0-1, stride layer 1, 7-tap kernels after it
+    "eff_s": _former("efficient_conformer", True, 4, 53, 511, (2, 147, [147, 90], 512), chunk_frames=64 * 3 + 67,
+                     required=(-16, 32), stride_layer_idx=1, group_layer_idx=(0, 1)),
+    "eff_n": _former("efficient_conformer", False, 4, 53, 513, (2, 147, [147, 86], 514), stride_layer_idx=1,
+                     group_layer_idx=(0, 1)),
+    # Squeezeformer: reduce before layer 1, recover before layer 3
+    "sq_s": _former("squeezeformer", True, 4, 59, 521, (2, 131, [131, 77], 522), chunk_frames=64 * 4 + 40,
+                    required=(-16, 32), reduce_idx=1, recover_idx=3),
+    "sq_n": _former("squeezeformer", False, 4, 59, 523, (2, 131, [131, 70], 524), reduce_idx=1, recover_idx=3),
+}
+for _gru in (False, True):
+    for _streaming in (True, False):
+        _k = "ds2" + ("g" if _gru else "") + ("_s" if _streaming else "_b")
+        SMALL[_k] = dict(family="deepspeech2", streaming=_streaming, L=2, V=47, sd_seed=531 + 2 * _gru + _streaming,
+                         x_spec=(3, 99, [99, 64, 31], 535), chunk_frames=(64 * 2 + 40) if _streaming else None,
+                         required=(), kw=dict(use_gru=_gru))
+
+# ---- BASELINE.json configs at full size (outputs stored sub-sampled, see make_ref_goldens.py) ------------------------
+FULL = {
+    # configs[1]: Conformer streaming, 32 x 1000 frames, V = 4233 (bench.py's workload, rank 0 seed)
+    "cfg2": _former("conformer", True, 12, 4233, 1234, (32, 1000, None, 20240 + 200)),
+    # configs[3]: Efficient-Conformer streaming, B = 64, beam 10 / 0.99 / top-40
+    "cfg4": _former("efficient_conformer", True, 12, 4233, 1234, (64, 1000, None, 20240 + 400)),
+    # configs[4]: Squeezeformer streaming, one GPU's share (16) of B = 128, lengths U{200..3000}
+    "cfg5": _former("squeezeformer", True, 12, 4233, 1234, (16, None, "ragged", 20240 + 500)),
+}
+BEAM = dict(beam_size=10, cutoff_prob=0.99, cutoff_top_n=40)
+SAMPLED_COLUMNS = 32
+
+
+def cfg5_lengths(n=16, seed=20240 + 500):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return np.sort(rng.integers(200, 3001, size=n))[::-1].astype(np.int64)
+
+
+def bucket_of(length, width=200):
+    """200-frame length buckets, a bucket is padded to its longest member."""
+    return (int(length) - 1) // width
+
+
+def sampled_columns(V, n=SAMPLED_COLUMNS):
+    return np.unique(np.concatenate([[0, 1, V - 1], np.linspace(2, V - 2, n - 3).astype(np.int64)]))
+
+
+def state_dict(case, perturb=True):
+    fam, L, V, seed, kw = case["family"], case["L"], case["V"], case["sd_seed"], case["kw"]
+    full = L == 12
+    pn = perturb and not full
+    if fam == "conformer":
+        return conformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn)
+    if fam == "efficient_conformer":
+        if full:
+            return efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=seed)
+        return efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn,
+                                              stride_layer_idx=kw["stride_layer_idx"], group_layer_idx=kw["group_layer_idx"])
+    if fam == "squeezeformer":
+        return squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn, streaming=case["streaming"])
+    if fam == "deepspeech2":
+        return deepspeech2_state_dict(vocab_size=V, num_rnn_layers=L, streaming=case["streaming"], seed=seed,
+                                      perturb_norm=pn, use_gru=kw.get("use_gru", False))
+    raise ValueError(fam)
+
+
+def features(case):
+    B, T, lens, seed = case["x_spec"]
+    if lens == "ragged":
+        lens = cfg5_lengths(B, seed)
+        return synth_features(B, int(lens.max()), lens=lens, seed=seed)
+    return synth_features(B, T, lens=lens, seed=seed)
+
+
+def chunk_features(case):
+    x, _ = synth_features(3 if case["family"] == "deepspeech2" else 1, case["chunk_frames"], seed=case["sd_seed"] + 50)
+    return x
+
+
+def reference_encoder_conf(case):
+    """encoder_conf exactly as the reference's constructors take it (flat keyword arguments; note that the nested
+    `efficient_conf:` block of configs/efficient_conformer.yml lands in **kwargs of EfficientConformerEncoder.__init__
+    and is ignored there -- efficient_conformer/encoder.py:26-56 -- the shipped values equal the defaults)."""
+    fam, L, kw = case["family"], case["L"], case["kw"]
+    if fam == "conformer":
+        return dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, dropout_rate=0.1,
+                    positional_dropout_rate=0.1, attention_dropout_rate=0.1, input_layer="conv2d", normalize_before=True,
+                    cnn_module_kernel=15, use_cnn_module=True, activation_type="swish", pos_enc_layer_type="rel_pos")
+    if fam == "efficient_conformer":
+        c = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, activation_type="swish",
+                 cnn_module_kernel=15, cnn_module_norm="layer_norm", dropout_rate=0.1, input_layer="conv2d",
+                 normalize_before=True, pos_enc_layer_type="rel_pos", attention_dropout_rate=0.1,
+                 positional_dropout_rate=0.1)
+        if L != 12:
+            c.update(stride_layer_idx=kw["stride_layer_idx"], stride=2, group_layer_idx=tuple(kw["group_layer_idx"]),
+                     group_size=3, stride_kernel=True)
+        else:
+            c["efficient_conf"] = dict(stride_layer_idx=[3], stride=[2], group_layer_idx=[0, 1, 2, 3], group_size=3,
+                                       stride_kernel=True)
+        return c
+    if fam == "squeezeformer":
+        return dict(encoder_dim=256, output_size=256, attention_heads=4, num_blocks=L,
+                    reduce_idx=kw.get("reduce_idx", 5), recover_idx=kw.get("recover_idx", 11),
+                    feed_forward_expansion_factor=8, input_dropout_rate=0.1, feed_forward_dropout_rate=0.1,
+                    attention_dropout_rate=0.1, adaptive_scale=True, cnn_module_kernel=31, normalize_before=False,
+                    activation_type="swish", pos_enc_layer_type="rel_pos")
+    if fam == "deepspeech2":
+        return dict(num_rnn_layers=L, rnn_size=1024, use_gru=kw.get("use_gru", False))
+    raise ValueError(fam)
+
+
+def product_encoder_conf(case):
+    """The same configuration in the form ppasr_amd's model wrappers take (YAML-shaped)."""
+    c = reference_encoder_conf(case)
+    if case["family"] == "efficient_conformer" and "efficient_conf" not in c:
+        c["efficient_conf"] = dict(stride_layer_idx=[c.pop("stride_layer_idx")], stride=[c.pop("stride")],
+                                   group_layer_idx=list(c.pop("group_layer_idx")), group_size=c.pop("group_size"),
+                                   stride_kernel=c.pop("stride_kernel"))
+    return c

@@ -1,0 +1,112 @@
+"""CPU: the oracles (oracle/*_oracle.py, the builder's restatements) against fixtures produced by the REFERENCE's OWN
+model source (tests/golden/ref_small.npz, written by tests/golden/make_ref_goldens.py which imports
+/root/reference/ppasr/model_utils/*/model.py unmodified on top of oracle/paddle_shim).  This is what pins the oracles:
+both sides are fp32 on torch CPU kernels, so they must agree to accumulation-order round-off (tolerance 2e-5 relative
+to the tensor's largest magnitude; measured values are printed)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ref_cases as rc
+from oracle.conformer_oracle import ConformerOracle
+from oracle.deepspeech2_oracle import DeepSpeech2Oracle
+from oracle.efficient_conformer_oracle import EfficientConformerOracle
+from oracle.squeezeformer_oracle import SqueezeformerOracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ref():
+    with np.load(os.path.join(HERE, "golden", "ref_small.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def make_oracle(case, sd):
+    fam, L, kw = case["family"], case["L"], case["kw"]
+    causal = case["streaming"]
+    if fam == "conformer":
+        return ConformerOracle(sd, num_blocks=L, causal=causal)
+    if fam == "efficient_conformer":
+        return EfficientConformerOracle(sd, num_blocks=L, stride_layer_idx=kw["stride_layer_idx"],
+                                        group_layer_idx=kw["group_layer_idx"], causal=causal)
+    if fam == "squeezeformer":
+        return SqueezeformerOracle(sd, num_blocks=L, reduce_idx=kw["reduce_idx"], recover_idx=kw["recover_idx"], causal=causal)
+    return DeepSpeech2Oracle(sd, num_rnn_layers=L, streaming=case["streaming"], use_gru=kw.get("use_gru", False))
+
+
+FORMERS = [k for k, c in rc.SMALL.items() if c["family"] != "deepspeech2"]
+DS2 = [k for k, c in rc.SMALL.items() if c["family"] == "deepspeech2"]
+
+
+@pytest.mark.parametrize("name", FORMERS)
+def test_former_oracle_matches_reference_source(ref, name):
+    case = rc.SMALL[name]
+    sd = rc.state_dict(case)
+    oracle = make_oracle(case, sd)
+    x, lens = rc.features(case)
+    probs, logits = oracle.get_encoder_out(x, lens, return_logits=True)
+    e_l, e_p = _rel(logits.numpy(), ref[f"{name}/logits"]), _rel(probs.numpy(), ref[f"{name}/probs"])
+    print(f"{name}: logits {e_l:.2e} probs {e_p:.2e}")
+    assert e_l < TOL and e_p < TOL
+    # greedy ids of every frame (padded ones too, like greedy_decoder_batch) are identical
+    assert np.array_equal(probs.numpy().argmax(-1), ref[f"{name}/probs"].argmax(-1))
+
+
+@pytest.mark.parametrize("name,required", [(k, r) for k in FORMERS for r in rc.SMALL[k]["required"]])
+def test_former_oracle_chunks_match_reference_source(ref, name, required):
+    case = rc.SMALL[name]
+    sd = rc.state_dict(case)
+    oracle = make_oracle(case, sd)
+    x = rc.chunk_features(case)
+    att = cnn = None
+    offset, outs = 0, []
+    for (a, b) in rc.windows(x.shape[1]):
+        p, att, cnn = oracle.get_encoder_out_chunk(x[:, a:b], offset, required, att, cnn)
+        outs.append(p.numpy())
+        offset += p.shape[1]
+    k = f"{name}/chunk{required}"
+    assert [o.shape[1] for o in outs] == ref[k + "/n"].tolist()
+    e_p = _rel(np.concatenate(outs, 1), ref[k + "/probs"])
+    e_a = _rel(att.numpy(), ref[k + "/att"]) if ref[k + "/att"].size else 0.0
+    e_c = _rel(cnn.numpy(), ref[k + "/cnn"])
+    print(f"{k}: probs {e_p:.2e} att {e_a:.2e} cnn {e_c:.2e}")
+    assert tuple(att.shape) == ref[k + "/att"].shape and tuple(cnn.shape) == ref[k + "/cnn"].shape
+    assert e_p < TOL and e_a < TOL and e_c < TOL
+
+
+@pytest.mark.parametrize("name", DS2)
+def test_ds2_oracle_matches_reference_source(ref, name):
+    case = rc.SMALL[name]
+    sd = rc.state_dict(case)
+    oracle = make_oracle(case, sd)
+    x, lens = rc.features(case)
+    probs, out_lens, h, c = oracle.forward(x, lens)
+    e = _rel(probs.numpy(), ref[f"{name}/probs"])
+    print(f"{name}: probs {e:.2e}")
+    assert e < TOL
+    if case["chunk_frames"]:
+        xc = rc.chunk_features(case)
+        B = xc.shape[0]
+        h = torch.zeros(case["L"], B, 1024)
+        c = torch.zeros(case["L"], B, 1024)
+        outs = []
+        for (a, b) in rc.windows(xc.shape[1]):
+            p, _, h, c = oracle.forward(xc[:, a:b], np.full(B, b - a, np.int64), h, c)
+            outs.append(p.numpy())
+        assert [o.shape[1] for o in outs] == ref[f"{name}/chunk/n"].tolist()
+        e_p, e_h = _rel(np.concatenate(outs, 1), ref[f"{name}/chunk/probs"]), _rel(h.numpy(), ref[f"{name}/chunk/h"])
+        print(f"{name}/chunk: probs {e_p:.2e} h {e_h:.2e}")
+        assert e_p < TOL and e_h < TOL
+        if not case["kw"].get("use_gru"):
+            assert _rel(c.numpy(), ref[f"{name}/chunk/c"]) < TOL
