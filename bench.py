@@ -8,19 +8,32 @@ features resident in HBM -> token ids + scores on device (+ one all-gather of th
 hypotheses when N > 1).  Utterances are sharded across ranks (weak scaling, no data-path
 collective other than that gather).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     - dominant kernel's algorithmic FLOP/s vs the fp32-MFMA peak, duration measured
-                 live with HIP events on the launch stream (ppasr_profile_* in the C-ABI)
-  cpu_baseline - the torch-CPU oracle + numpy greedy timed on this host's cores (rank 0, N=1)
+    python bench.py                       # N = 1
+    python bench.py --gpus 8              # starts its own 8 ranks (re-executes itself under torch.distributed.run)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 ...             # the driver's form: used as is
+    python bench.py --gpus 2 --dry-run-cpu   # plumbing check without a GPU: gloo, 2 ranks, stub kernels (value is null)
+
+Prints ONE JSON line on rank 0 (contract in the task statement): `value` comes from the wall time of EXACTLY K steps
+bracketed by barrier + synchronize (max over ranks).  Extra fields:
+  median_ms_per_step - median of the K per-step durations measured with HIP events on the launch stream
+  n_ranks_seen       - torch.distributed world size as RCCL saw it (asserted == --gpus), `backend`
+  roofline           - dominant kernel's algorithmic FLOP/s vs the fp32-MFMA peak, duration measured live with HIP events
+                       on the launch stream (ppasr_profile_* in the C-ABI); `traffic` = HBM bytes per launch from the
+                       committed rocprofv3 PMC passes, used only when they were collected for THIS build of the kernels
+  cpu_baseline       - the torch-CPU oracle + numpy greedy timed on this host's cores (rank 0, N=1)
 """
 import argparse
+import hashlib
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -51,59 +64,129 @@ def conformer_flops_per_utt(T, F=80, d=256, ff=2048, L=12, k=15, V=4233):
     return per, tp
 
 
-def main():
+def csrc_digest():
+    """sha256 over the kernel sources: stamps PMC evidence (profiles/hbm_traffic.json) to the build it was taken on.
+    (.git does not travel to the GPU box, so the git head cannot be the stamp.)"""
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "ppasr_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "ppasr_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="no GPU: gloo backend and a stub step; exercises launch, sharding, gather and timing plumbing")
+    return ap.parse_args()
 
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run and
+    pass their output through (rank 0 prints the JSON line)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (got {world})")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    dry = args.dry_run_cpu
+    backend = "gloo" if dry else "nccl"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # the collective library must have seen every rank: a silent single-rank run would report N x the work
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == backend, (dist.get_world_size(), dist.get_backend())
+    n_ranks_seen = dist.get_world_size() if dist else 1
+    device = torch.device("cpu") if dry else torch.device("cuda", local_rank)
+    if not dry:
+        torch.cuda.set_device(device)
 
-    from ppasr_amd.model_utils.conformer.model import ConformerModel
     from ppasr_amd.parallel import gather_hypotheses
     from ppasr_amd.utils.synth import DEFAULT_VOCAB_SIZE, conformer_state_dict, synth_features
 
     V, L = DEFAULT_VOCAB_SIZE, 12
-    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
-    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=1234)
-    model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device=device)
     B, T = args.batch, args.frames
     feats_np, lens_np = synth_features(B, T, seed=20240 + 200 + rank)
-    feats = torch.from_numpy(feats_np).to(device)
-    lens = torch.from_numpy(lens_np).to(device)
+    model = None
+    sd = None
+    if dry:
+        Tp = ((T - 1) // 2 - 1) // 2
+        g = torch.Generator().manual_seed(rank)
+        stub = (torch.randint(1, V, (B, Tp), dtype=torch.int32, generator=g), torch.full((B,), Tp, dtype=torch.int32),
+                torch.rand(B, dtype=torch.float64, generator=g))
+
+        def encode():
+            return stub
+    else:
+        from ppasr_amd.model_utils.conformer.model import ConformerModel
+        conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
+        sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=1234)
+        model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device=device)
+        feats = torch.from_numpy(feats_np).to(device)
+        lens = torch.from_numpy(lens_np).to(device)
+
+        def encode():
+            return model.encode_greedy(feats, lens)
 
     def step():
-        tokens, n_tokens, score = model.encode_greedy(feats, lens)
+        tokens, n_tokens, score = encode()
         if world > 1:
             return gather_hypotheses(tokens, n_tokens, score, dist)
         return tokens, n_tokens, score
 
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
     for _ in range(args.warmup):
-        step()
+        out = step()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
+    # per-step HIP events on the launch stream (torch's current stream IS the stream the C-ABI launches on)
+    events = None if dry else [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    if events:
+        events[0].record()
+    for i in range(args.steps):
         out = step()
-    torch.cuda.synchronize()
+        if events:
+            events[i + 1].record()
+    sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -111,17 +194,27 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the gathered batch really is N x B utterances
+        assert out[0].shape[0] == world * B, out[0].shape
     ms_per_step = elapsed / args.steps * 1e3
     audio_s_per_step = world * B * T * FRAME_SHIFT_S
     value = audio_s_per_step / (elapsed / args.steps)
+    median_ms = None
+    if events:
+        per = np.array([events[i].elapsed_time(events[i + 1]) for i in range(args.steps)])
+        median_ms = float(np.median(per))
+        if world > 1:
+            t = torch.tensor([median_ms], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            median_ms = float(t.item())
 
     # ---- roofline leg: per-kernel durations from HIP events on the launch stream ----
     roofline = None
     kernels = {}
-    if rank == 0:
+    if rank == 0 and not dry:
         per_utt, tp = conformer_flops_per_utt(T, V=V, L=L)
         acc = {}
-        reps = 3
+        reps = 5
         model.profile_kernels(True)
         for _ in range(reps):
             model.encode_greedy(feats, lens)
@@ -140,16 +233,24 @@ def main():
                              "share": round((ms / reps) / total_ms, 3)}
         dom = max(acc, key=lambda k: acc[k][0])
         ach = kernels[dom]["tflops"]
-        # HBM bytes per launch come from separate rocprofv3 --pmc passes (cannot be read live); the committed
-        # figure is keyed by kernel class and dropped (null) when the dominant kernel has no entry.
-        traffic = None
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes (cannot be read live).  The committed file is
+        # stamped with the digest of the kernel sources it was collected on (tools/collect_evidence.sh); a figure taken
+        # on other kernels is not reported.
+        traffic, traffic_note = None, "no PMC evidence for this build: run tools/collect_evidence.sh"
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as f:
-                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+                ev = json.load(f)
+            if ev.get("csrc_sha256") == csrc_digest():
+                traffic = ev.get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_note = ev.get("_source")
+            else:
+                traffic_note = (f"profiles/hbm_traffic.json was collected on kernels {ev.get('csrc_sha256')}, this build is "
+                                f"{csrc_digest()}: re-run tools/collect_evidence.sh")
         except OSError:
             pass
         roofline = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC)",
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 PMC)", "traffic_source": traffic_note,
                     "avg_launch_ms": kernels[dom]["avg_ms"],
                     "whole_path_tflops_per_gpu": round(sum(per_utt[k] * acc[k][1] / reps for k in acc) * B
                                                        / (ms_per_step * 1e-3) / 1e12, 2),
@@ -157,40 +258,50 @@ def main():
 
     # ---- CPU baseline leg (rank 0, N=1 only): the oracle on this host's cores ----
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         from oracle.conformer_oracle import ConformerOracle
         from oracle.ctc_decoders_oracle import greedy_tokens
-        # the reference's own CPU configuration: InferencePredictor(num_threads=10)
-        # (infer_utils/inference_predictor.py:20,68); more threads only oversubscribe these small GEMMs
-        ncores = min(10, os.cpu_count() or 1)
+        ncores = os.cpu_count() or 1
         torch.set_num_threads(ncores)
         oracle = ConformerOracle(sd, num_blocks=L)
-        xb, lb = feats_np[:2], lens_np[:2]
-        oracle.get_encoder_out(xb, lb)  # warm-up
-        done, t_cpu = 0, 0.0
-        while t_cpu < 10.0:  # bounded sample: ~10 s of CPU work, cycling over the batch
-            o = done % B
-            xb, lb = feats_np[o:o + 2], lens_np[o:o + 2]
-            t1 = time.perf_counter()
-            probs = oracle.get_encoder_out(xb, lb).numpy()
-            for p in probs:
-                greedy_tokens(p)
-            t_cpu += time.perf_counter() - t1
-            done += len(xb)
-        cpu = {"value": round(done * T * FRAME_SHIFT_S / t_cpu, 2), "unit": "audio-s/s", "cores": ncores, "kind": "port",
-               "sample": f"{done} utterances of the same workload (batches of 2, cycling over the {B}), torch-CPU fp32 restatement of the Paddle "
-                         f"reference + numpy greedy, {t_cpu:.1f} s of CPU work"}
+
+        def cpu_rate(bs, budget_s):
+            oracle.get_encoder_out(feats_np[:bs], lens_np[:bs])  # warm-up
+            done, t_cpu = 0, 0.0
+            while t_cpu < budget_s:
+                o = done % B
+                xb, lb = feats_np[o:o + bs], lens_np[o:o + bs]
+                t1 = time.perf_counter()
+                probs = oracle.get_encoder_out(xb, lb).numpy()
+                for p in probs:
+                    greedy_tokens(p)
+                t_cpu += time.perf_counter() - t1
+                done += len(xb)
+            return done * T * FRAME_SHIFT_S / t_cpu, done, t_cpu
+
+        # the reference evaluates in batches of 32 (trainer.py:592-645) and predicts single utterances; time the
+        # oracle at the batch shape of the GPU workload and at a small batch, report the faster
+        r32, n32, t32 = cpu_rate(B, 8.0)
+        r2, n2, t2 = cpu_rate(2, 8.0)
+        best, bs, n, tt = (r32, B, n32, t32) if r32 >= r2 else (r2, 2, n2, t2)
+        cpu = {"value": round(best, 2), "unit": "audio-s/s", "cores": ncores, "kind": "port",
+               "sample": f"{n} utterances of the same workload in batches of {bs} ({tt:.1f} s of CPU work; batches of {B}: "
+                         f"{r32:.1f}, batches of 2: {r2:.1f} audio-s/s), torch-CPU fp32 restatement of the Paddle reference "
+                         f"(pinned to the reference's own source, tests/test_ref_pin_cpu.py) + numpy greedy, {ncores} threads"}
 
     if rank == 0:
         line = {
             "metric": "audio-seconds/s (RTF^-1) Conformer-streaming fbank, batch32 per GPU, ctc_greedy",
-            "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "value": None if dry else round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "dry-run: stub kernels, plumbing only" if dry else "synthetic",
             "config": {"workload": "configs[1]: Conformer streaming (configs/conformer.yml), fbank-80, "
                                    f"{B} x {T * FRAME_SHIFT_S:.0f} s utterances per GPU, V=4233, ctc_greedy, "
                                    "features resident in HBM -> token ids + scores on device",
                        "global_batch": world * B, "frames": T, "parallelism": f"utterance-dp{world}"},
+            "median_ms_per_step": None if median_ms is None else round(median_ms, 3),
+            "value_from_median": None if median_ms is None else round(audio_s_per_step / (median_ms * 1e-3), 1),
+            "timed_region_s": round(elapsed, 3), "n_ranks_seen": n_ranks_seen, "backend": backend if world > 1 else None,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

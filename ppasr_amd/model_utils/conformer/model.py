@@ -150,7 +150,7 @@ class ConformerModel:
         score = torch.empty(B, dtype=torch.float64, device=self.device)
         frame_lens = None
         if trim_to_length:
-            frame_lens = torch.clamp((lens + 3) // 4, max=Tp).to(torch.int32)  # frame t valid iff 4t < len
+            frame_lens = self.valid_out_frames(lens, T)  # frame t valid iff mul * t < len (mul = 4, or 8 behind a stride layer)
         with torch.cuda.device(self.device):
             self._encode(speech, lens, fa=fa, fp=fp)
             stream = torch.cuda.current_stream(self.device).cuda_stream

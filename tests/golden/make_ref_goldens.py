@@ -167,7 +167,7 @@ def beam_tokens(lib, p, n_frames):
                                      ctypes.c_double(rc.BEAM["cutoff_prob"]), rc.BEAM["cutoff_top_n"], 0, 1, T,
                                      tokens.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p),
                                      scores.ctypes.data_as(ctypes.c_void_p))
-    assert rc_ == 0
+    assert rc_ >= 1  # number of hypotheses returned
     return tokens[0, :int(lens[0])].copy(), float(scores[0])
 
 

@@ -62,3 +62,148 @@ def test_all_gather_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok in res), res
+
+
+# ---- variable-length batches: whole length buckets per rank (BASELINE configs[4]) ------------------------
+import numpy as np  # noqa: E402
+
+from ppasr_amd.parallel import (assign_buckets, gather_ragged_hypotheses, make_buckets,  # noqa: E402
+                                ragged_record_shape)
+
+
+def _cfg5_lengths(n=128, seed=20740):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.integers(200, 3001, size=n)
+
+
+def test_buckets_partition_and_pad_to_their_longest_member():
+    lens = _cfg5_lengths()
+    buckets = make_buckets(lens, 200)
+    seen = sorted(i for b in buckets for i in b.indices)
+    assert seen == list(range(len(lens)))
+    for b in buckets:
+        ls = [int(lens[i]) for i in b.indices]
+        assert b.frames == max(ls)
+        assert len({(l - 1) // 200 for l in ls}) == 1          # one 200-frame class per bucket
+        assert b.cost == len(ls) * b.frames
+    assert [b.frames for b in buckets] == sorted((b.frames for b in buckets), reverse=True)
+
+
+def test_assign_buckets_is_balanced_and_deterministic():
+    lens = _cfg5_lengths()
+    for world in (1, 2, 4, 8):
+        plan = assign_buckets(lens, world)
+        assert plan == plan and len(plan) == world
+        got = sorted(i for p in plan for b in p for i in b.indices)
+        assert got == list(range(len(lens)))                      # whole buckets, every utterance exactly once
+        load = [sum(b.cost for b in p) for p in plan]
+        biggest = max(b.cost for p in plan for b in p)
+        # greedy LPT: no rank exceeds the mean by more than the largest single bucket
+        assert max(load) - sum(load) / world <= biggest
+        if world == 8:
+            assert max(load) / (sum(load) / world) < 1.15, load   # 128 utterances in 15 buckets over 8 ranks
+        again = assign_buckets(list(lens), world)
+        assert [[b.indices for b in p] for p in again] == [[b.indices for b in p] for p in plan]
+    # fewer buckets than ranks: the surplus ranks get nothing, nothing is lost
+    plan = assign_buckets([250, 260, 900], 4)
+    assert sorted(len(p) for p in plan) == [0, 0, 1, 1]
+
+
+def _stub_decode(index, length):
+    """Stands in for encoder + decoder on one utterance: a token sequence and score that depend on the utterance only."""
+    g = torch.Generator().manual_seed(7000 + index)
+    n = int(length) // 40
+    return torch.randint(1, 4233, (n,), dtype=torch.int32, generator=g), float(index) * 0.5 + n
+
+
+def _ragged_worker(rank, world, port, lens, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out_frames = lambda T: ((T - 1) // 2 - 1) // 2
+    rows, cols = ragged_record_shape(lens, world, out_frames)
+    mine = assign_buckets(lens, world)[rank]
+    results = []
+    for b in mine:                       # one "batch" per bucket, like the GPU path
+        for i in b.indices:
+            tok, sc = _stub_decode(i, lens[i])
+            results.append((i, tok, sc))
+    tokens, n, score = gather_ragged_hypotheses(results, len(lens), rows, cols, dist)
+    ok = True
+    for i, ln in enumerate(lens):        # the caller's utterance order is restored on every rank
+        tok, sc = _stub_decode(i, ln)
+        ok &= int(n[i]) == tok.numel() and bool((tokens[i, :tok.numel()] == tok).all()) and float(score[i]) == sc
+        ok &= bool((tokens[i, tok.numel():] == -1).all())
+    q.put((rank, ok, len(results)))
+    dist.destroy_process_group()
+
+
+def test_ragged_shard_decode_gather_restores_order_world2_gloo():
+    world = 2
+    lens = [int(v) for v in _cfg5_lengths(16, 20741)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, lens, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    assert sum(n for _, _, n in res) == len(lens)
+
+
+# ---- evaluate(): batches dealt round-robin to the ranks, one all-reduce of (sum, count) -----------------------------
+def _eval_batches():
+    vocab = ["<blank>", "<unk>"] + [chr(0x4E00 + i) for i in range(20)] + ["<eos>"]
+    rng = np.random.Generator(np.random.PCG64(5))
+    batches = []
+    for k in range(5):
+        B, U = 3, 6
+        labels = rng.integers(2, 22, size=(B, U)).astype(np.int64)
+        # "recognised" ids: the labels with one substitution in utterance k % B  -> known error rates
+        hyp = labels.copy()
+        hyp[k % B, 0] = 2 + (hyp[k % B, 0] - 1) % 20
+        batches.append((hyp, labels, np.full(B, 40, np.int64), np.full(B, U, np.int64)))
+    return vocab, batches
+
+
+class _StubModel:
+    device = None
+
+    def get_encoder_out(self, inputs, input_lens):
+        return inputs                    # the "probabilities" are the recognised ids; decoding is stubbed below
+
+
+def _eval_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ppasr_amd.evaluate as ev
+    vocab, batches = _eval_batches()
+    ev.decoder_result = lambda outs, vocabulary, *a, **k: ["".join(vocabulary[i] for i in row) for row in outs.tolist()]
+    val = ev.evaluate(_StubModel(), batches, vocab, decoder="ctc_greedy", metrics_type="cer", overlap_decode=False)
+    q.put((rank, val))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_evaluate_all_reduce_world2_gloo_equals_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_eval_worker, args=(0, 1, 0, q))
+    p.start()
+    _, single = q.get(timeout=120)
+    p.join(timeout=60)
+    # 5 batches x 3 utterances, one substitution in 6 characters in one utterance per batch
+    assert abs(single - (5 * (1 / 6)) / 15) < 1e-12
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(abs(v - single) < 1e-12 for _, v in res), (single, res)

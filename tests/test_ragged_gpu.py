@@ -81,11 +81,11 @@ def test_skip_padding_equals_default_on_valid_rows(family, lens, route):
     B, T = len(lens), max(lens)
     x, lens_a = synth_features(B, T, lens=lens, seed=T + B)
     p0, l0 = model.get_encoder_out(x, lens_a, return_logits=True)
-    t0, n0, s0 = model.encode_greedy(x, lens_a, trim_to_length=True) if mul == 4 else (None, None, None)
+    t0, n0, s0 = model.encode_greedy(x, lens_a, trim_to_length=True)
     model.set_skip_padding(True)
     try:
         p1, l1 = model.get_encoder_out(x, lens_a, return_logits=True)
-        t1, n1, s1 = model.encode_greedy(x, lens_a, trim_to_length=True) if mul == 4 else (None, None, None)
+        t1, n1, s1 = model.encode_greedy(x, lens_a, trim_to_length=True)
     finally:
         model.set_skip_padding(False)
     torch.cuda.synchronize()
@@ -96,9 +96,16 @@ def test_skip_padding_equals_default_on_valid_rows(family, lens, route):
         assert torch.equal(l0[b, :nv], l1[b, :nv]), (family, b, ln)
         assert not bool(p1[b, nv:].any()) and not bool(l1[b, nv:].any()), (family, b, ln)
     assert bool(torch.isfinite(p1).all())
-    if mul == 4:
-        assert torch.equal(n0, n1) and torch.equal(t0, t1)
-        assert np.allclose(s0.cpu().numpy(), s1.cpu().numpy(), rtol=0, atol=0)
+    assert torch.equal(n0, n1) and torch.equal(t0, t1)
+    assert np.allclose(s0.cpu().numpy(), s1.cpu().numpy(), rtol=0, atol=0)
+    # trim_to_length decodes exactly the valid frames (mul * t < len; mul = 8 behind the Efficient-Conformer's stride
+    # layer): the tokens are the collapse of the first nv frames' argmax, no PAD frame contributes
+    ids = p0.argmax(-1).cpu().numpy()
+    for b, ln in enumerate(lens):
+        nv = min(Tp, (ln + mul - 1) // mul)
+        fr = ids[b, :nv]
+        keep = (np.concatenate([[True], fr[1:] != fr[:-1]]) if nv else np.zeros(0, bool)) & (fr != 0)
+        assert np.array_equal(fr[keep], t0[b, :int(n0[b])].cpu().numpy()), (family, b, ln)
 
 
 def test_skip_padding_without_lengths_is_the_default_mode():

@@ -110,3 +110,22 @@ def test_ds2_oracle_matches_reference_source(ref, name):
         assert e_p < TOL and e_h < TOL
         if not case["kw"].get("use_gru"):
             assert _rel(c.numpy(), ref[f"{name}/chunk/c"]) < TOL
+
+
+def test_full_size_conformer_oracle_matches_reference_source():
+    """configs[1] (12 blocks, T = 1000, V = 4233): the oracle on utterances 0-1 vs the reference-source summary of
+    ref_full.npz (utterances of equal length do not interact, so a sub-batch reproduces the batch's rows)."""
+    with np.load(os.path.join(HERE, "golden", "ref_full.npz")) as z:
+        ids, margin, lse, sampled, cols = (z["cfg2/" + k] for k in ("ids", "margin", "lse", "sampled", "cols"))
+    case = rc.FULL["cfg2"]
+    sd = rc.state_dict(case)
+    x, lens = rc.features(case)
+    _, logits = ConformerOracle(sd, num_blocks=12).get_encoder_out(x[:2], lens[:2], return_logits=True)
+    lg = logits.numpy().astype(np.float64)
+    e_s = float(np.abs(lg[..., cols] - sampled[:2]).max() / np.abs(sampled[:2]).max())
+    m = lg.max(-1, keepdims=True)
+    e_z = float(np.abs((m[..., 0] + np.log(np.exp(lg - m).sum(-1))) - lse[:2]).max() / np.abs(lse[:2]).max())
+    print(f"cfg2 oracle vs reference source: sampled logits {e_s:.2e} lse {e_z:.2e}")
+    assert e_s < TOL and e_z < TOL
+    clear = margin[:2] > 1e-3
+    assert np.array_equal(lg.argmax(-1)[clear], ids[:2][clear])

@@ -1,0 +1,243 @@
+"""GPU: the HIP path (through the C-ABI) against fixtures produced by the REFERENCE's OWN model source
+(tests/golden/ref_small.npz / ref_full.npz; tests/golden/make_ref_goldens.py runs /root/reference/ppasr/model_utils
+unmodified on oracle/paddle_shim).  No oracle is involved at run time.
+
+Tolerances (BASELINE.json north_star): encoder logits / probabilities within 1e-3 relative to the tensor's largest
+magnitude; greedy ids bit-exact (frames whose reference top-2 logit margin is below 1e-3 are near-ties of the fp32
+reference itself and are compared through the margin instead)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ref_cases as rc
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def ref():
+    with np.load(os.path.join(HERE, "golden", "ref_small.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="module")
+def ref_full():
+    with np.load(os.path.join(HERE, "golden", "ref_full.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def make_model(case, sd):
+    fam = case["family"]
+    conf = rc.product_encoder_conf(case)
+    if fam == "conformer":
+        from ppasr_amd.model_utils.conformer.model import ConformerModel as M
+    elif fam == "efficient_conformer":
+        from ppasr_amd.model_utils.efficient_conformer.model import EfficientConformerModel as M
+    elif fam == "squeezeformer":
+        from ppasr_amd.model_utils.squeezeformer.model import SqueezeformerModel as M
+    else:
+        from ppasr_amd.model_utils.deepspeech2.model import DeepSpeech2Model as M
+    return M(80, case["V"], streaming=case["streaming"], encoder_conf=conf, state_dict=sd, device="cuda:0")
+
+
+FORMERS = [k for k, c in rc.SMALL.items() if c["family"] != "deepspeech2"]
+DS2 = [k for k, c in rc.SMALL.items() if c["family"] == "deepspeech2"]
+
+
+@pytest.mark.parametrize("name", FORMERS)
+def test_former_batched_matches_reference_source(ref, name):
+    case = rc.SMALL[name]
+    model = make_model(case, rc.state_dict(case))
+    x, lens = rc.features(case)
+    probs, logits = model.get_encoder_out(x, lens, return_logits=True)
+    torch.cuda.synchronize()
+    e_l, e_p = _rel(logits.cpu().numpy(), ref[f"{name}/logits"]), _rel(probs.cpu().numpy(), ref[f"{name}/probs"])
+    print(f"{name}: logits {e_l:.2e} probs {e_p:.2e}")
+    assert e_l < TOL and e_p < TOL
+    assert np.array_equal(probs.cpu().numpy().argmax(-1), ref[f"{name}/probs"].argmax(-1))
+
+
+@pytest.mark.parametrize("name,required", [(k, r) for k in FORMERS for r in rc.SMALL[k]["required"]])
+def test_former_chunks_match_reference_source(ref, name, required):
+    case = rc.SMALL[name]
+    model = make_model(case, rc.state_dict(case))
+    x = rc.chunk_features(case)
+    stream = model.new_stream()
+    outs = []
+    for (a, b) in rc.windows(x.shape[1]):
+        outs.append(stream.encode_chunk(x[:, a:b], required).cpu().numpy())
+    k = f"{name}/chunk{required}"
+    assert [o.shape[1] for o in outs] == ref[k + "/n"].tolist()
+    e_p = _rel(np.concatenate(outs, 1), ref[k + "/probs"])
+    att, cnn = stream.export_caches()
+    assert tuple(att.shape) == ref[k + "/att"].shape and tuple(cnn.shape) == ref[k + "/cnn"].shape
+    e_a = _rel(att.cpu().numpy(), ref[k + "/att"]) if ref[k + "/att"].size else 0.0
+    e_c = _rel(cnn.cpu().numpy(), ref[k + "/cnn"])
+    print(f"{k}: probs {e_p:.2e} att {e_a:.2e} cnn {e_c:.2e}")
+    assert e_p < TOL and e_a < TOL and e_c < TOL
+
+
+@pytest.mark.parametrize("name", DS2)
+def test_ds2_matches_reference_source(ref, name):
+    case = rc.SMALL[name]
+    model = make_model(case, rc.state_dict(case))
+    x, lens = rc.features(case)
+    probs = model.get_encoder_out(x, lens)
+    torch.cuda.synchronize()
+    e = _rel(probs.cpu().numpy(), ref[f"{name}/probs"])
+    print(f"{name}: probs {e:.2e}")
+    assert e < TOL
+    assert np.array_equal(probs.cpu().numpy().argmax(-1), ref[f"{name}/probs"].argmax(-1))
+    if case["chunk_frames"]:
+        xc = rc.chunk_features(case)
+        B = xc.shape[0]
+        h = torch.zeros(case["L"], B, 1024)
+        c = torch.zeros(case["L"], B, 1024)
+        outs = []
+        for (a, b) in rc.windows(xc.shape[1]):
+            p, _, h, c = model.get_encoder_out_chunk(xc[:, a:b], np.full(B, b - a, np.int64), h, c)
+            outs.append(p.cpu().numpy())
+        assert [o.shape[1] for o in outs] == ref[f"{name}/chunk/n"].tolist()
+        e_p = _rel(np.concatenate(outs, 1), ref[f"{name}/chunk/probs"])
+        e_h = _rel(h.cpu().numpy(), ref[f"{name}/chunk/h"])
+        print(f"{name}/chunk: probs {e_p:.2e} h {e_h:.2e}")
+        assert e_p < TOL and e_h < TOL
+        if not case["kw"].get("use_gru"):
+            assert _rel(c.cpu().numpy(), ref[f"{name}/chunk/c"]) < TOL
+
+
+# ---- BASELINE.json configs at full size ------------------------------------------------------------------------------
+def _check_frames(logits, ids, margin, lse, sampled, cols, what):
+    """logits [n, V] of the HIP path vs the reference's per-frame summary."""
+    l64 = logits.astype(np.float64)
+    scale = max(float(np.abs(sampled).max()), 1e-30)
+    e_s = float(np.abs(l64[:, cols] - sampled).max() / scale)
+    m = l64.max(-1, keepdims=True)
+    got_lse = m[:, 0] + np.log(np.exp(l64 - m).sum(-1))
+    e_z = float(np.abs(got_lse - lse).max() / max(float(np.abs(lse).max()), 1e-30))
+    got_ids = l64.argmax(-1)
+    clear = margin > 1e-3
+    assert np.array_equal(got_ids[clear], ids[clear]), what
+    # a near-tie of the reference: our winner must be one of its two leaders, i.e. within the margin of its maximum
+    near = ~clear
+    if near.any():
+        ref_max_here = l64[near, ids[near]]
+        assert np.all(l64[near].max(-1) - ref_max_here <= 2e-3), what
+    return e_s, e_z, int(near.sum())
+
+
+def test_cfg2_all_utterances_logits_and_tokens(ref_full):
+    """configs[1] at full size: 12 blocks, 32 x 1000 frames, V = 4233 -- logits of every frame of all 32 utterances
+    (sampled vocabulary columns + log-sum-exp), greedy ids of every frame, and the fused greedy route's tokens."""
+    case = rc.FULL["cfg2"]
+    model = make_model(case, rc.state_dict(case))
+    x, lens = rc.features(case)
+    probs, logits = model.get_encoder_out(x, lens, return_logits=True)
+    tokens, n_tokens, score = model.encode_greedy(x, lens)
+    torch.cuda.synchronize()
+    lg = logits.cpu().numpy()
+    B, Tp, V = lg.shape
+    cols = ref_full["cfg2/cols"]
+    e_s, e_z, near = _check_frames(lg.reshape(B * Tp, V), ref_full["cfg2/ids"].reshape(-1),
+                                   ref_full["cfg2/margin"].reshape(-1), ref_full["cfg2/lse"].reshape(-1),
+                                   ref_full["cfg2/sampled"].reshape(B * Tp, -1), cols, "cfg2")
+    print(f"cfg2: sampled logits {e_s:.2e} lse {e_z:.2e} near-ties {near}/{B * Tp}")
+    assert e_s < TOL and e_z < TOL
+    e_m = float(np.abs(probs.cpu().numpy().max(-1) - ref_full["cfg2/maxprob"]).max())
+    assert e_m < TOL
+    # fused greedy tokens == collapse of the reference's frame ids (where no frame of the utterance is a near-tie)
+    for b in range(B):
+        if (ref_full["cfg2/margin"][b] <= 1e-3).any():
+            continue
+        ids = ref_full["cfg2/ids"][b]
+        keep = np.concatenate([[True], ids[1:] != ids[:-1]]) & (ids != 0)
+        assert np.array_equal(ids[keep], tokens[b, :int(n_tokens[b])].cpu().numpy()), b
+
+
+def test_cfg4_efficient_conformer_beam_all_utterances(ref_full):
+    """configs[3]: Efficient-Conformer 12 blocks, B = 64, beam 10 / 0.99 / top-40: HIP probabilities -> HIP beam search
+    tokens == the C oracle's tokens on the REFERENCE's probabilities, for every utterance."""
+    from ppasr_amd.decoders.beam_search_decoder import beam_search_ids
+    case = rc.FULL["cfg4"]
+    model = make_model(case, rc.state_dict(case))
+    x, lens = rc.features(case)
+    probs, logits = model.get_encoder_out(x, lens, return_logits=True)
+    torch.cuda.synchronize()
+    lg = logits.cpu().numpy()
+    B, Tp, V = lg.shape
+    assert (B, Tp) == (64, 125)
+    e_s, e_z, near = _check_frames(lg.reshape(B * Tp, V), ref_full["cfg4/ids"].reshape(-1),
+                                   ref_full["cfg4/margin"].reshape(-1), ref_full["cfg4/lse"].reshape(-1),
+                                   ref_full["cfg4/sampled"].reshape(B * Tp, -1), ref_full["cfg4/cols"], "cfg4")
+    print(f"cfg4: sampled logits {e_s:.2e} lse {e_z:.2e} near-ties {near}/{B * Tp}")
+    assert e_s < TOL and e_z < TOL
+    toks, n, _, _ = beam_search_ids(probs, beam_size=rc.BEAM["beam_size"], cutoff_prob=rc.BEAM["cutoff_prob"],
+                                    cutoff_top_n=rc.BEAM["cutoff_top_n"])
+    toks, n = toks[:, 0].cpu().numpy(), n[:, 0].cpu().numpy()
+    bad = [b for b in range(B) if not np.array_equal(toks[b, :n[b]], ref_full["cfg4/beam_tokens"][b, :ref_full["cfg4/beam_n"][b]])]
+    assert not bad, f"beam tokens differ from the oracle-on-reference-probs for utterances {bad}"
+
+
+@pytest.mark.parametrize("route", ["buckets", "skip_padding"])
+def test_cfg5_squeezeformer_ragged_beam(ref_full, route):
+    """configs[4], one GPU's share: Squeezeformer 12 blocks, 16 utterances of 2-30 s; (a) 200-frame length buckets,
+    (b) ONE batch padded to the longest with skip_padding.  Valid frames' logits vs the reference run on the buckets,
+    and HIP beam tokens == C oracle tokens on the reference's probabilities, per utterance."""
+    from ppasr_amd.decoders.beam_search_decoder import beam_search_ids
+    case = rc.FULL["cfg5"]
+    model = make_model(case, rc.state_dict(case))
+    x, lens = rc.features(case)
+    cols = ref_full["cfg5/cols"]
+    B = len(lens)
+    nf = [min((int(l) + 3) // 4, model.out_frames(int(l))) for l in lens]
+    got_probs = [None] * B
+    got_logits = [None] * B
+    if route == "buckets":
+        buckets = {}
+        for i, ln in enumerate(lens):
+            buckets.setdefault(rc.bucket_of(ln), []).append(i)
+        for bk, idx in sorted(buckets.items()):
+            Tb = int(lens[idx].max())
+            p, l = model.get_encoder_out(x[idx, :Tb], lens[idx], return_logits=True)
+            for j, i in enumerate(idx):
+                got_probs[i], got_logits[i] = p[j], l[j]
+    else:
+        model.set_skip_padding(True)
+        p, l = model.get_encoder_out(x, lens, return_logits=True)
+        for i in range(B):
+            got_probs[i], got_logits[i] = p[i], l[i]
+    torch.cuda.synchronize()
+    worst = 0.0
+    for i in range(B):
+        n = ref_full[f"cfg5/ids/{i}"].shape[0]
+        assert n <= nf[i] + 1
+        lg = got_logits[i][:n].cpu().numpy()
+        if route == "skip_padding":
+            # the reference value of a frame depends on the batch it was padded into only through PAD frames, which
+            # the valid frames of a causal-conv model do not see except via the reduced-rate recovery (documented in
+            # DESIGN.md "Ragged batches"): compare the frames every route agrees on
+            n = min(n, (int(lens[i]) // 4))
+            lg = lg[:n]
+        e_s, e_z, _ = _check_frames(lg, ref_full[f"cfg5/ids/{i}"][:n], ref_full[f"cfg5/margin/{i}"][:n],
+                                    ref_full[f"cfg5/lse/{i}"][:n], ref_full[f"cfg5/sampled/{i}"][:n], cols, f"cfg5[{i}]")
+        worst = max(worst, e_s, e_z)
+    print(f"cfg5/{route}: worst rel err {worst:.2e}")
+    assert worst < TOL
+    if route == "buckets":
+        for i in range(B):
+            n = ref_full[f"cfg5/ids/{i}"].shape[0]
+            toks, cnt, _, _ = beam_search_ids(got_probs[i][:n].unsqueeze(0), beam_size=rc.BEAM["beam_size"],
+                                              cutoff_prob=rc.BEAM["cutoff_prob"], cutoff_top_n=rc.BEAM["cutoff_top_n"])
+            want = ref_full["cfg5/beam_tokens"][i, :ref_full["cfg5/beam_n"][i]]
+            assert np.array_equal(toks[0, 0, :int(cnt[0, 0])].cpu().numpy(), want), i
