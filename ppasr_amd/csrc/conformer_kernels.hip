@@ -8,6 +8,13 @@
 #include <math.h>
 
 namespace ppasr {
+#ifdef PPASR_PHASE_TS
+}  // namespace ppasr
+extern "C" int ppasr_debug_read_phase_ts(long long* out) {  // instrumented builds only (tools/phase_ts.py)
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_phase_ts), sizeof(long long) * 64);
+}
+namespace ppasr {
+#endif
 
 // =====================================================================================
 // create-time: ptab[pos][n] = sum_k pe[pos][k] * Wpos[k][n]   (attention.py:234, bias-free)
@@ -282,15 +289,19 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
   const int lane = lane_id(), wave = wave_id();
   rb_layernorm(bufX, bufA, kLda, kRows, w.ln_mac_g, w.ln_mac_b, 1e-5f);
   __syncthreads();
+  PPASR_TS(8);
   f32x16 acc2[1][1];
   acc_zero(acc2);
   const f32x4* wq = w.wqkv + (size_t)wave * kTs256;
   ffn_phase(bufA, bufH, w.ffm_w1, w.ffm_b1, w.ffm_w2, n_chunks, wq, ring, acc2);
+  PPASR_TS(9);
   residual_epilogue(bufX, acc2, w.ffm_b2, 0.5f);
   __syncthreads();
+  PPASR_TS(10);
   rb_store_rows(x1 + (size_t)r0 * kD, bufX, kLda, kRows, valid);
   rb_layernorm(bufX, bufA, kLda, kRows, w.ln_mha_g, w.ln_mha_b, 1e-5f);
   __syncthreads();
+  PPASR_TS(11);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     f32x16 acc[1][1];
@@ -304,6 +315,7 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
       int row = acc_row(r, lane);
       if (row < valid) qkv[(size_t)(r0 + row) * 768 + col] = acc[0][0][r] + bv;
     }
+    PPASR_TS(12 + c);
   }
 }
 
@@ -1285,6 +1297,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   const int col = wave * 32 + (lane & 31);
   BRing<1> ring;
   const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
+  PPASR_TS(0);
   ring_prime(ring, seg_pw2, 0);
   // residual rows and pad flags of the pointwise_conv2 epilogue: requested first thing, branch-free (clamped row),
   // so that their global round trips (~2.5 us each under load) overlap the depthwise-conv and LayerNorm phases.
@@ -1300,9 +1313,11 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   }
   dwconv_phase<KS, STREAM>(g, g_hist, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp, left_ctx);
   __syncthreads();
+  PPASR_TS(1);
   // conv-module LayerNorm (nn.LayerNorm(channels), eps 1e-5, convolution.py:71) + swish, in place
   rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
   __syncthreads();
+  PPASR_TS(2);
   {
     f32x16 acc[1][1];
     acc_zero(acc);
@@ -1316,18 +1331,24 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
     }
   }
   __syncthreads();
+  PPASR_TS(3);
   rb_layernorm(bufX, bufA, kLda, kRows, w.ln_ff_g, w.ln_ff_b, 1e-5f);
   __syncthreads();
+  PPASR_TS(4);
   f32x16 acc2[1][1];
   acc_zero(acc2);
   ffn_phase(bufA, bufH, w.ff_w1, w.ff_b1, w.ff_w2, n_chunks, NEXT ? wn.ffm_w1 + (size_t)wave * kTs256 : nullptr, ring,
             acc2);
+  PPASR_TS(5);
   residual_epilogue(bufX, acc2, w.ff_b2, 0.5f);
   __syncthreads();
+  PPASR_TS(6);
   rb_layernorm(bufX, bufX, kLda, kRows, w.ln_fin_g, w.ln_fin_b, 1e-5f);
   // rb_layernorm and rb_store_rows use the same wave->row mapping: no barrier needed
   rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);
+  PPASR_TS(7);
   if (NEXT) ffn_qkv_body(bufX, bufA, bufH, x1_next, qkv_next, wn, r0, valid, n_chunks, ring);
+  PPASR_TS(15);
 }
 constexpr size_t kLdsConvFfn = 4 * kRows * kLda * sizeof(float);
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
@@ -1383,6 +1404,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_pre(const float* __restrict__
   const int col = wave * 32 + (lane & 31);
   BRing<1> ring;
   const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
+  PPASR_TS(0);
   ring_prime(ring, seg_pw2, 0);
   PadRows is_pad{lens, r0, Tp, M, mask_mul};
   float res[16];
@@ -1562,6 +1584,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __res
   constexpr int LO = KS - 1;
   BRing<1> ring;
   const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
+  PPASR_TS(0);
   ring_prime(ring, seg_pw2, 0);
   {
     const f32x4 gp = *reinterpret_cast<const f32x4*>(w.glu_pad + 4 * lane);

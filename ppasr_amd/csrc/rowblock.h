@@ -35,6 +35,18 @@ constexpr int kThreads = 64 * kWaves;
 constexpr int kG256 = kD / 8;  // k-groups of a K=256 contraction
 constexpr int kTs256 = kG256 * 64;  // packed tile stride (f32x4 units) of a K=256 weight
 
+// Optional per-phase time stamps (tools/phase_ts.py builds a second copy of the library with -DPPASR_PHASE_TS):
+// thread 0 of one workgroup in the middle of the grid records the 100 MHz wall clock at phase boundaries.
+#ifdef PPASR_PHASE_TS
+static __device__ long long g_phase_ts[64];  // one copy per translation unit (no -fgpu-rdc)
+#define PPASR_TS(i)                                                                              \
+  do {                                                                                           \
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_phase_ts[i] = (long long)wall_clock64(); \
+  } while (0)
+#else
+#define PPASR_TS(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 

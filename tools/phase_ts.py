@@ -1,0 +1,66 @@
+"""Per-phase wall-clock stamps of the dominant kernel (k_conv_ffn<15,false,true>): builds a second copy of the library
+with -DPPASR_PHASE_TS into tools/_ts/ (git-ignored, travels with gpurun), runs the bench workload through it and prints
+the phase durations of one workgroup in the middle of the grid (100 MHz clock -> 10 ns resolution).
+
+    python tools/phase_ts.py --build        # here (cross-compiles)
+    python tools/phase_ts.py                # on the GPU box"""
+import ctypes
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "tools", "_ts", "libppasr_hip_ts.so")
+NAMES = {0: "start", 1: "dwconv done", 2: "LN_cm+swish", 3: "pw2 + epilogue", 4: "LN_ff", 5: "FFN (16 units)",
+         6: "residual epi", 7: "LN_final + store", 8: "LN_macaron (next)", 9: "FFN_macaron (16 units)", 10: "residual epi",
+         11: "x1 store + LN_mha", 12: "Q unit", 13: "K unit", 14: "V unit", 15: "end"}
+
+if "--build" in sys.argv:
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(ROOT, "ppasr_amd", "csrc", "*.hip")))
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DPPASR_PHASE_TS",
+                           "-o", LIB] + srcs)
+    print("built", LIB)
+    sys.exit(0)
+
+os.environ["PPASR_HIP_LIB"] = LIB
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from ppasr_amd import _lib  # noqa: E402
+from ppasr_amd.model_utils.conformer.model import ConformerModel  # noqa: E402
+from ppasr_amd.utils.synth import DEFAULT_VOCAB_SIZE, conformer_state_dict, synth_features  # noqa: E402
+
+V, L = DEFAULT_VOCAB_SIZE, 12
+conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
+model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=conformer_state_dict(vocab_size=V, num_blocks=L, seed=1234),
+                       device="cuda:0")
+x, lens = synth_features(32, 1000, seed=20440)
+x, lens = torch.from_numpy(x).cuda(), torch.from_numpy(lens).cuda()
+for _ in range(5):
+    model.encode_greedy(x, lens)
+torch.cuda.synchronize()
+lib = _lib.load()
+acc = np.zeros(64)
+reps = 10
+for _ in range(reps):
+    model.encode_greedy(x, lens)
+    torch.cuda.synchronize()
+    ts = (ctypes.c_longlong * 64)()
+    assert lib.ppasr_debug_read_phase_ts(ts) == 0
+    t = np.array(list(ts), np.float64)
+    acc += t - t[0]
+acc /= reps
+us = acc / 100.0  # 100 MHz
+print("k_conv_ffn<15,false,true> (last launch of the step), one workgroup, microseconds:")
+prev = 0.0
+for i in range(16):
+    print(f"  {NAMES[i]:28s} +{us[i] - prev:8.2f}   (t = {us[i]:8.2f})")
+    prev = us[i]
+print("last FFN executed (macaron of the next layer): per hidden chunk, [W1(c+1) gemm + swish side] -> barrier wait -> [W2(c)]")
+for c in range(8):
+    a, b = us[16 + 2 * c], us[17 + 2 * c]
+    nxt = us[16 + 2 * (c + 1)] if c < 7 else us[9]
+    print(f"  chunk {c}: barrier wait {b - a:6.2f}   W2(c)+W1(c+2) {nxt - b:6.2f}")
