@@ -261,33 +261,47 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         from oracle.conformer_oracle import ConformerOracle
         from oracle.ctc_decoders_oracle import greedy_tokens
-        ncores = os.cpu_count() or 1
-        torch.set_num_threads(ncores)
         oracle = ConformerOracle(sd, num_blocks=L)
 
+        def one_pass(bs, o):
+            xb, lb = feats_np[o:o + bs], lens_np[o:o + bs]
+            t1 = time.perf_counter()
+            probs = oracle.get_encoder_out(xb, lb).numpy()
+            for p in probs:
+                greedy_tokens(p)
+            return time.perf_counter() - t1, len(xb)
+
+        # thread count: the reference's own CPU configuration is num_threads=10 (inference_predictor.py:20,68); these
+        # GEMMs (M = 7968) do not scale to a whole 2-socket host and oversubscription is ruinous (256 threads: 2.4
+        # audio-s/s), so a few candidates are tried for one batch each and the fastest is used for the sample
+        avail = os.cpu_count() or 1
+        best_thr, best_t = 1, float("inf")
+        for thr in sorted({min(avail, c) for c in (10, 32, 64)}):
+            torch.set_num_threads(thr)
+            one_pass(2, 0)  # warm-up of the thread pool
+            t, _ = one_pass(B, 0)
+            if t < best_t:
+                best_thr, best_t = thr, t
+        torch.set_num_threads(best_thr)
+
         def cpu_rate(bs, budget_s):
-            oracle.get_encoder_out(feats_np[:bs], lens_np[:bs])  # warm-up
             done, t_cpu = 0, 0.0
             while t_cpu < budget_s:
-                o = done % B
-                xb, lb = feats_np[o:o + bs], lens_np[o:o + bs]
-                t1 = time.perf_counter()
-                probs = oracle.get_encoder_out(xb, lb).numpy()
-                for p in probs:
-                    greedy_tokens(p)
-                t_cpu += time.perf_counter() - t1
-                done += len(xb)
+                t, n = one_pass(bs, done % B)
+                t_cpu += t
+                done += n
             return done * T * FRAME_SHIFT_S / t_cpu, done, t_cpu
 
         # the reference evaluates in batches of 32 (trainer.py:592-645) and predicts single utterances; time the
         # oracle at the batch shape of the GPU workload and at a small batch, report the faster
         r32, n32, t32 = cpu_rate(B, 8.0)
-        r2, n2, t2 = cpu_rate(2, 8.0)
+        r2, n2, t2 = cpu_rate(2, 4.0)
         best, bs, n, tt = (r32, B, n32, t32) if r32 >= r2 else (r2, 2, n2, t2)
-        cpu = {"value": round(best, 2), "unit": "audio-s/s", "cores": ncores, "kind": "port",
+        cpu = {"value": round(best, 2), "unit": "audio-s/s", "cores": best_thr, "kind": "port",
                "sample": f"{n} utterances of the same workload in batches of {bs} ({tt:.1f} s of CPU work; batches of {B}: "
                          f"{r32:.1f}, batches of 2: {r2:.1f} audio-s/s), torch-CPU fp32 restatement of the Paddle reference "
-                         f"(pinned to the reference's own source, tests/test_ref_pin_cpu.py) + numpy greedy, {ncores} threads"}
+                         f"(pinned to the reference's own source, tests/test_ref_pin_cpu.py) + numpy greedy, {best_thr} of "
+                         f"{avail} host threads (fastest of 10/32/64)"}
 
     if rank == 0:
         line = {

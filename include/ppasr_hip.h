@@ -70,7 +70,9 @@ typedef struct {
   int stride_layer_idx;   /* layer with the stride-2 depthwise conv, -1 = none */
   int group_layer_mask;   /* bit i set: layer i uses grouped attention */
   int group_size;
-  int reserved[3];
+  /* DeepSpeech2 (configs/deepspeech2.yml:5, deepspeech2/encoder.py:36-42): nn.GRU layers instead of nn.LSTM */
+  int use_gru;
+  int reserved[2];
 } ppasr_model_desc;
 
 const char* ppasr_last_error(void);
@@ -145,11 +147,25 @@ ppasr_status ppasr_ctc_beam_search(const float* probs, const int32_t* frame_lens
 
 /* External scorer = `Scorer(alpha, beta, model_path, vocabulary)` of paddlespeech_ctcdecoders (decoders/swig_wrapper.py:18-33,
  * built by BeamSearchDecoder.__init__, decoders/beam_search_decoder.py:19-29): back-off n-gram model, CHARACTER-based
- * (every LM word is one UTF-8 character, as PPASR's Mandarin models are); read from the ARPA text format (KenLM .klm
- * binaries are refused with PPASR_EUNSUPPORTED, as are word-based models, which need the OpenFST dictionary).
+ * (every LM word is one UTF-8 character, as PPASR's Mandarin models are); word-based models, which need the OpenFST
+ * dictionary, are refused with PPASR_EUNSUPPORTED.  Model files: the ARPA text format (csrc/lm.hip) and KenLM binaries
+ * (.klm, what PPASR ships: decoders/beam_search_decoder.py:19-29) of the "probing" / "rest probing" and plain "trie"
+ * types (csrc/klm.hip; quantised / Bhiksha-array tries: PPASR_EUNSUPPORTED).  ppasr_lm_create sniffs the format from
+ * the file's magic, like KenLM's loader.
  * vocab_utf8[V]: the acoustic vocabulary (token id -> string), used to map token ids to LM words (unknown -> OOV). */
 typedef struct ppasr_lm_s* ppasr_lm_handle;
+ppasr_status ppasr_lm_create(const char* model_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
 ppasr_status ppasr_lm_create_arpa(const char* arpa_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
+ppasr_status ppasr_lm_create_klm(const char* klm_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
+const char*  ppasr_lm_format(ppasr_lm_handle lm);              /* "arpa", "klm-probing", "klm-rest-probing", "klm-trie" */
+int          ppasr_lm_word_index(ppasr_lm_handle lm, int token); /* LM word index of an acoustic token, 0 = OOV */
+int          ppasr_lm_bos(ppasr_lm_handle lm);
+int          ppasr_lm_eos(ppasr_lm_handle lm);
+/* Verification hooks of the model-file readers (no device is touched; the decoder never calls them):
+ * ppasr_lm_debug_load_host parses a model into the host-side table only, ppasr_lm_debug_host_score evaluates
+ * Scorer::get_log_cond_prob for a window of `order` LM word indices (oldest first) on that table. */
+ppasr_status ppasr_lm_debug_load_host(const char* model_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
+double       ppasr_lm_debug_host_score(ppasr_lm_handle lm, const int32_t* window);
 ppasr_status ppasr_lm_destroy(ppasr_lm_handle lm);
 int          ppasr_lm_order(ppasr_lm_handle lm);
 int          ppasr_lm_is_character_based(ppasr_lm_handle lm);

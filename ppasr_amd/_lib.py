@@ -15,6 +15,9 @@ c_i64p = ctypes.POINTER(ctypes.c_int64)
 c_f32p = ctypes.POINTER(ctypes.c_float)
 c_f64p = ctypes.POINTER(ctypes.c_double)
 
+# ppasr_status (include/ppasr_hip.h)
+PPASR_OK, PPASR_EINVAL, PPASR_EHIP, PPASR_EUNSUPPORTED, PPASR_EMISSING, PPASR_ENOSPACE = range(6)
+
 PPASR_MODEL_CONFORMER = 0
 PPASR_MODEL_EFFICIENT_CONFORMER = 1
 PPASR_MODEL_SQUEEZEFORMER = 2
@@ -33,7 +36,7 @@ class ModelDesc(ctypes.Structure):
                 ("num_blocks", ctypes.c_int), ("cnn_module_kernel", ctypes.c_int), ("causal", ctypes.c_int),
                 ("max_len", ctypes.c_int), ("reduce_idx", ctypes.c_int), ("recover_idx", ctypes.c_int),
                 ("stride_layer_idx", ctypes.c_int), ("group_layer_mask", ctypes.c_int), ("group_size", ctypes.c_int),
-                ("reserved", ctypes.c_int * 3)]
+                ("use_gru", ctypes.c_int), ("reserved", ctypes.c_int * 2)]
 
 
 # every symbol include/ppasr_hip.h declares: (name, restype, argtypes)
@@ -78,6 +81,17 @@ SYMBOLS = [
                                           _vp]),
     ("ppasr_lm_create_arpa", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int,
                                             ctypes.POINTER(_vp)]),
+    ("ppasr_lm_create", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int,
+                                       ctypes.POINTER(_vp)]),
+    ("ppasr_lm_create_klm", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int,
+                                           ctypes.POINTER(_vp)]),
+    ("ppasr_lm_debug_load_host", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int,
+                                                ctypes.POINTER(_vp)]),
+    ("ppasr_lm_debug_host_score", ctypes.c_double, [_vp, _vp]),
+    ("ppasr_lm_format", ctypes.c_char_p, [_vp]),
+    ("ppasr_lm_word_index", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("ppasr_lm_bos", ctypes.c_int, [_vp]),
+    ("ppasr_lm_eos", ctypes.c_int, [_vp]),
     ("ppasr_lm_destroy", ctypes.c_int, [_vp]),
     ("ppasr_lm_order", ctypes.c_int, [_vp]),
     ("ppasr_lm_is_character_based", ctypes.c_int, [_vp]),

@@ -40,7 +40,8 @@ ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd) {
   Getter get{sd, ""};
   ppasr_status st;
   Ds2W& W = m->ds2;
-  W.H = H; W.dirs = dirs; W.n_layers = L; W.V = V;
+  const int G = dsc.use_gru ? 3 : 4;  // gate rows per hidden unit: nn.GRU (r, z, c) / nn.LSTM (i, f, g, o)
+  W.H = H; W.dirs = dirs; W.n_layers = L; W.V = V; W.gates = G;
   W.Vpad = (V + 255) / 256 * 256;
   W.ldx = (C * F2 + 255) / 256 * 256;  // conv feature width padded to the GEMM's K granularity
   {
@@ -78,29 +79,35 @@ ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd) {
     const float* bhh[2] = {nullptr, nullptr};
     for (int d = 0; d < dirs; ++d) {
       const std::string sfx = d == 0 ? "_l0" : "_l0_reverse";
-      wih[d] = get(p + "weight_ih" + sfx, (size_t)4 * H * in_dim);
-      whh[d] = get(p + "weight_hh" + sfx, (size_t)4 * H * H);
-      bih[d] = get(p + "bias_ih" + sfx, 4 * H);
-      bhh[d] = get(p + "bias_hh" + sfx, 4 * H);
+      wih[d] = get(p + "weight_ih" + sfx, (size_t)G * H * in_dim);
+      whh[d] = get(p + "weight_hh" + sfx, (size_t)G * H * H);
+      bih[d] = get(p + "bias_ih" + sfx, G * H);
+      bhh[d] = get(p + "bias_hh" + sfx, G * H);
       if (!wih[d] || !whh[d] || !bih[d] || !bhh[d]) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + get.missing);
     }
     // one GEMM per layer: columns [d*4H, (d+1)*4H) = direction d's gate pre-activations; W[k][n] = weight_ih[n][k]
-    const int N = dirs * 4 * H;
+    const int N = dirs * G * H;
     UP4(pack_b(in_pad, N, [&](int k, int n) {
           if (k >= in_dim) return 0.f;
-          const int d = n / (4 * H), r = n % (4 * H);
+          const int d = n / (G * H), r = n % (G * H);
           return wih[d][(size_t)r * in_dim + k];
         }), Lw.w_ih);
-    std::vector<float> bsum(N), hh((size_t)dirs * 4 * H * H);
+    std::vector<float> bsum(N), hh((size_t)dirs * G * H * H);
     for (int d = 0; d < dirs; ++d) {
-      for (int r = 0; r < 4 * H; ++r) bsum[d * 4 * H + r] = bih[d][r] + bhh[d][r];
-      std::memcpy(&hh[(size_t)d * 4 * H * H], whh[d], (size_t)4 * H * H * sizeof(float));
+      // LSTM: both biases enter the gate pre-activation; GRU: b_hh stays with the recurrent product (k_gru_step)
+      for (int r = 0; r < G * H; ++r) bsum[d * G * H + r] = bih[d][r] + (G == 4 ? bhh[d][r] : 0.f);
+      std::memcpy(&hh[(size_t)d * G * H * H], whh[d], (size_t)G * H * H * sizeof(float));
     }
     UP(bsum, Lw.b_sum);
     UP(hh, Lw.w_hh);
+    if (G == 3) {
+      std::vector<float> bh((size_t)dirs * G * H);
+      for (int d = 0; d < dirs; ++d) std::memcpy(&bh[(size_t)d * G * H], bhh[d], (size_t)G * H * sizeof(float));
+      UP(bh, Lw.b_hh);
+    }
     // fragment-ordered copy for the batched step kernel: per direction, packed column 32 t + 8 gate + u = row
     // gate * H + 8 t + u of weight_hh (every gate of units 8t .. 8t+7 in one 32-column tile)
-    {
+    if (G == 4) {
       std::vector<float> pk;
       pk.reserve((size_t)dirs * 4 * H * H);
       for (int d = 0; d < dirs; ++d) {
@@ -113,7 +120,7 @@ ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd) {
       }
       UP4(pk, Lw.w_hh_pk);
     }
-    if (dirs == 1) {
+    if (dirs == 1 && G == 4) {
       wave[l] = Ds2WaveLayer{Lw.w_hh_pk, nullptr, nullptr, nullptr};
       if (l > 0) {
         // W' = W_ih diag(gamma_{l-1}) in the gate-interleaved fragment order; s_n = its column sums;
@@ -143,7 +150,7 @@ ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd) {
     prev_g = vec_of(lg, dirs * H);
     prev_b = vec_of(lb, dirs * H);
   }
-  if (dirs == 1 && H % 64 == 0) {
+  if (dirs == 1 && H % 64 == 0 && G == 4) {
     void* d = nullptr;
     if (hipMalloc(&d, L * sizeof(Ds2WaveLayer)) != hipSuccess) return fail(PPASR_EHIP, "hipMalloc failed");
     m->allocs.push_back(d);
@@ -172,7 +179,7 @@ static Ds2Ws ds2_ws(const ppasr_model_s* m, int B, int T) {
   size_t o = 0;
   w.y1 = o; o += al64((size_t)B * T1 * m->F1 * 32);
   w.x = o; o += al64(M * W.ldx);
-  w.gx = o; o += al64(M * W.dirs * 4 * W.H);
+  w.gx = o; o += al64(M * W.dirs * W.gates * W.H);
   w.ya = o; o += al64(M * W.dirs * W.H);
   w.yb = o; o += al64(M * W.dirs * W.H);
   w.h0 = o; o += al64((size_t)W.dirs * B * W.H);
@@ -206,7 +213,7 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(workspace);
   const int F = h->desc.input_dim, T1 = (T - 1) / 2, F1 = h->F1, Tp = (T1 - 1) / 2, F2 = h->F2;
-  const int M = B * Tp, H = W.H, dirs = W.dirs;
+  const int M = B * Tp, H = W.H, dirs = W.dirs, G = W.gates;
   float *y1 = ws + wl.y1, *x = ws + wl.x, *gx = ws + wl.gx, *ya = ws + wl.ya, *yb = ws + wl.yb;
   float *h0 = ws + wl.h0, *h1 = ws + wl.h1, *c = ws + wl.c;
   int32_t* lens32 = reinterpret_cast<int32_t*>(ws + wl.lens32);
@@ -253,20 +260,22 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
     // gate pre-activations of all frames and both directions: [M][dirs*4H]; the step kernel wants [dirs][M][4H]
     // -> run one GEMM per direction into its own slab
     for (int d = 0; d < dirs; ++d)
-      launch_dense(in, in_ld, Lw.w_ih + (size_t)d * (4 * H / 32) * (Lw.in_dim_padded / 8) * 64, Lw.b_sum + d * 4 * H,
-                   gx + (size_t)d * M * 4 * H, M, Lw.in_dim_padded, 4 * H, 4 * H, 4 * H, st);
+      launch_dense(in, in_ld, Lw.w_ih + (size_t)d * (G * H / 32) * (Lw.in_dim_padded / 8) * 64, Lw.b_sum + d * G * H,
+                   gx + (size_t)d * M * G * H, M, Lw.in_dim_padded, G * H, G * H, G * H, st);
     // initial states
     if (init_h) HIP_TRY(hipMemcpyAsync(h0, init_h + (size_t)l * dirs * B * H, sbytes, hipMemcpyDeviceToDevice, st));
     else HIP_TRY(hipMemsetAsync(h0, 0, sbytes, st));
+    // GRU: there is no cell state; the c box is handed through unchanged (deepspeech2/encoder.py:95-97)
     if (init_c) HIP_TRY(hipMemcpyAsync(c, init_c + (size_t)l * dirs * B * H, sbytes, hipMemcpyDeviceToDevice, st));
     else HIP_TRY(hipMemsetAsync(c, 0, sbytes, st));
     HIP_TRY(hipMemsetAsync(out, 0, (size_t)M * dirs * H * sizeof(float), st));
     float* hp = h0;
     float* hn = h1;
     // the matrix-core step needs H % 64 == 0 (8 waves x whole 8-wide k-groups); the VALU kernel handles the rest
-    const bool mfma_step = (H % 64 == 0) && B >= 2;  // (one utterance: the VALU kernel's 5.8 us per step is the faster one)
+    const bool mfma_step = (H % 64 == 0) && B >= 2 && G == 4;  // (one utterance: the VALU kernel's 5.8 us per step is the faster one)
     for (int s = 0; s < Tp; ++s) {
-      if (mfma_step) launch_lstm_step_mfma(gx, Lw.w_hh_pk, hp, hn, c, out, lens32, B, Tp, H, dirs, s, st);
+      if (G == 3) launch_gru_step(gx, Lw.w_hh, Lw.b_hh, hp, hn, out, lens32, B, Tp, H, dirs, s, st);
+      else if (mfma_step) launch_lstm_step_mfma(gx, Lw.w_hh_pk, hp, hn, c, out, lens32, B, Tp, H, dirs, s, st);
       else launch_lstm_step(gx, Lw.w_hh, hp, hn, c, out, lens32, B, Tp, H, dirs, s, st);
       std::swap(hp, hn);
     }

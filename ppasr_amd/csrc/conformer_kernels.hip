@@ -13,6 +13,9 @@ namespace ppasr {
 extern "C" int ppasr_debug_read_phase_ts(long long* out) {  // instrumented builds only (tools/phase_ts.py)
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_phase_ts), sizeof(long long) * 64);
 }
+extern "C" int ppasr_debug_read_wg_ts(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_wg_ts), sizeof(long long) * 2 * 1024);
+}
 namespace ppasr {
 #endif
 
@@ -1298,6 +1301,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   BRing<1> ring;
   const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
   PPASR_TS(0);
+  if (NEXT) PPASR_WG_TS(0);
   ring_prime(ring, seg_pw2, 0);
   // residual rows and pad flags of the pointwise_conv2 epilogue: requested first thing, branch-free (clamped row),
   // so that their global round trips (~2.5 us each under load) overlap the depthwise-conv and LayerNorm phases.
@@ -1349,6 +1353,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   PPASR_TS(7);
   if (NEXT) ffn_qkv_body(bufX, bufA, bufH, x1_next, qkv_next, wn, r0, valid, n_chunks, ring);
   PPASR_TS(15);
+  if (NEXT) PPASR_WG_TS(1);
 }
 constexpr size_t kLdsConvFfn = 4 * kRows * kLda * sizeof(float);
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
@@ -1404,7 +1409,6 @@ __global__ __launch_bounds__(kThreads) void k_conv_pre(const float* __restrict__
   const int col = wave * 32 + (lane & 31);
   BRing<1> ring;
   const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
-  PPASR_TS(0);
   ring_prime(ring, seg_pw2, 0);
   PadRows is_pad{lens, r0, Tp, M, mask_mul};
   float res[16];
@@ -1584,7 +1588,6 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __res
   constexpr int LO = KS - 1;
   BRing<1> ring;
   const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
-  PPASR_TS(0);
   ring_prime(ring, seg_pw2, 0);
   {
     const f32x4 gp = *reinterpret_cast<const f32x4*>(w.glu_pad + 4 * lane);

@@ -16,6 +16,7 @@ struct Ds2LayerW {
   const f32x4* w_hh_pk;
   const float *ln_g, *ln_b;  // [dirs*H]
   int in_dim_padded;
+  const float* b_hh = nullptr;  // GRU only: [dirs][3H] (the candidate gate needs W_hc h + b_hc on its own); b_sum = b_ih then
 };
 // unidirectional stack as a wavefront over (layer, time) -- see k_lstm_wave: per-layer device pointers
 struct Ds2WaveLayer {
@@ -29,6 +30,7 @@ struct Ds2W {
   const f32x4* ctc_w;  // packed [dirs*H][Vpad]
   const float* ctc_b;  // [Vpad]
   int H, dirs, n_layers, V, Vpad, ldx;
+  int gates = 4;  // 4 = LSTM (i, f, g, o), 3 = GRU (r, z, c)
   const Ds2WaveLayer* wave_tab = nullptr;  // device [n_layers]; nullptr: no wavefront path (bidirectional models)
 };
 
@@ -39,6 +41,10 @@ void launch_ds2_conv2(const float* y1, const float* w, const float* bias, float*
 void launch_ds2_lens(const int64_t* lens, int32_t* out32, int64_t* out64, int B, int Tp, hipStream_t st);
 void launch_lstm_step(const float* gx, const float* whh, const float* hprev, float* hnext, float* c, float* y,
                       const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st);
+// One GRU time step (paddle.nn.GRU, gate rows r, z, c):  r = s(x_r + h_r), z = s(x_z + h_z), c = tanh(x_c + r * h_c),
+// h' = (h - c) * z + c, with x_* = W_ih x + b_ih (gx [dirs][B*T][3H]) and h_* = W_hh h + b_hh.
+void launch_gru_step(const float* gx, const float* whh, const float* bhh, const float* hprev, float* hnext, float* y,
+                     const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st);
 // One LSTM time step for up to 32 utterances per workgroup row tile on the matrix cores (grid H/8 x dirs x ceil(B/32)):
 // gates = h_prev W_hh^T as a [32 x H] x [H x 32] MFMA tile per workgroup, the contraction split over its 8 waves.
 void launch_lstm_step_mfma(const float* gx, const f32x4* whh_pk, const float* hprev, float* hnext, float* c, float* y,

@@ -141,6 +141,67 @@ __global__ __launch_bounds__(256) void k_lstm_step(const float* __restrict__ gx,
   }
 }
 
+// One GRU time step for all utterances, both directions (blockIdx.y): the use_gru variant of the stack
+// (deepspeech2/encoder.py:36-42; paddle.nn.GRUCell: rows r, z, c of the 3H weights,
+//   r = sigmoid(x_r + h_r), z = sigmoid(x_z + h_z), c = tanh(x_c + r * h_c), h' = (h - c) * z + c
+// with x = W_ih x_t + b_ih (gx) and h_* = W_hh h + b_hh -- the candidate needs its recurrent part separately, so b_hh is
+// not folded into gx).  Same sharding as k_lstm_step: a workgroup owns 4 hidden units = 12 rows of W_hh.
+__global__ __launch_bounds__(256) void k_gru_step(const float* __restrict__ gx, const float* __restrict__ whh,
+                                                  const float* __restrict__ bhh, const float* __restrict__ hprev,
+                                                  float* __restrict__ hnext, float* __restrict__ y,
+                                                  const int32_t* __restrict__ lens, int B, int T, int H, int dirs, int step) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* hs = smem;          // [H]
+  float* hg = smem + H;      // [12] recurrent parts, [12..24) input parts
+  const int dir = blockIdx.y, j0 = blockIdx.x * 4, tid = threadIdx.x;
+  const int r = tid >> 4, part = tid & 15;  // r = gate*4 + unit ; 16 threads per row; rows 12..15 idle
+  const int gate = r >> 2, unit = r & 3;
+  const int per = H / 16;
+  const bool live_row = r < 12;
+  const float* wrow = whh + ((size_t)dir * 3 * H + (size_t)(live_row ? gate : 0) * H + j0 + unit) * H + part * per;
+  const float* hp = hprev + (size_t)dir * B * H;
+  float* hn = hnext + (size_t)dir * B * H;
+  const float* gxd = gx + (size_t)dir * B * T * 3 * H;
+  const float* bh = bhh + (size_t)dir * 3 * H;
+  for (int b = 0; b < B; ++b) {
+    const int len = lens[b];
+    if (step >= len) {
+      if (tid < 4) hn[(size_t)b * H + j0 + tid] = hp[(size_t)b * H + j0 + tid];
+      continue;
+    }
+    const int t = dir == 0 ? step : len - 1 - step;
+    for (int k = tid * 4; k < H; k += 1024) *reinterpret_cast<f32x4*>(hs + k) = *reinterpret_cast<const f32x4*>(hp + (size_t)b * H + k);
+    __syncthreads();
+    float acc = 0.f;
+    if (live_row) {
+      for (int k = 0; k < per; k += 4) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + k);
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(hs + part * per + k);
+        acc = fmaf(wv[0], hv[0], acc);
+        acc = fmaf(wv[1], hv[1], acc);
+        acc = fmaf(wv[2], hv[2], acc);
+        acc = fmaf(wv[3], hv[3], acc);
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (part == 0 && live_row) {
+      hg[r] = acc + bh[(size_t)gate * H + j0 + unit];
+      hg[12 + r] = gxd[((size_t)b * T + t) * 3 * H + (size_t)gate * H + j0 + unit];
+    }
+    __syncthreads();
+    if (tid < 4) {
+      const float gr = 1.0f / (1.0f + expf(-(hg[12 + 0 + tid] + hg[0 + tid])));
+      const float gz = 1.0f / (1.0f + expf(-(hg[12 + 4 + tid] + hg[4 + tid])));
+      const float cand = tanhf(hg[12 + 8 + tid] + gr * hg[8 + tid]);
+      const float hv = (hs[j0 + tid] - cand) * gz + cand;
+      hn[(size_t)b * H + j0 + tid] = hv;
+      y[((size_t)b * T + t) * (size_t)(dirs * H) + (size_t)dir * H + j0 + tid] = hv;
+    }
+    __syncthreads();
+  }
+}
+
 // The same step on the matrix cores, for batches: k_lstm_step walks the utterances one by one (B x the time); here a
 // workgroup owns 8 hidden units (their 4 gates = one 32-column MFMA tile, weights re-packed accordingly) for up to 32
 // utterances (the 32 rows of the tile), its 8 waves split the K = H contraction (a 32x32 tile with K = 1024 on one
@@ -433,6 +494,11 @@ void launch_ds2_lens(const int64_t* lens, int32_t* out32, int64_t* out64, int B,
 void launch_lstm_step(const float* gx, const float* whh, const float* hprev, float* hnext, float* c, float* y,
                       const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st) {
   hipLaunchKernelGGL(k_lstm_step, dim3(H / 4, dirs), dim3(256), (H + 16) * sizeof(float), st, gx, whh, hprev, hnext, c, y,
+                     lens, B, T, H, dirs, step);
+}
+void launch_gru_step(const float* gx, const float* whh, const float* bhh, const float* hprev, float* hnext, float* y,
+                     const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st) {
+  hipLaunchKernelGGL(k_gru_step, dim3(H / 4, dirs), dim3(256), (H + 32) * sizeof(float), st, gx, whh, bhh, hprev, hnext, y,
                      lens, B, T, H, dirs, step);
 }
 void launch_lstm_step_mfma(const float* gx, const f32x4* whh_pk, const float* hprev, float* hnext, float* c, float* y,

@@ -23,6 +23,8 @@ struct LmDev {
   const float* prob;         // log10 P
   const float* backoff;      // log10 back-off weight (0 when absent)
   const int32_t* tok2lm;     // [V] acoustic-vocabulary id -> LM word index, 0 = OOV (<unk>)
+  int kenlm_keys;            // 1: n-grams are keyed by KenLM's own word-hash chain (tables taken over from a "probing"
+                             //    .klm binary, whose entries carry only that hash); 0: by lm_key over the word ids
 };
 
 __host__ __device__ inline uint64_t lm_mix(uint64_t h, uint64_t v) {
@@ -38,8 +40,26 @@ __host__ __device__ inline uint64_t lm_key(const int32_t* w, int n) {
   return h | 1ull;
 }
 
+// KenLM's n-gram hash (lm/search_hashed.hh detail::CombineWordHash): starts from the LAST word's index and folds the
+// preceding words in one by one, newest first -- the key under which a probing-model entry for w[0..n-1] is stored.
+__host__ __device__ inline uint64_t kenlm_combine(uint64_t current, uint32_t next) {
+  return (current * 8978948897894561157ULL) ^ ((uint64_t)(1 + next) * 17894857484156487943ULL);
+}
+__host__ __device__ inline uint64_t kenlm_chain(const int32_t* w, int n) {
+  uint64_t h = (uint64_t)(uint32_t)w[n - 1];
+  for (int i = n - 2; i >= 0; --i) h = kenlm_combine(h, (uint32_t)w[i]);
+  return h;
+}
+// slot key of a KenLM-keyed entry of order n (the order is mixed in: KenLM keeps one table per order, we keep one)
+__host__ __device__ inline uint64_t lm_key_from_kenlm(uint64_t chain, int n) {
+  return lm_mix(0x2545f4914f6cdd1dull ^ (uint64_t)n, chain) | 1ull;
+}
+__host__ __device__ inline uint64_t lm_key_any(int kenlm_keys, const int32_t* w, int n) {
+  return kenlm_keys ? lm_key_from_kenlm(kenlm_chain(w, n), n) : lm_key(w, n);
+}
+
 __device__ inline bool lm_find(const LmDev& lm, const int32_t* w, int n, float& prob, float& backoff) {
-  const uint64_t key = lm_key(w, n);
+  const uint64_t key = lm_key_any(lm.kenlm_keys, w, n);
   uint32_t slot = (uint32_t)(key >> 17) & lm.mask;
   for (;;) {
     const uint64_t k = lm.keys[slot];

@@ -3,7 +3,7 @@
 // decoders/swig_wrapper.py:18-33, decoders/beam_search_decoder.py:28-29) for CHARACTER-BASED models, i.e. models whose
 // words are all single UTF-8 characters (scorer.cpp `load_lm`: is_character_based_), which is what PPASR's Mandarin
 // models are.  Word-based models need the OpenFST dictionary constraint of the trie and are refused.
-// The model file is read in the ARPA text format; KenLM's binary formats (.klm) are not parsed.
+// This file reads the ARPA text format; KenLM's binary formats (.klm) are read by klm.hip.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -14,20 +14,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "capi_internal.h"
-#include "lm.h"
-
-struct ppasr_lm_s {
-  LmDev dev{};
-  int order = 0;
-  int n_words = 0;
-  bool character_based = true;
-  size_t n_grams = 0;
-  std::vector<void*> allocs;
-  ~ppasr_lm_s() {
-    for (void* p : allocs) (void)hipFree(p);
-  }
-};
+#include "lm_host.h"
 
 namespace {
 
@@ -42,11 +29,7 @@ struct Gram {
   float prob, backoff;
 };
 
-}  // namespace
-
-extern "C" {
-
-ppasr_status ppasr_lm_create_arpa(const char* arpa_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out) {
+ppasr_status arpa_load(const char* arpa_path, const char* const* vocab_utf8, int V, bool host_only, ppasr_lm_handle* out) {
   if (!arpa_path || !vocab_utf8 || V <= 0 || !out) return fail(PPASR_EINVAL, "lm: null argument");
   std::ifstream in(arpa_path, std::ios::binary);
   if (!in) return fail(PPASR_EINVAL, std::string("lm: cannot open ") + arpa_path);
@@ -54,7 +37,7 @@ ppasr_status ppasr_lm_create_arpa(const char* arpa_path, const char* const* voca
     char magic[8] = {0};
     in.read(magic, 8);
     if (std::memcmp(magic, "mmap lm ", 8) == 0)
-      return fail(PPASR_EUNSUPPORTED, "lm: KenLM binary (.klm) files are not parsed; provide the ARPA text model");
+      return fail(PPASR_EINVAL, "lm: this is a KenLM binary, not an ARPA file (use ppasr_lm_create / ppasr_lm_create_klm)");
     in.clear();
     in.seekg(0);
   }
@@ -111,65 +94,172 @@ ppasr_status ppasr_lm_create_arpa(const char* arpa_path, const char* const* voca
   }
   if (grams.empty()) return fail(PPASR_EINVAL, "lm: no n-grams found (not an ARPA file?)");
   auto lm = std::make_unique<ppasr_lm_s>();
+  lm->format = "arpa";
   for (const Gram& g : grams) lm->order = std::max(lm->order, (int)g.w.size());
-  lm->n_words = (int)words.size();
-  lm->n_grams = grams.size();
-  if (!words.count("<s>") || !words.count("</s>")) return fail(PPASR_EINVAL, "lm: the model has no <s> / </s>");
-  for (const auto& kv : words)
-    if (kv.first != "<unk>" && kv.first != "<s>" && kv.first != "</s>" && utf8_len(kv.first) > 1) lm->character_based = false;
-  if (!lm->character_based)
-    return fail(PPASR_EUNSUPPORTED, "lm: word-based language model (needs the dictionary-constrained trie); only "
-                                    "character-based models are built");
-  // ---- hash table ----
-  size_t cap = 16;
-  while (cap < 2 * grams.size()) cap <<= 1;
-  std::vector<uint64_t> keys(cap, 0);
-  std::vector<float> prob(cap, 0.f), backoff(cap, 0.f);
-  for (const Gram& g : grams) {
-    const uint64_t key = lm_key(g.w.data(), (int)g.w.size());
-    size_t slot = (size_t)(key >> 17) & (cap - 1);
-    while (keys[slot] != 0) {
-      if (keys[slot] == key) return fail(PPASR_EINVAL, "lm: duplicate n-gram (or a 64-bit hash collision) in the model");
-      slot = (slot + 1) & (cap - 1);
-    }
-    keys[slot] = key;
-    prob[slot] = g.prob;
-    backoff[slot] = g.backoff;
+  std::string err = lm_bind_vocabulary(*lm, words, vocab_utf8, V);
+  if (!err.empty()) return fail(err.rfind("lm: word-based", 0) == 0 ? PPASR_EUNSUPPORTED : PPASR_EINVAL, err);
+  std::vector<LmEntry> entries;
+  entries.reserve(grams.size());
+  for (const Gram& g : grams) entries.push_back(LmEntry{lm_key(g.w.data(), (int)g.w.size()), g.prob, g.backoff});
+  err = lm_build_table(*lm, entries);
+  if (!err.empty()) return fail(PPASR_EINVAL, err);
+  if (host_only) {
+    *out = lm.release();
+    return PPASR_OK;
   }
-  std::vector<int32_t> tok2lm(V, 0);
+  ppasr_status s = lm_upload(*lm);
+  if (s != PPASR_OK) return s;
+  *out = lm.release();
+  return PPASR_OK;
+}
+
+}  // namespace
+
+namespace ppasr {
+
+std::string lm_bind_vocabulary(ppasr_lm_s& lm, const std::unordered_map<std::string, int32_t>& words,
+                               const char* const* vocab_utf8, int V) {
+  lm.n_words = (int)words.size();
+  auto bos = words.find("<s>"), eos = words.find("</s>");
+  if (bos == words.end() || eos == words.end()) return "lm: the model has no <s> / </s>";
+  lm.bos = bos->second;
+  lm.eos = eos->second;
+  lm.character_based = true;
+  for (const auto& kv : words)
+    if (kv.first != "<unk>" && kv.first != "<s>" && kv.first != "</s>" && utf8_len(kv.first) > 1) lm.character_based = false;
+  if (!lm.character_based)
+    return "lm: word-based language model (needs the dictionary-constrained trie); only character-based models are built";
+  lm.tok2lm.assign(V, 0);
   for (int v = 0; v < V; ++v) {
     if (!vocab_utf8[v]) continue;
     const std::string s(vocab_utf8[v]);
     // a literal space is SPACE_ID_: Scorer::make_ngram stops on it with an empty word, i.e. OOV (scorer.cpp)
     if (s == " ") continue;
     auto it = words.find(s);
-    if (it != words.end()) tok2lm[v] = it->second;
+    if (it != words.end()) lm.tok2lm[v] = it->second;
   }
+  return "";
+}
+
+std::string lm_build_table(ppasr_lm_s& lm, const std::vector<LmEntry>& entries) {
+  size_t cap = 16;
+  while (cap < 2 * entries.size()) cap <<= 1;
+  lm.keys.assign(cap, 0);
+  lm.prob.assign(cap, 0.f);
+  lm.backoff.assign(cap, 0.f);
+  for (const LmEntry& e : entries) {
+    size_t slot = (size_t)(e.key >> 17) & (cap - 1);
+    while (lm.keys[slot] != 0) {
+      if (lm.keys[slot] == e.key) return "lm: duplicate n-gram (or a 64-bit hash collision) in the model";
+      slot = (slot + 1) & (cap - 1);
+    }
+    lm.keys[slot] = e.key;
+    lm.prob[slot] = e.prob;
+    lm.backoff[slot] = e.backoff;
+  }
+  lm.n_grams = entries.size();
+  return "";
+}
+
+ppasr_status lm_upload(ppasr_lm_s& lm) {
   auto up = [&](const void* src, size_t bytes, const void** dst) -> ppasr_status {
     void* d = nullptr;
     HIP_TRY(hipMalloc(&d, bytes));
-    lm->allocs.push_back(d);
+    lm.allocs.push_back(d);
     HIP_TRY(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
     *dst = d;
     return PPASR_OK;
   };
   const void* p = nullptr;
   ppasr_status s;
-  if ((s = up(keys.data(), keys.size() * 8, &p)) != PPASR_OK) return s;
-  lm->dev.keys = static_cast<const uint64_t*>(p);
-  if ((s = up(prob.data(), prob.size() * 4, &p)) != PPASR_OK) return s;
-  lm->dev.prob = static_cast<const float*>(p);
-  if ((s = up(backoff.data(), backoff.size() * 4, &p)) != PPASR_OK) return s;
-  lm->dev.backoff = static_cast<const float*>(p);
-  if ((s = up(tok2lm.data(), tok2lm.size() * 4, &p)) != PPASR_OK) return s;
-  lm->dev.tok2lm = static_cast<const int32_t*>(p);
-  lm->dev.order = lm->order;
-  lm->dev.bos = words["<s>"];
-  lm->dev.eos = words["</s>"];
-  lm->dev.mask = (uint32_t)(cap - 1);
-  *out = lm.release();
+  if ((s = up(lm.keys.data(), lm.keys.size() * 8, &p)) != PPASR_OK) return s;
+  lm.dev.keys = static_cast<const uint64_t*>(p);
+  if ((s = up(lm.prob.data(), lm.prob.size() * 4, &p)) != PPASR_OK) return s;
+  lm.dev.prob = static_cast<const float*>(p);
+  if ((s = up(lm.backoff.data(), lm.backoff.size() * 4, &p)) != PPASR_OK) return s;
+  lm.dev.backoff = static_cast<const float*>(p);
+  if ((s = up(lm.tok2lm.data(), lm.tok2lm.size() * 4, &p)) != PPASR_OK) return s;
+  lm.dev.tok2lm = static_cast<const int32_t*>(p);
+  lm.dev.order = lm.order;
+  lm.dev.bos = lm.bos;
+  lm.dev.eos = lm.eos;
+  lm.dev.mask = (uint32_t)(lm.keys.size() - 1);
+  lm.dev.kenlm_keys = lm.kenlm_keys ? 1 : 0;
   return PPASR_OK;
 }
+
+}  // namespace ppasr
+
+// klm.hip
+ppasr_status klm_load(const char* path, const char* const* vocab_utf8, int V, bool host_only, ppasr_lm_handle* out);
+
+static bool is_klm(const char* path) {
+  std::ifstream in(path, std::ios::binary);
+  char magic[8] = {0};
+  in.read(magic, 8);
+  return in.gcount() == 8 && std::memcmp(magic, "mmap lm ", 8) == 0;
+}
+
+extern "C" {
+
+ppasr_status ppasr_lm_create_arpa(const char* arpa_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out) {
+  return arpa_load(arpa_path, vocab_utf8, V, false, out);
+}
+
+ppasr_status ppasr_lm_create_klm(const char* klm_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out) {
+  return klm_load(klm_path, vocab_utf8, V, false, out);
+}
+
+// Scorer(alpha, beta, model_path, vocabulary) accepts both formats like KenLM does (lm::ngram::LoadVirtual sniffs the magic)
+ppasr_status ppasr_lm_create(const char* model_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out) {
+  if (!model_path) return fail(PPASR_EINVAL, "lm: null argument");
+  return is_klm(model_path) ? klm_load(model_path, vocab_utf8, V, false, out) : arpa_load(model_path, vocab_utf8, V, false, out);
+}
+
+// Verification hook for the model-file readers (tests/test_klm_cpu.py): parses the file into the host table only (no
+// device is touched) so that `ppasr_lm_debug_host_score` can be compared between formats.  The decoder never uses it.
+ppasr_status ppasr_lm_debug_load_host(const char* model_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out) {
+  if (!model_path) return fail(PPASR_EINVAL, "lm: null argument");
+  return is_klm(model_path) ? klm_load(model_path, vocab_utf8, V, true, out) : arpa_load(model_path, vocab_utf8, V, true, out);
+}
+
+// Scorer::get_log_cond_prob of an `order`-word window of LM word indices (oldest first), evaluated on the HOST copy of
+// the table with the arithmetic of lm_log_cond_prob (lm.h).
+double ppasr_lm_debug_host_score(ppasr_lm_handle lm, const int32_t* win) {
+  if (!lm || !win) return 0.0;
+  const int order = lm->order;
+  const uint32_t mask = (uint32_t)(lm->keys.size() - 1);
+  auto find = [&](const int32_t* w, int n, float& p, float& b) {
+    const uint64_t key = lm_key_any(lm->kenlm_keys ? 1 : 0, w, n);
+    uint32_t slot = (uint32_t)(key >> 17) & mask;
+    for (;;) {
+      const uint64_t k = lm->keys[slot];
+      if (k == key) {
+        p = lm->prob[slot];
+        b = lm->backoff[slot];
+        return true;
+      }
+      if (k == 0) return false;
+      slot = (slot + 1) & mask;
+    }
+  };
+  for (int i = 0; i < order; ++i)
+    if (win[i] == 0) return kLmOovScore;
+  float acc = 0.f;
+  for (int n = order; n >= 1; --n) {
+    float p, b;
+    if (find(win + order - n, n, p, b)) return (double)(acc + p) / (double)kLmLog10E;
+    if (n > 1 && find(win + order - n, n - 1, p, b)) acc += b;
+  }
+  return kLmOovScore;
+}
+
+int ppasr_lm_word_index(ppasr_lm_handle lm, int token) {
+  return (lm && token >= 0 && token < (int)lm->tok2lm.size()) ? lm->tok2lm[token] : -1;
+}
+int ppasr_lm_bos(ppasr_lm_handle lm) { return lm ? lm->bos : -1; }
+int ppasr_lm_eos(ppasr_lm_handle lm) { return lm ? lm->eos : -1; }
+const char* ppasr_lm_format(ppasr_lm_handle lm) { return lm ? lm->format.c_str() : ""; }
 
 ppasr_status ppasr_lm_destroy(ppasr_lm_handle lm) {
   delete lm;

@@ -3,8 +3,9 @@
 beam search (``ppasr_ctc_beam_search`` in include/ppasr_hip.h).
 
 External scorer: the reference always builds a KenLM ``Scorer`` (beam_search_decoder.py:28-29).  Here
-``language_model_path`` may point to an ARPA text model of a CHARACTER-based n-gram LM (``Scorer`` below, backed by
-``ppasr_lm_*`` / ``ppasr_ctc_beam_search_lm``); KenLM binaries (.klm) and word-based models raise.  Without a model
+``language_model_path`` may point to a CHARACTER-based n-gram LM as an ARPA text file or as a KenLM binary (``.klm``:
+probing / rest-probing / plain trie; ``Scorer`` below, backed by ``ppasr_lm_*`` / ``ppasr_ctc_beam_search_lm``);
+word-based models and quantised / array-compressed tries raise.  Without a model
 path the search runs without a scorer (alpha / beta unused).  Returned scores follow the upstream convention:
 -log P(prefix), with the LM weight removed when a scorer is used ("approx_ctc").
 """
@@ -36,7 +37,7 @@ class Scorer:
         words = (ctypes.c_char_p * len(vocabulary))(*[str(w).encode("utf-8") for w in vocabulary])
         h = ctypes.c_void_p()
         with torch.cuda.device(self._device):
-            _lib.check(self._lib.ppasr_lm_create_arpa(str(model_path).encode(), words, len(vocabulary), ctypes.byref(h)))
+            _lib.check(self._lib.ppasr_lm_create(str(model_path).encode(), words, len(vocabulary), ctypes.byref(h)))
         self._h = h
 
     def __del__(self):

@@ -23,8 +23,7 @@ class DeepSpeech2Model:
         conf = dict(encoder_conf or {})
         self.num_rnn_layers = int(conf.get("num_rnn_layers", 5))
         self.rnn_size = int(conf.get("rnn_size", 1024))
-        if conf.get("use_gru", False):
-            raise NotImplementedError("use_gru=True is not built (configs/deepspeech2.yml:5 uses LSTM)")
+        self.use_gru = bool(conf.get("use_gru", False))  # nn.GRU layers (deepspeech2/encoder.py:36-42)
         self.dirs = 1 if streaming else 2
         sd = dict(state_dict)
         keep = []
@@ -38,7 +37,8 @@ class DeepSpeech2Model:
             for j in range(min(a.ndim, 4)):
                 blobs[i].shape[j] = a.shape[j]
         desc = _lib.ModelDesc(_lib.PPASR_MODEL_DEEPSPEECH2, input_dim, vocab_size, self.rnn_size, 0, 0,
-                              self.num_rnn_layers, 0, 1 if streaming else 0, 0, -1, -1, -1, 0, 0)
+                              self.num_rnn_layers, 0, 1 if streaming else 0, 0, -1, -1, -1, 0, 0,
+                              1 if self.use_gru else 0)
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ppasr_create(ctypes.byref(desc), blobs, len(sd), ctypes.byref(handle)))

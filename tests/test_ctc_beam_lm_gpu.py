@@ -154,3 +154,26 @@ def test_seeded_fuzz_against_oracle(tmp_path):
         got = tk[0, 0, :int(ln[0, 0])].cpu().numpy().tolist()
         assert got == ref[0][0], (seed, T, V, beam, use_lm)
         assert abs(float(sc[0, 0]) - ref[0][1]) <= 2e-4 * max(1.0, abs(ref[0][1])), (seed, float(sc[0, 0]), ref[0][1])
+
+
+@pytest.mark.parametrize("model_type,order", [("probing", 3), ("trie", 4), ("rest_probing", 2)])
+def test_scorer_from_klm_binary_equals_scorer_from_arpa(tmp_path, model_type, order):
+    """`Scorer(alpha, beta, 'lm.klm', vocab)` -- the file type PPASR ships (decoders/beam_search_decoder.py:19-29): the
+    KenLM binary (written by tests/klm_writer.py from the same ARPA model) gives the SAME hypotheses and scores as the
+    ARPA model, i.e. the device-side KenLM key chain (probing) / trie walk (trie) address the same n-grams."""
+    from klm_writer import write_klm
+    from ppasr_amd.decoders.beam_search_decoder import Scorer, beam_search_ids
+    T, V, beam, alpha, beta = 70, 300, 20, 2.2, 4.3
+    vocab = _vocab(V)
+    rng = np.random.Generator(np.random.PCG64(77 + order))
+    known = [c for c in vocab[2:-1] if rng.random() < 0.8]
+    arpa = write_synthetic_arpa(str(tmp_path / "lm.arpa"), known, order=order, n_sent=400, seed=order)
+    klm = write_klm(arpa, str(tmp_path / "zh.klm"), model_type=model_type)
+    sa, sk = Scorer(alpha, beta, arpa, vocab), Scorer(alpha, beta, klm, vocab)
+    assert sk.get_max_order() == order and sk.is_character_based() and sk.ngram_count() == sa.ngram_count()
+    batch = torch.from_numpy(np.stack([_probs(rng, T, V, k) for k in ("peaky", "flat", "peaky")])).cuda()
+    ta, la, ca, _ = beam_search_ids(batch, beam, 0.99, 40, 0, nbest=4, ext_scorer=sa)
+    tk, lk, ck, _ = beam_search_ids(batch, beam, 0.99, 40, 0, nbest=4, ext_scorer=sk)
+    torch.cuda.synchronize()
+    assert torch.equal(la, lk) and torch.equal(ta, tk) and torch.equal(ca, ck)
+    assert int(la[:, 0].min()) > 0

@@ -64,3 +64,18 @@ for c in range(8):
     a, b = us[16 + 2 * c], us[17 + 2 * c]
     nxt = us[16 + 2 * (c + 1)] if c < 7 else us[9]
     print(f"  chunk {c}: barrier wait {b - a:6.2f}   W2(c)+W1(c+2) {nxt - b:6.2f}")
+
+# per-workgroup start / end of the last k_conv_ffn<..,NEXT> launch: start skew, duration spread, per-XCD means
+wg = (ctypes.c_longlong * 2048)()
+assert lib.ppasr_debug_read_wg_ts(wg) == 0
+w = np.array(list(wg), np.float64).reshape(1024, 2)[:249] / 100.0
+t0 = w[:, 0].min()
+start, end = w[:, 0] - t0, w[:, 1] - t0
+dur = end - start
+print(f"249 workgroups of the last NEXT launch: start skew max {start.max():.2f} us, duration min/median/max "
+      f"{dur.min():.1f}/{np.median(dur):.1f}/{dur.max():.1f} us, last end {end.max():.1f} us")
+for xcd in range(8):
+    sel = np.arange(249) % 8 == xcd
+    print(f"  XCD {xcd}: n={sel.sum():2d} start {start[sel].mean():6.2f}  duration mean {dur[sel].mean():7.1f} max {dur[sel].max():7.1f}")
+order = np.argsort(-dur)[:8]
+print("  slowest workgroups:", [(int(i), round(float(dur[i]), 1)) for i in order])
