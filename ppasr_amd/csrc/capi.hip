@@ -498,8 +498,9 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       // fuse the next layer's S1 into this launch (it writes xb / qkv, which this layer no longer reads)
       const LayerW* next = (i + 1 < h->desc.num_blocks) ? &h->layers[i + 1] : nullptr;
       timed(next ? 8 : 6, [&] {
-        launch_conv_ffn(g, nullptr, xc, xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul, next, xb, qkv, st,
-                        h->desc.causal != 0, ps);
+        // with the next layer's S1 fused in, the layer output itself is only read by the debug taps: skip its store
+        launch_conv_ffn(g, nullptr, xc, (next && !h->taps) ? nullptr : xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul,
+                        next, xb, qkv, st, h->desc.causal != 0, ps);
       });
       s1_done = next != nullptr;
     }

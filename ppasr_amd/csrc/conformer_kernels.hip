@@ -284,6 +284,21 @@ void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, fl
 // S1: x1 = x + 0.5*FFN_macaron(LN(x)) ; qkv = LN_mha(x1) * [Wq|Wk|Wv] + b
 // (encoder.py:380-391, attention.py:75-77)
 // -------------------------------------------------------------------------------------
+// Epilogue slice of the previous Q / K / V tile inside the next unit's MFMA stream: qkv[row][col] = acc + bias
+struct QkvStoreSide {
+  const f32x16& acc;
+  float* out;  // qkv + r0 * 768 + column of this lane
+  float bias;
+  int lane, valid;
+  __device__ __forceinline__ void operator()(int g) const {
+    if ((g & 1) == 0) {
+      const int r = g >> 1;
+      const int row = acc_row(r, lane);
+      if (row < valid) out[(size_t)row * 768] = acc[r] + bias;
+    }
+  }
+};
+
 // Body of S1 on LDS-resident rows (bufX = layer input): FFN_macaron, residual, LN_mha, QKV.
 // `ring` must already stream w.ffm_w1 (tile `wave`).
 __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bufH, float* __restrict__ x1,
@@ -305,20 +320,32 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
   rb_layernorm(bufX, bufA, kLda, kRows, w.ln_mha_g, w.ln_mha_b, 1e-5f);
   __syncthreads();
   PPASR_TS(11);
+  // Q, K, V units: the global stores of unit c's tile (16 per lane) are sliced into the MFMA stream of unit c + 1
+  // (QkvStoreSide, one store every second k-group) instead of running between the units with the matrix pipe idle
+  // (0.4 - 1.5 us per unit, per-phase stamps); only V's tile is stored after its GEMM.
+  f32x16 tile[3][1][1];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    f32x16 acc[1][1];
-    acc_zero(acc);
+    acc_zero(tile[c]);
     const f32x4* seg = w.wqkv + (size_t)(c * 8 + wave) * kTs256;
-    rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, c < 2 ? seg + 8 * kTs256 : nullptr, 0, ring, acc);
-    const int col = c * 256 + wave * 32 + (lane & 31);
+    const f32x4* nseg = c < 2 ? seg + 8 * kTs256 : nullptr;
+    if (c == 0) {
+      rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, nseg, 0, ring, tile[c]);
+    } else {
+      const int pcol = (c - 1) * 256 + wave * 32 + (lane & 31);
+      rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, nseg, 0, ring, tile[c],
+                           QkvStoreSide{tile[c - 1][0][0], qkv + (size_t)r0 * 768 + pcol, w.bqkv[pcol], lane, valid});
+    }
+    PPASR_TS(12 + c);
+  }
+  {
+    const int col = 2 * 256 + wave * 32 + (lane & 31);
     const float bv = w.bqkv[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int row = acc_row(r, lane);
-      if (row < valid) qkv[(size_t)(r0 + row) * 768 + col] = acc[0][0][r] + bv;
+      if (row < valid) qkv[(size_t)(r0 + row) * 768 + col] = tile[2][0][0][r] + bv;
     }
-    PPASR_TS(12 + c);
   }
 }
 
@@ -1303,23 +1330,46 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   PPASR_TS(0);
   if (NEXT) PPASR_WG_TS(0);
   ring_prime(ring, seg_pw2, 0);
-  // residual rows and pad flags of the pointwise_conv2 epilogue: requested first thing, branch-free (clamped row),
-  // so that their global round trips (~2.5 us each under load) overlap the depthwise-conv and LayerNorm phases.
+  if (!STREAM && KS <= 15 && Tp >= kRows / kWaves) {
+    // depthwise conv + conv-module LayerNorm (nn.LayerNorm(channels), eps 1e-5, convolution.py:71) + swish in registers
+    if constexpr (!STREAM && KS <= 15)
+      dwconv_ln_phase<KS>(g, bufA, w.dw_w, w.dw_b, w.glu_pad, w.ln_cm_g, w.ln_cm_b, r0, M, Tp, left_ctx);
+    PPASR_TS(1);
+  } else {
+    dwconv_phase<KS, STREAM>(g, g_hist, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp, left_ctx);
+    __syncthreads();
+    PPASR_TS(1);
+    rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
+  }
+  // residual rows and pad flags of the pointwise_conv2 epilogue: requested before the GEMM, branch-free (clamped row),
+  // so that their global round trips (~2.5 us each under load) overlap the pointwise_conv2 GEMM (8 us; issued after
+  // the depthwise phase, whose register window they would otherwise compete with).
   // (Inside the epilogue the 16 conditional loads per lane ran as dependent round trips: 9 us.)
+  // The pad flags used to come from PadRows per row (a dependent lens[b] load + compare inside the loop): the 16
+  // residual loads then ran as 16 serial round trips (6.8 us, per-phase stamps).  A 32-row block touches at most two
+  // utterances when Tp >= 32: their lengths are two uniform loads, the flags plain arithmetic.
   PadRows is_pad{lens, r0, Tp, M, mask_mul};
   float res[16];
   unsigned pad_bits = 0;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = acc_row(r, lane);
-    res[r] = x2[(size_t)(r0 + min(row, valid - 1)) * kD + col];
-    pad_bits |= (is_pad(row) ? 1u : 0u) << r;
+  for (int r = 0; r < 16; ++r) res[r] = x2[(size_t)(r0 + min(acc_row(r, lane), valid - 1)) * kD + col];
+  if (lens) {
+    if (Tp >= kRows) {
+      const int b0 = r0 / Tp, t0 = r0 - b0 * Tp, nb = max(M / Tp, 1);
+      const int64_t len0 = lens[min(b0, nb - 1)], len1 = lens[min(b0 + 1, nb - 1)];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lane);
+        const int tt = t0 + row;
+        const bool over = tt >= Tp;
+        const int64_t t = over ? tt - Tp : tt, len = over ? len1 : len0;
+        pad_bits |= ((r0 + row < M && (int64_t)mask_mul * t >= len) ? 1u : 0u) << r;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pad_bits |= (is_pad(acc_row(r, lane)) ? 1u : 0u) << r;
+    }
   }
-  dwconv_phase<KS, STREAM>(g, g_hist, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp, left_ctx);
-  __syncthreads();
-  PPASR_TS(1);
-  // conv-module LayerNorm (nn.LayerNorm(channels), eps 1e-5, convolution.py:71) + swish, in place
-  rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
   __syncthreads();
   PPASR_TS(2);
   {
@@ -1349,7 +1399,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   PPASR_TS(6);
   rb_layernorm(bufX, bufX, kLda, kRows, w.ln_fin_g, w.ln_fin_b, 1e-5f);
   // rb_layernorm and rb_store_rows use the same wave->row mapping: no barrier needed
-  rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);
+  if (x_out) rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);  // (nullptr: nobody reads it, see capi.hip)
   PPASR_TS(7);
   if (NEXT) ffn_qkv_body(bufX, bufA, bufH, x1_next, qkv_next, wn, r0, valid, n_chunks, ring);
   PPASR_TS(15);

@@ -146,4 +146,70 @@ __device__ __forceinline__ void dwconv_phase(const float* __restrict__ g, const 
   }
 }
 
+// The batched (non-streaming-chunk) form of the conv module's depthwise stage, fused with the LayerNorm + swish that
+// follow it (convolution.py:129-134): wave w owns the RW = 4 CONSECUTIVE rows 4w .. 4w+3 of the block, so their
+// KS-tap windows overlap and the whole input it needs is NW = RW + KS - 1 rows of g, loaded ONCE from global memory
+// straight into registers (one coalesced 1 KiB row per load, lane = 4 columns), the tap weights likewise (KS x f32x4).
+// The conv walks the window rows q: row q feeds tap j = q - i of output row i, so every output row still accumulates
+// its taps in ascending order (bit-identical to dwconv_phase), and the "outside the utterance -> GLU(bias)" substitution
+// is decided once per window row.  A wave spans the whole 256-wide row (4 columns per lane), so the
+// LayerNorm runs on the accumulators themselves (wave sums) and the only LDS traffic is the store of the normalised rows.
+// (The LDS-staged dwconv_phase -- window + weights through LDS, a barrier, 2 ds_read_b128 per FMA, then a second pass
+// for the LayerNorm -- took 12.7 + 1.6 us of the dominant kernel; tools/phase_ts.py.)
+// A wave whose 4 rows straddle an utterance boundary runs the walk twice, once per utterance, and keeps per row the
+// result of the row's own utterance (needs Tp >= RW: the caller falls back to dwconv_phase below that).
+template <int KS>
+__device__ __forceinline__ void dwconv_ln_phase(const float* __restrict__ g, float* bufA, const float* __restrict__ dw_w,
+                                                const float* __restrict__ dw_b, const float* __restrict__ glu_pad,
+                                                const float* __restrict__ ln_g, const float* __restrict__ ln_b, int r0,
+                                                int M, int Tp, int left) {
+  const int lane = lane_id(), wave = wave_id();
+  constexpr int LO = KS - 1, RW = kRows / kWaves, NW = RW + LO;
+  const bool causal = (left == LO);
+  const int q0 = wave * RW;
+  f32x4 x[NW];
+#pragma unroll
+  for (int q = 0; q < NW; ++q) {
+    const int mq = r0 - left + q0 + q;
+    const int mc = min(max(mq, 0), M - 1);  // branch-free: clamped address, value masked below
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + (size_t)mc * kD + 4 * lane);
+    x[q] = (mq >= 0 && mq < M) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 wt[KS];
+#pragma unroll
+  for (int j = 0; j < KS; ++j) wt[j] = *reinterpret_cast<const f32x4*>(dw_w + j * kD + 4 * lane);
+  f32x4 gp = *reinterpret_cast<const f32x4*>(glu_pad + 4 * lane);
+  if (!causal) gp = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(dw_b + 4 * lane);
+  const int m0 = r0 + q0;
+  const int tq0 = m0 - (m0 / Tp) * Tp;           // frame of the wave's first row inside its utterance
+  const int npass = (tq0 + RW - 1 < Tp) ? 1 : 2;  // 2: the rows straddle an utterance boundary
+  f32x4 out[RW];
+#pragma unroll 1
+  for (int p = 0; p < npass; ++p) {
+    const int tqp = tq0 - p * Tp;  // frame of row 0 relative to the start of utterance p of this wave
+    f32x4 acc[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) acc[i] = bias;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const int tt = tqp - left + q;  // frame the window row holds, relative to the utterance
+      const f32x4 xq = (tt >= 0 && tt < Tp) ? x[q] : gp;
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        const int j = q - i;
+        if (j >= 0 && j < KS) acc[i] += wt[j] * xq;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+      if (npass == 1 || (tqp + i >= 0 && tqp + i < Tp)) out[i] = acc[i];
+  }
+  const f32x4 gam = *reinterpret_cast<const f32x4*>(ln_g + 4 * lane);
+  const f32x4 bet = *reinterpret_cast<const f32x4*>(ln_b + 4 * lane);
+  ln_rows_inreg<true, RW>(out, gam, bet, 1e-5f);
+#pragma unroll
+  for (int i = 0; i < RW; ++i) *reinterpret_cast<f32x4*>(bufA + (q0 + i) * kLda + 4 * lane) = out[i];
+}
+
 }  // namespace ppasr

@@ -211,6 +211,15 @@ def full(paddle, only):
                     out[f"{name}/ids/{i}"], out[f"{name}/margin/{i}"] = ids[j, :nf], margin[j, :nf]
                     out[f"{name}/lse/{i}"], out[f"{name}/sampled/{i}"] = lse[j, :nf], samp[j, :nf]
             out[f"{name}/beam_tokens"], out[f"{name}/beam_n"] = toks, nt
+            # the same 16 utterances as ONE batch padded to the longest: the reference's values depend on the batch an
+            # utterance is padded into (full-context attention sees the partially padded last frame, every PAD row is
+            # computed), so the one-batch route has its own reference
+            probs, logits = run_batched(paddle, model, case, x, lens)
+            ids, margin, lse, samp = summarise(logits, cols)
+            for i in range(len(lens)):
+                nf = min((int(lens[i]) + 3) // 4, probs.shape[1])
+                out[f"{name}pad/ids/{i}"], out[f"{name}pad/margin/{i}"] = ids[i, :nf], margin[i, :nf]
+                out[f"{name}pad/lse/{i}"], out[f"{name}pad/sampled/{i}"] = lse[i, :nf], samp[i, :nf]
         else:
             probs, logits = run_batched(paddle, model, case, x, lens)
             ids, margin, lse, samp = summarise(logits, cols)

@@ -115,9 +115,9 @@ def test_scorer_rejects_unsupported_models(tmp_path):
     from ppasr_amd import _lib
     from ppasr_amd.decoders.beam_search_decoder import Scorer
     vocab = _vocab(50)
-    klm = tmp_path / "x.klm"
-    klm.write_bytes(b"mmap lm http://kheafield.com/code format version 5\n\x00" + bytes(64))
-    with pytest.raises(_lib.PPASRHipError, match="KenLM binary"):
+    klm = tmp_path / "x.klm"   # a KenLM magic followed by garbage: refused, not mis-read
+    klm.write_bytes(b"mmap lm http://kheafield.com/code format version 5\n\x00" + bytes(200))
+    with pytest.raises(_lib.PPASRHipError, match="sanity block"):
         Scorer(1.0, 1.0, str(klm), vocab)
     word = tmp_path / "w.arpa"
     word.write_text("\\data\\\nngram 1=4\n\n\\1-grams:\n-1.0\t<unk>\n-99\t<s>\t-0.5\n-1.2\t</s>\n-2.0\thello\t-0.3\n\n\\end\\\n")
