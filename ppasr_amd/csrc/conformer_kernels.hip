@@ -842,6 +842,8 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
   const f32x4* seg_gate = w.pw1 + (size_t)(8 + wave) * kTs256;
   const int hh = lane >> 5, l31 = lane & 31;
   constexpr int NG = 16, PF = 4;
+  PPASR_TS(32);
+  PPASR_WG_TS(512 + 0);
 
   // ---- Q' fragments in registers: qa[gk][j] = Q'[row l31][8 gk + 4 hh + j], Q' = [q+u | q+v] ----
   f32x4 qa[NG];
@@ -864,6 +866,7 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
       qa[gq + 8] = q + v;
     }
   }
+  PPASR_TS(33);
   // K' fragment of k-group gk for key j: features 8gk + 4hh .. +3; the first 8 groups from k, the rest from p
   auto kfrag = [&](int j, int gk) -> f32x4 {
     const int jc = min(j, T2 - 1);  // keys >= T2 are masked afterwards
@@ -1008,6 +1011,7 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
       }
     }
   }
+  PPASR_TS(34);
   // ---- merge the two key halves of every head, normalise -> bufC ----
   if (hh == 0) {
     Stat[wave * 64 + l31] = m_run;
@@ -1021,6 +1025,7 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
   }
   ring_prime(ring, seg_o, 0);  // out-projection weights in flight across the barrier
   __syncthreads();
+  PPASR_TS(35);
   if (khalf == 0) {
     const float* P1 = Ps + (wave + 1) * kPTile;
 #pragma unroll
@@ -1041,6 +1046,7 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
     }
   }
   __syncthreads();
+  PPASR_TS(36);
   // ---- k_out_glu tail on the LDS-resident context ----
   const int r0 = b * T + q0;
   const int M = B * T;
@@ -1065,8 +1071,10 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
     }
   }
   __syncthreads();
+  PPASR_TS(37);
   rb_layernorm<false>(bufX, bufA, kLda, kRows, w.ln_conv_g, w.ln_conv_b, 1e-5f, PadRows{a.lens, r0, T, M, a.mask_mul});
   __syncthreads();
+  PPASR_TS(38);
   {
     f32x16 av[1][1], ag[1][1];
     acc_zero(av);
@@ -1081,6 +1089,8 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
       if (row < valid) g[(size_t)(r0 + row) * kD + col] = (av[0][0][r] + bval) * sigmoidf(ag[0][0][r] + bgate);
     }
   }
+  PPASR_TS(39);
+  PPASR_WG_TS(512 + 1);
 }
 constexpr size_t kLdsAttnOutGlu = (size_t)kFusedAttnFloats * sizeof(float);
 // a: plain-head batched attention arguments (group == 1, T1 == T2 frames, keys/values in the layer's own buffers)
@@ -1330,6 +1340,13 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   PPASR_TS(0);
   if (NEXT) PPASR_WG_TS(0);
   ring_prime(ring, seg_pw2, 0);
+  // lengths of the (at most two, when Tp >= 32) utterances this block touches: uniform loads, requested first thing
+  const int pb0 = r0 / Tp, pt0 = r0 - pb0 * Tp, pnb = max(M / Tp, 1);
+  int64_t plen0 = 0, plen1 = 0;
+  if (lens && Tp >= kRows) {
+    plen0 = lens[min(pb0, pnb - 1)];
+    plen1 = lens[min(pb0 + 1, pnb - 1)];
+  }
   if (!STREAM && KS <= 15 && Tp >= kRows / kWaves) {
     // depthwise conv + conv-module LayerNorm (nn.LayerNorm(channels), eps 1e-5, convolution.py:71) + swish in registers
     if constexpr (!STREAM && KS <= 15)
@@ -1355,14 +1372,12 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   for (int r = 0; r < 16; ++r) res[r] = x2[(size_t)(r0 + min(acc_row(r, lane), valid - 1)) * kD + col];
   if (lens) {
     if (Tp >= kRows) {
-      const int b0 = r0 / Tp, t0 = r0 - b0 * Tp, nb = max(M / Tp, 1);
-      const int64_t len0 = lens[min(b0, nb - 1)], len1 = lens[min(b0 + 1, nb - 1)];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = acc_row(r, lane);
-        const int tt = t0 + row;
+        const int tt = pt0 + row;
         const bool over = tt >= Tp;
-        const int64_t t = over ? tt - Tp : tt, len = over ? len1 : len0;
+        const int64_t t = over ? tt - Tp : tt, len = over ? plen1 : plen0;
         pad_bits |= ((r0 + row < M && (int64_t)mask_mul * t >= len) ? 1u : 0u) << r;
       }
     } else {

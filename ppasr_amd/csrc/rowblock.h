@@ -43,10 +43,10 @@ static __device__ long long g_phase_ts[64];  // one copy per translation unit (n
   do {                                                                                           \
     if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_phase_ts[i] = (long long)wall_clock64(); \
   } while (0)
-static __device__ long long g_wg_ts[2 * 1024];  // [workgroup][start, end] of the last launch that records them
+static __device__ long long g_wg_ts[2 * 1024];  // [kernel 0/1][workgroup < 256][start, end] of the last launch that records them (slot 0/1, 512/513)
 #define PPASR_WG_TS(slot)                                                                                  \
   do {                                                                                                     \
-    if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_ts[2 * blockIdx.x + (slot)] = (long long)wall_clock64(); \
+    if (threadIdx.x == 0 && blockIdx.x < 512) g_wg_ts[((slot) & ~1) + 2 * blockIdx.x + ((slot) & 1)] = (long long)wall_clock64(); \
   } while (0)
 #else
 #define PPASR_TS(i) do { } while (0)

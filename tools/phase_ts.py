@@ -79,3 +79,19 @@ for xcd in range(8):
     print(f"  XCD {xcd}: n={sel.sum():2d} start {start[sel].mean():6.2f}  duration mean {dur[sel].mean():7.1f} max {dur[sel].max():7.1f}")
 order = np.argsort(-dur)[:8]
 print("  slowest workgroups:", [(int(i), round(float(dur[i]), 1)) for i in order])
+
+# ---- k_attn_out_glu: phases of one workgroup + spans of all 256
+t = np.array(list(ts), np.float64)
+a = (t[32:40] - t[32]) / 100.0
+names = ["start", "Q staging", "key loop (S, softmax, PV)", "merge: stats + partial O to LDS", "barrier", "merge + bufC + barrier",
+         "out-proj + residual epilogue + barrier", "LN_conv + barrier", "pw1 value + gate + GLU store"]
+print("k_attn_out_glu (last launch), one workgroup, microseconds:")
+for i in range(1, 8):
+    print(f"  {names[i]:40s} +{a[i] - a[i - 1]:7.2f}   (t = {a[i]:7.2f})")
+w = np.array(list(wg), np.float64).reshape(1024, 2)[256:512] / 100.0
+ok = w[:, 1] > w[:, 0]
+w = w[ok]
+t0 = w[:, 0].min()
+dur = w[:, 1] - w[:, 0]
+print(f"{len(w)} workgroups: start skew max {(w[:, 0] - t0).max():.2f} us, duration min/median/max {dur.min():.1f}/{np.median(dur):.1f}/{dur.max():.1f} us,"
+      f" last end {(w[:, 1] - t0).max():.1f} us")
