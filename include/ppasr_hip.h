@@ -140,6 +140,14 @@ long long ppasr_edit_distance(const int32_t* a, int na, const int32_t* b, int nb
  *   holds the beam, the prefix arena (both kept between chunk calls) and the per-frame records of the
  *   pruning pre-pass (get_pruned_log_probs of every frame of the call: T <= max total frames). */
 size_t ppasr_ctc_beam_state_bytes(int B, int max_frames, int beam_size);
+/* Pruned characters per frame the kernel can hold (128).  DEVIATION from upstream: a configuration that lets more
+ * survive (cutoff_prob >= 1, where upstream ignores cutoff_top_n; or cutoff_top_n > 128) keeps the 128 most probable
+ * characters of each frame. */
+int ppasr_ctc_beam_candidate_cap(void);
+/* Reads back the per-utterance status words of a (streaming) state buffer: non-zero = the prefix arena ran out because
+ * more cumulative frames were decoded than the buffer was sized for; returns PPASR_ENOSPACE then.  Synchronises. */
+ppasr_status ppasr_ctc_beam_status(const void* state, size_t state_bytes, int B, int beam_size, int32_t* status_host,
+                                   void* stream);
 ppasr_status ppasr_ctc_beam_search(const float* probs, const int32_t* frame_lens, int B, int T, int V, int beam_size,
                                    double cutoff_prob, int cutoff_top_n, int blank, int nbest, int max_tokens,
                                    int32_t* tokens, int32_t* lens, double* scores, void* state, size_t state_bytes,

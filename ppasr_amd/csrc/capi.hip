@@ -4,6 +4,10 @@
 
 #include "capi_internal.h"
 
+namespace ppasr {
+thread_local LaunchProf g_launch_prof;  // launch.h
+}
+
 static thread_local std::string g_err;
 std::string& ppasr_err_slot() { return g_err; }
 
@@ -399,11 +403,17 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       fn();
       return;
     }
-    hipEvent_t a = h->next_event(), b = h->next_event();
-    (void)hipEventRecord(a, st);
+    // every kernel launched by fn() gets its own (start, stop) events attached to its dispatch (launch.h)
+    h->spans.push_back({cls, {}});
+    g_launch_prof.ctx = h;
+    g_launch_prof.next = [](void* ctx, hipEvent_t* s, hipEvent_t* e) {
+      ppasr_model_s* m = static_cast<ppasr_model_s*>(ctx);
+      *s = m->next_event();
+      *e = m->next_event();
+      m->spans.back().ev.emplace_back(*s, *e);
+    };
     fn();
-    (void)hipEventRecord(b, st);
-    h->spans.push_back({cls, a, b});
+    g_launch_prof = LaunchProf{};
   };
   // ragged batches (ppasr_set_skip_padding): rows behind an utterance's valid frames + slack are skipped.  Slack =
   // what valid outputs read from the rows behind them: the right context of the non-causal conv module, and with a
@@ -536,10 +546,17 @@ static ppasr_status beam_config(int V, int beam_size, double cutoff_prob, int cu
   if (nbest < 1 || nbest > beam_size || max_tokens < 1) return fail(PPASR_EINVAL, "beam search: bad nbest / max_tokens");
   if (cutoff_top_n < 1) return fail(PPASR_EINVAL, "beam search: cutoff_top_n < 1");
   // candidates per frame: pruned to cutoff_top_n only when cutoff_prob < 1 (upstream get_pruned_log_probs)
-  const int n_cand = (cutoff_prob < 1.0) ? (cutoff_top_n < V ? cutoff_top_n : V) : V;
-  if (n_cand > kMaxBeamCand)
-    return fail(PPASR_EUNSUPPORTED, "beam search: more than 128 characters per frame survive pruning "
-                                    "(cutoff_prob >= 1 disables cutoff_top_n upstream); lower cutoff_prob / cutoff_top_n");
+  int n_cand = (cutoff_prob < 1.0) ? (cutoff_top_n < V ? cutoff_top_n : V) : V;
+  if (n_cand > kMaxBeamCand) {
+    // DOCUMENTED DEVIATION: the kernel holds at most 128 pruned characters per frame.  Upstream keeps every character
+    // when cutoff_prob >= 1 (its cutoff_top_n is only applied inside the cutoff_prob < 1 branch) -- the default of the
+    // Python wrappers.  Here the 128 most probable characters of the frame are kept (cut early only where their
+    // cumulative probability already reaches 1 - 1e-12) instead of refusing the call; what is dropped are characters
+    // ranked below 128 in a frame (ppasr_ctc_beam_candidate_cap() reports the cap).
+    n_cand = kMaxBeamCand;
+    cutoff_top_n = kMaxBeamCand;
+    if (cutoff_prob >= 1.0) cutoff_prob = 1.0 - 1e-12;
+  }
   c->V = V; c->beam = beam_size; c->blank = blank; c->cutoff_top_n = cutoff_top_n; c->cutoff_prob = cutoff_prob;
   c->n_cand_max = n_cand; c->nbest = nbest; c->max_tokens = max_tokens; c->max_nodes = 0;
   if (beam_lds_bytes(*c) > 160 * 1024) return fail(PPASR_EUNSUPPORTED, "beam search: beam x candidates does not fit LDS");
@@ -549,6 +566,8 @@ static ppasr_status beam_config(int V, int beam_size, double cutoff_prob, int cu
 // state buffer = B x [header | beam arrays | arena of 1 + (F+1)*beam nodes] | B status words | scratch of the pruning
 // pre-pass (B x F frame records of the largest record size), F = max_frames.  The layout is recomputed from
 // (state_bytes, B, beam_size) on every call, so it is the same for every chunk of a streaming decode.
+extern "C" int ppasr_ctc_beam_candidate_cap(void) { return kMaxBeamCand; }
+
 static size_t beam_utt_fixed_bytes(int beam_size) {
   return 4 + 4 * (2 + (size_t)kBeamStateArrays * beam_size) + 8 * (size_t)(1 + beam_size);
 }
@@ -599,6 +618,32 @@ ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_l
   return PPASR_OK;
 }
 
+// Streaming callers of the C-ABI: the kernel flags an utterance whose prefix arena ran out (more cumulative frames than
+// the state buffer was sized for) in a status word of the state buffer; this reads the B words back (synchronises the
+// stream) and returns PPASR_ENOSPACE if any is set -- the hypotheses of that utterance are then truncated.
+ppasr_status ppasr_ctc_beam_status(const void* state, size_t state_bytes, int B, int beam_size, int32_t* status_host,
+                                   void* stream) {
+  if (!state || B <= 0 || beam_size < 1) return fail(PPASR_EINVAL, "null argument");
+  const size_t per_utt_bytes = state_bytes / (size_t)B;
+  if (per_utt_bytes < beam_utt_fixed_bytes(beam_size) + beam_frame_bytes(beam_size))
+    return fail(PPASR_ENOSPACE, "beam search: state buffer too small");
+  const size_t F = (per_utt_bytes - beam_utt_fixed_bytes(beam_size)) / beam_frame_bytes(beam_size);
+  const size_t fixed = 2 + (size_t)kBeamStateArrays * beam_size;
+  const size_t max_nodes = 1 + (F + 1) * (size_t)beam_size;
+  const int32_t* status = static_cast<const int32_t*>(state) + (size_t)B * (fixed + 2 * max_nodes);
+  std::vector<int32_t> host(B);
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(host.data(), status, (size_t)B * 4, hipMemcpyDeviceToHost, hs));
+  HIP_TRY(hipStreamSynchronize(hs));
+  bool any = false;
+  for (int b = 0; b < B; ++b) {
+    if (status_host) status_host[b] = host[b];
+    any |= host[b] != 0;
+  }
+  if (any) return fail(PPASR_ENOSPACE, "beam search: the prefix arena of at least one utterance is exhausted (state sized for fewer frames)");
+  return PPASR_OK;
+}
+
 static const char* kKernelClassNames[PPASR_N_KERNEL_CLASSES] = {
     "k_conv1", "k_gemm_stream<conv2>", "k_gemm_stream<embed>", "k_ffn_qkv", "k_attention", "k_out_glu", "k_conv_ffn",
     "k_ctc_head", "k_conv_ffn+ffn_qkv", "k_attn_out_glu"};
@@ -618,10 +663,13 @@ ppasr_status ppasr_profile_read(ppasr_handle h, float* total_ms_host, int* launc
     launches_host[i] = 0;
   }
   for (auto& sp : h->spans) {
-    HIP_TRY(hipEventSynchronize(sp.b));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, sp.a, sp.b));
-    total_ms_host[sp.cls] += ms;
+    if (sp.ev.empty()) continue;  // (a span whose kernels do not go through PPASR_LAUNCH)
+    for (auto& pr : sp.ev) {
+      HIP_TRY(hipEventSynchronize(pr.second));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+      total_ms_host[sp.cls] += ms;
+    }
     launches_host[sp.cls] += 1;
   }
   return PPASR_OK;

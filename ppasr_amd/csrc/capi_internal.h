@@ -12,6 +12,7 @@
 
 #include "../../include/ppasr_hip.h"
 #include "conformer_kernels.h"
+#include "launch.h"
 #include "ctc_beam.h"
 
 using namespace ppasr;
@@ -87,7 +88,7 @@ struct ppasr_model_s {
   bool skip_padding = false;  // ppasr_set_skip_padding: ragged batches compute only the rows valid outputs depend on
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
-  struct Span { int cls; hipEvent_t a, b; };
+  struct Span { int cls; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };  // one pair per kernel launched inside the span
   std::vector<Span> spans;
 
   ppasr_status upload(const std::vector<float>& v, const float** out) {

@@ -3,6 +3,7 @@
 // subsampling,embedding}.py, model_utils/loss/ctc.py, decoders/ctc_greedy_decoder.py
 // (file:line cited per kernel).  All arithmetic is fp32 (the reference's inference dtype).
 #include "conformer_kernels.h"
+#include "launch.h"
 #include "phases.h"
 
 #include <math.h>
@@ -36,7 +37,7 @@ __global__ void k_posproj(const float* __restrict__ pe, const float* __restrict_
   ptab[(size_t)pos * kD + n] = acc;
 }
 void launch_posproj(const float* pe, const float* wpos, const float* bpos, float* ptab, int max_len, hipStream_t st) {
-  hipLaunchKernelGGL(k_posproj, dim3(max_len), dim3(kD), 0, st, pe, wpos, bpos, ptab, max_len);
+  PPASR_LAUNCH(k_posproj, dim3(max_len), dim3(kD), 0, st, pe, wpos, bpos, ptab, max_len);
 }
 
 // =====================================================================================
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ feats, 
 }
 void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T, int F, int T1, int F1, hipStream_t st,
                   const PadSkip& ps) {
-  hipLaunchKernelGGL(k_conv1, dim3(T1, B), dim3(256), 0, st, feats, fw, y1, T, F, T1, F1, ps);
+  PPASR_LAUNCH(k_conv1, dim3(T1, B), dim3(256), 0, st, feats, fw, y1, T, F, T1, F1, ps);
 }
 
 // =====================================================================================
@@ -220,7 +221,7 @@ void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, i
     // less than one round of 128-row tiles (a single utterance, a streaming chunk): smaller tiles fill more CUs
     const int mt = (M + 32 * kCUs - 1) / (32 * kCUs);  // 1 .. 4
 #define CONV2_ALL(MTA)                                                                                                    \
-  hipLaunchKernelGGL((k_gemm_stream<MTA, KC, true, false, Conv2Src>), dim3((M + 32 * MTA - 1) / (32 * MTA)),              \
+  PPASR_LAUNCH((k_gemm_stream<MTA, KC, true, false, Conv2Src>), dim3((M + 32 * MTA - 1) / (32 * MTA)),              \
                      dim3(kThreads), lds_of(MTA), st, src, fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, 0, ps)
     if (mt <= 1) CONV2_ALL(1);
     else if (mt == 2) CONV2_ALL(2);
@@ -230,15 +231,15 @@ void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, i
     return;
   }
   if (rem_rows <= 0 || mt_rem >= 4) {
-    hipLaunchKernelGGL((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(tiles4), dim3(kThreads), lds_of(4), st, src,
+    PPASR_LAUNCH((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(tiles4), dim3(kThreads), lds_of(4), st, src,
                        fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, 0, ps);
     return;
   }
-  hipLaunchKernelGGL((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(full), dim3(kThreads), lds_of(4), st, src,
+  PPASR_LAUNCH((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(full), dim3(kThreads), lds_of(4), st, src,
                      fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, 0, ps);
   const int m0 = full * 128;
 #define CONV2_REM(MTR)                                                                                                    \
-  hipLaunchKernelGGL((k_gemm_stream<MTR, KC, true, false, Conv2Src>), dim3((rem_rows + 32 * MTR - 1) / (32 * MTR)),       \
+  PPASR_LAUNCH((k_gemm_stream<MTR, KC, true, false, Conv2Src>), dim3((rem_rows + 32 * MTR - 1) / (32 * MTR)),       \
                      dim3(kThreads), lds_of(MTR), st, src, fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, m0, ps)
   if (mt_rem <= 1) CONV2_REM(1);
   else if (mt_rem == 2) CONV2_REM(2);
@@ -251,17 +252,17 @@ void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, fl
   DenseSrc src{y2, K, KC};
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
   if (k_slices > 1 && part) {  // under-filled launch: the K = 4864 contraction over k_slices workgroups per row block
-    hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, 1, k_slices), dim3(kThreads), lds,
+    PPASR_LAUNCH((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, 1, k_slices), dim3(kThreads), lds,
                        st, src, fw.embed_w, fw.embed_b, part, M, K / KC, xscale, kD, kD, 0, ps);
-    hipLaunchKernelGGL(k_gemm_join, dim3((M + 3) / 4), dim3(256), 0, st, part, k_slices, fw.embed_b, xscale,
+    PPASR_LAUNCH(k_gemm_join, dim3((M + 3) / 4), dim3(256), 0, st, part, k_slices, fw.embed_b, xscale,
                        scale_before_bias ? 1 : 0, x0, M, ps);
     return;
   }
   if (scale_before_bias)
-    hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, true, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src,
+    PPASR_LAUNCH((k_gemm_stream<MT, KC, false, true, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src,
                        fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD, 0, ps);
   else
-    hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src,
+    PPASR_LAUNCH((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src,
                        fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD, 0, ps);
 }
 
@@ -272,7 +273,7 @@ void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, fl
   constexpr int MT = 1, KC = 256;
   DenseSrc src{a, lda, KC};
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
-  hipLaunchKernelGGL((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, n_cols_padded / 256),
+  PPASR_LAUNCH((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, n_cols_padded / 256),
                      dim3(kThreads), lds, st, src, w, bias, out, M, K / KC, 1.0f, ldc, n_valid, 0, PadSkip{});
 }
 
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ 
 constexpr size_t kLdsFfnQkv = 4 * kRows * kLda * sizeof(float);
 void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
                     const PadSkip& ps) {
-  hipLaunchKernelGGL(k_ffn_qkv, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsFfnQkv, st, x_in, x1, qkv, w, M,
+  PPASR_LAUNCH(k_ffn_qkv, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsFfnQkv, st, x_in, x1, qkv, w, M,
                      n_chunks, ps);
 }
 
@@ -662,9 +663,9 @@ constexpr size_t kLdsAttn = AttnCfg<64>::LDS_FLOATS * sizeof(float);
 constexpr size_t kLdsAttnG = AttnCfg<192>::LDS_FLOATS * sizeof(float);
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st) {
   if (a.group == 3)
-    hipLaunchKernelGGL(k_attention<192>, dim3((a.T1 + 63) / 64, H, B), dim3(256), kLdsAttnG, st, a);
+    PPASR_LAUNCH(k_attention<192>, dim3((a.T1 + 63) / 64, H, B), dim3(256), kLdsAttnG, st, a);
   else
-    hipLaunchKernelGGL(k_attention<64>, dim3((a.T1 + 63) / 64, H, B), dim3(256), kLdsAttn, st, a);
+    PPASR_LAUNCH(k_attention<64>, dim3((a.T1 + 63) / 64, H, B), dim3(256), kLdsAttn, st, a);
 }
 
 // -------------------------------------------------------------------------------------
@@ -773,10 +774,10 @@ void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, floa
   // split_xhat != nullptr (under-filled launches): out-projection + LayerNorm in one launch (the LayerNorm'd rows go to
   // split_xhat), pointwise_conv1 + GLU in a second one with the columns over two workgroups per row block
   float* xh = xhat_out ? xhat_out : split_xhat;
-  hipLaunchKernelGGL(k_out_glu, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsOutGlu, st, ctx, x1, x2, g, xh, w, lens,
+  PPASR_LAUNCH(k_out_glu, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsOutGlu, st, ctx, x1, x2, g, xh, w, lens,
                      M, Tp, mask_mul, ps, split_xhat ? 1 : 0);
   if (split_xhat)
-    hipLaunchKernelGGL(k_pw1_glu_cols, dim3((M + kRows - 1) / kRows, 2), dim3(kThreads), kLdsPw1Cols, st, xh, g, w, M, ps);
+    PPASR_LAUNCH(k_pw1_glu_cols, dim3((M + kRows - 1) / kRows, 2), dim3(kThreads), kLdsPw1Cols, st, xh, g, w, M, ps);
 }
 
 // -------------------------------------------------------------------------------------
@@ -1097,7 +1098,7 @@ constexpr size_t kLdsAttnOutGlu = (size_t)kFusedAttnFloats * sizeof(float);
 void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, float* g, const LayerW& w, hipStream_t st) {
   // 1-D grid of nq * ceil(B/8) * 8 workgroups (see the XCD map in the kernel)
   const int nq = (a.T1 + 31) / 32;
-  hipLaunchKernelGGL(k_attn_out_glu, dim3(nq * ((B + 7) / 8) * 8), dim3(kThreads), kLdsAttnOutGlu, st, a, B, x1, x2, g, w);
+  PPASR_LAUNCH(k_attn_out_glu, dim3(nq * ((B + 7) / 8) * 8), dim3(kThreads), kLdsAttnOutGlu, st, a, B, x1, x2, g, w);
 }
 
 // streaming: g_hist = GLU(pointwise_conv1(cnn_cache rows))  -- the reference re-applies pointwise_conv1+GLU
@@ -1162,10 +1163,10 @@ __global__ __launch_bounds__(kThreads) void k_pw1_glu_layers(const float* __rest
 constexpr size_t kLdsPw1Glu = kRows * kLda * sizeof(float);
 void launch_pw1_glu_layers(const float* xh_hist, float* g_hist, const HistLayer* tab, int n_layers, int lo_stride,
                            hipStream_t st) {
-  hipLaunchKernelGGL(k_pw1_glu_layers, dim3(n_layers), dim3(kThreads), kLdsPw1Glu, st, xh_hist, g_hist, tab, lo_stride);
+  PPASR_LAUNCH(k_pw1_glu_layers, dim3(n_layers), dim3(kThreads), kLdsPw1Glu, st, xh_hist, g_hist, tab, lo_stride);
 }
 void launch_pw1_glu(const float* xhat, float* g, const LayerW& w, int M, hipStream_t st) {
-  hipLaunchKernelGGL(k_pw1_glu, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsPw1Glu, st, xhat, g, w, M);
+  PPASR_LAUNCH(k_pw1_glu, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsPw1Glu, st, xhat, g, w, M);
 }
 
 // streaming: append this chunk's keys / values (columns 256.. / 512.. of qkv) to the per-layer caches
@@ -1176,7 +1177,7 @@ __global__ void k_kv_append(const float* __restrict__ qkv, float* __restrict__ k
   *reinterpret_cast<f32x4*>(dst) = v;
 }
 void launch_kv_append(const float* qkv, float* kc, float* vc, int n_rows, hipStream_t st) {
-  hipLaunchKernelGGL(k_kv_append, dim3(n_rows), dim3(128), 0, st, qkv, kc, vc, n_rows);
+  PPASR_LAUNCH(k_kv_append, dim3(n_rows), dim3(128), 0, st, qkv, kc, vc, n_rows);
 }
 
 // streaming: hist <- last `lo` rows of concat(hist[lo], fresh[n]); single block, read-all-then-write
@@ -1203,7 +1204,7 @@ __global__ __launch_bounds__(256) void k_hist_update(float* __restrict__ hist, c
   }
 }
 void launch_hist_update(float* hist, const float* fresh, int n, int lo, hipStream_t st) {
-  hipLaunchKernelGGL(k_hist_update, dim3(1), dim3(256), 0, st, hist, fresh, n, lo);
+  PPASR_LAUNCH(k_hist_update, dim3(1), dim3(256), 0, st, hist, fresh, n, lo);
 }
 
 // ---- multi-session streaming helpers (one launch for all active sessions) ----
@@ -1220,7 +1221,7 @@ __global__ void k_kv_append_group(const float* __restrict__ qkv, float* __restri
 }
 void launch_kv_append_group(const float* qkv, float* kc, float* vc, long long sess_stride, const SessDesc* sess, int n, int c,
                             hipStream_t st) {
-  hipLaunchKernelGGL(k_kv_append_group, dim3(n * c), dim3(128), 0, st, qkv, kc, vc, sess_stride, sess, c);
+  PPASR_LAUNCH(k_kv_append_group, dim3(n * c), dim3(128), 0, st, qkv, kc, vc, sess_stride, sess, c);
 }
 // dst[b][lo][256] <- conv-module input history of session sess[b] (this layer)
 __global__ void k_hist_gather(const float* __restrict__ hist, long long sess_stride, const SessDesc* __restrict__ sess,
@@ -1231,7 +1232,7 @@ __global__ void k_hist_gather(const float* __restrict__ hist, long long sess_str
 }
 void launch_hist_gather(const float* hist, long long sess_stride, const SessDesc* sess, float* dst, int n, int lo,
                         hipStream_t st) {
-  hipLaunchKernelGGL(k_hist_gather, dim3(n * lo), dim3(64), 0, st, hist, sess_stride, sess, dst, lo);
+  PPASR_LAUNCH(k_hist_gather, dim3(n * lo), dim3(64), 0, st, hist, sess_stride, sess, dst, lo);
 }
 // hist[sess[b]] <- last `lo` rows of concat(hist[sess[b]], fresh[b][c]); one 256-thread block per session
 __global__ __launch_bounds__(256) void k_hist_update_group(float* __restrict__ hist, long long sess_stride,
@@ -1262,7 +1263,7 @@ __global__ __launch_bounds__(256) void k_hist_update_group(float* __restrict__ h
 }
 void launch_hist_update_group(float* hist, long long sess_stride, const SessDesc* sess, const float* fresh, int n, int c,
                               int lo, hipStream_t st) {
-  hipLaunchKernelGGL(k_hist_update_group, dim3(n), dim3(256), 0, st, hist, sess_stride, sess, fresh, c, lo);
+  PPASR_LAUNCH(k_hist_update_group, dim3(n), dim3(256), 0, st, hist, sess_stride, sess, fresh, c, lo);
 }
 
 // [T][256] (col = h*64+f) k/v caches  <->  reference att_cache layout [h][T][2*dk]  (attention.py:232)
@@ -1295,13 +1296,13 @@ __global__ void k_cnn_transpose(const float* __restrict__ src, float* __restrict
   }
 }
 void launch_cache_export(const float* kc, const float* vc, float* att, int T, int div, hipStream_t st) {
-  if (T > 0) hipLaunchKernelGGL(k_cache_export, dim3(T), dim3(256), 0, st, kc, vc, att, T, div);
+  if (T > 0) PPASR_LAUNCH(k_cache_export, dim3(T), dim3(256), 0, st, kc, vc, att, T, div);
 }
 void launch_cache_import(const float* att, float* kc, float* vc, int T, int div, hipStream_t st) {
-  if (T > 0) hipLaunchKernelGGL(k_cache_import, dim3((T + div - 1) / div), dim3(256), 0, st, att, kc, vc, T, div);
+  if (T > 0) PPASR_LAUNCH(k_cache_import, dim3((T + div - 1) / div), dim3(256), 0, st, att, kc, vc, T, div);
 }
 void launch_cnn_transpose(const float* src, float* dst, int lo, int lo_ref, int to_ref, hipStream_t st) {
-  hipLaunchKernelGGL(k_cnn_transpose, dim3(1), dim3(256), 0, st, src, dst, lo, lo_ref, to_ref);
+  PPASR_LAUNCH(k_cnn_transpose, dim3(1), dim3(256), 0, st, src, dst, lo, lo_ref, to_ref);
 }
 void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStream_t st);
 __global__ void k_fill_rows(float* __restrict__ dst, const float* __restrict__ row, int n_rows) {
@@ -1309,7 +1310,7 @@ __global__ void k_fill_rows(float* __restrict__ dst, const float* __restrict__ r
   dst[(size_t)r * kD + c] = row ? row[c] : 0.f;
 }
 void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStream_t st) {
-  hipLaunchKernelGGL(k_fill_rows, dim3(n_rows), dim3(256), 0, st, dst, row_or_null, n_rows);
+  PPASR_LAUNCH(k_fill_rows, dim3(n_rows), dim3(256), 0, st, dst, row_or_null, n_rows);
 }
 
 // -------------------------------------------------------------------------------------
@@ -1429,13 +1430,13 @@ void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float
   const LayerW& wn = next ? *next : w;
 #define LAUNCH_CF(KS)                                                                                                  \
   if (g_hist)                                                                                                          \
-    hipLaunchKernelGGL((k_conv_ffn<KS, true, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
+    PPASR_LAUNCH((k_conv_ffn<KS, true, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
                        lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps);                                    \
   else if (next)                                                                                                       \
-    hipLaunchKernelGGL((k_conv_ffn<KS, false, true>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
+    PPASR_LAUNCH((k_conv_ffn<KS, false, true>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
                        lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps);                                    \
   else                                                                                                                 \
-    hipLaunchKernelGGL((k_conv_ffn<KS, false, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, \
+    PPASR_LAUNCH((k_conv_ffn<KS, false, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, \
                        lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps);
   if (ksize == 15) {
     LAUNCH_CF(15)
@@ -1599,10 +1600,10 @@ void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float
   const int left_ctx = causal ? ksize - 1 : (ksize - 1) / 2;
 #define LAUNCH_CP(KS)                                                                                                    \
   if (g_hist)                                                                                                            \
-    hipLaunchKernelGGL((k_conv_pre<KS, true>), grid, dim3(kThreads), kLdsConvPre, st, g, g_hist, x2, x3, w, lens, M, Tp,   \
+    PPASR_LAUNCH((k_conv_pre<KS, true>), grid, dim3(kThreads), kLdsConvPre, st, g, g_hist, x2, x3, w, lens, M, Tp,   \
                        mask_mul, left_ctx, ps);                                                                          \
   else                                                                                                                   \
-    hipLaunchKernelGGL((k_conv_pre<KS, false>), grid, dim3(kThreads), kLdsConvPre, st, g, g_hist, x2, x3, w, lens, M, Tp,  \
+    PPASR_LAUNCH((k_conv_pre<KS, false>), grid, dim3(kThreads), kLdsConvPre, st, g, g_hist, x2, x3, w, lens, M, Tp,  \
                        mask_mul, left_ctx, ps);
   if (ksize == 15) {
     LAUNCH_CP(15)
@@ -1617,14 +1618,14 @@ void launch_ffn_split(const float* x, const float* ln_g, const float* ln_b, cons
                       const f32x4* w2, const float* b2, float scale, const float* out_ln_g, const float* out_ln_b,
                       float* partial, float* out, int M, int n_chunks, int S, hipStream_t st, const PadSkip& ps,
                       bool residual_is_normed) {
-  hipLaunchKernelGGL(k_ffn_part, dim3((M + kRows - 1) / kRows, S), dim3(kThreads), kLdsFfnPart, st, x, ln_g, ln_b, w1, b1,
+  PPASR_LAUNCH(k_ffn_part, dim3((M + kRows - 1) / kRows, S), dim3(kThreads), kLdsFfnPart, st, x, ln_g, ln_b, w1, b1,
                      w2, partial, M, n_chunks, ps);
-  hipLaunchKernelGGL(k_ffn_join, dim3((M + 3) / 4), dim3(256), 0, st, x, partial, S, b2, scale, out_ln_g, out_ln_b, out, M,
+  PPASR_LAUNCH(k_ffn_join, dim3((M + 3) / 4), dim3(256), 0, st, x, partial, S, b2, scale, out_ln_g, out_ln_b, out, M,
                      ps, residual_is_normed ? ln_g : nullptr, residual_is_normed ? ln_b : nullptr);
 }
 void launch_ln_qkv(const float* x1, float* qkv, const LayerW& w, int M, hipStream_t st, const PadSkip& ps, float* kc,
                    float* vc) {
-  hipLaunchKernelGGL(k_ln_qkv, dim3((M + kRows - 1) / kRows, 3), dim3(kThreads), kLdsLnQkv, st, x1, qkv, w, M, ps, kc, vc);
+  PPASR_LAUNCH(k_ln_qkv, dim3((M + kRows - 1) / kRows, 3), dim3(kThreads), kLdsLnQkv, st, x1, qkv, w, M, ps, kc, vc);
 }
 
 // -------------------------------------------------------------------------------------
@@ -1717,10 +1718,10 @@ void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2
                             hipStream_t st, const PadSkip& ps, bool causal) {
   dim3 grid((B * Ts + kRows - 1) / kRows);
   if (ksize == 15)
-    hipLaunchKernelGGL(k_conv_ffn_stride<15>, grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, B, Tp, Ts,
+    PPASR_LAUNCH(k_conv_ffn_stride<15>, grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, B, Tp, Ts,
                        n_chunks, mask_mul_out, ps, causal ? 1 : 0);
   else if (ksize == 7)
-    hipLaunchKernelGGL(k_conv_ffn_stride<7>, grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, B, Tp, Ts,
+    PPASR_LAUNCH(k_conv_ffn_stride<7>, grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, B, Tp, Ts,
                        n_chunks, mask_mul_out, ps, causal ? 1 : 0);
 }
 
@@ -1870,13 +1871,13 @@ void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr
   const int ny = (n_slices > 1 && part) ? n_slices : 1;
   dim3 grid((M + kRows - 1) / kRows, ny);
   if (logits)
-    hipLaunchKernelGGL(k_ctc_head<true>, grid, dim3(kThreads), kLdsCtc, st, x, hw, logits, fr_argmax, fr_maxprob, row_max,
+    PPASR_LAUNCH(k_ctc_head<true>, grid, dim3(kThreads), kLdsCtc, st, x, hw, logits, fr_argmax, fr_maxprob, row_max,
                        row_sum, M, ps, part);
   else
-    hipLaunchKernelGGL(k_ctc_head<false>, grid, dim3(kThreads), kLdsCtc, st, x, hw, logits, fr_argmax, fr_maxprob, row_max,
+    PPASR_LAUNCH(k_ctc_head<false>, grid, dim3(kThreads), kLdsCtc, st, x, hw, logits, fr_argmax, fr_maxprob, row_max,
                        row_sum, M, ps, part);
   if (ny > 1)
-    hipLaunchKernelGGL(k_ctc_merge, dim3((M + 255) / 256), dim3(256), 0, st, part, ny, fr_argmax, fr_maxprob, row_max, row_sum,
+    PPASR_LAUNCH(k_ctc_merge, dim3((M + 255) / 256), dim3(256), 0, st, part, ny, fr_argmax, fr_maxprob, row_max, row_sum,
                        M, ps);
 }
 
@@ -1902,7 +1903,7 @@ __global__ __launch_bounds__(256) void k_softmax_rows(float* __restrict__ p, int
 }
 void launch_softmax_from_stats(float* probs_inout, const float*, const float*, int M, int V, hipStream_t st,
                                const PadSkip& ps) {
-  hipLaunchKernelGGL(k_softmax_rows, dim3((M + 3) / 4), dim3(256), 0, st, probs_inout, M, V, ps);
+  PPASR_LAUNCH(k_softmax_rows, dim3((M + 3) / 4), dim3(256), 0, st, probs_inout, M, V, ps);
 }
 
 __global__ __launch_bounds__(256) void k_zero_pad_rows(float* __restrict__ probs, float* __restrict__ logits,
@@ -1925,7 +1926,7 @@ __global__ __launch_bounds__(256) void k_zero_pad_rows(float* __restrict__ probs
 void launch_zero_pad_rows(float* probs, float* logits, int32_t* fr_argmax, float* fr_maxprob, const int64_t* lens, int B,
                           int Tp, int mul, int V, hipStream_t st) {
   const int M = B * Tp;
-  hipLaunchKernelGGL(k_zero_pad_rows, dim3((M + 3) / 4), dim3(256), 0, st, probs, logits, fr_argmax, fr_maxprob, lens, M, Tp,
+  PPASR_LAUNCH(k_zero_pad_rows, dim3((M + 3) / 4), dim3(256), 0, st, probs, logits, fr_argmax, fr_maxprob, lens, M, Tp,
                      mul, V);
 }
 
@@ -1964,7 +1965,7 @@ __global__ __launch_bounds__(256) void k_frame_argmax(const float* __restrict__ 
   }
 }
 void launch_frame_argmax(const float* probs, int32_t* fr_argmax, float* fr_maxprob, int M, int V, hipStream_t st) {
-  hipLaunchKernelGGL(k_frame_argmax, dim3((M + 3) / 4), dim3(256), 0, st, probs, fr_argmax, fr_maxprob, M, V);
+  PPASR_LAUNCH(k_frame_argmax, dim3((M + 3) / 4), dim3(256), 0, st, probs, fr_argmax, fr_maxprob, M, V);
 }
 
 // stage 2: groupby-collapse, drop blank, score = mean(non-blank max probs)*100; one wave per utterance
@@ -2014,7 +2015,7 @@ __global__ __launch_bounds__(64) void k_ctc_collapse(const int32_t* __restrict__
 }
 void launch_ctc_collapse(const int32_t* fr_argmax, const float* fr_maxprob, const int32_t* frame_lens, int B, int Tp,
                          int blank, int32_t* tokens, int32_t* n_tokens, double* score, hipStream_t st) {
-  hipLaunchKernelGGL(k_ctc_collapse, dim3(B), dim3(64), 0, st, fr_argmax, fr_maxprob, frame_lens, Tp, blank, tokens,
+  PPASR_LAUNCH(k_ctc_collapse, dim3(B), dim3(64), 0, st, fr_argmax, fr_maxprob, frame_lens, Tp, blank, tokens,
                      n_tokens, score);
 }
 

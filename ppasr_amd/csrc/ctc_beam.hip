@@ -827,7 +827,6 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
                            int32_t* prune_recs, int32_t* state, int init_state, int finalize, int32_t* out_tokens,
                            int32_t* out_lens, double* out_scores, int32_t* status, hipStream_t st) {
   const size_t lds = beam_lds_bytes(cfg), plds = prune_lds_bytes(cfg);
-  static size_t configured[5] = {0, 0, 0, 0, 0}, pconfigured = 0;
   // threads per utterance by the number of (hypothesis, candidate) elements of a frame: every phase is a chain of
   // block-wide steps, and a barrier over few waves is cheaper than one over 16
   const int n_elem = cfg.beam * (1 + cfg.n_cand_max);
@@ -842,16 +841,17 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
                         reinterpret_cast<const void*>(k_ctc_beam<256>), reinterpret_cast<const void*>(k_ctc_beam<512>),
                         reinterpret_cast<const void*>(k_ctc_beam<1024>)};
   const void* fn = fns[sel];
-  if (lds > configured[sel]) {
+  // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set it on every launch (a few host
+  // microseconds) rather than caching "already configured" in process-wide statics, which left a second GPU used from
+  // the same process unconfigured and was not thread-safe
+  if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    configured[sel] = lds;
   }
-  if (plds > pconfigured) {
+  if (plds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_prune<kPruneThreads>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
     if (e != hipSuccess) return e;
-    pconfigured = plds;
   }
   if (T > 0)
     hipLaunchKernelGGL(k_ctc_prune<kPruneThreads>, dim3(T, B), dim3(kPruneThreads), plds, st, probs, frame_lens, T, cfg,

@@ -163,6 +163,8 @@ class BeamSearchDecoder:
 
     def decode_beam_search_offline(self, probs_split):
         """-> (score, text) of the best hypothesis.  beam_search_decoder.py:45-56"""
+        if self._ext_scorer is not None:
+            self._ext_scorer.reset_params(self.alpha, self.beta)  # beam_search_decoder.py:46-47
         p = probs_split if isinstance(probs_split, torch.Tensor) else np.asarray(probs_split, np.float32)
         tokens, lens, scores, _ = beam_search_ids(torch.as_tensor(p)[None], self.beam_size, self.cutoff_prob,
                                                   self.cutoff_top_n, self.blank_id, nbest=1, ext_scorer=self._ext_scorer)
@@ -170,6 +172,8 @@ class BeamSearchDecoder:
 
     def decode_batch_beam_search_offline(self, probs_split):
         """-> list[str].  beam_search_decoder.py:59-73 (every row of every table is decoded)."""
+        if self._ext_scorer is not None:
+            self._ext_scorer.reset_params(self.alpha, self.beta)  # beam_search_decoder.py:60-61
         if isinstance(probs_split, torch.Tensor) and probs_split.dim() == 3:
             # only the best hypothesis is used (beam_search_decoder.py:72): ask the kernel for nbest = 1 instead of
             # copying and stringifying all beam_size hypotheses of every utterance

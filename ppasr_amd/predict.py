@@ -124,7 +124,9 @@ class PPASRPredictor:
         x_chunk = self._audio_featurizer.featurize(self.remained_wav, sample_rate)
         x_chunk = np.asarray(x_chunk, np.float32)[np.newaxis, :]
         self.cached_feat = x_chunk if self.cached_feat is None else np.concatenate([self.cached_feat, x_chunk], axis=1)
-        self.remained_wav = self.remained_wav[160 * x_chunk.shape[1]:]
+        # frames consumed x hop (10 ms) at the CALLER's sample rate (the reference's constant 160 is 10 ms at 16 kHz,
+        # predict.py:275)
+        self.remained_wav = self.remained_wav[int(round(sample_rate * 0.010)) * x_chunk.shape[1]:]
 
         decoding_chunk_size, context, subsampling = 16, 7, 4
         cached_feature_num = context - subsampling

@@ -45,7 +45,8 @@ class StreamPool:
         if feat.shape[0] > 0:
             feat = feat[np.newaxis]
             s.cached_feat = feat if s.cached_feat is None else np.concatenate([s.cached_feat, feat], axis=1)
-            s.remained_wav = s.remained_wav[160 * feat.shape[1]:]
+            hop = int(round(getattr(self.featurizer, "sample_rate", 16000) * 0.010))  # 10 ms at the featurizer's rate
+            s.remained_wav = s.remained_wav[hop * feat.shape[1]:]
 
     def step(self):
         """Advance, as often as possible, every session that holds a full 67-frame window; -> {session: result dict}

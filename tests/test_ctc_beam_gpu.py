@@ -121,3 +121,26 @@ def test_frame_lens_and_batch_api():
     for b in range(4):
         ref = _oracle_decode(lib, batch[b], beam, 0.99, 40, 0, 1)
         assert texts[b] == "".join(vocab[i] for i in ref[0][0])
+
+
+def test_unpruned_configuration_is_capped_at_128_characters_per_frame():
+    """cutoff_prob = 1.0 (the default of the Python wrappers): upstream then ignores cutoff_top_n and keeps all V
+    characters of every frame; the kernel holds 128 -- the documented deviation keeps the 128 most probable ones (cut
+    only where their cumulative probability already reaches 1 - 1e-12) instead of refusing the call.  Equals the oracle
+    run with that pruning rule; with the peaky tables below the dropped tail cannot change the best hypothesis, so it
+    also equals the oracle's genuinely unpruned decode."""
+    from ppasr_amd import _lib
+    from ppasr_amd.decoders.beam_search_decoder import beam_search_ids
+    lib = _oracle()
+    assert _lib.load().ppasr_ctc_beam_candidate_cap() == 128
+    rng = np.random.Generator(np.random.PCG64(4242))
+    T, V, beam = 40, 4233, 10
+    batch = np.stack([_probs(rng, T, V, "peaky") for _ in range(2)])
+    tokens, lens, scores, _ = beam_search_ids(torch.from_numpy(batch).cuda(), beam, 1.0, 40, 0, nbest=1)
+    torch.cuda.synchronize()
+    for b in range(2):
+        got = tokens[b, 0, :int(lens[b, 0])].cpu().tolist()
+        capped = _oracle_decode(lib, batch[b], beam, 1.0 - 1e-12, 128, 0, 1)
+        unpruned = _oracle_decode(lib, batch[b], beam, 1.0, 40, 0, 1)
+        assert got == capped[0][0] == unpruned[0][0]
+        assert abs(float(scores[b, 0]) - capped[0][1]) < 1e-3 * max(1.0, abs(capped[0][1]))
