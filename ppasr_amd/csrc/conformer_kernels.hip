@@ -12,7 +12,7 @@ namespace ppasr {
 #ifdef PPASR_PHASE_TS
 }  // namespace ppasr
 extern "C" int ppasr_debug_read_phase_ts(long long* out) {  // instrumented builds only (tools/phase_ts.py)
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_phase_ts), sizeof(long long) * 64);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_phase_ts), sizeof(long long) * 128);
 }
 extern "C" int ppasr_debug_read_wg_ts(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_wg_ts), sizeof(long long) * 2 * 1024);

@@ -38,10 +38,13 @@ constexpr int kTs256 = kG256 * 64;  // packed tile stride (f32x4 units) of a K=2
 // Optional per-phase time stamps (tools/phase_ts.py builds a second copy of the library with -DPPASR_PHASE_TS):
 // thread 0 of one workgroup in the middle of the grid records the 100 MHz wall clock at phase boundaries.
 #ifdef PPASR_PHASE_TS
-static __device__ long long g_phase_ts[64];  // one copy per translation unit (no -fgpu-rdc)
+static __device__ long long g_phase_ts[128];  // one copy per translation unit (no -fgpu-rdc); [64..128): shader clock
 #define PPASR_TS(i)                                                                              \
   do {                                                                                           \
-    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_phase_ts[i] = (long long)wall_clock64(); \
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {                                       \
+      g_phase_ts[i] = (long long)wall_clock64();                                                 \
+      g_phase_ts[64 + (i)] = (long long)clock64();                                               \
+    }                                                                                            \
   } while (0)
 static __device__ long long g_wg_ts[2 * 1024];  // [kernel 0/1][workgroup < 256][start, end] of the last launch that records them (slot 0/1, 512/513)
 #define PPASR_WG_TS(slot)                                                                                  \
@@ -130,14 +133,32 @@ struct BRing {
   f32x4 q[PF][NT];
 };
 
+// The weight stream uses BUFFER loads (buffer_load_dwordx4: SGPR resource = the wave's segment base, one constant
+// VGPR offset = lane * 16, the k-group offset in an SGPR), not global_load_dwordx4 with a 64-bit per-lane address:
+// tools/microbench_mfma.hip -- the same loop (LDS A operand, 1 KiB of B per wave per 4 MFMAs, two waves per SIMD)
+// reaches 97.7 % of the fp32-MFMA peak with buffer loads and 90 % with global loads, whatever the prefetch depth or
+// cache policy (the per-load 64-bit address arithmetic and address-register traffic of the global form steal issue
+// slots from the MFMA stream).  The segment base is made wave-uniform with readfirstlane so that the resource lives
+// in SGPRs without a waterfall loop.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wstream_rsrc(const void* p) {
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+// 16 bytes per lane at (resource base) + voff (per-lane bytes) + soff (wave-uniform bytes)
+__device__ __forceinline__ f32x4 wstream_load(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+
 // fill the ring with k-groups 0..PF-1 of the segment starting at bp (n-tile nt at bp + nt*tile_stride)
 template <int NT, int PF>
 __device__ __forceinline__ void ring_prime(BRing<NT, PF>& ring, const f32x4* __restrict__ bp, int tile_stride) {
-  const f32x4* p = bp + lane_id();
+  const __amdgpu_buffer_rsrc_t rs = wstream_rsrc(bp);
+  const int voff = lane_id() * 16;
 #pragma unroll
   for (int s = 0; s < PF; ++s)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) ring.q[s][nt] = p[(size_t)nt * tile_stride + s * 64];
+    for (int nt = 0; nt < NT; ++nt) ring.q[s][nt] = wstream_load(rs, voff, (nt * tile_stride + s * 64) * 16);
 }
 
 struct NoSide {
@@ -158,8 +179,8 @@ __device__ __forceinline__ void rb_gemm(const float* a_lds, int lda, const f32x4
   static_assert(G % PF == 0, "k-groups must be a multiple of the ring depth");
   const int lane = lane_id();
   const float* a_ptr = a_lds + (lane & 31) * lda + 4 * (lane >> 5);
-  const f32x4* b_ptr = bp + lane;
-  const f32x4* n_ptr = nxt + lane;
+  const __amdgpu_buffer_rsrc_t rs_b = wstream_rsrc(bp), rs_n = wstream_rsrc(nxt);
+  const int voff = lane * 16;
   f32x4 a_cur[MT], a_nxt[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) a_cur[mt] = *reinterpret_cast<const f32x4*>(a_ptr + mt * 32 * lda);
@@ -176,10 +197,10 @@ __device__ __forceinline__ void rb_gemm(const float* a_lds, int lda, const f32x4
     for (int nt = 0; nt < NT; ++nt) b[nt] = ring.q[s][nt];
     if (g + PF < G) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) ring.q[s][nt] = b_ptr[(size_t)nt * tile_stride + (size_t)(g + PF) * 64];
+      for (int nt = 0; nt < NT; ++nt) ring.q[s][nt] = wstream_load(rs_b, voff, (nt * tile_stride + (g + PF) * 64) * 16);
     } else if (nxt) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) ring.q[s][nt] = n_ptr[(size_t)nt * nxt_stride + (size_t)(g + PF - G) * 64];
+      for (int nt = 0; nt < NT; ++nt) ring.q[s][nt] = wstream_load(rs_n, voff, (nt * nxt_stride + (g + PF - G) * 64) * 16);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)

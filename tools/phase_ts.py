@@ -43,22 +43,27 @@ for _ in range(5):
     model.encode_greedy(x, lens)
 torch.cuda.synchronize()
 lib = _lib.load()
-acc = np.zeros(64)
+acc = np.zeros(128)
 reps = 10
 for _ in range(reps):
     model.encode_greedy(x, lens)
     torch.cuda.synchronize()
-    ts = (ctypes.c_longlong * 64)()
+    ts = (ctypes.c_longlong * 128)()
     assert lib.ppasr_debug_read_phase_ts(ts) == 0
     t = np.array(list(ts), np.float64)
-    acc += t - t[0]
+    acc[:64] += t[:64] - t[0]
+    acc[64:] += t[64:] - t[64]
 acc /= reps
 us = acc / 100.0  # 100 MHz
 print("k_conv_ffn<15,false,true> (last launch of the step), one workgroup, microseconds:")
 prev = 0.0
+cyc = acc[64:]  # shader-clock cycles since the first stamp
+prevc = 0.0
 for i in range(16):
-    print(f"  {NAMES[i]:28s} +{us[i] - prev:8.2f}   (t = {us[i]:8.2f})")
-    prev = us[i]
+    d_us, d_cyc = us[i] - prev, cyc[i] - prevc
+    ghz = f"{d_cyc / d_us / 1e3:5.2f} GHz" if d_us > 0.05 else ""
+    print(f"  {NAMES[i]:28s} +{d_us:8.2f}   (t = {us[i]:8.2f})   {ghz}")
+    prev, prevc = us[i], cyc[i]
 print("last FFN executed (macaron of the next layer): per hidden chunk, [W1(c+1) gemm + swish side] -> barrier wait -> [W2(c)]")
 for c in range(8):
     a, b = us[16 + 2 * c], us[17 + 2 * c]
@@ -83,11 +88,13 @@ print("  slowest workgroups:", [(int(i), round(float(dur[i]), 1)) for i in order
 # ---- k_attn_out_glu: phases of one workgroup + spans of all 256
 t = np.array(list(ts), np.float64)
 a = (t[32:40] - t[32]) / 100.0
-names = ["start", "Q staging", "key loop (S, softmax, PV)", "merge: stats + partial O to LDS", "barrier", "merge + bufC + barrier",
-         "out-proj + residual epilogue + barrier", "LN_conv + barrier", "pw1 value + gate + GLU store"]
+ac = t[96:104] - t[96]
+names = ["start", "Q staging", "key loop (S, softmax, PV)", "partial O -> LDS, barrier (waits for the slowest wave)",
+         "merge + bufC + barrier", "out-proj + residual epilogue + barrier", "LN_conv + barrier", "pw1 value + gate + GLU store"]
 print("k_attn_out_glu (last launch), one workgroup, microseconds:")
 for i in range(1, 8):
-    print(f"  {names[i]:40s} +{a[i] - a[i - 1]:7.2f}   (t = {a[i]:7.2f})")
+    d = a[i] - a[i - 1]
+    print(f"  {names[i]:56s} +{d:7.2f}   (t = {a[i]:7.2f})   {(ac[i] - ac[i - 1]) / d / 1e3 if d > 0.05 else 0:5.2f} GHz")
 w = np.array(list(wg), np.float64).reshape(1024, 2)[256:512] / 100.0
 ok = w[:, 1] > w[:, 0]
 w = w[ok]
