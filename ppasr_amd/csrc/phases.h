@@ -46,7 +46,11 @@ __device__ __forceinline__ void ffn_phase(const float* bufA, float* bufH, const 
     const float bias = b1[c * 256 + col];
     if (c + 1 < n_chunks) {
       acc_zero(nx);
+#ifdef PPASR_ABLATE_SWISH
+      rb_gemm<1, 1, kG256>(bufA, kLda, w1seg(c + 1), 0, w2seg(c), 0, ring, nx);
+#else
       rb_gemm<1, 1, kG256>(bufA, kLda, w1seg(c + 1), 0, w2seg(c), 0, ring, nx, SwishSide{cur[0][0], hb, bias, lane, col});
+#endif
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) hb[acc_row(r, lane) * kLda + col] = swishf(cur[0][0][r] + bias);

@@ -6,6 +6,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ppasr_amd/csrc tools/microbench_mfma.hip -o tools/mb_mfma
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -15,7 +16,7 @@ __global__ void k_pure(float* out, int iters) {
   f32x16 acc[CHAINS];
   for (int c = 0; c < CHAINS; ++c)
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-  float a = (float)threadIdx.x * 1e-3f, b = (float)blockIdx.x * 1e-3f + 1.f;
+  float a = __uint_as_float(0x3f000000u | ((threadIdx.x * 2654435761u) >> 9)) - 0.75f, b = __uint_as_float(0x3f000000u | (((blockIdx.x * 64 + threadIdx.x) * 40503u * 2654435761u) >> 9)) - 0.75f;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int j = 0; j < 16; ++j)
@@ -35,16 +36,17 @@ template <int PF, int MODE, bool DISTINCT>
 __global__ void k_mem(const f32x4* __restrict__ w, float* out, int iters) {
   constexpr bool GLOBAL = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  for (int i = threadIdx.x; i < 32 * 260; i += blockDim.x) smem[i] = (float)(i % 13) * 0.01f;
+  for (int i = threadIdx.x; i < 32 * 260; i += blockDim.x) smem[i] = __uint_as_float(0x3d000000u | ((i * 2654435761u) >> 9)) - 0.04f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* a_ptr = smem + (lane & 31) * 260 + 4 * (lane >> 5);
   const size_t wg_off = DISTINCT ? (size_t)(blockIdx.x % 16) * 64 * 8 * 32 * 64 : 0;
-  const f32x4* bp = w + wg_off + (size_t)wave * 32 * 64 + lane;
+  const size_t wave_stride = (MODE == 101) ? (size_t)8 * 32 * 64 : (size_t)32 * 64;  // 256 KB (W2-like) or 32 KB (W1-like) between waves
+  const f32x4* bp = w + wg_off + (size_t)wave * wave_stride + lane;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(w + wg_off), 0, 0x7fffffff, 0x00020000);
   auto ld = [&](const f32x4* p) -> f32x4 {
     if constexpr (MODE == 1) return *p;
-    else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((const char*)p - (const char*)(w + wg_off)), 0, MODE == 100 ? 0 : MODE));
+    else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((const char*)p - (const char*)(w + wg_off)), 0, (MODE == 100 || MODE == 101) ? 0 : MODE));
   };
   f32x4 ring[PF];
   for (int s = 0; s < PF; ++s) ring[s] = GLOBAL ? ld(bp + s * 64) : f32x4{1.f, 2.f, 3.f, 4.f};
@@ -52,7 +54,7 @@ __global__ void k_mem(const f32x4* __restrict__ w, float* out, int iters) {
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   f32x4 a_cur = *reinterpret_cast<const f32x4*>(a_ptr);
   for (int it = 0; it < iters; ++it) {
-    const f32x4* seg = bp + (size_t)((it & 7) * 8) * 32 * 64;
+    const f32x4* seg = bp + ((MODE == 101) ? (size_t)(it & 7) * 32 * 64 : (size_t)((it & 7) * 8) * 32 * 64);
 #pragma unroll
     for (int g = 0; g < 32; ++g) {
       const f32x4 a_nxt = *reinterpret_cast<const f32x4*>(a_ptr + 8 * ((g + 1) & 31));
@@ -96,6 +98,14 @@ int main() {
   const size_t wbytes = (size_t)17 * 64 * 8 * 32 * 64 * 16 + (1 << 20);
   hipMalloc(&w, wbytes);
   hipMemset(w, 0, wbytes);
+  const bool random_data = getenv("MB_RANDOM") != nullptr;   // zeros (default) or realistic operand bits
+  if (random_data) {
+    std::vector<float> hw(wbytes / 4);
+    unsigned x = 12345u;
+    for (auto& v : hw) { x = x * 1664525u + 1013904223u; v = ((int)(x >> 9) - (1 << 22)) * (1.0f / (1 << 22)) * 0.1f; }
+    hipMemcpy(w, hw.data(), wbytes, hipMemcpyHostToDevice);
+  }
+  printf("operand data: %s\n", random_data ? "random" : "zeros / constants");
   const int iters = 4000;
   for (int waves = 1; waves <= 4; waves *= 2) {
     char nm[96];
@@ -121,6 +131,7 @@ int main() {
   RUN(4, 17, false, 2, "  buffer_load sc0 sc1");
   RUN(4, 18, false, 2, "  buffer_load sc1 nt");
   RUN(4, 100, true, 2, "  buffer_load plain, every workgroup its own weights");
+  RUN(4, 101, false, 2, "  buffer_load plain, waves 256 KB apart (W2-like tiles)");
   RUN(8, 100, false, 2, "  buffer_load plain PF=8");
   return 0;
 }

@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "tools", "_ts", "libppasr_hip_ts.so")
+LIB = os.environ.get("PPASR_TS_LIB") or os.path.join(ROOT, "tools", "_ts", "libppasr_hip_ts.so")
 NAMES = {0: "start", 1: "dwconv done", 2: "LN_cm+swish", 3: "pw2 + epilogue", 4: "LN_ff", 5: "FFN (16 units)",
          6: "residual epi", 7: "LN_final + store", 8: "LN_macaron (next)", 9: "FFN_macaron (16 units)", 10: "residual epi",
          11: "x1 store + LN_mha", 12: "Q unit", 13: "K unit", 14: "V unit", 15: "end"}
