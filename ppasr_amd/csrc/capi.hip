@@ -307,6 +307,10 @@ WsLayout ws_layout(const ppasr_model_s* m, int B, int T) {
   w.fa = o; o += al(M);
   w.fp = o; o += al(M);
   w.xs = o; o += al(M * kD);  // saved full-resolution activations (Squeezeformer time reduction)
+  // values in fragment order for the fused attention route (VtOut): a key sub-block of 64 rows may start up to 7 rows
+  // before an utterance and end up to 63 rows behind the last one
+  w.vt_stride = (int)(al(M) + 128);
+  w.vt = o; o += al((size_t)kD * w.vt_stride);
   w.total = o;
   return w;
 }
@@ -388,6 +392,10 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     return squeezeformer_encode(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, ws, wl, st);
   float *y1 = ws + wl.y1, *y2 = ws + wl.y2, *xa = ws + wl.xa, *xb = ws + wl.xb, *xc = ws + wl.xc;
   float *qkv = ws + wl.qkv, *ctx = ws + wl.ctx, *g = ws + wl.g;
+  const VtOut vt_out{ws + wl.vt, wl.vt_stride};
+  // the fused attention reads whole 64-row key sub-blocks of V^T: rows outside an utterance (padding behind the last
+  // row, frames a ragged batch skips) are multiplied by p = 0 and must be finite
+  HIP_TRY(hipMemsetAsync(ws + wl.vt, 0, (size_t)kD * wl.vt_stride * sizeof(float), st));
   size_t tap_off = 0;
   auto tap = [&](const float* src, size_t n) {
     if (h->taps && tap_off + n <= h->taps_floats)
@@ -468,7 +476,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
           launch_ln_qkv(xb, qkv, L, Mi, st, ps);
         });
       } else {
-        timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st, ps); });
+        timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st, ps, fuse_attn ? vt_out : VtOut{}); });
       }
     }
     s1_done = false;
@@ -478,6 +486,8 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Tt, Tt, 0, lens, ctx, L.pos_u, L.pos_v, L.ptab, pstride,
                mul * grp, Ti, Ti, grp};
     a.pad_skip = skip ? ps.slack + 1 : 0;
+    a.vt = vt_out.vt;
+    a.vt_stride = vt_out.stride;
     if (fuse_attn) {
       timed(9, [&] { launch_attn_out_glu(a, B, xb, xc, g, L, st); });
     } else {
@@ -510,7 +520,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       timed(next ? 8 : 6, [&] {
         // with the next layer's S1 fused in, the layer output itself is only read by the debug taps: skip its store
         launch_conv_ffn(g, nullptr, xc, (next && !h->taps) ? nullptr : xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul,
-                        next, xb, qkv, st, h->desc.causal != 0, ps);
+                        next, xb, qkv, st, h->desc.causal != 0, ps, (next && fusable(i + 1)) ? vt_out : VtOut{});
       });
       s1_done = next != nullptr;
     }

@@ -121,7 +121,8 @@ struct ppasr_model_s {
 
 
 struct WsLayout {
-  size_t y1, y2, xa, xb, xc, qkv, ctx, g, rmax, rsum, fa, fp, xs, total;  // offsets in floats
+  size_t y1, y2, xa, xb, xc, qkv, ctx, g, rmax, rsum, fa, fp, xs, vt, total;  // offsets in floats
+  int vt_stride;  // row stride of the transposed values (fused attention route)
 };
 WsLayout ws_layout(const ppasr_model_s* m, int B, int T);
 // hidden-dimension slices per row block for M rows (1 = the fused kernels), see ppasr_set_ffn_split

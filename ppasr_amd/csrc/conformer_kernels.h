@@ -72,6 +72,18 @@ struct AttnArgs {
   // ragged batches: 0 = every query row / key block is computed; n > 0 = query rows behind the valid frames + (n - 1)
   // are skipped and the key loop stops after the last valid key (masked keys contribute exact zeros either way)
   int pad_skip;
+  // fused route (k_attn_out_glu) only: the values in MFMA-fragment order (written by the QKV stage, see VtOut) with
+  // room for vt_stride rows; a.v is not read then
+  const float* vt = nullptr;
+  int vt_stride = 0;
+};
+// Where the QKV stage puts the values when the layer's attention runs fused: in the order the attention's P V MFMAs
+// consume them, [8 slabs of 32 columns][stride / 8 row octets][64 lanes = column + 32 * (row quad)][4 rows] -- 1 KiB
+// contiguous per wave store / load; stride (rows of the batch) >= 32 * row blocks + 64, a multiple of 8.
+// nullptr: row-major in qkv
+struct VtOut {
+  float* vt = nullptr;
+  int stride = 0;
 };
 
 // ---- launchers (all asynchronous on `st`) ----
@@ -91,7 +103,7 @@ void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, fl
 void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, float* out, int M, int K, int n_cols_padded,
                   int ldc, int n_valid, hipStream_t st);
 void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
-                    const PadSkip& ps = PadSkip{});
+                    const PadSkip& ps = PadSkip{}, VtOut vt = VtOut{});
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
                     const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps = PadSkip{},
@@ -99,7 +111,8 @@ void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, floa
 // next != nullptr: also run the following layer's S1 (writes x1_next, qkv_next) in the same launch
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                      const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,
-                     float* x1_next, float* qkv_next, hipStream_t st, bool causal = true, const PadSkip& ps = PadSkip{});
+                     float* x1_next, float* qkv_next, hipStream_t st, bool causal = true, const PadSkip& ps = PadSkip{},
+                     VtOut vt_next = VtOut{});
 // ---- split route for under-filled grids (see conformer_kernels.hip): the layer tail cut at its FFNs, each FFN's hidden
 // dimension split over S (1, 2, 4 or 8; a divisor of n_chunks) workgroups per row block ----
 void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float* x3, const LayerW& w, const int64_t* lens,

@@ -14,6 +14,9 @@ namespace ppasr {
 extern "C" int ppasr_debug_read_phase_ts(long long* out) {  // instrumented builds only (tools/phase_ts.py)
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_phase_ts), sizeof(long long) * 128);
 }
+extern "C" int ppasr_debug_read_wave_ts(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_wave_ts), sizeof(long long) * 256);
+}
 extern "C" int ppasr_debug_read_wg_ts(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_wg_ts), sizeof(long long) * 2 * 1024);
 }
@@ -304,7 +307,7 @@ struct QkvStoreSide {
 // `ring` must already stream w.ffm_w1 (tile `wave`).
 __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bufH, float* __restrict__ x1,
                                              float* __restrict__ qkv, const LayerW& w, int r0, int valid, int n_chunks,
-                                             BRing<1>& ring) {
+                                             BRing<1>& ring, VtOut vt = VtOut{}) {
   const int lane = lane_id(), wave = wave_id();
   rb_layernorm(bufX, bufA, kLda, kRows, w.ln_mac_g, w.ln_mac_b, 1e-5f);
   __syncthreads();
@@ -339,7 +342,19 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
     }
     PPASR_TS(12 + c);
   }
-  {
+  if (vt.vt) {
+    // fused attention route: V in the order the attention's P V MFMAs consume it -- [slab = 32 value columns (this
+    // wave's)][row octet][lane = column + 32 * (row quad of the octet)][4 rows]: a lane's register quad i (rows 8i +
+    // 4hh .. +3 of its column) is one 16-byte piece and the wave's 64 pieces are 1 KiB contiguous, on the store side
+    // here and on the load side there (rows >= valid of the last block land in the padding behind row M)
+    const float bv = w.bqkv[2 * 256 + wave * 32 + (lane & 31)];
+    float* dst = vt.vt + ((size_t)wave * (vt.stride >> 3) + (r0 >> 3)) * 256 + 4 * lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x16& t = tile[2][0][0];
+      *reinterpret_cast<f32x4*>(dst + i * 256) = f32x4{t[4 * i] + bv, t[4 * i + 1] + bv, t[4 * i + 2] + bv, t[4 * i + 3] + bv};
+    }
+  } else {
     const int col = 2 * 256 + wave * 32 + (lane & 31);
     const float bv = w.bqkv[col];
 #pragma unroll
@@ -351,7 +366,8 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
 }
 
 __global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ x_in, float* __restrict__ x1,
-                                                      float* __restrict__ qkv, LayerW w, int M, int n_chunks, PadSkip ps) {
+                                                      float* __restrict__ qkv, LayerW w, int M, int n_chunks, PadSkip ps,
+                                                      VtOut vt) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
   float* bufX = smem;
@@ -363,13 +379,13 @@ __global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ 
   BRing<1> ring;
   ring_prime(ring, w.ffm_w1 + (size_t)wave * kTs256, 0);
   rb_load_rows(bufX, kLda, x_in + (size_t)r0 * kD, kRows, valid);
-  ffn_qkv_body(bufX, bufA, bufH, x1, qkv, w, r0, valid, n_chunks, ring);
+  ffn_qkv_body(bufX, bufA, bufH, x1, qkv, w, r0, valid, n_chunks, ring, vt);
 }
 constexpr size_t kLdsFfnQkv = 4 * kRows * kLda * sizeof(float);
 void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
-                    const PadSkip& ps) {
+                    const PadSkip& ps, VtOut vt) {
   PPASR_LAUNCH(k_ffn_qkv, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsFfnQkv, st, x_in, x1, qkv, w, M,
-                     n_chunks, ps);
+                     n_chunks, ps, vt);
 }
 
 // -------------------------------------------------------------------------------------
@@ -800,14 +816,14 @@ constexpr int kPLd = 68;                       // private score-tile row stride:
 constexpr int kPTile = 32 * kPLd;              // floats per wave
 constexpr int kFusedAttnFloats = kWaves * kPTile + kWaves * 64 + kRows * kLda;
 static_assert(2 * kRows * kLda <= kWaves * kPTile + kWaves * 64, "bufX/bufA alias the attention scratch");
-static_assert(32 * 65 <= kPTile, "merge scratch fits a wave's score tile");
+static_assert(kRows * kLda + 4 * kPTile <= kWaves * kPTile, "Q'_v and the four merge tiles fit in front of Stat");
 static_assert(kFusedAttnFloats * 4 <= 160 * 1024, "LDS budget");
 __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, const float* __restrict__ x1,
                                                            float* __restrict__ x2, float* __restrict__ g, LayerW w) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ps = smem;                          // [8 waves][32][68] private score / probability tiles
+  float* Ps = smem;                          // [32][260] Q'_v = q + pos_bias_v, then 4 merge tiles [head][32][68]
   float* Stat = Ps + kWaves * kPTile;        // [8 waves][2][32]: running max, running sum of each wave's key half
-  float* bufC = Stat + kWaves * 64;          // [32][260] context rows, all heads
+  float* bufC = Stat + kWaves * 64;          // [32][260] Q'_u = q + pos_bias_u during the key loop, then the context rows
   float* bufX = smem;                        // out phase (aliases the tiles)
   float* bufA = bufX + kRows * kLda;
   const int lane = lane_id(), wave = wave_id();
@@ -836,7 +852,8 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
     if (q0 >= min((int64_t)T, n_valid + (a.pad_skip - 1))) return;  // whole row block behind the needed frames
     T2 = (int)max((int64_t)1, min((int64_t)T2, n_valid));
   }
-  float* P = Ps + wave * kPTile;
+  float* QV = Ps;
+  float* P = Ps + kRows * kLda + (wave >> 1) * kPTile;  // merge tile of this wave's head (behind QV)
   BRing<1> ring;
   const f32x4* seg_o = w.wo + (size_t)wave * kTs256;
   const f32x4* seg_val = w.pw1 + (size_t)wave * kTs256;
@@ -846,205 +863,256 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
   PPASR_TS(32);
   PPASR_WG_TS(512 + 0);
 
-  // ---- Q' fragments in registers: qa[gk][j] = Q'[row l31][8 gk + 4 hh + j], Q' = [q+u | q+v] ----
-  f32x4 qa[NG];
+  // ---- key loop: flash attention on TRANSPOSED score tiles, everything between the two MFMA phases in registers ----
+  // S^T = K' Q'^T: the K' fragment is the MFMA's A operand and the Q' fragment its B operand, so a lane holds, for ITS
+  // query row l31, the scores of 16 keys per 32-key tile (key = (r&3) + 8(r>>2) + 4hh).  The row maximum / sum are
+  // then in-lane reductions plus ONE exchange with lane^32, the probabilities never leave the accumulator registers --
+  // p[t][4i+j] is exactly the B operand (k slot (hh, j)) of the i-th k-group of O^T += V^T P^T -- and the running
+  // rescale of O^T (lane = query row again) is a per-lane multiply.  (The row-major form went through a private LDS
+  // score tile: 32 ds_write_b32 + 16 ds_read_b128 + 8 ds_write_b128 + 16 ds_bpermute per 64 keys; every VALU / LDS
+  // instruction issued on a SIMD takes its issue cycles away from that SIMD's MFMA pipe -- tools/microbench_mfma.hip.)
+  // The keys are walked in the row space of the whole batch (row m = b*T + key) from the utterance's first row rounded
+  // DOWN to a multiple of 8: the values (a.vt, written by the QKV stage in fragment order: [32-column slab][row
+  // octet][64 lanes][4 rows]) are then read like the packed weights, 1 KiB contiguous per wave-load, whole cache lines;
+  // the <= 7 rows in front (u < shift) are masked like the keys >= kv_end.
+  const int mrow0 = b * T;
+  const int shift = mrow0 & 7;
+  int kv_end = (int)min((int64_t)T2, max((int64_t)0, (len_b + a.mask_mul - 1) / a.mask_mul));  // keys >= kv_end are PAD
+  const int U = kv_end > 0 ? kv_end + shift : 0;  // shifted key space: u = key + shift in [0, U)
+  constexpr float kScale = 0.125f * 1.4426950408889634f;  // 1/sqrt(dk) * log2(e): p = 2^(s*kScale - m*kScale)
+  const __amdgpu_buffer_rsrc_t rs_k = wstream_rsrc(kbp + h * 64), rs_p = wstream_rsrc(ptab + h * 64),
+                               rs_v = wstream_rsrc(a.vt + ((size_t)(2 * h) * (a.vt_stride >> 3) + ((mrow0 - shift) >> 3)) * 256);
+  const int voff_v = lane * 16;
+  const int kstride_b = a.k_stride * 4, pstride_b = pstride * kD * 4;
+  // byte offsets of this lane's two keys (tile 0 / 1) of the sub-block at u0, in K and in the positional table
+  int vk[2], vp[2];
+  auto key_offsets = [&](int u0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int key = min(max(u0 - shift + 32 * t + l31, 0), kv_end - 1);  // out-of-range keys are masked afterwards
+      vk[t] = key * kstride_b + 16 * hh;
+      vp[t] = key * pstride_b + 16 * hh;
+    }
+  };
+  // K' fragment of k-group gk (features 8gk + 4hh .. +3 of [k | p]) of this lane's key of tile t
+  auto kfrag = [&](int t, int gk) -> f32x4 {
+    return gk < 8 ? wstream_load(rs_k, vk[t], gk * 32) : wstream_load(rs_p, vp[t], (gk - 8) * 32);
+  };
+  // K' operands in bursts of 4 k-groups (= one whole 128-byte line of each key row: a lane's 16-byte pieces of 4
+  // consecutive k-groups are requested back to back, so the line is fetched from L2 once; one k-group at a time the
+  // 8 waves push 64 KiB through the 32 KiB L1 between two uses of a line and every line is fetched 4 times), double
+  // buffered: super-group sg + 1 is in flight while sg feeds the MFMAs
+  f32x4 kq[2][4][2];
+  auto load_sg = [&](int buf, int sg) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      kq[buf][i][0] = kfrag(0, 4 * sg + i);
+      kq[buf][i][1] = kfrag(1, 4 * sg + i);
+    }
+  };
+  auto prime_k = [&](int u0) {
+    key_offsets(u0);
+    load_sg(0, 0);
+  };
+#ifndef PPASR_ATT_KPRE
+#define PPASR_ATT_KPRE 0
+#endif
+#ifndef PPASR_ATT_VPRE
+#define PPASR_ATT_VPRE 0
+#endif
+  if (PPASR_ATT_KPRE && khalf * 128 < U) prime_k(khalf * 128);
+
+  // ---- Q' = [q + pos_bias_u | q + pos_bias_v] of the block's 32 query rows -> LDS (bufC / QV); the key loop reads
+  // its B-operand fragment Q'[row l31][8 gk + 4 hh .. +3] from there, one ds_read_b128 per k-group ----
   {
-    // the block's query rows go through LDS (bufC is free until the merge): whole 1 KiB rows per wave-load instead of
-    // 64 scattered 16-byte pieces per fragment load
+    const f32x4 pu = *reinterpret_cast<const f32x4*>(a.pos_u + 4 * lane), pv = *reinterpret_cast<const f32x4*>(a.pos_v + 4 * lane);
     for (int row = wave; row < kRows; row += kWaves) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row < valid) v = *reinterpret_cast<const f32x4*>(qb + (size_t)(q0 + row) * a.q_stride + 4 * lane);
-      *reinterpret_cast<f32x4*>(bufC + row * kLda + 4 * lane) = v;
+      *reinterpret_cast<f32x4*>(bufC + row * kLda + 4 * lane) = v + pu;
+      *reinterpret_cast<f32x4*>(QV + row * kLda + 4 * lane) = v + pv;
     }
     __syncthreads();
-    const float* qrow = bufC + l31 * kLda + h * 64 + 4 * hh;
-#pragma unroll
-    for (int gq = 0; gq < 8; ++gq) {
-      const f32x4 q = *reinterpret_cast<const f32x4*>(qrow + 8 * gq);
-      const f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + h * 64 + 8 * gq + 4 * hh);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + h * 64 + 8 * gq + 4 * hh);
-      qa[gq] = q + u;
-      qa[gq + 8] = q + v;
-    }
   }
+  const float* qfrag_u = bufC + l31 * kLda + h * 64 + 4 * hh;
+  const float* qfrag_v = QV + l31 * kLda + h * 64 + 4 * hh;
+  auto qfrag = [&](int gk) -> f32x4 {
+    return *reinterpret_cast<const f32x4*>(gk < 8 ? qfrag_u + 8 * gk : qfrag_v + 8 * (gk - 8));
+  };
   PPASR_TS(33);
-  // K' fragment of k-group gk for key j: features 8gk + 4hh .. +3; the first 8 groups from k, the rest from p
-  auto kfrag = [&](int j, int gk) -> f32x4 {
-    const int jc = min(j, T2 - 1);  // keys >= T2 are masked afterwards
-    const float* base = (gk < 8) ? kbp + (size_t)jc * a.k_stride + h * 64 + 8 * gk + 4 * hh
-                                 : ptab + (size_t)jc * pstride * kD + h * 64 + 8 * (gk - 8) + 4 * hh;
-    return *reinterpret_cast<const f32x4*>(base);
-  };
-  // K' fragments of a sub-block's first PF k-groups: requested one sub-block ahead (right before the previous
-  // sub-block's PV phase, when the score accumulators are dead) so that their L2 round trip hides behind PV
-  f32x4 ringk[PF][2];
-  auto prime_k = [&](int k0) {
-#pragma unroll
-    for (int sx = 0; sx < PF; ++sx) {
-      ringk[sx][0] = kfrag(k0 + l31, sx);
-      ringk[sx][1] = kfrag(k0 + l31 + 32, sx);
-    }
-  };
-  if (khalf * 128 < T2) prime_k(khalf * 128);
-  f32x16 acc_o[2];
+  if (!PPASR_ATT_KPRE && khalf * 128 < U) prime_k(khalf * 128);
+  f32x16 acc_o[2];  // O^T: acc_o[ct][r] = O[query l31][h*64 + 32ct + (r&3) + 8(r>>2) + 4hh]
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_o[t][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;  // of row l31 (both lane halves hold the same values)
+  float m_run = -INFINITY, l_run = 0.f;  // raw-score running max / running sum of row l31 (same in both lane halves)
+  bool first = true;
 
-  const int nkb = (T2 + 255) / 256;
+  const int nkb = (U + 255) / 256;
   for (int kb = 0; kb < nkb; ++kb) {
     for (int sb = 0; sb < 2; ++sb) {
-      const int key0 = kb * 256 + khalf * 128 + sb * 64;
-      if (key0 >= T2) break;  // wave-uniform
-      // the sub-block this wave handles next (wave-uniform), or -1
-      int key_next = sb == 0 ? key0 + 64 : (kb + 1) * 256 + khalf * 128;
-      if (key_next >= T2) key_next = (sb == 0 && (kb + 1) * 256 + khalf * 128 < T2) ? (kb + 1) * 256 + khalf * 128 : -1;
-      // ---- S = Q' K'^T for 64 keys (two 32-key tiles, two independent accumulator chains) ----
-      const int jk0 = key0 + l31, jk1 = jk0 + 32;
+      const int u0 = kb * 256 + khalf * 128 + sb * 64;
+      if (u0 >= U) break;  // wave-uniform
+      int u_next = sb == 0 ? u0 + 64 : (kb + 1) * 256 + khalf * 128;
+      if (u_next >= U) u_next = (sb == 0 && (kb + 1) * 256 + khalf * 128 < U) ? (kb + 1) * 256 + khalf * 128 : -1;
+      const bool edge = (u0 < shift) || (u0 + 64 > U);  // sub-block holds masked keys (wave-uniform)
+      if (kb == 0) PPASR_WAVE_TS(16 + 4 * sb);
+      // V^T operands of the first PQ k-groups: requested before the score MFMAs, consumed after the softmax.  k-group q = (tile t = q >> 2,
+      // i = q & 3) covers the keys u0 + 32t + 8i + 4hh .. +3; vt[q][ct] = those 4 keys of value column 32ct + l31
+      const int soff_v = (u0 >> 3) * 1024, soff_v1 = soff_v + (a.vt_stride >> 3) * 1024;
+      auto vload = [&](int q, int ct) -> f32x4 { return wstream_load(rs_v, voff_v, (ct ? soff_v1 : soff_v) + q * 1024); };
+      // (all 8 k-groups in one burst: 4 consecutive k-groups share the 128-byte lines of their columns)
+      constexpr int PQ = 8;
+      f32x4 ringv[PQ][2];
+      auto prime_v = [&]() {
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+          ringv[q][0] = vload(q, 0);
+          ringv[q][1] = vload(q, 1);
+        }
+      };
+      if (PPASR_ATT_VPRE) prime_v();
+      // ---- S^T = K' Q'^T for 64 keys (two 32-key tiles, two independent accumulator chains) ----
       f32x16 acc_s[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_s[t][r] = 0.f;
+      {
+        f32x4 q_cur = qfrag(0), q_nxt = q_cur;
 #pragma unroll
-      for (int gk = 0; gk < NG; ++gk) {
-        const f32x4 b0 = ringk[gk % PF][0], b1 = ringk[gk % PF][1];
-        if (gk + PF < NG) {
-          ringk[gk % PF][0] = kfrag(jk0, gk + PF);
-          ringk[gk % PF][1] = kfrag(jk1, gk + PF);
+        for (int sg = 0; sg < 4; ++sg) {
+          if (sg + 1 < 4) load_sg((sg + 1) & 1, sg + 1);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int gk = 4 * sg + i;
+            if (gk + 1 < NG) q_nxt = qfrag(gk + 1);
+            const f32x4 k0 = kq[sg & 1][i][0], k1 = kq[sg & 1][i][1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              acc_s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[j], q_cur[j], acc_s[0], 0, 0, 0);
+              acc_s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[j], q_cur[j], acc_s[1], 0, 0, 0);
+            }
+            q_cur = q_nxt;
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
+      }
+      if (kb == 0) PPASR_WAVE_TS(17 + 4 * sb);
+      if (!PPASR_ATT_VPRE) prime_v();
+      // ---- online softmax in registers ----
+      if (edge) {
+        // element r of tile t is key u = u0 + 4hh + c with c = 32t + (r&3) + 8(r>>2): masked iff c < lo or c >= hi
+        const int lo = shift - u0 - 4 * hh, hi = U - u0 - 4 * hh;
+        if (u0 < shift) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < lo) acc_s[0][r] = -INFINITY;  // shift <= 7: only the first register quad of tile 0 can be hit
+        }
+        if (u0 + 64 > U) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (32 * t + (r & 3) + 8 * (r >> 2) >= hi) acc_s[t][r] = -INFINITY;
+        }
+      }
+      float bm = max3f(acc_s[0][0], acc_s[0][1], acc_s[0][2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) bm = max3f(bm, acc_s[0][r], acc_s[0][r + 1]);
+      bm = max3f(bm, acc_s[0][15], acc_s[1][0]);
+#pragma unroll
+      for (int r = 1; r < 15; r += 2) bm = max3f(bm, acc_s[1][r], acc_s[1][r + 1]);
+      bm = fmaxf(bm, acc_s[1][15]);
+      bm = fmaxf(bm, __shfl_xor(bm, 32));
+      const float m_new = fmaxf(m_run, bm);
+      const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;  // every key so far masked: p = 0, alpha irrelevant (O = 0)
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_safe) * kScale);
+      const float mb = -m_safe * kScale;
+      f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 e = f32x2{acc_s[t][r], acc_s[t][r + 1]} * f32x2{kScale, kScale} + f32x2{mb, mb};  // v_pk_fma_f32
+          acc_s[t][r] = __builtin_amdgcn_exp2f(e[0]);
+          acc_s[t][r + 1] = __builtin_amdgcn_exp2f(e[1]);
+          ps2 += f32x2{acc_s[t][r], acc_s[t][r + 1]};
+        }
+      float ps = ps2[0] + ps2[1];
+      ps += __shfl_xor(ps, 32);
+      m_run = m_new;
+      l_run = l_run * alpha + ps;
+      if (u_next >= 0) prime_k(u_next);
+      if (kb == 0) PPASR_WAVE_TS(18 + 4 * sb);
+      // ---- O^T = O^T * alpha + V^T P^T ----
+      if (!first) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const f32x2 o = f32x2{acc_o[ct][r], acc_o[ct][r + 1]} * f32x2{alpha, alpha};  // v_pk_mul_f32
+            acc_o[ct][r] = o[0];
+            acc_o[ct][r + 1] = o[1];
+          }
+      }
+      first = false;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 v0 = ringv[q][0], v1 = ringv[q][1];
+        // (rows outside the utterance meet p = 0 exactly; they hold finite values -- other utterances' rows, or the zeros
+        //  ppasr_encode clears the buffer to -- so no select is needed on the values)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc_s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[gk][j], b0[j], acc_s[0], 0, 0, 0);
-          acc_s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[gk][j], b1[j], acc_s[1], 0, 0, 0);
+          const float pj = acc_s[q >> 2][4 * (q & 3) + j];
+          acc_o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[j], pj, acc_o[0], 0, 0, 0);
+          acc_o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[j], pj, acc_o[1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      // V operands of this sub-block's first groups: requested now, consumed after the softmax
-      const float* vcol = vbp + h * 64 + l31;
-      auto vval = [&](int key, int ct) -> float { return vcol[(size_t)min(key, T2 - 1) * a.v_stride + ct * 32]; };
-      constexpr int PQ = 2;
-      float ringv[PQ][4][2];
-#pragma unroll
-      for (int sx = 0; sx < PQ; ++sx)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct) ringv[sx][j][ct] = vval(key0 + 8 * sx + 4 * hh + j, ct);
-      // ---- scores -> private LDS tile (masked, scaled) ----
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int key = key0 + t * 32 + l31;
-        const bool masked = (key >= T2) || (a.mask_mul * (int64_t)key >= len_b);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) P[acc_row(r, lane) * kPLd + t * 32 + l31] = masked ? -INFINITY : acc_s[t][r] * 0.125f;
-      }
-      // ---- online softmax: lane (row l31, half hh) owns 32 scores of its row ----
-      float alpha;
-      {
-        float* prow = P + l31 * kPLd + hh * 32;
-        f32x4 sv[8];
-        float bm = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          sv[i] = *reinterpret_cast<const f32x4*>(prow + 4 * i);
-          bm = fmaxf(bm, fmaxf(fmaxf(sv[i][0], sv[i][1]), fmaxf(sv[i][2], sv[i][3])));
-        }
-        bm = fmaxf(bm, __shfl_xor(bm, 32));
-        const float m_new = fmaxf(m_run, bm);
-        float ps = 0.f;
-        alpha = 1.f;
-        if (m_new != -INFINITY) {
-          alpha = __expf(m_run - m_new);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              sv[i][e] = __expf(sv[i][e] - m_new);
-              ps += sv[i][e];
-            }
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) sv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        ps += __shfl_xor(ps, 32);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(prow + 4 * i) = sv[i];
-        m_run = m_new;
-        l_run = l_run * alpha + ps;
-      }
-      if (key_next >= 0) prime_k(key_next);
-      // ---- O = O * alpha + P V (alpha of row r lives in lane r) ----
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float ar = __shfl(alpha, acc_row(r, lane));
-        acc_o[0][r] *= ar;
-        acc_o[1][r] *= ar;
-      }
-      {
-        const float* a_ptr = P + l31 * kPLd + 4 * hh;
-        f32x4 a_cur = *reinterpret_cast<const f32x4*>(a_ptr), a_nxt = a_cur;
-#pragma unroll
-        for (int gq = 0; gq < 8; ++gq) {
-          if (gq + 1 < 8) a_nxt = *reinterpret_cast<const f32x4*>(a_ptr + 8 * (gq + 1));
-          float bv[4][2];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) bv[j][ct] = ringv[gq % PQ][j][ct];
-          if (gq + PQ < 8) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int ct = 0; ct < 2; ++ct) ringv[gq % PQ][j][ct] = vval(key0 + 8 * (gq + PQ) + 4 * hh + j, ct);
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc_o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], bv[j][0], acc_o[0], 0, 0, 0);
-            acc_o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], bv[j][1], acc_o[1], 0, 0, 0);
-          }
-          a_cur = a_nxt;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+      if (kb == 0) PPASR_WAVE_TS(19 + 4 * sb);
     }
   }
   PPASR_TS(34);
   // ---- merge the two key halves of every head, normalise -> bufC ----
-  if (hh == 0) {
-    Stat[wave * 64 + l31] = m_run;
-    Stat[wave * 64 + 32 + l31] = l_run;
-  }
+  // wave 2h+1 hands its O^T (row-major in its scratch tile: [query][64], 4 consecutive columns per register quad)
+  // and (m, l) to wave 2h; lane = query row on both sides, so the merge factors are per-lane scalars
   if (khalf == 1) {
+    if (hh == 0) {
+      Stat[wave * 64 + l31] = m_run;
+      Stat[wave * 64 + 32 + l31] = l_run;
+    }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) P[acc_row(r, lane) * 65 + t * 32 + l31] = acc_o[t][r];
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4*>(P + l31 * kPLd + 32 * ct + 8 * i + 4 * hh) =
+            f32x4{acc_o[ct][4 * i], acc_o[ct][4 * i + 1], acc_o[ct][4 * i + 2], acc_o[ct][4 * i + 3]};
   }
   ring_prime(ring, seg_o, 0);  // out-projection weights in flight across the barrier
   __syncthreads();
   PPASR_TS(35);
   if (khalf == 0) {
-    const float* P1 = Ps + (wave + 1) * kPTile;
+    const float* P1 = P;  // written by wave 2h+1
+    const float m1 = Stat[(wave + 1) * 64 + l31], l1 = Stat[(wave + 1) * 64 + 32 + l31];
+    const float m = fmaxf(m_run, m1);
+    const float e0 = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m) * kScale);
+    const float e1 = (m1 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m1 - m) * kScale);
+    const float l = l_run * e0 + l1 * e1;
+    float inv = (l > 0.f) ? 1.0f / l : 0.f;  // fully masked row -> 0 (attention.py:118)
+    if (l31 >= valid) inv = 0.f;
+    const float f0 = e0 * inv, f1 = e1 * inv;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = acc_row(r, lane);
-      const float m0 = Stat[wave * 64 + row], l0 = Stat[wave * 64 + 32 + row];
-      const float m1 = Stat[(wave + 1) * 64 + row], l1 = Stat[(wave + 1) * 64 + 32 + row];
-      const float m = fmaxf(m0, m1);
-      const float e0 = (m0 == -INFINITY) ? 0.f : __expf(m0 - m);
-      const float e1 = (m1 == -INFINITY) ? 0.f : __expf(m1 - m);
-      const float l = l0 * e0 + l1 * e1;
-      const float inv = (l > 0.f) ? 1.0f / l : 0.f;  // fully masked row -> 0 (attention.py:118)
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const float o = (acc_o[t][r] * e0 + P1[row * 65 + t * 32 + l31] * e1) * inv;
-        bufC[row * kLda + h * 64 + t * 32 + l31] = (row < valid) ? o : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 o1 = *reinterpret_cast<const f32x4*>(P1 + l31 * kPLd + 32 * ct + 8 * i + 4 * hh);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc_o[ct][4 * i + e] * f0 + o1[e] * f1;
+        *reinterpret_cast<f32x4*>(bufC + l31 * kLda + h * 64 + 32 * ct + 8 * i + 4 * hh) = o;
       }
-    }
   }
   __syncthreads();
   PPASR_TS(36);
@@ -1326,7 +1394,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
                                                        const float* __restrict__ x2, float* __restrict__ x_out, LayerW w,
                                                        const int64_t* __restrict__ lens, int M, int Tp, int n_chunks,
                                                        int mask_mul, LayerW wn, float* __restrict__ x1_next,
-                                                       float* __restrict__ qkv_next, int left_ctx, PadSkip ps) {
+                                                       float* __restrict__ qkv_next, int left_ctx, PadSkip ps, VtOut vt_next) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
   float* bufX = smem;
@@ -1417,27 +1485,27 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   // rb_layernorm and rb_store_rows use the same wave->row mapping: no barrier needed
   if (x_out) rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);  // (nullptr: nobody reads it, see capi.hip)
   PPASR_TS(7);
-  if (NEXT) ffn_qkv_body(bufX, bufA, bufH, x1_next, qkv_next, wn, r0, valid, n_chunks, ring);
+  if (NEXT) ffn_qkv_body(bufX, bufA, bufH, x1_next, qkv_next, wn, r0, valid, n_chunks, ring, vt_next);
   PPASR_TS(15);
   if (NEXT) PPASR_WG_TS(1);
 }
 constexpr size_t kLdsConvFfn = 4 * kRows * kLda * sizeof(float);
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                      const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,
-                     float* x1_next, float* qkv_next, hipStream_t st, bool causal, const PadSkip& ps) {
+                     float* x1_next, float* qkv_next, hipStream_t st, bool causal, const PadSkip& ps, VtOut vt_next) {
   dim3 grid((M + kRows - 1) / kRows);
   const int left_ctx = causal ? ksize - 1 : (ksize - 1) / 2;
   const LayerW& wn = next ? *next : w;
 #define LAUNCH_CF(KS)                                                                                                  \
   if (g_hist)                                                                                                          \
     PPASR_LAUNCH((k_conv_ffn<KS, true, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
-                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps);                                    \
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps, vt_next);                                    \
   else if (next)                                                                                                       \
     PPASR_LAUNCH((k_conv_ffn<KS, false, true>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
-                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps);                                    \
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps, vt_next);                                    \
   else                                                                                                                 \
     PPASR_LAUNCH((k_conv_ffn<KS, false, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, \
-                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps);
+                       lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps, vt_next);
   if (ksize == 15) {
     LAUNCH_CF(15)
   } else if (ksize == 31) {

@@ -56,10 +56,12 @@ __device__ __forceinline__ void ffn_phase(const float* bufA, float* bufH, const 
       for (int r = 0; r < 16; ++r) hb[acc_row(r, lane) * kLda + col] = swishf(cur[0][0][r] + bias);
     }
     if (c < 8) PPASR_TS(16 + 2 * c);
+    if (c < 8) PPASR_WAVE_TS(2 * c);
 #ifndef PPASR_ABLATE_FFN_BARRIER
     __syncthreads();
 #endif
     if (c < 8) PPASR_TS(17 + 2 * c);
+    if (c < 8) PPASR_WAVE_TS(2 * c + 1);
     const f32x4* nseg = (c + 2 < n_chunks) ? w1seg(c + 2) : (c + 1 < n_chunks ? w2seg(c + 1) : after);
     rb_gemm<1, 1, kG256>(hb, kLda, w2seg(c), 0, nseg, 0, ring, acc2);
     cur[0][0] = nx[0][0];

@@ -24,6 +24,15 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));  // v_pk_{add,mul,fma}_f32 operands
+
+// max(a, b, c) in ONE VALU instruction.  fmaxf() on MFMA results also emits a canonicalising v_max_f32 x, x per operand
+// (IEEE sNaN quieting); in an MFMA-bound kernel every VALU instruction costs matrix-pipe issue cycles.
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float d;
+  asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 
 namespace ppasr {
 
@@ -46,6 +55,12 @@ static __device__ long long g_phase_ts[128];  // one copy per translation unit (
       g_phase_ts[64 + (i)] = (long long)clock64();                                               \
     }                                                                                            \
   } while (0)
+static __device__ long long g_wave_ts[256];  // [slot < 32][wave < 8]: per-wave stamps of one workgroup (PPASR_WAVE_TS)
+#define PPASR_WAVE_TS(slot)                                                                          \
+  do {                                                                                               \
+    if (blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0)                                      \
+      g_wave_ts[(slot) * 8 + (threadIdx.x >> 6)] = (long long)wall_clock64();                        \
+  } while (0)
 static __device__ long long g_wg_ts[2 * 1024];  // [kernel 0/1][workgroup < 256][start, end] of the last launch that records them (slot 0/1, 512/513)
 #define PPASR_WG_TS(slot)                                                                                  \
   do {                                                                                                     \
@@ -53,11 +68,14 @@ static __device__ long long g_wg_ts[2 * 1024];  // [kernel 0/1][workgroup < 256]
   } while (0)
 #else
 #define PPASR_TS(i) do { } while (0)
+#define PPASR_WAVE_TS(slot) do { } while (0)
 #define PPASR_WG_TS(slot) do { } while (0)
 #endif
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+// wave-uniform by construction; readfirstlane tells the compiler so (everything derived from it -- weight segment
+// pointers, buffer-load offsets -- then lives in SGPRs instead of per-lane VALU arithmetic / waterfall loops)
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
 // Optional skipping of padding rows of a ragged batch (ppasr_set_skip_padding): utterance b occupies `Tp` time steps
 // of `unit` rows each, time step t is valid iff mul*t < lens[b], and only the first need(b) = min(Tp, valid + slack)

@@ -71,6 +71,194 @@ __global__ void k_mem(const f32x4* __restrict__ w, float* out, int iters) {
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// The FFN chunk loop of phases.h in miniature: unit 1 = A(buf0) x W1 tile -> acc1 (optionally with the swish side
+// writes of the previous tile into buf1), [barrier], unit 2 = A(buf1) x W2 tile -> acc2.  Buffer-load weight ring.
+//   BAR: workgroup barrier between the units (as ffn_phase has)    SIDE: swish side work    FUSE: both units as ONE
+//   64-k-group stream with interleaved k-groups and two accumulator chains (no transition in the middle)
+template <bool BAR, int SIDE, bool FUSE>
+__global__ void k_ffnlike(const f32x4* __restrict__ w, float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* buf0 = smem;
+  float* buf1 = smem + 32 * 260;
+  for (int i = threadIdx.x; i < 2 * 32 * 260; i += blockDim.x) smem[i] = __uint_as_float(0x3d000000u | ((i * 2654435761u) >> 9)) - 0.04f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* a0 = buf0 + (lane & 31) * 260 + 4 * (lane >> 5);
+  const float* a1 = buf1 + (lane & 31) * 260 + 4 * (lane >> 5);
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 0x7fffffff, 0x00020000);
+  const int voff = lane * 16 + wave * 32 * 64 * 16;
+  constexpr int PF = 4;
+  f32x4 ring[PF];
+  int pos = 0;  // k-group counter of the weight stream
+  auto ld = [&](int g) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, ((g & 2047) * 64) * 16 * 8 / 8, 0)); };
+  for (int s = 0; s < PF; ++s) ring[s] = ld(s);
+  f32x16 acc1, acc2, prev;
+  float live = 0.f;
+  for (int r = 0; r < 16; ++r) acc1[r] = acc2[r] = prev[r] = 0.f;
+  const int col = wave * 32 + (lane & 31);
+  for (int it = 0; it < iters; ++it) {
+    if (!FUSE) {
+      f32x4 a_cur = *reinterpret_cast<const f32x4*>(a0);
+#pragma unroll
+      for (int g = 0; g < 32; ++g) {
+        const f32x4 a_nxt = *reinterpret_cast<const f32x4*>(a0 + 8 * ((g + 1) & 31));
+        const f32x4 b = ring[g % PF];
+        ring[g % PF] = ld(pos + g + PF);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], b[j], acc1, 0, 0, 0);
+        if (SIDE >= 1 && SIDE <= 3 && (g & 1) == 0) {
+          const int r = g >> 1;
+          const float v = prev[r] + 0.1f;
+          const float sw = SIDE == 2 ? v * 0.5f : v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+          if (SIDE != 3) buf1[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 260 + col] = sw;
+          else prev[r] = sw;
+        }
+        if (SIDE == 4 && g == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = prev[r] + 0.1f;
+            buf1[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 260 + col] = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+          }
+        }
+        if (SIDE == 10 && (g & 1) == 0) {  // VALU only, result kept live
+          const float v = prev[g >> 1] + 0.1f;
+          live += v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        }
+        if (SIDE == 11 && (g & 1) == 0) {  // LDS write only (data = a register that needs no VALU work)
+          const int r = g >> 1;
+          buf1[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 260 + col] = prev[r];
+        }
+        if (SIDE == 12 && (g & 7) == 0) {  // 4 x ds_write_b128 per unit instead of 16 x b32, no VALU work
+          const int q = g >> 3;
+          *reinterpret_cast<f32x4*>(buf1 + (lane & 31) * 260 + wave * 32 + 8 * q + 4 * (lane >> 5)) =
+              f32x4{prev[4 * q], prev[4 * q + 1], prev[4 * q + 2], prev[4 * q + 3]};
+        }
+        if (SIDE == 13 && (g & 1) == 0) {  // swish spread over the even k-groups, results kept in registers ...
+          const float v = prev[g >> 1] + 0.1f;
+          prev[g >> 1] = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        }
+        if (SIDE == 13 && (g & 7) == 7) {  // ... and written 4 at a time (the layout a transposed accumulator gives)
+          const int q = g >> 3;
+          *reinterpret_cast<f32x4*>(buf1 + (lane & 31) * 260 + wave * 32 + 8 * q + 4 * (lane >> 5)) =
+              f32x4{prev[4 * q], prev[4 * q + 1], prev[4 * q + 2], prev[4 * q + 3]};
+        }
+        if (SIDE == 14 && (g & 1) == 0) {  // swish with v_exp/v_rcp replaced by plain multiply-adds of the same count
+          const int r = g >> 1;
+          const float v = prev[r] + 0.1f;
+          float e = v * -1.44f;
+          e = e * e + 1.0f;
+          e = e * v + 0.3f;
+          buf1[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 260 + col] = v * e;
+        }
+        if (SIDE == 5 && (g & 1) == 0) {  // swish computed here, the 16 LDS writes issued together at g == 31
+          const int r = g >> 1;
+          const float v = prev[r] + 0.1f;
+          prev[r] = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        }
+        if (SIDE == 5 && g == 31) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) buf1[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 260 + col] = prev[r];
+        }
+        a_cur = a_nxt;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      pos += 32;
+      if (BAR) __syncthreads();
+      a_cur = *reinterpret_cast<const f32x4*>(a1);
+#pragma unroll
+      for (int g = 0; g < 32; ++g) {
+        const f32x4 a_nxt = *reinterpret_cast<const f32x4*>(a1 + 8 * ((g + 1) & 31));
+        const f32x4 b = ring[g % PF];
+        ring[g % PF] = ld(pos + g + PF);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], b[j], acc2, 0, 0, 0);
+        a_cur = a_nxt;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      pos += 32;
+    } else {
+      // one stream: k-group g of unit 2 (A = buf1, previous chunk's hidden tile) and of unit 1 (A = buf0) alternate
+      if (BAR) __syncthreads();
+      f32x4 c0 = *reinterpret_cast<const f32x4*>(a0), c1 = *reinterpret_cast<const f32x4*>(a1);
+#pragma unroll
+      for (int g = 0; g < 32; ++g) {
+        const f32x4 n0 = *reinterpret_cast<const f32x4*>(a0 + 8 * ((g + 1) & 31));
+        const f32x4 n1 = *reinterpret_cast<const f32x4*>(a1 + 8 * ((g + 1) & 31));
+        const f32x4 b0 = ring[(2 * g) % PF], b1 = ring[(2 * g + 1) % PF];
+        ring[(2 * g) % PF] = ld(pos + 2 * g + PF);
+        ring[(2 * g + 1) % PF] = ld(pos + 2 * g + 1 + PF);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c0[j], b0[j], acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[j], b1[j], acc2, 0, 0, 0);
+        }
+        if (SIDE == 1 && (g & 1) == 0) {
+          const int r = g >> 1;
+          const float v = prev[r] + 0.1f;
+          buf1[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 260 + col] = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        }
+        c0 = n0;
+        c1 = n1;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      pos += 64;
+    }
+    prev = acc1;
+  }
+  float sum = 0.f;
+  for (int r = 0; r < 16; ++r) sum += acc1[r] + acc2[r];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum + live;
+}
+
+// Co-issue test: waves 0-3 (one per SIMD) run VALU work, waves 4-7 (their SIMD partners) run a saturating MFMA stream
+// (2 independent chains).  Each wave reports its own duration (100 MHz ticks) so that the two can be compared with the
+// partner idle.  VALU_KIND 0: independent v_fma (8 accumulators)   1: one dependent chain   2: v_exp (transcendental)
+template <bool DO_VALU, bool DO_MFMA, int VALU_KIND>
+__global__ void k_coissue(float* out, long long* ticks, int n_valu, int n_mfma) {
+  const int wave = threadIdx.x >> 6;
+  const long long t0 = (long long)wall_clock64();
+  float res = 0.f;
+  if (wave < 4) {
+    if (DO_VALU) {
+      float x[8];
+      for (int i = 0; i < 8; ++i) x[i] = threadIdx.x * 0.001f + i;
+      const float a = 0.999f, b = 0.001f;
+      for (int it = 0; it < n_valu; ++it) {
+        if (VALU_KIND == 0) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = fmaf(x[i], a, b);
+        } else if (VALU_KIND == 1) {
+#pragma unroll
+          for (int r = 0; r < 64; ++r) x[0] = fmaf(x[0], a, b);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_exp2f(x[i]);
+        }
+      }
+      for (int i = 0; i < 8; ++i) res += x[i];
+    }
+  } else if (DO_MFMA) {
+    f32x16 c0, c1;
+    for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
+    const float av = threadIdx.x * 0.01f, bv = 0.5f;
+    for (int it = 0; it < n_mfma; ++it) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, c1, 0, 0, 0);
+      }
+    }
+    for (int r = 0; r < 16; ++r) res += c0[r] + c1[r];
+  }
+  const long long t1 = (long long)wall_clock64();
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = res;
+  if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) ticks[wave] = t1 - t0;
+}
+
 template <class F>
 static void timeit(const char* name, double mfma_per_launch, F launch) {
   hipEvent_t a, b;
@@ -133,5 +321,41 @@ int main() {
   RUN(4, 100, true, 2, "  buffer_load plain, every workgroup its own weights");
   RUN(4, 101, false, 2, "  buffer_load plain, waves 256 KB apart (W2-like tiles)");
   RUN(8, 100, false, 2, "  buffer_load plain PF=8");
+  {
+    long long* ticks;
+    hipMalloc(&ticks, 64);
+    const int nv = 2000, nm = 2000;  // 128k VALU ops per wave; 32k MFMAs per wave (= 2.05 M cycles if the pipe is full)
+    auto report = [&](const char* name) {
+      hipDeviceSynchronize();
+      long long h[8];
+      hipMemcpy(h, ticks, 64, hipMemcpyDeviceToHost);
+      printf("%-44s VALU wave %8.1f us (%.1f cycles/op)   MFMA wave %8.1f us (%.1f cycles/MFMA)\n", name, h[0] / 100.0,
+             h[0] / 100.0 * 2400.0 / (nv * 64.0), h[4] / 100.0, h[4] / 100.0 * 2400.0 / (nm * 16.0));
+    };
+#define COI(V, M, K, name)                                                                           \
+  hipMemset(ticks, 0, 64);                                                                           \
+  hipLaunchKernelGGL((k_coissue<V, M, K>), dim3(CUS), dim3(512), 0, 0, out, ticks, nv, nm);          \
+  report(name);
+    COI(true, false, 0, "independent v_fma alone");
+    COI(false, true, 0, "MFMA 2 chains alone");
+    COI(true, true, 0, "independent v_fma + partner MFMA stream");
+    COI(true, false, 1, "dependent v_fma chain alone");
+    COI(true, true, 1, "dependent v_fma chain + partner MFMA stream");
+    COI(true, false, 2, "v_exp alone");
+    COI(true, true, 2, "v_exp + partner MFMA stream");
+  }
+  const size_t lds2 = 2 * 32 * 260 * 4;
+  const int it3 = 1000;
+#define RUNF(BAR, SIDE, FUSE, name)                                                                       \
+  timeit(name, (double)CUS * 8 * it3 * 256,                                                               \
+         [&] { hipLaunchKernelGGL((k_ffnlike<BAR, SIDE, FUSE>), dim3(CUS), dim3(512), lds2, 0, w, out, it3); })
+  RUNF(false, 0, false, "FFN-like: two 32-k-group units per chunk, no barrier, no side");
+  RUNF(true, 0, false, "  + barrier between the units");
+  RUNF(true, 1, false, "  + barrier + swish side work (= ffn_phase)");
+  RUNF(true, 10, false, "  side = swish VALU only (kept live), no LDS write");
+  RUNF(true, 11, false, "  side = 16 ds_write_b32 only, no VALU");
+  RUNF(true, 12, false, "  side = 4 ds_write_b128 only, no VALU");
+  RUNF(true, 13, false, "  side = swish spread + 4 ds_write_b128");
+  RUNF(true, 14, false, "  side = mul/add stand-in for exp/rcp + 16 ds_write_b32");
   return 0;
 }

@@ -71,6 +71,22 @@ for c in range(8):
     print(f"  chunk {c}: barrier wait {b - a:6.2f}   W2(c)+W1(c+2) {nxt - b:6.2f}")
 
 # per-workgroup start / end of the last k_conv_ffn<..,NEXT> launch: start skew, duration spread, per-XCD means
+wv = (ctypes.c_longlong * 256)()
+if lib.ppasr_debug_read_wave_ts(wv) == 0:
+    print("per-wave stamps around the FFN chunk barrier (last FFN executed), us relative to wave 0's arrival at chunk 0:")
+    t0 = wv[0]
+    for c in range(8):
+        arr = [(wv[(2 * c) * 8 + w] - t0) / 100.0 for w in range(8)]
+        rel = [(wv[(2 * c + 1) * 8 + w] - t0) / 100.0 for w in range(8)]
+        print(f"  chunk {c}: arrive " + " ".join(f"{a:7.2f}" for a in arr) + f"   | last - first {max(arr) - min(arr):5.2f}"
+              f"   release first {min(rel):7.2f} (barrier latency {min(rel) - max(arr):5.2f})")
+    print("k_attn_out_glu key loop, per wave (us since wave 0 entered its first sub-block): start | S MFMAs issued | softmax done | PV issued")
+    t0 = wv[16 * 8]
+    for sb in range(2):
+        for w_ in range(8):
+            v = [(wv[(16 + 4 * sb + k) * 8 + w_] - t0) / 100.0 for k in range(4)]
+            print(f"  sub-block {sb} wave {w_} (head {w_ >> 1}, half {w_ & 1}): " + " ".join(f"{x:7.2f}" for x in v)
+                  + f"   S {v[1] - v[0]:5.2f}  softmax {v[2] - v[1]:5.2f}  PV {v[3] - v[2]:5.2f}")
 wg = (ctypes.c_longlong * 2048)()
 assert lib.ppasr_debug_read_wg_ts(wg) == 0
 w = np.array(list(wg), np.float64).reshape(1024, 2)[:249] / 100.0
