@@ -15,7 +15,7 @@ extern "C" int ppasr_debug_read_phase_ts(long long* out) {  // instrumented buil
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_phase_ts), sizeof(long long) * 128);
 }
 extern "C" int ppasr_debug_read_wave_ts(long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_wave_ts), sizeof(long long) * 256);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_wave_ts), sizeof(long long) * 512);
 }
 extern "C" int ppasr_debug_read_wg_ts(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_wg_ts), sizeof(long long) * 2 * 1024);
@@ -130,22 +130,28 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
   const f32x4* wbase = wp + (size_t)(blockIdx.y * kWaves + wave) * tile_stride;  // blockIdx.y = 256-column block
   BRing<1> ring;
   ring_prime(ring, wbase + (size_t)kc0 * G * 64, 0);
-  const float* rowp[NL];
+  // A-tile rows through buffer loads: per-lane byte offsets relative to the tile's first row (computed once), the K
+  // chunk as the wave-uniform soffset -- the per-chunk request is then 8 VMEM instructions and NO vector ALU work.
+  // (With 64-bit per-lane addresses every chunk started with 16 v_add per lane; the younger waves of each SIMD sat
+  //  in those for 3 - 7 us while their older partners' MFMA streams had the issue port -- tools/phase_ts.py stamps --
+  //  and the workgroup then ran its two wave sets one after the other.)  Rows >= M read as zeros (offset out of range).
+  const float* tile_base = src.base(min(r0, M - 1));
+  const __amdgpu_buffer_rsrc_t rs_a = wstream_rsrc(tile_base);
+  int voff[NL];
   int lds_off[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     int idx = tid + kThreads * i;
     int row = idx / F4_PER_ROW, c4 = idx - row * F4_PER_ROW;
     int m = r0 + row;
-    rowp[i] = (m < M) ? src.base(m) + 4 * c4 : nullptr;
+    voff[i] = (m < M) ? (int)((src.base(m) - tile_base) * sizeof(float)) + 16 * c4 : 0x7fffffff;
     lds_off[i] = row * LD + 4 * c4;
   }
   f32x4 stg[NL];
   auto load_chunk = [&](int kc) {
-    size_t off = src.chunk_off(kc);
+    const int soff = (int)(src.chunk_off(kc) * sizeof(float));
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
-      stg[i] = rowp[i] ? *reinterpret_cast<const f32x4*>(rowp[i] + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NL; ++i) stg[i] = wstream_load(rs_a, voff[i], soff);
   };
   auto write_chunk = [&](float* buf) {
 #pragma unroll
@@ -162,9 +168,13 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
     const bool more = kc + 1 < kc1;
     if (more) load_chunk(kc + 1);
     const f32x4* seg = wbase + (size_t)kc * G * 64;
+    if (MT == 4 && kc < 8) PPASR_WAVE_TS(32 + 4 * kc);
     rb_gemm<MT, 1, G>(cur, LD, seg, 0, more ? seg + G * 64 : nullptr, 0, ring, acc);
+    if (MT == 4 && kc < 8) PPASR_WAVE_TS(33 + 4 * kc);
     if (more) write_chunk(nxt);
+    if (MT == 4 && kc < 8) PPASR_WAVE_TS(34 + 4 * kc);
     __syncthreads();
+    if (MT == 4 && kc < 8) PPASR_WAVE_TS(35 + 4 * kc);
   }
   const int col = blockIdx.y * 256 + wave * 32 + (lane & 31);
   if (gridDim.z > 1) {

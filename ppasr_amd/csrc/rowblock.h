@@ -55,7 +55,7 @@ static __device__ long long g_phase_ts[128];  // one copy per translation unit (
       g_phase_ts[64 + (i)] = (long long)clock64();                                               \
     }                                                                                            \
   } while (0)
-static __device__ long long g_wave_ts[256];  // [slot < 32][wave < 8]: per-wave stamps of one workgroup (PPASR_WAVE_TS)
+static __device__ long long g_wave_ts[512];  // [slot < 64][wave < 8]: per-wave stamps of one workgroup (PPASR_WAVE_TS)
 #define PPASR_WAVE_TS(slot)                                                                          \
   do {                                                                                               \
     if (blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0)                                      \

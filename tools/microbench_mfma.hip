@@ -71,6 +71,63 @@ __global__ void k_mem(const f32x4* __restrict__ w, float* out, int iters) {
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// Register-tile shapes of a wave: MT row tiles (A fragments from LDS, one ds_read_b128 each per k-group) x NT column
+// tiles (B fragments from the buffer-load ring), MT*NT accumulator chains, 4*MT*NT MFMAs per k-group.
+template <int MT, int NT>
+__global__ void k_tile(const f32x4* __restrict__ w, float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LD = 132;
+  for (int i = threadIdx.x; i < MT * 32 * LD; i += blockDim.x) smem[i] = __uint_as_float(0x3d000000u | ((i * 2654435761u) >> 9)) - 0.04f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float* a_ptr = smem + (lane & 31) * LD + 4 * (lane >> 5);
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 0x7fffffff, 0x00020000);
+  const int voff = lane * 16;
+  constexpr int PF = 4;
+  f32x4 ring[PF][NT];
+  auto ld = [&](int g, int nt) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (((g & 1023) * 8 + wave) * NT + nt) * 1024, 0));
+  };
+  for (int s = 0; s < PF; ++s)
+    for (int nt = 0; nt < NT; ++nt) ring[s][nt] = ld(s, nt);
+  f32x16 acc[MT][NT];
+  for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt)
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  f32x4 a_cur[MT], a_nxt[MT];
+  for (int mt = 0; mt < MT; ++mt) a_cur[mt] = *reinterpret_cast<const f32x4*>(a_ptr + mt * 32 * LD);
+  int pos = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = *reinterpret_cast<const f32x4*>(a_ptr + mt * 32 * LD + 8 * ((g + 1) & 15));
+      f32x4 b[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        b[nt] = ring[g % PF][nt];
+        ring[g % PF][nt] = ld(pos + g + PF, nt);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    pos += 16;
+  }
+  float sum = 0.f;
+  for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt)
+      for (int r = 0; r < 16; ++r) sum += acc[mt][nt][r];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
+}
+
 // The FFN chunk loop of phases.h in miniature: unit 1 = A(buf0) x W1 tile -> acc1 (optionally with the swish side
 // writes of the previous tile into buf1), [barrier], unit 2 = A(buf1) x W2 tile -> acc2.  Buffer-load weight ring.
 //   BAR: workgroup barrier between the units (as ffn_phase has)    SIDE: swish side work    FUSE: both units as ONE
@@ -343,6 +400,21 @@ int main() {
     COI(true, true, 1, "dependent v_fma chain + partner MFMA stream");
     COI(true, false, 2, "v_exp alone");
     COI(true, true, 2, "v_exp + partner MFMA stream");
+  }
+  {
+    const int it4 = 1000;
+#define RUNT(MT, NT, WAVES, name)                                                                                  \
+  timeit(name, (double)CUS * 4 * WAVES * it4 * 16 * 4 * MT * NT,                                                   \
+         [&] { hipLaunchKernelGGL((k_tile<MT, NT>), dim3(CUS), dim3(256 * WAVES), MT * 32 * 132 * 4, 0, w, out, it4 / (MT * NT)); })
+    RUNT(1, 1, 2, "wave tile 32x32 (1 chain), 2 waves/SIMD");
+    RUNT(2, 1, 2, "wave tile 64x32 (2 chains), 2 waves/SIMD");
+    RUNT(4, 1, 2, "wave tile 128x32 (4 chains, conv2 today), 2 waves/SIMD");
+    RUNT(4, 1, 1, "wave tile 128x32 (4 chains), 1 wave/SIMD");
+    RUNT(2, 2, 2, "wave tile 64x64 (4 chains), 2 waves/SIMD");
+    RUNT(2, 2, 1, "wave tile 64x64 (4 chains), 1 wave/SIMD");
+    RUNT(4, 2, 1, "wave tile 128x64 (8 chains), 1 wave/SIMD");
+    RUNT(4, 2, 2, "wave tile 128x64 (8 chains), 2 waves/SIMD");
+    RUNT(1, 2, 2, "wave tile 32x64 (2 chains), 2 waves/SIMD");
   }
   const size_t lds2 = 2 * 32 * 260 * 4;
   const int it3 = 1000;

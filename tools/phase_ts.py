@@ -71,7 +71,7 @@ for c in range(8):
     print(f"  chunk {c}: barrier wait {b - a:6.2f}   W2(c)+W1(c+2) {nxt - b:6.2f}")
 
 # per-workgroup start / end of the last k_conv_ffn<..,NEXT> launch: start skew, duration spread, per-XCD means
-wv = (ctypes.c_longlong * 256)()
+wv = (ctypes.c_longlong * 512)()
 if lib.ppasr_debug_read_wave_ts(wv) == 0:
     print("per-wave stamps around the FFN chunk barrier (last FFN executed), us relative to wave 0's arrival at chunk 0:")
     t0 = wv[0]
@@ -87,6 +87,17 @@ if lib.ppasr_debug_read_wave_ts(wv) == 0:
             v = [(wv[(16 + 4 * sb + k) * 8 + w_] - t0) / 100.0 for k in range(4)]
             print(f"  sub-block {sb} wave {w_} (head {w_ >> 1}, half {w_ & 1}): " + " ".join(f"{x:7.2f}" for x in v)
                   + f"   S {v[1] - v[0]:5.2f}  softmax {v[2] - v[1]:5.2f}  PV {v[3] - v[2]:5.2f}")
+    print("k_gemm_stream<conv2, 128-row tiles>, one workgroup, per K chunk and wave (us): gemm | LDS write of the next chunk | barrier wait")
+    t0 = wv[32 * 8]
+    for kc in range(8):
+        rows = []
+        for w_ in range(8):
+            v = [(wv[(32 + 4 * kc + k) * 8 + w_] - t0) / 100.0 for k in range(4)]
+            rows.append(v)
+        print(f"  chunk {kc}: start " + " ".join(f"{r[0]:6.2f}" for r in rows))
+        print("           gemm  " + " ".join(f"{r[1] - r[0]:6.2f}" for r in rows))
+        print("           write " + " ".join(f"{r[2] - r[1]:6.2f}" for r in rows))
+        print("           wait  " + " ".join(f"{r[3] - r[2]:6.2f}" for r in rows))
 wg = (ctypes.c_longlong * 2048)()
 assert lib.ppasr_debug_read_wg_ts(wg) == 0
 w = np.array(list(wg), np.float64).reshape(1024, 2)[:249] / 100.0
