@@ -6,17 +6,23 @@
 
 namespace ppasr {
 
-// Epilogue slice of the previous W1 tile, interleaved with the MFMAs of the next one:
-// H[row][col] = swish(acc + b1)   (two accumulator registers per k-group pair)
+// Epilogue slice of the previous W1 tile, interleaved with the MFMAs of the next one: H[row][col] = swish(acc + b1).
+// The W1 units run with swapped MFMA operands (rb_gemm SWAP): lane = row, register quad q = hidden columns
+// 8q + 4hh .. +3 of the wave's 32, so a quad is ONE 16-byte LDS store and its four values two packed-math pairs --
+// 17 instructions per quad, 68 per tile, against 7 per value / 112 per tile one column per lane.  (Every VALU / LDS
+// instruction of a wave takes issue cycles from the SIMD's matrix pipe: tools/microbench_mfma.hip, "side" rows.)
+// Quad q is handled during k-groups 8q (first pair) and 8q + 4 (second pair + store).
 struct SwishSide {
   const f32x16& acc;
-  float* hb;
-  float bias;
-  int lane, col;
+  float* dst;           // hb + (lane & 31) * kLda + wave * 32 + 4 * (lane >> 5)
+  const f32x4 (&bias)[4];  // b1 of this lane's columns, quad by quad
+  mutable f32x2 lo;
   __device__ __forceinline__ void operator()(int g) const {
-    if ((g & 1) == 0) {
-      const int r = g >> 1;
-      hb[acc_row(r, lane) * kLda + col] = swishf(acc[r] + bias);
+    const int q = g >> 3;
+    if ((g & 7) == 0) lo = swish2(f32x2{acc[4 * q] + bias[q][0], acc[4 * q + 1] + bias[q][1]});
+    if ((g & 7) == 4) {
+      const f32x2 hi = swish2(f32x2{acc[4 * q + 2] + bias[q][2], acc[4 * q + 3] + bias[q][3]});
+      *reinterpret_cast<f32x4*>(dst + 8 * q) = f32x4{lo[0], lo[1], hi[0], hi[1]};
     }
   }
 };
@@ -34,26 +40,33 @@ __device__ __forceinline__ void ffn_phase(const float* bufA, float* bufH, const 
                                           int c0 = 0, int n_total = -1) {
   const int lane = lane_id(), wave = wave_id();
   const int ts2 = (n_total > 0 ? n_total : n_chunks) * 32 * 64;  // W2: K = hidden
-  const int col = wave * 32 + (lane & 31);
   b1 += c0 * 256;
   auto w1seg = [&](int c) { return w1 + (size_t)((c0 + c) * 8 + wave) * kTs256; };
   auto w2seg = [&](int c) { return w2 + (size_t)wave * ts2 + (size_t)(c0 + c) * 32 * 64; };
   f32x16 cur[1][1], nx[1][1];
   acc_zero(cur);
-  rb_gemm<1, 1, kG256>(bufA, kLda, w1seg(0), 0, n_chunks > 1 ? w1seg(1) : w2seg(0), 0, ring, cur);
+  rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, w1seg(0), 0, n_chunks > 1 ? w1seg(1) : w2seg(0), 0, ring, cur);
+  const int hoff = (lane & 31) * kLda + wave * 32 + 4 * (lane >> 5);
   for (int c = 0; c < n_chunks; ++c) {
     float* hb = bufH + (c & 1) * kRows * kLda;
-    const float bias = b1[c * 256 + col];
+    f32x4 bias[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bias[q] = *reinterpret_cast<const f32x4*>(b1 + c * 256 + wave * 32 + 8 * q + 4 * (lane >> 5));
     if (c + 1 < n_chunks) {
       acc_zero(nx);
 #ifdef PPASR_ABLATE_SWISH
-      rb_gemm<1, 1, kG256>(bufA, kLda, w1seg(c + 1), 0, w2seg(c), 0, ring, nx);
+      rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, w1seg(c + 1), 0, w2seg(c), 0, ring, nx);
 #else
-      rb_gemm<1, 1, kG256>(bufA, kLda, w1seg(c + 1), 0, w2seg(c), 0, ring, nx, SwishSide{cur[0][0], hb, bias, lane, col});
+      rb_gemm<1, 1, kG256, kPF, SwishSide, true>(bufA, kLda, w1seg(c + 1), 0, w2seg(c), 0, ring, nx,
+                                                 SwishSide{cur[0][0], hb + hoff, bias, f32x2{0.f, 0.f}});
 #endif
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hb[acc_row(r, lane) * kLda + col] = swishf(cur[0][0][r] + bias);
+      for (int q = 0; q < 4; ++q) {
+        const f32x2 lo = swish2(f32x2{cur[0][0][4 * q] + bias[q][0], cur[0][0][4 * q + 1] + bias[q][1]});
+        const f32x2 hi = swish2(f32x2{cur[0][0][4 * q + 2] + bias[q][2], cur[0][0][4 * q + 3] + bias[q][3]});
+        *reinterpret_cast<f32x4*>(hb + hoff + 8 * q) = f32x4{lo[0], lo[1], hi[0], hi[1]};
+      }
     }
     if (c < 8) PPASR_TS(16 + 2 * c);
     if (c < 8) PPASR_WAVE_TS(2 * c);

@@ -133,6 +133,14 @@ __device__ __forceinline__ float wave_max(float v) {
 // sigmoid / swish on the hardware exp + rcp (about 1 ulp each; well inside the 1e-3 logit budget)
 __device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float swishf(float x) { return x * sigmoidf(x); }
+// swish of two values with the plain multiplies / adds as packed instructions (same operations, same roundings as
+// swishf: x * rcp(1 + exp2(x * -log2 e))): 4 v_pk_* + 4 transcendentals per pair instead of 8 + 4
+__device__ __forceinline__ f32x2 swish2(f32x2 x) {
+  const f32x2 t = x * f32x2{-1.4426950408889634f, -1.4426950408889634f};
+  f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  e += f32x2{1.0f, 1.0f};
+  return x * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+}
 
 template <int MT, int NT>
 __device__ __forceinline__ void acc_zero(f32x16 (&acc)[MT][NT]) {
@@ -190,7 +198,10 @@ struct NoSide {
 //   nxt   : segment the stream continues with after this call (nullptr: stream ends); must
 //           have the same NT; its n-tile stride is nxt_stride
 //   side(g): called once per k-group, after that group's MFMAs were issued
-template <int MT, int NT, int G, int PF = kPF, typename Side = NoSide>
+//   SWAP : issue the MFMAs with the operands exchanged (weights as A, activations as B): the accumulator then holds the
+//          TRANSPOSED tile -- lane = row (lane & 31), register r = column (r&3) + 8(r>>2) + 4(lane>>5) of the wave's 32 --
+//          so that 4 consecutive columns of a row sit in one register quad (16-byte LDS / global stores)
+template <int MT, int NT, int G, int PF = kPF, typename Side = NoSide, bool SWAP = false>
 __device__ __forceinline__ void rb_gemm(const float* a_lds, int lda, const f32x4* __restrict__ bp, int tile_stride,
                                         const f32x4* __restrict__ nxt, int nxt_stride, BRing<NT, PF>& ring,
                                         f32x16 (&acc)[MT][NT], Side side = Side()) {
@@ -226,7 +237,8 @@ __device__ __forceinline__ void rb_gemm(const float* a_lds, int lda, const f32x4
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b[nt][j], a_cur[mt][j], acc[mt][nt], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
     side(g);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
