@@ -62,6 +62,15 @@ class ConformerOracle:
         # nn.LayerNorm, biased variance, eps=1e-5 (utils/base.py:7; encoder.py:327-336)
         return F.layer_norm(x, (x.shape[-1],), self.p[prefix + ".weight"], self.p[prefix + ".bias"], eps)
 
+    def _cm_norm(self, x, prefix, eps=1e-5):
+        """ConvolutionModule.norm on [B, T, C]: nn.LayerNorm(channels), or -- cnn_module_norm: batch_norm
+        (convolution.py:65-71) -- nn.BatchNorm1D(channels) in eval mode: the per-channel running statistics
+        (parameters `_mean`, `_variance`; epsilon 1e-5), the same for every frame."""
+        if prefix + "._mean" in self.p:
+            inv = torch.rsqrt(self.p[prefix + "._variance"] + eps)
+            return (x - self.p[prefix + "._mean"]) * inv * self.p[prefix + ".weight"] + self.p[prefix + ".bias"]
+        return self._ln(x, prefix, eps)
+
     @staticmethod
     def _swish(x):
         return x * torch.sigmoid(x)  # utils/common.py:201 (paddle.nn.Swish)
@@ -153,7 +162,7 @@ class ConformerOracle:
         x = F.conv1d(x, self.p[prefix + ".depthwise_conv.weight"], self.p[prefix + ".depthwise_conv.bias"],
                      padding=pad, groups=x.shape[1])
         x = x.transpose(1, 2)
-        x = self._swish(self._ln(x, prefix + ".norm"))  # nn.LayerNorm(channels), eps 1e-5 (convolution.py:71)
+        x = self._swish(self._cm_norm(x, prefix + ".norm"))  # LayerNorm or BatchNorm1D(eval) (convolution.py:65-71)
         x = x.transpose(1, 2)
         x = F.conv1d(x, self.p[prefix + ".pointwise_conv2.weight"], self.p[prefix + ".pointwise_conv2.bias"])
         if mask_pad is not None and mask_pad.shape[2] > 0:

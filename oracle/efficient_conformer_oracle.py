@@ -90,7 +90,7 @@ class EfficientConformerOracle(ConformerOracle):
         x = F.conv1d(x, self.p[prefix + ".depthwise_conv.weight"], self.p[prefix + ".depthwise_conv.bias"],
                      stride=stride, padding=padding, groups=x.shape[1])
         x = x.transpose(1, 2)
-        x = self._swish(self._ln(x, prefix + ".norm"))
+        x = self._swish(self._cm_norm(x, prefix + ".norm"))
         x = x.transpose(1, 2)
         x = F.conv1d(x, self.p[prefix + ".pointwise_conv2.weight"], self.p[prefix + ".pointwise_conv2.bias"])
         if mask_pad.shape[2] != x.shape[2]:

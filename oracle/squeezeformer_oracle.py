@@ -85,7 +85,7 @@ class SqueezeformerOracle(ConformerOracle):
         x = F.conv1d(x, self.p[prefix + ".depthwise_conv.weight"], self.p[prefix + ".depthwise_conv.bias"],
                      padding=0 if self.causal else (self.k - 1) // 2, groups=x.shape[1])
         x = x.transpose(1, 2)
-        x = self._swish(self._ln(x, prefix + ".norm"))
+        x = self._swish(self._cm_norm(x, prefix + ".norm"))
         x = x.transpose(1, 2)
         x = F.conv1d(x, self.p[prefix + ".pointwise_conv2.weight"], self.p[prefix + ".pointwise_conv2.bias"])
         x = x.masked_fill(~mask_pad, 0.0)

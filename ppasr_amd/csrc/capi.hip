@@ -175,7 +175,26 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
     if ((st = ln("norm_conv", &L.ln_conv_g, &L.ln_conv_b)) != PPASR_OK) return st;
     if ((st = ln("norm_ff", &L.ln_ff_g, &L.ln_ff_b)) != PPASR_OK) return st;
     if ((st = ln("norm_final", &L.ln_fin_g, &L.ln_fin_b)) != PPASR_OK) return st;
-    if ((st = ln("conv_module.norm", &L.ln_cm_g, &L.ln_cm_b)) != PPASR_OK) return st;
+    // ConvolutionModule.norm (convolution.py:65-71): nn.LayerNorm, or nn.BatchNorm1D (cnn_module_norm: batch_norm), which
+    // at inference is the per-channel affine y = (x - _mean) / sqrt(_variance + 1e-5) * weight + bias: folded here into
+    // scale / shift vectors in the LayerNorm slots, marked by cm_eps < 0 (ln_rows_inreg then skips the row statistics)
+    L.cm_eps = 1e-5f;
+    if (sd.find(p + "conv_module.norm._mean") != sd.end()) {
+      const float* mean = get(p + "conv_module.norm._mean", d);
+      const float* var = get(p + "conv_module.norm._variance", d);
+      const float* gw = get(p + "conv_module.norm.weight", d);
+      const float* gb = get(p + "conv_module.norm.bias", d);
+      if (!mean || !var || !gw || !gb) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + missing);
+      std::vector<float> sc(d), sh(d);
+      for (int c = 0; c < d; ++c) {
+        sc[c] = gw[c] / std::sqrt(var[c] + 1e-5f);
+        sh[c] = gb[c] - mean[c] * sc[c];
+      }
+      if ((st = m->upload(sc, &L.ln_cm_g)) != PPASR_OK || (st = m->upload(sh, &L.ln_cm_b)) != PPASR_OK) return st;
+      L.cm_eps = -1.f;
+    } else if ((st = ln("conv_module.norm", &L.ln_cm_g, &L.ln_cm_b)) != PPASR_OK) {
+      return st;
+    }
     auto ffn = [&](const std::string& n, const f32x4** w1, const float** b1, const f32x4** w2,
                    const float** b2) -> ppasr_status {
       const float* a1 = get(p + n + ".w_1.weight", (size_t)d * H);

@@ -78,7 +78,25 @@ ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe
     if ((st = ln("layer_norm2", &W.ln2_g, &W.ln2_b)) != PPASR_OK) return st;
     if ((st = ln("layer_norm3", &W.ln3_g, &W.ln3_b)) != PPASR_OK) return st;
     if ((st = ln("layer_norm4", &W.ln4_g, &W.ln4_b)) != PPASR_OK) return st;
-    if ((st = ln("conv_module.norm", &W.ln_cm_g, &W.ln_cm_b)) != PPASR_OK) return st;
+    // conv-module norm: LayerNorm, or (cnn_norm_type: batch_norm) BatchNorm1D at inference folded into scale / shift,
+    // cm_eps < 0 -- same convention as the Conformer loader (capi.hip)
+    W.cm_eps = 1e-5f;
+    if (sd.find(p + "conv_module.norm._mean") != sd.end()) {
+      const float* mean = get(p + "conv_module.norm._mean", d);
+      const float* var = get(p + "conv_module.norm._variance", d);
+      const float* gw = get(p + "conv_module.norm.weight", d);
+      const float* gb = get(p + "conv_module.norm.bias", d);
+      if (!mean || !var || !gw || !gb) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + get.missing);
+      std::vector<float> sc(d), sh(d);
+      for (int c = 0; c < d; ++c) {
+        sc[c] = gw[c] / std::sqrt(var[c] + 1e-5f);
+        sh[c] = gb[c] - mean[c] * sc[c];
+      }
+      if ((st = m->upload(sc, &W.ln_cm_g)) != PPASR_OK || (st = m->upload(sh, &W.ln_cm_b)) != PPASR_OK) return st;
+      W.cm_eps = -1.f;
+    } else if ((st = ln("conv_module.norm", &W.ln_cm_g, &W.ln_cm_b)) != PPASR_OK) {
+      return st;
+    }
     // FFN with the adaptive scale folded into w_1:  (s.x + a) W1 + b1 = x (diag(s) W1) + (a W1 + b1)
     auto ffn = [&](const std::string& n, const f32x4** w1, const float** b1, const f32x4** w2,
                    const float** b2) -> ppasr_status {
@@ -223,7 +241,7 @@ ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe
 LayerW sq_conv_view(const SqLayerW& W) {
   LayerW v{};
   v.dw_w = W.dw_w; v.dw_b = W.dw_b; v.glu_pad = W.glu_pad;
-  v.ln_cm_g = W.ln_cm_g; v.ln_cm_b = W.ln_cm_b;
+  v.ln_cm_g = W.ln_cm_g; v.ln_cm_b = W.ln_cm_b; v.cm_eps = W.cm_eps;
   v.pw2 = W.pw2; v.pw2_b = W.pw2_b;
   return v;
 }

@@ -12,6 +12,7 @@ namespace ppasr {
 struct LayerW {
   const float *ln_mac_g, *ln_mac_b, *ln_mha_g, *ln_mha_b, *ln_conv_g, *ln_conv_b;
   const float *ln_ff_g, *ln_ff_b, *ln_fin_g, *ln_fin_b, *ln_cm_g, *ln_cm_b;
+  float cm_eps;  // conv-module norm: LayerNorm epsilon (1e-5), or < 0: ln_cm_g / ln_cm_b are a folded BatchNorm's scale / shift
   const f32x4 *ffm_w1, *ffm_w2, *ff_w1, *ff_w2, *wqkv, *wo, *pw1, *pw2;
   const float *ffm_b1, *ffm_b2, *ff_b1, *ff_b2, *bqkv, *bo, *pw1_b, *pw2_b;
   const float *dw_w;     // [k][256] tap-major depthwise weights

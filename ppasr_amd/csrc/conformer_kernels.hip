@@ -1429,13 +1429,13 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   if (!STREAM && KS <= 15 && Tp >= kRows / kWaves) {
     // depthwise conv + conv-module LayerNorm (nn.LayerNorm(channels), eps 1e-5, convolution.py:71) + swish in registers
     if constexpr (!STREAM && KS <= 15)
-      dwconv_ln_phase<KS>(g, bufA, w.dw_w, w.dw_b, w.glu_pad, w.ln_cm_g, w.ln_cm_b, r0, M, Tp, left_ctx);
+      dwconv_ln_phase<KS>(g, bufA, w.dw_w, w.dw_b, w.glu_pad, w.ln_cm_g, w.ln_cm_b, w.cm_eps, r0, M, Tp, left_ctx);
     PPASR_TS(1);
   } else {
     dwconv_phase<KS, STREAM>(g, g_hist, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp, left_ctx);
     __syncthreads();
     PPASR_TS(1);
-    rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
+    rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, w.cm_eps);
   }
   // residual rows and pad flags of the pointwise_conv2 epilogue: requested before the GEMM, branch-free (clamped row),
   // so that their global round trips (~2.5 us each under load) overlap the pointwise_conv2 GEMM (8 us; issued after
@@ -1565,7 +1565,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_pre(const float* __restrict__
   }
   dwconv_phase<KS, STREAM>(g, g_hist, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp, left_ctx);
   __syncthreads();
-  rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
+  rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, w.cm_eps);
   __syncthreads();
   f32x16 acc[1][1];
   acc_zero(acc);
@@ -1757,7 +1757,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __res
     }
   }
   __syncthreads();
-  rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
+  rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, w.cm_eps);
   __syncthreads();
   PadRows is_pad{lens, r0, Ts, Mo, mask_mul_out};
   {

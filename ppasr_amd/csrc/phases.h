@@ -180,7 +180,7 @@ __device__ __forceinline__ void dwconv_phase(const float* __restrict__ g, const 
 template <int KS>
 __device__ __forceinline__ void dwconv_ln_phase(const float* __restrict__ g, float* bufA, const float* __restrict__ dw_w,
                                                 const float* __restrict__ dw_b, const float* __restrict__ glu_pad,
-                                                const float* __restrict__ ln_g, const float* __restrict__ ln_b, int r0,
+                                                const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps, int r0,
                                                 int M, int Tp, int left) {
   const int lane = lane_id(), wave = wave_id();
   constexpr int LO = KS - 1, RW = kRows / kWaves, NW = RW + LO;
@@ -226,7 +226,7 @@ __device__ __forceinline__ void dwconv_ln_phase(const float* __restrict__ g, flo
   }
   const f32x4 gam = *reinterpret_cast<const f32x4*>(ln_g + 4 * lane);
   const f32x4 bet = *reinterpret_cast<const f32x4*>(ln_b + 4 * lane);
-  ln_rows_inreg<true, RW>(out, gam, bet, 1e-5f);
+  ln_rows_inreg<true, RW>(out, gam, bet, ln_eps);
 #pragma unroll
   for (int i = 0; i < RW; ++i) *reinterpret_cast<f32x4*>(bufA + (q0 + i) * kLda + 4 * lane) = out[i];
 }

@@ -263,6 +263,17 @@ struct NoZero {
 // (measured 1.6 us per 32-row LayerNorm phase, per-phase stamps of tools/phase_ts.py).
 template <bool SWISH, int RN>
 __device__ __forceinline__ void ln_rows_inreg(f32x4 (&x)[RN], const f32x4& g, const f32x4& b, float eps) {
+  if (eps < 0.f) {  // folded BatchNorm (conv module, cnn_module_norm: batch_norm): per-channel scale / shift, no statistics
+#pragma unroll
+    for (int i = 0; i < RN; ++i) {
+      x[i] = x[i] * g + b;
+      if (SWISH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[i][e] = swishf(x[i][e]);
+      }
+    }
+    return;
+  }
   float mean[RN], var[RN];
 #pragma unroll
   for (int i = 0; i < RN; ++i) {

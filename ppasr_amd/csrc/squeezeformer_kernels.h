@@ -13,6 +13,7 @@ struct SqLayerW {
   const f32x4 *wqkv, *wo, *ff1_w1, *ff1_w2, *pw1, *pw2, *ff2_w1, *ff2_w2;
   const float *bqkv, *bo, *ff1_b1, *ff1_b2, *pw1_b, *pw2_b, *ff2_b1, *ff2_b2;
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b, *ln4_g, *ln4_b, *ln_cm_g, *ln_cm_b;
+  float cm_eps;  // as LayerW::cm_eps
   const float *dw_w, *dw_b, *glu_pad;
   const float *pos_u, *pos_v, *ptab;
   // streaming (forward_chunk): the conv-module cache holds SCALED inputs ada_scale*x + ada_bias

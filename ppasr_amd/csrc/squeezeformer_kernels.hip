@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kThreads) void k_sq_tail(const float* __restrict__ 
   }
   dwconv_phase<KS, STREAM>(g, g_hist, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp, left_ctx);
   __syncthreads();
-  rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, 1e-5f);
+  rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, w.cm_eps);
   __syncthreads();
   {
     f32x16 acc[1][1];

@@ -55,9 +55,18 @@ class EfficientConformerModel(ConformerModel):
         if not one("stride_kernel", True):
             raise NotImplementedError("stride_kernel=False is not built")
         for key, want in (("input_layer", "conv2d"), ("pos_enc_layer_type", "rel_pos"), ("activation_type", "swish"),
-                          ("normalize_before", True), ("use_cnn_module", True), ("cnn_module_norm", "layer_norm")):
+                          ("normalize_before", True), ("use_cnn_module", True)):
             if key in conf and conf[key] != want:
                 raise NotImplementedError(f"encoder_conf.{key}={conf[key]!r}: only {want!r} is built")
+        # cnn_module_norm (convolution.py:65-71): layer_norm, or batch_norm = nn.BatchNorm1D in eval mode, which the
+        # library folds into a per-channel scale / shift; the checkpoint carries the running statistics then
+        norm = conf.get("cnn_module_norm", "layer_norm")
+        if norm not in ("layer_norm", "batch_norm"):
+            raise ValueError(f"encoder_conf.cnn_module_norm={norm!r}")
+        has_stats = any(k.endswith("conv_module.norm._mean") for k in state_dict)
+        if has_stats != (norm == "batch_norm"):
+            raise ValueError(f"encoder_conf.cnn_module_norm={norm!r} but the checkpoint "
+                             f"{'has' if has_stats else 'lacks'} conv_module.norm._mean / _variance")
         sd = dict(state_dict)
         sd["__pe_table__"] = _pe_table(self.output_size, self.max_len)
         keep = []

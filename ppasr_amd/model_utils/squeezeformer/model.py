@@ -38,9 +38,17 @@ class SqueezeformerModel(ConformerModel):
         self.reduce_idx = conf.get("reduce_idx", 5)
         self.recover_idx = conf.get("recover_idx", 11)
         for key, want in (("pos_enc_layer_type", "rel_pos"), ("activation_type", "swish"), ("normalize_before", False),
-                          ("adaptive_scale", True), ("dw_stride", False), ("cnn_norm_type", "layer_norm")):
+                          ("adaptive_scale", True), ("dw_stride", False)):
             if key in conf and conf[key] != want:
                 raise NotImplementedError(f"encoder_conf.{key}={conf[key]!r}: only {want!r} is built")
+        # cnn_norm_type (squeezeformer/encoder.py:41): layer_norm, or batch_norm = BatchNorm1D in eval mode (folded)
+        norm = conf.get("cnn_norm_type", "layer_norm")
+        if norm not in ("layer_norm", "batch_norm"):
+            raise ValueError(f"encoder_conf.cnn_norm_type={norm!r}")
+        has_stats = any(k.endswith("conv_module.norm._mean") for k in state_dict)
+        if has_stats != (norm == "batch_norm"):
+            raise ValueError(f"encoder_conf.cnn_norm_type={norm!r} but the checkpoint "
+                             f"{'has' if has_stats else 'lacks'} conv_module.norm._mean / _variance")
         sd = dict(state_dict)
         sd["__pe_table__"] = _pe_table(self.output_size, self.max_len)
         keep = []

@@ -44,6 +44,15 @@ def _layernorm(sd, prefix, size, rng, perturb):
         sd[prefix + ".bias"] = np.zeros(size, np.float32)
 
 
+def _batchnorm(sd, prefix, size, rng):
+    """nn.BatchNorm1D inference parameters (cnn_module_norm: batch_norm): affine + running statistics, all drawn away
+    from the (1, 0, 0, 1) initial values so that a dropped term shows."""
+    sd[prefix + ".weight"] = (1.0 + 0.1 * rng.standard_normal(size)).astype(np.float32)
+    sd[prefix + ".bias"] = (0.1 * rng.standard_normal(size)).astype(np.float32)
+    sd[prefix + "._mean"] = (0.3 * rng.standard_normal(size)).astype(np.float32)
+    sd[prefix + "._variance"] = rng.uniform(0.5, 1.5, size).astype(np.float32)
+
+
 def _linear(sd, prefix, fin, fout, rng, bias=True):
     # base.Linear: Paddle layout [in, out]; fan_in = shape[0]
     sd[prefix + ".weight"] = _kaiming(rng, (fin, fout), fin)
@@ -54,7 +63,8 @@ def _linear(sd, prefix, fin, fout, rng, bias=True):
 
 def conformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, output_size=256, attention_heads=4,
                          linear_units=2048, num_blocks=12, cnn_module_kernel=15, seed=1234,
-                         ctc_sharpen=8.0, perturb_norm=False, cmvn_mean=10.0, cmvn_istd=1.0 / 3.3):
+                         ctc_sharpen=8.0, perturb_norm=False, cmvn_mean=10.0, cmvn_istd=1.0 / 3.3,
+                         cnn_module_norm="layer_norm"):
     """Random-init ``ConformerModel`` inference parameters (encoder + CTC head).
 
     ``ctc_sharpen`` multiplies ``ctc.ctc_lo.weight`` so that greedy top-1 margins
@@ -94,7 +104,10 @@ def conformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, output_siz
         sd[p + "conv_module.pointwise_conv1.bias"] = _kaiming(rng, (2 * d,), 2 * d)
         sd[p + "conv_module.depthwise_conv.weight"] = _kaiming(rng, (d, 1, cnn_module_kernel), cnn_module_kernel)
         sd[p + "conv_module.depthwise_conv.bias"] = _kaiming(rng, (d,), d)
-        _layernorm(sd, p + "conv_module.norm", d, rng, perturb_norm)
+        if cnn_module_norm == "batch_norm":
+            _batchnorm(sd, p + "conv_module.norm", d, rng)
+        else:
+            _layernorm(sd, p + "conv_module.norm", d, rng, perturb_norm)
         sd[p + "conv_module.pointwise_conv2.weight"] = _kaiming(rng, (d, d, 1), d)
         sd[p + "conv_module.pointwise_conv2.bias"] = _kaiming(rng, (d,), d)
         for n in ("norm_ff", "norm_mha", "norm_ff_macaron", "norm_conv", "norm_final"):
@@ -129,7 +142,8 @@ def synth_vocabulary(vocab_size=DEFAULT_VOCAB_SIZE):
 
 def squeezeformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, encoder_dim=256, attention_heads=4,
                              feed_forward_expansion_factor=8, num_blocks=12, cnn_module_kernel=31, seed=1234,
-                             ctc_sharpen=8.0, perturb_norm=False, cmvn_mean=10.0, cmvn_istd=1.0 / 3.3, streaming=True):
+                             ctc_sharpen=8.0, perturb_norm=False, cmvn_mean=10.0, cmvn_istd=1.0 / 3.3, streaming=True,
+                             cnn_norm_type="layer_norm"):
     """Random-init ``SqueezeformerModel`` inference parameters (``streaming=False``: the time-reduction layer is
     ``TimeReductionLayer1D`` with a 5-tap depthwise conv instead of the 1-tap ``TimeReductionLayerStream``,
     squeezeformer/model.py:35-39).  The reference's ``init_weights()`` calls have
@@ -179,7 +193,10 @@ def squeezeformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, encode
         sd[p + "conv_module.pointwise_conv1.bias"] = _kaiming(rng, (2 * d,), 2 * d)
         sd[p + "conv_module.depthwise_conv.weight"] = _kaiming(rng, (d, 1, cnn_module_kernel), cnn_module_kernel)
         sd[p + "conv_module.depthwise_conv.bias"] = _kaiming(rng, (d,), d)
-        _layernorm(sd, p + "conv_module.norm", d, rng, perturb_norm)
+        if cnn_norm_type == "batch_norm":
+            _batchnorm(sd, p + "conv_module.norm", d, rng)
+        else:
+            _layernorm(sd, p + "conv_module.norm", d, rng, perturb_norm)
         sd[p + "conv_module.pointwise_conv2.weight"] = _kaiming(rng, (d, d, 1), d)
         sd[p + "conv_module.pointwise_conv2.bias"] = _kaiming(rng, (d,), d)
         for n in ("layer_norm1", "layer_norm2", "layer_norm3", "layer_norm4"):

@@ -35,6 +35,11 @@ SMALL = {
     "sq_s": _former("squeezeformer", True, 4, 59, 521, (2, 131, [131, 77], 522), chunk_frames=64 * 4 + 40,
                     required=(-16, 32), reduce_idx=1, recover_idx=3),
     "sq_n": _former("squeezeformer", False, 4, 59, 523, (2, 131, [131, 70], 524), reduce_idx=1, recover_idx=3),
+    # conv-module BatchNorm1D instead of LayerNorm (cnn_module_norm / cnn_norm_type: batch_norm)
+    "conf_bn": _former("conformer", True, 2, 61, 541, (2, 131, [131, 77], 542), chunk_frames=64 * 2 + 30,
+                       required=(-16, 32), cnn_module_norm="batch_norm"),
+    "sq_bn": _former("squeezeformer", False, 3, 59, 543, (2, 131, [131, 70], 544), reduce_idx=1, recover_idx=2,
+                     cnn_norm_type="batch_norm"),
 }
 for _gru in (False, True):
     for _streaming in (True, False):
@@ -75,14 +80,16 @@ def state_dict(case, perturb=True):
     full = L == 12
     pn = perturb and not full
     if fam == "conformer":
-        return conformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn)
+        return conformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn,
+                                    cnn_module_norm=kw.get("cnn_module_norm", "layer_norm"))
     if fam == "efficient_conformer":
         if full:
             return efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=seed)
         return efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn,
                                               stride_layer_idx=kw["stride_layer_idx"], group_layer_idx=kw["group_layer_idx"])
     if fam == "squeezeformer":
-        return squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn, streaming=case["streaming"])
+        return squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn, streaming=case["streaming"],
+                                        cnn_norm_type=kw.get("cnn_norm_type", "layer_norm"))
     if fam == "deepspeech2":
         return deepspeech2_state_dict(vocab_size=V, num_rnn_layers=L, streaming=case["streaming"], seed=seed,
                                       perturb_norm=pn, use_gru=kw.get("use_gru", False))
@@ -110,7 +117,8 @@ def reference_encoder_conf(case):
     if fam == "conformer":
         return dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, dropout_rate=0.1,
                     positional_dropout_rate=0.1, attention_dropout_rate=0.1, input_layer="conv2d", normalize_before=True,
-                    cnn_module_kernel=15, use_cnn_module=True, activation_type="swish", pos_enc_layer_type="rel_pos")
+                    cnn_module_kernel=15, use_cnn_module=True, activation_type="swish", pos_enc_layer_type="rel_pos",
+                    cnn_module_norm=kw.get("cnn_module_norm", "layer_norm"))
     if fam == "efficient_conformer":
         c = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, activation_type="swish",
                  cnn_module_kernel=15, cnn_module_norm="layer_norm", dropout_rate=0.1, input_layer="conv2d",
@@ -128,7 +136,8 @@ def reference_encoder_conf(case):
                     reduce_idx=kw.get("reduce_idx", 5), recover_idx=kw.get("recover_idx", 11),
                     feed_forward_expansion_factor=8, input_dropout_rate=0.1, feed_forward_dropout_rate=0.1,
                     attention_dropout_rate=0.1, adaptive_scale=True, cnn_module_kernel=31, normalize_before=False,
-                    activation_type="swish", pos_enc_layer_type="rel_pos")
+                    activation_type="swish", pos_enc_layer_type="rel_pos",
+                    cnn_norm_type=kw.get("cnn_norm_type", "layer_norm"))
     if fam == "deepspeech2":
         return dict(num_rnn_layers=L, rnn_size=1024, use_gru=kw.get("use_gru", False))
     raise ValueError(fam)
