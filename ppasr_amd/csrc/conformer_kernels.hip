@@ -1127,45 +1127,59 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
   __syncthreads();
   PPASR_TS(36);
   // ---- k_out_glu tail on the LDS-resident context ----
+  // The three GEMM units run with swapped MFMA operands (rb_gemm SWAP): lane = row l31, register quad q = columns
+  // wave*32 + 8q + 4hh .. +3, so residual loads, x2 / g stores and the LDS rows are 16-byte accesses (4 per tile
+  // instead of 16) and the epilogue arithmetic is packed.
   const int r0 = b * T + q0;
-  const int M = B * T;
-  const int col = wave * 32 + (lane & 31);
+  const int cq = wave * 32 + 4 * hh;                    // first column of this lane's quad 0
+  const size_t grow = (size_t)(r0 + min(l31, valid - 1)) * kD;  // this lane's row in x1 / x2 / g
+  const bool row_ok = l31 < valid;
   {
-    float res[16];
+    f32x4 res[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) res[r] = x1[(size_t)(r0 + min(acc_row(r, lane), valid - 1)) * kD + col];
+    for (int q = 0; q < 4; ++q) res[q] = *reinterpret_cast<const f32x4*>(x1 + grow + cq + 8 * q);
     f32x16 acc[1][1];
     acc_zero(acc);
-    rb_gemm<1, 1, kG256>(bufC, kLda, seg_o, 0, seg_val, 0, ring, acc);
-    const float bv = w.bo[col];
+    rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufC, kLda, seg_o, 0, seg_val, 0, ring, acc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = acc_row(r, lane);
-      float v = 0.f;
-      if (row < valid) {
-        v = res[r] + (acc[0][0][r] + bv);
-        x2[(size_t)(r0 + row) * kD + col] = v;
-      }
-      bufX[row * kLda + col] = v;
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bo = *reinterpret_cast<const f32x4*>(w.bo + cq + 8 * q);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = res[q][e] + (acc[0][0][4 * q + e] + bo[e]);
+      if (row_ok) *reinterpret_cast<f32x4*>(x2 + grow + cq + 8 * q) = v;
+      else v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(bufX + l31 * kLda + cq + 8 * q) = v;
     }
   }
   __syncthreads();
   PPASR_TS(37);
-  rb_layernorm<false>(bufX, bufA, kLda, kRows, w.ln_conv_g, w.ln_conv_b, 1e-5f, PadRows{a.lens, r0, T, M, a.mask_mul});
+  // conv-module pad mask (frame t of this utterance is PAD iff mask_mul * t >= len_b, convolution.py:104-106) from the
+  // length read at kernel start -- the row block lies inside one utterance, no per-row length loads
+  struct PadHere {
+    int64_t len_b;
+    int q0, mul;
+    __device__ __forceinline__ bool operator()(int row) const { return (int64_t)mul * (q0 + row) >= len_b; }
+  };
+  rb_layernorm<false>(bufX, bufA, kLda, kRows, w.ln_conv_g, w.ln_conv_b, 1e-5f,
+                      PadHere{a.lens ? len_b : (int64_t)1 << 62, q0, a.mask_mul});
   __syncthreads();
   PPASR_TS(38);
   {
     f32x16 av[1][1], ag[1][1];
     acc_zero(av);
     acc_zero(ag);
-    rb_gemm<1, 1, kG256>(bufA, kLda, seg_val, 0, seg_gate, 0, ring, av);
-    rb_gemm<1, 1, kG256>(bufA, kLda, seg_gate, 0, nullptr, 0, ring, ag);
-    const float bval = w.pw1_b[col];
-    const float bgate = w.pw1_b[kD + col];
+    rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg_val, 0, seg_gate, 0, ring, av);
+    rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg_gate, 0, nullptr, 0, ring, ag);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = acc_row(r, lane);
-      if (row < valid) g[(size_t)(r0 + row) * kD + col] = (av[0][0][r] + bval) * sigmoidf(ag[0][0][r] + bgate);
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bval = *reinterpret_cast<const f32x4*>(w.pw1_b + cq + 8 * q);
+      const f32x4 bgate = *reinterpret_cast<const f32x4*>(w.pw1_b + kD + cq + 8 * q);
+      const f32x2 s0 = sigmoid2(f32x2{ag[0][0][4 * q] + bgate[0], ag[0][0][4 * q + 1] + bgate[1]});
+      const f32x2 s1 = sigmoid2(f32x2{ag[0][0][4 * q + 2] + bgate[2], ag[0][0][4 * q + 3] + bgate[3]});
+      const f32x4 o = {(av[0][0][4 * q] + bval[0]) * s0[0], (av[0][0][4 * q + 1] + bval[1]) * s0[1],
+                       (av[0][0][4 * q + 2] + bval[2]) * s1[0], (av[0][0][4 * q + 3] + bval[3]) * s1[1]};
+      if (row_ok) *reinterpret_cast<f32x4*>(g + grow + cq + 8 * q) = o;
     }
   }
   PPASR_TS(39);

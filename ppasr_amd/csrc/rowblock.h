@@ -133,6 +133,13 @@ __device__ __forceinline__ float wave_max(float v) {
 // sigmoid / swish on the hardware exp + rcp (about 1 ulp each; well inside the 1e-3 logit budget)
 __device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float swishf(float x) { return x * sigmoidf(x); }
+// sigmoid of two values, packed like swish2
+__device__ __forceinline__ f32x2 sigmoid2(f32x2 x) {
+  const f32x2 t = x * f32x2{-1.4426950408889634f, -1.4426950408889634f};
+  f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  e += f32x2{1.0f, 1.0f};
+  return f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+}
 // swish of two values with the plain multiplies / adds as packed instructions (same operations, same roundings as
 // swishf: x * rcp(1 + exp2(x * -log2 e))): 4 v_pk_* + 4 transcendentals per pair instead of 8 + 4
 __device__ __forceinline__ f32x2 swish2(f32x2 x) {
