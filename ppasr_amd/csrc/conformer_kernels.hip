@@ -299,16 +299,17 @@ void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, fl
 // (encoder.py:380-391, attention.py:75-77)
 // -------------------------------------------------------------------------------------
 // Epilogue slice of the previous Q / K / V tile inside the next unit's MFMA stream: qkv[row][col] = acc + bias
+// (transposed tiles, rb_gemm SWAP: lane = row, register quad q = 4 consecutive columns -> one 16-byte store per quad,
+//  issued during k-groups 4, 12, 20, 28 of the next unit)
 struct QkvStoreSide {
   const f32x16& acc;
-  float* out;  // qkv + r0 * 768 + column of this lane
-  float bias;
-  int lane, valid;
+  float* out;  // qkv + (r0 + this lane's row) * 768 + first column of this lane's quad 0; nullptr: row >= valid
+  const f32x4 (&bias)[4];
   __device__ __forceinline__ void operator()(int g) const {
-    if ((g & 1) == 0) {
-      const int r = g >> 1;
-      const int row = acc_row(r, lane);
-      if (row < valid) out[(size_t)row * 768] = acc[r] + bias;
+    if ((g & 7) == 4 && out) {
+      const int q = g >> 3;
+      *reinterpret_cast<f32x4*>(out + 8 * q) = f32x4{acc[4 * q] + bias[q][0], acc[4 * q + 1] + bias[q][1],
+                                                     acc[4 * q + 2] + bias[q][2], acc[4 * q + 3] + bias[q][3]};
     }
   }
 };
@@ -325,9 +326,9 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
   f32x16 acc2[1][1];
   acc_zero(acc2);
   const f32x4* wq = w.wqkv + (size_t)wave * kTs256;
-  ffn_phase(bufA, bufH, w.ffm_w1, w.ffm_b1, w.ffm_w2, n_chunks, wq, ring, acc2);
+  ffn_phase<true>(bufA, bufH, w.ffm_w1, w.ffm_b1, w.ffm_w2, n_chunks, wq, ring, acc2);
   PPASR_TS(9);
-  residual_epilogue(bufX, acc2, w.ffm_b2, 0.5f);
+  residual_epilogue_t(bufX, acc2, w.ffm_b2, 0.5f);
   __syncthreads();
   PPASR_TS(10);
   rb_store_rows(x1 + (size_t)r0 * kD, bufX, kLda, kRows, valid);
@@ -338,17 +339,26 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
   // (QkvStoreSide, one store every second k-group) instead of running between the units with the matrix pipe idle
   // (0.4 - 1.5 us per unit, per-phase stamps); only V's tile is stored after its GEMM.
   f32x16 tile[3][1][1];
+  const int cq = wave * 32 + 4 * (lane >> 5);
+  float* qrow = (lane & 31) < valid ? qkv + (size_t)(r0 + (lane & 31)) * 768 + cq : nullptr;
+  f32x4 qb[2][4];  // biases of this lane's Q / K column quads
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) qb[c][q] = *reinterpret_cast<const f32x4*>(w.bqkv + c * 256 + cq + 8 * q);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     acc_zero(tile[c]);
     const f32x4* seg = w.wqkv + (size_t)(c * 8 + wave) * kTs256;
     const f32x4* nseg = c < 2 ? seg + 8 * kTs256 : nullptr;
     if (c == 0) {
-      rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, nseg, 0, ring, tile[c]);
-    } else {
-      const int pcol = (c - 1) * 256 + wave * 32 + (lane & 31);
-      rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, nseg, 0, ring, tile[c],
-                           QkvStoreSide{tile[c - 1][0][0], qkv + (size_t)r0 * 768 + pcol, w.bqkv[pcol], lane, valid});
+      rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg, 0, nseg, 0, ring, tile[c]);
+    } else if (c == 1) {
+      rb_gemm<1, 1, kG256, kPF, QkvStoreSide, true>(bufA, kLda, seg, 0, nseg, 0, ring, tile[c],
+                                                    QkvStoreSide{tile[0][0][0], qrow, qb[0]});
+    } else {  // V stays column-per-lane (its fragment-order store below needs that); K's tile is stored meanwhile
+      rb_gemm<1, 1, kG256, kPF, QkvStoreSide, false>(bufA, kLda, seg, 0, nseg, 0, ring, tile[c],
+                                                     QkvStoreSide{tile[1][0][0], qrow ? qrow + 256 : nullptr, qb[1]});
     }
     PPASR_TS(12 + c);
   }
@@ -1458,24 +1468,25 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   // The pad flags used to come from PadRows per row (a dependent lens[b] load + compare inside the loop): the 16
   // residual loads then ran as 16 serial round trips (6.8 us, per-phase stamps).  A 32-row block touches at most two
   // utterances when Tp >= 32: their lengths are two uniform loads, the flags plain arithmetic.
+  // (pointwise_conv2 runs with swapped operands: lane = row, so the residual row is four 16-byte loads and the pad
+  //  flag ONE value per lane)
   PadRows is_pad{lens, r0, Tp, M, mask_mul};
-  float res[16];
-  unsigned pad_bits = 0;
+  const int l31 = lane & 31, cq = wave * 32 + 4 * (lane >> 5);
+  f32x4 res[4];
+  {
+    const float* rp = x2 + (size_t)(r0 + min(l31, valid - 1)) * kD + cq;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) res[r] = x2[(size_t)(r0 + min(acc_row(r, lane), valid - 1)) * kD + col];
+    for (int q = 0; q < 4; ++q) res[q] = *reinterpret_cast<const f32x4*>(rp + 8 * q);
+  }
+  bool pad = false;
   if (lens) {
     if (Tp >= kRows) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, lane);
-        const int tt = pt0 + row;
-        const bool over = tt >= Tp;
-        const int64_t t = over ? tt - Tp : tt, len = over ? plen1 : plen0;
-        pad_bits |= ((r0 + row < M && (int64_t)mask_mul * t >= len) ? 1u : 0u) << r;
-      }
+      const int tt = pt0 + l31;
+      const bool over = tt >= Tp;
+      const int64_t t = over ? tt - Tp : tt, len = over ? plen1 : plen0;
+      pad = r0 + l31 < M && (int64_t)mask_mul * t >= len;
     } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pad_bits |= (is_pad(acc_row(r, lane)) ? 1u : 0u) << r;
+      pad = is_pad(l31);
     }
   }
   __syncthreads();
@@ -1483,13 +1494,14 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   {
     f32x16 acc[1][1];
     acc_zero(acc);
-    rb_gemm<1, 1, kG256>(bufA, kLda, seg_pw2, 0, w.ff_w1 + (size_t)wave * kTs256, 0, ring, acc);
-    const float bv = w.pw2_b[col];
+    rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg_pw2, 0, w.ff_w1 + (size_t)wave * kTs256, 0, ring, acc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = acc_row(r, lane);
-      const float c = ((pad_bits >> r) & 1u) ? 0.f : acc[0][0][r] + bv;
-      bufX[row * kLda + col] = (row < valid) ? res[r] + c : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(w.pw2_b + cq + 8 * q);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (l31 < valid) ? res[q][e] + (pad ? 0.f : acc[0][0][4 * q + e] + bv[e]) : 0.f;
+      *reinterpret_cast<f32x4*>(bufX + l31 * kLda + cq + 8 * q) = o;
     }
   }
   __syncthreads();
@@ -1499,10 +1511,10 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   PPASR_TS(4);
   f32x16 acc2[1][1];
   acc_zero(acc2);
-  ffn_phase(bufA, bufH, w.ff_w1, w.ff_b1, w.ff_w2, n_chunks, NEXT ? wn.ffm_w1 + (size_t)wave * kTs256 : nullptr, ring,
-            acc2);
+  ffn_phase<true>(bufA, bufH, w.ff_w1, w.ff_b1, w.ff_w2, n_chunks, NEXT ? wn.ffm_w1 + (size_t)wave * kTs256 : nullptr,
+                  ring, acc2);
   PPASR_TS(5);
-  residual_epilogue(bufX, acc2, w.ff_b2, 0.5f);
+  residual_epilogue_t(bufX, acc2, w.ff_b2, 0.5f);
   __syncthreads();
   PPASR_TS(6);
   rb_layernorm(bufX, bufX, kLda, kRows, w.ln_fin_g, w.ln_fin_b, 1e-5f);

@@ -34,6 +34,8 @@ struct SwishSide {
 // The swish epilogue of chunk c runs inside the W1(c+1) MFMA stream.
 // c0 / n_total: the call covers hidden chunks [c0, c0 + n_chunks) of a layer with n_total chunks (a slice of the hidden
 // dimension = a partial sum of the output, k_ffn_part); default = all of them.
+// T2: the W2 units run swapped as well -- acc2 is then the TRANSPOSED output tile (lane = row; residual_epilogue_t)
+template <bool T2 = false>
 __device__ __forceinline__ void ffn_phase(const float* bufA, float* bufH, const f32x4* __restrict__ w1,
                                           const float* __restrict__ b1, const f32x4* __restrict__ w2, int n_chunks,
                                           const f32x4* __restrict__ after, BRing<1>& ring, f32x16 (&acc2)[1][1],
@@ -76,7 +78,7 @@ __device__ __forceinline__ void ffn_phase(const float* bufA, float* bufH, const 
     if (c < 8) PPASR_TS(17 + 2 * c);
     if (c < 8) PPASR_WAVE_TS(2 * c + 1);
     const f32x4* nseg = (c + 2 < n_chunks) ? w1seg(c + 2) : (c + 1 < n_chunks ? w2seg(c + 1) : after);
-    rb_gemm<1, 1, kG256>(hb, kLda, w2seg(c), 0, nseg, 0, ring, acc2);
+    rb_gemm<1, 1, kG256, kPF, NoSide, T2>(hb, kLda, w2seg(c), 0, nseg, 0, ring, acc2);
     cur[0][0] = nx[0][0];
   }
 }
@@ -91,6 +93,23 @@ __device__ __forceinline__ void residual_epilogue(float* bufX, const f32x16 (&ac
   for (int r = 0; r < 16; ++r) {
     float* p = bufX + acc_row(r, lane) * kLda + col;
     *p = *p + scale * (acc[0][0][r] + bv);
+  }
+}
+
+// the same on a transposed accumulator (rb_gemm SWAP: lane = row, register quad q = columns wave*32 + 8q + 4hh .. +3):
+// 4 16-byte LDS read-modify-writes per lane instead of 16 4-byte ones
+__device__ __forceinline__ void residual_epilogue_t(float* bufX, const f32x16 (&acc)[1][1], const float* __restrict__ bias,
+                                                    float scale) {
+  const int lane = lane_id(), wave = wave_id();
+  const int cq = wave * 32 + 4 * (lane >> 5);
+  float* row = bufX + (lane & 31) * kLda + cq;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + cq + 8 * q);
+    f32x4 x = *reinterpret_cast<const f32x4*>(row + 8 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = x[e] + scale * (acc[0][0][4 * q + e] + bv[e]);
+    *reinterpret_cast<f32x4*>(row + 8 * q) = x;
   }
 }
 
