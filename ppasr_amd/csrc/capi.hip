@@ -478,7 +478,9 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     static const int fuse_min_blocks =
         getenv("PPASR_ATTN_FUSE_MIN_BLOCKS") ? atoi(getenv("PPASR_ATTN_FUSE_MIN_BLOCKS")) : 128;
     auto fusable = [&](int layer) {
-      return h->layer_group[layer] == 1 && h->desc.attention_heads == 4 && !h->taps &&
+      // (the fused kernel reads the values in fragment order, which only the fused QKV stage -- ffn_qkv_body -- writes: a
+      //  FORCED split of a large batch (ppasr_set_ffn_split(2 / 4 / 8), k_ln_qkv) therefore takes the two-kernel route)
+      return h->layer_group[layer] == 1 && h->desc.attention_heads == 4 && !h->taps && ffn_split_for(h, Mi) == 1 &&
              (h->ffn_split == 0 || (Mi + kRows - 1) / kRows > fuse_min_blocks);  // (ppasr_set_ffn_split(0): always fused)
     };
     const bool fuse_attn = fusable(i);

@@ -91,3 +91,22 @@ def test_split_mode_with_ragged_batch_and_skip_padding():
     for b, ln in enumerate(lens):
         nv = min(p0.shape[1], (ln + 3) // 4)
         assert torch.equal(p0[b, :nv], p1[b, :nv]) and not bool(p1[b, nv:].any())
+
+
+def test_forced_split_on_a_batch_above_the_fused_attention_threshold():
+    """> 128 row blocks: the default takes the fused kernels (attention reading the values in fragment order, which only
+    the fused QKV stage writes).  A FORCED split must not pair the split QKV kernel with that attention kernel
+    (tools/fuzz_split.py found logits off by 0.27 when it did): every mode within 1e-5 of the fused route."""
+    model, _ = _conformer(True)
+    B, T = 20, 1159
+    lens = [T] + [int(v) for v in np.random.Generator(np.random.PCG64(7)).integers(200, T, size=B - 1)]
+    x, la = synth_features(B, T, lens=lens, seed=11)
+    assert B * ((T - 3) // 4) > 128 * 32
+    model.set_ffn_split(0)
+    ref = model.get_encoder_out(x, la, return_logits=True)[1]
+    for mode in (2, 8, -1):
+        model.set_ffn_split(mode)
+        got = model.get_encoder_out(x, la, return_logits=True)[1]
+        torch.cuda.synchronize()
+        assert _rel(got.cpu().numpy(), ref.cpu().numpy()) < 1e-5, mode
+    model.set_ffn_split(-1)
