@@ -80,13 +80,33 @@ class ConformerOracle:
         # GlobalCMVN.forward  utils/cmvn.py:29-31
         return (x - self.p["encoder.global_cmvn.mean"]) * self.p["encoder.global_cmvn.istd"]
 
+    def _sub_kind(self):
+        """4, 6 or 8: which Conv2dSubsampling class the parameters belong to (subsampling.py:63, 118, 160): the 6x / 8x
+        classes name their projection `linear`, the 8x one has a third conv (`conv.4`)."""
+        if "encoder.embed.out.0.weight" in self.p:
+            return 4
+        return 8 if "encoder.embed.conv.4.weight" in self.p else 6
+
+    def _sub_masks(self, masks):
+        """The mask slicing of the subsampling classes (subsampling.py:115, 157, 205)."""
+        k = self._sub_kind()
+        if k == 4:
+            return masks[:, :, :-2:2][:, :, :-2:2]
+        if k == 6:
+            return masks[:, :, :-2:2][:, :, :-4:3]
+        return masks[:, :, :-2:2][:, :, :-2:2][:, :, :-2:2]
+
     def _embed(self, x, offset):
-        # Conv2dSubsampling4.forward  conformer/subsampling.py:96-115
+        # Conv2dSubsampling4 / 6 / 8 .forward  conformer/subsampling.py:96-115, 144-157, 191-205
+        k = self._sub_kind()
         x = x.unsqueeze(1)
         x = F.relu(F.conv2d(x, self.p["encoder.embed.conv.0.weight"], self.p["encoder.embed.conv.0.bias"], stride=2))
-        x = F.relu(F.conv2d(x, self.p["encoder.embed.conv.2.weight"], self.p["encoder.embed.conv.2.bias"], stride=2))
+        x = F.relu(F.conv2d(x, self.p["encoder.embed.conv.2.weight"], self.p["encoder.embed.conv.2.bias"],
+                            stride=3 if k == 6 else 2))
+        if k == 8:
+            x = F.relu(F.conv2d(x, self.p["encoder.embed.conv.4.weight"], self.p["encoder.embed.conv.4.bias"], stride=2))
         b, c, t, f = x.shape
-        x = self._linear(x.permute(0, 2, 1, 3).reshape(b, t, c * f), "encoder.embed.out.0")
+        x = self._linear(x.permute(0, 2, 1, 3).reshape(b, t, c * f), "encoder.embed.out.0" if k == 4 else "encoder.embed.linear")
         # RelPositionalEncoding.forward  conformer/embedding.py:102-115 (x*sqrt(d); pos_emb NOT added)
         assert offset + t < self.max_len
         x = x * math.sqrt(self.d)
@@ -203,7 +223,7 @@ class ConformerOracle:
         masks = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(1)  # [B,1,T] True=valid
         xs = self._cmvn(xs)
         xs, pos_emb = self._embed(xs, 0)
-        masks = masks[:, :, :-2:2][:, :, :-2:2]  # subsampling.py:115
+        masks = self._sub_masks(masks)  # subsampling.py:115 / 157 / 205
         mask_pad = ~masks
         # add_optional_chunk_mask with decoding_chunk_size<0: chunk = max_len -> all-ones & pad mask
         # (utils/mask.py:153-177) -> [B, T', T'] ; only keys are masked

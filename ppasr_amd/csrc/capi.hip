@@ -105,9 +105,15 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
   std::unique_ptr<ppasr_model_s> guard(m);
   m->desc = *desc;
   const int F = desc->input_dim, d = kD, H = desc->linear_units, V = desc->vocab_size, KS = desc->cnn_module_kernel;
+  const int il = desc->input_layer;
+  if (il != 0 && il != 6 && il != 8) return fail(PPASR_EINVAL, "input_layer: 0 (conv2d), 6 (conv2d6) or 8 (conv2d8)");
+  if (il != 0 && desc->model_type == PPASR_MODEL_SQUEEZEFORMER)
+    return fail(PPASR_EUNSUPPORTED, "squeezeformer: only the conv2d front end is built");
   m->F1 = (F - 1) / 2;
-  m->F2 = (m->F1 - 1) / 2;
-  const int F2 = m->F2;
+  m->F2 = il == 6 ? (m->F1 - 5) / 3 + 1 : (m->F1 - 1) / 2;
+  m->F3 = il == 8 ? (m->F2 - 1) / 2 : 0;
+  if (m->F_last() < 1) return fail(PPASR_EINVAL, "input_dim too small for this input_layer");
+  const int F2 = m->F_last();  // feature bins entering the linear layer
   ppasr_status st;
 #define UP(vec, dst) \
   if ((st = m->upload(vec, &(dst))) != PPASR_OK) return st
@@ -128,10 +134,13 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
     GET(istd, "encoder.global_cmvn.istd", F);
     GET(c1w, "encoder.embed.conv.0.weight", d * 9);
     GET(c1b, "encoder.embed.conv.0.bias", d);
-    GET(c2w, "encoder.embed.conv.2.weight", (size_t)d * d * 9);
+    const int k2 = il == 6 ? 5 : 3;  // Conv2dSubsampling6: Conv2D(odim, odim, 5, 3) (subsampling.py:139-141)
+    GET(c2w, "encoder.embed.conv.2.weight", (size_t)d * d * k2 * k2);
     GET(c2b, "encoder.embed.conv.2.bias", d);
-    GET(ew, "encoder.embed.out.0.weight", (size_t)d * F2 * d);
-    GET(eb, "encoder.embed.out.0.bias", d);
+    // Conv2dSubsampling4 names its projection `out` (a Sequential), the 6x / 8x classes `linear` (subsampling.py:142,189)
+    const std::string lin = il ? "encoder.embed.linear" : "encoder.embed.out.0";
+    GET(ew, lin + ".weight", (size_t)d * F2 * d);
+    GET(eb, lin + ".bias", d);
     UP(vec_of(mean, F), m->front.cmvn_mean);
     UP(vec_of(istd, F), m->front.cmvn_istd);
     std::vector<float> c1(9 * d);
@@ -139,9 +148,20 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
       for (int j = 0; j < 9; ++j) c1[j * d + c] = c1w[c * 9 + j];
     UP(c1, m->front.conv1_w);
     UP(vec_of(c1b, d), m->front.conv1_b);
-    // conv2: K index = (kh*3+kw)*256 + cin ; weight layout [cout][cin][kh][kw]
-    UP4(pack_b(9 * d, d, [&](int k, int n) { return c2w[((size_t)n * d + (k % d)) * 9 + (k / d)]; }), m->front.conv2_w);
+    // conv2: K index = (kh*k+kw)*256 + cin ; weight layout [cout][cin][kh][kw]
+    const int taps2 = k2 * k2;
+    UP4(pack_b(taps2 * d, d, [&](int k, int n) { return c2w[((size_t)n * d + (k % d)) * taps2 + (k / d)]; }), m->front.conv2_w);
     UP(vec_of(c2b, d), m->front.conv2_b);
+    m->front.conv2_k = k2;
+    m->front.conv2_s = il == 6 ? 3 : 2;
+    m->front.conv3_w = nullptr;
+    m->front.conv3_b = nullptr;
+    if (il == 8) {  // third Conv2D(odim, odim, 3, 2) (subsampling.py:183-187)
+      GET(c3w, "encoder.embed.conv.4.weight", (size_t)d * d * 9);
+      GET(c3b, "encoder.embed.conv.4.bias", d);
+      UP4(pack_b(9 * d, d, [&](int k, int n) { return c3w[((size_t)n * d + (k % d)) * 9 + (k / d)]; }), m->front.conv3_w);
+      UP(vec_of(c3b, d), m->front.conv3_b);
+    }
     // embed: our K index = f*256 + c ; Paddle's = c*F2 + f (subsampling.py:113 transpose+reshape)
     UP4(pack_b(F2 * d, d, [&](int k, int n) { return ew[((size_t)(k % d) * F2 + (k / d)) * d + n]; }), m->front.embed_w);
     UP(vec_of(eb, d), m->front.embed_b);
@@ -299,8 +319,8 @@ ppasr_status ppasr_destroy(ppasr_handle h) {
 }
 
 int ppasr_out_frames(ppasr_handle h, int T) {
-  if (T < 7) return 0;
-  int tp = ((T - 1) / 2 - 1) / 2;
+  if (T < (h ? h->min_frames() : 7)) return 0;
+  int tp = h ? h->front_dims(T).Tp : ((T - 1) / 2 - 1) / 2;
   // Efficient-Conformer: the stride-2 conv layer halves the frame rate (ceil), efficient_conformer/encoder.py:252-257
   if (h && h->desc.model_type == PPASR_MODEL_EFFICIENT_CONFORMER && h->desc.stride_layer_idx >= 0) tp = (tp + 1) / 2;
   return tp;
@@ -308,13 +328,14 @@ int ppasr_out_frames(ppasr_handle h, int T) {
 
 }  // extern "C"
 WsLayout ws_layout(const ppasr_model_s* m, int B, int T) {
-  const size_t T1 = (T - 1) / 2, Tp = (T1 - 1) / 2;
+  const auto fd = m->front_dims(T);
+  const size_t T1 = fd.T1, Tp = fd.Tp;
   const size_t M = (size_t)B * Tp;
   auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };
   WsLayout w;
   size_t o = 0;
-  w.y1 = o; o += al((size_t)B * T1 * m->F1 * kD);
-  w.y2 = o; o += al(M * m->F2 * kD);
+  w.y1 = o; o += al((size_t)B * T1 * m->F1 * kD);  // (conv2d8: the third conv's output reuses it)
+  w.y2 = o; o += al((size_t)B * (fd.T2 ? fd.T2 : Tp) * m->F2 * kD);
   w.xa = o; o += al(M * kD);
   w.xb = o; o += al(M * kD);
   w.xc = o; o += al(M * kD);
@@ -398,9 +419,11 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
                           float* logits, int32_t* frame_argmax, float* frame_maxprob, void* workspace,
                           size_t workspace_bytes, void* stream) {
   if (!h || !feats || !workspace) return fail(PPASR_EINVAL, "null argument");
-  if (B <= 0 || T < 7) return fail(PPASR_EINVAL, "need B > 0 and T >= 7 frames");
+  if (B <= 0 || T < h->min_frames()) return fail(PPASR_EINVAL, "need B > 0 and T >= 7 (conv2d6: 11, conv2d8: 15) frames");
   if (h->desc.model_type == PPASR_MODEL_DEEPSPEECH2) return fail(PPASR_EINVAL, "deepspeech2 handles use ppasr_ds2_encode");
-  const int F = h->desc.input_dim, T1 = (T - 1) / 2, F1 = h->F1, Tp = (T1 - 1) / 2, F2 = h->F2;
+  const auto fd = h->front_dims(T);
+  const int F = h->desc.input_dim, T1 = fd.T1, F1 = h->F1, Tp = fd.Tp, F2 = h->F2;
+  const int sub = h->sub_rate();  // frame t of the encoder is PAD iff sub * t >= len (the reference's mask slicing)
   if (Tp >= h->desc.max_len) return fail(PPASR_EINVAL, "utterance longer than the positional table (embedding.py:64-66)");
   const int M = B * Tp;
   const WsLayout wl = ws_layout(h, B, T);
@@ -446,7 +469,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   // what valid outputs read from the rows behind them: the right context of the non-causal conv module, and with a
   // rate change (Efficient-Conformer) the stride layer's 2j / 2j+1 rows and the 3-frame groups of grouped attention.
   const bool eff = h->desc.model_type == PPASR_MODEL_EFFICIENT_CONFORMER;
-  const bool skip = h->skip_padding && lens && !h->taps;
+  const bool skip = h->skip_padding && lens && !h->taps && h->desc.input_layer == 0;  // (6x / 8x front ends: all rows)
   const int rc = h->desc.causal ? 0 : (h->desc.cnn_module_kernel - 1) / 2;
   const int slack_half = rc + 4, slack_full = eff ? 2 * slack_half + rc + 8 : rc + 4;
   auto pskip = [&](int Tcur, int mul_cur) {
@@ -455,16 +478,25 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       ps.lens = lens;
       ps.Tp = Tcur;
       ps.mul = mul_cur;
-      ps.slack = mul_cur == 4 ? slack_full : slack_half;
+      ps.slack = mul_cur == 4 ? slack_full : slack_half;  // (skip mode exists for the 4x front end only)
     }
     return ps;
   };
-  timed(0, [&] { launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, pskip(Tp, 4)); });
-  timed(1, [&] { launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, pskip(Tp, 4)); });
-  timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st, pskip(Tp, 4), ffn_split_for(h, M), y1); });
+  timed(0, [&] { launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, pskip(Tp, sub)); });
+  if (h->desc.input_layer == 8) {
+    // Conv2dSubsampling8: conv1 -> conv2 (3x3 / 2) -> conv3 (3x3 / 2, written over conv1's output) -> linear
+    timed(1, [&] {
+      launch_conv_stage(y1, h->front.conv2_w, h->front.conv2_b, y2, B, T1, F1, fd.T2, F2, 3, 2, st);
+      launch_conv_stage(y2, h->front.conv3_w, h->front.conv3_b, y1, B, fd.T2, F2, Tp, h->F3, 3, 2, st);
+    });
+    timed(2, [&] { launch_embed(y1, h->front, xa, M, h->F3 * kD, sqrtf((float)kD), false, st, PadSkip{}, ffn_split_for(h, M), y2); });
+  } else {
+    timed(1, [&] { launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, pskip(Tp, sub)); });
+    timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st, pskip(Tp, sub), ffn_split_for(h, M), y1); });
+  }
   tap(xa, (size_t)M * kD);
   const int n_chunks = h->desc.linear_units / 256;
-  int Ti = Tp, mul = 4, pstride = 1;  // frames per utterance / pad-mask multiplier / positional stride of the current layer
+  int Ti = Tp, mul = sub, pstride = 1;  // frames per utterance / pad-mask multiplier / positional stride of the current layer
   bool s1_done = false;               // this layer's S1 already ran inside the previous layer's last launch
   for (int i = 0; i < h->desc.num_blocks; ++i) {
     const LayerW& L = h->layers[i];

@@ -65,6 +65,27 @@ typedef std::unordered_map<std::string, Blob> BlobMap;
 struct ppasr_model_s {
   ppasr_model_desc desc;
   int F1, F2;
+  int F3 = 0;  // conv2d8: feature bins behind the third conv (F2 behind the second); 0 otherwise
+  // front-end geometry for T input frames (Conv2dSubsampling4 / 6 / 8, subsampling.py): frames behind conv1, behind the
+  // intermediate conv (conv2d8 only, else 0) and encoder frames; F_last = feature bins entering the linear layer
+  struct Front {
+    int T1, T2, Tp;
+  };
+  int sub_rate() const { return desc.input_layer ? desc.input_layer : 4; }
+  int F_last() const { return desc.input_layer == 8 ? F3 : F2; }
+  int min_frames() const { return desc.input_layer == 6 ? 11 : desc.input_layer == 8 ? 15 : 7; }
+  Front front_dims(int T) const {
+    Front f{(T - 1) / 2, 0, 0};
+    if (desc.input_layer == 6) {
+      f.Tp = (f.T1 - 5) / 3 + 1;
+    } else if (desc.input_layer == 8) {
+      f.T2 = (f.T1 - 1) / 2;
+      f.Tp = (f.T2 - 1) / 2;
+    } else {
+      f.Tp = (f.T1 - 1) / 2;
+    }
+    return f;
+  }
   std::vector<void*> allocs;
   FrontW front;
   std::vector<LayerW> layers;

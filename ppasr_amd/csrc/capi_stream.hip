@@ -251,6 +251,8 @@ ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out) {
     return fail(PPASR_EUNSUPPORTED, "deepspeech2 streams carry their state in the h/c boxes of ppasr_ds2_encode");
   if (!h->desc.causal)
     return fail(PPASR_EUNSUPPORTED, "forward_chunk needs the causal conv module (a streaming=True model)");
+  if (h->desc.input_layer != 0)
+    return fail(PPASR_EUNSUPPORTED, "stream handles are built for the conv2d front end only (input_layer conv2d6 / conv2d8: batched encode)");
   auto* s = new ppasr_stream_s();
   s->m = h;
   s->cap = h->desc.max_len;
@@ -428,6 +430,7 @@ ppasr_status ppasr_stream_group_create(ppasr_handle h, int n_sessions, int max_f
   if (!h || !out || n_sessions < 1) return fail(PPASR_EINVAL, "bad argument");
   if (h->desc.model_type != PPASR_MODEL_CONFORMER || !h->desc.causal)
     return fail(PPASR_EUNSUPPORTED, "session groups are built for streaming (causal) model_type=conformer");
+  if (h->desc.input_layer != 0) return fail(PPASR_EUNSUPPORTED, "session groups are built for the conv2d front end only");
   auto g = std::make_unique<ppasr_stream_group_s>();
   g->m = h;
   g->n_sessions = n_sessions;

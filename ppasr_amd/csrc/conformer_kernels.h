@@ -25,8 +25,11 @@ struct LayerW {
 struct FrontW {
   const float *cmvn_mean, *cmvn_istd;  // [F]
   const float *conv1_w, *conv1_b;      // [9][256] tap-major, [256]
-  const f32x4 *conv2_w;                // packed, K = 9*256 ordered (kh,kw,cin)
+  const f32x4 *conv2_w;                // packed, K = k*k*256 ordered (kh,kw,cin)
   const float *conv2_b;
+  int conv2_k = 3, conv2_s = 2;        // 3, 2 (conv2d / conv2d8, Squeezeformer) or 5, 3 (conv2d6)
+  const f32x4 *conv3_w = nullptr;      // conv2d8 only: third 3x3 / 2 conv, packed like conv2_w
+  const float *conv3_b = nullptr;
   const f32x4 *embed_w;                // packed, K = f2*256 ordered (f', c)
   const float *embed_b;
 };
@@ -93,6 +96,9 @@ void launch_posproj(const float* pe, const float* wpos /*[256][256] in,out*/, co
 // every row-block launcher takes an optional PadSkip (rowblock.h): default = compute all rows
 void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T, int F, int T1, int F1, hipStream_t st,
                   const PadSkip& ps = PadSkip{});
+// one k x k / stride-s 256 -> 256 channel conv + ReLU of the front end on NHWC activations (implicit GEMM)
+void launch_conv_stage(const float* y_in, const f32x4* w, const float* bias, float* y_out, int B, int T_in, int F_in,
+                       int T_out, int F_out, int k, int s, hipStream_t st, const PadSkip& ps_frames = PadSkip{});
 void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st,
                   const PadSkip& ps = PadSkip{});
 // scale_before_bias: Squeezeformer scales the 4864-wide conv output by sqrt(d) BEFORE input_proj

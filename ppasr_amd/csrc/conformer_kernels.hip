@@ -88,17 +88,18 @@ void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T,
 struct Conv2Src {
   const float* y1;
   int T1, F1, Tp, F2;
+  int k = 3, s = 2;  // kernel size / stride (3, 2: Conv2dSubsampling4 / 8; 5, 3: the second conv of Conv2dSubsampling6)
   __device__ __forceinline__ const float* base(int m) const {
     int f2 = m % F2;
     int bt = m / F2;
     int tp = bt % Tp;
     int b = bt / Tp;
-    return y1 + ((size_t)((b * T1 + 2 * tp) * F1 + 2 * f2)) * 256;
+    return y1 + ((size_t)((b * T1 + s * tp) * F1 + s * f2)) * 256;
   }
   // KC = 128: chunk kc -> tap kc>>1 (kh,kw), channel half kc&1
   __device__ __forceinline__ size_t chunk_off(int kc) const {
     int tap = kc >> 1;
-    int kh = tap / 3, kw = tap - 3 * kh;
+    int kh = tap / k, kw = tap - k * kh;
     return ((size_t)(kh * F1 + kw)) * 256 + (kc & 1) * 128;
   }
 };
@@ -217,7 +218,12 @@ __global__ __launch_bounds__(256) void k_gemm_join(const float* __restrict__ par
 
 void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st,
                   const PadSkip& ps_frames) {
-  Conv2Src src{y1, T1, F1, Tp, F2};
+  launch_conv_stage(y1, fw.conv2_w, fw.conv2_b, y2, B, T1, F1, Tp, F2, fw.conv2_k, fw.conv2_s, st, ps_frames);
+}
+void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b, float* y2, int B, int T1, int F1, int Tp,
+                       int F2, int ksz, int stride, hipStream_t st, const PadSkip& ps_frames) {
+  Conv2Src src{y1, T1, F1, Tp, F2, ksz, stride};
+  const int n_kc = 2 * ksz * ksz;  // 128-wide K chunks: two per tap
   PadSkip ps = ps_frames;
   ps.unit = F2;  // rows are (frame, f2) pairs
   const int M = B * Tp * F2;
@@ -235,7 +241,7 @@ void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, i
     const int mt = (M + 32 * kCUs - 1) / (32 * kCUs);  // 1 .. 4
 #define CONV2_ALL(MTA)                                                                                                    \
   PPASR_LAUNCH((k_gemm_stream<MTA, KC, true, false, Conv2Src>), dim3((M + 32 * MTA - 1) / (32 * MTA)),              \
-                     dim3(kThreads), lds_of(MTA), st, src, fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, 0, ps)
+                     dim3(kThreads), lds_of(MTA), st, src, conv_w, conv_b, y2, M, n_kc, 1.0f, kD, kD, 0, ps)
     if (mt <= 1) CONV2_ALL(1);
     else if (mt == 2) CONV2_ALL(2);
     else if (mt == 3) CONV2_ALL(3);
@@ -245,15 +251,15 @@ void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, i
   }
   if (rem_rows <= 0 || mt_rem >= 4) {
     PPASR_LAUNCH((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(tiles4), dim3(kThreads), lds_of(4), st, src,
-                       fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, 0, ps);
+                       conv_w, conv_b, y2, M, n_kc, 1.0f, kD, kD, 0, ps);
     return;
   }
   PPASR_LAUNCH((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(full), dim3(kThreads), lds_of(4), st, src,
-                     fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, 0, ps);
+                     conv_w, conv_b, y2, M, n_kc, 1.0f, kD, kD, 0, ps);
   const int m0 = full * 128;
 #define CONV2_REM(MTR)                                                                                                    \
   PPASR_LAUNCH((k_gemm_stream<MTR, KC, true, false, Conv2Src>), dim3((rem_rows + 32 * MTR - 1) / (32 * MTR)),       \
-                     dim3(kThreads), lds_of(MTR), st, src, fw.conv2_w, fw.conv2_b, y2, M, 18, 1.0f, kD, kD, m0, ps)
+                     dim3(kThreads), lds_of(MTR), st, src, conv_w, conv_b, y2, M, n_kc, 1.0f, kD, kD, m0, ps)
   if (mt_rem <= 1) CONV2_REM(1);
   else if (mt_rem == 2) CONV2_REM(2);
   else CONV2_REM(3);

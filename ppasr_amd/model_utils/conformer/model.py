@@ -52,11 +52,17 @@ class ConformerModel:
         self.num_blocks = int(conf.get("num_blocks", 6))
         self.cnn_module_kernel = int(conf.get("cnn_module_kernel", 15))
         self.max_len = int(conf.get("max_len", 5000))
-        for key, want in (("input_layer", "conv2d"), ("pos_enc_layer_type", "rel_pos"), ("activation_type", "swish"),
+        for key, want in (("pos_enc_layer_type", "rel_pos"), ("activation_type", "swish"),
                           ("normalize_before", True), ("use_cnn_module", True),
                           ("macaron_style", True)):
             if key in conf and conf[key] != want:
                 raise NotImplementedError(f"encoder_conf.{key}={conf[key]!r}: only {want!r} is built")
+        # input_layer (encoder.py:93-104): Conv2dSubsampling4, or the 6x / 8x variants (batched encode only)
+        il = conf.get("input_layer", "conv2d")
+        if il not in ("conv2d", "conv2d6", "conv2d8"):
+            raise NotImplementedError(f"encoder_conf.input_layer={il!r}: conv2d, conv2d6 and conv2d8 are built")
+        self.input_layer = il
+        self.subsampling_rate = {"conv2d": 4, "conv2d6": 6, "conv2d8": 8}[il]
         # cnn_module_norm (convolution.py:65-71): layer_norm, or batch_norm = nn.BatchNorm1D in eval mode, which the
         # library folds into a per-channel scale / shift; the checkpoint carries the running statistics then
         norm = conf.get("cnn_module_norm", "layer_norm")
@@ -88,7 +94,8 @@ class ConformerModel:
                 blobs[i].shape[j] = a.shape[j]
         desc = _lib.ModelDesc(_lib.PPASR_MODEL_CONFORMER, input_dim, vocab_size, self.output_size,
                               self.attention_heads, self.linear_units, self.num_blocks, self.cnn_module_kernel,
-                              1 if streaming else 0, self.max_len, -1, -1, -1, 0, 0)
+                              1 if streaming else 0, self.max_len, -1, -1, -1, 0, 0, 0,
+                              {"conv2d": 0, "conv2d6": 6, "conv2d8": 8}[self.input_layer])
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ppasr_create(ctypes.byref(desc), blobs, len(sd), ctypes.byref(handle)))
@@ -174,7 +181,7 @@ class ConformerModel:
         ``mul * t < len`` with ``mul`` = the model's total time reduction (the reference's mask slicing,
         subsampling.py:115; x2 behind the Efficient-Conformer's stride layer)."""
         lens = torch.as_tensor(speech_lengths, dtype=torch.int64).to(self.device)
-        mul = 8 if getattr(self, "stride_layer_idx", None) is not None else 4
+        mul = getattr(self, "subsampling_rate", 4) * (2 if getattr(self, "stride_layer_idx", None) is not None else 1)
         return torch.clamp((lens + mul - 1) // mul, min=0, max=self.out_frames(int(T))).to(torch.int32)
 
     def set_skip_padding(self, enable=True):

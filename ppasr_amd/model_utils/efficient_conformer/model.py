@@ -54,10 +54,16 @@ class EfficientConformerModel(ConformerModel):
         self.group_size = int(one("group_size", 3))
         if not one("stride_kernel", True):
             raise NotImplementedError("stride_kernel=False is not built")
-        for key, want in (("input_layer", "conv2d"), ("pos_enc_layer_type", "rel_pos"), ("activation_type", "swish"),
+        for key, want in (("pos_enc_layer_type", "rel_pos"), ("activation_type", "swish"),
                           ("normalize_before", True), ("use_cnn_module", True)):
             if key in conf and conf[key] != want:
                 raise NotImplementedError(f"encoder_conf.{key}={conf[key]!r}: only {want!r} is built")
+        # input_layer (encoder.py:93-104): Conv2dSubsampling4, or the 6x / 8x variants (batched encode only)
+        il = conf.get("input_layer", "conv2d")
+        if il not in ("conv2d", "conv2d6", "conv2d8"):
+            raise NotImplementedError(f"encoder_conf.input_layer={il!r}: conv2d, conv2d6 and conv2d8 are built")
+        self.input_layer = il
+        self.subsampling_rate = {"conv2d": 4, "conv2d6": 6, "conv2d8": 8}[il]
         # cnn_module_norm (convolution.py:65-71): layer_norm, or batch_norm = nn.BatchNorm1D in eval mode, which the
         # library folds into a per-channel scale / shift; the checkpoint carries the running statistics then
         norm = conf.get("cnn_module_norm", "layer_norm")
@@ -86,7 +92,7 @@ class EfficientConformerModel(ConformerModel):
                               self.attention_heads, self.linear_units, self.num_blocks, self.cnn_module_kernel,
                               1 if streaming else 0,  # causal conv <=> streaming (efficient_conformer/model.py)
                               self.max_len, -1, -1, -1 if stride_idx is None else int(stride_idx), mask,
-                              self.group_size)
+                              self.group_size, 0, {"conv2d": 0, "conv2d6": 6, "conv2d8": 8}[self.input_layer])
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ppasr_create(ctypes.byref(desc), blobs, len(sd), ctypes.byref(handle)))

@@ -64,7 +64,7 @@ def _linear(sd, prefix, fin, fout, rng, bias=True):
 def conformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, output_size=256, attention_heads=4,
                          linear_units=2048, num_blocks=12, cnn_module_kernel=15, seed=1234,
                          ctc_sharpen=8.0, perturb_norm=False, cmvn_mean=10.0, cmvn_istd=1.0 / 3.3,
-                         cnn_module_norm="layer_norm"):
+                         cnn_module_norm="layer_norm", input_layer="conv2d"):
     """Random-init ``ConformerModel`` inference parameters (encoder + CTC head).
 
     ``ctc_sharpen`` multiplies ``ctc.ctc_lo.weight`` so that greedy top-1 margins
@@ -75,20 +75,33 @@ def conformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, output_siz
     rng = np.random.Generator(np.random.PCG64(seed))
     d, h = output_size, attention_heads
     dk = d // h
-    f2 = ((input_dim - 1) // 2 - 1) // 2
+    f1 = (input_dim - 1) // 2
     sd = {}
     sd["encoder.global_cmvn.mean"] = np.full(input_dim, cmvn_mean, np.float32)
     sd["encoder.global_cmvn.istd"] = np.full(input_dim, cmvn_istd, np.float32)
     if perturb_norm:
         sd["encoder.global_cmvn.mean"] += (0.5 * rng.standard_normal(input_dim)).astype(np.float32)
         sd["encoder.global_cmvn.istd"] *= (1.0 + 0.1 * rng.uniform(-1, 1, input_dim)).astype(np.float32)
-    # Conv2dSubsampling4: base.Conv2D (Kaiming, fan_in = Cin*kh*kw)
+    # Conv2dSubsampling4 / 6 / 8 (subsampling.py): base.Conv2D (Kaiming, fan_in = Cin*kh*kw)
     sd["encoder.embed.conv.0.weight"] = _kaiming(rng, (d, 1, 3, 3), 9)
     sd["encoder.embed.conv.0.bias"] = _kaiming(rng, (d,), d)
-    sd["encoder.embed.conv.2.weight"] = _kaiming(rng, (d, d, 3, 3), d * 9)
-    sd["encoder.embed.conv.2.bias"] = _kaiming(rng, (d,), d)
-    sd["encoder.embed.out.0.weight"] = _xavier(rng, (d * f2, d), d * f2, d)
-    sd["encoder.embed.out.0.bias"] = np.zeros(d, np.float32)
+    if input_layer == "conv2d":
+        f_last, lin = (f1 - 1) // 2, "encoder.embed.out.0"
+        sd["encoder.embed.conv.2.weight"] = _kaiming(rng, (d, d, 3, 3), d * 9)
+        sd["encoder.embed.conv.2.bias"] = _kaiming(rng, (d,), d)
+    elif input_layer == "conv2d6":  # Conv2D(odim, odim, 5, 3); projection named `linear`
+        f_last, lin = (f1 - 2) // 3, "encoder.embed.linear"
+        sd["encoder.embed.conv.2.weight"] = _kaiming(rng, (d, d, 5, 5), d * 25)
+        sd["encoder.embed.conv.2.bias"] = _kaiming(rng, (d,), d)
+    elif input_layer == "conv2d8":  # three 3x3 / 2 convs
+        f_last, lin = (((f1 - 1) // 2) - 1) // 2, "encoder.embed.linear"
+        for idx in (2, 4):
+            sd[f"encoder.embed.conv.{idx}.weight"] = _kaiming(rng, (d, d, 3, 3), d * 9)
+            sd[f"encoder.embed.conv.{idx}.bias"] = _kaiming(rng, (d,), d)
+    else:
+        raise ValueError(input_layer)
+    sd[lin + ".weight"] = _xavier(rng, (d * f_last, d), d * f_last, d)
+    sd[lin + ".bias"] = np.zeros(d, np.float32)
     for i in range(num_blocks):
         p = f"encoder.encoders.{i}."
         for name in ("linear_q", "linear_k", "linear_v", "linear_out"):

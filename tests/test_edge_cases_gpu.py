@@ -121,3 +121,32 @@ def test_maximum_length_and_one_past_it():
     assert model.out_frames(20003) == 5000
     with pytest.raises(_lib.PPASRHipError):
         model.get_encoder_out(x2, lens2)
+
+
+@pytest.mark.parametrize("input_layer,t_min,rate", [("conv2d6", 11, 6), ("conv2d8", 15, 8)])
+def test_wider_front_ends_edges(input_layer, t_min, rate):
+    """input_layer conv2d6 / conv2d8 (Conv2dSubsampling6 / 8, subsampling.py:118-205): the shortest input gives one frame,
+    one frame less is refused, ragged lengths follow the oracle (masks by rate * t < len), stream handles are refused."""
+    from oracle.conformer_oracle import ConformerOracle
+    from ppasr_amd import _lib
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    V, L = 50, 1
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=3, input_layer=input_layer)
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15,
+                input_layer=input_layer)
+    model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    assert model.subsampling_rate == rate and model.out_frames(t_min) == 1 and model.out_frames(t_min - 1) == 0
+    with pytest.raises(_lib.PPASRHipError):
+        model.get_encoder_out(np.zeros((1, t_min - 1, 80), np.float32), [t_min - 1])
+    oracle = ConformerOracle(sd, num_blocks=L)
+    for B, T, lens in ((1, t_min, [t_min]), (3, 157, [157, 80, 9]), (2, 1000, [1000, 333])):
+        x, la = synth_features(B, T, lens=lens, seed=T)
+        probs, logits = model.get_encoder_out(x, la, return_logits=True)
+        ref_probs, ref_logits = oracle.get_encoder_out(x, la, return_logits=True)
+        torch.cuda.synchronize()
+        assert tuple(probs.shape) == tuple(ref_probs.shape)
+        assert _rel(logits.cpu().numpy(), ref_logits.numpy()) < TOL
+        nv = model.valid_out_frames(la, T).cpu().numpy()
+        assert list(nv) == [min(probs.shape[1], (ln + rate - 1) // rate) for ln in lens]
+    with pytest.raises(_lib.PPASRHipError):
+        model.get_encoder_out_chunk(np.zeros((1, 67, 80), np.float32), 0, -1)
