@@ -149,6 +149,11 @@ size_t ppasr_ctc_beam_state_bytes(int B, int max_frames, int beam_size);
  * survive (cutoff_prob >= 1, where upstream ignores cutoff_top_n; or cutoff_top_n > 128) keeps the 128 most probable
  * characters of each frame. */
 int ppasr_ctc_beam_candidate_cap(void);
+/* Streaming past the sized capacity: copies the beams and prefix arenas of a state buffer into a LARGER one (sized with
+ * ppasr_ctc_beam_state_bytes for more frames), which then continues the same search.  The reference's decoder object has
+ * no frame limit; callers double the buffer when the next chunk would not fit.  Asynchronous on `stream`. */
+ppasr_status ppasr_ctc_beam_state_grow(const void* old_state, size_t old_bytes, void* new_state, size_t new_bytes, int B,
+                                       int beam_size, void* stream);
 /* Reads back the per-utterance status words of a (streaming) state buffer: non-zero = the prefix arena ran out because
  * more cumulative frames were decoded than the buffer was sized for; returns PPASR_ENOSPACE then.  Synchronises. */
 ppasr_status ppasr_ctc_beam_status(const void* state, size_t state_bytes, int B, int beam_size, int32_t* status_host,

@@ -681,6 +681,30 @@ ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_l
   return PPASR_OK;
 }
 
+// State layout: B blocks of (fixed + 2 * max_nodes) words (beam arrays, then the parent-pointer arena, node ids in
+// creation order), B status words, the per-call pruning records.  A larger buffer therefore holds the same search once
+// every block's words sit at the start of the new, longer block (the arena simply has room for more nodes behind them).
+ppasr_status ppasr_ctc_beam_state_grow(const void* old_state, size_t old_bytes, void* new_state, size_t new_bytes, int B,
+                                       int beam_size, void* stream) {
+  if (!old_state || !new_state || B <= 0 || beam_size < 1) return fail(PPASR_EINVAL, "null argument");
+  auto geometry = [&](size_t bytes, size_t* block_words) -> bool {
+    const size_t per_utt = bytes / (size_t)B;
+    if (per_utt < beam_utt_fixed_bytes(beam_size) + beam_frame_bytes(beam_size)) return false;
+    const size_t F = (per_utt - beam_utt_fixed_bytes(beam_size)) / beam_frame_bytes(beam_size);
+    *block_words = 2 + (size_t)kBeamStateArrays * beam_size + 2 * (1 + (F + 1) * (size_t)beam_size);
+    return true;
+  };
+  size_t ow = 0, nw = 0;
+  if (!geometry(old_bytes, &ow) || !geometry(new_bytes, &nw)) return fail(PPASR_ENOSPACE, "beam search: state buffer too small");
+  if (nw < ow) return fail(PPASR_EINVAL, "beam search: the new state buffer is smaller than the old one");
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  const int32_t* o = static_cast<const int32_t*>(old_state);
+  int32_t* n = static_cast<int32_t*>(new_state);
+  HIP_TRY(hipMemcpy2DAsync(n, nw * 4, o, ow * 4, ow * 4, (size_t)B, hipMemcpyDeviceToDevice, hs));
+  HIP_TRY(hipMemcpyAsync(n + (size_t)B * nw, o + (size_t)B * ow, (size_t)B * 4, hipMemcpyDeviceToDevice, hs));  // status
+  return PPASR_OK;
+}
+
 // Streaming callers of the C-ABI: the kernel flags an utterance whose prefix arena ran out (more cumulative frames than
 // the state buffer was sized for) in a status word of the state buffer; this reads the B words back (synchronises the
 // stream) and returns PPASR_ENOSPACE if any is set -- the hypotheses of that utterance are then truncated.

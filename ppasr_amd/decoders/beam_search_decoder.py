@@ -73,6 +73,21 @@ class _BeamState:
         self.B, self.max_frames, self.beam_size = B, max_frames, beam_size
         self.frames = 0
         self.fresh = True
+        self.growable = False  # streaming decoder objects: double the buffer instead of failing (the reference has no limit)
+
+    def grow(self, need_frames):
+        """Move the search into a buffer sized for at least ``need_frames`` cumulative frames (doubling)."""
+        lib = _lib.load()
+        cap = self.max_frames
+        while cap < need_frames:
+            cap *= 2
+        dev = self.buf.device
+        nbytes = int(lib.ppasr_ctc_beam_state_bytes(self.B, cap, self.beam_size))
+        new = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.ppasr_ctc_beam_state_grow(self.buf.data_ptr(), self.bytes, new.data_ptr(), nbytes, self.B,
+                                                     self.beam_size, torch.cuda.current_stream(dev).cuda_stream))
+        self.buf, self.bytes, self.max_frames = new, nbytes, cap
 
 
 def beam_search_ids(probs, beam_size, cutoff_prob=1.0, cutoff_top_n=40, blank_id=0, frame_lens=None, nbest=1,
@@ -89,7 +104,9 @@ def beam_search_ids(probs, beam_size, cutoff_prob=1.0, cutoff_top_n=40, blank_id
     if state is None:
         state = _BeamState(B, max_frames if max_frames is not None else T, beam_size, dev)
     if state.frames + T > state.max_frames:
-        raise _lib.PPASRHipError("beam-search state buffer exhausted: create the decoder with a larger max_frames")
+        if not (state.growable and not state.fresh):
+            raise _lib.PPASRHipError("beam-search state buffer exhausted: create the decoder with a larger max_frames")
+        state.grow(state.frames + T)
     L = max(state.frames + T, 1)
     tokens = torch.empty(B, nbest, L, dtype=torch.int32, device=dev)
     lens = torch.empty(B, nbest, dtype=torch.int32, device=dev)
@@ -193,7 +210,8 @@ class BeamSearchDecoder:
             p = p[None]
         if self._state is None:
             dev = p.device if p.is_cuda else torch.device("cuda", torch.cuda.current_device())
-            self._state = _BeamState(p.shape[0], self._max_stream_frames, self.beam_size, dev)
+            self._state = _BeamState(p.shape[0], max(self._max_stream_frames, p.shape[1]), self.beam_size, dev)
+            self._state.growable = True
         lens = np.asarray(logits_lens).astype(np.int32)
         tokens, ln, scores, _ = beam_search_ids(p, self.beam_size, self.cutoff_prob, self.cutoff_top_n, self.blank_id,
                                                 frame_lens=lens, nbest=1, state=self._state, ext_scorer=self._ext_scorer)

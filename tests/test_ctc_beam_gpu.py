@@ -104,6 +104,26 @@ def test_streaming_chunks_equal_offline_and_oracle_object():
     assert dec.decode_chunk(p[None, :16], np.array([16]))[1] != ""  # fresh state after reset
 
 
+def test_streaming_past_the_sized_capacity_grows_the_state():
+    """The reference's decoder object has no frame limit: a stream longer than `max_stream_frames` moves the beams and
+    prefix arenas into a doubled buffer (ppasr_ctc_beam_state_grow) and continues the SAME search -- every chunk's best
+    prefix equals the one of an object sized for the whole stream, the final one the offline decode."""
+    from ppasr_amd.decoders.beam_search_decoder import BeamSearchDecoder
+    rng = np.random.Generator(np.random.PCG64(15))
+    V, beam = 200, 8
+    vocab = ["<blank>"] + [chr(0x4E00 + i) for i in range(V - 1)]
+    p = _probs(rng, 150, V, "peaky")
+    small = BeamSearchDecoder(2.2, 4.3, beam, 0.99, 40, vocab, max_stream_frames=16)
+    big = BeamSearchDecoder(2.2, 4.3, beam, 0.99, 40, vocab, max_stream_frames=400)
+    off_score, off_text = big.decode_beam_search_offline(p)
+    for s in range(0, 150, 13):
+        chunk = np.ascontiguousarray(p[s:s + 13])
+        a = small.decode_chunk(chunk[None], np.array([chunk.shape[0]]))
+        b = big.decode_chunk(chunk[None], np.array([chunk.shape[0]]))
+        assert a[1] == b[1] and abs(a[0] - b[0]) < 1e-9 * max(1.0, abs(b[0])), s
+    assert small._state.max_frames >= 150 and a[1] == off_text
+
+
 def test_frame_lens_and_batch_api():
     from ppasr_amd.decoders.beam_search_decoder import BeamSearchDecoder, beam_search_ids
     lib = _oracle()
