@@ -13,7 +13,7 @@ std::string& ppasr_err_slot() { return g_err; }
 
 
 ppasr_status upload_pe_table(ppasr_model_s* m, BlobMap& sd, const float** pe_dev) {
-  const int d = kD;
+  const int d = m->desc.output_size > 0 ? m->desc.output_size : kD;
   const int max_len = m->desc.max_len > 0 ? m->desc.max_len : 5000;
   m->desc.max_len = max_len;
   std::vector<float> pe((size_t)max_len * d);
@@ -71,8 +71,13 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
     if (desc->stride_layer_idx >= 0 && desc->cnn_module_kernel != 15)
       return fail(PPASR_EUNSUPPORTED, "efficient_conformer: cnn_module_kernel must be 15 (7 after the stride layer)");
   }
-  if (desc->output_size != kD) return fail(PPASR_EUNSUPPORTED, "kernels are specialised for output_size=256");
-  if (desc->attention_heads * 64 != kD) return fail(PPASR_EUNSUPPORTED, "kernels are specialised for d_k=64");
+  // output_size 256 (4 heads of 64): the fused row-block kernels.  Other multiples of 256 up to 1024 (512 with 8 heads):
+  // the generic-width route of capi_generic.hip -- Conformer, conv2d front end, batched encode only.
+  if (desc->output_size % 256 != 0 || desc->output_size < 256 || desc->output_size > 1024)
+    return fail(PPASR_EUNSUPPORTED, "output_size must be 256, 512, 768 or 1024");
+  if (desc->attention_heads * 64 != desc->output_size) return fail(PPASR_EUNSUPPORTED, "kernels are specialised for d_k=64");
+  if (desc->output_size != kD && (desc->model_type != PPASR_MODEL_CONFORMER || desc->input_layer != 0))
+    return fail(PPASR_EUNSUPPORTED, "output_size != 256 is built for model_type=conformer with the conv2d front end");
   if (desc->linear_units % 256 != 0 || desc->linear_units <= 0) return fail(PPASR_EUNSUPPORTED, "linear_units % 256 != 0");
   if (desc->cnn_module_kernel != 15 && desc->cnn_module_kernel != 31 && desc->cnn_module_kernel != 7)
     return fail(PPASR_EUNSUPPORTED, "cnn_module_kernel must be 7, 15 or 31");
@@ -104,7 +109,7 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
   auto* m = new ppasr_model_s();
   std::unique_ptr<ppasr_model_s> guard(m);
   m->desc = *desc;
-  const int F = desc->input_dim, d = kD, H = desc->linear_units, V = desc->vocab_size, KS = desc->cnn_module_kernel;
+  const int F = desc->input_dim, d = desc->output_size, H = desc->linear_units, V = desc->vocab_size, KS = desc->cnn_module_kernel;
   const int il = desc->input_layer;
   if (il != 0 && il != 6 && il != 8) return fail(PPASR_EINVAL, "input_layer: 0 (conv2d), 6 (conv2d6) or 8 (conv2d8)");
   if (il != 0 && desc->model_type == PPASR_MODEL_SQUEEZEFORMER)
@@ -265,7 +270,7 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
       void* pt = nullptr;
       HIP_TRY(hipMalloc(&pt, (size_t)max_len * d * sizeof(float)));
       m->allocs.push_back(pt);
-      launch_posproj(pe_dev, wpos_dev, bpos_dev, static_cast<float*>(pt), max_len, nullptr);
+      launch_posproj(pe_dev, wpos_dev, bpos_dev, static_cast<float*>(pt), max_len, nullptr, d);
       HIP_TRY(hipGetLastError());
       L.ptab = static_cast<const float*>(pt);
     }
@@ -304,6 +309,14 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
     std::vector<float> cbp((size_t)m->head.n_tiles * 32, 0.f);
     std::memcpy(cbp.data(), cb, V * sizeof(float));
     UP(cbp, m->head.b);
+    if (d != kD) {  // generic-width route: the head as a plain dense layer, vocabulary padded to whole 256-column blocks
+      m->gen_vpad = (V + 255) / 256 * 256;
+      const int Vp = m->gen_vpad;
+      UP4(pack_b(d, Vp, [&](int k, int n) { return n < V ? cw[(size_t)k * V + n] : 0.f; }), m->gen_head_w);
+      std::vector<float> hb(Vp, 0.f);
+      std::memcpy(hb.data(), cb, V * sizeof(float));
+      UP(hb, m->gen_head_b);
+    }
   }
   HIP_TRY(hipDeviceSynchronize());
   *out = guard.release();
@@ -328,6 +341,11 @@ int ppasr_out_frames(ppasr_handle h, int T) {
 
 }  // extern "C"
 WsLayout ws_layout(const ppasr_model_s* m, int B, int T) {
+  if (m->desc.output_size != kD && m->desc.model_type == PPASR_MODEL_CONFORMER) {
+    WsLayout g{};
+    g.total = generic_ws_floats(m, B, T);
+    return g;
+  }
   const auto fd = m->front_dims(T);
   const size_t T1 = fd.T1, Tp = fd.Tp;
   const size_t M = (size_t)B * Tp;
@@ -432,6 +450,8 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   float* ws = static_cast<float*>(workspace);
   if (h->desc.model_type == PPASR_MODEL_SQUEEZEFORMER)
     return squeezeformer_encode(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, ws, wl, st);
+  if (h->desc.output_size != kD)
+    return generic_encode(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, ws, st);
   float *y1 = ws + wl.y1, *y2 = ws + wl.y2, *xa = ws + wl.xa, *xb = ws + wl.xb, *xc = ws + wl.xc;
   float *qkv = ws + wl.qkv, *ctx = ws + wl.ctx, *g = ws + wl.g;
   const VtOut vt_out{ws + wl.vt, wl.vt_stride};

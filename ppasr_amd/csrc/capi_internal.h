@@ -65,6 +65,10 @@ typedef std::unordered_map<std::string, Blob> BlobMap;
 struct ppasr_model_s {
   ppasr_model_desc desc;
   int F1, F2;
+  // generic-width route (output_size != 256, capi_generic.hip): CTC head as a dense layer over the padded vocabulary
+  const f32x4* gen_head_w = nullptr;
+  const float* gen_head_b = nullptr;
+  int gen_vpad = 0;
   int F3 = 0;  // conv2d8: feature bins behind the third conv (F2 behind the second); 0 otherwise
   // front-end geometry for T input frames (Conv2dSubsampling4 / 6 / 8, subsampling.py): frames behind conv1, behind the
   // intermediate conv (conv2d8 only, else 0) and encoder frames; F_last = feature bins entering the linear layer
@@ -151,6 +155,11 @@ int ffn_split_for(const ppasr_model_s* m, int M);
 ppasr::LayerW sq_conv_view(const ppasr::SqLayerW& W);  // capi_squeezeformer.hip
 
 ppasr_status upload_pe_table(ppasr_model_s* m, BlobMap& sd, const float** pe_dev);
+
+// generic-width Conformer (output_size 512 / 768 / 1024, heads of 64): capi_generic.hip
+size_t generic_ws_floats(const ppasr_model_s* m, int B, int T);
+ppasr_status generic_encode(ppasr_model_s* h, const float* feats, const int64_t* lens, int B, int T, float* probs,
+                            float* logits, int32_t* frame_argmax, float* frame_maxprob, float* ws, hipStream_t st);
 
 // model-family back ends
 ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd);

@@ -253,6 +253,7 @@ ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out) {
     return fail(PPASR_EUNSUPPORTED, "forward_chunk needs the causal conv module (a streaming=True model)");
   if (h->desc.input_layer != 0)
     return fail(PPASR_EUNSUPPORTED, "stream handles are built for the conv2d front end only (input_layer conv2d6 / conv2d8: batched encode)");
+  if (h->desc.output_size != kD) return fail(PPASR_EUNSUPPORTED, "stream handles are built for output_size=256");
   auto* s = new ppasr_stream_s();
   s->m = h;
   s->cap = h->desc.max_len;
@@ -431,6 +432,7 @@ ppasr_status ppasr_stream_group_create(ppasr_handle h, int n_sessions, int max_f
   if (h->desc.model_type != PPASR_MODEL_CONFORMER || !h->desc.causal)
     return fail(PPASR_EUNSUPPORTED, "session groups are built for streaming (causal) model_type=conformer");
   if (h->desc.input_layer != 0) return fail(PPASR_EUNSUPPORTED, "session groups are built for the conv2d front end only");
+  if (h->desc.output_size != kD) return fail(PPASR_EUNSUPPORTED, "session groups are built for output_size=256");
   auto g = std::make_unique<ppasr_stream_group_s>();
   g->m = h;
   g->n_sessions = n_sessions;

@@ -80,6 +80,9 @@ struct AttnArgs {
   // room for vt_stride rows; a.v is not read then
   const float* vt = nullptr;
   int vt_stride = 0;
+  // model width (row stride of ptab / ctx, h * 64 <= dm); 256 everywhere except the generic-width route (capi_generic.hip),
+  // which runs k_attention<64> with 8 heads on 512-wide activations
+  int dm = 256;
 };
 // Where the QKV stage puts the values when the layer's attention runs fused: in the order the attention's P V MFMAs
 // consume them, [8 slabs of 32 columns][stride / 8 row octets][64 lanes = column + 32 * (row quad)][4 rows] -- 1 KiB
@@ -91,14 +94,15 @@ struct VtOut {
 };
 
 // ---- launchers (all asynchronous on `st`) ----
-void launch_posproj(const float* pe, const float* wpos /*[256][256] in,out*/, const float* bpos_or_null, float* ptab,
-                    int max_len, hipStream_t st);
+void launch_posproj(const float* pe, const float* wpos /*[d][d] in,out*/, const float* bpos_or_null, float* ptab,
+                    int max_len, hipStream_t st, int d = 256);
 // every row-block launcher takes an optional PadSkip (rowblock.h): default = compute all rows
 void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T, int F, int T1, int F1, hipStream_t st,
-                  const PadSkip& ps = PadSkip{});
+                  const PadSkip& ps = PadSkip{}, int channels = 256);
 // one k x k / stride-s 256 -> 256 channel conv + ReLU of the front end on NHWC activations (implicit GEMM)
 void launch_conv_stage(const float* y_in, const f32x4* w, const float* bias, float* y_out, int B, int T_in, int F_in,
-                       int T_out, int F_out, int k, int s, hipStream_t st, const PadSkip& ps_frames = PadSkip{});
+                       int T_out, int F_out, int k, int s, hipStream_t st, const PadSkip& ps_frames = PadSkip{},
+                       int channels = 256);  // channels: 256, or a multiple of it (generic-width route)
 void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st,
                   const PadSkip& ps = PadSkip{});
 // scale_before_bias: Squeezeformer scales the 4864-wide conv output by sqrt(d) BEFORE input_proj
@@ -108,7 +112,7 @@ void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, i
 void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, bool scale_before_bias,
                   hipStream_t st, const PadSkip& ps = PadSkip{}, int k_slices = 1, float* part = nullptr);
 void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, float* out, int M, int K, int n_cols_padded,
-                  int ldc, int n_valid, hipStream_t st);
+                  int ldc, int n_valid, hipStream_t st, float scale = 1.0f);  // out = (a W + bias) * scale
 void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
                     const PadSkip& ps = PadSkip{}, VtOut vt = VtOut{});
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st);

@@ -28,19 +28,19 @@ namespace ppasr {
 // weight-only constant folding; not on the timed path, so a plain fmaf kernel.
 // =====================================================================================
 __global__ void k_posproj(const float* __restrict__ pe, const float* __restrict__ wpos,
-                          const float* __restrict__ bpos, float* __restrict__ ptab, int max_len) {
+                          const float* __restrict__ bpos, float* __restrict__ ptab, int max_len, int d) {
   int pos = blockIdx.x;
   int n = threadIdx.x;
-  __shared__ float row[kD];
-  row[n] = pe[(size_t)pos * kD + n];
+  __shared__ float row[1024];
+  row[n] = pe[(size_t)pos * d + n];
   __syncthreads();
   float acc = 0.f;
-  for (int k = 0; k < kD; ++k) acc = fmaf(row[k], wpos[k * kD + n], acc);
+  for (int k = 0; k < d; ++k) acc = fmaf(row[k], wpos[k * d + n], acc);
   if (bpos) acc += bpos[n];  // Squeezeformer / Efficient-Conformer linear_pos has a bias
-  ptab[(size_t)pos * kD + n] = acc;
+  ptab[(size_t)pos * d + n] = acc;
 }
-void launch_posproj(const float* pe, const float* wpos, const float* bpos, float* ptab, int max_len, hipStream_t st) {
-  PPASR_LAUNCH(k_posproj, dim3(max_len), dim3(kD), 0, st, pe, wpos, bpos, ptab, max_len);
+void launch_posproj(const float* pe, const float* wpos, const float* bpos, float* ptab, int max_len, hipStream_t st, int d) {
+  PPASR_LAUNCH(k_posproj, dim3(max_len), dim3(d), 0, st, pe, wpos, bpos, ptab, max_len, d);
 }
 
 // =====================================================================================
@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ feats, 
                                                int T, int F, int T1, int F1, PadSkip ps) {
   __shared__ float xs[3][128];
   const int b = blockIdx.y, t1 = blockIdx.x, tid = threadIdx.x;
+  const int C = 256 * gridDim.z, ch = 256 * blockIdx.z + tid;  // channels (256; the generic-width route: a multiple)
   if (ps.lens && t1 > 2 * pad_need_steps(ps, b)) return;  // conv2 output frame t' reads conv1 frames 2t' .. 2t'+2
   for (int idx = tid; idx < 3 * F; idx += 256) {
     int i = idx / F, f = idx - i * F;
@@ -61,9 +62,9 @@ __global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ feats, 
   __syncthreads();
   float w[9];
 #pragma unroll
-  for (int j = 0; j < 9; ++j) w[j] = fw.conv1_w[j * 256 + tid];
-  const float bias = fw.conv1_b[tid];
-  float* out = y1 + ((size_t)(b * T1 + t1) * F1) * 256 + tid;
+  for (int j = 0; j < 9; ++j) w[j] = fw.conv1_w[j * C + ch];
+  const float bias = fw.conv1_b[ch];
+  float* out = y1 + ((size_t)(b * T1 + t1) * F1) * C + ch;
   for (int f1 = 0; f1 < F1; ++f1) {
     float acc = 0.f;
 #pragma unroll
@@ -71,12 +72,12 @@ __global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ feats, 
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc = fmaf(w[i * 3 + j], xs[i][2 * f1 + j], acc);
     acc += bias;
-    out[(size_t)f1 * 256] = fmaxf(acc, 0.f);
+    out[(size_t)f1 * C] = fmaxf(acc, 0.f);
   }
 }
 void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T, int F, int T1, int F1, hipStream_t st,
-                  const PadSkip& ps) {
-  PPASR_LAUNCH(k_conv1, dim3(T1, B), dim3(256), 0, st, feats, fw, y1, T, F, T1, F1, ps);
+                  const PadSkip& ps, int channels) {
+  PPASR_LAUNCH(k_conv1, dim3(T1, B, channels / 256), dim3(256), 0, st, feats, fw, y1, T, F, T1, F1, ps);
 }
 
 // =====================================================================================
@@ -89,18 +90,20 @@ struct Conv2Src {
   const float* y1;
   int T1, F1, Tp, F2;
   int k = 3, s = 2;  // kernel size / stride (3, 2: Conv2dSubsampling4 / 8; 5, 3: the second conv of Conv2dSubsampling6)
+  int C = 256;       // input channels (NHWC)
   __device__ __forceinline__ const float* base(int m) const {
     int f2 = m % F2;
     int bt = m / F2;
     int tp = bt % Tp;
     int b = bt / Tp;
-    return y1 + ((size_t)((b * T1 + s * tp) * F1 + s * f2)) * 256;
+    return y1 + ((size_t)((b * T1 + s * tp) * F1 + s * f2)) * C;
   }
-  // KC = 128: chunk kc -> tap kc>>1 (kh,kw), channel half kc&1
+  // KC = 128: chunk kc -> tap kc / (C/128) (kh,kw), 128-channel slice kc % (C/128)
   __device__ __forceinline__ size_t chunk_off(int kc) const {
-    int tap = kc >> 1;
+    const int cpt = C >> 7;
+    int tap = kc / cpt, part = kc - tap * cpt;
     int kh = tap / k, kw = tap - k * kh;
-    return ((size_t)(kh * F1 + kw)) * 256 + (kc & 1) * 128;
+    return ((size_t)(kh * F1 + kw)) * C + part * 128;
   }
 };
 struct DenseSrc {
@@ -221,9 +224,10 @@ void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, i
   launch_conv_stage(y1, fw.conv2_w, fw.conv2_b, y2, B, T1, F1, Tp, F2, fw.conv2_k, fw.conv2_s, st, ps_frames);
 }
 void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b, float* y2, int B, int T1, int F1, int Tp,
-                       int F2, int ksz, int stride, hipStream_t st, const PadSkip& ps_frames) {
-  Conv2Src src{y1, T1, F1, Tp, F2, ksz, stride};
-  const int n_kc = 2 * ksz * ksz;  // 128-wide K chunks: two per tap
+                       int F2, int ksz, int stride, hipStream_t st, const PadSkip& ps_frames, int channels) {
+  Conv2Src src{y1, T1, F1, Tp, F2, ksz, stride, channels};
+  const int n_kc = ksz * ksz * (channels / 128);  // 128-wide K chunks: channels / 128 per tap
+  const int ny = channels / 256;                  // 256-column blocks of the output
   PadSkip ps = ps_frames;
   ps.unit = F2;  // rows are (frame, f2) pairs
   const int M = B * Tp * F2;
@@ -240,8 +244,8 @@ void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b
     // less than one round of 128-row tiles (a single utterance, a streaming chunk): smaller tiles fill more CUs
     const int mt = (M + 32 * kCUs - 1) / (32 * kCUs);  // 1 .. 4
 #define CONV2_ALL(MTA)                                                                                                    \
-  PPASR_LAUNCH((k_gemm_stream<MTA, KC, true, false, Conv2Src>), dim3((M + 32 * MTA - 1) / (32 * MTA)),              \
-                     dim3(kThreads), lds_of(MTA), st, src, conv_w, conv_b, y2, M, n_kc, 1.0f, kD, kD, 0, ps)
+  PPASR_LAUNCH((k_gemm_stream<MTA, KC, true, false, Conv2Src>), dim3((M + 32 * MTA - 1) / (32 * MTA), ny),              \
+                     dim3(kThreads), lds_of(MTA), st, src, conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, 0, ps)
     if (mt <= 1) CONV2_ALL(1);
     else if (mt == 2) CONV2_ALL(2);
     else if (mt == 3) CONV2_ALL(3);
@@ -250,16 +254,16 @@ void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b
     return;
   }
   if (rem_rows <= 0 || mt_rem >= 4) {
-    PPASR_LAUNCH((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(tiles4), dim3(kThreads), lds_of(4), st, src,
-                       conv_w, conv_b, y2, M, n_kc, 1.0f, kD, kD, 0, ps);
+    PPASR_LAUNCH((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(tiles4, ny), dim3(kThreads), lds_of(4), st, src,
+                       conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, 0, ps);
     return;
   }
-  PPASR_LAUNCH((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(full), dim3(kThreads), lds_of(4), st, src,
-                     conv_w, conv_b, y2, M, n_kc, 1.0f, kD, kD, 0, ps);
+  PPASR_LAUNCH((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(full, ny), dim3(kThreads), lds_of(4), st, src,
+                     conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, 0, ps);
   const int m0 = full * 128;
 #define CONV2_REM(MTR)                                                                                                    \
-  PPASR_LAUNCH((k_gemm_stream<MTR, KC, true, false, Conv2Src>), dim3((rem_rows + 32 * MTR - 1) / (32 * MTR)),       \
-                     dim3(kThreads), lds_of(MTR), st, src, conv_w, conv_b, y2, M, n_kc, 1.0f, kD, kD, m0, ps)
+  PPASR_LAUNCH((k_gemm_stream<MTR, KC, true, false, Conv2Src>), dim3((rem_rows + 32 * MTR - 1) / (32 * MTR), ny),       \
+                     dim3(kThreads), lds_of(MTR), st, src, conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, m0, ps)
   if (mt_rem <= 1) CONV2_REM(1);
   else if (mt_rem == 2) CONV2_REM(2);
   else CONV2_REM(3);
@@ -288,12 +292,12 @@ void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, fl
 // out[M][ldc] (columns < n_valid) = A[M][K] * Wpacked + bias ; K % 256 == 0 ; weights / bias padded to a multiple of
 // 256 columns.  Used by the DeepSpeech2 path (LSTM input projections, CTC head).
 void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, float* out, int M, int K, int n_cols_padded,
-                  int ldc, int n_valid, hipStream_t st) {
+                  int ldc, int n_valid, hipStream_t st, float scale) {
   constexpr int MT = 1, KC = 256;
   DenseSrc src{a, lda, KC};
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
   PPASR_LAUNCH((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, n_cols_padded / 256),
-                     dim3(kThreads), lds, st, src, w, bias, out, M, K / KC, 1.0f, ldc, n_valid, 0, PadSkip{});
+                     dim3(kThreads), lds, st, src, w, bias, out, M, K / KC, scale, ldc, n_valid, 0, PadSkip{});
 }
 
 // =====================================================================================
@@ -466,16 +470,17 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   const float* __restrict__ qb = a.q + (size_t)b * F1 * a.q_stride;
   const float* __restrict__ kbp = a.k + (size_t)b * F2 * a.k_stride;
   const float* __restrict__ vbp = a.v + (size_t)b * F2 * a.v_stride;
-  const float* __restrict__ ptab = a.ptab + (size_t)a.pos0 * kD;
+  const int dm = a.dm;  // model width: row stride of ptab / ctx (256; the generic-width route: 512, plain heads only)
+  const float* __restrict__ ptab = a.ptab + (size_t)a.pos0 * dm;
   if (a.sess) {  // multi-session streaming: per-session cache slot, length and position
     const SessDesc d = a.sess[b];
     T2 = F2 = d.cache_t + T1;
     kbp = a.k + (size_t)d.sess * a.sess_stride;
     vbp = a.v + (size_t)d.sess * a.sess_stride;
-    ptab = a.ptab + (size_t)d.pos0 * kD;
+    ptab = a.ptab + (size_t)d.pos0 * dm;
   }
   const int pstride = a.pos_stride;
-  float* __restrict__ ctx = a.ctx + (size_t)b * F1 * kD;
+  float* __restrict__ ctx = a.ctx + (size_t)b * F1 * dm;
   const int64_t len_b = a.lens ? a.lens[b] : (int64_t)a.mask_mul * T2;
   if (a.pad_skip > 0 && a.lens) {  // ragged batch: query tokens behind the needed frames, key blocks behind the valid keys
     const int64_t lb = len_b > 0 ? len_b : 0;
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   // valid frames (the zero-padded tail group).
   auto tok4 = [&](const float* base, int stride, int nframes, int j, int f) -> f32x4 {
     const int flat = j * (C::G * kD) + h * DK + f;
-    const int frame = flat >> 8, feat = flat & 255;
+    const int frame = C::G == 1 ? j : flat >> 8, feat = C::G == 1 ? h * DK + f : flat & 255;
     if (frame >= nframes) return f32x4{0.f, 0.f, 0.f, 0.f};
     return *reinterpret_cast<const f32x4*>(base + (size_t)frame * stride + feat);
   };
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
       // keys >= T2 are masked to -inf afterwards, so any in-bounds row will do: clamp instead of branching
       const int jc = min(j, T2 - 1);
       const float* base = (g < DK / 8) ? kbp + (size_t)jc * a.k_stride + h * DK + 8 * g + 4 * (lane >> 5)
-                                       : ptab + (size_t)jc * pstride * kD + h * DK + 8 * (g - DK / 8) + 4 * (lane >> 5);
+                                       : ptab + (size_t)jc * pstride * dm + h * DK + 8 * (g - DK / 8) + 4 * (lane >> 5);
       return *reinterpret_cast<const f32x4*>(base);
     }
     if (j >= T2) return f32x4{0.f, 0.f, 0.f, 0.f};
@@ -694,9 +699,10 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
           float o = acc_o[mt][t][r] + scratch[((ctg * C::NO + t) * 64 + row) * 33 + (lane & 31)];
           o = (l > 0.f) ? o / l : 0.f;  // fully masked row -> 0 (attention.py:118)
           if (q0 + row < T1) {
-            const int flat = (q0 + row) * (C::G * kD) + h * DK + (ctg * C::NO + t) * 32 + (lane & 31);
-            const int frame = flat >> 8, feat = flat & 255;
-            if (frame < F1) ctx[(size_t)frame * kD + feat] = o;  // x[:, :T - padding_q] (efficient attention.py:124-125)
+            const int cc = h * DK + (ctg * C::NO + t) * 32 + (lane & 31);
+            const int flat = (q0 + row) * (C::G * kD) + cc;
+            const int frame = C::G == 1 ? q0 + row : flat >> 8, feat = C::G == 1 ? cc : flat & 255;
+            if (frame < F1) ctx[(size_t)frame * dm + feat] = o;  // x[:, :T - padding_q] (efficient attention.py:124-125)
           }
         }
   }

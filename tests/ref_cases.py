@@ -41,6 +41,8 @@ SMALL = {
     # 6x / 8x front ends (input_layer: conv2d6 / conv2d8): batched encode, masks by 6t / 8t < len
     "conf6": _former("conformer", True, 2, 61, 545, (3, 197, [197, 120, 61], 546), input_layer="conv2d6"),
     "conf8": _former("conformer", False, 2, 61, 547, (3, 203, [203, 150, 47], 548), input_layer="conv2d8"),
+    # a width the fused 256-column kernels do not cover: output_size 512 with 8 heads (the generic-width route)
+    "conf512": _former("conformer", True, 2, 61, 549, (2, 131, [131, 77], 550), output_size=512, attention_heads=8),
     "sq_bn": _former("squeezeformer", False, 3, 59, 543, (2, 131, [131, 70], 544), reduce_idx=1, recover_idx=2,
                      cnn_norm_type="batch_norm"),
 }
@@ -85,7 +87,8 @@ def state_dict(case, perturb=True):
     if fam == "conformer":
         return conformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn,
                                     cnn_module_norm=kw.get("cnn_module_norm", "layer_norm"),
-                                    input_layer=kw.get("input_layer", "conv2d"))
+                                    input_layer=kw.get("input_layer", "conv2d"), output_size=kw.get("output_size", 256),
+                                    attention_heads=kw.get("attention_heads", 4))
     if fam == "efficient_conformer":
         if full:
             return efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=seed)
@@ -119,7 +122,8 @@ def reference_encoder_conf(case):
     and is ignored there -- efficient_conformer/encoder.py:26-56 -- the shipped values equal the defaults)."""
     fam, L, kw = case["family"], case["L"], case["kw"]
     if fam == "conformer":
-        return dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, dropout_rate=0.1,
+        return dict(output_size=kw.get("output_size", 256), attention_heads=kw.get("attention_heads", 4), linear_units=2048,
+                    num_blocks=L, dropout_rate=0.1,
                     positional_dropout_rate=0.1, attention_dropout_rate=0.1, input_layer=kw.get("input_layer", "conv2d"),
                     normalize_before=True, cnn_module_kernel=15, use_cnn_module=True, activation_type="swish", pos_enc_layer_type="rel_pos",
                     cnn_module_norm=kw.get("cnn_module_norm", "layer_norm"))

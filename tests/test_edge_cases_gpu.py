@@ -150,3 +150,33 @@ def test_wider_front_ends_edges(input_layer, t_min, rate):
         assert list(nv) == [min(probs.shape[1], (ln + rate - 1) // rate) for ln in lens]
     with pytest.raises(_lib.PPASRHipError):
         model.get_encoder_out_chunk(np.zeros((1, 67, 80), np.float32), 0, -1)
+
+
+@pytest.mark.parametrize("streaming,norm", [(True, "layer_norm"), (False, "batch_norm")])
+def test_generic_width_512_with_8_heads(streaming, norm):
+    """output_size 512 / attention_heads 8 (capi_generic.hip: dense layers + k_attention with 8 heads + row kernels):
+    logits vs the oracle on ragged batches (lengths 1 and 0 included, > 128 keys), the fused greedy call, refusals."""
+    from oracle.conformer_oracle import ConformerOracle
+    from ppasr_amd import _lib
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    V, L = 77, 2
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=5, output_size=512, attention_heads=8, perturb_norm=True,
+                              cnn_module_norm=norm)
+    conf = dict(output_size=512, attention_heads=8, linear_units=2048, num_blocks=L, cnn_module_kernel=15,
+                cnn_module_norm=norm)
+    model = ConformerModel(80, V, streaming=streaming, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    oracle = ConformerOracle(sd, num_blocks=L, causal=streaming, attention_heads=8)
+    for B, T, lens in ((1, 7, [7]), (3, 131, [131, 1, 0]), (2, 700, [700, 333])):
+        x, la = synth_features(B, T, lens=lens, seed=T)
+        probs, logits = model.get_encoder_out(x, la, return_logits=True)
+        ref_probs, ref_logits = oracle.get_encoder_out(x, la, return_logits=True)
+        tokens, n, _ = model.encode_greedy(x, la)
+        torch.cuda.synchronize()
+        assert torch.isfinite(probs).all()
+        assert _rel(logits.cpu().numpy(), ref_logits.numpy()) < TOL
+        for b in range(B):
+            ids, _, _ = greedy_tokens(ref_probs[b].numpy())
+            assert np.array_equal(ids, tokens[b, :int(n[b])].cpu().numpy()), b
+    if streaming:
+        with pytest.raises(_lib.PPASRHipError):
+            model.get_encoder_out_chunk(np.zeros((1, 67, 80), np.float32), 0, -1)

@@ -36,7 +36,7 @@ def make_oracle(case, sd):
     fam, L, kw = case["family"], case["L"], case["kw"]
     causal = case["streaming"]
     if fam == "conformer":
-        return ConformerOracle(sd, num_blocks=L, causal=causal)
+        return ConformerOracle(sd, num_blocks=L, causal=causal, attention_heads=kw.get("attention_heads", 4))
     if fam == "efficient_conformer":
         return EfficientConformerOracle(sd, num_blocks=L, stride_layer_idx=kw["stride_layer_idx"],
                                         group_layer_idx=kw["group_layer_idx"], causal=causal)
