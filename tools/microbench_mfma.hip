@@ -404,7 +404,7 @@ int main() {
   {
     const int it4 = 1000;
 #define RUNT(MT, NT, WAVES, name)                                                                                  \
-  timeit(name, (double)CUS * 4 * WAVES * it4 * 16 * 4 * MT * NT,                                                   \
+  timeit(name, (double)CUS * 4 * WAVES * (it4 / (MT * NT)) * 16 * 4 * MT * NT,                                     \
          [&] { hipLaunchKernelGGL((k_tile<MT, NT>), dim3(CUS), dim3(256 * WAVES), MT * 32 * 132 * 4, 0, w, out, it4 / (MT * NT)); })
     RUNT(1, 1, 2, "wave tile 32x32 (1 chain), 2 waves/SIMD");
     RUNT(2, 1, 2, "wave tile 64x32 (2 chains), 2 waves/SIMD");
@@ -415,6 +415,9 @@ int main() {
     RUNT(4, 2, 1, "wave tile 128x64 (8 chains), 1 wave/SIMD");
     RUNT(4, 2, 2, "wave tile 128x64 (8 chains), 2 waves/SIMD");
     RUNT(1, 2, 2, "wave tile 32x64 (2 chains), 2 waves/SIMD");
+    RUNT(1, 2, 1, "wave tile 32x64 (2 chains), 1 wave/SIMD");
+    RUNT(1, 1, 1, "wave tile 32x32 (1 chain), 1 wave/SIMD");
+    RUNT(1, 4, 1, "wave tile 32x128 (4 chains), 1 wave/SIMD");
   }
   const size_t lds2 = 2 * 32 * 260 * 4;
   const int it3 = 1000;
