@@ -946,13 +946,6 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
     key_offsets(u0);
     load_sg(0, 0);
   };
-#ifndef PPASR_ATT_KPRE
-#define PPASR_ATT_KPRE 0
-#endif
-#ifndef PPASR_ATT_VPRE
-#define PPASR_ATT_VPRE 0
-#endif
-  if (PPASR_ATT_KPRE && khalf * 128 < U) prime_k(khalf * 128);
 
   // ---- Q' = [q + pos_bias_u | q + pos_bias_v] of the block's 32 query rows -> LDS (bufC / QV); the key loop reads
   // its B-operand fragment Q'[row l31][8 gk + 4 hh .. +3] from there, one ds_read_b128 per k-group ----
@@ -972,7 +965,8 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
     return *reinterpret_cast<const f32x4*>(gk < 8 ? qfrag_u + 8 * gk : qfrag_v + 8 * (gk - 8));
   };
   PPASR_TS(33);
-  if (!PPASR_ATT_KPRE && khalf * 128 < U) prime_k(khalf * 128);
+  // (requesting these before the Q' staging, or the V operands before the score MFMAs, measured no better: DESIGN §4)
+  if (khalf * 128 < U) prime_k(khalf * 128);
   f32x16 acc_o[2];  // O^T: acc_o[ct][r] = O[query l31][h*64 + 32ct + (r&3) + 8(r>>2) + 4hh]
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -1004,7 +998,6 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
           ringv[q][1] = vload(q, 1);
         }
       };
-      if (PPASR_ATT_VPRE) prime_v();
       // ---- S^T = K' Q'^T for 64 keys (two 32-key tiles, two independent accumulator chains) ----
       f32x16 acc_s[2];
 #pragma unroll
@@ -1032,7 +1025,7 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
         }
       }
       if (kb == 0) PPASR_WAVE_TS(17 + 4 * sb);
-      if (!PPASR_ATT_VPRE) prime_v();
+      prime_v();
       // ---- online softmax in registers ----
       if (edge) {
         // element r of tile t is key u = u0 + 4hh + c with c = 32t + (r&3) + 8(r>>2): masked iff c < lo or c >= hi
