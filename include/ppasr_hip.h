@@ -74,8 +74,8 @@ typedef struct {
   int use_gru;
   /* Conformer / Efficient-Conformer front end, `input_layer` (conformer/encoder.py:93-104, subsampling.py):
      0 = conv2d (Conv2dSubsampling4: 3x3/2, 3x3/2), 6 = conv2d6 (Conv2dSubsampling6: 3x3/2, 5x5/3, `embed.linear`),
-     8 = conv2d8 (Conv2dSubsampling8: 3x3/2 three times, `embed.linear`).  6 / 8: batched encode only (no stream
-     handles), key-padding / conv pad masks use 6t / 8t < len (the reference's mask slicing) */
+     8 = conv2d8 (Conv2dSubsampling8: 3x3/2 three times, `embed.linear`).  6 / 8: batched encode and single stream
+     handles (no session groups); key-padding / conv pad masks use 6t / 8t < len (the reference's mask slicing) */
   int input_layer;
   int reserved[1];
 } ppasr_model_desc;

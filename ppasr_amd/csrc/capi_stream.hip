@@ -251,9 +251,9 @@ ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out) {
     return fail(PPASR_EUNSUPPORTED, "deepspeech2 streams carry their state in the h/c boxes of ppasr_ds2_encode");
   if (!h->desc.causal)
     return fail(PPASR_EUNSUPPORTED, "forward_chunk needs the causal conv module (a streaming=True model)");
-  if (h->desc.input_layer != 0)
-    return fail(PPASR_EUNSUPPORTED, "stream handles are built for the conv2d front end only (input_layer conv2d6 / conv2d8: batched encode)");
   if (h->desc.output_size != kD) return fail(PPASR_EUNSUPPORTED, "stream handles are built for output_size=256");
+  if (h->desc.input_layer != 0 && h->desc.model_type != PPASR_MODEL_CONFORMER)
+    return fail(PPASR_EUNSUPPORTED, "stream handles with the conv2d6 / conv2d8 front ends are built for model_type=conformer");
   auto* s = new ppasr_stream_s();
   s->m = h;
   s->cap = h->desc.max_len;
@@ -312,8 +312,8 @@ int ppasr_stream_offset(ppasr_stream s) { return s ? s->offset : -1; }
 int ppasr_stream_cache_frames(ppasr_stream s) { return s ? s->cache_t : -1; }
 
 size_t ppasr_chunk_workspace_bytes(ppasr_handle h, int T) {
-  if (!h || T < 7) return 0;
-  const size_t Tp = ((T - 1) / 2 - 1) / 2;
+  if (!h || T < h->min_frames()) return 0;
+  const size_t Tp = h->front_dims(T).Tp;
   // the full-utterance layout for B=1, plus the conv-module input rows and a cache-shift scratch
   return (ws_layout(h, 1, T).total + Tp * kD + 64 + (size_t)h->desc.max_len * kD) * sizeof(float);
 }
@@ -323,8 +323,10 @@ ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int r
                                 size_t workspace_bytes, void* stream) {
   if (!s || !feats || !workspace) return fail(PPASR_EINVAL, "null argument");
   ppasr_model_s* h = s->m;
-  if (T < 7) return fail(PPASR_EINVAL, "chunk shorter than the conv front-end's receptive field (7 frames)");
-  const int F = h->desc.input_dim, T1 = (T - 1) / 2, F1 = h->F1, c = (T1 - 1) / 2, F2 = h->F2;
+  if (T < h->min_frames())
+    return fail(PPASR_EINVAL, "chunk shorter than the conv front-end's receptive field (7 frames; conv2d6: 11, conv2d8: 15)");
+  const auto fd = h->front_dims(T);
+  const int F = h->desc.input_dim, T1 = fd.T1, F1 = h->F1, c = fd.Tp, F2 = h->F2;
   if (workspace_bytes < ppasr_chunk_workspace_bytes(h, T)) return fail(PPASR_ENOSPACE, "workspace too small");
   ChunkPlan p{};
   ppasr_status r = plan_chunk(s, c, required_cache_size, &p);
@@ -337,9 +339,15 @@ ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int r
   float* xhat = ws + wl.total;
   float* shift_tmp = xhat + (((size_t)c * kD + 63) & ~(size_t)63);
   launch_conv1(feats, h->front, y1, 1, T, F, T1, F1, st);
-  launch_conv2(y1, h->front, y2, 1, T1, F1, c, F2, st);
-  launch_embed(y2, h->front, xa, c, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/is_sq(h), st, PadSkip{},
-               ffn_split_for(h, c), y1);
+  if (h->desc.input_layer == 8) {  // Conv2dSubsampling8: three 3x3 / 2 convs, the third one over conv1's output buffer
+    launch_conv_stage(y1, h->front.conv2_w, h->front.conv2_b, y2, 1, T1, F1, fd.T2, F2, 3, 2, st);
+    launch_conv_stage(y2, h->front.conv3_w, h->front.conv3_b, y1, 1, fd.T2, F2, c, h->F3, 3, 2, st);
+    launch_embed(y1, h->front, xa, c, h->F3 * kD, sqrtf((float)kD), false, st, PadSkip{}, ffn_split_for(h, c), y2);
+  } else {
+    launch_conv2(y1, h->front, y2, 1, T1, F1, c, F2, st);  // (3x3 / 2, or conv2d6's 5x5 / 3: FrontW::conv2_k / _s)
+    launch_embed(y2, h->front, xa, c, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/is_sq(h), st, PadSkip{},
+                 ffn_split_for(h, c), y1);
+  }
   float* x_final = xa;
   int frames = c;
   if (is_sq(h)) r = squeezeformer_chunk(s, p, xa, xb, xc, qkv, ctx, g, ws + wl.xs, xhat, y1, &x_final, st);

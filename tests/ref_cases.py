@@ -38,9 +38,11 @@ SMALL = {
     # conv-module BatchNorm1D instead of LayerNorm (cnn_module_norm / cnn_norm_type: batch_norm)
     "conf_bn": _former("conformer", True, 2, 61, 541, (2, 131, [131, 77], 542), chunk_frames=64 * 2 + 30,
                        required=(-16, 32), cnn_module_norm="batch_norm"),
-    # 6x / 8x front ends (input_layer: conv2d6 / conv2d8): batched encode, masks by 6t / 8t < len
-    "conf6": _former("conformer", True, 2, 61, 545, (3, 197, [197, 120, 61], 546), input_layer="conv2d6"),
-    "conf8": _former("conformer", False, 2, 61, 547, (3, 203, [203, 150, 47], 548), input_layer="conv2d8"),
+    # 6x / 8x front ends (input_layer: conv2d6 / conv2d8): masks by 6t / 8t < len; chunks cut like the predictor does
+    "conf6": _former("conformer", True, 2, 61, 545, (3, 197, [197, 120, 61], 546), chunk_frames=64 * 3 + 40,
+                     required=(-16, 32), input_layer="conv2d6"),
+    "conf8": _former("conformer", True, 2, 61, 547, (3, 203, [203, 150, 47], 548), chunk_frames=64 * 3 + 50,
+                     required=(-16,), input_layer="conv2d8"),
     # a width the fused 256-column kernels do not cover: output_size 512 with 8 heads (the generic-width route)
     "conf512": _former("conformer", True, 2, 61, 549, (2, 131, [131, 77], 550), output_size=512, attention_heads=8),
     "sq_bn": _former("squeezeformer", False, 3, 59, 543, (2, 131, [131, 70], 544), reduce_idx=1, recover_idx=2,

@@ -126,7 +126,8 @@ def test_maximum_length_and_one_past_it():
 @pytest.mark.parametrize("input_layer,t_min,rate", [("conv2d6", 11, 6), ("conv2d8", 15, 8)])
 def test_wider_front_ends_edges(input_layer, t_min, rate):
     """input_layer conv2d6 / conv2d8 (Conv2dSubsampling6 / 8, subsampling.py:118-205): the shortest input gives one frame,
-    one frame less is refused, ragged lengths follow the oracle (masks by rate * t < len), stream handles are refused."""
+    one frame less is refused, ragged lengths follow the oracle (masks by rate * t < len), a chunk goes through
+    forward_chunk (chunk parity with the reference's source: tests/test_ref_pin_gpu.py, conf6 / conf8)."""
     from oracle.conformer_oracle import ConformerOracle
     from ppasr_amd import _lib
     from ppasr_amd.model_utils.conformer.model import ConformerModel
@@ -148,8 +149,11 @@ def test_wider_front_ends_edges(input_layer, t_min, rate):
         assert _rel(logits.cpu().numpy(), ref_logits.numpy()) < TOL
         nv = model.valid_out_frames(la, T).cpu().numpy()
         assert list(nv) == [min(probs.shape[1], (ln + rate - 1) // rate) for ln in lens]
-    with pytest.raises(_lib.PPASRHipError):
-        model.get_encoder_out_chunk(np.zeros((1, 67, 80), np.float32), 0, -1)
+    x, _ = synth_features(1, 67, seed=3)
+    p, att, cnn = model.get_encoder_out_chunk(x, 0, -1)
+    ref_p, _, _ = oracle.get_encoder_out_chunk(x, 0, -1)
+    assert tuple(p.shape) == tuple(ref_p.shape) == (1, model.out_frames(67), V)
+    assert _rel(p.cpu().numpy(), ref_p.numpy()) < TOL
 
 
 @pytest.mark.parametrize("streaming,norm", [(True, "layer_norm"), (False, "batch_norm")])
