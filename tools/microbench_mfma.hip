@@ -128,6 +128,55 @@ __global__ void k_tile(const f32x4* __restrict__ w, float* out, int iters) {
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
 }
 
+// Split-precision candidate: fp32 operands as fp16 hi + fp16 (scaled) lo, three
+// v_mfma_f32_32x32x16_f16 per 16-wide k step (hi*hi, hi*lo, lo*hi; fp32 accumulation) in the row-block GEMM's structure --
+// A (hi, lo) fragments from LDS, B (hi, lo) fragments from the buffer-load ring, 32 x 32 tile per wave.  Reported as
+// fp32-EQUIVALENT TFLOP/s (2 * 32 * 32 * 16 per step), i.e. directly comparable with the exact-fp32 MFMA figures.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+template <int TERMS>
+__global__ void k_split16(const f32x4* __restrict__ w, float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  for (int i = threadIdx.x; i < 2 * 32 * 132; i += blockDim.x) smem[i] = __uint_as_float(0x3c003c00u | ((i * 2654435761u) & 0x03ff03ffu));
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // A tile as fp16: [32 rows][256 k] hi, then lo; a lane reads row l&31, k = 16 step + 8 (l>>5) .. +7 = 16 bytes
+  const float* a_hi = smem + (lane & 31) * 132 + 4 * (lane >> 5);
+  const float* a_lo = a_hi + 32 * 132;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 0x7fffffff, 0x00020000);
+  const int voff = lane * 16;
+  constexpr int PF = 4;
+  f32x4 ring[PF][2];
+  auto ld = [&](int g, int part) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, ((((g & 63) * 8 + wave) * 2 + part)) * 1024, 0));
+  };
+  for (int s = 0; s < PF; ++s) { ring[s][0] = ld(s, 0); ring[s][1] = ld(s, 1); }
+  f32x16 acc, acc_lo;
+  for (int r = 0; r < 16; ++r) acc[r] = acc_lo[r] = 0.f;
+  int pos = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {  // 16 steps of 16 = K 256 (one GEMM unit)
+      const f32x4 ah = *reinterpret_cast<const f32x4*>(a_hi + 8 * g);
+      const f32x4 al = *reinterpret_cast<const f32x4*>(a_lo + 8 * g);
+      const f32x4 bh = ring[g % PF][0], bl = ring[g % PF][1];
+      ring[g % PF][0] = ld(pos + g + PF, 0);
+      ring[g % PF][1] = ld(pos + g + PF, 1);
+      const h16x8 Ah = __builtin_bit_cast(h16x8, ah), Al = __builtin_bit_cast(h16x8, al);
+      const h16x8 Bh = __builtin_bit_cast(h16x8, bh), Bl = __builtin_bit_cast(h16x8, bl);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
+      if (TERMS >= 3) {
+        acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc_lo, 0, 0, 0);
+        acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc_lo, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    pos += 16;
+  }
+  float sum = 0.f;
+  for (int r = 0; r < 16; ++r) sum += acc[r] + acc_lo[r] * (1.0f / 2048.0f);
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
+}
+
 // The FFN chunk loop of phases.h in miniature: unit 1 = A(buf0) x W1 tile -> acc1 (optionally with the swish side
 // writes of the previous tile into buf1), [barrier], unit 2 = A(buf1) x W2 tile -> acc2.  Buffer-load weight ring.
 //   BAR: workgroup barrier between the units (as ffn_phase has)    SIDE: swish side work    FUSE: both units as ONE
@@ -418,6 +467,16 @@ int main() {
     RUNT(1, 2, 1, "wave tile 32x64 (2 chains), 1 wave/SIMD");
     RUNT(1, 1, 1, "wave tile 32x32 (1 chain), 1 wave/SIMD");
     RUNT(1, 4, 1, "wave tile 32x128 (4 chains), 1 wave/SIMD");
+  }
+  {
+    const int it5 = 4000;
+    // mfma_per_launch in units of exact-fp32 MFMAs (4096 FLOP): one K = 16 step of a 32 x 32 tile = 8 of them
+#define RUNS(TERMS, WAVES, name)                                                                                  \
+  timeit(name, (double)CUS * 4 * WAVES * it5 * 16 * 8,                                                            \
+         [&] { hipLaunchKernelGGL((k_split16<TERMS>), dim3(CUS), dim3(256 * WAVES), 2 * 32 * 132 * 4, 0, w, out, it5); })
+    RUNS(3, 2, "fp16 hi/lo split, 3 MFMA 32x32x16 per step, 2 waves/SIMD (fp32-equivalent rate)");
+    RUNS(3, 1, "fp16 hi/lo split, 3 MFMA per step, 1 wave/SIMD");
+    RUNS(1, 2, "plain fp16 (1 MFMA per step) with the same operand traffic, 2 waves/SIMD");
   }
   const size_t lds2 = 2 * 32 * 260 * 4;
   const int it3 = 1000;
