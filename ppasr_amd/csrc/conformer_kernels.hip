@@ -1864,60 +1864,77 @@ __global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__
   rb_load_rows(bufA, kLda, x + (size_t)r0 * kD, kRows, valid);
   if (hw.ln_g) rb_layernorm(bufA, bufA, kLda, kRows, hw.ln_g, hw.ln_b, 1e-5f);
   __syncthreads();
-  float mx[16], sm[16];
-  int ix[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    mx[r] = -INFINITY;
-    sm[r] = 0.f;
-    ix[r] = 0x7fffffff;
-  }
+  // Transposed tiles (rb_gemm SWAP): lane = row l&31, its 16 registers = 16 columns of the vocabulary tile in increasing
+  // order (col = 8(r>>2) + 4(l>>5) + (r&3)).  The running (max, sum-exp, argmax) of a row is then ONE triple per lane,
+  // updated per tile with in-lane arithmetic: tile max (v_max3), one rescale of the running sum, 16 exponentials, and
+  // an index scan only when the tile raises the maximum (rare after the first tiles) -- against a triple per (row,
+  // column lane) with two exponentials per element and a 5-step cross-lane merge per row at the end.
+  float mx = -INFINITY, sm = 0.f;
+  int ix = 0x7fffffff;
+  const int l31 = lane & 31, hh = lane >> 5;
+  constexpr float kLog2e = 1.4426950408889634f;
   const int tstep = kWaves * ny;
   for (int tile = wave + 8 * y; tile < hw.n_tiles; tile += tstep) {
     f32x16 acc[1][1];
     acc_zero(acc);
     const f32x4* seg = hw.w + (size_t)tile * kTs256;
-    rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, tile + tstep < hw.n_tiles ? seg + (size_t)tstep * kTs256 : nullptr, 0, ring, acc);
-    const int col = tile * 32 + (lane & 31);
-    const float bv = (col < V) ? hw.b[col] : -INFINITY;  // padded columns never win and add exp(-inf)=0
+    rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg, 0, tile + tstep < hw.n_tiles ? seg + (size_t)tstep * kTs256 : nullptr,
+                                            0, ring, acc);
+    const int c0 = tile * 32 + 4 * hh;  // column of register 0
+    float v[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = acc[0][0][r] + bv;
-      if (LOGITS) {
-        const int row = acc_row(r, lane);
-        if (col < V && row < valid) logits[(size_t)(r0 + row) * V + col] = v;
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(hw.b + c0 + 8 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * q + e] = acc[0][0][4 * q + e] + bq[e];
+    }
+    if (tile == hw.n_tiles - 1 && (V & 31)) {  // padded columns of the last tile never win and add exp(-inf) = 0
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (c0 + 8 * (r >> 2) + (r & 3) >= V) v[r] = -INFINITY;
+    }
+    if (LOGITS) {
+      if (l31 < valid) {
+        float* lrow = logits + (size_t)(r0 + l31) * V;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int col = c0 + 8 * (r >> 2) + (r & 3);
+          if (col < V) lrow[col] = v[r];
+        }
       }
-      const float mn = fmaxf(mx[r], v);
-      // first valid column: mx = -inf -> exp(-inf) = 0; padded column with mx finite: exp(-inf) = 0
-      const float e_old = (mx[r] == mn) ? 1.0f : __expf(mx[r] - mn);
-      const float e_new = (v == -INFINITY) ? 0.f : __expf(v - mn);
-      sm[r] = sm[r] * e_old + e_new;
-      ix[r] = (v > mx[r]) ? col : ix[r];
-      mx[r] = mn;
     }
+    float tmax = max3f(v[0], v[1], v[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) tmax = max3f(tmax, v[r], v[r + 1]);
+    tmax = fmaxf(tmax, v[15]);
+    if (tmax > mx) {  // first column holding the new maximum (lowest index wins ties: numpy argmax)
+#pragma unroll
+      for (int r = 15; r >= 0; --r) ix = (v[r] == tmax) ? c0 + 8 * (r >> 2) + (r & 3) : ix;
+    }
+    const float mn = fmaxf(mx, tmax);
+    // (mx = -inf before the first tile: exp2(-inf) = 0; mn is finite from then on -- every tile has a real column)
+    sm *= __builtin_amdgcn_exp2f((mx - mn) * kLog2e);
+    f32x2 ps = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {  // (subtract first: logits reach +-30, a fused v * log2e - mn * log2e would round at 2e-6)
+      const f32x2 t = (f32x2{v[r], v[r + 1]} - f32x2{mn, mn}) * f32x2{kLog2e, kLog2e};
+      ps += f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    }
+    sm += ps[0] + ps[1];
+    mx = mn;
   }
-  // reduce over the 32 lanes (columns) of each half-wave
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float m = mx[r], s = sm[r];
-    int i = ix[r];
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-      float m2 = __shfl_xor(m, o), s2 = __shfl_xor(s, o);
-      int i2 = __shfl_xor(i, o);
-      float mn = fmaxf(m, m2);
-      float sa = (m == -INFINITY) ? 0.f : s * __expf(m - mn);
-      float sb = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mn);
-      bool take2 = (m2 > m) || (m2 == m && i2 < i);
-      i = take2 ? i2 : i;
-      m = mn;
-      s = sa + sb;
-    }
-    if ((lane & 31) == 0) {
-      int row = acc_row(r, lane);
-      redM[wave * 32 + row] = m;
-      redS[wave * 32 + row] = s;
-      redI[wave * 32 + row] = i;
+  // the two lane halves of a row (different columns), then one triple per (wave, row)
+  {
+    const float m2 = __shfl_xor(mx, 32), s2 = __shfl_xor(sm, 32);
+    const int i2 = __shfl_xor(ix, 32);
+    const float mn = fmaxf(mx, m2);
+    const float sa = (mx == -INFINITY) ? 0.f : sm * __expf(mx - mn);
+    const float sb = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mn);
+    const bool take2 = (m2 > mx) || (m2 == mx && i2 < ix);
+    if (hh == 0) {
+      redM[wave * 32 + l31] = mn;
+      redS[wave * 32 + l31] = sa + sb;
+      redI[wave * 32 + l31] = take2 ? i2 : ix;
     }
   }
   __syncthreads();
