@@ -129,3 +129,19 @@ t0 = w[:, 0].min()
 dur = w[:, 1] - w[:, 0]
 print(f"{len(w)} workgroups: start skew max {(w[:, 0] - t0).max():.2f} us, duration min/median/max {dur.min():.1f}/{np.median(dur):.1f}/{dur.max():.1f} us,"
       f" last end {(w[:, 1] - t0).max():.1f} us")
+# block id -> (utterance, query block) as in the kernel's XCD-aware map: slot = id >> 3, b = (slot / nq) * 8 + (id & 7)
+ids = np.nonzero(ok)[0]
+nq = 8
+slot = ids >> 3
+bb, qb = (slot // nq) * 8 + (ids & 7), slot % nq
+start = w[:, 0] - t0
+for q in range(nq):
+    sel = qb == q
+    print(f"  query block {q}: n={sel.sum():2d} start {start[sel].mean():5.2f} duration mean {dur[sel].mean():6.2f} max {dur[sel].max():6.2f}")
+for x in range(8):
+    sel = (ids & 7) == x
+    print(f"  XCD {x}: n={sel.sum():2d} duration mean {dur[sel].mean():6.2f} max {dur[sel].max():6.2f}   end max {(w[sel, 1] - t0).max():6.2f}")
+order = np.argsort(-dur)[:10]
+print("  slowest:", [(int(bb[i]), int(qb[i]), round(float(dur[i]), 1), round(float(start[i]), 2)) for i in order])
+order = np.argsort(dur)[:6]
+print("  fastest:", [(int(bb[i]), int(qb[i]), round(float(dur[i]), 1), round(float(start[i]), 2)) for i in order])
