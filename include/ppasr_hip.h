@@ -240,6 +240,15 @@ ppasr_status ppasr_profile_enable(ppasr_handle h, int enable);
 ppasr_status ppasr_profile_read(ppasr_handle h, float* total_ms_host, int* launches_host);
 const char* ppasr_kernel_class_name(int cls);
 
+/* Kernel-name profiler (bench.py roofline leg for every model family and the decoders; no reference counterpart).
+ * Between begin and end, every kernel the CALLING THREAD launches through this library carries a dispatch-attached HIP
+ * event pair; end synchronises them and returns one entry per distinct kernel (the names rocprofv3's kernel trace
+ * prints, without the parameter list): names_host [max_entries][PPASR_KPROF_NAME_LEN] chars, total_ms_host /
+ * launches_host [max_entries], *n_out_host = entries written.  Not to be combined with ppasr_profile_enable. */
+#define PPASR_KPROF_NAME_LEN 160
+ppasr_status ppasr_kprof_begin(void);
+ppasr_status ppasr_kprof_end(int max_entries, char* names_host, float* total_ms_host, int* launches_host, int* n_out_host);
+
 /* Replaces greedy_decoder / greedy_decoder_batch (decoders/ctc_greedy_decoder.py:6-49), as called
  * from PPASRPredictor.decode (predict.py:128) and PPASRTrainer.__decoder_result (trainer.py:351).
  *   probs [B,Tp,V] f32 (any row-normalised or not: argmax + value at argmax)

@@ -23,6 +23,7 @@ PPASR_MODEL_EFFICIENT_CONFORMER = 1
 PPASR_MODEL_SQUEEZEFORMER = 2
 PPASR_MODEL_DEEPSPEECH2 = 3
 N_KERNEL_CLASSES = 10
+KPROF_NAME_LEN = 160
 
 
 class WeightBlob(ctypes.Structure):
@@ -75,6 +76,8 @@ SYMBOLS = [
     ("ppasr_profile_enable", ctypes.c_int, [_vp, ctypes.c_int]),
     ("ppasr_profile_read", ctypes.c_int, [_vp, c_f32p, c_i32p]),
     ("ppasr_kernel_class_name", ctypes.c_char_p, [ctypes.c_int]),
+    ("ppasr_kprof_begin", ctypes.c_int, []),
+    ("ppasr_kprof_end", ctypes.c_int, [ctypes.c_int, _vp, c_f32p, c_i32p, ctypes.POINTER(ctypes.c_int)]),
     ("ppasr_ctc_greedy", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp,
                                         _vp, _vp, ctypes.c_size_t, _vp]),
     ("ppasr_ctc_collapse", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
@@ -148,3 +151,30 @@ def check(status):
     if status != 0:
         msg = load().ppasr_last_error()
         raise PPASRHipError(f"libppasr_hip status {status}: {msg.decode() if msg else ''}")
+
+
+class kernel_profile:
+    """``with kernel_profile() as kp: ...`` -- every kernel this thread launches through the library inside the block
+    carries its own dispatch-attached HIP events (``ppasr_kprof_*``); afterwards ``kp.kernels`` is
+    ``{kernel name: (total_ms, launches)}`` with the names rocprofv3 prints (parameter lists dropped)."""
+
+    def __init__(self, max_entries=128):
+        self.max_entries = max_entries
+        self.kernels = {}
+
+    def __enter__(self):
+        check(load().ppasr_kprof_begin())
+        return self
+
+    def __exit__(self, *exc):
+        n = self.max_entries
+        names = ctypes.create_string_buffer(n * KPROF_NAME_LEN)
+        ms = (ctypes.c_float * n)()
+        cnt = (ctypes.c_int32 * n)()
+        got = ctypes.c_int(0)
+        check(load().ppasr_kprof_end(n, ctypes.addressof(names), ms, cnt, ctypes.byref(got)))
+        for i in range(got.value):
+            nm = names.raw[i * KPROF_NAME_LEN:(i + 1) * KPROF_NAME_LEN].split(b"\0", 1)[0].decode()
+            t, c = self.kernels.get(nm, (0.0, 0))
+            self.kernels[nm] = (t + float(ms[i]), c + int(cnt[i]))
+        return False

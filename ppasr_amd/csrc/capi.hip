@@ -1,5 +1,6 @@
 // capi.hip -- the C-ABI of libppasr_hip.so (declared in include/ppasr_hip.h).
 // Host side: weight re-packing into MFMA fragment order, workspace carving, launch sequence.
+#include <cxxabi.h>
 #include <cstdlib>
 
 #include "capi_internal.h"
@@ -476,7 +477,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     // every kernel launched by fn() gets its own (start, stop) events attached to its dispatch (launch.h)
     h->spans.push_back({cls, {}});
     g_launch_prof.ctx = h;
-    g_launch_prof.next = [](void* ctx, hipEvent_t* s, hipEvent_t* e) {
+    g_launch_prof.next = [](void* ctx, const void*, hipEvent_t* s, hipEvent_t* e) {
       ppasr_model_s* m = static_cast<ppasr_model_s*>(ctx);
       *s = m->next_event();
       *e = m->next_event();
@@ -748,6 +749,94 @@ ppasr_status ppasr_ctc_beam_status(const void* state, size_t state_bytes, int B,
     any |= host[b] != 0;
   }
   if (any) return fail(PPASR_ENOSPACE, "beam search: the prefix arena of at least one utterance is exhausted (state sized for fewer frames)");
+  return PPASR_OK;
+}
+
+// ---- kernel-name profiler: every PPASR_LAUNCH of the calling thread between begin and end carries its own dispatch-attached
+// event pair (launch.h); entries are keyed by the kernel's function pointer and named from the code object, so the names
+// are the ones rocprofv3's kernel trace prints.  Covers every model family and the decoders (bench.py roofline leg). ----
+namespace {
+struct KProf {
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  struct Rec { const void* fn; hipEvent_t s, e; };
+  std::vector<Rec> recs;
+  hipEvent_t next() {
+    if (used == pool.size()) {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+};
+thread_local KProf g_kprof;
+
+std::string kernel_display_name(const void* fn) {
+  const char* mangled = hipKernelNameRefByPtr(fn, nullptr);
+  if (!mangled) return "?";
+  int status = 0;
+  char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+  std::string n = (status == 0 && dem) ? dem : mangled;
+  free(dem);
+  // drop the parameter list (the last balanced parenthesis group), "void " and the namespace
+  if (!n.empty() && n.back() == ')') {
+    int depth = 0;
+    for (size_t i = n.size(); i-- > 0;) {
+      if (n[i] == ')') ++depth;
+      else if (n[i] == '(' && --depth == 0) { n.erase(i); break; }
+    }
+  }
+  if (n.rfind("void ", 0) == 0) n.erase(0, 5);
+  for (size_t p; (p = n.find("ppasr::")) != std::string::npos;) n.erase(p, 7);
+  for (size_t p; (p = n.find("(anonymous namespace)::")) != std::string::npos;) n.erase(p, 23);
+  return n;
+}
+}  // namespace
+
+ppasr_status ppasr_kprof_begin(void) {
+  g_kprof.used = 0;
+  g_kprof.recs.clear();
+  g_launch_prof.ctx = &g_kprof;
+  g_launch_prof.next = [](void* ctx, const void* fn, hipEvent_t* s, hipEvent_t* e) {
+    KProf* k = static_cast<KProf*>(ctx);
+    *s = k->next();
+    *e = k->next();
+    k->recs.push_back({fn, *s, *e});
+  };
+  return PPASR_OK;
+}
+
+ppasr_status ppasr_kprof_end(int max_entries, char* names_host, float* total_ms_host, int* launches_host, int* n_out_host) {
+  g_launch_prof = LaunchProf{};
+  if (!names_host || !total_ms_host || !launches_host || !n_out_host || max_entries <= 0)
+    return fail(PPASR_EINVAL, "null argument");
+  std::vector<const void*> order;
+  std::unordered_map<const void*, std::pair<double, int>> acc;
+  for (auto& r : g_kprof.recs) {
+    HIP_TRY(hipEventSynchronize(r.e));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, r.s, r.e));
+    auto it = acc.find(r.fn);
+    if (it == acc.end()) {
+      order.push_back(r.fn);
+      it = acc.emplace(r.fn, std::make_pair(0.0, 0)).first;
+    }
+    it->second.first += ms;
+    it->second.second += 1;
+  }
+  g_kprof.recs.clear();
+  int n = 0;
+  for (const void* fn : order) {
+    if (n == max_entries) break;
+    const std::string name = kernel_display_name(fn);
+    char* dst = names_host + (size_t)n * PPASR_KPROF_NAME_LEN;
+    std::snprintf(dst, PPASR_KPROF_NAME_LEN, "%s", name.c_str());
+    total_ms_host[n] = (float)acc[fn].first;
+    launches_host[n] = acc[fn].second;
+    ++n;
+  }
+  *n_out_host = n;
   return PPASR_OK;
 }
 

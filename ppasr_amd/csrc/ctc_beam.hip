@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include "ctc_beam.h"
+#include "launch.h"
 
 namespace ppasr {
 
@@ -823,6 +824,385 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
   }
 }
 
+// ---- small beams: ONE WAVE per utterance, everything in registers ------------------------------------------------
+// beam_size <= BM (16) and <= 64 pruned characters per frame (PPASR's beam 10 / top-40 evaluation setting, BASELINE
+// configs[3], [4]).  The block-wide kernel above spends its 5-6 us per frame in a dozen workgroup barriers and LDS round
+// trips over 410 (hypothesis, candidate) elements; here lane k owns CANDIDATE k of the frame and lanes 0..nb-1 also own
+// HYPOTHESIS q, so that
+//   * a hypothesis' fields are wave-uniform when its children are formed (v_readlane -> SGPR), no LDS tables;
+//   * "is character c in the pruned list / which slot is my parent" are ballots;
+//   * the element space is nb + 1 registers per lane: slot i = child (hypothesis i, candidate = lane), plus the lane's
+//     own hypothesis; exact top-beam = repeated extraction of the minimum key (DPP reduction), ties at the cut resolved
+//     in the block kernel's (character, element id) order;
+//   * survivors are placed in element order with ballot prefix counts; only the new beam passes through LDS (scatter).
+// Same arithmetic, same keys, same order as k_ctc_beam: the two kernels return identical beams (tests run both).
+namespace {
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x111, 0xf, 0xf, false));
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x112, 0xf, 0xf, false));
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x114, 0xf, 0xf, false));
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x118, 0xf, 0xf, false));
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x142, 0xa, 0xf, false));
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x143, 0xc, 0xf, false));
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ float wave_min_f32(float x) {
+  for (int o = 32; o > 0; o >>= 1) x = fminf(x, __shfl_xor(x, o));
+  return x;
+}
+__device__ __forceinline__ int mbcnt(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
+}  // namespace
+
+template <int BM, bool HAS_LM>
+__global__ __launch_bounds__(64) void k_ctc_beam_wave(const int32_t* __restrict__ frame_lens, int T, BeamConfig cfg,
+                                                       const int32_t* __restrict__ recs, int32_t* __restrict__ state,
+                                                       int init_state, int finalize, int32_t* __restrict__ out_tokens,
+                                                       int32_t* __restrict__ out_lens, double* __restrict__ out_scores,
+                                                       int32_t* __restrict__ status) {
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
+  __shared__ int nx_i[3][BM];
+  __shared__ float nx_f[3][BM];
+  __shared__ int nx_ctx[BM][kLmCtx];
+  const int lane = threadIdx.x;
+  const int u = blockIdx.x;
+  const int beam = cfg.beam, blank = cfg.blank, CM = cfg.n_cand_max;
+  int32_t* st = state + (size_t)u * beam_state_words(beam, cfg.max_nodes);
+  int32_t* g_arr = st + 2;
+  int32_t* arena = st + 2 + (size_t)kBeamStateArrays * beam;
+  // hypothesis q lives in lane q
+  int h_node = -2, h_chr = -1, h_par = -1;
+  float h_b = kNegInf, h_nb = kNegInf, h_score = kNegInf;
+  int h_ctx[kLmCtx];
+#pragma unroll
+  for (int j = 0; j < kLmCtx; ++j) h_ctx[j] = cfg.lm.bos;
+  int nb, n_nodes;
+  if (init_state) {
+    nb = 1;
+    n_nodes = 1;
+    if (lane == 0) {
+      h_node = 0; h_chr = -1; h_par = -1;
+      h_b = 0.f; h_nb = kNegInf; h_score = 0.f;
+      arena[0] = -1; arena[1] = -1;
+    }
+  } else {
+    nb = st[0];
+    n_nodes = st[1];
+    if (lane < nb) {
+      h_node = g_arr[lane]; h_chr = g_arr[beam + lane]; h_par = g_arr[2 * beam + lane];
+      h_b = __int_as_float(g_arr[3 * beam + lane]); h_nb = __int_as_float(g_arr[4 * beam + lane]);
+      h_score = __int_as_float(g_arr[5 * beam + lane]);
+#pragma unroll
+      for (int j = 0; j < kLmCtx; ++j) h_ctx[j] = g_arr[(6 + j) * beam + lane];
+    }
+  }
+  nb = __builtin_amdgcn_readfirstlane(nb);
+  n_nodes = __builtin_amdgcn_readfirstlane(n_nodes);
+  const int n_frames = frame_lens ? min(max(frame_lens[u], 0), T) : T;
+  const int RW = prune_rec_words(CM);
+  const int32_t* rec_u = recs + (size_t)u * T * RW;
+  int pre_C = 0, pre_pb = 0, pre_c = 0, pre_lp = 0;
+  auto fetch = [&](int t) {
+    const int32_t* r = rec_u + (size_t)t * RW;
+    pre_C = r[0];
+    pre_pb = r[1];
+    pre_c = 0;
+    pre_lp = 0;
+    if (lane < CM) { pre_c = r[2 + lane]; pre_lp = r[2 + CM + lane]; }
+  };
+  if (n_frames > 0) fetch(0);
+#ifdef PPASR_BEAM_TS
+  long long ws_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ws_last = wall_clock64(), ws_c = 0, ws_nb = 0, ws_rounds = 0;
+#define WTS(i) do { long long now = wall_clock64(); ws_acc[i] += now - ws_last; ws_last = now; } while (0)
+#else
+#define WTS(i)
+#endif
+  for (int t = 0; t < n_frames; ++t) {
+    const int C = __builtin_amdgcn_readfirstlane(pre_C);
+    const float p_blank = __int_as_float(__builtin_amdgcn_readfirstlane(pre_pb));
+    const int cc = lane < C ? pre_c : -2;  // this lane's candidate character (-2: none)
+    const float clp = __int_as_float(pre_lp);
+    if (t + 1 < n_frames) fetch(t + 1);
+    // ---- blank among the candidates? ----
+    const unsigned long long mblank = __ballot(cc == blank);
+    const bool has_blank = mblank != 0;
+    const float lpb = has_blank ? rl_f(clp, __ffsll((long long)mblank) - 1) : 0.f;
+    // ---- external scorer: pruning threshold of the frame (see k_ctc_beam) ----
+    float min_cutoff = kNegInf;
+    bool full_beam = false;
+    if (HAS_LM) {
+      const float m = wave_min_f32(lane < nb ? h_score : FLT_MAX);
+      min_cutoff = (float)((double)m + log((double)p_blank) - fmax(0.0, cfg.beta));
+      full_beam = (nb == beam);
+    }
+    auto pruned = [&](float lp_c, float score) -> bool { return HAS_LM && full_beam && (lp_c + score < min_cutoff); };
+    auto lm_term = [&](const int* ctx, int c) -> float {  // alpha * ln P_lm(c | last order-1 words)
+      int32_t win[kLmMaxOrder];
+      const int order = cfg.lm.order;
+      for (int j = 0; j < order - 1; ++j) win[j] = ctx[(kLmCtx - (order - 1)) + j];
+      win[order - 1] = cfg.lm.tok2lm[c];
+      return (float)(lm_log_cond_prob(cfg.lm, win) * cfg.alpha);
+    };
+    WTS(0);
+    // ---- per hypothesis q (uniform loop): slot of its last character in the candidate list, slot of its parent in the
+    // beam, and the "child (parent, character) already exists" bit of candidate lane kq ----
+    int my_kq = -1, my_pi = -1;
+    float my_lq = kNotCand;
+    uint32_t exbits = 0;  // bit i: the child (hypothesis i, this lane's candidate) is already in the beam
+#pragma unroll
+    for (int q = 0; q < BM; ++q) {
+      if (q < nb) {
+        const int cq = rl_i(h_chr, q), pn = rl_i(h_par, q);
+        const unsigned long long mc = __ballot(cc == cq);
+        const unsigned long long mp = __ballot(lane < nb && h_node == pn);
+        const int kq = mc ? __ffsll((long long)mc) - 1 : -1;
+        const int pi = mp ? __ffsll((long long)mp) - 1 : -1;
+        const float lq = mc ? rl_f(clp, kq < 0 ? 0 : kq) : kNotCand;
+        if (lane == q) { my_kq = kq; my_pi = pi; my_lq = lq; }
+        if (mc && mp && cq != blank && lane == kq) exbits |= 1u << pi;
+      }
+    }
+    WTS(1);
+    // ---- (d) contributions received by the hypotheses already in the beam (lanes q < nb) ----
+    float new_b = kNegInf, new_nb = kNegInf, new_score = kNegInf;
+    {
+      const int pa = (my_pi < 0 ? 0 : my_pi) * 4;
+      const float p_score = __int_as_float(__builtin_amdgcn_ds_bpermute(pa, __float_as_int(h_score)));
+      const float p_b = __int_as_float(__builtin_amdgcn_ds_bpermute(pa, __float_as_int(h_b)));
+      const int p_chr = __builtin_amdgcn_ds_bpermute(pa, h_chr);
+      int p_ctx[kLmCtx];
+      if (HAS_LM) {
+#pragma unroll
+        for (int j = 0; j < kLmCtx; ++j) p_ctx[j] = __builtin_amdgcn_ds_bpermute(pa, h_ctx[j]);
+      }
+      if (lane < nb) {
+        float bc = (has_blank && !pruned(lpb, h_score)) ? lpb + h_score : kNegInf;
+        float nbc = kNegInf;
+        if (my_lq != kNotCand && h_chr != blank && h_chr >= 0) {
+          if (!pruned(my_lq, h_score)) nbc = my_lq + h_nb;  // repeated character
+          if (my_pi >= 0 && !pruned(my_lq, p_score)) {     // extension of the parent hypothesis lands on this prefix
+            float log_p = kNegInf;
+            if (h_chr == p_chr) { if (p_b > kNegInf) log_p = my_lq + p_b; }
+            else log_p = my_lq + p_score;
+            if (HAS_LM) {
+              log_p += lm_term(p_ctx, h_chr);
+              log_p = (float)((double)log_p + cfg.beta);
+            }
+            nbc = lse(nbc, log_p);
+          }
+        }
+        new_b = bc;
+        new_nb = nbc;
+        new_score = lse(bc, nbc);
+      }
+    }
+    WTS(2);
+    // ---- (e) keys: kk[i] = child (hypothesis i, this lane's candidate), kh = this lane's own hypothesis ----
+    uint32_t kk[BM], kk0[BM];
+    uint32_t kh = lane < nb ? desc_key(new_score) : kNone;
+    const uint32_t kh0 = kh;
+    int n_valid = nb;
+#pragma unroll
+    for (int i = 0; i < BM; ++i) {
+      kk[i] = kNone;
+      if (i < nb) {
+        const int ci = rl_i(h_chr, i);
+        const float bi = rl_f(h_b, i), si = rl_f(h_score, i);
+        const bool ok = cc >= 0 && cc != blank && !((exbits >> i) & 1u) && !pruned(clp, si);
+        float log_p = kNegInf;
+        if (cc == ci) { if (bi > kNegInf) log_p = clp + bi; }
+        else log_p = clp + si;
+        if (HAS_LM) {
+          if (ok) {
+            int ictx[kLmCtx];
+#pragma unroll
+            for (int j = 0; j < kLmCtx; ++j) ictx[j] = rl_i(h_ctx[j], i);
+            log_p += lm_term(ictx, cc);
+            log_p = (float)((double)log_p + cfg.beta);
+          }
+        }
+        kk[i] = ok ? desc_key(log_p) : kNone;
+        n_valid += __popcll(__ballot(ok));
+      }
+      kk0[i] = kk[i];
+    }
+    const int k_sel = n_valid >= beam ? beam : n_valid;
+    WTS(3);
+#ifdef PPASR_BEAM_TS
+    ws_c += C; ws_nb += nb;
+#endif
+    // ---- (f) exact top-k_sel in (score key, character, element id) order: extract the minimum key until k_sel elements
+    // are taken; a taken element's key becomes kNone (kk0 / kh0 keep the original).  k_sel == n_valid: everything stays.
+    if (k_sel < n_valid) {
+      int taken = 0;
+      while (taken < k_sel) {
+        uint32_t lm = kh;
+#pragma unroll
+        for (int i = 0; i < BM; ++i)
+          if (i < nb) lm = min(lm, kk[i]);
+        const uint32_t g = wave_min_u32(lm);
+        int total = __popcll(__ballot(kh == g));
+#pragma unroll
+        for (int i = 0; i < BM; ++i)
+          if (i < nb) total += __popcll(__ballot(kk[i] == g));
+        if (taken + total <= k_sel) {
+          if (kh == g) kh = kNone;
+#pragma unroll
+          for (int i = 0; i < BM; ++i)
+            if (i < nb && kk[i] == g) kk[i] = kNone;
+          taken += total;
+        } else {
+          // tie at the cut: of the elements with key g take the k_sel - taken smallest (character + 1, element id)
+          for (; taken < k_sel; ++taken) {
+            uint32_t tk = (kh == g) ? (((uint32_t)(h_chr + 1) << 18) | (uint32_t)lane) : kNone;
+#pragma unroll
+            for (int i = 0; i < BM; ++i)
+              if (i < nb && kk[i] == g) tk = min(tk, ((uint32_t)(cc + 1) << 18) | (uint32_t)(nb + i * C + lane));
+            const uint32_t w = wave_min_u32(tk);
+            if (kh == g && ((((uint32_t)(h_chr + 1) << 18) | (uint32_t)lane) == w)) kh = kNone;
+#pragma unroll
+            for (int i = 0; i < BM; ++i)
+              if (i < nb && kk[i] == g && ((((uint32_t)(cc + 1) << 18) | (uint32_t)(nb + i * C + lane)) == w)) kk[i] = kNone;
+          }
+        }
+      }
+    } else {
+      kh = kNone;
+#pragma unroll
+      for (int i = 0; i < BM; ++i) kk[i] = kNone;
+    }
+    WTS(4);
+    // ---- (g) survivors in element order -> slots of the next beam (scatter through LDS) ----
+    {
+      const bool keep_h = kh0 != kNone && kh == kNone;
+      const unsigned long long mh = __ballot(keep_h);
+      if (keep_h) {
+        const int pos = mbcnt(mh);
+        nx_i[0][pos] = h_node; nx_i[1][pos] = h_chr; nx_i[2][pos] = h_par;
+        nx_f[0][pos] = new_b; nx_f[1][pos] = new_nb; nx_f[2][pos] = new_score;
+#pragma unroll
+        for (int j = 0; j < kLmCtx; ++j) nx_ctx[pos][j] = h_ctx[j];
+      }
+      int base = __popcll(mh);
+#pragma unroll
+      for (int i = 0; i < BM; ++i) {
+        if (i < nb) {
+          const bool keep = kk0[i] != kNone && kk[i] == kNone;
+          const unsigned long long mk = __ballot(keep);
+          if (mk) {
+            const int node_i = rl_i(h_node, i);
+            if (keep) {
+              const int pos = base + mbcnt(mk);
+              const float log_p = score_of_key(kk0[i]);
+              const int id = n_nodes + pos;
+              if (id < cfg.max_nodes) { arena[2 * (size_t)id] = node_i; arena[2 * (size_t)id + 1] = cc; }
+              nx_i[0][pos] = id; nx_i[1][pos] = cc; nx_i[2][pos] = node_i;
+              nx_f[0][pos] = kNegInf; nx_f[1][pos] = log_p; nx_f[2][pos] = log_p;
+#pragma unroll
+              for (int j = 0; j + 1 < kLmCtx; ++j) nx_ctx[pos][j] = rl_i(h_ctx[j + 1], i);
+              nx_ctx[pos][kLmCtx - 1] = HAS_LM ? cfg.lm.tok2lm[cc] : 0;
+            }
+            base += __popcll(mk);
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      h_node = -2; h_chr = -1; h_par = -1;
+      h_b = kNegInf; h_nb = kNegInf; h_score = kNegInf;
+      if (lane < k_sel) {
+        h_node = nx_i[0][lane]; h_chr = nx_i[1][lane]; h_par = nx_i[2][lane];
+        h_b = nx_f[0][lane]; h_nb = nx_f[1][lane]; h_score = nx_f[2][lane];
+#pragma unroll
+        for (int j = 0; j < kLmCtx; ++j) h_ctx[j] = nx_ctx[lane][j];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    n_nodes += k_sel;
+    nb = k_sel;
+    WTS(5);
+    if (n_nodes + beam > cfg.max_nodes) {  // arena exhausted: report, stop consuming frames
+      if (lane == 0 && status) status[u] = 1;
+      break;
+    }
+  }
+#ifdef PPASR_BEAM_TS
+  if (lane == 0 && u == 0 && n_frames > 0)
+    printf("wave beam ts (x10ns/frame): fetch %lld qloop %lld contrib %lld keys %lld select %lld place %lld | C %lld nb %lld frames %d\n",
+           ws_acc[0] / n_frames, ws_acc[1] / n_frames, ws_acc[2] / n_frames, ws_acc[3] / n_frames, ws_acc[4] / n_frames,
+           ws_acc[5] / n_frames, ws_c / n_frames, ws_nb / n_frames, n_frames);
+#endif
+  // ---- persist the state (same layout as k_ctc_beam) ----
+  if (lane == 0) { st[0] = nb; st[1] = n_nodes; }
+  if (lane < nb) {
+    g_arr[lane] = h_node; g_arr[beam + lane] = h_chr; g_arr[2 * beam + lane] = h_par;
+    g_arr[3 * beam + lane] = __float_as_int(h_b); g_arr[4 * beam + lane] = __float_as_int(h_nb);
+    g_arr[5 * beam + lane] = __float_as_int(h_score);
+#pragma unroll
+    for (int j = 0; j < kLmCtx; ++j) g_arr[(6 + j) * beam + lane] = h_ctx[j];
+  }
+  if (!finalize) return;
+  __threadfence_block();  // this wave's arena stores are read back below
+  // ---- get_beam_search_result: rank the beam by prefix_compare, emit the n-best paths ----
+  {
+    const uint64_t kq = make_key(h_score, h_chr, lane);
+    int rank = 0;
+#pragma unroll
+    for (int i = 0; i < BM; ++i) {
+      if (i < nb) {
+        const uint64_t ki = make_key(rl_f(h_score, i), rl_i(h_chr, i), i);
+        rank += (ki < kq) ? 1 : 0;
+      }
+    }
+    if (lane < nb && rank < cfg.nbest) {
+      int len = 0;
+      for (int n = h_node; n > 0; n = arena[2 * (size_t)n]) ++len;
+      int32_t* dst = out_tokens + ((size_t)u * cfg.nbest + rank) * cfg.max_tokens;
+      for (int j = 0; j < cfg.max_tokens; ++j) dst[j] = -1;
+      int j = len;
+      for (int n = h_node; n > 0; n = arena[2 * (size_t)n]) {
+        --j;
+        if (j < cfg.max_tokens) dst[j] = arena[2 * (size_t)n + 1];
+      }
+      out_lens[(size_t)u * cfg.nbest + rank] = len;
+      double approx_ctc = (double)h_score;
+      if (HAS_LM) {
+        const int order = cfg.lm.order;
+        double sent = 0.0;
+        int32_t win[kLmMaxOrder];
+        auto window_of = [&](int node, int last_word) {
+          win[order - 1] = last_word;
+          int n = node;
+          for (int j2 = order - 2; j2 >= 0; --j2) {
+            if (n > 0) { win[j2] = cfg.lm.tok2lm[arena[2 * (size_t)n + 1]]; n = arena[2 * (size_t)n]; }
+            else win[j2] = cfg.lm.bos;
+          }
+        };
+        if (len == 0) {
+          for (int j2 = 0; j2 < order; ++j2) win[j2] = cfg.lm.bos;
+          sent += lm_log_cond_prob(cfg.lm, win);
+        }
+        window_of(h_node, cfg.lm.eos);
+        sent += lm_log_cond_prob(cfg.lm, win);
+        for (int n = h_node; n > 0; n = arena[2 * (size_t)n]) {
+          window_of(arena[2 * (size_t)n], cfg.lm.tok2lm[arena[2 * (size_t)n + 1]]);
+          sent += lm_log_cond_prob(cfg.lm, win);
+        }
+        approx_ctc = approx_ctc - (double)len * cfg.beta - sent * cfg.alpha;
+      }
+      out_scores[(size_t)u * cfg.nbest + rank] = -approx_ctc;
+    }
+    for (int r = nb + lane; r < cfg.nbest; r += 64) {
+      out_lens[(size_t)u * cfg.nbest + r] = -1;
+      out_scores[(size_t)u * cfg.nbest + r] = 0.0;
+    }
+  }
+}
+
+constexpr int kWaveBeamMax = 16;  // k_ctc_beam_wave: beam_size <= 16 and <= 64 pruned characters per frame
+
 hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B, int T, const BeamConfig& cfg,
                            int32_t* prune_recs, int32_t* state, int init_state, int finalize, int32_t* out_tokens,
                            int32_t* out_lens, double* out_scores, int32_t* status, hipStream_t st) {
@@ -854,10 +1234,23 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
     if (e != hipSuccess) return e;
   }
   if (T > 0)
-    hipLaunchKernelGGL(k_ctc_prune<kPruneThreads>, dim3(T, B), dim3(kPruneThreads), plds, st, probs, frame_lens, T, cfg,
+    PPASR_LAUNCH(k_ctc_prune<kPruneThreads>, dim3(T, B), dim3(kPruneThreads), plds, st, probs, frame_lens, T, cfg,
                        prune_recs);
+  // small beams: one wave per utterance.  OPT-IN for now (PPASR_BEAM_WAVE=1): measured 11 us per frame at beam 10 against
+  // 5.4 us for the block-wide kernel (a lone wave issues its readlane / ballot / branch sequences at ~9 cycles per
+  // instruction); kept because it needs no LDS tables and co-resides with the encoder's workgroups.
+  const char* wave_env = getenv("PPASR_BEAM_WAVE");
+  if (cfg.beam <= kWaveBeamMax && cfg.n_cand_max <= 64 && wave_env && atoi(wave_env) == 1) {
+    if (cfg.lm.order > 0)
+      PPASR_LAUNCH((k_ctc_beam_wave<kWaveBeamMax, true>), dim3(B), dim3(64), 0, st, frame_lens, T, cfg, prune_recs, state,
+                   init_state, finalize, out_tokens, out_lens, out_scores, status);
+    else
+      PPASR_LAUNCH((k_ctc_beam_wave<kWaveBeamMax, false>), dim3(B), dim3(64), 0, st, frame_lens, T, cfg, prune_recs, state,
+                   init_state, finalize, out_tokens, out_lens, out_scores, status);
+    return hipGetLastError();
+  }
 #define PPASR_LAUNCH_BEAM(BT)                                                                                          \
-  hipLaunchKernelGGL(k_ctc_beam<BT>, dim3(B), dim3(BT), lds, st, probs, frame_lens, T, cfg, prune_recs, state, init_state, \
+  PPASR_LAUNCH(k_ctc_beam<BT>, dim3(B), dim3(BT), lds, st, probs, frame_lens, T, cfg, prune_recs, state, init_state, \
                      finalize, out_tokens, out_lens, out_scores, status)
   switch (sel) {
     case 0: PPASR_LAUNCH_BEAM(64); break;

@@ -10,6 +10,7 @@
 //   LayerNorm       : nn.LayerNorm over 1024 / 2048 features (encoder.py:54,93)
 // The recurrence is latency-bound (one dependent step = h_{t-1} broadcast + 16 dot products per
 // workgroup), not MFMA- or HBM-bound.
+#include "launch.h"
 #include "ds2_kernels.h"
 
 #include <math.h>
@@ -482,37 +483,37 @@ __global__ __launch_bounds__(256) void k_ln_wide(float* __restrict__ x, const fl
 
 void launch_ds2_conv1(const float* feats, const float* mean, const float* istd, const float* w, const float* bias, float* y1,
                       int B, int T, int F, int T1, int F1, hipStream_t st) {
-  hipLaunchKernelGGL(k_ds2_conv1, dim3(T1, B), dim3(256), 0, st, feats, mean, istd, w, bias, y1, T, F, T1, F1);
+  PPASR_LAUNCH(k_ds2_conv1, dim3(T1, B), dim3(256), 0, st, feats, mean, istd, w, bias, y1, T, F, T1, F1);
 }
 void launch_ds2_conv2(const float* y1, const float* w, const float* bias, float* x, int B, int T1, int F1, int Tp, int F2,
                       int ldx, hipStream_t st) {
-  hipLaunchKernelGGL(k_ds2_conv2, dim3(Tp, B), dim3(256), 0, st, y1, w, bias, x, T1, F1, Tp, F2, ldx);
+  PPASR_LAUNCH(k_ds2_conv2, dim3(Tp, B), dim3(256), 0, st, y1, w, bias, x, T1, F1, Tp, F2, ldx);
 }
 void launch_ds2_lens(const int64_t* lens, int32_t* out32, int64_t* out64, int B, int Tp, hipStream_t st) {
-  hipLaunchKernelGGL(k_ds2_lens, dim3((B + 63) / 64), dim3(64), 0, st, lens, out32, out64, B, Tp);
+  PPASR_LAUNCH(k_ds2_lens, dim3((B + 63) / 64), dim3(64), 0, st, lens, out32, out64, B, Tp);
 }
 void launch_lstm_step(const float* gx, const float* whh, const float* hprev, float* hnext, float* c, float* y,
                       const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st) {
-  hipLaunchKernelGGL(k_lstm_step, dim3(H / 4, dirs), dim3(256), (H + 16) * sizeof(float), st, gx, whh, hprev, hnext, c, y,
+  PPASR_LAUNCH(k_lstm_step, dim3(H / 4, dirs), dim3(256), (H + 16) * sizeof(float), st, gx, whh, hprev, hnext, c, y,
                      lens, B, T, H, dirs, step);
 }
 void launch_gru_step(const float* gx, const float* whh, const float* bhh, const float* hprev, float* hnext, float* y,
                      const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st) {
-  hipLaunchKernelGGL(k_gru_step, dim3(H / 4, dirs), dim3(256), (H + 32) * sizeof(float), st, gx, whh, bhh, hprev, hnext, y,
+  PPASR_LAUNCH(k_gru_step, dim3(H / 4, dirs), dim3(256), (H + 32) * sizeof(float), st, gx, whh, bhh, hprev, hnext, y,
                      lens, B, T, H, dirs, step);
 }
 void launch_lstm_step_mfma(const float* gx, const f32x4* whh_pk, const float* hprev, float* hnext, float* c, float* y,
                            const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st) {
-  hipLaunchKernelGGL(k_lstm_step_mfma, dim3(H / 8, dirs, (B + 31) / 32), dim3(kThreads), 0, st, gx, whh_pk, hprev, hnext, c, y,
+  PPASR_LAUNCH(k_lstm_step_mfma, dim3(H / 8, dirs, (B + 31) / 32), dim3(kThreads), 0, st, gx, whh_pk, hprev, hnext, c, y,
                      lens, B, T, H, dirs, step);
 }
 void launch_lstm_wave(const float* gx0, const Ds2WaveLayer* tab, float* hbuf, float* cbuf, float* yring, float* out,
                       const int32_t* lens, int B, int T, int H, int L, int s, int l_lo, int n_l, hipStream_t st) {
-  hipLaunchKernelGGL(k_lstm_wave, dim3(H / 8, n_l, (B + 31) / 32), dim3(kThreads), 0, st, gx0, tab, hbuf, cbuf, yring, out, lens,
+  PPASR_LAUNCH(k_lstm_wave, dim3(H / 8, n_l, (B + 31) / 32), dim3(kThreads), 0, st, gx0, tab, hbuf, cbuf, yring, out, lens,
                      B, T, H, L, s, l_lo);
 }
 void launch_ln_wide(float* x, const float* g, const float* b, int M, int N, hipStream_t st) {
-  hipLaunchKernelGGL(k_ln_wide, dim3((M + 3) / 4), dim3(256), 0, st, x, g, b, M, N);
+  PPASR_LAUNCH(k_ln_wide, dim3((M + 3) / 4), dim3(256), 0, st, x, g, b, M, N);
 }
 
 }  // namespace ppasr

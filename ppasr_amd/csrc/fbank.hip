@@ -9,6 +9,7 @@
 // One 256-thread workgroup per frame: the frame lives in LDS from the raw samples to the 80 log-mel values
 // (radix-2 FFT, one butterfly per thread per stage); HBM traffic = the samples once (L2 absorbs the 2.5x frame
 // overlap) + 320 B per frame out.  HBM- / latency-bound: 4 B * 160 new samples + 320 B out per frame.
+#include "launch.h"
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -256,8 +257,8 @@ ppasr_status ppasr_fbank_compute(ppasr_fbank_handle f, const float* samples, int
   hipStream_t st = static_cast<hipStream_t>(stream);
   double* partial = static_cast<double*>(workspace);
   const int nblk = std::min(kMaxPartials, (n_samples + 4095) / 4096);
-  if (use_db_norm) hipLaunchKernelGGL(k_sumsq, dim3(nblk), dim3(256), 0, st, samples, n_samples, partial);
-  hipLaunchKernelGGL(k_fbank, dim3(frames), dim3(kFT), 0, st, samples, n_samples, partial, nblk, use_db_norm, target_db, f->tb,
+  if (use_db_norm) PPASR_LAUNCH(k_sumsq, dim3(nblk), dim3(256), 0, st, samples, n_samples, partial);
+  PPASR_LAUNCH(k_fbank, dim3(frames), dim3(kFT), 0, st, samples, n_samples, partial, nblk, use_db_norm, target_db, f->tb,
                      f->win, f->shift, f->nfft, f->log2n, f->n_mels, feats);
   HIP_TRY(hipGetLastError());
   return PPASR_OK;

@@ -12,8 +12,9 @@
 
 namespace ppasr {
 struct LaunchProf {
-  // hands out the event pair of the next launch; nullptr = no scope active
-  void (*next)(void* ctx, hipEvent_t* start, hipEvent_t* stop) = nullptr;
+  // hands out the event pair of the next launch (`fn` = the kernel's host-side function pointer, which names it);
+  // nullptr = no scope active
+  void (*next)(void* ctx, const void* fn, hipEvent_t* start, hipEvent_t* stop) = nullptr;
   void* ctx = nullptr;
 };
 extern thread_local LaunchProf g_launch_prof;  // defined in capi.hip
@@ -23,7 +24,7 @@ extern thread_local LaunchProf g_launch_prof;  // defined in capi.hip
   do {                                                                                        \
     if (ppasr::g_launch_prof.next) {                                                          \
       hipEvent_t _ps = nullptr, _pe = nullptr;                                                \
-      ppasr::g_launch_prof.next(ppasr::g_launch_prof.ctx, &_ps, &_pe);                        \
+      ppasr::g_launch_prof.next(ppasr::g_launch_prof.ctx, reinterpret_cast<const void*>(kernel), &_ps, &_pe); \
       hipExtLaunchKernelGGL(kernel, grid, block, lds, st, _ps, _pe, 0, __VA_ARGS__);          \
     } else {                                                                                  \
       hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                          \

@@ -7,6 +7,7 @@
 // dense layer on the host:  (s.x + a) W + c = x (diag(s) W) + (a W + c).  The conv module zeroes PAD
 // frames AFTER the scale (convolution.py:121-127), so PAD rows bypass the folded GEMM and take
 // GLU(bias) = `glu_pad` directly.
+#include "launch.h"
 #include "squeezeformer_kernels.h"
 
 #include "phases.h"
@@ -404,11 +405,11 @@ constexpr size_t kLds2 = 2 * kRows * kLda * sizeof(float);
 
 void launch_sq_qkv(const float* x, float* qkv, const f32x4* wqkv, const float* bqkv, int M, hipStream_t st,
                    const PadSkip& ps) {
-  hipLaunchKernelGGL(k_sq_qkv, rb_grid(M), dim3(kThreads), kLds1, st, x, qkv, wqkv, bqkv, M, ps);
+  PPASR_LAUNCH(k_sq_qkv, rb_grid(M), dim3(kThreads), kLds1, st, x, qkv, wqkv, bqkv, M, ps);
 }
 void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, float* xhat_out, const SqLayerW& w,
                    const int64_t* lens, int M, int Tp, int mask_mul, int n_chunks, hipStream_t st, const PadSkip& ps) {
-  hipLaunchKernelGGL(k_sq_mid, rb_grid(M), dim3(kThreads), kLdsSqMid, st, ctx, x, x2, g, xhat_out, w, lens, M, Tp, mask_mul,
+  PPASR_LAUNCH(k_sq_mid, rb_grid(M), dim3(kThreads), kLdsSqMid, st, ctx, x, x2, g, xhat_out, w, lens, M, Tp, mask_mul,
                      n_chunks, ps);
 }
 void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float* x_out, float* qkv_next, const SqLayerW& w,
@@ -416,7 +417,7 @@ void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float*
                     int n_chunks, int ksize, hipStream_t st, const PadSkip& ps, bool causal) {
   const int left_ctx = causal ? ksize - 1 : (ksize - 1) / 2;
 #define SQ_TAIL(KS, STREAM)                                                                                          \
-  hipLaunchKernelGGL((k_sq_tail<KS, STREAM>), rb_grid(M), dim3(kThreads), kLdsSqTail, st, g, g_hist, x2, x_out, qkv_next, w, \
+  PPASR_LAUNCH((k_sq_tail<KS, STREAM>), rb_grid(M), dim3(kThreads), kLdsSqTail, st, g, g_hist, x2, x_out, qkv_next, w, \
                      wqkv_next, bqkv_next, lens, M, Tp, mask_mul, n_chunks, ps, left_ctx)
   if (ksize == 31) {
     if (g_hist) SQ_TAIL(31, true); else SQ_TAIL(31, false);
@@ -426,24 +427,24 @@ void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float*
 #undef SQ_TAIL
 }
 void launch_sq_oproj(const float* ctx, const float* x, float* x1, const SqLayerW& w, int M, hipStream_t st, const PadSkip& ps) {
-  hipLaunchKernelGGL(k_sq_oproj, rb_grid(M), dim3(kThreads), kLds2, st, ctx, x, x1, w, M, ps);
+  PPASR_LAUNCH(k_sq_oproj, rb_grid(M), dim3(kThreads), kLds2, st, ctx, x, x1, w, M, ps);
 }
 void launch_sq_pw1glu(const float* x2, float* g, float* xhat_out, const SqLayerW& w, const int64_t* lens, int M, int Tp,
                       int mask_mul, hipStream_t st, const PadSkip& ps) {
-  hipLaunchKernelGGL(k_sq_pw1glu, rb_grid(M), dim3(kThreads), kLds1, st, x2, g, xhat_out, w, lens, M, Tp, mask_mul, ps);
+  PPASR_LAUNCH(k_sq_pw1glu, rb_grid(M), dim3(kThreads), kLds1, st, x2, g, xhat_out, w, lens, M, Tp, mask_mul, ps);
 }
 void launch_sq_reduce(const float* x, float* xr, float* qkv, const SqReduceW& rw, const f32x4* wqkv, const float* bqkv,
                       const int64_t* lens, int B, int Tp, int Tr, hipStream_t st, const PadSkip& ps) {
-  hipLaunchKernelGGL(k_sq_reduce, rb_grid(B * Tr), dim3(kThreads), kLds2, st, x, xr, qkv, rw, wqkv, bqkv, lens, B, Tp, Tr,
+  PPASR_LAUNCH(k_sq_reduce, rb_grid(B * Tr), dim3(kThreads), kLds2, st, x, xr, qkv, rw, wqkv, bqkv, lens, B, Tp, Tr,
                      ps);
 }
 void launch_sq_recover(const float* xr, const float* saved, float* x, float* qkv, const f32x4* wrec, const float* brec,
                        const f32x4* wqkv, const float* bqkv, int B, int Tp, int Tr, hipStream_t st, const PadSkip& ps) {
-  hipLaunchKernelGGL(k_sq_recover, rb_grid(B * Tp), dim3(kThreads), kLds2, st, xr, saved, x, qkv, wrec, brec, wqkv, bqkv, B,
+  PPASR_LAUNCH(k_sq_recover, rb_grid(B * Tp), dim3(kThreads), kLds2, st, xr, saved, x, qkv, wrec, brec, wqkv, bqkv, B,
                      Tp, Tr, ps);
 }
 void launch_ln_rows(float* x, const float* g, const float* b, int M, hipStream_t st, const PadSkip& ps) {
-  hipLaunchKernelGGL(k_ln_rows, rb_grid(M), dim3(kThreads), kLds1, st, x, g, b, M, ps);
+  PPASR_LAUNCH(k_ln_rows, rb_grid(M), dim3(kThreads), kLds1, st, x, g, b, M, ps);
 }
 
 hipError_t configure_squeezeformer_kernels() {

@@ -107,7 +107,8 @@ def cfg5():
 
 
 if __name__ == "__main__":
-    for f in (cfg1, cfg4, cfg5):
+    sel = sys.argv[1:] or ["cfg1", "cfg4", "cfg5"]
+    for f in [globals()[n] for n in sel]:
         r = f()
         for line in (r if isinstance(r, list) else [r]):
             print(json.dumps(line), flush=True)
