@@ -116,7 +116,9 @@ ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats);
  * stride / time-reduction reads): whole 32-row blocks behind them are skipped in every kernel and attention stops at
  * the last valid key.  Valid rows are bit-identical to the default mode; rows of `probs` / `logits` behind an
  * utterance's last valid frame are set to 0, `frame_argmax` to 0 (blank) and `frame_maxprob` to 0 -- pass frame_lens
- * to the decoders.  Default: off (= the reference's outputs for every row). */
+ * to the decoders.  Default: off (= the reference's outputs for every row).  Built into the fused 256-column kernels
+ * behind the conv2d (4x) front end: enabling it on a conv2d6 / conv2d8, generic-width or DeepSpeech2 handle returns
+ * PPASR_EUNSUPPORTED (those routes compute every row). */
 ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable);
 
 /* Under-filled launches.  A kernel with fewer 32-row blocks than the chip has CUs takes as long as a full one.  When a
@@ -234,7 +236,8 @@ ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, const int64_t*
 /* Measurement hook (bench.py roofline leg; no reference counterpart): when enabled, every kernel launch
  * of the next ppasr_encode is bracketed by a HIP event pair on the caller's stream; ppasr_profile_read
  * synchronises those events and returns, per kernel class, the summed duration (ms) and launch count
- * into HOST arrays of PPASR_N_KERNEL_CLASSES entries. */
+ * into HOST arrays of PPASR_N_KERNEL_CLASSES entries.  Conformer / Efficient-Conformer handles of width 256 only
+ * (PPASR_EUNSUPPORTED otherwise); ppasr_kprof_* below covers every route by kernel name. */
 #define PPASR_N_KERNEL_CLASSES 10
 ppasr_status ppasr_profile_enable(ppasr_handle h, int enable);
 ppasr_status ppasr_profile_read(ppasr_handle h, float* total_ms_host, int* launches_host);

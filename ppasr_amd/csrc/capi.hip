@@ -430,6 +430,11 @@ ppasr_status ppasr_set_ffn_split(ppasr_handle h, int mode) {
 
 ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable) {
   if (!h) return fail(PPASR_EINVAL, "null handle");
+  // the ragged mode is built into the fused 256-column kernels behind the 4x front end; other handles would silently
+  // compute (and return) every padded row, which is not what the caller asked for
+  if (enable && (h->desc.model_type == PPASR_MODEL_DEEPSPEECH2 || h->desc.input_layer != 0 ||
+                 (h->desc.output_size != kD && h->desc.model_type == PPASR_MODEL_CONFORMER)))
+    return fail(PPASR_EUNSUPPORTED, "skip_padding: built for output_size 256 behind the conv2d (4x) front end only");
   h->skip_padding = enable != 0;
   return PPASR_OK;
 }
@@ -846,6 +851,10 @@ static const char* kKernelClassNames[PPASR_N_KERNEL_CLASSES] = {
 
 ppasr_status ppasr_profile_enable(ppasr_handle h, int enable) {
   if (!h) return fail(PPASR_EINVAL, "null handle");
+  if (enable && (h->desc.model_type != PPASR_MODEL_CONFORMER && h->desc.model_type != PPASR_MODEL_EFFICIENT_CONFORMER))
+    return fail(PPASR_EUNSUPPORTED, "ppasr_profile_enable: kernel classes exist for the Conformer route only; use ppasr_kprof_begin / _end");
+  if (enable && h->desc.output_size != kD)
+    return fail(PPASR_EUNSUPPORTED, "ppasr_profile_enable: the generic-width route has no kernel classes; use ppasr_kprof_begin / _end");
   h->prof = enable != 0;
   h->spans.clear();
   h->ev_used = 0;

@@ -21,7 +21,8 @@ namespace {
 // swish, optionally with rows t of utterance b zeroed where mul * t >= lens[b] (the conv module's input mask,
 // convolution.py:104-106).  eps < 0: per-channel affine only (folded BatchNorm1D, see capi.hip).
 template <bool SWISH>
-__global__ __launch_bounds__(256) void k_g_ln(const float* __restrict__ x, float* __restrict__ out,
+// (x and out may be the same buffer -- the encoder normalises in place -- so neither is __restrict__)
+__global__ __launch_bounds__(256) void k_g_ln(const float* x, float* out,
                                               const float* __restrict__ g, const float* __restrict__ b, int M, int D,
                                               float eps, const int64_t* __restrict__ lens, int Tp, int mul) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;

@@ -90,6 +90,25 @@ class _BeamState:
         self.buf, self.bytes, self.max_frames = new, nbytes, cap
 
 
+_cap_warned = False
+
+
+def _warn_candidate_cap(lib, V, cutoff_prob, cutoff_top_n):
+    """DOCUMENTED DEVIATION made visible: the kernels keep at most 128 pruned characters per frame.  Upstream keeps the
+    whole vocabulary when cutoff_prob >= 1 (the swig wrappers' default, swig_wrapper.py:40) -- warn once instead of
+    differing silently."""
+    global _cap_warned
+    cap = int(lib.ppasr_ctc_beam_candidate_cap())
+    n_cand = min(int(cutoff_top_n), V) if cutoff_prob < 1.0 else V
+    if n_cand > cap and not _cap_warned:
+        _cap_warned = True
+        import warnings
+        warnings.warn(f"ctc beam search: cutoff_prob={cutoff_prob}, cutoff_top_n={cutoff_top_n}, V={V} lets {n_cand} characters "
+                      f"per frame survive pruning; the HIP decoder keeps the {cap} most probable ones (upstream "
+                      "paddlespeech_ctcdecoders would keep all of them). Use cutoff_prob < 1 with cutoff_top_n <= "
+                      f"{cap} for upstream-identical pruning.", RuntimeWarning, stacklevel=3)
+
+
 def beam_search_ids(probs, beam_size, cutoff_prob=1.0, cutoff_top_n=40, blank_id=0, frame_lens=None, nbest=1,
                     state=None, max_frames=None, ext_scorer=None):
     """probs [B,T,V] (numpy or device tensor) -> (tokens [B,nbest,L] i32, lens [B,nbest] i32, scores [B,nbest] f64)
@@ -97,6 +116,7 @@ def beam_search_ids(probs, beam_size, cutoff_prob=1.0, cutoff_top_n=40, blank_id
     lib = _lib.load()
     if not torch.cuda.is_available():
         raise _lib.PPASRHipError("no HIP device visible: ppasr_amd has no CPU fallback")
+    _warn_candidate_cap(lib, probs.shape[-1], cutoff_prob, cutoff_top_n)
     dev = probs.device if isinstance(probs, torch.Tensor) and probs.is_cuda else torch.device(
         "cuda", torch.cuda.current_device())
     p = torch.as_tensor(probs, dtype=torch.float32).to(dev).contiguous()

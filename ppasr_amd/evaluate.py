@@ -3,7 +3,9 @@
 CTC loss) and is out of scope; ``evaluate`` returns the mean CER / WER only.
 
 With ``torch.distributed`` initialised, every rank evaluates the batches ``rank::world`` and the per-utterance error
-rates are summed with one all-reduce (utterance data parallelism)."""
+rates are summed with one all-reduce (utterance data parallelism).  For variable-length batches
+``shard="buckets"`` splits EVERY batch over the ranks instead (``parallel.decode_ragged``: whole length buckets per rank
+by padded work, one all-gather of the hypotheses per batch), so that ranks finish together whatever the batch order."""
 import torch
 
 from ppasr_amd.decoders.beam_search_decoder import beam_search_ids
@@ -33,14 +35,21 @@ def decoder_result(outs, vocabulary, decoder="ctc_greedy", beam_search_decoder=N
 
 
 def evaluate(model, batches, vocab_list, decoder="ctc_greedy", metrics_type="cer", beam_search_decoder=None,
-             display_result=False, trim_padding=False, overlap_decode=True):
+             display_result=False, trim_padding=False, overlap_decode=True, shard="batches"):
     """model: any ppasr_amd model with ``get_encoder_out(inputs, input_lens)``;
     batches: iterable of (inputs [B,T,F], labels [B,U] (-1 padded), input_lens [B], label_lens [B]) like the reference's
     test_loader.  -> mean error rate (float), -1 if there is nothing to score (trainer.py:643).
     ``trim_padding=True`` (not the reference's behaviour, which decodes the padded rows of every utterance too): the
     encoder runs in its ragged-batch mode and the decoders stop at each utterance's last valid frame.
-    ``overlap_decode``: encode batch i+1 on a second HIP stream while batch i is being decoded (same results)."""
+    ``overlap_decode``: encode batch i+1 on a second HIP stream while batch i is being decoded (same results).
+    ``shard``: "batches" = batch i goes to rank i % world; "buckets" = every batch is cut into length buckets that are
+    dealt to the ranks by padded work (ragged batches; decoding then covers the valid frames only)."""
     dist = torch.distributed.is_available() and torch.distributed.is_initialized()
+    if shard == "buckets":
+        return _evaluate_bucketed(model, batches, vocab_list, decoder, metrics_type, beam_search_decoder, display_result,
+                                  torch.distributed if dist else None)
+    if shard != "batches":
+        raise ValueError(f"shard={shard!r}: 'batches' or 'buckets'")
     rank = torch.distributed.get_rank() if dist else 0
     world = torch.distributed.get_world_size() if dist else 1
     eos = len(vocab_list) - 1
@@ -102,4 +111,30 @@ def evaluate(model, batches, vocab_list, decoder="ctc_greedy", metrics_type="cer
         t = torch.tensor([total, float(count)], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t)
         total, count = float(t[0]), int(t[1])
+    return total / count if count > 0 else -1
+
+
+def _evaluate_bucketed(model, batches, vocab_list, decoder, metrics_type, beam_search_decoder, display_result, dist):
+    """Every rank walks every batch and decodes ITS length buckets of it; after the gather each rank holds all
+    hypotheses of the batch, so the error sums are identical on every rank and need no further collective."""
+    from ppasr_amd.parallel import beam_ids_decoder, decode_ragged, greedy_ids_decoder
+    if decoder == "ctc_greedy" or beam_search_decoder is None:
+        dec = greedy_ids_decoder()
+    else:
+        d = beam_search_decoder
+        dec = beam_ids_decoder(d.beam_size, d.cutoff_prob, d.cutoff_top_n, d.blank_id, d._ext_scorer)
+    eos = len(vocab_list) - 1
+    total, count = 0.0, 0
+    for inputs, labels, input_lens, _label_lens in batches:
+        lens = [int(v) for v in torch.as_tensor(input_lens).tolist()]
+        tokens, n, _ = decode_ragged(model, inputs, lens, dec, dist=dist)
+        tk, nn = tokens.cpu(), n.cpu()
+        labels_str = labels_to_string(labels, vocab_list, eos=eos)
+        for b, label in enumerate(labels_str):
+            out_string = "".join(vocab_list[i] for i in tk[b, :max(int(nn[b]), 0)].tolist()).replace("<space>", " ")
+            err = wer(out_string, label) if metrics_type == "wer" else cer(out_string, label)
+            total += err
+            count += 1
+            if display_result:
+                print(f"pred: {out_string}\nlabel: {label}\n{metrics_type}: {round(err, 6)}")
     return total / count if count > 0 else -1

@@ -66,7 +66,9 @@ class EfficientConformerModel(ConformerModel):
         self.subsampling_rate = {"conv2d": 4, "conv2d6": 6, "conv2d8": 8}[il]
         # cnn_module_norm (convolution.py:65-71): layer_norm, or batch_norm = nn.BatchNorm1D in eval mode, which the
         # library folds into a per-channel scale / shift; the checkpoint carries the running statistics then
-        norm = conf.get("cnn_module_norm", "layer_norm")
+        # (default = the reference constructor's: efficient_conformer/encoder.py:49 `cnn_module_norm="batch_norm"`; the
+        #  shipped YAML sets layer_norm explicitly, configs/efficient_conformer.yml:9)
+        norm = conf.get("cnn_module_norm", "batch_norm")
         if norm not in ("layer_norm", "batch_norm"):
             raise ValueError(f"encoder_conf.cnn_module_norm={norm!r}")
         has_stats = any(k.endswith("conv_module.norm._mean") for k in state_dict)

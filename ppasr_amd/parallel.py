@@ -19,7 +19,8 @@ Record layout per utterance (int32 words): tokens[L] (-1 padded) | n_tokens | sc
 import torch
 
 __all__ = ["shard_range", "pack_hypotheses", "unpack_hypotheses", "gather_hypotheses", "Bucket", "make_buckets",
-           "assign_buckets", "ragged_record_shape", "gather_ragged_hypotheses"]
+           "assign_buckets", "ragged_record_shape", "gather_ragged_hypotheses", "rank_batches", "greedy_ids_decoder",
+           "beam_ids_decoder", "decode_ragged", "RaggedPlan"]
 
 
 def shard_range(n_items, rank, world):
@@ -110,22 +111,40 @@ def ragged_record_shape(lengths, world, out_frames, width=200):
     return rows, cols
 
 
+def _collective_device(dist, device, group=None):
+    """Device the collective's tensors must live on: the caller's choice, else the current HIP device under the
+    nccl (= RCCL) backend (a rank that was dealt no bucket has no result tensor to take it from), else the host."""
+    if device is not None:
+        return torch.device(device)
+    try:
+        backend = dist.get_backend(group)
+    except Exception:  # a stub "dist" in tests
+        backend = "gloo"
+    if str(backend) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def gather_ragged_hypotheses(results, n_total, rows, cols, dist, device=None, group=None):
-    """``results``: this rank's list of (utterance index, tokens 1-D int32 tensor, score float) in any order.
+    """``results``: this rank's list of (utterance index, tokens 1-D int32 tensor / array, score float) in any order.
     -> (tokens [n_total, cols] i32 (-1 padded), n_tokens [n_total] i32, score [n_total] f64) in the CALLER's utterance
-    order, identical on every rank.  One all-gather of ``int32[rows, cols + 4]`` per rank; unused rows carry index -1."""
-    dev = device if device is not None else (results[0][1].device if results else "cpu")
-    rec = torch.full((rows, cols + 4), -1, dtype=torch.int32, device=dev)
+    order, identical on every rank.  One all-gather of ``int32[rows, cols + 4]`` per rank; unused rows carry index -1.
+    The record is assembled on the host and uploaded once."""
+    import numpy as np
+    dev = _collective_device(dist, device, group)
     if len(results) > rows:
         raise ValueError(f"{len(results)} results for a record of {rows} rows")
+    host = np.full((rows, cols + 4), -1, dtype=np.int32)
     for r, (idx, tok, sc) in enumerate(results):
-        n = int(tok.numel())
+        tok = tok.detach().cpu().numpy() if isinstance(tok, torch.Tensor) else np.asarray(tok)
+        n = int(tok.size)
         if n > cols:
             raise ValueError(f"hypothesis of {n} tokens for a record of {cols} columns")
-        rec[r, :n] = tok.to(torch.int32)
-        rec[r, cols] = n
-        rec[r, cols + 1:cols + 3] = torch.tensor([float(sc)], dtype=torch.float64).view(torch.int32).to(dev)
-        rec[r, cols + 3] = int(idx)
+        host[r, :n] = tok.astype(np.int32, copy=False)
+        host[r, cols] = n
+        host[r, cols + 1:cols + 3] = np.array([float(sc)], dtype=np.float64).view(np.int32)
+        host[r, cols + 3] = int(idx)
+    rec = torch.from_numpy(host).to(dev)
     world = dist.get_world_size(group)
     out = torch.empty(world * rows, cols + 4, dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(out, rec, group=group)
@@ -138,3 +157,227 @@ def gather_ragged_hypotheses(results, n_total, rows, cols, dist, device=None, gr
     g = out[order]
     score = g[:, cols + 1:cols + 3].contiguous().view(torch.float64).view(-1)
     return g[:, :cols], g[:, cols], score
+
+
+# ---- end to end: plan -> encode -> decode -> gather ---------------------------------------------------------------------
+def rank_batches(lengths, rank, world, width=200, mode="merged", max_batch_frames=None):
+    """The encoder batches of ``rank``: lists of utterance indices (positions in the caller's batch).
+    ``assign_buckets`` deals WHOLE 200-frame buckets to the ranks; then
+      mode "buckets": one batch per bucket (padded to the bucket's longest member; every padded row is computed -- the
+                      reference's arithmetic for that batch composition);
+      mode "merged":  the rank's buckets merged into ONE batch, longest utterance first, to be run with the encoder's
+                      ragged mode (``set_skip_padding``: rows behind an utterance's valid frames are not computed, so
+                      the padding costs nothing, while the merged grid fills the chip -- a bucket of 1-3 utterances is
+                      24-70 row blocks on 256 CUs).  ``max_batch_frames`` (sum of padded frames) cuts the merged list
+                      into several batches when a rank's share is larger than one workspace should hold."""
+    mine = assign_buckets(lengths, world, width)[rank]
+    if mode == "buckets":
+        return [list(b.indices) for b in sorted(mine, key=lambda b: -b.frames)]
+    if mode != "merged":
+        raise ValueError(f"mode {mode!r}: 'merged' or 'buckets'")
+    idx = sorted((i for b in mine for i in b.indices), key=lambda i: (-int(lengths[i]), i))
+    if not idx:
+        return []
+    if not max_batch_frames:
+        return [idx]
+    out, cur = [], []
+    for i in idx:
+        tmax = int(lengths[cur[0]]) if cur else int(lengths[i])
+        if cur and (len(cur) + 1) * tmax > max_batch_frames:
+            out.append(cur)
+            cur = []
+        cur.append(i)
+    out.append(cur)
+    return out
+
+
+def greedy_ids_decoder(blank=0):
+    """decoder callable for ``decode_ragged``: CTC greedy over each utterance's valid frames."""
+    from ppasr_amd.decoders.ctc_greedy_decoder import greedy_decode_ids
+
+    def run(probs, frame_lens):
+        tokens, n, score, _, _ = greedy_decode_ids(probs, frame_lens, blank)
+        return tokens, n, score
+    return run
+
+
+def beam_ids_decoder(beam_size, cutoff_prob=1.0, cutoff_top_n=40, blank=0, ext_scorer=None):
+    """decoder callable for ``decode_ragged``: CTC prefix beam search (best hypothesis) over the valid frames."""
+    from ppasr_amd.decoders.beam_search_decoder import beam_search_ids
+
+    def run(probs, frame_lens):
+        tokens, n, score, _ = beam_search_ids(probs, beam_size, cutoff_prob, cutoff_top_n, blank, frame_lens=frame_lens,
+                                              nbest=1, ext_scorer=ext_scorer)
+        return tokens[:, 0], n[:, 0], score[:, 0]
+    return run
+
+
+def _pad_batch(feats, lengths, idx, device):
+    """Zero-padded [n, Tmax, F] batch (collate_fn.py:17) + lengths of the listed utterances.  ``feats``: a padded
+    [N, T, F] tensor / array, or a sequence of per-utterance [T_i, F] arrays (only this rank's are touched)."""
+    tmax = max(int(lengths[i]) for i in idx)
+    lens = torch.tensor([int(lengths[i]) for i in idx], dtype=torch.int64)
+    if isinstance(feats, torch.Tensor) and feats.dim() == 3:
+        x = feats[torch.as_tensor(idx, dtype=torch.int64, device=feats.device), :tmax]
+        return x.to(device).contiguous(), lens.to(device)
+    first = torch.as_tensor(feats[idx[0]])
+    x = torch.zeros(len(idx), tmax, first.shape[-1], dtype=torch.float32)
+    for j, i in enumerate(idx):
+        f = torch.as_tensor(feats[i], dtype=torch.float32)
+        n = int(lengths[i])
+        x[j, :n] = f[:n]
+    return x.to(device), lens.to(device)
+
+
+class RaggedPlan:
+    """A variable-length batch prepared for repeated / pipelined decoding on this rank: the plan (``assign_buckets``),
+    this rank's encoder batches resident on the device, and the record geometry of the gather.
+
+    ``run(decoder)`` = encode -> decode -> (gather) of the prepared batch; with ``pipeline=True`` the encoder runs on
+    its own HIP stream and the decoder (+ gather) on a second one, linked by events only, so that consecutive ``run``
+    calls overlap: the beam search of call i (one workgroup per utterance, latency-bound) runs while the encoder of
+    call i+1 has the rest of the chip.  Results of every call are complete once its decode stream is synchronised."""
+
+    def __init__(self, model, feats, lengths, dist=None, group=None, width=200, mode="merged", max_batch_frames=None,
+                 device=None, pipeline=False):
+        self.model = model
+        self.lengths = [int(v) for v in lengths]
+        self.n_total = len(self.lengths)
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group) if dist is not None else 1
+        self.rank = dist.get_rank(group) if dist is not None else 0
+        self.dev = torch.device(device) if device is not None else torch.device(getattr(model, "device", "cpu"))
+        self.ragged = mode == "merged"
+        self.mode = mode
+        plan = assign_buckets(self.lengths, self.world, width)
+        self.rows = max(1, max(sum(len(b.indices) for b in p) for p in plan))
+        self.cols = max(1, int(model.out_frames(max(self.lengths))))
+        # row of every utterance in the gathered record: every rank's batches are known from the lengths alone, so the
+        # caller's order is restored with one precomputed index (no data-dependent step, no host synchronisation)
+        order = [-1] * self.n_total
+        for r in range(self.world):
+            pos = 0
+            for idx in rank_batches(self.lengths, r, self.world, width, mode, max_batch_frames):
+                for i in idx:
+                    if order[i] != -1:
+                        raise RuntimeError("ragged plan: an utterance was dealt to two ranks")
+                    order[i] = r * self.rows + pos
+                    pos += 1
+        if any(o < 0 for o in order):
+            raise RuntimeError("ragged plan: the ranks' batches do not cover the batch")
+        self.order = torch.tensor(order, dtype=torch.int64, device=self.dev)
+        self.batches = []
+        for idx in rank_batches(self.lengths, self.rank, self.world, width, mode, max_batch_frames):
+            x, lens = _pad_batch(feats, self.lengths, idx, self.dev)
+            frame_lens = model.valid_out_frames(lens, x.shape[1])
+            self.batches.append((torch.tensor(idx, dtype=torch.int32, device=self.dev), x, lens, frame_lens))
+        self.cuda = self.dev.type == "cuda"
+        self.pipeline = bool(pipeline) and self.cuda
+        self.enc_stream = torch.cuda.Stream(device=self.dev) if self.pipeline else None
+        self.dec_stream = torch.cuda.Stream(device=self.dev) if self.pipeline else None
+
+    def _record(self, outs):
+        """int32 [rows, cols + 4] record of this rank, assembled on the device with whole-batch copies (no per-row
+        host work): tokens (-1 padded) | n_tokens | score (f64 as two words) | utterance index (-1: unused row)."""
+        cols = self.cols
+        rec = torch.full((self.rows, cols + 4), -1, dtype=torch.int32, device=self.dev)
+        r = 0
+        for (idx, _x, _l, _fl), (tokens, n, score) in zip(self.batches, outs):
+            k = tokens.shape[0]
+            w = min(int(tokens.shape[1]), cols)
+            if int(tokens.shape[1]) > cols and bool((n > cols).any()):
+                raise ValueError(f"a hypothesis is longer than the record's {cols} columns")
+            rec[r:r + k, :w] = tokens[:, :w].to(torch.int32)
+            rec[r:r + k, cols] = n.to(torch.int32)
+            rec[r:r + k, cols + 1:cols + 3] = score.to(torch.float64).contiguous().view(torch.int32).view(k, 2)
+            rec[r:r + k, cols + 3] = idx
+            r += k
+        return rec
+
+    def _unpack(self, out):
+        cols = self.cols
+        g = out[self.order.to(out.device)]
+        score = g[:, cols + 1:cols + 3].contiguous().view(torch.float64).view(-1)
+        return g[:, :cols], g[:, cols], score
+
+    def verify(self, gathered_index_column):
+        """Host-side check (synchronises): the record rows really carry the utterance indices the plan expects."""
+        return bool((gathered_index_column.cpu() == torch.arange(self.n_total, dtype=torch.int32)).all())
+
+    def _encode_decode(self, decoder):
+        model = self.model
+        outs = []
+        if self.ragged and self.batches:
+            model.set_skip_padding(True)
+        try:
+            for (_idx, x, lens, frame_lens) in self.batches:
+                if self.pipeline:
+                    with torch.cuda.stream(self.enc_stream):
+                        probs = model.get_encoder_out(x, lens)
+                        ev = torch.cuda.Event()
+                        ev.record(self.enc_stream)
+                    with torch.cuda.stream(self.dec_stream):
+                        self.dec_stream.wait_event(ev)
+                        probs.record_stream(self.dec_stream)
+                        outs.append(decoder(probs, frame_lens))
+                else:
+                    probs = model.get_encoder_out(x, lens)
+                    outs.append(decoder(probs, frame_lens))
+        finally:
+            if self.ragged and self.batches:
+                model.set_skip_padding(False)
+        return outs
+
+    def run(self, decoder):
+        """-> (tokens [N, L] i32 -1 padded, n_tokens [N] i32, score [N] f64) device tensors in the caller's utterance
+        order, identical on every rank.  With ``pipeline`` the tensors are produced on ``self.dec_stream``: synchronise
+        it (or make your stream wait for it) before reading them."""
+        outs = self._encode_decode(decoder)
+        ctx = torch.cuda.stream(self.dec_stream) if self.pipeline else _null_ctx()
+        with ctx:
+            rec = self._record(outs)
+            if self.dist is None:
+                out = rec
+            else:
+                out = torch.empty(self.world * self.rows, self.cols + 4, dtype=torch.int32, device=rec.device)
+                self.dist.all_gather_into_tensor(out, rec, group=self.group)
+            self.last_index_column = out[self.order.to(out.device), self.cols + 3]
+            return self._unpack(out)
+
+    def sync(self):
+        if self.pipeline:
+            self.dec_stream.synchronize()
+            self.enc_stream.synchronize()
+
+
+class _null_ctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def decode_ragged(model, feats, lengths, decoder, dist=None, group=None, width=200, mode="merged", max_batch_frames=None,
+                  device=None):
+    """Variable-length batch, end to end (BASELINE configs[4]): plan (``assign_buckets``: whole length buckets per rank)
+    -> this rank's encoder batches (``rank_batches``) -> ``model.get_encoder_out`` -> ``decoder(probs, frame_lens)`` ->
+    ONE all-gather of the packed hypotheses.
+
+    model:   a ppasr_amd model (``get_encoder_out``, ``valid_out_frames``, ``out_frames``, ``set_skip_padding``);
+    feats:   padded [N, T, F] tensor / array or a sequence of per-utterance [T_i, F] arrays, caller's order (only this
+             rank's utterances are touched);
+    lengths: [N] input frames of every utterance (every rank knows all of them: the plan needs no collective);
+    decoder: ``greedy_ids_decoder()`` / ``beam_ids_decoder(...)`` or any callable (probs [n,T',V], frame_lens [n] i32)
+             -> (tokens [n,L] i32 -1 padded, n_tokens [n] i32, score [n] f64) device tensors;
+    dist:    an initialised ``torch.distributed`` (or None: one rank);
+    mode:    "merged" (one ragged batch per rank, ``set_skip_padding``) or "buckets" (one padded batch per bucket).
+    -> (tokens [N, L] i32, n_tokens [N] i32, score [N] f64) in the caller's order, identical on every rank, where
+    L = out_frames(longest utterance).  Decoding covers each utterance's VALID output frames only.
+    Repeated or pipelined decoding of prepared batches: ``RaggedPlan``."""
+    plan = RaggedPlan(model, feats, lengths, dist=dist, group=group, width=width, mode=mode,
+                      max_batch_frames=max_batch_frames, device=device)
+    tokens, n, score = plan.run(decoder)
+    if not plan.verify(plan.last_index_column):
+        raise RuntimeError("ragged gather: the ranks' utterance indices do not partition the batch")
+    return tokens, n, score

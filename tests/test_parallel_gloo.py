@@ -207,3 +207,140 @@ def test_evaluate_all_reduce_world2_gloo_equals_single_process():
     for p in procs:
         p.join(timeout=60)
     assert all(abs(v - single) < 1e-12 for _, v in res), (single, res)
+
+
+# ---- decode_ragged: plan -> encode -> decode -> gather, with a CPU model that has the real model interface ----------
+class _CpuRaggedModel:
+    """The interface ``decode_ragged`` drives (get_encoder_out / valid_out_frames / out_frames / set_skip_padding /
+    device) on the CPU: output frame t of an utterance is a one-hot "probability" row whose class is read from the
+    utterance's own feature frame 4t, so a hypothesis depends on the utterance only, not on what it was batched with."""
+    device = torch.device("cpu")
+    V = 50
+
+    def __init__(self):
+        self.calls = []          # (batch size, padded frames, skip_padding) of every encode
+        self.skip = False
+
+    def out_frames(self, T):
+        return ((int(T) - 1) // 2 - 1) // 2
+
+    def valid_out_frames(self, lens, T):
+        # (the real models count frame t valid iff 4t < len, capped by the BATCH's output frames; the stub uses the
+        #  utterance's own output frames so that the expected hypothesis does not depend on the batch it lands in)
+        lens = torch.as_tensor(lens, dtype=torch.int64)
+        return torch.clamp(((lens - 1) // 2 - 1) // 2, min=0, max=self.out_frames(T)).to(torch.int32)
+
+    def set_skip_padding(self, enable=True):
+        self.skip = bool(enable)
+
+    def get_encoder_out(self, x, lens):
+        B, T, _ = x.shape
+        Tp = self.out_frames(T)
+        self.calls.append((B, T, self.skip))
+        cls = (x[:, 0:4 * Tp:4, 0].round().to(torch.int64) % self.V)
+        return torch.nn.functional.one_hot(cls, self.V).to(torch.float32)
+
+
+def _cpu_greedy(probs, frame_lens):
+    B, Tp, _ = probs.shape
+    ids = probs.argmax(-1)
+    tokens = torch.full((B, Tp), -1, dtype=torch.int32)
+    n = torch.zeros(B, dtype=torch.int32)
+    score = torch.zeros(B, dtype=torch.float64)
+    for b in range(B):
+        row = ids[b, :int(frame_lens[b])].tolist()
+        out = [c for j, c in enumerate(row) if c != 0 and (j == 0 or c != row[j - 1])]
+        tokens[b, :len(out)] = torch.tensor(out, dtype=torch.int32)
+        n[b] = len(out)
+        score[b] = float(len(row))
+    return tokens, n, score
+
+
+def _ragged_feats(lens, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randint(0, 50, (int(l), 3), generator=g).to(torch.float32) for l in lens]
+
+
+def _decode_ragged_worker(rank, world, port, lens, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ppasr_amd.parallel import decode_ragged
+    model = _CpuRaggedModel()
+    feats = _ragged_feats(lens)
+    tokens, n, score = decode_ragged(model, feats, lens, _cpu_greedy, dist=dist, mode=mode)
+    single = _CpuRaggedModel()
+    ok = True
+    for i, ln in enumerate(lens):       # expected: the utterance decoded on its own
+        p = single.get_encoder_out(feats[i][None], [ln])
+        et, en, es = _cpu_greedy(p, single.valid_out_frames([ln], ln))
+        ok &= int(n[i]) == int(en[0]) and bool((tokens[i, :int(en[0])] == et[0, :int(en[0])]).all())
+        ok &= bool((tokens[i, int(en[0]):] == -1).all()) and float(score[i]) == float(es[0])
+    q.put((rank, ok, model.calls))
+    dist.destroy_process_group()
+
+
+def test_decode_ragged_world2_gloo_both_modes():
+    from ppasr_amd.parallel import assign_buckets
+    world = 2
+    lens = [int(v) for v in _cfg5_lengths(16, 20741)]
+    ctx = mp.get_context("spawn")
+    for k, mode in enumerate(("merged", "buckets")):
+        q = ctx.Queue()
+        port = 35500 + os.getpid() % 2000 + k
+        procs = [ctx.Process(target=_decode_ragged_worker, args=(r, world, port, lens, mode, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+        assert all(ok for _, ok, _ in res), (mode, res)
+        plan = assign_buckets(lens, world)
+        for rank, _, calls in res:
+            if mode == "merged":    # ONE ragged batch per rank, padded to the rank's longest utterance, skip_padding on
+                assert len(calls) == 1 and calls[0][2] is True
+                assert calls[0][0] == sum(len(b.indices) for b in plan[rank])
+                assert calls[0][1] == max(b.frames for b in plan[rank])
+            else:                   # one batch per bucket, every padded row computed
+                assert sorted((c[0], c[1]) for c in calls) == sorted((len(b.indices), b.frames) for b in plan[rank])
+                assert not any(c[2] for c in calls)
+
+
+def test_decode_ragged_single_process_and_rank_without_bucket():
+    """No process group: the whole batch on one rank; and a plan that leaves a rank empty still gathers (the empty rank
+    contributes a record of -1 rows on the collective's device)."""
+    from ppasr_amd.parallel import decode_ragged, rank_batches
+    lens = [250, 260, 900]
+    model = _CpuRaggedModel()
+    feats = _ragged_feats(lens, 5)
+    tokens, n, score = decode_ragged(model, feats, lens, _cpu_greedy)
+    assert tokens.shape == (3, model.out_frames(900)) and int((n > 0).sum()) == 3
+    assert rank_batches(lens, 3, 4) == [] and rank_batches(lens, 2, 4) == []
+    assert rank_batches(lens, 0, 1, max_batch_frames=1000) == [[2], [1, 0]]
+
+
+def test_evaluate_bucket_sharding_equals_plain_evaluate():
+    import ppasr_amd.evaluate as ev
+    vocab = ["<blank>"] + [chr(0x4E00 + i) for i in range(49)] + ["<eos>"]   # ids 0..49 are the model's classes
+    lens = [250, 260, 900, 1300, 420]
+    feats = _ragged_feats(lens, 9)
+    T = max(lens)
+    x = torch.zeros(len(lens), T, 3)
+    for i, f in enumerate(feats):
+        x[i, :lens[i]] = f
+    model = _CpuRaggedModel()
+    labels = np.full((len(lens), 400), -1, np.int64)
+    for i, ln in enumerate(lens):
+        et, en, _ = _cpu_greedy(model.get_encoder_out(feats[i][None], [ln]), model.valid_out_frames([ln], ln))
+        ids = et[0, :int(en[0])].numpy()
+        labels[i, :len(ids)] = ids
+        if i == 1:
+            labels[i, 0] = 1 + (labels[i, 0] % 40)   # one substitution
+    import ppasr_amd.parallel as par
+    old = par.greedy_ids_decoder
+    par.greedy_ids_decoder = lambda blank=0: _cpu_greedy
+    try:
+        val = ev.evaluate(model, [(x, labels, np.array(lens), None)], vocab, shard="buckets")
+    finally:
+        par.greedy_ids_decoder = old
+    assert 0.0 < val < 0.02

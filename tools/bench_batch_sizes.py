@@ -27,7 +27,7 @@ def models():
         encoder_dim=256, output_size=256, attention_heads=4, num_blocks=L, reduce_idx=5, recover_idx=11,
         feed_forward_expansion_factor=8, cnn_module_kernel=31), state_dict=squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=1))
     yield "efficient_conformer", EfficientConformerModel(80, V, streaming=True, encoder_conf=dict(
-        output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15,
+        output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15, cnn_module_norm="layer_norm",
         efficient_conf=dict(stride_layer_idx=[3], stride=[2], group_layer_idx=[0, 1, 2, 3], group_size=3)),
         state_dict=efficient_conformer_state_dict(vocab_size=V, seed=1))
 

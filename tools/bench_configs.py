@@ -39,7 +39,7 @@ def cfg1():
 def cfg4():
     from ppasr_amd.model_utils.efficient_conformer.model import EfficientConformerModel
     sd = efficient_conformer_state_dict(vocab_size=V, seed=1234)
-    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12, cnn_module_kernel=15,
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12, cnn_module_kernel=15, cnn_module_norm="layer_norm",
                 efficient_conf=dict(stride_layer_idx=[3], stride=[2], group_layer_idx=[0, 1, 2, 3], group_size=3))
     m = EfficientConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd)
     x, lens = synth_features(64, 1000, seed=20640)
