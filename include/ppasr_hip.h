@@ -166,18 +166,21 @@ ppasr_status ppasr_ctc_beam_search(const float* probs, const int32_t* frame_lens
                                    int init_state, void* stream);
 
 /* External scorer = `Scorer(alpha, beta, model_path, vocabulary)` of paddlespeech_ctcdecoders (decoders/swig_wrapper.py:18-33,
- * built by BeamSearchDecoder.__init__, decoders/beam_search_decoder.py:19-29): back-off n-gram model, CHARACTER-based
- * (every LM word is one UTF-8 character, as PPASR's Mandarin models are); word-based models, which need the OpenFST
- * dictionary, are refused with PPASR_EUNSUPPORTED.  Model files: the ARPA text format (csrc/lm.hip) and KenLM binaries
- * (.klm, what PPASR ships: decoders/beam_search_decoder.py:19-29) of the "probing" / "rest probing" and plain "trie"
- * types (csrc/klm.hip; quantised / Bhiksha-array tries: PPASR_EUNSUPPORTED).  ppasr_lm_create sniffs the format from
- * the file's magic, like KenLM's loader.
+ * built by BeamSearchDecoder.__init__, decoders/beam_search_decoder.py:19-29): back-off n-gram model, either
+ * CHARACTER-based (every LM word is one UTF-8 character, as PPASR's Mandarin models are: scored on every extension) or
+ * WORD-based (configs/english_example.yml: scored when a space completes a word, the prefixes constrained to spellings
+ * of the model's vocabulary by a dictionary -- upstream's OpenFST acceptor, here a character trie; the acoustic vocabulary
+ * must contain the space token " " or "<space>").  Model files: the ARPA text format (csrc/lm.hip) and KenLM binaries
+ * (.klm, what PPASR ships: decoders/beam_search_decoder.py:19-29) of every model type: "probing" / "rest probing",
+ * "trie", and the quantised (-q) / Bhiksha-array (-a) trie variants (csrc/klm.hip).  ppasr_lm_create sniffs the format
+ * from the file's magic, like KenLM's loader.
  * vocab_utf8[V]: the acoustic vocabulary (token id -> string), used to map token ids to LM words (unknown -> OOV). */
 typedef struct ppasr_lm_s* ppasr_lm_handle;
 ppasr_status ppasr_lm_create(const char* model_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
 ppasr_status ppasr_lm_create_arpa(const char* arpa_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
 ppasr_status ppasr_lm_create_klm(const char* klm_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
-const char*  ppasr_lm_format(ppasr_lm_handle lm);              /* "arpa", "klm-probing", "klm-rest-probing", "klm-trie" */
+const char*  ppasr_lm_format(ppasr_lm_handle lm);              /* "arpa", "klm-probing", "klm-rest-probing", "klm-trie",
+                                                                  "klm-quant-trie", "klm-array-trie", "klm-quant-array-trie" */
 int          ppasr_lm_word_index(ppasr_lm_handle lm, int token); /* LM word index of an acoustic token, 0 = OOV */
 int          ppasr_lm_bos(ppasr_lm_handle lm);
 int          ppasr_lm_eos(ppasr_lm_handle lm);
@@ -189,6 +192,8 @@ double       ppasr_lm_debug_host_score(ppasr_lm_handle lm, const int32_t* window
 ppasr_status ppasr_lm_destroy(ppasr_lm_handle lm);
 int          ppasr_lm_order(ppasr_lm_handle lm);
 int          ppasr_lm_is_character_based(ppasr_lm_handle lm);
+long long    ppasr_lm_dict_size(ppasr_lm_handle lm);   /* Scorer::get_dict_size(): words in the dictionary (word-based models) */
+int          ppasr_lm_space_id(ppasr_lm_handle lm);    /* acoustic token id of the space (" " or "<space>"), -1 if none */
 long long    ppasr_lm_ngram_count(ppasr_lm_handle lm);
 /* ppasr_ctc_beam_search with the scorer: alpha * ln P_lm(c | prefix) + beta on every extension, the min_cutoff pruning
  * of ctc_beam_search_decoder.cpp, and result scores = -(score - len*beta - alpha*ln P_lm(sentence)) ("approx_ctc").

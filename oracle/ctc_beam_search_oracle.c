@@ -28,6 +28,7 @@ typedef struct PathTrie {
   float log_prob_b_prev, log_prob_nb_prev, log_prob_b_cur, log_prob_nb_cur, score;
   int character;
   int exists;
+  int dict_state; /* word-based scorer: state of the dictionary acceptor this prefix has reached (path_trie.h dictionary_state_) */
   struct PathTrie* parent;
   struct PathTrie** children;
   int n_children, cap_children;
@@ -55,8 +56,21 @@ static float log_sum_exp(float x, float y) {
   return logf(expf(x - m) + expf(y - m)) + m;
 }
 
-/* PathTrie::get_path_trie(new_char, reset=true) without a dictionary */
-static PathTrie* get_path_trie(PathTrie* t, int c) {
+/* the dictionary of a word-based scorer: upstream an OpenFST acceptor of every vocabulary word spelt in characters + the
+ * space (Scorer::fill_dictionary), here handed in by the tests as a character trie in CSR form (node 0 = start; a node is
+ * final iff a word ends there, word[node] = its LM word index) */
+typedef struct {
+  int n_nodes;
+  const int *first, *arc_char, *arc_next, *word;
+} Dict;
+static int dict_arc(const Dict* d, int s, int c) {
+  for (int a = d->first[s]; a < d->first[s + 1]; ++a)
+    if (d->arc_char[a] == c) return d->arc_next[a];
+  return -1;
+}
+
+/* PathTrie::get_path_trie(new_char, reset=true); dict == NULL: no dictionary */
+static PathTrie* get_path_trie(PathTrie* t, int c, const Dict* dict) {
   for (int i = 0; i < t->n_children; ++i) {
     PathTrie* ch = t->children[i];
     if (ch->character == c) {
@@ -67,11 +81,22 @@ static PathTrie* get_path_trie(PathTrie* t, int c) {
       return ch;
     }
   }
+  int to = 0;
+  if (dict) {
+    /* matcher_->Find(new_char + 1) from dictionary_state_: not found -> no child; and if the state is final (a word has
+     * just ended) the state is reset to the start state as a side effect (path_trie.cpp, `if (is_final && reset)`) */
+    to = dict_arc(dict, t->dict_state, c);
+    if (to < 0) {
+      if (dict->word[t->dict_state] != 0) t->dict_state = 0;
+      return NULL;
+    }
+  }
   if (t->n_children == t->cap_children) {
     t->cap_children = t->cap_children ? 2 * t->cap_children : 4;
     t->children = (PathTrie**)realloc(t->children, sizeof(PathTrie*) * t->cap_children);
   }
   PathTrie* n = trie_new(c, t);
+  n->dict_state = to;
   t->children[t->n_children++] = n;
   return n;
 }
@@ -195,6 +220,8 @@ typedef struct {
   NGram* grams; /* sorted by (n, words) */
   int* tok2lm;  /* [V], 0 = OOV */
   double alpha, beta;
+  int word_based, space_id; /* scorer.cpp is_character_based_ == false: scored at spaces, dictionary-constrained */
+  Dict dict;
 } Lm;
 static const NGram* lm_find(const Lm* lm, const int* w, int n) {
   NGram key;
@@ -227,6 +254,34 @@ static void make_ngram(const Lm* lm, const PathTrie* node, int* win) {
     } else {
       win[j] = lm->bos;
     }
+  }
+}
+
+/* LM word index of the characters chars[0..n-1] (a word of the hypothesis): spelt through the dictionary; 0 = OOV */
+static int word_index_of(const Lm* lm, const int* chars, int n) {
+  int s = 0;
+  for (int i = 0; i < n && s >= 0; ++i) s = dict_arc(&lm->dict, s, chars[i]);
+  if (s >= 0) s = dict_arc(&lm->dict, s, lm->space_id);
+  return s >= 0 ? lm->dict.word[s] : 0;
+}
+/* Scorer::make_ngram for a word-based model: the last `order` WORDS of the prefix (split at the space token), <s>-padded */
+static void make_ngram_words(const Lm* lm, const PathTrie* node, int* win) {
+  int j = lm->order - 1;
+  const PathTrie* cur = node;
+  for (; j >= 0; --j) {
+    int chars[4096], n = 0;
+    const PathTrie* p = cur;
+    while (p->parent && p->character != lm->space_id) { /* get_path_vec(stop = SPACE_ID_) */
+      if (n < 4096) chars[n++] = p->character;
+      p = p->parent;
+    }
+    for (int a = 0, b = n - 1; a < b; ++a, --b) { int t = chars[a]; chars[a] = chars[b]; chars[b] = t; }
+    win[j] = word_index_of(lm, chars, n);
+    if (!p->parent) { /* reached the root: pad with <s> */
+      for (int q = j - 1; q >= 0; --q) win[q] = lm->bos;
+      break;
+    }
+    cur = p->parent; /* skipping the space */
   }
 }
 
@@ -281,6 +336,19 @@ void ctc_beam_oracle_set_lm(void* h, int order, int n_grams, const int* gram_n, 
   d->lm = lm;
 }
 
+/* make the attached scorer word-based: the space token and the dictionary (arrays owned by the caller, must outlive h) */
+void ctc_beam_oracle_set_dictionary(void* h, int space_id, int n_nodes, const int* first, const int* arc_char,
+                                    const int* arc_next, const int* word) {
+  Decoder* d = (Decoder*)h;
+  d->lm->word_based = 1;
+  d->lm->space_id = space_id;
+  d->lm->dict.n_nodes = n_nodes;
+  d->lm->dict.first = first;
+  d->lm->dict.arc_char = arc_char;
+  d->lm->dict.arc_next = arc_next;
+  d->lm->dict.word = word;
+}
+
 void ctc_beam_oracle_free(void* h) {
   Decoder* d = (Decoder*)h;
   if (d->lm) {
@@ -323,15 +391,19 @@ void ctc_beam_oracle_next(void* h, const float* probs, int T) {
         }
         if (c == prefix->character)
           prefix->log_prob_nb_cur = log_sum_exp(prefix->log_prob_nb_cur, log_prob_c + prefix->log_prob_nb_prev);
-        PathTrie* pn = get_path_trie(prefix, c);
+        PathTrie* pn = get_path_trie(prefix, c, (d->lm && d->lm->word_based) ? &d->lm->dict : NULL);
+        if (!pn) continue; /* the dictionary has no such spelling */
         float log_p = -NUM_FLT_INF;
         if (c == prefix->character && prefix->log_prob_b_prev > -NUM_FLT_INF)
           log_p = log_prob_c + prefix->log_prob_b_prev;
         else if (c != prefix->character)
           log_p = log_prob_c + prefix->score;
-        if (d->lm) { /* character-based scorer: every extension is scored on the NEW prefix */
+        if (d->lm && (!d->lm->word_based || c == d->lm->space_id)) {
+          /* character-based scorer: every extension is scored on the NEW prefix; word-based: a space scores the word it
+           * completes, i.e. the OLD prefix (`prefix_to_score = prefix`) */
           int win[LM_MAX_ORDER];
-          make_ngram(d->lm, pn, win);
+          if (d->lm->word_based) make_ngram_words(d->lm, prefix, win);
+          else make_ngram(d->lm, pn, win);
           float score = (float)(lm_log_cond_prob(d->lm, win) * d->lm->alpha);
           log_p += score;
           log_p = (float)((double)log_p + d->lm->beta);
@@ -357,6 +429,20 @@ int ctc_beam_oracle_result(void* h, int nbest, int max_len, int* tokens, int* le
   int n = d->prefixes.n < d->beam_size ? d->prefixes.n : d->beam_size;
   PathTrie** s = (PathTrie**)malloc(sizeof(PathTrie*) * (n ? n : 1));
   memcpy(s, d->prefixes.v, sizeof(PathTrie*) * n);
+  /* word-based scorer: "score the last word of each prefix that doesn't end with space" -- added to the score the result
+   * is ranked by.  (Upstream adds it to prefix->score in place; here the addition is undone after the ranking so that a
+   * streaming caller may ask for the current result after every chunk.) */
+  float* saved = (float*)malloc(sizeof(float) * (n ? n : 1));
+  for (int i = 0; i < n; ++i) {
+    saved[i] = s[i]->score;
+    if (d->lm && d->lm->word_based && s[i]->parent && s[i]->character != d->lm->space_id) {
+      int win[LM_MAX_ORDER];
+      make_ngram_words(d->lm, s[i], win);
+      float score = (float)(lm_log_cond_prob(d->lm, win) * d->lm->alpha);
+      score = (float)((double)score + d->lm->beta);
+      s[i]->score += score;
+    }
+  }
   qsort(s, n, sizeof(PathTrie*), cmp_prefix);
   int out = n < nbest ? n : nbest;
   for (int i = 0; i < out; ++i) {
@@ -373,26 +459,45 @@ int ctc_beam_oracle_result(void* h, int nbest, int max_len, int* tokens, int* le
     double approx_ctc = (double)s[i]->score;
     if (d->lm) {
       /* approx_ctc -= prefix_length * beta + alpha * get_sent_log_prob(words); sentence = <s>^(order-1) words </s>,
-       * one window per position (scorer.cpp get_sent_log_prob / get_log_prob) */
+       * one window per position (scorer.cpp get_sent_log_prob / get_log_prob); words = characters (character-based) or
+       * the pieces between spaces (word-based, split_labels) */
       const Lm* lm = d->lm;
-      int total = lm->order - 1 + len + 1;
-      if (len == 0) total = lm->order + 1;
+      int* chars = (int*)malloc(sizeof(int) * (len ? len : 1));
+      {
+        int jj = len;
+        for (PathTrie* p = s[i]; p->parent; p = p->parent) chars[--jj] = p->character;
+      }
+      int* words = (int*)malloc(sizeof(int) * (len + 1));
+      int n_words = 0;
+      if (lm->word_based) {
+        int start = 0;
+        for (int q = 0; q <= len; ++q) {
+          if (q == len || chars[q] == lm->space_id) {
+            if (q > start) words[n_words++] = word_index_of(lm, chars + start, q - start);
+            start = q + 1;
+          }
+        }
+      } else {
+        for (int q = 0; q < len; ++q) words[n_words++] = lm->tok2lm[chars[q]];
+      }
+      int total = lm->order - 1 + n_words + 1;
+      if (n_words == 0) total = lm->order + 1;
       int* sent = (int*)malloc(sizeof(int) * total);
       int pos = 0;
-      for (int q = 0; q < (len == 0 ? lm->order : lm->order - 1); ++q) sent[pos++] = lm->bos;
-      {
-        int jj = pos + len;
-        for (PathTrie* p = s[i]; p->parent; p = p->parent) sent[--jj] = lm->tok2lm[p->character];
-        pos += len;
-      }
+      for (int q = 0; q < (n_words == 0 ? lm->order : lm->order - 1); ++q) sent[pos++] = lm->bos;
+      for (int q = 0; q < n_words; ++q) sent[pos++] = words[q];
       sent[pos++] = lm->eos;
       double lp = 0.0;
       for (int q = 0; q + lm->order <= total; ++q) lp += lm_log_cond_prob(lm, sent + q);
       free(sent);
+      free(words);
+      free(chars);
       approx_ctc = approx_ctc - (double)len * lm->beta - lp * lm->alpha;
     }
     scores[i] = -approx_ctc;
   }
+  for (int i = 0; i < n; ++i) d->prefixes.v[i]->score = saved[i]; /* (saved[] is in the prefixes' own order) */
+  free(saved);
   free(s);
   return out;
 }

@@ -101,6 +101,8 @@ SYMBOLS = [
     ("ppasr_lm_destroy", ctypes.c_int, [_vp]),
     ("ppasr_lm_order", ctypes.c_int, [_vp]),
     ("ppasr_lm_is_character_based", ctypes.c_int, [_vp]),
+    ("ppasr_lm_dict_size", ctypes.c_longlong, [_vp]),
+    ("ppasr_lm_space_id", ctypes.c_int, [_vp]),
     ("ppasr_lm_ngram_count", ctypes.c_longlong, [_vp]),
     ("ppasr_ctc_beam_search_lm", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

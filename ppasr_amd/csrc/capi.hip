@@ -652,19 +652,29 @@ static ppasr_status beam_config(int V, int beam_size, double cutoff_prob, int cu
   return PPASR_OK;
 }
 
-// state buffer = B x [header | beam arrays | arena of 1 + (F+1)*beam nodes] | B status words | scratch of the pruning
-// pre-pass (B x F frame records of the largest record size), F = max_frames.  The layout is recomputed from
+// state buffer = B x [header | beam arrays | arena of 1 + (F+1)*beam nodes | node table] | B status words | scratch of the
+// pruning pre-pass (B x F frame records of the largest record size), F = max_frames.  The layout is recomputed from
 // (state_bytes, B, beam_size) on every call, so it is the same for every chunk of a streaming decode.
 extern "C" int ppasr_ctc_beam_candidate_cap(void) { return kMaxBeamCand; }
 
-static size_t beam_utt_fixed_bytes(int beam_size) {
-  return 4 + 4 * (2 + (size_t)kBeamStateArrays * beam_size) + 8 * (size_t)(1 + beam_size);
+// bytes of one utterance's share of the state buffer for a capacity of F frames: state block (ctc_beam.h: header, beam
+// arrays, arena and node table for max_nodes = 1 + (F + 1) * beam nodes) + its status word + F pruning records
+static size_t beam_max_nodes(size_t F, int beam_size) { return 1 + (F + 1) * (size_t)beam_size; }
+static size_t beam_utt_bytes(size_t F, int beam_size) {
+  return 4 * beam_state_words(beam_size, (int)beam_max_nodes(F, beam_size)) + 4 + F * 4 * (size_t)prune_rec_words(kMaxBeamCand);
 }
-static size_t beam_frame_bytes(int beam_size) { return 8 * (size_t)beam_size + 4 * (size_t)prune_rec_words(kMaxBeamCand); }
+// frame capacity a state buffer of `per_utt_bytes` per utterance was sized for (0: too small for one frame)
+static size_t beam_frame_capacity(size_t per_utt_bytes, int beam_size) {
+  if (per_utt_bytes < beam_utt_bytes(1, beam_size)) return 0;
+  const size_t per_frame = beam_utt_bytes(2, beam_size) - beam_utt_bytes(1, beam_size);
+  size_t F = 1 + (per_utt_bytes - beam_utt_bytes(1, beam_size)) / per_frame;
+  while (F > 1 && beam_utt_bytes(F, beam_size) > per_utt_bytes) --F;  // (the fixed part is padded to an even word)
+  return F;
+}
 
 size_t ppasr_ctc_beam_state_bytes(int B, int max_frames, int beam_size) {
   if (B <= 0 || max_frames < 0 || beam_size < 1) return 0;
-  return (size_t)B * (beam_utt_fixed_bytes(beam_size) + (size_t)max_frames * beam_frame_bytes(beam_size));
+  return (size_t)B * beam_utt_bytes((size_t)(max_frames < 1 ? 1 : max_frames), beam_size);
 }
 
 const ppasr::LmDev* ppasr_lm_device_view(ppasr_lm_handle lm);  // lm.hip
@@ -691,18 +701,26 @@ ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_l
   }
   ppasr_status s = beam_config(V, beam_size, cutoff_prob, cutoff_top_n, blank, nbest, max_tokens, &c);
   if (s != PPASR_OK) return s;
+  {
+    const char* e = getenv("PPASR_BEAM_NODE_TABLE");
+    c.node_table = e ? (atoi(e) != 0) : (lm && c.lm.word_based);
+  }
   const size_t per_utt_bytes = state_bytes / (size_t)B;
-  if (per_utt_bytes < beam_utt_fixed_bytes(beam_size) + beam_frame_bytes(beam_size))
-    return fail(PPASR_ENOSPACE, "beam search: state buffer too small");
-  const size_t F = (per_utt_bytes - beam_utt_fixed_bytes(beam_size)) / beam_frame_bytes(beam_size);  // frame capacity
+  const size_t F = beam_frame_capacity(per_utt_bytes, beam_size);
+  if (F == 0) return fail(PPASR_ENOSPACE, "beam search: state buffer too small");
   if ((size_t)T > F) return fail(PPASR_ENOSPACE, "beam search: more frames in one call than the state buffer was sized for");
-  const size_t fixed = 2 + (size_t)kBeamStateArrays * beam_size;
-  c.max_nodes = (int)(1 + (F + 1) * (size_t)beam_size);
+  c.max_nodes = (int)beam_max_nodes(F, beam_size);
+  const size_t block_words = beam_state_words(beam_size, c.max_nodes);
   int32_t* st_words = static_cast<int32_t*>(state);
-  int32_t* status = st_words + (size_t)B * (fixed + 2 * (size_t)c.max_nodes);
+  int32_t* status = st_words + (size_t)B * block_words;
   int32_t* prune_recs = status + B;
   hipStream_t hs = static_cast<hipStream_t>(stream);
-  if (init_state) HIP_TRY(hipMemsetAsync(status, 0, (size_t)B * 4, hs));
+  if (init_state) {
+    HIP_TRY(hipMemsetAsync(status, 0, (size_t)B * 4, hs));
+    // empty node tables (the kernel enters every prefix it creates)
+    const size_t tab_off = (beam_fixed_words(beam_size) + beam_arena_words(c.max_nodes)) * 4, tab_bytes = 12 * beam_table_slots(c.max_nodes);
+    HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(state) + tab_off, block_words * 4, 0, tab_bytes, (size_t)B, hs));
+  }
   HIP_TRY(launch_ctc_beam(probs, frame_lens, B, T, c, prune_recs, st_words, init_state, 1, tokens, lens, scores, status, hs));
   return PPASR_OK;
 }
@@ -713,21 +731,21 @@ ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_l
 ppasr_status ppasr_ctc_beam_state_grow(const void* old_state, size_t old_bytes, void* new_state, size_t new_bytes, int B,
                                        int beam_size, void* stream) {
   if (!old_state || !new_state || B <= 0 || beam_size < 1) return fail(PPASR_EINVAL, "null argument");
-  auto geometry = [&](size_t bytes, size_t* block_words) -> bool {
-    const size_t per_utt = bytes / (size_t)B;
-    if (per_utt < beam_utt_fixed_bytes(beam_size) + beam_frame_bytes(beam_size)) return false;
-    const size_t F = (per_utt - beam_utt_fixed_bytes(beam_size)) / beam_frame_bytes(beam_size);
-    *block_words = 2 + (size_t)kBeamStateArrays * beam_size + 2 * (1 + (F + 1) * (size_t)beam_size);
-    return true;
-  };
-  size_t ow = 0, nw = 0;
-  if (!geometry(old_bytes, &ow) || !geometry(new_bytes, &nw)) return fail(PPASR_ENOSPACE, "beam search: state buffer too small");
-  if (nw < ow) return fail(PPASR_EINVAL, "beam search: the new state buffer is smaller than the old one");
+  const size_t Fo = beam_frame_capacity(old_bytes / (size_t)B, beam_size), Fn = beam_frame_capacity(new_bytes / (size_t)B, beam_size);
+  if (Fo == 0 || Fn == 0) return fail(PPASR_ENOSPACE, "beam search: state buffer too small");
+  if (Fn < Fo) return fail(PPASR_EINVAL, "beam search: the new state buffer is smaller than the old one");
+  const int mo = (int)beam_max_nodes(Fo, beam_size), mn = (int)beam_max_nodes(Fn, beam_size);
+  const size_t ow = beam_state_words(beam_size, mo), nw = beam_state_words(beam_size, mn);
+  const size_t head_words = beam_fixed_words(beam_size) + beam_arena_words(mo);  // header, beam arrays, arena: same offsets in both
   hipStream_t hs = static_cast<hipStream_t>(stream);
   const int32_t* o = static_cast<const int32_t*>(old_state);
   int32_t* n = static_cast<int32_t*>(new_state);
-  HIP_TRY(hipMemcpy2DAsync(n, nw * 4, o, ow * 4, ow * 4, (size_t)B, hipMemcpyDeviceToDevice, hs));
+  HIP_TRY(hipMemcpy2DAsync(n, nw * 4, o, ow * 4, head_words * 4, (size_t)B, hipMemcpyDeviceToDevice, hs));
   HIP_TRY(hipMemcpyAsync(n + (size_t)B * nw, o + (size_t)B * ow, (size_t)B * 4, hipMemcpyDeviceToDevice, hs));  // status
+  // the node table is rebuilt for the new size from the arena (every node but the root is an entry)
+  const size_t tab_off = (beam_fixed_words(beam_size) + beam_arena_words(mn)) * 4, tab_bytes = 12 * beam_table_slots(mn);
+  HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(new_state) + tab_off, nw * 4, 0, tab_bytes, (size_t)B, hs));
+  HIP_TRY(launch_beam_rehash(n, B, beam_size, mn, hs));
   return PPASR_OK;
 }
 
@@ -737,13 +755,9 @@ ppasr_status ppasr_ctc_beam_state_grow(const void* old_state, size_t old_bytes, 
 ppasr_status ppasr_ctc_beam_status(const void* state, size_t state_bytes, int B, int beam_size, int32_t* status_host,
                                    void* stream) {
   if (!state || B <= 0 || beam_size < 1) return fail(PPASR_EINVAL, "null argument");
-  const size_t per_utt_bytes = state_bytes / (size_t)B;
-  if (per_utt_bytes < beam_utt_fixed_bytes(beam_size) + beam_frame_bytes(beam_size))
-    return fail(PPASR_ENOSPACE, "beam search: state buffer too small");
-  const size_t F = (per_utt_bytes - beam_utt_fixed_bytes(beam_size)) / beam_frame_bytes(beam_size);
-  const size_t fixed = 2 + (size_t)kBeamStateArrays * beam_size;
-  const size_t max_nodes = 1 + (F + 1) * (size_t)beam_size;
-  const int32_t* status = static_cast<const int32_t*>(state) + (size_t)B * (fixed + 2 * max_nodes);
+  const size_t F = beam_frame_capacity(state_bytes / (size_t)B, beam_size);
+  if (F == 0) return fail(PPASR_ENOSPACE, "beam search: state buffer too small");
+  const int32_t* status = static_cast<const int32_t*>(state) + (size_t)B * beam_state_words(beam_size, (int)beam_max_nodes(F, beam_size));
   std::vector<int32_t> host(B);
   hipStream_t hs = static_cast<hipStream_t>(stream);
   HIP_TRY(hipMemcpyAsync(host.data(), status, (size_t)B * 4, hipMemcpyDeviceToHost, hs));

@@ -70,6 +70,7 @@ struct Beam {  // one double-buffer half, all in LDS
   float* nb;
   float* score;
   int* ctx;  // [cap][kLmCtx] last LM word ids, most recent last, <s>-padded
+  int* dst;  // dictionary state (word-based LM: node of lm.h's character trie the prefix's current word has reached)
 };
 
 __device__ __forceinline__ Beam carve_beam(char*& p, int cap) {
@@ -81,6 +82,7 @@ __device__ __forceinline__ Beam carve_beam(char*& p, int cap) {
   b.nb = reinterpret_cast<float*>(p); p += cap * 4;
   b.score = reinterpret_cast<float*>(p); p += cap * 4;
   b.ctx = reinterpret_cast<int*>(p); p += cap * 4 * kLmCtx;
+  b.dst = reinterpret_cast<int*>(p); p += cap * 4;
   return b;
 }
 
@@ -229,20 +231,15 @@ size_t beam_lds_bytes(const BeamConfig& c) {
   size_t n = 8 * 256 * 4 + 3 * (kBT / 64) * 4 + 32;  // per-pass histograms, scan / reduction scratch, scalars
   n += (size_t)Vp * 4;                             // lp
   n += (size_t)kMaxBeamCand * 8;                   // cand_c, cand_lp
-  n += (size_t)2 * c.beam * (24 + 4 * kLmCtx);     // two beam halves
-  n += (size_t)c.beam * 12;                        // new_b, new_nb, new_score
+  n += (size_t)2 * c.beam * (28 + 4 * kLmCtx);     // two beam halves
+  n += (size_t)c.beam * 20;                        // new_b, new_nb, new_score, new_dst, k_reset
   n += (size_t)Vp * 2;                             // kidx (int16)
   n += (((size_t)c.beam * c.n_cand_max) + 3) & ~(size_t)3;  // exists flags
   n += (size_t)c.beam * (1 + c.n_cand_max) * 4;    // score keys
   return (n + 15) & ~(size_t)15;
 }
 
-// state layout per utterance in HBM (int32 words):
-//   [0] n_beam  [1] n_nodes  then kBeamStateArrays arrays of `beam` words (node, chr, par, b, nb, score, ctx[5]), then the
-//   arena (2 words per node: parent, char).
-__host__ __device__ inline size_t beam_state_words(int beam, int max_nodes) {
-  return 2 + (size_t)kBeamStateArrays * beam + (size_t)2 * max_nodes;
-}
+// (state layout per utterance: ctc_beam.h)
 size_t beam_state_bytes(const BeamConfig& c) { return beam_state_words(c.beam, c.max_nodes) * 4; }
 
 constexpr int kPruneThreads = 256;
@@ -431,7 +428,7 @@ __global__ __launch_bounds__(NT) void k_ctc_prune(const float* __restrict__ prob
   }
 }
 
-template <int BT>
+template <int BT, bool WORD_LM>
 __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs, const int32_t* __restrict__ frame_lens,
                                                   int T, BeamConfig cfg, const int32_t* __restrict__ recs,
                                                   int32_t* __restrict__ state, int init_state,
@@ -456,14 +453,21 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
   float* new_b = reinterpret_cast<float*>(p); p += beam * 4;
   float* new_nb = reinterpret_cast<float*>(p); p += beam * 4;
   float* new_score = reinterpret_cast<float*>(p); p += beam * 4;
+  int* new_dst = reinterpret_cast<int*>(p); p += beam * 4;    // word-based LM: dictionary state of a surviving hypothesis
+  int* k_reset = reinterpret_cast<int*>(p); p += beam * 4;    // ... candidate whose lookup reset the state (no child), or -1
   int16_t* kidx = reinterpret_cast<int16_t*>(p); p += (size_t)Vp * 2;
   const bool has_lm = cfg.lm.order > 0;
+  constexpr bool word_lm = WORD_LM;  // scorer consulted at spaces, prefixes constrained by the dictionary (lm.word_based)
+  const int space_id = cfg.lm.space_id;
   uint8_t* exists = reinterpret_cast<uint8_t*>(p); p += (((size_t)beam * CM) + 3) & ~(size_t)3;
   uint32_t* skey = reinterpret_cast<uint32_t*>(p);  // [beam * (1 + CM)] score keys of the frame's elements
 
   int32_t* st = state + (size_t)u * beam_state_words(beam, cfg.max_nodes);
   int32_t* g_arr = st + 2;
-  int32_t* arena = st + 2 + (size_t)kBeamStateArrays * beam;
+  int32_t* arena = st + beam_fixed_words(beam);
+  const size_t tslots = beam_table_slots(cfg.max_nodes);
+  unsigned long long* tkeys = reinterpret_cast<unsigned long long*>(arena + beam_arena_words(cfg.max_nodes));  // (8-byte aligned)
+  int32_t* tids = reinterpret_cast<int32_t*>(tkeys + tslots);
   int nb, n_nodes;
   if (init_state) {
     nb = 1;
@@ -472,7 +476,8 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
       cur.node[0] = 0; cur.chr[0] = -1; cur.par[0] = -1;
       cur.b[0] = 0.f; cur.nb[0] = kNegInf; cur.score[0] = 0.f;  // root.score = root.log_prob_b_prev = 0
       for (int j = 0; j < kLmCtx; ++j) cur.ctx[j] = cfg.lm.bos;  // Scorer::make_ngram pads with START_TOKEN
-      arena[0] = -1; arena[1] = -1;
+      cur.dst[0] = 0;                                             // dictionary start state
+      arena[0] = -1; arena[1] = -1; arena[2] = 0;
     }
   } else {
     nb = st[0];
@@ -482,6 +487,7 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
       cur.b[i] = __int_as_float(g_arr[3 * beam + i]); cur.nb[i] = __int_as_float(g_arr[4 * beam + i]);
       cur.score[i] = __int_as_float(g_arr[5 * beam + i]);
       for (int j = 0; j < kLmCtx; ++j) cur.ctx[i * kLmCtx + j] = g_arr[(6 + j) * beam + i];
+      cur.dst[i] = g_arr[(6 + kLmCtx) * beam + i];
     }
   }
   __syncthreads();
@@ -564,13 +570,28 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
       win[order - 1] = cfg.lm.tok2lm[c];
       return (float)(lm_log_cond_prob(cfg.lm, win) * cfg.alpha);
     };
-    // log-probability carried by the extension of hypothesis i with candidate k (its LM term included)
-    auto ext_logp = [&](int i, int k) -> float {
+    // word-based scorer: alpha * ln P_lm(word | last order-1 WORDS of hypothesis i), `word` = LM index of the word a space
+    // has just completed (ctc_beam_search_decoder.cpp scores `prefix`, not `prefix_new`, when c == space_id)
+    auto lm_term_word = [&](int i, int word) -> float {
+      int32_t win[kLmMaxOrder];
+      const int order = cfg.lm.order;
+      for (int j = 0; j < order - 1; ++j) win[j] = cur.ctx[i * kLmCtx + (kLmCtx - (order - 1)) + j];
+      win[order - 1] = word;
+      return (float)(lm_log_cond_prob(cfg.lm, win) * cfg.alpha);
+    };
+    // log-probability carried by the extension of hypothesis i with candidate k (its LM term included); `to_state`:
+    // dictionary state the extension lands in (word-based scorer only)
+    auto ext_logp = [&](int i, int k, int to_state) -> float {
       const int c = cand_c[k];
       float log_p = kNegInf;
       if (c == cur.chr[i]) { if (cur.b[i] > kNegInf) log_p = cand_lp[k] + cur.b[i]; }
       else log_p = cand_lp[k] + cur.score[i];
-      if (has_lm) {
+      if (word_lm) {
+        if (c == space_id) {
+          log_p += lm_term_word(i, cfg.lm.dict_word[to_state]);
+          log_p = (float)((double)log_p + cfg.beta);
+        }
+      } else if (has_lm) {
         log_p += lm_term(i, c);
         log_p = (float)((double)log_p + cfg.beta);
       }
@@ -591,7 +612,10 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
         for (int i = 0; i < nb; ++i)
           if (cur.node[i] == pn) pi = i;
         if (pi >= 0) {  // extension of the parent hypothesis by cq lands on this existing prefix
-          if (!pruned(lq, pi)) nbc = lse(nbc, ext_logp(pi, kidx[cq]));
+          // (word-based scorer: the word a space completes is read off the PARENT's dictionary state -- this prefix's own
+          //  state may already have been reset to the start state by a failed look-up, see below)
+          if (!pruned(lq, pi))
+            nbc = lse(nbc, ext_logp(pi, kidx[cq], (word_lm && cq == space_id) ? lm_dict_arc(cfg.lm, cur.dst[pi], cq) : 0));
           exists[pi * C + kidx[cq]] = 1;
         }
       }
@@ -600,6 +624,30 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
       new_score[q] = lse(bc, nbc);
     }
     lds_barrier();
+    if (word_lm) {
+      // PathTrie::get_path_trie with a dictionary: a character that has no arc from the prefix's dictionary state yields no
+      // child -- and when that state is FINAL (a word has just ended) the lookup resets the prefix's state to the start
+      // state as a side effect.  Upstream walks the candidates in list order for every prefix, so for a prefix in a final
+      // state the FIRST candidate that is looked up (not blank, not cut by min_cutoff, not an existing child) finds
+      // nothing and resets the state; every later candidate of the frame is looked up from the start state.
+      for (int q = tid; q < nb; q += BT) {
+        int kr = -1, nd = cur.dst[q];
+        if (lm_dict_final(cfg.lm, nd)) {
+          for (int k = 0; k < C; ++k) {
+            if (cand_c[k] == blank || exists[q * C + k] || pruned(cand_lp[k], q)) continue;
+            kr = k;
+            break;
+          }
+          if (kr >= 0) {
+            nd = 0;
+            if (cur.node[q] < cfg.max_nodes) arena[kArenaWords * (size_t)cur.node[q] + 2] = 0;  // (the node's own state)
+          }
+        }
+        k_reset[q] = kr;
+        new_dst[q] = nd;
+      }
+      lds_barrier();
+    }
     TS(2);
     // ---- (e) element space: [0,nb) existing hypotheses, nb + i*C + k = child (i, cand k).  The 32-bit score key of
     // every element is computed ONCE into LDS (0xFFFFFFFF = not a candidate); thread t owns the contiguous range
@@ -622,20 +670,37 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
         const int k1 = min(C, k0 + (e_hi - e));
         const int ci = cur.chr[i];
         const float bi = cur.b[i], si = cur.score[i];
+        // word-based scorer: dictionary state the children of i are looked up from (after the reset above), and the one
+        // candidate that triggered the reset
+        const int di = word_lm ? new_dst[i] : 0, kri = word_lm ? k_reset[i] : -1;
+        const bool dead = word_lm && lm_dict_final(cfg.lm, di);  // still final: no candidate was looked up this frame
         for (int k = k0; k < k1; ++k, ++e) {
           const int c = cand_c[k];
           const float lpk = cand_lp[k];
           uint32_t key = 0xFFFFFFFFu;
           if (c != blank && !exists[e - nb] && !(full_beam && (lpk + si < min_cutoff))) {
-            float log_p = kNegInf;
-            if (c == ci) { if (bi > kNegInf) log_p = lpk + bi; }
-            else log_p = lpk + si;
-            if (has_lm) {
-              log_p += lm_term(i, c);
-              log_p = (float)((double)log_p + cfg.beta);
+            int to = 0;
+            bool ok = true;
+            if (word_lm) {
+              to = (dead || k == kri) ? -1 : lm_dict_arc(cfg.lm, di, c);
+              ok = to >= 0;
             }
-            key = desc_key(log_p);
-            ++my_valid;
+            if (ok) {
+              float log_p = kNegInf;
+              if (c == ci) { if (bi > kNegInf) log_p = lpk + bi; }
+              else log_p = lpk + si;
+              if (word_lm) {
+                if (c == space_id) {
+                  log_p += lm_term_word(i, cfg.lm.dict_word[to]);
+                  log_p = (float)((double)log_p + cfg.beta);
+                }
+              } else if (has_lm) {
+                log_p += lm_term(i, c);
+                log_p = (float)((double)log_p + cfg.beta);
+              }
+              key = desc_key(log_p);
+              ++my_valid;
+            }
           }
           skey[e] = key;
         }
@@ -722,20 +787,80 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
     }
     lds_barrier();
     TS(6);
+    int n_nodes_next;
+    // node ids of the new prefixes: looked up in the node table first (a prefix that was in the beam before keeps its
+    // identity, ctc_beam.h), misses get fresh ids in slot order (one block scan) and are entered into the table
+    int my_parent = -1, my_char = 1, my_id = -1;  // (k_sel <= beam <= BT: one slot per thread)
+    if (!cfg.node_table) {
+      n_nodes_next = n_nodes + k_sel;  // every new prefix takes the id of its slot
+    } else {
+      const int pos = tid;
+      int miss = 0;
+      if (pos < k_sel && surv[pos] >= nb) {
+        const int r = surv[pos] - nb, i = r / C;
+        my_parent = cur.node[i];
+        my_char = cand_c[r - i * C];
+        const unsigned long long key = beam_node_key(my_parent, my_char);
+        size_t slot = beam_node_slot(key, tslots);
+        for (;;) {
+          const unsigned long long kx = tkeys[slot];
+          if (kx == key) { my_id = tids[slot]; break; }
+          if (kx == 0ull) break;
+          slot = slot + 1 == tslots ? 0 : slot + 1;
+        }
+        miss = my_id < 0 ? 1 : 0;
+      }
+      int n_miss;
+      const int before = block_excl_scan<BT / 64>(miss, wave_tot, n_miss);
+      if (miss) {
+        my_id = n_nodes + before;
+        if (my_id < cfg.max_nodes) {
+          arena[kArenaWords * (size_t)my_id] = my_parent;
+          arena[kArenaWords * (size_t)my_id + 1] = my_char;
+          const unsigned long long key = beam_node_key(my_parent, my_char);
+          size_t slot = beam_node_slot(key, tslots);
+          while (atomicCAS(&tkeys[slot], 0ull, key) != 0ull) slot = slot + 1 == tslots ? 0 : slot + 1;
+          tids[slot] = my_id;
+        }
+      }
+      my_char = miss;  // (re-used below: 1 = a new node, 0 = a revived one)
+      n_nodes_next = n_nodes + n_miss;
+    }
     for (int pos = tid; pos < k_sel; pos += BT) {
       const int e = surv[pos];
       if (e < nb) {
         nxt.node[pos] = cur.node[e]; nxt.chr[pos] = cur.chr[e]; nxt.par[pos] = cur.par[e];
         nxt.b[pos] = new_b[e]; nxt.nb[pos] = new_nb[e]; nxt.score[pos] = new_score[e];
         for (int j = 0; j < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[e * kLmCtx + j];
+        nxt.dst[pos] = word_lm ? new_dst[e] : 0;
       } else {
         const int r = e - nb, i = r / C, kk = r - i * C;
         const int c = cand_c[kk];
         const float log_p = score_of_key(skey[e]);  // the extension's log-probability, computed once in (e)
-        for (int j = 0; j + 1 < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[i * kLmCtx + j + 1];
-        nxt.ctx[pos * kLmCtx + kLmCtx - 1] = has_lm ? cfg.lm.tok2lm[c] : 0;
-        const int id = n_nodes + pos;
-        if (id < cfg.max_nodes) { arena[2 * (size_t)id] = cur.node[i]; arena[2 * (size_t)id + 1] = c; }
+        const int id = cfg.node_table ? my_id : n_nodes + pos;  // (with the table: pos == tid)
+        if (!cfg.node_table && id < cfg.max_nodes) { arena[kArenaWords * (size_t)id] = cur.node[i]; arena[kArenaWords * (size_t)id + 1] = c; }
+        if (word_lm) {
+          // the LM context holds WORDS: it moves on when a space completes one.  The dictionary state belongs to the trie
+          // node: a new node starts where the arc leads, a revived one is where it was left (a final state may have been
+          // reset to the start state by a failed look-up while the prefix was alive)
+          const int to = lm_dict_arc(cfg.lm, new_dst[i], c);
+          if (my_char) {
+            nxt.dst[pos] = to;
+            if (id < cfg.max_nodes) arena[kArenaWords * (size_t)id + 2] = to;
+          } else {
+            nxt.dst[pos] = arena[kArenaWords * (size_t)id + 2];
+          }
+          if (c == space_id) {
+            for (int j = 0; j + 1 < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[i * kLmCtx + j + 1];
+            nxt.ctx[pos * kLmCtx + kLmCtx - 1] = cfg.lm.dict_word[to];
+          } else {
+            for (int j = 0; j < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[i * kLmCtx + j];
+          }
+        } else {
+          nxt.dst[pos] = 0;
+          for (int j = 0; j + 1 < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[i * kLmCtx + j + 1];
+          nxt.ctx[pos * kLmCtx + kLmCtx - 1] = has_lm ? cfg.lm.tok2lm[c] : 0;
+        }
         nxt.node[pos] = id; nxt.chr[pos] = c; nxt.par[pos] = cur.node[i];
         nxt.b[pos] = kNegInf; nxt.nb[pos] = log_p; nxt.score[pos] = log_p;
       }
@@ -743,8 +868,9 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
     for (int k = tid; k < C; k += BT) { lp[cand_c[k]] = kNotCand; kidx[cand_c[k]] = -1; }  // reset for the next frame
     lds_barrier();
     TS(7);
-    n_nodes += k_sel;
     nb = k_sel;
+    n_nodes = n_nodes_next;
+    if (cfg.node_table) __threadfence_block();  // its entries are looked up by other threads of this block in later frames
     if (n_nodes + beam > cfg.max_nodes) {  // arena exhausted: report, stop consuming frames
       if (tid == 0 && status) status[u] = 1;
       Beam tmp = cur; cur = nxt; nxt = tmp;
@@ -766,29 +892,86 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
     g_arr[3 * beam + i] = __float_as_int(cur.b[i]); g_arr[4 * beam + i] = __float_as_int(cur.nb[i]);
     g_arr[5 * beam + i] = __float_as_int(cur.score[i]);
     for (int j = 0; j < kLmCtx; ++j) g_arr[(6 + j) * beam + i] = cur.ctx[i * kLmCtx + j];
+    g_arr[(6 + kLmCtx) * beam + i] = cur.dst[i];
   }
   if (!finalize) return;
   __threadfence_block();
   __syncthreads();
+  // word-based scorer (ctc_beam_search_decoder.cpp, after the last frame): "score the last word of each prefix that
+  // doesn't end with space" -- alpha * ln P(word | context) + beta is added to the score the prefixes are RANKED by; a
+  // partial word that is no vocabulary word scores OOV.  Done on a copy (new_score): the persisted beam keeps the
+  // running scores, so a streaming decoder that asks for the current best after every chunk does not accumulate it.
+  for (int q = tid; q < nb; q += BT) {
+    float sc = cur.score[q];
+    if (word_lm && cur.node[q] > 0 && cur.chr[q] != space_id) {
+      const int to = lm_dict_arc(cfg.lm, cur.dst[q], space_id);
+      int32_t win[kLmMaxOrder];
+      const int order = cfg.lm.order;
+      for (int j = 0; j < order - 1; ++j) win[j] = cur.ctx[q * kLmCtx + (kLmCtx - (order - 1)) + j];
+      win[order - 1] = to >= 0 ? cfg.lm.dict_word[to] : 0;
+      float add = (float)(lm_log_cond_prob(cfg.lm, win) * cfg.alpha);
+      add = (float)((double)add + cfg.beta);
+      sc += add;
+    }
+    new_score[q] = sc;
+  }
+  __syncthreads();
   // ---- get_beam_search_result: rank the beam by prefix_compare, emit the n-best paths ----
   // rank of slot q = number of slots that sort before it (beam <= a few hundred: O(beam^2 / 256))
   for (int q = tid; q < nb; q += BT) {
-    const uint64_t kq = make_key(cur.score[q], cur.chr[q], q);
+    const uint64_t kq = make_key(new_score[q], cur.chr[q], q);
     int rank = 0;
-    for (int i = 0; i < nb; ++i) rank += (make_key(cur.score[i], cur.chr[i], i) < kq) ? 1 : 0;
+    for (int i = 0; i < nb; ++i) rank += (make_key(new_score[i], cur.chr[i], i) < kq) ? 1 : 0;
     if (rank < cfg.nbest) {
       int len = 0;
-      for (int n = cur.node[q]; n > 0; n = arena[2 * (size_t)n]) ++len;
+      for (int n = cur.node[q]; n > 0; n = arena[kArenaWords * (size_t)n]) ++len;
       int32_t* dst = out_tokens + ((size_t)u * cfg.nbest + rank) * cfg.max_tokens;
       for (int j = 0; j < cfg.max_tokens; ++j) dst[j] = -1;
       int j = len;
-      for (int n = cur.node[q]; n > 0; n = arena[2 * (size_t)n]) {
+      for (int n = cur.node[q]; n > 0; n = arena[kArenaWords * (size_t)n]) {
         --j;
-        if (j < cfg.max_tokens) dst[j] = arena[2 * (size_t)n + 1];
+        if (j < cfg.max_tokens) dst[j] = arena[kArenaWords * (size_t)n + 1];
       }
       out_lens[(size_t)u * cfg.nbest + rank] = len;
-      double approx_ctc = (double)cur.score[q];
-      if (has_lm) {
+      double approx_ctc = (double)new_score[q];
+      if (word_lm) {
+        // approx_ctc = score - prefix_length * beta - alpha * get_sent_log_prob(split_labels(prefix)): the words between
+        // the spaces (a trailing partial word included), spelt back through the dictionary; prefix_length counts
+        // CHARACTERS (upstream subtracts one beta per character although the search added one per word)
+        const int order = cfg.lm.order;
+        int32_t win[kLmMaxOrder];
+        for (int j2 = 0; j2 < order; ++j2) win[j2] = cfg.lm.bos;
+        double sent = 0.0;
+        int n_words = 0, state = 0, run = 0;
+        auto push = [&](int word) {
+          for (int j2 = 0; j2 + 1 < order; ++j2) win[j2] = win[j2 + 1];
+          win[order - 1] = word;
+          sent += lm_log_cond_prob(cfg.lm, win);
+          ++n_words;
+        };
+        const int lim = min(len, cfg.max_tokens);
+        for (int t2 = 0; t2 < lim; ++t2) {
+          const int c = dst[t2];
+          if (c == space_id) {
+            if (run > 0) {
+              const int to = state >= 0 ? lm_dict_arc(cfg.lm, state, c) : -1;
+              push(to >= 0 ? cfg.lm.dict_word[to] : 0);
+            }
+            state = 0;
+            run = 0;
+          } else {
+            state = state >= 0 ? lm_dict_arc(cfg.lm, state, c) : -1;
+            ++run;
+          }
+        }
+        if (run > 0) {
+          const int to = state >= 0 ? lm_dict_arc(cfg.lm, state, space_id) : -1;
+          push(to >= 0 ? cfg.lm.dict_word[to] : 0);
+        }
+        if (n_words == 0) sent += lm_log_cond_prob(cfg.lm, win);  // no words: the sentence is order x <s>, then </s>
+        push(cfg.lm.eos);
+        approx_ctc = approx_ctc - (double)len * cfg.beta - sent * cfg.alpha;
+      } else if (has_lm) {
         // approx_ctc = score - prefix_length * beta - alpha * Scorer::get_sent_log_prob(words): the sentence is
         // <s> x (order-1) + words + </s>, scored window by window (scorer.cpp get_log_prob)
         const int order = cfg.lm.order;
@@ -798,7 +981,7 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
           win[order - 1] = last_word;
           int n = node;
           for (int j = order - 2; j >= 0; --j) {
-            if (n > 0) { win[j] = cfg.lm.tok2lm[arena[2 * (size_t)n + 1]]; n = arena[2 * (size_t)n]; }
+            if (n > 0) { win[j] = cfg.lm.tok2lm[arena[kArenaWords * (size_t)n + 1]]; n = arena[kArenaWords * (size_t)n]; }
             else win[j] = cfg.lm.bos;
           }
         };
@@ -808,8 +991,8 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
         }
         window_of(cur.node[q], cfg.lm.eos);
         sent += lm_log_cond_prob(cfg.lm, win);
-        for (int n = cur.node[q]; n > 0; n = arena[2 * (size_t)n]) {
-          window_of(arena[2 * (size_t)n], cfg.lm.tok2lm[arena[2 * (size_t)n + 1]]);
+        for (int n = cur.node[q]; n > 0; n = arena[kArenaWords * (size_t)n]) {
+          window_of(arena[kArenaWords * (size_t)n], cfg.lm.tok2lm[arena[kArenaWords * (size_t)n + 1]]);
           sent += lm_log_cond_prob(cfg.lm, win);
         }
         approx_ctc = approx_ctc - (double)len * cfg.beta - sent * cfg.alpha;
@@ -872,7 +1055,10 @@ __global__ __launch_bounds__(64) void k_ctc_beam_wave(const int32_t* __restrict_
   const int beam = cfg.beam, blank = cfg.blank, CM = cfg.n_cand_max;
   int32_t* st = state + (size_t)u * beam_state_words(beam, cfg.max_nodes);
   int32_t* g_arr = st + 2;
-  int32_t* arena = st + 2 + (size_t)kBeamStateArrays * beam;
+  int32_t* arena = st + beam_fixed_words(beam);
+  const size_t tslots = beam_table_slots(cfg.max_nodes);
+  unsigned long long* tkeys = reinterpret_cast<unsigned long long*>(arena + beam_arena_words(cfg.max_nodes));
+  int32_t* tids = reinterpret_cast<int32_t*>(tkeys + tslots);
   // hypothesis q lives in lane q
   int h_node = -2, h_chr = -1, h_par = -1;
   float h_b = kNegInf, h_nb = kNegInf, h_score = kNegInf;
@@ -1087,6 +1273,7 @@ __global__ __launch_bounds__(64) void k_ctc_beam_wave(const int32_t* __restrict_
         for (int j = 0; j < kLmCtx; ++j) nx_ctx[pos][j] = h_ctx[j];
       }
       int base = __popcll(mh);
+      int n_new = n_nodes;
 #pragma unroll
       for (int i = 0; i < BM; ++i) {
         if (i < nb) {
@@ -1094,11 +1281,37 @@ __global__ __launch_bounds__(64) void k_ctc_beam_wave(const int32_t* __restrict_
           const unsigned long long mk = __ballot(keep);
           if (mk) {
             const int node_i = rl_i(h_node, i);
+            // node id: the node table first (ctc_beam.h: a prefix keeps its identity), fresh ids for the misses
+            int id = -1;
+            if (keep && cfg.node_table) {
+              const unsigned long long key = beam_node_key(node_i, cc);
+              size_t slot = beam_node_slot(key, tslots);
+              for (;;) {
+                const unsigned long long kx = tkeys[slot];
+                if (kx == key) { id = tids[slot]; break; }
+                if (kx == 0ull) break;
+                slot = slot + 1 == tslots ? 0 : slot + 1;
+              }
+            }
+            const unsigned long long mm = __ballot(keep && id < 0);
+            if (keep && id < 0) {
+              id = n_new + mbcnt(mm);
+              if (id < cfg.max_nodes) {
+                arena[kArenaWords * (size_t)id] = node_i;
+                arena[kArenaWords * (size_t)id + 1] = cc;
+                arena[kArenaWords * (size_t)id + 2] = 0;
+                if (cfg.node_table) {
+                  const unsigned long long key = beam_node_key(node_i, cc);
+                  size_t slot = beam_node_slot(key, tslots);
+                  while (atomicCAS(&tkeys[slot], 0ull, key) != 0ull) slot = slot + 1 == tslots ? 0 : slot + 1;
+                  tids[slot] = id;
+                }
+              }
+            }
+            n_new += __popcll(mm);
             if (keep) {
               const int pos = base + mbcnt(mk);
               const float log_p = score_of_key(kk0[i]);
-              const int id = n_nodes + pos;
-              if (id < cfg.max_nodes) { arena[2 * (size_t)id] = node_i; arena[2 * (size_t)id + 1] = cc; }
               nx_i[0][pos] = id; nx_i[1][pos] = cc; nx_i[2][pos] = node_i;
               nx_f[0][pos] = kNegInf; nx_f[1][pos] = log_p; nx_f[2][pos] = log_p;
 #pragma unroll
@@ -1109,6 +1322,8 @@ __global__ __launch_bounds__(64) void k_ctc_beam_wave(const int32_t* __restrict_
           }
         }
       }
+      n_nodes = n_new;
+      if (cfg.node_table) __threadfence_block();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       h_node = -2; h_chr = -1; h_par = -1;
       h_b = kNegInf; h_nb = kNegInf; h_score = kNegInf;
@@ -1120,7 +1335,6 @@ __global__ __launch_bounds__(64) void k_ctc_beam_wave(const int32_t* __restrict_
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    n_nodes += k_sel;
     nb = k_sel;
     WTS(5);
     if (n_nodes + beam > cfg.max_nodes) {  // arena exhausted: report, stop consuming frames
@@ -1142,6 +1356,7 @@ __global__ __launch_bounds__(64) void k_ctc_beam_wave(const int32_t* __restrict_
     g_arr[5 * beam + lane] = __float_as_int(h_score);
 #pragma unroll
     for (int j = 0; j < kLmCtx; ++j) g_arr[(6 + j) * beam + lane] = h_ctx[j];
+    g_arr[(6 + kLmCtx) * beam + lane] = 0;  // (dictionary state: word-based scorers take the block-wide kernel)
   }
   if (!finalize) return;
   __threadfence_block();  // this wave's arena stores are read back below
@@ -1158,13 +1373,13 @@ __global__ __launch_bounds__(64) void k_ctc_beam_wave(const int32_t* __restrict_
     }
     if (lane < nb && rank < cfg.nbest) {
       int len = 0;
-      for (int n = h_node; n > 0; n = arena[2 * (size_t)n]) ++len;
+      for (int n = h_node; n > 0; n = arena[kArenaWords * (size_t)n]) ++len;
       int32_t* dst = out_tokens + ((size_t)u * cfg.nbest + rank) * cfg.max_tokens;
       for (int j = 0; j < cfg.max_tokens; ++j) dst[j] = -1;
       int j = len;
-      for (int n = h_node; n > 0; n = arena[2 * (size_t)n]) {
+      for (int n = h_node; n > 0; n = arena[kArenaWords * (size_t)n]) {
         --j;
-        if (j < cfg.max_tokens) dst[j] = arena[2 * (size_t)n + 1];
+        if (j < cfg.max_tokens) dst[j] = arena[kArenaWords * (size_t)n + 1];
       }
       out_lens[(size_t)u * cfg.nbest + rank] = len;
       double approx_ctc = (double)h_score;
@@ -1176,7 +1391,7 @@ __global__ __launch_bounds__(64) void k_ctc_beam_wave(const int32_t* __restrict_
           win[order - 1] = last_word;
           int n = node;
           for (int j2 = order - 2; j2 >= 0; --j2) {
-            if (n > 0) { win[j2] = cfg.lm.tok2lm[arena[2 * (size_t)n + 1]]; n = arena[2 * (size_t)n]; }
+            if (n > 0) { win[j2] = cfg.lm.tok2lm[arena[kArenaWords * (size_t)n + 1]]; n = arena[kArenaWords * (size_t)n]; }
             else win[j2] = cfg.lm.bos;
           }
         };
@@ -1186,8 +1401,8 @@ __global__ __launch_bounds__(64) void k_ctc_beam_wave(const int32_t* __restrict_
         }
         window_of(h_node, cfg.lm.eos);
         sent += lm_log_cond_prob(cfg.lm, win);
-        for (int n = h_node; n > 0; n = arena[2 * (size_t)n]) {
-          window_of(arena[2 * (size_t)n], cfg.lm.tok2lm[arena[2 * (size_t)n + 1]]);
+        for (int n = h_node; n > 0; n = arena[kArenaWords * (size_t)n]) {
+          window_of(arena[kArenaWords * (size_t)n], cfg.lm.tok2lm[arena[kArenaWords * (size_t)n + 1]]);
           sent += lm_log_cond_prob(cfg.lm, win);
         }
         approx_ctc = approx_ctc - (double)len * cfg.beta - sent * cfg.alpha;
@@ -1203,6 +1418,25 @@ __global__ __launch_bounds__(64) void k_ctc_beam_wave(const int32_t* __restrict_
 
 constexpr int kWaveBeamMax = 16;  // k_ctc_beam_wave: beam_size <= 16 and <= 64 pruned characters per frame
 
+__global__ __launch_bounds__(256) void k_beam_rehash(int32_t* __restrict__ state, int beam, int max_nodes) {
+  int32_t* st = state + (size_t)blockIdx.x * beam_state_words(beam, max_nodes);
+  const int32_t* arena = st + beam_fixed_words(beam);
+  const size_t tslots = beam_table_slots(max_nodes);
+  unsigned long long* tkeys = reinterpret_cast<unsigned long long*>(st + beam_fixed_words(beam) + beam_arena_words(max_nodes));
+  int32_t* tids = reinterpret_cast<int32_t*>(tkeys + tslots);
+  const int n_nodes = st[1];
+  for (int id = 1 + threadIdx.x; id < n_nodes; id += blockDim.x) {
+    const unsigned long long key = beam_node_key(arena[kArenaWords * (size_t)id], arena[kArenaWords * (size_t)id + 1]);
+    size_t slot = beam_node_slot(key, tslots);
+    while (atomicCAS(&tkeys[slot], 0ull, key) != 0ull) slot = slot + 1 == tslots ? 0 : slot + 1;
+    tids[slot] = id;
+  }
+}
+hipError_t launch_beam_rehash(int32_t* state, int B, int beam, int max_nodes, hipStream_t st) {
+  PPASR_LAUNCH(k_beam_rehash, dim3(B), dim3(256), 0, st, state, beam, max_nodes);
+  return hipGetLastError();
+}
+
 hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B, int T, const BeamConfig& cfg,
                            int32_t* prune_recs, int32_t* state, int init_state, int finalize, int32_t* out_tokens,
                            int32_t* out_lens, double* out_scores, int32_t* status, hipStream_t st) {
@@ -1217,10 +1451,16 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
     for (int i = 4; i >= 0; --i)
       if (atoi(e) <= kSizes[i]) sel = i;
   }
-  const void* fns[5] = {reinterpret_cast<const void*>(k_ctc_beam<64>), reinterpret_cast<const void*>(k_ctc_beam<128>),
-                        reinterpret_cast<const void*>(k_ctc_beam<256>), reinterpret_cast<const void*>(k_ctc_beam<512>),
-                        reinterpret_cast<const void*>(k_ctc_beam<1024>)};
-  const void* fn = fns[sel];
+  while (sel < 4 && kSizes[sel] < cfg.beam) ++sel;  // (the new beam is materialised one slot per thread)
+  const bool wl = cfg.lm.order > 0 && cfg.lm.word_based != 0;
+  const void* fns[2][5] = {
+      {reinterpret_cast<const void*>(k_ctc_beam<64, false>), reinterpret_cast<const void*>(k_ctc_beam<128, false>),
+       reinterpret_cast<const void*>(k_ctc_beam<256, false>), reinterpret_cast<const void*>(k_ctc_beam<512, false>),
+       reinterpret_cast<const void*>(k_ctc_beam<1024, false>)},
+      {reinterpret_cast<const void*>(k_ctc_beam<64, true>), reinterpret_cast<const void*>(k_ctc_beam<128, true>),
+       reinterpret_cast<const void*>(k_ctc_beam<256, true>), reinterpret_cast<const void*>(k_ctc_beam<512, true>),
+       reinterpret_cast<const void*>(k_ctc_beam<1024, true>)}};
+  const void* fn = fns[wl ? 1 : 0][sel];
   // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set it on every launch (a few host
   // microseconds) rather than caching "already configured" in process-wide statics, which left a second GPU used from
   // the same process unconfigured and was not thread-safe
@@ -1240,7 +1480,7 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
   // 5.4 us for the block-wide kernel (a lone wave issues its readlane / ballot / branch sequences at ~9 cycles per
   // instruction); kept because it needs no LDS tables and co-resides with the encoder's workgroups.
   const char* wave_env = getenv("PPASR_BEAM_WAVE");
-  if (cfg.beam <= kWaveBeamMax && cfg.n_cand_max <= 64 && wave_env && atoi(wave_env) == 1) {
+  if (cfg.beam <= kWaveBeamMax && cfg.n_cand_max <= 64 && wave_env && atoi(wave_env) == 1 && !cfg.lm.word_based) {
     if (cfg.lm.order > 0)
       PPASR_LAUNCH((k_ctc_beam_wave<kWaveBeamMax, true>), dim3(B), dim3(64), 0, st, frame_lens, T, cfg, prune_recs, state,
                    init_state, finalize, out_tokens, out_lens, out_scores, status);
@@ -1250,8 +1490,14 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
     return hipGetLastError();
   }
 #define PPASR_LAUNCH_BEAM(BT)                                                                                          \
-  PPASR_LAUNCH(k_ctc_beam<BT>, dim3(B), dim3(BT), lds, st, probs, frame_lens, T, cfg, prune_recs, state, init_state, \
-                     finalize, out_tokens, out_lens, out_scores, status)
+  do {                                                                                                                 \
+    if (wl)                                                                                                            \
+      PPASR_LAUNCH((k_ctc_beam<BT, true>), dim3(B), dim3(BT), lds, st, probs, frame_lens, T, cfg, prune_recs, state,   \
+                   init_state, finalize, out_tokens, out_lens, out_scores, status);                                    \
+    else                                                                                                               \
+      PPASR_LAUNCH((k_ctc_beam<BT, false>), dim3(B), dim3(BT), lds, st, probs, frame_lens, T, cfg, prune_recs, state,  \
+                   init_state, finalize, out_tokens, out_lens, out_scores, status);                                    \
+  } while (0)
   switch (sel) {
     case 0: PPASR_LAUNCH_BEAM(64); break;
     case 1: PPASR_LAUNCH_BEAM(128); break;

@@ -37,13 +37,27 @@
 //   A record's children are [next, next of the following record) one order up; the trie is keyed by the n-gram's
 //   words from the LAST to the first.  The walk enumerates every n-gram with its word ids, which are re-keyed with
 //   lm_key like an ARPA model.
-// QUANT_* and ARRAY_* variants are refused (PPASR_EUNSUPPORTED).
+// QUANT_TRIE / QUANT_ARRAY_TRIE (lm/quantize.hh SeparatelyQuantize; `build_binary -q N -b M trie`): the search memory
+//   STARTS with the quantiser: { uint8 version = 2; uint8 prob_bits; uint8 backoff_bits; 5 pad } then, per middle order
+//   2 .. order-1, 2^prob_bits float prob bins + 2^backoff_bits float back-off bins, then 2^prob_bits float bins of the
+//   longest order (Size = (order - 2) * middle_table + longest_table + 8); unigrams are not quantised.  A middle record is
+//   [word] [backoff bin : backoff_bits] [prob bin : prob_bits] [next], a longest record [word] [prob bin]; value = bin[i].
+// ARRAY_TRIE / QUANT_ARRAY_TRIE (lm/bhiksha.hh ArrayBhiksha; `build_binary -a N trie`): every middle block starts with
+//   the pointer-compression table: { uint8 version = 0; uint8 configured max bits }, then at the next 8-byte boundary an
+//   8-byte header slot followed by ArrayCount uint64 offsets (Size = 8 * (1 + ArrayCount) + 7), then -- unaligned -- the
+//   bit-packed records, whose `next` field keeps only the low InlineBits = RequiredBits(max_next) - chop bits.  chop =
+//   argmin over c in [0, min(RequiredBits(max_next), configured)] of (max_next >> (required - c)) * 64 - (entries + 1) * c
+//   (first minimum); ArrayCount = (max_next >> (required - chop)) + 1; offsets[e] = index of the first record whose
+//   pointer's high part is >= e, so next(r) = ((upper_bound(offsets, r) - offsets - 1) << InlineBits) | inline(r).
+//   The configured bits are read from the FIRST middle block (right behind the unigrams) and hold for every order.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -137,10 +151,9 @@ ppasr_status klm_load(const char* path, const char* const* vocab_utf8, int V, bo
                                     "needs them, as paddlespeech_ctcdecoders does");
   size_t pos = align8(kSanityBytes + kFixedBytes + 8 * (size_t)order);
   const bool probing = model_type == 0 || model_type == 1;
-  const bool trie = model_type == 2;
-  if (!probing && !trie)
-    return fail(PPASR_EUNSUPPORTED, "lm: quantised / Bhiksha-array trie models (KenLM model types 3-5) are not read; "
-                                    "rebuild with `build_binary trie` (no -q / -a) or `probing`");
+  const bool trie = model_type >= 2 && model_type <= 5;
+  const bool quant = model_type == 3 || model_type == 5, array = model_type == 4 || model_type == 5;
+  if (!probing && !trie) return fail(PPASR_EUNSUPPORTED, "lm: unknown KenLM model type " + std::to_string(model_type));
   auto lm = std::make_unique<ppasr_lm_s>();
   lm->order = order;
   std::vector<LmEntry> entries;
@@ -188,33 +201,111 @@ ppasr_status klm_load(const char* path, const char* const* vocab_utf8, int V, bo
                                       std::to_string(counts[n - 1]));
     }
   } else {
-    // ---- trie ----
+    // ---- trie (plain, quantised and / or Bhiksha-array pointer compression) ----
     const size_t vocab_bytes = 8 + 8 * counts[0];
-    const uint8_t* uni = f + pos + vocab_bytes;  // DontQuantize::Size == 0
-    size_t spos = pos + vocab_bytes + (counts[0] + 2) * 16;
+    size_t spos = pos + vocab_bytes;
+    int prob_bits = 0, backoff_bits = 0;
+    std::vector<const float*> prob_bins(order + 1, nullptr), backoff_bins(order + 1, nullptr);  // by n-gram order
+    if (quant) {
+      if (spos + 8 > m.n) return fail(PPASR_EINVAL, "lm: truncated quantiser header");
+      const int qv = f[spos];
+      prob_bits = f[spos + 1];
+      backoff_bits = f[spos + 2];
+      if (qv != 2) return fail(PPASR_EUNSUPPORTED, "lm: quantiser version " + std::to_string(qv) + " (this reader knows SeparatelyQuantize version 2)");
+      if (prob_bits < 1 || prob_bits > 25 || backoff_bits < 1 || backoff_bits > 25)
+        return fail(PPASR_EINVAL, "lm: quantiser bit widths outside 1..25");
+      const size_t longest_tab = ((size_t)1 << prob_bits) * 4, middle_tab = ((size_t)1 << backoff_bits) * 4 + longest_tab;
+      const size_t qsize = (size_t)(order - 2) * middle_tab + longest_tab + 8;
+      if (spos + qsize > m.n) return fail(PPASR_EINVAL, "lm: file shorter than its quantiser tables");
+      const float* t = reinterpret_cast<const float*>(f + spos + 8);
+      for (int n = 2; n < order; ++n) {
+        prob_bins[n] = t;
+        t += (size_t)1 << prob_bits;
+        backoff_bins[n] = t;
+        t += (size_t)1 << backoff_bits;
+      }
+      prob_bins[order] = t;
+      spos += qsize;
+    }
+    const uint8_t* uni = f + spos;
+    spos += (counts[0] + 2) * 16;
+    if (spos > m.n) return fail(PPASR_EINVAL, "lm: file shorter than its unigram array");
     const int word_bits = required_bits(counts[0]);
     struct Level {
-      const uint8_t* base;
-      int total_bits, next_bits;
+      const uint8_t* base;       // first bit-packed record
+      int total_bits, next_bits; // next_bits = inline bits of the pointer
       uint64_t entries;
+      const uint8_t* offsets;    // Bhiksha offset array (unaligned reads), or nullptr
+      uint64_t n_offsets;
+      int quant_bits;
     };
     std::vector<Level> mid;
+    int configured_bits = -1;
     for (int n = 2; n < order; ++n) {
-      const int next_bits = required_bits(counts[n]);
-      const int total = word_bits + 63 + next_bits;
-      mid.push_back(Level{f + spos, total, next_bits, counts[n - 1]});
-      spos += ((1 + counts[n - 1]) * (uint64_t)total + 7) / 8 + 8;
+      const uint64_t entries = counts[n - 1], max_next = counts[n], max_offset = entries + 1;
+      const int required = required_bits(max_next);
+      const int qbits = quant ? prob_bits + backoff_bits : 63;
+      Level L{};
+      L.entries = entries;
+      L.quant_bits = qbits;
+      if (array) {
+        if (spos + 2 > m.n) return fail(PPASR_EINVAL, "lm: truncated pointer-compression header");
+        if (f[spos] != 0) return fail(PPASR_EUNSUPPORTED, "lm: ArrayBhiksha version " + std::to_string((int)f[spos]) + " (this reader knows version 0)");
+        if (configured_bits < 0) configured_bits = f[spos + 1];  // (KenLM reads the first block's byte and applies it to all)
+        int chop = 0;
+        long long lowest = std::numeric_limits<long long>::max();
+        for (int c = 0; c <= std::min(required, configured_bits); ++c) {
+          const long long change = (long long)(max_next >> (required - c)) * 64 - (long long)max_offset * c;
+          if (change < lowest) {
+            lowest = change;
+            chop = c;
+          }
+        }
+        L.n_offsets = (max_next >> (required - chop)) + 1;
+        L.next_bits = required - chop;
+        L.offsets = f + align8(spos) + 8;
+        const size_t bsize = 8 * (1 + L.n_offsets) + 7;
+        L.base = f + spos + bsize;
+        L.total_bits = word_bits + qbits + L.next_bits;
+        spos += bsize + ((1 + entries) * (uint64_t)L.total_bits + 7) / 8 + 8;
+      } else {
+        L.next_bits = required;
+        L.total_bits = word_bits + qbits + required;
+        L.base = f + spos;
+        spos += ((1 + entries) * (uint64_t)L.total_bits + 7) / 8 + 8;
+      }
+      if (spos > m.n) return fail(PPASR_EINVAL, "lm: file shorter than its header says (trie arrays)");
+      mid.push_back(L);
     }
-    const int ltotal = word_bits + 31;
-    const Level lng{f + spos, ltotal, 0, counts[order - 1]};
+    const int lqbits = quant ? prob_bits : 31;
+    const int ltotal = word_bits + lqbits;
+    Level lng{};
+    lng.base = f + spos;
+    lng.total_bits = ltotal;
+    lng.entries = counts[order - 1];
+    lng.quant_bits = lqbits;
     spos += ((1 + counts[order - 1]) * (uint64_t)ltotal + 7) / 8 + 8;
     if (spos > m.n) return fail(PPASR_EINVAL, "lm: file shorter than its header says (trie arrays)");
     strings_at = spos;
-    lm->format = "klm-trie";
+    lm->format = quant ? (array ? "klm-quant-array-trie" : "klm-quant-trie") : (array ? "klm-array-trie" : "klm-trie");
     auto bits_to_float = [](uint32_t u) {
       float v;
       std::memcpy(&v, &u, 4);
       return v;
+    };
+    // `next` pointer of record r of a middle level (r == entries: the end sentinel)
+    auto next_of = [&](const Level& L, uint64_t r) -> uint64_t {
+      const uint64_t inl = read_bits(L.base, r * (uint64_t)L.total_bits + word_bits + L.quant_bits, L.next_bits);
+      if (!L.offsets) return inl;
+      // upper_bound(offsets, offsets + n, r) - 1: the last e with offsets[e] <= r
+      uint64_t lo = 0, hi = L.n_offsets;
+      while (lo < hi) {
+        const uint64_t midp = (lo + hi) / 2;
+        if (rd<uint64_t>(L.offsets + 8 * midp) <= r) lo = midp + 1;
+        else hi = midp;
+      }
+      const uint64_t e = lo ? lo - 1 : 0;
+      return (e << L.next_bits) | inl;
     };
     // depth-first walk: path[0] = last word of the n-gram, path[d] = the word d positions before it
     std::vector<int32_t> path(order), ngram(order);
@@ -237,14 +328,30 @@ ppasr_status klm_load(const char* path, const char* const* vocab_utf8, int V, bo
       for (uint64_t r = begin; r < end && walk_err.empty(); ++r) {
         const uint64_t off = r * (uint64_t)L.total_bits;
         path[depth] = (int32_t)read_bits(L.base, off, word_bits);
-        const float prob = neg_abs(bits_to_float((uint32_t)read_bits(L.base, off + word_bits, 31)));
+        const int n = depth + 1;
+        float prob, backoff = 0.f;
+        if (quant) {
+          // SeparatelyQuantize: [backoff bin][prob bin] in a middle record, [prob bin] in a longest one
+          if (last) {
+            prob = prob_bins[n][read_bits(L.base, off + word_bits, prob_bits)];
+          } else {
+            backoff = backoff_bins[n][read_bits(L.base, off + word_bits, backoff_bits)] + 0.f;
+            prob = prob_bins[n][read_bits(L.base, off + word_bits + backoff_bits, prob_bits)];
+          }
+          prob = neg_abs(prob);
+        } else {
+          prob = neg_abs(bits_to_float((uint32_t)read_bits(L.base, off + word_bits, 31)));
+          if (!last) backoff = bits_to_float((uint32_t)read_bits(L.base, off + word_bits + 31, 32)) + 0.f;
+        }
         if (last) {
           emit(depth, prob, 0.f);
         } else {
-          const float backoff = bits_to_float((uint32_t)read_bits(L.base, off + word_bits + 31, 32)) + 0.f;
           emit(depth, prob, backoff);
-          const uint64_t nb = read_bits(L.base, off + word_bits + 63, L.next_bits);
-          const uint64_t ne = read_bits(L.base, off + (uint64_t)L.total_bits + word_bits + 63, L.next_bits);
+          const uint64_t nb = next_of(L, r), ne = next_of(L, r + 1);
+          if (ne < nb) {
+            walk_err = "lm: decreasing trie pointers at order " + std::to_string(n);
+            return;
+          }
           if (ne > nb) descend(depth + 1, nb, ne);
         }
       }
@@ -278,7 +385,7 @@ ppasr_status klm_load(const char* path, const char* const* vocab_utf8, int V, bo
     if (p != m.n) return fail(PPASR_EINVAL, "lm: " + std::to_string(m.n - p) + " unexplained bytes after the vocabulary strings (layout mismatch)");
   }
   std::string err = lm_bind_vocabulary(*lm, words, vocab_utf8, V);
-  if (!err.empty()) return fail(err.rfind("lm: word-based", 0) == 0 ? PPASR_EUNSUPPORTED : PPASR_EINVAL, err);
+  if (!err.empty()) return fail(PPASR_EINVAL, err);
   err = lm_build_table(*lm, entries);
   if (!err.empty()) return fail(PPASR_EINVAL, err);
   if (!host_only) {

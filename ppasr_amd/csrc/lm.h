@@ -25,7 +25,32 @@ struct LmDev {
   const int32_t* tok2lm;     // [V] acoustic-vocabulary id -> LM word index, 0 = OOV (<unk>)
   int kenlm_keys;            // 1: n-grams are keyed by KenLM's own word-hash chain (tables taken over from a "probing"
                              //    .klm binary, whose entries carry only that hash); 0: by lm_key over the word ids
+  // ---- word-based models (scorer.cpp: is_character_based_ == false): the LM is consulted when a SPACE is appended, and
+  // the prefix trie is constrained to the model's vocabulary by a dictionary (upstream: an OpenFST acceptor of every
+  // vocabulary word spelt in acoustic characters + the space; here the same language as a plain character trie in CSR
+  // form: node s has the arcs [dict_first[s], dict_first[s + 1]), sorted by character; node 0 = start) ----
+  int word_based;            // 0: character-based
+  int space_id;              // acoustic token id of the space
+  const int32_t* dict_first;     // [n_nodes + 1]
+  const int32_t* dict_arc_char;  // [n_arcs] acoustic token id
+  const int32_t* dict_arc_next;  // [n_arcs] target node
+  const int32_t* dict_word;      // [n_nodes] LM word index of the word that ENDS at this node (nodes entered by a space
+                                 // arc: the dictionary's final states), 0 elsewhere
 };
+
+// arc of dictionary node `s` labelled `c`: target node, or -1 (binary search over the node's sorted arcs)
+__host__ __device__ inline int lm_dict_arc(const LmDev& lm, int s, int c) {
+  int lo = lm.dict_first[s], hi = lm.dict_first[s + 1];
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const int a = lm.dict_arc_char[mid];
+    if (a == c) return lm.dict_arc_next[mid];
+    if (a < c) lo = mid + 1;
+    else hi = mid;
+  }
+  return -1;
+}
+__host__ __device__ inline bool lm_dict_final(const LmDev& lm, int s) { return lm.dict_word[s] != 0; }
 
 __host__ __device__ inline uint64_t lm_mix(uint64_t h, uint64_t v) {
   h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);

@@ -2,7 +2,9 @@
 // Replaces `Scorer(alpha, beta, model_path, vocabulary)` of paddlespeech_ctcdecoders (PPASR call site
 // decoders/swig_wrapper.py:18-33, decoders/beam_search_decoder.py:28-29) for CHARACTER-BASED models, i.e. models whose
 // words are all single UTF-8 characters (scorer.cpp `load_lm`: is_character_based_), which is what PPASR's Mandarin
-// models are.  Word-based models need the OpenFST dictionary constraint of the trie and are refused.
+// models are, and for WORD-BASED models (any vocabulary word longer than one character; the English configs): those are
+// consulted when a space is appended and constrain the prefixes to spellings of their vocabulary through a dictionary
+// (upstream: an OpenFST acceptor built by Scorer::fill_dictionary; here the same language as a character trie, lm.h).
 // This file reads the ARPA text format; KenLM's binary formats (.klm) are read by klm.hip.
 #include <algorithm>
 #include <cstdio>
@@ -97,7 +99,7 @@ ppasr_status arpa_load(const char* arpa_path, const char* const* vocab_utf8, int
   lm->format = "arpa";
   for (const Gram& g : grams) lm->order = std::max(lm->order, (int)g.w.size());
   std::string err = lm_bind_vocabulary(*lm, words, vocab_utf8, V);
-  if (!err.empty()) return fail(err.rfind("lm: word-based", 0) == 0 ? PPASR_EUNSUPPORTED : PPASR_EINVAL, err);
+  if (!err.empty()) return fail(PPASR_EINVAL, err);
   std::vector<LmEntry> entries;
   entries.reserve(grams.size());
   for (const Gram& g : grams) entries.push_back(LmEntry{lm_key(g.w.data(), (int)g.w.size()), g.prob, g.backoff});
@@ -127,16 +129,74 @@ std::string lm_bind_vocabulary(ppasr_lm_s& lm, const std::unordered_map<std::str
   lm.character_based = true;
   for (const auto& kv : words)
     if (kv.first != "<unk>" && kv.first != "<s>" && kv.first != "</s>" && utf8_len(kv.first) > 1) lm.character_based = false;
-  if (!lm.character_based)
-    return "lm: word-based language model (needs the dictionary-constrained trie); only character-based models are built";
-  lm.tok2lm.assign(V, 0);
+  std::unordered_map<std::string, int> tok_of;  // acoustic character -> token id
   for (int v = 0; v < V; ++v) {
     if (!vocab_utf8[v]) continue;
     const std::string s(vocab_utf8[v]);
-    // a literal space is SPACE_ID_: Scorer::make_ngram stops on it with an empty word, i.e. OOV (scorer.cpp)
-    if (s == " ") continue;
-    auto it = words.find(s);
-    if (it != words.end()) lm.tok2lm[v] = it->second;
+    // the space token: " " (upstream DeepSpeech / early PaddleSpeech) or "<space>" (PaddleSpeech kSPACE; PPASR's
+    // vocabularies spell it that way, data_utils/featurizer/text_featurizer.py:23)
+    if (s == " " || s == "<space>") {
+      lm.space_id = v;
+      continue;
+    }
+    tok_of.emplace(s, v);
+  }
+  lm.tok2lm.assign(V, 0);
+  if (lm.character_based) {
+    for (int v = 0; v < V; ++v) {
+      if (!vocab_utf8[v] || v == lm.space_id) continue;  // a space: Scorer::make_ngram stops on it with an empty word = OOV
+      auto it = words.find(std::string(vocab_utf8[v]));
+      if (it != words.end()) lm.tok2lm[v] = it->second;
+    }
+    return "";
+  }
+  // ---- word-based: Scorer::fill_dictionary(add_space = true) -- every vocabulary word that can be spelt with the
+  // acoustic characters, followed by the space, goes into the dictionary ----
+  if (lm.space_id < 0) return "lm: word-based language model, but the acoustic vocabulary has no space token (\" \" or \"<space>\")";
+  struct Node {
+    std::vector<std::pair<int, int>> arcs;  // (char, target)
+    int word = 0;
+  };
+  std::vector<Node> nodes(1);
+  auto child = [&](int s, int c) {
+    for (auto& a : nodes[s].arcs)
+      if (a.first == c) return a.second;
+    const int t = (int)nodes.size();
+    nodes[s].arcs.emplace_back(c, t);
+    nodes.emplace_back();
+    return t;
+  };
+  for (const auto& kv : words) {
+    const std::string& w = kv.first;
+    if (w == "<unk>" || w == "<s>" || w == "</s>" || w.empty()) continue;
+    std::vector<int> spelt;
+    bool ok = true;
+    for (size_t i = 0; i < w.size() && ok;) {
+      size_t j = i + 1;
+      while (j < w.size() && ((unsigned char)w[j] & 0xc0) == 0x80) ++j;
+      auto it = tok_of.find(w.substr(i, j - i));
+      if (it == tok_of.end()) ok = false;
+      else spelt.push_back(it->second);
+      i = j;
+    }
+    if (!ok) continue;  // add_word_to_dictionary: a word with a character outside the acoustic vocabulary is skipped
+    int s = 0;
+    for (int c : spelt) s = child(s, c);
+    s = child(s, lm.space_id);
+    nodes[s].word = kv.second;
+    ++lm.dict_words;
+  }
+  if (lm.dict_words == 0) return "lm: word-based language model, but none of its words can be spelt with the acoustic vocabulary";
+  lm.dict_first.assign(nodes.size() + 1, 0);
+  lm.dict_word.assign(nodes.size(), 0);
+  for (size_t n = 0; n < nodes.size(); ++n) {
+    std::sort(nodes[n].arcs.begin(), nodes[n].arcs.end());
+    lm.dict_first[n + 1] = lm.dict_first[n] + (int32_t)nodes[n].arcs.size();
+    lm.dict_word[n] = nodes[n].word;
+    for (auto& a : nodes[n].arcs) {
+      lm.dict_arc_char.push_back(a.first);
+      lm.dict_arc_next.push_back(a.second);
+    }
   }
   return "";
 }
@@ -185,6 +245,18 @@ ppasr_status lm_upload(ppasr_lm_s& lm) {
   lm.dev.eos = lm.eos;
   lm.dev.mask = (uint32_t)(lm.keys.size() - 1);
   lm.dev.kenlm_keys = lm.kenlm_keys ? 1 : 0;
+  lm.dev.word_based = lm.character_based ? 0 : 1;
+  lm.dev.space_id = lm.space_id;
+  if (!lm.character_based) {
+    if ((s = up(lm.dict_first.data(), lm.dict_first.size() * 4, &p)) != PPASR_OK) return s;
+    lm.dev.dict_first = static_cast<const int32_t*>(p);
+    if ((s = up(lm.dict_arc_char.data(), lm.dict_arc_char.size() * 4, &p)) != PPASR_OK) return s;
+    lm.dev.dict_arc_char = static_cast<const int32_t*>(p);
+    if ((s = up(lm.dict_arc_next.data(), lm.dict_arc_next.size() * 4, &p)) != PPASR_OK) return s;
+    lm.dev.dict_arc_next = static_cast<const int32_t*>(p);
+    if ((s = up(lm.dict_word.data(), lm.dict_word.size() * 4, &p)) != PPASR_OK) return s;
+    lm.dev.dict_word = static_cast<const int32_t*>(p);
+  }
   return PPASR_OK;
 }
 
@@ -268,6 +340,8 @@ ppasr_status ppasr_lm_destroy(ppasr_lm_handle lm) {
 
 int ppasr_lm_order(ppasr_lm_handle lm) { return lm ? lm->order : 0; }
 int ppasr_lm_is_character_based(ppasr_lm_handle lm) { return lm ? (lm->character_based ? 1 : 0) : 0; }
+long long ppasr_lm_dict_size(ppasr_lm_handle lm) { return lm ? (long long)lm->dict_words : 0; }
+int ppasr_lm_space_id(ppasr_lm_handle lm) { return lm ? lm->space_id : -1; }
 long long ppasr_lm_ngram_count(ppasr_lm_handle lm) { return lm ? (long long)lm->n_grams : 0; }
 
 // internal (capi.hip): the device view handed to the beam-search kernel

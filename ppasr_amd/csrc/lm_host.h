@@ -23,6 +23,10 @@ struct ppasr_lm_s {
   std::vector<float> prob, backoff;
   std::vector<int32_t> tok2lm;
   int bos = 0, eos = 0;
+  // word-based models: the dictionary (lm.h) and the acoustic token of the space
+  int space_id = -1;
+  size_t dict_words = 0;  // Scorer::get_dict_size(): vocabulary words that could be spelt in acoustic characters
+  std::vector<int32_t> dict_first, dict_arc_char, dict_arc_next, dict_word;
   std::vector<void*> allocs;
   ~ppasr_lm_s() {
     for (void* p : allocs) (void)hipFree(p);

@@ -3,9 +3,9 @@
 beam search (``ppasr_ctc_beam_search`` in include/ppasr_hip.h).
 
 External scorer: the reference always builds a KenLM ``Scorer`` (beam_search_decoder.py:28-29).  Here
-``language_model_path`` may point to a CHARACTER-based n-gram LM as an ARPA text file or as a KenLM binary (``.klm``:
-probing / rest-probing / plain trie; ``Scorer`` below, backed by ``ppasr_lm_*`` / ``ppasr_ctc_beam_search_lm``);
-word-based models and quantised / array-compressed tries raise.  Without a model
+``language_model_path`` may point to a character-based or word-based n-gram LM as an ARPA text file or as a KenLM binary
+(``.klm``: probing / rest-probing / trie incl. the quantised and array-compressed variants; ``Scorer`` below, backed by
+``ppasr_lm_*`` / ``ppasr_ctc_beam_search_lm``).  Without a model
 path the search runs without a scorer (alpha / beta unused).  Returned scores follow the upstream convention:
 -log P(prefix), with the LM weight removed when a scorer is used ("approx_ctc").
 """
@@ -39,6 +39,19 @@ class Scorer:
         with torch.cuda.device(self._device):
             _lib.check(self._lib.ppasr_lm_create(str(model_path).encode(), words, len(vocabulary), ctypes.byref(h)))
         self._h = h
+        fmt = self._lib.ppasr_lm_format(h).decode()
+        if fmt.startswith("klm") and not Scorer._klm_warned:
+            # KenLM is not vendored with the reference and cannot be installed here: the binary layouts in csrc/klm.hip
+            # are written from the KenLM sources as recalled and have only met tests/klm_writer.py, never a file produced
+            # by build_binary itself.  Layout mismatches fail loudly at load; a file that loads is still unverified.
+            Scorer._klm_warned = True
+            import warnings
+            warnings.warn(f"language model {model_path}: KenLM binary ({fmt}) read by an UNVERIFIED reader (never checked "
+                          "against KenLM's own build_binary output); prefer the ARPA file of the model if you have it, and "
+                          "compare a few sentence scores with kenlm.Model.score before relying on it.", RuntimeWarning,
+                          stacklevel=2)
+
+    _klm_warned = False
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -54,6 +67,10 @@ class Scorer:
 
     def is_character_based(self):
         return bool(self._lib.ppasr_lm_is_character_based(self._h))
+
+    def get_dict_size(self):
+        """swig Scorer.get_dict_size(): words of a word-based model that can be spelt with the acoustic vocabulary."""
+        return int(self._lib.ppasr_lm_dict_size(self._h))
 
     def ngram_count(self):
         return int(self._lib.ppasr_lm_ngram_count(self._h))

@@ -1,9 +1,15 @@
-"""Test-side WRITER of KenLM binary models (probing, rest-probing and plain trie), following the layout cited in
+"""Test-side WRITER of KenLM binary models (probing, rest-probing, trie and the quantised / Bhiksha-array trie
+variants: model types 0-5), following the layout cited in
 ppasr_amd/csrc/klm.hip.  KenLM cannot be built here (not vendored, no network), so reader and writer are both written
 from the documented format; the writer sets KenLM's flag bits (prob sign = "extends left", back-off -0.0 = "no
 extension") the way build_binary does, so that the reader has to strip them.
 
-    write_klm(arpa_path, klm_path, model_type="probing" | "rest_probing" | "trie", multiplier=1.5)
+    write_klm(arpa_path, klm_path, model_type="probing" | "rest_probing" | "trie" | "quant_trie" | "array_trie" |
+              "quant_array_trie", multiplier=1.5, prob_bits=.., backoff_bits=.., bhiksha_bits=..)
+
+Quantised models: build_binary trains its bins on the model; here the bins are the model's own distinct values (padded
+to 2^bits entries), so a quantised binary still scores exactly like its ARPA source -- what is tested is the LAYOUT
+(bin tables in front of the unigrams, [backoff bin][prob bin] records, the reserved back-off bins 0 / 1).
 """
 import struct
 
@@ -118,7 +124,7 @@ def _flags(grams, order):
     return suffix_of, prefix_of
 
 
-def write_klm(arpa_path, klm_path, model_type="probing", multiplier=1.5):
+def write_klm(arpa_path, klm_path, model_type="probing", multiplier=1.5, prob_bits=12, backoff_bits=12, bhiksha_bits=64):
     words, grams = read_arpa_grams(arpa_path)
     order = max(grams)
     counts = [len(grams[n]) for n in range(1, order + 1)]
@@ -157,8 +163,9 @@ def write_klm(arpa_path, klm_path, model_type="probing", multiplier=1.5):
         items = [(chain(ids), -abs(p)) for ids, p, _ in grams[order]]
         body += _probing_table(items, _buckets(counts[order - 1], multiplier), 16, _f32)
         strings = words
-    elif model_type == "trie":
-        mt = 2
+    elif model_type in ("trie", "quant_trie", "array_trie", "quant_array_trie"):
+        quant, array = model_type.startswith("quant"), "array" in model_type
+        mt = 2 + (1 if quant else 0) + (2 if array else 0)
         # SortedVocabulary: words renumbered by the order of their hashes, <unk> = 0
         hashed = sorted((murmur64a(w.encode("utf-8")), w) for w in words[1:])
         new_index = {"<unk>": 0}
@@ -181,6 +188,26 @@ def write_klm(arpa_path, klm_path, model_type="probing", multiplier=1.5):
                 i += 1
             return i
 
+        # ---- SeparatelyQuantize tables (lm/quantize.cc): in FRONT of the unigrams ----
+        pbin, bbin = {}, {}
+        if quant:
+            def f32v(v):
+                return struct.unpack("<f", _f32(v))[0]
+            qbody = bytearray(struct.pack("<BBB5x", 2, prob_bits, backoff_bits))
+            for n in range(2, order + 1):
+                pv = sorted({f32v(-abs(p)) for _, p, _ in level[n]})
+                assert len(pv) <= (1 << prob_bits), "more distinct probabilities than bins"
+                pbin[n] = {v: i for i, v in enumerate(pv)}
+                qbody += b"".join(_f32(v) for v in pv) + _f32(float("inf")) * ((1 << prob_bits) - len(pv))
+                if n < order:
+                    # bins 0 / 1 are reserved: kNoExtensionBackoff (-0.0) and kExtensionBackoff (0.0)
+                    bv = sorted({f32v(b) for _, _, b in level[n] if b != 0.0})
+                    assert len(bv) + 2 <= (1 << backoff_bits), "more distinct back-offs than bins"
+                    bbin[n] = {v: i + 2 for i, v in enumerate(bv)}
+                    qbody += _f32(-0.0) + _f32(0.0) + b"".join(_f32(v) for v in bv) + _f32(float("inf")) * ((1 << backoff_bits) - 2 - len(bv))
+            assert len(qbody) == (order - 2) * 4 * ((1 << prob_bits) + (1 << backoff_bits)) + 4 * (1 << prob_bits) + 8
+            body += qbody
+
         word_bits = int(counts[0]).bit_length()
         uni = {rev[0]: (p, b) for rev, p, b in level[1]}
         ptr = 0
@@ -194,29 +221,73 @@ def write_klm(arpa_path, klm_path, model_type="probing", multiplier=1.5):
 
         def pack_bits(records, total_bits, n_records):
             nbytes = ((1 + n_records) * total_bits + 7) // 8 + 8
-            buf = bytearray(nbytes)
             acc = 0
             for r, fields in enumerate(records):
                 off = r * total_bits
                 for value, bits in fields:
                     acc |= (value & ((1 << bits) - 1)) << off
                     off += bits
-            raw = acc.to_bytes(nbytes, "little")
-            return raw
+            return acc.to_bytes(nbytes, "little")
+
+        def f32bits(v):
+            return struct.unpack("<I", _f32(v))[0]
+
+        def quant_fields(n, p, b, last):
+            if quant:
+                pi = pbin[n][struct.unpack("<f", _f32(-abs(p)))[0]]
+                if last:
+                    return [(pi, prob_bits)]
+                if b == 0.0:
+                    bi = 1 if (False) else 0   # either reserved bin decodes to a zero back-off
+                else:
+                    bi = bbin[n][struct.unpack("<f", _f32(b))[0]]
+                return [(bi, backoff_bits), (pi, prob_bits)]
+            if last:
+                return [(f32bits(abs(p)) & 0x7FFFFFFF, 31)]
+            return [(f32bits(abs(p)) & 0x7FFFFFFF, 31), (f32bits(b), 32)]
 
         for n in range(2, order):
-            next_bits = int(counts[n]).bit_length()
-            total = word_bits + 63 + next_bits
-            recs, ptr = [], 0
+            max_next, max_offset = counts[n], counts[n - 1] + 1
+            required = int(max_next).bit_length()
+            ptrs, ptr = [], 0
             for rev, p, b in level[n]:
                 ptr = first_child(n, rev, ptr)
-                pb = struct.unpack("<I", _f32(abs(p)))[0] & 0x7FFFFFFF
-                bb = struct.unpack("<I", _f32(b))[0]
-                recs.append([(rev[-1], word_bits), (pb, 31), (bb, 32), (ptr, next_bits)])
-            recs.append([(0, word_bits), (0, 31), (0, 32), (len(level[n + 1]), next_bits)])  # the final next pointer
+                ptrs.append(ptr)
+            ptrs.append(len(level[n + 1]))  # the final next pointer
+            chop = 0
+            if array:
+                # lm/bhiksha.cc ChopBits / ArrayCount
+                lowest = None
+                for c in range(0, min(required, bhiksha_bits) + 1):
+                    change = (max_next >> (required - c)) * 64 - max_offset * c
+                    if lowest is None or change < lowest:
+                        lowest, chop = change, c
+                inline_bits = required - chop
+                n_off = (max_next >> (required - chop)) + 1
+                offsets = [0] * n_off
+                w_to = 1
+                for index, value in enumerate(ptrs):           # ArrayBhiksha::WriteNext
+                    enc = value >> inline_bits
+                    while w_to <= enc:
+                        offsets[w_to] = index
+                        w_to += 1
+                assert w_to == n_off, (w_to, n_off)
+                blk = bytearray(8 * (1 + n_off) + 7)
+                start = len(_header(order, multiplier, mt, counts)) + len(body)   # file offset of the block
+                a8 = (-start) % 8
+                blk[0], blk[1] = 0, bhiksha_bits                # version, configured bits (FinishedLoading)
+                struct.pack_into("<%dQ" % n_off, blk, a8 + 8, *offsets)
+                body += blk
+            else:
+                inline_bits = required
+            total = word_bits + (prob_bits + backoff_bits if quant else 63) + inline_bits
+            recs = []
+            for (rev, p, b), pt in zip(level[n], ptrs):
+                recs.append([(rev[-1], word_bits)] + quant_fields(n, p, b, False) + [(pt & ((1 << inline_bits) - 1), inline_bits)])
+            recs.append([(0, word_bits)] + [(0, prob_bits + backoff_bits if quant else 63)] + [(ptrs[-1] & ((1 << inline_bits) - 1), inline_bits)])
             body += pack_bits(recs, total, counts[n - 1])
-        total = word_bits + 31
-        recs = [[(rev[-1], word_bits), (struct.unpack("<I", _f32(abs(p)))[0] & 0x7FFFFFFF, 31)] for rev, p, _ in level[order]]
+        total = word_bits + (prob_bits if quant else 31)
+        recs = [[(rev[-1], word_bits)] + quant_fields(order, p, b, True) for rev, p, b in level[order]]
         body += pack_bits(recs, total, counts[order - 1])
     else:
         raise ValueError(model_type)

@@ -79,4 +79,4 @@ def read_arpa(path, vocabulary):
         backoff[i] = np.float32(b)
     tok2lm = np.array([0 if t == " " else words.get(t, 0) for t in vocabulary], np.int32)
     return dict(order=int(gram_n.max()), gram_n=gram_n, gram_w=gram_w, prob=prob, backoff=backoff, tok2lm=tok2lm,
-                bos=words["<s>"], eos=words["</s>"])
+                bos=words["<s>"], eos=words["</s>"], words=dict(words))
