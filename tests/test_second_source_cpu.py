@@ -1,0 +1,178 @@
+"""CPU: second sources for the rows that cannot be pinned to the reference (their arithmetic lives in third-party modules
+that are not in /root/reference).  They do NOT replace a pin; they check each restatement against a formulation that was
+not written from the same reading:
+
+(a) beam search -- the C oracle (oracle/ctc_beam_search_oracle.c: upstream's prefix TRIE with node bookkeeping, float32)
+    against a dictionary-of-prefixes formulation ({prefix tuple: (log P_b, log P_nb)} per frame, no trie, no node
+    identity, float64) on random tables, with pruning disabled and with top-n / cumulative pruning.  Proves: the trie
+    bookkeeping (exists flags, revival of removed nodes, prev / cur swapping, repeated-character rule) computes the
+    prefix probabilities of the textbook recursion.  Does not prove: that upstream's pruning rule or score convention is
+    what the oracle says (both sides take the rule from the same recollection).
+(b) fbank -- oracle/fbank_oracle.py (numpy float64, explicit frame matrix + np.fft) against an independent construction
+    on torch: strided framing, the pre-emphasis / DC removal folded into one banded operator, torch.fft, a mel filter
+    bank built from bin EDGES in Hz mapped through the inverse mel scale.  Proves: framing, window, FFT size, filter
+    shapes agree between two derivations of Kaldi's published algorithm.  Does not prove: paddleaudio's defaults.
+"""
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FLT_MIN = float(np.finfo(np.float32).tiny)
+
+
+def _oracle_lib():
+    so = os.path.join(ROOT, "oracle", "_build", "libctc_beam_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    lib = ctypes.CDLL(so)
+    lib.ctc_beam_oracle_decode.restype = ctypes.c_int
+    return lib
+
+
+def _oracle_top(lib, p, beam, cutoff_prob, top_n, nbest=1):
+    T, V = p.shape
+    L = max(T, 1)
+    tokens = np.empty((nbest, L), np.int32)
+    lens = np.empty(nbest, np.int32)
+    scores = np.empty(nbest, np.float64)
+    p = np.ascontiguousarray(p, np.float32)
+    n = lib.ctc_beam_oracle_decode(p.ctypes.data_as(ctypes.c_void_p), T, V, beam, ctypes.c_double(cutoff_prob), top_n, 0,
+                                   nbest, L, tokens.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p),
+                                   scores.ctypes.data_as(ctypes.c_void_p))
+    return [(tuple(tokens[i, :lens[i]].tolist()), float(scores[i])) for i in range(n)]
+
+
+def _lse(a, b):
+    if a == -math.inf:
+        return b
+    if b == -math.inf:
+        return a
+    m = max(a, b)
+    return m + math.log(math.exp(a - m) + math.exp(b - m))
+
+
+def _prefix_dict_search(p, beam, cutoff_prob, top_n, blank=0):
+    """CTC prefix beam search over a dict {prefix: [log P_blank, log P_nonblank]} (float64): every frame, every kept
+    prefix spreads its mass to itself (blank, repeated last character) and to its one-character extensions (from P_b
+    only when the character repeats the last one); the best `beam` prefixes by log(P_b + P_nb) are kept."""
+    T, V = p.shape
+    beam_set = {(): [0.0, -math.inf]}
+    for t in range(T):
+        row = p[t].astype(np.float64)
+        order = sorted(range(V), key=lambda i: (-row[i], i))
+        if cutoff_prob < 1.0:
+            cum, keep = 0.0, []
+            for i in order:
+                cum += row[i]
+                keep.append(i)
+                if cum >= cutoff_prob or len(keep) >= top_n:
+                    break
+        else:
+            keep = order
+        logp = {c: math.log(row[c] + FLT_MIN) for c in keep}
+        nxt = {}
+        for pre, (pb, pnb) in beam_set.items():
+            tot = _lse(pb, pnb)
+            for c in keep:
+                lp = logp[c]
+                if c == blank:
+                    e = nxt.setdefault(pre, [-math.inf, -math.inf])
+                    e[0] = _lse(e[0], lp + tot)
+                    continue
+                if pre and c == pre[-1]:
+                    e = nxt.setdefault(pre, [-math.inf, -math.inf])
+                    e[1] = _lse(e[1], lp + pnb)
+                    if pb > -math.inf:
+                        e2 = nxt.setdefault(pre + (c,), [-math.inf, -math.inf])
+                        e2[1] = _lse(e2[1], lp + pb)
+                else:
+                    e2 = nxt.setdefault(pre + (c,), [-math.inf, -math.inf])
+                    e2[1] = _lse(e2[1], lp + tot)
+        # prefixes of the previous beam that received nothing stay in upstream's trie with probability 0: irrelevant
+        ranked = sorted(nxt.items(), key=lambda kv: (-_lse(*kv[1]), kv[0][-1] if kv[0] else -1))
+        beam_set = dict(ranked[:beam])
+    ranked = sorted(beam_set.items(), key=lambda kv: (-_lse(*kv[1]), kv[0][-1] if kv[0] else -1))
+    return [(k, -_lse(*v)) for k, v in ranked]
+
+
+@pytest.mark.parametrize("cutoff_prob,top_n", [(1.0, 40), (0.99, 40), (0.9, 5)])
+def test_beam_oracle_equals_prefix_dictionary_formulation(cutoff_prob, top_n):
+    lib = _oracle_lib()
+    rng = np.random.Generator(np.random.PCG64(int(cutoff_prob * 100) + top_n))
+    same = checked = 0
+    for case in range(200):
+        T, V, beam = int(rng.integers(1, 25)), int(rng.integers(3, 40)), int(rng.choice([1, 2, 5, 10, 30]))
+        sharp = float(rng.choice([0.5, 2.0, 5.0]))
+        logits = rng.standard_normal((T, V)) * sharp
+        p = np.exp(logits - logits.max(-1, keepdims=True))
+        p = (p / p.sum(-1, keepdims=True)).astype(np.float32)
+        ref = _oracle_top(lib, p, beam, cutoff_prob, top_n, nbest=min(beam, 3))
+        got = _prefix_dict_search(p, beam, cutoff_prob, top_n)
+        checked += 1
+        if got[0][0] == ref[0][0]:
+            same += 1
+            assert abs(got[0][1] - ref[0][1]) <= 2e-4 * max(1.0, abs(ref[0][1])), (case, got[0], ref[0])
+        else:
+            # float32 trie vs float64 dictionary: a different winner is only acceptable on a near-tie of the two leaders
+            alt = dict(got).get(ref[0][0])
+            assert alt is not None and abs(alt - got[0][1]) <= 1e-3 * max(1.0, abs(alt)), (case, got[:2], ref[:2])
+    assert same >= checked - 3, (same, checked)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _independent_fbank(int16_samples, sr=16000, n_mels=80, frame_ms=25.0, shift_ms=10.0):
+    x = torch.as_tensor(np.asarray(int16_samples), dtype=torch.float64)
+    win, hop = int(round(sr * frame_ms / 1000.0)), int(round(sr * shift_ms / 1000.0))
+    if x.numel() < win:
+        return torch.zeros(0, n_mels, dtype=torch.float64)
+    frames = x.unfold(0, win, hop)                                  # snip_edges: only whole frames
+    nfft = 1
+    while nfft < win:
+        nfft *= 2
+    # DC removal and pre-emphasis as ONE linear operator on a frame: y = P (I - 11^T / win) f, P = I - 0.97 * shift
+    # (with the first sample's predecessor replicated, Kaldi's convention)
+    eye = torch.eye(win, dtype=torch.float64)
+    center = eye - torch.full((win, win), 1.0 / win, dtype=torch.float64)
+    pre = eye.clone()
+    pre[torch.arange(1, win), torch.arange(0, win - 1)] -= 0.97
+    pre[0, 0] -= 0.97
+    n = torch.arange(win, dtype=torch.float64)
+    povey = torch.pow(0.5 * (1.0 - torch.cos(2.0 * math.pi * n / (win - 1))), 0.85)
+    op = torch.diag(povey) @ pre @ center
+    spec = torch.fft.rfft(frames @ op.T, n=nfft, dim=1)
+    power = spec.real ** 2 + spec.imag ** 2
+    # mel filters from band EDGES in Hz: equally spaced on the mel axis between 20 Hz and Nyquist, triangular in mel
+    inv_mel = lambda m: 700.0 * (math.exp(m / 1127.0) - 1.0)
+    mel = lambda f: 1127.0 * math.log(1.0 + f / 700.0)
+    lo, hi = mel(20.0), mel(sr / 2.0)
+    edges_hz = [inv_mel(lo + (hi - lo) * k / (n_mels + 1)) for k in range(n_mels + 2)]
+    fb = torch.zeros(n_mels, nfft // 2, dtype=torch.float64)
+    for b in range(n_mels):
+        ml, mc, mr = mel(edges_hz[b]), mel(edges_hz[b + 1]), mel(edges_hz[b + 2])
+        for k in range(nfft // 2):
+            m = mel(k * sr / nfft)
+            if ml < m < mr:
+                fb[b, k] = (m - ml) / (mc - ml) if m <= mc else (mr - m) / (mr - mc)
+    e = power[:, : nfft // 2] @ fb.T
+    return torch.log(torch.clamp(e, min=float(np.finfo(np.float32).eps)))
+
+
+@pytest.mark.parametrize("seconds,sr", [(1.0, 16000), (0.31, 16000), (0.024, 16000), (0.5, 8000)])
+def test_fbank_oracle_equals_independent_construction(seconds, sr):
+    from oracle.fbank_oracle import kaldi_fbank
+    rng = np.random.Generator(np.random.PCG64(int(seconds * 1000) + sr))
+    t = np.arange(int(seconds * sr)) / sr
+    wav = 0.3 * np.sin(2 * np.pi * 440 * t) + 0.1 * np.sin(2 * np.pi * 3100 * t + 1.0) + 0.05 * rng.standard_normal(t.shape)
+    pcm = np.clip(wav * 32768.0, -32768, 32767).astype(np.int16)
+    a = kaldi_fbank(pcm, sr=sr)
+    b = _independent_fbank(pcm, sr=sr).numpy()
+    assert a.shape == b.shape
+    if a.size:
+        assert a.shape[1] == 80 and a.shape[0] == 1 + (len(pcm) - int(sr * 0.025)) // int(sr * 0.010)
+        assert float(np.abs(a - b).max()) < 1e-5, float(np.abs(a - b).max())
