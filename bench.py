@@ -84,7 +84,7 @@ def class_of(name):
     """Kernel name (as rocprofv3 prints it, parameter list dropped) -> accounting class."""
     n = name
     if n.startswith("k_gemm_stream<"):
-        return "conv2" if "Conv2Src" in n else "dense"
+        return "conv2" if "Conv2S" in n else "dense"   # (rocprof summaries may truncate the name)
     m = re.match(r"(k_[a-z0-9_]+)(<[^>]*>)?", n)
     if not m:
         return n

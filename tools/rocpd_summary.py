@@ -16,6 +16,6 @@ try:
     if rows:
         print("\n# PMC (rocprofv3 --pmc, summed over XCDs/SEs): kernel | counter | dispatches | avg value per dispatch | avg ns")
         for r in rows:
-            print(f"{r[0][:60]} | {r[1]} | {r[2]} | {r[3]:.0f} | {r[4]:.0f}")
+            print(f"{r[0][:110]} | {r[1]} | {r[2]} | {r[3]:.0f} | {r[4]:.0f}")
 except sqlite3.Error as e:
     print("# (no pmc table:", e, ")")
