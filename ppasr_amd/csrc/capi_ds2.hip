@@ -107,14 +107,15 @@ ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd) {
     }
     // fragment-ordered copy for the batched step kernel: per direction, packed column 32 t + 8 gate + u = row
     // gate * H + 8 t + u of weight_hh (every gate of units 8t .. 8t+7 in one 32-column tile)
-    if (G == 4) {
+    // (GRU: three gates r, z, c; the fourth slot of every tile is zero)
+    {
       std::vector<float> pk;
       pk.reserve((size_t)dirs * 4 * H * H);
       for (int d = 0; d < dirs; ++d) {
         const float* wd = whh[d];
         std::vector<float> one = pack_b(H, 4 * H, [&](int k, int n) {
           const int t = n / 32, r = n % 32, gate = r / 8, u = r % 8;
-          return wd[(size_t)(gate * H + 8 * t + u) * H + k];
+          return gate < G ? wd[(size_t)(gate * H + 8 * t + u) * H + k] : 0.f;
         });
         pk.insert(pk.end(), one.begin(), one.end());
       }
@@ -225,7 +226,11 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
   float* out = ya;
   const size_t sbytes = (size_t)dirs * B * H * sizeof(float);
   // (the matrix-core tiles have 32 rows whatever the batch: below 4 utterances the per-step kernels are the faster ones)
-  if (W.wave_tab && dirs == 1 && Tp > 0 && B >= 4) {
+  // (the wavefront folds the input projections of layers >= 1 into the step: fewer dependent launches, but those
+  //  projections then run on the step kernel's 32-row tiles instead of the dense GEMM; measured, 5 x 1024 LSTM, 5 s
+  //  utterances: B = 32 6.6 ms against 9.2 per-step, B = 64 11.4 against 11.2, B = 128 21.9 against 21.0)
+  static const int wave_max_b = getenv("PPASR_DS2_WAVE_MAX_B") ? atoi(getenv("PPASR_DS2_WAVE_MAX_B")) : 48;
+  if (W.wave_tab && dirs == 1 && Tp > 0 && B >= 4 && B <= wave_max_b) {
     // ---- unidirectional stack: wavefront over (layer, time), Tp + L - 1 dependent launches (k_lstm_wave) ----
     const int L = W.n_layers;
     const Ds2LayerW& L0 = h->ds2_layers[0];
@@ -272,9 +277,10 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
     float* hp = h0;
     float* hn = h1;
     // the matrix-core step needs H % 64 == 0 (8 waves x whole 8-wide k-groups); the VALU kernel handles the rest
-    const bool mfma_step = (H % 64 == 0) && B >= 2 && G == 4;  // (one utterance: the VALU kernel's 5.8 us per step is the faster one)
+    const bool mfma_step = (H % 64 == 0) && B >= 2;  // (one utterance: the VALU kernel's 5.8 us per step is the faster one)
     for (int s = 0; s < Tp; ++s) {
-      if (G == 3) launch_gru_step(gx, Lw.w_hh, Lw.b_hh, hp, hn, out, lens32, B, Tp, H, dirs, s, st);
+      if (G == 3 && mfma_step) launch_gru_step_mfma(gx, Lw.w_hh_pk, Lw.b_hh, hp, hn, out, lens32, B, Tp, H, dirs, s, st);
+      else if (G == 3) launch_gru_step(gx, Lw.w_hh, Lw.b_hh, hp, hn, out, lens32, B, Tp, H, dirs, s, st);
       else if (mfma_step) launch_lstm_step_mfma(gx, Lw.w_hh_pk, hp, hn, c, out, lens32, B, Tp, H, dirs, s, st);
       else launch_lstm_step(gx, Lw.w_hh, hp, hn, c, out, lens32, B, Tp, H, dirs, s, st);
       std::swap(hp, hn);

@@ -49,6 +49,9 @@ void launch_gru_step(const float* gx, const float* whh, const float* bhh, const 
 // gates = h_prev W_hh^T as a [32 x H] x [H x 32] MFMA tile per workgroup, the contraction split over its 8 waves.
 void launch_lstm_step_mfma(const float* gx, const f32x4* whh_pk, const float* hprev, float* hnext, float* c, float* y,
                            const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st);
+// GRU layers on the same tiles (the fourth gate slot of the packed weights is zero); bhh [dirs][3H]
+void launch_gru_step_mfma(const float* gx, const f32x4* whh_pk, const float* bhh, const float* hprev, float* hnext, float* y,
+                          const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st);
 // One wavefront launch of the unidirectional stack: layers l_lo .. l_lo + n_l - 1, layer l at time s - l.
 //   gx0 [B*T][4H] layer-0 input projections; hbuf [L][2][B][H] (slot = time parity), cbuf [L][B][H],
 //   yring [L][2][B][H] raw outputs of the last two time steps, out [B*T][H] raw outputs of the last layer (pre-zeroed)

@@ -208,11 +208,15 @@ __global__ __launch_bounds__(256) void k_gru_step(const float* __restrict__ gx, 
 // utterances (the 32 rows of the tile), its 8 waves split the K = H contraction (a 32x32 tile with K = 1024 on one
 // wave would be a chain of 512 dependent MFMAs = 16 us; 64 per wave = 2 us) and the partial tiles are summed through
 // LDS.  H / 8 workgroups per direction = 256 for the bidirectional 1024-unit layer: one per CU.
+// GRU = true: nn.GRU layers (deepspeech2/encoder.py:36-42).  Same tiles -- 8 units x {r, z, c, (unused)} = 32 columns, the
+// fourth gate slot packed as zeros --; the recurrent sums keep b_hh and stay SEPARATE from the input projections because
+// the candidate is tanh(x_c + r * (W_hc h + b_hc)); h' = (h - c~) * z + c~ (the arithmetic of k_gru_step, batched).
+template <bool GRU>
 __global__ __launch_bounds__(kThreads) void k_lstm_step_mfma(const float* __restrict__ gx, const f32x4* __restrict__ whh_pk,
-                                                             const float* __restrict__ hprev, float* __restrict__ hnext,
-                                                             float* __restrict__ c, float* __restrict__ y,
-                                                             const int32_t* __restrict__ lens, int B, int T, int H, int dirs,
-                                                             int step) {
+                                                             const float* __restrict__ bhh, const float* __restrict__ hprev,
+                                                             float* __restrict__ hnext, float* __restrict__ c,
+                                                             float* __restrict__ y, const int32_t* __restrict__ lens, int B,
+                                                             int T, int H, int dirs, int step) {
   __shared__ float part[kWaves][32][33];
   __shared__ float gates[32][33];
   const int tile = blockIdx.x, dir = blockIdx.y, b0 = blockIdx.z * 32;
@@ -253,18 +257,21 @@ __global__ __launch_bounds__(kThreads) void k_lstm_step_mfma(const float* __rest
   for (int r = 0; r < 16; ++r) part[wave][acc_row(r, lane)][l31] = acc[r];
   __syncthreads();
   // sum of the 8 partial tiles + input projection: thread -> (row, col) = 2 of the 1024 tile elements
-  const float* gxd = gx + (size_t)dir * B * T * 4 * H;
+  constexpr int NG = GRU ? 3 : 4;
+  const float* gxd = gx + (size_t)dir * B * T * NG * H;
   for (int e = threadIdx.x; e < 32 * 32; e += kThreads) {
     const int row = e >> 5, col = e & 31;
     const int bb = b0 + row;
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) v += part[w][row][col];
-    if (bb < B) {
+    const int gate = col >> 3, unit = tile * 8 + (col & 7);
+    if (GRU) {
+      if (gate < 3) v += bhh[(size_t)dir * 3 * H + (size_t)gate * H + unit];  // (the input parts are read in the cell update)
+    } else if (bb < B) {
       const int len = lens[bb];
       if (step < len) {
         const int t = dir == 0 ? step : len - 1 - step;
-        const int gate = col >> 3, unit = tile * 8 + (col & 7);
         v += gxd[((size_t)bb * T + t) * 4 * H + (size_t)gate * H + unit];
       }
     }
@@ -279,6 +286,15 @@ __global__ __launch_bounds__(kThreads) void k_lstm_step_mfma(const float* __rest
       const size_t si = ((size_t)dir * B + bb) * H + tile * 8 + u;
       if (step >= len) {
         hnext[si] = hprev[si];  // finished utterance: carry the state (final state = last valid step)
+      } else if (GRU) {
+        const int t = dir == 0 ? step : len - 1 - step;
+        const float* gxr = gxd + ((size_t)bb * T + t) * 3 * H + tile * 8 + u;
+        const float gr = 1.0f / (1.0f + expf(-(gxr[0] + gates[row][0 + u])));
+        const float gz = 1.0f / (1.0f + expf(-(gxr[(size_t)H] + gates[row][8 + u])));
+        const float cand = tanhf(gxr[(size_t)2 * H] + gr * gates[row][16 + u]);
+        const float hv = (hprev[si] - cand) * gz + cand;
+        hnext[si] = hv;
+        y[((size_t)bb * T + t) * (size_t)(dirs * H) + (size_t)dir * H + tile * 8 + u] = hv;
       } else {
         const int t = dir == 0 ? step : len - 1 - step;
         const float gi = 1.0f / (1.0f + expf(-gates[row][0 + u]));
@@ -504,8 +520,13 @@ void launch_gru_step(const float* gx, const float* whh, const float* bhh, const 
 }
 void launch_lstm_step_mfma(const float* gx, const f32x4* whh_pk, const float* hprev, float* hnext, float* c, float* y,
                            const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st) {
-  PPASR_LAUNCH(k_lstm_step_mfma, dim3(H / 8, dirs, (B + 31) / 32), dim3(kThreads), 0, st, gx, whh_pk, hprev, hnext, c, y,
-                     lens, B, T, H, dirs, step);
+  PPASR_LAUNCH(k_lstm_step_mfma<false>, dim3(H / 8, dirs, (B + 31) / 32), dim3(kThreads), 0, st, gx, whh_pk, nullptr, hprev,
+               hnext, c, y, lens, B, T, H, dirs, step);
+}
+void launch_gru_step_mfma(const float* gx, const f32x4* whh_pk, const float* bhh, const float* hprev, float* hnext, float* y,
+                          const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st) {
+  PPASR_LAUNCH(k_lstm_step_mfma<true>, dim3(H / 8, dirs, (B + 31) / 32), dim3(kThreads), 0, st, gx, whh_pk, bhh, hprev,
+               hnext, nullptr, y, lens, B, T, H, dirs, step);
 }
 void launch_lstm_wave(const float* gx0, const Ds2WaveLayer* tab, float* hbuf, float* cbuf, float* yring, float* out,
                       const int32_t* lens, int B, int T, int H, int L, int s, int l_lo, int n_l, hipStream_t st) {

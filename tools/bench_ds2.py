@@ -63,7 +63,7 @@ for sh in shapes():
         if base in ("k_lstm_step", "k_gru_step"):
             byts = cnt * dirs * gates * H * H * 4   # every launch reads the recurrent weights of the layer's direction(s)
             e.update(bound="hbm", gbs=round(byts / (ms * scale * 1e-3) / 1e9, 1), frac=round(byts / (ms * scale * 1e-3) / 1e9 / PEAK_GBS, 4))
-        elif base in ("k_lstm_step_mfma", "k_lstm_wave"):
+        elif base in ("k_lstm_step_mfma", "k_lstm_wave"):   # (k_lstm_step_mfma<true> = the GRU layers on the same tiles)
             fl = rec_flops + (in_flops - 2 * 608 * gates * H * Tp * B * dirs if base == "k_lstm_wave" else 0)
             # weights a launch streams: one layer's W_hh per direction (step kernel); W_hh of every layer + the folded input
             # projection of layers >= 1 (the (layer, time) wavefront: all layers are in flight in one launch)
@@ -71,7 +71,10 @@ for sh in shapes():
             e.update(bound="mfma|hbm", tflops=round(fl / (ms * scale * 1e-3) / 1e12, 2), frac_mfma=round(fl / (ms * scale * 1e-3) / 1e12 / PEAK_TF, 4),
                      weight_gbs=round(wbytes / (ms * scale * 1e-3) / 1e9, 1), frac_hbm=round(wbytes / (ms * scale * 1e-3) / 1e9 / PEAK_GBS, 4))
         elif base == "k_gemm_stream":
-            e.update(bound="mfma", tflops=round((in_flops + 2 * dirs * H * V * Tp * B) / (ms * scale * 1e-3) / 1e12, 2))
+            # input projections (all layers, or layer 0 only when the wavefront kernel folds the others) + CTC head
+            folded = any(k.startswith("k_lstm_wave") for k in kp.kernels)
+            fl = (2 * 608 * gates * H * Tp * B * dirs if folded else in_flops) + 2 * dirs * H * V * Tp * B
+            e.update(bound="mfma", tflops=round(fl / (ms * scale * 1e-3) / 1e12, 2), frac=round(fl / (ms * scale * 1e-3) / 1e12 / PEAK_TF, 4))
         kernels[name] = e
     print(json.dumps({"model": "DeepSpeech2 5x1024 " + ("GRU" if gru else "LSTM") + (" unidirectional" if streaming else " bidirectional"),
                       "B": B, "frames": T, "ms": round(dt * 1e3, 3), "audio_s_per_s": round(B * T * 0.01 / dt, 1), "kernels": kernels}), flush=True)
