@@ -1,6 +1,8 @@
 // capi_ds2.hip -- DeepSpeech2Model.get_encoder_out / get_encoder_out_chunk (ppasr/model_utils/deepspeech2/
 // model.py:62-72) behind the C-ABI: weight packing and launch sequence of CRNNEncoder.forward
 // (deepspeech2/encoder.py:61-104) + ctc softmax.
+#include <algorithm>
+
 #include "capi_internal.h"
 
 namespace {
@@ -171,7 +173,7 @@ ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd) {
 }
 
 struct Ds2Ws {
-  size_t y1, x, gx, ya, yb, h0, h1, c, lens32, hbuf, cbuf, yring, total;  // float offsets
+  size_t y1, x, gx, ya, yb, h0, h1, c, lens32, hbuf, cbuf, yring, part, part_floats, total;  // float offsets
 };
 static Ds2Ws ds2_ws(const ppasr_model_s* m, int B, int T) {
   const Ds2W& W = m->ds2;
@@ -191,6 +193,9 @@ static Ds2Ws ds2_ws(const ppasr_model_s* m, int B, int T) {
   w.hbuf = o; o += al64((size_t)W.n_layers * 2 * B * W.H);
   w.cbuf = o; o += al64((size_t)W.n_layers * B * W.H);
   w.yring = o; o += al64((size_t)W.n_layers * 2 * B * W.H);
+  // K-slice partial sums of the dense layers when the launch is under-filled (few frames: single utterances)
+  w.part_floats = M <= 512 ? (size_t)8 * M * std::max((size_t)W.gates * W.H, (size_t)W.Vpad) : 0;
+  w.part = o; o += al64(w.part_floats);
   w.total = o;
   return w;
 }
@@ -217,6 +222,7 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
   const int M = B * Tp, H = W.H, dirs = W.dirs, G = W.gates;
   float *y1 = ws + wl.y1, *x = ws + wl.x, *gx = ws + wl.gx, *ya = ws + wl.ya, *yb = ws + wl.yb;
   float *h0 = ws + wl.h0, *h1 = ws + wl.h1, *c = ws + wl.c;
+  float* part = wl.part_floats ? ws + wl.part : nullptr;
   int32_t* lens32 = reinterpret_cast<int32_t*>(ws + wl.lens32);
   launch_ds2_conv1(feats, W.cmvn_mean, W.cmvn_istd, W.c1_w, W.c1_b, y1, B, T, F, T1, F1, st);
   launch_ds2_conv2(y1, W.c2_w, W.c2_b, x, B, T1, F1, Tp, F2, W.ldx, st);
@@ -234,7 +240,7 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
     // ---- unidirectional stack: wavefront over (layer, time), Tp + L - 1 dependent launches (k_lstm_wave) ----
     const int L = W.n_layers;
     const Ds2LayerW& L0 = h->ds2_layers[0];
-    launch_dense(x, W.ldx, L0.w_ih, L0.b_sum, gx, M, L0.in_dim_padded, 4 * H, 4 * H, 4 * H, st);
+    launch_dense(x, W.ldx, L0.w_ih, L0.b_sum, gx, M, L0.in_dim_padded, 4 * H, 4 * H, 4 * H, st, 1.0f, part, wl.part_floats);
     float *hbuf = ws + wl.hbuf, *cbuf = ws + wl.cbuf, *yring = ws + wl.yring;
     const size_t BH = (size_t)B * H;
     for (int l = 0; l < L; ++l) {
@@ -255,7 +261,7 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
     }
     const Ds2LayerW& Ll = h->ds2_layers[L - 1];
     launch_ln_wide(out, Ll.ln_g, Ll.ln_b, M, H, st);
-    launch_dense(out, H, W.ctc_w, W.ctc_b, probs, M, H, W.Vpad, W.V, W.V, st);
+    launch_dense(out, H, W.ctc_w, W.ctc_b, probs, M, H, W.Vpad, W.V, W.V, st, 1.0f, part, wl.part_floats);
     launch_softmax_from_stats(probs, nullptr, nullptr, M, W.V, st);
     HIP_TRY(hipGetLastError());
     return PPASR_OK;
@@ -266,7 +272,7 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
     // -> run one GEMM per direction into its own slab
     for (int d = 0; d < dirs; ++d)
       launch_dense(in, in_ld, Lw.w_ih + (size_t)d * (G * H / 32) * (Lw.in_dim_padded / 8) * 64, Lw.b_sum + d * G * H,
-                   gx + (size_t)d * M * G * H, M, Lw.in_dim_padded, G * H, G * H, G * H, st);
+                   gx + (size_t)d * M * G * H, M, Lw.in_dim_padded, G * H, G * H, G * H, st, 1.0f, part, wl.part_floats);
     // initial states
     if (init_h) HIP_TRY(hipMemcpyAsync(h0, init_h + (size_t)l * dirs * B * H, sbytes, hipMemcpyDeviceToDevice, st));
     else HIP_TRY(hipMemsetAsync(h0, 0, sbytes, st));
@@ -292,7 +298,7 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
     in_ld = dirs * H;
     out = (out == ya) ? yb : ya;
   }
-  launch_dense(in, in_ld, W.ctc_w, W.ctc_b, probs, M, dirs * H, W.Vpad, W.V, W.V, st);
+  launch_dense(in, in_ld, W.ctc_w, W.ctc_b, probs, M, dirs * H, W.Vpad, W.V, W.V, st, 1.0f, part, wl.part_floats);
   launch_softmax_from_stats(probs, nullptr, nullptr, M, W.V, st);
   HIP_TRY(hipGetLastError());
   return PPASR_OK;

@@ -112,7 +112,7 @@ void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, i
 void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, bool scale_before_bias,
                   hipStream_t st, const PadSkip& ps = PadSkip{}, int k_slices = 1, float* part = nullptr);
 void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, float* out, int M, int K, int n_cols_padded,
-                  int ldc, int n_valid, hipStream_t st, float scale = 1.0f);  // out = (a W + bias) * scale
+                  int ldc, int n_valid, hipStream_t st, float scale = 1.0f, float* part = nullptr, size_t part_floats = 0);  // out = (a W + bias) * scale
 void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
                     const PadSkip& ps = PadSkip{}, VtOut vt = VtOut{});
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st);

@@ -289,13 +289,45 @@ void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, fl
                        fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD, 0, ps);
 }
 
+// out[m][c] = (sum_z part[z][m][c] + bias[c]) * scale for c < n_valid: the join of launch_dense's K slices (any width)
+__global__ __launch_bounds__(256) void k_dense_join(const float* __restrict__ part, int nz, const float* __restrict__ bias,
+                                                    float scale, float* __restrict__ out, int M, int ldc, int n_valid) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = (n_valid + 3) / 4;
+  if (i >= (size_t)M * per_row) return;
+  const int m = (int)(i / per_row), c = 4 * (int)(i - (size_t)m * per_row);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < nz; ++z)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < n_valid) acc[e] += part[((size_t)z * M + m) * ldc + c + e];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (c + e < n_valid) out[(size_t)m * ldc + c + e] = (acc[e] + bias[c + e]) * scale;
+}
+
 // out[M][ldc] (columns < n_valid) = A[M][K] * Wpacked + bias ; K % 256 == 0 ; weights / bias padded to a multiple of
-// 256 columns.  Used by the DeepSpeech2 path (LSTM input projections, CTC head).
+// 256 columns.  Used by the DeepSpeech2 path (LSTM input projections, CTC head) and the generic-width route.
+// Under-filled launches (few rows: one utterance): with a scratch buffer `part` of >= k_slices * M * ldc floats the K
+// contraction is cut over up to 8 workgroups per tile (partial sums joined by k_dense_join), like the embed GEMM.
 void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, float* out, int M, int K, int n_cols_padded,
-                  int ldc, int n_valid, hipStream_t st, float scale) {
+                  int ldc, int n_valid, hipStream_t st, float scale, float* part, size_t part_floats) {
   constexpr int MT = 1, KC = 256;
   DenseSrc src{a, lda, KC};
   size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
+  const int tiles = ((M + 31) / 32) * (n_cols_padded / 256), n_kc = K / KC;
+  int S = 1;
+  if (part && tiles <= 128) {
+    S = 8;
+    while (S > 1 && (tiles * S > 256 || n_kc % S != 0 || (size_t)S * M * ldc > part_floats)) S >>= 1;
+  }
+  if (S > 1) {
+    PPASR_LAUNCH((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, n_cols_padded / 256, S), dim3(kThreads),
+                 lds, st, src, w, bias, part, M, n_kc, scale, ldc, n_valid, 0, PadSkip{});
+    const size_t n4 = (size_t)M * ((n_valid + 3) / 4);
+    PPASR_LAUNCH(k_dense_join, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, S, bias, scale, out, M, ldc, n_valid);
+    return;
+  }
   PPASR_LAUNCH((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, n_cols_padded / 256),
                      dim3(kThreads), lds, st, src, w, bias, out, M, K / KC, scale, ldc, n_valid, 0, PadSkip{});
 }

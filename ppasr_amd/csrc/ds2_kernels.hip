@@ -99,7 +99,10 @@ __global__ __launch_bounds__(256) void k_lstm_step(const float* __restrict__ gx,
   const int r = tid >> 4, part = tid & 15;  // r = gate*4 + unit ; 16 threads per row
   const int gate = r >> 2, unit = r & 3;
   const int per = H / 16;                  // elements per thread (64 for H = 1024)
-  const float* wrow = whh + ((size_t)dir * 4 * H + (size_t)gate * H + j0 + unit) * H + part * per;
+  // the 16 threads of a row read it INTERLEAVED (thread `part` takes the float4s part, part + 16, ...): one load
+  // instruction of the group covers 256 contiguous bytes = two whole cache lines.  (With a contiguous 256-byte slice per
+  // thread every lane touched its own line and took 16 bytes of it per instruction, 64 lines in flight per wave.)
+  const float* wrow = whh + ((size_t)dir * 4 * H + (size_t)gate * H + j0 + unit) * H + part * 4;
   const float* hp = hprev + (size_t)dir * B * H;
   float* hn = hnext + (size_t)dir * B * H;
   float* cc = c + (size_t)dir * B * H;
@@ -115,8 +118,8 @@ __global__ __launch_bounds__(256) void k_lstm_step(const float* __restrict__ gx,
     __syncthreads();
     float acc = 0.f;
     for (int k = 0; k < per; k += 4) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + k);
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(hs + part * per + k);
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + 16 * k);
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(hs + part * 4 + 16 * k);
       acc = fmaf(wv[0], hv[0], acc);
       acc = fmaf(wv[1], hv[1], acc);
       acc = fmaf(wv[2], hv[2], acc);
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void k_gru_step(const float* __restrict__ gx, 
   const int gate = r >> 2, unit = r & 3;
   const int per = H / 16;
   const bool live_row = r < 12;
-  const float* wrow = whh + ((size_t)dir * 3 * H + (size_t)(live_row ? gate : 0) * H + j0 + unit) * H + part * per;
+  const float* wrow = whh + ((size_t)dir * 3 * H + (size_t)(live_row ? gate : 0) * H + j0 + unit) * H + part * 4;  // (interleaved, see k_lstm_step)
   const float* hp = hprev + (size_t)dir * B * H;
   float* hn = hnext + (size_t)dir * B * H;
   const float* gxd = gx + (size_t)dir * B * T * 3 * H;
@@ -176,8 +179,8 @@ __global__ __launch_bounds__(256) void k_gru_step(const float* __restrict__ gx, 
     float acc = 0.f;
     if (live_row) {
       for (int k = 0; k < per; k += 4) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + k);
-        const f32x4 hv = *reinterpret_cast<const f32x4*>(hs + part * per + k);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + 16 * k);
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(hs + part * 4 + 16 * k);
         acc = fmaf(wv[0], hv[0], acc);
         acc = fmaf(wv[1], hv[1], acc);
         acc = fmaf(wv[2], hv[2], acc);
