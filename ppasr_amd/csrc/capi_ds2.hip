@@ -190,9 +190,10 @@ static Ds2Ws ds2_ws(const ppasr_model_s* m, int B, int T) {
   w.c = o; o += al64((size_t)W.dirs * B * W.H);
   w.lens32 = o; o += al64(B);
   // wavefront path (unidirectional models): per-layer state / output rings
-  w.hbuf = o; o += al64((size_t)W.n_layers * 2 * B * W.H);
+  const size_t Bp = (size_t)(B + 31) / 32 * 32;  // (fragment-ordered buffers hold whole 32-row tiles)
+  w.hbuf = o; o += al64((size_t)W.n_layers * 2 * Bp * W.H);
   w.cbuf = o; o += al64((size_t)W.n_layers * B * W.H);
-  w.yring = o; o += al64((size_t)W.n_layers * 2 * B * W.H);
+  w.yring = o; o += al64((size_t)W.n_layers * 2 * Bp * W.H);
   // K-slice partial sums of the dense layers when the launch is under-filled (few frames: single utterances)
   w.part_floats = M <= 512 ? (size_t)8 * M * std::max((size_t)W.gates * W.H, (size_t)W.Vpad) : 0;
   w.part = o; o += al64(w.part_floats);
@@ -242,11 +243,11 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
     const Ds2LayerW& L0 = h->ds2_layers[0];
     launch_dense(x, W.ldx, L0.w_ih, L0.b_sum, gx, M, L0.in_dim_padded, 4 * H, 4 * H, 4 * H, st, 1.0f, part, wl.part_floats);
     float *hbuf = ws + wl.hbuf, *cbuf = ws + wl.cbuf, *yring = ws + wl.yring;
-    const size_t BH = (size_t)B * H;
+    const size_t BH = (size_t)B * H, BHp = (size_t)((B + 31) / 32) * 32 * H;  // row-major box / fragment-ordered slot
     for (int l = 0; l < L; ++l) {
-      float* h_l = hbuf + (size_t)l * 2 * BH;  // slot 0 = state before time 0
-      if (init_h) HIP_TRY(hipMemcpyAsync(h_l, init_h + (size_t)l * BH, BH * sizeof(float), hipMemcpyDeviceToDevice, st));
-      else HIP_TRY(hipMemsetAsync(h_l, 0, BH * sizeof(float), st));
+      float* h_l = hbuf + (size_t)l * 2 * BHp;  // slot 0 = state before time 0 (fragment order, ds2_kernels.hip)
+      HIP_TRY(hipMemsetAsync(h_l, 0, BHp * sizeof(float), st));
+      if (init_h) launch_state_reorder(init_h + (size_t)l * BH, h_l, B, H, true, st);
       if (init_c) HIP_TRY(hipMemcpyAsync(cbuf + (size_t)l * BH, init_c + (size_t)l * BH, BH * sizeof(float), hipMemcpyDeviceToDevice, st));
       else HIP_TRY(hipMemsetAsync(cbuf + (size_t)l * BH, 0, BH * sizeof(float), st));
     }
@@ -256,7 +257,7 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
       launch_lstm_wave(gx, W.wave_tab, hbuf, cbuf, yring, out, lens32, B, Tp, H, L, s, l_lo, l_hi - l_lo + 1, st);
     }
     for (int l = 0; l < L; ++l) {
-      if (final_h) HIP_TRY(hipMemcpyAsync(final_h + (size_t)l * BH, hbuf + ((size_t)l * 2 + (Tp & 1)) * BH, BH * sizeof(float), hipMemcpyDeviceToDevice, st));
+      if (final_h) launch_state_reorder(hbuf + ((size_t)l * 2 + (Tp & 1)) * BHp, final_h + (size_t)l * BH, B, H, false, st);
       if (final_c) HIP_TRY(hipMemcpyAsync(final_c + (size_t)l * BH, cbuf + (size_t)l * BH, BH * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     const Ds2LayerW& Ll = h->ds2_layers[L - 1];

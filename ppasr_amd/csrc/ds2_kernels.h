@@ -57,6 +57,8 @@ void launch_gru_step_mfma(const float* gx, const f32x4* whh_pk, const float* bhh
 //   yring [L][2][B][H] raw outputs of the last two time steps, out [B*T][H] raw outputs of the last layer (pre-zeroed)
 void launch_lstm_wave(const float* gx0, const Ds2WaveLayer* tab, float* hbuf, float* cbuf, float* yring, float* out,
                       const int32_t* lens, int B, int T, int H, int L, int s, int l_lo, int n_l, hipStream_t st);
+// [B][H] row-major <-> the MFMA-fragment order of the wavefront kernel's state buffers (hbuf / yring)
+void launch_state_reorder(const float* src, float* dst, int B, int H, bool to_frag, hipStream_t st);
 void launch_ln_wide(float* x, const float* g, const float* b, int M, int N, hipStream_t st);
 
 }  // namespace ppasr

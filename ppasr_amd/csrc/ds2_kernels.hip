@@ -321,7 +321,15 @@ __global__ __launch_bounds__(kThreads) void k_lstm_step_mfma(const float* __rest
 // so the MFMA runs on the RAW previous-layer output y_{l-1}[t] (a second accumulator tile next to h_{t-1} W_hh^T) and
 // the LayerNorm of the row enters through its mean / rstd, which the waves accumulate from the very A fragments they
 // load (sum and sum of squares per row).  Same workgroup shape as k_lstm_step_mfma.
-__global__ __launch_bounds__(kThreads) void k_lstm_wave(const float* __restrict__ gx0, const Ds2WaveLayer* __restrict__ tab,
+// Occupancy: at 152 VGPRs (prefetch depth 8) ONE workgroup fits a CU and the 5 x 128 workgroups of a launch ran as 2.5
+// rounds; capped at 3 workgroups per CU (depth 4) the launch is one round: 6.57 -> 5.70 ms per 32 x 5 s batch (round 3).
+#ifndef PPASR_WAVE_OCC
+#define PPASR_WAVE_OCC 3
+#endif
+#ifndef PPASR_WAVE_PFD
+#define PPASR_WAVE_PFD 4
+#endif
+__global__ __launch_bounds__(kThreads, PPASR_WAVE_OCC) void k_lstm_wave(const float* __restrict__ gx0, const Ds2WaveLayer* __restrict__ tab,
                                                         float* __restrict__ hbuf, float* __restrict__ cbuf,
                                                         float* __restrict__ yring, float* __restrict__ out,
                                                         const int32_t* __restrict__ lens, int B, int T, int H, int L, int s,
@@ -340,25 +348,28 @@ __global__ __launch_bounds__(kThreads) void k_lstm_wave(const float* __restrict_
   const int n_groups = H / 8, gpw = n_groups / kWaves, g0 = wave * gpw;
   const int b = b0 + l31;
   const bool row_live = b < B && t < lens[min(b, B - 1)];
-  const size_t BH = (size_t)B * H;
+  // hbuf / yring hold the states and layer outputs in MFMA FRAGMENT order -- [row tile z][k-group][64 lanes = row + 32 *
+  // (k quad)][4 k] -- so that a wave's A-operand load is 1 KiB contiguous like its weight load (row-major, every lane of a
+  // load touched its own 4 KiB-strided row: 32 cache lines per instruction, 64 such instructions per wave and launch)
+  const size_t BH = (size_t)((B + 31) / 32) * 32 * H;
   const float* hprev = hbuf + ((size_t)l * 2 + (t & 1)) * BH;
   float* hnext = hbuf + ((size_t)l * 2 + ((t + 1) & 1)) * BH;
-  float* cc = cbuf + (size_t)l * BH;
+  float* cc = cbuf + (size_t)l * B * H;  // (the cell state stays row-major: it is only read and written element-wise)
   const float* yprev = l > 0 ? yring + ((size_t)(l - 1) * 2 + (t & 1)) * BH : nullptr;
   float* ycur = yring + ((size_t)l * 2 + (t & 1)) * BH;
-  const size_t rowoff = (size_t)min(b, B - 1) * H + 4 * hh;
+  const size_t fragoff = (size_t)blockIdx.z * n_groups * 256 + (size_t)lane * 4;  // + 256 * k-group
   const f32x4* wh = lay.whh_pk + (size_t)tile * n_groups * 64 + lane;
   const f32x4* wi = lay.wih_pk + (size_t)tile * n_groups * 64 + lane;
   f32x16 acc_h, acc_i;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc_h[r] = acc_i[r] = 0.f;
-  constexpr int PFD = 8;
+  constexpr int PFD = PPASR_WAVE_PFD;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   {  // ---- h_{t-1} W_hh^T ----
     f32x4 ra[PFD], rb[PFD];
 #pragma unroll
     for (int q = 0; q < PFD; ++q) {
-      ra[q] = row_live ? *reinterpret_cast<const f32x4*>(hprev + rowoff + 8 * (g0 + q)) : zero4;
+      ra[q] = row_live ? *reinterpret_cast<const f32x4*>(hprev + fragoff + 256 * (size_t)(g0 + q)) : zero4;
       rb[q] = wh[(size_t)(g0 + q) * 64];
     }
     for (int g = 0; g < gpw; g += PFD) {
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(kThreads) void k_lstm_wave(const float* __restrict_
       for (int q = 0; q < PFD; ++q) {
         const f32x4 a = ra[q], bq = rb[q];
         if (g + PFD + q < gpw) {
-          ra[q] = row_live ? *reinterpret_cast<const f32x4*>(hprev + rowoff + 8 * (g0 + g + PFD + q)) : zero4;
+          ra[q] = row_live ? *reinterpret_cast<const f32x4*>(hprev + fragoff + 256 * (size_t)(g0 + g + PFD + q)) : zero4;
           rb[q] = wh[(size_t)(g0 + g + PFD + q) * 64];
         }
 #pragma unroll
@@ -379,7 +390,7 @@ __global__ __launch_bounds__(kThreads) void k_lstm_wave(const float* __restrict_
     f32x4 ra[PFD], rb[PFD];
 #pragma unroll
     for (int q = 0; q < PFD; ++q) {
-      ra[q] = row_live ? *reinterpret_cast<const f32x4*>(yprev + rowoff + 8 * (g0 + q)) : zero4;
+      ra[q] = row_live ? *reinterpret_cast<const f32x4*>(yprev + fragoff + 256 * (size_t)(g0 + q)) : zero4;
       rb[q] = wi[(size_t)(g0 + q) * 64];
     }
     for (int g = 0; g < gpw; g += PFD) {
@@ -387,7 +398,7 @@ __global__ __launch_bounds__(kThreads) void k_lstm_wave(const float* __restrict_
       for (int q = 0; q < PFD; ++q) {
         const f32x4 a = ra[q], bq = rb[q];
         if (g + PFD + q < gpw) {
-          ra[q] = row_live ? *reinterpret_cast<const f32x4*>(yprev + rowoff + 8 * (g0 + g + PFD + q)) : zero4;
+          ra[q] = row_live ? *reinterpret_cast<const f32x4*>(yprev + fragoff + 256 * (size_t)(g0 + g + PFD + q)) : zero4;
           rb[q] = wi[(size_t)(g0 + g + PFD + q) * 64];
         }
         sum += a[0] + a[1] + a[2] + a[3];
@@ -454,9 +465,10 @@ __global__ __launch_bounds__(kThreads) void k_lstm_wave(const float* __restrict_
     const int bb = b0 + row;
     if (bb < B) {
       const int len = lens[bb];
-      const size_t si = (size_t)bb * H + tile * 8 + u;
+      const size_t si = (size_t)bb * H + tile * 8 + u;                                     // row-major (cell state)
+      const size_t fi = ((size_t)blockIdx.z * n_groups + tile) * 256 + (row + 32 * (u >> 2)) * 4 + (u & 3);  // fragment order
       if (t >= len) {
-        hnext[si] = hprev[si];  // finished utterance: carry the state (final state = last valid step)
+        hnext[fi] = hprev[fi];  // finished utterance: carry the state (final state = last valid step)
       } else {
         const float gi = 1.0f / (1.0f + expf(-gates[row][0 + u]));
         const float gf = 1.0f / (1.0f + expf(-gates[row][8 + u]));
@@ -465,8 +477,8 @@ __global__ __launch_bounds__(kThreads) void k_lstm_wave(const float* __restrict_
         const float cn = gf * cc[si] + gi * gg;
         const float hv = go * tanhf(cn);
         cc[si] = cn;
-        hnext[si] = hv;
-        ycur[si] = hv;
+        hnext[fi] = hv;
+        ycur[fi] = hv;
         if (l == L - 1) out[((size_t)bb * T + t) * (size_t)H + tile * 8 + u] = hv;
       }
     }
@@ -535,6 +547,19 @@ void launch_lstm_wave(const float* gx0, const Ds2WaveLayer* tab, float* hbuf, fl
                       const int32_t* lens, int B, int T, int H, int L, int s, int l_lo, int n_l, hipStream_t st) {
   PPASR_LAUNCH(k_lstm_wave, dim3(H / 8, n_l, (B + 31) / 32), dim3(kThreads), 0, st, gx0, tab, hbuf, cbuf, yring, out, lens,
                      B, T, H, L, s, l_lo);
+}
+// [B][H] row-major <-> the fragment order of k_lstm_wave's state buffers (initial / final state boxes)
+__global__ __launch_bounds__(256) void k_state_reorder(const float* __restrict__ src, float* __restrict__ dst, int B, int H,
+                                                       int to_frag) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)B * H) return;
+  const int bb = (int)(i / H), k = (int)(i - (size_t)bb * H);
+  const size_t fi = ((size_t)(bb >> 5) * (H / 8) + (k >> 3)) * 256 + ((bb & 31) + 32 * ((k & 7) >> 2)) * 4 + (k & 3);
+  if (to_frag) dst[fi] = src[i];
+  else dst[i] = src[fi];
+}
+void launch_state_reorder(const float* src, float* dst, int B, int H, bool to_frag, hipStream_t st) {
+  PPASR_LAUNCH(k_state_reorder, dim3((unsigned)(((size_t)B * H + 255) / 256)), dim3(256), 0, st, src, dst, B, H, to_frag ? 1 : 0);
 }
 void launch_ln_wide(float* x, const float* g, const float* b, int M, int N, hipStream_t st) {
   PPASR_LAUNCH(k_ln_wide, dim3((M + 3) / 4), dim3(256), 0, st, x, g, b, M, N);
