@@ -76,9 +76,30 @@ typedef struct {
      0 = conv2d (Conv2dSubsampling4: 3x3/2, 3x3/2), 6 = conv2d6 (Conv2dSubsampling6: 3x3/2, 5x5/3, `embed.linear`),
      8 = conv2d8 (Conv2dSubsampling8: 3x3/2 three times, `embed.linear`).  6 / 8: batched encode and single stream
      handles (no session groups); key-padding / conv pad masks use 6t / 8t < len (the reference's mask slicing) */
-  int input_layer;
-  int reserved[1];
+  int input_layer;        /* 1 = linear (LinearNoSubsampling, subsampling.py:24-65: no time reduction; general route only) */
+  /* Non-default ConformerEncoder constructor arguments (conformer/encoder.py:38-48), PPASR_OPT_* below; 0 = the shipped
+     configuration (rel_pos, normalize_before, macaron_style, use_cnn_module, swish).  Any other value -- like
+     output_size != 256, input_layer = linear or a cnn_module_kernel other than 7 / 15 / 31 -- selects the general layer
+     route (capi_generic.hip: the same packed weights and matrix-core GEMMs, one launch per layer piece instead of the
+     fused 256-wide row-block kernels).  model_type = conformer only. */
+  int options;
 } ppasr_model_desc;
+
+enum {
+  PPASR_OPT_POS_REL = 0,       /* pos_enc_layer_type: rel_pos -> RelPositionMultiHeadedAttention */
+  PPASR_OPT_POS_ABS = 1,       /*   abs_pos: x * sqrt(d) + pe, MultiHeadedAttention (embedding.py:25-84) */
+  PPASR_OPT_POS_NONE = 2,      /*   no_pos: MultiHeadedAttention, x unchanged (embedding.py:10-22) */
+  PPASR_OPT_POS_MASK = 3,
+  PPASR_OPT_POST_NORM = 4,     /* normalize_before = False (encoder.py:380-428; no after_norm) */
+  PPASR_OPT_CONCAT_AFTER = 8,  /* concat_after = True: x + concat_linear([x | att(x)]) (encoder.py:395-397) */
+  PPASR_OPT_NO_MACARON = 16,   /* macaron_style = False: no feed_forward_macaron, ff_scale 1 (encoder.py:330-334) */
+  PPASR_OPT_NO_CNN = 32,       /* use_cnn_module = False: no conv module, no norm_final */
+  PPASR_OPT_ACT_SHIFT = 8,     /* activation_type (utils/common.py:189-206) in bits 8..11: */
+  PPASR_OPT_ACT_MASK = 15
+};
+enum { PPASR_ACT_SWISH = 0, PPASR_ACT_RELU = 1, PPASR_ACT_GELU = 2, PPASR_ACT_TANH = 3, PPASR_ACT_HARDTANH = 4,
+       PPASR_ACT_RELU6 = 5, PPASR_ACT_LEAKYRELU = 6, PPASR_ACT_SELU = 7, PPASR_ACT_ELU = 8, PPASR_ACT_HARDSWISH = 9,
+       PPASR_ACT_HARDSHRINK = 10 };
 
 const char* ppasr_last_error(void);
 const char* ppasr_version(void);

@@ -23,6 +23,8 @@ PPASR_MODEL_EFFICIENT_CONFORMER = 1
 PPASR_MODEL_SQUEEZEFORMER = 2
 PPASR_MODEL_DEEPSPEECH2 = 3
 N_KERNEL_CLASSES = 10
+# ppasr_model_desc::options (include/ppasr_hip.h)
+PPASR_OPT_POST_NORM, PPASR_OPT_CONCAT_AFTER, PPASR_OPT_NO_MACARON, PPASR_OPT_NO_CNN, PPASR_OPT_ACT_SHIFT = 4, 8, 16, 32, 8
 KPROF_NAME_LEN = 160
 
 
@@ -37,7 +39,7 @@ class ModelDesc(ctypes.Structure):
                 ("num_blocks", ctypes.c_int), ("cnn_module_kernel", ctypes.c_int), ("causal", ctypes.c_int),
                 ("max_len", ctypes.c_int), ("reduce_idx", ctypes.c_int), ("recover_idx", ctypes.c_int),
                 ("stride_layer_idx", ctypes.c_int), ("group_layer_mask", ctypes.c_int), ("group_size", ctypes.c_int),
-                ("use_gru", ctypes.c_int), ("input_layer", ctypes.c_int), ("reserved", ctypes.c_int * 1)]
+                ("use_gru", ctypes.c_int), ("input_layer", ctypes.c_int), ("options", ctypes.c_int)]
 
 
 # every symbol include/ppasr_hip.h declares: (name, restype, argtypes)

@@ -72,20 +72,35 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
     if (desc->stride_layer_idx >= 0 && desc->cnn_module_kernel != 15)
       return fail(PPASR_EUNSUPPORTED, "efficient_conformer: cnn_module_kernel must be 15 (7 after the stride layer)");
   }
-  // output_size 256 (4 heads of 64): the fused row-block kernels.  Other multiples of 256 up to 1024 (512 with 8 heads):
-  // the generic-width route of capi_generic.hip -- Conformer, conv2d front end, batched encode only.
+  // output_size 256 (4 heads of 64) with the shipped constructor arguments: the fused row-block kernels.  Other multiples
+  // of 256 up to 1024, non-default ConformerEncoder options (ppasr_model_desc::options), input_layer = linear or another
+  // conv kernel size: the general layer route of capi_generic.hip (model_type = conformer).
   if (desc->output_size % 256 != 0 || desc->output_size < 256 || desc->output_size > 1024)
     return fail(PPASR_EUNSUPPORTED, "output_size must be 256, 512, 768 or 1024");
   if (desc->attention_heads * 64 != desc->output_size) return fail(PPASR_EUNSUPPORTED, "kernels are specialised for d_k=64");
-  if (desc->output_size != kD && (desc->model_type != PPASR_MODEL_CONFORMER || desc->input_layer != 0))
-    return fail(PPASR_EUNSUPPORTED, "output_size != 256 is built for model_type=conformer with the conv2d front end");
+  const bool fused_ks = desc->cnn_module_kernel == 15 || desc->cnn_module_kernel == 31 || desc->cnn_module_kernel == 7;
+  const bool generic = desc->model_type == PPASR_MODEL_CONFORMER &&
+                       (desc->output_size != kD || desc->options != 0 || desc->input_layer == 1 || !fused_ks);
+  if (desc->output_size != kD && desc->model_type != PPASR_MODEL_CONFORMER)
+    return fail(PPASR_EUNSUPPORTED, "output_size != 256 is built for model_type=conformer");
+  if ((desc->options != 0 || desc->input_layer == 1) && desc->model_type != PPASR_MODEL_CONFORMER)
+    return fail(PPASR_EUNSUPPORTED, "non-default encoder options / input_layer=linear are built for model_type=conformer");
   if (desc->linear_units % 256 != 0 || desc->linear_units <= 0) return fail(PPASR_EUNSUPPORTED, "linear_units % 256 != 0");
-  if (desc->cnn_module_kernel != 15 && desc->cnn_module_kernel != 31 && desc->cnn_module_kernel != 7)
-    return fail(PPASR_EUNSUPPORTED, "cnn_module_kernel must be 7, 15 or 31");
+  if (!generic && !fused_ks) return fail(PPASR_EUNSUPPORTED, "cnn_module_kernel must be 7, 15 or 31");
+  if (generic) {
+    const int ks = desc->cnn_module_kernel;
+    const bool use_cnn = !(desc->options & PPASR_OPT_NO_CNN);
+    if (use_cnn && (ks < 1 || ks > 255 || (!desc->causal && ks % 2 == 0)))
+      return fail(PPASR_EINVAL, "cnn_module_kernel: 1..255, odd for the non-causal conv module (convolution.py:38)");
+    if ((desc->options & PPASR_OPT_POS_MASK) == 3 || ((desc->options >> PPASR_OPT_ACT_SHIFT) & PPASR_OPT_ACT_MASK) > PPASR_ACT_HARDSHRINK)
+      return fail(PPASR_EINVAL, "options: unknown pos_enc_layer_type / activation_type code");
+  }
   if (desc->model_type == PPASR_MODEL_SQUEEZEFORMER && desc->cnn_module_kernel == 7)
     return fail(PPASR_EUNSUPPORTED, "squeezeformer: cnn_module_kernel must be 15 or 31");
-  if (desc->input_dim > 128 || desc->input_dim < 7) return fail(PPASR_EUNSUPPORTED, "input_dim out of range");
+  if (desc->input_dim > 128 || (desc->input_dim < 7 && desc->input_layer != 1) || desc->input_dim < 1)
+    return fail(PPASR_EUNSUPPORTED, "input_dim out of range");
   HIP_TRY(configure_kernels());
+  HIP_TRY(configure_generic_kernels());
   HIP_TRY(configure_squeezeformer_kernels());
 
   BlobMap sd;
@@ -112,13 +127,22 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
   m->desc = *desc;
   const int F = desc->input_dim, d = desc->output_size, H = desc->linear_units, V = desc->vocab_size, KS = desc->cnn_module_kernel;
   const int il = desc->input_layer;
-  if (il != 0 && il != 6 && il != 8) return fail(PPASR_EINVAL, "input_layer: 0 (conv2d), 6 (conv2d6) or 8 (conv2d8)");
+  if (il != 0 && il != 1 && il != 6 && il != 8)
+    return fail(PPASR_EINVAL, "input_layer: 0 (conv2d), 1 (linear), 6 (conv2d6) or 8 (conv2d8)");
+  m->generic = generic;
+  m->gen.pos = desc->options & PPASR_OPT_POS_MASK;
+  m->gen.post_norm = (desc->options & PPASR_OPT_POST_NORM) != 0;
+  m->gen.concat_after = (desc->options & PPASR_OPT_CONCAT_AFTER) != 0;
+  m->gen.macaron = !(desc->options & PPASR_OPT_NO_MACARON);
+  m->gen.use_cnn = !(desc->options & PPASR_OPT_NO_CNN);
+  m->gen.act = (desc->options >> PPASR_OPT_ACT_SHIFT) & PPASR_OPT_ACT_MASK;
+  const auto& go = m->gen;
   if (il != 0 && desc->model_type == PPASR_MODEL_SQUEEZEFORMER)
     return fail(PPASR_EUNSUPPORTED, "squeezeformer: only the conv2d front end is built");
   m->F1 = (F - 1) / 2;
   m->F2 = il == 6 ? (m->F1 - 5) / 3 + 1 : (m->F1 - 1) / 2;
   m->F3 = il == 8 ? (m->F2 - 1) / 2 : 0;
-  if (m->F_last() < 1) return fail(PPASR_EINVAL, "input_dim too small for this input_layer");
+  if (il != 1 && m->F_last() < 1) return fail(PPASR_EINVAL, "input_dim too small for this input_layer");
   const int F2 = m->F_last();  // feature bins entering the linear layer
   ppasr_status st;
 #define UP(vec, dst) \
@@ -135,7 +159,23 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
     *out = guard.release();
     return PPASR_OK;
   }
-  {  // ---- front end ----
+  if (il == 1) {  // ---- LinearNoSubsampling (subsampling.py:24-65): out.0 = Linear(idim, odim), out.1 = LayerNorm(eps 1e-12), ReLU ----
+    GET(mean, "encoder.global_cmvn.mean", F);
+    GET(istd, "encoder.global_cmvn.istd", F);
+    GET(ew, "encoder.embed.out.0.weight", (size_t)F * d);
+    GET(eb, "encoder.embed.out.0.bias", d);
+    GET(lg, "encoder.embed.out.1.weight", d);
+    GET(lb, "encoder.embed.out.1.bias", d);
+    UP(vec_of(mean, F), m->front.cmvn_mean);
+    UP(vec_of(istd, F), m->front.cmvn_istd);
+    m->lin_kpad = (F + 255) / 256 * 256;  // the feature rows are zero-padded to whole K chunks (k_g_cmvn_pad)
+    UP4(pack_b(m->lin_kpad, d, [&](int k, int n) { return k < F ? ew[(size_t)k * d + n] : 0.f; }), m->front.embed_w);
+    UP(vec_of(eb, d), m->front.embed_b);
+    UP(vec_of(lg, d), m->lin_ln_g);
+    UP(vec_of(lb, d), m->lin_ln_b);
+    m->front.conv1_w = m->front.conv1_b = m->front.conv2_b = nullptr;
+    m->front.conv2_w = nullptr;
+  } else {  // ---- conv front ends ----
     GET(mean, "encoder.global_cmvn.mean", F);
     GET(istd, "encoder.global_cmvn.istd", F);
     GET(c1w, "encoder.embed.conv.0.weight", d * 9);
@@ -175,6 +215,9 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
 
   const float* pe_dev = nullptr;
   if ((st = upload_pe_table(m, sd, &pe_dev)) != PPASR_OK) return st;
+  m->pe_dev = pe_dev;
+  UP(std::vector<float>(d, 0.f), m->zero_vec);
+  if (generic) m->gen_x.resize(desc->num_blocks);
   const int max_len = m->desc.max_len;
   m->layers.resize(desc->num_blocks);
   m->layer_ks.assign(desc->num_blocks, KS);
@@ -196,16 +239,19 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
       if (s1 != PPASR_OK) return s1;
       return m->upload(vec_of(gb, d), b);
     };
-    if ((st = ln("norm_ff_macaron", &L.ln_mac_g, &L.ln_mac_b)) != PPASR_OK) return st;
+    L = LayerW{};
+    // (encoder.py:327-336: norm_ff_macaron exists with the macaron half only, norm_conv / norm_final with the conv module only)
+    if (go.macaron && (st = ln("norm_ff_macaron", &L.ln_mac_g, &L.ln_mac_b)) != PPASR_OK) return st;
     if ((st = ln("norm_mha", &L.ln_mha_g, &L.ln_mha_b)) != PPASR_OK) return st;
-    if ((st = ln("norm_conv", &L.ln_conv_g, &L.ln_conv_b)) != PPASR_OK) return st;
+    if (go.use_cnn && (st = ln("norm_conv", &L.ln_conv_g, &L.ln_conv_b)) != PPASR_OK) return st;
     if ((st = ln("norm_ff", &L.ln_ff_g, &L.ln_ff_b)) != PPASR_OK) return st;
-    if ((st = ln("norm_final", &L.ln_fin_g, &L.ln_fin_b)) != PPASR_OK) return st;
+    if (go.use_cnn && (st = ln("norm_final", &L.ln_fin_g, &L.ln_fin_b)) != PPASR_OK) return st;
     // ConvolutionModule.norm (convolution.py:65-71): nn.LayerNorm, or nn.BatchNorm1D (cnn_module_norm: batch_norm), which
     // at inference is the per-channel affine y = (x - _mean) / sqrt(_variance + 1e-5) * weight + bias: folded here into
     // scale / shift vectors in the LayerNorm slots, marked by cm_eps < 0 (ln_rows_inreg then skips the row statistics)
     L.cm_eps = 1e-5f;
-    if (sd.find(p + "conv_module.norm._mean") != sd.end()) {
+    if (!go.use_cnn) {
+    } else if (sd.find(p + "conv_module.norm._mean") != sd.end()) {
       const float* mean = get(p + "conv_module.norm._mean", d);
       const float* var = get(p + "conv_module.norm._variance", d);
       const float* gw = get(p + "conv_module.norm.weight", d);
@@ -234,7 +280,7 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
       if ((s = m->upload4(pack_b(H, d, [&](int k, int nn) { return a2[(size_t)k * d + nn]; }), w2)) != PPASR_OK) return s;
       return m->upload(vec_of(c2, d), b2);
     };
-    if ((st = ffn("feed_forward_macaron", &L.ffm_w1, &L.ffm_b1, &L.ffm_w2, &L.ffm_b2)) != PPASR_OK) return st;
+    if (go.macaron && (st = ffn("feed_forward_macaron", &L.ffm_w1, &L.ffm_b1, &L.ffm_w2, &L.ffm_b2)) != PPASR_OK) return st;
     if ((st = ffn("feed_forward", &L.ff_w1, &L.ff_b1, &L.ff_w2, &L.ff_b2)) != PPASR_OK) return st;
     {
       GET(wq, p + "self_attn.linear_q.weight", d * d);
@@ -245,9 +291,14 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
       GET(bv, p + "self_attn.linear_v.bias", d);
       GET(wo, p + "self_attn.linear_out.weight", d * d);
       GET(bo, p + "self_attn.linear_out.bias", d);
-      GET(wp, p + "self_attn.linear_pos.weight", d * d);
-      GET(pu, p + "self_attn.pos_bias_u", pbn);
-      GET(pv, p + "self_attn.pos_bias_v", pbn);
+      const bool rel = go.pos == PPASR_OPT_POS_REL;  // MultiHeadedAttention (abs_pos / no_pos) has no positional parameters
+      const float *wp = nullptr, *pu = nullptr, *pv = nullptr;
+      if (rel) {
+        wp = get(p + "self_attn.linear_pos.weight", (size_t)d * d);
+        pu = get(p + "self_attn.pos_bias_u", pbn);
+        pv = get(p + "self_attn.pos_bias_v", pbn);
+        if (!wp || !pu || !pv) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + missing);
+      }
       const float* bp = nullptr;  // linear_pos has a bias only in GroupedRelPositionMultiHeadedAttention
       if (grouped) {
         bp = get(p + "self_attn.linear_pos.bias", d);
@@ -262,20 +313,30 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
       UP(bqkv, L.bqkv);
       UP4(pack_b(d, d, [&](int k, int n) { return wo[(size_t)k * d + n]; }), L.wo);
       UP(vec_of(bo, d), L.bo);
-      UP(vec_of(pu, pbn), L.pos_u);
-      UP(vec_of(pv, pbn), L.pos_v);
-      const float* bpos_dev = nullptr;
-      if (bp) UP(vec_of(bp, d), bpos_dev);
-      const float* wpos_dev = nullptr;
-      UP(vec_of(wp, (size_t)d * d), wpos_dev);
-      void* pt = nullptr;
-      HIP_TRY(hipMalloc(&pt, (size_t)max_len * d * sizeof(float)));
-      m->allocs.push_back(pt);
-      launch_posproj(pe_dev, wpos_dev, bpos_dev, static_cast<float*>(pt), max_len, nullptr, d);
-      HIP_TRY(hipGetLastError());
-      L.ptab = static_cast<const float*>(pt);
+      if (rel) {
+        UP(vec_of(pu, pbn), L.pos_u);
+        UP(vec_of(pv, pbn), L.pos_v);
+        const float* bpos_dev = nullptr;
+        if (bp) UP(vec_of(bp, d), bpos_dev);
+        const float* wpos_dev = nullptr;
+        UP(vec_of(wp, (size_t)d * d), wpos_dev);
+        void* pt = nullptr;
+        HIP_TRY(hipMalloc(&pt, (size_t)max_len * d * sizeof(float)));
+        m->allocs.push_back(pt);
+        launch_posproj(pe_dev, wpos_dev, bpos_dev, static_cast<float*>(pt), max_len, nullptr, d);
+        HIP_TRY(hipGetLastError());
+        L.ptab = static_cast<const float*>(pt);
+      } else {  // the attention kernel's positional half contracts with zeros (capi_generic.hip)
+        L.pos_u = L.pos_v = L.ptab = m->zero_vec;
+      }
+      if (go.concat_after) {  // concat_linear = Linear(2 size, size) (encoder.py:341-342)
+        GET(wc, p + "concat_linear.weight", (size_t)2 * d * d);
+        GET(bc, p + "concat_linear.bias", d);
+        UP4(pack_b(2 * d, d, [&](int k, int n) { return wc[(size_t)k * d + n]; }), m->gen_x[i].wcat);
+        UP(vec_of(bc, d), m->gen_x[i].bcat);
+      }
     }
-    {
+    if (go.use_cnn) {
       GET(p1w, p + "conv_module.pointwise_conv1.weight", 2 * d * d);
       GET(p1b, p + "conv_module.pointwise_conv1.bias", 2 * d);
       GET(dww, p + "conv_module.depthwise_conv.weight", d * KSi);
@@ -310,7 +371,7 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
     std::vector<float> cbp((size_t)m->head.n_tiles * 32, 0.f);
     std::memcpy(cbp.data(), cb, V * sizeof(float));
     UP(cbp, m->head.b);
-    if (d != kD) {  // generic-width route: the head as a plain dense layer, vocabulary padded to whole 256-column blocks
+    if (generic) {  // general route: the head as a plain dense layer, vocabulary padded to whole 256-column blocks
       m->gen_vpad = (V + 255) / 256 * 256;
       const int Vp = m->gen_vpad;
       UP4(pack_b(d, Vp, [&](int k, int n) { return n < V ? cw[(size_t)k * V + n] : 0.f; }), m->gen_head_w);
@@ -342,7 +403,7 @@ int ppasr_out_frames(ppasr_handle h, int T) {
 
 }  // extern "C"
 WsLayout ws_layout(const ppasr_model_s* m, int B, int T) {
-  if (m->desc.output_size != kD && m->desc.model_type == PPASR_MODEL_CONFORMER) {
+  if (m->generic) {
     WsLayout g{};
     g.total = generic_ws_floats(m, B, T);
     return g;
@@ -433,8 +494,8 @@ ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable) {
   // the ragged mode is built into the fused 256-column kernels behind the 4x front end; other handles would silently
   // compute (and return) every padded row, which is not what the caller asked for
   if (enable && (h->desc.model_type == PPASR_MODEL_DEEPSPEECH2 || h->desc.input_layer != 0 ||
-                 (h->desc.output_size != kD && h->desc.model_type == PPASR_MODEL_CONFORMER)))
-    return fail(PPASR_EUNSUPPORTED, "skip_padding: built for output_size 256 behind the conv2d (4x) front end only");
+                 h->generic))
+    return fail(PPASR_EUNSUPPORTED, "skip_padding: built for the fused 256-wide route behind the conv2d (4x) front end only");
   h->skip_padding = enable != 0;
   return PPASR_OK;
 }
@@ -456,7 +517,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   float* ws = static_cast<float*>(workspace);
   if (h->desc.model_type == PPASR_MODEL_SQUEEZEFORMER)
     return squeezeformer_encode(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, ws, wl, st);
-  if (h->desc.output_size != kD)
+  if (h->generic)
     return generic_encode(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, ws, st);
   float *y1 = ws + wl.y1, *y2 = ws + wl.y2, *xa = ws + wl.xa, *xb = ws + wl.xb, *xc = ws + wl.xc;
   float *qkv = ws + wl.qkv, *ctx = ws + wl.ctx, *g = ws + wl.g;
@@ -867,8 +928,8 @@ ppasr_status ppasr_profile_enable(ppasr_handle h, int enable) {
   if (!h) return fail(PPASR_EINVAL, "null handle");
   if (enable && (h->desc.model_type != PPASR_MODEL_CONFORMER && h->desc.model_type != PPASR_MODEL_EFFICIENT_CONFORMER))
     return fail(PPASR_EUNSUPPORTED, "ppasr_profile_enable: kernel classes exist for the Conformer route only; use ppasr_kprof_begin / _end");
-  if (enable && h->desc.output_size != kD)
-    return fail(PPASR_EUNSUPPORTED, "ppasr_profile_enable: the generic-width route has no kernel classes; use ppasr_kprof_begin / _end");
+  if (enable && h->generic)
+    return fail(PPASR_EUNSUPPORTED, "ppasr_profile_enable: the general layer route has no kernel classes; use ppasr_kprof_begin / _end");
   h->prof = enable != 0;
   h->spans.clear();
   h->ev_used = 0;

@@ -1,30 +1,155 @@
-// capi_generic.hip -- Conformer encoders whose width is NOT 256 (output_size 512 / 768 / 1024 with heads of 64).
+// capi_generic.hip -- the GENERAL Conformer layer route: every configuration of ConformerEncoder
+// (conformer/encoder.py:24-160) the fused 256-wide row-block kernels are not specialised for --
+//   * output_size 512 / 768 / 1024 with heads of 64 (configs/conformer.yml:3-4, "for big data use 512 / 8");
+//   * pos_enc_layer_type abs_pos / no_pos (MultiHeadedAttention instead of RelPositionMultiHeadedAttention);
+//   * normalize_before = False, concat_after = True, macaron_style = False, use_cnn_module = False;
+//   * every activation_type of utils/common.py:189-206;
+//   * input_layer = linear (LinearNoSubsampling) besides conv2d / conv2d6 / conv2d8;
+//   * any cnn_module_kernel;
+// batched (ConformerEncoder.forward) and chunk by chunk (forward_chunk, encoder.py:208-283).
 //
-// The fused row-block kernels (conformer_kernels.hip) are specialised for 256 columns = 8 waves x 32 and four
-// 32 x 260 LDS buffers per workgroup; a 512-wide row block does not fit that scheme.  This route runs the same layer
-// (ConformerEncoderLayer.forward, conformer/encoder.py:346-431) as a sequence of general pieces instead:
-//   * every Linear / pointwise Conv1D  -> launch_dense: the fragment-ordered streamed-weight MFMA GEMM (k_gemm_stream),
-//     the SAME packed weights the fused kernels use (ppasr_create packs them for any width);
-//   * attention                        -> k_attention<64> with 8+ heads (AttnArgs::dm = model width);
-//   * LayerNorm, swish, GLU, depthwise conv, residual / mask updates -> the small row kernels below (HBM-bound, one
-//     pass each; none of the activations stays in LDS between them).
-// Results follow the reference exactly like the fused route (same arithmetic, different fusion); it is several times
-// slower per FLOP than the 256-wide kernels and exists for coverage of the non-shipped `output_size: 512,
-// attention_heads: 8` configurations.  Batched encode only: no stream handles, no debug taps, no skip-padding mode.
+// The fused kernels (conformer_kernels.hip) keep a 32 x 256 row block in four LDS buffers per workgroup; a 512-wide row
+// block, a post-norm layer or a layer without its macaron half does not fit that scheme.  This route runs the same layer
+// (ConformerEncoderLayer.forward, encoder.py:346-431) as a sequence of general pieces:
+//   * every Linear / pointwise Conv1D -> k_dense_epi: the fragment-ordered streamed-weight matrix-core GEMM on the SAME
+//     packed weights the fused kernels use (ppasr_create packs them for any width), with the activation, the residual
+//     add (x += scale * y) and the conv module's pad mask in its epilogue;
+//   * attention -> k_attention<64> with any number of heads (AttnArgs::dm = model width); without relative positions
+//     the positional half of its score contraction runs on a zero row (q . k + (q + v) . 0: bit-identical to q . k);
+//   * LayerNorm, GLU, depthwise conv -> the small row kernels below (HBM-bound, one pass each).
+// Results follow the reference exactly like the fused route (same arithmetic, different fusion).
 #include "capi_internal.h"
 
 using namespace ppasr;
 
 namespace {
 
-// LayerNorm over D columns (nn.LayerNorm, biased variance, eps inside the sqrt), one wave per row; optionally followed by
-// swish, optionally with rows t of utterance b zeroed where mul * t >= lens[b] (the conv module's input mask,
-// convolution.py:104-106).  eps < 0: per-channel affine only (folded BatchNorm1D, see capi.hip).
-template <bool SWISH>
-// (x and out may be the same buffer -- the encoder normalises in place -- so neither is __restrict__)
-__global__ __launch_bounds__(256) void k_g_ln(const float* x, float* out,
-                                              const float* __restrict__ g, const float* __restrict__ b, int M, int D,
-                                              float eps, const int64_t* __restrict__ lens, int Tp, int mul) {
+constexpr int kActNone = -1;
+
+// activation_type (utils/common.py:189-206; Paddle's defaults for every parameter)
+__device__ __forceinline__ float act_apply(int act, float v) {
+  switch (act) {
+    case PPASR_ACT_SWISH: return swishf(v);
+    case PPASR_ACT_RELU: return fmaxf(v, 0.f);
+    case PPASR_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // approximate=False
+    case PPASR_ACT_TANH: return tanhf(v);
+    case PPASR_ACT_HARDTANH: return fminf(fmaxf(v, -1.0f), 1.0f);
+    case PPASR_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.0f);
+    case PPASR_ACT_LEAKYRELU: return v >= 0.f ? v : 0.01f * v;
+    case PPASR_ACT_SELU: return 1.0507009873554804934193349852946f * (v > 0.f ? v : 1.6732632423543772848170429916717f * expm1f(v));
+    case PPASR_ACT_ELU: return v > 0.f ? v : expm1f(v);
+    case PPASR_ACT_HARDSWISH: return v * fminf(fmaxf(v + 3.0f, 0.f), 6.0f) * (1.0f / 6.0f);
+    case PPASR_ACT_HARDSHRINK: return fabsf(v) > 0.5f ? v : 0.f;
+    default: return v;
+  }
+}
+
+// epilogue of k_dense_epi: v = act((acc + bias) * scale); res == nullptr: out = v; else out = res + rscale * v, with
+// the rows of PAD frames (mul * t >= lens[b], rows are [b][t < Tp]) left at res -- the mask behind pointwise_conv2
+// (convolution.py:138-140) folded into the residual add
+struct GemmEpi {
+  int act = kActNone;
+  const float* res = nullptr;
+  float rscale = 1.f;
+  const int64_t* lens = nullptr;
+  int Tp = 1, mul = 1;
+};
+
+// out[M][ldc] (columns < n_valid) = epilogue(A[M][K] Wpacked + bias): the streamed-weight GEMM of k_gemm_stream
+// (conformer_kernels.hip) for dense activations, on 32 * MT-row tiles with K chunks of KC through a double-buffered
+// LDS tile.  blockIdx.y = 256-column block, wave = its 32-column tile.  (out may alias res: every element is read and
+// written by the same lane.)
+template <int MT, int KC>
+__global__ __launch_bounds__(kThreads) void k_dense_epi(const float* __restrict__ a, int lda, const f32x4* __restrict__ wp,
+                                                        const float* __restrict__ bias, float* out, int M, int n_chunks,
+                                                        float scale, int ldc, int n_valid, GemmEpi epi) {
+  constexpr int BM = 32 * MT, LD = KC + 4, F4_PER_ROW = KC / 4, NL = BM * F4_PER_ROW / kThreads, G = KC / 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  const int r0 = blockIdx.x * BM;
+  const int tile_stride = n_chunks * G * 64;
+  const f32x4* wbase = wp + (size_t)(blockIdx.y * kWaves + wave) * tile_stride;
+  BRing<1> ring;
+  ring_prime(ring, wbase, 0);
+  const float* tile_base = a + (size_t)r0 * lda;
+  const __amdgpu_buffer_rsrc_t rs_a = wstream_rsrc(tile_base);
+  int voff[NL], lds_off[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int idx = tid + kThreads * i;
+    const int row = idx / F4_PER_ROW, c4 = idx - row * F4_PER_ROW;
+    voff[i] = (r0 + row < M) ? row * lda * 4 + 16 * c4 : 0x7fffffff;  // rows >= M read as zeros (offset out of range)
+    lds_off[i] = row * LD + 4 * c4;
+  }
+  f32x4 stg[NL];
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) stg[i] = wstream_load(rs_a, voff[i], kc * KC * 4);
+  };
+  auto write_chunk = [&](float* buf) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4*>(buf + lds_off[i]) = stg[i];
+  };
+  f32x16 acc[MT][1];
+  acc_zero(acc);
+  load_chunk(0);
+  write_chunk(smem);
+  __syncthreads();
+  for (int kc = 0; kc < n_chunks; ++kc) {
+    float* cur = smem + (kc & 1) * BM * LD;
+    float* nxt = smem + ((kc + 1) & 1) * BM * LD;
+    const bool more = kc + 1 < n_chunks;
+    if (more) load_chunk(kc + 1);
+    const f32x4* seg = wbase + (size_t)kc * G * 64;
+    rb_gemm<MT, 1, G>(cur, LD, seg, 0, more ? seg + G * 64 : nullptr, 0, ring, acc);
+    if (more) write_chunk(nxt);
+    __syncthreads();
+  }
+  const int col = blockIdx.y * 256 + wave * 32 + (lane & 31);
+  if (col >= n_valid) return;
+  const float bv = bias[col];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = r0 + mt * 32 + acc_row(r, lane);
+      if (m >= M) continue;
+      float v = (acc[mt][0][r] + bv) * scale;
+      if (epi.act != kActNone) v = act_apply(epi.act, v);
+      if (epi.res) {
+        const float rv = epi.res[(size_t)m * ldc + col];
+        bool pad = false;
+        if (epi.lens) {
+          const int bb = m / epi.Tp, t = m - bb * epi.Tp;
+          pad = (int64_t)epi.mul * t >= epi.lens[bb];
+        }
+        v = pad ? rv : rv + epi.rscale * v;
+      }
+      out[(size_t)m * ldc + col] = v;
+    }
+}
+template <int MT, int KC>
+constexpr size_t dense_lds() { return (size_t)2 * (32 * MT) * (KC + 4) * sizeof(float); }
+
+// 32-row tiles with 256-wide K chunks (67 KB of LDS: two workgroups per CU, one's load / store phases behind the other's
+// MFMAs).  Taller tiles were measured on the 512-wide model (32 x 10 s, tools/profile_generic.py) and lost: 64 rows x
+// KC 128: 11.5 ms of dense time per step against 11.1; 128 rows (135 KB, one workgroup per CU, what conv2's K = 2304 ..
+// 4608 contraction runs on) 12.3 ms -- with K = 512 a tile has four chunks and nothing hides its first loads and its
+// epilogue.
+void dense(const float* a, int lda, const f32x4* w, const float* bias, float* out, int M, int K, int n_cols_padded, int ldc,
+           int n_valid, hipStream_t st, float scale = 1.0f, const GemmEpi& epi = GemmEpi{}) {
+  PPASR_LAUNCH((k_dense_epi<1, 256>), dim3((M + 31) / 32, n_cols_padded / 256), dim3(kThreads), (dense_lds<1, 256>()), st, a,
+               lda, w, bias, out, M, K / 256, scale, ldc, n_valid, epi);
+}
+
+// LayerNorm over D columns (nn.LayerNorm, biased variance, eps inside the sqrt), one wave per row, optionally followed
+// by an activation, optionally with rows t of utterance b zeroed where mul * t >= lens[b] (the conv module's input
+// mask, convolution.py:104-106).  eps < 0: per-channel affine only (folded BatchNorm, see capi.hip).  g == nullptr:
+// identity (mask / activation only).  The result is multiplied by post_scale (1 everywhere but behind
+// LinearNoSubsampling, where the positional encoding's x * sqrt(d) follows the ReLU).  (x and out may be the same buffer, so neither is __restrict__)
+__global__ __launch_bounds__(256) void k_g_ln(const float* x, float* out, const float* __restrict__ g,
+                                              const float* __restrict__ b, int M, int D, float eps, int act,
+                                              const int64_t* __restrict__ lens, int Tp, int mul, float post_scale) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const float* xr = x + (size_t)row * D;
@@ -37,7 +162,7 @@ __global__ __launch_bounds__(256) void k_g_ln(const float* x, float* out,
     }
   }
   float mean = 0.f, rstd = 1.f;
-  if (eps >= 0.f) {
+  if (g && eps >= 0.f) {
     float s = 0.f;
     for (int c = lane; c < D; c += 64) s += xr[c];
     mean = wave_sum(s) / D;
@@ -49,28 +174,10 @@ __global__ __launch_bounds__(256) void k_g_ln(const float* x, float* out,
     rstd = 1.0f / sqrtf(wave_sum(v) / D + eps);
   }
   for (int c = lane; c < D; c += 64) {
-    float y = (xr[c] - mean) * rstd * g[c] + b[c];
-    if (SWISH) y = swishf(y);
-    o[c] = y;
+    float y = g ? (xr[c] - mean) * rstd * g[c] + b[c] : xr[c];
+    if (act != kActNone) y = act_apply(act, y);
+    o[c] = y * post_scale;
   }
-}
-
-__global__ void k_g_swish(float* __restrict__ x, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] = swishf(x[i]);
-}
-
-// x += scale * y, with rows of y dropped where the frame is PAD (lens != nullptr: the mask behind pointwise_conv2,
-// convolution.py:138-140)
-__global__ void k_g_axpy(float* __restrict__ x, const float* __restrict__ y, float scale, int M, int D,
-                         const int64_t* __restrict__ lens, int Tp, int mul) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)M * D) return;
-  if (lens) {
-    const int row = (int)(i / D), bb = row / Tp, t = row - bb * Tp;
-    if ((int64_t)mul * t >= lens[bb]) return;
-  }
-  x[i] += scale * y[i];
 }
 
 // GLU over the channel halves of pointwise_conv1's output: g[m][c] = pg[m][c] * sigmoid(pg[m][D + c])  (convolution.py:126)
@@ -81,123 +188,220 @@ __global__ void k_g_glu(const float* __restrict__ pg, float* __restrict__ g, int
   g[i] = pg[row * 2 * D + c] * sigmoidf(pg[row * 2 * D + D + c]);
 }
 
-// Depthwise conv over time of g [B*Tp][D] (KS taps, `left` frames of left context: KS-1 causal, (KS-1)/2 non-causal).
-// Taps outside the utterance read pad[c] = GLU(pointwise_conv1 bias) in the causal module (the reference zero-pads
-// BEFORE pointwise_conv1, convolution.py:108-126) and 0 in the non-causal one (its depthwise conv pads its own input).
+// Depthwise conv over time (KS taps, `left` frames of left context: KS-1 causal, (KS-1)/2 non-causal).  Output row
+// (b, t < Tp) reads the input rows (b, t + row_off - left + j) of utterances that are Tp + row_off rows long: row_off = 0
+// batched; streaming (one utterance) the input is [lo cached rows | chunk rows] and row_off = left = lo.  Taps outside
+// the utterance read pad[c] = GLU(pointwise_conv1 bias) in the causal module (the reference zero-pads BEFORE
+// pointwise_conv1, convolution.py:108-126) and 0 in the non-causal one (its depthwise conv pads its own input).
 __global__ void k_g_dwconv(const float* __restrict__ g, float* __restrict__ out, const float* __restrict__ w /*[KS][D]*/,
                            const float* __restrict__ bias, const float* __restrict__ pad, int M, int Tp, int D, int KS,
-                           int left) {
+                           int left, int row_off) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * D) return;
   const int row = (int)(i / D), c = (int)(i - (size_t)row * D);
-  const int bb = row / Tp, t = row - bb * Tp;
+  const int bb = row / Tp, t = row - bb * Tp, Tin = Tp + row_off;
   const bool causal = left == KS - 1;
   float acc = bias[c];
   for (int j = 0; j < KS; ++j) {
-    const int tt = t - left + j;
+    const int tt = t + row_off - left + j;
     float v;
-    if (tt >= 0 && tt < Tp) v = g[((size_t)bb * Tp + tt) * D + c];
+    if (tt >= 0 && tt < Tin) v = g[((size_t)bb * Tin + tt) * D + c];
     else v = causal ? pad[c] : 0.f;
     acc = fmaf(w[(size_t)j * D + c], v, acc);
   }
   out[i] = acc;
 }
 
+// abs_pos (PositionalEncoding.forward, embedding.py:70: x * xscale + pe[offset : offset + T]; the scale is the embed
+// GEMM's): x[b][t] += pe[pos0 + t]
+__global__ void k_g_add_pe(float* __restrict__ x, const float* __restrict__ pe, int M, int D, int Tp, int pos0) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * D) return;
+  const int row = (int)(i / D), c = (int)(i - (size_t)row * D);
+  x[i] += pe[(size_t)(pos0 + row % Tp) * D + c];
+}
+
+// input_layer = linear: GlobalCMVN (utils/cmvn.py:29-31) of the feature rows, zero-padded to the GEMM's K chunk
+__global__ void k_g_cmvn_pad(const float* __restrict__ feats, const float* __restrict__ mean, const float* __restrict__ istd,
+                             float* __restrict__ out, int M, int F, int Kp) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * Kp) return;
+  const int row = (int)(i / Kp), k = (int)(i - (size_t)row * Kp);
+  out[i] = k < F ? (feats[(size_t)row * F + k] - mean[k]) * istd[k] : 0.f;
+}
+
+// concat_after: out[m] = [a[m] | b[m]]  (encoder.py:395-396)
+__global__ void k_g_concat(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int M, int D) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * 2 * D) return;
+  const size_t row = i / (2 * D), c = i - row * 2 * D;
+  out[i] = c < (size_t)D ? a[row * D + c] : b[row * D + c - D];
+}
+
+// streaming: this chunk's keys / values (columns D.. / 2D.. of qkv) -> cache rows
+__global__ void k_g_kv_append(const float* __restrict__ qkv, float* __restrict__ kc, float* __restrict__ vc, int n, int D) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n * D) return;
+  const size_t row = i / D, c = i - row * D;
+  kc[i] = qkv[row * 3 * D + D + c];
+  vc[i] = qkv[row * 3 * D + 2 * D + c];
+}
+
 inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
+inline dim3 blocks(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 struct GenWs {
-  size_t y1, y2, x, a, big, y, g, ctx, lg, total;
+  size_t y1, y2, x, a, big, y, g, ctx, cat, lg, total;
 };
 GenWs gen_layout(const ppasr_model_s* m, int B, int T) {
   const int D = m->desc.output_size, H = m->desc.linear_units, V = m->desc.vocab_size;
   const auto fd = m->front_dims(T);
   const size_t M = (size_t)B * fd.Tp;
-  const size_t wide = (size_t)std::max(std::max(3 * D, 2 * D), H);
+  const size_t lo = m->desc.cnn_module_kernel > 0 ? m->desc.cnn_module_kernel - 1 : 0;  // streaming: cached conv rows in front
+  const size_t wide = (size_t)std::max(3 * D, H);
   GenWs w{};
   size_t o = 0;
-  w.y1 = o; o += al64((size_t)B * fd.T1 * m->F1 * D);
-  w.y2 = o; o += al64(M * m->F2 * D);
+  if (m->desc.input_layer == 1) {
+    w.y1 = o; o += al64(M * m->lin_kpad);
+    w.y2 = o;
+  } else {
+    w.y1 = o; o += al64((size_t)B * fd.T1 * m->F1 * D);  // (conv2d8: the third conv's output reuses it)
+    w.y2 = o; o += al64((size_t)B * (fd.T2 ? fd.T2 : fd.Tp) * m->F2 * D);
+  }
   w.x = o; o += al64(M * D);
-  w.a = o; o += al64(M * D);
-  w.big = o; o += al64(M * wide);  // FFN hidden / qkv / pointwise_conv1 output
+  w.a = o; o += al64((M + lo) * D);
+  w.big = o; o += al64((M + lo) * wide);  // FFN hidden / qkv / pointwise_conv1 output
   w.y = o; o += al64(M * D);
-  w.g = o; o += al64(M * D);
+  w.g = o; o += al64((M + lo) * D);
   w.ctx = o; o += al64(M * D);
+  w.cat = o; o += m->gen.concat_after ? al64(M * 2 * D) : 0;
   w.lg = o; o += al64(M * (size_t)V);  // logits / probabilities when the caller does not ask for them
   w.total = o;
   return w;
 }
 
-}  // namespace
+// one call = the encoder layers + head on M = B * Tp rows that the front end left in x
+struct GenRun {
+  ppasr_model_s* h;
+  hipStream_t st;
+  int B, Tp;
+  const int64_t* lens;  // nullptr: no masks (forward_chunk)
+  float *x, *a, *big, *y, *g, *ctx, *cat, *lg;
+  ppasr_stream_s* s = nullptr;  // streaming: caches hold s->cache_t frames, key 0 at positional row pos0
+  int pos0 = 0;
+};
 
-size_t generic_ws_floats(const ppasr_model_s* m, int B, int T) { return gen_layout(m, B, T).total; }
-
-ppasr_status generic_encode(ppasr_model_s* h, const float* feats, const int64_t* lens, int B, int T, float* probs,
-                            float* logits, int32_t* frame_argmax, float* frame_maxprob, float* ws, hipStream_t st) {
-  if (h->taps) return fail(PPASR_EUNSUPPORTED, "debug taps are built for output_size=256");
+ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* frame_argmax, float* frame_maxprob) {
+  ppasr_model_s* h = r.h;
+  hipStream_t st = r.st;
+  const auto& o = h->gen;
   const int D = h->desc.output_size, H = h->desc.linear_units, V = h->desc.vocab_size, heads = h->desc.attention_heads;
-  const auto fd = h->front_dims(T);
-  const int F = h->desc.input_dim, T1 = fd.T1, F1 = h->F1, Tp = fd.Tp, F2 = h->F2;
-  const int M = B * Tp, mul = 4;
-  const GenWs wl = gen_layout(h, B, T);
-  float *y1 = ws + wl.y1, *y2 = ws + wl.y2, *x = ws + wl.x, *a = ws + wl.a, *big = ws + wl.big, *y = ws + wl.y;
-  float *g = ws + wl.g, *ctx = ws + wl.ctx;
-  const size_t MD = (size_t)M * D;
-  auto blocks = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
-  auto ln = [&](const float* in, float* out, const float* gg, const float* bb, float eps, bool swish, bool mask) {
-    if (swish)
-      PPASR_LAUNCH(k_g_ln<true>, dim3((M + 3) / 4), dim3(256), 0, st, in, out, gg, bb, M, D, eps, mask ? lens : nullptr, Tp, mul);
-    else
-      PPASR_LAUNCH(k_g_ln<false>, dim3((M + 3) / 4), dim3(256), 0, st, in, out, gg, bb, M, D, eps, mask ? lens : nullptr, Tp, mul);
+  const int B = r.B, Tp = r.Tp, M = B * Tp, mul = h->sub_rate();
+  const int64_t* lens = r.lens;
+  float *x = r.x, *a = r.a, *big = r.big, *y = r.y, *g = r.g, *ctx = r.ctx;
+  const bool rel = o.pos == PPASR_OPT_POS_REL;
+  const int n_cache = r.s ? r.s->cache_t : 0;
+  auto ln = [&](const float* in, float* out, const float* gg, const float* bb, float eps, int act, bool mask, int rows) {
+    PPASR_LAUNCH(k_g_ln, dim3((rows + 3) / 4), dim3(256), 0, st, in, out, gg, bb, rows, D, eps, act, mask ? lens : nullptr, Tp, mul, 1.0f);
   };
-  auto axpy = [&](const float* yy, float scale, bool mask) {
-    PPASR_LAUNCH(k_g_axpy, blocks(MD), dim3(256), 0, st, x, yy, scale, M, D, mask ? lens : nullptr, Tp, mul);
+  auto act_epi = [&](int act) {
+    GemmEpi e;
+    e.act = act;
+    return e;
   };
-  // PositionwiseFeedForward (positionwise.py:32-39): x += 0.5 * W2 swish(W1 LN(x) + b1) + b2
-  auto ffn = [&](const float* lg, const float* lb, const f32x4* w1, const float* b1, const f32x4* w2, const float* b2) {
-    ln(x, a, lg, lb, 1e-5f, false, false);
-    launch_dense(a, D, w1, b1, big, M, D, H, H, H, st);
-    PPASR_LAUNCH(k_g_swish, blocks((size_t)M * H), dim3(256), 0, st, big, (size_t)M * H);
-    launch_dense(big, H, w2, b2, y, M, H, D, D, D, st);
-    axpy(y, 0.5f, false);
+  auto res_epi = [&](float scale, bool mask) {
+    GemmEpi e;
+    e.res = x;
+    e.rscale = scale;
+    if (mask && lens) {
+      e.lens = lens;
+      e.Tp = Tp;
+      e.mul = mul;
+    }
+    return e;
   };
-
-  // ---- front end: GlobalCMVN + Conv2dSubsampling4 + x * sqrt(d) (subsampling.py:96-115, embedding.py:112) ----
-  launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, PadSkip{}, D);
-  launch_conv_stage(y1, h->front.conv2_w, h->front.conv2_b, y2, B, T1, F1, Tp, F2, 3, 2, st, PadSkip{}, D);
-  launch_dense(y2, F2 * D, h->front.embed_w, h->front.embed_b, x, M, F2 * D, D, D, D, st, sqrtf((float)D));
-
-  const int left = h->desc.causal ? h->desc.cnn_module_kernel - 1 : (h->desc.cnn_module_kernel - 1) / 2;
+  // PositionwiseFeedForward (positionwise.py:32-39) inside the layer's residual (encoder.py:380-386 / 411-417)
+  auto ffn = [&](const float* lg, const float* lb, const f32x4* w1, const float* b1, const f32x4* w2, const float* b2, float scale) {
+    const float* in = x;
+    if (!o.post_norm) {
+      ln(x, a, lg, lb, 1e-5f, kActNone, false, M);
+      in = a;
+    }
+    dense(in, D, w1, b1, big, M, D, H, H, H, st, 1.0f, act_epi(o.act));
+    dense(big, H, w2, b2, x, M, H, D, D, D, st, 1.0f, res_epi(scale, false));
+    if (o.post_norm) ln(x, x, lg, lb, 1e-5f, kActNone, false, M);
+  };
+  const float ff_scale = o.macaron ? 0.5f : 1.0f;
+  const int KS_model = h->desc.cnn_module_kernel;
+  const int left = h->desc.causal ? KS_model - 1 : (KS_model - 1) / 2;
+  const int lo_s = (r.s && o.use_cnn) ? r.s->lo : 0;  // cached conv-input rows in front of the chunk
   for (int i = 0; i < h->desc.num_blocks; ++i) {
     const LayerW& L = h->layers[i];
-    const int KS = h->layer_ks[i];
-    ffn(L.ln_mac_g, L.ln_mac_b, L.ffm_w1, L.ffm_b1, L.ffm_w2, L.ffm_b2);
-    // ---- RelPositionMultiHeadedAttention (attention.py:198-262) ----
-    ln(x, a, L.ln_mha_g, L.ln_mha_b, 1e-5f, false, false);
-    launch_dense(a, D, L.wqkv, L.bqkv, big, M, D, 3 * D, 3 * D, 3 * D, st);
-    AttnArgs at{big, 3 * D, big + D, 3 * D, big + 2 * D, 3 * D, Tp, Tp, 0, lens, ctx, L.pos_u, L.pos_v, L.ptab, 1, mul, Tp, Tp, 1};
-    at.pad_skip = 0;
-    at.dm = D;
-    launch_attention(at, B, heads, st);
-    launch_dense(ctx, D, L.wo, L.bo, y, M, D, D, D, D, st);
-    axpy(y, 1.0f, false);
+    if (o.macaron) ffn(L.ln_mac_g, L.ln_mac_b, L.ffm_w1, L.ffm_b1, L.ffm_w2, L.ffm_b2, ff_scale);
+    // ---- (Rel)MultiHeadedAttention (attention.py:123-262) ----
+    {
+      const float* in = x;
+      if (!o.post_norm) {
+        ln(x, a, L.ln_mha_g, L.ln_mha_b, 1e-5f, kActNone, false, M);
+        in = a;
+      }
+      dense(in, D, L.wqkv, L.bqkv, big, M, D, 3 * D, 3 * D, 3 * D, st);
+      AttnArgs at{big, 3 * D, big + D, 3 * D, big + 2 * D, 3 * D, Tp, Tp, rel ? r.pos0 : 0, lens, ctx, L.pos_u, L.pos_v,
+                  L.ptab, rel ? 1 : 0, mul, Tp, Tp, 1};
+      if (r.s) {  // keys / values: [cache | chunk] in the layer's device caches
+        float* kc = r.s->kc + ((size_t)i * r.s->cap + n_cache) * D;
+        float* vc = r.s->vc + ((size_t)i * r.s->cap + n_cache) * D;
+        PPASR_LAUNCH(k_g_kv_append, blocks((size_t)M * D), dim3(256), 0, st, big, kc, vc, M, D);
+        at.k = r.s->kc + (size_t)i * r.s->cap * D;
+        at.v = r.s->vc + (size_t)i * r.s->cap * D;
+        at.k_stride = at.v_stride = D;
+        at.T2 = at.kv_frames = n_cache + Tp;
+      }
+      at.pad_skip = 0;
+      at.dm = D;
+      launch_attention(at, B, heads, st);
+      if (o.concat_after) {  // x + concat_linear([attention input | linear_out(ctx)])
+        dense(ctx, D, L.wo, L.bo, y, M, D, D, D, D, st);
+        PPASR_LAUNCH(k_g_concat, blocks((size_t)M * 2 * D), dim3(256), 0, st, in, y, r.cat, M, D);
+        dense(r.cat, 2 * D, h->gen_x[i].wcat, h->gen_x[i].bcat, x, M, 2 * D, D, D, D, st, 1.0f, res_epi(1.0f, false));
+      } else {
+        dense(ctx, D, L.wo, L.bo, x, M, D, D, D, D, st, 1.0f, res_epi(1.0f, false));
+      }
+      if (o.post_norm) ln(x, x, L.ln_mha_g, L.ln_mha_b, 1e-5f, kActNone, false, M);
+    }
     // ---- ConvolutionModule (convolution.py:82-143) ----
-    ln(x, a, L.ln_conv_g, L.ln_conv_b, 1e-5f, false, true);  // LN_conv, PAD frames -> 0
-    launch_dense(a, D, L.pw1, L.pw1_b, big, M, D, 2 * D, 2 * D, 2 * D, st);
-    PPASR_LAUNCH(k_g_glu, blocks(MD), dim3(256), 0, st, big, g, M, D);
-    PPASR_LAUNCH(k_g_dwconv, blocks(MD), dim3(256), 0, st, g, a, L.dw_w, L.dw_b, L.glu_pad, M, Tp, D, KS, left);
-    ln(a, a, L.ln_cm_g, L.ln_cm_b, L.cm_eps, true, false);  // LayerNorm / folded BatchNorm + swish
-    launch_dense(a, D, L.pw2, L.pw2_b, y, M, D, D, D, D, st);
-    axpy(y, 1.0f, true);  // PAD frames of the conv output -> 0, then the residual
-    ffn(L.ln_ff_g, L.ln_ff_b, L.ff_w1, L.ff_b1, L.ff_w2, L.ff_b2);
-    ln(x, x, L.ln_fin_g, L.ln_fin_b, 1e-5f, false, false);
+    if (o.use_cnn) {
+      const int KS = h->layer_ks[i];
+      float* a_new = a + (size_t)lo_s * D;
+      if (!o.post_norm) ln(x, a_new, L.ln_conv_g, L.ln_conv_b, 1e-5f, kActNone, true, M);  // LN_conv, PAD frames -> 0
+      else ln(x, a_new, nullptr, nullptr, 0.f, kActNone, true, M);                           // PAD frames -> 0 only
+      const int rows = lo_s + M;
+      if (lo_s) {
+        float* hist = r.s->xh_hist + (size_t)i * r.s->lo * D;
+        HIP_TRY(hipMemcpyAsync(a, hist, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+        // new cache = the last lo rows of [cache | chunk] (convolution.py:110-116)
+        HIP_TRY(hipMemcpyAsync(hist, a + (size_t)M * D, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+      }
+      dense(a, D, L.pw1, L.pw1_b, big, rows, D, 2 * D, 2 * D, 2 * D, st);
+      PPASR_LAUNCH(k_g_glu, blocks((size_t)rows * D), dim3(256), 0, st, big, g, rows, D);
+      PPASR_LAUNCH(k_g_dwconv, blocks((size_t)M * D), dim3(256), 0, st, g, y, L.dw_w, L.dw_b, L.glu_pad, M, Tp, D, KS, left, lo_s);
+      ln(y, y, L.ln_cm_g, L.ln_cm_b, L.cm_eps, o.act, false, M);  // LayerNorm / folded BatchNorm + activation
+      dense(y, D, L.pw2, L.pw2_b, x, M, D, D, D, D, st, 1.0f, res_epi(1.0f, true));  // PAD frames of the conv output -> 0, + residual
+      if (o.post_norm) ln(x, x, L.ln_conv_g, L.ln_conv_b, 1e-5f, kActNone, false, M);
+    }
+    ffn(L.ln_ff_g, L.ln_ff_b, L.ff_w1, L.ff_b1, L.ff_w2, L.ff_b2, ff_scale);
+    if (o.use_cnn) ln(x, x, L.ln_fin_g, L.ln_fin_b, 1e-5f, kActNone, false, M);
   }
-  // ---- after_norm -> ctc_lo -> softmax (encoder.py:201, ctc.py:62-70) ----
-  ln(x, a, h->head.ln_g, h->head.ln_b, 1e-5f, false, false);
-  float* lg = logits ? logits : (probs ? probs : ws + wl.lg);
-  launch_dense(a, D, h->gen_head_w, h->gen_head_b, lg, M, D, h->gen_vpad, V, V, st);
+  // ---- after_norm (normalize_before only, encoder.py:201) -> ctc_lo -> softmax (ctc.py:62-70) ----
+  const float* enc = x;
+  if (!o.post_norm) {
+    ln(x, a, h->head.ln_g, h->head.ln_b, 1e-5f, kActNone, false, M);
+    enc = a;
+  }
+  float* lg = logits ? logits : (probs ? probs : r.lg);
+  dense(enc, D, h->gen_head_w, h->gen_head_b, lg, M, D, h->gen_vpad, V, V, st);
   float* pr = probs;
-  if (!pr && (frame_argmax || frame_maxprob)) pr = (lg == ws + wl.lg) ? lg : ws + wl.lg;
+  if (!pr && (frame_argmax || frame_maxprob)) pr = (lg == r.lg) ? lg : r.lg;
   if (pr) {
     if (pr != lg) HIP_TRY(hipMemcpyAsync(pr, lg, (size_t)M * V * sizeof(float), hipMemcpyDeviceToDevice, st));
     launch_softmax_from_stats(pr, nullptr, nullptr, M, V, st);
@@ -209,4 +413,78 @@ ppasr_status generic_encode(ppasr_model_s* h, const float* feats, const int64_t*
   }
   HIP_TRY(hipGetLastError());
   return PPASR_OK;
+}
+
+// front end: GlobalCMVN + the subsampling class + the positional encoding's scaling (subsampling.py, embedding.py)
+// -> x [B * Tp][D]; pe_off = position of the first output frame (abs_pos)
+ppasr_status gen_front(ppasr_model_s* h, const float* feats, int B, int T, float* ws, const GenWs& wl, int pe_off,
+                       hipStream_t st) {
+  const int D = h->desc.output_size, F = h->desc.input_dim;
+  const auto fd = h->front_dims(T);
+  const int Tp = fd.Tp, M = B * Tp, il = h->desc.input_layer;
+  float *y1 = ws + wl.y1, *y2 = ws + wl.y2, *x = ws + wl.x;
+  // x * sqrt(d) belongs to PositionalEncoding / RelPositionalEncoding; NoPositionalEncoding returns x as it is
+  const float xscale = h->gen.pos == PPASR_OPT_POS_NONE ? 1.0f : sqrtf((float)D);
+  if (il == 1) {
+    // LinearNoSubsampling (subsampling.py:39-42): Linear -> LayerNorm(eps 1e-12) -> ReLU
+    const int Kp = h->lin_kpad;
+    PPASR_LAUNCH(k_g_cmvn_pad, blocks((size_t)M * Kp), dim3(256), 0, st, feats, h->front.cmvn_mean, h->front.cmvn_istd, y1, M, F, Kp);
+    dense(y1, Kp, h->front.embed_w, h->front.embed_b, x, M, Kp, D, D, D, st);
+    PPASR_LAUNCH(k_g_ln, dim3((M + 3) / 4), dim3(256), 0, st, x, x, h->lin_ln_g, h->lin_ln_b, M, D, 1e-12f, (int)PPASR_ACT_RELU,
+                 (const int64_t*)nullptr, Tp, 1, xscale);
+  } else {
+    launch_conv1(feats, h->front, y1, B, T, F, fd.T1, h->F1, st, PadSkip{}, D);
+    if (il == 8) {  // Conv2dSubsampling8: three 3x3 / 2 convs, the third one over conv1's output buffer
+      launch_conv_stage(y1, h->front.conv2_w, h->front.conv2_b, y2, B, fd.T1, h->F1, fd.T2, h->F2, 3, 2, st, PadSkip{}, D);
+      launch_conv_stage(y2, h->front.conv3_w, h->front.conv3_b, y1, B, fd.T2, h->F2, Tp, h->F3, 3, 2, st, PadSkip{}, D);
+      dense(y1, h->F3 * D, h->front.embed_w, h->front.embed_b, x, M, h->F3 * D, D, D, D, st, xscale);
+    } else {  // conv2d (3x3 / 2) or conv2d6 (5x5 / 3): FrontW::conv2_k / _s
+      launch_conv_stage(y1, h->front.conv2_w, h->front.conv2_b, y2, B, fd.T1, h->F1, Tp, h->F2, h->front.conv2_k,
+                        h->front.conv2_s, st, PadSkip{}, D);
+      dense(y2, h->F2 * D, h->front.embed_w, h->front.embed_b, x, M, h->F2 * D, D, D, D, st, xscale);
+    }
+  }
+  if (h->gen.pos == PPASR_OPT_POS_ABS)
+    PPASR_LAUNCH(k_g_add_pe, blocks((size_t)M * D), dim3(256), 0, st, x, h->pe_dev, M, D, Tp, pe_off);
+  return PPASR_OK;
+}
+
+}  // namespace
+
+hipError_t configure_generic_kernels() {
+  hipError_t e;
+#define SET_LDS(k, bytes)                                                                                        \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                               (int)(bytes))) != hipSuccess)                                                     \
+  return e
+  SET_LDS((k_dense_epi<1, 256>), (dense_lds<1, 256>()));
+#undef SET_LDS
+  return hipSuccess;
+}
+
+size_t generic_ws_floats(const ppasr_model_s* m, int B, int T) { return gen_layout(m, B, T).total; }
+
+ppasr_status generic_encode(ppasr_model_s* h, const float* feats, const int64_t* lens, int B, int T, float* probs,
+                            float* logits, int32_t* frame_argmax, float* frame_maxprob, float* ws, hipStream_t st) {
+  if (h->taps) return fail(PPASR_EUNSUPPORTED, "debug taps are built for the fused 256-wide route");
+  const GenWs wl = gen_layout(h, B, T);
+  ppasr_status rs = gen_front(h, feats, B, T, ws, wl, 0, st);
+  if (rs != PPASR_OK) return rs;
+  GenRun r{h, st, B, h->front_dims(T).Tp, lens, ws + wl.x, ws + wl.a, ws + wl.big, ws + wl.y, ws + wl.g, ws + wl.ctx,
+           ws + wl.cat, ws + wl.lg};
+  return gen_layers(r, probs, logits, frame_argmax, frame_maxprob);
+}
+
+ppasr_status generic_chunk(ppasr_stream_s* s, const float* feats, int T, int pos0, float* probs, int32_t* frame_argmax,
+                           float* frame_maxprob, float* ws, hipStream_t st) {
+  ppasr_model_s* h = s->m;
+  const GenWs wl = gen_layout(h, 1, T);
+  // PositionalEncoding.forward(x, offset) (abs_pos): the chunk's first frame sits at position `offset`
+  ppasr_status rs = gen_front(h, feats, 1, T, ws, wl, s->offset, st);
+  if (rs != PPASR_OK) return rs;
+  GenRun r{h, st, 1, h->front_dims(T).Tp, nullptr, ws + wl.x, ws + wl.a, ws + wl.big, ws + wl.y, ws + wl.g, ws + wl.ctx,
+           ws + wl.cat, ws + wl.lg};
+  r.s = s;
+  r.pos0 = pos0;
+  return gen_layers(r, probs, nullptr, frame_argmax, frame_maxprob);
 }

@@ -75,10 +75,11 @@ struct ppasr_model_s {
   struct Front {
     int T1, T2, Tp;
   };
-  int sub_rate() const { return desc.input_layer ? desc.input_layer : 4; }
+  int sub_rate() const { return desc.input_layer == 1 ? 1 : desc.input_layer ? desc.input_layer : 4; }
   int F_last() const { return desc.input_layer == 8 ? F3 : F2; }
-  int min_frames() const { return desc.input_layer == 6 ? 11 : desc.input_layer == 8 ? 15 : 7; }
+  int min_frames() const { return desc.input_layer == 1 ? 1 : desc.input_layer == 6 ? 11 : desc.input_layer == 8 ? 15 : 7; }
   Front front_dims(int T) const {
+    if (desc.input_layer == 1) return Front{0, 0, T};  // LinearNoSubsampling: one encoder frame per feature frame
     Front f{(T - 1) / 2, 0, 0};
     if (desc.input_layer == 6) {
       f.Tp = (f.T1 - 5) / 3 + 1;
@@ -90,6 +91,23 @@ struct ppasr_model_s {
     }
     return f;
   }
+  // ---- general layer route (capi_generic.hip): any width that is a multiple of 256 and every ConformerEncoder
+  // constructor option (ppasr_model_desc::options, input_layer = linear, any conv kernel size) ----
+  bool generic = false;
+  struct GenOpts {
+    int pos = 0;  // PPASR_OPT_POS_*
+    bool post_norm = false, concat_after = false, macaron = true, use_cnn = true;
+    int act = 0;  // PPASR_ACT_*
+  } gen;
+  struct GenLayerX {  // what LayerW has no slot for
+    const f32x4* wcat = nullptr;  // concat_linear [2d][d], packed
+    const float* bcat = nullptr;
+  };
+  std::vector<GenLayerX> gen_x;
+  const float* pe_dev = nullptr;    // positional table [max_len][d] (abs_pos adds it to the embedded frames)
+  const float* zero_vec = nullptr;  // [d] zeros: pos_bias_u / _v and the one-row "positional table" of MultiHeadedAttention
+  const float *lin_ln_g = nullptr, *lin_ln_b = nullptr;  // LinearNoSubsampling's LayerNorm (eps 1e-12)
+  int lin_kpad = 0;                                      //   and its input width padded to whole 256-wide K chunks
   std::vector<void*> allocs;
   FrontW front;
   std::vector<LayerW> layers;
@@ -145,6 +163,21 @@ struct ppasr_model_s {
 };
 
 
+// streaming state of one session (capi_stream.hip; the general route of capi_generic.hip shares it)
+struct ppasr_stream_s {
+  ppasr_model_s* m;
+  int D;        // model width = row stride of the caches (256 on the fused route)
+  int cap;      // key capacity per layer (frames)
+  int cache_t;  // cached key/value frames of the full-rate layers (cache_t1 in the reference)
+  int cache_r;  // frames held by the half-rate layers
+  int offset;   // encoder-output frames emitted so far (the reference's `offset` argument)
+  int lo;       // longest conv left context = cnn_module_kernel - 1
+  float *kc, *vc;   // [L][cap][D]
+  float* xh_hist;   // [L][lo][D]  conv-module input history
+  float* g_hist;    // [L][lo][256] GLU(pointwise_conv1(history)) of every layer, recomputed at the start of each chunk (fused route)
+  HistLayer* hist_tab;  // device [L]: per-layer pointwise_conv1 weights / history rows for that launch (fused route)
+};
+
 struct WsLayout {
   size_t y1, y2, xa, xb, xc, qkv, ctx, g, rmax, rsum, fa, fp, xs, vt, total;  // offsets in floats
   int vt_stride;  // row stride of the transposed values (fused attention route)
@@ -156,10 +189,15 @@ ppasr::LayerW sq_conv_view(const ppasr::SqLayerW& W);  // capi_squeezeformer.hip
 
 ppasr_status upload_pe_table(ppasr_model_s* m, BlobMap& sd, const float** pe_dev);
 
-// generic-width Conformer (output_size 512 / 768 / 1024, heads of 64): capi_generic.hip
+// general Conformer layer route (widths 512 / 768 / 1024, non-default constructor options): capi_generic.hip
 size_t generic_ws_floats(const ppasr_model_s* m, int B, int T);
 ppasr_status generic_encode(ppasr_model_s* h, const float* feats, const int64_t* lens, int B, int T, float* probs,
                             float* logits, int32_t* frame_argmax, float* frame_maxprob, float* ws, hipStream_t st);
+// one chunk of ConformerEncoder.forward_chunk (conformer/encoder.py:208-283) on the general route: the caches of `s`
+// hold cache_t frames, key 0 sits at positional row pos0; appends this chunk's keys / values and conv inputs
+ppasr_status generic_chunk(ppasr_stream_s* s, const float* feats, int T, int pos0, float* probs, int32_t* frame_argmax,
+                           float* frame_maxprob, float* ws, hipStream_t st);
+hipError_t configure_generic_kernels();
 
 // model-family back ends
 ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd);

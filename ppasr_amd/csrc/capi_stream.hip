@@ -16,19 +16,6 @@
 
 #include "capi_internal.h"
 
-struct ppasr_stream_s {
-  ppasr_model_s* m;
-  int cap;      // key capacity per layer (frames)
-  int cache_t;  // cached key/value frames of the full-rate layers (cache_t1 in the reference)
-  int cache_r;  // frames held by the half-rate layers
-  int offset;   // encoder-output frames emitted so far (the reference's `offset` argument)
-  int lo;       // longest conv left context = cnn_module_kernel - 1
-  float *kc, *vc;   // [L][cap][256]
-  float* xh_hist;   // [L][lo][256]  conv-module input history
-  float* g_hist;    // [L][lo][256] GLU(pointwise_conv1(history)) of every layer, recomputed at the start of each chunk
-  HistLayer* hist_tab;  // device [L]: per-layer pointwise_conv1 weights / history rows for that launch
-};
-
 namespace {
 
 inline bool is_sq(const ppasr_model_s* h) { return h->desc.model_type == PPASR_MODEL_SQUEEZEFORMER; }
@@ -46,10 +33,10 @@ inline int layer_lo(const ppasr_model_s* h, int i) {
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // keep rows [from, from+keep) of a [cap][256] cache at its start
-ppasr_status shift_cache(float* buf, int from, int keep, float* tmp, hipStream_t st) {
+ppasr_status shift_cache(float* buf, int from, int keep, float* tmp, hipStream_t st, int D = kD) {
   if (keep <= 0 || from <= 0) return PPASR_OK;
-  const size_t bytes = (size_t)keep * kD * sizeof(float);
-  HIP_TRY(hipMemcpyAsync(tmp, buf + (size_t)from * kD, bytes, hipMemcpyDeviceToDevice, st));
+  const size_t bytes = (size_t)keep * D * sizeof(float);
+  HIP_TRY(hipMemcpyAsync(tmp, buf + (size_t)from * D, bytes, hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipMemcpyAsync(buf, tmp, bytes, hipMemcpyDeviceToDevice, st));
   return PPASR_OK;
 }
@@ -106,10 +93,10 @@ ppasr_status finish_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* shift_tm
   const int from_r = p.ncs / 2;
   const int keep_r = std::max(p.T2_r - from_r, 0);
   for (int i = 0; i < h->desc.num_blocks; ++i) {
-    float* bufs[2] = {s->kc + (size_t)i * s->cap * kD, s->vc + (size_t)i * s->cap * kD};
+    float* bufs[2] = {s->kc + (size_t)i * s->cap * s->D, s->vc + (size_t)i * s->cap * s->D};
     const bool half = layer_factor(h, i) == 2;
     for (float* b : bufs) {
-      ppasr_status r = half ? shift_cache(b, from_r, keep_r, shift_tmp, st) : shift_cache(b, p.ncs, keep, shift_tmp, st);
+      ppasr_status r = half ? shift_cache(b, from_r, keep_r, shift_tmp, st, s->D) : shift_cache(b, p.ncs, keep, shift_tmp, st, s->D);
       if (r != PPASR_OK) return r;
     }
   }
@@ -251,18 +238,21 @@ ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out) {
     return fail(PPASR_EUNSUPPORTED, "deepspeech2 streams carry their state in the h/c boxes of ppasr_ds2_encode");
   if (!h->desc.causal)
     return fail(PPASR_EUNSUPPORTED, "forward_chunk needs the causal conv module (a streaming=True model)");
-  if (h->desc.output_size != kD) return fail(PPASR_EUNSUPPORTED, "stream handles are built for output_size=256");
+  if (h->generic && h->desc.input_layer == 1)
+    return fail(PPASR_EUNSUPPORTED, "stream handles are built for the conv front ends (input_layer=linear: batched encode)");
   if (h->desc.input_layer != 0 && h->desc.model_type != PPASR_MODEL_CONFORMER)
     return fail(PPASR_EUNSUPPORTED, "stream handles with the conv2d6 / conv2d8 front ends are built for model_type=conformer");
   auto* s = new ppasr_stream_s();
   s->m = h;
+  s->D = h->desc.output_size;
   s->cap = h->desc.max_len;
-  s->lo = h->desc.cnn_module_kernel - 1;
+  s->lo = (h->generic && !h->gen.use_cnn) ? 0 : h->desc.cnn_module_kernel - 1;
   const size_t L = h->desc.num_blocks;
-  hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&s->kc), L * s->cap * kD * sizeof(float));
-  hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&s->vc), L * s->cap * kD * sizeof(float));
-  hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&s->xh_hist), L * s->lo * kD * sizeof(float));
-  hipError_t e4 = hipMalloc(reinterpret_cast<void**>(&s->g_hist), L * s->lo * kD * sizeof(float));
+  const size_t D = s->D, lo_alloc = s->lo > 0 ? s->lo : 1;
+  hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&s->kc), L * s->cap * D * sizeof(float));
+  hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&s->vc), L * s->cap * D * sizeof(float));
+  hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&s->xh_hist), L * lo_alloc * D * sizeof(float));
+  hipError_t e4 = hipMalloc(reinterpret_cast<void**>(&s->g_hist), L * lo_alloc * D * sizeof(float));
   s->hist_tab = nullptr;
   if (e4 == hipSuccess) e4 = hipMalloc(reinterpret_cast<void**>(&s->hist_tab), L * sizeof(HistLayer));
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
@@ -274,10 +264,11 @@ ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out) {
   s->cache_t = 0;
   s->cache_r = 0;
   s->offset = 0;
-  hipError_t e5 = hipMemset(s->xh_hist, 0, L * s->lo * kD * sizeof(float));
+  hipError_t e5 = hipMemset(s->xh_hist, 0, L * lo_alloc * D * sizeof(float));
   std::vector<HistLayer> tab(L);
   for (size_t i = 0; i < L; ++i) {
-    if (is_sq(h)) tab[i] = HistLayer{h->sq_layers[i].pw1_raw, h->sq_layers[i].pw1_b_raw, layer_lo(h, (int)i), 0};
+    if (h->generic) tab[i] = HistLayer{nullptr, nullptr, 0, 0};  // (the general route recomputes the history's GLU inside the layer)
+    else if (is_sq(h)) tab[i] = HistLayer{h->sq_layers[i].pw1_raw, h->sq_layers[i].pw1_b_raw, layer_lo(h, (int)i), 0};
     else tab[i] = HistLayer{h->layers[i].pw1, h->layers[i].pw1_b, layer_lo(h, (int)i), 0};
   }
   if (e5 == hipSuccess) e5 = hipMemcpy(s->hist_tab, tab.data(), L * sizeof(HistLayer), hipMemcpyHostToDevice);
@@ -303,7 +294,7 @@ ppasr_status ppasr_stream_reset(ppasr_stream s, void* stream) {
   s->cache_t = 0;
   s->cache_r = 0;
   s->offset = 0;
-  HIP_TRY(hipMemsetAsync(s->xh_hist, 0, (size_t)s->m->desc.num_blocks * s->lo * kD * sizeof(float),
+  HIP_TRY(hipMemsetAsync(s->xh_hist, 0, (size_t)s->m->desc.num_blocks * s->lo * s->D * sizeof(float),
                          static_cast<hipStream_t>(stream)));
   return PPASR_OK;
 }
@@ -314,6 +305,7 @@ int ppasr_stream_cache_frames(ppasr_stream s) { return s ? s->cache_t : -1; }
 size_t ppasr_chunk_workspace_bytes(ppasr_handle h, int T) {
   if (!h || T < h->min_frames()) return 0;
   const size_t Tp = h->front_dims(T).Tp;
+  if (h->generic) return (generic_ws_floats(h, 1, T) + (size_t)h->desc.max_len * h->desc.output_size) * sizeof(float);
   // the full-utterance layout for B=1, plus the conv-module input rows and a cache-shift scratch
   return (ws_layout(h, 1, T).total + Tp * kD + 64 + (size_t)h->desc.max_len * kD) * sizeof(float);
 }
@@ -334,6 +326,15 @@ ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int r
   hipStream_t st = static_cast<hipStream_t>(stream);
   const WsLayout wl = ws_layout(h, 1, T);
   float* ws = static_cast<float*>(workspace);
+  if (h->generic) {  // the general layer route (capi_generic.hip): same cache bookkeeping, its own layer pieces
+    r = generic_chunk(s, feats, T, p.pos0, probs, frame_argmax, frame_maxprob, ws, st);
+    if (r != PPASR_OK) return r;
+    r = finish_chunk(s, p, ws + wl.total, st);
+    if (r != PPASR_OK) return r;
+    s->offset += c;
+    if (c_out_host) *c_out_host = c;
+    return PPASR_OK;
+  }
   float *y1 = ws + wl.y1, *y2 = ws + wl.y2, *xa = ws + wl.xa, *xb = ws + wl.xb, *xc = ws + wl.xc;
   float *qkv = ws + wl.qkv, *ctx = ws + wl.ctx, *g = ws + wl.g;
   float* xhat = ws + wl.total;
@@ -379,11 +380,11 @@ ppasr_status ppasr_stream_export_cache(ppasr_stream s, float* att_cache, float* 
       // repeat_interleave(cache, 2)[:max_att_len] must cover t frames, or the reference's concat over layers fails
       if (div == 2 && (2 * s->cache_r < t || (is_eff(h) && 2 * s->cache_r != t)))
         return fail(PPASR_EINVAL, "half-rate cache does not match the first layer's cache length (odd cache length)");
-      launch_cache_export(s->kc + (size_t)i * s->cap * kD, s->vc + (size_t)i * s->cap * kD,
-                          att_cache + (size_t)i * 4 * t * 128, t, div, st);
+      launch_cache_export(s->kc + (size_t)i * s->cap * s->D, s->vc + (size_t)i * s->cap * s->D,
+                          att_cache + (size_t)i * (s->D / 64) * t * 128, t, div, st, s->D);
     }
-    if (cnn_cache)
-      launch_cnn_transpose(s->xh_hist + (size_t)i * s->lo * kD, cnn_cache + (size_t)i * kD * s->lo, layer_lo(h, i), s->lo, 1, st);
+    if (cnn_cache && s->lo > 0)
+      launch_cnn_transpose(s->xh_hist + (size_t)i * s->lo * s->D, cnn_cache + (size_t)i * s->D * s->lo, layer_lo(h, i), s->lo, 1, st, s->D);
   }
   HIP_TRY(hipGetLastError());
   return PPASR_OK;
@@ -399,13 +400,13 @@ ppasr_status ppasr_stream_import_cache(ppasr_stream s, const float* att_cache, i
   const int L = h->desc.num_blocks;
   for (int i = 0; i < L; ++i) {
     if (cache_t > 0)
-      launch_cache_import(att_cache + (size_t)i * 4 * cache_t * 128, s->kc + (size_t)i * s->cap * kD,
-                          s->vc + (size_t)i * s->cap * kD, cache_t, layer_factor(h, i), st);
-    if (cnn_cache)
-      launch_cnn_transpose(cnn_cache + (size_t)i * kD * s->lo, s->xh_hist + (size_t)i * s->lo * kD, layer_lo(h, i), s->lo, 0, st);
+      launch_cache_import(att_cache + (size_t)i * (s->D / 64) * cache_t * 128, s->kc + (size_t)i * s->cap * s->D,
+                          s->vc + (size_t)i * s->cap * s->D, cache_t, layer_factor(h, i), st, s->D);
+    if (cnn_cache && s->lo > 0)
+      launch_cnn_transpose(cnn_cache + (size_t)i * s->D * s->lo, s->xh_hist + (size_t)i * s->lo * s->D, layer_lo(h, i), s->lo, 0, st, s->D);
   }
-  if (!cnn_cache)
-    HIP_TRY(hipMemsetAsync(s->xh_hist, 0, (size_t)L * s->lo * kD * sizeof(float), st));
+  if (!cnn_cache && s->lo > 0)
+    HIP_TRY(hipMemsetAsync(s->xh_hist, 0, (size_t)L * s->lo * s->D * sizeof(float), st));
   s->cache_t = cache_t;
   s->cache_r = ceil_div(cache_t, 2);  // att_cache[i][:, :, ::2]
   s->offset = offset;
@@ -440,7 +441,7 @@ ppasr_status ppasr_stream_group_create(ppasr_handle h, int n_sessions, int max_f
   if (h->desc.model_type != PPASR_MODEL_CONFORMER || !h->desc.causal)
     return fail(PPASR_EUNSUPPORTED, "session groups are built for streaming (causal) model_type=conformer");
   if (h->desc.input_layer != 0) return fail(PPASR_EUNSUPPORTED, "session groups are built for the conv2d front end only");
-  if (h->desc.output_size != kD) return fail(PPASR_EUNSUPPORTED, "session groups are built for output_size=256");
+  if (h->generic) return fail(PPASR_EUNSUPPORTED, "session groups are built for the fused 256-wide route");
   auto g = std::make_unique<ppasr_stream_group_s>();
   g->m = h;
   g->n_sessions = n_sessions;

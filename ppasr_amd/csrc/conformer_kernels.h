@@ -163,9 +163,10 @@ void launch_hist_gather(const float* hist, long long sess_stride, const SessDesc
 void launch_hist_update_group(float* hist, long long sess_stride, const SessDesc* sess, const float* fresh, int n, int c,
                               int lo, hipStream_t st);
 void launch_hist_update(float* hist, const float* fresh, int n, int lo, hipStream_t st);
-void launch_cache_export(const float* kc, const float* vc, float* att, int T, int div, hipStream_t st);
-void launch_cache_import(const float* att, float* kc, float* vc, int T, int div, hipStream_t st);
-void launch_cnn_transpose(const float* src, float* dst, int lo, int lo_ref, int to_ref, hipStream_t st);
+// (D = model width: 256, or the general route's 512 / 768 / 1024 -- one thread per column)
+void launch_cache_export(const float* kc, const float* vc, float* att, int T, int div, hipStream_t st, int D = 256);
+void launch_cache_import(const float* att, float* kc, float* vc, int T, int div, hipStream_t st, int D = 256);
+void launch_cnn_transpose(const float* src, float* dst, int lo, int lo_ref, int to_ref, hipStream_t st, int D = 256);
 void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStream_t st);
 // hw.ln_g == nullptr: no final LayerNorm (Squeezeformer has no after_norm, squeezeformer/encoder.py:232-235)
 void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr_argmax, float* fr_maxprob,

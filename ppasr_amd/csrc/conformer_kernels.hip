@@ -1410,38 +1410,38 @@ void launch_hist_update_group(float* hist, long long sess_stride, const SessDesc
 // back with [::2] (squeezeformer/encoder.py:355,367-369; efficient_conformer/encoder.py:349,368); ours holds each frame once.
 __global__ void k_cache_export(const float* __restrict__ kc, const float* __restrict__ vc, float* __restrict__ att, int T,
                                int div) {
-  const int t = blockIdx.x, tid = threadIdx.x;  // 256 threads: (h, f)
+  const int t = blockIdx.x, tid = threadIdx.x, D = blockDim.x;  // D = heads * 64 threads: (h, f)
   const int h = tid >> 6, f = tid & 63;
-  att[((size_t)h * T + t) * 128 + f] = kc[(size_t)(t / div) * kD + tid];
-  att[((size_t)h * T + t) * 128 + 64 + f] = vc[(size_t)(t / div) * kD + tid];
+  att[((size_t)h * T + t) * 128 + f] = kc[(size_t)(t / div) * D + tid];
+  att[((size_t)h * T + t) * 128 + 64 + f] = vc[(size_t)(t / div) * D + tid];
 }
 __global__ void k_cache_import(const float* __restrict__ att, float* __restrict__ kc, float* __restrict__ vc, int T, int div) {
-  const int j = blockIdx.x, tid = threadIdx.x;  // j = stored frame <- exported frame j * div
+  const int j = blockIdx.x, tid = threadIdx.x, D = blockDim.x;  // j = stored frame <- exported frame j * div
   const int h = tid >> 6, f = tid & 63;
-  kc[(size_t)j * kD + tid] = att[((size_t)h * T + (size_t)j * div) * 128 + f];
-  vc[(size_t)j * kD + tid] = att[((size_t)h * T + (size_t)j * div) * 128 + 64 + f];
+  kc[(size_t)j * D + tid] = att[((size_t)h * T + (size_t)j * div) * 128 + f];
+  vc[(size_t)j * D + tid] = att[((size_t)h * T + (size_t)j * div) * 128 + 64 + f];
 }
 // cnn cache: ours [lo][256] (row = frame)  <->  reference [256][lo]
 // `lo_ref` >= lo: width of the reference tensor; ours maps to its LAST lo columns, the rest is zero on export
 // (F.pad to cnn_module_kernel-1, efficient_conformer/encoder.py:371-374; convolution.py:106 reads cache[:, :, -lorder:]).
 __global__ void k_cnn_transpose(const float* __restrict__ src, float* __restrict__ dst, int lo, int lo_ref, int to_ref) {
-  const int c = threadIdx.x;
+  const int c = threadIdx.x, D = blockDim.x;
   const int skip = lo_ref - lo;
   if (to_ref)
     for (int j = 0; j < skip; ++j) dst[(size_t)c * lo_ref + j] = 0.f;
   for (int j = 0; j < lo; ++j) {
-    if (to_ref) dst[(size_t)c * lo_ref + skip + j] = src[(size_t)j * kD + c];
-    else dst[(size_t)j * kD + c] = src[(size_t)c * lo_ref + skip + j];
+    if (to_ref) dst[(size_t)c * lo_ref + skip + j] = src[(size_t)j * D + c];
+    else dst[(size_t)j * D + c] = src[(size_t)c * lo_ref + skip + j];
   }
 }
-void launch_cache_export(const float* kc, const float* vc, float* att, int T, int div, hipStream_t st) {
-  if (T > 0) PPASR_LAUNCH(k_cache_export, dim3(T), dim3(256), 0, st, kc, vc, att, T, div);
+void launch_cache_export(const float* kc, const float* vc, float* att, int T, int div, hipStream_t st, int D) {
+  if (T > 0) PPASR_LAUNCH(k_cache_export, dim3(T), dim3(D), 0, st, kc, vc, att, T, div);
 }
-void launch_cache_import(const float* att, float* kc, float* vc, int T, int div, hipStream_t st) {
-  if (T > 0) PPASR_LAUNCH(k_cache_import, dim3((T + div - 1) / div), dim3(256), 0, st, att, kc, vc, T, div);
+void launch_cache_import(const float* att, float* kc, float* vc, int T, int div, hipStream_t st, int D) {
+  if (T > 0) PPASR_LAUNCH(k_cache_import, dim3((T + div - 1) / div), dim3(D), 0, st, att, kc, vc, T, div);
 }
-void launch_cnn_transpose(const float* src, float* dst, int lo, int lo_ref, int to_ref, hipStream_t st) {
-  PPASR_LAUNCH(k_cnn_transpose, dim3(1), dim3(256), 0, st, src, dst, lo, lo_ref, to_ref);
+void launch_cnn_transpose(const float* src, float* dst, int lo, int lo_ref, int to_ref, hipStream_t st, int D) {
+  PPASR_LAUNCH(k_cnn_transpose, dim3(1), dim3(D), 0, st, src, dst, lo, lo_ref, to_ref);
 }
 void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStream_t st);
 __global__ void k_fill_rows(float* __restrict__ dst, const float* __restrict__ row, int n_rows) {

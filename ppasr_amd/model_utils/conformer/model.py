@@ -15,6 +15,11 @@ from ppasr_amd import _lib
 
 __all__ = ["ConformerModel"]
 
+# ppasr_model_desc::options codes (include/ppasr_hip.h)
+_POS_CODES = {"rel_pos": 0, "abs_pos": 1, "no_pos": 2}
+_ACT_CODES = {"swish": 0, "relu": 1, "gelu": 2, "tanh": 3, "hardtanh": 4, "relu6": 5, "leakyrelu": 6, "selu": 7, "elu": 8,
+              "hardswish": 9, "hardshrink": 10}
+
 
 def _pe_table(d_model, max_len):
     # PositionalEncoding.__init__  (conformer/embedding.py:38-53), fp32 like the reference
@@ -52,24 +57,33 @@ class ConformerModel:
         self.num_blocks = int(conf.get("num_blocks", 6))
         self.cnn_module_kernel = int(conf.get("cnn_module_kernel", 15))
         self.max_len = int(conf.get("max_len", 5000))
-        for key, want in (("pos_enc_layer_type", "rel_pos"), ("activation_type", "swish"),
-                          ("normalize_before", True), ("use_cnn_module", True),
-                          ("macaron_style", True)):
-            if key in conf and conf[key] != want:
-                raise NotImplementedError(f"encoder_conf.{key}={conf[key]!r}: only {want!r} is built")
-        # input_layer (encoder.py:93-104): Conv2dSubsampling4, or the 6x / 8x variants (batched encode only)
+        # The remaining ConformerEncoder constructor arguments (conformer/encoder.py:38-48).  The shipped values run on
+        # the fused kernels; anything else (like output_size != 256) selects the library's general layer route.
+        pos = conf.get("pos_enc_layer_type", "rel_pos")
+        act = conf.get("activation_type", "swish")
+        if pos not in _POS_CODES:
+            raise ValueError("unknown pos_enc_layer: " + str(pos))  # encoder.py:102
+        if act not in _ACT_CODES:
+            raise KeyError(act)  # get_activation (utils/common.py:206)
+        self.options = (_POS_CODES[pos] | (0 if conf.get("normalize_before", True) else _lib.PPASR_OPT_POST_NORM)
+                        | (_lib.PPASR_OPT_CONCAT_AFTER if conf.get("concat_after", False) else 0)
+                        | (0 if conf.get("macaron_style", True) else _lib.PPASR_OPT_NO_MACARON)
+                        | (0 if conf.get("use_cnn_module", True) else _lib.PPASR_OPT_NO_CNN)
+                        | (_ACT_CODES[act] << _lib.PPASR_OPT_ACT_SHIFT))
+        self.use_cnn_module = bool(conf.get("use_cnn_module", True))
+        # input_layer (encoder.py:104-113): LinearNoSubsampling, Conv2dSubsampling4, or the 6x / 8x variants
         il = conf.get("input_layer", "conv2d")
-        if il not in ("conv2d", "conv2d6", "conv2d8"):
-            raise NotImplementedError(f"encoder_conf.input_layer={il!r}: conv2d, conv2d6 and conv2d8 are built")
+        if il not in ("linear", "conv2d", "conv2d6", "conv2d8"):
+            raise ValueError("unknown input_layer: " + str(il))
         self.input_layer = il
-        self.subsampling_rate = {"conv2d": 4, "conv2d6": 6, "conv2d8": 8}[il]
+        self.subsampling_rate = {"linear": 1, "conv2d": 4, "conv2d6": 6, "conv2d8": 8}[il]
         # cnn_module_norm (convolution.py:65-71): layer_norm, or batch_norm = nn.BatchNorm1D in eval mode, which the
         # library folds into a per-channel scale / shift; the checkpoint carries the running statistics then
         norm = conf.get("cnn_module_norm", "layer_norm")
         if norm not in ("layer_norm", "batch_norm"):
             raise ValueError(f"encoder_conf.cnn_module_norm={norm!r}")
         has_stats = any(k.endswith("conv_module.norm._mean") for k in state_dict)
-        if has_stats != (norm == "batch_norm"):
+        if self.use_cnn_module and has_stats != (norm == "batch_norm"):
             raise ValueError(f"encoder_conf.cnn_module_norm={norm!r} but the checkpoint "
                              f"{'has' if has_stats else 'lacks'} conv_module.norm._mean / _variance")
         sd = dict(state_dict)
@@ -95,7 +109,7 @@ class ConformerModel:
         desc = _lib.ModelDesc(_lib.PPASR_MODEL_CONFORMER, input_dim, vocab_size, self.output_size,
                               self.attention_heads, self.linear_units, self.num_blocks, self.cnn_module_kernel,
                               1 if streaming else 0, self.max_len, -1, -1, -1, 0, 0, 0,
-                              {"conv2d": 0, "conv2d6": 6, "conv2d8": 8}[self.input_layer])
+                              {"conv2d": 0, "linear": 1, "conv2d6": 6, "conv2d8": 8}[self.input_layer], self.options)
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ppasr_create(ctypes.byref(desc), blobs, len(sd), ctypes.byref(handle)))
@@ -295,11 +309,15 @@ class ConformerStream:
         t = self.cache_frames
         att = torch.empty(m.num_blocks, m.attention_heads, t, 2 * (m.output_size // m.attention_heads),
                           dtype=torch.float32, device=m.device)
-        cnn = torch.empty(m.num_blocks, 1, m.output_size, m.cnn_module_kernel - 1, dtype=torch.float32,
-                          device=m.device)
+        # (use_cnn_module = False: every layer returns zeros([0, 0, 0]) as its conv cache, encoder.py:405 -> [L, 0, 0, 0])
+        if getattr(m, "use_cnn_module", True):
+            cnn = torch.empty(m.num_blocks, 1, m.output_size, m.cnn_module_kernel - 1, dtype=torch.float32, device=m.device)
+        else:
+            cnn = torch.empty(m.num_blocks, 0, 0, 0, dtype=torch.float32, device=m.device)
         with torch.cuda.device(m.device):
             stream = torch.cuda.current_stream(m.device).cuda_stream
-            _lib.check(self.lib.ppasr_stream_export_cache(self._s, att.data_ptr() if t > 0 else None, cnn.data_ptr(),
+            _lib.check(self.lib.ppasr_stream_export_cache(self._s, att.data_ptr() if t > 0 else None,
+                                                          cnn.data_ptr() if cnn.numel() else None,
                                                           stream))
         return att, cnn
 

@@ -64,13 +64,16 @@ def _linear(sd, prefix, fin, fout, rng, bias=True):
 def conformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, output_size=256, attention_heads=4,
                          linear_units=2048, num_blocks=12, cnn_module_kernel=15, seed=1234,
                          ctc_sharpen=8.0, perturb_norm=False, cmvn_mean=10.0, cmvn_istd=1.0 / 3.3,
-                         cnn_module_norm="layer_norm", input_layer="conv2d"):
+                         cnn_module_norm="layer_norm", input_layer="conv2d", pos_enc_layer_type="rel_pos",
+                         macaron_style=True, use_cnn_module=True, concat_after=False):
     """Random-init ``ConformerModel`` inference parameters (encoder + CTC head).
 
     ``ctc_sharpen`` multiplies ``ctc.ctc_lo.weight`` so that greedy top-1 margins
     are realistic for un-trained weights (documented deviation).
     ``perturb_norm`` draws LayerNorm gamma/beta away from (1, 0) so tests notice
-    a dropped affine term.
+    a dropped affine term.  The keyword arguments behind ``input_layer`` follow ``ConformerEncoder.__init__``
+    (conformer/encoder.py:38-48): the parameter SET changes with them exactly as the reference's ``state_dict()`` does
+    (checked by loading the dict by name into the reference classes, tests/golden/make_ref_goldens.py).
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     d, h = output_size, attention_heads
@@ -82,10 +85,16 @@ def conformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, output_siz
     if perturb_norm:
         sd["encoder.global_cmvn.mean"] += (0.5 * rng.standard_normal(input_dim)).astype(np.float32)
         sd["encoder.global_cmvn.istd"] *= (1.0 + 0.1 * rng.uniform(-1, 1, input_dim)).astype(np.float32)
-    # Conv2dSubsampling4 / 6 / 8 (subsampling.py): base.Conv2D (Kaiming, fan_in = Cin*kh*kw)
-    sd["encoder.embed.conv.0.weight"] = _kaiming(rng, (d, 1, 3, 3), 9)
-    sd["encoder.embed.conv.0.bias"] = _kaiming(rng, (d,), d)
-    if input_layer == "conv2d":
+    if input_layer == "linear":  # LinearNoSubsampling (subsampling.py:39-42): nn.Linear, nn.LayerNorm, Dropout, ReLU
+        _linear(sd, "encoder.embed.out.0", input_dim, d, rng)
+        _layernorm(sd, "encoder.embed.out.1", d, rng, perturb_norm)
+    else:
+        # Conv2dSubsampling4 / 6 / 8 (subsampling.py): base.Conv2D (Kaiming, fan_in = Cin*kh*kw)
+        sd["encoder.embed.conv.0.weight"] = _kaiming(rng, (d, 1, 3, 3), 9)
+        sd["encoder.embed.conv.0.bias"] = _kaiming(rng, (d,), d)
+    if input_layer == "linear":
+        pass
+    elif input_layer == "conv2d":
         f_last, lin = (f1 - 1) // 2, "encoder.embed.out.0"
         sd["encoder.embed.conv.2.weight"] = _kaiming(rng, (d, d, 3, 3), d * 9)
         sd["encoder.embed.conv.2.bias"] = _kaiming(rng, (d,), d)
@@ -100,31 +109,38 @@ def conformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, output_siz
             sd[f"encoder.embed.conv.{idx}.bias"] = _kaiming(rng, (d,), d)
     else:
         raise ValueError(input_layer)
-    sd[lin + ".weight"] = _xavier(rng, (d * f_last, d), d * f_last, d)
-    sd[lin + ".bias"] = np.zeros(d, np.float32)
+    if input_layer != "linear":
+        sd[lin + ".weight"] = _xavier(rng, (d * f_last, d), d * f_last, d)
+        sd[lin + ".bias"] = np.zeros(d, np.float32)
     for i in range(num_blocks):
         p = f"encoder.encoders.{i}."
         for name in ("linear_q", "linear_k", "linear_v", "linear_out"):
             _linear(sd, p + "self_attn." + name, d, d, rng)
-        _linear(sd, p + "self_attn.linear_pos", d, d, rng, bias=False)
-        sd[p + "self_attn.pos_bias_u"] = _xavier(rng, (h, dk), h, dk)
-        sd[p + "self_attn.pos_bias_v"] = _xavier(rng, (h, dk), h, dk)
-        for ff in ("feed_forward", "feed_forward_macaron"):
+        if pos_enc_layer_type == "rel_pos":  # RelPositionMultiHeadedAttention; abs_pos / no_pos: MultiHeadedAttention
+            _linear(sd, p + "self_attn.linear_pos", d, d, rng, bias=False)
+            sd[p + "self_attn.pos_bias_u"] = _xavier(rng, (h, dk), h, dk)
+            sd[p + "self_attn.pos_bias_v"] = _xavier(rng, (h, dk), h, dk)
+        for ff in ("feed_forward", "feed_forward_macaron") if macaron_style else ("feed_forward",):
             _linear(sd, p + ff + ".w_1", d, linear_units, rng)
             _linear(sd, p + ff + ".w_2", linear_units, d, rng)
-        # ConvolutionModule: base.Conv1D, weight [out, in/groups, k]
-        sd[p + "conv_module.pointwise_conv1.weight"] = _kaiming(rng, (2 * d, d, 1), d)
-        sd[p + "conv_module.pointwise_conv1.bias"] = _kaiming(rng, (2 * d,), 2 * d)
-        sd[p + "conv_module.depthwise_conv.weight"] = _kaiming(rng, (d, 1, cnn_module_kernel), cnn_module_kernel)
-        sd[p + "conv_module.depthwise_conv.bias"] = _kaiming(rng, (d,), d)
-        if cnn_module_norm == "batch_norm":
-            _batchnorm(sd, p + "conv_module.norm", d, rng)
-        else:
-            _layernorm(sd, p + "conv_module.norm", d, rng, perturb_norm)
-        sd[p + "conv_module.pointwise_conv2.weight"] = _kaiming(rng, (d, d, 1), d)
-        sd[p + "conv_module.pointwise_conv2.bias"] = _kaiming(rng, (d,), d)
-        for n in ("norm_ff", "norm_mha", "norm_ff_macaron", "norm_conv", "norm_final"):
+        if use_cnn_module:
+            # ConvolutionModule: base.Conv1D, weight [out, in/groups, k]
+            sd[p + "conv_module.pointwise_conv1.weight"] = _kaiming(rng, (2 * d, d, 1), d)
+            sd[p + "conv_module.pointwise_conv1.bias"] = _kaiming(rng, (2 * d,), 2 * d)
+            sd[p + "conv_module.depthwise_conv.weight"] = _kaiming(rng, (d, 1, cnn_module_kernel), cnn_module_kernel)
+            sd[p + "conv_module.depthwise_conv.bias"] = _kaiming(rng, (d,), d)
+            if cnn_module_norm == "batch_norm":
+                _batchnorm(sd, p + "conv_module.norm", d, rng)
+            else:
+                _layernorm(sd, p + "conv_module.norm", d, rng, perturb_norm)
+            sd[p + "conv_module.pointwise_conv2.weight"] = _kaiming(rng, (d, d, 1), d)
+            sd[p + "conv_module.pointwise_conv2.bias"] = _kaiming(rng, (d,), d)
+        norms = ["norm_ff", "norm_mha"] + (["norm_ff_macaron"] if macaron_style else []) + \
+                (["norm_conv", "norm_final"] if use_cnn_module else [])
+        for n in norms:
             _layernorm(sd, p + n, d, rng, perturb_norm)
+        if concat_after:  # encoder.py:341-342
+            _linear(sd, p + "concat_linear", 2 * d, d, rng)
     _layernorm(sd, "encoder.after_norm", d, rng, perturb_norm)
     sd["ctc.ctc_lo.weight"] = _xavier(rng, (d, vocab_size), d, vocab_size) * np.float32(ctc_sharpen)
     sd["ctc.ctc_lo.bias"] = np.zeros(vocab_size, np.float32)

@@ -44,7 +44,33 @@ SMALL = {
     "conf8": _former("conformer", True, 2, 61, 547, (3, 203, [203, 150, 47], 548), chunk_frames=64 * 3 + 50,
                      required=(-16,), input_layer="conv2d8"),
     # a width the fused 256-column kernels do not cover: output_size 512 with 8 heads (the generic-width route)
-    "conf512": _former("conformer", True, 2, 61, 549, (2, 131, [131, 77], 550), output_size=512, attention_heads=8),
+    "conf512": _former("conformer", True, 2, 61, 549, (2, 131, [131, 77], 550), chunk_frames=64 * 3 + 30,
+                       required=(-16, 32), output_size=512, attention_heads=8),
+    "conf768_8": _former("conformer", False, 1, 61, 551, (2, 147, [147, 80], 552), output_size=768, attention_heads=12,
+                         input_layer="conv2d8"),
+    # ---- the ConformerEncoder constructor arguments no shipped YAML sets (conformer/encoder.py:38-48): the general
+    # layer route.  Between them the cases cover every pos_enc_layer_type, normalize_before / concat_after /
+    # macaron_style / use_cnn_module = both values, input_layer = linear, an unusual conv kernel, every activation ----
+    "opt_abs": _former("conformer", True, 2, 61, 561, (2, 131, [131, 77], 562), chunk_frames=64 * 3 + 30, required=(-16, 32),
+                       pos_enc_layer_type="abs_pos", activation_type="leakyrelu"),
+    "opt_nopos_post": _former("conformer", True, 2, 61, 563, (2, 131, [131, 90], 564), chunk_frames=64 * 2 + 30,
+                              required=(-16,), pos_enc_layer_type="no_pos", normalize_before=False, activation_type="relu"),
+    "opt_nomac_concat": _former("conformer", False, 2, 61, 565, (3, 131, [131, 100, 1], 566), macaron_style=False,
+                                concat_after=True, activation_type="gelu"),
+    "opt_nocnn": _former("conformer", True, 2, 61, 567, (2, 131, [131, 77], 568), chunk_frames=64 * 2 + 30, required=(-16, 32),
+                         use_cnn_module=False, activation_type="tanh"),
+    "opt_linear": _former("conformer", False, 2, 61, 569, (2, 61, [61, 38], 570), input_layer="linear",
+                          activation_type="hardswish"),
+    "opt_k9": _former("conformer", False, 2, 61, 571, (2, 131, [131, 70], 572), cnn_module_kernel=9, activation_type="selu",
+                      cnn_module_norm="batch_norm"),
+    "opt_k5_post": _former("conformer", True, 1, 61, 573, (2, 99, [99, 50], 574), chunk_frames=64 * 2 + 30, required=(32,),
+                           cnn_module_kernel=5, normalize_before=False, concat_after=True, pos_enc_layer_type="abs_pos",
+                           activation_type="elu"),
+    "act_hardtanh": _former("conformer", True, 1, 61, 575, (1, 99, [99], 576), activation_type="hardtanh"),
+    # (31-tap causal conv: the 30 cached conv inputs outnumber a 16-frame chunk)
+    "act_relu6": _former("conformer", True, 1, 61, 577, (1, 99, [99], 578), chunk_frames=64 * 2 + 30, required=(-16,),
+                         activation_type="relu6", cnn_module_kernel=31),
+    "act_hardshrink": _former("conformer", True, 1, 61, 579, (1, 99, [99], 580), activation_type="hardshrink"),
     "sq_bn": _former("squeezeformer", False, 3, 59, 543, (2, 131, [131, 70], 544), reduce_idx=1, recover_idx=2,
                      cnn_norm_type="batch_norm"),
 }
@@ -88,9 +114,7 @@ def state_dict(case, perturb=True):
     pn = perturb and not full
     if fam == "conformer":
         return conformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn,
-                                    cnn_module_norm=kw.get("cnn_module_norm", "layer_norm"),
-                                    input_layer=kw.get("input_layer", "conv2d"), output_size=kw.get("output_size", 256),
-                                    attention_heads=kw.get("attention_heads", 4))
+                                    **{k: v for k, v in kw.items() if k not in ("activation_type", "normalize_before")})
     if fam == "efficient_conformer":
         if full:
             return efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=seed)
@@ -124,11 +148,12 @@ def reference_encoder_conf(case):
     and is ignored there -- efficient_conformer/encoder.py:26-56 -- the shipped values equal the defaults)."""
     fam, L, kw = case["family"], case["L"], case["kw"]
     if fam == "conformer":
-        return dict(output_size=kw.get("output_size", 256), attention_heads=kw.get("attention_heads", 4), linear_units=2048,
-                    num_blocks=L, dropout_rate=0.1,
-                    positional_dropout_rate=0.1, attention_dropout_rate=0.1, input_layer=kw.get("input_layer", "conv2d"),
-                    normalize_before=True, cnn_module_kernel=15, use_cnn_module=True, activation_type="swish", pos_enc_layer_type="rel_pos",
-                    cnn_module_norm=kw.get("cnn_module_norm", "layer_norm"))
+        c = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, dropout_rate=0.1,
+                 positional_dropout_rate=0.1, attention_dropout_rate=0.1, input_layer="conv2d", normalize_before=True,
+                 cnn_module_kernel=15, use_cnn_module=True, activation_type="swish", pos_enc_layer_type="rel_pos",
+                 cnn_module_norm="layer_norm")
+        c.update(kw)  # (concat_after / macaron_style appear only where a case sets them)
+        return c
     if fam == "efficient_conformer":
         c = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, activation_type="swish",
                  cnn_module_kernel=15, cnn_module_norm="layer_norm", dropout_rate=0.1, input_layer="conv2d",

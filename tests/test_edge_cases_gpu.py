@@ -159,7 +159,7 @@ def test_wider_front_ends_edges(input_layer, t_min, rate):
 @pytest.mark.parametrize("streaming,norm", [(True, "layer_norm"), (False, "batch_norm")])
 def test_generic_width_512_with_8_heads(streaming, norm):
     """output_size 512 / attention_heads 8 (capi_generic.hip: dense layers + k_attention with 8 heads + row kernels):
-    logits vs the oracle on ragged batches (lengths 1 and 0 included, > 128 keys), the fused greedy call, refusals."""
+    logits vs the oracle on ragged batches (lengths 1 and 0 included, > 128 keys), the fused greedy call, chunks."""
     from oracle.conformer_oracle import ConformerOracle
     from ppasr_amd import _lib
     from ppasr_amd.model_utils.conformer.model import ConformerModel
@@ -181,6 +181,17 @@ def test_generic_width_512_with_8_heads(streaming, norm):
         for b in range(B):
             ids, _, _ = greedy_tokens(ref_probs[b].numpy())
             assert np.array_equal(ids, tokens[b, :int(n[b])].cpu().numpy()), b
-    if streaming:
-        with pytest.raises(_lib.PPASRHipError):
-            model.get_encoder_out_chunk(np.zeros((1, 67, 80), np.float32), 0, -1)
+    if streaming:  # forward_chunk on the general route: the stateless signature, caches through the reference layouts
+        x, _ = synth_features(1, 67 + 64 + 40, seed=11)
+        att = cnn = r_att = r_cnn = None
+        off = 0
+        for (a, b) in ((0, 67), (64, 131), (128, 171)):
+            p, att, cnn = model.get_encoder_out_chunk(x[:, a:b], off, 20, att, cnn)
+            rp, r_att, r_cnn = oracle.get_encoder_out_chunk(x[:, a:b], off, 20, r_att, r_cnn)
+            off += p.shape[1]
+            assert _rel(p.cpu().numpy(), rp.numpy()) < TOL
+        assert tuple(att.shape) == tuple(r_att.shape) == (L, 8, 20, 128)
+        assert _rel(att.cpu().numpy(), r_att.numpy()) < TOL and _rel(cnn.cpu().numpy(), r_cnn.numpy()) < TOL
+        with pytest.raises(_lib.PPASRHipError):  # session groups stay on the fused route
+            from ppasr_amd.model_utils.conformer.model import ConformerStreamGroup
+            ConformerStreamGroup(model, 2)

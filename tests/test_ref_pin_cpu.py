@@ -45,7 +45,9 @@ def make_oracle(case, sd):
     return DeepSpeech2Oracle(sd, num_rnn_layers=L, streaming=case["streaming"], use_gru=kw.get("use_gru", False))
 
 
-FORMERS = [k for k, c in rc.SMALL.items() if c["family"] != "deepspeech2"]
+# (the opt_* / act_* cases -- non-default ConformerEncoder arguments -- have no torch restatement: the HIP path is compared
+#  with the reference-source fixtures directly, tests/test_ref_pin_gpu.py)
+FORMERS = [k for k, c in rc.SMALL.items() if c["family"] != "deepspeech2" and not k.startswith(("opt_", "act_"))]
 DS2 = [k for k, c in rc.SMALL.items() if c["family"] == "deepspeech2"]
 
 
