@@ -93,6 +93,11 @@ struct VtOut {
   int stride = 0;
 };
 
+// dynamic-LDS request of a ragged (PadSkip) launch: more than half of a CU's LDS, so that workgroups do not share a CU
+// (see the comment at ragged_lds in conformer_kernels.hip); kernels launched with it set kLdsExclusive as their maximum
+constexpr size_t kLdsExclusive = 82 * 1024;
+size_t ragged_lds(size_t lds, const PadSkip& ps, int n_blocks);
+
 // ---- launchers (all asynchronous on `st`) ----
 void launch_posproj(const float* pe, const float* wpos /*[d][d] in,out*/, const float* bpos_or_null, float* ptab,
                     int max_len, hipStream_t st, int d = 256);

@@ -2,6 +2,8 @@
 // Reference semantics: ppasr/model_utils/conformer/{encoder,attention,convolution,positionwise,
 // subsampling,embedding}.py, model_utils/loss/ctc.py, decoders/ctc_greedy_decoder.py
 // (file:line cited per kernel).  All arithmetic is fp32 (the reference's inference dtype).
+#include <cstdlib>
+
 #include "conformer_kernels.h"
 #include "launch.h"
 #include "phases.h"
@@ -269,11 +271,24 @@ void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b
   else CONV2_REM(3);
 #undef CONV2_REM
 }
+// Ragged launches (PadSkip) of kernels whose LDS footprint lets two or more workgroups share a CU: the whole grid is
+// resident at once, the workgroups of skipped row blocks exit immediately, and the ACTIVE ones are left wherever they
+// were placed -- two on some CUs, none on others (cfg5: 208 active of 375 row blocks: the CTC head ran 307 us where one
+// block per CU takes ~ 140).  Asking for more than half of the LDS makes the workgroups exclusive: 256 are placed, a
+// skipped one frees its CU for the next, and the active blocks end up one per CU.
+size_t ragged_lds(size_t lds, const PadSkip& ps, int n_blocks) {
+  static const bool on = [] {
+    const char* e = std::getenv("PPASR_RAGGED_EXCLUSIVE");  // (0: the kernels' own footprints, for A/B measurements)
+    return !(e && e[0] == '0');
+  }();
+  return (on && ps.lens && n_blocks > 256 && lds < kLdsExclusive) ? kLdsExclusive : lds;
+}
+
 void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, bool scale_before_bias,
                   hipStream_t st, const PadSkip& ps, int k_slices, float* part) {
   constexpr int MT = 1, KC = 256;
   DenseSrc src{y2, K, KC};
-  size_t lds = 2 * (32 * MT) * (KC + 4) * sizeof(float);
+  size_t lds = ragged_lds(2 * (32 * MT) * (KC + 4) * sizeof(float), ps, (M + 31) / 32);
   if (k_slices > 1 && part) {  // under-filled launch: the K = 4864 contraction over k_slices workgroups per row block
     PPASR_LAUNCH((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, 1, k_slices), dim3(kThreads), lds,
                        st, src, fw.embed_w, fw.embed_b, part, M, K / KC, xscale, kD, kD, 0, ps);
@@ -479,8 +494,9 @@ struct AttnCfg {
 
 // Block = (64-query tile, head, utterance), 4 waves.  Per 128-key block:
 //   S phase : wave w owns keys [32w, 32w+32); the B operand (K' rows) is read straight from global / L2 into
-//             registers (lane = key, 4 consecutive features per load, the row-block GEMM's fragment trick) with a
-//             4-deep prefetch ring -- no LDS staging, no barriers; A = Q' from LDS; two row tiles share each B load.
+//             registers (lane = key, 4 consecutive features per load, the row-block GEMM's fragment trick) in
+//             double-buffered bursts of 4 k-groups (whole cache lines) -- no LDS staging, no barriers; A = Q' from
+//             LDS; two row tiles share each B load.
 //   softmax : online (running max / sum per query row), 16-lane groups handle one row each (4 rows per wave-op).
 //   PV      : wave = (column-tile group, key half); B = V rows from global (one dword per lane per MFMA, two
 //             coalesced 128-B segments per wave-load), A = P from LDS.
@@ -580,11 +596,20 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
       for (int r = 0; r < 16; ++r) acc_o[mt][t][r] = 0.f;
   const int ctg = wave & 1, kh = wave >> 1;
   const float score_mul = DK == 64 ? 0.125f : 0.07216878364870322f;  // 1 / sqrt(d_k [* group_size])
-  constexpr int PF = 4, PFV = 8;
-  f32x4 ring[PF];           // K' fragments, primed one key block ahead (loads stay in flight across softmax / PV)
-  float ringv[PFV][C::NO];  // V values, primed before the softmax pass
+  constexpr int PFV = 8, NSG = C::NG / 4;
+  static_assert(NSG % 2 == 0, "the K' double buffer keeps its parity across key blocks");
+  // K' fragments in bursts of 4 k-groups = one whole 128-byte line of the lane's key row (its 16-byte pieces of 4
+  // consecutive k-groups are requested back to back, so the line comes from L2 once; one k-group at a time the 4 waves
+  // of the workgroups sharing a CU push their 32 lines per load through the 32 KiB L1 between two uses of a line --
+  // the measure k_attn_out_glu took in round 2), double buffered: super-group sg + 1 is in flight while sg feeds the
+  // MFMAs, the first one of the next key block across the softmax / PV phases
+  f32x4 kq[2][4];
+  auto load_sg = [&](int buf, int j, int sg) {
 #pragma unroll
-  for (int s = 0; s < PF; ++s) ring[s] = kfrag(wave * 32 + (lane & 31), s);
+    for (int i = 0; i < 4; ++i) kq[buf][i] = kfrag(j, 4 * sg + i);
+  };
+  float ringv[PFV][C::NO];  // V values, primed before the softmax pass
+  load_sg(0, wave * 32 + (lane & 31), 0);
   __syncthreads();
 
   const int nkb = (T2 + 127) / 128;
@@ -600,18 +625,22 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
       const int jkey = key0 + wave * 32 + (lane & 31);
       const float* a_ptr = Qs + (lane & 31) * C::QLD + 4 * (lane >> 5);
 #pragma unroll
-      for (int g = 0; g < C::NG; ++g) {
-        const f32x4 bb = ring[g % PF];
-        if (g + PF < C::NG) ring[g % PF] = kfrag(jkey, g + PF);
-        else if (kb + 1 < nkb) ring[g % PF] = kfrag(jkey + 128, g + PF - C::NG);  // next key block's first groups
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(a_ptr + 8 * g);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(a_ptr + 32 * C::QLD + 8 * g);
+      for (int sg = 0; sg < NSG; ++sg) {
+        if (sg + 1 < NSG) load_sg((sg + 1) & 1, jkey, sg + 1);
+        else if (kb + 1 < nkb) load_sg(0, jkey + 128, 0);  // next key block's first super-group
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc_s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb[j], acc_s[0], 0, 0, 0);
-          acc_s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bb[j], acc_s[1], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+          const int g = 4 * sg + i;
+          const f32x4 bb = kq[sg & 1][i];
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(a_ptr + 8 * g);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(a_ptr + 32 * C::QLD + 8 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc_s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb[j], acc_s[0], 0, 0, 0);
+            acc_s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bb[j], acc_s[1], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (kb > 0) __syncthreads();  // every wave finished the previous block's PV reads of Ss
@@ -2028,11 +2057,12 @@ void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr
                      float* row_sum, int M, hipStream_t st, const PadSkip& ps, int n_slices, float* part) {
   const int ny = (n_slices > 1 && part) ? n_slices : 1;
   dim3 grid((M + kRows - 1) / kRows, ny);
+  const size_t lds = ragged_lds(kLdsCtc, ps, (int)(grid.x * grid.y));
   if (logits)
-    PPASR_LAUNCH(k_ctc_head<true>, grid, dim3(kThreads), kLdsCtc, st, x, hw, logits, fr_argmax, fr_maxprob, row_max,
+    PPASR_LAUNCH(k_ctc_head<true>, grid, dim3(kThreads), lds, st, x, hw, logits, fr_argmax, fr_maxprob, row_max,
                        row_sum, M, ps, part);
   else
-    PPASR_LAUNCH(k_ctc_head<false>, grid, dim3(kThreads), kLdsCtc, st, x, hw, logits, fr_argmax, fr_maxprob, row_max,
+    PPASR_LAUNCH(k_ctc_head<false>, grid, dim3(kThreads), lds, st, x, hw, logits, fr_argmax, fr_maxprob, row_max,
                        row_sum, M, ps, part);
   if (ny > 1)
     PPASR_LAUNCH(k_ctc_merge, dim3((M + 255) / 256), dim3(256), 0, st, part, ny, fr_argmax, fr_maxprob, row_max, row_sum,
@@ -2207,14 +2237,14 @@ hipError_t configure_kernels() {
   SET_LDS(k_attn_out_glu, kLdsAttnOutGlu);
   SET_LDS(k_conv_ffn_stride<15>, kLdsConvFfn);
   SET_LDS(k_conv_ffn_stride<7>, kLdsConvFfn);
-  SET_LDS(k_ctc_head<true>, kLdsCtc);
-  SET_LDS(k_ctc_head<false>, kLdsCtc);
+  SET_LDS(k_ctc_head<true>, kLdsExclusive);  // (>= kLdsCtc: see ragged_lds)
+  SET_LDS(k_ctc_head<false>, kLdsExclusive);
   SET_LDS((k_gemm_stream<4, 128, true, false, Conv2Src>), 2 * 128 * 132 * sizeof(float));
   SET_LDS((k_gemm_stream<3, 128, true, false, Conv2Src>), 2 * 96 * 132 * sizeof(float));
   SET_LDS((k_gemm_stream<2, 128, true, false, Conv2Src>), 2 * 64 * 132 * sizeof(float));
   SET_LDS((k_gemm_stream<1, 128, true, false, Conv2Src>), 2 * 32 * 132 * sizeof(float));
-  SET_LDS((k_gemm_stream<1, 256, false, false, DenseSrc>), 2 * 32 * 260 * sizeof(float));
-  SET_LDS((k_gemm_stream<1, 256, false, true, DenseSrc>), 2 * 32 * 260 * sizeof(float));
+  SET_LDS((k_gemm_stream<1, 256, false, false, DenseSrc>), kLdsExclusive);
+  SET_LDS((k_gemm_stream<1, 256, false, true, DenseSrc>), kLdsExclusive);
 #undef SET_LDS
   return hipSuccess;
 }

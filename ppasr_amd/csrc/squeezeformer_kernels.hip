@@ -9,6 +9,7 @@
 // GLU(bias) = `glu_pad` directly.
 #include "launch.h"
 #include "squeezeformer_kernels.h"
+#include "conformer_kernels.h"  // ragged_lds / kLdsExclusive
 
 #include "phases.h"
 
@@ -405,7 +406,7 @@ constexpr size_t kLds2 = 2 * kRows * kLda * sizeof(float);
 
 void launch_sq_qkv(const float* x, float* qkv, const f32x4* wqkv, const float* bqkv, int M, hipStream_t st,
                    const PadSkip& ps) {
-  PPASR_LAUNCH(k_sq_qkv, rb_grid(M), dim3(kThreads), kLds1, st, x, qkv, wqkv, bqkv, M, ps);
+  PPASR_LAUNCH(k_sq_qkv, rb_grid(M), dim3(kThreads), ragged_lds(kLds1, ps, (int)rb_grid(M).x), st, x, qkv, wqkv, bqkv, M, ps);
 }
 void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, float* xhat_out, const SqLayerW& w,
                    const int64_t* lens, int M, int Tp, int mask_mul, int n_chunks, hipStream_t st, const PadSkip& ps) {
@@ -435,13 +436,13 @@ void launch_sq_pw1glu(const float* x2, float* g, float* xhat_out, const SqLayerW
 }
 void launch_sq_reduce(const float* x, float* xr, float* qkv, const SqReduceW& rw, const f32x4* wqkv, const float* bqkv,
                       const int64_t* lens, int B, int Tp, int Tr, hipStream_t st, const PadSkip& ps) {
-  PPASR_LAUNCH(k_sq_reduce, rb_grid(B * Tr), dim3(kThreads), kLds2, st, x, xr, qkv, rw, wqkv, bqkv, lens, B, Tp, Tr,
-                     ps);
+  PPASR_LAUNCH(k_sq_reduce, rb_grid(B * Tr), dim3(kThreads), ragged_lds(kLds2, ps, (int)rb_grid(B * Tr).x), st, x, xr, qkv,
+               rw, wqkv, bqkv, lens, B, Tp, Tr, ps);
 }
 void launch_sq_recover(const float* xr, const float* saved, float* x, float* qkv, const f32x4* wrec, const float* brec,
                        const f32x4* wqkv, const float* bqkv, int B, int Tp, int Tr, hipStream_t st, const PadSkip& ps) {
-  PPASR_LAUNCH(k_sq_recover, rb_grid(B * Tp), dim3(kThreads), kLds2, st, xr, saved, x, qkv, wrec, brec, wqkv, bqkv, B,
-                     Tp, Tr, ps);
+  PPASR_LAUNCH(k_sq_recover, rb_grid(B * Tp), dim3(kThreads), ragged_lds(kLds2, ps, (int)rb_grid(B * Tp).x), st, xr, saved,
+               x, qkv, wrec, brec, wqkv, bqkv, B, Tp, Tr, ps);
 }
 void launch_ln_rows(float* x, const float* g, const float* b, int M, hipStream_t st, const PadSkip& ps) {
   PPASR_LAUNCH(k_ln_rows, rb_grid(M), dim3(kThreads), kLds1, st, x, g, b, M, ps);
@@ -457,9 +458,10 @@ hipError_t configure_squeezeformer_kernels() {
   SET_LDS((k_sq_tail<15, false>), kLdsSqTail);
   SET_LDS((k_sq_tail<31, true>), kLdsSqTail);
   SET_LDS((k_sq_tail<15, true>), kLdsSqTail);
-  SET_LDS(k_sq_reduce, kLds2);
+  SET_LDS(k_sq_reduce, kLdsExclusive);  // (ragged launches: ragged_lds)
   SET_LDS(k_sq_oproj, kLds2);
-  SET_LDS(k_sq_recover, kLds2);
+  SET_LDS(k_sq_recover, kLdsExclusive);
+  SET_LDS(k_sq_qkv, kLdsExclusive);
 #undef SET_LDS
   return hipSuccess;
 }
