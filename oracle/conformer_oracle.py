@@ -24,12 +24,37 @@ def _t(sd, name, dtype):
     return torch.from_numpy(np.ascontiguousarray(sd[name])).to(dtype)
 
 
+_ACTIVATIONS = {
+    "swish": lambda x: x * torch.sigmoid(x),  # utils/common.py:201 (paddle.nn.Swish)
+    "relu": torch.relu,
+    "relu6": lambda x: torch.clamp(x, 0.0, 6.0),
+    "tanh": torch.tanh,
+    "gelu": lambda x: F.gelu(x),  # paddle.nn.GELU(approximate=False)
+    "elu": lambda x: F.elu(x, 1.0),
+    "selu": torch.selu,
+    "leakyrelu": lambda x: F.leaky_relu(x, 0.01),
+    "hardtanh": lambda x: torch.clamp(x, -1.0, 1.0),
+    "hardswish": F.hardswish,
+    "hardshrink": lambda x: F.hardshrink(x, 0.5),
+}
+
+
 class ConformerOracle:
     """Functional restatement of ``ConformerModel`` (model_utils/conformer/model.py:16)
     for inference: ``get_encoder_out`` (:148) and ``get_encoder_out_chunk`` (:164)."""
 
     def __init__(self, sd, attention_heads=4, num_blocks=12, cnn_module_kernel=15, causal=True,
-                 max_len=5000, dtype=torch.float32):
+                 max_len=5000, dtype=torch.float32, pos_enc_layer_type="rel_pos", normalize_before=True,
+                 concat_after=False, macaron_style=True, use_cnn_module=True, activation_type="swish"):
+        # the remaining ConformerEncoder.__init__ arguments (conformer/encoder.py:38-48); input_layer is read off the
+        # parameter names (_sub_kind)
+        self.pos_type = pos_enc_layer_type
+        self.pre_norm = normalize_before
+        self.concat_after = concat_after
+        self.macaron = macaron_style
+        self.use_cnn = use_cnn_module
+        self.act = _ACTIVATIONS[activation_type]  # get_activation (utils/common.py:189-206), Paddle's default parameters
+        self.ff_scale = 0.5 if macaron_style else 1.0  # encoder.py:330-334
         self.dtype = dtype
         self.h = attention_heads
         self.L = num_blocks
@@ -71,9 +96,8 @@ class ConformerOracle:
             return (x - self.p[prefix + "._mean"]) * inv * self.p[prefix + ".weight"] + self.p[prefix + ".bias"]
         return self._ln(x, prefix, eps)
 
-    @staticmethod
-    def _swish(x):
-        return x * torch.sigmoid(x)  # utils/common.py:201 (paddle.nn.Swish)
+    def _swish(self, x):
+        return self.act(x)  # `activation` of PositionwiseFeedForward / ConvolutionModule (swish in every shipped YAML)
 
     # ---- embed --------------------------------------------------------------
     def _cmvn(self, x):
@@ -83,6 +107,8 @@ class ConformerOracle:
     def _sub_kind(self):
         """4, 6 or 8: which Conv2dSubsampling class the parameters belong to (subsampling.py:63, 118, 160): the 6x / 8x
         classes name their projection `linear`, the 8x one has a third conv (`conv.4`)."""
+        if "encoder.embed.out.1.weight" in self.p:
+            return 1  # LinearNoSubsampling (subsampling.py:24-65): out = Sequential(Linear, LayerNorm, Dropout, ReLU)
         if "encoder.embed.out.0.weight" in self.p:
             return 4
         return 8 if "encoder.embed.conv.4.weight" in self.p else 6
@@ -90,6 +116,8 @@ class ConformerOracle:
     def _sub_masks(self, masks):
         """The mask slicing of the subsampling classes (subsampling.py:115, 157, 205)."""
         k = self._sub_kind()
+        if k == 1:
+            return masks
         if k == 4:
             return masks[:, :, :-2:2][:, :, :-2:2]
         if k == 6:
@@ -99,19 +127,27 @@ class ConformerOracle:
     def _embed(self, x, offset):
         # Conv2dSubsampling4 / 6 / 8 .forward  conformer/subsampling.py:96-115, 144-157, 191-205
         k = self._sub_kind()
-        x = x.unsqueeze(1)
-        x = F.relu(F.conv2d(x, self.p["encoder.embed.conv.0.weight"], self.p["encoder.embed.conv.0.bias"], stride=2))
-        x = F.relu(F.conv2d(x, self.p["encoder.embed.conv.2.weight"], self.p["encoder.embed.conv.2.bias"],
-                            stride=3 if k == 6 else 2))
-        if k == 8:
-            x = F.relu(F.conv2d(x, self.p["encoder.embed.conv.4.weight"], self.p["encoder.embed.conv.4.bias"], stride=2))
-        b, c, t, f = x.shape
-        x = self._linear(x.permute(0, 2, 1, 3).reshape(b, t, c * f), "encoder.embed.out.0" if k == 4 else "encoder.embed.linear")
-        # RelPositionalEncoding.forward  conformer/embedding.py:102-115 (x*sqrt(d); pos_emb NOT added)
+        if k == 1:
+            x = F.relu(self._ln(self._linear(x, "encoder.embed.out.0"), "encoder.embed.out.1", eps=1e-12))
+            t = x.shape[1]
+        else:
+            x = x.unsqueeze(1)
+            x = F.relu(F.conv2d(x, self.p["encoder.embed.conv.0.weight"], self.p["encoder.embed.conv.0.bias"], stride=2))
+            x = F.relu(F.conv2d(x, self.p["encoder.embed.conv.2.weight"], self.p["encoder.embed.conv.2.bias"],
+                                stride=3 if k == 6 else 2))
+            if k == 8:
+                x = F.relu(F.conv2d(x, self.p["encoder.embed.conv.4.weight"], self.p["encoder.embed.conv.4.bias"], stride=2))
+            b, c, t, f = x.shape
+            x = self._linear(x.permute(0, 2, 1, 3).reshape(b, t, c * f),
+                             "encoder.embed.out.0" if k == 4 else "encoder.embed.linear")
+        if self.pos_type == "no_pos":  # NoPositionalEncoding.forward  embedding.py:18-19
+            return x, None
         assert offset + t < self.max_len
-        x = x * math.sqrt(self.d)
         pos_emb = self.pe[:, offset:offset + t]
-        return x, pos_emb
+        if self.pos_type == "abs_pos":  # PositionalEncoding.forward  embedding.py:55-72
+            return x * math.sqrt(self.d) + pos_emb, pos_emb
+        # RelPositionalEncoding.forward  conformer/embedding.py:102-115 (x*sqrt(d); pos_emb NOT added)
+        return x * math.sqrt(self.d), pos_emb
 
     def conv_intermediates(self, speech):
         """conv1 / conv2 activations (NCHW) for kernel-level parity tests."""
@@ -137,13 +173,16 @@ class ConformerOracle:
             k = torch.cat([key_cache, k], dim=2)
             v = torch.cat([value_cache, v], dim=2)
         new_cache = torch.cat((k, v), dim=-1)  # :232
-        p = self._linear(pos_emb, prefix + ".linear_pos", bias=False)
-        p = p.reshape(pos_emb.shape[0], -1, h, dk).permute(0, 2, 1, 3)  # :234-236
-        q_u = q + self.p[prefix + ".pos_bias_u"].unsqueeze(1)  # :241
-        q_v = q + self.p[prefix + ".pos_bias_v"].unsqueeze(1)  # :243
-        matrix_ac = q_u @ k.transpose(-1, -2)  # :250
-        matrix_bd = q_v @ p.transpose(-1, -2)  # :255  (rel_shift disabled :256-258)
-        scores = (matrix_ac + matrix_bd) / math.sqrt(dk)  # :260
+        if self.pos_type == "rel_pos":
+            p = self._linear(pos_emb, prefix + ".linear_pos", bias=False)
+            p = p.reshape(pos_emb.shape[0], -1, h, dk).permute(0, 2, 1, 3)  # :234-236
+            q_u = q + self.p[prefix + ".pos_bias_u"].unsqueeze(1)  # :241
+            q_v = q + self.p[prefix + ".pos_bias_v"].unsqueeze(1)  # :243
+            matrix_ac = q_u @ k.transpose(-1, -2)  # :250
+            matrix_bd = q_v @ p.transpose(-1, -2)  # :255  (rel_shift disabled :256-258)
+            scores = (matrix_ac + matrix_bd) / math.sqrt(dk)  # :260
+        else:  # MultiHeadedAttention.forward  conformer/attention.py:123-170 (abs_pos / no_pos)
+            scores = (q @ k.transpose(-1, -2)) / math.sqrt(dk)
         # MultiHeadedAttention.forward_attention  conformer/attention.py:86-126
         if mask is not None and mask.shape[2] > 0:
             m = (mask.unsqueeze(1) == 0)[:, :, :, :scores.shape[-1]]
@@ -190,27 +229,47 @@ class ConformerOracle:
         return x.transpose(1, 2), new_cache
 
     def _layer(self, i, x, mask, pos_emb, mask_pad, att_cache=None, cnn_cache=None):
-        # ConformerEncoderLayer.forward  conformer/encoder.py:346-431 (pre-norm, macaron, ff_scale 0.5)
+        # ConformerEncoderLayer.forward  conformer/encoder.py:346-431
         p = f"encoder.encoders.{i}"
-        residual = x
-        x = self._ln(x, p + ".norm_ff_macaron")
-        x = residual + 0.5 * self._ffn(x, p + ".feed_forward_macaron")
+        pre = self.pre_norm
+        if self.macaron:
+            residual = x
+            if pre:
+                x = self._ln(x, p + ".norm_ff_macaron")
+            x = residual + self.ff_scale * self._ffn(x, p + ".feed_forward_macaron")
+            if not pre:
+                x = self._ln(x, p + ".norm_ff_macaron")
         if self.trace is not None:
             self.trace[p + ".x1"] = x
         residual = x
-        x = self._ln(x, p + ".norm_mha")
+        if pre:
+            x = self._ln(x, p + ".norm_mha")
         x_att, new_att_cache = self._attention(x, mask, pos_emb, att_cache, p + ".self_attn")
-        x = residual + x_att
+        if self.concat_after:  # :395-397
+            x = residual + self._linear(torch.cat((x, x_att), dim=-1), p + ".concat_linear")
+        else:
+            x = residual + x_att
+        if not pre:
+            x = self._ln(x, p + ".norm_mha")
         if self.trace is not None:
             self.trace[p + ".x2"] = x
+        new_cnn_cache = torch.zeros(0, 0, 0, dtype=x.dtype)  # :405
+        if self.use_cnn:
+            residual = x
+            if pre:
+                x = self._ln(x, p + ".norm_conv")
+            x, new_cnn_cache = self._conv_module(x, mask_pad, cnn_cache, p + ".conv_module")
+            x = residual + x
+            if not pre:
+                x = self._ln(x, p + ".norm_conv")
         residual = x
-        x = self._ln(x, p + ".norm_conv")
-        x, new_cnn_cache = self._conv_module(x, mask_pad, cnn_cache, p + ".conv_module")
-        x = residual + x
-        residual = x
-        x = self._ln(x, p + ".norm_ff")
-        x = residual + 0.5 * self._ffn(x, p + ".feed_forward")
-        x = self._ln(x, p + ".norm_final")
+        if pre:
+            x = self._ln(x, p + ".norm_ff")
+        x = residual + self.ff_scale * self._ffn(x, p + ".feed_forward")
+        if not pre:
+            x = self._ln(x, p + ".norm_ff")
+        if self.use_cnn:
+            x = self._ln(x, p + ".norm_final")
         return x, new_att_cache, new_cnn_cache
 
     # ---- encoder ------------------------------------------------------------------
@@ -232,7 +291,8 @@ class ConformerOracle:
         for i in range(self.L):
             xs, _, _ = self._layer(i, xs, chunk_masks, pos_emb, mask_pad)
             layers.append(xs)
-        xs = self._ln(xs, "encoder.after_norm")
+        if self.pre_norm:  # :201
+            xs = self._ln(xs, "encoder.after_norm")
         if return_layers:
             return xs, masks, layers
         return xs, masks
@@ -260,8 +320,10 @@ class ConformerOracle:
         chunk_size = xs.shape[1]
         attention_key_size = cache_t1 + chunk_size
         start = offset - cache_t1
-        assert start + attention_key_size < self.max_len  # embedding.py:84
-        pos_emb = self.pe[:, start:start + attention_key_size]  # :253
+        pos_emb = None
+        if self.pos_type != "no_pos":
+            assert start + attention_key_size < self.max_len  # embedding.py:84
+            pos_emb = self.pe[:, start:start + attention_key_size]  # :253
         if required_cache_size < 0:
             next_cache_start = 0
         elif required_cache_size == 0:
@@ -275,7 +337,8 @@ class ConformerOracle:
             xs, new_att, new_cnn = self._layer(i, xs, None, pos_emb, None, ac, cc)
             r_att.append(new_att[:, :, next_cache_start:, :])
             r_cnn.append(new_cnn)
-        xs = self._ln(xs, "encoder.after_norm")
+        if self.pre_norm:  # :276
+            xs = self._ln(xs, "encoder.after_norm")
         return xs, torch.cat(r_att, dim=0), torch.stack(r_cnn, dim=0)
 
     def get_encoder_out_chunk(self, speech, offset, required_cache_size, att_cache=None, cnn_cache=None):
