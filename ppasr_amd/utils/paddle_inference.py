@@ -180,12 +180,23 @@ def find_inference_model(model_dir):
     return None
 
 
+_warned = False
+
+
 def load_inference_model(model_dir_or_pdmodel, pdiparams=None, info=None):
     """-> ({structured name: float32 ndarray}, extras) ready for the ``state_dict=`` argument of the ppasr_amd models.
 
     Variables are matched to their structured (``state_dict``) names through ``.pdiparams.info``; variables without a
     structured name (constants the dygraph-to-static pass captured, e.g. the positional table) come back in ``extras``
     under their program names.  Shapes in the parameter file are checked against the ProgramDesc."""
+    global _warned
+    if not _warned:  # (once per process; ADVICE r02: the byte layouts were written from the Paddle sources as recalled)
+        _warned = True
+        import warnings
+        warnings.warn("exported Paddle inference model (.pdmodel / .pdiparams) read by an UNVERIFIED reader: it was never "
+                      "checked against a file written by Paddle itself (none is reachable offline), only against "
+                      "tests/paddle_format_writer.py; tensor counts and shapes are cross-checked between the two files, "
+                      "values are taken as found", RuntimeWarning, stacklevel=2)
     if pdiparams is None:
         found = find_inference_model(model_dir_or_pdmodel)
         if found is None:
