@@ -90,3 +90,26 @@ def test_deepspeech2_streaming_batch_wavefront_with_state_carry():
         assert ol.cpu().tolist() == rl.tolist()
         assert _rel(probs.cpu().numpy(), rp.numpy()) < TOL
         assert _rel(h.cpu().numpy(), rh.numpy()) < TOL and _rel(c.cpu().numpy(), rc.numpy()) < TOL
+
+
+@pytest.mark.parametrize("streaming,gru,B", [(True, False, 6), (False, False, 1), (True, True, 3), (False, True, 2)])
+def test_deepspeech2_rnn_size_2048(streaming, gru, B):
+    """rnn_size 2048 (configs/deepspeech2.yml:4 "for big data ... 2048"; the library accepts 1024 and 2048) on every
+    recurrence route: the (layer, time) wavefront (B >= 4 unidirectional LSTM), the batched per-step kernels, the
+    single-utterance kernels."""
+    from ppasr_amd.model_utils.deepspeech2.model import DeepSpeech2Model
+    V, L, H = 97, 2, 2048
+    sd = deepspeech2_state_dict(vocab_size=V, num_rnn_layers=L, rnn_size=H, streaming=streaming, seed=291, perturb_norm=True,
+                                use_gru=gru)
+    lens = [99] + [int(v) for v in np.linspace(90, 30, B - 1)] if B > 1 else [99]
+    x, lens = synth_features(B, 99, lens=lens, seed=292)
+    model = DeepSpeech2Model(80, V, streaming=streaming, encoder_conf=dict(num_rnn_layers=L, rnn_size=H, use_gru=gru),
+                             state_dict=sd, device="cuda:0")
+    probs, out_lens, fh, fc = model.get_encoder_out_chunk(x, lens)
+    torch.cuda.synchronize()
+    rp, rl, rh, rc = DeepSpeech2Oracle(sd, L, H, streaming, use_gru=gru).forward(x, lens)
+    assert out_lens.cpu().tolist() == rl.tolist()
+    e = _rel(probs.cpu().numpy(), rp.numpy())
+    print(f"H=2048 streaming={streaming} gru={gru} B={B}: probs {e:.2e}")
+    assert e < TOL
+    assert _rel(fh.cpu().numpy(), rh.numpy()) < TOL
