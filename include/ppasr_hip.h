@@ -138,7 +138,7 @@ ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats);
  * the last valid key.  Valid rows are bit-identical to the default mode; rows of `probs` / `logits` behind an
  * utterance's last valid frame are set to 0, `frame_argmax` to 0 (blank) and `frame_maxprob` to 0 -- pass frame_lens
  * to the decoders.  Default: off (= the reference's outputs for every row).  Built into the fused 256-column kernels
- * behind the conv2d (4x) front end: enabling it on a conv2d6 / conv2d8, generic-width or DeepSpeech2 handle returns
+ * behind the conv2d (4x) front end: enabling it on a conv2d6 / conv2d8, general-route (see options) or DeepSpeech2 handle returns
  * PPASR_EUNSUPPORTED (those routes compute every row). */
 ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable);
 
@@ -229,7 +229,9 @@ ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_l
  * InferencePredictor.predict_chunk_conformer / reset_stream (inference_predictor.py:184-220) and
  * PPASRPredictor.predict_stream (predict.py:232-337).  The attention key/value cache and the conv-module
  * cache stay resident on the device inside the stream object; `offset` (inference_predictor.py:39,211)
- * is tracked by the object.  B = 1 per stream (encoder.py:238); run several streams for several sessions. */
+ * is tracked by the object.  B = 1 per stream (encoder.py:238); run several streams for several sessions.
+ * Any causal Conformer-family handle behind a conv front end, general-route handles (output_size 512 .. 1024,
+ * ppasr_model_desc.options) included; use_cnn_module = 0 handles carry no conv cache (export: cnn_cache untouched). */
 ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out);
 ppasr_status ppasr_stream_destroy(ppasr_stream s);
 ppasr_status ppasr_stream_reset(ppasr_stream s, void* stream);
@@ -242,7 +244,8 @@ size_t ppasr_chunk_workspace_bytes(ppasr_handle h, int T);
 ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int required_cache_size, float* probs,
                                 int32_t* frame_argmax, float* frame_maxprob, int* c_out_host, void* workspace,
                                 size_t workspace_bytes, void* stream);
-/* Reference tensor layouts of the caches: att_cache [L][h][t][2*dk], cnn_cache [L][1][d][k-1]. */
+/* Reference tensor layouts of the caches: att_cache [L][h][t][2*dk] (h = attention_heads, dk = 64), cnn_cache [L][1][d][k-1]
+ * (d = output_size). */
 ppasr_status ppasr_stream_export_cache(ppasr_stream s, float* att_cache, float* cnn_cache, void* stream);
 ppasr_status ppasr_stream_import_cache(ppasr_stream s, const float* att_cache, int cache_t, const float* cnn_cache,
                                        int offset, void* stream);
