@@ -596,7 +596,10 @@ class DryRun(Workload):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def roofline_leg(w, ms_per_step, reps=5):
+ROOFLINE_REPS = 5
+
+
+def roofline_leg(w, ms_per_step, reps=ROOFLINE_REPS):
     """Per-kernel durations of `reps` instrumented steps (dispatch-attached HIP events, ppasr_kprof_*), anchored on the
     un-instrumented step: marker packets stretch every kernel of an instrumented pass by the same few percent, so the
     events give each kernel's SHARE of the summed kernel time and the timed region gives the step.  With the beam search
@@ -777,9 +780,20 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             median_ms = float(t.item())
 
+    # The roofline leg runs `reps` more steps of the workload; with N > 1 a step ends in the hypothesis all-gather, so
+    # EVERY rank runs the leg (each profiles its own kernels; rank 0's figures are reported) -- a rank-0-only leg would
+    # leave rank 0 waiting in a collective the other ranks never enter.  The dry run mirrors the extra steps.
     roofline = None
-    if rank == 0 and not dry:
+    if dry:
+        for _ in range(ROOFLINE_REPS):
+            w.step()
+        w.finish()
+    else:
         roofline = build_roofline(w, args, ms_per_step)
+        if rank != 0:
+            roofline = None
+    if world > 1:
+        dist.barrier()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
