@@ -182,6 +182,9 @@ def parse_args():
                     help="cfg4 / cfg5: run the beam search of a step on the encoder's stream instead of overlapping it "
                          "with the next step's encoder")
     ap.add_argument("--ragged-mode", default="merged", choices=["merged", "buckets"], help="cfg5: encoder batches per rank")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="N > 1 on a box with fewer GPUs: the ranks share the visible devices, gloo backend with host-staged "
+                         "collectives; the real workload and the whole multi-rank flow, NOT a measurement")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="no GPU: gloo backend and a stub step; exercises launch, sharding, gather and timing plumbing")
     a = ap.parse_args()
@@ -711,13 +714,13 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     dry = args.dry_run_cpu
-    backend = "gloo" if dry else "nccl"
+    backend = "gloo" if (dry or args.share_gpu) else "nccl"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if dry:
+        if backend == "gloo":
             dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local_rank)
@@ -725,7 +728,9 @@ def main():
         # the collective library must have seen every rank: a silent single-rank run would report N x the work
         assert dist.get_world_size() == args.gpus and dist.get_backend() == backend, (dist.get_world_size(), dist.get_backend())
     n_ranks_seen = dist.get_world_size() if dist else 1
-    device = torch.device("cpu") if dry else torch.device("cuda", local_rank)
+    device = torch.device("cpu") if dry else torch.device(
+        "cuda", local_rank % torch.cuda.device_count() if args.share_gpu else local_rank)
+    red_device = device if backend == "nccl" else torch.device("cpu")  # where the timing reductions live
     if not dry:
         torch.cuda.set_device(device)
 
@@ -763,7 +768,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # the gathered batch really holds every rank's utterances
@@ -776,7 +781,7 @@ def main():
         per = np.array([events[i].elapsed_time(events[i + 1]) for i in range(args.steps)])
         median_ms = float(np.median(per))
         if world > 1:
-            t = torch.tensor([median_ms], dtype=torch.float64, device=device)
+            t = torch.tensor([median_ms], dtype=torch.float64, device=red_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             median_ms = float(t.item())
 
@@ -806,7 +811,9 @@ def main():
             "metric": w.metric,
             "value": None if dry else round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "dry-run: stub kernels, plumbing only" if dry else "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": ("dry-run: stub kernels, plumbing only" if dry else
+                                         "synthetic (ranks SHARE devices, host-staged gloo collectives: plumbing check, not a measurement)"
+                                         if args.share_gpu else "synthetic"),
             "config": {"workload": w.desc, "baseline_config": cfg_name,
                        "global_batch": getattr(w, "n_global", None) or world * args.batch, "frames": args.frames,
                        "decoder": w.decoder, "parallelism": f"utterance-dp{world}",

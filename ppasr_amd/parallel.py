@@ -47,13 +47,28 @@ def unpack_hypotheses(rec):
     return tokens, n_tokens, score
 
 
+def _all_gather_rows(out, rec, dist, group=None):
+    """``dist.all_gather_into_tensor(out, rec)``; device tensors under a host-only backend (gloo: the shared-GPU plumbing
+    check of ``bench.py --share-gpu``, CPU tests) are staged through the host -- RCCL takes them as they are."""
+    try:
+        backend = str(dist.get_backend(group))
+    except Exception:  # a stub "dist" in tests
+        backend = "gloo"
+    if rec.is_cuda and backend != "nccl":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, rec.cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, rec, group=group)
+
+
 def gather_hypotheses(tokens, n_tokens, score, dist, group=None):
     """All ranks end up with the hypotheses of the whole global batch, in rank order.
     Every rank must contribute the same [B_local, Tp] shape (pad the batch if needed)."""
     rec = pack_hypotheses(tokens, n_tokens, score)
     world = dist.get_world_size(group)
     out = torch.empty(world * rec.shape[0], rec.shape[1], dtype=torch.int32, device=rec.device)
-    dist.all_gather_into_tensor(out, rec, group=group)
+    _all_gather_rows(out, rec, dist, group)
     return unpack_hypotheses(out)
 
 
@@ -147,7 +162,7 @@ def gather_ragged_hypotheses(results, n_total, rows, cols, dist, device=None, gr
     rec = torch.from_numpy(host).to(dev)
     world = dist.get_world_size(group)
     out = torch.empty(world * rows, cols + 4, dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(out, rec, group=group)
+    _all_gather_rows(out, rec, dist, group)
     idx = out[:, cols + 3].to(torch.int64)
     valid = idx >= 0
     if int(valid.sum()) != n_total or sorted(idx[valid].tolist()) != list(range(n_total)):
@@ -340,7 +355,7 @@ class RaggedPlan:
                 out = rec
             else:
                 out = torch.empty(self.world * self.rows, self.cols + 4, dtype=torch.int32, device=rec.device)
-                self.dist.all_gather_into_tensor(out, rec, group=self.group)
+                _all_gather_rows(out, rec, self.dist, self.group)
             self.last_index_column = out[self.order.to(out.device), self.cols + 3]
             return self._unpack(out)
 
