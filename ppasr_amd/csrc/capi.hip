@@ -79,10 +79,11 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
     return fail(PPASR_EUNSUPPORTED, "output_size must be 256, 512, 768 or 1024");
   if (desc->attention_heads * 64 != desc->output_size) return fail(PPASR_EUNSUPPORTED, "kernels are specialised for d_k=64");
   const bool fused_ks = desc->cnn_module_kernel == 15 || desc->cnn_module_kernel == 31 || desc->cnn_module_kernel == 7;
-  const bool generic = desc->model_type == PPASR_MODEL_CONFORMER &&
-                       (desc->output_size != kD || desc->options != 0 || desc->input_layer == 1 || !fused_ks);
-  if (desc->output_size != kD && desc->model_type != PPASR_MODEL_CONFORMER)
-    return fail(PPASR_EUNSUPPORTED, "output_size != 256 is built for model_type=conformer");
+  const bool generic = (desc->model_type == PPASR_MODEL_CONFORMER &&
+                        (desc->output_size != kD || desc->options != 0 || desc->input_layer == 1 || !fused_ks)) ||
+                       (desc->model_type == PPASR_MODEL_SQUEEZEFORMER && desc->output_size != kD);
+  if (desc->output_size != kD && desc->model_type != PPASR_MODEL_CONFORMER && desc->model_type != PPASR_MODEL_SQUEEZEFORMER)
+    return fail(PPASR_EUNSUPPORTED, "output_size != 256 is built for model_type=conformer and squeezeformer");
   if ((desc->options != 0 || desc->input_layer == 1) && desc->model_type != PPASR_MODEL_CONFORMER)
     return fail(PPASR_EUNSUPPORTED, "non-default encoder options / input_layer=linear are built for model_type=conformer");
   if (desc->linear_units % 256 != 0 || desc->linear_units <= 0) return fail(PPASR_EUNSUPPORTED, "linear_units % 256 != 0");
@@ -515,10 +516,12 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   if (workspace_bytes < wl.total * sizeof(float)) return fail(PPASR_ENOSPACE, "workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(workspace);
+  if (h->generic)
+    return h->desc.model_type == PPASR_MODEL_SQUEEZEFORMER
+               ? generic_sq_encode(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, ws, st)
+               : generic_encode(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, ws, st);
   if (h->desc.model_type == PPASR_MODEL_SQUEEZEFORMER)
     return squeezeformer_encode(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, ws, wl, st);
-  if (h->generic)
-    return generic_encode(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, ws, st);
   float *y1 = ws + wl.y1, *y2 = ws + wl.y2, *xa = ws + wl.xa, *xb = ws + wl.xb, *xc = ws + wl.xc;
   float *qkv = ws + wl.qkv, *ctx = ws + wl.ctx, *g = ws + wl.g;
   const VtOut vt_out{ws + wl.vt, wl.vt_stride};

@@ -48,6 +48,7 @@ __device__ __forceinline__ float act_apply(int act, float v) {
 // the rows of PAD frames (mul * t >= lens[b], rows are [b][t < Tp]) left at res -- the mask behind pointwise_conv2
 // (convolution.py:138-140) folded into the residual add
 struct GemmEpi {
+  int sb = 0;  // 1: acc * scale + bias (Squeezeformer scales the conv features BEFORE input_proj, subsampling.py:66-67)
   int act = kActNone;
   const float* res = nullptr;
   float rscale = 1.f;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(kThreads) void k_dense_epi(const float* __restrict_
     for (int r = 0; r < 16; ++r) {
       const int m = r0 + mt * 32 + acc_row(r, lane);
       if (m >= M) continue;
-      float v = (acc[mt][0][r] + bv) * scale;
+      float v = epi.sb ? acc[mt][0][r] * scale + bv : (acc[mt][0][r] + bv) * scale;
       if (epi.act != kActNone) v = act_apply(epi.act, v);
       if (epi.res) {
         const float rv = epi.res[(size_t)m * ldc + col];
@@ -251,7 +252,7 @@ inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
 inline dim3 blocks(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 struct GenWs {
-  size_t y1, y2, x, a, big, y, g, ctx, cat, lg, total;
+  size_t y1, y2, x, a, big, y, g, ctx, cat, lg, xs, xr, total;
 };
 GenWs gen_layout(const ppasr_model_s* m, int B, int T) {
   const int D = m->desc.output_size, H = m->desc.linear_units, V = m->desc.vocab_size;
@@ -276,6 +277,9 @@ GenWs gen_layout(const ppasr_model_s* m, int B, int T) {
   w.ctx = o; o += al64(M * D);
   w.cat = o; o += m->gen.concat_after ? al64(M * 2 * D) : 0;
   w.lg = o; o += al64(M * (size_t)V);  // logits / probabilities when the caller does not ask for them
+  const bool sq = m->desc.model_type == PPASR_MODEL_SQUEEZEFORMER;
+  w.xs = o; o += sq ? al64(M * D) : 0;  // Squeezeformer: full-rate activations saved at the time reduction
+  w.xr = o; o += sq ? al64(M * D) : 0;  //   and a second activation buffer (reduced / recovered rows)
   w.total = o;
   return w;
 }
@@ -449,7 +453,181 @@ ppasr_status gen_front(ppasr_model_s* h, const float* feats, int B, int T, float
   return PPASR_OK;
 }
 
+// ---- Squeezeformer pieces ----
+// time reduction, depthwise part (TimeReductionLayerStream / TimeReductionLayer1D, time_reduction.py:183-206 / 80-131): zero
+// the PAD frames, Conv1D(ks, stride 2, padding max(0, ks - 2)) per channel: reduced row (b, j) <- frames 2j - pad + k
+__global__ void k_g_sq_reduce_dw(const float* __restrict__ x, float* __restrict__ out, const float* __restrict__ dw_w,
+                                 const float* __restrict__ dw_b, int ks, const int64_t* __restrict__ lens, int B, int Tp, int Tr,
+                                 int D) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * Tr * D) return;
+  const int row = (int)(i / D), c = (int)(i - (size_t)row * D);
+  const int b = row / Tr, j = row - b * Tr;
+  const int pad = ks > 2 ? ks - 2 : 0;
+  float v = dw_b[c];
+  for (int k = 0; k < ks; ++k) {
+    const int t = 2 * j - pad + k;
+    if (t < 0 || t >= Tp) continue;                     // the conv's own zero padding
+    if (lens && 4 * (int64_t)t >= lens[b]) continue;    // masked_fill(xs, mask_pad == 0, 0)
+    v = fmaf(x[((size_t)b * Tp + t) * D + c], dw_w[(size_t)k * D + c], v);
+  }
+  out[i] = v;
+}
+// time recovery, gather part (encoder.py:224): repeat_interleave(xs, 2)[:, :T'] -> row (b, t) <- reduced row (b, t >> 1)
+__global__ void k_g_sq_repeat(const float* __restrict__ xr, float* __restrict__ out, int B, int Tp, int Tr, int D) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * Tp * D) return;
+  const int row = (int)(i / D), c = (int)(i - (size_t)row * D);
+  const int b = row / Tp, t = row - b * Tp;
+  out[i] = xr[((size_t)b * Tr + (t >> 1)) * D + c];
+}
+
 }  // namespace
+
+// SqueezeformerEncoder.forward / forward_chunk (squeezeformer/encoder.py:172-236, 260-381; layer :435-506) + ctc softmax as
+// general pieces: the post-norm block MHA -> FFN -> conv -> FFN with the adaptive scale / bias of every module folded into
+// its first projection at pack time (capi_squeezeformer.hip), time reduction before layer reduce_idx (keys / positions of
+// the reduced layers: mask 8 t < len, every second positional row) and recovery before layer recover_idx.
+// s != nullptr: one chunk of one stream (B = 1, no masks): keys / values in the stream's caches (the half-rate layers hold
+// each cached frame once, capi_stream.hip), the conv modules read [cached scaled inputs | chunk] (convolution.py:119-137).
+namespace {
+ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, int B, int T, float* probs, float* logits,
+                    int32_t* frame_argmax, float* frame_maxprob, float* ws, hipStream_t st, ppasr_stream_s* s,
+                    const ChunkPlan* plan) {
+  if (h->taps) return fail(PPASR_EUNSUPPORTED, "debug taps are built for the fused 256-wide route");
+  const GenWs wl = gen_layout(h, B, T);
+  const int D = h->desc.output_size, H = h->desc.linear_units, V = h->desc.vocab_size, heads = h->desc.attention_heads;
+  const int F = h->desc.input_dim, L = h->desc.num_blocks, KS = h->desc.cnn_module_kernel;
+  const auto fd = h->front_dims(T);
+  const int Tp = fd.Tp, Tr = (Tp + 1) / 2, M = B * Tp;  // Conv1D(stride 2): ceil(T'/2) reduced frames
+  float *y1 = ws + wl.y1, *y2 = ws + wl.y2, *xa = ws + wl.x, *a = ws + wl.a, *big = ws + wl.big, *y = ws + wl.y;
+  float *g = ws + wl.g, *ctx = ws + wl.ctx, *xs = ws + wl.xs, *xb = ws + wl.xr;
+  const bool causal = h->desc.causal != 0;
+  const int left = causal ? KS - 1 : (KS - 1) / 2;
+  const int lo_s = s ? s->lo : 0;  // cached conv-input rows in front of the chunk
+  // ---- DepthwiseConv2DSubsampling4 (dw_stride = False: two ordinary 3x3 / 2 convs) + input_proj + preln ----
+  launch_conv1(feats, h->front, y1, B, T, F, fd.T1, h->F1, st, PadSkip{}, D);
+  launch_conv_stage(y1, h->front.conv2_w, h->front.conv2_b, y2, B, fd.T1, h->F1, Tp, h->F2, 3, 2, st, PadSkip{}, D);
+  {
+    GemmEpi e;
+    e.sb = 1;
+    dense(y2, h->F2 * D, h->front.embed_w, h->front.embed_b, xa, M, h->F2 * D, D, D, D, st, sqrtf((float)D), e);
+  }
+  auto ln = [&](const float* in, float* out, const float* gg, const float* bb, float eps, int act, bool mask, int rows, int Ti,
+                int mul) {
+    PPASR_LAUNCH(k_g_ln, dim3((rows + 3) / 4), dim3(256), 0, st, in, out, gg, bb, rows, D, eps, act, mask ? lens : nullptr, Ti, mul, 1.0f);
+  };
+  ln(xa, xa, h->preln_g, h->preln_b, 1e-5f, kActNone, false, M, Tp, 4);
+  float* x = xa;
+  bool reduced = false;
+  for (int i = 0; i < L; ++i) {
+    const SqLayerW& W = h->sq_layers[i];
+    if (i == h->desc.reduce_idx) {
+      HIP_TRY(hipMemcpyAsync(xs, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+      PPASR_LAUNCH(k_g_sq_reduce_dw, blocks((size_t)B * Tr * D), dim3(256), 0, st, x, a, h->sq_reduce.dw_w, h->sq_reduce.dw_b,
+                   h->sq_reduce.ks, lens, B, Tp, Tr, D);
+      dense(a, D, h->sq_reduce.pw, h->sq_reduce.pw_b, xb, B * Tr, D, D, D, D, st);
+      x = xb;
+      reduced = true;
+    }
+    if (i == h->desc.recover_idx && reduced) {
+      PPASR_LAUNCH(k_g_sq_repeat, blocks((size_t)M * D), dim3(256), 0, st, x, a, B, Tp, Tr, D);
+      GemmEpi e;
+      e.res = xs;  // recover_tensor + time_recover_layer(repeat_interleave(xs, 2))
+      dense(a, D, h->sq_wrec, h->sq_brec, xa, M, D, D, D, D, st, 1.0f, e);
+      x = xa;
+      reduced = false;
+    }
+    const int Ti = reduced ? Tr : Tp, Mi = B * Ti, mul = reduced ? 8 : 4;
+    auto res_epi = [&](bool mask) {
+      GemmEpi e;
+      e.res = x;
+      if (mask && lens) {
+        e.lens = lens;
+        e.Tp = Ti;
+        e.mul = mul;
+      }
+      return e;
+    };
+    auto act_epi = [&]() {
+      GemmEpi e;
+      e.act = PPASR_ACT_SWISH;
+      return e;
+    };
+    // ---- x = LN1(x + MHA(x)) ----
+    dense(x, D, W.wqkv, W.bqkv, big, Mi, D, 3 * D, 3 * D, 3 * D, st);
+    AttnArgs at{big, 3 * D, big + D, 3 * D, big + 2 * D, 3 * D, Ti, Ti, 0, lens, ctx, W.pos_u, W.pos_v, W.ptab, reduced ? 2 : 1,
+                mul, Ti, Ti, 1};
+    if (s) {  // keys / values: [cache | chunk] in the layer's device caches
+      const int n_cache = reduced ? plan->used_r : s->cache_t;
+      float* kc = s->kc + (size_t)i * s->cap * D;
+      float* vc = s->vc + (size_t)i * s->cap * D;
+      PPASR_LAUNCH(k_g_kv_append, blocks((size_t)Mi * D), dim3(256), 0, st, big, kc + (size_t)n_cache * D,
+                   vc + (size_t)n_cache * D, Mi, D);
+      at.k = kc;
+      at.v = vc;
+      at.k_stride = at.v_stride = D;
+      at.T2 = at.kv_frames = n_cache + Ti;
+      at.pos0 = plan->pos0;
+    }
+    at.pad_skip = 0;
+    at.dm = D;
+    launch_attention(at, B, heads, st);
+    dense(ctx, D, W.wo, W.bo, x, Mi, D, D, D, D, st, 1.0f, res_epi(false));
+    ln(x, x, W.ln1_g, W.ln1_b, 1e-5f, kActNone, false, Mi, Ti, mul);
+    // ---- x = LN2(x + FFN1(x)) ----
+    dense(x, D, W.ff1_w1, W.ff1_b1, big, Mi, D, H, H, H, st, 1.0f, act_epi());
+    dense(big, H, W.ff1_w2, W.ff1_b2, x, Mi, H, D, D, D, st, 1.0f, res_epi(false));
+    ln(x, x, W.ln2_g, W.ln2_b, 1e-5f, kActNone, false, Mi, Ti, mul);
+    // ---- x = LN3(x + conv(x)): ada scale / bias, THEN the pad mask (convolution.py:119-127), the unfolded pointwise_conv1 ----
+    {
+      float* a_new = a + (size_t)lo_s * D;
+      ln(x, a_new, W.cm_scale, W.cm_bias, -1.0f, kActNone, true, Mi, Ti, mul);
+      const int rows = lo_s + Mi;
+      if (lo_s) {  // the cache holds the SCALED inputs of the previous chunks; new cache = last lo rows of [cache | chunk]
+        float* hist = s->xh_hist + (size_t)i * s->lo * D;
+        HIP_TRY(hipMemcpyAsync(a, hist, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(hist, a + (size_t)Mi * D, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+      }
+      dense(a, D, W.pw1_raw, W.pw1_b_raw, big, rows, D, 2 * D, 2 * D, 2 * D, st);
+      PPASR_LAUNCH(k_g_glu, blocks((size_t)rows * D), dim3(256), 0, st, big, g, rows, D);
+      PPASR_LAUNCH(k_g_dwconv, blocks((size_t)Mi * D), dim3(256), 0, st, g, y, W.dw_w, W.dw_b, W.glu_pad, Mi, Ti, D, KS, left, lo_s);
+      ln(y, y, W.ln_cm_g, W.ln_cm_b, W.cm_eps, (int)PPASR_ACT_SWISH, false, Mi, Ti, mul);
+      dense(y, D, W.pw2, W.pw2_b, x, Mi, D, D, D, D, st, 1.0f, res_epi(true));
+      ln(x, x, W.ln3_g, W.ln3_b, 1e-5f, kActNone, false, Mi, Ti, mul);
+    }
+    // ---- x = LN4(x + FFN2(x)) ----
+    dense(x, D, W.ff2_w1, W.ff2_b1, big, Mi, D, H, H, H, st, 1.0f, act_epi());
+    dense(big, H, W.ff2_w2, W.ff2_b2, x, Mi, H, D, D, D, st, 1.0f, res_epi(false));
+    ln(x, x, W.ln4_g, W.ln4_b, 1e-5f, kActNone, false, Mi, Ti, mul);
+  }
+  // ---- ctc_lo -> softmax (no after_norm in Squeezeformer, encoder.py:232-235) ----
+  float* lg = logits ? logits : (probs ? probs : ws + wl.lg);
+  dense(x, D, h->gen_head_w, h->gen_head_b, lg, M, D, h->gen_vpad, V, V, st);
+  float* pr = probs;
+  if (!pr && (frame_argmax || frame_maxprob)) pr = (lg == ws + wl.lg) ? lg : ws + wl.lg;
+  if (pr) {
+    if (pr != lg) HIP_TRY(hipMemcpyAsync(pr, lg, (size_t)M * V * sizeof(float), hipMemcpyDeviceToDevice, st));
+    launch_softmax_from_stats(pr, nullptr, nullptr, M, V, st);
+    if (frame_argmax || frame_maxprob) {
+      int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(y);
+      float* fp = frame_maxprob ? frame_maxprob : y + M;
+      launch_frame_argmax(pr, fa, fp, M, V, st);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return PPASR_OK;
+}
+}  // namespace
+
+ppasr_status generic_sq_encode(ppasr_model_s* h, const float* feats, const int64_t* lens, int B, int T, float* probs,
+                               float* logits, int32_t* frame_argmax, float* frame_maxprob, float* ws, hipStream_t st) {
+  return sq_run(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, ws, st, nullptr, nullptr);
+}
+ppasr_status generic_sq_chunk(ppasr_stream_s* s, const ChunkPlan& p, const float* feats, int T, float* probs,
+                              int32_t* frame_argmax, float* frame_maxprob, float* ws, hipStream_t st) {
+  return sq_run(s->m, feats, nullptr, 1, T, probs, nullptr, frame_argmax, frame_maxprob, ws, st, s, &p);
+}
 
 hipError_t configure_generic_kernels() {
   hipError_t e;

@@ -178,6 +178,16 @@ struct ppasr_stream_s {
   HistLayer* hist_tab;  // device [L]: per-layer pointwise_conv1 weights / history rows for that launch (fused route)
 };
 
+// the reference's shape arithmetic for one chunk (capi_stream.hip: plan_chunk)
+struct ChunkPlan {
+  int c;        // full-rate frames of this chunk
+  int c_r;      // half-rate frames
+  int used_r;   // half-rate cache frames that take part
+  int T2, T2_r; // keys of the full-rate / half-rate layers
+  int ncs;      // next_cache_start
+  int pos0;     // position of key 0
+};
+
 struct WsLayout {
   size_t y1, y2, xa, xb, xc, qkv, ctx, g, rmax, rsum, fa, fp, xs, vt, total;  // offsets in floats
   int vt_stride;  // row stride of the transposed values (fused attention route)
@@ -197,7 +207,13 @@ ppasr_status generic_encode(ppasr_model_s* h, const float* feats, const int64_t*
 // hold cache_t frames, key 0 sits at positional row pos0; appends this chunk's keys / values and conv inputs
 ppasr_status generic_chunk(ppasr_stream_s* s, const float* feats, int T, int pos0, float* probs, int32_t* frame_argmax,
                            float* frame_maxprob, float* ws, hipStream_t st);
+// SqueezeformerEncoder.forward_chunk (squeezeformer/encoder.py:260-381) on the general route
+ppasr_status generic_sq_chunk(ppasr_stream_s* s, const ChunkPlan& p, const float* feats, int T, float* probs,
+                              int32_t* frame_argmax, float* frame_maxprob, float* ws, hipStream_t st);
 hipError_t configure_generic_kernels();
+// SqueezeformerEncoder.forward (squeezeformer/encoder.py:172-236) on the general route (encoder_dim 512 / 768 / 1024)
+ppasr_status generic_sq_encode(ppasr_model_s* h, const float* feats, const int64_t* lens, int B, int T, float* probs,
+                               float* logits, int32_t* frame_argmax, float* frame_maxprob, float* ws, hipStream_t st);
 
 // model-family back ends
 ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd);

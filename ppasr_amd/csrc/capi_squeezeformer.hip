@@ -32,7 +32,7 @@ std::vector<float> vec_of(const float* p, size_t n) { return std::vector<float>(
 
 ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe_dev) {
   const ppasr_model_desc& dsc = m->desc;
-  const int F = dsc.input_dim, d = kD, H = dsc.linear_units, V = dsc.vocab_size, KS = dsc.cnn_module_kernel;
+  const int F = dsc.input_dim, d = dsc.output_size, H = dsc.linear_units, V = dsc.vocab_size, KS = dsc.cnn_module_kernel;
   const int F2 = m->F2, L = dsc.num_blocks, max_len = dsc.max_len;
   if (dsc.reduce_idx >= 0 && (dsc.recover_idx <= dsc.reduce_idx || dsc.recover_idx >= L || dsc.reduce_idx == 0))
     return fail(PPASR_EUNSUPPORTED, "squeezeformer: need 0 < reduce_idx < recover_idx < num_blocks (or reduce_idx = -1)");
@@ -157,7 +157,7 @@ ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe
       void* pt = nullptr;
       HIP_TRY(hipMalloc(&pt, (size_t)max_len * d * sizeof(float)));
       m->allocs.push_back(pt);
-      launch_posproj(pe_dev, wpos_dev, bpos_dev, static_cast<float*>(pt), max_len, nullptr);
+      launch_posproj(pe_dev, wpos_dev, bpos_dev, static_cast<float*>(pt), max_len, nullptr, d);
       HIP_TRY(hipGetLastError());
       W.ptab = static_cast<const float*>(pt);
     }
@@ -233,6 +233,14 @@ ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe
     std::vector<float> cbp((size_t)m->head.n_tiles * 32, 0.f);
     std::memcpy(cbp.data(), cb, V * sizeof(float));
     UP(cbp, m->head.b);
+    if (m->generic) {  // general route (encoder_dim 512 ..): the head as a plain dense layer over the padded vocabulary
+      m->gen_vpad = (V + 255) / 256 * 256;
+      const int Vp = m->gen_vpad;
+      UP4(pack_b(d, Vp, [&](int k, int n) { return n < V ? cw[(size_t)k * V + n] : 0.f; }), m->gen_head_w);
+      std::vector<float> hb(Vp, 0.f);
+      std::memcpy(hb.data(), cb, V * sizeof(float));
+      UP(hb, m->gen_head_b);
+    }
   }
   return PPASR_OK;
 }

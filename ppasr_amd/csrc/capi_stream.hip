@@ -47,15 +47,6 @@ void history_glu_all(ppasr_stream_s* s, hipStream_t st) {
   launch_pw1_glu_layers(s->xh_hist, s->g_hist, s->hist_tab, s->m->desc.num_blocks, s->lo, st);
 }
 
-struct ChunkPlan {
-  int c;        // full-rate frames of this chunk
-  int c_r;      // half-rate frames
-  int used_r;   // half-rate cache frames that take part
-  int T2, T2_r; // keys of the full-rate / half-rate layers
-  int ncs;      // next_cache_start
-  int pos0;     // position of key 0
-};
-
 // the reference's shape arithmetic for one chunk
 ppasr_status plan_chunk(const ppasr_stream_s* s, int c, int required_cache_size, ChunkPlan* p) {
   const ppasr_model_s* h = s->m;
@@ -327,7 +318,8 @@ ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int r
   const WsLayout wl = ws_layout(h, 1, T);
   float* ws = static_cast<float*>(workspace);
   if (h->generic) {  // the general layer route (capi_generic.hip): same cache bookkeeping, its own layer pieces
-    r = generic_chunk(s, feats, T, p.pos0, probs, frame_argmax, frame_maxprob, ws, st);
+    r = is_sq(h) ? generic_sq_chunk(s, p, feats, T, probs, frame_argmax, frame_maxprob, ws, st)
+                 : generic_chunk(s, feats, T, p.pos0, probs, frame_argmax, frame_maxprob, ws, st);
     if (r != PPASR_OK) return r;
     r = finish_chunk(s, p, ws + wl.total, st);
     if (r != PPASR_OK) return r;

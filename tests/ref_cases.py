@@ -73,6 +73,11 @@ SMALL = {
     "act_hardshrink": _former("conformer", True, 1, 61, 579, (1, 99, [99], 580), activation_type="hardshrink"),
     "sq_bn": _former("squeezeformer", False, 3, 59, 543, (2, 131, [131, 70], 544), reduce_idx=1, recover_idx=2,
                      cnn_norm_type="batch_norm"),
+    # encoder_dim 512 / 8 heads (configs/squeezeformer.yml:3-5 "for big data ... 512"): the general layer route
+    "sq512_s": _former("squeezeformer", True, 3, 59, 581, (3, 131, [131, 90, 5], 582), chunk_frames=64 * 4 + 40,
+                       required=(-16, 32), reduce_idx=1, recover_idx=2, encoder_dim=512, attention_heads=8),
+    "sq512_n": _former("squeezeformer", False, 3, 59, 583, (2, 147, [147, 70], 584), reduce_idx=1, recover_idx=2,
+                       encoder_dim=512, attention_heads=8, cnn_norm_type="batch_norm"),
 }
 for _gru in (False, True):
     for _streaming in (True, False):
@@ -122,7 +127,8 @@ def state_dict(case, perturb=True):
                                               stride_layer_idx=kw["stride_layer_idx"], group_layer_idx=kw["group_layer_idx"])
     if fam == "squeezeformer":
         return squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn, streaming=case["streaming"],
-                                        cnn_norm_type=kw.get("cnn_norm_type", "layer_norm"))
+                                        cnn_norm_type=kw.get("cnn_norm_type", "layer_norm"),
+                                        encoder_dim=kw.get("encoder_dim", 256), attention_heads=kw.get("attention_heads", 4))
     if fam == "deepspeech2":
         return deepspeech2_state_dict(vocab_size=V, num_rnn_layers=L, streaming=case["streaming"], seed=seed,
                                       perturb_norm=pn, use_gru=kw.get("use_gru", False))
@@ -167,7 +173,8 @@ def reference_encoder_conf(case):
                                        stride_kernel=True)
         return c
     if fam == "squeezeformer":
-        return dict(encoder_dim=256, output_size=256, attention_heads=4, num_blocks=L,
+        return dict(encoder_dim=kw.get("encoder_dim", 256), output_size=kw.get("encoder_dim", 256),
+                    attention_heads=kw.get("attention_heads", 4), num_blocks=L,
                     reduce_idx=kw.get("reduce_idx", 5), recover_idx=kw.get("recover_idx", 11),
                     feed_forward_expansion_factor=8, input_dropout_rate=0.1, feed_forward_dropout_rate=0.1,
                     attention_dropout_rate=0.1, adaptive_scale=True, cnn_module_kernel=31, normalize_before=False,

@@ -43,7 +43,8 @@ def make_oracle(case, sd):
         return EfficientConformerOracle(sd, num_blocks=L, stride_layer_idx=kw["stride_layer_idx"],
                                         group_layer_idx=kw["group_layer_idx"], causal=causal)
     if fam == "squeezeformer":
-        return SqueezeformerOracle(sd, num_blocks=L, reduce_idx=kw["reduce_idx"], recover_idx=kw["recover_idx"], causal=causal)
+        return SqueezeformerOracle(sd, num_blocks=L, reduce_idx=kw["reduce_idx"], recover_idx=kw["recover_idx"], causal=causal,
+                                   attention_heads=kw.get("attention_heads", 4))
     return DeepSpeech2Oracle(sd, num_rnn_layers=L, streaming=case["streaming"], use_gru=kw.get("use_gru", False))
 
 
