@@ -69,7 +69,7 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
     if (desc->group_layer_mask != 0 && desc->group_size != 3)
       return fail(PPASR_EUNSUPPORTED, "efficient_conformer: grouped attention is built for group_size=3");
     if (desc->stride_layer_idx >= desc->num_blocks) return fail(PPASR_EINVAL, "stride_layer_idx out of range");
-    if (desc->stride_layer_idx >= 0 && desc->cnn_module_kernel != 15)
+    if (desc->stride_layer_idx >= 0 && desc->cnn_module_kernel != 15 && desc->output_size == kD)
       return fail(PPASR_EUNSUPPORTED, "efficient_conformer: cnn_module_kernel must be 15 (7 after the stride layer)");
   }
   // output_size 256 (4 heads of 64) with the shipped constructor arguments: the fused row-block kernels.  Other multiples
@@ -81,9 +81,8 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
   const bool fused_ks = desc->cnn_module_kernel == 15 || desc->cnn_module_kernel == 31 || desc->cnn_module_kernel == 7;
   const bool generic = (desc->model_type == PPASR_MODEL_CONFORMER &&
                         (desc->output_size != kD || desc->options != 0 || desc->input_layer == 1 || !fused_ks)) ||
-                       (desc->model_type == PPASR_MODEL_SQUEEZEFORMER && desc->output_size != kD);
-  if (desc->output_size != kD && desc->model_type != PPASR_MODEL_CONFORMER && desc->model_type != PPASR_MODEL_SQUEEZEFORMER)
-    return fail(PPASR_EUNSUPPORTED, "output_size != 256 is built for model_type=conformer and squeezeformer");
+                       ((desc->model_type == PPASR_MODEL_SQUEEZEFORMER || desc->model_type == PPASR_MODEL_EFFICIENT_CONFORMER) &&
+                        desc->output_size != kD);
   if ((desc->options != 0 || desc->input_layer == 1) && desc->model_type != PPASR_MODEL_CONFORMER)
     return fail(PPASR_EUNSUPPORTED, "non-default encoder options / input_layer=linear are built for model_type=conformer");
   if (desc->linear_units % 256 != 0 || desc->linear_units <= 0) return fail(PPASR_EUNSUPPORTED, "linear_units % 256 != 0");

@@ -196,15 +196,17 @@ __global__ void k_g_glu(const float* __restrict__ pg, float* __restrict__ g, int
 // pointwise_conv1, convolution.py:108-126) and 0 in the non-causal one (its depthwise conv pads its own input).
 __global__ void k_g_dwconv(const float* __restrict__ g, float* __restrict__ out, const float* __restrict__ w /*[KS][D]*/,
                            const float* __restrict__ bias, const float* __restrict__ pad, int M, int Tp, int D, int KS,
-                           int left, int row_off) {
+                           int left, int row_off, int stride, int Tp_in) {
+  // stride 2: the Efficient-Conformer's stride layer (efficient_conformer/convolution.py:54-60): output frame t of the Tp =
+  // ceil(Tp_in / 2) reads the input frames 2 t - left .. ; stride 1: Tp_in == Tp
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * D) return;
   const int row = (int)(i / D), c = (int)(i - (size_t)row * D);
-  const int bb = row / Tp, t = row - bb * Tp, Tin = Tp + row_off;
+  const int bb = row / Tp, t = row - bb * Tp, Tin = Tp_in + row_off;
   const bool causal = left == KS - 1;
   float acc = bias[c];
   for (int j = 0; j < KS; ++j) {
-    const int tt = t + row_off - left + j;
+    const int tt = stride * t + row_off - left + j;
     float v;
     if (tt >= 0 && tt < Tin) v = g[((size_t)bb * Tin + tt) * D + c];
     else v = causal ? pad[c] : 0.f;
@@ -229,6 +231,17 @@ __global__ void k_g_cmvn_pad(const float* __restrict__ feats, const float* __res
   if (i >= (size_t)M * Kp) return;
   const int row = (int)(i / Kp), k = (int)(i - (size_t)row * Kp);
   out[i] = k < F ? (feats[(size_t)row * F + k] - mean[k]) * istd[k] : 0.f;
+}
+
+// stride layer, residual branch: AvgPool1D(kernel 2, stride 2, ceil_mode, exclusive) over time
+// (efficient_conformer/encoder.py:431-436, 521-527): row (b, j) <- mean of frames 2j, 2j + 1 (the last one alone if T is odd)
+__global__ void k_g_avgpool2(const float* __restrict__ x, float* __restrict__ out, int B, int Tp, int Ts, int D) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * Ts * D) return;
+  const int row = (int)(i / D), c = (int)(i - (size_t)row * D);
+  const int b = row / Ts, j = row - b * Ts;
+  const float v0 = x[((size_t)b * Tp + 2 * j) * D + c];
+  out[i] = 2 * j + 1 < Tp ? (v0 + x[((size_t)b * Tp + 2 * j + 1) * D + c]) * 0.5f : v0;
 }
 
 // concat_after: out[m] = [a[m] | b[m]]  (encoder.py:395-396)
@@ -293,6 +306,8 @@ struct GenRun {
   float *x, *a, *big, *y, *g, *ctx, *cat, *lg;
   ppasr_stream_s* s = nullptr;  // streaming: caches hold s->cache_t frames, key 0 at positional row pos0
   int pos0 = 0;
+  int used_r = 0;               // cached frames of the half-rate layers that take part (Efficient-Conformer, ChunkPlan)
+  int* frames_out = nullptr;    // encoder frames this call produced (half of the chunk's behind a stride layer)
 };
 
 ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* frame_argmax, float* frame_maxprob) {
@@ -300,11 +315,15 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
   hipStream_t st = r.st;
   const auto& o = h->gen;
   const int D = h->desc.output_size, H = h->desc.linear_units, V = h->desc.vocab_size, heads = h->desc.attention_heads;
-  const int B = r.B, Tp = r.Tp, M = B * Tp, mul = h->sub_rate();
+  const int B = r.B;
+  // frames per utterance / rows / mask multiplier / positional stride of the CURRENT layer: the Efficient-Conformer's
+  // stride layer halves the rate (masks[:, :, ::2], pos_emb[:, ::2], efficient_conformer/encoder.py:252-257)
+  int Tp = r.Tp, M = B * Tp, mul = h->sub_rate(), pstride = 1;
+  const bool eff = h->desc.model_type == PPASR_MODEL_EFFICIENT_CONFORMER;
   const int64_t* lens = r.lens;
   float *x = r.x, *a = r.a, *big = r.big, *y = r.y, *g = r.g, *ctx = r.ctx;
   const bool rel = o.pos == PPASR_OPT_POS_REL;
-  const int n_cache = r.s ? r.s->cache_t : 0;
+  bool half = false;  // behind the stride layer
   auto ln = [&](const float* in, float* out, const float* gg, const float* bb, float eps, int act, bool mask, int rows) {
     PPASR_LAUNCH(k_g_ln, dim3((rows + 3) / 4), dim3(256), 0, st, in, out, gg, bb, rows, D, eps, act, mask ? lens : nullptr, Tp, mul, 1.0f);
   };
@@ -336,11 +355,12 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
     if (o.post_norm) ln(x, x, lg, lb, 1e-5f, kActNone, false, M);
   };
   const float ff_scale = o.macaron ? 0.5f : 1.0f;
-  const int KS_model = h->desc.cnn_module_kernel;
-  const int left = h->desc.causal ? KS_model - 1 : (KS_model - 1) / 2;
-  const int lo_s = (r.s && o.use_cnn) ? r.s->lo : 0;  // cached conv-input rows in front of the chunk
   for (int i = 0; i < h->desc.num_blocks; ++i) {
     const LayerW& L = h->layers[i];
+    // streaming: cached conv-input rows in front of the chunk (this layer's kernel - 1: the slot's first rows, like the
+    // fused route) and cached key / value frames (the half-rate layers hold each cached frame once, capi_stream.hip)
+    const int lo_s = (r.s && o.use_cnn) ? h->layer_ks[i] - 1 : 0;
+    const int n_cache = r.s ? (half ? r.used_r : r.s->cache_t) : 0;
     if (o.macaron) ffn(L.ln_mac_g, L.ln_mac_b, L.ffm_w1, L.ffm_b1, L.ffm_w2, L.ffm_b2, ff_scale);
     // ---- (Rel)MultiHeadedAttention (attention.py:123-262) ----
     {
@@ -350,8 +370,10 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
         in = a;
       }
       dense(in, D, L.wqkv, L.bqkv, big, M, D, 3 * D, 3 * D, 3 * D, st);
-      AttnArgs at{big, 3 * D, big + D, 3 * D, big + 2 * D, 3 * D, Tp, Tp, rel ? r.pos0 : 0, lens, ctx, L.pos_u, L.pos_v,
-                  L.ptab, rel ? 1 : 0, mul, Tp, Tp, 1};
+      // tokens: frames, or zero-padded groups of 3 (GroupedRelPositionMultiHeadedAttention, pad4group)
+      const int grp = h->layer_group[i], Tt = (Tp + grp - 1) / grp;
+      AttnArgs at{big, 3 * D, big + D, 3 * D, big + 2 * D, 3 * D, Tt, Tt, rel ? r.pos0 : 0, lens, ctx, L.pos_u, L.pos_v,
+                  L.ptab, rel ? pstride : 0, mul * grp, Tp, Tp, grp};
       if (r.s) {  // keys / values: [cache | chunk] in the layer's device caches
         float* kc = r.s->kc + ((size_t)i * r.s->cap + n_cache) * D;
         float* vc = r.s->vc + ((size_t)i * r.s->cap + n_cache) * D;
@@ -359,7 +381,10 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
         at.k = r.s->kc + (size_t)i * r.s->cap * D;
         at.v = r.s->vc + (size_t)i * r.s->cap * D;
         at.k_stride = at.v_stride = D;
-        at.T2 = at.kv_frames = n_cache + Tp;
+        // grouped attention re-cuts cache + chunk frames into groups of 3 from the START of the cache (pad4group on the
+        // concatenated keys, efficient_conformer/attention.py:160-175)
+        at.kv_frames = n_cache + Tp;
+        at.T2 = (n_cache + Tp + grp - 1) / grp;
       }
       at.pad_skip = 0;
       at.dm = D;
@@ -376,6 +401,8 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
     // ---- ConvolutionModule (convolution.py:82-143) ----
     if (o.use_cnn) {
       const int KS = h->layer_ks[i];
+      const int left = h->desc.causal ? KS - 1 : (KS - 1) / 2;
+      const bool stride2 = eff && i == h->desc.stride_layer_idx;
       float* a_new = a + (size_t)lo_s * D;
       if (!o.post_norm) ln(x, a_new, L.ln_conv_g, L.ln_conv_b, 1e-5f, kActNone, true, M);  // LN_conv, PAD frames -> 0
       else ln(x, a_new, nullptr, nullptr, 0.f, kActNone, true, M);                           // PAD frames -> 0 only
@@ -388,7 +415,21 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
       }
       dense(a, D, L.pw1, L.pw1_b, big, rows, D, 2 * D, 2 * D, 2 * D, st);
       PPASR_LAUNCH(k_g_glu, blocks((size_t)rows * D), dim3(256), 0, st, big, g, rows, D);
-      PPASR_LAUNCH(k_g_dwconv, blocks((size_t)M * D), dim3(256), 0, st, g, y, L.dw_w, L.dw_b, L.glu_pad, M, Tp, D, KS, left, lo_s);
+      if (stride2) {
+        // StrideConformerEncoderLayer (efficient_conformer/encoder.py:455-548): depthwise conv with stride 2, the residual
+        // through AvgPool1D(2, ceil_mode); everything behind runs on ceil(T / 2) frames with masks / positions [::2]
+        const int Ts = (Tp + 1) / 2, Ms = B * Ts;
+        PPASR_LAUNCH(k_g_dwconv, blocks((size_t)Ms * D), dim3(256), 0, st, g, y, L.dw_w, L.dw_b, L.glu_pad, Ms, Ts, D, KS, left, lo_s, 2, Tp);
+        half = true;
+        PPASR_LAUNCH(k_g_avgpool2, blocks((size_t)Ms * D), dim3(256), 0, st, x, ctx, B, Tp, Ts, D);
+        Tp = Ts;
+        M = Ms;
+        mul *= 2;
+        pstride *= 2;
+        std::swap(x, ctx);  // (res_epi below reads the new x = the pooled residual)
+      } else {
+        PPASR_LAUNCH(k_g_dwconv, blocks((size_t)M * D), dim3(256), 0, st, g, y, L.dw_w, L.dw_b, L.glu_pad, M, Tp, D, KS, left, lo_s, 1, Tp);
+      }
       ln(y, y, L.ln_cm_g, L.ln_cm_b, L.cm_eps, o.act, false, M);  // LayerNorm / folded BatchNorm + activation
       dense(y, D, L.pw2, L.pw2_b, x, M, D, D, D, D, st, 1.0f, res_epi(1.0f, true));  // PAD frames of the conv output -> 0, + residual
       if (o.post_norm) ln(x, x, L.ln_conv_g, L.ln_conv_b, 1e-5f, kActNone, false, M);
@@ -396,6 +437,7 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
     ffn(L.ln_ff_g, L.ln_ff_b, L.ff_w1, L.ff_b1, L.ff_w2, L.ff_b2, ff_scale);
     if (o.use_cnn) ln(x, x, L.ln_fin_g, L.ln_fin_b, 1e-5f, kActNone, false, M);
   }
+  if (r.frames_out) *r.frames_out = Tp;
   // ---- after_norm (normalize_before only, encoder.py:201) -> ctc_lo -> softmax (ctc.py:62-70) ----
   const float* enc = x;
   if (!o.post_norm) {
@@ -591,7 +633,8 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
       }
       dense(a, D, W.pw1_raw, W.pw1_b_raw, big, rows, D, 2 * D, 2 * D, 2 * D, st);
       PPASR_LAUNCH(k_g_glu, blocks((size_t)rows * D), dim3(256), 0, st, big, g, rows, D);
-      PPASR_LAUNCH(k_g_dwconv, blocks((size_t)Mi * D), dim3(256), 0, st, g, y, W.dw_w, W.dw_b, W.glu_pad, Mi, Ti, D, KS, left, lo_s);
+      PPASR_LAUNCH(k_g_dwconv, blocks((size_t)Mi * D), dim3(256), 0, st, g, y, W.dw_w, W.dw_b, W.glu_pad, Mi, Ti, D, KS, left, lo_s,
+                   1, Ti);
       ln(y, y, W.ln_cm_g, W.ln_cm_b, W.cm_eps, (int)PPASR_ACT_SWISH, false, Mi, Ti, mul);
       dense(y, D, W.pw2, W.pw2_b, x, Mi, D, D, D, D, st, 1.0f, res_epi(true));
       ln(x, x, W.ln3_g, W.ln3_b, 1e-5f, kActNone, false, Mi, Ti, mul);
@@ -653,8 +696,8 @@ ppasr_status generic_encode(ppasr_model_s* h, const float* feats, const int64_t*
   return gen_layers(r, probs, logits, frame_argmax, frame_maxprob);
 }
 
-ppasr_status generic_chunk(ppasr_stream_s* s, const float* feats, int T, int pos0, float* probs, int32_t* frame_argmax,
-                           float* frame_maxprob, float* ws, hipStream_t st) {
+ppasr_status generic_chunk(ppasr_stream_s* s, const ChunkPlan& p, const float* feats, int T, float* probs,
+                           int32_t* frame_argmax, float* frame_maxprob, float* ws, hipStream_t st, int* frames_out) {
   ppasr_model_s* h = s->m;
   const GenWs wl = gen_layout(h, 1, T);
   // PositionalEncoding.forward(x, offset) (abs_pos): the chunk's first frame sits at position `offset`
@@ -663,6 +706,8 @@ ppasr_status generic_chunk(ppasr_stream_s* s, const float* feats, int T, int pos
   GenRun r{h, st, 1, h->front_dims(T).Tp, nullptr, ws + wl.x, ws + wl.a, ws + wl.big, ws + wl.y, ws + wl.g, ws + wl.ctx,
            ws + wl.cat, ws + wl.lg};
   r.s = s;
-  r.pos0 = pos0;
+  r.pos0 = p.pos0;
+  r.used_r = p.used_r;
+  r.frames_out = frames_out;
   return gen_layers(r, probs, nullptr, frame_argmax, frame_maxprob);
 }

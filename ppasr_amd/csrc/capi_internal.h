@@ -203,10 +203,11 @@ ppasr_status upload_pe_table(ppasr_model_s* m, BlobMap& sd, const float** pe_dev
 size_t generic_ws_floats(const ppasr_model_s* m, int B, int T);
 ppasr_status generic_encode(ppasr_model_s* h, const float* feats, const int64_t* lens, int B, int T, float* probs,
                             float* logits, int32_t* frame_argmax, float* frame_maxprob, float* ws, hipStream_t st);
-// one chunk of ConformerEncoder.forward_chunk (conformer/encoder.py:208-283) on the general route: the caches of `s`
-// hold cache_t frames, key 0 sits at positional row pos0; appends this chunk's keys / values and conv inputs
-ppasr_status generic_chunk(ppasr_stream_s* s, const float* feats, int T, int pos0, float* probs, int32_t* frame_argmax,
-                           float* frame_maxprob, float* ws, hipStream_t st);
+// one chunk of ConformerEncoder / EfficientConformerEncoder.forward_chunk (conformer/encoder.py:208-283,
+// efficient_conformer/encoder.py:266-393) on the general route: the caches of `s` hold cache_t (cache_r behind the stride
+// layer) frames, key 0 sits at positional row p.pos0; appends this chunk's keys / values and conv inputs
+ppasr_status generic_chunk(ppasr_stream_s* s, const ChunkPlan& p, const float* feats, int T, float* probs,
+                           int32_t* frame_argmax, float* frame_maxprob, float* ws, hipStream_t st, int* frames_out);
 // SqueezeformerEncoder.forward_chunk (squeezeformer/encoder.py:260-381) on the general route
 ppasr_status generic_sq_chunk(ppasr_stream_s* s, const ChunkPlan& p, const float* feats, int T, float* probs,
                               int32_t* frame_argmax, float* frame_maxprob, float* ws, hipStream_t st);

@@ -318,13 +318,14 @@ ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int r
   const WsLayout wl = ws_layout(h, 1, T);
   float* ws = static_cast<float*>(workspace);
   if (h->generic) {  // the general layer route (capi_generic.hip): same cache bookkeeping, its own layer pieces
+    int gframes = c;
     r = is_sq(h) ? generic_sq_chunk(s, p, feats, T, probs, frame_argmax, frame_maxprob, ws, st)
-                 : generic_chunk(s, feats, T, p.pos0, probs, frame_argmax, frame_maxprob, ws, st);
+                 : generic_chunk(s, p, feats, T, probs, frame_argmax, frame_maxprob, ws, st, &gframes);
     if (r != PPASR_OK) return r;
     r = finish_chunk(s, p, ws + wl.total, st);
     if (r != PPASR_OK) return r;
-    s->offset += c;
-    if (c_out_host) *c_out_host = c;
+    s->offset += gframes;
+    if (c_out_host) *c_out_host = gframes;
     return PPASR_OK;
   }
   float *y1 = ws + wl.y1, *y2 = ws + wl.y2, *xa = ws + wl.xa, *xb = ws + wl.xb, *xc = ws + wl.xc;

@@ -528,7 +528,18 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   const float* __restrict__ qb = a.q + (size_t)b * F1 * a.q_stride;
   const float* __restrict__ kbp = a.k + (size_t)b * F2 * a.k_stride;
   const float* __restrict__ vbp = a.v + (size_t)b * F2 * a.v_stride;
-  const int dm = a.dm;  // model width: row stride of ptab / ctx (256; the generic-width route: 512, plain heads only)
+  const int dm = a.dm;  // model width: row stride of ptab / ctx (256; the general layer route: 512 .. 1024)
+  // grouped heads cut a token's G x dm contiguous floats into dm / 64 heads of 192: flat offset -> (frame, feature)
+  const int dm_shift = (dm & (dm - 1)) == 0 ? 31 - __builtin_clz(dm) : -1;  // (768: no shift)
+  auto split = [&](int flat, int& frame, int& feat) {
+    if (dm_shift >= 0) {
+      frame = flat >> dm_shift;
+      feat = flat & (dm - 1);
+    } else {
+      frame = flat / dm;
+      feat = flat - frame * dm;
+    }
+  };
   const float* __restrict__ ptab = a.ptab + (size_t)a.pos0 * dm;
   if (a.sess) {  // multi-session streaming: per-session cache slot, length and position
     const SessDesc d = a.sess[b];
@@ -551,8 +562,8 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   // activations (G = 1: plain heads; G = 3: pad4group's re-cut of 3 frames into 4 heads of 192); zero beyond the
   // valid frames (the zero-padded tail group).
   auto tok4 = [&](const float* base, int stride, int nframes, int j, int f) -> f32x4 {
-    const int flat = j * (C::G * kD) + h * DK + f;
-    const int frame = C::G == 1 ? j : flat >> 8, feat = C::G == 1 ? h * DK + f : flat & 255;
+    int frame = j, feat = h * DK + f;
+    if (C::G != 1) split(j * (C::G * dm) + h * DK + f, frame, feat);
     if (frame >= nframes) return f32x4{0.f, 0.f, 0.f, 0.f};
     return *reinterpret_cast<const f32x4*>(base + (size_t)frame * stride + feat);
   };
@@ -568,16 +579,16 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
     if (j >= T2) return f32x4{0.f, 0.f, 0.f, 0.f};
     const int f = 8 * (g < DK / 8 ? g : g - DK / 8) + 4 * (lane >> 5);
     if (g < DK / 8) return tok4(kbp, a.k_stride, F2, j, f);
-    const int flat = j * (C::G * kD) + h * DK + f;
-    const int frame = flat >> 8, feat = flat & 255;
+    int frame, feat;
+    split(j * (C::G * dm) + h * DK + f, frame, feat);
     if (frame >= F2) return f32x4{0.f, 0.f, 0.f, 0.f};
-    return *reinterpret_cast<const f32x4*>(ptab + (size_t)frame * pstride * kD + feat);
+    return *reinterpret_cast<const f32x4*>(ptab + (size_t)frame * pstride * dm + feat);
   };
   auto vval = [&](int j, int col) -> float {
     if (C::G == 1) return vbp[(size_t)min(j, T2 - 1) * a.v_stride + h * DK + col];  // P is 0 for keys >= T2
     if (j >= T2) return 0.f;
-    const int flat = j * (C::G * kD) + h * DK + col;
-    const int frame = flat >> 8, feat = flat & 255;
+    int frame, feat;
+    split(j * (C::G * dm) + h * DK + col, frame, feat);
     return frame < F2 ? vbp[(size_t)frame * a.v_stride + feat] : 0.f;
   };
 
@@ -771,8 +782,8 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
           o = (l > 0.f) ? o / l : 0.f;  // fully masked row -> 0 (attention.py:118)
           if (q0 + row < T1) {
             const int cc = h * DK + (ctg * C::NO + t) * 32 + (lane & 31);
-            const int flat = (q0 + row) * (C::G * kD) + cc;
-            const int frame = C::G == 1 ? q0 + row : flat >> 8, feat = C::G == 1 ? cc : flat & 255;
+            int frame = q0 + row, feat = cc;
+            if (C::G != 1) split((q0 + row) * (C::G * dm) + cc, frame, feat);
             if (frame < F1) ctx[(size_t)frame * dm + feat] = o;  // x[:, :T - padding_q] (efficient attention.py:124-125)
           }
         }

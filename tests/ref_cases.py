@@ -31,6 +31,11 @@ SMALL = {
                      required=(-16, 32), stride_layer_idx=1, group_layer_idx=(0, 1)),
     "eff_n": _former("efficient_conformer", False, 4, 53, 513, (2, 147, [147, 86], 514), stride_layer_idx=1,
                      group_layer_idx=(0, 1)),
+    # output_size 512 / 8 heads (configs/efficient_conformer.yml:3-4): the general layer route (batched), an 11-tap conv
+    "eff512_s": _former("efficient_conformer", True, 3, 53, 585, (3, 149, [149, 101, 9], 586), chunk_frames=64 * 3 + 67,
+                        required=(-16, 32), stride_layer_idx=1, group_layer_idx=(0, 1), output_size=512, attention_heads=8),
+    "eff512_n": _former("efficient_conformer", False, 3, 53, 587, (2, 148, [148, 77], 588), stride_layer_idx=1,
+                        group_layer_idx=(0,), output_size=512, attention_heads=8, cnn_module_kernel=11),
     # Squeezeformer: reduce before layer 1, recover before layer 3
     "sq_s": _former("squeezeformer", True, 4, 59, 521, (2, 131, [131, 77], 522), chunk_frames=64 * 4 + 40,
                     required=(-16, 32), reduce_idx=1, recover_idx=3),
@@ -124,7 +129,9 @@ def state_dict(case, perturb=True):
         if full:
             return efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=seed)
         return efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn,
-                                              stride_layer_idx=kw["stride_layer_idx"], group_layer_idx=kw["group_layer_idx"])
+                                              stride_layer_idx=kw["stride_layer_idx"], group_layer_idx=kw["group_layer_idx"],
+                                              output_size=kw.get("output_size", 256), attention_heads=kw.get("attention_heads", 4),
+                                              cnn_module_kernel=kw.get("cnn_module_kernel", 15))
     if fam == "squeezeformer":
         return squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn, streaming=case["streaming"],
                                         cnn_norm_type=kw.get("cnn_norm_type", "layer_norm"),
@@ -161,8 +168,9 @@ def reference_encoder_conf(case):
         c.update(kw)  # (concat_after / macaron_style appear only where a case sets them)
         return c
     if fam == "efficient_conformer":
-        c = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, activation_type="swish",
-                 cnn_module_kernel=15, cnn_module_norm="layer_norm", dropout_rate=0.1, input_layer="conv2d",
+        c = dict(output_size=kw.get("output_size", 256), attention_heads=kw.get("attention_heads", 4), linear_units=2048,
+                 num_blocks=L, activation_type="swish", cnn_module_kernel=kw.get("cnn_module_kernel", 15),
+                 cnn_module_norm="layer_norm", dropout_rate=0.1, input_layer="conv2d",
                  normalize_before=True, pos_enc_layer_type="rel_pos", attention_dropout_rate=0.1,
                  positional_dropout_rate=0.1)
         if L != 12:

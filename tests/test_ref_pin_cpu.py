@@ -41,7 +41,9 @@ def make_oracle(case, sd):
         return ConformerOracle(sd, num_blocks=L, causal=causal, attention_heads=kw.get("attention_heads", 4), **opts)
     if fam == "efficient_conformer":
         return EfficientConformerOracle(sd, num_blocks=L, stride_layer_idx=kw["stride_layer_idx"],
-                                        group_layer_idx=kw["group_layer_idx"], causal=causal)
+                                        group_layer_idx=kw["group_layer_idx"], causal=causal,
+                                        attention_heads=kw.get("attention_heads", 4),
+                                        cnn_module_kernel=kw.get("cnn_module_kernel", 15))
     if fam == "squeezeformer":
         return SqueezeformerOracle(sd, num_blocks=L, reduce_idx=kw["reduce_idx"], recover_idx=kw["recover_idx"], causal=causal,
                                    attention_heads=kw.get("attention_heads", 4))
