@@ -45,7 +45,7 @@ def test_unsupported_configs_are_refused_not_emulated():
     for desc in (_lib.ModelDesc(99, 80, 100, 256, 4, 2048, 2, 15, 1, 5000, -1, -1, -1, 0, 0),  # unknown model family
                  _lib.ModelDesc(0, 80, 100, 384, 6, 2048, 2, 15, 1, 5000, -1, -1, -1, 0, 0),   # width not a multiple of 256
                  _lib.ModelDesc(0, 80, 100, 512, 4, 2048, 2, 15, 1, 5000, -1, -1, -1, 0, 0),   # d_k != 64
-                 _lib.ModelDesc(1, 80, 100, 512, 8, 2048, 2, 15, 1, 5000, -1, -1, -1, 0, 0),   # width 512: conformer only
+                 _lib.ModelDesc(1, 80, 100, 256, 4, 2048, 2, 15, 1, 5000, -1, -1, -1, 0, 0, 0, 0, 4),  # options: conformer only
                  _lib.ModelDesc(0, 80, 100, 256, 4, 2000, 2, 15, 1, 5000, -1, -1, -1, 0, 0)):  # ffn % 256
         rc = lib.ppasr_create(ctypes.byref(desc), blob, 1, ctypes.byref(h))
         assert rc == 3, lib.ppasr_last_error()
