@@ -81,7 +81,8 @@ typedef struct {
      configuration (rel_pos, normalize_before, macaron_style, use_cnn_module, swish).  Any other value -- like
      output_size != 256, input_layer = linear or a cnn_module_kernel other than 7 / 15 / 31 -- selects the general layer
      route (capi_generic.hip: the same packed weights and matrix-core GEMMs, one launch per layer piece instead of the
-     fused 256-wide row-block kernels).  model_type = conformer only. */
+     fused 256-wide row-block kernels).  options / input_layer = linear: model_type = conformer only; output_size 512 / 768 /
+     1024 (heads of 64): conformer, efficient_conformer and squeezeformer, batched and streaming. */
   int options;
 } ppasr_model_desc;
 
