@@ -97,3 +97,80 @@ def test_random_options_chunked(seed):
         assert tuple(cnn.shape) == tuple(r_cnn.shape), (cnn.shape, r_cnn.shape)
         if r_cnn.numel():
             assert _rel(cnn.cpu().numpy(), r_cnn.numpy()) < TOL
+
+
+# ---- the other *former families at widths the fused kernels do not cover (Squeezeformer encoder_dim, Efficient-Conformer
+# output_size 512: "for big data", configs/squeezeformer.yml:3-5, configs/efficient_conformer.yml:3-4) ----------------------
+def _build_family(family, seed, streaming):
+    from oracle.efficient_conformer_oracle import EfficientConformerOracle
+    from oracle.squeezeformer_oracle import SqueezeformerOracle
+    from ppasr_amd.model_utils.efficient_conformer.model import EfficientConformerModel
+    from ppasr_amd.model_utils.squeezeformer.model import SqueezeformerModel
+    from ppasr_amd.utils.synth import efficient_conformer_state_dict, squeezeformer_state_dict
+    rng = np.random.Generator(np.random.PCG64(11000 + seed))
+    V, L, width = 47, int(rng.integers(3, 5)), 512
+    norm = str(rng.choice(["layer_norm", "batch_norm"]))
+    if family == "squeezeformer":
+        red = int(rng.integers(1, L - 1))
+        rec = int(rng.integers(red + 1, L))
+        ks = int(rng.choice([15, 31]))
+        sd = squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=12000 + seed, perturb_norm=True, streaming=streaming,
+                                      cnn_norm_type=norm, encoder_dim=width, attention_heads=8, cnn_module_kernel=ks)
+        conf = dict(encoder_dim=width, output_size=width, attention_heads=8, num_blocks=L, reduce_idx=red, recover_idx=rec,
+                    feed_forward_expansion_factor=8, cnn_module_kernel=ks, cnn_norm_type=norm)
+        model = SqueezeformerModel(80, V, streaming=streaming, encoder_conf=conf, state_dict=sd, device="cuda:0")
+        oracle = SqueezeformerOracle(sd, num_blocks=L, reduce_idx=red, recover_idx=rec, causal=streaming, attention_heads=8,
+                                     cnn_module_kernel=ks)
+    else:
+        stride_idx = int(rng.integers(0, L - 1))
+        groups = tuple(sorted(set(int(v) for v in rng.integers(0, stride_idx + 1, size=2))))
+        sd = efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=12000 + seed, perturb_norm=True,
+                                            stride_layer_idx=stride_idx, group_layer_idx=groups, output_size=width,
+                                            attention_heads=8, cnn_module_norm=norm)
+        conf = dict(output_size=width, attention_heads=8, linear_units=2048, num_blocks=L, cnn_module_kernel=15,
+                    cnn_module_norm=norm,
+                    efficient_conf=dict(stride_layer_idx=[stride_idx], stride=[2], group_layer_idx=list(groups), group_size=3,
+                                        stride_kernel=True))
+        model = EfficientConformerModel(80, V, streaming=streaming, encoder_conf=conf, state_dict=sd, device="cuda:0")
+        oracle = EfficientConformerOracle(sd, num_blocks=L, stride_layer_idx=stride_idx, group_layer_idx=groups, causal=streaming,
+                                          attention_heads=8)
+    return model, oracle, conf, rng
+
+
+@pytest.mark.parametrize("family", ["squeezeformer", "efficient_conformer"])
+@pytest.mark.parametrize("seed", range(4))
+def test_width_512_families_batched(family, seed):
+    streaming = bool(seed & 1)
+    model, oracle, conf, rng = _build_family(family, seed, streaming)
+    T = int(rng.integers(70, 300))
+    for B, Tb, lens in ((4, T, [T, int(rng.integers(2, T)), 1, 0]), (1, 7, [7])):
+        x, la = synth_features(B, Tb, lens=lens, seed=seed + Tb)
+        probs, logits = model.get_encoder_out(x, la, return_logits=True)
+        ref_probs, ref_logits = oracle.get_encoder_out(x, la, return_logits=True)
+        torch.cuda.synchronize()
+        assert torch.isfinite(probs).all()
+        e = _rel(logits.cpu().numpy(), ref_logits.numpy())
+        print(f"{family} seed {seed} {conf} B={B} T={Tb}: logits {e:.2e}")
+        assert e < TOL, conf
+
+
+@pytest.mark.parametrize("family", ["squeezeformer", "efficient_conformer"])
+@pytest.mark.parametrize("seed", range(3))
+def test_width_512_families_chunked(family, seed):
+    model, oracle, conf, rng = _build_family(family, 50 + seed, True)
+    required = int(rng.choice([-16, 32, 16]))  # (even cache lengths: the reference's half-rate arithmetic needs them)
+    # (whole 67-frame windows only: a short last window leaves an odd cache length, on which the Efficient-Conformer's
+    #  export -- repeat_interleave of the half-rate caches -- fails in the reference and is refused here)
+    x, _ = synth_features(1, 64 * 4 + 67, seed=seed + 23)
+    att = cnn = r_att = r_cnn = None
+    off = 0
+    for cur in range(0, x.shape[1] - 7 + 1, 64):  # the predictor's 67-frame windows, stride 64 (predict.py:277-298)
+        chunk = x[:, cur:min(cur + 67, x.shape[1])]
+        p, att, cnn = model.get_encoder_out_chunk(chunk, off, required, att, cnn)
+        rp, r_att, r_cnn = oracle.get_encoder_out_chunk(chunk, off, required, r_att, r_cnn)
+        off += p.shape[1]
+        e = _rel(p.cpu().numpy(), rp.numpy())
+        print(f"{family} seed {seed} window {cur} required {required}: probs {e:.2e}")
+        assert e < TOL, conf
+        assert tuple(att.shape) == tuple(r_att.shape), (att.shape, r_att.shape)
+        assert _rel(att.cpu().numpy(), r_att.numpy()) < TOL and _rel(cnn.cpu().numpy(), r_cnn.numpy()) < TOL
