@@ -65,7 +65,7 @@ typedef std::unordered_map<std::string, Blob> BlobMap;
 struct ppasr_model_s {
   ppasr_model_desc desc;
   int F1, F2;
-  // generic-width route (output_size != 256, capi_generic.hip): CTC head as a dense layer over the padded vocabulary
+  // general layer route (capi_generic.hip): CTC head as a dense layer over the padded vocabulary
   const f32x4* gen_head_w = nullptr;
   const float* gen_head_b = nullptr;
   int gen_vpad = 0;

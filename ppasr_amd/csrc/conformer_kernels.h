@@ -80,7 +80,7 @@ struct AttnArgs {
   // room for vt_stride rows; a.v is not read then
   const float* vt = nullptr;
   int vt_stride = 0;
-  // model width (row stride of ptab / ctx, h * 64 <= dm); 256 everywhere except the generic-width route (capi_generic.hip),
+  // model width (row stride of ptab / ctx, h * 64 <= dm); 256 everywhere except the general layer route (capi_generic.hip),
   // which runs k_attention<64> with 8 heads on 512-wide activations
   int dm = 256;
 };
@@ -107,7 +107,7 @@ void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T,
 // one k x k / stride-s 256 -> 256 channel conv + ReLU of the front end on NHWC activations (implicit GEMM)
 void launch_conv_stage(const float* y_in, const f32x4* w, const float* bias, float* y_out, int B, int T_in, int F_in,
                        int T_out, int F_out, int k, int s, hipStream_t st, const PadSkip& ps_frames = PadSkip{},
-                       int channels = 256);  // channels: 256, or a multiple of it (generic-width route)
+                       int channels = 256);  // channels: 256, or a multiple of it (general layer route)
 void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st,
                   const PadSkip& ps = PadSkip{});
 // scale_before_bias: Squeezeformer scales the 4864-wide conv output by sqrt(d) BEFORE input_proj

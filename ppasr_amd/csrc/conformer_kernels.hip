@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void k_dense_join(const float* __restrict__ pa
 }
 
 // out[M][ldc] (columns < n_valid) = A[M][K] * Wpacked + bias ; K % 256 == 0 ; weights / bias padded to a multiple of
-// 256 columns.  Used by the DeepSpeech2 path (LSTM input projections, CTC head) and the generic-width route.
+// 256 columns.  Used by the DeepSpeech2 path (LSTM input projections, CTC head) and the general layer route.
 // Under-filled launches (few rows: one utterance): with a scratch buffer `part` of >= k_slices * M * ldc floats the K
 // contraction is cut over up to 8 workgroups per tile (partial sums joined by k_dense_join), like the embed GEMM.
 void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, float* out, int M, int K, int n_cols_padded,

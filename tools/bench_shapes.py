@@ -27,7 +27,7 @@ for name, kw in (("output_size 256 / 4 heads (the bench shape)", {}),
                  ("cnn_module_norm batch_norm", dict(cnn_module_norm="batch_norm")),
                  ("input_layer conv2d6", dict(input_layer="conv2d6")),
                  ("input_layer conv2d8", dict(input_layer="conv2d8")),
-                 ("output_size 512 / 8 heads (generic-width route)", dict(output_size=512, attention_heads=8))):
+                 ("output_size 512 / 8 heads (general layer route)", dict(output_size=512, attention_heads=8))):
     sd = conformer_state_dict(vocab_size=V, num_blocks=12, seed=1234, **kw)
     conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12, cnn_module_kernel=15)
     conf.update(kw)
