@@ -511,7 +511,9 @@ struct AttnCfg {
 //   PV      : wave = (column-tile group, key half); B = V rows from global (one dword per lane per MFMA, two
 //             coalesced 128-B segments per wave-load), A = P from LDS.
 // Three barriers per key block; LDS holds only Q' and the score block, so several workgroups share a CU.
-template <int DK>
+// W256: model width 256 known at compile time (the grouped heads' flat-offset arithmetic folds to shifts / masks: the
+// fused-route Efficient-Conformer; a run-time width costs k_attention<192> 17 %)
+template <int DK, bool W256 = false>
 __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   using C = AttnCfg<DK>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -528,11 +530,14 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   const float* __restrict__ qb = a.q + (size_t)b * F1 * a.q_stride;
   const float* __restrict__ kbp = a.k + (size_t)b * F2 * a.k_stride;
   const float* __restrict__ vbp = a.v + (size_t)b * F2 * a.v_stride;
-  const int dm = a.dm;  // model width: row stride of ptab / ctx (256; the general layer route: 512 .. 1024)
+  const int dm = W256 ? kD : a.dm;  // model width: row stride of ptab / ctx (256; the general layer route: 512 .. 1024)
   // grouped heads cut a token's G x dm contiguous floats into dm / 64 heads of 192: flat offset -> (frame, feature)
   const int dm_shift = (dm & (dm - 1)) == 0 ? 31 - __builtin_clz(dm) : -1;  // (768: no shift)
   auto split = [&](int flat, int& frame, int& feat) {
-    if (dm_shift >= 0) {
+    if (W256) {
+      frame = flat >> 8;
+      feat = flat & 255;
+    } else if (dm_shift >= 0) {
       frame = flat >> dm_shift;
       feat = flat & (dm - 1);
     } else {
@@ -792,8 +797,10 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
 constexpr size_t kLdsAttn = AttnCfg<64>::LDS_FLOATS * sizeof(float);
 constexpr size_t kLdsAttnG = AttnCfg<192>::LDS_FLOATS * sizeof(float);
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st) {
-  if (a.group == 3)
-    PPASR_LAUNCH(k_attention<192>, dim3((a.T1 + 63) / 64, H, B), dim3(256), kLdsAttnG, st, a);
+  if (a.group == 3 && a.dm == kD)
+    PPASR_LAUNCH((k_attention<192, true>), dim3((a.T1 + 63) / 64, H, B), dim3(256), kLdsAttnG, st, a);
+  else if (a.group == 3)
+    PPASR_LAUNCH((k_attention<192, false>), dim3((a.T1 + 63) / 64, H, B), dim3(256), kLdsAttnG, st, a);
   else
     PPASR_LAUNCH(k_attention<64>, dim3((a.T1 + 63) / 64, H, B), dim3(256), kLdsAttn, st, a);
 }
@@ -2235,7 +2242,8 @@ hipError_t configure_kernels() {
   if (e != hipSuccess) return e;
   SET_LDS(k_ffn_qkv, kLdsFfnQkv);
   SET_LDS(k_attention<64>, kLdsAttn);
-  SET_LDS(k_attention<192>, kLdsAttnG);
+  SET_LDS((k_attention<192, true>), kLdsAttnG);
+  SET_LDS((k_attention<192, false>), kLdsAttnG);
   SET_LDS(k_out_glu, kLdsOutGlu);
   SET_LDS(k_pw1_glu_cols, kLdsPw1Cols);
   SET_LDS((k_conv_ffn<15, false, false>), kLdsConvFfn);
