@@ -58,3 +58,25 @@ def test_model_wrapper_refuses_to_run_without_gpu():
     from ppasr_amd.model_utils.conformer.model import ConformerModel
     with pytest.raises(_lib.PPASRHipError):
         ConformerModel(80, 10, state_dict={"x": [0.0]})
+
+
+def test_option_codes_match_the_header():
+    """ppasr_model_desc::options: the PPASR_OPT_* / PPASR_ACT_* values of include/ppasr_hip.h are the ones the Python layer
+    packs (ppasr_amd/_lib.py, model_utils/conformer/model.py), and every activation name of the reference's get_activation
+    (utils/common.py:189-206) has a code."""
+    import re
+    from ppasr_amd.model_utils.conformer import model as cm
+    text = open(os.path.join(ROOT, "include", "ppasr_hip.h")).read()
+    enums = {k: int(v) for k, v in re.findall(r"\b(PPASR_(?:OPT|ACT)_[A-Z0-9_]+)\s*=\s*(\d+)", text)}
+    assert enums["PPASR_OPT_POS_REL"] == cm._POS_CODES["rel_pos"] == 0
+    assert enums["PPASR_OPT_POS_ABS"] == cm._POS_CODES["abs_pos"] and enums["PPASR_OPT_POS_NONE"] == cm._POS_CODES["no_pos"]
+    assert (enums["PPASR_OPT_POST_NORM"], enums["PPASR_OPT_CONCAT_AFTER"], enums["PPASR_OPT_NO_MACARON"], enums["PPASR_OPT_NO_CNN"],
+            enums["PPASR_OPT_ACT_SHIFT"]) == (_lib.PPASR_OPT_POST_NORM, _lib.PPASR_OPT_CONCAT_AFTER, _lib.PPASR_OPT_NO_MACARON,
+                                              _lib.PPASR_OPT_NO_CNN, _lib.PPASR_OPT_ACT_SHIFT)
+    for name, code in cm._ACT_CODES.items():
+        assert enums["PPASR_ACT_" + name.upper()] == code, name
+    assert set(cm._ACT_CODES) == {"hardshrink", "hardswish", "hardtanh", "tanh", "relu", "relu6", "leakyrelu", "selu", "swish",
+                                  "gelu", "elu"}
+    assert max(cm._ACT_CODES.values()) <= enums["PPASR_OPT_ACT_MASK"]
+    # the descriptor the bindings build has the header's field count (18 ints)
+    assert ctypes.sizeof(_lib.ModelDesc) == 18 * ctypes.sizeof(ctypes.c_int)
