@@ -18,6 +18,8 @@
 //     the positional half of its score contraction runs on a zero row (q . k + (q + v) . 0: bit-identical to q . k);
 //   * LayerNorm, GLU, depthwise conv -> the small row kernels below (HBM-bound, one pass each).
 // Results follow the reference exactly like the fused route (same arithmetic, different fusion).
+#include <cstdlib>
+
 #include "capi_internal.h"
 
 using namespace ppasr;
@@ -143,6 +145,91 @@ void dense(const float* a, int lda, const f32x4* w, const float* bias, float* ou
                lda, w, bias, out, M, K / 256, scale, ldc, n_valid, epi);
 }
 
+// ---- fused feed-forward module for 512-wide models -----------------------------------------------------------------
+// out = x + scale * W2 act(W1 LN(x) + b1) + b2 for a 32-row block, the hidden activations never leaving LDS (the 256-wide
+// kernels' scheme, phases.h: ffn_phase): LDS = the LayerNorm'd rows [32][516] + two hidden chunks [32][260] = 132.6 KB.
+// Wave w owns hidden columns [32w, 32w + 32) of every 256-wide chunk and the output columns [64w, 64w + 64) (two 32-column
+// tiles, contracted one after the other so that ONE weight ring streams W1(c), W2(c, tile 0), W2(c, tile 1), W1(c + 1) ..
+// without draining).  ln_g == nullptr: no LayerNorm in front (post-norm layers normalise the sum afterwards).
+// Replaces k_g_ln + two k_dense_epi launches (the 65 MB hidden tensor of a 32 x 10 s batch stays on chip).
+constexpr int kD512 = 512, kLd512 = kD512 + 4;
+constexpr size_t kLdsFfn512 = (size_t)(kRows * kLd512 + 2 * kRows * kLda) * sizeof(float);
+__global__ __launch_bounds__(kThreads) void k_g_ffn512(const float* x, float* out, const float* __restrict__ ln_g,
+                                                       const float* __restrict__ ln_b, const f32x4* __restrict__ w1,
+                                                       const float* __restrict__ b1, const f32x4* __restrict__ w2,
+                                                       const float* __restrict__ b2, float scale, int act, int M,
+                                                       int n_chunks) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufA = smem;                    // [32][516]
+  float* bufH = bufA + kRows * kLd512;   // [2][32][260]
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blockIdx.x * kRows, valid = min(kRows, M - r0);
+  BRing<1> ring;
+  const int ts1 = (kD512 / 8) * 64;      // W1: K = 512 -> 64 k-groups per 32-column tile
+  const int ts2 = n_chunks * 32 * 64;    // W2: K = hidden
+  auto w1seg = [&](int c) { return w1 + (size_t)(c * 8 + wave) * ts1; };
+  auto w2seg = [&](int c, int t) { return w2 + (size_t)(2 * wave + t) * ts2 + (size_t)c * 32 * 64; };
+  ring_prime(ring, w1seg(0), 0);
+  {  // rows -> (LayerNorm) -> bufA; a row = two f32x4 per lane (columns 4 lane .. and 256 + 4 lane ..)
+    f32x4 g0, g1, be0, be1;
+    if (ln_g) {
+      g0 = *reinterpret_cast<const f32x4*>(ln_g + 4 * lane);
+      g1 = *reinterpret_cast<const f32x4*>(ln_g + 256 + 4 * lane);
+      be0 = *reinterpret_cast<const f32x4*>(ln_b + 4 * lane);
+      be1 = *reinterpret_cast<const f32x4*>(ln_b + 256 + 4 * lane);
+    }
+    for (int row = wave; row < kRows; row += kWaves) {
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+      if (row < valid) {
+        v0 = *reinterpret_cast<const f32x4*>(x + (size_t)(r0 + row) * kD512 + 4 * lane);
+        v1 = *reinterpret_cast<const f32x4*>(x + (size_t)(r0 + row) * kD512 + 256 + 4 * lane);
+        if (ln_g) {
+          const float mean = wave_sum(v0[0] + v0[1] + v0[2] + v0[3] + v1[0] + v1[1] + v1[2] + v1[3]) * (1.0f / kD512);
+          v0 = v0 - mean;
+          v1 = v1 - mean;
+          const float var = wave_sum(v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2] + v0[3] * v0[3] + v1[0] * v1[0] +
+                                     v1[1] * v1[1] + v1[2] * v1[2] + v1[3] * v1[3]) * (1.0f / kD512);
+          const float rstd = 1.0f / sqrtf(var + 1e-5f);
+          v0 = v0 * rstd * g0 + be0;
+          v1 = v1 * rstd * g1 + be1;
+        }
+      }
+      *reinterpret_cast<f32x4*>(bufA + row * kLd512 + 4 * lane) = v0;
+      *reinterpret_cast<f32x4*>(bufA + row * kLd512 + 256 + 4 * lane) = v1;
+    }
+  }
+  __syncthreads();
+  f32x16 acc2[2][1][1];
+  acc_zero(acc2[0]);
+  acc_zero(acc2[1]);
+  const int hcol = wave * 32 + (lane & 31);
+  for (int c = 0; c < n_chunks; ++c) {
+    float* hb = bufH + (c & 1) * kRows * kLda;
+    f32x16 acc1[1][1];
+    acc_zero(acc1);
+    rb_gemm<1, 1, kD512 / 8>(bufA, kLd512, w1seg(c), 0, w2seg(c, 0), 0, ring, acc1);
+    const float bv = b1[c * 256 + hcol];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hb[acc_row(r, lane) * kLda + hcol] = act_apply(act, acc1[0][0][r] + bv);
+    __syncthreads();  // (two hidden buffers: the next chunk's epilogue writes the other one, see the comment in ffn_phase)
+    rb_gemm<1, 1, kG256>(hb, kLda, w2seg(c, 0), 0, w2seg(c, 1), 0, ring, acc2[0]);
+    rb_gemm<1, 1, kG256>(hb, kLda, w2seg(c, 1), 0, c + 1 < n_chunks ? w1seg(c + 1) : nullptr, 0, ring, acc2[1]);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int col = wave * 64 + t * 32 + (lane & 31);
+    const float bv = b2[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, lane);
+      if (row < valid) {
+        const size_t o = (size_t)(r0 + row) * kD512 + col;
+        out[o] = x[o] + scale * (acc2[t][0][0][r] + bv);  // (out may alias x: same lane reads and writes the element)
+      }
+    }
+  }
+}
+
 // LayerNorm over D columns (nn.LayerNorm, biased variance, eps inside the sqrt), one wave per row, optionally followed
 // by an activation, optionally with rows t of utterance b zeroed where mul * t >= lens[b] (the conv module's input
 // mask, convolution.py:104-106).  eps < 0: per-channel affine only (folded BatchNorm, see capi.hip).  g == nullptr:
@@ -261,6 +348,13 @@ __global__ void k_g_kv_append(const float* __restrict__ qkv, float* __restrict__
   vc[i] = qkv[row * 3 * D + 2 * D + c];
 }
 
+inline bool fused_ffn512() {
+  static const bool on = [] {
+    const char* e = std::getenv("PPASR_GEN_FUSED_FFN");  // (0: LayerNorm + two GEMM launches, for A/B measurements)
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
 inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
 inline dim3 blocks(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
@@ -344,7 +438,14 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
     return e;
   };
   // PositionwiseFeedForward (positionwise.py:32-39) inside the layer's residual (encoder.py:380-386 / 411-417)
+  const bool fused_ffn = fused_ffn512();
   auto ffn = [&](const float* lg, const float* lb, const f32x4* w1, const float* b1, const f32x4* w2, const float* b2, float scale) {
+    if (fused_ffn && D == kD512) {  // one launch, hidden activations in LDS
+      PPASR_LAUNCH(k_g_ffn512, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsFfn512, st, x, x, o.post_norm ? nullptr : lg,
+                   o.post_norm ? nullptr : lb, w1, b1, w2, b2, scale, o.act, M, H / 256);
+      if (o.post_norm) ln(x, x, lg, lb, 1e-5f, kActNone, false, M);
+      return;
+    }
     const float* in = x;
     if (!o.post_norm) {
       ln(x, a, lg, lb, 1e-5f, kActNone, false, M);
@@ -618,8 +719,16 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
     dense(ctx, D, W.wo, W.bo, x, Mi, D, D, D, D, st, 1.0f, res_epi(false));
     ln(x, x, W.ln1_g, W.ln1_b, 1e-5f, kActNone, false, Mi, Ti, mul);
     // ---- x = LN2(x + FFN1(x)) ----
-    dense(x, D, W.ff1_w1, W.ff1_b1, big, Mi, D, H, H, H, st, 1.0f, act_epi());
-    dense(big, H, W.ff1_w2, W.ff1_b2, x, Mi, H, D, D, D, st, 1.0f, res_epi(false));
+    auto sq_ffn = [&](const f32x4* w1, const float* b1, const f32x4* w2, const float* b2) {
+      if (fused_ffn512() && D == kD512) {
+        PPASR_LAUNCH(k_g_ffn512, dim3((Mi + kRows - 1) / kRows), dim3(kThreads), kLdsFfn512, st, x, x, (const float*)nullptr,
+                     (const float*)nullptr, w1, b1, w2, b2, 1.0f, (int)PPASR_ACT_SWISH, Mi, H / 256);
+        return;
+      }
+      dense(x, D, w1, b1, big, Mi, D, H, H, H, st, 1.0f, act_epi());
+      dense(big, H, w2, b2, x, Mi, H, D, D, D, st, 1.0f, res_epi(false));
+    };
+    sq_ffn(W.ff1_w1, W.ff1_b1, W.ff1_w2, W.ff1_b2);
     ln(x, x, W.ln2_g, W.ln2_b, 1e-5f, kActNone, false, Mi, Ti, mul);
     // ---- x = LN3(x + conv(x)): ada scale / bias, THEN the pad mask (convolution.py:119-127), the unfolded pointwise_conv1 ----
     {
@@ -640,8 +749,7 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
       ln(x, x, W.ln3_g, W.ln3_b, 1e-5f, kActNone, false, Mi, Ti, mul);
     }
     // ---- x = LN4(x + FFN2(x)) ----
-    dense(x, D, W.ff2_w1, W.ff2_b1, big, Mi, D, H, H, H, st, 1.0f, act_epi());
-    dense(big, H, W.ff2_w2, W.ff2_b2, x, Mi, H, D, D, D, st, 1.0f, res_epi(false));
+    sq_ffn(W.ff2_w1, W.ff2_b1, W.ff2_w2, W.ff2_b2);
     ln(x, x, W.ln4_g, W.ln4_b, 1e-5f, kActNone, false, Mi, Ti, mul);
   }
   // ---- ctc_lo -> softmax (no after_norm in Squeezeformer, encoder.py:232-235) ----
@@ -679,6 +787,7 @@ hipError_t configure_generic_kernels() {
                                (int)(bytes))) != hipSuccess)                                                     \
   return e
   SET_LDS((k_dense_epi<1, 256>), (dense_lds<1, 256>()));
+  SET_LDS(k_g_ffn512, kLdsFfn512);
 #undef SET_LDS
   return hipSuccess;
 }
