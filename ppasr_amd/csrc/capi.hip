@@ -90,8 +90,8 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
   if (generic) {
     const int ks = desc->cnn_module_kernel;
     const bool use_cnn = !(desc->options & PPASR_OPT_NO_CNN);
-    if (use_cnn && (ks < 1 || ks > 255 || (!desc->causal && ks % 2 == 0)))
-      return fail(PPASR_EINVAL, "cnn_module_kernel: 1..255, odd for the non-causal conv module (convolution.py:38)");
+    if (use_cnn && (ks < 1 || ks > 63 || (!desc->causal && ks % 2 == 0)))
+      return fail(PPASR_EINVAL, "cnn_module_kernel: 1..63, odd for the non-causal conv module (convolution.py:38)");
     if ((desc->options & PPASR_OPT_POS_MASK) == 3 || ((desc->options >> PPASR_OPT_ACT_SHIFT) & PPASR_OPT_ACT_MASK) > PPASR_ACT_HARDSHRINK)
       return fail(PPASR_EINVAL, "options: unknown pos_enc_layer_type / activation_type code");
   }

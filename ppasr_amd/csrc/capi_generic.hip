@@ -230,6 +230,104 @@ __global__ __launch_bounds__(kThreads) void k_g_ffn512(const float* x, float* ou
   }
 }
 
+// Row-block projection for 512-wide models: rows -> (LayerNorm | per-channel affine | nothing) -> (pad mask) -> LDS [32][516]
+// -> 32-column output tiles, wave w owning n_tiles_per_wave consecutive ones (one weight ring across them).
+//   GLU = false: out[m][col] = rows W + bias            (QKV: 1536 columns = 6 tiles per wave)
+//   GLU = true : out[m][c]   = (rows W_val + b_val)[c] * sigmoid((rows W_gate + b_gate)[c]), W = pointwise_conv1 with the
+//                value channels in tiles [0, 16) and the gate channels in tiles [16, 32) (2 output tiles per wave);
+//                a PAD row is all zeros in LDS, so it yields GLU(bias) like the reference's masked input.
+// Replaces k_g_ln + k_dense_epi (+ k_g_glu): one launch, the A rows read once, 66 KB of LDS = two workgroups per CU.
+// ln_g == nullptr: rows as they are; eps < 0: y = x * g + b (Squeezeformer's ada scale / bias in front of its conv module).
+constexpr size_t kLdsProj512 = (size_t)kRows * kLd512 * sizeof(float);
+template <bool GLU>
+__global__ __launch_bounds__(kThreads) void k_g_proj512(const float* __restrict__ x, float* __restrict__ out, int ldo,
+                                                        const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                        float eps, const int64_t* __restrict__ lens, int Tp, int mul,
+                                                        const f32x4* __restrict__ w, const float* __restrict__ bias,
+                                                        int n_tiles_per_wave, int M) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufA = smem;
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blockIdx.x * kRows, valid = min(kRows, M - r0);
+  constexpr int ts = (kD512 / 8) * 64;  // K = 512: 64 k-groups per 32-column tile
+  BRing<1> ring;
+  const int t0 = GLU ? 2 * wave : wave * n_tiles_per_wave;
+  ring_prime(ring, w + (size_t)t0 * ts, 0);
+  {
+    f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0, be0 = {0.f, 0.f, 0.f, 0.f}, be1 = be0;
+    if (ln_g) {
+      g0 = *reinterpret_cast<const f32x4*>(ln_g + 4 * lane);
+      g1 = *reinterpret_cast<const f32x4*>(ln_g + 256 + 4 * lane);
+      be0 = *reinterpret_cast<const f32x4*>(ln_b + 4 * lane);
+      be1 = *reinterpret_cast<const f32x4*>(ln_b + 256 + 4 * lane);
+    }
+    for (int row = wave; row < kRows; row += kWaves) {
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+      bool live = row < valid;
+      if (live && lens) {
+        const int m = r0 + row, bb = m / Tp, t = m - bb * Tp;
+        live = (int64_t)mul * t < lens[bb];
+      }
+      if (live) {
+        v0 = *reinterpret_cast<const f32x4*>(x + (size_t)(r0 + row) * kD512 + 4 * lane);
+        v1 = *reinterpret_cast<const f32x4*>(x + (size_t)(r0 + row) * kD512 + 256 + 4 * lane);
+        if (ln_g && eps >= 0.f) {
+          const float mean = wave_sum(v0[0] + v0[1] + v0[2] + v0[3] + v1[0] + v1[1] + v1[2] + v1[3]) * (1.0f / kD512);
+          v0 = v0 - mean;
+          v1 = v1 - mean;
+          const float var = wave_sum(v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2] + v0[3] * v0[3] + v1[0] * v1[0] +
+                                     v1[1] * v1[1] + v1[2] * v1[2] + v1[3] * v1[3]) * (1.0f / kD512);
+          const float rstd = 1.0f / sqrtf(var + eps);
+          v0 = v0 * rstd * g0 + be0;
+          v1 = v1 * rstd * g1 + be1;
+        } else if (ln_g) {
+          v0 = v0 * g0 + be0;
+          v1 = v1 * g1 + be1;
+        }
+      }
+      *reinterpret_cast<f32x4*>(bufA + row * kLd512 + 4 * lane) = v0;
+      *reinterpret_cast<f32x4*>(bufA + row * kLd512 + 256 + 4 * lane) = v1;
+    }
+  }
+  __syncthreads();
+  if (GLU) {
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+      const int jt = 2 * wave + t;  // output tile: value channels tile jt, gate channels tile 16 + jt
+      f32x16 av[1][1], ag[1][1];
+      acc_zero(av);
+      acc_zero(ag);
+      const f32x4* sv = w + (size_t)jt * ts;
+      const f32x4* sg = w + (size_t)(16 + jt) * ts;
+      rb_gemm<1, 1, kD512 / 8>(bufA, kLd512, sv, 0, sg, 0, ring, av);
+      rb_gemm<1, 1, kD512 / 8>(bufA, kLd512, sg, 0, t == 0 ? w + (size_t)(jt + 1) * ts : nullptr, 0, ring, ag);
+      const int col = jt * 32 + (lane & 31);
+      const float bv = bias[col], bg = bias[kD512 + col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lane);
+        if (row < valid) out[(size_t)(r0 + row) * ldo + col] = (av[0][0][r] + bv) * sigmoidf(ag[0][0][r] + bg);
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int t = 0; t < n_tiles_per_wave; ++t) {
+      const int nt = t0 + t;
+      f32x16 acc[1][1];
+      acc_zero(acc);
+      rb_gemm<1, 1, kD512 / 8>(bufA, kLd512, w + (size_t)nt * ts, 0, t + 1 < n_tiles_per_wave ? w + (size_t)(nt + 1) * ts : nullptr, 0,
+                               ring, acc);
+      const int col = nt * 32 + (lane & 31);
+      const float bv = bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lane);
+        if (row < valid) out[(size_t)(r0 + row) * ldo + col] = acc[0][0][r] + bv;
+      }
+    }
+  }
+}
+
 // LayerNorm over D columns (nn.LayerNorm, biased variance, eps inside the sqrt), one wave per row, optionally followed
 // by an activation, optionally with rows t of utterance b zeroed where mul * t >= lens[b] (the conv module's input
 // mask, convolution.py:104-106).  eps < 0: per-channel affine only (folded BatchNorm, see capi.hip).  g == nullptr:
@@ -281,25 +379,47 @@ __global__ void k_g_glu(const float* __restrict__ pg, float* __restrict__ g, int
 // batched; streaming (one utterance) the input is [lo cached rows | chunk rows] and row_off = left = lo.  Taps outside
 // the utterance read pad[c] = GLU(pointwise_conv1 bias) in the causal module (the reference zero-pads BEFORE
 // pointwise_conv1, convolution.py:108-126) and 0 in the non-causal one (its depthwise conv pads its own input).
-__global__ void k_g_dwconv(const float* __restrict__ g, float* __restrict__ out, const float* __restrict__ w /*[KS][D]*/,
-                           const float* __restrict__ bias, const float* __restrict__ pad, int M, int Tp, int D, int KS,
-                           int left, int row_off, int stride, int Tp_in) {
+// One workgroup = (tile of TT <= 32 output frames, utterance, 256-channel slab): the input rows it needs and the taps go
+// through LDS once (the one-thread-per-output form re-read every input row KS times through L1 / L2: 47 us per layer of a
+// 32 x 10 s batch at width 512, 6 x the time of its HBM traffic); thread = channel, fmaf chain in tap order as before.
+__global__ __launch_bounds__(256) void k_g_dwconv(const float* __restrict__ g, float* __restrict__ out,
+                                                  const float* __restrict__ w /*[KS][D]*/, const float* __restrict__ bias,
+                                                  const float* __restrict__ pad, int Tp, int D, int KS, int left, int row_off,
+                                                  int stride, int Tp_in, int TT) {
   // stride 2: the Efficient-Conformer's stride layer (efficient_conformer/convolution.py:54-60): output frame t of the Tp =
   // ceil(Tp_in / 2) reads the input frames 2 t - left .. ; stride 1: Tp_in == Tp
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)M * D) return;
-  const int row = (int)(i / D), c = (int)(i - (size_t)row * D);
-  const int bb = row / Tp, t = row - bb * Tp, Tin = Tp_in + row_off;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int c = blockIdx.z * 256 + threadIdx.x, bb = blockIdx.y, t0 = blockIdx.x * TT;
+  const int n_out = min(TT, Tp - t0), Tin = Tp_in + row_off;
+  const int n_in = stride * (n_out - 1) + KS;       // input rows of this tile
+  const int tt0 = stride * t0 + row_off - left;     // first of them
+  float* xs = smem;                                  // [n_in][256]
+  float* ws = smem + (size_t)(stride * (TT - 1) + KS) * 256;  // [KS][256]
   const bool causal = left == KS - 1;
-  float acc = bias[c];
-  for (int j = 0; j < KS; ++j) {
-    const int tt = stride * t + row_off - left + j;
-    float v;
-    if (tt >= 0 && tt < Tin) v = g[((size_t)bb * Tin + tt) * D + c];
-    else v = causal ? pad[c] : 0.f;
-    acc = fmaf(w[(size_t)j * D + c], v, acc);
+  const float pv = causal ? pad[c] : 0.f;
+  for (int i = 0; i < n_in; ++i) {
+    const int tt = tt0 + i;
+    xs[i * 256 + threadIdx.x] = (tt >= 0 && tt < Tin) ? g[((size_t)bb * Tin + tt) * D + c] : pv;
   }
-  out[i] = acc;
+  for (int j = 0; j < KS; ++j) ws[j * 256 + threadIdx.x] = w[(size_t)j * D + c];
+  // (every thread reads back only what it wrote -- its own channel column -- so no barrier is needed)
+  const float bv = bias[c];
+  for (int o = 0; o < n_out; ++o) {
+    float acc = bv;
+    const float* xr = xs + (size_t)(stride * o) * 256 + threadIdx.x;
+    for (int j = 0; j < KS; ++j) acc = fmaf(ws[j * 256 + threadIdx.x], xr[j * 256], acc);
+    out[((size_t)bb * Tp + t0 + o) * D + c] = acc;
+  }
+}
+constexpr int kDwMaxKs = 63;                 // cnn_module_kernel of the general route (ppasr_create checks it)
+constexpr size_t kDwLdsRows = 150;            // LDS budget in 1 KiB rows: input rows + taps
+// B * Tp output rows; tile = up to 32 output frames, fewer when the kernel is long (stride * (TT - 1) + 2 KS rows of LDS)
+inline void launch_dwconv(const float* g, float* out, const float* w, const float* bias, const float* pad, int B, int Tp, int D,
+                          int KS, int left, int row_off, int stride, int Tp_in, hipStream_t st) {
+  const int TT = std::max(1, std::min(32, (int)(kDwLdsRows - 2 * KS) / stride + 1));
+  const size_t lds = (size_t)(stride * (TT - 1) + 2 * KS) * 256 * sizeof(float);
+  PPASR_LAUNCH(k_g_dwconv, dim3((Tp + TT - 1) / TT, B, D / 256), dim3(256), lds, st, g, out, w, bias, pad, Tp, D, KS, left,
+               row_off, stride, Tp_in, TT);
 }
 
 // abs_pos (PositionalEncoding.forward, embedding.py:70: x * xscale + pe[offset : offset + T]; the scale is the embed
@@ -466,11 +586,17 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
     // ---- (Rel)MultiHeadedAttention (attention.py:123-262) ----
     {
       const float* in = x;
-      if (!o.post_norm) {
-        ln(x, a, L.ln_mha_g, L.ln_mha_b, 1e-5f, kActNone, false, M);
-        in = a;
+      if (fused_ffn && D == kD512 && !o.concat_after) {  // LayerNorm + QKV in one launch
+        PPASR_LAUNCH(k_g_proj512<false>, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsProj512, st, x, big, 3 * D,
+                     o.post_norm ? nullptr : L.ln_mha_g, o.post_norm ? nullptr : L.ln_mha_b, 1e-5f, (const int64_t*)nullptr, Tp, mul,
+                     L.wqkv, L.bqkv, 3 * D / 32 / kWaves, M);
+      } else {
+        if (!o.post_norm) {
+          ln(x, a, L.ln_mha_g, L.ln_mha_b, 1e-5f, kActNone, false, M);
+          in = a;
+        }
+        dense(in, D, L.wqkv, L.bqkv, big, M, D, 3 * D, 3 * D, 3 * D, st);
       }
-      dense(in, D, L.wqkv, L.bqkv, big, M, D, 3 * D, 3 * D, 3 * D, st);
       // tokens: frames, or zero-padded groups of 3 (GroupedRelPositionMultiHeadedAttention, pad4group)
       const int grp = h->layer_group[i], Tt = (Tp + grp - 1) / grp;
       AttnArgs at{big, 3 * D, big + D, 3 * D, big + 2 * D, 3 * D, Tt, Tt, rel ? r.pos0 : 0, lens, ctx, L.pos_u, L.pos_v,
@@ -505,22 +631,28 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
       const int left = h->desc.causal ? KS - 1 : (KS - 1) / 2;
       const bool stride2 = eff && i == h->desc.stride_layer_idx;
       float* a_new = a + (size_t)lo_s * D;
-      if (!o.post_norm) ln(x, a_new, L.ln_conv_g, L.ln_conv_b, 1e-5f, kActNone, true, M);  // LN_conv, PAD frames -> 0
-      else ln(x, a_new, nullptr, nullptr, 0.f, kActNone, true, M);                           // PAD frames -> 0 only
       const int rows = lo_s + M;
-      if (lo_s) {
-        float* hist = r.s->xh_hist + (size_t)i * r.s->lo * D;
-        HIP_TRY(hipMemcpyAsync(a, hist, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
-        // new cache = the last lo rows of [cache | chunk] (convolution.py:110-116)
-        HIP_TRY(hipMemcpyAsync(hist, a + (size_t)M * D, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+      if (fused_ffn && D == kD512 && lo_s == 0) {  // (LayerNorm) + pad mask + pointwise_conv1 + GLU in one launch
+        PPASR_LAUNCH(k_g_proj512<true>, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsProj512, st, x, g, D,
+                     o.post_norm ? nullptr : L.ln_conv_g, o.post_norm ? nullptr : L.ln_conv_b, 1e-5f, lens, Tp, mul, L.pw1,
+                     L.pw1_b, 2, M);
+      } else {
+        if (!o.post_norm) ln(x, a_new, L.ln_conv_g, L.ln_conv_b, 1e-5f, kActNone, true, M);  // LN_conv, PAD frames -> 0
+        else ln(x, a_new, nullptr, nullptr, 0.f, kActNone, true, M);                           // PAD frames -> 0 only
+        if (lo_s) {
+          float* hist = r.s->xh_hist + (size_t)i * r.s->lo * D;
+          HIP_TRY(hipMemcpyAsync(a, hist, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+          // new cache = the last lo rows of [cache | chunk] (convolution.py:110-116)
+          HIP_TRY(hipMemcpyAsync(hist, a + (size_t)M * D, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        dense(a, D, L.pw1, L.pw1_b, big, rows, D, 2 * D, 2 * D, 2 * D, st);
+        PPASR_LAUNCH(k_g_glu, blocks((size_t)rows * D), dim3(256), 0, st, big, g, rows, D);
       }
-      dense(a, D, L.pw1, L.pw1_b, big, rows, D, 2 * D, 2 * D, 2 * D, st);
-      PPASR_LAUNCH(k_g_glu, blocks((size_t)rows * D), dim3(256), 0, st, big, g, rows, D);
       if (stride2) {
         // StrideConformerEncoderLayer (efficient_conformer/encoder.py:455-548): depthwise conv with stride 2, the residual
         // through AvgPool1D(2, ceil_mode); everything behind runs on ceil(T / 2) frames with masks / positions [::2]
         const int Ts = (Tp + 1) / 2, Ms = B * Ts;
-        PPASR_LAUNCH(k_g_dwconv, blocks((size_t)Ms * D), dim3(256), 0, st, g, y, L.dw_w, L.dw_b, L.glu_pad, Ms, Ts, D, KS, left, lo_s, 2, Tp);
+        launch_dwconv(g, y, L.dw_w, L.dw_b, L.glu_pad, B, Ts, D, KS, left, lo_s, 2, Tp, st);
         half = true;
         PPASR_LAUNCH(k_g_avgpool2, blocks((size_t)Ms * D), dim3(256), 0, st, x, ctx, B, Tp, Ts, D);
         Tp = Ts;
@@ -529,7 +661,7 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
         pstride *= 2;
         std::swap(x, ctx);  // (res_epi below reads the new x = the pooled residual)
       } else {
-        PPASR_LAUNCH(k_g_dwconv, blocks((size_t)M * D), dim3(256), 0, st, g, y, L.dw_w, L.dw_b, L.glu_pad, M, Tp, D, KS, left, lo_s, 1, Tp);
+        launch_dwconv(g, y, L.dw_w, L.dw_b, L.glu_pad, B, Tp, D, KS, left, lo_s, 1, Tp, st);
       }
       ln(y, y, L.ln_cm_g, L.ln_cm_b, L.cm_eps, o.act, false, M);  // LayerNorm / folded BatchNorm + activation
       dense(y, D, L.pw2, L.pw2_b, x, M, D, D, D, D, st, 1.0f, res_epi(1.0f, true));  // PAD frames of the conv output -> 0, + residual
@@ -698,7 +830,12 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
       return e;
     };
     // ---- x = LN1(x + MHA(x)) ----
-    dense(x, D, W.wqkv, W.bqkv, big, Mi, D, 3 * D, 3 * D, 3 * D, st);
+    if (fused_ffn512() && D == kD512)
+      PPASR_LAUNCH(k_g_proj512<false>, dim3((Mi + kRows - 1) / kRows), dim3(kThreads), kLdsProj512, st, x, big, 3 * D,
+                   (const float*)nullptr, (const float*)nullptr, 1e-5f, (const int64_t*)nullptr, Ti, mul, W.wqkv, W.bqkv,
+                   3 * D / 32 / kWaves, Mi);
+    else
+      dense(x, D, W.wqkv, W.bqkv, big, Mi, D, 3 * D, 3 * D, 3 * D, st);
     AttnArgs at{big, 3 * D, big + D, 3 * D, big + 2 * D, 3 * D, Ti, Ti, 0, lens, ctx, W.pos_u, W.pos_v, W.ptab, reduced ? 2 : 1,
                 mul, Ti, Ti, 1};
     if (s) {  // keys / values: [cache | chunk] in the layer's device caches
@@ -733,17 +870,21 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
     // ---- x = LN3(x + conv(x)): ada scale / bias, THEN the pad mask (convolution.py:119-127), the unfolded pointwise_conv1 ----
     {
       float* a_new = a + (size_t)lo_s * D;
-      ln(x, a_new, W.cm_scale, W.cm_bias, -1.0f, kActNone, true, Mi, Ti, mul);
       const int rows = lo_s + Mi;
-      if (lo_s) {  // the cache holds the SCALED inputs of the previous chunks; new cache = last lo rows of [cache | chunk]
-        float* hist = s->xh_hist + (size_t)i * s->lo * D;
-        HIP_TRY(hipMemcpyAsync(a, hist, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(hist, a + (size_t)Mi * D, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+      if (fused_ffn512() && D == kD512 && lo_s == 0) {  // ada scale / bias + pad mask + pointwise_conv1 + GLU in one launch
+        PPASR_LAUNCH(k_g_proj512<true>, dim3((Mi + kRows - 1) / kRows), dim3(kThreads), kLdsProj512, st, x, g, D, W.cm_scale,
+                     W.cm_bias, -1.0f, lens, Ti, mul, W.pw1_raw, W.pw1_b_raw, 2, Mi);
+      } else {
+        ln(x, a_new, W.cm_scale, W.cm_bias, -1.0f, kActNone, true, Mi, Ti, mul);
+        if (lo_s) {  // the cache holds the SCALED inputs of the previous chunks; new cache = last lo rows of [cache | chunk]
+          float* hist = s->xh_hist + (size_t)i * s->lo * D;
+          HIP_TRY(hipMemcpyAsync(a, hist, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+          HIP_TRY(hipMemcpyAsync(hist, a + (size_t)Mi * D, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        dense(a, D, W.pw1_raw, W.pw1_b_raw, big, rows, D, 2 * D, 2 * D, 2 * D, st);
+        PPASR_LAUNCH(k_g_glu, blocks((size_t)rows * D), dim3(256), 0, st, big, g, rows, D);
       }
-      dense(a, D, W.pw1_raw, W.pw1_b_raw, big, rows, D, 2 * D, 2 * D, 2 * D, st);
-      PPASR_LAUNCH(k_g_glu, blocks((size_t)rows * D), dim3(256), 0, st, big, g, rows, D);
-      PPASR_LAUNCH(k_g_dwconv, blocks((size_t)Mi * D), dim3(256), 0, st, g, y, W.dw_w, W.dw_b, W.glu_pad, Mi, Ti, D, KS, left, lo_s,
-                   1, Ti);
+      launch_dwconv(g, y, W.dw_w, W.dw_b, W.glu_pad, B, Ti, D, KS, left, lo_s, 1, Ti, st);
       ln(y, y, W.ln_cm_g, W.ln_cm_b, W.cm_eps, (int)PPASR_ACT_SWISH, false, Mi, Ti, mul);
       dense(y, D, W.pw2, W.pw2_b, x, Mi, D, D, D, D, st, 1.0f, res_epi(true));
       ln(x, x, W.ln3_g, W.ln3_b, 1e-5f, kActNone, false, Mi, Ti, mul);
@@ -788,6 +929,9 @@ hipError_t configure_generic_kernels() {
   return e
   SET_LDS((k_dense_epi<1, 256>), (dense_lds<1, 256>()));
   SET_LDS(k_g_ffn512, kLdsFfn512);
+  SET_LDS(k_g_dwconv, (kDwLdsRows + 2) * 256 * sizeof(float));
+  SET_LDS(k_g_proj512<false>, kLdsProj512);
+  SET_LDS(k_g_proj512<true>, kLdsProj512);
 #undef SET_LDS
   return hipSuccess;
 }
