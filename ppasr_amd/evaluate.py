@@ -10,6 +10,7 @@ import torch
 
 from ppasr_amd.decoders.beam_search_decoder import beam_search_ids
 from ppasr_amd.decoders.ctc_greedy_decoder import greedy_decode_ids, greedy_decoder_batch
+from ppasr_amd.parallel import set_skip_padding_if_built
 from ppasr_amd.utils.metrics import cer, labels_to_string, wer
 
 __all__ = ["decoder_result", "evaluate"]
@@ -61,13 +62,13 @@ def evaluate(model, batches, vocab_list, decoder="ctc_greedy", metrics_type="cer
     def encode(inputs, input_lens):
         frame_lens = None
         if trim_padding:
-            model.set_skip_padding(True)
+            set_skip_padding_if_built(model, True)
             frame_lens = model.valid_out_frames(input_lens, inputs.shape[1])
         try:
             outs = model.get_encoder_out(inputs, input_lens)
         finally:
             if trim_padding:
-                model.set_skip_padding(False)
+                set_skip_padding_if_built(model, False)
         return outs, frame_lens
 
     def score(outs, frame_lens, labels):

@@ -126,6 +126,22 @@ def ragged_record_shape(lengths, world, out_frames, width=200):
     return rows, cols
 
 
+def set_skip_padding_if_built(model, enable):
+    """``model.set_skip_padding(enable)`` where the model's route has the ragged mode; the routes that compute every row
+    (general layer route, the 6x / 8x front ends, DeepSpeech2 -- the library answers PPASR_EUNSUPPORTED) keep doing so:
+    the decoders trim by ``frame_lens`` either way, only the padded rows' compute is not saved.  -> whether it is on."""
+    fn = getattr(model, "set_skip_padding", None)
+    if fn is None:
+        return False
+    try:
+        fn(enable)
+        return bool(enable)
+    except RuntimeError as e:  # PPASRHipError
+        if "skip_padding" in str(e):
+            return False
+        raise
+
+
 def _collective_device(dist, device, group=None):
     """Device the collective's tensors must live on: the caller's choice, else the current HIP device under the
     nccl (= RCCL) backend (a rank that was dealt no bucket has no result tensor to take it from), else the host."""
@@ -323,7 +339,7 @@ class RaggedPlan:
         model = self.model
         outs = []
         if self.ragged and self.batches:
-            model.set_skip_padding(True)
+            set_skip_padding_if_built(model, True)
         try:
             for (_idx, x, lens, frame_lens) in self.batches:
                 if self.pipeline:
@@ -340,7 +356,7 @@ class RaggedPlan:
                     outs.append(decoder(probs, frame_lens))
         finally:
             if self.ragged and self.batches:
-                model.set_skip_padding(False)
+                set_skip_padding_if_built(model, False)
         return outs
 
     def run(self, decoder):

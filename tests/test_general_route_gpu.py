@@ -174,3 +174,26 @@ def test_width_512_families_chunked(family, seed):
         assert e < TOL, conf
         assert tuple(att.shape) == tuple(r_att.shape), (att.shape, r_att.shape)
         assert _rel(att.cpu().numpy(), r_att.numpy()) < TOL and _rel(cnn.cpu().numpy(), r_cnn.numpy()) < TOL
+
+
+def test_ragged_decode_on_a_route_without_the_ragged_mode():
+    """decode_ragged / evaluate(trim_padding) on a general-route model: the library refuses skip_padding there
+    (PPASR_EUNSUPPORTED), the drivers then run the padded rows and trim by frame_lens -- same tokens as the plain padded
+    batch decoded over its valid frames."""
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    from ppasr_amd.parallel import decode_ragged, greedy_ids_decoder, set_skip_padding_if_built
+    V, L = 53, 2
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=31, perturb_norm=True, output_size=512, attention_heads=8)
+    conf = dict(output_size=512, attention_heads=8, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
+    model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    assert set_skip_padding_if_built(model, True) is False
+    lens = np.array([260, 90, 411, 33, 187], np.int64)
+    x, _ = synth_features(len(lens), int(lens.max()), lens=lens, seed=32)
+    tokens, n, _ = decode_ragged(model, x, lens, greedy_ids_decoder(), mode="merged")
+    torch.cuda.synchronize()
+    # the same batch composition without the driver (an utterance's last frames depend on what it is padded with, so the
+    # single-utterance call is not the reference here): padded batch -> valid frames -> greedy
+    probs = model.get_encoder_out(x, lens)
+    t1, n1, _ = greedy_ids_decoder()(probs, model.valid_out_frames(lens, x.shape[1]))
+    for i in range(len(lens)):
+        assert int(n[i]) > 0 and tokens[i, :int(n[i])].cpu().tolist() == t1[i, :int(n1[i])].cpu().tolist(), i
