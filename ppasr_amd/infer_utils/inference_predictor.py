@@ -57,7 +57,15 @@ class InferencePredictor:
             from ppasr_amd.model_utils.deepspeech2.model import DeepSpeech2Model as cls
         self.model = cls(input_dim, vocab_size, streaming=streaming, encoder_conf=enc, state_dict=state_dict,
                          device=device)
-        self._stream = self.model.new_stream() if (streaming and "former" in use_model) else None
+        # (a configuration whose forward_chunk the library does not build -- input_layer: linear, an Efficient-Conformer
+        #  behind conv2d6 / conv2d8 -- still serves predict(); predict_chunk_conformer then raises NotImplementedError)
+        self._stream = None
+        if streaming and "former" in use_model:
+            try:
+                self._stream = self.model.new_stream()
+            except RuntimeError as e:  # PPASRHipError: PPASR_EUNSUPPORTED
+                if "stream" not in str(e):
+                    raise
         self.output_state_h = None
         self.output_state_c = None
 
