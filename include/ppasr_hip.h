@@ -22,6 +22,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: these entry points are its whole dynamic symbol table
+ * (tests/test_capi_cpu.py compares `nm -D --defined-only` with this header). */
+#define PPASR_API __attribute__((visibility("default")))
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -102,19 +106,19 @@ enum { PPASR_ACT_SWISH = 0, PPASR_ACT_RELU = 1, PPASR_ACT_GELU = 2, PPASR_ACT_TA
        PPASR_ACT_RELU6 = 5, PPASR_ACT_LEAKYRELU = 6, PPASR_ACT_SELU = 7, PPASR_ACT_ELU = 8, PPASR_ACT_HARDSWISH = 9,
        PPASR_ACT_HARDSHRINK = 10 };
 
-const char* ppasr_last_error(void);
-const char* ppasr_version(void);
+PPASR_API const char* ppasr_last_error(void);
+PPASR_API const char* ppasr_version(void);
 
 /* Replaces: model construction + paddle.inference.create_predictor
  * (infer_utils/inference_predictor.py:41-77) / PPASRTrainer.__setup_model
  * (trainer.py:172-210).  Uploads and re-packs the weights into MFMA fragment order. */
-ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob* weights_host, int n_weights,
+PPASR_API ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob* weights_host, int n_weights,
                           ppasr_handle* out);
-ppasr_status ppasr_destroy(ppasr_handle h);
+PPASR_API ppasr_status ppasr_destroy(ppasr_handle h);
 
 /* frames after the conv front-end: ((T-1)/2-1)/2  (conformer/subsampling.py:84-94,115) */
-int ppasr_out_frames(ppasr_handle h, int T);
-size_t ppasr_workspace_bytes(ppasr_handle h, int B, int T);
+PPASR_API int ppasr_out_frames(ppasr_handle h, int T);
+PPASR_API size_t ppasr_workspace_bytes(ppasr_handle h, int B, int T);
 
 /* Replaces ConformerModel.get_encoder_out (model_utils/conformer/model.py:148-162), as called by
  * PPASRTrainer.evaluate (trainer.py:626) and InferencePredictor.predict (inference_predictor.py:103-145).
@@ -124,13 +128,13 @@ size_t ppasr_workspace_bytes(ppasr_handle h, int B, int T);
  *   frame_argmax [B,T'] i32, frame_maxprob [B,T'] f32: per-frame argmax / probability at the
  *     argmax, produced inside the CTC-head kernel (fused ctc_greedy first stage,
  *     decoders/ctc_greedy_decoder.py:21-22); pass NULL for outputs not wanted. */
-ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* lens, int B, int T,
+PPASR_API ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* lens, int B, int T,
                           float* probs, float* logits, int32_t* frame_argmax, float* frame_maxprob,
                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* Debug taps: when set (host call, before ppasr_encode), intermediate activations are copied
  * to `taps` in the order documented in DESIGN.md; pass NULL to clear. */
-ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats);
+PPASR_API ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats);
 
 /* Ragged batches.  The reference computes every padded row of a batch (its batched decoders even consume them,
  * trainer.py:347).  With enable != 0, ppasr_encode computes, per utterance, only the rows its VALID output frames
@@ -141,7 +145,7 @@ ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t n_floats);
  * to the decoders.  Default: off (= the reference's outputs for every row).  Built into the fused 256-column kernels
  * behind the conv2d (4x) front end: enabling it on a conv2d6 / conv2d8, general-route (see options) or DeepSpeech2 handle returns
  * PPASR_EUNSUPPORTED (those routes compute every row). */
-ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable);
+PPASR_API ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable);
 
 /* Under-filled launches.  A kernel with fewer 32-row blocks than the chip has CUs takes as long as a full one.  When a
  * call has <= 128 row blocks (small batches, the half-rate layers of the Efficient-Conformer, a single streaming
@@ -149,11 +153,11 @@ ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable);
  * split over 2 / 4 / 8 workgroups per row block (partial sums joined by the next launch).  Same arithmetic up to the
  * order of the final sum over hidden chunks.  mode: -1 = decide by grid size (default), 0 = never (always the fused
  * kernels, the fused attention kernel included), 2 / 4 / 8 = always that many slices. */
-ppasr_status ppasr_set_ffn_split(ppasr_handle h, int mode);
+PPASR_API ppasr_status ppasr_set_ffn_split(ppasr_handle h, int mode);
 
 /* Host helper (no device work): Levenshtein distance between two int32 sequences -- what ppasr/utils/metrics.py:4-29
  * (cer / wer) gets from the `Levenshtein` C extension.  Returns -1 on a null argument with a positive length. */
-long long ppasr_edit_distance(const int32_t* a, int na, const int32_t* b, int nb);
+PPASR_API long long ppasr_edit_distance(const int32_t* a, int na, const int32_t* b, int nb);
 
 /* Replaces the third-party `paddlespeech_ctcdecoders` entry points PPASR calls:
  *   ctc_beam_search_decoding / ctc_beam_search_decoding_batch  (decoders/swig_wrapper.py:61-62,98-100,
@@ -168,21 +172,21 @@ long long ppasr_edit_distance(const int32_t* a, int na, const int32_t* b, int nb
  *   state: device scratch of ppasr_ctc_beam_state_bytes(B, max total frames, beam_size) bytes that
  *   holds the beam, the prefix arena (both kept between chunk calls) and the per-frame records of the
  *   pruning pre-pass (get_pruned_log_probs of every frame of the call: T <= max total frames). */
-size_t ppasr_ctc_beam_state_bytes(int B, int max_frames, int beam_size);
+PPASR_API size_t ppasr_ctc_beam_state_bytes(int B, int max_frames, int beam_size);
 /* Pruned characters per frame the kernel can hold (128).  DEVIATION from upstream: a configuration that lets more
  * survive (cutoff_prob >= 1, where upstream ignores cutoff_top_n; or cutoff_top_n > 128) keeps the 128 most probable
  * characters of each frame. */
-int ppasr_ctc_beam_candidate_cap(void);
+PPASR_API int ppasr_ctc_beam_candidate_cap(void);
 /* Streaming past the sized capacity: copies the beams and prefix arenas of a state buffer into a LARGER one (sized with
  * ppasr_ctc_beam_state_bytes for more frames), which then continues the same search.  The reference's decoder object has
  * no frame limit; callers double the buffer when the next chunk would not fit.  Asynchronous on `stream`. */
-ppasr_status ppasr_ctc_beam_state_grow(const void* old_state, size_t old_bytes, void* new_state, size_t new_bytes, int B,
+PPASR_API ppasr_status ppasr_ctc_beam_state_grow(const void* old_state, size_t old_bytes, void* new_state, size_t new_bytes, int B,
                                        int beam_size, void* stream);
 /* Reads back the per-utterance status words of a (streaming) state buffer: non-zero = the prefix arena ran out because
  * more cumulative frames were decoded than the buffer was sized for; returns PPASR_ENOSPACE then.  Synchronises. */
-ppasr_status ppasr_ctc_beam_status(const void* state, size_t state_bytes, int B, int beam_size, int32_t* status_host,
+PPASR_API ppasr_status ppasr_ctc_beam_status(const void* state, size_t state_bytes, int B, int beam_size, int32_t* status_host,
                                    void* stream);
-ppasr_status ppasr_ctc_beam_search(const float* probs, const int32_t* frame_lens, int B, int T, int V, int beam_size,
+PPASR_API ppasr_status ppasr_ctc_beam_search(const float* probs, const int32_t* frame_lens, int B, int T, int V, int beam_size,
                                    double cutoff_prob, int cutoff_top_n, int blank, int nbest, int max_tokens,
                                    int32_t* tokens, int32_t* lens, double* scores, void* state, size_t state_bytes,
                                    int init_state, void* stream);
@@ -198,29 +202,29 @@ ppasr_status ppasr_ctc_beam_search(const float* probs, const int32_t* frame_lens
  * from the file's magic, like KenLM's loader.
  * vocab_utf8[V]: the acoustic vocabulary (token id -> string), used to map token ids to LM words (unknown -> OOV). */
 typedef struct ppasr_lm_s* ppasr_lm_handle;
-ppasr_status ppasr_lm_create(const char* model_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
-ppasr_status ppasr_lm_create_arpa(const char* arpa_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
-ppasr_status ppasr_lm_create_klm(const char* klm_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
-const char*  ppasr_lm_format(ppasr_lm_handle lm);              /* "arpa", "klm-probing", "klm-rest-probing", "klm-trie",
+PPASR_API ppasr_status ppasr_lm_create(const char* model_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
+PPASR_API ppasr_status ppasr_lm_create_arpa(const char* arpa_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
+PPASR_API ppasr_status ppasr_lm_create_klm(const char* klm_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
+PPASR_API const char*  ppasr_lm_format(ppasr_lm_handle lm);              /* "arpa", "klm-probing", "klm-rest-probing", "klm-trie",
                                                                   "klm-quant-trie", "klm-array-trie", "klm-quant-array-trie" */
-int          ppasr_lm_word_index(ppasr_lm_handle lm, int token); /* LM word index of an acoustic token, 0 = OOV */
-int          ppasr_lm_bos(ppasr_lm_handle lm);
-int          ppasr_lm_eos(ppasr_lm_handle lm);
+PPASR_API int          ppasr_lm_word_index(ppasr_lm_handle lm, int token); /* LM word index of an acoustic token, 0 = OOV */
+PPASR_API int          ppasr_lm_bos(ppasr_lm_handle lm);
+PPASR_API int          ppasr_lm_eos(ppasr_lm_handle lm);
 /* Verification hooks of the model-file readers (no device is touched; the decoder never calls them):
  * ppasr_lm_debug_load_host parses a model into the host-side table only, ppasr_lm_debug_host_score evaluates
  * Scorer::get_log_cond_prob for a window of `order` LM word indices (oldest first) on that table. */
-ppasr_status ppasr_lm_debug_load_host(const char* model_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
-double       ppasr_lm_debug_host_score(ppasr_lm_handle lm, const int32_t* window);
-ppasr_status ppasr_lm_destroy(ppasr_lm_handle lm);
-int          ppasr_lm_order(ppasr_lm_handle lm);
-int          ppasr_lm_is_character_based(ppasr_lm_handle lm);
-long long    ppasr_lm_dict_size(ppasr_lm_handle lm);   /* Scorer::get_dict_size(): words in the dictionary (word-based models) */
-int          ppasr_lm_space_id(ppasr_lm_handle lm);    /* acoustic token id of the space (" " or "<space>"), -1 if none */
-long long    ppasr_lm_ngram_count(ppasr_lm_handle lm);
+PPASR_API ppasr_status ppasr_lm_debug_load_host(const char* model_path, const char* const* vocab_utf8, int V, ppasr_lm_handle* out);
+PPASR_API double       ppasr_lm_debug_host_score(ppasr_lm_handle lm, const int32_t* window);
+PPASR_API ppasr_status ppasr_lm_destroy(ppasr_lm_handle lm);
+PPASR_API int          ppasr_lm_order(ppasr_lm_handle lm);
+PPASR_API int          ppasr_lm_is_character_based(ppasr_lm_handle lm);
+PPASR_API long long    ppasr_lm_dict_size(ppasr_lm_handle lm);   /* Scorer::get_dict_size(): words in the dictionary (word-based models) */
+PPASR_API int          ppasr_lm_space_id(ppasr_lm_handle lm);    /* acoustic token id of the space (" " or "<space>"), -1 if none */
+PPASR_API long long    ppasr_lm_ngram_count(ppasr_lm_handle lm);
 /* ppasr_ctc_beam_search with the scorer: alpha * ln P_lm(c | prefix) + beta on every extension, the min_cutoff pruning
  * of ctc_beam_search_decoder.cpp, and result scores = -(score - len*beta - alpha*ln P_lm(sentence)) ("approx_ctc").
  * lm == NULL: identical to ppasr_ctc_beam_search. */
-ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_lens, int B, int T, int V, int beam_size,
+PPASR_API ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_lens, int B, int T, int V, int beam_size,
                                       double cutoff_prob, int cutoff_top_n, int blank, int nbest, int max_tokens,
                                       int32_t* tokens, int32_t* lens, double* scores, void* state, size_t state_bytes,
                                       int init_state, ppasr_lm_handle lm, double alpha, double beta, void* stream);
@@ -233,22 +237,22 @@ ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_l
  * is tracked by the object.  B = 1 per stream (encoder.py:238); run several streams for several sessions.
  * Any causal Conformer-family handle behind a conv front end, general-route handles (output_size 512 .. 1024,
  * ppasr_model_desc.options) included; use_cnn_module = 0 handles carry no conv cache (export: cnn_cache untouched). */
-ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out);
-ppasr_status ppasr_stream_destroy(ppasr_stream s);
-ppasr_status ppasr_stream_reset(ppasr_stream s, void* stream);
-int ppasr_stream_offset(ppasr_stream s);        /* encoder frames emitted so far */
-int ppasr_stream_cache_frames(ppasr_stream s);  /* cache_t1: key/value frames currently cached */
-size_t ppasr_chunk_workspace_bytes(ppasr_handle h, int T);
+PPASR_API ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out);
+PPASR_API ppasr_status ppasr_stream_destroy(ppasr_stream s);
+PPASR_API ppasr_status ppasr_stream_reset(ppasr_stream s, void* stream);
+PPASR_API int ppasr_stream_offset(ppasr_stream s);        /* encoder frames emitted so far */
+PPASR_API int ppasr_stream_cache_frames(ppasr_stream s);  /* cache_t1: key/value frames currently cached */
+PPASR_API size_t ppasr_chunk_workspace_bytes(ppasr_handle h, int T);
 /*   feats [1,T,F] f32; required_cache_size as in encoder.py:255-260 (<0 keep everything, the value
  *   predict_stream uses; 0 none; >0 last n frames); probs [1,c,V] or NULL; c = ((T-1)/2-1)/2 is also
  *   written to *c_out_host (host int, may be NULL). */
-ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int required_cache_size, float* probs,
+PPASR_API ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int required_cache_size, float* probs,
                                 int32_t* frame_argmax, float* frame_maxprob, int* c_out_host, void* workspace,
                                 size_t workspace_bytes, void* stream);
 /* Reference tensor layouts of the caches: att_cache [L][h][t][2*dk] (h = attention_heads, dk = 64), cnn_cache [L][1][d][k-1]
  * (d = output_size). */
-ppasr_status ppasr_stream_export_cache(ppasr_stream s, float* att_cache, float* cnn_cache, void* stream);
-ppasr_status ppasr_stream_import_cache(ppasr_stream s, const float* att_cache, int cache_t, const float* cnn_cache,
+PPASR_API ppasr_status ppasr_stream_export_cache(ppasr_stream s, float* att_cache, float* cnn_cache, void* stream);
+PPASR_API ppasr_status ppasr_stream_import_cache(ppasr_stream s, const float* att_cache, int cache_t, const float* cnn_cache,
                                        int offset, void* stream);
 
 /* ---- DeepSpeech2: DeepSpeech2Model.get_encoder_out / get_encoder_out_chunk (model_utils/deepspeech2/model.py:62-72),
@@ -258,8 +262,8 @@ ppasr_status ppasr_stream_import_cache(ppasr_stream s, const float* att_cache, i
  * the bidirectional one (deepspeech2/model.py:40).
  *   feats [B,T,F], lens [B] i64 -> probs [B,T',V] f32, out_lens [B] i64 (= ((len-1)/2-1)/2, may be NULL);
  *   init_h / init_c / final_h / final_c: [num_rnn_layers*dirs, B, rnn_size] state boxes (NULL = zeros / not wanted). */
-size_t ppasr_ds2_workspace_bytes(ppasr_handle h, int B, int T);
-ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, const int64_t* lens, int B, int T, const float* init_h,
+PPASR_API size_t ppasr_ds2_workspace_bytes(ppasr_handle h, int B, int T);
+PPASR_API ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, const int64_t* lens, int B, int T, const float* init_h,
                               const float* init_c, float* probs, int64_t* out_lens, float* final_h, float* final_c,
                               void* workspace, size_t workspace_bytes, void* stream);
 
@@ -269,9 +273,9 @@ ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, const int64_t*
  * into HOST arrays of PPASR_N_KERNEL_CLASSES entries.  Conformer / Efficient-Conformer handles of width 256 only
  * (PPASR_EUNSUPPORTED otherwise); ppasr_kprof_* below covers every route by kernel name. */
 #define PPASR_N_KERNEL_CLASSES 10
-ppasr_status ppasr_profile_enable(ppasr_handle h, int enable);
-ppasr_status ppasr_profile_read(ppasr_handle h, float* total_ms_host, int* launches_host);
-const char* ppasr_kernel_class_name(int cls);
+PPASR_API ppasr_status ppasr_profile_enable(ppasr_handle h, int enable);
+PPASR_API ppasr_status ppasr_profile_read(ppasr_handle h, float* total_ms_host, int* launches_host);
+PPASR_API const char* ppasr_kernel_class_name(int cls);
 
 /* Kernel-name profiler (bench.py roofline leg for every model family and the decoders; no reference counterpart).
  * Between begin and end, every kernel the CALLING THREAD launches through this library carries a dispatch-attached HIP
@@ -279,21 +283,21 @@ const char* ppasr_kernel_class_name(int cls);
  * prints, without the parameter list): names_host [max_entries][PPASR_KPROF_NAME_LEN] chars, total_ms_host /
  * launches_host [max_entries], *n_out_host = entries written.  Not to be combined with ppasr_profile_enable. */
 #define PPASR_KPROF_NAME_LEN 160
-ppasr_status ppasr_kprof_begin(void);
-ppasr_status ppasr_kprof_end(int max_entries, char* names_host, float* total_ms_host, int* launches_host, int* n_out_host);
+PPASR_API ppasr_status ppasr_kprof_begin(void);
+PPASR_API ppasr_status ppasr_kprof_end(int max_entries, char* names_host, float* total_ms_host, int* launches_host, int* n_out_host);
 
 /* Replaces greedy_decoder / greedy_decoder_batch (decoders/ctc_greedy_decoder.py:6-49), as called
  * from PPASRPredictor.decode (predict.py:128) and PPASRTrainer.__decoder_result (trainer.py:351).
  *   probs [B,Tp,V] f32 (any row-normalised or not: argmax + value at argmax)
  *   frame_lens [B] i32 or NULL (NULL = decode all Tp rows, the reference's batch behaviour)
  *   tokens [B,Tp] i32 (-1 padded), n_tokens [B] i32, score [B] f64 (mean non-blank max prob * 100) */
-ppasr_status ppasr_ctc_greedy(const float* probs, const int32_t* frame_lens, int B, int Tp, int V, int blank,
+PPASR_API ppasr_status ppasr_ctc_greedy(const float* probs, const int32_t* frame_lens, int B, int Tp, int V, int blank,
                               int32_t* tokens, int32_t* n_tokens, double* score,
                               void* workspace /* >= 8*B*Tp bytes */, size_t workspace_bytes, void* stream);
 
 /* Second stage only: collapse repeats / drop blank / score, from per-frame argmax+maxprob
  * (the outputs of ppasr_encode).  Same outputs as ppasr_ctc_greedy. */
-ppasr_status ppasr_ctc_collapse(const int32_t* frame_argmax, const float* frame_maxprob, const int32_t* frame_lens,
+PPASR_API ppasr_status ppasr_ctc_collapse(const int32_t* frame_argmax, const float* frame_maxprob, const int32_t* frame_lens,
                                 int B, int Tp, int blank, int32_t* tokens, int32_t* n_tokens, double* score,
                                 void* stream);
 
@@ -305,12 +309,12 @@ ppasr_status ppasr_ctc_collapse(const int32_t* frame_argmax, const float* frame_
  *   sessions_host [n] distinct slot indices; feats [n][T][F]; outputs by list position: probs [n][c][V] or NULL,
  *   frame_argmax / frame_maxprob [n][c] or NULL. */
 typedef struct ppasr_stream_group_s* ppasr_stream_group;
-ppasr_status ppasr_stream_group_create(ppasr_handle h, int n_sessions, int max_frames, ppasr_stream_group* out);
-ppasr_status ppasr_stream_group_destroy(ppasr_stream_group g);
-ppasr_status ppasr_stream_group_reset(ppasr_stream_group g, int session /* < 0: all */, void* stream);
-int          ppasr_stream_group_offset(ppasr_stream_group g, int session);
-size_t       ppasr_group_chunk_workspace_bytes(ppasr_handle h, int n, int T);
-ppasr_status ppasr_encode_chunk_group(ppasr_stream_group g, const int* sessions_host, int n, const float* feats, int T,
+PPASR_API ppasr_status ppasr_stream_group_create(ppasr_handle h, int n_sessions, int max_frames, ppasr_stream_group* out);
+PPASR_API ppasr_status ppasr_stream_group_destroy(ppasr_stream_group g);
+PPASR_API ppasr_status ppasr_stream_group_reset(ppasr_stream_group g, int session /* < 0: all */, void* stream);
+PPASR_API int          ppasr_stream_group_offset(ppasr_stream_group g, int session);
+PPASR_API size_t       ppasr_group_chunk_workspace_bytes(ppasr_handle h, int n, int T);
+PPASR_API ppasr_status ppasr_encode_chunk_group(ppasr_stream_group g, const int* sessions_host, int n, const float* feats, int T,
                                       float* probs, int32_t* frame_argmax, float* frame_maxprob, int* c_out_host,
                                       void* workspace, size_t workspace_bytes, void* stream);
 
@@ -320,12 +324,12 @@ ppasr_status ppasr_encode_chunk_group(ppasr_stream_group g, const int* sessions_
  * paddleaudio.compliance.kaldi.fbank(n_mels, frame_length=25, frame_shift=10, dither=0, sr) (third-party,
  * paddleaudio>=1.0.1).  samples: device f32 mono in [-1,1]; feats: device f32 [frames][n_mels]. */
 typedef struct ppasr_fbank_s* ppasr_fbank_handle;
-ppasr_status ppasr_fbank_create(int sample_rate, int n_mels, float frame_length_ms, float frame_shift_ms,
+PPASR_API ppasr_status ppasr_fbank_create(int sample_rate, int n_mels, float frame_length_ms, float frame_shift_ms,
                                 ppasr_fbank_handle* out);
-ppasr_status ppasr_fbank_destroy(ppasr_fbank_handle f);
-int          ppasr_fbank_frames(ppasr_fbank_handle f, int n_samples);          /* snip_edges frame count */
-size_t       ppasr_fbank_workspace_bytes(ppasr_fbank_handle f, int n_samples);
-ppasr_status ppasr_fbank_compute(ppasr_fbank_handle f, const float* samples, int n_samples, int use_db_norm,
+PPASR_API ppasr_status ppasr_fbank_destroy(ppasr_fbank_handle f);
+PPASR_API int          ppasr_fbank_frames(ppasr_fbank_handle f, int n_samples);          /* snip_edges frame count */
+PPASR_API size_t       ppasr_fbank_workspace_bytes(ppasr_fbank_handle f, int n_samples);
+PPASR_API ppasr_status ppasr_fbank_compute(ppasr_fbank_handle f, const float* samples, int n_samples, int use_db_norm,
                                  float target_db, float* feats, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus

@@ -130,7 +130,12 @@ _lib = None
 
 
 class PPASRHipError(RuntimeError):
-    pass
+    """`status`: the library's numeric ppasr_status (PPASR_E*) when the error came through check(), else None -- callers
+    that tolerate one specific refusal (PPASR_EUNSUPPORTED) test the code, never the message text."""
+
+    def __init__(self, msg, status=None):
+        super().__init__(msg)
+        self.status = status
 
 
 def load():
@@ -154,7 +159,7 @@ def load():
 def check(status):
     if status != 0:
         msg = load().ppasr_last_error()
-        raise PPASRHipError(f"libppasr_hip status {status}: {msg.decode() if msg else ''}")
+        raise PPASRHipError(f"libppasr_hip status {status}: {msg.decode() if msg else ''}", status=int(status))
 
 
 class kernel_profile:

@@ -740,7 +740,9 @@ size_t ppasr_ctc_beam_state_bytes(int B, int max_frames, int beam_size) {
   return (size_t)B * beam_utt_bytes((size_t)(max_frames < 1 ? 1 : max_frames), beam_size);
 }
 
-const ppasr::LmDev* ppasr_lm_device_view(ppasr_lm_handle lm);  // lm.hip
+}  // extern "C"
+namespace ppasr { const LmDev* lm_device_view(ppasr_lm_handle lm); }  // lm.hip (internal: C++ linkage, not exported)
+extern "C" {
 
 ppasr_status ppasr_ctc_beam_search(const float* probs, const int32_t* frame_lens, int B, int T, int V, int beam_size,
                                    double cutoff_prob, int cutoff_top_n, int blank, int nbest, int max_tokens,
@@ -758,7 +760,7 @@ ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_l
   if (B <= 0 || T < 0) return fail(PPASR_EINVAL, "empty batch");
   BeamConfig c{};
   if (lm) {  // before beam_config: the LDS budget depends on it
-    c.lm = *ppasr_lm_device_view(lm);
+    c.lm = *ppasr::lm_device_view(lm);
     c.alpha = alpha;
     c.beta = beta;
   }
@@ -780,9 +782,13 @@ ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_l
   hipStream_t hs = static_cast<hipStream_t>(stream);
   if (init_state) {
     HIP_TRY(hipMemsetAsync(status, 0, (size_t)B * 4, hs));
-    // empty node tables (the kernel enters every prefix it creates)
+    // empty node tables (the kernel enters every prefix it creates) -- only where the search uses them: the default route
+    // of scorer-less / character-LM searches never reads the table, and clearing 24 bytes per node per call is tens of MB
+    // of memset on the latency-bound decoder path
+    if (c.node_table) {
     const size_t tab_off = (beam_fixed_words(beam_size) + beam_arena_words(c.max_nodes)) * 4, tab_bytes = 12 * beam_table_slots(c.max_nodes);
     HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(state) + tab_off, block_words * 4, 0, tab_bytes, (size_t)B, hs));
+    }
   }
   HIP_TRY(launch_ctc_beam(probs, frame_lens, B, T, c, prune_recs, st_words, init_state, 1, tokens, lens, scores, status, hs));
   return PPASR_OK;
@@ -837,6 +843,7 @@ ppasr_status ppasr_ctc_beam_status(const void* state, size_t state_bytes, int B,
 // ---- kernel-name profiler: every PPASR_LAUNCH of the calling thread between begin and end carries its own dispatch-attached
 // event pair (launch.h); entries are keyed by the kernel's function pointer and named from the code object, so the names
 // are the ones rocprofv3's kernel trace prints.  Covers every model family and the decoders (bench.py roofline leg). ----
+}  // extern "C"
 namespace {
 struct KProf {
   std::vector<hipEvent_t> pool;
@@ -875,6 +882,7 @@ std::string kernel_display_name(const void* fn) {
   return n;
 }
 }  // namespace
+extern "C" {
 
 ppasr_status ppasr_kprof_begin(void) {
   g_kprof.used = 0;

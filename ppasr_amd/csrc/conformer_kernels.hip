@@ -13,13 +13,13 @@
 namespace ppasr {
 #ifdef PPASR_PHASE_TS
 }  // namespace ppasr
-extern "C" int ppasr_debug_read_phase_ts(long long* out) {  // instrumented builds only (tools/phase_ts.py)
+extern "C" __attribute__((visibility("default"))) int ppasr_debug_read_phase_ts(long long* out) {  // instrumented builds only (tools/phase_ts.py)
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_phase_ts), sizeof(long long) * 128);
 }
-extern "C" int ppasr_debug_read_wave_ts(long long* out) {
+extern "C" __attribute__((visibility("default"))) int ppasr_debug_read_wave_ts(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_wave_ts), sizeof(long long) * 512);
 }
-extern "C" int ppasr_debug_read_wg_ts(long long* out) {
+extern "C" __attribute__((visibility("default"))) int ppasr_debug_read_wg_ts(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ppasr::g_wg_ts), sizeof(long long) * 2 * 1024);
 }
 namespace ppasr {

@@ -46,7 +46,8 @@ __host__ __device__ inline size_t beam_state_words(int beam, int max_nodes) {
   return beam_fixed_words(beam) + beam_arena_words(max_nodes) + 3 * beam_table_slots(max_nodes);
 }
 __host__ __device__ inline uint64_t beam_node_key(int parent, int ch) {
-  return ((uint64_t)(uint32_t)parent << 16) | (uint64_t)(uint32_t)(ch & 0xffff) | (1ull << 63);
+  // node ids and characters are non-negative 31-bit values: (parent, character) pairs never share a key, whatever V is
+  return ((uint64_t)(uint32_t)parent << 32) | (uint64_t)(uint32_t)ch | (1ull << 63);
 }
 __host__ __device__ inline size_t beam_node_slot(uint64_t key, size_t slots) {
   return (size_t)(((key * 0x9E3779B97F4A7C15ull) >> 20) % slots);

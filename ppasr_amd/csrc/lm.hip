@@ -344,7 +344,9 @@ long long ppasr_lm_dict_size(ppasr_lm_handle lm) { return lm ? (long long)lm->di
 int ppasr_lm_space_id(ppasr_lm_handle lm) { return lm ? lm->space_id : -1; }
 long long ppasr_lm_ngram_count(ppasr_lm_handle lm) { return lm ? (long long)lm->n_grams : 0; }
 
-// internal (capi.hip): the device view handed to the beam-search kernel
-const ppasr::LmDev* ppasr_lm_device_view(ppasr_lm_handle lm) { return lm ? &lm->dev : nullptr; }
-
 }  // extern "C"
+
+// internal (capi.hip): the device view handed to the beam-search kernel
+namespace ppasr {
+const LmDev* lm_device_view(ppasr_lm_handle lm) { return lm ? &lm->dev : nullptr; }
+}  // namespace ppasr

@@ -16,6 +16,27 @@ from ppasr_amd.utils.metrics import cer, labels_to_string, wer
 __all__ = ["decoder_result", "evaluate"]
 
 
+def _ids_to_text(ids, vocabulary, greedy):
+    """Token ids -> string the way the reference's two decoders do it: greedy_decoder replaces "<space>" by " "
+    (ctc_greedy_decoder.py:31); the beam-search module joins the vocabulary entries as they are (its vocabulary is handed
+    over with " " already in place, beam_search_decoder.py:59-73)."""
+    text = "".join(vocabulary[i] for i in ids)
+    return text.replace("<space>", " ") if greedy else text
+
+
+def _use_greedy(decoder, beam_search_decoder):
+    return decoder == "ctc_greedy" or beam_search_decoder is None
+
+
+def _reset_scorer(beam_search_decoder):
+    """decode_batch_beam_search_offline re-applies the decoder object's alpha / beta to the scorer on every call
+    (beam_search_decoder.py:60-61); every beam route of this module does the same, so alpha / beta tuned on the decoder
+    object after construction are honoured whichever route decodes."""
+    sc = getattr(beam_search_decoder, "_ext_scorer", None)
+    if sc is not None:
+        sc.reset_params(beam_search_decoder.alpha, beam_search_decoder.beta)
+
+
 def decoder_result(outs, vocabulary, decoder="ctc_greedy", beam_search_decoder=None, frame_lens=None):
     """trainer.py:330-352: outs [B,T',V] (device tensor or numpy) -> list[str]; every one of the T' rows is decoded
     (the reference's behaviour) unless ``frame_lens`` [B] names the valid frames of every utterance."""
@@ -23,16 +44,17 @@ def decoder_result(outs, vocabulary, decoder="ctc_greedy", beam_search_decoder=N
         if decoder == "ctc_greedy" or beam_search_decoder is None:
             return greedy_decoder_batch(outs, vocabulary)
         return beam_search_decoder.decode_batch_beam_search_offline(probs_split=outs)
-    if decoder == "ctc_greedy" or beam_search_decoder is None:
+    greedy = _use_greedy(decoder, beam_search_decoder)
+    if greedy:
         tokens, n, _, _, _ = greedy_decode_ids(outs, frame_lens)
     else:
         d = beam_search_decoder
+        _reset_scorer(d)
         tokens, n, _, _ = beam_search_ids(outs, d.beam_size, d.cutoff_prob, d.cutoff_top_n, d.blank_id,
                                           frame_lens=frame_lens, nbest=1, ext_scorer=d._ext_scorer)
         tokens, n = tokens[:, 0], n[:, 0]
     tk, nn = tokens.cpu(), n.cpu()
-    return ["".join(vocabulary[i] for i in tk[b, :max(int(nn[b]), 0)].tolist()).replace("<space>", " ")
-            for b in range(tk.shape[0])]
+    return [_ids_to_text(tk[b, :max(int(nn[b]), 0)].tolist(), vocabulary, greedy) for b in range(tk.shape[0])]
 
 
 def evaluate(model, batches, vocab_list, decoder="ctc_greedy", metrics_type="cer", beam_search_decoder=None,
@@ -44,7 +66,10 @@ def evaluate(model, batches, vocab_list, decoder="ctc_greedy", metrics_type="cer
     encoder runs in its ragged-batch mode and the decoders stop at each utterance's last valid frame.
     ``overlap_decode``: encode batch i+1 on a second HIP stream while batch i is being decoded (same results).
     ``shard``: "batches" = batch i goes to rank i % world; "buckets" = every batch is cut into length buckets that are
-    dealt to the ranks by padded work (ragged batches; decoding then covers the valid frames only)."""
+    dealt to the ranks by padded work (ragged batches).  "buckets" ALWAYS has ``trim_padding=True`` semantics -- the
+    encoder skips the padding and decoding covers each utterance's valid frames only, whatever ``trim_padding`` says --
+    so for batches with padding its error rate equals ``shard="batches", trim_padding=True``, not the reference's
+    padded-row decoding; with ``decoder != "ctc_greedy"`` a ``beam_search_decoder`` is required (no silent greedy)."""
     dist = torch.distributed.is_available() and torch.distributed.is_initialized()
     if shard == "buckets":
         return _evaluate_bucketed(model, batches, vocab_list, decoder, metrics_type, beam_search_decoder, display_result,
@@ -119,10 +144,14 @@ def _evaluate_bucketed(model, batches, vocab_list, decoder, metrics_type, beam_s
     """Every rank walks every batch and decodes ITS length buckets of it; after the gather each rank holds all
     hypotheses of the batch, so the error sums are identical on every rank and need no further collective."""
     from ppasr_amd.parallel import beam_ids_decoder, decode_ragged, greedy_ids_decoder
-    if decoder == "ctc_greedy" or beam_search_decoder is None:
+    if decoder != "ctc_greedy" and beam_search_decoder is None:
+        raise ValueError(f"evaluate(shard='buckets', decoder={decoder!r}) needs a beam_search_decoder")
+    greedy = _use_greedy(decoder, beam_search_decoder)
+    if greedy:
         dec = greedy_ids_decoder()
     else:
         d = beam_search_decoder
+        _reset_scorer(d)
         dec = beam_ids_decoder(d.beam_size, d.cutoff_prob, d.cutoff_top_n, d.blank_id, d._ext_scorer)
     eos = len(vocab_list) - 1
     total, count = 0.0, 0
@@ -132,7 +161,7 @@ def _evaluate_bucketed(model, batches, vocab_list, decoder, metrics_type, beam_s
         tk, nn = tokens.cpu(), n.cpu()
         labels_str = labels_to_string(labels, vocab_list, eos=eos)
         for b, label in enumerate(labels_str):
-            out_string = "".join(vocab_list[i] for i in tk[b, :max(int(nn[b]), 0)].tolist()).replace("<space>", " ")
+            out_string = _ids_to_text(tk[b, :max(int(nn[b]), 0)].tolist(), vocab_list, greedy)
             err = wer(out_string, label) if metrics_type == "wer" else cer(out_string, label)
             total += err
             count += 1

@@ -12,6 +12,7 @@ import os
 import numpy as np
 import torch
 
+from ppasr_amd import _lib
 from ppasr_amd.model_utils.conformer.model import ConformerModel
 from ppasr_amd.utils.checkpoint import find_state_dict, load_state_dict
 
@@ -63,8 +64,9 @@ class InferencePredictor:
         if streaming and "former" in use_model:
             try:
                 self._stream = self.model.new_stream()
-            except RuntimeError as e:  # PPASRHipError: PPASR_EUNSUPPORTED
-                if "stream" not in str(e):
+            except _lib.PPASRHipError as e:
+                # only "this route builds no stream handles"; a failed cache allocation (PPASR_EHIP) must surface here
+                if e.status != _lib.PPASR_EUNSUPPORTED:
                     raise
         self.output_state_h = None
         self.output_state_c = None

@@ -18,6 +18,8 @@ Record layout per utterance (int32 words): tokens[L] (-1 padded) | n_tokens | sc
 """
 import torch
 
+from ppasr_amd import _lib
+
 __all__ = ["shard_range", "pack_hypotheses", "unpack_hypotheses", "gather_hypotheses", "Bucket", "make_buckets",
            "assign_buckets", "ragged_record_shape", "gather_ragged_hypotheses", "rank_batches", "greedy_ids_decoder",
            "beam_ids_decoder", "decode_ragged", "RaggedPlan"]
@@ -136,8 +138,8 @@ def set_skip_padding_if_built(model, enable):
     try:
         fn(enable)
         return bool(enable)
-    except RuntimeError as e:  # PPASRHipError
-        if "skip_padding" in str(e):
+    except _lib.PPASRHipError as e:
+        if e.status == _lib.PPASR_EUNSUPPORTED:  # (any other status -- an allocation failure, a bad handle -- is an error)
             return False
         raise
 
@@ -306,6 +308,17 @@ class RaggedPlan:
         self.pipeline = bool(pipeline) and self.cuda
         self.enc_stream = torch.cuda.Stream(device=self.dev) if self.pipeline else None
         self.dec_stream = torch.cuda.Stream(device=self.dev) if self.pipeline else None
+        # the batches above were prepared (gather, pad, .contiguous()) on the CALLER's current stream: the side streams
+        # must not read them before that work is done
+        self.ready = None
+        if self.pipeline:
+            self.ready = torch.cuda.Event()
+            self.ready.record(torch.cuda.current_stream(self.dev))
+            for (idx, x, lens, frame_lens) in self.batches:
+                for t in (idx, x, lens, frame_lens):
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(self.enc_stream)
+                        t.record_stream(self.dec_stream)
 
     def _record(self, outs):
         """int32 [rows, cols + 4] record of this rank, assembled on the device with whole-batch copies (no per-row
@@ -340,6 +353,12 @@ class RaggedPlan:
         outs = []
         if self.ragged and self.batches:
             set_skip_padding_if_built(model, True)
+        if self.pipeline:
+            # inputs ready (see __init__).  enc_stream does NOT wait for the previous call's decode: that is the overlap --
+            # call i's decoder reads only probs(i) (its own allocation, record_stream below) and the decoder's state, the
+            # encoder of call i + 1 only the model's workspace and these inputs, all in stream order on enc_stream
+            self.enc_stream.wait_event(self.ready)
+            self.dec_stream.wait_event(self.ready)
         try:
             for (_idx, x, lens, frame_lens) in self.batches:
                 if self.pipeline:

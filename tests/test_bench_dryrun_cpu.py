@@ -66,13 +66,20 @@ def test_skip_padding_helper_on_stub_models():
         def set_skip_padding(self, on):
             self.on = on
 
+    from ppasr_amd import _lib
+
     class Refuses:
         def set_skip_padding(self, on):
-            raise RuntimeError("libppasr_hip status 3: skip_padding: built for the fused 256-wide route ...")
+            raise _lib.PPASRHipError("libppasr_hip status 3: skip_padding: built for the fused 256-wide route ...",
+                                     status=_lib.PPASR_EUNSUPPORTED)
 
     class Broken:
         def set_skip_padding(self, on):
             raise RuntimeError("hipErrorLaunchFailure")
+
+    class OutOfMemory:  # the same words in the message, another status: must NOT be swallowed
+        def set_skip_padding(self, on):
+            raise _lib.PPASRHipError("libppasr_hip status 2: skip_padding: hipMalloc failed", status=_lib.PPASR_EHIP)
 
     b = Built()
     assert set_skip_padding_if_built(b, True) is True and b.on is True
@@ -82,3 +89,12 @@ def test_skip_padding_helper_on_stub_models():
     import pytest
     with pytest.raises(RuntimeError):
         set_skip_padding_if_built(Broken(), True)
+    with pytest.raises(_lib.PPASRHipError):
+        set_skip_padding_if_built(OutOfMemory(), True)
+    # check() carries the numeric status
+    try:
+        _lib.check(_lib.load().ppasr_set_skip_padding(None, 1))
+    except _lib.PPASRHipError as e:
+        assert e.status == _lib.PPASR_EINVAL
+    else:
+        raise AssertionError("null handle accepted")

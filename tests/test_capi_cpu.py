@@ -27,6 +27,20 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == bound, (set(names) ^ bound)
 
 
+def test_dynamic_symbol_table_is_exactly_the_header():
+    """A drop-in library exports its header and nothing else: `nm -D --defined-only` == the PPASR_API declarations
+    (-fvisibility=hidden + csrc/exports.map; no mangled internals, kernel handles or libstdc++ instantiations)."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == _declared_symbols(), sorted(set(exported) ^ set(_declared_symbols()))
+    kinds = {line.split()[-2] for line in out.splitlines() if line.strip()}
+    assert kinds == {"T"}, kinds
+    # every declaration carries the export attribute
+    src = open(os.path.join(ROOT, "include", "ppasr_hip.h")).read()
+    assert src.count("PPASR_API ") - 1 == len(exported)  # (-1: the #define itself)
+
+
 def test_version_and_error_strings():
     lib = _lib.load()
     assert b"gfx950" in lib.ppasr_version()

@@ -5,5 +5,10 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p tools/_ts
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude "$@" -o tools/_ts/lib_${name}.so ppasr_amd/csrc/*.hip
+python -c "
+import sys, os
+sys.path.insert(0, os.getcwd())
+import __graft_entry__ as g
+g.build_lib(lib='tools/_ts/lib_' + sys.argv[1] + '.so', extra_flags=sys.argv[2:], obj_dir='build/obj_' + sys.argv[1], verbose=False)
+" "$name" "$@"
 echo built tools/_ts/lib_${name}.so

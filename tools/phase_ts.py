@@ -18,9 +18,9 @@ NAMES = {0: "start", 1: "dwconv done", 2: "LN_cm+swish", 3: "pw2 + epilogue", 4:
 
 if "--build" in sys.argv:
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    srcs = sorted(glob.glob(os.path.join(ROOT, "ppasr_amd", "csrc", "*.hip")))
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DPPASR_PHASE_TS",
-                           "-o", LIB] + srcs)
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    entry.build_lib(lib=LIB, extra_flags=["-DPPASR_PHASE_TS"], obj_dir=os.path.join(ROOT, "build", "obj_phase_ts"))
     print("built", LIB)
     sys.exit(0)
 
