@@ -89,6 +89,14 @@ def class_of(name):
     if not m:
         return n
     base, targs = m.group(1), m.group(2) or ""
+    # round-4 kernels on transposed accumulators (csrc/rbt.h, attention_kernels.hip): the classes of the kernels they
+    # replace -- k_sq_mid_t<R> -> k_sq_mid, k_sq_tail_t<R, KS> -> k_sq_tail<KS>, k_attention_t<DK> -> k_attention<DK>
+    if base == "k_sq_mid_t":
+        return "k_sq_mid"
+    if base == "k_sq_tail_t":
+        return "k_sq_tail<%s>" % targs.strip("<>").split(",")[-1].strip()
+    if base == "k_attention_t":
+        return "k_attention<%s>" % targs.strip("<>").split(",")[0].strip()
     if base == "k_conv_ffn":
         a = [t.strip() for t in targs.strip("<>").split(",")]
         return f"k_conv_ffn<{a[0]}>+next" if a[-1] in ("true", "1") else f"k_conv_ffn<{a[0]}>"
@@ -785,6 +793,37 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             median_ms = float(t.item())
 
+    # Pipelined workloads (cfg4 / cfg5): the same steps once more with the overlap switched off -- encoder, then its beam
+    # search, then the next step -- so that the line carries BOTH figures: `value` = the pipelined rate (a caller with a
+    # stream of batches), config.serial = what a caller with ONE batch at a time gets.  Every rank runs it (N > 1: a
+    # step ends in the all-gather).
+    serial = None
+    if w.pipelined and not dry:
+        holder, attr = (w.plan, "pipeline") if hasattr(w, "plan") else (w.pipe, "enable")
+        setattr(holder, attr, False)
+        try:
+            n_ser = max(5, min(args.steps, 30))
+            for _ in range(2):
+                w.step()
+            sync()
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(n_ser):
+                w.step()
+            sync()
+            if world > 1:
+                dist.barrier()
+            el = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([el], dtype=torch.float64, device=red_device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            serial = {"steps": n_ser, "ms_per_step": round(el / n_ser * 1e3, 3), "value": round(audio_s_per_step / (el / n_ser), 1),
+                      "unit": "audio-s/s", "note": "same workload, encoder and beam search of a step back to back on one stream"}
+        finally:
+            setattr(holder, attr, True)
+
     # The roofline leg runs `reps` more steps of the workload; with N > 1 a step ends in the hypothesis all-gather, so
     # EVERY rank runs the leg (each profiles its own kernels; rank 0's figures are reported) -- a rank-0-only leg would
     # leave rank 0 waiting in a collective the other ranks never enter.  The dry run mirrors the extra steps.
@@ -817,7 +856,7 @@ def main():
             "config": {"workload": w.desc, "baseline_config": cfg_name,
                        "global_batch": getattr(w, "n_global", None) or world * args.batch, "frames": args.frames,
                        "decoder": w.decoder, "parallelism": f"utterance-dp{world}",
-                       "pipelined": bool(w.pipelined),
+                       "pipelined": bool(w.pipelined), "serial": serial,
                        "pipelined_note": ("the beam search of step i runs on a second HIP stream and overlaps the encoder of step "
                                           "i+1; all K steps are complete when the timed region ends") if w.pipelined else None},
             "median_ms_per_step": None if median_ms is None else round(median_ms, 3),

@@ -155,6 +155,16 @@ PPASR_API ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable);
  * kernels, the fused attention kernel included), 2 / 4 / 8 = always that many slices. */
 PPASR_API ppasr_status ppasr_set_ffn_split(ppasr_handle h, int mode);
 
+/* Rows per workgroup of the layer kernels (no reference counterpart): -1 (default) = by grid size -- 16-row blocks
+ * (v_mfma_f32_16x16x4_f32, csrc/rbt.h) for launches whose 32-row blocks would fill at most half of the chip, else 32;
+ * 16 / 32 = always.  Same arithmetic up to the summation order inside a 16-wide k step (1e-6 relative).  Built for the
+ * Squeezeformer layer kernels; other routes ignore it. */
+PPASR_API ppasr_status ppasr_set_row_block(ppasr_handle h, int rows);
+/* Host copy of the `lens` the following ppasr_encode calls of a batch of B utterances will pass (NULL / 0: forget it).
+ * Only ever used to CHOOSE between kernel variants for ragged batches (ppasr_set_skip_padding), whose count of computed
+ * rows the host cannot otherwise know; no kernel reads it and a wrong hint costs speed, never correctness. */
+PPASR_API ppasr_status ppasr_set_lengths_hint(ppasr_handle h, const int64_t* lens_host, int B);
+
 /* Host helper (no device work): Levenshtein distance between two int32 sequences -- what ppasr/utils/metrics.py:4-29
  * (cer / wer) gets from the `Levenshtein` C extension.  Returns -1 on a null argument with a positive length. */
 PPASR_API long long ppasr_edit_distance(const int32_t* a, int na, const int32_t* b, int nb);

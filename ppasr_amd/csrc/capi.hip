@@ -445,7 +445,47 @@ int ffn_split_for(const ppasr_model_s* m, int M) {
   return S;
 }
 
+int row_block_for(const ppasr_model_s* m, int B, int Tcur, int mul, int slack, bool skip) {
+  if (m->row_block == 16 || m->row_block == 32) return m->row_block;
+  long long rows = (long long)B * Tcur;
+  if (skip && (int)m->lens_hint.size() == B) {
+    rows = 0;
+    for (int b = 0; b < B; ++b) {
+      const long long len = m->lens_hint[b];
+      const long long need = (len > 0 ? (len + mul - 1) / mul : 0) + slack;
+      rows += need < Tcur ? need : Tcur;
+    }
+  }
+  // Rounds of one workgroup per CU: ceil(blocks / 256), a 16-row round 0.52 of a 32-row one (tools/microbench_rb16: 4.3 us
+  // per 16-row GEMM unit against 8.4 us per 32-row one; tools/r04_tune_rows.py: whole-encoder timings over batch sizes).
+  // 33 .. 128 blocks of 32 rows: one half-as-long round instead of a half-empty one; 257 .. 384: three short rounds instead
+  // of two long ones.  Up to 32 blocks the split route (ffn_split_for: 8 hidden slices per row block) fills more CUs than
+  // 2 x the blocks would.
+  static const int min_blocks = [] {
+    const char* e = getenv("PPASR_R16_MIN_BLOCKS");  // (tuning knob)
+    return e ? atoi(e) : 32;
+  }();
+  const long long b32 = (rows + 31) / 32, b16 = (rows + 15) / 16;
+  if (b32 <= min_blocks) return 32;
+  const double c32 = (double)((b32 + 255) / 256), c16 = 0.52 * (double)((b16 + 255) / 256);
+  return c16 < c32 ? 16 : 32;
+}
+
 extern "C" {
+
+ppasr_status ppasr_set_row_block(ppasr_handle h, int rows) {
+  if (!h) return fail(PPASR_EINVAL, "null handle");
+  if (rows != -1 && rows != 16 && rows != 32) return fail(PPASR_EINVAL, "row block: -1 (by grid size), 16 or 32");
+  h->row_block = rows;
+  return PPASR_OK;
+}
+
+ppasr_status ppasr_set_lengths_hint(ppasr_handle h, const int64_t* lens_host, int B) {
+  if (!h) return fail(PPASR_EINVAL, "null handle");
+  if (!lens_host || B <= 0) h->lens_hint.clear();
+  else h->lens_hint.assign(lens_host, lens_host + B);
+  return PPASR_OK;
+}
 
 size_t ppasr_workspace_bytes(ppasr_handle h, int B, int T) {
   if (!h || B <= 0 || T < 7) return 0;
@@ -580,7 +620,11 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     });
     timed(2, [&] { launch_embed(y1, h->front, xa, M, h->F3 * kD, sqrtf((float)kD), false, st, PadSkip{}, ffn_split_for(h, M), y2); });
   } else {
-    timed(1, [&] { launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, pskip(Tp, sub)); });
+    timed(1, [&] {
+      // (ragged batches: the active-tile table of conv2 lives in the CTC head's statistics buffer, unused until the head)
+      int* tile_tab = (size_t)B + 2 <= ((size_t)M + 63) / 64 * 64 ? reinterpret_cast<int*>(ws + wl.rmax) : nullptr;
+      launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, pskip(Tp, sub), tile_tab);
+    });
     timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st, pskip(Tp, sub), ffn_split_for(h, M), y1); });
   }
   tap(xa, (size_t)M * kD);

@@ -129,6 +129,8 @@ struct ppasr_model_s {
   bool prof = false;
   int ffn_split = -1;  // ppasr_set_ffn_split: -1 = by grid size, 0 = never, 2 / 4 / 8 = always that many slices
   bool skip_padding = false;  // ppasr_set_skip_padding: ragged batches compute only the rows valid outputs depend on
+  int row_block = -1;         // ppasr_set_row_block: -1 = by grid size, 32 / 16 = always that many rows per workgroup
+  std::vector<int64_t> lens_hint;  // ppasr_set_lengths_hint: host copy of the batch's lengths (route selection only)
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   struct Span { int cls; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };  // one pair per kernel launched inside the span
@@ -195,6 +197,11 @@ struct WsLayout {
 WsLayout ws_layout(const ppasr_model_s* m, int B, int T);
 // hidden-dimension slices per row block for M rows (1 = the fused kernels), see ppasr_set_ffn_split
 int ffn_split_for(const ppasr_model_s* m, int M);
+// rows per workgroup (32 or 16) for a row-block launch over B utterances of Tcur rows each: 16 when the rows that will
+// actually be computed fill at most half of the chip as 32-row blocks.  With skip_padding the computed rows are
+// sum_b min(Tcur, ceil(len_b / mul) + slack) -- known on the host only through ppasr_set_lengths_hint; without a hint the
+// padded count decides.
+int row_block_for(const ppasr_model_s* m, int B, int Tcur, int mul, int slack, bool skip);
 ppasr::LayerW sq_conv_view(const ppasr::SqLayerW& W);  // capi_squeezeformer.hip
 
 ppasr_status upload_pe_table(ppasr_model_s* m, BlobMap& sd, const float** pe_dev);

@@ -288,7 +288,7 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
   };
   const PadSkip psF = pskip(Tp, 4), psH = pskip(Tr, 8);
   launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, psF);
-  launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, psF);
+  launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, psF, (size_t)B + 2 <= ((size_t)M + 63) / 64 * 64 ? reinterpret_cast<int*>(ws + wl.rmax) : nullptr);
   launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/true, st, psF, ffn_split_for(h, M), y1);
   launch_ln_rows(xa, h->preln_g, h->preln_b, M, st, psF);
   tap(xa, (size_t)M * kD);
@@ -323,7 +323,9 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
     launch_attention(a, B, H, st);
     tap(ctx, (size_t)Mi * kD);
     // under-filled grid (ppasr_set_ffn_split): K_B / K_C cut at their feed-forward modules, partial sums in the conv1 buffer
-    const int S = ffn_split_for(h, Mi);
+    // under-filled launch: 16-row blocks (twice the workgroups, each half as long) before the split route
+    const int rows = h->taps ? 32 : row_block_for(h, B, Ti, mul, ps.slack, skip);
+    const int S = rows == 16 && h->ffn_split < 0 ? 1 : ffn_split_for(h, Mi);  // (an explicit ffn_split mode wins)
     const bool fuse_next = (i + 1 < L) && (i + 1 != h->desc.reduce_idx) && !(i + 1 == h->desc.recover_idx && reduced);
     const SqLayerW* Wn = fuse_next ? &h->sq_layers[i + 1] : nullptr;
     if (S > 1) {
@@ -338,11 +340,11 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
                        n_chunks, S, st, ps, /*residual_is_normed=*/true);
       if (Wn) launch_sq_qkv(other, qkv, Wn->wqkv, Wn->bqkv, Mi, st, ps);
     } else {
-      launch_sq_mid(ctx, x, xc, g, nullptr, W, lens, Mi, Ti, mul, n_chunks, st, ps);
+      launch_sq_mid(ctx, x, xc, g, nullptr, W, lens, Mi, Ti, mul, n_chunks, st, ps, rows);
       tap(xc, (size_t)Mi * kD);
       tap(g, (size_t)Mi * kD);
       launch_sq_tail(g, nullptr, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, lens, Mi, Ti, mul,
-                     n_chunks, KS, st, ps, causal);
+                     n_chunks, KS, st, ps, causal, rows);
     }
     std::swap(x, other);
     have_qkv = fuse_next;

@@ -98,6 +98,11 @@ struct VtOut {
 constexpr size_t kLdsExclusive = 82 * 1024;
 size_t ragged_lds(size_t lds, const PadSkip& ps, int n_blocks);
 
+// attention_kernels.hip: the stand-alone attention launch (transposed flash attention, keys split over the waves of a
+// workgroup); false = configuration it does not take (the caller falls back to k_attention)
+bool launch_attention_t(const AttnArgs& a, int B, int H, hipStream_t st);
+hipError_t configure_attention_kernels();
+
 // ---- launchers (all asynchronous on `st`) ----
 void launch_posproj(const float* pe, const float* wpos /*[d][d] in,out*/, const float* bpos_or_null, float* ptab,
                     int max_len, hipStream_t st, int d = 256);
@@ -107,9 +112,10 @@ void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T,
 // one k x k / stride-s 256 -> 256 channel conv + ReLU of the front end on NHWC activations (implicit GEMM)
 void launch_conv_stage(const float* y_in, const f32x4* w, const float* bias, float* y_out, int B, int T_in, int F_in,
                        int T_out, int F_out, int k, int s, hipStream_t st, const PadSkip& ps_frames = PadSkip{},
-                       int channels = 256);  // channels: 256, or a multiple of it (general layer route)
+                       int channels = 256, int* tile_scratch = nullptr);  // channels: 256, or a multiple of it (general layer route)
+// tile_scratch (ragged batches): device scratch of B + 2 ints for the active-tile table (k_tile_prefix)
 void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st,
-                  const PadSkip& ps = PadSkip{});
+                  const PadSkip& ps = PadSkip{}, int* tile_scratch = nullptr);
 // scale_before_bias: Squeezeformer scales the 4864-wide conv output by sqrt(d) BEFORE input_proj
 // (squeezeformer/subsampling.py:66-67) -> acc*scale + b ; Conformer: (acc + b)*scale (embedding.py:112)
 // k_slices > 1 (under-filled launches): the contraction is split over that many workgroups per row block, partial sums

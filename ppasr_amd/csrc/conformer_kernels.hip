@@ -129,16 +129,38 @@ template <int MT, int KC, bool RELU, bool SB, typename Src>
 __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ out, int M,
                                                           int n_chunks, float scale, int ldc, int n_valid, int m0,
-                                                          PadSkip ps) {
+                                                          PadSkip ps, const int* __restrict__ tile_tab) {
   constexpr int BM = 32 * MT;
-  if (pad_block_skippable(ps, m0 + blockIdx.x * BM, BM, M)) return;
+  // Ragged batch with a tile table (k_tile_prefix): workgroup t takes the t-th ACTIVE tile -- tiles are cut per utterance
+  // (utterance b: rows b*S + [BM i, BM i + BM) for i < ceil(need rows / BM)), so the active tiles are the first `total`
+  // workgroups of the grid and are dealt evenly to the 8 XCDs.  (With the padded row space tiled directly and the tiles
+  // behind an utterance's valid frames exiting at once, an XCD that happens to be dealt 129 active tiles for its 32 CUs
+  // runs five rounds where four would do: cfg5's conv2 took 1.5 ms against 1.1.)  Every row is computed by the same
+  // arithmetic whichever tile it lands in.
+  int r0_map = 0, Mlim = M;
+  if (tile_tab) {
+    const int t = blockIdx.x, nb = tile_tab[0];
+    const int* pre = tile_tab + 1;  // pre[b] = active tiles in front of utterance b; pre[nb] = their total
+    if (t >= pre[nb]) return;
+    int lo = 0, hi = nb;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (pre[mid] <= t) lo = mid;
+      else hi = mid;
+    }
+    const int S = ps.Tp * ps.unit;
+    r0_map = lo * S + (t - pre[lo]) * BM;
+    Mlim = min(M, (lo + 1) * S);
+  } else if (pad_block_skippable(ps, m0 + blockIdx.x * BM, BM, M)) {
+    return;
+  }
   constexpr int LD = KC + 4;
   constexpr int F4_PER_ROW = KC / 4;
   constexpr int NL = BM * F4_PER_ROW / kThreads;  // float4 loads per thread per chunk
   constexpr int G = KC / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-  const int r0 = m0 + blockIdx.x * BM;  // m0: first row of this launch (row ranges split across launches)
+  const int r0 = tile_tab ? r0_map : m0 + blockIdx.x * BM;  // m0: first row of this launch (row ranges split across launches)
   const int tile_stride = n_chunks * G * 64;
   // gridDim.z > 1 (under-filled launches): workgroup z contracts K chunks [kc0, kc1) only and stores its raw partial sums
   // to out + z * M * ldc; k_gemm_join adds them up and applies bias / scale / activation
@@ -160,7 +182,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
     int idx = tid + kThreads * i;
     int row = idx / F4_PER_ROW, c4 = idx - row * F4_PER_ROW;
     int m = r0 + row;
-    voff[i] = (m < M) ? (int)((src.base(m) - tile_base) * sizeof(float)) + 16 * c4 : 0x7fffffff;
+    voff[i] = (m < Mlim) ? (int)((src.base(m) - tile_base) * sizeof(float)) + 16 * c4 : 0x7fffffff;
     lds_off[i] = row * LD + 4 * c4;
   }
   f32x4 stg[NL];
@@ -200,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int m = r0 + mt * 32 + acc_row(r, lane);
-        if (m < M && col < n_valid) po[(size_t)m * ldc + col] = acc[mt][0][r];
+        if (m < Mlim && col < n_valid) po[(size_t)m * ldc + col] = acc[mt][0][r];
       }
     return;
   }
@@ -212,8 +234,30 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
       int m = r0 + mt * 32 + acc_row(r, lane);
       float v = SB ? acc[mt][0][r] * scale + bv : (acc[mt][0][r] + bv) * scale;
       if (RELU) v = fmaxf(v, 0.f);
-      if (m < M && col < n_valid) out[(size_t)m * ldc + col] = v;
+      if (m < Mlim && col < n_valid) out[(size_t)m * ldc + col] = v;
     }
+}
+// tab[0] = B, tab[1 + b] = number of BM-row tiles the utterances in front of b need (rows b*S + [0, need(b) * unit)),
+// tab[1 + B] = their total: the tile table of a ragged k_gemm_stream launch
+__global__ __launch_bounds__(256) void k_tile_prefix(PadSkip ps, int B, int BM, int* __restrict__ tab) {
+  __shared__ int cnt[256];
+  int run = 0;
+  if (threadIdx.x == 0) {
+    tab[0] = B;
+    tab[1] = 0;
+  }
+  for (int b0 = 0; b0 < B; b0 += 256) {
+    const int b = b0 + threadIdx.x;
+    cnt[threadIdx.x] = b < B ? (pad_need_steps(ps, b) * ps.unit + BM - 1) / BM : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < 256 && b0 + i < B; ++i) {
+        run += cnt[i];
+        tab[2 + b0 + i] = run;
+      }
+    }
+    __syncthreads();
+  }
 }
 // out[m][c] = (sum_z part[z][m][c] + bias[c]) * scale   or   sum * scale + bias (scale_before_bias); one float4 per thread
 __global__ __launch_bounds__(256) void k_gemm_join(const float* __restrict__ part, int nz, const float* __restrict__ bias,
@@ -232,11 +276,11 @@ __global__ __launch_bounds__(256) void k_gemm_join(const float* __restrict__ par
 }
 
 void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st,
-                  const PadSkip& ps_frames) {
-  launch_conv_stage(y1, fw.conv2_w, fw.conv2_b, y2, B, T1, F1, Tp, F2, fw.conv2_k, fw.conv2_s, st, ps_frames);
+                  const PadSkip& ps_frames, int* tile_scratch) {
+  launch_conv_stage(y1, fw.conv2_w, fw.conv2_b, y2, B, T1, F1, Tp, F2, fw.conv2_k, fw.conv2_s, st, ps_frames, 256, tile_scratch);
 }
 void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b, float* y2, int B, int T1, int F1, int Tp,
-                       int F2, int ksz, int stride, hipStream_t st, const PadSkip& ps_frames, int channels) {
+                       int F2, int ksz, int stride, hipStream_t st, const PadSkip& ps_frames, int channels, int* tile_scratch) {
   Conv2Src src{y1, T1, F1, Tp, F2, ksz, stride, channels};
   const int n_kc = ksz * ksz * (channels / 128);  // 128-wide K chunks: channels / 128 per tap
   const int ny = channels / 256;                  // 256-column blocks of the output
@@ -245,6 +289,15 @@ void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b
   const int M = B * Tp * F2;
   constexpr int KC = 128, kCUs = 256;
   auto lds_of = [](int mt) { return (size_t)2 * (32 * mt) * (KC + 4) * sizeof(float); };
+  const int* no_tab = nullptr;
+  if (ps.lens && tile_scratch && M > 128 * kCUs) {
+    // ragged batch, more than one round of 128-row tiles: the active tiles in front of the grid (see k_gemm_stream)
+    PPASR_LAUNCH(k_tile_prefix, dim3(1), dim3(256), 0, st, ps, B, 128, tile_scratch);
+    const int per_utt = (Tp * F2 + 127) / 128;
+    PPASR_LAUNCH((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(B * per_utt, ny), dim3(kThreads), lds_of(4), st, src, conv_w,
+                 conv_b, y2, M, n_kc, 1.0f, channels, channels, 0, ps, (const int*)tile_scratch);
+    return;
+  }
   // Wave quantisation: 128-row tiles over 256 CUs (one workgroup per CU at this LDS footprint) would run
   // ceil(tiles / 256) rounds, the last one mostly empty (1183 tiles = 4.62 rounds for 32 x 10 s).  The whole rounds
   // run with 128-row tiles; the remainder is re-cut into <= 256 tiles of 32 / 64 / 96 rows (one shorter round).
@@ -257,7 +310,7 @@ void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b
     const int mt = (M + 32 * kCUs - 1) / (32 * kCUs);  // 1 .. 4
 #define CONV2_ALL(MTA)                                                                                                    \
   PPASR_LAUNCH((k_gemm_stream<MTA, KC, true, false, Conv2Src>), dim3((M + 32 * MTA - 1) / (32 * MTA), ny),              \
-                     dim3(kThreads), lds_of(MTA), st, src, conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, 0, ps)
+                     dim3(kThreads), lds_of(MTA), st, src, conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, 0, ps, no_tab)
     if (mt <= 1) CONV2_ALL(1);
     else if (mt == 2) CONV2_ALL(2);
     else if (mt == 3) CONV2_ALL(3);
@@ -267,15 +320,15 @@ void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b
   }
   if (rem_rows <= 0 || mt_rem >= 4) {
     PPASR_LAUNCH((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(tiles4, ny), dim3(kThreads), lds_of(4), st, src,
-                       conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, 0, ps);
+                       conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, 0, ps, no_tab);
     return;
   }
   PPASR_LAUNCH((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(full, ny), dim3(kThreads), lds_of(4), st, src,
-                     conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, 0, ps);
+                     conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, 0, ps, no_tab);
   const int m0 = full * 128;
 #define CONV2_REM(MTR)                                                                                                    \
   PPASR_LAUNCH((k_gemm_stream<MTR, KC, true, false, Conv2Src>), dim3((rem_rows + 32 * MTR - 1) / (32 * MTR), ny),       \
-                     dim3(kThreads), lds_of(MTR), st, src, conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, m0, ps)
+                     dim3(kThreads), lds_of(MTR), st, src, conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, m0, ps, no_tab)
   if (mt_rem <= 1) CONV2_REM(1);
   else if (mt_rem == 2) CONV2_REM(2);
   else CONV2_REM(3);
@@ -301,17 +354,17 @@ void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, fl
   size_t lds = ragged_lds(2 * (32 * MT) * (KC + 4) * sizeof(float), ps, (M + 31) / 32);
   if (k_slices > 1 && part) {  // under-filled launch: the K = 4864 contraction over k_slices workgroups per row block
     PPASR_LAUNCH((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, 1, k_slices), dim3(kThreads), lds,
-                       st, src, fw.embed_w, fw.embed_b, part, M, K / KC, xscale, kD, kD, 0, ps);
+                       st, src, fw.embed_w, fw.embed_b, part, M, K / KC, xscale, kD, kD, 0, ps, (const int*)nullptr);
     PPASR_LAUNCH(k_gemm_join, dim3((M + 3) / 4), dim3(256), 0, st, part, k_slices, fw.embed_b, xscale,
                        scale_before_bias ? 1 : 0, x0, M, ps);
     return;
   }
   if (scale_before_bias)
     PPASR_LAUNCH((k_gemm_stream<MT, KC, false, true, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src,
-                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD, 0, ps);
+                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD, 0, ps, (const int*)nullptr);
   else
     PPASR_LAUNCH((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32), dim3(kThreads), lds, st, src,
-                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD, 0, ps);
+                       fw.embed_w, fw.embed_b, x0, M, K / KC, xscale, kD, kD, 0, ps, (const int*)nullptr);
 }
 
 // out[m][c] = (sum_z part[z][m][c] + bias[c]) * scale for c < n_valid: the join of launch_dense's K slices (any width)
@@ -348,13 +401,13 @@ void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, fl
   }
   if (S > 1) {
     PPASR_LAUNCH((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, n_cols_padded / 256, S), dim3(kThreads),
-                 lds, st, src, w, bias, part, M, n_kc, scale, ldc, n_valid, 0, PadSkip{});
+                 lds, st, src, w, bias, part, M, n_kc, scale, ldc, n_valid, 0, PadSkip{}, (const int*)nullptr);
     const size_t n4 = (size_t)M * ((n_valid + 3) / 4);
     PPASR_LAUNCH(k_dense_join, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, S, bias, scale, out, M, ldc, n_valid);
     return;
   }
   PPASR_LAUNCH((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, n_cols_padded / 256),
-                     dim3(kThreads), lds, st, src, w, bias, out, M, K / KC, scale, ldc, n_valid, 0, PadSkip{});
+                     dim3(kThreads), lds, st, src, w, bias, out, M, K / KC, scale, ldc, n_valid, 0, PadSkip{}, (const int*)nullptr);
 }
 
 // =====================================================================================
@@ -797,6 +850,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
 constexpr size_t kLdsAttn = AttnCfg<64>::LDS_FLOATS * sizeof(float);
 constexpr size_t kLdsAttnG = AttnCfg<192>::LDS_FLOATS * sizeof(float);
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st) {
+  if (launch_attention_t(a, B, H, st)) return;  // attention_kernels.hip (the kernels below: grouped heads on width 768)
   if (a.group == 3 && a.dm == kD)
     PPASR_LAUNCH((k_attention<192, true>), dim3((a.T1 + 63) / 64, H, B), dim3(256), kLdsAttnG, st, a);
   else if (a.group == 3)
@@ -2236,7 +2290,8 @@ void launch_ctc_collapse(const int32_t* fr_argmax, const float* fr_maxprob, cons
 }
 
 hipError_t configure_kernels() {
-  hipError_t e;
+  hipError_t e = configure_attention_kernels();
+  if (e != hipSuccess) return e;
 #define SET_LDS(fn, bytes)                                                                                     \
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
   if (e != hipSuccess) return e;

@@ -213,6 +213,20 @@ class ConformerModel:
         2 / 4 / 8 = always that many slices."""
         _lib.check(self.lib.ppasr_set_ffn_split(self._h, int(mode)))
 
+    def set_row_block(self, rows=-1):
+        """Rows per workgroup of the layer kernels (``ppasr_set_row_block``): -1 = by grid size (16-row blocks for launches
+        whose 32-row blocks would fill at most half of the chip), 16 / 32 = always."""
+        _lib.check(self.lib.ppasr_set_row_block(self._h, int(rows)))
+
+    def set_lengths_hint(self, lengths=None):
+        """Host copy of the lengths of the batches the following calls encode (``ppasr_set_lengths_hint``; None: forget).
+        Route selection for ragged batches only -- a wrong hint costs speed, never correctness."""
+        if lengths is None:
+            _lib.check(self.lib.ppasr_set_lengths_hint(self._h, None, 0))
+            return
+        arr = (ctypes.c_int64 * len(lengths))(*[int(v) for v in lengths])
+        _lib.check(self.lib.ppasr_set_lengths_hint(self._h, arr, len(lengths)))
+
     def set_debug_taps(self, n_floats):
         """Allocate a tap buffer; layout in DESIGN.md (x0, then per layer x1,qkv,ctx,x2,g,x_out)."""
         self._taps = torch.zeros(n_floats, dtype=torch.float32, device=self.device) if n_floats else None

@@ -300,10 +300,14 @@ class RaggedPlan:
             raise RuntimeError("ragged plan: the ranks' batches do not cover the batch")
         self.order = torch.tensor(order, dtype=torch.int64, device=self.dev)
         self.batches = []
+        # the plan knows every length on the host: each ragged batch's lengths go to models that can use them to pick kernel
+        # variants (ppasr_set_lengths_hint)
+        self.hints = []
         for idx in rank_batches(self.lengths, self.rank, self.world, width, mode, max_batch_frames):
             x, lens = _pad_batch(feats, self.lengths, idx, self.dev)
             frame_lens = model.valid_out_frames(lens, x.shape[1])
             self.batches.append((torch.tensor(idx, dtype=torch.int32, device=self.dev), x, lens, frame_lens))
+            self.hints.append([int(self.lengths[i]) for i in idx] if hasattr(model, "set_lengths_hint") else None)
         self.cuda = self.dev.type == "cuda"
         self.pipeline = bool(pipeline) and self.cuda
         self.enc_stream = torch.cuda.Stream(device=self.dev) if self.pipeline else None
@@ -360,7 +364,9 @@ class RaggedPlan:
             self.enc_stream.wait_event(self.ready)
             self.dec_stream.wait_event(self.ready)
         try:
-            for (_idx, x, lens, frame_lens) in self.batches:
+            for (_idx, x, lens, frame_lens), hint in zip(self.batches, self.hints):
+                if hint is not None:
+                    model.set_lengths_hint(hint)  # (host-side route selection for the ragged batch; see the C header)
                 if self.pipeline:
                     with torch.cuda.stream(self.enc_stream):
                         probs = model.get_encoder_out(x, lens)
@@ -376,6 +382,8 @@ class RaggedPlan:
         finally:
             if self.ragged and self.batches:
                 set_skip_padding_if_built(model, False)
+            if any(h is not None for h in self.hints):
+                model.set_lengths_hint(None)
         return outs
 
     def run(self, decoder):

@@ -1,0 +1,118 @@
+"""GPU: the Squeezeformer layer kernels on transposed accumulators (csrc/rbt.h, phases_t.h) -- 32-row blocks are
+bit-identical to the round-3 kernels they replace (same sums, same order), 16-row blocks (v_mfma_f32_16x16x4_f32) agree
+to rounding, hold the oracle tolerance on their own, and the route choice (ppasr_set_row_block, ppasr_set_lengths_hint)
+never changes which rows are computed."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.squeezeformer_oracle import SqueezeformerOracle
+from ppasr_amd.utils.synth import squeezeformer_state_dict, synth_features
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+V, L, RED, REC = 300, 5, 2, 4
+# 16 utterances of 152 frames: 76 blocks of 32 rows on the full-rate layers, 38 on the reduced ones -- both inside the
+# window (33 .. 128 blocks) where the grid-size rule picks the 16-row kernels
+LENS = [611, 600, 333, 97, 611, 13, 250, 480, 611, 420, 77, 590, 611, 305, 150, 555]
+
+
+def _model(streaming=True, kernel=31, norm="layer_norm"):
+    from ppasr_amd.model_utils.squeezeformer.model import SqueezeformerModel
+    sd = squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=71, perturb_norm=True, cnn_module_kernel=kernel,
+                                  streaming=streaming, cnn_norm_type=norm)
+    conf = dict(encoder_dim=256, output_size=256, attention_heads=4, num_blocks=L, reduce_idx=RED, recover_idx=REC,
+                feed_forward_expansion_factor=8, cnn_module_kernel=kernel, cnn_norm_type=norm)
+    return SqueezeformerModel(80, V, streaming=streaming, encoder_conf=conf, state_dict=sd, device="cuda:0"), sd
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _run(model, x, lens, rows):
+    model.set_row_block(rows)
+    try:
+        probs, logits = model.get_encoder_out(x, lens, return_logits=True)
+        torch.cuda.synchronize()
+        return probs.cpu().numpy(), logits.cpu().numpy()
+    finally:
+        model.set_row_block(-1)
+
+
+@pytest.mark.parametrize("streaming,kernel,norm", [(True, 31, "layer_norm"), (False, 31, "layer_norm"), (True, 15, "batch_norm")])
+def test_16_row_blocks_match_32_row_blocks_and_the_oracle(streaming, kernel, norm):
+    model, sd = _model(streaming, kernel, norm)
+    x, lens = synth_features(len(LENS), 611, lens=LENS, seed=72)
+    p32, l32 = _run(model, x, lens, 32)
+    p16, l16 = _run(model, x, lens, 16)
+    pa, la = _run(model, x, lens, -1)   # the grid-size rule picks the 16-row kernels for every layer of this batch
+    assert np.array_equal(la, l16)
+    e = _rel(l16, l32)
+    print("16 vs 32 rows: max rel logit diff", e)
+    assert e < 2e-5
+    oracle = SqueezeformerOracle(sd, num_blocks=L, cnn_module_kernel=kernel, reduce_idx=RED, recover_idx=REC, causal=streaming)
+    with torch.no_grad():
+        enc, _ = oracle.encoder_forward(x, lens)[:2]
+        ref = oracle.ctc_logits(enc).numpy()
+    e16, e32 = _rel(l16, ref), _rel(l32, ref)
+    print("vs oracle: 16-row", e16, "32-row", e32)
+    assert e16 < 1e-3 and e32 < 1e-3
+    assert np.array_equal(p16.argmax(-1), p32.argmax(-1)) or (np.sort(p32, -1)[..., -1] - np.sort(p32, -1)[..., -2]).min() < 1e-5
+
+
+def test_ragged_mode_with_hint_computes_the_same_valid_rows():
+    """skip_padding + lengths hint: the hint only picks the kernel variant; valid rows equal the unhinted ragged run of the
+    same variant bit for bit, and the 16-row variant stays within rounding of the 32-row one."""
+    model, _ = _model()
+    # 24 utterances: with the hint the computed rows are ~78 blocks of 32 at the full rate and ~41 at the reduced one --
+    # inside the window where the rule picks 16-row blocks for every layer (<= 32 blocks would take the split route)
+    LENS = [611, 600, 333, 197, 611, 213, 250, 480, 611, 420, 177, 590, 611, 305, 250, 555, 380, 611, 444, 290, 505, 160, 611, 350]
+    x, lens = synth_features(len(LENS), 611, lens=LENS, seed=73)
+    fl = model.valid_out_frames(lens, 611).cpu().numpy()
+    model.set_skip_padding(True)
+    try:
+        model.set_row_block(16)
+        a = model.get_encoder_out(x, lens).cpu().numpy()
+        model.set_row_block(-1)
+        model.set_lengths_hint(LENS)
+        b = model.get_encoder_out(x, lens).cpu().numpy()   # hint: few active rows -> 16-row kernels
+        model.set_lengths_hint(None)
+        model.set_row_block(32)
+        c = model.get_encoder_out(x, lens).cpu().numpy()
+    finally:
+        model.set_row_block(-1)
+        model.set_lengths_hint(None)
+        model.set_skip_padding(False)
+    for u in range(len(LENS)):
+        n = int(fl[u])
+        assert np.array_equal(a[u, :n], b[u, :n])
+        assert _rel(a[u, :n], c[u, :n]) < 2e-5
+        assert not a[u, n:].any() and not b[u, n:].any() and not c[u, n:].any()
+
+
+def test_32_row_kernels_are_bit_identical_to_the_round3_kernels():
+    """PPASR_SQ_LEGACY=1 (read once at library load: separate processes) runs k_sq_mid / k_sq_tail of round 3."""
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from tests.test_row_block_gpu import _model, LENS\n"
+        "from ppasr_amd.utils.synth import synth_features\n"
+        "m, _ = _model()\n"
+        "x, lens = synth_features(len(LENS), 611, lens=LENS, seed=74)\n"
+        "m.set_row_block(32)\n"
+        "p, l = m.get_encoder_out(x, lens, return_logits=True)\n"
+        "torch.cuda.synchronize()\n"
+        "np.save(sys.argv[1], l.cpu().numpy())\n")
+    outs = []
+    for legacy in ("0", "1"):
+        path = f"/tmp/_sq_legacy_{legacy}.npy"
+        env = dict(os.environ, PPASR_SQ_LEGACY=legacy)
+        subprocess.check_call([sys.executable, "-c", code, path], env=env, cwd=ROOT)
+        outs.append(np.load(path))
+    assert np.array_equal(outs[0], outs[1]), _rel(outs[0], outs[1])

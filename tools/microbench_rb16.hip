@@ -1,0 +1,73 @@
+// Microbenchmark of the 16-row row-block GEMM core (csrc/rbt.h, v_mfma_f32_16x16x4_f32 on the 32-row kernels' packed
+// weights) next to the 32-row one, in the real kernels' pattern: every workgroup streams the same 4 MiB of weights
+// (one FFN's worth) through its register ring, A operand from LDS.  Reports TFLOP/s over the whole chip and the
+// fraction of the fp32-MFMA rate of the CUs that have work.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ppasr_amd/csrc tools/microbench_rb16.hip -o /tmp/mb16
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "rbt.h"
+using namespace ppasr;
+
+template <int R>
+__global__ __launch_bounds__(kThreads) void k_mb(const f32x4* __restrict__ w, float* __restrict__ out, int iters, int n_seg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wave = wave_id();
+  for (int i = threadIdx.x; i < R * kLda; i += kThreads) smem[i] = (float)(i % 13) * 0.01f;
+  __syncthreads();
+  typename RBT<R>::Ring ring;
+  const f32x4* base = w + (size_t)wave * kTs256;
+  rbt_prime(ring, base);
+  typename RBT<R>::Acc acc;
+  RBT<R>::zero(acc);
+  for (int it = 0; it < iters; ++it) {
+    const f32x4* seg = base + (size_t)((it % n_seg) * 8) * kTs256;
+    const f32x4* nxt = base + (size_t)(((it + 1) % n_seg) * 8) * kTs256;
+    rbt_gemm<kG256>(smem, kLda, seg, nxt, ring, acc);
+  }
+  float s = 0.f;
+  for (int q = 0; q < RBT<R>::NQ; ++q) {
+    const f32x4 v = RBT<R>::quad(acc, q);
+    s += v[0] + v[1] + v[2] + v[3];
+  }
+  out[(size_t)blockIdx.x * kThreads + threadIdx.x] = s;
+}
+
+template <int R>
+void run(const f32x4* w, float* out, int blocks, int iters, int n_seg, size_t lds, const char* name) {
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k_mb<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL((k_mb<R>), dim3(blocks), dim3(kThreads), lds, 0, w, out, iters, n_seg);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+  }
+  float ms; hipEventElapsedTime(&ms, a, b);
+  const double flops = (double)blocks * iters * (double)R * 256.0 * 256.0 * 2.0;
+  const double tf = flops / ms / 1e9;
+  const int cus = blocks < 256 ? blocks : 256;
+  printf("%-44s R=%2d blocks=%4d lds=%3zuK: %.3f ms  %6.1f TFLOP/s  = %.1f %% of the fp32-MFMA rate of %d CUs; %.2f us per unit\n", name, R,
+         blocks, lds / 1024, ms, tf, 100.0 * tf / (157.3 * cus / 256.0), cus, ms * 1e3 / iters / ((blocks + 255) / 256));
+}
+
+int main() {
+  const int n_seg = 16;
+  size_t n = (size_t)n_seg * 8 * kTs256 + 8 * kTs256;
+  std::vector<float> h(n * 4);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 1000) * 1e-3f - 0.5f;
+  f32x4* w; float* out;
+  hipMalloc(&w, n * 16); hipMalloc(&out, 4096 * kThreads * 4);
+  hipMemcpy(w, h.data(), n * 16, hipMemcpyHostToDevice);
+  const int iters = 256;
+  run<32>(w, out, 256, iters, n_seg, 133120, "32-row, one block per CU");
+  run<32>(w, out, 104, iters, n_seg, 133120, "32-row, 104 blocks (cfg5 half-rate layers)");
+  run<16>(w, out, 256, iters, n_seg, 133120, "16-row, one block per CU");
+  run<16>(w, out, 208, iters, n_seg, 133120, "16-row, 208 blocks");
+  run<16>(w, out, 512, iters, n_seg, 66560, "16-row, two blocks per CU (4 waves / SIMD)");
+  run<16>(w, out, 416, iters, n_seg, 66560, "16-row, 416 blocks at two per CU");
+  run<16>(w, out, 1024, iters, n_seg, 33280, "16-row, four blocks per CU");
+  run<32>(w, out, 512, iters, n_seg, 66560, "32-row, two blocks per CU");
+  return 0;
+}
