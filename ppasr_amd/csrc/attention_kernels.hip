@@ -35,19 +35,19 @@ namespace ppasr {
 // utterance's waves take different query blocks; 1: always 4 key splits), V k-groups in flight, waves per SIMD the
 // register allocation leaves room for, and the split rule (0: a wave walks <= 4 sub-blocks; 1: as many splits as sub-blocks)
 #ifndef PPASR_ATTN_MAXQ
-#define PPASR_ATTN_MAXQ 4
+#define PPASR_ATTN_MAXQ 1
 #endif
 #ifndef PPASR_ATTN_PQ
-#define PPASR_ATTN_PQ 8
+#define PPASR_ATTN_PQ 2
 #endif
 #ifndef PPASR_ATTN_OCC
-#define PPASR_ATTN_OCC 2
+#define PPASR_ATTN_OCC 4
 #endif
 #ifndef PPASR_ATTN_RULE
 #define PPASR_ATTN_RULE 1
 #endif
 #ifndef PPASR_ATTN_NT
-#define PPASR_ATTN_NT 2  // 32-key tiles per sub-block of the plain heads
+#define PPASR_ATTN_NT 1  // 32-key tiles per sub-block of the plain heads
 #endif
 
 template <int DK>
@@ -89,7 +89,10 @@ __global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) 
   // alternate between the XCDs' pair lists, which keeps a ragged batch balanced.
   const int nq = (a.T1 + 31) / 32;
   const int slot = blockIdx.x >> 3;
-  const int pair = __builtin_amdgcn_readfirstlane((slot / nq) * 8 + (blockIdx.x & 7));
+  // (boustrophedon over the groups of 8 pairs: with utterances sorted by length, XCD x gets pairs x, 15 - x, 16 + x, ...
+  //  instead of always the longer half of every group)
+  const int grp8 = slot / nq, x8 = blockIdx.x & 7;
+  const int pair = __builtin_amdgcn_readfirstlane(grp8 * 8 + ((grp8 & 1) ? 7 - x8 : x8));
   const int b = pair / H, h = pair - b * H;
   const int li = slot % nq;  // this workgroup's index among the pair's workgroups
   if (b >= B) return;
@@ -135,21 +138,7 @@ __global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) 
     frame = flat >> dm_shift;
     feat = flat & (dm - 1);
   };
-  float* Qt = Qs + qi * 32 * C::QLD;  // this wave's query block's tile, staged by the NS waves that share it
-  for (int idx = ks * 64 + lane; idx < 32 * (DK / 4); idx += 64 * NS) {
-    const int row = idx / (DK / 4), f4 = idx - row * (DK / 4);
-    f32x4 q = {0.f, 0.f, 0.f, 0.f};
-    if (q0 + row < T1) {
-      int frame = q0 + row, feat = h * DK + 4 * f4;
-      if (G != 1) split((q0 + row) * (G * dm) + h * DK + 4 * f4, frame, feat);
-      if (frame < F1) q = *reinterpret_cast<const f32x4*>(qb + (size_t)frame * a.q_stride + feat);
-    }
-    const f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + h * DK + 4 * f4);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + h * DK + 4 * f4);
-    *reinterpret_cast<f32x4*>(Qt + row * C::QLD + 4 * f4) = q + u;
-    *reinterpret_cast<f32x4*>(Qt + row * C::QLD + DK + 4 * f4) = q + v;
-  }
-  if (NS > 1) __syncthreads();  // (NS == 1: every wave staged its own tile -- the whole kernel is barrier-free)
+  float* Qt = Qs + qi * 32 * C::QLD;  // this wave's query block's tile, staged by the NS waves that share it (below)
 
   // ---- operand resources: one per 64-feature chunk (a chunk never straddles a frame of the grouped re-cut).  Chunk c3
   // of head h starts at flat feature c = h * DK + 64 c3 = (frame offset fo, feature feat0) of a token's G frames; rows
@@ -207,6 +196,23 @@ __global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) 
     key_offsets(sb_lo * C::SB);
     load_sg(0, 0);
   }
+  // Q' staging AFTER the first K' requests: the key rows' first cache lines are in flight while the query rows are
+  // fetched, summed with the position biases and parked in LDS
+  for (int idx = ks * 64 + lane; idx < 32 * (DK / 4); idx += 64 * NS) {
+    const int row = idx / (DK / 4), f4 = idx - row * (DK / 4);
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    if (q0 + row < T1) {
+      int frame = q0 + row, feat = h * DK + 4 * f4;
+      if (G != 1) split((q0 + row) * (G * dm) + h * DK + 4 * f4, frame, feat);
+      if (frame < F1) q = *reinterpret_cast<const f32x4*>(qb + (size_t)frame * a.q_stride + feat);
+    }
+    const f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + h * DK + 4 * f4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + h * DK + 4 * f4);
+    *reinterpret_cast<f32x4*>(Qt + row * C::QLD + 4 * f4) = q + u;
+    *reinterpret_cast<f32x4*>(Qt + row * C::QLD + DK + 4 * f4) = q + v;
+  }
+  if (NS > 1) __syncthreads();  // (NS == 1: every wave staged its own tile -- the whole kernel is barrier-free)
+
   for (int sb = sb_lo; sb < sb_hi; ++sb) {
     const int u0 = sb * C::SB;
     const bool edge = u0 + C::SB > kv_end;  // the sub-block holds masked keys (wave-uniform)

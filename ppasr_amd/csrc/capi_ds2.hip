@@ -123,15 +123,24 @@ ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd) {
       }
       UP4(pk, Lw.w_hh_pk);
     }
-    if (dirs == 1 && G == 4) {
+    if (dirs == 1) {
       wave[l] = Ds2WaveLayer{Lw.w_hh_pk, nullptr, nullptr, nullptr};
+      // packed column n = 32 t + 8 gate + u  <->  row gate * H + 8 t + u of the [G*H][.] weights; -1: the unused fourth gate
+      // slot of a GRU tile
+      auto rowof = [&](int n) { const int t = n / 32, r = n % 32; return r / 8 < G ? (r / 8) * H + 8 * t + (r % 8) : -1; };
+      if (G == 3) {
+        std::vector<float> bn(4 * H, 0.f);
+        for (int n = 0; n < 4 * H; ++n)
+          if (rowof(n) >= 0) bn[n] = bhh[0][rowof(n)];
+        UP(bn, wave[l].bhh_n);
+      }
       if (l > 0) {
         // W' = W_ih diag(gamma_{l-1}) in the gate-interleaved fragment order; s_n = its column sums;
-        // c_n = W_ih beta_{l-1} + b_ih + b_hh  (k_lstm_wave applies the LayerNorm through mean / rstd of the raw row)
+        // c_n = W_ih beta_{l-1} + b_ih (+ b_hh: LSTM)  (k_lstm_wave applies the LayerNorm through mean / rstd of the raw row)
         const float* wd = wih[0];
-        auto rowof = [&](int n) { const int t = n / 32, r = n % 32; return (r / 8) * H + 8 * t + (r % 8); };
-        std::vector<float> sn(4 * H), cn(4 * H);
+        std::vector<float> sn(4 * H, 0.f), cn(4 * H, 0.f);
         for (int n = 0; n < 4 * H; ++n) {
+          if (rowof(n) < 0) continue;
           const float* wr = wd + (size_t)rowof(n) * H;
           double a = 0.0, c0 = 0.0;
           for (int k = 0; k < H; ++k) {
@@ -139,9 +148,10 @@ ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd) {
             c0 += (double)prev_b[k] * (double)wr[k];
           }
           sn[n] = (float)a;
-          cn[n] = (float)(c0 + (double)bih[0][rowof(n)] + (double)bhh[0][rowof(n)]);
+          cn[n] = (float)(c0 + (double)bih[0][rowof(n)] + (G == 4 ? (double)bhh[0][rowof(n)] : 0.0));
         }
-        UP4(pack_b(H, 4 * H, [&](int k, int n) { return prev_g[k] * wd[(size_t)rowof(n) * H + k]; }), wave[l].wih_pk);
+        UP4(pack_b(H, 4 * H, [&](int k, int n) { return rowof(n) >= 0 ? prev_g[k] * wd[(size_t)rowof(n) * H + k] : 0.f; }),
+            wave[l].wih_pk);
         UP(sn, wave[l].s_n);
         UP(cn, wave[l].c_n);
       }
@@ -153,7 +163,7 @@ ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd) {
     prev_g = vec_of(lg, dirs * H);
     prev_b = vec_of(lb, dirs * H);
   }
-  if (dirs == 1 && H % 64 == 0 && G == 4) {
+  if (dirs == 1 && H % 64 == 0) {
     void* d = nullptr;
     if (hipMalloc(&d, L * sizeof(Ds2WaveLayer)) != hipSuccess) return fail(PPASR_EHIP, "hipMalloc failed");
     m->allocs.push_back(d);
@@ -236,25 +246,29 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
   // (the wavefront folds the input projections of layers >= 1 into the step: fewer dependent launches, but those
   //  projections then run on the step kernel's 32-row tiles instead of the dense GEMM; measured, 5 x 1024 LSTM, 5 s
   //  utterances: B = 32 6.6 ms against 9.2 per-step, B = 64 11.4 against 11.2, B = 128 21.9 against 21.0)
-  static const int wave_max_b = getenv("PPASR_DS2_WAVE_MAX_B") ? atoi(getenv("PPASR_DS2_WAVE_MAX_B")) : 48;
+  // (round 4: a workgroup of the wavefront kernel takes up to 128 utterances -- 1 / 2 / 4 row tiles -- and streams its gate
+  //  columns' weights once for all of them, so the wavefront wins at every batch size; nn.GRU stacks take it too.
+  //  PPASR_DS2_WAVE_MAX_B: the per-step route above that batch size, for A/B measurements)
+  static const int wave_max_b = getenv("PPASR_DS2_WAVE_MAX_B") ? atoi(getenv("PPASR_DS2_WAVE_MAX_B")) : (1 << 30);
   if (W.wave_tab && dirs == 1 && Tp > 0 && B >= 4 && B <= wave_max_b) {
     // ---- unidirectional stack: wavefront over (layer, time), Tp + L - 1 dependent launches (k_lstm_wave) ----
     const int L = W.n_layers;
     const Ds2LayerW& L0 = h->ds2_layers[0];
-    launch_dense(x, W.ldx, L0.w_ih, L0.b_sum, gx, M, L0.in_dim_padded, 4 * H, 4 * H, 4 * H, st, 1.0f, part, wl.part_floats);
+    launch_dense(x, W.ldx, L0.w_ih, L0.b_sum, gx, M, L0.in_dim_padded, G * H, G * H, G * H, st, 1.0f, part, wl.part_floats);
     float *hbuf = ws + wl.hbuf, *cbuf = ws + wl.cbuf, *yring = ws + wl.yring;
     const size_t BH = (size_t)B * H, BHp = (size_t)((B + 31) / 32) * 32 * H;  // row-major box / fragment-ordered slot
     for (int l = 0; l < L; ++l) {
       float* h_l = hbuf + (size_t)l * 2 * BHp;  // slot 0 = state before time 0 (fragment order, ds2_kernels.hip)
       HIP_TRY(hipMemsetAsync(h_l, 0, BHp * sizeof(float), st));
       if (init_h) launch_state_reorder(init_h + (size_t)l * BH, h_l, B, H, true, st);
+      // (GRU: no cell state; the c box is handed through unchanged, deepspeech2/encoder.py:95-97)
       if (init_c) HIP_TRY(hipMemcpyAsync(cbuf + (size_t)l * BH, init_c + (size_t)l * BH, BH * sizeof(float), hipMemcpyDeviceToDevice, st));
       else HIP_TRY(hipMemsetAsync(cbuf + (size_t)l * BH, 0, BH * sizeof(float), st));
     }
     HIP_TRY(hipMemsetAsync(out, 0, (size_t)M * H * sizeof(float), st));
     for (int s = 0; s < Tp + L - 1; ++s) {
       const int l_lo = s - (Tp - 1) > 0 ? s - (Tp - 1) : 0, l_hi = s < L - 1 ? s : L - 1;
-      launch_lstm_wave(gx, W.wave_tab, hbuf, cbuf, yring, out, lens32, B, Tp, H, L, s, l_lo, l_hi - l_lo + 1, st);
+      launch_lstm_wave(gx, W.wave_tab, hbuf, cbuf, yring, out, lens32, B, Tp, H, L, s, l_lo, l_hi - l_lo + 1, st, G == 3);
     }
     for (int l = 0; l < L; ++l) {
       if (final_h) launch_state_reorder(hbuf + ((size_t)l * 2 + (Tp & 1)) * BHp, final_h + (size_t)l * BH, B, H, false, st);

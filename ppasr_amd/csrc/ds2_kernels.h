@@ -23,7 +23,8 @@ struct Ds2WaveLayer {
   const f32x4* whh_pk;  // recurrent weights, fragment order, gate-interleaved tiles (as Ds2LayerW::w_hh_pk)
   const f32x4* wih_pk;  // layers >= 1: input weights with the previous layer's LayerNorm gamma folded in, same order
   const float* s_n;     // [4H] column sums of those folded weights (gate-interleaved order)
-  const float* c_n;     // [4H] b_ih + b_hh + W_ih * beta of the previous layer's LayerNorm
+  const float* c_n;     // [4H] b_ih + b_hh + W_ih * beta of the previous layer's LayerNorm (GRU: without b_hh)
+  const float* bhh_n = nullptr;  // GRU only: [4H] b_hh in the gate-interleaved column order (fourth slot zero)
 };
 struct Ds2W {
   const float *cmvn_mean, *cmvn_istd, *c1_w, *c1_b, *c2_w, *c2_b;
@@ -56,7 +57,7 @@ void launch_gru_step_mfma(const float* gx, const f32x4* whh_pk, const float* bhh
 //   gx0 [B*T][4H] layer-0 input projections; hbuf [L][2][B][H] (slot = time parity), cbuf [L][B][H],
 //   yring [L][2][B][H] raw outputs of the last two time steps, out [B*T][H] raw outputs of the last layer (pre-zeroed)
 void launch_lstm_wave(const float* gx0, const Ds2WaveLayer* tab, float* hbuf, float* cbuf, float* yring, float* out,
-                      const int32_t* lens, int B, int T, int H, int L, int s, int l_lo, int n_l, hipStream_t st);
+                      const int32_t* lens, int B, int T, int H, int L, int s, int l_lo, int n_l, hipStream_t st, bool gru = false);
 // [B][H] row-major <-> the MFMA-fragment order of the wavefront kernel's state buffers (hbuf / yring)
 void launch_state_reorder(const float* src, float* dst, int B, int H, bool to_frag, hipStream_t st);
 void launch_ln_wide(float* x, const float* g, const float* b, int M, int N, hipStream_t st);

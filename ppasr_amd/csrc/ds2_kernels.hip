@@ -322,13 +322,24 @@ __global__ __launch_bounds__(kThreads) void k_lstm_step_mfma(const float* __rest
 // the LayerNorm of the row enters through its mean / rstd, which the waves accumulate from the very A fragments they
 // load (sum and sum of squares per row).  Same workgroup shape as k_lstm_step_mfma.
 // Occupancy: at 152 VGPRs (prefetch depth 8) ONE workgroup fits a CU and the 5 x 128 workgroups of a launch ran as 2.5
-// rounds; capped at 3 workgroups per CU (depth 4) the launch is one round: 6.57 -> 5.70 ms per 32 x 5 s batch (round 3).
+// rounds (round 3: depth 4, 103 registers: two workgroups per CU, 1.25 rounds).  Round 4: one accumulator tile for both
+// products, buffer loads instead of 64-bit per-lane addresses and depth 2 keep the kernel at 80 registers = six waves per
+// SIMD = three workgroups per CU (their 53 KB of LDS allow no more), so a launch is ONE round; same-box A/B of the
+// depth, 5 x 1024 LSTM, 5 s utterances: B = 32 5.46 ms (depth 4) -> 5.00 (depth 2), B = 128 15.47 -> 15.22, depth 8
+// (spills) 12.2 / 42.3.
 #ifndef PPASR_WAVE_OCC
-#define PPASR_WAVE_OCC 3
+#define PPASR_WAVE_OCC 6
 #endif
 #ifndef PPASR_WAVE_PFD
-#define PPASR_WAVE_PFD 4
+#define PPASR_WAVE_PFD 2
 #endif
+// RT = 32-row tiles of the batch per workgroup (1, 2, 4): the 8 waves are RT row tiles x KS = 8 / RT slices of the
+// contraction, so a workgroup streams its 32 gate columns' weights ONCE for up to 128 utterances (round 3 ran one
+// workgroup per 32 utterances: at B = 128 every weight byte was fetched four times per launch and the wavefront lost to
+// the per-step kernel; the partial-tile buffer stays [KS][32 RT][33] = 34 KB whatever RT).
+// GRU: nn.GRU layers (gate slots r, z, c, unused).  The recurrent sums keep b_hh and stay separate from the input part,
+// because the candidate is tanh(x_c + r (W_hc h + b_hc)); h' = (h - c~) z + c~; no cell state.
+template <int RT, bool GRU>
 __global__ __launch_bounds__(kThreads, PPASR_WAVE_OCC) void k_lstm_wave(const float* __restrict__ gx0, const Ds2WaveLayer* __restrict__ tab,
                                                         float* __restrict__ hbuf, float* __restrict__ cbuf,
                                                         float* __restrict__ yring, float* __restrict__ out,
@@ -338,17 +349,20 @@ __global__ __launch_bounds__(kThreads, PPASR_WAVE_OCC) void k_lstm_wave(const fl
   // (4 + 4) was measured and is slower: 7.9 against 6.8 ms per 32 x 5 s batch
   // (ONE partial-tile buffer used twice -- for h W_hh^T, then for y W'_ih^T -- keeps the workgroup at 40 KB of LDS: the up
   //  to 5 x 128 workgroups of a launch then fit the chip in one round)
-  __shared__ float part[kWaves][32][33];
-  __shared__ float stat_s[kWaves][32], stat_q[kWaves][32];
-  __shared__ float gates[32][33];
-  const int tile = blockIdx.x, l = l_lo + blockIdx.y, t = s - l, b0 = blockIdx.z * 32;
+  constexpr int KS = kWaves / RT, NR = 32 * RT, NGATE = GRU ? 3 : 4;
+  __shared__ float part[KS * NR * 33];
+  __shared__ float stat_s[KS * NR], stat_q[KS * NR];
+  __shared__ float gates[NR * 33];  // gate pre-activations (GRU: the input part x; the recurrent part W_hh h + b_hh is
+                                    // parked in slice 0 of `part`: element (row, col) is read and rewritten by ONE thread)
+  const int tile = blockIdx.x, l = l_lo + blockIdx.y, t = s - l, b0 = blockIdx.z * NR;
   const Ds2WaveLayer lay = tab[l];
   const int lane = lane_id(), wave = wave_id();
   const int l31 = lane & 31, hh = lane >> 5;
-  const int n_groups = H / 8, gpw = n_groups / kWaves, g0 = wave * gpw;
-  const int b = b0 + l31;
+  const int rt = wave % RT, kq = wave / RT;  // this wave's row tile and K slice
+  const int n_groups = H / 8, gpw = n_groups / KS, g0 = kq * gpw;
+  const int b = b0 + 32 * rt + l31;
   const bool row_live = b < B && t < lens[min(b, B - 1)];
-  // hbuf / yring hold the states and layer outputs in MFMA FRAGMENT order -- [row tile z][k-group][64 lanes = row + 32 *
+  // hbuf / yring hold the states and layer outputs in MFMA FRAGMENT order -- [row tile][k-group][64 lanes = row + 32 *
   // (k quad)][4 k] -- so that a wave's A-operand load is 1 KiB contiguous like its weight load (row-major, every lane of a
   // load touched its own 4 KiB-strided row: 32 cache lines per instruction, 64 such instructions per wave and launch)
   const size_t BH = (size_t)((B + 31) / 32) * 32 * H;
@@ -357,123 +371,150 @@ __global__ __launch_bounds__(kThreads, PPASR_WAVE_OCC) void k_lstm_wave(const fl
   float* cc = cbuf + (size_t)l * B * H;  // (the cell state stays row-major: it is only read and written element-wise)
   const float* yprev = l > 0 ? yring + ((size_t)(l - 1) * 2 + (t & 1)) * BH : nullptr;
   float* ycur = yring + ((size_t)l * 2 + (t & 1)) * BH;
-  const size_t fragoff = (size_t)blockIdx.z * n_groups * 256 + (size_t)lane * 4;  // + 256 * k-group
-  const f32x4* wh = lay.whh_pk + (size_t)tile * n_groups * 64 + lane;
-  const f32x4* wi = lay.wih_pk + (size_t)tile * n_groups * 64 + lane;
-  f32x16 acc_h, acc_i;
+  // ONE accumulator tile, used for h W_hh^T and then for y W'_ih^T: the first product's partial tile goes to LDS and is
+  // summed into two values per thread BEFORE the second product starts, so the kernel stays inside 85 registers = six waves
+  // per SIMD = three workgroups per CU, and the 5 x 128 workgroups of a launch are one round (at 103 registers -- both
+  // tiles live -- two workgroups fitted a CU and every launch ran a second, quarter-full round)
+  f32x16 acc;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc_h[r] = acc_i[r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   constexpr int PFD = PPASR_WAVE_PFD;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto pidx = [&](int k, int row, int col) { return (k * NR + row) * 33 + col; };
+  // operands through BUFFER loads: wave-uniform bases (row tile / column tile folded in) in SGPRs, ONE per-lane 32-bit offset
+  // (lane * 16; out of range for the rows of finished utterances, which then read zeros), the k-group as the scalar offset --
+  // no 64-bit per-lane addresses to keep (and spill) across the loops, no per-load address arithmetic
+  const int voff_a = row_live ? lane * 16 : 0x7fffffff, voff_w = lane * 16;
+  const size_t rtile_f = (size_t)(blockIdx.z * RT + rt) * n_groups * 256;  // floats in front of this wave's row tile
   {  // ---- h_{t-1} W_hh^T ----
+    const __amdgpu_buffer_rsrc_t rs_a = wstream_rsrc(hprev + rtile_f), rs_w = wstream_rsrc(lay.whh_pk + (size_t)tile * n_groups * 64);
     f32x4 ra[PFD], rb[PFD];
 #pragma unroll
     for (int q = 0; q < PFD; ++q) {
-      ra[q] = row_live ? *reinterpret_cast<const f32x4*>(hprev + fragoff + 256 * (size_t)(g0 + q)) : zero4;
-      rb[q] = wh[(size_t)(g0 + q) * 64];
+      ra[q] = wstream_load(rs_a, voff_a, (g0 + q) * 1024);
+      rb[q] = wstream_load(rs_w, voff_w, (g0 + q) * 1024);
     }
     for (int g = 0; g < gpw; g += PFD) {
 #pragma unroll
       for (int q = 0; q < PFD; ++q) {
         const f32x4 a = ra[q], bq = rb[q];
         if (g + PFD + q < gpw) {
-          ra[q] = row_live ? *reinterpret_cast<const f32x4*>(hprev + fragoff + 256 * (size_t)(g0 + g + PFD + q)) : zero4;
-          rb[q] = wh[(size_t)(g0 + g + PFD + q) * 64];
+          ra[q] = wstream_load(rs_a, voff_a, (g0 + g + PFD + q) * 1024);
+          rb[q] = wstream_load(rs_w, voff_w, (g0 + g + PFD + q) * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc_h = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bq[j], acc_h, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bq[j], acc, 0, 0, 0);
       }
     }
   }
-  float sum = 0.f, sq = 0.f;
-  if (l > 0) {  // ---- y_{l-1}[t] W'_ih^T on the raw row, LayerNorm statistics on the side ----
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[pidx(kq, 32 * rt + acc_row(r, lane), l31)] = acc[r];
+  __syncthreads();
+  constexpr int EPT = 2 * RT;  // tile elements per thread: NR x 32 over 512 threads
+  float vh2[EPT];
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int e = threadIdx.x + q * kThreads, row = e >> 5, col = e & 31;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < KS; ++w) v += part[pidx(w, row, col)];
+    vh2[q] = v;
+  }
+  if (l > 0) {  // ---- y_{l-1}[t] W'_ih^T on the raw row, LayerNorm statistics on the side ---- (block-uniform)
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const __amdgpu_buffer_rsrc_t rs_a = wstream_rsrc(yprev + rtile_f), rs_w = wstream_rsrc(lay.wih_pk + (size_t)tile * n_groups * 64);
     f32x4 ra[PFD], rb[PFD];
 #pragma unroll
     for (int q = 0; q < PFD; ++q) {
-      ra[q] = row_live ? *reinterpret_cast<const f32x4*>(yprev + fragoff + 256 * (size_t)(g0 + q)) : zero4;
-      rb[q] = wi[(size_t)(g0 + q) * 64];
+      ra[q] = wstream_load(rs_a, voff_a, (g0 + q) * 1024);
+      rb[q] = wstream_load(rs_w, voff_w, (g0 + q) * 1024);
     }
     for (int g = 0; g < gpw; g += PFD) {
 #pragma unroll
       for (int q = 0; q < PFD; ++q) {
         const f32x4 a = ra[q], bq = rb[q];
         if (g + PFD + q < gpw) {
-          ra[q] = row_live ? *reinterpret_cast<const f32x4*>(yprev + fragoff + 256 * (size_t)(g0 + g + PFD + q)) : zero4;
-          rb[q] = wi[(size_t)(g0 + g + PFD + q) * 64];
+          ra[q] = wstream_load(rs_a, voff_a, (g0 + g + PFD + q) * 1024);
+          rb[q] = wstream_load(rs_w, voff_w, (g0 + g + PFD + q) * 1024);
         }
         sum += a[0] + a[1] + a[2] + a[3];
         sq += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc_i = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bq[j], acc_i, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bq[j], acc, 0, 0, 0);
       }
     }
     sum += __shfl_xor(sum, 32);
     sq += __shfl_xor(sq, 32);
     if (hh == 0) {
-      stat_s[wave][l31] = sum;
-      stat_q[wave][l31] = sq;
+      stat_s[kq * NR + 32 * rt + l31] = sum;
+      stat_q[kq * NR + 32 * rt + l31] = sq;
     }
-  }
+    __syncthreads();  // every thread has read the first product's partial tiles
 #pragma unroll
-  for (int r = 0; r < 16; ++r) part[wave][acc_row(r, lane)][l31] = acc_h[r];
-  __syncthreads();
-  float vh2[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int e = threadIdx.x + q * kThreads, row = e >> 5, col = e & 31;
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) v += part[w][row][col];
-    vh2[q] = v;
-  }
-  if (l > 0) {  // (block-uniform)
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) part[wave][acc_row(r, lane)][l31] = acc_i[r];
+    for (int r = 0; r < 16; ++r) part[pidx(kq, 32 * rt + acc_row(r, lane), l31)] = acc[r];
     __syncthreads();
   }
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < EPT; ++q) {
     const int e = threadIdx.x + q * kThreads;
     const int row = e >> 5, col = e & 31;
     const int bb = b0 + row;
-    float vi = 0.f;
-    float v = vh2[q];
+    float vi = 0.f;   // input part (x W_ih^T + b_ih [+ b_hh for the LSTM])
+    float v = vh2[q];  // recurrent part
     if (bb < B && t < lens[bb]) {
       const int n = tile * 32 + col;  // gate-interleaved column
       if (l == 0) {
-        v += gx0[((size_t)bb * T + t) * 4 * H + (size_t)(col >> 3) * H + tile * 8 + (col & 7)];
+        if (!GRU || (col >> 3) < 3) vi = gx0[((size_t)bb * T + t) * NGATE * H + (size_t)(col >> 3) * H + tile * 8 + (col & 7)];
       } else {
-        float ss = 0.f, qq = 0.f;
+        float ss = 0.f, qq = 0.f, acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-          vi += part[w][row][col];
-          ss += stat_s[w][row];
-          qq += stat_q[w][row];
+        for (int w = 0; w < KS; ++w) {
+          acc += part[pidx(w, row, col)];
+          ss += stat_s[w * NR + row];
+          qq += stat_q[w * NR + row];
         }
         const float mean = ss / (float)H;
         const float var = fmaxf(qq / (float)H - mean * mean, 0.f);
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
-        v += rstd * (vi - mean * lay.s_n[n]) + lay.c_n[n];
+        vi = rstd * (acc - mean * lay.s_n[n]) + lay.c_n[n];
       }
+      if (GRU) v += lay.bhh_n[n];
     }
-    gates[row][col] = v;
+    if (GRU) {
+      gates[row * 33 + col] = vi;
+      part[pidx(0, row, col)] = v;
+    } else {
+      gates[row * 33 + col] = v + vi;
+    }
   }
   __syncthreads();
-  if (threadIdx.x < 32 * 8) {
-    const int row = threadIdx.x >> 3, u = threadIdx.x & 7;
+  for (int idx = threadIdx.x; idx < NR * 8; idx += kThreads) {
+    const int row = idx >> 3, u = idx & 7;
     const int bb = b0 + row;
     if (bb < B) {
       const int len = lens[bb];
       const size_t si = (size_t)bb * H + tile * 8 + u;                                     // row-major (cell state)
-      const size_t fi = ((size_t)blockIdx.z * n_groups + tile) * 256 + (row + 32 * (u >> 2)) * 4 + (u & 3);  // fragment order
+      const size_t fi = ((size_t)(blockIdx.z * RT + (row >> 5)) * n_groups + tile) * 256 + ((row & 31) + 32 * (u >> 2)) * 4 + (u & 3);  // fragment order
       if (t >= len) {
         hnext[fi] = hprev[fi];  // finished utterance: carry the state (final state = last valid step)
+      } else if (GRU) {
+        const float* gxr = gates + row * 33;
+        const float* ghr = part + row * 33;  // (= pidx(0, row, .))
+        const float gr = 1.0f / (1.0f + expf(-(gxr[u] + ghr[u])));
+        const float gz = 1.0f / (1.0f + expf(-(gxr[8 + u] + ghr[8 + u])));
+        const float cand = tanhf(gxr[16 + u] + gr * ghr[16 + u]);
+        const float hv = (hprev[fi] - cand) * gz + cand;
+        hnext[fi] = hv;
+        ycur[fi] = hv;
+        if (l == L - 1) out[((size_t)bb * T + t) * (size_t)H + tile * 8 + u] = hv;
       } else {
-        const float gi = 1.0f / (1.0f + expf(-gates[row][0 + u]));
-        const float gf = 1.0f / (1.0f + expf(-gates[row][8 + u]));
-        const float gg = tanhf(gates[row][16 + u]);
-        const float go = 1.0f / (1.0f + expf(-gates[row][24 + u]));
+        const float* gr_ = gates + row * 33;
+        const float gi = 1.0f / (1.0f + expf(-gr_[0 + u]));
+        const float gf = 1.0f / (1.0f + expf(-gr_[8 + u]));
+        const float gg = tanhf(gr_[16 + u]);
+        const float go = 1.0f / (1.0f + expf(-gr_[24 + u]));
         const float cn = gf * cc[si] + gi * gg;
         const float hv = go * tanhf(cn);
         cc[si] = cn;
@@ -544,9 +585,18 @@ void launch_gru_step_mfma(const float* gx, const f32x4* whh_pk, const float* bhh
                hnext, nullptr, y, lens, B, T, H, dirs, step);
 }
 void launch_lstm_wave(const float* gx0, const Ds2WaveLayer* tab, float* hbuf, float* cbuf, float* yring, float* out,
-                      const int32_t* lens, int B, int T, int H, int L, int s, int l_lo, int n_l, hipStream_t st) {
-  PPASR_LAUNCH(k_lstm_wave, dim3(H / 8, n_l, (B + 31) / 32), dim3(kThreads), 0, st, gx0, tab, hbuf, cbuf, yring, out, lens,
-                     B, T, H, L, s, l_lo);
+                      const int32_t* lens, int B, int T, int H, int L, int s, int l_lo, int n_l, hipStream_t st, bool gru) {
+  // row tiles per workgroup: the whole batch up to 128 utterances streams a layer's weights once
+  const int rt = B <= 32 ? 1 : (B <= 64 ? 2 : 4);
+  const dim3 grid(H / 8, n_l, (B + 32 * rt - 1) / (32 * rt));
+#define WAVE_LAUNCH(RT, GRU) \
+  PPASR_LAUNCH((k_lstm_wave<RT, GRU>), grid, dim3(kThreads), 0, st, gx0, tab, hbuf, cbuf, yring, out, lens, B, T, H, L, s, l_lo)
+  if (gru) {
+    if (rt == 1) WAVE_LAUNCH(1, true); else if (rt == 2) WAVE_LAUNCH(2, true); else WAVE_LAUNCH(4, true);
+  } else {
+    if (rt == 1) WAVE_LAUNCH(1, false); else if (rt == 2) WAVE_LAUNCH(2, false); else WAVE_LAUNCH(4, false);
+  }
+#undef WAVE_LAUNCH
 }
 // [B][H] row-major <-> the fragment order of k_lstm_wave's state buffers (initial / final state boxes)
 __global__ __launch_bounds__(256) void k_state_reorder(const float* __restrict__ src, float* __restrict__ dst, int B, int H,

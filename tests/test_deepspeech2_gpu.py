@@ -113,3 +113,35 @@ def test_deepspeech2_rnn_size_2048(streaming, gru, B):
     print(f"H=2048 streaming={streaming} gru={gru} B={B}: probs {e:.2e}")
     assert e < TOL
     assert _rel(fh.cpu().numpy(), rh.numpy()) < TOL
+
+
+@pytest.mark.parametrize("gru,B", [(False, 40), (False, 70), (True, 6), (True, 45), (True, 100)])
+def test_deepspeech2_wavefront_row_tiles_and_gru(gru, B):
+    """Round 4: the (layer, time) wavefront takes every batch size -- a workgroup holds 1 / 2 / 4 row tiles of 32 utterances
+    (B <= 32 / <= 64 / more) and streams its gate columns' weights once for all of them -- and nn.GRU stacks as well
+    (recurrent part kept apart from the input part for the candidate gate).  Ragged lengths, three layers, the final
+    states of one call as the initial states of the next, against the oracle (whose cell arithmetic is pinned to the
+    reference's CRNNEncoder through the shim)."""
+    V, L = 70, 3
+    sd = deepspeech2_state_dict(vocab_size=V, num_rnn_layers=L, streaming=True, seed=397, perturb_norm=True, use_gru=gru)
+    from ppasr_amd.model_utils.deepspeech2.model import DeepSpeech2Model
+    model = DeepSpeech2Model(80, V, streaming=True, encoder_conf=dict(num_rnn_layers=L, rnn_size=1024, use_gru=gru),
+                             state_dict=sd, device="cuda:0")
+    oracle = DeepSpeech2Oracle(sd, L, 1024, True, use_gru=gru)
+    x, _ = synth_features(B, 118, seed=398)
+    rng = np.random.default_rng(B)
+    h = c = rh = rc = None
+    for s0 in (0, 59):
+        chunk = x[:, s0:s0 + 59]
+        la = rng.integers(7, 60, size=B)
+        la[0] = 59
+        probs, ol, h, c = model.get_encoder_out_chunk(chunk, la, h, c)
+        rp, rl, rh, rc = oracle.forward(chunk, la, rh, rc)
+        torch.cuda.synchronize()
+        assert ol.cpu().tolist() == rl.tolist()
+        e = _rel(probs.cpu().numpy(), rp.numpy())
+        print(f"gru={gru} B={B}: probs {e:.2e}")
+        assert e < TOL
+        assert _rel(h.cpu().numpy(), rh.numpy()) < TOL
+        if not gru:
+            assert _rel(c.cpu().numpy(), rc.numpy()) < TOL

@@ -1,0 +1,65 @@
+"""Every committed bench line is reproducible from its sibling rocprofv3 kernel trace: for each
+profiles/rNN*_bench.json whose roofline names kernel instances, the dominant kernel's launches per step x its average
+dispatch duration in profiles/rNN*_kernel_trace_bench.txt must fit inside the step the line reports -- a roofline whose
+kernel time exceeds `ms_per_step` cannot be evidence for that step."""
+import glob
+import json
+import os
+import re
+
+import pytest
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PAIRS = [(f, f.replace("_bench.json", "_kernel_trace_bench.txt")) for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench.json")))]
+PAIRS = [(b, t) for b, t in PAIRS if os.path.exists(t)]
+
+
+def _short(full):
+    n = full.strip()
+    if n.endswith(")"):
+        depth = 0
+        for i in range(len(n) - 1, -1, -1):
+            depth += (n[i] == ")") - (n[i] == "(")
+            if depth == 0:
+                n = n[:i]
+                break
+    return re.sub(r"^void ", "", n).replace("ppasr::", "")
+
+
+def _trace(path):
+    out = {}
+    for line in open(path):
+        parts = [p.strip() for p in line.split("|")]
+        if len(parts) == 5 and not line.startswith("#") and "ppasr::" in parts[0]:
+            out[_short(parts[0])] = (int(parts[1]), float(parts[3]))
+    return out
+
+
+@pytest.mark.parametrize("bench_json,trace_txt", PAIRS, ids=[os.path.basename(b) for b, _ in PAIRS])
+def test_dominant_kernel_time_fits_the_step(bench_json, trace_txt):
+    line = json.load(open(bench_json))
+    roof = line.get("roofline") or {}
+    inst = roof.get("kernel_instances")
+    if not inst:
+        pytest.skip("round-1 / round-2 line without kernel_instances")
+    tr = _trace(trace_txt)
+    found = [k for k in inst if k in tr]
+    assert found, (inst, sorted(tr)[:5])
+    dom = roof["kernel"]
+    launches = roof["classes"][dom]["launches_per_step"]
+    calls = sum(tr[k][0] for k in found)
+    avg_us = sum(tr[k][0] * tr[k][1] for k in found) / calls
+    per_step_ms = launches * avg_us * 1e-3
+    assert per_step_ms <= 1.10 * line["ms_per_step"], (dom, launches, avg_us, line["ms_per_step"])
+    # and the line's own figure for that kernel agrees with the profiler's (marker stretch and box-to-box spread: 25 %).
+    # (Not for the one-workgroup-per-utterance beam search of the pipelined round-3 lines: overlapped with the encoder's
+    #  kernels it runs 30 - 40 % longer under the profiler; round 4 names the encoder's largest kernel instead.)
+    if not dom.startswith("k_ctc_beam"):
+        assert abs(roof["avg_launch_ms"] * 1e3 - avg_us) <= 0.25 * avg_us + 1.2, (roof["avg_launch_ms"], avg_us)
+    # every profiled ppasr kernel has an accounting class that the line lists
+    for name in tr:
+        if name.startswith("k_posproj"):
+            continue  # (create-time constant folding, not a per-step kernel)
+        assert bench.class_of(name) in roof["classes"], name

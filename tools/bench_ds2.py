@@ -25,10 +25,12 @@ PEAK_TF, PEAK_GBS = 157.3, 8000.0
 
 
 def shapes():
-    yield dict(streaming=False, use_gru=False, B=1)
-    yield dict(streaming=False, use_gru=True, B=1)
-    for gru in (False, True):
-        for B in (32, 128):
+    uni_only = "uni" in sys.argv[1:]  # (kernel-variant A/B runs: the unidirectional LSTM shapes only)
+    if not uni_only:
+        yield dict(streaming=False, use_gru=False, B=1)
+        yield dict(streaming=False, use_gru=True, B=1)
+    for gru in ((False,) if uni_only else (False, True)):
+        for B in ((32, 64, 128) if uni_only else (32, 128)):
             yield dict(streaming=True, use_gru=gru, B=B)
 
 

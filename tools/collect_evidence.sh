@@ -34,7 +34,7 @@ for cfg in $cfgs; do
   { echo "# FETCH_SIZE and WRITE_SIZE collected in two separate rocprofv3 --pmc passes (tools/collect_evidence.sh $tag $cfg); unit KiB per dispatch.";
     echo "# gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of wide coalesced reads -> HBM read bytes = 2 x FETCH_SIZE.";
     grep "| FETCH_SIZE |" gpurun_out/pmc_fetch_$pre.txt; grep "| WRITE_SIZE |" gpurun_out/pmc_write_$pre.txt; } > profiles/${pre}_pmc_hbm_traffic.txt
-  python tools/make_hbm_traffic.py gpurun_out/pmc_fetch_$pre.txt gpurun_out/pmc_write_$pre.txt $tag $cfg > gpurun_out/hbm_traffic_$pre.json
+  python tools/make_hbm_traffic.py gpurun_out/pmc_fetch_$pre.txt gpurun_out/pmc_write_$pre.txt $tag $cfg gpurun_out/prof_$pre.txt > gpurun_out/hbm_traffic_$pre.json
   # the bench line again, now that the traffic evidence belongs to this build
   python bench.py --config $cfg > $R/gpurun_out/bench_$pre.json 2>> $R/gpurun_out/bench_$pre.err
   cp gpurun_out/bench_$pre.json profiles/${pre}_bench.json

@@ -2,7 +2,10 @@
 tools/collect_evidence.sh, stamped with the digest of the kernel sources they were collected on (bench.py only reports
 `roofline.traffic` when the stamp matches the build it is running).
 
-    python tools/make_hbm_traffic.py gpurun_out/pmc_fetch_TAG.txt gpurun_out/pmc_write_TAG.txt TAG [CFG]
+    python tools/make_hbm_traffic.py gpurun_out/pmc_fetch_TAG.txt gpurun_out/pmc_write_TAG.txt TAG [CFG [KERNEL_TRACE.txt]]
+
+With the kernel-trace summary of the same evidence pass (tools/rocpd_summary.py output) every class also carries
+`rocprof_avg_us` / `rocprof_calls`, which bench.py prints next to its own HIP-event figure (`avg_launch_ms_rocprof`).
 
 Entries are keyed by bench.py's kernel classes (bench.class_of).  HBM read bytes = 2 x FETCH_SIZE KiB (gfx950
 correction, MI355X_MICROARCH.md HBM section); written bytes = WRITE_SIZE KiB."""
@@ -46,9 +49,23 @@ def parse(path, counter):
     return {k: v[1] / v[0] for k, v in out.items() if v[0]}
 
 
+def parse_trace(path):
+    """{class: (calls, avg_us)} from a '# name | calls | total_us | avg_us | pct' summary"""
+    out = {}
+    for line in open(path):
+        parts = [p.strip() for p in line.split("|")]
+        if len(parts) == 5 and "ppasr::" in parts[0] and not line.startswith("#"):
+            cls = class_of(short_name(parts[0]))
+            a = out.setdefault(cls, [0, 0.0])
+            a[0] += int(parts[1])
+            a[1] += float(parts[2])
+    return {k: (v[0], v[1] / v[0]) for k, v in out.items() if v[0]}
+
+
 def main():
     fetch, write, tag = sys.argv[1], sys.argv[2], sys.argv[3]
     cfg = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
+    trace = parse_trace(sys.argv[5]) if len(sys.argv) > 5 and os.path.exists(sys.argv[5]) else {}
     f, w = parse(fetch, "FETCH_SIZE"), parse(write, "WRITE_SIZE")
     src = f"profiles/{tag}_pmc_hbm_traffic.txt" if cfg == "cfg2" else f"profiles/{tag}_{cfg}_pmc_hbm_traffic.txt"
     doc = {"_source": f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; read bytes = "
@@ -57,6 +74,8 @@ def main():
     for cls in sorted(set(f) | set(w)):
         fk, wk = f.get(cls, 0.0), w.get(cls, 0.0)
         doc[cls] = {"fetch_kib": round(fk), "write_kib": round(wk), "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+        if cls in trace:
+            doc[cls].update(rocprof_calls=trace[cls][0], rocprof_avg_us=round(trace[cls][1], 3))
     name = "hbm_traffic.json" if cfg == "cfg2" else f"hbm_traffic_{cfg}.json"
     with open(os.path.join(ROOT, "profiles", name), "w") as fh:
         json.dump(doc, fh, indent=2)
