@@ -648,10 +648,14 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       return h->layer_group[layer] == 1 && h->desc.attention_heads == 4 && !h->taps && ffn_split_for(h, Mi) == 1 &&
              (h->ffn_split == 0 || (Mi + kRows - 1) / kRows > fuse_min_blocks);  // (ppasr_set_ffn_split(0): always fused)
     };
-    const bool fuse_attn = fusable(i);
     const PadSkip ps = pskip(Ti, mul);
+    // under-filled launch, 33 .. 128 row blocks: the 16-row-block kernels (conformer_kernels_t.hip) -- twice the
+    // workgroups, each half as long -- with the stand-alone attention between them; up to 32 blocks the split route below
+    const bool r16 = !h->taps && h->ffn_split < 0 && conv_ffn_16_supported(h->layer_ks[i], Ti) &&
+                     row_block_for(h, B, Ti, mul, ps.slack, skip) == 16;
+    const bool fuse_attn = !r16 && fusable(i);
     // under-filled grid: FFNs split over S workgroups per row block (partial sums in the conv1 buffer, free by now)
-    const int S = ffn_split_for(h, Mi);
+    const int S = r16 ? 1 : ffn_split_for(h, Mi);
     float* partial = y1;
     float* x3 = ctx;
     if (!s1_done) {
@@ -661,6 +665,8 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
                            xb, Mi, n_chunks, S, st, ps);
           launch_ln_qkv(xb, qkv, L, Mi, st, ps);
         });
+      } else if (r16) {
+        timed(3, [&] { launch_ffn_qkv_16(xa, xb, qkv, L, Mi, n_chunks, st, ps); });
       } else {
         timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st, ps, fuse_attn ? vt_out : VtOut{}); });
       }
@@ -681,7 +687,8 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       tap(ctx, (size_t)Mi * kD);
       // (under-filled launch: pointwise_conv1 + GLU as its own two-column-half launch; the LayerNorm'd rows pass through
       //  xa, which is free between this layer's S1 and its output)
-      timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, L, lens, Mi, Ti, mul, st, ps, S > 1 ? xa : nullptr); });
+      if (r16) timed(5, [&] { launch_out_glu_16(ctx, xb, xc, g, L, lens, Mi, Ti, mul, st, ps); });
+      else timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, L, lens, Mi, Ti, mul, st, ps, S > 1 ? xa : nullptr); });
     }
     tap(xc, (size_t)Mi * kD);
     tap(g, (size_t)Mi * kD);
@@ -705,8 +712,12 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       const LayerW* next = (i + 1 < h->desc.num_blocks) ? &h->layers[i + 1] : nullptr;
       timed(next ? 8 : 6, [&] {
         // with the next layer's S1 fused in, the layer output itself is only read by the debug taps: skip its store
-        launch_conv_ffn(g, nullptr, xc, (next && !h->taps) ? nullptr : xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul,
-                        next, xb, qkv, st, h->desc.causal != 0, ps, (next && fusable(i + 1)) ? vt_out : VtOut{});
+        if (r16)
+          launch_conv_ffn_16(g, xc, next ? nullptr : xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul, next, xb, qkv, st,
+                             h->desc.causal != 0, ps);
+        else
+          launch_conv_ffn(g, nullptr, xc, (next && !h->taps) ? nullptr : xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul,
+                          next, xb, qkv, st, h->desc.causal != 0, ps, (next && fusable(i + 1)) ? vt_out : VtOut{});
       });
       s1_done = next != nullptr;
     }

@@ -103,6 +103,17 @@ size_t ragged_lds(size_t lds, const PadSkip& ps, int n_blocks);
 bool launch_attention_t(const AttnArgs& a, int B, int H, hipStream_t st);
 hipError_t configure_attention_kernels();
 
+// conformer_kernels_t.hip: the layer kernels on 16-row blocks (under-filled launches; values row-major in qkv)
+void launch_ffn_qkv_16(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
+                       const PadSkip& ps);
+void launch_out_glu_16(const float* ctx, const float* x1, float* x2, float* g, const LayerW& w, const int64_t* lens, int M,
+                       int Tp, int mask_mul, hipStream_t st, const PadSkip& ps);
+bool conv_ffn_16_supported(int ksize, int Tp);
+void launch_conv_ffn_16(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int M, int Tp,
+                        int n_chunks, int ksize, int mask_mul, const LayerW* next, float* x1_next, float* qkv_next,
+                        hipStream_t st, bool causal, const PadSkip& ps);
+hipError_t configure_conformer_t_kernels();
+
 // ---- launchers (all asynchronous on `st`) ----
 void launch_posproj(const float* pe, const float* wpos /*[d][d] in,out*/, const float* bpos_or_null, float* ptab,
                     int max_len, hipStream_t st, int d = 256);

@@ -2292,6 +2292,8 @@ void launch_ctc_collapse(const int32_t* fr_argmax, const float* fr_maxprob, cons
 hipError_t configure_kernels() {
   hipError_t e = configure_attention_kernels();
   if (e != hipSuccess) return e;
+  e = configure_conformer_t_kernels();
+  if (e != hipSuccess) return e;
 #define SET_LDS(fn, bytes)                                                                                     \
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
   if (e != hipSuccess) return e;

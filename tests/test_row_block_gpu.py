@@ -116,3 +116,44 @@ def test_32_row_kernels_are_bit_identical_to_the_round3_kernels():
         subprocess.check_call([sys.executable, "-c", code, path], env=env, cwd=ROOT)
         outs.append(np.load(path))
     assert np.array_equal(outs[0], outs[1]), _rel(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("family", ["conformer", "conformer_noncausal_k31", "efficient"])
+def test_conformer_family_16_row_blocks(family):
+    """The Conformer / Efficient-Conformer layer kernels on 16-row blocks (csrc/conformer_kernels_t.hip: k_ffn_qkv_t,
+    k_out_glu_t, k_conv_ffn_t with the next layer's S1 fused in, the stand-alone attention between them) against the fused
+    32-row route (ppasr_set_ffn_split(0)) and the oracle; the grid-size rule picks them by itself for 33 .. 128 row blocks."""
+    from oracle.conformer_oracle import ConformerOracle
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    from ppasr_amd.utils.synth import conformer_state_dict, efficient_conformer_state_dict
+    V, L = 211, 4
+    lens = [611, 600, 333, 97, 611, 13, 250, 480, 611, 420, 77, 590]   # 12 x 152 frames = 57 blocks of 32 rows
+    if family == "efficient":
+        from oracle.efficient_conformer_oracle import EfficientConformerOracle
+        from ppasr_amd.model_utils.efficient_conformer.model import EfficientConformerModel
+        sd = efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=81, perturb_norm=True, stride_layer_idx=1,
+                                            group_layer_idx=(0, 1))
+        conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15,
+                    cnn_module_norm="layer_norm",
+                    efficient_conf=dict(stride_layer_idx=[1], stride=[2], group_layer_idx=[0, 1], group_size=3, stride_kernel=True))
+        model = EfficientConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+        oracle = EfficientConformerOracle(sd, num_blocks=L, stride_layer_idx=1, group_layer_idx=(0, 1))
+        lens = lens + lens   # 24 utterances: 114 blocks at the full rate, 57 behind the stride layer
+    else:
+        k, streaming = (31, False) if family.endswith("k31") else (15, True)
+        sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=82, perturb_norm=True, cnn_module_kernel=k)
+        conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=k)
+        model = ConformerModel(80, V, streaming=streaming, encoder_conf=conf, state_dict=sd, device="cuda:0")
+        oracle = ConformerOracle(sd, num_blocks=L, cnn_module_kernel=k, causal=streaming)
+    x, la = synth_features(len(lens), 611, lens=lens, seed=83)
+    model.set_ffn_split(0)
+    p32, l32 = _run(model, x, la, 32)          # the fused 32-row kernels
+    model.set_ffn_split(-1)
+    p16, l16 = _run(model, x, la, 16)
+    pa, la_ = _run(model, x, la, -1)           # 57 / 114 blocks: the rule picks the 16-row kernels
+    assert np.array_equal(la_, l16)
+    e = _rel(l16, l32)
+    ref = oracle.get_encoder_out(x, la, return_logits=True)[1].numpy()
+    e16, e32 = _rel(l16, ref), _rel(l32, ref)
+    print(family, "16 vs 32 rows", e, "vs oracle: 16-row", e16, "32-row", e32)
+    assert e < 2e-5 and e16 < 1e-3 and e32 < 1e-3
