@@ -7,10 +7,9 @@
 // contraction over the concatenated operands Q' = [q+u | q+v], K' = [k | p]; key-padding mask from the lengths (token j
 // masked iff mask_mul * j >= len[b], subsampling.py:115), softmax, masked probabilities -> 0, times V.
 //
-// Design: the barrier-free transposed flash attention of k_attn_out_glu (conformer_kernels.hip).  A workgroup's NW waves
-// are (query blocks) x (key splits): NS = 1 / 2 / 4 waves share the keys of one 32-query block, chosen per utterance
-// from its key count so that a wave walks at most ~256 keys (a 750-key utterance is not one 60 us chain) but short
-// utterances do not pay staging + merge for every 64 keys.  Every wave is an independent worker on
+// Design: the barrier-free transposed flash attention of k_attn_out_glu (conformer_kernels.hip) with the keys of a
+// (utterance, head, 32-query block) split over the NW waves of the workgroup (sub-blocks w, w + NW, ...: a 750-key
+// utterance is not one 60 us chain).  Every wave is an independent worker on
 // TRANSPOSED score tiles S^T = K' Q'^T: the K' fragment (one key row per lane, straight from L2 in whole-line bursts)
 // is the MFMA A operand, the Q' fragment (LDS) the B operand, so a lane owns ITS query row's scores -- row max / sum are
 // in-lane (v_max3, packed math, one lane^32 exchange each), the probabilities never leave the accumulator registers (they
@@ -31,20 +30,20 @@
 
 namespace ppasr {
 
-// tuning knobs (tools/build_variant.sh NAME -DPPASR_ATTN_...): most query blocks per workgroup for plain heads (4: a short
-// utterance's waves take different query blocks; 1: always 4 key splits), V k-groups in flight, waves per SIMD the
-// register allocation leaves room for, and the split rule (0: a wave walks <= 4 sub-blocks; 1: as many splits as sub-blocks)
-#ifndef PPASR_ATTN_MAXQ
-#define PPASR_ATTN_MAXQ 1
-#endif
+// tuning knobs (tools/build_variant.sh NAME -DPPASR_ATTN_...): V k-groups in flight, waves per SIMD the register allocation
+// leaves room for, 32-key tiles per sub-block of the plain heads.  Measured on BASELINE configs[4] (same box, ms per step of
+// the 12 attention launches): 64-key sub-blocks / 2 waves per SIMD / 8 V k-groups in flight 0.645; 32-key / 3 / 4: 0.637;
+// 32-key / 4 / 2 (the defaults): 0.591.  Splitting the keys of a query block over FEWER waves for short utterances
+// (1 / 2 / 4 by key count, the spare waves taking other query blocks) was measured and is slower -- 0.985 (adaptive),
+// 1.06 (never split), 0.74 (two), 0.66 (always four): a launch is bounded by its longest chains, not by its staging.
 #ifndef PPASR_ATTN_PQ
 #define PPASR_ATTN_PQ 2
 #endif
 #ifndef PPASR_ATTN_OCC
 #define PPASR_ATTN_OCC 4
 #endif
-#ifndef PPASR_ATTN_RULE
-#define PPASR_ATTN_RULE 1
+#ifndef PPASR_ATTN_NW
+#define PPASR_ATTN_NW 4  // waves = key splits per workgroup of the plain heads
 #endif
 #ifndef PPASR_ATTN_NT
 #define PPASR_ATTN_NT 1  // 32-key tiles per sub-block of the plain heads
@@ -56,8 +55,8 @@ struct AttnT {
   static constexpr int NC2 = DK / 64;          // 64-column chunks of the context (two output tiles each: even / odd columns)
   static constexpr int NGK = 2 * DK / 8;       // 8-wide k-groups of the score contraction over K' = [k | p]
   static constexpr int NT = DK == 64 ? PPASR_ATTN_NT : 1;  // 32-key tiles per sub-block (accumulator budget)
-  static constexpr int NW = DK == 64 ? 4 : 2;  // waves per workgroup = (query blocks) x (key splits NS of each), NS chosen per utterance
-  static constexpr int MAXQ = DK == 64 ? PPASR_ATTN_MAXQ : 1;  // most query blocks per workgroup (LDS: one Q' tile each)
+  static constexpr int NW = DK == 64 ? PPASR_ATTN_NW : 2;  // waves per workgroup = key splits of its query block
+  static constexpr int MAXQ = 1;               // query blocks per workgroup (LDS: one Q' tile)
   static constexpr int PQ = DK == 64 ? PPASR_ATTN_PQ : 2;  // V k-groups in flight
   static constexpr int QLD = 2 * DK + 4;       // Q' row stride (floats)
   static constexpr int OLD = DK + 4;           // partial O row stride
@@ -75,7 +74,7 @@ __device__ __forceinline__ f32x2 load_b64(__amdgpu_buffer_rsrc_t rs, int voff, i
 // (second launch bound = waves per SIMD the register allocation must leave room for: 226 / 224 registers, so that two
 //  workgroups of plain heads / three of grouped heads share a CU)
 template <int DK>
-__global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) void k_attention_t(AttnArgs a, int B, int H, int ns_force) {
+__global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) void k_attention_t(AttnArgs a, int B, int H) {
   using C = AttnT<DK>;
   constexpr int G = C::G, NT = C::NT, NW = C::NW, NC2 = C::NC2, NGK = C::NGK, PQ = C::PQ;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -112,54 +111,55 @@ __global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) 
     ptab = a.ptab + (size_t)d.pos0 * dm;
   }
   float* __restrict__ ctx = a.ctx + (size_t)b * F1 * dm;
-  const int64_t len_b = a.lens ? a.lens[b] : (int64_t)a.mask_mul * T2;
-  int q_need = T1;  // query tokens that are computed
-  if (a.pad_skip > 0 && a.lens) {  // ragged batch: query blocks behind the needed frames are not computed
-    const int64_t lb = len_b > 0 ? len_b : 0;
-    const int fmul = a.mask_mul / G;  // frame f is valid iff fmul * f < len
-    const int need_frames = (int)min((int64_t)F1, (lb + fmul - 1) / fmul + (a.pad_skip - 1));
-    q_need = min(T1, (need_frames + G - 1) / G);
-  }
-  // keys >= kv_end are PAD (mask_mul * j >= len) or beyond the key tokens: they are never loaded
-  const int kv_end = (int)min((int64_t)T2, max((int64_t)0, (len_b + a.mask_mul - 1) / a.mask_mul));
-  const int nfr = min(G * kv_end, F2);  // frames behind the valid tokens (the zero-padded tail group reads zeros)
-  const int n_sb = (kv_end + C::SB - 1) / C::SB;
-  // key splits per query block: a wave walks <= 4 sub-blocks where the workgroup has the waves for it
-  int NS = PPASR_ATTN_RULE ? (n_sb <= 1 ? 1 : (n_sb <= 2 ? 2 : 4)) : (n_sb <= 4 ? 1 : (n_sb <= 8 ? 2 : 4));
-  if (ns_force > 0) NS = ns_force;
-  NS = min(max(NS, NW / C::MAXQ), NW);
-  const int QPW = NW / NS;                 // query blocks of this workgroup
-  const int qi = wave / NS, ks = wave - qi * NS;
-  if (li * QPW * 32 >= q_need) return;     // (uniform: before any barrier)
-  const int q0 = (li * QPW + qi) * 32;     // this wave's query block (may lie behind q_need: computed, never stored)
-
-  // ---- Q' = [q + pos_bias_u | q + pos_bias_v] of the block's 32 query tokens -> LDS ----
+  static_assert(C::MAXQ == 1, "one query block per workgroup: its NW waves split the keys");
+  constexpr int NS = NW;
+  const int ks = wave;                    // this wave's key split: sub-blocks ks, ks + NS, ks + 2 NS, ...
+  const int q0 = li * 32;                 // the workgroup's query block
   auto split = [&](int flat, int& frame, int& feat) {
     frame = flat >> dm_shift;
     feat = flat & (dm - 1);
   };
-  float* Qt = Qs + qi * 32 * C::QLD;  // this wave's query block's tile, staged by the NS waves that share it (below)
+  // Everything the first MFMA needs is requested BEFORE the utterance's length is looked at: the length load, the query
+  // rows and the first K' burst are then one memory round trip instead of three dependent ones (the launches of a ragged
+  // batch's reduced layers are a handful of sub-blocks per wave: their prologue was as long as their key loop).
+  // ---- Q' = [q + pos_bias_u | q + pos_bias_v] of the block's 32 query tokens -> LDS ----
+  float* Qt = Qs;
+  for (int idx = tid; idx < 32 * (DK / 4); idx += 64 * NW) {
+    const int row = idx / (DK / 4), f4 = idx - row * (DK / 4);
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    if (q0 + row < T1) {
+      int frame = q0 + row, feat = h * DK + 4 * f4;
+      if (G != 1) split((q0 + row) * (G * dm) + h * DK + 4 * f4, frame, feat);
+      if (frame < F1) q = *reinterpret_cast<const f32x4*>(qb + (size_t)frame * a.q_stride + feat);
+    }
+    const f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + h * DK + 4 * f4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + h * DK + 4 * f4);
+    *reinterpret_cast<f32x4*>(Qt + row * C::QLD + 4 * f4) = q + u;
+    *reinterpret_cast<f32x4*>(Qt + row * C::QLD + DK + 4 * f4) = q + v;
+  }
 
   // ---- operand resources: one per 64-feature chunk (a chunk never straddles a frame of the grouped re-cut).  Chunk c3
-  // of head h starts at flat feature c = h * DK + 64 c3 = (frame offset fo, feature feat0) of a token's G frames; rows
-  // past the valid frames are out of the resource's range and read as zeros. ----
+  // of head h starts at flat feature c = h * DK + 64 c3 = (frame offset fo, feature feat0) of a token's G frames.  Keys /
+  // positions: bounded by the key FRAMES of the call (rows past them -- the zero-padded tail group -- read zeros; keys
+  // behind the utterance's valid ones hold whatever the batch holds there and are masked by index after the score MFMAs) ----
   const int krow_b = G * a.k_stride * 4, prow_b = G * a.pos_stride * dm * 4, vrow_b = G * a.v_stride * 4;
   __amdgpu_buffer_rsrc_t rs_k[NC2], rs_p[NC2], rs_v[NC2];
+  int fo_c[NC2], feat_c[NC2];
 #pragma unroll
   for (int c3 = 0; c3 < NC2; ++c3) {
-    int fo = 0, feat0 = h * DK + 64 * c3;
-    if (G != 1) split(h * DK + 64 * c3, fo, feat0);
-    const long long rows = (long long)nfr - fo - 1;  // last valid row relative to the chunk's base row
-    rs_k[c3] = buf_rsrc(kbp + (size_t)fo * a.k_stride + feat0, rows < 0 ? 0 : (size_t)rows * a.k_stride * 4 + 256);
-    rs_p[c3] = buf_rsrc(ptab + (size_t)fo * a.pos_stride * dm + feat0, rows < 0 ? 0 : (size_t)rows * a.pos_stride * dm * 4 + 256);
-    rs_v[c3] = buf_rsrc(vbp + (size_t)fo * a.v_stride + feat0, rows < 0 ? 0 : (size_t)rows * a.v_stride * 4 + 256);
+    fo_c[c3] = 0;
+    feat_c[c3] = h * DK + 64 * c3;
+    if (G != 1) split(h * DK + 64 * c3, fo_c[c3], feat_c[c3]);
+    const long long rows = (long long)F2 - fo_c[c3] - 1;  // last row relative to the chunk's base row
+    rs_k[c3] = buf_rsrc(kbp + (size_t)fo_c[c3] * a.k_stride + feat_c[c3], rows < 0 ? 0 : (size_t)rows * a.k_stride * 4 + 256);
+    rs_p[c3] = buf_rsrc(ptab + (size_t)fo_c[c3] * a.pos_stride * dm + feat_c[c3], rows < 0 ? 0 : (size_t)rows * a.pos_stride * dm * 4 + 256);
   }
   // byte offsets of this lane's key (tile t) of the sub-block at u0, in K and in the positional table
   int vk[NT], vp[NT];
   auto key_offsets = [&](int u0) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int key = min(u0 + 32 * t + l31, kv_end - 1);  // keys >= kv_end are masked afterwards
+      const int key = min(u0 + 32 * t + l31, T2 - 1);  // (keys >= kv_end are masked afterwards)
       vk[t] = key * krow_b + 16 * hh;
       vp[t] = key * prow_b + 16 * hh;
     }
@@ -179,10 +179,29 @@ __global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) 
   };
   const float* qfrag_p = Qt + l31 * C::QLD + 4 * hh;
   auto qfrag = [&](int gk) -> f32x4 { return *reinterpret_cast<const f32x4*>(qfrag_p + 8 * gk); };
+  key_offsets(ks * C::SB);
+  load_sg(0, 0);  // (a wave whose first sub-block lies behind the valid keys requested 8 lines for nothing)
 
-  // this wave's key range: a contiguous run of sub-blocks
-  const int per = (n_sb + NS - 1) / NS;
-  const int sb_lo = ks * per, sb_hi = min(n_sb, sb_lo + per);
+  // ---- now the length: valid keys, needed queries ----
+  const int64_t len_b = a.lens ? a.lens[b] : (int64_t)a.mask_mul * T2;
+  int q_need = T1;  // query tokens that are computed
+  if (a.pad_skip > 0 && a.lens) {  // ragged batch: query blocks behind the needed frames are not computed
+    const int64_t lb = len_b > 0 ? len_b : 0;
+    const int fmul = a.mask_mul / G;  // frame f is valid iff fmul * f < len
+    const int need_frames = (int)min((int64_t)F1, (lb + fmul - 1) / fmul + (a.pad_skip - 1));
+    q_need = min(T1, (need_frames + G - 1) / G);
+  }
+  if (q0 >= q_need) return;  // (uniform: before any barrier)
+  // keys >= kv_end are PAD (mask_mul * j >= len) or beyond the key tokens
+  const int kv_end = (int)min((int64_t)T2, max((int64_t)0, (len_b + a.mask_mul - 1) / a.mask_mul));
+  const int nfr = min(G * kv_end, F2);  // frames behind the valid tokens: the VALUES are bounded by them (p = 0 times an
+                                        // uninitialised row of a ragged batch would be NaN; out of range reads 0)
+  const int n_sb = (kv_end + C::SB - 1) / C::SB;
+#pragma unroll
+  for (int c3 = 0; c3 < NC2; ++c3) {
+    const long long rows = (long long)nfr - fo_c[c3] - 1;
+    rs_v[c3] = buf_rsrc(vbp + (size_t)fo_c[c3] * a.v_stride + feat_c[c3], rows < 0 ? 0 : (size_t)rows * a.v_stride * 4 + 256);
+  }
   constexpr float kScale = (DK == 64 ? 0.125f : 0.07216878364870322f) * 1.4426950408889634f;  // 1/sqrt(d_k) * log2(e)
   f32x16 acc_o[2 * NC2];  // O^T: acc_o[2 c3 + e][r] = O[query l31][64 c3 + 2 ((r&3) + 8(r>>2) + 4hh) + e]
 #pragma unroll
@@ -192,28 +211,9 @@ __global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) 
   float m_run = -INFINITY, l_run = 0.f;  // raw-score running max / running sum of query row l31 (same in both lane halves)
   bool first = true;
   const int vlane = 4 * hh * vrow_b + 8 * l31;
-  if (sb_lo < sb_hi) {
-    key_offsets(sb_lo * C::SB);
-    load_sg(0, 0);
-  }
-  // Q' staging AFTER the first K' requests: the key rows' first cache lines are in flight while the query rows are
-  // fetched, summed with the position biases and parked in LDS
-  for (int idx = ks * 64 + lane; idx < 32 * (DK / 4); idx += 64 * NS) {
-    const int row = idx / (DK / 4), f4 = idx - row * (DK / 4);
-    f32x4 q = {0.f, 0.f, 0.f, 0.f};
-    if (q0 + row < T1) {
-      int frame = q0 + row, feat = h * DK + 4 * f4;
-      if (G != 1) split((q0 + row) * (G * dm) + h * DK + 4 * f4, frame, feat);
-      if (frame < F1) q = *reinterpret_cast<const f32x4*>(qb + (size_t)frame * a.q_stride + feat);
-    }
-    const f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + h * DK + 4 * f4);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + h * DK + 4 * f4);
-    *reinterpret_cast<f32x4*>(Qt + row * C::QLD + 4 * f4) = q + u;
-    *reinterpret_cast<f32x4*>(Qt + row * C::QLD + DK + 4 * f4) = q + v;
-  }
-  if (NS > 1) __syncthreads();  // (NS == 1: every wave staged its own tile -- the whole kernel is barrier-free)
+  __syncthreads();  // Q' is in LDS
 
-  for (int sb = sb_lo; sb < sb_hi; ++sb) {
+  for (int sb = ks; sb < n_sb; sb += NS) {
     const int u0 = sb * C::SB;
     const bool edge = u0 + C::SB > kv_end;  // the sub-block holds masked keys (wave-uniform)
     // V^T operands: k-group q = (tile t = q >> 2, i = q & 3) covers keys u0 + 32t + 8i + 4hh + j, j = 0..3; a lane holds
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) 
     ps += __shfl_xor(ps, 32);
     m_run = m_new;
     l_run = l_run * alpha + ps;
-    if (sb + 1 < sb_hi) {  // next sub-block's first K' super-group: in flight across the PV phase
-      key_offsets(u0 + C::SB);
+    if (sb + NS < n_sb) {  // next sub-block's first K' super-group: in flight across the PV phase
+      key_offsets(u0 + NS * C::SB);
       load_sg(0, 0);
     }
     // ---- O^T = O^T * alpha + V^T P^T ----
@@ -329,9 +329,9 @@ __global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) 
     }
   }
 
-  // ---- merge the key splits of every query block: O = sum_s O_s e^{m_s - m} / sum_s l_s e^{m_s - m}; rows stored
-  // coalesced.  Wave w parks its partial O^T in tile slot w (NS == 1: its own Q' tile, nobody else's) ----
-  if (NS > 1) __syncthreads();  // every wave is done with the Q' tiles
+  // ---- merge the key splits: O = sum_s O_s e^{m_s - m} / sum_s l_s e^{m_s - m}; rows stored coalesced.  Wave w parks its
+  // partial O^T in tile slot w (over the Q' tile, which every wave is done with) ----
+  __syncthreads();  // every wave is done with the Q' tile
   {
     float* Pt = Qs + wave * C::PSTR + l31 * C::OLD;
 #pragma unroll
@@ -348,10 +348,10 @@ __global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) 
       Stat[wave * 64 + 32 + l31] = l_run;
     }
   }
-  if (NS > 1) __syncthreads();
-  for (int idx = ks * 64 + lane; idx < 32 * (DK / 4); idx += 64 * NS) {
+  __syncthreads();
+  for (int idx = tid; idx < 32 * (DK / 4); idx += 64 * NS) {
     const int row = idx / (DK / 4), f4 = idx - row * (DK / 4);
-    const int w0 = qi * NS;  // first wave of this query block
+    constexpr int w0 = 0;
     float m = -INFINITY;
     for (int s2 = 0; s2 < NS; ++s2) m = fmaxf(m, Stat[(w0 + s2) * 64 + row]);
     float l = 0.f;
@@ -380,10 +380,6 @@ bool launch_attention_t(const AttnArgs& a, int B, int H, hipStream_t st) {
     const char* e = std::getenv("PPASR_ATTN_LEGACY");  // (A/B measurements against the round-1 kernel)
     return e && e[0] == '1';
   }();
-  static const int ns_force = [] {
-    const char* e = std::getenv("PPASR_ATTN_SPLIT");  // (tuning: key splits per query block, 1 / 2 / 4; default by key count)
-    return e ? atoi(e) : 0;
-  }();
   if (legacy) return false;
   if (a.group != 1 && a.group != 3) return false;
   if (a.group == 3 && (a.dm & (a.dm - 1)) != 0) return false;
@@ -392,9 +388,9 @@ bool launch_attention_t(const AttnArgs& a, int B, int H, hipStream_t st) {
   const int pairs8 = (B * H + 7) / 8;
   const dim3 grid(nq * pairs8 * 8);
   if (a.group == 3)
-    PPASR_LAUNCH(k_attention_t<192>, grid, dim3(64 * AttnT<192>::NW), kLdsAttnT192, st, a, B, H, ns_force);
+    PPASR_LAUNCH(k_attention_t<192>, grid, dim3(64 * AttnT<192>::NW), kLdsAttnT192, st, a, B, H);
   else
-    PPASR_LAUNCH(k_attention_t<64>, grid, dim3(64 * AttnT<64>::NW), kLdsAttnT64, st, a, B, H, ns_force);
+    PPASR_LAUNCH(k_attention_t<64>, grid, dim3(64 * AttnT<64>::NW), kLdsAttnT64, st, a, B, H);
   return true;
 }
 

@@ -229,7 +229,6 @@ __device__ __forceinline__ void select_bin_reg(const int* hist, int k_rem, int& 
 size_t beam_lds_bytes(const BeamConfig& c) {
   const int Vp = (c.V + 3) & ~3;
   size_t n = 8 * 256 * 4 + 3 * (kBT / 64) * 4 + 32;  // per-pass histograms, scan / reduction scratch, scalars
-  n += (size_t)Vp * 4;                             // lp
   n += (size_t)kMaxBeamCand * 8;                   // cand_c, cand_lp
   n += (size_t)2 * c.beam * (28 + 4 * kLmCtx);     // two beam halves
   n += (size_t)c.beam * 20;                        // new_b, new_nb, new_score, new_dst, k_reset
@@ -445,7 +444,6 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
   int* wave_tot = reinterpret_cast<int*>(p); p += 2 * (BT / 64) * 4;
   float* red_p = reinterpret_cast<float*>(p); p += (BT / 64) * 4;
   int* sh_i = reinterpret_cast<int*>(p); p += 32;            // misc shared ints
-  float* lp = reinterpret_cast<float*>(p); p += (size_t)Vp * 4;
   int* cand_c = reinterpret_cast<int*>(p); p += kMaxBeamCand * 4;
   float* cand_lp = reinterpret_cast<float*>(p); p += kMaxBeamCand * 4;
   Beam cur = carve_beam(p, beam);
@@ -493,9 +491,16 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
   __syncthreads();
 
   const int n_frames = frame_lens ? min(max(frame_lens[u], 0), T) : T;
-  // lp[] = log-prob of the frame's candidates / marker, kidx[] = candidate index: cleared once, then only the entries of
-  // the previous frame's characters are reset
-  for (int v = tid; v < V; v += BT) { lp[v] = kNotCand; kidx[v] = -1; }
+  // kidx[] = index of a character in the frame's candidate list (-1: not a candidate): cleared once, then only the entries
+  // of the previous frame's characters are reset.  A character's log-prob is cand_lp[kidx[c]] -- a V-wide table of its own
+  // (17 KB of LDS at V = 4233) kept the workgroup from sharing a CU with the encoder's 133 KB row-block workgroups when
+  // the search of step i runs beside the encoder of step i + 1 (bench.py --config cfg4 / cfg5, evaluate()): the encoder's
+  // launches then had 16 .. 64 fewer CUs and ran extra rounds.
+  for (int v = tid; v < V; v += BT) kidx[v] = -1;
+  auto lp_of = [&](int c) -> float {
+    const int k = kidx[c];
+    return k >= 0 ? cand_lp[k] : kNotCand;
+  };
   // per-frame records of the pruning pre-pass (k_ctc_prune); the next frame's record is fetched into registers while
   // the current frame is processed
   const int RW = prune_rec_words(CM);
@@ -534,7 +539,6 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
       if (k < C) {
         cand_c[k] = pre_c[j];
         cand_lp[k] = __int_as_float(pre_lp[j]);
-        lp[pre_c[j]] = __int_as_float(pre_lp[j]);
         kidx[pre_c[j]] = (int16_t)k;
       }
     }
@@ -599,12 +603,12 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
     };
     TS(1);
     // ---- (d) contributions received by the hypotheses already in the beam ----
-    const float lpb = lp[blank];
+    const float lpb = lp_of(blank);
     for (int q = tid; q < nb; q += BT) {
       const int cq = cur.chr[q];
       float bc = (lpb != kNotCand && !pruned(lpb, q)) ? lpb + cur.score[q] : kNegInf;
       float nbc = kNegInf;
-      const float lq = (cq >= 0) ? lp[cq] : kNotCand;
+      const float lq = (cq >= 0) ? lp_of(cq) : kNotCand;
       if (lq != kNotCand && cq != blank) {
         if (!pruned(lq, q)) nbc = lq + cur.nb[q];  // repeated character
         const int pn = cur.par[q];
@@ -865,7 +869,7 @@ __global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs
         nxt.b[pos] = kNegInf; nxt.nb[pos] = log_p; nxt.score[pos] = log_p;
       }
     }
-    for (int k = tid; k < C; k += BT) { lp[cand_c[k]] = kNotCand; kidx[cand_c[k]] = -1; }  // reset for the next frame
+    for (int k = tid; k < C; k += BT) kidx[cand_c[k]] = -1;  // reset for the next frame
     lds_barrier();
     TS(7);
     nb = k_sel;
