@@ -97,6 +97,13 @@ def class_of(name):
         return "k_sq_tail<%s>" % targs.strip("<>").split(",")[-1].strip()
     if base == "k_attention_t":
         return "k_attention<%s>" % targs.strip("<>").split(",")[0].strip()
+    # ... and the Conformer-family kernels on the 16-row / 16-wave block forms (conformer_kernels_t.hip):
+    # k_conv_ffn_t<R, KS, NEXT> -> k_conv_ffn<KS>[+next], k_ffn_qkv_t<R> -> k_ffn_qkv, k_out_glu_t<R> -> k_out_glu
+    if base == "k_conv_ffn_t":
+        a = [t.strip() for t in targs.strip("<>").split(",")]
+        return f"k_conv_ffn<{a[1]}>+next" if a[-1] in ("true", "1") else f"k_conv_ffn<{a[1]}>"
+    if base in ("k_ffn_qkv_t", "k_out_glu_t"):
+        return base[:-2]
     if base == "k_conv_ffn":
         a = [t.strip() for t in targs.strip("<>").split(",")]
         return f"k_conv_ffn<{a[0]}>+next" if a[-1] in ("true", "1") else f"k_conv_ffn<{a[0]}>"

@@ -155,10 +155,14 @@ PPASR_API ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable);
  * kernels, the fused attention kernel included), 2 / 4 / 8 = always that many slices. */
 PPASR_API ppasr_status ppasr_set_ffn_split(ppasr_handle h, int mode);
 
-/* Rows per workgroup of the layer kernels (no reference counterpart): -1 (default) = by grid size -- 16-row blocks
- * (v_mfma_f32_16x16x4_f32, csrc/rbt.h) for launches whose 32-row blocks would fill at most half of the chip, else 32;
- * 16 / 32 = always.  Same arithmetic up to the summation order inside a 16-wide k step (1e-6 relative).  Built for the
- * Squeezeformer layer kernels; other routes ignore it. */
+/* Block form of the layer kernels (no reference counterpart; csrc/rbt.h): -1 (default) = by grid size -- up to 32 row
+ * blocks of 32 rows the split route above; 16-row blocks (v_mfma_f32_16x16x4_f32 on 8 waves) where two short rounds of
+ * them beat the 32-row rounds (33 .. 128 blocks: under-filled launches); else 32-row blocks (v_mfma_f32_32x32x2_f32 on
+ * 8 waves).  16 / 32 = always that form; PPASR_ROW_BLOCK_32_W16 = 32 rows on SIXTEEN waves (v_mfma_f32_16x16x4_f32 on
+ * four waves per SIMD; measured equal to the 8-wave kernels end to end, kept as an option).  Same arithmetic up to the
+ * summation order inside a 16-wide k step (1e-6 relative).  Built for the Conformer / Efficient-Conformer /
+ * Squeezeformer layer kernels behind the conv2d (4x) front end; other routes ignore it. */
+#define PPASR_ROW_BLOCK_32_W16 1032
 PPASR_API ppasr_status ppasr_set_row_block(ppasr_handle h, int rows);
 /* Host copy of the `lens` the following ppasr_encode calls of a batch of B utterances will pass (NULL / 0: forget it).
  * Only ever used to CHOOSE between kernel variants for ragged batches (ppasr_set_skip_padding), whose count of computed

@@ -446,7 +446,17 @@ int ffn_split_for(const ppasr_model_s* m, int M) {
 }
 
 int row_block_for(const ppasr_model_s* m, int B, int Tcur, int mul, int slack, bool skip) {
-  if (m->row_block == 16 || m->row_block == 32) return m->row_block;
+  // 32 rows on 16 waves (rbt.h kW16) in place of the 8-wave 32-row kernels: OPT-IN (PPASR_W16=1, or per handle with
+  // ppasr_set_row_block(PPASR_ROW_BLOCK_32_W16)).  Measured on the three bench configurations it is a wash -- the
+  // feed-forward streams gain 3 % (92.6 against 89.6 % of the matrix-pipe rate, tools/phase_ts.py --t), the 16-wave
+  // depthwise-conv phase requests each window row twice as often and the launch is longer: cfg2 5.99 ms against 5.92,
+  // cfg4 9.10 = 9.10, cfg5 6.73 against 6.80 (DESIGN.md "Measured and not adopted").
+  static const bool w16_on = [] {
+    const char* e = getenv("PPASR_W16");
+    return e && e[0] == '1';
+  }();
+  const int full = w16_on ? kW16 : 32;
+  if (m->row_block == 16 || m->row_block == 32 || m->row_block == kW16) return m->row_block;
   long long rows = (long long)B * Tcur;
   if (skip && (int)m->lens_hint.size() == B) {
     rows = 0;
@@ -466,16 +476,17 @@ int row_block_for(const ppasr_model_s* m, int B, int Tcur, int mul, int slack, b
     return e ? atoi(e) : 32;
   }();
   const long long b32 = (rows + 31) / 32, b16 = (rows + 15) / 16;
-  if (b32 <= min_blocks) return 32;
-  const double c32 = (double)((b32 + 255) / 256), c16 = 0.52 * (double)((b16 + 255) / 256);
-  return c16 < c32 ? 16 : 32;
+  if (b32 <= min_blocks) return 32;  // (split route: the 8-wave kernels)
+  const double c32 = (w16_on ? 0.88 : 1.0) * (double)((b32 + 255) / 256), c16 = 0.52 * (double)((b16 + 255) / 256);
+  return c16 < c32 ? 16 : full;
 }
 
 extern "C" {
 
 ppasr_status ppasr_set_row_block(ppasr_handle h, int rows) {
   if (!h) return fail(PPASR_EINVAL, "null handle");
-  if (rows != -1 && rows != 16 && rows != 32) return fail(PPASR_EINVAL, "row block: -1 (by grid size), 16 or 32");
+  if (rows != -1 && rows != 16 && rows != 32 && rows != PPASR_ROW_BLOCK_32_W16)
+    return fail(PPASR_EINVAL, "row block: -1 (by grid size), 16, 32 or PPASR_ROW_BLOCK_32_W16");
   h->row_block = rows;
   return PPASR_OK;
 }
@@ -651,11 +662,13 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     const PadSkip ps = pskip(Ti, mul);
     // under-filled launch, 33 .. 128 row blocks: the 16-row-block kernels (conformer_kernels_t.hip) -- twice the
     // workgroups, each half as long -- with the stand-alone attention between them; up to 32 blocks the split route below
-    const bool r16 = !h->taps && h->ffn_split < 0 && conv_ffn_16_supported(h->layer_ks[i], Ti) &&
-                     row_block_for(h, B, Ti, mul, ps.slack, skip) == 16;
+    const int rows = (!h->taps && conv_ffn_16_supported(h->layer_ks[i], Ti)) ? row_block_for(h, B, Ti, mul, ps.slack, skip) : 32;
+    const bool r16 = rows == 16 && h->ffn_split < 0;
     const bool fuse_attn = !r16 && fusable(i);
     // under-filled grid: FFNs split over S workgroups per row block (partial sums in the conv1 buffer, free by now)
     const int S = r16 ? 1 : ffn_split_for(h, Mi);
+    // full grid: the same 32-row blocks on 16 waves (k_*_t<kW16>: drop-in for k_ffn_qkv / k_out_glu / k_conv_ffn)
+    const bool w16 = rows == kW16 && S == 1;
     float* partial = y1;
     float* x3 = ctx;
     if (!s1_done) {
@@ -667,6 +680,8 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
         });
       } else if (r16) {
         timed(3, [&] { launch_ffn_qkv_16(xa, xb, qkv, L, Mi, n_chunks, st, ps); });
+      } else if (w16) {
+        timed(3, [&] { launch_ffn_qkv_w16(xa, xb, qkv, L, Mi, n_chunks, st, ps, fuse_attn ? vt_out : VtOut{}); });
       } else {
         timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st, ps, fuse_attn ? vt_out : VtOut{}); });
       }
@@ -688,6 +703,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       // (under-filled launch: pointwise_conv1 + GLU as its own two-column-half launch; the LayerNorm'd rows pass through
       //  xa, which is free between this layer's S1 and its output)
       if (r16) timed(5, [&] { launch_out_glu_16(ctx, xb, xc, g, L, lens, Mi, Ti, mul, st, ps); });
+      else if (w16) timed(5, [&] { launch_out_glu_w16(ctx, xb, xc, g, L, lens, Mi, Ti, mul, st, ps); });
       else timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, L, lens, Mi, Ti, mul, st, ps, S > 1 ? xa : nullptr); });
     }
     tap(xc, (size_t)Mi * kD);
@@ -715,6 +731,9 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
         if (r16)
           launch_conv_ffn_16(g, xc, next ? nullptr : xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul, next, xb, qkv, st,
                              h->desc.causal != 0, ps);
+        else if (w16)
+          launch_conv_ffn_w16(g, xc, next ? nullptr : xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul, next, xb, qkv, st,
+                              h->desc.causal != 0, ps, (next && fusable(i + 1)) ? vt_out : VtOut{});
         else
           launch_conv_ffn(g, nullptr, xc, (next && !h->taps) ? nullptr : xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul,
                           next, xb, qkv, st, h->desc.causal != 0, ps, (next && fusable(i + 1)) ? vt_out : VtOut{});

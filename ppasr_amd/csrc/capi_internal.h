@@ -129,7 +129,7 @@ struct ppasr_model_s {
   bool prof = false;
   int ffn_split = -1;  // ppasr_set_ffn_split: -1 = by grid size, 0 = never, 2 / 4 / 8 = always that many slices
   bool skip_padding = false;  // ppasr_set_skip_padding: ragged batches compute only the rows valid outputs depend on
-  int row_block = -1;         // ppasr_set_row_block: -1 = by grid size, 32 / 16 = always that many rows per workgroup
+  int row_block = -1;         // ppasr_set_row_block: -1 = by grid size, 32 / 16 / kW16 = always that block form (rbt.h)
   std::vector<int64_t> lens_hint;  // ppasr_set_lengths_hint: host copy of the batch's lengths (route selection only)
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;

@@ -324,6 +324,7 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
     tap(ctx, (size_t)Mi * kD);
     // under-filled grid (ppasr_set_ffn_split): K_B / K_C cut at their feed-forward modules, partial sums in the conv1 buffer
     // under-filled launch: 16-row blocks (twice the workgroups, each half as long) before the split route
+    // ... and full launches: the 32-row blocks on 16 waves (rbt.h kW16)
     const int rows = h->taps ? 32 : row_block_for(h, B, Ti, mul, ps.slack, skip);
     const int S = rows == 16 && h->ffn_split < 0 ? 1 : ffn_split_for(h, Mi);  // (an explicit ffn_split mode wins)
     const bool fuse_next = (i + 1 < L) && (i + 1 != h->desc.reduce_idx) && !(i + 1 == h->desc.recover_idx && reduced);

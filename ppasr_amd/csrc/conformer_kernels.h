@@ -112,6 +112,14 @@ bool conv_ffn_16_supported(int ksize, int Tp);
 void launch_conv_ffn_16(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int M, int Tp,
                         int n_chunks, int ksize, int mask_mul, const LayerW* next, float* x1_next, float* qkv_next,
                         hipStream_t st, bool causal, const PadSkip& ps);
+// ... and on 32 rows x 16 waves (full launches): drop-in for launch_ffn_qkv / launch_out_glu / launch_conv_ffn
+void launch_ffn_qkv_w16(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
+                        const PadSkip& ps, VtOut vt);
+void launch_out_glu_w16(const float* ctx, const float* x1, float* x2, float* g, const LayerW& w, const int64_t* lens, int M,
+                        int Tp, int mask_mul, hipStream_t st, const PadSkip& ps);
+void launch_conv_ffn_w16(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int M, int Tp,
+                         int n_chunks, int ksize, int mask_mul, const LayerW* next, float* x1_next, float* qkv_next,
+                         hipStream_t st, bool causal, const PadSkip& ps, VtOut vt_next);
 hipError_t configure_conformer_t_kernels();
 
 // ---- launchers (all asynchronous on `st`) ----

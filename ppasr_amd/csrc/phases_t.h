@@ -1,8 +1,8 @@
-// phases_t.h -- row-block phase functions on TRANSPOSED accumulators, templated on the rows per block R = 32 / 16
-// (rbt.h): LayerNorm, feed-forward module with LDS-resident hidden chunks, residual / QKV epilogues, depthwise conv +
-// LayerNorm + swish in registers, per-lane pad flag.  Every epilogue sees a wave's R x 32 output tile as NQ column
-// quads per lane (lane = row RBT<R>::lrow, quad q = columns wave*32 + RBT<R>::qcol(q) .. +3), so the same code serves
-// the 32-row kernels (v_mfma_f32_32x32x2_f32) and the 16-row ones (v_mfma_f32_16x16x4_f32).
+// phases_t.h -- row-block phase functions on TRANSPOSED accumulators, templated on the block form R (rbt.h: 32 or 16
+// rows on 8 waves, kW16 = 32 rows on 16 waves): LayerNorm, feed-forward module with LDS-resident hidden chunks,
+// residual / QKV epilogues, depthwise conv + LayerNorm + swish in registers, per-lane pad flags.  Every epilogue sees a
+// wave's output tile as NQ quads per lane (quad q = row RBT<R>::row(q, lane), 4 consecutive columns from
+// RBT<R>::col(q, lane, wave)), so the same code serves v_mfma_f32_32x32x2_f32 and both v_mfma_f32_16x16x4_f32 forms.
 #pragma once
 #include "phases.h"
 #include "rbt.h"
@@ -10,47 +10,80 @@
 namespace ppasr {
 
 template <int R>
-struct LaneT {  // this lane's place in a transposed R x 32 wave tile
-  int lane, wave, row;
-  __device__ __forceinline__ LaneT() : lane(lane_id()), wave(wave_id()), row(RBT<R>::lrow(lane_id())) {}
+struct LaneT {  // this lane's place in a transposed wave tile
+  int lane, wave;
+  __device__ __forceinline__ LaneT() : lane(lane_id()), wave(wave_id()) {}
+  __device__ __forceinline__ int row(int q) const { return RBT<R>::row(q, lane); }  // row (of the block) of quad q
   // first of the 4 consecutive columns (of the block's 256) of quad q
-  __device__ __forceinline__ int col(int q) const { return wave * 32 + RBT<R>::qcol(q, lane); }
+  __device__ __forceinline__ int col(int q) const { return RBT<R>::col(q, lane, wave); }
+  __device__ __forceinline__ int off(int q) const { return row(q) * kLda + col(q); }  // in an LDS row buffer
+  __device__ __forceinline__ int tile() const { return RBT<R>::tile(wave); }        // weight tile the wave streams
+  // quads whose row is inside the block's `valid` rows (a lane's rows ascend with q)
+  __device__ __forceinline__ int quads_ok(int valid) const {
+    int n = 0;
+#pragma unroll
+    for (int q = 0; q < RBT<R>::NQ; ++q) n += row(q) < valid ? 1 : 0;
+    return n;
+  }
 };
-// floats between the first columns of consecutive quads of a lane
-template <int R>
-constexpr int kQuadStep = 32 / RBT<R>::NQ;
 
-// LayerNorm of the block's R rows in LDS (rowblock.h rb_layernorm): wave w normalises rows w, w + 8, ...
+// LDS(row stride kLda) <-> global(row stride 256) with the wave -> row mapping of the LayerNorm below (wave w: rows w,
+// w + WAVES, ...), so that a LayerNorm may follow a load or precede a store without a barrier
+template <int R>
+__device__ __forceinline__ void rbt_load_rows(float* dst, const float* __restrict__ src, int valid) {
+  const int lane = lane_id();
+  for (int row = wave_id(); row < RBT<R>::ROWS; row += RBT<R>::WAVES) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < valid) v = *reinterpret_cast<const f32x4*>(src + (size_t)row * kD + 4 * lane);
+    *reinterpret_cast<f32x4*>(dst + row * kLda + 4 * lane) = v;
+  }
+}
+template <int R>
+__device__ __forceinline__ void rbt_store_rows(float* __restrict__ dst, const float* src, int valid) {
+  const int lane = lane_id();
+  for (int row = wave_id(); row < RBT<R>::ROWS && row < valid; row += RBT<R>::WAVES)
+    *reinterpret_cast<f32x4*>(dst + (size_t)row * kD + 4 * lane) = *reinterpret_cast<const f32x4*>(src + row * kLda + 4 * lane);
+}
+
+// LayerNorm of the block's rows in LDS (rowblock.h rb_layernorm): wave w normalises rows w, w + WAVES, ...
 template <int R, bool SWISH = false, typename ZeroRow = NoZero>
 __device__ __forceinline__ void rbt_layernorm(const float* src, float* dst, const float* __restrict__ gamma,
                                               const float* __restrict__ beta, float eps, ZeroRow zero_row = ZeroRow()) {
   const int lane = lane_id(), wave = wave_id();
   const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * lane);
   const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * lane);
-  constexpr int RN = R / kWaves;
+  constexpr int RN = RBT<R>::ROWS / RBT<R>::WAVES, WV = RBT<R>::WAVES;
   f32x4 x[RN];
 #pragma unroll
-  for (int i = 0; i < RN; ++i) x[i] = *reinterpret_cast<const f32x4*>(src + (wave + i * kWaves) * kLda + 4 * lane);
+  for (int i = 0; i < RN; ++i) x[i] = *reinterpret_cast<const f32x4*>(src + (wave + i * WV) * kLda + 4 * lane);
   ln_rows_inreg<SWISH, RN>(x, g, b, eps);
 #pragma unroll
   for (int i = 0; i < RN; ++i) {
-    const int row = wave + i * kWaves;
+    const int row = wave + i * WV;
     if (zero_row(row)) x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     *reinterpret_cast<f32x4*>(dst + row * kLda + 4 * lane) = x[i];
   }
 }
 
-// frame (row m of the flattened [B][Tp] rows) is PAD iff mul * t >= lens[b]; one per-lane length load, to be issued early
-struct PadLane {
-  bool pad = false;
-  __device__ __forceinline__ PadLane() {}
-  __device__ __forceinline__ PadLane(const int64_t* __restrict__ lens, int m, int M, int Tp, int mul) {
-    if (lens) {
-      const int nb = max(M / Tp, 1);
-      const int b = min(m / Tp, nb - 1), t = m - b * Tp;
-      pad = m < M && (int64_t)mul * t >= lens[b];
+// frame (row m of the flattened [B][Tp] rows) is PAD iff mul * t >= lens[b]; one length load per row the lane's quads
+// touch, to be issued early
+template <int R>
+struct PadLaneT {
+  bool pad_[RBT<R>::NR];
+  __device__ __forceinline__ PadLaneT(const int64_t* __restrict__ lens, int r0, int M, int Tp, int mul) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int i = 0; i < RBT<R>::NR; ++i) {
+      pad_[i] = false;
+      if (lens) {
+        const int m = r0 + RBT<R>::row(i, lane);
+        const int nb = max(M / Tp, 1);
+        const int b = min(m / Tp, nb - 1), t = m - b * Tp;
+        pad_[i] = m < M && (int64_t)mul * t >= lens[b];
+      }
     }
   }
+  __device__ __forceinline__ bool pad(int q) const { return pad_[RBT<R>::NR == 1 ? 0 : q]; }
 };
 
 // Swish epilogue of the previous W1 tile inside the next unit's MFMA stream (phases.h SwishSide on the quad view): quad
@@ -58,7 +91,7 @@ struct PadLane {
 template <int R>
 struct SwishSideT {
   const typename RBT<R>::Acc& acc;
-  float* dst;  // hidden buffer + row * kLda + first column of the lane's quad 0
+  float* dst;  // hidden buffer + place of the lane's quad 0 (LaneT::off(0))
   const f32x4 (&bias)[RBT<R>::NQ];
   mutable f32x2 lo;
   __device__ __forceinline__ void operator()(int g) const {
@@ -71,14 +104,14 @@ struct SwishSideT {
     if (g % STEP == STEP / 2) {
       const f32x4 v = RBT<R>::quad(acc, q);
       const f32x2 hi = swish2(f32x2{v[2] + bias[q][2], v[3] + bias[q][3]});
-      *reinterpret_cast<f32x4*>(dst + q * kQuadStep<R>) = f32x4{lo[0], lo[1], hi[0], hi[1]};
+      *reinterpret_cast<f32x4*>(dst + q * RBT<R>::QLDS) = f32x4{lo[0], lo[1], hi[0], hi[1]};
     }
   }
 };
 
 // PositionwiseFeedForward on LDS-resident rows (phases.h ffn_phase<true>): acc2 += swish(A W1 + b1) W2 with the hidden
 // dimension in 256-wide chunks that never leave LDS (bufH: two R x kLda buffers); weight stream W1(0), W1(1), W2(0),
-// W1(2), W2(1), ..., W2(n-1), then `after`.
+// W1(2), W2(1), ..., W2(n-1), then `after` (k-group 0 of the wave's weight TILE, as every segment passed to rbt_gemm).
 template <int R>
 __device__ __forceinline__ void ffn_phase_t(const float* bufA, float* bufH, const f32x4* __restrict__ w1,
                                             const float* __restrict__ b1, const f32x4* __restrict__ w2, int n_chunks,
@@ -87,14 +120,14 @@ __device__ __forceinline__ void ffn_phase_t(const float* bufA, float* bufH, cons
   using T = RBT<R>;
   const LaneT<R> L;
   const int ts2 = n_chunks * 32 * 64;  // W2: K = hidden
-  auto w1seg = [&](int c) { return w1 + (size_t)(c * 8 + L.wave) * kTs256; };
-  auto w2seg = [&](int c) { return w2 + (size_t)L.wave * ts2 + (size_t)c * 32 * 64; };
+  auto w1seg = [&](int c) { return w1 + (size_t)(c * 8 + L.tile()) * kTs256; };
+  auto w2seg = [&](int c) { return w2 + (size_t)L.tile() * ts2 + (size_t)c * 32 * 64; };
   typename T::Acc cur, nx;
   T::zero(cur);
   rbt_gemm<kG256>(bufA, kLda, w1seg(0), n_chunks > 1 ? w1seg(1) : w2seg(0), ring, cur);
-  const int hoff = L.row * kLda + L.col(0);
+  const int hoff = L.off(0);
   for (int c = 0; c < n_chunks; ++c) {
-    float* hb = bufH + (c & 1) * R * kLda;
+    float* hb = bufH + (c & 1) * T::ROWS * kLda;
     f32x4 bias[T::NQ];
 #pragma unroll
     for (int q = 0; q < T::NQ; ++q) bias[q] = *reinterpret_cast<const f32x4*>(b1 + c * 256 + L.col(q));
@@ -107,10 +140,12 @@ __device__ __forceinline__ void ffn_phase_t(const float* bufA, float* bufH, cons
         const f32x4 v = T::quad(cur, q);
         const f32x2 lo = swish2(f32x2{v[0] + bias[q][0], v[1] + bias[q][1]});
         const f32x2 hi = swish2(f32x2{v[2] + bias[q][2], v[3] + bias[q][3]});
-        *reinterpret_cast<f32x4*>(hb + hoff + q * kQuadStep<R>) = f32x4{lo[0], lo[1], hi[0], hi[1]};
+        *reinterpret_cast<f32x4*>(hb + hoff + q * T::QLDS) = f32x4{lo[0], lo[1], hi[0], hi[1]};
       }
     }
+    if (c < 8) PPASR_TS(16 + 2 * c);
     __syncthreads();
+    if (c < 8) PPASR_TS(17 + 2 * c);
     const f32x4* nseg = (c + 2 < n_chunks) ? w1seg(c + 2) : (c + 1 < n_chunks ? w2seg(c + 1) : after);
     rbt_gemm<kG256>(hb, kLda, w2seg(c), nseg, ring, acc2);
     cur = nx;
@@ -124,7 +159,7 @@ __device__ __forceinline__ void residual_epilogue_q(float* bufX, const typename 
   const LaneT<R> L;
 #pragma unroll
   for (int q = 0; q < RBT<R>::NQ; ++q) {
-    float* p = bufX + L.row * kLda + L.col(q);
+    float* p = bufX + L.off(q);
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + L.col(q));
     const f32x4 a = RBT<R>::quad(acc, q);
     f32x4 x = *reinterpret_cast<const f32x4*>(p);
@@ -138,26 +173,33 @@ __device__ __forceinline__ void residual_epilogue_q(float* bufX, const typename 
 template <int R>
 struct QuadStoreSide {
   const typename RBT<R>::Acc& acc;
-  float* out;  // global row of this lane + first column of its quad 0; nullptr: row >= valid
+  float* out;   // place of the lane's quad 0 in the global matrix
+  int qstep;    // floats from one quad of the lane to the next there (RBT<R>::qstep(row stride))
+  int n_ok;     // the lane's first n_ok quads lie in valid rows
   const f32x4 (&bias)[RBT<R>::NQ];
   __device__ __forceinline__ void operator()(int g) const {
     constexpr int STEP = 32 / RBT<R>::NQ;
-    if (g % STEP == STEP / 2 && out) {
-      const int q = g / STEP;
+    const int q = g / STEP;
+    if (g % STEP == STEP / 2 && q < n_ok) {
       const f32x4 v = RBT<R>::quad(acc, q);
-      *reinterpret_cast<f32x4*>(out + q * kQuadStep<R>) = f32x4{v[0] + bias[q][0], v[1] + bias[q][1], v[2] + bias[q][2], v[3] + bias[q][3]};
+      *reinterpret_cast<f32x4*>(out + q * qstep) = f32x4{v[0] + bias[q][0], v[1] + bias[q][1], v[2] + bias[q][2], v[3] + bias[q][3]};
     }
   }
 };
 
 // qkv[r0 + row][0 .. 768) = bufX * [Wq | Wk | Wv] + b (row-major): three transposed units, the stores of unit c sliced
-// into the MFMA stream of unit c + 1.  `ring` already streams wqkv tile `wave`.
+// into the MFMA stream of unit c + 1.  `ring` already streams wqkv tile LaneT::tile().
+// vt != nullptr (16-wave form only): the values go to vt in the fragment order of the fused attention kernel instead
+// (conformer_kernels.h VtOut: [32-column slab][row octet][lane = column + 32 (row quad)][4 rows]) -- the V unit then runs
+// in the plain orientation, where a lane's register quad IS four consecutive rows of one column = one 16-byte piece.
 template <int R>
 __device__ __forceinline__ void qkv_phase_t(const float* bufX, float* __restrict__ qkv, const f32x4* __restrict__ wqkv,
-                                            const float* __restrict__ bqkv, int r0, int valid, typename RBT<R>::Ring& ring) {
+                                            const float* __restrict__ bqkv, int r0, int valid, typename RBT<R>::Ring& ring,
+                                            float* __restrict__ vt = nullptr, int vt_stride = 0) {
   using T = RBT<R>;
   const LaneT<R> L;
-  float* qrow = L.row < valid ? qkv + (size_t)(r0 + L.row) * 768 + L.col(0) : nullptr;
+  float* q0 = qkv + (size_t)(r0 + L.row(0)) * 768 + L.col(0);
+  const int qs = T::qstep(768), n_ok = L.quads_ok(valid);
   f32x4 qb[3][T::NQ];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
@@ -167,17 +209,36 @@ __device__ __forceinline__ void qkv_phase_t(const float* bufX, float* __restrict
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     T::zero(tile[c]);
-    const f32x4* seg = wqkv + (size_t)(c * 8 + L.wave) * kTs256;
+    const f32x4* seg = wqkv + (size_t)(c * 8 + L.tile()) * kTs256;
     const f32x4* nseg = c < 2 ? seg + 8 * kTs256 : nullptr;
-    if (c == 0) rbt_gemm<kG256>(bufX, kLda, seg, nseg, ring, tile[c]);
-    else rbt_gemm<kG256>(bufX, kLda, seg, nseg, ring, tile[c], QuadStoreSide<R>{tile[c - 1], qrow ? qrow + (c - 1) * 256 : nullptr, qb[c - 1]});
-  }
-  if (qrow) {
-#pragma unroll
-    for (int q = 0; q < T::NQ; ++q) {
-      const f32x4 v = T::quad(tile[2], q);
-      *reinterpret_cast<f32x4*>(qrow + 512 + q * kQuadStep<R>) = v + qb[2][q];
+    if (c == 0) {
+      rbt_gemm<kG256>(bufX, kLda, seg, nseg, ring, tile[c]);
+    } else {
+      const QuadStoreSide<R> store{tile[c - 1], q0 + (c - 1) * 256, qs, n_ok, qb[c - 1]};
+      if constexpr (R == kW16) {
+        if (c == 2 && vt) rbt_gemm<kG256, QuadStoreSide<R>, false>(bufX, kLda, seg, nseg, ring, tile[c], store);
+        else rbt_gemm<kG256>(bufX, kLda, seg, nseg, ring, tile[c], store);
+      } else {
+        rbt_gemm<kG256>(bufX, kLda, seg, nseg, ring, tile[c], store);
+      }
     }
+  }
+  if constexpr (R == kW16) {
+    if (vt) {
+      const int c32 = 16 * (L.wave & 1) + (L.lane & 15), kq = L.lane >> 4;
+      const float bv = bqkv[512 + 16 * L.wave + (L.lane & 15)];
+      float* dst = vt + ((size_t)(L.wave >> 1) * (vt_stride >> 3) + (r0 >> 3) + (kq >> 1)) * 256 + 4 * (c32 + 32 * (kq & 1));
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 v = tile[2].s[q];
+        *reinterpret_cast<f32x4*>(dst + q * 512) = f32x4{v[0] + bv, v[1] + bv, v[2] + bv, v[3] + bv};
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < T::NQ; ++q) {
+    if (q < n_ok) *reinterpret_cast<f32x4*>(q0 + 512 + q * qs) = T::quad(tile[2], q) + qb[2][q];
   }
 }
 
@@ -235,13 +296,9 @@ __device__ __forceinline__ void dw_chunks(__amdgpu_buffer_rsrc_t rs_g, __amdgpu_
   }
 }
 
-#ifndef PPASR_DW_TC
-#define PPASR_DW_TC 16  // taps per chunk of a module with more than 16 taps (31: chunks of 16 and 15)
-#endif
-
 // Depthwise conv (KS taps) + conv-module LayerNorm + swish of the block's rows, in registers (phases.h dwconv_ln_phase
-// for any R and KS): wave w owns the RW = R / 8 consecutive rows RW w .. RW w + RW - 1; the taps are walked in chunks
-// of <= 16 so that window rows + tap weights stay inside the register budget for the 31-tap Squeezeformer module
+// for any form and KS): wave w owns the RW = ROWS / WAVES consecutive rows RW w .. RW w + RW - 1; the taps are walked in
+// chunks of <= RBT<R>::DW_TC (16; 8 in the 16-wave form) so that window rows + tap weights stay inside the register budget
 // (every output row still accumulates its taps in ascending order: bit-identical to the one-pass form).  A wave whose
 // rows straddle an utterance boundary runs the walk twice, once per utterance, and keeps per row the result of the
 // row's own utterance (needs Tp >= RW).
@@ -254,7 +311,7 @@ __device__ __forceinline__ void dwconv_ln_phase_t(const float* __restrict__ g, f
                                                   const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps,
                                                   int r0, int M, int Tp, int left, Between between) {
   const int lane = lane_id(), wave = wave_id();
-  constexpr int LO = KS - 1, RW = R / kWaves, TC = KS <= 16 ? 16 : PPASR_DW_TC;
+  constexpr int LO = KS - 1, RW = RBT<R>::RW, TC = KS <= RBT<R>::DW_TC ? 16 : RBT<R>::DW_TC;
   const bool causal = (left == LO);
   const int q0 = wave * RW;
   f32x4 gp = *reinterpret_cast<const f32x4*>(glu_pad + 4 * lane);

@@ -41,6 +41,7 @@ constexpr int kLda = kD + 4;   // LDS row stride (floats) of a [rows][256] activ
 constexpr int kRows = 32;      // rows per MFMA row tile
 constexpr int kWaves = 8;      // waves per row-block workgroup
 constexpr int kThreads = 64 * kWaves;
+constexpr int kW16 = 1032;     // form id of "32 rows on 16 waves" (rbt.h; the 8-wave forms are named by their row count)
 constexpr int kG256 = kD / 8;  // k-groups of a K=256 contraction
 constexpr int kTs256 = kG256 * 64;  // packed tile stride (f32x4 units) of a K=256 weight
 

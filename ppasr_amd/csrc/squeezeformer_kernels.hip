@@ -68,7 +68,7 @@ __device__ __forceinline__ void qkv_from_lds(const float* bufX, float* __restric
 }
 
 
-// ---- K_B / K_C on transposed accumulators, R = 32 or 16 rows per block (rbt.h, phases_t.h) ----
+// ---- K_B / K_C on transposed accumulators, block forms of rbt.h: R = 32 / 16 rows on 8 waves, kW16 = 32 rows on 16 ----
 // Same arithmetic as k_sq_mid / k_sq_tail below (R = 32: bit-identical -- the swapped MFMA form computes the same sums in
 // the same order); what changed is how the work is issued: every epilogue on 16-byte quads (lane = row), residual rows
 // and the pad flag requested at kernel start (one length load per lane instead of one per accumulator register), the
@@ -76,44 +76,46 @@ __device__ __forceinline__ void qkv_from_lds(const float* bufX, float* __restric
 // round trips), the hidden-tile / QKV stores sliced into the next unit's MFMA stream.  R = 16 (v_mfma_f32_16x16x4_f32):
 // for launches whose 32-row blocks would leave more than half of the CUs idle.
 template <int R>
-__global__ __launch_bounds__(kThreads) void k_sq_mid_t(const float* __restrict__ ctx, const float* __restrict__ x,
+__global__ __launch_bounds__(RBT<R>::THREADS) void k_sq_mid_t(const float* __restrict__ ctx, const float* __restrict__ x,
                                                        float* __restrict__ x2, float* __restrict__ g,
                                                        float* __restrict__ xhat_out, SqLayerW w,
                                                        const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
                                                        int n_chunks, PadSkip ps) {
   using T = RBT<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * R, R, M)) return;
+  if (pad_block_skippable(ps, blockIdx.x * T::ROWS, T::ROWS, M)) return;
   float* bufX = smem;
-  float* bufH = bufX + R * kLda;  // 2 buffers; bufH[0] doubles as the ctx staging tile
+  float* bufH = bufX + T::ROWS * kLda;  // 2 buffers; bufH[0] doubles as the ctx staging tile
   const LaneT<R> L;
-  const int r0 = blockIdx.x * R;
-  const int valid = min(R, M - r0);
+  const int r0 = blockIdx.x * T::ROWS;
+  const int valid = min(T::ROWS, M - r0);
   typename T::Ring ring;
-  const f32x4* seg_o = w.wo + (size_t)L.wave * kTs256;
-  const f32x4* seg_val = w.pw1 + (size_t)L.wave * kTs256;
-  const f32x4* seg_gate = w.pw1 + (size_t)(8 + L.wave) * kTs256;
+  const f32x4* seg_o = w.wo + (size_t)L.tile() * kTs256;
+  const f32x4* seg_val = w.pw1 + (size_t)L.tile() * kTs256;
+  const f32x4* seg_gate = w.pw1 + (size_t)(8 + L.tile()) * kTs256;
   rbt_prime(ring, seg_o);
-  rb_load_rows(bufH, kLda, ctx + (size_t)r0 * kD, R, valid);
-  const size_t grow = (size_t)(r0 + min(L.row, valid - 1)) * kD;  // this lane's row in x / g (clamped: branch-free loads)
-  const bool row_ok = L.row < valid;
+  rbt_load_rows<R>(bufH, ctx + (size_t)r0 * kD, valid);
+  size_t gq[T::NQ];  // place of quad q in x / g (row clamped: branch-free loads)
+#pragma unroll
+  for (int q = 0; q < T::NQ; ++q) gq[q] = (size_t)(r0 + min(L.row(q), valid - 1)) * kD + L.col(q);
+  const int n_ok = L.quads_ok(valid);
   f32x4 res[T::NQ];
 #pragma unroll
-  for (int q = 0; q < T::NQ; ++q) res[q] = *reinterpret_cast<const f32x4*>(x + grow + L.col(q));
-  const PadLane pl(lens, r0 + L.row, M, Tp, mask_mul);
+  for (int q = 0; q < T::NQ; ++q) res[q] = *reinterpret_cast<const f32x4*>(x + gq[q]);
+  const PadLaneT<R> pl(lens, r0, M, Tp, mask_mul);
   __syncthreads();
   {
     typename T::Acc acc;
     T::zero(acc);
-    rbt_gemm<kG256>(bufH, kLda, seg_o, w.ff1_w1 + (size_t)L.wave * kTs256, ring, acc);
+    rbt_gemm<kG256>(bufH, kLda, seg_o, w.ff1_w1 + (size_t)L.tile() * kTs256, ring, acc);
 #pragma unroll
     for (int q = 0; q < T::NQ; ++q) {
       const f32x4 bo = *reinterpret_cast<const f32x4*>(w.bo + L.col(q));
       const f32x4 a = T::quad(acc, q);
       f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = row_ok ? res[q][e] + (a[e] + bo[e]) : 0.f;
-      *reinterpret_cast<f32x4*>(bufX + L.row * kLda + L.col(q)) = v;
+      for (int e = 0; e < 4; ++e) v[e] = q < n_ok ? res[q][e] + (a[e] + bo[e]) : 0.f;
+      *reinterpret_cast<f32x4*>(bufX + L.off(q)) = v;
     }
   }
   __syncthreads();
@@ -125,11 +127,11 @@ __global__ __launch_bounds__(kThreads) void k_sq_mid_t(const float* __restrict__
   residual_epilogue_q<R>(bufX, acc2, w.ff1_b2, 1.0f);
   __syncthreads();
   rbt_layernorm<R>(bufX, bufX, w.ln2_g, w.ln2_b, 1e-5f);
-  rb_store_rows(x2 + (size_t)r0 * kD, bufX, kLda, R, valid);  // (same wave -> row mapping as the LayerNorm)
+  rbt_store_rows<R>(x2 + (size_t)r0 * kD, bufX, valid);  // (same wave -> row mapping as the LayerNorm)
   if (xhat_out) {  // streaming: what the reference keeps as cnn_cache = the scaled conv-module input
     const f32x4 sc = *reinterpret_cast<const f32x4*>(w.cm_scale + 4 * L.lane);
     const f32x4 sb = *reinterpret_cast<const f32x4*>(w.cm_bias + 4 * L.lane);
-    for (int row = L.wave; row < valid; row += kWaves)
+    for (int row = L.wave; row < valid; row += T::WAVES)
       *reinterpret_cast<f32x4*>(xhat_out + (size_t)(r0 + row) * kD + 4 * L.lane) =
           sc * *reinterpret_cast<const f32x4*>(bufX + row * kLda + 4 * L.lane) + sb;
   }
@@ -149,14 +151,14 @@ __global__ __launch_bounds__(kThreads) void k_sq_mid_t(const float* __restrict__
       const f32x2 s0 = sigmoid2(f32x2{b[0] + bgate[0], b[1] + bgate[1]});
       const f32x2 s1 = sigmoid2(f32x2{b[2] + bgate[2], b[3] + bgate[3]});
       f32x4 o = {(a[0] + bval[0]) * s0[0], (a[1] + bval[1]) * s0[1], (a[2] + bval[2]) * s1[0], (a[3] + bval[3]) * s1[1]};
-      if (pl.pad) o = gpad;
-      if (row_ok) *reinterpret_cast<f32x4*>(g + grow + L.col(q)) = o;
+      if (pl.pad(q)) o = gpad;
+      if (q < n_ok) *reinterpret_cast<f32x4*>(g + gq[q]) = o;
     }
   }
 }
 
 template <int R, int KS>
-__global__ __launch_bounds__(kThreads) void k_sq_tail_t(const float* __restrict__ g, const float* __restrict__ x2,
+__global__ __launch_bounds__(RBT<R>::THREADS) void k_sq_tail_t(const float* __restrict__ g, const float* __restrict__ x2,
                                                         float* __restrict__ x_out, float* __restrict__ qkv_next,
                                                         SqLayerW w, const f32x4* __restrict__ wqkv_next,
                                                         const float* __restrict__ bqkv_next,
@@ -164,39 +166,39 @@ __global__ __launch_bounds__(kThreads) void k_sq_tail_t(const float* __restrict_
                                                         int n_chunks, PadSkip ps, int left_ctx) {
   using T = RBT<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * R, R, M)) return;
+  if (pad_block_skippable(ps, blockIdx.x * T::ROWS, T::ROWS, M)) return;
   float* bufX = smem;
-  float* bufA = bufX + R * kLda;
-  float* bufH = bufA + R * kLda;
+  float* bufA = bufX + T::ROWS * kLda;
+  float* bufH = bufA + T::ROWS * kLda;
   const LaneT<R> L;
-  const int r0 = blockIdx.x * R;
-  const int valid = min(R, M - r0);
+  const int r0 = blockIdx.x * T::ROWS;
+  const int valid = min(T::ROWS, M - r0);
   typename T::Ring ring;
-  const f32x4* seg_pw2 = w.pw2 + (size_t)L.wave * kTs256;
-  const PadLane pl(lens, r0 + L.row, M, Tp, mask_mul);
-  const bool row_ok = L.row < valid;
+  const f32x4* seg_pw2 = w.pw2 + (size_t)L.tile() * kTs256;
+  const PadLaneT<R> pl(lens, r0, M, Tp, mask_mul);
+  const int n_ok = L.quads_ok(valid);
   // weight stream and the residual rows of the pointwise_conv2 epilogue: requested after the depthwise multiply-adds
   // (whose register window they would otherwise compete with), in flight during the conv-module LayerNorm; branch-free
   f32x4 res[T::NQ];
   dwconv_ln_phase_t<R, KS>(g, bufA, w.dw_w, w.dw_b, w.glu_pad, w.ln_cm_g, w.ln_cm_b, w.cm_eps, r0, M, Tp, left_ctx, [&] {
     rbt_prime(ring, seg_pw2);
-    const float* rp = x2 + (size_t)(r0 + min(L.row, valid - 1)) * kD;
 #pragma unroll
-    for (int q = 0; q < T::NQ; ++q) res[q] = *reinterpret_cast<const f32x4*>(rp + L.col(q));
+    for (int q = 0; q < T::NQ; ++q)
+      res[q] = *reinterpret_cast<const f32x4*>(x2 + (size_t)(r0 + min(L.row(q), valid - 1)) * kD + L.col(q));
   });
   __syncthreads();
   {
     typename T::Acc acc;
     T::zero(acc);
-    rbt_gemm<kG256>(bufA, kLda, seg_pw2, w.ff2_w1 + (size_t)L.wave * kTs256, ring, acc);
+    rbt_gemm<kG256>(bufA, kLda, seg_pw2, w.ff2_w1 + (size_t)L.tile() * kTs256, ring, acc);
 #pragma unroll
     for (int q = 0; q < T::NQ; ++q) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(w.pw2_b + L.col(q));
       const f32x4 a = T::quad(acc, q);
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = row_ok ? res[q][e] + (pl.pad ? 0.f : a[e] + bv[e]) : 0.f;
-      *reinterpret_cast<f32x4*>(bufX + L.row * kLda + L.col(q)) = o;
+      for (int e = 0; e < 4; ++e) o[e] = q < n_ok ? res[q][e] + (pl.pad(q) ? 0.f : a[e] + bv[e]) : 0.f;
+      *reinterpret_cast<f32x4*>(bufX + L.off(q)) = o;
     }
   }
   __syncthreads();
@@ -204,12 +206,12 @@ __global__ __launch_bounds__(kThreads) void k_sq_tail_t(const float* __restrict_
   __syncthreads();
   typename T::Acc acc2;
   T::zero(acc2);
-  ffn_phase_t<R>(bufX, bufH, w.ff2_w1, w.ff2_b1, w.ff2_w2, n_chunks, wqkv_next ? wqkv_next + (size_t)L.wave * kTs256 : nullptr,
+  ffn_phase_t<R>(bufX, bufH, w.ff2_w1, w.ff2_b1, w.ff2_w2, n_chunks, wqkv_next ? wqkv_next + (size_t)L.tile() * kTs256 : nullptr,
                  ring, acc2);
   residual_epilogue_q<R>(bufX, acc2, w.ff2_b2, 1.0f);
   __syncthreads();
   rbt_layernorm<R>(bufX, bufX, w.ln4_g, w.ln4_b, 1e-5f);
-  rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, R, valid);
+  rbt_store_rows<R>(x_out + (size_t)r0 * kD, bufX, valid);
   if (wqkv_next) {
     __syncthreads();
     qkv_phase_t<R>(bufX, qkv_next, wqkv_next, bqkv_next, r0, valid, ring);
@@ -580,6 +582,9 @@ void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, float*
   else if (rows == 16)
     PPASR_LAUNCH(k_sq_mid_t<16>, dim3((M + 15) / 16), dim3(kThreads), lds16(kLdsSqMid16), st, ctx, x, x2, g, xhat_out, w, lens,
                  M, Tp, mask_mul, n_chunks, ps);
+  else if (rows == kW16)
+    PPASR_LAUNCH(k_sq_mid_t<kW16>, rb_grid(M), dim3(1024), kLdsSqMid, st, ctx, x, x2, g, xhat_out, w, lens, M, Tp, mask_mul,
+                 n_chunks, ps);
   else
     PPASR_LAUNCH(k_sq_mid_t<32>, rb_grid(M), dim3(kThreads), kLdsSqMid, st, ctx, x, x2, g, xhat_out, w, lens, M, Tp, mask_mul,
                  n_chunks, ps);
@@ -592,10 +597,12 @@ void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float*
   // chunks (g_hist) keep the LDS-staged form
   if (!g_hist && !sq_legacy() && Tp >= 4 && (ksize == 31 || ksize == 15)) {
 #define SQ_TAIL_T(R, KS, LDS)                                                                                         \
-  PPASR_LAUNCH((k_sq_tail_t<R, KS>), dim3((M + R - 1) / R), dim3(kThreads), LDS, st, g, x2, x_out, qkv_next, w,       \
-               wqkv_next, bqkv_next, lens, M, Tp, mask_mul, n_chunks, ps, left_ctx)
+  PPASR_LAUNCH((k_sq_tail_t<R, KS>), dim3((M + RBT<R>::ROWS - 1) / RBT<R>::ROWS), dim3(RBT<R>::THREADS), LDS, st, g, x2, \
+               x_out, qkv_next, w, wqkv_next, bqkv_next, lens, M, Tp, mask_mul, n_chunks, ps, left_ctx)
     if (rows == 16) {
       if (ksize == 31) SQ_TAIL_T(16, 31, lds16(kLdsSqTail16)); else SQ_TAIL_T(16, 15, lds16(kLdsSqTail16));
+    } else if (rows == kW16) {
+      if (ksize == 31) SQ_TAIL_T(kW16, 31, kLdsSqTail); else SQ_TAIL_T(kW16, 15, kLdsSqTail);
     } else {
       if (ksize == 31) SQ_TAIL_T(32, 31, kLdsSqTail); else SQ_TAIL_T(32, 15, kLdsSqTail);
     }
@@ -641,6 +648,9 @@ hipError_t configure_squeezeformer_kernels() {
   SET_LDS(k_sq_mid, kLdsSqMid);
   SET_LDS(k_sq_mid_t<32>, kLdsSqMid);
   SET_LDS(k_sq_mid_t<16>, kLdsExclusive);
+  SET_LDS(k_sq_mid_t<kW16>, kLdsSqMid);
+  SET_LDS((k_sq_tail_t<kW16, 31>), kLdsSqTail);
+  SET_LDS((k_sq_tail_t<kW16, 15>), kLdsSqTail);
   SET_LDS((k_sq_tail_t<32, 31>), kLdsSqTail);
   SET_LDS((k_sq_tail_t<32, 15>), kLdsSqTail);
   SET_LDS((k_sq_tail_t<16, 31>), kLdsExclusive);

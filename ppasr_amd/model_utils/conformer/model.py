@@ -214,8 +214,8 @@ class ConformerModel:
         _lib.check(self.lib.ppasr_set_ffn_split(self._h, int(mode)))
 
     def set_row_block(self, rows=-1):
-        """Rows per workgroup of the layer kernels (``ppasr_set_row_block``): -1 = by grid size (16-row blocks for launches
-        whose 32-row blocks would fill at most half of the chip), 16 / 32 = always."""
+        """Block form of the layer kernels (``ppasr_set_row_block``): -1 = by grid size (16-row blocks for under-filled
+        launches, else 32), 16 / 32 = always, 1032 (``PPASR_ROW_BLOCK_32_W16``) = 32 rows on 16 waves (optional form)."""
         _lib.check(self.lib.ppasr_set_row_block(self._h, int(rows)))
 
     def set_lengths_hint(self, lengths=None):

@@ -1,7 +1,7 @@
-"""GPU: the Squeezeformer layer kernels on transposed accumulators (csrc/rbt.h, phases_t.h) -- 32-row blocks are
-bit-identical to the round-3 kernels they replace (same sums, same order), 16-row blocks (v_mfma_f32_16x16x4_f32) agree
-to rounding, hold the oracle tolerance on their own, and the route choice (ppasr_set_row_block, ppasr_set_lengths_hint)
-never changes which rows are computed."""
+"""GPU: the layer kernels on the block forms of csrc/rbt.h (phases_t.h) -- 32-row blocks on 8 waves are bit-identical to
+the round-3 kernels they replace (same sums, same order); 16-row blocks and 32 rows on 16 waves (both
+v_mfma_f32_16x16x4_f32) agree to rounding, hold the oracle tolerance on their own, and the route choice
+(ppasr_set_row_block, ppasr_set_lengths_hint) never changes which rows are computed."""
 import os
 import subprocess
 import sys
@@ -16,6 +16,7 @@ from ppasr_amd.utils.synth import squeezeformer_state_dict, synth_features
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 V, L, RED, REC = 300, 5, 2, 4
+W16 = 1032  # PPASR_ROW_BLOCK_32_W16
 # 16 utterances of 152 frames: 76 blocks of 32 rows on the full-rate layers, 38 on the reduced ones -- both inside the
 # window (33 .. 128 blocks) where the grid-size rule picks the 16-row kernels
 LENS = [611, 600, 333, 97, 611, 13, 250, 480, 611, 420, 77, 590, 611, 305, 150, 555]
@@ -51,19 +52,41 @@ def test_16_row_blocks_match_32_row_blocks_and_the_oracle(streaming, kernel, nor
     x, lens = synth_features(len(LENS), 611, lens=LENS, seed=72)
     p32, l32 = _run(model, x, lens, 32)
     p16, l16 = _run(model, x, lens, 16)
+    pw, lw = _run(model, x, lens, W16)
     pa, la = _run(model, x, lens, -1)   # the grid-size rule picks the 16-row kernels for every layer of this batch
     assert np.array_equal(la, l16)
-    e = _rel(l16, l32)
-    print("16 vs 32 rows: max rel logit diff", e)
-    assert e < 2e-5
+    e, ew = _rel(l16, l32), _rel(lw, l32)
+    print("16 vs 32 rows: max rel logit diff", e, " 32 rows on 16 waves vs 8:", ew)
+    assert e < 2e-5 and ew < 2e-5
     oracle = SqueezeformerOracle(sd, num_blocks=L, cnn_module_kernel=kernel, reduce_idx=RED, recover_idx=REC, causal=streaming)
     with torch.no_grad():
         enc, _ = oracle.encoder_forward(x, lens)[:2]
         ref = oracle.ctc_logits(enc).numpy()
-    e16, e32 = _rel(l16, ref), _rel(l32, ref)
-    print("vs oracle: 16-row", e16, "32-row", e32)
-    assert e16 < 1e-3 and e32 < 1e-3
-    assert np.array_equal(p16.argmax(-1), p32.argmax(-1)) or (np.sort(p32, -1)[..., -1] - np.sort(p32, -1)[..., -2]).min() < 1e-5
+    e16, e32, ew16 = _rel(l16, ref), _rel(l32, ref), _rel(lw, ref)
+    print("vs oracle: 16-row", e16, "32-row", e32, "32 rows on 16 waves", ew16)
+    assert e16 < 1e-3 and e32 < 1e-3 and ew16 < 1e-3
+    near_tie = (np.sort(p32, -1)[..., -1] - np.sort(p32, -1)[..., -2]).min() < 1e-5
+    assert np.array_equal(p16.argmax(-1), p32.argmax(-1)) or near_tie
+    assert np.array_equal(pw.argmax(-1), p32.argmax(-1)) or near_tie
+
+
+def test_16_wave_kernels_on_a_full_launch_with_a_partial_last_block():
+    """32 utterances x 151 frames = 151 blocks of 32 rows (the last one 16 rows): 32 rows on 16 waves (an option,
+    PPASR_ROW_BLOCK_32_W16) against the 8-wave kernels; the grid-size rule mixes 32-row blocks at the full rate with
+    16-row blocks at the reduced one (76 blocks)."""
+    model, _ = _model()
+    lens_l = (LENS + LENS[::-1])
+    lens_l = [min(v, 607) for v in lens_l]
+    x, lens = synth_features(len(lens_l), 607, lens=lens_l, seed=75)
+    pa, la = _run(model, x, lens, -1)
+    pw, lw = _run(model, x, lens, W16)
+    p32, l32 = _run(model, x, lens, 32)
+    fl = model.valid_out_frames(lens, 607).cpu().numpy()
+    # the auto route mixes forms per layer; both it and the forced form stay within rounding of the 8-wave kernels
+    for u in range(len(lens_l)):
+        n = int(fl[u])
+        assert _rel(la[u, :n], l32[u, :n]) < 2e-5 and _rel(lw[u, :n], l32[u, :n]) < 2e-5
+    assert not np.array_equal(lw, l32)   # (a different summation order: the 16-wave kernels did run)
 
 
 def test_ragged_mode_with_hint_computes_the_same_valid_rows():
@@ -85,6 +108,8 @@ def test_ragged_mode_with_hint_computes_the_same_valid_rows():
         model.set_lengths_hint(None)
         model.set_row_block(32)
         c = model.get_encoder_out(x, lens).cpu().numpy()
+        model.set_row_block(W16)
+        d = model.get_encoder_out(x, lens).cpu().numpy()
     finally:
         model.set_row_block(-1)
         model.set_lengths_hint(None)
@@ -92,8 +117,8 @@ def test_ragged_mode_with_hint_computes_the_same_valid_rows():
     for u in range(len(LENS)):
         n = int(fl[u])
         assert np.array_equal(a[u, :n], b[u, :n])
-        assert _rel(a[u, :n], c[u, :n]) < 2e-5
-        assert not a[u, n:].any() and not b[u, n:].any() and not c[u, n:].any()
+        assert _rel(a[u, :n], c[u, :n]) < 2e-5 and _rel(d[u, :n], c[u, :n]) < 2e-5
+        assert not a[u, n:].any() and not b[u, n:].any() and not c[u, n:].any() and not d[u, n:].any()
 
 
 def test_32_row_kernels_are_bit_identical_to_the_round3_kernels():
@@ -152,8 +177,45 @@ def test_conformer_family_16_row_blocks(family):
     p16, l16 = _run(model, x, la, 16)
     pa, la_ = _run(model, x, la, -1)           # 57 / 114 blocks: the rule picks the 16-row kernels
     assert np.array_equal(la_, l16)
-    e = _rel(l16, l32)
+    # 32 rows on 16 waves inside the fused route (ppasr_set_ffn_split(0)): k_ffn_qkv_t / k_conv_ffn_t<kW16> write the values
+    # in the fragment order the fused attention kernel reads; grouped-attention layers take k_out_glu_t<kW16>
+    model.set_ffn_split(0)
+    pw, lw = _run(model, x, la, W16)
+    model.set_ffn_split(-1)
+    e, ew = _rel(l16, l32), _rel(lw, l32)
     ref = oracle.get_encoder_out(x, la, return_logits=True)[1].numpy()
-    e16, e32 = _rel(l16, ref), _rel(l32, ref)
-    print(family, "16 vs 32 rows", e, "vs oracle: 16-row", e16, "32-row", e32)
-    assert e < 2e-5 and e16 < 1e-3 and e32 < 1e-3
+    e16, e32, ew16 = _rel(l16, ref), _rel(l32, ref), _rel(lw, ref)
+    print(family, "16 vs 32 rows", e, "16 waves vs 8", ew, "vs oracle: 16-row", e16, "32-row", e32, "16 waves", ew16)
+    assert e < 2e-5 and ew < 2e-5 and e16 < 1e-3 and e32 < 1e-3 and ew16 < 1e-3
+    assert not np.array_equal(lw, l32)
+
+
+def test_conformer_16_wave_kernels_around_the_fused_attention():
+    """40 x 151 frames = 189 blocks (the last one partial), ragged lengths, skip_padding on and off: the fused attention
+    kernel between 16-wave layer kernels (which write its fragment-ordered values); same valid rows as the default route
+    (8 waves) to rounding."""
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    from ppasr_amd.utils.synth import conformer_state_dict
+    V, L = 211, 3
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=84, perturb_norm=True)
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
+    model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    rng = np.random.default_rng(85)
+    lens_l = [607] + [int(v) for v in rng.integers(40, 608, size=39)]
+    x, lens = synth_features(len(lens_l), 607, lens=lens_l, seed=86)
+    fl = model.valid_out_frames(lens, 607).cpu().numpy()
+    for skip in (False, True):
+        model.set_skip_padding(skip)
+        try:
+            pa, la = _run(model, x, lens, -1)
+            pw, lw = _run(model, x, lens, W16)
+            p32, l32 = _run(model, x, lens, 32)
+        finally:
+            model.set_skip_padding(False)
+        assert np.array_equal(la, l32)          # 189 blocks: the rule picks the 8-wave 32-row kernels
+        assert not np.array_equal(lw, l32)
+        for u in range(len(lens_l)):
+            n = int(fl[u])
+            assert _rel(lw[u, :n], l32[u, :n]) < 2e-5
+            if skip:
+                assert not lw[u, n:].any()

@@ -49,7 +49,9 @@ for _ in range(reps):
     model.encode_greedy(x, lens)
     torch.cuda.synchronize()
     ts = (ctypes.c_longlong * 128)()
-    assert lib.ppasr_debug_read_phase_ts(ts) == 0
+    # --t: the stamps of k_conv_ffn_t (conformer_kernels_t.hip: the 16-wave / 16-row forms; PPASR_W16=0 selects the 8-wave
+    # k_conv_ffn read by the default)
+    assert (lib.ppasr_debug_read_phase_ts_t if "--t" in sys.argv else lib.ppasr_debug_read_phase_ts)(ts) == 0
     t = np.array(list(ts), np.float64)
     acc[:64] += t[:64] - t[0]
     acc[64:] += t[64:] - t[64]
@@ -69,6 +71,8 @@ for c in range(8):
     a, b = us[16 + 2 * c], us[17 + 2 * c]
     nxt = us[16 + 2 * (c + 1)] if c < 7 else us[9]
     print(f"  chunk {c}: barrier wait {b - a:6.2f}   W2(c)+W1(c+2) {nxt - b:6.2f}")
+if "--t" in sys.argv:
+    sys.exit(0)
 
 # per-workgroup start / end of the last k_conv_ffn<..,NEXT> launch: start skew, duration spread, per-XCD means
 wv = (ctypes.c_longlong * 512)()
