@@ -399,6 +399,8 @@ class EfficientBeam(Workload):         # cfg4
         return out
 
     def step(self):
+        # (next to the previous step's beam search the two-launch front end is the faster one: include/ppasr_hip.h)
+        self.model.set_front_fused(0 if self.pipe.enable else -1)
         return self.pipe.run(lambda: self.model.get_encoder_out(self.feats, self.lens), self._decode)
 
     def finish(self):

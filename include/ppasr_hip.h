@@ -155,6 +155,14 @@ PPASR_API ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable);
  * kernels, the fused attention kernel included), 2 / 4 / 8 = always that many slices. */
 PPASR_API ppasr_status ppasr_set_ffn_split(ppasr_handle h, int mode);
 
+/* Conv2dSubsampling4 (conformer/subsampling.py:84-88) as ONE launch (csrc/front_fused.hip: conv1's output is computed
+ * tile by tile inside conv2's implicit GEMM and never written to HBM) or as two (k_conv1, then conv2 reading its output).
+ * Bit-identical results.  mode: -1 (default) / 1 = one launch, 0 = two.  The one-launch kernel is 0.5 - 0.8 % faster
+ * end to end on its own stream; with a beam search of the previous batch running on a second stream the two-launch form
+ * is the faster one (conv2's workgroups leave room on a CU for the search's, the fused kernel's do not), which is why
+ * the pipelined plans of ppasr_amd/parallel.py select it.  Other front ends ignore the setting. */
+PPASR_API ppasr_status ppasr_set_front_fused(ppasr_handle h, int mode);
+
 /* Block form of the layer kernels (no reference counterpart; csrc/rbt.h): -1 (default) = by grid size -- up to 32 row
  * blocks of 32 rows the split route above; 16-row blocks (v_mfma_f32_16x16x4_f32 on 8 waves) where two short rounds of
  * them beat the 32-row rounds (33 .. 128 blocks: under-filled launches); else 32-row blocks (v_mfma_f32_32x32x2_f32 on

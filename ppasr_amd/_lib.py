@@ -59,6 +59,7 @@ SYMBOLS = [
     ("ppasr_set_row_block", ctypes.c_int, [_vp, ctypes.c_int]),
     ("ppasr_set_lengths_hint", ctypes.c_int, [_vp, _vp, ctypes.c_int]),
     ("ppasr_set_ffn_split", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("ppasr_set_front_fused", ctypes.c_int, [_vp, ctypes.c_int]),
     ("ppasr_edit_distance", ctypes.c_longlong, [_vp, ctypes.c_int, _vp, ctypes.c_int]),
     ("ppasr_ctc_beam_state_bytes", ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     ("ppasr_ctc_beam_search", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -445,6 +445,14 @@ int ffn_split_for(const ppasr_model_s* m, int M) {
   return S;
 }
 
+bool conv12_enabled(const ppasr_model_s* m) {
+  static const bool on = [] {
+    const char* e = getenv("PPASR_CONV12");  // (A/B switch: 0 = k_conv1 + k_gemm_stream<conv2>)
+    return !(e && e[0] == '0');
+  }();
+  return m->front_fused != 0 && on;
+}
+
 int row_block_for(const ppasr_model_s* m, int B, int Tcur, int mul, int slack, bool skip) {
   // 32 rows on 16 waves (rbt.h kW16) in place of the 8-wave 32-row kernels: OPT-IN (PPASR_W16=1, or per handle with
   // ppasr_set_row_block(PPASR_ROW_BLOCK_32_W16)).  Measured on the three bench configurations it is a wash -- the
@@ -540,6 +548,13 @@ ppasr_status ppasr_set_ffn_split(ppasr_handle h, int mode) {
   return PPASR_OK;
 }
 
+ppasr_status ppasr_set_front_fused(ppasr_handle h, int mode) {
+  if (!h) return fail(PPASR_EINVAL, "null handle");
+  if (mode < -1 || mode > 1) return fail(PPASR_EINVAL, "front fused: -1 (default), 0 or 1");
+  h->front_fused = mode;
+  return PPASR_OK;
+}
+
 ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable) {
   if (!h) return fail(PPASR_EINVAL, "null handle");
   // the ragged mode is built into the fused 256-column kernels behind the 4x front end; other handles would silently
@@ -622,7 +637,9 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     }
     return ps;
   };
-  timed(0, [&] { launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, pskip(Tp, sub)); });
+  // Conv2dSubsampling4: both convolutions in one launch, conv1's output never leaves the chip (front_fused.hip)
+  const bool conv12 = h->desc.input_layer == 0 && conv12_enabled(h) && conv12_supported(h->front, F, F2);
+  if (!conv12) timed(0, [&] { launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, pskip(Tp, sub)); });
   if (h->desc.input_layer == 8) {
     // Conv2dSubsampling8: conv1 -> conv2 (3x3 / 2) -> conv3 (3x3 / 2, written over conv1's output) -> linear
     timed(1, [&] {
@@ -634,7 +651,8 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     timed(1, [&] {
       // (ragged batches: the active-tile table of conv2 lives in the CTC head's statistics buffer, unused until the head)
       int* tile_tab = (size_t)B + 2 <= ((size_t)M + 63) / 64 * 64 ? reinterpret_cast<int*>(ws + wl.rmax) : nullptr;
-      launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, pskip(Tp, sub), tile_tab);
+      if (conv12) launch_conv12(feats, h->front, y2, B, T, F, Tp, F2, st, pskip(Tp, sub), tile_tab);
+      else launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, pskip(Tp, sub), tile_tab);
     });
     timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st, pskip(Tp, sub), ffn_split_for(h, M), y1); });
   }

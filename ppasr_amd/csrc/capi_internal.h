@@ -127,6 +127,7 @@ struct ppasr_model_s {
   size_t taps_floats = 0;
   // optional per-kernel timing (bench.py roofline leg): one event pair per launch on the caller's stream
   bool prof = false;
+  int front_fused = -1;  // ppasr_set_front_fused: -1 / 1 = conv1 + conv2 of the 4x front end as one launch, 0 = two launches
   int ffn_split = -1;  // ppasr_set_ffn_split: -1 = by grid size, 0 = never, 2 / 4 / 8 = always that many slices
   bool skip_padding = false;  // ppasr_set_skip_padding: ragged batches compute only the rows valid outputs depend on
   int row_block = -1;         // ppasr_set_row_block: -1 = by grid size, 32 / 16 / kW16 = always that block form (rbt.h)
@@ -202,6 +203,8 @@ int ffn_split_for(const ppasr_model_s* m, int M);
 // sum_b min(Tcur, ceil(len_b / mul) + slack) -- known on the host only through ppasr_set_lengths_hint; without a hint the
 // padded count decides.
 int row_block_for(const ppasr_model_s* m, int B, int Tcur, int mul, int slack, bool skip);
+// the 4x front end as one launch (front_fused.hip)?  ppasr_set_front_fused, then PPASR_CONV12=0 (A/B switch)
+bool conv12_enabled(const ppasr_model_s* m);
 ppasr::LayerW sq_conv_view(const ppasr::SqLayerW& W);  // capi_squeezeformer.hip
 
 ppasr_status upload_pe_table(ppasr_model_s* m, BlobMap& sd, const float** pe_dev);

@@ -287,8 +287,13 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
     return ps;
   };
   const PadSkip psF = pskip(Tp, 4), psH = pskip(Tr, 8);
-  launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, psF);
-  launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, psF, (size_t)B + 2 <= ((size_t)M + 63) / 64 * 64 ? reinterpret_cast<int*>(ws + wl.rmax) : nullptr);
+  int* tile_tab = (size_t)B + 2 <= ((size_t)M + 63) / 64 * 64 ? reinterpret_cast<int*>(ws + wl.rmax) : nullptr;
+  if (conv12_enabled(h) && conv12_supported(h->front, F, F2)) {  // both convolutions in one launch (front_fused.hip)
+    launch_conv12(feats, h->front, y2, B, T, F, Tp, F2, st, psF, tile_tab);
+  } else {
+    launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, psF);
+    launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, psF, tile_tab);
+  }
   launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/true, st, psF, ffn_split_for(h, M), y1);
   launch_ln_rows(xa, h->preln_g, h->preln_b, M, st, psF);
   tap(xa, (size_t)M * kD);

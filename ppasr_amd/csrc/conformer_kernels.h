@@ -103,6 +103,12 @@ size_t ragged_lds(size_t lds, const PadSkip& ps, int n_blocks);
 bool launch_attention_t(const AttnArgs& a, int B, int H, hipStream_t st);
 hipError_t configure_attention_kernels();
 
+// front_fused.hip: conv1 + conv2 of Conv2dSubsampling4 as one launch (y1 is never written); same results bit for bit
+bool conv12_supported(const FrontW& fw, int F, int F2);
+void launch_conv12(const float* feats, const FrontW& fw, float* y2, int B, int T, int F, int Tp, int F2, hipStream_t st,
+                   const PadSkip& ps_frames, int* tile_scratch);
+hipError_t configure_front_fused_kernels();
+
 // conformer_kernels_t.hip: the layer kernels on 16-row blocks (under-filled launches; values row-major in qkv)
 void launch_ffn_qkv_16(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
                        const PadSkip& ps);

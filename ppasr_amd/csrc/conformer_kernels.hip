@@ -259,6 +259,9 @@ __global__ __launch_bounds__(256) void k_tile_prefix(PadSkip ps, int B, int BM, 
     __syncthreads();
   }
 }
+void launch_tile_prefix(const PadSkip& ps, int B, int BM, int* tab, hipStream_t st) {
+  PPASR_LAUNCH(k_tile_prefix, dim3(1), dim3(256), 0, st, ps, B, BM, tab);
+}
 // out[m][c] = (sum_z part[z][m][c] + bias[c]) * scale   or   sum * scale + bias (scale_before_bias); one float4 per thread
 __global__ __launch_bounds__(256) void k_gemm_join(const float* __restrict__ part, int nz, const float* __restrict__ bias,
                                                    float scale, int scale_before_bias, float* __restrict__ out, int M,
@@ -2293,6 +2296,8 @@ hipError_t configure_kernels() {
   hipError_t e = configure_attention_kernels();
   if (e != hipSuccess) return e;
   e = configure_conformer_t_kernels();
+  if (e != hipSuccess) return e;
+  e = configure_front_fused_kernels();
   if (e != hipSuccess) return e;
 #define SET_LDS(fn, bytes)                                                                                     \
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \

@@ -427,8 +427,11 @@ __global__ __launch_bounds__(NT) void k_ctc_prune(const float* __restrict__ prob
   }
 }
 
+#ifndef PPASR_BEAM_WAVES_PER_SIMD
+#define PPASR_BEAM_WAVES_PER_SIMD 1  // (launch-bounds hint = register budget 512 / n per lane; tuning knob)
+#endif
 template <int BT, bool WORD_LM>
-__global__ __launch_bounds__(BT) void k_ctc_beam(const float* __restrict__ probs, const int32_t* __restrict__ frame_lens,
+__global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(const float* __restrict__ probs, const int32_t* __restrict__ frame_lens,
                                                   int T, BeamConfig cfg, const int32_t* __restrict__ recs,
                                                   int32_t* __restrict__ state, int init_state,
                                                   int finalize, int32_t* __restrict__ out_tokens,

@@ -213,6 +213,11 @@ class ConformerModel:
         2 / 4 / 8 = always that many slices."""
         _lib.check(self.lib.ppasr_set_ffn_split(self._h, int(mode)))
 
+    def set_front_fused(self, mode=-1):
+        """Conv2dSubsampling4 as one launch (-1 / 1, default) or two (0): ``ppasr_set_front_fused``; same results bit for
+        bit.  Two launches are the faster form when another stream's kernels (a pipelined beam search) share the GPU."""
+        _lib.check(self.lib.ppasr_set_front_fused(self._h, int(mode)))
+
     def set_row_block(self, rows=-1):
         """Block form of the layer kernels (``ppasr_set_row_block``): -1 = by grid size (16-row blocks for under-filled
         launches, else 32), 16 / 32 = always, 1032 (``PPASR_ROW_BLOCK_32_W16``) = 32 rows on 16 waves (optional form)."""

@@ -357,6 +357,9 @@ class RaggedPlan:
         outs = []
         if self.ragged and self.batches:
             set_skip_padding_if_built(model, True)
+        if hasattr(model, "set_front_fused"):
+            # next to the previous call's beam search the two-launch front end is the faster one (see the C header)
+            model.set_front_fused(0 if self.pipeline else -1)
         if self.pipeline:
             # inputs ready (see __init__).  enc_stream does NOT wait for the previous call's decode: that is the overlap --
             # call i's decoder reads only probs(i) (its own allocation, record_stream below) and the decoder's state, the
