@@ -663,6 +663,10 @@ def build_roofline(w, args, ms_per_step):
             ran = [p for p in parts if p in classes]
             if fused in fl and ran and fused not in classes:
                 fl["+".join([fused, "split"])] = fl.pop(fused)
+        # the 4x front end as one launch (csrc/front_fused.hip): both convolutions' algorithmic FLOPs on the one kernel
+        # (each conv1 element counted once, as in the two-launch route; the kernel recomputes it ~2.25 times)
+        if "k_conv12" in classes:
+            fl["k_conv12"] = fl.pop("k_conv1", 0) + fl.pop("conv2", 0)
         work = {c: (v, "flop", "mfma") for c, v in fl.items()}
         for c in classes:
             if c.startswith("k_ctc_beam") or c.startswith("k_ctc_prune"):

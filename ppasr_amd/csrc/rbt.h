@@ -44,6 +44,9 @@ namespace ppasr {
 template <int R>
 struct RBT;
 
+#ifndef PPASR_DW_TC32
+#define PPASR_DW_TC32 16  // 8-wave 32-row form: taps per chunk of the register depthwise conv (tuning knob)
+#endif
 #ifndef PPASR_W16_PF
 #define PPASR_W16_PF 4  // weight-stream prefetch depth of the 16-wave form, in K = 16 super-groups (256 B per lane-row each)
 #endif
@@ -55,7 +58,7 @@ struct RBT<32> {
   static constexpr int RW = 4;  // rows per wave in the row-wise phases (LayerNorm, depthwise conv)
   static constexpr int NR = 1;  // distinct rows among a lane's quads
   static constexpr int QLDS = 8;  // floats between a lane's consecutive quads in an LDS row buffer
-  static constexpr int DW_TC = 16;  // taps per chunk of the register depthwise conv (modules with more taps)
+  static constexpr int DW_TC = PPASR_DW_TC32;  // taps per chunk of the register depthwise conv (modules with more taps)
   static __device__ __forceinline__ int row(int, int lane) { return lane & 31; }
   static __device__ __forceinline__ int col(int q, int lane, int wave) { return wave * 32 + 8 * q + 4 * (lane >> 5); }
   static __device__ __forceinline__ int tile(int wave) { return wave; }  // 32-column weight tile the wave streams
