@@ -728,8 +728,13 @@ def build_roofline(w, args, ms_per_step):
                                          "adds ~1 us per dispatch, which shows on 5 us kernels (cfg1) and not on 300 us ones"),
              hidden_decode_ms_per_step=(round(sum(out_classes[c]["ms_per_step"] for c in hidden), 4) if hidden else None),
              avg_launch_ms_method=("HIP-event share of the step x un-instrumented ms_per_step / launches" if not w.pipelined else
-                                   "dispatch-attached HIP events / 1.05 (the marker stretch measured on the serial route; the "
-                                   "overlapped beam search makes kernel times sum to more than the step)"),
+                                   "dispatch-attached HIP events / 1.05 (the marker stretch measured on the serial route).  The "
+                                   "event pairs serialise the two streams, so this is the kernel's UNDISTURBED duration and `frac` "
+                                   "the kernel's own efficiency; in the pipelined timed region the same kernel runs beside the "
+                                   "previous step's beam search and takes longer (avg_launch_ms_rocprof, from the kernel trace of "
+                                   "this command: +30 .. 45 % on cfg5's layer kernels) -- frac_in_pipeline prices it at that duration"),
+             frac_in_pipeline=(round(de["frac"] * avg_launch_ms / rocprof_avg_ms, 4)
+                               if (w.pipelined and rocprof_avg_ms and de.get("frac")) else None),
              whole_path_tflops_per_gpu=round(whole / (ms_per_step * 1e-3) / 1e12, 2),
              kernel_time_ms_per_step=round(total_ms, 3), classes=out_classes, kernels=kernels)
     if w.family == "deepspeech2" and dom.startswith("k_lstm_step"):

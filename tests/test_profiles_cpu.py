@@ -56,10 +56,22 @@ def test_dominant_kernel_time_fits_the_step(bench_json, trace_txt):
     # and the line's own figure for that kernel agrees with the profiler's (marker stretch and box-to-box spread: 25 %).
     # (Not for the one-workgroup-per-utterance beam search of the pipelined round-3 lines: overlapped with the encoder's
     #  kernels it runs 30 - 40 % longer under the profiler; round 4 names the encoder's largest kernel instead.)
-    if not dom.startswith("k_ctc_beam"):
+    pipelined = bool((line.get("config") or {}).get("pipelined"))
+    if pipelined and not dom.startswith("k_ctc_beam"):
+        # round 4: the line's own figure is the kernel's UNDISTURBED duration (the dispatch-attached event pairs serialise the
+        # two streams); the trace of the pipelined command shows the same kernel beside the previous step's beam search,
+        # longer by up to ~50 %.  The line carries both: the profiler's figure must be the trace's, the own one below it.
+        assert roof["avg_launch_ms"] * 1e3 <= 1.05 * avg_us, (roof["avg_launch_ms"], avg_us)
+        assert roof["avg_launch_ms"] * 1e3 >= 0.6 * avg_us, (roof["avg_launch_ms"], avg_us)
+        if roof.get("avg_launch_ms_rocprof") is not None:
+            assert abs(roof["avg_launch_ms_rocprof"] * 1e3 - avg_us) <= 0.02 * avg_us + 0.5, (roof["avg_launch_ms_rocprof"], avg_us)
+    elif not dom.startswith("k_ctc_beam"):
         assert abs(roof["avg_launch_ms"] * 1e3 - avg_us) <= 0.25 * avg_us + 1.2, (roof["avg_launch_ms"], avg_us)
     # every profiled ppasr kernel has an accounting class that the line lists
     for name in tr:
         if name.startswith("k_posproj"):
             continue  # (create-time constant folding, not a per-step kernel)
-        assert bench.class_of(name) in roof["classes"], name
+        cls = bench.class_of(name)
+        # (a pipelined line's trace also holds its serial leg, which runs the 4x front end as ONE launch: k_conv12 stands for
+        #  the conv2 + k_conv1 classes of the pipelined leg -- include/ppasr_hip.h ppasr_set_front_fused)
+        assert cls in roof["classes"] or (cls == "k_conv12" and pipelined and "conv2" in roof["classes"]), name
