@@ -11,6 +11,8 @@
 // The recurrence is latency-bound (one dependent step = h_{t-1} broadcast + 16 dot products per
 // workgroup), not MFMA- or HBM-bound.
 #include "launch.h"
+#include <cstdlib>
+
 #include "ds2_kernels.h"
 
 #include <math.h>
@@ -586,8 +588,14 @@ void launch_gru_step_mfma(const float* gx, const f32x4* whh_pk, const float* bhh
 }
 void launch_lstm_wave(const float* gx0, const Ds2WaveLayer* tab, float* hbuf, float* cbuf, float* yring, float* out,
                       const int32_t* lens, int B, int T, int H, int L, int s, int l_lo, int n_l, hipStream_t st, bool gru) {
-  // row tiles per workgroup: the whole batch up to 128 utterances streams a layer's weights once
-  const int rt = B <= 32 ? 1 : (B <= 64 ? 2 : 4);
+  // row tiles per workgroup: up to 64 utterances stream a layer's weights once.  Beyond that two row tiles per workgroup
+  // again (B = 128: 5 x 128 x 2 workgroups = five per CU, dealt as they finish) beat four (640 workgroups = 2.5 per CU,
+  // i.e. three on some CUs): 95.3 against 99.8 us per launch, same box; the second read of the weights comes from L2 / MALL
+  int rt = B <= 32 ? 1 : 2;
+  if (const char* e = getenv("PPASR_WAVE_RT")) {  // (measurement switch)
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) rt = v;
+  }
   const dim3 grid(H / 8, n_l, (B + 32 * rt - 1) / (32 * rt));
 #define WAVE_LAUNCH(RT, GRU) \
   PPASR_LAUNCH((k_lstm_wave<RT, GRU>), grid, dim3(kThreads), 0, st, gx0, tab, hbuf, cbuf, yring, out, lens, B, T, H, L, s, l_lo)
