@@ -445,6 +445,14 @@ int ffn_split_for(const ppasr_model_s* m, int M) {
   return S;
 }
 
+bool block_tables_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("PPASR_BLOCK_TABLE");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 bool conv12_enabled(const ppasr_model_s* m) {
   static const bool on = [] {
     const char* e = getenv("PPASR_CONV12");  // (A/B switch: 0 = k_conv1 + k_gemm_stream<conv2>)
@@ -658,6 +666,25 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   }
   tap(xa, (size_t)M * kD);
   const int n_chunks = h->desc.linear_units / 256;
+  // ragged batches: lists of the active row blocks per (frame rate, block size), made on first use (rowblock.h
+  // PadSkip::tab; they live behind conv2's tile table in the CTC head's statistics buffers, unused until the head)
+  struct BlkTab { int Ti, R; int* tab; } btabs[4];
+  int n_bt = 0;
+  size_t bt_off = ((size_t)B + 2 + 15) / 16 * 16;
+  const bool bt_ok = skip && block_tables_enabled() && (size_t)B + 2 <= ((size_t)M + 63) / 64 * 64;
+  auto with_table = [&](PadSkip p, int Tcur, int R) {
+    if (!bt_ok) return p;
+    for (int k = 0; k < n_bt; ++k)
+      if (btabs[k].Ti == Tcur && btabs[k].R == R) { p.tab = btabs[k].tab; return p; }
+    const size_t n = 1 + ((size_t)B * Tcur + R - 1) / R;
+    if (n_bt == 4 || bt_off + n > 2 * (((size_t)M + 63) / 64 * 64)) return p;
+    int* t = reinterpret_cast<int*>(ws + wl.rmax) + bt_off;
+    launch_block_table(p, B * Tcur, R, t, st);
+    btabs[n_bt++] = BlkTab{Tcur, R, t};
+    bt_off += (n + 15) / 16 * 16;
+    p.tab = t;
+    return p;
+  };
   int Ti = Tp, mul = sub, pstride = 1;  // frames per utterance / pad-mask multiplier / positional stride of the current layer
   bool s1_done = false;               // this layer's S1 already ran inside the previous layer's last launch
   for (int i = 0; i < h->desc.num_blocks; ++i) {
@@ -687,6 +714,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     const int S = r16 ? 1 : ffn_split_for(h, Mi);
     // full grid: the same 32-row blocks on 16 waves (k_*_t<kW16>: drop-in for k_ffn_qkv / k_out_glu / k_conv_ffn)
     const bool w16 = rows == kW16 && S == 1;
+    const PadSkip psb = S == 1 ? with_table(ps, Ti, r16 ? 16 : 32) : ps;  // (for the kernels of this layer's block size)
     float* partial = y1;
     float* x3 = ctx;
     if (!s1_done) {
@@ -697,11 +725,11 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
           launch_ln_qkv(xb, qkv, L, Mi, st, ps);
         });
       } else if (r16) {
-        timed(3, [&] { launch_ffn_qkv_16(xa, xb, qkv, L, Mi, n_chunks, st, ps); });
+        timed(3, [&] { launch_ffn_qkv_16(xa, xb, qkv, L, Mi, n_chunks, st, psb); });
       } else if (w16) {
-        timed(3, [&] { launch_ffn_qkv_w16(xa, xb, qkv, L, Mi, n_chunks, st, ps, fuse_attn ? vt_out : VtOut{}); });
+        timed(3, [&] { launch_ffn_qkv_w16(xa, xb, qkv, L, Mi, n_chunks, st, psb, fuse_attn ? vt_out : VtOut{}); });
       } else {
-        timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st, ps, fuse_attn ? vt_out : VtOut{}); });
+        timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st, psb, fuse_attn ? vt_out : VtOut{}); });
       }
     }
     s1_done = false;
@@ -720,9 +748,9 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       tap(ctx, (size_t)Mi * kD);
       // (under-filled launch: pointwise_conv1 + GLU as its own two-column-half launch; the LayerNorm'd rows pass through
       //  xa, which is free between this layer's S1 and its output)
-      if (r16) timed(5, [&] { launch_out_glu_16(ctx, xb, xc, g, L, lens, Mi, Ti, mul, st, ps); });
-      else if (w16) timed(5, [&] { launch_out_glu_w16(ctx, xb, xc, g, L, lens, Mi, Ti, mul, st, ps); });
-      else timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, L, lens, Mi, Ti, mul, st, ps, S > 1 ? xa : nullptr); });
+      if (r16) timed(5, [&] { launch_out_glu_16(ctx, xb, xc, g, L, lens, Mi, Ti, mul, st, psb); });
+      else if (w16) timed(5, [&] { launch_out_glu_w16(ctx, xb, xc, g, L, lens, Mi, Ti, mul, st, psb); });
+      else timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, L, lens, Mi, Ti, mul, st, psb, S > 1 ? xa : nullptr); });
     }
     tap(xc, (size_t)Mi * kD);
     tap(g, (size_t)Mi * kD);
@@ -748,13 +776,13 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
         // with the next layer's S1 fused in, the layer output itself is only read by the debug taps: skip its store
         if (r16)
           launch_conv_ffn_16(g, xc, next ? nullptr : xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul, next, xb, qkv, st,
-                             h->desc.causal != 0, ps);
+                             h->desc.causal != 0, psb);
         else if (w16)
           launch_conv_ffn_w16(g, xc, next ? nullptr : xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul, next, xb, qkv, st,
-                              h->desc.causal != 0, ps, (next && fusable(i + 1)) ? vt_out : VtOut{});
+                              h->desc.causal != 0, psb, (next && fusable(i + 1)) ? vt_out : VtOut{});
         else
           launch_conv_ffn(g, nullptr, xc, (next && !h->taps) ? nullptr : xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul,
-                          next, xb, qkv, st, h->desc.causal != 0, ps, (next && fusable(i + 1)) ? vt_out : VtOut{});
+                          next, xb, qkv, st, h->desc.causal != 0, psb, (next && fusable(i + 1)) ? vt_out : VtOut{});
       });
       s1_done = next != nullptr;
     }

@@ -203,6 +203,7 @@ int ffn_split_for(const ppasr_model_s* m, int M);
 // sum_b min(Tcur, ceil(len_b / mul) + slack) -- known on the host only through ppasr_set_lengths_hint; without a hint the
 // padded count decides.
 int row_block_for(const ppasr_model_s* m, int B, int Tcur, int mul, int slack, bool skip);
+bool block_tables_enabled();  // active-block lists for ragged layer kernels (PPASR_BLOCK_TABLE=0: padded grids; A/B switch)
 // the 4x front end as one launch (front_fused.hip)?  ppasr_set_front_fused, then PPASR_CONV12=0 (A/B switch)
 bool conv12_enabled(const ppasr_model_s* m);
 ppasr::LayerW sq_conv_view(const ppasr::SqLayerW& W);  // capi_squeezeformer.hip

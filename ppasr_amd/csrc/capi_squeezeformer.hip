@@ -288,13 +288,33 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
   };
   const PadSkip psF = pskip(Tp, 4), psH = pskip(Tr, 8);
   int* tile_tab = (size_t)B + 2 <= ((size_t)M + 63) / 64 * 64 ? reinterpret_cast<int*>(ws + wl.rmax) : nullptr;
+  // ragged batch: the active row blocks of the two frame rates as lists (PadSkip::tab), for the layer kernels K_B / K_C --
+  // with the beam search of the previous batch on some CUs a padded grid with early exits runs extra rounds (rowblock.h).
+  // The lists live behind conv2's tile table in the CTC head's statistics buffers (2 al(M) floats, unused until the head).
+  const int rowsF = h->taps ? 32 : row_block_for(h, B, Tp, 4, psF.slack, skip);
+  const int rowsH = h->taps ? 32 : row_block_for(h, B, Tr, 8, psH.slack, skip);
+  PadSkip psF_rb = psF, psH_rb = psH;
+  if (skip && tile_tab && block_tables_enabled()) {
+    const int RF = rowsF == 16 ? 16 : 32, RH = rowsH == 16 ? 16 : 32;
+    const size_t nF = 1 + ((size_t)M + RF - 1) / RF, nH = 1 + ((size_t)B * Tr + RH - 1) / RH;
+    const size_t o1 = ((size_t)B + 2 + 15) / 16 * 16, o2 = o1 + (nF + 15) / 16 * 16;
+    if (o2 + nH <= 2 * (((size_t)M + 63) / 64 * 64)) {
+      int* base = reinterpret_cast<int*>(ws + wl.rmax);
+      launch_block_table(psF, M, RF, base + o1, st);
+      launch_block_table(psH, B * Tr, RH, base + o2, st);
+      psF_rb.tab = base + o1;
+      psH_rb.tab = base + o2;
+    }
+  }
   if (conv12_enabled(h) && conv12_supported(h->front, F, F2)) {  // both convolutions in one launch (front_fused.hip)
     launch_conv12(feats, h->front, y2, B, T, F, Tp, F2, st, psF, tile_tab);
   } else {
     launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, psF);
     launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, psF, tile_tab);
   }
-  launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/true, st, psF, ffn_split_for(h, M), y1);
+  // (the embed GEMM works on 32-row blocks: it takes the full-rate list when that is the 32-row one)
+  launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/true, st,
+               (rowsF != 16 && ffn_split_for(h, M) == 1) ? psF_rb : psF, ffn_split_for(h, M), y1);
   launch_ln_rows(xa, h->preln_g, h->preln_b, M, st, psF);
   tap(xa, (size_t)M * kD);
   float* x = xa;      // current layer input / residual
@@ -330,7 +350,8 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
     // under-filled grid (ppasr_set_ffn_split): K_B / K_C cut at their feed-forward modules, partial sums in the conv1 buffer
     // under-filled launch: 16-row blocks (twice the workgroups, each half as long) before the split route
     // ... and full launches: the 32-row blocks on 16 waves (rbt.h kW16)
-    const int rows = h->taps ? 32 : row_block_for(h, B, Ti, mul, ps.slack, skip);
+    const int rows = reduced ? rowsH : rowsF;
+    const PadSkip& ps_rb = reduced ? psH_rb : psF_rb;  // (with the list of active blocks of THIS block size)
     const int S = rows == 16 && h->ffn_split < 0 ? 1 : ffn_split_for(h, Mi);  // (an explicit ffn_split mode wins)
     const bool fuse_next = (i + 1 < L) && (i + 1 != h->desc.reduce_idx) && !(i + 1 == h->desc.recover_idx && reduced);
     const SqLayerW* Wn = fuse_next ? &h->sq_layers[i + 1] : nullptr;
@@ -346,11 +367,11 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
                        n_chunks, S, st, ps, /*residual_is_normed=*/true);
       if (Wn) launch_sq_qkv(other, qkv, Wn->wqkv, Wn->bqkv, Mi, st, ps);
     } else {
-      launch_sq_mid(ctx, x, xc, g, nullptr, W, lens, Mi, Ti, mul, n_chunks, st, ps, rows);
+      launch_sq_mid(ctx, x, xc, g, nullptr, W, lens, Mi, Ti, mul, n_chunks, st, ps_rb, rows);
       tap(xc, (size_t)Mi * kD);
       tap(g, (size_t)Mi * kD);
       launch_sq_tail(g, nullptr, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, lens, Mi, Ti, mul,
-                     n_chunks, KS, st, ps, causal, rows);
+                     n_chunks, KS, st, ps_rb, causal, rows);
     }
     std::swap(x, other);
     have_qkv = fuse_next;

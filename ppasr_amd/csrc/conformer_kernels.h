@@ -103,6 +103,9 @@ size_t ragged_lds(size_t lds, const PadSkip& ps, int n_blocks);
 bool launch_attention_t(const AttnArgs& a, int B, int H, hipStream_t st);
 hipError_t configure_attention_kernels();
 
+// the list of active R-row blocks of a ragged batch (rowblock.h PadSkip::tab): 1 + ceil(M / R) ints at `tab`
+void launch_block_table(const PadSkip& ps, int M, int R, int* tab, hipStream_t st);
+
 // front_fused.hip: conv1 + conv2 of Conv2dSubsampling4 as one launch (y1 is never written); same results bit for bit
 bool conv12_supported(const FrontW& fw, int F, int F2);
 void launch_conv12(const float* feats, const FrontW& fw, float* y2, int B, int T, int F, int Tp, int F2, hipStream_t st,

@@ -151,6 +151,10 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
     const int S = ps.Tp * ps.unit;
     r0_map = lo * S + (t - pre[lo]) * BM;
     Mlim = min(M, (lo + 1) * S);
+  } else if (ps.tab) {  // list of the active BM-row blocks (rowblock.h PadSkip::tab; whole-matrix launches: m0 = 0)
+    const int blk = pad_block_of(ps, BM, M);
+    if (blk < 0) return;
+    r0_map = blk * BM;
   } else if (pad_block_skippable(ps, m0 + blockIdx.x * BM, BM, M)) {
     return;
   }
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
   constexpr int G = KC / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-  const int r0 = tile_tab ? r0_map : m0 + blockIdx.x * BM;  // m0: first row of this launch (row ranges split across launches)
+  const int r0 = (tile_tab || ps.tab) ? r0_map : m0 + blockIdx.x * BM;  // m0: first row of this launch (row ranges split across launches)
   const int tile_stride = n_chunks * G * 64;
   // gridDim.z > 1 (under-filled launches): workgroup z contracts K chunks [kc0, kc1) only and stores its raw partial sums
   // to out + z * M * ldc; k_gemm_join adds them up and applies bias / scale / activation
@@ -258,6 +262,34 @@ __global__ __launch_bounds__(256) void k_tile_prefix(PadSkip ps, int B, int BM, 
     }
     __syncthreads();
   }
+}
+// tab[0] = number of R-row blocks of the flattened [M] rows that hold a row some valid output frame depends on,
+// tab[1 + i] = index of the i-th such block (ascending): PadSkip::tab of the ragged row-block launches
+__global__ __launch_bounds__(256) void k_block_table(PadSkip ps, int M, int R, int* __restrict__ tab) {
+  __shared__ int cnt[256];
+  const int nblk = (M + R - 1) / R, tid = threadIdx.x;
+  int run = 0;
+  for (int b0 = 0; b0 < nblk; b0 += 256) {
+    const int i = b0 + tid;
+    const int act = (i < nblk && !pad_block_skippable(ps, i * R, R, M)) ? 1 : 0;
+    cnt[tid] = act;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {  // inclusive scan
+      const int v = tid >= o ? cnt[tid - o] : 0;
+      __syncthreads();
+      cnt[tid] += v;
+      __syncthreads();
+    }
+    if (act) tab[1 + run + cnt[tid] - 1] = i;
+    run += cnt[255];
+    __syncthreads();
+  }
+  if (tid == 0) tab[0] = run;
+}
+void launch_block_table(const PadSkip& ps, int M, int R, int* tab, hipStream_t st) {
+  PadSkip p = ps;
+  p.tab = nullptr;
+  PPASR_LAUNCH(k_block_table, dim3(1), dim3(256), 0, st, p, M, R, tab);
 }
 void launch_tile_prefix(const PadSkip& ps, int B, int BM, int* tab, hipStream_t st) {
   PPASR_LAUNCH(k_tile_prefix, dim3(1), dim3(256), 0, st, ps, B, BM, tab);
@@ -512,12 +544,13 @@ __global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ 
                                                       float* __restrict__ qkv, LayerW w, int M, int n_chunks, PadSkip ps,
                                                       VtOut vt) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
+  const int blk = pad_block_of(ps, kRows, M);  // (ragged batches: PadSkip::tab or the padded grid)
+  if (blk < 0) return;
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
   float* bufH = bufA + kRows * kLda;
   const int wave = wave_id();
-  const int r0 = blockIdx.x * kRows;
+  const int r0 = blk * kRows;
   const int valid = min(kRows, M - r0);
   BRing<1> ring;
   ring_prime(ring, w.ffm_w1 + (size_t)wave * kTs256, 0);
@@ -872,11 +905,12 @@ __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ 
                                                       const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
                                                       PadSkip ps, int stop_after_ln) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
+  const int blk = pad_block_of(ps, kRows, M);  // (ragged batches: PadSkip::tab or the padded grid)
+  if (blk < 0) return;
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
   const int lane = lane_id(), wave = wave_id();
-  const int r0 = blockIdx.x * kRows;
+  const int r0 = blk * kRows;
   const int valid = min(kRows, M - r0);
   const int col = wave * 32 + (lane & 31);
   BRing<1> ring;
@@ -931,11 +965,12 @@ __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ 
 __global__ __launch_bounds__(kThreads) void k_pw1_glu_cols(const float* __restrict__ xhat, float* __restrict__ g, LayerW w,
                                                            int M, PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
+  const int blk = pad_block_of(ps, kRows, M);  // (ragged batches: PadSkip::tab or the padded grid)
+  if (blk < 0) return;
   float* bufA = smem;
   float* vals = bufA + kRows * kLda;  // [32][132]
   const int lane = lane_id(), wave = wave_id();
-  const int r0 = blockIdx.x * kRows;
+  const int r0 = blk * kRows;
   const int valid = min(kRows, M - r0);
   const int is_gate = wave >> 2, t = wave & 3, y = blockIdx.y;
   const int col = 128 * y + 32 * t + (lane & 31);              // output column
@@ -1581,12 +1616,13 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
                                                        int mask_mul, LayerW wn, float* __restrict__ x1_next,
                                                        float* __restrict__ qkv_next, int left_ctx, PadSkip ps, VtOut vt_next) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
+  const int blk = pad_block_of(ps, kRows, M);  // (ragged batches: PadSkip::tab or the padded grid)
+  if (blk < 0) return;
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
   float* bufH = bufA + kRows * kLda;
   const int lane = lane_id(), wave = wave_id();
-  const int r0 = blockIdx.x * kRows;
+  const int r0 = blk * kRows;
   const int valid = min(kRows, M - r0);
   const int col = wave * 32 + (lane & 31);
   BRing<1> ring;
@@ -1720,12 +1756,13 @@ __global__ __launch_bounds__(kThreads) void k_conv_pre(const float* __restrict__
                                                        const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
                                                        int left_ctx, PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
+  const int blk = pad_block_of(ps, kRows, M);  // (ragged batches: PadSkip::tab or the padded grid)
+  if (blk < 0) return;
   float* bufX = smem;
   float* bufA = bufX + kRows * kLda;
   float* bufH = bufA + kRows * kLda;
   const int lane = lane_id(), wave = wave_id();
-  const int r0 = blockIdx.x * kRows;
+  const int r0 = blk * kRows;
   const int valid = min(kRows, M - r0);
   const int col = wave * 32 + (lane & 31);
   BRing<1> ring;
@@ -1761,11 +1798,12 @@ __global__ __launch_bounds__(kThreads) void k_ffn_part(const float* __restrict__
                                                        const float* __restrict__ b1, const f32x4* __restrict__ w2,
                                                        float* __restrict__ partial, int M, int n_total, PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
+  const int blk = pad_block_of(ps, kRows, M);  // (ragged batches: PadSkip::tab or the padded grid)
+  if (blk < 0) return;
   float* bufA = smem;
   float* bufH = bufA + kRows * kLda;  // two hidden-chunk buffers
   const int lane = lane_id(), wave = wave_id();
-  const int r0 = blockIdx.x * kRows;
+  const int r0 = blk * kRows;
   const int valid = min(kRows, M - r0);
   const int n_chunks = n_total / gridDim.y, c0 = blockIdx.y * n_chunks;
   BRing<1> ring;
@@ -1819,10 +1857,11 @@ __global__ __launch_bounds__(256) void k_ffn_join(const float* __restrict__ x, c
 __global__ __launch_bounds__(kThreads) void k_ln_qkv(const float* __restrict__ x1, float* __restrict__ qkv, LayerW w, int M,
                                                      PadSkip ps, float* __restrict__ kc, float* __restrict__ vc) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
+  const int blk = pad_block_of(ps, kRows, M);  // (ragged batches: PadSkip::tab or the padded grid)
+  if (blk < 0) return;
   float* bufA = smem;
   const int lane = lane_id(), wave = wave_id();
-  const int r0 = blockIdx.x * kRows;
+  const int r0 = blk * kRows;
   const int valid = min(kRows, M - r0);
   const int c = blockIdx.y;  // 0: q, 1: k, 2: v
   BRing<1> ring;
@@ -1993,7 +2032,8 @@ __global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__
                                                        float* __restrict__ row_max, float* __restrict__ row_sum, int M,
                                                        PadSkip ps, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
+  const int blk = pad_block_of(ps, kRows, M);  // (ragged batches: PadSkip::tab or the padded grid)
+  if (blk < 0) return;
   // gridDim.y > 1 (under-filled launches): workgroup y walks vocabulary tiles wave + 8 (y + gridDim.y k) and leaves its
   // per-row (max, sum-exp, argmax) in part[3][gridDim.y][M]; k_ctc_merge combines the slices
   const int ny = gridDim.y, y = blockIdx.y;
@@ -2002,7 +2042,7 @@ __global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__
   float* redS = redM + kWaves * 32;                            // [8][32]
   int* redI = reinterpret_cast<int*>(redS + kWaves * 32);      // [8][32]
   const int lane = lane_id(), wave = wave_id();
-  const int r0 = blockIdx.x * kRows;
+  const int r0 = blk * kRows;
   const int valid = min(kRows, M - r0);
   const int V = hw.V;
   BRing<1> ring;

@@ -53,11 +53,12 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_ffn_qkv_t(const float* __re
                                                                PadSkip ps, VtOut vt) {
   using T = RBT<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * T::ROWS, T::ROWS, M)) return;
+  const int blk = pad_block_of(ps, T::ROWS, M);
+  if (blk < 0) return;
   float* bufX = smem;
   float* bufA = bufX + T::ROWS * kLda;
   float* bufH = bufA + T::ROWS * kLda;
-  const int r0 = blockIdx.x * T::ROWS;
+  const int r0 = blk * T::ROWS;
   const int valid = min(T::ROWS, M - r0);
   typename T::Ring ring;
   rbt_prime(ring, w.ffm_w1 + (size_t)T::tile(wave_id()) * kTs256);
@@ -73,11 +74,12 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_out_glu_t(const float* __re
                                                                int mask_mul, PadSkip ps) {
   using T = RBT<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * T::ROWS, T::ROWS, M)) return;
+  const int blk = pad_block_of(ps, T::ROWS, M);
+  if (blk < 0) return;
   float* bufX = smem;
   float* bufA = bufX + T::ROWS * kLda;
   const LaneT<R> L;
-  const int r0 = blockIdx.x * T::ROWS;
+  const int r0 = blk * T::ROWS;
   const int valid = min(T::ROWS, M - r0);
   typename T::Ring ring;
   const f32x4* seg_o = w.wo + (size_t)L.tile() * kTs256;
@@ -142,12 +144,13 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_conv_ffn_t(const float* __r
                                                                 int left_ctx, PadSkip ps, VtOut vt_next) {
   using T = RBT<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * T::ROWS, T::ROWS, M)) return;
+  const int blk = pad_block_of(ps, T::ROWS, M);
+  if (blk < 0) return;
   float* bufX = smem;
   float* bufA = bufX + T::ROWS * kLda;
   float* bufH = bufA + T::ROWS * kLda;
   const LaneT<R> L;
-  const int r0 = blockIdx.x * T::ROWS;
+  const int r0 = blk * T::ROWS;
   const int valid = min(T::ROWS, M - r0);
   typename T::Ring ring;
   const f32x4* seg_pw2 = w.pw2 + (size_t)L.tile() * kTs256;

@@ -86,6 +86,14 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 struct PadSkip {
   const int64_t* lens = nullptr;  // nullptr: every row is computed (the reference's behaviour)
   int Tp = 0, mul = 4, slack = 0, unit = 1;
+  // optional list of the ACTIVE row blocks of this launch's block size (k_block_table: tab[0] = their number, tab[1 + i] =
+  // index of the i-th one): workgroup i then takes block tab[1 + i] and the workgroups behind the list exit.  The padded
+  // grid with early exits is as fast on an otherwise idle chip (the dispatcher refills a CU as soon as a workgroup exits),
+  // but workgroups are dealt to the shader engines by INDEX: with a few CUs taken by another stream's long-running kernel
+  // (the beam search of the previous batch) an engine that happens to be dealt more active blocks than it has free CUs
+  // runs a second round -- tools/cu_mask_probe.hip: 213 active of 372 blocks beside 16 foreign workgroups 1634 us, the same
+  // blocks as the first 213 workgroups of the grid 832 us
+  const int* tab = nullptr;
 };
 __device__ __forceinline__ int pad_need_steps(const PadSkip& s, int b) {
   const long long len = s.lens[b];
@@ -104,6 +112,12 @@ __device__ __forceinline__ bool pad_block_skippable(const PadSkip& s, int m0, in
     if (first < pad_need_steps(s, b) * s.unit) return false;
   }
   return true;
+}
+
+// row block (of R rows) this workgroup of a ragged launch works on, or -1: none
+__device__ __forceinline__ int pad_block_of(const PadSkip& s, int R, int M) {
+  if (s.tab) return (int)blockIdx.x < s.tab[0] ? s.tab[1 + blockIdx.x] : -1;
+  return pad_block_skippable(s, blockIdx.x * R, R, M) ? -1 : (int)blockIdx.x;
 }
 
 // row of accumulator register r inside a 32x32 tile for this lane

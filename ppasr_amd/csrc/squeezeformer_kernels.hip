@@ -83,11 +83,12 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_sq_mid_t(const float* __res
                                                        int n_chunks, PadSkip ps) {
   using T = RBT<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * T::ROWS, T::ROWS, M)) return;
+  const int blk = pad_block_of(ps, T::ROWS, M);
+  if (blk < 0) return;
   float* bufX = smem;
   float* bufH = bufX + T::ROWS * kLda;  // 2 buffers; bufH[0] doubles as the ctx staging tile
   const LaneT<R> L;
-  const int r0 = blockIdx.x * T::ROWS;
+  const int r0 = blk * T::ROWS;
   const int valid = min(T::ROWS, M - r0);
   typename T::Ring ring;
   const f32x4* seg_o = w.wo + (size_t)L.tile() * kTs256;
@@ -166,12 +167,13 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_sq_tail_t(const float* __re
                                                         int n_chunks, PadSkip ps, int left_ctx) {
   using T = RBT<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * T::ROWS, T::ROWS, M)) return;
+  const int blk = pad_block_of(ps, T::ROWS, M);
+  if (blk < 0) return;
   float* bufX = smem;
   float* bufA = bufX + T::ROWS * kLda;
   float* bufH = bufA + T::ROWS * kLda;
   const LaneT<R> L;
-  const int r0 = blockIdx.x * T::ROWS;
+  const int r0 = blk * T::ROWS;
   const int valid = min(T::ROWS, M - r0);
   typename T::Ring ring;
   const f32x4* seg_pw2 = w.pw2 + (size_t)L.tile() * kTs256;

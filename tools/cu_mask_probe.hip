@@ -59,15 +59,24 @@ static void run(const char* name, const std::vector<uint32_t>& mask, int blocks)
 __global__ __launch_bounds__(512) void k_busy(uint32_t* out, long long* t, int spin) {
   extern __shared__ float smem[];
   const long long t0 = wall_clock64();
+  const long long c0 = clock64();
   float a = threadIdx.x;
   for (int i = 0; i < spin; ++i) a = a * 1.0001f + 0.5f;
   smem[threadIdx.x] = a;
+  (void)c0;
   if (threadIdx.x == 0) {
     out[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
     out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     t[2 * blockIdx.x] = t0;
     t[2 * blockIdx.x + 1] = wall_clock64();
   }
+}
+__global__ __launch_bounds__(512) void k_spin(float* out, int spin) {
+  extern __shared__ float smem[];
+  float a = threadIdx.x;
+  for (int i = 0; i < spin; ++i) a = a * 1.0001f + 0.5f;
+  smem[threadIdx.x] = a;
+  if (a == 12345.f) out[0] = a;
 }
 // ragged launch: the whole padded grid is launched, the workgroups of skipped row blocks exit at once (what the layer
 // kernels do under ppasr_set_skip_padding); `active` = the table variant: only the active blocks, in front
@@ -80,8 +89,13 @@ __global__ __launch_bounds__(512) void k_ragged(const uint8_t* act, long long* t
   smem[threadIdx.x] = a;
   if (threadIdx.x == 0) { t[2 * blockIdx.x] = t0; t[2 * blockIdx.x + 1] = wall_clock64(); }
 }
-static void ragged(const char* name, const std::vector<uint8_t>& act, size_t lds) {
+static void ragged(const char* name, const std::vector<uint8_t>& act, size_t lds, bool with_search = false) {
   const int blocks = (int)act.size();
+  hipStream_t s2;
+  (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+  float* o2;
+  (void)hipMalloc(&o2, 64);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_spin), hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024);
   uint8_t* d; long long* t;
   (void)hipMalloc(&d, blocks); (void)hipMalloc(&t, blocks * 16);
   (void)hipMemcpy(d, act.data(), blocks, hipMemcpyHostToDevice);
@@ -91,6 +105,8 @@ static void ragged(const char* name, const std::vector<uint8_t>& act, size_t lds
   for (auto a : act) n_act += a;
   for (int rep = 0; rep < 6; ++rep) {
     (void)hipMemset(t, 0, blocks * 16);
+    // (40 KB of LDS: the 16 "search" workgroups cannot share a CU with the 133 KB blocks, they only take CUs away)
+    if (with_search) hipLaunchKernelGGL(k_spin, dim3(16), dim3(512), 40 * 1024, s2, o2, 400000);
     hipLaunchKernelGGL(k_ragged, dim3(blocks), dim3(512), lds, 0, d, t, 60000);
     (void)hipDeviceSynchronize();
     std::vector<long long> ht(blocks * 2);
@@ -100,8 +116,9 @@ static void ragged(const char* name, const std::vector<uint8_t>& act, size_t lds
       if (act[b]) { if (!tmin || ht[2 * b] < tmin) tmin = ht[2 * b]; tmax = std::max(tmax, ht[2 * b + 1]); }
     if (rep) { worst = std::max(worst, (tmax - tmin) / 100.0); sum += (tmax - tmin) / 100.0; }
   }
-  printf("%-46s grid %3d, %3d active, LDS %3zu KB: launch mean %.1f us, worst %.1f us (one block ~820)\n", name, blocks, n_act, lds / 1024, sum / 5, worst);
-  (void)hipFree(d); (void)hipFree(t);
+  printf("%-46s grid %3d, %3d active, LDS %3zu KB%s: launch mean %.1f us, worst %.1f us (one block ~820)\n", name, blocks, n_act, lds / 1024,
+         with_search ? ", 16 x 512-thread workgroups on another stream" : "", sum / 5, worst);
+  (void)hipFree(d); (void)hipFree(t); (void)hipFree(o2); (void)hipStreamDestroy(s2);
 }
 
 static void busy(const char* name, const std::vector<uint32_t>& mask, int blocks) {
@@ -134,7 +151,56 @@ static void busy(const char* name, const std::vector<uint32_t>& mask, int blocks
   (void)hipFree(d); (void)hipFree(t); (void)hipStreamDestroy(st);
 }
 
+// does a kernel slow down merely because ANOTHER queue has a kernel running?  `blocks` busy workgroups (fixed work, ~820 us
+// alone) on one stream while 16 spinning workgroups (19 KB of LDS, 512 threads: the beam search's footprint) occupy
+// another stream for ~4 ms
+static void concurrent(int blocks, bool with_other, int prio, int other_wgs = 16, int other_threads = 512) {
+  hipStream_t s1, s2;
+  int lo, hi;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  (void)hipStreamCreateWithPriority(&s1, hipStreamNonBlocking, prio ? hi : 0);
+  (void)hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, 0);
+  uint32_t* d; long long* t; float* o;
+  (void)hipMalloc(&d, blocks * 8); (void)hipMalloc(&t, blocks * 16); (void)hipMalloc(&o, 64);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_busy), hipFuncAttributeMaxDynamicSharedMemorySize, 133 * 1024);
+  double sum = 0;
+  for (int rep = 0; rep < 4; ++rep) {
+    if (with_other) hipLaunchKernelGGL(k_spin, dim3(other_wgs), dim3(other_threads), 19 * 1024, s2, o, 300000);
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s1);
+    for (int k = 0; k < 3; ++k) hipLaunchKernelGGL(k_busy, dim3(blocks), dim3(512), 133 * 1024, s1, d, t, 60000);
+    (void)hipEventRecord(b, s1);
+    (void)hipDeviceSynchronize();
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    if (rep) sum += ms / 3;
+  }
+  // shader clock of the last launch's blocks: s_memtime cycles / wall-clock time
+  std::vector<long long> ht(blocks * 2);
+  (void)hipMemcpy(ht.data(), t, blocks * 16, hipMemcpyDeviceToHost);
+  printf("%3d busy blocks (133 KB) on stream A%s%s: %.1f us per launch", blocks, with_other ? " + spinning workgroups on stream B" : "",
+         prio ? " (A high priority)" : "", sum / 3 * 1000);
+  if (with_other) printf(" [B: %d x %d threads]", other_wgs, other_threads);
+  long long tmin = ht[0], tmax = ht[1], dmax = 0;
+  for (int b = 0; b < blocks; ++b) {
+    tmin = std::min(tmin, ht[2 * b]); tmax = std::max(tmax, ht[2 * b + 1]); dmax = std::max(dmax, ht[2 * b + 1] - ht[2 * b]);
+  }
+  printf("; last launch: first start -> last end %.1f us, longest block %.1f us\n", (tmax - tmin) / 100.0, dmax / 100.0);
+  (void)hipFree(d); (void)hipFree(t); (void)hipFree(o); (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2);
+}
+
 int main() {
+  concurrent(207, false, 0);
+  concurrent(207, true, 0);
+  concurrent(207, true, 1);
+  concurrent(207, true, 0, 1, 512);
+  concurrent(207, true, 0, 1, 64);
+  concurrent(207, true, 0, 16, 64);
+  concurrent(207, true, 0, 64, 64);
+  concurrent(64, false, 0);
+  concurrent(64, true, 0);
+  concurrent(256, false, 0);
+  concurrent(256, true, 0);
   {
     // cfg5's batch: valid encoder frames of the 16 utterances, padded to 743 frames each, 32-row blocks of the flattened rows
     const int fl[16] = {743, 596, 588, 550, 510, 444, 429, 424, 400, 387, 374, 318, 245, 172, 115, 70};
@@ -147,6 +213,8 @@ int main() {
     std::vector<uint8_t> dense(n_act, 1);
     ragged("cfg5 full-rate layer, padded grid + early exits", act, 133 * 1024);
     ragged("the same active blocks as a dense grid", dense, 133 * 1024);
+    ragged("cfg5 full-rate layer, padded grid + early exits", act, 133 * 1024, true);
+    ragged("the same active blocks as a dense grid", dense, 133 * 1024, true);
     std::vector<uint8_t> act16((M + 15) / 16, 0);
     for (int b = 0; b < 16; ++b)
       for (int r = b * Tp; r < b * Tp + std::min(fl[b] + 4, Tp); ++r) act16[r / 16] = 1;
