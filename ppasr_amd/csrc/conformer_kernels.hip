@@ -441,6 +441,9 @@ void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, fl
     PPASR_LAUNCH(k_dense_join, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, S, bias, scale, out, M, ldc, n_valid);
     return;
   }
+  // (128-row tiles -- conv2's shape -- were measured for the big DeepSpeech2 GEMMs and are slower, 0.68 against 0.78 of
+  //  the peak at M = 15 872: one 135 KB workgroup per CU, eight K chunks per tile and 64 dword stores per lane leave
+  //  prologue and epilogue uncovered, where two 32-row workgroups per CU cover each other's)
   PPASR_LAUNCH((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, n_cols_padded / 256),
                      dim3(kThreads), lds, st, src, w, bias, out, M, K / KC, scale, ldc, n_valid, 0, PadSkip{}, (const int*)nullptr);
 }

@@ -328,12 +328,13 @@ __global__ __launch_bounds__(kThreads) void k_lstm_step_mfma(const float* __rest
 // products, buffer loads instead of 64-bit per-lane addresses and depth 2 keep the kernel at 80 registers = six waves per
 // SIMD = three workgroups per CU (their 53 KB of LDS allow no more), so a launch is ONE round; same-box A/B of the
 // depth, 5 x 1024 LSTM, 5 s utterances: B = 32 5.46 ms (depth 4) -> 5.00 (depth 2), B = 128 15.47 -> 15.22, depth 8
-// (spills) 12.2 / 42.3.
+// (spills) 12.2 / 42.3.  With six waves per SIMD the occupancy hides the latency: depth 1 is faster still (B = 32
+// 5.05 -> 4.75 ms, B = 64 8.09 -> 7.81, B = 128 14.64 -> 14.28, same box; depth 4 at that occupancy: 5.37 / 8.35 / 15.59).
 #ifndef PPASR_WAVE_OCC
 #define PPASR_WAVE_OCC 6
 #endif
 #ifndef PPASR_WAVE_PFD
-#define PPASR_WAVE_PFD 2
+#define PPASR_WAVE_PFD 1
 #endif
 // RT = 32-row tiles of the batch per workgroup (1, 2, 4): the 8 waves are RT row tiles x KS = 8 / RT slices of the
 // contraction, so a workgroup streams its 32 gate columns' weights ONCE for up to 128 utterances (round 3 ran one
