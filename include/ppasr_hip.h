@@ -99,6 +99,10 @@ enum {
   PPASR_OPT_CONCAT_AFTER = 8,  /* concat_after = True: x + concat_linear([x | att(x)]) (encoder.py:395-397) */
   PPASR_OPT_NO_MACARON = 16,   /* macaron_style = False: no feed_forward_macaron, ff_scale 1 (encoder.py:330-334) */
   PPASR_OPT_NO_CNN = 32,       /* use_cnn_module = False: no conv module, no norm_final */
+  PPASR_OPT_SQ_NO_ADAPTIVE_SCALE = 4096, /* model_type squeezeformer only: adaptive_scale = False (squeezeformer/encoder.py:44;
+                                  the checkpoint's ada_scale / ada_bias are then not applied).  The two other options of that
+                                  encoder need no flag: dw_stride = True is recognised by the [d][1][3][3] shape of
+                                  encoder.embed.dw_conv.weight, final_proj by the presence of encoder.final_proj.weight */
   PPASR_OPT_ACT_SHIFT = 8,     /* activation_type (utils/common.py:189-206) in bits 8..11: */
   PPASR_OPT_ACT_MASK = 15
 };

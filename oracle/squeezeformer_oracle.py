@@ -14,19 +14,36 @@ class SqueezeformerOracle(ConformerOracle):
     (causal conv module, TimeReductionLayerStream; squeezeformer/model.py:35-39)."""
 
     def __init__(self, sd, attention_heads=4, num_blocks=12, cnn_module_kernel=31, reduce_idx=5, recover_idx=11,
-                 max_len=5000, dtype=torch.float32, causal=True):
+                 max_len=5000, dtype=torch.float32, causal=True, adaptive_scale=True):
         # causal=False: the non-streaming model (non-causal conv modules, TimeReductionLayer1D; model.py:35-39)
         sd = dict(sd)
         sd.setdefault("encoder.after_norm.weight", sd["encoder.preln.weight"])  # only used for self.d
         super().__init__(sd, attention_heads, num_blocks, cnn_module_kernel, causal, max_len, dtype)
         self.reduce_idx = reduce_idx
         self.recover_idx = recover_idx
+        # adaptive_scale = False (squeezeformer/encoder.py:44): the parameters exist but are not applied
+        # (attention.py:120-123, positionwise.py:63-64, convolution.py:119-120)
+        self.adaptive_scale = adaptive_scale
+        # dw_stride = True (subsampling.py:38): the second conv of the front end is depthwise (weight [d, 1, 3, 3])
+        self.dw_groups = self.d if self.p["encoder.embed.dw_conv.weight"].shape[1] == 1 else 1
+
+    def _ada(self, x, prefix):
+        if not self.adaptive_scale:
+            return x
+        return self.p[prefix + ".ada_scale"].reshape(1, 1, -1) * x + self.p[prefix + ".ada_bias"].reshape(1, 1, -1)
+
+    def ctc_logits(self, enc):
+        # final_proj (encoder.py:165-167, 234-235, 381-382): Linear(encoder_dim, output_size) in front of ctc_lo
+        if "encoder.final_proj.weight" in self.p:
+            enc = enc @ self.p["encoder.final_proj.weight"] + self.p["encoder.final_proj.bias"]
+        return enc @ self.p["ctc.ctc_lo.weight"] + self.p["ctc.ctc_lo.bias"]
 
     def _embed_sq(self, x):
         # DepthwiseConv2DSubsampling4.forward  squeezeformer/subsampling.py:53-68 (dw_stride False -> groups=1)
         x = x.unsqueeze(1)
         x = F.relu(F.conv2d(x, self.p["encoder.embed.pw_conv.weight"], self.p["encoder.embed.pw_conv.bias"], stride=2))
-        x = F.relu(F.conv2d(x, self.p["encoder.embed.dw_conv.weight"], self.p["encoder.embed.dw_conv.bias"], stride=2))
+        x = F.relu(F.conv2d(x, self.p["encoder.embed.dw_conv.weight"], self.p["encoder.embed.dw_conv.bias"], stride=2,
+                            groups=self.dw_groups))
         b, c, t, f = x.shape
         x = x.permute(0, 2, 1, 3).reshape(b, t, c * f)
         x = x * math.sqrt(self.d)  # RelPositionalEncoding on the c*f-wide tensor (pos_emb not added)
@@ -36,7 +53,7 @@ class SqueezeformerOracle(ConformerOracle):
 
     def _attention_sq(self, x, mask, pos_emb, prefix, cache=None):
         # squeezeformer/attention.py:96-162 (adaptive scale :120-123, linear_pos WITH bias :28, cache :128-135)
-        x = self.p[prefix + ".ada_scale"].reshape(1, 1, -1) * x + self.p[prefix + ".ada_bias"].reshape(1, 1, -1)
+        x = self._ada(x, prefix)
         B, T, _ = x.shape
         h, dk = self.h, self.dk
         q = self._linear(x, prefix + ".linear_q").reshape(B, T, h, dk).permute(0, 2, 1, 3)
@@ -62,12 +79,12 @@ class SqueezeformerOracle(ConformerOracle):
 
     def _ffn_sq(self, x, prefix):
         # squeezeformer/positionwise.py:55-65
-        x = self.p[prefix + ".ada_scale"].reshape(1, 1, -1) * x + self.p[prefix + ".ada_bias"].reshape(1, 1, -1)
+        x = self._ada(x, prefix)
         return self._linear(self._swish(self._linear(x, prefix + ".w_1")), prefix + ".w_2")
 
     def _conv_sq(self, x, mask_pad, prefix, cache=None):
         # squeezeformer/convolution.py:102-163 ; mask_pad True = valid here (fill where ~mask_pad)
-        x = self.p[prefix + ".ada_scale"].reshape(1, 1, -1) * x + self.p[prefix + ".ada_bias"].reshape(1, 1, -1)
+        x = self._ada(x, prefix)
         x = x.transpose(1, 2)
         x = x.masked_fill(~mask_pad, 0.0)
         if self.lorder > 0:

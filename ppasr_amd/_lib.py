@@ -25,6 +25,7 @@ PPASR_MODEL_DEEPSPEECH2 = 3
 N_KERNEL_CLASSES = 10
 # ppasr_model_desc::options (include/ppasr_hip.h)
 PPASR_OPT_POST_NORM, PPASR_OPT_CONCAT_AFTER, PPASR_OPT_NO_MACARON, PPASR_OPT_NO_CNN, PPASR_OPT_ACT_SHIFT = 4, 8, 16, 32, 8
+PPASR_OPT_SQ_NO_ADAPTIVE_SCALE = 4096
 KPROF_NAME_LEN = 160
 
 

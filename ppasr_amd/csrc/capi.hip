@@ -83,8 +83,11 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
                         (desc->output_size != kD || desc->options != 0 || desc->input_layer == 1 || !fused_ks)) ||
                        ((desc->model_type == PPASR_MODEL_SQUEEZEFORMER || desc->model_type == PPASR_MODEL_EFFICIENT_CONFORMER) &&
                         desc->output_size != kD);
-  if ((desc->options != 0 || desc->input_layer == 1) && desc->model_type != PPASR_MODEL_CONFORMER)
+  const int sq_opts = desc->model_type == PPASR_MODEL_SQUEEZEFORMER ? PPASR_OPT_SQ_NO_ADAPTIVE_SCALE : 0;
+  if (((desc->options & ~sq_opts) != 0 || desc->input_layer == 1) && desc->model_type != PPASR_MODEL_CONFORMER)
     return fail(PPASR_EUNSUPPORTED, "non-default encoder options / input_layer=linear are built for model_type=conformer");
+  if ((desc->options & PPASR_OPT_SQ_NO_ADAPTIVE_SCALE) && desc->model_type != PPASR_MODEL_SQUEEZEFORMER)
+    return fail(PPASR_EINVAL, "PPASR_OPT_SQ_NO_ADAPTIVE_SCALE is a Squeezeformer option");
   if (desc->linear_units % 256 != 0 || desc->linear_units <= 0) return fail(PPASR_EUNSUPPORTED, "linear_units % 256 != 0");
   if (!generic && !fused_ks) return fail(PPASR_EUNSUPPORTED, "cnn_module_kernel must be 7, 15 or 31");
   if (generic) {

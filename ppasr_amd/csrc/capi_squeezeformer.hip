@@ -38,12 +38,30 @@ ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe
     return fail(PPASR_EUNSUPPORTED, "squeezeformer: need 0 < reduce_idx < recover_idx < num_blocks (or reduce_idx = -1)");
   Getter get{sd, ""};
   ppasr_status st;
-  {  // DepthwiseConv2DSubsampling4 with dw_stride=False (subsampling.py:36-47): two ordinary 3x3/s2 convs
+  // adaptive_scale = False (encoder.py:44): the ada_scale / ada_bias parameters exist in the checkpoint (every module creates
+  // them, attention.py:34-37) but are not applied -- fold ones / zeros instead
+  const bool no_ada = (dsc.options & PPASR_OPT_SQ_NO_ADAPTIVE_SCALE) != 0;
+  const std::vector<float> ones_d(d, 1.f), zeros_d(d, 0.f);
+  auto adapt = [&](const float*& as, const float*& ab) {
+    if (no_ada) {
+      as = ones_d.data();
+      ab = zeros_d.data();
+    }
+  };
+  {  // DepthwiseConv2DSubsampling4 (subsampling.py:36-47): two 3x3 / 2 convs; dw_stride = True makes the second one depthwise
     GETW(mean, "encoder.global_cmvn.mean", F);
     GETW(istd, "encoder.global_cmvn.istd", F);
     GETW(c1w, "encoder.embed.pw_conv.weight", d * 9);
     GETW(c1b, "encoder.embed.pw_conv.bias", d);
-    GETW(c2w, "encoder.embed.dw_conv.weight", (size_t)d * d * 9);
+    // dw_stride = True (groups = odim): weight [d][1][3][3].  Run as the ordinary conv with a block-diagonal weight -- the
+    // off-diagonal products are exact zeros, so the sums are the depthwise conv's; no shipped config sets the option
+    const float* c2w = get("encoder.embed.dw_conv.weight", (size_t)d * d * 9);
+    const bool dw_stride = !c2w;
+    if (!c2w) {
+      get.missing.clear();
+      c2w = get("encoder.embed.dw_conv.weight", (size_t)d * 9);
+    }
+    if (!c2w) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + get.missing);
     GETW(c2b, "encoder.embed.dw_conv.bias", d);
     GETW(ew, "encoder.embed.input_proj.0.weight", (size_t)d * F2 * d);
     GETW(eb, "encoder.embed.input_proj.0.bias", d);
@@ -56,7 +74,10 @@ ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe
       for (int j = 0; j < 9; ++j) c1[j * d + c] = c1w[c * 9 + j];
     UP(c1, m->front.conv1_w);
     UP(vec_of(c1b, d), m->front.conv1_b);
-    UP4(pack_b(9 * d, d, [&](int k, int n) { return c2w[((size_t)n * d + (k % d)) * 9 + (k / d)]; }), m->front.conv2_w);
+    UP4(pack_b(9 * d, d, [&](int k, int n) {
+          if (dw_stride) return (k % d) == n ? c2w[(size_t)n * 9 + (k / d)] : 0.f;
+          return c2w[((size_t)n * d + (k % d)) * 9 + (k / d)];
+        }), m->front.conv2_w);
     UP(vec_of(c2b, d), m->front.conv2_b);
     UP4(pack_b(F2 * d, d, [&](int k, int n) { return ew[((size_t)(k % d) * F2 + (k / d)) * d + n]; }), m->front.embed_w);
     UP(vec_of(eb, d), m->front.embed_b);
@@ -107,6 +128,7 @@ ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe
       const float* as = get(p + n + ".ada_scale", d);
       const float* ab = get(p + n + ".ada_bias", d);
       if (!a1 || !c1 || !a2 || !c2 || !as || !ab) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + get.missing);
+      adapt(as, ab);
       std::vector<float> b1f(c1, c1 + H);
       for (int nn = 0; nn < H; ++nn) {
         double acc = 0.0;
@@ -136,6 +158,7 @@ ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe
       GETW(pv, p + "self_attn.pos_bias_v", d);
       GETW(as, p + "self_attn.ada_scale", d);
       GETW(ab, p + "self_attn.ada_bias", d);
+      adapt(as, ab);
       const float* ws[3] = {wq, wk, wv};
       const float* bs[3] = {bq, bk, bv};
       UP4(pack_b(d, 3 * d, [&](int k, int n) { return as[k] * ws[n / d][(size_t)k * d + (n % d)]; }), W.wqkv);
@@ -170,6 +193,7 @@ ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe
       GETW(p2b, p + "conv_module.pointwise_conv2.bias", d);
       GETW(as, p + "conv_module.ada_scale", d);
       GETW(ab, p + "conv_module.ada_bias", d);
+      adapt(as, ab);
       UP4(pack_b(d, 2 * d, [&](int k, int n) { return as[k] * p1w[(size_t)n * d + k]; }), W.pw1);
       std::vector<float> b1f(2 * d), gp(d);
       for (int n = 0; n < 2 * d; ++n) {
@@ -223,8 +247,43 @@ ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe
     UP(vec_of(rb, d), m->sq_brec);
   }
   {
-    GETW(cw, "ctc.ctc_lo.weight", (size_t)d * V);
-    GETW(cb, "ctc.ctc_lo.bias", V);
+    // final_proj (output_size != encoder_dim, encoder.py:165-167,234-235): a Linear between the last layer and ctc_lo with
+    // nothing in between -- folded into the head at create time, logits = x (W_fp W_ctc) + (b_fp W_ctc + b_ctc), in double
+    std::vector<float> cw_f, cb_f;
+    const float *cw = nullptr, *cb = nullptr;
+    auto fp = sd.find("encoder.final_proj.weight");
+    if (fp != sd.end()) {
+      const Blob& fb = fp->second;
+      if (fb.ndim != 2 || fb.shape[0] != d) return fail(PPASR_EMISSING, "mis-shaped weight: encoder.final_proj.weight");
+      const int O = (int)fb.shape[1];
+      const float* fw = fb.p;
+      GETW(fbias, "encoder.final_proj.bias", O);
+      GETW(cw_o, "ctc.ctc_lo.weight", (size_t)O * V);
+      GETW(cb_o, "ctc.ctc_lo.bias", V);
+      cw_f.resize((size_t)d * V);
+      cb_f.resize(V);
+      std::vector<double> acc(V);
+      for (int k = 0; k < d; ++k) {
+        std::fill(acc.begin(), acc.end(), 0.0);
+        for (int o = 0; o < O; ++o) {
+          const double f = fw[(size_t)k * O + o];
+          const float* row = cw_o + (size_t)o * V;
+          for (int n = 0; n < V; ++n) acc[n] += f * (double)row[n];
+        }
+        for (int n = 0; n < V; ++n) cw_f[(size_t)k * V + n] = (float)acc[n];
+      }
+      for (int n = 0; n < V; ++n) acc[n] = (double)cb_o[n];
+      for (int o = 0; o < O; ++o)
+        for (int n = 0; n < V; ++n) acc[n] += (double)fbias[o] * (double)cw_o[(size_t)o * V + n];
+      for (int n = 0; n < V; ++n) cb_f[n] = (float)acc[n];
+      cw = cw_f.data();
+      cb = cb_f.data();
+    } else {
+      GETW(cw_d, "ctc.ctc_lo.weight", (size_t)d * V);
+      GETW(cb_d, "ctc.ctc_lo.bias", V);
+      cw = cw_d;
+      cb = cb_d;
+    }
     m->head.ln_g = nullptr;  // no after_norm in Squeezeformer
     m->head.ln_b = nullptr;
     m->head.V = V;

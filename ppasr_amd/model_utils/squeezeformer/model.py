@@ -28,8 +28,11 @@ class SqueezeformerModel(ConformerModel):
         self.input_dim, self.vocab_size, self.streaming = input_dim, vocab_size, streaming
         conf = dict(encoder_conf or {})
         self.output_size = int(conf.get("encoder_dim", 256))
-        if int(conf.get("output_size", self.output_size)) != self.output_size:
-            raise NotImplementedError("final_proj (output_size != encoder_dim) is not built")
+        # output_size != encoder_dim: the reference appends final_proj = Linear(encoder_dim, output_size) (encoder.py:165-167);
+        # ppasr_create folds it into the CTC head when the checkpoint carries encoder.final_proj.weight
+        self.final_output_size = int(conf.get("output_size", self.output_size))
+        if (self.final_output_size != self.output_size) != ("encoder.final_proj.weight" in state_dict):
+            raise ValueError("encoder_conf.output_size != encoder_dim <=> the checkpoint has encoder.final_proj.*")
         self.attention_heads = int(conf.get("attention_heads", 4))
         self.linear_units = self.output_size * int(conf.get("feed_forward_expansion_factor", 8))
         self.num_blocks = int(conf.get("num_blocks", 12))
@@ -37,10 +40,15 @@ class SqueezeformerModel(ConformerModel):
         self.max_len = int(conf.get("max_len", 5000))
         self.reduce_idx = conf.get("reduce_idx", 5)
         self.recover_idx = conf.get("recover_idx", 11)
-        for key, want in (("pos_enc_layer_type", "rel_pos"), ("activation_type", "swish"), ("normalize_before", False),
-                          ("adaptive_scale", True), ("dw_stride", False)):
+        for key, want in (("pos_enc_layer_type", "rel_pos"), ("activation_type", "swish"), ("normalize_before", False)):
             if key in conf and conf[key] != want:
                 raise NotImplementedError(f"encoder_conf.{key}={conf[key]!r}: only {want!r} is built")
+        # adaptive_scale = False: a flag (the checkpoint still carries the unused ada_scale / ada_bias, attention.py:34-37);
+        # dw_stride = True: recognised by ppasr_create from the depthwise shape of encoder.embed.dw_conv.weight
+        self.adaptive_scale = bool(conf.get("adaptive_scale", True))
+        dw = bool(conf.get("dw_stride", False))
+        if "encoder.embed.dw_conv.weight" in state_dict and (np.asarray(state_dict["encoder.embed.dw_conv.weight"]).shape[1] == 1) != dw:
+            raise ValueError(f"encoder_conf.dw_stride={dw} does not match the shape of encoder.embed.dw_conv.weight")
         # cnn_norm_type (squeezeformer/encoder.py:41): layer_norm, or batch_norm = BatchNorm1D in eval mode (folded)
         norm = conf.get("cnn_norm_type", "layer_norm")
         if norm not in ("layer_norm", "batch_norm"):
@@ -66,6 +74,8 @@ class SqueezeformerModel(ConformerModel):
                               1 if streaming else 0,  # causal conv + stream time-reduction <=> streaming (model.py:35-39)
                               self.max_len, -1 if self.reduce_idx is None else int(self.reduce_idx),
                               -1 if self.recover_idx is None else int(self.recover_idx), -1, 0, 0)
+        if not self.adaptive_scale:
+            desc.options |= _lib.PPASR_OPT_SQ_NO_ADAPTIVE_SCALE
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ppasr_create(ctypes.byref(desc), blobs, len(sd), ctypes.byref(handle)))

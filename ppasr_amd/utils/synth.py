@@ -172,13 +172,15 @@ def synth_vocabulary(vocab_size=DEFAULT_VOCAB_SIZE):
 def squeezeformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, encoder_dim=256, attention_heads=4,
                              feed_forward_expansion_factor=8, num_blocks=12, cnn_module_kernel=31, seed=1234,
                              ctc_sharpen=8.0, perturb_norm=False, cmvn_mean=10.0, cmvn_istd=1.0 / 3.3, streaming=True,
-                             cnn_norm_type="layer_norm"):
+                             cnn_norm_type="layer_norm", dw_stride=False, output_size=None):
     """Random-init ``SqueezeformerModel`` inference parameters (``streaming=False``: the time-reduction layer is
     ``TimeReductionLayer1D`` with a 5-tap depthwise conv instead of the 1-tap ``TimeReductionLayerStream``,
     squeezeformer/model.py:35-39).  The reference's ``init_weights()`` calls have
     no effect on the values (SURVEY Appendix B.14): every layer keeps the ``utils/base.py`` Kaiming-uniform init;
     attention / conv ``ada_scale``/``ada_bias`` are 1/0, the FFN ones are Xavier-uniform
-    (squeezeformer/positionwise.py:39-42).  ``perturb_norm`` randomises every norm / adaptive-scale vector."""
+    (squeezeformer/positionwise.py:39-42).  ``perturb_norm`` randomises every norm / adaptive-scale vector.
+    ``dw_stride``: the front end's second conv is depthwise (subsampling.py:38); ``output_size`` != ``encoder_dim``: the
+    encoder ends in ``final_proj`` and the CTC head reads ``output_size`` features (encoder.py:165-167)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     d, h = encoder_dim, attention_heads
     dk = d // h
@@ -189,7 +191,7 @@ def squeezeformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, encode
     sd["encoder.global_cmvn.istd"] = np.full(input_dim, cmvn_istd, np.float32)
     sd["encoder.embed.pw_conv.weight"] = _kaiming(rng, (d, 1, 3, 3), 9)
     sd["encoder.embed.pw_conv.bias"] = _kaiming(rng, (d,), d)
-    sd["encoder.embed.dw_conv.weight"] = _kaiming(rng, (d, d, 3, 3), d * 9)
+    sd["encoder.embed.dw_conv.weight"] = _kaiming(rng, (d, 1, 3, 3), 9) if dw_stride else _kaiming(rng, (d, d, 3, 3), d * 9)
     sd["encoder.embed.dw_conv.bias"] = _kaiming(rng, (d,), d)
     _linear(sd, "encoder.embed.input_proj.0", d * f2, d, rng)
     _layernorm(sd, "encoder.preln", d, rng, perturb_norm)
@@ -236,6 +238,9 @@ def squeezeformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, encode
     sd["encoder.time_reduction_layer.pw_conv.weight"] = _kaiming(rng, (d, d, 1), d)
     sd["encoder.time_reduction_layer.pw_conv.bias"] = _kaiming(rng, (d,), d)
     _linear(sd, "encoder.time_recover_layer", d, d, rng)
+    if output_size is not None and output_size != d:
+        _linear(sd, "encoder.final_proj", d, output_size, rng)
+        d = output_size
     sd["ctc.ctc_lo.weight"] = _xavier(rng, (d, vocab_size), d, vocab_size) * np.float32(ctc_sharpen)
     sd["ctc.ctc_lo.bias"] = np.zeros(vocab_size, np.float32)
     return sd

@@ -241,10 +241,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also regenerate ref_full.npz (BASELINE configs, minutes of CPU)")
     ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--add", nargs="*", default=None,
+                    help="run only these SMALL cases and MERGE their outputs into the existing ref_small.npz")
     args = ap.parse_args()
     if not os.path.isdir(REFERENCE):
         raise SystemExit("needs /root/reference (build container only)")
     paddle = enter_reference()
+    if args.add:
+        path = os.path.join(HERE, "ref_small.npz")
+        old = dict(np.load(path))
+        new = small(paddle, args.add)
+        old = {k: v for k, v in old.items() if k.split("/")[0] not in args.add}
+        old.update(new)
+        np.savez_compressed(path, **old)
+        print("merged", sorted({k.split("/")[0] for k in new}), "into ref_small.npz:", len(old), "arrays")
+        return
     if not args.full or args.only:
         out = small(paddle, args.only)
         if out and not args.only:

@@ -40,6 +40,12 @@ SMALL = {
     "sq_s": _former("squeezeformer", True, 4, 59, 521, (2, 131, [131, 77], 522), chunk_frames=64 * 4 + 40,
                     required=(-16, 32), reduce_idx=1, recover_idx=3),
     "sq_n": _former("squeezeformer", False, 4, 59, 523, (2, 131, [131, 70], 524), reduce_idx=1, recover_idx=3),
+    # the SqueezeformerEncoder constructor arguments no shipped YAML sets (squeezeformer/encoder.py:28-44): adaptive_scale =
+    # False with a depthwise second front-end conv (dw_stride), and final_proj (output_size != encoder_dim)
+    "sq_opt": _former("squeezeformer", True, 3, 59, 525, (2, 131, [131, 77], 526), chunk_frames=64 * 3 + 40,
+                      required=(-16,), reduce_idx=1, recover_idx=2, adaptive_scale=False, dw_stride=True),
+    "sq_fproj": _former("squeezeformer", False, 3, 59, 527, (2, 131, [131, 70], 528), reduce_idx=1, recover_idx=2,
+                        output_size=144),
     # conv-module BatchNorm1D instead of LayerNorm (cnn_module_norm / cnn_norm_type: batch_norm)
     "conf_bn": _former("conformer", True, 2, 61, 541, (2, 131, [131, 77], 542), chunk_frames=64 * 2 + 30,
                        required=(-16, 32), cnn_module_norm="batch_norm"),
@@ -135,7 +141,8 @@ def state_dict(case, perturb=True):
     if fam == "squeezeformer":
         return squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn, streaming=case["streaming"],
                                         cnn_norm_type=kw.get("cnn_norm_type", "layer_norm"),
-                                        encoder_dim=kw.get("encoder_dim", 256), attention_heads=kw.get("attention_heads", 4))
+                                        encoder_dim=kw.get("encoder_dim", 256), attention_heads=kw.get("attention_heads", 4),
+                                        dw_stride=kw.get("dw_stride", False), output_size=kw.get("output_size"))
     if fam == "deepspeech2":
         return deepspeech2_state_dict(vocab_size=V, num_rnn_layers=L, streaming=case["streaming"], seed=seed,
                                       perturb_norm=pn, use_gru=kw.get("use_gru", False))
@@ -181,11 +188,12 @@ def reference_encoder_conf(case):
                                        stride_kernel=True)
         return c
     if fam == "squeezeformer":
-        return dict(encoder_dim=kw.get("encoder_dim", 256), output_size=kw.get("encoder_dim", 256),
+        return dict(encoder_dim=kw.get("encoder_dim", 256), output_size=kw.get("output_size", kw.get("encoder_dim", 256)),
                     attention_heads=kw.get("attention_heads", 4), num_blocks=L,
                     reduce_idx=kw.get("reduce_idx", 5), recover_idx=kw.get("recover_idx", 11),
                     feed_forward_expansion_factor=8, input_dropout_rate=0.1, feed_forward_dropout_rate=0.1,
-                    attention_dropout_rate=0.1, adaptive_scale=True, cnn_module_kernel=31, normalize_before=False,
+                    attention_dropout_rate=0.1, adaptive_scale=kw.get("adaptive_scale", True),
+                    dw_stride=kw.get("dw_stride", False), cnn_module_kernel=31, normalize_before=False,
                     activation_type="swish", pos_enc_layer_type="rel_pos",
                     cnn_norm_type=kw.get("cnn_norm_type", "layer_norm"))
     if fam == "deepspeech2":

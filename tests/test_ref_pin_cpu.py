@@ -46,7 +46,7 @@ def make_oracle(case, sd):
                                         cnn_module_kernel=kw.get("cnn_module_kernel", 15))
     if fam == "squeezeformer":
         return SqueezeformerOracle(sd, num_blocks=L, reduce_idx=kw["reduce_idx"], recover_idx=kw["recover_idx"], causal=causal,
-                                   attention_heads=kw.get("attention_heads", 4))
+                                   attention_heads=kw.get("attention_heads", 4), adaptive_scale=kw.get("adaptive_scale", True))
     return DeepSpeech2Oracle(sd, num_rnn_layers=L, streaming=case["streaming"], use_gru=kw.get("use_gru", False))
 
 
