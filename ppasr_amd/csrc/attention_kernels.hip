@@ -45,6 +45,9 @@ namespace ppasr {
 #ifndef PPASR_ATTN_NW
 #define PPASR_ATTN_NW 4  // waves = key splits per workgroup of the plain heads
 #endif
+#ifndef PPASR_ATTN_NW192
+#define PPASR_ATTN_NW192 2  // ... of the grouped heads (d_k = 192); cfg4, same box, the 4 launches of a step: 2 waves 0.166 ms, 3: 0.197, 4: 0.186
+#endif
 #ifndef PPASR_ATTN_NT
 #define PPASR_ATTN_NT 1  // 32-key tiles per sub-block of the plain heads
 #endif
@@ -55,7 +58,7 @@ struct AttnT {
   static constexpr int NC2 = DK / 64;          // 64-column chunks of the context (two output tiles each: even / odd columns)
   static constexpr int NGK = 2 * DK / 8;       // 8-wide k-groups of the score contraction over K' = [k | p]
   static constexpr int NT = DK == 64 ? PPASR_ATTN_NT : 1;  // 32-key tiles per sub-block (accumulator budget)
-  static constexpr int NW = DK == 64 ? PPASR_ATTN_NW : 2;  // waves per workgroup = key splits of its query block
+  static constexpr int NW = DK == 64 ? PPASR_ATTN_NW : PPASR_ATTN_NW192;  // waves per workgroup = key splits of its query block
   static constexpr int MAXQ = 1;               // query blocks per workgroup (LDS: one Q' tile)
   static constexpr int PQ = DK == 64 ? PPASR_ATTN_PQ : 2;  // V k-groups in flight
   static constexpr int QLD = 2 * DK + 4;       // Q' row stride (floats)
