@@ -570,9 +570,9 @@ ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable) {
   if (!h) return fail(PPASR_EINVAL, "null handle");
   // the ragged mode is built into the fused 256-column kernels behind the 4x front end; other handles would silently
   // compute (and return) every padded row, which is not what the caller asked for
-  if (enable && (h->desc.model_type == PPASR_MODEL_DEEPSPEECH2 || h->desc.input_layer != 0 ||
-                 h->generic))
-    return fail(PPASR_EUNSUPPORTED, "skip_padding: built for the fused 256-wide route behind the conv2d (4x) front end only");
+  if (enable && (h->desc.model_type == PPASR_MODEL_DEEPSPEECH2 || h->desc.input_layer == 1 || h->generic))
+    return fail(PPASR_EUNSUPPORTED, "skip_padding: built for the fused 256-wide route behind the conv front ends (DeepSpeech2, "
+                                    "input_layer = linear and the general layer route compute every row)");
   h->skip_padding = enable != 0;
   return PPASR_OK;
 }
@@ -635,7 +635,10 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   // what valid outputs read from the rows behind them: the right context of the non-causal conv module, and with a
   // rate change (Efficient-Conformer) the stride layer's 2j / 2j+1 rows and the 3-frame groups of grouped attention.
   const bool eff = h->desc.model_type == PPASR_MODEL_EFFICIENT_CONFORMER;
-  const bool skip = h->skip_padding && lens && !h->taps && h->desc.input_layer == 0;  // (6x / 8x front ends: all rows)
+  // (6x / 8x front ends: the LAYERS and the head skip -- frame t is valid iff 6t / 8t < len --, the front end itself
+  //  computes every row: its skip rules are written for the 3x3 / 2 pair of Conv2dSubsampling4)
+  const bool skip = h->skip_padding && lens && !h->taps && h->desc.input_layer != 1;
+  const bool skip_front = skip && h->desc.input_layer == 0;
   const int rc = h->desc.causal ? 0 : (h->desc.cnn_module_kernel - 1) / 2;
   const int slack_half = rc + 4, slack_full = eff ? 2 * slack_half + rc + 8 : rc + 4;
   auto pskip = [&](int Tcur, int mul_cur) {
@@ -644,13 +647,14 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       ps.lens = lens;
       ps.Tp = Tcur;
       ps.mul = mul_cur;
-      ps.slack = mul_cur == 4 ? slack_full : slack_half;  // (skip mode exists for the 4x front end only)
+      ps.slack = mul_cur == sub ? slack_full : slack_half;
     }
     return ps;
   };
   // Conv2dSubsampling4: both convolutions in one launch, conv1's output never leaves the chip (front_fused.hip)
   const bool conv12 = h->desc.input_layer == 0 && conv12_enabled(h) && conv12_supported(h->front, F, F2);
-  if (!conv12) timed(0, [&] { launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, pskip(Tp, sub)); });
+  const PadSkip ps_front = skip_front ? pskip(Tp, sub) : PadSkip{};  // (the front end's own kernels)
+  if (!conv12) timed(0, [&] { launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, ps_front); });
   if (h->desc.input_layer == 8) {
     // Conv2dSubsampling8: conv1 -> conv2 (3x3 / 2) -> conv3 (3x3 / 2, written over conv1's output) -> linear
     timed(1, [&] {
@@ -662,10 +666,10 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     timed(1, [&] {
       // (ragged batches: the active-tile table of conv2 lives in the CTC head's statistics buffer, unused until the head)
       int* tile_tab = (size_t)B + 2 <= ((size_t)M + 63) / 64 * 64 ? reinterpret_cast<int*>(ws + wl.rmax) : nullptr;
-      if (conv12) launch_conv12(feats, h->front, y2, B, T, F, Tp, F2, st, pskip(Tp, sub), tile_tab);
-      else launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, pskip(Tp, sub), tile_tab);
+      if (conv12) launch_conv12(feats, h->front, y2, B, T, F, Tp, F2, st, ps_front, tile_tab);
+      else launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, ps_front, tile_tab);
     });
-    timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st, pskip(Tp, sub), ffn_split_for(h, M), y1); });
+    timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st, ps_front, ffn_split_for(h, M), y1); });
   }
   tap(xa, (size_t)M * kD);
   const int n_chunks = h->desc.linear_units / 256;

@@ -61,8 +61,19 @@ def _squeezeformer_noncausal(V):
     return SqueezeformerModel(80, V, streaming=False, encoder_conf=conf, state_dict=sd, device="cuda:0"), 4
 
 
+def _conformer_front(V, input_layer, mul):
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    L = 2
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=10 + mul, perturb_norm=True, input_layer=input_layer)
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15, input_layer=input_layer)
+    return ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0"), mul
+
+
 FAMILIES = {
     "conformer": lambda V: _conformer(V, True),
+    # the 6x / 8x front ends (input_layer: conv2d6 / conv2d8): the layers skip, the front end computes every row
+    "conformer-conv2d6": lambda V: _conformer_front(V, "conv2d6", 6),
+    "conformer-conv2d8": lambda V: _conformer_front(V, "conv2d8", 8),
     "conformer-noncausal": lambda V: _conformer(V, False),
     "squeezeformer": _squeezeformer,
     "efficient": _efficient,
