@@ -146,10 +146,10 @@ PPASR_API ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t 
  * stride / time-reduction reads): whole 32-row blocks behind them are skipped in every kernel and attention stops at
  * the last valid key.  Valid rows are bit-identical to the default mode; rows of `probs` / `logits` behind an
  * utterance's last valid frame are set to 0, `frame_argmax` to 0 (blank) and `frame_maxprob` to 0 -- pass frame_lens
- * to the decoders.  Default: off (= the reference's outputs for every row).  Built into the fused 256-column kernels
- * behind the conv front ends (behind conv2d6 / conv2d8 the layers and the head skip, the front end itself computes every
- * row): enabling it on a general-route (see options), input_layer = linear or DeepSpeech2 handle returns PPASR_EUNSUPPORTED
- * (those routes compute every row). */
+ * to the decoders.  Default: off (= the reference's outputs for every row).  Built into the fused 256-column kernels and
+ * the general layer route (widths 512 .., constructor options) behind the conv front ends (behind conv2d6 / conv2d8 and on
+ * the general route the layers and the head skip, the front end itself computes every row): enabling it on an
+ * input_layer = linear or DeepSpeech2 handle returns PPASR_EUNSUPPORTED (those compute every row). */
 PPASR_API ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable);
 
 /* Under-filled launches.  A kernel with fewer 32-row blocks than the chip has CUs takes as long as a full one.  When a

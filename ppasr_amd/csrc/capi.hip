@@ -570,9 +570,9 @@ ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable) {
   if (!h) return fail(PPASR_EINVAL, "null handle");
   // the ragged mode is built into the fused 256-column kernels behind the 4x front end; other handles would silently
   // compute (and return) every padded row, which is not what the caller asked for
-  if (enable && (h->desc.model_type == PPASR_MODEL_DEEPSPEECH2 || h->desc.input_layer == 1 || h->generic))
-    return fail(PPASR_EUNSUPPORTED, "skip_padding: built for the fused 256-wide route behind the conv front ends (DeepSpeech2, "
-                                    "input_layer = linear and the general layer route compute every row)");
+  if (enable && (h->desc.model_type == PPASR_MODEL_DEEPSPEECH2 || h->desc.input_layer == 1))
+    return fail(PPASR_EUNSUPPORTED, "skip_padding: built behind the conv front ends (DeepSpeech2 and input_layer = linear "
+                                    "compute every row)");
   h->skip_padding = enable != 0;
   return PPASR_OK;
 }

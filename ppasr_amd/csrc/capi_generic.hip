@@ -56,6 +56,7 @@ struct GemmEpi {
   float rscale = 1.f;
   const int64_t* lens = nullptr;
   int Tp = 1, mul = 1;
+  PadSkip ps;  // ragged batches (ppasr_set_skip_padding): row tiles behind an utterance's needed frames are not computed
 };
 
 // out[M][ldc] (columns < n_valid) = epilogue(A[M][K] Wpacked + bias): the streamed-weight GEMM of k_gemm_stream
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(kThreads) void k_dense_epi(const float* __restrict_
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const int r0 = blockIdx.x * BM;
+  if (pad_block_skippable(epi.ps, r0, BM, M)) return;
   const int tile_stride = n_chunks * G * 64;
   const f32x4* wbase = wp + (size_t)(blockIdx.y * kWaves + wave) * tile_stride;
   BRing<1> ring;
@@ -158,8 +160,9 @@ __global__ __launch_bounds__(kThreads) void k_g_ffn512(const float* x, float* ou
                                                        const float* __restrict__ ln_b, const f32x4* __restrict__ w1,
                                                        const float* __restrict__ b1, const f32x4* __restrict__ w2,
                                                        const float* __restrict__ b2, float scale, int act, int M,
-                                                       int n_chunks) {
+                                                       int n_chunks, PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
   float* bufA = smem;                    // [32][516]
   float* bufH = bufA + kRows * kLd512;   // [2][32][260]
   const int lane = lane_id(), wave = wave_id();
@@ -244,8 +247,9 @@ __global__ __launch_bounds__(kThreads) void k_g_proj512(const float* __restrict_
                                                         const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                         float eps, const int64_t* __restrict__ lens, int Tp, int mul,
                                                         const f32x4* __restrict__ w, const float* __restrict__ bias,
-                                                        int n_tiles_per_wave, int M) {
+                                                        int n_tiles_per_wave, int M, PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
   float* bufA = smem;
   const int lane = lane_id(), wave = wave_id();
   const int r0 = blockIdx.x * kRows, valid = min(kRows, M - r0);
@@ -335,9 +339,10 @@ __global__ __launch_bounds__(kThreads) void k_g_proj512(const float* __restrict_
 // LinearNoSubsampling, where the positional encoding's x * sqrt(d) follows the ReLU).  (x and out may be the same buffer, so neither is __restrict__)
 __global__ __launch_bounds__(256) void k_g_ln(const float* x, float* out, const float* __restrict__ g,
                                               const float* __restrict__ b, int M, int D, float eps, int act,
-                                              const int64_t* __restrict__ lens, int Tp, int mul, float post_scale) {
+                                              const int64_t* __restrict__ lens, int Tp, int mul, float post_scale, PadSkip ps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
+  if (pad_block_skippable(ps, row, 1, M)) return;  // ragged batches: a row behind its utterance's needed frames
   const float* xr = x + (size_t)row * D;
   float* o = out + (size_t)row * D;
   if (lens) {
@@ -385,11 +390,12 @@ __global__ void k_g_glu(const float* __restrict__ pg, float* __restrict__ g, int
 __global__ __launch_bounds__(256) void k_g_dwconv(const float* __restrict__ g, float* __restrict__ out,
                                                   const float* __restrict__ w /*[KS][D]*/, const float* __restrict__ bias,
                                                   const float* __restrict__ pad, int Tp, int D, int KS, int left, int row_off,
-                                                  int stride, int Tp_in, int TT) {
+                                                  int stride, int Tp_in, int TT, PadSkip ps) {
   // stride 2: the Efficient-Conformer's stride layer (efficient_conformer/convolution.py:54-60): output frame t of the Tp =
   // ceil(Tp_in / 2) reads the input frames 2 t - left .. ; stride 1: Tp_in == Tp
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int c = blockIdx.z * 256 + threadIdx.x, bb = blockIdx.y, t0 = blockIdx.x * TT;
+  if (ps.lens && t0 >= pad_need_steps(ps, bb)) return;  // ragged batches: a tile of OUTPUT frames nobody needs (ps.Tp == Tp)
   const int n_out = min(TT, Tp - t0), Tin = Tp_in + row_off;
   const int n_in = stride * (n_out - 1) + KS;       // input rows of this tile
   const int tt0 = stride * t0 + row_off - left;     // first of them
@@ -415,11 +421,11 @@ constexpr int kDwMaxKs = 63;                 // cnn_module_kernel of the general
 constexpr size_t kDwLdsRows = 150;            // LDS budget in 1 KiB rows: input rows + taps
 // B * Tp output rows; tile = up to 32 output frames, fewer when the kernel is long (stride * (TT - 1) + 2 KS rows of LDS)
 inline void launch_dwconv(const float* g, float* out, const float* w, const float* bias, const float* pad, int B, int Tp, int D,
-                          int KS, int left, int row_off, int stride, int Tp_in, hipStream_t st) {
+                          int KS, int left, int row_off, int stride, int Tp_in, hipStream_t st, const PadSkip& ps = PadSkip{}) {
   const int TT = std::max(1, std::min(32, (int)(kDwLdsRows - 2 * KS) / stride + 1));
   const size_t lds = (size_t)(stride * (TT - 1) + 2 * KS) * 256 * sizeof(float);
   PPASR_LAUNCH(k_g_dwconv, dim3((Tp + TT - 1) / TT, B, D / 256), dim3(256), lds, st, g, out, w, bias, pad, Tp, D, KS, left,
-               row_off, stride, Tp_in, TT);
+               row_off, stride, Tp_in, TT, ps);
 }
 
 // abs_pos (PositionalEncoding.forward, embedding.py:70: x * xscale + pe[offset : offset + T]; the scale is the embed
@@ -538,18 +544,45 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
   float *x = r.x, *a = r.a, *big = r.big, *y = r.y, *g = r.g, *ctx = r.ctx;
   const bool rel = o.pos == PPASR_OPT_POS_REL;
   bool half = false;  // behind the stride layer
+  // ragged batches (ppasr_set_skip_padding; batched calls only): per utterance only the rows its valid output frames depend
+  // on are computed, with the slack of the fused route (capi.hip ppasr_encode): the right context of a non-causal conv
+  // module, and with a rate change the stride layer's 2j / 2j + 1 rows and the 3-frame groups of grouped attention.  Rows
+  // behind them keep whatever the buffers hold; the valid rows never read them (PAD frames enter the conv module through
+  // its mask, keys and values through the attention's) and the outputs behind the valid frames are zeroed at the end.
+  const bool skip = h->skip_padding && lens && !r.s;
+  const int rc = (h->desc.causal || !o.use_cnn) ? 0 : (h->desc.cnn_module_kernel - 1) / 2;
+  const int slack_half = rc + 4, slack_full = eff ? 2 * slack_half + rc + 8 : rc + 4, mul0 = mul;
+  auto pskip = [&](int Tcur, int mul_cur) {
+    PadSkip p;
+    if (skip) {
+      p.lens = lens;
+      p.Tp = Tcur;
+      p.mul = mul_cur;
+      p.slack = mul_cur == mul0 ? slack_full : slack_half;
+    }
+    return p;
+  };
+  PadSkip ps = pskip(Tp, mul);
   auto ln = [&](const float* in, float* out, const float* gg, const float* bb, float eps, int act, bool mask, int rows) {
-    PPASR_LAUNCH(k_g_ln, dim3((rows + 3) / 4), dim3(256), 0, st, in, out, gg, bb, rows, D, eps, act, mask ? lens : nullptr, Tp, mul, 1.0f);
+    PPASR_LAUNCH(k_g_ln, dim3((rows + 3) / 4), dim3(256), 0, st, in, out, gg, bb, rows, D, eps, act, mask ? lens : nullptr, Tp, mul, 1.0f,
+                 rows == M ? ps : PadSkip{});
+  };
+  auto plain_epi = [&]() {
+    GemmEpi e;
+    e.ps = ps;
+    return e;
   };
   auto act_epi = [&](int act) {
     GemmEpi e;
     e.act = act;
+    e.ps = ps;
     return e;
   };
   auto res_epi = [&](float scale, bool mask) {
     GemmEpi e;
     e.res = x;
     e.rscale = scale;
+    e.ps = ps;
     if (mask && lens) {
       e.lens = lens;
       e.Tp = Tp;
@@ -562,7 +595,7 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
   auto ffn = [&](const float* lg, const float* lb, const f32x4* w1, const float* b1, const f32x4* w2, const float* b2, float scale) {
     if (fused_ffn && D == kD512) {  // one launch, hidden activations in LDS
       PPASR_LAUNCH(k_g_ffn512, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsFfn512, st, x, x, o.post_norm ? nullptr : lg,
-                   o.post_norm ? nullptr : lb, w1, b1, w2, b2, scale, o.act, M, H / 256);
+                   o.post_norm ? nullptr : lb, w1, b1, w2, b2, scale, o.act, M, H / 256, ps);
       if (o.post_norm) ln(x, x, lg, lb, 1e-5f, kActNone, false, M);
       return;
     }
@@ -589,13 +622,13 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
       if (fused_ffn && D == kD512 && !o.concat_after) {  // LayerNorm + QKV in one launch
         PPASR_LAUNCH(k_g_proj512<false>, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsProj512, st, x, big, 3 * D,
                      o.post_norm ? nullptr : L.ln_mha_g, o.post_norm ? nullptr : L.ln_mha_b, 1e-5f, (const int64_t*)nullptr, Tp, mul,
-                     L.wqkv, L.bqkv, 3 * D / 32 / kWaves, M);
+                     L.wqkv, L.bqkv, 3 * D / 32 / kWaves, M, ps);
       } else {
         if (!o.post_norm) {
           ln(x, a, L.ln_mha_g, L.ln_mha_b, 1e-5f, kActNone, false, M);
           in = a;
         }
-        dense(in, D, L.wqkv, L.bqkv, big, M, D, 3 * D, 3 * D, 3 * D, st);
+        dense(in, D, L.wqkv, L.bqkv, big, M, D, 3 * D, 3 * D, 3 * D, st, 1.0f, plain_epi());
       }
       // tokens: frames, or zero-padded groups of 3 (GroupedRelPositionMultiHeadedAttention, pad4group)
       const int grp = h->layer_group[i], Tt = (Tp + grp - 1) / grp;
@@ -613,11 +646,11 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
         at.kv_frames = n_cache + Tp;
         at.T2 = (n_cache + Tp + grp - 1) / grp;
       }
-      at.pad_skip = 0;
+      at.pad_skip = skip ? ps.slack + 1 : 0;
       at.dm = D;
       launch_attention(at, B, heads, st);
       if (o.concat_after) {  // x + concat_linear([attention input | linear_out(ctx)])
-        dense(ctx, D, L.wo, L.bo, y, M, D, D, D, D, st);
+        dense(ctx, D, L.wo, L.bo, y, M, D, D, D, D, st, 1.0f, plain_epi());
         PPASR_LAUNCH(k_g_concat, blocks((size_t)M * 2 * D), dim3(256), 0, st, in, y, r.cat, M, D);
         dense(r.cat, 2 * D, h->gen_x[i].wcat, h->gen_x[i].bcat, x, M, 2 * D, D, D, D, st, 1.0f, res_epi(1.0f, false));
       } else {
@@ -635,7 +668,7 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
       if (fused_ffn && D == kD512 && lo_s == 0) {  // (LayerNorm) + pad mask + pointwise_conv1 + GLU in one launch
         PPASR_LAUNCH(k_g_proj512<true>, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsProj512, st, x, g, D,
                      o.post_norm ? nullptr : L.ln_conv_g, o.post_norm ? nullptr : L.ln_conv_b, 1e-5f, lens, Tp, mul, L.pw1,
-                     L.pw1_b, 2, M);
+                     L.pw1_b, 2, M, ps);
       } else {
         if (!o.post_norm) ln(x, a_new, L.ln_conv_g, L.ln_conv_b, 1e-5f, kActNone, true, M);  // LN_conv, PAD frames -> 0
         else ln(x, a_new, nullptr, nullptr, 0.f, kActNone, true, M);                           // PAD frames -> 0 only
@@ -645,23 +678,24 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
           // new cache = the last lo rows of [cache | chunk] (convolution.py:110-116)
           HIP_TRY(hipMemcpyAsync(hist, a + (size_t)M * D, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
         }
-        dense(a, D, L.pw1, L.pw1_b, big, rows, D, 2 * D, 2 * D, 2 * D, st);
+        dense(a, D, L.pw1, L.pw1_b, big, rows, D, 2 * D, 2 * D, 2 * D, st, 1.0f, lo_s ? GemmEpi{} : plain_epi());
         PPASR_LAUNCH(k_g_glu, blocks((size_t)rows * D), dim3(256), 0, st, big, g, rows, D);
       }
       if (stride2) {
         // StrideConformerEncoderLayer (efficient_conformer/encoder.py:455-548): depthwise conv with stride 2, the residual
         // through AvgPool1D(2, ceil_mode); everything behind runs on ceil(T / 2) frames with masks / positions [::2]
         const int Ts = (Tp + 1) / 2, Ms = B * Ts;
-        launch_dwconv(g, y, L.dw_w, L.dw_b, L.glu_pad, B, Ts, D, KS, left, lo_s, 2, Tp, st);
+        launch_dwconv(g, y, L.dw_w, L.dw_b, L.glu_pad, B, Ts, D, KS, left, lo_s, 2, Tp, st, pskip(Ts, mul * 2));
         half = true;
         PPASR_LAUNCH(k_g_avgpool2, blocks((size_t)Ms * D), dim3(256), 0, st, x, ctx, B, Tp, Ts, D);
         Tp = Ts;
         M = Ms;
         mul *= 2;
         pstride *= 2;
+        ps = pskip(Tp, mul);
         std::swap(x, ctx);  // (res_epi below reads the new x = the pooled residual)
       } else {
-        launch_dwconv(g, y, L.dw_w, L.dw_b, L.glu_pad, B, Tp, D, KS, left, lo_s, 1, Tp, st);
+        launch_dwconv(g, y, L.dw_w, L.dw_b, L.glu_pad, B, Tp, D, KS, left, lo_s, 1, Tp, st, ps);
       }
       ln(y, y, L.ln_cm_g, L.ln_cm_b, L.cm_eps, o.act, false, M);  // LayerNorm / folded BatchNorm + activation
       dense(y, D, L.pw2, L.pw2_b, x, M, D, D, D, D, st, 1.0f, res_epi(1.0f, true));  // PAD frames of the conv output -> 0, + residual
@@ -678,7 +712,7 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
     enc = a;
   }
   float* lg = logits ? logits : (probs ? probs : r.lg);
-  dense(enc, D, h->gen_head_w, h->gen_head_b, lg, M, D, h->gen_vpad, V, V, st);
+  dense(enc, D, h->gen_head_w, h->gen_head_b, lg, M, D, h->gen_vpad, V, V, st, 1.0f, plain_epi());
   float* pr = probs;
   if (!pr && (frame_argmax || frame_maxprob)) pr = (lg == r.lg) ? lg : r.lg;
   if (pr) {
@@ -690,6 +724,7 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
       launch_frame_argmax(pr, fa, fp, M, V, st);
     }
   }
+  if (skip) launch_zero_pad_rows(probs, logits, frame_argmax, frame_maxprob, lens, B, Tp, mul, V, st);
   HIP_TRY(hipGetLastError());
   return PPASR_OK;
 }
@@ -710,7 +745,7 @@ ppasr_status gen_front(ppasr_model_s* h, const float* feats, int B, int T, float
     PPASR_LAUNCH(k_g_cmvn_pad, blocks((size_t)M * Kp), dim3(256), 0, st, feats, h->front.cmvn_mean, h->front.cmvn_istd, y1, M, F, Kp);
     dense(y1, Kp, h->front.embed_w, h->front.embed_b, x, M, Kp, D, D, D, st);
     PPASR_LAUNCH(k_g_ln, dim3((M + 3) / 4), dim3(256), 0, st, x, x, h->lin_ln_g, h->lin_ln_b, M, D, 1e-12f, (int)PPASR_ACT_RELU,
-                 (const int64_t*)nullptr, Tp, 1, xscale);
+                 (const int64_t*)nullptr, Tp, 1, xscale, PadSkip{});
   } else {
     launch_conv1(feats, h->front, y1, B, T, F, fd.T1, h->F1, st, PadSkip{}, D);
     if (il == 8) {  // Conv2dSubsampling8: three 3x3 / 2 convs, the third one over conv1's output buffer
@@ -788,9 +823,25 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
     e.sb = 1;
     dense(y2, h->F2 * D, h->front.embed_w, h->front.embed_b, xa, M, h->F2 * D, D, D, D, st, sqrtf((float)D), e);
   }
+  // ragged batches (ppasr_set_skip_padding, batched calls): as gen_layers, with the Squeezeformer's slack (capi_squeezeformer.hip:
+  // the time reduction reads full-rate rows 2j - 3 .. 2j + 1, the recovery reduced row t / 2)
+  const bool skip = h->skip_padding && lens && !s;
+  const int rc = causal ? 0 : (KS - 1) / 2;
+  auto pskip = [&](int Tcur, int mul_cur) {
+    PadSkip p;
+    if (skip) {
+      p.lens = lens;
+      p.Tp = Tcur;
+      p.mul = mul_cur;
+      p.slack = mul_cur == 4 ? 2 * (rc + 4) + rc + 8 : rc + 4;
+    }
+    return p;
+  };
+  const PadSkip psF = pskip(Tp, 4), psH = pskip(Tr, 8);
   auto ln = [&](const float* in, float* out, const float* gg, const float* bb, float eps, int act, bool mask, int rows, int Ti,
                 int mul) {
-    PPASR_LAUNCH(k_g_ln, dim3((rows + 3) / 4), dim3(256), 0, st, in, out, gg, bb, rows, D, eps, act, mask ? lens : nullptr, Ti, mul, 1.0f);
+    PPASR_LAUNCH(k_g_ln, dim3((rows + 3) / 4), dim3(256), 0, st, in, out, gg, bb, rows, D, eps, act, mask ? lens : nullptr, Ti, mul, 1.0f,
+                 rows == B * Ti ? (mul == 4 ? psF : psH) : PadSkip{});
   };
   ln(xa, xa, h->preln_g, h->preln_b, 1e-5f, kActNone, false, M, Tp, 4);
   float* x = xa;
@@ -801,7 +852,11 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
       HIP_TRY(hipMemcpyAsync(xs, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
       PPASR_LAUNCH(k_g_sq_reduce_dw, blocks((size_t)B * Tr * D), dim3(256), 0, st, x, a, h->sq_reduce.dw_w, h->sq_reduce.dw_b,
                    h->sq_reduce.ks, lens, B, Tp, Tr, D);
-      dense(a, D, h->sq_reduce.pw, h->sq_reduce.pw_b, xb, B * Tr, D, D, D, D, st);
+      {
+        GemmEpi e;
+        e.ps = psH;
+        dense(a, D, h->sq_reduce.pw, h->sq_reduce.pw_b, xb, B * Tr, D, D, D, D, st, 1.0f, e);
+      }
       x = xb;
       reduced = true;
     }
@@ -809,14 +864,17 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
       PPASR_LAUNCH(k_g_sq_repeat, blocks((size_t)M * D), dim3(256), 0, st, x, a, B, Tp, Tr, D);
       GemmEpi e;
       e.res = xs;  // recover_tensor + time_recover_layer(repeat_interleave(xs, 2))
+      e.ps = psF;
       dense(a, D, h->sq_wrec, h->sq_brec, xa, M, D, D, D, D, st, 1.0f, e);
       x = xa;
       reduced = false;
     }
     const int Ti = reduced ? Tr : Tp, Mi = B * Ti, mul = reduced ? 8 : 4;
+    const PadSkip& ps = reduced ? psH : psF;
     auto res_epi = [&](bool mask) {
       GemmEpi e;
       e.res = x;
+      e.ps = ps;
       if (mask && lens) {
         e.lens = lens;
         e.Tp = Ti;
@@ -827,15 +885,21 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
     auto act_epi = [&]() {
       GemmEpi e;
       e.act = PPASR_ACT_SWISH;
+      e.ps = ps;
+      return e;
+    };
+    auto plain_epi = [&]() {
+      GemmEpi e;
+      e.ps = ps;
       return e;
     };
     // ---- x = LN1(x + MHA(x)) ----
     if (fused_ffn512() && D == kD512)
       PPASR_LAUNCH(k_g_proj512<false>, dim3((Mi + kRows - 1) / kRows), dim3(kThreads), kLdsProj512, st, x, big, 3 * D,
                    (const float*)nullptr, (const float*)nullptr, 1e-5f, (const int64_t*)nullptr, Ti, mul, W.wqkv, W.bqkv,
-                   3 * D / 32 / kWaves, Mi);
+                   3 * D / 32 / kWaves, Mi, ps);
     else
-      dense(x, D, W.wqkv, W.bqkv, big, Mi, D, 3 * D, 3 * D, 3 * D, st);
+      dense(x, D, W.wqkv, W.bqkv, big, Mi, D, 3 * D, 3 * D, 3 * D, st, 1.0f, plain_epi());
     AttnArgs at{big, 3 * D, big + D, 3 * D, big + 2 * D, 3 * D, Ti, Ti, 0, lens, ctx, W.pos_u, W.pos_v, W.ptab, reduced ? 2 : 1,
                 mul, Ti, Ti, 1};
     if (s) {  // keys / values: [cache | chunk] in the layer's device caches
@@ -850,7 +914,7 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
       at.T2 = at.kv_frames = n_cache + Ti;
       at.pos0 = plan->pos0;
     }
-    at.pad_skip = 0;
+    at.pad_skip = skip ? ps.slack + 1 : 0;
     at.dm = D;
     launch_attention(at, B, heads, st);
     dense(ctx, D, W.wo, W.bo, x, Mi, D, D, D, D, st, 1.0f, res_epi(false));
@@ -859,7 +923,7 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
     auto sq_ffn = [&](const f32x4* w1, const float* b1, const f32x4* w2, const float* b2) {
       if (fused_ffn512() && D == kD512) {
         PPASR_LAUNCH(k_g_ffn512, dim3((Mi + kRows - 1) / kRows), dim3(kThreads), kLdsFfn512, st, x, x, (const float*)nullptr,
-                     (const float*)nullptr, w1, b1, w2, b2, 1.0f, (int)PPASR_ACT_SWISH, Mi, H / 256);
+                     (const float*)nullptr, w1, b1, w2, b2, 1.0f, (int)PPASR_ACT_SWISH, Mi, H / 256, ps);
         return;
       }
       dense(x, D, w1, b1, big, Mi, D, H, H, H, st, 1.0f, act_epi());
@@ -873,7 +937,7 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
       const int rows = lo_s + Mi;
       if (fused_ffn512() && D == kD512 && lo_s == 0) {  // ada scale / bias + pad mask + pointwise_conv1 + GLU in one launch
         PPASR_LAUNCH(k_g_proj512<true>, dim3((Mi + kRows - 1) / kRows), dim3(kThreads), kLdsProj512, st, x, g, D, W.cm_scale,
-                     W.cm_bias, -1.0f, lens, Ti, mul, W.pw1_raw, W.pw1_b_raw, 2, Mi);
+                     W.cm_bias, -1.0f, lens, Ti, mul, W.pw1_raw, W.pw1_b_raw, 2, Mi, ps);
       } else {
         ln(x, a_new, W.cm_scale, W.cm_bias, -1.0f, kActNone, true, Mi, Ti, mul);
         if (lo_s) {  // the cache holds the SCALED inputs of the previous chunks; new cache = last lo rows of [cache | chunk]
@@ -881,10 +945,10 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
           HIP_TRY(hipMemcpyAsync(a, hist, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
           HIP_TRY(hipMemcpyAsync(hist, a + (size_t)Mi * D, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
         }
-        dense(a, D, W.pw1_raw, W.pw1_b_raw, big, rows, D, 2 * D, 2 * D, 2 * D, st);
+        dense(a, D, W.pw1_raw, W.pw1_b_raw, big, rows, D, 2 * D, 2 * D, 2 * D, st, 1.0f, lo_s ? GemmEpi{} : plain_epi());
         PPASR_LAUNCH(k_g_glu, blocks((size_t)rows * D), dim3(256), 0, st, big, g, rows, D);
       }
-      launch_dwconv(g, y, W.dw_w, W.dw_b, W.glu_pad, B, Ti, D, KS, left, lo_s, 1, Ti, st);
+      launch_dwconv(g, y, W.dw_w, W.dw_b, W.glu_pad, B, Ti, D, KS, left, lo_s, 1, Ti, st, ps);
       ln(y, y, W.ln_cm_g, W.ln_cm_b, W.cm_eps, (int)PPASR_ACT_SWISH, false, Mi, Ti, mul);
       dense(y, D, W.pw2, W.pw2_b, x, Mi, D, D, D, D, st, 1.0f, res_epi(true));
       ln(x, x, W.ln3_g, W.ln3_b, 1e-5f, kActNone, false, Mi, Ti, mul);
@@ -895,7 +959,11 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
   }
   // ---- ctc_lo -> softmax (no after_norm in Squeezeformer, encoder.py:232-235) ----
   float* lg = logits ? logits : (probs ? probs : ws + wl.lg);
-  dense(x, D, h->gen_head_w, h->gen_head_b, lg, M, D, h->gen_vpad, V, V, st);
+  {
+    GemmEpi e;
+    e.ps = reduced ? PadSkip{} : psF;  // (without a recovery layer the encoder ends at the reduced rate: every row)
+    dense(x, D, h->gen_head_w, h->gen_head_b, lg, M, D, h->gen_vpad, V, V, st, 1.0f, e);
+  }
   float* pr = probs;
   if (!pr && (frame_argmax || frame_maxprob)) pr = (lg == ws + wl.lg) ? lg : ws + wl.lg;
   if (pr) {
@@ -907,6 +975,7 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
       launch_frame_argmax(pr, fa, fp, M, V, st);
     }
   }
+  if (skip && !reduced) launch_zero_pad_rows(probs, logits, frame_argmax, frame_maxprob, lens, B, Tp, 4, V, st);
   HIP_TRY(hipGetLastError());
   return PPASR_OK;
 }

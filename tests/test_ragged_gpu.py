@@ -69,8 +69,47 @@ def _conformer_front(V, input_layer, mul):
     return ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0"), mul
 
 
+def _conformer512(V, streaming, **opts):
+    """output_size 512 / 8 heads (+ constructor options): the general layer route (csrc/capi_generic.hip)"""
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    L = 2
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=21, perturb_norm=True, output_size=512, attention_heads=8,
+                              **{k: v for k, v in opts.items() if k not in ("activation_type", "normalize_before")})
+    conf = dict(output_size=512, attention_heads=8, linear_units=2048, num_blocks=L, cnn_module_kernel=15, **opts)
+    return ConformerModel(80, V, streaming=streaming, encoder_conf=conf, state_dict=sd, device="cuda:0"), 4
+
+
+def _squeezeformer512(V):
+    from ppasr_amd.model_utils.squeezeformer.model import SqueezeformerModel
+    L = 3
+    sd = squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=22, perturb_norm=True, encoder_dim=512, attention_heads=8)
+    conf = dict(encoder_dim=512, output_size=512, attention_heads=8, num_blocks=L, reduce_idx=1, recover_idx=2,
+                feed_forward_expansion_factor=8, cnn_module_kernel=31)
+    return SqueezeformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0"), 4
+
+
+def _efficient512(V, streaming):
+    from ppasr_amd.model_utils.efficient_conformer.model import EfficientConformerModel
+    L = 3
+    sd = efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=23, perturb_norm=True, stride_layer_idx=1,
+                                        group_layer_idx=(0, 1), output_size=512, attention_heads=8)
+    conf = dict(output_size=512, attention_heads=8, linear_units=2048, num_blocks=L, cnn_module_kernel=15,
+                cnn_module_norm="layer_norm",
+                efficient_conf=dict(stride_layer_idx=[1], stride=[2], group_layer_idx=[0, 1], group_size=3,
+                                    stride_kernel=True))
+    return EfficientConformerModel(80, V, streaming=streaming, encoder_conf=conf, state_dict=sd, device="cuda:0"), 8
+
+
 FAMILIES = {
     "conformer": lambda V: _conformer(V, True),
+    # the general layer route (width 512; a post-norm / no-macaron / abs_pos variant; the other two families)
+    "conformer512": lambda V: _conformer512(V, True),
+    "conformer512-noncausal": lambda V: _conformer512(V, False),
+    "conformer512-postnorm-abs": lambda V: _conformer512(V, True, normalize_before=False, macaron_style=False,
+                                                         pos_enc_layer_type="abs_pos", activation_type="relu"),
+    "squeezeformer512": _squeezeformer512,
+    "efficient512": lambda V: _efficient512(V, True),
+    "efficient512-noncausal": lambda V: _efficient512(V, False),
     # the 6x / 8x front ends (input_layer: conv2d6 / conv2d8): the layers skip, the front end computes every row
     "conformer-conv2d6": lambda V: _conformer_front(V, "conv2d6", 6),
     "conformer-conv2d8": lambda V: _conformer_front(V, "conv2d8", 8),
