@@ -177,16 +177,23 @@ def test_width_512_families_chunked(family, seed):
 
 
 def test_ragged_decode_on_a_route_without_the_ragged_mode():
-    """decode_ragged / evaluate(trim_padding) on a general-route model: the library refuses skip_padding there
-    (PPASR_EUNSUPPORTED), the drivers then run the padded rows and trim by frame_lens -- same tokens as the plain padded
-    batch decoded over its valid frames."""
+    """decode_ragged / evaluate(trim_padding) on a model whose route has no ragged mode (input_layer = linear: the library
+    refuses skip_padding there, PPASR_EUNSUPPORTED; round 4 built it for the conv front ends of the general route): the
+    drivers then run the padded rows and trim by frame_lens -- same tokens as the plain padded batch decoded over its valid
+    frames."""
     from ppasr_amd.model_utils.conformer.model import ConformerModel
     from ppasr_amd.parallel import decode_ragged, greedy_ids_decoder, set_skip_padding_if_built
     V, L = 53, 2
-    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=31, perturb_norm=True, output_size=512, attention_heads=8)
-    conf = dict(output_size=512, attention_heads=8, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=31, perturb_norm=True, output_size=512, attention_heads=8,
+                              input_layer="linear")
+    conf = dict(output_size=512, attention_heads=8, linear_units=2048, num_blocks=L, cnn_module_kernel=15, input_layer="linear")
     model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
     assert set_skip_padding_if_built(model, True) is False
+    wide = ConformerModel(80, V, streaming=True, encoder_conf=dict(conf, input_layer="conv2d"), device="cuda:0",
+                          state_dict=conformer_state_dict(vocab_size=V, num_blocks=L, seed=31, perturb_norm=True, output_size=512,
+                                                          attention_heads=8))
+    assert set_skip_padding_if_built(wide, True) is True   # (the general route behind a conv front end has the mode now)
+    wide.set_skip_padding(False)
     lens = np.array([260, 90, 411, 33, 187], np.int64)
     x, _ = synth_features(len(lens), int(lens.max()), lens=lens, seed=32)
     tokens, n, _ = decode_ragged(model, x, lens, greedy_ids_decoder(), mode="merged")
