@@ -48,6 +48,9 @@ namespace ppasr {
 #ifndef PPASR_ATTN_NW192
 #define PPASR_ATTN_NW192 2  // ... of the grouped heads (d_k = 192); cfg4, same box, the 4 launches of a step: 2 waves 0.166 ms, 3: 0.197, 4: 0.186
 #endif
+#ifndef PPASR_ATTN_QB192
+#define PPASR_ATTN_QB192 3  // query blocks per workgroup of the grouped heads (1: the one-block form, two waves)
+#endif
 #ifndef PPASR_ATTN_NT
 #define PPASR_ATTN_NT 1  // 32-key tiles per sub-block of the plain heads
 #endif
@@ -59,15 +62,29 @@ struct AttnT {
   static constexpr int NGK = 2 * DK / 8;       // 8-wide k-groups of the score contraction over K' = [k | p]
   static constexpr int NT = DK == 64 ? PPASR_ATTN_NT : 1;  // 32-key tiles per sub-block (accumulator budget)
   static constexpr int NW = DK == 64 ? PPASR_ATTN_NW : PPASR_ATTN_NW192;  // waves per workgroup = key splits of its query block
-  static constexpr int MAXQ = 1;               // query blocks per workgroup (LDS: one Q' tile)
+  static constexpr int MAXQ = 1;               // (historic: query blocks per wave set)
+  // Query blocks per workgroup.  Plain heads: one, its NW waves split the keys.  Grouped heads (d_k = 192): THREE on eight
+  // waves -- at 222 registers a SIMD holds two waves, and a (query block, 32-key sub-block) unit is 288 MFMAs that keep a
+  // SIMD's matrix pipe busy on their own, so what matters is how the units are dealt to the SIMDs: with one query block
+  // per two-wave workgroup, BASELINE configs[3]'s 83 tokens (three query blocks x three sub-blocks per (utterance, head))
+  // put up to four units on one SIMD of a CU and one on another (41 us per launch, per-phase stamps); one workgroup per
+  // (utterance, head) with waves = (block 0: three key splits, block 1: three, block 2: two) puts 2 / 2 / 3 / 2 units
+  // on the four SIMDs whatever the dispatcher does
+  static constexpr int QB = DK == 64 ? 1 : PPASR_ATTN_QB192;
+  static constexpr int WV = QB == 1 ? NW : 8;  // waves per workgroup
+  static constexpr int NSMAX = QB == 1 ? NW : 3;
+  static __device__ __forceinline__ int wave_qi(int w) { return QB == 1 ? 0 : (w < 3 ? 0 : (w < 6 ? 1 : 2)); }
+  static __device__ __forceinline__ int wave_ks(int w) { return QB == 1 ? w : (w < 6 ? w % 3 : w - 6); }
+  static __device__ __forceinline__ int qb_ns(int qi) { return QB == 1 ? NW : (qi < 2 ? 3 : 2); }  // key splits of block qi
+  static __device__ __forceinline__ int qb_w0(int qi) { return QB == 1 ? 0 : 3 * qi; }             // its first wave
   static constexpr int PQ = DK == 64 ? PPASR_ATTN_PQ : 2;  // V k-groups in flight
   static constexpr int QLD = 2 * DK + 4;       // Q' row stride (floats)
   static constexpr int OLD = DK + 4;           // partial O row stride
   static constexpr int SB = 32 * NT;           // keys per sub-block
   // a wave parks its partial O^T in slot `wave`: its own Q' tile where every wave has one (NS == 1 then needs no barrier)
-  static constexpr int PSTR = MAXQ == NW ? 32 * QLD : 32 * OLD;
-  static constexpr int TILE_FLOATS = (MAXQ * 32 * QLD > NW * PSTR) ? MAXQ * 32 * QLD : NW * PSTR;
-  static constexpr int LDS_FLOATS = TILE_FLOATS + NW * 64;
+  static constexpr int PSTR = 32 * OLD;
+  static constexpr int TILE_FLOATS = (QB * 32 * QLD > NSMAX * PSTR) ? QB * 32 * QLD : NSMAX * PSTR;
+  static constexpr int LDS_FLOATS = TILE_FLOATS + WV * 64;
 };
 
 __device__ __forceinline__ f32x2 load_b64(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
@@ -77,19 +94,19 @@ __device__ __forceinline__ f32x2 load_b64(__amdgpu_buffer_rsrc_t rs, int voff, i
 // (second launch bound = waves per SIMD the register allocation must leave room for: 226 / 224 registers, so that two
 //  workgroups of plain heads / three of grouped heads share a CU)
 template <int DK>
-__global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) void k_attention_t(AttnArgs a, int B, int H) {
+__global__ __launch_bounds__(64 * AttnT<DK>::WV, DK == 64 ? PPASR_ATTN_OCC : 2) void k_attention_t(AttnArgs a, int B, int H) {
   using C = AttnT<DK>;
-  constexpr int G = C::G, NT = C::NT, NW = C::NW, NC2 = C::NC2, NGK = C::NGK, PQ = C::PQ;
+  constexpr int G = C::G, NT = C::NT, NC2 = C::NC2, NGK = C::NGK, PQ = C::PQ, QB = C::QB, WV = C::WV;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Qs = smem;                       // MAXQ tiles [32][QLD] Q' = [q+u | q+v]; after the key loop: NW partial O tiles [32][OLD]
-  float* Stat = smem + C::TILE_FLOATS;    // [NW][2][32]: running max, running sum of each wave's key range
+  float* Qs = smem;                       // QB tiles [32][QLD] Q' = [q+u | q+v]; after the key loop: partial O tiles [32][OLD]
+  float* Stat = smem + C::TILE_FLOATS;    // [WV][2][32]: running max, running sum of each wave's key range
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const int hh = lane >> 5, l31 = lane & 31;
   // XCD-aware block -> (utterance, head, query block) map.  Workgroups go round-robin to the 8 XCDs (linear id % 8), each
   // with its own L2: all query blocks of the pair (b, h) run on XCD (b * H + h) % 8, so that pair's key / value / position
   // columns are fetched into ONE L2 instead of eight, and consecutive utterances (RaggedPlan sorts them by length)
   // alternate between the XCDs' pair lists, which keeps a ragged batch balanced.
-  const int nq = (a.T1 + 31) / 32;
+  const int nq = ((a.T1 + 31) / 32 + QB - 1) / QB;  // workgroups per (utterance, head): groups of QB query blocks
   const int slot = blockIdx.x >> 3;
   // (boustrophedon over the groups of 8 pairs: with utterances sorted by length, XCD x gets pairs x, 15 - x, 16 + x, ...
   //  instead of always the longer half of every group)
@@ -114,10 +131,11 @@ __global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) 
     ptab = a.ptab + (size_t)d.pos0 * dm;
   }
   float* __restrict__ ctx = a.ctx + (size_t)b * F1 * dm;
-  static_assert(C::MAXQ == 1, "one query block per workgroup: its NW waves split the keys");
-  constexpr int NS = NW;
-  const int ks = wave;                    // this wave's key split: sub-blocks ks, ks + NS, ks + 2 NS, ...
-  const int q0 = li * 32;                 // the workgroup's query block
+  const int my_qi = C::wave_qi(wave);     // this wave's query block among the workgroup's QB
+  const int ks = C::wave_ks(wave);        // its key split: sub-blocks ks, ks + NS, ks + 2 NS, ...
+  const int NS = C::qb_ns(my_qi);         // key splits of that query block
+  const int q0g = li * QB * 32;           // the workgroup's first query token
+  const int q0 = q0g + my_qi * 32;        // this wave's query block
   auto split = [&](int flat, int& frame, int& feat) {
     frame = flat >> dm_shift;
     feat = flat & (dm - 1);
@@ -126,19 +144,19 @@ __global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) 
   // rows and the first K' burst are then one memory round trip instead of three dependent ones (the launches of a ragged
   // batch's reduced layers are a handful of sub-blocks per wave: their prologue was as long as their key loop).
   // ---- Q' = [q + pos_bias_u | q + pos_bias_v] of the block's 32 query tokens -> LDS ----
-  float* Qt = Qs;
-  for (int idx = tid; idx < 32 * (DK / 4); idx += 64 * NW) {
-    const int row = idx / (DK / 4), f4 = idx - row * (DK / 4);
+  float* Qt = Qs + my_qi * 32 * C::QLD;
+  for (int idx = tid; idx < QB * 32 * (DK / 4); idx += 64 * WV) {
+    const int row = idx / (DK / 4), f4 = idx - row * (DK / 4);  // row: query token q0g + row (tile row / 32)
     f32x4 q = {0.f, 0.f, 0.f, 0.f};
-    if (q0 + row < T1) {
-      int frame = q0 + row, feat = h * DK + 4 * f4;
-      if (G != 1) split((q0 + row) * (G * dm) + h * DK + 4 * f4, frame, feat);
+    if (q0g + row < T1) {
+      int frame = q0g + row, feat = h * DK + 4 * f4;
+      if (G != 1) split((q0g + row) * (G * dm) + h * DK + 4 * f4, frame, feat);
       if (frame < F1) q = *reinterpret_cast<const f32x4*>(qb + (size_t)frame * a.q_stride + feat);
     }
     const f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + h * DK + 4 * f4);
     const f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + h * DK + 4 * f4);
-    *reinterpret_cast<f32x4*>(Qt + row * C::QLD + 4 * f4) = q + u;
-    *reinterpret_cast<f32x4*>(Qt + row * C::QLD + DK + 4 * f4) = q + v;
+    *reinterpret_cast<f32x4*>(Qs + row * C::QLD + 4 * f4) = q + u;
+    *reinterpret_cast<f32x4*>(Qs + row * C::QLD + DK + 4 * f4) = q + v;
   }
 
   // ---- operand resources: one per 64-feature chunk (a chunk never straddles a frame of the grouped re-cut).  Chunk c3
@@ -194,12 +212,13 @@ __global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) 
     const int need_frames = (int)min((int64_t)F1, (lb + fmul - 1) / fmul + (a.pad_skip - 1));
     q_need = min(T1, (need_frames + G - 1) / G);
   }
-  if (q0 >= q_need) return;  // (uniform: before any barrier)
+  if (q0g >= q_need) return;  // (workgroup-uniform: before any barrier)
+  const bool active = q0 < q_need;  // (QB > 1: a wave whose query block is not needed only takes part in the barriers)
   // keys >= kv_end are PAD (mask_mul * j >= len) or beyond the key tokens
   const int kv_end = (int)min((int64_t)T2, max((int64_t)0, (len_b + a.mask_mul - 1) / a.mask_mul));
   const int nfr = min(G * kv_end, F2);  // frames behind the valid tokens: the VALUES are bounded by them (p = 0 times an
                                         // uninitialised row of a ragged batch would be NaN; out of range reads 0)
-  const int n_sb = (kv_end + C::SB - 1) / C::SB;
+  const int n_sb = active ? (kv_end + C::SB - 1) / C::SB : 0;
 #pragma unroll
   for (int c3 = 0; c3 < NC2; ++c3) {
     const long long rows = (long long)nfr - fo_c[c3] - 1;
@@ -332,46 +351,53 @@ __global__ __launch_bounds__(64 * AttnT<DK>::NW, DK == 64 ? PPASR_ATTN_OCC : 2) 
     }
   }
 
-  // ---- merge the key splits: O = sum_s O_s e^{m_s - m} / sum_s l_s e^{m_s - m}; rows stored coalesced.  Wave w parks its
-  // partial O^T in tile slot w (over the Q' tile, which every wave is done with) ----
-  __syncthreads();  // every wave is done with the Q' tile
-  {
-    float* Pt = Qs + wave * C::PSTR + l31 * C::OLD;
+  // ---- merge the key splits: O = sum_s O_s e^{m_s - m} / sum_s l_s e^{m_s - m}; rows stored coalesced.  One round per
+  // query block of the workgroup: its waves park their partial O^T in tile slots 0 .. NS - 1 (over the Q' tiles, which every
+  // wave is done with), then all threads merge and store that block's rows ----
+  __syncthreads();  // every wave is done with the Q' tiles
 #pragma unroll
-    for (int c3 = 0; c3 < NC2; ++c3)
+  for (int qbi = 0; qbi < QB; ++qbi) {
+    if (my_qi == qbi) {
+      float* Pt = Qs + ks * C::PSTR + l31 * C::OLD;
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const f32x16 &o0 = acc_o[2 * c3], &o1 = acc_o[2 * c3 + 1];
-        float* p = Pt + 64 * c3 + 16 * q4 + 8 * hh;  // columns 64 c3 + 2 (8 q4 + 4hh + e) + {0, 1}, e = 0..3
-        *reinterpret_cast<f32x4*>(p) = f32x4{o0[4 * q4], o1[4 * q4], o0[4 * q4 + 1], o1[4 * q4 + 1]};
-        *reinterpret_cast<f32x4*>(p + 4) = f32x4{o0[4 * q4 + 2], o1[4 * q4 + 2], o0[4 * q4 + 3], o1[4 * q4 + 3]};
+      for (int c3 = 0; c3 < NC2; ++c3)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x16 &o0 = acc_o[2 * c3], &o1 = acc_o[2 * c3 + 1];
+          float* p = Pt + 64 * c3 + 16 * q4 + 8 * hh;  // columns 64 c3 + 2 (8 q4 + 4hh + e) + {0, 1}, e = 0..3
+          *reinterpret_cast<f32x4*>(p) = f32x4{o0[4 * q4], o1[4 * q4], o0[4 * q4 + 1], o1[4 * q4 + 1]};
+          *reinterpret_cast<f32x4*>(p + 4) = f32x4{o0[4 * q4 + 2], o1[4 * q4 + 2], o0[4 * q4 + 3], o1[4 * q4 + 3]};
+        }
+      if (hh == 0) {
+        Stat[wave * 64 + l31] = m_run;
+        Stat[wave * 64 + 32 + l31] = l_run;
       }
-    if (hh == 0) {
-      Stat[wave * 64 + l31] = m_run;
-      Stat[wave * 64 + 32 + l31] = l_run;
     }
-  }
-  __syncthreads();
-  for (int idx = tid; idx < 32 * (DK / 4); idx += 64 * NS) {
-    const int row = idx / (DK / 4), f4 = idx - row * (DK / 4);
-    constexpr int w0 = 0;
-    float m = -INFINITY;
-    for (int s2 = 0; s2 < NS; ++s2) m = fmaxf(m, Stat[(w0 + s2) * 64 + row]);
-    float l = 0.f;
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    for (int s2 = 0; s2 < NS; ++s2) {
-      const float mw = Stat[(w0 + s2) * 64 + row];
-      const float fw = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mw - m) * kScale);
-      l += Stat[(w0 + s2) * 64 + 32 + row] * fw;
-      o += *reinterpret_cast<const f32x4*>(Qs + (w0 + s2) * C::PSTR + row * C::OLD + 4 * f4) * fw;
+    __syncthreads();
+    const int nsq = C::qb_ns(qbi), w0 = C::qb_w0(qbi), q0r = q0g + 32 * qbi;
+    if (q0r < q_need) {
+      for (int idx = tid; idx < 32 * (DK / 4); idx += 64 * WV) {
+        const int row = idx / (DK / 4), f4 = idx - row * (DK / 4);
+        float m = -INFINITY;
+        for (int s2 = 0; s2 < nsq; ++s2) m = fmaxf(m, Stat[(w0 + s2) * 64 + row]);
+        float l = 0.f;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int s2 = 0; s2 < nsq; ++s2) {
+          const float mw = Stat[(w0 + s2) * 64 + row];
+          const float fw = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mw - m) * kScale);
+          l += Stat[(w0 + s2) * 64 + 32 + row] * fw;
+          o += *reinterpret_cast<const f32x4*>(Qs + s2 * C::PSTR + row * C::OLD + 4 * f4) * fw;
+        }
+        const float inv = (l > 0.f) ? 1.0f / l : 0.f;  // fully masked row -> 0 (attention.py:118)
+        o *= inv;
+        if (q0r + row < T1) {
+          int frame = q0r + row, feat = h * DK + 4 * f4;
+          if (G != 1) split((q0r + row) * (G * dm) + h * DK + 4 * f4, frame, feat);
+          if (frame < F1) *reinterpret_cast<f32x4*>(ctx + (size_t)frame * dm + feat) = o;  // x[:, :T - padding_q] (attention.py:124-125)
+        }
+      }
     }
-    const float inv = (l > 0.f) ? 1.0f / l : 0.f;  // fully masked row -> 0 (attention.py:118)
-    o *= inv;
-    if (q0 + row < T1) {
-      int frame = q0 + row, feat = h * DK + 4 * f4;
-      if (G != 1) split((q0 + row) * (G * dm) + h * DK + 4 * f4, frame, feat);
-      if (frame < F1) *reinterpret_cast<f32x4*>(ctx + (size_t)frame * dm + feat) = o;  // x[:, :T - padding_q] (attention.py:124-125)
-    }
+    if (qbi + 1 < QB) __syncthreads();  // the slots are reused by the next query block's waves
   }
 }
 
@@ -387,13 +413,14 @@ bool launch_attention_t(const AttnArgs& a, int B, int H, hipStream_t st) {
   if (a.group != 1 && a.group != 3) return false;
   if (a.group == 3 && (a.dm & (a.dm - 1)) != 0) return false;
   if ((a.q_stride | a.k_stride | a.v_stride | a.dm) & 3) return false;
-  const int nq = (a.T1 + 31) / 32;
+  const int nqb = (a.T1 + 31) / 32;
   const int pairs8 = (B * H + 7) / 8;
-  const dim3 grid(nq * pairs8 * 8);
-  if (a.group == 3)
-    PPASR_LAUNCH(k_attention_t<192>, grid, dim3(64 * AttnT<192>::NW), kLdsAttnT192, st, a, B, H);
-  else
-    PPASR_LAUNCH(k_attention_t<64>, grid, dim3(64 * AttnT<64>::NW), kLdsAttnT64, st, a, B, H);
+  if (a.group == 3) {
+    const int nq = (nqb + AttnT<192>::QB - 1) / AttnT<192>::QB;  // workgroups per (utterance, head)
+    PPASR_LAUNCH(k_attention_t<192>, dim3(nq * pairs8 * 8), dim3(64 * AttnT<192>::WV), kLdsAttnT192, st, a, B, H);
+  } else {
+    PPASR_LAUNCH(k_attention_t<64>, dim3(nqb * pairs8 * 8), dim3(64 * AttnT<64>::WV), kLdsAttnT64, st, a, B, H);
+  }
   return true;
 }
 
