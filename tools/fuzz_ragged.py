@@ -18,7 +18,7 @@ for family, make in t.FAMILIES.items():
     model, mul = make(211)
     for case in range(25):
         B = int(rng.integers(1, 12))
-        T = int(rng.integers(7, 1600))
+        T = int(rng.integers(16, 1600))  # (>= the 8x front end's shortest utterance)
         lens = [int(v) for v in rng.integers(1, T + 1, size=B)]
         if rng.random() < 0.7:
             lens[int(rng.integers(0, B))] = T
