@@ -104,6 +104,12 @@ def class_of(name):
         return f"k_conv_ffn<{a[1]}>+next" if a[-1] in ("true", "1") else f"k_conv_ffn<{a[1]}>"
     if base in ("k_ffn_qkv_t", "k_out_glu_t"):
         return base[:-2]
+    # the opt-in fp16 x3 instantiations (ppasr_set_gemm_mode, csrc/h3.h): k_conv_ffn_h3<KS, NEXT>, k_ffn_qkv_h3
+    if base == "k_conv_ffn_h3":
+        a = [t.strip() for t in targs.strip("<>").split(",")]
+        return f"k_conv_ffn<{a[0]}>+next" if a[-1] in ("true", "1") else f"k_conv_ffn<{a[0]}>"
+    if base == "k_ffn_qkv_h3":
+        return "k_ffn_qkv"
     if base == "k_conv_ffn":
         a = [t.strip() for t in targs.strip("<>").split(",")]
         return f"k_conv_ffn<{a[0]}>+next" if a[-1] in ("true", "1") else f"k_conv_ffn<{a[0]}>"
@@ -879,6 +885,43 @@ def main():
     if world > 1:
         dist.barrier()
 
+    # cfg2 / cfg3: the same steps once more with the feed-forward GEMMs on the opt-in fp16 x3 route (ppasr_set_gemm_mode,
+    # csrc/h3.h).  NOT the headline: `value` above is the default fp32-MFMA mode; this figure goes to config.f16x3 together
+    # with whether the greedy ids of the batch are the default mode's.  Every rank runs it (a step ends in the all-gather).
+    f16x3 = None
+    if not dry and isinstance(w, FormerGreedy) and args.config == "cfg2":
+        ref_ids = [t.clone() for t in w.model.encode_greedy(w.feats, w.lens)]
+        try:
+            w.model.set_gemm_mode("f16x3")
+            n_h = max(5, min(args.steps, 100))
+            for _ in range(3):
+                w.step()
+            sync()
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(n_h):
+                w.step()
+            sync()
+            if world > 1:
+                dist.barrier()
+            el = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([el], dtype=torch.float64, device=red_device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            got = w.model.encode_greedy(w.feats, w.lens)
+            same = all(bool(torch.equal(a, b)) for a, b in zip(ref_ids[:2], got[:2]))
+            f16x3 = {"steps": n_h, "ms_per_step": round(el / n_h * 1e3, 3), "value": round(audio_s_per_step / (el / n_h), 1),
+                     "unit": "audio-s/s", "greedy_ids_equal_default_mode": same,
+                     "note": "opt-in mode, not the headline: feed-forward GEMMs of the layer kernels as three fp16 MFMAs per "
+                             "16-wide k step on two-piece operands (22 significant bits, exact products, fp32 accumulation; "
+                             "DESIGN.md 9.8); everything else unchanged"}
+        except Exception as e:  # (a build without the mode: report, do not fail the headline)
+            f16x3 = {"error": str(e)[:200]}
+        finally:
+            w.model.set_gemm_mode("f32")
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         cpu = w.cpu_baseline()
@@ -896,7 +939,7 @@ def main():
             "config": {"workload": w.desc, "baseline_config": cfg_name,
                        "global_batch": getattr(w, "n_global", None) or world * args.batch, "frames": args.frames,
                        "decoder": w.decoder, "parallelism": f"utterance-dp{world}",
-                       "pipelined": bool(w.pipelined), "serial": serial,
+                       "pipelined": bool(w.pipelined), "serial": serial, "f16x3": f16x3,
                        "pipelined_note": ("the beam search of step i runs on a second HIP stream and overlaps the encoder of step "
                                           "i+1; all K steps are complete when the timed region ends") if w.pipelined else None},
             "median_ms_per_step": None if median_ms is None else round(median_ms, 3),

@@ -26,6 +26,8 @@ N_KERNEL_CLASSES = 10
 # ppasr_model_desc::options (include/ppasr_hip.h)
 PPASR_OPT_POST_NORM, PPASR_OPT_CONCAT_AFTER, PPASR_OPT_NO_MACARON, PPASR_OPT_NO_CNN, PPASR_OPT_ACT_SHIFT = 4, 8, 16, 32, 8
 PPASR_OPT_SQ_NO_ADAPTIVE_SCALE = 4096
+PPASR_GEMM_F32 = 0
+PPASR_GEMM_F16X3 = 1
 KPROF_NAME_LEN = 160
 
 
@@ -61,6 +63,7 @@ SYMBOLS = [
     ("ppasr_set_lengths_hint", ctypes.c_int, [_vp, _vp, ctypes.c_int]),
     ("ppasr_set_ffn_split", ctypes.c_int, [_vp, ctypes.c_int]),
     ("ppasr_set_front_fused", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("ppasr_set_gemm_mode", ctypes.c_int, [_vp, ctypes.c_int]),
     ("ppasr_edit_distance", ctypes.c_longlong, [_vp, ctypes.c_int, _vp, ctypes.c_int]),
     ("ppasr_ctc_beam_state_bytes", ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     ("ppasr_ctc_beam_search", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

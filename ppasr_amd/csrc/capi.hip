@@ -566,6 +566,39 @@ ppasr_status ppasr_set_front_fused(ppasr_handle h, int mode) {
   return PPASR_OK;
 }
 
+ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
+  if (!h) return fail(PPASR_EINVAL, "null handle");
+  if (mode != PPASR_GEMM_F32 && mode != PPASR_GEMM_F16X3) return fail(PPASR_EINVAL, "gemm mode: PPASR_GEMM_F32 or PPASR_GEMM_F16X3");
+  if (mode == PPASR_GEMM_F16X3) {
+    bool ok = h->desc.model_type == PPASR_MODEL_CONFORMER && !h->generic && !h->layers.empty();
+    for (size_t i = 0; ok && i < h->layers.size(); ++i)
+      ok = conv_ffn_h3_supported(h->layer_ks[i]) && h->layer_group[i] == 1 && h->layers[i].ffm_w1 != nullptr;
+    if (!ok)
+      return fail(PPASR_EUNSUPPORTED, "fp16 x3 GEMMs: built for plain Conformer handles on the fused 256-wide route "
+                                      "(macaron layers, cnn_module_kernel 15)");
+    if (h->layers_h3.empty()) {
+      const int d = h->desc.output_size, H = h->desc.linear_units;
+      std::vector<LayerW> view = h->layers;
+      for (LayerW& L : view) {
+        const f32x4** w[4] = {&L.ffm_w1, &L.ffm_w2, &L.ff_w1, &L.ff_w2};
+        for (int j = 0; j < 4; ++j) {
+          void* dst = nullptr;
+          HIP_TRY(hipMalloc(&dst, (size_t)d * H * sizeof(float)));
+          h->allocs.push_back(dst);
+          // W1 [d][H]: H / 32 column tiles of d / 8 k-groups; W2 [H][d]: d / 32 tiles of H / 8 k-groups
+          launch_repack_h3(*w[j], static_cast<f32x4*>(dst), (j & 1) ? d / 32 : H / 32, (j & 1) ? H / 8 : d / 8, nullptr);
+          *w[j] = static_cast<const f32x4*>(dst);
+        }
+      }
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipDeviceSynchronize());
+      h->layers_h3 = std::move(view);
+    }
+  }
+  h->gemm_mode = mode;
+  return PPASR_OK;
+}
+
 ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable) {
   if (!h) return fail(PPASR_EINVAL, "null handle");
   // the ragged mode is built into the fused 256-column kernels behind the 4x front end; other handles would silently
@@ -722,6 +755,9 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     // full grid: the same 32-row blocks on 16 waves (k_*_t<kW16>: drop-in for k_ffn_qkv / k_out_glu / k_conv_ffn)
     const bool w16 = rows == kW16 && S == 1;
     const PadSkip psb = S == 1 ? with_table(ps, Ti, r16 ? 16 : 32) : ps;  // (for the kernels of this layer's block size)
+    // feed-forward GEMMs on the fp16 x3 route (ppasr_set_gemm_mode): the 8-wave 32-row kernels only
+    const bool h3 = h->gemm_mode == PPASR_GEMM_F16X3 && !r16 && !w16 && S == 1 && !(eff && i == h->desc.stride_layer_idx);
+    const LayerW& Lk = h3 ? h->layers_h3[i] : L;
     float* partial = y1;
     float* x3 = ctx;
     if (!s1_done) {
@@ -736,7 +772,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       } else if (w16) {
         timed(3, [&] { launch_ffn_qkv_w16(xa, xb, qkv, L, Mi, n_chunks, st, psb, fuse_attn ? vt_out : VtOut{}); });
       } else {
-        timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, L, Mi, n_chunks, st, psb, fuse_attn ? vt_out : VtOut{}); });
+        timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, Lk, Mi, n_chunks, st, psb, fuse_attn ? vt_out : VtOut{}, h3); });
       }
     }
     s1_done = false;
@@ -778,7 +814,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       });
     } else {
       // fuse the next layer's S1 into this launch (it writes xb / qkv, which this layer no longer reads)
-      const LayerW* next = (i + 1 < h->desc.num_blocks) ? &h->layers[i + 1] : nullptr;
+      const LayerW* next = (i + 1 < h->desc.num_blocks) ? (h3 ? &h->layers_h3[i + 1] : &h->layers[i + 1]) : nullptr;
       timed(next ? 8 : 6, [&] {
         // with the next layer's S1 fused in, the layer output itself is only read by the debug taps: skip its store
         if (r16)
@@ -788,8 +824,8 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
           launch_conv_ffn_w16(g, xc, next ? nullptr : xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul, next, xb, qkv, st,
                               h->desc.causal != 0, psb, (next && fusable(i + 1)) ? vt_out : VtOut{});
         else
-          launch_conv_ffn(g, nullptr, xc, (next && !h->taps) ? nullptr : xa, L, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul,
-                          next, xb, qkv, st, h->desc.causal != 0, psb, (next && fusable(i + 1)) ? vt_out : VtOut{});
+          launch_conv_ffn(g, nullptr, xc, (next && !h->taps) ? nullptr : xa, Lk, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul,
+                          next, xb, qkv, st, h->desc.causal != 0, psb, (next && fusable(i + 1)) ? vt_out : VtOut{}, h3);
       });
       s1_done = next != nullptr;
     }

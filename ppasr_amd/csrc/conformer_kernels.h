@@ -152,8 +152,12 @@ void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, fl
                   hipStream_t st, const PadSkip& ps = PadSkip{}, int k_slices = 1, float* part = nullptr);
 void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, float* out, int M, int K, int n_cols_padded,
                   int ldc, int n_valid, hipStream_t st, float scale = 1.0f, float* part = nullptr, size_t part_floats = 0);  // out = (a W + bias) * scale
+// h3: the feed-forward modules on the fp16 x3 route (csrc/h3.h); w (and *next) must then be the layers' h3 views
 void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
-                    const PadSkip& ps = PadSkip{}, VtOut vt = VtOut{});
+                    const PadSkip& ps = PadSkip{}, VtOut vt = VtOut{}, bool h3 = false);
+// fp32 fragment-packed weight (pack_b: n_tiles x G k-groups x 1 KiB) -> the fp16 x3 packing of csrc/h3.h, same size
+void launch_repack_h3(const f32x4* src, f32x4* dst, int n_tiles, int G, hipStream_t st);
+inline bool conv_ffn_h3_supported(int ksize) { return ksize == 15; }
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
                     const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps = PadSkip{},
@@ -162,7 +166,7 @@ void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, floa
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                      const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,
                      float* x1_next, float* qkv_next, hipStream_t st, bool causal = true, const PadSkip& ps = PadSkip{},
-                     VtOut vt_next = VtOut{});
+                     VtOut vt_next = VtOut{}, bool h3 = false);
 // ---- split route for under-filled grids (see conformer_kernels.hip): the layer tail cut at its FFNs, each FFN's hidden
 // dimension split over S (1, 2, 4 or 8; a divisor of n_chunks) workgroups per row block ----
 void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float* x3, const LayerW& w, const int64_t* lens,

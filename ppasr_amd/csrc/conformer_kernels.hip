@@ -7,6 +7,7 @@
 #include "conformer_kernels.h"
 #include "launch.h"
 #include "phases.h"
+#include "h3.h"
 
 #include <math.h>
 
@@ -474,6 +475,8 @@ struct QkvStoreSide {
 
 // Body of S1 on LDS-resident rows (bufX = layer input): FFN_macaron, residual, LN_mha, QKV.
 // `ring` must already stream w.ffm_w1 (tile `wave`).
+// H3: the feed-forward module on the fp16 x3 route (h3.h; w.ffm_w1 / w.ffm_w2 are then the re-packed weights)
+template <bool H3 = false>
 __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bufH, float* __restrict__ x1,
                                              float* __restrict__ qkv, const LayerW& w, int r0, int valid, int n_chunks,
                                              BRing<1>& ring, VtOut vt = VtOut{}) {
@@ -484,7 +487,8 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
   f32x16 acc2[1][1];
   acc_zero(acc2);
   const f32x4* wq = w.wqkv + (size_t)wave * kTs256;
-  ffn_phase<true>(bufA, bufH, w.ffm_w1, w.ffm_b1, w.ffm_w2, n_chunks, wq, ring, acc2);
+  if constexpr (H3) ffn_phase_h3(bufA, w.ffm_w1, w.ffm_b1, w.ffm_w2, n_chunks, wq, ring, acc2);
+  else ffn_phase<true>(bufA, bufH, w.ffm_w1, w.ffm_b1, w.ffm_w2, n_chunks, wq, ring, acc2);
   PPASR_TS(9);
   residual_epilogue_t(bufX, acc2, w.ffm_b2, 0.5f);
   __syncthreads();
@@ -560,9 +564,57 @@ __global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ 
   rb_load_rows(bufX, kLda, x_in + (size_t)r0 * kD, kRows, valid);
   ffn_qkv_body(bufX, bufA, bufH, x1, qkv, w, r0, valid, n_chunks, ring, vt);
 }
+// fp32 fragment packing -> fp16 x3 packing (h3.h): thread = (tile, 16-wide k step, lane); its 8 weights k = 16 ks + 8 (l >> 5)
+// + e of column 32 tile + (l & 31) sit in k-group 2 ks + (l >> 5) of the source, lanes (l & 31) and (l & 31) + 32
+__global__ __launch_bounds__(256) void k_repack_h3(const float* __restrict__ src, _Float16* __restrict__ dst, int n_tiles, int G) {
+  const int KS = G >> 1;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)n_tiles * KS * 64) return;
+  const int l = (int)(t & 63), ks = (int)((t >> 6) % KS), nt = (int)((t >> 6) / KS);
+  const float* g = src + ((size_t)nt * G + 2 * ks + (l >> 5)) * 256;
+  f16x8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = g[((l & 31) + 32 * (e >> 2)) * 4 + (e & 3)] * kH3Sw;
+    hi[e] = (_Float16)v;
+    lo[e] = (_Float16)(v - (float)hi[e]);
+  }
+  _Float16* d = dst + (((size_t)nt * KS + ks) * 2 * 64 + l) * 8;
+  *reinterpret_cast<f16x8*>(d) = hi;
+  *reinterpret_cast<f16x8*>(d + 64 * 8) = lo;
+}
+void launch_repack_h3(const f32x4* src, f32x4* dst, int n_tiles, int G, hipStream_t st) {
+  const long long n = (long long)n_tiles * (G >> 1) * 64;
+  PPASR_LAUNCH(k_repack_h3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(src),
+               reinterpret_cast<_Float16*>(dst), n_tiles, G);
+}
+
+// the same with the feed-forward module on the fp16 x3 route (ppasr_set_gemm_mode; w: the layer's h3 view)
+__global__ __launch_bounds__(kThreads) void k_ffn_qkv_h3(const float* __restrict__ x_in, float* __restrict__ x1,
+                                                         float* __restrict__ qkv, LayerW w, int M, int n_chunks, PadSkip ps,
+                                                         VtOut vt) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int blk = pad_block_of(ps, kRows, M);
+  if (blk < 0) return;
+  float* bufX = smem;
+  float* bufA = bufX + kRows * kLda;
+  float* bufH = bufA + kRows * kLda;
+  const int wave = wave_id();
+  const int r0 = blk * kRows;
+  const int valid = min(kRows, M - r0);
+  BRing<1> ring;
+  ring_prime(ring, w.ffm_w1 + (size_t)wave * kTs256, 0);
+  rb_load_rows(bufX, kLda, x_in + (size_t)r0 * kD, kRows, valid);
+  ffn_qkv_body<true>(bufX, bufA, bufH, x1, qkv, w, r0, valid, n_chunks, ring, vt);
+}
 constexpr size_t kLdsFfnQkv = 4 * kRows * kLda * sizeof(float);
 void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
-                    const PadSkip& ps, VtOut vt) {
+                    const PadSkip& ps, VtOut vt, bool h3) {
+  if (h3) {
+    PPASR_LAUNCH(k_ffn_qkv_h3, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsFfnQkv + kH3ExtraLds, st, x_in, x1, qkv, w,
+                 M, n_chunks, ps, vt);
+    return;
+  }
   PPASR_LAUNCH(k_ffn_qkv, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsFfnQkv, st, x_in, x1, qkv, w, M,
                      n_chunks, ps, vt);
 }
@@ -1612,12 +1664,14 @@ void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStrea
 // -------------------------------------------------------------------------------------
 // NEXT: the following layer's S1 (FFN_macaron + QKV, encoder.py:380-391) runs in the same launch on the rows that
 // are already LDS-resident (one launch, one store/load of the residual stream and one pipeline fill saved per layer).
-template <int KS, bool STREAM, bool NEXT>
-__global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__ g, const float* __restrict__ g_hist,
-                                                       const float* __restrict__ x2, float* __restrict__ x_out, LayerW w,
-                                                       const int64_t* __restrict__ lens, int M, int Tp, int n_chunks,
-                                                       int mask_mul, LayerW wn, float* __restrict__ x1_next,
-                                                       float* __restrict__ qkv_next, int left_ctx, PadSkip ps, VtOut vt_next) {
+// H3: both feed-forward modules (this layer's, the next layer's macaron one) on the fp16 x3 route (h3.h; w / wn are then
+// the layers' h3 views: their FFN weight pointers are the re-packed arrays)
+template <int KS, bool STREAM, bool NEXT, bool H3>
+__device__ __forceinline__ void conv_ffn_body(const float* __restrict__ g, const float* __restrict__ g_hist,
+                                              const float* __restrict__ x2, float* __restrict__ x_out, const LayerW& w,
+                                              const int64_t* __restrict__ lens, int M, int Tp, int n_chunks, int mask_mul,
+                                              const LayerW& wn, float* __restrict__ x1_next, float* __restrict__ qkv_next,
+                                              int left_ctx, const PadSkip& ps, VtOut vt_next) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int blk = pad_block_of(ps, kRows, M);  // (ragged batches: PadSkip::tab or the padded grid)
   if (blk < 0) return;
@@ -1701,8 +1755,11 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   PPASR_TS(4);
   f32x16 acc2[1][1];
   acc_zero(acc2);
-  ffn_phase<true>(bufA, bufH, w.ff_w1, w.ff_b1, w.ff_w2, n_chunks, NEXT ? wn.ffm_w1 + (size_t)wave * kTs256 : nullptr,
-                  ring, acc2);
+  if constexpr (H3)
+    ffn_phase_h3(bufA, w.ff_w1, w.ff_b1, w.ff_w2, n_chunks, NEXT ? wn.ffm_w1 + (size_t)wave * kTs256 : nullptr, ring, acc2);
+  else
+    ffn_phase<true>(bufA, bufH, w.ff_w1, w.ff_b1, w.ff_w2, n_chunks, NEXT ? wn.ffm_w1 + (size_t)wave * kTs256 : nullptr,
+                    ring, acc2);
   PPASR_TS(5);
   residual_epilogue_t(bufX, acc2, w.ff_b2, 0.5f);
   __syncthreads();
@@ -1711,17 +1768,44 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__
   // rb_layernorm and rb_store_rows use the same wave->row mapping: no barrier needed
   if (x_out) rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);  // (nullptr: nobody reads it, see capi.hip)
   PPASR_TS(7);
-  if (NEXT) ffn_qkv_body(bufX, bufA, bufH, x1_next, qkv_next, wn, r0, valid, n_chunks, ring, vt_next);
+  if (NEXT) ffn_qkv_body<H3>(bufX, bufA, bufH, x1_next, qkv_next, wn, r0, valid, n_chunks, ring, vt_next);
   PPASR_TS(15);
   if (NEXT) PPASR_WG_TS(1);
+}
+template <int KS, bool STREAM, bool NEXT>
+__global__ __launch_bounds__(kThreads) void k_conv_ffn(const float* __restrict__ g, const float* __restrict__ g_hist,
+                                                       const float* __restrict__ x2, float* __restrict__ x_out, LayerW w,
+                                                       const int64_t* __restrict__ lens, int M, int Tp, int n_chunks,
+                                                       int mask_mul, LayerW wn, float* __restrict__ x1_next,
+                                                       float* __restrict__ qkv_next, int left_ctx, PadSkip ps, VtOut vt_next) {
+  conv_ffn_body<KS, STREAM, NEXT, false>(g, g_hist, x2, x_out, w, lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next,
+                                         left_ctx, ps, vt_next);
+}
+template <int KS, bool NEXT>
+__global__ __launch_bounds__(kThreads) void k_conv_ffn_h3(const float* __restrict__ g, const float* __restrict__ x2,
+                                                          float* __restrict__ x_out, LayerW w, const int64_t* __restrict__ lens,
+                                                          int M, int Tp, int n_chunks, int mask_mul, LayerW wn,
+                                                          float* __restrict__ x1_next, float* __restrict__ qkv_next,
+                                                          int left_ctx, PadSkip ps, VtOut vt_next) {
+  conv_ffn_body<KS, false, NEXT, true>(g, nullptr, x2, x_out, w, lens, M, Tp, n_chunks, mask_mul, wn, x1_next, qkv_next,
+                                       left_ctx, ps, vt_next);
 }
 constexpr size_t kLdsConvFfn = 4 * kRows * kLda * sizeof(float);
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                      const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,
-                     float* x1_next, float* qkv_next, hipStream_t st, bool causal, const PadSkip& ps, VtOut vt_next) {
+                     float* x1_next, float* qkv_next, hipStream_t st, bool causal, const PadSkip& ps, VtOut vt_next, bool h3) {
   dim3 grid((M + kRows - 1) / kRows);
   const int left_ctx = causal ? ksize - 1 : (ksize - 1) / 2;
   const LayerW& wn = next ? *next : w;
+  if (h3) {  // (conv_ffn_h3_supported: kernel 15, no history rows)
+    if (next)
+      PPASR_LAUNCH((k_conv_ffn_h3<15, true>), grid, dim3(kThreads), kLdsConvFfn + kH3ExtraLds, st, g, x2, x_out, w, lens, M, Tp,
+                   n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps, vt_next);
+    else
+      PPASR_LAUNCH((k_conv_ffn_h3<15, false>), grid, dim3(kThreads), kLdsConvFfn + kH3ExtraLds, st, g, x2, x_out, w, lens, M, Tp,
+                   n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps, vt_next);
+    return;
+  }
 #define LAUNCH_CF(KS)                                                                                                  \
   if (g_hist)                                                                                                          \
     PPASR_LAUNCH((k_conv_ffn<KS, true, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w,  \
@@ -2346,6 +2430,9 @@ hipError_t configure_kernels() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
   if (e != hipSuccess) return e;
   SET_LDS(k_ffn_qkv, kLdsFfnQkv);
+  SET_LDS(k_ffn_qkv_h3, kLdsFfnQkv + kH3ExtraLds);
+  SET_LDS((k_conv_ffn_h3<15, true>), kLdsConvFfn + kH3ExtraLds);
+  SET_LDS((k_conv_ffn_h3<15, false>), kLdsConvFfn + kH3ExtraLds);
   SET_LDS(k_attention<64>, kLdsAttn);
   SET_LDS((k_attention<192, true>), kLdsAttnG);
   SET_LDS((k_attention<192, false>), kLdsAttnG);

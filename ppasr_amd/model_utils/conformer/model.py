@@ -218,6 +218,16 @@ class ConformerModel:
         bit.  Two launches are the faster form when another stream's kernels (a pipelined beam search) share the GPU."""
         _lib.check(self.lib.ppasr_set_front_fused(self._h, int(mode)))
 
+    def set_gemm_mode(self, mode="f32"):
+        """Arithmetic of the feed-forward GEMMs (``ppasr_set_gemm_mode``): "f32" (default, exact fp32 products on
+        ``v_mfma_f32_32x32x2_f32``) or "f16x3" (opt-in: two fp16 pieces per operand, three fp16 MFMAs per 16-wide k step,
+        fp32 accumulation -- closer to float64 than fp32 arithmetic on one module, not bit-identical to "f32"; plain
+        Conformer on the fused route, full 32-row launches)."""
+        modes = {"f32": _lib.PPASR_GEMM_F32, "f16x3": _lib.PPASR_GEMM_F16X3}
+        if mode not in modes:
+            raise ValueError(f"gemm mode {mode!r}: 'f32' or 'f16x3'")
+        _lib.check(self.lib.ppasr_set_gemm_mode(self._h, modes[mode]))
+
     def set_row_block(self, rows=-1):
         """Block form of the layer kernels (``ppasr_set_row_block``): -1 = by grid size (16-row blocks for under-filled
         launches, else 32), 16 / 32 = always, 1032 (``PPASR_ROW_BLOCK_32_W16``) = 32 rows on 16 waves (optional form)."""

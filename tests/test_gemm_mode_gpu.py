@@ -1,0 +1,89 @@
+"""GPU: the opt-in fp16 x3 arithmetic of the feed-forward GEMMs (ppasr_set_gemm_mode, csrc/h3.h) against the torch-CPU
+oracle and against the default fp32-MFMA mode.  Every operand is split into two fp16 pieces (22 significant bits), the
+products of pieces are exact in fp32 and accumulate in fp32, so the mode is held to the SAME bar as the fp32 kernels:
+logits within 1e-3 of the oracle (measured: the fp32 kernels' own 1e-6 class), greedy ids identical."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.conformer_oracle import ConformerOracle  # noqa: E402
+from ppasr_amd import _lib  # noqa: E402
+from ppasr_amd.model_utils.conformer.model import ConformerModel  # noqa: E402
+from ppasr_amd.model_utils.squeezeformer.model import SqueezeformerModel  # noqa: E402
+from ppasr_amd.utils.synth import conformer_state_dict, squeezeformer_state_dict, synth_features  # noqa: E402
+
+
+def _model(V, blocks, seed, causal=True):
+    sd = conformer_state_dict(vocab_size=V, num_blocks=blocks, seed=seed, perturb_norm=True)
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=blocks, cnn_module_kernel=15)
+    return sd, ConformerModel(80, V, streaming=causal, encoder_conf=conf, state_dict=sd, device="cuda:0")
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+@pytest.mark.parametrize("B,T,lens", [(3, 331, [331, 200, 57]), (9, 403, None)])
+def test_f16x3_mode_against_the_oracle_and_the_fp32_mode(B, T, lens):
+    V, blocks = 211, 3
+    sd, m = _model(V, blocks, 171)
+    m.set_row_block(32)  # the mode is built into the 8-wave 32-row kernels: keep small batches off the other block forms
+    m.set_ffn_split(0)
+    x, la = synth_features(B, T, lens=lens, seed=172 + B)
+    m.set_gemm_mode("f32")
+    p32, l32 = m.get_encoder_out(x, la, return_logits=True)
+    m.set_gemm_mode("f16x3")
+    ph, lh = m.get_encoder_out(x, la, return_logits=True)
+    l32, lh = l32.cpu().numpy(), lh.cpu().numpy()
+    assert np.isfinite(lh).all()
+    assert not np.array_equal(l32, lh)  # the mode really ran (its roundings differ from the fp32 MFMAs')
+    orc = ConformerOracle(sd, num_blocks=blocks)
+    _, lo = orc.get_encoder_out(torch.as_tensor(x), torch.as_tensor(la), return_logits=True)
+    lo = lo.numpy()
+    e32, eh = _rel(l32, lo), _rel(lh, lo)
+    assert e32 < 1e-3 and eh < 1e-3, (e32, eh)
+    assert eh < 2e-5, eh  # (measured 1e-6 .. 3e-6: the same class as the fp32 kernels)
+    assert np.array_equal(lh.argmax(-1), l32.argmax(-1))
+    # back to the default: bit-identical to the first pass
+    m.set_gemm_mode("f32")
+    _, l32b = m.get_encoder_out(x, la, return_logits=True)
+    assert np.array_equal(l32b.cpu().numpy(), l32)
+
+
+def test_f16x3_mode_at_the_baseline_shape_with_ragged_lengths():
+    """BASELINE configs[1]'s shape (32 x 1000 frames, 12 blocks, V = 4233): full launches take the 32-row kernels by
+    themselves; ragged lengths + skip_padding exercise the padded rows and the active-block lists."""
+    V, blocks = 4233, 12
+    sd, m = _model(V, blocks, 1234)
+    rng = np.random.default_rng(5)
+    lens = [1000] + [int(v) for v in rng.integers(300, 1001, size=31)]
+    x, la = synth_features(32, 1000, lens=lens, seed=20240 + 7)
+    m.set_gemm_mode("f32")
+    _, l32 = m.get_encoder_out(x, la, return_logits=True)
+    m.set_gemm_mode("f16x3")
+    _, lh = m.get_encoder_out(x, la, return_logits=True)
+    m.set_skip_padding(True)
+    _, lhs = m.get_encoder_out(x, la, return_logits=True)
+    m.set_skip_padding(False)
+    l32, lh, lhs = l32.cpu().numpy(), lh.cpu().numpy(), lhs.cpu().numpy()
+    assert np.isfinite(lh).all() and not np.array_equal(lh, l32)
+    assert _rel(lh, l32) < 2e-5
+    tp = lh.shape[1]
+    tv = [min(tp, (int(n) + 3) // 4) for n in la]  # frame t is valid iff 4 t < len (subsampling.py:115)
+    for b in range(32):
+        assert np.array_equal(lh[b, :tv[b]].argmax(-1), l32[b, :tv[b]].argmax(-1)), b
+        assert np.array_equal(lhs[b, :tv[b]], lh[b, :tv[b]]), b  # ragged mode: valid rows bit-identical within the mode
+
+
+def test_f16x3_mode_is_refused_where_it_is_not_built():
+    sq_sd = squeezeformer_state_dict(vocab_size=97, num_blocks=2, seed=92)
+    sq_conf = dict(encoder_dim=256, output_size=256, attention_heads=4, num_blocks=2, reduce_idx=None, recover_idx=None,
+                   feed_forward_expansion_factor=8, cnn_module_kernel=31)
+    sm = SqueezeformerModel(80, 97, streaming=True, encoder_conf=sq_conf, state_dict=sq_sd, device="cuda:0")
+    st = sm.lib.ppasr_set_gemm_mode(sm._h, _lib.PPASR_GEMM_F16X3)
+    assert st != 0
+    assert sm.lib.ppasr_set_gemm_mode(sm._h, _lib.PPASR_GEMM_F32) == 0
+    sd, m = _model(97, 1, 3)
+    assert m.lib.ppasr_set_gemm_mode(m._h, 7) != 0
