@@ -885,12 +885,16 @@ def main():
     if world > 1:
         dist.barrier()
 
-    # cfg2 / cfg3: the same steps once more with the feed-forward GEMMs on the opt-in fp16 x3 route (ppasr_set_gemm_mode,
-    # csrc/h3.h).  NOT the headline: `value` above is the default fp32-MFMA mode; this figure goes to config.f16x3 together
-    # with whether the greedy ids of the batch are the default mode's.  Every rank runs it (a step ends in the all-gather).
+    # cfg2 / cfg4: the same steps once more with the large GEMMs on the opt-in fp16 x3 route (ppasr_set_gemm_mode, csrc/h3.h).
+    # NOT the headline: `value` above is the default fp32-MFMA mode; this figure goes to config.f16x3 together with whether
+    # the token ids of the batch (greedy / beam search) are the default mode's.  Every rank runs it (a step ends in the
+    # all-gather).
     f16x3 = None
-    if not dry and isinstance(w, FormerGreedy) and args.config == "cfg2":
-        ref_ids = [t.clone() for t in w.model.encode_greedy(w.feats, w.lens)]
+    if not dry and args.config in ("cfg2", "cfg4"):
+        ref_out = w.step()
+        sync()
+        ref_ids = [t.clone() for t in ref_out[:2]]
+        sync()
         try:
             w.model.set_gemm_mode("f16x3")
             n_h = max(5, min(args.steps, 100))
@@ -910,13 +914,18 @@ def main():
                 t = torch.tensor([el], dtype=torch.float64, device=red_device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 el = float(t.item())
-            got = w.model.encode_greedy(w.feats, w.lens)
-            same = all(bool(torch.equal(a, b)) for a, b in zip(ref_ids[:2], got[:2]))
+            got = w.step()
+            sync()
+            # per utterance: same token count and the same tokens (a beam search prunes on a cumulative-probability
+            # threshold, so a 1e-6 change of the probabilities can change a candidate set and with it a hypothesis)
+            rt, rn, gt, gn = ref_ids[0].cpu(), ref_ids[1].cpu(), got[0].cpu(), got[1].cpu()
+            same = sum(int(rn[i] == gn[i] and bool(torch.equal(rt[i, :int(rn[i])], gt[i, :int(gn[i])])))
+                       for i in range(rt.shape[0]))
             f16x3 = {"steps": n_h, "ms_per_step": round(el / n_h * 1e3, 3), "value": round(audio_s_per_step / (el / n_h), 1),
-                     "unit": "audio-s/s", "greedy_ids_equal_default_mode": same,
-                     "note": "opt-in mode, not the headline: feed-forward GEMMs of the layer kernels as three fp16 MFMAs per "
-                             "16-wide k step on two-piece operands (22 significant bits, exact products, fp32 accumulation; "
-                             "DESIGN.md 9.8); everything else unchanged"}
+                     "unit": "audio-s/s", "utterances_with_the_default_modes_tokens": f"{same} of {rt.shape[0]}",
+                     "note": "opt-in mode, not the headline: the feed-forward GEMMs of the layer kernels and conv2 of the front end "
+                             "as three fp16 MFMAs per 16-wide k step on two-piece operands (22 significant bits, exact "
+                             "products, fp32 accumulation; DESIGN.md 9.8); everything else unchanged"}
         except Exception as e:  # (a build without the mode: report, do not fail the headline)
             f16x3 = {"error": str(e)[:200]}
         finally:

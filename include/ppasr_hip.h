@@ -178,15 +178,16 @@ PPASR_API ppasr_status ppasr_set_front_fused(ppasr_handle h, int mode);
 #define PPASR_ROW_BLOCK_32_W16 1032
 PPASR_API ppasr_status ppasr_set_row_block(ppasr_handle h, int rows);
 
-/* Arithmetic of the feed-forward GEMMs of the fused Conformer layer kernels (no reference counterpart; csrc/h3.h).
+/* Arithmetic of the large GEMMs of the fused Conformer-family routes (no reference counterpart; csrc/h3.h).
  * PPASR_GEMM_F32 (default): v_mfma_f32_32x32x2_f32, exact fp32 products.  PPASR_GEMM_F16X3 (opt-in): every operand is the
  * sum of two fp16 pieces (22 significant bits; products of pieces are exact in fp32, accumulation in fp32), three
  * v_mfma_f32_32x32x16_f16 per 16-wide k step instead of eight fp32 MFMAs -- one feed-forward module deviates from float64
  * by 2.7e-7 where fp32 arithmetic deviates by 5.5e-7 (tools/experiments/r05/ffn_h3.hip), but NOT bit-identical to the
  * default mode, and an operand beyond 4 094 would overflow (operands are LayerNorm outputs and swish values).  The first
- * call re-packs the feed-forward weights of every layer (second copy, 8 MB per layer).  Built for plain Conformer
- * handles on the fused 256-wide route with cnn_module_kernel 15, full 32-row launches (the other block forms, the split
- * route, streaming handles and every other kernel keep fp32 arithmetic); PPASR_EUNSUPPORTED elsewhere. */
+ * call re-packs the weights concerned (second copy, 8 MB per layer).  Built for Conformer and Efficient-Conformer handles
+ * on the fused 256-wide route: the feed-forward modules of the 8-wave 32-row layer kernels (full launches; the other
+ * block forms, the split route, the stride layer, streaming handles keep fp32 arithmetic) and the second convolution of
+ * the 4x front end (which then runs as its own launch); PPASR_EUNSUPPORTED elsewhere. */
 #define PPASR_GEMM_F32 0
 #define PPASR_GEMM_F16X3 1
 PPASR_API ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode);

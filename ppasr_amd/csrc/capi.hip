@@ -570,12 +570,12 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
   if (!h) return fail(PPASR_EINVAL, "null handle");
   if (mode != PPASR_GEMM_F32 && mode != PPASR_GEMM_F16X3) return fail(PPASR_EINVAL, "gemm mode: PPASR_GEMM_F32 or PPASR_GEMM_F16X3");
   if (mode == PPASR_GEMM_F16X3) {
-    bool ok = h->desc.model_type == PPASR_MODEL_CONFORMER && !h->generic && !h->layers.empty();
-    for (size_t i = 0; ok && i < h->layers.size(); ++i)
-      ok = conv_ffn_h3_supported(h->layer_ks[i]) && h->layer_group[i] == 1 && h->layers[i].ffm_w1 != nullptr;
+    bool ok = (h->desc.model_type == PPASR_MODEL_CONFORMER || h->desc.model_type == PPASR_MODEL_EFFICIENT_CONFORMER) &&
+              !h->generic && !h->layers.empty();
+    for (size_t i = 0; ok && i < h->layers.size(); ++i) ok = conv_ffn_h3_supported(h->layer_ks[i]) && h->layers[i].ffm_w1 != nullptr;
     if (!ok)
-      return fail(PPASR_EUNSUPPORTED, "fp16 x3 GEMMs: built for plain Conformer handles on the fused 256-wide route "
-                                      "(macaron layers, cnn_module_kernel 15)");
+      return fail(PPASR_EUNSUPPORTED, "fp16 x3 GEMMs: built for Conformer / Efficient-Conformer handles on the fused 256-wide "
+                                      "route (macaron layers, depthwise kernels 15 / 7)");
     if (h->layers_h3.empty()) {
       const int d = h->desc.output_size, H = h->desc.linear_units;
       std::vector<LayerW> view = h->layers;
@@ -589,6 +589,13 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
           launch_repack_h3(*w[j], static_cast<f32x4*>(dst), (j & 1) ? d / 32 : H / 32, (j & 1) ? H / 8 : d / 8, nullptr);
           *w[j] = static_cast<const f32x4*>(dst);
         }
+      }
+      if (h->desc.input_layer == 0 && h->front.conv2_k == 3) {  // Conv2dSubsampling4's second convolution: K = 9 * 256
+        void* dst = nullptr;
+        HIP_TRY(hipMalloc(&dst, (size_t)9 * d * d * sizeof(float)));
+        h->allocs.push_back(dst);
+        launch_repack_h3(h->front.conv2_w, static_cast<f32x4*>(dst), d / 32, 9 * d / 8, nullptr);
+        h->conv2_w_h3 = static_cast<const f32x4*>(dst);
       }
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipDeviceSynchronize());
@@ -685,7 +692,9 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     return ps;
   };
   // Conv2dSubsampling4: both convolutions in one launch, conv1's output never leaves the chip (front_fused.hip)
-  const bool conv12 = h->desc.input_layer == 0 && conv12_enabled(h) && conv12_supported(h->front, F, F2);
+  // (fp16 x3 mode: conv2 runs on that route as its own launch behind k_conv1)
+  const f32x4* conv2_h3 = h->gemm_mode == PPASR_GEMM_F16X3 ? h->conv2_w_h3 : nullptr;
+  const bool conv12 = h->desc.input_layer == 0 && !conv2_h3 && conv12_enabled(h) && conv12_supported(h->front, F, F2);
   const PadSkip ps_front = skip_front ? pskip(Tp, sub) : PadSkip{};  // (the front end's own kernels)
   if (!conv12) timed(0, [&] { launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, ps_front); });
   if (h->desc.input_layer == 8) {
@@ -700,7 +709,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       // (ragged batches: the active-tile table of conv2 lives in the CTC head's statistics buffer, unused until the head)
       int* tile_tab = (size_t)B + 2 <= ((size_t)M + 63) / 64 * 64 ? reinterpret_cast<int*>(ws + wl.rmax) : nullptr;
       if (conv12) launch_conv12(feats, h->front, y2, B, T, F, Tp, F2, st, ps_front, tile_tab);
-      else launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, ps_front, tile_tab);
+      else launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, ps_front, tile_tab, h->desc.input_layer == 0 ? conv2_h3 : nullptr);
     });
     timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st, ps_front, ffn_split_for(h, M), y1); });
   }

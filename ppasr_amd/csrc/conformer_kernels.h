@@ -140,10 +140,11 @@ void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T,
 // one k x k / stride-s 256 -> 256 channel conv + ReLU of the front end on NHWC activations (implicit GEMM)
 void launch_conv_stage(const float* y_in, const f32x4* w, const float* bias, float* y_out, int B, int T_in, int F_in,
                        int T_out, int F_out, int k, int s, hipStream_t st, const PadSkip& ps_frames = PadSkip{},
-                       int channels = 256, int* tile_scratch = nullptr);  // channels: 256, or a multiple of it (general layer route)
+                       int channels = 256, int* tile_scratch = nullptr,  // channels: 256, or a multiple of it (general layer route)
+                       bool h3 = false);  // h3: w is the fp16 x3 re-packing (launch_repack_h3), the units run on that route
 // tile_scratch (ragged batches): device scratch of B + 2 ints for the active-tile table (k_tile_prefix)
 void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st,
-                  const PadSkip& ps = PadSkip{}, int* tile_scratch = nullptr);
+                  const PadSkip& ps = PadSkip{}, int* tile_scratch = nullptr, const f32x4* w_h3 = nullptr);
 // scale_before_bias: Squeezeformer scales the 4864-wide conv output by sqrt(d) BEFORE input_proj
 // (squeezeformer/subsampling.py:66-67) -> acc*scale + b ; Conformer: (acc + b)*scale (embedding.py:112)
 // k_slices > 1 (under-filled launches): the contraction is split over that many workgroups per row block, partial sums
@@ -157,7 +158,7 @@ void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, i
                     const PadSkip& ps = PadSkip{}, VtOut vt = VtOut{}, bool h3 = false);
 // fp32 fragment-packed weight (pack_b: n_tiles x G k-groups x 1 KiB) -> the fp16 x3 packing of csrc/h3.h, same size
 void launch_repack_h3(const f32x4* src, f32x4* dst, int n_tiles, int G, hipStream_t st);
-inline bool conv_ffn_h3_supported(int ksize) { return ksize == 15; }
+inline bool conv_ffn_h3_supported(int ksize) { return ksize == 15 || ksize == 7; }
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
                     const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps = PadSkip{},

@@ -126,11 +126,12 @@ struct DenseSrc {
   __device__ __forceinline__ size_t chunk_off(int kc) const { return (size_t)kc * KC; }
 };
 
-template <int MT, int KC, bool RELU, bool SB, typename Src>
-__global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* __restrict__ wp,
-                                                          const float* __restrict__ bias, float* __restrict__ out, int M,
-                                                          int n_chunks, float scale, int ldc, int n_valid, int m0,
-                                                          PadSkip ps, const int* __restrict__ tile_tab) {
+// H3: the A chunks are staged as fp16 operand planes and the units run on the fp16 x3 route (h3.h; wp is then the
+// re-packed weight)
+template <int MT, int KC, bool RELU, bool SB, typename Src, bool H3>
+__device__ __forceinline__ void gemm_stream_body(const Src& src, const f32x4* __restrict__ wp, const float* __restrict__ bias,
+                                                 float* __restrict__ out, int M, int n_chunks, float scale, int ldc,
+                                                 int n_valid, int m0, const PadSkip& ps, const int* __restrict__ tile_tab) {
   constexpr int BM = 32 * MT;
   // Ragged batch with a tile table (k_tile_prefix): workgroup t takes the t-th ACTIVE tile -- tiles are cut per utterance
   // (utterance b: rows b*S + [BM i, BM i + BM) for i < ceil(need rows / BM)), so the active tiles are the first `total`
@@ -159,7 +160,9 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
   } else if (pad_block_skippable(ps, m0 + blockIdx.x * BM, BM, M)) {
     return;
   }
-  constexpr int LD = KC + 4;
+  constexpr int LD = H3 ? (KC + 8) / 2 : KC + 4;  // floats per row of a chunk buffer (H3: one fp16 plane row of KC + 8)
+  constexpr int LDH = KC + 8, PLANE = BM * LDH;   // fp16 plane geometry (H3)
+  constexpr int BUF = H3 ? PLANE : BM * LD;       // floats per chunk buffer (H3: two planes of PLANE fp16 = PLANE floats)
   constexpr int F4_PER_ROW = KC / 4;
   constexpr int NL = BM * F4_PER_ROW / kThreads;  // float4 loads per thread per chunk
   constexpr int G = KC / 8;
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
     int row = idx / F4_PER_ROW, c4 = idx - row * F4_PER_ROW;
     int m = r0 + row;
     voff[i] = (m < Mlim) ? (int)((src.base(m) - tile_base) * sizeof(float)) + 16 * c4 : 0x7fffffff;
-    lds_off[i] = row * LD + 4 * c4;
+    lds_off[i] = H3 ? row * LDH + 4 * c4 : row * LD + 4 * c4;  // (H3: fp16 elements inside a plane)
   }
   f32x4 stg[NL];
   auto load_chunk = [&](int kc) {
@@ -197,27 +200,45 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
     for (int i = 0; i < NL; ++i) stg[i] = wstream_load(rs_a, voff[i], soff);
   };
   auto write_chunk = [&](float* buf) {
+    if constexpr (H3) {
+      _Float16* pl = reinterpret_cast<_Float16*>(buf);
 #pragma unroll
-    for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4*>(buf + lds_off[i]) = stg[i];
+      for (int i = 0; i < NL; ++i) {
+        f16x4 hi, lo;
+        h3_split4(stg[i] * kH3Sa, hi, lo);
+        *reinterpret_cast<f16x4*>(pl + lds_off[i]) = hi;
+        *reinterpret_cast<f16x4*>(pl + PLANE + lds_off[i]) = lo;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4*>(buf + lds_off[i]) = stg[i];
+    }
   };
   f32x16 acc[MT][1];
   acc_zero(acc);
   load_chunk(kc0);
-  write_chunk(smem + (kc0 & 1) * BM * LD);
+  write_chunk(smem + (kc0 & 1) * BUF);
   __syncthreads();
   for (int kc = kc0; kc < kc1; ++kc) {
-    float* cur = smem + (kc & 1) * BM * LD;
-    float* nxt = smem + ((kc + 1) & 1) * BM * LD;
+    float* cur = smem + (kc & 1) * BUF;
+    float* nxt = smem + ((kc + 1) & 1) * BUF;
     const bool more = kc + 1 < kc1;
     if (more) load_chunk(kc + 1);
     const f32x4* seg = wbase + (size_t)kc * G * 64;
     if (MT == 4 && kc < 8) PPASR_WAVE_TS(32 + 4 * kc);
-    rb_gemm<MT, 1, G>(cur, LD, seg, 0, more ? seg + G * 64 : nullptr, 0, ring, acc);
+    if constexpr (H3)
+      rb_gemm_h3_rows<MT, KC / 16>(reinterpret_cast<const _Float16*>(cur), LDH, PLANE, seg, more ? seg + G * 64 : nullptr, ring, acc);
+    else
+      rb_gemm<MT, 1, G>(cur, LD, seg, 0, more ? seg + G * 64 : nullptr, 0, ring, acc);
     if (MT == 4 && kc < 8) PPASR_WAVE_TS(33 + 4 * kc);
     if (more) write_chunk(nxt);
     if (MT == 4 && kc < 8) PPASR_WAVE_TS(34 + 4 * kc);
     __syncthreads();
     if (MT == 4 && kc < 8) PPASR_WAVE_TS(35 + 4 * kc);
+  }
+  if constexpr (H3) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] *= kH3Inv;
   }
   const int col = blockIdx.y * 256 + wave * 32 + (lane & 31);
   if (gridDim.z > 1) {
@@ -241,6 +262,21 @@ __global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* 
       if (RELU) v = fmaxf(v, 0.f);
       if (m < Mlim && col < n_valid) out[(size_t)m * ldc + col] = v;
     }
+}
+template <int MT, int KC, bool RELU, bool SB, typename Src>
+__global__ __launch_bounds__(kThreads) void k_gemm_stream(Src src, const f32x4* __restrict__ wp,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int M,
+                                                          int n_chunks, float scale, int ldc, int n_valid, int m0,
+                                                          PadSkip ps, const int* __restrict__ tile_tab) {
+  gemm_stream_body<MT, KC, RELU, SB, Src, false>(src, wp, bias, out, M, n_chunks, scale, ldc, n_valid, m0, ps, tile_tab);
+}
+// the convolution stage (conv2's implicit GEMM + ReLU) on the fp16 x3 route
+template <int MT>
+__global__ __launch_bounds__(kThreads) void k_conv_stage_h3(Conv2Src src, const f32x4* __restrict__ wp,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int M,
+                                                            int n_chunks, float scale, int ldc, int n_valid, int m0, PadSkip ps,
+                                                            const int* __restrict__ tile_tab) {
+  gemm_stream_body<MT, 128, true, false, Conv2Src, true>(src, wp, bias, out, M, n_chunks, scale, ldc, n_valid, m0, ps, tile_tab);
 }
 // tab[0] = B, tab[1 + b] = number of BM-row tiles the utterances in front of b need (rows b*S + [0, need(b) * unit)),
 // tab[1 + B] = their total: the tile table of a ragged k_gemm_stream launch
@@ -312,11 +348,13 @@ __global__ __launch_bounds__(256) void k_gemm_join(const float* __restrict__ par
 }
 
 void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st,
-                  const PadSkip& ps_frames, int* tile_scratch) {
-  launch_conv_stage(y1, fw.conv2_w, fw.conv2_b, y2, B, T1, F1, Tp, F2, fw.conv2_k, fw.conv2_s, st, ps_frames, 256, tile_scratch);
+                  const PadSkip& ps_frames, int* tile_scratch, const f32x4* w_h3) {
+  launch_conv_stage(y1, w_h3 ? w_h3 : fw.conv2_w, fw.conv2_b, y2, B, T1, F1, Tp, F2, fw.conv2_k, fw.conv2_s, st, ps_frames, 256,
+                    tile_scratch, w_h3 != nullptr);
 }
 void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b, float* y2, int B, int T1, int F1, int Tp,
-                       int F2, int ksz, int stride, hipStream_t st, const PadSkip& ps_frames, int channels, int* tile_scratch) {
+                       int F2, int ksz, int stride, hipStream_t st, const PadSkip& ps_frames, int channels, int* tile_scratch,
+                       bool h3) {
   Conv2Src src{y1, T1, F1, Tp, F2, ksz, stride, channels};
   const int n_kc = ksz * ksz * (channels / 128);  // 128-wide K chunks: channels / 128 per tap
   const int ny = channels / 256;                  // 256-column blocks of the output
@@ -324,14 +362,25 @@ void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b
   ps.unit = F2;  // rows are (frame, f2) pairs
   const int M = B * Tp * F2;
   constexpr int KC = 128, kCUs = 256;
-  auto lds_of = [](int mt) { return (size_t)2 * (32 * mt) * (KC + 4) * sizeof(float); };
+  auto lds_of = [h3](int mt) {
+    return h3 ? (size_t)2 * 2 * (32 * mt) * (KC + 8) * sizeof(_Float16) : (size_t)2 * (32 * mt) * (KC + 4) * sizeof(float);
+  };
   const int* no_tab = nullptr;
+  // (conv_w: the fp16 x3 re-packing when h3.  One macro per launch site below picks the kernel.)
+#define CONV_STAGE_LAUNCH(MTX, GRID, M0, TAB)                                                                            \
+  do {                                                                                                                    \
+    if (h3)                                                                                                               \
+      PPASR_LAUNCH((k_conv_stage_h3<MTX>), GRID, dim3(kThreads), lds_of(MTX), st, src, conv_w, conv_b, y2, M, n_kc, 1.0f, \
+                   channels, channels, M0, ps, TAB);                                                                      \
+    else                                                                                                                  \
+      PPASR_LAUNCH((k_gemm_stream<MTX, KC, true, false, Conv2Src>), GRID, dim3(kThreads), lds_of(MTX), st, src, conv_w,   \
+                   conv_b, y2, M, n_kc, 1.0f, channels, channels, M0, ps, TAB);                                           \
+  } while (0)
   if (ps.lens && tile_scratch && M > 128 * kCUs) {
     // ragged batch, more than one round of 128-row tiles: the active tiles in front of the grid (see k_gemm_stream)
     PPASR_LAUNCH(k_tile_prefix, dim3(1), dim3(256), 0, st, ps, B, 128, tile_scratch);
     const int per_utt = (Tp * F2 + 127) / 128;
-    PPASR_LAUNCH((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(B * per_utt, ny), dim3(kThreads), lds_of(4), st, src, conv_w,
-                 conv_b, y2, M, n_kc, 1.0f, channels, channels, 0, ps, (const int*)tile_scratch);
+    CONV_STAGE_LAUNCH(4, dim3(B * per_utt, ny), 0, (const int*)tile_scratch);
     return;
   }
   // Wave quantisation: 128-row tiles over 256 CUs (one workgroup per CU at this LDS footprint) would run
@@ -344,9 +393,7 @@ void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b
   if (full == 0) {
     // less than one round of 128-row tiles (a single utterance, a streaming chunk): smaller tiles fill more CUs
     const int mt = (M + 32 * kCUs - 1) / (32 * kCUs);  // 1 .. 4
-#define CONV2_ALL(MTA)                                                                                                    \
-  PPASR_LAUNCH((k_gemm_stream<MTA, KC, true, false, Conv2Src>), dim3((M + 32 * MTA - 1) / (32 * MTA), ny),              \
-                     dim3(kThreads), lds_of(MTA), st, src, conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, 0, ps, no_tab)
+#define CONV2_ALL(MTA) CONV_STAGE_LAUNCH(MTA, dim3((M + 32 * MTA - 1) / (32 * MTA), ny), 0, no_tab)
     if (mt <= 1) CONV2_ALL(1);
     else if (mt == 2) CONV2_ALL(2);
     else if (mt == 3) CONV2_ALL(3);
@@ -355,20 +402,17 @@ void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b
     return;
   }
   if (rem_rows <= 0 || mt_rem >= 4) {
-    PPASR_LAUNCH((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(tiles4, ny), dim3(kThreads), lds_of(4), st, src,
-                       conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, 0, ps, no_tab);
+    CONV_STAGE_LAUNCH(4, dim3(tiles4, ny), 0, no_tab);
     return;
   }
-  PPASR_LAUNCH((k_gemm_stream<4, KC, true, false, Conv2Src>), dim3(full, ny), dim3(kThreads), lds_of(4), st, src,
-                     conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, 0, ps, no_tab);
+  CONV_STAGE_LAUNCH(4, dim3(full, ny), 0, no_tab);
   const int m0 = full * 128;
-#define CONV2_REM(MTR)                                                                                                    \
-  PPASR_LAUNCH((k_gemm_stream<MTR, KC, true, false, Conv2Src>), dim3((rem_rows + 32 * MTR - 1) / (32 * MTR), ny),       \
-                     dim3(kThreads), lds_of(MTR), st, src, conv_w, conv_b, y2, M, n_kc, 1.0f, channels, channels, m0, ps, no_tab)
+#define CONV2_REM(MTR) CONV_STAGE_LAUNCH(MTR, dim3((rem_rows + 32 * MTR - 1) / (32 * MTR), ny), m0, no_tab)
   if (mt_rem <= 1) CONV2_REM(1);
   else if (mt_rem == 2) CONV2_REM(2);
   else CONV2_REM(3);
 #undef CONV2_REM
+#undef CONV_STAGE_LAUNCH
 }
 // Ragged launches (PadSkip) of kernels whose LDS footprint lets two or more workgroups share a CU: the whole grid is
 // resident at once, the workgroups of skipped row blocks exit immediately, and the ACTIVE ones are left wherever they
@@ -1797,13 +1841,15 @@ void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float
   dim3 grid((M + kRows - 1) / kRows);
   const int left_ctx = causal ? ksize - 1 : (ksize - 1) / 2;
   const LayerW& wn = next ? *next : w;
-  if (h3) {  // (conv_ffn_h3_supported: kernel 15, no history rows)
-    if (next)
-      PPASR_LAUNCH((k_conv_ffn_h3<15, true>), grid, dim3(kThreads), kLdsConvFfn + kH3ExtraLds, st, g, x2, x_out, w, lens, M, Tp,
-                   n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps, vt_next);
-    else
-      PPASR_LAUNCH((k_conv_ffn_h3<15, false>), grid, dim3(kThreads), kLdsConvFfn + kH3ExtraLds, st, g, x2, x_out, w, lens, M, Tp,
-                   n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps, vt_next);
+  if (h3) {  // (conv_ffn_h3_supported: kernels 15 and 7, no history rows)
+#define LAUNCH_CF_H3(KS, NX)                                                                                                 \
+  PPASR_LAUNCH((k_conv_ffn_h3<KS, NX>), grid, dim3(kThreads), kLdsConvFfn + kH3ExtraLds, st, g, x2, x_out, w, lens, M, Tp, \
+               n_chunks, mask_mul, wn, x1_next, qkv_next, left_ctx, ps, vt_next)
+    if (ksize == 15 && next) LAUNCH_CF_H3(15, true);
+    else if (ksize == 15) LAUNCH_CF_H3(15, false);
+    else if (next) LAUNCH_CF_H3(7, true);
+    else LAUNCH_CF_H3(7, false);
+#undef LAUNCH_CF_H3
     return;
   }
 #define LAUNCH_CF(KS)                                                                                                  \
@@ -2433,6 +2479,8 @@ hipError_t configure_kernels() {
   SET_LDS(k_ffn_qkv_h3, kLdsFfnQkv + kH3ExtraLds);
   SET_LDS((k_conv_ffn_h3<15, true>), kLdsConvFfn + kH3ExtraLds);
   SET_LDS((k_conv_ffn_h3<15, false>), kLdsConvFfn + kH3ExtraLds);
+  SET_LDS((k_conv_ffn_h3<7, true>), kLdsConvFfn + kH3ExtraLds);
+  SET_LDS((k_conv_ffn_h3<7, false>), kLdsConvFfn + kH3ExtraLds);
   SET_LDS(k_attention<64>, kLdsAttn);
   SET_LDS((k_attention<192, true>), kLdsAttnG);
   SET_LDS((k_attention<192, false>), kLdsAttnG);
@@ -2460,6 +2508,10 @@ hipError_t configure_kernels() {
   SET_LDS(k_conv_ffn_stride<7>, kLdsConvFfn);
   SET_LDS(k_ctc_head<true>, kLdsExclusive);  // (>= kLdsCtc: see ragged_lds)
   SET_LDS(k_ctc_head<false>, kLdsExclusive);
+  SET_LDS(k_conv_stage_h3<4>, 2 * 2 * 128 * 136 * sizeof(_Float16));
+  SET_LDS(k_conv_stage_h3<3>, 2 * 2 * 96 * 136 * sizeof(_Float16));
+  SET_LDS(k_conv_stage_h3<2>, 2 * 2 * 64 * 136 * sizeof(_Float16));
+  SET_LDS(k_conv_stage_h3<1>, 2 * 2 * 32 * 136 * sizeof(_Float16));
   SET_LDS((k_gemm_stream<4, 128, true, false, Conv2Src>), 2 * 128 * 132 * sizeof(float));
   SET_LDS((k_gemm_stream<3, 128, true, false, Conv2Src>), 2 * 96 * 132 * sizeof(float));
   SET_LDS((k_gemm_stream<2, 128, true, false, Conv2Src>), 2 * 64 * 132 * sizeof(float));

@@ -100,6 +100,59 @@ __device__ __forceinline__ void rb_gemm_h3(const _Float16* pl, const f32x4* __re
   }
 }
 
+// The streamed-A GEMM's unit (k_gemm_stream: conv2's implicit GEMM) on the fp16 x3 route: MT 32-row tiles share every weight
+// fragment, accumulators in the standard layout (lane = column).  acc[mt] += 2^12 * A[32 mt ..][16 KS] W.
+//   pl: operand planes [2][rows][ldh] of the K chunk (plane = fp16 elements per plane); KS 16-wide k steps
+template <int MT, int KS>
+__device__ __forceinline__ void rb_gemm_h3_rows(const _Float16* pl, int ldh, int plane, const f32x4* __restrict__ bp,
+                                                const f32x4* __restrict__ nxt, BRing<1>& ring, f32x16 (&acc)[MT][1]) {
+  static_assert(kPF == 4, "two k steps of two blocks each in flight");
+  const int lane = lane_id();
+  const _Float16* a_hi = pl + (lane & 31) * ldh + 8 * (lane >> 5);
+  const _Float16* a_lo = a_hi + plane;
+  const __amdgpu_buffer_rsrc_t rs_b = wstream_rsrc(bp), rs_n = wstream_rsrc(nxt);
+  const int voff = lane * 16;
+  f16x8 a0[MT], a1[MT], n0[MT], n1[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    a0[mt] = *reinterpret_cast<const f16x8*>(a_hi + mt * 32 * ldh);
+    a1[mt] = *reinterpret_cast<const f16x8*>(a_lo + mt * 32 * ldh);
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int s = (2 * ks) % kPF;
+    if (ks + 1 < KS) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        n0[mt] = *reinterpret_cast<const f16x8*>(a_hi + mt * 32 * ldh + 16 * (ks + 1));
+        n1[mt] = *reinterpret_cast<const f16x8*>(a_lo + mt * 32 * ldh + 16 * (ks + 1));
+      }
+    }
+    const f16x8 w0 = __builtin_bit_cast(f16x8, ring.q[s][0]), w1 = __builtin_bit_cast(f16x8, ring.q[s + 1][0]);
+    if (2 * ks + kPF < 2 * KS) {
+      ring.q[s][0] = wstream_load(rs_b, voff, (2 * ks + kPF) * 1024);
+      ring.q[s + 1][0] = wstream_load(rs_b, voff, (2 * ks + kPF + 1) * 1024);
+    } else if (nxt) {
+      ring.q[s][0] = wstream_load(rs_n, voff, (2 * ks + kPF - 2 * KS) * 1024);
+      ring.q[s + 1][0] = wstream_load(rs_n, voff, (2 * ks + kPF + 1 - 2 * KS) * 1024);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[mt], w1, acc[mt][0], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[mt], w0, acc[mt][0], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[mt], w0, acc[mt][0], 0, 0, 0);
+    if (ks + 1 < KS) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        a0[mt] = n0[mt];
+        a1[mt] = n1[mt];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // PositionwiseFeedForward (positionwise.py:32-39) on the fp16 x3 route: acc2 = swish(A W1 + b1) W2 (transposed tile, as
 // ffn_phase<true> leaves it: residual_epilogue_t applies).  The hidden dimension in 256-wide chunks, W1(c) -> swish ->
 // operand planes -> W2(c); weight stream order W1(0), W2(0), W1(1), ..., W2(n-1), `after`.

@@ -25,7 +25,7 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / np.abs(b).max())
 
 
-@pytest.mark.parametrize("B,T,lens", [(3, 331, [331, 200, 57]), (9, 403, None)])
+@pytest.mark.parametrize("B,T,lens", [(3, 331, [331, 200, 57]), (9, 403, None), (16, 611, None)])  # conv2 tiles: 32, 96, 128 + 64
 def test_f16x3_mode_against_the_oracle_and_the_fp32_mode(B, T, lens):
     V, blocks = 211, 3
     sd, m = _model(V, blocks, 171)
@@ -50,6 +50,33 @@ def test_f16x3_mode_against_the_oracle_and_the_fp32_mode(B, T, lens):
     m.set_gemm_mode("f32")
     _, l32b = m.get_encoder_out(x, la, return_logits=True)
     assert np.array_equal(l32b.cpu().numpy(), l32)
+
+
+def test_f16x3_mode_on_the_efficient_conformer():
+    """Stride layer (stays fp32), grouped-attention layers and the halved depthwise kernel behind the stride layer."""
+    from oracle.efficient_conformer_oracle import EfficientConformerOracle
+    from ppasr_amd.model_utils.efficient_conformer.model import EfficientConformerModel
+    from ppasr_amd.utils.synth import efficient_conformer_state_dict
+    V, L, stride_idx, groups = 211, 4, 1, (0, 1)
+    sd = efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=175, perturb_norm=True, stride_layer_idx=stride_idx,
+                                        group_layer_idx=groups)
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15,
+                cnn_module_norm="layer_norm",
+                efficient_conf=dict(stride_layer_idx=[stride_idx], stride=[2], group_layer_idx=list(groups), group_size=3,
+                                    stride_kernel=True))
+    m = EfficientConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    m.set_row_block(32)
+    m.set_ffn_split(0)
+    x, la = synth_features(5, 611, lens=[611, 600, 333, 97, 611], seed=176)
+    _, l32 = m.get_encoder_out(x, la, return_logits=True)
+    m.set_gemm_mode("f16x3")
+    _, lh = m.get_encoder_out(x, la, return_logits=True)
+    l32, lh = l32.cpu().numpy(), lh.cpu().numpy()
+    orc = EfficientConformerOracle(sd, num_blocks=L, stride_layer_idx=stride_idx, group_layer_idx=groups)
+    _, lo = orc.get_encoder_out(x, la, return_logits=True)
+    assert np.isfinite(lh).all() and not np.array_equal(lh, l32)
+    assert _rel(lh, lo.numpy()) < 2e-5 and _rel(l32, lo.numpy()) < 2e-5
+    assert np.array_equal(lh.argmax(-1), l32.argmax(-1))
 
 
 def test_f16x3_mode_at_the_baseline_shape_with_ragged_lengths():
