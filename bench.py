@@ -885,12 +885,12 @@ def main():
     if world > 1:
         dist.barrier()
 
-    # cfg2 / cfg4: the same steps once more with the large GEMMs on the opt-in fp16 x3 route (ppasr_set_gemm_mode, csrc/h3.h).
+    # cfg2 / cfg4 / cfg5: the same steps once more with the large GEMMs on the opt-in fp16 x3 route (ppasr_set_gemm_mode, csrc/h3.h).
     # NOT the headline: `value` above is the default fp32-MFMA mode; this figure goes to config.f16x3 together with whether
     # the token ids of the batch (greedy / beam search) are the default mode's.  Every rank runs it (a step ends in the
     # all-gather).
     f16x3 = None
-    if not dry and args.config in ("cfg2", "cfg4"):
+    if not dry and args.config in ("cfg2", "cfg4", "cfg5"):
         ref_out = w.step()
         sync()
         ref_ids = [t.clone() for t in ref_out[:2]]
@@ -923,8 +923,9 @@ def main():
                        for i in range(rt.shape[0]))
             f16x3 = {"steps": n_h, "ms_per_step": round(el / n_h * 1e3, 3), "value": round(audio_s_per_step / (el / n_h), 1),
                      "unit": "audio-s/s", "utterances_with_the_default_modes_tokens": f"{same} of {rt.shape[0]}",
-                     "note": "opt-in mode, not the headline: the feed-forward GEMMs of the layer kernels and conv2 of the front end "
-                             "as three fp16 MFMAs per 16-wide k step on two-piece operands (22 significant bits, exact "
+                     "note": "opt-in mode, not the headline: " + ("conv2 of the front end" if args.config == "cfg5" else
+                                                                   "the feed-forward GEMMs of the layer kernels and conv2 of the front end") +
+                             " as three fp16 MFMAs per 16-wide k step on two-piece operands (22 significant bits, exact "
                              "products, fp32 accumulation; DESIGN.md 9.8); everything else unchanged"}
         except Exception as e:  # (a build without the mode: report, do not fail the headline)
             f16x3 = {"error": str(e)[:200]}

@@ -570,14 +570,20 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
   if (!h) return fail(PPASR_EINVAL, "null handle");
   if (mode != PPASR_GEMM_F32 && mode != PPASR_GEMM_F16X3) return fail(PPASR_EINVAL, "gemm mode: PPASR_GEMM_F32 or PPASR_GEMM_F16X3");
   if (mode == PPASR_GEMM_F16X3) {
-    bool ok = (h->desc.model_type == PPASR_MODEL_CONFORMER || h->desc.model_type == PPASR_MODEL_EFFICIENT_CONFORMER) &&
-              !h->generic && !h->layers.empty();
-    for (size_t i = 0; ok && i < h->layers.size(); ++i) ok = conv_ffn_h3_supported(h->layer_ks[i]) && h->layers[i].ffm_w1 != nullptr;
-    if (!ok)
-      return fail(PPASR_EUNSUPPORTED, "fp16 x3 GEMMs: built for Conformer / Efficient-Conformer handles on the fused 256-wide "
-                                      "route (macaron layers, depthwise kernels 15 / 7)");
-    if (h->layers_h3.empty()) {
-      const int d = h->desc.output_size, H = h->desc.linear_units;
+    const int mt = h->desc.model_type;
+    // the layer kernels' feed-forward modules (Conformer, Efficient-Conformer) ...
+    bool layers_ok = (mt == PPASR_MODEL_CONFORMER || mt == PPASR_MODEL_EFFICIENT_CONFORMER) && !h->generic && !h->layers.empty();
+    for (size_t i = 0; layers_ok && i < h->layers.size(); ++i)
+      layers_ok = conv_ffn_h3_supported(h->layer_ks[i]) && h->layers[i].ffm_w1 != nullptr;
+    // ... and the second convolution of the 4x front end (Squeezeformer's depthwise-separable one is folded into the same
+    // dense [9 * 256][256] weight at create time)
+    const bool front_ok = !h->generic && mt != PPASR_MODEL_DEEPSPEECH2 && h->desc.input_layer == 0 && h->front.conv2_k == 3 &&
+                          h->front.conv2_w != nullptr;
+    if (!layers_ok && !front_ok)
+      return fail(PPASR_EUNSUPPORTED, "fp16 x3 GEMMs: built for the fused 256-wide routes (feed-forward modules of Conformer / "
+                                      "Efficient-Conformer layers with depthwise kernels 15 / 7; conv2 of the 4x front end)");
+    const int d = h->desc.output_size, H = h->desc.linear_units;
+    if (layers_ok && h->layers_h3.empty()) {
       std::vector<LayerW> view = h->layers;
       for (LayerW& L : view) {
         const f32x4** w[4] = {&L.ffm_w1, &L.ffm_w2, &L.ff_w1, &L.ff_w2};
@@ -590,16 +596,18 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
           *w[j] = static_cast<const f32x4*>(dst);
         }
       }
-      if (h->desc.input_layer == 0 && h->front.conv2_k == 3) {  // Conv2dSubsampling4's second convolution: K = 9 * 256
-        void* dst = nullptr;
-        HIP_TRY(hipMalloc(&dst, (size_t)9 * d * d * sizeof(float)));
-        h->allocs.push_back(dst);
-        launch_repack_h3(h->front.conv2_w, static_cast<f32x4*>(dst), d / 32, 9 * d / 8, nullptr);
-        h->conv2_w_h3 = static_cast<const f32x4*>(dst);
-      }
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipDeviceSynchronize());
       h->layers_h3 = std::move(view);
+    }
+    if (front_ok && !h->conv2_w_h3) {  // K = 9 * 256
+      void* dst = nullptr;
+      HIP_TRY(hipMalloc(&dst, (size_t)9 * d * d * sizeof(float)));
+      h->allocs.push_back(dst);
+      launch_repack_h3(h->front.conv2_w, static_cast<f32x4*>(dst), d / 32, 9 * d / 8, nullptr);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipDeviceSynchronize());
+      h->conv2_w_h3 = static_cast<const f32x4*>(dst);
     }
   }
   h->gemm_mode = mode;
@@ -765,7 +773,8 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     const bool w16 = rows == kW16 && S == 1;
     const PadSkip psb = S == 1 ? with_table(ps, Ti, r16 ? 16 : 32) : ps;  // (for the kernels of this layer's block size)
     // feed-forward GEMMs on the fp16 x3 route (ppasr_set_gemm_mode): the 8-wave 32-row kernels only
-    const bool h3 = h->gemm_mode == PPASR_GEMM_F16X3 && !r16 && !w16 && S == 1 && !(eff && i == h->desc.stride_layer_idx);
+    const bool h3 = h->gemm_mode == PPASR_GEMM_F16X3 && !h->layers_h3.empty() && !r16 && !w16 && S == 1 &&
+                    !(eff && i == h->desc.stride_layer_idx);
     const LayerW& Lk = h3 ? h->layers_h3[i] : L;
     float* partial = y1;
     float* x3 = ctx;

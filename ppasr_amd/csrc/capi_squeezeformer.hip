@@ -365,11 +365,13 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
       psH_rb.tab = base + o2;
     }
   }
-  if (conv12_enabled(h) && conv12_supported(h->front, F, F2)) {  // both convolutions in one launch (front_fused.hip)
+  // (fp16 x3 mode, ppasr_set_gemm_mode: conv2 on that route as its own launch behind k_conv1)
+  const f32x4* conv2_h3 = h->gemm_mode == PPASR_GEMM_F16X3 ? h->conv2_w_h3 : nullptr;
+  if (!conv2_h3 && conv12_enabled(h) && conv12_supported(h->front, F, F2)) {  // both convolutions in one launch (front_fused.hip)
     launch_conv12(feats, h->front, y2, B, T, F, Tp, F2, st, psF, tile_tab);
   } else {
     launch_conv1(feats, h->front, y1, B, T, F, T1, F1, st, psF);
-    launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, psF, tile_tab);
+    launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, psF, tile_tab, conv2_h3);
   }
   // (the embed GEMM works on 32-row blocks: it takes the full-rate list when that is the 32-row one)
   launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/true, st,

@@ -104,13 +104,35 @@ def test_f16x3_mode_at_the_baseline_shape_with_ragged_lengths():
         assert np.array_equal(lhs[b, :tv[b]], lh[b, :tv[b]]), b  # ragged mode: valid rows bit-identical within the mode
 
 
-def test_f16x3_mode_is_refused_where_it_is_not_built():
-    sq_sd = squeezeformer_state_dict(vocab_size=97, num_blocks=2, seed=92)
+def test_f16x3_mode_on_the_squeezeformer_front_end():
+    """Squeezeformer handles: the mode covers the front end's second convolution (the layers keep fp32 arithmetic)."""
+    from oracle.squeezeformer_oracle import SqueezeformerOracle
+    V = 97
+    sq_sd = squeezeformer_state_dict(vocab_size=V, num_blocks=2, seed=92, perturb_norm=True)
     sq_conf = dict(encoder_dim=256, output_size=256, attention_heads=4, num_blocks=2, reduce_idx=None, recover_idx=None,
                    feed_forward_expansion_factor=8, cnn_module_kernel=31)
-    sm = SqueezeformerModel(80, 97, streaming=True, encoder_conf=sq_conf, state_dict=sq_sd, device="cuda:0")
-    st = sm.lib.ppasr_set_gemm_mode(sm._h, _lib.PPASR_GEMM_F16X3)
-    assert st != 0
-    assert sm.lib.ppasr_set_gemm_mode(sm._h, _lib.PPASR_GEMM_F32) == 0
+    sm = SqueezeformerModel(80, V, streaming=True, encoder_conf=sq_conf, state_dict=sq_sd, device="cuda:0")
+    x, la = synth_features(6, 611, lens=[611, 600, 333, 97, 611, 13], seed=94)
+    _, l32 = sm.get_encoder_out(x, la, return_logits=True)
+    sm.set_gemm_mode("f16x3")
+    _, lh = sm.get_encoder_out(x, la, return_logits=True)
+    sm.set_skip_padding(True)
+    _, lhs = sm.get_encoder_out(x, la, return_logits=True)
+    l32, lh, lhs = l32.cpu().numpy(), lh.cpu().numpy(), lhs.cpu().numpy()
+    assert np.isfinite(lh).all() and not np.array_equal(lh, l32)
+    assert _rel(lh, l32) < 2e-5
+    assert np.array_equal(lh.argmax(-1), l32.argmax(-1))
+    for b, n in enumerate(la):
+        tv = min(lh.shape[1], (int(n) + 3) // 4)
+        assert np.array_equal(lhs[b, :tv], lh[b, :tv]), b
+
+
+def test_f16x3_mode_is_refused_where_it_is_not_built():
+    # the general layer route (width 512) has neither the fused layer kernels nor their front end
+    sd = conformer_state_dict(vocab_size=97, num_blocks=1, seed=4, output_size=512, attention_heads=8)
+    conf = dict(output_size=512, attention_heads=8, linear_units=2048, num_blocks=1, cnn_module_kernel=15)
+    wide = ConformerModel(80, 97, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    assert wide.lib.ppasr_set_gemm_mode(wide._h, _lib.PPASR_GEMM_F16X3) != 0
+    assert wide.lib.ppasr_set_gemm_mode(wide._h, _lib.PPASR_GEMM_F32) == 0
     sd, m = _model(97, 1, 3)
     assert m.lib.ppasr_set_gemm_mode(m._h, 7) != 0
