@@ -110,6 +110,12 @@ def class_of(name):
         return f"k_conv_ffn<{a[0]}>+next" if a[-1] in ("true", "1") else f"k_conv_ffn<{a[0]}>"
     if base == "k_ffn_qkv_h3":
         return "k_ffn_qkv"
+    if base == "k_sq_mid_h3":
+        return "k_sq_mid"
+    if base == "k_sq_tail_h3":
+        return "k_sq_tail<%s>" % targs.strip("<>").split(",")[0].strip()
+    if base == "k_conv_stage_h3":
+        return "conv2"
     if base == "k_conv_ffn":
         a = [t.strip() for t in targs.strip("<>").split(",")]
         return f"k_conv_ffn<{a[0]}>+next" if a[-1] in ("true", "1") else f"k_conv_ffn<{a[0]}>"
@@ -923,7 +929,8 @@ def main():
                        for i in range(rt.shape[0]))
             f16x3 = {"steps": n_h, "ms_per_step": round(el / n_h * 1e3, 3), "value": round(audio_s_per_step / (el / n_h), 1),
                      "unit": "audio-s/s", "utterances_with_the_default_modes_tokens": f"{same} of {rt.shape[0]}",
-                     "note": "opt-in mode, not the headline: " + ("conv2 of the front end" if args.config == "cfg5" else
+                     "note": "opt-in mode, not the headline: " + ("the feed-forward GEMMs of the 32-row layer kernels and conv2 of the "
+                                                                   "front end" if args.config == "cfg5" else
                                                                    "the feed-forward GEMMs of the layer kernels and conv2 of the front end") +
                              " as three fp16 MFMAs per 16-wide k step on two-piece operands (22 significant bits, exact "
                              "products, fp32 accumulation; DESIGN.md 9.8); everything else unchanged"}

@@ -579,9 +579,12 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
     // dense [9 * 256][256] weight at create time)
     const bool front_ok = !h->generic && mt != PPASR_MODEL_DEEPSPEECH2 && h->desc.input_layer == 0 && h->front.conv2_k == 3 &&
                           h->front.conv2_w != nullptr;
-    if (!layers_ok && !front_ok)
+    // ... Squeezeformer: the two feed-forward modules of a layer (k_sq_mid_h3 / k_sq_tail_h3)
+    const bool sq_ok = mt == PPASR_MODEL_SQUEEZEFORMER && !h->generic && !h->sq_layers.empty() &&
+                       sq_h3_supported(h->desc.cnn_module_kernel, 4);
+    if (!layers_ok && !front_ok && !sq_ok)
       return fail(PPASR_EUNSUPPORTED, "fp16 x3 GEMMs: built for the fused 256-wide routes (feed-forward modules of Conformer / "
-                                      "Efficient-Conformer layers with depthwise kernels 15 / 7; conv2 of the 4x front end)");
+                                      "Efficient-Conformer / Squeezeformer layers; conv2 of the 4x front end)");
     const int d = h->desc.output_size, H = h->desc.linear_units;
     if (layers_ok && h->layers_h3.empty()) {
       std::vector<LayerW> view = h->layers;
@@ -599,6 +602,22 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipDeviceSynchronize());
       h->layers_h3 = std::move(view);
+    }
+    if (sq_ok && h->sq_layers_h3.empty()) {
+      std::vector<SqLayerW> view = h->sq_layers;
+      for (SqLayerW& L : view) {
+        const f32x4** w[4] = {&L.ff1_w1, &L.ff1_w2, &L.ff2_w1, &L.ff2_w2};
+        for (int j = 0; j < 4; ++j) {
+          void* dst = nullptr;
+          HIP_TRY(hipMalloc(&dst, (size_t)d * H * sizeof(float)));
+          h->allocs.push_back(dst);
+          launch_repack_h3(*w[j], static_cast<f32x4*>(dst), (j & 1) ? d / 32 : H / 32, (j & 1) ? H / 8 : d / 8, nullptr);
+          *w[j] = static_cast<const f32x4*>(dst);
+        }
+      }
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipDeviceSynchronize());
+      h->sq_layers_h3 = std::move(view);
     }
     if (front_ok && !h->conv2_w_h3) {  // K = 9 * 256
       void* dst = nullptr;

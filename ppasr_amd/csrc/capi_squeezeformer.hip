@@ -428,11 +428,15 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
                        n_chunks, S, st, ps, /*residual_is_normed=*/true);
       if (Wn) launch_sq_qkv(other, qkv, Wn->wqkv, Wn->bqkv, Mi, st, ps);
     } else {
-      launch_sq_mid(ctx, x, xc, g, nullptr, W, lens, Mi, Ti, mul, n_chunks, st, ps_rb, rows);
+      // feed-forward modules on the fp16 x3 route (ppasr_set_gemm_mode): the 8-wave 32-row kernels only
+      const bool h3 = h->gemm_mode == PPASR_GEMM_F16X3 && !h->sq_layers_h3.empty() && rows == 32 && !h->taps &&
+                      sq_h3_supported(KS, Ti);
+      const SqLayerW& Wk = h3 ? h->sq_layers_h3[i] : W;
+      launch_sq_mid(ctx, x, xc, g, nullptr, Wk, lens, Mi, Ti, mul, n_chunks, st, ps_rb, rows, h3);
       tap(xc, (size_t)Mi * kD);
       tap(g, (size_t)Mi * kD);
-      launch_sq_tail(g, nullptr, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, lens, Mi, Ti, mul,
-                     n_chunks, KS, st, ps_rb, causal, rows);
+      launch_sq_tail(g, nullptr, xc, other, qkv, Wk, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, lens, Mi, Ti, mul,
+                     n_chunks, KS, st, ps_rb, causal, rows, h3);
     }
     std::swap(x, other);
     have_qkv = fuse_next;

@@ -160,13 +160,13 @@ __device__ __forceinline__ void rb_gemm_h3_rows(const _Float16* pl, int ldh, int
 //          [A | hidden chunk, even | hidden chunk, odd] = 3 * kH3TileBytes -- bufA, bufH[0], bufH[1] of the fp32 route
 //          plus kH3ExtraLds bytes (the launch asks for them)
 //   w1, w2: fp16-x3-packed (pack_h3 / k_repack_h3)
-__device__ __forceinline__ void ffn_phase_h3(float* bufA, const f32x4* __restrict__ w1, const float* __restrict__ b1,
-                                             const f32x4* __restrict__ w2, int n_chunks, const f32x4* __restrict__ after,
-                                             BRing<1>& ring, f32x16 (&acc2)[1][1]) {
+//   general form: src = the fp32 rows, pa = where their operand planes go (kH3TileBytes; may overlap src), ph = the two
+//   hidden-chunk tiles (2 * kH3TileBytes)
+__device__ __forceinline__ void ffn_phase_h3(const float* src, _Float16* pa, _Float16* ph, const f32x4* __restrict__ w1,
+                                             const float* __restrict__ b1, const f32x4* __restrict__ w2, int n_chunks,
+                                             const f32x4* __restrict__ after, BRing<1>& ring, f32x16 (&acc2)[1][1]) {
   const int lane = lane_id(), wave = wave_id();
-  _Float16* pa = reinterpret_cast<_Float16*>(bufA);
-  _Float16* ph = pa + 2 * kPlaneH;
-  h3_planes_from_tile(bufA, pa);
+  h3_planes_from_tile(src, pa);
   const int ts2 = n_chunks * 32 * 64;  // W2: K = hidden
   auto w1seg = [&](int c) { return w1 + (size_t)(c * 8 + wave) * kTs256; };
   auto w2seg = [&](int c) { return w2 + (size_t)wave * ts2 + (size_t)c * 32 * 64; };
@@ -195,6 +195,14 @@ __device__ __forceinline__ void ffn_phase_h3(float* bufA, const f32x4* __restric
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc2[0][0][r] = acc[r] * kH3Inv;
+}
+
+// (the Conformer kernels' layout: the planes take over bufA, bufH[0], bufH[1])
+__device__ __forceinline__ void ffn_phase_h3(float* bufA, const f32x4* __restrict__ w1, const float* __restrict__ b1,
+                                             const f32x4* __restrict__ w2, int n_chunks, const f32x4* __restrict__ after,
+                                             BRing<1>& ring, f32x16 (&acc2)[1][1]) {
+  _Float16* pa = reinterpret_cast<_Float16*>(bufA);
+  ffn_phase_h3(bufA, pa, pa + 2 * kPlaneH, w1, b1, w2, n_chunks, after, ring, acc2);
 }
 
 }  // namespace ppasr

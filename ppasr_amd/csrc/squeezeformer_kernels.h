@@ -33,11 +33,15 @@ void launch_sq_qkv(const float* x, float* qkv, const f32x4* wqkv, const float* b
                    const PadSkip& ps = PadSkip{});
 void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, float* xhat_out, const SqLayerW& w,
                    const int64_t* lens, int M, int Tp, int mask_mul, int n_chunks, hipStream_t st,
-                   const PadSkip& ps = PadSkip{}, int rows = 32);  // rows: 32, or 16 = the 16-row-block kernels (rbt.h)
+                   const PadSkip& ps = PadSkip{}, int rows = 32,  // rows: 32, or 16 = the 16-row-block kernels (rbt.h)
+                   bool h3 = false);  // h3: the feed-forward module on the fp16 x3 route (csrc/h3.h; w = the layer's h3 view; rows 32)
+// the register depthwise conv of the transposed forms (and with them the fp16 x3 tail kernel) exists for kernels 31 / 15
+inline bool sq_h3_supported(int ksize, int Tp) { return Tp >= 4 && (ksize == 31 || ksize == 15); }
 // g_hist != nullptr: streaming (single stream, rows = frames of one chunk; left context from g_hist [ksize-1][256])
 void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float* x_out, float* qkv_next, const SqLayerW& w,
                     const f32x4* wqkv_next, const float* bqkv_next, const int64_t* lens, int M, int Tp, int mask_mul,
-                    int n_chunks, int ksize, hipStream_t st, const PadSkip& ps = PadSkip{}, bool causal = true, int rows = 32);
+                    int n_chunks, int ksize, hipStream_t st, const PadSkip& ps = PadSkip{}, bool causal = true, int rows = 32,
+                    bool h3 = false);
 // split route for under-filled launches (ppasr_set_ffn_split): the pieces of K_B / K_C around their feed-forward modules
 void launch_sq_oproj(const float* ctx, const float* x, float* x1, const SqLayerW& w, int M, hipStream_t st,
                      const PadSkip& ps = PadSkip{});

@@ -14,6 +14,7 @@
 #include "conformer_kernels.h"  // ragged_lds / kLdsExclusive
 
 #include "phases_t.h"
+#include "h3.h"
 
 namespace ppasr {
 
@@ -75,12 +76,13 @@ __device__ __forceinline__ void qkv_from_lds(const float* bufX, float* __restric
 // 31-tap depthwise conv + LayerNorm + swish in registers from two tap chunks (no LDS staging, no dependent global -> LDS
 // round trips), the hidden-tile / QKV stores sliced into the next unit's MFMA stream.  R = 16 (v_mfma_f32_16x16x4_f32):
 // for launches whose 32-row blocks would leave more than half of the CUs idle.
-template <int R>
-__global__ __launch_bounds__(RBT<R>::THREADS) void k_sq_mid_t(const float* __restrict__ ctx, const float* __restrict__ x,
-                                                       float* __restrict__ x2, float* __restrict__ g,
-                                                       float* __restrict__ xhat_out, SqLayerW w,
-                                                       const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
-                                                       int n_chunks, PadSkip ps) {
+// H3 (R = 32): the feed-forward module on the fp16 x3 route (h3.h; w.ff1_w1 / w.ff1_w2 are then the re-packed weights; the
+// operand planes take bufH's place and 34 KB behind it)
+template <int R, bool H3>
+__device__ __forceinline__ void sq_mid_body(const float* __restrict__ ctx, const float* __restrict__ x, float* __restrict__ x2,
+                                            float* __restrict__ g, float* __restrict__ xhat_out, const SqLayerW& w,
+                                            const int64_t* __restrict__ lens, int M, int Tp, int mask_mul, int n_chunks,
+                                            const PadSkip& ps) {
   using T = RBT<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int blk = pad_block_of(ps, T::ROWS, M);
@@ -124,7 +126,13 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_sq_mid_t(const float* __res
   __syncthreads();
   typename T::Acc acc2;
   T::zero(acc2);
-  ffn_phase_t<R>(bufX, bufH, w.ff1_w1, w.ff1_b1, w.ff1_w2, n_chunks, seg_val, ring, acc2);
+  if constexpr (H3) {
+    static_assert(R == 32, "fp16 x3: the 8-wave 32-row form");
+    _Float16* pa = reinterpret_cast<_Float16*>(bufH);
+    ffn_phase_h3(bufX, pa, pa + 2 * kPlaneH, w.ff1_w1, w.ff1_b1, w.ff1_w2, n_chunks, seg_val, ring, acc2.v);
+  } else {
+    ffn_phase_t<R>(bufX, bufH, w.ff1_w1, w.ff1_b1, w.ff1_w2, n_chunks, seg_val, ring, acc2);
+  }
   residual_epilogue_q<R>(bufX, acc2, w.ff1_b2, 1.0f);
   __syncthreads();
   rbt_layernorm<R>(bufX, bufX, w.ln2_g, w.ln2_b, 1e-5f);
@@ -158,13 +166,27 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_sq_mid_t(const float* __res
   }
 }
 
-template <int R, int KS>
-__global__ __launch_bounds__(RBT<R>::THREADS) void k_sq_tail_t(const float* __restrict__ g, const float* __restrict__ x2,
-                                                        float* __restrict__ x_out, float* __restrict__ qkv_next,
-                                                        SqLayerW w, const f32x4* __restrict__ wqkv_next,
-                                                        const float* __restrict__ bqkv_next,
+template <int R>
+__global__ __launch_bounds__(RBT<R>::THREADS) void k_sq_mid_t(const float* __restrict__ ctx, const float* __restrict__ x,
+                                                       float* __restrict__ x2, float* __restrict__ g,
+                                                       float* __restrict__ xhat_out, SqLayerW w,
+                                                       const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
+                                                       int n_chunks, PadSkip ps) {
+  sq_mid_body<R, false>(ctx, x, x2, g, xhat_out, w, lens, M, Tp, mask_mul, n_chunks, ps);
+}
+__global__ __launch_bounds__(kThreads) void k_sq_mid_h3(const float* __restrict__ ctx, const float* __restrict__ x,
+                                                        float* __restrict__ x2, float* __restrict__ g,
+                                                        float* __restrict__ xhat_out, SqLayerW w,
                                                         const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
-                                                        int n_chunks, PadSkip ps, int left_ctx) {
+                                                        int n_chunks, PadSkip ps) {
+  sq_mid_body<32, true>(ctx, x, x2, g, xhat_out, w, lens, M, Tp, mask_mul, n_chunks, ps);
+}
+
+template <int R, int KS, bool H3>
+__device__ __forceinline__ void sq_tail_body(const float* __restrict__ g, const float* __restrict__ x2, float* __restrict__ x_out,
+                                             float* __restrict__ qkv_next, const SqLayerW& w, const f32x4* __restrict__ wqkv_next,
+                                             const float* __restrict__ bqkv_next, const int64_t* __restrict__ lens, int M, int Tp,
+                                             int mask_mul, int n_chunks, const PadSkip& ps, int left_ctx) {
   using T = RBT<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int blk = pad_block_of(ps, T::ROWS, M);
@@ -208,8 +230,15 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_sq_tail_t(const float* __re
   __syncthreads();
   typename T::Acc acc2;
   T::zero(acc2);
-  ffn_phase_t<R>(bufX, bufH, w.ff2_w1, w.ff2_b1, w.ff2_w2, n_chunks, wqkv_next ? wqkv_next + (size_t)L.tile() * kTs256 : nullptr,
-                 ring, acc2);
+  if constexpr (H3) {
+    static_assert(R == 32, "fp16 x3: the 8-wave 32-row form");
+    _Float16* pa = reinterpret_cast<_Float16*>(bufA);  // (bufA is free behind pointwise_conv2; the planes run on through bufH)
+    ffn_phase_h3(bufX, pa, pa + 2 * kPlaneH, w.ff2_w1, w.ff2_b1, w.ff2_w2, n_chunks,
+                 wqkv_next ? wqkv_next + (size_t)L.tile() * kTs256 : nullptr, ring, acc2.v);
+  } else {
+    ffn_phase_t<R>(bufX, bufH, w.ff2_w1, w.ff2_b1, w.ff2_w2, n_chunks, wqkv_next ? wqkv_next + (size_t)L.tile() * kTs256 : nullptr,
+                   ring, acc2);
+  }
   residual_epilogue_q<R>(bufX, acc2, w.ff2_b2, 1.0f);
   __syncthreads();
   rbt_layernorm<R>(bufX, bufX, w.ln4_g, w.ln4_b, 1e-5f);
@@ -218,6 +247,23 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_sq_tail_t(const float* __re
     __syncthreads();
     qkv_phase_t<R>(bufX, qkv_next, wqkv_next, bqkv_next, r0, valid, ring);
   }
+}
+template <int R, int KS>
+__global__ __launch_bounds__(RBT<R>::THREADS) void k_sq_tail_t(const float* __restrict__ g, const float* __restrict__ x2,
+                                                        float* __restrict__ x_out, float* __restrict__ qkv_next,
+                                                        SqLayerW w, const f32x4* __restrict__ wqkv_next,
+                                                        const float* __restrict__ bqkv_next,
+                                                        const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
+                                                        int n_chunks, PadSkip ps, int left_ctx) {
+  sq_tail_body<R, KS, false>(g, x2, x_out, qkv_next, w, wqkv_next, bqkv_next, lens, M, Tp, mask_mul, n_chunks, ps, left_ctx);
+}
+template <int KS>
+__global__ __launch_bounds__(kThreads) void k_sq_tail_h3(const float* __restrict__ g, const float* __restrict__ x2,
+                                                         float* __restrict__ x_out, float* __restrict__ qkv_next, SqLayerW w,
+                                                         const f32x4* __restrict__ wqkv_next, const float* __restrict__ bqkv_next,
+                                                         const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
+                                                         int n_chunks, PadSkip ps, int left_ctx) {
+  sq_tail_body<32, KS, true>(g, x2, x_out, qkv_next, w, wqkv_next, bqkv_next, lens, M, Tp, mask_mul, n_chunks, ps, left_ctx);
 }
 
 // K_B: x1 = LN1(x + ctx Wo + bo) ; x2 = LN2(x1 + FFN1(x1)) ; g = GLU(pw1(x2))   (encoder.py:469-497)
@@ -576,9 +622,15 @@ static bool sq_legacy() {
 static size_t lds16(size_t own) { return own < kLdsExclusive ? kLdsExclusive : own; }
 constexpr size_t kLdsSqMid16 = 3 * 16 * kLda * sizeof(float), kLdsSqTail16 = 4 * 16 * kLda * sizeof(float);
 
+// fp16 x3 forms (h3.h): the residual tile + three operand tiles
+constexpr size_t kLdsSqMidH3 = kRows * kLda * sizeof(float) + 3 * kH3TileBytes;
 void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, float* xhat_out, const SqLayerW& w,
-                   const int64_t* lens, int M, int Tp, int mask_mul, int n_chunks, hipStream_t st, const PadSkip& ps, int rows) {
-  if (sq_legacy())
+                   const int64_t* lens, int M, int Tp, int mask_mul, int n_chunks, hipStream_t st, const PadSkip& ps, int rows,
+                   bool h3) {
+  if (h3 && rows == 32 && !sq_legacy())  // (w: the layer's fp16 x3 view)
+    PPASR_LAUNCH(k_sq_mid_h3, rb_grid(M), dim3(kThreads), kLdsSqMidH3, st, ctx, x, x2, g, xhat_out, w, lens, M, Tp, mask_mul,
+                 n_chunks, ps);
+  else if (sq_legacy())
     PPASR_LAUNCH(k_sq_mid, rb_grid(M), dim3(kThreads), kLdsSqMid, st, ctx, x, x2, g, xhat_out, w, lens, M, Tp, mask_mul,
                  n_chunks, ps);
   else if (rows == 16)
@@ -593,8 +645,17 @@ void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, float*
 }
 void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float* x_out, float* qkv_next, const SqLayerW& w,
                     const f32x4* wqkv_next, const float* bqkv_next, const int64_t* lens, int M, int Tp, int mask_mul,
-                    int n_chunks, int ksize, hipStream_t st, const PadSkip& ps, bool causal, int rows) {
+                    int n_chunks, int ksize, hipStream_t st, const PadSkip& ps, bool causal, int rows, bool h3) {
   const int left_ctx = causal ? ksize - 1 : (ksize - 1) / 2;
+  if (h3 && rows == 32 && sq_h3_supported(ksize, Tp) && !g_hist && !sq_legacy()) {  // (w: the layer's fp16 x3 view)
+    if (ksize == 31)
+      PPASR_LAUNCH(k_sq_tail_h3<31>, rb_grid(M), dim3(kThreads), kLdsSqTail + kH3ExtraLds, st, g, x2, x_out, qkv_next, w, wqkv_next,
+                   bqkv_next, lens, M, Tp, mask_mul, n_chunks, ps, left_ctx);
+    else
+      PPASR_LAUNCH(k_sq_tail_h3<15>, rb_grid(M), dim3(kThreads), kLdsSqTail + kH3ExtraLds, st, g, x2, x_out, qkv_next, w, wqkv_next,
+                   bqkv_next, lens, M, Tp, mask_mul, n_chunks, ps, left_ctx);
+    return;
+  }
   // the register depthwise conv needs a wave's rows to span at most two utterances (Tp >= rows per wave); streaming
   // chunks (g_hist) keep the LDS-staged form
   if (!g_hist && !sq_legacy() && Tp >= 4 && (ksize == 31 || ksize == 15)) {
@@ -649,6 +710,9 @@ hipError_t configure_squeezeformer_kernels() {
   if (e != hipSuccess) return e;
   SET_LDS(k_sq_mid, kLdsSqMid);
   SET_LDS(k_sq_mid_t<32>, kLdsSqMid);
+  SET_LDS(k_sq_mid_h3, kLdsSqMidH3);
+  SET_LDS(k_sq_tail_h3<31>, kLdsSqTail + kH3ExtraLds);
+  SET_LDS(k_sq_tail_h3<15>, kLdsSqTail + kH3ExtraLds);
   SET_LDS(k_sq_mid_t<16>, kLdsExclusive);
   SET_LDS(k_sq_mid_t<kW16>, kLdsSqMid);
   SET_LDS((k_sq_tail_t<kW16, 31>), kLdsSqTail);

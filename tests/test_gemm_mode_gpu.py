@@ -104,18 +104,23 @@ def test_f16x3_mode_at_the_baseline_shape_with_ragged_lengths():
         assert np.array_equal(lhs[b, :tv[b]], lh[b, :tv[b]]), b  # ragged mode: valid rows bit-identical within the mode
 
 
-def test_f16x3_mode_on_the_squeezeformer_front_end():
-    """Squeezeformer handles: the mode covers the front end's second convolution (the layers keep fp32 arithmetic)."""
+def test_f16x3_mode_on_the_squeezeformer():
+    """Squeezeformer handles: conv2 of the front end and both feed-forward modules of the 32-row layer kernels."""
     from oracle.squeezeformer_oracle import SqueezeformerOracle
     V = 97
     sq_sd = squeezeformer_state_dict(vocab_size=V, num_blocks=2, seed=92, perturb_norm=True)
     sq_conf = dict(encoder_dim=256, output_size=256, attention_heads=4, num_blocks=2, reduce_idx=None, recover_idx=None,
                    feed_forward_expansion_factor=8, cnn_module_kernel=31)
     sm = SqueezeformerModel(80, V, streaming=True, encoder_conf=sq_conf, state_dict=sq_sd, device="cuda:0")
+    sm.set_row_block(32)
+    sm.set_ffn_split(0)
     x, la = synth_features(6, 611, lens=[611, 600, 333, 97, 611, 13], seed=94)
     _, l32 = sm.get_encoder_out(x, la, return_logits=True)
     sm.set_gemm_mode("f16x3")
     _, lh = sm.get_encoder_out(x, la, return_logits=True)
+    orc = SqueezeformerOracle(sq_sd, num_blocks=2, cnn_module_kernel=31, reduce_idx=None, recover_idx=None)
+    _, lo = orc.get_encoder_out(x, la, return_logits=True)
+    assert _rel(lh.cpu().numpy(), lo.numpy()) < 2e-5
     sm.set_skip_padding(True)
     _, lhs = sm.get_encoder_out(x, la, return_logits=True)
     l32, lh, lhs = l32.cpu().numpy(), lh.cpu().numpy(), lhs.cpu().numpy()
