@@ -589,14 +589,17 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
     if (layers_ok && h->layers_h3.empty()) {
       std::vector<LayerW> view = h->layers;
       for (LayerW& L : view) {
-        const f32x4** w[4] = {&L.ffm_w1, &L.ffm_w2, &L.ff_w1, &L.ff_w2};
-        for (int j = 0; j < 4; ++j) {
+        // W1 [d][H]: H / 32 column tiles of d / 8 k-groups; W2 [H][d]: d / 32 tiles of H / 8 k-groups; then the d-deep
+        // projections [Wq|Wk|Wv] (3d columns), linear_out, pointwise_conv1 (2d columns), pointwise_conv2
+        struct { const f32x4** w; int n_tiles, G; } items[8] = {
+            {&L.ffm_w1, H / 32, d / 8}, {&L.ffm_w2, d / 32, H / 8}, {&L.ff_w1, H / 32, d / 8}, {&L.ff_w2, d / 32, H / 8},
+            {&L.wqkv, 3 * d / 32, d / 8}, {&L.wo, d / 32, d / 8},   {&L.pw1, 2 * d / 32, d / 8}, {&L.pw2, d / 32, d / 8}};
+        for (auto& it : items) {
           void* dst = nullptr;
-          HIP_TRY(hipMalloc(&dst, (size_t)d * H * sizeof(float)));
+          HIP_TRY(hipMalloc(&dst, (size_t)it.n_tiles * it.G * 256 * sizeof(float)));
           h->allocs.push_back(dst);
-          // W1 [d][H]: H / 32 column tiles of d / 8 k-groups; W2 [H][d]: d / 32 tiles of H / 8 k-groups
-          launch_repack_h3(*w[j], static_cast<f32x4*>(dst), (j & 1) ? d / 32 : H / 32, (j & 1) ? H / 8 : d / 8, nullptr);
-          *w[j] = static_cast<const f32x4*>(dst);
+          launch_repack_h3(*it.w, static_cast<f32x4*>(dst), it.n_tiles, it.G, nullptr);
+          *it.w = static_cast<const f32x4*>(dst);
         }
       }
       HIP_TRY(hipGetLastError());
@@ -822,7 +825,7 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
     a.vt = vt_out.vt;
     a.vt_stride = vt_out.stride;
     if (fuse_attn) {
-      timed(9, [&] { launch_attn_out_glu(a, B, xb, xc, g, L, st); });
+      timed(9, [&] { launch_attn_out_glu(a, B, xb, xc, g, Lk, st, h3); });
     } else {
       timed(4, [&] { launch_attention(a, B, h->desc.attention_heads, st); });
       tap(ctx, (size_t)Mi * kD);

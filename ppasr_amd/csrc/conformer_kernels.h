@@ -187,7 +187,8 @@ void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2
                             const PadSkip& ps = PadSkip{}, bool causal = true);
 // streaming helpers
 // fused S2+S3 for the batched plain-head path (4 heads x 64): attention + out-projection + LN_conv + pw1 + GLU
-void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, float* g, const LayerW& w, hipStream_t st);
+void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, float* g, const LayerW& w, hipStream_t st,
+                         bool h3 = false);  // h3: out-projection / pointwise_conv1 on the fp16 x3 route (w = the h3 view)
 void launch_pw1_glu(const float* xhat, float* g, const LayerW& w, int M, hipStream_t st);
 // all layers' conv histories in one launch: layer i reads xh_hist + i*lo_stride*256 (tab[i].rows <= 32 rows), writes
 // g_hist + i*lo_stride*256; tab is a DEVICE array

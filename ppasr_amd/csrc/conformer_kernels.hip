@@ -504,6 +504,20 @@ void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, fl
 // Epilogue slice of the previous Q / K / V tile inside the next unit's MFMA stream: qkv[row][col] = acc + bias
 // (transposed tiles, rb_gemm SWAP: lane = row, register quad q = 4 consecutive columns -> one 16-byte store per quad,
 //  issued during k-groups 4, 12, 20, 28 of the next unit)
+// ... the same inside an fp16 x3 unit (h3.h: 16 k steps, accumulators scaled by 2^12): stores during k steps 2, 6, 10, 14
+struct QkvStoreSideH3 {
+  const f32x16& acc;
+  float* out;
+  const f32x4 (&bias)[4];
+  __device__ __forceinline__ void operator()(int ks) const {
+    if ((ks & 3) == 2 && out) {
+      const int q = ks >> 2;
+      *reinterpret_cast<f32x4*>(out + 8 * q) =
+          f32x4{acc[4 * q] * kH3Inv + bias[q][0], acc[4 * q + 1] * kH3Inv + bias[q][1], acc[4 * q + 2] * kH3Inv + bias[q][2],
+                acc[4 * q + 3] * kH3Inv + bias[q][3]};
+    }
+  }
+};
 struct QkvStoreSide {
   const f32x16& acc;
   float* out;  // qkv + (r0 + this lane's row) * 768 + first column of this lane's quad 0; nullptr: row >= valid
@@ -540,6 +554,7 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
   rb_store_rows(x1 + (size_t)r0 * kD, bufX, kLda, kRows, valid);
   rb_layernorm(bufX, bufA, kLda, kRows, w.ln_mha_g, w.ln_mha_b, 1e-5f);
   __syncthreads();
+  if constexpr (H3) h3_planes_from_tile(bufA, reinterpret_cast<_Float16*>(bufA));  // (in place; 512 B run on into bufH)
   PPASR_TS(11);
   // Q, K, V units: the global stores of unit c's tile (16 per lane) are sliced into the MFMA stream of unit c + 1
   // (QkvStoreSide, one store every second k-group) instead of running between the units with the matrix pipe idle
@@ -557,7 +572,16 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
     acc_zero(tile[c]);
     const f32x4* seg = w.wqkv + (size_t)(c * 8 + wave) * kTs256;
     const f32x4* nseg = c < 2 ? seg + 8 * kTs256 : nullptr;
-    if (c == 0) {
+    if constexpr (H3) {  // (w.wqkv: the re-packed weight; the LayerNorm'd rows were turned into operand planes above)
+      const _Float16* pa = reinterpret_cast<const _Float16*>(bufA);
+      if (c == 0)
+        rb_gemm_h3(pa, seg, nseg, ring, tile[c][0][0]);
+      else if (c == 1)
+        rb_gemm_h3<QkvStoreSideH3>(pa, seg, nseg, ring, tile[c][0][0], QkvStoreSideH3{tile[0][0][0], qrow, qb[0]});
+      else
+        rb_gemm_h3_rows<1, 16, QkvStoreSideH3>(pa, kLdh, kPlaneH, seg, nseg, ring, tile[c],
+                                               QkvStoreSideH3{tile[1][0][0], qrow ? qrow + 256 : nullptr, qb[1]});
+    } else if (c == 0) {
       rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg, 0, nseg, 0, ring, tile[c]);
     } else if (c == 1) {
       rb_gemm<1, 1, kG256, kPF, QkvStoreSide, true>(bufA, kLda, seg, 0, nseg, 0, ring, tile[c],
@@ -575,6 +599,7 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
     // here and on the load side there (rows >= valid of the last block land in the padding behind row M)
     const float bv = w.bqkv[2 * 256 + wave * 32 + (lane & 31)];
     float* dst = vt.vt + ((size_t)wave * (vt.stride >> 3) + (r0 >> 3)) * 256 + 4 * lane;
+    if constexpr (H3) tile[2][0][0] *= kH3Inv;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const f32x16& t = tile[2][0][0];
@@ -583,6 +608,7 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
   } else {
     const int col = 2 * 256 + wave * 32 + (lane & 31);
     const float bv = w.bqkv[col];
+    if constexpr (H3) tile[2][0][0] *= kH3Inv;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int row = acc_row(r, lane);
@@ -1129,9 +1155,12 @@ constexpr int kPTile = 32 * kPLd;              // floats per wave
 constexpr int kFusedAttnFloats = kWaves * kPTile + kWaves * 64 + kRows * kLda;
 static_assert(2 * kRows * kLda <= kWaves * kPTile + kWaves * 64, "bufX/bufA alias the attention scratch");
 static_assert(kRows * kLda + 4 * kPTile <= kWaves * kPTile, "Q'_v and the four merge tiles fit in front of Stat");
+static_assert(kRows * kLda * 4 + kH3TileBytes <= kWaves * kPTile * 4, "fp16 x3: operand planes at bufA stay in front of Stat");
 static_assert(kFusedAttnFloats * 4 <= 160 * 1024, "LDS budget");
-__global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, const float* __restrict__ x1,
-                                                           float* __restrict__ x2, float* __restrict__ g, LayerW w) {
+// H3: the out-projection and pointwise_conv1 units on the fp16 x3 route (h3.h; w.wo / w.pw1 are then the re-packed weights)
+template <bool H3>
+__device__ __forceinline__ void attn_out_glu_body(const AttnArgs& a, int B, const float* __restrict__ x1, float* __restrict__ x2,
+                                                  float* __restrict__ g, const LayerW& w) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ps = smem;                          // [32][260] Q'_v = q + pos_bias_v, then 4 merge tiles [head][32][68]
   float* Stat = Ps + kWaves * kPTile;        // [8 waves][2][32]: running max, running sum of each wave's key half
@@ -1435,7 +1464,13 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
     for (int q = 0; q < 4; ++q) res[q] = *reinterpret_cast<const f32x4*>(x1 + grow + cq + 8 * q);
     f32x16 acc[1][1];
     acc_zero(acc);
-    rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufC, kLda, seg_o, 0, seg_val, 0, ring, acc);
+    if constexpr (H3) {  // (the context rows' operand planes go where bufA will be: free until the LayerNorm below)
+      h3_planes_from_tile(bufC, reinterpret_cast<_Float16*>(bufA));
+      rb_gemm_h3(reinterpret_cast<const _Float16*>(bufA), seg_o, seg_val, ring, acc[0][0]);
+      acc[0][0] *= kH3Inv;
+    } else {
+      rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufC, kLda, seg_o, 0, seg_val, 0, ring, acc);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 bo = *reinterpret_cast<const f32x4*>(w.bo + cq + 8 * q);
@@ -1464,8 +1499,16 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
     f32x16 av[1][1], ag[1][1];
     acc_zero(av);
     acc_zero(ag);
-    rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg_val, 0, seg_gate, 0, ring, av);
-    rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg_gate, 0, nullptr, 0, ring, ag);
+    if constexpr (H3) {
+      h3_planes_from_tile(bufA, reinterpret_cast<_Float16*>(bufA));  // (in place: 512 B run on into the unused tile space)
+      rb_gemm_h3(reinterpret_cast<const _Float16*>(bufA), seg_val, seg_gate, ring, av[0][0]);
+      rb_gemm_h3(reinterpret_cast<const _Float16*>(bufA), seg_gate, nullptr, ring, ag[0][0]);
+      av[0][0] *= kH3Inv;
+      ag[0][0] *= kH3Inv;
+    } else {
+      rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg_val, 0, seg_gate, 0, ring, av);
+      rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg_gate, 0, nullptr, 0, ring, ag);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 bval = *reinterpret_cast<const f32x4*>(w.pw1_b + cq + 8 * q);
@@ -1480,12 +1523,23 @@ __global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, co
   PPASR_TS(39);
   PPASR_WG_TS(512 + 1);
 }
+__global__ __launch_bounds__(kThreads) void k_attn_out_glu(AttnArgs a, int B, const float* __restrict__ x1,
+                                                           float* __restrict__ x2, float* __restrict__ g, LayerW w) {
+  attn_out_glu_body<false>(a, B, x1, x2, g, w);
+}
+__global__ __launch_bounds__(kThreads) void k_attn_out_glu_h3(AttnArgs a, int B, const float* __restrict__ x1,
+                                                              float* __restrict__ x2, float* __restrict__ g, LayerW w) {
+  attn_out_glu_body<true>(a, B, x1, x2, g, w);
+}
 constexpr size_t kLdsAttnOutGlu = (size_t)kFusedAttnFloats * sizeof(float);
 // a: plain-head batched attention arguments (group == 1, T1 == T2 frames, keys/values in the layer's own buffers)
-void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, float* g, const LayerW& w, hipStream_t st) {
+void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, float* g, const LayerW& w, hipStream_t st, bool h3) {
   // 1-D grid of nq * ceil(B/8) * 8 workgroups (see the XCD map in the kernel)
   const int nq = (a.T1 + 31) / 32;
-  PPASR_LAUNCH(k_attn_out_glu, dim3(nq * ((B + 7) / 8) * 8), dim3(kThreads), kLdsAttnOutGlu, st, a, B, x1, x2, g, w);
+  if (h3)  // (w: the layer's fp16 x3 view)
+    PPASR_LAUNCH(k_attn_out_glu_h3, dim3(nq * ((B + 7) / 8) * 8), dim3(kThreads), kLdsAttnOutGlu, st, a, B, x1, x2, g, w);
+  else
+    PPASR_LAUNCH(k_attn_out_glu, dim3(nq * ((B + 7) / 8) * 8), dim3(kThreads), kLdsAttnOutGlu, st, a, B, x1, x2, g, w);
 }
 
 // streaming: g_hist = GLU(pointwise_conv1(cnn_cache rows))  -- the reference re-applies pointwise_conv1+GLU
@@ -1782,7 +1836,13 @@ __device__ __forceinline__ void conv_ffn_body(const float* __restrict__ g, const
   {
     f32x16 acc[1][1];
     acc_zero(acc);
-    rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg_pw2, 0, w.ff_w1 + (size_t)wave * kTs256, 0, ring, acc);
+    if constexpr (H3) {  // (w.pw2: the re-packed weight)
+      h3_planes_from_tile(bufA, reinterpret_cast<_Float16*>(bufA));
+      rb_gemm_h3(reinterpret_cast<const _Float16*>(bufA), seg_pw2, w.ff_w1 + (size_t)wave * kTs256, ring, acc[0][0]);
+      acc[0][0] *= kH3Inv;
+    } else {
+      rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg_pw2, 0, w.ff_w1 + (size_t)wave * kTs256, 0, ring, acc);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(w.pw2_b + cq + 8 * q);
@@ -2504,6 +2564,7 @@ hipError_t configure_kernels() {
   SET_LDS((k_conv_pre<7, true>), kLdsConvPre);
   SET_LDS(k_ffn_part, kLdsFfnPart);
   SET_LDS(k_attn_out_glu, kLdsAttnOutGlu);
+  SET_LDS(k_attn_out_glu_h3, kLdsAttnOutGlu);
   SET_LDS(k_conv_ffn_stride<15>, kLdsConvFfn);
   SET_LDS(k_conv_ffn_stride<7>, kLdsConvFfn);
   SET_LDS(k_ctc_head<true>, kLdsExclusive);  // (>= kLdsCtc: see ragged_lds)

@@ -103,9 +103,10 @@ __device__ __forceinline__ void rb_gemm_h3(const _Float16* pl, const f32x4* __re
 // The streamed-A GEMM's unit (k_gemm_stream: conv2's implicit GEMM) on the fp16 x3 route: MT 32-row tiles share every weight
 // fragment, accumulators in the standard layout (lane = column).  acc[mt] += 2^12 * A[32 mt ..][16 KS] W.
 //   pl: operand planes [2][rows][ldh] of the K chunk (plane = fp16 elements per plane); KS 16-wide k steps
-template <int MT, int KS>
+template <int MT, int KS, typename Side = NoSide>
 __device__ __forceinline__ void rb_gemm_h3_rows(const _Float16* pl, int ldh, int plane, const f32x4* __restrict__ bp,
-                                                const f32x4* __restrict__ nxt, BRing<1>& ring, f32x16 (&acc)[MT][1]) {
+                                                const f32x4* __restrict__ nxt, BRing<1>& ring, f32x16 (&acc)[MT][1],
+                                                Side side = Side()) {
   static_assert(kPF == 4, "two k steps of two blocks each in flight");
   const int lane = lane_id();
   const _Float16* a_hi = pl + (lane & 31) * ldh + 8 * (lane >> 5);
@@ -142,6 +143,7 @@ __device__ __forceinline__ void rb_gemm_h3_rows(const _Float16* pl, int ldh, int
     for (int mt = 0; mt < MT; ++mt) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[mt], w0, acc[mt][0], 0, 0, 0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[mt], w0, acc[mt][0], 0, 0, 0);
+    side(ks);
     if (ks + 1 < KS) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
