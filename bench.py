@@ -116,6 +116,8 @@ def class_of(name):
         return "k_sq_tail<%s>" % targs.strip("<>").split(",")[0].strip()
     if base == "k_conv_stage_h3":
         return "conv2"
+    if base == "k_embed_h3":
+        return "dense"
     if base == "k_conv_ffn":
         a = [t.strip() for t in targs.strip("<>").split(",")]
         return f"k_conv_ffn<{a[0]}>+next" if a[-1] in ("true", "1") else f"k_conv_ffn<{a[0]}>"

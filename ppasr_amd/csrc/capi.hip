@@ -630,6 +630,15 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipDeviceSynchronize());
       h->conv2_w_h3 = static_cast<const f32x4*>(dst);
+      // the input projection behind it: K = F2 * 256 (a whole number of 256-deep chunks), 256 columns
+      const int Ke = h->F2 * d;
+      void* dste = nullptr;
+      HIP_TRY(hipMalloc(&dste, (size_t)Ke * d * sizeof(float)));
+      h->allocs.push_back(dste);
+      launch_repack_h3(h->front.embed_w, static_cast<f32x4*>(dste), d / 32, Ke / 8, nullptr);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipDeviceSynchronize());
+      h->embed_w_h3 = static_cast<const f32x4*>(dste);
     }
   }
   h->gemm_mode = mode;
@@ -741,7 +750,10 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
       if (conv12) launch_conv12(feats, h->front, y2, B, T, F, Tp, F2, st, ps_front, tile_tab);
       else launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, ps_front, tile_tab, h->desc.input_layer == 0 ? conv2_h3 : nullptr);
     });
-    timed(2, [&] { launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st, ps_front, ffn_split_for(h, M), y1); });
+    timed(2, [&] {
+      launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st, ps_front, ffn_split_for(h, M), y1,
+                   conv2_h3 ? h->embed_w_h3 : nullptr);
+    });
   }
   tap(xa, (size_t)M * kD);
   const int n_chunks = h->desc.linear_units / 256;

@@ -133,6 +133,7 @@ struct ppasr_model_s {
   int gemm_mode = 0;          // ppasr_set_gemm_mode: PPASR_GEMM_F32 / PPASR_GEMM_F16X3 (feed-forward GEMMs, csrc/h3.h)
   std::vector<LayerW> layers_h3;  // layers[] with the FFN weight pointers replaced by their fp16 x3 re-packing
   const f32x4* conv2_w_h3 = nullptr;  // the 4x front end's second convolution, re-packed likewise
+  const f32x4* embed_w_h3 = nullptr;  // ... and its input projection
   std::vector<SqLayerW> sq_layers_h3;  // Squeezeformer: sq_layers[] with the two feed-forward modules' weights re-packed
   int row_block = -1;         // ppasr_set_row_block: -1 = by grid size, 32 / 16 / kW16 = always that block form (rbt.h)
   std::vector<int64_t> lens_hint;  // ppasr_set_lengths_hint: host copy of the batch's lengths (route selection only)

@@ -375,7 +375,8 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
   }
   // (the embed GEMM works on 32-row blocks: it takes the full-rate list when that is the 32-row one)
   launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/true, st,
-               (rowsF != 16 && ffn_split_for(h, M) == 1) ? psF_rb : psF, ffn_split_for(h, M), y1);
+               (rowsF != 16 && ffn_split_for(h, M) == 1) ? psF_rb : psF, ffn_split_for(h, M), y1,
+               conv2_h3 ? h->embed_w_h3 : nullptr);
   launch_ln_rows(xa, h->preln_g, h->preln_b, M, st, psF);
   tap(xa, (size_t)M * kD);
   float* x = xa;      // current layer input / residual

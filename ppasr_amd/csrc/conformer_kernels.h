@@ -150,7 +150,8 @@ void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, i
 // k_slices > 1 (under-filled launches): the contraction is split over that many workgroups per row block, partial sums
 // in part (k_slices * M * 256 floats)
 void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, bool scale_before_bias,
-                  hipStream_t st, const PadSkip& ps = PadSkip{}, int k_slices = 1, float* part = nullptr);
+                  hipStream_t st, const PadSkip& ps = PadSkip{}, int k_slices = 1, float* part = nullptr,
+                  const f32x4* w_h3 = nullptr);  // w_h3: fw.embed_w re-packed for the fp16 x3 route (full launches take it)
 void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, float* out, int M, int K, int n_cols_padded,
                   int ldc, int n_valid, hipStream_t st, float scale = 1.0f, float* part = nullptr, size_t part_floats = 0);  // out = (a W + bias) * scale
 // h3: the feed-forward modules on the fp16 x3 route (csrc/h3.h); w (and *next) must then be the layers' h3 views

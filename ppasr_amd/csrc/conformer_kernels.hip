@@ -278,6 +278,13 @@ __global__ __launch_bounds__(kThreads) void k_conv_stage_h3(Conv2Src src, const 
                                                             const int* __restrict__ tile_tab) {
   gemm_stream_body<MT, 128, true, false, Conv2Src, true>(src, wp, bias, out, M, n_chunks, scale, ldc, n_valid, m0, ps, tile_tab);
 }
+// the input projection behind the front end (embed GEMM, K = F2 * 256) on the fp16 x3 route
+template <bool SB>
+__global__ __launch_bounds__(kThreads) void k_embed_h3(DenseSrc src, const f32x4* __restrict__ wp, const float* __restrict__ bias,
+                                                       float* __restrict__ out, int M, int n_chunks, float scale, int ldc,
+                                                       int n_valid, int m0, PadSkip ps, const int* __restrict__ tile_tab) {
+  gemm_stream_body<1, 256, false, SB, DenseSrc, true>(src, wp, bias, out, M, n_chunks, scale, ldc, n_valid, m0, ps, tile_tab);
+}
 // tab[0] = B, tab[1 + b] = number of BM-row tiles the utterances in front of b need (rows b*S + [0, need(b) * unit)),
 // tab[1 + B] = their total: the tile table of a ragged k_gemm_stream launch
 __global__ __launch_bounds__(256) void k_tile_prefix(PadSkip ps, int B, int BM, int* __restrict__ tab) {
@@ -428,10 +435,20 @@ size_t ragged_lds(size_t lds, const PadSkip& ps, int n_blocks) {
 }
 
 void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, bool scale_before_bias,
-                  hipStream_t st, const PadSkip& ps, int k_slices, float* part) {
+                  hipStream_t st, const PadSkip& ps, int k_slices, float* part, const f32x4* w_h3) {
   constexpr int MT = 1, KC = 256;
   DenseSrc src{y2, K, KC};
   size_t lds = ragged_lds(2 * (32 * MT) * (KC + 4) * sizeof(float), ps, (M + 31) / 32);
+  if (w_h3 && !(k_slices > 1 && part)) {  // fp16 x3 route (full launches): two chunk buffers of two fp16 planes
+    lds = ragged_lds((size_t)2 * 2 * 32 * (KC + 8) * sizeof(_Float16), ps, (M + 31) / 32);
+    if (scale_before_bias)
+      PPASR_LAUNCH(k_embed_h3<true>, dim3((M + 31) / 32), dim3(kThreads), lds, st, src, w_h3, fw.embed_b, x0, M, K / KC, xscale,
+                   kD, kD, 0, ps, (const int*)nullptr);
+    else
+      PPASR_LAUNCH(k_embed_h3<false>, dim3((M + 31) / 32), dim3(kThreads), lds, st, src, w_h3, fw.embed_b, x0, M, K / KC, xscale,
+                   kD, kD, 0, ps, (const int*)nullptr);
+    return;
+  }
   if (k_slices > 1 && part) {  // under-filled launch: the K = 4864 contraction over k_slices workgroups per row block
     PPASR_LAUNCH((k_gemm_stream<MT, KC, false, false, DenseSrc>), dim3((M + 31) / 32, 1, k_slices), dim3(kThreads), lds,
                        st, src, fw.embed_w, fw.embed_b, part, M, K / KC, xscale, kD, kD, 0, ps, (const int*)nullptr);
@@ -2577,6 +2594,8 @@ hipError_t configure_kernels() {
   SET_LDS((k_gemm_stream<3, 128, true, false, Conv2Src>), 2 * 96 * 132 * sizeof(float));
   SET_LDS((k_gemm_stream<2, 128, true, false, Conv2Src>), 2 * 64 * 132 * sizeof(float));
   SET_LDS((k_gemm_stream<1, 128, true, false, Conv2Src>), 2 * 32 * 132 * sizeof(float));
+  SET_LDS(k_embed_h3<false>, kLdsExclusive);
+  SET_LDS(k_embed_h3<true>, kLdsExclusive);
   SET_LDS((k_gemm_stream<1, 256, false, false, DenseSrc>), kLdsExclusive);
   SET_LDS((k_gemm_stream<1, 256, false, true, DenseSrc>), kLdsExclusive);
 #undef SET_LDS
