@@ -118,6 +118,8 @@ def class_of(name):
         return "conv2"
     if base == "k_embed_h3":
         return "dense"
+    if base == "k_ctc_head_h3":
+        return "k_ctc_head"
     if base == "k_conv_ffn":
         a = [t.strip() for t in targs.strip("<>").split(",")]
         return f"k_conv_ffn<{a[0]}>+next" if a[-1] in ("true", "1") else f"k_conv_ffn<{a[0]}>"

@@ -622,6 +622,15 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
       HIP_TRY(hipDeviceSynchronize());
       h->sq_layers_h3 = std::move(view);
     }
+    if ((layers_ok || sq_ok || front_ok) && !h->head_w_h3 && h->head.w) {  // the CTC head of the fused routes
+      void* dst = nullptr;
+      HIP_TRY(hipMalloc(&dst, (size_t)h->head.n_tiles * (d / 8) * 256 * sizeof(float)));
+      h->allocs.push_back(dst);
+      launch_repack_h3(h->head.w, static_cast<f32x4*>(dst), h->head.n_tiles, d / 8, nullptr);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipDeviceSynchronize());
+      h->head_w_h3 = static_cast<const f32x4*>(dst);
+    }
     if (front_ok && !h->conv2_w_h3) {  // K = 9 * 256
       void* dst = nullptr;
       HIP_TRY(hipMalloc(&dst, (size_t)9 * d * d * sizeof(float)));
@@ -889,7 +898,10 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   float* fp = frame_maxprob ? frame_maxprob : ws + wl.fp;
   // (under-filled launch: the vocabulary tiles are split over several workgroups per row block, scratch = conv1 buffer)
   timed(7, [&] {
-    launch_ctc_head(xa, h->head, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, Mo, st, pskip(Ti, mul), ffn_split_for(h, Mo), y1);
+    const bool head_h3 = h->gemm_mode == PPASR_GEMM_F16X3 && h->head_w_h3;
+    HeadW hw = h->head;
+    if (head_h3) hw.w = h->head_w_h3;
+    launch_ctc_head(xa, hw, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, Mo, st, pskip(Ti, mul), ffn_split_for(h, Mo), y1, head_h3);
   });
   if (probs) {
     if (logits)

@@ -134,6 +134,7 @@ struct ppasr_model_s {
   std::vector<LayerW> layers_h3;  // layers[] with the FFN weight pointers replaced by their fp16 x3 re-packing
   const f32x4* conv2_w_h3 = nullptr;  // the 4x front end's second convolution, re-packed likewise
   const f32x4* embed_w_h3 = nullptr;  // ... and its input projection
+  const f32x4* head_w_h3 = nullptr;   // the CTC head's weight [256][32 * n_tiles]
   std::vector<SqLayerW> sq_layers_h3;  // Squeezeformer: sq_layers[] with the two feed-forward modules' weights re-packed
   int row_block = -1;         // ppasr_set_row_block: -1 = by grid size, 32 / 16 / kW16 = always that block form (rbt.h)
   std::vector<int64_t> lens_hint;  // ppasr_set_lengths_hint: host copy of the batch's lengths (route selection only)

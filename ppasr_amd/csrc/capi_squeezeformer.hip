@@ -449,7 +449,10 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
   // (the encoder ends at the full rate after the recovery; without one it stays reduced and M rows = B * Tp is the
   //  caller's contract either way)
   const PadSkip psO = reduced ? PadSkip{} : psF;
-  launch_ctc_head(x, h->head, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, M, st, psO, ffn_split_for(h, M), y1);
+  const bool head_h3 = h->gemm_mode == PPASR_GEMM_F16X3 && h->head_w_h3;
+  HeadW hw = h->head;
+  if (head_h3) hw.w = h->head_w_h3;
+  launch_ctc_head(x, hw, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, M, st, psO, ffn_split_for(h, M), y1, head_h3);
   if (probs) {
     if (logits)
       HIP_TRY(hipMemcpyAsync(probs, logits, (size_t)M * h->head.V * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -217,7 +217,7 @@ void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStrea
 // hw.ln_g == nullptr: no final LayerNorm (Squeezeformer has no after_norm, squeezeformer/encoder.py:232-235)
 void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr_argmax, float* fr_maxprob,
                      float* row_max, float* row_sum, int M, hipStream_t st, const PadSkip& ps = PadSkip{},
-                     int n_slices = 1, float* part = nullptr);  // n_slices > 1: vocabulary tiles over that many workgroups
+                     int n_slices = 1, float* part = nullptr, bool h3 = false);  // h3: hw.w re-packed, tiles on the fp16 x3 route  // n_slices > 1: vocabulary tiles over that many workgroups
                                                                 // per row block, part = 3 * n_slices * M floats of scratch
 void launch_softmax_from_stats(float* probs_inout, const float* row_max, const float* row_sum, int M, int V,
                                hipStream_t st, const PadSkip& ps = PadSkip{});

@@ -2236,11 +2236,13 @@ void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2
 // Wave w walks vocabulary tiles w, w+8, ...; each lane keeps a running (max, sum-exp, argmax)
 // for its 16 rows, merged across lanes / waves at the end (ties -> lowest index = numpy argmax).
 // -------------------------------------------------------------------------------------
-template <bool LOGITS>
-__global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__ x, HeadW hw, float* __restrict__ logits,
-                                                       int32_t* __restrict__ fr_argmax, float* __restrict__ fr_maxprob,
-                                                       float* __restrict__ row_max, float* __restrict__ row_sum, int M,
-                                                       PadSkip ps, float* __restrict__ part) {
+// H3: the vocabulary tiles on the fp16 x3 route (h3.h; hw.w is then the re-packed weight; the operand planes replace bufA
+// and the reduction arrays move 512 B back)
+template <bool LOGITS, bool H3>
+__device__ __forceinline__ void ctc_head_body(const float* __restrict__ x, const HeadW& hw, float* __restrict__ logits,
+                                              int32_t* __restrict__ fr_argmax, float* __restrict__ fr_maxprob,
+                                              float* __restrict__ row_max, float* __restrict__ row_sum, int M, const PadSkip& ps,
+                                              float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int blk = pad_block_of(ps, kRows, M);  // (ragged batches: PadSkip::tab or the padded grid)
   if (blk < 0) return;
@@ -2248,7 +2250,7 @@ __global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__
   // per-row (max, sum-exp, argmax) in part[3][gridDim.y][M]; k_ctc_merge combines the slices
   const int ny = gridDim.y, y = blockIdx.y;
   float* bufA = smem;                                          // [32][260]
-  float* redM = bufA + kRows * kLda;                           // [8][32]
+  float* redM = bufA + (H3 ? kH3TileBytes / 4 : kRows * kLda);  // [8][32]
   float* redS = redM + kWaves * 32;                            // [8][32]
   int* redI = reinterpret_cast<int*>(redS + kWaves * 32);      // [8][32]
   const int lane = lane_id(), wave = wave_id();
@@ -2260,6 +2262,7 @@ __global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__
   rb_load_rows(bufA, kLda, x + (size_t)r0 * kD, kRows, valid);
   if (hw.ln_g) rb_layernorm(bufA, bufA, kLda, kRows, hw.ln_g, hw.ln_b, 1e-5f);
   __syncthreads();
+  if constexpr (H3) h3_planes_from_tile(bufA, reinterpret_cast<_Float16*>(bufA));
   // Transposed tiles (rb_gemm SWAP): lane = row l&31, its 16 registers = 16 columns of the vocabulary tile in increasing
   // order (col = 8(r>>2) + 4(l>>5) + (r&3)).  The running (max, sum-exp, argmax) of a row is then ONE triple per lane,
   // updated per tile with in-lane arithmetic: tile max (v_max3), one rescale of the running sum, 16 exponentials, and
@@ -2274,8 +2277,14 @@ __global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__
     f32x16 acc[1][1];
     acc_zero(acc);
     const f32x4* seg = hw.w + (size_t)tile * kTs256;
-    rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg, 0, tile + tstep < hw.n_tiles ? seg + (size_t)tstep * kTs256 : nullptr,
-                                            0, ring, acc);
+    if constexpr (H3) {
+      rb_gemm_h3(reinterpret_cast<const _Float16*>(bufA), seg, tile + tstep < hw.n_tiles ? seg + (size_t)tstep * kTs256 : nullptr,
+                 ring, acc[0][0]);
+      acc[0][0] *= kH3Inv;
+    } else {
+      rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg, 0, tile + tstep < hw.n_tiles ? seg + (size_t)tstep * kTs256 : nullptr,
+                                              0, ring, acc);
+    }
     const int c0 = tile * 32 + 4 * hh;  // column of register 0
     float v[16];
 #pragma unroll
@@ -2387,13 +2396,33 @@ __global__ void k_ctc_merge(const float* __restrict__ part, int ny, int32_t* __r
   if (row_max) row_max[row] = m;
   if (row_sum) row_sum[row] = s;
 }
+template <bool LOGITS>
+__global__ __launch_bounds__(kThreads) void k_ctc_head(const float* __restrict__ x, HeadW hw, float* __restrict__ logits,
+                                                       int32_t* __restrict__ fr_argmax, float* __restrict__ fr_maxprob,
+                                                       float* __restrict__ row_max, float* __restrict__ row_sum, int M,
+                                                       PadSkip ps, float* __restrict__ part) {
+  ctc_head_body<LOGITS, false>(x, hw, logits, fr_argmax, fr_maxprob, row_max, row_sum, M, ps, part);
+}
+template <bool LOGITS>
+__global__ __launch_bounds__(kThreads) void k_ctc_head_h3(const float* __restrict__ x, HeadW hw, float* __restrict__ logits,
+                                                          int32_t* __restrict__ fr_argmax, float* __restrict__ fr_maxprob,
+                                                          float* __restrict__ row_max, float* __restrict__ row_sum, int M,
+                                                          PadSkip ps, float* __restrict__ part) {
+  ctc_head_body<LOGITS, true>(x, hw, logits, fr_argmax, fr_maxprob, row_max, row_sum, M, ps, part);
+}
 constexpr size_t kLdsCtc = (kRows * kLda + 3 * kWaves * 32) * sizeof(float);
 void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr_argmax, float* fr_maxprob, float* row_max,
-                     float* row_sum, int M, hipStream_t st, const PadSkip& ps, int n_slices, float* part) {
+                     float* row_sum, int M, hipStream_t st, const PadSkip& ps, int n_slices, float* part, bool h3) {
   const int ny = (n_slices > 1 && part) ? n_slices : 1;
   dim3 grid((M + kRows - 1) / kRows, ny);
-  const size_t lds = ragged_lds(kLdsCtc, ps, (int)(grid.x * grid.y));
-  if (logits)
+  const size_t lds = ragged_lds(kLdsCtc + (h3 ? 512 : 0), ps, (int)(grid.x * grid.y));
+  if (h3 && logits)  // (hw: the head's fp16 x3 view)
+    PPASR_LAUNCH(k_ctc_head_h3<true>, grid, dim3(kThreads), lds, st, x, hw, logits, fr_argmax, fr_maxprob, row_max, row_sum, M, ps,
+                 part);
+  else if (h3)
+    PPASR_LAUNCH(k_ctc_head_h3<false>, grid, dim3(kThreads), lds, st, x, hw, logits, fr_argmax, fr_maxprob, row_max, row_sum, M, ps,
+                 part);
+  else if (logits)
     PPASR_LAUNCH(k_ctc_head<true>, grid, dim3(kThreads), lds, st, x, hw, logits, fr_argmax, fr_maxprob, row_max,
                        row_sum, M, ps, part);
   else
@@ -2585,6 +2614,8 @@ hipError_t configure_kernels() {
   SET_LDS(k_conv_ffn_stride<15>, kLdsConvFfn);
   SET_LDS(k_conv_ffn_stride<7>, kLdsConvFfn);
   SET_LDS(k_ctc_head<true>, kLdsExclusive);  // (>= kLdsCtc: see ragged_lds)
+  SET_LDS(k_ctc_head_h3<true>, kLdsExclusive);
+  SET_LDS(k_ctc_head_h3<false>, kLdsExclusive);
   SET_LDS(k_ctc_head<false>, kLdsExclusive);
   SET_LDS(k_conv_stage_h3<4>, 2 * 2 * 128 * 136 * sizeof(_Float16));
   SET_LDS(k_conv_stage_h3<3>, 2 * 2 * 96 * 136 * sizeof(_Float16));
