@@ -104,22 +104,23 @@ def class_of(name):
         return f"k_conv_ffn<{a[1]}>+next" if a[-1] in ("true", "1") else f"k_conv_ffn<{a[1]}>"
     if base in ("k_ffn_qkv_t", "k_out_glu_t"):
         return base[:-2]
-    # the opt-in fp16 x3 instantiations (ppasr_set_gemm_mode, csrc/h3.h): k_conv_ffn_h3<KS, NEXT>, k_ffn_qkv_h3
-    if base == "k_conv_ffn_h3":
-        a = [t.strip() for t in targs.strip("<>").split(",")]
-        return f"k_conv_ffn<{a[0]}>+next" if a[-1] in ("true", "1") else f"k_conv_ffn<{a[0]}>"
-    if base == "k_ffn_qkv_h3":
-        return "k_ffn_qkv"
-    if base == "k_sq_mid_h3":
-        return "k_sq_mid"
-    if base == "k_sq_tail_h3":
-        return "k_sq_tail<%s>" % targs.strip("<>").split(",")[0].strip()
-    if base == "k_conv_stage_h3":
-        return "conv2"
-    if base == "k_embed_h3":
-        return "dense"
-    if base == "k_ctc_head_h3":
-        return "k_ctc_head"
+    # the opt-in fp16 x3 instantiations (ppasr_set_gemm_mode, csrc/h3.h) keep classes of their own -- "<class of the
+    # fp32 kernel>/f16x3" -- so that a trace holding both modes (bench.py runs the mode's steps after the timed region)
+    # never averages the two: k_conv_ffn_h3<KS, NEXT>, k_ffn_qkv_h3, k_attn_out_glu_h3, k_sq_mid_h3, k_sq_tail_h3<KS>,
+    # k_conv_stage_h3<MT>, k_embed_h3<SB>, k_ctc_head_h3<LOGITS>
+    if base.endswith("_h3"):
+        a = [t.strip() for t in targs.strip("<>").split(",")] if targs else []
+        if base == "k_conv_ffn_h3":
+            c = f"k_conv_ffn<{a[0]}>+next" if a[-1] in ("true", "1") else f"k_conv_ffn<{a[0]}>"
+        elif base == "k_sq_tail_h3":
+            c = f"k_sq_tail<{a[0]}>"
+        elif base == "k_conv_stage_h3":
+            c = "conv2"
+        elif base == "k_embed_h3":
+            c = "dense"
+        else:
+            c = base[:-3]
+        return c + "/f16x3"
     if base == "k_conv_ffn":
         a = [t.strip() for t in targs.strip("<>").split(",")]
         return f"k_conv_ffn<{a[0]}>+next" if a[-1] in ("true", "1") else f"k_conv_ffn<{a[0]}>"
@@ -724,8 +725,18 @@ def build_roofline(w, args, ms_per_step):
             if isinstance(ev.get(dom), dict):
                 traffic = ev[dom].get("hbm_bytes_per_launch")
                 traffic_note = ev.get("_source")
+                ti = ev[dom].get("hbm_bytes_per_launch_instances") or {}
+                tw = sum(kernels[k]["launches_per_step"] for k in members if k in ti)
+                if tw > 0:  # (instances weighted by this line's launch mix, as the profiler's durations below)
+                    traffic = int(sum(kernels[k]["launches_per_step"] * ti[k] for k in members if k in ti) / tw)
                 if ev[dom].get("rocprof_avg_us") is not None:
                     rocprof_avg_ms = round(ev[dom]["rocprof_avg_us"] * 1e-3, 4)
+                # the class's instances (block forms) weighted by THIS line's launch mix: the traced command also runs the
+                # serial and the fp16 x3 legs, which launch another mix of the same kernels
+                ri = ev[dom].get("rocprof_instances") or {}
+                wsum = sum(kernels[k]["launches_per_step"] for k in members if k in ri)
+                if wsum > 0:
+                    rocprof_avg_ms = round(sum(kernels[k]["launches_per_step"] * ri[k][1] for k in members if k in ri) / wsum * 1e-3, 4)
         else:
             traffic_note = (f"profiles/{tname} was collected on kernels {ev.get('csrc_sha256')}, this build is "
                             f"{csrc_digest()}: re-run tools/collect_evidence.sh")
@@ -740,7 +751,8 @@ def build_roofline(w, args, ms_per_step):
     r.update(traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 PMC)", traffic_source=traffic_note,
              avg_launch_ms=avg_launch_ms, avg_launch_ms_rocprof=rocprof_avg_ms,
              avg_launch_ms_rocprof_note=("average dispatch duration of the same kernel(s) in the rocprofv3 --kernel-trace pass of "
-                                         "tools/collect_evidence.sh on this build (profiles/*_kernel_trace_bench.txt); the profiler "
+                                         "tools/collect_evidence.sh on this build (profiles/*_kernel_trace_bench.txt), instances "
+                                         "weighted by this line's launches per step; the profiler "
                                          "adds ~1 us per dispatch, which shows on 5 us kernels (cfg1) and not on 300 us ones"),
              hidden_decode_ms_per_step=(round(sum(out_classes[c]["ms_per_step"] for c in hidden), 4) if hidden else None),
              avg_launch_ms_method=("HIP-event share of the step x un-instrumented ms_per_step / launches" if not w.pipelined else
