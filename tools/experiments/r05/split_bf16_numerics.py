@@ -114,8 +114,8 @@ class FProxy:
         return y if b is None else y + b[None, :, None, None]
 
 
-def run(sd, feats, lens, dtype, mode=None, trunc=False, hscale=(1.0, 256.0)):
-    m = co.ConformerOracle(sd, dtype=dtype)
+def run(sd, feats, lens, dtype, mode=None, trunc=False, hscale=(1.0, 256.0), **oracle_kw):
+    m = co.ConformerOracle(sd, dtype=dtype, **oracle_kw)
     x = torch.as_tensor(feats, dtype=dtype)
     if mode is None:
         _, logits = m.get_encoder_out(x, torch.as_tensor(lens), return_logits=True)
@@ -146,7 +146,7 @@ def main():
     torch.set_num_threads(os.cpu_count() or 8)
     sd = synth.conformer_state_dict(num_blocks=a.blocks)
     feats, lens = synth.synth_features(a.batch, a.frames)
-    truth = run(sd, feats, lens, torch.float64)
+    truth = run(sd, feats, lens, torch.float64, num_blocks=a.blocks)
     scale = truth.abs().max().item()
     ids_t = truth.argmax(-1)
     # how close are the two best logits of a frame?  (a frame can only flip if the error reaches half this margin)
@@ -155,9 +155,9 @@ def main():
     print(f"model: conformer {a.blocks} blocks, B={a.batch} T={a.frames} -> {truth.shape[1]} frames, V={truth.shape[2]}; "
           f"max |logit| {scale:.3f}; top-2 margin: min {margin.min().item():.3e}, "
           f"1e-4 quantile {torch.quantile(margin.flatten(), 1e-4).item():.3e}")
-    rows = [("float32 (the fp32-MFMA kernels)", run(sd, feats, lens, torch.float32).double())]
+    rows = [("float32 (the fp32-MFMA kernels)", run(sd, feats, lens, torch.float32, num_blocks=a.blocks).double())]
     for mode in a.modes.split(","):
-        rows.append((f"split {mode}" + (" trunc" if a.trunc else ""), run(sd, feats, lens, torch.float32, mode, a.trunc, tuple(float(v) for v in a.hscale.split(","))).double()))
+        rows.append((f"split {mode}" + (" trunc" if a.trunc else ""), run(sd, feats, lens, torch.float32, mode, a.trunc, tuple(float(v) for v in a.hscale.split(",")), num_blocks=a.blocks).double()))
     print(f"{'route':36s} {'max|err|/max|logit|':>20s} {'rms err / rms logit':>20s} {'greedy frames changed':>22s}")
     for name, lg in rows:
         err = (lg - truth).abs()
