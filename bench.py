@@ -47,6 +47,9 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E
+# --gemm f16x3 (opt-in mode, csrc/h3.h): one fp32 product = three fp16 MFMA products, so the mode's own denominator is the
+# dense fp16 matrix peak (2.5 PFLOP/s, MI355X_MICROARCH.md) / 3, in fp32-equivalent FLOPs
+F16X3_PEAK_TFLOPS = 2500.0 / 3.0
 FRAME_SHIFT_S = 0.010
 D, FF, F_IN, V_DEFAULT = 256, 2048, 80, 4233
 BEAM = dict(beam_size=10, cutoff_prob=0.99, cutoff_top_n=40)
@@ -210,6 +213,9 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm", default="f32", choices=["f32", "f16x3"],
+                    help="f16x3: the WHOLE line in the opt-in fp16 x 3 GEMM mode (ppasr_set_gemm_mode; cfg2 / cfg4 / cfg5), dtype "
+                         "'f16x3-split', its own roofline denominator; never the headline (default f32: exact fp32 MFMA)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="cfg4 / cfg5: run the beam search of a step on the encoder's stream instead of overlapping it "
                          "with the next step's encoder")
@@ -694,14 +700,23 @@ def build_roofline(w, args, ms_per_step):
                     n_fr = sum((ln + 7) // 8 for ln in w.utt_frames)
                 per_frame = w.V * 4 if c.startswith("k_ctc_prune") else (2 + 2 * 40) * 4
                 work[c] = (n_fr * per_frame, "bytes", "hbm")
+    # --gemm f16x3: the mode's kernels keep classes of their own ("<fp32 class>/f16x3") with the fp32 class's algorithmic
+    # FLOPs (fp32-equivalent) over the mode's own peak
+    for c in list(classes):
+        if c.endswith("/f16x3") and c[:-6] in work and c not in work:
+            v, unit, _b = work.pop(c[:-6]) if c[:-6] not in classes else work[c[:-6]]
+            work[c] = (v, unit, "mfma16x3")
     out_classes = {}
     for c, (ms, launches) in sorted(classes.items(), key=lambda kv: -kv[1][0]):
         e = {"ms_per_step": round(ms, 4), "launches_per_step": round(launches, 2)}
         if c in work and ms > 0:
             v, unit, bound = work[c]
             if unit == "flop":
+                peak = F16X3_PEAK_TFLOPS if bound == "mfma16x3" else FP32_MFMA_PEAK_TFLOPS
                 e.update(tflops=round(v / (ms * 1e-3) / 1e12, 2), gflop_per_step=round(v / 1e9, 3),
-                         frac=round(v / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), bound=bound)
+                         frac=round(v / (ms * 1e-3) / 1e12 / peak, 4), bound="mfma")
+                if bound == "mfma16x3":
+                    e.update(peak_tflops=round(peak, 1), arithmetic="fp16 x 3")
             else:
                 e.update(gbs=round(v / (ms * 1e-3) / 1e9, 1), mbytes_per_step=round(v / 1e6, 3),
                          frac=round(v / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), bound=bound)
@@ -747,7 +762,11 @@ def build_roofline(w, args, ms_per_step):
     if de.get("bound") == "hbm":
         r.update(achieved=de.get("gbs"), peak=HBM_PEAK_GBS, unit="GB/s", frac=de.get("frac"))
     else:
-        r.update(achieved=de.get("tflops"), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=de.get("frac"))
+        r.update(achieved=de.get("tflops"), peak=de.get("peak_tflops", FP32_MFMA_PEAK_TFLOPS), unit="TFLOP/s", frac=de.get("frac"))
+        if de.get("arithmetic"):
+            r.update(peak_note="fp32-equivalent FLOPs over the dense fp16 matrix peak / 3 (three fp16 MFMA products per fp32 "
+                               "product, csrc/h3.h); what bounds these kernels in practice is the L2 weight stream and the "
+                               "chip's sustained 16-bit MFMA clock (DESIGN 9.8)")
     r.update(traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 PMC)", traffic_source=traffic_note,
              avg_launch_ms=avg_launch_ms, avg_launch_ms_rocprof=rocprof_avg_ms,
              avg_launch_ms_rocprof_note=("average dispatch duration of the same kernel(s) in the rocprofv3 --kernel-trace pass of "
@@ -813,6 +832,10 @@ def main():
     cls = DryRun if dry else {"cfg1": DeepSpeech2Greedy, "cfg2": FormerGreedy, "cfg3": FormerGreedy, "cfg4": EfficientBeam,
                               "cfg5": SqueezeformerRagged}[args.config]
     w = cls(args, device, rank, world, dist)
+    if args.gemm == "f16x3" and not dry:
+        if args.config not in ("cfg2", "cfg3", "cfg4", "cfg5"):
+            raise SystemExit("--gemm f16x3: built for the *former configs (cfg2 .. cfg5)")
+        w.model.set_gemm_mode("f16x3")
 
     def sync():
         w.finish()
@@ -912,7 +935,7 @@ def main():
     # the token ids of the batch (greedy / beam search) are the default mode's.  Every rank runs it (a step ends in the
     # all-gather).
     f16x3 = None
-    if not dry and args.config in ("cfg2", "cfg4", "cfg5"):
+    if not dry and args.config in ("cfg2", "cfg4", "cfg5") and args.gemm == "f32":
         ref_out = w.step()
         sync()
         ref_ids = [t.clone() for t in ref_out[:2]]
@@ -966,13 +989,13 @@ def main():
             "metric": w.metric,
             "value": None if dry else round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": ("dry-run: stub kernels, plumbing only" if dry else
+            "vs_baseline": None, "dtype": ("f16x3-split" if args.gemm == "f16x3" else "f32"), "data": ("dry-run: stub kernels, plumbing only" if dry else
                                          "synthetic (ranks SHARE devices, host-staged gloo collectives: plumbing check, not a measurement)"
                                          if args.share_gpu else "synthetic"),
             "config": {"workload": w.desc, "baseline_config": cfg_name,
                        "global_batch": getattr(w, "n_global", None) or world * args.batch, "frames": args.frames,
                        "decoder": w.decoder, "parallelism": f"utterance-dp{world}",
-                       "pipelined": bool(w.pipelined), "serial": serial, "f16x3": f16x3,
+                       "pipelined": bool(w.pipelined), "serial": serial, "f16x3": f16x3, "gemm": args.gemm,
                        "pipelined_note": ("the beam search of step i runs on a second HIP stream and overlaps the encoder of step "
                                           "i+1; all K steps are complete when the timed region ends") if w.pipelined else None},
             "median_ms_per_step": None if median_ms is None else round(median_ms, 3),
