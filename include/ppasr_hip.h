@@ -184,10 +184,14 @@ PPASR_API ppasr_status ppasr_set_row_block(ppasr_handle h, int rows);
  * v_mfma_f32_32x32x16_f16 per 16-wide k step instead of eight fp32 MFMAs -- one feed-forward module deviates from float64
  * by 2.7e-7 where fp32 arithmetic deviates by 5.5e-7 (tools/experiments/r05/ffn_h3.hip), but NOT bit-identical to the
  * default mode, and an operand beyond 4 094 would overflow (operands are LayerNorm outputs and swish values).  The first
- * call re-packs the weights concerned (second copy, 8 MB per layer).  Built for Conformer and Efficient-Conformer handles
- * on the fused 256-wide route: the feed-forward modules of the 8-wave 32-row layer kernels (full launches; the other
- * block forms, the split route, the stride layer, streaming handles keep fp32 arithmetic) and the second convolution of
- * the 4x front end (which then runs as its own launch); PPASR_EUNSUPPORTED elsewhere. */
+ * call re-packs the weights concerned on the device (second copy, ~ 10 MB per layer).  Built for the fused 256-wide routes:
+ * Conformer / Efficient-Conformer -- feed-forward modules, Q/K/V, pointwise_conv2 (8-wave 32-row layer kernels), linear_out
+ * + pointwise_conv1 (fused attention kernel); Squeezeformer -- both feed-forward modules of the 32-row layer kernels; all
+ * three -- the second convolution of the 4x front end (then its own launch behind conv1), the input projection, the CTC
+ * head.  The other block forms (16 rows, 16 waves), the split route for under-filled launches, the Efficient-Conformer's
+ * stride layer, attention products, depthwise convolutions and streaming handles keep fp32 arithmetic.  PPASR_EUNSUPPORTED
+ * on DeepSpeech2 handles and on the general layer route.  Measured: logits within 1e-6 .. 3e-6 of the
+ * default mode's, the reference-source pin tests pass with unchanged criteria, 1.2 - 1.7 x faster end to end. */
 #define PPASR_GEMM_F32 0
 #define PPASR_GEMM_F16X3 1
 PPASR_API ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode);
