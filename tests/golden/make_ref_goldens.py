@@ -243,6 +243,8 @@ def main():
     ap.add_argument("--only", nargs="*", default=None)
     ap.add_argument("--add", nargs="*", default=None,
                     help="run only these SMALL cases and MERGE their outputs into the existing ref_small.npz")
+    ap.add_argument("--add-full", nargs="*", default=None,
+                    help="run only these FULL cases and MERGE their outputs into the existing ref_full.npz")
     args = ap.parse_args()
     if not os.path.isdir(REFERENCE):
         raise SystemExit("needs /root/reference (build container only)")
@@ -255,6 +257,15 @@ def main():
         old.update(new)
         np.savez_compressed(path, **old)
         print("merged", sorted({k.split("/")[0] for k in new}), "into ref_small.npz:", len(old), "arrays")
+        return
+    if args.add_full:
+        path = os.path.join(HERE, "ref_full.npz")
+        old = dict(np.load(path))
+        new = full(paddle, args.add_full)
+        old = {k: v for k, v in old.items() if k.split("/")[0] not in args.add_full}
+        old.update(new)
+        np.savez_compressed(path, **old)
+        print("merged", sorted({k.split("/")[0] for k in new}), "into ref_full.npz:", len(old), "arrays")
         return
     if not args.full or args.only:
         out = small(paddle, args.only)

@@ -99,6 +99,9 @@ for _gru in (False, True):
 
 # ---- BASELINE.json configs at full size (outputs stored sub-sampled, see make_ref_goldens.py) ------------------------
 FULL = {
+    # configs[0]: DeepSpeech2 non-streaming (bidirectional LSTM, deepspeech2/encoder.py:61-104), 5 x 1024, one 5 s utterance
+    "cfg1": dict(family="deepspeech2", streaming=False, L=5, V=4233, sd_seed=1234, x_spec=(1, 498, None, 20240 + 100),
+                 chunk_frames=None, required=(), kw=dict(use_gru=False)),
     # configs[1]: Conformer streaming, 32 x 1000 frames, V = 4233 (bench.py's workload, rank 0 seed)
     "cfg2": _former("conformer", True, 12, 4233, 1234, (32, 1000, None, 20240 + 200)),
     # configs[3]: Efficient-Conformer streaming, B = 64, beam 10 / 0.99 / top-40

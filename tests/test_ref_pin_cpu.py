@@ -134,3 +134,23 @@ def test_full_size_conformer_oracle_matches_reference_source():
     assert e_s < TOL and e_z < TOL
     clear = margin[:2] > 1e-3
     assert np.array_equal(lg.argmax(-1)[clear], ids[:2][clear])
+
+
+def test_full_size_deepspeech2_oracle_matches_reference_source():
+    """configs[0] (5 x 1024 bidirectional LSTM, B = 1, T = 498, V = 4233): oracle/deepspeech2_oracle.py vs the
+    reference-source summary of ref_full.npz (probabilities on the sampled columns = exp(logit - lse), greedy ids)."""
+    with np.load(os.path.join(HERE, "golden", "ref_full.npz")) as z:
+        ids, margin, lse, sampled, cols, maxprob = (z["cfg1/" + k] for k in ("ids", "margin", "lse", "sampled", "cols", "maxprob"))
+    case = rc.FULL["cfg1"]
+    sd = rc.state_dict(case)
+    x, lens = rc.features(case)
+    probs, out_lens, _, _ = make_oracle(case, sd).forward(x, lens)
+    p = probs.numpy().astype(np.float64)
+    assert p.shape == (1, 123, 4233) and out_lens.tolist() == [123]
+    want = np.exp(sampled.astype(np.float64) - lse.astype(np.float64)[..., None])
+    e_p = float(np.abs(p[..., cols] - want).max() / want.max())
+    e_m = float(np.abs(p.max(-1) - maxprob).max())
+    print(f"cfg1 oracle vs reference source: sampled probs {e_p:.2e} max-prob {e_m:.2e}")
+    assert e_p < TOL and e_m < TOL
+    clear = margin > 1e-3
+    assert np.array_equal(p.argmax(-1)[clear], ids[clear])

@@ -180,6 +180,42 @@ def _check_frames(logits, ids, margin, lse, sampled, cols, what, measured_err=No
     return e_s, e_z, int(near.sum()), set(int(f) for f in differ)
 
 
+def _check_probs_against_summary(p, z, key, what):
+    """probabilities [n, V] against the reference-source summary of a full-size case (per-frame greedy id, top-2 logit
+    margin, log-sum-exp, logits of the sampled columns): the reference's probabilities on those columns are
+    exp(logit - lse)."""
+    ids, margin, lse, sampled, cols = (z[f"{key}/{k}"].reshape((-1,) + z[f"{key}/{k}"].shape[2:]) if k != "cols" else z[f"{key}/cols"]
+                                       for k in ("ids", "margin", "lse", "sampled", "cols"))
+    want = np.exp(sampled.astype(np.float64) - lse.astype(np.float64)[:, None])
+    e_p = float(np.abs(p[:, cols].astype(np.float64) - want).max() / max(want.max(), 1e-30))
+    e_m = float(np.abs(p.max(-1) - z[f"{key}/maxprob"].reshape(-1)).max())
+    clear = margin > 1e-3
+    assert np.array_equal(p.argmax(-1)[clear], ids[clear]), what
+    print(f"{what}: sampled probs {e_p:.2e} max-prob {e_m:.2e}; near-tie frames {int((~clear).sum())}/{len(ids)}")
+    return e_p, e_m
+
+
+def test_cfg1_deepspeech2_full_size_matches_reference_source(ref_full):
+    """configs[0] at full size: DeepSpeech2 non-streaming, 5 x 1024 bidirectional LSTM (deepspeech2/encoder.py:61-104),
+    B = 1, one 5 s utterance (498 frames -> 123), V = 4233 -- the reference's CRNNEncoder + CTC head run from source on the
+    shim (whose LSTM cell is second-sourced against torch.nn.LSTM, tests/test_second_source_cpu.py), every frame: greedy id,
+    sampled probabilities, max probability; then the greedy decoder's tokens == collapse of the reference's ids."""
+    from ppasr_amd.decoders.ctc_greedy_decoder import greedy_decode_ids
+    case = rc.FULL["cfg1"]
+    model = make_model(case, rc.state_dict(case))
+    x, lens = rc.features(case)
+    probs = model.get_encoder_out(x, lens)
+    torch.cuda.synchronize()
+    assert tuple(probs.shape) == (1, 123, 4233)
+    e_p, e_m = _check_probs_against_summary(probs.cpu().numpy()[0], ref_full, "cfg1", "cfg1")
+    assert e_p < TOL and e_m < TOL
+    tokens, n, _, _, _ = greedy_decode_ids(probs)
+    rid = ref_full["cfg1/ids"][0]
+    if (ref_full["cfg1/margin"][0] > 1e-3).all():
+        keep = np.concatenate([[True], rid[1:] != rid[:-1]]) & (rid != 0)
+        assert np.array_equal(tokens[0, :int(n[0])].cpu().numpy(), rid[keep])
+
+
 @pytest.mark.parametrize("gemm", GEMM_MODES)
 def test_cfg2_all_utterances_logits_and_tokens(ref_full, gemm):
     """configs[1] at full size: 12 blocks, 32 x 1000 frames, V = 4233 -- logits of every frame of all 32 utterances

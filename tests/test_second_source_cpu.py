@@ -176,3 +176,63 @@ def test_fbank_oracle_equals_independent_construction(seconds, sr):
     if a.size:
         assert a.shape[1] == 80 and a.shape[0] == 1 + (len(pcm) - int(sr * 0.025)) // int(sr * 0.010)
         assert float(np.abs(a - b).max()) < 1e-5, float(np.abs(a - b).max())
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# (c) recurrent cells -- oracle/paddle_shim's nn.LSTM / nn.GRU (the arithmetic the DeepSpeech2 reference-source fixtures
+#     run on: gate order, `h = z h + (1 - z) c`, `sequence_length` freezing; written from Paddle's documentation) against
+#     torch.nn.LSTM / torch.nn.GRU with the same weights, bidirectional, padded batches as packed sequences.  torch's
+#     cells are an independent implementation (ATen C++, fused gate kernels) of the same documented equations.
+#     Proves: the shim's step arithmetic, the reverse direction starting at len - 1, zeros behind len and the final states.
+#     Does not prove: that Paddle's gate order / candidate formula equals torch's (both are the cuDNN convention as far as
+#     either project documents it).
+def _shim_paddle():
+    import sys
+    shim = os.path.join(ROOT, "oracle", "paddle_shim")
+    if shim not in sys.path:
+        sys.path.insert(0, shim)
+    import paddle  # noqa: F401  (the torch-backed shim)
+    return paddle
+
+
+@pytest.mark.parametrize("kind", ["LSTM", "GRU"])
+@pytest.mark.parametrize("direction", ["forward", "bidirect"])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_shim_rnn_equals_torch_rnn(kind, direction, ragged):
+    paddle = _shim_paddle()
+    torch.manual_seed(11)
+    B, T, I, H = 3, 17, 24, 32
+    shim = getattr(paddle.nn, kind)(I, H, direction=direction)
+    bi = direction != "forward"
+    ref = getattr(torch.nn, kind)(I, H, num_layers=1, batch_first=True, bidirectional=bi).double()
+    with torch.no_grad():
+        for sfx in ([""] + (["_reverse"] if bi else [])):
+            for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                getattr(ref, f"{n}_l0{sfx}").copy_(getattr(shim, f"{n}_l0{sfx}")._t.double())
+    x = torch.randn(B, T, I)
+    lens = torch.tensor([T, 9, 1]) if ragged else torch.tensor([T] * B)
+    nd = 2 if bi else 1
+    h0 = torch.randn(nd, B, H) * 0.5
+    c0 = torch.randn(nd, B, H) * 0.5
+    init = (paddle.to_tensor(h0.numpy()), paddle.to_tensor(c0.numpy())) if kind == "LSTM" else paddle.to_tensor(h0.numpy())
+    y, st = shim(paddle.to_tensor(x.numpy()), init, paddle.to_tensor(lens.numpy()) if ragged else None)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x.double(), lens, batch_first=True, enforce_sorted=True)
+    with torch.no_grad():
+        yp, st_ref = ref(packed, (h0.double(), c0.double()) if kind == "LSTM" else h0.double())
+    y_ref, _ = torch.nn.utils.rnn.pad_packed_sequence(yp, batch_first=True, total_length=T)
+    assert (y._t.double() - y_ref).abs().max().item() < 1e-6
+    for b in range(B):  # zeros behind len, both directions
+        assert y._t[b, int(lens[b]):].abs().max().item() == 0 if int(lens[b]) < T else True
+    finals = st if kind == "LSTM" else (st,)
+    finals_ref = st_ref if kind == "LSTM" else (st_ref,)
+    for a, b_ in zip(finals, finals_ref):
+        assert (a._t.double() - b_).abs().max().item() < 1e-6
+
+
+def test_shim_rnn_state_dict_names_are_paddles():
+    """RNNBase registers each tensor as weight_ih_l0[_reverse] AND under 0.cell[_fw|_bw] (the names the reference's
+    checkpoints carry, deepspeech2/encoder.py:36-48)."""
+    paddle = _shim_paddle()
+    names = set(paddle.nn.LSTM(4, 8, direction="bidirect").state_dict().keys())
+    for n in ("weight_ih_l0", "weight_hh_l0_reverse", "0.cell_fw.weight_ih", "0.cell_bw.bias_hh"):
+        assert n in names, (n, sorted(names))
