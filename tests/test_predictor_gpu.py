@@ -269,3 +269,91 @@ def test_predict_long_with_given_segments():
     assert p.predict_long(audio_data=wav, vad_predictor=_Vad())["text"] == "，".join(r["text"] for r in parts[:2] if r["text"])
     with pytest.raises(NotImplementedError):
         p.predict_long(audio_data=wav)
+
+
+# ---- the reference's own audio file through the drop-in surface ------------------------------------------------------
+def _wav_fixture():
+    import os
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_wav.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _collapse_text(ids, vocab):
+    keep = np.concatenate([[True], ids[1:] != ids[:-1]]) & (ids != 0)
+    return "".join(vocab[i] for i in ids[keep]).replace("<space>", " ")
+
+
+def test_predict_reference_wav_gpu(tmp_path):
+    """/root/reference/dataset/test.wav (the file docs/infer.md:93 recognises; carried in tests/golden/ref_wav.npz as int16
+    samples) through PPASRPredictor.predict (file path, predict.py:163-187) and through predict_stream in 0.5 s PCM chunks
+    (predict.py:232-337), against what the REFERENCE's own PPASRPredictor source returned for the same file and the same
+    random-init configs/conformer.yml model (tests/golden/make_wav_goldens.py: reference predict.py / audio.py /
+    audio_featurizer.py / inference_predictor.py / ctc_greedy_decoder.py / conformer model source, on the shim, with
+    oracle/fbank_oracle.py as paddleaudio's fbank).  Token for token; every None / text of the streaming session."""
+    import os
+    import wave
+
+    import yaml
+    from ppasr_amd.predict import PPASRPredictor
+    from ppasr_amd.utils.synth import synth_vocabulary
+    z = _wav_fixture()
+    V = int(z["vocab_size"])
+    vocab = synth_vocabulary(V)
+    sd = conformer_state_dict(vocab_size=V, num_blocks=12, seed=int(z["sd_seed"]))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "configs", "conformer.yml"), "r", encoding="utf-8") as f:
+        cfg = yaml.load(f.read(), Loader=yaml.FullLoader)
+    cfg["decoder"] = "ctc_greedy"
+    p = PPASRPredictor(configs=cfg, state_dict=sd, vocab_list=vocab, warmup=True)
+    path = str(tmp_path / "test.wav")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(int(z["sample_rate"]))
+        w.writeframes(z["samples"].tobytes())
+
+    # (1) the feature front end on this audio: the reference-side features (float64 Kaldi restatement, every 16th frame)
+    feats = p._audio_featurizer.featurize(z["samples"].astype(np.float32) / 32768.0, int(z["sample_rate"]))
+    assert feats.shape == (int(z["n_feature_frames"]), 80)
+    e_f = float(np.abs(feats[::16] - z["feats_16"]).max())
+    print(f"test.wav: {feats.shape[0]} feature frames, |fbank - reference-side fbank| max {e_f:.2e}")
+    assert e_f < 2e-3
+
+    # (2) whole utterance: frame ids, then the text and the score of predict()
+    probs = p.predictor.predict_device(feats[np.newaxis], np.array([feats.shape[0]], np.int64))[0].cpu().numpy()
+    assert probs.shape[0] == z["ids"].shape[0]
+    ids = probs.argmax(-1)
+    differ = np.nonzero(ids != z["ids"])[0]
+    print(f"predict: {len(ids)} frames, ids differing from the reference's: {len(differ)} "
+          f"(reference top-2 probability margins there: {z['margin'][differ]}; smallest margin of the utterance {z['margin'].min():.1e})")
+    assert np.all(z["margin"][differ] < 1e-4), differ  # only a near-tie of the reference itself may differ
+    assert float(np.abs(probs.max(-1) - z["maxprob"]).max()) < 1e-3
+    res = p.predict(audio_data=path)
+    assert set(res) == {"text", "score"}
+    assert res["text"] == _collapse_text(ids, vocab)            # predict() == the collapse of the HIP path's own frames
+    if len(differ) == 0:
+        assert res["text"] == str(z["predict_text"])              # == the reference's PPASRPredictor.predict text
+        assert abs(res["score"] - float(z["predict_score"])) < 5e-2  # (score = 100 x mean max-prob of non-blank frames)
+
+    # (3) streaming session: 0.5 s PCM16 chunks, is_end on the last (infer_path.py:49-65)
+    pcm = z["samples"].tobytes()
+    step = int(int(z["sample_rate"]) * float(z["chunk_seconds"])) * 2
+    p.reset_stream()
+    calls = range(0, len(pcm), step)
+    assert len(calls) == len(z["stream_none"])
+    n_text_equal = n_text = 0
+    for k, i in enumerate(calls):
+        r = p.predict_stream(audio_data=pcm[i:i + step], is_end=(i + step >= len(pcm)))
+        assert (r is None) == bool(z["stream_none"][k]), k
+        if r is not None:
+            n_text += 1
+            n_text_equal += int(r["text"] == str(z["stream_texts"][k]))
+    assert int(p.predictor.offset[0]) == int(z["stream_out_frames"])
+    final = r
+    print(f"predict_stream: {len(calls)} calls, {n_text} texts, {n_text_equal} equal to the reference's; smallest reference "
+          f"top-2 margin of the session {z['stream_margin'].min():.1e}")
+    if z["stream_margin"].min() > 1e-4:
+        assert n_text_equal == n_text
+        assert final["text"] == str(z["stream_texts"][-1])
+        assert abs(final["score"] - float(z["stream_scores"][-1])) < 5e-2
+    p.reset_stream()
