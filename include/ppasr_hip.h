@@ -144,7 +144,11 @@ PPASR_API ppasr_status ppasr_set_debug_taps(ppasr_handle h, float* taps, size_t 
  * trainer.py:347).  With enable != 0, ppasr_encode computes, per utterance, only the rows its VALID output frames
  * depend on (t < ceil(len/4), or ceil(len/8) after a rate change, plus a few rows of slack for the grouped-attention /
  * stride / time-reduction reads): whole 32-row blocks behind them are skipped in every kernel and attention stops at
- * the last valid key.  Valid rows are bit-identical to the default mode; rows of `probs` / `logits` behind an
+ * the last valid key.  Valid rows are bit-identical to the default mode AS LONG AS both runs use the same block form of the
+ * layer kernels (ppasr_set_row_block): with the default rule (-1) the form is chosen from the rows actually computed
+ * (ppasr_set_lengths_hint), so a ragged call may take the 16-row kernels where the padded call takes the 32-row ones --
+ * the same sums in another order, equal to ~1e-6 relative; pin the form (16 / 32) where bit-identity between the modes,
+ * between ranks or between batch compositions is required.  Rows of `probs` / `logits` behind an
  * utterance's last valid frame are set to 0, `frame_argmax` to 0 (blank) and `frame_maxprob` to 0 -- pass frame_lens
  * to the decoders.  Default: off (= the reference's outputs for every row).  Built into the fused 256-column kernels and
  * the general layer route (widths 512 .., constructor options) behind the conv front ends (behind conv2d6 / conv2d8 and on
@@ -183,21 +187,41 @@ PPASR_API ppasr_status ppasr_set_row_block(ppasr_handle h, int rows);
  * sum of two fp16 pieces (22 significant bits; products of pieces are exact in fp32, accumulation in fp32), three
  * v_mfma_f32_32x32x16_f16 per 16-wide k step instead of eight fp32 MFMAs -- one feed-forward module deviates from float64
  * by 2.7e-7 where fp32 arithmetic deviates by 5.5e-7 (tools/experiments/r05/ffn_h3.hip), but NOT bit-identical to the
- * default mode, and an operand beyond 4 094 would overflow (operands are LayerNorm outputs and swish values).  The first
- * call re-packs the weights concerned on the device (second copy, ~ 10 MB per layer).  Built for the fused 256-wide routes:
- * Conformer / Efficient-Conformer -- feed-forward modules, Q/K/V, pointwise_conv2 (8-wave 32-row layer kernels), linear_out
- * + pointwise_conv1 (fused attention kernel); Squeezeformer -- both feed-forward modules of the 32-row layer kernels; all
- * three -- the second convolution of the 4x front end (then its own launch behind conv1), the input projection, the CTC
- * head.  The other block forms (16 rows, 16 waves), the split route for under-filled launches, the Efficient-Conformer's
- * stride layer, attention products, depthwise convolutions and streaming handles keep fp32 arithmetic.  PPASR_EUNSUPPORTED
- * on DeepSpeech2 handles and on the general layer route.  Measured: logits within 1e-6 .. 3e-6 of the
- * default mode's, the reference-source pin tests pass with unchanged criteria, 1.2 - 1.7 x faster end to end. */
+ * default mode.  The first call re-packs the weights concerned on the device (second copy, ~ 10 MB per layer).
+ * Range.  Weights are scaled by 2^8, activations by 2^4 before they are cut into fp16 pieces: a weight of magnitude >= 255.9
+ * makes this call fail with PPASR_EUNSUPPORTED (the handle stays in its previous mode); an activation beyond 4 094 at a
+ * GEMM input (ReLU outputs in front of conv2 / the input projection, swish values in front of W2, LayerNorm outputs
+ * elsewhere) is handled by the range guard below -- never Inf / NaN.
+ * Built for the fused 256-wide routes: Conformer / Efficient-Conformer -- feed-forward modules, Q/K/V, pointwise_conv2
+ * (8-wave 32-row layer kernels; depthwise kernel sizes 15 and 7), linear_out + pointwise_conv1 (fused attention kernel);
+ * Squeezeformer -- both feed-forward modules of the 32-row layer kernels (depthwise kernel sizes 31 and 15); all three -- the
+ * second convolution of the 4x front end (then its own launch behind conv1), the input projection, the CTC head.  The
+ * other block forms (16 rows, 16 waves), the split route for under-filled launches, the Efficient-Conformer's stride
+ * layer, attention products, depthwise convolutions and streaming handles keep fp32 arithmetic.  ppasr_gemm_coverage
+ * tells which of the three parts switched (a Conformer with cnn_module_kernel 31 gets the front end and the head only).
+ * PPASR_EUNSUPPORTED on DeepSpeech2 handles and on the general layer route.  Measured (DESIGN): logits within 1e-6 .. 3e-6
+ * of the default mode's, the reference-source pin tests pass with unchanged criteria, 1.2 - 1.7 x faster end to end. */
 #define PPASR_GEMM_F32 0
 #define PPASR_GEMM_F16X3 1
+#define PPASR_GEMM_COVERS_LAYERS 1 /* the encoder layers' GEMMs */
+#define PPASR_GEMM_COVERS_FRONT 2  /* conv2 + input projection of the 4x front end */
+#define PPASR_GEMM_COVERS_HEAD 4   /* the CTC head */
 PPASR_API ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode);
+PPASR_API int ppasr_gemm_coverage(ppasr_handle h); /* PPASR_GEMM_COVERS_* bits of the current mode; 0 in PPASR_GEMM_F32 */
+/* Range guard of PPASR_GEMM_F16X3.  The kernels saturate an out-of-range (or NaN) GEMM input to +-65 504 / 2^4 and count
+ * the event in a device counter.  enable = 1 (default): ppasr_encode reads the counters back after its launches (it then
+ * SYNCHRONISES `stream` before it returns) and, if the call saturated anything, runs the call again on the fp32 kernels:
+ * the caller always gets finite-input-exact results, the fp32 mode's bit for bit in that case.  enable = 0: ppasr_encode
+ * stays asynchronous, a saturated result stands, and the caller polls ppasr_gemm_guard_stats.  The counters are shared by
+ * the handles of a process: concurrent fp16 x3 handles can cause each other a spurious fp32 re-run, never a missed one. */
+PPASR_API ppasr_status ppasr_set_gemm_guard(ppasr_handle h, int enable);
+/* -> calls that were re-run on the fp32 kernels / saturation events seen by this handle (guard off: waits for the device,
+ * then counts the events since this handle last looked).  Either pointer may be NULL. */
+PPASR_API ppasr_status ppasr_gemm_guard_stats(ppasr_handle h, long long* fallbacks_host, long long* events_host);
 /* Host copy of the `lens` the following ppasr_encode calls of a batch of B utterances will pass (NULL / 0: forget it).
  * Only ever used to CHOOSE between kernel variants for ragged batches (ppasr_set_skip_padding), whose count of computed
- * rows the host cannot otherwise know; no kernel reads it and a wrong hint costs speed, never correctness. */
+ * rows the host cannot otherwise know; no kernel reads it.  A wrong hint costs speed; the variants differ in the order of
+ * their sums (~1e-6 relative, see ppasr_set_row_block), so two calls with different hints need not agree bit for bit. */
 PPASR_API ppasr_status ppasr_set_lengths_hint(ppasr_handle h, const int64_t* lens_host, int B);
 
 /* Host helper (no device work): Levenshtein distance between two int32 sequences -- what ppasr/utils/metrics.py:4-29

@@ -28,6 +28,7 @@ PPASR_OPT_POST_NORM, PPASR_OPT_CONCAT_AFTER, PPASR_OPT_NO_MACARON, PPASR_OPT_NO_
 PPASR_OPT_SQ_NO_ADAPTIVE_SCALE = 4096
 PPASR_GEMM_F32 = 0
 PPASR_GEMM_F16X3 = 1
+PPASR_GEMM_COVERS_LAYERS, PPASR_GEMM_COVERS_FRONT, PPASR_GEMM_COVERS_HEAD = 1, 2, 4
 KPROF_NAME_LEN = 160
 
 
@@ -64,6 +65,9 @@ SYMBOLS = [
     ("ppasr_set_ffn_split", ctypes.c_int, [_vp, ctypes.c_int]),
     ("ppasr_set_front_fused", ctypes.c_int, [_vp, ctypes.c_int]),
     ("ppasr_set_gemm_mode", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("ppasr_gemm_coverage", ctypes.c_int, [_vp]),
+    ("ppasr_set_gemm_guard", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("ppasr_gemm_guard_stats", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
     ("ppasr_edit_distance", ctypes.c_longlong, [_vp, ctypes.c_int, _vp, ctypes.c_int]),
     ("ppasr_ctc_beam_state_bytes", ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     ("ppasr_ctc_beam_search", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

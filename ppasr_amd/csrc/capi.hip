@@ -566,6 +566,27 @@ ppasr_status ppasr_set_front_fused(ppasr_handle h, int mode) {
   return PPASR_OK;
 }
 
+// ---- range guard of the fp16 x3 mode (csrc/h3.h): the two translation units' event counters, snapshotted in stream order
+__global__ void k_h3_snapshot(const unsigned int* a, const unsigned int* b, unsigned int* dst) {
+  dst[0] = *a;
+  dst[1] = *b;
+}
+
+static ppasr_status guard_alloc(ppasr_handle h) {
+  if (h->guard_dev) return PPASR_OK;
+  h->guard_ctr[0] = conformer_h3_ovf_counter();
+  h->guard_ctr[1] = squeezeformer_h3_ovf_counter();
+  if (!h->guard_ctr[0] || !h->guard_ctr[1]) return fail(PPASR_EHIP, "fp16 x3 range guard: counter symbols not found");
+  void* d = nullptr;
+  HIP_TRY(hipMalloc(&d, 4 * sizeof(unsigned int)));
+  h->allocs.push_back(d);
+  h->guard_dev = static_cast<unsigned int*>(d);
+  void* p = nullptr;
+  HIP_TRY(hipHostMalloc(&p, 4 * sizeof(unsigned int), hipHostMallocDefault));
+  h->guard_host = static_cast<unsigned int*>(p);
+  return PPASR_OK;
+}
+
 ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
   if (!h) return fail(PPASR_EINVAL, "null handle");
   if (mode != PPASR_GEMM_F32 && mode != PPASR_GEMM_F16X3) return fail(PPASR_EINVAL, "gemm mode: PPASR_GEMM_F32 or PPASR_GEMM_F16X3");
@@ -586,6 +607,14 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
       return fail(PPASR_EUNSUPPORTED, "fp16 x3 GEMMs: built for the fused 256-wide routes (feed-forward modules of Conformer / "
                                       "Efficient-Conformer / Squeezeformer layers; conv2 of the 4x front end)");
     const int d = h->desc.output_size, H = h->desc.linear_units;
+    {
+      const ppasr_status g = guard_alloc(h);
+      if (g != PPASR_OK) return g;
+    }
+    // weights are scaled by 2^8 into fp16: |w| >= 255.9 would overflow (k_repack_h3 counts such weights)
+    unsigned int w_before = 0, w_after = 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&w_before, h->guard_ctr[0], sizeof(unsigned int), hipMemcpyDeviceToHost));
     if (layers_ok && h->layers_h3.empty()) {
       std::vector<LayerW> view = h->layers;
       for (LayerW& L : view) {
@@ -649,10 +678,29 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
       HIP_TRY(hipDeviceSynchronize());
       h->embed_w_h3 = static_cast<const f32x4*>(dste);
     }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&w_after, h->guard_ctr[0], sizeof(unsigned int), hipMemcpyDeviceToHost));
+    if (w_after != w_before) {
+      // (the re-packed copies stay allocated until ppasr_destroy; the mode stays off and the views are dropped so that a
+      //  later call re-checks)
+      h->layers_h3.clear();
+      h->sq_layers_h3.clear();
+      h->head_w_h3 = h->conv2_w_h3 = h->embed_w_h3 = nullptr;
+      h->guard_seen[0] = w_after;
+      return fail(PPASR_EUNSUPPORTED, "fp16 x3 GEMMs: a weight of magnitude >= 255.9 does not fit the 2^8-scaled fp16 pieces");
+    }
+    h->guard_seen[0] = w_after;
+    HIP_TRY(hipMemcpy(&h->guard_seen[1], h->guard_ctr[1], sizeof(unsigned int), hipMemcpyDeviceToHost));
+    h->gemm_coverage = (layers_ok ? PPASR_GEMM_COVERS_LAYERS : 0) | (sq_ok ? PPASR_GEMM_COVERS_LAYERS : 0) |
+                       (front_ok ? PPASR_GEMM_COVERS_FRONT : 0) | (h->head_w_h3 ? PPASR_GEMM_COVERS_HEAD : 0);
+  } else {
+    h->gemm_coverage = 0;
   }
   h->gemm_mode = mode;
   return PPASR_OK;
 }
+
+int ppasr_gemm_coverage(ppasr_handle h) { return h ? h->gemm_coverage : 0; }
 
 ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable) {
   if (!h) return fail(PPASR_EINVAL, "null handle");
@@ -665,9 +713,9 @@ ppasr_status ppasr_set_skip_padding(ppasr_handle h, int enable) {
   return PPASR_OK;
 }
 
-ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* lens, int B, int T, float* probs,
-                          float* logits, int32_t* frame_argmax, float* frame_maxprob, void* workspace,
-                          size_t workspace_bytes, void* stream) {
+static ppasr_status encode_impl(ppasr_handle h, const float* feats, const int64_t* lens, int B, int T, float* probs,
+                                float* logits, int32_t* frame_argmax, float* frame_maxprob, void* workspace,
+                                size_t workspace_bytes, void* stream) {
   if (!h || !feats || !workspace) return fail(PPASR_EINVAL, "null argument");
   if (B <= 0 || T < h->min_frames()) return fail(PPASR_EINVAL, "need B > 0 and T >= 7 (conv2d6: 11, conv2d8: 15) frames");
   if (h->desc.model_type == PPASR_MODEL_DEEPSPEECH2) return fail(PPASR_EINVAL, "deepspeech2 handles use ppasr_ds2_encode");
@@ -910,6 +958,54 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   }
   if (skip) launch_zero_pad_rows(probs, logits, fa, fp, lens, B, Ti, mul, h->head.V, st);
   HIP_TRY(hipGetLastError());
+  return PPASR_OK;
+}
+
+ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* lens, int B, int T, float* probs,
+                          float* logits, int32_t* frame_argmax, float* frame_maxprob, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  if (!h) return fail(PPASR_EINVAL, "null argument");
+  if (h->gemm_mode != PPASR_GEMM_F16X3 || !h->gemm_guard || !h->guard_dev)
+    return encode_impl(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, workspace, workspace_bytes, stream);
+  // fp16 x3 mode, guard on: counters before / after the call's launches (stream order), one 16-byte read-back, and on a
+  // changed counter the same call again on the fp32 kernels (same weights, same workspace; the inputs are untouched)
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(k_h3_snapshot, dim3(1), dim3(1), 0, st, h->guard_ctr[0], h->guard_ctr[1], h->guard_dev);
+  ppasr_status rc = encode_impl(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, workspace, workspace_bytes, stream);
+  if (rc != PPASR_OK) return rc;
+  hipLaunchKernelGGL(k_h3_snapshot, dim3(1), dim3(1), 0, st, h->guard_ctr[0], h->guard_ctr[1], h->guard_dev + 2);
+  HIP_TRY(hipMemcpyAsync(h->guard_host, h->guard_dev, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  h->guard_seen[0] = h->guard_host[2];
+  h->guard_seen[1] = h->guard_host[3];
+  if (h->guard_host[0] == h->guard_host[2] && h->guard_host[1] == h->guard_host[3]) return PPASR_OK;
+  h->guard_events += (long long)(h->guard_host[2] - h->guard_host[0]) + (long long)(h->guard_host[3] - h->guard_host[1]);
+  h->guard_fallbacks += 1;
+  h->gemm_mode = PPASR_GEMM_F32;
+  rc = encode_impl(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, workspace, workspace_bytes, stream);
+  h->gemm_mode = PPASR_GEMM_F16X3;
+  return rc;
+}
+
+ppasr_status ppasr_set_gemm_guard(ppasr_handle h, int enable) {
+  if (!h) return fail(PPASR_EINVAL, "null handle");
+  h->gemm_guard = enable != 0;
+  return PPASR_OK;
+}
+
+ppasr_status ppasr_gemm_guard_stats(ppasr_handle h, long long* fallbacks_host, long long* events_host) {
+  if (!h) return fail(PPASR_EINVAL, "null handle");
+  if (h->guard_dev) {  // (guard off: the events since this handle last looked -- a device-wide wait, then the counters)
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned int now[2] = {0, 0};
+    HIP_TRY(hipMemcpy(&now[0], h->guard_ctr[0], sizeof(unsigned int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&now[1], h->guard_ctr[1], sizeof(unsigned int), hipMemcpyDeviceToHost));
+    h->guard_events += (long long)(now[0] - h->guard_seen[0]) + (long long)(now[1] - h->guard_seen[1]);
+    h->guard_seen[0] = now[0];
+    h->guard_seen[1] = now[1];
+  }
+  if (fallbacks_host) *fallbacks_host = h->guard_fallbacks;
+  if (events_host) *events_host = h->guard_events;
   return PPASR_OK;
 }
 

@@ -136,6 +136,14 @@ struct ppasr_model_s {
   const f32x4* embed_w_h3 = nullptr;  // ... and its input projection
   const f32x4* head_w_h3 = nullptr;   // the CTC head's weight [256][32 * n_tiles]
   std::vector<SqLayerW> sq_layers_h3;  // Squeezeformer: sq_layers[] with the two feed-forward modules' weights re-packed
+  int gemm_coverage = 0;      // PPASR_GEMM_COVERS_* of the current mode (ppasr_gemm_coverage)
+  // range guard of the fp16 x3 mode (csrc/h3.h, ppasr_set_gemm_guard / ppasr_gemm_guard_stats)
+  bool gemm_guard = true;
+  unsigned int* guard_ctr[2] = {nullptr, nullptr};  // device addresses of the two translation units' event counters
+  unsigned int* guard_dev = nullptr;                // [before a, before b, after a, after b]
+  unsigned int* guard_host = nullptr;               // pinned mirror
+  unsigned int guard_seen[2] = {0, 0};              // counter values this handle last read
+  long long guard_fallbacks = 0, guard_events = 0;
   int row_block = -1;         // ppasr_set_row_block: -1 = by grid size, 32 / 16 / kW16 = always that block form (rbt.h)
   std::vector<int64_t> lens_hint;  // ppasr_set_lengths_hint: host copy of the batch's lengths (route selection only)
   std::vector<hipEvent_t> ev_pool;
@@ -168,6 +176,7 @@ struct ppasr_model_s {
   ~ppasr_model_s() {
     for (void* p : allocs) (void)hipFree(p);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+    if (guard_host) (void)hipHostFree(guard_host);
   }
 };
 

@@ -160,6 +160,7 @@ void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, i
 // fp32 fragment-packed weight (pack_b: n_tiles x G k-groups x 1 KiB) -> the fp16 x3 packing of csrc/h3.h, same size
 void launch_repack_h3(const f32x4* src, f32x4* dst, int n_tiles, int G, hipStream_t st);
 inline bool conv_ffn_h3_supported(int ksize) { return ksize == 15 || ksize == 7; }
+unsigned int* conformer_h3_ovf_counter();  // device address of conformer_kernels.hip's range-guard counter (h3.h)
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
                     const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps = PadSkip{},

@@ -663,6 +663,7 @@ __global__ __launch_bounds__(256) void k_repack_h3(const float* __restrict__ src
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float v = g[((l & 31) + 32 * (e >> 2)) * 4 + (e & 3)] * kH3Sw;
+    if (!(fabsf(v) <= kH3Max)) atomicAdd(&g_h3_ovf, 1u);  // |w| >= 255.9: ppasr_set_gemm_mode refuses the mode
     hi[e] = (_Float16)v;
     lo[e] = (_Float16)(v - (float)hi[e]);
   }
@@ -670,6 +671,7 @@ __global__ __launch_bounds__(256) void k_repack_h3(const float* __restrict__ src
   *reinterpret_cast<f16x8*>(d) = hi;
   *reinterpret_cast<f16x8*>(d + 64 * 8) = lo;
 }
+unsigned int* conformer_h3_ovf_counter() { return h3_ovf_counter(); }
 void launch_repack_h3(const f32x4* src, f32x4* dst, int n_tiles, int G, hipStream_t st) {
   const long long n = (long long)n_tiles * (G >> 1) * 64;
   PPASR_LAUNCH(k_repack_h3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(src),

@@ -60,9 +60,13 @@ __global__ __launch_bounds__(kFT) void k_fbank(const float* __restrict__ x, int 
     if ((tid & 63) == 0) dred[tid >> 6] = s;
     __syncthreads();
     if (tid == 0) {
-      const double ms = (dred[0] + dred[1] + dred[2] + dred[3]) / (double)n;
-      const double rms_db = 10.0 * log10(ms != 0.0 ? ms : 1.0);
-      s_gain = (float)pow(10.0, ((double)target_db - rms_db) / 20.0);
+      // AudioSegment.rms_db / normalize / gain_db (audio.py:519-530,287-304,256-264) with numpy 1.x's scalar types: the mean
+      // square, rms_db and `target_db - rms_db` are float32, the power is taken in float64 and rounded to float32
+      // (pinned by tests/golden/ref_wav.npz: a float64 rms_db moves the gain by 3 ulp)
+      const float ms = (float)((dred[0] + dred[1] + dred[2] + dred[3]) / (double)n);
+      const float rms_db = 10.0f * (float)log10((double)(ms != 0.f ? ms : 1.f));
+      const float gain_db = target_db - rms_db;
+      s_gain = (float)pow(10.0, (double)gain_db / 20.0);
     }
     __syncthreads();
   } else if (tid == 0) {

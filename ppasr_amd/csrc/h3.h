@@ -10,8 +10,14 @@
 // profiles/r04f_split_bf16_microbench.txt): one 256-deep unit 2.6e-7 of float64 (an fp32 fmaf chain: 5.7e-7), the whole
 // feed-forward module 2.7e-7 (fp32 arithmetic 5.5e-7), the 12-block Conformer's logits as close to float64 as fp32
 // arithmetic is; 3.0 - 3.2 us per unit against 7.1 (the weight stream -- the same 4 bytes per weight -- is the bound).
-// Range: an activation beyond 4 094 (65 504 / 2^4) would overflow the high piece; the operands here are LayerNorm outputs
-// and swish(hidden) values.  [not guarded: the mode is opt-in, DESIGN.md 9.8]
+// Range guard.  An activation beyond 4 094 (65 504 / 2^4) does not fit the high piece (the GEMM inputs of conv2 and the
+// input projection are ReLU outputs, W2's are swish values: unbounded, checkpoint- and feature-dependent).  h3_split4
+// saturates such a value to +-65 504 (so nothing becomes Inf / NaN on the way) and counts the event in g_h3_ovf, a
+// monotonic device counter of this translation unit.  ppasr_encode snapshots the counters around its launches
+// (capi.hip: encode_guarded): with the guard on (default) a changed counter makes it run the call again on the fp32
+// kernels -- the caller gets the fp32 result and ppasr_gemm_guard_stats counts the fallback; with the guard off the
+// saturated result stands and the caller polls the same statistics.  Weights: |w| >= 255.9 (65 504 / 2^8) is refused by
+// ppasr_set_gemm_mode (k_repack_h3 counts them in the same counter).
 //
 // Layouts.  Weights: the fp32 fragment stream's geometry -- per 32-column tile and 16-wide k step two 1 KiB blocks
 // (high pieces, low pieces), lane l = 8 consecutive k (16 ks + 8 (l >> 5) ..) of column 32 tile + (l & 31) -- i.e. the
@@ -34,12 +40,27 @@ constexpr int kH3TileBytes = 2 * kPlaneH * 2;  // both planes of a [32][256] ope
 constexpr int kH3ExtraLds = 3 * kH3TileBytes - 3 * kRows * kLda * (int)sizeof(float);
 constexpr float kH3Sa = 16.f, kH3Sw = 256.f, kH3Inv = 1.f / (16.f * 256.f);
 
+constexpr float kH3Max = 65504.f;  // largest finite fp16
+
+// events of the range guard in this translation unit's kernels (see the header comment); never reset: callers compare
+// snapshots.  (No -fgpu-rdc: every .hip that includes this header owns one; h3_ovf_counter() is that one's address.)
+static __device__ unsigned int g_h3_ovf = 0;
+static inline unsigned int* h3_ovf_counter() {
+  void* p = nullptr;
+  return hipGetSymbolAddress(&p, HIP_SYMBOL(g_h3_ovf)) == hipSuccess ? static_cast<unsigned int*>(p) : nullptr;
+}
+
+// v: already scaled by 2^4.  Out-of-range (and NaN) inputs: saturated, counted.
 __device__ __forceinline__ void h3_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
+  bool bad = false;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    hi[i] = (_Float16)v[i];
-    lo[i] = (_Float16)(v[i] - (float)hi[i]);
+    const float c = fminf(fmaxf(v[i], -kH3Max), kH3Max);
+    bad |= c != v[i];
+    hi[i] = (_Float16)c;
+    lo[i] = (_Float16)(c - (float)hi[i]);
   }
+  if (bad) atomicAdd(&g_h3_ovf, 1u);
 }
 
 // fp32 tile [32][kLda] (complete: the caller has synchronised) -> operand planes at dst, which may overlap src: every

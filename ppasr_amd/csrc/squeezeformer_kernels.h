@@ -37,6 +37,7 @@ void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, float*
                    bool h3 = false);  // h3: the feed-forward module on the fp16 x3 route (csrc/h3.h; w = the layer's h3 view; rows 32)
 // the register depthwise conv of the transposed forms (and with them the fp16 x3 tail kernel) exists for kernels 31 / 15
 inline bool sq_h3_supported(int ksize, int Tp) { return Tp >= 4 && (ksize == 31 || ksize == 15); }
+unsigned int* squeezeformer_h3_ovf_counter();  // device address of this translation unit's range-guard counter (h3.h)
 // g_hist != nullptr: streaming (single stream, rows = frames of one chunk; left context from g_hist [ksize-1][256])
 void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float* x_out, float* qkv_next, const SqLayerW& w,
                     const f32x4* wqkv_next, const float* bqkv_next, const int64_t* lens, int M, int Tp, int mask_mul,

@@ -703,6 +703,8 @@ void launch_ln_rows(float* x, const float* g, const float* b, int M, hipStream_t
   PPASR_LAUNCH(k_ln_rows, rb_grid(M), dim3(kThreads), kLds1, st, x, g, b, M, ps);
 }
 
+unsigned int* squeezeformer_h3_ovf_counter() { return h3_ovf_counter(); }
+
 hipError_t configure_squeezeformer_kernels() {
   hipError_t e;
 #define SET_LDS(fn, bytes)                                                                                     \

@@ -217,6 +217,7 @@ class ConformerModel:
         """Conv2dSubsampling4 as one launch (-1 / 1, default) or two (0): ``ppasr_set_front_fused``; same results bit for
         bit.  Two launches are the faster form when another stream's kernels (a pipelined beam search) share the GPU."""
         _lib.check(self.lib.ppasr_set_front_fused(self._h, int(mode)))
+        self.front_fused = int(mode)  # (callers that switch it for one call restore this: parallel.RaggedPlan)
 
     def set_gemm_mode(self, mode="f32"):
         """Arithmetic of the feed-forward GEMMs (``ppasr_set_gemm_mode``): "f32" (default, exact fp32 products on
@@ -227,6 +228,27 @@ class ConformerModel:
         if mode not in modes:
             raise ValueError(f"gemm mode {mode!r}: 'f32' or 'f16x3'")
         _lib.check(self.lib.ppasr_set_gemm_mode(self._h, modes[mode]))
+
+    def gemm_coverage(self):
+        """Which parts the current GEMM mode switched (``ppasr_gemm_coverage``): a set out of {"layers", "front", "head"};
+        empty in "f32"."""
+        bits = int(self.lib.ppasr_gemm_coverage(self._h))
+        names = ((_lib.PPASR_GEMM_COVERS_LAYERS, "layers"), (_lib.PPASR_GEMM_COVERS_FRONT, "front"),
+                 (_lib.PPASR_GEMM_COVERS_HEAD, "head"))
+        return {n for b, n in names if bits & b}
+
+    def set_gemm_guard(self, enable=True):
+        """Range guard of the "f16x3" mode (``ppasr_set_gemm_guard``).  On (default): a call whose GEMM inputs left the
+        fp16 pieces' range (|activation| > 4 094) is run again on the fp32 kernels before ``ppasr_encode`` returns -- the
+        call then synchronises its stream.  Off: calls stay asynchronous, out-of-range inputs are saturated (never Inf /
+        NaN) and counted; poll ``gemm_guard_stats``."""
+        _lib.check(self.lib.ppasr_set_gemm_guard(self._h, 1 if enable else 0))
+
+    def gemm_guard_stats(self):
+        """-> (calls re-run on the fp32 kernels, saturation events seen) of this handle (``ppasr_gemm_guard_stats``)."""
+        f, e = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        _lib.check(self.lib.ppasr_gemm_guard_stats(self._h, ctypes.byref(f), ctypes.byref(e)))
+        return int(f.value), int(e.value)
 
     def set_row_block(self, rows=-1):
         """Block form of the layer kernels (``ppasr_set_row_block``): -1 = by grid size (16-row blocks for under-filled

@@ -360,9 +360,11 @@ class RaggedPlan:
         outs = []
         if self.ragged and self.batches:
             set_skip_padding_if_built(model, True)
-        if hasattr(model, "set_front_fused"):
-            # next to the previous call's beam search the two-launch front end is the faster one (see the C header)
-            model.set_front_fused(0 if self.pipeline else -1)
+        prev_front = getattr(model, "front_fused", -1)
+        if self.pipeline and hasattr(model, "set_front_fused"):
+            # next to the previous call's beam search the two-launch front end is the faster one (see the C header); for
+            # this call only: the caller's own setting is restored below
+            model.set_front_fused(0)
         if self.pipeline:
             # inputs ready (see __init__).  enc_stream does NOT wait for the previous call's decode: that is the overlap --
             # call i's decoder reads only probs(i) (its own allocation, record_stream below) and the decoder's state, the
@@ -390,6 +392,8 @@ class RaggedPlan:
                 set_skip_padding_if_built(model, False)
             if any(h is not None for h in self.hints):
                 model.set_lengths_hint(None)
+            if self.pipeline and hasattr(model, "set_front_fused"):
+                model.set_front_fused(prev_front)
         return outs
 
     def run(self, decoder):

@@ -52,8 +52,17 @@ def main():
         np.sctypes = {"int": [np.int8, np.int16, np.int32, np.int64], "uint": [np.uint8, np.uint16, np.uint32, np.uint64],
                       "float": [np.float16, np.float32, np.float64, np.longdouble],
                       "complex": [np.complex64, np.complex128, np.clongdouble], "others": [bool, object, bytes, str, np.void]}
+    from ppasr.data_utils.audio import AudioSegment
     from ppasr.model_utils.conformer.model import ConformerModel
     from ppasr.predict import PPASRPredictor
+
+    # numpy 1.x scalar promotion for AudioSegment.gain_db (data_utils/audio.py:256-264).  The reference only runs on
+    # numpy 1.x (np.sctypes above); there `np.float32 gain / 20.` is a float64 (legacy value-based promotion), the power is
+    # taken in float64 and rounded to float32 once when it scales the samples.  numpy 2 (NEP 50) keeps the whole expression
+    # in float32: a gain 1 ulp away, 63 of this file's 134 240 int16 samples one LSB away, log-mel values up to 5e-3 away.
+    # Handing the method the same value as a Python float reproduces the numpy 1.x arithmetic on numpy 2.
+    _gain_db = AudioSegment.gain_db
+    AudioSegment.gain_db = lambda self, gain: _gain_db(self, float(gain))
 
     with open(os.path.join(REFERENCE, "configs", "conformer.yml"), "r", encoding="utf-8") as f:
         configs = yaml.load(f.read(), Loader=yaml.FullLoader)

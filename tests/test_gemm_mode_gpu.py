@@ -141,3 +141,110 @@ def test_f16x3_mode_is_refused_where_it_is_not_built():
     assert wide.lib.ppasr_set_gemm_mode(wide._h, _lib.PPASR_GEMM_F32) == 0
     sd, m = _model(97, 1, 3)
     assert m.lib.ppasr_set_gemm_mode(m._h, 7) != 0
+
+
+# ---- range guard (csrc/h3.h, ppasr_set_gemm_guard / ppasr_gemm_guard_stats) ------------------------------------------
+def test_f16x3_range_guard_falls_back_to_fp32_and_counts():
+    """A GEMM input beyond the fp16 pieces' range (features x 1e4: ReLU(conv1) in front of conv2 reaches ~1e5 > 4 094) -- guard
+    on: the call returns the fp32 mode's result BIT FOR BIT (it was re-run on the fp32 kernels) and the fallback is counted;
+    guard off: finite (saturated) output, events counted, no fallback.  In-range inputs: no event, no fallback."""
+    V, blocks = 157, 2
+    sd, m = _model(V, blocks, 301)
+    m.set_row_block(32)
+    m.set_ffn_split(0)
+    x, la = synth_features(3, 203, lens=[203, 150, 64], seed=302)
+    big = (x * 1e4).astype(np.float32)
+    m.set_gemm_mode("f32")
+    _, ref_big = m.get_encoder_out(big, la, return_logits=True)
+    _, ref = m.get_encoder_out(x, la, return_logits=True)
+    ref_big, ref = ref_big.cpu().numpy(), ref.cpu().numpy()
+    assert np.isfinite(ref_big).all()
+    m.set_gemm_mode("f16x3")
+    assert m.gemm_coverage() == {"layers", "front", "head"}
+    assert m.gemm_guard_stats() == (0, 0)
+    # in range: the mode runs, nothing is counted
+    _, lh = m.get_encoder_out(x, la, return_logits=True)
+    lh = lh.cpu().numpy()
+    assert not np.array_equal(lh, ref) and _rel(lh, ref) < 2e-5
+    assert m.gemm_guard_stats() == (0, 0)
+    # out of range, guard on (default)
+    _, lb = m.get_encoder_out(big, la, return_logits=True)
+    lb = lb.cpu().numpy()
+    f, e = m.gemm_guard_stats()
+    print(f"guard on: fallbacks {f}, events {e}")
+    assert f == 1 and e > 0
+    assert np.array_equal(lb, ref_big)
+    tokens_g, n_g, _ = m.encode_greedy(big, la)
+    assert m.gemm_guard_stats()[0] == 2
+    m.set_gemm_mode("f32")
+    tokens_r, n_r, _ = m.encode_greedy(big, la)
+    assert torch.equal(tokens_g, tokens_r) and torch.equal(n_g, n_r)
+    # out of range, guard off: saturated, finite, counted -- and not the fp32 result
+    m.set_gemm_mode("f16x3")
+    m.set_gemm_guard(False)
+    _, ls = m.get_encoder_out(big, la, return_logits=True)
+    ls = ls.cpu().numpy()
+    f2, e2 = m.gemm_guard_stats()
+    print(f"guard off: fallbacks {f2}, events {e2}")
+    assert np.isfinite(ls).all()
+    assert f2 == 2 and e2 > e
+    assert not np.array_equal(ls, ref_big)
+    # guard back on, in-range input: the mode's own result again, no new fallback
+    m.set_gemm_guard(True)
+    _, lh2 = m.get_encoder_out(x, la, return_logits=True)
+    assert np.array_equal(lh2.cpu().numpy(), lh)
+    assert m.gemm_guard_stats()[0] == 2
+
+
+def test_f16x3_range_guard_squeezeformer():
+    """The Squeezeformer kernels live in another translation unit (their own event counter): swish(hidden) beyond the range
+    through a scaled feed-forward weight... is not reachable without touching the checkpoint, so the feature route again
+    (the front end is shared) plus an in-range pass that must count nothing."""
+    V, L = 101, 3
+    sd = squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=311, perturb_norm=True, streaming=True)
+    conf = dict(encoder_dim=256, output_size=256, attention_heads=4, num_blocks=L, reduce_idx=1, recover_idx=2,
+                feed_forward_expansion_factor=8, cnn_module_kernel=31)
+    m = SqueezeformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    m.set_row_block(32)
+    x, la = synth_features(3, 203, lens=[203, 150, 64], seed=312)
+    m.set_gemm_mode("f32")
+    _, ref = m.get_encoder_out((x * 1e4).astype(np.float32), la, return_logits=True)
+    m.set_gemm_mode("f16x3")
+    _, a = m.get_encoder_out(x, la, return_logits=True)
+    assert m.gemm_guard_stats() == (0, 0) and np.isfinite(a.cpu().numpy()).all()
+    _, b = m.get_encoder_out((x * 1e4).astype(np.float32), la, return_logits=True)
+    assert m.gemm_guard_stats()[0] == 1
+    assert torch.equal(b, ref)
+
+
+def test_f16x3_mode_refuses_weights_beyond_the_fp16_range():
+    """|w| >= 255.9 does not fit the 2^8-scaled pieces: ppasr_set_gemm_mode fails with PPASR_EUNSUPPORTED, the handle stays in
+    the default mode and keeps working."""
+    V, blocks = 157, 2
+    sd = conformer_state_dict(vocab_size=V, num_blocks=blocks, seed=303, perturb_norm=True)
+    k = "encoder.encoders.1.feed_forward.w_1.weight"
+    sd[k] = sd[k].copy()
+    sd[k][3, 5] = 300.0
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=blocks, cnn_module_kernel=15)
+    m = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    x, la = synth_features(2, 131, seed=304)
+    _, before = m.get_encoder_out(x, la, return_logits=True)
+    with pytest.raises(_lib.PPASRHipError) as ei:
+        m.set_gemm_mode("f16x3")
+    assert ei.value.status == _lib.PPASR_EUNSUPPORTED
+    assert m.gemm_coverage() == set()
+    _, after = m.get_encoder_out(x, la, return_logits=True)
+    assert torch.equal(before, after)
+
+
+def test_f16x3_coverage_reports_uncovered_layer_kernels():
+    """cnn_module_kernel 31 on a Conformer: the layer kernels have no fp16 x3 form (7 / 15 only) -- the mode is accepted for
+    the front end and the head, and ppasr_gemm_coverage says so."""
+    V, blocks = 157, 1
+    sd = conformer_state_dict(vocab_size=V, num_blocks=blocks, seed=305, cnn_module_kernel=31)
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=blocks, cnn_module_kernel=31)
+    m = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    m.set_gemm_mode("f16x3")
+    assert m.gemm_coverage() == {"front", "head"}
+    m.set_gemm_mode("f32")
+    assert m.gemm_coverage() == set()

@@ -154,3 +154,29 @@ def test_full_size_deepspeech2_oracle_matches_reference_source():
     assert e_p < TOL and e_m < TOL
     clear = margin > 1e-3
     assert np.array_equal(p.argmax(-1)[clear], ids[clear])
+
+
+def test_reference_wav_oracle_chain_matches_reference_predictor_source():
+    """tests/golden/ref_wav.npz (the reference's PPASRPredictor source on /root/reference/dataset/test.wav): the oracle chain
+    fbank_oracle.featurize -> ConformerOracle -> ctc_decoders_oracle.greedy_tokens reproduces the reference's features
+    (the reference's AudioSegment.normalize / to('int16') source ran in front of the same fbank arithmetic), frame ids and
+    text."""
+    from oracle import fbank_oracle
+    from oracle.ctc_decoders_oracle import greedy_tokens
+    from ppasr_amd.utils.synth import conformer_state_dict, synth_vocabulary
+    with np.load(os.path.join(HERE, "golden", "ref_wav.npz")) as z:
+        z = {k: z[k] for k in z.files}
+    V = int(z["vocab_size"])
+    feats = fbank_oracle.featurize(z["samples"].astype(np.float32) / 32768.0, int(z["sample_rate"])).astype(np.float32)
+    assert feats.shape[0] == int(z["n_feature_frames"])
+    assert float(np.abs(feats[::16] - z["feats_16"]).max()) < 1e-4
+    sd = conformer_state_dict(vocab_size=V, num_blocks=12, seed=int(z["sd_seed"]))
+    probs = ConformerOracle(sd, num_blocks=12).get_encoder_out(feats[None], np.array([feats.shape[0]]))[0].numpy()
+    ids = probs.argmax(-1)
+    clear = z["margin"] > 1e-4
+    assert np.array_equal(ids[clear], z["ids"][clear])
+    assert float(np.abs(probs.max(-1) - z["maxprob"]).max()) < TOL
+    tok, _, _ = greedy_tokens(probs)
+    vocab = synth_vocabulary(V)
+    if clear.all():
+        assert "".join(vocab[i] for i in tok).replace("<space>", " ") == str(z["predict_text"])

@@ -402,10 +402,13 @@ def test_cfg5_decode_ragged_end_to_end(ref_full, mode):
             top = _oracle_decode(_oracle(), pr[i, :fl[i]], rc.BEAM["beam_size"], rc.BEAM["cutoff_prob"], rc.BEAM["cutoff_top_n"], 0, 1)
             assert top[0][0] == tokens[j, :n[j]].tolist(), i
         # the pipelined plan object (encoder and beam search on two streams) returns the same hypotheses, call after call
+        model.set_front_fused(1)  # the caller's own setting: the pipelined plan switches it per call and must restore it
         plan = RaggedPlan(model, feats, [int(v) for v in lens], mode="merged", pipeline=True)
         for _ in range(3):
             t2, n2, _ = plan.run(dec)
         plan.sync()
+        assert model.front_fused == 1
+        model.set_front_fused(-1)
         t2, n2 = t2.cpu().numpy(), n2.cpu().numpy()
         for j, i in enumerate(perm):
             assert np.array_equal(t2[i, :n2[i]], tokens[j, :n[j]]), i
