@@ -118,7 +118,6 @@ __global__ __launch_bounds__(64 * AttnT<DK>::WV, DK == 64 ? PPASR_ATTN_OCC : 2) 
   const int T1 = a.T1, F1 = a.q_frames;
   int T2 = a.T2, F2 = a.kv_frames;
   const int dm = a.dm;
-  const int dm_shift = 31 - __builtin_clz(dm);  // (grouped heads: dm is a power of two on this kernel)
   const float* __restrict__ qb = a.q + (size_t)b * F1 * a.q_stride;
   const float* __restrict__ kbp = a.k + (size_t)b * F2 * a.k_stride;
   const float* __restrict__ vbp = a.v + (size_t)b * F2 * a.v_stride;
@@ -136,9 +135,11 @@ __global__ __launch_bounds__(64 * AttnT<DK>::WV, DK == 64 ? PPASR_ATTN_OCC : 2) 
   const int NS = C::qb_ns(my_qi);         // key splits of that query block
   const int q0g = li * QB * 32;           // the workgroup's first query token
   const int q0 = q0g + my_qi * 32;        // this wave's query block
-  auto split = [&](int flat, int& frame, int& feat) {
-    frame = flat >> dm_shift;
-    feat = flat & (dm - 1);
+  // grouped heads: flat feature c (< G * dm) of token tok = (frame G * tok + c / dm, feature c % dm); any width
+  auto split = [&](int tok, int c, int& frame, int& feat) {
+    const int k = (c >= dm) + (c >= 2 * dm);
+    frame = G * tok + k;
+    feat = c - k * dm;
   };
   // Everything the first MFMA needs is requested BEFORE the utterance's length is looked at: the length load, the query
   // rows and the first K' burst are then one memory round trip instead of three dependent ones (the launches of a ragged
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(64 * AttnT<DK>::WV, DK == 64 ? PPASR_ATTN_OCC : 2) 
     f32x4 q = {0.f, 0.f, 0.f, 0.f};
     if (q0g + row < T1) {
       int frame = q0g + row, feat = h * DK + 4 * f4;
-      if (G != 1) split((q0g + row) * (G * dm) + h * DK + 4 * f4, frame, feat);
+      if (G != 1) split(q0g + row, h * DK + 4 * f4, frame, feat);
       if (frame < F1) q = *reinterpret_cast<const f32x4*>(qb + (size_t)frame * a.q_stride + feat);
     }
     const f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + h * DK + 4 * f4);
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(64 * AttnT<DK>::WV, DK == 64 ? PPASR_ATTN_OCC : 2) 
   for (int c3 = 0; c3 < NC2; ++c3) {
     fo_c[c3] = 0;
     feat_c[c3] = h * DK + 64 * c3;
-    if (G != 1) split(h * DK + 64 * c3, fo_c[c3], feat_c[c3]);
+    if (G != 1) split(0, h * DK + 64 * c3, fo_c[c3], feat_c[c3]);
     const long long rows = (long long)F2 - fo_c[c3] - 1;  // last row relative to the chunk's base row
     rs_k[c3] = buf_rsrc(kbp + (size_t)fo_c[c3] * a.k_stride + feat_c[c3], rows < 0 ? 0 : (size_t)rows * a.k_stride * 4 + 256);
     rs_p[c3] = buf_rsrc(ptab + (size_t)fo_c[c3] * a.pos_stride * dm + feat_c[c3], rows < 0 ? 0 : (size_t)rows * a.pos_stride * dm * 4 + 256);
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(64 * AttnT<DK>::WV, DK == 64 ? PPASR_ATTN_OCC : 2) 
         o *= inv;
         if (q0r + row < T1) {
           int frame = q0r + row, feat = h * DK + 4 * f4;
-          if (G != 1) split((q0r + row) * (G * dm) + h * DK + 4 * f4, frame, feat);
+          if (G != 1) split(q0r + row, h * DK + 4 * f4, frame, feat);
           if (frame < F1) *reinterpret_cast<f32x4*>(ctx + (size_t)frame * dm + feat) = o;  // x[:, :T - padding_q] (attention.py:124-125)
         }
       }
@@ -403,15 +404,9 @@ __global__ __launch_bounds__(64 * AttnT<DK>::WV, DK == 64 ? PPASR_ATTN_OCC : 2) 
 
 constexpr size_t kLdsAttnT64 = AttnT<64>::LDS_FLOATS * sizeof(float), kLdsAttnT192 = AttnT<192>::LDS_FLOATS * sizeof(float);
 
-// -> true if the launch was taken (plain heads; grouped heads on power-of-two widths); PPASR_ATTN_LEGACY=1: never
+// -> false: a configuration the kernels do not take (group sizes other than 1 / 3, rows not 16-byte aligned)
 bool launch_attention_t(const AttnArgs& a, int B, int H, hipStream_t st) {
-  static const bool legacy = [] {
-    const char* e = std::getenv("PPASR_ATTN_LEGACY");  // (A/B measurements against the round-1 kernel)
-    return e && e[0] == '1';
-  }();
-  if (legacy) return false;
   if (a.group != 1 && a.group != 3) return false;
-  if (a.group == 3 && (a.dm & (a.dm - 1)) != 0) return false;
   if ((a.q_stride | a.k_stride | a.v_stride | a.dm) & 3) return false;
   const int nqb = (a.T1 + 31) / 32;
   const int pairs8 = (B * H + 7) / 8;

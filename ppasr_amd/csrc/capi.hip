@@ -456,25 +456,14 @@ bool block_tables_enabled() {
   return on;
 }
 
-bool conv12_enabled(const ppasr_model_s* m) {
-  static const bool on = [] {
-    const char* e = getenv("PPASR_CONV12");  // (A/B switch: 0 = k_conv1 + k_gemm_stream<conv2>)
-    return !(e && e[0] == '0');
-  }();
-  return m->front_fused != 0 && on;
-}
+bool conv12_enabled(const ppasr_model_s* m) { return m->front_fused != 0; }  // ppasr_set_front_fused
 
 int row_block_for(const ppasr_model_s* m, int B, int Tcur, int mul, int slack, bool skip) {
-  // 32 rows on 16 waves (rbt.h kW16) in place of the 8-wave 32-row kernels: OPT-IN (PPASR_W16=1, or per handle with
-  // ppasr_set_row_block(PPASR_ROW_BLOCK_32_W16)).  Measured on the three bench configurations it is a wash -- the
+  // 32 rows on 16 waves (rbt.h kW16) in place of the 8-wave 32-row kernels: OPT-IN per handle,
+  // ppasr_set_row_block(PPASR_ROW_BLOCK_32_W16).  Measured on the three bench configurations it is a wash -- the
   // feed-forward streams gain 3 % (92.6 against 89.6 % of the matrix-pipe rate, tools/phase_ts.py --t), the 16-wave
   // depthwise-conv phase requests each window row twice as often and the launch is longer: cfg2 5.99 ms against 5.92,
-  // cfg4 9.10 = 9.10, cfg5 6.73 against 6.80 (DESIGN.md "Measured and not adopted").
-  static const bool w16_on = [] {
-    const char* e = getenv("PPASR_W16");
-    return e && e[0] == '1';
-  }();
-  const int full = w16_on ? kW16 : 32;
+  // cfg4 9.10 = 9.10, cfg5 6.73 against 6.80 (NOTES.md "Measured and not adopted").
   if (m->row_block == 16 || m->row_block == 32 || m->row_block == kW16) return m->row_block;
   long long rows = (long long)B * Tcur;
   if (skip && (int)m->lens_hint.size() == B) {
@@ -496,8 +485,8 @@ int row_block_for(const ppasr_model_s* m, int B, int Tcur, int mul, int slack, b
   }();
   const long long b32 = (rows + 31) / 32, b16 = (rows + 15) / 16;
   if (b32 <= min_blocks) return 32;  // (split route: the 8-wave kernels)
-  const double c32 = (w16_on ? 0.88 : 1.0) * (double)((b32 + 255) / 256), c16 = 0.52 * (double)((b16 + 255) / 256);
-  return c16 < c32 ? 16 : full;
+  const double c32 = (double)((b32 + 255) / 256), c16 = 0.52 * (double)((b16 + 255) / 256);
+  return c16 < c32 ? 16 : 32;
 }
 
 extern "C" {

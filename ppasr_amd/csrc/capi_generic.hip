@@ -474,13 +474,7 @@ __global__ void k_g_kv_append(const float* __restrict__ qkv, float* __restrict__
   vc[i] = qkv[row * 3 * D + 2 * D + c];
 }
 
-inline bool fused_ffn512() {
-  static const bool on = [] {
-    const char* e = std::getenv("PPASR_GEN_FUSED_FFN");  // (0: LayerNorm + two GEMM launches, for A/B measurements)
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+inline bool fused_ffn512() { return true; }  // width 512: the fused feed-forward kernels (other widths: LayerNorm + two GEMM launches)
 inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
 inline dim3 blocks(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 

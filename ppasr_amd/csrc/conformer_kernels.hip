@@ -427,11 +427,7 @@ void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b
 // block per CU takes ~ 140).  Asking for more than half of the LDS makes the workgroups exclusive: 256 are placed, a
 // skipped one frees its CU for the next, and the active blocks end up one per CU.
 size_t ragged_lds(size_t lds, const PadSkip& ps, int n_blocks) {
-  static const bool on = [] {
-    const char* e = std::getenv("PPASR_RAGGED_EXCLUSIVE");  // (0: the kernels' own footprints, for A/B measurements)
-    return !(e && e[0] == '0');
-  }();
-  return (on && ps.lens && n_blocks > 256 && lds < kLdsExclusive) ? kLdsExclusive : lds;
+  return (ps.lens && n_blocks > 256 && lds < kLdsExclusive) ? kLdsExclusive : lds;
 }
 
 void launch_embed(const float* y2, const FrontW& fw, float* x0, int M, int K, float xscale, bool scale_before_bias,
@@ -709,334 +705,16 @@ void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, i
 }
 
 // -------------------------------------------------------------------------------------
-// Attention: RelPositionMultiHeadedAttention.forward + forward_attention
-// (attention.py:198-262, 86-126).  scores = ((q+u) k^T + (q+v) p^T) / sqrt(dk) (rel_shift is
-// disabled in the reference, :256-258) == one contraction over the concatenated operands
-// Q' = [q+u | q+v], K' = [k | p].  Key-padding mask from lengths (token j masked iff
-// mask_mul*j >= len[b], subsampling.py:115), softmax, masked probs -> 0, times V.  Flash-style over
-// 128-key blocks with running (max, sum) so any key count fits the same LDS footprint.
-// Block = (32-query tile, head, utterance); waves split keys for QK^T and (column tiles, key half) for PV.
-//
-// DK = 64: plain heads.  DK = 192: GroupedRelPositionMultiHeadedAttention of the Efficient-Conformer
-// (efficient_conformer/attention.py:40-79,128-193, group_size 3): the time axis is zero-padded to a
-// multiple of 3 and every 3 consecutive frames (3 x 256 contiguous floats) are re-cut into 4 "heads"
-// of 192, i.e. token j / head h / feature f lives at flat offset j*768 + h*192 + f of the utterance's
-// [T'][256] activations -- the same formula as DK = 64 with a token stride of 256.
+// Attention: RelPositionMultiHeadedAttention.forward + forward_attention (attention.py:198-262, 86-126) and the
+// Efficient-Conformer's grouped form (efficient_conformer/attention.py:40-79,128-193): attention_kernels.hip
+// (k_attention_t<64 / 192>); the batched plain-head layers run it fused with the out-projection (k_attn_out_glu below).
 // -------------------------------------------------------------------------------------
-constexpr int kSld = 129;
-template <int DK>
-struct AttnCfg {
-  static constexpr int G = DK / 64;        // frames per token
-  static constexpr int NG = 2 * DK / 8;    // 8-wide k-groups of the score contraction over K' = [k | p]
-  static constexpr int QLD = 2 * DK + 4;
-  static constexpr int NCT = DK / 32;      // 32-column tiles of the context
-  static constexpr int NO = NCT / 2;       // context column tiles per wave
-  static constexpr int QT = 64;            // queries per workgroup (two MFMA row tiles)
-  static constexpr int LDS_FLOATS = QT * QLD + QT * kSld + 3 * QT;
-};
-
-// Block = (64-query tile, head, utterance), 4 waves.  Per 128-key block:
-//   S phase : wave w owns keys [32w, 32w+32); the B operand (K' rows) is read straight from global / L2 into
-//             registers (lane = key, 4 consecutive features per load, the row-block GEMM's fragment trick) in
-//             double-buffered bursts of 4 k-groups (whole cache lines) -- no LDS staging, no barriers; A = Q' from
-//             LDS; two row tiles share each B load.
-//   softmax : online (running max / sum per query row), 16-lane groups handle one row each (4 rows per wave-op).
-//   PV      : wave = (column-tile group, key half); B = V rows from global (one dword per lane per MFMA, two
-//             coalesced 128-B segments per wave-load), A = P from LDS.
-// Three barriers per key block; LDS holds only Q' and the score block, so several workgroups share a CU.
-// W256: model width 256 known at compile time (the grouped heads' flat-offset arithmetic folds to shifts / masks: the
-// fused-route Efficient-Conformer; a run-time width costs k_attention<192> 17 %)
-template <int DK, bool W256 = false>
-__global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
-  using C = AttnCfg<DK>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Qs = smem;                      // [64][QLD]  Q' = [q+u | q+v]
-  float* Ss = Qs + C::QT * C::QLD;       // [64][129]  scores / probabilities of the current key block; final O scratch
-  float* stM = Ss + C::QT * kSld;        // running max   [64]
-  float* stL = stM + C::QT;              // running sum   [64]
-  float* stA = stL + C::QT;              // rescale alpha [64]
-  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-  const int q0 = blockIdx.x * C::QT, h = blockIdx.y, b = blockIdx.z;
-  const int T1 = a.T1;                           // query tokens
-  int T2 = a.T2, F2 = a.kv_frames;               // key tokens / valid key frames (== tokens when G == 1)
-  const int F1 = a.q_frames;
-  const float* __restrict__ qb = a.q + (size_t)b * F1 * a.q_stride;
-  const float* __restrict__ kbp = a.k + (size_t)b * F2 * a.k_stride;
-  const float* __restrict__ vbp = a.v + (size_t)b * F2 * a.v_stride;
-  const int dm = W256 ? kD : a.dm;  // model width: row stride of ptab / ctx (256; the general layer route: 512 .. 1024)
-  // grouped heads cut a token's G x dm contiguous floats into dm / 64 heads of 192: flat offset -> (frame, feature)
-  const int dm_shift = (dm & (dm - 1)) == 0 ? 31 - __builtin_clz(dm) : -1;  // (768: no shift)
-  auto split = [&](int flat, int& frame, int& feat) {
-    if (W256) {
-      frame = flat >> 8;
-      feat = flat & 255;
-    } else if (dm_shift >= 0) {
-      frame = flat >> dm_shift;
-      feat = flat & (dm - 1);
-    } else {
-      frame = flat / dm;
-      feat = flat - frame * dm;
-    }
-  };
-  const float* __restrict__ ptab = a.ptab + (size_t)a.pos0 * dm;
-  if (a.sess) {  // multi-session streaming: per-session cache slot, length and position
-    const SessDesc d = a.sess[b];
-    T2 = F2 = d.cache_t + T1;
-    kbp = a.k + (size_t)d.sess * a.sess_stride;
-    vbp = a.v + (size_t)d.sess * a.sess_stride;
-    ptab = a.ptab + (size_t)d.pos0 * dm;
-  }
-  const int pstride = a.pos_stride;
-  float* __restrict__ ctx = a.ctx + (size_t)b * F1 * dm;
-  const int64_t len_b = a.lens ? a.lens[b] : (int64_t)a.mask_mul * T2;
-  if (a.pad_skip > 0 && a.lens) {  // ragged batch: query tokens behind the needed frames, key blocks behind the valid keys
-    const int64_t lb = len_b > 0 ? len_b : 0;
-    const int fmul = a.mask_mul / C::G;  // frame f is valid iff fmul * f < len
-    const int need_frames = (int)min((int64_t)F1, (lb + fmul - 1) / fmul + (a.pad_skip - 1));
-    if (q0 * C::G >= need_frames) return;  // (uniform: before any barrier)
-    T2 = (int)max((int64_t)1, min((int64_t)T2, (lb + a.mask_mul - 1) / a.mask_mul));
-  }
-  // element (token j, head h, feature f) lives at flat offset j*G*256 + h*DK + f of the utterance's [frames][256]
-  // activations (G = 1: plain heads; G = 3: pad4group's re-cut of 3 frames into 4 heads of 192); zero beyond the
-  // valid frames (the zero-padded tail group).
-  auto tok4 = [&](const float* base, int stride, int nframes, int j, int f) -> f32x4 {
-    int frame = j, feat = h * DK + f;
-    if (C::G != 1) split(j * (C::G * dm) + h * DK + f, frame, feat);
-    if (frame >= nframes) return f32x4{0.f, 0.f, 0.f, 0.f};
-    return *reinterpret_cast<const f32x4*>(base + (size_t)frame * stride + feat);
-  };
-  // K' fragment of k-group g for key j: features 8g+4*(lane>>5).. ; first DK/8 groups from k, the rest from p
-  auto kfrag = [&](int j, int g) -> f32x4 {
-    if (C::G == 1) {
-      // keys >= T2 are masked to -inf afterwards, so any in-bounds row will do: clamp instead of branching
-      const int jc = min(j, T2 - 1);
-      const float* base = (g < DK / 8) ? kbp + (size_t)jc * a.k_stride + h * DK + 8 * g + 4 * (lane >> 5)
-                                       : ptab + (size_t)jc * pstride * dm + h * DK + 8 * (g - DK / 8) + 4 * (lane >> 5);
-      return *reinterpret_cast<const f32x4*>(base);
-    }
-    if (j >= T2) return f32x4{0.f, 0.f, 0.f, 0.f};
-    const int f = 8 * (g < DK / 8 ? g : g - DK / 8) + 4 * (lane >> 5);
-    if (g < DK / 8) return tok4(kbp, a.k_stride, F2, j, f);
-    int frame, feat;
-    split(j * (C::G * dm) + h * DK + f, frame, feat);
-    if (frame >= F2) return f32x4{0.f, 0.f, 0.f, 0.f};
-    return *reinterpret_cast<const f32x4*>(ptab + (size_t)frame * pstride * dm + feat);
-  };
-  auto vval = [&](int j, int col) -> float {
-    if (C::G == 1) return vbp[(size_t)min(j, T2 - 1) * a.v_stride + h * DK + col];  // P is 0 for keys >= T2
-    if (j >= T2) return 0.f;
-    int frame, feat;
-    split(j * (C::G * dm) + h * DK + col, frame, feat);
-    return frame < F2 ? vbp[(size_t)frame * a.v_stride + feat] : 0.f;
-  };
-
-  // ---- Q' ----
-#pragma unroll
-  for (int i = 0; i < C::QT * DK / 4 / 256; ++i) {
-    int idx = tid + 256 * i;
-    int row = idx / (DK / 4), f4 = idx - row * (DK / 4);
-    f32x4 q = {0.f, 0.f, 0.f, 0.f};
-    if (q0 + row < T1) q = tok4(qb, a.q_stride, F1, q0 + row, f4 * 4);
-    f32x4 u = *reinterpret_cast<const f32x4*>(a.pos_u + h * DK + f4 * 4);
-    f32x4 v = *reinterpret_cast<const f32x4*>(a.pos_v + h * DK + f4 * 4);
-    *reinterpret_cast<f32x4*>(Qs + row * C::QLD + f4 * 4) = q + u;
-    *reinterpret_cast<f32x4*>(Qs + row * C::QLD + DK + f4 * 4) = q + v;
-  }
-  if (tid < C::QT) {
-    stM[tid] = -INFINITY;
-    stL[tid] = 0.f;
-  }
-  f32x16 acc_o[2][C::NO];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int t = 0; t < C::NO; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc_o[mt][t][r] = 0.f;
-  const int ctg = wave & 1, kh = wave >> 1;
-  const float score_mul = DK == 64 ? 0.125f : 0.07216878364870322f;  // 1 / sqrt(d_k [* group_size])
-  constexpr int PFV = 8, NSG = C::NG / 4;
-  static_assert(NSG % 2 == 0, "the K' double buffer keeps its parity across key blocks");
-  // K' fragments in bursts of 4 k-groups = one whole 128-byte line of the lane's key row (its 16-byte pieces of 4
-  // consecutive k-groups are requested back to back, so the line comes from L2 once; one k-group at a time the 4 waves
-  // of the workgroups sharing a CU push their 32 lines per load through the 32 KiB L1 between two uses of a line --
-  // the measure k_attn_out_glu took in round 2), double buffered: super-group sg + 1 is in flight while sg feeds the
-  // MFMAs, the first one of the next key block across the softmax / PV phases
-  f32x4 kq[2][4];
-  auto load_sg = [&](int buf, int j, int sg) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) kq[buf][i] = kfrag(j, 4 * sg + i);
-  };
-  float ringv[PFV][C::NO];  // V values, primed before the softmax pass
-  load_sg(0, wave * 32 + (lane & 31), 0);
-  __syncthreads();
-
-  const int nkb = (T2 + 127) / 128;
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int key0 = kb * 128;
-    // ---- S = Q' K'^T : keys of this wave = key0 + 32*wave + (lane & 31) ----
-    f32x16 acc_s[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc_s[mt][r] = 0.f;
-    {
-      const int jkey = key0 + wave * 32 + (lane & 31);
-      const float* a_ptr = Qs + (lane & 31) * C::QLD + 4 * (lane >> 5);
-#pragma unroll
-      for (int sg = 0; sg < NSG; ++sg) {
-        if (sg + 1 < NSG) load_sg((sg + 1) & 1, jkey, sg + 1);
-        else if (kb + 1 < nkb) load_sg(0, jkey + 128, 0);  // next key block's first super-group
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int g = 4 * sg + i;
-          const f32x4 bb = kq[sg & 1][i];
-          const f32x4 a0 = *reinterpret_cast<const f32x4*>(a_ptr + 8 * g);
-          const f32x4 a1 = *reinterpret_cast<const f32x4*>(a_ptr + 32 * C::QLD + 8 * g);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc_s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb[j], acc_s[0], 0, 0, 0);
-            acc_s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bb[j], acc_s[1], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    if (kb > 0) __syncthreads();  // every wave finished the previous block's PV reads of Ss
-    {
-      const int kl = wave * 32 + (lane & 31);
-      const int key = key0 + kl;
-      const bool masked = (key >= T2) || (a.mask_mul * (int64_t)key >= len_b);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          Ss[(mt * 32 + acc_row(r, lane)) * kSld + kl] = masked ? -INFINITY : acc_s[mt][r] * score_mul;
-    }
-    __syncthreads();
-    const int kbase = key0 + kh * 64 + (lane >> 5);
-    const int cbase = ctg * C::NO * 32 + (lane & 31);
-#pragma unroll
-    for (int s = 0; s < PFV; ++s)
-#pragma unroll
-      for (int t = 0; t < C::NO; ++t) ringv[s][t] = vval(kbase + 2 * s, cbase + t * 32);
-    // ---- online softmax: a 16-lane group owns one row (8 keys per lane); 4 rows per wave-op, 16 rows per wave ----
-    {
-      const int grp = lane >> 4, gl = lane & 15;
-#pragma unroll 1
-      for (int it = 0; it < 4; ++it) {
-        const int row = wave * 16 + it * 4 + grp;
-        float* srow = Ss + row * kSld + gl;
-        float v[8];
-        float bm = -INFINITY;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[e] = srow[16 * e];
-          bm = fmaxf(bm, v[e]);
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o));
-        const float m_old = stM[row];
-        const float m_new = fmaxf(m_old, bm);
-        float alpha = 1.f, ps = 0.f;
-        if (m_new != -INFINITY) {
-          alpha = __expf(m_old - m_new);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            v[e] = __expf(v[e] - m_new);
-            ps += v[e];
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) ps += __shfl_xor(ps, o);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) srow[16 * e] = v[e];
-        if (gl == 0) {
-          stM[row] = m_new;
-          stL[row] = stL[row] * alpha + ps;
-          stA[row] = alpha;
-        }
-      }
-    }
-    __syncthreads();
-    // ---- O = O*alpha + P V : wave -> (column-tile group ctg, 64-key half kh) ----
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int t = 0; t < C::NO; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_o[mt][t][r] *= stA[mt * 32 + acc_row(r, lane)];
-    {
-      const float* a_ptr = Ss + (lane & 31) * kSld + kh * 64 + (lane >> 5);
-#pragma unroll
-      for (int s = 0; s < 32; ++s) {
-        float bv[C::NO];
-#pragma unroll
-        for (int t = 0; t < C::NO; ++t) bv[t] = ringv[s % PFV][t];
-        if (s + PFV < 32) {
-#pragma unroll
-          for (int t = 0; t < C::NO; ++t) ringv[s % PFV][t] = vval(kbase + 2 * (s + PFV), cbase + t * 32);
-        }
-        const float a0 = a_ptr[2 * s];
-        const float a1 = a_ptr[32 * kSld + 2 * s];
-#pragma unroll
-        for (int t = 0; t < C::NO; ++t) {
-          acc_o[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[t], acc_o[0][t], 0, 0, 0);
-          acc_o[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[t], acc_o[1][t], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-  __syncthreads();
-  // combine the two key halves, normalise, store
-  float* Osum = Ss;  // [NCT][64][33]  (NCT*64*33 <= 64*129 for NCT <= 3 ... checked below)
-  static_assert(C::NO * 2 * 64 * 33 <= 2 * 64 * kSld || DK == 192, "scratch");
-  // DK = 192 needs 6*64*33 floats = 12672 > 64*129: the Q' region (64*388 floats) is free by now
-  float* scratch = (DK == 192) ? Qs : Osum;
-  if (kh == 1) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int t = 0; t < C::NO; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          scratch[((ctg * C::NO + t) * 64 + mt * 32 + acc_row(r, lane)) * 33 + (lane & 31)] = acc_o[mt][t][r];
-  }
-  __syncthreads();
-  if (kh == 0) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int t = 0; t < C::NO; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = mt * 32 + acc_row(r, lane);
-          const float l = stL[row];
-          float o = acc_o[mt][t][r] + scratch[((ctg * C::NO + t) * 64 + row) * 33 + (lane & 31)];
-          o = (l > 0.f) ? o / l : 0.f;  // fully masked row -> 0 (attention.py:118)
-          if (q0 + row < T1) {
-            const int cc = h * DK + (ctg * C::NO + t) * 32 + (lane & 31);
-            int frame = q0 + row, feat = cc;
-            if (C::G != 1) split((q0 + row) * (C::G * dm) + cc, frame, feat);
-            if (frame < F1) ctx[(size_t)frame * dm + feat] = o;  // x[:, :T - padding_q] (efficient attention.py:124-125)
-          }
-        }
-  }
-}
-constexpr size_t kLdsAttn = AttnCfg<64>::LDS_FLOATS * sizeof(float);
-constexpr size_t kLdsAttnG = AttnCfg<192>::LDS_FLOATS * sizeof(float);
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st) {
-  if (launch_attention_t(a, B, H, st)) return;  // attention_kernels.hip (the kernels below: grouped heads on width 768)
-  if (a.group == 3 && a.dm == kD)
-    PPASR_LAUNCH((k_attention<192, true>), dim3((a.T1 + 63) / 64, H, B), dim3(256), kLdsAttnG, st, a);
-  else if (a.group == 3)
-    PPASR_LAUNCH((k_attention<192, false>), dim3((a.T1 + 63) / 64, H, B), dim3(256), kLdsAttnG, st, a);
-  else
-    PPASR_LAUNCH(k_attention<64>, dim3((a.T1 + 63) / 64, H, B), dim3(256), kLdsAttn, st, a);
+  if (!launch_attention_t(a, B, H, st)) {  // (row strides / widths are multiples of 256 by construction: never taken)
+    fprintf(stderr, "ppasr_hip: attention launch refused (group %d, strides %d %d %d, width %d)\n", a.group, a.q_stride,
+            a.k_stride, a.v_stride, a.dm);
+    abort();
+  }
 }
 
 // -------------------------------------------------------------------------------------
@@ -2589,9 +2267,6 @@ hipError_t configure_kernels() {
   SET_LDS((k_conv_ffn_h3<15, false>), kLdsConvFfn + kH3ExtraLds);
   SET_LDS((k_conv_ffn_h3<7, true>), kLdsConvFfn + kH3ExtraLds);
   SET_LDS((k_conv_ffn_h3<7, false>), kLdsConvFfn + kH3ExtraLds);
-  SET_LDS(k_attention<64>, kLdsAttn);
-  SET_LDS((k_attention<192, true>), kLdsAttnG);
-  SET_LDS((k_attention<192, false>), kLdsAttnG);
   SET_LDS(k_out_glu, kLdsOutGlu);
   SET_LDS(k_pw1_glu_cols, kLdsPw1Cols);
   SET_LDS((k_conv_ffn<15, false, false>), kLdsConvFfn);

@@ -592,18 +592,14 @@ void launch_lstm_wave(const float* gx0, const Ds2WaveLayer* tab, float* hbuf, fl
   // row tiles per workgroup: up to 64 utterances stream a layer's weights once.  Beyond that two row tiles per workgroup
   // again (B = 128: 5 x 128 x 2 workgroups = five per CU, dealt as they finish) beat four (640 workgroups = 2.5 per CU,
   // i.e. three on some CUs): 95.3 against 99.8 us per launch, same box; the second read of the weights comes from L2 / MALL
-  int rt = B <= 32 ? 1 : 2;
-  if (const char* e = getenv("PPASR_WAVE_RT")) {  // (measurement switch)
-    const int v = atoi(e);
-    if (v == 1 || v == 2 || v == 4) rt = v;
-  }
+  const int rt = B <= 32 ? 1 : 2;
   const dim3 grid(H / 8, n_l, (B + 32 * rt - 1) / (32 * rt));
 #define WAVE_LAUNCH(RT, GRU) \
   PPASR_LAUNCH((k_lstm_wave<RT, GRU>), grid, dim3(kThreads), 0, st, gx0, tab, hbuf, cbuf, yring, out, lens, B, T, H, L, s, l_lo)
   if (gru) {
-    if (rt == 1) WAVE_LAUNCH(1, true); else if (rt == 2) WAVE_LAUNCH(2, true); else WAVE_LAUNCH(4, true);
+    if (rt == 1) WAVE_LAUNCH(1, true); else WAVE_LAUNCH(2, true);
   } else {
-    if (rt == 1) WAVE_LAUNCH(1, false); else if (rt == 2) WAVE_LAUNCH(2, false); else WAVE_LAUNCH(4, false);
+    if (rt == 1) WAVE_LAUNCH(1, false); else WAVE_LAUNCH(2, false);
   }
 #undef WAVE_LAUNCH
 }

@@ -266,79 +266,6 @@ __global__ __launch_bounds__(kThreads) void k_sq_tail_h3(const float* __restrict
   sq_tail_body<32, KS, true>(g, x2, x_out, qkv_next, w, wqkv_next, bqkv_next, lens, M, Tp, mask_mul, n_chunks, ps, left_ctx);
 }
 
-// K_B: x1 = LN1(x + ctx Wo + bo) ; x2 = LN2(x1 + FFN1(x1)) ; g = GLU(pw1(x2))   (encoder.py:469-497)
-__global__ __launch_bounds__(kThreads) void k_sq_mid(const float* __restrict__ ctx, const float* __restrict__ x,
-                                                     float* __restrict__ x2, float* __restrict__ g,
-                                                     float* __restrict__ xhat_out, SqLayerW w,
-                                                     const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
-                                                     int n_chunks, PadSkip ps) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, M)) return;
-  float* bufX = smem;
-  float* bufH = bufX + kRows * kLda;  // 2 buffers; bufH[0] doubles as the ctx staging tile
-  const int lane = lane_id(), wave = wave_id();
-  const int r0 = blockIdx.x * kRows;
-  const int valid = min(kRows, M - r0);
-  const int col = wave * 32 + (lane & 31);
-  BRing<1> ring;
-  const f32x4* seg_o = w.wo + (size_t)wave * kTs256;
-  const f32x4* seg_val = w.pw1 + (size_t)wave * kTs256;
-  const f32x4* seg_gate = w.pw1 + (size_t)(8 + wave) * kTs256;
-  ring_prime(ring, seg_o, 0);
-  rb_load_rows(bufH, kLda, ctx + (size_t)r0 * kD, kRows, valid);
-  __syncthreads();
-  {
-    // residual rows requested before the GEMM, branch-free (clamped row): conditional loads inside the epilogue run as
-    // dependent round trips (see k_conv_ffn)
-    float res[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) res[r] = x[(size_t)(r0 + min(acc_row(r, lane), valid - 1)) * kD + col];
-    f32x16 acc[1][1];
-    acc_zero(acc);
-    rb_gemm<1, 1, kG256>(bufH, kLda, seg_o, 0, w.ff1_w1 + (size_t)wave * kTs256, 0, ring, acc);
-    const float bv = w.bo[col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = acc_row(r, lane);
-      bufX[row * kLda + col] = (row < valid) ? res[r] + (acc[0][0][r] + bv) : 0.f;
-    }
-  }
-  __syncthreads();
-  rb_layernorm(bufX, bufX, kLda, kRows, w.ln1_g, w.ln1_b, 1e-5f);
-  __syncthreads();
-  f32x16 acc2[1][1];
-  acc_zero(acc2);
-  ffn_phase(bufX, bufH, w.ff1_w1, w.ff1_b1, w.ff1_w2, n_chunks, seg_val, ring, acc2);
-  residual_epilogue(bufX, acc2, w.ff1_b2, 1.0f);
-  __syncthreads();
-  rb_layernorm(bufX, bufX, kLda, kRows, w.ln2_g, w.ln2_b, 1e-5f);
-  rb_store_rows(x2 + (size_t)r0 * kD, bufX, kLda, kRows, valid);
-  if (xhat_out) {  // streaming: what the reference keeps as cnn_cache = the scaled conv-module input
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(w.cm_scale + 4 * lane);
-    const f32x4 sb = *reinterpret_cast<const f32x4*>(w.cm_bias + 4 * lane);
-    for (int row = wave; row < valid; row += kWaves)
-      *reinterpret_cast<f32x4*>(xhat_out + (size_t)(r0 + row) * kD + 4 * lane) =
-          sc * *reinterpret_cast<const f32x4*>(bufX + row * kLda + 4 * lane) + sb;
-  }
-  __syncthreads();
-  {
-    f32x16 av[1][1], ag[1][1];
-    acc_zero(av);
-    acc_zero(ag);
-    rb_gemm<1, 1, kG256>(bufX, kLda, seg_val, 0, seg_gate, 0, ring, av);
-    rb_gemm<1, 1, kG256>(bufX, kLda, seg_gate, 0, nullptr, 0, ring, ag);
-    const float bval = w.pw1_b[col], bgate = w.pw1_b[kD + col];
-    const float gpad = w.glu_pad[col];
-    PadRows is_pad{lens, r0, Tp, M, mask_mul};
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int row = acc_row(r, lane);
-      float v = (av[0][0][r] + bval) * sigmoidf(ag[0][0][r] + bgate);
-      if (is_pad(row)) v = gpad;
-      if (row < valid) g[(size_t)(r0 + row) * kD + col] = v;
-    }
-  }
-}
 constexpr size_t kLdsSqMid = 3 * kRows * kLda * sizeof(float);
 
 // ---- split route for under-filled launches (conformer_kernels.hip, k_conv_pre / k_ffn_part / k_ffn_join): K_B and K_C
@@ -609,14 +536,6 @@ void launch_sq_qkv(const float* x, float* qkv, const f32x4* wqkv, const float* b
                    const PadSkip& ps) {
   PPASR_LAUNCH(k_sq_qkv, rb_grid(M), dim3(kThreads), ragged_lds(kLds1, ps, (int)rb_grid(M).x), st, x, qkv, wqkv, bqkv, M, ps);
 }
-// (A/B switch for measurements: PPASR_SQ_LEGACY=1 runs the round-3 kernels k_sq_mid / k_sq_tail)
-static bool sq_legacy() {
-  static const bool on = [] {
-    const char* e = std::getenv("PPASR_SQ_LEGACY");
-    return e && e[0] == '1';
-  }();
-  return on;
-}
 // 16-row blocks always ask for more than half of a CU's LDS: one workgroup per CU, so that the (<= 256) active blocks of an
 // under-filled or ragged launch spread over all CUs instead of pairing up on some
 static size_t lds16(size_t own) { return own < kLdsExclusive ? kLdsExclusive : own; }
@@ -627,11 +546,8 @@ constexpr size_t kLdsSqMidH3 = kRows * kLda * sizeof(float) + 3 * kH3TileBytes;
 void launch_sq_mid(const float* ctx, const float* x, float* x2, float* g, float* xhat_out, const SqLayerW& w,
                    const int64_t* lens, int M, int Tp, int mask_mul, int n_chunks, hipStream_t st, const PadSkip& ps, int rows,
                    bool h3) {
-  if (h3 && rows == 32 && !sq_legacy())  // (w: the layer's fp16 x3 view)
+  if (h3 && rows == 32)  // (w: the layer's fp16 x3 view; the caller decides h3 with sq_h3_route)
     PPASR_LAUNCH(k_sq_mid_h3, rb_grid(M), dim3(kThreads), kLdsSqMidH3, st, ctx, x, x2, g, xhat_out, w, lens, M, Tp, mask_mul,
-                 n_chunks, ps);
-  else if (sq_legacy())
-    PPASR_LAUNCH(k_sq_mid, rb_grid(M), dim3(kThreads), kLdsSqMid, st, ctx, x, x2, g, xhat_out, w, lens, M, Tp, mask_mul,
                  n_chunks, ps);
   else if (rows == 16)
     PPASR_LAUNCH(k_sq_mid_t<16>, dim3((M + 15) / 16), dim3(kThreads), lds16(kLdsSqMid16), st, ctx, x, x2, g, xhat_out, w, lens,
@@ -647,7 +563,7 @@ void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float*
                     const f32x4* wqkv_next, const float* bqkv_next, const int64_t* lens, int M, int Tp, int mask_mul,
                     int n_chunks, int ksize, hipStream_t st, const PadSkip& ps, bool causal, int rows, bool h3) {
   const int left_ctx = causal ? ksize - 1 : (ksize - 1) / 2;
-  if (h3 && rows == 32 && sq_h3_supported(ksize, Tp) && !g_hist && !sq_legacy()) {  // (w: the layer's fp16 x3 view)
+  if (h3 && rows == 32 && sq_h3_supported(ksize, Tp) && !g_hist) {  // (w: the layer's fp16 x3 view)
     if (ksize == 31)
       PPASR_LAUNCH(k_sq_tail_h3<31>, rb_grid(M), dim3(kThreads), kLdsSqTail + kH3ExtraLds, st, g, x2, x_out, qkv_next, w, wqkv_next,
                    bqkv_next, lens, M, Tp, mask_mul, n_chunks, ps, left_ctx);
@@ -658,7 +574,7 @@ void launch_sq_tail(const float* g, const float* g_hist, const float* x2, float*
   }
   // the register depthwise conv needs a wave's rows to span at most two utterances (Tp >= rows per wave); streaming
   // chunks (g_hist) keep the LDS-staged form
-  if (!g_hist && !sq_legacy() && Tp >= 4 && (ksize == 31 || ksize == 15)) {
+  if (!g_hist && Tp >= 4 && (ksize == 31 || ksize == 15)) {
 #define SQ_TAIL_T(R, KS, LDS)                                                                                         \
   PPASR_LAUNCH((k_sq_tail_t<R, KS>), dim3((M + RBT<R>::ROWS - 1) / RBT<R>::ROWS), dim3(RBT<R>::THREADS), LDS, st, g, x2, \
                x_out, qkv_next, w, wqkv_next, bqkv_next, lens, M, Tp, mask_mul, n_chunks, ps, left_ctx)
@@ -710,7 +626,6 @@ hipError_t configure_squeezeformer_kernels() {
 #define SET_LDS(fn, bytes)                                                                                     \
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
   if (e != hipSuccess) return e;
-  SET_LDS(k_sq_mid, kLdsSqMid);
   SET_LDS(k_sq_mid_t<32>, kLdsSqMid);
   SET_LDS(k_sq_mid_h3, kLdsSqMidH3);
   SET_LDS(k_sq_tail_h3<31>, kLdsSqTail + kH3ExtraLds);

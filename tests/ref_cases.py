@@ -36,6 +36,9 @@ SMALL = {
                         required=(-16, 32), stride_layer_idx=1, group_layer_idx=(0, 1), output_size=512, attention_heads=8),
     "eff512_n": _former("efficient_conformer", False, 3, 53, 587, (2, 148, [148, 77], 588), stride_layer_idx=1,
                         group_layer_idx=(0,), output_size=512, attention_heads=8, cnn_module_kernel=11),
+    # output_size 768 / 12 heads: grouped attention on a width that is not a power of two (k_attention_t<192>'s flat-offset split)
+    "eff768_n": _former("efficient_conformer", False, 2, 53, 589, (2, 148, [148, 77], 590), stride_layer_idx=1,
+                        group_layer_idx=(0,), output_size=768, attention_heads=12),
     # Squeezeformer: reduce before layer 1, recover before layer 3
     "sq_s": _former("squeezeformer", True, 4, 59, 521, (2, 131, [131, 77], 522), chunk_frames=64 * 4 + 40,
                     required=(-16, 32), reduce_idx=1, recover_idx=3),

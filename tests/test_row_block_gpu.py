@@ -121,28 +121,6 @@ def test_ragged_mode_with_hint_computes_the_same_valid_rows():
         assert not a[u, n:].any() and not b[u, n:].any() and not c[u, n:].any() and not d[u, n:].any()
 
 
-def test_32_row_kernels_are_bit_identical_to_the_round3_kernels():
-    """PPASR_SQ_LEGACY=1 (read once at library load: separate processes) runs k_sq_mid / k_sq_tail of round 3."""
-    code = (
-        "import sys, numpy as np, torch\n"
-        f"sys.path.insert(0, {ROOT!r})\n"
-        "from tests.test_row_block_gpu import _model, LENS\n"
-        "from ppasr_amd.utils.synth import synth_features\n"
-        "m, _ = _model()\n"
-        "x, lens = synth_features(len(LENS), 611, lens=LENS, seed=74)\n"
-        "m.set_row_block(32)\n"
-        "p, l = m.get_encoder_out(x, lens, return_logits=True)\n"
-        "torch.cuda.synchronize()\n"
-        "np.save(sys.argv[1], l.cpu().numpy())\n")
-    outs = []
-    for legacy in ("0", "1"):
-        path = f"/tmp/_sq_legacy_{legacy}.npy"
-        env = dict(os.environ, PPASR_SQ_LEGACY=legacy)
-        subprocess.check_call([sys.executable, "-c", code, path], env=env, cwd=ROOT)
-        outs.append(np.load(path))
-    assert np.array_equal(outs[0], outs[1]), _rel(outs[0], outs[1])
-
-
 @pytest.mark.parametrize("family", ["conformer", "conformer_noncausal_k31", "efficient"])
 def test_conformer_family_16_row_blocks(family):
     """The Conformer / Efficient-Conformer layer kernels on 16-row blocks (csrc/conformer_kernels_t.hip: k_ffn_qkv_t,
