@@ -1081,6 +1081,8 @@ ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_l
   {
     const char* e = getenv("PPASR_BEAM_NODE_TABLE");
     c.node_table = e ? (atoi(e) != 0) : (lm && c.lm.word_based);
+    const char* f = getenv("PPASR_BEAM_FAST");  // (read per call: the tests run both selections in one process)
+    c.fast_path = f ? (atoi(f) != 0) : 1;
   }
   const size_t per_utt_bytes = state_bytes / (size_t)B;
   const size_t F = beam_frame_capacity(per_utt_bytes, beam_size);

@@ -21,6 +21,8 @@ struct BeamConfig {
   int max_nodes;   // arena capacity per utterance
   int nbest, max_tokens;
   int node_table;  // 1: prefixes keep their node id across drop / re-creation (see the state layout below)
+  int fast_path;   // 1 (default): small beams without a scorer rank a staircase-restricted element list first (ctc_beam.hip
+                   // (e')); 0 (PPASR_BEAM_FAST=0, tests): always the general selection.  Same results bit for bit
   // external scorer (ctc_beam_search_decoder.cpp `ext_scorer`): lm.order == 0 -> none
   LmDev lm;
   double alpha, beta;

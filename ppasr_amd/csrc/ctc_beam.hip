@@ -34,6 +34,9 @@ namespace ppasr {
 
 namespace {
 
+constexpr int kFastBeam = 16;   // staircase fast path: beams up to this size ...
+constexpr int kFastCap = 128;   // ... whose restricted element list fits this many entries (two per lane of a wave)
+constexpr int kFastMargin = 2;  // extra candidates per hypothesis beyond the (rank + 1) (k + 1) <= beam staircase
 constexpr int kBT = 1024;  // threads per utterance: 16 waves = 4 per SIMD (a batch of 32 utterances occupies 32 CUs with one
                           // workgroup each, and every phase is a chain of dependent LDS reads: latency hidden by wave count)
 constexpr int kBW = kBT / 64;  // waves
@@ -234,6 +237,9 @@ size_t beam_lds_bytes(const BeamConfig& c) {
   n += (size_t)c.beam * 20;                        // new_b, new_nb, new_score, new_dst, k_reset
   n += (size_t)Vp * 2;                             // kidx (int16)
   n += (((size_t)c.beam * c.n_cand_max) + 3) & ~(size_t)3;  // exists flags
+  n = (n + 7) & ~(size_t)7;                        // (fkey: 8-byte entries)
+  n += (size_t)kFastCap * 16 + (size_t)kFastBeam * 8;  // staircase fast path: keys, element ids, log-probs, rank tables
+  n += (size_t)c.beam * 4;                         // surv_lp
   n += (size_t)c.beam * (1 + c.n_cand_max) * 4;    // score keys
   return (n + 15) & ~(size_t)15;
 }
@@ -461,6 +467,14 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
   constexpr bool word_lm = WORD_LM;  // scorer consulted at spaces, prefixes constrained by the dictionary (lm.word_based)
   const int space_id = cfg.lm.space_id;
   uint8_t* exists = reinterpret_cast<uint8_t*>(p); p += (((size_t)beam * CM) + 3) & ~(size_t)3;
+  // staircase fast path (small beams without a scorer, see (e')): the restricted element list and its bookkeeping
+  p = smem + (((size_t)(p - smem) + 7) & ~(size_t)7);
+  unsigned long long* fkey = reinterpret_cast<unsigned long long*>(p); p += kFastCap * 8;
+  int* f_e = reinterpret_cast<int*>(p); p += kFastCap * 4;
+  float* f_lp = reinterpret_cast<float*>(p); p += kFastCap * 4;
+  int* hyp_of_rank = reinterpret_cast<int*>(p); p += kFastBeam * 4;
+  int* srank_s = reinterpret_cast<int*>(p); p += kFastBeam * 4;
+  float* surv_lp = reinterpret_cast<float*>(p); p += beam * 4;  // log-probability of a surviving CHILD, by slot of the next beam
   uint32_t* skey = reinterpret_cast<uint32_t*>(p);  // [beam * (1 + CM)] score keys of the frame's elements
 
   int32_t* st = state + (size_t)u * beam_state_words(beam, cfg.max_nodes);
@@ -532,6 +546,8 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
 #define TS(i)
 #define TSN()
 #endif
+  // (e') is taken by searches without an external scorer (its upper bound on a child's score needs score = acoustic only)
+  const bool fast_ok = !has_lm && beam <= kFastBeam && BT >= 128 && cfg.fast_path != 0;
   for (int t = 0; t < n_frames; ++t) {
     // ---- (b, c) this frame's pruned characters (get_pruned_log_probs, done by the pre-pass) ----
     const int C = pre_C;
@@ -547,7 +563,7 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
     }
     if (t + 1 < n_frames) fetch(t + 1);
     for (int e = tid; e < nb * C; e += BT) exists[e] = 0;
-    for (int i = tid; i < 8 * 256; i += BT) hist[i] = 0;  // 4 + 4 per-pass histograms of the two selects below
+    if (tid == 0) { sh_i[0] = 0; sh_i[1] = 0; }  // fast path: merged children of the frame, "verification failed"
     lds_barrier();
     TS(0);
     // ---- external scorer: pruning threshold of this frame and the LM term of every possible extension ----
@@ -624,11 +640,21 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
           if (!pruned(lq, pi))
             nbc = lse(nbc, ext_logp(pi, kidx[cq], (word_lm && cq == space_id) ? lm_dict_arc(cfg.lm, cur.dst[pi], cq) : 0));
           exists[pi * C + kidx[cq]] = 1;
+          if (fast_ok) atomicAdd(&sh_i[0], 1);  // (distinct (parent, character) per hypothesis: one flag each)
         }
       }
       new_b[q] = bc;
       new_nb[q] = nbc;
       new_score[q] = lse(bc, nbc);
+      if (fast_ok && nb <= kFastBeam) {  // rank of the hypothesis by its CURRENT score (rows of the staircase, see (e'))
+        const float sq = cur.score[q];
+        int r = 0;
+        for (int i = 0; i < nb; ++i) {
+          const float si = cur.score[i];
+          r += (si > sq || (si == sq && i < q)) ? 1 : 0;
+        }
+        hyp_of_rank[r] = q;
+      }
     }
     lds_barrier();
     if (word_lm) {
@@ -656,144 +682,241 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
       lds_barrier();
     }
     TS(2);
-    // ---- (e) element space: [0,nb) existing hypotheses, nb + i*C + k = child (i, cand k).  The 32-bit score key of
-    // every element is computed ONCE into LDS (0xFFFFFFFF = not a candidate); thread t owns the contiguous range
-    // [t*per, (t+1)*per) so that the compaction below keeps element order with a single block scan ----
-    const int N = nb + nb * C;
-    // (an ODD range length: thread t starts at word t*per of skey[], and an even stride would put the 64 lanes of a
-    //  wave on 16 or fewer of the 64 LDS banks)
-    const int per = ((N + BT - 1) / BT) | 1;
-    const int e_lo = min(tid * per, N), e_hi = min(e_lo + per, N);
-    auto elem_char = [&](int e) -> int { return e < nb ? cur.chr[e] : cand_c[(e - nb) % C]; };
-    int my_valid = 0;
-    {
-      int e = e_lo;
-      for (; e < e_hi && e < nb; ++e) {  // hypotheses already in the beam
-        skey[e] = desc_key(new_score[e]);
-        ++my_valid;
-      }
-      while (e < e_hi) {  // children: one hypothesis i at a time (its fields stay in registers), candidates k0..k1
-        const int r = e - nb, i = r / C, k0 = r - i * C;
-        const int k1 = min(C, k0 + (e_hi - e));
-        const int ci = cur.chr[i];
-        const float bi = cur.b[i], si = cur.score[i];
-        // word-based scorer: dictionary state the children of i are looked up from (after the reset above), and the one
-        // candidate that triggered the reset
-        const int di = word_lm ? new_dst[i] : 0, kri = word_lm ? k_reset[i] : -1;
-        const bool dead = word_lm && lm_dict_final(cfg.lm, di);  // still final: no candidate was looked up this frame
-        for (int k = k0; k < k1; ++k, ++e) {
-          const int c = cand_c[k];
-          const float lpk = cand_lp[k];
-          uint32_t key = 0xFFFFFFFFu;
-          if (c != blank && !exists[e - nb] && !(full_beam && (lpk + si < min_cutoff))) {
-            int to = 0;
-            bool ok = true;
-            if (word_lm) {
-              to = (dead || k == kri) ? -1 : lm_dict_arc(cfg.lm, di, c);
-              ok = to >= 0;
+    // ---- (e') staircase fast path: small beams, no scorer ----
+    // Without a scorer the score of child (i, k) is at most U(i, k) = lp[k] + score[i], and U falls along both axes when
+    // the hypotheses are taken in score order (rank r) and the candidates in list order (probability descending).  A child
+    // with (r + 1)(k + 1) > beam has beam elements in front of it -- unless some of those are lowered (a repeated
+    // character uses log P_b) or merged into an existing hypothesis.  So: rank only the existing hypotheses and the children
+    // with k < K_r = beam / (r + 1) + margin (<= kFastCap elements instead of nb (1 + C)), each key against all others with
+    // ballots (no histograms, no scans), and VERIFY afterwards that the best excluded child of every row, bounded by
+    // U(i, K_r), is strictly below the last score taken.  If that fails -- or the list does not hold `beam` valid elements
+    // -- the frame falls through to the general selection below; so the result is the general one bit for bit: same
+    // survivors, same (element) order, same node ids.
+    int k_sel = 0;
+    int* surv = nxt.par;  // temporary list in the next beam's `par` column: slot p is read, then overwritten, by thread p
+    bool fast_done = false;
+    if (fast_ok && nb <= kFastBeam && C > 0) {
+      const int has_blank = kidx[blank] >= 0 ? 1 : 0;
+      const int n_valid_f = nb + nb * (C - has_blank) - sh_i[0];  // = n_valid of (e): existing + non-blank, non-merged children
+      int n_s = nb;  // list: [0, nb) the existing hypotheses, then row r = rank r's children k < K_r
+      for (int r = 0; r < nb; ++r) n_s += min(C, beam / (r + 1) + kFastMargin);
+      if (n_valid_f > beam && n_s <= kFastCap) {  // (block-uniform)
+        for (int sidx = tid; sidx < n_s; sidx += BT) {
+          unsigned long long key = ~0ull;
+          int e = sidx;
+          float log_p = 0.f;
+          if (sidx < nb) {
+            key = make_key(new_score[sidx], cur.chr[sidx], sidx);
+          } else {
+            int r = 0, off = sidx - nb;
+            for (;; ++r) {
+              const int kr = min(C, beam / (r + 1) + kFastMargin);
+              if (off < kr) break;
+              off -= kr;
             }
-            if (ok) {
-              float log_p = kNegInf;
-              if (c == ci) { if (bi > kNegInf) log_p = lpk + bi; }
-              else log_p = lpk + si;
-              if (word_lm) {
-                if (c == space_id) {
-                  log_p += lm_term_word(i, cfg.lm.dict_word[to]);
-                  log_p = (float)((double)log_p + cfg.beta);
-                }
-              } else if (has_lm) {
-                log_p += lm_term(i, c);
-                log_p = (float)((double)log_p + cfg.beta);
-              }
-              key = desc_key(log_p);
-              ++my_valid;
+            const int i = hyp_of_rank[r], k = off;
+            const int c = cand_c[k];
+            e = nb + i * C + k;
+            if (c != blank && !exists[i * C + k]) {
+              const float lpk = cand_lp[k];
+              log_p = kNegInf;
+              if (c == cur.chr[i]) { if (cur.b[i] > kNegInf) log_p = lpk + cur.b[i]; }
+              else log_p = lpk + cur.score[i];
+              key = make_key(log_p, c, e);
             }
           }
-          skey[e] = key;
+          fkey[sidx] = key;
+          f_e[sidx] = e;
+          f_lp[sidx] = log_p;
         }
-      }
-    }
-    int n_valid;
-    (void)block_excl_scan<BT / 64>(my_valid, wave_tot, n_valid);  // (barrier inside: skey[] is complete afterwards)
-    const int k_sel = n_valid >= beam ? beam : n_valid;
-    TS(3); TSN();
-    // ---- (f) exact top-k_sel in prefix_compare order = ascending (score key, char, element id): MSD radix select of
-    // the k_sel-th smallest 32-bit score key over the LDS array; if the threshold class has more members than slots
-    // left (ties), a second select over (char, id) inside that class ----
-    // 4-pass radix select of the k-th smallest value of f(e) over elements with pred(e); returns the value and how
-    // many members of its class are needed (k_need) / exist (k_have)
-    auto radix_select32 = [&](auto&& value_of, int k, int* hists, uint32_t& out, int& k_need, int& k_have) {
-      uint32_t prefix = 0;
-      int k_rem = k;
-      k_have = 0;
-      for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        const uint32_t hi_mask = pass == 0 ? 0u : (~0u << (shift + 8));
-        int* h = hists + pass * 256;  // zeroed at the start of the frame; one histogram per pass = one barrier per pass
-        {
-          RunHist rh(h);
-          for (int e = tid; e < N; e += BT) {
-            uint32_t v;
-            if (value_of(e, v) && (v & hi_mask) == prefix) rh.add((int)((v >> shift) & 0xff));
+        if (tid < kFastBeam) srank_s[tid] = -1;
+        lds_barrier();
+        TS(3);
+        {  // rank of every key = number of smaller keys (keys are unique: the element id is part of them)
+          const unsigned long long k0 = lane < n_s ? fkey[lane] : ~0ull, k1 = lane + 64 < n_s ? fkey[lane + 64] : ~0ull;
+          for (int i = wave; i < n_s; i += BT / 64) {
+            const unsigned long long ki = fkey[i];
+            const int rank = __popcll(__ballot(k0 < ki)) + __popcll(__ballot(k1 < ki));
+            if (lane == 0 && ki != ~0ull && rank < beam) srank_s[rank] = i;
           }
-          rh.flush_wave();
         }
         lds_barrier();
-        int bin;
-        select_bin_reg(h, k_rem, bin, k_rem, k_have);
-        prefix |= (uint32_t)bin << shift;
-        if (k_have == k_rem && shift > 0) {  // the searched value is the last of its class: take the whole class
-          prefix |= (1u << shift) - 1u;
-          break;
+        TS(5);
+        // survivors in ELEMENT order (the order the general compaction leaves them in) + the verification
+        if (tid < beam) {
+          const int sp = srank_s[tid];
+          if (sp < 0) {
+            sh_i[1] = 1;  // fewer than `beam` valid elements in the list
+          } else {
+            const int ep = f_e[sp];
+            int pos = 0;
+            for (int j = 0; j < beam; ++j) {
+              const int sj = srank_s[j];
+              pos += (sj >= 0 && f_e[sj] < ep) ? 1 : 0;
+            }
+            surv[pos] = ep;
+            surv_lp[pos] = f_lp[sp];
+          }
+        } else if (tid >= 64 && tid < 64 + nb) {  // (another wave: row r = tid - 64)
+          const int r = tid - 64;
+          const int kr = beam / (r + 1) + kFastMargin;
+          const int s_last = srank_s[beam - 1];
+          if (kr < C && s_last >= 0) {
+            const uint32_t thr = (uint32_t)(fkey[s_last] >> 32);  // score key of the last element taken
+            const float ub = cand_lp[kr] + cur.score[hyp_of_rank[r]];
+            if (desc_key(ub) <= thr) sh_i[1] = 1;  // an excluded child could score >= the last one taken
+          }
+        }
+        lds_barrier();
+        if (sh_i[1] == 0) {
+          fast_done = true;
+          k_sel = beam;
+        }
+        TS(6);
+      }
+    }
+    if (!fast_done) {
+      // ---- (e) element space: [0,nb) existing hypotheses, nb + i*C + k = child (i, cand k).  The 32-bit score key of
+      // every element is computed ONCE into LDS (0xFFFFFFFF = not a candidate); thread t owns the contiguous range
+      // [t*per, (t+1)*per) so that the compaction below keeps element order with a single block scan ----
+      for (int i = tid; i < 8 * 256; i += BT) hist[i] = 0;  // 4 + 4 per-pass histograms of the two selects below (complete
+                                                            // behind the barrier of the scan that closes (e))
+      const int N = nb + nb * C;
+      // (an ODD range length: thread t starts at word t*per of skey[], and an even stride would put the 64 lanes of a
+      //  wave on 16 or fewer of the 64 LDS banks)
+      const int per = ((N + BT - 1) / BT) | 1;
+      const int e_lo = min(tid * per, N), e_hi = min(e_lo + per, N);
+      auto elem_char = [&](int e) -> int { return e < nb ? cur.chr[e] : cand_c[(e - nb) % C]; };
+      int my_valid = 0;
+      {
+        int e = e_lo;
+        for (; e < e_hi && e < nb; ++e) {  // hypotheses already in the beam
+          skey[e] = desc_key(new_score[e]);
+          ++my_valid;
+        }
+        while (e < e_hi) {  // children: one hypothesis i at a time (its fields stay in registers), candidates k0..k1
+          const int r = e - nb, i = r / C, k0 = r - i * C;
+          const int k1 = min(C, k0 + (e_hi - e));
+          const int ci = cur.chr[i];
+          const float bi = cur.b[i], si = cur.score[i];
+          // word-based scorer: dictionary state the children of i are looked up from (after the reset above), and the one
+          // candidate that triggered the reset
+          const int di = word_lm ? new_dst[i] : 0, kri = word_lm ? k_reset[i] : -1;
+          const bool dead = word_lm && lm_dict_final(cfg.lm, di);  // still final: no candidate was looked up this frame
+          for (int k = k0; k < k1; ++k, ++e) {
+            const int c = cand_c[k];
+            const float lpk = cand_lp[k];
+            uint32_t key = 0xFFFFFFFFu;
+            if (c != blank && !exists[e - nb] && !(full_beam && (lpk + si < min_cutoff))) {
+              int to = 0;
+              bool ok = true;
+              if (word_lm) {
+                to = (dead || k == kri) ? -1 : lm_dict_arc(cfg.lm, di, c);
+                ok = to >= 0;
+              }
+              if (ok) {
+                float log_p = kNegInf;
+                if (c == ci) { if (bi > kNegInf) log_p = lpk + bi; }
+                else log_p = lpk + si;
+                if (word_lm) {
+                  if (c == space_id) {
+                    log_p += lm_term_word(i, cfg.lm.dict_word[to]);
+                    log_p = (float)((double)log_p + cfg.beta);
+                  }
+                } else if (has_lm) {
+                  log_p += lm_term(i, c);
+                  log_p = (float)((double)log_p + cfg.beta);
+                }
+                key = desc_key(log_p);
+                ++my_valid;
+              }
+            }
+            skey[e] = key;
+          }
         }
       }
-      out = prefix;
-      k_need = k_rem;
-    };
-    uint32_t thr1 = 0xFFFFFFFEu, thr2 = 0xFFFFFFFFu;  // keep: key < thr1, or key == thr1 and (char, id) <= thr2
-    bool exact_class = false;                        // thr1 names one exact key value whose class is only partly taken
-    if (k_sel < n_valid) {
-      int need, have;
-      radix_select32([&](int e, uint32_t& v) { v = skey[e]; return v != 0xFFFFFFFFu; }, k_sel, hist, thr1, need, have);
-      // after an early exit thr1 is an upper bound of a wholly taken class; after 4 passes it is an exact key value
-      if (need < have) {
-        exact_class = true;
-        const uint32_t eq = thr1;
-        int n2, h2;
-        radix_select32([&](int e, uint32_t& v) {
-          if (skey[e] != eq) return false;
-          v = ((uint32_t)(elem_char(e) + 1) << 18) | (uint32_t)e;
-          return true;
-        }, need, hist + 4 * 256, thr2, n2, h2);
+      int n_valid;
+      (void)block_excl_scan<BT / 64>(my_valid, wave_tot, n_valid);  // (barrier inside: skey[] is complete afterwards)
+      k_sel = n_valid >= beam ? beam : n_valid;
+      TS(3); TSN();
+      // ---- (f) exact top-k_sel in prefix_compare order = ascending (score key, char, element id): MSD radix select of
+      // the k_sel-th smallest 32-bit score key over the LDS array; if the threshold class has more members than slots
+      // left (ties), a second select over (char, id) inside that class ----
+      // 4-pass radix select of the k-th smallest value of f(e) over elements with pred(e); returns the value and how
+      // many members of its class are needed (k_need) / exist (k_have)
+      auto radix_select32 = [&](auto&& value_of, int k, int* hists, uint32_t& out, int& k_need, int& k_have) {
+        uint32_t prefix = 0;
+        int k_rem = k;
+        k_have = 0;
+        for (int pass = 0; pass < 4; ++pass) {
+          const int shift = 24 - 8 * pass;
+          const uint32_t hi_mask = pass == 0 ? 0u : (~0u << (shift + 8));
+          int* h = hists + pass * 256;  // zeroed at the start of the frame; one histogram per pass = one barrier per pass
+          {
+            RunHist rh(h);
+            for (int e = tid; e < N; e += BT) {
+              uint32_t v;
+              if (value_of(e, v) && (v & hi_mask) == prefix) rh.add((int)((v >> shift) & 0xff));
+            }
+            rh.flush_wave();
+          }
+          lds_barrier();
+          int bin;
+          select_bin_reg(h, k_rem, bin, k_rem, k_have);
+          prefix |= (uint32_t)bin << shift;
+          if (k_have == k_rem && shift > 0) {  // the searched value is the last of its class: take the whole class
+            prefix |= (1u << shift) - 1u;
+            break;
+          }
+        }
+        out = prefix;
+        k_need = k_rem;
+      };
+      uint32_t thr1 = 0xFFFFFFFEu, thr2 = 0xFFFFFFFFu;  // keep: key < thr1, or key == thr1 and (char, id) <= thr2
+      bool exact_class = false;                        // thr1 names one exact key value whose class is only partly taken
+      if (k_sel < n_valid) {
+        int need, have;
+        radix_select32([&](int e, uint32_t& v) { v = skey[e]; return v != 0xFFFFFFFFu; }, k_sel, hist, thr1, need, have);
+        // after an early exit thr1 is an upper bound of a wholly taken class; after 4 passes it is an exact key value
+        if (need < have) {
+          exact_class = true;
+          const uint32_t eq = thr1;
+          int n2, h2;
+          radix_select32([&](int e, uint32_t& v) {
+            if (skey[e] != eq) return false;
+            v = ((uint32_t)(elem_char(e) + 1) << 18) | (uint32_t)e;
+            return true;
+          }, need, hist + 4 * 256, thr2, n2, h2);
+        }
       }
+      TS(5);
+      auto keeps = [&](int e) -> bool {
+        const uint32_t v = skey[e];
+        if (v == 0xFFFFFFFFu) return false;
+        if (!exact_class) return v <= thr1;
+        if (v != thr1) return v < thr1;
+        return (((uint32_t)(elem_char(e) + 1) << 18) | (uint32_t)e) <= thr2;
+      };
+      // ---- (g) ordered compaction: survivors' element ids in element order (one block scan over per-thread counts), then
+      // slot p of the next beam is materialised by thread p (the survivors of one thread's range can be many) ----
+      int my_keep = 0;
+      unsigned long long keep_bits = 0;  // verdicts of the first 64 elements of this thread's range, evaluated once
+      for (int e = e_lo; e < e_hi; ++e) {
+        const bool k = keeps(e);
+        my_keep += k ? 1 : 0;
+        if (e - e_lo < 64) keep_bits |= (unsigned long long)(k ? 1 : 0) << (e - e_lo);
+      }
+      int tot_keep;
+      int wpos = block_excl_scan<BT / 64>(my_keep, wave_tot + BT / 64, tot_keep);
+      for (int e = e_lo; e < e_hi; ++e) {
+        const bool k = (e - e_lo < 64) ? (((keep_bits >> (e - e_lo)) & 1ull) != 0) : keeps(e);
+        if (!k || wpos >= beam) continue;
+        surv_lp[wpos] = e >= nb ? score_of_key(skey[e]) : 0.f;  // the extension's log-probability, computed once in (e)
+        surv[wpos++] = e;
+      }
+      lds_barrier();
+      TS(6);
     }
-    TS(5);
-    auto keeps = [&](int e) -> bool {
-      const uint32_t v = skey[e];
-      if (v == 0xFFFFFFFFu) return false;
-      if (!exact_class) return v <= thr1;
-      if (v != thr1) return v < thr1;
-      return (((uint32_t)(elem_char(e) + 1) << 18) | (uint32_t)e) <= thr2;
-    };
-    // ---- (g) ordered compaction: survivors' element ids in element order (one block scan over per-thread counts), then
-    // slot p of the next beam is materialised by thread p (the survivors of one thread's range can be many) ----
-    int my_keep = 0;
-    unsigned long long keep_bits = 0;  // verdicts of the first 64 elements of this thread's range, evaluated once
-    for (int e = e_lo; e < e_hi; ++e) {
-      const bool k = keeps(e);
-      my_keep += k ? 1 : 0;
-      if (e - e_lo < 64) keep_bits |= (unsigned long long)(k ? 1 : 0) << (e - e_lo);
-    }
-    int tot_keep;
-    int wpos = block_excl_scan<BT / 64>(my_keep, wave_tot + BT / 64, tot_keep);
-    int* surv = nxt.par;  // temporary list in the next beam's `par` column: slot p is read, then overwritten, by thread p
-    for (int e = e_lo; e < e_hi; ++e) {
-      const bool k = (e - e_lo < 64) ? (((keep_bits >> (e - e_lo)) & 1ull) != 0) : keeps(e);
-      if (!k || wpos >= beam) continue;
-      surv[wpos++] = e;
-    }
-    lds_barrier();
-    TS(6);
     int n_nodes_next;
     // node ids of the new prefixes: looked up in the node table first (a prefix that was in the beam before keeps its
     // identity, ctc_beam.h), misses get fresh ids in slot order (one block scan) and are entered into the table
@@ -843,7 +966,7 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
       } else {
         const int r = e - nb, i = r / C, kk = r - i * C;
         const int c = cand_c[kk];
-        const float log_p = score_of_key(skey[e]);  // the extension's log-probability, computed once in (e)
+        const float log_p = surv_lp[pos];  // the extension's log-probability, computed once in (e) / (e')
         const int id = cfg.node_table ? my_id : n_nodes + pos;  // (with the table: pos == tid)
         if (!cfg.node_table && id < cfg.max_nodes) { arena[kArenaWords * (size_t)id] = cur.node[i]; arena[kArenaWords * (size_t)id + 1] = c; }
         if (word_lm) {

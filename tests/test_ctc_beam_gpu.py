@@ -164,3 +164,90 @@ def test_unpruned_configuration_is_capped_at_128_characters_per_frame():
         unpruned = _oracle_decode(lib, batch[b], beam, 1.0, 40, 0, 1)
         assert got == capped[0][0] == unpruned[0][0]
         assert abs(float(scores[b, 0]) - capped[0][1]) < 1e-3 * max(1.0, abs(capped[0][1]))
+
+
+class _beam_fast:
+    """PPASR_BEAM_FAST is read at every call: 1 (default) = small beams rank the staircase-restricted element list first
+    (ctc_beam.hip (e')), 0 = always the general selection."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        self.old = os.environ.get("PPASR_BEAM_FAST")
+        os.environ["PPASR_BEAM_FAST"] = "1" if self.on else "0"
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("PPASR_BEAM_FAST", None)
+        else:
+            os.environ["PPASR_BEAM_FAST"] = self.old
+
+
+def _tied_probs(rng, T, V):
+    """Tables with EXACT ties: probabilities drawn from a handful of values (equal candidates inside a frame, equal scores
+    between hypotheses), frames that repeat, frames where the blank takes nearly everything."""
+    vals = np.array([1.0, 2.0, 2.0, 4.0, 8.0, 8.0, 16.0], np.float32)
+    w = vals[rng.integers(0, len(vals), size=(T, V))]
+    w[:, 0] *= np.where(rng.random(T) < 0.3, 400.0, 1.0).astype(np.float32)
+    for t in range(1, T):
+        if rng.random() < 0.25:
+            w[t] = w[t - 1]
+    return (w / w.sum(1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.parametrize("T,V,beam,cutoff_prob,top_n", [
+    (249, 4233, 10, 0.99, 40),   # BASELINE configs[3] / [4]
+    (200, 500, 10, 0.99, 40),
+    (150, 90, 16, 0.999, 40),
+    (120, 64, 5, 0.99, 12),
+    (100, 300, 1, 0.99, 40),
+    (80, 50, 8, 1.0, 40),        # no pruning: every character of every frame
+    (60, 700, 13, 0.9, 7),
+])
+@pytest.mark.parametrize("kind", ["peaky", "flat", "tied"])
+def test_staircase_fast_path_is_bit_identical_to_the_general_selection(T, V, beam, cutoff_prob, top_n, kind):
+    """Same survivors, same order, same node ids: every n-best token sequence and every score bit for bit, with and without
+    the fast path -- and the best path equal to the C oracle's."""
+    from ppasr_amd.decoders.beam_search_decoder import beam_search_ids
+    lib = _oracle()
+    rng = np.random.Generator(np.random.PCG64(T * 11 + V + beam))
+    B = 4
+    batch = np.stack([_tied_probs(rng, T, V) if kind == "tied" else _probs(rng, T, V, kind) for _ in range(B)])
+    lens = np.array([T, T - 7, T // 2, 1], np.int32)
+    nbest = beam
+    outs = []
+    for on in (True, False):
+        with _beam_fast(on):
+            tokens, ln, sc, _ = beam_search_ids(torch.from_numpy(batch).cuda(), beam, cutoff_prob, top_n, 0, nbest=nbest,
+                                                frame_lens=lens)
+            torch.cuda.synchronize()
+        outs.append((tokens.cpu().numpy(), ln.cpu().numpy(), sc.cpu().numpy()))
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][2], outs[1][2])  # float64 scores: the same sums in the same order
+    tokens, ln, sc = outs[0]
+    if kind == "tied":  # (exact score ties at the cut: the oracle's container order decides there; only the two selections
+        return          #  of the kernel are compared on these tables)
+    for b in range(B):
+        ref = _oracle_decode(lib, batch[b, :lens[b]], beam, cutoff_prob, top_n, 0, 1)
+        assert tokens[b, 0, :ln[b, 0]].tolist() == ref[0][0], b
+        assert abs(sc[b, 0] - ref[0][1]) <= 1e-4 * max(1.0, abs(ref[0][1]))
+
+
+def test_staircase_fast_path_streaming_state_is_identical():
+    """Chunked decoding (state carried between calls): the persisted beams of both selections agree after every chunk."""
+    from ppasr_amd.decoders.beam_search_decoder import BeamSearchDecoder
+    rng = np.random.Generator(np.random.PCG64(77))
+    V, beam = 300, 10
+    vocab = ["<blank>"] + [chr(0x4E00 + i) for i in range(V - 1)]
+    p = _probs(rng, 160, V, "peaky")
+    res = []
+    for on in (True, False):
+        with _beam_fast(on):
+            dec = BeamSearchDecoder(2.2, 4.3, beam, 0.99, 40, vocab)
+            out = []
+            for s0 in range(0, 160, 16):
+                out.append(dec.decode_chunk(p[None, s0:s0 + 16], np.array([16])))
+        res.append(out)
+    assert res[0] == res[1]
