@@ -539,7 +539,7 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
   if (n_frames > 0) fetch(0);
   __syncthreads();
 #ifdef PPASR_BEAM_TS
-  long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ts_last = wall_clock64(), ts_n = 0, ts_c = 0, ts_nb = 0;
+  long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ts_last = wall_clock64(), ts_n = 0, ts_c = 0, ts_nb = 0, ts_att = 0, ts_ok = 0;
 #define TS(i) do { if (tid == 0 && u == 0) { long long now = wall_clock64(); ts_acc[i] += now - ts_last; ts_last = now; } } while (0)
 #define TSN() do { ts_n += N; ts_c += C; ts_nb += nb; } while (0)
 #else
@@ -547,7 +547,10 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
 #define TSN()
 #endif
   // (e') is taken by searches without an external scorer (its upper bound on a child's score needs score = acoustic only)
-  const bool fast_ok = !has_lm && beam <= kFastBeam && BT >= 128 && cfg.fast_path != 0;
+  // ... whose candidate lists are sorted by probability (k_ctc_prune leaves them in index order when nothing is pruned:
+  // cutoff_prob >= 1 with cutoff_top_n >= V)
+  const bool fast_ok = !has_lm && beam <= kFastBeam && BT >= 128 && cfg.fast_path != 0 &&
+                       (cfg.cutoff_prob < 1.0 || cfg.cutoff_top_n < V);
   for (int t = 0; t < n_frames; ++t) {
     // ---- (b, c) this frame's pruned characters (get_pruned_log_probs, done by the pre-pass) ----
     const int C = pre_C;
@@ -701,6 +704,9 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
       int n_s = nb;  // list: [0, nb) the existing hypotheses, then row r = rank r's children k < K_r
       for (int r = 0; r < nb; ++r) n_s += min(C, beam / (r + 1) + kFastMargin);
       if (n_valid_f > beam && n_s <= kFastCap) {  // (block-uniform)
+#ifdef PPASR_BEAM_TS
+        ++ts_att;
+#endif
         for (int sidx = tid; sidx < n_s; sidx += BT) {
           unsigned long long key = ~0ull;
           int e = sidx;
@@ -771,6 +777,9 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
         if (sh_i[1] == 0) {
           fast_done = true;
           k_sel = beam;
+#ifdef PPASR_BEAM_TS
+          ++ts_ok;
+#endif
         }
         TS(6);
       }
@@ -1011,9 +1020,9 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
   __syncthreads();
 #ifdef PPASR_BEAM_TS
   if (tid == 0 && u == 0 && n_frames > 0)
-    printf("beam ts (x10ns/frame): inst %lld lm %lld contrib %lld keys %lld sel %lld keep %lld mat %lld | N %lld C %lld nb %lld frames %d\n",
+    printf("beam ts (x10ns/frame): inst %lld lm %lld contrib %lld keys %lld sel %lld keep %lld mat %lld | N %lld C %lld nb %lld frames %d | fast path: attempted %lld taken %lld\n",
            ts_acc[0] / n_frames, ts_acc[1] / n_frames, ts_acc[2] / n_frames, ts_acc[3] / n_frames, ts_acc[5] / n_frames,
-           ts_acc[6] / n_frames, ts_acc[7] / n_frames, ts_n / n_frames, ts_c / n_frames, ts_nb / n_frames, n_frames);
+           ts_acc[6] / n_frames, ts_acc[7] / n_frames, ts_n / n_frames, ts_c / n_frames, ts_nb / n_frames, n_frames, ts_att, ts_ok);
 #endif
   // ---- persist the state (streaming: CtcBeamSearchDecoderBatch keeps its trie between next() calls) ----
   if (tid == 0) { st[0] = nb; st[1] = n_nodes; }

@@ -14,7 +14,7 @@ import wave
 import numpy as np
 import torch
 
-__all__ = ["AudioFeaturizer", "TextFeaturizer", "load_audio"]
+__all__ = ["AudioFeaturizer", "TextFeaturizer", "load_audio", "db_gain"]
 
 
 
@@ -49,6 +49,19 @@ def resample(samples, sample_rate, target_sample_rate):
     g = gcd(int(sample_rate), int(target_sample_rate))
     up, down = int(target_sample_rate) // g, int(sample_rate) // g
     return resample_poly(np.asarray(samples, np.float64), up, down, window=("kaiser", 14.769656459379492)).astype(np.float32)
+
+
+def db_gain(samples, target_db=-20.0):
+    """Gain factor of ``AudioSegment.normalize(target_db)`` (data_utils/audio.py:287-304 -> rms_db :519-530 -> gain_db
+    :256-264) with the scalar types numpy 1.x gives the reference there: mean square, rms_db and ``target_db - rms_db`` in
+    float32, the power in float64, rounded to float32 when it scales the float32 samples (the arithmetic of csrc/fbank.hip,
+    pinned by tests/golden/ref_wav.npz).  Host-side: ``predict_stream`` needs it because the reference normalises its
+    buffered ``remained_wav`` IN PLACE (see ppasr_amd/predict.py)."""
+    x = np.asarray(samples, np.float32)
+    ms = np.mean(x ** 2) if x.size else np.float32(0.0)
+    rms_db = np.float32(10) * np.log10(ms if ms != 0 else np.float32(1))
+    gain = np.float32(np.float32(target_db) - rms_db)
+    return np.float32(10.0 ** (float(gain) / 20.0))
 
 
 def pcm_bytes_to_float(data, channels=1, samp_width=2):
@@ -94,6 +107,14 @@ class AudioFeaturizer:
     @property
     def feature_dim(self):
         return self._n_mels
+
+    @property
+    def use_db_normalization(self):
+        return bool(self._use_db)
+
+    @property
+    def target_db(self):
+        return self._target_db
 
     def featurize_device(self, samples, sample_rate=None):
         """float32 mono samples in [-1, 1] (numpy or tensor) -> fbank [T, n_mels] float32 DEVICE tensor."""

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 import yaml
 
-from ppasr_amd.data_utils.featurizer import AudioFeaturizer, TextFeaturizer, load_audio, pcm_bytes_to_float
+from ppasr_amd.data_utils.featurizer import AudioFeaturizer, TextFeaturizer, db_gain, load_audio, pcm_bytes_to_float
 from ppasr_amd.decoders.ctc_greedy_decoder import greedy_decoder, greedy_decoder_chunk
 from ppasr_amd.infer_utils.inference_predictor import InferencePredictor
 
@@ -124,6 +124,13 @@ class PPASRPredictor:
         x_chunk = self._audio_featurizer.featurize(self.remained_wav, sample_rate)
         x_chunk = np.asarray(x_chunk, np.float32)[np.newaxis, :]
         self.cached_feat = x_chunk if self.cached_feat is None else np.concatenate([self.cached_feat, x_chunk], axis=1)
+        # The reference's featurize() normalises the AudioSegment it is given IN PLACE (audio_featurizer.py:48-50 ->
+        # audio.py:287-304, `self._samples *= gain`), and here that segment is the buffered `remained_wav`: the samples
+        # that stay buffered for the next call are the GAINED ones, and they are gained again with the next chunk's
+        # factor.  Reproduced (found by tests/golden/ref_wav.npz: without it 12 of 13 streaming texts of the reference's
+        # own test.wav differed).
+        if self._audio_featurizer.use_db_normalization and self.remained_wav.size:
+            self.remained_wav = self.remained_wav * db_gain(self.remained_wav, self._audio_featurizer.target_db)
         # frames consumed x hop (10 ms) at the CALLER's sample rate (the reference's constant 160 is 10 ms at 16 kHz,
         # predict.py:275)
         self.remained_wav = self.remained_wav[int(round(sample_rate * 0.010)) * x_chunk.shape[1]:]

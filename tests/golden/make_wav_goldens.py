@@ -101,6 +101,7 @@ def main():
         captured["probs"] = self._out["output_0"].value
         captured["speech"] = self._in["speech"].value
         captured.setdefault("all", []).append(captured["probs"][0])
+        captured.setdefault("inputs", []).append(captured["speech"][0].copy())
         return r
 
     paddle_infer._Predictor.run = run_and_capture
@@ -122,7 +123,7 @@ def main():
     step = int(sr * CHUNK_SECONDS) * sw
     stream_texts, stream_scores, stream_none = [], [], []
     p.reset_stream()
-    captured["all"] = []
+    captured["all"], captured["inputs"] = [], []
     for i in range(0, len(pcm), step):
         r = p.predict_stream(audio_data=pcm[i:i + step], is_end=(i + step >= len(pcm)))
         stream_none.append(r is None)
@@ -135,6 +136,12 @@ def main():
     s_top2 = np.sort(sp, axis=-1)[:, -2:]
     s_ids, s_margin = sp.argmax(-1).astype(np.int32), (s_top2[:, 1] - s_top2[:, 0]).astype(np.float32)
     print(f"[ref] predict_stream: min top-2 margin {s_margin.min():.2e}")
+    # the feature windows the reference's state machine fed to the model (67 frames, the last one shorter): their sizes
+    # and float64 sums -- they pin the per-call featurisation, the IN-PLACE dB normalisation of the buffered samples
+    # (audio_featurizer.py:48-50 on predict.py:262-268's `remained_wav`) and the window / stride / cache arithmetic
+    win_frames = np.array([w.shape[0] for w in captured["inputs"]], np.int32)
+    win_sums = np.array([w.astype(np.float64).sum() for w in captured["inputs"]], np.float64)
+    win_first = np.stack([w[0] for w in captured["inputs"]]).astype(np.float32)
     print(f"[ref] predict_stream: {len(stream_none)} calls, {sum(stream_none)} returned None, {n_out} output frames, "
           f"final text {len(stream_texts[-1])} characters (== predict's: {stream_texts[-1] == res['text']})")
 
@@ -144,7 +151,7 @@ def main():
                n_feature_frames=np.int32(feats.shape[0]),
                stream_texts=np.array(stream_texts), stream_scores=np.array(stream_scores, np.float64),
                stream_none=np.array(stream_none), stream_out_frames=np.int32(n_out), stream_ids=s_ids,
-               stream_margin=s_margin,
+               stream_margin=s_margin, stream_win_frames=win_frames, stream_win_sums=win_sums, stream_win_first=win_first,
                chunk_seconds=np.float64(CHUNK_SECONDS), vocab_size=np.int32(V), sd_seed=np.int32(SD_SEED))
     np.savez_compressed(os.path.join(HERE, "ref_wav.npz"), **out)
     print("wrote ref_wav.npz", os.path.getsize(os.path.join(HERE, "ref_wav.npz")) // 1024, "KiB")

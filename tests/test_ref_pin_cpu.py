@@ -180,3 +180,37 @@ def test_reference_wav_oracle_chain_matches_reference_predictor_source():
     vocab = synth_vocabulary(V)
     if clear.all():
         assert "".join(vocab[i] for i in tok).replace("<space>", " ") == str(z["predict_text"])
+
+
+def test_reference_wav_stream_windows_with_in_place_normalisation():
+    """predict_stream's state machine (predict.py:232-337) restated with the fbank oracle: per call the buffered samples are
+    featurised, NORMALISED IN PLACE (the reference's AudioSegment.normalize mutates `remained_wav`), cut by 160 x frames;
+    windows of 67 frames, stride 64, 3 cached frames.  The windows must be the ones the reference's own source fed to its
+    model (sizes, first rows, float64 sums from tests/golden/ref_wav.npz)."""
+    from oracle import fbank_oracle
+    from ppasr_amd.data_utils.featurizer import db_gain
+    with np.load(os.path.join(HERE, "golden", "ref_wav.npz")) as z:
+        z = {k: z[k] for k in z.files}
+    x = z["samples"].astype(np.float32) / 32768.0
+    step = int(int(z["sample_rate"]) * float(z["chunk_seconds"]))
+    remained, cached, wins = None, None, []
+    for i in range(0, len(x), step):
+        is_end = i + step >= len(x)
+        remained = x[i:i + step] if remained is None else np.concatenate([remained, x[i:i + step]])
+        feat = fbank_oracle.featurize(remained, int(z["sample_rate"])).astype(np.float32)
+        remained = remained * db_gain(remained, -20)
+        cached = feat if cached is None else np.concatenate([cached, feat], 0)
+        remained = remained[160 * feat.shape[0]:]
+        n = cached.shape[0]
+        if (n < 67 and not is_end) or n < 7:
+            continue
+        end = None
+        for cur in range(0, n - (7 if is_end else 67) + 1, 64):
+            end = min(cur + 67, n)
+            wins.append(cached[cur:end])
+        cached = cached[end - 3:]
+    assert [w.shape[0] for w in wins] == z["stream_win_frames"].tolist()
+    first = np.stack([w[0] for w in wins])
+    assert float(np.abs(first - z["stream_win_first"]).max()) < 1e-4
+    sums = np.array([w.astype(np.float64).sum() for w in wins])
+    assert float(np.abs(sums - z["stream_win_sums"]).max()) < 0.05  # (5 360 values of magnitude ~10 per window)
