@@ -238,7 +238,7 @@ size_t beam_lds_bytes(const BeamConfig& c) {
   n += (size_t)Vp * 2;                             // kidx (int16)
   n += (((size_t)c.beam * c.n_cand_max) + 3) & ~(size_t)3;  // exists flags
   n = (n + 7) & ~(size_t)7;                        // (fkey: 8-byte entries)
-  n += (size_t)kFastCap * 16 + (size_t)kFastBeam * 8;  // staircase fast path: keys, element ids, log-probs, rank tables
+  n += (size_t)kFastCap * 8 + (size_t)kFastBeam * 12;  // staircase fast path: slot keys, the selected keys, rank table
   n += (size_t)c.beam * 4;                         // surv_lp
   n += (size_t)c.beam * (1 + c.n_cand_max) * 4;    // score keys
   return (n + 15) & ~(size_t)15;
@@ -469,11 +469,9 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
   uint8_t* exists = reinterpret_cast<uint8_t*>(p); p += (((size_t)beam * CM) + 3) & ~(size_t)3;
   // staircase fast path (small beams without a scorer, see (e')): the restricted element list and its bookkeeping
   p = smem + (((size_t)(p - smem) + 7) & ~(size_t)7);
-  unsigned long long* fkey = reinterpret_cast<unsigned long long*>(p); p += kFastCap * 8;
-  int* f_e = reinterpret_cast<int*>(p); p += kFastCap * 4;
-  float* f_lp = reinterpret_cast<float*>(p); p += kFastCap * 4;
+  unsigned long long* fkey = reinterpret_cast<unsigned long long*>(p); p += kFastCap * 8;          // keys of the list's slots
+  unsigned long long* srank_key = reinterpret_cast<unsigned long long*>(p); p += kFastBeam * 8;  // the `beam` smallest, by rank
   int* hyp_of_rank = reinterpret_cast<int*>(p); p += kFastBeam * 4;
-  int* srank_s = reinterpret_cast<int*>(p); p += kFastBeam * 4;
   float* surv_lp = reinterpret_cast<float*>(p); p += beam * 4;  // log-probability of a surviving CHILD, by slot of the next beam
   uint32_t* skey = reinterpret_cast<uint32_t*>(p);  // [beam * (1 + CM)] score keys of the frame's elements
 
@@ -549,8 +547,22 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
   // (e') is taken by searches without an external scorer (its upper bound on a child's score needs score = acoustic only)
   // ... whose candidate lists are sorted by probability (k_ctc_prune leaves them in index order when nothing is pruned:
   // cutoff_prob >= 1 with cutoff_top_n >= V)
-  const bool fast_ok = !has_lm && beam <= kFastBeam && BT >= 128 && cfg.fast_path != 0 &&
-                       (cfg.cutoff_prob < 1.0 || cfg.cutoff_top_n < V);
+  bool fast_ok = !has_lm && beam <= kFastBeam && BT >= 128 && cfg.fast_path != 0 &&
+                 (cfg.cutoff_prob < 1.0 || cfg.cutoff_top_n < V);
+  // the list's slots are the same in every frame: slot q < beam = existing hypothesis q, then row r (the hypothesis of score
+  // rank r) with its first K_r = beam / (r + 1) + margin candidates; slot `tid` is this thread's (my_r < 0: none)
+  int my_r = -1, my_k = 0, n_s0 = beam;
+  if (fast_ok) {
+    int off = tid - beam;
+    for (int r = 0; r < beam; ++r) {
+      const int kr = beam / (r + 1) + kFastMargin;
+      if (my_r < 0 && off >= 0 && off < kr) { my_r = r; my_k = off; }
+      off -= kr;
+      n_s0 += kr;
+    }
+    fast_ok = n_s0 <= kFastCap;
+  }
+  const int my_row_k = beam / (lane + 1) + kFastMargin;  // K_r of row r = lane (the verification's lanes)
   for (int t = 0; t < n_frames; ++t) {
     // ---- (b, c) this frame's pruned characters (get_pruned_log_probs, done by the pre-pass) ----
     const int C = pre_C;
@@ -566,7 +578,7 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
     }
     if (t + 1 < n_frames) fetch(t + 1);
     for (int e = tid; e < nb * C; e += BT) exists[e] = 0;
-    if (tid == 0) { sh_i[0] = 0; sh_i[1] = 0; }  // fast path: merged children of the frame, "verification failed"
+    if (tid == 0) sh_i[1] = 0;  // fast path: "verification failed"
     lds_barrier();
     TS(0);
     // ---- external scorer: pruning threshold of this frame and the LM term of every possible extension ----
@@ -626,6 +638,7 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
     TS(1);
     // ---- (d) contributions received by the hypotheses already in the beam ----
     const float lpb = lp_of(blank);
+    bool merged = false;
     for (int q = tid; q < nb; q += BT) {
       const int cq = cur.chr[q];
       float bc = (lpb != kNotCand && !pruned(lpb, q)) ? lpb + cur.score[q] : kNegInf;
@@ -643,21 +656,25 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
           if (!pruned(lq, pi))
             nbc = lse(nbc, ext_logp(pi, kidx[cq], (word_lm && cq == space_id) ? lm_dict_arc(cfg.lm, cur.dst[pi], cq) : 0));
           exists[pi * C + kidx[cq]] = 1;
-          if (fast_ok) atomicAdd(&sh_i[0], 1);  // (distinct (parent, character) per hypothesis: one flag each)
+          merged = true;  // (distinct (parent, character) per hypothesis: one flag each)
         }
       }
       new_b[q] = bc;
       new_nb[q] = nbc;
       new_score[q] = lse(bc, nbc);
-      if (fast_ok && nb <= kFastBeam) {  // rank of the hypothesis by its CURRENT score (rows of the staircase, see (e'))
-        const float sq = cur.score[q];
-        int r = 0;
-        for (int i = 0; i < nb; ++i) {
-          const float si = cur.score[i];
-          r += (si > sq || (si == sq && i < q)) ? 1 : 0;
-        }
-        hyp_of_rank[r] = q;
+    }
+    if (fast_ok && wave == 0) {  // (nb <= beam <= 16: the loop above ran in lanes of wave 0) merged children of the frame
+      const unsigned long long m = __ballot(merged);
+      if (lane == 0) sh_i[0] = __popcll(m);
+    }
+    if (fast_ok && wave == 1 && lane < nb) {  // an otherwise idle wave: rank of every hypothesis by its CURRENT score
+      const float sq = cur.score[lane];       // (rows of the staircase, see (e'))
+      int r = 0;
+      for (int i = 0; i < nb; ++i) {
+        const float si = cur.score[i];
+        r += (si > sq || (si == sq && i < lane)) ? 1 : 0;
       }
+      hyp_of_rank[r] = lane;
     }
     lds_barrier();
     if (word_lm) {
@@ -690,86 +707,81 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
     // the hypotheses are taken in score order (rank r) and the candidates in list order (probability descending).  A child
     // with (r + 1)(k + 1) > beam has beam elements in front of it -- unless some of those are lowered (a repeated
     // character uses log P_b) or merged into an existing hypothesis.  So: rank only the existing hypotheses and the children
-    // with k < K_r = beam / (r + 1) + margin (<= kFastCap elements instead of nb (1 + C)), each key against all others with
-    // ballots (no histograms, no scans), and VERIFY afterwards that the best excluded child of every row, bounded by
+    // with k < K_r = beam / (r + 1) + margin (<= kFastCap slots instead of nb (1 + C) elements), each key against all others
+    // with ballots (no histograms, no scans), and VERIFY afterwards that the best excluded child of every row, bounded by
     // U(i, K_r), is strictly below the last score taken.  If that fails -- or the list does not hold `beam` valid elements
-    // -- the frame falls through to the general selection below; so the result is the general one bit for bit: same
-    // survivors, same (element) order, same node ids.
+    // -- the frame takes the general selection below; so the result is the general one bit for bit: same survivors, same
+    // (element) order, same node ids.  (Tried and slower, tools/experiments/r05: the whole path in ONE wave without
+    // barriers -- a lone wave issues a dependent instruction every ~9 cycles: 5.4 us per frame against 4.8.)
     int k_sel = 0;
     int* surv = nxt.par;  // temporary list in the next beam's `par` column: slot p is read, then overwritten, by thread p
     bool fast_done = false;
-    if (fast_ok && nb <= kFastBeam && C > 0) {
+    if (fast_ok && C > 0) {
       const int has_blank = kidx[blank] >= 0 ? 1 : 0;
       const int n_valid_f = nb + nb * (C - has_blank) - sh_i[0];  // = n_valid of (e): existing + non-blank, non-merged children
-      int n_s = nb;  // list: [0, nb) the existing hypotheses, then row r = rank r's children k < K_r
-      for (int r = 0; r < nb; ++r) n_s += min(C, beam / (r + 1) + kFastMargin);
-      if (n_valid_f > beam && n_s <= kFastCap) {  // (block-uniform)
+      if (n_valid_f > beam) {  // (block-uniform)
 #ifdef PPASR_BEAM_TS
         ++ts_att;
 #endif
-        for (int sidx = tid; sidx < n_s; sidx += BT) {
+        if (tid < n_s0) {
           unsigned long long key = ~0ull;
-          int e = sidx;
-          float log_p = 0.f;
-          if (sidx < nb) {
-            key = make_key(new_score[sidx], cur.chr[sidx], sidx);
-          } else {
-            int r = 0, off = sidx - nb;
-            for (;; ++r) {
-              const int kr = min(C, beam / (r + 1) + kFastMargin);
-              if (off < kr) break;
-              off -= kr;
-            }
-            const int i = hyp_of_rank[r], k = off;
+          if (tid < beam) {
+            if (tid < nb) key = make_key(new_score[tid], cur.chr[tid], tid);
+          } else if (my_r < nb && my_k < C) {
+            const int i = hyp_of_rank[my_r], k = my_k;
             const int c = cand_c[k];
-            e = nb + i * C + k;
             if (c != blank && !exists[i * C + k]) {
               const float lpk = cand_lp[k];
-              log_p = kNegInf;
+              float log_p = kNegInf;
               if (c == cur.chr[i]) { if (cur.b[i] > kNegInf) log_p = lpk + cur.b[i]; }
               else log_p = lpk + cur.score[i];
-              key = make_key(log_p, c, e);
+              key = make_key(log_p, c, nb + i * C + k);
             }
           }
-          fkey[sidx] = key;
-          f_e[sidx] = e;
-          f_lp[sidx] = log_p;
+          fkey[tid] = key;
         }
-        if (tid < kFastBeam) srank_s[tid] = -1;
+        if (tid < kFastBeam) srank_key[tid] = ~0ull;
         lds_barrier();
         TS(3);
-        {  // rank of every key = number of smaller keys (keys are unique: the element id is part of them)
-          const unsigned long long k0 = lane < n_s ? fkey[lane] : ~0ull, k1 = lane + 64 < n_s ? fkey[lane + 64] : ~0ull;
-          for (int i = wave; i < n_s; i += BT / 64) {
+        {  // rank of every key = number of smaller keys (keys are unique: the element id is part of them): wave w ranks the
+           // keys w, w + NW, ...  (requesting all of a wave's keys before the first is used was measured slower: the
+           //  unrolled form walks kFastCap / NW slots whatever the list holds)
+          const unsigned long long k0 = lane < n_s0 ? fkey[lane] : ~0ull, k1 = lane + 64 < n_s0 ? fkey[lane + 64] : ~0ull;
+          for (int i = wave; i < n_s0; i += BT / 64) {
             const unsigned long long ki = fkey[i];
             const int rank = __popcll(__ballot(k0 < ki)) + __popcll(__ballot(k1 < ki));
-            if (lane == 0 && ki != ~0ull && rank < beam) srank_s[rank] = i;
+            if (lane == 0 && ki != ~0ull && rank < beam) srank_key[rank] = ki;
           }
         }
         lds_barrier();
         TS(5);
         // survivors in ELEMENT order (the order the general compaction leaves them in) + the verification
-        if (tid < beam) {
-          const int sp = srank_s[tid];
-          if (sp < 0) {
-            sh_i[1] = 1;  // fewer than `beam` valid elements in the list
-          } else {
-            const int ep = f_e[sp];
-            int pos = 0;
-            for (int j = 0; j < beam; ++j) {
-              const int sj = srank_s[j];
-              pos += (sj >= 0 && f_e[sj] < ep) ? 1 : 0;
-            }
-            surv[pos] = ep;
-            surv_lp[pos] = f_lp[sp];
+        if (wave == 0) {  // lane = (survivor p = lane & 15, quarter g = lane >> 4 of the others it is compared with)
+          const int pidx = lane & 15, g = lane >> 4;
+          const unsigned long long kp = pidx < beam ? srank_key[pidx] : ~0ull;
+          const int ep = (int)(kp & 0x3FFFFull);  // (make_key: the element id is the low 18 bits)
+          int pos = 0;
+#pragma unroll
+          for (int j = 0; j < kFastBeam / 4; ++j) {
+            const int jj = g + 4 * j;
+            const unsigned long long kj = jj < beam ? srank_key[jj] : ~0ull;
+            pos += (kj != ~0ull && (int)(kj & 0x3FFFFull) < ep) ? 1 : 0;
           }
-        } else if (tid >= 64 && tid < 64 + nb) {  // (another wave: row r = tid - 64)
-          const int r = tid - 64;
-          const int kr = beam / (r + 1) + kFastMargin;
-          const int s_last = srank_s[beam - 1];
-          if (kr < C && s_last >= 0) {
-            const uint32_t thr = (uint32_t)(fkey[s_last] >> 32);  // score key of the last element taken
-            const float ub = cand_lp[kr] + cur.score[hyp_of_rank[r]];
+          pos += __shfl_xor(pos, 16);
+          pos += __shfl_xor(pos, 32);
+          if (lane < beam) {
+            if (kp == ~0ull) {
+              sh_i[1] = 1;  // fewer than `beam` valid elements in the list
+            } else {
+              surv[pos] = ep;
+              surv_lp[pos] = score_of_key((uint32_t)(kp >> 32));
+            }
+          }
+        } else if (wave == 1 && lane < nb) {  // (another wave: row r = lane)
+          const unsigned long long kl = srank_key[beam - 1];
+          if (my_row_k < C && kl != ~0ull) {
+            const uint32_t thr = (uint32_t)(kl >> 32);  // score key of the last element taken
+            const float ub = cand_lp[my_row_k] + cur.score[hyp_of_rank[lane]];
             if (desc_key(ub) <= thr) sh_i[1] = 1;  // an excluded child could score >= the last one taken
           }
         }

@@ -224,8 +224,13 @@ def test_staircase_fast_path_is_bit_identical_to_the_general_selection(T, V, bea
             torch.cuda.synchronize()
         outs.append((tokens.cpu().numpy(), ln.cpu().numpy(), sc.cpu().numpy()))
     assert np.array_equal(outs[0][1], outs[1][1])
-    assert np.array_equal(outs[0][0], outs[1][0])
-    assert np.array_equal(outs[0][2], outs[1][2])  # float64 scores: the same sums in the same order
+    for b in range(B):
+        for r in range(nbest):
+            n = outs[0][1][b, r]
+            if n < 0:  # fewer hypotheses than nbest (short utterances): the row is not written
+                continue
+            assert np.array_equal(outs[0][0][b, r, :n], outs[1][0][b, r, :n]), (b, r)
+            assert outs[0][2][b, r] == outs[1][2][b, r], (b, r)  # float64 scores: the same sums in the same order
     tokens, ln, sc = outs[0]
     if kind == "tied":  # (exact score ties at the cut: the oracle's container order decides there; only the two selections
         return          #  of the kernel are compared on these tables)
