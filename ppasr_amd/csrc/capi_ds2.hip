@@ -183,7 +183,7 @@ ppasr_status ds2_create(ppasr_model_s* m, BlobMap& sd) {
 }
 
 struct Ds2Ws {
-  size_t y1, x, gx, ya, yb, h0, h1, c, lens32, hbuf, cbuf, yring, part, part_floats, total;  // float offsets
+  size_t y1, x, gx, ya, yb, h0, h1, c, lens32, hbuf, cbuf, yring, part, part_floats, xbuf, pflag, total;  // float offsets
 };
 static Ds2Ws ds2_ws(const ppasr_model_s* m, int B, int T) {
   const Ds2W& W = m->ds2;
@@ -207,6 +207,9 @@ static Ds2Ws ds2_ws(const ppasr_model_s* m, int B, int T) {
   // K-slice partial sums of the dense layers when the launch is under-filled (few frames: single utterances)
   w.part_floats = M <= 512 ? (size_t)8 * M * std::max((size_t)W.gates * W.H, (size_t)W.Vpad) : 0;
   w.part = o; o += al64(w.part_floats);
+  // persistent recurrence of single utterances (k_lstm_persist): exchange granules [2][dirs][H] x 8 bytes, abort flag
+  w.xbuf = o; o += al64((size_t)4 * W.dirs * W.H);
+  w.pflag = o; o += 64;
   w.total = o;
   return w;
 }
@@ -281,6 +284,14 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
     HIP_TRY(hipGetLastError());
     return PPASR_OK;
   }
+  // (PPASR_DS2_PERSIST=0, read per call: the per-step kernels, for A/B measurements and the route-equality test)
+  const char* persist_env = getenv("PPASR_DS2_PERSIST");
+  const bool persist = B == 1 && G == 4 && H == 1024 && Tp > 0 && h->ds2_persist && !(persist_env && persist_env[0] == '0') &&
+                       lstm_persist_fits(H, dirs);
+  if (persist) {
+    HIP_TRY(hipMemsetAsync(ws + wl.xbuf, 0, (size_t)4 * dirs * H * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(ws + wl.pflag, 0, 64 * sizeof(float), st));
+  }
   for (int l = 0; l < W.n_layers; ++l) {
     const Ds2LayerW& Lw = h->ds2_layers[l];
     // gate pre-activations of all frames and both directions: [M][dirs*4H]; the step kernel wants [dirs][M][4H]
@@ -299,6 +310,12 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
     float* hn = h1;
     // the matrix-core step needs H % 64 == 0 (8 waves x whole 8-wide k-groups); the VALU kernel handles the rest
     const bool mfma_step = (H % 64 == 0) && B >= 2;  // (one utterance: the VALU kernel's 5.8 us per step is the faster one)
+    if (persist) {
+      // one utterance, LSTM, H = 1024: the layer's recurrence as ONE launch with W_hh in registers (ds2_kernels.hip)
+      launch_lstm_persist(gx, Lw.w_hh, h0, c, h1, out, lens32, Tp, H, dirs, reinterpret_cast<unsigned long long*>(ws + wl.xbuf),
+                          1u + (unsigned int)l * (unsigned int)(Tp + 1), reinterpret_cast<int*>(ws + wl.pflag), st);
+      hp = h1;
+    } else
     for (int s = 0; s < Tp; ++s) {
       if (G == 3 && mfma_step) launch_gru_step_mfma(gx, Lw.w_hh_pk, Lw.b_hh, hp, hn, out, lens32, B, Tp, H, dirs, s, st);
       else if (G == 3) launch_gru_step(gx, Lw.w_hh, Lw.b_hh, hp, hn, out, lens32, B, Tp, H, dirs, s, st);
@@ -316,5 +333,18 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
   launch_dense(in, in_ld, W.ctc_w, W.ctc_b, probs, M, dirs * H, W.Vpad, W.V, W.V, st, 1.0f, part, wl.part_floats);
   launch_softmax_from_stats(probs, nullptr, nullptr, M, W.V, st);
   HIP_TRY(hipGetLastError());
+  if (persist) {
+    // the persistent launches wait for one another's workgroups: if one gave up (the chip was not free for the whole
+    // grid), say so instead of returning what it left -- this call synchronises, re-runs on the per-step kernels, and the
+    // handle stays on them
+    int gave_up = 0;
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(&gave_up, ws + wl.pflag, sizeof(int), hipMemcpyDeviceToHost));
+    if (gave_up) {
+      h->ds2_persist = false;
+      return ppasr_ds2_encode(h, feats, lens, B, T, init_h, init_c, probs, out_lens, final_h, final_c, workspace, workspace_bytes,
+                              stream);
+    }
+  }
   return PPASR_OK;
 }

@@ -122,6 +122,7 @@ struct ppasr_model_s {
   const float *preln_g = nullptr, *preln_b = nullptr;
   // DeepSpeech2 (model_type == PPASR_MODEL_DEEPSPEECH2)
   Ds2W ds2{};
+  bool ds2_persist = true;  // single utterances: the recurrence of a layer as one persistent launch (cleared if one ever gave up)
   std::vector<Ds2LayerW> ds2_layers;
   float* taps = nullptr;
   size_t taps_floats = 0;

@@ -42,6 +42,15 @@ void launch_ds2_conv2(const float* y1, const float* w, const float* bias, float*
 void launch_ds2_lens(const int64_t* lens, int32_t* out32, int64_t* out64, int B, int Tp, hipStream_t st);
 void launch_lstm_step(const float* gx, const float* whh, const float* hprev, float* hnext, float* c, float* y,
                       const int32_t* lens, int B, int T, int H, int dirs, int step, hipStream_t st);
+// The whole recurrence of ONE utterance's layer as a single persistent launch (ds2_kernels.hip k_lstm_persist; LSTM,
+// H = 1024): W_hh stays in registers, the time steps exchange h through xbuf (2 * dirs * H 8-byte granules, tags epoch ..
+// epoch + T - 1 must not occur in it beforehand: zero it once per call and give every layer its own range).
+//   gx [dirs][T][4H], h_init / h_final [dirs][H], c_state [dirs][H] (in: initial, out: final), y [T][dirs * H] pre-zeroed,
+//   lens [1] valid steps, *abort_flag != 0 afterwards: a workgroup gave up waiting -- the outputs are invalid
+bool lstm_persist_fits(int H, int dirs);
+void launch_lstm_persist(const float* gx, const float* whh, const float* h_init, float* c_state, float* h_final, float* y,
+                         const int32_t* lens, int T, int H, int dirs, unsigned long long* xbuf, unsigned int epoch, int* abort_flag,
+                         hipStream_t st);
 // One GRU time step (paddle.nn.GRU, gate rows r, z, c):  r = s(x_r + h_r), z = s(x_z + h_z), c = tanh(x_c + r * h_c),
 // h' = (h - c) * z + c, with x_* = W_ih x + b_ih (gx [dirs][B*T][3H]) and h_* = W_hh h + b_hh.
 void launch_gru_step(const float* gx, const float* whh, const float* bhh, const float* hprev, float* hnext, float* y,

@@ -603,6 +603,145 @@ void launch_lstm_wave(const float* gx0, const Ds2WaveLayer* tab, float* hbuf, fl
   }
 #undef WAVE_LAUNCH
 }
+// ---- persistent recurrence of a single utterance (B = 1, H = 1024, LSTM; any number of directions): ONE launch per
+// layer instead of one per time step ----
+// k_lstm_step streams the layer's W_hh (33.5 MB for both directions) from L2 / MALL at every step: 125 x the bytes the
+// weights have.  Here workgroup (j, dir) keeps the 32 rows of W_hh that belong to its 8 hidden units (4 gates x 8 units x
+// 1024 columns = 128 KB) in REGISTERS for the whole layer -- 512 threads x 64 weights: thread (row = lane & 31, column
+// segment = 2 wave + (lane >> 5)) holds W[row][64 seg .. 64 seg + 64) -- and the time steps are separated by an exchange
+// of the new h through memory instead of a kernel boundary:
+//   * publish: the 8 lanes that own a unit store {bits of h, tag = epoch + step} as ONE 8-byte agent-scope store into
+//     slot (step & 1) of the exchange buffer (data and tag travel together: no separate flag, no fence);
+//   * gather : every thread polls the two granules it stages into LDS (8-byte agent-scope loads) until both carry the tag of
+//     the previous step.  Two slots suffice: a workgroup publishes step s + 1 only after it gathered all of step s, which
+//     every workgroup published only after ITS gather of step s - 1 was complete.
+// Per step: 16 broadcast LDS reads + 64 FMAs per thread, two workgroup barriers, one exchange (MI355X_MICROARCH.md
+// "allgather": 8 KB published by 128 CUs, 2.4 - 3 us).  Bounded spins: a workgroup that waits longer than kPersistSpins
+// polls raises *abort_flag (so do all others on seeing it) and the host falls back to the per-step kernels -- the launch
+// needs all its workgroups resident (H / 8 x dirs <= CUs x occupancy, checked on the host), nothing else may hold the chip.
+constexpr int kPersistThreads = 512;
+constexpr int kPersistSpins = 200000;  // ~0.2 s
+__global__ __launch_bounds__(kPersistThreads) void k_lstm_persist(const float* __restrict__ gx, const float* __restrict__ whh,
+                                                                  const float* __restrict__ h_init, float* __restrict__ c_state,
+                                                                  float* __restrict__ h_final, float* __restrict__ y,
+                                                                  const int32_t* __restrict__ lens, int T, int dirs,
+                                                                  unsigned long long* __restrict__ xbuf, unsigned int epoch,
+                                                                  int* __restrict__ abort_flag) {
+  constexpr int H = 1024;
+  __shared__ __attribute__((aligned(16))) float hs[H];
+  __shared__ float part[kPersistThreads / 64][32];
+  __shared__ int s_abort;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dir = blockIdx.y, u0 = blockIdx.x * 8;
+  const int row = lane & 31, seg = 2 * wave + (lane >> 5);
+  const int gate = row >> 3, unit = row & 7;
+  float w[64];
+  {
+    const float* wr = whh + ((size_t)dir * 4 * H + (size_t)gate * H + u0 + unit) * H + seg * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wr + 4 * i);
+      w[4 * i] = v[0]; w[4 * i + 1] = v[1]; w[4 * i + 2] = v[2]; w[4 * i + 3] = v[3];
+    }
+  }
+  const int len = min(max(lens[0], 0), T);
+  const float* gxd = gx + (size_t)dir * T * 4 * H + (size_t)gate * H + u0 + unit;  // + t * 4H: this lane's gate row (wave 0, lanes < 32)
+  unsigned long long* xb = xbuf + (size_t)dir * H;                                  // + (slot) * dirs * H
+  const bool owner = wave == 0 && lane < 8;
+  float c_reg = owner ? c_state[(size_t)dir * H + u0 + lane] : 0.f;
+  float h_last = owner ? h_init[(size_t)dir * H + u0 + lane] : 0.f;
+  if (tid == 0) s_abort = 0;
+  for (int s = 0; s < len; ++s) {
+    const int t = dir == 0 ? s : len - 1 - s;
+    float gxv = 0.f;
+    if (wave == 0 && lane < 32) gxv = gxd[(size_t)t * 4 * H];  // (requested before the gather: off the critical path)
+    if (s == 0) {
+      hs[2 * tid] = h_init[(size_t)dir * H + 2 * tid];
+      hs[2 * tid + 1] = h_init[(size_t)dir * H + 2 * tid + 1];
+    } else {
+      const unsigned long long* src = xb + (size_t)((s - 1) & 1) * dirs * H + 2 * tid;
+      const unsigned int want = epoch + (unsigned int)(s - 1);
+      unsigned long long v0, v1;
+      int spins = 0;
+      for (;;) {
+        v0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned int)(v0 >> 32) == want && (unsigned int)(v1 >> 32) == want) break;
+        __builtin_amdgcn_s_sleep(2);
+        ++spins;
+        if (spins > kPersistSpins ||
+            ((spins & 63) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_abort = 1;
+          break;
+        }
+      }
+      hs[2 * tid] = __uint_as_float((unsigned int)v0);
+      hs[2 * tid + 1] = __uint_as_float((unsigned int)v1);
+    }
+    __syncthreads();
+    if (s_abort) break;  // (uniform: written before the barrier)
+    float acc = 0.f;
+    {
+      const float* hp = hs + seg * 64;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(hp + 4 * i);
+        acc = fmaf(w[4 * i], hv[0], acc);
+        acc = fmaf(w[4 * i + 1], hv[1], acc);
+        acc = fmaf(w[4 * i + 2], hv[2], acc);
+        acc = fmaf(w[4 * i + 3], hv[3], acc);
+      }
+    }
+    acc += __shfl_xor(acc, 32);
+    if (lane < 32) part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+      float g = gxv;
+      if (lane < 32) {
+#pragma unroll
+        for (int wv = 0; wv < kPersistThreads / 64; ++wv) g += part[wv][lane];
+      }
+      // lane u < 8 owns unit u: its gates sit in lanes u, 8 + u, 16 + u, 24 + u
+      const float gi = __shfl(g, lane & 7), gf = __shfl(g, 8 + (lane & 7)), gg = __shfl(g, 16 + (lane & 7)),
+                  go = __shfl(g, 24 + (lane & 7));
+      if (lane < 8) {
+        const float ig = 1.0f / (1.0f + expf(-gi));
+        const float fg = 1.0f / (1.0f + expf(-gf));
+        const float cg = tanhf(gg);
+        const float og = 1.0f / (1.0f + expf(-go));
+        c_reg = fg * c_reg + ig * cg;
+        h_last = og * tanhf(c_reg);
+        const unsigned long long granule = ((unsigned long long)(epoch + (unsigned int)s) << 32) | (unsigned long long)__float_as_uint(h_last);
+        __hip_atomic_store(xb + (size_t)(s & 1) * dirs * H + u0 + lane, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        y[(size_t)t * (size_t)(dirs * H) + (size_t)dir * H + u0 + lane] = h_last;
+      }
+    }
+  }
+  if (owner) {
+    c_state[(size_t)dir * H + u0 + lane] = c_reg;
+    h_final[(size_t)dir * H + u0 + lane] = h_last;
+  }
+}
+
+// -> false: the launch would not be wholly resident (hipOccupancy x CUs < workgroups); the caller takes the per-step route
+bool lstm_persist_fits(int H, int dirs) {
+  if (H != 1024) return false;
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lstm_persist, kPersistThreads, 0) != hipSuccess) return false;
+  // (one workgroup per CU is the intended shape; a partitioned device with fewer CUs takes the per-step kernels)
+  return per_cu >= 1 && cus >= (H / 8) * dirs;
+}
+void launch_lstm_persist(const float* gx, const float* whh, const float* h_init, float* c_state, float* h_final, float* y,
+                         const int32_t* lens, int T, int H, int dirs, unsigned long long* xbuf, unsigned int epoch, int* abort_flag,
+                         hipStream_t st) {
+  (void)H;
+  PPASR_LAUNCH(k_lstm_persist, dim3(1024 / 8, dirs), dim3(kPersistThreads), 0, st, gx, whh, h_init, c_state, h_final, y, lens, T,
+               dirs, xbuf, epoch, abort_flag);
+}
+
 // [B][H] row-major <-> the fragment order of k_lstm_wave's state buffers (initial / final state boxes)
 __global__ __launch_bounds__(256) void k_state_reorder(const float* __restrict__ src, float* __restrict__ dst, int B, int H,
                                                        int to_frag) {

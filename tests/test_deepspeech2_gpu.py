@@ -145,3 +145,52 @@ def test_deepspeech2_wavefront_row_tiles_and_gru(gru, B):
         assert _rel(h.cpu().numpy(), rh.numpy()) < TOL
         if not gru:
             assert _rel(c.cpu().numpy(), rc.numpy()) < TOL
+
+
+class _persist:
+    """PPASR_DS2_PERSIST is read at every call: 0 = the per-step kernels for single utterances."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        import os
+        self.old = os.environ.get("PPASR_DS2_PERSIST")
+        os.environ["PPASR_DS2_PERSIST"] = "1" if self.on else "0"
+
+    def __exit__(self, *a):
+        import os
+        if self.old is None:
+            os.environ.pop("PPASR_DS2_PERSIST", None)
+        else:
+            os.environ["PPASR_DS2_PERSIST"] = self.old
+
+
+@pytest.mark.parametrize("streaming,T,length", [(False, 498, 498), (False, 211, 150), (True, 331, 331), (False, 9, 9)])
+def test_single_utterance_persistent_recurrence_equals_per_step_route(streaming, T, length):
+    """B = 1, LSTM, 1024 units: a layer's recurrence as ONE persistent launch (W_hh in registers, time steps exchanged through
+    tagged 8-byte granules, ds2_kernels.hip k_lstm_persist) against the per-step kernels and the oracle -- probabilities,
+    final states, a padded utterance (length < T: the reverse direction starts at length - 1), initial states carried in."""
+    V, L = 211, 3
+    sd = deepspeech2_state_dict(vocab_size=V, num_rnn_layers=L, streaming=streaming, seed=401, perturb_norm=True)
+    model = _model(sd, V, L, streaming)
+    x, _ = synth_features(1, T, seed=402)
+    lens = np.array([length])
+    dirs = 1 if streaming else 2
+    rng = np.random.default_rng(5)
+    h0 = (0.3 * rng.standard_normal((L * dirs, 1, 1024))).astype(np.float32)
+    c0 = (0.3 * rng.standard_normal((L * dirs, 1, 1024))).astype(np.float32)
+    outs = []
+    for on in (True, False):
+        with _persist(on):
+            probs, ol, fh, fc = model.get_encoder_out_chunk(x, lens, h0, c0)
+            torch.cuda.synchronize()
+        outs.append((probs.cpu().numpy(), ol.cpu().numpy(), fh.cpu().numpy(), fc.cpu().numpy()))
+    rp, rl, rh, rc = DeepSpeech2Oracle(sd, L, 1024, streaming).forward(x, lens, torch.from_numpy(h0), torch.from_numpy(c0))
+    for got in outs:
+        assert got[1].tolist() == rl.tolist()
+        assert _rel(got[0], rp.numpy()) < TOL and _rel(got[2], rh.numpy()) < TOL and _rel(got[3], rc.numpy()) < TOL
+    e = _rel(outs[0][0], outs[1][0])
+    print(f"persistent vs per-step: probs {e:.2e} h {_rel(outs[0][2], outs[1][2]):.2e} c {_rel(outs[0][3], outs[1][3]):.2e}")
+    assert e < 2e-5 and _rel(outs[0][2], outs[1][2]) < 2e-5 and _rel(outs[0][3], outs[1][3]) < 2e-5
+    assert model._h is not None
