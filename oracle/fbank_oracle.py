@@ -16,15 +16,14 @@ def normalize_to_int16(samples, use_db_normalization=True, target_db=-20.0):
     x = np.asarray(samples, np.float32).copy()
     if use_db_normalization:
         # AudioSegment.rms_db / normalize / gain_db (data_utils/audio.py:519-530,287-304,256-264) with the scalar types numpy
-        # 1.x gives them there (the reference needs numpy 1.x: it reads np.sctypes): mean square and rms_db are float32,
-        # `target_db - rms_db` (int - float32) is float32, `gain / 20.` is float64, the power is taken in float64 and
-        # rounded to float32 when it scales the float32 samples.  Pinned by tests/golden/ref_wav.npz (the reference's
-        # source on its own dataset/test.wav): rounding rms_db to float32 moves the gain by 3 ulp and 1 in 2000 int16
-        # samples by one LSB.
+        # 1.x gives them there (the reference needs numpy 1.x: it reads np.sctypes): the mean square is float32 (np.mean of
+        # the float32 squares: numpy's pairwise sums over 8192-element chunks), its log10 is float32; `10 * <float32
+        # scalar>`, `target_db - rms_db` and `gain / 20.` are float64 (legacy promotion of all-scalar operands), the power
+        # is taken in float64 and rounded to float32 when it scales the float32 samples.  Pinned by tests/golden/
+        # ref_wav.npz (the reference's source on its own dataset/test.wav, make_wav_goldens.py emulating numpy 1.x).
         ms = np.mean(x ** 2) if x.size else np.float32(0.0)
-        rms_db = np.float32(10) * np.log10(ms if ms != 0 else np.float32(1))
-        gain = np.float32(np.float32(target_db) - rms_db)
-        x *= np.float32(10.0 ** (float(gain) / 20.0))
+        rms_db = 10.0 * float(np.log10(ms)) if ms != 0 else 0.0
+        x *= np.float32(10.0 ** ((float(target_db) - rms_db) / 20.0))
     return np.clip(x * np.float32(32768.0), -32768, 32767).astype(np.int16)
 
 

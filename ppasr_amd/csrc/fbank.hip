@@ -22,7 +22,6 @@ namespace {
 
 constexpr int kFT = 256;       // threads per frame
 constexpr int kNfftMax = 512;  // 25 ms at <= 16 kHz (20.48 kHz would still fit)
-constexpr int kMaxPartials = 1024;
 
 struct FbankTables {
   const float* window;   // [win]
@@ -33,45 +32,96 @@ struct FbankTables {
   const int* bank_hi;    // [n_mels] one past the last
 };
 
-__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ x, int n, double* __restrict__ partial) {
-  __shared__ double red[4];
-  double s = 0.0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) s += (double)x[i] * (double)x[i];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+// ---- mean square of AudioSegment.rms_db (audio.py:526: np.mean(self._samples ** 2) on float32 samples) ----
+// numpy reduces a contiguous float32 array in chunks of 8192 elements (the ufunc buffer size), res = 0; res += S(chunk),
+// and S is its pairwise sum: n <= 128 -> eight running sums r[j] += a[8i + j], ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)),
+// then the n % 8 tail element by element; n > 128 -> S(first n2) + S(rest), n2 = n/2 rounded down to a multiple of 8.
+// All float32, squares rounded before they are added (x ** 2 is an array of its own).  The oracle calls np.mean, so the
+// kernel has to reproduce this order bit for bit: one ulp of the mean square moves the gain and with it one int16 sample
+// in a few thousand by one LSB (tests/test_fbank_gpu.py, the 10 s case).
+// One workgroup per chunk: heap node h (root 1) of the chunk's tree = 8 lanes (the eight running sums of a leaf).
+constexpr int kPwChunk = 8192, kPwLeaf = 128, kPwDepth = 6;  // 8192 / 128 = 2^6 leaves at most
+
+// node h of the pairwise tree over n elements: its range; false when an ancestor is already a leaf
+__device__ __forceinline__ bool pw_node(int h, int n, int& off, int& len) {
+  off = 0;
+  len = n;
+  for (int d = 30 - __clz(h); d >= 0; --d) {
+    if (len <= kPwLeaf) return false;
+    int n2 = len / 2;
+    n2 -= n2 % 8;
+    if ((h >> d) & 1) {
+      off += n2;
+      len -= n2;
+    } else {
+      len = n2;
+    }
+  }
+  return true;
 }
 
-__global__ __launch_bounds__(kFT) void k_fbank(const float* __restrict__ x, int n, const double* __restrict__ partial,
-                                               int n_partial, int use_db, float target_db, FbankTables tb, int win, int shift,
+__global__ __launch_bounds__(1024) void k_sumsq(const float* __restrict__ x, int n, float* __restrict__ chunk_sum) {
+  __shared__ float val[2 << kPwDepth];
+  const int c0 = blockIdx.x * kPwChunk, cn = min(kPwChunk, n - c0);
+  const float* a = x + c0;
+  const int h = threadIdx.x >> 3, j = threadIdx.x & 7;  // 128 heap slots x 8 lanes
+  int off = 0, len = 0;
+  const bool node = h >= 1 && pw_node(h, cn, off, len);
+  const bool leaf = node && len <= kPwLeaf;
+  float r = 0.f;
+  if (leaf && len >= 8) {
+    const int full = len - (len % 8);
+    float v = a[off + j];
+    r = __fmul_rn(v, v);
+    for (int i = 8; i < full; i += 8) {
+      v = a[off + i + j];
+      r = __fadd_rn(r, __fmul_rn(v, v));
+    }
+  }
+  // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)): a butterfly over the 8 lanes (float addition commutes)
+  r = __fadd_rn(r, __shfl_xor(r, 1));
+  r = __fadd_rn(r, __shfl_xor(r, 2));
+  r = __fadd_rn(r, __shfl_xor(r, 4));
+  if (leaf && j == 0) {
+    int i = len - (len % 8);
+    if (len < 8) {
+      r = 0.f;
+      i = 0;
+    }
+    for (; i < len; ++i) {
+      const float v = a[off + i];
+      r = __fadd_rn(r, __fmul_rn(v, v));
+    }
+    val[h] = r;
+  }
+  __syncthreads();
+  for (int d = kPwDepth - 1; d >= 0; --d) {
+    if (node && !leaf && j == 0 && 31 - __clz(h) == d) val[h] = __fadd_rn(val[2 * h], val[2 * h + 1]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 8) chunk_sum[blockIdx.x] = val[1];
+}
+
+// gain of AudioSegment.normalize (audio.py:287-304, gain_db :256-264), once per call: ws[n_chunks] <- the linear gain
+__global__ void k_gain(float* __restrict__ ws, int n_chunks, int n, float target_db) {
+  float s = 0.f;
+  for (int c = 0; c < n_chunks; ++c) s = __fadd_rn(s, ws[c]);
+  // the scalar types numpy 1.x gives the reference here (oracle/fbank_oracle.py; pinned by tests/golden/ref_wav.npz): the
+  // mean square and its log10 are float32, 10 * log10, target_db - rms_db and the power are float64, the gain is rounded
+  // to float32 when it scales the float32 samples
+  const float ms = (float)((double)s / (double)n);
+  const double rms_db = ms != 0.f ? 10.0 * (double)(float)log10((double)ms) : 0.0;
+  ws[n_chunks] = (float)pow(10.0, ((double)target_db - rms_db) / 20.0);
+}
+
+__global__ __launch_bounds__(kFT) void k_fbank(const float* __restrict__ x, int n, const float* __restrict__ gain_p,
+                                               int use_db, float target_db, FbankTables tb, int win, int shift,
                                                int nfft, int log2n, int n_mels, float* __restrict__ feats) {
   __shared__ float re[kNfftMax], im[kNfftMax];
   __shared__ double dred[4];
   __shared__ float s_gain, s_mean;
   const int tid = threadIdx.x, frame = blockIdx.x;
-  // ---- gain of AudioSegment.normalize: every frame re-reduces the (<= 1024) partial sums ----
-  if (use_db) {
-    double s = 0.0;
-    for (int i = tid; i < n_partial; i += kFT) s += partial[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((tid & 63) == 0) dred[tid >> 6] = s;
-    __syncthreads();
-    if (tid == 0) {
-      // AudioSegment.rms_db / normalize / gain_db (audio.py:519-530,287-304,256-264) with numpy 1.x's scalar types: the mean
-      // square, rms_db and `target_db - rms_db` are float32, the power is taken in float64 and rounded to float32
-      // (pinned by tests/golden/ref_wav.npz: a float64 rms_db moves the gain by 3 ulp)
-      const float ms = (float)((dred[0] + dred[1] + dred[2] + dred[3]) / (double)n);
-      const float rms_db = 10.0f * (float)log10((double)(ms != 0.f ? ms : 1.f));
-      const float gain_db = target_db - rms_db;
-      s_gain = (float)pow(10.0, (double)gain_db / 20.0);
-    }
-    __syncthreads();
-  } else if (tid == 0) {
-    s_gain = 1.0f;
-  }
+  if (tid == 0) s_gain = use_db ? *gain_p : 1.0f;
   __syncthreads();
   const float gain = s_gain;
   // ---- load: float -> gain -> int16 (clip, truncate) ----
@@ -247,22 +297,28 @@ int ppasr_fbank_frames(ppasr_fbank_handle f, int n_samples) {
   return 1 + (n_samples - f->win) / f->shift;  // snip_edges
 }
 
-size_t ppasr_fbank_workspace_bytes(ppasr_fbank_handle f, int n_samples) {
-  (void)n_samples;
-  return f ? kMaxPartials * sizeof(double) : 0;
+static size_t fbank_ws_bytes(int n_samples) {
+  // one float per 8192-sample chunk of the mean square + the gain; never less than the 8 KiB earlier versions asked for
+  const size_t chunks = n_samples > 0 ? ((size_t)n_samples + kPwChunk - 1) / kPwChunk : 0;
+  return std::max<size_t>(8192, (chunks + 1) * sizeof(float));
 }
+
+size_t ppasr_fbank_workspace_bytes(ppasr_fbank_handle f, int n_samples) { return f ? fbank_ws_bytes(n_samples) : 0; }
 
 ppasr_status ppasr_fbank_compute(ppasr_fbank_handle f, const float* samples, int n_samples, int use_db_norm,
                                  float target_db, float* feats, void* workspace, size_t workspace_bytes, void* stream) {
   if (!f || !samples || !feats || !workspace) return fail(PPASR_EINVAL, "fbank: null argument");
-  if (workspace_bytes < kMaxPartials * sizeof(double)) return fail(PPASR_ENOSPACE, "fbank: workspace too small");
+  if (workspace_bytes < fbank_ws_bytes(n_samples)) return fail(PPASR_ENOSPACE, "fbank: workspace too small");
   const int frames = ppasr_fbank_frames(f, n_samples);
   if (frames <= 0) return PPASR_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  double* partial = static_cast<double*>(workspace);
-  const int nblk = std::min(kMaxPartials, (n_samples + 4095) / 4096);
-  if (use_db_norm) PPASR_LAUNCH(k_sumsq, dim3(nblk), dim3(256), 0, st, samples, n_samples, partial);
-  PPASR_LAUNCH(k_fbank, dim3(frames), dim3(kFT), 0, st, samples, n_samples, partial, nblk, use_db_norm, target_db, f->tb,
+  float* ws = static_cast<float*>(workspace);
+  const int chunks = (n_samples + kPwChunk - 1) / kPwChunk;
+  if (use_db_norm) {
+    PPASR_LAUNCH(k_sumsq, dim3(chunks), dim3(1024), 0, st, samples, n_samples, ws);
+    PPASR_LAUNCH(k_gain, dim3(1), dim3(1), 0, st, ws, chunks, n_samples, target_db);
+  }
+  PPASR_LAUNCH(k_fbank, dim3(frames), dim3(kFT), 0, st, samples, n_samples, ws + chunks, use_db_norm, target_db, f->tb,
                      f->win, f->shift, f->nfft, f->log2n, f->n_mels, feats);
   HIP_TRY(hipGetLastError());
   return PPASR_OK;

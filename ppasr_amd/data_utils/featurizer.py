@@ -53,15 +53,14 @@ def resample(samples, sample_rate, target_sample_rate):
 
 def db_gain(samples, target_db=-20.0):
     """Gain factor of ``AudioSegment.normalize(target_db)`` (data_utils/audio.py:287-304 -> rms_db :519-530 -> gain_db
-    :256-264) with the scalar types numpy 1.x gives the reference there: mean square, rms_db and ``target_db - rms_db`` in
-    float32, the power in float64, rounded to float32 when it scales the float32 samples (the arithmetic of csrc/fbank.hip,
-    pinned by tests/golden/ref_wav.npz).  Host-side: ``predict_stream`` needs it because the reference normalises its
-    buffered ``remained_wav`` IN PLACE (see ppasr_amd/predict.py)."""
+    :256-264) with the scalar types numpy 1.x gives the reference there: the mean square and its log10 in float32, ``10 *
+    log10``, ``target_db - rms_db`` and the power in float64, rounded to float32 when it scales the float32 samples (the
+    arithmetic of csrc/fbank.hip, pinned by tests/golden/ref_wav.npz).  Host-side: ``predict_stream`` needs it because the
+    reference normalises its buffered ``remained_wav`` IN PLACE (see ppasr_amd/predict.py)."""
     x = np.asarray(samples, np.float32)
     ms = np.mean(x ** 2) if x.size else np.float32(0.0)
-    rms_db = np.float32(10) * np.log10(ms if ms != 0 else np.float32(1))
-    gain = np.float32(np.float32(target_db) - rms_db)
-    return np.float32(10.0 ** (float(gain) / 20.0))
+    rms_db = 10.0 * float(np.log10(ms)) if ms != 0 else 0.0
+    return np.float32(10.0 ** ((float(target_db) - rms_db) / 20.0))
 
 
 def pcm_bytes_to_float(data, channels=1, samp_width=2):

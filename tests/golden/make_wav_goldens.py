@@ -56,11 +56,22 @@ def main():
     from ppasr.model_utils.conformer.model import ConformerModel
     from ppasr.predict import PPASRPredictor
 
-    # numpy 1.x scalar promotion for AudioSegment.gain_db (data_utils/audio.py:256-264).  The reference only runs on
-    # numpy 1.x (np.sctypes above); there `np.float32 gain / 20.` is a float64 (legacy value-based promotion), the power is
-    # taken in float64 and rounded to float32 once when it scales the samples.  numpy 2 (NEP 50) keeps the whole expression
-    # in float32: a gain 1 ulp away, 63 of this file's 134 240 int16 samples one LSB away, log-mel values up to 5e-3 away.
-    # Handing the method the same value as a Python float reproduces the numpy 1.x arithmetic on numpy 2.
+    # numpy 1.x scalar promotion in AudioSegment.rms_db / normalize / gain_db (data_utils/audio.py:519-530,287-304,256-264).
+    # The reference only runs on numpy 1.x (np.sctypes above).  There an operation between a numpy scalar and a Python
+    # number promotes like two arrays (legacy rule for all-scalar operands; NEP 50's table: `uint8(1) + 2 -> int64`,
+    # `float32(1) + 3e100 -> float64`): `10 * np.log10(mean_square)` is int64 x float32 = float64 -- ten times the float32
+    # logarithm, exactly --, `target_db - rms_db` and `gain / 20.` stay float64, the power is taken in float64 and rounded
+    # to float32 once, when it scales the float32 samples.  numpy 2 (NEP 50) keeps rms_db and the gain in float32 instead
+    # (3 ulp of the linear gain; about 1 int16 sample in 2 000 one LSB away, log-mel values up to 5e-3 away).  Handing the
+    # two methods Python floats reproduces the numpy 1.x arithmetic on numpy 2: rms_db below is the reference's property
+    # with the float32 logarithm converted before the multiplication.
+    def _rms_db_numpy1(self):
+        mean_square = np.mean(self._samples ** 2)  # float32: pairwise sums of 8192-element chunks, both numpy versions
+        if mean_square == 0:
+            mean_square = 1
+        return 10 * float(np.log10(mean_square))
+
+    AudioSegment.rms_db = property(_rms_db_numpy1)
     _gain_db = AudioSegment.gain_db
     AudioSegment.gain_db = lambda self, gain: _gain_db(self, float(gain))
 

@@ -16,7 +16,8 @@ def _audio(seconds, seed=0, sr=16000):
     return x.astype(np.float32)
 
 
-@pytest.mark.parametrize("seconds,use_db", [(2.0, True), (2.0, False), (0.0251, True), (10.0, True)])
+@pytest.mark.parametrize("seconds,use_db", [(2.0, True), (2.0, False), (0.0251, True), (10.0, True), (0.5123, True), (1.0240625, True),
+                                            (29.97, True)])
 def test_fbank_matches_oracle(seconds, use_db):
     from ppasr_amd.data_utils.featurizer import AudioFeaturizer
     wav = _audio(seconds, seed=int(seconds * 10))
@@ -25,10 +26,17 @@ def test_fbank_matches_oracle(seconds, use_db):
     ref = fbank_oracle.featurize(wav, 16000, 80, use_db, -20.0)
     assert got.shape == ref.shape and got.dtype == np.float32
     assert got.shape[0] == 1 + (len(wav) - 400) // 160
-    # log-mel values are O(10); fp32 FFT + an occasional int16 LSB flip from the fp32 gain stay far below 1e-3 abs
-    err = float(np.abs(got.astype(np.float64) - ref).max())
-    print("max abs err", err)
-    assert err < 1e-3
+    # The gain is bit-exact (the kernel sums the squares in numpy's order: pairwise, 8192-element chunks), so every int16
+    # sample equals the oracle's; what is left is fp32 arithmetic (window, radix-2 FFT, mel sums) against the oracle's
+    # float64.  Its error scales with the frame's LARGEST spectral amplitude, so a mel bin that sits e_max / e below the
+    # frame's peak carries a relative energy error ~ sqrt(e_max / e): measured <= 2.2e-5 * sqrt(e_max / e) (tools/
+    # experiments/r05/fbank_diag.py) -- below 2e-4 for most bins, 1.2e-2 in a spectral null 21 nepers below a sine (the
+    # 29.97 s case, frame 1716; paddleaudio's own fbank is an fp32 rfft with the same property).
+    err = np.abs(got.astype(np.float64) - ref)
+    tol = 2e-4 + 4e-5 * np.exp(0.5 * (ref.max(axis=1, keepdims=True) - ref))
+    print("max abs err", float(err.max()), "max err / tol", float((err / tol).max()))
+    assert (err <= tol).all()
+    assert np.median(err) < 2e-5
 
 
 def test_fbank_edge_cases():
