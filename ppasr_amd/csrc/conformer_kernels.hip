@@ -199,16 +199,18 @@ __device__ __forceinline__ void gemm_stream_body(const Src& src, const f32x4* __
 #pragma unroll
     for (int i = 0; i < NL; ++i) stg[i] = wstream_load(rs_a, voff[i], soff);
   };
+  bool bad = false;  // fp16 x3 range-guard events of this workgroup's loaders (h3.h)
+  auto write_piece = [&](float* buf, int i) {  // (H3) f32x4 number i of the staged chunk -> the two operand planes
+    _Float16* pl = reinterpret_cast<_Float16*>(buf);
+    f16x4 hi, lo;
+    h3_split4(stg[i] * kH3Sa, hi, lo, bad);
+    *reinterpret_cast<f16x4*>(pl + lds_off[i]) = hi;
+    *reinterpret_cast<f16x4*>(pl + PLANE + lds_off[i]) = lo;
+  };
   auto write_chunk = [&](float* buf) {
     if constexpr (H3) {
-      _Float16* pl = reinterpret_cast<_Float16*>(buf);
 #pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        f16x4 hi, lo;
-        h3_split4(stg[i] * kH3Sa, hi, lo);
-        *reinterpret_cast<f16x4*>(pl + lds_off[i]) = hi;
-        *reinterpret_cast<f16x4*>(pl + PLANE + lds_off[i]) = lo;
-      }
+      for (int i = 0; i < NL; ++i) write_piece(buf, i);
     } else {
 #pragma unroll
       for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4*>(buf + lds_off[i]) = stg[i];
@@ -226,17 +228,34 @@ __device__ __forceinline__ void gemm_stream_body(const Src& src, const f32x4* __
     if (more) load_chunk(kc + 1);
     const f32x4* seg = wbase + (size_t)kc * G * 64;
     if (MT == 4 && kc < 8) PPASR_WAVE_TS(32 + 4 * kc);
-    if constexpr (H3)
-      rb_gemm_h3_rows<MT, KC / 16>(reinterpret_cast<const _Float16*>(cur), LDH, PLANE, seg, more ? seg + G * 64 : nullptr, ring, acc);
-    else
+    if constexpr (H3) {
+      // the next chunk's split + plane stores ride inside this chunk's MFMA stream, NL / (KC / 16) pieces per k step (its
+      // rows were requested above, before the stream's weight fragments: vmcnt retires in order, so the first fragment
+      // wait covers them; the buffer they go to was last read in iteration kc - 1).  After the unit, as on the fp32
+      // route, the split was 0.9 - 1.8 us of every 5.6 us chunk with the matrix pipe idle (tools/phase_ts.py --h3)
+      constexpr int KS = KC / 16, PER = (NL + KS - 1) / KS;
+      auto side = [&](int ks) {
+        if (more) {
+#pragma unroll
+          for (int j = 0; j < PER; ++j)
+            if (ks * PER + j < NL) write_piece(nxt, ks * PER + j);
+        }
+      };
+      rb_gemm_h3_rows<MT, KS>(reinterpret_cast<const _Float16*>(cur), LDH, PLANE, seg, more ? seg + G * 64 : nullptr, ring, acc,
+                              side);
+    } else {
       rb_gemm<MT, 1, G>(cur, LD, seg, 0, more ? seg + G * 64 : nullptr, 0, ring, acc);
+    }
     if (MT == 4 && kc < 8) PPASR_WAVE_TS(33 + 4 * kc);
-    if (more) write_chunk(nxt);
+    if constexpr (!H3) {
+      if (more) write_chunk(nxt);
+    }
     if (MT == 4 && kc < 8) PPASR_WAVE_TS(34 + 4 * kc);
     __syncthreads();
     if (MT == 4 && kc < 8) PPASR_WAVE_TS(35 + 4 * kc);
   }
   if constexpr (H3) {
+    h3_note(bad);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt][0] *= kH3Inv;
   }
@@ -517,18 +536,24 @@ void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, fl
 // Epilogue slice of the previous Q / K / V tile inside the next unit's MFMA stream: qkv[row][col] = acc + bias
 // (transposed tiles, rb_gemm SWAP: lane = row, register quad q = 4 consecutive columns -> one 16-byte store per quad,
 //  issued during k-groups 4, 12, 20, 28 of the next unit)
-// ... the same inside an fp16 x3 unit (h3.h: 16 k steps, accumulators scaled by 2^12): stores during k steps 2, 6, 10, 14
-struct QkvStoreSideH3 {
-  const f32x16& acc;
-  float* out;
-  const f32x4 (&bias)[4];
+// fp16 x3 units are a third as long as fp32 ones and gfx9's vmcnt retires in order: a store sliced into the middle of a
+// unit makes the next wait for a weight fragment wait for the store's write acknowledge as well (tools/phase_ts.py --h3,
+// round 5: Q unit 3.8 us, K unit with Q's four stores inside 6.6, V unit with K's 7.4).  The Q / K tiles are therefore
+// stored during the LAST two k steps of the V unit, after the final weight load of the stream: nothing waits behind them.
+struct QkStoreTailH3 {
+  const f32x16& q_acc;
+  const f32x16& k_acc;
+  float* out;  // qkv + (r0 + this lane's row) * 768 + first column of this lane's quad 0; nullptr: row >= valid
+  const f32x4 (&bias)[2][4];
   __device__ __forceinline__ void operator()(int ks) const {
-    if ((ks & 3) == 2 && out) {
-      const int q = ks >> 2;
-      *reinterpret_cast<f32x4*>(out + 8 * q) =
-          f32x4{acc[4 * q] * kH3Inv + bias[q][0], acc[4 * q + 1] * kH3Inv + bias[q][1], acc[4 * q + 2] * kH3Inv + bias[q][2],
-                acc[4 * q + 3] * kH3Inv + bias[q][3]};
-    }
+    if (ks < 14 || !out) return;
+    const int c = ks - 14;
+    const f32x16& acc = c ? k_acc : q_acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<f32x4*>(out + c * 256 + 8 * q) =
+          f32x4{acc[4 * q] * kH3Inv + bias[c][q][0], acc[4 * q + 1] * kH3Inv + bias[c][q][1],
+                acc[4 * q + 2] * kH3Inv + bias[c][q][2], acc[4 * q + 3] * kH3Inv + bias[c][q][3]};
   }
 };
 struct QkvStoreSide {
@@ -587,13 +612,11 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
     const f32x4* nseg = c < 2 ? seg + 8 * kTs256 : nullptr;
     if constexpr (H3) {  // (w.wqkv: the re-packed weight; the LayerNorm'd rows were turned into operand planes above)
       const _Float16* pa = reinterpret_cast<const _Float16*>(bufA);
-      if (c == 0)
+      if (c < 2)
         rb_gemm_h3(pa, seg, nseg, ring, tile[c][0][0]);
-      else if (c == 1)
-        rb_gemm_h3<QkvStoreSideH3>(pa, seg, nseg, ring, tile[c][0][0], QkvStoreSideH3{tile[0][0][0], qrow, qb[0]});
       else
-        rb_gemm_h3_rows<1, 16, QkvStoreSideH3>(pa, kLdh, kPlaneH, seg, nseg, ring, tile[c],
-                                               QkvStoreSideH3{tile[1][0][0], qrow ? qrow + 256 : nullptr, qb[1]});
+        rb_gemm_h3_rows<1, 16, QkStoreTailH3>(pa, kLdh, kPlaneH, seg, nseg, ring, tile[c],
+                                              QkStoreTailH3{tile[0][0][0], tile[1][0][0], qrow, qb});
     } else if (c == 0) {
       rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg, 0, nseg, 0, ring, tile[c]);
     } else if (c == 1) {
@@ -1121,6 +1144,17 @@ __device__ __forceinline__ void attn_out_glu_body(const AttnArgs& a, int B, cons
         *reinterpret_cast<f32x4*>(P + l31 * kPLd + 32 * ct + 8 * i + 4 * hh) =
             f32x4{acc_o[ct][4 * i], acc_o[ct][4 * i + 1], acc_o[ct][4 * i + 2], acc_o[ct][4 * i + 3]};
   }
+  // fp16 x3: the residual rows of the out-projection epilogue are requested BEFORE the weight stream starts (vmcnt
+  // retires in order: behind the stream's first fragments they would hold every later fragment wait for an HBM round trip)
+  const int r0 = b * T + q0;
+  const int cq = wave * 32 + 4 * hh;                    // first column of this lane's quad 0
+  const size_t grow = (size_t)(r0 + min(l31, valid - 1)) * kD;  // this lane's row in x1 / x2 / g
+  const bool row_ok = l31 < valid;
+  f32x4 res[4];
+  if constexpr (H3) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) res[q] = *reinterpret_cast<const f32x4*>(x1 + grow + cq + 8 * q);
+  }
   ring_prime(ring, seg_o, 0);  // out-projection weights in flight across the barrier
   __syncthreads();
   PPASR_TS(35);
@@ -1151,14 +1185,12 @@ __device__ __forceinline__ void attn_out_glu_body(const AttnArgs& a, int B, cons
   // The three GEMM units run with swapped MFMA operands (rb_gemm SWAP): lane = row l31, register quad q = columns
   // wave*32 + 8q + 4hh .. +3, so residual loads, x2 / g stores and the LDS rows are 16-byte accesses (4 per tile
   // instead of 16) and the epilogue arithmetic is packed.
-  const int r0 = b * T + q0;
-  const int cq = wave * 32 + 4 * hh;                    // first column of this lane's quad 0
-  const size_t grow = (size_t)(r0 + min(l31, valid - 1)) * kD;  // this lane's row in x1 / x2 / g
-  const bool row_ok = l31 < valid;
+  f32x4 x2v[4];  // fp16 x3: the x2 rows, stored behind the last weight load of the kernel (with g)
   {
-    f32x4 res[4];
+    if constexpr (!H3) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) res[q] = *reinterpret_cast<const f32x4*>(x1 + grow + cq + 8 * q);
+      for (int q = 0; q < 4; ++q) res[q] = *reinterpret_cast<const f32x4*>(x1 + grow + cq + 8 * q);
+    }
     f32x16 acc[1][1];
     acc_zero(acc);
     if constexpr (H3) {  // (the context rows' operand planes go where bufA will be: free until the LayerNorm below)
@@ -1174,8 +1206,9 @@ __device__ __forceinline__ void attn_out_glu_body(const AttnArgs& a, int B, cons
       f32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = res[q][e] + (acc[0][0][4 * q + e] + bo[e]);
-      if (row_ok) *reinterpret_cast<f32x4*>(x2 + grow + cq + 8 * q) = v;
-      else v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (H3) x2v[q] = v;
+      else if (row_ok) *reinterpret_cast<f32x4*>(x2 + grow + cq + 8 * q) = v;
+      if (!row_ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(bufX + l31 * kLda + cq + 8 * q) = v;
     }
   }
@@ -1215,6 +1248,12 @@ __device__ __forceinline__ void attn_out_glu_body(const AttnArgs& a, int B, cons
       const f32x4 o = {(av[0][0][4 * q] + bval[0]) * s0[0], (av[0][0][4 * q + 1] + bval[1]) * s0[1],
                        (av[0][0][4 * q + 2] + bval[2]) * s1[0], (av[0][0][4 * q + 3] + bval[3]) * s1[1]};
       if (row_ok) *reinterpret_cast<f32x4*>(g + grow + cq + 8 * q) = o;
+    }
+    if constexpr (H3) {
+      if (row_ok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(x2 + grow + cq + 8 * q) = x2v[q];
+      }
     }
   }
   PPASR_TS(39);

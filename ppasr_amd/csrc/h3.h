@@ -50,9 +50,10 @@ static inline unsigned int* h3_ovf_counter() {
   return hipGetSymbolAddress(&p, HIP_SYMBOL(g_h3_ovf)) == hipSuccess ? static_cast<unsigned int*>(p) : nullptr;
 }
 
-// v: already scaled by 2^4.  Out-of-range (and NaN) inputs: saturated, counted.
-__device__ __forceinline__ void h3_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
-  bool bad = false;
+// v: already scaled by 2^4.  Out-of-range (and NaN) inputs: saturated; `bad` collects the event (branch-free: the callers
+// sit inside MFMA streams, where a branch per quad would cut the schedule into pieces) and h3_note() counts it once per
+// phase.
+__device__ __forceinline__ void h3_split4(const f32x4 v, f16x4& hi, f16x4& lo, bool& bad) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float c = fminf(fmaxf(v[i], -kH3Max), kH3Max);
@@ -60,6 +61,8 @@ __device__ __forceinline__ void h3_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
     hi[i] = (_Float16)c;
     lo[i] = (_Float16)(c - (float)hi[i]);
   }
+}
+__device__ __forceinline__ void h3_note(bool bad) {
   if (bad) atomicAdd(&g_h3_ovf, 1u);
 }
 
@@ -71,13 +74,15 @@ __device__ __forceinline__ void h3_planes_from_tile(const float* src, _Float16* 
 #pragma unroll
   for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + row * kLda + c0 + 4 * i);
   __syncthreads();
+  bool bad = false;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     f16x4 hi, lo;
-    h3_split4(v[i] * kH3Sa, hi, lo);
+    h3_split4(v[i] * kH3Sa, hi, lo, bad);
     *reinterpret_cast<f16x4*>(dst + row * kLdh + c0 + 4 * i) = hi;
     *reinterpret_cast<f16x4*>(dst + kPlaneH + row * kLdh + c0 + 4 * i) = lo;
   }
+  h3_note(bad);
   __syncthreads();
 }
 
@@ -176,9 +181,34 @@ __device__ __forceinline__ void rb_gemm_h3_rows(const _Float16* pl, int ldh, int
   }
 }
 
+// Swish epilogue of hidden chunk c as a slice of the W1(c + 1) MFMA stream (what SwishSide of phases.h is to the fp32
+// route): quad q of the wave's 32 hidden columns is handled during k steps 4q .. 4q + 3 -- two packed swish pairs, the
+// split into the two fp16 pieces, the two 8-byte plane stores.  Exposed after the unit (round 4) the epilogue and the
+// barrier behind it cost 1.5 us per unit, half as much again as the unit itself (tools/phase_ts.py --h3: 16 units 74 us).
+struct SwishSideH3 {
+  const f32x16& acc;       // raw accumulators of W1(c): 2^12 * (A W1)
+  _Float16* dst;           // hb + (lane & 31) * kLdh + wave * 32 + 4 * (lane >> 5)
+  const f32x4 (&bias)[4];  // b1 of this lane's columns, quad by quad
+  bool& bad;               // range-guard events (h3_split4), counted by the caller once per phase
+  mutable f32x2 s01, s23;
+  mutable f16x4 hi, lo;
+  __device__ __forceinline__ void operator()(int ks) const {
+    const int q = ks >> 2;
+    switch (ks & 3) {
+      case 0: s01 = swish2(f32x2{acc[4 * q] * kH3Inv + bias[q][0], acc[4 * q + 1] * kH3Inv + bias[q][1]}); break;
+      case 1: s23 = swish2(f32x2{acc[4 * q + 2] * kH3Inv + bias[q][2], acc[4 * q + 3] * kH3Inv + bias[q][3]}); break;
+      case 2: h3_split4(f32x4{s01[0], s01[1], s23[0], s23[1]} * kH3Sa, hi, lo, bad); break;
+      default:
+        *reinterpret_cast<f16x4*>(dst + 8 * q) = hi;
+        *reinterpret_cast<f16x4*>(dst + kPlaneH + 8 * q) = lo;
+    }
+  }
+};
+
 // PositionwiseFeedForward (positionwise.py:32-39) on the fp16 x3 route: acc2 = swish(A W1 + b1) W2 (transposed tile, as
-// ffn_phase<true> leaves it: residual_epilogue_t applies).  The hidden dimension in 256-wide chunks, W1(c) -> swish ->
-// operand planes -> W2(c); weight stream order W1(0), W2(0), W1(1), ..., W2(n-1), `after`.
+// ffn_phase<true> leaves it: residual_epilogue_t applies).  The hidden dimension in 256-wide chunks that never leave LDS
+// (operand planes, double-buffered); weight stream order as on the fp32 route: W1(0), W1(1), W2(0), W1(2), W2(1), ...,
+// W2(n-1), `after`; the swish epilogue of chunk c runs inside the W1(c + 1) MFMA stream.
 //   bufA : the LayerNorm'd rows, fp32 [32][kLda], complete.  The operand planes take over the LDS from bufA on:
 //          [A | hidden chunk, even | hidden chunk, odd] = 3 * kH3TileBytes -- bufA, bufH[0], bufH[1] of the fp32 route
 //          plus kH3ExtraLds bytes (the launch asks for them)
@@ -194,28 +224,35 @@ __device__ __forceinline__ void ffn_phase_h3(const float* src, _Float16* pa, _Fl
   auto w1seg = [&](int c) { return w1 + (size_t)(c * 8 + wave) * kTs256; };
   auto w2seg = [&](int c) { return w2 + (size_t)wave * ts2 + (size_t)c * 32 * 64; };
   const int hoff = (lane & 31) * kLdh + wave * 32 + 4 * (lane >> 5);
-  f32x16 acc = acc2[0][0];
+  f32x16 acc = acc2[0][0], cur, nx;
+  bool bad = false;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cur[r] = 0.f;
+  rb_gemm_h3(pa, w1seg(0), n_chunks > 1 ? w1seg(1) : w2seg(0), ring, cur);
   for (int c = 0; c < n_chunks; ++c) {
     _Float16* hb = ph + (c & 1) * 2 * kPlaneH;
-    f32x16 cur;
+    f32x4 bias[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cur[r] = 0.f;
-    rb_gemm_h3(pa, w1seg(c), w2seg(c), ring, cur);
+    for (int q = 0; q < 4; ++q) bias[q] = *reinterpret_cast<const f32x4*>(b1 + c * 256 + wave * 32 + 8 * q + 4 * (lane >> 5));
+    const SwishSideH3 epi{cur, hb + hoff, bias, bad, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f16x4{0, 0, 0, 0}, f16x4{0, 0, 0, 0}};
+    if (c + 1 < n_chunks) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 bias = *reinterpret_cast<const f32x4*>(b1 + c * 256 + wave * 32 + 8 * q + 4 * (lane >> 5));
-      const f32x2 s01 = swish2(f32x2{cur[4 * q] * kH3Inv + bias[0], cur[4 * q + 1] * kH3Inv + bias[1]});
-      const f32x2 s23 = swish2(f32x2{cur[4 * q + 2] * kH3Inv + bias[2], cur[4 * q + 3] * kH3Inv + bias[3]});
-      f16x4 hi, lo;
-      h3_split4(f32x4{s01[0], s01[1], s23[0], s23[1]} * kH3Sa, hi, lo);
-      *reinterpret_cast<f16x4*>(hb + hoff + 8 * q) = hi;
-      *reinterpret_cast<f16x4*>(hb + kPlaneH + hoff + 8 * q) = lo;
+      for (int r = 0; r < 16; ++r) nx[r] = 0.f;
+      rb_gemm_h3(pa, w1seg(c + 1), w2seg(c), ring, nx, epi);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) epi(ks);
     }
     // (two hidden buffers: the buffer written here was last read by W2(c - 2), which every wave has left before it
     //  passed the barrier of chunk c - 1)
+    if (c < 8) PPASR_TS(16 + 2 * c);
     __syncthreads();
-    rb_gemm_h3(hb, w2seg(c), c + 1 < n_chunks ? w1seg(c + 1) : after, ring, acc);
+    if (c < 8) PPASR_TS(17 + 2 * c);
+    const f32x4* nseg = (c + 2 < n_chunks) ? w1seg(c + 2) : (c + 1 < n_chunks ? w2seg(c + 1) : after);
+    rb_gemm_h3(hb, w2seg(c), nseg, ring, acc);
+    cur = nx;
   }
+  h3_note(bad);
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc2[0][0][r] = acc[r] * kH3Inv;
 }

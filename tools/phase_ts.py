@@ -37,6 +37,8 @@ V, L = DEFAULT_VOCAB_SIZE, 12
 conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
 model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=conformer_state_dict(vocab_size=V, num_blocks=L, seed=1234),
                        device="cuda:0")
+if "--h3" in sys.argv:  # the fp16 x3 mode's kernels (k_conv_ffn_h3 / k_attn_out_glu_h3 carry the same stamps)
+    model.set_gemm_mode("f16x3")
 x, lens = synth_features(32, 1000, seed=20440)
 x, lens = torch.from_numpy(x).cuda(), torch.from_numpy(lens).cuda()
 for _ in range(5):
