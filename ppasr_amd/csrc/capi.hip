@@ -479,10 +479,7 @@ int row_block_for(const ppasr_model_s* m, int B, int Tcur, int mul, int slack, b
   // 33 .. 128 blocks of 32 rows: one half-as-long round instead of a half-empty one; 257 .. 384: three short rounds instead
   // of two long ones.  Up to 32 blocks the split route (ffn_split_for: 8 hidden slices per row block) fills more CUs than
   // 2 x the blocks would.
-  static const int min_blocks = [] {
-    const char* e = getenv("PPASR_R16_MIN_BLOCKS");  // (tuning knob)
-    return e ? atoi(e) : 32;
-  }();
+  constexpr int min_blocks = 32;
   const long long b32 = (rows + 31) / 32, b16 = (rows + 15) / 16;
   if (b32 <= min_blocks) return 32;  // (split route: the 8-wave kernels)
   const double c32 = (double)((b32 + 255) / 256), c16 = 0.52 * (double)((b16 + 255) / 256);
@@ -831,10 +828,9 @@ static ppasr_status encode_impl(ppasr_handle h, const float* feats, const int64_
     // plain 4 x 64 heads: attention and the out-projection / GLU stage run as one launch (context rows stay in LDS);
     // the debug taps need the context tensor, so they take the two-kernel route
     // (an under-filled grid is latency-bound either way, and the two-kernel route then has 4x the workgroups in its
-    //  attention half, one per head: 2 - 6 % faster end to end up to 128 row blocks (tools/ab_attention_route.py), 10 %
-    //  slower at the bench shape; PPASR_ATTN_FUSE_MIN_BLOCKS overrides the threshold)
-    static const int fuse_min_blocks =
-        getenv("PPASR_ATTN_FUSE_MIN_BLOCKS") ? atoi(getenv("PPASR_ATTN_FUSE_MIN_BLOCKS")) : 128;
+    //  attention half, one per head: 2 - 6 % faster end to end up to 128 row blocks, measured in round 3), 10 %
+    //  slower at the bench shape)
+    constexpr int fuse_min_blocks = 128;
     auto fusable = [&](int layer) {
       // (the fused kernel reads the values in fragment order, which only the fused QKV stage -- ffn_qkv_body -- writes: a
       //  FORCED split of a large batch (ppasr_set_ffn_split(2 / 4 / 8), k_ln_qkv) therefore takes the two-kernel route)

@@ -1597,11 +1597,6 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
   const int n_elem = cfg.beam * (1 + cfg.n_cand_max);
   static const int kSizes[5] = {64, 128, 256, 512, 1024};
   int sel = n_elem <= 1024 ? 3 : 4;
-  if (const char* e = getenv("PPASR_BEAM_THREADS")) {
-    sel = 4;
-    for (int i = 4; i >= 0; --i)
-      if (atoi(e) <= kSizes[i]) sel = i;
-  }
   while (sel < 4 && kSizes[sel] < cfg.beam) ++sel;  // (the new beam is materialised one slot per thread)
   const bool wl = cfg.lm.order > 0 && cfg.lm.word_based != 0;
   const void* fns[2][5] = {
