@@ -588,6 +588,9 @@ class DeepSpeech2Greedy(Workload):     # cfg1
         H, dirs = self.H, 2
         w = {}
         w["k_lstm_step"] = (self.L * Tp * dirs * (4 * H * H * 4 + self.B * (4 * H + 3 * H) * 4), "bytes", "hbm")
+        # persistent recurrence (B = 1): W_hh crosses HBM ONCE per layer launch (it lives in registers for the whole layer);
+        # per time step the gate pre-activations in, h out (the layer output) and the 8-byte exchange granules out and back
+        w["k_lstm_persist"] = (self.L * dirs * (4 * H * H * 4 + Tp * (4 * H * 4 + H * 4 + 2 * H * 8)), "bytes", "hbm")
         k_in = [608] + [2 * H] * (self.L - 1)
         w["dense"] = (sum(2 * k * 4 * H * Tp * self.B * dirs for k in k_in) + 2 * 2 * H * self.V * Tp * self.B, "flop", "mfma")
         return w
@@ -766,7 +769,7 @@ def build_roofline(w, args, ms_per_step):
         if de.get("arithmetic"):
             r.update(peak_note="fp32-equivalent FLOPs over the dense fp16 matrix peak / 3 (three fp16 MFMA products per fp32 "
                                "product, csrc/h3.h); what bounds these kernels in practice is the L2 weight stream and the "
-                               "chip's sustained 16-bit MFMA clock (DESIGN 9.8)")
+                               "chip's sustained 16-bit MFMA clock (NOTES 9.8)")
     r.update(traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 PMC)", traffic_source=traffic_note,
              avg_launch_ms=avg_launch_ms, avg_launch_ms_rocprof=rocprof_avg_ms,
              avg_launch_ms_rocprof_note=("average dispatch duration of the same kernel(s) in the rocprofv3 --kernel-trace pass of "
@@ -794,6 +797,17 @@ def build_roofline(w, args, ms_per_step):
                              "from the 256 MB Infinity Cache, not from HBM; peak stays the contract's HBM 8 TB/s for reference"),
                  weights_once_mbytes=round(once / 1e6, 1),
                  traffic_per_step_over_weights_once=(round(traffic * de["launches_per_step"] / once, 1) if traffic else None))
+    if w.family == "deepspeech2" and dom.startswith("k_lstm_persist"):
+        once = w.L * 2 * 4 * w.H * w.H * 4
+        Tp = ((w.T - 1) // 2 - 1) // 2
+        r.update(bound_note=("latency chain, not a bandwidth stream: W_hh stays in registers for the whole layer (it crosses HBM once "
+                             "per launch), and the launch is T' dependent time steps, each ending in one exchange of the new h "
+                             "(8 KB of tagged 8-byte granules) between the 256 workgroups -- the step time is that exchange's round "
+                             "trip (MI355X_MICROARCH.md 'allgather': 2.4 - 3 us), so `frac` against the HBM peak only says how "
+                             "far from bandwidth-bound the recurrence of ONE utterance is"),
+                 us_per_time_step=round(avg_launch_ms * 1e3 / max(Tp, 1), 2),
+                 weights_once_mbytes=round(once / 1e6, 1),
+                 traffic_per_step_over_weights_once=(round(traffic * de["launches_per_step"] / once, 2) if traffic else None))
     return r
 
 
@@ -972,7 +986,7 @@ def main():
                                                                    "front end" if args.config == "cfg5" else
                                                                    "the feed-forward GEMMs of the layer kernels and conv2 of the front end") +
                              " as three fp16 MFMAs per 16-wide k step on two-piece operands (22 significant bits, exact "
-                             "products, fp32 accumulation; DESIGN.md 9.8); everything else unchanged"}
+                             "products, fp32 accumulation; NOTES.md 9.8); everything else unchanged"}
         except Exception as e:  # (a build without the mode: report, do not fail the headline)
             f16x3 = {"error": str(e)[:200]}
         finally:

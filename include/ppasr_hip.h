@@ -199,7 +199,7 @@ PPASR_API ppasr_status ppasr_set_row_block(ppasr_handle h, int rows);
  * other block forms (16 rows, 16 waves), the split route for under-filled launches, the Efficient-Conformer's stride
  * layer, attention products, depthwise convolutions and streaming handles keep fp32 arithmetic.  ppasr_gemm_coverage
  * tells which of the three parts switched (a Conformer with cnn_module_kernel 31 gets the front end and the head only).
- * PPASR_EUNSUPPORTED on DeepSpeech2 handles and on the general layer route.  Measured (DESIGN): logits within 1e-6 .. 3e-6
+ * PPASR_EUNSUPPORTED on DeepSpeech2 handles and on the general layer route.  Measured (NOTES.md 9.8): logits within 1e-6 .. 3e-6
  * of the default mode's, the reference-source pin tests pass with unchanged criteria, 1.2 - 1.7 x faster end to end. */
 #define PPASR_GEMM_F32 0
 #define PPASR_GEMM_F16X3 1

@@ -994,7 +994,7 @@ __device__ __forceinline__ void attn_out_glu_body(const AttnArgs& a, int B, cons
     return *reinterpret_cast<const f32x4*>(gk < 8 ? qfrag_u + 8 * gk : qfrag_v + 8 * (gk - 8));
   };
   PPASR_TS(33);
-  // (requesting these before the Q' staging, or the V operands before the score MFMAs, measured no better: DESIGN §4)
+  // (requesting these before the Q' staging, or the V operands before the score MFMAs, measured no better: NOTES §4)
   if (khalf * 128 < U) prime_k(khalf * 128);
   f32x16 acc_o[2];  // O^T: acc_o[ct][r] = O[query l31][h*64 + 32ct + (r&3) + 8(r>>2) + 4hh]
 #pragma unroll

@@ -3,7 +3,7 @@
 CTC loss) and is out of scope; ``evaluate`` returns the mean CER / WER only.
 
 With ``torch.distributed`` initialised, every rank evaluates the batches ``rank::world`` and the per-utterance error
-rates are summed with one all-reduce (utterance data parallelism).  For variable-length batches
+rates are summed with one all-reduce (utterance data parallelism, NOTES.md §6).  For variable-length batches
 ``shard="buckets"`` splits EVERY batch over the ranks instead (``parallel.decode_ragged``: whole length buckets per rank
 by padded work, one all-gather of the hypotheses per batch), so that ranks finish together whatever the batch order."""
 import torch

@@ -116,7 +116,7 @@ class InferencePredictor:
         if not ("former" in self.use_model and self.streaming):
             raise Exception(f"当前模型不支持该方法，当前模型为：{self.use_model}")
         if self._stream is None:
-            raise NotImplementedError(f"forward_chunk of {self.use_model} is not built yet (DESIGN.md §7)")
+            raise NotImplementedError(f"forward_chunk of {self.use_model} is not built yet (NOTES.md §7)")
         return self._stream.encode_chunk(np.asarray(x_chunk, np.float32), int(required_cache_size)).cpu().numpy()
 
     def predict_chunk_deepspeech(self, x_chunk):

@@ -311,7 +311,7 @@ class RaggedPlan:
         self.cuda = self.dev.type == "cuda"
         self.pipeline = bool(pipeline) and self.cuda
         # (plain streams: the search's workgroups and the encoder's share the chip.  Giving each side its own CUs through
-        #  hipExtStreamCreateWithCUMask was measured -- tools/cu_mask_probe.hip, DESIGN.md -- and is slower: 8.9 ms per
+        #  hipExtStreamCreateWithCUMask was measured -- tools/cu_mask_probe.hip, NOTES.md 9.5 -- and is slower: 8.9 ms per
         #  cfg5 step against 6.8, wherever the search's CUs are placed)
         self.enc_stream = torch.cuda.Stream(device=self.dev) if self.pipeline else None
         self.dec_stream = torch.cuda.Stream(device=self.dev) if self.pipeline else None

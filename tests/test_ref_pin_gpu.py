@@ -7,7 +7,7 @@ magnitude; greedy ids bit-exact (frames whose reference top-2 logit margin is be
 reference itself and are compared through the margin instead).
 
 The batched tests run twice: in the default arithmetic and with the opt-in fp16 x 3 GEMM mode (ppasr_set_gemm_mode,
-DESIGN 9.8) -- the same fixtures, the same 1e-3 / greedy-id criteria."""
+NOTES 9.8) -- the same fixtures, the same 1e-3 / greedy-id criteria."""
 import os
 
 import numpy as np

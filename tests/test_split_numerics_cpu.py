@@ -1,4 +1,4 @@
-"""CPU: the arithmetic behind the opt-in fp16 x3 GEMM mode (csrc/h3.h), checked on the oracle.
+"""CPU: the arithmetic behind the opt-in fp16 x3 GEMM mode (csrc/h3.h, NOTES 9.8), checked on the oracle.
 
 tools/experiments/r05/split_bf16_numerics.py replaces every GEMM of the Conformer oracle by a sum of products of 16-bit
 pieces (products of pieces are exact in fp32, accumulation in fp32 -- what the matrix cores compute) and measures the logits

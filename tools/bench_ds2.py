@@ -2,7 +2,7 @@
 B = 1 bidirectional (BASELINE configs[0]), B = 32 / 128 unidirectional (streaming model), LSTM and GRU.
 One JSON line per shape; kernel durations from dispatch-attached HIP events (ppasr_kprof_*).
 
-Roofline conventions (DeepSpeech2): the recurrence kernels re-read the recurrent weights every time step, so
+Roofline conventions (NOTES.md 7, DeepSpeech2): the recurrence kernels re-read the recurrent weights every time step, so
 their algorithmic BYTES per launch are those weights (k_lstm_step / k_gru_step: one utterance per launch, matrix-vector,
 HBM / Infinity-Cache bound); the batched kernels (k_lstm_step_mfma, k_lstm_wave) are priced both ways: algorithmic FLOPs
 against the fp32-MFMA peak and weight bytes against HBM -- with 32 rows per weight byte they sit at the ridge."""

@@ -128,7 +128,7 @@ __global__ void k_tile(const f32x4* __restrict__ w, float* out, int iters) {
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
 }
 
-// Split-precision candidate: fp32 operands as fp16 hi + fp16 (scaled) lo, three
+// Split-precision candidate (NOTES section 8): fp32 operands as fp16 hi + fp16 (scaled) lo, three
 // v_mfma_f32_32x32x16_f16 per 16-wide k step (hi*hi, hi*lo, lo*hi; fp32 accumulation) in the row-block GEMM's structure --
 // A (hi, lo) fragments from LDS, B (hi, lo) fragments from the buffer-load ring, 32 x 32 tile per wave.  Reported as
 // fp32-EQUIVALENT TFLOP/s (2 * 32 * 32 * 16 per step), i.e. directly comparable with the exact-fp32 MFMA figures.
