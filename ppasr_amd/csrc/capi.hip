@@ -552,23 +552,35 @@ ppasr_status ppasr_set_front_fused(ppasr_handle h, int mode) {
   return PPASR_OK;
 }
 
-// ---- range guard of the fp16 x3 mode (csrc/h3.h): the two translation units' event counters, snapshotted in stream order
-__global__ void k_h3_snapshot(const unsigned int* a, const unsigned int* b, unsigned int* dst) {
-  dst[0] = *a;
-  dst[1] = *b;
+// ---- range guard of the fp16 x3 mode (csrc/h3.h): the event counters of the translation units that hold fp16 x3 kernels,
+// snapshotted in stream order
+struct GuardPtrs {
+  const unsigned int* p[ppasr_model_s::kGuardN];
+};
+__global__ void k_h3_snapshot(GuardPtrs g, unsigned int* dst) {
+  for (int i = 0; i < ppasr_model_s::kGuardN; ++i) dst[i] = *g.p[i];
+}
+static GuardPtrs guard_ptrs(ppasr_handle h) {
+  GuardPtrs g;
+  for (int i = 0; i < ppasr_model_s::kGuardN; ++i) g.p[i] = h->guard_ctr[i];
+  return g;
 }
 
 static ppasr_status guard_alloc(ppasr_handle h) {
   if (h->guard_dev) return PPASR_OK;
+  constexpr int N = ppasr_model_s::kGuardN;
   h->guard_ctr[0] = conformer_h3_ovf_counter();
   h->guard_ctr[1] = squeezeformer_h3_ovf_counter();
-  if (!h->guard_ctr[0] || !h->guard_ctr[1]) return fail(PPASR_EHIP, "fp16 x3 range guard: counter symbols not found");
+  h->guard_ctr[2] = front_h3_ovf_counter();
+  h->guard_ctr[3] = ctc_head_h3_ovf_counter();
+  for (int i = 0; i < N; ++i)
+    if (!h->guard_ctr[i]) return fail(PPASR_EHIP, "fp16 x3 range guard: counter symbols not found");
   void* d = nullptr;
-  HIP_TRY(hipMalloc(&d, 4 * sizeof(unsigned int)));
+  HIP_TRY(hipMalloc(&d, 2 * N * sizeof(unsigned int)));
   h->allocs.push_back(d);
   h->guard_dev = static_cast<unsigned int*>(d);
   void* p = nullptr;
-  HIP_TRY(hipHostMalloc(&p, 4 * sizeof(unsigned int), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc(&p, 2 * N * sizeof(unsigned int), hipHostMallocDefault));
   h->guard_host = static_cast<unsigned int*>(p);
   return PPASR_OK;
 }
@@ -955,16 +967,20 @@ ppasr_status ppasr_encode(ppasr_handle h, const float* feats, const int64_t* len
   // fp16 x3 mode, guard on: counters before / after the call's launches (stream order), one 16-byte read-back, and on a
   // changed counter the same call again on the fp32 kernels (same weights, same workspace; the inputs are untouched)
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(k_h3_snapshot, dim3(1), dim3(1), 0, st, h->guard_ctr[0], h->guard_ctr[1], h->guard_dev);
+  constexpr int N = ppasr_model_s::kGuardN;
+  PPASR_LAUNCH(k_h3_snapshot, dim3(1), dim3(1), 0, st, guard_ptrs(h), h->guard_dev);
   ppasr_status rc = encode_impl(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, workspace, workspace_bytes, stream);
   if (rc != PPASR_OK) return rc;
-  hipLaunchKernelGGL(k_h3_snapshot, dim3(1), dim3(1), 0, st, h->guard_ctr[0], h->guard_ctr[1], h->guard_dev + 2);
-  HIP_TRY(hipMemcpyAsync(h->guard_host, h->guard_dev, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+  PPASR_LAUNCH(k_h3_snapshot, dim3(1), dim3(1), 0, st, guard_ptrs(h), h->guard_dev + N);
+  HIP_TRY(hipMemcpyAsync(h->guard_host, h->guard_dev, 2 * N * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  h->guard_seen[0] = h->guard_host[2];
-  h->guard_seen[1] = h->guard_host[3];
-  if (h->guard_host[0] == h->guard_host[2] && h->guard_host[1] == h->guard_host[3]) return PPASR_OK;
-  h->guard_events += (long long)(h->guard_host[2] - h->guard_host[0]) + (long long)(h->guard_host[3] - h->guard_host[1]);
+  long long events = 0;
+  for (int i = 0; i < N; ++i) {
+    h->guard_seen[i] = h->guard_host[N + i];
+    events += (long long)(h->guard_host[N + i] - h->guard_host[i]);
+  }
+  if (events == 0) return PPASR_OK;
+  h->guard_events += events;
   h->guard_fallbacks += 1;
   h->gemm_mode = PPASR_GEMM_F32;
   rc = encode_impl(h, feats, lens, B, T, probs, logits, frame_argmax, frame_maxprob, workspace, workspace_bytes, stream);
@@ -982,12 +998,12 @@ ppasr_status ppasr_gemm_guard_stats(ppasr_handle h, long long* fallbacks_host, l
   if (!h) return fail(PPASR_EINVAL, "null handle");
   if (h->guard_dev) {  // (guard off: the events since this handle last looked -- a device-wide wait, then the counters)
     HIP_TRY(hipDeviceSynchronize());
-    unsigned int now[2] = {0, 0};
-    HIP_TRY(hipMemcpy(&now[0], h->guard_ctr[0], sizeof(unsigned int), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&now[1], h->guard_ctr[1], sizeof(unsigned int), hipMemcpyDeviceToHost));
-    h->guard_events += (long long)(now[0] - h->guard_seen[0]) + (long long)(now[1] - h->guard_seen[1]);
-    h->guard_seen[0] = now[0];
-    h->guard_seen[1] = now[1];
+    for (int i = 0; i < ppasr_model_s::kGuardN; ++i) {
+      unsigned int now = 0;
+      HIP_TRY(hipMemcpy(&now, h->guard_ctr[i], sizeof(unsigned int), hipMemcpyDeviceToHost));
+      h->guard_events += (long long)(now - h->guard_seen[i]);
+      h->guard_seen[i] = now;
+    }
   }
   if (fallbacks_host) *fallbacks_host = h->guard_fallbacks;
   if (events_host) *events_host = h->guard_events;

@@ -60,7 +60,7 @@ struct GemmEpi {
 };
 
 // out[M][ldc] (columns < n_valid) = epilogue(A[M][K] Wpacked + bias): the streamed-weight GEMM of k_gemm_stream
-// (conformer_kernels.hip) for dense activations, on 32 * MT-row tiles with K chunks of KC through a double-buffered
+// (front_kernels.hip) for dense activations, on 32 * MT-row tiles with K chunks of KC through a double-buffered
 // LDS tile.  blockIdx.y = 256-column block, wave = its 32-column tile.  (out may alias res: every element is read and
 // written by the same lane.)
 template <int MT, int KC>

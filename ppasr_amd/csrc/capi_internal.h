@@ -140,10 +140,11 @@ struct ppasr_model_s {
   int gemm_coverage = 0;      // PPASR_GEMM_COVERS_* of the current mode (ppasr_gemm_coverage)
   // range guard of the fp16 x3 mode (csrc/h3.h, ppasr_set_gemm_guard / ppasr_gemm_guard_stats)
   bool gemm_guard = true;
-  unsigned int* guard_ctr[2] = {nullptr, nullptr};  // device addresses of the two translation units' event counters
-  unsigned int* guard_dev = nullptr;                // [before a, before b, after a, after b]
+  static constexpr int kGuardN = 4;                 // translation units with fp16 x3 kernels (h3.h: one event counter each)
+  unsigned int* guard_ctr[kGuardN] = {};            // device addresses of their counters
+  unsigned int* guard_dev = nullptr;                // [kGuardN counters before the call | kGuardN after]
   unsigned int* guard_host = nullptr;               // pinned mirror
-  unsigned int guard_seen[2] = {0, 0};              // counter values this handle last read
+  unsigned int guard_seen[kGuardN] = {};            // counter values this handle last read
   long long guard_fallbacks = 0, guard_events = 0;
   int row_block = -1;         // ppasr_set_row_block: -1 = by grid size, 32 / 16 / kW16 = always that block form (rbt.h)
   std::vector<int64_t> lens_hint;  // ppasr_set_lengths_hint: host copy of the batch's lengths (route selection only)

@@ -94,7 +94,7 @@ struct VtOut {
 };
 
 // dynamic-LDS request of a ragged (PadSkip) launch: more than half of a CU's LDS, so that workgroups do not share a CU
-// (see the comment at ragged_lds in conformer_kernels.hip); kernels launched with it set kLdsExclusive as their maximum
+// (see the comment at ragged_lds in front_kernels.hip); kernels launched with it set kLdsExclusive as their maximum
 constexpr size_t kLdsExclusive = 82 * 1024;
 size_t ragged_lds(size_t lds, const PadSkip& ps, int n_blocks);
 
@@ -161,6 +161,13 @@ void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, i
 void launch_repack_h3(const f32x4* src, f32x4* dst, int n_tiles, int G, hipStream_t st);
 inline bool conv_ffn_h3_supported(int ksize) { return ksize == 15 || ksize == 7; }
 unsigned int* conformer_h3_ovf_counter();  // device address of conformer_kernels.hip's range-guard counter (h3.h)
+unsigned int* front_h3_ovf_counter();      // ... front_kernels.hip's (conv2 / input projection in the fp16 x3 mode)
+unsigned int* ctc_head_h3_ovf_counter();   // ... ctc_head_kernels.hip's
+// per-file parts of configure_kernels() (dynamic-LDS limits of the kernels each translation unit owns)
+hipError_t configure_front_kernels();
+hipError_t configure_stream_kernels();
+hipError_t configure_split_route_kernels();
+hipError_t configure_ctc_head_kernels();
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
                     const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps = PadSkip{},
@@ -170,7 +177,7 @@ void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float
                      const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,
                      float* x1_next, float* qkv_next, hipStream_t st, bool causal = true, const PadSkip& ps = PadSkip{},
                      VtOut vt_next = VtOut{}, bool h3 = false);
-// ---- split route for under-filled grids (see conformer_kernels.hip): the layer tail cut at its FFNs, each FFN's hidden
+// ---- split route for under-filled grids (see split_route_kernels.hip): the layer tail cut at its FFNs, each FFN's hidden
 // dimension split over S (1, 2, 4 or 8; a divisor of n_chunks) workgroups per row block ----
 void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float* x3, const LayerW& w, const int64_t* lens,
                      int M, int Tp, int ksize, int mask_mul, hipStream_t st, bool causal = true,
@@ -214,7 +221,6 @@ void launch_hist_update(float* hist, const float* fresh, int n, int lo, hipStrea
 void launch_cache_export(const float* kc, const float* vc, float* att, int T, int div, hipStream_t st, int D = 256);
 void launch_cache_import(const float* att, float* kc, float* vc, int T, int div, hipStream_t st, int D = 256);
 void launch_cnn_transpose(const float* src, float* dst, int lo, int lo_ref, int to_ref, hipStream_t st, int D = 256);
-void launch_fill_rows(float* dst, const float* row_or_null, int n_rows, hipStream_t st);
 // hw.ln_g == nullptr: no final LayerNorm (Squeezeformer has no after_norm, squeezeformer/encoder.py:232-235)
 void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr_argmax, float* fr_maxprob,
                      float* row_max, float* row_sum, int M, hipStream_t st, const PadSkip& ps = PadSkip{},

@@ -1595,17 +1595,12 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
   // threads per utterance by the number of (hypothesis, candidate) elements of a frame: every phase is a chain of
   // block-wide steps, and a barrier over few waves is cheaper than one over 16
   const int n_elem = cfg.beam * (1 + cfg.n_cand_max);
-  static const int kSizes[5] = {64, 128, 256, 512, 1024};
-  int sel = n_elem <= 1024 ? 3 : 4;
-  while (sel < 4 && kSizes[sel] < cfg.beam) ++sel;  // (the new beam is materialised one slot per thread)
+  // 512 threads up to 1 024 elements (and beams of at most 512: the new beam is materialised one slot per thread), else 1 024
+  const int sel = (n_elem <= 1024 && cfg.beam <= 512) ? 0 : 1;
   const bool wl = cfg.lm.order > 0 && cfg.lm.word_based != 0;
-  const void* fns[2][5] = {
-      {reinterpret_cast<const void*>(k_ctc_beam<64, false>), reinterpret_cast<const void*>(k_ctc_beam<128, false>),
-       reinterpret_cast<const void*>(k_ctc_beam<256, false>), reinterpret_cast<const void*>(k_ctc_beam<512, false>),
-       reinterpret_cast<const void*>(k_ctc_beam<1024, false>)},
-      {reinterpret_cast<const void*>(k_ctc_beam<64, true>), reinterpret_cast<const void*>(k_ctc_beam<128, true>),
-       reinterpret_cast<const void*>(k_ctc_beam<256, true>), reinterpret_cast<const void*>(k_ctc_beam<512, true>),
-       reinterpret_cast<const void*>(k_ctc_beam<1024, true>)}};
+  const void* fns[2][2] = {
+      {reinterpret_cast<const void*>(k_ctc_beam<512, false>), reinterpret_cast<const void*>(k_ctc_beam<1024, false>)},
+      {reinterpret_cast<const void*>(k_ctc_beam<512, true>), reinterpret_cast<const void*>(k_ctc_beam<1024, true>)}};
   const void* fn = fns[wl ? 1 : 0][sel];
   // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set it on every launch (a few host
   // microseconds) rather than caching "already configured" in process-wide statics, which left a second GPU used from
@@ -1644,13 +1639,8 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
       PPASR_LAUNCH((k_ctc_beam<BT, false>), dim3(B), dim3(BT), lds, st, probs, frame_lens, T, cfg, prune_recs, state,  \
                    init_state, finalize, out_tokens, out_lens, out_scores, status);                                    \
   } while (0)
-  switch (sel) {
-    case 0: PPASR_LAUNCH_BEAM(64); break;
-    case 1: PPASR_LAUNCH_BEAM(128); break;
-    case 2: PPASR_LAUNCH_BEAM(256); break;
-    case 3: PPASR_LAUNCH_BEAM(512); break;
-    default: PPASR_LAUNCH_BEAM(1024); break;
-  }
+  if (sel == 0) PPASR_LAUNCH_BEAM(512);
+  else PPASR_LAUNCH_BEAM(1024);
 #undef PPASR_LAUNCH_BEAM
   return hipGetLastError();
 }

@@ -153,7 +153,7 @@ bool conv12_supported(const FrontW& fw, int F, int F2) {
          (size_t)((127 / F2) + 2) * 7 * F < 0xffff;  // (16-bit window offsets)
 }
 
-// tile_prefix_launch: the ragged launch's tile table (conformer_kernels.hip k_tile_prefix)
+// tile_prefix_launch: the ragged launch's tile table (front_kernels.hip k_tile_prefix)
 void launch_tile_prefix(const PadSkip& ps, int B, int BM, int* tab, hipStream_t st);
 
 void launch_conv12(const float* feats, const FrontW& fw, float* y2, int B, int T, int F, int Tp, int F2, hipStream_t st,

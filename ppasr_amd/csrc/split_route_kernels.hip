@@ -1,0 +1,212 @@
+// split_route_kernels.hip -- the layer tail cut at its feed-forward modules for UNDER-FILLED grids (small batches,
+// half-rate layers, single streaming sessions).  (Split from conformer_kernels.hip in round 5.)
+#include <cstdlib>
+
+#include "conformer_kernels.h"
+#include "launch.h"
+#include "phases.h"
+#include "h3.h"
+
+#include <math.h>
+
+namespace ppasr {
+
+// -------------------------------------------------------------------------------------
+// Split route for UNDER-FILLED grids (<= 128 row blocks: small batches, half-rate layers, single streaming sessions).
+// A launch with fewer row blocks than CUs takes as long as a full one, and 89 % of the fused kernel's time is the two
+// FFNs; here the layer tail is cut at the FFNs and each FFN's hidden dimension is split over S workgroups per row
+// block (partial sums through HBM, joined by the next launch -- kernel boundaries are the only synchronisation, so
+// nothing can deadlock).  Same arithmetic except for the order of the final sum over hidden chunks.
+//   k_conv_pre : dwconv -> LN -> swish -> pw2 -> mask -> +res                        -> x3
+//   k_ffn_part : LN(x) -> FFN over hidden chunks [s n/S, (s+1) n/S)                  -> partial[s]   (grid blocks x S)
+//   k_ffn_join : x + scale (sum_s partial[s] + b2) [-> LN]                           -> out
+//   k_ln_qkv   : LN_mha(x1) -> one 256-column third of [Wq|Wk|Wv]                    -> qkv          (grid blocks x 3)
+// -------------------------------------------------------------------------------------
+template <int KS, bool STREAM>
+__global__ __launch_bounds__(kThreads) void k_conv_pre(const float* __restrict__ g, const float* __restrict__ g_hist,
+                                                       const float* __restrict__ x2, float* __restrict__ x3, LayerW w,
+                                                       const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
+                                                       int left_ctx, PadSkip ps) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int blk = pad_block_of(ps, kRows, M);  // (ragged batches: PadSkip::tab or the padded grid)
+  if (blk < 0) return;
+  float* bufX = smem;
+  float* bufA = bufX + kRows * kLda;
+  float* bufH = bufA + kRows * kLda;
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blk * kRows;
+  const int valid = min(kRows, M - r0);
+  const int col = wave * 32 + (lane & 31);
+  BRing<1> ring;
+  const f32x4* seg_pw2 = w.pw2 + (size_t)wave * kTs256;
+  ring_prime(ring, seg_pw2, 0);
+  PadRows is_pad{lens, r0, Tp, M, mask_mul};
+  float res[16];
+  unsigned pad_bits = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, lane);
+    res[r] = x2[(size_t)(r0 + min(row, valid - 1)) * kD + col];
+    pad_bits |= (is_pad(row) ? 1u : 0u) << r;
+  }
+  dwconv_phase<KS, STREAM>(g, g_hist, bufA, bufH, bufX, w.dw_w, w.dw_b, w.glu_pad, r0, M, Tp, left_ctx);
+  __syncthreads();
+  rb_layernorm<true>(bufA, bufA, kLda, kRows, w.ln_cm_g, w.ln_cm_b, w.cm_eps);
+  __syncthreads();
+  f32x16 acc[1][1];
+  acc_zero(acc);
+  rb_gemm<1, 1, kG256>(bufA, kLda, seg_pw2, 0, nullptr, 0, ring, acc);
+  const float bv = w.pw2_b[col];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, lane);
+    const float c = ((pad_bits >> r) & 1u) ? 0.f : acc[0][0][r] + bv;
+    if (row < valid) x3[(size_t)(r0 + row) * kD + col] = res[r] + c;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_ffn_part(const float* __restrict__ x, const float* __restrict__ ln_g,
+                                                       const float* __restrict__ ln_b, const f32x4* __restrict__ w1,
+                                                       const float* __restrict__ b1, const f32x4* __restrict__ w2,
+                                                       float* __restrict__ partial, int M, int n_total, PadSkip ps) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int blk = pad_block_of(ps, kRows, M);  // (ragged batches: PadSkip::tab or the padded grid)
+  if (blk < 0) return;
+  float* bufA = smem;
+  float* bufH = bufA + kRows * kLda;  // two hidden-chunk buffers
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blk * kRows;
+  const int valid = min(kRows, M - r0);
+  const int n_chunks = n_total / gridDim.y, c0 = blockIdx.y * n_chunks;
+  BRing<1> ring;
+  ring_prime(ring, w1 + (size_t)(c0 * 8 + wave) * kTs256, 0);
+  rb_load_rows(bufA, kLda, x + (size_t)r0 * kD, kRows, valid);
+  // (same wave -> row mapping as the load: no barrier between; ln_g == nullptr: the rows are used as they are)
+  if (ln_g) rb_layernorm(bufA, bufA, kLda, kRows, ln_g, ln_b, 1e-5f);
+  __syncthreads();
+  f32x16 acc2[1][1];
+  acc_zero(acc2);
+  ffn_phase(bufA, bufH, w1, b1, w2, n_chunks, nullptr, ring, acc2, c0, n_total);
+  float* out = partial + (size_t)blockIdx.y * M * kD;
+  const int col = wave * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, lane);
+    if (row < valid) out[(size_t)(r0 + row) * kD + col] = acc2[0][0][r];
+  }
+}
+
+__device__ __forceinline__ f32x4 ln_row(f32x4 y, const float* __restrict__ g, const float* __restrict__ b, int lane) {
+  const float mean = wave_sum(y[0] + y[1] + y[2] + y[3]) * (1.0f / kD);
+  const f32x4 c = y - mean;
+  const float var = wave_sum(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3]) * (1.0f / kD);
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  return c * rstd * *reinterpret_cast<const f32x4*>(g + 4 * lane) + *reinterpret_cast<const f32x4*>(b + 4 * lane);
+}
+// one wave per row: out = LN_out?(LN_pre?(x) + scale * (sum_s partial[s] + b2))
+__global__ __launch_bounds__(256) void k_ffn_join(const float* __restrict__ x, const float* __restrict__ partial, int S,
+                                                  const float* __restrict__ b2, float scale, const float* __restrict__ ln_g,
+                                                  const float* __restrict__ ln_b, float* __restrict__ out, int M,
+                                                  PadSkip ps, const float* __restrict__ pre_g,
+                                                  const float* __restrict__ pre_b) {
+  const int row = blockIdx.x * 4 + wave_id();
+  if (row >= M) return;
+  if (pad_block_skippable(ps, row & ~(kRows - 1), kRows, M)) return;
+  const int lane = lane_id();
+  f32x4 acc = *reinterpret_cast<const f32x4*>(partial + (size_t)row * kD + 4 * lane);
+  for (int s = 1; s < S; ++s) acc += *reinterpret_cast<const f32x4*>(partial + ((size_t)s * M + row) * kD + 4 * lane);
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + 4 * lane);
+  f32x4 y = *reinterpret_cast<const f32x4*>(x + (size_t)row * kD + 4 * lane);
+  if (pre_g) y = ln_row(y, pre_g, pre_b, lane);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) y[e] = y[e] + scale * (acc[e] + bv[e]);
+  if (ln_g) y = ln_row(y, ln_g, ln_b, lane);
+  *reinterpret_cast<f32x4*>(out + (size_t)row * kD + 4 * lane) = y;
+}
+
+// kc / vc != nullptr (single-session streaming): the K and V thirds go straight to the session's cache rows (row m of
+// the chunk -> kc + m*256) instead of qkv -- the separate append launch disappears
+__global__ __launch_bounds__(kThreads) void k_ln_qkv(const float* __restrict__ x1, float* __restrict__ qkv, LayerW w, int M,
+                                                     PadSkip ps, float* __restrict__ kc, float* __restrict__ vc) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int blk = pad_block_of(ps, kRows, M);  // (ragged batches: PadSkip::tab or the padded grid)
+  if (blk < 0) return;
+  float* bufA = smem;
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blk * kRows;
+  const int valid = min(kRows, M - r0);
+  const int c = blockIdx.y;  // 0: q, 1: k, 2: v
+  BRing<1> ring;
+  const f32x4* seg = w.wqkv + (size_t)(c * 8 + wave) * kTs256;
+  ring_prime(ring, seg, 0);
+  rb_load_rows(bufA, kLda, x1 + (size_t)r0 * kD, kRows, valid);
+  rb_layernorm(bufA, bufA, kLda, kRows, w.ln_mha_g, w.ln_mha_b, 1e-5f);
+  __syncthreads();
+  f32x16 acc[1][1];
+  acc_zero(acc);
+  rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, nullptr, 0, ring, acc);
+  const int col = c * 256 + wave * 32 + (lane & 31);
+  const float bv = w.bqkv[col];
+  float* cache = (c == 1) ? kc : (c == 2 ? vc : nullptr);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, lane);
+    if (row >= valid) continue;
+    if (cache) cache[(size_t)(r0 + row) * kD + wave * 32 + (lane & 31)] = acc[0][0][r] + bv;
+    else qkv[(size_t)(r0 + row) * 768 + col] = acc[0][0][r] + bv;
+  }
+}
+
+constexpr size_t kLdsConvPre = 4 * kRows * kLda * sizeof(float);  // (the depthwise window uses the three buffers + halo)
+constexpr size_t kLdsFfnPart = 3 * kRows * kLda * sizeof(float);
+constexpr size_t kLdsLnQkv = kRows * kLda * sizeof(float);
+void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float* x3, const LayerW& w, const int64_t* lens,
+                     int M, int Tp, int ksize, int mask_mul, hipStream_t st, bool causal, const PadSkip& ps) {
+  dim3 grid((M + kRows - 1) / kRows);
+  const int left_ctx = causal ? ksize - 1 : (ksize - 1) / 2;
+#define LAUNCH_CP(KS)                                                                                                    \
+  if (g_hist)                                                                                                            \
+    PPASR_LAUNCH((k_conv_pre<KS, true>), grid, dim3(kThreads), kLdsConvPre, st, g, g_hist, x2, x3, w, lens, M, Tp,   \
+                       mask_mul, left_ctx, ps);                                                                          \
+  else                                                                                                                   \
+    PPASR_LAUNCH((k_conv_pre<KS, false>), grid, dim3(kThreads), kLdsConvPre, st, g, g_hist, x2, x3, w, lens, M, Tp,  \
+                       mask_mul, left_ctx, ps);
+  if (ksize == 15) {
+    LAUNCH_CP(15)
+  } else if (ksize == 31) {
+    LAUNCH_CP(31)
+  } else if (ksize == 7) {
+    LAUNCH_CP(7)
+  }
+#undef LAUNCH_CP
+}
+void launch_ffn_split(const float* x, const float* ln_g, const float* ln_b, const f32x4* w1, const float* b1,
+                      const f32x4* w2, const float* b2, float scale, const float* out_ln_g, const float* out_ln_b,
+                      float* partial, float* out, int M, int n_chunks, int S, hipStream_t st, const PadSkip& ps,
+                      bool residual_is_normed) {
+  PPASR_LAUNCH(k_ffn_part, dim3((M + kRows - 1) / kRows, S), dim3(kThreads), kLdsFfnPart, st, x, ln_g, ln_b, w1, b1,
+                     w2, partial, M, n_chunks, ps);
+  PPASR_LAUNCH(k_ffn_join, dim3((M + 3) / 4), dim3(256), 0, st, x, partial, S, b2, scale, out_ln_g, out_ln_b, out, M,
+                     ps, residual_is_normed ? ln_g : nullptr, residual_is_normed ? ln_b : nullptr);
+}
+void launch_ln_qkv(const float* x1, float* qkv, const LayerW& w, int M, hipStream_t st, const PadSkip& ps, float* kc,
+                   float* vc) {
+  PPASR_LAUNCH(k_ln_qkv, dim3((M + kRows - 1) / kRows, 3), dim3(kThreads), kLdsLnQkv, st, x1, qkv, w, M, ps, kc, vc);
+}
+hipError_t configure_split_route_kernels() {
+  hipError_t e = hipSuccess;
+#define SET_LDS(fn, bytes)                                                                                     \
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+  if (e != hipSuccess) return e;
+  SET_LDS((k_conv_pre<15, false>), kLdsConvPre);
+  SET_LDS((k_conv_pre<31, false>), kLdsConvPre);
+  SET_LDS((k_conv_pre<7, false>), kLdsConvPre);
+  SET_LDS((k_conv_pre<15, true>), kLdsConvPre);
+  SET_LDS((k_conv_pre<31, true>), kLdsConvPre);
+  SET_LDS((k_conv_pre<7, true>), kLdsConvPre);
+  SET_LDS(k_ffn_part, kLdsFfnPart);
+#undef SET_LDS
+  return hipSuccess;
+}
+
+}  // namespace ppasr

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void k_sq_tail_h3(const float* __restrict
 
 constexpr size_t kLdsSqMid = 3 * kRows * kLda * sizeof(float);
 
-// ---- split route for under-filled launches (conformer_kernels.hip, k_conv_pre / k_ffn_part / k_ffn_join): K_B and K_C
+// ---- split route for under-filled launches (split_route_kernels.hip, k_conv_pre / k_ffn_part / k_ffn_join): K_B and K_C
 // cut at their feed-forward modules.  K_B = k_sq_oproj -> FFN1 split -> k_sq_pw1glu ; K_C = k_conv_pre -> FFN2 split
 // [-> k_sq_qkv of the next layer] ----
 // x1 = LN1(x + ctx Wo + bo)

@@ -36,3 +36,28 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# PPASR_KCOV=<file>: every GPU test runs inside the library's own per-kernel profile (ppasr_kprof_*, dispatch-attached events)
+# and the names of the kernels it launched are appended to <file>, one "kernel<TAB>launches<TAB>test" line each --
+# tools/kernel_coverage.py compares them with the kernels compiled into the library.  (Launches of child processes the
+# tests start are not seen; rocprofv3 around the whole suite was tried and is unusably slow on the bench-spawning tests.)
+import pytest  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _kernel_coverage(request):
+    path = os.environ.get("PPASR_KCOV")
+    if not path or "gpu" not in request.keywords:
+        yield
+        return
+    from ppasr_amd._lib import kernel_profile
+    kp = kernel_profile(max_entries=512)
+    kp.__enter__()
+    try:
+        yield
+    finally:
+        kp.__exit__(None, None, None)
+        with open(path, "a") as f:
+            for name, (_ms, n) in kp.kernels.items():
+                f.write(f"{name}\t{n}\t{request.node.nodeid}\n")

@@ -2,11 +2,12 @@
 
     python tools/kernel_coverage.py --list            # build box: every __global__ instantiation of csrc/*.hip ->
                                                       # tools/_ts/kernels_compiled.txt (travels with gpurun) + profiles/
-    python tools/kernel_coverage.py --run             # GPU box: pytest -m gpu under rocprofv3 --kernel-trace, then the report
-    python tools/kernel_coverage.py --report DB...    # compare rocpd databases with the compiled list
+    PPASR_KCOV=gpurun_out/kcov.tsv python -m pytest tests -m gpu -q     # GPU box: tests/conftest.py records each test's kernels
+    python tools/kernel_coverage.py --report gpurun_out/kcov.tsv        # compare with the compiled list
+    python tools/kernel_coverage.py --report-db DB...                   # the same from rocprofv3 rocpd databases
 
 The compiled list comes from the device assembly (`hipcc -S --cuda-device-only`: one `.amdhsa_kernel` per kernel), the
-launched set from rocprofv3's kernel trace of the whole suite (child processes of the tests included)."""
+launched set from the library's own per-kernel profile (ppasr_kprof_*) around every GPU test."""
 import glob
 import os
 import re
@@ -74,18 +75,28 @@ def launched(dbs):
     return names
 
 
-def report(dbs):
+def launched_tsv(paths):
+    names, tests = {}, {}
+    for p in paths:
+        for ln in open(p):
+            k, n, t = ln.rstrip("\n").split("\t")
+            k = short(k)  # (a name the runtime's demangler could not resolve arrives mangled)
+            names[k] = names.get(k, 0) + int(n)
+            tests.setdefault(k, set()).add(t.split("::")[0])
+    return names, tests
+
+
+def report(seen, source):
     comp = [ln.rstrip("\n").split("\t") for ln in open(LIST)]
-    seen = launched(dbs)
     missing = [(k, f) for k, f in comp if k not in seen]
     print(f"# {len(comp)} kernels compiled into libppasr_hip.so, {len(comp) - len(missing)} launched by `pytest -m gpu` "
-          f"({len(dbs)} rocprofv3 kernel-trace database(s), {sum(seen.values())} dispatches)")
+          f"({source}, {sum(seen.values())} dispatches)")
     print("# never launched by the GPU suite:")
     for k, f in missing:
         print(f"{k}\t{f}")
     extra = sorted(k for k in seen if k not in {c for c, _f in comp})
     if extra:
-        print("# launched but not in the compiled list (other libraries: torch, rocprim ...):", len(extra))
+        print("# launched but not in the compiled list:", ", ".join(extra))
     return missing
 
 
@@ -96,18 +107,9 @@ if __name__ == "__main__":
         with open(LIST, "w") as f:
             f.writelines(f"{k}\t{src}\n" for k, src in ks)
         print(f"{len(ks)} kernels -> {LIST}")
-    elif "--run" in sys.argv:
-        out = os.path.join(ROOT, "gpurun_out", "kcov")
-        subprocess.call(f"cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d {out} -o kcov -- "
-                        f"python -m pytest {ROOT}/tests -m gpu -q -p no:cacheprovider > {ROOT}/gpurun_out/kcov_pytest.log 2>&1",
-                        shell=True)
-        dbs = glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)
-        with open(os.path.join(ROOT, "gpurun_out", "kcov_report.txt"), "w") as f:
-            sys.stdout = f
-            report(dbs)
-        sys.stdout = sys.__stdout__
-        subprocess.call(["rm", "-rf", out])
-        print(open(os.path.join(ROOT, "gpurun_out", "kcov_report.txt")).read())
-        print(open(os.path.join(ROOT, "gpurun_out", "kcov_pytest.log")).read()[-600:])
+    elif "--report-db" in sys.argv:
+        dbs = [a for a in sys.argv[1:] if not a.startswith("--")]
+        report(launched(dbs), f"{len(dbs)} rocprofv3 kernel-trace database(s)")
     else:
-        report([a for a in sys.argv[1:] if not a.startswith("--")][1:] if "--report" in sys.argv else sys.argv[1:])
+        files = [a for a in sys.argv[1:] if not a.startswith("--")]
+        report(launched_tsv(files)[0], "ppasr_kprof around every test")

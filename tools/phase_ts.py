@@ -94,6 +94,8 @@ if lib.ppasr_debug_read_wave_ts(wv) == 0:
             print(f"  sub-block {sb} wave {w_} (head {w_ >> 1}, half {w_ & 1}): " + " ".join(f"{x:7.2f}" for x in v)
                   + f"   S {v[1] - v[0]:5.2f}  softmax {v[2] - v[1]:5.2f}  PV {v[3] - v[2]:5.2f}")
     print("k_gemm_stream<conv2, 128-row tiles>, one workgroup, per K chunk and wave (us): gemm | LDS write of the next chunk | barrier wait")
+    wv = (ctypes.c_longlong * 512)()  # (conv2 lives in front_kernels.hip: that translation unit's stamps)
+    assert lib.ppasr_debug_read_wave_ts_front(wv) == 0
     t0 = wv[32 * 8]
     for kc in range(8):
         rows = []
