@@ -628,6 +628,14 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
           launch_repack_h3(*it.w, static_cast<f32x4*>(dst), it.n_tiles, it.G, nullptr);
           *it.w = static_cast<const f32x4*>(dst);
         }
+        // the layer's projected positional table as operand planes (the fused attention's score MFMAs in the mode)
+        if (L.ptab != h->zero_vec) {
+          void* dst = nullptr;
+          HIP_TRY(hipMalloc(&dst, (size_t)h->desc.max_len * d * sizeof(float)));
+          h->allocs.push_back(dst);
+          launch_split_rows_h3(L.ptab, static_cast<float*>(dst), h->desc.max_len, nullptr);
+          L.ptab = static_cast<const float*>(dst);
+        }
       }
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipDeviceSynchronize());
@@ -685,10 +693,11 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
       h->sq_layers_h3.clear();
       h->head_w_h3 = h->conv2_w_h3 = h->embed_w_h3 = nullptr;
       h->guard_seen[0] = w_after;
-      return fail(PPASR_EUNSUPPORTED, "fp16 x3 GEMMs: a weight of magnitude >= 255.9 does not fit the 2^8-scaled fp16 pieces");
+      return fail(PPASR_EUNSUPPORTED, "fp16 x3 GEMMs: a weight of magnitude >= 255.9 (or a positional-table entry >= 4094) does not fit the scaled fp16 pieces");
     }
     h->guard_seen[0] = w_after;
-    HIP_TRY(hipMemcpy(&h->guard_seen[1], h->guard_ctr[1], sizeof(unsigned int), hipMemcpyDeviceToHost));
+    for (int i = 1; i < ppasr_model_s::kGuardN; ++i)
+      HIP_TRY(hipMemcpy(&h->guard_seen[i], h->guard_ctr[i], sizeof(unsigned int), hipMemcpyDeviceToHost));
     h->gemm_coverage = (layers_ok ? PPASR_GEMM_COVERS_LAYERS : 0) | (sq_ok ? PPASR_GEMM_COVERS_LAYERS : 0) |
                        (front_ok ? PPASR_GEMM_COVERS_FRONT : 0) | (h->head_w_h3 ? PPASR_GEMM_COVERS_HEAD : 0);
   } else {
@@ -864,6 +873,15 @@ static ppasr_status encode_impl(ppasr_handle h, const float* feats, const int64_
     const bool h3 = h->gemm_mode == PPASR_GEMM_F16X3 && !h->layers_h3.empty() && !r16 && !w16 && S == 1 &&
                     !(eff && i == h->desc.stride_layer_idx);
     const LayerW& Lk = h3 ? h->layers_h3[i] : L;
+    // ... and with the fused attention the score MFMAs: the QKV stage then leaves K as fp16 hi / lo planes (VtOut::k_h3) and the
+    // attention reads the layer's positional planes.  Producer and consumer follow the same rule: layer j's K is planes iff
+    // layer j runs k_attn_out_glu_h3 (the producer of j's QKV is j's own S1 launch or the NEXT tail of j - 1, which shares
+    // j's row count and block form unless j is the stride layer)
+    auto vt_for = [&](bool fused, bool mode) {
+      VtOut v = fused ? vt_out : VtOut{};
+      v.k_h3 = (fused && mode) ? 1 : 0;
+      return v;
+    };
     float* partial = y1;
     float* x3 = ctx;
     if (!s1_done) {
@@ -878,14 +896,14 @@ static ppasr_status encode_impl(ppasr_handle h, const float* feats, const int64_
       } else if (w16) {
         timed(3, [&] { launch_ffn_qkv_w16(xa, xb, qkv, L, Mi, n_chunks, st, psb, fuse_attn ? vt_out : VtOut{}); });
       } else {
-        timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, Lk, Mi, n_chunks, st, psb, fuse_attn ? vt_out : VtOut{}, h3); });
+        timed(3, [&] { launch_ffn_qkv(xa, xb, qkv, Lk, Mi, n_chunks, st, psb, vt_for(fuse_attn, h3), h3); });
       }
     }
     s1_done = false;
     tap(xb, (size_t)Mi * kD);
     tap(qkv, (size_t)Mi * 3 * kD);
     const int Tt = (Ti + grp - 1) / grp;  // tokens: frames, or zero-padded groups of 3 (pad4group)
-    AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Tt, Tt, 0, lens, ctx, L.pos_u, L.pos_v, L.ptab, pstride,
+    AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Tt, Tt, 0, lens, ctx, L.pos_u, L.pos_v, (h3 && fuse_attn) ? Lk.ptab : L.ptab, pstride,
                mul * grp, Ti, Ti, grp};
     a.pad_skip = skip ? ps.slack + 1 : 0;
     a.vt = vt_out.vt;
@@ -931,7 +949,8 @@ static ppasr_status encode_impl(ppasr_handle h, const float* feats, const int64_
                               h->desc.causal != 0, psb, (next && fusable(i + 1)) ? vt_out : VtOut{});
         else
           launch_conv_ffn(g, nullptr, xc, (next && !h->taps) ? nullptr : xa, Lk, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul,
-                          next, xb, qkv, st, h->desc.causal != 0, psb, (next && fusable(i + 1)) ? vt_out : VtOut{}, h3);
+                          next, xb, qkv, st, h->desc.causal != 0, psb,
+                          vt_for(next && fusable(i + 1), h3 && !(eff && i + 1 == h->desc.stride_layer_idx)), h3);
       });
       s1_done = next != nullptr;
     }

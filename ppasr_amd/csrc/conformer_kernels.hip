@@ -49,15 +49,30 @@ struct QkStoreTailH3 {
   const f32x16& k_acc;
   float* out;  // qkv + (r0 + this lane's row) * 768 + first column of this lane's quad 0; nullptr: row >= valid
   const f32x4 (&bias)[2][4];
+  // fused attention in the mode (VtOut::k_h3): the K third of the row holds [hi: 256 fp16 | lo: 256 fp16] of 2^4 K instead of
+  // 256 floats -- the attention's score MFMAs read their K' fragments from it (attn_out_glu_body<true>)
+  bool k_planes;
+  bool& bad;
+  int out_col;  // wave * 32 + 4 * (lane >> 5): column of `out` inside its 256-wide third
   __device__ __forceinline__ void operator()(int ks) const {
     if (ks < 14 || !out) return;
     const int c = ks - 14;
     const f32x16& acc = c ? k_acc : q_acc;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<f32x4*>(out + c * 256 + 8 * q) =
-          f32x4{acc[4 * q] * kH3Inv + bias[c][q][0], acc[4 * q + 1] * kH3Inv + bias[c][q][1],
-                acc[4 * q + 2] * kH3Inv + bias[c][q][2], acc[4 * q + 3] * kH3Inv + bias[c][q][3]};
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = f32x4{acc[4 * q] * kH3Inv + bias[c][q][0], acc[4 * q + 1] * kH3Inv + bias[c][q][1],
+                            acc[4 * q + 2] * kH3Inv + bias[c][q][2], acc[4 * q + 3] * kH3Inv + bias[c][q][3]};
+      if (c == 1 && k_planes) {
+        f16x4 hi, lo;
+        h3_split4(v * kH3Sa, hi, lo, bad);
+        // (out + 256 = this lane's columns of the K third as floats; as fp16 the same columns start half as far in)
+        _Float16* kp = reinterpret_cast<_Float16*>(out + 256 - (out_col)) + out_col + 8 * q;
+        *reinterpret_cast<f16x4*>(kp) = hi;
+        *reinterpret_cast<f16x4*>(kp + 256) = lo;
+      } else {
+        *reinterpret_cast<f32x4*>(out + c * 256 + 8 * q) = v;
+      }
+    }
   }
 };
 struct QkvStoreSide {
@@ -102,6 +117,7 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
   // (QkvStoreSide, one store every second k-group) instead of running between the units with the matrix pipe idle
   // (0.4 - 1.5 us per unit, per-phase stamps); only V's tile is stored after its GEMM.
   f32x16 tile[3][1][1];
+  bool qk_bad = false;  // (fp16 x3, K planes: range-guard events of the K split)
   const int cq = wave * 32 + 4 * (lane >> 5);
   float* qrow = (lane & 31) < valid ? qkv + (size_t)(r0 + (lane & 31)) * 768 + cq : nullptr;
   f32x4 qb[2][4];  // biases of this lane's Q / K column quads
@@ -120,7 +136,7 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
         rb_gemm_h3(pa, seg, nseg, ring, tile[c][0][0]);
       else
         rb_gemm_h3_rows<1, 16, QkStoreTailH3>(pa, kLdh, kPlaneH, seg, nseg, ring, tile[c],
-                                              QkStoreTailH3{tile[0][0][0], tile[1][0][0], qrow, qb});
+                                              QkStoreTailH3{tile[0][0][0], tile[1][0][0], qrow, qb, vt.k_h3 != 0, qk_bad, cq});
     } else if (c == 0) {
       rb_gemm<1, 1, kG256, kPF, NoSide, true>(bufA, kLda, seg, 0, nseg, 0, ring, tile[c]);
     } else if (c == 1) {
@@ -132,6 +148,7 @@ __device__ __forceinline__ void ffn_qkv_body(float* bufX, float* bufA, float* bu
     }
     PPASR_TS(12 + c);
   }
+  if constexpr (H3) h3_note(qk_bad);
   if (vt.vt) {
     // fused attention route: V in the order the attention's P V MFMAs consume it -- [slab = 32 value columns (this
     // wave's)][row octet][lane = column + 32 * (row quad of the octet)][4 rows]: a lane's register quad i (rows 8i +
@@ -193,6 +210,24 @@ __global__ __launch_bounds__(256) void k_repack_h3(const float* __restrict__ src
   _Float16* d = dst + (((size_t)nt * KS + ks) * 2 * 64 + l) * 8;
   *reinterpret_cast<f16x8*>(d) = hi;
   *reinterpret_cast<f16x8*>(d + 64 * 8) = lo;
+}
+// rows of 256 floats -> [hi: 256 fp16 | lo: 256 fp16] of 2^4 x (the positional table of a layer, for the attention's fp16 x3
+// score MFMAs); out-of-range entries are counted like out-of-range weights
+__global__ __launch_bounds__(256) void k_split_rows_h3(const float* __restrict__ src, _Float16* __restrict__ dst, long long n_quads) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_quads) return;
+  const long long row = i >> 6;
+  const int c = (int)(i & 63) * 4;
+  f16x4 hi, lo;
+  bool bad = false;
+  h3_split4(*reinterpret_cast<const f32x4*>(src + row * 256 + c) * kH3Sa, hi, lo, bad);
+  h3_note(bad);
+  *reinterpret_cast<f16x4*>(dst + row * 512 + c) = hi;
+  *reinterpret_cast<f16x4*>(dst + row * 512 + 256 + c) = lo;
+}
+void launch_split_rows_h3(const float* src, float* dst, long long n_rows, hipStream_t st) {
+  const long long n = n_rows * 64;
+  PPASR_LAUNCH(k_split_rows_h3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, reinterpret_cast<_Float16*>(dst), n);
 }
 unsigned int* conformer_h3_ovf_counter() { return h3_ovf_counter(); }
 void launch_repack_h3(const f32x4* src, f32x4* dst, int n_tiles, int G, hipStream_t st) {
@@ -378,7 +413,8 @@ constexpr int kPLd = 68;                       // private score-tile row stride:
 constexpr int kPTile = 32 * kPLd;              // floats per wave
 constexpr int kFusedAttnFloats = kWaves * kPTile + kWaves * 64 + kRows * kLda;
 static_assert(2 * kRows * kLda <= kWaves * kPTile + kWaves * 64, "bufX/bufA alias the attention scratch");
-static_assert(kRows * kLda + 4 * kPTile <= kWaves * kPTile, "Q'_v and the four merge tiles fit in front of Stat");
+static_assert(kRows * kLda + 128 + 4 * kPTile <= kWaves * kPTile, "Q'_v (fp16 x3: its planes, 512 B longer) and the four merge tiles fit in front of Stat");
+static_assert(kH3TileBytes <= kRows * kLda * 4 + 512, "fp16 x3: the Q'_u planes at bufC run 512 B past it (the launch asks for them)");
 static_assert(kRows * kLda * 4 + kH3TileBytes <= kWaves * kPTile * 4, "fp16 x3: operand planes at bufA stay in front of Stat");
 static_assert(kFusedAttnFloats * 4 <= 160 * 1024, "LDS budget");
 // H3: the out-projection and pointwise_conv1 units on the fp16 x3 route (h3.h; w.wo / w.pw1 are then the re-packed weights)
@@ -418,7 +454,8 @@ __device__ __forceinline__ void attn_out_glu_body(const AttnArgs& a, int B, cons
     T2 = (int)max((int64_t)1, min((int64_t)T2, n_valid));
   }
   float* QV = Ps;
-  float* P = Ps + kRows * kLda + (wave >> 1) * kPTile;  // merge tile of this wave's head (behind QV)
+  // merge tile of this wave's head (behind QV; fp16 x3: behind the Q'_v operand planes, which are 512 B longer)
+  float* P = Ps + kRows * kLda + (H3 ? 128 : 0) + (wave >> 1) * kPTile;
   BRing<1> ring;
   const f32x4* seg_o = w.wo + (size_t)wave * kTs256;
   const f32x4* seg_val = w.pw1 + (size_t)wave * kTs256;
@@ -444,8 +481,11 @@ __device__ __forceinline__ void attn_out_glu_body(const AttnArgs& a, int B, cons
   const int shift = mrow0 & 7;
   int kv_end = (int)min((int64_t)T2, max((int64_t)0, (len_b + a.mask_mul - 1) / a.mask_mul));  // keys >= kv_end are PAD
   const int U = kv_end > 0 ? kv_end + shift : 0;  // shifted key space: u = key + shift in [0, U)
-  constexpr float kScale = 0.125f * 1.4426950408889634f;  // 1/sqrt(dk) * log2(e): p = 2^(s*kScale - m*kScale)
-  const __amdgpu_buffer_rsrc_t rs_k = wstream_rsrc(kbp + h * 64), rs_p = wstream_rsrc(ptab + h * 64),
+  // 1/sqrt(dk) * log2(e): p = 2^(s*kScale - m*kScale).  fp16 x3: K' and Q' both arrive scaled by 2^4 (h3.h), the raw scores by 2^8
+  constexpr float kScale = 0.125f * 1.4426950408889634f * (H3 ? 1.0f / (kH3Sa * kH3Sa) : 1.0f);
+  // fp16 x3: the key rows (K third of qkv, written by the QKV stage: QkStoreTailH3) and the positional rows (a.ptab: the layer's
+  // re-packed table) are [hi: 256 fp16 | lo: 256 fp16] per row -- the same 1 KiB, head h at byte 128 h of each plane
+  const __amdgpu_buffer_rsrc_t rs_k = wstream_rsrc(kbp + h * (H3 ? 32 : 64)), rs_p = wstream_rsrc(ptab + h * (H3 ? 32 : 64)),
                                rs_v = wstream_rsrc(a.vt + ((size_t)(2 * h) * (a.vt_stride >> 3) + ((mrow0 - shift) >> 3)) * 256);
   const int voff_v = lane * 16;
   const int kstride_b = a.k_stride * 4, pstride_b = pstride * kD * 4;
@@ -467,29 +507,55 @@ __device__ __forceinline__ void attn_out_glu_body(const AttnArgs& a, int B, cons
   // consecutive k-groups are requested back to back, so the line is fetched from L2 once; one k-group at a time the
   // 8 waves push 64 KiB through the 32 KiB L1 between two uses of a line and every line is fetched 4 times), double
   // buffered: super-group sg + 1 is in flight while sg feeds the MFMAs
-  f32x4 kq[2][4][2];
+  // (fp16 x3: FOUR buffers -- a super-group's MFMAs are 0.2 us and no longer cover the next one's L2 round trip, so all four
+  //  planes of a sub-block are in flight at once; the values' ring below is not live yet while they are)
+  constexpr int NKB = H3 ? 4 : 2;
+  f32x4 kq[NKB][4][2];
+  // fp16 x3: super-group sg = one PLANE of one operand (0: K hi, 1: K lo, 2: positions hi, 3: positions lo), its four 16-wide
+  // k steps -- a lane's 16-byte pieces of one 128-byte line of its key's plane row, requested back to back as on the fp32 route
   auto load_sg = [&](int buf, int sg) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      kq[buf][i][0] = kfrag(0, 4 * sg + i);
-      kq[buf][i][1] = kfrag(1, 4 * sg + i);
+      if constexpr (H3) {
+        const int soff = (sg & 1) * 512 + 32 * i;
+        kq[buf][i][0] = sg < 2 ? wstream_load(rs_k, vk[0], soff) : wstream_load(rs_p, vp[0], soff);
+        kq[buf][i][1] = sg < 2 ? wstream_load(rs_k, vk[1], soff) : wstream_load(rs_p, vp[1], soff);
+      } else {
+        kq[buf][i][0] = kfrag(0, 4 * sg + i);
+        kq[buf][i][1] = kfrag(1, 4 * sg + i);
+      }
     }
   };
   auto prime_k = [&](int u0) {
     key_offsets(u0);
     load_sg(0, 0);
+    if constexpr (H3) load_sg(1, 1);
   };
 
   // ---- Q' = [q + pos_bias_u | q + pos_bias_v] of the block's 32 query rows -> LDS (bufC / QV); the key loop reads
   // its B-operand fragment Q'[row l31][8 gk + 4 hh .. +3] from there, one ds_read_b128 per k-group ----
   {
     const f32x4 pu = *reinterpret_cast<const f32x4*>(a.pos_u + 4 * lane), pv = *reinterpret_cast<const f32x4*>(a.pos_v + 4 * lane);
+    bool bad = false;
     for (int row = wave; row < kRows; row += kWaves) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row < valid) v = *reinterpret_cast<const f32x4*>(qb + (size_t)(q0 + row) * a.q_stride + 4 * lane);
-      *reinterpret_cast<f32x4*>(bufC + row * kLda + 4 * lane) = v + pu;
-      *reinterpret_cast<f32x4*>(QV + row * kLda + 4 * lane) = v + pv;
+      if constexpr (H3) {  // operand planes [hi | lo][32][kLdh] of Q'_u (at bufC) and Q'_v (at QV), scaled by 2^4
+        f16x4 hi, lo;
+        h3_split4((v + pu) * kH3Sa, hi, lo, bad);
+        _Float16* pu_pl = reinterpret_cast<_Float16*>(bufC) + row * kLdh + 4 * lane;
+        *reinterpret_cast<f16x4*>(pu_pl) = hi;
+        *reinterpret_cast<f16x4*>(pu_pl + kPlaneH) = lo;
+        h3_split4((v + pv) * kH3Sa, hi, lo, bad);
+        _Float16* pv_pl = reinterpret_cast<_Float16*>(QV) + row * kLdh + 4 * lane;
+        *reinterpret_cast<f16x4*>(pv_pl) = hi;
+        *reinterpret_cast<f16x4*>(pv_pl + kPlaneH) = lo;
+      } else {
+        *reinterpret_cast<f32x4*>(bufC + row * kLda + 4 * lane) = v + pu;
+        *reinterpret_cast<f32x4*>(QV + row * kLda + 4 * lane) = v + pv;
+      }
     }
+    if constexpr (H3) h3_note(bad);
     __syncthreads();
   }
   const float* qfrag_u = bufC + l31 * kLda + h * 64 + 4 * hh;
@@ -537,7 +603,31 @@ __device__ __forceinline__ void attn_out_glu_body(const AttnArgs& a, int B, cons
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_s[t][r] = 0.f;
-      {
+      if constexpr (H3) {
+        // three fp16 products per 16-wide k step (h3.h): with a HIGH plane of K' in registers K'hi Q'lo + K'hi Q'hi, with
+        // the LOW plane K'lo Q'hi -- 48 v_mfma_f32_32x32x16_f16 per 64 keys where the fp32 route issues 128 32x32x2
+        const _Float16* qu = reinterpret_cast<const _Float16*>(bufC) + l31 * kLdh + h * 64 + 8 * hh;
+        const _Float16* qv = reinterpret_cast<const _Float16*>(QV) + l31 * kLdh + h * 64 + 8 * hh;
+        load_sg(2, 2);
+        load_sg(3, 3);
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+          const _Float16* qp = sg < 2 ? qu : qv;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f16x8 qh = *reinterpret_cast<const f16x8*>(qp + 16 * i);
+            const f16x8 k0 = __builtin_bit_cast(f16x8, kq[sg][i][0]), k1 = __builtin_bit_cast(f16x8, kq[sg][i][1]);
+            if ((sg & 1) == 0) {
+              const f16x8 ql = *reinterpret_cast<const f16x8*>(qp + kPlaneH + 16 * i);
+              acc_s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, ql, acc_s[0], 0, 0, 0);
+              acc_s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, ql, acc_s[1], 0, 0, 0);
+            }
+            acc_s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qh, acc_s[0], 0, 0, 0);
+            acc_s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qh, acc_s[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else {
         f32x4 q_cur = qfrag(0), q_nxt = q_cur;
 #pragma unroll
         for (int sg = 0; sg < 4; ++sg) {
@@ -777,7 +867,7 @@ void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, f
   // 1-D grid of nq * ceil(B/8) * 8 workgroups (see the XCD map in the kernel)
   const int nq = (a.T1 + 31) / 32;
   if (h3)  // (w: the layer's fp16 x3 view)
-    PPASR_LAUNCH(k_attn_out_glu_h3, dim3(nq * ((B + 7) / 8) * 8), dim3(kThreads), kLdsAttnOutGlu, st, a, B, x1, x2, g, w);
+    PPASR_LAUNCH(k_attn_out_glu_h3, dim3(nq * ((B + 7) / 8) * 8), dim3(kThreads), kLdsAttnOutGlu + 512, st, a, B, x1, x2, g, w);
   else
     PPASR_LAUNCH(k_attn_out_glu, dim3(nq * ((B + 7) / 8) * 8), dim3(kThreads), kLdsAttnOutGlu, st, a, B, x1, x2, g, w);
 }
@@ -1090,7 +1180,7 @@ hipError_t configure_kernels() {
   SET_LDS((k_conv_ffn<31, true, false>), kLdsConvFfn);
   SET_LDS((k_conv_ffn<7, true, false>), kLdsConvFfn);
   SET_LDS(k_attn_out_glu, kLdsAttnOutGlu);
-  SET_LDS(k_attn_out_glu_h3, kLdsAttnOutGlu);
+  SET_LDS(k_attn_out_glu_h3, kLdsAttnOutGlu + 512);
   SET_LDS(k_conv_ffn_stride<15>, kLdsConvFfn);
 #undef SET_LDS
   return hipSuccess;
