@@ -236,3 +236,58 @@ def test_shim_rnn_state_dict_names_are_paddles():
     names = set(paddle.nn.LSTM(4, 8, direction="bidirect").state_dict().keys())
     for n in ("weight_ih_l0", "weight_hh_l0_reverse", "0.cell_fw.weight_ih", "0.cell_bw.bias_hh"):
         assert n in names, (n, sorted(names))
+
+
+# ---- the mean square of AudioSegment.rms_db: numpy's summation order, restated element by element ----
+def _pairwise_f32(a):
+    """numpy's float32 pairwise sum (what csrc/fbank.hip k_sumsq reproduces): <= 128 elements -> eight running sums combined
+    ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the n % 8 tail; longer -> split at n/2 rounded down to a multiple of 8."""
+    f32 = np.float32
+    n = len(a)
+    if n < 8:
+        r = f32(0.0)
+        for v in a:
+            r = f32(r + v)
+        return r
+    if n <= 128:
+        r = [a[j] for j in range(8)]
+        i = 8
+        while i < n - (n % 8):
+            for j in range(8):
+                r[j] = f32(r[j] + a[i + j])
+            i += 8
+        res = f32(f32(f32(r[0] + r[1]) + f32(r[2] + r[3])) + f32(f32(r[4] + r[5]) + f32(r[6] + r[7])))
+        while i < n:
+            res = f32(res + a[i])
+            i += 1
+        return res
+    n2 = n // 2
+    n2 -= n2 % 8
+    return f32(_pairwise_f32(a[:n2]) + _pairwise_f32(a[n2:]))
+
+
+def test_numpy_sums_float32_in_8192_element_chunks_of_pairwise_sums():
+    """The GPU fbank front end computes AudioSegment.normalize's gain bit-exactly because it sums the squares in numpy's
+    order: `np.mean(x ** 2)` on float32 = sequential accumulation of pairwise sums over 8192-element chunks (the ufunc
+    buffer size), divided once.  If a numpy release changes that order this test says so before the GPU test does."""
+    import warnings
+    from oracle.fbank_oracle import normalize_to_int16
+    from ppasr_amd.data_utils.featurizer import db_gain
+    f32 = np.float32
+    for n in (1, 7, 8, 129, 1000, 8192, 8193, 20000, 40000):
+        x = np.random.default_rng(n).standard_normal(n).astype(f32) * f32(0.1)
+        a = x ** 2
+        s = f32(0.0)
+        for i in range(0, n, 8192):
+            s = f32(s + _pairwise_f32(a[i:i + 8192]))
+        assert s == np.sum(a), n
+        ms = f32(np.float64(s) / n)
+        assert ms == np.mean(a), n
+        # ... and the gain on top of it with numpy 1.x's scalar types (float32 mean square and log10, everything after in float64)
+        rms_db = 10.0 * float(np.log10(ms))
+        gain = f32(10.0 ** ((-20.0 - rms_db) / 20.0))
+        assert gain == db_gain(x, -20.0), n
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = np.clip((x * gain) * f32(32768.0), -32768, 32767).astype(np.int16)
+        assert np.array_equal(normalize_to_int16(x, True, -20.0), want), n
