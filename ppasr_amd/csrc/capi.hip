@@ -573,6 +573,7 @@ static ppasr_status guard_alloc(ppasr_handle h) {
   h->guard_ctr[1] = squeezeformer_h3_ovf_counter();
   h->guard_ctr[2] = front_h3_ovf_counter();
   h->guard_ctr[3] = ctc_head_h3_ovf_counter();
+  h->guard_ctr[4] = split_route_h3_ovf_counter();
   for (int i = 0; i < N; ++i)
     if (!h->guard_ctr[i]) return fail(PPASR_EHIP, "fp16 x3 range guard: counter symbols not found");
   void* d = nullptr;
@@ -872,7 +873,10 @@ static ppasr_status encode_impl(ppasr_handle h, const float* feats, const int64_
     // feed-forward GEMMs on the fp16 x3 route (ppasr_set_gemm_mode): the 8-wave 32-row kernels only
     const bool h3 = h->gemm_mode == PPASR_GEMM_F16X3 && !h->layers_h3.empty() && !r16 && !w16 && S == 1 &&
                     !(eff && i == h->desc.stride_layer_idx);
-    const LayerW& Lk = h3 ? h->layers_h3[i] : L;
+    // ... the split route of under-filled launches likewise (its kernels' units; h3 view for the weights only -- the
+    // stand-alone attention keeps the fp32 positional table)
+    const bool h3s = h->gemm_mode == PPASR_GEMM_F16X3 && !h->layers_h3.empty() && S > 1 && !(eff && i == h->desc.stride_layer_idx);
+    const LayerW& Lk = (h3 || h3s) ? h->layers_h3[i] : L;
     // ... and with the fused attention the score MFMAs: the QKV stage then leaves K as fp16 hi / lo planes (VtOut::k_h3) and the
     // attention reads the layer's positional planes.  Producer and consumer follow the same rule: layer j's K is planes iff
     // layer j runs k_attn_out_glu_h3 (the producer of j's QKV is j's own S1 launch or the NEXT tail of j - 1, which shares
@@ -887,9 +891,9 @@ static ppasr_status encode_impl(ppasr_handle h, const float* feats, const int64_
     if (!s1_done) {
       if (S > 1) {
         timed(3, [&] {
-          launch_ffn_split(xa, L.ln_mac_g, L.ln_mac_b, L.ffm_w1, L.ffm_b1, L.ffm_w2, L.ffm_b2, 0.5f, nullptr, nullptr, partial,
-                           xb, Mi, n_chunks, S, st, ps);
-          launch_ln_qkv(xb, qkv, L, Mi, st, ps);
+          launch_ffn_split(xa, L.ln_mac_g, L.ln_mac_b, Lk.ffm_w1, L.ffm_b1, Lk.ffm_w2, L.ffm_b2, 0.5f, nullptr, nullptr, partial,
+                           xb, Mi, n_chunks, S, st, ps, false, h3s);
+          launch_ln_qkv(xb, qkv, Lk, Mi, st, ps, nullptr, nullptr, h3s);
         });
       } else if (r16) {
         timed(3, [&] { launch_ffn_qkv_16(xa, xb, qkv, L, Mi, n_chunks, st, psb); });
@@ -917,7 +921,7 @@ static ppasr_status encode_impl(ppasr_handle h, const float* feats, const int64_
       //  xa, which is free between this layer's S1 and its output)
       if (r16) timed(5, [&] { launch_out_glu_16(ctx, xb, xc, g, L, lens, Mi, Ti, mul, st, psb); });
       else if (w16) timed(5, [&] { launch_out_glu_w16(ctx, xb, xc, g, L, lens, Mi, Ti, mul, st, psb); });
-      else timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, L, lens, Mi, Ti, mul, st, psb, S > 1 ? xa : nullptr); });
+      else timed(5, [&] { launch_out_glu(ctx, xb, xc, g, nullptr, h3s ? Lk : L, lens, Mi, Ti, mul, st, psb, S > 1 ? xa : nullptr, h3s); });
     }
     tap(xc, (size_t)Mi * kD);
     tap(g, (size_t)Mi * kD);
@@ -932,9 +936,9 @@ static ppasr_status encode_impl(ppasr_handle h, const float* feats, const int64_
       pstride *= 2;
     } else if (S > 1) {
       timed(6, [&] {
-        launch_conv_pre(g, nullptr, xc, x3, L, lens, Mi, Ti, h->layer_ks[i], mul, st, h->desc.causal != 0, ps);
-        launch_ffn_split(x3, L.ln_ff_g, L.ln_ff_b, L.ff_w1, L.ff_b1, L.ff_w2, L.ff_b2, 0.5f, L.ln_fin_g, L.ln_fin_b, partial,
-                         xa, Mi, n_chunks, S, st, ps);
+        launch_conv_pre(g, nullptr, xc, x3, Lk, lens, Mi, Ti, h->layer_ks[i], mul, st, h->desc.causal != 0, ps, h3s);
+        launch_ffn_split(x3, L.ln_ff_g, L.ln_ff_b, Lk.ff_w1, L.ff_b1, Lk.ff_w2, L.ff_b2, 0.5f, L.ln_fin_g, L.ln_fin_b, partial,
+                         xa, Mi, n_chunks, S, st, ps, false, h3s);
       });
     } else {
       // fuse the next layer's S1 into this launch (it writes xb / qkv, which this layer no longer reads)

@@ -140,7 +140,7 @@ struct ppasr_model_s {
   int gemm_coverage = 0;      // PPASR_GEMM_COVERS_* of the current mode (ppasr_gemm_coverage)
   // range guard of the fp16 x3 mode (csrc/h3.h, ppasr_set_gemm_guard / ppasr_gemm_guard_stats)
   bool gemm_guard = true;
-  static constexpr int kGuardN = 4;                 // translation units with fp16 x3 kernels (h3.h: one event counter each)
+  static constexpr int kGuardN = 5;                 // translation units with fp16 x3 kernels (h3.h: one event counter each)
   unsigned int* guard_ctr[kGuardN] = {};            // device addresses of their counters
   unsigned int* guard_dev = nullptr;                // [kGuardN counters before the call | kGuardN after]
   unsigned int* guard_host = nullptr;               // pinned mirror

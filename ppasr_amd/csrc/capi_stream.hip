@@ -117,10 +117,15 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
     float* xh = s->xh_hist + (size_t)i * s->lo * kD;
     const int lo_i = layer_lo(h, i);
     const int S = ffn_split_for(h, Ti);
+    // ppasr_set_gemm_mode(h, PPASR_GEMM_F16X3): the split route's GEMM units on the fp16 x3 route (Lk = the layer's h3 view: the
+    // same LayerNorm / bias pointers, re-packed weights; its ptab are operand planes, so the attention below keeps L's).
+    // Out-of-range activations are saturated and counted (ppasr_gemm_guard_stats); a chunk is not re-run.
+    const bool h3 = S > 1 && h->gemm_mode == PPASR_GEMM_F16X3 && !h->layers_h3.empty();
+    const LayerW& Lk = h3 ? h->layers_h3[i] : L;
     if (S > 1) {
-      launch_ffn_split(xa, L.ln_mac_g, L.ln_mac_b, L.ffm_w1, L.ffm_b1, L.ffm_w2, L.ffm_b2, 0.5f, nullptr, nullptr, partial, xb,
-                       Ti, n_chunks, S, st);
-      launch_ln_qkv(xb, qkv, L, Ti, st, PadSkip{}, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD);
+      launch_ffn_split(xa, L.ln_mac_g, L.ln_mac_b, Lk.ffm_w1, L.ffm_b1, Lk.ffm_w2, L.ffm_b2, 0.5f, nullptr, nullptr, partial, xb,
+                       Ti, n_chunks, S, st, PadSkip{}, false, h3);
+      launch_ln_qkv(xb, qkv, Lk, Ti, st, PadSkip{}, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD, h3);
     } else {
       launch_ffn_qkv(xa, xb, qkv, L, Ti, n_chunks, st);
       launch_kv_append(qkv, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD, Ti, st);
@@ -131,7 +136,7 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
                L.ptab, pstride, mul * grp, Ti, T2f, grp};
     launch_attention(a, 1, H, st);
     float* gh = s->g_hist + (size_t)i * s->lo * kD;
-    launch_out_glu(ctx, xb, xc, g, xhat, L, nullptr, Ti, Ti, mul, st, PadSkip{}, S > 1 ? xhat : nullptr);
+    launch_out_glu(ctx, xb, xc, g, xhat, Lk, nullptr, Ti, Ti, mul, st, PadSkip{}, S > 1 ? xhat : nullptr, h3);
     if (is_eff(h) && i == h->desc.stride_layer_idx) {
       const int Ts = ceil_div(Ti, 2);
       launch_conv_ffn_stride(g, gh, xc, xa, L, nullptr, 1, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st);
@@ -142,9 +147,9 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
       half = true;
     } else {
       if (S > 1) {
-        launch_conv_pre(g, gh, xc, ctx, L, nullptr, Ti, Ti, h->layer_ks[i], mul, st);
-        launch_ffn_split(ctx, L.ln_ff_g, L.ln_ff_b, L.ff_w1, L.ff_b1, L.ff_w2, L.ff_b2, 0.5f, L.ln_fin_g, L.ln_fin_b, partial,
-                         xa, Ti, n_chunks, S, st);
+        launch_conv_pre(g, gh, xc, ctx, Lk, nullptr, Ti, Ti, h->layer_ks[i], mul, st, true, PadSkip{}, h3);
+        launch_ffn_split(ctx, L.ln_ff_g, L.ln_ff_b, Lk.ff_w1, L.ff_b1, Lk.ff_w2, L.ff_b2, 0.5f, L.ln_fin_g, L.ln_fin_b, partial,
+                         xa, Ti, n_chunks, S, st, PadSkip{}, false, h3);
       } else {
         launch_conv_ffn(g, gh, xc, xa, L, nullptr, Ti, Ti, n_chunks, h->layer_ks[i], mul, nullptr, nullptr, nullptr, st);
       }
@@ -549,10 +554,12 @@ ppasr_status ppasr_encode_chunk_group(ppasr_stream_group g, const int* sessions_
     float* vc = g->vc + (size_t)i * g->cap * kD;
     float* xh = g->xh_hist + (size_t)i * lo * kD;
     const int S = ffn_split_for(h, M);  // few sessions = an under-filled grid: split route (partial sums in y1)
+    const bool h3 = S > 1 && h->gemm_mode == PPASR_GEMM_F16X3 && !h->layers_h3.empty();  // (see conformer_chunk)
+    const LayerW& Wk = h3 ? h->layers_h3[i] : W;
     if (S > 1) {
-      launch_ffn_split(xa, W.ln_mac_g, W.ln_mac_b, W.ffm_w1, W.ffm_b1, W.ffm_w2, W.ffm_b2, 0.5f, nullptr, nullptr, y1, xb, M,
-                       n_chunks, S, st);
-      launch_ln_qkv(xb, qkv, W, M, st);
+      launch_ffn_split(xa, W.ln_mac_g, W.ln_mac_b, Wk.ffm_w1, W.ffm_b1, Wk.ffm_w2, W.ffm_b2, 0.5f, nullptr, nullptr, y1, xb, M,
+                       n_chunks, S, st, PadSkip{}, false, h3);
+      launch_ln_qkv(xb, qkv, Wk, M, st, PadSkip{}, nullptr, nullptr, h3);
     } else {
       launch_ffn_qkv(xa, xb, qkv, W, M, n_chunks, st);
     }
@@ -561,11 +568,11 @@ ppasr_status ppasr_encode_chunk_group(ppasr_stream_group g, const int* sessions_
     launch_attention(a, n, H, st);
     launch_hist_gather(xh, hist_sess, desc_dev, xh_act, n, lo, st);
     launch_pw1_glu(xh_act, g_hist, W, n * lo, st);
-    launch_out_glu(ctx, xb, xc, gg, xhat, W, nullptr, M, c, 4, st, PadSkip{}, S > 1 ? xhat : nullptr);
+    launch_out_glu(ctx, xb, xc, gg, xhat, Wk, nullptr, M, c, 4, st, PadSkip{}, S > 1 ? xhat : nullptr, h3);
     if (S > 1) {
-      launch_conv_pre(gg, g_hist, xc, ctx, W, nullptr, M, c, h->desc.cnn_module_kernel, 4, st);
-      launch_ffn_split(ctx, W.ln_ff_g, W.ln_ff_b, W.ff_w1, W.ff_b1, W.ff_w2, W.ff_b2, 0.5f, W.ln_fin_g, W.ln_fin_b, y1, xa, M,
-                       n_chunks, S, st);
+      launch_conv_pre(gg, g_hist, xc, ctx, Wk, nullptr, M, c, h->desc.cnn_module_kernel, 4, st, true, PadSkip{}, h3);
+      launch_ffn_split(ctx, W.ln_ff_g, W.ln_ff_b, Wk.ff_w1, W.ff_b1, Wk.ff_w2, W.ff_b2, 0.5f, W.ln_fin_g, W.ln_fin_b, y1, xa, M,
+                       n_chunks, S, st, PadSkip{}, false, h3);
     } else {
       launch_conv_ffn(gg, g_hist, xc, xa, W, nullptr, M, c, n_chunks, h->desc.cnn_module_kernel, 4, nullptr, nullptr, nullptr, st);
     }

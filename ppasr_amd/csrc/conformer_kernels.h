@@ -167,6 +167,7 @@ void launch_split_rows_h3(const float* src, float* dst, long long n_rows, hipStr
 unsigned int* conformer_h3_ovf_counter();  // device address of conformer_kernels.hip's range-guard counter (h3.h)
 unsigned int* front_h3_ovf_counter();      // ... front_kernels.hip's (conv2 / input projection in the fp16 x3 mode)
 unsigned int* ctc_head_h3_ovf_counter();   // ... ctc_head_kernels.hip's
+unsigned int* split_route_h3_ovf_counter();  // ... split_route_kernels.hip's
 // per-file parts of configure_kernels() (dynamic-LDS limits of the kernels each translation unit owns)
 hipError_t configure_front_kernels();
 hipError_t configure_stream_kernels();
@@ -175,7 +176,8 @@ hipError_t configure_ctc_head_kernels();
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
                     const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps = PadSkip{},
-                    float* split_xhat = nullptr);  // != nullptr: two launches (under-filled grids), M*256 floats of scratch
+                    float* split_xhat = nullptr,  // != nullptr: two launches (under-filled grids), M*256 floats of scratch
+                    bool h3 = false);             // the units on the fp16 x3 route (w: the layer's h3 view)
 // next != nullptr: also run the following layer's S1 (writes x1_next, qkv_next) in the same launch
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                      const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,
@@ -185,16 +187,16 @@ void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float
 // dimension split over S (1, 2, 4 or 8; a divisor of n_chunks) workgroups per row block ----
 void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float* x3, const LayerW& w, const int64_t* lens,
                      int M, int Tp, int ksize, int mask_mul, hipStream_t st, bool causal = true,
-                     const PadSkip& ps = PadSkip{});
+                     const PadSkip& ps = PadSkip{}, bool h3 = false);
 // out = LN_out?(r + scale * FFN(LN?(x))) with r = x (pre-LN blocks) or r = LN(x) (residual_is_normed: post-LN blocks);
 // ln_g == nullptr: no LN in front of the FFN; partial: S * M * 256 floats of scratch
 void launch_ffn_split(const float* x, const float* ln_g, const float* ln_b, const f32x4* w1, const float* b1,
                       const f32x4* w2, const float* b2, float scale, const float* out_ln_g, const float* out_ln_b,
                       float* partial, float* out, int M, int n_chunks, int S, hipStream_t st, const PadSkip& ps = PadSkip{},
-                      bool residual_is_normed = false);
+                      bool residual_is_normed = false, bool h3 = false);  // h3: w1 / w2 are the re-packed weights
 // kc / vc: write the K / V thirds to these cache rows instead of qkv (single-session streaming)
 void launch_ln_qkv(const float* x1, float* qkv, const LayerW& w, int M, hipStream_t st, const PadSkip& ps = PadSkip{},
-                   float* kc = nullptr, float* vc = nullptr);
+                   float* kc = nullptr, float* vc = nullptr, bool h3 = false);
 void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int B,
                             int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out, hipStream_t st,
                             const PadSkip& ps = PadSkip{}, bool causal = true);

@@ -283,6 +283,8 @@ void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st) {
 // S3: x2 = x1 + ctx*Wo + bo ; g = GLU(pointwise_conv1(mask(LN_conv(x2))))
 // (attention.py:126, encoder.py:399-409, convolution.py:104-106,125-126)
 // -------------------------------------------------------------------------------------
+// H3: the units on the fp16 x3 route (split route / stream handles in the mode; w: the layer's h3 view)
+template <bool H3>
 __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ ctx, const float* __restrict__ x1,
                                                       float* __restrict__ x2, float* __restrict__ g,
                                                       float* __restrict__ xhat_out, LayerW w,
@@ -310,7 +312,8 @@ __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ 
     for (int r = 0; r < 16; ++r) res[r] = x1[(size_t)(r0 + min(acc_row(r, lane), valid - 1)) * kD + col];
     f32x16 acc[1][1];
     acc_zero(acc);
-    rb_gemm<1, 1, kG256>(bufA, kLda, seg_o, 0, stop_after_ln ? nullptr : seg_val, 0, ring, acc);
+    if constexpr (H3) unit_std_h3(bufA, seg_o, stop_after_ln ? nullptr : seg_val, ring, acc);  // (planes: 512 B past bufA)
+    else rb_gemm<1, 1, kG256>(bufA, kLda, seg_o, 0, stop_after_ln ? nullptr : seg_val, 0, ring, acc);
     const float bv = w.bo[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -330,8 +333,17 @@ __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ 
     f32x16 av[1][1], ag[1][1];
     acc_zero(av);
     acc_zero(ag);
-    rb_gemm<1, 1, kG256>(bufA, kLda, seg_val, 0, seg_gate, 0, ring, av);
-    rb_gemm<1, 1, kG256>(bufA, kLda, seg_gate, 0, nullptr, 0, ring, ag);
+    if constexpr (H3) {
+      h3_planes_from_tile(bufA, reinterpret_cast<_Float16*>(bufA));
+      const _Float16* pl = reinterpret_cast<const _Float16*>(bufA);
+      rb_gemm_h3_rows<1, 16>(pl, kLdh, kPlaneH, seg_val, seg_gate, ring, av);
+      rb_gemm_h3_rows<1, 16>(pl, kLdh, kPlaneH, seg_gate, nullptr, ring, ag);
+      av[0][0] *= kH3Inv;
+      ag[0][0] *= kH3Inv;
+    } else {
+      rb_gemm<1, 1, kG256>(bufA, kLda, seg_val, 0, seg_gate, 0, ring, av);
+      rb_gemm<1, 1, kG256>(bufA, kLda, seg_gate, 0, nullptr, 0, ring, ag);
+    }
     const float bval = w.pw1_b[col];
     const float bgate = w.pw1_b[kD + col];
 #pragma unroll
@@ -346,13 +358,14 @@ __global__ __launch_bounds__(kThreads) void k_out_glu(const float* __restrict__ 
 // pointwise_conv1 + GLU of LayerNorm'd (and pad-masked) rows, the 256 output columns over gridDim.y = 2 workgroups:
 // waves 0-3 compute the VALUE tiles of the workgroup's 128 columns, waves 4-7 the GATE tiles of the same columns (one
 // GEMM unit each instead of two in sequence); values cross to the gate waves through LDS.
+template <bool H3>
 __global__ __launch_bounds__(kThreads) void k_pw1_glu_cols(const float* __restrict__ xhat, float* __restrict__ g, LayerW w,
                                                            int M, PadSkip ps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int blk = pad_block_of(ps, kRows, M);  // (ragged batches: PadSkip::tab or the padded grid)
   if (blk < 0) return;
   float* bufA = smem;
-  float* vals = bufA + kRows * kLda;  // [32][132]
+  float* vals = bufA + kRows * kLda + (H3 ? 128 : 0);  // [32][132] (H3: behind the operand planes, 512 B longer than bufA)
   const int lane = lane_id(), wave = wave_id();
   const int r0 = blk * kRows;
   const int valid = min(kRows, M - r0);
@@ -365,7 +378,8 @@ __global__ __launch_bounds__(kThreads) void k_pw1_glu_cols(const float* __restri
   __syncthreads();
   f32x16 acc[1][1];
   acc_zero(acc);
-  rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, nullptr, 0, ring, acc);
+  if constexpr (H3) unit_std_h3(bufA, seg, nullptr, ring, acc);
+  else rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, nullptr, 0, ring, acc);
   const float bv = w.pw1_b[(is_gate ? kD : 0) + col];
   if (!is_gate) {
 #pragma unroll
@@ -383,14 +397,24 @@ __global__ __launch_bounds__(kThreads) void k_pw1_glu_cols(const float* __restri
 constexpr size_t kLdsOutGlu = 2 * kRows * kLda * sizeof(float);
 constexpr size_t kLdsPw1Cols = (kRows * kLda + kRows * 132) * sizeof(float);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
-                    const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps, float* split_xhat) {
+                    const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps, float* split_xhat,
+                    bool h3) {
   // split_xhat != nullptr (under-filled launches): out-projection + LayerNorm in one launch (the LayerNorm'd rows go to
   // split_xhat), pointwise_conv1 + GLU in a second one with the columns over two workgroups per row block
   float* xh = xhat_out ? xhat_out : split_xhat;
-  PPASR_LAUNCH(k_out_glu, dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsOutGlu, st, ctx, x1, x2, g, xh, w, lens,
-                     M, Tp, mask_mul, ps, split_xhat ? 1 : 0);
-  if (split_xhat)
-    PPASR_LAUNCH(k_pw1_glu_cols, dim3((M + kRows - 1) / kRows, 2), dim3(kThreads), kLdsPw1Cols, st, xh, g, w, M, ps);
+  const dim3 grid((M + kRows - 1) / kRows);
+  if (h3)
+    PPASR_LAUNCH(k_out_glu<true>, grid, dim3(kThreads), kLdsOutGlu + 512, st, ctx, x1, x2, g, xh, w, lens, M, Tp, mask_mul, ps,
+                 split_xhat ? 1 : 0);
+  else
+    PPASR_LAUNCH(k_out_glu<false>, grid, dim3(kThreads), kLdsOutGlu, st, ctx, x1, x2, g, xh, w, lens, M, Tp, mask_mul, ps,
+                 split_xhat ? 1 : 0);
+  if (split_xhat) {
+    if (h3)
+      PPASR_LAUNCH(k_pw1_glu_cols<true>, dim3(grid.x, 2), dim3(kThreads), kLdsPw1Cols + 512, st, xh, g, w, M, ps);
+    else
+      PPASR_LAUNCH(k_pw1_glu_cols<false>, dim3(grid.x, 2), dim3(kThreads), kLdsPw1Cols, st, xh, g, w, M, ps);
+  }
 }
 
 // -------------------------------------------------------------------------------------
@@ -1168,8 +1192,10 @@ hipError_t configure_kernels() {
   SET_LDS((k_conv_ffn_h3<15, false>), kLdsConvFfn + kH3ExtraLds);
   SET_LDS((k_conv_ffn_h3<7, true>), kLdsConvFfn + kH3ExtraLds);
   SET_LDS((k_conv_ffn_h3<7, false>), kLdsConvFfn + kH3ExtraLds);
-  SET_LDS(k_out_glu, kLdsOutGlu);
-  SET_LDS(k_pw1_glu_cols, kLdsPw1Cols);
+  SET_LDS(k_out_glu<false>, kLdsOutGlu);
+  SET_LDS(k_out_glu<true>, kLdsOutGlu + 512);
+  SET_LDS(k_pw1_glu_cols<false>, kLdsPw1Cols);
+  SET_LDS(k_pw1_glu_cols<true>, kLdsPw1Cols + 512);
   SET_LDS((k_conv_ffn<15, false, false>), kLdsConvFfn);
   SET_LDS((k_conv_ffn<31, false, false>), kLdsConvFfn);
   SET_LDS((k_conv_ffn<7, false, false>), kLdsConvFfn);

@@ -215,14 +215,18 @@ struct SwishSideH3 {
 //   w1, w2: fp16-x3-packed (pack_h3 / k_repack_h3)
 //   general form: src = the fp32 rows, pa = where their operand planes go (kH3TileBytes; may overlap src), ph = the two
 //   hidden-chunk tiles (2 * kH3TileBytes)
+//   c0 / n_total: the call covers hidden chunks [c0, c0 + n_chunks) of a layer with n_total chunks (k_ffn_part's slice of the
+//   hidden dimension = a partial sum of the output); default = all of them
 __device__ __forceinline__ void ffn_phase_h3(const float* src, _Float16* pa, _Float16* ph, const f32x4* __restrict__ w1,
                                              const float* __restrict__ b1, const f32x4* __restrict__ w2, int n_chunks,
-                                             const f32x4* __restrict__ after, BRing<1>& ring, f32x16 (&acc2)[1][1]) {
+                                             const f32x4* __restrict__ after, BRing<1>& ring, f32x16 (&acc2)[1][1],
+                                             int c0 = 0, int n_total = -1) {
   const int lane = lane_id(), wave = wave_id();
   h3_planes_from_tile(src, pa);
-  const int ts2 = n_chunks * 32 * 64;  // W2: K = hidden
-  auto w1seg = [&](int c) { return w1 + (size_t)(c * 8 + wave) * kTs256; };
-  auto w2seg = [&](int c) { return w2 + (size_t)wave * ts2 + (size_t)c * 32 * 64; };
+  const int ts2 = (n_total > 0 ? n_total : n_chunks) * 32 * 64;  // W2: K = hidden
+  b1 += c0 * 256;
+  auto w1seg = [&](int c) { return w1 + (size_t)((c0 + c) * 8 + wave) * kTs256; };
+  auto w2seg = [&](int c) { return w2 + (size_t)wave * ts2 + (size_t)(c0 + c) * 32 * 64; };
   const int hoff = (lane & 31) * kLdh + wave * 32 + 4 * (lane >> 5);
   f32x16 acc = acc2[0][0], cur, nx;
   bool bad = false;
@@ -260,9 +264,18 @@ __device__ __forceinline__ void ffn_phase_h3(const float* src, _Float16* pa, _Fl
 // (the Conformer kernels' layout: the planes take over bufA, bufH[0], bufH[1])
 __device__ __forceinline__ void ffn_phase_h3(float* bufA, const f32x4* __restrict__ w1, const float* __restrict__ b1,
                                              const f32x4* __restrict__ w2, int n_chunks, const f32x4* __restrict__ after,
-                                             BRing<1>& ring, f32x16 (&acc2)[1][1]) {
+                                             BRing<1>& ring, f32x16 (&acc2)[1][1], int c0 = 0, int n_total = -1) {
   _Float16* pa = reinterpret_cast<_Float16*>(bufA);
-  ffn_phase_h3(bufA, pa, pa + 2 * kPlaneH, w1, b1, w2, n_chunks, after, ring, acc2);
+  ffn_phase_h3(bufA, pa, pa + 2 * kPlaneH, w1, b1, w2, n_chunks, after, ring, acc2, c0, n_total);
+}
+
+// One 256-deep unit of a complete fp32 tile with the accumulator in the STANDARD layout (lane = column: what the split
+// route's kernels store from), on the fp16 x3 route: the tile becomes operand planes in place (they run 512 B past it)
+__device__ __forceinline__ void unit_std_h3(float* tile, const f32x4* __restrict__ seg, const f32x4* __restrict__ nxt,
+                                            BRing<1>& ring, f32x16 (&acc)[1][1]) {
+  h3_planes_from_tile(tile, reinterpret_cast<_Float16*>(tile));
+  rb_gemm_h3_rows<1, 16>(reinterpret_cast<const _Float16*>(tile), kLdh, kPlaneH, seg, nxt, ring, acc);
+  acc[0][0] *= kH3Inv;
 }
 
 }  // namespace ppasr

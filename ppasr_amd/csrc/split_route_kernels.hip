@@ -21,8 +21,10 @@ namespace ppasr {
 //   k_ffn_part : LN(x) -> FFN over hidden chunks [s n/S, (s+1) n/S)                  -> partial[s]   (grid blocks x S)
 //   k_ffn_join : x + scale (sum_s partial[s] + b2) [-> LN]                           -> out
 //   k_ln_qkv   : LN_mha(x1) -> one 256-column third of [Wq|Wk|Wv]                    -> qkv          (grid blocks x 3)
+// H3 (round 5): the GEMM units on the fp16 x3 route (ppasr_set_gemm_mode; w: the layer's h3 view) -- a streaming chunk is
+// a chain of these launches, each a few units long, so the units' 7 -> 3 us show directly in the chunk latency.
 // -------------------------------------------------------------------------------------
-template <int KS, bool STREAM>
+template <int KS, bool STREAM, bool H3>
 __global__ __launch_bounds__(kThreads) void k_conv_pre(const float* __restrict__ g, const float* __restrict__ g_hist,
                                                        const float* __restrict__ x2, float* __restrict__ x3, LayerW w,
                                                        const int64_t* __restrict__ lens, int M, int Tp, int mask_mul,
@@ -55,7 +57,8 @@ __global__ __launch_bounds__(kThreads) void k_conv_pre(const float* __restrict__
   __syncthreads();
   f32x16 acc[1][1];
   acc_zero(acc);
-  rb_gemm<1, 1, kG256>(bufA, kLda, seg_pw2, 0, nullptr, 0, ring, acc);
+  if constexpr (H3) unit_std_h3(bufA, seg_pw2, nullptr, ring, acc);  // (the planes run on into bufH, free since the conv)
+  else rb_gemm<1, 1, kG256>(bufA, kLda, seg_pw2, 0, nullptr, 0, ring, acc);
   const float bv = w.pw2_b[col];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -65,6 +68,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_pre(const float* __restrict__
   }
 }
 
+template <bool H3>
 __global__ __launch_bounds__(kThreads) void k_ffn_part(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                        const float* __restrict__ ln_b, const f32x4* __restrict__ w1,
                                                        const float* __restrict__ b1, const f32x4* __restrict__ w2,
@@ -86,8 +90,19 @@ __global__ __launch_bounds__(kThreads) void k_ffn_part(const float* __restrict__
   __syncthreads();
   f32x16 acc2[1][1];
   acc_zero(acc2);
-  ffn_phase(bufA, bufH, w1, b1, w2, n_chunks, nullptr, ring, acc2, c0, n_total);
   float* out = partial + (size_t)blockIdx.y * M * kD;
+  if constexpr (H3) {  // (transposed tile: lane = row, register quad q = columns wave * 32 + 8 q + 4 (lane >> 5) .. +3)
+    ffn_phase_h3(bufA, w1, b1, w2, n_chunks, nullptr, ring, acc2, c0, n_total);
+    const int row = lane & 31, cq = wave * 32 + 4 * (lane >> 5);
+    if (row < valid) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(out + (size_t)(r0 + row) * kD + cq + 8 * q) =
+            f32x4{acc2[0][0][4 * q], acc2[0][0][4 * q + 1], acc2[0][0][4 * q + 2], acc2[0][0][4 * q + 3]};
+    }
+    return;
+  }
+  ffn_phase(bufA, bufH, w1, b1, w2, n_chunks, nullptr, ring, acc2, c0, n_total);
   const int col = wave * 32 + (lane & 31);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -126,6 +141,7 @@ __global__ __launch_bounds__(256) void k_ffn_join(const float* __restrict__ x, c
 
 // kc / vc != nullptr (single-session streaming): the K and V thirds go straight to the session's cache rows (row m of
 // the chunk -> kc + m*256) instead of qkv -- the separate append launch disappears
+template <bool H3>
 __global__ __launch_bounds__(kThreads) void k_ln_qkv(const float* __restrict__ x1, float* __restrict__ qkv, LayerW w, int M,
                                                      PadSkip ps, float* __restrict__ kc, float* __restrict__ vc) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -144,7 +160,8 @@ __global__ __launch_bounds__(kThreads) void k_ln_qkv(const float* __restrict__ x
   __syncthreads();
   f32x16 acc[1][1];
   acc_zero(acc);
-  rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, nullptr, 0, ring, acc);
+  if constexpr (H3) unit_std_h3(bufA, seg, nullptr, ring, acc);
+  else rb_gemm<1, 1, kG256>(bufA, kLda, seg, 0, nullptr, 0, ring, acc);
   const int col = c * 256 + wave * 32 + (lane & 31);
   const float bv = w.bqkv[col];
   float* cache = (c == 1) ? kc : (c == 2 ? vc : nullptr);
@@ -161,16 +178,17 @@ constexpr size_t kLdsConvPre = 4 * kRows * kLda * sizeof(float);  // (the depthw
 constexpr size_t kLdsFfnPart = 3 * kRows * kLda * sizeof(float);
 constexpr size_t kLdsLnQkv = kRows * kLda * sizeof(float);
 void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float* x3, const LayerW& w, const int64_t* lens,
-                     int M, int Tp, int ksize, int mask_mul, hipStream_t st, bool causal, const PadSkip& ps) {
+                     int M, int Tp, int ksize, int mask_mul, hipStream_t st, bool causal, const PadSkip& ps, bool h3) {
   dim3 grid((M + kRows - 1) / kRows);
   const int left_ctx = causal ? ksize - 1 : (ksize - 1) / 2;
-#define LAUNCH_CP(KS)                                                                                                    \
-  if (g_hist)                                                                                                            \
-    PPASR_LAUNCH((k_conv_pre<KS, true>), grid, dim3(kThreads), kLdsConvPre, st, g, g_hist, x2, x3, w, lens, M, Tp,   \
-                       mask_mul, left_ctx, ps);                                                                          \
-  else                                                                                                                   \
-    PPASR_LAUNCH((k_conv_pre<KS, false>), grid, dim3(kThreads), kLdsConvPre, st, g, g_hist, x2, x3, w, lens, M, Tp,  \
-                       mask_mul, left_ctx, ps);
+#define LAUNCH_CP2(KS, STREAM, H3)                                                                                      \
+  PPASR_LAUNCH((k_conv_pre<KS, STREAM, H3>), grid, dim3(kThreads), kLdsConvPre, st, g, g_hist, x2, x3, w, lens, M, Tp, \
+               mask_mul, left_ctx, ps)
+#define LAUNCH_CP(KS)                                      \
+  if (g_hist && h3) LAUNCH_CP2(KS, true, true);            \
+  else if (g_hist) LAUNCH_CP2(KS, true, false);            \
+  else if (h3) LAUNCH_CP2(KS, false, true);                \
+  else LAUNCH_CP2(KS, false, false);
   if (ksize == 15) {
     LAUNCH_CP(15)
   } else if (ksize == 31) {
@@ -179,32 +197,49 @@ void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float
     LAUNCH_CP(7)
   }
 #undef LAUNCH_CP
+#undef LAUNCH_CP2
 }
 void launch_ffn_split(const float* x, const float* ln_g, const float* ln_b, const f32x4* w1, const float* b1,
                       const f32x4* w2, const float* b2, float scale, const float* out_ln_g, const float* out_ln_b,
                       float* partial, float* out, int M, int n_chunks, int S, hipStream_t st, const PadSkip& ps,
-                      bool residual_is_normed) {
-  PPASR_LAUNCH(k_ffn_part, dim3((M + kRows - 1) / kRows, S), dim3(kThreads), kLdsFfnPart, st, x, ln_g, ln_b, w1, b1,
-                     w2, partial, M, n_chunks, ps);
+                      bool residual_is_normed, bool h3) {
+  if (h3)  // (w1 / w2: the re-packed weights)
+    PPASR_LAUNCH(k_ffn_part<true>, dim3((M + kRows - 1) / kRows, S), dim3(kThreads), kLdsFfnPart + kH3ExtraLds, st, x, ln_g, ln_b,
+                 w1, b1, w2, partial, M, n_chunks, ps);
+  else
+    PPASR_LAUNCH(k_ffn_part<false>, dim3((M + kRows - 1) / kRows, S), dim3(kThreads), kLdsFfnPart, st, x, ln_g, ln_b, w1, b1,
+                 w2, partial, M, n_chunks, ps);
   PPASR_LAUNCH(k_ffn_join, dim3((M + 3) / 4), dim3(256), 0, st, x, partial, S, b2, scale, out_ln_g, out_ln_b, out, M,
                      ps, residual_is_normed ? ln_g : nullptr, residual_is_normed ? ln_b : nullptr);
 }
 void launch_ln_qkv(const float* x1, float* qkv, const LayerW& w, int M, hipStream_t st, const PadSkip& ps, float* kc,
-                   float* vc) {
-  PPASR_LAUNCH(k_ln_qkv, dim3((M + kRows - 1) / kRows, 3), dim3(kThreads), kLdsLnQkv, st, x1, qkv, w, M, ps, kc, vc);
+                   float* vc, bool h3) {
+  if (h3)
+    PPASR_LAUNCH(k_ln_qkv<true>, dim3((M + kRows - 1) / kRows, 3), dim3(kThreads), kLdsLnQkv + 512, st, x1, qkv, w, M, ps, kc, vc);
+  else
+    PPASR_LAUNCH(k_ln_qkv<false>, dim3((M + kRows - 1) / kRows, 3), dim3(kThreads), kLdsLnQkv, st, x1, qkv, w, M, ps, kc, vc);
 }
+unsigned int* split_route_h3_ovf_counter() { return h3_ovf_counter(); }
 hipError_t configure_split_route_kernels() {
   hipError_t e = hipSuccess;
 #define SET_LDS(fn, bytes)                                                                                     \
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
   if (e != hipSuccess) return e;
-  SET_LDS((k_conv_pre<15, false>), kLdsConvPre);
-  SET_LDS((k_conv_pre<31, false>), kLdsConvPre);
-  SET_LDS((k_conv_pre<7, false>), kLdsConvPre);
-  SET_LDS((k_conv_pre<15, true>), kLdsConvPre);
-  SET_LDS((k_conv_pre<31, true>), kLdsConvPre);
-  SET_LDS((k_conv_pre<7, true>), kLdsConvPre);
-  SET_LDS(k_ffn_part, kLdsFfnPart);
+  SET_LDS((k_conv_pre<15, false, false>), kLdsConvPre);
+  SET_LDS((k_conv_pre<31, false, false>), kLdsConvPre);
+  SET_LDS((k_conv_pre<7, false, false>), kLdsConvPre);
+  SET_LDS((k_conv_pre<15, true, false>), kLdsConvPre);
+  SET_LDS((k_conv_pre<31, true, false>), kLdsConvPre);
+  SET_LDS((k_conv_pre<7, true, false>), kLdsConvPre);
+  SET_LDS((k_conv_pre<15, false, true>), kLdsConvPre);
+  SET_LDS((k_conv_pre<31, false, true>), kLdsConvPre);
+  SET_LDS((k_conv_pre<7, false, true>), kLdsConvPre);
+  SET_LDS((k_conv_pre<15, true, true>), kLdsConvPre);
+  SET_LDS((k_conv_pre<31, true, true>), kLdsConvPre);
+  SET_LDS((k_conv_pre<7, true, true>), kLdsConvPre);
+  SET_LDS(k_ffn_part<false>, kLdsFfnPart);
+  SET_LDS(k_ffn_part<true>, kLdsFfnPart + kH3ExtraLds);
+  SET_LDS(k_ln_qkv<true>, kLdsLnQkv + 512);
 #undef SET_LDS
   return hipSuccess;
 }

@@ -248,3 +248,81 @@ def test_f16x3_coverage_reports_uncovered_layer_kernels():
     assert m.gemm_coverage() == {"front", "head"}
     m.set_gemm_mode("f32")
     assert m.gemm_coverage() == set()
+
+
+@pytest.mark.parametrize("family", ["conformer", "efficient"])
+@pytest.mark.parametrize("lens", [[333, 280, 120], [67]])
+def test_f16x3_mode_on_the_split_route(family, lens):
+    """Under-filled launches (a few row blocks: small batches, single utterances) take the split route; in the mode its
+    kernels' GEMM units run on the fp16 x3 route too (k_ffn_part / k_ln_qkv / k_out_glu / k_pw1_glu_cols / k_conv_pre <.., true>):
+    logits against the oracle and the default mode, per-frame argmax unchanged."""
+    from oracle.conformer_oracle import ConformerOracle
+    from oracle.efficient_conformer_oracle import EfficientConformerOracle
+    from ppasr_amd._lib import kernel_profile
+    V, L = 157, 4
+    if family == "conformer":
+        from ppasr_amd.model_utils.conformer.model import ConformerModel
+        sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=901)
+        conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
+        model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+        oracle = ConformerOracle(sd, num_blocks=L)
+    else:
+        from ppasr_amd.model_utils.efficient_conformer.model import EfficientConformerModel
+        from ppasr_amd.utils.synth import efficient_conformer_state_dict
+        sd = efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=902, perturb_norm=True, stride_layer_idx=1,
+                                            group_layer_idx=(0, 1))
+        conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15,
+                    cnn_module_norm="layer_norm",
+                    efficient_conf=dict(stride_layer_idx=[1], stride=[2], group_layer_idx=[0, 1], group_size=3, stride_kernel=True))
+        model = EfficientConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+        oracle = EfficientConformerOracle(sd, num_blocks=L, stride_layer_idx=1, group_layer_idx=(0, 1))
+    x, la = synth_features(len(lens), max(lens), lens=lens, seed=903)
+    _, base = model.get_encoder_out(x, la, return_logits=True)
+    base = base.cpu().numpy()
+    model.set_gemm_mode("f16x3")
+    with kernel_profile() as kp:
+        _, got = model.get_encoder_out(x, la, return_logits=True)
+        torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    assert any(k.startswith("k_ffn_part<true>") for k in kp.kernels), sorted(kp.kernels)
+    _, ref = oracle.get_encoder_out(x, la, return_logits=True)
+    ref = ref.numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() / scale < 2e-5
+    assert np.abs(got - base).max() / scale < 2e-5
+    for b, n in enumerate(lens):
+        tp = ref.shape[1] if family == "conformer" else got.shape[1]
+        assert np.array_equal(got[b].argmax(-1), base[b].argmax(-1)), b
+
+
+def test_f16x3_mode_on_stream_handles_and_session_groups():
+    """A stream handle / a session group of a model in the mode: the chunk's split-route kernels run their units on the
+    fp16 x3 route; chunk by chunk against the default mode's stream (pinned to the reference source in
+    tests/test_ref_pin_gpu.py, which runs in the mode as well)."""
+    from ppasr_amd._lib import kernel_profile
+    from ppasr_amd.model_utils.conformer.model import ConformerModel, ConformerStreamGroup
+    V, L = 157, 3
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=911)
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
+    model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    x, _ = synth_features(2, 64 * 3 + 67, seed=912)
+    wins = [(c, min(c + 67, x.shape[1])) for c in range(0, x.shape[1] - 7 + 1, 64)]
+
+    def run():
+        s = model.new_stream()
+        single = [s.encode_chunk(x[:1, a:b], -16).cpu().numpy() for a, b in wins]
+        grp = ConformerStreamGroup(model, 2, max_frames=16 * 8)
+        fa = [grp.encode_chunks([0, 1], torch.from_numpy(x[:, a:b]).cuda())[0].cpu().numpy() for a, b in wins if b - a == 67]
+        return single, fa
+
+    base_single, base_fa = run()
+    model.set_gemm_mode("f16x3")
+    with kernel_profile() as kp:
+        got_single, got_fa = run()
+        torch.cuda.synchronize()
+    assert any(k.startswith("k_ffn_part<true>") for k in kp.kernels) and any(k.startswith("k_ln_qkv<true>") for k in kp.kernels)
+    for a, b in zip(got_single, base_single):
+        assert a.shape == b.shape and np.abs(a - b).max() < 1e-5  # (probabilities)
+        assert np.array_equal(a.argmax(-1), b.argmax(-1))
+    for a, b in zip(got_fa, base_fa):
+        assert np.array_equal(a, b)  # per-frame argmax of both sessions

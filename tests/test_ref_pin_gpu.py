@@ -98,10 +98,14 @@ def test_former_batched_matches_reference_source(ref, name, gemm):
         assert np.array_equal(got[(top2[..., 1] - top2[..., 0]) > 1e-5], want[(top2[..., 1] - top2[..., 0]) > 1e-5])
 
 
+@pytest.mark.parametrize("gemm", GEMM_MODES)
 @pytest.mark.parametrize("name,required", [(k, r) for k in FORMERS for r in rc.SMALL[k]["required"]])
-def test_former_chunks_match_reference_source(ref, name, required):
+def test_former_chunks_match_reference_source(ref, name, required, gemm):
+    """gemm = "f16x3": the stream handle's split-route kernels on the fp16 x3 route (Conformer / Efficient-Conformer; on a
+    Squeezeformer handle the mode covers batched launches only and the chunks keep fp32 arithmetic) -- same fixtures, same
+    criteria."""
     case = rc.SMALL[name]
-    model = make_model(case, rc.state_dict(case))
+    model = make_model(case, rc.state_dict(case), gemm)
     x = rc.chunk_features(case)
     stream = model.new_stream()
     outs = []
@@ -114,7 +118,7 @@ def test_former_chunks_match_reference_source(ref, name, required):
     assert tuple(att.shape) == ref[k + "/att"].shape and tuple(cnn.shape) == ref[k + "/cnn"].shape
     e_a = _rel(att.cpu().numpy(), ref[k + "/att"]) if ref[k + "/att"].size else 0.0
     e_c = _rel(cnn.cpu().numpy(), ref[k + "/cnn"]) if ref[k + "/cnn"].size else 0.0  # (use_cnn_module=False: empty)
-    print(f"{k}: probs {e_p:.2e} att {e_a:.2e} cnn {e_c:.2e}")
+    print(f"{k} [{gemm}]: probs {e_p:.2e} att {e_a:.2e} cnn {e_c:.2e}")
     assert e_p < TOL and e_a < TOL and e_c < TOL
 
 

@@ -49,3 +49,37 @@ for n_sessions in (8, 64, 256, 496):
     print(json.dumps({"group_sessions": n_sessions, "ms_per_chunk_round": round(dt / n_chunks * 1e3, 2),
                       "audio_s_per_s": round(n_sessions * n_chunks * 0.64 / dt, 1)}), flush=True)
     del group
+
+# ---- the opt-in fp16 x3 GEMM mode (ppasr_set_gemm_mode): the chunk's split-route kernels run their units on that route ----
+model.set_gemm_mode("f16x3")
+for n_sessions in (1, 8):
+    sessions = [model.new_stream() for _ in range(n_sessions)]
+    streams = [torch.cuda.Stream() for _ in range(n_sessions)]
+    for rep in range(2):
+        for s in sessions:
+            s.reset()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n_chunks):
+            for s, st in zip(sessions, streams):
+                with torch.cuda.stream(st):
+                    s.encode_chunk(chunk, -16, want_probs=False, want_frames=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+    print(json.dumps({"gemm": "f16x3", "sessions": n_sessions, "ms_per_chunk_round": round(dt / n_chunks * 1e3, 2),
+                      "audio_s_per_s": round(n_sessions * n_chunks * 0.64 / dt, 1)}), flush=True)
+for n_sessions in (8, 64):
+    group = ConformerStreamGroup(model, n_sessions, max_frames=16 * (n_chunks * 2 + 2))
+    batch = chunk.repeat(n_sessions, 1, 1).contiguous()
+    ids = list(range(n_sessions))
+    for rep in range(2):
+        group.reset()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n_chunks):
+            group.encode_chunks(ids, batch)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+    print(json.dumps({"gemm": "f16x3", "group_sessions": n_sessions, "ms_per_chunk_round": round(dt / n_chunks * 1e3, 2),
+                      "audio_s_per_s": round(n_sessions * n_chunks * 0.64 / dt, 1)}), flush=True)
+    del group
