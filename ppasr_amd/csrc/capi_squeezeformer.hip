@@ -418,15 +418,18 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
     const bool fuse_next = (i + 1 < L) && (i + 1 != h->desc.reduce_idx) && !(i + 1 == h->desc.recover_idx && reduced);
     const SqLayerW* Wn = fuse_next ? &h->sq_layers[i + 1] : nullptr;
     if (S > 1) {
+      // (fp16 x3 mode: the two feed-forward modules' slices on that route -- the re-packed weights of the layer's h3 view)
+      const bool h3s = h->gemm_mode == PPASR_GEMM_F16X3 && !h->sq_layers_h3.empty();
+      const SqLayerW& Ws = h3s ? h->sq_layers_h3[i] : W;
       launch_sq_oproj(ctx, x, other, W, Mi, st, ps);  // x1 = LN1(x + MHA) in `other` (free until this layer's output)
-      launch_ffn_split(other, nullptr, nullptr, W.ff1_w1, W.ff1_b1, W.ff1_w2, W.ff1_b2, 1.0f, W.ln2_g, W.ln2_b, y1, xc, Mi,
-                       n_chunks, S, st, ps);
+      launch_ffn_split(other, nullptr, nullptr, Ws.ff1_w1, W.ff1_b1, Ws.ff1_w2, W.ff1_b2, 1.0f, W.ln2_g, W.ln2_b, y1, xc, Mi,
+                       n_chunks, S, st, ps, false, h3s);
       launch_sq_pw1glu(xc, g, nullptr, W, lens, Mi, Ti, mul, st, ps);
       tap(xc, (size_t)Mi * kD);
       tap(g, (size_t)Mi * kD);
       launch_conv_pre(g, nullptr, xc, ctx, sq_conv_view(W), lens, Mi, Ti, KS, mul, st, causal, ps);
-      launch_ffn_split(ctx, W.ln3_g, W.ln3_b, W.ff2_w1, W.ff2_b1, W.ff2_w2, W.ff2_b2, 1.0f, W.ln4_g, W.ln4_b, y1, other, Mi,
-                       n_chunks, S, st, ps, /*residual_is_normed=*/true);
+      launch_ffn_split(ctx, W.ln3_g, W.ln3_b, Ws.ff2_w1, W.ff2_b1, Ws.ff2_w2, W.ff2_b2, 1.0f, W.ln4_g, W.ln4_b, y1, other, Mi,
+                       n_chunks, S, st, ps, /*residual_is_normed=*/true, h3s);
       if (Wn) launch_sq_qkv(other, qkv, Wn->wqkv, Wn->bqkv, Mi, st, ps);
     } else {
       // feed-forward modules on the fp16 x3 route (ppasr_set_gemm_mode): the 8-wave 32-row kernels only

@@ -203,13 +203,15 @@ ppasr_status squeezeformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* x
     const SqLayerW* Wn = fuse_next ? &h->sq_layers[i + 1] : nullptr;
     const int S = ffn_split_for(h, Ti);  // one row block: split route (see squeezeformer_encode)
     if (S > 1) {
+      const bool h3s = h->gemm_mode == PPASR_GEMM_F16X3 && !h->sq_layers_h3.empty();  // (the FFN slices in the mode)
+      const SqLayerW& Ws = h3s ? h->sq_layers_h3[i] : W;
       launch_sq_oproj(ctx, x, other, W, Ti, st);
-      launch_ffn_split(other, nullptr, nullptr, W.ff1_w1, W.ff1_b1, W.ff1_w2, W.ff1_b2, 1.0f, W.ln2_g, W.ln2_b, partial, xc,
-                       Ti, n_chunks, S, st);
+      launch_ffn_split(other, nullptr, nullptr, Ws.ff1_w1, W.ff1_b1, Ws.ff1_w2, W.ff1_b2, 1.0f, W.ln2_g, W.ln2_b, partial, xc,
+                       Ti, n_chunks, S, st, PadSkip{}, false, h3s);
       launch_sq_pw1glu(xc, g, xhat, W, nullptr, Ti, Ti, mul, st);
       launch_conv_pre(g, gh, xc, ctx, sq_conv_view(W), nullptr, Ti, Ti, KS, mul, st);
-      launch_ffn_split(ctx, W.ln3_g, W.ln3_b, W.ff2_w1, W.ff2_b1, W.ff2_w2, W.ff2_b2, 1.0f, W.ln4_g, W.ln4_b, partial, other,
-                       Ti, n_chunks, S, st, PadSkip{}, /*residual_is_normed=*/true);
+      launch_ffn_split(ctx, W.ln3_g, W.ln3_b, Ws.ff2_w1, W.ff2_b1, Ws.ff2_w2, W.ff2_b2, 1.0f, W.ln4_g, W.ln4_b, partial, other,
+                       Ti, n_chunks, S, st, PadSkip{}, /*residual_is_normed=*/true, h3s);
       if (Wn) launch_sq_qkv(other, qkv, Wn->wqkv, Wn->bqkv, Ti, st);
     } else {
       launch_sq_mid(ctx, x, xc, g, xhat, W, nullptr, Ti, Ti, mul, n_chunks, st);

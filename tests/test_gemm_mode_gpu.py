@@ -326,3 +326,36 @@ def test_f16x3_mode_on_stream_handles_and_session_groups():
         assert np.array_equal(a.argmax(-1), b.argmax(-1))
     for a, b in zip(got_fa, base_fa):
         assert np.array_equal(a, b)  # per-frame argmax of both sessions
+
+
+def test_f16x3_mode_on_the_squeezeformer_split_route_and_stream():
+    """Squeezeformer in the mode on under-filled launches and stream handles: the feed-forward slices (k_ffn_part<true>) on the
+    fp16 x3 route, the rest of the split route in fp32; against the oracle (batched) and the default mode's stream (chunks)."""
+    from oracle.squeezeformer_oracle import SqueezeformerOracle
+    from ppasr_amd._lib import kernel_profile
+    V, L = 97, 3
+    sd = squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=921, perturb_norm=True)
+    conf = dict(encoder_dim=256, output_size=256, attention_heads=4, num_blocks=L, reduce_idx=1, recover_idx=2,
+                feed_forward_expansion_factor=8, cnn_module_kernel=31)
+    sm = SqueezeformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    x, la = synth_features(2, 331, lens=[331, 200], seed=922)
+    xs, _ = synth_features(1, 64 * 2 + 67, seed=923)
+    wins = [(c, min(c + 67, xs.shape[1])) for c in range(0, xs.shape[1] - 7 + 1, 64)]
+
+    def stream_out():
+        s = sm.new_stream()
+        return [s.encode_chunk(xs[:, a:b], -16).cpu().numpy() for a, b in wins]
+
+    base_chunks = stream_out()
+    sm.set_gemm_mode("f16x3")
+    with kernel_profile() as kp:
+        _, lh = sm.get_encoder_out(x, la, return_logits=True)
+        got_chunks = stream_out()
+        torch.cuda.synchronize()
+    assert any(k.startswith("k_ffn_part<true>") for k in kp.kernels), sorted(kp.kernels)
+    _, lo = SqueezeformerOracle(sd, num_blocks=L, cnn_module_kernel=31, reduce_idx=1, recover_idx=2).get_encoder_out(
+        x, la, return_logits=True)
+    assert _rel(lh.cpu().numpy(), lo.numpy()) < 2e-5
+    for a, b in zip(got_chunks, base_chunks):
+        assert a.shape == b.shape and np.abs(a - b).max() < 1e-5
+        assert np.array_equal(a.argmax(-1), b.argmax(-1))
