@@ -193,15 +193,15 @@ PPASR_API ppasr_status ppasr_set_row_block(ppasr_handle h, int rows);
  * GEMM input (ReLU outputs in front of conv2 / the input projection, swish values in front of W2, LayerNorm outputs
  * elsewhere) is handled by the range guard below -- never Inf / NaN.
  * Built for the fused 256-wide routes: Conformer / Efficient-Conformer -- feed-forward modules, Q/K/V, pointwise_conv2
- * (8-wave 32-row layer kernels; depthwise kernel sizes 15 and 7), linear_out + pointwise_conv1 and the score contraction
+ * (8-wave 32-row layer kernels incl. the Efficient-Conformer's stride layer; depthwise kernel sizes 15 and 7), linear_out +
+ * pointwise_conv1 and the score contraction
  * [q+u | q+v] [k | p]^T of the fused attention kernel (K as fp16 hi / lo planes from the QKV stage, the layer's positional
  * table re-packed by this call: + 1 KiB per table row; an entry beyond 4 094 refuses the mode like a weight does);
  * Squeezeformer -- both feed-forward modules of the 32-row layer kernels (depthwise kernel sizes 31 and 15); all three -- the
  * second convolution of the 4x front end (then its own launch behind conv1), the input projection, the CTC head;
  * Conformer / Efficient-Conformer also on the split route of under-filled launches and therefore on their stream handles and
  * session groups (ppasr_encode_chunk*: a saturated chunk is counted in the guard statistics, NOT re-run).  The other block
- * forms (16 rows, 16 waves), the Efficient-Conformer's stride layer, the non-feed-forward units of Squeezeformer's split
- * route and streams, the attention's P V product and depthwise convolutions keep fp32 arithmetic.  ppasr_gemm_coverage
+ * forms (16 rows, 16 waves), the non-feed-forward units of Squeezeformer's split route and streams, the attention's P V product and depthwise convolutions keep fp32 arithmetic.  ppasr_gemm_coverage
  * tells which of the three parts switched (a Conformer with cnn_module_kernel 31 gets the front end and the head only).
  * PPASR_EUNSUPPORTED on DeepSpeech2 handles and on the general layer route.  Measured (NOTES.md 9.8): logits within 1e-6 .. 3e-6
  * of the default mode's, the reference-source pin tests pass with unchanged criteria, 1.2 - 1.7 x faster end to end. */

@@ -871,16 +871,15 @@ static ppasr_status encode_impl(ppasr_handle h, const float* feats, const int64_
     const bool w16 = rows == kW16 && S == 1;
     const PadSkip psb = S == 1 ? with_table(ps, Ti, r16 ? 16 : 32) : ps;  // (for the kernels of this layer's block size)
     // feed-forward GEMMs on the fp16 x3 route (ppasr_set_gemm_mode): the 8-wave 32-row kernels only
-    const bool h3 = h->gemm_mode == PPASR_GEMM_F16X3 && !h->layers_h3.empty() && !r16 && !w16 && S == 1 &&
-                    !(eff && i == h->desc.stride_layer_idx);
+    const bool h3 = h->gemm_mode == PPASR_GEMM_F16X3 && !h->layers_h3.empty() && !r16 && !w16 && S == 1;
     // ... the split route of under-filled launches likewise (its kernels' units; h3 view for the weights only -- the
     // stand-alone attention keeps the fp32 positional table)
-    const bool h3s = h->gemm_mode == PPASR_GEMM_F16X3 && !h->layers_h3.empty() && S > 1 && !(eff && i == h->desc.stride_layer_idx);
+    const bool h3s = h->gemm_mode == PPASR_GEMM_F16X3 && !h->layers_h3.empty() && S > 1;
     const LayerW& Lk = (h3 || h3s) ? h->layers_h3[i] : L;
     // ... and with the fused attention the score MFMAs: the QKV stage then leaves K as fp16 hi / lo planes (VtOut::k_h3) and the
     // attention reads the layer's positional planes.  Producer and consumer follow the same rule: layer j's K is planes iff
     // layer j runs k_attn_out_glu_h3 (the producer of j's QKV is j's own S1 launch or the NEXT tail of j - 1, which shares
-    // j's row count and block form unless j is the stride layer)
+    // j's row count and block form; the stride layer has no NEXT tail)
     auto vt_for = [&](bool fused, bool mode) {
       VtOut v = fused ? vt_out : VtOut{};
       v.k_h3 = (fused && mode) ? 1 : 0;
@@ -928,8 +927,8 @@ static ppasr_status encode_impl(ppasr_handle h, const float* feats, const int64_
     if (eff && i == h->desc.stride_layer_idx) {
       const int Ts = (Ti + 1) / 2;
       timed(6, [&] {
-        launch_conv_ffn_stride(g, nullptr, xc, xa, L, lens, B, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st,
-                               pskip(Ts, mul * 2), h->desc.causal != 0);
+        launch_conv_ffn_stride(g, nullptr, xc, xa, (h3 || h3s) ? Lk : L, lens, B, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st,
+                               pskip(Ts, mul * 2), h->desc.causal != 0, h3 || h3s);
       });
       Ti = Ts;  // masks[:, :, ::2], pos_emb[:, ::2]  (efficient_conformer/encoder.py:252-257)
       mul *= 2;
@@ -954,7 +953,7 @@ static ppasr_status encode_impl(ppasr_handle h, const float* feats, const int64_
         else
           launch_conv_ffn(g, nullptr, xc, (next && !h->taps) ? nullptr : xa, Lk, lens, Mi, Ti, n_chunks, h->layer_ks[i], mul,
                           next, xb, qkv, st, h->desc.causal != 0, psb,
-                          vt_for(next && fusable(i + 1), h3 && !(eff && i + 1 == h->desc.stride_layer_idx)), h3);
+                          vt_for(next && fusable(i + 1), h3), h3);
       });
       s1_done = next != nullptr;
     }

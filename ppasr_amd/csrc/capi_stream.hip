@@ -139,7 +139,7 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
     launch_out_glu(ctx, xb, xc, g, xhat, Lk, nullptr, Ti, Ti, mul, st, PadSkip{}, S > 1 ? xhat : nullptr, h3);
     if (is_eff(h) && i == h->desc.stride_layer_idx) {
       const int Ts = ceil_div(Ti, 2);
-      launch_conv_ffn_stride(g, gh, xc, xa, L, nullptr, 1, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st);
+      launch_conv_ffn_stride(g, gh, xc, xa, Lk, nullptr, 1, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st, PadSkip{}, true, h3);
       launch_hist_update(xh, xhat, Ti, lo_i, st);
       Ti = Ts;
       mul *= 2;

@@ -1081,7 +1081,8 @@ void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float
 // AvgPool1D(2, 2, ceil_mode, exclusive) (encoder.py:171-172,521-531), the pad mask is mask_pad[:, :, ::2].
 // Rows of this kernel are OUTPUT rows (b, j), j < Ts = ceil(Tp/2); g and x2 are full-resolution.
 // -------------------------------------------------------------------------------------
-template <int KS>
+// H3: pointwise_conv2 and the feed-forward module on the fp16 x3 route (w: the layer's h3 view)
+template <int KS, bool H3>
 __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __restrict__ g, const float* __restrict__ g_hist,
                                                               const float* __restrict__ x2, float* __restrict__ x_out,
                                                               LayerW w,
@@ -1131,7 +1132,8 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __res
   {
     f32x16 acc[1][1];
     acc_zero(acc);
-    rb_gemm<1, 1, kG256>(bufA, kLda, seg_pw2, 0, w.ff_w1 + (size_t)wave * kTs256, 0, ring, acc);
+    if constexpr (H3) unit_std_h3(bufA, seg_pw2, w.ff_w1 + (size_t)wave * kTs256, ring, acc);  // (planes run on into bufH: free here)
+    else rb_gemm<1, 1, kG256>(bufA, kLda, seg_pw2, 0, w.ff_w1 + (size_t)wave * kTs256, 0, ring, acc);
     const float bv = w.pw2_b[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1153,19 +1155,28 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __res
   __syncthreads();
   f32x16 acc2[1][1];
   acc_zero(acc2);
-  ffn_phase(bufA, bufH, w.ff_w1, w.ff_b1, w.ff_w2, n_chunks, nullptr, ring, acc2);
-  residual_epilogue(bufX, acc2, w.ff_b2, 0.5f);
+  if constexpr (H3) {
+    ffn_phase_h3(bufA, w.ff_w1, w.ff_b1, w.ff_w2, n_chunks, nullptr, ring, acc2);
+    residual_epilogue_t(bufX, acc2, w.ff_b2, 0.5f);
+  } else {
+    ffn_phase(bufA, bufH, w.ff_w1, w.ff_b1, w.ff_w2, n_chunks, nullptr, ring, acc2);
+    residual_epilogue(bufX, acc2, w.ff_b2, 0.5f);
+  }
   __syncthreads();
   rb_layernorm(bufX, bufX, kLda, kRows, w.ln_fin_g, w.ln_fin_b, 1e-5f);
   rb_store_rows(x_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);
 }
 void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                             const int64_t* lens, int B, int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out,
-                            hipStream_t st, const PadSkip& ps, bool causal) {
+                            hipStream_t st, const PadSkip& ps, bool causal, bool h3) {
   dim3 grid((B * Ts + kRows - 1) / kRows);
   (void)ksize;  // (the 256-wide route is built for cnn_module_kernel 15 in front of the stride layer: capi.hip refuses others)
-  PPASR_LAUNCH(k_conv_ffn_stride<15>, grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, B, Tp, Ts,
-                     n_chunks, mask_mul_out, ps, causal ? 1 : 0);
+  if (h3)
+    PPASR_LAUNCH((k_conv_ffn_stride<15, true>), grid, dim3(kThreads), kLdsConvFfn + kH3ExtraLds, st, g, g_hist, x2, x_out, w, lens,
+                 B, Tp, Ts, n_chunks, mask_mul_out, ps, causal ? 1 : 0);
+  else
+    PPASR_LAUNCH((k_conv_ffn_stride<15, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, B, Tp, Ts,
+                 n_chunks, mask_mul_out, ps, causal ? 1 : 0);
 }
 
 hipError_t configure_kernels() {
@@ -1207,7 +1218,8 @@ hipError_t configure_kernels() {
   SET_LDS((k_conv_ffn<7, true, false>), kLdsConvFfn);
   SET_LDS(k_attn_out_glu, kLdsAttnOutGlu);
   SET_LDS(k_attn_out_glu_h3, kLdsAttnOutGlu + 512);
-  SET_LDS(k_conv_ffn_stride<15>, kLdsConvFfn);
+  SET_LDS((k_conv_ffn_stride<15, false>), kLdsConvFfn);
+  SET_LDS((k_conv_ffn_stride<15, true>), kLdsConvFfn + kH3ExtraLds);
 #undef SET_LDS
   return hipSuccess;
 }
