@@ -178,16 +178,16 @@ class kernel_profile:
     carries its own dispatch-attached HIP events (``ppasr_kprof_*``); afterwards ``kp.kernels`` is
     ``{kernel name: (total_ms, launches)}`` with the names rocprofv3 prints (parameter lists dropped)."""
 
+    _stack = []  # active scopes of this process, innermost last (the library keeps ONE recording per thread: a nested scope
+                 # drains it at its boundaries and credits what it drained to every scope that was open meanwhile)
+
     def __init__(self, max_entries=128):
         self.max_entries = max_entries
         self.kernels = {}
 
-    def __enter__(self):
-        check(load().ppasr_kprof_begin())
-        return self
-
-    def __exit__(self, *exc):
-        n = self.max_entries
+    @staticmethod
+    def _drain():
+        n = max([k.max_entries for k in kernel_profile._stack] + [512])
         names = ctypes.create_string_buffer(n * KPROF_NAME_LEN)
         ms = (ctypes.c_float * n)()
         cnt = (ctypes.c_int32 * n)()
@@ -195,6 +195,20 @@ class kernel_profile:
         check(load().ppasr_kprof_end(n, ctypes.addressof(names), ms, cnt, ctypes.byref(got)))
         for i in range(got.value):
             nm = names.raw[i * KPROF_NAME_LEN:(i + 1) * KPROF_NAME_LEN].split(b"\0", 1)[0].decode()
-            t, c = self.kernels.get(nm, (0.0, 0))
-            self.kernels[nm] = (t + float(ms[i]), c + int(cnt[i]))
+            for scope in kernel_profile._stack:
+                t, c = scope.kernels.get(nm, (0.0, 0))
+                scope.kernels[nm] = (t + float(ms[i]), c + int(cnt[i]))
+
+    def __enter__(self):
+        if kernel_profile._stack:
+            kernel_profile._drain()  # what ran so far belongs to the outer scopes only
+        kernel_profile._stack.append(self)
+        check(load().ppasr_kprof_begin())
+        return self
+
+    def __exit__(self, *exc):
+        kernel_profile._drain()
+        kernel_profile._stack.pop()
+        if kernel_profile._stack:
+            check(load().ppasr_kprof_begin())
         return False

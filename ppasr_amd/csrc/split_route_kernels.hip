@@ -191,8 +191,9 @@ void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float
   else LAUNCH_CP2(KS, false, false);
   if (ksize == 15) {
     LAUNCH_CP(15)
-  } else if (ksize == 31) {
-    LAUNCH_CP(31)
+  } else if (ksize == 31) {  // (31 taps: Squeezeformer's view and Conformer variants the fp16 x3 layer views do not exist for)
+    if (g_hist) LAUNCH_CP2(31, true, false);
+    else LAUNCH_CP2(31, false, false);
   } else if (ksize == 7) {
     LAUNCH_CP(7)
   }
@@ -232,10 +233,8 @@ hipError_t configure_split_route_kernels() {
   SET_LDS((k_conv_pre<31, true, false>), kLdsConvPre);
   SET_LDS((k_conv_pre<7, true, false>), kLdsConvPre);
   SET_LDS((k_conv_pre<15, false, true>), kLdsConvPre);
-  SET_LDS((k_conv_pre<31, false, true>), kLdsConvPre);
   SET_LDS((k_conv_pre<7, false, true>), kLdsConvPre);
   SET_LDS((k_conv_pre<15, true, true>), kLdsConvPre);
-  SET_LDS((k_conv_pre<31, true, true>), kLdsConvPre);
   SET_LDS((k_conv_pre<7, true, true>), kLdsConvPre);
   SET_LDS(k_ffn_part<false>, kLdsFfnPart);
   SET_LDS(k_ffn_part<true>, kLdsFfnPart + kH3ExtraLds);
