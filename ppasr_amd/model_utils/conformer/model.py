@@ -389,6 +389,47 @@ class ConformerStream:
             torch.cuda.current_stream(m.device).synchronize()  # att / cnn temporaries must outlive the copy
 
 
+class StreamHandleSet:
+    """The interface of ``ConformerStreamGroup`` over per-session stream handles (``model.new_stream()``): for the handles
+    whose sessions the C-ABI cannot advance in one call (``ppasr_stream_group_create`` is built for plain Conformer
+    handles; Squeezeformer / Efficient-Conformer models keep half-rate layers, grouped attention or a stride layer per
+    session).  Same results as driving each session's own stream; N sets of launches per round instead of one."""
+
+    def __init__(self, model, n_sessions, max_frames=0):
+        self.model = model
+        self.n_sessions = int(n_sessions)
+        self._streams = [model.new_stream() for _ in range(self.n_sessions)]
+
+    def offset(self, session):
+        return self._streams[int(session)].offset
+
+    def reset(self, session=-1):
+        for i in (range(self.n_sessions) if int(session) < 0 else [int(session)]):
+            self._streams[i].reset()
+
+    def encode_chunks(self, sessions, speech, want_probs=False):
+        m = self.model
+        x = torch.as_tensor(speech, dtype=torch.float32).to(m.device)
+        assert x.dim() == 3 and int(x.shape[0]) == len(sessions)
+        outs = [self._streams[int(sid)].encode_chunk(x[k:k + 1], -16, want_probs=want_probs, want_frames=True)
+                for k, sid in enumerate(sessions)]
+        fa = torch.cat([o[1] for o in outs], 0)
+        fp = torch.cat([o[2] for o in outs], 0)
+        if want_probs:
+            return fa, fp, torch.cat([o[0] for o in outs], 0)
+        return fa, fp
+
+
+def make_stream_group(model, n_sessions, max_frames=0):
+    """``ConformerStreamGroup`` where the library builds session groups for the handle, else ``StreamHandleSet``."""
+    try:
+        return ConformerStreamGroup(model, n_sessions, max_frames=max_frames)
+    except _lib.PPASRHipError as e:
+        if e.status != _lib.PPASR_EUNSUPPORTED:
+            raise
+        return StreamHandleSet(model, n_sessions, max_frames=max_frames)
+
+
 class ConformerStreamGroup:
     """Many streaming sessions advanced together (no reference counterpart: PPASR streams one session per call,
     predict.py:232-337).  The sessions' K/V and conv caches live in one device allocation;

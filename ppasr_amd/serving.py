@@ -1,4 +1,5 @@
-"""Many-session streaming recogniser built on session groups (``ppasr_encode_chunk_group``).
+"""Many-session streaming recogniser built on session groups (``ppasr_encode_chunk_group``; per-session stream handles for
+the families the library has no group call for).
 
 No reference counterpart: PPASR serves one stream per ``PPASRPredictor`` (``predict_stream``, predict.py:232-337, one
 global predictor behind its FastAPI / GUI apps).  ``StreamPool`` keeps the per-session state machine of
@@ -10,7 +11,7 @@ import numpy as np
 import torch
 
 from ppasr_amd.data_utils.featurizer import AudioFeaturizer, db_gain, pcm_bytes_to_float
-from ppasr_amd.model_utils.conformer.model import ConformerStreamGroup
+from ppasr_amd.model_utils.conformer.model import make_stream_group
 
 __all__ = ["StreamPool"]
 
@@ -31,7 +32,9 @@ class StreamPool:
         self.model = model
         self.vocab = list(vocab_list)
         self.blank = blank_index
-        self.group = ConformerStreamGroup(model, n_sessions, max_frames=min(model.max_len, int(max_seconds * 25) + 32))
+        # (one set of launches per round for plain Conformer handles; per-session stream handles behind the same interface
+        #  for the Squeezeformer and the Efficient-Conformer)
+        self.group = make_stream_group(model, n_sessions, max_frames=min(model.max_len, int(max_seconds * 25) + 32))
         self.featurizer = AudioFeaturizer(**(preprocess_conf or {}))
         self.sessions = [_Session() for _ in range(n_sessions)]
 

@@ -364,3 +364,52 @@ def test_predict_reference_wav_gpu(tmp_path):
         assert final["text"] == str(z["stream_texts"][-1])
         assert abs(final["score"] - float(z["stream_scores"][-1])) < 5e-2
     p.reset_stream()
+
+
+@pytest.mark.parametrize("use_model", ["squeezeformer", "efficient_conformer"])
+def test_stream_pool_serves_the_other_former_families(use_model):
+    """serving.StreamPool on a Squeezeformer / Efficient-Conformer model: the library has no session-group call for these
+    handles, so the pool drives one stream handle per session behind the group interface (StreamHandleSet) -- every session
+    still reproduces its own PPASRPredictor.predict_stream, the late joiner and the final `finish` included."""
+    from ppasr_amd.model_utils.conformer.model import StreamHandleSet
+    from ppasr_amd.predict import PPASRPredictor
+    from ppasr_amd.serving import StreamPool
+    from ppasr_amd.utils.synth import efficient_conformer_state_dict, squeezeformer_state_dict
+    V = 300
+    vocab = synth_vocabulary(V)
+    cfg = _cfg(use_model=use_model, L=4)
+    if use_model == "squeezeformer":
+        cfg["encoder_conf"] = dict(encoder_dim=256, output_size=256, attention_heads=4, num_blocks=4, reduce_idx=1,
+                                   recover_idx=3, feed_forward_expansion_factor=8, cnn_module_kernel=31)
+        sd = squeezeformer_state_dict(vocab_size=V, num_blocks=4, seed=5)
+    else:
+        cfg["encoder_conf"] = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=4, cnn_module_kernel=15,
+                                   cnn_module_norm="layer_norm",
+                                   efficient_conf=dict(stride_layer_idx=[1], stride=[2], group_layer_idx=[0, 1], group_size=3,
+                                                       stride_kernel=True))
+        sd = efficient_conformer_state_dict(vocab_size=V, num_blocks=4, seed=5, stride_layer_idx=1, group_layer_idx=(0, 1))
+    p = PPASRPredictor(configs=cfg, state_dict=sd, vocab_list=vocab, warmup=False)
+    wavs = [_audio(2.4, seed=21), _audio(1.93, seed=22)]
+    pcms = [(np.clip(w, -1, 1) * 32767).astype(np.int16).tobytes() for w in wavs]
+    step = 16000  # 0.5 s packets
+    want = []
+    for pcm in pcms:
+        p.reset_stream()
+        out = None
+        for i in range(0, len(pcm), step):
+            out = p.predict_stream(audio_data=pcm[i:i + step], is_end=(i + step >= len(pcm))) or out
+        want.append(out)
+    p.reset_stream()
+    pool = StreamPool(p.predictor.model, vocab, n_sessions=2, preprocess_conf=cfg["preprocess_conf"])
+    assert isinstance(pool.group, StreamHandleSet)
+    for i in range(0, max(len(x) for x in pcms), step):
+        for s, pcm in enumerate(pcms):
+            if i < len(pcm):
+                pool.feed(s, pcm[i:i + step])
+        pool.step()
+    for s in range(2):
+        got = pool.finish(s)
+        assert got is not None and want[s] is not None and got["text"] == want[s]["text"], s
+        assert abs(got["score"] - want[s]["score"]) < 1e-3
+    pool.reset(0)
+    assert pool.group.offset(0) == 0
