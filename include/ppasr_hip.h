@@ -401,8 +401,9 @@ PPASR_API ppasr_status ppasr_fbank_create(int sample_rate, int n_mels, float fra
                                 ppasr_fbank_handle* out);
 PPASR_API ppasr_status ppasr_fbank_destroy(ppasr_fbank_handle f);
 PPASR_API int          ppasr_fbank_frames(ppasr_fbank_handle f, int n_samples);          /* snip_edges frame count */
-/* (workspace: one float per 8192-sample chunk of the mean square -- summed in numpy's order, see csrc/fbank.hip -- + the gain;
- *  never less than 8 KiB) */
+/* (workspace: one float per 8192-sample chunk of the mean square -- summed in numpy's order, see csrc/fbank.hip -- + the gain
+ *  + the gain in dB (ws[chunks], ws[chunks + 1]: the host mirror raises ValueError beyond 300 dB like audio.py:301); never less
+ *  than 8 KiB) */
 PPASR_API size_t       ppasr_fbank_workspace_bytes(ppasr_fbank_handle f, int n_samples);
 PPASR_API ppasr_status ppasr_fbank_compute(ppasr_fbank_handle f, const float* samples, int n_samples, int use_db_norm,
                                  float target_db, float* feats, void* workspace, size_t workspace_bytes, void* stream);

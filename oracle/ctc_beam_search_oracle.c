@@ -32,7 +32,12 @@ typedef struct PathTrie {
   struct PathTrie* parent;
   struct PathTrie** children;
   int n_children, cap_children;
+  int* child_slot; /* test-speed only: character -> index into children[] + 1 (0 = none), allocated once a node has more
+                    * than CHILD_INDEX_MIN children (unpruned searches give every prefix V children per frame; upstream's
+                    * linear scan over them is O(V^2) per prefix).  Same lookups, same container order. */
 } PathTrie;
+#define CHILD_INDEX_MIN 32
+static int g_vocab_size = 0; /* size of child_slot[] (set by ctc_beam_oracle_create; the tests use one V at a time) */
 
 static PathTrie* trie_new(int ch, PathTrie* parent) {
   PathTrie* t = (PathTrie*)calloc(1, sizeof(PathTrie));
@@ -46,6 +51,7 @@ static PathTrie* trie_new(int ch, PathTrie* parent) {
 static void trie_free(PathTrie* t) {
   for (int i = 0; i < t->n_children; ++i) trie_free(t->children[i]);
   free(t->children);
+  free(t->child_slot);
   free(t);
 }
 
@@ -71,7 +77,13 @@ static int dict_arc(const Dict* d, int s, int c) {
 
 /* PathTrie::get_path_trie(new_char, reset=true); dict == NULL: no dictionary */
 static PathTrie* get_path_trie(PathTrie* t, int c, const Dict* dict) {
-  for (int i = 0; i < t->n_children; ++i) {
+  int lo = 0, hi = t->n_children;
+  if (t->child_slot) { /* indexed: look at the one slot (or none) instead of all children */
+    const int s1 = t->child_slot[c];
+    lo = s1 ? s1 - 1 : 0;
+    hi = s1 ? s1 : 0;
+  }
+  for (int i = lo; i < hi; ++i) {
     PathTrie* ch = t->children[i];
     if (ch->character == c) {
       if (!ch->exists) {
@@ -98,6 +110,12 @@ static PathTrie* get_path_trie(PathTrie* t, int c, const Dict* dict) {
   PathTrie* n = trie_new(c, t);
   n->dict_state = to;
   t->children[t->n_children++] = n;
+  if (t->child_slot) {
+    t->child_slot[c] = t->n_children;
+  } else if (t->n_children > CHILD_INDEX_MIN && g_vocab_size > 0) {
+    t->child_slot = (int*)calloc(g_vocab_size, sizeof(int));
+    for (int i = 0; i < t->n_children; ++i) t->child_slot[t->children[i]->character] = i + 1;
+  }
   return n;
 }
 
@@ -131,12 +149,20 @@ static void trie_remove(PathTrie* t) {
   t->exists = 0;
   if (t->n_children == 0 && t->parent) {
     PathTrie* p = t->parent;
-    for (int i = 0; i < p->n_children; ++i)
-      if (p->children[i] == t) {
-        p->children[i] = p->children[--p->n_children];
-        break;
+    int at = -1;
+    if (p->child_slot) at = p->child_slot[t->character] - 1;
+    else
+      for (int i = 0; i < p->n_children; ++i)
+        if (p->children[i] == t) { at = i; break; }
+    if (at >= 0) { /* swap-with-last removal, as before */
+      p->children[at] = p->children[--p->n_children];
+      if (p->child_slot) {
+        p->child_slot[t->character] = 0;
+        if (at < p->n_children) p->child_slot[p->children[at]->character] = at + 1;
       }
+    }
     free(t->children);
+    free(t->child_slot);
     free(t);
     if (p->n_children == 0 && !p->exists) trie_remove(p);
   }
@@ -298,6 +324,7 @@ typedef struct {
 
 void* ctc_beam_oracle_create(int V, int beam_size, double cutoff_prob, int cutoff_top_n, int blank_id) {
   Decoder* d = (Decoder*)calloc(1, sizeof(Decoder));
+  g_vocab_size = V;
   d->V = V;
   d->beam_size = beam_size;
   d->cutoff_prob = cutoff_prob;

@@ -40,13 +40,19 @@ struct FbankTables {
 // kernel has to reproduce this order bit for bit: one ulp of the mean square moves the gain and with it one int16 sample
 // in a few thousand by one LSB (tests/test_fbank_gpu.py, the 10 s case).
 // One workgroup per chunk: heap node h (root 1) of the chunk's tree = 8 lanes (the eight running sums of a leaf).
-constexpr int kPwChunk = 8192, kPwLeaf = 128, kPwDepth = 6;  // 8192 / 128 = 2^6 leaves at most
+constexpr int kPwChunk = 8192, kPwLeaf = 128;
+// A FULL chunk is 2^6 leaves of 128.  A shorter last chunk can be one level deeper: the "rest" half keeps up to 7 extra
+// elements per split (8191 -> 4103 -> 2055 -> 1031 -> 519 -> 263 -> 135 -> 71), so 135 > 128 at depth 6 splits once more.
+// Depth 7 is the bound for every n <= 8192 (tests/test_fbank_cpu.py walks all 8192 lengths): 256 heap slots.
+constexpr int kPwDepth = 7, kPwSlots = 1 << (kPwDepth + 1);
 
 // node h of the pairwise tree over n elements: its range; false when an ancestor is already a leaf
-__device__ __forceinline__ bool pw_node(int h, int n, int& off, int& len) {
+__host__ __device__ __forceinline__ bool pw_node(int h, int n, int& off, int& len) {
   off = 0;
   len = n;
-  for (int d = 30 - __clz(h); d >= 0; --d) {
+  int top = 0;
+  while ((h >> (top + 1)) != 0) ++top;  // depth of h (root 1 = depth 0)
+  for (int d = top - 1; d >= 0; --d) {
     if (len <= kPwLeaf) return false;
     int n2 = len / 2;
     n2 -= n2 % 8;
@@ -61,45 +67,52 @@ __device__ __forceinline__ bool pw_node(int h, int n, int& off, int& len) {
 }
 
 __global__ __launch_bounds__(1024) void k_sumsq(const float* __restrict__ x, int n, float* __restrict__ chunk_sum) {
-  __shared__ float val[2 << kPwDepth];
+  __shared__ float val[kPwSlots];
+  __shared__ unsigned char inner[kPwSlots];  // 1: node with two children
   const int c0 = blockIdx.x * kPwChunk, cn = min(kPwChunk, n - c0);
   const float* a = x + c0;
-  const int h = threadIdx.x >> 3, j = threadIdx.x & 7;  // 128 heap slots x 8 lanes
-  int off = 0, len = 0;
-  const bool node = h >= 1 && pw_node(h, cn, off, len);
-  const bool leaf = node && len <= kPwLeaf;
-  float r = 0.f;
-  if (leaf && len >= 8) {
-    const int full = len - (len % 8);
-    float v = a[off + j];
-    r = __fmul_rn(v, v);
-    for (int i = 8; i < full; i += 8) {
-      v = a[off + i + j];
-      r = __fadd_rn(r, __fmul_rn(v, v));
+  const int j = threadIdx.x & 7;  // 8 lanes per heap slot; 128 slots per pass, two passes
+  for (int h = threadIdx.x >> 3; h < kPwSlots; h += 128) {
+    int off = 0, len = 0;
+    const bool node = h >= 1 && pw_node(h, cn, off, len);
+    const bool leaf = node && len <= kPwLeaf;
+    float r = 0.f;
+    if (leaf && len >= 8) {
+      const int full = len - (len % 8);
+      float v = a[off + j];
+      r = __fmul_rn(v, v);
+      for (int i = 8; i < full; i += 8) {
+        v = a[off + i + j];
+        r = __fadd_rn(r, __fmul_rn(v, v));
+      }
     }
-  }
-  // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)): a butterfly over the 8 lanes (float addition commutes)
-  r = __fadd_rn(r, __shfl_xor(r, 1));
-  r = __fadd_rn(r, __shfl_xor(r, 2));
-  r = __fadd_rn(r, __shfl_xor(r, 4));
-  if (leaf && j == 0) {
-    int i = len - (len % 8);
-    if (len < 8) {
-      r = 0.f;
-      i = 0;
+    // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)): a butterfly over the 8 lanes (float addition commutes)
+    r = __fadd_rn(r, __shfl_xor(r, 1));
+    r = __fadd_rn(r, __shfl_xor(r, 2));
+    r = __fadd_rn(r, __shfl_xor(r, 4));
+    if (j == 0) {
+      inner[h] = node && !leaf;
+      if (leaf) {
+        int i = len - (len % 8);
+        if (len < 8) {
+          r = 0.f;
+          i = 0;
+        }
+        for (; i < len; ++i) {
+          const float v = a[off + i];
+          r = __fadd_rn(r, __fmul_rn(v, v));
+        }
+        val[h] = r;
+      }
     }
-    for (; i < len; ++i) {
-      const float v = a[off + i];
-      r = __fadd_rn(r, __fmul_rn(v, v));
-    }
-    val[h] = r;
   }
   __syncthreads();
-  for (int d = kPwDepth - 1; d >= 0; --d) {
-    if (node && !leaf && j == 0 && 31 - __clz(h) == d) val[h] = __fadd_rn(val[2 * h], val[2 * h + 1]);
+  for (int d = kPwDepth - 1; d >= 0; --d) {  // inner nodes of depth d: slots [2^d, 2^(d+1))
+    const int h = (1 << d) + (int)threadIdx.x;
+    if ((int)threadIdx.x < (1 << d) && inner[h]) val[h] = __fadd_rn(val[2 * h], val[2 * h + 1]);
     __syncthreads();
   }
-  if (threadIdx.x == 8) chunk_sum[blockIdx.x] = val[1];
+  if (threadIdx.x == 0) chunk_sum[blockIdx.x] = val[1];
 }
 
 // gain of AudioSegment.normalize (audio.py:287-304, gain_db :256-264), once per call: ws[n_chunks] <- the linear gain
@@ -112,6 +125,7 @@ __global__ void k_gain(float* __restrict__ ws, int n_chunks, int n, float target
   const float ms = (float)((double)s / (double)n);
   const double rms_db = ms != 0.f ? 10.0 * (double)(float)log10((double)ms) : 0.0;
   ws[n_chunks] = (float)pow(10.0, ((double)target_db - rms_db) / 20.0);
+  ws[n_chunks + 1] = (float)((double)target_db - rms_db);  // the host raises beyond max_gain_db = 300 like audio.py:301
 }
 
 __global__ __launch_bounds__(kFT) void k_fbank(const float* __restrict__ x, int n, const float* __restrict__ gain_p,
@@ -298,9 +312,10 @@ int ppasr_fbank_frames(ppasr_fbank_handle f, int n_samples) {
 }
 
 static size_t fbank_ws_bytes(int n_samples) {
-  // one float per 8192-sample chunk of the mean square + the gain; never less than the 8 KiB earlier versions asked for
+  // one float per 8192-sample chunk of the mean square + the gain + the gain in dB; never less than the 8 KiB earlier
+  // versions asked for
   const size_t chunks = n_samples > 0 ? ((size_t)n_samples + kPwChunk - 1) / kPwChunk : 0;
-  return std::max<size_t>(8192, (chunks + 1) * sizeof(float));
+  return std::max<size_t>(8192, (chunks + 2) * sizeof(float));
 }
 
 size_t ppasr_fbank_workspace_bytes(ppasr_fbank_handle f, int n_samples) { return f ? fbank_ws_bytes(n_samples) : 0; }

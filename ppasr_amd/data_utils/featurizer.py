@@ -60,7 +60,17 @@ def db_gain(samples, target_db=-20.0):
     x = np.asarray(samples, np.float32)
     ms = np.mean(x ** 2) if x.size else np.float32(0.0)
     rms_db = 10.0 * float(np.log10(ms)) if ms != 0 else 0.0
+    check_gain_db(float(target_db) - rms_db, target_db)
     return np.float32(10.0 ** ((float(target_db) - rms_db) / 20.0))
+
+
+MAX_GAIN_DB = 300.0  # AudioSegment.normalize's max_gain_db default (data_utils/audio.py:287)
+
+
+def check_gain_db(gain, target_db):
+    """``AudioSegment.normalize`` refuses a gain beyond max_gain_db (audio.py:301-303): same exception type and text."""
+    if gain > MAX_GAIN_DB:
+        raise ValueError(f"无法将段规范化到{target_db}dB，音频增益{gain}增益已经超过max_gain_db ({MAX_GAIN_DB}dB)")
 
 
 def pcm_bytes_to_float(data, channels=1, samp_width=2):
@@ -136,6 +146,10 @@ class AudioFeaturizer:
             _lib.check(self._lib.ppasr_fbank_compute(h, x.data_ptr(), n, int(bool(self._use_db)), float(self._target_db),
                                                      feats.data_ptr(), self._ws.data_ptr(), self._ws.numel(), stream))
             torch.cuda.current_stream(self._device).synchronize()  # `x` must outlive the kernel
+        if self._use_db:  # the workspace's tail: [.. chunk sums .., gain, gain in dB] (csrc/fbank.hip k_gain)
+            chunks = (n + 8191) // 8192
+            self.last_gain, gain_db = (float(v) for v in self._ws[4 * chunks:4 * chunks + 8].view(torch.float32).cpu())
+            check_gain_db(gain_db, self._target_db)
         return feats
 
     def featurize(self, samples, sample_rate=None):

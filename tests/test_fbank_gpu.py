@@ -51,3 +51,37 @@ def test_fbank_edge_cases():
     w = _audio(1.0, seed=3, sr=8000)
     ref = fbank_oracle.featurize(w, 8000, 40, True, -20.0)
     assert np.abs(f40.featurize(w, 8000) - ref).max() < 1e-3
+
+
+def test_db_gain_bit_exact_for_every_last_chunk_length():
+    """The mean square is summed in numpy's order (pairwise tree per 8192-sample chunk).  A SHORT last chunk's tree can be
+    one level deeper than a full chunk's (8191 -> ... -> 135 -> 71: depth 7); lengths with n % 8192 in 7689..8191 used to
+    read unwritten LDS (round-5 advisor finding).  Sweep that whole range, plus a coarse sweep of the rest, with one and
+    with two preceding full chunks, against np.mean(x ** 2) through db_gain, bit for bit."""
+    from ppasr_amd.data_utils.featurizer import AudioFeaturizer, db_gain
+    f = AudioFeaturizer(n_mels=80, sample_rate=16000, use_dB_normalization=True, target_dB=-20)
+    base = _audio(1.6, seed=11)
+    assert base.size >= 3 * 8192
+    tails = list(range(7600, 8193)) + list(range(400, 7600, 97)) + [128, 129, 135, 136, 143, 144, 263, 519, 1031, 2055, 4103]
+    bad = []
+    for full in (0, 1, 2):
+        for tail in tails:
+            n = full * 8192 + tail
+            if n < 400:
+                continue
+            wav = base[:n]
+            f.featurize_device(wav)
+            if np.float32(f.last_gain).tobytes() != np.float32(db_gain(wav, -20)).tobytes():
+                bad.append(n)
+    assert not bad, bad[:20]
+
+
+def test_normalize_refuses_gain_beyond_max_gain_db():
+    """AudioSegment.normalize raises ValueError when the gain exceeds max_gain_db = 300 (data_utils/audio.py:301-303)."""
+    from ppasr_amd.data_utils.featurizer import AudioFeaturizer, db_gain
+    wav = np.full(1600, 1e-20, np.float32)  # mean square 1e-40 (denormal, non-zero): rms -400 dB, gain 380 dB
+    with pytest.raises(ValueError):
+        db_gain(wav, -20)
+    with pytest.raises(ValueError):
+        AudioFeaturizer(n_mels=80, sample_rate=16000).featurize(wav)
+    assert db_gain(np.zeros(1600, np.float32), -20) == np.float32(0.1)  # all-zero: rms_db 0 by definition (audio.py:527)
