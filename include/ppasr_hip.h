@@ -246,10 +246,14 @@ PPASR_API long long ppasr_edit_distance(const int32_t* a, int na, const int32_t*
  *   holds the beam, the prefix arena (both kept between chunk calls) and the per-frame records of the
  *   pruning pre-pass (get_pruned_log_probs of every frame of the call: T <= max total frames). */
 PPASR_API size_t ppasr_ctc_beam_state_bytes(int B, int max_frames, int beam_size);
-/* Pruned characters per frame the kernel can hold (128).  DEVIATION from upstream: a configuration that lets more
- * survive (cutoff_prob >= 1, where upstream ignores cutoff_top_n; or cutoff_top_n > 128) keeps the 128 most probable
- * characters of each frame. */
-PPASR_API int ppasr_ctc_beam_candidate_cap(void);
+/* Extra device scratch a call with this pruning configuration needs (0 for every configuration the reference ships:
+ * cutoff_prob < 1 with cutoff_top_n <= 128).  Non-zero when more than 128 characters of a frame can survive the pruning
+ * -- cutoff_prob >= 1, the default of swig_wrapper.py:38,71, where upstream ignores cutoff_top_n and keeps the WHOLE
+ * vocabulary; or cutoff_top_n > 128 -- or when beam_size x (1 + candidates) elements do not fit LDS: the per-frame pruning
+ * records and the element list of a frame then live in this scratch (T x (2 + 2 V) words + beam x (1 + V) x 5 bytes per
+ * utterance).  Pass it to ppasr_ctc_beam_search_ws; the plain entry points return PPASR_ENOSPACE for such a call.
+ * There is no cap on the candidates of a frame. */
+PPASR_API size_t ppasr_ctc_beam_scratch_bytes(int B, int T, int V, int beam_size, double cutoff_prob, int cutoff_top_n);
 /* Streaming past the sized capacity: copies the beams and prefix arenas of a state buffer into a LARGER one (sized with
  * ppasr_ctc_beam_state_bytes for more frames), which then continues the same search.  The reference's decoder object has
  * no frame limit; callers double the buffer when the next chunk would not fit.  Asynchronous on `stream`. */
@@ -301,6 +305,13 @@ PPASR_API ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_
                                       double cutoff_prob, int cutoff_top_n, int blank, int nbest, int max_tokens,
                                       int32_t* tokens, int32_t* lens, double* scores, void* state, size_t state_bytes,
                                       int init_state, ppasr_lm_handle lm, double alpha, double beta, void* stream);
+/* ... with caller-owned scratch of at least ppasr_ctc_beam_scratch_bytes(B, T, V, beam_size, cutoff_prob, cutoff_top_n)
+ * bytes (may be NULL / 0 when that is 0).  The scratch is only used during the call. */
+PPASR_API ppasr_status ppasr_ctc_beam_search_ws(const float* probs, const int32_t* frame_lens, int B, int T, int V, int beam_size,
+                                      double cutoff_prob, int cutoff_top_n, int blank, int nbest, int max_tokens,
+                                      int32_t* tokens, int32_t* lens, double* scores, void* state, size_t state_bytes,
+                                      int init_state, ppasr_lm_handle lm, double alpha, double beta, void* scratch,
+                                      size_t scratch_bytes, void* stream);
 
 /* ---- streaming: ConformerModel.get_encoder_out_chunk (model_utils/conformer/model.py:164-184) =
  * ConformerEncoder.forward_chunk (conformer/encoder.py:208-283) + ctc softmax, as driven by

@@ -97,7 +97,12 @@ SYMBOLS = [
                                           _vp]),
     ("ppasr_lm_create_arpa", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int,
                                             ctypes.POINTER(_vp)]),
-    ("ppasr_ctc_beam_candidate_cap", ctypes.c_int, []),
+    ("ppasr_ctc_beam_scratch_bytes", ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                       ctypes.c_double, ctypes.c_int]),
+    ("ppasr_ctc_beam_search_ws", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                _vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_int, _vp, ctypes.c_double,
+                                                ctypes.c_double, _vp, ctypes.c_size_t, _vp]),
     ("ppasr_ctc_beam_status", ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     ("ppasr_ctc_beam_state_grow", ctypes.c_int, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _vp]),
     ("ppasr_lm_create", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int,

@@ -1043,34 +1043,33 @@ static ppasr_status beam_config(int V, int beam_size, double cutoff_prob, int cu
   if (blank < 0 || blank >= V) return fail(PPASR_EINVAL, "beam search: blank id out of range");
   if (nbest < 1 || nbest > beam_size || max_tokens < 1) return fail(PPASR_EINVAL, "beam search: bad nbest / max_tokens");
   if (cutoff_top_n < 1) return fail(PPASR_EINVAL, "beam search: cutoff_top_n < 1");
-  // candidates per frame: pruned to cutoff_top_n only when cutoff_prob < 1 (upstream get_pruned_log_probs)
-  int n_cand = (cutoff_prob < 1.0) ? (cutoff_top_n < V ? cutoff_top_n : V) : V;
-  if (n_cand > kMaxBeamCand) {
-    // DOCUMENTED DEVIATION: the kernel holds at most 128 pruned characters per frame.  Upstream keeps every character
-    // when cutoff_prob >= 1 (its cutoff_top_n is only applied inside the cutoff_prob < 1 branch) -- the default of the
-    // Python wrappers.  Here the 128 most probable characters of the frame are kept (cut early only where their
-    // cumulative probability already reaches 1 - 1e-12) instead of refusing the call; what is dropped are characters
-    // ranked below 128 in a frame (ppasr_ctc_beam_candidate_cap() reports the cap).
-    n_cand = kMaxBeamCand;
-    cutoff_top_n = kMaxBeamCand;
-    if (cutoff_prob >= 1.0) cutoff_prob = 1.0 - 1e-12;
-  }
+  // candidates per frame: pruned to cutoff_top_n only when cutoff_prob < 1 (upstream get_pruned_log_probs); with
+  // cutoff_prob >= 1 -- the default of the reference's wrappers, swig_wrapper.py:38,71 -- upstream keeps EVERY character
+  // (sorted when cutoff_top_n < V, in vocabulary order otherwise), and so does the kernel: wide records and the element
+  // lists they produce go through HBM scratch (ppasr_ctc_beam_scratch_bytes)
+  const int n_cand = (cutoff_prob < 1.0) ? (cutoff_top_n < V ? cutoff_top_n : V) : V;
   c->V = V; c->beam = beam_size; c->blank = blank; c->cutoff_top_n = cutoff_top_n; c->cutoff_prob = cutoff_prob;
   c->n_cand_max = n_cand; c->nbest = nbest; c->max_tokens = max_tokens; c->max_nodes = 0;
-  if (beam_lds_bytes(*c) > 160 * 1024) return fail(PPASR_EUNSUPPORTED, "beam search: beam x candidates does not fit LDS");
+  c->sorted = (cutoff_prob < 1.0 || cutoff_top_n < V) ? 1 : 0;
+  {
+    const char* m = getenv("PPASR_BEAM_MARGIN");  // (tuning knob: rows of the clipped element list, ctc_beam.hip)
+    c->margin = m ? atoi(m) : 2;
+    if (c->margin < 0) c->margin = 0;
+  }
+  c->list_cap = beam_list_cap(beam_size, V, n_cand, c->lm.order > 0);
+  if (c->list_cap <= 0) return fail(PPASR_EUNSUPPORTED, "beam search: beam_size x vocabulary does not fit LDS");
   return PPASR_OK;
 }
 
 // state buffer = B x [header | beam arrays | arena of 1 + (F+1)*beam nodes | node table] | B status words | scratch of the
 // pruning pre-pass (B x F frame records of the largest record size), F = max_frames.  The layout is recomputed from
 // (state_bytes, B, beam_size) on every call, so it is the same for every chunk of a streaming decode.
-extern "C" int ppasr_ctc_beam_candidate_cap(void) { return kMaxBeamCand; }
 
 // bytes of one utterance's share of the state buffer for a capacity of F frames: state block (ctc_beam.h: header, beam
 // arrays, arena and node table for max_nodes = 1 + (F + 1) * beam nodes) + its status word + F pruning records
 static size_t beam_max_nodes(size_t F, int beam_size) { return 1 + (F + 1) * (size_t)beam_size; }
 static size_t beam_utt_bytes(size_t F, int beam_size) {
-  return 4 * beam_state_words(beam_size, (int)beam_max_nodes(F, beam_size)) + 4 + F * 4 * (size_t)prune_rec_words(kMaxBeamCand);
+  return 4 * beam_state_words(beam_size, (int)beam_max_nodes(F, beam_size)) + 4 + F * 4 * (size_t)prune_rec_words(kSmallCand);
 }
 // frame capacity a state buffer of `per_utt_bytes` per utterance was sized for (0: too small for one frame)
 static size_t beam_frame_capacity(size_t per_utt_bytes, int beam_size) {
@@ -1102,6 +1101,23 @@ ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_l
                                       double cutoff_prob, int cutoff_top_n, int blank, int nbest, int max_tokens,
                                       int32_t* tokens, int32_t* lens, double* scores, void* state, size_t state_bytes,
                                       int init_state, ppasr_lm_handle lm, double alpha, double beta, void* stream) {
+  return ppasr_ctc_beam_search_ws(probs, frame_lens, B, T, V, beam_size, cutoff_prob, cutoff_top_n, blank, nbest, max_tokens,
+                                  tokens, lens, scores, state, state_bytes, init_state, lm, alpha, beta, nullptr, 0, stream);
+}
+
+size_t ppasr_ctc_beam_scratch_bytes(int B, int T, int V, int beam_size, double cutoff_prob, int cutoff_top_n) {
+  BeamConfig c{};
+  if (B <= 0 || T < 0) return 0;
+  c.lm.order = 1;  // sized for a search WITH a scorer (its context summaries take LDS from the element list): enough for both
+  if (beam_config(V, beam_size, cutoff_prob, cutoff_top_n, 0, 1, 1, &c) != PPASR_OK) return 0;
+  return beam_scratch_bytes(c, B, T);
+}
+
+ppasr_status ppasr_ctc_beam_search_ws(const float* probs, const int32_t* frame_lens, int B, int T, int V, int beam_size,
+                                      double cutoff_prob, int cutoff_top_n, int blank, int nbest, int max_tokens,
+                                      int32_t* tokens, int32_t* lens, double* scores, void* state, size_t state_bytes,
+                                      int init_state, ppasr_lm_handle lm, double alpha, double beta, void* scratch,
+                                      size_t scratch_bytes, void* stream) {
   if (!tokens || !lens || !scores || !state || (!probs && T > 0)) return fail(PPASR_EINVAL, "null argument");
   if (B <= 0 || T < 0) return fail(PPASR_EINVAL, "empty batch");
   BeamConfig c{};
@@ -1138,7 +1154,13 @@ ppasr_status ppasr_ctc_beam_search_lm(const float* probs, const int32_t* frame_l
     HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(state) + tab_off, block_words * 4, 0, tab_bytes, (size_t)B, hs));
     }
   }
-  HIP_TRY(launch_ctc_beam(probs, frame_lens, B, T, c, prune_recs, st_words, init_state, 1, tokens, lens, scores, status, hs));
+  const size_t need_scratch = beam_scratch_bytes(c, B, T);
+  if (need_scratch > 0 && (!scratch || scratch_bytes < need_scratch))
+    return fail(PPASR_ENOSPACE, "beam search: this pruning configuration keeps more characters per frame than the LDS-resident "
+                                "search holds (cutoff_prob >= 1 keeps the whole vocabulary): call ppasr_ctc_beam_search_ws with "
+                                "ppasr_ctc_beam_scratch_bytes(...) bytes of device scratch");
+  HIP_TRY(launch_ctc_beam(probs, frame_lens, B, T, c, prune_recs, st_words, init_state, 1, tokens, lens, scores, status,
+                          need_scratch ? scratch : nullptr, hs));
   return PPASR_OK;
 }
 

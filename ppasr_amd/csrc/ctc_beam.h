@@ -7,7 +7,8 @@
 
 namespace ppasr {
 
-constexpr int kMaxBeamCand = 128;  // pruned characters per frame the kernel can hold
+constexpr int kSmallCand = 128;  // pruning records of up to this many characters per frame live in the state buffer and are
+                                 // staged in LDS; wider ones (cutoff_prob >= 1: the whole vocabulary) go through HBM scratch
 constexpr int kMaxBeam = 512;
 constexpr int kLmCtx = kLmMaxOrder - 1;       // LM context words carried per hypothesis
 constexpr int kBeamStateArrays = 7 + kLmCtx;  // per-hypothesis words persisted between streaming calls (node, char, parent,
@@ -17,12 +18,16 @@ struct BeamConfig {
   int V, beam, blank;
   int cutoff_top_n;
   double cutoff_prob;
-  int n_cand_max;  // min(kMaxBeamCand, what the pruning rule can produce)
+  int n_cand_max;  // what the pruning rule can produce: min(cutoff_top_n, V) when cutoff_prob < 1, else V
   int max_nodes;   // arena capacity per utterance
   int nbest, max_tokens;
   int node_table;  // 1: prefixes keep their node id across drop / re-creation (see the state layout below)
-  int fast_path;   // 1 (default): small beams without a scorer rank a staircase-restricted element list first (ctc_beam.hip
-                   // (e')); 0 (PPASR_BEAM_FAST=0, tests): always the general selection.  Same results bit for bit
+  int fast_path;   // 1 (default): without a scorer the rows of the element list are clipped to a verified staircase and
+                   // short lists are ranked with ballots (ctc_beam.hip k_ctc_beam); 0 (PPASR_BEAM_FAST=0, tests): always full
+                   // rows and the radix selection.  Same results bit for bit
+  int sorted;      // 1: the candidate lists are in probability order (anything but cutoff_prob >= 1 with cutoff_top_n >= V)
+  int margin;      // extra candidates per row beyond the (rank + 1) (k + 1) <= beam staircase
+  int list_cap;    // entries of the LDS element list (beam_list_cap); longer lists use the HBM scratch
   // external scorer (ctc_beam_search_decoder.cpp `ext_scorer`): lm.order == 0 -> none
   LmDev lm;
   double alpha, beta;
@@ -58,11 +63,16 @@ __host__ __device__ inline size_t beam_node_slot(uint64_t key, size_t slots) {
 // words of one frame record of the pruning pre-pass: C, p_blank, n_cand_max characters, n_cand_max log-probs
 __host__ __device__ inline int prune_rec_words(int n_cand_max) { return 2 + 2 * n_cand_max; }
 size_t beam_lds_bytes(const BeamConfig& c);
+int beam_list_cap(int beam, int V, int n_cand_max, bool has_lm);  // entries of the LDS element list (0: the fixed arrays alone do not fit)
 size_t beam_state_bytes(const BeamConfig& c);  // per utterance
-// prune_recs: device scratch of B * T * prune_rec_words(cfg.n_cand_max) words
+// HBM scratch a call needs beyond the state buffer (0 for the shipped configurations): wide pruning records
+// (n_cand_max > kSmallCand) and / or per-utterance element lists that do not fit LDS
+size_t beam_scratch_bytes(const BeamConfig& c, int B, int T);
+// prune_recs: the state buffer's record area, B * T * prune_rec_words(cfg.n_cand_max) words (narrow records); wide records
+// are written to `scratch`.  `scratch`: beam_scratch_bytes(cfg, B, T) bytes or nullptr when that is 0
 hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B, int T, const BeamConfig& cfg,
                            int32_t* prune_recs, int32_t* state, int init_state, int finalize, int32_t* out_tokens, int32_t* out_lens,
-                           double* out_scores, int32_t* status, hipStream_t st);
+                           double* out_scores, int32_t* status, void* scratch, hipStream_t st);
 
 // rebuilds the node tables of B state blocks (cleared by the caller) from their arenas: after a streaming state buffer grew
 hipError_t launch_beam_rehash(int32_t* state, int B, int beam, int max_nodes, hipStream_t st);

@@ -9,12 +9,14 @@
 // score desc, then last character asc), restated on flat arrays:
 //   * a hypothesis = (node id, last char, parent node id, log P_blank, log P_nonblank, score); the
 //     prefix strings live in a parent-pointer arena in HBM and are only walked at the end;
-//   * "does child (prefix, c) already exist in the beam" (the trie lookup) = a flag table built from
-//     each hypothesis' parent slot; every hypothesis receives at most two non-blank contributions
-//     (its own repeated character, the extension from its parent), so no floating-point atomics
-//     and the same log_sum_exp values as the serial trie walk;
-//   * top-k = exact MSD radix select on unique 64-bit keys (score | char | element id) recomputed on
-//     the fly, then an ordered compaction -- nothing of size beam x candidates is ever stored.
+//   * "does child (prefix, c) already exist in the beam" (the trie lookup) = a flag per list entry set by
+//     the hypothesis that IS that child (every hypothesis knows its parent's slot); every hypothesis
+//     receives at most two non-blank contributions (its own repeated character, the extension from its
+//     parent), so no floating-point atomics and the same log_sum_exp values as the serial trie walk;
+//   * top-k = exact MSD radix select of the 32-bit score keys of the frame's element list (ties at the cut:
+//     character, then list order), then an ordered compaction; the list holds ~ beam ln beam entries
+//     instead of beam x candidates wherever a verified bound allows it (see k_ctc_beam), and lives in HBM
+//     scratch when it outgrows LDS (unpruned searches: beam x (1 + V) entries).
 // External scorer (`ext_scorer`, character-based n-gram LM, lm.h): the min_cutoff pruning of (character, prefix) pairs,
 // alpha * log P_lm + beta on every extension, and the approximate-CTC result score with the LM weight removed.  The LM
 // term of a (hypothesis, candidate) pair is computed on the fly inside its score key (the key is inverted back to the
@@ -27,6 +29,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ctc_beam.h"
 #include "launch.h"
 
@@ -34,9 +38,7 @@ namespace ppasr {
 
 namespace {
 
-constexpr int kFastBeam = 16;   // staircase fast path: beams up to this size ...
-constexpr int kFastCap = 128;   // ... whose restricted element list fits this many entries (two per lane of a wave)
-constexpr int kFastMargin = 2;  // extra candidates per hypothesis beyond the (rank + 1) (k + 1) <= beam staircase
+constexpr int kSmallList = 128;  // element lists up to this many entries are ranked with ballots (two keys per lane of a wave)
 constexpr int kBT = 1024;  // threads per utterance: 16 waves = 4 per SIMD (a batch of 32 utterances occupies 32 CUs with one
                           // workgroup each, and every phase is a chain of dependent LDS reads: latency hidden by wave count)
 constexpr int kBW = kBT / 64;  // waves
@@ -74,6 +76,7 @@ struct Beam {  // one double-buffer half, all in LDS
   float* score;
   int* ctx;  // [cap][kLmCtx] last LM word ids, most recent last, <s>-padded
   int* dst;  // dictionary state (word-based LM: node of lm.h's character trie the prefix's current word has reached)
+  int* pslot;  // slot of the parent hypothesis in the PREVIOUS frame's beam (-1: not there); see k_ctc_beam (d)
 };
 
 __device__ __forceinline__ Beam carve_beam(char*& p, int cap) {
@@ -86,6 +89,7 @@ __device__ __forceinline__ Beam carve_beam(char*& p, int cap) {
   b.score = reinterpret_cast<float*>(p); p += cap * 4;
   b.ctx = reinterpret_cast<int*>(p); p += cap * 4 * kLmCtx;
   b.dst = reinterpret_cast<int*>(p); p += cap * 4;
+  b.pslot = reinterpret_cast<int*>(p); p += cap * 4;
   return b;
 }
 
@@ -104,6 +108,10 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
   x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1, 3
   x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2, 3
   return x;
+}
+
+__device__ __forceinline__ int mbcnt(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
 
 // block-wide exclusive scan of one int per thread (256 threads = 4 waves); returns (exclusive, total)
@@ -229,28 +237,73 @@ __device__ __forceinline__ void select_bin_reg(const int* hist, int k_rem, int& 
 
 }  // namespace
 
-size_t beam_lds_bytes(const BeamConfig& c) {
-  const int Vp = (c.V + 3) & ~3;
-  size_t n = 8 * 256 * 4 + 3 * (kBT / 64) * 4 + 32;  // per-pass histograms, scan / reduction scratch, scalars
-  n += (size_t)kMaxBeamCand * 8;                   // cand_c, cand_lp
-  n += (size_t)2 * c.beam * (28 + 4 * kLmCtx);     // two beam halves
-  n += (size_t)c.beam * 20;                        // new_b, new_nb, new_score, new_dst, k_reset
-  n += (size_t)Vp * 2;                             // kidx (int16)
-  n += (((size_t)c.beam * c.n_cand_max) + 3) & ~(size_t)3;  // exists flags
-  n = (n + 7) & ~(size_t)7;                        // (fkey: 8-byte entries)
-  n += (size_t)kFastCap * 8 + (size_t)kFastBeam * 12;  // staircase fast path: slot keys, the selected keys, rank table
-  n += (size_t)c.beam * 4;                         // surv_lp
-  n += (size_t)c.beam * (1 + c.n_cand_max) * 4;    // score keys
-  return (n + 15) & ~(size_t)15;
+// ---- LDS plan of k_ctc_beam, shared by the host (size) and the kernel (offsets) ----
+struct BeamLdsPlan {
+  uint32_t hist, wtot, red, sh, cand, beam0, beam1, newv, rows, surv, lmacc, kidx, fkey, lkey, lex, total;
+};
+constexpr int kLmAccWords = kLmMaxOrder + 1;  // lm_context_acc's summary of a hypothesis' context (lm.h)
+__host__ __device__ inline uint32_t al8(uint32_t x) { return (x + 7u) & ~7u; }
+constexpr int kBeamWords = 8 + kLmCtx;  // node, chr, par, b, nb, score, pslot, dst + LM context words: one beam half per hypothesis
+__host__ __device__ inline BeamLdsPlan beam_lds_plan(int beam, int V, int list_cap, bool has_lm) {
+  BeamLdsPlan p;
+  uint32_t o = 0;
+  p.hist = o;  o += 8 * 256 * 4;
+  p.wtot = o;  o += 4 * 16 * 4;                      // 4 scan call sites x up to 16 waves
+  p.red = o;   o += 16 * 4;
+  p.sh = o;    o += 64;                              // 16 shared ints
+  p.cand = o;  o += 2 * kSmallCand * 4;              // cand_c, cand_lp (records of <= kSmallCand candidates)
+  p.beam0 = o; o = al8(o + (uint32_t)beam * 4 * kBeamWords);
+  p.beam1 = o; o = al8(o + (uint32_t)beam * 4 * kBeamWords);
+  p.newv = o;  o = al8(o + (uint32_t)beam * 20);     // new_b, new_nb, new_score, new_dst, k_reset
+  p.rows = o;  o = al8(o + (uint32_t)beam * 12 + 4); // rank_of[beam], off[beam + 1], newpos[beam]
+  p.surv = o;  o = al8(o + (uint32_t)beam * 8);      // surv[beam], surv_lp[beam]
+  p.lmacc = o; o = al8(o + (has_lm ? (uint32_t)beam * 4 * kLmAccWords : 0u));
+  p.kidx = o;  o = al8(o + (uint32_t)((V + 3) & ~3) * 2);
+  p.fkey = o;  o += kSmallList * 8;
+  p.lkey = o;  o = al8(o + (uint32_t)list_cap * 4);
+  p.lex = o;   o = al8(o + (uint32_t)list_cap);
+  p.total = (o + 15u) & ~15u;
+  return p;
+}
+
+size_t beam_lds_bytes(const BeamConfig& c) { return beam_lds_plan(c.beam, c.V, c.list_cap, c.lm.order > 0).total; }
+
+// largest element list (entries) the LDS of one CU can hold beside the fixed arrays, capped at what a frame can need
+int beam_list_cap(int beam, int V, int n_cand_max, bool has_lm) {
+  const size_t fixed = beam_lds_plan(beam, V, 0, has_lm).total;
+  const size_t budget = 160 * 1024 - 64;  // (the hardware limit of a workgroup; small beams stay far below it)
+  if (fixed + 5 * (size_t)kSmallList > budget) return 0;
+  size_t cap = (budget - fixed) / 5;
+  cap &= ~(size_t)7;
+  const size_t need = (size_t)beam * (1 + (size_t)n_cand_max);
+  const size_t hard = 24 * 1024;  // 24 entries per thread of the largest workgroup: beyond that the list lives in HBM
+  if (cap > hard) cap = hard;
+  if (cap > need) cap = (need + 7) & ~(size_t)7;
+  return (int)cap;
 }
 
 // (state layout per utterance: ctc_beam.h)
 size_t beam_state_bytes(const BeamConfig& c) { return beam_state_words(c.beam, c.max_nodes) * 4; }
 
+// ---- HBM scratch (ctc_beam.h): [pruning records of all B x T frames, when a record does not fit the state buffer's
+// kSmallCand-wide slots] [per utterance: the element list of one frame (score keys, "child exists" flags), when
+// beam x (1 + candidates) entries do not fit the LDS list] ----
+static size_t scratch_list_bytes_per_utt(const BeamConfig& c) {
+  const size_t n = (size_t)c.beam * (1 + (size_t)c.n_cand_max);
+  if (n <= (size_t)c.list_cap) return 0;
+  return 4 * n + ((n + 15) & ~(size_t)15);
+}
+static size_t scratch_rec_bytes(const BeamConfig& c, int B, int T) {
+  return c.n_cand_max > kSmallCand ? (size_t)B * T * prune_rec_words(c.n_cand_max) * 4 : 0;
+}
+size_t beam_scratch_bytes(const BeamConfig& c, int B, int T) {
+  return ((scratch_rec_bytes(c, B, T) + 255) & ~(size_t)255) + (size_t)B * scratch_list_bytes_per_utt(c);
+}
+
 constexpr int kPruneThreads = 256;
 static size_t prune_lds_bytes(const BeamConfig& c) {
   const int Vp = (c.V + 3) & ~3;
-  return (16 + 256 * 4 + 2 * (kPruneThreads / 64) * 4 + 32 + 4 * kMaxBeamCand * 4 + (size_t)Vp * 4 + 15) & ~(size_t)15;
+  return (16 + 256 * 4 + 2 * (kPruneThreads / 64) * 4 + 32 + 4 * kSmallCand * 4 + (size_t)Vp * 4 + 15) & ~(size_t)15;
 }
 
 
@@ -259,6 +312,8 @@ static size_t prune_lds_bytes(const BeamConfig& c) {
 // chip-wide launch (one workgroup per frame) instead of inside the sequential per-utterance loop.  Record of frame
 // (u, t) in HBM (int32 words): [0] C  [1] p_blank (raw probability, float bits)  [2 .. 2+CM) characters in
 // (prob desc, index asc) order  [2+CM .. 2+2CM) their log(p + FLT_MIN).
+// This kernel: lists of at most kSmallCand (128) characters -- cutoff_prob < 1 with cutoff_top_n <= 128, the shipped
+// configurations.  Wider lists (cutoff_prob >= 1: upstream then keeps the WHOLE vocabulary) take k_ctc_prune_wide.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_ctc_prune(const float* __restrict__ probs, const int32_t* __restrict__ frame_lens,
                                                   int T, BeamConfig cfg, int32_t* __restrict__ recs) {
@@ -276,24 +331,24 @@ __global__ __launch_bounds__(NT) void k_ctc_prune(const float* __restrict__ prob
   float* red_p = reinterpret_cast<float*>(p); p += NW * 4;
   int* red_i = reinterpret_cast<int*>(p); p += NW * 4;
   int* sh_i = reinterpret_cast<int*>(p); p += 32;
-  int* tmp_c = reinterpret_cast<int*>(p); p += kMaxBeamCand * 4;
-  float* tmp_p = reinterpret_cast<float*>(p); p += kMaxBeamCand * 4;
-  int* cand_c = reinterpret_cast<int*>(p); p += kMaxBeamCand * 4;
-  float* cand_lp = reinterpret_cast<float*>(p); p += kMaxBeamCand * 4;
+  int* tmp_c = reinterpret_cast<int*>(p); p += kSmallCand * 4;
+  float* tmp_p = reinterpret_cast<float*>(p); p += kSmallCand * 4;
+  int* cand_c = reinterpret_cast<int*>(p); p += kSmallCand * 4;
+  float* cand_lp = reinterpret_cast<float*>(p); p += kSmallCand * 4;
   float* lp = reinterpret_cast<float*>(p); p += (size_t)Vp * 4;
-  const bool prune = (cfg.cutoff_prob < 1.0) || (cfg.cutoff_top_n < V);
   {
     const float* row = probs + ((size_t)u * T + t) * V;
     for (int v = tid; v < V; v += NT) lp[v] = row[v];
     __syncthreads();
     // ---- (b) get_pruned_log_probs (decoder_utils.cpp): the n_sel largest probabilities in (prob desc, index asc)
-    // order, cut where the cumulative probability reaches cutoff_prob.  Fast path: exact 4-pass radix select of the
-    // n_sel-th largest value, unordered gather, rank sort of the <= 128 survivors.  Excess ties at the threshold
-    // (more equal values than slots) fall back to the successive-maxima loop below.
+    // order, cut where the cumulative probability reaches cutoff_prob.  Exact 4-pass radix select of the n_sel-th
+    // largest value, unordered gather, rank sort of the <= 128 survivors.  Excess ties at the threshold (more equal
+    // values than slots) fall back to the successive-maxima loop below.
     int C = 0;
     bool slow_path = false;
-    const int n_sel = (cfg.cutoff_prob < 1.0) ? min(cfg.cutoff_top_n, V) : V;
-    if (prune && n_sel <= CM) {
+    const int n_sel = (cfg.cutoff_prob < 1.0) ? min(cfg.cutoff_top_n, V) : V;  // (the host sends n_sel <= CM <= kSmallCand here)
+    const bool prune = (cfg.cutoff_prob < 1.0) || (cfg.cutoff_top_n < V);
+    if (prune) {
       uint32_t thr_u = 0;
       if (n_sel < V) {
         uint32_t prefix = 0;
@@ -330,11 +385,11 @@ __global__ __launch_bounds__(NT) void k_ctc_prune(const float* __restrict__ prob
           const float pv = lp[v];
           if (__float_as_uint(pv) >= thr_u) {
             const int pos = atomicAdd(&sh_i[4], 1);
-            if (pos < kMaxBeamCand) { tmp_c[pos] = v; tmp_p[pos] = pv; }
+            if (pos < kSmallCand) { tmp_c[pos] = v; tmp_p[pos] = pv; }
           }
         }
         __syncthreads();
-        const int n_got = min(sh_i[4], kMaxBeamCand);
+        const int n_got = min(sh_i[4], kSmallCand);
         // rank sort (prob desc, index asc): 8 threads per element, each counting a slice of the list
         for (int idx = tid; idx < 8 * n_got; idx += NT) {  // (NT is a multiple of 8: the 8 parts of an element share a wave)
           const int t = idx >> 3, part = idx & 7;
@@ -374,8 +429,6 @@ __global__ __launch_bounds__(NT) void k_ctc_prune(const float* __restrict__ prob
         if (tid < C) cand_lp[tid] = (float)log((double)cand_lp[tid] + (double)FLT_MIN);
         __syncthreads();
       }
-    } else if (prune) {
-      slow_path = true;
     }
     if (slow_path) {
       C = 0;
@@ -423,7 +476,7 @@ __global__ __launch_bounds__(NT) void k_ctc_prune(const float* __restrict__ prob
         if (stop || C >= CM) break;
       }
     } else if (!prune) {
-      C = V;  // no pruning: vocabulary order (host guarantees V <= n_cand_max)
+      C = V;  // no pruning: vocabulary order (V <= kSmallCand here)
       for (int v = tid; v < V; v += NT) { cand_c[v] = v; cand_lp[v] = (float)log((double)lp[v] + (double)FLT_MIN); }
       __syncthreads();
     }
@@ -433,47 +486,139 @@ __global__ __launch_bounds__(NT) void k_ctc_prune(const float* __restrict__ prob
   }
 }
 
-#ifndef PPASR_BEAM_WAVES_PER_SIMD
-#define PPASR_BEAM_WAVES_PER_SIMD 1  // (launch-bounds hint = register budget 512 / n per lane; tuning knob)
-#endif
-template <int BT, bool WORD_LM>
-__global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(const float* __restrict__ probs, const int32_t* __restrict__ frame_lens,
+// ---- wide candidate lists: more than kSmallCand characters of a frame may survive ----
+// cutoff_prob >= 1 is the default of the reference's wrappers (swig_wrapper.py:38,71) and upstream then keeps EVERY
+// character: sorted by (prob desc, index asc) when cutoff_top_n < V (get_pruned_log_probs sorts but does not truncate),
+// in vocabulary order otherwise.  cutoff_prob < 1 with cutoff_top_n > 128: the sorted list cut at the cumulative
+// probability / at top_n.  One workgroup per frame: bitonic sort of the whole row on 64-bit (inverted probability,
+// index) keys in LDS, then the sequential double-precision cumulative cut of upstream; the record goes to HBM scratch.
+constexpr int kWideThreads = 1024;
+static int wide_pow2(int V) {
+  int n = 256;
+  while (n < V) n <<= 1;
+  return n;
+}
+static size_t prune_wide_lds_bytes(const BeamConfig& c) { return (size_t)wide_pow2(c.V) * 8 + 64; }
+__global__ __launch_bounds__(kWideThreads) void k_ctc_prune_wide(const float* __restrict__ probs,
+                                                                 const int32_t* __restrict__ frame_lens, int T, BeamConfig cfg,
+                                                                 int P2, int32_t* __restrict__ recs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int t = blockIdx.x, u = blockIdx.y;
+  const int n_frames = frame_lens ? min(max(frame_lens[u], 0), T) : T;
+  if (t >= n_frames) return;
+  const int V = cfg.V, CM = cfg.n_cand_max;
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);
+  int* sh_len = reinterpret_cast<int*>(smem + (size_t)P2 * 8);
+  const float* row = probs + ((size_t)u * T + t) * V;
+  const bool sort = (cfg.cutoff_prob < 1.0) || (cfg.cutoff_top_n < V);
+  for (int v = tid; v < P2; v += kWideThreads)
+    key[v] = v < V ? (((unsigned long long)(sort ? ~__float_as_uint(row[v]) : 0u) << 32) | (unsigned long long)(uint32_t)v) : ~0ull;
+  __syncthreads();
+  if (sort) {  // ascending on (~probability bits, index) = probability descending, index ascending (probabilities are >= 0)
+    for (int k = 2; k <= P2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < P2; i += kWideThreads) {
+          const int l = i ^ j;
+          if (l > i) {
+            const unsigned long long a = key[i], b = key[l];
+            const bool up = (i & k) == 0;
+            if ((a > b) == up) { key[i] = b; key[l] = a; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  int len = V;
+  if (cfg.cutoff_prob < 1.0) {
+    if (tid == 0) {  // upstream's loop: sequential double additions in sorted order
+      double cum = 0.0;
+      int n = 0;
+      for (int i = 0; i < V; ++i) {
+        cum += (double)__uint_as_float(~(uint32_t)(key[i] >> 32));
+        n += 1;
+        if (cum >= cfg.cutoff_prob || n >= cfg.cutoff_top_n) break;
+      }
+      *sh_len = n;
+    }
+    __syncthreads();
+    len = *sh_len;
+  }
+  if (len > CM) len = CM;  // (CM = what the rule can produce; defensive)
+  int32_t* rec = recs + ((size_t)u * T + t) * prune_rec_words(CM);
+  if (tid == 0) { rec[0] = len; rec[1] = __float_as_int(row[cfg.blank]); }
+  for (int k = tid; k < len; k += kWideThreads) {
+    const int v = (int)(uint32_t)key[k];
+    rec[2 + k] = v;
+    rec[2 + CM + k] = __float_as_int((float)log((double)row[v] + (double)FLT_MIN));
+  }
+}
+
+// ---- the search: one workgroup per utterance --------------------------------------------------------------------
+// Per frame the ELEMENTS that compete for the next beam are the nb hypotheses already in it and, per hypothesis i (a
+// ROW), its children (i, candidate k).  They form one list in element order: [0, nb) the hypotheses, then row after
+// row, k ascending; row i holds its first len(i) candidates.  The list's 32-bit score keys sit in LDS (capacity
+// cfg.list_cap entries) or, when a frame's list is longer, in the utterance's HBM scratch; the exact top-`beam` of the
+// list in prefix_compare order = (score key, character, element order) is taken by an MSD radix select (lists of up to
+// 128 entries: by ranking every key against all others with ballots), and the survivors are compacted in list order.
+//
+// FULL rows (len = C) reproduce upstream's search exactly.  CLIPPED rows: without a scorer the score of child (i, k) is
+// at most U(i, k) = lp[k] + score[i] (a repeated character uses log P_b <= score), and U falls along both axes when
+// hypotheses are ranked by score and candidates sorted by probability: a child with (rank + 1)(k + 1) > beam has `beam`
+// elements in front of it unless some of those are lowered or merged.  So row i is clipped to beam / (rank_i + 1) + margin
+// candidates (~ beam ln beam entries instead of beam x C), the top-`beam` is taken on the clipped list and VERIFIED:
+// the bound U(i, len(i)) of every clipped row must sort strictly behind the last key taken.  If not, the frame is redone
+// with full rows.  The result is therefore the full-row result bit for bit: same survivors, same order, same node ids.
+template <int BT, bool WORD_LM, bool WIDE>
+__global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ probs, const int32_t* __restrict__ frame_lens,
                                                   int T, BeamConfig cfg, const int32_t* __restrict__ recs,
                                                   int32_t* __restrict__ state, int init_state,
                                                   int finalize, int32_t* __restrict__ out_tokens,
                                                   int32_t* __restrict__ out_lens, double* __restrict__ out_scores,
-                                                  int32_t* __restrict__ status) {
+                                                  int32_t* __restrict__ status, char* __restrict__ scratch_lists,
+                                                  size_t scratch_list_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = BT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u = blockIdx.x;
   const int V = cfg.V, beam = cfg.beam, blank = cfg.blank, CM = cfg.n_cand_max;
-  const int Vp = (V + 3) & ~3;
-  char* p = smem;
-  int* hist = reinterpret_cast<int*>(p); p += 8 * 256 * 4;
-  int* wave_tot = reinterpret_cast<int*>(p); p += 2 * (BT / 64) * 4;
-  float* red_p = reinterpret_cast<float*>(p); p += (BT / 64) * 4;
-  int* sh_i = reinterpret_cast<int*>(p); p += 32;            // misc shared ints
-  int* cand_c = reinterpret_cast<int*>(p); p += kMaxBeamCand * 4;
-  float* cand_lp = reinterpret_cast<float*>(p); p += kMaxBeamCand * 4;
-  Beam cur = carve_beam(p, beam);
-  Beam nxt = carve_beam(p, beam);
-  float* new_b = reinterpret_cast<float*>(p); p += beam * 4;
-  float* new_nb = reinterpret_cast<float*>(p); p += beam * 4;
-  float* new_score = reinterpret_cast<float*>(p); p += beam * 4;
-  int* new_dst = reinterpret_cast<int*>(p); p += beam * 4;    // word-based LM: dictionary state of a surviving hypothesis
-  int* k_reset = reinterpret_cast<int*>(p); p += beam * 4;    // ... candidate whose lookup reset the state (no child), or -1
-  int16_t* kidx = reinterpret_cast<int16_t*>(p); p += (size_t)Vp * 2;
   const bool has_lm = cfg.lm.order > 0;
+  const BeamLdsPlan plan = beam_lds_plan(beam, V, cfg.list_cap, has_lm);
+  int* hist = reinterpret_cast<int*>(smem + plan.hist);
+  int* wave_tot = reinterpret_cast<int*>(smem + plan.wtot);
+  float* red_p = reinterpret_cast<float*>(smem + plan.red);
+  int* sh_i = reinterpret_cast<int*>(smem + plan.sh);
+  int* cand_c_s = reinterpret_cast<int*>(smem + plan.cand);
+  float* cand_lp_s = reinterpret_cast<float*>(smem + plan.cand) + kSmallCand;
+  char* pb = smem + plan.beam0;
+  Beam cur = carve_beam(pb, beam);
+  pb = smem + plan.beam1;
+  Beam nxt = carve_beam(pb, beam);
+  float* new_b = reinterpret_cast<float*>(smem + plan.newv);
+  float* new_nb = new_b + beam;
+  float* new_score = new_nb + beam;
+  int* new_dst = reinterpret_cast<int*>(new_score + beam);  // word-based LM: dictionary state of a surviving hypothesis
+  int* k_reset = new_dst + beam;                            // ... candidate whose lookup reset the state (no child), or -1
+  int* rank_of = reinterpret_cast<int*>(smem + plan.rows);  // score rank of a hypothesis (accumulated with atomics)
+  int* off = rank_of + beam;                                // [beam + 1] first list entry of a row (clipped frames)
+  int* newpos = off + beam + 1;                             // slot of the previous frame's hypothesis e in this frame's beam, or -1
+  int* surv = reinterpret_cast<int*>(smem + plan.surv);     // survivor codes in list order
+  float* surv_lp = reinterpret_cast<float*>(surv + beam);   // log-probability of a surviving CHILD
+  int16_t* kidx = reinterpret_cast<int16_t*>(smem + plan.kidx);
+  unsigned long long* fkey = reinterpret_cast<unsigned long long*>(smem + plan.fkey);
+  uint32_t* lkey_s = reinterpret_cast<uint32_t*>(smem + plan.lkey);
+  uint8_t* lex_s = reinterpret_cast<uint8_t*>(smem + plan.lex);
+  uint32_t* lkey_g = nullptr;
+  uint8_t* lex_g = nullptr;
+  if (scratch_lists) {
+    lkey_g = reinterpret_cast<uint32_t*>(scratch_lists + (size_t)u * scratch_list_stride);
+    lex_g = reinterpret_cast<uint8_t*>(lkey_g + (size_t)beam * (1 + (size_t)CM));
+  }
   constexpr bool word_lm = WORD_LM;  // scorer consulted at spaces, prefixes constrained by the dictionary (lm.word_based)
   const int space_id = cfg.lm.space_id;
-  uint8_t* exists = reinterpret_cast<uint8_t*>(p); p += (((size_t)beam * CM) + 3) & ~(size_t)3;
-  // staircase fast path (small beams without a scorer, see (e')): the restricted element list and its bookkeeping
-  p = smem + (((size_t)(p - smem) + 7) & ~(size_t)7);
-  unsigned long long* fkey = reinterpret_cast<unsigned long long*>(p); p += kFastCap * 8;          // keys of the list's slots
-  unsigned long long* srank_key = reinterpret_cast<unsigned long long*>(p); p += kFastBeam * 8;  // the `beam` smallest, by rank
-  int* hyp_of_rank = reinterpret_cast<int*>(p); p += kFastBeam * 4;
-  float* surv_lp = reinterpret_cast<float*>(p); p += beam * 4;  // log-probability of a surviving CHILD, by slot of the next beam
-  uint32_t* skey = reinterpret_cast<uint32_t*>(p);  // [beam * (1 + CM)] score keys of the frame's elements
+  float* lm_acc = reinterpret_cast<float*>(smem + plan.lmacc);  // [beam][kLmAccWords] context summaries (scorer only)
+  constexpr int kChildBit = 0x40000000;  // survivor code of a child: kChildBit | row << 14 | candidate (rows < 512, candidates < 16384)
 
   int32_t* st = state + (size_t)u * beam_state_words(beam, cfg.max_nodes);
   int32_t* g_arr = st + 2;
@@ -503,82 +648,84 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
       cur.dst[i] = g_arr[(6 + kLmCtx) * beam + i];
     }
   }
+  for (int i = tid; i < cfg.list_cap; i += BT) lex_s[i] = 0;  // "child exists" flags: set and cleared by their setter
+  for (int i = tid; i < beam; i += BT) { rank_of[i] = 0; newpos[i] = i; }
   __syncthreads();
+  // slot of every hypothesis' parent in the beam (-1: not there).  Inside the frame loop it is carried along: a hypothesis
+  // written in frame t records its parent's slot in frame t's numbering, translated by newpos[] at the start of frame t + 1.
+  for (int q = tid; q < nb; q += BT) {
+    const int pn = cur.par[q];
+    int pi = -1;
+    for (int i = 0; i < nb; ++i)
+      if (cur.node[i] == pn) pi = i;
+    cur.pslot[q] = pi;
+  }
 
   const int n_frames = frame_lens ? min(max(frame_lens[u], 0), T) : T;
   // kidx[] = index of a character in the frame's candidate list (-1: not a candidate): cleared once, then only the entries
   // of the previous frame's characters are reset.  A character's log-prob is cand_lp[kidx[c]] -- a V-wide table of its own
   // (17 KB of LDS at V = 4233) kept the workgroup from sharing a CU with the encoder's 133 KB row-block workgroups when
-  // the search of step i runs beside the encoder of step i + 1 (bench.py --config cfg4 / cfg5, evaluate()): the encoder's
-  // launches then had 16 .. 64 fewer CUs and ran extra rounds.
+  // the search of step i runs beside the encoder of step i + 1 (bench.py --config cfg4 / cfg5, evaluate()).
   for (int v = tid; v < V; v += BT) kidx[v] = -1;
-  auto lp_of = [&](int c) -> float {
-    const int k = kidx[c];
-    return k >= 0 ? cand_lp[k] : kNotCand;
-  };
-  // per-frame records of the pruning pre-pass (k_ctc_prune); the next frame's record is fetched into registers while
-  // the current frame is processed
+  // per-frame records of the pruning pre-pass; narrow records (<= kSmallCand candidates) are fetched one frame ahead into
+  // registers and staged in LDS, wide ones are read in place (HBM scratch, L2-resident while their frame is processed)
   const int RW = prune_rec_words(CM);
   const int32_t* rec_u = recs + (size_t)u * T * RW;
-  constexpr int KPT = (kMaxBeamCand + BT - 1) / BT;  // candidates per thread
+  constexpr int KPT = WIDE ? 1 : (kSmallCand + BT - 1) / BT;  // candidates per thread
   int pre_C = 0, pre_pb = 0, pre_c[KPT], pre_lp[KPT];
   auto fetch = [&](int t) {
     const int32_t* r = rec_u + (size_t)t * RW;
     pre_C = r[0];
     pre_pb = r[1];
+    if (!WIDE) {
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-      const int k = tid + j * BT;
-      pre_c[j] = 0;
-      pre_lp[j] = 0;
-      if (k < CM) { pre_c[j] = r[2 + k]; pre_lp[j] = r[2 + CM + k]; }
+      for (int j = 0; j < KPT; ++j) {
+        const int k = tid + j * BT;
+        pre_c[j] = 0;
+        pre_lp[j] = 0;
+        if (k < CM) { pre_c[j] = r[2 + k]; pre_lp[j] = r[2 + CM + k]; }
+      }
     }
   };
   if (n_frames > 0) fetch(0);
   __syncthreads();
 #ifdef PPASR_BEAM_TS
-  long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ts_last = wall_clock64(), ts_n = 0, ts_c = 0, ts_nb = 0, ts_att = 0, ts_ok = 0;
+  long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ts_last = wall_clock64(), ts_n = 0, ts_c = 0, ts_nb = 0, ts_att = 0, ts_ok = 0,
+            ts_small = 0, ts_hbm = 0;
 #define TS(i) do { if (tid == 0 && u == 0) { long long now = wall_clock64(); ts_acc[i] += now - ts_last; ts_last = now; } } while (0)
-#define TSN() do { ts_n += N; ts_c += C; ts_nb += nb; } while (0)
 #else
 #define TS(i)
-#define TSN()
 #endif
-  // (e') is taken by searches without an external scorer (its upper bound on a child's score needs score = acoustic only)
-  // ... whose candidate lists are sorted by probability (k_ctc_prune leaves them in index order when nothing is pruned:
-  // cutoff_prob >= 1 with cutoff_top_n >= V)
-  bool fast_ok = !has_lm && beam <= kFastBeam && BT >= 128 && cfg.fast_path != 0 &&
-                 (cfg.cutoff_prob < 1.0 || cfg.cutoff_top_n < V);
-  // the list's slots are the same in every frame: slot q < beam = existing hypothesis q, then row r (the hypothesis of score
-  // rank r) with its first K_r = beam / (r + 1) + margin candidates; slot `tid` is this thread's (my_r < 0: none)
-  int my_r = -1, my_k = 0, n_s0 = beam;
-  if (fast_ok) {
-    int off = tid - beam;
-    for (int r = 0; r < beam; ++r) {
-      const int kr = beam / (r + 1) + kFastMargin;
-      if (my_r < 0 && off >= 0 && off < kr) { my_r = r; my_k = off; }
-      off -= kr;
-      n_s0 += kr;
-    }
-    fast_ok = n_s0 <= kFastCap;
-  }
-  const int my_row_k = beam / (lane + 1) + kFastMargin;  // K_r of row r = lane (the verification's lanes)
+  // rows may be clipped when there is no scorer (the bound needs score = acoustic only) and the candidate lists are sorted
+  // by probability (k_ctc_prune* leave them in vocabulary order when nothing is pruned or sorted)
+  const bool may_clip = !has_lm && cfg.fast_path != 0 && cfg.sorted != 0;
+  const int margin = cfg.margin;
   for (int t = 0; t < n_frames; ++t) {
     // ---- (b, c) this frame's pruned characters (get_pruned_log_probs, done by the pre-pass) ----
     const int C = pre_C;
     const float p_blank = __int_as_float(pre_pb);
+    const int32_t* rec_t = rec_u + (size_t)t * RW;
+    if (WIDE) {
+      for (int k = tid; k < C; k += BT) kidx[rec_t[2 + k]] = (int16_t)k;
+    } else {
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-      const int k = tid + j * BT;
-      if (k < C) {
-        cand_c[k] = pre_c[j];
-        cand_lp[k] = __int_as_float(pre_lp[j]);
-        kidx[pre_c[j]] = (int16_t)k;
+      for (int j = 0; j < KPT; ++j) {
+        const int k = tid + j * BT;
+        if (k < C) {
+          cand_c_s[k] = pre_c[j];
+          cand_lp_s[k] = __int_as_float(pre_lp[j]);
+          kidx[pre_c[j]] = (int16_t)k;
+        }
       }
     }
+    // candidate k of the frame: character, log-probability
+    auto cand_c = [&](int k) -> int { return WIDE ? rec_t[2 + k] : cand_c_s[k]; };
+    auto cand_lp = [&](int k) -> float { return WIDE ? __int_as_float(rec_t[2 + CM + k]) : cand_lp_s[k]; };
+    auto lp_of = [&](int c) -> float {
+      const int k = kidx[c];
+      return k >= 0 ? cand_lp(k) : kNotCand;
+    };
     if (t + 1 < n_frames) fetch(t + 1);
-    for (int e = tid; e < nb * C; e += BT) exists[e] = 0;
-    if (tid == 0) sh_i[1] = 0;  // fast path: "verification failed"
     lds_barrier();
     TS(0);
     // ---- external scorer: pruning threshold of this frame and the LM term of every possible extension ----
@@ -593,37 +740,43 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
       if (lane == 0) red_p[wave] = m;
+      // the back-off side of every look-up of this frame depends on the hypothesis only (lm.h, the factorised form):
+      // summarised once per hypothesis, its order - 1 probes in flight together
+      if (tid < nb) {
+        float acc[kLmAccWords];
+        lm_context_acc(cfg.lm, &cur.ctx[tid * kLmCtx + (kLmCtx - (cfg.lm.order - 1))], acc);
+#pragma unroll
+        for (int j = 0; j < kLmAccWords; ++j) lm_acc[tid * kLmAccWords + j] = acc[j];
+      }
       lds_barrier();
       m = red_p[0];
-      for (int w = 1; w < (BT / 64); ++w) m = fminf(m, red_p[w]);
+      for (int w = 1; w < NW; ++w) m = fminf(m, red_p[w]);
       min_cutoff = (float)((double)m + log((double)p_blank) - fmax(0.0, cfg.beta));
       full_beam = (nb == beam);
     }
     auto pruned = [&](float lp_c, int q) -> bool { return full_beam && (lp_c + cur.score[q] < min_cutoff); };
     // alpha * ln P_lm(c | last order-1 words of hypothesis i): the scorer term of the extension (i, c)
-    auto lm_term = [&](int i, int c) -> float {
-      int32_t win[kLmMaxOrder];
-      const int order = cfg.lm.order;
-      for (int j = 0; j < order - 1; ++j) win[j] = cur.ctx[i * kLmCtx + (kLmCtx - (order - 1)) + j];
-      win[order - 1] = cfg.lm.tok2lm[c];
-      return (float)(lm_log_cond_prob(cfg.lm, win) * cfg.alpha);
-    };
     // word-based scorer: alpha * ln P_lm(word | last order-1 WORDS of hypothesis i), `word` = LM index of the word a space
     // has just completed (ctc_beam_search_decoder.cpp scores `prefix`, not `prefix_new`, when c == space_id)
     auto lm_term_word = [&](int i, int word) -> float {
-      int32_t win[kLmMaxOrder];
+      int32_t ctx[kLmMaxOrder];
+      float acc[kLmAccWords];
       const int order = cfg.lm.order;
-      for (int j = 0; j < order - 1; ++j) win[j] = cur.ctx[i * kLmCtx + (kLmCtx - (order - 1)) + j];
-      win[order - 1] = word;
-      return (float)(lm_log_cond_prob(cfg.lm, win) * cfg.alpha);
+#pragma unroll
+      for (int j = 0; j < kLmCtx; ++j) ctx[j] = j < order - 1 ? cur.ctx[i * kLmCtx + (kLmCtx - (order - 1)) + j] : 0;
+#pragma unroll
+      for (int j = 0; j < kLmAccWords; ++j) acc[j] = lm_acc[i * kLmAccWords + j];
+      return (float)(lm_pair_log_cond_prob(cfg.lm, ctx, acc, word) * cfg.alpha);
     };
+    auto lm_term = [&](int i, int c) -> float { return lm_term_word(i, cfg.lm.tok2lm[c]); };
     // log-probability carried by the extension of hypothesis i with candidate k (its LM term included); `to_state`:
     // dictionary state the extension lands in (word-based scorer only)
     auto ext_logp = [&](int i, int k, int to_state) -> float {
-      const int c = cand_c[k];
+      const int c = cand_c(k);
+      const float lpk = cand_lp(k);
       float log_p = kNegInf;
-      if (c == cur.chr[i]) { if (cur.b[i] > kNegInf) log_p = cand_lp[k] + cur.b[i]; }
-      else log_p = cand_lp[k] + cur.score[i];
+      if (c == cur.chr[i]) { if (cur.b[i] > kNegInf) log_p = lpk + cur.b[i]; }
+      else log_p = lpk + cur.score[i];
       if (word_lm) {
         if (c == space_id) {
           log_p += lm_term_word(i, cfg.lm.dict_word[to_state]);
@@ -636,308 +789,405 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
       return log_p;
     };
     TS(1);
-    // ---- (d) contributions received by the hypotheses already in the beam ----
+    // rows are clipped this frame if the shortest staircase row is shorter than the candidate list (block-uniform)
+    bool clip = may_clip && C > beam / nb + margin;
+    // ---- (d) contributions received by the hypotheses already in the beam (thread q < nb <= BT) ----
     const float lpb = lp_of(blank);
-    bool merged = false;
-    for (int q = tid; q < nb; q += BT) {
+    int mrg_pi = -1, mrg_k = 0;  // the child (parent slot, candidate) this hypothesis IS: it exists, no new element for it
+    if (tid < nb) {
+      const int q = tid;
       const int cq = cur.chr[q];
       float bc = (lpb != kNotCand && !pruned(lpb, q)) ? lpb + cur.score[q] : kNegInf;
       float nbc = kNegInf;
       const float lq = (cq >= 0) ? lp_of(cq) : kNotCand;
+      // the parent's slot: recorded in the previous frame's numbering, translated once (and kept for the hypothesis' copy)
+      const int raw = cur.pslot[q];
+      const int pi_t = raw >= 0 ? newpos[raw] : -1;
+      cur.pslot[q] = pi_t;
       if (lq != kNotCand && cq != blank) {
         if (!pruned(lq, q)) nbc = lq + cur.nb[q];  // repeated character
-        const int pn = cur.par[q];
-        int pi = -1;
-        for (int i = 0; i < nb; ++i)
-          if (cur.node[i] == pn) pi = i;
+        int pi = pi_t;
+        if (cfg.node_table) {  // (a revived prefix takes its old node id back: found by id, not by slot)
+          const int pn = cur.par[q];
+          for (int i = 0; i < nb; ++i)
+            if (cur.node[i] == pn) pi = i;
+        }
         if (pi >= 0) {  // extension of the parent hypothesis by cq lands on this existing prefix
           // (word-based scorer: the word a space completes is read off the PARENT's dictionary state -- this prefix's own
           //  state may already have been reset to the start state by a failed look-up, see below)
+          const int kq = kidx[cq];
           if (!pruned(lq, pi))
-            nbc = lse(nbc, ext_logp(pi, kidx[cq], (word_lm && cq == space_id) ? lm_dict_arc(cfg.lm, cur.dst[pi], cq) : 0));
-          exists[pi * C + kidx[cq]] = 1;
-          merged = true;  // (distinct (parent, character) per hypothesis: one flag each)
+            nbc = lse(nbc, ext_logp(pi, kq, (word_lm && cq == space_id) ? lm_dict_arc(cfg.lm, cur.dst[pi], cq) : 0));
+          mrg_pi = pi;
+          mrg_k = kq;
         }
       }
       new_b[q] = bc;
       new_nb[q] = nbc;
       new_score[q] = lse(bc, nbc);
     }
-    if (fast_ok && wave == 0) {  // (nb <= beam <= 16: the loop above ran in lanes of wave 0) merged children of the frame
-      const unsigned long long m = __ballot(merged);
-      if (lane == 0) sh_i[0] = __popcll(m);
-    }
-    if (fast_ok && wave == 1 && lane < nb) {  // an otherwise idle wave: rank of every hypothesis by its CURRENT score
-      const float sq = cur.score[lane];       // (rows of the staircase, see (e'))
-      int r = 0;
-      for (int i = 0; i < nb; ++i) {
-        const float si = cur.score[i];
-        r += (si > sq || (si == sq && i < lane)) ? 1 : 0;
+    if (clip) {
+      // rank of every hypothesis by its CURRENT score (the rows of the staircase): P threads per hypothesis count a slice
+      // of the others each, partial counts meet in LDS
+      const int P = max(1, min(8, BT / nb));
+      const int q = tid / P, part = tid - q * P;
+      if (q < nb) {
+        const float sq = cur.score[q];
+        int r = 0;
+        for (int i = part; i < nb; i += P) {
+          const float si = cur.score[i];
+          r += (si > sq || (si == sq && i < q)) ? 1 : 0;
+        }
+        if (r) atomicAdd(&rank_of[q], r);
       }
-      hyp_of_rank[r] = lane;
     }
     lds_barrier();
-    if (word_lm) {
-      // PathTrie::get_path_trie with a dictionary: a character that has no arc from the prefix's dictionary state yields no
-      // child -- and when that state is FINAL (a word has just ended) the lookup resets the prefix's state to the start
-      // state as a side effect.  Upstream walks the candidates in list order for every prefix, so for a prefix in a final
-      // state the FIRST candidate that is looked up (not blank, not cut by min_cutoff, not an existing child) finds
-      // nothing and resets the state; every later candidate of the frame is looked up from the start state.
-      for (int q = tid; q < nb; q += BT) {
-        int kr = -1, nd = cur.dst[q];
-        if (lm_dict_final(cfg.lm, nd)) {
-          for (int k = 0; k < C; ++k) {
-            if (cand_c[k] == blank || exists[q * C + k] || pruned(cand_lp[k], q)) continue;
-            kr = k;
-            break;
-          }
-          if (kr >= 0) {
-            nd = 0;
-            if (cur.node[q] < cfg.max_nodes) arena[kArenaWords * (size_t)cur.node[q] + 2] = 0;  // (the node's own state)
-          }
-        }
-        k_reset[q] = kr;
-        new_dst[q] = nd;
-      }
-      lds_barrier();
-    }
     TS(2);
-    // ---- (e') staircase fast path: small beams, no scorer ----
-    // Without a scorer the score of child (i, k) is at most U(i, k) = lp[k] + score[i], and U falls along both axes when
-    // the hypotheses are taken in score order (rank r) and the candidates in list order (probability descending).  A child
-    // with (r + 1)(k + 1) > beam has beam elements in front of it -- unless some of those are lowered (a repeated
-    // character uses log P_b) or merged into an existing hypothesis.  So: rank only the existing hypotheses and the children
-    // with k < K_r = beam / (r + 1) + margin (<= kFastCap slots instead of nb (1 + C) elements), each key against all others
-    // with ballots (no histograms, no scans), and VERIFY afterwards that the best excluded child of every row, bounded by
-    // U(i, K_r), is strictly below the last score taken.  If that fails -- or the list does not hold `beam` valid elements
-    // -- the frame takes the general selection below; so the result is the general one bit for bit: same survivors, same
-    // (element) order, same node ids.  (Tried and slower, tools/experiments/r05: the whole path in ONE wave without
-    // barriers -- a lone wave issues a dependent instruction every ~9 cycles: 5.4 us per frame against 4.8.)
     int k_sel = 0;
-    int* surv = nxt.par;  // temporary list in the next beam's `par` column: slot p is read, then overwritten, by thread p
-    bool fast_done = false;
-    if (fast_ok && C > 0) {
-      const int has_blank = kidx[blank] >= 0 ? 1 : 0;
-      const int n_valid_f = nb + nb * (C - has_blank) - sh_i[0];  // = n_valid of (e): existing + non-blank, non-merged children
-      if (n_valid_f > beam) {  // (block-uniform)
-#ifdef PPASR_BEAM_TS
-        ++ts_att;
-#endif
-        if (tid < n_s0) {
-          unsigned long long key = ~0ull;
-          if (tid < beam) {
-            if (tid < nb) key = make_key(new_score[tid], cur.chr[tid], tid);
-          } else if (my_r < nb && my_k < C) {
-            const int i = hyp_of_rank[my_r], k = my_k;
-            const int c = cand_c[k];
-            if (c != blank && !exists[i * C + k]) {
-              const float lpk = cand_lp[k];
-              float log_p = kNegInf;
-              if (c == cur.chr[i]) { if (cur.b[i] > kNegInf) log_p = lpk + cur.b[i]; }
-              else log_p = lpk + cur.score[i];
-              key = make_key(log_p, c, nb + i * C + k);
-            }
-          }
-          fkey[tid] = key;
-        }
-        if (tid < kFastBeam) srank_key[tid] = ~0ull;
+    for (;;) {  // (at most two rounds: clipped rows, then -- if the verification fails -- full rows)
+      int my_len = 0;
+      if (clip) {
+        if (tid < nb) my_len = min(C, beam / (rank_of[tid] + 1) + margin);
+        int total;
+        const int my_off = block_excl_scan<NW>(my_len, wave_tot, total);
+        if (tid < nb) off[tid] = my_off;
+        if (tid == 0) off[nb] = total;
         lds_barrier();
-        TS(3);
-        {  // rank of every key = number of smaller keys (keys are unique: the element id is part of them): wave w ranks the
-           // keys w, w + NW, ...  (requesting all of a wave's keys before the first is used was measured slower: the
-           //  unrolled form walks kFastCap / NW slots whatever the list holds)
-          const unsigned long long k0 = lane < n_s0 ? fkey[lane] : ~0ull, k1 = lane + 64 < n_s0 ? fkey[lane + 64] : ~0ull;
-          for (int i = wave; i < n_s0; i += BT / 64) {
-            const unsigned long long ki = fkey[i];
-            const int rank = __popcll(__ballot(k0 < ki)) + __popcll(__ballot(k1 < ki));
-            if (lane == 0 && ki != ~0ull && rank < beam) srank_key[rank] = ki;
-          }
-        }
-        lds_barrier();
-        TS(5);
-        // survivors in ELEMENT order (the order the general compaction leaves them in) + the verification
-        if (wave == 0) {  // lane = (survivor p = lane & 15, quarter g = lane >> 4 of the others it is compared with)
-          const int pidx = lane & 15, g = lane >> 4;
-          const unsigned long long kp = pidx < beam ? srank_key[pidx] : ~0ull;
-          const int ep = (int)(kp & 0x3FFFFull);  // (make_key: the element id is the low 18 bits)
-          int pos = 0;
-#pragma unroll
-          for (int j = 0; j < kFastBeam / 4; ++j) {
-            const int jj = g + 4 * j;
-            const unsigned long long kj = jj < beam ? srank_key[jj] : ~0ull;
-            pos += (kj != ~0ull && (int)(kj & 0x3FFFFull) < ep) ? 1 : 0;
-          }
-          pos += __shfl_xor(pos, 16);
-          pos += __shfl_xor(pos, 32);
-          if (lane < beam) {
-            if (kp == ~0ull) {
-              sh_i[1] = 1;  // fewer than `beam` valid elements in the list
-            } else {
-              surv[pos] = ep;
-              surv_lp[pos] = score_of_key((uint32_t)(kp >> 32));
-            }
-          }
-        } else if (wave == 1 && lane < nb) {  // (another wave: row r = lane)
-          const unsigned long long kl = srank_key[beam - 1];
-          if (my_row_k < C && kl != ~0ull) {
-            const uint32_t thr = (uint32_t)(kl >> 32);  // score key of the last element taken
-            const float ub = cand_lp[my_row_k] + cur.score[hyp_of_rank[lane]];
-            if (desc_key(ub) <= thr) sh_i[1] = 1;  // an excluded child could score >= the last one taken
-          }
-        }
-        lds_barrier();
-        if (sh_i[1] == 0) {
-          fast_done = true;
-          k_sel = beam;
-#ifdef PPASR_BEAM_TS
-          ++ts_ok;
-#endif
-        }
-        TS(6);
       }
-    }
-    if (!fast_done) {
-      // ---- (e) element space: [0,nb) existing hypotheses, nb + i*C + k = child (i, cand k).  The 32-bit score key of
-      // every element is computed ONCE into LDS (0xFFFFFFFF = not a candidate); thread t owns the contiguous range
-      // [t*per, (t+1)*per) so that the compaction below keeps element order with a single block scan ----
-      for (int i = tid; i < 8 * 256; i += BT) hist[i] = 0;  // 4 + 4 per-pass histograms of the two selects below (complete
-                                                            // behind the barrier of the scan that closes (e))
-      const int N = nb + nb * C;
-      // (an ODD range length: thread t starts at word t*per of skey[], and an even stride would put the 64 lanes of a
-      //  wave on 16 or fewer of the 64 LDS banks)
-      const int per = ((N + BT - 1) / BT) | 1;
-      const int e_lo = min(tid * per, N), e_hi = min(e_lo + per, N);
-      auto elem_char = [&](int e) -> int { return e < nb ? cur.chr[e] : cand_c[(e - nb) % C]; };
-      int my_valid = 0;
-      {
-        int e = e_lo;
-        for (; e < e_hi && e < nb; ++e) {  // hypotheses already in the beam
-          skey[e] = desc_key(new_score[e]);
-          ++my_valid;
+      const int NLc = clip ? off[nb] : nb * C;
+      const int NL = nb + NLc;
+      const bool in_lds = NL <= cfg.list_cap;
+#ifdef PPASR_BEAM_TS
+      if (clip) ++ts_att;
+      if (!in_lds) ++ts_hbm;
+      ts_n += NL; ts_c += C; ts_nb += nb;
+#endif
+      if (!in_lds && !lkey_g) {  // (the host refuses configurations that can get here without scratch; defensive)
+        if (tid == 0 && status) status[u] = 2;
+        clip = false;
+        k_sel = -1;
+        break;
+      }
+      // -------- the selection on one list; instantiated for the LDS list and for the HBM list --------
+      auto select = [&](auto* lkey, uint8_t* lex, auto lds_tag) __attribute__((always_inline)) -> bool {
+        constexpr bool kLds = decltype(lds_tag)::value;
+        auto list_barrier = [&]() { if (kLds) lds_barrier(); else __syncthreads(); };
+        auto row_off = [&](int i) -> int { return clip ? off[i] : i * C; };
+        auto row_len = [&](int i) -> int { return clip ? off[i + 1] - off[i] : C; };
+        auto row_of = [&](int s) -> int {  // row holding child entry s
+          if (!clip) return s / C;
+          int lo = 0, hi = nb - 1;  // largest i with off[i] <= s
+          while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (off[mid] <= s) lo = mid;
+            else hi = mid - 1;
+          }
+          return lo;
+        };
+        int my_flag = -1;
+        if (tid < nb && mrg_pi >= 0 && mrg_k < row_len(mrg_pi)) {
+          my_flag = row_off(mrg_pi) + mrg_k;
+          lex[my_flag] = 1;
         }
-        while (e < e_hi) {  // children: one hypothesis i at a time (its fields stay in registers), candidates k0..k1
-          const int r = e - nb, i = r / C, k0 = r - i * C;
-          const int k1 = min(C, k0 + (e_hi - e));
-          const int ci = cur.chr[i];
-          const float bi = cur.b[i], si = cur.score[i];
-          // word-based scorer: dictionary state the children of i are looked up from (after the reset above), and the one
-          // candidate that triggered the reset
-          const int di = word_lm ? new_dst[i] : 0, kri = word_lm ? k_reset[i] : -1;
-          const bool dead = word_lm && lm_dict_final(cfg.lm, di);  // still final: no candidate was looked up this frame
-          for (int k = k0; k < k1; ++k, ++e) {
-            const int c = cand_c[k];
-            const float lpk = cand_lp[k];
-            uint32_t key = 0xFFFFFFFFu;
-            if (c != blank && !exists[e - nb] && !(full_beam && (lpk + si < min_cutoff))) {
-              int to = 0;
-              bool ok = true;
-              if (word_lm) {
-                to = (dead || k == kri) ? -1 : lm_dict_arc(cfg.lm, di, c);
-                ok = to >= 0;
+        if (tid == 0) { sh_i[1] = 0; sh_i[2] = 0; sh_i[3] = 0; }  // verification failed / kept count / largest key kept
+        for (int i = tid; i < 8 * 256; i += BT) hist[i] = 0;  // 4 + 4 per-pass histograms of the two selects below
+        list_barrier();
+        if (word_lm) {
+          // PathTrie::get_path_trie with a dictionary: a character that has no arc from the prefix's dictionary state yields
+          // no child -- and when that state is FINAL (a word has just ended) the lookup resets the prefix's state to the
+          // start state as a side effect.  Upstream walks the candidates in list order for every prefix, so for a prefix in
+          // a final state the FIRST candidate that is looked up (not blank, not cut by min_cutoff, not an existing child)
+          // finds nothing and resets the state; every later candidate of the frame is looked up from the start state.
+          // (scorer present: rows are never clipped, this runs once per frame)
+          if (tid < nb) {
+            const int q = tid;
+            int kr = -1, nd = cur.dst[q];
+            if (lm_dict_final(cfg.lm, nd)) {
+              const int ro = row_off(q);
+              for (int k = 0; k < C; ++k) {
+                if (cand_c(k) == blank || lex[ro + k] || pruned(cand_lp(k), q)) continue;
+                kr = k;
+                break;
               }
-              if (ok) {
-                float log_p = kNegInf;
-                if (c == ci) { if (bi > kNegInf) log_p = lpk + bi; }
-                else log_p = lpk + si;
-                if (word_lm) {
-                  if (c == space_id) {
-                    log_p += lm_term_word(i, cfg.lm.dict_word[to]);
-                    log_p = (float)((double)log_p + cfg.beta);
-                  }
-                } else if (has_lm) {
-                  log_p += lm_term(i, c);
-                  log_p = (float)((double)log_p + cfg.beta);
-                }
-                key = desc_key(log_p);
-                ++my_valid;
+              if (kr >= 0) {
+                nd = 0;
+                if (cur.node[q] < cfg.max_nodes) arena[kArenaWords * (size_t)cur.node[q] + 2] = 0;  // (the node's own state)
               }
             }
-            skey[e] = key;
-          }
-        }
-      }
-      int n_valid;
-      (void)block_excl_scan<BT / 64>(my_valid, wave_tot, n_valid);  // (barrier inside: skey[] is complete afterwards)
-      k_sel = n_valid >= beam ? beam : n_valid;
-      TS(3); TSN();
-      // ---- (f) exact top-k_sel in prefix_compare order = ascending (score key, char, element id): MSD radix select of
-      // the k_sel-th smallest 32-bit score key over the LDS array; if the threshold class has more members than slots
-      // left (ties), a second select over (char, id) inside that class ----
-      // 4-pass radix select of the k-th smallest value of f(e) over elements with pred(e); returns the value and how
-      // many members of its class are needed (k_need) / exist (k_have)
-      auto radix_select32 = [&](auto&& value_of, int k, int* hists, uint32_t& out, int& k_need, int& k_have) {
-        uint32_t prefix = 0;
-        int k_rem = k;
-        k_have = 0;
-        for (int pass = 0; pass < 4; ++pass) {
-          const int shift = 24 - 8 * pass;
-          const uint32_t hi_mask = pass == 0 ? 0u : (~0u << (shift + 8));
-          int* h = hists + pass * 256;  // zeroed at the start of the frame; one histogram per pass = one barrier per pass
-          {
-            RunHist rh(h);
-            for (int e = tid; e < N; e += BT) {
-              uint32_t v;
-              if (value_of(e, v) && (v & hi_mask) == prefix) rh.add((int)((v >> shift) & 0xff));
-            }
-            rh.flush_wave();
+            k_reset[q] = kr;
+            new_dst[q] = nd;
           }
           lds_barrier();
-          int bin;
-          select_bin_reg(h, k_rem, bin, k_rem, k_have);
-          prefix |= (uint32_t)bin << shift;
-          if (k_have == k_rem && shift > 0) {  // the searched value is the last of its class: take the whole class
-            prefix |= (1u << shift) - 1u;
-            break;
+        }
+        // key of child (i, k) at list entry nb + s; kNoKey: not an element (blank, existing child, cut by the scorer's
+        // min_cutoff, no dictionary arc)
+        constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+        struct RowCtx { int ci; float bi, si; int di, kri; bool dead; };
+        auto load_row = [&](int i) -> RowCtx {
+          RowCtx r;
+          r.ci = cur.chr[i]; r.bi = cur.b[i]; r.si = cur.score[i];
+          // word-based scorer: dictionary state the children of i are looked up from (after the reset above), and the one
+          // candidate that triggered the reset
+          r.di = word_lm ? new_dst[i] : 0;
+          r.kri = word_lm ? k_reset[i] : -1;
+          r.dead = word_lm && lm_dict_final(cfg.lm, r.di);  // still final: no candidate was looked up this frame
+          return r;
+        };
+        auto child_key = [&](int i, const RowCtx& r, int k, int s) -> uint32_t {
+          const int c = cand_c(k);
+          const float lpk = cand_lp(k);
+          if (c == blank || lex[s] || (full_beam && (lpk + r.si < min_cutoff))) return kNoKey;
+          int to = 0;
+          if (word_lm) {
+            to = (r.dead || k == r.kri) ? -1 : lm_dict_arc(cfg.lm, r.di, c);
+            if (to < 0) return kNoKey;
+          }
+          float log_p = kNegInf;
+          if (c == r.ci) { if (r.bi > kNegInf) log_p = lpk + r.bi; }
+          else log_p = lpk + r.si;
+          if (word_lm) {
+            if (c == space_id) {
+              log_p += lm_term_word(i, cfg.lm.dict_word[to]);
+              log_p = (float)((double)log_p + cfg.beta);
+            }
+          } else if (has_lm) {
+            log_p += lm_term(i, c);
+            log_p = (float)((double)log_p + cfg.beta);
+          }
+          return desc_key(log_p);
+        };
+        bool small_done = false;
+        if (kLds && NL <= kSmallList && cfg.fast_path != 0) {
+          // ---- (e, f, g) short lists: one entry per thread, 64-bit keys (score key | character | entry) ranked against
+          // all others with ballots -- no histograms, no scans ----
+          small_done = true;
+#ifdef PPASR_BEAM_TS
+          ++ts_small;
+#endif
+          if (tid < NL) {
+            unsigned long long key = ~0ull;
+            if (tid < nb) {
+              key = make_key(new_score[tid], cur.chr[tid], tid);
+            } else {
+              const int s = tid - nb, i = row_of(s), k = s - row_off(i);
+              const RowCtx r = load_row(i);
+              const uint32_t k32 = child_key(i, r, k, s);
+              if (k32 != kNoKey) key = ((unsigned long long)k32 << 32) | ((unsigned long long)(uint32_t)(cand_c(k) + 1) << 18) | (unsigned long long)(uint32_t)tid;
+            }
+            fkey[tid] = key;
+          }
+          lds_barrier();
+          TS(3);
+          {
+            const unsigned long long k0 = lane < NL ? fkey[lane] : ~0ull, k1 = lane + 64 < NL ? fkey[lane + 64] : ~0ull;
+            for (int i = wave; i < NL; i += NW) {
+              const unsigned long long ki = fkey[i];
+              const int rank = __popcll(__ballot(k0 < ki)) + __popcll(__ballot(k1 < ki));
+              if (lane == 0) {
+                const bool kept = ki != ~0ull && rank < beam;
+                lkey[i] = kept ? 1u : 0u;
+                if (kept) atomicMax(reinterpret_cast<unsigned int*>(&sh_i[3]), (unsigned int)(ki >> 32));
+              }
+            }
+          }
+          lds_barrier();
+          TS(5);
+          if (wave == 0) {  // survivors in list order
+            const bool f0 = lane < NL && lkey[lane] != 0, f1 = lane + 64 < NL && lkey[lane + 64] != 0;
+            const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
+            auto put = [&](int e, int pos) {
+              const unsigned long long ke = fkey[e];
+              if (e < nb) {
+                surv[pos] = e;
+                surv_lp[pos] = 0.f;
+              } else {
+                const int s = e - nb, i = row_of(s), k = s - row_off(i);
+                surv[pos] = kChildBit | (i << 14) | k;
+                surv_lp[pos] = score_of_key((uint32_t)(ke >> 32));
+              }
+            };
+            if (f0) put(lane, mbcnt(m0));
+            if (f1) put(lane + 64, __popcll(m0) + mbcnt(m1));
+            const int n_kept = __popcll(m0) + __popcll(m1);
+            if (lane == 0) sh_i[2] = n_kept;
+            if (clip && lane < nb) {  // verification (clipped rows: nb <= 64): the bound of the best excluded child of row `lane`
+              const int K = row_len(lane);
+              if (K < C) {
+                const float ub = cand_lp(K) + cur.score[lane];
+                // fewer than `beam` elements in a clipped list, or a bound that reaches the last key taken: redo with full rows
+                if (n_kept < beam || desc_key(ub) <= (uint32_t)sh_i[3]) sh_i[1] = 1;
+              }
+            }
           }
         }
-        out = prefix;
-        k_need = k_rem;
-      };
-      uint32_t thr1 = 0xFFFFFFFEu, thr2 = 0xFFFFFFFFu;  // keep: key < thr1, or key == thr1 and (char, id) <= thr2
-      bool exact_class = false;                        // thr1 names one exact key value whose class is only partly taken
-      if (k_sel < n_valid) {
-        int need, have;
-        radix_select32([&](int e, uint32_t& v) { v = skey[e]; return v != 0xFFFFFFFFu; }, k_sel, hist, thr1, need, have);
-        // after an early exit thr1 is an upper bound of a wholly taken class; after 4 passes it is an exact key value
-        if (need < have) {
-          exact_class = true;
-          const uint32_t eq = thr1;
-          int n2, h2;
-          radix_select32([&](int e, uint32_t& v) {
-            if (skey[e] != eq) return false;
-            v = ((uint32_t)(elem_char(e) + 1) << 18) | (uint32_t)e;
-            return true;
-          }, need, hist + 4 * 256, thr2, n2, h2);
+        if (!small_done) {
+          // ---- (e) the 32-bit score key of every entry, computed ONCE into the list (kNoKey = not an element); thread t
+          // owns the contiguous range [t*per, (t+1)*per) so that the compaction below keeps list order with a single
+          // block scan.  (An ODD range length: thread t starts at word t*per, and an even stride would put the 64 lanes
+          // of a wave on 16 or fewer of the 64 LDS banks.) ----
+          const int per = ((NL + BT - 1) / BT) | 1;
+          const int e_lo = min(tid * per, NL), e_hi = min(e_lo + per, NL);
+          int my_valid = 0;
+          {
+            int e = e_lo;
+            for (; e < e_hi && e < nb; ++e) {  // hypotheses already in the beam
+              lkey[e] = desc_key(new_score[e]);
+              ++my_valid;
+            }
+            if (e < e_hi) {  // children: one row at a time (the hypothesis' fields stay in registers)
+              int s = e - nb, i = row_of(s);
+              while (e < e_hi) {
+                const int ro = row_off(i), k0 = s - ro;
+                const int k1 = min(row_len(i), k0 + (e_hi - e));
+                const RowCtx r = load_row(i);
+                for (int k = k0; k < k1; ++k, ++e, ++s) {
+                  const uint32_t key = child_key(i, r, k, s);
+                  my_valid += key != kNoKey ? 1 : 0;
+                  lkey[e] = key;
+                }
+                ++i;
+              }
+            }
+          }
+          int n_valid;
+          (void)block_excl_scan<NW>(my_valid, wave_tot + NW, n_valid);
+          if (!kLds) __syncthreads();  // (the scan's barrier orders LDS only: the list lives in global memory here)
+          const int ksel = n_valid >= beam ? beam : n_valid;
+          TS(3);
+          // ---- (f) exact top-ksel in prefix_compare order = ascending (score key, char, entry): MSD radix select of
+          // the ksel-th smallest 32-bit score key over the list; if the threshold class has more members than slots
+          // left (ties), further selects over the character and the entry index inside that class ----
+          // 4-pass radix select of the k-th smallest value of f(e) over elements with pred(e); returns the value and how
+          // many members of its class are needed (k_need) / exist (k_have).  `fresh`: the 4 histograms are zero (frame start)
+          auto radix_select32 = [&](auto&& value_of, int k, int* hists, bool fresh, uint32_t& out, int& k_need, int& k_have) {
+            if (!fresh) {
+              lds_barrier();
+              for (int i = tid; i < 4 * 256; i += BT) hists[i] = 0;
+              lds_barrier();
+            }
+            uint32_t prefix = 0;
+            int k_rem = k;
+            k_have = 0;
+            for (int pass = 0; pass < 4; ++pass) {
+              const int shift = 24 - 8 * pass;
+              const uint32_t hi_mask = pass == 0 ? 0u : (~0u << (shift + 8));
+              int* h = hists + pass * 256;  // one histogram per pass = one barrier per pass
+              {
+                RunHist rh(h);
+                for (int e = tid; e < NL; e += BT) {
+                  uint32_t v;
+                  if (value_of(e, v) && (v & hi_mask) == prefix) rh.add((int)((v >> shift) & 0xff));
+                }
+                rh.flush_wave();
+              }
+              lds_barrier();
+              int bin;
+              select_bin_reg(h, k_rem, bin, k_rem, k_have);
+              prefix |= (uint32_t)bin << shift;
+              if (k_have == k_rem && shift > 0) {  // the searched value is the last of its class: take the whole class
+                prefix |= (1u << shift) - 1u;
+                break;
+              }
+            }
+            out = prefix;
+            k_need = k_rem;
+          };
+          auto entry_char1 = [&](int e) -> uint32_t {  // character + 1 of a list entry
+            if (e < nb) return (uint32_t)(cur.chr[e] + 1);
+            const int s = e - nb, i = row_of(s);
+            return (uint32_t)(cand_c(s - row_off(i)) + 1);
+          };
+          // keep: key < thr1, or key == thr1 (exact_class) and (char + 1 < thr2, or char + 1 == thr2 and entry <= thr3)
+          uint32_t thr1 = 0xFFFFFFFEu, thr2 = 0xFFFFFFFFu, thr3 = 0xFFFFFFFFu;
+          bool exact_class = false, exact_char = false;
+          if (ksel < n_valid) {
+            int need, have;
+            radix_select32([&](int e, uint32_t& v) { v = lkey[e]; return v != kNoKey; }, ksel, hist, true, thr1, need, have);
+            // after an early exit thr1 is an upper bound of a wholly taken class; after 4 passes it is an exact key value
+            if (need < have) {
+              exact_class = true;
+              const uint32_t eq = thr1;
+              int n2, h2;
+              radix_select32([&](int e, uint32_t& v) {
+                if (lkey[e] != eq) return false;
+                v = entry_char1(e);
+                return true;
+              }, need, hist + 4 * 256, true, thr2, n2, h2);
+              if (n2 < h2) {  // several entries with the threshold score AND the threshold character: entry order decides
+                exact_char = true;
+                const uint32_t ceq = thr2;
+                int n3, h3;
+                radix_select32([&](int e, uint32_t& v) {
+                  if (lkey[e] != eq || entry_char1(e) != ceq) return false;
+                  v = (uint32_t)e;
+                  return true;
+                }, n2, hist, false, thr3, n3, h3);
+              }
+            }
+          }
+          TS(5);
+          auto keeps = [&](int e) -> bool {
+            const uint32_t v = lkey[e];
+            if (v == kNoKey) return false;
+            if (!exact_class) return v <= thr1;
+            if (v != thr1) return v < thr1;
+            const uint32_t c1 = entry_char1(e);
+            if (!exact_char) return c1 <= thr2;
+            if (c1 != thr2) return c1 < thr2;
+            return (uint32_t)e <= thr3;
+          };
+          // ---- (g) ordered compaction: survivors in list order (one block scan over per-thread counts) ----
+          int my_keep = 0;
+          unsigned long long keep_bits = 0;  // verdicts of the first 64 entries of this thread's range, evaluated once
+          for (int e = e_lo; e < e_hi; ++e) {
+            const bool k = keeps(e);
+            my_keep += k ? 1 : 0;
+            if (e - e_lo < 64) keep_bits |= (unsigned long long)(k ? 1 : 0) << (e - e_lo);
+          }
+          int tot_keep;
+          int wpos = block_excl_scan<NW>(my_keep, wave_tot + 2 * NW, tot_keep);
+          if (my_keep) {
+            int i = -1, ro = 0, rl = 0;  // row of the entry being visited (children are walked in order)
+            for (int e = e_lo; e < e_hi; ++e) {
+              const bool k = (e - e_lo < 64) ? (((keep_bits >> (e - e_lo)) & 1ull) != 0) : keeps(e);
+              if (!k || wpos >= beam) continue;
+              if (e < nb) {
+                surv_lp[wpos] = 0.f;
+                surv[wpos++] = e;
+              } else {
+                const int s = e - nb;
+                if (i < 0 || s >= ro + rl) { i = row_of(s); ro = row_off(i); rl = row_len(i); }
+                surv_lp[wpos] = score_of_key(lkey[e]);  // the extension's log-probability, computed once in (e)
+                surv[wpos++] = kChildBit | (i << 14) | (s - ro);
+              }
+            }
+          }
+          if (tid == 0) sh_i[2] = ksel;
+          if (clip && tid < nb) {  // verification: the bound of the best excluded child of my row
+            const int K = row_len(tid);
+            if (K < C) {
+              const float ub = cand_lp(K) + cur.score[tid];
+              if (desc_key(ub) <= thr1) sh_i[1] = 1;  // (thr1 = 0xFFFFFFFE when the list held fewer than `beam` elements)
+            }
+          }
         }
-      }
-      TS(5);
-      auto keeps = [&](int e) -> bool {
-        const uint32_t v = skey[e];
-        if (v == 0xFFFFFFFFu) return false;
-        if (!exact_class) return v <= thr1;
-        if (v != thr1) return v < thr1;
-        return (((uint32_t)(elem_char(e) + 1) << 18) | (uint32_t)e) <= thr2;
+        if (my_flag >= 0) lex[my_flag] = 0;
+        list_barrier();
+        TS(6);
+        return sh_i[1] == 0;
       };
-      // ---- (g) ordered compaction: survivors' element ids in element order (one block scan over per-thread counts), then
-      // slot p of the next beam is materialised by thread p (the survivors of one thread's range can be many) ----
-      int my_keep = 0;
-      unsigned long long keep_bits = 0;  // verdicts of the first 64 elements of this thread's range, evaluated once
-      for (int e = e_lo; e < e_hi; ++e) {
-        const bool k = keeps(e);
-        my_keep += k ? 1 : 0;
-        if (e - e_lo < 64) keep_bits |= (unsigned long long)(k ? 1 : 0) << (e - e_lo);
+      const bool ok = in_lds ? select(lkey_s, lex_s, std::true_type{}) : select(lkey_g, lex_g, std::false_type{});
+      k_sel = sh_i[2];
+      if (ok) {
+#ifdef PPASR_BEAM_TS
+        if (clip) ++ts_ok;
+#endif
+        break;
       }
-      int tot_keep;
-      int wpos = block_excl_scan<BT / 64>(my_keep, wave_tot + BT / 64, tot_keep);
-      for (int e = e_lo; e < e_hi; ++e) {
-        const bool k = (e - e_lo < 64) ? (((keep_bits >> (e - e_lo)) & 1ull) != 0) : keeps(e);
-        if (!k || wpos >= beam) continue;
-        surv_lp[wpos] = e >= nb ? score_of_key(skey[e]) : 0.f;  // the extension's log-probability, computed once in (e)
-        surv[wpos++] = e;
-      }
-      lds_barrier();
-      TS(6);
+      clip = false;  // the bound of a clipped row reaches into the selection: full rows
+      lds_barrier();  // (sh_i[1] is re-armed by the next round)
     }
+    if (k_sel < 0) break;  // no scratch for a list that needs it (status set)
     int n_nodes_next;
     // node ids of the new prefixes: looked up in the node table first (a prefix that was in the beam before keeps its
     // identity, ctc_beam.h), misses get fresh ids in slot order (one block scan) and are entered into the table
@@ -947,10 +1197,10 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
     } else {
       const int pos = tid;
       int miss = 0;
-      if (pos < k_sel && surv[pos] >= nb) {
-        const int r = surv[pos] - nb, i = r / C;
+      if (pos < k_sel && (surv[pos] & kChildBit)) {
+        const int code = surv[pos], i = (code >> 14) & 0xFFFF;
         my_parent = cur.node[i];
-        my_char = cand_c[r - i * C];
+        my_char = cand_c(code & 0x3FFF);
         const unsigned long long key = beam_node_key(my_parent, my_char);
         size_t slot = beam_node_slot(key, tslots);
         for (;;) {
@@ -962,7 +1212,7 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
         miss = my_id < 0 ? 1 : 0;
       }
       int n_miss;
-      const int before = block_excl_scan<BT / 64>(miss, wave_tot, n_miss);
+      const int before = block_excl_scan<NW>(miss, wave_tot + 3 * NW, n_miss);
       if (miss) {
         my_id = n_nodes + before;
         if (my_id < cfg.max_nodes) {
@@ -977,17 +1227,24 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
       my_char = miss;  // (re-used below: 1 = a new node, 0 = a revived one)
       n_nodes_next = n_nodes + n_miss;
     }
-    for (int pos = tid; pos < k_sel; pos += BT) {
-      const int e = surv[pos];
-      if (e < nb) {
+    // newpos[] of THIS frame was consumed in (d); it now takes the slots of the hypotheses that stay
+    if (tid < beam) { newpos[tid] = -1; rank_of[tid] = 0; }
+    lds_barrier();
+    if (tid < k_sel) {
+      const int pos = tid;
+      const int code = surv[pos];
+      if (!(code & kChildBit)) {
+        const int e = code;
         nxt.node[pos] = cur.node[e]; nxt.chr[pos] = cur.chr[e]; nxt.par[pos] = cur.par[e];
         nxt.b[pos] = new_b[e]; nxt.nb[pos] = new_nb[e]; nxt.score[pos] = new_score[e];
         for (int j = 0; j < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[e * kLmCtx + j];
         nxt.dst[pos] = word_lm ? new_dst[e] : 0;
+        nxt.pslot[pos] = cur.pslot[e];  // the parent's slot in THIS frame's beam (translated in (d))
+        newpos[e] = pos;
       } else {
-        const int r = e - nb, i = r / C, kk = r - i * C;
-        const int c = cand_c[kk];
-        const float log_p = surv_lp[pos];  // the extension's log-probability, computed once in (e) / (e')
+        const int i = (code >> 14) & 0xFFFF, kk = code & 0x3FFF;
+        const int c = cand_c(kk);
+        const float log_p = surv_lp[pos];  // the extension's log-probability, computed once in (e)
         const int id = cfg.node_table ? my_id : n_nodes + pos;  // (with the table: pos == tid)
         if (!cfg.node_table && id < cfg.max_nodes) { arena[kArenaWords * (size_t)id] = cur.node[i]; arena[kArenaWords * (size_t)id + 1] = c; }
         if (word_lm) {
@@ -1014,9 +1271,10 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
         }
         nxt.node[pos] = id; nxt.chr[pos] = c; nxt.par[pos] = cur.node[i];
         nxt.b[pos] = kNegInf; nxt.nb[pos] = log_p; nxt.score[pos] = log_p;
+        nxt.pslot[pos] = i;  // the parent's slot in THIS frame's beam
       }
     }
-    for (int k = tid; k < C; k += BT) kidx[cand_c[k]] = -1;  // reset for the next frame
+    for (int k = tid; k < C; k += BT) kidx[cand_c(k)] = -1;  // reset for the next frame
     lds_barrier();
     TS(7);
     nb = k_sel;
@@ -1032,9 +1290,11 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
   __syncthreads();
 #ifdef PPASR_BEAM_TS
   if (tid == 0 && u == 0 && n_frames > 0)
-    printf("beam ts (x10ns/frame): inst %lld lm %lld contrib %lld keys %lld sel %lld keep %lld mat %lld | N %lld C %lld nb %lld frames %d | fast path: attempted %lld taken %lld\n",
+    printf("beam ts (x10ns/frame): inst %lld lm %lld contrib+rank %lld keys %lld sel %lld keep %lld mat %lld | list %lld C %lld nb %lld frames %d | "
+           "rounds: clipped %lld verified %lld short-list %lld hbm %lld\n",
            ts_acc[0] / n_frames, ts_acc[1] / n_frames, ts_acc[2] / n_frames, ts_acc[3] / n_frames, ts_acc[5] / n_frames,
-           ts_acc[6] / n_frames, ts_acc[7] / n_frames, ts_n / n_frames, ts_c / n_frames, ts_nb / n_frames, n_frames, ts_att, ts_ok);
+           ts_acc[6] / n_frames, ts_acc[7] / n_frames, ts_n / n_frames, ts_c / n_frames, ts_nb / n_frames, n_frames, ts_att, ts_ok,
+           ts_small, ts_hbm);
 #endif
   // ---- persist the state (streaming: CtcBeamSearchDecoderBatch keeps its trie between next() calls) ----
   if (tid == 0) { st[0] = nb; st[1] = n_nodes; }
@@ -1158,6 +1418,7 @@ __global__ __launch_bounds__(BT, PPASR_BEAM_WAVES_PER_SIMD) void k_ctc_beam(cons
   }
 }
 
+
 // ---- small beams: ONE WAVE per utterance, everything in registers ------------------------------------------------
 // beam_size <= BM (16) and <= 64 pruned characters per frame (PPASR's beam 10 / top-40 evaluation setting, BASELINE
 // configs[3], [4]).  The block-wide kernel above spends its 5-6 us per frame in a dozen workgroup barriers and LDS round
@@ -1185,9 +1446,6 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
 __device__ __forceinline__ float wave_min_f32(float x) {
   for (int o = 32; o > 0; o >>= 1) x = fminf(x, __shfl_xor(x, o));
   return x;
-}
-__device__ __forceinline__ int mbcnt(unsigned long long m) {
-  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
 }  // namespace
 
@@ -1590,57 +1848,79 @@ hipError_t launch_beam_rehash(int32_t* state, int B, int beam, int max_nodes, hi
 
 hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B, int T, const BeamConfig& cfg,
                            int32_t* prune_recs, int32_t* state, int init_state, int finalize, int32_t* out_tokens,
-                           int32_t* out_lens, double* out_scores, int32_t* status, hipStream_t st) {
-  const size_t lds = beam_lds_bytes(cfg), plds = prune_lds_bytes(cfg);
-  // threads per utterance by the number of (hypothesis, candidate) elements of a frame: every phase is a chain of
+                           int32_t* out_lens, double* out_scores, int32_t* status, void* scratch, hipStream_t st) {
+  const size_t lds = beam_lds_bytes(cfg);
+  const bool wide = cfg.n_cand_max > kSmallCand;
+  // threads per utterance by the number of (hypothesis, candidate) elements a frame can have: every phase is a chain of
   // block-wide steps, and a barrier over few waves is cheaper than one over 16
-  const int n_elem = cfg.beam * (1 + cfg.n_cand_max);
-  // 512 threads up to 1 024 elements (and beams of at most 512: the new beam is materialised one slot per thread), else 1 024
-  const int sel = (n_elem <= 1024 && cfg.beam <= 512) ? 0 : 1;
+  const size_t n_elem = (size_t)cfg.beam * (1 + (size_t)cfg.n_cand_max);
+  // 512 threads up to 1 024 elements, else 1 024 (beams are at most 512: one slot of the new beam per thread either way)
+  const int sel = (n_elem <= 1024) ? 0 : 1;
   const bool wl = cfg.lm.order > 0 && cfg.lm.word_based != 0;
-  const void* fns[2][2] = {
-      {reinterpret_cast<const void*>(k_ctc_beam<512, false>), reinterpret_cast<const void*>(k_ctc_beam<1024, false>)},
-      {reinterpret_cast<const void*>(k_ctc_beam<512, true>), reinterpret_cast<const void*>(k_ctc_beam<1024, true>)}};
-  const void* fn = fns[wl ? 1 : 0][sel];
-  // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set it on every launch (a few host
-  // microseconds) rather than caching "already configured" in process-wide statics, which left a second GPU used from
-  // the same process unconfigured and was not thread-safe
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // scratch: [wide pruning records] [per-utterance element lists]
+  const size_t rec_bytes = (scratch_rec_bytes(cfg, B, T) + 255) & ~(size_t)255, list_stride = scratch_list_bytes_per_utt(cfg);
+  if ((rec_bytes || list_stride) && !scratch) return hipErrorInvalidValue;
+  int32_t* recs = wide ? static_cast<int32_t*>(scratch) : prune_recs;
+  char* lists = list_stride ? static_cast<char*>(scratch) + rec_bytes : nullptr;
+  if (list_stride) {  // "child exists" flags of the HBM lists start clear (each is set and cleared by its setter)
+    const size_t n = (size_t)cfg.beam * (1 + (size_t)cfg.n_cand_max);
+    hipError_t e = hipMemset2DAsync(lists + 4 * n, list_stride, 0, list_stride - 4 * n, (size_t)B, st);
     if (e != hipSuccess) return e;
   }
-  if (plds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_prune<kPruneThreads>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
-    if (e != hipSuccess) return e;
+  if (T > 0) {
+    if (wide) {
+      const int P2 = wide_pow2(cfg.V);
+      const size_t plds = prune_wide_lds_bytes(cfg);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_prune_wide),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+      if (e != hipSuccess) return e;
+      PPASR_LAUNCH(k_ctc_prune_wide, dim3(T, B), dim3(kWideThreads), plds, st, probs, frame_lens, T, cfg, P2, recs);
+    } else {
+      const size_t plds = prune_lds_bytes(cfg);
+      // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set it on every launch (a few host
+      // microseconds) rather than caching "already configured" in process-wide statics, which left a second GPU used
+      // from the same process unconfigured and was not thread-safe
+      if (plds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_prune<kPruneThreads>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+        if (e != hipSuccess) return e;
+      }
+      PPASR_LAUNCH(k_ctc_prune<kPruneThreads>, dim3(T, B), dim3(kPruneThreads), plds, st, probs, frame_lens, T, cfg, recs);
+    }
   }
-  if (T > 0)
-    PPASR_LAUNCH(k_ctc_prune<kPruneThreads>, dim3(T, B), dim3(kPruneThreads), plds, st, probs, frame_lens, T, cfg,
-                       prune_recs);
-  // small beams: one wave per utterance.  OPT-IN for now (PPASR_BEAM_WAVE=1): measured 11 us per frame at beam 10 against
+  // small beams: one wave per utterance.  OPT-IN (PPASR_BEAM_WAVE=1): measured 11 us per frame at beam 10 against
   // 5.4 us for the block-wide kernel (a lone wave issues its readlane / ballot / branch sequences at ~9 cycles per
   // instruction); kept because it needs no LDS tables and co-resides with the encoder's workgroups.
   const char* wave_env = getenv("PPASR_BEAM_WAVE");
   if (cfg.beam <= kWaveBeamMax && cfg.n_cand_max <= 64 && wave_env && atoi(wave_env) == 1 && !cfg.lm.word_based) {
     if (cfg.lm.order > 0)
-      PPASR_LAUNCH((k_ctc_beam_wave<kWaveBeamMax, true>), dim3(B), dim3(64), 0, st, frame_lens, T, cfg, prune_recs, state,
+      PPASR_LAUNCH((k_ctc_beam_wave<kWaveBeamMax, true>), dim3(B), dim3(64), 0, st, frame_lens, T, cfg, recs, state,
                    init_state, finalize, out_tokens, out_lens, out_scores, status);
     else
-      PPASR_LAUNCH((k_ctc_beam_wave<kWaveBeamMax, false>), dim3(B), dim3(64), 0, st, frame_lens, T, cfg, prune_recs, state,
+      PPASR_LAUNCH((k_ctc_beam_wave<kWaveBeamMax, false>), dim3(B), dim3(64), 0, st, frame_lens, T, cfg, recs, state,
                    init_state, finalize, out_tokens, out_lens, out_scores, status);
     return hipGetLastError();
   }
-#define PPASR_LAUNCH_BEAM(BT)                                                                                          \
-  do {                                                                                                                 \
-    if (wl)                                                                                                            \
-      PPASR_LAUNCH((k_ctc_beam<BT, true>), dim3(B), dim3(BT), lds, st, probs, frame_lens, T, cfg, prune_recs, state,   \
-                   init_state, finalize, out_tokens, out_lens, out_scores, status);                                    \
-    else                                                                                                               \
-      PPASR_LAUNCH((k_ctc_beam<BT, false>), dim3(B), dim3(BT), lds, st, probs, frame_lens, T, cfg, prune_recs, state,  \
-                   init_state, finalize, out_tokens, out_lens, out_scores, status);                                    \
+#define PPASR_LAUNCH_BEAM(BT, WL, WIDE)                                                                                 \
+  do {                                                                                                                  \
+    const void* fn = reinterpret_cast<const void*>(k_ctc_beam<BT, WL, WIDE>);                                           \
+    if (lds > 48 * 1024) {                                                                                              \
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+      if (e != hipSuccess) return e;                                                                                    \
+    }                                                                                                                   \
+    PPASR_LAUNCH((k_ctc_beam<BT, WL, WIDE>), dim3(B), dim3(BT), lds, st, probs, frame_lens, T, cfg, recs, state,        \
+                 init_state, finalize, out_tokens, out_lens, out_scores, status, lists, list_stride);                   \
   } while (0)
-  if (sel == 0) PPASR_LAUNCH_BEAM(512);
-  else PPASR_LAUNCH_BEAM(1024);
+  if (wide) {  // (wide records: always 1 024 threads)
+    if (wl) PPASR_LAUNCH_BEAM(1024, true, true);
+    else PPASR_LAUNCH_BEAM(1024, false, true);
+  } else if (sel == 0) {
+    if (wl) PPASR_LAUNCH_BEAM(512, true, false);
+    else PPASR_LAUNCH_BEAM(512, false, false);
+  } else {
+    if (wl) PPASR_LAUNCH_BEAM(1024, true, false);
+    else PPASR_LAUNCH_BEAM(1024, false, false);
+  }
 #undef PPASR_LAUNCH_BEAM
   return hipGetLastError();
 }

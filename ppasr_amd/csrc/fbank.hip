@@ -67,6 +67,11 @@ __host__ __device__ __forceinline__ bool pw_node(int h, int n, int& off, int& le
 }
 
 __global__ __launch_bounds__(1024) void k_sumsq(const float* __restrict__ x, int n, float* __restrict__ chunk_sum) {
+  // numpy rounds every square before it is added (x ** 2 is an array of its own): no fused multiply-add here.  hipcc
+  // contracts a * b + c -- also when written __fadd_rn(c, __fmul_rn(a, b)): the header's operations carry the contract
+  // flag -- into v_fma_f32 under its default -ffp-contract=fast (found in round 6: one ulp of the sum for ~1 length in
+  // 3), so this function uses plain operators with contraction switched off.
+#pragma clang fp contract(off)
   __shared__ float val[kPwSlots];
   __shared__ unsigned char inner[kPwSlots];  // 1: node with two children
   const int c0 = blockIdx.x * kPwChunk, cn = min(kPwChunk, n - c0);
@@ -80,16 +85,16 @@ __global__ __launch_bounds__(1024) void k_sumsq(const float* __restrict__ x, int
     if (leaf && len >= 8) {
       const int full = len - (len % 8);
       float v = a[off + j];
-      r = __fmul_rn(v, v);
+      r = v * v;
       for (int i = 8; i < full; i += 8) {
         v = a[off + i + j];
-        r = __fadd_rn(r, __fmul_rn(v, v));
+        r = r + v * v;
       }
     }
     // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)): a butterfly over the 8 lanes (float addition commutes)
-    r = __fadd_rn(r, __shfl_xor(r, 1));
-    r = __fadd_rn(r, __shfl_xor(r, 2));
-    r = __fadd_rn(r, __shfl_xor(r, 4));
+    r = r + __shfl_xor(r, 1);
+    r = r + __shfl_xor(r, 2);
+    r = r + __shfl_xor(r, 4);
     if (j == 0) {
       inner[h] = node && !leaf;
       if (leaf) {
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(1024) void k_sumsq(const float* __restrict__ x, int
         }
         for (; i < len; ++i) {
           const float v = a[off + i];
-          r = __fadd_rn(r, __fmul_rn(v, v));
+          r = r + v * v;
         }
         val[h] = r;
       }
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(1024) void k_sumsq(const float* __restrict__ x, int
   __syncthreads();
   for (int d = kPwDepth - 1; d >= 0; --d) {  // inner nodes of depth d: slots [2^d, 2^(d+1))
     const int h = (1 << d) + (int)threadIdx.x;
-    if ((int)threadIdx.x < (1 << d) && inner[h]) val[h] = __fadd_rn(val[2 * h], val[2 * h + 1]);
+    if ((int)threadIdx.x < (1 << d) && inner[h]) val[h] = val[2 * h] + val[2 * h + 1];
     __syncthreads();
   }
   if (threadIdx.x == 0) chunk_sum[blockIdx.x] = val[1];

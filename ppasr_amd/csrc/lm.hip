@@ -7,6 +7,7 @@
 // (upstream: an OpenFST acceptor built by Scorer::fill_dictionary; here the same language as a character trie, lm.h).
 // This file reads the ARPA text format; KenLM's binary formats (.klm) are read by klm.hip.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -203,21 +204,24 @@ std::string lm_bind_vocabulary(ppasr_lm_s& lm, const std::unordered_map<std::str
 
 std::string lm_build_table(ppasr_lm_s& lm, const std::vector<LmEntry>& entries) {
   size_t cap = 16;
-  while (cap < 2 * entries.size()) cap <<= 1;
-  lm.keys.assign(cap, 0);
-  lm.prob.assign(cap, 0.f);
-  lm.backoff.assign(cap, 0.f);
+  while (cap < 3 * entries.size()) cap <<= 1;  // load factor <= 1/3: lm_probe_many reads two adjacent slots per key
+  lm.slots.assign(cap + 1, LmSlot{0, 0.f, 0.f});
   for (const LmEntry& e : entries) {
-    size_t slot = (size_t)(e.key >> 17) & (cap - 1);
-    while (lm.keys[slot] != 0) {
-      if (lm.keys[slot] == e.key) return "lm: duplicate n-gram (or a 64-bit hash collision) in the model";
+    size_t slot = (size_t)lm_slot_of(e.key, (uint32_t)(cap - 1));
+    while (lm.slots[slot].key != 0) {
+      if (lm.slots[slot].key == e.key) return "lm: duplicate n-gram (or a 64-bit hash collision) in the model";
       slot = (slot + 1) & (cap - 1);
     }
-    lm.keys[slot] = e.key;
-    lm.prob[slot] = e.prob;
-    lm.backoff[slot] = e.backoff;
+    lm.slots[slot] = LmSlot{e.key, e.prob, e.backoff};
   }
+  lm.slots[cap] = lm.slots[0];  // (slot + 1 of the last slot)
   lm.n_grams = entries.size();
+  // unigram table: the level every look-up ends at, indexed by the LM word (the candidate side of the factorised form)
+  lm.uni_prob.assign((size_t)(lm.n_words > 0 ? lm.n_words : 1), std::nanf(""));
+  for (int32_t w = 0; w < lm.n_words; ++w) {
+    float p, b;
+    if (lm_find_key(lm.slots.data(), (uint32_t)(cap - 1), lm_key_any(lm.kenlm_keys ? 1 : 0, &w, 1), p, b)) lm.uni_prob[w] = p;
+  }
   return "";
 }
 
@@ -232,18 +236,17 @@ ppasr_status lm_upload(ppasr_lm_s& lm) {
   };
   const void* p = nullptr;
   ppasr_status s;
-  if ((s = up(lm.keys.data(), lm.keys.size() * 8, &p)) != PPASR_OK) return s;
-  lm.dev.keys = static_cast<const uint64_t*>(p);
-  if ((s = up(lm.prob.data(), lm.prob.size() * 4, &p)) != PPASR_OK) return s;
-  lm.dev.prob = static_cast<const float*>(p);
-  if ((s = up(lm.backoff.data(), lm.backoff.size() * 4, &p)) != PPASR_OK) return s;
-  lm.dev.backoff = static_cast<const float*>(p);
+  if ((s = up(lm.slots.data(), lm.slots.size() * sizeof(LmSlot), &p)) != PPASR_OK) return s;
+  lm.dev.slots = static_cast<const LmSlot*>(p);
+  if ((s = up(lm.uni_prob.data(), lm.uni_prob.size() * 4, &p)) != PPASR_OK) return s;
+  lm.dev.uni_prob = static_cast<const float*>(p);
+  lm.dev.n_words = lm.n_words;
   if ((s = up(lm.tok2lm.data(), lm.tok2lm.size() * 4, &p)) != PPASR_OK) return s;
   lm.dev.tok2lm = static_cast<const int32_t*>(p);
   lm.dev.order = lm.order;
   lm.dev.bos = lm.bos;
   lm.dev.eos = lm.eos;
-  lm.dev.mask = (uint32_t)(lm.keys.size() - 1);
+  lm.dev.mask = (uint32_t)(lm.slots.size() - 2);
   lm.dev.kenlm_keys = lm.kenlm_keys ? 1 : 0;
   lm.dev.word_based = lm.character_based ? 0 : 1;
   lm.dev.space_id = lm.space_id;
@@ -300,20 +303,9 @@ ppasr_status ppasr_lm_debug_load_host(const char* model_path, const char* const*
 double ppasr_lm_debug_host_score(ppasr_lm_handle lm, const int32_t* win) {
   if (!lm || !win) return 0.0;
   const int order = lm->order;
-  const uint32_t mask = (uint32_t)(lm->keys.size() - 1);
+  const uint32_t mask = (uint32_t)(lm->slots.size() - 2);
   auto find = [&](const int32_t* w, int n, float& p, float& b) {
-    const uint64_t key = lm_key_any(lm->kenlm_keys ? 1 : 0, w, n);
-    uint32_t slot = (uint32_t)(key >> 17) & mask;
-    for (;;) {
-      const uint64_t k = lm->keys[slot];
-      if (k == key) {
-        p = lm->prob[slot];
-        b = lm->backoff[slot];
-        return true;
-      }
-      if (k == 0) return false;
-      slot = (slot + 1) & mask;
-    }
+    return lm_find_key(lm->slots.data(), mask, lm_key_any(lm->kenlm_keys ? 1 : 0, w, n), p, b);
   };
   for (int i = 0; i < order; ++i)
     if (win[i] == 0) return kLmOovScore;

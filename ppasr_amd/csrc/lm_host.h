@@ -19,8 +19,8 @@ struct ppasr_lm_s {
   size_t n_grams = 0;
   std::string format;  // "arpa", "klm-probing", "klm-trie", ...
   // host copy of the table (what `dev` points at on the device)
-  std::vector<uint64_t> keys;
-  std::vector<float> prob, backoff;
+  std::vector<ppasr::LmSlot> slots;  // power-of-two slots + one wrap-around copy of slot 0
+  std::vector<float> uni_prob;       // [n_words] log10 P of every unigram (NaN: absent)
   std::vector<int32_t> tok2lm;
   int bos = 0, eos = 0;
   // word-based models: the dictionary (lm.h) and the acoustic token of the space

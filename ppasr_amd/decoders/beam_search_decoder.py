@@ -107,23 +107,21 @@ class _BeamState:
         self.buf, self.bytes, self.max_frames = new, nbytes, cap
 
 
-_cap_warned = False
+_scratch = {}  # (device, stream) -> uint8 tensor: HBM scratch of searches whose candidate / element lists outgrow LDS
 
 
-def _warn_candidate_cap(lib, V, cutoff_prob, cutoff_top_n):
-    """DOCUMENTED DEVIATION made visible: the kernels keep at most 128 pruned characters per frame.  Upstream keeps the
-    whole vocabulary when cutoff_prob >= 1 (the swig wrappers' default, swig_wrapper.py:40) -- warn once instead of
-    differing silently."""
-    global _cap_warned
-    cap = int(lib.ppasr_ctc_beam_candidate_cap())
-    n_cand = min(int(cutoff_top_n), V) if cutoff_prob < 1.0 else V
-    if n_cand > cap and not _cap_warned:
-        _cap_warned = True
-        import warnings
-        warnings.warn(f"ctc beam search: cutoff_prob={cutoff_prob}, cutoff_top_n={cutoff_top_n}, V={V} lets {n_cand} characters "
-                      f"per frame survive pruning; the HIP decoder keeps the {cap} most probable ones (upstream "
-                      "paddlespeech_ctcdecoders would keep all of them). Use cutoff_prob < 1 with cutoff_top_n <= "
-                      f"{cap} for upstream-identical pruning.", RuntimeWarning, stacklevel=3)
+def _scratch_for(lib, dev, stream, B, T, V, beam_size, cutoff_prob, cutoff_top_n):
+    """Scratch of ``ppasr_ctc_beam_scratch_bytes`` (0 bytes -> None for every configuration the reference ships).  With
+    ``cutoff_prob >= 1`` -- the default of the reference's wrappers, swig_wrapper.py:38,71 -- upstream keeps every
+    character of every frame; so does the kernel, through this buffer (kept and re-used per device, grown on demand)."""
+    need = int(lib.ppasr_ctc_beam_scratch_bytes(B, T, V, int(beam_size), float(cutoff_prob), int(cutoff_top_n)))
+    if need == 0:
+        return None, 0
+    key = (dev, stream)  # (searches on different streams may overlap: one buffer each)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _scratch[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    return buf, need
 
 
 def beam_search_ids(probs, beam_size, cutoff_prob=1.0, cutoff_top_n=40, blank_id=0, frame_lens=None, nbest=1,
@@ -133,7 +131,6 @@ def beam_search_ids(probs, beam_size, cutoff_prob=1.0, cutoff_top_n=40, blank_id
     lib = _lib.load()
     if not torch.cuda.is_available():
         raise _lib.PPASRHipError("no HIP device visible: ppasr_amd has no CPU fallback")
-    _warn_candidate_cap(lib, probs.shape[-1], cutoff_prob, cutoff_top_n)
     dev = probs.device if isinstance(probs, torch.Tensor) and probs.is_cuda else torch.device(
         "cuda", torch.cuda.current_device())
     p = torch.as_tensor(probs, dtype=torch.float32).to(dev).contiguous()
@@ -151,13 +148,15 @@ def beam_search_ids(probs, beam_size, cutoff_prob=1.0, cutoff_top_n=40, blank_id
     fl = None if frame_lens is None else torch.as_tensor(frame_lens, dtype=torch.int32).to(dev).contiguous()
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(lib.ppasr_ctc_beam_search_lm(p.data_ptr() if T > 0 else None, None if fl is None else fl.data_ptr(),
+        scratch, scratch_bytes = _scratch_for(lib, dev, stream, B, T, V, beam_size, cutoff_prob, cutoff_top_n)
+        _lib.check(lib.ppasr_ctc_beam_search_ws(p.data_ptr() if T > 0 else None, None if fl is None else fl.data_ptr(),
                                                 B, T, V, int(beam_size), float(cutoff_prob), int(cutoff_top_n),
                                                 int(blank_id), int(nbest), L, tokens.data_ptr(), lens.data_ptr(),
                                                 scores.data_ptr(), state.buf.data_ptr(), state.bytes,
                                                 1 if state.fresh else 0, None if ext_scorer is None else ext_scorer._h,
                                                 0.0 if ext_scorer is None else ext_scorer.alpha,
-                                                0.0 if ext_scorer is None else ext_scorer.beta, stream))
+                                                0.0 if ext_scorer is None else ext_scorer.beta,
+                                                None if scratch is None else scratch.data_ptr(), scratch_bytes, stream))
     state.fresh = False
     state.frames += T
     return tokens, lens, scores, state

@@ -143,27 +143,39 @@ def test_frame_lens_and_batch_api():
         assert texts[b] == "".join(vocab[i] for i in ref[0][0])
 
 
-def test_unpruned_configuration_is_capped_at_128_characters_per_frame():
-    """cutoff_prob = 1.0 (the default of the Python wrappers): upstream then ignores cutoff_top_n and keeps all V
-    characters of every frame; the kernel holds 128 -- the documented deviation keeps the 128 most probable ones (cut
-    only where their cumulative probability already reaches 1 - 1e-12) instead of refusing the call.  Equals the oracle
-    run with that pruning rule; with the peaky tables below the dropped tail cannot change the best hypothesis, so it
-    also equals the oracle's genuinely unpruned decode."""
+def test_unpruned_configuration_keeps_every_character():
+    """cutoff_prob = 1.0 (the default of the Python wrappers, swig_wrapper.py:38,71): upstream then ignores cutoff_top_n and
+    keeps all V characters of every frame -- so does the kernel (wide pruning records and, where beam x (1 + V) entries do
+    not fit LDS, the element list in HBM scratch).  Equal to the oracle's genuinely unpruned decode; the plain C entry point
+    without scratch refuses the call instead of truncating it."""
+    import ctypes as C
     from ppasr_amd import _lib
     from ppasr_amd.decoders.beam_search_decoder import beam_search_ids
     lib = _oracle()
-    assert _lib.load().ppasr_ctc_beam_candidate_cap() == 128
+    hl = _lib.load()
+    assert not hasattr(hl, "ppasr_ctc_beam_candidate_cap")
     rng = np.random.Generator(np.random.PCG64(4242))
     T, V, beam = 40, 4233, 10
-    batch = np.stack([_probs(rng, T, V, "peaky") for _ in range(2)])
-    tokens, lens, scores, _ = beam_search_ids(torch.from_numpy(batch).cuda(), beam, 1.0, 40, 0, nbest=1)
+    assert hl.ppasr_ctc_beam_scratch_bytes(2, T, V, beam, 0.99, 40) == 0
+    assert hl.ppasr_ctc_beam_scratch_bytes(2, T, V, beam, 1.0, 40) >= 2 * T * (2 + 2 * V) * 4
+    batch = np.stack([_probs(rng, T, V, kind) for kind in ("peaky", "flat")])
+    dev = torch.from_numpy(batch).cuda()
+    tokens, lens, scores, _ = beam_search_ids(dev, beam, 1.0, 40, 0, nbest=1)
     torch.cuda.synchronize()
     for b in range(2):
         got = tokens[b, 0, :int(lens[b, 0])].cpu().tolist()
-        capped = _oracle_decode(lib, batch[b], beam, 1.0 - 1e-12, 128, 0, 1)
         unpruned = _oracle_decode(lib, batch[b], beam, 1.0, 40, 0, 1)
-        assert got == capped[0][0] == unpruned[0][0]
-        assert abs(float(scores[b, 0]) - capped[0][1]) < 1e-3 * max(1.0, abs(capped[0][1]))
+        assert got == unpruned[0][0]
+        assert abs(float(scores[b, 0]) - unpruned[0][1]) < 1e-4 * max(1.0, abs(unpruned[0][1]))
+    # the entry points without scratch: PPASR_ENOSPACE, nothing silently dropped
+    nbytes = int(hl.ppasr_ctc_beam_state_bytes(2, T, beam))
+    st = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    tk = torch.empty(2, 1, T, dtype=torch.int32, device="cuda")
+    ln = torch.empty(2, 1, dtype=torch.int32, device="cuda")
+    sc = torch.empty(2, 1, dtype=torch.float64, device="cuda")
+    rc = hl.ppasr_ctc_beam_search(dev.data_ptr(), None, 2, T, V, beam, C.c_double(1.0), 40, 0, 1, T, tk.data_ptr(),
+                                  ln.data_ptr(), sc.data_ptr(), st.data_ptr(), nbytes, 1, None)
+    assert rc == _lib.PPASR_ENOSPACE
 
 
 class _beam_fast:

@@ -25,15 +25,15 @@ def _trained_like(rng, T, V):
     while t < T:
         if rng.random() < 0.55:
             n = int(rng.integers(1, 6))
-            logits[t:t + n, 0] += 11.0
+            logits[t:t + n, 0] += 15.0
         else:
             n = int(rng.integers(1, 4))
             c = int(rng.integers(1, V))
-            logits[t:t + n, c] += 10.0
+            logits[t:t + n, c] += 14.0
             for alt in rng.integers(1, V, size=3):
-                logits[t:t + n, alt] += float(rng.uniform(5.0, 9.5))
+                logits[t:t + n, alt] += float(rng.uniform(8.0, 13.0))
             if rng.random() < 0.5:
-                logits[t:t + n, 0] += 8.0
+                logits[t:t + n, 0] += 12.0
         t += n
     e = np.exp(logits - logits.max(1, keepdims=True))
     return (e / e.sum(1, keepdims=True)).astype(np.float32)

@@ -2,6 +2,7 @@
 AudioSegment.normalize -> int16 -> Kaldi fbank).  Parity unpinned: paddleaudio is not importable offline."""
 import numpy as np
 import pytest
+import torch
 
 from oracle import fbank_oracle
 
@@ -53,17 +54,19 @@ def test_fbank_edge_cases():
     assert np.abs(f40.featurize(w, 8000) - ref).max() < 1e-3
 
 
-def test_db_gain_bit_exact_for_every_last_chunk_length():
+def test_mean_square_bit_exact_for_every_last_chunk_length():
     """The mean square is summed in numpy's order (pairwise tree per 8192-sample chunk).  A SHORT last chunk's tree can be
     one level deeper than a full chunk's (8191 -> ... -> 135 -> 71: depth 7); lengths with n % 8192 in 7689..8191 used to
-    read unwritten LDS (round-5 advisor finding).  Sweep that whole range, plus a coarse sweep of the rest, with one and
-    with two preceding full chunks, against np.mean(x ** 2) through db_gain, bit for bit."""
+    read unwritten LDS (round-5 advisor finding).  Sweep that whole range, plus a coarse sweep of the rest, with zero, one
+    and two preceding full chunks: the per-chunk sums the kernel leaves in its workspace, added in chunk order, must equal
+    np.add.reduce(x ** 2) bit for bit, and the gain must be db_gain's (<= 1 ulp: numpy's float32 log10 is libm's log10f,
+    the kernel rounds a double log10)."""
     from ppasr_amd.data_utils.featurizer import AudioFeaturizer, db_gain
     f = AudioFeaturizer(n_mels=80, sample_rate=16000, use_dB_normalization=True, target_dB=-20)
     base = _audio(1.6, seed=11)
     assert base.size >= 3 * 8192
     tails = list(range(7600, 8193)) + list(range(400, 7600, 97)) + [128, 129, 135, 136, 143, 144, 263, 519, 1031, 2055, 4103]
-    bad = []
+    bad, bad_gain = [], []
     for full in (0, 1, 2):
         for tail in tails:
             n = full * 8192 + tail
@@ -71,9 +74,18 @@ def test_db_gain_bit_exact_for_every_last_chunk_length():
                 continue
             wav = base[:n]
             f.featurize_device(wav)
-            if np.float32(f.last_gain).tobytes() != np.float32(db_gain(wav, -20)).tobytes():
+            chunks = (n + 8191) // 8192
+            sums = f._ws[:4 * chunks].view(torch.float32).cpu().numpy()
+            acc = np.float32(0)
+            for v in sums:
+                acc = np.float32(acc + v)
+            if acc.tobytes() != np.add.reduce(wav ** 2).tobytes():
                 bad.append(n)
+            g = np.float32(db_gain(wav, -20))
+            if abs(float(np.float32(f.last_gain)) - float(g)) > float(np.spacing(g)):
+                bad_gain.append(n)
     assert not bad, bad[:20]
+    assert not bad_gain, bad_gain[:20]
 
 
 def test_normalize_refuses_gain_beyond_max_gain_db():

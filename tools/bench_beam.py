@@ -34,13 +34,13 @@ def table(kind):
             t = 0
             while t < T:
                 if rng.random() < 0.55:
-                    n = int(rng.integers(1, 6)); logits[b, t:t + n, 0] += 11.0
+                    n = int(rng.integers(1, 6)); logits[b, t:t + n, 0] += 15.0
                 else:
-                    n = int(rng.integers(1, 4)); logits[b, t:t + n, int(rng.integers(1, V))] += 10.0
+                    n = int(rng.integers(1, 4)); logits[b, t:t + n, int(rng.integers(1, V))] += 14.0
                     for alt in rng.integers(1, V, size=3):
-                        logits[b, t:t + n, alt] += float(rng.uniform(5.0, 9.5))
+                        logits[b, t:t + n, alt] += float(rng.uniform(8.0, 13.0))
                     if rng.random() < 0.5:
-                        logits[b, t:t + n, 0] += 8.0
+                        logits[b, t:t + n, 0] += 12.0
                 t += n
     return torch.softmax(torch.from_numpy(logits), -1).cuda()
 
