@@ -313,6 +313,20 @@ PPASR_API ppasr_status ppasr_ctc_beam_search_ws(const float* probs, const int32_
                                       int init_state, ppasr_lm_handle lm, double alpha, double beta, void* scratch,
                                       size_t scratch_bytes, void* stream);
 
+/* ---- hypothesis records of the utterance-parallel path (north_star: "a single RCCL all-gather ... for decoded
+ * hypotheses"; no reference counterpart -- the reference has no multi-GPU inference, trainer.py:529-544 is training DP).
+ * A record row is int32 [cols + extra]: tokens (-1 padded to cols) | n_tokens | score (f64, low word first)
+ * [| utterance index when extra = 4].  ppasr_hyp_pack writes the k hypotheses of one decoder call (tokens [k][L] with
+ * row stride token_stride; n_tokens / score with element strides, so that the n-best = 1 column of the beam search's
+ * [B][nbest] outputs can be passed in place; index [k] or NULL) into rows row0 .. row0 + k - 1 of `rec`;
+ * ppasr_hyp_unpack reads N rows (row order[r], or r when order is NULL) back into tokens [N][cols], n_tokens [N],
+ * score [N] and (optionally) the index column.  One launch each, on `stream`. */
+PPASR_API ppasr_status ppasr_hyp_pack(const int32_t* tokens, long long token_stride, int L, const int32_t* n_tokens,
+                                      long long n_stride, const double* score, long long score_stride, const int32_t* index,
+                                      int k, int32_t* rec, int row0, int cols, int extra, void* stream);
+PPASR_API ppasr_status ppasr_hyp_unpack(const int32_t* rec, const int64_t* order, int N, int cols, int extra, int32_t* tokens,
+                                        int32_t* n_tokens, double* score, int32_t* index, void* stream);
+
 /* ---- streaming: ConformerModel.get_encoder_out_chunk (model_utils/conformer/model.py:164-184) =
  * ConformerEncoder.forward_chunk (conformer/encoder.py:208-283) + ctc softmax, as driven by
  * InferencePredictor.predict_chunk_conformer / reset_stream (inference_predictor.py:184-220) and
@@ -345,7 +359,12 @@ PPASR_API ppasr_status ppasr_stream_import_cache(ppasr_stream s, const float* at
  * output_size = rnn_size, num_blocks = num_rnn_layers, causal = 1 for the streaming ('forward') model and 0 for
  * the bidirectional one (deepspeech2/model.py:40).
  *   feats [B,T,F], lens [B] i64 -> probs [B,T',V] f32, out_lens [B] i64 (= ((len-1)/2-1)/2, may be NULL);
- *   init_h / init_c / final_h / final_c: [num_rnn_layers*dirs, B, rnn_size] state boxes (NULL = zeros / not wanted). */
+ *   init_h / init_c / final_h / final_c: [num_rnn_layers*dirs, B, rnn_size] state boxes (NULL = zeros / not wanted).
+ * Synchronisation: asynchronous on `stream`, EXCEPT single-utterance LSTM calls (B = 1, rnn_size 1024) on the persistent
+ * recurrence route: its launches need every workgroup of their grid resident at once, so the call ends with a stream
+ * synchronisation and a 4-byte read-back of the kernels' give-up flag; when a launch gave up (the chip was shared with
+ * another stream / process) the call re-runs on the per-step kernels before it returns, and the handle stays on those for
+ * the next 64 .. 1 024 calls before it tries the persistent route again.  PPASR_DS2_PERSIST=0 switches the route off. */
 PPASR_API size_t ppasr_ds2_workspace_bytes(ppasr_handle h, int B, int T);
 PPASR_API ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, const int64_t* lens, int B, int T, const float* init_h,
                               const float* init_c, float* probs, int64_t* out_lens, float* final_h, float* final_c,

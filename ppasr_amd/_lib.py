@@ -105,6 +105,9 @@ SYMBOLS = [
                                                 ctypes.c_double, _vp, ctypes.c_size_t, _vp]),
     ("ppasr_ctc_beam_status", ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     ("ppasr_ctc_beam_state_grow", ctypes.c_int, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _vp]),
+    ("ppasr_hyp_pack", ctypes.c_int, [_vp, ctypes.c_longlong, ctypes.c_int, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp,
+                                      ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    ("ppasr_hyp_unpack", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     ("ppasr_lm_create", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int,
                                        ctypes.POINTER(_vp)]),
     ("ppasr_lm_create_klm", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int,

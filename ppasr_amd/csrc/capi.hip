@@ -610,10 +610,16 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
       const ppasr_status g = guard_alloc(h);
       if (g != PPASR_OK) return g;
     }
-    // weights are scaled by 2^8 into fp16: |w| >= 255.9 would overflow (k_repack_h3 counts such weights)
+    // weights are scaled by 2^8 into fp16: |w| >= 255.9 would overflow (k_repack_h3 counts such weights -- in a word of this
+    // call's own, not in the run-time guard's process-wide counters, which a concurrent fp16 x3 encode on another handle
+    // may raise at any time)
     unsigned int w_before = 0, w_after = 0;
+    unsigned int* w_ovf = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w_ovf), sizeof(unsigned int)));
+    struct OvfFree { unsigned int* p; ~OvfFree() { (void)hipFree(p); } } w_ovf_free{w_ovf};
+    HIP_TRY(hipMemset(w_ovf, 0, sizeof(unsigned int)));
+    const size_t alloc_mark = h->allocs.size();  // re-packed copies made by THIS call start here (freed if the mode is refused)
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(&w_before, h->guard_ctr[0], sizeof(unsigned int), hipMemcpyDeviceToHost));
     if (layers_ok && h->layers_h3.empty()) {
       std::vector<LayerW> view = h->layers;
       for (LayerW& L : view) {
@@ -626,7 +632,7 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
           void* dst = nullptr;
           HIP_TRY(hipMalloc(&dst, (size_t)it.n_tiles * it.G * 256 * sizeof(float)));
           h->allocs.push_back(dst);
-          launch_repack_h3(*it.w, static_cast<f32x4*>(dst), it.n_tiles, it.G, nullptr);
+          launch_repack_h3(*it.w, static_cast<f32x4*>(dst), it.n_tiles, it.G, w_ovf, nullptr);
           *it.w = static_cast<const f32x4*>(dst);
         }
         // the layer's projected positional table as operand planes (the fused attention's score MFMAs in the mode)
@@ -634,7 +640,7 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
           void* dst = nullptr;
           HIP_TRY(hipMalloc(&dst, (size_t)h->desc.max_len * d * sizeof(float)));
           h->allocs.push_back(dst);
-          launch_split_rows_h3(L.ptab, static_cast<float*>(dst), h->desc.max_len, nullptr);
+          launch_split_rows_h3(L.ptab, static_cast<float*>(dst), h->desc.max_len, w_ovf, nullptr);
           L.ptab = static_cast<const float*>(dst);
         }
       }
@@ -650,7 +656,7 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
           void* dst = nullptr;
           HIP_TRY(hipMalloc(&dst, (size_t)d * H * sizeof(float)));
           h->allocs.push_back(dst);
-          launch_repack_h3(*w[j], static_cast<f32x4*>(dst), (j & 1) ? d / 32 : H / 32, (j & 1) ? H / 8 : d / 8, nullptr);
+          launch_repack_h3(*w[j], static_cast<f32x4*>(dst), (j & 1) ? d / 32 : H / 32, (j & 1) ? H / 8 : d / 8, w_ovf, nullptr);
           *w[j] = static_cast<const f32x4*>(dst);
         }
       }
@@ -662,7 +668,7 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
       void* dst = nullptr;
       HIP_TRY(hipMalloc(&dst, (size_t)h->head.n_tiles * (d / 8) * 256 * sizeof(float)));
       h->allocs.push_back(dst);
-      launch_repack_h3(h->head.w, static_cast<f32x4*>(dst), h->head.n_tiles, d / 8, nullptr);
+      launch_repack_h3(h->head.w, static_cast<f32x4*>(dst), h->head.n_tiles, d / 8, w_ovf, nullptr);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipDeviceSynchronize());
       h->head_w_h3 = static_cast<const f32x4*>(dst);
@@ -671,7 +677,7 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
       void* dst = nullptr;
       HIP_TRY(hipMalloc(&dst, (size_t)9 * d * d * sizeof(float)));
       h->allocs.push_back(dst);
-      launch_repack_h3(h->front.conv2_w, static_cast<f32x4*>(dst), d / 32, 9 * d / 8, nullptr);
+      launch_repack_h3(h->front.conv2_w, static_cast<f32x4*>(dst), d / 32, 9 * d / 8, w_ovf, nullptr);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipDeviceSynchronize());
       h->conv2_w_h3 = static_cast<const f32x4*>(dst);
@@ -680,24 +686,24 @@ ppasr_status ppasr_set_gemm_mode(ppasr_handle h, int mode) {
       void* dste = nullptr;
       HIP_TRY(hipMalloc(&dste, (size_t)Ke * d * sizeof(float)));
       h->allocs.push_back(dste);
-      launch_repack_h3(h->front.embed_w, static_cast<f32x4*>(dste), d / 32, Ke / 8, nullptr);
+      launch_repack_h3(h->front.embed_w, static_cast<f32x4*>(dste), d / 32, Ke / 8, w_ovf, nullptr);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipDeviceSynchronize());
       h->embed_w_h3 = static_cast<const f32x4*>(dste);
     }
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(&w_after, h->guard_ctr[0], sizeof(unsigned int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&w_after, w_ovf, sizeof(unsigned int), hipMemcpyDeviceToHost));
     if (w_after != w_before) {
-      // (the re-packed copies stay allocated until ppasr_destroy; the mode stays off and the views are dropped so that a
-      //  later call re-checks)
+      // the mode stays off, the views are dropped so that a later call re-checks, and the copies this call made are freed
+      // (a retry does not pile up second copies of the weights)
       h->layers_h3.clear();
       h->sq_layers_h3.clear();
       h->head_w_h3 = h->conv2_w_h3 = h->embed_w_h3 = nullptr;
-      h->guard_seen[0] = w_after;
+      for (size_t i = alloc_mark; i < h->allocs.size(); ++i) (void)hipFree(h->allocs[i]);
+      h->allocs.resize(alloc_mark);
       return fail(PPASR_EUNSUPPORTED, "fp16 x3 GEMMs: a weight of magnitude >= 255.9 (or a positional-table entry >= 4094) does not fit the scaled fp16 pieces");
     }
-    h->guard_seen[0] = w_after;
-    for (int i = 1; i < ppasr_model_s::kGuardN; ++i)
+    for (int i = 0; i < ppasr_model_s::kGuardN; ++i)
       HIP_TRY(hipMemcpy(&h->guard_seen[i], h->guard_ctr[i], sizeof(unsigned int), hipMemcpyDeviceToHost));
     h->gemm_coverage = (layers_ok ? PPASR_GEMM_COVERS_LAYERS : 0) | (sq_ok ? PPASR_GEMM_COVERS_LAYERS : 0) |
                        (front_ok ? PPASR_GEMM_COVERS_FRONT : 0) | (h->head_w_h3 ? PPASR_GEMM_COVERS_HEAD : 0);
@@ -1361,6 +1367,77 @@ ppasr_status ppasr_ctc_greedy(const float* probs, const int32_t* frame_lens, int
   float* fp = reinterpret_cast<float*>(fa + n);
   launch_frame_argmax(probs, fa, fp, B * Tp, V, st);
   launch_ctc_collapse(fa, fp, frame_lens, B, Tp, blank, tokens, n_tokens, score, st);
+  HIP_TRY(hipGetLastError());
+  return PPASR_OK;
+}
+
+// ---- hypothesis records of the data-parallel path (ppasr_amd/parallel.py): int32 rows
+// tokens[cols] (-1 padded) | n_tokens | score (f64 as two words) [| utterance index].  One launch packs a batch's
+// hypotheses into its rows of the rank's record, one launch restores the caller's utterance order after the all-gather --
+// the record never passes through torch's indexing / elementwise kernels. ----
+}  // extern "C"
+namespace {
+__global__ __launch_bounds__(256) void k_hyp_pack(const int32_t* __restrict__ tokens, long long token_stride, int L,
+                                                  const int32_t* __restrict__ n, long long n_stride,
+                                                  const double* __restrict__ score, long long score_stride,
+                                                  const int32_t* __restrict__ index, int k, int32_t* __restrict__ rec,
+                                                  int row0, int cols, int extra) {
+  const int W = cols + extra;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)k * W) return;
+  const int r = (int)(i / W), j = (int)(i - (long long)r * W);
+  int32_t v;
+  if (j < cols) {
+    v = j < L ? tokens[r * token_stride + j] : -1;
+  } else if (j == cols) {
+    v = n[r * n_stride];
+  } else if (j <= cols + 2) {
+    const long long bits = __double_as_longlong(score[r * score_stride]);
+    v = (int32_t)(j == cols + 1 ? (uint32_t)bits : (uint32_t)((unsigned long long)bits >> 32));
+  } else {
+    v = index ? index[r] : -1;
+  }
+  rec[(size_t)(row0 + r) * W + j] = v;
+}
+__global__ __launch_bounds__(256) void k_hyp_unpack(const int32_t* __restrict__ rec, const int64_t* __restrict__ order, int N,
+                                                    int cols, int extra, int32_t* __restrict__ tokens, int32_t* __restrict__ n,
+                                                    double* __restrict__ score, int32_t* __restrict__ index) {
+  const int W = cols + extra;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)N * (cols + 1)) return;
+  const int r = (int)(i / (cols + 1)), j = (int)(i - (long long)r * (cols + 1));
+  const int32_t* src = rec + (size_t)(order ? order[r] : r) * W;
+  if (j < cols) {
+    tokens[(size_t)r * cols + j] = src[j];
+  } else {
+    n[r] = src[cols];
+    const unsigned long long bits = (unsigned long long)(uint32_t)src[cols + 1] | ((unsigned long long)(uint32_t)src[cols + 2] << 32);
+    score[r] = __longlong_as_double((long long)bits);
+    if (index) index[r] = extra > 3 ? src[cols + 3] : -1;
+  }
+}
+}  // namespace
+extern "C" {
+
+ppasr_status ppasr_hyp_pack(const int32_t* tokens, long long token_stride, int L, const int32_t* n_tokens, long long n_stride,
+                            const double* score, long long score_stride, const int32_t* index, int k, int32_t* rec, int row0,
+                            int cols, int extra, void* stream) {
+  if (!tokens || !n_tokens || !score || !rec) return fail(PPASR_EINVAL, "null argument");
+  if (k <= 0 || cols <= 0 || L < 0 || row0 < 0 || (extra != 3 && extra != 4)) return fail(PPASR_EINVAL, "hyp_pack: bad shape");
+  const long long total = (long long)k * (cols + extra);
+  PPASR_LAUNCH(k_hyp_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), tokens,
+               token_stride, L, n_tokens, n_stride, score, score_stride, index, k, rec, row0, cols, extra);
+  HIP_TRY(hipGetLastError());
+  return PPASR_OK;
+}
+
+ppasr_status ppasr_hyp_unpack(const int32_t* rec, const int64_t* order, int N, int cols, int extra, int32_t* tokens,
+                              int32_t* n_tokens, double* score, int32_t* index, void* stream) {
+  if (!rec || !tokens || !n_tokens || !score) return fail(PPASR_EINVAL, "null argument");
+  if (N <= 0 || cols <= 0 || (extra != 3 && extra != 4)) return fail(PPASR_EINVAL, "hyp_unpack: bad shape");
+  const long long total = (long long)N * (cols + 1);
+  PPASR_LAUNCH(k_hyp_unpack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), rec, order,
+               N, cols, extra, tokens, n_tokens, score, index);
   HIP_TRY(hipGetLastError());
   return PPASR_OK;
 }

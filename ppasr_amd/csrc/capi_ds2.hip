@@ -286,8 +286,9 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
   }
   // (PPASR_DS2_PERSIST=0, read per call: the per-step kernels, for A/B measurements and the route-equality test)
   const char* persist_env = getenv("PPASR_DS2_PERSIST");
-  const bool persist = B == 1 && G == 4 && H == 1024 && Tp > 0 && h->ds2_persist && !(persist_env && persist_env[0] == '0') &&
-                       lstm_persist_fits(H, dirs);
+  const bool persist_shape = B == 1 && G == 4 && H == 1024 && Tp > 0 && !(persist_env && persist_env[0] == '0') && lstm_persist_fits(H, dirs);
+  const bool persist = persist_shape && h->ds2_persist_hold == 0;
+  if (persist_shape && h->ds2_persist_hold > 0) --h->ds2_persist_hold;
   if (persist) {
     HIP_TRY(hipMemsetAsync(ws + wl.xbuf, 0, (size_t)4 * dirs * H * sizeof(float), st));
     HIP_TRY(hipMemsetAsync(ws + wl.pflag, 0, 64 * sizeof(float), st));
@@ -336,12 +337,13 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
   if (persist) {
     // the persistent launches wait for one another's workgroups: if one gave up (the chip was not free for the whole
     // grid), say so instead of returning what it left -- this call synchronises, re-runs on the per-step kernels, and the
-    // handle stays on them
+    // handle stays on them for the next 64 .. 1 024 calls (capi_internal.h ds2_persist_hold)
     int gave_up = 0;
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpy(&gave_up, ws + wl.pflag, sizeof(int), hipMemcpyDeviceToHost));
     if (gave_up) {
-      h->ds2_persist = false;
+      h->ds2_persist_hold = 64 << (h->ds2_persist_giveups < 4 ? h->ds2_persist_giveups : 4);
+      ++h->ds2_persist_giveups;
       return ppasr_ds2_encode(h, feats, lens, B, T, init_h, init_c, probs, out_lens, final_h, final_c, workspace, workspace_bytes,
                               stream);
     }

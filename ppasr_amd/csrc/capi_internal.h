@@ -122,7 +122,10 @@ struct ppasr_model_s {
   const float *preln_g = nullptr, *preln_b = nullptr;
   // DeepSpeech2 (model_type == PPASR_MODEL_DEEPSPEECH2)
   Ds2W ds2{};
-  bool ds2_persist = true;  // single utterances: the recurrence of a layer as one persistent launch (cleared if one ever gave up)
+  // single utterances: the recurrence of a layer as one persistent launch.  It needs every workgroup of its grid resident at
+  // once; when a launch gives up (the chip was shared) the next `ds2_persist_hold` calls take the per-step kernels, then the
+  // route is tried again (hold doubles with every give-up, 64 .. 1 024 calls)
+  int ds2_persist_hold = 0, ds2_persist_giveups = 0;
   std::vector<Ds2LayerW> ds2_layers;
   float* taps = nullptr;
   size_t taps_floats = 0;

@@ -161,9 +161,9 @@ void launch_dense(const float* a, int lda, const f32x4* w, const float* bias, fl
 void launch_ffn_qkv(const float* x_in, float* x1, float* qkv, const LayerW& w, int M, int n_chunks, hipStream_t st,
                     const PadSkip& ps = PadSkip{}, VtOut vt = VtOut{}, bool h3 = false);
 // fp32 fragment-packed weight (pack_b: n_tiles x G k-groups x 1 KiB) -> the fp16 x3 packing of csrc/h3.h, same size
-void launch_repack_h3(const f32x4* src, f32x4* dst, int n_tiles, int G, hipStream_t st);
+void launch_repack_h3(const f32x4* src, f32x4* dst, int n_tiles, int G, unsigned int* ovf, hipStream_t st);  // ovf: device word counting weights beyond the range
 inline bool conv_ffn_h3_supported(int ksize) { return ksize == 15 || ksize == 7; }
-void launch_split_rows_h3(const float* src, float* dst, long long n_rows, hipStream_t st);  // [n][256] f32 -> [n][hi 256 | lo 256] fp16 of 2^4 x
+void launch_split_rows_h3(const float* src, float* dst, long long n_rows, unsigned int* ovf, hipStream_t st);  // [n][256] f32 -> [n][hi 256 | lo 256] fp16 of 2^4 x
 unsigned int* conformer_h3_ovf_counter();  // device address of conformer_kernels.hip's range-guard counter (h3.h)
 unsigned int* front_h3_ovf_counter();      // ... front_kernels.hip's (conv2 / input projection in the fp16 x3 mode)
 unsigned int* ctc_head_h3_ovf_counter();   // ... ctc_head_kernels.hip's

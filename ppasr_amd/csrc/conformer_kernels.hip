@@ -193,7 +193,8 @@ __global__ __launch_bounds__(kThreads) void k_ffn_qkv(const float* __restrict__ 
 }
 // fp32 fragment packing -> fp16 x3 packing (h3.h): thread = (tile, 16-wide k step, lane); its 8 weights k = 16 ks + 8 (l >> 5)
 // + e of column 32 tile + (l & 31) sit in k-group 2 ks + (l >> 5) of the source, lanes (l & 31) and (l & 31) + 32
-__global__ __launch_bounds__(256) void k_repack_h3(const float* __restrict__ src, _Float16* __restrict__ dst, int n_tiles, int G) {
+__global__ __launch_bounds__(256) void k_repack_h3(const float* __restrict__ src, _Float16* __restrict__ dst, int n_tiles, int G,
+                                                   unsigned int* __restrict__ ovf) {
   const int KS = G >> 1;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= (long long)n_tiles * KS * 64) return;
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(256) void k_repack_h3(const float* __restrict__ src
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float v = g[((l & 31) + 32 * (e >> 2)) * 4 + (e & 3)] * kH3Sw;
-    if (!(fabsf(v) <= kH3Max)) atomicAdd(&g_h3_ovf, 1u);  // |w| >= 255.9: ppasr_set_gemm_mode refuses the mode
+    if (!(fabsf(v) <= kH3Max)) atomicAdd(ovf, 1u);  // |w| >= 255.9: ppasr_set_gemm_mode refuses the mode (its own counter word:
+                                                    // the run-time range guard of other handles counts elsewhere)
     hi[e] = (_Float16)v;
     lo[e] = (_Float16)(v - (float)hi[e]);
   }
@@ -213,7 +215,8 @@ __global__ __launch_bounds__(256) void k_repack_h3(const float* __restrict__ src
 }
 // rows of 256 floats -> [hi: 256 fp16 | lo: 256 fp16] of 2^4 x (the positional table of a layer, for the attention's fp16 x3
 // score MFMAs); out-of-range entries are counted like out-of-range weights
-__global__ __launch_bounds__(256) void k_split_rows_h3(const float* __restrict__ src, _Float16* __restrict__ dst, long long n_quads) {
+__global__ __launch_bounds__(256) void k_split_rows_h3(const float* __restrict__ src, _Float16* __restrict__ dst, long long n_quads,
+                                                       unsigned int* __restrict__ ovf) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_quads) return;
   const long long row = i >> 6;
@@ -221,19 +224,19 @@ __global__ __launch_bounds__(256) void k_split_rows_h3(const float* __restrict__
   f16x4 hi, lo;
   bool bad = false;
   h3_split4(*reinterpret_cast<const f32x4*>(src + row * 256 + c) * kH3Sa, hi, lo, bad);
-  h3_note(bad);
+  if (bad) atomicAdd(ovf, 1u);
   *reinterpret_cast<f16x4*>(dst + row * 512 + c) = hi;
   *reinterpret_cast<f16x4*>(dst + row * 512 + 256 + c) = lo;
 }
-void launch_split_rows_h3(const float* src, float* dst, long long n_rows, hipStream_t st) {
+void launch_split_rows_h3(const float* src, float* dst, long long n_rows, unsigned int* ovf, hipStream_t st) {
   const long long n = n_rows * 64;
-  PPASR_LAUNCH(k_split_rows_h3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, reinterpret_cast<_Float16*>(dst), n);
+  PPASR_LAUNCH(k_split_rows_h3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, reinterpret_cast<_Float16*>(dst), n, ovf);
 }
 unsigned int* conformer_h3_ovf_counter() { return h3_ovf_counter(); }
-void launch_repack_h3(const f32x4* src, f32x4* dst, int n_tiles, int G, hipStream_t st) {
+void launch_repack_h3(const f32x4* src, f32x4* dst, int n_tiles, int G, unsigned int* ovf, hipStream_t st) {
   const long long n = (long long)n_tiles * (G >> 1) * 64;
   PPASR_LAUNCH(k_repack_h3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(src),
-               reinterpret_cast<_Float16*>(dst), n_tiles, G);
+               reinterpret_cast<_Float16*>(dst), n_tiles, G, ovf);
 }
 
 // the same with the feed-forward module on the fp16 x3 route (ppasr_set_gemm_mode; w: the layer's h3 view)

@@ -39,6 +39,7 @@ namespace ppasr {
 namespace {
 
 constexpr int kSmallList = 128;  // element lists up to this many entries are ranked with ballots (two keys per lane of a wave)
+constexpr int kTinyBeam = 16;    // beams up to this size take the static-layout form of the clipped list (k_ctc_beam (e'))
 constexpr int kBT = 1024;  // threads per utterance: 16 waves = 4 per SIMD (a batch of 32 utterances occupies 32 CUs with one
                           // workgroup each, and every phase is a chain of dependent LDS reads: latency hidden by wave count)
 constexpr int kBW = kBT / 64;  // waves
@@ -110,6 +111,8 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
   return x;
 }
 
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ int mbcnt(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
@@ -239,41 +242,48 @@ __device__ __forceinline__ void select_bin_reg(const int* hist, int k_rem, int& 
 
 // ---- LDS plan of k_ctc_beam, shared by the host (size) and the kernel (offsets) ----
 struct BeamLdsPlan {
-  uint32_t hist, wtot, red, sh, cand, beam0, beam1, newv, rows, surv, lmacc, kidx, fkey, lkey, lex, total;
+  uint32_t hist, wtot, red, sh, cand, beam0, beam1, newv, rows, surv, lmacc, cmask, frow, kidx, fkey, lkey, lex, total;
 };
 constexpr int kLmAccWords = kLmMaxOrder + 1;  // lm_context_acc's summary of a hypothesis' context (lm.h)
 __host__ __device__ inline uint32_t al8(uint32_t x) { return (x + 7u) & ~7u; }
 constexpr int kBeamWords = 8 + kLmCtx;  // node, chr, par, b, nb, score, pslot, dst + LM context words: one beam half per hypothesis
-__host__ __device__ inline BeamLdsPlan beam_lds_plan(int beam, int V, int list_cap, bool has_lm) {
+constexpr int kMaskWords = kSmallCand / 32;  // "child exists" bits of a hypothesis: one per candidate of a narrow list
+__host__ __device__ inline BeamLdsPlan beam_lds_plan(int beam, int V, int list_cap, bool has_lm, bool wide) {
   BeamLdsPlan p;
   uint32_t o = 0;
   p.hist = o;  o += 8 * 256 * 4;
   p.wtot = o;  o += 4 * 16 * 4;                      // 4 scan call sites x up to 16 waves
-  p.red = o;   o += 16 * 4;
+  p.red = o;   o += 32 * 4;
   p.sh = o;    o += 64;                              // 16 shared ints
-  p.cand = o;  o += 2 * kSmallCand * 4;              // cand_c, cand_lp (records of <= kSmallCand candidates)
+  p.cand = o;  o += (has_lm ? 4 : 2) * kSmallCand * 4;  // cand_c, cand_lp (records of <= kSmallCand candidates); scorer: + the
+                                                       // candidates' LM word ids and unigram log10 probabilities
   p.beam0 = o; o = al8(o + (uint32_t)beam * 4 * kBeamWords);
   p.beam1 = o; o = al8(o + (uint32_t)beam * 4 * kBeamWords);
   p.newv = o;  o = al8(o + (uint32_t)beam * 20);     // new_b, new_nb, new_score, new_dst, k_reset
   p.rows = o;  o = al8(o + (uint32_t)beam * 12 + 4); // rank_of[beam], off[beam + 1], newpos[beam]
   p.surv = o;  o = al8(o + (uint32_t)beam * 8);      // surv[beam], surv_lp[beam]
   p.lmacc = o; o = al8(o + (has_lm ? (uint32_t)beam * 4 * kLmAccWords : 0u));
+  p.cmask = o; o = al8(o + (wide ? 0u : (uint32_t)beam * 4 * kMaskWords));
+  p.frow = o;  o += 1024 * 2;                        // first_row[thread] (int16)
   p.kidx = o;  o = al8(o + (uint32_t)((V + 3) & ~3) * 2);
-  p.fkey = o;  o += kSmallList * 8;
+  p.fkey = o;  o += kSmallList * 8 + kTinyBeam * 8 + kTinyBeam * 4;  // + srank_key, hyp_of_rank of the tiny-beam path
   p.lkey = o;  o = al8(o + (uint32_t)list_cap * 4);
-  p.lex = o;   o = al8(o + (uint32_t)list_cap);
+  p.lex = o;   o = al8(o + (wide ? (uint32_t)list_cap : 0u));  // wide lists: one "child exists" flag per entry
   p.total = (o + 15u) & ~15u;
   return p;
 }
 
-size_t beam_lds_bytes(const BeamConfig& c) { return beam_lds_plan(c.beam, c.V, c.list_cap, c.lm.order > 0).total; }
+size_t beam_lds_bytes(const BeamConfig& c) {
+  return beam_lds_plan(c.beam, c.V, c.list_cap, c.lm.order > 0, c.n_cand_max > kSmallCand).total;
+}
 
 // largest element list (entries) the LDS of one CU can hold beside the fixed arrays, capped at what a frame can need
 int beam_list_cap(int beam, int V, int n_cand_max, bool has_lm) {
-  const size_t fixed = beam_lds_plan(beam, V, 0, has_lm).total;
+  const bool wide = n_cand_max > kSmallCand;
+  const size_t fixed = beam_lds_plan(beam, V, 0, has_lm, wide).total, per_entry = wide ? 5 : 4;
   const size_t budget = 160 * 1024 - 64;  // (the hardware limit of a workgroup; small beams stay far below it)
-  if (fixed + 5 * (size_t)kSmallList > budget) return 0;
-  size_t cap = (budget - fixed) / 5;
+  if (fixed + per_entry * (size_t)kSmallList > budget) return 0;
+  size_t cap = (budget - fixed) / per_entry;
   cap &= ~(size_t)7;
   const size_t need = (size_t)beam * (1 + (size_t)n_cand_max);
   const size_t hard = 24 * 1024;  // 24 entries per thread of the largest workgroup: beyond that the list lives in HBM
@@ -584,13 +594,15 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
   const int u = blockIdx.x;
   const int V = cfg.V, beam = cfg.beam, blank = cfg.blank, CM = cfg.n_cand_max;
   const bool has_lm = cfg.lm.order > 0;
-  const BeamLdsPlan plan = beam_lds_plan(beam, V, cfg.list_cap, has_lm);
+  const BeamLdsPlan plan = beam_lds_plan(beam, V, cfg.list_cap, has_lm, WIDE);
   int* hist = reinterpret_cast<int*>(smem + plan.hist);
   int* wave_tot = reinterpret_cast<int*>(smem + plan.wtot);
   float* red_p = reinterpret_cast<float*>(smem + plan.red);
   int* sh_i = reinterpret_cast<int*>(smem + plan.sh);
   int* cand_c_s = reinterpret_cast<int*>(smem + plan.cand);
   float* cand_lp_s = reinterpret_cast<float*>(smem + plan.cand) + kSmallCand;
+  int* cand_word_s = cand_c_s + 2 * kSmallCand;                      // (scorer, narrow lists) tok2lm[character of candidate k]
+  float* cand_uni_s = reinterpret_cast<float*>(cand_c_s + 3 * kSmallCand);  // ... uni_prob of that word (NaN: OOV / absent)
   char* pb = smem + plan.beam0;
   Beam cur = carve_beam(pb, beam);
   pb = smem + plan.beam1;
@@ -607,8 +619,12 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
   float* surv_lp = reinterpret_cast<float*>(surv + beam);   // log-probability of a surviving CHILD
   int16_t* kidx = reinterpret_cast<int16_t*>(smem + plan.kidx);
   unsigned long long* fkey = reinterpret_cast<unsigned long long*>(smem + plan.fkey);
+  unsigned long long* srank_key = fkey + kSmallList;               // tiny beams: the `beam` smallest keys, by rank
+  int* hyp_of_rank = reinterpret_cast<int*>(srank_key + kTinyBeam);  // ... hypothesis of score rank r
   uint32_t* lkey_s = reinterpret_cast<uint32_t*>(smem + plan.lkey);
-  uint8_t* lex_s = reinterpret_cast<uint8_t*>(smem + plan.lex);
+  uint8_t* lex_s = reinterpret_cast<uint8_t*>(smem + plan.lex);            // (wide lists only)
+  uint32_t* cmask = reinterpret_cast<uint32_t*>(smem + plan.cmask);        // [beam][kMaskWords] (narrow lists only)
+  int16_t* first_row = reinterpret_cast<int16_t*>(smem + plan.frow);       // row of the first child entry of a thread's range
   uint32_t* lkey_g = nullptr;
   uint8_t* lex_g = nullptr;
   if (scratch_lists) {
@@ -648,7 +664,11 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
       cur.dst[i] = g_arr[(6 + kLmCtx) * beam + i];
     }
   }
-  for (int i = tid; i < cfg.list_cap; i += BT) lex_s[i] = 0;  // "child exists" flags: set and cleared by their setter
+  if (WIDE) {
+    for (int i = tid; i < cfg.list_cap; i += BT) lex_s[i] = 0;  // "child exists" flags: set and cleared by their setter
+  } else {
+    for (int i = tid; i < beam * kMaskWords; i += BT) cmask[i] = 0;  // ... bits: set in (d), cleared when the beam is rewritten
+  }
   for (int i = tid; i < beam; i += BT) { rank_of[i] = 0; newpos[i] = i; }
   __syncthreads();
   // slot of every hypothesis' parent in the beam (-1: not there).  Inside the frame loop it is carried along: a hypothesis
@@ -661,6 +681,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
     cur.pslot[q] = pi;
   }
 
+  nb = __builtin_amdgcn_readfirstlane(nb);
   const int n_frames = frame_lens ? min(max(frame_lens[u], 0), T) : T;
   // kidx[] = index of a character in the frame's candidate list (-1: not a candidate): cleared once, then only the entries
   // of the previous frame's characters are reset.  A character's log-prob is cand_lp[kidx[c]] -- a V-wide table of its own
@@ -690,19 +711,41 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
   if (n_frames > 0) fetch(0);
   __syncthreads();
 #ifdef PPASR_BEAM_TS
-  long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ts_last = wall_clock64(), ts_n = 0, ts_c = 0, ts_nb = 0, ts_att = 0, ts_ok = 0,
+  long long ts_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts_last = wall_clock64(), ts_n = 0, ts_c = 0, ts_nb = 0, ts_att = 0, ts_ok = 0,
             ts_small = 0, ts_hbm = 0;
 #define TS(i) do { if (tid == 0 && u == 0) { long long now = wall_clock64(); ts_acc[i] += now - ts_last; ts_last = now; } } while (0)
+  long long tw_last = 0, tw_acc[4] = {0, 0, 0, 0};
+#define TW0() do { if (tid == BT - 64 && u == 0) tw_last = wall_clock64(); } while (0)
+#define TW(i) do { if (tid == BT - 64 && u == 0) { long long now = wall_clock64(); tw_acc[i] += now - tw_last; tw_last = now; } } while (0)
 #else
 #define TS(i)
+#define TW0()
+#define TW(i)
 #endif
   // rows may be clipped when there is no scorer (the bound needs score = acoustic only) and the candidate lists are sorted
   // by probability (k_ctc_prune* leave them in vocabulary order when nothing is pruned or sorted)
   const bool may_clip = !has_lm && cfg.fast_path != 0 && cfg.sorted != 0;
   const int margin = cfg.margin;
+  // (e') tiny beams (<= 16, the beam-10 evaluation setting of BASELINE configs[3] / [4]): the clipped list has a STATIC
+  // layout -- slot q < beam = existing hypothesis q, then row r (the hypothesis of score rank r) with its first
+  // K_r = beam / (r + 1) + margin candidates -- so slot `tid` is this thread's (my_r < 0: none) in every frame: no
+  // offsets, no scans.  Same verification, same result as the general form below (survivors re-ordered to list order).
+  bool tiny_ok = may_clip && !WIDE && beam <= kTinyBeam && BT >= 128;
+  int my_r = -1, my_k = 0, n_s0 = beam;
+  if (tiny_ok) {
+    int o = tid - beam;
+    for (int r = 0; r < beam; ++r) {
+      const int kr = beam / (r + 1) + margin;
+      if (my_r < 0 && o >= 0 && o < kr) { my_r = r; my_k = o; }
+      o -= kr;
+      n_s0 += kr;
+    }
+    tiny_ok = n_s0 <= kSmallList;
+  }
+  const int my_row_k = beam / (lane + 1) + margin;  // K_r of row r = lane (the verification's lanes)
   for (int t = 0; t < n_frames; ++t) {
     // ---- (b, c) this frame's pruned characters (get_pruned_log_probs, done by the pre-pass) ----
-    const int C = pre_C;
+    const int C = __builtin_amdgcn_readfirstlane(pre_C);  // (block-uniform: tell the compiler)
     const float p_blank = __int_as_float(pre_pb);
     const int32_t* rec_t = rec_u + (size_t)t * RW;
     if (WIDE) {
@@ -715,6 +758,11 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
           cand_c_s[k] = pre_c[j];
           cand_lp_s[k] = __int_as_float(pre_lp[j]);
           kidx[pre_c[j]] = (int16_t)k;
+          if (has_lm && !word_lm) {  // the candidate side of the factorised scorer look-up: once per frame, not per pair
+            const int w = cfg.lm.tok2lm[pre_c[j]];
+            cand_word_s[k] = w;
+            cand_uni_s[k] = (w > 0 && w < cfg.lm.n_words) ? cfg.lm.uni_prob[w] : __builtin_nanf("");
+          }
         }
       }
     }
@@ -726,6 +774,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
       return k >= 0 ? cand_lp(k) : kNotCand;
     };
     if (t + 1 < n_frames) fetch(t + 1);
+    if (tid == 0) { sh_i[1] = 0; sh_i[2] = 0; sh_i[3] = 0; }  // verification failed / kept count / largest key kept
     lds_barrier();
     TS(0);
     // ---- external scorer: pruning threshold of this frame and the LM term of every possible extension ----
@@ -769,6 +818,18 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
       return (float)(lm_pair_log_cond_prob(cfg.lm, ctx, acc, word) * cfg.alpha);
     };
     auto lm_term = [&](int i, int c) -> float { return lm_term_word(i, cfg.lm.tok2lm[c]); };
+    // character-based scorer, candidate k of a narrow list: word id and unigram from the frame's LDS tables
+    auto lm_term_k = [&](int i, int k) -> float {
+      if (WIDE) return lm_term(i, cand_c(k));
+      int32_t ctx[kLmMaxOrder];
+      float acc[kLmAccWords];
+      const int order = cfg.lm.order;
+#pragma unroll
+      for (int j = 0; j < kLmCtx; ++j) ctx[j] = j < order - 1 ? cur.ctx[i * kLmCtx + (kLmCtx - (order - 1)) + j] : 0;
+#pragma unroll
+      for (int j = 0; j < kLmAccWords; ++j) acc[j] = lm_acc[i * kLmAccWords + j];
+      return (float)(lm_pair_log_cond_prob(cfg.lm, ctx, acc, cand_word_s[k], cand_uni_s[k]) * cfg.alpha);
+    };
     // log-probability carried by the extension of hypothesis i with candidate k (its LM term included); `to_state`:
     // dictionary state the extension lands in (word-based scorer only)
     auto ext_logp = [&](int i, int k, int to_state) -> float {
@@ -783,14 +844,16 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
           log_p = (float)((double)log_p + cfg.beta);
         }
       } else if (has_lm) {
-        log_p += lm_term(i, c);
+        log_p += lm_term_k(i, k);
         log_p = (float)((double)log_p + cfg.beta);
       }
       return log_p;
     };
     TS(1);
+    TW0();
     // rows are clipped this frame if the shortest staircase row is shorter than the candidate list (block-uniform)
-    bool clip = may_clip && C > beam / nb + margin;
+    const bool tiny = tiny_ok && C > 0;
+    bool clip = may_clip && !tiny && C > beam / nb + margin;
     // ---- (d) contributions received by the hypotheses already in the beam (thread q < nb <= BT) ----
     const float lpb = lp_of(blank);
     int mrg_pi = -1, mrg_k = 0;  // the child (parent slot, candidate) this hypothesis IS: it exists, no new element for it
@@ -820,41 +883,212 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
             nbc = lse(nbc, ext_logp(pi, kq, (word_lm && cq == space_id) ? lm_dict_arc(cfg.lm, cur.dst[pi], cq) : 0));
           mrg_pi = pi;
           mrg_k = kq;
+          if (!WIDE) atomicOr(&cmask[pi * kMaskWords + (kq >> 5)], 1u << (kq & 31));
         }
       }
       new_b[q] = bc;
       new_nb[q] = nbc;
       new_score[q] = lse(bc, nbc);
     }
-    if (clip) {
-      // rank of every hypothesis by its CURRENT score (the rows of the staircase): P threads per hypothesis count a slice
-      // of the others each, partial counts meet in LDS
-      const int P = max(1, min(8, BT / nb));
-      const int q = tid / P, part = tid - q * P;
-      if (q < nb) {
-        const float sq = cur.score[q];
-        int r = 0;
-        for (int i = part; i < nb; i += P) {
-          const float si = cur.score[i];
-          r += (si > sq || (si == sq && i < q)) ? 1 : 0;
-        }
-        if (r) atomicAdd(&rank_of[q], r);
-      }
+    if (tiny && wave == 0) {  // (nb <= 16: (d) ran in lanes of wave 0) merged children of the frame
+      const unsigned long long m = __ballot(tid < nb && mrg_pi >= 0);
+      if (lane == 0) sh_i[0] = __popcll(m);
     }
+    if (tiny && wave == 1 && lane < nb) {  // an otherwise idle wave: rank of every hypothesis by its CURRENT score
+      const float sq = cur.score[lane];
+      int r = 0;
+      for (int i = 0; i < nb; ++i) {
+        const float si = cur.score[i];
+        r += (si > sq || (si == sq && i < lane)) ? 1 : 0;
+      }
+      hyp_of_rank[r] = lane;
+    }
+    TS(8);
+    TW(0);
+    // ---- clipped rows: rank of every hypothesis by its CURRENT score (the rows of the staircase), row lengths, offsets ----
+    int NLc_clip = 0;  // child entries of the clipped list
+    auto write_first_rows = [&](int i, int my_off, int my_len, int per) {
+      // first_row[t] = row holding the first child entry of thread t's range [t*per, (t+1)*per) of the list (threads whose
+      // range ends inside the hypotheses need none): row i covers child entries [my_off, my_off + my_len)
+      if (my_len <= 0) return;
+      const int t0 = nb / per;  // first thread whose range reaches the children; its first child entry is 0
+      int tt = (nb + my_off + per - 1) / per;
+      if (tt < t0 || my_off == 0) tt = t0;
+      for (; tt < BT && max(0, tt * per - nb) < my_off + my_len; ++tt) first_row[tt] = (int16_t)i;
+    };
+    auto per_of = [&](int NL) -> int { return (NL <= kSmallList && cfg.fast_path != 0 && NL <= cfg.list_cap) ? 1 : (((NL + BT - 1) / BT) | 1); };
+    if (clip && nb <= 64) {
+      // up to 64 hypotheses: ONE wave (the last: (d) runs in the first) does the whole computation in registers -- no
+      // atomics, no scan across waves, no barrier of its own (the results are read behind the barrier that closes (d))
+      if (wave == NW - 1) {
+      const float sq = lane < nb ? cur.score[lane] : 0.f;
+      int r = 0;
+      for (int i = 0; i < nb; ++i) {
+        const float si = rl_f(sq, i);
+        r += (si > sq || (si == sq && i < lane)) ? 1 : 0;
+      }
+      TW(1);
+      const int my_len = lane < nb ? min(C, beam / (r + 1) + margin) : 0;
+      const int incl = wave_incl_scan(my_len);
+      NLc_clip = __builtin_amdgcn_readlane(incl, 63);
+      const int my_off = incl - my_len;
+      if (lane < nb) off[lane] = my_off;
+      if (lane == 0) { off[nb] = NLc_clip; sh_i[4] = NLc_clip; }
+      write_first_rows(lane, my_off, my_len, per_of(nb + NLc_clip));
+      }
+    } else if (clip) {
+      // more than 64 hypotheses: exact ranks cost nb^2 comparisons (2.6 us of VALU time at nb = 300); the staircase only
+      // needs a rank that is NOT ABOVE the true one (a longer row is still verified), so the scores are bucketed -- 256 equal
+      // buckets between the best and the worst score of the beam (the top-`beam` of a frame sit within a fraction of a nat
+      // of one another on flat posteriors, tens of nats apart on peaked ones) -- and a hypothesis takes the number of
+      // hypotheses in strictly better buckets as its rank.  This phase: best and worst score per wave.
+      const float sc = tid < nb ? cur.score[tid] : kNegInf;
+      float m = sc, mn = (tid < nb && sc > -1e30f) ? sc : FLT_MAX;  // (a prefix of probability zero is no lower end)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, o));
+        mn = fminf(mn, __shfl_xor(mn, o));
+      }
+      if (lane == 0) { red_p[wave] = m; red_p[16 + wave] = mn; }
+      if (tid < 256) hist[tid] = 0;
+    }
+    TS(9);
+    TW(2);
     lds_barrier();
     TS(2);
+    TW(3);
+    if (tid < beam) newpos[tid] = -1;  // consumed in (d); takes the new slots of the hypotheses that stay (end of the frame)
+    if (clip && nb <= 64) NLc_clip = sh_i[4];
     int k_sel = 0;
+    bool tiny_done = false;
+    if (tiny) {
+      const int has_blank = kidx[blank] >= 0 ? 1 : 0;
+      const int n_valid_f = nb + nb * (C - has_blank) - sh_i[0];  // existing + non-blank, non-merged children
+      if (n_valid_f > beam) {  // (block-uniform)
+#ifdef PPASR_BEAM_TS
+        ++ts_att;
+#endif
+        // keys: score key | character + 1 | id, id = e for hypothesis e, 1 << 17 | i << 7 | k for child (i, k): the order of
+        // the general list (hypotheses, then children by (row, candidate))
+        if (tid < n_s0) {
+          unsigned long long key = ~0ull;
+          if (tid < beam) {
+            if (tid < nb) key = make_key(new_score[tid], cur.chr[tid], tid);
+          } else if (my_r < nb && my_k < C) {
+            const int i = hyp_of_rank[my_r], k = my_k;
+            const int c = cand_c_s[k];
+            if (c != blank && !((cmask[i * kMaskWords + (k >> 5)] >> (k & 31)) & 1u)) {
+              const float lpk = cand_lp_s[k];
+              float log_p = kNegInf;
+              if (c == cur.chr[i]) { if (cur.b[i] > kNegInf) log_p = lpk + cur.b[i]; }
+              else log_p = lpk + cur.score[i];
+              key = make_key(log_p, c, (1 << 17) | (i << 7) | k);
+            }
+          }
+          fkey[tid] = key;
+        }
+        if (tid < kTinyBeam) srank_key[tid] = ~0ull;
+        lds_barrier();
+        TS(3);
+        {  // rank of every key = number of smaller keys (keys are unique: the id is part of them): wave w ranks the keys
+           // w, w + NW, ...
+          const unsigned long long k0 = lane < n_s0 ? fkey[lane] : ~0ull, k1 = lane + 64 < n_s0 ? fkey[lane + 64] : ~0ull;
+          for (int i = wave; i < n_s0; i += NW) {
+            const unsigned long long ki = fkey[i];
+            const int rank = __popcll(__ballot(k0 < ki)) + __popcll(__ballot(k1 < ki));
+            if (lane == 0 && ki != ~0ull && rank < beam) srank_key[rank] = ki;
+          }
+        }
+        lds_barrier();
+        TS(5);
+        // survivors in LIST order (the order the general compaction leaves them in) + the verification
+        if (wave == 0) {  // lane = (survivor p = lane & 15, quarter g = lane >> 4 of the others it is compared with)
+          const int pidx = lane & 15, g = lane >> 4;
+          const unsigned long long kp = pidx < beam ? srank_key[pidx] : ~0ull;
+          const int ep = (int)(kp & 0x3FFFFull);  // (make_key: the id is the low 18 bits)
+          int pos = 0;
+#pragma unroll
+          for (int j = 0; j < kTinyBeam / 4; ++j) {
+            const int jj = g + 4 * j;
+            const unsigned long long kj = jj < beam ? srank_key[jj] : ~0ull;
+            pos += (kj != ~0ull && (int)(kj & 0x3FFFFull) < ep) ? 1 : 0;
+          }
+          pos += __shfl_xor(pos, 16);
+          pos += __shfl_xor(pos, 32);
+          if (lane < beam) {
+            if (kp == ~0ull) {
+              sh_i[1] = 1;  // fewer than `beam` valid elements in the list
+            } else {
+              surv[pos] = (ep >> 17) ? (kChildBit | (((ep >> 7) & 0xF) << 14) | (ep & 0x7F)) : ep;
+              surv_lp[pos] = score_of_key((uint32_t)(kp >> 32));
+            }
+          }
+        } else if (wave == 1 && lane < nb) {  // (another wave: row r = lane)
+          const unsigned long long kl = srank_key[beam - 1];
+          if (my_row_k < C && kl != ~0ull) {
+            const uint32_t thr = (uint32_t)(kl >> 32);  // score key of the last element taken
+            const float ub = cand_lp_s[my_row_k] + cur.score[hyp_of_rank[lane]];
+            if (desc_key(ub) <= thr) sh_i[1] = 1;  // an excluded child could score >= the last one taken
+          }
+        }
+        lds_barrier();
+        if (sh_i[1] == 0) {
+          tiny_done = true;
+          k_sel = beam;
+#ifdef PPASR_BEAM_TS
+          ++ts_ok;
+          ++ts_small;
+#endif
+        } else {
+          lds_barrier();  // (everyone has read the flag)
+          if (tid == 0) sh_i[1] = 0;
+        }
+        TS(6);
+      }
+    }
+    if (!tiny_done)
     for (;;) {  // (at most two rounds: clipped rows, then -- if the verification fails -- full rows)
-      int my_len = 0;
-      if (clip) {
-        if (tid < nb) my_len = min(C, beam / (rank_of[tid] + 1) + margin);
-        int total;
-        const int my_off = block_excl_scan<NW>(my_len, wave_tot, total);
-        if (tid < nb) off[tid] = my_off;
-        if (tid == 0) off[nb] = total;
+      if (clip && nb > 64) {
+        float m = red_p[0], mn = red_p[16];
+        for (int w = 1; w < NW; ++w) {
+          m = fmaxf(m, red_p[w]);
+          mn = fminf(mn, red_p[16 + w]);
+        }
+        const float bscale = (m > mn) ? 255.f / (m - mn) : 0.f;
+        int bkt = 0;
+        if (tid < nb) {
+          const float d = (m - cur.score[tid]) * bscale;
+          bkt = !(d < 255.f) ? 255 : (int)d;
+          atomicAdd(&hist[bkt], 1);
+        }
+        lds_barrier();
+        int my_len = 0;
+        {
+          // exclusive prefix of the 256 buckets, computed by every wave for itself (lane l: buckets 4 l .. 4 l + 3)
+          int c[4], sum = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            c[j] = hist[4 * lane + j];
+            sum += c[j];
+          }
+          const int excl = wave_incl_scan(sum) - sum;
+          const int src = (bkt >> 2) * 4;  // (byte address of the lane for ds_bpermute)
+          int r = __builtin_amdgcn_ds_bpermute(src, excl);
+          const int c0 = __builtin_amdgcn_ds_bpermute(src, c[0]), c1 = __builtin_amdgcn_ds_bpermute(src, c[1]),
+                    c2 = __builtin_amdgcn_ds_bpermute(src, c[2]);
+          const int j = bkt & 3;
+          r += (j > 0 ? c0 : 0) + (j > 1 ? c1 : 0) + (j > 2 ? c2 : 0);
+          if (tid < nb) my_len = min(C, beam / (r + 1) + margin);
+        }
+        const int my_off = block_excl_scan<NW>(my_len, wave_tot, NLc_clip);
+        if (tid < nb) {
+          off[tid] = my_off;
+          write_first_rows(tid, my_off, my_len, per_of(nb + NLc_clip));
+        }
+        if (tid == 0) off[nb] = NLc_clip;
         lds_barrier();
       }
-      const int NLc = clip ? off[nb] : nb * C;
+      const int NLc = clip ? NLc_clip : nb * C;
       const int NL = nb + NLc;
       const bool in_lds = NL <= cfg.list_cap;
 #ifdef PPASR_BEAM_TS
@@ -874,7 +1108,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
         auto list_barrier = [&]() { if (kLds) lds_barrier(); else __syncthreads(); };
         auto row_off = [&](int i) -> int { return clip ? off[i] : i * C; };
         auto row_len = [&](int i) -> int { return clip ? off[i + 1] - off[i] : C; };
-        auto row_of = [&](int s) -> int {  // row holding child entry s
+        auto row_of = [&](int s) -> int {  // row holding child entry s (any s: binary search over the offsets)
           if (!clip) return s / C;
           int lo = 0, hi = nb - 1;  // largest i with off[i] <= s
           while (lo < hi) {
@@ -884,14 +1118,20 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
           }
           return lo;
         };
+        // "the child (i, k) is already a hypothesis of the beam": narrow lists keep one bit per (hypothesis, candidate), set
+        // in (d); wide lists one flag per list entry, set here by the hypothesis that IS the child and cleared by it below
         int my_flag = -1;
-        if (tid < nb && mrg_pi >= 0 && mrg_k < row_len(mrg_pi)) {
-          my_flag = row_off(mrg_pi) + mrg_k;
-          lex[my_flag] = 1;
+        if (WIDE) {
+          if (tid < nb && mrg_pi >= 0 && mrg_k < row_len(mrg_pi)) {
+            my_flag = row_off(mrg_pi) + mrg_k;
+            lex[my_flag] = 1;
+          }
+          list_barrier();
         }
-        if (tid == 0) { sh_i[1] = 0; sh_i[2] = 0; sh_i[3] = 0; }  // verification failed / kept count / largest key kept
-        for (int i = tid; i < 8 * 256; i += BT) hist[i] = 0;  // 4 + 4 per-pass histograms of the two selects below
-        list_barrier();
+        auto child_exists = [&](int i, int k, int s) -> bool {
+          if (WIDE) return lex[s] != 0;
+          return ((cmask[i * kMaskWords + (k >> 5)] >> (k & 31)) & 1u) != 0;
+        };
         if (word_lm) {
           // PathTrie::get_path_trie with a dictionary: a character that has no arc from the prefix's dictionary state yields
           // no child -- and when that state is FINAL (a word has just ended) the lookup resets the prefix's state to the
@@ -905,7 +1145,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
             if (lm_dict_final(cfg.lm, nd)) {
               const int ro = row_off(q);
               for (int k = 0; k < C; ++k) {
-                if (cand_c(k) == blank || lex[ro + k] || pruned(cand_lp(k), q)) continue;
+                if (cand_c(k) == blank || child_exists(q, k, ro + k) || pruned(cand_lp(k), q)) continue;
                 kr = k;
                 break;
               }
@@ -936,7 +1176,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
         auto child_key = [&](int i, const RowCtx& r, int k, int s) -> uint32_t {
           const int c = cand_c(k);
           const float lpk = cand_lp(k);
-          if (c == blank || lex[s] || (full_beam && (lpk + r.si < min_cutoff))) return kNoKey;
+          if (c == blank || child_exists(i, k, s) || (full_beam && (lpk + r.si < min_cutoff))) return kNoKey;
           int to = 0;
           if (word_lm) {
             to = (r.dead || k == r.kri) ? -1 : lm_dict_arc(cfg.lm, r.di, c);
@@ -951,7 +1191,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
               log_p = (float)((double)log_p + cfg.beta);
             }
           } else if (has_lm) {
-            log_p += lm_term(i, c);
+            log_p += lm_term_k(i, k);
             log_p = (float)((double)log_p + cfg.beta);
           }
           return desc_key(log_p);
@@ -969,7 +1209,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
             if (tid < nb) {
               key = make_key(new_score[tid], cur.chr[tid], tid);
             } else {
-              const int s = tid - nb, i = row_of(s), k = s - row_off(i);
+              const int s = tid - nb, i = clip ? (int)first_row[tid] : s / C, k = s - row_off(i);
               const RowCtx r = load_row(i);
               const uint32_t k32 = child_key(i, r, k, s);
               if (k32 != kNoKey) key = ((unsigned long long)k32 << 32) | ((unsigned long long)(uint32_t)(cand_c(k) + 1) << 18) | (unsigned long long)(uint32_t)tid;
@@ -1001,7 +1241,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
                 surv[pos] = e;
                 surv_lp[pos] = 0.f;
               } else {
-                const int s = e - nb, i = row_of(s), k = s - row_off(i);
+                const int s = e - nb, i = clip ? (int)first_row[e] : s / C, k = s - row_off(i);
                 surv[pos] = kChildBit | (i << 14) | k;
                 surv_lp[pos] = score_of_key((uint32_t)(ke >> 32));
               }
@@ -1027,6 +1267,9 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
           // of a wave on 16 or fewer of the 64 LDS banks.) ----
           const int per = ((NL + BT - 1) / BT) | 1;
           const int e_lo = min(tid * per, NL), e_hi = min(e_lo + per, NL);
+          for (int i = tid; i < 8 * 256; i += BT) hist[i] = 0;  // 4 + 4 per-pass histograms of the selects below (complete
+                                                                // behind the barrier of the scan that closes (e))
+          const int row0 = e_hi > nb ? (clip ? (int)first_row[tid] : max(0, e_lo - nb) / C) : 0;  // row of my first child entry
           int my_valid = 0;
           {
             int e = e_lo;
@@ -1035,7 +1278,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
               ++my_valid;
             }
             if (e < e_hi) {  // children: one row at a time (the hypothesis' fields stay in registers)
-              int s = e - nb, i = row_of(s);
+              int s = e - nb, i = row0;
               while (e < e_hi) {
                 const int ro = row_off(i), k0 = s - ro;
                 const int k1 = min(row_len(i), k0 + (e_hi - e));
@@ -1147,7 +1390,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
           int tot_keep;
           int wpos = block_excl_scan<NW>(my_keep, wave_tot + 2 * NW, tot_keep);
           if (my_keep) {
-            int i = -1, ro = 0, rl = 0;  // row of the entry being visited (children are walked in order)
+            int i = row0, ro = row_off(row0), rl = row_len(row0);  // row of the entry being visited (children are walked in order)
             for (int e = e_lo; e < e_hi; ++e) {
               const bool k = (e - e_lo < 64) ? (((keep_bits >> (e - e_lo)) & 1ull) != 0) : keeps(e);
               if (!k || wpos >= beam) continue;
@@ -1156,7 +1399,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
                 surv[wpos++] = e;
               } else {
                 const int s = e - nb;
-                if (i < 0 || s >= ro + rl) { i = row_of(s); ro = row_off(i); rl = row_len(i); }
+                while (s >= ro + rl) { ++i; ro += rl; rl = row_len(i); }
                 surv_lp[wpos] = score_of_key(lkey[e]);  // the extension's log-probability, computed once in (e)
                 surv[wpos++] = kChildBit | (i << 14) | (s - ro);
               }
@@ -1171,7 +1414,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
             }
           }
         }
-        if (my_flag >= 0) lex[my_flag] = 0;
+        if (WIDE && my_flag >= 0) lex[my_flag] = 0;
         list_barrier();
         TS(6);
         return sh_i[1] == 0;
@@ -1185,7 +1428,8 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
         break;
       }
       clip = false;  // the bound of a clipped row reaches into the selection: full rows
-      lds_barrier();  // (sh_i[1] is re-armed by the next round)
+      if (tid == 0) { sh_i[1] = 0; sh_i[2] = 0; sh_i[3] = 0; }
+      lds_barrier();
     }
     if (k_sel < 0) break;  // no scratch for a list that needs it (status set)
     int n_nodes_next;
@@ -1227,9 +1471,10 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
       my_char = miss;  // (re-used below: 1 = a new node, 0 = a revived one)
       n_nodes_next = n_nodes + n_miss;
     }
-    // newpos[] of THIS frame was consumed in (d); it now takes the slots of the hypotheses that stay
-    if (tid < beam) { newpos[tid] = -1; rank_of[tid] = 0; }
-    lds_barrier();
+    if (!WIDE && tid < beam) {  // the "child exists" bits of this frame
+#pragma unroll
+      for (int j = 0; j < kMaskWords; ++j) cmask[tid * kMaskWords + j] = 0;
+    }
     if (tid < k_sel) {
       const int pos = tid;
       const int code = surv[pos];
@@ -1277,7 +1522,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
     for (int k = tid; k < C; k += BT) kidx[cand_c(k)] = -1;  // reset for the next frame
     lds_barrier();
     TS(7);
-    nb = k_sel;
+    nb = __builtin_amdgcn_readfirstlane(k_sel);
     n_nodes = n_nodes_next;
     if (cfg.node_table) __threadfence_block();  // its entries are looked up by other threads of this block in later frames
     if (n_nodes + beam > cfg.max_nodes) {  // arena exhausted: report, stop consuming frames
@@ -1289,10 +1534,13 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
   }
   __syncthreads();
 #ifdef PPASR_BEAM_TS
+  if (tid == BT - 64 && u == 0 && n_frames > 0)
+    printf("last wave (x10ns/frame): to-d %lld rank-loop %lld scan+rows %lld barrier %lld\n", tw_acc[0] / n_frames, tw_acc[1] / n_frames,
+           tw_acc[2] / n_frames, tw_acc[3] / n_frames);
   if (tid == 0 && u == 0 && n_frames > 0)
-    printf("beam ts (x10ns/frame): inst %lld lm %lld contrib+rank %lld keys %lld sel %lld keep %lld mat %lld | list %lld C %lld nb %lld frames %d | "
+    printf("beam ts (x10ns/frame): [d %lld rank %lld] inst %lld lm %lld contrib+rank %lld keys %lld sel %lld keep %lld mat %lld | list %lld C %lld nb %lld frames %d | "
            "rounds: clipped %lld verified %lld short-list %lld hbm %lld\n",
-           ts_acc[0] / n_frames, ts_acc[1] / n_frames, ts_acc[2] / n_frames, ts_acc[3] / n_frames, ts_acc[5] / n_frames,
+           ts_acc[8] / n_frames, ts_acc[9] / n_frames, ts_acc[0] / n_frames, ts_acc[1] / n_frames, ts_acc[2] / n_frames, ts_acc[3] / n_frames, ts_acc[5] / n_frames,
            ts_acc[6] / n_frames, ts_acc[7] / n_frames, ts_n / n_frames, ts_c / n_frames, ts_nb / n_frames, n_frames, ts_att, ts_ok,
            ts_small, ts_hbm);
 #endif
@@ -1432,8 +1680,6 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
 //   * survivors are placed in element order with ballot prefix counts; only the new beam passes through LDS (scatter).
 // Same arithmetic, same keys, same order as k_ctc_beam: the two kernels return identical beams (tests run both).
 namespace {
-__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
   x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x111, 0xf, 0xf, false));
   x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x112, 0xf, 0xf, false));
@@ -1855,7 +2101,8 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
   // block-wide steps, and a barrier over few waves is cheaper than one over 16
   const size_t n_elem = (size_t)cfg.beam * (1 + (size_t)cfg.n_cand_max);
   // 512 threads up to 1 024 elements, else 1 024 (beams are at most 512: one slot of the new beam per thread either way)
-  const int sel = (n_elem <= 1024) ? 0 : 1;
+  int sel = (n_elem <= 1024 || cfg.beam <= 128) ? 0 : 1;  // (measured: beam 100 12.2 us / frame on 512 threads, 14.7 on 1 024; beam 300 25.4 / 20.7)
+  if (const char* e = getenv("PPASR_BEAM_BT")) sel = atoi(e) >= 1024 ? 1 : 0;  // (tuning knob)
   const bool wl = cfg.lm.order > 0 && cfg.lm.word_based != 0;
   // scratch: [wide pruning records] [per-utterance element lists]
   const size_t rec_bytes = (scratch_rec_bytes(cfg, B, T) + 255) & ~(size_t)255, list_stride = scratch_list_bytes_per_utt(cfg);

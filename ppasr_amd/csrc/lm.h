@@ -221,7 +221,8 @@ __device__ inline void lm_context_acc(const LmDev& lm, const int32_t* ctx, float
 
 // Scorer::get_log_cond_prob of the window (ctx, word) with the context summary `acc` of lm_context_acc(ctx): the n-grams
 // that end in `word` are probed together, the highest order that exists decides.  Equal to lm_log_cond_prob bit for bit.
-__device__ inline double lm_pair_log_cond_prob(const LmDev& lm, const int32_t* ctx, const float* acc, int32_t word) {
+// `uni`: log10 P of the unigram of `word` (lm.uni_prob[word]; NaN when there is none)
+__device__ inline double lm_pair_log_cond_prob(const LmDev& lm, const int32_t* ctx, const float* acc, int32_t word, float uni) {
   if (acc[0] != 0.f || word == 0) return kLmOovScore;
   const int order = lm.order;
   uint64_t key[kLmMaxOrder];
@@ -243,9 +244,12 @@ __device__ inline double lm_pair_log_cond_prob(const LmDev& lm, const int32_t* c
 #pragma unroll
   for (int j = kLmMaxOrder - 1; j >= 1; --j)
     if (found[j]) return (double)(acc[j + 1] + p[j]) / (double)kLmLog10E;
-  const float u = word < lm.n_words ? lm.uni_prob[word] : __builtin_nanf("");
-  if (u != u) return kLmOovScore;  // (the unigram of an in-vocabulary word always exists; defensive)
-  return (double)(acc[1] + u) / (double)kLmLog10E;
+  if (uni != uni) return kLmOovScore;  // (the unigram of an in-vocabulary word always exists; defensive)
+  return (double)(acc[1] + uni) / (double)kLmLog10E;
+}
+__device__ inline double lm_pair_log_cond_prob(const LmDev& lm, const int32_t* ctx, const float* acc, int32_t word) {
+  const float u = (word > 0 && word < lm.n_words) ? lm.uni_prob[word] : __builtin_nanf("");
+  return lm_pair_log_cond_prob(lm, ctx, acc, word, u);
 }
 
 }  // namespace ppasr

@@ -32,9 +32,44 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _hip_records(*tensors):
+    """Device records are packed / unpacked by the library's own kernels (ppasr_hyp_pack / ppasr_hyp_unpack: one launch
+    each); host tensors (the gloo tests of the plan and gather logic) by the plain tensor expressions below."""
+    return all(t.is_cuda for t in tensors)
+
+
+def _hip_pack(tokens, n_tokens, score, index, rec, row0, cols, extra):
+    lib = _lib.load()
+    tokens = tokens if (tokens.dtype == torch.int32 and tokens.stride(1) == 1) else tokens.to(torch.int32).contiguous()
+    n_tokens = n_tokens if n_tokens.dtype == torch.int32 else n_tokens.to(torch.int32)
+    score = score if score.dtype == torch.float64 else score.to(torch.float64)
+    k, L = tokens.shape
+    with torch.cuda.device(rec.device):
+        _lib.check(lib.ppasr_hyp_pack(tokens.data_ptr(), tokens.stride(0), L, n_tokens.data_ptr(), n_tokens.stride(0),
+                                      score.data_ptr(), score.stride(0), None if index is None else index.data_ptr(), k,
+                                      rec.data_ptr(), row0, cols, extra, torch.cuda.current_stream(rec.device).cuda_stream))
+
+
+def _hip_unpack(rec, order, n_rows, cols, extra, want_index=False):
+    lib = _lib.load()
+    dev = rec.device
+    tokens = torch.empty(n_rows, cols, dtype=torch.int32, device=dev)
+    n_tokens = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    score = torch.empty(n_rows, dtype=torch.float64, device=dev)
+    index = torch.empty(n_rows, dtype=torch.int32, device=dev) if want_index else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.ppasr_hyp_unpack(rec.data_ptr(), None if order is None else order.data_ptr(), n_rows, cols, extra,
+                                        tokens.data_ptr(), n_tokens.data_ptr(), score.data_ptr(),
+                                        None if index is None else index.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+    return tokens, n_tokens, score, index
+
+
 def pack_hypotheses(tokens, n_tokens, score):
     B, Tp = tokens.shape
     rec = torch.empty(B, Tp + 3, dtype=torch.int32, device=tokens.device)
+    if _hip_records(tokens, n_tokens, score):
+        _hip_pack(tokens, n_tokens, score, None, rec, 0, Tp, 3)
+        return rec
     rec[:, :Tp] = tokens
     rec[:, Tp] = n_tokens
     rec[:, Tp + 1:] = score.to(torch.float64).contiguous().view(torch.int32).view(B, 2)
@@ -43,6 +78,9 @@ def pack_hypotheses(tokens, n_tokens, score):
 
 def unpack_hypotheses(rec):
     Tp = rec.shape[1] - 3
+    if rec.is_cuda:
+        tokens, n_tokens, score, _ = _hip_unpack(rec, None, rec.shape[0], Tp, 3)
+        return tokens, n_tokens, score
     tokens = rec[:, :Tp]
     n_tokens = rec[:, Tp]
     score = rec[:, Tp + 1:].contiguous().view(torch.float64).view(-1)
@@ -309,6 +347,7 @@ class RaggedPlan:
             self.batches.append((torch.tensor(idx, dtype=torch.int32, device=self.dev), x, lens, frame_lens))
             self.hints.append([int(self.lengths[i]) for i in idx] if hasattr(model, "set_lengths_hint") else None)
         self.cuda = self.dev.type == "cuda"
+        self._rec = self._gathered = None  # device record buffers, kept across runs (see _record)
         self.pipeline = bool(pipeline) and self.cuda
         # (plain streams: the search's workgroups and the encoder's share the chip.  Giving each side its own CUs through
         #  hipExtStreamCreateWithCUMask was measured -- tools/cu_mask_probe.hip, NOTES.md 9.5 -- and is slower: 8.9 ms per
@@ -328,9 +367,21 @@ class RaggedPlan:
                         t.record_stream(self.dec_stream)
 
     def _record(self, outs):
-        """int32 [rows, cols + 4] record of this rank, assembled on the device with whole-batch copies (no per-row
-        host work): tokens (-1 padded) | n_tokens | score (f64 as two words) | utterance index (-1: unused row)."""
+        """int32 [rows, cols + 4] record of this rank: tokens (-1 padded) | n_tokens | score (f64 as two words) |
+        utterance index (-1: unused row).  On the device: ONE launch of the library's packing kernel per decoder call into
+        a record buffer that is kept across runs (rows this rank never uses were set to -1 once; the buffer is only touched
+        in stream order -- pack, gather, unpack of run i come before the pack of run i + 1 on the same stream)."""
         cols = self.cols
+        if self.cuda and all(t.is_cuda for o in outs for t in o):
+            if self._rec is None:
+                self._rec = torch.full((self.rows, cols + 4), -1, dtype=torch.int32, device=self.dev)
+            r = 0
+            for (idx, _x, _l, _fl), (tokens, n, score) in zip(self.batches, outs):
+                if int(tokens.shape[1]) > cols and bool((n > cols).any()):
+                    raise ValueError(f"a hypothesis is longer than the record's {cols} columns")
+                _hip_pack(tokens, n, score, idx, self._rec, r, cols, 4)  # (columns beyond `cols` are not read)
+                r += tokens.shape[0]
+            return self._rec
         rec = torch.full((self.rows, cols + 4), -1, dtype=torch.int32, device=self.dev)
         r = 0
         for (idx, _x, _l, _fl), (tokens, n, score) in zip(self.batches, outs):
@@ -347,6 +398,9 @@ class RaggedPlan:
 
     def _unpack(self, out):
         cols = self.cols
+        if out.is_cuda:
+            tokens, n, score, self.last_index_column = _hip_unpack(out, self.order, self.n_total, cols, 4, want_index=True)
+            return tokens, n, score
         g = out[self.order.to(out.device)]
         score = g[:, cols + 1:cols + 3].contiguous().view(torch.float64).view(-1)
         return g[:, :cols], g[:, cols], score
@@ -407,9 +461,12 @@ class RaggedPlan:
             if self.dist is None:
                 out = rec
             else:
-                out = torch.empty(self.world * self.rows, self.cols + 4, dtype=torch.int32, device=rec.device)
+                if self._gathered is None or self._gathered.device != rec.device:
+                    self._gathered = torch.empty(self.world * self.rows, self.cols + 4, dtype=torch.int32, device=rec.device)
+                out = self._gathered
                 _all_gather_rows(out, rec, self.dist, self.group)
-            self.last_index_column = out[self.order.to(out.device), self.cols + 3]
+            if not out.is_cuda:
+                self.last_index_column = out[self.order.to(out.device), self.cols + 3]
             return self._unpack(out)
 
     def sync(self):

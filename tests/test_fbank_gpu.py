@@ -59,8 +59,8 @@ def test_mean_square_bit_exact_for_every_last_chunk_length():
     one level deeper than a full chunk's (8191 -> ... -> 135 -> 71: depth 7); lengths with n % 8192 in 7689..8191 used to
     read unwritten LDS (round-5 advisor finding).  Sweep that whole range, plus a coarse sweep of the rest, with zero, one
     and two preceding full chunks: the per-chunk sums the kernel leaves in its workspace, added in chunk order, must equal
-    np.add.reduce(x ** 2) bit for bit, and the gain must be db_gain's (<= 1 ulp: numpy's float32 log10 is libm's log10f,
-    the kernel rounds a double log10)."""
+    np.add.reduce(x ** 2) bit for bit, and the gain must be db_gain's to a few ulp (numpy's float32 log10 is libm's
+    log10f, the kernel rounds a double log10: one ulp of rms_db is two of the gain)."""
     from ppasr_amd.data_utils.featurizer import AudioFeaturizer, db_gain
     f = AudioFeaturizer(n_mels=80, sample_rate=16000, use_dB_normalization=True, target_dB=-20)
     base = _audio(1.6, seed=11)
@@ -82,7 +82,7 @@ def test_mean_square_bit_exact_for_every_last_chunk_length():
             if acc.tobytes() != np.add.reduce(wav ** 2).tobytes():
                 bad.append(n)
             g = np.float32(db_gain(wav, -20))
-            if abs(float(np.float32(f.last_gain)) - float(g)) > float(np.spacing(g)):
+            if abs(float(np.float32(f.last_gain)) - float(g)) > 4 * float(np.spacing(g)):
                 bad_gain.append(n)
     assert not bad, bad[:20]
     assert not bad_gain, bad_gain[:20]
