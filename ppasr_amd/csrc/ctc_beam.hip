@@ -580,7 +580,9 @@ __global__ __launch_bounds__(kWideThreads) void k_ctc_prune_wide(const float* __
 // candidates (~ beam ln beam entries instead of beam x C), the top-`beam` is taken on the clipped list and VERIFIED:
 // the bound U(i, len(i)) of every clipped row must sort strictly behind the last key taken.  If not, the frame is redone
 // with full rows.  The result is therefore the full-row result bit for bit: same survivors, same order, same node ids.
-template <int BT, bool WORD_LM, bool WIDE>
+// LM: 0 no scorer, 1 character-based, 2 word-based (compile-time: the scorer's look-ups cost ~80 registers, which a
+// 1 024-thread workgroup -- 128 per lane -- does not have to spare on the scorer-less path)
+template <int BT, int LM, bool WIDE>
 __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ probs, const int32_t* __restrict__ frame_lens,
                                                   int T, BeamConfig cfg, const int32_t* __restrict__ recs,
                                                   int32_t* __restrict__ state, int init_state,
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u = blockIdx.x;
   const int V = cfg.V, beam = cfg.beam, blank = cfg.blank, CM = cfg.n_cand_max;
-  const bool has_lm = cfg.lm.order > 0;
+  constexpr bool has_lm = LM != 0;
   const BeamLdsPlan plan = beam_lds_plan(beam, V, cfg.list_cap, has_lm, WIDE);
   int* hist = reinterpret_cast<int*>(smem + plan.hist);
   int* wave_tot = reinterpret_cast<int*>(smem + plan.wtot);
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
     lkey_g = reinterpret_cast<uint32_t*>(scratch_lists + (size_t)u * scratch_list_stride);
     lex_g = reinterpret_cast<uint8_t*>(lkey_g + (size_t)beam * (1 + (size_t)CM));
   }
-  constexpr bool word_lm = WORD_LM;  // scorer consulted at spaces, prefixes constrained by the dictionary (lm.word_based)
+  constexpr bool word_lm = LM == 2;  // scorer consulted at spaces, prefixes constrained by the dictionary (lm.word_based)
   const int space_id = cfg.lm.space_id;
   float* lm_acc = reinterpret_cast<float*>(smem + plan.lmacc);  // [beam][kLmAccWords] context summaries (scorer only)
   constexpr int kChildBit = 0x40000000;  // survivor code of a child: kChildBit | row << 14 | candidate (rows < 512, candidates < 16384)
@@ -2148,26 +2150,26 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
                    init_state, finalize, out_tokens, out_lens, out_scores, status);
     return hipGetLastError();
   }
-#define PPASR_LAUNCH_BEAM(BT, WL, WIDE)                                                                                 \
+#define PPASR_LAUNCH_BEAM(BT, LMK, WIDE)                                                                                \
   do {                                                                                                                  \
-    const void* fn = reinterpret_cast<const void*>(k_ctc_beam<BT, WL, WIDE>);                                           \
+    const void* fn = reinterpret_cast<const void*>(k_ctc_beam<BT, LMK, WIDE>);                                          \
     if (lds > 48 * 1024) {                                                                                              \
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
       if (e != hipSuccess) return e;                                                                                    \
     }                                                                                                                   \
-    PPASR_LAUNCH((k_ctc_beam<BT, WL, WIDE>), dim3(B), dim3(BT), lds, st, probs, frame_lens, T, cfg, recs, state,        \
+    PPASR_LAUNCH((k_ctc_beam<BT, LMK, WIDE>), dim3(B), dim3(BT), lds, st, probs, frame_lens, T, cfg, recs, state,       \
                  init_state, finalize, out_tokens, out_lens, out_scores, status, lists, list_stride);                   \
   } while (0)
-  if (wide) {  // (wide records: always 1 024 threads)
-    if (wl) PPASR_LAUNCH_BEAM(1024, true, true);
-    else PPASR_LAUNCH_BEAM(1024, false, true);
-  } else if (sel == 0) {
-    if (wl) PPASR_LAUNCH_BEAM(512, true, false);
-    else PPASR_LAUNCH_BEAM(512, false, false);
-  } else {
-    if (wl) PPASR_LAUNCH_BEAM(1024, true, false);
-    else PPASR_LAUNCH_BEAM(1024, false, false);
-  }
+#define PPASR_LAUNCH_BEAM_LM(BT, WIDE)                                                                                  \
+  do {                                                                                                                  \
+    if (wl) PPASR_LAUNCH_BEAM(BT, 2, WIDE);                                                                             \
+    else if (cfg.lm.order > 0) PPASR_LAUNCH_BEAM(BT, 1, WIDE);                                                          \
+    else PPASR_LAUNCH_BEAM(BT, 0, WIDE);                                                                                \
+  } while (0)
+  if (wide) PPASR_LAUNCH_BEAM_LM(1024, true);  // (wide records: always 1 024 threads)
+  else if (sel == 0) PPASR_LAUNCH_BEAM_LM(512, false);
+  else PPASR_LAUNCH_BEAM_LM(1024, false);
+#undef PPASR_LAUNCH_BEAM_LM
 #undef PPASR_LAUNCH_BEAM
   return hipGetLastError();
 }

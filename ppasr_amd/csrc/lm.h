@@ -145,14 +145,17 @@ __device__ inline double lm_log_cond_prob(const LmDev& lm, const int32_t* win /*
 }
 
 // ---- the factorised form (see the header comment) ----
-// Probes of up to kLmMaxOrder keys issued TOGETHER: both candidate slots of every key are requested before the first is
-// looked at (load factor <= 1/3: a key or the end of its cluster is in the first two slots in ~95 % of the probes; the
-// rest continue slot by slot).  want[j] selects the keys; found[j] / prob[j] / backoff[j] are the results.
+// Probes of up to kLmPar keys issued TOGETHER: both candidate slots of every key are requested before the first is looked
+// at (load factor <= 1/3: a key or the end of its cluster is in the first two slots in ~95 % of the probes; the rest
+// continue slot by slot).  want[j] selects the keys; found[j] / prob[j] / backoff[j] are the results.  (Three at a time:
+// the slots in flight are registers, and a 1 024-thread search workgroup has 128 per lane; orders above 4 take a second
+// round.)
+constexpr int kLmPar = 3;
 __device__ inline void lm_probe_many(const LmDev& lm, const uint64_t* key, const bool* want, bool* found, float* prob,
                                      float* backoff) {
-  LmSlot s0[kLmMaxOrder], s1[kLmMaxOrder];
+  LmSlot s0[kLmPar], s1[kLmPar];
 #pragma unroll
-  for (int j = 0; j < kLmMaxOrder; ++j) {
+  for (int j = 0; j < kLmPar; ++j) {
     if (want[j]) {
       const uint32_t slot = lm_slot_of(key[j], lm.mask);
       s0[j] = lm.slots[slot];
@@ -160,7 +163,7 @@ __device__ inline void lm_probe_many(const LmDev& lm, const uint64_t* key, const
     }
   }
 #pragma unroll
-  for (int j = 0; j < kLmMaxOrder; ++j) {
+  for (int j = 0; j < kLmPar; ++j) {
     found[j] = false;
     prob[j] = 0.f;
     backoff[j] = 0.f;
@@ -191,59 +194,93 @@ __device__ inline void lm_context_acc(const LmDev& lm, const int32_t* ctx, float
   const int order = lm.order;
   bool oov = false;
   for (int i = 0; i < order - 1; ++i) oov |= ctx[i] == 0;
-  uint64_t key[kLmMaxOrder];
-  bool want[kLmMaxOrder], found[kLmMaxOrder];
-  float p[kLmMaxOrder], b[kLmMaxOrder];
+  // back-off of the m-gram = last m context words, m = 1 .. order - 1, in rounds of kLmPar (the fold runs newest -> oldest)
+  float bo[kLmMaxOrder];
+  bool has[kLmMaxOrder];
+#pragma unroll
+  for (int m = 0; m < kLmMaxOrder; ++m) { bo[m] = 0.f; has[m] = false; }
   uint64_t h = 0;
 #pragma unroll
-  for (int m = 1; m < kLmMaxOrder; ++m) {  // the m-gram = last m context words -> index m
-    want[m] = !oov && m <= order - 1;
-    key[m] = 0;
-    if (m <= order - 1) {
-      const uint32_t w = (uint32_t)ctx[order - 1 - m];
-      h = m == 1 ? lm_fold_init(lm.kenlm_keys, w) : lm_fold(lm.kenlm_keys, h, w);
-      key[m] = lm_fold_key(lm.kenlm_keys, h, m);
+  for (int r0 = 1; r0 < kLmMaxOrder; r0 += kLmPar) {
+    if (r0 <= order - 1) {
+      uint64_t key[kLmPar];
+      bool want[kLmPar], found[kLmPar];
+      float p[kLmPar], b[kLmPar];
+#pragma unroll
+      for (int j = 0; j < kLmPar; ++j) {
+        const int m = r0 + j;
+        want[j] = !oov && m <= order - 1;
+        key[j] = 0;
+        if (m <= order - 1) {
+          const uint32_t w = (uint32_t)ctx[order - 1 - m];
+          h = m == 1 ? lm_fold_init(lm.kenlm_keys, w) : lm_fold(lm.kenlm_keys, h, w);
+          key[j] = lm_fold_key(lm.kenlm_keys, h, m);
+        }
+      }
+      lm_probe_many(lm, key, want, found, p, b);
+#pragma unroll
+      for (int j = 0; j < kLmPar; ++j)
+        if (r0 + j < kLmMaxOrder) { bo[r0 + j] = b[j]; has[r0 + j] = found[j]; }
     }
   }
-  want[0] = false;
-  key[0] = 0;
-  lm_probe_many(lm, key, want, found, p, b);
   acc[0] = oov ? 1.f : 0.f;
   float a = 0.f;
 #pragma unroll
   for (int n = kLmMaxOrder; n >= 1; --n) {
     if (n <= order) {
       acc[n] = a;
-      if (n >= 2 && found[n - 1]) a += b[n - 1];
+      if (n >= 2 && has[n - 1]) a += bo[n - 1];
     }
   }
 }
 
 // Scorer::get_log_cond_prob of the window (ctx, word) with the context summary `acc` of lm_context_acc(ctx): the n-grams
-// that end in `word` are probed together, the highest order that exists decides.  Equal to lm_log_cond_prob bit for bit.
-// `uni`: log10 P of the unigram of `word` (lm.uni_prob[word]; NaN when there is none)
+// that end in `word` are probed together (highest orders first, kLmPar at a time), the highest order that exists decides.
+// Equal to lm_log_cond_prob bit for bit.  `uni`: log10 P of the unigram of `word` (lm.uni_prob[word]; NaN: none)
 __device__ inline double lm_pair_log_cond_prob(const LmDev& lm, const int32_t* ctx, const float* acc, int32_t word, float uni) {
   if (acc[0] != 0.f || word == 0) return kLmOovScore;
   const int order = lm.order;
-  uint64_t key[kLmMaxOrder];
-  bool want[kLmMaxOrder], found[kLmMaxOrder];
-  float p[kLmMaxOrder], b[kLmMaxOrder];
+  // keys of the n-grams ending in `word`, n = 2 .. order (the fold runs newest -> oldest: all of them are computed first)
+  uint64_t keyn[kLmMaxOrder + 1];
   uint64_t h = lm_fold_init(lm.kenlm_keys, (uint32_t)word);
-  want[0] = false;
-  key[0] = 0;
 #pragma unroll
-  for (int j = 1; j < kLmMaxOrder; ++j) {  // index j: the (j + 1)-gram ending in `word`
-    want[j] = j + 1 <= order;
-    key[j] = 0;
-    if (j + 1 <= order) {
-      h = lm_fold(lm.kenlm_keys, h, (uint32_t)ctx[order - 1 - j]);
-      key[j] = lm_fold_key(lm.kenlm_keys, h, j + 1);
+  for (int n = 2; n <= kLmMaxOrder; ++n) {
+    keyn[n] = 0;
+    if (n <= order) {
+      h = lm_fold(lm.kenlm_keys, h, (uint32_t)ctx[order - n]);
+      keyn[n] = lm_fold_key(lm.kenlm_keys, h, n);
     }
   }
-  lm_probe_many(lm, key, want, found, p, b);
 #pragma unroll
-  for (int j = kLmMaxOrder - 1; j >= 1; --j)
-    if (found[j]) return (double)(acc[j + 1] + p[j]) / (double)kLmLog10E;
+  for (int r = 0; r < (kLmMaxOrder - 1 + kLmPar - 1) / kLmPar; ++r) {
+    const int n_hi = order - kLmPar * r;  // this round: n_hi, n_hi - 1, ... (>= 2)
+    if (n_hi >= 2) {
+      uint64_t key[kLmPar];
+      bool want[kLmPar], found[kLmPar];
+      float p[kLmPar], b[kLmPar];
+#pragma unroll
+      for (int j = 0; j < kLmPar; ++j) {
+        const int n = n_hi - j;
+        want[j] = n >= 2;
+        key[j] = 0;
+#pragma unroll
+        for (int q = 2; q <= kLmMaxOrder; ++q)
+          if (q == n) key[j] = keyn[q];
+      }
+      lm_probe_many(lm, key, want, found, p, b);
+#pragma unroll
+      for (int j = 0; j < kLmPar; ++j) {
+        if (found[j]) {
+          const int n = n_hi - j;
+          float a = 0.f;
+#pragma unroll
+          for (int q = 1; q <= kLmMaxOrder; ++q)
+            if (q == n) a = acc[q];
+          return (double)(a + p[j]) / (double)kLmLog10E;
+        }
+      }
+    }
+  }
   if (uni != uni) return kLmOovScore;  // (the unigram of an in-vocabulary word always exists; defensive)
   return (double)(acc[1] + uni) / (double)kLmLog10E;
 }
