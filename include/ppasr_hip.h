@@ -366,6 +366,11 @@ PPASR_API ppasr_status ppasr_stream_import_cache(ppasr_stream s, const float* at
  * another stream / process) the call re-runs on the per-step kernels before it returns, and the handle stays on those for
  * the next 64 .. 1 024 calls before it tries the persistent route again.  PPASR_DS2_PERSIST=0 switches the route off. */
 PPASR_API size_t ppasr_ds2_workspace_bytes(ppasr_handle h, int B, int T);
+/* Test hook, not part of any product path: `n_workgroups` workgroups that each take a whole CU (1 024 threads, 128
+ * registers per lane) and spin for `milliseconds` on `stream`.  With part of the chip held like this the persistent
+ * recurrence above cannot become fully resident and gives up: the tests check that the call then returns the per-step
+ * kernels' result. */
+PPASR_API ppasr_status ppasr_debug_occupy_cus(int n_workgroups, int milliseconds, void* stream);
 PPASR_API ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, const int64_t* lens, int B, int T, const float* init_h,
                               const float* init_c, float* probs, int64_t* out_lens, float* final_h, float* final_c,
                               void* workspace, size_t workspace_bytes, void* stream);

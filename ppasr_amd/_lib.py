@@ -86,6 +86,7 @@ SYMBOLS = [
     ("ppasr_ds2_workspace_bytes", ctypes.c_size_t, [_vp, ctypes.c_int, ctypes.c_int]),
     ("ppasr_ds2_encode", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                         ctypes.c_size_t, _vp]),
+    ("ppasr_debug_occupy_cus", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp]),
     ("ppasr_profile_enable", ctypes.c_int, [_vp, ctypes.c_int]),
     ("ppasr_profile_read", ctypes.c_int, [_vp, c_f32p, c_i32p]),
     ("ppasr_kernel_class_name", ctypes.c_char_p, [ctypes.c_int]),

@@ -286,7 +286,7 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
   }
   // (PPASR_DS2_PERSIST=0, read per call: the per-step kernels, for A/B measurements and the route-equality test)
   const char* persist_env = getenv("PPASR_DS2_PERSIST");
-  const bool persist_shape = B == 1 && G == 4 && H == 1024 && Tp > 0 && !(persist_env && persist_env[0] == '0') && lstm_persist_fits(H, dirs);
+  const bool persist_shape = B == 1 && (G == 4 || G == 3) && H == 1024 && Tp > 0 && !(persist_env && persist_env[0] == '0') && lstm_persist_fits(H, dirs);
   const bool persist = persist_shape && h->ds2_persist_hold == 0;
   if (persist_shape && h->ds2_persist_hold > 0) --h->ds2_persist_hold;
   if (persist) {
@@ -312,8 +312,8 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
     // the matrix-core step needs H % 64 == 0 (8 waves x whole 8-wide k-groups); the VALU kernel handles the rest
     const bool mfma_step = (H % 64 == 0) && B >= 2;  // (one utterance: the VALU kernel's 5.8 us per step is the faster one)
     if (persist) {
-      // one utterance, LSTM, H = 1024: the layer's recurrence as ONE launch with W_hh in registers (ds2_kernels.hip)
-      launch_lstm_persist(gx, Lw.w_hh, h0, c, h1, out, lens32, Tp, H, dirs, reinterpret_cast<unsigned long long*>(ws + wl.xbuf),
+      // one utterance, LSTM or GRU, H = 1024: the layer's recurrence as ONE launch with W_hh in registers (ds2_kernels.hip)
+      launch_lstm_persist(gx, Lw.w_hh, Lw.b_hh, G == 3, h0, c, h1, out, lens32, Tp, H, dirs, reinterpret_cast<unsigned long long*>(ws + wl.xbuf),
                           1u + (unsigned int)l * (unsigned int)(Tp + 1), reinterpret_cast<int*>(ws + wl.pflag), st);
       hp = h1;
     } else
@@ -348,5 +348,14 @@ extern "C" ppasr_status ppasr_ds2_encode(ppasr_handle h, const float* feats, con
                               stream);
     }
   }
+  return PPASR_OK;
+}
+
+// Test hook (not used by any product path): holds `n_workgroups` whole CUs for `milliseconds` on `stream` (ds2_kernels.hip
+// k_occupy).  tests/test_deepspeech2_gpu.py forces the persistent recurrence's give-up path with it.
+extern "C" ppasr_status ppasr_debug_occupy_cus(int n_workgroups, int milliseconds, void* stream) {
+  if (n_workgroups <= 0 || milliseconds <= 0 || milliseconds > 5000) return fail(PPASR_EINVAL, "occupy: bad arguments");
+  launch_occupy(n_workgroups, milliseconds, nullptr, static_cast<hipStream_t>(stream));
+  HIP_TRY(hipGetLastError());
   return PPASR_OK;
 }

@@ -909,16 +909,27 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
     TW(0);
     // ---- clipped rows: rank of every hypothesis by its CURRENT score (the rows of the staircase), row lengths, offsets ----
     int NLc_clip = 0;  // child entries of the clipped list
+    // a / per for 0 <= a < 2^22 without the integer-division sequence (two of them sat on every row thread's critical path)
+    auto div_per = [&](int a, int per) -> int {
+      int q = (int)((float)a * __builtin_amdgcn_rcpf((float)per));
+      if (q * per > a) --q;
+      if ((q + 1) * per <= a) ++q;
+      return q;
+    };
     auto write_first_rows = [&](int i, int my_off, int my_len, int per) {
       // first_row[t] = row holding the first child entry of thread t's range [t*per, (t+1)*per) of the list (threads whose
       // range ends inside the hypotheses need none): row i covers child entries [my_off, my_off + my_len)
       if (my_len <= 0) return;
-      const int t0 = nb / per;  // first thread whose range reaches the children; its first child entry is 0
-      int tt = (nb + my_off + per - 1) / per;
+      const int t0 = div_per(nb, per);  // first thread whose range reaches the children; its first child entry is 0
+      int tt = div_per(nb + my_off + per - 1, per);
       if (tt < t0 || my_off == 0) tt = t0;
       for (; tt < BT && max(0, tt * per - nb) < my_off + my_len; ++tt) first_row[tt] = (int16_t)i;
     };
-    auto per_of = [&](int NL) -> int { return (NL <= kSmallList && cfg.fast_path != 0 && NL <= cfg.list_cap) ? 1 : (((NL + BT - 1) / BT) | 1); };
+    // entries per thread of the radix path (an ODD range length: thread t starts at word t*per of the list, and an even
+    // stride would put the 64 lanes of a wave on 16 or fewer of the 64 LDS banks); 1 on the short-list path
+    auto per_of = [&](int NL) -> int {
+      return (NL <= kSmallList && cfg.fast_path != 0 && NL <= cfg.list_cap) ? 1 : (((NL + BT - 1) / BT) | 1);
+    };
     if (clip && nb <= 64) {
       // up to 64 hypotheses: ONE wave (the last: (d) runs in the first) does the whole computation in registers -- no
       // atomics, no scan across waves, no barrier of its own (the results are read behind the barrier that closes (d))
@@ -995,10 +1006,18 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
         {  // rank of every key = number of smaller keys (keys are unique: the id is part of them): wave w ranks the keys
            // w, w + NW, ...
           const unsigned long long k0 = lane < n_s0 ? fkey[lane] : ~0ull, k1 = lane + 64 < n_s0 ? fkey[lane + 64] : ~0ull;
-          for (int i = wave; i < n_s0; i += NW) {
-            const unsigned long long ki = fkey[i];
-            const int rank = __popcll(__ballot(k0 < ki)) + __popcll(__ballot(k1 < ki));
-            if (lane == 0 && ki != ~0ull && rank < beam) srank_key[rank] = ki;
+          if (n_s0 <= 64) {  // (beam 10: 57 slots -- one key per lane, one ballot per ranked key)
+            for (int i = wave; i < n_s0; i += NW) {
+              const unsigned long long ki = fkey[i];
+              const int rank = __popcll(__ballot(k0 < ki));
+              if (lane == 0 && ki != ~0ull && rank < beam) srank_key[rank] = ki;
+            }
+          } else {
+            for (int i = wave; i < n_s0; i += NW) {
+              const unsigned long long ki = fkey[i];
+              const int rank = __popcll(__ballot(k0 < ki)) + __popcll(__ballot(k1 < ki));
+              if (lane == 0 && ki != ~0ull && rank < beam) srank_key[rank] = ki;
+            }
           }
         }
         lds_barrier();
@@ -1064,6 +1083,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
           atomicAdd(&hist[bkt], 1);
         }
         lds_barrier();
+        TS(10);
         int my_len = 0;
         {
           // exclusive prefix of the 256 buckets, computed by every wave for itself (lane l: buckets 4 l .. 4 l + 3)
@@ -1083,12 +1103,14 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
           if (tid < nb) my_len = min(C, beam / (r + 1) + margin);
         }
         const int my_off = block_excl_scan<NW>(my_len, wave_tot, NLc_clip);
+        TS(11);
         if (tid < nb) {
           off[tid] = my_off;
           write_first_rows(tid, my_off, my_len, per_of(nb + NLc_clip));
         }
         if (tid == 0) off[nb] = NLc_clip;
         lds_barrier();
+        TS(12);
       }
       const int NLc = clip ? NLc_clip : nb * C;
       const int NL = nb + NLc;
@@ -1267,7 +1289,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
           // owns the contiguous range [t*per, (t+1)*per) so that the compaction below keeps list order with a single
           // block scan.  (An ODD range length: thread t starts at word t*per, and an even stride would put the 64 lanes
           // of a wave on 16 or fewer of the 64 LDS banks.) ----
-          const int per = ((NL + BT - 1) / BT) | 1;
+          const int per = per_of(NL);
           const int e_lo = min(tid * per, NL), e_hi = min(e_lo + per, NL);
           for (int i = tid; i < 8 * 256; i += BT) hist[i] = 0;  // 4 + 4 per-pass histograms of the selects below (complete
                                                                 // behind the barrier of the scan that closes (e))
@@ -1294,6 +1316,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
               }
             }
           }
+          TS(13);
           int n_valid;
           (void)block_excl_scan<NW>(my_valid, wave_tot + NW, n_valid);
           if (!kLds) __syncthreads();  // (the scan's barrier orders LDS only: the list lives in global memory here)
@@ -1540,8 +1563,9 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
     printf("last wave (x10ns/frame): to-d %lld rank-loop %lld scan+rows %lld barrier %lld\n", tw_acc[0] / n_frames, tw_acc[1] / n_frames,
            tw_acc[2] / n_frames, tw_acc[3] / n_frames);
   if (tid == 0 && u == 0 && n_frames > 0)
-    printf("beam ts (x10ns/frame): [d %lld rank %lld] inst %lld lm %lld contrib+rank %lld keys %lld sel %lld keep %lld mat %lld | list %lld C %lld nb %lld frames %d | "
+    printf("beam ts (x10ns/frame): [bucket %lld prefix+scan %lld rows %lld gen %lld] [d %lld rank %lld] inst %lld lm %lld contrib+rank %lld keys %lld sel %lld keep %lld mat %lld | list %lld C %lld nb %lld frames %d | "
            "rounds: clipped %lld verified %lld short-list %lld hbm %lld\n",
+           ts_acc[10] / n_frames, ts_acc[11] / n_frames, ts_acc[12] / n_frames, ts_acc[13] / n_frames,
            ts_acc[8] / n_frames, ts_acc[9] / n_frames, ts_acc[0] / n_frames, ts_acc[1] / n_frames, ts_acc[2] / n_frames, ts_acc[3] / n_frames, ts_acc[5] / n_frames,
            ts_acc[6] / n_frames, ts_acc[7] / n_frames, ts_n / n_frames, ts_c / n_frames, ts_nb / n_frames, n_frames, ts_att, ts_ok,
            ts_small, ts_hbm);
@@ -2103,8 +2127,11 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
   // block-wide steps, and a barrier over few waves is cheaper than one over 16
   const size_t n_elem = (size_t)cfg.beam * (1 + (size_t)cfg.n_cand_max);
   // 512 threads up to 1 024 elements, else 1 024 (beams are at most 512: one slot of the new beam per thread either way)
-  int sel = (n_elem <= 1024 || cfg.beam <= 128) ? 0 : 1;  // (measured: beam 100 12.2 us / frame on 512 threads, 14.7 on 1 024; beam 300 25.4 / 20.7)
-  if (const char* e = getenv("PPASR_BEAM_BT")) sel = atoi(e) >= 1024 ? 1 : 0;  // (tuning knob)
+  // 512 threads up to 1 024 elements and for beams up to 128, else 768 (12 waves: 170 registers per lane -- the 1 024-thread
+  // form has 128, which the scorer's look-ups overflow into scratch -- and cheaper barriers; measured, flat posteriors, us per
+  // frame on 512 / 768 / 1 024 threads: beam 100 10.8 / 11.3 / 11.5, beam 300 14.3 / 12.8 / 13.0)
+  int sel = (n_elem <= 1024 || cfg.beam <= 128) ? 0 : 2;
+  if (const char* e = getenv("PPASR_BEAM_BT")) sel = atoi(e) >= 1024 ? 1 : (atoi(e) >= 768 ? 2 : 0);  // (tuning knob)
   const bool wl = cfg.lm.order > 0 && cfg.lm.word_based != 0;
   // scratch: [wide pruning records] [per-utterance element lists]
   const size_t rec_bytes = (scratch_rec_bytes(cfg, B, T) + 255) & ~(size_t)255, list_stride = scratch_list_bytes_per_utt(cfg);
@@ -2168,6 +2195,7 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
   } while (0)
   if (wide) PPASR_LAUNCH_BEAM_LM(1024, true);  // (wide records: always 1 024 threads)
   else if (sel == 0) PPASR_LAUNCH_BEAM_LM(512, false);
+  else if (sel == 2) PPASR_LAUNCH_BEAM_LM(768, false);
   else PPASR_LAUNCH_BEAM_LM(1024, false);
 #undef PPASR_LAUNCH_BEAM_LM
 #undef PPASR_LAUNCH_BEAM

@@ -48,9 +48,10 @@ void launch_lstm_step(const float* gx, const float* whh, const float* hprev, flo
 //   gx [dirs][T][4H], h_init / h_final [dirs][H], c_state [dirs][H] (in: initial, out: final), y [T][dirs * H] pre-zeroed,
 //   lens [1] valid steps, *abort_flag != 0 afterwards: a workgroup gave up waiting -- the outputs are invalid
 bool lstm_persist_fits(int H, int dirs);
-void launch_lstm_persist(const float* gx, const float* whh, const float* h_init, float* c_state, float* h_final, float* y,
-                         const int32_t* lens, int T, int H, int dirs, unsigned long long* xbuf, unsigned int epoch, int* abort_flag,
-                         hipStream_t st);
+void launch_lstm_persist(const float* gx, const float* whh, const float* bhh, bool gru, const float* h_init, float* c_state,
+                         float* h_final, float* y, const int32_t* lens, int T, int H, int dirs, unsigned long long* xbuf,
+                         unsigned int epoch, int* abort_flag, hipStream_t st);
+void launch_occupy(int n_wg, int ms, float* sink, hipStream_t st);  // test hook: holds n_wg CUs for ms milliseconds
 // One GRU time step (paddle.nn.GRU, gate rows r, z, c):  r = s(x_r + h_r), z = s(x_z + h_z), c = tanh(x_c + r * h_c),
 // h' = (h - c) * z + c, with x_* = W_ih x + b_ih (gx [dirs][B*T][3H]) and h_* = W_hh h + b_hh.
 void launch_gru_step(const float* gx, const float* whh, const float* bhh, const float* hprev, float* hnext, float* y,

@@ -621,13 +621,18 @@ void launch_lstm_wave(const float* gx0, const Ds2WaveLayer* tab, float* hbuf, fl
 // needs all its workgroups resident (H / 8 x dirs <= CUs x occupancy, checked on the host), nothing else may hold the chip.
 constexpr int kPersistThreads = 512;
 constexpr int kPersistSpins = 200000;  // ~0.2 s
+// GRU = true (round 6): nn.GRU layers the same way -- 3 gates x 8 units = 24 of the 32 weight rows of a workgroup are in
+// use (96 KB of W_hh in registers), the recurrent parts keep their b_hh and stay apart from the input parts until the cell
+// (the candidate gate multiplies only the recurrent part by r: k_gru_step's arithmetic); there is no cell state.
+template <bool GRU>
 __global__ __launch_bounds__(kPersistThreads) void k_lstm_persist(const float* __restrict__ gx, const float* __restrict__ whh,
+                                                                  const float* __restrict__ bhh,
                                                                   const float* __restrict__ h_init, float* __restrict__ c_state,
                                                                   float* __restrict__ h_final, float* __restrict__ y,
                                                                   const int32_t* __restrict__ lens, int T, int dirs,
                                                                   unsigned long long* __restrict__ xbuf, unsigned int epoch,
                                                                   int* __restrict__ abort_flag) {
-  constexpr int H = 1024;
+  constexpr int H = 1024, NG = GRU ? 3 : 4;
   __shared__ __attribute__((aligned(16))) float hs[H];
   __shared__ float part[kPersistThreads / 64][32];
   __shared__ int s_abort;
@@ -635,26 +640,29 @@ __global__ __launch_bounds__(kPersistThreads) void k_lstm_persist(const float* _
   const int dir = blockIdx.y, u0 = blockIdx.x * 8;
   const int row = lane & 31, seg = 2 * wave + (lane >> 5);
   const int gate = row >> 3, unit = row & 7;
+  const bool live_row = gate < NG;  // (GRU: rows 24 .. 31 of the 32 carry zeros)
   float w[64];
   {
-    const float* wr = whh + ((size_t)dir * 4 * H + (size_t)gate * H + u0 + unit) * H + seg * 64;
+    const float* wr = whh + ((size_t)dir * NG * H + (size_t)(live_row ? gate : 0) * H + u0 + unit) * H + seg * 64;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(wr + 4 * i);
+      f32x4 v = *reinterpret_cast<const f32x4*>(wr + 4 * i);
+      if (!live_row) v = f32x4{0.f, 0.f, 0.f, 0.f};
       w[4 * i] = v[0]; w[4 * i + 1] = v[1]; w[4 * i + 2] = v[2]; w[4 * i + 3] = v[3];
     }
   }
   const int len = min(max(lens[0], 0), T);
-  const float* gxd = gx + (size_t)dir * T * 4 * H + (size_t)gate * H + u0 + unit;  // + t * 4H: this lane's gate row (wave 0, lanes < 32)
+  const float* gxd = gx + (size_t)dir * T * NG * H + (size_t)(live_row ? gate : 0) * H + u0 + unit;  // + t * NG * H: this lane's gate row (wave 0, lanes < 32)
   unsigned long long* xb = xbuf + (size_t)dir * H;                                  // + (slot) * dirs * H
   const bool owner = wave == 0 && lane < 8;
-  float c_reg = owner ? c_state[(size_t)dir * H + u0 + lane] : 0.f;
+  const float bh = (GRU && wave == 0 && lane < 32 && live_row) ? bhh[(size_t)dir * NG * H + (size_t)gate * H + u0 + unit] : 0.f;
+  float c_reg = (!GRU && owner) ? c_state[(size_t)dir * H + u0 + lane] : 0.f;
   float h_last = owner ? h_init[(size_t)dir * H + u0 + lane] : 0.f;
   if (tid == 0) s_abort = 0;
   for (int s = 0; s < len; ++s) {
     const int t = dir == 0 ? s : len - 1 - s;
     float gxv = 0.f;
-    if (wave == 0 && lane < 32) gxv = gxd[(size_t)t * 4 * H];  // (requested before the gather: off the critical path)
+    if (wave == 0 && lane < 32 && live_row) gxv = gxd[(size_t)t * NG * H];  // (requested before the gather: off the critical path)
     if (s == 0) {
       hs[2 * tid] = h_init[(size_t)dir * H + 2 * tid];
       hs[2 * tid + 1] = h_init[(size_t)dir * H + 2 * tid + 1];
@@ -696,7 +704,28 @@ __global__ __launch_bounds__(kPersistThreads) void k_lstm_persist(const float* _
     acc += __shfl_xor(acc, 32);
     if (lane < 32) part[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0) {
+    if (wave == 0 && GRU) {
+      // recurrent part (+ b_hh) and input part of every gate row stay apart (k_gru_step): lane u < 8 owns unit u, its
+      // gates r, z, candidate sit in lanes u, 8 + u, 16 + u
+      float rec = bh;
+      if (lane < 32) {
+#pragma unroll
+        for (int wv = 0; wv < kPersistThreads / 64; ++wv) rec += part[wv][lane];
+      }
+      const int u = lane & 7;
+      const float rr = __shfl(rec, u), rz = __shfl(rec, 8 + u), rc = __shfl(rec, 16 + u);
+      const float xr = __shfl(gxv, u), xz = __shfl(gxv, 8 + u), xc = __shfl(gxv, 16 + u);
+      if (lane < 8) {
+        const float gr = 1.0f / (1.0f + expf(-(xr + rr)));
+        const float gz = 1.0f / (1.0f + expf(-(xz + rz)));
+        const float cand = tanhf(xc + gr * rc);
+        h_last = (hs[u0 + lane] - cand) * gz + cand;
+        const unsigned long long granule = ((unsigned long long)(epoch + (unsigned int)s) << 32) | (unsigned long long)__float_as_uint(h_last);
+        __hip_atomic_store(xb + (size_t)(s & 1) * dirs * H + u0 + lane, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        y[(size_t)t * (size_t)(dirs * H) + (size_t)dir * H + u0 + lane] = h_last;
+      }
+    }
+    if (wave == 0 && !GRU) {
       float g = gxv;
       if (lane < 32) {
 #pragma unroll
@@ -719,7 +748,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_lstm_persist(const float* _
     }
   }
   if (owner) {
-    c_state[(size_t)dir * H + u0 + lane] = c_reg;
+    if (!GRU) c_state[(size_t)dir * H + u0 + lane] = c_reg;  // (GRU: the c box is handed through unchanged by the host)
     h_final[(size_t)dir * H + u0 + lane] = h_last;
   }
 }
@@ -730,16 +759,42 @@ bool lstm_persist_fits(int H, int dirs) {
   int dev = 0, cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lstm_persist, kPersistThreads, 0) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lstm_persist<false>, kPersistThreads, 0) != hipSuccess) return false;
   // (one workgroup per CU is the intended shape; a partitioned device with fewer CUs takes the per-step kernels)
   return per_cu >= 1 && cus >= (H / 8) * dirs;
 }
-void launch_lstm_persist(const float* gx, const float* whh, const float* h_init, float* c_state, float* h_final, float* y,
-                         const int32_t* lens, int T, int H, int dirs, unsigned long long* xbuf, unsigned int epoch, int* abort_flag,
-                         hipStream_t st) {
+void launch_lstm_persist(const float* gx, const float* whh, const float* bhh, bool gru, const float* h_init, float* c_state,
+                         float* h_final, float* y, const int32_t* lens, int T, int H, int dirs, unsigned long long* xbuf,
+                         unsigned int epoch, int* abort_flag, hipStream_t st) {
   (void)H;
-  PPASR_LAUNCH(k_lstm_persist, dim3(1024 / 8, dirs), dim3(kPersistThreads), 0, st, gx, whh, h_init, c_state, h_final, y, lens, T,
-               dirs, xbuf, epoch, abort_flag);
+  if (gru)
+    PPASR_LAUNCH(k_lstm_persist<true>, dim3(1024 / 8, dirs), dim3(kPersistThreads), 0, st, gx, whh, bhh, h_init, c_state,
+                 h_final, y, lens, T, dirs, xbuf, epoch, abort_flag);
+  else
+    PPASR_LAUNCH(k_lstm_persist<false>, dim3(1024 / 8, dirs), dim3(kPersistThreads), 0, st, gx, whh, bhh, h_init, c_state,
+                 h_final, y, lens, T, dirs, xbuf, epoch, abort_flag);
+}
+
+// ---- test hook (ppasr_debug_occupy_cus): `n_wg` workgroups that each take a whole CU's registers (1 024 threads x 128
+// VGPRs) and spin for `ms` milliseconds -- the chip is then PARTLY held, which is the situation the persistent recurrence
+// cannot wait out (its grid needs every workgroup resident): tests force its give-up path with this ----
+__global__ __launch_bounds__(1024) void k_occupy(long long ticks, float* __restrict__ sink) {
+  float r[96];  // (held across the spin: the kernel's register budget is what keeps other workgroups off the CU)
+#pragma unroll
+  for (int i = 0; i < 96; ++i) r[i] = (float)(threadIdx.x + i);
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {
+#pragma unroll
+    for (int i = 0; i < 96; ++i) r[i] = r[i] * 1.0000001f + 1e-9f;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  float a = 0.f;
+#pragma unroll
+  for (int i = 0; i < 96; ++i) a += r[i];
+  if (a == 12345.678f) sink[0] = a;  // (keeps the registers live)
+}
+void launch_occupy(int n_wg, int ms, float* sink, hipStream_t st) {
+  PPASR_LAUNCH(k_occupy, dim3(n_wg), dim3(1024), 0, st, (long long)ms * 100000ll /* 100 MHz wall clock */, sink);
 }
 
 // [B][H] row-major <-> the fragment order of k_lstm_wave's state buffers (initial / final state boxes)

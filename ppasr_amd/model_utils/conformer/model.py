@@ -241,7 +241,13 @@ class ConformerModel:
         """Range guard of the "f16x3" mode (``ppasr_set_gemm_guard``).  On (default): a call whose GEMM inputs left the
         fp16 pieces' range (|activation| > 4 094) is run again on the fp32 kernels before ``ppasr_encode`` returns -- the
         call then synchronises its stream.  Off: calls stay asynchronous, out-of-range inputs are saturated (never Inf /
-        NaN) and counted; poll ``gemm_guard_stats``."""
+        NaN) and counted; poll ``gemm_guard_stats``.
+
+        STREAMING IS EXCLUDED from the re-run: ``get_encoder_out_chunk`` / stream handles / session groups
+        (``ppasr_encode_chunk``, ``ppasr_encode_chunk_group``) only saturate and count -- a chunk is never run again, and
+        the saturated values are what enter the K / V and conv caches, i.e. they colour every later chunk of that session.
+        Serving code that runs the mode on streams should snapshot ``gemm_guard_stats()`` around a chunk and, when the event
+        count moved, reset the session (``reset_stream``) or replay it with ``set_gemm_mode("f32")``."""
         _lib.check(self.lib.ppasr_set_gemm_guard(self._h, 1 if enable else 0))
 
     def gemm_guard_stats(self):

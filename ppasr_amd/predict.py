@@ -132,7 +132,11 @@ class PPASRPredictor:
         if self._audio_featurizer.use_db_normalization and self.remained_wav.size:
             self.remained_wav = self.remained_wav * db_gain(self.remained_wav, self._audio_featurizer.target_db)
         # frames consumed x hop (10 ms) at the CALLER's sample rate (the reference's constant 160 is 10 ms at 16 kHz,
-        # predict.py:275)
+        # predict.py:275).  DIVERGENCE for streams that are not 16 kHz: the reference resamples its buffered AudioSegment in
+        # place (audio_featurizer.py:46-47), so from the second call on it concatenates 16 kHz remainders with raw samples
+        # of the caller's rate under the caller's rate label and drops 160 samples per frame of that mixture; here the
+        # buffer stays at the caller's rate (featurize() resamples a copy) and the gain above is computed on the
+        # un-resampled samples.  16 kHz streams -- the only ones the reference handles consistently -- are identical.
         self.remained_wav = self.remained_wav[int(round(sample_rate * 0.010)) * x_chunk.shape[1]:]
 
         decoding_chunk_size, context, subsampling = 16, 7, 4

@@ -194,3 +194,71 @@ def test_single_utterance_persistent_recurrence_equals_per_step_route(streaming,
     print(f"persistent vs per-step: probs {e:.2e} h {_rel(outs[0][2], outs[1][2]):.2e} c {_rel(outs[0][3], outs[1][3]):.2e}")
     assert e < 2e-5 and _rel(outs[0][2], outs[1][2]) < 2e-5 and _rel(outs[0][3], outs[1][3]) < 2e-5
     assert model._h is not None
+
+
+@pytest.mark.parametrize("streaming,T,length", [(False, 331, 331), (False, 211, 150), (True, 331, 331), (False, 9, 9)])
+def test_single_utterance_gru_persistent_recurrence_equals_per_step_route(streaming, T, length):
+    """nn.GRU stacks (deepspeech2/encoder.py:36-42, `use_gru`) on the persistent route (k_lstm_persist<GRU>): one launch per
+    layer with 3 x 8 weight rows per workgroup in registers, against the per-step kernels (k_gru_step) and the oracle --
+    probabilities and final h; the c box is handed through unchanged (encoder.py:95-97)."""
+    from ppasr_amd.model_utils.deepspeech2.model import DeepSpeech2Model
+    V, L = 211, 3
+    sd = deepspeech2_state_dict(vocab_size=V, num_rnn_layers=L, streaming=streaming, seed=411, perturb_norm=True, use_gru=True)
+    model = DeepSpeech2Model(80, V, streaming=streaming, encoder_conf=dict(num_rnn_layers=L, rnn_size=1024, use_gru=True),
+                             state_dict=sd, device="cuda:0")
+    x, _ = synth_features(1, T, seed=412)
+    lens = np.array([length])
+    dirs = 1 if streaming else 2
+    rng = np.random.default_rng(6)
+    h0 = (0.3 * rng.standard_normal((L * dirs, 1, 1024))).astype(np.float32)
+    c0 = (0.3 * rng.standard_normal((L * dirs, 1, 1024))).astype(np.float32)
+    outs = []
+    for on in (True, False):
+        with _persist(on):
+            probs, ol, fh, fc = model.get_encoder_out_chunk(x, lens, h0, c0)
+            torch.cuda.synchronize()
+        outs.append((probs.cpu().numpy(), ol.cpu().numpy(), fh.cpu().numpy(), fc.cpu().numpy()))
+    rp, rl, rh, _ = DeepSpeech2Oracle(sd, L, 1024, streaming, use_gru=True).forward(x, lens, torch.from_numpy(h0), torch.from_numpy(c0))
+    for got in outs:
+        assert got[1].tolist() == rl.tolist()
+        assert _rel(got[0], rp.numpy()) < TOL and _rel(got[2], rh.numpy()) < TOL
+        assert np.array_equal(got[3], c0)  # handed through
+    e = _rel(outs[0][0], outs[1][0])
+    print(f"GRU persistent vs per-step: probs {e:.2e} h {_rel(outs[0][2], outs[1][2]):.2e}")
+    assert e < 2e-5 and _rel(outs[0][2], outs[1][2]) < 2e-5
+
+
+@pytest.mark.parametrize("gru", [False, True])
+def test_persistent_recurrence_gives_up_when_the_chip_is_partly_held(gru):
+    """The persistent launch needs every workgroup of its grid resident at once (256 workgroups; two fit a CU).  With 224
+    of the 256 CUs held by another stream's kernel for ~1.5 s (ppasr_debug_occupy_cus) it cannot be: its workgroups spin to
+    their bound, raise the give-up flag, and
+    the call re-runs on the per-step kernels before it returns -- the result must be the per-step route's, the handle must
+    stay off the persistent route for its hold period and come back to it afterwards."""
+    import time
+    from ppasr_amd import _lib
+    from ppasr_amd.model_utils.deepspeech2.model import DeepSpeech2Model
+    lib = _lib.load()
+    V, L, T = 157, 2, 131
+    sd = deepspeech2_state_dict(vocab_size=V, num_rnn_layers=L, streaming=False, seed=421, perturb_norm=True, use_gru=gru)
+    model = DeepSpeech2Model(80, V, streaming=False, encoder_conf=dict(num_rnn_layers=L, rnn_size=1024, use_gru=gru),
+                             state_dict=sd, device="cuda:0")
+    x, _ = synth_features(1, T, seed=422)
+    lens = np.array([T])
+    with _persist(False):
+        want = model.get_encoder_out_chunk(x, lens)[0].cpu().numpy()
+    with _persist(True):
+        free = model.get_encoder_out_chunk(x, lens)[0].cpu().numpy()  # (the chip is free: the persistent route)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        _lib.check(lib.ppasr_debug_occupy_cus(224, 1500, side.cuda_stream))
+        time.sleep(0.05)  # (the occupier's workgroups are on their CUs)
+        t0 = time.perf_counter()
+        held = model.get_encoder_out_chunk(x, lens)[0].cpu().numpy()
+        dt = time.perf_counter() - t0
+        side.synchronize()
+        after = model.get_encoder_out_chunk(x, lens)[0].cpu().numpy()  # inside the hold period: per-step kernels
+    print(f"give-up path ({'GRU' if gru else 'LSTM'}): call took {dt * 1e3:.0f} ms with 224 CUs held")
+    assert _rel(free, want) < 2e-5
+    assert np.array_equal(held, want), "the give-up path must return the per-step route's result"
+    assert np.array_equal(after, want)
