@@ -73,7 +73,7 @@ typedef struct {
   /* Efficient-Conformer (configs/efficient_conformer.yml:16-21) */
   int stride_layer_idx;   /* layer with the stride-2 depthwise conv, -1 = none */
   int group_layer_mask;   /* bit i set: layer i uses grouped attention */
-  int group_size;
+  int group_size;         /* 2, 3 (the shipped value) or 4 frames per attention token */
   /* DeepSpeech2 (configs/deepspeech2.yml:5, deepspeech2/encoder.py:36-42): nn.GRU layers instead of nn.LSTM */
   int use_gru;
   /* Conformer / Efficient-Conformer front end, `input_layer` (conformer/encoder.py:93-104, subsampling.py):
@@ -88,6 +88,11 @@ typedef struct {
      fused 256-wide row-block kernels).  options / input_layer = linear: model_type = conformer only; output_size 512 / 768 /
      1024 (heads of 64): conformer, efficient_conformer and squeezeformer, batched and streaming. */
   int options;
+  /* Efficient-Conformer with SEVERAL stride layers (`stride_layer_idx: [1, 3]`, `stride: [2, 2]`, efficient_conformer/
+     encoder.py:50-54,117-128): bit i set = layer i is a stride-2 layer (its depthwise conv strides, the residual goes
+     through AvgPool1D(2, ceil_mode), every later layer's conv kernel is halved once more).  0 = use stride_layer_idx.  More
+     than one bit: the general layer route, batched encode only (stream handles are refused). */
+  int stride_layer_mask;
 } ppasr_model_desc;
 
 enum {

@@ -22,9 +22,11 @@ class EfficientConformerOracle(ConformerOracle):
 
     def _kernel(self, i):
         # cnn_module_kernels: halves after each stride layer (encoder.py:123-128, stride_kernel=True)
-        if self.stride_layer_idx is not None and i > self.stride_layer_idx:
-            return self.k // 2
-        return self.k
+        return self.k >> sum(1 for v in self._strides() if v < i)
+
+    def _strides(self):
+        s = self.stride_layer_idx
+        return [] if s is None else ([s] if isinstance(s, int) else list(s))
 
     def _grouped_attention(self, x, mask, pos_emb, prefix, cache=None):
         # GroupedRelPositionMultiHeadedAttention.forward  efficient_conformer/attention.py:128-193
@@ -109,7 +111,7 @@ class EfficientConformerOracle(ConformerOracle):
             x_att, new_att = self._attention(xn, mask, pos_emb, att_cache, p + ".self_attn")
         x = x + x_att
         residual = x
-        stride = 2 if (self.stride_layer_idx is not None and i == self.stride_layer_idx) else 1
+        stride = 2 if i in self._strides() else 1
         y, new_cnn = self._conv_eff(self._ln(x, p + ".norm_conv"), mask_pad, p + ".conv_module", self._kernel(i), stride,
                                     cnn_cache)
         if stride > 1:
@@ -125,7 +127,7 @@ class EfficientConformerOracle(ConformerOracle):
 
     def _factor(self, i):
         # calculate_downsampling_factor  efficient_conformer/encoder.py:205-210
-        return 2 if (self.stride_layer_idx is not None and i > self.stride_layer_idx) else 1
+        return 2 ** sum(1 for v in self._strides() if v < i)
 
     def forward_chunk(self, xs, offset, required_cache_size, att_cache=None, cnn_cache=None):
         """EfficientConformerEncoder.forward_chunk  efficient_conformer/encoder.py:266-393 (B = 1, empty att_mask,
@@ -155,7 +157,7 @@ class EfficientConformerOracle(ConformerOracle):
             ac = att_cache[i:i + 1, :, ::factor, :] if cache_t1 > 0 else None
             cc = None if cnn_cache is None or cnn_cache.numel() == 0 else cnn_cache[i]
             xs, new_att, new_cnn = self._layer_eff(i, xs, None, pos_emb, mask_pad, ac, cc, return_caches=True)
-            if self.stride_layer_idx is not None and i == self.stride_layer_idx:
+            if i in self._strides():
                 mask_pad = mask_pad[:, :, ::2]
                 pos_emb = pos_emb[:, ::2, :]
             new_att = new_att[:, :, next_cache_start // factor:, :]
@@ -189,7 +191,7 @@ class EfficientConformerOracle(ConformerOracle):
         layers = [xs]
         for i in range(self.L):
             xs = self._layer_eff(i, xs, chunk_masks, pos_emb, mask_pad)
-            if self.stride_layer_idx is not None and i == self.stride_layer_idx:
+            if i in self._strides():
                 masks = masks[:, :, ::2]
                 chunk_masks = chunk_masks[:, ::2, ::2]
                 mask_pad = masks

@@ -14,11 +14,12 @@ class SqueezeformerOracle(ConformerOracle):
     (causal conv module, TimeReductionLayerStream; squeezeformer/model.py:35-39)."""
 
     def __init__(self, sd, attention_heads=4, num_blocks=12, cnn_module_kernel=31, reduce_idx=5, recover_idx=11,
-                 max_len=5000, dtype=torch.float32, causal=True, adaptive_scale=True):
+                 max_len=5000, dtype=torch.float32, causal=True, adaptive_scale=True, activation_type="swish"):
         # causal=False: the non-streaming model (non-causal conv modules, TimeReductionLayer1D; model.py:35-39)
         sd = dict(sd)
         sd.setdefault("encoder.after_norm.weight", sd["encoder.preln.weight"])  # only used for self.d
-        super().__init__(sd, attention_heads, num_blocks, cnn_module_kernel, causal, max_len, dtype)
+        super().__init__(sd, attention_heads, num_blocks, cnn_module_kernel, causal, max_len, dtype,
+                         activation_type=activation_type)  # (squeezeformer/encoder.py:45,103: FFN and conv module activation)
         self.reduce_idx = reduce_idx
         self.recover_idx = recover_idx
         # adaptive_scale = False (squeezeformer/encoder.py:44): the parameters exist but are not applied

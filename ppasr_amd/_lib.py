@@ -43,7 +43,8 @@ class ModelDesc(ctypes.Structure):
                 ("num_blocks", ctypes.c_int), ("cnn_module_kernel", ctypes.c_int), ("causal", ctypes.c_int),
                 ("max_len", ctypes.c_int), ("reduce_idx", ctypes.c_int), ("recover_idx", ctypes.c_int),
                 ("stride_layer_idx", ctypes.c_int), ("group_layer_mask", ctypes.c_int), ("group_size", ctypes.c_int),
-                ("use_gru", ctypes.c_int), ("input_layer", ctypes.c_int), ("options", ctypes.c_int)]
+                ("use_gru", ctypes.c_int), ("input_layer", ctypes.c_int), ("options", ctypes.c_int),
+                ("stride_layer_mask", ctypes.c_int)]
 
 
 # every symbol include/ppasr_hip.h declares: (name, restype, argtypes)

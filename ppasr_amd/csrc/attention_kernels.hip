@@ -57,11 +57,13 @@ namespace ppasr {
 
 template <int DK>
 struct AttnT {
-  static constexpr int G = DK / 64;            // frames per token: 1, or 3 = pad4group's re-cut of 3 frames into heads of 192
+  static constexpr int G = DK / 64;            // frames per token: 1, or group_size = pad4group's re-cut of 2 / 3 / 4 frames into
+                                               // heads of 128 / 192 / 256 (3: the shipped configuration, tuned below; 2 and 4: the
+                                               // constructor's other values, the plain one-block form)
   static constexpr int NC2 = DK / 64;          // 64-column chunks of the context (two output tiles each: even / odd columns)
   static constexpr int NGK = 2 * DK / 8;       // 8-wide k-groups of the score contraction over K' = [k | p]
   static constexpr int NT = DK == 64 ? PPASR_ATTN_NT : 1;  // 32-key tiles per sub-block (accumulator budget)
-  static constexpr int NW = DK == 64 ? PPASR_ATTN_NW : PPASR_ATTN_NW192;  // waves per workgroup = key splits of its query block
+  static constexpr int NW = DK == 64 ? PPASR_ATTN_NW : (DK == 192 ? PPASR_ATTN_NW192 : 2);  // waves per workgroup = key splits of its query block
   static constexpr int MAXQ = 1;               // (historic: query blocks per wave set)
   // Query blocks per workgroup.  Plain heads: one, its NW waves split the keys.  Grouped heads (d_k = 192): THREE on eight
   // waves -- at 222 registers a SIMD holds two waves, and a (query block, 32-key sub-block) unit is 288 MFMAs that keep a
@@ -70,7 +72,7 @@ struct AttnT {
   // put up to four units on one SIMD of a CU and one on another (41 us per launch, per-phase stamps); one workgroup per
   // (utterance, head) with waves = (block 0: three key splits, block 1: three, block 2: two) puts 2 / 2 / 3 / 2 units
   // on the four SIMDs whatever the dispatcher does
-  static constexpr int QB = DK == 64 ? 1 : PPASR_ATTN_QB192;
+  static constexpr int QB = DK == 192 ? PPASR_ATTN_QB192 : 1;
   static constexpr int WV = QB == 1 ? NW : 8;  // waves per workgroup
   static constexpr int NSMAX = QB == 1 ? NW : 3;
   static __device__ __forceinline__ int wave_qi(int w) { return QB == 1 ? 0 : (w < 3 ? 0 : (w < 6 ? 1 : 2)); }
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(64 * AttnT<DK>::WV, DK == 64 ? PPASR_ATTN_OCC : 2) 
   const int q0 = q0g + my_qi * 32;        // this wave's query block
   // grouped heads: flat feature c (< G * dm) of token tok = (frame G * tok + c / dm, feature c % dm); any width
   auto split = [&](int tok, int c, int& frame, int& feat) {
-    const int k = (c >= dm) + (c >= 2 * dm);
+    const int k = (c >= dm) + (c >= 2 * dm) + (c >= 3 * dm);
     frame = G * tok + k;
     feat = c - k * dm;
   };
@@ -225,7 +227,8 @@ __global__ __launch_bounds__(64 * AttnT<DK>::WV, DK == 64 ? PPASR_ATTN_OCC : 2) 
     const long long rows = (long long)nfr - fo_c[c3] - 1;
     rs_v[c3] = buf_rsrc(vbp + (size_t)fo_c[c3] * a.v_stride + feat_c[c3], rows < 0 ? 0 : (size_t)rows * a.v_stride * 4 + 256);
   }
-  constexpr float kScale = (DK == 64 ? 0.125f : 0.07216878364870322f) * 1.4426950408889634f;  // 1/sqrt(d_k) * log2(e)
+  constexpr float kScale = (DK == 64 ? 0.125f : DK == 128 ? 0.08838834764831845f : DK == 192 ? 0.07216878364870322f : 0.0625f) *
+                           1.4426950408889634f;  // 1/sqrt(d_k * group) * log2(e)
   f32x16 acc_o[2 * NC2];  // O^T: acc_o[2 c3 + e][r] = O[query l31][64 c3 + 2 ((r&3) + 8(r>>2) + 4hh) + e]
 #pragma unroll
   for (int t = 0; t < 2 * NC2; ++t)
@@ -403,16 +406,21 @@ __global__ __launch_bounds__(64 * AttnT<DK>::WV, DK == 64 ? PPASR_ATTN_OCC : 2) 
 }
 
 constexpr size_t kLdsAttnT64 = AttnT<64>::LDS_FLOATS * sizeof(float), kLdsAttnT192 = AttnT<192>::LDS_FLOATS * sizeof(float);
+constexpr size_t kLdsAttnT128 = AttnT<128>::LDS_FLOATS * sizeof(float), kLdsAttnT256 = AttnT<256>::LDS_FLOATS * sizeof(float);
 
 // -> false: a configuration the kernels do not take (group sizes other than 1 / 3, rows not 16-byte aligned)
 bool launch_attention_t(const AttnArgs& a, int B, int H, hipStream_t st) {
-  if (a.group != 1 && a.group != 3) return false;
+  if (a.group < 1 || a.group > 4) return false;
   if ((a.q_stride | a.k_stride | a.v_stride | a.dm) & 3) return false;
   const int nqb = (a.T1 + 31) / 32;
   const int pairs8 = (B * H + 7) / 8;
   if (a.group == 3) {
     const int nq = (nqb + AttnT<192>::QB - 1) / AttnT<192>::QB;  // workgroups per (utterance, head)
     PPASR_LAUNCH(k_attention_t<192>, dim3(nq * pairs8 * 8), dim3(64 * AttnT<192>::WV), kLdsAttnT192, st, a, B, H);
+  } else if (a.group == 2) {
+    PPASR_LAUNCH(k_attention_t<128>, dim3(nqb * pairs8 * 8), dim3(64 * AttnT<128>::WV), kLdsAttnT128, st, a, B, H);
+  } else if (a.group == 4) {
+    PPASR_LAUNCH(k_attention_t<256>, dim3(nqb * pairs8 * 8), dim3(64 * AttnT<256>::WV), kLdsAttnT256, st, a, B, H);
   } else {
     PPASR_LAUNCH(k_attention_t<64>, dim3(nqb * pairs8 * 8), dim3(64 * AttnT<64>::WV), kLdsAttnT64, st, a, B, H);
   }
@@ -423,8 +431,14 @@ hipError_t configure_attention_kernels() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_t<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)kLdsAttnT64);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_t<192>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)kLdsAttnT192);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_t<192>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kLdsAttnT192);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_t<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kLdsAttnT128);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_t<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)kLdsAttnT256);
 }
 
 }  // namespace ppasr

@@ -65,12 +65,16 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
       desc->model_type != PPASR_MODEL_EFFICIENT_CONFORMER)
     return fail(PPASR_EUNSUPPORTED, "model_type not built (conformer, efficient_conformer, squeezeformer are)");
   const bool eff = desc->model_type == PPASR_MODEL_EFFICIENT_CONFORMER;
+  const unsigned smask = eff_stride_mask(*desc);
+  const bool multi_stride = __builtin_popcount(smask) > 1;
   if (eff) {
-    if (desc->group_layer_mask != 0 && desc->group_size != 3)
-      return fail(PPASR_EUNSUPPORTED, "efficient_conformer: grouped attention is built for group_size=3");
-    if (desc->stride_layer_idx >= desc->num_blocks) return fail(PPASR_EINVAL, "stride_layer_idx out of range");
-    if (desc->stride_layer_idx >= 0 && desc->cnn_module_kernel != 15 && desc->output_size == kD)
+    if (desc->group_layer_mask != 0 && (desc->group_size < 2 || desc->group_size > 4))
+      return fail(PPASR_EUNSUPPORTED, "efficient_conformer: grouped attention is built for group_size 2, 3 and 4");
+    if (desc->num_blocks > 31 || (smask >> desc->num_blocks) != 0) return fail(PPASR_EINVAL, "stride layer index out of range");
+    if (smask != 0 && !multi_stride && desc->cnn_module_kernel != 15 && desc->output_size == kD)
       return fail(PPASR_EUNSUPPORTED, "efficient_conformer: cnn_module_kernel must be 15 (7 after the stride layer)");
+    if ((desc->cnn_module_kernel >> __builtin_popcount(smask)) < 1)
+      return fail(PPASR_EINVAL, "efficient_conformer: cnn_module_kernel halves to 0 behind the stride layers");
   }
   // output_size 256 (4 heads of 64) with the shipped constructor arguments: the fused row-block kernels.  Other multiples
   // of 256 up to 1024, non-default ConformerEncoder options (ppasr_model_desc::options), input_layer = linear or another
@@ -82,8 +86,13 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
   const bool generic = (desc->model_type == PPASR_MODEL_CONFORMER &&
                         (desc->output_size != kD || desc->options != 0 || desc->input_layer == 1 || !fused_ks)) ||
                        ((desc->model_type == PPASR_MODEL_SQUEEZEFORMER || desc->model_type == PPASR_MODEL_EFFICIENT_CONFORMER) &&
-                        desc->output_size != kD);
-  const int sq_opts = desc->model_type == PPASR_MODEL_SQUEEZEFORMER ? PPASR_OPT_SQ_NO_ADAPTIVE_SCALE : 0;
+                        desc->output_size != kD) ||
+                       (eff && multi_stride) ||  // (several stride layers: kernels 15 -> 7 -> 3 ..., the general route)
+                       (desc->model_type == PPASR_MODEL_SQUEEZEFORMER &&
+                        ((desc->options >> PPASR_OPT_ACT_SHIFT) & PPASR_OPT_ACT_MASK) != PPASR_ACT_SWISH);  // (activation_type)
+  // Squeezeformer takes two of the option fields: adaptive_scale = False and activation_type (squeezeformer/encoder.py:44-45)
+  const int sq_opts = desc->model_type == PPASR_MODEL_SQUEEZEFORMER
+                          ? (PPASR_OPT_SQ_NO_ADAPTIVE_SCALE | (PPASR_OPT_ACT_MASK << PPASR_OPT_ACT_SHIFT)) : 0;
   if (((desc->options & ~sq_opts) != 0 || desc->input_layer == 1) && desc->model_type != PPASR_MODEL_CONFORMER)
     return fail(PPASR_EUNSUPPORTED, "non-default encoder options / input_layer=linear are built for model_type=conformer");
   if ((desc->options & PPASR_OPT_SQ_NO_ADAPTIVE_SCALE) && desc->model_type != PPASR_MODEL_SQUEEZEFORMER)
@@ -128,6 +137,10 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
   auto* m = new ppasr_model_s();
   std::unique_ptr<ppasr_model_s> guard(m);
   m->desc = *desc;
+  if (eff) {  // one representation inside: the mask, and stride_layer_idx = its first (for the shipped shape: only) layer
+    m->desc.stride_layer_mask = (int)smask;
+    m->desc.stride_layer_idx = smask ? __builtin_ctz(smask) : -1;
+  }
   const int F = desc->input_dim, d = desc->output_size, H = desc->linear_units, V = desc->vocab_size, KS = desc->cnn_module_kernel;
   const int il = desc->input_layer;
   if (il != 0 && il != 1 && il != 6 && il != 8)
@@ -228,11 +241,11 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
   for (int i = 0; i < desc->num_blocks; ++i) {
     LayerW& L = m->layers[i];
     // Efficient-Conformer: kernel halves after the stride layer (encoder.py:123-128), grouped attention layers
-    const int KSi = (eff && desc->stride_layer_idx >= 0 && i > desc->stride_layer_idx) ? KS / 2 : KS;
+    const int KSi = eff ? (KS >> eff_strides_before(*desc, i)) : KS;  // (cnn_module_kernels: // 2 per stride layer passed)
     const bool grouped = eff && ((desc->group_layer_mask >> i) & 1);
     m->layer_ks[i] = KSi;
-    m->layer_group[i] = grouped ? 3 : 1;
-    const int pbn = grouped ? 3 * d : d;  // pos_bias_u/v are [h][dk*group_size] on grouped layers
+    m->layer_group[i] = grouped ? desc->group_size : 1;
+    const int pbn = grouped ? desc->group_size * d : d;  // pos_bias_u/v are [h][dk*group_size] on grouped layers
     const std::string p = "encoder.encoders." + std::to_string(i) + ".";
     auto ln = [&](const std::string& n, const float** g, const float** b) -> ppasr_status {
       const float* gw = get(p + n + ".weight", d);
@@ -400,7 +413,8 @@ int ppasr_out_frames(ppasr_handle h, int T) {
   if (T < (h ? h->min_frames() : 7)) return 0;
   int tp = h ? h->front_dims(T).Tp : ((T - 1) / 2 - 1) / 2;
   // Efficient-Conformer: the stride-2 conv layer halves the frame rate (ceil), efficient_conformer/encoder.py:252-257
-  if (h && h->desc.model_type == PPASR_MODEL_EFFICIENT_CONFORMER && h->desc.stride_layer_idx >= 0) tp = (tp + 1) / 2;
+  if (h)
+    for (int n = __builtin_popcount(eff_stride_mask(h->desc)); n > 0; --n) tp = (tp + 1) / 2;
   return tp;
 }
 

@@ -656,7 +656,7 @@ ppasr_status gen_layers(const GenRun& r, float* probs, float* logits, int32_t* f
     if (o.use_cnn) {
       const int KS = h->layer_ks[i];
       const int left = h->desc.causal ? KS - 1 : (KS - 1) / 2;
-      const bool stride2 = eff && i == h->desc.stride_layer_idx;
+      const bool stride2 = eff && ((eff_stride_mask(h->desc) >> i) & 1u);
       float* a_new = a + (size_t)lo_s * D;
       const int rows = lo_s + M;
       if (fused_ffn && D == kD512 && lo_s == 0) {  // (LayerNorm) + pad mask + pointwise_conv1 + GLU in one launch
@@ -878,7 +878,7 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
     };
     auto act_epi = [&]() {
       GemmEpi e;
-      e.act = PPASR_ACT_SWISH;
+      e.act = h->gen.act;  // activation_type (swish in every shipped YAML)
       e.ps = ps;
       return e;
     };
@@ -917,7 +917,7 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
     auto sq_ffn = [&](const f32x4* w1, const float* b1, const f32x4* w2, const float* b2) {
       if (fused_ffn512() && D == kD512) {
         PPASR_LAUNCH(k_g_ffn512, dim3((Mi + kRows - 1) / kRows), dim3(kThreads), kLdsFfn512, st, x, x, (const float*)nullptr,
-                     (const float*)nullptr, w1, b1, w2, b2, 1.0f, (int)PPASR_ACT_SWISH, Mi, H / 256, ps);
+                     (const float*)nullptr, w1, b1, w2, b2, 1.0f, h->gen.act, Mi, H / 256, ps);
         return;
       }
       dense(x, D, w1, b1, big, Mi, D, H, H, H, st, 1.0f, act_epi());
@@ -943,7 +943,7 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
         PPASR_LAUNCH(k_g_glu, blocks((size_t)rows * D), dim3(256), 0, st, big, g, rows, D);
       }
       launch_dwconv(g, y, W.dw_w, W.dw_b, W.glu_pad, B, Ti, D, KS, left, lo_s, 1, Ti, st, ps);
-      ln(y, y, W.ln_cm_g, W.ln_cm_b, W.cm_eps, (int)PPASR_ACT_SWISH, false, Mi, Ti, mul);
+      ln(y, y, W.ln_cm_g, W.ln_cm_b, W.cm_eps, h->gen.act, false, Mi, Ti, mul);
       dense(y, D, W.pw2, W.pw2_b, x, Mi, D, D, D, D, st, 1.0f, res_epi(true));
       ln(x, x, W.ln3_g, W.ln3_b, 1e-5f, kActNone, false, Mi, Ti, mul);
     }

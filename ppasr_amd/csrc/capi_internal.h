@@ -62,6 +62,17 @@ inline std::vector<float> pack_b(int K, int N, Acc w) {
 
 typedef std::unordered_map<std::string, Blob> BlobMap;
 
+// Efficient-Conformer: bit i = layer i is a stride-2 layer (ppasr_model_desc::stride_layer_mask, or the single
+// stride_layer_idx of the shipped configuration)
+inline unsigned eff_stride_mask(const ppasr_model_desc& d) {
+  if (d.model_type != PPASR_MODEL_EFFICIENT_CONFORMER) return 0u;
+  if (d.stride_layer_mask != 0) return (unsigned)d.stride_layer_mask;
+  return d.stride_layer_idx >= 0 ? (1u << d.stride_layer_idx) : 0u;
+}
+inline int eff_strides_before(const ppasr_model_desc& d, int layer) {  // stride layers among layers 0 .. layer - 1
+  return __builtin_popcount(eff_stride_mask(d) & ((1u << layer) - 1u));
+}
+
 struct ppasr_model_s {
   ppasr_model_desc desc;
   int F1, F2;

@@ -238,6 +238,8 @@ ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out) {
     return fail(PPASR_EUNSUPPORTED, "forward_chunk needs the causal conv module (a streaming=True model)");
   if (h->generic && h->desc.input_layer == 1)
     return fail(PPASR_EUNSUPPORTED, "stream handles are built for the conv front ends (input_layer=linear: batched encode)");
+  if (__builtin_popcount(eff_stride_mask(h->desc)) > 1)
+    return fail(PPASR_EUNSUPPORTED, "stream handles are built for one stride layer (several: batched encode)");
   if (h->desc.input_layer != 0 && h->desc.model_type != PPASR_MODEL_CONFORMER)
     return fail(PPASR_EUNSUPPORTED, "stream handles with the conv2d6 / conv2d8 front ends are built for model_type=conformer");
   auto* s = new ppasr_stream_s();

@@ -255,8 +255,8 @@ __host__ __device__ inline BeamLdsPlan beam_lds_plan(int beam, int V, int list_c
   p.wtot = o;  o += 4 * 16 * 4;                      // 4 scan call sites x up to 16 waves
   p.red = o;   o += 32 * 4;
   p.sh = o;    o += 64;                              // 16 shared ints
-  p.cand = o;  o += (has_lm ? 4 : 2) * kSmallCand * 4;  // cand_c, cand_lp (records of <= kSmallCand candidates); scorer: + the
-                                                       // candidates' LM word ids and unigram log10 probabilities
+  p.cand = o;  o += 2 * (has_lm ? 4 : 2) * kSmallCand * 4;  // TWO frames of cand_c, cand_lp (records of <= kSmallCand candidates);
+                                                           // scorer: + the candidates' LM word ids and unigram log10 probabilities
   p.beam0 = o; o = al8(o + (uint32_t)beam * 4 * kBeamWords);
   p.beam1 = o; o = al8(o + (uint32_t)beam * 4 * kBeamWords);
   p.newv = o;  o = al8(o + (uint32_t)beam * 20);     // new_b, new_nb, new_score, new_dst, k_reset
@@ -265,7 +265,7 @@ __host__ __device__ inline BeamLdsPlan beam_lds_plan(int beam, int V, int list_c
   p.lmacc = o; o = al8(o + (has_lm ? (uint32_t)beam * 4 * kLmAccWords : 0u));
   p.cmask = o; o = al8(o + (wide ? 0u : (uint32_t)beam * 4 * kMaskWords));
   p.frow = o;  o += 1024 * 2;                        // first_row[thread] (int16)
-  p.kidx = o;  o = al8(o + (uint32_t)((V + 3) & ~3) * 2);
+  p.kidx = o;  o = al8(o + 2 * (uint32_t)((V + 3) & ~3) * 2);  // two frames
   p.fkey = o;  o += kSmallList * 8 + kTinyBeam * 8 + kTinyBeam * 4;  // + srank_key, hyp_of_rank of the tiny-beam path
   p.lkey = o;  o = al8(o + (uint32_t)list_cap * 4);
   p.lex = o;   o = al8(o + (wide ? (uint32_t)list_cap : 0u));  // wide lists: one "child exists" flag per entry
@@ -601,10 +601,13 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
   int* wave_tot = reinterpret_cast<int*>(smem + plan.wtot);
   float* red_p = reinterpret_cast<float*>(smem + plan.red);
   int* sh_i = reinterpret_cast<int*>(smem + plan.sh);
-  int* cand_c_s = reinterpret_cast<int*>(smem + plan.cand);
-  float* cand_lp_s = reinterpret_cast<float*>(smem + plan.cand) + kSmallCand;
-  int* cand_word_s = cand_c_s + 2 * kSmallCand;                      // (scorer, narrow lists) tok2lm[character of candidate k]
-  float* cand_uni_s = reinterpret_cast<float*>(cand_c_s + 3 * kSmallCand);  // ... uni_prob of that word (NaN: OOV / absent)
+  // candidate arrays and kidx[] exist twice: frame t + 1 is staged (from the prefetched record) in the last phase of frame t
+  constexpr int kCandWords = (has_lm ? 4 : 2) * kSmallCand;  // words of one frame's block
+  int* cand_base = reinterpret_cast<int*>(smem + plan.cand);
+  int* cand_c_s = cand_base;                                           // (re-pointed every frame)
+  float* cand_lp_s = reinterpret_cast<float*>(cand_base) + kSmallCand;
+  int* cand_word_s = cand_base + 2 * kSmallCand;                       // (scorer, narrow lists) tok2lm[character of candidate k]
+  float* cand_uni_s = reinterpret_cast<float*>(cand_base + 3 * kSmallCand);  // ... uni_prob of that word (NaN: OOV / absent)
   char* pb = smem + plan.beam0;
   Beam cur = carve_beam(pb, beam);
   pb = smem + plan.beam1;
@@ -619,7 +622,9 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
   int* newpos = off + beam + 1;                             // slot of the previous frame's hypothesis e in this frame's beam, or -1
   int* surv = reinterpret_cast<int*>(smem + plan.surv);     // survivor codes in list order
   float* surv_lp = reinterpret_cast<float*>(surv + beam);   // log-probability of a surviving CHILD
-  int16_t* kidx = reinterpret_cast<int16_t*>(smem + plan.kidx);
+  int16_t* kidx_base = reinterpret_cast<int16_t*>(smem + plan.kidx);
+  const int Vp4 = (V + 3) & ~3;
+  int16_t* kidx = kidx_base;  // (re-pointed every frame)
   unsigned long long* fkey = reinterpret_cast<unsigned long long*>(smem + plan.fkey);
   unsigned long long* srank_key = fkey + kSmallList;               // tiny beams: the `beam` smallest keys, by rank
   int* hyp_of_rank = reinterpret_cast<int*>(srank_key + kTinyBeam);  // ... hypothesis of score rank r
@@ -689,7 +694,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
   // of the previous frame's characters are reset.  A character's log-prob is cand_lp[kidx[c]] -- a V-wide table of its own
   // (17 KB of LDS at V = 4233) kept the workgroup from sharing a CU with the encoder's 133 KB row-block workgroups when
   // the search of step i runs beside the encoder of step i + 1 (bench.py --config cfg4 / cfg5, evaluate()).
-  for (int v = tid; v < V; v += BT) kidx[v] = -1;
+  for (int v = tid; v < 2 * Vp4; v += BT) kidx_base[v] = -1;
   // per-frame records of the pruning pre-pass; narrow records (<= kSmallCand candidates) are fetched one frame ahead into
   // registers and staged in LDS, wide ones are read in place (HBM scratch, L2-resident while their frame is processed)
   const int RW = prune_rec_words(CM);
@@ -710,7 +715,42 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
       }
     }
   };
-  if (n_frames > 0) fetch(0);
+  // stage the prefetched record as frame `tf` (into buffer tf & 1): candidate arrays, kidx[], the scorer's candidate side
+  int C_st = 0;
+  float pb_st = 0.f;
+  auto stage = [&](int tf) {
+    const int b = tf & 1;
+    C_st = __builtin_amdgcn_readfirstlane(pre_C);  // (block-uniform: tell the compiler)
+    pb_st = __int_as_float(pre_pb);
+    int16_t* kx = kidx_base + b * Vp4;
+    if (WIDE) {
+      const int32_t* r = rec_u + (size_t)tf * RW;
+      for (int k = tid; k < C_st; k += BT) kx[r[2 + k]] = (int16_t)k;
+    } else {
+      int* cc = cand_base + b * kCandWords;
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const int k = tid + j * BT;
+        if (k < C_st) {
+          cc[k] = pre_c[j];
+          cc[kSmallCand + k] = pre_lp[j];
+          kx[pre_c[j]] = (int16_t)k;
+          if (has_lm && !word_lm) {  // the candidate side of the factorised scorer look-up: once per frame, not per pair
+            const int w = cfg.lm.tok2lm[pre_c[j]];
+            cc[2 * kSmallCand + k] = w;
+            cc[3 * kSmallCand + k] = __float_as_int((w > 0 && w < cfg.lm.n_words) ? cfg.lm.uni_prob[w] : __builtin_nanf(""));
+          }
+        }
+      }
+    }
+  };
+  __syncthreads();  // (kidx cleared)
+  if (n_frames > 0) {
+    fetch(0);
+    stage(0);
+    if (n_frames > 1) fetch(1);
+  }
+  if (tid == 0) { sh_i[1] = 0; sh_i[2] = 0; sh_i[3] = 0; sh_i[6] = 0; sh_i[7] = 0; }  // verification failed / kept count / largest key kept / tiny beams' flags
   __syncthreads();
 #ifdef PPASR_BEAM_TS
   long long ts_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts_last = wall_clock64(), ts_n = 0, ts_c = 0, ts_nb = 0, ts_att = 0, ts_ok = 0,
@@ -746,28 +786,16 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
   }
   const int my_row_k = beam / (lane + 1) + margin;  // K_r of row r = lane (the verification's lanes)
   for (int t = 0; t < n_frames; ++t) {
-    // ---- (b, c) this frame's pruned characters (get_pruned_log_probs, done by the pre-pass) ----
-    const int C = __builtin_amdgcn_readfirstlane(pre_C);  // (block-uniform: tell the compiler)
-    const float p_blank = __int_as_float(pre_pb);
+    // ---- (b, c) this frame's pruned characters (get_pruned_log_probs, done by the pre-pass; staged in the last phase of
+    // the previous frame) ----
+    const int C = C_st;
+    const float p_blank = pb_st;
     const int32_t* rec_t = rec_u + (size_t)t * RW;
-    if (WIDE) {
-      for (int k = tid; k < C; k += BT) kidx[rec_t[2 + k]] = (int16_t)k;
-    } else {
-#pragma unroll
-      for (int j = 0; j < KPT; ++j) {
-        const int k = tid + j * BT;
-        if (k < C) {
-          cand_c_s[k] = pre_c[j];
-          cand_lp_s[k] = __int_as_float(pre_lp[j]);
-          kidx[pre_c[j]] = (int16_t)k;
-          if (has_lm && !word_lm) {  // the candidate side of the factorised scorer look-up: once per frame, not per pair
-            const int w = cfg.lm.tok2lm[pre_c[j]];
-            cand_word_s[k] = w;
-            cand_uni_s[k] = (w > 0 && w < cfg.lm.n_words) ? cfg.lm.uni_prob[w] : __builtin_nanf("");
-          }
-        }
-      }
-    }
+    kidx = kidx_base + (t & 1) * Vp4;
+    cand_c_s = cand_base + (t & 1) * kCandWords;
+    cand_lp_s = reinterpret_cast<float*>(cand_c_s) + kSmallCand;
+    cand_word_s = cand_c_s + 2 * kSmallCand;
+    cand_uni_s = reinterpret_cast<float*>(cand_c_s + 3 * kSmallCand);
     // candidate k of the frame: character, log-probability
     auto cand_c = [&](int k) -> int { return WIDE ? rec_t[2 + k] : cand_c_s[k]; };
     auto cand_lp = [&](int k) -> float { return WIDE ? __int_as_float(rec_t[2 + CM + k]) : cand_lp_s[k]; };
@@ -775,9 +803,6 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
       const int k = kidx[c];
       return k >= 0 ? cand_lp(k) : kNotCand;
     };
-    if (t + 1 < n_frames) fetch(t + 1);
-    if (tid == 0) { sh_i[1] = 0; sh_i[2] = 0; sh_i[3] = 0; }  // verification failed / kept count / largest key kept
-    lds_barrier();
     TS(0);
     // ---- external scorer: pruning threshold of this frame and the LM term of every possible extension ----
     // (ctc_beam_search_decoder.cpp: prefixes sorted, min_cutoff = worst score + log(p_blank) - max(0, beta), and the
@@ -972,6 +997,64 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
     TW(3);
     if (tid < beam) newpos[tid] = -1;  // consumed in (d); takes the new slots of the hypotheses that stay (end of the frame)
     if (clip && nb <= 64) NLc_clip = sh_i[4];
+    // one slot of the next beam: survivor `code` (an existing hypothesis e, or kChildBit | row << 14 | candidate) at slot `pos`;
+    // log_p: the extension's log-probability (children); id / fresh: node id of a child and whether the node is new
+    auto mat_slot = [&](int pos, int code, float log_p, int id, bool fresh) {
+      if (!(code & kChildBit)) {
+        const int e = code;
+        nxt.node[pos] = cur.node[e]; nxt.chr[pos] = cur.chr[e]; nxt.par[pos] = cur.par[e];
+        nxt.b[pos] = new_b[e]; nxt.nb[pos] = new_nb[e]; nxt.score[pos] = new_score[e];
+        for (int j = 0; j < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[e * kLmCtx + j];
+        nxt.dst[pos] = word_lm ? new_dst[e] : 0;
+        nxt.pslot[pos] = cur.pslot[e];  // the parent's slot in THIS frame's beam (translated in (d))
+        newpos[e] = pos;
+      } else {
+        const int i = (code >> 14) & 0xFFFF, kk = code & 0x3FFF;
+        const int c = cand_c(kk);
+        if (!cfg.node_table && id < cfg.max_nodes) { arena[kArenaWords * (size_t)id] = cur.node[i]; arena[kArenaWords * (size_t)id + 1] = c; }
+        if (word_lm) {
+          // the LM context holds WORDS: it moves on when a space completes one.  The dictionary state belongs to the trie
+          // node: a new node starts where the arc leads, a revived one is where it was left (a final state may have been
+          // reset to the start state by a failed look-up while the prefix was alive)
+          const int to = lm_dict_arc(cfg.lm, new_dst[i], c);
+          if (fresh) {
+            nxt.dst[pos] = to;
+            if (id < cfg.max_nodes) arena[kArenaWords * (size_t)id + 2] = to;
+          } else {
+            nxt.dst[pos] = arena[kArenaWords * (size_t)id + 2];
+          }
+          if (c == space_id) {
+            for (int j = 0; j + 1 < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[i * kLmCtx + j + 1];
+            nxt.ctx[pos * kLmCtx + kLmCtx - 1] = cfg.lm.dict_word[to];
+          } else {
+            for (int j = 0; j < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[i * kLmCtx + j];
+          }
+        } else {
+          nxt.dst[pos] = 0;
+          for (int j = 0; j + 1 < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[i * kLmCtx + j + 1];
+          nxt.ctx[pos * kLmCtx + kLmCtx - 1] = has_lm ? cfg.lm.tok2lm[c] : 0;
+        }
+        nxt.node[pos] = id; nxt.chr[pos] = c; nxt.par[pos] = cur.node[i];
+        nxt.b[pos] = kNegInf; nxt.nb[pos] = log_p; nxt.score[pos] = log_p;
+        nxt.pslot[pos] = i;  // the parent's slot in THIS frame's beam
+      }
+    };
+    // last phase of a frame: this frame's "child exists" bits and kidx[] entries are cleared (the buffers are clean again for
+    // frame t + 2), the next frame's candidates staged into the other buffer, its successor's record requested
+    bool staged_next = false;
+    auto end_of_frame = [&]() {
+      if (!WIDE && tid < beam) {
+#pragma unroll
+        for (int j = 0; j < kMaskWords; ++j) cmask[tid * kMaskWords + j] = 0;
+      }
+      for (int k = tid; k < C; k += BT) kidx[cand_c(k)] = -1;
+      if (!staged_next && t + 1 < n_frames) {
+        stage(t + 1);
+        if (t + 2 < n_frames) fetch(t + 2);
+      }
+      staged_next = true;
+      if (tid == 0) { sh_i[1] = 0; sh_i[2] = 0; sh_i[3] = 0; }  // verification failed / kept count / largest key kept
+    };
     int k_sel = 0;
     bool tiny_done = false;
     if (tiny) {
@@ -1022,7 +1105,14 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
         }
         lds_barrier();
         TS(5);
-        // survivors in LIST order (the order the general compaction leaves them in) + the verification
+        // survivors in LIST order (the order the general compaction leaves them in), written straight into the next beam, +
+        // the verification, + the end-of-frame work: ONE phase.  (If the verification fails -- rare -- the slots written here
+        // are overwritten by the general form below, which first rebuilds what the end-of-frame work cleared.)
+        const bool merged_tail = !cfg.node_table;
+        // (merged tail: the flag word alternates with the frame's parity -- this frame's is read behind the phase's only
+        //  barrier while the other one is re-armed for the next frame)
+        int* vflag = sh_i + (merged_tail ? 6 + (t & 1) : 1);
+        if (merged_tail && tid == 0) sh_i[6 + ((t + 1) & 1)] = 0;
         if (wave == 0) {  // lane = (survivor p = lane & 15, quarter g = lane >> 4 of the others it is compared with)
           const int pidx = lane & 15, g = lane >> 4;
           const unsigned long long kp = pidx < beam ? srank_key[pidx] : ~0ull;
@@ -1038,10 +1128,16 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
           pos += __shfl_xor(pos, 32);
           if (lane < beam) {
             if (kp == ~0ull) {
-              sh_i[1] = 1;  // fewer than `beam` valid elements in the list
+              *vflag = 1;  // fewer than `beam` valid elements in the list
             } else {
-              surv[pos] = (ep >> 17) ? (kChildBit | (((ep >> 7) & 0xF) << 14) | (ep & 0x7F)) : ep;
-              surv_lp[pos] = score_of_key((uint32_t)(kp >> 32));
+              const int code = (ep >> 17) ? (kChildBit | (((ep >> 7) & 0xF) << 14) | (ep & 0x7F)) : ep;
+              const float lp = score_of_key((uint32_t)(kp >> 32));
+              if (merged_tail) {
+                mat_slot(pos, code, lp, n_nodes + pos, true);
+              } else {
+                surv[pos] = code;
+                surv_lp[pos] = lp;
+              }
             }
           }
         } else if (wave == 1 && lane < nb) {  // (another wave: row r = lane)
@@ -1049,11 +1145,31 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
           if (my_row_k < C && kl != ~0ull) {
             const uint32_t thr = (uint32_t)(kl >> 32);  // score key of the last element taken
             const float ub = cand_lp_s[my_row_k] + cur.score[hyp_of_rank[lane]];
-            if (desc_key(ub) <= thr) sh_i[1] = 1;  // an excluded child could score >= the last one taken
+            if (desc_key(ub) <= thr) *vflag = 1;  // an excluded child could score >= the last one taken
           }
         }
-        lds_barrier();
-        if (sh_i[1] == 0) {
+        if (merged_tail && wave >= 2) {  // (waves 0 and 1 are busy above; kidx / cmask are not read in this phase)
+          if (!WIDE && tid - 128 < beam) {
+#pragma unroll
+            for (int j = 0; j < kMaskWords; ++j) cmask[(tid - 128) * kMaskWords + j] = 0;
+          }
+          for (int k = tid - 128; k < C; k += BT - 128) kidx[cand_c(k)] = -1;
+        }
+        int fail;
+        if (merged_tail) {
+          // staging needs every thread's prefetched registers: all waves, after their part above
+          if (t + 1 < n_frames) {
+            stage(t + 1);
+            if (t + 2 < n_frames) fetch(t + 2);
+          }
+          staged_next = true;
+          lds_barrier();
+          fail = *vflag;
+        } else {
+          lds_barrier();
+          fail = sh_i[1];
+        }
+        if (fail == 0) {
           tiny_done = true;
           k_sel = beam;
 #ifdef PPASR_BEAM_TS
@@ -1061,8 +1177,17 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
           ++ts_small;
 #endif
         } else {
-          lds_barrier();  // (everyone has read the flag)
-          if (tid == 0) sh_i[1] = 0;
+          if (merged_tail) {
+            // undo what the merged phase cleared / wrote: the frame's kidx[] and "child exists" bits, the slots map
+            for (int k = tid; k < C; k += BT) kidx[cand_c(k)] = (int16_t)k;
+            if (tid < beam) newpos[tid] = -1;
+            lds_barrier();  // (cmask was cleared by other threads than those that set its bits)
+            if (tid < nb && mrg_pi >= 0) atomicOr(&cmask[mrg_pi * kMaskWords + (mrg_k >> 5)], 1u << (mrg_k & 31));
+          } else {
+            lds_barrier();  // (everyone has read the flag)
+            if (tid == 0) sh_i[1] = 0;
+          }
+          lds_barrier();
         }
         TS(6);
       }
@@ -1458,6 +1583,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
     }
     if (k_sel < 0) break;  // no scratch for a list that needs it (status set)
     int n_nodes_next;
+    const bool tail_done = tiny_done && !cfg.node_table;  // the tiny-beam path wrote the beam and did the end-of-frame work
     // node ids of the new prefixes: looked up in the node table first (a prefix that was in the beam before keeps its
     // identity, ctc_beam.h), misses get fresh ids in slot order (one block scan) and are entered into the table
     int my_parent = -1, my_char = 1, my_id = -1;  // (k_sel <= beam <= BT: one slot per thread)
@@ -1496,56 +1622,14 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
       my_char = miss;  // (re-used below: 1 = a new node, 0 = a revived one)
       n_nodes_next = n_nodes + n_miss;
     }
-    if (!WIDE && tid < beam) {  // the "child exists" bits of this frame
-#pragma unroll
-      for (int j = 0; j < kMaskWords; ++j) cmask[tid * kMaskWords + j] = 0;
-    }
-    if (tid < k_sel) {
-      const int pos = tid;
-      const int code = surv[pos];
-      if (!(code & kChildBit)) {
-        const int e = code;
-        nxt.node[pos] = cur.node[e]; nxt.chr[pos] = cur.chr[e]; nxt.par[pos] = cur.par[e];
-        nxt.b[pos] = new_b[e]; nxt.nb[pos] = new_nb[e]; nxt.score[pos] = new_score[e];
-        for (int j = 0; j < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[e * kLmCtx + j];
-        nxt.dst[pos] = word_lm ? new_dst[e] : 0;
-        nxt.pslot[pos] = cur.pslot[e];  // the parent's slot in THIS frame's beam (translated in (d))
-        newpos[e] = pos;
-      } else {
-        const int i = (code >> 14) & 0xFFFF, kk = code & 0x3FFF;
-        const int c = cand_c(kk);
-        const float log_p = surv_lp[pos];  // the extension's log-probability, computed once in (e)
-        const int id = cfg.node_table ? my_id : n_nodes + pos;  // (with the table: pos == tid)
-        if (!cfg.node_table && id < cfg.max_nodes) { arena[kArenaWords * (size_t)id] = cur.node[i]; arena[kArenaWords * (size_t)id + 1] = c; }
-        if (word_lm) {
-          // the LM context holds WORDS: it moves on when a space completes one.  The dictionary state belongs to the trie
-          // node: a new node starts where the arc leads, a revived one is where it was left (a final state may have been
-          // reset to the start state by a failed look-up while the prefix was alive)
-          const int to = lm_dict_arc(cfg.lm, new_dst[i], c);
-          if (my_char) {
-            nxt.dst[pos] = to;
-            if (id < cfg.max_nodes) arena[kArenaWords * (size_t)id + 2] = to;
-          } else {
-            nxt.dst[pos] = arena[kArenaWords * (size_t)id + 2];
-          }
-          if (c == space_id) {
-            for (int j = 0; j + 1 < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[i * kLmCtx + j + 1];
-            nxt.ctx[pos * kLmCtx + kLmCtx - 1] = cfg.lm.dict_word[to];
-          } else {
-            for (int j = 0; j < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[i * kLmCtx + j];
-          }
-        } else {
-          nxt.dst[pos] = 0;
-          for (int j = 0; j + 1 < kLmCtx; ++j) nxt.ctx[pos * kLmCtx + j] = cur.ctx[i * kLmCtx + j + 1];
-          nxt.ctx[pos * kLmCtx + kLmCtx - 1] = has_lm ? cfg.lm.tok2lm[c] : 0;
-        }
-        nxt.node[pos] = id; nxt.chr[pos] = c; nxt.par[pos] = cur.node[i];
-        nxt.b[pos] = kNegInf; nxt.nb[pos] = log_p; nxt.score[pos] = log_p;
-        nxt.pslot[pos] = i;  // the parent's slot in THIS frame's beam
+    if (!tail_done) {
+      if (tid < k_sel) {
+        const int code = surv[tid];
+        mat_slot(tid, code, surv_lp[tid], cfg.node_table ? my_id : n_nodes + tid, my_char != 0);
       }
+      end_of_frame();
+      lds_barrier();
     }
-    for (int k = tid; k < C; k += BT) kidx[cand_c(k)] = -1;  // reset for the next frame
-    lds_barrier();
     TS(7);
     nb = __builtin_amdgcn_readfirstlane(k_sel);
     n_nodes = n_nodes_next;

@@ -195,7 +195,7 @@ class ConformerModel:
         ``mul * t < len`` with ``mul`` = the model's total time reduction (the reference's mask slicing,
         subsampling.py:115; x2 behind the Efficient-Conformer's stride layer)."""
         lens = torch.as_tensor(speech_lengths, dtype=torch.int64).to(self.device)
-        mul = getattr(self, "subsampling_rate", 4) * (2 if getattr(self, "stride_layer_idx", None) is not None else 1)
+        mul = getattr(self, "subsampling_rate", 4) * (2 ** len(getattr(self, "_stride_layers", ())))
         return torch.clamp((lens + mul - 1) // mul, min=0, max=self.out_frames(int(T))).to(torch.int32)
 
     def set_skip_padding(self, enable=True):

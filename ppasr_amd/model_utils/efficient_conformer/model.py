@@ -38,18 +38,22 @@ class EfficientConformerModel(ConformerModel):
             v = conf.get(v, eff.get(v, default))
             return v
 
+        # stride_layer_idx / stride: an int or a list each (efficient_conformer/encoder.py:50-51,117-121); every stride must be
+        # 2 (AvgPool1D(2) residual, kernel // 2 behind it).  One stride layer: the fused kernels and stream handles; several:
+        # the library's general layer route, batched encode
         stride_idx = one("stride_layer_idx", 3)
-        if isinstance(stride_idx, (list, tuple)):
-            if len(stride_idx) > 1:
-                raise NotImplementedError("one stride layer is built")
-            stride_idx = stride_idx[0] if stride_idx else None
+        stride_idx = [] if stride_idx is None else ([int(stride_idx)] if isinstance(stride_idx, int) else [int(v) for v in stride_idx])
         stride = one("stride", 2)
-        stride = stride[0] if isinstance(stride, (list, tuple)) and stride else stride
-        if stride_idx is not None and stride != 2:
+        stride = [int(stride)] * len(stride_idx) if isinstance(stride, int) else [int(v) for v in stride]
+        assert len(stride) == len(stride_idx)  # encoder.py:122
+        if any(v != 2 for v in stride):
             raise NotImplementedError("stride 2 is built")
+        if len(set(stride_idx)) != len(stride_idx) or any(v < 0 or v >= self.num_blocks for v in stride_idx):
+            raise ValueError(f"stride_layer_idx={stride_idx}")
         groups = one("group_layer_idx", (0, 1, 2, 3))
         groups = [groups] if isinstance(groups, int) else list(groups or [])
-        self.stride_layer_idx = stride_idx
+        self.stride_layer_idx = stride_idx[0] if len(stride_idx) == 1 else (None if not stride_idx else list(stride_idx))
+        self._stride_layers = list(stride_idx)
         self.group_layer_idx = groups
         self.group_size = int(one("group_size", 3))
         if not one("stride_kernel", True):
@@ -93,8 +97,9 @@ class EfficientConformerModel(ConformerModel):
         desc = _lib.ModelDesc(_lib.PPASR_MODEL_EFFICIENT_CONFORMER, input_dim, vocab_size, self.output_size,
                               self.attention_heads, self.linear_units, self.num_blocks, self.cnn_module_kernel,
                               1 if streaming else 0,  # causal conv <=> streaming (efficient_conformer/model.py)
-                              self.max_len, -1, -1, -1 if stride_idx is None else int(stride_idx), mask,
-                              self.group_size, 0, {"conv2d": 0, "conv2d6": 6, "conv2d8": 8}[self.input_layer])
+                              self.max_len, -1, -1, int(stride_idx[0]) if len(stride_idx) == 1 else -1, mask,
+                              self.group_size, 0, {"conv2d": 0, "conv2d6": 6, "conv2d8": 8}[self.input_layer], 0,
+                              sum(1 << v for v in stride_idx) if len(stride_idx) > 1 else 0)
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ppasr_create(ctypes.byref(desc), blobs, len(sd), ctypes.byref(handle)))

@@ -40,9 +40,16 @@ class SqueezeformerModel(ConformerModel):
         self.max_len = int(conf.get("max_len", 5000))
         self.reduce_idx = conf.get("reduce_idx", 5)
         self.recover_idx = conf.get("recover_idx", 11)
-        for key, want in (("pos_enc_layer_type", "rel_pos"), ("activation_type", "swish"), ("normalize_before", False)):
+        for key, want in (("pos_enc_layer_type", "rel_pos"), ("normalize_before", False)):
             if key in conf and conf[key] != want:
                 raise NotImplementedError(f"encoder_conf.{key}={conf[key]!r}: only {want!r} is built")
+        # activation_type (squeezeformer/encoder.py:45: the feed-forward modules' and the conv module's activation): anything
+        # but swish runs on the library's general layer route
+        from ppasr_amd.model_utils.conformer.model import _ACT_CODES
+        act = conf.get("activation_type", "swish")
+        if act not in _ACT_CODES:
+            raise KeyError(act)  # get_activation (utils/common.py:206)
+        self.activation_type = act
         # adaptive_scale = False: a flag (the checkpoint still carries the unused ada_scale / ada_bias, attention.py:34-37);
         # dw_stride = True: recognised by ppasr_create from the depthwise shape of encoder.embed.dw_conv.weight
         self.adaptive_scale = bool(conf.get("adaptive_scale", True))
@@ -76,6 +83,7 @@ class SqueezeformerModel(ConformerModel):
                               -1 if self.recover_idx is None else int(self.recover_idx), -1, 0, 0)
         if not self.adaptive_scale:
             desc.options |= _lib.PPASR_OPT_SQ_NO_ADAPTIVE_SCALE
+        desc.options |= _ACT_CODES[act] << _lib.PPASR_OPT_ACT_SHIFT
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ppasr_create(ctypes.byref(desc), blobs, len(sd), ctypes.byref(handle)))

@@ -263,8 +263,10 @@ def efficient_conformer_state_dict(stride_layer_idx=3, group_layer_idx=(0, 1, 2,
             sd[p + "self_attn.pos_bias_u"] = _xavier(rng, (h, dk * group_size), h, dk * group_size)
             sd[p + "self_attn.pos_bias_v"] = _xavier(rng, (h, dk * group_size), h, dk * group_size)
             sd[p + "self_attn.linear_pos.bias"] = _kaiming(rng, (d,), d)
-        if stride_layer_idx is not None and i > stride_layer_idx:
-            k2 = cnn_module_kernel // 2
+        strides = [] if stride_layer_idx is None else ([stride_layer_idx] if isinstance(stride_layer_idx, int) else list(stride_layer_idx))
+        n_before = sum(1 for v in strides if v < i)
+        if n_before:  # cnn_module_kernels: // 2 per stride layer passed (encoder.py:123-128)
+            k2 = cnn_module_kernel >> n_before
             sd[p + "conv_module.depthwise_conv.weight"] = _kaiming(rng, (d, 1, k2), k2)
     return sd
 

@@ -39,6 +39,18 @@ SMALL = {
     # output_size 768 / 12 heads: grouped attention on a width that is not a power of two (k_attention_t<192>'s flat-offset split)
     "eff768_n": _former("efficient_conformer", False, 2, 53, 589, (2, 148, [148, 77], 590), stride_layer_idx=1,
                         group_layer_idx=(0,), output_size=768, attention_heads=12),
+    # the EfficientConformerEncoder constructor arguments no shipped YAML sets (efficient_conformer/encoder.py:50-54,117-128):
+    # SEVERAL stride layers (kernels 15 -> 7 -> 3, 16x frame rate; the general layer route, batched) and group_size 2 / 4
+    "eff_ms": _former("efficient_conformer", False, 5, 53, 591, (2, 197, [197, 120], 592), stride_layer_idx=[1, 3],
+                      group_layer_idx=(0, 1, 2)),
+    "eff_ms_c": _former("efficient_conformer", True, 4, 53, 593, (2, 163, [163, 77], 594), stride_layer_idx=[0, 2],
+                        group_layer_idx=(0,)),
+    "eff_g2": _former("efficient_conformer", False, 3, 53, 595, (2, 147, [147, 86], 596), stride_layer_idx=1,
+                      group_layer_idx=(0, 1), group_size=2),
+    "eff_g4": _former("efficient_conformer", True, 3, 53, 597, (3, 150, [150, 101, 13], 598), chunk_frames=64 * 3 + 67,
+                      required=(-16, 32), stride_layer_idx=1, group_layer_idx=(0, 2), group_size=4),
+    "eff512_g2": _former("efficient_conformer", False, 2, 53, 599, (2, 148, [148, 77], 600), stride_layer_idx=1,
+                         group_layer_idx=(0, 1), group_size=2, output_size=512, attention_heads=8),
     # Squeezeformer: reduce before layer 1, recover before layer 3
     "sq_s": _former("squeezeformer", True, 4, 59, 521, (2, 131, [131, 77], 522), chunk_frames=64 * 4 + 40,
                     required=(-16, 32), reduce_idx=1, recover_idx=3),
@@ -85,6 +97,11 @@ SMALL = {
     "act_relu6": _former("conformer", True, 1, 61, 577, (1, 99, [99], 578), chunk_frames=64 * 2 + 30, required=(-16,),
                          activation_type="relu6", cnn_module_kernel=31),
     "act_hardshrink": _former("conformer", True, 1, 61, 579, (1, 99, [99], 580), activation_type="hardshrink"),
+    # activation_type (squeezeformer/encoder.py:45) other than swish: the general layer route at width 256
+    "sq_gelu_s": _former("squeezeformer", True, 3, 59, 601, (2, 131, [131, 77], 602), chunk_frames=64 * 3 + 40, required=(-16,),
+                         reduce_idx=1, recover_idx=2, activation_type="gelu"),
+    "sq_relu_n": _former("squeezeformer", False, 3, 59, 603, (2, 131, [131, 70], 604), reduce_idx=1, recover_idx=2,
+                         activation_type="relu", cnn_norm_type="batch_norm"),
     "sq_bn": _former("squeezeformer", False, 3, 59, 543, (2, 131, [131, 70], 544), reduce_idx=1, recover_idx=2,
                      cnn_norm_type="batch_norm"),
     # encoder_dim 512 / 8 heads (configs/squeezeformer.yml:3-5 "for big data ... 512"): the general layer route
@@ -142,6 +159,7 @@ def state_dict(case, perturb=True):
             return efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=seed)
         return efficient_conformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn,
                                               stride_layer_idx=kw["stride_layer_idx"], group_layer_idx=kw["group_layer_idx"],
+                                              group_size=kw.get("group_size", 3),
                                               output_size=kw.get("output_size", 256), attention_heads=kw.get("attention_heads", 4),
                                               cnn_module_kernel=kw.get("cnn_module_kernel", 15))
     if fam == "squeezeformer":
@@ -187,8 +205,9 @@ def reference_encoder_conf(case):
                  normalize_before=True, pos_enc_layer_type="rel_pos", attention_dropout_rate=0.1,
                  positional_dropout_rate=0.1)
         if L != 12:
-            c.update(stride_layer_idx=kw["stride_layer_idx"], stride=2, group_layer_idx=tuple(kw["group_layer_idx"]),
-                     group_size=3, stride_kernel=True)
+            sl = kw["stride_layer_idx"]
+            c.update(stride_layer_idx=sl, stride=2 if isinstance(sl, int) else [2] * len(sl),
+                     group_layer_idx=tuple(kw["group_layer_idx"]), group_size=kw.get("group_size", 3), stride_kernel=True)
         else:
             c["efficient_conf"] = dict(stride_layer_idx=[3], stride=[2], group_layer_idx=[0, 1, 2, 3], group_size=3,
                                        stride_kernel=True)
@@ -200,7 +219,7 @@ def reference_encoder_conf(case):
                     feed_forward_expansion_factor=8, input_dropout_rate=0.1, feed_forward_dropout_rate=0.1,
                     attention_dropout_rate=0.1, adaptive_scale=kw.get("adaptive_scale", True),
                     dw_stride=kw.get("dw_stride", False), cnn_module_kernel=31, normalize_before=False,
-                    activation_type="swish", pos_enc_layer_type="rel_pos",
+                    activation_type=kw.get("activation_type", "swish"), pos_enc_layer_type="rel_pos",
                     cnn_norm_type=kw.get("cnn_norm_type", "layer_norm"))
     if fam == "deepspeech2":
         return dict(num_rnn_layers=L, rnn_size=1024, use_gru=kw.get("use_gru", False))
@@ -211,7 +230,9 @@ def product_encoder_conf(case):
     """The same configuration in the form ppasr_amd's model wrappers take (YAML-shaped)."""
     c = reference_encoder_conf(case)
     if case["family"] == "efficient_conformer" and "efficient_conf" not in c:
-        c["efficient_conf"] = dict(stride_layer_idx=[c.pop("stride_layer_idx")], stride=[c.pop("stride")],
+        sl, st = c.pop("stride_layer_idx"), c.pop("stride")
+        c["efficient_conf"] = dict(stride_layer_idx=[sl] if isinstance(sl, int) else list(sl),
+                                   stride=[st] if isinstance(st, int) else list(st),
                                    group_layer_idx=list(c.pop("group_layer_idx")), group_size=c.pop("group_size"),
                                    stride_kernel=c.pop("stride_kernel"))
     return c

@@ -268,3 +268,39 @@ def test_staircase_fast_path_streaming_state_is_identical():
                 out.append(dec.decode_chunk(p[None, s0:s0 + 16], np.array([16])))
         res.append(out)
     assert res[0] == res[1]
+
+
+@pytest.mark.parametrize("beam,V,T", [(10, 300, 120), (16, 90, 100), (100, 500, 80), (300, 4233, 60)])
+@pytest.mark.parametrize("kind", ["peaky", "tied", "flat"])
+def test_clipped_rows_without_margin_fall_back_to_full_rows(beam, V, T, kind):
+    """PPASR_BEAM_MARGIN=0 (rows clipped to the bare (rank + 1)(k + 1) <= beam staircase): the verification now fails on a
+    share of the frames, so the fall-back -- full rows after a clipped attempt, including the tiny-beam path's merged last
+    phase being undone -- is exercised; results must still equal the full-row selection bit for bit."""
+    from ppasr_amd.decoders.beam_search_decoder import beam_search_ids
+    rng = np.random.Generator(np.random.PCG64(beam * 3 + V))
+    B = 3
+    batch = np.stack([_tied_probs(rng, T, V) if kind == "tied" else _probs(rng, T, V, kind) for _ in range(B)])
+    dev = torch.from_numpy(batch).cuda()
+    old = os.environ.get("PPASR_BEAM_MARGIN")
+    os.environ["PPASR_BEAM_MARGIN"] = "0"
+    try:
+        with _beam_fast(True):
+            a = beam_search_ids(dev, beam, 0.99, 40, 0, nbest=min(beam, 8))
+            torch.cuda.synchronize()
+    finally:
+        if old is None:
+            os.environ.pop("PPASR_BEAM_MARGIN", None)
+        else:
+            os.environ["PPASR_BEAM_MARGIN"] = old
+    with _beam_fast(False):
+        b = beam_search_ids(dev, beam, 0.99, 40, 0, nbest=min(beam, 8))
+        torch.cuda.synchronize()
+    assert torch.equal(a[1], b[1])
+    ln = a[1].cpu().numpy()
+    ta, tb = a[0].cpu().numpy(), b[0].cpu().numpy()
+    for u in range(B):
+        for r in range(ln.shape[1]):
+            n = ln[u, r]
+            if n >= 0:
+                assert np.array_equal(ta[u, r, :n], tb[u, r, :n]), (u, r)
+    assert torch.equal(a[2], b[2])

@@ -41,12 +41,13 @@ def make_oracle(case, sd):
         return ConformerOracle(sd, num_blocks=L, causal=causal, attention_heads=kw.get("attention_heads", 4), **opts)
     if fam == "efficient_conformer":
         return EfficientConformerOracle(sd, num_blocks=L, stride_layer_idx=kw["stride_layer_idx"],
-                                        group_layer_idx=kw["group_layer_idx"], causal=causal,
+                                        group_layer_idx=kw["group_layer_idx"], group_size=kw.get("group_size", 3), causal=causal,
                                         attention_heads=kw.get("attention_heads", 4),
                                         cnn_module_kernel=kw.get("cnn_module_kernel", 15))
     if fam == "squeezeformer":
         return SqueezeformerOracle(sd, num_blocks=L, reduce_idx=kw["reduce_idx"], recover_idx=kw["recover_idx"], causal=causal,
-                                   attention_heads=kw.get("attention_heads", 4), adaptive_scale=kw.get("adaptive_scale", True))
+                                   attention_heads=kw.get("attention_heads", 4), adaptive_scale=kw.get("adaptive_scale", True),
+                                   activation_type=kw.get("activation_type", "swish"))
     return DeepSpeech2Oracle(sd, num_rnn_layers=L, streaming=case["streaming"], use_gru=kw.get("use_gru", False))
 
 
