@@ -108,6 +108,8 @@ enum {
                                   the checkpoint's ada_scale / ada_bias are then not applied).  The two other options of that
                                   encoder need no flag: dw_stride = True is recognised by the [d][1][3][3] shape of
                                   encoder.embed.dw_conv.weight, final_proj by the presence of encoder.final_proj.weight */
+  PPASR_OPT_SQ_PRE_NORM = 8192, /* model_type squeezeformer only: normalize_before = True (squeezeformer/encoder.py:49,467-493:
+                                  LayerNorm_k in front of module k instead of behind the residual sum); general layer route */
   PPASR_OPT_ACT_SHIFT = 8,     /* activation_type (utils/common.py:189-206) in bits 8..11: */
   PPASR_OPT_ACT_MASK = 15
 };

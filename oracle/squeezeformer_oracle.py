@@ -14,7 +14,8 @@ class SqueezeformerOracle(ConformerOracle):
     (causal conv module, TimeReductionLayerStream; squeezeformer/model.py:35-39)."""
 
     def __init__(self, sd, attention_heads=4, num_blocks=12, cnn_module_kernel=31, reduce_idx=5, recover_idx=11,
-                 max_len=5000, dtype=torch.float32, causal=True, adaptive_scale=True, activation_type="swish"):
+                 max_len=5000, dtype=torch.float32, causal=True, adaptive_scale=True, activation_type="swish",
+                 normalize_before=False):
         # causal=False: the non-streaming model (non-causal conv modules, TimeReductionLayer1D; model.py:35-39)
         sd = dict(sd)
         sd.setdefault("encoder.after_norm.weight", sd["encoder.preln.weight"])  # only used for self.d
@@ -22,6 +23,7 @@ class SqueezeformerOracle(ConformerOracle):
                          activation_type=activation_type)  # (squeezeformer/encoder.py:45,103: FFN and conv module activation)
         self.reduce_idx = reduce_idx
         self.recover_idx = recover_idx
+        self.normalize_before = normalize_before  # squeezeformer/encoder.py:49
         # adaptive_scale = False (squeezeformer/encoder.py:44): the parameters exist but are not applied
         # (attention.py:120-123, positionwise.py:63-64, convolution.py:119-120)
         self.adaptive_scale = adaptive_scale
@@ -112,6 +114,16 @@ class SqueezeformerOracle(ConformerOracle):
     def _layer_sq(self, i, x, mask, pos_emb, mask_pad, att_cache=None, cnn_cache=None, return_caches=False):
         # SqueezeformerEncoderLayer.forward  squeezeformer/encoder.py:435-506 (normalize_before=False)
         p = f"encoder.encoders.{i}"
+        if self.normalize_before:  # :467-493: LayerNorm_k in front of module k, the residual is the un-normalised x
+            att, new_att = self._attention_sq(self._ln(x, p + ".layer_norm1"), mask, pos_emb, p + ".self_attn", att_cache)
+            x = x + att
+            x = x + self._ffn_sq(self._ln(x, p + ".layer_norm2"), p + ".ffn1")
+            cv, new_cnn = self._conv_sq(self._ln(x, p + ".layer_norm3"), mask_pad, p + ".conv_module", cnn_cache)
+            x = x + cv
+            x = x + self._ffn_sq(self._ln(x, p + ".layer_norm4"), p + ".ffn2")
+            if return_caches:
+                return x, new_att, new_cnn
+            return x
         att, new_att = self._attention_sq(x, mask, pos_emb, p + ".self_attn", att_cache)
         x = self._ln(x + att, p + ".layer_norm1")
         x = self._ln(x + self._ffn_sq(x, p + ".ffn1"), p + ".layer_norm2")

@@ -26,6 +26,7 @@ N_KERNEL_CLASSES = 10
 # ppasr_model_desc::options (include/ppasr_hip.h)
 PPASR_OPT_POST_NORM, PPASR_OPT_CONCAT_AFTER, PPASR_OPT_NO_MACARON, PPASR_OPT_NO_CNN, PPASR_OPT_ACT_SHIFT = 4, 8, 16, 32, 8
 PPASR_OPT_SQ_NO_ADAPTIVE_SCALE = 4096
+PPASR_OPT_SQ_PRE_NORM = 8192
 PPASR_GEMM_F32 = 0
 PPASR_GEMM_F16X3 = 1
 PPASR_GEMM_COVERS_LAYERS, PPASR_GEMM_COVERS_FRONT, PPASR_GEMM_COVERS_HEAD = 1, 2, 4

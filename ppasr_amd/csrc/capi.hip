@@ -89,14 +89,15 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
                         desc->output_size != kD) ||
                        (eff && multi_stride) ||  // (several stride layers: kernels 15 -> 7 -> 3 ..., the general route)
                        (desc->model_type == PPASR_MODEL_SQUEEZEFORMER &&
-                        ((desc->options >> PPASR_OPT_ACT_SHIFT) & PPASR_OPT_ACT_MASK) != PPASR_ACT_SWISH);  // (activation_type)
+                        (((desc->options >> PPASR_OPT_ACT_SHIFT) & PPASR_OPT_ACT_MASK) != PPASR_ACT_SWISH ||
+                         (desc->options & PPASR_OPT_SQ_PRE_NORM) != 0));  // (activation_type, normalize_before = True)
   // Squeezeformer takes two of the option fields: adaptive_scale = False and activation_type (squeezeformer/encoder.py:44-45)
   const int sq_opts = desc->model_type == PPASR_MODEL_SQUEEZEFORMER
-                          ? (PPASR_OPT_SQ_NO_ADAPTIVE_SCALE | (PPASR_OPT_ACT_MASK << PPASR_OPT_ACT_SHIFT)) : 0;
+                          ? (PPASR_OPT_SQ_NO_ADAPTIVE_SCALE | PPASR_OPT_SQ_PRE_NORM | (PPASR_OPT_ACT_MASK << PPASR_OPT_ACT_SHIFT)) : 0;
   if (((desc->options & ~sq_opts) != 0 || desc->input_layer == 1) && desc->model_type != PPASR_MODEL_CONFORMER)
     return fail(PPASR_EUNSUPPORTED, "non-default encoder options / input_layer=linear are built for model_type=conformer");
-  if ((desc->options & PPASR_OPT_SQ_NO_ADAPTIVE_SCALE) && desc->model_type != PPASR_MODEL_SQUEEZEFORMER)
-    return fail(PPASR_EINVAL, "PPASR_OPT_SQ_NO_ADAPTIVE_SCALE is a Squeezeformer option");
+  if ((desc->options & (PPASR_OPT_SQ_NO_ADAPTIVE_SCALE | PPASR_OPT_SQ_PRE_NORM)) && desc->model_type != PPASR_MODEL_SQUEEZEFORMER)
+    return fail(PPASR_EINVAL, "PPASR_OPT_SQ_NO_ADAPTIVE_SCALE / PPASR_OPT_SQ_PRE_NORM are Squeezeformer options");
   if (desc->linear_units % 256 != 0 || desc->linear_units <= 0) return fail(PPASR_EUNSUPPORTED, "linear_units % 256 != 0");
   if (!generic && !fused_ks) return fail(PPASR_EUNSUPPORTED, "cnn_module_kernel must be 7, 15 or 31");
   if (generic) {
@@ -152,6 +153,7 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
   m->gen.macaron = !(desc->options & PPASR_OPT_NO_MACARON);
   m->gen.use_cnn = !(desc->options & PPASR_OPT_NO_CNN);
   m->gen.act = (desc->options >> PPASR_OPT_ACT_SHIFT) & PPASR_OPT_ACT_MASK;
+  m->gen.sq_pre_norm = (desc->options & PPASR_OPT_SQ_PRE_NORM) != 0;
   const auto& go = m->gen;
   if (il != 0 && desc->model_type == PPASR_MODEL_SQUEEZEFORMER)
     return fail(PPASR_EUNSUPPORTED, "squeezeformer: only the conv2d front end is built");

@@ -887,8 +887,14 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
       e.ps = ps;
       return e;
     };
-    // ---- x = LN1(x + MHA(x)) ----
-    if (fused_ffn512() && D == kD512)
+    // normalize_before (squeezeformer/encoder.py:49,467-493; False in every shipped YAML): LayerNorm_k in FRONT of module k
+    // (its output feeds the module, the residual stays x) instead of behind the residual sum
+    const bool pre = h->gen.sq_pre_norm;
+    // ---- x = LN1(x + MHA(x))   [pre: x + MHA(LN1(x))] ----
+    if (pre) {
+      ln(x, y, W.ln1_g, W.ln1_b, 1e-5f, kActNone, false, Mi, Ti, mul);
+      dense(y, D, W.wqkv, W.bqkv, big, Mi, D, 3 * D, 3 * D, 3 * D, st, 1.0f, plain_epi());
+    } else if (fused_ffn512() && D == kD512)
       PPASR_LAUNCH(k_g_proj512<false>, dim3((Mi + kRows - 1) / kRows), dim3(kThreads), kLdsProj512, st, x, big, 3 * D,
                    (const float*)nullptr, (const float*)nullptr, 1e-5f, (const int64_t*)nullptr, Ti, mul, W.wqkv, W.bqkv,
                    3 * D / 32 / kWaves, Mi, ps);
@@ -912,9 +918,15 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
     at.dm = D;
     launch_attention(at, B, heads, st);
     dense(ctx, D, W.wo, W.bo, x, Mi, D, D, D, D, st, 1.0f, res_epi(false));
-    ln(x, x, W.ln1_g, W.ln1_b, 1e-5f, kActNone, false, Mi, Ti, mul);
-    // ---- x = LN2(x + FFN1(x)) ----
-    auto sq_ffn = [&](const f32x4* w1, const float* b1, const f32x4* w2, const float* b2) {
+    if (!pre) ln(x, x, W.ln1_g, W.ln1_b, 1e-5f, kActNone, false, Mi, Ti, mul);
+    // ---- x = LN2(x + FFN1(x))   [pre: x + FFN1(LN2(x))] ----
+    auto sq_ffn = [&](const f32x4* w1, const float* b1, const f32x4* w2, const float* b2, const float* lg, const float* lb) {
+      if (pre) {
+        ln(x, y, lg, lb, 1e-5f, kActNone, false, Mi, Ti, mul);
+        dense(y, D, w1, b1, big, Mi, D, H, H, H, st, 1.0f, act_epi());
+        dense(big, H, w2, b2, x, Mi, H, D, D, D, st, 1.0f, res_epi(false));
+        return;
+      }
       if (fused_ffn512() && D == kD512) {
         PPASR_LAUNCH(k_g_ffn512, dim3((Mi + kRows - 1) / kRows), dim3(kThreads), kLdsFfn512, st, x, x, (const float*)nullptr,
                      (const float*)nullptr, w1, b1, w2, b2, 1.0f, h->gen.act, Mi, H / 256, ps);
@@ -923,17 +935,19 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
       dense(x, D, w1, b1, big, Mi, D, H, H, H, st, 1.0f, act_epi());
       dense(big, H, w2, b2, x, Mi, H, D, D, D, st, 1.0f, res_epi(false));
     };
-    sq_ffn(W.ff1_w1, W.ff1_b1, W.ff1_w2, W.ff1_b2);
-    ln(x, x, W.ln2_g, W.ln2_b, 1e-5f, kActNone, false, Mi, Ti, mul);
+    sq_ffn(W.ff1_w1, W.ff1_b1, W.ff1_w2, W.ff1_b2, W.ln2_g, W.ln2_b);
+    if (!pre) ln(x, x, W.ln2_g, W.ln2_b, 1e-5f, kActNone, false, Mi, Ti, mul);
     // ---- x = LN3(x + conv(x)): ada scale / bias, THEN the pad mask (convolution.py:119-127), the unfolded pointwise_conv1 ----
     {
       float* a_new = a + (size_t)lo_s * D;
       const int rows = lo_s + Mi;
-      if (fused_ffn512() && D == kD512 && lo_s == 0) {  // ada scale / bias + pad mask + pointwise_conv1 + GLU in one launch
+      if (pre) ln(x, y, W.ln3_g, W.ln3_b, 1e-5f, kActNone, false, Mi, Ti, mul);
+      const float* cin = pre ? y : x;  // the conv module's input
+      if (!pre && fused_ffn512() && D == kD512 && lo_s == 0) {  // ada scale / bias + pad mask + pointwise_conv1 + GLU in one launch
         PPASR_LAUNCH(k_g_proj512<true>, dim3((Mi + kRows - 1) / kRows), dim3(kThreads), kLdsProj512, st, x, g, D, W.cm_scale,
                      W.cm_bias, -1.0f, lens, Ti, mul, W.pw1_raw, W.pw1_b_raw, 2, Mi, ps);
       } else {
-        ln(x, a_new, W.cm_scale, W.cm_bias, -1.0f, kActNone, true, Mi, Ti, mul);
+        ln(cin, a_new, W.cm_scale, W.cm_bias, -1.0f, kActNone, true, Mi, Ti, mul);
         if (lo_s) {  // the cache holds the SCALED inputs of the previous chunks; new cache = last lo rows of [cache | chunk]
           float* hist = s->xh_hist + (size_t)i * s->lo * D;
           HIP_TRY(hipMemcpyAsync(a, hist, (size_t)lo_s * D * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -945,11 +959,11 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
       launch_dwconv(g, y, W.dw_w, W.dw_b, W.glu_pad, B, Ti, D, KS, left, lo_s, 1, Ti, st, ps);
       ln(y, y, W.ln_cm_g, W.ln_cm_b, W.cm_eps, h->gen.act, false, Mi, Ti, mul);
       dense(y, D, W.pw2, W.pw2_b, x, Mi, D, D, D, D, st, 1.0f, res_epi(true));
-      ln(x, x, W.ln3_g, W.ln3_b, 1e-5f, kActNone, false, Mi, Ti, mul);
+      if (!pre) ln(x, x, W.ln3_g, W.ln3_b, 1e-5f, kActNone, false, Mi, Ti, mul);
     }
     // ---- x = LN4(x + FFN2(x)) ----
-    sq_ffn(W.ff2_w1, W.ff2_b1, W.ff2_w2, W.ff2_b2);
-    ln(x, x, W.ln4_g, W.ln4_b, 1e-5f, kActNone, false, Mi, Ti, mul);
+    sq_ffn(W.ff2_w1, W.ff2_b1, W.ff2_w2, W.ff2_b2, W.ln4_g, W.ln4_b);
+    if (!pre) ln(x, x, W.ln4_g, W.ln4_b, 1e-5f, kActNone, false, Mi, Ti, mul);
   }
   // ---- ctc_lo -> softmax (no after_norm in Squeezeformer, encoder.py:232-235) ----
   float* lg = logits ? logits : (probs ? probs : ws + wl.lg);

@@ -109,6 +109,7 @@ struct ppasr_model_s {
     int pos = 0;  // PPASR_OPT_POS_*
     bool post_norm = false, concat_after = false, macaron = true, use_cnn = true;
     int act = 0;  // PPASR_ACT_*
+    bool sq_pre_norm = false;  // Squeezeformer normalize_before = True
   } gen;
   struct GenLayerX {  // what LayerW has no slot for
     const f32x4* wcat = nullptr;  // concat_linear [2d][d], packed

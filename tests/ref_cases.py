@@ -102,6 +102,11 @@ SMALL = {
                          reduce_idx=1, recover_idx=2, activation_type="gelu"),
     "sq_relu_n": _former("squeezeformer", False, 3, 59, 603, (2, 131, [131, 70], 604), reduce_idx=1, recover_idx=2,
                          activation_type="relu", cnn_norm_type="batch_norm"),
+    # normalize_before = True (squeezeformer/encoder.py:49): pre-norm layers
+    "sq_pre_s": _former("squeezeformer", True, 3, 59, 605, (2, 131, [131, 77], 606), chunk_frames=64 * 3 + 40, required=(-16,),
+                        reduce_idx=1, recover_idx=2, normalize_before=True),
+    "sq_pre_n": _former("squeezeformer", False, 3, 59, 607, (2, 131, [131, 70], 608), reduce_idx=1, recover_idx=2,
+                        normalize_before=True, activation_type="hardswish"),
     "sq_bn": _former("squeezeformer", False, 3, 59, 543, (2, 131, [131, 70], 544), reduce_idx=1, recover_idx=2,
                      cnn_norm_type="batch_norm"),
     # encoder_dim 512 / 8 heads (configs/squeezeformer.yml:3-5 "for big data ... 512"): the general layer route
@@ -218,7 +223,7 @@ def reference_encoder_conf(case):
                     reduce_idx=kw.get("reduce_idx", 5), recover_idx=kw.get("recover_idx", 11),
                     feed_forward_expansion_factor=8, input_dropout_rate=0.1, feed_forward_dropout_rate=0.1,
                     attention_dropout_rate=0.1, adaptive_scale=kw.get("adaptive_scale", True),
-                    dw_stride=kw.get("dw_stride", False), cnn_module_kernel=31, normalize_before=False,
+                    dw_stride=kw.get("dw_stride", False), cnn_module_kernel=31, normalize_before=kw.get("normalize_before", False),
                     activation_type=kw.get("activation_type", "swish"), pos_enc_layer_type="rel_pos",
                     cnn_norm_type=kw.get("cnn_norm_type", "layer_norm"))
     if fam == "deepspeech2":

@@ -47,7 +47,8 @@ def make_oracle(case, sd):
     if fam == "squeezeformer":
         return SqueezeformerOracle(sd, num_blocks=L, reduce_idx=kw["reduce_idx"], recover_idx=kw["recover_idx"], causal=causal,
                                    attention_heads=kw.get("attention_heads", 4), adaptive_scale=kw.get("adaptive_scale", True),
-                                   activation_type=kw.get("activation_type", "swish"))
+                                   activation_type=kw.get("activation_type", "swish"),
+                                   normalize_before=kw.get("normalize_before", False))
     return DeepSpeech2Oracle(sd, num_rnn_layers=L, streaming=case["streaming"], use_gru=kw.get("use_gru", False))
 
 
