@@ -92,5 +92,12 @@ def test_option_codes_match_the_header():
     assert set(cm._ACT_CODES) == {"hardshrink", "hardswish", "hardtanh", "tanh", "relu", "relu6", "leakyrelu", "selu", "swish",
                                   "gelu", "elu"}
     assert max(cm._ACT_CODES.values()) <= enums["PPASR_OPT_ACT_MASK"]
-    # the descriptor the bindings build has the header's field count (18 ints)
-    assert ctypes.sizeof(_lib.ModelDesc) == 18 * ctypes.sizeof(ctypes.c_int)
+    assert enums["PPASR_OPT_SQ_NO_ADAPTIVE_SCALE"] == _lib.PPASR_OPT_SQ_NO_ADAPTIVE_SCALE
+    assert enums["PPASR_OPT_SQ_PRE_NORM"] == _lib.PPASR_OPT_SQ_PRE_NORM
+    # the descriptor the bindings build has the header's field count (19 ints: + stride_layer_mask in round 6) and order
+    end = text.index("} ppasr_model_desc;")
+    hdr = text[text.rindex("typedef struct", 0, end):end]
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    fields = re.findall(r"\bint\s+(\w+)\s*;", hdr)
+    assert fields == [f[0] for f in _lib.ModelDesc._fields_]
+    assert ctypes.sizeof(_lib.ModelDesc) == 19 * ctypes.sizeof(ctypes.c_int)
