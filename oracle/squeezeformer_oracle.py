@@ -15,7 +15,7 @@ class SqueezeformerOracle(ConformerOracle):
 
     def __init__(self, sd, attention_heads=4, num_blocks=12, cnn_module_kernel=31, reduce_idx=5, recover_idx=11,
                  max_len=5000, dtype=torch.float32, causal=True, adaptive_scale=True, activation_type="swish",
-                 normalize_before=False):
+                 normalize_before=False, pos_enc_layer_type="rel_pos"):
         # causal=False: the non-streaming model (non-causal conv modules, TimeReductionLayer1D; model.py:35-39)
         sd = dict(sd)
         sd.setdefault("encoder.after_norm.weight", sd["encoder.preln.weight"])  # only used for self.d
@@ -24,6 +24,7 @@ class SqueezeformerOracle(ConformerOracle):
         self.reduce_idx = reduce_idx
         self.recover_idx = recover_idx
         self.normalize_before = normalize_before  # squeezeformer/encoder.py:49
+        self.plain_mha = pos_enc_layer_type != "rel_pos"  # :101-105: conformer's MultiHeadedAttention (no ada scale, no positions)
         # adaptive_scale = False (squeezeformer/encoder.py:44): the parameters exist but are not applied
         # (attention.py:120-123, positionwise.py:63-64, convolution.py:119-120)
         self.adaptive_scale = adaptive_scale
@@ -56,6 +57,12 @@ class SqueezeformerOracle(ConformerOracle):
 
     def _attention_sq(self, x, mask, pos_emb, prefix, cache=None):
         # squeezeformer/attention.py:96-162 (adaptive scale :120-123, linear_pos WITH bias :28, cache :128-135)
+        if self.plain_mha:  # conformer/attention.py:123-170
+            saved, self.pos_type = getattr(self, "pos_type", "rel_pos"), "no_pos"
+            try:
+                return self._attention(x, mask, pos_emb, cache, prefix)
+            finally:
+                self.pos_type = saved
         x = self._ada(x, prefix)
         B, T, _ = x.shape
         h, dk = self.h, self.dk

@@ -90,10 +90,13 @@ ppasr_status ppasr_create(const ppasr_model_desc* desc, const ppasr_weight_blob*
                        (eff && multi_stride) ||  // (several stride layers: kernels 15 -> 7 -> 3 ..., the general route)
                        (desc->model_type == PPASR_MODEL_SQUEEZEFORMER &&
                         (((desc->options >> PPASR_OPT_ACT_SHIFT) & PPASR_OPT_ACT_MASK) != PPASR_ACT_SWISH ||
-                         (desc->options & PPASR_OPT_SQ_PRE_NORM) != 0));  // (activation_type, normalize_before = True)
+                         (desc->options & PPASR_OPT_SQ_PRE_NORM) != 0 ||
+                         (desc->options & PPASR_OPT_POS_MASK) != PPASR_OPT_POS_REL));  // (activation_type, normalize_before = True,
+                                                                                       //  pos_enc_layer_type != rel_pos)
   // Squeezeformer takes two of the option fields: adaptive_scale = False and activation_type (squeezeformer/encoder.py:44-45)
   const int sq_opts = desc->model_type == PPASR_MODEL_SQUEEZEFORMER
-                          ? (PPASR_OPT_SQ_NO_ADAPTIVE_SCALE | PPASR_OPT_SQ_PRE_NORM | (PPASR_OPT_ACT_MASK << PPASR_OPT_ACT_SHIFT)) : 0;
+                          ? (PPASR_OPT_SQ_NO_ADAPTIVE_SCALE | PPASR_OPT_SQ_PRE_NORM | PPASR_OPT_POS_MASK |
+                             (PPASR_OPT_ACT_MASK << PPASR_OPT_ACT_SHIFT)) : 0;
   if (((desc->options & ~sq_opts) != 0 || desc->input_layer == 1) && desc->model_type != PPASR_MODEL_CONFORMER)
     return fail(PPASR_EUNSUPPORTED, "non-default encoder options / input_layer=linear are built for model_type=conformer");
   if ((desc->options & (PPASR_OPT_SQ_NO_ADAPTIVE_SCALE | PPASR_OPT_SQ_PRE_NORM)) && desc->model_type != PPASR_MODEL_SQUEEZEFORMER)

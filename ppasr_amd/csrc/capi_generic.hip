@@ -900,7 +900,10 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
                    3 * D / 32 / kWaves, Mi, ps);
     else
       dense(x, D, W.wqkv, W.bqkv, big, Mi, D, 3 * D, 3 * D, 3 * D, st, 1.0f, plain_epi());
-    AttnArgs at{big, 3 * D, big + D, 3 * D, big + 2 * D, 3 * D, Ti, Ti, 0, lens, ctx, W.pos_u, W.pos_v, W.ptab, reduced ? 2 : 1,
+    // (pos_enc_layer_type != rel_pos: plain MultiHeadedAttention -- the positional operand is one row of zeros, stride 0)
+    const bool plain_mha = h->gen.pos != PPASR_OPT_POS_REL;
+    AttnArgs at{big, 3 * D, big + D, 3 * D, big + 2 * D, 3 * D, Ti, Ti, 0, lens, ctx, W.pos_u, W.pos_v, W.ptab,
+                plain_mha ? 0 : (reduced ? 2 : 1),
                 mul, Ti, Ti, 1};
     if (s) {  // keys / values: [cache | chunk] in the layer's device caches
       const int n_cache = reduced ? plan->used_r : s->cache_t;

@@ -152,13 +152,21 @@ ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe
       GETW(bv, p + "self_attn.linear_v.bias", d);
       GETW(wo, p + "self_attn.linear_out.weight", d * d);
       GETW(bo, p + "self_attn.linear_out.bias", d);
-      GETW(wp, p + "self_attn.linear_pos.weight", d * d);
-      GETW(bp, p + "self_attn.linear_pos.bias", d);  // linear_pos HAS a bias here (squeezeformer/attention.py:28)
-      GETW(pu, p + "self_attn.pos_bias_u", d);
-      GETW(pv, p + "self_attn.pos_bias_v", d);
-      GETW(as, p + "self_attn.ada_scale", d);
-      GETW(ab, p + "self_attn.ada_bias", d);
-      adapt(as, ab);
+      // pos_enc_layer_type != rel_pos (squeezeformer/encoder.py:101-105): conformer's plain MultiHeadedAttention -- no
+      // linear_pos, no pos_bias_u / _v, no adaptive scale.  The attention kernels then contract the positional half with a
+      // row of zeros (pos_bias = 0, table stride 0), like the Conformer's abs_pos / no_pos layers
+      const bool plain_mha = (dsc.options & PPASR_OPT_POS_MASK) != PPASR_OPT_POS_REL;
+      const float *wp = nullptr, *bp = nullptr, *pu = zeros_d.data(), *pv = zeros_d.data(), *as = ones_d.data(), *ab = zeros_d.data();
+      if (!plain_mha) {
+        wp = get(p + "self_attn.linear_pos.weight", (size_t)d * d);
+        bp = get(p + "self_attn.linear_pos.bias", d);  // linear_pos HAS a bias here (squeezeformer/attention.py:28)
+        pu = get(p + "self_attn.pos_bias_u", d);
+        pv = get(p + "self_attn.pos_bias_v", d);
+        as = get(p + "self_attn.ada_scale", d);
+        ab = get(p + "self_attn.ada_bias", d);
+        if (!wp || !bp || !pu || !pv || !as || !ab) return fail(PPASR_EMISSING, "missing or mis-shaped weight: " + get.missing);
+        adapt(as, ab);
+      }
       const float* ws[3] = {wq, wk, wv};
       const float* bs[3] = {bq, bk, bv};
       UP4(pack_b(d, 3 * d, [&](int k, int n) { return as[k] * ws[n / d][(size_t)k * d + (n % d)]; }), W.wqkv);
@@ -173,16 +181,20 @@ ppasr_status squeezeformer_create(ppasr_model_s* m, BlobMap& sd, const float* pe
       UP(vec_of(bo, d), W.bo);
       UP(vec_of(pu, d), W.pos_u);
       UP(vec_of(pv, d), W.pos_v);
-      const float* wpos_dev = nullptr;
-      UP(vec_of(wp, (size_t)d * d), wpos_dev);
-      const float* bpos_dev = nullptr;
-      UP(vec_of(bp, d), bpos_dev);
-      void* pt = nullptr;
-      HIP_TRY(hipMalloc(&pt, (size_t)max_len * d * sizeof(float)));
-      m->allocs.push_back(pt);
-      launch_posproj(pe_dev, wpos_dev, bpos_dev, static_cast<float*>(pt), max_len, nullptr, d);
-      HIP_TRY(hipGetLastError());
-      W.ptab = static_cast<const float*>(pt);
+      if (plain_mha) {
+        W.ptab = W.pos_u;  // (a row of zeros; read with stride 0)
+      } else {
+        const float* wpos_dev = nullptr;
+        UP(vec_of(wp, (size_t)d * d), wpos_dev);
+        const float* bpos_dev = nullptr;
+        UP(vec_of(bp, d), bpos_dev);
+        void* pt = nullptr;
+        HIP_TRY(hipMalloc(&pt, (size_t)max_len * d * sizeof(float)));
+        m->allocs.push_back(pt);
+        launch_posproj(pe_dev, wpos_dev, bpos_dev, static_cast<float*>(pt), max_len, nullptr, d);
+        HIP_TRY(hipGetLastError());
+        W.ptab = static_cast<const float*>(pt);
+      }
     }
     {
       GETW(p1w, p + "conv_module.pointwise_conv1.weight", 2 * d * d);

@@ -40,9 +40,9 @@ class SqueezeformerModel(ConformerModel):
         self.max_len = int(conf.get("max_len", 5000))
         self.reduce_idx = conf.get("reduce_idx", 5)
         self.recover_idx = conf.get("recover_idx", 11)
-        for key, want in (("pos_enc_layer_type", "rel_pos"),):
-            if key in conf and conf[key] != want:
-                raise NotImplementedError(f"encoder_conf.{key}={conf[key]!r}: only {want!r} is built")
+        # pos_enc_layer_type (squeezeformer/encoder.py:101-112): "rel_pos", or anything else = conformer's plain
+        # MultiHeadedAttention (the front end keeps its RelPositionalEncoding scaling either way); general route
+        self.pos_enc_layer_type = str(conf.get("pos_enc_layer_type", "rel_pos"))
         # normalize_before = True (squeezeformer/encoder.py:49,467-493): LayerNorm in front of every module; general route
         self.normalize_before = bool(conf.get("normalize_before", False))
         # activation_type (squeezeformer/encoder.py:45: the feed-forward modules' and the conv module's activation): anything
@@ -88,6 +88,8 @@ class SqueezeformerModel(ConformerModel):
         desc.options |= _ACT_CODES[act] << _lib.PPASR_OPT_ACT_SHIFT
         if self.normalize_before:
             desc.options |= _lib.PPASR_OPT_SQ_PRE_NORM
+        if self.pos_enc_layer_type != "rel_pos":
+            desc.options |= 2  # PPASR_OPT_POS_NONE: no positional term in the attention scores
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ppasr_create(ctypes.byref(desc), blobs, len(sd), ctypes.byref(handle)))

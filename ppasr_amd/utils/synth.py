@@ -172,7 +172,7 @@ def synth_vocabulary(vocab_size=DEFAULT_VOCAB_SIZE):
 def squeezeformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, encoder_dim=256, attention_heads=4,
                              feed_forward_expansion_factor=8, num_blocks=12, cnn_module_kernel=31, seed=1234,
                              ctc_sharpen=8.0, perturb_norm=False, cmvn_mean=10.0, cmvn_istd=1.0 / 3.3, streaming=True,
-                             cnn_norm_type="layer_norm", dw_stride=False, output_size=None):
+                             cnn_norm_type="layer_norm", dw_stride=False, output_size=None, plain_mha=False):
     """Random-init ``SqueezeformerModel`` inference parameters (``streaming=False``: the time-reduction layer is
     ``TimeReductionLayer1D`` with a 5-tap depthwise conv instead of the 1-tap ``TimeReductionLayerStream``,
     squeezeformer/model.py:35-39).  The reference's ``init_weights()`` calls have
@@ -210,11 +210,12 @@ def squeezeformer_state_dict(input_dim=80, vocab_size=DEFAULT_VOCAB_SIZE, encode
 
     for i in range(num_blocks):
         p = f"encoder.encoders.{i}."
-        for name in ("linear_q", "linear_k", "linear_v", "linear_out", "linear_pos"):
+        for name in ("linear_q", "linear_k", "linear_v", "linear_out") + (() if plain_mha else ("linear_pos",)):
             _linear(sd, p + "self_attn." + name, d, d, rng)
-        sd[p + "self_attn.pos_bias_u"] = _xavier(rng, (h, dk), h, dk)
-        sd[p + "self_attn.pos_bias_v"] = _xavier(rng, (h, dk), h, dk)
-        ada(p + "self_attn", False)
+        if not plain_mha:  # (pos_enc_layer_type != rel_pos: conformer's MultiHeadedAttention has none of these)
+            sd[p + "self_attn.pos_bias_u"] = _xavier(rng, (h, dk), h, dk)
+            sd[p + "self_attn.pos_bias_v"] = _xavier(rng, (h, dk), h, dk)
+            ada(p + "self_attn", False)
         for ffn in ("ffn1", "ffn2"):
             _linear(sd, p + ffn + ".w_1", d, ff, rng)
             _linear(sd, p + ffn + ".w_2", ff, d, rng)

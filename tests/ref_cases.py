@@ -107,6 +107,11 @@ SMALL = {
                         reduce_idx=1, recover_idx=2, normalize_before=True),
     "sq_pre_n": _former("squeezeformer", False, 3, 59, 607, (2, 131, [131, 70], 608), reduce_idx=1, recover_idx=2,
                         normalize_before=True, activation_type="hardswish"),
+    # pos_enc_layer_type != rel_pos (squeezeformer/encoder.py:101-105): conformer's plain MultiHeadedAttention
+    "sq_abs_s": _former("squeezeformer", True, 3, 59, 609, (2, 131, [131, 77], 610), chunk_frames=64 * 3 + 40, required=(-16, 32),
+                        reduce_idx=1, recover_idx=2, pos_enc_layer_type="abs_pos"),
+    "sq_nopos_n": _former("squeezeformer", False, 3, 59, 611, (2, 131, [131, 70], 612), reduce_idx=1, recover_idx=2,
+                          pos_enc_layer_type="no_pos", normalize_before=True),
     "sq_bn": _former("squeezeformer", False, 3, 59, 543, (2, 131, [131, 70], 544), reduce_idx=1, recover_idx=2,
                      cnn_norm_type="batch_norm"),
     # encoder_dim 512 / 8 heads (configs/squeezeformer.yml:3-5 "for big data ... 512"): the general layer route
@@ -171,7 +176,8 @@ def state_dict(case, perturb=True):
         return squeezeformer_state_dict(vocab_size=V, num_blocks=L, seed=seed, perturb_norm=pn, streaming=case["streaming"],
                                         cnn_norm_type=kw.get("cnn_norm_type", "layer_norm"),
                                         encoder_dim=kw.get("encoder_dim", 256), attention_heads=kw.get("attention_heads", 4),
-                                        dw_stride=kw.get("dw_stride", False), output_size=kw.get("output_size"))
+                                        dw_stride=kw.get("dw_stride", False), output_size=kw.get("output_size"),
+                                        plain_mha=kw.get("pos_enc_layer_type", "rel_pos") != "rel_pos")
     if fam == "deepspeech2":
         return deepspeech2_state_dict(vocab_size=V, num_rnn_layers=L, streaming=case["streaming"], seed=seed,
                                       perturb_norm=pn, use_gru=kw.get("use_gru", False))
@@ -224,7 +230,7 @@ def reference_encoder_conf(case):
                     feed_forward_expansion_factor=8, input_dropout_rate=0.1, feed_forward_dropout_rate=0.1,
                     attention_dropout_rate=0.1, adaptive_scale=kw.get("adaptive_scale", True),
                     dw_stride=kw.get("dw_stride", False), cnn_module_kernel=31, normalize_before=kw.get("normalize_before", False),
-                    activation_type=kw.get("activation_type", "swish"), pos_enc_layer_type="rel_pos",
+                    activation_type=kw.get("activation_type", "swish"), pos_enc_layer_type=kw.get("pos_enc_layer_type", "rel_pos"),
                     cnn_norm_type=kw.get("cnn_norm_type", "layer_norm"))
     if fam == "deepspeech2":
         return dict(num_rnn_layers=L, rnn_size=1024, use_gru=kw.get("use_gru", False))

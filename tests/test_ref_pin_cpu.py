@@ -48,7 +48,8 @@ def make_oracle(case, sd):
         return SqueezeformerOracle(sd, num_blocks=L, reduce_idx=kw["reduce_idx"], recover_idx=kw["recover_idx"], causal=causal,
                                    attention_heads=kw.get("attention_heads", 4), adaptive_scale=kw.get("adaptive_scale", True),
                                    activation_type=kw.get("activation_type", "swish"),
-                                   normalize_before=kw.get("normalize_before", False))
+                                   normalize_before=kw.get("normalize_before", False),
+                                   pos_enc_layer_type=kw.get("pos_enc_layer_type", "rel_pos"))
     return DeepSpeech2Oracle(sd, num_rnn_layers=L, streaming=case["streaming"], use_gru=kw.get("use_gru", False))
 
 
