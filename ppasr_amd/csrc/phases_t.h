@@ -112,16 +112,19 @@ struct SwishSideT {
 // PositionwiseFeedForward on LDS-resident rows (phases.h ffn_phase<true>): acc2 += swish(A W1 + b1) W2 with the hidden
 // dimension in 256-wide chunks that never leave LDS (bufH: two R x kLda buffers); weight stream W1(0), W1(1), W2(0),
 // W1(2), W2(1), ..., W2(n-1), then `after` (k-group 0 of the wave's weight TILE, as every segment passed to rbt_gemm).
+// c0 / n_total (split route): this call covers the hidden chunks [c0, c0 + n_chunks) of a module with n_total chunks (its
+// partial sum); n_total = 0: the whole module.
 template <int R>
 __device__ __forceinline__ void ffn_phase_t(const float* bufA, float* bufH, const f32x4* __restrict__ w1,
                                             const float* __restrict__ b1, const f32x4* __restrict__ w2, int n_chunks,
                                             const f32x4* __restrict__ after, typename RBT<R>::Ring& ring,
-                                            typename RBT<R>::Acc& acc2) {
+                                            typename RBT<R>::Acc& acc2, int c0 = 0, int n_total = 0) {
   using T = RBT<R>;
   const LaneT<R> L;
-  const int ts2 = n_chunks * 32 * 64;  // W2: K = hidden
-  auto w1seg = [&](int c) { return w1 + (size_t)(c * 8 + L.tile()) * kTs256; };
-  auto w2seg = [&](int c) { return w2 + (size_t)L.tile() * ts2 + (size_t)c * 32 * 64; };
+  const int ts2 = (n_total > 0 ? n_total : n_chunks) * 32 * 64;  // W2: K = hidden
+  b1 += c0 * 256;
+  auto w1seg = [&](int c) { return w1 + (size_t)((c0 + c) * 8 + L.tile()) * kTs256; };
+  auto w2seg = [&](int c) { return w2 + (size_t)L.tile() * ts2 + (size_t)(c0 + c) * 32 * 64; };
   typename T::Acc cur, nx;
   T::zero(cur);
   rbt_gemm<kG256>(bufA, kLda, w1seg(0), n_chunks > 1 ? w1seg(1) : w2seg(0), ring, cur);

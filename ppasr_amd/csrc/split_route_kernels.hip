@@ -5,6 +5,7 @@
 #include "conformer_kernels.h"
 #include "launch.h"
 #include "phases.h"
+#include "phases_t.h"
 #include "h3.h"
 
 #include <math.h>
@@ -174,6 +175,83 @@ __global__ __launch_bounds__(kThreads) void k_ln_qkv(const float* __restrict__ x
   }
 }
 
+// ---- the same two launches on 16-ROW blocks (rbt.h: v_mfma_f32_16x16x4_f32 on the same packed weights) ----
+// A streaming chunk is 16 frames (decoding_chunk_size 16): on the 32-row forms above half of every tile is padding, and a
+// GEMM unit is bound by one CU's matrix pipe (6.8 us for 32 rows x 256 x 256 in fp32) -- the 16-row unit takes half.
+// Round 6: the feed-forward slices and the Q / K / V thirds, 36 of a chunk's ~110 units.  Results agree with the 32-row
+// forms to the order of the sums inside a 16-wide k step.
+template <int R>
+__global__ __launch_bounds__(RBT<R>::THREADS) void k_ffn_part_t(const float* __restrict__ x, const float* __restrict__ ln_g,
+                                                                const float* __restrict__ ln_b, const f32x4* __restrict__ w1,
+                                                                const float* __restrict__ b1, const f32x4* __restrict__ w2,
+                                                                float* __restrict__ partial, int M, int n_total, PadSkip ps) {
+  using T = RBT<R>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int blk = pad_block_of(ps, T::ROWS, M);
+  if (blk < 0) return;
+  float* bufA = smem;
+  float* bufH = bufA + T::ROWS * kLda;  // two hidden-chunk buffers
+  const LaneT<R> L;
+  const int r0 = blk * T::ROWS;
+  const int valid = min(T::ROWS, M - r0);
+  const int n_chunks = n_total / gridDim.y, c0 = blockIdx.y * n_chunks;
+  typename T::Ring ring;
+  rbt_prime(ring, w1 + (size_t)(c0 * 8 + L.tile()) * kTs256);
+  rbt_load_rows<R>(bufA, x + (size_t)r0 * kD, valid);
+  // (same wave -> row mapping as the load: no barrier between; ln_g == nullptr: the rows are used as they are)
+  if (ln_g) rbt_layernorm<R>(bufA, bufA, ln_g, ln_b, 1e-5f);
+  __syncthreads();
+  typename T::Acc acc2;
+  T::zero(acc2);
+  ffn_phase_t<R>(bufA, bufH, w1, b1, w2, n_chunks, nullptr, ring, acc2, c0, n_total);
+  float* out = partial + (size_t)blockIdx.y * M * kD;
+#pragma unroll
+  for (int q = 0; q < T::NQ; ++q)
+    if (L.row(q) < valid) *reinterpret_cast<f32x4*>(out + (size_t)(r0 + L.row(q)) * kD + L.col(q)) = T::quad(acc2, q);
+}
+
+template <int R>
+__global__ __launch_bounds__(RBT<R>::THREADS) void k_ln_qkv_t(const float* __restrict__ x1, float* __restrict__ qkv, LayerW w,
+                                                              int M, PadSkip ps, float* __restrict__ kc,
+                                                              float* __restrict__ vc) {
+  using T = RBT<R>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int blk = pad_block_of(ps, T::ROWS, M);
+  if (blk < 0) return;
+  float* bufA = smem;
+  const LaneT<R> L;
+  const int r0 = blk * T::ROWS;
+  const int valid = min(T::ROWS, M - r0);
+  const int c = blockIdx.y;  // 0: q, 1: k, 2: v
+  typename T::Ring ring;
+  const f32x4* seg = w.wqkv + (size_t)(c * 8 + L.tile()) * kTs256;
+  rbt_prime(ring, seg);
+  rbt_load_rows<R>(bufA, x1 + (size_t)r0 * kD, valid);
+  rbt_layernorm<R>(bufA, bufA, w.ln_mha_g, w.ln_mha_b, 1e-5f);
+  __syncthreads();
+  typename T::Acc acc;
+  T::zero(acc);
+  rbt_gemm<kG256>(bufA, kLda, seg, nullptr, ring, acc);
+  float* cache = (c == 1) ? kc : (c == 2 ? vc : nullptr);
+#pragma unroll
+  for (int q = 0; q < T::NQ; ++q) {
+    if (L.row(q) >= valid) continue;
+    const f32x4 v = T::quad(acc, q) + *reinterpret_cast<const f32x4*>(w.bqkv + c * 256 + L.col(q));
+    if (cache) *reinterpret_cast<f32x4*>(cache + (size_t)(r0 + L.row(q)) * kD + L.col(q)) = v;
+    else *reinterpret_cast<f32x4*>(qkv + (size_t)(r0 + L.row(q)) * 768 + c * 256 + L.col(q)) = v;
+  }
+}
+// (LDS asked for: kLdsExclusive, so that a CU holds ONE of these workgroups -- co-resident row-block workgroups share the
+//  matrix pipe and the weight stream's lead time no longer covers a unit: with 32 / 64 independent sessions on their own
+//  HIP streams the own-size allocation, 3 workgroups per CU, was 13 % slower per chunk round, same box)
+constexpr size_t kLdsFfnPart16 = kLdsExclusive, kLdsLnQkv16 = kLdsExclusive;
+static_assert(3 * 16 * kLda * sizeof(float) <= kLdsExclusive, "LDS of the 16-row feed-forward slice");
+// (up to 16 rows -- one streaming chunk, single short utterances: the 16-row forms; PPASR_SPLIT_ROWS16=0 switches them off)
+static bool split_rows16(int M) {
+  static const bool on = !(getenv("PPASR_SPLIT_ROWS16") && atoi(getenv("PPASR_SPLIT_ROWS16")) == 0);
+  return on && M <= 16;
+}
+
 constexpr size_t kLdsConvPre = 4 * kRows * kLda * sizeof(float);  // (the depthwise window uses the three buffers + halo)
 constexpr size_t kLdsFfnPart = 3 * kRows * kLda * sizeof(float);
 constexpr size_t kLdsLnQkv = kRows * kLda * sizeof(float);
@@ -207,6 +285,9 @@ void launch_ffn_split(const float* x, const float* ln_g, const float* ln_b, cons
   if (h3)  // (w1 / w2: the re-packed weights)
     PPASR_LAUNCH(k_ffn_part<true>, dim3((M + kRows - 1) / kRows, S), dim3(kThreads), kLdsFfnPart + kH3ExtraLds, st, x, ln_g, ln_b,
                  w1, b1, w2, partial, M, n_chunks, ps);
+  else if (split_rows16(M) && !ps.tab)
+    PPASR_LAUNCH(k_ffn_part_t<16>, dim3((M + 15) / 16, S), dim3(kThreads), kLdsFfnPart16, st, x, ln_g, ln_b, w1, b1, w2, partial, M,
+                 n_chunks, ps);
   else
     PPASR_LAUNCH(k_ffn_part<false>, dim3((M + kRows - 1) / kRows, S), dim3(kThreads), kLdsFfnPart, st, x, ln_g, ln_b, w1, b1,
                  w2, partial, M, n_chunks, ps);
@@ -217,6 +298,8 @@ void launch_ln_qkv(const float* x1, float* qkv, const LayerW& w, int M, hipStrea
                    float* vc, bool h3) {
   if (h3)
     PPASR_LAUNCH(k_ln_qkv<true>, dim3((M + kRows - 1) / kRows, 3), dim3(kThreads), kLdsLnQkv + 512, st, x1, qkv, w, M, ps, kc, vc);
+  else if (split_rows16(M) && !ps.tab)
+    PPASR_LAUNCH(k_ln_qkv_t<16>, dim3((M + 15) / 16, 3), dim3(kThreads), kLdsLnQkv16, st, x1, qkv, w, M, ps, kc, vc);
   else
     PPASR_LAUNCH(k_ln_qkv<false>, dim3((M + kRows - 1) / kRows, 3), dim3(kThreads), kLdsLnQkv, st, x1, qkv, w, M, ps, kc, vc);
 }
@@ -237,6 +320,8 @@ hipError_t configure_split_route_kernels() {
   SET_LDS((k_conv_pre<15, true, true>), kLdsConvPre);
   SET_LDS((k_conv_pre<7, true, true>), kLdsConvPre);
   SET_LDS(k_ffn_part<false>, kLdsFfnPart);
+  SET_LDS(k_ffn_part_t<16>, kLdsFfnPart16);
+  SET_LDS(k_ln_qkv_t<16>, kLdsLnQkv16);
   SET_LDS(k_ffn_part<true>, kLdsFfnPart + kH3ExtraLds);
   SET_LDS(k_ln_qkv<true>, kLdsLnQkv + 512);
 #undef SET_LDS
