@@ -211,6 +211,7 @@ struct ppasr_stream_s {
   float* xh_hist;   // [L][lo][D]  conv-module input history
   float* g_hist;    // [L][lo][256] GLU(pointwise_conv1(history)) of every layer, recomputed at the start of each chunk (fused route)
   HistLayer* hist_tab;  // device [L]: per-layer pointwise_conv1 weights / history rows for that launch (fused route)
+  int* ticket = nullptr;  // device [16], zero between launches: arrival counters of the feed-forward slices that join in-kernel
 };
 
 // the reference's shape arithmetic for one chunk (capi_stream.hip: plan_chunk)

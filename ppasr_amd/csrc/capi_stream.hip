@@ -124,7 +124,7 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
     const LayerW& Lk = h3 ? h->layers_h3[i] : L;
     if (S > 1) {
       launch_ffn_split(xa, L.ln_mac_g, L.ln_mac_b, Lk.ffm_w1, L.ffm_b1, Lk.ffm_w2, L.ffm_b2, 0.5f, nullptr, nullptr, partial, xb,
-                       Ti, n_chunks, S, st, PadSkip{}, false, h3);
+                       Ti, n_chunks, S, st, PadSkip{}, false, h3, s->ticket);
       launch_ln_qkv(xb, qkv, Lk, Ti, st, PadSkip{}, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD, h3);
     } else {
       launch_ffn_qkv(xa, xb, qkv, L, Ti, n_chunks, st);
@@ -149,7 +149,7 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
       if (S > 1) {
         launch_conv_pre(g, gh, xc, ctx, Lk, nullptr, Ti, Ti, h->layer_ks[i], mul, st, true, PadSkip{}, h3);
         launch_ffn_split(ctx, L.ln_ff_g, L.ln_ff_b, Lk.ff_w1, L.ff_b1, Lk.ff_w2, L.ff_b2, 0.5f, L.ln_fin_g, L.ln_fin_b, partial,
-                         xa, Ti, n_chunks, S, st, PadSkip{}, false, h3);
+                         xa, Ti, n_chunks, S, st, PadSkip{}, false, h3, s->ticket);
       } else {
         launch_conv_ffn(g, gh, xc, xa, L, nullptr, Ti, Ti, n_chunks, h->layer_ks[i], mul, nullptr, nullptr, nullptr, st);
       }
@@ -207,11 +207,11 @@ ppasr_status squeezeformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* x
       const SqLayerW& Ws = h3s ? h->sq_layers_h3[i] : W;
       launch_sq_oproj(ctx, x, other, W, Ti, st);
       launch_ffn_split(other, nullptr, nullptr, Ws.ff1_w1, W.ff1_b1, Ws.ff1_w2, W.ff1_b2, 1.0f, W.ln2_g, W.ln2_b, partial, xc,
-                       Ti, n_chunks, S, st, PadSkip{}, false, h3s);
+                       Ti, n_chunks, S, st, PadSkip{}, false, h3s, s->ticket);
       launch_sq_pw1glu(xc, g, xhat, W, nullptr, Ti, Ti, mul, st);
       launch_conv_pre(g, gh, xc, ctx, sq_conv_view(W), nullptr, Ti, Ti, KS, mul, st);
       launch_ffn_split(ctx, W.ln3_g, W.ln3_b, Ws.ff2_w1, W.ff2_b1, Ws.ff2_w2, W.ff2_b2, 1.0f, W.ln4_g, W.ln4_b, partial, other,
-                       Ti, n_chunks, S, st, PadSkip{}, /*residual_is_normed=*/true, h3s);
+                       Ti, n_chunks, S, st, PadSkip{}, /*residual_is_normed=*/true, h3s, s->ticket);
       if (Wn) launch_sq_qkv(other, qkv, Wn->wqkv, Wn->bqkv, Ti, st);
     } else {
       launch_sq_mid(ctx, x, xc, g, xhat, W, nullptr, Ti, Ti, mul, n_chunks, st);
@@ -255,9 +255,12 @@ ppasr_status ppasr_stream_create(ppasr_handle h, ppasr_stream* out) {
   hipError_t e4 = hipMalloc(reinterpret_cast<void**>(&s->g_hist), L * lo_alloc * D * sizeof(float));
   s->hist_tab = nullptr;
   if (e4 == hipSuccess) e4 = hipMalloc(reinterpret_cast<void**>(&s->hist_tab), L * sizeof(HistLayer));
+  if (e4 == hipSuccess) e4 = hipMalloc(reinterpret_cast<void**>(&s->ticket), 16 * sizeof(int));
+  if (e4 == hipSuccess) e4 = hipMemset(s->ticket, 0, 16 * sizeof(int));
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
     (void)hipFree(s->kc); (void)hipFree(s->vc); (void)hipFree(s->xh_hist); (void)hipFree(s->g_hist);
     (void)hipFree(s->hist_tab);
+    (void)hipFree(s->ticket);
     delete s;
     return fail(PPASR_EHIP, "hipMalloc failed for the stream caches");
   }
@@ -284,6 +287,7 @@ ppasr_status ppasr_stream_destroy(ppasr_stream s) {
   if (!s) return PPASR_OK;
   (void)hipFree(s->kc); (void)hipFree(s->vc); (void)hipFree(s->xh_hist); (void)hipFree(s->g_hist);
   (void)hipFree(s->hist_tab);
+  (void)hipFree(s->ticket);
   delete s;
   return PPASR_OK;
 }

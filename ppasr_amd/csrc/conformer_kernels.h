@@ -120,6 +120,8 @@ void launch_ffn_qkv_16(const float* x_in, float* x1, float* qkv, const LayerW& w
                        const PadSkip& ps);
 void launch_out_glu_16(const float* ctx, const float* x1, float* x2, float* g, const LayerW& w, const int64_t* lens, int M,
                        int Tp, int mask_mul, hipStream_t st, const PadSkip& ps);
+void launch_out_glu_split_16(const float* ctx, const float* x1, float* x2, float* g, float* xhat, const LayerW& w,
+                             const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps);  // split route, <= 16 rows
 bool conv_ffn_16_supported(int ksize, int Tp);
 void launch_conv_ffn_16(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int M, int Tp,
                         int n_chunks, int ksize, int mask_mul, const LayerW* next, float* x1_next, float* qkv_next,
@@ -193,7 +195,7 @@ void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float
 void launch_ffn_split(const float* x, const float* ln_g, const float* ln_b, const f32x4* w1, const float* b1,
                       const f32x4* w2, const float* b2, float scale, const float* out_ln_g, const float* out_ln_b,
                       float* partial, float* out, int M, int n_chunks, int S, hipStream_t st, const PadSkip& ps = PadSkip{},
-                      bool residual_is_normed = false, bool h3 = false);  // h3: w1 / w2 are the re-packed weights
+                      bool residual_is_normed = false, bool h3 = false, int* ticket = nullptr);  // h3: w1 / w2 are the re-packed weights
 // kc / vc: write the K / V thirds to these cache rows instead of qkv (single-session streaming)
 void launch_ln_qkv(const float* x1, float* qkv, const LayerW& w, int M, hipStream_t st, const PadSkip& ps = PadSkip{},
                    float* kc = nullptr, float* vc = nullptr, bool h3 = false);

@@ -405,6 +405,12 @@ void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, floa
   // split_xhat != nullptr (under-filled launches): out-projection + LayerNorm in one launch (the LayerNorm'd rows go to
   // split_xhat), pointwise_conv1 + GLU in a second one with the columns over two workgroups per row block
   float* xh = xhat_out ? xhat_out : split_xhat;
+  // up to 16 rows (one streaming chunk): the 16-row forms (conformer_kernels_t.hip) -- half the matrix-pipe time per unit
+  static const bool rows16 = !(getenv("PPASR_SPLIT_ROWS16") && atoi(getenv("PPASR_SPLIT_ROWS16")) == 0);
+  if (split_xhat && !h3 && rows16 && M <= 16 && !ps.tab) {
+    launch_out_glu_split_16(ctx, x1, x2, g, xh, w, lens, M, Tp, mask_mul, st, ps);
+    return;
+  }
   const dim3 grid((M + kRows - 1) / kRows);
   if (h3)
     PPASR_LAUNCH(k_out_glu<true>, grid, dim3(kThreads), kLdsOutGlu + 512, st, ctx, x1, x2, g, xh, w, lens, M, Tp, mask_mul, ps,

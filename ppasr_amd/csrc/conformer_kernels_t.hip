@@ -67,11 +67,14 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_ffn_qkv_t(const float* __re
 }
 
 // S3: x2 = x1 + ctx Wo + bo ; g = GLU(pointwise_conv1(mask(LN_conv(x2))))   (attention.py:126, encoder.py:399-409)
+// xhat_out != nullptr: the LayerNorm'd (pad-masked) rows are also stored (streaming: what the reference keeps as cnn_cache;
+// split route: the input of k_pw1_glu_cols_t); stop_after_ln: the launch ends there (split route)
 template <int R>
 __global__ __launch_bounds__(RBT<R>::THREADS) void k_out_glu_t(const float* __restrict__ ctx, const float* __restrict__ x1,
                                                                float* __restrict__ x2, float* __restrict__ g, LayerW w,
                                                                const int64_t* __restrict__ lens, int M, int Tp,
-                                                               int mask_mul, PadSkip ps) {
+                                                               int mask_mul, PadSkip ps, float* __restrict__ xhat_out,
+                                                               int stop_after_ln) {
   using T = RBT<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int blk = pad_block_of(ps, T::ROWS, M);
@@ -113,6 +116,9 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_out_glu_t(const float* __re
   }
   __syncthreads();
   rbt_layernorm<R, false>(bufX, bufA, w.ln_conv_g, w.ln_conv_b, 1e-5f, PadRows{lens, r0, Tp, M, mask_mul});
+  // (LayerNorm and row store use the same wave -> row mapping: no barrier between them)
+  if (xhat_out) rbt_store_rows<R>(xhat_out + (size_t)r0 * kD, bufA, valid);
+  if (stop_after_ln) return;
   __syncthreads();
   {
     typename T::Acc av, ag;
@@ -129,6 +135,53 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_out_glu_t(const float* __re
       const f32x2 s1 = sigmoid2(f32x2{b[2] + bgate[2], b[3] + bgate[3]});
       const f32x4 o = {(a[0] + bval[0]) * s0[0], (a[1] + bval[1]) * s0[1], (a[2] + bval[2]) * s1[0], (a[3] + bval[3]) * s1[1]};
       if (q < n_ok) *reinterpret_cast<f32x4*>(g + gq[q]) = o;
+    }
+  }
+}
+
+// pointwise_conv1 + GLU of LayerNorm'd (and pad-masked) rows on 16-row blocks, the 256 output columns over gridDim.y = 2
+// workgroups (conformer_kernels.hip k_pw1_glu_cols): waves 0-3 compute the VALUE tiles of the workgroup's 128 columns,
+// waves 4-7 the GATE tiles of the same columns; values cross to the gate waves through LDS.
+template <int R>
+__global__ __launch_bounds__(RBT<R>::THREADS) void k_pw1_glu_cols_t(const float* __restrict__ xhat, float* __restrict__ g,
+                                                                    LayerW w, int M, PadSkip ps) {
+  using T = RBT<R>;
+  static_assert(R == 16, "the quad view below is the 16-row form's");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int blk = pad_block_of(ps, T::ROWS, M);
+  if (blk < 0) return;
+  float* bufA = smem;
+  float* vals = bufA + T::ROWS * kLda;  // [ROWS][132]
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blk * T::ROWS;
+  const int valid = min(T::ROWS, M - r0);
+  const int is_gate = wave >> 2, t = wave & 3, y = blockIdx.y;
+  const f32x4* seg = w.pw1 + (size_t)((is_gate ? 8 : 0) + 4 * y + t) * kTs256;
+  typename T::Ring ring;
+  rbt_prime(ring, seg);
+  rbt_load_rows<R>(bufA, xhat + (size_t)r0 * kD, valid);
+  __syncthreads();
+  typename T::Acc acc;
+  T::zero(acc);
+  rbt_gemm<kG256>(bufA, kLda, seg, nullptr, ring, acc);
+  const int row = lane & 15;
+#pragma unroll
+  for (int q = 0; q < T::NQ; ++q) {
+    const int c128 = 32 * t + 16 * q + 4 * (lane >> 4);  // column inside the workgroup's 128
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(w.pw1_b + (is_gate ? kD : 0) + 128 * y + c128);
+    const f32x4 a = T::quad(acc, q) + bv;
+    if (!is_gate) *reinterpret_cast<f32x4*>(vals + row * 132 + c128) = a;
+    else acc.s[q] = a;
+  }
+  __syncthreads();
+  if (is_gate && row < valid) {
+#pragma unroll
+    for (int q = 0; q < T::NQ; ++q) {
+      const int c128 = 32 * t + 16 * q + 4 * (lane >> 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(vals + row * 132 + c128);
+      const f32x4 b = acc.s[q];
+      const f32x2 s0 = sigmoid2(f32x2{b[0], b[1]}), s1 = sigmoid2(f32x2{b[2], b[3]});
+      *reinterpret_cast<f32x4*>(g + (size_t)(r0 + row) * kD + 128 * y + c128) = f32x4{v[0] * s0[0], v[1] * s0[1], v[2] * s1[0], v[3] * s1[1]};
     }
   }
 }
@@ -214,7 +267,16 @@ void launch_ffn_qkv_16(const float* x_in, float* x1, float* qkv, const LayerW& w
 void launch_out_glu_16(const float* ctx, const float* x1, float* x2, float* g, const LayerW& w, const int64_t* lens, int M,
                        int Tp, int mask_mul, hipStream_t st, const PadSkip& ps) {
   PPASR_LAUNCH(k_out_glu_t<16>, dim3((M + 15) / 16), dim3(kThreads), excl(kLds16x2), st, ctx, x1, x2, g, w, lens, M, Tp,
-               mask_mul, ps);
+               mask_mul, ps, (float*)nullptr, 0);
+}
+// split route on 16-row blocks (a streaming chunk): out-projection + LayerNorm (rows -> xhat), then pointwise_conv1 + GLU
+// with the columns over two workgroups
+void launch_out_glu_split_16(const float* ctx, const float* x1, float* x2, float* g, float* xhat, const LayerW& w,
+                             const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps) {
+  PPASR_LAUNCH(k_out_glu_t<16>, dim3((M + 15) / 16), dim3(kThreads), excl(kLds16x2), st, ctx, x1, x2, g, w, lens, M, Tp,
+               mask_mul, ps, xhat, 1);
+  PPASR_LAUNCH(k_pw1_glu_cols_t<16>, dim3((M + 15) / 16, 2), dim3(kThreads), excl((16 * kLda + 16 * 132) * sizeof(float)), st,
+               xhat, g, w, M, ps);
 }
 bool conv_ffn_16_supported(int ksize, int Tp) { return (ksize == 7 || ksize == 15 || ksize == 31) && Tp >= 2; }
 void launch_conv_ffn_16(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int M, int Tp,
@@ -249,7 +311,7 @@ void launch_ffn_qkv_w16(const float* x_in, float* x1, float* qkv, const LayerW& 
 void launch_out_glu_w16(const float* ctx, const float* x1, float* x2, float* g, const LayerW& w, const int64_t* lens, int M,
                         int Tp, int mask_mul, hipStream_t st, const PadSkip& ps) {
   PPASR_LAUNCH(k_out_glu_t<kW16>, dim3((M + 31) / 32), dim3(1024), excl(kLdsW16x2), st, ctx, x1, x2, g, w, lens, M, Tp,
-               mask_mul, ps);
+               mask_mul, ps, (float*)nullptr, 0);
 }
 bool conv_ffn_w16_supported(int ksize, int Tp) { return (ksize == 7 || ksize == 15 || ksize == 31) && Tp >= 2; }
 void launch_conv_ffn_w16(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int M, int Tp,
@@ -282,6 +344,7 @@ hipError_t configure_conformer_t_kernels() {
   if (e != hipSuccess) return e;
   SET_LDS(k_ffn_qkv_t<16>);
   SET_LDS(k_out_glu_t<16>);
+  SET_LDS(k_pw1_glu_cols_t<16>);
   SET_LDS((k_conv_ffn_t<16, 15, true>));
   SET_LDS((k_conv_ffn_t<16, 15, false>));
   SET_LDS((k_conv_ffn_t<16, 31, true>));

@@ -346,6 +346,10 @@ __global__ __launch_bounds__(NT) void k_ctc_prune(const float* __restrict__ prob
   int* cand_c = reinterpret_cast<int*>(p); p += kSmallCand * 4;
   float* cand_lp = reinterpret_cast<float*>(p); p += kSmallCand * 4;
   float* lp = reinterpret_cast<float*>(p); p += (size_t)Vp * 4;
+#ifdef PPASR_BEAM_POISON
+  for (uint32_t i = tid; i < (uint32_t)(p - smem) / 4; i += NT) reinterpret_cast<uint32_t*>(smem)[i] = (uint32_t)(PPASR_BEAM_POISON);
+  __syncthreads();
+#endif
   {
     const float* row = probs + ((size_t)u * T + t) * V;
     for (int v = tid; v < V; v += NT) lp[v] = row[v];
@@ -643,6 +647,13 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
   float* lm_acc = reinterpret_cast<float*>(smem + plan.lmacc);  // [beam][kLmAccWords] context summaries (scorer only)
   constexpr int kChildBit = 0x40000000;  // survivor code of a child: kChildBit | row << 14 | candidate (rows < 512, candidates < 16384)
 
+#ifdef PPASR_BEAM_POISON
+  // debug builds (tools/build_variant.sh poisonX -DPPASR_BEAM_POISON=0x...): the LDS a workgroup starts with is whatever
+  // the previous workgroup on that CU left -- the decode must not depend on it (tests/test_ctc_beam_gpu.py under
+  // PPASR_HIP_LIB=tools/_ts/lib_poisonX.so must give the same results)
+  for (uint32_t i = tid; i < plan.total / 4; i += BT) reinterpret_cast<uint32_t*>(smem)[i] = (uint32_t)(PPASR_BEAM_POISON);
+  __syncthreads();
+#endif
   int32_t* st = state + (size_t)u * beam_state_words(beam, cfg.max_nodes);
   int32_t* g_arr = st + 2;
   int32_t* arena = st + beam_fixed_words(beam);
@@ -750,7 +761,12 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
     stage(0);
     if (n_frames > 1) fetch(1);
   }
-  if (tid == 0) { sh_i[1] = 0; sh_i[2] = 0; sh_i[3] = 0; sh_i[6] = 0; sh_i[7] = 0; }  // verification failed / kept count / largest key kept / tiny beams' flags
+  // sh_i: [0] merged children (tiny beams)  [1] tiny beams' flag (node-table form)  [4] clipped list length  [6 + parity]
+  // tiny beams' flags  [8 + 4 parity + {1, 2, 3}] the selection's words of a frame: verification failed / kept count /
+  // largest key kept.  They alternate with the frame's parity: the words of frame t are read behind the selection's last
+  // barrier and the tail of the frame has no barrier before its reset -- a wave that is late behind that barrier (the CU is
+  // shared with other kernels when the search overlaps the encoder) must not find them re-armed; frame t re-arms t + 1's.
+  if (tid < 16) sh_i[tid] = 0;
   __syncthreads();
 #ifdef PPASR_BEAM_TS
   long long ts_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts_last = wall_clock64(), ts_n = 0, ts_c = 0, ts_nb = 0, ts_att = 0, ts_ok = 0,
@@ -791,6 +807,8 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
     const int C = C_st;
     const float p_blank = pb_st;
     const int32_t* rec_t = rec_u + (size_t)t * RW;
+    int* fl = sh_i + 8 + 4 * (t & 1);        // this frame's selection words ([1] failed, [2] kept, [3] largest key kept)
+    int* fl_next = sh_i + 8 + 4 * (~t & 1);  // the next frame's: re-armed by this frame's tail
     kidx = kidx_base + (t & 1) * Vp4;
     cand_c_s = cand_base + (t & 1) * kCandWords;
     cand_lp_s = reinterpret_cast<float*>(cand_c_s) + kSmallCand;
@@ -1053,7 +1071,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
         if (t + 2 < n_frames) fetch(t + 2);
       }
       staged_next = true;
-      if (tid == 0) { sh_i[1] = 0; sh_i[2] = 0; sh_i[3] = 0; }  // verification failed / kept count / largest key kept
+      if (tid == 0) { fl_next[1] = 0; fl_next[2] = 0; fl_next[3] = 0; }
     };
     int k_sel = 0;
     bool tiny_done = false;
@@ -1112,7 +1130,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
         // (merged tail: the flag word alternates with the frame's parity -- this frame's is read behind the phase's only
         //  barrier while the other one is re-armed for the next frame)
         int* vflag = sh_i + (merged_tail ? 6 + (t & 1) : 1);
-        if (merged_tail && tid == 0) sh_i[6 + ((t + 1) & 1)] = 0;
+        if (merged_tail && tid == 0) { sh_i[6 + ((t + 1) & 1)] = 0; fl_next[1] = 0; fl_next[2] = 0; fl_next[3] = 0; }
         if (wave == 0) {  // lane = (survivor p = lane & 15, quarter g = lane >> 4 of the others it is compared with)
           const int pidx = lane & 15, g = lane >> 4;
           const unsigned long long kp = pidx < beam ? srank_key[pidx] : ~0ull;
@@ -1375,7 +1393,7 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
               if (lane == 0) {
                 const bool kept = ki != ~0ull && rank < beam;
                 lkey[i] = kept ? 1u : 0u;
-                if (kept) atomicMax(reinterpret_cast<unsigned int*>(&sh_i[3]), (unsigned int)(ki >> 32));
+                if (kept) atomicMax(reinterpret_cast<unsigned int*>(&fl[3]), (unsigned int)(ki >> 32));
               }
             }
           }
@@ -1398,13 +1416,13 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
             if (f0) put(lane, mbcnt(m0));
             if (f1) put(lane + 64, __popcll(m0) + mbcnt(m1));
             const int n_kept = __popcll(m0) + __popcll(m1);
-            if (lane == 0) sh_i[2] = n_kept;
+            if (lane == 0) fl[2] = n_kept;
             if (clip && lane < nb) {  // verification (clipped rows: nb <= 64): the bound of the best excluded child of row `lane`
               const int K = row_len(lane);
               if (K < C) {
                 const float ub = cand_lp(K) + cur.score[lane];
                 // fewer than `beam` elements in a clipped list, or a bound that reaches the last key taken: redo with full rows
-                if (n_kept < beam || desc_key(ub) <= (uint32_t)sh_i[3]) sh_i[1] = 1;
+                if (n_kept < beam || desc_key(ub) <= (uint32_t)fl[3]) fl[1] = 1;
               }
             }
           }
@@ -1555,22 +1573,22 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
               }
             }
           }
-          if (tid == 0) sh_i[2] = ksel;
+          if (tid == 0) fl[2] = ksel;
           if (clip && tid < nb) {  // verification: the bound of the best excluded child of my row
             const int K = row_len(tid);
             if (K < C) {
               const float ub = cand_lp(K) + cur.score[tid];
-              if (desc_key(ub) <= thr1) sh_i[1] = 1;  // (thr1 = 0xFFFFFFFE when the list held fewer than `beam` elements)
+              if (desc_key(ub) <= thr1) fl[1] = 1;  // (thr1 = 0xFFFFFFFE when the list held fewer than `beam` elements)
             }
           }
         }
         if (WIDE && my_flag >= 0) lex[my_flag] = 0;
         list_barrier();
         TS(6);
-        return sh_i[1] == 0;
+        return fl[1] == 0;
       };
       const bool ok = in_lds ? select(lkey_s, lex_s, std::true_type{}) : select(lkey_g, lex_g, std::false_type{});
-      k_sel = sh_i[2];
+      k_sel = fl[2];
       if (ok) {
 #ifdef PPASR_BEAM_TS
         if (clip) ++ts_ok;
@@ -1578,7 +1596,8 @@ __global__ __launch_bounds__(BT, 1) void k_ctc_beam(const float* __restrict__ pr
         break;
       }
       clip = false;  // the bound of a clipped row reaches into the selection: full rows
-      if (tid == 0) { sh_i[1] = 0; sh_i[2] = 0; sh_i[3] = 0; }
+      lds_barrier();  // (every wave has read the words)
+      if (tid == 0) { fl[1] = 0; fl[2] = 0; fl[3] = 0; }
       lds_barrier();
     }
     if (k_sel < 0) break;  // no scratch for a list that needs it (status set)

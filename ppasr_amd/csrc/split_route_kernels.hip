@@ -180,11 +180,24 @@ __global__ __launch_bounds__(kThreads) void k_ln_qkv(const float* __restrict__ x
 // GEMM unit is bound by one CU's matrix pipe (6.8 us for 32 rows x 256 x 256 in fp32) -- the 16-row unit takes half.
 // Round 6: the feed-forward slices and the Q / K / V thirds, 36 of a chunk's ~110 units.  Results agree with the 32-row
 // forms to the order of the sums inside a 16-wide k step.
+// In-kernel join (jn.ticket != nullptr; single stream handles): the S workgroups of a row block take a ticket when their
+// partial tile is in memory, and the LAST one to arrive runs k_ffn_join's row loop for the block -- no spinning (the others
+// have left), so nothing can deadlock; the counter goes back to 0 for the next launch.  One launch per feed-forward module
+// instead of two.
+struct FfnJoin {
+  const float* b2;
+  float scale;
+  const float *ln_g, *ln_b;  // LayerNorm behind the residual sum (or nullptr)
+  float* out;
+  const float *pre_g, *pre_b;  // the residual is LN_pre(x) (Squeezeformer's second module) or x
+  int* ticket;               // [row blocks] arrival counters, zero between launches
+};
 template <int R>
 __global__ __launch_bounds__(RBT<R>::THREADS) void k_ffn_part_t(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                                 const float* __restrict__ ln_b, const f32x4* __restrict__ w1,
                                                                 const float* __restrict__ b1, const f32x4* __restrict__ w2,
-                                                                float* __restrict__ partial, int M, int n_total, PadSkip ps) {
+                                                                float* __restrict__ partial, int M, int n_total, PadSkip ps,
+                                                                FfnJoin jn) {
   using T = RBT<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int blk = pad_block_of(ps, T::ROWS, M);
@@ -208,6 +221,32 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_ffn_part_t(const float* __r
 #pragma unroll
   for (int q = 0; q < T::NQ; ++q)
     if (L.row(q) < valid) *reinterpret_cast<f32x4*>(out + (size_t)(r0 + L.row(q)) * kD + L.col(q)) = T::quad(acc2, q);
+  if (!jn.ticket) return;
+  __shared__ int s_last;
+  __threadfence();  // this workgroup's partial tile is visible device-wide before its ticket is
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int S = (int)gridDim.y;
+    const int t = atomicAdd(&jn.ticket[blk], 1);
+    s_last = (t == S - 1) ? 1 : 0;
+    if (t == S - 1) jn.ticket[blk] = 0;  // (everyone has arrived: re-armed for the next launch on this stream)
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();  // (the other workgroups' tiles: no stale lines of this CU's vector cache)
+  const int S = (int)gridDim.y, lane = L.lane;
+  for (int row = r0 + L.wave; row < r0 + valid; row += T::WAVES) {  // k_ffn_join, one wave per row
+    f32x4 acc = *reinterpret_cast<const f32x4*>(partial + (size_t)row * kD + 4 * lane);
+    for (int sidx = 1; sidx < S; ++sidx)
+      acc += *reinterpret_cast<const f32x4*>(partial + ((size_t)sidx * M + row) * kD + 4 * lane);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(jn.b2 + 4 * lane);
+    f32x4 y = *reinterpret_cast<const f32x4*>(x + (size_t)row * kD + 4 * lane);
+    if (jn.pre_g) y = ln_row(y, jn.pre_g, jn.pre_b, lane);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = y[e] + jn.scale * (acc[e] + bv[e]);
+    if (jn.ln_g) y = ln_row(y, jn.ln_g, jn.ln_b, lane);
+    *reinterpret_cast<f32x4*>(jn.out + (size_t)row * kD + 4 * lane) = y;
+  }
 }
 
 template <int R>
@@ -281,14 +320,23 @@ void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float
 void launch_ffn_split(const float* x, const float* ln_g, const float* ln_b, const f32x4* w1, const float* b1,
                       const f32x4* w2, const float* b2, float scale, const float* out_ln_g, const float* out_ln_b,
                       float* partial, float* out, int M, int n_chunks, int S, hipStream_t st, const PadSkip& ps,
-                      bool residual_is_normed, bool h3) {
+                      bool residual_is_normed, bool h3, int* ticket) {
   if (h3)  // (w1 / w2: the re-packed weights)
     PPASR_LAUNCH(k_ffn_part<true>, dim3((M + kRows - 1) / kRows, S), dim3(kThreads), kLdsFfnPart + kH3ExtraLds, st, x, ln_g, ln_b,
                  w1, b1, w2, partial, M, n_chunks, ps);
-  else if (split_rows16(M) && !ps.tab)
+  else if (split_rows16(M) && !ps.tab) {
+    // (out == x would let the joining workgroup overwrite rows another slice is still reading: two launches then)
+    // OPT-IN (PPASR_STREAM_TICKET=1): measured on one box, one 0.64 s chunk of one session 1.35 ms with the in-kernel join
+    // against 1.24 ms with the join as its own launch (the last slice's workgroup joins 16 rows x S partial tiles alone; the
+    // join kernel spreads them over 4 workgroups) -- four launches fewer per block, and slower.  32 sessions: 14.26 / 14.5 ms.
+    const char* tk = getenv("PPASR_STREAM_TICKET");
+    const bool join_in_kernel = tk && atoi(tk) == 1 && ticket != nullptr && out != x && (M + 15) / 16 <= 16;
     PPASR_LAUNCH(k_ffn_part_t<16>, dim3((M + 15) / 16, S), dim3(kThreads), kLdsFfnPart16, st, x, ln_g, ln_b, w1, b1, w2, partial, M,
-                 n_chunks, ps);
-  else
+                 n_chunks, ps,
+                 FfnJoin{b2, scale, out_ln_g, out_ln_b, out, residual_is_normed ? ln_g : nullptr, residual_is_normed ? ln_b : nullptr,
+                         join_in_kernel ? ticket : nullptr});
+    if (join_in_kernel) return;
+  } else
     PPASR_LAUNCH(k_ffn_part<false>, dim3((M + kRows - 1) / kRows, S), dim3(kThreads), kLdsFfnPart, st, x, ln_g, ln_b, w1, b1,
                  w2, partial, M, n_chunks, ps);
   PPASR_LAUNCH(k_ffn_join, dim3((M + 3) / 4), dim3(256), 0, st, x, partial, S, b2, scale, out_ln_g, out_ln_b, out, M,

@@ -216,6 +216,42 @@ def test_evaluate_overlapped_decode_gives_the_same_result(decoder):
         assert a == b and a >= 0
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("beam", [20, 48])
+def test_beam_search_beside_the_encoder_is_deterministic(beam):
+    """Round 6: the search of step i shares CUs with the encoder of step i + 1 (evaluate(overlap_decode=True)); waves of
+    its workgroup are then delayed unevenly, and a word of the selection that thread 0 re-armed in the barrier-less tail of
+    a frame was read late by another wave (wrong survivor count -> a different beam, or a hang).  The selection words now
+    alternate with the frame's parity (ctc_beam.hip); this is the stress that showed 5-7 differing decodes in 300."""
+    from ppasr_amd.decoders.beam_search_decoder import beam_search_ids
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    from ppasr_amd.utils.synth import synth_features
+    V = 120
+    sd = conformer_state_dict(vocab_size=V, num_blocks=2, seed=19)
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=2, cnn_module_kernel=15)
+    model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    rng = np.random.Generator(np.random.PCG64(3))
+    batches = []
+    for seed in range(5):
+        lens = sorted((int(v) for v in rng.integers(60, 400, size=4)), reverse=True)
+        batches.append(synth_features(4, lens[0], lens=lens, seed=seed))
+    tables = [model.get_encoder_out(x, la).clone() for x, la in batches]
+    want = []
+    for q in tables:
+        t, n, s, _ = beam_search_ids(q, beam, 0.99, 40, 0, nbest=1)
+        torch.cuda.synchronize()
+        want.append((t.clone(), n.clone(), s.clone()))
+    side = torch.cuda.Stream()
+    for _ in range(30):
+        for i, q in enumerate(tables):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model.get_encoder_out(*batches[(i + 1) % 5])
+            t, n, s, _ = beam_search_ids(q, beam, 0.99, 40, 0, nbest=1)
+            torch.cuda.synchronize()
+            assert torch.equal(t, want[i][0]) and torch.equal(n, want[i][1]) and torch.equal(s, want[i][2])
+
+
 def test_stream_pool_finish_equals_predict_stream_is_end():
     """StreamPool.finish flushes the last, shorter window like predict_stream(is_end=True) (predict.py:291-298)."""
     from ppasr_amd.predict import PPASRPredictor
