@@ -136,11 +136,12 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
                L.ptab, pstride, mul * grp, Ti, T2f, grp};
     launch_attention(a, 1, H, st);
     float* gh = s->g_hist + (size_t)i * s->lo * kD;
-    launch_out_glu(ctx, xb, xc, g, xhat, Lk, nullptr, Ti, Ti, mul, st, PadSkip{}, S > 1 ? xhat : nullptr, h3);
+    HistMove hm{xh, lo_i, false};
+    launch_out_glu(ctx, xb, xc, g, xhat, Lk, nullptr, Ti, Ti, mul, st, PadSkip{}, S > 1 ? xhat : nullptr, h3, &hm);
     if (is_eff(h) && i == h->desc.stride_layer_idx) {
       const int Ts = ceil_div(Ti, 2);
       launch_conv_ffn_stride(g, gh, xc, xa, Lk, nullptr, 1, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st, PadSkip{}, true, h3);
-      launch_hist_update(xh, xhat, Ti, lo_i, st);
+      if (!hm.done) launch_hist_update(xh, xhat, Ti, lo_i, st);
       Ti = Ts;
       mul *= 2;
       pstride *= 2;
@@ -153,7 +154,7 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
       } else {
         launch_conv_ffn(g, gh, xc, xa, L, nullptr, Ti, Ti, n_chunks, h->layer_ks[i], mul, nullptr, nullptr, nullptr, st);
       }
-      launch_hist_update(xh, xhat, Ti, lo_i, st);
+      if (!hm.done) launch_hist_update(xh, xhat, Ti, lo_i, st);
     }
   }
   *frames_out = Ti;

@@ -121,7 +121,8 @@ void launch_ffn_qkv_16(const float* x_in, float* x1, float* qkv, const LayerW& w
 void launch_out_glu_16(const float* ctx, const float* x1, float* x2, float* g, const LayerW& w, const int64_t* lens, int M,
                        int Tp, int mask_mul, hipStream_t st, const PadSkip& ps);
 void launch_out_glu_split_16(const float* ctx, const float* x1, float* x2, float* g, float* xhat, const LayerW& w,
-                             const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps);  // split route, <= 16 rows
+                             const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps,
+                             float* hist = nullptr, int lo = 0);  // split route, <= 16 rows; hist: see HistMove
 bool conv_ffn_16_supported(int ksize, int Tp);
 void launch_conv_ffn_16(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int M, int Tp,
                         int n_chunks, int ksize, int mask_mul, const LayerW* next, float* x1_next, float* qkv_next,
@@ -176,10 +177,18 @@ hipError_t configure_stream_kernels();
 hipError_t configure_split_route_kernels();
 hipError_t configure_ctc_head_kernels();
 void launch_attention(const AttnArgs& a, int B, int H, hipStream_t st);
+// one streaming session: the layer's conv-module input history [lo][256] is to move on by the chunk's M rows of xhat; a
+// launch that can do it on the side sets `done` (otherwise the caller runs launch_hist_update)
+struct HistMove {
+  float* hist;
+  int lo;
+  bool done;
+};
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
                     const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps = PadSkip{},
                     float* split_xhat = nullptr,  // != nullptr: two launches (under-filled grids), M*256 floats of scratch
-                    bool h3 = false);             // the units on the fp16 x3 route (w: the layer's h3 view)
+                    bool h3 = false,              // the units on the fp16 x3 route (w: the layer's h3 view)
+                    HistMove* hm = nullptr);
 // next != nullptr: also run the following layer's S1 (writes x1_next, qkv_next) in the same launch
 void launch_conv_ffn(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                      const int64_t* lens, int M, int Tp, int n_chunks, int ksize, int mask_mul, const LayerW* next,

@@ -401,14 +401,16 @@ constexpr size_t kLdsOutGlu = 2 * kRows * kLda * sizeof(float);
 constexpr size_t kLdsPw1Cols = (kRows * kLda + kRows * 132) * sizeof(float);
 void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, float* xhat_out, const LayerW& w,
                     const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps, float* split_xhat,
-                    bool h3) {
+                    bool h3, HistMove* hm) {
   // split_xhat != nullptr (under-filled launches): out-projection + LayerNorm in one launch (the LayerNorm'd rows go to
   // split_xhat), pointwise_conv1 + GLU in a second one with the columns over two workgroups per row block
   float* xh = xhat_out ? xhat_out : split_xhat;
   // up to 16 rows (one streaming chunk): the 16-row forms (conformer_kernels_t.hip) -- half the matrix-pipe time per unit
   static const bool rows16 = !(getenv("PPASR_SPLIT_ROWS16") && atoi(getenv("PPASR_SPLIT_ROWS16")) == 0);
   if (split_xhat && !h3 && rows16 && M <= 16 && !ps.tab) {
-    launch_out_glu_split_16(ctx, x1, x2, g, xh, w, lens, M, Tp, mask_mul, st, ps);
+    const bool move = hm && hm->hist && hm->lo > 0 && hm->lo <= 30;
+    launch_out_glu_split_16(ctx, x1, x2, g, xh, w, lens, M, Tp, mask_mul, st, ps, move ? hm->hist : nullptr, move ? hm->lo : 0);
+    if (move) hm->done = true;
     return;
   }
   const dim3 grid((M + kRows - 1) / kRows);

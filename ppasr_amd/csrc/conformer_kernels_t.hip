@@ -144,7 +144,8 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_out_glu_t(const float* __re
 // waves 4-7 the GATE tiles of the same columns; values cross to the gate waves through LDS.
 template <int R>
 __global__ __launch_bounds__(RBT<R>::THREADS) void k_pw1_glu_cols_t(const float* __restrict__ xhat, float* __restrict__ g,
-                                                                    LayerW w, int M, PadSkip ps) {
+                                                                    LayerW w, int M, PadSkip ps, float* __restrict__ hist,
+                                                                    int lo) {
   using T = RBT<R>;
   static_assert(R == 16, "the quad view below is the 16-row form's");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -160,7 +161,30 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_pw1_glu_cols_t(const float*
   typename T::Ring ring;
   rbt_prime(ring, seg);
   rbt_load_rows<R>(bufA, xhat + (size_t)r0 * kD, valid);
+  // hist != nullptr (one streaming session, M <= 16 rows, lo <= 30): the session's conv-module input history of this layer
+  // moves on by the chunk's rows -- hist <- last `lo` rows of concat(hist, xhat) (stream_kernels.hip k_hist_update: read all,
+  // barrier, write) -- in workgroup y = 0 of this launch instead of a launch of its own (12 per chunk, 4.7 us each)
+  f32x4 moved[4];
+  const bool mover = hist != nullptr && y == 0;
+  if (mover) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = (int)threadIdx.x + T::THREADS * i;
+      if (idx < lo * 64) {
+        const int j = M + (idx >> 6), c4 = idx & 63;  // row of concat(hist, xhat)
+        moved[i] = j < lo ? *reinterpret_cast<const f32x4*>(hist + (size_t)j * kD + 4 * c4)
+                          : *reinterpret_cast<const f32x4*>(xhat + (size_t)(j - lo) * kD + 4 * c4);
+      }
+    }
+  }
   __syncthreads();
+  if (mover) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = (int)threadIdx.x + T::THREADS * i;
+      if (idx < lo * 64) *reinterpret_cast<f32x4*>(hist + (size_t)(idx >> 6) * kD + 4 * (idx & 63)) = moved[i];
+    }
+  }
   typename T::Acc acc;
   T::zero(acc);
   rbt_gemm<kG256>(bufA, kLda, seg, nullptr, ring, acc);
@@ -272,11 +296,12 @@ void launch_out_glu_16(const float* ctx, const float* x1, float* x2, float* g, c
 // split route on 16-row blocks (a streaming chunk): out-projection + LayerNorm (rows -> xhat), then pointwise_conv1 + GLU
 // with the columns over two workgroups
 void launch_out_glu_split_16(const float* ctx, const float* x1, float* x2, float* g, float* xhat, const LayerW& w,
-                             const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps) {
+                             const int64_t* lens, int M, int Tp, int mask_mul, hipStream_t st, const PadSkip& ps, float* hist,
+                             int lo) {
   PPASR_LAUNCH(k_out_glu_t<16>, dim3((M + 15) / 16), dim3(kThreads), excl(kLds16x2), st, ctx, x1, x2, g, w, lens, M, Tp,
                mask_mul, ps, xhat, 1);
   PPASR_LAUNCH(k_pw1_glu_cols_t<16>, dim3((M + 15) / 16, 2), dim3(kThreads), excl((16 * kLda + 16 * 132) * sizeof(float)), st,
-               xhat, g, w, M, ps);
+               xhat, g, w, M, ps, hist, lo);
 }
 bool conv_ffn_16_supported(int ksize, int Tp) { return (ksize == 7 || ksize == 15 || ksize == 31) && Tp >= 2; }
 void launch_conv_ffn_16(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int M, int Tp,

@@ -1,5 +1,6 @@
 // split_route_kernels.hip -- the layer tail cut at its feed-forward modules for UNDER-FILLED grids (small batches,
 // half-rate layers, single streaming sessions).  (Split from conformer_kernels.hip in round 5.)
+#include <algorithm>
 #include <cstdlib>
 
 #include "conformer_kernels.h"
@@ -280,12 +281,136 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_ln_qkv_t(const float* __res
     else *reinterpret_cast<f32x4*>(qkv + (size_t)(r0 + L.row(q)) * 768 + c * 256 + L.col(q)) = v;
   }
 }
+// ---- a feed-forward slice of HALF a hidden chunk (128 units) on 16 rows: gridDim.y = 2 x chunks ----
+// One chunk per workgroup is two dependent 256 x 256 units on one CU's matrix pipes (3.4 us each on 16 rows: 8 waves, two
+// per SIMD); with 128 hidden units per workgroup the first unit is 4 waves x 32 hidden columns (one wave per SIMD) and the
+// second contracts K = 128 on all 8 waves -- 1.7 us each, twice as many CUs at work, twice as many partial tiles for the
+// join.  Both weight streams are requested before the LayerNorm (two rings: 64 registers).
+__global__ __launch_bounds__(RBT<16>::THREADS) void k_ffn_half16(const float* __restrict__ x, const float* __restrict__ ln_g,
+                                                                 const float* __restrict__ ln_b, const f32x4* __restrict__ w1,
+                                                                 const float* __restrict__ b1, const f32x4* __restrict__ w2,
+                                                                 float* __restrict__ partial, int M, int n_total, PadSkip ps) {
+  using T = RBT<16>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int blk = pad_block_of(ps, T::ROWS, M);
+  if (blk < 0) return;
+  float* bufA = smem;
+  float* bufH = bufA + T::ROWS * kLda;  // [16][128 of kLda]
+  const int lane = lane_id(), wave = wave_id();
+  const int r0 = blk * T::ROWS;
+  const int valid = min(T::ROWS, M - r0);
+  const int c = blockIdx.y >> 1, half = blockIdx.y & 1;
+  const int ts2 = n_total * 32 * 64;  // W2: K = hidden
+  const f32x4* seg1 = w1 + (size_t)(c * 8 + 4 * half + (wave & 3)) * kTs256;
+  const f32x4* seg2 = w2 + (size_t)wave * ts2 + (size_t)(c * 32 + 16 * half) * 64;
+  typename T::Ring ring1, ring2;
+  if (wave < 4) rbt_prime(ring1, seg1);
+  rbt_prime(ring2, seg2);
+  rbt_load_rows<16>(bufA, x + (size_t)r0 * kD, valid);
+  if (ln_g) rbt_layernorm<16>(bufA, bufA, ln_g, ln_b, 1e-5f);
+  __syncthreads();
+  const int row = lane & 15;
+  if (wave < 4) {
+    typename T::Acc cur;
+    T::zero(cur);
+    rbt_gemm<kG256>(bufA, kLda, seg1, nullptr, ring1, cur);
+#pragma unroll
+    for (int q = 0; q < T::NQ; ++q) {
+      const int c128 = 32 * wave + 16 * q + 4 * (lane >> 4);  // hidden unit inside the workgroup's 128
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(b1 + c * 256 + 128 * half + c128);
+      const f32x4 v = cur.s[q];
+      const f32x2 lo = swish2(f32x2{v[0] + bv[0], v[1] + bv[1]});
+      const f32x2 hi = swish2(f32x2{v[2] + bv[2], v[3] + bv[3]});
+      *reinterpret_cast<f32x4*>(bufH + row * kLda + c128) = f32x4{lo[0], lo[1], hi[0], hi[1]};
+    }
+  }
+  __syncthreads();
+  typename T::Acc acc2;
+  T::zero(acc2);
+  rbt_gemm<kG256 / 2>(bufH, kLda, seg2, nullptr, ring2, acc2);
+  float* out = partial + (size_t)blockIdx.y * M * kD;
+#pragma unroll
+  for (int q = 0; q < T::NQ; ++q)
+    if (row < valid) *reinterpret_cast<f32x4*>(out + (size_t)(r0 + row) * kD + wave * 32 + 16 * q + 4 * (lane >> 4)) = acc2.s[q];
+}
+
+// ---- the conv module of ONE streaming session's chunk (<= 16 frames) with pointwise_conv2's columns over gridDim.y = 2 ----
+// k_conv_pre<KS, true> runs it on one 32-row workgroup: 18.6 us per block of the encoder (12 % of a chunk), half of it the
+// 32-row unit on one CU.  Here both workgroups stage the window (history rows, then the chunk's), run the depthwise conv +
+// LayerNorm / folded BatchNorm + swish for all 256 channels (wave w: rows 2w, 2w + 1; taps in ascending order like
+// dwconv_phase) and waves 0-3 contract their 128 output columns; the feed-forward slices that follow normalise their input
+// themselves, so the halves need no join.
+template <int KS>
+__global__ __launch_bounds__(RBT<16>::THREADS) void k_conv_pre_cols16(const float* __restrict__ g, const float* __restrict__ g_hist,
+                                                                      const float* __restrict__ x2, float* __restrict__ x3,
+                                                                      LayerW w, int M) {
+  using T = RBT<16>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LO = KS - 1;
+  float* win = smem;                     // [LO + 16][kLda]: g_hist rows, then the chunk's rows (zero past M)
+  float* taps = win + (LO + 16) * kLda;  // [KS][kLda]
+  float* bufA = taps + KS * kLda;        // [16][kLda]
+  const int lane = lane_id(), wave = wave_id(), y = blockIdx.y;
+  const f32x4* seg = w.pw2 + (size_t)(4 * y + (wave & 3)) * kTs256;
+  typename T::Ring ring;
+  if (wave < 4) rbt_prime(ring, seg);
+  for (int q = wave; q < LO + 16; q += T::WAVES) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q < LO) v = *reinterpret_cast<const f32x4*>(g_hist + (size_t)q * kD + 4 * lane);
+    else if (q - LO < M) v = *reinterpret_cast<const f32x4*>(g + (size_t)(q - LO) * kD + 4 * lane);
+    *reinterpret_cast<f32x4*>(win + q * kLda + 4 * lane) = v;
+  }
+  for (int j = wave; j < KS; j += T::WAVES)
+    *reinterpret_cast<f32x4*>(taps + j * kLda + 4 * lane) = *reinterpret_cast<const f32x4*>(w.dw_w + j * kD + 4 * lane);
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(w.dw_b + 4 * lane);
+  const f32x4 gam = *reinterpret_cast<const f32x4*>(w.ln_cm_g + 4 * lane);
+  const f32x4 bet = *reinterpret_cast<const f32x4*>(w.ln_cm_b + 4 * lane);
+  __syncthreads();
+  f32x4 out[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 2 * wave + i;
+    f32x4 acc = bias;
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+      acc += *reinterpret_cast<const f32x4*>(taps + j * kLda + 4 * lane) * *reinterpret_cast<const f32x4*>(win + (row + j) * kLda + 4 * lane);
+    out[i] = acc;
+  }
+  ln_rows_inreg<true, 2>(out, gam, bet, w.cm_eps);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(bufA + (2 * wave + i) * kLda + 4 * lane) = out[i];
+  __syncthreads();
+  if (wave >= 4) return;
+  typename T::Acc acc;
+  T::zero(acc);
+  rbt_gemm<kG256>(bufA, kLda, seg, nullptr, ring, acc);
+  const int row = lane & 15;
+  if (row >= M) return;
+#pragma unroll
+  for (int q = 0; q < T::NQ; ++q) {
+    const int col = 128 * y + 32 * wave + 16 * q + 4 * (lane >> 4);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(w.pw2_b + col);
+    const f32x4 r = *reinterpret_cast<const f32x4*>(x2 + (size_t)row * kD + col);
+    const f32x4 a = acc.s[q];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = r[e] + (a[e] + bv[e]);
+    *reinterpret_cast<f32x4*>(x3 + (size_t)row * kD + col) = o;
+  }
+}
+template <int KS>
+constexpr size_t conv_cols16_lds() { return (size_t)(KS - 1 + 16 + KS + 16) * kLda * sizeof(float); }
+
 // (LDS asked for: kLdsExclusive, so that a CU holds ONE of these workgroups -- co-resident row-block workgroups share the
 //  matrix pipe and the weight stream's lead time no longer covers a unit: with 32 / 64 independent sessions on their own
 //  HIP streams the own-size allocation, 3 workgroups per CU, was 13 % slower per chunk round, same box)
 constexpr size_t kLdsFfnPart16 = kLdsExclusive, kLdsLnQkv16 = kLdsExclusive;
 static_assert(3 * 16 * kLda * sizeof(float) <= kLdsExclusive, "LDS of the 16-row feed-forward slice");
 // (up to 16 rows -- one streaming chunk, single short utterances: the 16-row forms; PPASR_SPLIT_ROWS16=0 switches them off)
+static bool ffn_half16_on() {  // (PPASR_FFN_HALF16=0: whole chunks per workgroup, the A/B knob of the measurement above)
+  static const bool on = !(getenv("PPASR_FFN_HALF16") && atoi(getenv("PPASR_FFN_HALF16")) == 0);
+  return on;
+}
 static bool split_rows16(int M) {
   static const bool on = !(getenv("PPASR_SPLIT_ROWS16") && atoi(getenv("PPASR_SPLIT_ROWS16")) == 0);
   return on && M <= 16;
@@ -298,6 +423,17 @@ void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float
                      int M, int Tp, int ksize, int mask_mul, hipStream_t st, bool causal, const PadSkip& ps, bool h3) {
   dim3 grid((M + kRows - 1) / kRows);
   const int left_ctx = causal ? ksize - 1 : (ksize - 1) / 2;
+  // one session's chunk of up to 16 frames: the column-split 16-row form
+  if (g_hist && !h3 && !lens && !ps.tab && causal && M == Tp && split_rows16(M) && (ksize == 15 || ksize == 31 || ksize == 7)) {
+#define LAUNCH_CC16(KS)                                                                                               \
+  PPASR_LAUNCH(k_conv_pre_cols16<KS>, dim3(1, 2), dim3(kThreads), std::max(conv_cols16_lds<KS>(), kLdsExclusive), st, g, g_hist, \
+               x2, x3, w, M)
+    if (ksize == 15) LAUNCH_CC16(15);
+    else if (ksize == 31) LAUNCH_CC16(31);
+    else LAUNCH_CC16(7);
+#undef LAUNCH_CC16
+    return;
+  }
 #define LAUNCH_CP2(KS, STREAM, H3)                                                                                      \
   PPASR_LAUNCH((k_conv_pre<KS, STREAM, H3>), grid, dim3(kThreads), kLdsConvPre, st, g, g_hist, x2, x3, w, lens, M, Tp, \
                mask_mul, left_ctx, ps)
@@ -324,7 +460,12 @@ void launch_ffn_split(const float* x, const float* ln_g, const float* ln_b, cons
   if (h3)  // (w1 / w2: the re-packed weights)
     PPASR_LAUNCH(k_ffn_part<true>, dim3((M + kRows - 1) / kRows, S), dim3(kThreads), kLdsFfnPart + kH3ExtraLds, st, x, ln_g, ln_b,
                  w1, b1, w2, partial, M, n_chunks, ps);
-  else if (split_rows16(M) && !ps.tab) {
+  else if (split_rows16(M) && !ps.tab && S == n_chunks && ffn_half16_on() && !(getenv("PPASR_STREAM_TICKET") && atoi(getenv("PPASR_STREAM_TICKET")) == 1)) {
+    // one chunk per workgroup already: cut the chunks in halves (k_ffn_half16), 2 S partial tiles
+    PPASR_LAUNCH(k_ffn_half16, dim3((M + 15) / 16, 2 * S), dim3(kThreads), kLdsFfnPart16, st, x, ln_g, ln_b, w1, b1, w2, partial, M,
+                 n_chunks, ps);
+    S *= 2;
+  } else if (split_rows16(M) && !ps.tab) {
     // (out == x would let the joining workgroup overwrite rows another slice is still reading: two launches then)
     // OPT-IN (PPASR_STREAM_TICKET=1): measured on one box, one 0.64 s chunk of one session 1.35 ms with the in-kernel join
     // against 1.24 ms with the join as its own launch (the last slice's workgroup joins 16 rows x S partial tiles alone; the
@@ -369,6 +510,10 @@ hipError_t configure_split_route_kernels() {
   SET_LDS((k_conv_pre<7, true, true>), kLdsConvPre);
   SET_LDS(k_ffn_part<false>, kLdsFfnPart);
   SET_LDS(k_ffn_part_t<16>, kLdsFfnPart16);
+  SET_LDS(k_ffn_half16, kLdsFfnPart16);
+  SET_LDS(k_conv_pre_cols16<15>, std::max(conv_cols16_lds<15>(), kLdsExclusive));
+  SET_LDS(k_conv_pre_cols16<31>, std::max(conv_cols16_lds<31>(), kLdsExclusive));
+  SET_LDS(k_conv_pre_cols16<7>, std::max(conv_cols16_lds<7>(), kLdsExclusive));
   SET_LDS(k_ln_qkv_t<16>, kLdsLnQkv16);
   SET_LDS(k_ffn_part<true>, kLdsFfnPart + kH3ExtraLds);
   SET_LDS(k_ln_qkv<true>, kLdsLnQkv + 512);

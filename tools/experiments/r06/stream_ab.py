@@ -14,7 +14,7 @@ x, _ = synth_features(1, 67, seed=5)
 chunk = torch.from_numpy(x).cuda()
 n_chunks = 40
 out = {"tag": os.environ.get("TAG", "")}
-for n_sessions in (1, 32):
+for n_sessions in [int(v) for v in os.environ.get("SESS", "1,32").split(",")]:
     sessions = [model.new_stream() for _ in range(n_sessions)]
     streams = [torch.cuda.Stream() for _ in range(n_sessions)]
     best = 1e9
