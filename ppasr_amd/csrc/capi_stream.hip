@@ -312,7 +312,9 @@ size_t ppasr_chunk_workspace_bytes(ppasr_handle h, int T) {
   const size_t Tp = h->front_dims(T).Tp;
   if (h->generic) return (generic_ws_floats(h, 1, T) + (size_t)h->desc.max_len * h->desc.output_size) * sizeof(float);
   // the full-utterance layout for B=1, plus the conv-module input rows and a cache-shift scratch
-  return (ws_layout(h, 1, T).total + Tp * kD + 64 + (size_t)h->desc.max_len * kD) * sizeof(float);
+  // (+ the K-split scratch of the chunk's conv2 launch)
+  return (ws_layout(h, 1, T).total + Tp * kD + 64 + (size_t)h->desc.max_len * kD + conv_stage_part_floats((int)Tp * h->F2)) *
+         sizeof(float);
 }
 
 ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int required_cache_size, float* probs,
@@ -352,9 +354,12 @@ ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int r
     launch_conv_stage(y2, h->front.conv3_w, h->front.conv3_b, y1, 1, fd.T2, F2, c, h->F3, 3, 2, st);
     launch_embed(y1, h->front, xa, c, h->F3 * kD, sqrtf((float)kD), false, st, PadSkip{}, ffn_split_for(h, c), y2);
   } else {
-    launch_conv2(y1, h->front, y2, 1, T1, F1, c, F2, st);  // (3x3 / 2, or conv2d6's 5x5 / 3: FrontW::conv2_k / _s)
+    // (3x3 / 2, or conv2d6's 5x5 / 3: FrontW::conv2_k / _s)
+    launch_conv2(y1, h->front, y2, 1, T1, F1, c, F2, st, PadSkip{}, nullptr, nullptr, shift_tmp + (size_t)h->desc.max_len * kD,
+                 conv_stage_part_floats(c * F2));
+    // (one row block: a workgroup per 256-wide K chunk -- F2 of them -- instead of 8 workgroups of 2 - 3 chunks)
     launch_embed(y2, h->front, xa, c, F2 * kD, sqrtf((float)kD), /*scale_before_bias=*/is_sq(h), st, PadSkip{},
-                 ffn_split_for(h, c), y1);
+                 (c <= 32 && ffn_split_for(h, c) > 1) ? F2 : ffn_split_for(h, c), y1);
   }
   float* x_final = xa;
   int frames = c;
@@ -363,8 +368,10 @@ ppasr_status ppasr_encode_chunk(ppasr_stream s, const float* feats, int T, int r
   if (r != PPASR_OK) return r;
   int32_t* fa = frame_argmax ? frame_argmax : reinterpret_cast<int32_t*>(ws + wl.fa);
   float* fp = frame_maxprob ? frame_maxprob : ws + wl.fp;
-  launch_ctc_head(x_final, h->head, probs, fa, fp, ws + wl.rmax, ws + wl.rsum, frames, st, PadSkip{}, ffn_split_for(h, frames),
-                  y1);
+  // (one row block: as many column slices as give every wave ONE 32-column vocabulary tile -- 17 at V = 4233 -- not 8)
+  const int head_slices = (frames <= 32 && ffn_split_for(h, frames) > 1) ? std::min((h->head.n_tiles + 7) / 8, 32)
+                                                                        : ffn_split_for(h, frames);
+  launch_ctc_head(x_final, h->head, probs, fa, fp, ws + wl.rmax, ws + wl.rsum, frames, st, PadSkip{}, head_slices, y1);
   if (probs) launch_softmax_from_stats(probs, ws + wl.rmax, ws + wl.rsum, frames, h->head.V, st);
   r = finish_chunk(s, p, shift_tmp, st);
   if (r != PPASR_OK) return r;

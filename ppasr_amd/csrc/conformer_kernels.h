@@ -147,10 +147,14 @@ void launch_conv1(const float* feats, const FrontW& fw, float* y1, int B, int T,
 void launch_conv_stage(const float* y_in, const f32x4* w, const float* bias, float* y_out, int B, int T_in, int F_in,
                        int T_out, int F_out, int k, int s, hipStream_t st, const PadSkip& ps_frames = PadSkip{},
                        int channels = 256, int* tile_scratch = nullptr,  // channels: 256, or a multiple of it (general layer route)
-                       bool h3 = false);  // h3: w is the fp16 x3 re-packing (launch_repack_h3), the units run on that route
+                       bool h3 = false,  // h3: w is the fp16 x3 re-packing (launch_repack_h3), the units run on that route
+                       float* part = nullptr, size_t part_floats = 0);  // scratch: under-filled launches split the taps (K)
+// floats of `part` that let launch_conv_stage split a launch of M output rows over its K chunks (0: it would not split)
+size_t conv_stage_part_floats(int M, int channels = 256);
 // tile_scratch (ragged batches): device scratch of B + 2 ints for the active-tile table (k_tile_prefix)
 void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st,
-                  const PadSkip& ps = PadSkip{}, int* tile_scratch = nullptr, const f32x4* w_h3 = nullptr);
+                  const PadSkip& ps = PadSkip{}, int* tile_scratch = nullptr, const f32x4* w_h3 = nullptr, float* part = nullptr,
+                  size_t part_floats = 0);
 // scale_before_bias: Squeezeformer scales the 4864-wide conv output by sqrt(d) BEFORE input_proj
 // (squeezeformer/subsampling.py:66-67) -> acc*scale + b ; Conformer: (acc + b)*scale (embedding.py:112)
 // k_slices > 1 (under-filled launches): the contraction is split over that many workgroups per row block, partial sums

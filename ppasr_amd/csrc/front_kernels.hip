@@ -364,18 +364,25 @@ __global__ __launch_bounds__(256) void k_gemm_join(const float* __restrict__ par
   const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * lane);
   f32x4 y;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) y[e] = scale_before_bias ? acc[e] * scale + bv[e] : (acc[e] + bv[e]) * scale;
+  for (int e = 0; e < 4; ++e) {
+    y[e] = (scale_before_bias & 1) ? acc[e] * scale + bv[e] : (acc[e] + bv[e]) * scale;
+    if (scale_before_bias & 2) y[e] = fmaxf(y[e], 0.f);  // (bit 1: ReLU -- the convolution stages)
+  }
   *reinterpret_cast<f32x4*>(out + (size_t)row * kD + 4 * lane) = y;
+}
+constexpr int kConvSplitMax = 9;  // K slices of an under-filled convolution stage (3 x 3 taps x 2 chunks = 18 chunks: 2 each)
+size_t conv_stage_part_floats(int M, int channels) {
+  return (channels == 256 && M <= 32 * 28) ? (size_t)kConvSplitMax * M * 256 : 0;
 }
 
 void launch_conv2(const float* y1, const FrontW& fw, float* y2, int B, int T1, int F1, int Tp, int F2, hipStream_t st,
-                  const PadSkip& ps_frames, int* tile_scratch, const f32x4* w_h3) {
+                  const PadSkip& ps_frames, int* tile_scratch, const f32x4* w_h3, float* part, size_t part_floats) {
   launch_conv_stage(y1, w_h3 ? w_h3 : fw.conv2_w, fw.conv2_b, y2, B, T1, F1, Tp, F2, fw.conv2_k, fw.conv2_s, st, ps_frames, 256,
-                    tile_scratch, w_h3 != nullptr);
+                    tile_scratch, w_h3 != nullptr, part, part_floats);
 }
 void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b, float* y2, int B, int T1, int F1, int Tp,
                        int F2, int ksz, int stride, hipStream_t st, const PadSkip& ps_frames, int channels, int* tile_scratch,
-                       bool h3) {
+                       bool h3, float* part, size_t part_floats) {
   Conv2Src src{y1, T1, F1, Tp, F2, ksz, stride, channels};
   const int n_kc = ksz * ksz * (channels / 128);  // 128-wide K chunks: channels / 128 per tap
   const int ny = channels / 256;                  // 256-column blocks of the output
@@ -414,6 +421,19 @@ void launch_conv_stage(const float* y1, const f32x4* conv_w, const float* conv_b
   if (full == 0) {
     // less than one round of 128-row tiles (a single utterance, a streaming chunk): smaller tiles fill more CUs
     const int mt = (M + 32 * kCUs - 1) / (32 * kCUs);  // 1 .. 4
+    // a streaming chunk (16 frames x 19 bins = 10 tiles): each workgroup would walk all 18 K chunks alone, 74 us of a 1 ms
+    // chunk -- with scratch the chunks go over up to 9 workgroups per tile (raw partial sums; k_gemm_join adds bias + ReLU)
+    const int tiles = (M + 31) / 32;
+    if (part && !h3 && ny == 1 && !ps.lens && tiles <= 28) {
+      int z = kConvSplitMax;
+      while (z > 1 && (n_kc % z != 0 || tiles * z > kCUs || (size_t)z * M * 256 > part_floats)) --z;
+      if (z > 1) {
+        PPASR_LAUNCH((k_gemm_stream<1, KC, true, false, Conv2Src>), dim3(tiles, 1, z), dim3(kThreads), lds_of(1), st, src, conv_w,
+                     conv_b, part, M, n_kc, 1.0f, channels, channels, 0, ps, no_tab);
+        PPASR_LAUNCH(k_gemm_join, dim3((M + 3) / 4), dim3(256), 0, st, part, z, conv_b, 1.0f, 2, y2, M, PadSkip{});
+        return;
+      }
+    }
 #define CONV2_ALL(MTA) CONV_STAGE_LAUNCH(MTA, dim3((M + 32 * MTA - 1) / (32 * MTA), ny), 0, no_tab)
     if (mt <= 1) CONV2_ALL(1);
     else if (mt == 2) CONV2_ALL(2);

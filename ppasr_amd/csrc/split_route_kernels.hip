@@ -130,10 +130,19 @@ __global__ __launch_bounds__(256) void k_ffn_join(const float* __restrict__ x, c
   if (row >= M) return;
   if (pad_block_skippable(ps, row & ~(kRows - 1), kRows, M)) return;
   const int lane = lane_id();
-  f32x4 acc = *reinterpret_cast<const f32x4*>(partial + (size_t)row * kD + 4 * lane);
-  for (int s = 1; s < S; ++s) acc += *reinterpret_cast<const f32x4*>(partial + ((size_t)s * M + row) * kD + 4 * lane);
+  // (the S tiles' loads in flight four at a time, added in slice order: a chain of S dependent L2 round trips otherwise)
   const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + 4 * lane);
   f32x4 y = *reinterpret_cast<const f32x4*>(x + (size_t)row * kD + 4 * lane);
+  f32x4 acc = *reinterpret_cast<const f32x4*>(partial + (size_t)row * kD + 4 * lane);
+  int s = 1;
+  for (; s + 4 <= S; s += 4) {
+    f32x4 p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = *reinterpret_cast<const f32x4*>(partial + ((size_t)(s + j) * M + row) * kD + 4 * lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc += p[j];
+  }
+  for (; s < S; ++s) acc += *reinterpret_cast<const f32x4*>(partial + ((size_t)s * M + row) * kD + 4 * lane);
   if (pre_g) y = ln_row(y, pre_g, pre_b, lane);
 #pragma unroll
   for (int e = 0; e < 4; ++e) y[e] = y[e] + scale * (acc[e] + bv[e]);

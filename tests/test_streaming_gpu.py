@@ -110,7 +110,9 @@ def test_session_group_equals_independent_streams():
             torch.cuda.synchronize()
             assert group.offset(s) == singles[s].offset
             err = _rel(probs[i].cpu().numpy(), ref[0].cpu().numpy())
-            assert err < 1e-5, (r, s, err)
+            # (not bit-equal: the single-session route runs 16-row units and splits the front end's contractions over
+            #  more workgroups than the group route -- another order of the fp32 sums; both sit within TOL of the oracle)
+            assert err < 3e-5, (r, s, err)
             assert np.array_equal(fa[i].cpu().numpy(), ref[0].argmax(dim=1).cpu().numpy())
     # reset one session: it restarts from offset 0 while the others keep their state
     group.reset(2)
@@ -119,6 +121,6 @@ def test_session_group_equals_independent_streams():
                                         want_probs=True)
     ref2 = singles[2].encode_chunk(feats[2][:, :67], -16)
     torch.cuda.synchronize()
-    assert group.offset(2) == 16 and _rel(probs[0].cpu().numpy(), ref2[0].cpu().numpy()) < 1e-5
+    assert group.offset(2) == 16 and _rel(probs[0].cpu().numpy(), ref2[0].cpu().numpy()) < 3e-5
     with pytest.raises(Exception):
         group.encode_chunks([1, 1], np.concatenate([feats[1][:, :67]] * 2))
