@@ -14,6 +14,15 @@ cd $R
 db=$(find gpurun_out/prof_${TAG}_beam -name '*_results.db' 2>/dev/null | head -1)
 [ -n "$db" ] && python tools/rocpd_summary.py $db > gpurun_out/${TAG}_beam_kernel_trace.txt
 rm -rf gpurun_out/prof_${TAG}_beam
+# one streaming session's chunk under rocprofv3: launches, busy / wall time per chunk, per-kernel averages
+cd /tmp
+SESS=1 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_chunk -o chunk --output-format csv -- python $R/tools/experiments/r06/stream_ab.py > $R/gpurun_out/prof_${TAG}_chunk.log 2>&1
+cd $R
+csv=$(find gpurun_out/prof_${TAG}_chunk -name '*kernel_trace.csv' 2>/dev/null | head -1)
+[ -n "$csv" ] && python tools/experiments/r06/trace_chunks.py $csv > gpurun_out/${TAG}_stream_chunk_trace.txt
+rm -rf gpurun_out/prof_${TAG}_chunk
+for i in 1 2 3; do python tools/experiments/r06/stream_ab.py; done > gpurun_out/${TAG}_stream_ab.txt 2>/dev/null
+cp gpurun_out/${TAG}_stream_chunk_trace.txt gpurun_out/${TAG}_stream_ab.txt profiles/ 2>/dev/null
 # every compiled kernel launched by the GPU suite (tools/kernel_coverage.py --list was run on the build box)
 PPASR_KCOV=gpurun_out/kcov.tsv python -m pytest tests -m gpu -q > gpurun_out/${TAG}_gpu_suite.txt 2>&1
 python tools/kernel_coverage.py --report gpurun_out/kcov.tsv > gpurun_out/${TAG}_kernel_coverage.txt 2>&1
