@@ -2229,12 +2229,11 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
   // threads per utterance by the number of (hypothesis, candidate) elements a frame can have: every phase is a chain of
   // block-wide steps, and a barrier over few waves is cheaper than one over 16
   const size_t n_elem = (size_t)cfg.beam * (1 + (size_t)cfg.n_cand_max);
-  // 512 threads up to 1 024 elements, else 1 024 (beams are at most 512: one slot of the new beam per thread either way)
   // 512 threads up to 1 024 elements and for beams up to 128, else 768 (12 waves: 170 registers per lane -- the 1 024-thread
   // form has 128, which the scorer's look-ups overflow into scratch -- and cheaper barriers; measured, flat posteriors, us per
   // frame on 512 / 768 / 1 024 threads: beam 100 10.8 / 11.3 / 11.5, beam 300 14.3 / 12.8 / 13.0)
   int sel = (n_elem <= 1024 || cfg.beam <= 128) ? 0 : 2;
-  if (const char* e = getenv("PPASR_BEAM_BT")) sel = atoi(e) >= 1024 ? 1 : (atoi(e) >= 768 ? 2 : 0);  // (tuning knob)
+  if (const char* e = getenv("PPASR_BEAM_BT")) sel = atoi(e) >= 768 ? 2 : 0;  // (tuning knob: 512 / 768 threads)
   const bool wl = cfg.lm.order > 0 && cfg.lm.word_based != 0;
   // scratch: [wide pruning records] [per-utterance element lists]
   const size_t rec_bytes = (scratch_rec_bytes(cfg, B, T) + 255) & ~(size_t)255, list_stride = scratch_list_bytes_per_utt(cfg);
@@ -2298,8 +2297,7 @@ hipError_t launch_ctc_beam(const float* probs, const int32_t* frame_lens, int B,
   } while (0)
   if (wide) PPASR_LAUNCH_BEAM_LM(1024, true);  // (wide records: always 1 024 threads)
   else if (sel == 0) PPASR_LAUNCH_BEAM_LM(512, false);
-  else if (sel == 2) PPASR_LAUNCH_BEAM_LM(768, false);
-  else PPASR_LAUNCH_BEAM_LM(1024, false);
+  else PPASR_LAUNCH_BEAM_LM(768, false);
 #undef PPASR_LAUNCH_BEAM_LM
 #undef PPASR_LAUNCH_BEAM
   return hipGetLastError();

@@ -25,10 +25,10 @@ WORDS = ["the", "cat", "sat", "on", "a", "mat", "it's", "at", "an", "ant", "anth
          "note", "notes", "one", "once", "we", "were", "where", "when", "what", "who", "why", "how", "now", "new", "news"]
 
 
-def _dictionary(lm):
+def _dictionary(lm, vocab=None):
     """character trie of every LM word + space in CSR form, nodes numbered by a BFS of my own (independent of the
     library's builder): -> (first, arc_char, arc_next, word)"""
-    tok = {c: i for i, c in enumerate(VOCAB)}
+    tok = {c: i for i, c in enumerate(vocab or VOCAB)}
     nodes = [{}]
     word_at = {}
     for w, wid in lm["words"].items():
@@ -101,6 +101,7 @@ def _oracle_word_decode(lib, chunks, V, beam, cutoff_prob, top_n, lm, dic, alpha
 
 @pytest.mark.parametrize("fmt,beam,order,alpha,beta", [("arpa", 20, 3, 1.9, 0.3),      # english_example.yml weights
                                                         ("arpa", 100, 2, 1.9, 0.3),
+                                                        ("arpa", 160, 3, 1.9, 0.3),     # (the 768-thread form of the search)
                                                         ("arpa", 8, 3, 0.8, -0.5),
                                                         ("trie", 30, 3, 1.9, 0.3),
                                                         ("probing", 30, 3, 1.9, 0.3),
@@ -141,6 +142,38 @@ def test_word_based_scorer_matches_c_oracle(tmp_path, fmt, beam, order, alpha, b
         assert all(w in WORDS for w in text[:-1])      # every completed word is a dictionary word
         spoken += int(text == sents[b])
     print(f"word LM [{fmt}, beam {beam}]: {spoken}/{B} tables decoded to exactly the sentence they speak")
+
+
+def test_word_based_scorer_on_an_unpruned_wide_vocabulary(tmp_path):
+    """cutoff_prob = 1.0 keeps the whole vocabulary (upstream sorts it when cutoff_top_n < V) -- more than 128 characters
+    per frame is the wide form of the search (records and element lists in HBM scratch), here with the word-based scorer
+    and its dictionary on top: 130 extra symbols that no word uses behind the letters."""
+    from ppasr_amd.decoders.beam_search_decoder import Scorer, beam_search_ids
+    lib = _oracle()
+    vocab = VOCAB + [f"<x{i}>" for i in range(130)]
+    V = len(vocab)
+    rng = np.random.Generator(np.random.PCG64(99))
+    arpa = write_synthetic_arpa(str(tmp_path / "w.arpa"), WORDS, order=3, n_sent=300, sent_len=8, seed=5)
+    lm = read_arpa(arpa, vocab)
+    scorer = Scorer(1.9, 0.3, arpa, vocab)
+    assert not scorer.is_character_based()
+    dic = _dictionary(lm, vocab)
+    sents = [["the", "cat", "sat"], ["here", "we", "were", "soon"]]
+    tabs = [_spoken_probs(rng, s, V, noise=0.05) for s in sents]
+    T = max(t.shape[0] for t in tabs)
+    batch = np.zeros((len(tabs), T, V), np.float32)
+    lens = np.array([t.shape[0] for t in tabs], np.int32)
+    for b, t in enumerate(tabs):
+        batch[b, :t.shape[0]] = t
+    beam = 12
+    tokens, ln, scores, _ = beam_search_ids(torch.from_numpy(batch).cuda(), beam, 1.0, 40, 0, frame_lens=lens, nbest=2,
+                                            ext_scorer=scorer)
+    torch.cuda.synchronize()
+    tokens, ln, scores = tokens.cpu().numpy(), ln.cpu().numpy(), scores.cpu().numpy()
+    for b in range(len(tabs)):
+        ref = _oracle_word_decode(lib, [batch[b, :lens[b]]], V, beam, 1.0, 40, lm, dic, 1.9, 0.3, 2)
+        assert tokens[b, 0, :ln[b, 0]].tolist() == ref[0][0], b
+        assert abs(scores[b, 0] - ref[0][1]) <= 2e-4 * max(1.0, abs(ref[0][1]))
 
 
 class _nullcontext:

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 from ppasr_amd.decoders.beam_search_decoder import beam_search_ids  # noqa: E402
 from ppasr_amd.model_utils.conformer.model import ConformerModel  # noqa: E402
-from ppasr_amd.utils.synth import conformer_state_dict, synth_features  # noqa: E402
+from ppasr_amd.utils.synth import conformer_state_dict, synth_features, synth_vocabulary  # noqa: E402
 
 V = 120
 reps = int(os.environ.get("REPS", 40))
@@ -27,6 +27,17 @@ for seed in range(5):
     x, la = synth_features(4, lens[0], lens=lens, seed=seed)
     batches.append((x, la))
 
+cutoff = float(os.environ.get("CUTOFF", "0.99"))
+topn = int(os.environ.get("TOPN", "40"))
+scorer = None
+if os.environ.get("SCORER", "0") == "1":  # a character-based 3-gram scorer over most of the vocabulary
+    import tempfile
+    from lm_util import write_synthetic_arpa
+    from ppasr_amd.decoders.beam_search_decoder import Scorer
+    vocab = synth_vocabulary(V)
+    arpa = write_synthetic_arpa(os.path.join(tempfile.mkdtemp(), "lm.arpa"), vocab[2:100], order=3, seed=4)
+    scorer = Scorer(2.2, 4.3, arpa, vocab)
+print("cutoff", cutoff, "top_n", topn, "scorer", scorer is not None, flush=True)
 quiet = [model.get_encoder_out(x, la).clone() for x, la in batches]
 torch.cuda.synchronize()
 side = torch.cuda.Stream()
@@ -50,7 +61,7 @@ print("encoder outputs that differ under concurrency:", bad_enc, "of", reps * 5,
 for beam in beams:
     ref = []
     for q in quiet:
-        t, n, s, _ = beam_search_ids(q, beam, 0.99, 40, 0, nbest=1)
+        t, n, s, _ = beam_search_ids(q, beam, cutoff, topn, 0, nbest=1, ext_scorer=scorer)
         torch.cuda.synchronize()
         ref.append((t.clone(), n.clone(), s.clone()))
     for load in os.environ.get("LOADS", "none,encoder,gemm").split(","):
@@ -65,7 +76,7 @@ for beam in beams:
                     elif load == "gemm":
                         for _ in range(3):
                             big @ big
-                t, n, s, _ = beam_search_ids(q, beam, 0.99, 40, 0, nbest=1)
+                t, n, s, _ = beam_search_ids(q, beam, cutoff, topn, 0, nbest=1, ext_scorer=scorer)
                 torch.cuda.synchronize()
                 if not (torch.equal(t, ref[i][0]) and torch.equal(n, ref[i][1]) and torch.equal(s, ref[i][2])):
                     bad += 1
