@@ -915,7 +915,10 @@ ppasr_status sq_run(ppasr_model_s* h, const float* feats, const int64_t* lens, i
       at.v = vc;
       at.k_stride = at.v_stride = D;
       at.T2 = at.kv_frames = n_cache + Ti;
-      at.pos0 = plan->pos0;
+      // (plain MHA: the table is ONE row of zeros -- k_attention_t adds pos0 rows to its base whatever the stride, so a
+      //  chunk behind a trimmed cache (pos0 > 0) read past it: garbage in the positional half, a fault when the row sat at
+      //  the end of a mapping -- found by the instrumented full suite, round 6)
+      at.pos0 = plain_mha ? 0 : plan->pos0;
     }
     at.pad_skip = skip ? ps.slack + 1 : 0;
     at.dm = D;
