@@ -107,6 +107,14 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
   int Ti = p.c, mul = 4, pstride = 1;
   bool half = false;
   history_glu_all(s, st);
+  // Consumer-side joins (conformer_kernels.h JoinIn; fp32 route, <= 16 rows): a feed-forward module leaves 2 S partial tiles
+  // and a PENDING join that the next launch computes in its prologue.  Macaron slices go to partial, final slices to
+  // the tiles behind them (the pending final join of block i is read while block i + 1's macaron slices are written).
+  JoinIn pending;
+  auto flush = [&](int M) {  // a launch that cannot take a pending join in: the join alone
+    if (pending.partial) launch_join16(pending, M, st);
+    pending = JoinIn{};
+  };
   for (int i = 0; i < h->desc.num_blocks; ++i) {
     const LayerW& L = h->layers[i];
     const int grp = h->layer_group[i];
@@ -122,11 +130,19 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
     // Out-of-range activations are saturated and counted (ppasr_gemm_guard_stats); a chunk is not re-run.
     const bool h3 = S > 1 && h->gemm_mode == PPASR_GEMM_F16X3 && !h->layers_h3.empty();
     const LayerW& Lk = h3 ? h->layers_h3[i] : L;
-    if (S > 1) {
+    const bool fused_joins = !h3 && ffn_half16_route(Ti, S, n_chunks);
+    if (fused_joins) {
+      launch_ffn_half16(xa, pending, L.ln_mac_g, L.ln_mac_b, L.ffm_w1, L.ffm_b1, L.ffm_w2, partial, Ti, n_chunks, st);
+      const JoinIn mac{partial, 2 * S, L.ffm_b2, 0.5f, xa, nullptr, nullptr, xb};
+      launch_join_ln_qkv16(mac, qkv, L, Ti, st, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD);
+      pending = JoinIn{};
+    } else if (S > 1) {
+      flush(Ti);
       launch_ffn_split(xa, L.ln_mac_g, L.ln_mac_b, Lk.ffm_w1, L.ffm_b1, Lk.ffm_w2, L.ffm_b2, 0.5f, nullptr, nullptr, partial, xb,
                        Ti, n_chunks, S, st, PadSkip{}, false, h3, s->ticket);
       launch_ln_qkv(xb, qkv, Lk, Ti, st, PadSkip{}, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD, h3);
     } else {
+      flush(Ti);
       launch_ffn_qkv(xa, xb, qkv, L, Ti, n_chunks, st);
       launch_kv_append(qkv, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD, Ti, st);
     }
@@ -147,7 +163,12 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
       pstride *= 2;
       half = true;
     } else {
-      if (S > 1) {
+      if (fused_joins) {
+        launch_conv_pre(g, gh, xc, ctx, L, nullptr, Ti, Ti, h->layer_ks[i], mul, st, true, PadSkip{}, false);
+        float* part_fin = partial + (size_t)2 * S * Ti * kD;  // (behind the macaron module's 2 S tiles of Ti rows)
+        launch_ffn_half16(ctx, JoinIn{}, L.ln_ff_g, L.ln_ff_b, L.ff_w1, L.ff_b1, L.ff_w2, part_fin, Ti, n_chunks, st);
+        pending = JoinIn{part_fin, 2 * S, L.ff_b2, 0.5f, ctx, L.ln_fin_g, L.ln_fin_b, xa};
+      } else if (S > 1) {
         launch_conv_pre(g, gh, xc, ctx, Lk, nullptr, Ti, Ti, h->layer_ks[i], mul, st, true, PadSkip{}, h3);
         launch_ffn_split(ctx, L.ln_ff_g, L.ln_ff_b, Lk.ff_w1, L.ff_b1, Lk.ff_w2, L.ff_b2, 0.5f, L.ln_fin_g, L.ln_fin_b, partial,
                          xa, Ti, n_chunks, S, st, PadSkip{}, false, h3, s->ticket);
@@ -157,6 +178,7 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
       if (!hm.done) launch_hist_update(xh, xhat, Ti, lo_i, st);
     }
   }
+  flush(Ti);  // (the last block's final join)
   *frames_out = Ti;
   return PPASR_OK;
 }

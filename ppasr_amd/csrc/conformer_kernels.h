@@ -210,6 +210,28 @@ void launch_ffn_split(const float* x, const float* ln_g, const float* ln_b, cons
                       float* partial, float* out, int M, int n_chunks, int S, hipStream_t st, const PadSkip& ps = PadSkip{},
                       bool residual_is_normed = false, bool h3 = false, int* ticket = nullptr);  // h3: w1 / w2 are the re-packed weights
 // kc / vc: write the K / V thirds to these cache rows instead of qkv (single-session streaming)
+// ---- one streaming session's chunk (<= 16 rows): feed-forward slices whose partial tiles are joined by their CONSUMER ----
+// JoinIn describes a pending join  out = LN?(x + scale (sum_s partial[s] + b2))  of S partial tiles [S][M][256]: the launch
+// that needs `out` as its input computes it in its prologue (every workgroup for itself, from L2) and workgroup 0 also
+// stores it to `out` -- the join launch (4.4 us for 16 KB of work) disappears.  partial == nullptr: no pending join.
+struct JoinIn {
+  const float* partial = nullptr;
+  int S = 0;
+  const float* b2 = nullptr;
+  float scale = 0.f;
+  const float* x = nullptr;                        // residual input of the joined module
+  const float *ln_g = nullptr, *ln_b = nullptr;    // LayerNorm behind the residual sum (or nullptr)
+  float* out = nullptr;
+};
+// true iff launch_ffn_half16 / launch_join_ln_qkv16 serve this shape (M rows, S = n_chunks slices; PPASR_* switches on)
+bool ffn_half16_route(int M, int S, int n_chunks);
+// partial[2 S][M][256] <- the 2 S half-chunk slices of FFN(LN(x_in)), x_in = x or the join `jn` (then jn.out is written)
+void launch_ffn_half16(const float* x, const JoinIn& jn, const float* ln_g, const float* ln_b, const f32x4* w1, const float* b1,
+                       const f32x4* w2, float* partial, int M, int n_chunks, hipStream_t st);
+// qkv (K / V thirds to kc / vc) <- LN_mha(jn) [Wq | Wk | Wv]; jn.out is written
+void launch_join_ln_qkv16(const JoinIn& jn, float* qkv, const LayerW& w, int M, hipStream_t st, float* kc, float* vc);
+// out <- the join alone (the last layer's)
+void launch_join16(const JoinIn& jn, int M, hipStream_t st);
 void launch_ln_qkv(const float* x1, float* qkv, const LayerW& w, int M, hipStream_t st, const PadSkip& ps = PadSkip{},
                    float* kc = nullptr, float* vc = nullptr, bool h3 = false);
 void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int B,

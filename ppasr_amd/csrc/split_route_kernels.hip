@@ -130,17 +130,17 @@ __global__ __launch_bounds__(256) void k_ffn_join(const float* __restrict__ x, c
   if (row >= M) return;
   if (pad_block_skippable(ps, row & ~(kRows - 1), kRows, M)) return;
   const int lane = lane_id();
-  // (the S tiles' loads in flight four at a time, added in slice order: a chain of S dependent L2 round trips otherwise)
+  // (the S tiles' loads in flight eight at a time, added in slice order: a chain of S dependent L2 round trips otherwise)
   const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + 4 * lane);
   f32x4 y = *reinterpret_cast<const f32x4*>(x + (size_t)row * kD + 4 * lane);
   f32x4 acc = *reinterpret_cast<const f32x4*>(partial + (size_t)row * kD + 4 * lane);
   int s = 1;
-  for (; s + 4 <= S; s += 4) {
-    f32x4 p[4];
+  for (; s + 8 <= S; s += 8) {
+    f32x4 p[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p[j] = *reinterpret_cast<const f32x4*>(partial + ((size_t)(s + j) * M + row) * kD + 4 * lane);
+    for (int j = 0; j < 8; ++j) p[j] = *reinterpret_cast<const f32x4*>(partial + ((size_t)(s + j) * M + row) * kD + 4 * lane);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc += p[j];
+    for (int j = 0; j < 8; ++j) acc += p[j];
   }
   for (; s < S; ++s) acc += *reinterpret_cast<const f32x4*>(partial + ((size_t)s * M + row) * kD + 4 * lane);
   if (pre_g) y = ln_row(y, pre_g, pre_b, lane);
@@ -148,6 +148,48 @@ __global__ __launch_bounds__(256) void k_ffn_join(const float* __restrict__ x, c
   for (int e = 0; e < 4; ++e) y[e] = y[e] + scale * (acc[e] + bv[e]);
   if (ln_g) y = ln_row(y, ln_g, ln_b, lane);
   *reinterpret_cast<f32x4*>(out + (size_t)row * kD + 4 * lane) = y;
+}
+
+// rows of a 16-row block <- the pending join `jn` (conformer_kernels.h JoinIn), with the wave -> row mapping of
+// rbt_load_rows / rbt_layernorm (wave w: rows w, w + 8): LDS rows for this workgroup, global rows if `store`
+__device__ __forceinline__ void join_rows16(float* buf, const JoinIn& jn, int M, bool store) {
+  const int lane = lane_id(), wave = wave_id();
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(jn.b2 + 4 * lane);
+  // the tiles were written by workgroups all over the chip (other XCDs' L2s): a load is a ~ 2 us round trip, so both rows'
+  // tiles are requested eight slices at a time (16 loads in flight) and added in slice order (k_ffn_join's sums)
+  f32x4 y[2], acc[2];
+  const float* src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = min(wave + 8 * i, M - 1);  // (rows past M: a clamped address, the result is dropped)
+    y[i] = *reinterpret_cast<const f32x4*>(jn.x + (size_t)row * kD + 4 * lane);
+    src[i] = jn.partial + (size_t)row * kD + 4 * lane;
+    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const size_t tile = (size_t)M * kD;
+  for (int s0 = 0; s0 < jn.S; s0 += 8) {
+    f32x4 p[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        p[i][j] = s0 + j < jn.S ? *reinterpret_cast<const f32x4*>(src[i] + (size_t)(s0 + j) * tile) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (s0 + j < jn.S) acc[i] += p[i][j];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wave + 8 * i;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[i][e] = y[i][e] + jn.scale * (acc[i][e] + bv[e]);
+    if (jn.ln_g) y[i] = ln_row(y[i], jn.ln_g, jn.ln_b, lane);
+    if (row >= M) y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    else if (store) *reinterpret_cast<f32x4*>(jn.out + (size_t)row * kD + 4 * lane) = y[i];
+    *reinterpret_cast<f32x4*>(buf + row * kLda + 4 * lane) = y[i];
+  }
 }
 
 // kc / vc != nullptr (single-session streaming): the K and V thirds go straight to the session's cache rows (row m of
@@ -262,7 +304,7 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_ffn_part_t(const float* __r
 template <int R>
 __global__ __launch_bounds__(RBT<R>::THREADS) void k_ln_qkv_t(const float* __restrict__ x1, float* __restrict__ qkv, LayerW w,
                                                               int M, PadSkip ps, float* __restrict__ kc,
-                                                              float* __restrict__ vc) {
+                                                              float* __restrict__ vc, JoinIn jn) {
   using T = RBT<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int blk = pad_block_of(ps, T::ROWS, M);
@@ -275,7 +317,8 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_ln_qkv_t(const float* __res
   typename T::Ring ring;
   const f32x4* seg = w.wqkv + (size_t)(c * 8 + L.tile()) * kTs256;
   rbt_prime(ring, seg);
-  rbt_load_rows<R>(bufA, x1 + (size_t)r0 * kD, valid);
+  if (R == 16 && jn.partial) join_rows16(bufA, jn, M, c == 0);  // (one row block; x1 = jn.out is written here)
+  else rbt_load_rows<R>(bufA, x1 + (size_t)r0 * kD, valid);
   rbt_layernorm<R>(bufA, bufA, w.ln_mha_g, w.ln_mha_b, 1e-5f);
   __syncthreads();
   typename T::Acc acc;
@@ -298,7 +341,8 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_ln_qkv_t(const float* __res
 __global__ __launch_bounds__(RBT<16>::THREADS) void k_ffn_half16(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                                  const float* __restrict__ ln_b, const f32x4* __restrict__ w1,
                                                                  const float* __restrict__ b1, const f32x4* __restrict__ w2,
-                                                                 float* __restrict__ partial, int M, int n_total, PadSkip ps) {
+                                                                 float* __restrict__ partial, int M, int n_total, PadSkip ps,
+                                                                 JoinIn jn) {
   using T = RBT<16>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int blk = pad_block_of(ps, T::ROWS, M);
@@ -315,7 +359,8 @@ __global__ __launch_bounds__(RBT<16>::THREADS) void k_ffn_half16(const float* __
   typename T::Ring ring1, ring2;
   if (wave < 4) rbt_prime(ring1, seg1);
   rbt_prime(ring2, seg2);
-  rbt_load_rows<16>(bufA, x + (size_t)r0 * kD, valid);
+  if (jn.partial) join_rows16(bufA, jn, M, blockIdx.y == 0);  // (one row block: r0 = 0)
+  else rbt_load_rows<16>(bufA, x + (size_t)r0 * kD, valid);
   if (ln_g) rbt_layernorm<16>(bufA, bufA, ln_g, ln_b, 1e-5f);
   __syncthreads();
   const int row = lane & 15;
@@ -472,7 +517,7 @@ void launch_ffn_split(const float* x, const float* ln_g, const float* ln_b, cons
   else if (split_rows16(M) && !ps.tab && S == n_chunks && ffn_half16_on() && !(getenv("PPASR_STREAM_TICKET") && atoi(getenv("PPASR_STREAM_TICKET")) == 1)) {
     // one chunk per workgroup already: cut the chunks in halves (k_ffn_half16), 2 S partial tiles
     PPASR_LAUNCH(k_ffn_half16, dim3((M + 15) / 16, 2 * S), dim3(kThreads), kLdsFfnPart16, st, x, ln_g, ln_b, w1, b1, w2, partial, M,
-                 n_chunks, ps);
+                 n_chunks, ps, JoinIn{});
     S *= 2;
   } else if (split_rows16(M) && !ps.tab) {
     // (out == x would let the joining workgroup overwrite rows another slice is still reading: two launches then)
@@ -497,9 +542,27 @@ void launch_ln_qkv(const float* x1, float* qkv, const LayerW& w, int M, hipStrea
   if (h3)
     PPASR_LAUNCH(k_ln_qkv<true>, dim3((M + kRows - 1) / kRows, 3), dim3(kThreads), kLdsLnQkv + 512, st, x1, qkv, w, M, ps, kc, vc);
   else if (split_rows16(M) && !ps.tab)
-    PPASR_LAUNCH(k_ln_qkv_t<16>, dim3((M + 15) / 16, 3), dim3(kThreads), kLdsLnQkv16, st, x1, qkv, w, M, ps, kc, vc);
+    PPASR_LAUNCH(k_ln_qkv_t<16>, dim3((M + 15) / 16, 3), dim3(kThreads), kLdsLnQkv16, st, x1, qkv, w, M, ps, kc, vc, JoinIn{});
   else
     PPASR_LAUNCH(k_ln_qkv<false>, dim3((M + kRows - 1) / kRows, 3), dim3(kThreads), kLdsLnQkv, st, x1, qkv, w, M, ps, kc, vc);
+}
+// ---- consumer-side joins of one streaming session's chunk (conformer_kernels.h JoinIn) ----
+bool ffn_half16_route(int M, int S, int n_chunks) {
+  static const bool fuse = !(getenv("PPASR_JOIN_FUSED") && atoi(getenv("PPASR_JOIN_FUSED")) == 0);  // (A/B switch)
+  return fuse && M <= 16 && S > 1 && S == n_chunks && split_rows16(M) && ffn_half16_on() &&
+         !(getenv("PPASR_STREAM_TICKET") && atoi(getenv("PPASR_STREAM_TICKET")) == 1);
+}
+void launch_ffn_half16(const float* x, const JoinIn& jn, const float* ln_g, const float* ln_b, const f32x4* w1, const float* b1,
+                       const f32x4* w2, float* partial, int M, int n_chunks, hipStream_t st) {
+  PPASR_LAUNCH(k_ffn_half16, dim3(1, 2 * n_chunks), dim3(kThreads), kLdsFfnPart16, st, x, ln_g, ln_b, w1, b1, w2, partial, M,
+               n_chunks, PadSkip{}, jn);
+}
+void launch_join_ln_qkv16(const JoinIn& jn, float* qkv, const LayerW& w, int M, hipStream_t st, float* kc, float* vc) {
+  PPASR_LAUNCH(k_ln_qkv_t<16>, dim3(1, 3), dim3(kThreads), kLdsLnQkv16, st, (const float*)jn.out, qkv, w, M, PadSkip{}, kc, vc, jn);
+}
+void launch_join16(const JoinIn& jn, int M, hipStream_t st) {
+  PPASR_LAUNCH(k_ffn_join, dim3((M + 3) / 4), dim3(256), 0, st, jn.x, jn.partial, jn.S, jn.b2, jn.scale, jn.ln_g, jn.ln_b, jn.out, M,
+               PadSkip{}, (const float*)nullptr, (const float*)nullptr);
 }
 unsigned int* split_route_h3_ovf_counter() { return h3_ovf_counter(); }
 hipError_t configure_split_route_kernels() {
