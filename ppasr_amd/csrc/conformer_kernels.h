@@ -223,6 +223,7 @@ struct JoinIn {
   const float *ln_g = nullptr, *ln_b = nullptr;    // LayerNorm behind the residual sum (or nullptr)
   float* out = nullptr;
 };
+int split_rows16_max();  // rows up to which the split route runs its 16-row forms (split_route_kernels.hip)
 // true iff launch_ffn_half16 / launch_join_ln_qkv16 serve this shape (M rows, S = n_chunks slices; PPASR_* switches on)
 bool ffn_half16_route(int M, int S, int n_chunks);
 // partial[2 S][M][256] <- the 2 S half-chunk slices of FFN(LN(x_in)), x_in = x or the join `jn` (then jn.out is written)

@@ -406,8 +406,7 @@ void launch_out_glu(const float* ctx, const float* x1, float* x2, float* g, floa
   // split_xhat), pointwise_conv1 + GLU in a second one with the columns over two workgroups per row block
   float* xh = xhat_out ? xhat_out : split_xhat;
   // up to 16 rows (one streaming chunk): the 16-row forms (conformer_kernels_t.hip) -- half the matrix-pipe time per unit
-  static const bool rows16 = !(getenv("PPASR_SPLIT_ROWS16") && atoi(getenv("PPASR_SPLIT_ROWS16")) == 0);
-  if (split_xhat && !h3 && rows16 && M <= 16 && !ps.tab) {
+  if (split_xhat && !h3 && M <= split_rows16_max() && !ps.tab) {
     const bool move = hm && hm->hist && hm->lo > 0 && hm->lo <= 30;
     launch_out_glu_split_16(ctx, x1, x2, g, xh, w, lens, M, Tp, mask_mul, st, ps, move ? hm->hist : nullptr, move ? hm->lo : 0);
     if (move) hm->done = true;

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_pw1_glu_cols_t(const float*
   // moves on by the chunk's rows -- hist <- last `lo` rows of concat(hist, xhat) (stream_kernels.hip k_hist_update: read all,
   // barrier, write) -- in workgroup y = 0 of this launch instead of a launch of its own (12 per chunk, 4.7 us each)
   f32x4 moved[4];
-  const bool mover = hist != nullptr && y == 0;
+  const bool mover = hist != nullptr && y == 0 && blockIdx.x == 0;  // (any M: every row is read before the barrier)
   if (mover) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -460,15 +460,25 @@ constexpr size_t conv_cols16_lds() { return (size_t)(KS - 1 + 16 + KS + 16) * kL
 //  HIP streams the own-size allocation, 3 workgroups per CU, was 13 % slower per chunk round, same box)
 constexpr size_t kLdsFfnPart16 = kLdsExclusive, kLdsLnQkv16 = kLdsExclusive;
 static_assert(3 * 16 * kLda * sizeof(float) <= kLdsExclusive, "LDS of the 16-row feed-forward slice");
-// (up to 16 rows -- one streaming chunk, single short utterances: the 16-row forms; PPASR_SPLIT_ROWS16=0 switches them off)
+// (up to split_rows16_max() rows -- streaming chunks, single utterances, small batches: the 16-row forms; PPASR_SPLIT_ROWS16=0
+//  switches them off)
 static bool ffn_half16_on() {  // (PPASR_FFN_HALF16=0: whole chunks per workgroup, the A/B knob of the measurement above)
   static const bool on = !(getenv("PPASR_FFN_HALF16") && atoi(getenv("PPASR_FFN_HALF16")) == 0);
   return on;
 }
-static bool split_rows16(int M) {
-  static const bool on = !(getenv("PPASR_SPLIT_ROWS16") && atoi(getenv("PPASR_SPLIT_ROWS16")) == 0);
-  return on && M <= 16;
+// Rows up to which the split route runs its 16-row forms (PPASR_SPLIT_ROWS16_MAX: tuning knob).  512 rows = 32 blocks x 8
+// feed-forward slices = one round of 256 half-as-long workgroups.  Encoder latency of ONE utterance, same box, 16-row forms up
+// to 16 rows (a streaming chunk only) / up to 512: 5 s 1.64 / 1.23 ms, 10 s 1.69 / 1.28 ms, 20 s 1.85 / 1.47 ms
+// (tools/experiments/r06/single_utt.py).
+int split_rows16_max() {
+  static const int m = [] {
+    if (getenv("PPASR_SPLIT_ROWS16") && atoi(getenv("PPASR_SPLIT_ROWS16")) == 0) return 0;
+    const char* e = getenv("PPASR_SPLIT_ROWS16_MAX");
+    return e ? atoi(e) : 512;
+  }();
+  return m;
 }
+static bool split_rows16(int M) { return M <= split_rows16_max(); }
 
 constexpr size_t kLdsConvPre = 4 * kRows * kLda * sizeof(float);  // (the depthwise window uses the three buffers + halo)
 constexpr size_t kLdsFfnPart = 3 * kRows * kLda * sizeof(float);
@@ -478,7 +488,8 @@ void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float
   dim3 grid((M + kRows - 1) / kRows);
   const int left_ctx = causal ? ksize - 1 : (ksize - 1) / 2;
   // one session's chunk of up to 16 frames: the column-split 16-row form
-  if (g_hist && !h3 && !lens && !ps.tab && causal && M == Tp && split_rows16(M) && (ksize == 15 || ksize == 31 || ksize == 7)) {
+  if (g_hist && !h3 && !lens && !ps.tab && causal && M == Tp && M <= 16 && split_rows16(M) &&
+      (ksize == 15 || ksize == 31 || ksize == 7)) {
 #define LAUNCH_CC16(KS)                                                                                               \
   PPASR_LAUNCH(k_conv_pre_cols16<KS>, dim3(1, 2), dim3(kThreads), std::max(conv_cols16_lds<KS>(), kLdsExclusive), st, g, g_hist, \
                x2, x3, w, M)
@@ -514,7 +525,8 @@ void launch_ffn_split(const float* x, const float* ln_g, const float* ln_b, cons
   if (h3)  // (w1 / w2: the re-packed weights)
     PPASR_LAUNCH(k_ffn_part<true>, dim3((M + kRows - 1) / kRows, S), dim3(kThreads), kLdsFfnPart + kH3ExtraLds, st, x, ln_g, ln_b,
                  w1, b1, w2, partial, M, n_chunks, ps);
-  else if (split_rows16(M) && !ps.tab && S == n_chunks && ffn_half16_on() && !(getenv("PPASR_STREAM_TICKET") && atoi(getenv("PPASR_STREAM_TICKET")) == 1)) {
+  else if (split_rows16(M) && !ps.tab && S == n_chunks && ffn_half16_on() && ((M + 15) / 16) * 2 * S <= 256 &&
+           !(getenv("PPASR_STREAM_TICKET") && atoi(getenv("PPASR_STREAM_TICKET")) == 1)) {
     // one chunk per workgroup already: cut the chunks in halves (k_ffn_half16), 2 S partial tiles
     PPASR_LAUNCH(k_ffn_half16, dim3((M + 15) / 16, 2 * S), dim3(kThreads), kLdsFfnPart16, st, x, ln_g, ln_b, w1, b1, w2, partial, M,
                  n_chunks, ps, JoinIn{});
