@@ -388,30 +388,39 @@ __global__ __launch_bounds__(RBT<16>::THREADS) void k_ffn_half16(const float* __
     if (row < valid) *reinterpret_cast<f32x4*>(out + (size_t)(r0 + row) * kD + wave * 32 + 16 * q + 4 * (lane >> 4)) = acc2.s[q];
 }
 
-// ---- the conv module of ONE streaming session's chunk (<= 16 frames) with pointwise_conv2's columns over gridDim.y = 2 ----
-// k_conv_pre<KS, true> runs it on one 32-row workgroup: 18.6 us per block of the encoder (12 % of a chunk), half of it the
-// 32-row unit on one CU.  Here both workgroups stage the window (history rows, then the chunk's), run the depthwise conv +
-// LayerNorm / folded BatchNorm + swish for all 256 channels (wave w: rows 2w, 2w + 1; taps in ascending order like
-// dwconv_phase) and waves 0-3 contract their 128 output columns; the feed-forward slices that follow normalise their input
-// themselves, so the halves need no join.
-template <int KS>
+// ---- the conv module on 16-row blocks with pointwise_conv2's columns over gridDim.y = 2 ----
+// k_conv_pre<KS, ..> runs it on 32-row workgroups: 18.6 us per block of the encoder for one row block, half of it the 32-row
+// unit on one CU.  Here both workgroups of a row block stage the window, run the depthwise conv + LayerNorm / folded BatchNorm
+// + swish for all 256 channels (wave w: rows 2w, 2w + 1; taps in ascending order like dwconv_phase) and waves 0 - 3 contract
+// their 128 output columns; the feed-forward slices that follow normalise their input themselves, so the halves need no join.
+// BATCH = false: ONE streaming session's chunk (M <= 16 rows = the only row block; the window's first KS - 1 rows are the
+// session's g_hist).  BATCH = true: rows of B utterances of Tp frames (single utterances, small batches): taps outside the
+// row's utterance read glu_pad (causal) / 0, padded frames pass the residual through (k_conv_pre's semantics).
+template <int KS, bool BATCH>
 __global__ __launch_bounds__(RBT<16>::THREADS) void k_conv_pre_cols16(const float* __restrict__ g, const float* __restrict__ g_hist,
                                                                       const float* __restrict__ x2, float* __restrict__ x3,
-                                                                      LayerW w, int M) {
+                                                                      LayerW w, const int64_t* __restrict__ lens, int M, int Tp,
+                                                                      int mask_mul, int left) {
   using T = RBT<16>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LO = KS - 1;
-  float* win = smem;                     // [LO + 16][kLda]: g_hist rows, then the chunk's rows (zero past M)
+  float* win = smem;                     // [LO + 16][kLda]: rows r0 - left .. (stream: g_hist rows, then the chunk's)
   float* taps = win + (LO + 16) * kLda;  // [KS][kLda]
   float* bufA = taps + KS * kLda;        // [16][kLda]
   const int lane = lane_id(), wave = wave_id(), y = blockIdx.y;
+  const int r0 = blockIdx.x * 16;
   const f32x4* seg = w.pw2 + (size_t)(4 * y + (wave & 3)) * kTs256;
   typename T::Ring ring;
   if (wave < 4) rbt_prime(ring, seg);
   for (int q = wave; q < LO + 16; q += T::WAVES) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (q < LO) v = *reinterpret_cast<const f32x4*>(g_hist + (size_t)q * kD + 4 * lane);
-    else if (q - LO < M) v = *reinterpret_cast<const f32x4*>(g + (size_t)(q - LO) * kD + 4 * lane);
+    if (BATCH) {
+      const int mq = r0 - left + q;
+      if (mq >= 0 && mq < M) v = *reinterpret_cast<const f32x4*>(g + (size_t)mq * kD + 4 * lane);
+    } else {
+      if (q < LO) v = *reinterpret_cast<const f32x4*>(g_hist + (size_t)q * kD + 4 * lane);
+      else if (q - LO < M) v = *reinterpret_cast<const f32x4*>(g + (size_t)(q - LO) * kD + 4 * lane);
+    }
     *reinterpret_cast<f32x4*>(win + q * kLda + 4 * lane) = v;
   }
   for (int j = wave; j < KS; j += T::WAVES)
@@ -419,15 +428,25 @@ __global__ __launch_bounds__(RBT<16>::THREADS) void k_conv_pre_cols16(const floa
   const f32x4 bias = *reinterpret_cast<const f32x4*>(w.dw_b + 4 * lane);
   const f32x4 gam = *reinterpret_cast<const f32x4*>(w.ln_cm_g + 4 * lane);
   const f32x4 bet = *reinterpret_cast<const f32x4*>(w.ln_cm_b + 4 * lane);
+  f32x4 gp = {0.f, 0.f, 0.f, 0.f};
+  if (BATCH && left == LO) gp = *reinterpret_cast<const f32x4*>(w.glu_pad + 4 * lane);
   __syncthreads();
   f32x4 out[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = 2 * wave + i;
+    const int m = r0 + row;
+    const int t = BATCH ? m - (m / Tp) * Tp : 0;
     f32x4 acc = bias;
 #pragma unroll
-    for (int j = 0; j < KS; ++j)
-      acc += *reinterpret_cast<const f32x4*>(taps + j * kLda + 4 * lane) * *reinterpret_cast<const f32x4*>(win + (row + j) * kLda + 4 * lane);
+    for (int j = 0; j < KS; ++j) {
+      f32x4 xv = *reinterpret_cast<const f32x4*>(win + (row + j) * kLda + 4 * lane);
+      if (BATCH) {
+        const int tt = t - left + j;  // frame this tap reads inside the row's utterance
+        if (!(tt >= 0 && tt < Tp)) xv = gp;
+      }
+      acc += *reinterpret_cast<const f32x4*>(taps + j * kLda + 4 * lane) * xv;
+    }
     out[i] = acc;
   }
   ln_rows_inreg<true, 2>(out, gam, bet, w.cm_eps);
@@ -439,17 +458,18 @@ __global__ __launch_bounds__(RBT<16>::THREADS) void k_conv_pre_cols16(const floa
   T::zero(acc);
   rbt_gemm<kG256>(bufA, kLda, seg, nullptr, ring, acc);
   const int row = lane & 15;
-  if (row >= M) return;
+  if (r0 + row >= M) return;
+  const bool pad = BATCH && PadRows{lens, r0, Tp, M, mask_mul}(row);
 #pragma unroll
   for (int q = 0; q < T::NQ; ++q) {
     const int col = 128 * y + 32 * wave + 16 * q + 4 * (lane >> 4);
     const f32x4 bv = *reinterpret_cast<const f32x4*>(w.pw2_b + col);
-    const f32x4 r = *reinterpret_cast<const f32x4*>(x2 + (size_t)row * kD + col);
+    const f32x4 r = *reinterpret_cast<const f32x4*>(x2 + (size_t)(r0 + row) * kD + col);
     const f32x4 a = acc.s[q];
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = r[e] + (a[e] + bv[e]);
-    *reinterpret_cast<f32x4*>(x3 + (size_t)row * kD + col) = o;
+    for (int e = 0; e < 4; ++e) o[e] = r[e] + (pad ? 0.f : a[e] + bv[e]);
+    *reinterpret_cast<f32x4*>(x3 + (size_t)(r0 + row) * kD + col) = o;
   }
 }
 template <int KS>
@@ -487,12 +507,18 @@ void launch_conv_pre(const float* g, const float* g_hist, const float* x2, float
                      int M, int Tp, int ksize, int mask_mul, hipStream_t st, bool causal, const PadSkip& ps, bool h3) {
   dim3 grid((M + kRows - 1) / kRows);
   const int left_ctx = causal ? ksize - 1 : (ksize - 1) / 2;
-  // one session's chunk of up to 16 frames: the column-split 16-row form
-  if (g_hist && !h3 && !lens && !ps.tab && causal && M == Tp && M <= 16 && split_rows16(M) &&
-      (ksize == 15 || ksize == 31 || ksize == 7)) {
-#define LAUNCH_CC16(KS)                                                                                               \
-  PPASR_LAUNCH(k_conv_pre_cols16<KS>, dim3(1, 2), dim3(kThreads), std::max(conv_cols16_lds<KS>(), kLdsExclusive), st, g, g_hist, \
-               x2, x3, w, M)
+  // one session's chunk of up to 16 frames, or batched rows (single utterances, small batches): the column-split 16-row form
+  const bool one_chunk = g_hist && !lens && causal && M == Tp && M <= 16;
+  if ((one_chunk || !g_hist) && !h3 && !ps.tab && split_rows16(M) && (ksize == 15 || ksize == 31 || ksize == 7)) {
+#define LAUNCH_CC16(KS)                                                                                                  \
+  do {                                                                                                                   \
+    if (g_hist)                                                                                                          \
+      PPASR_LAUNCH((k_conv_pre_cols16<KS, false>), dim3(1, 2), dim3(kThreads), std::max(conv_cols16_lds<KS>(), kLdsExclusive), st, \
+                   g, g_hist, x2, x3, w, lens, M, Tp, mask_mul, left_ctx);                                               \
+    else                                                                                                                 \
+      PPASR_LAUNCH((k_conv_pre_cols16<KS, true>), dim3((M + 15) / 16, 2), dim3(kThreads),                                \
+                   std::max(conv_cols16_lds<KS>(), kLdsExclusive), st, g, g_hist, x2, x3, w, lens, M, Tp, mask_mul, left_ctx); \
+  } while (0)
     if (ksize == 15) LAUNCH_CC16(15);
     else if (ksize == 31) LAUNCH_CC16(31);
     else LAUNCH_CC16(7);
@@ -595,9 +621,12 @@ hipError_t configure_split_route_kernels() {
   SET_LDS(k_ffn_part<false>, kLdsFfnPart);
   SET_LDS(k_ffn_part_t<16>, kLdsFfnPart16);
   SET_LDS(k_ffn_half16, kLdsFfnPart16);
-  SET_LDS(k_conv_pre_cols16<15>, std::max(conv_cols16_lds<15>(), kLdsExclusive));
-  SET_LDS(k_conv_pre_cols16<31>, std::max(conv_cols16_lds<31>(), kLdsExclusive));
-  SET_LDS(k_conv_pre_cols16<7>, std::max(conv_cols16_lds<7>(), kLdsExclusive));
+  SET_LDS((k_conv_pre_cols16<15, false>), std::max(conv_cols16_lds<15>(), kLdsExclusive));
+  SET_LDS((k_conv_pre_cols16<15, true>), std::max(conv_cols16_lds<15>(), kLdsExclusive));
+  SET_LDS((k_conv_pre_cols16<31, false>), std::max(conv_cols16_lds<31>(), kLdsExclusive));
+  SET_LDS((k_conv_pre_cols16<31, true>), std::max(conv_cols16_lds<31>(), kLdsExclusive));
+  SET_LDS((k_conv_pre_cols16<7, false>), std::max(conv_cols16_lds<7>(), kLdsExclusive));
+  SET_LDS((k_conv_pre_cols16<7, true>), std::max(conv_cols16_lds<7>(), kLdsExclusive));
   SET_LDS(k_ln_qkv_t<16>, kLdsLnQkv16);
   SET_LDS(k_ffn_part<true>, kLdsFfnPart + kH3ExtraLds);
   SET_LDS(k_ln_qkv<true>, kLdsLnQkv + 512);
