@@ -456,6 +456,14 @@ WsLayout ws_layout(const ppasr_model_s* m, int B, int T) {
   w.total = o;
   return w;
 }
+// slices of a launch with `units` independent pieces per row block (K chunks of the input projection, vocabulary tile
+// groups of the CTC head) on the split route: as many as fill the chip once, at least the feed-forward split
+int wide_slices_for(const ppasr_model_s* m, int M, int units) {
+  const int S = ffn_split_for(m, M);
+  if (S <= 1) return S;
+  const int blocks = (M + kRows - 1) / kRows;
+  return std::max(S, std::min(units, 256 / blocks));
+}
 int ffn_split_for(const ppasr_model_s* m, int M) {
   if (m->desc.model_type == PPASR_MODEL_DEEPSPEECH2) return 1;
   const int n_chunks = m->desc.linear_units / 256;
@@ -841,7 +849,7 @@ static ppasr_status encode_impl(ppasr_handle h, const float* feats, const int64_
       else launch_conv2(y1, h->front, y2, B, T1, F1, Tp, F2, st, ps_front, tile_tab, h->desc.input_layer == 0 ? conv2_h3 : nullptr);
     });
     timed(2, [&] {
-      launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st, ps_front, ffn_split_for(h, M), y1,
+      launch_embed(y2, h->front, xa, M, F2 * kD, sqrtf((float)kD), false, st, ps_front, wide_slices_for(h, M, F2), y1,
                    conv2_h3 ? h->embed_w_h3 : nullptr);
     });
   }
@@ -993,7 +1001,8 @@ static ppasr_status encode_impl(ppasr_handle h, const float* feats, const int64_
     const bool head_h3 = h->gemm_mode == PPASR_GEMM_F16X3 && h->head_w_h3;
     HeadW hw = h->head;
     if (head_h3) hw.w = h->head_w_h3;
-    launch_ctc_head(xa, hw, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, Mo, st, pskip(Ti, mul), ffn_split_for(h, Mo), y1, head_h3);
+    launch_ctc_head(xa, hw, lg, fa, fp, ws + wl.rmax, ws + wl.rsum, Mo, st, pskip(Ti, mul),
+                    wide_slices_for(h, Mo, std::min((hw.n_tiles + 7) / 8, 32)), y1, head_h3);
   });
   if (probs) {
     if (logits)

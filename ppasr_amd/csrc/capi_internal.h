@@ -231,6 +231,7 @@ struct WsLayout {
 WsLayout ws_layout(const ppasr_model_s* m, int B, int T);
 // hidden-dimension slices per row block for M rows (1 = the fused kernels), see ppasr_set_ffn_split
 int ffn_split_for(const ppasr_model_s* m, int M);
+int wide_slices_for(const ppasr_model_s* m, int M, int units);  // embed K chunks / head tile groups on the split route
 // rows per workgroup (32 or 16) for a row-block launch over B utterances of Tcur rows each: 16 when the rows that will
 // actually be computed fill at most half of the chip as 32-row blocks.  With skip_padding the computed rows are
 // sum_b min(Tcur, ceil(len_b / mul) + slack) -- known on the host only through ppasr_set_lengths_hint; without a hint the

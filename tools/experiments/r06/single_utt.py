@@ -11,7 +11,7 @@ conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12
 sd = conformer_state_dict(vocab_size=V, num_blocks=12, seed=1234)
 model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
 out = {"tag": os.environ.get("TAG", "")}
-for T in (500, 1000, 2000):
+for T in [int(v) for v in os.environ.get("TS", "500,1000,2000").split(",")]:
     x, la = synth_features(1, T, seed=5)
     xd = torch.from_numpy(x).cuda()
     lad = torch.as_tensor(la).cuda()
