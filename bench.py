@@ -723,6 +723,9 @@ def build_roofline(w, args, ms_per_step):
                     n_fr = sum((ln + 7) // 8 for ln in w.utt_frames)
                 per_frame = w.V * 4 if c.startswith("k_ctc_prune") else (2 + 2 * 40) * 4
                 work[c] = (n_fr * per_frame, "bytes", "hbm")
+            if c.startswith("k_softmax_row_wg"):  # logits in, probabilities out: one read and one write of every valid row
+                n_fr = sum((ln + 7) // 8 if w.family == "efficient_conformer" else (ln + 3) // 4 for ln in w.utt_frames)
+                work[c] = (n_fr * w.V * 4 * 2, "bytes", "hbm")
     # --gemm f16x3: the mode's kernels keep classes of their own ("<fp32 class>/f16x3") with the fp32 class's algorithmic
     # FLOPs (fp32-equivalent) over the mode's own peak
     for c in list(classes):
