@@ -217,73 +217,68 @@ void launch_ctc_head(const float* x, const HeadW& hw, float* logits, int32_t* fr
                        M, ps);
 }
 
-// probs = softmax(logits) recomputed exactly (max, then exp(x-max)/sum) in place; one wave per row.
-__global__ __launch_bounds__(256) void k_softmax_rows(float* __restrict__ p, int M, int V, PadSkip ps) {
-  const int row = blockIdx.x * 4 + wave_id();
-  if (row >= M) return;
-  // ragged batch: the CTC head skipped whole 32-row blocks; the same blocks keep their cleared (all-zero) rows here
-  if (pad_block_skippable(ps, row & ~(kRows - 1), kRows, M)) return;
-  const int lane = lane_id();
-  float* x = p + (size_t)row * V;
-  float m = -INFINITY;
-  for (int c = lane; c < V; c += 64) m = fmaxf(m, x[c]);
-  m = wave_max(m);
-  float s = 0.f;
-  for (int c = lane; c < V; c += 64) {
-    float e = expf(x[c] - m);
-    x[c] = e;
-    s += e;
-  }
-  s = wave_sum(s);
-  for (int c = lane; c < V; c += 64) x[c] = x[c] / s;
-}
-// The same (max, then exp(x - max) / sum: exact, not the head's running statistics) with ONE workgroup per row and the row in
-// registers: one read and one write of the row instead of three reads and two writes, 256 lanes on a row instead of 64
-// (a 10 s utterance: 33 -> 8 us; 15 936 rows of cfg4: 96 -> 60 us).  NV = values per thread (V <= 256 NV).
+// probs = softmax(logits) recomputed exactly (max, then exp(x - max) / sum -- not the head's running statistics) in place.
+// ONE workgroup per row with the row in registers: one read and one write of the row, 256 lanes on it (the one-wave-per-row
+// kernel this replaces read it three times: a 10 s utterance 33 -> 8 us, 15 936 rows of cfg4 96 -> 60 us).  NV = values per
+// thread (V <= 256 NV); NV = 0: any V, the row re-read from memory in each pass.
 template <int NV>
 __global__ __launch_bounds__(256) void k_softmax_row_wg(float* __restrict__ p, int M, int V, PadSkip ps) {
   const int row = blockIdx.x;
+  // ragged batch: the CTC head skipped whole 32-row blocks; the same blocks keep their cleared (all-zero) rows here
   if (pad_block_skippable(ps, row & ~(kRows - 1), kRows, M)) return;
   __shared__ float red[8];
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   float* x = p + (size_t)row * V;
-  float v[NV];
+  constexpr int NR = NV > 0 ? NV : 1;
+  float v[NR];
   float m = -INFINITY;
+  if (NV > 0) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = tid + 256 * i;
-    v[i] = c < V ? x[c] : -INFINITY;
-    m = fmaxf(m, v[i]);
+    for (int i = 0; i < NR; ++i) {
+      const int c = tid + 256 * i;
+      v[i] = c < V ? x[c] : -INFINITY;
+      m = fmaxf(m, v[i]);
+    }
+  } else {
+    for (int c = tid; c < V; c += 256) m = fmaxf(m, x[c]);
   }
   m = wave_max(m);
   if (lane == 0) red[wave] = m;
   __syncthreads();
   m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float s = 0.f;
+  if (NV > 0) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    v[i] = expf(v[i] - m);  // (columns past V: exp(-inf) = 0)
-    s += v[i];
+    for (int i = 0; i < NR; ++i) {
+      v[i] = expf(v[i] - m);  // (columns past V: exp(-inf) = 0)
+      s += v[i];
+    }
+  } else {
+    for (int c = tid; c < V; c += 256) {
+      const float e = expf(x[c] - m);
+      x[c] = e;
+      s += e;
+    }
   }
   s = wave_sum(s);
   if (lane == 0) red[4 + wave] = s;
   __syncthreads();
   s = (red[4] + red[5]) + (red[6] + red[7]);
+  if (NV > 0) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = tid + 256 * i;
-    if (c < V) x[c] = v[i] / s;
+    for (int i = 0; i < NR; ++i) {
+      const int c = tid + 256 * i;
+      if (c < V) x[c] = v[i] / s;
+    }
+  } else {
+    for (int c = tid; c < V; c += 256) x[c] = x[c] / s;
   }
 }
 void launch_softmax_from_stats(float* probs_inout, const float*, const float*, int M, int V, hipStream_t st,
                                const PadSkip& ps) {
-  static const bool wg_rows = !(getenv("PPASR_SOFTMAX_WG") && atoi(getenv("PPASR_SOFTMAX_WG")) == 0);  // (A/B switch)
-  if (wg_rows && V <= 256 * 8)
-    PPASR_LAUNCH(k_softmax_row_wg<8>, dim3(M), dim3(256), 0, st, probs_inout, M, V, ps);
-  else if (wg_rows && V <= 256 * 20)
-    PPASR_LAUNCH(k_softmax_row_wg<20>, dim3(M), dim3(256), 0, st, probs_inout, M, V, ps);
-  else
-    PPASR_LAUNCH(k_softmax_rows, dim3((M + 3) / 4), dim3(256), 0, st, probs_inout, M, V, ps);
+  if (V <= 256 * 8) PPASR_LAUNCH(k_softmax_row_wg<8>, dim3(M), dim3(256), 0, st, probs_inout, M, V, ps);
+  else if (V <= 256 * 20) PPASR_LAUNCH(k_softmax_row_wg<20>, dim3(M), dim3(256), 0, st, probs_inout, M, V, ps);
+  else PPASR_LAUNCH(k_softmax_row_wg<0>, dim3(M), dim3(256), 0, st, probs_inout, M, V, ps);
 }
 
 __global__ __launch_bounds__(256) void k_zero_pad_rows(float* __restrict__ probs, float* __restrict__ logits,

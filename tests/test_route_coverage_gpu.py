@@ -132,3 +132,21 @@ def test_gru_single_utterance_step_kernel():
         assert out_lens.cpu().tolist() == rl.tolist()
         assert _rel(probs.cpu().numpy(), rp.numpy()) < 1e-3
         assert _rel(fh.cpu().numpy(), rh.numpy()) < 1e-3
+
+
+def test_probabilities_of_a_vocabulary_beyond_5120_characters():
+    """The softmax of the probability rows keeps a row in registers up to 5 120 columns (k_softmax_row_wg<8 / 20>); larger
+    vocabularies take the form that re-reads the row (k_softmax_row_wg<0>): a one-block Conformer with 5 500 characters
+    against the oracle, rows summing to one."""
+    from oracle.conformer_oracle import ConformerOracle
+    from ppasr_amd.model_utils.conformer.model import ConformerModel
+    V, L = 5500, 1
+    sd = conformer_state_dict(vocab_size=V, num_blocks=L, seed=77)
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=L, cnn_module_kernel=15)
+    model = ConformerModel(80, V, streaming=True, encoder_conf=conf, state_dict=sd, device="cuda:0")
+    x, lens = synth_features(2, 131, lens=[131, 90], seed=78)
+    got = model.get_encoder_out(x, lens).cpu().numpy()
+    want = ConformerOracle(sd, num_blocks=L).get_encoder_out(x, lens).numpy()
+    assert got.shape == want.shape
+    assert _rel(got, want) < 1e-3
+    assert np.abs(got.sum(-1) - 1.0).max() < 1e-5
