@@ -30,7 +30,9 @@ for seed in range(6):
             torch.cuda.synchronize()
             err = float((probs[i] - ref[0]).abs().max() / ref[0].abs().max())
             n += 1
-            if err > 1e-5 or group.offset(s) != singles[s].offset:
+            # (3e-5: since round 6 the single-session route runs 16-row units and wider K splits than the group route --
+            #  another order of the fp32 sums, tests/test_streaming_gpu.py::test_session_group_equals_independent_streams)
+            if err > 3e-5 or group.offset(s) != singles[s].offset:
                 bad += 1
                 print("MISMATCH", seed, rnd, s, T, err, group.offset(s), singles[s].offset)
     del group
