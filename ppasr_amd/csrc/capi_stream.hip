@@ -83,6 +83,16 @@ ppasr_status finish_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* shift_tm
   const int keep = p.T2 - p.ncs;
   const int from_r = p.ncs / 2;
   const int keep_r = std::max(p.T2_r - from_r, 0);
+  if (h->desc.num_blocks <= 64 && s->D % 4 == 0 && s->D <= 1024) {  // one launch for every layer's K and V cache
+    unsigned long long half_mask = 0;
+    for (int i = 0; i < h->desc.num_blocks; ++i)
+      if (layer_factor(h, i) == 2) half_mask |= 1ull << i;
+    if ((p.ncs > 0 && keep > 0) || (half_mask && from_r > 0 && keep_r > 0))
+      launch_shift_caches(s->kc, s->vc, (long long)s->cap * s->D, s->D, h->desc.num_blocks, p.ncs, keep, from_r, keep_r, half_mask, st);
+    s->cache_t = keep;
+    s->cache_r = keep_r;
+    return PPASR_OK;
+  }
   for (int i = 0; i < h->desc.num_blocks; ++i) {
     float* bufs[2] = {s->kc + (size_t)i * s->cap * s->D, s->vc + (size_t)i * s->cap * s->D};
     const bool half = layer_factor(h, i) == 2;
@@ -195,6 +205,16 @@ ppasr_status squeezeformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* x
   float* x = xa;
   float* other = xb;
   bool reduced = false, have_qkv = false;
+  // Round 6: on the split route (fp32) the layer's single-unit launches run on the Conformer's 16-row kernels through weight
+  // views -- Q / K / V thirds (no LayerNorm: ln_mha_g = nullptr; K and V straight into the cache rows), out-projection +
+  // LayerNorm, pointwise_conv1 + GLU over two column halves (which also moves the SCALED conv-input history on)
+  bool kv_in_cache = false;  // this layer's K / V rows were written to its cache by the launch that made its qkv
+  auto qkv_view = [](const SqLayerW& w) {
+    LayerW v{};
+    v.wqkv = w.wqkv;
+    v.bqkv = w.bqkv;
+    return v;
+  };
   for (int i = 0; i < L; ++i) {
     const SqLayerW& W = h->sq_layers[i];
     if (i == h->desc.reduce_idx) {
@@ -216,32 +236,62 @@ ppasr_status squeezeformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* x
     float* kc = s->kc + (size_t)i * s->cap * kD;
     float* vc = s->vc + (size_t)i * s->cap * kD;
     float* xh = s->xh_hist + (size_t)i * s->lo * kD;
-    if (!have_qkv) launch_sq_qkv(x, qkv, W.wqkv, W.bqkv, Ti, st);
-    launch_kv_append(qkv, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD, Ti, st);
+    const int S = ffn_split_for(h, Ti);  // one row block: split route (see squeezeformer_encode)
+    const bool h3s = S > 1 && h->gemm_mode == PPASR_GEMM_F16X3 && !h->sq_layers_h3.empty();  // (the FFN slices in the mode)
+    const bool r16 = S > 1 && !h3s && Ti <= split_rows16_max();
+    if (!have_qkv) {
+      if (r16) {
+        launch_ln_qkv(x, qkv, qkv_view(W), Ti, st, PadSkip{}, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD, false);
+        kv_in_cache = true;
+      } else {
+        launch_sq_qkv(x, qkv, W.wqkv, W.bqkv, Ti, st);
+      }
+    }
+    if (!kv_in_cache) launch_kv_append(qkv, kc + (size_t)n_cache * kD, vc + (size_t)n_cache * kD, Ti, st);
+    kv_in_cache = false;
     AttnArgs a{qkv, 768, kc, kD, vc, kD, Ti, n_cache + Ti, p.pos0, nullptr, ctx, W.pos_u, W.pos_v, W.ptab, reduced ? 2 : 1,
                mul, Ti, n_cache + Ti, 1};
     launch_attention(a, 1, H, st);
     float* gh = s->g_hist + (size_t)i * s->lo * kD;
     const bool fuse_next = (i + 1 < L) && (i + 1 != h->desc.reduce_idx) && !(i + 1 == h->desc.recover_idx && reduced);
     const SqLayerW* Wn = fuse_next ? &h->sq_layers[i + 1] : nullptr;
-    const int S = ffn_split_for(h, Ti);  // one row block: split route (see squeezeformer_encode)
+    bool hist_moved = false;
     if (S > 1) {
-      const bool h3s = h->gemm_mode == PPASR_GEMM_F16X3 && !h->sq_layers_h3.empty();  // (the FFN slices in the mode)
       const SqLayerW& Ws = h3s ? h->sq_layers_h3[i] : W;
-      launch_sq_oproj(ctx, x, other, W, Ti, st);
+      if (r16) {  // x1 = LN1(x + ctx Wo + bo) (the plain sum goes to g, dead until pointwise_conv1 writes it)
+        LayerW vo{};
+        vo.wo = W.wo; vo.bo = W.bo; vo.ln_conv_g = W.ln1_g; vo.ln_conv_b = W.ln1_b;
+        launch_oproj_ln_16(ctx, x, g, other, vo, Ti, st);
+      } else {
+        launch_sq_oproj(ctx, x, other, W, Ti, st);
+      }
       launch_ffn_split(other, nullptr, nullptr, Ws.ff1_w1, W.ff1_b1, Ws.ff1_w2, W.ff1_b2, 1.0f, W.ln2_g, W.ln2_b, partial, xc,
                        Ti, n_chunks, S, st, PadSkip{}, false, h3s, s->ticket);
-      launch_sq_pw1glu(xc, g, xhat, W, nullptr, Ti, Ti, mul, st);
+      if (r16 && KS - 1 <= 30) {
+        LayerW vp{};
+        vp.pw1 = W.pw1; vp.pw1_b = W.pw1_b;
+        launch_pw1_glu_cols_16(xc, g, vp, Ti, st, xh, KS - 1, W.cm_scale, W.cm_bias);
+        hist_moved = true;
+      } else {
+        launch_sq_pw1glu(xc, g, xhat, W, nullptr, Ti, Ti, mul, st);
+      }
       launch_conv_pre(g, gh, xc, ctx, sq_conv_view(W), nullptr, Ti, Ti, KS, mul, st);
       launch_ffn_split(ctx, W.ln3_g, W.ln3_b, Ws.ff2_w1, W.ff2_b1, Ws.ff2_w2, W.ff2_b2, 1.0f, W.ln4_g, W.ln4_b, partial, other,
                        Ti, n_chunks, S, st, PadSkip{}, /*residual_is_normed=*/true, h3s, s->ticket);
-      if (Wn) launch_sq_qkv(other, qkv, Wn->wqkv, Wn->bqkv, Ti, st);
+      if (Wn && r16) {  // (fuse_next: layer i + 1 runs at this layer's rate -- same rows, same cache length)
+        float* kcn = s->kc + (size_t)(i + 1) * s->cap * kD;
+        float* vcn = s->vc + (size_t)(i + 1) * s->cap * kD;
+        launch_ln_qkv(other, qkv, qkv_view(*Wn), Ti, st, PadSkip{}, kcn + (size_t)n_cache * kD, vcn + (size_t)n_cache * kD, false);
+        kv_in_cache = true;
+      } else if (Wn) {
+        launch_sq_qkv(other, qkv, Wn->wqkv, Wn->bqkv, Ti, st);
+      }
     } else {
       launch_sq_mid(ctx, x, xc, g, xhat, W, nullptr, Ti, Ti, mul, n_chunks, st);
       launch_sq_tail(g, gh, xc, other, qkv, W, Wn ? Wn->wqkv : nullptr, Wn ? Wn->bqkv : nullptr, nullptr, Ti, Ti, mul,
                      n_chunks, KS, st);
     }
-    launch_hist_update(xh, xhat, Ti, KS - 1, st);
+    if (!hist_moved) launch_hist_update(xh, xhat, Ti, KS - 1, st);
     std::swap(x, other);
     have_qkv = fuse_next;
   }

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_out_glu_t(const float* __re
 template <int R>
 __global__ __launch_bounds__(RBT<R>::THREADS) void k_pw1_glu_cols_t(const float* __restrict__ xhat, float* __restrict__ g,
                                                                     LayerW w, int M, PadSkip ps, float* __restrict__ hist,
-                                                                    int lo) {
+                                                                    int lo, const float* __restrict__ hist_scale,
+                                                                    const float* __restrict__ hist_bias) {
   using T = RBT<R>;
   static_assert(R == 16, "the quad view below is the 16-row form's");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -172,8 +173,13 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_pw1_glu_cols_t(const float*
       const int idx = (int)threadIdx.x + T::THREADS * i;
       if (idx < lo * 64) {
         const int j = M + (idx >> 6), c4 = idx & 63;  // row of concat(hist, xhat)
-        moved[i] = j < lo ? *reinterpret_cast<const f32x4*>(hist + (size_t)j * kD + 4 * c4)
-                          : *reinterpret_cast<const f32x4*>(xhat + (size_t)(j - lo) * kD + 4 * c4);
+        if (j < lo) {
+          moved[i] = *reinterpret_cast<const f32x4*>(hist + (size_t)j * kD + 4 * c4);
+        } else {  // (hist_scale: Squeezeformer keeps ada_scale * x + ada_bias, its pointwise_conv1 here has the scale folded in)
+          moved[i] = *reinterpret_cast<const f32x4*>(xhat + (size_t)(j - lo) * kD + 4 * c4);
+          if (hist_scale)
+            moved[i] = *reinterpret_cast<const f32x4*>(hist_scale + 4 * c4) * moved[i] + *reinterpret_cast<const f32x4*>(hist_bias + 4 * c4);
+        }
       }
     }
   }
@@ -301,7 +307,20 @@ void launch_out_glu_split_16(const float* ctx, const float* x1, float* x2, float
   PPASR_LAUNCH(k_out_glu_t<16>, dim3((M + 15) / 16), dim3(kThreads), excl(kLds16x2), st, ctx, x1, x2, g, w, lens, M, Tp,
                mask_mul, ps, xhat, 1);
   PPASR_LAUNCH(k_pw1_glu_cols_t<16>, dim3((M + 15) / 16, 2), dim3(kThreads), excl((16 * kLda + 16 * 132) * sizeof(float)), st,
-               xhat, g, w, M, ps, hist, lo);
+               xhat, g, w, M, ps, hist, lo, (const float*)nullptr, (const float*)nullptr);
+}
+// the two launches on their own, for layers that are not the Conformer's (Squeezeformer's chunk: weight views):
+// xhat_out = LN(x1 + ctx Wo + bo) with w.wo / bo / ln_conv_g / ln_conv_b (the plain sum goes to x2_sink)
+void launch_oproj_ln_16(const float* ctx, const float* x1, float* x2_sink, float* xhat_out, const LayerW& w, int M,
+                        hipStream_t st) {
+  PPASR_LAUNCH(k_out_glu_t<16>, dim3((M + 15) / 16), dim3(kThreads), excl(kLds16x2), st, ctx, x1, x2_sink, (float*)nullptr, w,
+               (const int64_t*)nullptr, M, M, 1, PadSkip{}, xhat_out, 1);
+}
+// g = GLU(pointwise_conv1(x)) with w.pw1 / pw1_b; hist (M <= 16, one session): moves on by scale * x + bias
+void launch_pw1_glu_cols_16(const float* x, float* g, const LayerW& w, int M, hipStream_t st, float* hist, int lo,
+                            const float* hist_scale, const float* hist_bias) {
+  PPASR_LAUNCH(k_pw1_glu_cols_t<16>, dim3((M + 15) / 16, 2), dim3(kThreads), excl((16 * kLda + 16 * 132) * sizeof(float)), st, x,
+               g, w, M, PadSkip{}, hist, lo, hist_scale, hist_bias);
 }
 bool conv_ffn_16_supported(int ksize, int Tp) { return (ksize == 7 || ksize == 15 || ksize == 31) && Tp >= 2; }
 void launch_conv_ffn_16(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int M, int Tp,

@@ -319,7 +319,8 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_ln_qkv_t(const float* __res
   rbt_prime(ring, seg);
   if (R == 16 && jn.partial) join_rows16(bufA, jn, M, c == 0);  // (one row block; x1 = jn.out is written here)
   else rbt_load_rows<R>(bufA, x1 + (size_t)r0 * kD, valid);
-  rbt_layernorm<R>(bufA, bufA, w.ln_mha_g, w.ln_mha_b, 1e-5f);
+  // (w.ln_mha_g == nullptr: the rows are used as they are -- Squeezeformer's projection, whose scale is folded into wqkv)
+  if (w.ln_mha_g) rbt_layernorm<R>(bufA, bufA, w.ln_mha_g, w.ln_mha_b, 1e-5f);
   __syncthreads();
   typename T::Acc acc;
   T::zero(acc);

@@ -115,6 +115,40 @@ __global__ __launch_bounds__(256) void k_hist_update(float* __restrict__ hist, c
     if (idx < total) *reinterpret_cast<f32x4*>(hist + (size_t)(idx >> 6) * kD + 4 * (idx & 63)) = tmp[i];
   }
 }
+// Attention caches of ALL layers trimmed in one launch (required_cache_size > 0: every chunk drops its oldest frames): rows
+// [from, from + keep) of every layer's K and V cache [cap][D] move to its start.  Workgroup (layer, K | V) walks its rows in
+// blocks of 16 -- read a block, barrier, write it: the destination lies below the source, so a later block's source is never
+// a block already written.  (Two device-to-device copies through a scratch per cache: 48 launches of ~3.3 us per chunk.)
+__global__ __launch_bounds__(256) void k_shift_caches(float* __restrict__ kc, float* __restrict__ vc, long long layer_stride, int D,
+                                                      int from_full, int keep_full, int from_half, int keep_half,
+                                                      unsigned long long half_mask) {
+  const int layer = blockIdx.x;
+  float* buf = (blockIdx.y == 0 ? kc : vc) + (size_t)layer * layer_stride;
+  const bool half = (half_mask >> layer) & 1ull;
+  const int from = half ? from_half : from_full, keep = half ? keep_half : keep_full;
+  if (keep <= 0 || from <= 0) return;
+  const int d4 = D / 4, per_blk = 16 * d4;  // f32x4 elements of a 16-row block (<= 16 per thread up to D = 1024)
+  for (int r0 = 0; r0 < keep; r0 += 16) {
+    const int n = min(16, keep - r0) * d4;
+    f32x4 tmp[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = (int)threadIdx.x + 256 * i;
+      if (idx < n && idx < per_blk) tmp[i] = *reinterpret_cast<const f32x4*>(buf + (size_t)(from + r0) * D + 4 * (size_t)idx);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = (int)threadIdx.x + 256 * i;
+      if (idx < n && idx < per_blk) *reinterpret_cast<f32x4*>(buf + (size_t)r0 * D + 4 * (size_t)idx) = tmp[i];
+    }
+  }
+}
+void launch_shift_caches(float* kc, float* vc, long long layer_stride, int D, int n_layers, int from_full, int keep_full,
+                         int from_half, int keep_half, unsigned long long half_mask, hipStream_t st) {
+  PPASR_LAUNCH(k_shift_caches, dim3(n_layers, 2), dim3(256), 0, st, kc, vc, layer_stride, D, from_full, keep_full, from_half,
+               keep_half, half_mask);
+}
 void launch_hist_update(float* hist, const float* fresh, int n, int lo, hipStream_t st) {
   PPASR_LAUNCH(k_hist_update, dim3(1), dim3(256), 0, st, hist, fresh, n, lo);
 }
