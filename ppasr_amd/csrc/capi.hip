@@ -960,8 +960,16 @@ static ppasr_status encode_impl(ppasr_handle h, const float* feats, const int64_
     if (eff && i == h->desc.stride_layer_idx) {
       const int Ts = (Ti + 1) / 2;
       timed(6, [&] {
-        launch_conv_ffn_stride(g, nullptr, xc, xa, (h3 || h3s) ? Lk : L, lens, B, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st,
-                               pskip(Ts, mul * 2), h->desc.causal != 0, h3 || h3s);
+        const int Ss = r16 ? 1 : ffn_split_for(h, B * Ts);
+        if (Ss > 1) {  // under-filled: the conv half alone (x3 -> ctx), the feed-forward module over the slices
+          launch_conv_ffn_stride(g, nullptr, xc, xa, h3s ? Lk : L, lens, B, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st,
+                                 pskip(Ts, mul * 2), h->desc.causal != 0, h3s, ctx);
+          launch_ffn_split(ctx, L.ln_ff_g, L.ln_ff_b, Lk.ff_w1, L.ff_b1, Lk.ff_w2, L.ff_b2, 0.5f, L.ln_fin_g, L.ln_fin_b, partial,
+                           xa, B * Ts, n_chunks, Ss, st, pskip(Ts, mul * 2), false, h3s);
+        } else {
+          launch_conv_ffn_stride(g, nullptr, xc, xa, (h3 || h3s) ? Lk : L, lens, B, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st,
+                                 pskip(Ts, mul * 2), h->desc.causal != 0, h3 || h3s);
+        }
       });
       Ti = Ts;  // masks[:, :, ::2], pos_emb[:, ::2]  (efficient_conformer/encoder.py:252-257)
       mul *= 2;

@@ -166,7 +166,14 @@ ppasr_status conformer_chunk(ppasr_stream_s* s, const ChunkPlan& p, float* xa, f
     launch_out_glu(ctx, xb, xc, g, xhat, Lk, nullptr, Ti, Ti, mul, st, PadSkip{}, S > 1 ? xhat : nullptr, h3, &hm);
     if (is_eff(h) && i == h->desc.stride_layer_idx) {
       const int Ts = ceil_div(Ti, 2);
-      launch_conv_ffn_stride(g, gh, xc, xa, Lk, nullptr, 1, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st, PadSkip{}, true, h3);
+      const int Ss = ffn_split_for(h, Ts);
+      if (Ss > 1) {  // one row block: the conv half of the stride layer alone, its feed-forward module over the slices
+        launch_conv_ffn_stride(g, gh, xc, xa, Lk, nullptr, 1, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st, PadSkip{}, true, h3, ctx);
+        launch_ffn_split(ctx, L.ln_ff_g, L.ln_ff_b, Lk.ff_w1, L.ff_b1, Lk.ff_w2, L.ff_b2, 0.5f, L.ln_fin_g, L.ln_fin_b, partial, xa, Ts,
+                         n_chunks, Ss, st, PadSkip{}, false, h3, s->ticket);
+      } else {
+        launch_conv_ffn_stride(g, gh, xc, xa, Lk, nullptr, 1, Ti, Ts, n_chunks, h->layer_ks[i], mul * 2, st, PadSkip{}, true, h3);
+      }
       if (!hm.done) launch_hist_update(xh, xhat, Ti, lo_i, st);
       Ti = Ts;
       mul *= 2;

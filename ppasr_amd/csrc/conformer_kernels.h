@@ -243,7 +243,8 @@ void launch_ln_qkv(const float* x1, float* qkv, const LayerW& w, int M, hipStrea
                    float* kc = nullptr, float* vc = nullptr, bool h3 = false);
 void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int B,
                             int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out, hipStream_t st,
-                            const PadSkip& ps = PadSkip{}, bool causal = true, bool h3 = false);
+                            const PadSkip& ps = PadSkip{}, bool causal = true, bool h3 = false,
+                            float* x3_out = nullptr);  // x3_out: stop at the conv module's output (the caller runs the FFN split)
 // streaming helpers
 // fused S2+S3 for the batched plain-head path (4 heads x 64): attention + out-projection + LN_conv + pw1 + GLU
 void launch_attn_out_glu(const AttnArgs& a, int B, const float* x1, float* x2, float* g, const LayerW& w, hipStream_t st,

@@ -1097,7 +1097,8 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __res
                                                               const float* __restrict__ x2, float* __restrict__ x_out,
                                                               LayerW w,
                                                               const int64_t* __restrict__ lens, int B, int Tp, int Ts,
-                                                              int n_chunks, int mask_mul_out, PadSkip ps, int causal) {
+                                                              int n_chunks, int mask_mul_out, PadSkip ps, int causal,
+                                                              float* __restrict__ x3_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (pad_block_skippable(ps, blockIdx.x * kRows, kRows, B * Ts)) return;  // (ps describes the OUTPUT rows)
   float* bufX = smem;
@@ -1161,6 +1162,10 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __res
     }
   }
   __syncthreads();
+  if (x3_out) {  // under-filled launches: the launch ends at the conv module's output; the feed-forward module runs split
+    rb_store_rows(x3_out + (size_t)r0 * kD, bufX, kLda, kRows, valid);
+    return;
+  }
   rb_layernorm(bufX, bufA, kLda, kRows, w.ln_ff_g, w.ln_ff_b, 1e-5f);
   __syncthreads();
   f32x16 acc2[1][1];
@@ -1178,15 +1183,15 @@ __global__ __launch_bounds__(kThreads) void k_conv_ffn_stride(const float* __res
 }
 void launch_conv_ffn_stride(const float* g, const float* g_hist, const float* x2, float* x_out, const LayerW& w,
                             const int64_t* lens, int B, int Tp, int Ts, int n_chunks, int ksize, int mask_mul_out,
-                            hipStream_t st, const PadSkip& ps, bool causal, bool h3) {
+                            hipStream_t st, const PadSkip& ps, bool causal, bool h3, float* x3_out) {
   dim3 grid((B * Ts + kRows - 1) / kRows);
   (void)ksize;  // (the 256-wide route is built for cnn_module_kernel 15 in front of the stride layer: capi.hip refuses others)
   if (h3)
     PPASR_LAUNCH((k_conv_ffn_stride<15, true>), grid, dim3(kThreads), kLdsConvFfn + kH3ExtraLds, st, g, g_hist, x2, x_out, w, lens,
-                 B, Tp, Ts, n_chunks, mask_mul_out, ps, causal ? 1 : 0);
+                 B, Tp, Ts, n_chunks, mask_mul_out, ps, causal ? 1 : 0, x3_out);
   else
     PPASR_LAUNCH((k_conv_ffn_stride<15, false>), grid, dim3(kThreads), kLdsConvFfn, st, g, g_hist, x2, x_out, w, lens, B, Tp, Ts,
-                 n_chunks, mask_mul_out, ps, causal ? 1 : 0);
+                 n_chunks, mask_mul_out, ps, causal ? 1 : 0, x3_out);
 }
 
 hipError_t configure_kernels() {
