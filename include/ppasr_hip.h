@@ -347,7 +347,8 @@ PPASR_API ppasr_status ppasr_stream_destroy(ppasr_stream s);
 PPASR_API ppasr_status ppasr_stream_reset(ppasr_stream s, void* stream);
 PPASR_API int ppasr_stream_offset(ppasr_stream s);        /* encoder frames emitted so far */
 PPASR_API int ppasr_stream_cache_frames(ppasr_stream s);  /* cache_t1: key/value frames currently cached */
-PPASR_API size_t ppasr_chunk_workspace_bytes(ppasr_handle h, int T);
+PPASR_API size_t ppasr_chunk_workspace_bytes(ppasr_handle h, int T);  /* (query it per T: it holds the chunk's activations, the
+                                                                         cache-trim scratch and the front end's K-split tiles) */
 /*   feats [1,T,F] f32; required_cache_size as in encoder.py:255-260 (<0 keep everything, the value
  *   predict_stream uses; 0 none; >0 last n frames); probs [1,c,V] or NULL; c = ((T-1)/2-1)/2 is also
  *   written to *c_out_host (host int, may be NULL). */
