@@ -415,7 +415,20 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
     const int Mi = B * Ti;
     const int mul = reduced ? 8 : 4;
     const PadSkip& ps = reduced ? psH : psF;
-    if (!have_qkv) launch_sq_qkv(x, qkv, W.wqkv, W.bqkv, Mi, st, ps);
+    // under-filled launches up to split_rows16_max() rows (one utterance, small batches; fp32): the single-unit launches on
+    // the Conformer's 16-row kernels through weight views, as the streaming chunk does (capi_stream.hip)
+    const bool views16 = ffn_split_for(h, Mi) > 1 && !(rowsF == 16 && h->ffn_split < 0) && Mi <= split_rows16_max() &&
+                         !(h->gemm_mode == PPASR_GEMM_F16X3 && !h->sq_layers_h3.empty());
+    auto qkv_view = [](const SqLayerW& w) {
+      LayerW v{};
+      v.wqkv = w.wqkv;
+      v.bqkv = w.bqkv;
+      return v;
+    };
+    if (!have_qkv) {
+      if (views16) launch_ln_qkv(x, qkv, qkv_view(W), Mi, st, ps, nullptr, nullptr, false);
+      else launch_sq_qkv(x, qkv, W.wqkv, W.bqkv, Mi, st, ps);
+    }
     tap(qkv, (size_t)Mi * 3 * kD);
     AttnArgs a{qkv, 768, qkv + 256, 768, qkv + 512, 768, Ti, Ti, 0, lens, ctx, W.pos_u, W.pos_v, W.ptab, reduced ? 2 : 1, mul, Ti, Ti, 1};
     a.pad_skip = skip ? ps.slack + 1 : 0;
@@ -433,16 +446,30 @@ ppasr_status squeezeformer_encode(ppasr_model_s* h, const float* feats, const in
       // (fp16 x3 mode: the two feed-forward modules' slices on that route -- the re-packed weights of the layer's h3 view)
       const bool h3s = h->gemm_mode == PPASR_GEMM_F16X3 && !h->sq_layers_h3.empty();
       const SqLayerW& Ws = h3s ? h->sq_layers_h3[i] : W;
-      launch_sq_oproj(ctx, x, other, W, Mi, st, ps);  // x1 = LN1(x + MHA) in `other` (free until this layer's output)
+      // x1 = LN1(x + MHA) in `other` (free until this layer's output)
+      if (views16) {
+        LayerW vo{};
+        vo.wo = W.wo; vo.bo = W.bo; vo.ln_conv_g = W.ln1_g; vo.ln_conv_b = W.ln1_b;
+        launch_oproj_ln_16(ctx, x, g, other, vo, Mi, st, ps);  // (the plain sum goes to g, dead until pointwise_conv1 writes it)
+      } else {
+        launch_sq_oproj(ctx, x, other, W, Mi, st, ps);
+      }
       launch_ffn_split(other, nullptr, nullptr, Ws.ff1_w1, W.ff1_b1, Ws.ff1_w2, W.ff1_b2, 1.0f, W.ln2_g, W.ln2_b, y1, xc, Mi,
                        n_chunks, S, st, ps, false, h3s);
-      launch_sq_pw1glu(xc, g, nullptr, W, lens, Mi, Ti, mul, st, ps);
+      if (views16) {
+        LayerW vp{};
+        vp.pw1 = W.pw1; vp.pw1_b = W.pw1_b; vp.glu_pad = W.glu_pad;
+        launch_pw1_glu_cols_16(xc, g, vp, Mi, st, nullptr, 0, nullptr, nullptr, ps, lens, Ti, mul);
+      } else {
+        launch_sq_pw1glu(xc, g, nullptr, W, lens, Mi, Ti, mul, st, ps);
+      }
       tap(xc, (size_t)Mi * kD);
       tap(g, (size_t)Mi * kD);
       launch_conv_pre(g, nullptr, xc, ctx, sq_conv_view(W), lens, Mi, Ti, KS, mul, st, causal, ps);
       launch_ffn_split(ctx, W.ln3_g, W.ln3_b, Ws.ff2_w1, W.ff2_b1, Ws.ff2_w2, W.ff2_b2, 1.0f, W.ln4_g, W.ln4_b, y1, other, Mi,
                        n_chunks, S, st, ps, /*residual_is_normed=*/true, h3s);
-      if (Wn) launch_sq_qkv(other, qkv, Wn->wqkv, Wn->bqkv, Mi, st, ps);
+      if (Wn && views16) launch_ln_qkv(other, qkv, qkv_view(*Wn), Mi, st, ps, nullptr, nullptr, false);
+      else if (Wn) launch_sq_qkv(other, qkv, Wn->wqkv, Wn->bqkv, Mi, st, ps);
     } else {
       // feed-forward modules on the fp16 x3 route (ppasr_set_gemm_mode): the 8-wave 32-row kernels only
       const bool h3 = h->gemm_mode == PPASR_GEMM_F16X3 && !h->sq_layers_h3.empty() && rows == 32 && !h->taps &&

@@ -126,9 +126,11 @@ void launch_out_glu_split_16(const float* ctx, const float* x1, float* x2, float
 void launch_shift_caches(float* kc, float* vc, long long layer_stride, int D, int n_layers, int from_full, int keep_full,
                          int from_half, int keep_half, unsigned long long half_mask, hipStream_t st);  // stream_kernels.hip
 void launch_oproj_ln_16(const float* ctx, const float* x1, float* x2_sink, float* xhat_out, const LayerW& w, int M,
-                        hipStream_t st);  // xhat_out = LN(x1 + ctx Wo + bo): w.wo / bo / ln_conv_g / ln_conv_b
+                        hipStream_t st, const PadSkip& ps = PadSkip{});  // xhat_out = LN(x1 + ctx Wo + bo): w.wo / bo / ln_conv_g / _b
+// (lens != nullptr: PAD frames of the batch read w.glu_pad -- Squeezeformer's batched launches)
 void launch_pw1_glu_cols_16(const float* x, float* g, const LayerW& w, int M, hipStream_t st, float* hist = nullptr, int lo = 0,
-                            const float* hist_scale = nullptr, const float* hist_bias = nullptr);
+                            const float* hist_scale = nullptr, const float* hist_bias = nullptr, const PadSkip& ps = PadSkip{},
+                            const int64_t* lens = nullptr, int Tp = 1, int mask_mul = 1);
 bool conv_ffn_16_supported(int ksize, int Tp);
 void launch_conv_ffn_16(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int M, int Tp,
                         int n_chunks, int ksize, int mask_mul, const LayerW* next, float* x1_next, float* qkv_next,

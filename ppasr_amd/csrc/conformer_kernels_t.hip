@@ -146,7 +146,8 @@ template <int R>
 __global__ __launch_bounds__(RBT<R>::THREADS) void k_pw1_glu_cols_t(const float* __restrict__ xhat, float* __restrict__ g,
                                                                     LayerW w, int M, PadSkip ps, float* __restrict__ hist,
                                                                     int lo, const float* __restrict__ hist_scale,
-                                                                    const float* __restrict__ hist_bias) {
+                                                                    const float* __restrict__ hist_bias,
+                                                                    const int64_t* __restrict__ lens, int Tp, int mask_mul) {
   using T = RBT<R>;
   static_assert(R == 16, "the quad view below is the 16-row form's");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -205,13 +206,17 @@ __global__ __launch_bounds__(RBT<R>::THREADS) void k_pw1_glu_cols_t(const float*
   }
   __syncthreads();
   if (is_gate && row < valid) {
+    // (lens != nullptr -- Squeezeformer's batched launches: PAD frames read GLU(pointwise_conv1(0)) = w.glu_pad, k_sq_pw1glu)
+    const bool pad = lens != nullptr && PadRows{lens, r0, Tp, M, mask_mul}(row);
 #pragma unroll
     for (int q = 0; q < T::NQ; ++q) {
       const int c128 = 32 * t + 16 * q + 4 * (lane >> 4);
       const f32x4 v = *reinterpret_cast<const f32x4*>(vals + row * 132 + c128);
       const f32x4 b = acc.s[q];
       const f32x2 s0 = sigmoid2(f32x2{b[0], b[1]}), s1 = sigmoid2(f32x2{b[2], b[3]});
-      *reinterpret_cast<f32x4*>(g + (size_t)(r0 + row) * kD + 128 * y + c128) = f32x4{v[0] * s0[0], v[1] * s0[1], v[2] * s1[0], v[3] * s1[1]};
+      f32x4 o = f32x4{v[0] * s0[0], v[1] * s0[1], v[2] * s1[0], v[3] * s1[1]};
+      if (pad) o = *reinterpret_cast<const f32x4*>(w.glu_pad + 128 * y + c128);
+      *reinterpret_cast<f32x4*>(g + (size_t)(r0 + row) * kD + 128 * y + c128) = o;
     }
   }
 }
@@ -307,20 +312,21 @@ void launch_out_glu_split_16(const float* ctx, const float* x1, float* x2, float
   PPASR_LAUNCH(k_out_glu_t<16>, dim3((M + 15) / 16), dim3(kThreads), excl(kLds16x2), st, ctx, x1, x2, g, w, lens, M, Tp,
                mask_mul, ps, xhat, 1);
   PPASR_LAUNCH(k_pw1_glu_cols_t<16>, dim3((M + 15) / 16, 2), dim3(kThreads), excl((16 * kLda + 16 * 132) * sizeof(float)), st,
-               xhat, g, w, M, ps, hist, lo, (const float*)nullptr, (const float*)nullptr);
+               xhat, g, w, M, ps, hist, lo, (const float*)nullptr, (const float*)nullptr, (const int64_t*)nullptr, 1, 1);
 }
 // the two launches on their own, for layers that are not the Conformer's (Squeezeformer's chunk: weight views):
 // xhat_out = LN(x1 + ctx Wo + bo) with w.wo / bo / ln_conv_g / ln_conv_b (the plain sum goes to x2_sink)
 void launch_oproj_ln_16(const float* ctx, const float* x1, float* x2_sink, float* xhat_out, const LayerW& w, int M,
-                        hipStream_t st) {
+                        hipStream_t st, const PadSkip& ps) {
   PPASR_LAUNCH(k_out_glu_t<16>, dim3((M + 15) / 16), dim3(kThreads), excl(kLds16x2), st, ctx, x1, x2_sink, (float*)nullptr, w,
-               (const int64_t*)nullptr, M, M, 1, PadSkip{}, xhat_out, 1);
+               (const int64_t*)nullptr, M, M, 1, ps, xhat_out, 1);
 }
 // g = GLU(pointwise_conv1(x)) with w.pw1 / pw1_b; hist (M <= 16, one session): moves on by scale * x + bias
 void launch_pw1_glu_cols_16(const float* x, float* g, const LayerW& w, int M, hipStream_t st, float* hist, int lo,
-                            const float* hist_scale, const float* hist_bias) {
+                            const float* hist_scale, const float* hist_bias, const PadSkip& ps, const int64_t* lens, int Tp,
+                            int mask_mul) {
   PPASR_LAUNCH(k_pw1_glu_cols_t<16>, dim3((M + 15) / 16, 2), dim3(kThreads), excl((16 * kLda + 16 * 132) * sizeof(float)), st, x,
-               g, w, M, PadSkip{}, hist, lo, hist_scale, hist_bias);
+               g, w, M, ps, hist, lo, hist_scale, hist_bias, lens, Tp, mask_mul);
 }
 bool conv_ffn_16_supported(int ksize, int Tp) { return (ksize == 7 || ksize == 15 || ksize == 31) && Tp >= 2; }
 void launch_conv_ffn_16(const float* g, const float* x2, float* x_out, const LayerW& w, const int64_t* lens, int M, int Tp,
